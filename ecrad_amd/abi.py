@@ -1,0 +1,223 @@
+"""ctypes mirror of include/ecrad_hip.h (struct layouts must match; tests check sizeof via
+``ecrad_hip_abi_sizeof``).  This is the Python stand-in for the ISO_C_BINDING layer a Fortran host
+uses (ecrad_amd/fortran/ecrad_hip_binding.F90 is the Fortran twin of this file)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+ABI_VERSION = 1
+NMAXGASES = 12
+NMAXCLOUDTYPES = 12
+
+MEM_HOST, MEM_DEVICE = 0, 1
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class CkdGas(C.Structure):
+    _fields_ = [
+        ("i_gas_code", C.c_int32), ("i_conc_dependence", C.c_int32),
+        ("n_mole_frac", C.c_int32), ("reserved_", C.c_int32),
+        ("reference_mole_frac", C.c_double), ("log_mole_frac1", C.c_double),
+        ("d_log_mole_frac", C.c_double),
+        ("molar_abs", c_double_p),
+    ]
+
+
+class CkdModel(C.Structure):
+    _fields_ = [
+        ("is_sw", C.c_int32), ("ng", C.c_int32), ("npress", C.c_int32), ("ntemp", C.c_int32),
+        ("ngas", C.c_int32), ("nplanck", C.c_int32),
+        ("log_pressure1", C.c_double), ("d_log_pressure", C.c_double), ("d_temperature", C.c_double),
+        ("temperature1_planck", C.c_double), ("d_temperature_planck", C.c_double),
+        ("temperature1", c_double_p), ("planck_function", c_double_p),
+        ("norm_solar_irradiance", c_double_p), ("norm_amplitude_solar_irradiance", c_double_p),
+        ("rayleigh_molar_scat", c_double_p),
+        ("single_gas", CkdGas * NMAXGASES),
+    ]
+
+
+class CloudOptics(C.Structure):
+    _fields_ = [
+        ("n_bands", C.c_int32), ("n_effective_radius", C.c_int32),
+        ("effective_radius_0", C.c_double), ("d_effective_radius", C.c_double),
+        ("mass_ext", c_double_p), ("ssa", c_double_p), ("asymmetry", c_double_p),
+    ]
+
+
+class AerosolOptics(C.Structure):
+    _fields_ = [
+        ("n_bands_sw", C.c_int32), ("n_bands_lw", C.c_int32),
+        ("n_type_phobic", C.c_int32), ("n_type_philic", C.c_int32), ("nrh", C.c_int32),
+        ("use_hydrophilic", C.c_int32), ("ntype", C.c_int32), ("reserved_", C.c_int32),
+        ("iclass", c_int32_p), ("itype", c_int32_p), ("rh_lower", c_double_p),
+        ("mass_ext_sw_phobic", c_double_p), ("ssa_sw_phobic", c_double_p), ("g_sw_phobic", c_double_p),
+        ("mass_ext_lw_phobic", c_double_p), ("ssa_lw_phobic", c_double_p), ("g_lw_phobic", c_double_p),
+        ("mass_ext_sw_philic", c_double_p), ("ssa_sw_philic", c_double_p), ("g_sw_philic", c_double_p),
+        ("mass_ext_lw_philic", c_double_p), ("ssa_lw_philic", c_double_p), ("g_lw_philic", c_double_p),
+    ]
+
+
+class PdfSampler(C.Structure):
+    _fields_ = [
+        ("ncdf", C.c_int32), ("nfsd", C.c_int32),
+        ("fsd1", C.c_double), ("inv_fsd_interval", C.c_double),
+        ("val", c_double_p),
+    ]
+
+
+_CONFIG_INTS = [
+    "abi_version",
+    "do_sw", "do_lw", "do_clear", "do_sw_direct", "do_lw_derivatives",
+    "do_clouds", "use_aerosols",
+    "i_solver_sw", "i_solver_lw",
+    "i_gas_model_sw", "i_gas_model_lw",
+    "do_lw_cloud_scattering", "do_lw_aerosol_scattering",
+    "do_sw_delta_scaling_with_gases",
+    "use_general_cloud_optics", "is_homogeneous",
+    "i_overlap_scheme", "use_beta_overlap", "use_vectorizable_generator", "i_cloud_pdf_shape",
+    "do_cloud_aerosol_per_sw_g_point", "do_cloud_aerosol_per_lw_g_point",
+    "do_surface_sw_spectral_flux", "do_toa_spectral_flux",
+    "do_canopy_fluxes_sw", "do_canopy_fluxes_lw",
+    "use_canopy_full_spectrum_sw", "use_canopy_full_spectrum_lw",
+    "do_nearest_spectral_sw_albedo", "do_nearest_spectral_lw_emiss",
+    "do_save_spectral_flux",
+    "n_g_sw", "n_g_lw", "n_bands_sw", "n_bands_lw",
+    "n_g_lw_if_scattering", "n_bands_lw_if_scattering",
+    "n_canopy_bands_sw", "n_canopy_bands_lw",
+    "n_albedo_intervals_sw", "n_emiss_intervals_lw",
+    "n_cloud_types", "reserved_",
+]
+
+
+class Config(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in _CONFIG_INTS]
+        + [("cloud_fraction_threshold", C.c_double), ("cloud_mixing_ratio_threshold", C.c_double),
+           ("cloud_inhom_decorr_scaling", C.c_double), ("max_cloud_od", C.c_double),
+           ("i_band_from_reordered_g_sw", c_int32_p), ("i_band_from_reordered_g_lw", c_int32_p),
+           ("sw_albedo_weights", c_double_p), ("lw_emiss_weights", c_double_p),
+           ("i_albedo_from_band_sw", c_int32_p), ("i_emiss_from_band_lw", c_int32_p),
+           ("gas_optics_sw", CkdModel), ("gas_optics_lw", CkdModel),
+           ("cloud_optics_sw", CloudOptics * NMAXCLOUDTYPES),
+           ("cloud_optics_lw", CloudOptics * NMAXCLOUDTYPES),
+           ("aerosol_optics", AerosolOptics),
+           ("pdf_sampler", PdfSampler)]
+    )
+
+
+class Inputs(C.Structure):
+    _fields_ = [
+        ("memory", C.c_int32), ("n_sw_albedo", C.c_int32), ("n_lw_emissivity", C.c_int32),
+        ("n_cloud_types", C.c_int32), ("n_aerosol_types", C.c_int32),
+        ("aerosol_istartlev", C.c_int32), ("aerosol_iendlev", C.c_int32), ("reserved_", C.c_int32),
+        ("solar_irradiance", C.c_double), ("spectral_solar_cycle_multiplier", C.c_double),
+        ("pressure_hl", c_double_p), ("temperature_hl", c_double_p), ("h2o_sat_liq", c_double_p),
+        ("cos_sza", c_double_p), ("skin_temperature", c_double_p),
+        ("sw_albedo", c_double_p), ("sw_albedo_direct", c_double_p), ("lw_emissivity", c_double_p),
+        ("iseed", c_int32_p),
+        ("gas_mixing_ratio", c_double_p),
+        ("cloud_fraction", c_double_p), ("cloud_mixing_ratio", c_double_p),
+        ("cloud_effective_radius", c_double_p), ("cloud_fractional_std", c_double_p),
+        ("cloud_overlap_param", c_double_p),
+        ("aerosol_mixing_ratio", c_double_p),
+    ]
+
+
+FLUX_PROFILE_FIELDS = ["lw_up", "lw_dn", "sw_up", "sw_dn", "sw_dn_direct",
+                       "lw_up_clear", "lw_dn_clear", "sw_up_clear", "sw_dn_clear", "sw_dn_direct_clear",
+                       "lw_derivatives"]
+FLUX_G_FIELDS = ["lw_dn_surf_g", "lw_dn_surf_clear_g", "sw_dn_diffuse_surf_g", "sw_dn_direct_surf_g",
+                 "sw_dn_diffuse_surf_clear_g", "sw_dn_direct_surf_clear_g",
+                 "lw_up_toa_g", "lw_up_toa_clear_g", "sw_dn_toa_g", "sw_up_toa_g", "sw_up_toa_clear_g"]
+FLUX_BAND_FIELDS = ["sw_dn_surf_band", "sw_dn_direct_surf_band", "sw_dn_surf_clear_band",
+                    "sw_dn_direct_surf_clear_band", "lw_up_toa_band", "lw_up_toa_clear_band",
+                    "sw_dn_toa_band", "sw_up_toa_band", "sw_up_toa_clear_band"]
+FLUX_CANOPY_FIELDS = ["lw_dn_surf_canopy", "sw_dn_diffuse_surf_canopy", "sw_dn_direct_surf_canopy"]
+FLUX_COL_FIELDS = ["cloud_cover_lw", "cloud_cover_sw"]
+FLUX_FIELDS = FLUX_PROFILE_FIELDS + FLUX_G_FIELDS + FLUX_BAND_FIELDS + FLUX_CANOPY_FIELDS + FLUX_COL_FIELDS
+
+
+class Flux(C.Structure):
+    _fields_ = [("memory", C.c_int32), ("reserved_", C.c_int32)] + [(n, c_double_p) for n in FLUX_FIELDS]
+
+
+OPTICS_FIELDS = ["od_lw", "ssa_lw", "g_lw", "od_sw", "ssa_sw", "g_sw", "planck_hl",
+                 "lw_emission", "lw_albedo", "sw_albedo_direct", "sw_albedo_diffuse", "incoming_sw",
+                 "od_lw_cloud", "ssa_lw_cloud", "g_lw_cloud", "od_sw_cloud", "ssa_sw_cloud", "g_sw_cloud"]
+
+
+class Optics(C.Structure):
+    _fields_ = [("memory", C.c_int32), ("reserved_", C.c_int32)] + [(n, c_double_p) for n in OPTICS_FIELDS]
+
+
+STRUCT_BY_INDEX = [Config, Inputs, Flux, Optics, CkdModel, CkdGas, CloudOptics, AerosolOptics, PdfSampler]
+
+
+# ---------------------------------------------------------------------------------------------------
+def dptr(a):
+    """Pointer to a float64 C-contiguous numpy array (None -> NULL)."""
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags["C_CONTIGUOUS"], \
+        "expected C-contiguous float64 array"
+    return a.ctypes.data_as(c_double_p)
+
+
+def iptr(a):
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.dtype == np.int32 and a.flags["C_CONTIGUOUS"], \
+        "expected C-contiguous int32 array"
+    return a.ctypes.data_as(c_int32_p)
+
+
+def raw_dptr(addr: int):
+    """Device address (e.g. torch.Tensor.data_ptr()) as a double*."""
+    return C.cast(C.c_void_p(addr), c_double_p) if addr else None
+
+
+def raw_iptr(addr: int):
+    return C.cast(C.c_void_p(addr), c_int32_p) if addr else None
+
+
+def declare_prototypes(lib) -> None:
+    """Set argtypes/restype for every entry point include/ecrad_hip.h declares."""
+    H = C.c_void_p
+    lib.ecrad_hip_create.argtypes = [C.POINTER(H), C.c_int]
+    lib.ecrad_hip_create.restype = C.c_int
+    lib.ecrad_hip_setup.argtypes = [H, C.POINTER(Config)]
+    lib.ecrad_hip_setup.restype = C.c_int
+    lib.ecrad_hip_set_stream.argtypes = [H, C.c_void_p]
+    lib.ecrad_hip_set_stream.restype = C.c_int
+    lib.ecrad_hip_radiation.argtypes = [H, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(Inputs), C.POINTER(Flux)]
+    lib.ecrad_hip_radiation.restype = C.c_int
+    lib.ecrad_hip_optics.argtypes = [H, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(Inputs), C.POINTER(Optics)]
+    lib.ecrad_hip_optics.restype = C.c_int
+    lib.ecrad_hip_synchronize.argtypes = [H]
+    lib.ecrad_hip_synchronize.restype = C.c_int
+    lib.ecrad_hip_last_kernel_ms.argtypes = [H, C.POINTER(C.c_double)]
+    lib.ecrad_hip_last_kernel_ms.restype = C.c_int
+    lib.ecrad_hip_scratch_bytes.argtypes = [H, C.POINTER(C.c_size_t)]
+    lib.ecrad_hip_scratch_bytes.restype = C.c_int
+    lib.ecrad_hip_last_error.argtypes = [H]
+    lib.ecrad_hip_last_error.restype = C.c_char_p
+    lib.ecrad_hip_destroy.argtypes = [H]
+    lib.ecrad_hip_destroy.restype = C.c_int
+    lib.ecrad_hip_abi_sizeof.argtypes = [C.c_int]
+    lib.ecrad_hip_abi_sizeof.restype = C.c_size_t
+    lib.ecrad_hip_abi_version.argtypes = []
+    lib.ecrad_hip_abi_version.restype = C.c_int
+
+
+EXPORTED_SYMBOLS = [
+    "ecrad_hip_create", "ecrad_hip_setup", "ecrad_hip_set_stream", "ecrad_hip_radiation",
+    "ecrad_hip_optics", "ecrad_hip_synchronize", "ecrad_hip_last_kernel_ms",
+    "ecrad_hip_scratch_bytes", "ecrad_hip_last_error", "ecrad_hip_destroy",
+    "ecrad_hip_abi_sizeof", "ecrad_hip_abi_version",
+]

@@ -1,0 +1,280 @@
+"""Offline-driver counterpart: netCDF input -> types, types -> netCDF output.
+
+Mirrors driver/ecrad_driver_read_input.F90:21-620 (variable names, unit handling, overrides) and
+the variable names of radiation/radiation_save.F90:35-460 (save_fluxes).  The program flow of
+driver/ecrad_driver.F90:28-420 is in :func:`main`:  ``python -m ecrad_amd.driver cfg.nam in.nc out.nc``.
+"""
+from __future__ import annotations
+
+import sys
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+from .config import Config
+from .namelist import read_namelist
+from .ncfile import NcFile, write_nc
+from .tables import GAS_LOWER_CASE_NAMES, NMaxGases, IH2O, IO3
+from .types import (Aerosol, Cloud, Flux, Gas, SingleLevel, Thermodynamics,
+                    IMassMixingRatio, IVolumeMixingRatio)
+
+
+@dataclass
+class DriverConfig:
+    """driver_config_type (driver/ecrad_driver_config.F90:27-140), defaults :230-300."""
+    do_parallel: bool = True
+    nblocksize: int = 8
+    istartcol: int = 0
+    iendcol: int = 0
+    nrepeat: int = 1
+    iverbose: int = 2
+    do_write_double_precision: bool = False
+    do_save_net_fluxes: bool = False
+    fractional_std_override: float = -1.0
+    overlap_decorr_length_override: float = -1.0
+    overlap_decorr_length_scaling: float = -1.0
+    sw_albedo_override: float = -1.0
+    lw_emissivity_override: float = -1.0
+    q_liq_scaling: float = -1.0
+    q_ice_scaling: float = -1.0
+    cloud_fraction_scaling: float = -1.0
+    skin_temperature_override: float = -1.0
+    solar_irradiance_override: float = -1.0
+    cos_sza_override: float = -1.0
+    vmr_suffix_str: str = "_vmr"
+    gas_scaling: dict = None
+
+    @classmethod
+    def read(cls, file_name: str) -> "DriverConfig":
+        nml = read_namelist(file_name).get("radiation_driver", {})
+        d = cls()
+        d.gas_scaling = {}
+        for k, v in nml.items():
+            if k.endswith("_scaling") and k[:-8] in GAS_LOWER_CASE_NAMES:
+                d.gas_scaling[k[:-8]] = float(v)
+            elif hasattr(d, k) and k != "gas_scaling" and v is not None:
+                cur = getattr(d, k)
+                setattr(d, k, float(v) if isinstance(cur, float) else v)
+        return d
+
+
+def _colfast(a: np.ndarray) -> np.ndarray:
+    """netCDF (column, x) -> numpy (x, column): what file%transpose_matrices(.true.) achieves
+    (driver/ecrad_driver.F90:255, utilities/easy_netcdf.F90:1040-1150)."""
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).T)
+
+
+def read_input(path: str, config: Config, driver_config: DriverConfig):
+    """read_input (driver/ecrad_driver_read_input.F90:21-620).
+
+    Returns (ncol, nlev, single_level, thermodynamics, gas, cloud, aerosol)."""
+    dc = driver_config
+    with NcFile(path) as f:
+        pressure_hl = _colfast(f.get("pressure_hl"))
+        temperature_hl = _colfast(f.get("temperature_hl"))
+        nlev = pressure_hl.shape[0] - 1
+        ncol = pressure_hl.shape[1]
+        thermodynamics = Thermodynamics(pressure_hl, temperature_hl)
+
+        if dc.solar_irradiance_override > 0.0:
+            solar_irradiance = dc.solar_irradiance_override
+        elif f.exists("solar_irradiance"):
+            solar_irradiance = f.get_scalar("solar_irradiance")
+        else:
+            solar_irradiance = 1366.0
+        if dc.cos_sza_override >= 0.0:
+            cos_sza = np.full(ncol, dc.cos_sza_override)
+        elif f.exists("cos_solar_zenith_angle"):
+            cos_sza = np.ascontiguousarray(f.get("cos_solar_zenith_angle"), dtype=np.float64)
+        elif not config.do_sw:
+            cos_sza = np.zeros(ncol)
+        else:
+            raise RuntimeError("cos_solar_zenith_angle not provided")
+
+        cloud = None
+        iseed = None
+        if config.do_clouds:
+            fraction = _colfast(f.get("cloud_fraction"))
+            fractional_std = _colfast(f.get("fractional_std")) if f.exists("fractional_std") else None
+            if f.exists("q_hydrometeor"):
+                # (column, type, level) -> numpy (type, level, column)
+                mixing_ratio = np.ascontiguousarray(np.transpose(f.get("q_hydrometeor"), (1, 2, 0)))
+                effective_radius = np.ascontiguousarray(np.transpose(f.get("re_hydrometeor"), (1, 2, 0)))
+            else:
+                mixing_ratio = np.stack([_colfast(f.get("q_liquid")), _colfast(f.get("q_ice"))])
+                effective_radius = np.stack([_colfast(f.get("re_liquid")), _colfast(f.get("re_ice"))])
+            iseed = np.arange(1, ncol + 1, dtype=np.int32)          # init_seed_simple
+            if f.exists("iseed"):
+                iseed = np.ascontiguousarray(f.get("iseed")).astype(np.int32)
+            overlap_param = _colfast(f.get("overlap_param")) if f.exists("overlap_param") else None
+            if dc.q_liq_scaling >= 0.0 and dc.q_liq_scaling != 1.0:
+                mixing_ratio[0] *= dc.q_liq_scaling
+            if dc.q_ice_scaling >= 0.0 and dc.q_ice_scaling != 1.0:
+                mixing_ratio[1] *= dc.q_ice_scaling
+            if dc.cloud_fraction_scaling >= 0.0 and dc.cloud_fraction_scaling != 1.0:
+                fraction *= dc.cloud_fraction_scaling
+            if dc.overlap_decorr_length_override > 0.0 or overlap_param is None:
+                raise NotImplementedError("overlap_param must be present in the input file "
+                                          "(cloud%set_overlap_param is not implemented)")
+            if dc.overlap_decorr_length_scaling > 0.0:
+                pos = overlap_param > 0.0
+                overlap_param[pos] = overlap_param[pos] ** (1.0 / dc.overlap_decorr_length_scaling)
+            elif dc.overlap_decorr_length_scaling == 0.0:
+                overlap_param[:] = 0.0
+            if dc.fractional_std_override >= 0.0:
+                fractional_std = np.full((nlev, ncol), dc.fractional_std_override)
+            elif fractional_std is None:
+                fractional_std = np.zeros((nlev, ncol))
+            cloud = Cloud(fraction, np.ascontiguousarray(mixing_ratio),
+                          np.ascontiguousarray(effective_radius), fractional_std, overlap_param)
+
+        if f.exists("skin_temperature"):
+            skin_temperature = np.ascontiguousarray(f.get("skin_temperature"), dtype=np.float64)
+        else:
+            skin_temperature = temperature_hl[nlev].copy()
+        if dc.sw_albedo_override >= 0.0:
+            sw_albedo = np.full((1, ncol), dc.sw_albedo_override)
+            sw_albedo_direct = None
+        else:
+            a = f.get("sw_albedo")
+            sw_albedo = a.reshape(1, ncol).copy() if a.ndim == 1 else _colfast(a)
+            sw_albedo_direct = None
+            if f.exists("sw_albedo_direct"):
+                a = f.get("sw_albedo_direct")
+                sw_albedo_direct = a.reshape(1, ncol).copy() if a.ndim == 1 else _colfast(a)
+        if dc.lw_emissivity_override >= 0.0:
+            lw_emissivity = np.full((1, ncol), dc.lw_emissivity_override)
+        else:
+            a = f.get("lw_emissivity")
+            lw_emissivity = a.reshape(1, ncol).copy() if a.ndim == 1 else _colfast(a)
+        if dc.skin_temperature_override >= 0.0:
+            skin_temperature[:] = dc.skin_temperature_override
+        single_level = SingleLevel(cos_sza=cos_sza, skin_temperature=skin_temperature,
+                                   sw_albedo=sw_albedo, lw_emissivity=lw_emissivity,
+                                   sw_albedo_direct=sw_albedo_direct,
+                                   solar_irradiance=solar_irradiance, iseed=iseed)
+
+        aerosol = None
+        if config.use_aerosols:
+            # (column, type, level) -> Fortran (col, lev, type) == numpy (type, level, column)
+            mr = np.ascontiguousarray(np.transpose(f.get("aerosol_mmr"), (1, 2, 0)))
+            aerosol = Aerosol(mixing_ratio=mr, istartlev=1, iendlev=mr.shape[1])
+
+        gas = Gas.allocate(ncol, nlev)
+        for jgas in range(1, NMaxGases + 1):
+            if jgas == IH2O:
+                if f.exists("q"):
+                    gas.put(IH2O, IMassMixingRatio, _colfast(f.get("q")))
+                elif f.exists("h2o_mmr"):
+                    gas.put(IH2O, IMassMixingRatio, _colfast(f.get("h2o_mmr")))
+                else:
+                    gas.put(IH2O, IVolumeMixingRatio, _colfast(f.get("h2o" + dc.vmr_suffix_str)))
+            elif jgas == IO3:
+                if f.exists("o3_mmr"):
+                    gas.put(IO3, IMassMixingRatio, _colfast(f.get("o3_mmr")))
+                else:
+                    gas.put(IO3, IVolumeMixingRatio, _colfast(f.get("o3" + dc.vmr_suffix_str)))
+            else:
+                name = GAS_LOWER_CASE_NAMES[jgas - 1] + dc.vmr_suffix_str
+                rank = f.rank(name)
+                if rank == 0:
+                    gas.put(jgas, IVolumeMixingRatio, f.get_scalar(name))
+                elif rank == 2:
+                    gas.put(jgas, IVolumeMixingRatio, _colfast(f.get(name)))
+                elif rank > 0:
+                    raise RuntimeError(f"{name} does not have 0 or 2 dimensions")
+        for name, s in (dc.gas_scaling or {}).items():
+            gas.scale(GAS_LOWER_CASE_NAMES.index(name) + 1, s)
+    return ncol, nlev, single_level, thermodynamics, gas, cloud, aerosol
+
+
+# (netCDF name, flux member, second dimension)
+_SAVE_SPEC = [
+    ("flux_up_lw", "lw_up", "half_level"), ("flux_dn_lw", "lw_dn", "half_level"),
+    ("flux_up_lw_clear", "lw_up_clear", "half_level"), ("flux_dn_lw_clear", "lw_dn_clear", "half_level"),
+    ("lw_derivative", "lw_derivatives", "half_level"),
+    ("spectral_flux_up_lw_toa", "lw_up_toa_band", "band_lw"),
+    ("spectral_flux_up_lw_toa_clear", "lw_up_toa_clear_band", "band_lw"),
+    ("canopy_flux_dn_lw_surf", "lw_dn_surf_canopy", "canopy_band_lw"),
+    ("flux_up_sw", "sw_up", "half_level"), ("flux_dn_sw", "sw_dn", "half_level"),
+    ("flux_dn_direct_sw", "sw_dn_direct", "half_level"),
+    ("flux_up_sw_clear", "sw_up_clear", "half_level"), ("flux_dn_sw_clear", "sw_dn_clear", "half_level"),
+    ("flux_dn_direct_sw_clear", "sw_dn_direct_clear", "half_level"),
+    ("spectral_flux_dn_sw_surf", "sw_dn_surf_band", "band_sw"),
+    ("spectral_flux_dn_direct_sw_surf", "sw_dn_direct_surf_band", "band_sw"),
+    ("spectral_flux_dn_sw_surf_clear", "sw_dn_surf_clear_band", "band_sw"),
+    ("spectral_flux_dn_direct_sw_surf_clear", "sw_dn_direct_surf_clear_band", "band_sw"),
+    ("spectral_flux_dn_sw_toa", "sw_dn_toa_band", "band_sw"),
+    ("spectral_flux_up_sw_toa", "sw_up_toa_band", "band_sw"),
+    ("spectral_flux_up_sw_toa_clear", "sw_up_toa_clear_band", "band_sw"),
+    ("canopy_flux_dn_diffuse_sw_surf", "sw_dn_diffuse_surf_canopy", "canopy_band_sw"),
+    ("canopy_flux_dn_direct_sw_surf", "sw_dn_direct_surf_canopy", "canopy_band_sw"),
+]
+
+
+def flux_to_output_dict(config: Config, thermodynamics: Thermodynamics, flux: Flux) -> dict:
+    """Arrays keyed by the reference's output variable names, each in netCDF order
+    (column first), as save_fluxes writes them (radiation_save.F90:153-460)."""
+    out = {"pressure_hl": thermodynamics.pressure_hl.T.copy()}
+    for ncname, member, dim in _SAVE_SPEC:
+        arr = getattr(flux, member)
+        if arr is None:
+            continue
+        if dim == "half_level":
+            out[ncname] = arr.T.copy()          # numpy (nlev+1, ncol) -> (column, half_level)
+        else:
+            out[ncname] = arr.copy()            # numpy (ncol, nband) already (column, band)
+    for n in ("cloud_cover_lw", "cloud_cover_sw"):
+        if getattr(flux, n) is not None and ((n.endswith("lw") and config.do_lw) or
+                                             (n.endswith("sw") and config.do_sw)):
+            if config.do_clouds:
+                out[n] = getattr(flux, n).copy()
+    return out
+
+
+def save_fluxes(path: str, config: Config, thermodynamics: Thermodynamics, flux: Flux,
+                is_double_precision: bool = False) -> None:
+    out = flux_to_output_dict(config, thermodynamics, flux)
+    ncol = thermodynamics.pressure_hl.shape[1]
+    dims = {"column": ncol, "half_level": thermodynamics.pressure_hl.shape[0]}
+    variables = {}
+    dim2 = {n: d for n, _, d in _SAVE_SPEC}
+    for name, arr in out.items():
+        if arr.ndim == 1:
+            variables[name] = (("column",), arr)
+        else:
+            d = "half_level" if name == "pressure_hl" else dim2[name]
+            dims.setdefault(d, arr.shape[1])
+            variables[name] = (("column", d), arr)
+    write_nc(path, dims, variables,
+             attrs={"title": "Radiative flux profiles from the ecrad_amd MI355X radiation path",
+                    "source": "ecrad_amd"},
+             double=is_double_precision)
+
+
+def main(argv=None) -> int:
+    from .interface import Radiation
+    argv = sys.argv[1:] if argv is None else argv
+    if len(argv) < 3:
+        print("Usage: python -m ecrad_amd.driver config.nam input_file.nc output_file.nc")
+        return 1
+    config = Config.read(argv[0])
+    dc = DriverConfig.read(argv[0])
+    rad = Radiation(config)                      # setup_radiation
+    ncol, nlev, single_level, thermodynamics, gas, cloud, aerosol = read_input(argv[1], config, dc)
+    iend = dc.iendcol if 1 <= dc.iendcol <= ncol else ncol
+    istart = max(dc.istartcol, 1)
+    rad.set_gas_units(gas)
+    thermodynamics.calc_saturation_wrt_liquid()
+    flux = Flux.allocate(config, ncol, nlev)
+    t0 = time.perf_counter()
+    for _ in range(max(dc.nrepeat, 1)):
+        rad.radiation(ncol, nlev, istart, iend, single_level, thermodynamics, gas, cloud, aerosol, flux)
+    print(f"Time elapsed in radiative transfer: {time.perf_counter() - t0:12.5g} seconds")
+    save_fluxes(argv[2], config, thermodynamics, flux, is_double_precision=dc.do_write_double_precision)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

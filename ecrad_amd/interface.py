@@ -1,0 +1,378 @@
+"""Host mirror of radiation/radiation_interface.F90: ``setup_radiation``, ``set_gas_units`` and
+``radiation`` with the reference's argument meaning, implemented over the C-ABI of
+include/ecrad_hip.h (libecrad_hip.so: hand-written HIP kernels for gfx950).
+
+There is deliberately no CPU path here: if the HIP library cannot be loaded or no GPU is present,
+construction of :class:`Radiation` with ``backend="hip"`` raises.  (tests/ and bench.py's
+``cpu_baseline`` leg drive the *same marshalling* into oracle/ through ``backend=<callable>``.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .config import (Config, ConfigError, IGasModelECCKD, IGasModelIFSRRTMG, IGasModelMonochromatic,
+                     ISolverMcICA, ISolverSpartacus, NMaxAlbedoIntervals)
+from .spectral import SOLAR_REFERENCE_TEMPERATURE, TERRESTRIAL_REFERENCE_TEMPERATURE
+from .tables import AerosolOptics, CkdModel, GeneralCloudOptics, PdfSampler
+from .types import Flux, IVolumeMixingRatio
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libecrad_hip.so")
+
+
+class EcradHipError(RuntimeError):
+    pass
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen libecrad_hip.so and declare its prototypes; raises if it has not been built."""
+    if not os.path.exists(path):
+        raise EcradHipError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU fallback)")
+    lib = C.CDLL(path)
+    abi.declare_prototypes(lib)
+    if lib.ecrad_hip_abi_version() != abi.ABI_VERSION:
+        raise EcradHipError("libecrad_hip.so ABI version mismatch")
+    for i, s in enumerate(abi.STRUCT_BY_INDEX):
+        if lib.ecrad_hip_abi_sizeof(i) != C.sizeof(s):
+            raise EcradHipError(f"struct layout mismatch for {s.__name__}: "
+                                f"C {lib.ecrad_hip_abi_sizeof(i)} vs ctypes {C.sizeof(s)}")
+    return lib
+
+
+# ----------------------------------------------------------------------------------------------------
+def setup_radiation(config: Config) -> None:
+    """setup_radiation (radiation_interface.F90:37-158): read and map every look-up table."""
+    config.consolidate()
+    for m in (config.i_gas_model_sw, config.i_gas_model_lw):
+        if m != IGasModelECCKD:
+            raise ConfigError("only the ECCKD gas model is implemented in this build "
+                              "(RRTMG-IFS is a later scope row)")
+    if ISolverSpartacus in (config.i_solver_sw, config.i_solver_lw):
+        raise ConfigError("the SPARTACUS solver is not implemented in this build")
+    # setup_gas_optics (radiation_ecckd_interface.F90:27-150)
+    if config.do_sw:
+        config.gas_optics_sw = CkdModel(config.gas_optics_sw_file_name)
+        config.n_g_sw = config.gas_optics_sw.ng
+        if config.do_cloud_aerosol_per_sw_g_point:
+            config.n_bands_sw = config.n_g_sw
+            config.i_band_from_reordered_g_sw = np.arange(1, config.n_g_sw + 1, dtype=np.int32)
+        else:
+            config.n_bands_sw = config.gas_optics_sw.spectral_def.nband
+            config.i_band_from_reordered_g_sw = config.gas_optics_sw.spectral_def.i_band_number.astype(np.int32)
+    if config.do_lw:
+        config.gas_optics_lw = CkdModel(config.gas_optics_lw_file_name)
+        config.n_g_lw = config.gas_optics_lw.ng
+        if config.do_cloud_aerosol_per_lw_g_point:
+            config.n_bands_lw = config.n_g_lw
+            config.i_band_from_reordered_g_lw = np.arange(1, config.n_g_lw + 1, dtype=np.int32)
+        else:
+            config.n_bands_lw = config.gas_optics_lw.spectral_def.nband
+            config.i_band_from_reordered_g_lw = config.gas_optics_lw.spectral_def.i_band_number.astype(np.int32)
+    if config.do_save_spectral_flux:
+        raise ConfigError("do_save_spectral_flux (spectral flux profiles) is not implemented in this build")
+
+    if config.do_lw_aerosol_scattering and not config.do_lw_cloud_scattering:
+        raise ConfigError("longwave aerosol scattering requires longwave cloud scattering")
+    config.n_g_lw_if_scattering = config.n_g_lw if config.do_lw_aerosol_scattering else 0
+    config.n_bands_lw_if_scattering = config.n_bands_lw if config.do_lw_cloud_scattering else 0
+    if config.do_lw_cloud_scattering and config.i_solver_lw == ISolverMcICA:
+        config.n_g_lw_if_scattering = config.n_g_lw
+
+    # consolidate_sw_albedo_intervals / consolidate_lw_emiss_intervals (radiation_config.F90:1947-2100)
+    def intervals(index, bound, full_spectrum, ng):
+        ninterval = 0
+        for j, v in enumerate(index[:NMaxAlbedoIntervals]):
+            if v > 0:
+                ninterval = j + 1
+            else:
+                break
+        if ninterval < 1:
+            idx, ncanopy = [1], (ng if full_spectrum else 1)
+            ninterval = 1
+        else:
+            idx = list(index[:ninterval])
+            ncanopy = ng if full_spectrum else max(idx)
+        return idx, list(bound[:ninterval - 1]), ncanopy
+
+    if config.do_sw:
+        idx, bnd, config.n_canopy_bands_sw = intervals(config.i_sw_albedo_index, config.sw_albedo_wavelength_bound,
+                                                       config.use_canopy_full_spectrum_sw, config.n_g_sw)
+        config.sw_albedo_weights = np.ascontiguousarray(
+            config.gas_optics_sw.spectral_def.calc_mapping_from_bands(
+                bnd, idx, use_bands=not config.do_cloud_aerosol_per_sw_g_point))
+        if config.do_nearest_spectral_sw_albedo:
+            config.i_albedo_from_band_sw = (np.argmax(config.sw_albedo_weights, axis=1) + 1).astype(np.int32)
+    if config.do_lw:
+        idx, bnd, config.n_canopy_bands_lw = intervals(config.i_lw_emiss_index, config.lw_emiss_wavelength_bound,
+                                                       config.use_canopy_full_spectrum_lw, config.n_g_lw)
+        config.lw_emiss_weights = np.ascontiguousarray(
+            config.gas_optics_lw.spectral_def.calc_mapping_from_bands(
+                bnd, idx, use_bands=not config.do_cloud_aerosol_per_lw_g_point))
+        if config.do_nearest_spectral_lw_emiss:
+            config.i_emiss_from_band_lw = (np.argmax(config.lw_emiss_weights, axis=1) + 1).astype(np.int32)
+
+    # setup_general_cloud_optics (radiation_general_cloud_optics.F90:32-128)
+    if config.do_clouds:
+        if not config.use_general_cloud_optics:
+            raise ConfigError("ecCKD gas optics requires use_general_cloud_optics=true")
+        names = [n for n in config.cloud_type_name if n]
+        if not names:
+            names = ["mie_droplet", "baum-general-habit-mixture_ice"]
+        config.n_cloud_types = len(names)
+        config.cloud_optics_sw, config.cloud_optics_lw = [], []
+        for j, name in enumerate(names):
+            if name.startswith("/"):
+                fn = name
+            elif name.endswith(".nc"):
+                fn = os.path.join(config.directory_name, name)
+            else:
+                fn = os.path.join(config.directory_name, name + "_scattering.nc")
+            thick = config.use_thick_cloud_spectral_averaging[j]
+            if config.do_sw:
+                config.cloud_optics_sw.append(GeneralCloudOptics(
+                    fn, config.gas_optics_sw.spectral_def, not config.do_cloud_aerosol_per_sw_g_point,
+                    thick, SOLAR_REFERENCE_TEMPERATURE, name))
+            if config.do_lw:
+                config.cloud_optics_lw.append(GeneralCloudOptics(
+                    fn, config.gas_optics_lw.spectral_def, not config.do_cloud_aerosol_per_lw_g_point,
+                    thick, TERRESTRIAL_REFERENCE_TEMPERATURE, name))
+
+    # setup_aerosol_optics (radiation_aerosol_optics.F90:36-90)
+    if config.use_aerosols:
+        if config.n_aerosol_types > 0:
+            if not config.use_general_aerosol_optics:
+                raise ConfigError("only use_general_aerosol_optics=true is implemented")
+            config.aerosol_optics = AerosolOptics(
+                config.aerosol_optics_file_name,
+                config.gas_optics_sw.spectral_def if config.do_sw else None,
+                config.gas_optics_lw.spectral_def if config.do_lw else None,
+                config.do_cloud_aerosol_per_sw_g_point, config.do_cloud_aerosol_per_lw_g_point,
+                config.do_sw, config.do_lw)
+            config.aerosol_optics.set_types(config.i_aerosol_type_map[:config.n_aerosol_types])
+        else:
+            config.use_aerosols = False   # "Aerosols are deactivated if this is zero"
+
+    if ISolverMcICA in (config.i_solver_sw, config.i_solver_lw):
+        config.pdf_sampler = PdfSampler(config.cloud_pdf_file_name)
+
+
+# ----------------------------------------------------------------------------------------------------
+def build_config_struct(config: Config):
+    """Flatten ``config`` into an ecrad_config_t.  Returns (struct, keepalive list)."""
+    keep = []
+
+    def d(a):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        keep.append(a)
+        return abi.dptr(a)
+
+    def i(a):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        keep.append(a)
+        return abi.iptr(a)
+
+    c = abi.Config()
+    c.abi_version = abi.ABI_VERSION
+    for name in ("do_sw", "do_lw", "do_clear", "do_sw_direct", "do_lw_derivatives", "do_clouds",
+                 "use_aerosols", "i_solver_sw", "i_solver_lw", "i_gas_model_sw", "i_gas_model_lw",
+                 "do_lw_cloud_scattering", "do_lw_aerosol_scattering", "do_sw_delta_scaling_with_gases",
+                 "use_general_cloud_optics", "is_homogeneous", "i_overlap_scheme", "use_beta_overlap",
+                 "use_vectorizable_generator", "i_cloud_pdf_shape", "do_cloud_aerosol_per_sw_g_point",
+                 "do_cloud_aerosol_per_lw_g_point", "do_surface_sw_spectral_flux", "do_toa_spectral_flux",
+                 "do_canopy_fluxes_sw", "do_canopy_fluxes_lw", "use_canopy_full_spectrum_sw",
+                 "use_canopy_full_spectrum_lw", "do_nearest_spectral_sw_albedo",
+                 "do_nearest_spectral_lw_emiss", "do_save_spectral_flux", "n_g_sw", "n_g_lw", "n_bands_sw",
+                 "n_bands_lw", "n_g_lw_if_scattering", "n_bands_lw_if_scattering", "n_canopy_bands_sw",
+                 "n_canopy_bands_lw", "n_cloud_types"):
+        setattr(c, name, int(getattr(config, name)))
+    c.cloud_fraction_threshold = config.cloud_fraction_threshold
+    c.cloud_mixing_ratio_threshold = config.cloud_mixing_ratio_threshold
+    c.cloud_inhom_decorr_scaling = config.cloud_inhom_decorr_scaling
+    c.max_cloud_od = config.max_cloud_od
+    c.i_band_from_reordered_g_sw = i(config.i_band_from_reordered_g_sw)
+    c.i_band_from_reordered_g_lw = i(config.i_band_from_reordered_g_lw)
+    if config.sw_albedo_weights is not None:
+        c.n_albedo_intervals_sw = config.sw_albedo_weights.shape[1]
+        c.sw_albedo_weights = d(config.sw_albedo_weights)
+    if config.lw_emiss_weights is not None:
+        c.n_emiss_intervals_lw = config.lw_emiss_weights.shape[1]
+        c.lw_emiss_weights = d(config.lw_emiss_weights)
+    c.i_albedo_from_band_sw = i(config.i_albedo_from_band_sw)
+    c.i_emiss_from_band_lw = i(config.i_emiss_from_band_lw)
+
+    def fill_ckd(dst, m):
+        if m is None:
+            return
+        dst.is_sw = int(m.is_sw)
+        dst.ng, dst.npress, dst.ntemp, dst.ngas, dst.nplanck = m.ng, m.npress, m.ntemp, m.ngas, m.nplanck
+        dst.log_pressure1, dst.d_log_pressure, dst.d_temperature = m.log_pressure1, m.d_log_pressure, m.d_temperature
+        dst.temperature1_planck, dst.d_temperature_planck = m.temperature1_planck, m.d_temperature_planck
+        dst.temperature1 = d(m.temperature1)
+        dst.planck_function = d(m.planck_function)
+        dst.norm_solar_irradiance = d(m.norm_solar_irradiance)
+        dst.norm_amplitude_solar_irradiance = d(m.norm_amplitude_solar_irradiance)
+        dst.rayleigh_molar_scat = d(m.rayleigh_molar_scat)
+        for j, g in enumerate(m.single_gas):
+            sg = dst.single_gas[j]
+            sg.i_gas_code, sg.i_conc_dependence, sg.n_mole_frac = g.i_gas_code, g.i_conc_dependence, g.n_mole_frac
+            sg.reference_mole_frac, sg.log_mole_frac1, sg.d_log_mole_frac = \
+                g.reference_mole_frac, g.log_mole_frac1, g.d_log_mole_frac
+            sg.molar_abs = d(g.molar_abs)
+
+    fill_ckd(c.gas_optics_sw, config.gas_optics_sw)
+    fill_ckd(c.gas_optics_lw, config.gas_optics_lw)
+    for arr, src in ((c.cloud_optics_sw, config.cloud_optics_sw), (c.cloud_optics_lw, config.cloud_optics_lw)):
+        for j, co in enumerate(src or []):
+            arr[j].n_bands, arr[j].n_effective_radius = co.n_bands, co.n_effective_radius
+            arr[j].effective_radius_0, arr[j].d_effective_radius = co.effective_radius_0, co.d_effective_radius
+            arr[j].mass_ext, arr[j].ssa, arr[j].asymmetry = d(co.mass_ext), d(co.ssa), d(co.asymmetry)
+    ao = config.aerosol_optics
+    if ao is not None and config.use_aerosols:
+        a = c.aerosol_optics
+        a.n_bands_sw, a.n_bands_lw = ao.n_bands_sw, ao.n_bands_lw
+        a.n_type_phobic, a.n_type_philic, a.nrh = ao.n_type_phobic, ao.n_type_philic, ao.nrh
+        a.use_hydrophilic, a.ntype = int(ao.use_hydrophilic), ao.ntype
+        a.iclass, a.itype = i(ao.iclass), i(ao.itype)
+        a.rh_lower = d(getattr(ao, "rh_lower", None))
+        for tag in ("sw", "lw"):
+            for kind in ("phobic", "philic"):
+                for q in ("mass_ext", "ssa", "g"):
+                    n = f"{q}_{tag}_{kind}"
+                    setattr(a, n, d(getattr(ao, n, None)))
+    ps = config.pdf_sampler
+    if ps is not None:
+        c.pdf_sampler.ncdf, c.pdf_sampler.nfsd = ps.ncdf, ps.nfsd
+        c.pdf_sampler.fsd1, c.pdf_sampler.inv_fsd_interval = ps.fsd1, ps.inv_fsd_interval
+        c.pdf_sampler.val = d(ps.val)
+    return c, keep
+
+
+def build_inputs_struct(config: Config, ncol, nlev, single_level, thermodynamics, gas, cloud, aerosol):
+    """Flatten the five input types into an ecrad_inputs_t over host numpy arrays."""
+    keep = []
+
+    def d(a, shape=None):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if shape is not None and tuple(a.shape) != tuple(shape):
+            raise ValueError(f"array has shape {a.shape}, expected {shape}")
+        keep.append(a)
+        return abi.dptr(a)
+
+    s = abi.Inputs()
+    s.memory = abi.MEM_HOST
+    s.solar_irradiance = float(single_level.solar_irradiance)
+    s.spectral_solar_cycle_multiplier = float(single_level.spectral_solar_cycle_multiplier)
+    s.pressure_hl = d(thermodynamics.pressure_hl, (nlev + 1, ncol))
+    s.temperature_hl = d(thermodynamics.temperature_hl, (nlev + 1, ncol))
+    s.h2o_sat_liq = d(thermodynamics.h2o_sat_liq)
+    s.cos_sza = d(single_level.cos_sza, (ncol,))
+    s.skin_temperature = d(single_level.skin_temperature, (ncol,))
+    s.n_sw_albedo = single_level.sw_albedo.shape[0]
+    s.sw_albedo = d(single_level.sw_albedo)
+    s.sw_albedo_direct = d(single_level.sw_albedo_direct)
+    s.n_lw_emissivity = single_level.lw_emissivity.shape[0]
+    s.lw_emissivity = d(single_level.lw_emissivity)
+    if single_level.iseed is not None:
+        iseed = np.ascontiguousarray(single_level.iseed, dtype=np.int32)
+        keep.append(iseed)
+        s.iseed = abi.iptr(iseed)
+    s.gas_mixing_ratio = d(gas.mixing_ratio, (12, nlev, ncol))
+    if cloud is not None and config.do_clouds:
+        s.n_cloud_types = cloud.ntype
+        # INOUT: must alias the caller's array so the crop side effect is visible
+        if not (cloud.fraction.dtype == np.float64 and cloud.fraction.flags["C_CONTIGUOUS"]):
+            raise ValueError("cloud.fraction must be C-contiguous float64 (it is modified in place)")
+        s.cloud_fraction = abi.dptr(cloud.fraction)
+        s.cloud_mixing_ratio = d(cloud.mixing_ratio, (cloud.ntype, nlev, ncol))
+        s.cloud_effective_radius = d(cloud.effective_radius, (cloud.ntype, nlev, ncol))
+        s.cloud_fractional_std = d(cloud.fractional_std, (nlev, ncol))
+        s.cloud_overlap_param = d(cloud.overlap_param, (nlev - 1, ncol))
+    if aerosol is not None and config.use_aerosols:
+        s.n_aerosol_types = aerosol.mixing_ratio.shape[0]
+        s.aerosol_istartlev, s.aerosol_iendlev = aerosol.istartlev, aerosol.iendlev
+        s.aerosol_mixing_ratio = d(aerosol.mixing_ratio)
+    return s, keep
+
+
+def build_flux_struct(flux: Flux):
+    f = abi.Flux()
+    f.memory = abi.MEM_HOST
+    for name in abi.FLUX_FIELDS:
+        arr = getattr(flux, name)
+        if arr is not None:
+            setattr(f, name, abi.dptr(arr))
+    return f
+
+
+# ----------------------------------------------------------------------------------------------------
+class Radiation:
+    """Owns a configured handle: ``Radiation(config)`` == ``call setup_radiation(config)``;
+    ``.radiation(...)`` == ``call radiation(ncol,nlev,istartcol,iendcol,config,...)``."""
+
+    def __init__(self, config: Config, backend="hip", device_id: int = -1):
+        if not config.is_consolidated or config.gas_optics_lw is None and config.gas_optics_sw is None:
+            setup_radiation(config)
+        self.config = config
+        self.cconfig, self._keep = build_config_struct(config)
+        self.backend = backend
+        self.lib = None
+        self.handle = None
+        if backend == "hip":
+            self.lib = load_library()
+            h = C.c_void_p()
+            st = self.lib.ecrad_hip_create(C.byref(h), device_id)
+            if st != 0:
+                raise EcradHipError(f"ecrad_hip_create failed with status {st} (no usable gfx950 device?)")
+            self.handle = h
+            self._check(self.lib.ecrad_hip_setup(self.handle, C.byref(self.cconfig)), "ecrad_hip_setup")
+        elif not callable(backend):
+            raise ValueError("backend must be 'hip' or a callable (tests/bench cpu_baseline only)")
+
+    def _check(self, status: int, what: str) -> None:
+        if status != 0:
+            msg = self.lib.ecrad_hip_last_error(self.handle)
+            raise EcradHipError(f"{what} failed with status {status}: {msg.decode() if msg else ''}")
+
+    def set_gas_units(self, gas) -> None:
+        """set_gas_units (radiation_interface.F90:164-190 -> radiation_ecckd_interface.F90:153-171)."""
+        gas.set_units(IVolumeMixingRatio)
+
+    def radiation(self, ncol, nlev, istartcol, iendcol, single_level, thermodynamics, gas,
+                  cloud, aerosol, flux) -> None:
+        cin, keep = build_inputs_struct(self.config, ncol, nlev, single_level, thermodynamics, gas, cloud, aerosol)
+        cflux = build_flux_struct(flux)
+        if self.backend == "hip":
+            self._check(self.lib.ecrad_hip_radiation(self.handle, ncol, nlev, istartcol, iendcol,
+                                                     C.byref(cin), C.byref(cflux)), "ecrad_hip_radiation")
+        else:
+            st = self.backend(self.cconfig, ncol, nlev, istartcol, iendcol, cin, cflux)
+            if st != 0:
+                raise RuntimeError(f"backend returned status {st}")
+        del keep
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_double()
+        self._check(self.lib.ecrad_hip_last_kernel_ms(self.handle, C.byref(ms)), "ecrad_hip_last_kernel_ms")
+        return ms.value
+
+    def close(self) -> None:
+        if self.handle is not None and self.lib is not None:
+            self.lib.ecrad_hip_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

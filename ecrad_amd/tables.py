@@ -1,0 +1,226 @@
+"""Look-up tables that ``setup_radiation`` hangs off ``config`` (host side, setup time only).
+
+Each class restates the *setup* half of one reference module; the per-call half runs on the GPU.
+numpy arrays are stored so that their C-order bytes equal the reference's Fortran arrays
+(first Fortran index == last numpy index), i.e. they can be handed to the C-ABI unchanged.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .ncfile import NcFile
+from .spectral import SpectralDefinition
+
+# radiation_gas_constants.F90:28-70
+GAS_LOWER_CASE_NAMES = ["h2o", "co2", "o3", "n2o", "co", "ch4", "o2", "cfc11", "cfc12",
+                        "hcfc22", "ccl4", "no2"]
+NMaxGases = 12
+IH2O, ICO2, IO3, IN2O, ICO, ICH4, IO2, ICFC11, ICFC12, IHCFC22, ICCl4, INO2 = range(1, 13)
+AIR_MOLAR_MASS = 28.970
+GAS_MOLAR_MASS = [0.0, 18.0152833, 44.011, 47.9982, 44.013, 28.0101, 16.043, 31.9988,
+                  137.3686, 120.914, 86.469, 153.823, 46.0055]
+
+IConcDependenceNone, IConcDependenceLinear, IConcDependenceLUT, IConcDependenceRelativeLinear = range(4)
+
+
+class CkdGas:
+    """ckd_gas_type + read_ckd_gas (radiation_ecckd_gas.F90:39-124)."""
+
+    def __init__(self, nc: NcFile, gas_name: str, i_gas_code: int):
+        self.name = gas_name
+        self.i_gas_code = i_gas_code
+        self.i_conc_dependence = int(nc.get_scalar(gas_name + "_conc_dependence_code"))
+        self.reference_mole_frac = 0.0
+        self.log_mole_frac1 = 0.0
+        self.d_log_mole_frac = 1.0
+        self.n_mole_frac = 0
+        # numpy ([nconc,] ntemp, npress, ng) == Fortran (ng, npress, ntemp[, nconc])
+        self.molar_abs = np.ascontiguousarray(nc.get(gas_name + "_molar_absorption_coeff"))
+        if self.i_conc_dependence == IConcDependenceLUT:
+            mole_fraction = nc.get(gas_name + "_mole_fraction")
+            self.log_mole_frac1 = float(np.log(mole_fraction[0]))
+            self.n_mole_frac = int(mole_fraction.size)
+            self.d_log_mole_frac = float((np.log(mole_fraction[-1]) - self.log_mole_frac1)
+                                         / (self.n_mole_frac - 1))
+        if self.i_conc_dependence == IConcDependenceRelativeLinear:
+            self.reference_mole_frac = nc.get_scalar(gas_name + "_reference_mole_fraction")
+
+
+class CkdModel:
+    """ckd_model_type + read_ckd_model (radiation_ecckd.F90:34-119, :127-237)."""
+
+    def __init__(self, filename: str):
+        self.filename = filename
+        with NcFile(filename) as nc:
+            pressure_lut = nc.get("pressure")
+            self.log_pressure1 = float(np.log(pressure_lut[0]))
+            self.npress = int(pressure_lut.size)
+            self.d_log_pressure = float(np.log(pressure_lut[1]) - self.log_pressure1)
+            temperature_full = nc.get("temperature")          # numpy (ntemp, npress)
+            self.temperature1 = np.ascontiguousarray(temperature_full[0, :])
+            self.d_temperature = float(temperature_full[1, 0] - temperature_full[0, 0])
+            self.ntemp = int(temperature_full.shape[0])
+            self.nplanck = 0
+            self.temperature1_planck = 0.0
+            self.d_temperature_planck = 1.0
+            self.planck_function = None
+            self.norm_solar_irradiance = None
+            self.norm_amplitude_solar_irradiance = None
+            self.rayleigh_molar_scat = None
+            if nc.exists("solar_irradiance"):
+                self.is_sw = True
+                si = nc.get("solar_irradiance")
+                self.norm_solar_irradiance = si / np.sum(si)
+                self.rayleigh_molar_scat = nc.get("rayleigh_molar_scattering_coeff")
+            else:
+                self.is_sw = False
+                temperature_planck = nc.get("temperature_planck")
+                self.nplanck = int(temperature_planck.size)
+                self.temperature1_planck = float(temperature_planck[0])
+                self.d_temperature_planck = float(temperature_planck[1] - temperature_planck[0])
+                # numpy (nplanck, ng) == Fortran (ng, nplanck)
+                self.planck_function = np.ascontiguousarray(nc.get("planck_function"))
+            self.spectral_def = SpectralDefinition.read(nc)
+            self.ng = self.spectral_def.ng
+            self.ngas = int(nc.get_scalar("n_gases"))
+            names = nc.global_attr("constituent_id").split()
+            if len(names) != self.ngas:
+                raise ValueError(f"constituent_id {names} does not list n_gases={self.ngas} gases")
+            self.single_gas = []
+            self.i_gas_mapping = [0] * (NMaxGases + 1)
+            for jgas, name in enumerate(names, start=1):
+                code = GAS_LOWER_CASE_NAMES.index(name) + 1 if name in GAS_LOWER_CASE_NAMES else 0
+                self.i_gas_mapping[code] = jgas
+                self.single_gas.append(CkdGas(nc, name, code))
+
+
+class GeneralCloudOptics:
+    """general_cloud_optics_type%setup (radiation_general_cloud_optics_data.F90:71-243)."""
+
+    def __init__(self, file_name: str, specdef: SpectralDefinition, use_bands: bool,
+                 use_thick_averaging: bool, weighting_temperature: float, type_name: str = ""):
+        self.type_name = type_name
+        with NcFile(file_name) as nc:
+            wavenumber = nc.get("wavenumber")
+            effective_radius = nc.get("effective_radius")
+            mass_ext = nc.get("mass_extinction_coefficient")   # numpy (nre, nwav)
+            ssa = nc.get("single_scattering_albedo")
+            asymmetry = nc.get("asymmetry_factor")
+        d = np.diff(effective_radius)
+        diff_spread = (d.max() - d.min()) / np.abs(d).min()
+        if diff_spread > 0.01:
+            raise ValueError(f"effective_radius in {file_name} is not evenly spaced to 1%")
+        self.n_effective_radius = int(effective_radius.size)
+        self.effective_radius_0 = float(effective_radius[0])
+        self.d_effective_radius = float(effective_radius[1] - effective_radius[0])
+        mapping = specdef.calc_mapping(wavenumber, weighting_temperature=weighting_temperature,
+                                       use_bands=use_bands)      # (nband, nwav)
+        # delta_eddington on the file data (radiation_delta_eddington.h:21-35)
+        f = asymmetry * asymmetry
+        mass_ext = mass_ext * (1.0 - ssa * f)
+        ssa = ssa * (1.0 - f) / (1.0 - ssa * f)
+        asymmetry = asymmetry / (1.0 + asymmetry)
+        me = mass_ext @ mapping.T                                  # (nre, nband)
+        s = (mass_ext * ssa) @ mapping.T / me
+        g = (mass_ext * ssa * asymmetry) @ mapping.T / (me * s)
+        if use_thick_averaging:
+            ref_inf = np.sqrt((1.0 - ssa) / (1.0 - ssa * asymmetry))
+            ref_inf = (1.0 - ref_inf) / (1.0 + ref_inf)
+            s = ref_inf @ mapping.T
+            s = 4.0 * s / ((1.0 + s) ** 2 - g * (1.0 - s) ** 2)
+        # revert_delta_eddington (radiation_delta_eddington.h:133-142)
+        g = g / (1.0 - g)
+        f = g * g
+        s = s / (1.0 - f + f * s)
+        me = me / (1.0 - s * f)
+        self.mass_ext = np.ascontiguousarray(me)
+        self.ssa = np.ascontiguousarray(s)
+        self.asymmetry = np.ascontiguousarray(g)
+        self.n_bands = int(me.shape[1])
+
+
+# radiation_aerosol_optics_data.F90:40-41
+IAerosolClassUndefined, IAerosolClassIgnored, IAerosolClassHydrophobic, IAerosolClassHydrophilic = range(4)
+
+
+class AerosolOptics:
+    """aerosol_optics_type filled by setup_general_aerosol_optics
+    (radiation_aerosol_optics.F90:96-338) + initialize_types/set_types
+    (radiation_aerosol_optics_data.F90:318-334, :500-633)."""
+
+    def __init__(self, file_name: str, specdef_sw, specdef_lw, per_g_sw: bool, per_g_lw: bool,
+                 do_sw: bool = True, do_lw: bool = True):
+        with NcFile(file_name) as nc:
+            if not nc.exists("wavenumber"):
+                raise ValueError("legacy band-wise aerosol files are not supported: " + file_name)
+            self.use_hydrophilic = nc.exists("mass_ext_hydrophilic")
+            wavenumber = nc.get("wavenumber")
+            me_pho = nc.get("mass_ext_hydrophobic")     # (ntype, nwav)
+            ssa_pho = nc.get("ssa_hydrophobic")
+            g_pho = nc.get("asymmetry_hydrophobic")
+            if self.use_hydrophilic:
+                me_phi = nc.get("mass_ext_hydrophilic")  # (ntype, nrh, nwav)
+                ssa_phi = nc.get("ssa_hydrophilic")
+                g_phi = nc.get("asymmetry_hydrophilic")
+                self.rh_lower = np.ascontiguousarray(nc.get("relative_humidity1"))
+        self.n_type_phobic = int(me_pho.shape[0])
+        self.n_type_philic = int(me_phi.shape[0]) if self.use_hydrophilic else 0
+        self.nrh = int(self.rh_lower.size) if self.use_hydrophilic else 0
+        self.n_bands_sw = self.n_bands_lw = 0
+
+        def project(mapping, me, ssa, g):
+            m = me @ mapping.T
+            s = (me * ssa) @ mapping.T / m
+            a = (me * ssa * g) @ mapping.T / (m * s)
+            return (np.ascontiguousarray(m), np.ascontiguousarray(s), np.ascontiguousarray(a))
+
+        for tag, do, sd, per_g in (("sw", do_sw, specdef_sw, per_g_sw), ("lw", do_lw, specdef_lw, per_g_lw)):
+            if not do:
+                continue
+            mapping = sd.calc_mapping(wavenumber, use_bands=not per_g)
+            setattr(self, "n_bands_" + tag, int(mapping.shape[0]))
+            m, s, a = project(mapping, me_pho, ssa_pho, g_pho)
+            setattr(self, f"mass_ext_{tag}_phobic", m)
+            setattr(self, f"ssa_{tag}_phobic", s)
+            setattr(self, f"g_{tag}_phobic", a)
+            if self.use_hydrophilic:
+                m, s, a = project(mapping, me_phi, ssa_phi, g_phi)
+                setattr(self, f"mass_ext_{tag}_philic", m)
+                setattr(self, f"ssa_{tag}_philic", s)
+                setattr(self, f"g_{tag}_philic", a)
+        self.ntype = 0
+        self.iclass = np.zeros(0, dtype=np.int32)
+        self.itype = np.zeros(0, dtype=np.int32)
+
+    def set_types(self, itypes) -> None:
+        self.ntype = len(itypes)
+        self.iclass = np.full(self.ntype, IAerosolClassUndefined, dtype=np.int32)
+        self.itype = np.zeros(self.ntype, dtype=np.int32)
+        for j, it in enumerate(itypes):
+            if it == 0:
+                self.iclass[j] = IAerosolClassIgnored
+            elif it > 0:
+                if it > self.n_type_phobic:
+                    raise ValueError(f"hydrophobic type must be in the range 1 to {self.n_type_phobic}")
+                self.iclass[j] = IAerosolClassHydrophobic
+                self.itype[j] = it
+            else:
+                if not self.use_hydrophilic:
+                    raise ValueError("attempt to set hydrophilic aerosol type when no such types present")
+                if -it > self.n_type_philic:
+                    raise ValueError(f"hydrophilic type must be in the range 1 to {self.n_type_philic}")
+                self.iclass[j] = IAerosolClassHydrophilic
+                self.itype[j] = -it
+
+
+class PdfSampler:
+    """pdf_sampler_type%setup (radiation_pdf_sampler.F90:56-92)."""
+
+    def __init__(self, file_name: str):
+        with NcFile(file_name) as nc:
+            fsd = nc.get("fsd")
+            self.val = np.ascontiguousarray(nc.get("x"))    # numpy (nfsd, ncdf) == Fortran (ncdf, nfsd)
+        self.ncdf = int(self.val.shape[1])
+        self.nfsd = int(self.val.shape[0])
+        self.fsd1 = float(fsd[0])
+        self.inv_fsd_interval = float(1.0 / (fsd[1] - fsd[0]))

@@ -1,0 +1,305 @@
+/*
+ * ecrad_hip.h -- C-ABI of the MI355X (gfx950) implementation of ecRad's radiation() hot path.
+ *
+ * This is the drop-in boundary: the entry points below are what a thin ISO_C_BINDING layer
+ * inside the reference's radiation/radiation_interface.F90 would bind instead of running the
+ * CPU stages (gas optics -> cloud optics -> aerosol optics -> LW/SW solvers).  Each struct
+ * flattens one of the reference's derived types into plain pointers + sizes; array layouts are
+ * exactly the reference's Fortran layouts (first index fastest), so the Fortran side passes
+ * c_loc(array) with no copies.
+ *
+ *   ecrad_hip_create      <-> (new) one handle per host thread / GPU
+ *   ecrad_hip_setup       <-> setup_radiation(config)          radiation_interface.F90:37
+ *                             (called AFTER the Fortran setup has filled config's look-up tables)
+ *   ecrad_hip_radiation   <-> radiation(ncol,nlev,istartcol,iendcol,config,single_level,
+ *                                       thermodynamics,gas,cloud,aerosol,flux)
+ *                                                              radiation_interface.F90:200
+ *   ecrad_hip_gas_optics  <-> gas_optics (ecCKD)               radiation_ecckd_interface.F90:174
+ *                             (stage-level entry used by parity tests; not needed by a host model)
+ *   ecrad_hip_destroy     <-> (new)
+ *
+ * All functions return 0 on success or a negative ECRAD_E* status; the Fortran wrapper maps a
+ * non-zero status to radiation_abort() (utilities/radiation_io.F90:44).  There is NO CPU
+ * fallback: if no gfx950 device is usable the calls fail with ECRAD_ENODEVICE.
+ *
+ * No torch / C++ types appear in any signature.
+ */
+#ifndef ECRAD_HIP_H
+#define ECRAD_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ECRAD_ABI_VERSION 1
+
+/* Status codes */
+#define ECRAD_OK            0
+#define ECRAD_EINVAL      (-1)  /* bad argument / inconsistent sizes            */
+#define ECRAD_ENODEVICE   (-2)  /* no usable HIP device                          */
+#define ECRAD_EUNSUPPORTED (-3) /* configuration outside the implemented scope   */
+#define ECRAD_EHIP        (-4)  /* HIP runtime error (see ecrad_hip_last_error)  */
+#define ECRAD_ENOMEM      (-5)
+#define ECRAD_ENOTSETUP   (-6)
+
+/* Gas codes: radiation_gas_constants.F90:28-41 (index of the 3rd dim of gas%mixing_ratio) */
+#define ECRAD_NMAXGASES 12
+enum { ECRAD_IH2O = 1, ECRAD_ICO2, ECRAD_IO3, ECRAD_IN2O, ECRAD_ICO, ECRAD_ICH4, ECRAD_IO2,
+       ECRAD_ICFC11, ECRAD_ICFC12, ECRAD_IHCFC22, ECRAD_ICCL4, ECRAD_INO2 };
+
+/* radiation_ecckd_gas.F90:29-34 */
+enum { ECRAD_CONC_NONE = 0, ECRAD_CONC_LINEAR = 1, ECRAD_CONC_LUT = 2, ECRAD_CONC_RELATIVE_LINEAR = 3 };
+/* radiation_config.F90:53-56 */
+enum { ECRAD_SOLVER_CLOUDLESS = 0, ECRAD_SOLVER_HOMOGENEOUS = 1, ECRAD_SOLVER_MCICA = 2,
+       ECRAD_SOLVER_SPARTACUS = 3, ECRAD_SOLVER_TRIPLECLOUDS = 4 };
+/* radiation_config.F90:87-89 */
+enum { ECRAD_GAS_MONOCHROMATIC = 0, ECRAD_GAS_IFSRRTMG = 1, ECRAD_GAS_ECCKD = 2 };
+/* radiation_cloud_cover.F90:32-36 */
+enum { ECRAD_OVERLAP_MAX_RAN = 0, ECRAD_OVERLAP_EXP_RAN = 1, ECRAD_OVERLAP_EXP_EXP = 2 };
+/* radiation_config.F90:124-126 */
+enum { ECRAD_PDF_LOGNORMAL = 0, ECRAD_PDF_GAMMA = 1 };
+/* radiation_aerosol_optics_data.F90 IAerosolClass* */
+enum { ECRAD_AEROSOL_UNDEFINED = 0, ECRAD_AEROSOL_IGNORED = 1, ECRAD_AEROSOL_HYDROPHOBIC = 2,
+       ECRAD_AEROSOL_HYDROPHILIC = 3 };
+
+/* Where the input/output arrays of ecrad_inputs_t / ecrad_flux_t live */
+enum { ECRAD_MEM_HOST = 0, ECRAD_MEM_DEVICE = 1 };
+
+#define ECRAD_NMAXCLOUDTYPES 12
+#define ECRAD_NMAXAEROSOLTYPES 256
+
+/* ---- ckd_gas_type, radiation_ecckd_gas.F90:39-77 ------------------------------------------- */
+typedef struct ecrad_ckd_gas {
+  int32_t i_gas_code;          /* 0 = composite of well-mixed gases, else ECRAD_I* */
+  int32_t i_conc_dependence;   /* ECRAD_CONC_* */
+  int32_t n_mole_frac;         /* LUT only */
+  int32_t reserved_;
+  double  reference_mole_frac; /* RELATIVE_LINEAR only */
+  double  log_mole_frac1;      /* LUT only */
+  double  d_log_mole_frac;     /* LUT only */
+  /* molar_abs(ng,npress,ntemp) or molar_abs_conc(ng,npress,ntemp,n_mole_frac), m2 mol-1 */
+  const double* molar_abs;
+} ecrad_ckd_gas_t;
+
+/* ---- ckd_model_type, radiation_ecckd.F90:34-119 --------------------------------------------- */
+typedef struct ecrad_ckd_model {
+  int32_t is_sw;
+  int32_t ng;
+  int32_t npress, ntemp;
+  int32_t ngas;
+  int32_t nplanck;                               /* LW only */
+  double  log_pressure1, d_log_pressure;
+  double  d_temperature;
+  double  temperature1_planck, d_temperature_planck;
+  const double* temperature1;                    /* (npress) */
+  const double* planck_function;                 /* (ng,nplanck)  LW */
+  const double* norm_solar_irradiance;           /* (ng)  SW */
+  const double* norm_amplitude_solar_irradiance; /* (ng)  SW, may be NULL */
+  const double* rayleigh_molar_scat;             /* (ng)  SW */
+  ecrad_ckd_gas_t single_gas[ECRAD_NMAXGASES];
+} ecrad_ckd_model_t;
+
+/* ---- general_cloud_optics_type, radiation_general_cloud_optics_data.F90:31-62 --------------- */
+typedef struct ecrad_cloud_optics {
+  int32_t n_bands;             /* first dim of the three tables */
+  int32_t n_effective_radius;
+  double  effective_radius_0, d_effective_radius;
+  const double* mass_ext;      /* (n_bands, n_effective_radius) */
+  const double* ssa;
+  const double* asymmetry;
+} ecrad_cloud_optics_t;
+
+/* ---- aerosol_optics_type, radiation_aerosol_optics_data.F90:50-148 (runtime part) ----------- */
+typedef struct ecrad_aerosol_optics {
+  int32_t n_bands_sw, n_bands_lw;
+  int32_t n_type_phobic, n_type_philic, nrh;
+  int32_t use_hydrophilic;
+  int32_t ntype;                              /* = config%n_aerosol_types */
+  int32_t reserved_;
+  const int32_t* iclass;                      /* (ntype) ECRAD_AEROSOL_* */
+  const int32_t* itype;                       /* (ntype) 1-based index into phobic/philic tables */
+  const double*  rh_lower;                    /* (nrh) */
+  const double *mass_ext_sw_phobic, *ssa_sw_phobic, *g_sw_phobic;   /* (n_bands_sw, n_type_phobic) */
+  const double *mass_ext_lw_phobic, *ssa_lw_phobic, *g_lw_phobic;   /* (n_bands_lw, n_type_phobic) */
+  const double *mass_ext_sw_philic, *ssa_sw_philic, *g_sw_philic;   /* (n_bands_sw, nrh, n_type_philic) */
+  const double *mass_ext_lw_philic, *ssa_lw_philic, *g_lw_philic;   /* (n_bands_lw, nrh, n_type_philic) */
+} ecrad_aerosol_optics_t;
+
+/* ---- pdf_sampler_type, radiation_pdf_sampler.F90:28-50 -------------------------------------- */
+typedef struct ecrad_pdf_sampler {
+  int32_t ncdf, nfsd;
+  double  fsd1, inv_fsd_interval;
+  const double* val;           /* (ncdf, nfsd) */
+} ecrad_pdf_sampler_t;
+
+/* ---- config_type, radiation_config.F90:163-649 (the members the hot path reads) ------------- */
+typedef struct ecrad_config {
+  int32_t abi_version;         /* must be ECRAD_ABI_VERSION */
+  /* switches */
+  int32_t do_sw, do_lw, do_clear, do_sw_direct, do_lw_derivatives;
+  int32_t do_clouds, use_aerosols;
+  int32_t i_solver_sw, i_solver_lw;
+  int32_t i_gas_model_sw, i_gas_model_lw;
+  int32_t do_lw_cloud_scattering, do_lw_aerosol_scattering;
+  int32_t do_sw_delta_scaling_with_gases;
+  int32_t use_general_cloud_optics, is_homogeneous;
+  int32_t i_overlap_scheme, use_beta_overlap, use_vectorizable_generator, i_cloud_pdf_shape;
+  int32_t do_cloud_aerosol_per_sw_g_point, do_cloud_aerosol_per_lw_g_point;
+  int32_t do_surface_sw_spectral_flux, do_toa_spectral_flux;
+  int32_t do_canopy_fluxes_sw, do_canopy_fluxes_lw;
+  int32_t use_canopy_full_spectrum_sw, use_canopy_full_spectrum_lw;
+  int32_t do_nearest_spectral_sw_albedo, do_nearest_spectral_lw_emiss;
+  int32_t do_save_spectral_flux;
+  /* spectral sizes */
+  int32_t n_g_sw, n_g_lw, n_bands_sw, n_bands_lw;
+  int32_t n_g_lw_if_scattering, n_bands_lw_if_scattering;
+  int32_t n_canopy_bands_sw, n_canopy_bands_lw;
+  int32_t n_albedo_intervals_sw;   /* = size(sw_albedo_weights,1) */
+  int32_t n_emiss_intervals_lw;    /* = size(lw_emiss_weights,1)  */
+  int32_t n_cloud_types;
+  int32_t reserved_;
+  /* thresholds */
+  double cloud_fraction_threshold, cloud_mixing_ratio_threshold;
+  double cloud_inhom_decorr_scaling;
+  double max_cloud_od;             /* reserved for SPARTACUS */
+  /* index / weight tables */
+  const int32_t* i_band_from_reordered_g_sw;  /* (n_g_sw), 1-based */
+  const int32_t* i_band_from_reordered_g_lw;  /* (n_g_lw), 1-based */
+  const double*  sw_albedo_weights;           /* (n_albedo_intervals_sw, n_bands_sw) */
+  const double*  lw_emiss_weights;            /* (n_emiss_intervals_lw,  n_bands_lw) */
+  const int32_t* i_albedo_from_band_sw;       /* (n_bands_sw) 1-based, nearest-albedo mode only */
+  const int32_t* i_emiss_from_band_lw;        /* (n_bands_lw) 1-based, nearest-emissivity mode only */
+  /* look-up tables owned by config after setup_radiation */
+  ecrad_ckd_model_t      gas_optics_sw, gas_optics_lw;
+  ecrad_cloud_optics_t   cloud_optics_sw[ECRAD_NMAXCLOUDTYPES];
+  ecrad_cloud_optics_t   cloud_optics_lw[ECRAD_NMAXCLOUDTYPES];
+  ecrad_aerosol_optics_t aerosol_optics;
+  ecrad_pdf_sampler_t    pdf_sampler;
+} ecrad_config_t;
+
+/* ---- single_level_type + thermodynamics_type + gas_type + cloud_type + aerosol_type --------- */
+/* All arrays use the reference's layout: (ncol, nlev[+1][, ntype]) with the column index     */
+/* fastest (radiation_thermodynamics.F90:29-49, radiation_gas.F90:36-80,                       */
+/* radiation_cloud.F90:33-96, radiation_aerosol.F90:28-57, radiation_single_level.F90:29-102). */
+typedef struct ecrad_inputs {
+  int32_t memory;                 /* ECRAD_MEM_HOST or ECRAD_MEM_DEVICE (applies to every pointer below) */
+  int32_t n_sw_albedo;            /* size(single_level%sw_albedo,2)     */
+  int32_t n_lw_emissivity;        /* size(single_level%lw_emissivity,2) */
+  int32_t n_cloud_types;          /* cloud%ntype */
+  int32_t n_aerosol_types;        /* size(aerosol%mixing_ratio,3) */
+  int32_t aerosol_istartlev, aerosol_iendlev;  /* 1-based bounds of dim 2 of aerosol%mixing_ratio */
+  int32_t reserved_;
+  double  solar_irradiance;                    /* single_level%solar_irradiance */
+  double  spectral_solar_cycle_multiplier;
+  /* thermodynamics */
+  const double* pressure_hl;      /* (ncol,nlev+1) Pa */
+  const double* temperature_hl;   /* (ncol,nlev+1) K  */
+  const double* h2o_sat_liq;      /* (ncol,nlev) may be NULL when aerosols are off */
+  /* single level */
+  const double* cos_sza;          /* (ncol) */
+  const double* skin_temperature; /* (ncol) */
+  const double* sw_albedo;        /* (ncol,n_sw_albedo) */
+  const double* sw_albedo_direct; /* (ncol,n_sw_albedo) or NULL (= use sw_albedo) */
+  const double* lw_emissivity;    /* (ncol,n_lw_emissivity) */
+  const int32_t* iseed;           /* (ncol) McICA only */
+  /* gas: mixing_ratio(ncol,nlev,ECRAD_NMAXGASES) already in the units the gas model wants
+     (set_gas_units has been called: volume mixing ratio, scale 1, for ecCKD) */
+  const double* gas_mixing_ratio;
+  /* cloud */
+  double*       cloud_fraction;   /* (ncol,nlev) INOUT: crop_cloud_fraction side effect (radiation_cloud.F90:700) */
+  const double* cloud_mixing_ratio;     /* (ncol,nlev,n_cloud_types) */
+  const double* cloud_effective_radius; /* (ncol,nlev,n_cloud_types) */
+  const double* cloud_fractional_std;   /* (ncol,nlev) */
+  const double* cloud_overlap_param;    /* (ncol,nlev-1) */
+  /* aerosol */
+  const double* aerosol_mixing_ratio;   /* (ncol, istartlev:iendlev, n_aerosol_types) */
+} ecrad_inputs_t;
+
+/* ---- flux_type, radiation_flux.F90:38-118; any pointer may be NULL (= not allocated) -------- */
+typedef struct ecrad_flux {
+  int32_t memory;                 /* ECRAD_MEM_HOST or ECRAD_MEM_DEVICE */
+  int32_t reserved_;
+  /* (ncol,nlev+1) */
+  double *lw_up, *lw_dn, *sw_up, *sw_dn, *sw_dn_direct;
+  double *lw_up_clear, *lw_dn_clear, *sw_up_clear, *sw_dn_clear, *sw_dn_direct_clear;
+  double *lw_derivatives;
+  /* (ng,ncol) */
+  double *lw_dn_surf_g, *lw_dn_surf_clear_g;
+  double *sw_dn_diffuse_surf_g, *sw_dn_direct_surf_g;
+  double *sw_dn_diffuse_surf_clear_g, *sw_dn_direct_surf_clear_g;
+  double *lw_up_toa_g, *lw_up_toa_clear_g, *sw_dn_toa_g, *sw_up_toa_g, *sw_up_toa_clear_g;
+  /* (nband,ncol) */
+  double *sw_dn_surf_band, *sw_dn_direct_surf_band, *sw_dn_surf_clear_band, *sw_dn_direct_surf_clear_band;
+  double *lw_up_toa_band, *lw_up_toa_clear_band, *sw_dn_toa_band, *sw_up_toa_band, *sw_up_toa_clear_band;
+  /* (ncanopy,ncol) */
+  double *lw_dn_surf_canopy, *sw_dn_diffuse_surf_canopy, *sw_dn_direct_surf_canopy;
+  /* (ncol) */
+  double *cloud_cover_lw, *cloud_cover_sw;
+} ecrad_flux_t;
+
+/* ---- stage-interface arrays of radiation(), radiation_interface.F90:260-301 ------------------ */
+/* Used only by the stage-level entry points; every pointer is (ng, nlev[+1], ncol_local) with   */
+/* ncol_local = iendcol-istartcol+1, g fastest, and may be NULL if not wanted.                   */
+typedef struct ecrad_optics {
+  int32_t memory;
+  int32_t reserved_;
+  double *od_lw, *ssa_lw, *g_lw;          /* (n_g_lw, nlev, ncol_local) */
+  double *od_sw, *ssa_sw, *g_sw;          /* (n_g_sw, nlev, ncol_local) */
+  double *planck_hl;                      /* (n_g_lw, nlev+1, ncol_local) */
+  double *lw_emission, *lw_albedo;        /* (n_g_lw, ncol_local) */
+  double *sw_albedo_direct, *sw_albedo_diffuse, *incoming_sw; /* (n_g_sw, ncol_local) */
+  double *od_lw_cloud, *ssa_lw_cloud, *g_lw_cloud;  /* (n_bands_lw, nlev, ncol_local) */
+  double *od_sw_cloud, *ssa_sw_cloud, *g_sw_cloud;  /* (n_bands_sw, nlev, ncol_local) */
+} ecrad_optics_t;
+
+typedef struct ecrad_hip_handle_s* ecrad_hip_handle_t;
+
+/* Create a context bound to HIP device `device_id` (-1 = current device). */
+int ecrad_hip_create(ecrad_hip_handle_t* handle, int device_id);
+
+/* Copy every look-up table reachable from `config` to the device (tables whose values are
+   exactly representable in fp32 -- all of the reference's data files are float32 on disk --
+   are stored as fp32 and widened on load, which is lossless).  The caller's arrays may be
+   freed after this returns.  May be called again to change configuration. */
+int ecrad_hip_setup(ecrad_hip_handle_t handle, const ecrad_config_t* config);
+
+/* Optional: run subsequent work on this HIP stream (a hipStream_t cast to void*). */
+int ecrad_hip_set_stream(ecrad_hip_handle_t handle, void* hip_stream);
+
+/* The operator.  Columns outside istartcol..iendcol (1-based, inclusive) are not touched.
+   With ECRAD_MEM_HOST pointers the call stages the needed column range through device buffers
+   (H2D, kernels, D2H) and is synchronous; with ECRAD_MEM_DEVICE pointers it only enqueues
+   kernels on the handle's stream (call ecrad_hip_synchronize before reading results). */
+int ecrad_hip_radiation(ecrad_hip_handle_t handle, int ncol, int nlev, int istartcol, int iendcol,
+                        const ecrad_inputs_t* in, ecrad_flux_t* flux);
+
+/* Stage-level entry: everything radiation() computes before the solvers (albedo mapping, gas
+   optics, cloud optics, aerosol optics), written to the arrays of `out` that are non-NULL. */
+int ecrad_hip_optics(ecrad_hip_handle_t handle, int ncol, int nlev, int istartcol, int iendcol,
+                     const ecrad_inputs_t* in, ecrad_optics_t* out);
+
+int ecrad_hip_synchronize(ecrad_hip_handle_t handle);
+
+/* Timing of the most recent ecrad_hip_radiation call, measured with HIP events on the handle's
+   stream: milliseconds spent in the kernels (excludes H2D/D2H staging). */
+int ecrad_hip_last_kernel_ms(ecrad_hip_handle_t handle, double* ms);
+
+/* Bytes of device scratch currently held by the handle. */
+int ecrad_hip_scratch_bytes(ecrad_hip_handle_t handle, size_t* bytes);
+
+const char* ecrad_hip_last_error(ecrad_hip_handle_t handle);
+
+int ecrad_hip_destroy(ecrad_hip_handle_t handle);
+
+/* ABI self-description used by the loaders: sizeof the struct `which` (0 config, 1 inputs,
+   2 flux, 3 optics, 4 ckd_model, 5 ckd_gas, 6 cloud_optics, 7 aerosol_optics, 8 pdf_sampler). */
+size_t ecrad_hip_abi_sizeof(int which);
+int    ecrad_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ECRAD_HIP_H */
