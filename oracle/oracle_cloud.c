@@ -1,0 +1,350 @@
+/*
+ * oracle_cloud.c -- TEST INFRASTRUCTURE (see ecrad_oracle.h).
+ * Restates radiation_cloud_cover.F90, radiation_regions.F90, radiation_overlap.F90,
+ * utilities/radiation_random_numbers_mix.F90, radiation_pdf_sampler.F90 and
+ * radiation_cloud_generator.F90 (non-vectorizable generator, Exp-Ran / Max-Ran overlap).
+ */
+#include <math.h>
+#include <float.h>
+#include <stdlib.h>
+#include <string.h>
+#include "ecrad_oracle.h"
+
+static inline double dmax(double a, double b) { return a > b ? a : b; }
+static inline double dmin(double a, double b) { return a < b ? a : b; }
+
+/* radiation_cloud_cover.F90:43 */
+#define MAX_CLOUD_FRAC (1.0 - DBL_EPSILON * 10.0)
+
+/* radiation_cloud_cover.F90:51-68 */
+static double beta2alpha(double beta, double frac1, double frac2)
+{
+  if (beta < 1.0) {
+    double frac_diff = fabs(frac1 - frac2);
+    return beta + (1.0 - beta) * frac_diff / (frac_diff + 1.0 / beta - 1.0);
+  }
+  return 1.0;
+}
+
+/* radiation_cloud_cover.F90:169-222 */
+void oracle_cum_cloud_cover_max_ran(int nlev, const double* frac,
+     double* cum_cloud_cover, double* pair_cloud_cover)
+{
+  double cum_product = 1.0 - frac[0];
+  cum_cloud_cover[0] = frac[0];
+  for (int l = 0; l < nlev - 1; ++l) {
+    pair_cloud_cover[l] = dmax(frac[l], frac[l + 1]);
+    if (frac[l] >= MAX_CLOUD_FRAC) cum_product = 0.0;
+    else cum_product = cum_product * (1.0 - pair_cloud_cover[l]) / (1.0 - frac[l]);
+    cum_cloud_cover[l + 1] = 1.0 - cum_product;
+  }
+}
+
+/* radiation_cloud_cover.F90:231-330 */
+void oracle_cum_cloud_cover_exp_ran(int nlev, const double* frac, const double* overlap_param,
+     double* cum_cloud_cover, double* pair_cloud_cover, int is_beta_overlap)
+{
+  double cum_product = 1.0 - frac[0];
+  cum_cloud_cover[0] = frac[0];
+  for (int l = 0; l < nlev - 1; ++l) {
+    double overlap_alpha = is_beta_overlap ? beta2alpha(overlap_param[l], frac[l], frac[l + 1])
+                                           : overlap_param[l];
+    pair_cloud_cover[l] = overlap_alpha * dmax(frac[l], frac[l + 1])
+        + (1.0 - overlap_alpha) * (frac[l] + frac[l + 1] - frac[l] * frac[l + 1]);
+    if (frac[l] >= MAX_CLOUD_FRAC) cum_product = 0.0;
+    else cum_product = cum_product * (1.0 - pair_cloud_cover[l]) / (1.0 - frac[l]);
+    cum_cloud_cover[l + 1] = 1.0 - cum_product;
+  }
+}
+
+/* radiation_regions.F90:35-199, nreg == 3.  reg_fracs(3,nlev), od_scaling(2,nlev) [regions 2,3] */
+void oracle_calc_region_properties(int nlev, int do_gamma, const double* cloud_fraction,
+     const double* frac_std, double frac_threshold, double* reg_fracs, double* od_scaling)
+{
+  const double MinGammaODScaling = 0.025, MinLowerFrac = 0.5, MaxLowerFrac = 0.9;
+  const double FSDAtMinLowerFrac = 1.5, FSDAtMaxLowerFrac = 3.725;
+  const double LowerFracFSDGradient = (MaxLowerFrac - MinLowerFrac) / (FSDAtMaxLowerFrac - FSDAtMinLowerFrac);
+  const double LowerFracFSDIntercept = MinLowerFrac - FSDAtMinLowerFrac * LowerFracFSDGradient;
+  for (int l = 0; l < nlev; ++l) {
+    double* rf = reg_fracs + 3 * l;
+    double* os = od_scaling + 2 * l;
+    double cf = cloud_fraction[l], fsd = frac_std[l];
+    if (cf < frac_threshold) {
+      rf[0] = 1.0; rf[1] = 0.0; rf[2] = 0.0; os[0] = 1.0; os[1] = 1.0;
+    } else if (!do_gamma) {
+      rf[0] = 1.0 - cf; rf[1] = cf * 0.5; rf[2] = cf * 0.5;
+      os[0] = exp(-sqrt(log(fsd * fsd + 1.0))) / sqrt(fsd * fsd + 1.0);
+      os[1] = 2.0 - os[0];
+    } else {
+      rf[0] = 1.0 - cf;
+      rf[1] = cf * dmax(MinLowerFrac, dmin(MaxLowerFrac, LowerFracFSDIntercept + fsd * LowerFracFSDGradient));
+      os[0] = MinGammaODScaling + (1.0 - MinGammaODScaling)
+          * exp(-fsd * (1.0 + 0.5 * fsd * (1.0 + 0.5 * fsd)));
+      rf[2] = 1.0 - rf[0] - rf[1];
+      os[1] = (cf - rf[1] * os[0]) / rf[2];
+    }
+  }
+}
+
+/* radiation_overlap.F90:64-122 ; matrices are (3,3) first index fastest: M[jupper + 3*jlower] */
+static void calc_beta_overlap_matrix(const double* op, const double* frac_upper, const double* frac_lower,
+                                     double frac_threshold, double* M)
+{
+  double op_x_frac_min[3], denominator = 1.0;
+  for (int r = 0; r < 3; ++r) {
+    op_x_frac_min[r] = op[r] * dmin(frac_upper[r], frac_lower[r]);
+    denominator -= op_x_frac_min[r];
+  }
+  if (denominator >= frac_threshold) {
+    double factor = 1.0 / denominator;
+    for (int ju = 0; ju < 3; ++ju)
+      for (int jl = 0; jl < 3; ++jl)
+        M[ju + 3 * jl] = factor * (frac_lower[jl] - op_x_frac_min[jl]) * (frac_upper[ju] - op_x_frac_min[ju]);
+  } else {
+    for (int i = 0; i < 9; ++i) M[i] = 0.0;
+  }
+  for (int r = 0; r < 3; ++r) M[r + 3 * r] += op_x_frac_min[r];
+}
+
+/* radiation_overlap.F90:130-215, nreg == 3 */
+static void calc_alpha_overlap_matrix(double op, double op_inhom, const double* frac_upper,
+                                      const double* frac_lower, double* M)
+{
+  double cf_upper = frac_upper[1] + frac_upper[2];
+  double cf_lower = frac_lower[1] + frac_lower[2];
+  double pair_cloud_cover = op * dmax(cf_upper, cf_lower)
+      + (1.0 - op) * (cf_upper + cf_lower - cf_upper * cf_lower);
+#define OM(i, j) M[((i) - 1) + 3 * ((j) - 1)]
+  OM(1, 1) = 1.0 - pair_cloud_cover;
+  double one_over_cf = 1.0 / dmax(cf_lower, 1.0e-6);
+  OM(1, 2) = (pair_cloud_cover - cf_upper) * frac_lower[1] * one_over_cf;
+  OM(1, 3) = (pair_cloud_cover - cf_upper) * frac_lower[2] * one_over_cf;
+  one_over_cf = 1.0 / dmax(cf_upper, 1.0e-6);
+  OM(2, 1) = (pair_cloud_cover - cf_lower) * frac_upper[1] * one_over_cf;
+  OM(3, 1) = (pair_cloud_cover - cf_lower) * frac_upper[2] * one_over_cf;
+  double frac_both = cf_upper + cf_lower - pair_cloud_cover;
+  cf_upper = frac_upper[2] / dmax(cf_upper, 1.0e-6);
+  cf_lower = frac_lower[2] / dmax(cf_lower, 1.0e-6);
+  pair_cloud_cover = op_inhom * dmax(cf_upper, cf_lower)
+      + (1.0 - op_inhom) * (cf_upper + cf_lower - cf_upper * cf_lower);
+  OM(2, 2) = frac_both * (1.0 - pair_cloud_cover);
+  OM(2, 3) = frac_both * (pair_cloud_cover - cf_upper);
+  OM(3, 2) = frac_both * (pair_cloud_cover - cf_lower);
+  OM(3, 3) = frac_both * (cf_upper + cf_lower - pair_cloud_cover);
+#undef OM
+}
+
+/* radiation_overlap.F90:280-457, single column.  u/v_matrix(3,3,nlev+1), first index fastest. */
+void oracle_calc_overlap_matrices(int nlev, const double* region_fracs, const double* overlap_param,
+     double decorrelation_scaling, double frac_threshold, int use_beta_overlap,
+     double* u_matrix, double* v_matrix, double* cloud_cover)
+{
+  double frac_upper[3] = {1.0, 0.0, 0.0}, frac_lower[3], op[3] = {1.0, 1.0, 1.0}, M[9];
+  for (int jlev = 1; jlev <= nlev + 1; ++jlev) {
+    if (jlev > nlev) { frac_lower[0] = 1.0; frac_lower[1] = 0.0; frac_lower[2] = 0.0; }
+    else for (int r = 0; r < 3; ++r) frac_lower[r] = region_fracs[r + 3 * (jlev - 1)];
+    if (jlev == 1 || jlev > nlev) { op[0] = op[1] = op[2] = 1.0; }
+    else {
+      op[0] = overlap_param[jlev - 2];
+      if (op[0] >= 0.0) op[1] = op[2] = pow(op[0], 1.0 / decorrelation_scaling);
+      else op[1] = op[2] = op[0];
+    }
+    if (use_beta_overlap) calc_beta_overlap_matrix(op, frac_upper, frac_lower, frac_threshold, M);
+    else calc_alpha_overlap_matrix(op[0], op[1], frac_upper, frac_lower, M);
+    double* U = u_matrix + 9 * (jlev - 1);
+    double* V = v_matrix + 9 * (jlev - 1);
+    for (int ju = 0; ju < 3; ++ju)
+      for (int jl = 0; jl < 3; ++jl) {
+        U[ju + 3 * jl] = (frac_lower[jl] >= frac_threshold) ? M[ju + 3 * jl] / frac_lower[jl] : 0.0;
+        V[jl + 3 * ju] = (frac_upper[ju] >= frac_threshold) ? M[ju + 3 * jl] / frac_upper[ju] : 0.0;
+      }
+    for (int r = 0; r < 3; ++r) frac_upper[r] = frac_lower[r];
+  }
+  if (cloud_cover) {
+    double prod = 1.0;
+    for (int jlev = 0; jlev <= nlev; ++jlev) prod *= v_matrix[9 * jlev];
+    *cloud_cover = 1.0 - prod;
+  }
+}
+
+/* ---- utilities/radiation_random_numbers_mix.F90 -------------------------------------------- */
+#define JPP 273
+#define JPQ 607
+#define JPS 105
+#define JPMM 30
+
+/* :142-231 */
+void oracle_initialize_random_numbers(int32_t kseed, oracle_rng_t* s)
+{
+  const int32_t JPMASK = 123459876;
+  uint32_t idum;
+  {
+    int32_t v = kseed ^ JPMASK;
+    if (v < 0) v = -v;                 /* ABS(IEOR(KSEED,JPMASK)) */
+    if (v == 0) v = JPMASK;
+    idum = (uint32_t)v;
+  }
+  for (int jj = 0; jj < 64; ++jj) {
+    if (idum & 0x80000000u) idum = ((idum ^ 87u) << 1) | 1u;
+    else idum = (idum << 1) & ~1u;
+  }
+  for (int i = 0; i < JPQ - 1; ++i) s->ix[i] = 0;
+  s->ix[1] = (int32_t)((idum & ((1u << (JPMM - 1)) - 1u)) << 1);   /* IX(2) */
+  s->ix[JPQ - 1] = (int32_t)(idum >> (JPMM - 1));                  /* IX(JPQ) = IBITS(IDUM,29,3) */
+  for (int jbit = 1; jbit <= JPMM - 1; ++jbit) {
+    for (int jj = 3; jj <= JPQ - 1; ++jj) {
+      if (idum & 0x80000000u) {
+        idum = ((idum ^ 87u) << 1) | 1u;
+        s->ix[jj - 1] |= (int32_t)(1u << jbit);
+      } else {
+        idum = (idum << 1) & ~1u;
+      }
+    }
+  }
+  s->ix[JPQ - JPS - 1] |= 1;
+  s->iused = JPQ;
+  s->zrm = 1.0 / (double)(1 << JPMM);
+  double zwarmup[999];
+  oracle_uniform_distribution(zwarmup, 999, s);
+}
+
+/* :237-312 */
+void oracle_uniform_distribution(double* px, int n, oracle_rng_t* s)
+{
+  const int32_t IVAR = 0x3FFFFFFF;
+  int ifilled = 0;
+  int last = s->iused + n < JPQ ? s->iused + n : JPQ;
+  for (int jj = s->iused + 1; jj <= last; ++jj) {
+    px[jj - s->iused - 1] = s->ix[jj - 1] * s->zrm;
+    ifilled++;
+  }
+  s->iused += ifilled;
+  if (ifilled == n) return;
+  while (ifilled < n) {
+    for (int jj = 1; jj <= JPP; ++jj)
+      s->ix[jj - 1] = IVAR & (s->ix[jj - 1] + s->ix[jj - JPP + JPQ - 1]);
+    for (int jj = JPP + 1; jj <= JPQ; ++jj)
+      s->ix[jj - 1] = IVAR & (s->ix[jj - 1] + s->ix[jj - JPP - 1]);
+    int take = n - ifilled < JPQ ? n - ifilled : JPQ;
+    s->iused = take;
+    for (int k = 0; k < take; ++k) px[ifilled + k] = s->ix[k] * s->zrm;
+    ifilled += take;
+  }
+}
+
+/* radiation_pdf_sampler.F90:126-156 ; val(ncdf,nfsd) */
+double oracle_pdf_sample(const ecrad_pdf_sampler_t* p, double fsd, double cdf)
+{
+  double wcdf = cdf * (p->ncdf - 1) + 1.0;
+  int icdf = (int)wcdf;
+  if (icdf > p->ncdf - 1) icdf = p->ncdf - 1;
+  if (icdf < 1) icdf = 1;
+  wcdf = dmax(0.0, dmin(wcdf - icdf, 1.0));
+  double wfsd = (fsd - p->fsd1) * p->inv_fsd_interval + 1.0;
+  int ifsd = (int)wfsd;
+  if (ifsd > p->nfsd - 1) ifsd = p->nfsd - 1;
+  if (ifsd < 1) ifsd = 1;
+  wfsd = dmax(0.0, dmin(wfsd - ifsd, 1.0));
+#define VAL(i, j) p->val[((i) - 1) + (size_t)p->ncdf * ((j) - 1)]
+  return (1.0 - wcdf) * (1.0 - wfsd) * VAL(icdf, ifsd)
+       + (1.0 - wcdf) * wfsd * VAL(icdf, ifsd + 1)
+       + wcdf * (1.0 - wfsd) * VAL(icdf + 1, ifsd)
+       + wcdf * wfsd * VAL(icdf + 1, ifsd + 1);
+#undef VAL
+}
+
+/* radiation_cloud_generator.F90:262-390.  All level indices below are 1-based as in the reference;
+   arrays are accessed with [idx-1]. */
+static void generate_column_exp_ran(int ng, int nlev, int ig, oracle_rng_t* rs,
+     const ecrad_pdf_sampler_t* pdf, const double* frac, const double* pair_cloud_cover,
+     const double* cum_cloud_cover, const double* overhang, const double* fractional_std,
+     const double* overlap_param_inhom, int itrigger, int iend, double* od_scaling,
+     double* rand_cloud, double* rand_inhom1, double* rand_inhom2)
+{
+  (void)nlev;
+  int n_layers_to_scale = 1;
+  int iy = 0;
+  oracle_uniform_distribution(rand_cloud, iend + 1 - itrigger, rs);
+  for (int jlev = itrigger + 1; jlev <= iend + 1; ++jlev) {
+    int do_fill_od_scaling = 0;
+    if (jlev <= iend) {
+      iy++;
+      if (n_layers_to_scale > 0) {
+        if (rand_cloud[iy - 1] * frac[jlev - 2] < frac[jlev - 1] + frac[jlev - 2] - pair_cloud_cover[jlev - 2])
+          n_layers_to_scale++;
+        else
+          do_fill_od_scaling = 1;
+      } else {
+        if (rand_cloud[iy - 1] * (cum_cloud_cover[jlev - 2] - frac[jlev - 2])
+            < pair_cloud_cover[jlev - 2] - overhang[jlev - 2] - frac[jlev - 2])
+          n_layers_to_scale = 1;
+      }
+    } else {
+      do_fill_od_scaling = 1;
+    }
+    if (do_fill_od_scaling) {
+      oracle_uniform_distribution(rand_inhom1, n_layers_to_scale, rs);
+      oracle_uniform_distribution(rand_inhom2, n_layers_to_scale, rs);
+      for (int jcloud = 2; jcloud <= n_layers_to_scale; ++jcloud) {
+        if (rand_inhom2[jcloud - 1] < overlap_param_inhom[jlev - n_layers_to_scale + jcloud - 2 - 1])
+          rand_inhom1[jcloud - 1] = rand_inhom1[jcloud - 2];
+      }
+      for (int k = 0; k < n_layers_to_scale; ++k) {
+        int lev = jlev - n_layers_to_scale + k;   /* 1-based level */
+        od_scaling[ig + (size_t)ng * (lev - 1)] = oracle_pdf_sample(pdf, fractional_std[lev - 1], rand_inhom1[k]);
+      }
+      n_layers_to_scale = 0;
+    }
+  }
+}
+
+/* radiation_cloud_generator.F90:37-255 (use_vectorizable_generator = false; Exp-Exp not restated) */
+void oracle_cloud_generator(int ng, int nlev, int i_overlap_scheme, int32_t iseed,
+     double frac_threshold, const double* frac, const double* overlap_param,
+     double decorrelation_scaling, const double* fractional_std,
+     const ecrad_pdf_sampler_t* pdf_sampler, double* od_scaling, double* total_cloud_cover,
+     int use_beta_overlap)
+{
+  double* cum_cloud_cover = (double*)malloc(sizeof(double) * nlev * 8);
+  double* pair_cloud_cover = cum_cloud_cover + nlev;
+  double* overhang = pair_cloud_cover + nlev;
+  double* overlap_param_inhom = overhang + nlev;
+  double* rand_cloud = overlap_param_inhom + nlev;
+  double* rand_inhom1 = rand_cloud + nlev;
+  double* rand_inhom2 = rand_inhom1 + nlev;
+  double* rand_top = (double*)malloc(sizeof(double) * ng);
+  if (i_overlap_scheme == ECRAD_OVERLAP_EXP_RAN)
+    oracle_cum_cloud_cover_exp_ran(nlev, frac, overlap_param, cum_cloud_cover, pair_cloud_cover, use_beta_overlap);
+  else
+    oracle_cum_cloud_cover_max_ran(nlev, frac, cum_cloud_cover, pair_cloud_cover);
+  *total_cloud_cover = cum_cloud_cover[nlev - 1];
+  for (int l = 0; l < nlev - 1; ++l) overhang[l] = cum_cloud_cover[l + 1] - cum_cloud_cover[l];
+  if (*total_cloud_cover < frac_threshold) {
+    *total_cloud_cover = 0.0;
+  } else {
+    int jlev = 1;
+    while (frac[jlev - 1] <= 0.0) jlev++;
+    int ibegin = jlev, iend = jlev;
+    for (jlev = jlev + 1; jlev <= nlev; ++jlev)
+      if (frac[jlev - 1] > 0.0) iend = jlev;
+    for (int l = 0; l < nlev - 1; ++l) overlap_param_inhom[l] = overlap_param[l];
+    for (jlev = ibegin; jlev <= iend - 1; ++jlev)
+      if (overlap_param[jlev - 1] > 0.0)
+        overlap_param_inhom[jlev - 1] = pow(overlap_param[jlev - 1], 1.0 / decorrelation_scaling);
+    memset(od_scaling, 0, sizeof(double) * (size_t)ng * nlev);
+    oracle_rng_t rs;
+    oracle_initialize_random_numbers(iseed, &rs);
+    oracle_uniform_distribution(rand_top, ng, &rs);
+    for (int jg = 0; jg < ng; ++jg) {
+      double trigger = rand_top[jg] * (*total_cloud_cover);
+      jlev = ibegin;
+      while (trigger > cum_cloud_cover[jlev - 1] && jlev < iend) jlev++;
+      int itrigger = jlev;
+      generate_column_exp_ran(ng, nlev, jg, &rs, pdf_sampler, frac, pair_cloud_cover,
+                              cum_cloud_cover, overhang, fractional_std, overlap_param_inhom,
+                              itrigger, iend, od_scaling, rand_cloud, rand_inhom1, rand_inhom2);
+    }
+  }
+  free(cum_cloud_cover);
+  free(rand_top);
+}
