@@ -1,0 +1,184 @@
+! ref_leaf_wrappers.F90 -- TEST INFRASTRUCTURE.
+!
+! Our own bind(C) shims that call the REFERENCE's leaf module procedures (compiled unmodified from
+! /root/reference by oracle/Makefile target "ref").  They exist so that tests can check the C
+! restatement in oracle/*.c against the reference's real code for every routine that can be built
+! without netCDF.  Nothing here re-implements reference logic.
+module ref_leaf_wrappers
+  use iso_c_binding
+  use parkind1, only : jprb
+  implicit none
+contains
+
+  subroutine ref_calc_two_stream_gammas_lw(ng, ssa, g, gamma1, gamma2) bind(C, name='ref_calc_two_stream_gammas_lw')
+    use radiation_two_stream, only : calc_two_stream_gammas_lw
+    integer(c_int), value :: ng
+    real(c_double), intent(in)  :: ssa(ng), g(ng)
+    real(c_double), intent(out) :: gamma1(ng), gamma2(ng)
+    call calc_two_stream_gammas_lw(ng, ssa, g, gamma1, gamma2)
+  end subroutine
+
+  subroutine ref_calc_two_stream_gammas_sw(ng, mu0, ssa, g, gamma1, gamma2, gamma3) &
+       &  bind(C, name='ref_calc_two_stream_gammas_sw')
+    use radiation_two_stream, only : calc_two_stream_gammas_sw
+    integer(c_int), value :: ng
+    real(c_double), value :: mu0
+    real(c_double), intent(in)  :: ssa(ng), g(ng)
+    real(c_double), intent(out) :: gamma1(ng), gamma2(ng), gamma3(ng)
+    call calc_two_stream_gammas_sw(ng, mu0, ssa, g, gamma1, gamma2, gamma3)
+  end subroutine
+
+  subroutine ref_calc_reflectance_transmittance_lw(ng, od, gamma1, gamma2, planck_top, planck_bot, &
+       &  reflectance, transmittance, source_up, source_dn) bind(C, name='ref_calc_reflectance_transmittance_lw')
+    use radiation_two_stream, only : calc_reflectance_transmittance_lw
+    integer(c_int), value :: ng
+    real(c_double), intent(in)  :: od(ng), gamma1(ng), gamma2(ng), planck_top(ng), planck_bot(ng)
+    real(c_double), intent(out) :: reflectance(ng), transmittance(ng), source_up(ng), source_dn(ng)
+    call calc_reflectance_transmittance_lw(ng, od, gamma1, gamma2, planck_top, planck_bot, &
+         &  reflectance, transmittance, source_up, source_dn)
+  end subroutine
+
+  subroutine ref_calc_ref_trans_lw(ng, od, ssa, asymmetry, planck_top, planck_bot, &
+       &  reflectance, transmittance, source_up, source_dn) bind(C, name='ref_calc_ref_trans_lw')
+    use radiation_two_stream, only : calc_ref_trans_lw
+    integer(c_int), value :: ng
+    real(c_double), intent(in)  :: od(ng), ssa(ng), asymmetry(ng), planck_top(ng), planck_bot(ng)
+    real(c_double), intent(out) :: reflectance(ng), transmittance(ng), source_up(ng), source_dn(ng)
+    call calc_ref_trans_lw(ng, od, ssa, asymmetry, planck_top, planck_bot, &
+         &  reflectance, transmittance, source_up, source_dn)
+  end subroutine
+
+  subroutine ref_calc_no_scattering_transmittance_lw(ng, od, planck_top, planck_bot, &
+       &  transmittance, source_up, source_dn) bind(C, name='ref_calc_no_scattering_transmittance_lw')
+    use radiation_two_stream, only : calc_no_scattering_transmittance_lw
+    integer(c_int), value :: ng
+    real(c_double), intent(in)  :: od(ng), planck_top(ng), planck_bot(ng)
+    real(c_double), intent(out) :: transmittance(ng), source_up(ng), source_dn(ng)
+    call calc_no_scattering_transmittance_lw(ng, od, planck_top, planck_bot, transmittance, source_up, source_dn)
+  end subroutine
+
+  subroutine ref_calc_reflectance_transmittance_sw(ng, mu0, od, ssa, gamma1, gamma2, gamma3, &
+       &  ref_diff, trans_diff, ref_dir, trans_dir_diff, trans_dir_dir) &
+       &  bind(C, name='ref_calc_reflectance_transmittance_sw')
+    use radiation_two_stream, only : calc_reflectance_transmittance_sw
+    integer(c_int), value :: ng
+    real(c_double), value :: mu0
+    real(c_double), intent(in)  :: od(ng), ssa(ng), gamma1(ng), gamma2(ng), gamma3(ng)
+    real(c_double), intent(out) :: ref_diff(ng), trans_diff(ng), ref_dir(ng), trans_dir_diff(ng), trans_dir_dir(ng)
+    call calc_reflectance_transmittance_sw(ng, mu0, od, ssa, gamma1, gamma2, gamma3, &
+         &  ref_diff, trans_diff, ref_dir, trans_dir_diff, trans_dir_dir)
+  end subroutine
+
+  subroutine ref_calc_ref_trans_sw(ng, mu0, od, ssa, asymmetry, &
+       &  ref_diff, trans_diff, ref_dir, trans_dir_diff, trans_dir_dir) bind(C, name='ref_calc_ref_trans_sw')
+    use radiation_two_stream, only : calc_ref_trans_sw
+    integer(c_int), value :: ng
+    real(c_double), value :: mu0
+    real(c_double), intent(in)  :: od(ng), ssa(ng), asymmetry(ng)
+    real(c_double), intent(out) :: ref_diff(ng), trans_diff(ng), ref_dir(ng), trans_dir_diff(ng), trans_dir_dir(ng)
+    call calc_ref_trans_sw(ng, mu0, od, ssa, asymmetry, ref_diff, trans_diff, ref_dir, trans_dir_diff, trans_dir_dir)
+  end subroutine
+
+  subroutine ref_adding_ica_sw(ncol, nlev, incoming_toa, albedo_surf_diffuse, albedo_surf_direct, cos_sza, &
+       &  reflectance, transmittance, ref_dir, trans_dir_diff, trans_dir_dir, &
+       &  flux_up, flux_dn_diffuse, flux_dn_direct) bind(C, name='ref_adding_ica_sw')
+    use radiation_adding_ica_sw, only : adding_ica_sw
+    integer(c_int), value :: ncol, nlev
+    real(c_double), intent(in)  :: incoming_toa(ncol), albedo_surf_diffuse(ncol), albedo_surf_direct(ncol), cos_sza(ncol)
+    real(c_double), intent(in)  :: reflectance(ncol,nlev), transmittance(ncol,nlev), ref_dir(ncol,nlev), &
+         &                         trans_dir_diff(ncol,nlev), trans_dir_dir(ncol,nlev)
+    real(c_double), intent(out) :: flux_up(ncol,nlev+1), flux_dn_diffuse(ncol,nlev+1), flux_dn_direct(ncol,nlev+1)
+    call adding_ica_sw(ncol, nlev, incoming_toa, albedo_surf_diffuse, albedo_surf_direct, cos_sza, &
+         &  reflectance, transmittance, ref_dir, trans_dir_diff, trans_dir_dir, flux_up, flux_dn_diffuse, flux_dn_direct)
+  end subroutine
+
+  subroutine ref_adding_ica_lw(ncol, nlev, reflectance, transmittance, source_up, source_dn, &
+       &  emission_surf, albedo_surf, flux_up, flux_dn) bind(C, name='ref_adding_ica_lw')
+    use radiation_adding_ica_lw, only : adding_ica_lw
+    integer(c_int), value :: ncol, nlev
+    real(c_double), intent(in)  :: reflectance(ncol,nlev), transmittance(ncol,nlev), source_up(ncol,nlev), source_dn(ncol,nlev)
+    real(c_double), intent(in)  :: emission_surf(ncol), albedo_surf(ncol)
+    real(c_double), intent(out) :: flux_up(ncol,nlev+1), flux_dn(ncol,nlev+1)
+    call adding_ica_lw(ncol, nlev, reflectance, transmittance, source_up, source_dn, emission_surf, albedo_surf, flux_up, flux_dn)
+  end subroutine
+
+  subroutine ref_fast_adding_ica_lw(ncol, nlev, reflectance, transmittance, source_up, source_dn, &
+       &  emission_surf, albedo_surf, is_clear_sky_layer, i_cloud_top, flux_dn_clear, flux_up, flux_dn) &
+       &  bind(C, name='ref_fast_adding_ica_lw')
+    use radiation_adding_ica_lw, only : fast_adding_ica_lw
+    integer(c_int), value :: ncol, nlev, i_cloud_top
+    real(c_double), intent(in)  :: reflectance(ncol,nlev), transmittance(ncol,nlev), source_up(ncol,nlev), source_dn(ncol,nlev)
+    real(c_double), intent(in)  :: emission_surf(ncol), albedo_surf(ncol), flux_dn_clear(ncol,nlev+1)
+    integer(c_int), intent(in)  :: is_clear_sky_layer(nlev)
+    real(c_double), intent(out) :: flux_up(ncol,nlev+1), flux_dn(ncol,nlev+1)
+    logical :: lclear(nlev)
+    lclear = (is_clear_sky_layer /= 0)
+    call fast_adding_ica_lw(ncol, nlev, reflectance, transmittance, source_up, source_dn, emission_surf, albedo_surf, &
+         &  lclear, i_cloud_top, flux_dn_clear, flux_up, flux_dn)
+  end subroutine
+
+  subroutine ref_calc_fluxes_no_scattering_lw(ncol, nlev, transmittance, source_up, source_dn, &
+       &  emission_surf, albedo_surf, flux_up, flux_dn) bind(C, name='ref_calc_fluxes_no_scattering_lw')
+    use radiation_adding_ica_lw, only : calc_fluxes_no_scattering_lw
+    integer(c_int), value :: ncol, nlev
+    real(c_double), intent(in)  :: transmittance(ncol,nlev), source_up(ncol,nlev), source_dn(ncol,nlev)
+    real(c_double), intent(in)  :: emission_surf(ncol), albedo_surf(ncol)
+    real(c_double), intent(out) :: flux_up(ncol,nlev+1), flux_dn(ncol,nlev+1)
+    call calc_fluxes_no_scattering_lw(ncol, nlev, transmittance, source_up, source_dn, emission_surf, albedo_surf, flux_up, flux_dn)
+  end subroutine
+
+  subroutine ref_cum_cloud_cover_exp_ran(nlev, frac, overlap_param, cum_cloud_cover, pair_cloud_cover, is_beta) &
+       &  bind(C, name='ref_cum_cloud_cover_exp_ran')
+    use radiation_cloud_cover, only : cum_cloud_cover_exp_ran
+    integer(c_int), value :: nlev, is_beta
+    real(c_double), intent(in)  :: frac(1,nlev), overlap_param(1,nlev-1)
+    real(c_double), intent(out) :: cum_cloud_cover(1,nlev), pair_cloud_cover(1,nlev-1)
+    call cum_cloud_cover_exp_ran(1, 1, 1, nlev, frac, overlap_param, cum_cloud_cover, pair_cloud_cover, is_beta /= 0)
+  end subroutine
+
+  subroutine ref_cum_cloud_cover_max_ran(nlev, frac, cum_cloud_cover, pair_cloud_cover) &
+       &  bind(C, name='ref_cum_cloud_cover_max_ran')
+    use radiation_cloud_cover, only : cum_cloud_cover_max_ran
+    integer(c_int), value :: nlev
+    real(c_double), intent(in)  :: frac(1,nlev)
+    real(c_double), intent(out) :: cum_cloud_cover(1,nlev), pair_cloud_cover(1,nlev-1)
+    call cum_cloud_cover_max_ran(1, 1, 1, nlev, frac, cum_cloud_cover, pair_cloud_cover)
+  end subroutine
+
+  subroutine ref_calc_region_properties(nlev, do_gamma, cloud_fraction, frac_std, frac_threshold, &
+       &  reg_fracs, od_scaling) bind(C, name='ref_calc_region_properties')
+    use radiation_regions, only : calc_region_properties
+    integer(c_int), value :: nlev, do_gamma
+    real(c_double), value :: frac_threshold
+    real(c_double), intent(in)  :: cloud_fraction(1,nlev), frac_std(1,nlev)
+    real(c_double), intent(out) :: reg_fracs(3,nlev,1), od_scaling(2:3,nlev,1)
+    call calc_region_properties(nlev, 3, 1, 1, do_gamma /= 0, cloud_fraction, frac_std, reg_fracs, od_scaling, frac_threshold)
+  end subroutine
+
+  subroutine ref_calc_overlap_matrices(nlev, region_fracs, overlap_param, decorrelation_scaling, &
+       &  frac_threshold, use_beta_overlap, u_matrix, v_matrix, cloud_cover) bind(C, name='ref_calc_overlap_matrices')
+    use radiation_overlap, only : calc_overlap_matrices
+    integer(c_int), value :: nlev, use_beta_overlap
+    real(c_double), value :: decorrelation_scaling, frac_threshold
+    real(c_double), intent(in)  :: region_fracs(3,nlev,1), overlap_param(1,nlev-1)
+    real(c_double), intent(out) :: u_matrix(3,3,nlev+1,1), v_matrix(3,3,nlev+1,1), cloud_cover
+    real(c_double) :: cc(1)
+    call calc_overlap_matrices(nlev, 3, 1, 1, region_fracs, overlap_param, u_matrix, v_matrix, &
+         &  decorrelation_scaling=decorrelation_scaling, cloud_fraction_threshold=frac_threshold, &
+         &  cloud_cover=cc, use_beta_overlap=(use_beta_overlap /= 0))
+    cloud_cover = cc(1)
+  end subroutine
+
+  ! First n uniform deviates after initialize_random_numbers(iseed) followed by a second request of
+  ! m more (exercises the buffering across calls)
+  subroutine ref_random_numbers(iseed, n, x, m, y) bind(C, name='ref_random_numbers')
+    use radiation_random_numbers_mix, only : randomnumberstream, initialize_random_numbers, uniform_distribution
+    integer(c_int), value :: iseed, n, m
+    real(c_double), intent(out) :: x(n), y(m)
+    type(randomnumberstream) :: stream
+    call initialize_random_numbers(iseed, stream)
+    call uniform_distribution(x, stream)
+    call uniform_distribution(y, stream)
+  end subroutine
+
+end module ref_leaf_wrappers

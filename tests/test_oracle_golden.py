@@ -1,0 +1,62 @@
+"""Pin the oracle (oracle/*.c + ecrad_amd host setup) against the reference's OWN golden output.
+
+test/ifs/ecrad_meridian_ecckd_mcica_out_REFERENCE.nc was produced by the reference (gfortran,
+double precision, `make test_ecckd_mcica`: configCY49R1_ecckd.nam with McICA solvers) and is stored
+as float32, so agreement is limited to float32 rounding (2^-24 = 6e-8 relative).  The reference's
+own ctest thresholds for this file are 1e-3 (LW) / 0.1 (SW) W m-2 absolute
+(test/ifs/CMakeLists.txt:14-20); we require 2e-7 relative, i.e. ~1000x tighter than ctest and 5x
+tighter than the 1e-6 parity bar.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from ecrad_amd.driver import flux_to_output_dict
+from ecrad_amd.ncfile import NcFile
+from helpers import GOLDEN_DIR, make_config, rel_err, run_case
+
+GOLDEN = os.path.join(GOLDEN_DIR, "ecrad_meridian_ecckd_mcica_out_REFERENCE.nc")
+FLOAT32_TOL = 2.0e-7
+
+
+@pytest.fixture(scope="module")
+def oracle_mcica(oracle_lib):
+    config = make_config("McICA")
+    flux, th, _ = run_case(config, oracle_lib.backend)
+    return config, flux_to_output_dict(config, th, flux)
+
+
+def test_golden_has_expected_variables(oracle_mcica):
+    config, out = oracle_mcica
+    with NcFile(GOLDEN) as g:
+        names = list(g._f.variables)
+    assert len(names) == 21
+    missing = [n for n in names if n not in out]
+    assert not missing, missing
+
+
+@pytest.mark.parametrize("name", [
+    "flux_up_lw", "flux_dn_lw", "flux_up_lw_clear", "flux_dn_lw_clear", "lw_derivative",
+    "canopy_flux_dn_lw_surf", "flux_up_sw", "flux_dn_sw", "flux_dn_direct_sw", "flux_up_sw_clear",
+    "flux_dn_sw_clear", "flux_dn_direct_sw_clear", "spectral_flux_dn_sw_surf",
+    "spectral_flux_dn_direct_sw_surf", "spectral_flux_dn_sw_surf_clear",
+    "spectral_flux_dn_direct_sw_surf_clear", "canopy_flux_dn_diffuse_sw_surf",
+    "canopy_flux_dn_direct_sw_surf", "cloud_cover_lw", "cloud_cover_sw", "pressure_hl"])
+def test_oracle_matches_reference_golden(oracle_mcica, name):
+    _, out = oracle_mcica
+    with NcFile(GOLDEN) as g:
+        ref = g.get(name)
+    assert out[name].shape == ref.shape
+    assert rel_err(out[name], ref) < FLOAT32_TOL
+
+
+def test_night_columns_have_zero_sw_and_cloud_cover_minus_one(oracle_mcica):
+    """SURVEY App. C-2 / test/ifs/README: cloud_cover_sw stays -1 where the sun is down."""
+    _, out = oracle_mcica
+    with NcFile(GOLDEN) as g:
+        ref = g.get("cloud_cover_sw")
+    night = ref < 0
+    assert night.any()
+    assert np.all(out["cloud_cover_sw"][night] == -1.0)
+    assert np.all(out["flux_dn_sw"][night] == 0.0)
