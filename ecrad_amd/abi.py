@@ -203,6 +203,8 @@ def declare_prototypes(lib) -> None:
     lib.ecrad_hip_synchronize.restype = C.c_int
     lib.ecrad_hip_last_kernel_ms.argtypes = [H, C.POINTER(C.c_double)]
     lib.ecrad_hip_last_kernel_ms.restype = C.c_int
+    lib.ecrad_hip_last_stage_ms.argtypes = [H, C.c_int, C.POINTER(C.c_double)]
+    lib.ecrad_hip_last_stage_ms.restype = C.c_int
     lib.ecrad_hip_scratch_bytes.argtypes = [H, C.POINTER(C.c_size_t)]
     lib.ecrad_hip_scratch_bytes.restype = C.c_int
     lib.ecrad_hip_last_error.argtypes = [H]
@@ -217,7 +219,7 @@ def declare_prototypes(lib) -> None:
 
 EXPORTED_SYMBOLS = [
     "ecrad_hip_create", "ecrad_hip_setup", "ecrad_hip_set_stream", "ecrad_hip_radiation",
-    "ecrad_hip_optics", "ecrad_hip_synchronize", "ecrad_hip_last_kernel_ms",
+    "ecrad_hip_optics", "ecrad_hip_synchronize", "ecrad_hip_last_kernel_ms", "ecrad_hip_last_stage_ms",
     "ecrad_hip_scratch_bytes", "ecrad_hip_last_error", "ecrad_hip_destroy",
     "ecrad_hip_abi_sizeof", "ecrad_hip_abi_version",
 ]

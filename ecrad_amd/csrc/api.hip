@@ -1,0 +1,766 @@
+// api.hip -- the C-ABI of include/ecrad_hip.h: context, table upload, staging, kernel sequencing.
+// Mirrors radiation() in radiation/radiation_interface.F90:200-510 at the level of "which stage runs
+// when"; all arithmetic lives in the kernel_*.hip files.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device_types.h"
+#include "launch.h"
+#include "optics_device.h"
+
+using namespace ecrad;
+
+namespace {
+
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct ecrad_hip_handle_s {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int num_cu = 256;
+  int blocks_per_cu = 4;
+  std::string err;
+  bool is_setup = false;
+  ecrad_config_t cfg{};            // scalar members only are meaningful (pointers are the caller's)
+  DevConfig hcfg{};                // host copy of the device config (device pointers inside)
+  DevConfig* dcfg = nullptr;
+  std::vector<void*> tables;
+  int ngp_sw = 0, ngp_lw = 0;
+  Buf scratch, prep, staging_in, staging_out;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t evs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries
+  double stage_ms[4] = {0, 0, 0, 0};
+  bool timing_pending = false;
+  double last_ms = 0.0;
+};
+
+namespace {
+
+int fail(ecrad_hip_handle_t h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                          \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(h, ECRAD_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
+  } while (0)
+
+template <typename T>
+int upload(ecrad_hip_handle_t h, const T* src, size_t n, const T** dst) {
+  *dst = nullptr;
+  if (!src || n == 0) return ECRAD_OK;
+  void* p = nullptr;
+  HIP_TRY(h, hipMalloc(&p, n * sizeof(T)));
+  h->tables.push_back(p);
+  HIP_TRY(h, hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+  *dst = reinterpret_cast<const T*>(p);
+  return ECRAD_OK;
+}
+
+bool all_float_exact(const double* a, size_t n) {
+  for (size_t i = 0; i < n; ++i)
+    if ((double)(float)a[i] != a[i]) return false;
+  return true;
+}
+
+int upload_as_float(ecrad_hip_handle_t h, const double* src, size_t n, const void** dst) {
+  std::vector<float> tmp(n);
+  for (size_t i = 0; i < n; ++i) tmp[i] = (float)src[i];
+  const float* d = nullptr;
+  int st = upload<float>(h, tmp.data(), n, &d);
+  *dst = d;
+  return st;
+}
+
+int padded_ng(int ng) { return ng <= 16 ? 16 : (ng <= 32 ? 32 : (ng <= 64 ? 64 : 0)); }
+
+int setup_ckd(ecrad_hip_handle_t h, const ecrad_ckd_model_t& m, DevCkdModel& d) {
+  std::memset(&d, 0, sizeof(d));
+  d.is_sw = m.is_sw; d.ng = m.ng; d.npress = m.npress; d.ntemp = m.ntemp; d.ngas = m.ngas; d.nplanck = m.nplanck;
+  d.log_pressure1 = m.log_pressure1; d.d_log_pressure = m.d_log_pressure; d.d_temperature = m.d_temperature;
+  d.temperature1_planck = m.temperature1_planck; d.d_temperature_planck = m.d_temperature_planck;
+  if (m.ngas < 1 || m.ngas > ECRAD_NMAXGASES) return fail(h, ECRAD_EINVAL, "ckd model: ngas out of range");
+  if (m.npress > 256 || m.ntemp > 256) return fail(h, ECRAD_EUNSUPPORTED, "ckd model: more than 256 pressures/temperatures");
+  // float storage only if EVERY absorption/Planck table of the model survives the round trip exactly
+  bool f32 = true;
+  const size_t n3 = (size_t)m.ng * m.npress * m.ntemp;
+  for (int j = 0; j < m.ngas && f32; ++j) {
+    const ecrad_ckd_gas_t& g = m.single_gas[j];
+    const size_t n = g.i_conc_dependence == ECRAD_CONC_LUT ? n3 * g.n_mole_frac : n3;
+    f32 = all_float_exact(g.molar_abs, n);
+  }
+  if (f32 && !m.is_sw) f32 = all_float_exact(m.planck_function, (size_t)m.ng * m.nplanck);
+  d.table_f32 = f32 ? 1 : 0;
+  int st;
+  if ((st = upload<double>(h, m.temperature1, m.npress, &d.temperature1))) return st;
+  if (!m.is_sw) {
+    if (f32) st = upload_as_float(h, m.planck_function, (size_t)m.ng * m.nplanck, &d.planck_function);
+    else { const double* p; st = upload<double>(h, m.planck_function, (size_t)m.ng * m.nplanck, &p); d.planck_function = p; }
+    if (st) return st;
+  } else {
+    if ((st = upload<double>(h, m.norm_solar_irradiance, m.ng, &d.norm_solar_irradiance))) return st;
+    if ((st = upload<double>(h, m.norm_amplitude_solar_irradiance, m.ng, &d.norm_amplitude_solar_irradiance))) return st;
+    if ((st = upload<double>(h, m.rayleigh_molar_scat, m.ng, &d.rayleigh_molar_scat))) return st;
+  }
+  for (int j = 0; j < m.ngas; ++j) {
+    const ecrad_ckd_gas_t& g = m.single_gas[j];
+    DevCkdGas& dg = d.gas[j];
+    dg.i_gas_code = g.i_gas_code; dg.i_conc_dependence = g.i_conc_dependence; dg.n_mole_frac = g.n_mole_frac;
+    dg.reference_mole_frac = g.reference_mole_frac; dg.log_mole_frac1 = g.log_mole_frac1;
+    dg.d_log_mole_frac = g.d_log_mole_frac; dg.mole_frac1 = std::exp(g.log_mole_frac1);
+    if (g.i_conc_dependence != ECRAD_CONC_NONE && (g.i_gas_code < 1 || g.i_gas_code > ECRAD_NMAXGASES))
+      return fail(h, ECRAD_EINVAL, "ckd model: gas code out of range");
+    if (g.i_conc_dependence == ECRAD_CONC_LUT && g.n_mole_frac > 32767)
+      return fail(h, ECRAD_EUNSUPPORTED, "ckd model: mole-fraction LUT too long");
+    const size_t n = g.i_conc_dependence == ECRAD_CONC_LUT ? n3 * g.n_mole_frac : n3;
+    if (f32) st = upload_as_float(h, g.molar_abs, n, &dg.molar_abs);
+    else { const double* p; st = upload<double>(h, g.molar_abs, n, &p); dg.molar_abs = p; }
+    if (st) return st;
+  }
+  return ECRAD_OK;
+}
+
+void free_tables(ecrad_hip_handle_t h) {
+  for (void* p : h->tables) (void)hipFree(p);
+  h->tables.clear();
+  if (h->dcfg) { (void)hipFree(h->dcfg); h->dcfg = nullptr; }
+  h->is_setup = false;
+}
+
+// sub-allocator over one device buffer (256-byte aligned pieces)
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(void* b) : base(reinterpret_cast<char*>(b)) {}
+  template <typename T> T* take(size_t n) {
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += (n * sizeof(T) + 255) & ~size_t(255);
+    return p;
+  }
+};
+
+struct Range { int ncol, nlev, i0, i1, nloc; };
+
+// Layout of the staged input copy (host-memory mode).  Run once with base=nullptr to size it.
+struct StagedInputs {
+  double *pressure_hl, *temperature_hl, *h2o_sat_liq, *cos_sza, *skin_temperature, *sw_albedo, *sw_albedo_direct,
+         *lw_emissivity, *gas_mixing_ratio, *cloud_fraction, *cloud_mixing_ratio, *cloud_effective_radius,
+         *cloud_fractional_std, *cloud_overlap_param, *aerosol_mixing_ratio;
+  int32_t* iseed;
+  size_t bytes;
+};
+
+StagedInputs carve_inputs(void* base, const ecrad_config_t& c, const ecrad_inputs_t& in, const Range& r) {
+  Carver cv(base);
+  StagedInputs s{};
+  const size_t n = r.nloc, L = r.nlev;
+  s.pressure_hl = cv.take<double>(n * (L + 1));
+  s.temperature_hl = cv.take<double>(n * (L + 1));
+  s.h2o_sat_liq = in.h2o_sat_liq ? cv.take<double>(n * L) : nullptr;
+  s.cos_sza = cv.take<double>(n);
+  s.skin_temperature = cv.take<double>(n);
+  s.sw_albedo = in.sw_albedo ? cv.take<double>(n * in.n_sw_albedo) : nullptr;
+  s.sw_albedo_direct = in.sw_albedo_direct ? cv.take<double>(n * in.n_sw_albedo) : nullptr;
+  s.lw_emissivity = in.lw_emissivity ? cv.take<double>(n * in.n_lw_emissivity) : nullptr;
+  s.iseed = in.iseed ? cv.take<int32_t>(n) : nullptr;
+  s.gas_mixing_ratio = cv.take<double>(n * L * ECRAD_NMAXGASES);
+  if (c.do_clouds) {
+    s.cloud_fraction = cv.take<double>(n * L);
+    s.cloud_mixing_ratio = cv.take<double>(n * L * in.n_cloud_types);
+    s.cloud_effective_radius = cv.take<double>(n * L * in.n_cloud_types);
+    s.cloud_fractional_std = cv.take<double>(n * L);
+    s.cloud_overlap_param = cv.take<double>(n * (L - 1));
+  }
+  if (c.use_aerosols)
+    s.aerosol_mixing_ratio = cv.take<double>(n * (in.aerosol_iendlev - in.aerosol_istartlev + 1) * in.n_aerosol_types);
+  s.bytes = cv.off;
+  return s;
+}
+
+struct FluxField { double* ecrad_flux_t::*host; double* DevFlux::*dev; int kind; };   // kind 0 profile,1 g_lw,2 g_sw,3 band_lw,4 band_sw,5 canopy_lw,6 canopy_sw,7 column
+#define FF(n, k) { &ecrad_flux_t::n, &DevFlux::n, k }
+const FluxField kFluxFields[] = {
+  FF(lw_up, 0), FF(lw_dn, 0), FF(sw_up, 0), FF(sw_dn, 0), FF(sw_dn_direct, 0), FF(lw_up_clear, 0), FF(lw_dn_clear, 0),
+  FF(sw_up_clear, 0), FF(sw_dn_clear, 0), FF(sw_dn_direct_clear, 0), FF(lw_derivatives, 0),
+  FF(lw_dn_surf_g, 1), FF(lw_dn_surf_clear_g, 1), FF(sw_dn_diffuse_surf_g, 2), FF(sw_dn_direct_surf_g, 2),
+  FF(sw_dn_diffuse_surf_clear_g, 2), FF(sw_dn_direct_surf_clear_g, 2), FF(lw_up_toa_g, 1), FF(lw_up_toa_clear_g, 1),
+  FF(sw_dn_toa_g, 2), FF(sw_up_toa_g, 2), FF(sw_up_toa_clear_g, 2),
+  FF(sw_dn_surf_band, 4), FF(sw_dn_direct_surf_band, 4), FF(sw_dn_surf_clear_band, 4), FF(sw_dn_direct_surf_clear_band, 4),
+  FF(lw_up_toa_band, 3), FF(lw_up_toa_clear_band, 3), FF(sw_dn_toa_band, 4), FF(sw_up_toa_band, 4), FF(sw_up_toa_clear_band, 4),
+  FF(lw_dn_surf_canopy, 5), FF(sw_dn_diffuse_surf_canopy, 6), FF(sw_dn_direct_surf_canopy, 6),
+  FF(cloud_cover_lw, 7), FF(cloud_cover_sw, 7),
+};
+#undef FF
+
+size_t flux_rows(const ecrad_config_t& c, int kind, int nlev) {
+  switch (kind) {
+    case 0: return (size_t)nlev + 1;
+    case 1: return c.n_g_lw;
+    case 2: return c.n_g_sw;
+    case 3: return c.n_bands_lw;
+    case 4: return c.n_bands_sw;
+    case 5: return c.n_canopy_bands_lw;
+    case 6: return c.n_canopy_bands_sw;
+    default: return 1;
+  }
+}
+
+int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
+  if (c.abi_version != ECRAD_ABI_VERSION) return fail(h, ECRAD_EINVAL, "ABI version mismatch");
+  if (c.do_sw && c.i_gas_model_sw != ECRAD_GAS_ECCKD) return fail(h, ECRAD_EUNSUPPORTED, "only the ECCKD shortwave gas model is implemented");
+  if (c.do_lw && c.i_gas_model_lw != ECRAD_GAS_ECCKD) return fail(h, ECRAD_EUNSUPPORTED, "only the ECCKD longwave gas model is implemented");
+  for (int s : {c.do_sw ? c.i_solver_sw : -1, c.do_lw ? c.i_solver_lw : -1}) {
+    if (s == ECRAD_SOLVER_SPARTACUS) return fail(h, ECRAD_EUNSUPPORTED, "the SPARTACUS solver is not implemented");
+    if (s > ECRAD_SOLVER_TRIPLECLOUDS) return fail(h, ECRAD_EINVAL, "unknown solver");
+  }
+  if (c.do_save_spectral_flux) return fail(h, ECRAD_EUNSUPPORTED, "do_save_spectral_flux is not implemented");
+  if (c.do_lw && c.do_lw_aerosol_scattering) return fail(h, ECRAD_EUNSUPPORTED, "do_lw_aerosol_scattering is not implemented");
+  const bool mcica = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_MCICA) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_MCICA);
+  if (mcica) {
+    if (!c.do_clear) return fail(h, ECRAD_EINVAL, "McICA requires clear-sky calculation to be performed");  // radiation_mcica_sw.F90:141
+    if (c.i_overlap_scheme == ECRAD_OVERLAP_EXP_EXP) return fail(h, ECRAD_EUNSUPPORTED, "Exp-Exp overlap is not implemented");
+    if (c.use_vectorizable_generator) return fail(h, ECRAD_EUNSUPPORTED, "use_vectorizable_generator is not implemented");
+    if (!c.pdf_sampler.val) return fail(h, ECRAD_EINVAL, "McICA needs the PDF sampler table");
+  }
+  const bool tc = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_TRIPLECLOUDS) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_TRIPLECLOUDS);
+  if (tc && c.i_overlap_scheme != ECRAD_OVERLAP_EXP_RAN) return fail(h, ECRAD_EINVAL, "Tripleclouds can only do Exp-Ran overlap");
+  if (c.do_sw && padded_ng(c.n_g_sw) == 0) return fail(h, ECRAD_EUNSUPPORTED, "more than 64 shortwave g-points");
+  if (c.do_lw && padded_ng(c.n_g_lw) == 0) return fail(h, ECRAD_EUNSUPPORTED, "more than 64 longwave g-points");
+  if (c.do_clouds && (c.n_cloud_types < 1 || c.n_cloud_types > ECRAD_NMAXCLOUDTYPES)) return fail(h, ECRAD_EINVAL, "n_cloud_types out of range");
+  return ECRAD_OK;
+}
+
+}  // namespace
+
+// ====================================================================================================
+extern "C" {
+
+int ecrad_hip_abi_version(void) { return ECRAD_ABI_VERSION; }
+
+size_t ecrad_hip_abi_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(ecrad_config_t);
+    case 1: return sizeof(ecrad_inputs_t);
+    case 2: return sizeof(ecrad_flux_t);
+    case 3: return sizeof(ecrad_optics_t);
+    case 4: return sizeof(ecrad_ckd_model_t);
+    case 5: return sizeof(ecrad_ckd_gas_t);
+    case 6: return sizeof(ecrad_cloud_optics_t);
+    case 7: return sizeof(ecrad_aerosol_optics_t);
+    case 8: return sizeof(ecrad_pdf_sampler_t);
+    default: return 0;
+  }
+}
+
+int ecrad_hip_create(ecrad_hip_handle_t* handle, int device_id) {
+  if (!handle) return ECRAD_EINVAL;
+  *handle = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ECRAD_ENODEVICE;
+  if (device_id < 0) { if (hipGetDevice(&device_id) != hipSuccess) return ECRAD_ENODEVICE; }
+  if (device_id >= n) return ECRAD_ENODEVICE;
+  if (hipSetDevice(device_id) != hipSuccess) return ECRAD_ENODEVICE;
+  ecrad_hip_handle_t h = new ecrad_hip_handle_s();
+  h->device = device_id;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) h->num_cu = prop.multiProcessorCount;
+  if (const char* e = std::getenv("ECRAD_HIP_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= 8) h->blocks_per_cu = v; }
+  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { delete h; return ECRAD_EHIP; }
+  for (auto& e : h->evs) if (hipEventCreate(&e) != hipSuccess) { delete h; return ECRAD_EHIP; }
+  *handle = h;
+  return ECRAD_OK;
+}
+
+int ecrad_hip_set_stream(ecrad_hip_handle_t h, void* hip_stream) {
+  if (!h) return ECRAD_EINVAL;
+  h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return ECRAD_OK;
+}
+
+const char* ecrad_hip_last_error(ecrad_hip_handle_t h) { return h ? h->err.c_str() : "null handle"; }
+
+int ecrad_hip_destroy(ecrad_hip_handle_t h) {
+  if (!h) return ECRAD_EINVAL;
+  (void)hipSetDevice(h->device);
+  free_tables(h);
+  h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (auto& e : h->evs) if (e) (void)hipEventDestroy(e);
+  delete h;
+  return ECRAD_OK;
+}
+
+int ecrad_hip_scratch_bytes(ecrad_hip_handle_t h, size_t* bytes) {
+  if (!h || !bytes) return ECRAD_EINVAL;
+  *bytes = h->scratch.cap + h->prep.cap + h->staging_in.cap + h->staging_out.cap;
+  return ECRAD_OK;
+}
+
+int ecrad_hip_synchronize(ecrad_hip_handle_t h) {
+  if (!h) return ECRAD_EINVAL;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return ECRAD_OK;
+}
+
+int ecrad_hip_last_kernel_ms(ecrad_hip_handle_t h, double* ms) {
+  if (!h || !ms) return ECRAD_EINVAL;
+  if (h->timing_pending) {
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    float f = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&f, h->ev0, h->ev1));
+    h->last_ms = f;
+    for (int k = 0; k < 4; ++k) {
+      HIP_TRY(h, hipEventElapsedTime(&f, h->evs[k], h->evs[k + 1]));
+      h->stage_ms[k] = f;
+    }
+    h->timing_pending = false;
+  }
+  *ms = h->last_ms;
+  return ECRAD_OK;
+}
+
+int ecrad_hip_last_stage_ms(ecrad_hip_handle_t h, int which, double* ms) {
+  if (!h || !ms || which < 0 || which > 3) return ECRAD_EINVAL;
+  double total;
+  int st = ecrad_hip_last_kernel_ms(h, &total);
+  if (st) return st;
+  *ms = h->stage_ms[which];
+  return ECRAD_OK;
+}
+
+// ----------------------------------------------------------------------------------------------------
+int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
+  if (!h || !cp) return ECRAD_EINVAL;
+  HIP_TRY(h, hipSetDevice(h->device));
+  const ecrad_config_t& c = *cp;
+  int st = validate_config(h, c);
+  if (st) return st;
+  free_tables(h);
+  h->cfg = c;
+  DevConfig& d = h->hcfg;
+  std::memset(&d, 0, sizeof(d));
+#define CP(n) d.n = c.n
+  CP(do_sw); CP(do_lw); CP(do_clear); CP(do_sw_direct); CP(do_lw_derivatives); CP(do_clouds); CP(use_aerosols);
+  CP(i_solver_sw); CP(i_solver_lw); CP(do_lw_cloud_scattering); CP(do_lw_aerosol_scattering);
+  CP(do_sw_delta_scaling_with_gases); CP(is_homogeneous); CP(i_overlap_scheme); CP(use_beta_overlap);
+  CP(i_cloud_pdf_shape); CP(do_cloud_aerosol_per_sw_g_point); CP(do_cloud_aerosol_per_lw_g_point);
+  CP(do_surface_sw_spectral_flux); CP(do_toa_spectral_flux); CP(do_canopy_fluxes_sw); CP(do_canopy_fluxes_lw);
+  CP(use_canopy_full_spectrum_sw); CP(use_canopy_full_spectrum_lw); CP(do_nearest_spectral_sw_albedo);
+  CP(do_nearest_spectral_lw_emiss); CP(n_g_sw); CP(n_g_lw); CP(n_bands_sw); CP(n_bands_lw);
+  CP(n_canopy_bands_sw); CP(n_canopy_bands_lw); CP(n_albedo_intervals_sw); CP(n_emiss_intervals_lw);
+  CP(n_cloud_types); CP(cloud_fraction_threshold); CP(cloud_mixing_ratio_threshold); CP(cloud_inhom_decorr_scaling);
+#undef CP
+  if (c.do_sw) {
+    if ((st = upload<int32_t>(h, c.i_band_from_reordered_g_sw, c.n_g_sw, &d.i_band_from_reordered_g_sw))) return st;
+    if ((st = upload<double>(h, c.sw_albedo_weights, (size_t)c.n_albedo_intervals_sw * c.n_bands_sw, &d.sw_albedo_weights))) return st;
+    if ((st = upload<int32_t>(h, c.i_albedo_from_band_sw, c.n_bands_sw, &d.i_albedo_from_band_sw))) return st;
+    if ((st = setup_ckd(h, c.gas_optics_sw, d.gas_sw))) return st;
+    if (d.gas_sw.ng != c.n_g_sw) return fail(h, ECRAD_EINVAL, "n_g_sw does not match the shortwave gas model");
+    if (!d.i_band_from_reordered_g_sw) return fail(h, ECRAD_EINVAL, "i_band_from_reordered_g_sw missing");
+    if (!c.use_canopy_full_spectrum_sw && !c.do_nearest_spectral_sw_albedo && !d.sw_albedo_weights)
+      return fail(h, ECRAD_EINVAL, "sw_albedo_weights missing");
+    h->ngp_sw = padded_ng(c.n_g_sw);
+  }
+  if (c.do_lw) {
+    if ((st = upload<int32_t>(h, c.i_band_from_reordered_g_lw, c.n_g_lw, &d.i_band_from_reordered_g_lw))) return st;
+    if ((st = upload<double>(h, c.lw_emiss_weights, (size_t)c.n_emiss_intervals_lw * c.n_bands_lw, &d.lw_emiss_weights))) return st;
+    if ((st = upload<int32_t>(h, c.i_emiss_from_band_lw, c.n_bands_lw, &d.i_emiss_from_band_lw))) return st;
+    if ((st = setup_ckd(h, c.gas_optics_lw, d.gas_lw))) return st;
+    if (d.gas_lw.ng != c.n_g_lw) return fail(h, ECRAD_EINVAL, "n_g_lw does not match the longwave gas model");
+    if (!d.i_band_from_reordered_g_lw) return fail(h, ECRAD_EINVAL, "i_band_from_reordered_g_lw missing");
+    h->ngp_lw = padded_ng(c.n_g_lw);
+  }
+  if (c.do_clouds) {
+    for (int t = 0; t < c.n_cloud_types; ++t) {
+      for (int pass = 0; pass < 2; ++pass) {
+        if ((pass == 0 && !c.do_sw) || (pass == 1 && !c.do_lw)) continue;
+        const ecrad_cloud_optics_t& s = pass == 0 ? c.cloud_optics_sw[t] : c.cloud_optics_lw[t];
+        DevCloudOptics& o = pass == 0 ? d.cloud_sw[t] : d.cloud_lw[t];
+        if (s.n_bands != (pass == 0 ? c.n_bands_sw : c.n_bands_lw) || !s.mass_ext)
+          return fail(h, ECRAD_EINVAL, "cloud optics table does not match the number of bands");
+        o.n_bands = s.n_bands; o.n_effective_radius = s.n_effective_radius;
+        o.effective_radius_0 = s.effective_radius_0; o.d_effective_radius = s.d_effective_radius;
+        const size_t n = (size_t)s.n_bands * s.n_effective_radius;
+        if ((st = upload<double>(h, s.mass_ext, n, &o.mass_ext))) return st;
+        if ((st = upload<double>(h, s.ssa, n, &o.ssa))) return st;
+        if ((st = upload<double>(h, s.asymmetry, n, &o.asymmetry))) return st;
+      }
+    }
+  }
+  if (c.use_aerosols) {
+    const ecrad_aerosol_optics_t& a = c.aerosol_optics;
+    DevAerosolOptics& o = d.aerosol;
+    o.n_bands_sw = a.n_bands_sw; o.n_bands_lw = a.n_bands_lw; o.n_type_phobic = a.n_type_phobic;
+    o.n_type_philic = a.n_type_philic; o.nrh = a.nrh; o.use_hydrophilic = a.use_hydrophilic; o.ntype = a.ntype;
+    if ((c.do_sw && a.n_bands_sw != c.n_bands_sw) || (c.do_lw && a.n_bands_lw != c.n_bands_lw))
+      return fail(h, ECRAD_EINVAL, "number of bands does not match aerosol optics look-up table");   // radiation_aerosol_optics.F90:62-74
+    if ((st = upload<int32_t>(h, a.iclass, a.ntype, &o.iclass))) return st;
+    if ((st = upload<int32_t>(h, a.itype, a.ntype, &o.itype))) return st;
+    if ((st = upload<double>(h, a.rh_lower, a.nrh, &o.rh_lower))) return st;
+    for (int j = 0; j < a.ntype; ++j) {
+      if (a.iclass[j] == ECRAD_AEROSOL_UNDEFINED) return fail(h, ECRAD_EINVAL, "not all aerosol types are defined");  // :545-550
+      if (a.iclass[j] == ECRAD_AEROSOL_HYDROPHOBIC && (a.itype[j] < 1 || a.itype[j] > a.n_type_phobic)) return fail(h, ECRAD_EINVAL, "hydrophobic type out of range");
+      if (a.iclass[j] == ECRAD_AEROSOL_HYDROPHILIC && (a.itype[j] < 1 || a.itype[j] > a.n_type_philic)) return fail(h, ECRAD_EINVAL, "hydrophilic type out of range");
+    }
+    const double* src_sw_pho[3] = {a.mass_ext_sw_phobic, a.ssa_sw_phobic, a.g_sw_phobic};
+    const double* src_lw_pho[3] = {a.mass_ext_lw_phobic, a.ssa_lw_phobic, a.g_lw_phobic};
+    const double* src_sw_phi[3] = {a.mass_ext_sw_philic, a.ssa_sw_philic, a.g_sw_philic};
+    const double* src_lw_phi[3] = {a.mass_ext_lw_philic, a.ssa_lw_philic, a.g_lw_philic};
+    for (int k = 0; k < 3; ++k) {
+      if (c.do_sw) {
+        if ((st = upload<double>(h, src_sw_pho[k], (size_t)a.n_bands_sw * a.n_type_phobic, &o.sw_phobic[k]))) return st;
+        if ((st = upload<double>(h, src_sw_phi[k], (size_t)a.n_bands_sw * a.nrh * a.n_type_philic, &o.sw_philic[k]))) return st;
+      }
+      if (c.do_lw) {
+        if ((st = upload<double>(h, src_lw_pho[k], (size_t)a.n_bands_lw * a.n_type_phobic, &o.lw_phobic[k]))) return st;
+        if ((st = upload<double>(h, src_lw_phi[k], (size_t)a.n_bands_lw * a.nrh * a.n_type_philic, &o.lw_philic[k]))) return st;
+      }
+    }
+  }
+  if (c.pdf_sampler.val) {
+    const ecrad_pdf_sampler_t& p = c.pdf_sampler;
+    d.pdf.ncdf = p.ncdf; d.pdf.nfsd = p.nfsd; d.pdf.fsd1 = p.fsd1; d.pdf.inv_fsd_interval = p.inv_fsd_interval;
+    const size_t n = (size_t)p.ncdf * p.nfsd;
+    if (all_float_exact(p.val, n)) {
+      const void* v = nullptr;
+      if ((st = upload_as_float(h, p.val, n, &v))) return st;
+      d.pdf.val = reinterpret_cast<const float*>(v);
+    } else if ((st = upload<double>(h, p.val, n, &d.pdf.val64))) return st;
+  }
+  HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->dcfg), sizeof(DevConfig)));
+  HIP_TRY(h, hipMemcpy(h->dcfg, &d, sizeof(DevConfig), hipMemcpyHostToDevice));
+  h->is_setup = true;
+  return ECRAD_OK;
+}
+
+}  // extern "C"
+
+// ----------------------------------------------------------------------------------------------------
+namespace {
+
+struct CallCtx {
+  DevInputs din{};
+  Range r{};
+  StagedInputs si{};
+  bool host_mem = false;
+};
+
+int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol, const ecrad_inputs_t* in, CallCtx& cx) {
+  const ecrad_config_t& c = h->cfg;
+  if (ncol < 1 || nlev < 2 || istartcol < 1 || iendcol > ncol || iendcol < istartcol) return fail(h, ECRAD_EINVAL, "bad column/level range");
+  if (nlev > 256) return fail(h, ECRAD_EUNSUPPORTED, "more than 256 levels");
+  if (!in->pressure_hl || !in->temperature_hl || !in->gas_mixing_ratio) return fail(h, ECRAD_EINVAL, "thermodynamics/gas arrays missing");
+  if (c.do_sw && (!in->cos_sza || !in->sw_albedo)) return fail(h, ECRAD_EINVAL, "cos_sza/sw_albedo missing");
+  if (c.do_lw && (!in->skin_temperature || !in->lw_emissivity)) return fail(h, ECRAD_EINVAL, "skin_temperature/lw_emissivity missing");
+  if (c.do_sw && !c.use_canopy_full_spectrum_sw && !c.do_nearest_spectral_sw_albedo && in->n_sw_albedo != c.n_albedo_intervals_sw)
+    return fail(h, ECRAD_EINVAL, "single_level%sw_albedo does not have the expected number of bands");      // radiation_single_level.F90:262
+  if (c.do_lw && !c.use_canopy_full_spectrum_lw && !c.do_nearest_spectral_lw_emiss && in->n_lw_emissivity != c.n_emiss_intervals_lw)
+    return fail(h, ECRAD_EINVAL, "single_level%lw_emissivity does not have the expected number of bands"); // :338
+  if (c.do_clouds) {
+    if (!in->cloud_fraction || !in->cloud_mixing_ratio || !in->cloud_effective_radius || !in->cloud_fractional_std || !in->cloud_overlap_param)
+      return fail(h, ECRAD_EINVAL, "cloud arrays missing");
+    if (in->n_cloud_types != c.n_cloud_types) return fail(h, ECRAD_EINVAL, "cloud%ntype does not match config%n_cloud_types");
+  }
+  if (c.use_aerosols) {
+    if (!in->aerosol_mixing_ratio || !in->h2o_sat_liq) return fail(h, ECRAD_EINVAL, "aerosol mixing ratio / h2o_sat_liq missing");
+    if (in->n_aerosol_types != c.aerosol_optics.ntype) return fail(h, ECRAD_EINVAL, "aerosol%mixing_ratio has the wrong number of types");  // radiation_aerosol_optics.F90:573
+    if (in->aerosol_istartlev < 1 || in->aerosol_iendlev > nlev) return fail(h, ECRAD_EINVAL, "aerosol level range");
+  }
+  const bool mcica = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_MCICA) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_MCICA);
+  if (mcica && !in->iseed) return fail(h, ECRAD_EINVAL, "McICA needs single_level%iseed");
+  cx.host_mem = in->memory == ECRAD_MEM_HOST;
+  cx.r = {ncol, nlev, istartcol, iendcol, iendcol - istartcol + 1};
+  DevInputs& d = cx.din;
+  d.nlev = nlev;
+  d.n_sw_albedo = in->n_sw_albedo; d.n_lw_emissivity = in->n_lw_emissivity; d.n_cloud_types = in->n_cloud_types;
+  d.n_aerosol_types = in->n_aerosol_types; d.aerosol_istartlev = in->aerosol_istartlev; d.aerosol_iendlev = in->aerosol_iendlev;
+  d.has_sw_albedo_direct = in->sw_albedo_direct != nullptr;
+  d.solar_irradiance = in->solar_irradiance; d.spectral_solar_cycle_multiplier = in->spectral_solar_cycle_multiplier;
+  if (!cx.host_mem) {
+    d.ncol = ncol; d.istartcol = istartcol; d.iendcol = iendcol;
+    d.pressure_hl = in->pressure_hl; d.temperature_hl = in->temperature_hl; d.h2o_sat_liq = in->h2o_sat_liq;
+    d.cos_sza = in->cos_sza; d.skin_temperature = in->skin_temperature; d.sw_albedo = in->sw_albedo;
+    d.sw_albedo_direct = in->sw_albedo_direct; d.lw_emissivity = in->lw_emissivity; d.iseed = in->iseed;
+    d.gas_mixing_ratio = in->gas_mixing_ratio; d.cloud_fraction = in->cloud_fraction;
+    d.cloud_mixing_ratio = in->cloud_mixing_ratio; d.cloud_effective_radius = in->cloud_effective_radius;
+    d.cloud_fractional_std = in->cloud_fractional_std; d.cloud_overlap_param = in->cloud_overlap_param;
+    d.aerosol_mixing_ratio = in->aerosol_mixing_ratio;
+    return ECRAD_OK;
+  }
+  // radiation_reverse (radiation_interface.F90:310-317, :519-661) is not implemented
+  if (in->pressure_hl[(size_t)(istartcol - 1) + (size_t)ncol] < in->pressure_hl[istartcol - 1])
+    return fail(h, ECRAD_EUNSUPPORTED, "inputs ordered surface-first (radiation_reverse) are not implemented");
+  const Range& r = cx.r;
+  StagedInputs sz = carve_inputs(nullptr, c, *in, r);
+  HIP_TRY(h, h->staging_in.ensure(sz.bytes));
+  cx.si = carve_inputs(h->staging_in.p, c, *in, r);
+  const StagedInputs& s = cx.si;
+  hipStream_t st = h->stream;
+  auto copy2d = [&](void* dst, const void* src, size_t rows, size_t elem) -> hipError_t {
+    if (!dst || !src || rows == 0) return hipSuccess;
+    return hipMemcpy2DAsync(dst, r.nloc * elem, reinterpret_cast<const char*>(src) + (size_t)(r.i0 - 1) * elem,
+                            (size_t)r.ncol * elem, r.nloc * elem, rows, hipMemcpyHostToDevice, st);
+  };
+  const size_t L = nlev;
+  HIP_TRY(h, copy2d(s.pressure_hl, in->pressure_hl, L + 1, 8));
+  HIP_TRY(h, copy2d(s.temperature_hl, in->temperature_hl, L + 1, 8));
+  HIP_TRY(h, copy2d(s.h2o_sat_liq, in->h2o_sat_liq, L, 8));
+  HIP_TRY(h, copy2d(s.cos_sza, in->cos_sza, 1, 8));
+  HIP_TRY(h, copy2d(s.skin_temperature, in->skin_temperature, 1, 8));
+  HIP_TRY(h, copy2d(s.sw_albedo, in->sw_albedo, in->n_sw_albedo, 8));
+  HIP_TRY(h, copy2d(s.sw_albedo_direct, in->sw_albedo_direct, in->n_sw_albedo, 8));
+  HIP_TRY(h, copy2d(s.lw_emissivity, in->lw_emissivity, in->n_lw_emissivity, 8));
+  HIP_TRY(h, copy2d(s.iseed, in->iseed, 1, 4));
+  HIP_TRY(h, copy2d(s.gas_mixing_ratio, in->gas_mixing_ratio, L * ECRAD_NMAXGASES, 8));
+  if (c.do_clouds) {
+    HIP_TRY(h, copy2d(s.cloud_fraction, in->cloud_fraction, L, 8));
+    HIP_TRY(h, copy2d(s.cloud_mixing_ratio, in->cloud_mixing_ratio, L * in->n_cloud_types, 8));
+    HIP_TRY(h, copy2d(s.cloud_effective_radius, in->cloud_effective_radius, L * in->n_cloud_types, 8));
+    HIP_TRY(h, copy2d(s.cloud_fractional_std, in->cloud_fractional_std, L, 8));
+    HIP_TRY(h, copy2d(s.cloud_overlap_param, in->cloud_overlap_param, L - 1, 8));
+  }
+  if (c.use_aerosols)
+    HIP_TRY(h, copy2d(s.aerosol_mixing_ratio, in->aerosol_mixing_ratio,
+                      (size_t)(in->aerosol_iendlev - in->aerosol_istartlev + 1) * in->n_aerosol_types, 8));
+  d.ncol = r.nloc; d.istartcol = 1; d.iendcol = r.nloc;
+  d.pressure_hl = s.pressure_hl; d.temperature_hl = s.temperature_hl; d.h2o_sat_liq = s.h2o_sat_liq;
+  d.cos_sza = s.cos_sza; d.skin_temperature = s.skin_temperature; d.sw_albedo = s.sw_albedo;
+  d.sw_albedo_direct = s.sw_albedo_direct; d.lw_emissivity = s.lw_emissivity; d.iseed = s.iseed;
+  d.gas_mixing_ratio = s.gas_mixing_ratio; d.cloud_fraction = s.cloud_fraction;
+  d.cloud_mixing_ratio = s.cloud_mixing_ratio; d.cloud_effective_radius = s.cloud_effective_radius;
+  d.cloud_fractional_std = s.cloud_fractional_std; d.cloud_overlap_param = s.cloud_overlap_param;
+  d.aerosol_mixing_ratio = s.aerosol_mixing_ratio;
+  return ECRAD_OK;
+}
+
+int grid_for(ecrad_hip_handle_t h, int nloc, int ngp) {
+  const int cpb = kBlock / ngp;
+  const int groups = (nloc + cpb - 1) / cpb;
+  const int maxgrid = h->num_cu * h->blocks_per_cu;
+  return groups < maxgrid ? groups : maxgrid;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
+                        const ecrad_inputs_t* in, ecrad_flux_t* flux) {
+  if (!h || !in || !flux) return ECRAD_EINVAL;
+  if (!h->is_setup) return fail(h, ECRAD_ENOTSETUP, "ecrad_hip_setup has not been called");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (in->memory != flux->memory) return fail(h, ECRAD_EINVAL, "inputs and fluxes must live in the same memory space");
+  const ecrad_config_t& c = h->cfg;
+  CallCtx cx;
+  int st = stage_inputs(h, ncol, nlev, istartcol, iendcol, in, cx);
+  if (st) return st;
+  const Range& r = cx.r;
+  hipStream_t stream = h->stream;
+
+  // ---- output arrays -------------------------------------------------------------------------------
+  DevFlux dfx{};
+  std::vector<std::pair<const FluxField*, double*>> staged;
+  if (!cx.host_mem) {
+    for (const FluxField& f : kFluxFields) dfx.*(f.dev) = flux->*(f.host);
+  } else {
+    size_t off = 0;
+    for (const FluxField& f : kFluxFields)
+      if (flux->*(f.host)) off += (flux_rows(c, f.kind, nlev) * r.nloc * 8 + 255) & ~size_t(255);
+    HIP_TRY(h, h->staging_out.ensure(off));
+    Carver cv(h->staging_out.p);
+    for (const FluxField& f : kFluxFields)
+      if (flux->*(f.host)) {
+        double* p = cv.take<double>(flux_rows(c, f.kind, nlev) * r.nloc);
+        dfx.*(f.dev) = p;
+        staged.emplace_back(&f, p);
+      }
+    // cloud cover keeps the caller's initial value where a solver does not write it (e.g. -1 at night)
+    for (auto& sp : staged)
+      if (sp.first->kind == 7)
+        HIP_TRY(h, hipMemcpyAsync(sp.second, flux->*(sp.first->host) + (r.i0 - 1), r.nloc * 8, hipMemcpyHostToDevice, stream));
+  }
+  // the solvers write these unconditionally
+  if (c.do_lw && (!dfx.lw_up || !dfx.lw_dn || !dfx.lw_dn_surf_g || !dfx.lw_up_toa_g)) return fail(h, ECRAD_EINVAL, "flux%lw_up/lw_dn/lw_dn_surf_g/lw_up_toa_g must be allocated");
+  if (c.do_sw && (!dfx.sw_up || !dfx.sw_dn || !dfx.sw_dn_diffuse_surf_g || !dfx.sw_dn_direct_surf_g || !dfx.sw_up_toa_g))
+    return fail(h, ECRAD_EINVAL, "flux%sw_up/sw_dn/sw_dn_*_surf_g/sw_up_toa_g must be allocated");
+  if (c.do_clear) {
+    if (c.do_lw && (!dfx.lw_up_clear || !dfx.lw_dn_clear || !dfx.lw_dn_surf_clear_g || !dfx.lw_up_toa_clear_g)) return fail(h, ECRAD_EINVAL, "clear-sky longwave flux arrays must be allocated when do_clear");
+    if (c.do_sw && (!dfx.sw_up_clear || !dfx.sw_dn_clear || !dfx.sw_dn_diffuse_surf_clear_g || !dfx.sw_dn_direct_surf_clear_g || !dfx.sw_up_toa_clear_g))
+      return fail(h, ECRAD_EINVAL, "clear-sky shortwave flux arrays must be allocated when do_clear");
+  }
+  if (c.do_clouds && (!dfx.cloud_cover_lw || !dfx.cloud_cover_sw)) return fail(h, ECRAD_EINVAL, "flux%cloud_cover_* must be allocated");
+
+  // ---- scratch & prep buffers ------------------------------------------------------------------------
+  const bool sw_mcica = c.do_sw && c.i_solver_sw == ECRAD_SOLVER_MCICA, lw_mcica = c.do_lw && c.i_solver_lw == ECRAD_SOLVER_MCICA;
+  const bool sw_tc = c.do_sw && c.i_solver_sw == ECRAD_SOLVER_TRIPLECLOUDS, lw_tc = c.do_lw && c.i_solver_lw == ECRAD_SOLVER_TRIPLECLOUDS;
+  const int grid_sw = c.do_sw ? grid_for(h, r.nloc, h->ngp_sw) : 0;
+  const int grid_lw = c.do_lw ? grid_for(h, r.nloc, h->ngp_lw) : 0;
+  const int na_sw = c.do_sw ? (sw_tc ? sw_tc_num_scratch_arrays() : sw_ica_num_scratch_arrays(c.i_solver_sw)) : 0;
+  const int na_lw = c.do_lw ? (lw_tc ? lw_tc_num_scratch_arrays() : lw_ica_num_scratch_arrays(c.i_solver_lw)) : 0;
+  const size_t per_block_sw = (size_t)na_sw * (nlev + 1) * kBlock, per_block_lw = (size_t)na_lw * (nlev + 1) * kBlock;
+  const size_t need_sw = per_block_sw * grid_sw * 8, need_lw = per_block_lw * grid_lw * 8;
+  HIP_TRY(h, h->scratch.ensure(need_sw > need_lw ? need_sw : need_lw));
+  DevCloudPrep prep{};
+  double* mcica_work = nullptr;
+  {
+    const size_t n = r.nloc, L = nlev;
+    for (int pass = 0; pass < 2; ++pass) {
+      Carver cv(pass == 0 ? nullptr : h->prep.p);
+      if (sw_tc || lw_tc) {
+        prep.region_fracs = cv.take<double>(3 * L * n);
+        prep.od_scaling_reg = cv.take<double>(2 * L * n);
+        prep.v_matrix = cv.take<double>(9 * (L + 1) * n);
+        prep.u_matrix = cv.take<double>(9 * (L + 1) * n);
+      }
+      if (sw_mcica) { prep.od_scaling_sw = cv.take<double>((size_t)c.n_g_sw * L * n); prep.total_cloud_cover_sw = cv.take<double>(n); }
+      if (lw_mcica) { prep.od_scaling_lw = cv.take<double>((size_t)c.n_g_lw * L * n); prep.total_cloud_cover_lw = cv.take<double>(n); }
+      if (sw_mcica || lw_mcica) {
+        prep.rng_state = cv.take<int32_t>(607 * n);
+        const int ngmax = c.n_g_sw > c.n_g_lw ? c.n_g_sw : c.n_g_lw;
+        mcica_work = cv.take<double>(mcica_work_doubles(nlev, ngmax, r.nloc));
+      }
+      if (pass == 0) HIP_TRY(h, h->prep.ensure(cv.off));
+    }
+  }
+  const DevInputs& din = cx.din;
+  double* scratch = reinterpret_cast<double*>(h->scratch.p);
+
+  // ---- kernels (radiation_interface.F90:323-504) ------------------------------------------------------
+  HIP_TRY(h, hipEventRecord(h->ev0, stream));
+  HIP_TRY(h, hipEventRecord(h->evs[0], stream));
+  if (c.do_clouds) HIP_TRY(h, launch_crop(stream, h->dcfg, din));                      // :361
+  if (sw_tc || lw_tc)
+    HIP_TRY(h, launch_tripleclouds_prep(stream, h->dcfg, din, prep, sw_tc ? dfx.cloud_cover_sw : nullptr,
+                                        lw_tc ? dfx.cloud_cover_lw : nullptr));
+  // (the McICA generators are accounted to the LW/SW stage they feed)
+  HIP_TRY(h, hipEventRecord(h->evs[1], stream));
+  if (c.do_lw) {                                                                        // :422-457
+    const DevCkdModel& m = h->hcfg.gas_lw;
+    const int nct = (c.i_solver_lw != ECRAD_SOLVER_CLOUDLESS) ? c.n_cloud_types : 0;
+    const size_t lds = lds_bytes(m.ngas, nct);
+    if (lw_mcica) {
+      HIP_TRY(h, hipMemsetAsync(prep.od_scaling_lw, 0, (size_t)c.n_g_lw * nlev * r.nloc * 8, stream));
+      HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_lw, 997, prep.od_scaling_lw,
+                                        prep.total_cloud_cover_lw, prep.rng_state, mcica_work));
+    }
+    if (lw_tc) HIP_TRY(h, launch_lw_tc(h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_lw));
+    else HIP_TRY(h, launch_lw_ica(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_lw));
+  }
+  HIP_TRY(h, hipEventRecord(h->evs[2], stream));
+  if (c.do_sw) {                                                                        // :459-499
+    const DevCkdModel& m = h->hcfg.gas_sw;
+    const int nct = (c.i_solver_sw != ECRAD_SOLVER_CLOUDLESS) ? c.n_cloud_types : 0;
+    const size_t lds = lds_bytes(m.ngas, nct);
+    if (sw_mcica) {
+      HIP_TRY(h, hipMemsetAsync(prep.od_scaling_sw, 0, (size_t)c.n_g_sw * nlev * r.nloc * 8, stream));
+      HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_sw, 0, prep.od_scaling_sw,
+                                        prep.total_cloud_cover_sw, prep.rng_state, mcica_work));
+    }
+    if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_sw));
+    else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_sw));
+  }
+  HIP_TRY(h, hipEventRecord(h->evs[3], stream));
+  HIP_TRY(h, launch_spectral_post(stream, h->dcfg, din, dfx));                          // :503-504
+  HIP_TRY(h, hipEventRecord(h->evs[4], stream));
+  HIP_TRY(h, hipEventRecord(h->ev1, stream));
+  h->timing_pending = true;
+
+  if (cx.host_mem) {
+    // D2H of the processed column range only: columns outside istartcol..iendcol are not touched
+    for (auto& sp : staged) {
+      const FluxField& f = *sp.first;
+      double* hostp = flux->*(f.host);
+      const size_t rows = flux_rows(c, f.kind, nlev);
+      if (f.kind == 0) {
+        HIP_TRY(h, hipMemcpy2DAsync(hostp + (r.i0 - 1), (size_t)r.ncol * 8, sp.second, (size_t)r.nloc * 8,
+                                    (size_t)r.nloc * 8, rows, hipMemcpyDeviceToHost, stream));
+      } else {
+        HIP_TRY(h, hipMemcpyAsync(hostp + rows * (r.i0 - 1), sp.second, rows * r.nloc * 8, hipMemcpyDeviceToHost, stream));
+      }
+    }
+    if (c.do_clouds)   // crop_cloud_fraction side effect on the caller's array
+      HIP_TRY(h, hipMemcpy2DAsync(in->cloud_fraction + (r.i0 - 1), (size_t)r.ncol * 8, cx.si.cloud_fraction,
+                                  (size_t)r.nloc * 8, (size_t)r.nloc * 8, nlev, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(h, hipStreamSynchronize(stream));
+  }
+  return ECRAD_OK;
+}
+
+int ecrad_hip_optics(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
+                     const ecrad_inputs_t* in, ecrad_optics_t* out) {
+  if (!h || !in || !out) return ECRAD_EINVAL;
+  if (!h->is_setup) return fail(h, ECRAD_ENOTSETUP, "ecrad_hip_setup has not been called");
+  HIP_TRY(h, hipSetDevice(h->device));
+  const ecrad_config_t& c = h->cfg;
+  CallCtx cx;
+  int st = stage_inputs(h, ncol, nlev, istartcol, iendcol, in, cx);
+  if (st) return st;
+  const Range& r = cx.r;
+  hipStream_t stream = h->stream;
+  struct OF { double* ecrad_optics_t::*host; double* DevOptics::*dev; size_t n; };
+  const size_t n = r.nloc, L = nlev, glw = c.n_g_lw, gsw = c.n_g_sw, blw = c.n_bands_lw, bsw = c.n_bands_sw;
+#define OFD(f, cnt) { &ecrad_optics_t::f, &DevOptics::f, (cnt) }
+  const OF fields[] = {
+    OFD(od_lw, glw * L * n), OFD(ssa_lw, glw * L * n), OFD(g_lw, glw * L * n), OFD(od_sw, gsw * L * n), OFD(ssa_sw, gsw * L * n),
+    OFD(g_sw, gsw * L * n), OFD(planck_hl, glw * (L + 1) * n), OFD(lw_emission, glw * n), OFD(lw_albedo, glw * n),
+    OFD(sw_albedo_direct, gsw * n), OFD(sw_albedo_diffuse, gsw * n), OFD(incoming_sw, gsw * n),
+    OFD(od_lw_cloud, blw * L * n), OFD(ssa_lw_cloud, blw * L * n), OFD(g_lw_cloud, blw * L * n),
+    OFD(od_sw_cloud, bsw * L * n), OFD(ssa_sw_cloud, bsw * L * n), OFD(g_sw_cloud, bsw * L * n),
+  };
+#undef OFD
+  DevOptics dop{};
+  const bool host_mem = out->memory == ECRAD_MEM_HOST;
+  if (host_mem != cx.host_mem) return fail(h, ECRAD_EINVAL, "inputs and outputs must live in the same memory space");
+  if (!host_mem) {
+    for (const OF& f : fields) dop.*(f.dev) = out->*(f.host);
+  } else {
+    size_t off = 0;
+    for (const OF& f : fields) if (out->*(f.host)) off += (f.n * 8 + 255) & ~size_t(255);
+    HIP_TRY(h, h->staging_out.ensure(off));
+    HIP_TRY(h, hipMemsetAsync(h->staging_out.p, 0, off, stream));
+    Carver cv(h->staging_out.p);
+    for (const OF& f : fields) if (out->*(f.host)) dop.*(f.dev) = cv.take<double>(f.n);
+  }
+  if (c.do_clouds) HIP_TRY(h, launch_crop(stream, h->dcfg, cx.din));
+  const int nct = c.do_clouds ? c.n_cloud_types : 0;
+  if (c.do_sw) HIP_TRY(h, launch_optics_dump(true, h->ngp_sw, h->hcfg.gas_sw.table_f32, grid_for(h, r.nloc, h->ngp_sw),
+                                             lds_bytes(h->hcfg.gas_sw.ngas, nct), stream, h->dcfg, cx.din, dop));
+  if (c.do_lw) HIP_TRY(h, launch_optics_dump(false, h->ngp_lw, h->hcfg.gas_lw.table_f32, grid_for(h, r.nloc, h->ngp_lw),
+                                             lds_bytes(h->hcfg.gas_lw.ngas, nct), stream, h->dcfg, cx.din, dop));
+  if (host_mem) {
+    for (const OF& f : fields)
+      if (out->*(f.host)) HIP_TRY(h, hipMemcpyAsync(out->*(f.host), dop.*(f.dev), f.n * 8, hipMemcpyDeviceToHost, stream));
+    if (c.do_clouds)
+      HIP_TRY(h, hipMemcpy2DAsync(in->cloud_fraction + (r.i0 - 1), (size_t)r.ncol * 8, cx.si.cloud_fraction,
+                                  (size_t)r.nloc * 8, (size_t)r.nloc * 8, nlev, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(h, hipStreamSynchronize(stream));
+  }
+  return ECRAD_OK;
+}
+
+}  // extern "C"

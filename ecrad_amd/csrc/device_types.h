@@ -1,0 +1,136 @@
+// device_types.h -- device-resident mirror of the look-up tables and switches of ecrad_config_t,
+// plus the per-call argument blocks passed to the kernels.  gfx950 only.
+#pragma once
+#include <stdint.h>
+#include "../../include/ecrad_hip.h"
+
+namespace ecrad {
+
+constexpr int kMaxGas = ECRAD_NMAXGASES;
+constexpr int kMaxCloudTypes = ECRAD_NMAXCLOUDTYPES;
+constexpr int kNReg = 3;
+constexpr double kAccelDueToGravity = 9.80665;          // radiation_constants.F90:26
+constexpr double kAirMolarMass = 28.970;                // radiation_gas_constants.F90:41
+constexpr double kH2OMolarMass = 18.0152833;            // radiation_gas_constants.F90:44
+
+struct DevCkdGas {
+  int32_t i_gas_code;         // 0 composite, else 1-based gas code
+  int32_t i_conc_dependence;
+  int32_t n_mole_frac;
+  int32_t pad_;
+  double reference_mole_frac, log_mole_frac1, d_log_mole_frac, mole_frac1;
+  const void* molar_abs;      // float or double (see DevCkdModel::table_f32), (ng,npress,ntemp[,nconc])
+};
+
+struct DevCkdModel {
+  int32_t is_sw, ng, npress, ntemp, ngas, nplanck;
+  int32_t table_f32;          // 1: molar_abs / planck tables stored as float (lossless), 0: double
+  int32_t pad_;
+  double log_pressure1, d_log_pressure, d_temperature;
+  double temperature1_planck, d_temperature_planck;
+  const double* temperature1;              // (npress)
+  const void*   planck_function;           // (ng,nplanck) float/double
+  const double* norm_solar_irradiance;     // (ng)
+  const double* norm_amplitude_solar_irradiance;
+  const double* rayleigh_molar_scat;       // (ng)
+  DevCkdGas gas[kMaxGas];
+};
+
+struct DevCloudOptics {
+  int32_t n_bands, n_effective_radius;
+  double effective_radius_0, d_effective_radius;
+  const double *mass_ext, *ssa, *asymmetry;   // (n_bands, n_re)
+};
+
+struct DevAerosolOptics {
+  int32_t n_bands_sw, n_bands_lw, n_type_phobic, n_type_philic, nrh, use_hydrophilic, ntype, pad_;
+  const int32_t *iclass, *itype;
+  const double* rh_lower;
+  // Pre-combined per-band tables (bands fastest): ext, ext*ssa, ext*ssa*g (SW); LW: ext*(1-ssa) or the
+  // same three when aerosols scatter in the longwave.  Hydrophilic tables are (nb, nrh, ntype).
+  const double *sw_phobic[3], *sw_philic[3], *lw_phobic[3], *lw_philic[3];
+};
+
+struct DevPdfSampler {
+  int32_t ncdf, nfsd;
+  double fsd1, inv_fsd_interval;
+  const float* val;          // (ncdf, nfsd); mcica_*.nc tables are float32 on disk
+  const double* val64;       // used instead when the caller's table is not float-exact
+};
+
+struct DevConfig {
+  // switches / sizes: same names as ecrad_config_t
+  int32_t do_sw, do_lw, do_clear, do_sw_direct, do_lw_derivatives, do_clouds, use_aerosols;
+  int32_t i_solver_sw, i_solver_lw;
+  int32_t do_lw_cloud_scattering, do_lw_aerosol_scattering, do_sw_delta_scaling_with_gases;
+  int32_t is_homogeneous, i_overlap_scheme, use_beta_overlap, i_cloud_pdf_shape;
+  int32_t do_cloud_aerosol_per_sw_g_point, do_cloud_aerosol_per_lw_g_point;
+  int32_t do_surface_sw_spectral_flux, do_toa_spectral_flux, do_canopy_fluxes_sw, do_canopy_fluxes_lw;
+  int32_t use_canopy_full_spectrum_sw, use_canopy_full_spectrum_lw;
+  int32_t do_nearest_spectral_sw_albedo, do_nearest_spectral_lw_emiss;
+  int32_t n_g_sw, n_g_lw, n_bands_sw, n_bands_lw, n_canopy_bands_sw, n_canopy_bands_lw;
+  int32_t n_albedo_intervals_sw, n_emiss_intervals_lw, n_cloud_types, pad_;
+  double cloud_fraction_threshold, cloud_mixing_ratio_threshold, cloud_inhom_decorr_scaling;
+  const int32_t *i_band_from_reordered_g_sw, *i_band_from_reordered_g_lw;
+  const double *sw_albedo_weights, *lw_emiss_weights;
+  const int32_t *i_albedo_from_band_sw, *i_emiss_from_band_lw;
+  DevCkdModel gas_sw, gas_lw;
+  DevCloudOptics cloud_sw[kMaxCloudTypes], cloud_lw[kMaxCloudTypes];
+  DevAerosolOptics aerosol;
+  DevPdfSampler pdf;
+};
+
+// Input arrays on the device (same layouts as ecrad_inputs_t)
+struct DevInputs {
+  int32_t ncol, nlev, istartcol, iendcol;      // 1-based inclusive range as in the reference
+  int32_t n_sw_albedo, n_lw_emissivity, n_cloud_types, n_aerosol_types;
+  int32_t aerosol_istartlev, aerosol_iendlev, has_sw_albedo_direct, pad_;
+  double solar_irradiance, spectral_solar_cycle_multiplier;
+  const double *pressure_hl, *temperature_hl, *h2o_sat_liq;
+  const double *cos_sza, *skin_temperature, *sw_albedo, *sw_albedo_direct, *lw_emissivity;
+  const int32_t* iseed;
+  const double* gas_mixing_ratio;
+  double* cloud_fraction;
+  const double *cloud_mixing_ratio, *cloud_effective_radius, *cloud_fractional_std, *cloud_overlap_param;
+  const double* aerosol_mixing_ratio;
+};
+
+// Output arrays on the device (same layouts as ecrad_flux_t); NULL = not wanted
+struct DevFlux {
+  double *lw_up, *lw_dn, *sw_up, *sw_dn, *sw_dn_direct;
+  double *lw_up_clear, *lw_dn_clear, *sw_up_clear, *sw_dn_clear, *sw_dn_direct_clear;
+  double *lw_derivatives;
+  double *lw_dn_surf_g, *lw_dn_surf_clear_g;
+  double *sw_dn_diffuse_surf_g, *sw_dn_direct_surf_g, *sw_dn_diffuse_surf_clear_g, *sw_dn_direct_surf_clear_g;
+  double *lw_up_toa_g, *lw_up_toa_clear_g, *sw_dn_toa_g, *sw_up_toa_g, *sw_up_toa_clear_g;
+  double *sw_dn_surf_band, *sw_dn_direct_surf_band, *sw_dn_surf_clear_band, *sw_dn_direct_surf_clear_band;
+  double *lw_up_toa_band, *lw_up_toa_clear_band, *sw_dn_toa_band, *sw_up_toa_band, *sw_up_toa_clear_band;
+  double *lw_dn_surf_canopy, *sw_dn_diffuse_surf_canopy, *sw_dn_direct_surf_canopy;
+  double *cloud_cover_lw, *cloud_cover_sw;
+};
+
+// Optional stage-interface dump (ecrad_hip_optics); layouts (ng, nlev[+1], ncol_local)
+struct DevOptics {
+  double *od_lw, *ssa_lw, *g_lw, *od_sw, *ssa_sw, *g_sw, *planck_hl, *lw_emission, *lw_albedo;
+  double *sw_albedo_direct, *sw_albedo_diffuse, *incoming_sw;
+  double *od_lw_cloud, *ssa_lw_cloud, *g_lw_cloud, *od_sw_cloud, *ssa_sw_cloud, *g_sw_cloud;
+};
+
+// Per-call cloud geometry produced by the "prep" kernels (lane = column) and consumed by the
+// spectral kernels (lane = g-point).
+struct DevCloudPrep {
+  // Tripleclouds: (ncol_local, nlev[+1], k) with the LOCAL column fastest
+  double* region_fracs;    // [3][nlev][nloc]
+  double* od_scaling_reg;  // [2][nlev][nloc]      regions 2,3
+  double* v_matrix;        // [9][nlev+1][nloc]    element (i + 3*j)
+  double* u_matrix;        // [9][nlev+1][nloc]
+  // McICA: per-g optical-depth scalings, (ng, nlev, nloc) with g fastest; float is NOT used: the
+  // values feed 1e-6-level parity
+  double* od_scaling_sw;
+  double* od_scaling_lw;
+  double* total_cloud_cover_sw;   // [nloc]
+  double* total_cloud_cover_lw;   // [nloc]
+  int32_t* rng_state;             // [607][nloc] lagged-Fibonacci state, column fastest
+};
+
+}  // namespace ecrad

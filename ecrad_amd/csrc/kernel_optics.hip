@@ -1,0 +1,120 @@
+// kernel_optics.hip -- stage-interface dump used by ecrad_hip_optics(): runs the same device
+// functions as the fused solver kernels (optics_device.h) but writes the arrays that the reference
+// passes between stages (radiation_interface.F90:260-301) so that tests can compare them one by one.
+#include "kernels_common.h"
+#include "optics_device.h"
+#include "launch.h"
+
+namespace ecrad {
+
+template <typename TAB, int NGP, bool IS_SW>
+__global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevOptics out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const DevConfig& cfg = *cfgp;
+  const DevCkdModel& m = IS_SW ? cfg.gas_sw : cfg.gas_lw;
+  constexpr int CPB = kBlock / NGP;
+  const int tid = threadIdx.x;
+  const int glane = tid % NGP, cib = tid / NGP;
+  const int ng = m.ng, nlev = in.nlev;
+  const int ncol_loc = in.iendcol - in.istartcol + 1;
+  const int ngroups = (ncol_loc + CPB - 1) / CPB;
+  const bool want_clouds = cfg.do_clouds != 0;
+  const int nct = want_clouds ? cfg.n_cloud_types : 0;
+  const LdsLayout L = make_lds(smem, m.ngas, nct);
+  const int g = glane < ng ? glane : ng - 1;
+  const int ib = (IS_SW ? cfg.i_band_from_reordered_g_sw[g] : cfg.i_band_from_reordered_g_lw[g]) - 1;
+  const int nb = IS_SW ? cfg.n_bands_sw : cfg.n_bands_lw;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int cloc_raw = grp * CPB + cib;
+    const bool col_ok = cloc_raw < ncol_loc;
+    const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
+    const int col = in.istartcol - 1 + cloc;
+    const bool valid = col_ok && glane < ng;
+    const size_t og = g + (size_t)ng * cloc;
+    double lw_albedo = 0.0;
+    if (IS_SW) {
+      double ad, adir;
+      albedo_sw_g(cfg, in, col, g, ad, adir);
+      if (valid) {
+        if (out.sw_albedo_diffuse) out.sw_albedo_diffuse[og] = ad;
+        if (out.sw_albedo_direct) out.sw_albedo_direct[og] = adir;
+        if (out.incoming_sw) out.incoming_sw[og] = incoming_sw_g(m, in, g);
+      }
+    } else {
+      lw_albedo = albedo_lw_g(cfg, in, col, g);
+      if (valid) {
+        if (out.lw_albedo) out.lw_albedo[og] = lw_albedo;
+        if (out.lw_emission) out.lw_emission[og] = planck_at<TAB>(m, in.skin_temperature[col], g) * (1.0 - lw_albedo);
+      }
+    }
+    double planck_top = 0.0;
+    for (int l0 = 0; l0 < nlev; l0 += NGP) {
+      __syncthreads();
+      {
+        const int lev = l0 + glane;
+        if (lev < nlev) level_scalars<IS_SW>(cfg, m, in, L, tid, col, lev, want_clouds);
+      }
+      __syncthreads();
+      const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
+      for (int j = 0; j < nl; ++j) {
+        const int lev = l0 + j;
+        const int slot = cib * NGP + j;
+        const size_t o = g + (size_t)ng * (lev + (size_t)nlev * cloc);
+        double od = gas_absorption_od<TAB>(m, L, slot, g);
+        if (IS_SW) {
+          double ssa = L.D(F_SM, slot) * m.rayleigh_molar_scat[g];
+          od = od + ssa;
+          ssa = ssa / od;
+          double asym = 0.0;
+          if (cfg.use_aerosols) {
+            AerosolLayer a = aerosol_layer<true>(cfg, in, L, slot, col, lev, ib);
+            if (!cfg.do_sw_delta_scaling_with_gases) delta_eddington_extensive_vec(a);
+            merge_aerosol_sw(cfg, a, od, ssa, asym);
+          }
+          if (valid) {
+            if (out.od_sw) out.od_sw[o] = od;
+            if (out.ssa_sw) out.ssa_sw[o] = ssa;
+            if (out.g_sw) out.g_sw[o] = asym;
+          }
+        } else {
+          if (lev == 0) planck_top = planck_lookup<TAB>(m, L.I(I_PL_TOP, slot), L.D(F_PLW_TOP, slot), g);
+          const double planck_bot = planck_lookup<TAB>(m, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
+          if (cfg.use_aerosols) od = od + aerosol_layer<false>(cfg, in, L, slot, col, lev, ib).od;
+          if (valid) {
+            if (out.od_lw) out.od_lw[o] = od;
+            if (out.planck_hl) {
+              const size_t op = g + (size_t)ng * (lev + (size_t)(nlev + 1) * cloc);
+              if (lev == 0) out.planck_hl[op] = planck_top;
+              out.planck_hl[op + ng] = planck_bot;
+            }
+          }
+          planck_top = planck_bot;
+        }
+        if (want_clouds && glane < nb && col_ok) {
+          // cloud tables are per band: lane b < n_bands writes band b
+          const CloudLayer cl = cloud_layer<IS_SW>(cfg, L, slot, glane);
+          const size_t oc = glane + (size_t)nb * (lev + (size_t)nlev * cloc);
+          double* pod = IS_SW ? out.od_sw_cloud : out.od_lw_cloud;
+          double* pss = IS_SW ? out.ssa_sw_cloud : out.ssa_lw_cloud;
+          double* pg = IS_SW ? out.g_sw_cloud : out.g_lw_cloud;
+          if (pod) pod[oc] = cl.od;
+          if (pss) pss[oc] = cl.ssa;
+          if (pg) pg[oc] = cl.g;
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
+                              const DevConfig* cfg, const DevInputs& in, const DevOptics& out) {
+#define ECRAD_L(T, N, S) hipLaunchKernelGGL((optics_dump_kernel<T, N, S>), dim3(grid), dim3(kBlock), lds, st, cfg, in, out)
+#define ECRAD_N(T, S) do { if (ngp == 16) ECRAD_L(T, 16, S); else if (ngp == 32) ECRAD_L(T, 32, S); else ECRAD_L(T, 64, S); } while (0)
+  if (is_sw) { if (table_f32) ECRAD_N(float, true); else ECRAD_N(double, true); }
+  else { if (table_f32) ECRAD_N(float, false); else ECRAD_N(double, false); }
+#undef ECRAD_N
+#undef ECRAD_L
+  return hipGetLastError();
+}
+
+}  // namespace ecrad

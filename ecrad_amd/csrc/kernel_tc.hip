@@ -1,0 +1,571 @@
+// kernel_tc.hip -- fused Tripleclouds kernels (3 regions: clear, optically thin cloud, thick cloud)
+//   solver_tripleclouds_sw   radiation_tripleclouds_sw.F90:42-661
+//   solver_tripleclouds_lw   radiation_tripleclouds_lw.F90:38-605
+//   calc_lw_derivatives_region  radiation_lw_derivatives.F90:200-255
+// Region fractions, optical-depth scalings and the 3x3 overlap matrices come from
+// tripleclouds_prep_kernel (kernel_prep.hip).  As in the ICA kernels, gas/aerosol/cloud optics and the
+// two-stream coefficients are computed in the same launch; only what the vertical sweeps need later
+// goes through block-private scratch.
+#include "kernels_common.h"
+#include "optics_device.h"
+#include "launch.h"
+
+namespace ecrad {
+
+// broadcast readers for the per-(column,level) geometry produced by the prep kernel
+struct TcGeom {
+  const DevCloudPrep& p;
+  int nloc, nlev, cloc;
+  ECRAD_DEV double frac(int r, int lev) const { return p.region_fracs[((size_t)r * nlev + lev) * nloc + cloc]; }
+  ECRAD_DEV double odsc(int r /*1,2*/, int lev) const { return p.od_scaling_reg[((size_t)(r - 1) * nlev + lev) * nloc + cloc]; }
+  ECRAD_DEV double v(int i, int j, int hl) const { return p.v_matrix[((size_t)(i + 3 * j) * (nlev + 1) + hl) * nloc + cloc]; }
+  ECRAD_DEV double u(int i, int j, int hl) const { return p.u_matrix[((size_t)(i + 3 * j) * (nlev + 1) + hl) * nloc + cloc]; }
+};
+
+// ===================================================================================================
+// Shortwave
+// ===================================================================================================
+enum { S_R = 0, S_T = 5, S_RD = 10, S_TDF = 15, S_TDD = 20 };   // unused; kept for documentation
+// array index helpers: coefficient k (0 R,1 T,2 rd,3 tdf,4 tdd) of region r (0 clear,1,2)
+ECRAD_DEV int sw_coef(int k, int r) { return k * 3 + r; }                 // 0..14
+constexpr int SW_TA = 15;      // total_albedo[3]          15,16,17
+constexpr int SW_TAD = 18;     // total_albedo_direct[3]   18,19,20
+constexpr int SW_TAC = 21;     // total_albedo_clear
+constexpr int SW_TACD = 22;    // total_albedo_clear_direct
+constexpr int SW_TC_NUM = 23;
+
+template <typename TAB, int NGP>
+__global__ __launch_bounds__(kBlock) void sw_tc_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevFlux fx,
+                                                      DevCloudPrep prep, double* scratch_base, size_t scratch_per_block) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const DevConfig& cfg = *cfgp;
+  const DevCkdModel& m = cfg.gas_sw;
+  constexpr int CPB = kBlock / NGP;
+  const int tid = threadIdx.x;
+  const int glane = tid % NGP, cib = tid / NGP;
+  const int ng = m.ng, nlev = in.nlev;
+  const size_t ncol = in.ncol;
+  const int ncol_loc = in.iendcol - in.istartcol + 1;
+  const int ngroups = (ncol_loc + CPB - 1) / CPB;
+  const LdsLayout L = make_lds(smem, m.ngas, cfg.n_cloud_types);
+  const Scratch s{scratch_base + (size_t)blockIdx.x * scratch_per_block, nlev + 1};
+  const int g = glane < ng ? glane : ng - 1;
+  const int ib = cfg.i_band_from_reordered_g_sw[g] - 1;
+  const double ray_g = m.rayleigh_molar_scat[g];
+  const bool do_clear = cfg.do_clear != 0;
+
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int cloc_raw = grp * CPB + cib;
+    const bool col_ok = cloc_raw < ncol_loc;
+    const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
+    const int col = in.istartcol - 1 + cloc;
+    const bool valid = col_ok && glane < ng;
+    const bool lead = glane == 0 && col_ok;
+    const double mu0 = in.cos_sza[col];
+    const bool sun_up = !(mu0 < 1.0e-10);
+    const TcGeom geo{prep, ncol_loc, nlev, cloc};
+    double alb_dif = 0.0, alb_dir = 0.0, incoming = 0.0;
+    if (sun_up) {
+      albedo_sw_g(cfg, in, col, g, alb_dif, alb_dir);
+      incoming = incoming_sw_g(m, in, g);
+    }
+    LevMask cloudy;
+    cloudy.clear();
+
+    // ---- pass A ---------------------------------------------------------------------------------------
+    for (int l0 = 0; l0 < nlev; l0 += NGP) {
+      __syncthreads();
+      {
+        const int lev = l0 + glane;
+        if (lev < nlev) level_scalars<true>(cfg, m, in, L, tid, col, lev, true);
+      }
+      __syncthreads();
+      const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
+      if (sun_up) {
+        for (int j = 0; j < nl; ++j) {
+          const int lev = l0 + j;
+          const int slot = cib * NGP + j;
+          double od = gas_absorption_od<TAB>(m, L, slot, g);
+          double ssa = L.D(F_SM, slot) * ray_g;
+          od = od + ssa;
+          ssa = ssa / od;
+          double asym = 0.0;
+          if (cfg.use_aerosols) {
+            AerosolLayer a = aerosol_layer<true>(cfg, in, L, slot, col, lev, ib);
+            if (!cfg.do_sw_delta_scaling_with_gases) delta_eddington_extensive_vec(a);
+            merge_aerosol_sw(cfg, a, od, ssa, asym);
+          }
+          {
+            const SwCoef c = ref_trans_sw_fused(mu0, od, ssa, asym);
+            s.at(sw_coef(0, 0), lev, tid) = c.ref_diff;
+            s.at(sw_coef(1, 0), lev, tid) = c.trans_diff;
+            s.at(sw_coef(2, 0), lev, tid) = c.ref_dir;
+            s.at(sw_coef(3, 0), lev, tid) = c.trans_dir_diff;
+            s.at(sw_coef(4, 0), lev, tid) = c.trans_dir_dir;
+          }
+          if (L.D(F_FRAC, slot) > 0.0) {
+            cloudy.set(lev);
+            const CloudLayer cl = cloud_layer<true>(cfg, L, slot, ib);
+#pragma unroll
+            for (int jreg = 1; jreg < 3; ++jreg) {   // radiation_tripleclouds_sw.F90:278-300
+              const double osc = geo.odsc(jreg, lev);
+              const double scat_od = od * ssa;
+              const double scat_od_cloud = cl.od * cl.ssa * osc;
+              double od_total = od + cl.od * osc;
+              double ssa_total = (scat_od + scat_od_cloud) / od_total;
+              double g_total = (scat_od * asym + scat_od_cloud * cl.g) / (scat_od + scat_od_cloud);
+              if (cfg.do_sw_delta_scaling_with_gases) delta_eddington(od_total, ssa_total, g_total);
+              const SwCoef c = ref_trans_sw_fused(mu0, od_total, ssa_total, g_total);
+              s.at(sw_coef(0, jreg), lev, tid) = c.ref_diff;
+              s.at(sw_coef(1, jreg), lev, tid) = c.trans_diff;
+              s.at(sw_coef(2, jreg), lev, tid) = c.ref_dir;
+              s.at(sw_coef(3, jreg), lev, tid) = c.trans_dir_diff;
+              s.at(sw_coef(4, jreg), lev, tid) = c.trans_dir_dir;
+            }
+          }
+        }
+      }
+    }
+
+    if (!sun_up) {   // radiation_tripleclouds_sw.F90:212-249
+      if (lead) {
+        for (int l = 0; l <= nlev; ++l) {
+          const size_t o = col + ncol * l;
+          fx.sw_up[o] = 0.0; fx.sw_dn[o] = 0.0;
+          if (fx.sw_dn_direct) fx.sw_dn_direct[o] = 0.0;
+          if (do_clear) {
+            fx.sw_up_clear[o] = 0.0; fx.sw_dn_clear[o] = 0.0;
+            if (fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[o] = 0.0;
+          }
+        }
+      }
+      if (valid) {
+        const size_t og = g + (size_t)ng * col;
+        fx.sw_dn_diffuse_surf_g[og] = 0.0;
+        fx.sw_dn_direct_surf_g[og] = 0.0;
+        if (do_clear) { fx.sw_dn_diffuse_surf_clear_g[og] = 0.0; fx.sw_dn_direct_surf_clear_g[og] = 0.0; }
+      }
+      continue;
+    }
+
+    // ---- pass B: upward sweep: albedo of everything below each half level, per region ------------
+    double ta[3], tad[3];
+    ta[0] = alb_dif;
+    tad[0] = mu0 * alb_dir;
+    if (cloudy.test(nlev - 1)) { ta[1] = ta[2] = ta[0]; tad[1] = tad[2] = tad[0]; }
+    else { ta[1] = ta[2] = 0.0; tad[1] = tad[2] = 0.0; }
+    double tac = ta[0], tacd = tad[0];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { s.at(SW_TA + r, nlev, tid) = ta[r]; s.at(SW_TAD + r, nlev, tid) = tad[r]; }
+    if (do_clear) { s.at(SW_TAC, nlev, tid) = tac; s.at(SW_TACD, nlev, tid) = tacd; }
+    for (int l = nlev - 1; l >= 0; --l) {
+      const double Rc = s.at(sw_coef(0, 0), l, tid), Tc = s.at(sw_coef(1, 0), l, tid), rdc = s.at(sw_coef(2, 0), l, tid),
+                   tdfc = s.at(sw_coef(3, 0), l, tid), tddc = s.at(sw_coef(4, 0), l, tid);
+      if (do_clear) {
+        const double inv = 1.0 / (1.0 - tac * Rc);
+        const double tac_new = Rc + Tc * Tc * tac * inv;
+        tacd = rdc + (tddc * tacd + tdfc * tac) * Tc * inv;
+        tac = tac_new;
+        s.at(SW_TAC, l, tid) = tac;
+        s.at(SW_TACD, l, tid) = tacd;
+      }
+      double below[3] = {0.0, 0.0, 0.0}, belowd[3] = {0.0, 0.0, 0.0};
+      {
+        const double inv = 1.0 / (1.0 - ta[0] * Rc);
+        below[0] = Rc + Tc * Tc * ta[0] * inv;
+        belowd[0] = rdc + (tddc * tad[0] + tdfc * ta[0]) * Tc * inv;
+      }
+      const bool cl_here = cloudy.test(l);
+      if (cl_here) {
+#pragma unroll
+        for (int r = 1; r < 3; ++r) {
+          const double R = s.at(sw_coef(0, r), l, tid), T = s.at(sw_coef(1, r), l, tid), rd = s.at(sw_coef(2, r), l, tid),
+                       tdf = s.at(sw_coef(3, r), l, tid), tdd = s.at(sw_coef(4, r), l, tid);
+          const double inv = 1.0 / (1.0 - ta[r] * R);
+          below[r] = R + T * T * ta[r] * inv;
+          belowd[r] = rd + (tdd * tad[r] + tdf * ta[r]) * T * inv;
+        }
+      }
+      const bool cl_above = l > 0 && cloudy.test(l - 1);
+      if (!cl_here && !cl_above) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { ta[r] = below[r]; tad[r] = belowd[r]; }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {   // total_albedo(:,jreg,jlev) = sum_jreg2 below(:,jreg2) * v(jreg2,jreg,jlev)
+          double a = 0.0, b = 0.0;
+#pragma unroll
+          for (int r2 = 0; r2 < 3; ++r2) {
+            const double v = geo.v(r2, r, l);
+            a = a + below[r2] * v;
+            b = b + belowd[r2] * v;
+          }
+          ta[r] = a; tad[r] = b;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { s.at(SW_TA + r, l, tid) = ta[r]; s.at(SW_TAD + r, l, tid) = tad[r]; }
+    }
+
+    // ---- pass C: downward sweep ------------------------------------------------------------------------
+    double fdn[3] = {0.0, 0.0, 0.0}, ddn[3], fup[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { ddn[r] = incoming * geo.frac(r, 0); fup[r] = ddn[r] * tad[r]; }
+    double fdn_c = 0.0, ddn_c = incoming, fup_c = ddn_c * tacd;
+    if (valid) {
+      const size_t og = g + (size_t)ng * col;
+      fx.sw_up_toa_g[og] = fup[0] + fup[1] + fup[2];
+      if (fx.sw_dn_toa_g) fx.sw_dn_toa_g[og] = incoming * mu0;
+      if (do_clear) fx.sw_up_toa_clear_g[og] = fup_c;
+    }
+    for (int hl = 0; hl <= nlev; ++hl) {
+      if (hl > 0) {
+        const int l = hl - 1;
+        const double Rc = s.at(sw_coef(0, 0), l, tid), Tc = s.at(sw_coef(1, 0), l, tid),
+                     tdfc = s.at(sw_coef(3, 0), l, tid), tddc = s.at(sw_coef(4, 0), l, tid);
+        if (do_clear) {
+          const double tacn = s.at(SW_TAC, hl, tid), tacdn = s.at(SW_TACD, hl, tid);
+          fdn_c = (Tc * fdn_c + ddn_c * (tddc * tacdn * Rc + tdfc)) / (1.0 - Rc * tacn);
+          ddn_c = tddc * ddn_c;
+          fup_c = ddn_c * tacdn + fdn_c * tacn;
+        }
+        {
+          const double tan_ = s.at(SW_TA + 0, hl, tid), tadn = s.at(SW_TAD + 0, hl, tid);
+          fdn[0] = (Tc * fdn[0] + ddn[0] * (tddc * tadn * Rc + tdfc)) / (1.0 - Rc * tan_);
+          ddn[0] = tddc * ddn[0];
+          fup[0] = ddn[0] * tadn + fdn[0] * tan_;
+        }
+        const bool cl_here = cloudy.test(l);
+        if (!cl_here) {
+          fdn[1] = fdn[2] = 0.0; fup[1] = fup[2] = 0.0; ddn[1] = ddn[2] = 0.0;
+        } else {
+#pragma unroll
+          for (int r = 1; r < 3; ++r) {
+            const double R = s.at(sw_coef(0, r), l, tid), T = s.at(sw_coef(1, r), l, tid),
+                         tdf = s.at(sw_coef(3, r), l, tid), tdd = s.at(sw_coef(4, r), l, tid);
+            const double tan_ = s.at(SW_TA + r, hl, tid), tadn = s.at(SW_TAD + r, hl, tid);
+            fdn[r] = (T * fdn[r] + ddn[r] * (tdd * tadn * R + tdf)) / (1.0 - R * tan_);
+            ddn[r] = tdd * ddn[r];
+            fup[r] = ddn[r] * tadn + fdn[r] * tan_;
+          }
+        }
+        const bool cl_below = hl < nlev && cloudy.test(hl);
+        if (cl_here || cl_below) {   // singlemat_x_vec(v_matrix(:,:,jlev+1), .)
+          double nf[3], nd[3];
+#pragma unroll
+          for (int j1 = 0; j1 < 3; ++j1) {
+            double a = 0.0, b = 0.0;
+#pragma unroll
+            for (int j2 = 0; j2 < 3; ++j2) {
+              const double v = geo.v(j1, j2, hl);
+              a = a + v * fdn[j2];
+              b = b + v * ddn[j2];
+            }
+            nf[j1] = a; nd[j1] = b;
+          }
+#pragma unroll
+          for (int r = 0; r < 3; ++r) { fdn[r] = nf[r]; ddn[r] = nd[r]; }
+        }
+      }
+      const double su = group_sum<NGP>(valid ? fup[0] + fup[1] + fup[2] : 0.0);
+      const double sd = group_sum<NGP>(valid ? fdn[0] + fdn[1] + fdn[2] : 0.0);
+      const double sdir = group_sum<NGP>(valid ? ddn[0] + ddn[1] + ddn[2] : 0.0);
+      double suc = 0.0, sdc = 0.0, sdirc = 0.0;
+      if (do_clear) {
+        suc = group_sum<NGP>(valid ? fup_c : 0.0);
+        sdc = group_sum<NGP>(valid ? fdn_c : 0.0);
+        sdirc = group_sum<NGP>(valid ? ddn_c : 0.0);
+      }
+      if (lead) {
+        const size_t o = col + ncol * hl;
+        fx.sw_up[o] = su;
+        fx.sw_dn[o] = mu0 * sdir + sd;
+        if (fx.sw_dn_direct) fx.sw_dn_direct[o] = mu0 * sdir;
+        if (do_clear) {
+          fx.sw_up_clear[o] = suc;
+          fx.sw_dn_clear[o] = mu0 * sdirc + sdc;
+          if (fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[o] = mu0 * sdirc;
+        }
+      }
+    }
+    if (valid) {
+      const size_t og = g + (size_t)ng * col;
+      fx.sw_dn_diffuse_surf_g[og] = fdn[0] + fdn[1] + fdn[2];
+      fx.sw_dn_direct_surf_g[og] = mu0 * (ddn[0] + ddn[1] + ddn[2]);
+      if (do_clear) {
+        fx.sw_dn_diffuse_surf_clear_g[og] = fdn_c;
+        fx.sw_dn_direct_surf_clear_g[og] = mu0 * ddn_c;
+      }
+    }
+  }
+}
+
+int sw_tc_num_scratch_arrays() { return SW_TC_NUM; }
+
+hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig* cfg,
+                        const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block) {
+#define ECRAD_L(T, N) hipLaunchKernelGGL((sw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block)
+  if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
+  else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }
+#undef ECRAD_L
+  return hipGetLastError();
+}
+
+// ===================================================================================================
+// Longwave
+// ===================================================================================================
+constexpr int LT_T1 = 0, LT_SU1 = 1, LT_SD1 = 2;          // clear-sky layer coefficients (region 1)
+ECRAD_DEV int lw_coef(int k, int r /*1,2*/) { return 3 + k * 2 + (r - 1); }   // k: 0 R,1 T,2 su,3 sd -> 3..10
+constexpr int LT_TA = 11;     // total_albedo[3]   11..13
+constexpr int LT_TS = 14;     // total_source[3]   14..16
+constexpr int LW_TC_NUM = 17;
+
+template <typename TAB, int NGP>
+__global__ __launch_bounds__(kBlock) void lw_tc_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevFlux fx,
+                                                      DevCloudPrep prep, double* scratch_base, size_t scratch_per_block) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const DevConfig& cfg = *cfgp;
+  const DevCkdModel& m = cfg.gas_lw;
+  constexpr int CPB = kBlock / NGP;
+  const int tid = threadIdx.x;
+  const int glane = tid % NGP, cib = tid / NGP;
+  const int ng = m.ng, nlev = in.nlev;
+  const size_t ncol = in.ncol;
+  const int ncol_loc = in.iendcol - in.istartcol + 1;
+  const int ngroups = (ncol_loc + CPB - 1) / CPB;
+  const LdsLayout L = make_lds(smem, m.ngas, cfg.n_cloud_types);
+  const Scratch s{scratch_base + (size_t)blockIdx.x * scratch_per_block, nlev + 1};
+  const int g = glane < ng ? glane : ng - 1;
+  const int ib = cfg.i_band_from_reordered_g_lw[g] - 1;
+  const bool do_clear = cfg.do_clear != 0;
+  const bool do_deriv = cfg.do_lw_derivatives != 0 && fx.lw_derivatives != nullptr;
+
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int cloc_raw = grp * CPB + cib;
+    const bool col_ok = cloc_raw < ncol_loc;
+    const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
+    const int col = in.istartcol - 1 + cloc;
+    const bool valid = col_ok && glane < ng;
+    const bool lead = glane == 0 && col_ok;
+    const TcGeom geo{prep, ncol_loc, nlev, cloc};
+    const double albedo = albedo_lw_g(cfg, in, col, g);
+    const double emission = planck_at<TAB>(m, in.skin_temperature[col], g) * (1.0 - albedo);
+    LevMask cloudy;
+    cloudy.clear();
+    int ict = nlev;             // 0-based layer index of cloud top (= i_cloud_top-1); nlev if none
+    double fdn_c = 0.0, fdn_ctop = 0.0, planck_top = 0.0;
+
+    // ---- pass A ---------------------------------------------------------------------------------------
+    if (lead) {
+      if (do_clear) fx.lw_dn_clear[col] = 0.0;
+      fx.lw_dn[col] = 0.0;
+    }
+    for (int l0 = 0; l0 < nlev; l0 += NGP) {
+      __syncthreads();
+      {
+        const int lev = l0 + glane;
+        if (lev < nlev) level_scalars<false>(cfg, m, in, L, tid, col, lev, true);
+      }
+      __syncthreads();
+      const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
+      for (int j = 0; j < nl; ++j) {
+        const int lev = l0 + j;
+        const int slot = cib * NGP + j;
+        double od = gas_absorption_od<TAB>(m, L, slot, g);
+        if (lev == 0) planck_top = planck_lookup<TAB>(m, L.I(I_PL_TOP, slot), L.D(F_PLW_TOP, slot), g);
+        const double planck_bot = planck_lookup<TAB>(m, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
+        if (cfg.use_aerosols) od = od + aerosol_layer<false>(cfg, in, L, slot, col, lev, ib).od;
+        const LwCoef c = no_scattering_lw(od, planck_top, planck_bot);
+        s.at(LT_T1, lev, tid) = c.transmittance;
+        s.at(LT_SU1, lev, tid) = c.source_up;
+        s.at(LT_SD1, lev, tid) = c.source_dn;
+        if (L.D(F_FRAC, slot) > 0.0) {
+          if (!cloudy.any()) { ict = lev; fdn_ctop = fdn_c; }
+          cloudy.set(lev);
+          const CloudLayer cl = cloud_layer<false>(cfg, L, slot, ib);
+#pragma unroll
+          for (int jreg = 1; jreg < 3; ++jreg) {    // radiation_tripleclouds_lw.F90:318-372
+            const double od_cloud_new = cl.od * geo.odsc(jreg, lev);
+            const double od_total = od + od_cloud_new;
+            LwCoef c2;
+            if (cfg.do_lw_cloud_scattering) {
+              double ssa_total = 0.0, g_total = 0.0;
+              if (od_total > 0.0) ssa_total = cl.ssa * od_cloud_new / od_total;
+              if (ssa_total > 0.0 && od_total > 0.0) g_total = cl.g * cl.ssa * od_cloud_new / (ssa_total * od_total);
+              c2 = ref_trans_lw(od_total, ssa_total, g_total, planck_top, planck_bot);
+            } else {
+              c2 = no_scattering_lw(od_total, planck_top, planck_bot);
+            }
+            s.at(lw_coef(0, jreg), lev, tid) = c2.reflectance;
+            s.at(lw_coef(1, jreg), lev, tid) = c2.transmittance;
+            s.at(lw_coef(2, jreg), lev, tid) = c2.source_up;
+            s.at(lw_coef(3, jreg), lev, tid) = c2.source_dn;
+          }
+        }
+        fdn_c = c.transmittance * fdn_c + c.source_dn;
+        const double sd = group_sum<NGP>(valid ? fdn_c : 0.0);
+        if (lead) {
+          const size_t o = col + ncol * (lev + 1);
+          fx.lw_dn[o] = sd;      // provisional: replaced below cloud top by the all-sky value
+          if (do_clear) fx.lw_dn_clear[o] = sd;
+        }
+        planck_top = planck_bot;
+      }
+    }
+    if (!cloudy.any()) { ict = nlev; fdn_ctop = fdn_c; }
+
+    // ---- clear-sky upward sweep (calc_fluxes_no_scattering_lw) ---------------------------------------
+    {
+      double fup = emission + albedo * fdn_c;
+      double su = group_sum<NGP>(valid ? fup : 0.0);
+      if (lead && do_clear) fx.lw_up_clear[col + ncol * nlev] = su;
+      for (int l = nlev - 1; l >= 0; --l) {
+        fup = s.at(LT_T1, l, tid) * fup + s.at(LT_SU1, l, tid);
+        if (do_clear) {
+          su = group_sum<NGP>(valid ? fup : 0.0);
+          if (lead) fx.lw_up_clear[col + ncol * l] = su;
+        }
+      }
+      if (valid && do_clear) {
+        const size_t og = g + (size_t)ng * col;
+        fx.lw_dn_surf_clear_g[og] = fdn_c;
+        fx.lw_up_toa_clear_g[og] = fup;
+      }
+    }
+
+    // ---- upward sweep from the surface to cloud top (radiation_tripleclouds_lw.F90:392-445) -------
+    double ta[3], ts[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      ts[r] = geo.frac(r, nlev - 1) * emission;
+      ta[r] = albedo;
+      s.at(LT_TA + r, nlev, tid) = ta[r];
+      s.at(LT_TS + r, nlev, tid) = ts[r];
+    }
+    for (int l = nlev - 1; l >= ict; --l) {
+      double below[3] = {0.0, 0.0, 0.0}, sbelow[3] = {0.0, 0.0, 0.0};
+      const bool cl_here = cloudy.test(l);
+      const double T1 = s.at(LT_T1, l, tid);
+      {
+        const double f = cl_here ? geo.frac(0, l) : 1.0;
+        const double su1 = f * s.at(LT_SU1, l, tid), sd1 = f * s.at(LT_SD1, l, tid);
+        // region 1 has zero reflectance (no longwave aerosol scattering): inv_denom = 1
+        below[0] = T1 * T1 * ta[0];
+        sbelow[0] = su1 + T1 * (ts[0] + ta[0] * sd1);
+      }
+      if (cl_here) {
+#pragma unroll
+        for (int r = 1; r < 3; ++r) {
+          const double f = geo.frac(r, l);
+          const double R = s.at(lw_coef(0, r), l, tid), T = s.at(lw_coef(1, r), l, tid);
+          const double su = f * s.at(lw_coef(2, r), l, tid), sd = f * s.at(lw_coef(3, r), l, tid);
+          const double inv = 1.0 / (1.0 - ta[r] * R);
+          below[r] = R + T * T * ta[r] * inv;
+          sbelow[r] = su + T * (ts[r] + ta[r] * sd) * inv;
+        }
+      }
+      const bool cl_above = l > 0 && cloudy.test(l - 1);
+      if (!cl_here && !cl_above) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { ta[r] = below[r]; ts[r] = sbelow[r]; }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          double a = 0.0, b = 0.0;
+#pragma unroll
+          for (int r2 = 0; r2 < 3; ++r2) {
+            a = a + below[r2] * geo.v(r2, r, l);       // total_albedo: v_matrix(jreg2,jreg,jlev)
+            b = b + geo.u(r, r2, l) * sbelow[r2];      // total_source: singlemat_x_vec(u_matrix(:,:,jlev), .)
+          }
+          ta[r] = a; ts[r] = b;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { s.at(LT_TA + r, l, tid) = ta[r]; s.at(LT_TS + r, l, tid) = ts[r]; }
+    }
+    // ---- flux at cloud top and upward through the clear layers above --------------------------------
+    double fup[3] = {ts[0] + ta[0] * fdn_ctop, 0.0, 0.0};
+    {
+      double su = group_sum<NGP>(valid ? fup[0] : 0.0);
+      if (lead) fx.lw_up[col + ncol * ict] = su;
+      for (int l = ict - 1; l >= 0; --l) {
+        fup[0] = s.at(LT_T1, l, tid) * fup[0] + s.at(LT_SU1, l, tid);
+        su = group_sum<NGP>(valid ? fup[0] : 0.0);
+        if (lead) fx.lw_up[col + ncol * l] = su;
+      }
+      if (valid) fx.lw_up_toa_g[g + (size_t)ng * col] = fup[0];
+    }
+    // ---- downward sweep below cloud top --------------------------------------------------------------
+    double fdn[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) fdn[r] = geo.v(r, 0, ict) * fdn_ctop;
+    for (int l = ict; l < nlev; ++l) {
+      const bool cl_here = cloudy.test(l);
+      {
+        const double f = cl_here ? geo.frac(0, l) : 1.0;
+        const double tsn = s.at(LT_TS + 0, l + 1, tid), tan_ = s.at(LT_TA + 0, l + 1, tid);
+        fdn[0] = s.at(LT_T1, l, tid) * fdn[0] + f * s.at(LT_SD1, l, tid);
+        fup[0] = tsn + fdn[0] * tan_;
+      }
+      if (!cl_here) {
+        fdn[1] = fdn[2] = 0.0; fup[1] = fup[2] = 0.0;
+      } else {
+#pragma unroll
+        for (int r = 1; r < 3; ++r) {
+          const double R = s.at(lw_coef(0, r), l, tid);
+          const double tsn = s.at(LT_TS + r, l + 1, tid), tan_ = s.at(LT_TA + r, l + 1, tid);
+          fdn[r] = (s.at(lw_coef(1, r), l, tid) * fdn[r] + R * tsn + geo.frac(r, l) * s.at(lw_coef(3, r), l, tid))
+                   / (1.0 - R * tan_);
+          fup[r] = tsn + fdn[r] * tan_;
+        }
+      }
+      const bool cl_below = (l + 1) < nlev && cloudy.test(l + 1);
+      if (cl_here || cl_below) {
+        double nf[3];
+#pragma unroll
+        for (int j1 = 0; j1 < 3; ++j1)
+          nf[j1] = geo.v(j1, 0, l + 1) * fdn[0] + geo.v(j1, 1, l + 1) * fdn[1] + geo.v(j1, 2, l + 1) * fdn[2];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) fdn[r] = nf[r];
+      }
+      const double su = group_sum<NGP>(valid ? fup[0] + fup[1] + fup[2] : 0.0);
+      const double sd = group_sum<NGP>(valid ? fdn[0] + fdn[1] + fdn[2] : 0.0);
+      if (lead) {
+        const size_t o = col + ncol * (l + 1);
+        fx.lw_up[o] = su;
+        fx.lw_dn[o] = sd;
+      }
+    }
+    if (valid) fx.lw_dn_surf_g[g + (size_t)ng * col] = fdn[0] + fdn[1] + fdn[2];
+    if (do_deriv) {   // calc_lw_derivatives_region, radiation_lw_derivatives.F90:200-255
+      const double fs = fup[0] + fup[1] + fup[2];
+      const double tot = group_sum<NGP>(valid ? fs : 0.0);
+      double d[3] = {fs / tot, 0.0, 0.0};
+      if (lead) fx.lw_derivatives[col + ncol * nlev] = 1.0;
+      for (int l = nlev - 1; l >= 0; --l) {
+        double n[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) n[r] = geo.u(r, 0, l + 1) * d[0] + geo.u(r, 1, l + 1) * d[1] + geo.u(r, 2, l + 1) * d[2];
+        const bool cl_here = l >= ict && cloudy.test(l);
+        d[0] = n[0] * s.at(LT_T1, l, tid);
+        d[1] = n[1] * (cl_here ? s.at(lw_coef(1, 1), l, tid) : 1.0);
+        d[2] = n[2] * (cl_here ? s.at(lw_coef(1, 2), l, tid) : 1.0);
+        const double sder = group_sum<NGP>(valid ? d[0] + d[1] + d[2] : 0.0);
+        if (lead) fx.lw_derivatives[col + ncol * l] = sder;
+      }
+    }
+  }
+}
+
+int lw_tc_num_scratch_arrays() { return LW_TC_NUM; }
+
+hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig* cfg,
+                        const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block) {
+#define ECRAD_L(T, N) hipLaunchKernelGGL((lw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block)
+  if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
+  else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }
+#undef ECRAD_L
+  return hipGetLastError();
+}
+
+}  // namespace ecrad

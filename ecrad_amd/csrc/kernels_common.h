@@ -1,0 +1,210 @@
+// kernels_common.h -- device-side building blocks shared by the spectral kernels (lane = g-point).
+//
+// Thread mapping used by every spectral kernel (DESIGN.md "Kernel mapping"):
+//   block = 256 threads = 4 wave64;  NGP = g-points per column padded to a power of two (16/32/64);
+//   a group of NGP consecutive lanes owns one column, CPB = 256/NGP columns per block;
+//   the vertical (nlev) loop runs sequentially inside each lane, sums over g are group reductions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_types.h"
+
+namespace ecrad {
+
+constexpr int kBlock = 256;
+
+#define ECRAD_DEV __device__ __forceinline__
+
+ECRAD_DEV double dmax(double a, double b) { return a > b ? a : b; }
+ECRAD_DEV double dmin(double a, double b) { return a < b ? a : b; }
+
+// Sum over the NGP lanes of a column group (NGP power of two <= 64). All lanes get the result.
+template <int NGP>
+ECRAD_DEV double group_sum(double v) {
+#pragma unroll
+  for (int m = NGP / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, NGP);
+  return v;
+}
+
+// ---- two-stream layer coefficients ---------------------------------------------------------------
+constexpr double kLwDiffusivity = 1.66;   // radiation_two_stream.F90:38-39
+
+struct SwCoef { double ref_diff, trans_diff, ref_dir, trans_dir_diff, trans_dir_dir; };
+
+// calc_ref_trans_sw (radiation_two_stream.F90:563-771, double precision, non-DWD): McICA/Tripleclouds
+ECRAD_DEV SwCoef ref_trans_sw_fused(double mu0, double od, double ssa, double asymmetry) {
+  SwCoef c;
+  double t = dmax(-dmax(od * (1.0 / mu0), 0.0), -1000.0);
+  c.trans_dir_dir = exp(t);
+  double factor = 0.75 * asymmetry;
+  double gamma1 = 2.0 - ssa * (1.25 + factor);
+  double gamma2 = ssa * (0.75 - factor);
+  double gamma3 = 0.5 - mu0 * factor;
+  double gamma4 = 1.0 - gamma3;
+  double alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
+  double alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
+  double k_exponent = sqrt(dmax((gamma1 - gamma2) * (gamma1 + gamma2), 1.0e-12));
+  double exponential = exp(-k_exponent * od);
+  double k_mu0 = k_exponent * mu0;
+  double one_minus_kmu0_sqr = 1.0 - k_mu0 * k_mu0;
+  double k_gamma3 = k_exponent * gamma3;
+  double k_gamma4 = k_exponent * gamma4;
+  double exponential2 = exponential * exponential;
+  double k_2_exponential = 2.0 * k_exponent * exponential;
+  double reftrans_factor = 1.0 / (k_exponent + gamma1 + (k_exponent - gamma1) * exponential2);
+  c.ref_diff = gamma2 * (1.0 - exponential2) * reftrans_factor;
+  c.trans_diff = dmax(0.0, dmin(k_2_exponential * reftrans_factor, 1.0 - c.ref_diff));
+  const double eps = 2.220446049250313e-16;
+  reftrans_factor = mu0 * ssa * reftrans_factor / (fabs(one_minus_kmu0_sqr) > eps ? one_minus_kmu0_sqr : eps);
+  double rd = reftrans_factor * ((1.0 - k_mu0) * (alpha2 + k_gamma3)
+                                 - (1.0 + k_mu0) * (alpha2 - k_gamma3) * exponential2
+                                 - k_2_exponential * (gamma3 - alpha2 * mu0) * c.trans_dir_dir);
+  double td = reftrans_factor * (k_2_exponential * (gamma4 + alpha1 * mu0)
+                                 - c.trans_dir_dir * ((1.0 + k_mu0) * (alpha1 + k_gamma4)
+                                                      - (1.0 - k_mu0) * (alpha1 - k_gamma4) * exponential2));
+  double lim = mu0 * (1.0 - c.trans_dir_dir);
+  c.ref_dir = dmax(0.0, dmin(rd, lim));
+  c.trans_dir_diff = dmax(0.0, dmin(td, lim - c.ref_dir));
+  return c;
+}
+
+// calc_two_stream_gammas_sw + calc_reflectance_transmittance_sw
+// (radiation_two_stream.F90:96-140, :421-550): cloudless/homogeneous solvers
+ECRAD_DEV SwCoef ref_trans_sw_classic(double mu0, double od, double ssa, double g) {
+  SwCoef c;
+  double factor = 0.75 * g;
+  double gamma1 = 2.0 - ssa * (1.25 + factor);
+  double gamma2 = ssa * (0.75 - factor);
+  double gamma3 = 0.5 - mu0 * factor;
+  double gamma4 = 1.0 - gamma3;
+  double alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
+  double alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
+  double k_exponent = sqrt(dmax((gamma1 - gamma2) * (gamma1 + gamma2), 1.0e-12));
+  const double eps = 2.220446049250313e-16;
+  double mu0_local = mu0;
+  if (fabs(1.0 - k_exponent * mu0) < 1000.0 * eps) mu0_local = mu0 * (1.0 - 10.0 * eps);
+  double od_over_mu0 = dmax(od / mu0_local, 0.0);
+  double k_mu0 = k_exponent * mu0_local;
+  double k_gamma3 = k_exponent * gamma3;
+  double k_gamma4 = k_exponent * gamma4;
+  double exponential0 = exp(-od_over_mu0);
+  c.trans_dir_dir = exponential0;
+  double exponential = exp(-k_exponent * od);
+  double exponential2 = exponential * exponential;
+  double k_2_exponential = 2.0 * k_exponent * exponential;
+  double reftrans_factor = 1.0 / (k_exponent + gamma1 + (k_exponent - gamma1) * exponential2);
+  c.ref_diff = gamma2 * (1.0 - exponential2) * reftrans_factor;
+  c.trans_diff = k_2_exponential * reftrans_factor;
+  reftrans_factor = mu0_local * ssa * reftrans_factor / (1.0 - k_mu0 * k_mu0);
+  double rd = reftrans_factor * ((1.0 - k_mu0) * (alpha2 + k_gamma3)
+                                 - (1.0 + k_mu0) * (alpha2 - k_gamma3) * exponential2
+                                 - k_2_exponential * (gamma3 - alpha2 * mu0_local) * exponential0);
+  double td = reftrans_factor * (k_2_exponential * (gamma4 + alpha1 * mu0_local)
+                                 - exponential0 * ((1.0 + k_mu0) * (alpha1 + k_gamma4)
+                                                   - (1.0 - k_mu0) * (alpha1 - k_gamma4) * exponential2));
+  c.ref_dir = dmax(0.0, dmin(rd, 1.0));
+  c.trans_dir_diff = dmax(0.0, dmin(td, 1.0 - c.ref_dir));
+  return c;
+}
+
+struct LwCoef { double reflectance, transmittance, source_up, source_dn; };
+
+// calc_ref_trans_lw (radiation_two_stream.F90:246-333); in double precision this is also
+// calc_two_stream_gammas_lw + calc_reflectance_transmittance_lw (:51-91, :148-237)
+ECRAD_DEV LwCoef ref_trans_lw(double od, double ssa, double asymmetry, double planck_top, double planck_bot) {
+  LwCoef c;
+  double factor = (kLwDiffusivity * 0.5) * ssa;
+  double gamma1 = kLwDiffusivity - factor * (1.0 + asymmetry);
+  double gamma2 = factor * (1.0 - asymmetry);
+  double k_exponent = sqrt(dmax((gamma1 - gamma2) * (gamma1 + gamma2), 1.0e-12));
+  if (od > 1.0e-3) {
+    double exponential = exp(-k_exponent * od);
+    double exponential2 = exponential * exponential;
+    double reftrans_factor = 1.0 / (k_exponent + gamma1 + (k_exponent - gamma1) * exponential2);
+    c.reflectance = gamma2 * (1.0 - exponential2) * reftrans_factor;
+    c.transmittance = 2.0 * k_exponent * exponential * reftrans_factor;
+    double coeff = (planck_bot - planck_top) / (od * (gamma1 + gamma2));
+    double coeff_up_top = coeff + planck_top;
+    double coeff_up_bot = coeff + planck_bot;
+    double coeff_dn_top = -coeff + planck_top;
+    double coeff_dn_bot = -coeff + planck_bot;
+    c.source_up = coeff_up_top - c.reflectance * coeff_dn_top - c.transmittance * coeff_up_bot;
+    c.source_dn = coeff_dn_bot - c.reflectance * coeff_up_bot - c.transmittance * coeff_dn_top;
+  } else {
+    c.reflectance = gamma2 * od;
+    c.transmittance = (1.0 - k_exponent * od) / (1.0 + od * (gamma1 - k_exponent));
+    c.source_up = (1.0 - c.reflectance - c.transmittance) * 0.5 * (planck_top + planck_bot);
+    c.source_dn = c.source_up;
+  }
+  return c;
+}
+
+// calc_no_scattering_transmittance_lw (radiation_two_stream.F90:342-411, non-DWD branch)
+ECRAD_DEV LwCoef no_scattering_lw(double od, double planck_top, double planck_bot) {
+  LwCoef c;
+  c.reflectance = 0.0;
+  c.transmittance = exp(-kLwDiffusivity * od);
+  double coeff = kLwDiffusivity * od;
+  if (od > 1.0e-3) {
+    coeff = (planck_bot - planck_top) / coeff;
+    double coeff_up_top = coeff + planck_top;
+    double coeff_up_bot = coeff + planck_bot;
+    double coeff_dn_top = -coeff + planck_top;
+    double coeff_dn_bot = -coeff + planck_bot;
+    c.source_up = coeff_up_top - c.transmittance * coeff_up_bot;
+    c.source_dn = coeff_dn_bot - c.transmittance * coeff_dn_top;
+  } else {
+    c.source_up = coeff * 0.5 * (planck_top + planck_bot);
+    c.source_dn = c.source_up;
+  }
+  return c;
+}
+
+// delta_eddington (radiation_delta_eddington.h:21-35)
+ECRAD_DEV void delta_eddington(double& od, double& ssa, double& g) {
+  double f = g * g;
+  od = od * (1.0 - ssa * f);
+  ssa = ssa * (1.0 - f) / (1.0 - ssa * f);
+  g = g / (1.0 + g);
+}
+
+// delta_eddington_extensive (radiation_delta_eddington.h:44-58)
+ECRAD_DEV void delta_eddington_extensive(double& od, double& scat_od, double& scat_od_g) {
+  double g = scat_od > 0.0 ? scat_od_g / scat_od : 0.0;
+  double f = g * g;
+  od = od - scat_od * f;
+  scat_od = scat_od * (1.0 - f);
+  scat_od_g = scat_od * g / (1.0 + g);
+}
+
+// ---- per-block scratch in HBM ----------------------------------------------------------------------
+// Each block owns a private slab reused for every column group it processes (persistent blocks), so
+// the working set stays bounded (and largely L2/Infinity-Cache resident) however many columns a
+// call has.  Array `a`, half-level `lev`: element for thread `tid` at ((a*(nlev+1)+lev)*256 + tid),
+// i.e. every wave reads/writes 512 contiguous bytes.
+struct Scratch {
+  double* base;
+  int nlevp1;
+  ECRAD_DEV double& at(int a, int lev, int tid) const {
+    return base[((size_t)a * nlevp1 + lev) * kBlock + tid];
+  }
+};
+
+// Per-lane level mask held in registers (up to 256 levels); no dynamic register indexing.
+struct LevMask {
+  unsigned long long w0, w1, w2, w3;
+  ECRAD_DEV void clear() { w0 = w1 = w2 = w3 = 0ull; }
+  ECRAD_DEV void set(int l) {
+    unsigned long long b = 1ull << (l & 63);
+    int k = l >> 6;
+    w0 |= (k == 0) ? b : 0ull; w1 |= (k == 1) ? b : 0ull; w2 |= (k == 2) ? b : 0ull; w3 |= (k == 3) ? b : 0ull;
+  }
+  ECRAD_DEV bool test(int l) const {
+    int k = l >> 6;
+    unsigned long long w = (k == 0) ? w0 : (k == 1) ? w1 : (k == 2) ? w2 : w3;
+    return (w >> (l & 63)) & 1ull;
+  }
+  ECRAD_DEV bool any() const { return (w0 | w1 | w2 | w3) != 0ull; }
+};
+constexpr int kMaxLev = 256;
+
+}  // namespace ecrad

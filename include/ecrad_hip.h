@@ -14,7 +14,8 @@
  *   ecrad_hip_radiation   <-> radiation(ncol,nlev,istartcol,iendcol,config,single_level,
  *                                       thermodynamics,gas,cloud,aerosol,flux)
  *                                                              radiation_interface.F90:200
- *   ecrad_hip_gas_optics  <-> gas_optics (ecCKD)               radiation_ecckd_interface.F90:174
+ *   ecrad_hip_optics      <-> the pre-solver stages of radiation(): get_albedos, gas_optics,
+ *                             cloud optics, add_aerosol_optics  (radiation_interface.F90:323-401)
  *                             (stage-level entry used by parity tests; not needed by a host model)
  *   ecrad_hip_destroy     <-> (new)
  *
@@ -286,6 +287,14 @@ int ecrad_hip_synchronize(ecrad_hip_handle_t handle);
 /* Timing of the most recent ecrad_hip_radiation call, measured with HIP events on the handle's
    stream: milliseconds spent in the kernels (excludes H2D/D2H staging). */
 int ecrad_hip_last_kernel_ms(ecrad_hip_handle_t handle, double* ms);
+
+/* Same, per stage of the most recent call: which = ECRAD_STAGE_* (HIP events recorded on the
+   handle's stream around that stage's kernels; 0 ms if the stage did not run). */
+#define ECRAD_STAGE_PREP 0   /* crop_cloud_fraction, cloud generator / region+overlap geometry */
+#define ECRAD_STAGE_LW   1   /* fused longwave kernel  (gas optics ... solver) */
+#define ECRAD_STAGE_SW   2   /* fused shortwave kernel (gas optics ... solver) */
+#define ECRAD_STAGE_POST 3   /* surface/TOA spectral sums */
+int ecrad_hip_last_stage_ms(ecrad_hip_handle_t handle, int which, double* ms);
 
 /* Bytes of device scratch currently held by the handle. */
 int ecrad_hip_scratch_bytes(ecrad_hip_handle_t handle, size_t* bytes);

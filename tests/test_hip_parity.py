@@ -1,0 +1,120 @@
+"""Parity tests proper (GPU): the HIP path, called through the C-ABI, against the oracle on the
+reference's own test case (test/ifs/ecrad_meridian.nc: 32 columns x 137 levels pole-to-pole incl.
+night-time columns, clouds and 12 aerosol types) and against the reference's golden output.
+
+Tolerance: the north-star bar is 1e-6 relative (double precision); these tests demand 1e-9 so that a
+regression in operation order is caught long before it matters.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from ecrad_amd.driver import flux_to_output_dict
+from ecrad_amd.ncfile import NcFile
+from helpers import GOLDEN_DIR, compare_flux, load_meridian, make_config, rel_err, run_case
+
+pytestmark = pytest.mark.gpu
+TOL = 1.0e-9
+
+CASES = {
+    "cloudless_noaer": dict(sw_solver="Cloudless", use_aerosols=False),
+    "cloudless_aer": dict(sw_solver="Cloudless"),
+    "homogeneous_noaer": dict(sw_solver="Homogeneous", use_aerosols=False),
+    "homogeneous_aer": dict(sw_solver="Homogeneous"),
+    "mcica_aer": dict(sw_solver="McICA"),
+    "mcica_noaer": dict(sw_solver="McICA", use_aerosols=False),
+    "mcica_maxran": dict(sw_solver="McICA", i_overlap_scheme=0),
+    "tripleclouds_aer": dict(sw_solver="Tripleclouds"),
+    "tripleclouds_noaer": dict(sw_solver="Tripleclouds", use_aerosols=False),
+    "tripleclouds_lognormal": dict(sw_solver="Tripleclouds", i_cloud_pdf_shape=0),
+    "tripleclouds_beta": dict(sw_solver="Tripleclouds", use_beta_overlap=True),
+    "tripleclouds_no_lw_scat": dict(sw_solver="Tripleclouds", do_lw_cloud_scattering=False),
+    "mcica_no_clear_derivs_off": dict(sw_solver="McICA", do_lw_derivatives=False, do_canopy_fluxes_sw=False,
+                                      do_canopy_fluxes_lw=False),
+    "homogeneous_noclear": dict(sw_solver="Homogeneous", do_clear=False),
+    "tripleclouds_noclear": dict(sw_solver="Tripleclouds", do_clear=False, do_sw_direct=False),
+    "sw64": dict(sw_solver="Tripleclouds", gas_optics_sw_override_file_name="ecckd-1.2_sw_climate_window-64b_ckd-definition.nc"),
+    "mixed_solvers": dict(sw_solver="Tripleclouds", lw_solver="McICA"),
+    "per_band_cloud_aerosol": dict(sw_solver="Tripleclouds", do_cloud_aerosol_per_sw_g_point=False,
+                                   do_cloud_aerosol_per_lw_g_point=False),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_hip_matches_oracle_on_meridian(case, oracle_lib):
+    kw = dict(CASES[case])
+    sw = kw.pop("sw_solver")
+    lw = kw.pop("lw_solver", None)
+    f_hip, _, rad = run_case(make_config(sw, lw, **kw), "hip")
+    f_ora, _, _ = run_case(make_config(sw, lw, **kw), oracle_lib.backend)
+    worst = compare_flux(f_hip, f_ora, TOL)
+    rad.close()
+    print(case, "max rel diff", max(worst.values()))
+
+
+def test_hip_matches_reference_golden():
+    """HIP path vs the reference's own output file (float32): same bar as the oracle pin."""
+    config = make_config("McICA")
+    flux, th, rad = run_case(config, "hip")
+    out = flux_to_output_dict(config, th, flux)
+    with NcFile(os.path.join(GOLDEN_DIR, "ecrad_meridian_ecckd_mcica_out_REFERENCE.nc")) as g:
+        for name in g._f.variables:
+            assert rel_err(out[name], g.get(name)) < 2.0e-7, name
+    rad.close()
+
+
+def test_column_subrange_does_not_touch_other_columns(oracle_lib):
+    """radiation(ncol,nlev,istartcol,iendcol,...): columns outside the range keep their values, and the
+    crop_cloud_fraction side effect is confined to the range (radiation_interface.F90:200-251)."""
+    config = make_config("Tripleclouds")
+    inputs = load_meridian(config)
+    frac_before = inputs[5].fraction.copy()
+    f_hip, _, rad = run_case(config, "hip", columns=(5, 20), inputs=inputs)
+    assert np.array_equal(inputs[5].fraction[:, :4], frac_before[:, :4])
+    assert np.array_equal(inputs[5].fraction[:, 20:], frac_before[:, 20:])
+    for name, a in f_hip.arrays.items():
+        if name.startswith("cloud_cover"):
+            assert np.all(a[:4] == -1.0) and np.all(a[20:] == -1.0)
+        elif a.shape[-1] == 32:
+            assert np.all(a[..., :4] == 0.0) and np.all(a[..., 20:] == 0.0), name
+        else:
+            assert np.all(a[:4] == 0.0) and np.all(a[20:] == 0.0), name
+    f_ora, _, _ = run_case(make_config("Tripleclouds"), oracle_lib.backend, columns=(5, 20))
+    compare_flux(f_hip, f_ora, TOL, cols=(5, 20))
+    rad.close()
+
+
+def test_crop_cloud_fraction_side_effect_matches(oracle_lib):
+    c1, c2 = make_config("Tripleclouds"), make_config("Tripleclouds")
+    in1, in2 = load_meridian(c1), load_meridian(c2)
+    _, _, rad = run_case(c1, "hip", inputs=in1)
+    run_case(c2, oracle_lib.backend, inputs=in2)
+    assert np.array_equal(in1[5].fraction, in2[5].fraction)
+    rad.close()
+
+
+def test_stage_intermediates_match_oracle(oracle_lib):
+    """od/ssa/g, Planck, albedos, cloud optics: the arrays radiation() passes between stages."""
+    import ctypes as C
+    from ecrad_amd import abi
+    from ecrad_amd.interface import Radiation, build_inputs_struct
+    config = make_config("Tripleclouds")
+    rad = Radiation(config, backend="hip")
+    ncol, nlev, sl, th, gas, cloud, aer = load_meridian(config)
+    rad.set_gas_units(gas)
+    th.calc_saturation_wrt_liquid()
+    cin, keep = build_inputs_struct(config, ncol, nlev, sl, th, gas, cloud, aer)
+    want = oracle_lib.optics(config, rad.cconfig, ncol, nlev, 1, ncol, cin)
+    # fresh inputs for the HIP run (crop already applied in place by the oracle is idempotent)
+    out = abi.Optics()
+    got = {k: np.zeros(v) for k, v in oracle_lib.optics_shapes(config, nlev, ncol).items()}
+    for k, a in got.items():
+        setattr(out, k, abi.dptr(a))
+    st = rad.lib.ecrad_hip_optics(rad.handle, ncol, nlev, 1, ncol, C.byref(cin), C.byref(out))
+    assert st == 0, rad.lib.ecrad_hip_last_error(rad.handle)
+    for k in got:
+        if k in ("ssa_lw", "g_lw"):
+            continue
+        assert rel_err(got[k], want[k], floor_frac=1e-9) < 1e-10, k
+    rad.close()
