@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py -- columns/sec (SW+LW) of the radiation() hot path on MI355X.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched by the driver through
+``python -m torch.distributed.run``).  One "step" = one pass of radiation() over one batch of
+synthetic IFS-shaped columns that is already resident in HBM.  At N=1 the workload is BASELINE.json
+configs[1]: 100 000 clear-sky columns, 137 levels, ecCKD-32 SW+LW, homogeneous solver, double
+precision.  Columns shard across ranks with no data-path collective other than the gather of flux
+profiles to rank 0 (weak scaling: the per-GPU batch is fixed).
+
+Prints ONE JSON line on rank 0 with the contract's keys plus:
+  "roofline":     dominant kernel's algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak
+  "cpu_baseline": the oracle (plain-C restatement, OpenMP over column blocks like the reference's
+                  driver) timed on this box's host cores on a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_column(config, nlev, which):
+    """SURVEY.md section 8(d) figure "A", split per fused kernel: stage-interface arrays (each written
+    once by its producer stage and read once by its consumer) + the compulsory inputs/outputs of the
+    columns.  `which` is 'sw' or 'lw'.  W = 8 bytes."""
+    W = 8
+    c = 1 if config.do_clouds and config.i_solver_sw != 0 else 0
+    if which == "sw":
+        a = 1 if config.use_aerosols else 0
+        stage = 2 * W * nlev * (config.n_g_sw * (2 + a) + c * 3 * config.n_bands_sw)
+        n_gas = len(config.gas_optics_sw.single_gas) - 1
+        inputs = 2 * (nlev + 1) + n_gas * nlev + 1 + 2 * 6
+        outputs = (6 if config.do_clear else 3) * (nlev + 1) + 7 * config.n_g_sw
+    else:
+        s = 1 if config.do_lw_cloud_scattering else 0
+        stage = 2 * W * nlev * (config.n_g_lw * (1 + (nlev + 1) / nlev) + c * config.n_bands_lw * (1 + 2 * s))
+        n_gas = len(config.gas_optics_lw.single_gas) - 1
+        inputs = 2 * (nlev + 1) + n_gas * nlev + 1 + 2
+        outputs = (4 if config.do_clear else 2) * (nlev + 1) + (nlev + 1) + 4 * config.n_g_lw
+    if c:
+        inputs += 5 * nlev + (nlev - 1)
+    if config.use_aerosols:
+        inputs += 12 * nlev + nlev
+    return stage + W * (inputs + outputs)
+
+
+def cpu_baseline(config, workload, nlev_expected, seconds_target=12.0):
+    """Time the oracle on a bounded sample (2048 columns, repeated) of the same workload."""
+    from ecrad_amd.interface import Radiation
+    from ecrad_amd.synthetic import BENCH_CONFIGS, make_columns
+    from ecrad_amd.types import Flux
+    from oracle import pyoracle
+    pyoracle.build()
+    nthreads = pyoracle.lib().ecrad_oracle_max_threads()
+    nsample = 2048
+    spec = BENCH_CONFIGS[workload]
+    rad = Radiation(config, backend=pyoracle.make_blocked_backend(nblocksize=32, nthreads=nthreads))
+    ncol, nlev, sl, th, gas, cloud, aer = make_columns(config, nsample, spec["clear_sky"])
+    flux = Flux.allocate(config, ncol, nlev)
+    rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)       # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds_target or reps >= 200:
+            break
+    return {"value": nsample * reps / dt, "unit": "columns/s", "cores": int(nthreads), "kind": "port",
+            "sample": f"{nsample} columns x {reps} repeats of the same synthetic workload, oracle/ (plain C, "
+                      f"OpenMP over blocks of 32 columns as in driver/ecrad_driver.F90:348), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ncol", type=int, default=100000, help="columns per GPU per step")
+    ap.add_argument("--workload", default="clear_homogeneous_ecckd32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="skip the flux-profile gather at N>1")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes", file=sys.stderr)
+            sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from helpers import make_config
+    from ecrad_amd.device import DeviceCase
+    from ecrad_amd.interface import Radiation
+    from ecrad_amd.parallel import gather_profiles, pack_profiles
+    from ecrad_amd.synthetic import BENCH_CONFIGS, make_columns
+    from ecrad_amd.types import Flux
+
+    spec = dict(BENCH_CONFIGS[args.workload])
+    clear_sky = spec.pop("clear_sky")
+    sw_solver = spec.pop("sw_solver")
+    config = make_config(sw_solver, **spec)
+    rad = Radiation(config, backend="hip", device_id=local_rank)
+    stream = torch.cuda.current_stream()
+    rad.lib.ecrad_hip_set_stream(rad.handle, C.c_void_p(stream.cuda_stream))
+
+    # weak scaling: every rank owns args.ncol columns of the global batch world*args.ncol
+    ncol, nlev, sl, th, gas, cloud, aer = make_columns(config, args.ncol, clear_sky, first_column=rank * args.ncol)
+    flux = Flux.allocate(config, ncol, nlev)
+    case = DeviceCase(config, ncol, nlev, sl, th, gas, cloud, aer, flux, device=f"cuda:{local_rank}")
+    profile_names = [n for n in ("lw_up", "lw_dn", "sw_up", "sw_dn", "sw_dn_direct", "lw_up_clear", "lw_dn_clear",
+                                 "sw_up_clear", "sw_dn_clear", "sw_dn_direct_clear", "lw_derivatives")
+                     if n in case.flux_tensors]
+    do_gather = world > 1 and not args.no_gather
+    fraction0 = case.tensors["cloud_fraction"].clone() if "cloud_fraction" in case.tensors else None
+
+    def step():
+        if fraction0 is not None:      # radiation() crops cloud%fraction in place: restore the input
+            case.tensors["cloud_fraction"].copy_(fraction0)
+        st = rad.lib.ecrad_hip_radiation(rad.handle, ncol, nlev, 1, ncol, C.byref(case.inputs), C.byref(case.flux))
+        if st != 0:
+            raise RuntimeError(rad.lib.ecrad_hip_last_error(rad.handle).decode())
+        if do_gather:
+            packed = pack_profiles(case.flux_tensors, profile_names)
+            gather_profiles(packed, [ncol] * world, dst=0)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    stage_ms = {"lw": [], "sw": [], "prep": [], "post": []}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # per-stage HIP-event durations are read after the loop for the LAST step only (reading them
+        # earlier would synchronise the stream inside the timed region)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ms = C.c_double()
+    for k, name in ((0, "prep"), (1, "lw"), (2, "sw"), (3, "post")):
+        rad.lib.ecrad_hip_last_stage_ms(rad.handle, k, C.byref(ms))
+        stage_ms[name].append(ms.value)
+    # a few extra untimed steps to average the per-kernel duration
+    for _ in range(3):
+        step()
+        torch.cuda.synchronize()
+        for k, name in ((1, "lw"), (2, "sw")):
+            rad.lib.ecrad_hip_last_stage_ms(rad.handle, k, C.byref(ms))
+            stage_ms[name].append(ms.value)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        total_cols = world * ncol * args.steps
+        value = total_cols / elapsed
+        dom = "sw" if np.mean(stage_ms["sw"]) >= np.mean(stage_ms["lw"]) else "lw"
+        dom_ms = float(np.mean(stage_ms[dom]))
+        a_bytes = algorithmic_bytes_per_column(config, nlev, dom)
+        achieved = a_bytes * ncol / (dom_ms * 1e-3) / 1e9
+        out = {
+            "metric": "columns/sec (SW+LW) at 137 lev, ecCKD-32", "value": value, "unit": "columns/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "columns_per_gpu_per_step": ncol, "nlev": nlev,
+                       "n_g_sw": config.n_g_sw, "n_g_lw": config.n_g_lw, "sw_solver": sw_solver,
+                       "aerosols": bool(config.use_aerosols), "clouds": not clear_sky,
+                       "parallelism": f"columns sharded over {world} GPU(s)" + (", flux profiles gathered on rank 0" if do_gather else "")},
+            "roofline": {"bound": "hbm", "kernel": f"{dom}_ica_kernel" if sw_solver != "Tripleclouds" else f"{dom}_tc_kernel",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes_per_column": a_bytes, "kernel_ms": dom_ms,
+                         "stage_ms": {k: float(np.mean(v)) for k, v in stage_ms.items() if v}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(config, args.workload, nlev)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""Synthetic "IFS-shaped" column generator for benchmarks.
+
+Column i is built from base profile ``b = i mod 32`` of the reference's meridian test slice
+(tests/golden/ecrad_meridian.nc) with seeded perturbations:
+
+* ``pressure_hl`` scaled by ``ps_i/ps_b``, ``ps_i ~ U(0.95,1.05) ps_b``;
+* ``temperature_hl += N(0, 2 K)`` (one draw per column), ``skin_temperature = T_hl(surface) + N(0,1)``;
+* ``q *= LogN(0, 0.2)``; all other gases, albedos, emissivities, aerosols from ``b``;
+* ``cos_sza ~ U(0.05, 1)`` so that no column short-circuits the shortwave;
+* clouds (when wanted): fraction of ``b`` times ``U(0.5,1.5)`` clipped to [0,1]; ``iseed = i+1``;
+  clear-sky configurations set the fraction to zero everywhere.
+
+Everything is float64 in the C-ABI layout (column index fastest).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from .config import Config
+from .driver import DriverConfig, read_input
+from .types import Aerosol, Cloud, Gas, SingleLevel, Thermodynamics
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MERIDIAN = os.path.join(ROOT, "tests", "golden", "ecrad_meridian.nc")
+SEED = 20260929
+
+
+def make_columns(config: Config, ncol: int, clear_sky: bool, seed: int = SEED, first_column: int = 0,
+                 base_file: str = MERIDIAN):
+    """Return (ncol, nlev, single_level, thermodynamics, gas, cloud, aerosol) with gas units already
+    set for the gas model and h2o_sat_liq computed (i.e. ready for Radiation.radiation)."""
+    dc = DriverConfig()
+    nb, nlev, sl0, th0, gas0, cloud0, aer0 = read_input(base_file, config, dc)
+    gas0.set_units(1)      # IVolumeMixingRatio, as set_gas_units does for ecCKD
+    rng = np.random.default_rng([seed, first_column])
+    idx = (first_column + np.arange(ncol)) % nb
+    ps_scale = rng.uniform(0.95, 1.05, ncol)
+    dT = rng.normal(0.0, 2.0, ncol)
+    qfac = np.exp(rng.normal(0.0, 0.2, ncol))
+    cos_sza = rng.uniform(0.05, 1.0, ncol)
+    dTskin = rng.normal(0.0, 1.0, ncol)
+    cf_fac = rng.uniform(0.5, 1.5, ncol)
+
+    pressure_hl = np.ascontiguousarray(th0.pressure_hl[:, idx] * ps_scale[None, :])
+    temperature_hl = np.ascontiguousarray(th0.temperature_hl[:, idx] + dT[None, :])
+    th = Thermodynamics(pressure_hl, temperature_hl)
+    th.calc_saturation_wrt_liquid()
+    sl = SingleLevel(
+        cos_sza=np.ascontiguousarray(cos_sza),
+        skin_temperature=np.ascontiguousarray(temperature_hl[nlev] + dTskin),
+        sw_albedo=np.ascontiguousarray(sl0.sw_albedo[:, idx]),
+        lw_emissivity=np.ascontiguousarray(sl0.lw_emissivity[:, idx]),
+        sw_albedo_direct=None if sl0.sw_albedo_direct is None else np.ascontiguousarray(sl0.sw_albedo_direct[:, idx]),
+        solar_irradiance=sl0.solar_irradiance,
+        iseed=(first_column + 1 + np.arange(ncol)).astype(np.int32))
+    gas = Gas(mixing_ratio=np.ascontiguousarray(gas0.mixing_ratio[:, :, idx]))
+    gas.iunits = list(gas0.iunits)
+    gas.scale_factor = list(gas0.scale_factor)
+    gas.is_present = list(gas0.is_present)
+    gas.mixing_ratio[0] *= qfac[None, :]          # H2O
+    cloud = None
+    if config.do_clouds:
+        frac = np.zeros((nlev, ncol)) if clear_sky else np.clip(cloud0.fraction[:, idx] * cf_fac[None, :], 0.0, 1.0)
+        cloud = Cloud(fraction=np.ascontiguousarray(frac),
+                      mixing_ratio=np.ascontiguousarray(cloud0.mixing_ratio[:, :, idx]),
+                      effective_radius=np.ascontiguousarray(cloud0.effective_radius[:, :, idx]),
+                      fractional_std=np.ascontiguousarray(cloud0.fractional_std[:, idx]),
+                      overlap_param=np.ascontiguousarray(cloud0.overlap_param[:, idx]))
+    aerosol = None
+    if config.use_aerosols and aer0 is not None:
+        aerosol = Aerosol(mixing_ratio=np.ascontiguousarray(aer0.mixing_ratio[:, :, idx]),
+                          istartlev=aer0.istartlev, iendlev=aer0.iendlev)
+    return ncol, nlev, sl, th, gas, cloud, aerosol
+
+
+# The BASELINE.json configurations that the implemented scope covers, as namelist-style edits to
+# test/ifs/configCY49R1_ecckd.nam.
+BENCH_CONFIGS = {
+    # configs[1]: 100k clear-sky columns, ecCKD-32 SW+LW, homogeneous solver, double precision
+    "clear_homogeneous_ecckd32": dict(sw_solver="Homogeneous", use_aerosols=False, clear_sky=True),
+    # north-star target configuration: ecCKD-32 Tripleclouds with clouds and aerosols
+    "tripleclouds_ecckd32": dict(sw_solver="Tripleclouds", use_aerosols=True, clear_sky=False),
+    "mcica_ecckd32": dict(sw_solver="McICA", use_aerosols=True, clear_sky=False),
+}
