@@ -31,12 +31,12 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes_per_column(config, nlev, which):
+def algorithmic_bytes_per_column(config, nlev, which, clear_sky):
     """SURVEY.md section 8(d) figure "A", split per fused kernel: stage-interface arrays (each written
     once by its producer stage and read once by its consumer) + the compulsory inputs/outputs of the
     columns.  `which` is 'sw' or 'lw'.  W = 8 bytes."""
     W = 8
-    c = 1 if config.do_clouds and config.i_solver_sw != 0 else 0
+    c = 0 if clear_sky else (1 if config.do_clouds and config.i_solver_sw != 0 else 0)   # SURVEY 8d: c=0 for config 2
     if which == "sw":
         a = 1 if config.use_aerosols else 0
         stage = 2 * W * nlev * (config.n_g_sw * (2 + a) + c * 3 * config.n_bands_sw)
@@ -184,7 +184,7 @@ def main():
         value = total_cols / elapsed
         dom = "sw" if np.mean(stage_ms["sw"]) >= np.mean(stage_ms["lw"]) else "lw"
         dom_ms = float(np.mean(stage_ms[dom]))
-        a_bytes = algorithmic_bytes_per_column(config, nlev, dom)
+        a_bytes = algorithmic_bytes_per_column(config, nlev, dom, clear_sky)
         achieved = a_bytes * ncol / (dom_ms * 1e-3) / 1e9
         out = {
             "metric": "columns/sec (SW+LW) at 137 lev, ecCKD-32", "value": value, "unit": "columns/s",
