@@ -40,7 +40,7 @@ def main(tag):
     out += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline`", "",
             "| kernel | calls | total (ms) | average (ms) | % |", "|---|---|---|---|---|"]
     for n, c, t, a, p in stats:
-        out.append(f"| `{short(n)}` | {c} | {t/1e6:.2f} | {a/1e6:.3f} | {p:.2f} |")
+        out.append(f"| `{short(n)}` | {c} | {t/1e3:.2f} | {a/1e3:.3f} | {p:.2f} |")
     out.append("")
     # calibration
     cal_f = dict((short(k), (v, n)) for k, v, n in q(os.path.join(src, "cal_fetch", "cal_results.db"),
@@ -68,7 +68,7 @@ def main(tag):
             continue
         r = fetch[k][0] / fetch[k][1] * f_corr * 1024 / 1e9
         w = write[k][0] / write[k][1] * w_corr * 1024 / 1e9
-        ms = avg.get(k, 0) / 1e6
+        ms = avg.get(k, 0) / 1e3      # top_kernels durations are in microseconds
         traffic[short(k)] = (r + w) * 1e9
         out.append(f"| `{short(k)}` | {r:.2f} | {w:.2f} | {r+w:.2f} | {(r+w)*1e6/ncol:.1f} | {ms:.3f} | {((r+w)/(ms*1e-3)) if ms else 0:.0f} |")
     out.append("")
