@@ -1,0 +1,196 @@
+! ecrad_hip_binding.F90 -- ISO_C_BINDING twin of include/ecrad_hip.h.
+!
+! This is the thin layer the north star asks for: Fortran host code reaches the HIP kernels only
+! through these interoperable types and interfaces.  Field order and kinds mirror the C structs
+! exactly (tests compare c_sizeof with ecrad_hip_abi_sizeof).
+module ecrad_hip_binding
+  use, intrinsic :: iso_c_binding
+  implicit none
+  public
+
+  integer(c_int), parameter :: ECRAD_ABI_VERSION = 1
+  integer(c_int), parameter :: ECRAD_OK = 0
+  integer(c_int), parameter :: ECRAD_NMAXGASES = 12, ECRAD_NMAXCLOUDTYPES = 12
+  integer(c_int), parameter :: ECRAD_MEM_HOST = 0, ECRAD_MEM_DEVICE = 1
+
+  type, bind(C) :: ecrad_ckd_gas_t
+    integer(c_int32_t) :: i_gas_code, i_conc_dependence, n_mole_frac, reserved_
+    real(c_double)     :: reference_mole_frac, log_mole_frac1, d_log_mole_frac
+    type(c_ptr)        :: molar_abs = c_null_ptr
+  end type
+
+  type, bind(C) :: ecrad_ckd_model_t
+    integer(c_int32_t) :: is_sw, ng, npress, ntemp, ngas, nplanck
+    real(c_double)     :: log_pressure1, d_log_pressure, d_temperature
+    real(c_double)     :: temperature1_planck, d_temperature_planck
+    type(c_ptr)        :: temperature1 = c_null_ptr, planck_function = c_null_ptr
+    type(c_ptr)        :: norm_solar_irradiance = c_null_ptr, norm_amplitude_solar_irradiance = c_null_ptr
+    type(c_ptr)        :: rayleigh_molar_scat = c_null_ptr
+    type(ecrad_ckd_gas_t) :: single_gas(ECRAD_NMAXGASES)
+  end type
+
+  type, bind(C) :: ecrad_cloud_optics_t
+    integer(c_int32_t) :: n_bands, n_effective_radius
+    real(c_double)     :: effective_radius_0, d_effective_radius
+    type(c_ptr)        :: mass_ext = c_null_ptr, ssa = c_null_ptr, asymmetry = c_null_ptr
+  end type
+
+  type, bind(C) :: ecrad_aerosol_optics_t
+    integer(c_int32_t) :: n_bands_sw, n_bands_lw, n_type_phobic, n_type_philic, nrh, use_hydrophilic, ntype, reserved_
+    type(c_ptr) :: iclass = c_null_ptr, itype = c_null_ptr, rh_lower = c_null_ptr
+    type(c_ptr) :: mass_ext_sw_phobic = c_null_ptr, ssa_sw_phobic = c_null_ptr, g_sw_phobic = c_null_ptr
+    type(c_ptr) :: mass_ext_lw_phobic = c_null_ptr, ssa_lw_phobic = c_null_ptr, g_lw_phobic = c_null_ptr
+    type(c_ptr) :: mass_ext_sw_philic = c_null_ptr, ssa_sw_philic = c_null_ptr, g_sw_philic = c_null_ptr
+    type(c_ptr) :: mass_ext_lw_philic = c_null_ptr, ssa_lw_philic = c_null_ptr, g_lw_philic = c_null_ptr
+  end type
+
+  type, bind(C) :: ecrad_pdf_sampler_t
+    integer(c_int32_t) :: ncdf, nfsd
+    real(c_double)     :: fsd1, inv_fsd_interval
+    type(c_ptr)        :: val = c_null_ptr
+  end type
+
+  type, bind(C) :: ecrad_config_t
+    integer(c_int32_t) :: abi_version
+    integer(c_int32_t) :: do_sw, do_lw, do_clear, do_sw_direct, do_lw_derivatives
+    integer(c_int32_t) :: do_clouds, use_aerosols
+    integer(c_int32_t) :: i_solver_sw, i_solver_lw
+    integer(c_int32_t) :: i_gas_model_sw, i_gas_model_lw
+    integer(c_int32_t) :: do_lw_cloud_scattering, do_lw_aerosol_scattering
+    integer(c_int32_t) :: do_sw_delta_scaling_with_gases
+    integer(c_int32_t) :: use_general_cloud_optics, is_homogeneous
+    integer(c_int32_t) :: i_overlap_scheme, use_beta_overlap, use_vectorizable_generator, i_cloud_pdf_shape
+    integer(c_int32_t) :: do_cloud_aerosol_per_sw_g_point, do_cloud_aerosol_per_lw_g_point
+    integer(c_int32_t) :: do_surface_sw_spectral_flux, do_toa_spectral_flux
+    integer(c_int32_t) :: do_canopy_fluxes_sw, do_canopy_fluxes_lw
+    integer(c_int32_t) :: use_canopy_full_spectrum_sw, use_canopy_full_spectrum_lw
+    integer(c_int32_t) :: do_nearest_spectral_sw_albedo, do_nearest_spectral_lw_emiss
+    integer(c_int32_t) :: do_save_spectral_flux
+    integer(c_int32_t) :: n_g_sw, n_g_lw, n_bands_sw, n_bands_lw
+    integer(c_int32_t) :: n_g_lw_if_scattering, n_bands_lw_if_scattering
+    integer(c_int32_t) :: n_canopy_bands_sw, n_canopy_bands_lw
+    integer(c_int32_t) :: n_albedo_intervals_sw, n_emiss_intervals_lw
+    integer(c_int32_t) :: n_cloud_types, reserved_
+    real(c_double) :: cloud_fraction_threshold, cloud_mixing_ratio_threshold
+    real(c_double) :: cloud_inhom_decorr_scaling, max_cloud_od
+    type(c_ptr) :: i_band_from_reordered_g_sw = c_null_ptr, i_band_from_reordered_g_lw = c_null_ptr
+    type(c_ptr) :: sw_albedo_weights = c_null_ptr, lw_emiss_weights = c_null_ptr
+    type(c_ptr) :: i_albedo_from_band_sw = c_null_ptr, i_emiss_from_band_lw = c_null_ptr
+    type(ecrad_ckd_model_t) :: gas_optics_sw, gas_optics_lw
+    type(ecrad_cloud_optics_t) :: cloud_optics_sw(ECRAD_NMAXCLOUDTYPES), cloud_optics_lw(ECRAD_NMAXCLOUDTYPES)
+    type(ecrad_aerosol_optics_t) :: aerosol_optics
+    type(ecrad_pdf_sampler_t) :: pdf_sampler
+  end type
+
+  type, bind(C) :: ecrad_inputs_t
+    integer(c_int32_t) :: memory, n_sw_albedo, n_lw_emissivity, n_cloud_types, n_aerosol_types
+    integer(c_int32_t) :: aerosol_istartlev, aerosol_iendlev, reserved_
+    real(c_double) :: solar_irradiance, spectral_solar_cycle_multiplier
+    type(c_ptr) :: pressure_hl = c_null_ptr, temperature_hl = c_null_ptr, h2o_sat_liq = c_null_ptr
+    type(c_ptr) :: cos_sza = c_null_ptr, skin_temperature = c_null_ptr
+    type(c_ptr) :: sw_albedo = c_null_ptr, sw_albedo_direct = c_null_ptr, lw_emissivity = c_null_ptr
+    type(c_ptr) :: iseed = c_null_ptr
+    type(c_ptr) :: gas_mixing_ratio = c_null_ptr
+    type(c_ptr) :: cloud_fraction = c_null_ptr, cloud_mixing_ratio = c_null_ptr
+    type(c_ptr) :: cloud_effective_radius = c_null_ptr, cloud_fractional_std = c_null_ptr
+    type(c_ptr) :: cloud_overlap_param = c_null_ptr
+    type(c_ptr) :: aerosol_mixing_ratio = c_null_ptr
+  end type
+
+  type, bind(C) :: ecrad_flux_t
+    integer(c_int32_t) :: memory, reserved_
+    type(c_ptr) :: lw_up = c_null_ptr, lw_dn = c_null_ptr, sw_up = c_null_ptr, sw_dn = c_null_ptr, sw_dn_direct = c_null_ptr
+    type(c_ptr) :: lw_up_clear = c_null_ptr, lw_dn_clear = c_null_ptr, sw_up_clear = c_null_ptr
+    type(c_ptr) :: sw_dn_clear = c_null_ptr, sw_dn_direct_clear = c_null_ptr
+    type(c_ptr) :: lw_derivatives = c_null_ptr
+    type(c_ptr) :: lw_dn_surf_g = c_null_ptr, lw_dn_surf_clear_g = c_null_ptr
+    type(c_ptr) :: sw_dn_diffuse_surf_g = c_null_ptr, sw_dn_direct_surf_g = c_null_ptr
+    type(c_ptr) :: sw_dn_diffuse_surf_clear_g = c_null_ptr, sw_dn_direct_surf_clear_g = c_null_ptr
+    type(c_ptr) :: lw_up_toa_g = c_null_ptr, lw_up_toa_clear_g = c_null_ptr, sw_dn_toa_g = c_null_ptr
+    type(c_ptr) :: sw_up_toa_g = c_null_ptr, sw_up_toa_clear_g = c_null_ptr
+    type(c_ptr) :: sw_dn_surf_band = c_null_ptr, sw_dn_direct_surf_band = c_null_ptr
+    type(c_ptr) :: sw_dn_surf_clear_band = c_null_ptr, sw_dn_direct_surf_clear_band = c_null_ptr
+    type(c_ptr) :: lw_up_toa_band = c_null_ptr, lw_up_toa_clear_band = c_null_ptr, sw_dn_toa_band = c_null_ptr
+    type(c_ptr) :: sw_up_toa_band = c_null_ptr, sw_up_toa_clear_band = c_null_ptr
+    type(c_ptr) :: lw_dn_surf_canopy = c_null_ptr, sw_dn_diffuse_surf_canopy = c_null_ptr
+    type(c_ptr) :: sw_dn_direct_surf_canopy = c_null_ptr
+    type(c_ptr) :: cloud_cover_lw = c_null_ptr, cloud_cover_sw = c_null_ptr
+  end type
+
+  interface
+    function ecrad_hip_create(handle, device_id) bind(C, name='ecrad_hip_create') result(status)
+      import :: c_ptr, c_int
+      type(c_ptr), intent(out) :: handle
+      integer(c_int), value    :: device_id
+      integer(c_int)           :: status
+    end function
+    function ecrad_hip_setup(handle, config) bind(C, name='ecrad_hip_setup') result(status)
+      import :: c_ptr, c_int, ecrad_config_t
+      type(c_ptr), value :: handle
+      type(ecrad_config_t), intent(in) :: config
+      integer(c_int) :: status
+    end function
+    function ecrad_hip_radiation(handle, ncol, nlev, istartcol, iendcol, inputs, flux) &
+         &  bind(C, name='ecrad_hip_radiation') result(status)
+      import :: c_ptr, c_int, ecrad_inputs_t, ecrad_flux_t
+      type(c_ptr), value    :: handle
+      integer(c_int), value :: ncol, nlev, istartcol, iendcol
+      type(ecrad_inputs_t), intent(in)  :: inputs
+      type(ecrad_flux_t), intent(inout) :: flux
+      integer(c_int) :: status
+    end function
+    function ecrad_hip_synchronize(handle) bind(C, name='ecrad_hip_synchronize') result(status)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: handle
+      integer(c_int) :: status
+    end function
+    function ecrad_hip_last_kernel_ms(handle, ms) bind(C, name='ecrad_hip_last_kernel_ms') result(status)
+      import :: c_ptr, c_int, c_double
+      type(c_ptr), value :: handle
+      real(c_double), intent(out) :: ms
+      integer(c_int) :: status
+    end function
+    function ecrad_hip_last_error(handle) bind(C, name='ecrad_hip_last_error') result(msg)
+      import :: c_ptr
+      type(c_ptr), value :: handle
+      type(c_ptr) :: msg
+    end function
+    function ecrad_hip_destroy(handle) bind(C, name='ecrad_hip_destroy') result(status)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: handle
+      integer(c_int) :: status
+    end function
+    function ecrad_hip_abi_sizeof(which) bind(C, name='ecrad_hip_abi_sizeof') result(n)
+      import :: c_int, c_size_t
+      integer(c_int), value :: which
+      integer(c_size_t) :: n
+    end function
+    function ecrad_hip_abi_version() bind(C, name='ecrad_hip_abi_version') result(v)
+      import :: c_int
+      integer(c_int) :: v
+    end function
+  end interface
+
+contains
+
+  ! Copy the NUL-terminated message of ecrad_hip_last_error into a Fortran string
+  function ecrad_hip_error_string(handle) result(str)
+    type(c_ptr), intent(in) :: handle
+    character(len=:), allocatable :: str
+    type(c_ptr) :: p
+    character(kind=c_char), pointer :: ch(:)
+    integer :: n
+    p = ecrad_hip_last_error(handle)
+    str = ''
+    if (.not. c_associated(p)) return
+    call c_f_pointer(p, ch, [4096])
+    n = 0
+    do while (n < 4096)
+      if (ch(n+1) == c_null_char) exit
+      n = n + 1
+    end do
+    allocate(character(len=n) :: str)
+    if (n > 0) str = transfer(ch(1:n), str)
+  end function
+
+end module ecrad_hip_binding
