@@ -592,6 +592,10 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
     for (const FluxField& f : kFluxFields)
       if (flux->*(f.host)) off += (flux_rows(c, f.kind, nlev) * r.nloc * 8 + 255) & ~size_t(255);
     HIP_TRY(h, h->staging_out.ensure(off));
+    // Entries that a solver never writes for a processed column (e.g. sw_dn_toa_g outside
+    // Tripleclouds, per-g TOA values of night-time Tripleclouds columns) are undefined in the
+    // reference (never assigned after allocate); here they are deterministically zero.
+    HIP_TRY(h, hipMemsetAsync(h->staging_out.p, 0, off, stream));
     Carver cv(h->staging_out.p);
     for (const FluxField& f : kFluxFields)
       if (flux->*(f.host)) {
