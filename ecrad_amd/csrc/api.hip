@@ -46,7 +46,7 @@ struct ecrad_hip_handle_s {
   DevConfig* dcfg = nullptr;
   std::vector<void*> tables;
   int ngp_sw = 0, ngp_lw = 0;
-  Buf scratch, prep, staging_in, staging_out;
+  Buf scratch, prep, staging_in, staging_out, counters;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t evs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries
   double stage_ms[4] = {0, 0, 0, 0};
@@ -306,7 +306,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
   if (!h) return ECRAD_EINVAL;
   (void)hipSetDevice(h->device);
   free_tables(h);
-  h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
+  h->counters.release(); h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (auto& e : h->evs) if (e) (void)hipEventDestroy(e);
@@ -624,11 +624,12 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
   const bool sw_tc = c.do_sw && c.i_solver_sw == ECRAD_SOLVER_TRIPLECLOUDS, lw_tc = c.do_lw && c.i_solver_lw == ECRAD_SOLVER_TRIPLECLOUDS;
   const int grid_sw = c.do_sw ? grid_for(h, r.nloc, h->ngp_sw) : 0;
   const int grid_lw = c.do_lw ? grid_for(h, r.nloc, h->ngp_lw) : 0;
-  const int na_sw = c.do_sw ? (sw_tc ? sw_tc_num_scratch_arrays() : sw_ica_num_scratch_arrays(c.i_solver_sw)) : 0;
-  const int na_lw = c.do_lw ? (lw_tc ? lw_tc_num_scratch_arrays() : lw_ica_num_scratch_arrays(c.i_solver_lw)) : 0;
-  const size_t per_block_sw = (size_t)na_sw * (nlev + 1) * kBlock, per_block_lw = (size_t)na_lw * (nlev + 1) * kBlock;
+  const size_t per_block_sw = !c.do_sw ? 0 : (sw_tc ? sw_tc_scratch_doubles(nlev) : sw_ica_scratch_doubles(c.i_solver_sw, nlev));
+  const size_t per_block_lw = !c.do_lw ? 0 : (lw_tc ? lw_tc_scratch_doubles(nlev) : lw_ica_scratch_doubles(c.i_solver_lw, nlev));
   const size_t need_sw = per_block_sw * grid_sw * 8, need_lw = per_block_lw * grid_lw * 8;
   HIP_TRY(h, h->scratch.ensure(need_sw > need_lw ? need_sw : need_lw));
+  HIP_TRY(h, h->counters.ensure(256));
+  int* counters = reinterpret_cast<int*>(h->counters.p);   // [0] LW kernel, [16] SW kernel work queues
   DevCloudPrep prep{};
   double* mcica_work = nullptr;
   {
@@ -657,6 +658,7 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
   // ---- kernels (radiation_interface.F90:323-504) ------------------------------------------------------
   HIP_TRY(h, hipEventRecord(h->ev0, stream));
   HIP_TRY(h, hipEventRecord(h->evs[0], stream));
+  HIP_TRY(h, hipMemsetAsync(counters, 0, 256, stream));
   if (c.do_clouds) HIP_TRY(h, launch_crop(stream, h->dcfg, din));                      // :361
   if (sw_tc || lw_tc)
     HIP_TRY(h, launch_tripleclouds_prep(stream, h->dcfg, din, prep, sw_tc ? dfx.cloud_cover_sw : nullptr,
@@ -672,8 +674,8 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
       HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_lw, 997, prep.od_scaling_lw,
                                         prep.total_cloud_cover_lw, prep.rng_state, mcica_work));
     }
-    if (lw_tc) HIP_TRY(h, launch_lw_tc(h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_lw));
-    else HIP_TRY(h, launch_lw_ica(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_lw));
+    if (lw_tc) HIP_TRY(h, launch_lw_tc(h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_lw, counters));
+    else HIP_TRY(h, launch_lw_ica(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_lw, counters));
   }
   HIP_TRY(h, hipEventRecord(h->evs[2], stream));
   if (c.do_sw) {                                                                        // :459-499
@@ -685,8 +687,8 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
       HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_sw, 0, prep.od_scaling_sw,
                                         prep.total_cloud_cover_sw, prep.rng_state, mcica_work));
     }
-    if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_sw));
-    else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_sw));
+    if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_sw, counters + 16));
+    else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_sw, counters + 16));
   }
   HIP_TRY(h, hipEventRecord(h->evs[3], stream));
   HIP_TRY(h, launch_spectral_post(stream, h->dcfg, din, dfx));                          // :503-504

@@ -17,9 +17,11 @@ namespace ecrad {
 enum { L_T1 = 0, L_SU1, L_SD1, L_R2, L_T2, L_SU2, L_SD2, L_ALB, L_SRC, L_NUM };
 
 template <typename TAB, int NGP, int MODE>
-__global__ __launch_bounds__(kBlock) void lw_ica_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevFlux fx,
-                                                       DevCloudPrep prep, double* scratch_base, size_t scratch_per_block) {
+__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevFlux fx,
+                                                       DevCloudPrep prep, double* scratch_base, size_t scratch_per_block,
+                                                       int* work_counter) {
   extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int next_group;
   const DevConfig& cfg = *cfgp;
   const DevCkdModel& m = cfg.gas_lw;
   constexpr int CPB = kBlock / NGP;
@@ -38,7 +40,12 @@ __global__ __launch_bounds__(kBlock) void lw_ica_kernel(const DevConfig* __restr
   const bool have_clear_out = cfg.do_clear != 0;
   const bool do_deriv = cfg.do_lw_derivatives != 0 && fx.lw_derivatives != nullptr;
 
-  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) next_group = atomicAdd(work_counter, 1);
+    __syncthreads();
+    const int grp = next_group;
+    if (grp >= ngroups) break;
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
@@ -250,28 +257,30 @@ __global__ __launch_bounds__(kBlock) void lw_ica_kernel(const DevConfig* __restr
 template <typename TAB, int NGP>
 static hipError_t launch_lw_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const DevConfig* cfg,
                                  const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                                 double* scratch, size_t per_block) {
+                                 double* scratch, size_t per_block, int* counter) {
   switch (mode) {
     case ECRAD_SOLVER_CLOUDLESS:
-      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 0>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block);
+      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 0>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter);
       break;
     case ECRAD_SOLVER_HOMOGENEOUS:
-      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 1>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block);
+      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 1>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter);
       break;
     default:
-      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 2>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block);
+      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 2>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter);
       break;
   }
   return hipGetLastError();
 }
 
-int lw_ica_num_scratch_arrays(int mode) { return mode == ECRAD_SOLVER_CLOUDLESS ? L_R2 : L_NUM; }
+size_t lw_ica_scratch_doubles(int mode, int nlev) {
+  return (size_t)(mode == ECRAD_SOLVER_CLOUDLESS ? L_R2 : L_NUM) * (nlev + 1) * kBlock;
+}
 
 hipError_t launch_lw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig* cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                         double* scratch, size_t per_block) {
+                         double* scratch, size_t per_block, int* counter) {
   dim3 g(grid);
-#define ECRAD_DISPATCH(T, N) return launch_lw_mode<T, N>(mode, g, lds, st, cfg, in, fx, prep, scratch, per_block)
+#define ECRAD_DISPATCH(T, N) return launch_lw_mode<T, N>(mode, g, lds, st, cfg, in, fx, prep, scratch, per_block, counter)
   if (table_f32) {
     if (ngp == 16) ECRAD_DISPATCH(float, 16);
     if (ngp == 32) ECRAD_DISPATCH(float, 32);

@@ -5,69 +5,77 @@
 // One launch does, per column: albedo mapping (radiation_single_level.F90:216), ecCKD gas optics +
 // Rayleigh (radiation_ecckd_interface.F90:256-291), aerosol merge (radiation_aerosol_optics.F90:487),
 // cloud optics (radiation_general_cloud_optics.F90:134), two-stream layer coefficients
-// (radiation_two_stream.F90:421 / :563) and the adding method (radiation_adding_ica_sw.F90:24),
-// i.e. stages that the reference separates by (ng,nlev,ncol) arrays are fused; only the per-layer
-// two-stream coefficients the two vertical sweeps need go through (block-private) HBM scratch.
+// (radiation_two_stream.F90:421 / :563) and the adding method (radiation_adding_ica_sw.F90:24).
+//
+// Two vertical sweeps instead of the reference's three.  adding_ica_sw first walks DOWN to get the
+// direct beam F(l), then UP for albedo A(l) and source S(l), then DOWN for the fluxes.  S is linear in
+// the direct beam: S(l) = F(l)*sigma(l) with  sigma(l) = ref_dir + T (sigma(l+1) t_dd + A(l+1) t_df) / (1 - A(l+1) R),
+// which needs nothing from above.  So sweep 1 goes UP from the surface doing optics + two-stream +
+// the A/sigma recurrences and stores, per layer, only what the flux sweep needs:
+//     a1 = T/(1-A R),  b = (R sigma t_dd + t_df)/(1-A R),  t_dd,  A(l+1),  sigma(l+1)
+// and sweep 2 goes DOWN:  F' = F t_dd;  Fdn' = a1 Fdn + F b;  Fup' = A Fdn' + sigma F'.
+// Same arithmetic as radiation_adding_ica_sw.F90:85-147 up to re-association (parity tests: 1e-8).
+// HBM traffic per (g, layer): 5 doubles written + 5 read (was 7 + 13 with three sweeps).
 #include "kernels_common.h"
 #include "optics_device.h"
 #include "launch.h"
 
 namespace ecrad {
 
-enum { A_R1 = 0, A_T1, A_RD1, A_TDF1, A_FDIR1, A_ALB, A_SRC, A_R2, A_T2, A_RD2, A_TDF2, A_FDIR2, A_NUM_SW };
-
-template <bool SET2>
-struct SwCoefReader {
-  const Scratch& s;
-  const LevMask& cloudy;
-  int tid;
-  ECRAD_DEV void get(int l, double& R, double& T, double& rd, double& tdf) const {
-    const bool c2 = SET2 && cloudy.test(l);
-    R = s.at(c2 ? A_R2 : A_R1, l, tid);
-    T = s.at(c2 ? A_T2 : A_T1, l, tid);
-    rd = s.at(c2 ? A_RD2 : A_RD1, l, tid);
-    tdf = s.at(c2 ? A_TDF2 : A_TDF1, l, tid);
+// scratch "pair" slots (16 B per lane) and single slots per half level
+//   pair 0: (a1, b)      pair 1: (t_dd, A_below)      single: sigma_below        -- set 1 (clear sky)
+//   pair 2, pair 3, single 1                                                      -- set 2 (cloudy / overcast)
+struct SwScratch {
+  double* base;
+  int nlev;
+  // per block: [set][level][ (pair0: 512 doubles) (pair1: 512 doubles) (single: 256 doubles) ]
+  ECRAD_DEV double2& pair(int set, int k, int lev, int tid) const {
+    return reinterpret_cast<double2*>(base + ((size_t)(set * nlev + lev) * 5 + 2 * k) * kBlock)[tid];
   }
-  ECRAD_DEV double fdir(int l) const { return s.at(SET2 ? A_FDIR2 : A_FDIR1, l, tid); }
+  ECRAD_DEV double& single(int set, int lev, int tid) const {
+    return base[((size_t)(set * nlev + lev) * 5 + 4) * kBlock + tid];
+  }
 };
 
-// adding_ica_sw (radiation_adding_ica_sw.F90:85-147) for one (column, g) lane + sums over g.
-// out_*: broadband profile pointers (may be NULL); blend: McICA weighting against the clear profiles.
-template <int NGP, bool SET2>
-ECRAD_DEV void sw_adding(const Scratch& s, const LevMask& cloudy, int tid, int nlev, double mu0,
-                         double alb_dif, double alb_dir, bool valid, bool leader, size_t ncol, int col,
-                         double* out_up, double* out_dn, double* out_dir, double weight,
-                         const double* clr_up, const double* clr_dn, const double* clr_dir,
-                         double& fdn_surf, double& fdir_surf, double& fup_toa) {
-  SwCoefReader<SET2> cf{s, cloudy, tid};
-  double alb = alb_dif;
-  double src = alb_dir * cf.fdir(nlev) * mu0;
-  s.at(A_ALB, nlev, tid) = alb;
-  s.at(A_SRC, nlev, tid) = src;
-  for (int l = nlev - 1; l >= 0; --l) {
-    double R, T, rd, tdf;
-    cf.get(l, R, T, rd, tdf);
-    const double Fd = cf.fdir(l);
-    const double inv = 1.0 / (1.0 - alb * R);
-    const double src_new = rd * Fd + T * (src + alb * tdf * Fd) * inv;
-    alb = R + T * T * alb * inv;
-    src = src_new;
-    s.at(A_ALB, l, tid) = alb;
-    s.at(A_SRC, l, tid) = src;
-  }
-  double fdn = 0.0, fup = src;
+struct SwSweepState {   // albedo / normalised source below the current half level
+  double alb, sig;
+};
+
+ECRAD_DEV void sw_up_step(const SwScratch& s, int set, int lev, int tid, const SwCoef& c, SwSweepState& st) {
+  const double inv = 1.0 / (1.0 - st.alb * c.ref_diff);
+  double2 p0, p1;
+  p0.x = c.trans_diff * inv;                                                       // a1
+  p0.y = (c.ref_diff * st.sig * c.trans_dir_dir + c.trans_dir_diff) * inv;         // b
+  p1.x = c.trans_dir_dir;
+  p1.y = st.alb;
+  s.pair(set, 0, lev, tid) = p0;
+  s.pair(set, 1, lev, tid) = p1;
+  s.single(set, lev, tid) = st.sig;
+  const double sig_new = c.ref_dir + c.trans_diff * (st.sig * c.trans_dir_dir + st.alb * c.trans_dir_diff) * inv;
+  st.alb = c.ref_diff + c.trans_diff * c.trans_diff * st.alb * inv;
+  st.sig = sig_new;
+}
+
+// Flux sweep (top -> bottom) for one coefficient set; for SET2 layers below the lowest cloudy layer
+// `lcb` reuse set 1's records (identical there).  Sums over g are written by the group leader.
+template <int NGP>
+ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, int nlev, double mu0, double incoming,
+                             double sig_top, bool valid, bool leader, size_t ncol, int col,
+                             double* out_up, double* out_dn, double* out_dir, double weight,
+                             const double* clr_up, const double* clr_dn, const double* clr_dir,
+                             double& fdn_surf, double& fdir_surf, double& fup_toa) {
+  double Fd = incoming, fdn = 0.0, fup = incoming * sig_top;
   fup_toa = fup;
   const bool blend = weight < 1.0;
   for (int l = 0; l <= nlev; ++l) {
-    double Fd = cf.fdir(l);
     if (l > 0) {
-      double R, T, rd, tdf;
-      cf.get(l - 1, R, T, rd, tdf);
-      const double Fd_above = cf.fdir(l - 1);
-      const double albn = s.at(A_ALB, l, tid), srcn = s.at(A_SRC, l, tid);
-      const double inv = 1.0 / (1.0 - albn * R);
-      fdn = (T * fdn + R * srcn + tdf * Fd_above) * inv;
-      fup = albn * fdn + srcn;
+      const int set = (set2 && (l - 1) <= lcb) ? 1 : 0;
+      const double2 p0 = s.pair(set, 0, l - 1, tid);
+      const double2 p1 = s.pair(set, 1, l - 1, tid);
+      const double sign = s.single(set, l - 1, tid);
+      fdn = p0.x * fdn + Fd * p0.y;
+      Fd = Fd * p1.x;
+      fup = p1.y * fdn + sign * Fd;
     }
     const double su = group_sum<NGP>(valid ? fup : 0.0);
     const double sd = group_sum<NGP>(valid ? fdn : 0.0);
@@ -86,13 +94,15 @@ ECRAD_DEV void sw_adding(const Scratch& s, const LevMask& cloudy, int tid, int n
     }
   }
   fdn_surf = fdn;
-  fdir_surf = cf.fdir(nlev) * mu0;
+  fdir_surf = Fd * mu0;
 }
 
 template <typename TAB, int NGP, int MODE>
-__global__ __launch_bounds__(kBlock) void sw_ica_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevFlux fx,
-                                                       DevCloudPrep prep, double* scratch_base, size_t scratch_per_block) {
+__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(const DevConfig* __restrict__ cfgp, DevInputs in,
+                                                                        DevFlux fx, DevCloudPrep prep, double* scratch_base,
+                                                                        size_t scratch_per_block, int* work_counter) {
   extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int next_group;
   const DevConfig& cfg = *cfgp;
   const DevCkdModel& m = cfg.gas_sw;
   constexpr int CPB = kBlock / NGP;
@@ -105,13 +115,21 @@ __global__ __launch_bounds__(kBlock) void sw_ica_kernel(const DevConfig* __restr
   const bool want_clouds = MODE != 0;
   const int nct = want_clouds ? cfg.n_cloud_types : 0;
   const LdsLayout L = make_lds(smem, m.ngas, nct);
-  const Scratch s{scratch_base + (size_t)blockIdx.x * scratch_per_block, nlev + 1};
+  const SwScratch s{scratch_base + (size_t)blockIdx.x * scratch_per_block, nlev};
   const int g = glane < ng ? glane : ng - 1;
   const int ib = cfg.i_band_from_reordered_g_sw[g] - 1;
   const bool leader = glane == 0;
   const double ray_g = m.rayleigh_molar_scat[g];
+  const bool have_clear_out = cfg.do_clear != 0;
 
-  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  for (;;) {
+    // dynamic work distribution: blocks pull the next group of CPB columns
+    __syncthreads();
+    if (tid == 0) next_group = atomicAdd(work_counter, 1);
+    __syncthreads();
+    const int grp = next_group;
+    if (grp >= ngroups) break;
+
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
@@ -127,13 +145,14 @@ __global__ __launch_bounds__(kBlock) void sw_ica_kernel(const DevConfig* __restr
     }
     double tcc = 0.0;
     if (MODE == 2) tcc = prep.total_cloud_cover_sw[cloc];
-    LevMask cloudy;
-    cloudy.clear();
-    double fdir1 = incoming, fdir2 = incoming;
+    int lcb = -1;                 // lowest cloudy layer (0-based), -1 if none met yet
+    SwSweepState st1{alb_dif, alb_dir * mu0}, st2{alb_dif, alb_dir * mu0};
 
-    // ---- pass A: top -> bottom, optics + layer coefficients -------------------------------------
-    for (int l0 = 0; l0 < nlev; l0 += NGP) {
-      __syncthreads();
+    // ---- sweep 1: surface -> top: optics + two-stream + albedo/source recurrences ---------------
+    const int nchunk = (nlev + NGP - 1) / NGP;
+    for (int ch = nchunk - 1; ch >= 0; --ch) {
+      const int l0 = ch * NGP;
+      if (ch != nchunk - 1) __syncthreads();
       {
         const int lev = l0 + glane;
         if (lev < nlev) level_scalars<true>(cfg, m, in, L, tid, col, lev, want_clouds);
@@ -141,7 +160,7 @@ __global__ __launch_bounds__(kBlock) void sw_ica_kernel(const DevConfig* __restr
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
       if (sun_up) {
-        for (int j = 0; j < nl; ++j) {
+        for (int j = nl - 1; j >= 0; --j) {
           const int lev = l0 + j;
           const int slot = cib * NGP + j;
           // gas optics: radiation_ecckd_interface.F90:256-281
@@ -155,65 +174,48 @@ __global__ __launch_bounds__(kBlock) void sw_ica_kernel(const DevConfig* __restr
             if (!cfg.do_sw_delta_scaling_with_gases) delta_eddington_extensive_vec(a);
             merge_aerosol_sw(cfg, a, od, ssa, asym);
           }
-          {
-            double od1 = od, ssa1 = ssa, g1 = asym;
-            if (cfg.do_sw_delta_scaling_with_gases) delta_eddington(od1, ssa1, g1);
-            const SwCoef c = (MODE == 2) ? ref_trans_sw_fused(mu0, od1, ssa1, g1) : ref_trans_sw_classic(mu0, od1, ssa1, g1);
-            s.at(A_R1, lev, tid) = c.ref_diff;
-            s.at(A_T1, lev, tid) = c.trans_diff;
-            s.at(A_RD1, lev, tid) = c.ref_dir;
-            s.at(A_TDF1, lev, tid) = c.trans_dir_diff;
-            s.at(A_FDIR1, lev, tid) = fdir1;
-            fdir1 = fdir1 * c.trans_dir_dir;
-            if (MODE != 0) {
-              s.at(A_FDIR2, lev, tid) = fdir2;
-              const bool layer_cloudy = L.D(F_FRAC, slot) >= cfg.cloud_fraction_threshold;
-              if (!layer_cloudy) {
-                fdir2 = fdir2 * c.trans_dir_dir;
-              } else {
-                cloudy.set(lev);
-                const CloudLayer cl = cloud_layer<true>(cfg, L, slot, ib);
-                double od_total, ssa_total = 0.0, g_total = 0.0;
-                if (MODE == 1) {   // radiation_homogeneous_sw.F90:236-253
-                  od_total = od + cl.od;
-                  if (od_total > 0.0) ssa_total = (ssa * od + cl.ssa * cl.od) / od_total;
-                  if (ssa_total > 0.0 && od_total > 0.0)
-                    g_total = (asym * ssa * od + cl.g * cl.ssa * cl.od) / (ssa_total * od_total);
-                } else {           // radiation_mcica_sw.F90:250-268
-                  const double od_cloud_new = prep.od_scaling_sw[g + (size_t)ng * (lev + (size_t)nlev * cloc)] * cl.od;
-                  od_total = od + od_cloud_new;
-                  if (od_total > 0.0) {
-                    const double scat_od = ssa * od + cl.ssa * od_cloud_new;
-                    ssa_total = scat_od / od_total;
-                    if (scat_od > 0.0) g_total = (asym * ssa * od + cl.g * cl.ssa * od_cloud_new) / scat_od;
-                  }
+          double od1 = od, ssa1 = ssa, g1 = asym;
+          if (cfg.do_sw_delta_scaling_with_gases) delta_eddington(od1, ssa1, g1);
+          const SwCoef c = (MODE == 2) ? ref_trans_sw_fused(mu0, od1, ssa1, g1) : ref_trans_sw_classic(mu0, od1, ssa1, g1);
+          if (MODE != 0) {
+            const bool layer_cloudy = L.D(F_FRAC, slot) >= cfg.cloud_fraction_threshold;
+            if (layer_cloudy) {
+              if (lcb < 0) { lcb = lev; st2 = st1; }     // below the lowest cloud both sets coincide
+              const CloudLayer cl = cloud_layer<true>(cfg, L, slot, ib);
+              double od_total, ssa_total = 0.0, g_total = 0.0;
+              if (MODE == 1) {   // radiation_homogeneous_sw.F90:236-253
+                od_total = od + cl.od;
+                if (od_total > 0.0) ssa_total = (ssa * od + cl.ssa * cl.od) / od_total;
+                if (ssa_total > 0.0 && od_total > 0.0)
+                  g_total = (asym * ssa * od + cl.g * cl.ssa * cl.od) / (ssa_total * od_total);
+              } else {           // radiation_mcica_sw.F90:250-268
+                const double od_cloud_new = prep.od_scaling_sw[g + (size_t)ng * (lev + (size_t)nlev * cloc)] * cl.od;
+                od_total = od + od_cloud_new;
+                if (od_total > 0.0) {
+                  const double scat_od = ssa * od + cl.ssa * od_cloud_new;
+                  ssa_total = scat_od / od_total;
+                  if (scat_od > 0.0) g_total = (asym * ssa * od + cl.g * cl.ssa * od_cloud_new) / scat_od;
                 }
-                if (cfg.do_sw_delta_scaling_with_gases) delta_eddington(od_total, ssa_total, g_total);
-                const SwCoef c2 = (MODE == 2) ? ref_trans_sw_fused(mu0, od_total, ssa_total, g_total)
-                                              : ref_trans_sw_classic(mu0, od_total, ssa_total, g_total);
-                s.at(A_R2, lev, tid) = c2.ref_diff;
-                s.at(A_T2, lev, tid) = c2.trans_diff;
-                s.at(A_RD2, lev, tid) = c2.ref_dir;
-                s.at(A_TDF2, lev, tid) = c2.trans_dir_diff;
-                fdir2 = fdir2 * c2.trans_dir_dir;
               }
+              if (cfg.do_sw_delta_scaling_with_gases) delta_eddington(od_total, ssa_total, g_total);
+              const SwCoef c2 = (MODE == 2) ? ref_trans_sw_fused(mu0, od_total, ssa_total, g_total)
+                                            : ref_trans_sw_classic(mu0, od_total, ssa_total, g_total);
+              sw_up_step(s, 1, lev, tid, c2, st2);
+            } else if (lcb >= 0) {
+              sw_up_step(s, 1, lev, tid, c, st2);
             }
           }
+          sw_up_step(s, 0, lev, tid, c, st1);
         }
       }
     }
-    if (sun_up) {
-      s.at(A_FDIR1, nlev, tid) = fdir1;
-      if (MODE != 0) s.at(A_FDIR2, nlev, tid) = fdir2;
-    }
 
-    // ---- passes B/C: adding method ---------------------------------------------------------------
-    const bool have_clear_out = cfg.do_clear != 0;
+    // ---- sweep 2: top -> surface: fluxes ------------------------------------------------------------
     if (sun_up) {
-      double fdn_s, fdir_s, fup_t;
+      double fdn_s = 0.0, fdir_s = 0.0, fup_t = 0.0;
       if (MODE == 0) {
-        sw_adding<NGP, false>(s, cloudy, tid, nlev, mu0, alb_dif, alb_dir, valid, lead, ncol, col,
-                              fx.sw_up, fx.sw_dn, fx.sw_dn_direct, 1.0, nullptr, nullptr, nullptr, fdn_s, fdir_s, fup_t);
+        sw_flux_sweep<NGP>(s, false, -1, tid, nlev, mu0, incoming, st1.sig, valid, lead, ncol, col,
+                           fx.sw_up, fx.sw_dn, fx.sw_dn_direct, 1.0, nullptr, nullptr, nullptr, fdn_s, fdir_s, fup_t);
         if (valid) {
           const size_t og = g + (size_t)ng * col;
           fx.sw_dn_diffuse_surf_g[og] = fdn_s;
@@ -236,9 +238,9 @@ __global__ __launch_bounds__(kBlock) void sw_ica_kernel(const DevConfig* __restr
       } else {
         double fdn_c = 0.0, fdir_c = 0.0, fup_c = 0.0;
         if (have_clear_out) {
-          sw_adding<NGP, false>(s, cloudy, tid, nlev, mu0, alb_dif, alb_dir, valid, lead, ncol, col,
-                                fx.sw_up_clear, fx.sw_dn_clear, fx.sw_dn_direct_clear, 1.0, nullptr, nullptr, nullptr,
-                                fdn_c, fdir_c, fup_c);
+          sw_flux_sweep<NGP>(s, false, -1, tid, nlev, mu0, incoming, st1.sig, valid, lead, ncol, col,
+                             fx.sw_up_clear, fx.sw_dn_clear, fx.sw_dn_direct_clear, 1.0, nullptr, nullptr, nullptr,
+                             fdn_c, fdir_c, fup_c);
           if (valid) {
             const size_t og = g + (size_t)ng * col;
             fx.sw_dn_diffuse_surf_clear_g[og] = fdn_c;
@@ -246,12 +248,12 @@ __global__ __launch_bounds__(kBlock) void sw_ica_kernel(const DevConfig* __restr
             fx.sw_up_toa_clear_g[og] = fup_c;
           }
         }
-        const bool do_set2 = (MODE == 1) ? (cloudy.any() || !have_clear_out) : (tcc >= cfg.cloud_fraction_threshold);
+        const bool do_set2 = (MODE == 1) ? (lcb >= 0 || !have_clear_out) : (tcc >= cfg.cloud_fraction_threshold);
         if (do_set2) {
           const double w = (MODE == 2) ? tcc : 1.0;
-          sw_adding<NGP, true>(s, cloudy, tid, nlev, mu0, alb_dif, alb_dir, valid, lead, ncol, col,
-                               fx.sw_up, fx.sw_dn, fx.sw_dn_direct, w, fx.sw_up_clear, fx.sw_dn_clear,
-                               fx.sw_dn_direct_clear, fdn_s, fdir_s, fup_t);
+          sw_flux_sweep<NGP>(s, lcb >= 0, lcb, tid, nlev, mu0, incoming, lcb >= 0 ? st2.sig : st1.sig, valid, lead, ncol, col,
+                             fx.sw_up, fx.sw_dn, fx.sw_dn_direct, w, fx.sw_up_clear, fx.sw_dn_clear,
+                             fx.sw_dn_direct_clear, fdn_s, fdir_s, fup_t);
           if (valid) {
             const size_t og = g + (size_t)ng * col;
             if (MODE == 2) {
@@ -316,28 +318,31 @@ __global__ __launch_bounds__(kBlock) void sw_ica_kernel(const DevConfig* __restr
 template <typename TAB, int NGP>
 static hipError_t launch_sw_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const DevConfig* cfg,
                                  const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                                 double* scratch, size_t per_block) {
+                                 double* scratch, size_t per_block, int* counter) {
   switch (mode) {
     case ECRAD_SOLVER_CLOUDLESS:
-      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 0>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block);
+      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 0>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter);
       break;
     case ECRAD_SOLVER_HOMOGENEOUS:
-      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 1>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block);
+      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 1>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter);
       break;
     default:
-      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 2>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block);
+      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 2>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter);
       break;
   }
   return hipGetLastError();
 }
 
-int sw_ica_num_scratch_arrays(int mode) { return mode == ECRAD_SOLVER_CLOUDLESS ? A_R2 : A_NUM_SW; }
+// doubles of scratch per block: [set][level][5 * 256]
+size_t sw_ica_scratch_doubles(int mode, int nlev) {
+  return (size_t)(mode == ECRAD_SOLVER_CLOUDLESS ? 1 : 2) * nlev * 5 * kBlock;
+}
 
 hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig* cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                         double* scratch, size_t per_block) {
+                         double* scratch, size_t per_block, int* counter) {
   dim3 g(grid);
-#define ECRAD_DISPATCH(T, N) return launch_sw_mode<T, N>(mode, g, lds, st, cfg, in, fx, prep, scratch, per_block)
+#define ECRAD_DISPATCH(T, N) return launch_sw_mode<T, N>(mode, g, lds, st, cfg, in, fx, prep, scratch, per_block, counter)
   if (table_f32) {
     if (ngp == 16) ECRAD_DISPATCH(float, 16);
     if (ngp == 32) ECRAD_DISPATCH(float, 32);

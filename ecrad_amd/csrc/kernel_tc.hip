@@ -35,9 +35,11 @@ constexpr int SW_TACD = 22;    // total_albedo_clear_direct
 constexpr int SW_TC_NUM = 23;
 
 template <typename TAB, int NGP>
-__global__ __launch_bounds__(kBlock) void sw_tc_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevFlux fx,
-                                                      DevCloudPrep prep, double* scratch_base, size_t scratch_per_block) {
+__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevFlux fx,
+                                                      DevCloudPrep prep, double* scratch_base, size_t scratch_per_block,
+                                                      int* work_counter) {
   extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int next_group;
   const DevConfig& cfg = *cfgp;
   const DevCkdModel& m = cfg.gas_sw;
   constexpr int CPB = kBlock / NGP;
@@ -54,7 +56,12 @@ __global__ __launch_bounds__(kBlock) void sw_tc_kernel(const DevConfig* __restri
   const double ray_g = m.rayleigh_molar_scat[g];
   const bool do_clear = cfg.do_clear != 0;
 
-  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) next_group = atomicAdd(work_counter, 1);
+    __syncthreads();
+    const int grp = next_group;
+    if (grp >= ngroups) break;
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
@@ -300,11 +307,12 @@ __global__ __launch_bounds__(kBlock) void sw_tc_kernel(const DevConfig* __restri
   }
 }
 
-int sw_tc_num_scratch_arrays() { return SW_TC_NUM; }
+size_t sw_tc_scratch_doubles(int nlev) { return (size_t)SW_TC_NUM * (nlev + 1) * kBlock; }
 
 hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig* cfg,
-                        const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block) {
-#define ECRAD_L(T, N) hipLaunchKernelGGL((sw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block)
+                        const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block,
+                        int* counter) {
+#define ECRAD_L(T, N) hipLaunchKernelGGL((sw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter)
   if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
   else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }
 #undef ECRAD_L
@@ -321,9 +329,11 @@ constexpr int LT_TS = 14;     // total_source[3]   14..16
 constexpr int LW_TC_NUM = 17;
 
 template <typename TAB, int NGP>
-__global__ __launch_bounds__(kBlock) void lw_tc_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevFlux fx,
-                                                      DevCloudPrep prep, double* scratch_base, size_t scratch_per_block) {
+__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevFlux fx,
+                                                      DevCloudPrep prep, double* scratch_base, size_t scratch_per_block,
+                                                      int* work_counter) {
   extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ int next_group;
   const DevConfig& cfg = *cfgp;
   const DevCkdModel& m = cfg.gas_lw;
   constexpr int CPB = kBlock / NGP;
@@ -340,7 +350,12 @@ __global__ __launch_bounds__(kBlock) void lw_tc_kernel(const DevConfig* __restri
   const bool do_clear = cfg.do_clear != 0;
   const bool do_deriv = cfg.do_lw_derivatives != 0 && fx.lw_derivatives != nullptr;
 
-  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) next_group = atomicAdd(work_counter, 1);
+    __syncthreads();
+    const int grp = next_group;
+    if (grp >= ngroups) break;
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
@@ -557,11 +572,12 @@ __global__ __launch_bounds__(kBlock) void lw_tc_kernel(const DevConfig* __restri
   }
 }
 
-int lw_tc_num_scratch_arrays() { return LW_TC_NUM; }
+size_t lw_tc_scratch_doubles(int nlev) { return (size_t)LW_TC_NUM * (nlev + 1) * kBlock; }
 
 hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig* cfg,
-                        const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block) {
-#define ECRAD_L(T, N) hipLaunchKernelGGL((lw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block)
+                        const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block,
+                        int* counter) {
+#define ECRAD_L(T, N) hipLaunchKernelGGL((lw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter)
   if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
   else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }
 #undef ECRAD_L

@@ -11,6 +11,10 @@
 namespace ecrad {
 
 constexpr int kBlock = 256;
+// minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
+#ifndef ECRAD_MIN_WAVES
+#define ECRAD_MIN_WAVES 2
+#endif
 
 #define ECRAD_DEV __device__ __forceinline__
 

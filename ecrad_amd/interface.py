@@ -21,7 +21,7 @@ from .tables import AerosolOptics, CkdModel, GeneralCloudOptics, PdfSampler
 from .types import Flux, IVolumeMixingRatio
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libecrad_hip.so")
+LIB_PATH = os.environ.get("ECRAD_HIP_LIB", os.path.join(_HERE, "csrc", "libecrad_hip.so"))
 
 
 class EcradHipError(RuntimeError):
