@@ -95,6 +95,30 @@ int upload_as_float(ecrad_hip_handle_t h, const double* src, size_t n, const voi
   return st;
 }
 
+// quads of (p,T) neighbours, see optics_device.h: out[(g + ng*(ip + (np-1)*(it + (nt-1)*ic)))*4 + k]
+std::vector<double> build_quads(const double* a, int ng, int np, int nt, int nc) {
+  std::vector<double> q((size_t)ng * (np - 1) * (nt - 1) * nc * 4);
+  for (int ic = 0; ic < nc; ++ic)
+    for (int it = 0; it < nt - 1; ++it)
+      for (int ip = 0; ip < np - 1; ++ip)
+        for (int g = 0; g < ng; ++g) {
+          auto A = [&](int p, int t) { return a[g + (size_t)ng * (p + (size_t)np * (t + (size_t)nt * ic))]; };
+          double* o = &q[((size_t)g + (size_t)ng * (ip + (size_t)(np - 1) * (it + (size_t)(nt - 1) * ic))) * 4];
+          o[0] = A(ip, it); o[1] = A(ip + 1, it); o[2] = A(ip, it + 1); o[3] = A(ip + 1, it + 1);
+        }
+  return q;
+}
+
+std::vector<double> build_pairs(const double* a, int ng, int n) {
+  std::vector<double> q((size_t)ng * (n - 1) * 2);
+  for (int i = 0; i < n - 1; ++i)
+    for (int g = 0; g < ng; ++g) {
+      q[((size_t)g + (size_t)ng * i) * 2] = a[g + (size_t)ng * i];
+      q[((size_t)g + (size_t)ng * i) * 2 + 1] = a[g + (size_t)ng * (i + 1)];
+    }
+  return q;
+}
+
 int padded_ng(int ng) { return ng <= 16 ? 16 : (ng <= 32 ? 32 : (ng <= 64 ? 64 : 0)); }
 
 int setup_ckd(ecrad_hip_handle_t h, const ecrad_ckd_model_t& m, DevCkdModel& d) {
@@ -113,18 +137,28 @@ int setup_ckd(ecrad_hip_handle_t h, const ecrad_ckd_model_t& m, DevCkdModel& d) 
     f32 = all_float_exact(g.molar_abs, n);
   }
   if (f32 && !m.is_sw) f32 = all_float_exact(m.planck_function, (size_t)m.ng * m.nplanck);
+  if (const char* e = std::getenv("ECRAD_HIP_TABLE_F64")) { if (e[0] == '1') f32 = false; }   // tuning knob
   d.table_f32 = f32 ? 1 : 0;
   int st;
   if ((st = upload<double>(h, m.temperature1, m.npress, &d.temperature1))) return st;
+  if (m.npress < 2 || m.ntemp < 2) return fail(h, ECRAD_EINVAL, "ckd model: needs at least 2 pressures and temperatures");
   if (!m.is_sw) {
-    if (f32) st = upload_as_float(h, m.planck_function, (size_t)m.ng * m.nplanck, &d.planck_function);
-    else { const double* p; st = upload<double>(h, m.planck_function, (size_t)m.ng * m.nplanck, &p); d.planck_function = p; }
+    if (m.nplanck < 2) return fail(h, ECRAD_EINVAL, "ckd model: Planck table too short");
+    const std::vector<double> pp = build_pairs(m.planck_function, m.ng, m.nplanck);
+    if (f32) st = upload_as_float(h, pp.data(), pp.size(), &d.planck_function);
+    else { const double* p; st = upload<double>(h, pp.data(), pp.size(), &p); d.planck_function = p; }
     if (st) return st;
   } else {
     if ((st = upload<double>(h, m.norm_solar_irradiance, m.ng, &d.norm_solar_irradiance))) return st;
     if ((st = upload<double>(h, m.norm_amplitude_solar_irradiance, m.ng, &d.norm_amplitude_solar_irradiance))) return st;
     if ((st = upload<double>(h, m.rayleigh_molar_scat, m.ng, &d.rayleigh_molar_scat))) return st;
   }
+  // one table with the quads of every gas; GasHot addresses them by 32-bit offsets
+  std::vector<double> all_quads;
+  GasHot& hot = d.hot;
+  hot.nquad = 0;
+  hot.lutmask = 0;
+  const size_t slice = (size_t)m.ng * (m.npress - 1) * (m.ntemp - 1);
   for (int j = 0; j < m.ngas; ++j) {
     const ecrad_ckd_gas_t& g = m.single_gas[j];
     DevCkdGas& dg = d.gas[j];
@@ -133,13 +167,24 @@ int setup_ckd(ecrad_hip_handle_t h, const ecrad_ckd_model_t& m, DevCkdModel& d) 
     dg.d_log_mole_frac = g.d_log_mole_frac; dg.mole_frac1 = std::exp(g.log_mole_frac1);
     if (g.i_conc_dependence != ECRAD_CONC_NONE && (g.i_gas_code < 1 || g.i_gas_code > ECRAD_NMAXGASES))
       return fail(h, ECRAD_EINVAL, "ckd model: gas code out of range");
-    if (g.i_conc_dependence == ECRAD_CONC_LUT && g.n_mole_frac > 32767)
-      return fail(h, ECRAD_EUNSUPPORTED, "ckd model: mole-fraction LUT too long");
-    const size_t n = g.i_conc_dependence == ECRAD_CONC_LUT ? n3 * g.n_mole_frac : n3;
-    if (f32) st = upload_as_float(h, g.molar_abs, n, &dg.molar_abs);
-    else { const double* p; st = upload<double>(h, g.molar_abs, n, &p); dg.molar_abs = p; }
-    if (st) return st;
+    const bool lut = g.i_conc_dependence == ECRAD_CONC_LUT;
+    if (lut && g.n_mole_frac < 2) return fail(h, ECRAD_EINVAL, "ckd model: mole-fraction LUT too short");
+    const std::vector<double> quads = build_quads(g.molar_abs, m.ng, m.npress, m.ntemp, lut ? g.n_mole_frac : 1);
+    const size_t off = all_quads.size() / 4;
+    if (off + quads.size() / 4 > 0x0fffffffull) return fail(h, ECRAD_EUNSUPPORTED, "ckd model: absorption tables too large");
+    all_quads.insert(all_quads.end(), quads.begin(), quads.end());
+    const int n = lut ? 2 : 1;
+    if (hot.nquad + n > kMaxQuads)
+      return fail(h, ECRAD_EUNSUPPORTED, "ckd model needs more than 10 table look-ups per layer (ngas + LUT gases)");
+    for (int k = 0; k < n; ++k) {
+      hot.qoff[hot.nquad] = (uint32_t)(off + (k == 1 ? slice : 0));
+      if (lut) hot.lutmask |= 1u << hot.nquad;
+      hot.nquad++;
+    }
   }
+  if (f32) st = upload_as_float(h, all_quads.data(), all_quads.size(), &hot.tab);
+  else { const double* p; st = upload<double>(h, all_quads.data(), all_quads.size(), &p); hot.tab = p; }
+  if (st) return st;
   return ECRAD_OK;
 }
 
@@ -668,27 +713,27 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
   if (c.do_lw) {                                                                        // :422-457
     const DevCkdModel& m = h->hcfg.gas_lw;
     const int nct = (c.i_solver_lw != ECRAD_SOLVER_CLOUDLESS) ? c.n_cloud_types : 0;
-    const size_t lds = lds_bytes(m.ngas, nct);
+    const size_t lds = lds_bytes(m.hot.nquad, nct);
     if (lw_mcica) {
       HIP_TRY(h, hipMemsetAsync(prep.od_scaling_lw, 0, (size_t)c.n_g_lw * nlev * r.nloc * 8, stream));
       HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_lw, 997, prep.od_scaling_lw,
                                         prep.total_cloud_cover_lw, prep.rng_state, mcica_work));
     }
     if (lw_tc) HIP_TRY(h, launch_lw_tc(h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_lw, counters));
-    else HIP_TRY(h, launch_lw_ica(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_lw, counters));
+    else HIP_TRY(h, launch_lw_ica(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_lw, counters, m));
   }
   HIP_TRY(h, hipEventRecord(h->evs[2], stream));
   if (c.do_sw) {                                                                        // :459-499
     const DevCkdModel& m = h->hcfg.gas_sw;
     const int nct = (c.i_solver_sw != ECRAD_SOLVER_CLOUDLESS) ? c.n_cloud_types : 0;
-    const size_t lds = lds_bytes(m.ngas, nct);
+    const size_t lds = lds_bytes(m.hot.nquad, nct);
     if (sw_mcica) {
       HIP_TRY(h, hipMemsetAsync(prep.od_scaling_sw, 0, (size_t)c.n_g_sw * nlev * r.nloc * 8, stream));
       HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_sw, 0, prep.od_scaling_sw,
                                         prep.total_cloud_cover_sw, prep.rng_state, mcica_work));
     }
     if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_sw, counters + 16));
-    else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_sw, counters + 16));
+    else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m));
   }
   HIP_TRY(h, hipEventRecord(h->evs[3], stream));
   HIP_TRY(h, launch_spectral_post(stream, h->dcfg, din, dfx));                          // :503-504
@@ -755,9 +800,9 @@ int ecrad_hip_optics(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, in
   if (c.do_clouds) HIP_TRY(h, launch_crop(stream, h->dcfg, cx.din));
   const int nct = c.do_clouds ? c.n_cloud_types : 0;
   if (c.do_sw) HIP_TRY(h, launch_optics_dump(true, h->ngp_sw, h->hcfg.gas_sw.table_f32, grid_for(h, r.nloc, h->ngp_sw),
-                                             lds_bytes(h->hcfg.gas_sw.ngas, nct), stream, h->dcfg, cx.din, dop));
+                                             lds_bytes(h->hcfg.gas_sw.hot.nquad, nct), stream, h->dcfg, cx.din, dop));
   if (c.do_lw) HIP_TRY(h, launch_optics_dump(false, h->ngp_lw, h->hcfg.gas_lw.table_f32, grid_for(h, r.nloc, h->ngp_lw),
-                                             lds_bytes(h->hcfg.gas_lw.ngas, nct), stream, h->dcfg, cx.din, dop));
+                                             lds_bytes(h->hcfg.gas_lw.hot.nquad, nct), stream, h->dcfg, cx.din, dop));
   if (host_mem) {
     for (const OF& f : fields)
       if (out->*(f.host)) HIP_TRY(h, hipMemcpyAsync(out->*(f.host), dop.*(f.dev), f.n * 8, hipMemcpyDeviceToHost, stream));

@@ -9,6 +9,7 @@ namespace ecrad {
 constexpr int kMaxGas = ECRAD_NMAXGASES;
 constexpr int kMaxCloudTypes = ECRAD_NMAXCLOUDTYPES;
 constexpr int kNReg = 3;
+constexpr int kMaxQuads = 10;   // quad loads per layer: ngas + (number of LUT gases); 9 for ecCKD LW-32
 constexpr double kAccelDueToGravity = 9.80665;          // radiation_constants.F90:26
 constexpr double kAirMolarMass = 28.970;                // radiation_gas_constants.F90:41
 constexpr double kH2OMolarMass = 18.0152833;            // radiation_gas_constants.F90:44
@@ -19,7 +20,16 @@ struct DevCkdGas {
   int32_t n_mole_frac;
   int32_t pad_;
   double reference_mole_frac, log_mole_frac1, d_log_mole_frac, mole_frac1;
-  const void* molar_abs;      // float or double (see DevCkdModel::table_f32), (ng,npress,ntemp[,nconc])
+};
+
+// What the lane=g loops need from a gas-optics model, small enough to live in scalar registers:
+// one table holding the quads (see optics_device.h) of every gas and their offsets in it.
+struct GasHot {
+  const void* tab;             // quads of float or double, per gas (ng,npress-1,ntemp-1[,nconc]) x 4
+  uint32_t qoff[kMaxQuads];    // offset of quad k's array in `tab`, in quads (+ one concentration slice for
+                               // the upper half of a look-up-table gas)
+  int32_t nquad;
+  uint32_t lutmask;            // bit k: quad k belongs to a look-up-table gas (add the layer's I_LUT offset)
 };
 
 struct DevCkdModel {
@@ -29,11 +39,13 @@ struct DevCkdModel {
   double log_pressure1, d_log_pressure, d_temperature;
   double temperature1_planck, d_temperature_planck;
   const double* temperature1;              // (npress)
-  const void*   planck_function;           // (ng,nplanck) float/double
+  const void*   planck_function;           // (T,T+1) pairs of float/double, (ng,nplanck-1) x 2
   const double* norm_solar_irradiance;     // (ng)
   const double* norm_amplitude_solar_irradiance;
   const double* rayleigh_molar_scat;       // (ng)
   DevCkdGas gas[kMaxGas];
+  // Flattened list of the quad loads one layer needs (one per gas in order, two for a look-up-table gas)
+  GasHot hot;
 };
 
 struct DevCloudOptics {
@@ -131,6 +143,18 @@ struct DevCloudPrep {
   double* total_cloud_cover_sw;   // [nloc]
   double* total_cloud_cover_lw;   // [nloc]
   int32_t* rng_state;             // [607][nloc] lagged-Fibonacci state, column fastest
+};
+
+// Argument block of the spectral (lane = g) kernels; see kernarg_block() in kernels_common.h
+struct SpectralArgs {
+  const DevConfig* cfg;
+  DevInputs in;
+  DevFlux fx;
+  DevCloudPrep prep;
+  double* scratch;             // block-private sweep scratch, `per_block` doubles each
+  size_t per_block;
+  int* counter;                // dynamic work queue (next column group)
+  GasHot gas;
 };
 
 }  // namespace ecrad

@@ -14,48 +14,80 @@
 
 namespace ecrad {
 
-enum { L_T1 = 0, L_SU1, L_SD1, L_R2, L_T2, L_SU2, L_SD2, L_ALB, L_SRC, L_NUM };
+// Block-private scratch, level-major: per level and lane
+//   P_CLR  pair (transmittance, source_up) of the clear-sky layer        S_SD1  its source_dn
+//   P_RT2  pair (reflectance, transmittance) of a cloudy layer           P_S2   pair (source_up, source_dn)
+//   P_AS   pair (albedo, source) below the half level (cloudy-sky sweep)
+// The cloudless solver only needs P_CLR.
+enum { P_CLR = 0, S_SD1 = 2, P_RT2 = 3, P_S2 = 5, P_AS = 7, L_WIDTH_FULL = 9, L_WIDTH_CLEAR = 2 };
+
+struct LwScratch {
+  double* base;
+  int width;
+  ECRAD_DEV double2& pair(int off, int lev, int tid) const {
+    return reinterpret_cast<double2*>(base + ((size_t)lev * width + off) * kBlock)[tid];
+  }
+  ECRAD_DEV double& single(int off, int lev, int tid) const {
+    return base[((size_t)lev * width + off) * kBlock + tid];
+  }
+};
+
+constexpr int kLwBatch = ECRAD_SWEEP_BATCH;
 
 template <typename TAB, int NGP, int MODE>
-__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevFlux fx,
-                                                       DevCloudPrep prep, double* scratch_base, size_t scratch_per_block,
-                                                       int* work_counter) {
+__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
-  const DevConfig& cfg = *cfgp;
-  const DevCkdModel& m = cfg.gas_lw;
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
   const int glane = tid % NGP, cib = tid / NGP;
-  const int ng = m.ng, nlev = in.nlev;
-  const size_t ncol = in.ncol;
-  const int ncol_loc = in.iendcol - in.istartcol + 1;
-  const int ngroups = (ncol_loc + CPB - 1) / CPB;
   const bool want_clouds = MODE != 0;
-  const int nct = want_clouds ? cfg.n_cloud_types : 0;
-  const LdsLayout L = make_lds(smem, m.ngas, nct);
-  const Scratch s{scratch_base + (size_t)blockIdx.x * scratch_per_block, nlev + 1};
-  const int g = glane < ng ? glane : ng - 1;
-  const int ib = cfg.i_band_from_reordered_g_lw[g] - 1;
-  const bool have_clear_out = cfg.do_clear != 0;
-  const bool do_deriv = cfg.do_lw_derivatives != 0 && fx.lw_derivatives != nullptr;
+#ifdef ECRAD_TIMING
+  PhaseTimer tm;
+  tm.reset();
+  int tm_levels = 0;
+#endif
 
   for (;;) {
+    // ---- per column group (see kernarg_block() for why the arguments are re-read per phase) --------
+    const SpectralArgs& a = kernarg_block<SpectralArgs>();
+    const DevConfig& cfg = *a.cfg;
+    const DevCkdModel& m = cfg.gas_lw;
+    const int ng = m.ng, nlev = a.in.nlev;
+    const size_t ncol = a.in.ncol;
+    const int ncol_loc = a.in.iendcol - a.in.istartcol + 1;
+    const int ngroups = (ncol_loc + CPB - 1) / CPB;
+    const int nct = want_clouds ? cfg.n_cloud_types : 0;
+    const int nquad = a.gas.nquad;
     __syncthreads();
-    if (tid == 0) next_group = atomicAdd(work_counter, 1);
+    if (tid == 0) next_group = atomicAdd(a.counter, 1);
     __syncthreads();
     const int grp = next_group;
     if (grp >= ngroups) break;
+#ifdef ECRAD_TIMING
+    tm.start();
+#endif
+
+    const LdsLayout L = make_lds(smem, nquad, nct);
+    const LwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block, MODE == 0 ? L_WIDTH_CLEAR : L_WIDTH_FULL};
+    const int g = glane < ng ? glane : ng - 1;
+    const int ib = cfg.i_band_from_reordered_g_lw[g] - 1;
+    const bool have_clear_out = cfg.do_clear != 0;
+    const bool do_deriv = cfg.do_lw_derivatives != 0 && a.fx.lw_derivatives != nullptr;
+    const bool use_aerosols = cfg.use_aerosols != 0;
+    const bool cloud_scattering = cfg.do_lw_cloud_scattering != 0;
+    const double cloud_fraction_threshold = cfg.cloud_fraction_threshold;
+
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
-    const int col = in.istartcol - 1 + cloc;
+    const int col = a.in.istartcol - 1 + cloc;
     const bool valid = col_ok && glane < ng;
     const bool lead = glane == 0 && col_ok;
-    const double albedo = albedo_lw_g(cfg, in, col, g);
-    const double emission = planck_at<TAB>(m, in.skin_temperature[col], g) * (1.0 - albedo);
+    const double albedo = albedo_lw_g(cfg, a.in, col, g);
+    const double emission = planck_at<TAB>(m, a.in.skin_temperature[col], g) * (1.0 - albedo);
     double tcc = 0.0;
-    if (MODE == 2) tcc = prep.total_cloud_cover_lw[cloc];
+    if (MODE == 2) tcc = a.prep.total_cloud_cover_lw[cloc];
     LevMask cloudy;
     cloudy.clear();
     int ict = nlev;              // 0-based index of the first cloudy layer (= its top half level)
@@ -66,42 +98,71 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(const D
     // ---- pass A: top -> bottom ---------------------------------------------------------------------
     if (lead) {                  // flux_dn(:,1) = 0
       const size_t o = col;
-      fx.lw_dn[o] = 0.0;
-      if (have_clear_out) fx.lw_dn_clear[o] = 0.0;
+      a.fx.lw_dn[o] = 0.0;
+      if (have_clear_out) a.fx.lw_dn_clear[o] = 0.0;
     }
     for (int l0 = 0; l0 < nlev; l0 += NGP) {
       __syncthreads();
       {
+        const SpectralArgs& b = kernarg_block<SpectralArgs>();
         const int lev = l0 + glane;
-        if (lev < nlev) level_scalars<false>(cfg, m, in, L, tid, col, lev, want_clouds);
+        if (lev < nlev) level_scalars<false>(*b.cfg, b.cfg->gas_lw, b.in, L, tid, col, lev, want_clouds);
       }
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
+      const SpectralArgs& c0 = kernarg_block<SpectralArgs>();
+      const void* const tab = c0.gas.tab;
+      const PlanckTab<TAB> pt{c0.cfg->gas_lw.planck_function, ng};
+      double* const lw_dn = c0.fx.lw_dn;
+      double* const lw_dn_clear = have_clear_out ? c0.fx.lw_dn_clear : nullptr;
+#if ECRAD_PREFETCH
+      // software prefetch of the next layer's table quads (see kernel_ica_sw.hip)
+      GasRegs<TAB> cur;
+      gas_load<TAB>(tab, nquad, L, cib * NGP, g, cur);
+#endif
+      ECRAD_LAP0(tm, 7);     // level scalars + group set-up (timing build: booked with the up-sweep)
       for (int j = 0; j < nl; ++j) {
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
-        double od = gas_absorption_od<TAB>(m, L, slot, g);
-        if (lev == 0) planck_top = planck_lookup<TAB>(m, L.I(I_PL_TOP, slot), L.D(F_PLW_TOP, slot), g);
-        const double planck_bot = planck_lookup<TAB>(m, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
-        if (cfg.use_aerosols) {
-          const AerosolLayer a = aerosol_layer<false>(cfg, in, L, slot, col, lev, ib);
-          od = od + a.od;   // radiation_aerosol_optics.F90:805-818 (no longwave aerosol scattering)
+        const int nq = launder_uniform(nquad);
+#if ECRAD_PREFETCH
+        GasRegs<TAB> nxt;
+        if (j + 1 < nl) gas_load<TAB>(tab, nq, L, slot + 1, g, nxt);
+#else
+        GasRegs<TAB> cur;
+        gas_load<TAB>(tab, nq, L, slot, g, cur);
+#endif
+#ifdef ECRAD_TIMING
+        ECRAD_LAP(tm, 0, cur.q[0].x);   // (timing build: table loads alone, booked under "scalars")
+#endif
+        if (lev == 0) planck_top = pt.lookup(L.I(I_PL_TOP, slot), L.D(F_PLW_TOP, slot), g);
+        const double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
+        ECRAD_LAP(tm, 1, planck_bot);   // table + Planck loads returned
+        double od = gas_combine<TAB>(nq, L, slot, cur);
+        ECRAD_LAP(tm, 2, od);           // combine
+        if (use_aerosols) {
+          const SpectralArgs& b = kernarg_block<SpectralArgs>();
+          const AerosolLayer al = aerosol_layer<false>(*b.cfg, b.in, L, slot, col, lev, ib);
+          od = od + al.od;   // radiation_aerosol_optics.F90:805-818 (no longwave aerosol scattering)
         }
         const LwCoef c = no_scattering_lw(od, planck_top, planck_bot);
-        s.at(L_T1, lev, tid) = c.transmittance;
-        s.at(L_SU1, lev, tid) = c.source_up;
-        s.at(L_SD1, lev, tid) = c.source_dn;
+        ECRAD_LAP(tm, 3, c.source_dn);  // layer coefficients
+#if !(ECRAD_ABLATE & 8)
+        s.pair(P_CLR, lev, tid) = make_double2(c.transmittance, c.source_up);
+#endif
+        ECRAD_LAP0(tm, 4);              // scratch store acknowledged
         if (MODE != 0) {
-          const bool layer_cloudy = L.D(F_FRAC, slot) >= cfg.cloud_fraction_threshold;
+          const bool layer_cloudy = L.D(F_FRAC, slot) >= cloud_fraction_threshold;
           if (layer_cloudy) {
             if (!cloudy.any()) { ict = lev; fdn_ctop = fdn_c; }
             cloudy.set(lev);
-            const CloudLayer cl = cloud_layer<false>(cfg, L, slot, ib);
+            const SpectralArgs& b = kernarg_block<SpectralArgs>();
+            const CloudLayer cl = cloud_layer<false>(*b.cfg, L, slot, ib);
             double od_cloud_new = cl.od;
-            if (MODE == 2) od_cloud_new = prep.od_scaling_lw[g + (size_t)ng * (lev + (size_t)nlev * cloc)] * cl.od;
+            if (MODE == 2) od_cloud_new = b.prep.od_scaling_lw[g + (size_t)ng * (lev + (size_t)nlev * cloc)] * cl.od;
             const double od_total = od + od_cloud_new;
             LwCoef c2;
-            if (cfg.do_lw_cloud_scattering) {
+            if (cloud_scattering) {
               double ssa_total = 0.0, g_total = 0.0;
               if (MODE == 1) {    // radiation_homogeneous_lw.F90:218-228
                 if (od_total > 0.0) ssa_total = cl.ssa * od_cloud_new / od_total;
@@ -117,25 +178,35 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(const D
             } else {
               c2 = no_scattering_lw(od_total, planck_top, planck_bot);
             }
-            s.at(L_R2, lev, tid) = c2.reflectance;
-            s.at(L_T2, lev, tid) = c2.transmittance;
-            s.at(L_SU2, lev, tid) = c2.source_up;
-            s.at(L_SD2, lev, tid) = c2.source_dn;
+            s.pair(P_RT2, lev, tid) = make_double2(c2.reflectance, c2.transmittance);
+            s.pair(P_S2, lev, tid) = make_double2(c2.source_up, c2.source_dn);
+          } else if (cloudy.any()) {
+            // clear layer below the first cloudy one: the cloudy-sky sweep needs its downward source too
+            s.single(S_SD1, lev, tid) = c.source_dn;
           }
         }
         // clear-sky downward recurrence (radiation_adding_ica_lw.F90:305-311) + sum over g
         fdn_c = c.transmittance * fdn_c + c.source_dn;
         const double sd = group_sum<NGP>(valid ? fdn_c : 0.0);
+        ECRAD_LAP(tm, 5, sd);           // cross-lane sum
         if (lead) {
           const size_t o = col + ncol * (lev + 1);
-          fx.lw_dn[o] = sd;
-          if (have_clear_out) fx.lw_dn_clear[o] = sd;
+          lw_dn[o] = sd;
+          if (lw_dn_clear) lw_dn_clear[o] = sd;
         }
+        ECRAD_LAP0(tm, 6);              // flux store acknowledged
+#ifdef ECRAD_TIMING
+        tm_levels++;
+#endif
         planck_top = planck_bot;
+#if ECRAD_PREFETCH
+        if (j + 1 < nl) cur = nxt;
+#endif
       }
     }
 
     // ---- pass B1: clear-sky upward sweep (+ clear-sky derivatives) --------------------------------
+    const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
     double fup = emission + albedo * fdn_c;
     const double fup_surf_clear = fup;
     double dsum = group_sum<NGP>(valid ? fup : 0.0);
@@ -146,29 +217,50 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(const D
       if (have_clear_out) fx.lw_up_clear[o] = dsum;
       if (do_deriv) fx.lw_derivatives[o] = 1.0;
     }
-    for (int l = nlev - 1; l >= 0; --l) {
-      const double T = s.at(L_T1, l, tid);
-      fup = T * fup + s.at(L_SU1, l, tid);
-      const double su = group_sum<NGP>(valid ? fup : 0.0);
-      double sder = 0.0;
-      if (do_deriv) { deriv = deriv * T; sder = group_sum<NGP>(valid ? deriv : 0.0); }
-      if (lead) {
-        const size_t o = col + ncol * l;
-        fx.lw_up[o] = su;
-        if (have_clear_out) fx.lw_up_clear[o] = su;
-        if (do_deriv) fx.lw_derivatives[o] = sder;
+#if !(ECRAD_ABLATE & 4)
+    {
+      // records of the next kLwBatch layers are requested before the current batch is consumed
+      double2 cur[kLwBatch], nxt[kLwBatch];
+#pragma unroll
+      for (int k = 0; k < kLwBatch; ++k)
+        if (nlev - 1 - k >= 0) cur[k] = s.pair(P_CLR, nlev - 1 - k, tid);
+      for (int l0 = nlev - 1; l0 >= 0; l0 -= kLwBatch) {
+#pragma unroll
+        for (int k = 0; k < kLwBatch; ++k)
+          if (l0 - kLwBatch - k >= 0) nxt[k] = s.pair(P_CLR, l0 - kLwBatch - k, tid);
+#pragma unroll
+        for (int k = 0; k < kLwBatch; ++k) {
+          const int l = l0 - k;
+          if (l >= 0) {
+            const double T = cur[k].x;
+            fup = T * fup + cur[k].y;
+            const double su = group_sum<NGP>(valid ? fup : 0.0);
+            double sder = 0.0;
+            if (do_deriv) { deriv = deriv * T; sder = group_sum<NGP>(valid ? deriv : 0.0); }
+            if (lead) {
+              const size_t o = col + ncol * l;
+              fx.lw_up[o] = su;
+              if (have_clear_out) fx.lw_up_clear[o] = su;
+              if (do_deriv) fx.lw_derivatives[o] = sder;
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kLwBatch; ++k) cur[k] = nxt[k];
       }
     }
+#endif
     if (valid) {
       const size_t og = g + (size_t)ng * col;
       fx.lw_dn_surf_g[og] = fdn_c;
       fx.lw_up_toa_g[og] = fup;
       if (have_clear_out) { fx.lw_dn_surf_clear_g[og] = fdn_c; fx.lw_up_toa_clear_g[og] = fup; }
     }
+    ECRAD_LAP0(tm, 7);                  // clear-sky upward sweep
     if (MODE == 0) continue;
 
     // ---- cloudy-sky calculation ---------------------------------------------------------------------
-    const bool do_set2 = (MODE == 1) ? (cloudy.any() || !have_clear_out) : (tcc >= cfg.cloud_fraction_threshold);
+    const bool do_set2 = (MODE == 1) ? (cloudy.any() || !have_clear_out) : (tcc >= cloud_fraction_threshold);
     if (MODE == 2 && lead) fx.cloud_cover_lw[col] = tcc;
     if (!do_set2) continue;
     if (!cloudy.any()) { ict = nlev; fdn_ctop = fdn_c; }
@@ -176,28 +268,28 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(const D
     const bool blend = w < 1.0;
     // upward sweep from the surface to cloud top: albedo & source below each half level
     double alb = albedo, src = emission;
-    s.at(L_ALB, nlev, tid) = alb;
-    s.at(L_SRC, nlev, tid) = src;
+    s.pair(P_AS, nlev, tid) = make_double2(alb, src);
     for (int l = nlev - 1; l >= ict; --l) {
       if (cloudy.test(l)) {
-        const double R = s.at(L_R2, l, tid), T = s.at(L_T2, l, tid);
+        const double2 rt = s.pair(P_RT2, l, tid), sud = s.pair(P_S2, l, tid);
+        const double R = rt.x, T = rt.y;
         const double inv = 1.0 / (1.0 - alb * R);
-        const double src_new = s.at(L_SU2, l, tid) + T * (src + alb * s.at(L_SD2, l, tid)) * inv;
+        const double src_new = sud.x + T * (src + alb * sud.y) * inv;
         alb = R + T * T * alb * inv;
         src = src_new;
       } else {
-        const double T = s.at(L_T1, l, tid);
-        const double src_new = s.at(L_SU1, l, tid) + T * (src + alb * s.at(L_SD1, l, tid));
+        const double2 ts = s.pair(P_CLR, l, tid);
+        const double T = ts.x;
+        const double src_new = ts.y + T * (src + alb * s.single(S_SD1, l, tid));
         alb = T * T * alb;
         src = src_new;
       }
-      s.at(L_ALB, l, tid) = alb;
-      s.at(L_SRC, l, tid) = src;
+      s.pair(P_AS, l, tid) = make_double2(alb, src);
     }
     // flux at cloud top and upward through the clear layers above it
     fup = src + alb * fdn_ctop;
     for (int l = ict; l >= 0; --l) {
-      if (l < ict) fup = s.at(L_T1, l, tid) * fup + s.at(L_SU1, l, tid);
+      if (l < ict) { const double2 ts = s.pair(P_CLR, l, tid); fup = ts.x * fup + ts.y; }
       const double su = group_sum<NGP>(valid ? fup : 0.0);
       if (lead) {
         const size_t o = col + ncol * l;
@@ -208,13 +300,15 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(const D
     // downward sweep below cloud top
     double fdn = fdn_ctop;
     for (int l = ict; l < nlev; ++l) {
-      const double albn = s.at(L_ALB, l + 1, tid), srcn = s.at(L_SRC, l + 1, tid);
+      const double2 as = s.pair(P_AS, l + 1, tid);
+      const double albn = as.x, srcn = as.y;
       if (cloudy.test(l)) {
-        const double R = s.at(L_R2, l, tid);
+        const double2 rt = s.pair(P_RT2, l, tid);
+        const double R = rt.x;
         const double inv = 1.0 / (1.0 - albn * R);
-        fdn = (s.at(L_T2, l, tid) * fdn + R * srcn + s.at(L_SD2, l, tid)) * inv;
+        fdn = (rt.y * fdn + R * srcn + s.pair(P_S2, l, tid).y) * inv;
       } else {
-        fdn = s.at(L_T1, l, tid) * fdn + s.at(L_SD1, l, tid);
+        fdn = s.pair(P_CLR, l, tid).x * fdn + s.single(S_SD1, l, tid);
       }
       fup = albn * fdn + srcn;
       const double su = group_sum<NGP>(valid ? fup : 0.0);
@@ -227,7 +321,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(const D
     }
     if (ict == nlev) {   // no cloudy layer at all: surface values come from the clear-sky sweep
       fdn = fdn_c;
-      fup = s.at(L_ALB, nlev, tid) * fdn + s.at(L_SRC, nlev, tid);
+      const double2 as = s.pair(P_AS, nlev, tid);
+      fup = as.x * fdn + as.y;
     }
     if (valid) {
       const size_t og = g + (size_t)ng * col;
@@ -239,10 +334,10 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(const D
       // modify_lw_derivatives_ica with weight 1-tcc towards the clear-sky profile already stored
       const double ssurf = group_sum<NGP>(valid ? fup : 0.0);
       double d = fup / ssurf;
-      const bool modify = MODE == 2 && tcc < 1.0 - cfg.cloud_fraction_threshold;
+      const bool modify = MODE == 2 && tcc < 1.0 - cloud_fraction_threshold;
       const double wclr = 1.0 - tcc;
       for (int l = nlev - 1; l >= 0; --l) {
-        d = d * (cloudy.test(l) ? s.at(L_T2, l, tid) : s.at(L_T1, l, tid));
+        d = d * (cloudy.test(l) ? s.pair(P_RT2, l, tid).y : s.pair(P_CLR, l, tid).x);
         const double sder = group_sum<NGP>(valid ? d : 0.0);
         if (lead) {
           const size_t o = col + ncol * l;
@@ -252,35 +347,43 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(const D
     }
     (void)fup_surf_clear;
   }
+#ifdef ECRAD_TIMING
+  if (blockIdx.x == 0 && tid == 0)
+    printf("lw_ica timing (cycles/level): scalars %.0f loads %.0f combine %.0f coef %.0f scratch-store %.0f sum %.0f flux-store %.0f upsweep %.0f levels %d\n",
+           (double)tm.acc[0] / tm_levels, (double)tm.acc[1] / tm_levels, (double)tm.acc[2] / tm_levels, (double)tm.acc[3] / tm_levels,
+           (double)tm.acc[4] / tm_levels, (double)tm.acc[5] / tm_levels, (double)tm.acc[6] / tm_levels, (double)tm.acc[7] / tm_levels, tm_levels);
+#endif
 }
 
 template <typename TAB, int NGP>
-static hipError_t launch_lw_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const DevConfig* cfg,
-                                 const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                                 double* scratch, size_t per_block, int* counter) {
+static hipError_t launch_lw_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const SpectralArgs& args) {
   switch (mode) {
     case ECRAD_SOLVER_CLOUDLESS:
-      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 0>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter);
+      ECRAD_ALLOW_LDS((lw_ica_kernel<TAB, NGP, 0>), lds);
+      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 0>), grid, dim3(kBlock), lds, st, args);
       break;
     case ECRAD_SOLVER_HOMOGENEOUS:
-      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 1>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter);
+      ECRAD_ALLOW_LDS((lw_ica_kernel<TAB, NGP, 1>), lds);
+      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 1>), grid, dim3(kBlock), lds, st, args);
       break;
     default:
-      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 2>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter);
+      ECRAD_ALLOW_LDS((lw_ica_kernel<TAB, NGP, 2>), lds);
+      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 2>), grid, dim3(kBlock), lds, st, args);
       break;
   }
   return hipGetLastError();
 }
 
 size_t lw_ica_scratch_doubles(int mode, int nlev) {
-  return (size_t)(mode == ECRAD_SOLVER_CLOUDLESS ? L_R2 : L_NUM) * (nlev + 1) * kBlock;
+  return (size_t)(mode == ECRAD_SOLVER_CLOUDLESS ? L_WIDTH_CLEAR : L_WIDTH_FULL) * (nlev + 1) * kBlock;
 }
 
 hipError_t launch_lw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig* cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                         double* scratch, size_t per_block, int* counter) {
+                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m) {
   dim3 g(grid);
-#define ECRAD_DISPATCH(T, N) return launch_lw_mode<T, N>(mode, g, lds, st, cfg, in, fx, prep, scratch, per_block, counter)
+  const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot};
+#define ECRAD_DISPATCH(T, N) return launch_lw_mode<T, N>(mode, g, lds, st, args)
   if (table_f32) {
     if (ngp == 16) ECRAD_DISPATCH(float, 16);
     if (ngp == 32) ECRAD_DISPATCH(float, 32);

@@ -48,16 +48,41 @@ ECRAD_DEV void sw_up_step(const SwScratch& s, int set, int lev, int tid, const S
   p0.y = (c.ref_diff * st.sig * c.trans_dir_dir + c.trans_dir_diff) * inv;         // b
   p1.x = c.trans_dir_dir;
   p1.y = st.alb;
+#if !(ECRAD_ABLATE & 8)
   s.pair(set, 0, lev, tid) = p0;
   s.pair(set, 1, lev, tid) = p1;
   s.single(set, lev, tid) = st.sig;
+#endif
   const double sig_new = c.ref_dir + c.trans_diff * (st.sig * c.trans_dir_dir + st.alb * c.trans_dir_diff) * inv;
   st.alb = c.ref_diff + c.trans_diff * c.trans_diff * st.alb * inv;
   st.sig = sig_new;
 }
 
+// One layer's record for the flux sweep.
+struct SwRec {
+  double2 p0, p1;
+  double sig;
+};
+
+constexpr int kSwBatch = ECRAD_SWEEP_BATCH;     // layers fetched per batch in the flux sweep (software pipelining depth)
+
+ECRAD_DEV void sw_load_batch(const SwScratch& s, bool set2, int lcb, int tid, int nlev, int lay0, SwRec (&r)[kSwBatch]) {
+#pragma unroll
+  for (int k = 0; k < kSwBatch; ++k) {
+    const int lay = lay0 + k;
+    if (lay < nlev) {
+      const int set = (set2 && lay <= lcb) ? 1 : 0;
+      r[k].p0 = s.pair(set, 0, lay, tid);
+      r[k].p1 = s.pair(set, 1, lay, tid);
+      r[k].sig = s.single(set, lay, tid);
+    }
+  }
+}
+
 // Flux sweep (top -> bottom) for one coefficient set; for SET2 layers below the lowest cloudy layer
 // `lcb` reuse set 1's records (identical there).  Sums over g are written by the group leader.
+// The records of the next kSwBatch layers are requested before the current batch is consumed, so that
+// each wave keeps 2*kSwBatch layers of scratch reads in flight (the sweep has almost no arithmetic).
 template <int NGP>
 ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, int nlev, double mu0, double incoming,
                              double sig_top, bool valid, bool leader, size_t ncol, int col,
@@ -67,16 +92,7 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
   double Fd = incoming, fdn = 0.0, fup = incoming * sig_top;
   fup_toa = fup;
   const bool blend = weight < 1.0;
-  for (int l = 0; l <= nlev; ++l) {
-    if (l > 0) {
-      const int set = (set2 && (l - 1) <= lcb) ? 1 : 0;
-      const double2 p0 = s.pair(set, 0, l - 1, tid);
-      const double2 p1 = s.pair(set, 1, l - 1, tid);
-      const double sign = s.single(set, l - 1, tid);
-      fdn = p0.x * fdn + Fd * p0.y;
-      Fd = Fd * p1.x;
-      fup = p1.y * fdn + sign * Fd;
-    }
+  auto emit = [&](int l) {
     const double su = group_sum<NGP>(valid ? fup : 0.0);
     const double sd = group_sum<NGP>(valid ? fdn : 0.0);
     const double sdir = group_sum<NGP>(valid ? Fd : 0.0) * mu0;
@@ -92,59 +108,83 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
       out_dn[o] = vd;
       if (out_dir) out_dir[o] = vdir;
     }
+  };
+  SwRec cur[kSwBatch], nxt[kSwBatch];
+  sw_load_batch(s, set2, lcb, tid, nlev, 0, cur);
+  emit(0);
+  for (int lay0 = 0; lay0 < nlev; lay0 += kSwBatch) {
+    if (lay0 + kSwBatch < nlev) sw_load_batch(s, set2, lcb, tid, nlev, lay0 + kSwBatch, nxt);
+#pragma unroll
+    for (int k = 0; k < kSwBatch; ++k) {
+      if (lay0 + k < nlev) {
+        fdn = cur[k].p0.x * fdn + Fd * cur[k].p0.y;
+        Fd = Fd * cur[k].p1.x;
+        fup = cur[k].p1.y * fdn + cur[k].sig * Fd;
+        emit(lay0 + k + 1);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kSwBatch; ++k) cur[k] = nxt[k];
   }
   fdn_surf = fdn;
   fdir_surf = Fd * mu0;
 }
 
+// uniform switches of the level loop, gathered once per column group
+enum { SWF_AEROSOLS = 1, SWF_DELTA_GASES = 2 };
+
 template <typename TAB, int NGP, int MODE>
-__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(const DevConfig* __restrict__ cfgp, DevInputs in,
-                                                                        DevFlux fx, DevCloudPrep prep, double* scratch_base,
-                                                                        size_t scratch_per_block, int* work_counter) {
+__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
-  const DevConfig& cfg = *cfgp;
-  const DevCkdModel& m = cfg.gas_sw;
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
   const int glane = tid % NGP, cib = tid / NGP;
-  const int ng = m.ng, nlev = in.nlev;
-  const size_t ncol = in.ncol;
-  const int ncol_loc = in.iendcol - in.istartcol + 1;
-  const int ngroups = (ncol_loc + CPB - 1) / CPB;
   const bool want_clouds = MODE != 0;
-  const int nct = want_clouds ? cfg.n_cloud_types : 0;
-  const LdsLayout L = make_lds(smem, m.ngas, nct);
-  const SwScratch s{scratch_base + (size_t)blockIdx.x * scratch_per_block, nlev};
-  const int g = glane < ng ? glane : ng - 1;
-  const int ib = cfg.i_band_from_reordered_g_sw[g] - 1;
   const bool leader = glane == 0;
-  const double ray_g = m.rayleigh_molar_scat[g];
-  const bool have_clear_out = cfg.do_clear != 0;
 
   for (;;) {
+    // ---- per column group ---------------------------------------------------------------------------
+    const SpectralArgs& a = kernarg_block<SpectralArgs>();
+    const DevConfig& cfg = *a.cfg;
+    const DevCkdModel& m = cfg.gas_sw;
+    const int ng = m.ng, nlev = a.in.nlev;
+    const size_t ncol = a.in.ncol;
+    const int ncol_loc = a.in.iendcol - a.in.istartcol + 1;
+    const int ngroups = (ncol_loc + CPB - 1) / CPB;
+    const int nct = want_clouds ? cfg.n_cloud_types : 0;
+    const int nquad = a.gas.nquad;
     // dynamic work distribution: blocks pull the next group of CPB columns
     __syncthreads();
-    if (tid == 0) next_group = atomicAdd(work_counter, 1);
+    if (tid == 0) next_group = atomicAdd(a.counter, 1);
     __syncthreads();
     const int grp = next_group;
     if (grp >= ngroups) break;
 
+    const LdsLayout L = make_lds(smem, nquad, nct);
+    const SwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block, nlev};
+    const int g = glane < ng ? glane : ng - 1;
+    const int ib = cfg.i_band_from_reordered_g_sw[g] - 1;
+    const double ray_g = m.rayleigh_molar_scat[g];
+    const bool have_clear_out = cfg.do_clear != 0;
+    const unsigned flags = (cfg.use_aerosols ? SWF_AEROSOLS : 0) | (cfg.do_sw_delta_scaling_with_gases ? SWF_DELTA_GASES : 0);
+    const double cloud_fraction_threshold = cfg.cloud_fraction_threshold;
+
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
-    const int col = in.istartcol - 1 + cloc;
+    const int col = a.in.istartcol - 1 + cloc;
     const bool valid = col_ok && glane < ng;
     const bool lead = leader && col_ok;
-    const double mu0 = in.cos_sza[col];
+    const double mu0 = a.in.cos_sza[col];
     const bool sun_up = mu0 > 0.0;
     double alb_dif = 0.0, alb_dir = 0.0, incoming = 0.0;
     if (sun_up) {
-      albedo_sw_g(cfg, in, col, g, alb_dif, alb_dir);
-      incoming = incoming_sw_g(m, in, g);
+      albedo_sw_g(cfg, a.in, col, g, alb_dif, alb_dir);
+      incoming = incoming_sw_g(m, a.in, g);
     }
     double tcc = 0.0;
-    if (MODE == 2) tcc = prep.total_cloud_cover_sw[cloc];
+    if (MODE == 2) tcc = a.prep.total_cloud_cover_sw[cloc];
     int lcb = -1;                 // lowest cloudy layer (0-based), -1 if none met yet
     SwSweepState st1{alb_dif, alb_dir * mu0}, st2{alb_dif, alb_dir * mu0};
 
@@ -154,34 +194,51 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(const D
       const int l0 = ch * NGP;
       if (ch != nchunk - 1) __syncthreads();
       {
+        const SpectralArgs& b = kernarg_block<SpectralArgs>();
         const int lev = l0 + glane;
-        if (lev < nlev) level_scalars<true>(cfg, m, in, L, tid, col, lev, want_clouds);
+        if (lev < nlev) level_scalars<true>(*b.cfg, b.cfg->gas_sw, b.in, L, tid, col, lev, want_clouds);
       }
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
       if (sun_up) {
+        const void* const tab = kernarg_block<SpectralArgs>().gas.tab;
+#if ECRAD_PREFETCH
+        // table loads of layer j-1 are issued before layer j is computed and stored
+        GasRegs<TAB> cur;
+        gas_load<TAB>(tab, nquad, L, cib * NGP + nl - 1, g, cur);
+#endif
         for (int j = nl - 1; j >= 0; --j) {
           const int lev = l0 + j;
           const int slot = cib * NGP + j;
+          const int nq = launder_uniform(nquad);
+#if ECRAD_PREFETCH
+          GasRegs<TAB> nxt;
+          if (j > 0) gas_load<TAB>(tab, nq, L, slot - 1, g, nxt);
+#else
+          GasRegs<TAB> cur;
+          gas_load<TAB>(tab, nq, L, slot, g, cur);
+#endif
           // gas optics: radiation_ecckd_interface.F90:256-281
-          double od = gas_absorption_od<TAB>(m, L, slot, g);
+          double od = gas_combine<TAB>(nq, L, slot, cur);
           double ssa = L.D(F_SM, slot) * ray_g;       // Rayleigh optical depth
           od = od + ssa;
           ssa = ssa / od;
           double asym = 0.0;
-          if (cfg.use_aerosols) {
-            AerosolLayer a = aerosol_layer<true>(cfg, in, L, slot, col, lev, ib);
-            if (!cfg.do_sw_delta_scaling_with_gases) delta_eddington_extensive_vec(a);
-            merge_aerosol_sw(cfg, a, od, ssa, asym);
+          if (flags & SWF_AEROSOLS) {
+            const SpectralArgs& b = kernarg_block<SpectralArgs>();
+            AerosolLayer al = aerosol_layer<true>(*b.cfg, b.in, L, slot, col, lev, ib);
+            if (!(flags & SWF_DELTA_GASES)) delta_eddington_extensive_vec(al);
+            merge_aerosol_sw(*b.cfg, al, od, ssa, asym);
           }
           double od1 = od, ssa1 = ssa, g1 = asym;
-          if (cfg.do_sw_delta_scaling_with_gases) delta_eddington(od1, ssa1, g1);
+          if (flags & SWF_DELTA_GASES) delta_eddington(od1, ssa1, g1);
           const SwCoef c = (MODE == 2) ? ref_trans_sw_fused(mu0, od1, ssa1, g1) : ref_trans_sw_classic(mu0, od1, ssa1, g1);
           if (MODE != 0) {
-            const bool layer_cloudy = L.D(F_FRAC, slot) >= cfg.cloud_fraction_threshold;
+            const bool layer_cloudy = L.D(F_FRAC, slot) >= cloud_fraction_threshold;
             if (layer_cloudy) {
               if (lcb < 0) { lcb = lev; st2 = st1; }     // below the lowest cloud both sets coincide
-              const CloudLayer cl = cloud_layer<true>(cfg, L, slot, ib);
+              const SpectralArgs& b = kernarg_block<SpectralArgs>();
+              const CloudLayer cl = cloud_layer<true>(*b.cfg, L, slot, ib);
               double od_total, ssa_total = 0.0, g_total = 0.0;
               if (MODE == 1) {   // radiation_homogeneous_sw.F90:236-253
                 od_total = od + cl.od;
@@ -189,7 +246,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(const D
                 if (ssa_total > 0.0 && od_total > 0.0)
                   g_total = (asym * ssa * od + cl.g * cl.ssa * cl.od) / (ssa_total * od_total);
               } else {           // radiation_mcica_sw.F90:250-268
-                const double od_cloud_new = prep.od_scaling_sw[g + (size_t)ng * (lev + (size_t)nlev * cloc)] * cl.od;
+                const double od_cloud_new = b.prep.od_scaling_sw[g + (size_t)ng * (lev + (size_t)nlev * cloc)] * cl.od;
                 od_total = od + od_cloud_new;
                 if (od_total > 0.0) {
                   const double scat_od = ssa * od + cl.ssa * od_cloud_new;
@@ -197,7 +254,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(const D
                   if (scat_od > 0.0) g_total = (asym * ssa * od + cl.g * cl.ssa * od_cloud_new) / scat_od;
                 }
               }
-              if (cfg.do_sw_delta_scaling_with_gases) delta_eddington(od_total, ssa_total, g_total);
+              if (flags & SWF_DELTA_GASES) delta_eddington(od_total, ssa_total, g_total);
               const SwCoef c2 = (MODE == 2) ? ref_trans_sw_fused(mu0, od_total, ssa_total, g_total)
                                             : ref_trans_sw_classic(mu0, od_total, ssa_total, g_total);
               sw_up_step(s, 1, lev, tid, c2, st2);
@@ -206,12 +263,16 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(const D
             }
           }
           sw_up_step(s, 0, lev, tid, c, st1);
+#if ECRAD_PREFETCH
+          if (j > 0) cur = nxt;
+#endif
         }
       }
     }
 
     // ---- sweep 2: top -> surface: fluxes ------------------------------------------------------------
-    if (sun_up) {
+    const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
+    if (sun_up && !(ECRAD_ABLATE & 4)) {
       double fdn_s = 0.0, fdir_s = 0.0, fup_t = 0.0;
       if (MODE == 0) {
         sw_flux_sweep<NGP>(s, false, -1, tid, nlev, mu0, incoming, st1.sig, valid, lead, ncol, col,
@@ -248,7 +309,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(const D
             fx.sw_up_toa_clear_g[og] = fup_c;
           }
         }
-        const bool do_set2 = (MODE == 1) ? (lcb >= 0 || !have_clear_out) : (tcc >= cfg.cloud_fraction_threshold);
+        const bool do_set2 = (MODE == 1) ? (lcb >= 0 || !have_clear_out) : (tcc >= cloud_fraction_threshold);
         if (do_set2) {
           const double w = (MODE == 2) ? tcc : 1.0;
           sw_flux_sweep<NGP>(s, lcb >= 0, lcb, tid, nlev, mu0, incoming, lcb >= 0 ? st2.sig : st1.sig, valid, lead, ncol, col,
@@ -316,18 +377,19 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(const D
 }
 
 template <typename TAB, int NGP>
-static hipError_t launch_sw_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const DevConfig* cfg,
-                                 const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                                 double* scratch, size_t per_block, int* counter) {
+static hipError_t launch_sw_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const SpectralArgs& args) {
   switch (mode) {
     case ECRAD_SOLVER_CLOUDLESS:
-      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 0>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter);
+      ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 0>), lds);
+      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 0>), grid, dim3(kBlock), lds, st, args);
       break;
     case ECRAD_SOLVER_HOMOGENEOUS:
-      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 1>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter);
+      ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 1>), lds);
+      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 1>), grid, dim3(kBlock), lds, st, args);
       break;
     default:
-      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 2>), grid, dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter);
+      ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 2>), lds);
+      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 2>), grid, dim3(kBlock), lds, st, args);
       break;
   }
   return hipGetLastError();
@@ -340,9 +402,10 @@ size_t sw_ica_scratch_doubles(int mode, int nlev) {
 
 hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig* cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                         double* scratch, size_t per_block, int* counter) {
+                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m) {
   dim3 g(grid);
-#define ECRAD_DISPATCH(T, N) return launch_sw_mode<T, N>(mode, g, lds, st, cfg, in, fx, prep, scratch, per_block, counter)
+  const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot};
+#define ECRAD_DISPATCH(T, N) return launch_sw_mode<T, N>(mode, g, lds, st, args)
   if (table_f32) {
     if (ngp == 16) ECRAD_DISPATCH(float, 16);
     if (ngp == 32) ECRAD_DISPATCH(float, 32);

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
   const int ngroups = (ncol_loc + CPB - 1) / CPB;
   const bool want_clouds = cfg.do_clouds != 0;
   const int nct = want_clouds ? cfg.n_cloud_types : 0;
-  const LdsLayout L = make_lds(smem, m.ngas, nct);
+  const LdsLayout L = make_lds(smem, m.hot.nquad, nct);
   const int g = glane < ng ? glane : ng - 1;
   const int ib = (IS_SW ? cfg.i_band_from_reordered_g_sw[g] : cfg.i_band_from_reordered_g_lw[g]) - 1;
   const int nb = IS_SW ? cfg.n_bands_sw : cfg.n_bands_lw;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
         const size_t o = g + (size_t)ng * (lev + (size_t)nlev * cloc);
-        double od = gas_absorption_od<TAB>(m, L, slot, g);
+        double od = gas_absorption_od<TAB>(m.hot, L, slot, g);
         if (IS_SW) {
           double ssa = L.D(F_SM, slot) * m.rayleigh_molar_scat[g];
           od = od + ssa;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
 
 hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                               const DevConfig* cfg, const DevInputs& in, const DevOptics& out) {
-#define ECRAD_L(T, N, S) hipLaunchKernelGGL((optics_dump_kernel<T, N, S>), dim3(grid), dim3(kBlock), lds, st, cfg, in, out)
+#define ECRAD_L(T, N, S) do { ECRAD_ALLOW_LDS((optics_dump_kernel<T, N, S>), lds); hipLaunchKernelGGL((optics_dump_kernel<T, N, S>), dim3(grid), dim3(kBlock), lds, st, cfg, in, out); } while (0)
 #define ECRAD_N(T, S) do { if (ngp == 16) ECRAD_L(T, 16, S); else if (ngp == 32) ECRAD_L(T, 32, S); else ECRAD_L(T, 64, S); } while (0)
   if (is_sw) { if (table_f32) ECRAD_N(float, true); else ECRAD_N(double, true); }
   else { if (table_f32) ECRAD_N(float, false); else ECRAD_N(double, false); }

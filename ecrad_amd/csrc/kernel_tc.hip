@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(const De
   const size_t ncol = in.ncol;
   const int ncol_loc = in.iendcol - in.istartcol + 1;
   const int ngroups = (ncol_loc + CPB - 1) / CPB;
-  const LdsLayout L = make_lds(smem, m.ngas, cfg.n_cloud_types);
+  const LdsLayout L = make_lds(smem, m.hot.nquad, cfg.n_cloud_types);
   const Scratch s{scratch_base + (size_t)blockIdx.x * scratch_per_block, nlev + 1};
   const int g = glane < ng ? glane : ng - 1;
   const int ib = cfg.i_band_from_reordered_g_sw[g] - 1;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(const De
         for (int j = 0; j < nl; ++j) {
           const int lev = l0 + j;
           const int slot = cib * NGP + j;
-          double od = gas_absorption_od<TAB>(m, L, slot, g);
+          double od = gas_absorption_od<TAB>(m.hot, L, slot, g);
           double ssa = L.D(F_SM, slot) * ray_g;
           od = od + ssa;
           ssa = ssa / od;
@@ -312,7 +312,7 @@ size_t sw_tc_scratch_doubles(int nlev) { return (size_t)SW_TC_NUM * (nlev + 1) *
 hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig* cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block,
                         int* counter) {
-#define ECRAD_L(T, N) hipLaunchKernelGGL((sw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter)
+#define ECRAD_L(T, N) do { ECRAD_ALLOW_LDS((sw_tc_kernel<T, N>), lds); hipLaunchKernelGGL((sw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter); } while (0)
   if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
   else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }
 #undef ECRAD_L
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(const De
   const size_t ncol = in.ncol;
   const int ncol_loc = in.iendcol - in.istartcol + 1;
   const int ngroups = (ncol_loc + CPB - 1) / CPB;
-  const LdsLayout L = make_lds(smem, m.ngas, cfg.n_cloud_types);
+  const LdsLayout L = make_lds(smem, m.hot.nquad, cfg.n_cloud_types);
   const Scratch s{scratch_base + (size_t)blockIdx.x * scratch_per_block, nlev + 1};
   const int g = glane < ng ? glane : ng - 1;
   const int ib = cfg.i_band_from_reordered_g_lw[g] - 1;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(const De
       for (int j = 0; j < nl; ++j) {
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
-        double od = gas_absorption_od<TAB>(m, L, slot, g);
+        double od = gas_absorption_od<TAB>(m.hot, L, slot, g);
         if (lev == 0) planck_top = planck_lookup<TAB>(m, L.I(I_PL_TOP, slot), L.D(F_PLW_TOP, slot), g);
         const double planck_bot = planck_lookup<TAB>(m, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
         if (cfg.use_aerosols) od = od + aerosol_layer<false>(cfg, in, L, slot, col, lev, ib).od;
@@ -577,7 +577,7 @@ size_t lw_tc_scratch_doubles(int nlev) { return (size_t)LW_TC_NUM * (nlev + 1) *
 hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig* cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block,
                         int* counter) {
-#define ECRAD_L(T, N) hipLaunchKernelGGL((lw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter)
+#define ECRAD_L(T, N) do { ECRAD_ALLOW_LDS((lw_tc_kernel<T, N>), lds); hipLaunchKernelGGL((lw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter); } while (0)
   if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
   else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }
 #undef ECRAD_L

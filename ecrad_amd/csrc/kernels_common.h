@@ -15,18 +15,120 @@ constexpr int kBlock = 256;
 #ifndef ECRAD_MIN_WAVES
 #define ECRAD_MIN_WAVES 2
 #endif
+// Tuning / ablation knobs (tools/variants.sh builds and times alternatives; the shipped library uses
+// the defaults).  ECRAD_ABLATE bits give WRONG results and exist only to attribute time:
+//   1 no table loads, 2 no cross-lane sums, 4 no flux sweep, 8 no scratch stores in the optics sweep
+#ifndef ECRAD_PREFETCH
+#define ECRAD_PREFETCH 1        // issue the next layer's gas-table loads before computing the current one
+#endif
+#ifndef ECRAD_SWEEP_BATCH
+#define ECRAD_SWEEP_BATCH 4     // layers of scratch records requested per batch in the flux sweeps
+#endif
+#ifndef ECRAD_ABLATE
+#define ECRAD_ABLATE 0
+#endif
+#ifndef ECRAD_SHFL_SUM
+#define ECRAD_SHFL_SUM 0         // 1: cross-lane sums through __shfl_xor (ds_bpermute) instead of DPP
+#endif
 
 #define ECRAD_DEV __device__ __forceinline__
+
+// Kernel arguments travel as ONE struct; the kernels read it through a pointer to the kernarg segment
+// that is re-derived ("laundered") at the start of each phase.  Scalar loads of the fields a phase
+// needs then sit inside that phase instead of all being hoisted to the kernel entry, where ~200 live
+// scalars overflow the SGPR file and get spilled to VGPR lanes (v_readlane in the level loops).
+template <typename T>
+ECRAD_DEV const T& kernarg_block() {
+  auto p = __builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return *(const T*)p;
+}
+
+// Hide a wave-uniform int from loop-invariant code motion (keeps tests on it as scalar compares at
+// the point of use instead of hoisted 64-bit lane masks).
+ECRAD_DEV int launder_uniform(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
+// Tuning-only instrumentation (-DECRAD_TIMING): serialising time stamps inside the level loops; the
+// accumulated shader-clock cycles of block 0 / wave 0 are printed at the end of the kernel.
+#ifdef ECRAD_TIMING
+struct PhaseTimer {
+  unsigned long long t, acc[8];
+  ECRAD_DEV void reset() { for (int i = 0; i < 8; ++i) acc[i] = 0; }
+  ECRAD_DEV void start() { t = stamp(); }
+  ECRAD_DEV void lap(int k) { const unsigned long long n = stamp(); acc[k] += n - t; t = n; }
+  // waits for every outstanding memory operation, then reads the shader clock
+  static ECRAD_DEV unsigned long long stamp() {
+    unsigned long long v;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) :: "memory");
+    return v;
+  }
+};
+#define ECRAD_LAP(timer, k, dep) do { asm volatile("" :: "v"(dep)); (timer).lap(k); } while (0)
+#define ECRAD_LAP0(timer, k) (timer).lap(k)
+#else
+#define ECRAD_LAP(timer, k, dep) do { } while (0)
+#define ECRAD_LAP0(timer, k) do { } while (0)
+#endif
 
 ECRAD_DEV double dmax(double a, double b) { return a > b ? a : b; }
 ECRAD_DEV double dmin(double a, double b) { return a < b ? a : b; }
 
-// Sum over the NGP lanes of a column group (NGP power of two <= 64). All lanes get the result.
+// Sum over the NGP lanes of a column group (NGP = 16, 32 or 64 consecutive lanes).  All lanes get the
+// result.  Butterfly on the VALU's data-parallel primitives -- quad_perm / row mirrors within a row
+// of 16 lanes, v_permlane16_swap / v_permlane32_swap (gfx950) across rows -- instead of ds_bpermute:
+// a step costs two 32-bit DPP moves and an add with VALU latency, not a trip through the LDS crossbar.
+// The partial sums are the same as those of an xor butterfly, bit for bit.
+template <int CTRL>
+ECRAD_DEV double dpp_move(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+  lo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
+  hi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// v(lane) + v(lane ^ 16)
+ECRAD_DEV double row_pair_sum(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __longlong_as_double((long long)(((unsigned long long)b[0] << 32) | a[0])) +
+         __longlong_as_double((long long)(((unsigned long long)b[1] << 32) | a[1]));
+}
+
+// v(lane) + v(lane ^ 32)
+ECRAD_DEV double half_pair_sum(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __longlong_as_double((long long)(((unsigned long long)b[0] << 32) | a[0])) +
+         __longlong_as_double((long long)(((unsigned long long)b[1] << 32) | a[1]));
+}
+
 template <int NGP>
 ECRAD_DEV double group_sum(double v) {
+  static_assert(NGP == 16 || NGP == 32 || NGP == 64, "column groups are 16, 32 or 64 lanes");
+#if ECRAD_ABLATE & 2
+  return v;
+#endif
+#if ECRAD_SHFL_SUM
 #pragma unroll
   for (int m = NGP / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m, NGP);
   return v;
+#else
+  v += dpp_move<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);    // row_half_mirror
+  v += dpp_move<0x140>(v);    // row_mirror
+  if (NGP >= 32) v = row_pair_sum(v);
+  if (NGP >= 64) v = half_pair_sum(v);
+  return v;
+#endif
 }
 
 // ---- two-stream layer coefficients ---------------------------------------------------------------

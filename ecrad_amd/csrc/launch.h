@@ -5,6 +5,16 @@
 
 namespace ecrad {
 
+// Dynamic LDS above 64 KB per block needs an explicit opt-in (gfx950 has 160 KB per CU)
+#define ECRAD_ALLOW_LDS(kernel, bytes)                                                                       \
+  do {                                                                                                       \
+    if ((bytes) > 60 * 1024) {                                                                               \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&kernel),                            \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));         \
+      if (e_ != hipSuccess) return e_;                                                                       \
+    }                                                                                                        \
+  } while (0)
+
 // doubles of block-private sweep scratch each kernel needs per block
 size_t sw_ica_scratch_doubles(int mode, int nlev);
 size_t lw_ica_scratch_doubles(int mode, int nlev);
@@ -14,10 +24,10 @@ size_t mcica_work_doubles(int nlev, int ng, int nloc);
 
 hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig* cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                         double* scratch, size_t per_block, int* counter);
+                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m);
 hipError_t launch_lw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig* cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                         double* scratch, size_t per_block, int* counter);
+                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m);
 hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig* cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block, int* counter);
 hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig* cfg,

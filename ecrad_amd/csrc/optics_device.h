@@ -2,42 +2,54 @@
 // per-g optical properties (lane = g-point) for: ecCKD gas optics, Planck function, general cloud
 // optics and aerosol optics.  Reference routines are cited at each function.
 //
-// LDS layout ("level scalars"): structure-of-arrays, one slot per thread of the block:
-//   slot = (column-in-block)*NGP + (level-in-chunk); double field f at ldsd[f*256+slot], int field f at
-//   ldsi[f*256+slot].  In the lane=g phase all NGP lanes of a column read the SAME slot (LDS broadcast).
+// LDS layout ("level scalars"): one record of `rec` doubles per slot, slot = (column-in-block)*NGP +
+// (level-in-chunk).  In the lane=g phase all NGP lanes of a column read the SAME record (LDS
+// broadcast) at compile-time field offsets, so one address register serves the whole record and
+// neighbouring fields merge into 16-byte reads.
 #pragma once
 #include "kernels_common.h"
 
 namespace ecrad {
 
-// double fields
-enum { F_PW2 = 0, F_TW2, F_CW2, F_SM, F_DPG, F_PLW_TOP, F_PLW_BOT, F_FRAC, F_NFIXED };
-// int fields
-enum { I_IDX = 0, I_PL_TOP, I_PL_BOT, I_RH, I_NFIXED };
-// Layout of the variable part: doubles [F_NFIXED .. F_NFIXED+ngas) per-gas multipliers, then per cloud
-// type (water_path, re weight2); ints [I_NFIXED .. I_NFIXED+nct) effective-radius index per type.
+// double fields of a record; F_INT1/F_INT2 hold two ints each, F_QIDX.. kMaxQuads ints.  The
+// shortwave-only F_SM shares its place with the longwave-only Planck weight.
+enum { F_PW2 = 0, F_TW2, F_SM, F_PLW_TOP = F_SM, F_PLW_BOT, F_DPG, F_FRAC, F_INT1, F_INT2, F_QIDX,
+       F_QMULT = F_QIDX + (kMaxQuads + 1) / 2 + 1 };
+static_assert(F_QIDX % 2 == 0 && F_QMULT % 2 == 0, "16-byte alignment of the vector fields");
+// int fields (index into the record viewed as ints)
+enum { I_PL_TOP = 2 * F_INT1, I_PL_BOT = 2 * F_INT1 + 1, I_RH = 2 * F_INT2, I_QIDX = 2 * F_QIDX };
+// I_QIDX + k: index of quad k of this layer in the gas table (without the lane's g).
+// Variable part: doubles [F_QMULT .. F_QMULT+nquad): multiplier of each table quad (the gas multiplier
+// of radiation_ecckd.F90:558-600 times the concentration weight of a look-up-table gas), then per cloud
+// type (water_path, effective-radius weight2, {effective-radius index, pad}).
 
 struct LdsLayout {
   double* d;
-  int* i;
-  int ngas, nct;
-  ECRAD_DEV double& D(int f, int slot) const { return d[f * kBlock + slot]; }
-  ECRAD_DEV int& I(int f, int slot) const { return i[f * kBlock + slot]; }
-  ECRAD_DEV int f_gas(int j) const { return F_NFIXED + j; }
-  ECRAD_DEV int f_wp(int t) const { return F_NFIXED + ngas + 2 * t; }
-  ECRAD_DEV int f_rew(int t) const { return F_NFIXED + ngas + 2 * t + 1; }
-  ECRAD_DEV int i_re(int t) const { return I_NFIXED + t; }
+  int rec2;         // 16-byte units per record
+  int nquad, nct;
+  // record base as a 16-byte aligned pointer so that neighbouring fields can be read with ds_read_b128
+  ECRAD_DEV double* R(int slot) const {
+    return reinterpret_cast<double*>(__builtin_assume_aligned(reinterpret_cast<double2*>(d) + slot * rec2, 16));
+  }
+  ECRAD_DEV double& D(int f, int slot) const { return R(slot)[f]; }
+  ECRAD_DEV int& I(int f, int slot) const { return reinterpret_cast<int*>(R(slot))[f]; }
+  ECRAD_DEV int f_wp(int t) const { return F_QMULT + nquad + 3 * t; }
+  ECRAD_DEV int f_rew(int t) const { return F_QMULT + nquad + 3 * t + 1; }
+  ECRAD_DEV int i_re(int t) const { return 2 * (F_QMULT + nquad + 3 * t + 2); }
+  // (nquad here is the model's count rounded up to even)
 };
 
-__host__ __device__ inline size_t lds_bytes(int ngas, int nct) {
-  return (size_t)kBlock * ((F_NFIXED + ngas + 2 * nct) * sizeof(double) + (I_NFIXED + nct) * sizeof(int));
+__host__ __device__ inline int lds_record_doubles(int nquad, int nct) { return (F_QMULT + ((nquad + 1) & ~1) + 3 * nct + 1) & ~1; }
+
+__host__ __device__ inline size_t lds_bytes(int nquad, int nct) {
+  return (size_t)kBlock * lds_record_doubles(nquad, nct) * sizeof(double);
 }
 
-ECRAD_DEV LdsLayout make_lds(void* smem, int ngas, int nct) {
+ECRAD_DEV LdsLayout make_lds(void* smem, int nquad, int nct) {
   LdsLayout L;
   L.d = reinterpret_cast<double*>(smem);
-  L.i = reinterpret_cast<int*>(L.d + (size_t)(F_NFIXED + ngas + 2 * nct) * kBlock);
-  L.ngas = ngas;
+  L.rec2 = lds_record_doubles(nquad, nct) / 2;
+  L.nquad = (nquad + 1) & ~1;
   L.nct = nct;
   return L;
 }
@@ -71,7 +83,7 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
   const double global_multiplier = 1.0 / (kAccelDueToGravity * 0.001 * kAirMolarMass);
   const double simple_multiplier = global_multiplier * (p1 - p0);
   int ic1 = 1;
-  double cw2 = 0.0;
+  int k = 0;
   for (int j = 0; j < m.ngas; ++j) {
     const DevCkdGas& sg = m.gas[j];
     double mult = simple_multiplier;
@@ -79,29 +91,42 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
       const double vmr = in.gas_mixing_ratio[col + ncol * (lev + (size_t)in.nlev * (sg.i_gas_code - 1))];
       if (sg.i_conc_dependence == ECRAD_CONC_LINEAR) mult = simple_multiplier * vmr;
       else if (sg.i_conc_dependence == ECRAD_CONC_RELATIVE_LINEAR) mult = simple_multiplier * (vmr - sg.reference_mole_frac);
-      else {  // LUT
+      else {  // LUT: two quads, weighted (1-cw2, cw2)
         double log_conc = log(dmax(vmr, sg.mole_frac1));
         double cindex1 = (log_conc - sg.log_mole_frac1) / sg.d_log_mole_frac;
         cindex1 = 1.0 + dmax(0.0, dmin(cindex1, sg.n_mole_frac - 1.0001));
         ic1 = (int)cindex1;
-        cw2 = cindex1 - ic1;
+        const double cw2 = cindex1 - ic1;
         mult = simple_multiplier * vmr;
+        L.D(F_QMULT + k, slot) = mult * (1.0 - cw2);
+        k++;
+        mult = mult * cw2;
       }
     }
-    L.D(L.f_gas(j), slot) = mult;
+    L.D(F_QMULT + k, slot) = mult;
+    k++;
   }
   L.D(F_PW2, slot) = pw2;
   L.D(F_TW2, slot) = tw2;
-  L.D(F_CW2, slot) = cw2;
-  L.D(F_SM, slot) = simple_multiplier;
+  if (IS_SW) L.D(F_SM, slot) = simple_multiplier;
   L.D(F_DPG, slot) = (p1 - p0) * (1.0 / kAccelDueToGravity);
-  L.I(I_IDX, slot) = (ip1 - 1) | ((it1 - 1) << 8) | ((ic1 - 1) << 16);
+  {
+    const int npm1 = m.npress - 1;
+    const int cell = m.ng * ((ip1 - 1) + npm1 * (it1 - 1));
+    const int lut = cell + m.ng * npm1 * (m.ntemp - 1) * (ic1 - 1);
+    for (int q = 0; q < m.hot.nquad; ++q)
+      L.I(I_QIDX + q, slot) = (int)m.hot.qoff[q] + (((m.hot.lutmask >> q) & 1u) ? lut : cell);
+    if (m.hot.nquad & 1) {      // pad to a whole pair: zero-weight copy of quad 0
+      L.I(I_QIDX + m.hot.nquad, slot) = (int)m.hot.qoff[0] + ((m.hot.lutmask & 1u) ? lut : cell);
+      L.D(F_QMULT + m.hot.nquad, slot) = 0.0;
+    }
+  }
   if (!IS_SW) {
     // Planck look-up position for T at the top and bottom half levels (radiation_ecckd.F90:910-926);
     // index -1 flags "below the table": planck = planck(:,1) * T/T1 with the ratio kept in the weight.
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const double T = k == 0 ? t0 : t1;
+    for (int kk = 0; kk < 2; ++kk) {
+      const double T = kk == 0 ? t0 : t1;
       double tindex = (T - m.temperature1_planck) * (1.0 / m.d_temperature_planck);
       int it;
       double w2;
@@ -115,8 +140,8 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
         it = -1;
         w2 = T / m.temperature1_planck;
       }
-      L.I(k == 0 ? I_PL_TOP : I_PL_BOT, slot) = it;
-      L.D(k == 0 ? F_PLW_TOP : F_PLW_BOT, slot) = w2;
+      L.I(kk == 0 ? I_PL_TOP : I_PL_BOT, slot) = it;
+      L.D(kk == 0 ? F_PLW_TOP : F_PLW_BOT, slot) = w2;
     }
   }
   int irh = 0;
@@ -155,49 +180,107 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Lane = g.  Absorption optical depth of one layer at g-point g: radiation_ecckd.F90:549-640.
+// Table layout on the device ("quads"): for every (g, ip, it[, ic]) the four (p,T)-neighbours
+//   { a(g,ip,it), a(g,ip+1,it), a(g,ip,it+1), a(g,ip+1,it+1) }
+// are stored adjacently (built once in ecrad_hip_setup), so the bilinear interpolation of
+// radiation_ecckd.F90:565-595 costs ONE 16-byte load per gas and lane (two for the H2O look-up table)
+// instead of four (eight) 4-byte loads; consecutive lanes (g) read consecutive quads = 512 B per
+// 32-lane column group.  All gases live in one allocation (GasHot::tab) and are addressed by 32-bit
+// quad offsets, so the lane=g loop needs 2 + nquad scalar registers for the whole gas model.
+// The Planck LUT is stored as (T, T+1) pairs for the same reason.
+template <typename TAB> struct QuadOf;
+template <> struct QuadOf<float> { using type = float4; using pair = float2; };
+template <> struct QuadOf<double> { using type = double4; using pair = double2; };
+
+// Registers holding one layer's table quads for one lane
 template <typename TAB>
-ECRAD_DEV double gas_absorption_od(const DevCkdModel& m, const LdsLayout& L, int slot, int g) {
-  const int idx = L.I(I_IDX, slot);
-  const int ip = idx & 0xff, it = (idx >> 8) & 0xff, ic = idx >> 16;
-  const double pw2 = L.D(F_PW2, slot), pw1 = 1.0 - pw2;
-  const double tw2 = L.D(F_TW2, slot), tw1 = 1.0 - tw2;
-  const int ng = m.ng;
-  const int sp = ng;                 // stride to ip+1
-  const int st = ng * m.npress;      // stride to it+1
-  const int base = g + ng * (ip + m.npress * it);
+struct GasRegs {
+  typename QuadOf<TAB>::type q[kMaxQuads];
+};
+
+// Lane = g.  Issue the table loads of one layer (radiation_ecckd.F90:549-640): no arithmetic that
+// depends on the loaded data, so the loads can be in flight while another layer is being computed.
+// Quads are handled in pairs (level_scalars pads an odd count with a zero-weight copy of quad 0).
+// `nquad` should be a value the compiler cannot hoist tests of out of the level loop (see
+// launder_uniform): otherwise it materialises one 64-bit lane mask per test and runs out of SGPRs.
+template <typename TAB>
+ECRAD_DEV void gas_load(const void* table, int nquad, const LdsLayout& L, int slot, int g, GasRegs<TAB>& r) {
+  using Quad = typename QuadOf<TAB>::type;
+  static_assert(kMaxQuads == 10, "index vector reads below assume 10 quads");
+  const Quad* __restrict__ tab = reinterpret_cast<const Quad*>(table);
+  const int* rec = reinterpret_cast<const int*>(L.R(slot));
+  const int4 qa = *reinterpret_cast<const int4*>(rec + I_QIDX);
+  const int4 qb = *reinterpret_cast<const int4*>(rec + I_QIDX + 4);
+  const int2 qc = *reinterpret_cast<const int2*>(rec + I_QIDX + 8);
+  const int qi[kMaxQuads] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y};
+#pragma unroll
+  for (int k = 0; k < kMaxQuads; k += 2) {
+    if (k < nquad) {
+#if ECRAD_ABLATE & 1
+      r.q[k].x = r.q[k].y = r.q[k].z = r.q[k].w = 1e-3f * (g & 7);
+      r.q[k + 1] = r.q[k];
+#else
+      r.q[k] = tab[(unsigned)(qi[k] + g)];
+      r.q[k + 1] = tab[(unsigned)(qi[k + 1] + g)];
+#endif
+    }
+  }
+}
+
+// Combine the loaded quads into the layer's absorption optical depth.
+template <typename TAB>
+ECRAD_DEV double gas_combine(int nquad, const LdsLayout& L, int slot, const GasRegs<TAB>& r) {
+  const double* rec = L.R(slot);
+  const double2 w = *reinterpret_cast<const double2*>(rec + F_PW2);
+  const double pw2 = w.x, pw1 = 1.0 - pw2;
+  const double tw2 = w.y, tw1 = 1.0 - tw2;
+  const double w00 = tw1 * pw1, w10 = tw1 * pw2, w01 = tw2 * pw1, w11 = tw2 * pw2;
   double od = 0.0;
-  for (int j = 0; j < m.ngas; ++j) {
-    const DevCkdGas& sg = m.gas[j];
-    const TAB* __restrict__ ma = reinterpret_cast<const TAB*>(sg.molar_abs);
-    const double mult = L.D(L.f_gas(j), slot);
-    if (sg.i_conc_dependence != ECRAD_CONC_LUT) {
-      const double a00 = ma[base], a10 = ma[base + sp], a01 = ma[base + st], a11 = ma[base + st + sp];
-      od += mult * (tw1 * (pw1 * a00 + pw2 * a10) + tw2 * (pw1 * a01 + pw2 * a11));
-    } else {
-      const double cw2 = L.D(F_CW2, slot), cw1 = 1.0 - cw2;
-      const int sc = st * m.ntemp;
-      const int b = base + sc * ic;
-      const double a000 = ma[b], a100 = ma[b + sp], a010 = ma[b + st], a110 = ma[b + st + sp];
-      const double a001 = ma[b + sc], a101 = ma[b + sc + sp], a011 = ma[b + sc + st], a111 = ma[b + sc + st + sp];
-      od += mult * ((cw1 * tw1 * pw1) * a000 + (cw1 * tw1 * pw2) * a100 + (cw1 * tw2 * pw1) * a010
-                    + (cw1 * tw2 * pw2) * a110 + (cw2 * tw1 * pw1) * a001 + (cw2 * tw1 * pw2) * a101
-                    + (cw2 * tw2 * pw1) * a011 + (cw2 * tw2 * pw2) * a111);
+#pragma unroll
+  for (int k = 0; k < kMaxQuads; k += 2) {
+    if (k < nquad) {
+      const double2 qm = *reinterpret_cast<const double2*>(rec + F_QMULT + k);
+      od += qm.x * (w00 * r.q[k].x + w10 * r.q[k].y + w01 * r.q[k].z + w11 * r.q[k].w);
+      od += qm.y * (w00 * r.q[k + 1].x + w10 * r.q[k + 1].y + w01 * r.q[k + 1].z + w11 * r.q[k + 1].w);
     }
   }
   return dmax(0.0, od);
 }
 
+template <typename TAB>
+ECRAD_DEV double gas_absorption_od(const GasHot& gh, const LdsLayout& L, int slot, int g) {
+  GasRegs<TAB> r;
+  gas_load<TAB>(gh.tab, gh.nquad, L, slot, g, r);
+  return gas_combine<TAB>(gh.nquad, L, slot, r);
+}
+
 // calc_planck_function (radiation_ecckd.F90:900-928) at position (it, w2) prepared by level_scalars
 template <typename TAB>
 ECRAD_DEV double planck_lookup(const DevCkdModel& m, int it, double w2, int g) {
-  const TAB* __restrict__ pf = reinterpret_cast<const TAB*>(m.planck_function);
+  using Pair = typename QuadOf<TAB>::pair;
+  const Pair* __restrict__ pf = reinterpret_cast<const Pair*>(m.planck_function);
   if (it >= 0) {
-    const double a = pf[g + m.ng * it], b = pf[g + m.ng * (it + 1)];
-    return (1.0 - w2) * a + w2 * b;
+    const Pair p = pf[g + m.ng * it];
+    return (1.0 - w2) * p.x + w2 * p.y;
   }
-  return (double)pf[g] * w2;
+  return (double)pf[g].x * w2;
 }
+
+// The same with the table pointer and ng held by the caller (two scalars instead of the model)
+template <typename TAB>
+struct PlanckTab {
+  const void* table;
+  int ng;
+  ECRAD_DEV double lookup(int it, double w2, int g) const {
+    using Pair = typename QuadOf<TAB>::pair;
+    const Pair* __restrict__ pf = reinterpret_cast<const Pair*>(table);
+    if (it >= 0) {
+      const Pair p = pf[g + ng * it];
+      return (1.0 - w2) * p.x + w2 * p.y;
+    }
+    return (double)pf[g].x * w2;
+  }
+};
 
 // Planck function for an arbitrary temperature (surface emission)
 template <typename TAB>

@@ -1,0 +1,18 @@
+#!/bin/bash
+# tools/variants.sh NAME "EXTRA_HIPCC_FLAGS"
+# Build a tuning/ablation variant of libecrad_hip.so into build_variants/NAME/ (git-ignored, but it
+# travels to the GPU box).  Time it with:  ECRAD_HIP_LIB=build_variants/NAME/libecrad_hip.so python bench.py ...
+set -e
+name=$1; shift
+extra="$*"
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/build_variants/$name
+mkdir -p $out
+src="api kernel_ica_sw kernel_ica_lw kernel_tc kernel_prep kernel_optics"
+for f in $src; do
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $extra -c $root/ecrad_amd/csrc/$f.hip -o $out/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out/libecrad_hip.so $out/*.o
+rm -f $out/*.o
+echo "built $out/libecrad_hip.so"
