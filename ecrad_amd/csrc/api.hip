@@ -157,8 +157,9 @@ int setup_ckd(ecrad_hip_handle_t h, const ecrad_ckd_model_t& m, DevCkdModel& d) 
   std::vector<double> all_quads;
   GasHot& hot = d.hot;
   hot.nquad = 0;
-  hot.lutmask = 0;
+  hot.pad_pos = -1;
   const size_t slice = (size_t)m.ng * (m.npress - 1) * (m.ntemp - 1);
+  std::vector<size_t> gas_off(m.ngas);
   for (int j = 0; j < m.ngas; ++j) {
     const ecrad_ckd_gas_t& g = m.single_gas[j];
     DevCkdGas& dg = d.gas[j];
@@ -170,18 +171,35 @@ int setup_ckd(ecrad_hip_handle_t h, const ecrad_ckd_model_t& m, DevCkdModel& d) 
     const bool lut = g.i_conc_dependence == ECRAD_CONC_LUT;
     if (lut && g.n_mole_frac < 2) return fail(h, ECRAD_EINVAL, "ckd model: mole-fraction LUT too short");
     const std::vector<double> quads = build_quads(g.molar_abs, m.ng, m.npress, m.ntemp, lut ? g.n_mole_frac : 1);
-    const size_t off = all_quads.size() / 4;
-    if (off + quads.size() / 4 > 0x0fffffffull) return fail(h, ECRAD_EUNSUPPORTED, "ckd model: absorption tables too large");
+    gas_off[j] = all_quads.size() / 4;
+    if (gas_off[j] + quads.size() / 4 > 0x0fffffffull) return fail(h, ECRAD_EUNSUPPORTED, "ckd model: absorption tables too large");
     all_quads.insert(all_quads.end(), quads.begin(), quads.end());
-    const int n = lut ? 2 : 1;
-    if (hot.nquad + n > kMaxQuads)
-      return fail(h, ECRAD_EUNSUPPORTED, "ckd model needs more than 10 table look-ups per layer (ngas + LUT gases)");
-    for (int k = 0; k < n; ++k) {
-      hot.qoff[hot.nquad] = (uint32_t)(off + (k == 1 ? slice : 0));
-      if (lut) hot.lutmask |= 1u << hot.nquad;
-      hot.nquad++;
-    }
   }
+  // quad order: plain gases, padding to an even count, then the look-up-table gases (see GasHot)
+  int pos = 0;
+  for (int j = 0; j < m.ngas; ++j)
+    if (d.gas[j].i_conc_dependence != ECRAD_CONC_LUT) {
+      if (pos >= kMaxQuads) return fail(h, ECRAD_EUNSUPPORTED, "ckd model needs more than 10 table look-ups per layer");
+      d.gas[j].qpos = pos;
+      hot.qoff[pos++] = (uint32_t)gas_off[j];
+    }
+  if (pos & 1) {
+    if (pos >= kMaxQuads) return fail(h, ECRAD_EUNSUPPORTED, "ckd model needs more than 10 table look-ups per layer");
+    hot.pad_pos = pos;
+    hot.qoff[pos++] = hot.qoff[0];
+  }
+  hot.nplain = pos;
+  int nlut = 0;
+  for (int j = 0; j < m.ngas; ++j) nlut += d.gas[j].i_conc_dependence == ECRAD_CONC_LUT;
+  if (nlut > 1) return fail(h, ECRAD_EUNSUPPORTED, "ckd model with more than one look-up-table gas");
+  for (int j = 0; j < m.ngas; ++j)
+    if (d.gas[j].i_conc_dependence == ECRAD_CONC_LUT) {
+      if (pos + 2 > kMaxQuads) return fail(h, ECRAD_EUNSUPPORTED, "ckd model needs more than 10 table look-ups per layer");
+      d.gas[j].qpos = pos;
+      hot.qoff[pos++] = (uint32_t)gas_off[j];
+      hot.qoff[pos++] = (uint32_t)(gas_off[j] + slice);
+    }
+  hot.nquad = pos;
   if (f32) st = upload_as_float(h, all_quads.data(), all_quads.size(), &hot.tab);
   else { const double* p; st = upload<double>(h, all_quads.data(), all_quads.size(), &p); hot.tab = p; }
   if (st) return st;

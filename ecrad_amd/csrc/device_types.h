@@ -20,16 +20,22 @@ struct DevCkdGas {
   int32_t n_mole_frac;
   int32_t pad_;
   double reference_mole_frac, log_mole_frac1, d_log_mole_frac, mole_frac1;
+  int32_t qpos;               // position of this gas's (first) quad in the model's quad order
+  int32_t pad2_;
 };
 
 // What the lane=g loops need from a gas-optics model, small enough to live in scalar registers:
 // one table holding the quads (see optics_device.h) of every gas and their offsets in it.
+// Quad order: first the gases interpolated in (p,T) only ("plain"), padded to an even count with a
+// zero-weight copy of quad 0, then two quads (lower/upper concentration) per look-up-table gas.
 struct GasHot {
   const void* tab;             // quads of float or double, per gas (ng,npress-1,ntemp-1[,nconc]) x 4
   uint32_t qoff[kMaxQuads];    // offset of quad k's array in `tab`, in quads (+ one concentration slice for
                                // the upper half of a look-up-table gas)
-  int32_t nquad;
-  uint32_t lutmask;            // bit k: quad k belongs to a look-up-table gas (add the layer's I_LUT offset)
+  int32_t nquad;               // even
+  int32_t nplain;              // even; quads [0,nplain) depend on the (p,T) cell only
+  int32_t pad_pos;             // position of the padding quad, -1 if none
+  int32_t pad_;
 };
 
 struct DevCkdModel {

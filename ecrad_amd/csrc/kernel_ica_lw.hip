@@ -42,6 +42,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
   const int tid = threadIdx.x;
   const int glane = tid % NGP, cib = tid / NGP;
   const bool want_clouds = MODE != 0;
+  GasRegs<TAB> quads;        // table values of the cell this lane last looked up; survive across layers and columns
+  quads.invalidate();
 #ifdef ECRAD_TIMING
   PhaseTimer tm;
   tm.reset();
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
     const int ncol_loc = a.in.iendcol - a.in.istartcol + 1;
     const int ngroups = (ncol_loc + CPB - 1) / CPB;
     const int nct = want_clouds ? cfg.n_cloud_types : 0;
-    const int nquad = a.gas.nquad;
+    const int nquad = a.gas.nquad, nplain = a.gas.nplain;
     __syncthreads();
     if (tid == 0) next_group = atomicAdd(a.counter, 1);
     __syncthreads();
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
     int ict = nlev;              // 0-based index of the first cloudy layer (= its top half level)
     double fdn_c = 0.0;          // clear-sky downwelling flux at the current half level
     double fdn_ctop = 0.0;       // ... captured at cloud top
-    double planck_top = 0.0;
+    double planck_top = planck_at<TAB>(m, a.in.temperature_hl[col], g);   // top-of-atmosphere half level
 
     // ---- pass A: top -> bottom ---------------------------------------------------------------------
     if (lead) {                  // flux_dn(:,1) = 0
@@ -111,34 +113,22 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
       const SpectralArgs& c0 = kernarg_block<SpectralArgs>();
-      const void* const tab = c0.gas.tab;
+      const GasHot gh = c0.gas;
       const PlanckTab<TAB> pt{c0.cfg->gas_lw.planck_function, ng};
       double* const lw_dn = c0.fx.lw_dn;
       double* const lw_dn_clear = have_clear_out ? c0.fx.lw_dn_clear : nullptr;
-#if ECRAD_PREFETCH
-      // software prefetch of the next layer's table quads (see kernel_ica_sw.hip)
-      GasRegs<TAB> cur;
-      gas_load<TAB>(tab, nquad, L, cib * NGP, g, cur);
-#endif
       ECRAD_LAP0(tm, 7);     // level scalars + group set-up (timing build: booked with the up-sweep)
       for (int j = 0; j < nl; ++j) {
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
         const int nq = launder_uniform(nquad);
-#if ECRAD_PREFETCH
-        GasRegs<TAB> nxt;
-        if (j + 1 < nl) gas_load<TAB>(tab, nq, L, slot + 1, g, nxt);
-#else
-        GasRegs<TAB> cur;
-        gas_load<TAB>(tab, nq, L, slot, g, cur);
-#endif
+        gas_load<TAB>(gh, nq, launder_uniform(nplain), L, slot, g, quads);
 #ifdef ECRAD_TIMING
-        ECRAD_LAP(tm, 0, cur.q[0].x);   // (timing build: table loads alone, booked under "scalars")
+        ECRAD_LAP(tm, 0, quads.q[0].x);   // (timing build: table loads alone, booked under "scalars")
 #endif
-        if (lev == 0) planck_top = pt.lookup(L.I(I_PL_TOP, slot), L.D(F_PLW_TOP, slot), g);
         const double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
         ECRAD_LAP(tm, 1, planck_bot);   // table + Planck loads returned
-        double od = gas_combine<TAB>(nq, L, slot, cur);
+        double od = gas_combine<TAB>(nq, L, slot, quads);
         ECRAD_LAP(tm, 2, od);           // combine
         if (use_aerosols) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
@@ -199,9 +189,6 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
         tm_levels++;
 #endif
         planck_top = planck_bot;
-#if ECRAD_PREFETCH
-        if (j + 1 < nl) cur = nxt;
-#endif
       }
     }
 

@@ -142,6 +142,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
   const int glane = tid % NGP, cib = tid / NGP;
   const bool want_clouds = MODE != 0;
   const bool leader = glane == 0;
+  GasRegs<TAB> quads;        // table values of the cell this lane last looked up; survive across layers and columns
+  quads.invalidate();
 
   for (;;) {
     // ---- per column group ---------------------------------------------------------------------------
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
     const int ncol_loc = a.in.iendcol - a.in.istartcol + 1;
     const int ngroups = (ncol_loc + CPB - 1) / CPB;
     const int nct = want_clouds ? cfg.n_cloud_types : 0;
-    const int nquad = a.gas.nquad;
+    const int nquad = a.gas.nquad, nplain = a.gas.nplain;
     // dynamic work distribution: blocks pull the next group of CPB columns
     __syncthreads();
     if (tid == 0) next_group = atomicAdd(a.counter, 1);
@@ -201,25 +203,14 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
       if (sun_up) {
-        const void* const tab = kernarg_block<SpectralArgs>().gas.tab;
-#if ECRAD_PREFETCH
-        // table loads of layer j-1 are issued before layer j is computed and stored
-        GasRegs<TAB> cur;
-        gas_load<TAB>(tab, nquad, L, cib * NGP + nl - 1, g, cur);
-#endif
+        const GasHot gh = kernarg_block<SpectralArgs>().gas;
         for (int j = nl - 1; j >= 0; --j) {
           const int lev = l0 + j;
           const int slot = cib * NGP + j;
           const int nq = launder_uniform(nquad);
-#if ECRAD_PREFETCH
-          GasRegs<TAB> nxt;
-          if (j > 0) gas_load<TAB>(tab, nq, L, slot - 1, g, nxt);
-#else
-          GasRegs<TAB> cur;
-          gas_load<TAB>(tab, nq, L, slot, g, cur);
-#endif
           // gas optics: radiation_ecckd_interface.F90:256-281
-          double od = gas_combine<TAB>(nq, L, slot, cur);
+          gas_load<TAB>(gh, nq, launder_uniform(nplain), L, slot, g, quads);
+          double od = gas_combine<TAB>(nq, L, slot, quads);
           double ssa = L.D(F_SM, slot) * ray_g;       // Rayleigh optical depth
           od = od + ssa;
           ssa = ssa / od;
@@ -263,9 +254,6 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
             }
           }
           sw_up_step(s, 0, lev, tid, c, st1);
-#if ECRAD_PREFETCH
-          if (j > 0) cur = nxt;
-#endif
         }
       }
     }

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
         if (out.lw_emission) out.lw_emission[og] = planck_at<TAB>(m, in.skin_temperature[col], g) * (1.0 - lw_albedo);
       }
     }
-    double planck_top = 0.0;
+    double planck_top = IS_SW ? 0.0 : planck_at<TAB>(m, in.temperature_hl[col], g);   // top-of-atmosphere half level
     for (int l0 = 0; l0 < nlev; l0 += NGP) {
       __syncthreads();
       {
@@ -77,8 +77,7 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
             if (out.g_sw) out.g_sw[o] = asym;
           }
         } else {
-          if (lev == 0) planck_top = planck_lookup<TAB>(m, L.I(I_PL_TOP, slot), L.D(F_PLW_TOP, slot), g);
-          const double planck_bot = planck_lookup<TAB>(m, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
+            const double planck_bot = planck_lookup<TAB>(m, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
           if (cfg.use_aerosols) od = od + aerosol_layer<false>(cfg, in, L, slot, col, lev, ib).od;
           if (valid) {
             if (out.od_lw) out.od_lw[o] = od;

@@ -368,7 +368,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(const De
     LevMask cloudy;
     cloudy.clear();
     int ict = nlev;             // 0-based layer index of cloud top (= i_cloud_top-1); nlev if none
-    double fdn_c = 0.0, fdn_ctop = 0.0, planck_top = 0.0;
+    double fdn_c = 0.0, fdn_ctop = 0.0;
+    double planck_top = planck_at<TAB>(m, in.temperature_hl[col], g);   // top-of-atmosphere half level
 
     // ---- pass A ---------------------------------------------------------------------------------------
     if (lead) {
@@ -387,7 +388,6 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(const De
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
         double od = gas_absorption_od<TAB>(m.hot, L, slot, g);
-        if (lev == 0) planck_top = planck_lookup<TAB>(m, L.I(I_PL_TOP, slot), L.D(F_PLW_TOP, slot), g);
         const double planck_bot = planck_lookup<TAB>(m, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
         if (cfg.use_aerosols) od = od + aerosol_layer<false>(cfg, in, L, slot, col, lev, ib).od;
         const LwCoef c = no_scattering_lw(od, planck_top, planck_bot);

@@ -13,19 +13,19 @@ namespace ecrad {
 constexpr int kBlock = 256;
 // minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
 #ifndef ECRAD_MIN_WAVES
-#define ECRAD_MIN_WAVES 2
+#define ECRAD_MIN_WAVES 3
 #endif
 // Tuning / ablation knobs (tools/variants.sh builds and times alternatives; the shipped library uses
 // the defaults).  ECRAD_ABLATE bits give WRONG results and exist only to attribute time:
 //   1 no table loads, 2 no cross-lane sums, 4 no flux sweep, 8 no scratch stores in the optics sweep
-#ifndef ECRAD_PREFETCH
-#define ECRAD_PREFETCH 1        // issue the next layer's gas-table loads before computing the current one
-#endif
 #ifndef ECRAD_SWEEP_BATCH
-#define ECRAD_SWEEP_BATCH 4     // layers of scratch records requested per batch in the flux sweeps
+#define ECRAD_SWEEP_BATCH 2     // layers of scratch records requested per batch in the flux sweeps
 #endif
 #ifndef ECRAD_ABLATE
 #define ECRAD_ABLATE 0
+#endif
+#ifndef ECRAD_QUAD_CACHE
+#define ECRAD_QUAD_CACHE 1      // keep table quads in registers while a column stays in the same (p,T) cell
 #endif
 #ifndef ECRAD_SHFL_SUM
 #define ECRAD_SHFL_SUM 0         // 1: cross-lane sums through __shfl_xor (ds_bpermute) instead of DPP

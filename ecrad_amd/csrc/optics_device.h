@@ -11,14 +11,15 @@
 
 namespace ecrad {
 
-// double fields of a record; F_INT1/F_INT2 hold two ints each, F_QIDX.. kMaxQuads ints.  The
-// shortwave-only F_SM shares its place with the longwave-only Planck weight.
-enum { F_PW2 = 0, F_TW2, F_SM, F_PLW_TOP = F_SM, F_PLW_BOT, F_DPG, F_FRAC, F_INT1, F_INT2, F_QIDX,
-       F_QMULT = F_QIDX + (kMaxQuads + 1) / 2 + 1 };
-static_assert(F_QIDX % 2 == 0 && F_QMULT % 2 == 0, "16-byte alignment of the vector fields");
+// double fields of a record; F_INT1/F_INT3 hold two ints each.  The shortwave-only F_SM shares its
+// place with the longwave-only Planck weight.
+enum { F_PW2 = 0, F_TW2, F_SM, F_PLW_BOT = F_SM, F_DPG, F_FRAC, F_INT1, F_INT3, F_PAD, F_QMULT };
+static_assert(F_QMULT % 2 == 0, "16-byte alignment of the multiplier pairs");
 // int fields (index into the record viewed as ints)
-enum { I_PL_TOP = 2 * F_INT1, I_PL_BOT = 2 * F_INT1 + 1, I_RH = 2 * F_INT2, I_QIDX = 2 * F_QIDX };
-// I_QIDX + k: index of quad k of this layer in the gas table (without the lane's g).
+enum { I_PL_BOT = 2 * F_INT1, I_RH = 2 * F_INT1 + 1, I_CELL = 2 * F_INT3, I_LUT = 2 * F_INT3 + 1 };
+// I_CELL / I_LUT: index of the layer's (p,T) cell, and of its (p,T,concentration) cell, in a gas's quad
+// array (quad k of the layer sits at GasHot::qoff[k] + cell-or-lut + g).  A lane whose cell is
+// unchanged from the previous layer still holds the right table values in registers (see gas_load).
 // Variable part: doubles [F_QMULT .. F_QMULT+nquad): multiplier of each table quad (the gas multiplier
 // of radiation_ecckd.F90:558-600 times the concentration weight of a look-up-table gas), then per cloud
 // type (water_path, effective-radius weight2, {effective-radius index, pad}).
@@ -83,10 +84,10 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
   const double global_multiplier = 1.0 / (kAccelDueToGravity * 0.001 * kAirMolarMass);
   const double simple_multiplier = global_multiplier * (p1 - p0);
   int ic1 = 1;
-  int k = 0;
   for (int j = 0; j < m.ngas; ++j) {
     const DevCkdGas& sg = m.gas[j];
     double mult = simple_multiplier;
+    int k = sg.qpos;
     if (sg.i_conc_dependence != ECRAD_CONC_NONE) {
       const double vmr = in.gas_mixing_ratio[col + ncol * (lev + (size_t)in.nlev * (sg.i_gas_code - 1))];
       if (sg.i_conc_dependence == ECRAD_CONC_LINEAR) mult = simple_multiplier * vmr;
@@ -104,45 +105,40 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
       }
     }
     L.D(F_QMULT + k, slot) = mult;
-    k++;
   }
+  if (m.hot.pad_pos >= 0) L.D(F_QMULT + m.hot.pad_pos, slot) = 0.0;
   L.D(F_PW2, slot) = pw2;
   L.D(F_TW2, slot) = tw2;
   if (IS_SW) L.D(F_SM, slot) = simple_multiplier;
   L.D(F_DPG, slot) = (p1 - p0) * (1.0 / kAccelDueToGravity);
   {
+    // one concentration index per layer: ecrad_hip_setup rejects models with more than one
+    // look-up-table gas (every ecCKD model so far has H2O only)
     const int npm1 = m.npress - 1;
     const int cell = m.ng * ((ip1 - 1) + npm1 * (it1 - 1));
     const int lut = cell + m.ng * npm1 * (m.ntemp - 1) * (ic1 - 1);
-    for (int q = 0; q < m.hot.nquad; ++q)
-      L.I(I_QIDX + q, slot) = (int)m.hot.qoff[q] + (((m.hot.lutmask >> q) & 1u) ? lut : cell);
-    if (m.hot.nquad & 1) {      // pad to a whole pair: zero-weight copy of quad 0
-      L.I(I_QIDX + m.hot.nquad, slot) = (int)m.hot.qoff[0] + ((m.hot.lutmask & 1u) ? lut : cell);
-      L.D(F_QMULT + m.hot.nquad, slot) = 0.0;
-    }
+    L.I(I_CELL, slot) = cell;
+    L.I(I_LUT, slot) = lut;
   }
   if (!IS_SW) {
-    // Planck look-up position for T at the top and bottom half levels (radiation_ecckd.F90:910-926);
-    // index -1 flags "below the table": planck = planck(:,1) * T/T1 with the ratio kept in the weight.
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const double T = kk == 0 ? t0 : t1;
-      double tindex = (T - m.temperature1_planck) * (1.0 / m.d_temperature_planck);
-      int it;
-      double w2;
-      if (tindex >= 0) {
-        tindex = 1.0 + tindex;
-        it = (int)tindex;
-        if (it > m.nplanck - 1) it = m.nplanck - 1;
-        w2 = tindex - it;
-        it -= 1;
-      } else {
-        it = -1;
-        w2 = T / m.temperature1_planck;
-      }
-      L.I(kk == 0 ? I_PL_TOP : I_PL_BOT, slot) = it;
-      L.D(kk == 0 ? F_PLW_TOP : F_PLW_BOT, slot) = w2;
+    // Planck look-up position for T at the layer's bottom half level (radiation_ecckd.F90:910-926; the
+    // top value is the previous layer's bottom, or planck_at() for the first layer); index -1 flags
+    // "below the table": planck = planck(:,1) * T/T1 with the ratio kept in the weight.
+    double tindex = (t1 - m.temperature1_planck) * (1.0 / m.d_temperature_planck);
+    int it;
+    double w2;
+    if (tindex >= 0) {
+      tindex = 1.0 + tindex;
+      it = (int)tindex;
+      if (it > m.nplanck - 1) it = m.nplanck - 1;
+      w2 = tindex - it;
+      it -= 1;
+    } else {
+      it = -1;
+      w2 = t1 / m.temperature1_planck;
     }
+    L.I(I_PL_BOT, slot) = it;
+    L.D(F_PLW_BOT, slot) = w2;
   }
   int irh = 0;
   if (cfg.use_aerosols) {
@@ -192,39 +188,49 @@ template <typename TAB> struct QuadOf;
 template <> struct QuadOf<float> { using type = float4; using pair = float2; };
 template <> struct QuadOf<double> { using type = double4; using pair = double2; };
 
-// Registers holding one layer's table quads for one lane
+// Registers holding one layer's table quads for one lane, and which cells they were loaded from.
+// Model layers are finer than the table's (p,T) grid, so consecutive layers of a column mostly fall
+// in the same cell: the quads are then still valid and only the interpolation weights change.
 template <typename TAB>
 struct GasRegs {
   typename QuadOf<TAB>::type q[kMaxQuads];
+  int cell, lut;
+  ECRAD_DEV void invalidate() { cell = -1; lut = -1; }
 };
 
-// Lane = g.  Issue the table loads of one layer (radiation_ecckd.F90:549-640): no arithmetic that
-// depends on the loaded data, so the loads can be in flight while another layer is being computed.
-// Quads are handled in pairs (level_scalars pads an odd count with a zero-weight copy of quad 0).
-// `nquad` should be a value the compiler cannot hoist tests of out of the level loop (see
+// Lane = g.  Bring the table quads of one layer into `r` (radiation_ecckd.F90:549-640), re-loading
+// only the pairs whose cell differs from what `r` holds.  Quads are handled in pairs.
+// `nquad`/`nplain` should be values the compiler cannot hoist tests of out of the level loop (see
 // launder_uniform): otherwise it materialises one 64-bit lane mask per test and runs out of SGPRs.
 template <typename TAB>
-ECRAD_DEV void gas_load(const void* table, int nquad, const LdsLayout& L, int slot, int g, GasRegs<TAB>& r) {
+ECRAD_DEV void gas_load(const GasHot& gh, int nquad, int nplain, const LdsLayout& L, int slot, int g, GasRegs<TAB>& r) {
   using Quad = typename QuadOf<TAB>::type;
-  static_assert(kMaxQuads == 10, "index vector reads below assume 10 quads");
-  const Quad* __restrict__ tab = reinterpret_cast<const Quad*>(table);
-  const int* rec = reinterpret_cast<const int*>(L.R(slot));
-  const int4 qa = *reinterpret_cast<const int4*>(rec + I_QIDX);
-  const int4 qb = *reinterpret_cast<const int4*>(rec + I_QIDX + 4);
-  const int2 qc = *reinterpret_cast<const int2*>(rec + I_QIDX + 8);
-  const int qi[kMaxQuads] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w, qc.x, qc.y};
+  const Quad* __restrict__ tab = reinterpret_cast<const Quad*>(gh.tab);
+  const int2 key = *reinterpret_cast<const int2*>(reinterpret_cast<const int*>(L.R(slot)) + I_CELL);   // {cell, lut}
+#if ECRAD_QUAD_CACHE
+  const bool new_cell = key.x != r.cell, new_lut = key.y != r.lut;
+#else
+  const bool new_cell = true, new_lut = true;
+#endif
+  const unsigned plain_g = (unsigned)(key.x + g), lut_g = (unsigned)(key.y + g);
 #pragma unroll
   for (int k = 0; k < kMaxQuads; k += 2) {
     if (k < nquad) {
+      const bool is_plain = k < nplain;
+      if (is_plain ? new_cell : new_lut) {
 #if ECRAD_ABLATE & 1
-      r.q[k].x = r.q[k].y = r.q[k].z = r.q[k].w = 1e-3f * (g & 7);
-      r.q[k + 1] = r.q[k];
+        r.q[k].x = r.q[k].y = r.q[k].z = r.q[k].w = 1e-3f * (g & 7);
+        r.q[k + 1] = r.q[k];
 #else
-      r.q[k] = tab[(unsigned)(qi[k] + g)];
-      r.q[k + 1] = tab[(unsigned)(qi[k + 1] + g)];
+        const unsigned base = is_plain ? plain_g : lut_g;
+        r.q[k] = tab[base + gh.qoff[k]];
+        r.q[k + 1] = tab[base + gh.qoff[k + 1]];
 #endif
+      }
     }
   }
+  r.cell = key.x;
+  r.lut = key.y;
 }
 
 // Combine the loaded quads into the layer's absorption optical depth.
@@ -250,7 +256,8 @@ ECRAD_DEV double gas_combine(int nquad, const LdsLayout& L, int slot, const GasR
 template <typename TAB>
 ECRAD_DEV double gas_absorption_od(const GasHot& gh, const LdsLayout& L, int slot, int g) {
   GasRegs<TAB> r;
-  gas_load<TAB>(gh.tab, gh.nquad, L, slot, g, r);
+  r.invalidate();
+  gas_load<TAB>(gh, gh.nquad, gh.nplain, L, slot, g, r);
   return gas_combine<TAB>(gh.nquad, L, slot, r);
 }
 
