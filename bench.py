@@ -179,6 +179,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    def measured_traffic(kernel_prefix):
+        """HBM bytes per launch of the dominant kernel from the newest committed PMC summary
+        (profiles/*_traffic.json, written by tools/profile.sh + tools/summarize_prof.py from separate
+        --pmc FETCH_SIZE / WRITE_SIZE passes of this same command), or None if none matches this
+        workload and column count."""
+        import glob
+        best = None
+        for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")),
+                        key=os.path.getmtime):
+            try:
+                d = json.load(open(f))
+            except Exception:
+                continue
+            if d.get("columns") != ncol or d.get("workload") != args.workload:
+                continue
+            for k, v in d.get("traffic_bytes_per_launch", {}).items():
+                if k.startswith(kernel_prefix):
+                    best = {"bytes_per_launch": v, "source": "profiles/" + os.path.basename(f)}
+        return best
+
     if rank == 0:
         total_cols = world * ncol * args.steps
         value = total_cols / elapsed
@@ -186,6 +206,8 @@ def main():
         dom_ms = float(np.mean(stage_ms[dom]))
         a_bytes = algorithmic_bytes_per_column(config, nlev, dom, clear_sky)
         achieved = a_bytes * ncol / (dom_ms * 1e-3) / 1e9
+        dom_kernel = f"{dom}_ica_kernel" if sw_solver != "Tripleclouds" else f"{dom}_tc_kernel"
+        traffic = measured_traffic(dom_kernel)
         out = {
             "metric": "columns/sec (SW+LW) at 137 lev, ecCKD-32", "value": value, "unit": "columns/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -195,9 +217,11 @@ def main():
                        "n_g_sw": config.n_g_sw, "n_g_lw": config.n_g_lw, "sw_solver": sw_solver,
                        "aerosols": bool(config.use_aerosols), "clouds": not clear_sky,
                        "parallelism": f"columns sharded over {world} GPU(s)" + (", flux profiles gathered on rank 0" if do_gather else "")},
-            "roofline": {"bound": "hbm", "kernel": f"{dom}_ica_kernel" if sw_solver != "Tripleclouds" else f"{dom}_tc_kernel",
+            "roofline": {"bound": "hbm", "kernel": dom_kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes_per_column": a_bytes, "kernel_ms": dom_ms,
+                         "traffic": traffic["bytes_per_launch"] if traffic else None,
+                         "traffic_source": traffic["source"] if traffic else None,
+                         "algorithmic_bytes": a_bytes * ncol, "algorithmic_bytes_per_column": a_bytes, "kernel_ms": dom_ms,
                          "stage_ms": {k: float(np.mean(v)) for k, v in stage_ms.items() if v}},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -75,7 +75,8 @@ def main(tag):
     os.makedirs("profiles", exist_ok=True)
     path = os.path.join("profiles", f"{tag}.md")
     open(path, "w").write("\n".join(out) + "\n")
-    json.dump({"traffic_bytes_per_launch": traffic, "fetch_correction": f_corr, "write_correction": w_corr},
+    json.dump({"traffic_bytes_per_launch": traffic, "fetch_correction": f_corr, "write_correction": w_corr,
+               "columns": ncol, "workload": bench["config"]["workload"] if bench else None},
               open(os.path.join("profiles", f"{tag}_traffic.json"), "w"), indent=1)
     print("\n".join(out))
 
