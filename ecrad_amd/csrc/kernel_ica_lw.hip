@@ -115,6 +115,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
       const SpectralArgs& c0 = kernarg_block<SpectralArgs>();
       const GasHot gh = c0.gas;
       const PlanckTab<TAB> pt{c0.cfg->gas_lw.planck_function, ng};
+      double keep_dn = 0.0;
       double* const lw_dn = c0.fx.lw_dn;
       double* const lw_dn_clear = have_clear_out ? c0.fx.lw_dn_clear : nullptr;
       ECRAD_LAP0(tm, 7);     // level scalars + group set-up (timing build: booked with the up-sweep)
@@ -179,17 +180,19 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
         fdn_c = c.transmittance * fdn_c + c.source_dn;
         const double sd = group_sum<NGP>(valid ? fdn_c : 0.0);
         ECRAD_LAP(tm, 5, sd);           // cross-lane sum
-        if (lead) {
-          const size_t o = col + ncol * (lev + 1);
-          lw_dn[o] = sd;
-          if (lw_dn_clear) lw_dn_clear[o] = sd;
-        }
-        ECRAD_LAP0(tm, 6);              // flux store acknowledged
+        // lane j of the column group keeps the sum of the chunk's layer j; one store per chunk
+        if (glane == j) keep_dn = sd;
 #ifdef ECRAD_TIMING
         tm_levels++;
 #endif
         planck_top = planck_bot;
       }
+      if (col_ok && glane < nl) {
+        const size_t o = col + ncol * (l0 + glane + 1);
+        lw_dn[o] = keep_dn;
+        if (lw_dn_clear) lw_dn_clear[o] = keep_dn;
+      }
+      ECRAD_LAP0(tm, 6);              // flux stores acknowledged
     }
 
     // ---- pass B1: clear-sky upward sweep (+ clear-sky derivatives) --------------------------------
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
     {
       // records of the next kLwBatch layers are requested before the current batch is consumed
       double2 cur[kLwBatch], nxt[kLwBatch];
+      double keep_up = 0.0, keep_der = 0.0;
 #pragma unroll
       for (int k = 0; k < kLwBatch; ++k)
         if (nlev - 1 - k >= 0) cur[k] = s.pair(P_CLR, nlev - 1 - k, tid);
@@ -224,11 +228,16 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
             const double su = group_sum<NGP>(valid ? fup : 0.0);
             double sder = 0.0;
             if (do_deriv) { deriv = deriv * T; sder = group_sum<NGP>(valid ? deriv : 0.0); }
-            if (lead) {
-              const size_t o = col + ncol * l;
-              fx.lw_up[o] = su;
-              if (have_clear_out) fx.lw_up_clear[o] = su;
-              if (do_deriv) fx.lw_derivatives[o] = sder;
+            // lane (l mod NGP) keeps half level l; NGP half levels are written at a time
+            if ((l & (NGP - 1)) == glane) { keep_up = su; keep_der = sder; }
+            if ((l & (NGP - 1)) == 0) {
+              const int lv = l + glane;
+              if (col_ok && lv < nlev) {
+                const size_t o = col + ncol * lv;
+                fx.lw_up[o] = keep_up;
+                if (have_clear_out) fx.lw_up_clear[o] = keep_up;
+                if (do_deriv) fx.lw_derivatives[o] = keep_der;
+              }
             }
           }
         }

@@ -85,28 +85,43 @@ ECRAD_DEV void sw_load_batch(const SwScratch& s, bool set2, int lcb, int tid, in
 // each wave keeps 2*kSwBatch layers of scratch reads in flight (the sweep has almost no arithmetic).
 template <int NGP>
 ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, int nlev, double mu0, double incoming,
-                             double sig_top, bool valid, bool leader, size_t ncol, int col,
+                             double sig_top, bool valid, bool col_ok, size_t ncol, int col,
                              double* out_up, double* out_dn, double* out_dir, double weight,
                              const double* clr_up, const double* clr_dn, const double* clr_dir,
+                             double* dup_up, double* dup_dn, double* dup_dir,
                              double& fdn_surf, double& fdir_surf, double& fup_toa) {
   double Fd = incoming, fdn = 0.0, fup = incoming * sig_top;
   fup_toa = fup;
   const bool blend = weight < 1.0;
+  const int glane = tid % NGP;
+  // The sums over g of half level l are kept by lane (l mod NGP) of the column group and written NGP
+  // half levels at a time: 3 store instructions per NGP levels instead of 3 per level, and no stores
+  // between the scratch reads of consecutive layers.
+  double keep_u = 0.0, keep_d = 0.0, keep_dir = 0.0;
   auto emit = [&](int l) {
     const double su = group_sum<NGP>(valid ? fup : 0.0);
     const double sd = group_sum<NGP>(valid ? fdn : 0.0);
     const double sdir = group_sum<NGP>(valid ? Fd : 0.0) * mu0;
-    if (leader) {
-      const size_t o = col + ncol * l;
-      double vu = su, vd = sd + sdir, vdir = sdir;
-      if (blend) {
-        vu = weight * vu + (1.0 - weight) * clr_up[o];
-        vd = weight * vd + (1.0 - weight) * clr_dn[o];
-        if (out_dir) vdir = weight * vdir + (1.0 - weight) * clr_dir[o];
+    if ((l & (NGP - 1)) == glane) { keep_u = su; keep_d = sd + sdir; keep_dir = sdir; }
+    if ((l & (NGP - 1)) == NGP - 1 || l == nlev) {
+      const int lv = (l & ~(NGP - 1)) + glane;
+      if (col_ok && lv <= l) {
+        const size_t o = col + ncol * lv;
+        double vu = keep_u, vd = keep_d, vdir = keep_dir;
+        if (blend) {
+          vu = weight * vu + (1.0 - weight) * clr_up[o];
+          vd = weight * vd + (1.0 - weight) * clr_dn[o];
+          if (out_dir) vdir = weight * vdir + (1.0 - weight) * clr_dir[o];
+        }
+        out_up[o] = vu;
+        out_dn[o] = vd;
+        if (out_dir) out_dir[o] = vdir;
+        if (dup_up) {              // the same profile is also another output (e.g. total sky = clear sky)
+          dup_up[o] = vu;
+          dup_dn[o] = vd;
+          if (dup_dir) dup_dir[o] = vdir;
+        }
       }
-      out_up[o] = vu;
-      out_dn[o] = vd;
-      if (out_dir) out_dir[o] = vdir;
     }
   };
   SwRec cur[kSwBatch], nxt[kSwBatch];
@@ -144,6 +159,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
   const bool leader = glane == 0;
   GasRegs<TAB> quads;        // table values of the cell this lane last looked up; survive across layers and columns
   quads.invalidate();
+#ifdef ECRAD_TIMING
+  PhaseTimer tm;
+  tm.reset();
+  int tm_levels = 0;
+#endif
 
   for (;;) {
     // ---- per column group ---------------------------------------------------------------------------
@@ -162,6 +182,9 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
     __syncthreads();
     const int grp = next_group;
     if (grp >= ngroups) break;
+#ifdef ECRAD_TIMING
+    tm.start();
+#endif
 
     const LdsLayout L = make_lds(smem, nquad, nct);
     const SwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block, nlev};
@@ -195,22 +218,27 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
     for (int ch = nchunk - 1; ch >= 0; --ch) {
       const int l0 = ch * NGP;
       if (ch != nchunk - 1) __syncthreads();
+      ECRAD_LAP0(tm, 5);              // (timing build) wait at the first barrier + group set-up
       {
         const SpectralArgs& b = kernarg_block<SpectralArgs>();
         const int lev = l0 + glane;
         if (lev < nlev) level_scalars<true>(*b.cfg, b.cfg->gas_sw, b.in, L, tid, col, lev, want_clouds);
       }
+      ECRAD_LAP0(tm, 7);              // (timing build) level records computed
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
       if (sun_up) {
         const GasHot gh = kernarg_block<SpectralArgs>().gas;
+        ECRAD_LAP0(tm, 0);            // level records + barriers (+ group set-up)
         for (int j = nl - 1; j >= 0; --j) {
           const int lev = l0 + j;
           const int slot = cib * NGP + j;
           const int nq = launder_uniform(nquad);
           // gas optics: radiation_ecckd_interface.F90:256-281
           gas_load<TAB>(gh, nq, launder_uniform(nplain), L, slot, g, quads);
+          ECRAD_LAP(tm, 1, quads.q[0].x);   // table loads returned
           double od = gas_combine<TAB>(nq, L, slot, quads);
+          ECRAD_LAP(tm, 2, od);             // combine
           double ssa = L.D(F_SM, slot) * ray_g;       // Rayleigh optical depth
           od = od + ssa;
           ssa = ssa / od;
@@ -224,6 +252,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
           double od1 = od, ssa1 = ssa, g1 = asym;
           if (flags & SWF_DELTA_GASES) delta_eddington(od1, ssa1, g1);
           const SwCoef c = (MODE == 2) ? ref_trans_sw_fused(mu0, od1, ssa1, g1) : ref_trans_sw_classic(mu0, od1, ssa1, g1);
+          ECRAD_LAP(tm, 3, c.trans_dir_diff + c.ref_dir);   // Rayleigh, delta-Eddington, two-stream
           if (MODE != 0) {
             const bool layer_cloudy = L.D(F_FRAC, slot) >= cloud_fraction_threshold;
             if (layer_cloudy) {
@@ -254,17 +283,24 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
             }
           }
           sw_up_step(s, 0, lev, tid, c, st1);
+          ECRAD_LAP(tm, 4, st1.sig);        // recurrences + scratch stores acknowledged
+#ifdef ECRAD_TIMING
+          tm_levels++;
+#endif
         }
       }
     }
 
     // ---- sweep 2: top -> surface: fluxes ------------------------------------------------------------
     const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
+    ECRAD_LAP0(tm, 0);
     if (sun_up && !(ECRAD_ABLATE & 4)) {
       double fdn_s = 0.0, fdir_s = 0.0, fup_t = 0.0;
       if (MODE == 0) {
-        sw_flux_sweep<NGP>(s, false, -1, tid, nlev, mu0, incoming, st1.sig, valid, lead, ncol, col,
-                           fx.sw_up, fx.sw_dn, fx.sw_dn_direct, 1.0, nullptr, nullptr, nullptr, fdn_s, fdir_s, fup_t);
+        sw_flux_sweep<NGP>(s, false, -1, tid, nlev, mu0, incoming, st1.sig, valid, col_ok, ncol, col,
+                           fx.sw_up, fx.sw_dn, fx.sw_dn_direct, 1.0, nullptr, nullptr, nullptr,
+                           have_clear_out ? fx.sw_up_clear : nullptr, fx.sw_dn_clear, fx.sw_dn_direct_clear,
+                           fdn_s, fdir_s, fup_t);
         if (valid) {
           const size_t og = g + (size_t)ng * col;
           fx.sw_dn_diffuse_surf_g[og] = fdn_s;
@@ -276,19 +312,14 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
             fx.sw_up_toa_clear_g[og] = fup_t;
           }
         }
-        if (lead && have_clear_out) {
-          for (int l = 0; l <= nlev; ++l) {
-            const size_t o = col + ncol * l;
-            fx.sw_up_clear[o] = fx.sw_up[o];
-            fx.sw_dn_clear[o] = fx.sw_dn[o];
-            if (fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[o] = fx.sw_dn_direct[o];
-          }
-        }
       } else {
         double fdn_c = 0.0, fdir_c = 0.0, fup_c = 0.0;
+        const bool do_set2 = (MODE == 1) ? (lcb >= 0 || !have_clear_out) : (tcc >= cloud_fraction_threshold);
         if (have_clear_out) {
-          sw_flux_sweep<NGP>(s, false, -1, tid, nlev, mu0, incoming, st1.sig, valid, lead, ncol, col,
+          // without a second (cloudy) sweep the total-sky profiles are the clear-sky ones
+          sw_flux_sweep<NGP>(s, false, -1, tid, nlev, mu0, incoming, st1.sig, valid, col_ok, ncol, col,
                              fx.sw_up_clear, fx.sw_dn_clear, fx.sw_dn_direct_clear, 1.0, nullptr, nullptr, nullptr,
+                             do_set2 ? nullptr : fx.sw_up, fx.sw_dn, fx.sw_dn_direct,
                              fdn_c, fdir_c, fup_c);
           if (valid) {
             const size_t og = g + (size_t)ng * col;
@@ -297,12 +328,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
             fx.sw_up_toa_clear_g[og] = fup_c;
           }
         }
-        const bool do_set2 = (MODE == 1) ? (lcb >= 0 || !have_clear_out) : (tcc >= cloud_fraction_threshold);
         if (do_set2) {
           const double w = (MODE == 2) ? tcc : 1.0;
-          sw_flux_sweep<NGP>(s, lcb >= 0, lcb, tid, nlev, mu0, incoming, lcb >= 0 ? st2.sig : st1.sig, valid, lead, ncol, col,
+          sw_flux_sweep<NGP>(s, lcb >= 0, lcb, tid, nlev, mu0, incoming, lcb >= 0 ? st2.sig : st1.sig, valid, col_ok, ncol, col,
                              fx.sw_up, fx.sw_dn, fx.sw_dn_direct, w, fx.sw_up_clear, fx.sw_dn_clear,
-                             fx.sw_dn_direct_clear, fdn_s, fdir_s, fup_t);
+                             fx.sw_dn_direct_clear, nullptr, nullptr, nullptr, fdn_s, fdir_s, fup_t);
           if (valid) {
             const size_t og = g + (size_t)ng * col;
             if (MODE == 2) {
@@ -322,22 +352,14 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
             fx.sw_dn_direct_surf_g[og] = fdir_c;
             fx.sw_up_toa_g[og] = fup_c;
           }
-          if (lead) {
-            for (int l = 0; l <= nlev; ++l) {
-              const size_t o = col + ncol * l;
-              fx.sw_up[o] = fx.sw_up_clear[o];
-              fx.sw_dn[o] = fx.sw_dn_clear[o];
-              if (fx.sw_dn_direct) fx.sw_dn_direct[o] = fx.sw_dn_direct_clear[o];
-            }
-          }
         }
         if (MODE == 2 && lead) fx.cloud_cover_sw[col] = tcc;
       }
     } else {
       // sun below the horizon: zero fluxes (radiation_cloudless_sw.F90:203-241, _homogeneous :336-373,
       // _mcica :383-405); McICA leaves cloud_cover_sw at its initial -1
-      if (lead) {
-        for (int l = 0; l <= nlev; ++l) {
+      if (col_ok) {
+        for (int l = glane; l <= nlev; l += NGP) {      // the lanes of a column share its half levels
           const size_t o = col + ncol * l;
           fx.sw_up[o] = 0.0;
           fx.sw_dn[o] = 0.0;
@@ -361,7 +383,16 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
         }
       }
     }
+#ifdef ECRAD_TIMING
+    tm.lap(6);                          // flux sweep
+#endif
   }
+#ifdef ECRAD_TIMING
+  if (blockIdx.x == 0 && tid == 0)
+    printf("sw_ica timing (cycles/level): barrier2 %.0f loads %.0f combine %.0f two-stream %.0f step+store %.0f barrier1+setup %.0f flux-sweep %.0f level_scalars %.0f levels %d\n",
+           (double)tm.acc[0] / tm_levels, (double)tm.acc[1] / tm_levels, (double)tm.acc[2] / tm_levels, (double)tm.acc[3] / tm_levels,
+           (double)tm.acc[4] / tm_levels, (double)tm.acc[5] / tm_levels, (double)tm.acc[6] / tm_levels, (double)tm.acc[7] / tm_levels, tm_levels);
+#endif
 }
 
 template <typename TAB, int NGP>
