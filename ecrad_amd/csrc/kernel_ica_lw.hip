@@ -24,11 +24,11 @@ enum { P_CLR = 0, S_SD1 = 2, P_RT2 = 3, P_S2 = 5, P_AS = 7, L_WIDTH_FULL = 9, L_
 struct LwScratch {
   double* base;
   int width;
-  ECRAD_DEV double2& pair(int off, int lev, int tid) const {
-    return reinterpret_cast<double2*>(base + ((size_t)lev * width + off) * kBlock)[tid];
+  ECRAD_DEV StreamRef<double2> pair(int off, int lev, int tid) const {
+    return {reinterpret_cast<double2*>(base + ((size_t)lev * width + off) * kBlock) + tid};
   }
-  ECRAD_DEV double& single(int off, int lev, int tid) const {
-    return base[((size_t)lev * width + off) * kBlock + tid];
+  ECRAD_DEV StreamRef<double> single(int off, int lev, int tid) const {
+    return {base + ((size_t)lev * width + off) * kBlock + tid};
   }
 };
 
@@ -302,9 +302,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
         const double2 rt = s.pair(P_RT2, l, tid);
         const double R = rt.x;
         const double inv = 1.0 / (1.0 - albn * R);
-        fdn = (rt.y * fdn + R * srcn + s.pair(P_S2, l, tid).y) * inv;
+        const double2 s2 = s.pair(P_S2, l, tid);
+        fdn = (rt.y * fdn + R * srcn + s2.y) * inv;
       } else {
-        fdn = s.pair(P_CLR, l, tid).x * fdn + s.single(S_SD1, l, tid);
+        const double2 ts = s.pair(P_CLR, l, tid);
+        fdn = ts.x * fdn + s.single(S_SD1, l, tid);
       }
       fup = albn * fdn + srcn;
       const double su = group_sum<NGP>(valid ? fup : 0.0);
@@ -333,7 +335,10 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
       const bool modify = MODE == 2 && tcc < 1.0 - cloud_fraction_threshold;
       const double wclr = 1.0 - tcc;
       for (int l = nlev - 1; l >= 0; --l) {
-        d = d * (cloudy.test(l) ? s.pair(P_RT2, l, tid).y : s.pair(P_CLR, l, tid).x);
+        double tl;
+        if (cloudy.test(l)) { const double2 rt = s.pair(P_RT2, l, tid); tl = rt.y; }
+        else { const double2 ts = s.pair(P_CLR, l, tid); tl = ts.x; }
+        d = d * tl;
         const double sder = group_sum<NGP>(valid ? d : 0.0);
         if (lead) {
           const size_t o = col + ncol * l;

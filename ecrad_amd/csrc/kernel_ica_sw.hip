@@ -29,11 +29,11 @@ struct SwScratch {
   double* base;
   int nlev;
   // per block: [set][level][ (pair0: 512 doubles) (pair1: 512 doubles) (single: 256 doubles) ]
-  ECRAD_DEV double2& pair(int set, int k, int lev, int tid) const {
-    return reinterpret_cast<double2*>(base + ((size_t)(set * nlev + lev) * 5 + 2 * k) * kBlock)[tid];
+  ECRAD_DEV StreamRef<double2> pair(int set, int k, int lev, int tid) const {
+    return {reinterpret_cast<double2*>(base + ((size_t)(set * nlev + lev) * 5 + 2 * k) * kBlock) + tid};
   }
-  ECRAD_DEV double& single(int set, int lev, int tid) const {
-    return base[((size_t)(set * nlev + lev) * 5 + 4) * kBlock + tid];
+  ECRAD_DEV StreamRef<double> single(int set, int lev, int tid) const {
+    return {base + ((size_t)(set * nlev + lev) * 5 + 4) * kBlock + tid};
   }
 };
 

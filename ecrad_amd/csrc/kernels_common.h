@@ -282,6 +282,53 @@ ECRAD_DEV void delta_eddington_extensive(double& od, double& scat_od, double& sc
   scat_od_g = scat_od * g / (1.0 + g);
 }
 
+// ---- streaming accesses -----------------------------------------------------------------------------
+// The sweep scratch is written once and read once per column group and is far larger than the caches;
+// marking its accesses non-temporal keeps it from evicting the gas tables (re-read by every layer of
+// every column) from the XCD's L2.
+#ifndef ECRAD_NT_SCRATCH
+#define ECRAD_NT_SCRATCH 1
+#endif
+typedef double ecrad_v2d __attribute__((ext_vector_type(2)));
+
+template <typename T> struct StreamRef;
+template <> struct StreamRef<double> {
+  double* p;
+  ECRAD_DEV void operator=(double v) const {
+#if ECRAD_NT_SCRATCH
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+  }
+  ECRAD_DEV operator double() const {
+#if ECRAD_NT_SCRATCH
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+  }
+};
+template <> struct StreamRef<double2> {
+  double2* p;
+  ECRAD_DEV void operator=(const double2& v) const {
+#if ECRAD_NT_SCRATCH
+    ecrad_v2d t; t.x = v.x; t.y = v.y;
+    __builtin_nontemporal_store(t, reinterpret_cast<ecrad_v2d*>(p));
+#else
+    *p = v;
+#endif
+  }
+  ECRAD_DEV operator double2() const {
+#if ECRAD_NT_SCRATCH
+    const ecrad_v2d t = __builtin_nontemporal_load(reinterpret_cast<const ecrad_v2d*>(p));
+    return make_double2(t.x, t.y);
+#else
+    return *p;
+#endif
+  }
+};
+
 // ---- per-block scratch in HBM ----------------------------------------------------------------------
 // Each block owns a private slab reused for every column group it processes (persistent blocks), so
 // the working set stays bounded (and largely L2/Infinity-Cache resident) however many columns a
