@@ -200,6 +200,7 @@ int setup_ckd(ecrad_hip_handle_t h, const ecrad_ckd_model_t& m, DevCkdModel& d) 
       hot.qoff[pos++] = (uint32_t)(gas_off[j] + slice);
     }
   hot.nquad = pos;
+  for (int k = pos; k < kMaxQuads; ++k) hot.qoff[k] = 0;    // padding look-ups (ECRAD_FIXED_QUADS) stay inside the table
   if (f32) st = upload_as_float(h, all_quads.data(), all_quads.size(), &hot.tab);
   else { const double* p; st = upload<double>(h, all_quads.data(), all_quads.size(), &p); hot.tab = p; }
   if (st) return st;

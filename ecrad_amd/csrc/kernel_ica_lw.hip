@@ -119,17 +119,25 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
       double* const lw_dn = c0.fx.lw_dn;
       double* const lw_dn_clear = have_clear_out ? c0.fx.lw_dn_clear : nullptr;
       ECRAD_LAP0(tm, 7);     // level scalars + group set-up (timing build: booked with the up-sweep)
+#if ECRAD_PIPELINE_LOADS
+      gas_load<TAB>(gh, nquad, nplain, L, cib * NGP, g, quads);     // see kernel_ica_sw.hip
+#endif
       for (int j = 0; j < nl; ++j) {
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
         const int nq = launder_uniform(nquad);
+#if !ECRAD_PIPELINE_LOADS
         gas_load<TAB>(gh, nq, launder_uniform(nplain), L, slot, g, quads);
+#endif
 #ifdef ECRAD_TIMING
         ECRAD_LAP(tm, 0, quads.q[0].x);   // (timing build: table loads alone, booked under "scalars")
 #endif
         const double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
         ECRAD_LAP(tm, 1, planck_bot);   // table + Planck loads returned
         double od = gas_combine<TAB>(nq, L, slot, quads);
+#if ECRAD_PIPELINE_LOADS
+        if (j + 1 < nl) gas_load<TAB>(gh, nq, launder_uniform(nplain), L, slot + 1, g, quads);
+#endif
         ECRAD_LAP(tm, 2, od);           // combine
         if (use_aerosols) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();

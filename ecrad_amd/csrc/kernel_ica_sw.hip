@@ -230,14 +230,25 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
       if (sun_up) {
         const GasHot gh = kernarg_block<SpectralArgs>().gas;
         ECRAD_LAP0(tm, 0);            // level records + barriers (+ group set-up)
+#if ECRAD_PIPELINE_LOADS
+        // Software pipeline without a second register set: the quads of layer j-1 are requested into
+        // the same registers as soon as layer j's have been combined, and travel while the two-stream
+        // and adding arithmetic of layer j runs.
+        gas_load<TAB>(gh, nquad, nplain, L, cib * NGP + nl - 1, g, quads);
+#endif
         for (int j = nl - 1; j >= 0; --j) {
           const int lev = l0 + j;
           const int slot = cib * NGP + j;
           const int nq = launder_uniform(nquad);
           // gas optics: radiation_ecckd_interface.F90:256-281
+#if !ECRAD_PIPELINE_LOADS
           gas_load<TAB>(gh, nq, launder_uniform(nplain), L, slot, g, quads);
+#endif
           ECRAD_LAP(tm, 1, quads.q[0].x);   // table loads returned
           double od = gas_combine<TAB>(nq, L, slot, quads);
+#if ECRAD_PIPELINE_LOADS
+          if (j > 0) gas_load<TAB>(gh, nq, launder_uniform(nplain), L, slot - 1, g, quads);
+#endif
           ECRAD_LAP(tm, 2, od);             // combine
           double ssa = L.D(F_SM, slot) * ray_g;       // Rayleigh optical depth
           od = od + ssa;

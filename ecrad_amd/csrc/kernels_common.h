@@ -24,6 +24,12 @@ constexpr int kBlock = 256;
 #ifndef ECRAD_ABLATE
 #define ECRAD_ABLATE 0
 #endif
+#ifndef ECRAD_FIXED_QUADS
+#define ECRAD_FIXED_QUADS 0     // 1: always issue kMaxQuads table loads (zero-weight padding) -- branch-free level loop
+#endif
+#ifndef ECRAD_PIPELINE_LOADS
+#define ECRAD_PIPELINE_LOADS 0  // request the next layer's table quads right after the current layer's were consumed
+#endif
 #ifndef ECRAD_QUAD_CACHE
 #define ECRAD_QUAD_CACHE 1      // keep table quads in registers while a column stays in the same (p,T) cell
 #endif

@@ -40,7 +40,8 @@ struct LdsLayout {
   // (nquad here is the model's count rounded up to even)
 };
 
-__host__ __device__ inline int lds_record_doubles(int nquad, int nct) { return (F_QMULT + ((nquad + 1) & ~1) + 3 * nct + 1) & ~1; }
+__host__ __device__ inline int lds_padded_quads(int nquad) { return ECRAD_FIXED_QUADS ? kMaxQuads : ((nquad + 1) & ~1); }
+__host__ __device__ inline int lds_record_doubles(int nquad, int nct) { return (F_QMULT + lds_padded_quads(nquad) + 3 * nct + 1) & ~1; }
 
 __host__ __device__ inline size_t lds_bytes(int nquad, int nct) {
   return (size_t)kBlock * lds_record_doubles(nquad, nct) * sizeof(double);
@@ -50,7 +51,7 @@ ECRAD_DEV LdsLayout make_lds(void* smem, int nquad, int nct) {
   LdsLayout L;
   L.d = reinterpret_cast<double*>(smem);
   L.rec2 = lds_record_doubles(nquad, nct) / 2;
-  L.nquad = (nquad + 1) & ~1;
+  L.nquad = lds_padded_quads(nquad);
   L.nct = nct;
   return L;
 }
@@ -107,6 +108,9 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
     L.D(F_QMULT + k, slot) = mult;
   }
   if (m.hot.pad_pos >= 0) L.D(F_QMULT + m.hot.pad_pos, slot) = 0.0;
+#if ECRAD_FIXED_QUADS
+  for (int q = m.hot.nquad; q < kMaxQuads; ++q) L.D(F_QMULT + q, slot) = 0.0;
+#endif
   L.D(F_PW2, slot) = pw2;
   L.D(F_TW2, slot) = tw2;
   if (IS_SW) L.D(F_SM, slot) = simple_multiplier;
@@ -207,15 +211,20 @@ ECRAD_DEV void gas_load(const GasHot& gh, int nquad, int nplain, const LdsLayout
   using Quad = typename QuadOf<TAB>::type;
   const Quad* __restrict__ tab = reinterpret_cast<const Quad*>(gh.tab);
   const int2 key = *reinterpret_cast<const int2*>(reinterpret_cast<const int*>(L.R(slot)) + I_CELL);   // {cell, lut}
-#if ECRAD_QUAD_CACHE
+#if ECRAD_QUAD_CACHE == 2
+  // per-lane decision: fewest bytes, but every conditional pair of loads becomes its own exec-masked
+  // region and the compiler waits for each before the next (five serialised L2 round trips)
   const bool new_cell = key.x != r.cell, new_lut = key.y != r.lut;
+#elif ECRAD_QUAD_CACHE
+  // wave-uniform decision (a wave holds 64/NGP columns): re-load when any of them changed cell
+  const bool new_cell = __ballot(key.x != r.cell) != 0ull, new_lut = __ballot(key.y != r.lut) != 0ull;
 #else
   const bool new_cell = true, new_lut = true;
 #endif
   const unsigned plain_g = (unsigned)(key.x + g), lut_g = (unsigned)(key.y + g);
 #pragma unroll
   for (int k = 0; k < kMaxQuads; k += 2) {
-    if (k < nquad) {
+    if (ECRAD_FIXED_QUADS || k < nquad) {
       const bool is_plain = k < nplain;
       if (is_plain ? new_cell : new_lut) {
 #if ECRAD_ABLATE & 1
@@ -244,7 +253,7 @@ ECRAD_DEV double gas_combine(int nquad, const LdsLayout& L, int slot, const GasR
   double od = 0.0;
 #pragma unroll
   for (int k = 0; k < kMaxQuads; k += 2) {
-    if (k < nquad) {
+    if (ECRAD_FIXED_QUADS || k < nquad) {
       const double2 qm = *reinterpret_cast<const double2*>(rec + F_QMULT + k);
       od += qm.x * (w00 * r.q[k].x + w10 * r.q[k].y + w01 * r.q[k].z + w11 * r.q[k].w);
       od += qm.y * (w00 * r.q[k + 1].x + w10 * r.q[k + 1].y + w01 * r.q[k + 1].z + w11 * r.q[k + 1].w);
