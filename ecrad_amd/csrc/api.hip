@@ -483,27 +483,54 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
     o.n_type_philic = a.n_type_philic; o.nrh = a.nrh; o.use_hydrophilic = a.use_hydrophilic; o.ntype = a.ntype;
     if ((c.do_sw && a.n_bands_sw != c.n_bands_sw) || (c.do_lw && a.n_bands_lw != c.n_bands_lw))
       return fail(h, ECRAD_EINVAL, "number of bands does not match aerosol optics look-up table");   // radiation_aerosol_optics.F90:62-74
-    if ((st = upload<int32_t>(h, a.iclass, a.ntype, &o.iclass))) return st;
-    if ((st = upload<int32_t>(h, a.itype, a.ntype, &o.itype))) return st;
     if ((st = upload<double>(h, a.rh_lower, a.nrh, &o.rh_lower))) return st;
+    std::vector<int32_t> jt, row0, philic;
     for (int j = 0; j < a.ntype; ++j) {
       if (a.iclass[j] == ECRAD_AEROSOL_UNDEFINED) return fail(h, ECRAD_EINVAL, "not all aerosol types are defined");  // :545-550
       if (a.iclass[j] == ECRAD_AEROSOL_HYDROPHOBIC && (a.itype[j] < 1 || a.itype[j] > a.n_type_phobic)) return fail(h, ECRAD_EINVAL, "hydrophobic type out of range");
       if (a.iclass[j] == ECRAD_AEROSOL_HYDROPHILIC && (a.itype[j] < 1 || a.itype[j] > a.n_type_philic)) return fail(h, ECRAD_EINVAL, "hydrophilic type out of range");
+      if (a.iclass[j] == ECRAD_AEROSOL_HYDROPHILIC && !a.use_hydrophilic) return fail(h, ECRAD_EINVAL, "hydrophilic aerosol type without hydrophilic tables");
+      if (a.iclass[j] == ECRAD_AEROSOL_HYDROPHOBIC) { jt.push_back(j); row0.push_back(a.itype[j] - 1); philic.push_back(0); }
+      else if (a.iclass[j] == ECRAD_AEROSOL_HYDROPHILIC) {
+        jt.push_back(j); row0.push_back(a.n_type_phobic + a.nrh * (a.itype[j] - 1)); philic.push_back(1);
+      }
     }
+    o.nactive = (int32_t)jt.size();
+    if (o.nactive > kMaxActiveAerosols) return fail(h, ECRAD_EUNSUPPORTED, "more than 16 active (hydrophobic or hydrophilic) aerosol types");
+    for (int k = 0; k < o.nactive; ++k) {
+      if (jt[k] > 255 || row0[k] >= (1 << 23)) return fail(h, ECRAD_EUNSUPPORTED, "aerosol type table too large");
+      o.active[k] = (uint32_t)jt[k] | ((uint32_t)philic[k] << 8) | ((uint32_t)row0[k] << 9);
+    }
+    // {mass_ext, ssa} pairs and asymmetry per (row, band): hydrophobic rows then hydrophilic rows
+    auto build = [&](int nb, const double* const pho[3], const double* const phi[3], std::vector<double>& t01, std::vector<double>& t2) {
+      const size_t nrow = (size_t)a.n_type_phobic + (size_t)a.nrh * a.n_type_philic;
+      t01.assign(nrow * nb * 2, 0.0);
+      t2.assign(nrow * nb, 0.0);
+      for (int k = 0; k < 3; ++k) {
+        for (size_t r = 0; r < nrow; ++r)
+          for (int b = 0; b < nb; ++b) {
+            const bool is_pho = r < (size_t)a.n_type_phobic;
+            const double* src = is_pho ? pho[k] : phi[k];
+            if (!src) continue;
+            const double v = src[b + (size_t)nb * (is_pho ? r : r - a.n_type_phobic)];
+            if (k < 2) t01[(r * nb + b) * 2 + k] = v; else t2[r * nb + b] = v;
+          }
+      }
+    };
     const double* src_sw_pho[3] = {a.mass_ext_sw_phobic, a.ssa_sw_phobic, a.g_sw_phobic};
     const double* src_lw_pho[3] = {a.mass_ext_lw_phobic, a.ssa_lw_phobic, a.g_lw_phobic};
     const double* src_sw_phi[3] = {a.mass_ext_sw_philic, a.ssa_sw_philic, a.g_sw_philic};
     const double* src_lw_phi[3] = {a.mass_ext_lw_philic, a.ssa_lw_philic, a.g_lw_philic};
-    for (int k = 0; k < 3; ++k) {
-      if (c.do_sw) {
-        if ((st = upload<double>(h, src_sw_pho[k], (size_t)a.n_bands_sw * a.n_type_phobic, &o.sw_phobic[k]))) return st;
-        if ((st = upload<double>(h, src_sw_phi[k], (size_t)a.n_bands_sw * a.nrh * a.n_type_philic, &o.sw_philic[k]))) return st;
-      }
-      if (c.do_lw) {
-        if ((st = upload<double>(h, src_lw_pho[k], (size_t)a.n_bands_lw * a.n_type_phobic, &o.lw_phobic[k]))) return st;
-        if ((st = upload<double>(h, src_lw_phi[k], (size_t)a.n_bands_lw * a.nrh * a.n_type_philic, &o.lw_philic[k]))) return st;
-      }
+    std::vector<double> t01, t2;
+    if (c.do_sw) {
+      build(a.n_bands_sw, src_sw_pho, src_sw_phi, t01, t2);
+      if ((st = upload<double>(h, t01.data(), t01.size(), &o.sw_tab01))) return st;
+      if ((st = upload<double>(h, t2.data(), t2.size(), &o.sw_tab2))) return st;
+    }
+    if (c.do_lw) {
+      build(a.n_bands_lw, src_lw_pho, src_lw_phi, t01, t2);
+      if ((st = upload<double>(h, t01.data(), t01.size(), &o.lw_tab01))) return st;
+      if ((st = upload<double>(h, t2.data(), t2.size(), &o.lw_tab2))) return st;
     }
   }
   if (c.pdf_sampler.val) {
@@ -738,8 +765,8 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
       HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_lw, 997, prep.od_scaling_lw,
                                         prep.total_cloud_cover_lw, prep.rng_state, mcica_work));
     }
-    if (lw_tc) HIP_TRY(h, launch_lw_tc(h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_lw, counters));
-    else HIP_TRY(h, launch_lw_ica(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_lw, counters, m));
+    if (lw_tc) HIP_TRY(h, launch_lw_tc(h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_lw, counters, m));
+    else HIP_TRY(h, launch_lw_ica(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_lw, counters, m));
   }
   HIP_TRY(h, hipEventRecord(h->evs[2], stream));
   if (c.do_sw) {                                                                        // :459-499
@@ -751,8 +778,8 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
       HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_sw, 0, prep.od_scaling_sw,
                                         prep.total_cloud_cover_sw, prep.rng_state, mcica_work));
     }
-    if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_sw, counters + 16));
-    else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->dcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m));
+    if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m));
+    else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m));
   }
   HIP_TRY(h, hipEventRecord(h->evs[3], stream));
   HIP_TRY(h, launch_spectral_post(stream, h->dcfg, din, dfx));                          // :503-504

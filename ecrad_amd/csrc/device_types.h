@@ -9,6 +9,7 @@ namespace ecrad {
 constexpr int kMaxGas = ECRAD_NMAXGASES;
 constexpr int kMaxCloudTypes = ECRAD_NMAXCLOUDTYPES;
 constexpr int kNReg = 3;
+constexpr int kMaxActiveAerosols = 16;   // hydrophobic + hydrophilic types in one call (IFS: 12)
 constexpr int kMaxQuads = 10;   // quad loads per layer: ngas + (number of LUT gases); 9 for ecCKD LW-32
 constexpr double kAccelDueToGravity = 9.80665;          // radiation_constants.F90:26
 constexpr double kAirMolarMass = 28.970;                // radiation_gas_constants.F90:41
@@ -61,12 +62,18 @@ struct DevCloudOptics {
 };
 
 struct DevAerosolOptics {
-  int32_t n_bands_sw, n_bands_lw, n_type_phobic, n_type_philic, nrh, use_hydrophilic, ntype, pad_;
-  const int32_t *iclass, *itype;
+  int32_t n_bands_sw, n_bands_lw, n_type_phobic, n_type_philic, nrh, use_hydrophilic, ntype;
+  int32_t nactive;             // types that are hydrophobic or hydrophilic (the others are ignored)
   const double* rh_lower;
-  // Pre-combined per-band tables (bands fastest): ext, ext*ssa, ext*ssa*g (SW); LW: ext*(1-ssa) or the
-  // same three when aerosols scatter in the longwave.  Hydrophilic tables are (nb, nrh, ntype).
-  const double *sw_phobic[3], *sw_philic[3], *lw_phobic[3], *lw_philic[3];
+  // Tables per spectrum, row-major [row][band] with the band (= lane) fastest: {mass_ext, ssa} pairs and
+  // the asymmetry factor; rows [0, n_type_phobic) are the hydrophobic types, then (nrh x n_type_philic)
+  // hydrophilic rows.  A column group reads 512 + 256 contiguous bytes per type.
+  const double *sw_tab01, *sw_tab2, *lw_tab01, *lw_tab2;
+  // per ACTIVE type, in the order of the caller's type list, packed as
+  //   bits 0-7 index into aerosol%mixing_ratio | bit 8 hydrophilic (add the humidity bin to the row) |
+  //   bits 9-31 first row in the tables
+  // (held in the struct, i.e. in the kernel-argument segment: scalar loads, no pointer chasing)
+  uint32_t active[kMaxActiveAerosols];
 };
 
 struct DevPdfSampler {
@@ -152,8 +159,12 @@ struct DevCloudPrep {
 };
 
 // Argument block of the spectral (lane = g) kernels; see kernarg_block() in kernels_common.h
+// The whole configuration travels by value (3.3 KB of the 4 KB kernel-argument segment): reads of
+// switches, sizes and table pointers are then scalar loads from constant memory wherever they occur,
+// whereas loads through a pointer to global memory stop being scalar as soon as the kernel has stored
+// anything (the compiler cannot prove the stores do not alias the configuration).
 struct SpectralArgs {
-  const DevConfig* cfg;
+  DevConfig cfg;
   DevInputs in;
   DevFlux fx;
   DevCloudPrep prep;

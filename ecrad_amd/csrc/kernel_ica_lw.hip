@@ -32,7 +32,10 @@ struct LwScratch {
   }
 };
 
-constexpr int kLwBatch = ECRAD_SWEEP_BATCH;
+#ifndef ECRAD_LW_BATCH
+#define ECRAD_LW_BATCH ECRAD_SWEEP_BATCH
+#endif
+constexpr int kLwBatch = ECRAD_LW_BATCH;    // (T, S) pairs are 16 B per layer, so the longwave sweep can look further ahead
 
 template <typename TAB, int NGP, int MODE>
 __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(SpectralArgs args_in_kernarg) {
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
   for (;;) {
     // ---- per column group (see kernarg_block() for why the arguments are re-read per phase) --------
     const SpectralArgs& a = kernarg_block<SpectralArgs>();
-    const DevConfig& cfg = *a.cfg;
+    const DevConfig& cfg = a.cfg;
     const DevCkdModel& m = cfg.gas_lw;
     const int ng = m.ng, nlev = a.in.nlev;
     const size_t ncol = a.in.ncol;
@@ -108,13 +111,13 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
       {
         const SpectralArgs& b = kernarg_block<SpectralArgs>();
         const int lev = l0 + glane;
-        if (lev < nlev) level_scalars<false>(*b.cfg, b.cfg->gas_lw, b.in, L, tid, col, lev, want_clouds);
+        if (lev < nlev) level_scalars<false>(b.cfg, b.cfg.gas_lw, b.in, L, tid, col, lev, want_clouds);
       }
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
       const SpectralArgs& c0 = kernarg_block<SpectralArgs>();
       const GasHot gh = c0.gas;
-      const PlanckTab<TAB> pt{c0.cfg->gas_lw.planck_function, ng};
+      const PlanckTab<TAB> pt{c0.cfg.gas_lw.planck_function, ng};
       double keep_dn = 0.0;
       double* const lw_dn = c0.fx.lw_dn;
       double* const lw_dn_clear = have_clear_out ? c0.fx.lw_dn_clear : nullptr;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
         ECRAD_LAP(tm, 2, od);           // combine
         if (use_aerosols) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
-          const AerosolLayer al = aerosol_layer<false>(*b.cfg, b.in, L, slot, col, lev, ib);
+          const AerosolLayer al = aerosol_layer<false>(b.cfg, b.in, L, slot, col, lev, ib);
           od = od + al.od;   // radiation_aerosol_optics.F90:805-818 (no longwave aerosol scattering)
         }
         const LwCoef c = no_scattering_lw(od, planck_top, planck_bot);
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
             if (!cloudy.any()) { ict = lev; fdn_ctop = fdn_c; }
             cloudy.set(lev);
             const SpectralArgs& b = kernarg_block<SpectralArgs>();
-            const CloudLayer cl = cloud_layer<false>(*b.cfg, L, slot, ib);
+            const CloudLayer cl = cloud_layer<false>(b.cfg, L, slot, ib);
             double od_cloud_new = cl.od;
             if (MODE == 2) od_cloud_new = b.prep.od_scaling_lw[g + (size_t)ng * (lev + (size_t)nlev * cloc)] * cl.od;
             const double od_total = od + od_cloud_new;
@@ -388,7 +391,7 @@ size_t lw_ica_scratch_doubles(int mode, int nlev) {
 }
 
 hipError_t launch_lw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
-                         const DevConfig* cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
+                         const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
                          double* scratch, size_t per_block, int* counter, const DevCkdModel& m) {
   dim3 g(grid);
   const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot};

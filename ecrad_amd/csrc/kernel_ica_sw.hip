@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
   for (;;) {
     // ---- per column group ---------------------------------------------------------------------------
     const SpectralArgs& a = kernarg_block<SpectralArgs>();
-    const DevConfig& cfg = *a.cfg;
+    const DevConfig& cfg = a.cfg;
     const DevCkdModel& m = cfg.gas_sw;
     const int ng = m.ng, nlev = a.in.nlev;
     const size_t ncol = a.in.ncol;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
       {
         const SpectralArgs& b = kernarg_block<SpectralArgs>();
         const int lev = l0 + glane;
-        if (lev < nlev) level_scalars<true>(*b.cfg, b.cfg->gas_sw, b.in, L, tid, col, lev, want_clouds);
+        if (lev < nlev) level_scalars<true>(b.cfg, b.cfg.gas_sw, b.in, L, tid, col, lev, want_clouds);
       }
       ECRAD_LAP0(tm, 7);              // (timing build) level records computed
       __syncthreads();
@@ -256,9 +256,9 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
           double asym = 0.0;
           if (flags & SWF_AEROSOLS) {
             const SpectralArgs& b = kernarg_block<SpectralArgs>();
-            AerosolLayer al = aerosol_layer<true>(*b.cfg, b.in, L, slot, col, lev, ib);
+            AerosolLayer al = aerosol_layer<true>(b.cfg, b.in, L, slot, col, lev, ib);
             if (!(flags & SWF_DELTA_GASES)) delta_eddington_extensive_vec(al);
-            merge_aerosol_sw(*b.cfg, al, od, ssa, asym);
+            merge_aerosol_sw(b.cfg, al, od, ssa, asym);
           }
           double od1 = od, ssa1 = ssa, g1 = asym;
           if (flags & SWF_DELTA_GASES) delta_eddington(od1, ssa1, g1);
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
             if (layer_cloudy) {
               if (lcb < 0) { lcb = lev; st2 = st1; }     // below the lowest cloud both sets coincide
               const SpectralArgs& b = kernarg_block<SpectralArgs>();
-              const CloudLayer cl = cloud_layer<true>(*b.cfg, L, slot, ib);
+              const CloudLayer cl = cloud_layer<true>(b.cfg, L, slot, ib);
               double od_total, ssa_total = 0.0, g_total = 0.0;
               if (MODE == 1) {   // radiation_homogeneous_sw.F90:236-253
                 od_total = od + cl.od;
@@ -431,7 +431,7 @@ size_t sw_ica_scratch_doubles(int mode, int nlev) {
 }
 
 hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
-                         const DevConfig* cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
+                         const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
                          double* scratch, size_t per_block, int* counter, const DevCkdModel& m) {
   dim3 g(grid);
   const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot};

@@ -35,41 +35,45 @@ constexpr int SW_TACD = 22;    // total_albedo_clear_direct
 constexpr int SW_TC_NUM = 23;
 
 template <typename TAB, int NGP>
-__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevFlux fx,
-                                                      DevCloudPrep prep, double* scratch_base, size_t scratch_per_block,
-                                                      int* work_counter) {
+__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
-  const DevConfig& cfg = *cfgp;
-  const DevCkdModel& m = cfg.gas_sw;
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
   const int glane = tid % NGP, cib = tid / NGP;
-  const int ng = m.ng, nlev = in.nlev;
-  const size_t ncol = in.ncol;
-  const int ncol_loc = in.iendcol - in.istartcol + 1;
-  const int ngroups = (ncol_loc + CPB - 1) / CPB;
-  const LdsLayout L = make_lds(smem, m.hot.nquad, cfg.n_cloud_types);
-  const Scratch s{scratch_base + (size_t)blockIdx.x * scratch_per_block, nlev + 1};
-  const int g = glane < ng ? glane : ng - 1;
-  const int ib = cfg.i_band_from_reordered_g_sw[g] - 1;
-  const double ray_g = m.rayleigh_molar_scat[g];
-  const bool do_clear = cfg.do_clear != 0;
+  GasRegs<TAB> quads;
+  quads.invalidate();
 
   for (;;) {
+    // per column group; the argument block is re-read per phase (see kernarg_block)
+    const SpectralArgs& a = kernarg_block<SpectralArgs>();
+    const DevConfig& cfg = a.cfg;
+    const DevCkdModel& m = cfg.gas_sw;
+    const DevInputs& in = a.in;
+    const int ng = m.ng, nlev = in.nlev;
+    const size_t ncol = in.ncol;
+    const int ncol_loc = in.iendcol - in.istartcol + 1;
+    const int ngroups = (ncol_loc + CPB - 1) / CPB;
     __syncthreads();
-    if (tid == 0) next_group = atomicAdd(work_counter, 1);
+    if (tid == 0) next_group = atomicAdd(a.counter, 1);
     __syncthreads();
     const int grp = next_group;
     if (grp >= ngroups) break;
+    const LdsLayout L = make_lds(smem, m.hot.nquad, cfg.n_cloud_types);
+    const Scratch s{a.scratch + (size_t)blockIdx.x * a.per_block, nlev + 1};
+    const int g = glane < ng ? glane : ng - 1;
+    const int ib = cfg.i_band_from_reordered_g_sw[g] - 1;
+    const double ray_g = m.rayleigh_molar_scat[g];
+    const bool do_clear = cfg.do_clear != 0;
+    const bool use_aerosols = cfg.use_aerosols != 0, delta_gases = cfg.do_sw_delta_scaling_with_gases != 0;
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
     const int col = in.istartcol - 1 + cloc;
     const bool valid = col_ok && glane < ng;
-    const bool lead = glane == 0 && col_ok;
     const double mu0 = in.cos_sza[col];
     const bool sun_up = !(mu0 < 1.0e-10);
+    const DevCloudPrep prep = a.prep;
     const TcGeom geo{prep, ncol_loc, nlev, cloc};
     double alb_dif = 0.0, alb_dir = 0.0, incoming = 0.0;
     if (sun_up) {
@@ -83,24 +87,28 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(const De
     for (int l0 = 0; l0 < nlev; l0 += NGP) {
       __syncthreads();
       {
+        const SpectralArgs& b = kernarg_block<SpectralArgs>();
         const int lev = l0 + glane;
-        if (lev < nlev) level_scalars<true>(cfg, m, in, L, tid, col, lev, true);
+        if (lev < nlev) level_scalars<true>(b.cfg, b.cfg.gas_sw, b.in, L, tid, col, lev, true);
       }
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
       if (sun_up) {
+        const GasHot gh = kernarg_block<SpectralArgs>().gas;
         for (int j = 0; j < nl; ++j) {
           const int lev = l0 + j;
           const int slot = cib * NGP + j;
-          double od = gas_absorption_od<TAB>(m.hot, L, slot, g);
+          gas_load<TAB>(gh, launder_uniform(gh.nquad), launder_uniform(gh.nplain), L, slot, g, quads);
+          double od = gas_combine<TAB>(launder_uniform(gh.nquad), L, slot, quads);
           double ssa = L.D(F_SM, slot) * ray_g;
           od = od + ssa;
           ssa = ssa / od;
           double asym = 0.0;
-          if (cfg.use_aerosols) {
-            AerosolLayer a = aerosol_layer<true>(cfg, in, L, slot, col, lev, ib);
-            if (!cfg.do_sw_delta_scaling_with_gases) delta_eddington_extensive_vec(a);
-            merge_aerosol_sw(cfg, a, od, ssa, asym);
+          if (use_aerosols) {
+            const SpectralArgs& b = kernarg_block<SpectralArgs>();
+            AerosolLayer al = aerosol_layer<true>(b.cfg, b.in, L, slot, col, lev, ib);
+            if (!delta_gases) delta_eddington_extensive_vec(al);
+            merge_aerosol_sw(b.cfg, al, od, ssa, asym);
           }
           {
             const SwCoef c = ref_trans_sw_fused(mu0, od, ssa, asym);
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(const De
           }
           if (L.D(F_FRAC, slot) > 0.0) {
             cloudy.set(lev);
-            const CloudLayer cl = cloud_layer<true>(cfg, L, slot, ib);
+            const CloudLayer cl = cloud_layer<true>(kernarg_block<SpectralArgs>().cfg, L, slot, ib);
 #pragma unroll
             for (int jreg = 1; jreg < 3; ++jreg) {   // radiation_tripleclouds_sw.F90:278-300
               const double osc = geo.odsc(jreg, lev);
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(const De
               double od_total = od + cl.od * osc;
               double ssa_total = (scat_od + scat_od_cloud) / od_total;
               double g_total = (scat_od * asym + scat_od_cloud * cl.g) / (scat_od + scat_od_cloud);
-              if (cfg.do_sw_delta_scaling_with_gases) delta_eddington(od_total, ssa_total, g_total);
+              if (delta_gases) delta_eddington(od_total, ssa_total, g_total);
               const SwCoef c = ref_trans_sw_fused(mu0, od_total, ssa_total, g_total);
               s.at(sw_coef(0, jreg), lev, tid) = c.ref_diff;
               s.at(sw_coef(1, jreg), lev, tid) = c.trans_diff;
@@ -134,9 +142,10 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(const De
       }
     }
 
+    const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
     if (!sun_up) {   // radiation_tripleclouds_sw.F90:212-249
-      if (lead) {
-        for (int l = 0; l <= nlev; ++l) {
+      if (col_ok) {
+        for (int l = glane; l <= nlev; l += NGP) {     // the lanes of a column share its half levels
           const size_t o = col + ncol * l;
           fx.sw_up[o] = 0.0; fx.sw_dn[o] = 0.0;
           if (fx.sw_dn_direct) fx.sw_dn_direct[o] = 0.0;
@@ -225,6 +234,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(const De
       if (fx.sw_dn_toa_g) fx.sw_dn_toa_g[og] = incoming * mu0;
       if (do_clear) fx.sw_up_toa_clear_g[og] = fup_c;
     }
+    LevelSums<NGP, 6> kept;
     for (int hl = 0; hl <= nlev; ++hl) {
       if (hl > 0) {
         const int l = hl - 1;
@@ -274,24 +284,28 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(const De
           for (int r = 0; r < 3; ++r) { fdn[r] = nf[r]; ddn[r] = nd[r]; }
         }
       }
-      const double su = group_sum<NGP>(valid ? fup[0] + fup[1] + fup[2] : 0.0);
-      const double sd = group_sum<NGP>(valid ? fdn[0] + fdn[1] + fdn[2] : 0.0);
-      const double sdir = group_sum<NGP>(valid ? ddn[0] + ddn[1] + ddn[2] : 0.0);
-      double suc = 0.0, sdc = 0.0, sdirc = 0.0;
+      double sums[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      sums[0] = group_sum<NGP>(valid ? fup[0] + fup[1] + fup[2] : 0.0);
+      sums[1] = group_sum<NGP>(valid ? fdn[0] + fdn[1] + fdn[2] : 0.0);
+      sums[2] = group_sum<NGP>(valid ? ddn[0] + ddn[1] + ddn[2] : 0.0);
       if (do_clear) {
-        suc = group_sum<NGP>(valid ? fup_c : 0.0);
-        sdc = group_sum<NGP>(valid ? fdn_c : 0.0);
-        sdirc = group_sum<NGP>(valid ? ddn_c : 0.0);
+        sums[3] = group_sum<NGP>(valid ? fup_c : 0.0);
+        sums[4] = group_sum<NGP>(valid ? fdn_c : 0.0);
+        sums[5] = group_sum<NGP>(valid ? ddn_c : 0.0);
       }
-      if (lead) {
-        const size_t o = col + ncol * hl;
-        fx.sw_up[o] = su;
-        fx.sw_dn[o] = mu0 * sdir + sd;
-        if (fx.sw_dn_direct) fx.sw_dn_direct[o] = mu0 * sdir;
-        if (do_clear) {
-          fx.sw_up_clear[o] = suc;
-          fx.sw_dn_clear[o] = mu0 * sdirc + sdc;
-          if (fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[o] = mu0 * sdirc;
+      kept.keep(hl, glane, sums);
+      if ((hl & (NGP - 1)) == NGP - 1 || hl == nlev) {      // write NGP half levels at a time
+        const int lv = kept.mine(hl, glane);
+        if (col_ok && lv <= hl) {
+          const size_t o = col + ncol * lv;
+          fx.sw_up[o] = kept.v[0];
+          fx.sw_dn[o] = mu0 * kept.v[2] + kept.v[1];
+          if (fx.sw_dn_direct) fx.sw_dn_direct[o] = mu0 * kept.v[2];
+          if (do_clear) {
+            fx.sw_up_clear[o] = kept.v[3];
+            fx.sw_dn_clear[o] = mu0 * kept.v[5] + kept.v[4];
+            if (fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[o] = mu0 * kept.v[5];
+          }
         }
       }
     }
@@ -309,10 +323,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(const De
 
 size_t sw_tc_scratch_doubles(int nlev) { return (size_t)SW_TC_NUM * (nlev + 1) * kBlock; }
 
-hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig* cfg,
+hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block,
-                        int* counter) {
-#define ECRAD_L(T, N) do { ECRAD_ALLOW_LDS((sw_tc_kernel<T, N>), lds); hipLaunchKernelGGL((sw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter); } while (0)
+                        int* counter, const DevCkdModel& m) {
+  const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot};
+#define ECRAD_L(T, N) do { ECRAD_ALLOW_LDS((sw_tc_kernel<T, N>), lds); hipLaunchKernelGGL((sw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
   if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
   else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }
 #undef ECRAD_L
@@ -329,39 +344,44 @@ constexpr int LT_TS = 14;     // total_source[3]   14..16
 constexpr int LW_TC_NUM = 17;
 
 template <typename TAB, int NGP>
-__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevFlux fx,
-                                                      DevCloudPrep prep, double* scratch_base, size_t scratch_per_block,
-                                                      int* work_counter) {
+__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
-  const DevConfig& cfg = *cfgp;
-  const DevCkdModel& m = cfg.gas_lw;
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
   const int glane = tid % NGP, cib = tid / NGP;
-  const int ng = m.ng, nlev = in.nlev;
-  const size_t ncol = in.ncol;
-  const int ncol_loc = in.iendcol - in.istartcol + 1;
-  const int ngroups = (ncol_loc + CPB - 1) / CPB;
-  const LdsLayout L = make_lds(smem, m.hot.nquad, cfg.n_cloud_types);
-  const Scratch s{scratch_base + (size_t)blockIdx.x * scratch_per_block, nlev + 1};
-  const int g = glane < ng ? glane : ng - 1;
-  const int ib = cfg.i_band_from_reordered_g_lw[g] - 1;
-  const bool do_clear = cfg.do_clear != 0;
-  const bool do_deriv = cfg.do_lw_derivatives != 0 && fx.lw_derivatives != nullptr;
+  GasRegs<TAB> quads;
+  quads.invalidate();
 
   for (;;) {
+    // per column group; the argument block is re-read per phase (see kernarg_block)
+    const SpectralArgs& a = kernarg_block<SpectralArgs>();
+    const DevConfig& cfg = a.cfg;
+    const DevCkdModel& m = cfg.gas_lw;
+    const DevInputs& in = a.in;
+    const int ng = m.ng, nlev = in.nlev;
+    const size_t ncol = in.ncol;
+    const int ncol_loc = in.iendcol - in.istartcol + 1;
+    const int ngroups = (ncol_loc + CPB - 1) / CPB;
     __syncthreads();
-    if (tid == 0) next_group = atomicAdd(work_counter, 1);
+    if (tid == 0) next_group = atomicAdd(a.counter, 1);
     __syncthreads();
     const int grp = next_group;
     if (grp >= ngroups) break;
+    const LdsLayout L = make_lds(smem, m.hot.nquad, cfg.n_cloud_types);
+    const Scratch s{a.scratch + (size_t)blockIdx.x * a.per_block, nlev + 1};
+    const int g = glane < ng ? glane : ng - 1;
+    const int ib = cfg.i_band_from_reordered_g_lw[g] - 1;
+    const bool do_clear = cfg.do_clear != 0;
+    const bool do_deriv = cfg.do_lw_derivatives != 0 && a.fx.lw_derivatives != nullptr;
+    const bool use_aerosols = cfg.use_aerosols != 0, cloud_scattering = cfg.do_lw_cloud_scattering != 0;
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
     const int col = in.istartcol - 1 + cloc;
     const bool valid = col_ok && glane < ng;
     const bool lead = glane == 0 && col_ok;
+    const DevCloudPrep prep = a.prep;
     const TcGeom geo{prep, ncol_loc, nlev, cloc};
     const double albedo = albedo_lw_g(cfg, in, col, g);
     const double emission = planck_at<TAB>(m, in.skin_temperature[col], g) * (1.0 - albedo);
@@ -373,23 +393,34 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(const De
 
     // ---- pass A ---------------------------------------------------------------------------------------
     if (lead) {
-      if (do_clear) fx.lw_dn_clear[col] = 0.0;
-      fx.lw_dn[col] = 0.0;
+      if (do_clear) a.fx.lw_dn_clear[col] = 0.0;
+      a.fx.lw_dn[col] = 0.0;
     }
     for (int l0 = 0; l0 < nlev; l0 += NGP) {
       __syncthreads();
       {
+        const SpectralArgs& b = kernarg_block<SpectralArgs>();
         const int lev = l0 + glane;
-        if (lev < nlev) level_scalars<false>(cfg, m, in, L, tid, col, lev, true);
+        if (lev < nlev) level_scalars<false>(b.cfg, b.cfg.gas_lw, b.in, L, tid, col, lev, true);
       }
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
+      const SpectralArgs& c0 = kernarg_block<SpectralArgs>();
+      const GasHot gh = c0.gas;
+      const PlanckTab<TAB> pt{c0.cfg.gas_lw.planck_function, ng};
+      double* const lw_dn = c0.fx.lw_dn;
+      double* const lw_dn_clear = do_clear ? c0.fx.lw_dn_clear : nullptr;
+      double keep_dn = 0.0;
       for (int j = 0; j < nl; ++j) {
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
-        double od = gas_absorption_od<TAB>(m.hot, L, slot, g);
-        const double planck_bot = planck_lookup<TAB>(m, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
-        if (cfg.use_aerosols) od = od + aerosol_layer<false>(cfg, in, L, slot, col, lev, ib).od;
+        gas_load<TAB>(gh, launder_uniform(gh.nquad), launder_uniform(gh.nplain), L, slot, g, quads);
+        const double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
+        double od = gas_combine<TAB>(launder_uniform(gh.nquad), L, slot, quads);
+        if (use_aerosols) {
+          const SpectralArgs& b = kernarg_block<SpectralArgs>();
+          od = od + aerosol_layer<false>(b.cfg, b.in, L, slot, col, lev, ib).od;
+        }
         const LwCoef c = no_scattering_lw(od, planck_top, planck_bot);
         s.at(LT_T1, lev, tid) = c.transmittance;
         s.at(LT_SU1, lev, tid) = c.source_up;
@@ -397,13 +428,13 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(const De
         if (L.D(F_FRAC, slot) > 0.0) {
           if (!cloudy.any()) { ict = lev; fdn_ctop = fdn_c; }
           cloudy.set(lev);
-          const CloudLayer cl = cloud_layer<false>(cfg, L, slot, ib);
+          const CloudLayer cl = cloud_layer<false>(kernarg_block<SpectralArgs>().cfg, L, slot, ib);
 #pragma unroll
           for (int jreg = 1; jreg < 3; ++jreg) {    // radiation_tripleclouds_lw.F90:318-372
             const double od_cloud_new = cl.od * geo.odsc(jreg, lev);
             const double od_total = od + od_cloud_new;
             LwCoef c2;
-            if (cfg.do_lw_cloud_scattering) {
+            if (cloud_scattering) {
               double ssa_total = 0.0, g_total = 0.0;
               if (od_total > 0.0) ssa_total = cl.ssa * od_cloud_new / od_total;
               if (ssa_total > 0.0 && od_total > 0.0) g_total = cl.g * cl.ssa * od_cloud_new / (ssa_total * od_total);
@@ -419,26 +450,33 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(const De
         }
         fdn_c = c.transmittance * fdn_c + c.source_dn;
         const double sd = group_sum<NGP>(valid ? fdn_c : 0.0);
-        if (lead) {
-          const size_t o = col + ncol * (lev + 1);
-          fx.lw_dn[o] = sd;      // provisional: replaced below cloud top by the all-sky value
-          if (do_clear) fx.lw_dn_clear[o] = sd;
-        }
+        if (glane == j) keep_dn = sd;     // lane j keeps the chunk's layer j; one store per chunk
         planck_top = planck_bot;
+      }
+      if (col_ok && glane < nl) {
+        const size_t o = col + ncol * (l0 + glane + 1);
+        lw_dn[o] = keep_dn;      // provisional: replaced below cloud top by the all-sky value
+        if (lw_dn_clear) lw_dn_clear[o] = keep_dn;
       }
     }
     if (!cloudy.any()) { ict = nlev; fdn_ctop = fdn_c; }
+    const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
 
     // ---- clear-sky upward sweep (calc_fluxes_no_scattering_lw) ---------------------------------------
     {
       double fup = emission + albedo * fdn_c;
       double su = group_sum<NGP>(valid ? fup : 0.0);
       if (lead && do_clear) fx.lw_up_clear[col + ncol * nlev] = su;
+      double keep_up = 0.0;
       for (int l = nlev - 1; l >= 0; --l) {
         fup = s.at(LT_T1, l, tid) * fup + s.at(LT_SU1, l, tid);
         if (do_clear) {
           su = group_sum<NGP>(valid ? fup : 0.0);
-          if (lead) fx.lw_up_clear[col + ncol * l] = su;
+          if ((l & (NGP - 1)) == glane) keep_up = su;
+          if ((l & (NGP - 1)) == 0) {
+            const int lv = l + glane;
+            if (col_ok && lv < nlev) fx.lw_up_clear[col + ncol * lv] = keep_up;
+          }
         }
       }
       if (valid && do_clear) {
@@ -503,10 +541,15 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(const De
     {
       double su = group_sum<NGP>(valid ? fup[0] : 0.0);
       if (lead) fx.lw_up[col + ncol * ict] = su;
+      double keep_up = 0.0;
       for (int l = ict - 1; l >= 0; --l) {
         fup[0] = s.at(LT_T1, l, tid) * fup[0] + s.at(LT_SU1, l, tid);
         su = group_sum<NGP>(valid ? fup[0] : 0.0);
-        if (lead) fx.lw_up[col + ncol * l] = su;
+        if ((l & (NGP - 1)) == glane) keep_up = su;
+        if ((l & (NGP - 1)) == 0) {
+          const int lv = l + glane;
+          if (col_ok && lv < ict) fx.lw_up[col + ncol * lv] = keep_up;
+        }
       }
       if (valid) fx.lw_up_toa_g[g + (size_t)ng * col] = fup[0];
     }
@@ -514,6 +557,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(const De
     double fdn[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) fdn[r] = geo.v(r, 0, ict) * fdn_ctop;
+    LevelSums<NGP, 2> kept;
     for (int l = ict; l < nlev; ++l) {
       const bool cl_here = cloudy.test(l);
       {
@@ -543,12 +587,17 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(const De
 #pragma unroll
         for (int r = 0; r < 3; ++r) fdn[r] = nf[r];
       }
-      const double su = group_sum<NGP>(valid ? fup[0] + fup[1] + fup[2] : 0.0);
-      const double sd = group_sum<NGP>(valid ? fdn[0] + fdn[1] + fdn[2] : 0.0);
-      if (lead) {
-        const size_t o = col + ncol * (l + 1);
-        fx.lw_up[o] = su;
-        fx.lw_dn[o] = sd;
+      const double sums[2] = {group_sum<NGP>(valid ? fup[0] + fup[1] + fup[2] : 0.0),
+                              group_sum<NGP>(valid ? fdn[0] + fdn[1] + fdn[2] : 0.0)};
+      const int hl = l + 1;
+      kept.keep(hl, glane, sums);
+      if ((hl & (NGP - 1)) == NGP - 1 || hl == nlev) {
+        const int lv = kept.mine(hl, glane);
+        if (col_ok && lv > ict && lv <= hl) {
+          const size_t o = col + ncol * lv;
+          fx.lw_up[o] = kept.v[0];
+          fx.lw_dn[o] = kept.v[1];
+        }
       }
     }
     if (valid) fx.lw_dn_surf_g[g + (size_t)ng * col] = fdn[0] + fdn[1] + fdn[2];
@@ -557,6 +606,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(const De
       const double tot = group_sum<NGP>(valid ? fs : 0.0);
       double d[3] = {fs / tot, 0.0, 0.0};
       if (lead) fx.lw_derivatives[col + ncol * nlev] = 1.0;
+      double keep_der = 0.0;
       for (int l = nlev - 1; l >= 0; --l) {
         double n[3];
 #pragma unroll
@@ -566,7 +616,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(const De
         d[1] = n[1] * (cl_here ? s.at(lw_coef(1, 1), l, tid) : 1.0);
         d[2] = n[2] * (cl_here ? s.at(lw_coef(1, 2), l, tid) : 1.0);
         const double sder = group_sum<NGP>(valid ? d[0] + d[1] + d[2] : 0.0);
-        if (lead) fx.lw_derivatives[col + ncol * l] = sder;
+        if ((l & (NGP - 1)) == glane) keep_der = sder;
+        if ((l & (NGP - 1)) == 0) {
+          const int lv = l + glane;
+          if (col_ok && lv < nlev) fx.lw_derivatives[col + ncol * lv] = keep_der;
+        }
       }
     }
   }
@@ -574,10 +628,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(const De
 
 size_t lw_tc_scratch_doubles(int nlev) { return (size_t)LW_TC_NUM * (nlev + 1) * kBlock; }
 
-hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig* cfg,
+hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block,
-                        int* counter) {
-#define ECRAD_L(T, N) do { ECRAD_ALLOW_LDS((lw_tc_kernel<T, N>), lds); hipLaunchKernelGGL((lw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, cfg, in, fx, prep, scratch, per_block, counter); } while (0)
+                        int* counter, const DevCkdModel& m) {
+  const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot};
+#define ECRAD_L(T, N) do { ECRAD_ALLOW_LDS((lw_tc_kernel<T, N>), lds); hipLaunchKernelGGL((lw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
   if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
   else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }
 #undef ECRAD_L

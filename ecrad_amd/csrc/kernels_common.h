@@ -343,9 +343,25 @@ template <> struct StreamRef<double2> {
 struct Scratch {
   double* base;
   int nlevp1;
-  ECRAD_DEV double& at(int a, int lev, int tid) const {
-    return base[((size_t)a * nlevp1 + lev) * kBlock + tid];
+  ECRAD_DEV StreamRef<double> at(int a, int lev, int tid) const {
+    return {base + ((size_t)a * nlevp1 + lev) * kBlock + tid};
   }
+};
+
+// Column sums of NV quantities per half level are kept by the lane whose index equals (level mod NGP)
+// and written NGP half levels at a time (one store instruction per NGP levels and quantity).
+template <int NGP, int NV>
+struct LevelSums {
+  double v[NV];
+  // all lanes of the column group hold the sums `s`; lane (l mod NGP) keeps them
+  ECRAD_DEV void keep(int l, int glane, const double (&s)[NV]) {
+    if ((l & (NGP - 1)) == glane) {
+#pragma unroll
+      for (int k = 0; k < NV; ++k) v[k] = s[k];
+    }
+  }
+  // half level this lane holds within the NGP-aligned block that contains l
+  static ECRAD_DEV int mine(int l, int glane) { return (l & ~(NGP - 1)) + glane; }
 };
 
 // Per-lane level mask held in registers (up to 256 levels); no dynamic register indexing.

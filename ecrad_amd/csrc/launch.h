@@ -23,15 +23,17 @@ size_t lw_tc_scratch_doubles(int nlev);
 size_t mcica_work_doubles(int nlev, int ng, int nloc);
 
 hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
-                         const DevConfig* cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
+                         const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
                          double* scratch, size_t per_block, int* counter, const DevCkdModel& m);
 hipError_t launch_lw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
-                         const DevConfig* cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
+                         const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
                          double* scratch, size_t per_block, int* counter, const DevCkdModel& m);
-hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig* cfg,
-                        const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block, int* counter);
-hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig* cfg,
-                        const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block, int* counter);
+hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
+                        const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block, int* counter,
+                        const DevCkdModel& m);
+hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
+                        const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block, int* counter,
+                        const DevCkdModel& m);
 hipError_t launch_crop(hipStream_t st, const DevConfig* cfg, const DevInputs& in);
 hipError_t launch_tripleclouds_prep(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevCloudPrep& prep,
                                     double* cc_sw, double* cc_lw);

@@ -378,24 +378,51 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, 
   const int nb = IS_SW ? ao.n_bands_sw : ao.n_bands_lw;
   const double factor = L.D(F_DPG, slot);
   const int irh = L.I(I_RH, slot);
+  const int rh_row = irh > 0 ? irh - 1 : 0;
   const size_t ncol = in.ncol;
   const int nlev_aer = in.aerosol_iendlev - in.aerosol_istartlev + 1;
-  for (int jtype = 0; jtype < ao.ntype; ++jtype) {
-    const int iclass = ao.iclass[jtype];
-    if (iclass != ECRAD_AEROSOL_HYDROPHOBIC && iclass != ECRAD_AEROSOL_HYDROPHILIC) continue;
-    const int itype = ao.itype[jtype] - 1;
-    const double mixing_ratio = in.aerosol_mixing_ratio[col + ncol * ((jlev - in.aerosol_istartlev) + (size_t)nlev_aer * jtype)];
-    const bool phobic = iclass == ECRAD_AEROSOL_HYDROPHOBIC;
-    const int o = phobic ? ib + nb * itype : ib + nb * ((irh - 1) + ao.nrh * itype);
-    const double* const* tab = IS_SW ? (phobic ? ao.sw_phobic : ao.sw_philic) : (phobic ? ao.lw_phobic : ao.lw_philic);
-    const double ext = tab[0][o], ssa = tab[1][o];
-    if (IS_SW || cfg.do_lw_aerosol_scattering) {
-      const double local_od = factor * mixing_ratio * ext;
-      a.od = a.od + local_od;
-      a.scat = a.scat + local_od * ssa;
-      a.scat_g = a.scat_g + local_od * ssa * tab[2][o];
-    } else {
-      a.od = a.od + factor * mixing_ratio * ext * (1.0 - ssa);
+  const size_t type_stride = ncol * (size_t)nlev_aer;
+  const double* __restrict__ mr0 = in.aerosol_mixing_ratio + col + ncol * (size_t)(jlev - in.aerosol_istartlev);
+  const double2* __restrict__ tab01 = reinterpret_cast<const double2*>(IS_SW ? ao.sw_tab01 : ao.lw_tab01);
+  const double* __restrict__ tab2 = IS_SW ? ao.sw_tab2 : ao.lw_tab2;
+  const int n = ao.nactive;
+  const bool scattering = IS_SW || cfg.do_lw_aerosol_scattering;
+  // The loads of kBatch types are requested together (each is a full L2 round trip: the mixing ratio
+  // is one broadcast line per column, the table row 16 + 8 B per lane); the sums keep the reference's
+  // order over types.
+#ifndef ECRAD_AEROSOL_BATCH
+#define ECRAD_AEROSOL_BATCH 4
+#endif
+  constexpr int kBatch = ECRAD_AEROSOL_BATCH;
+  for (int k0 = 0; k0 < n; k0 += kBatch) {
+    double mr[kBatch];
+    double2 t01[kBatch];
+    double t2[kBatch];
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      mr[u] = 0.0; t01[u] = make_double2(0.0, 0.0); t2[u] = 0.0;
+      const int k = k0 + u;
+      if (k < n) {
+        const uint32_t desc = ao.active[k];
+        const int row = (int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0);
+        mr[u] = mr0[type_stride * (desc & 0xffu)];
+        const size_t o = ib + (size_t)nb * row;
+        t01[u] = tab01[o];                       // mass_ext, ssa
+        if (scattering) t2[u] = tab2[o];         // asymmetry
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kBatch; ++u) {
+      if (k0 + u < n) {
+        if (scattering) {
+          const double local_od = factor * mr[u] * t01[u].x;
+          a.od = a.od + local_od;
+          a.scat = a.scat + local_od * t01[u].y;
+          a.scat_g = a.scat_g + local_od * t01[u].y * t2[u];
+        } else {
+          a.od = a.od + factor * mr[u] * t01[u].x * (1.0 - t01[u].y);
+        }
+      }
     }
   }
   return a;

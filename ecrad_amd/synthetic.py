@@ -83,4 +83,9 @@ BENCH_CONFIGS = {
     # north-star target configuration: ecCKD-32 Tripleclouds with clouds and aerosols
     "tripleclouds_ecckd32": dict(sw_solver="Tripleclouds", use_aerosols=True, clear_sky=False),
     "mcica_ecckd32": dict(sw_solver="McICA", use_aerosols=True, clear_sky=False),
+    # attribution variants (not bench lines): the same without aerosols / without clouds
+    "tripleclouds_noaer": dict(sw_solver="Tripleclouds", use_aerosols=False, clear_sky=False),
+    "tripleclouds_clear_aer": dict(sw_solver="Tripleclouds", use_aerosols=True, clear_sky=True),
+    "mcica_noaer": dict(sw_solver="McICA", use_aerosols=False, clear_sky=False),
+    "homogeneous_clear_aer": dict(sw_solver="Homogeneous", use_aerosols=True, clear_sky=True),
 }
