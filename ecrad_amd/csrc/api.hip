@@ -543,6 +543,30 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
       d.pdf.val = reinterpret_cast<const float*>(v);
     } else if ((st = upload<double>(h, p.val, n, &d.pdf.val64))) return st;
   }
+  {
+    // Jump-ahead matrices of the 32-bit Galois shift register that seeds the McICA random-number
+    // generator (utilities/radiation_random_numbers_mix.F90:165-200): row i of block k has bit j set iff
+    // bit j of the register influences bit i after k*274 steps (the step is linear over GF(2)).
+    auto step = [](uint32_t s) { return (s & 0x80000000u) ? (((s ^ 87u) << 1) | 1u) : (s << 1); };
+    auto mul = [](const uint32_t* A, const uint32_t* B, uint32_t* C) {   // C = A * B (row form)
+      for (int i = 0; i < 32; ++i) {
+        uint32_t r = 0;
+        for (int j = 0; j < 32; ++j) if ((A[i] >> j) & 1u) r ^= B[j];
+        C[i] = r;
+      }
+    };
+    uint32_t M[32] = {0}, P[32], T[32];
+    for (int j = 0; j < 32; ++j) {
+      const uint32_t col = step(1u << j);
+      for (int i = 0; i < 32; ++i) if ((col >> i) & 1u) M[i] |= 1u << j;
+    }
+    for (int i = 0; i < 32; ++i) P[i] = 1u << i;                    // identity
+    for (int k = 0; k < 274; ++k) { mul(M, P, T); std::memcpy(P, T, sizeof P); }   // P = M^274
+    std::vector<uint32_t> jump(64 * 32);
+    for (int i = 0; i < 32; ++i) jump[i] = 1u << i;
+    for (int k = 1; k < 64; ++k) mul(P, &jump[32 * (k - 1)], &jump[32 * k]);
+    if ((st = upload<uint32_t>(h, jump.data(), jump.size(), &d.lfsr_jump))) return st;
+  }
   HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->dcfg), sizeof(DevConfig)));
   HIP_TRY(h, hipMemcpy(h->dcfg, &d, sizeof(DevConfig), hipMemcpyHostToDevice));
   h->is_setup = true;

@@ -103,6 +103,7 @@ struct DevConfig {
   DevCloudOptics cloud_sw[kMaxCloudTypes], cloud_lw[kMaxCloudTypes];
   DevAerosolOptics aerosol;
   DevPdfSampler pdf;
+  const uint32_t* lfsr_jump;   // 64 x 32 rows: the seeding shift register advanced by k*274 steps (kernel_prep.hip)
 };
 
 // Input arrays on the device (same layouts as ecrad_inputs_t)

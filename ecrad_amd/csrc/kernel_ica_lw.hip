@@ -295,17 +295,25 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
     }
     // flux at cloud top and upward through the clear layers above it
     fup = src + alb * fdn_ctop;
-    for (int l = ict; l >= 0; --l) {
-      if (l < ict) { const double2 ts = s.pair(P_CLR, l, tid); fup = ts.x * fup + ts.y; }
-      const double su = group_sum<NGP>(valid ? fup : 0.0);
-      if (lead) {
-        const size_t o = col + ncol * l;
-        fx.lw_up[o] = blend ? w * su + (1.0 - w) * fx.lw_up_clear[o] : su;
+    {
+      double keep_up = 0.0;      // lane (l mod NGP) keeps half level l; written NGP half levels at a time
+      for (int l = ict; l >= 0; --l) {
+        if (l < ict) { const double2 ts = s.pair(P_CLR, l, tid); fup = ts.x * fup + ts.y; }
+        const double su = group_sum<NGP>(valid ? fup : 0.0);
+        if ((l & (NGP - 1)) == glane) keep_up = su;
+        if ((l & (NGP - 1)) == 0) {
+          const int lv = l + glane;
+          if (col_ok && lv <= ict) {
+            const size_t o = col + ncol * lv;
+            fx.lw_up[o] = blend ? w * keep_up + (1.0 - w) * fx.lw_up_clear[o] : keep_up;
+          }
+        }
       }
     }
     const double fup_toa = fup;
     // downward sweep below cloud top
     double fdn = fdn_ctop;
+    LevelSums<NGP, 2> kept;
     for (int l = ict; l < nlev; ++l) {
       const double2 as = s.pair(P_AS, l + 1, tid);
       const double albn = as.x, srcn = as.y;
@@ -320,12 +328,16 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
         fdn = ts.x * fdn + s.single(S_SD1, l, tid);
       }
       fup = albn * fdn + srcn;
-      const double su = group_sum<NGP>(valid ? fup : 0.0);
-      const double sd = group_sum<NGP>(valid ? fdn : 0.0);
-      if (lead) {
-        const size_t o = col + ncol * (l + 1);
-        fx.lw_up[o] = blend ? w * su + (1.0 - w) * fx.lw_up_clear[o] : su;
-        fx.lw_dn[o] = blend ? w * sd + (1.0 - w) * fx.lw_dn_clear[o] : sd;
+      const double sums[2] = {group_sum<NGP>(valid ? fup : 0.0), group_sum<NGP>(valid ? fdn : 0.0)};
+      const int hl = l + 1;
+      kept.keep(hl, glane, sums);
+      if ((hl & (NGP - 1)) == NGP - 1 || hl == nlev) {
+        const int lv = kept.mine(hl, glane);
+        if (col_ok && lv > ict && lv <= hl) {
+          const size_t o = col + ncol * lv;
+          fx.lw_up[o] = blend ? w * kept.v[0] + (1.0 - w) * fx.lw_up_clear[o] : kept.v[0];
+          fx.lw_dn[o] = blend ? w * kept.v[1] + (1.0 - w) * fx.lw_dn_clear[o] : kept.v[1];
+        }
       }
     }
     if (ict == nlev) {   // no cloudy layer at all: surface values come from the clear-sky sweep
@@ -345,15 +357,20 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
       double d = fup / ssurf;
       const bool modify = MODE == 2 && tcc < 1.0 - cloud_fraction_threshold;
       const double wclr = 1.0 - tcc;
+      double keep_der = 0.0;
       for (int l = nlev - 1; l >= 0; --l) {
         double tl;
         if (cloudy.test(l)) { const double2 rt = s.pair(P_RT2, l, tid); tl = rt.y; }
         else { const double2 ts = s.pair(P_CLR, l, tid); tl = ts.x; }
         d = d * tl;
         const double sder = group_sum<NGP>(valid ? d : 0.0);
-        if (lead) {
-          const size_t o = col + ncol * l;
-          fx.lw_derivatives[o] = modify ? (1.0 - wclr) * sder + wclr * fx.lw_derivatives[o] : sder;
+        if ((l & (NGP - 1)) == glane) keep_der = sder;
+        if ((l & (NGP - 1)) == 0) {
+          const int lv = l + glane;
+          if (col_ok && lv < nlev) {
+            const size_t o = col + ncol * lv;
+            fx.lw_derivatives[o] = modify ? (1.0 - wclr) * keep_der + wclr * fx.lw_derivatives[o] : keep_der;
+          }
         }
       }
     }

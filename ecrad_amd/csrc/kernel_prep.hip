@@ -230,115 +230,240 @@ ECRAD_DEV double pdf_sample(const DevPdfSampler& p, double fsd, double cdf) {
   return (1.0 - wcdf) * (1.0 - wfsd) * v00 + (1.0 - wcdf) * wfsd * v01 + wcdf * (1.0 - wfsd) * v10 + wcdf * wfsd * v11;
 }
 
-// Per-lane work arrays in the slab `work`: [K_* * nlev + lev][nloc]
-enum { K_CUM = 0, K_PAIR, K_OPI, K_RC, K_RI1, K_RI2, K_NUM };
+// ---------------------------------------------------------------------------------------------------
+// McICA cloud generator: ONE WAVE PER COLUMN, everything in LDS.
+//
+// The reference algorithm is serial per column twice over: the lagged-Fibonacci stream is one sequence
+// shared by all g-points (how many numbers a g-point consumes depends on the numbers themselves), and
+// the generator walks down the levels as a Markov chain.  A lane-per-column kernel therefore runs a
+// chain of ~25 000 dependent global-memory accesses per column (RNG state, work arrays, PDF table):
+// 48 ms for 100 000 columns, three times the spectral kernel it feeds.  Here the 64 lanes of a wave
+// share one column instead:
+//   * the generator state (607 words) and all per-level work arrays live in LDS;
+//   * the control flow is wave-uniform: every lane executes the same serial logic on the same LDS
+//     values (cheap), while everything that IS parallel uses the lanes --
+//       - seeding: the Galois shift register that fills the 607 x 29 state bits is linear over GF(2),
+//         so lane k starts from the register advanced by k*274 steps (32x32 bit-matrix from
+//         ecrad_hip_setup) and produces its own 274 of the 17 516 bits;
+//       - refilling the state block (x[j] += x[j-273] mod 2^30): 64 elements per step, the lag of 273
+//         keeps them independent;
+//       - moving random numbers out of the state block, the inhomogeneity PDF look-ups and the
+//         od_scaling stores of a run of cloudy layers.
+// Same integer stream and same floating-point expressions as before (integer-exact RNG; the oracle
+// and the reference's golden file pin it).
+constexpr int kLfsrSteps = (JPMM - 1) * (JPQ - 3);      // 17 516 output bits of the seeding register
+constexpr int kLfsrPerLane = (kLfsrSteps + 63) / 64;     // 274
 
-__global__ void mcica_generator_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, int ng, int seed_offset,
-                                      double* od_scaling, double* total_cloud_cover, int32_t* rng_state,
-                                      double* work) {
+ECRAD_DEV uint32_t lfsr_step(uint32_t s) { return (s & 0x80000000u) ? (((s ^ 87u) << 1) | 1u) : (s << 1); }
+
+struct GenLds {
+  int32_t* X;        // [608], 1-based like the reference
+  double *frac, *fsd, *ovp, *cum, *pair, *opi, *rc, *ri1, *ri2, *xs, *rtop;
+};
+
+ECRAD_DEV GenLds gen_lds(unsigned char* smem, int nlev, int ng) {
+  GenLds g;
+  double* d = reinterpret_cast<double*>(smem);
+  g.frac = d; d += nlev; g.fsd = d; d += nlev; g.ovp = d; d += nlev; g.cum = d; d += nlev; g.pair = d; d += nlev;
+  g.opi = d; d += nlev; g.rc = d; d += nlev + 1; g.ri1 = d; d += nlev; g.ri2 = d; d += nlev; g.xs = d; d += nlev;
+  g.rtop = d; d += ng;
+  g.X = reinterpret_cast<int32_t*>(d);
+  return g;
+}
+
+size_t mcica_generator_lds_bytes(int nlev, int ng) { return (size_t)(10 * nlev + 1 + ng) * 8 + 608 * 4; }
+
+// x(1:607) <- next block of the lagged-Fibonacci sequence (radiation_random_numbers_mix.F90:270-282)
+ECRAD_DEV void gen_next_batch(const GenLds& g, int lane) {
+  const int32_t IVAR = 0x3FFFFFFF;
+  for (int jj = 1 + lane; jj <= JPP; jj += 64) g.X[jj] = IVAR & (g.X[jj] + g.X[jj - JPP + JPQ]);
+  __syncthreads();
+  for (int base = JPP + 1; base <= JPQ; base += 64) {     // in order: element j needs the NEW element j-273
+    const int jj = base + lane;
+    if (jj <= JPQ) g.X[jj] = IVAR & (g.X[jj] + g.X[jj - JPP]);
+    __syncthreads();
+  }
+}
+
+// CALL UNIFORM_DISTRIBUTION(dst(1:n)) with the reference's batch semantics (see rng_draw above);
+// dst may be null (warm-up).  iused is wave-uniform.
+ECRAD_DEV void gen_draw(const GenLds& g, int lane, int& iused, int n, double* dst) {
+  const double zrm = 1.0 / (double)(1 << JPMM);
+  int k = 0;
+  while (k < n) {
+    if (iused == JPQ) { gen_next_batch(g, lane); iused = 0; }
+    const int take = (n - k < JPQ - iused) ? n - k : JPQ - iused;
+    if (dst)
+      for (int i = lane; i < take; i += 64) dst[k + i] = g.X[iused + 1 + i] * zrm;
+    iused += take;
+    k += take;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, int ng,
+                                                             int seed_offset, double* od_scaling, double* total_cloud_cover) {
+  extern __shared__ __align__(16) unsigned char smem[];
   const DevConfig& cfg = *cfgp;
+  const int lane = threadIdx.x;
   const int nloc = in.iendcol - in.istartcol + 1;
-  const int cloc = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cloc >= nloc) return;
-  const int col = in.istartcol - 1 + cloc;
-  const size_t ncol = in.ncol;
   const int nlev = in.nlev;
-  auto W = [&](int k, int lev1) -> double& { return work[((size_t)k * nlev + (lev1 - 1)) * nloc + cloc]; };
-  auto FRAC = [&](int lev1) { return in.cloud_fraction[col + ncol * (lev1 - 1)]; };
-  auto FSD = [&](int lev1) { return in.cloud_fractional_std[col + ncol * (lev1 - 1)]; };
-  auto OVP = [&](int lev1) { return in.cloud_overlap_param[col + ncol * (lev1 - 1)]; };
+  const size_t ncol = in.ncol;
+  const GenLds g = gen_lds(smem, nlev, ng);
   const double MaxCloudFrac = 1.0 - 2.220446049250313e-16 * 10.0;
-  // cum_cloud_cover_exp_ran / _max_ran (radiation_cloud_cover.F90:169-330)
-  double cum_product = 1.0 - FRAC(1);
-  W(K_CUM, 1) = FRAC(1);
-  for (int jlev = 1; jlev <= nlev - 1; ++jlev) {
-    const double f0 = FRAC(jlev), f1 = FRAC(jlev + 1);
-    double pair;
-    if (cfg.i_overlap_scheme == ECRAD_OVERLAP_EXP_RAN) {
-      double alpha = OVP(jlev);
-      if (cfg.use_beta_overlap) {   // beta2alpha, radiation_cloud_cover.F90:51-68
-        if (alpha < 1.0) {
-          const double frac_diff = fabs(f0 - f1);
-          alpha = alpha + (1.0 - alpha) * frac_diff / (frac_diff + 1.0 / alpha - 1.0);
-        } else alpha = 1.0;
-      }
-      pair = alpha * dmax(f0, f1) + (1.0 - alpha) * (f0 + f1 - f0 * f1);
-    } else {
-      pair = dmax(f0, f1);
+  for (int cloc = blockIdx.x; cloc < nloc; cloc += gridDim.x) {
+    const int col = in.istartcol - 1 + cloc;
+    __syncthreads();
+    for (int l = lane; l < nlev; l += 64) {
+      g.frac[l] = in.cloud_fraction[col + ncol * l];
+      g.fsd[l] = in.cloud_fractional_std[col + ncol * l];
+      if (l < nlev - 1) g.ovp[l] = in.cloud_overlap_param[col + ncol * l];
     }
-    W(K_PAIR, jlev) = pair;
-    if (f0 >= MaxCloudFrac) cum_product = 0.0;
-    else cum_product = cum_product * (1.0 - pair) / (1.0 - f0);
-    W(K_CUM, jlev + 1) = 1.0 - cum_product;
-  }
-  double tcc = W(K_CUM, nlev);
-  if (tcc < cfg.cloud_fraction_threshold) { total_cloud_cover[cloc] = 0.0; return; }
-  total_cloud_cover[cloc] = tcc;
-  int jlev = 1;
-  while (FRAC(jlev) <= 0.0) jlev++;
-  const int ibegin = jlev;
-  int iend = jlev;
-  for (jlev = jlev + 1; jlev <= nlev; ++jlev) if (FRAC(jlev) > 0.0) iend = jlev;
-  for (jlev = 1; jlev <= nlev - 1; ++jlev) {
-    double op = OVP(jlev);
-    if (jlev >= ibegin && jlev <= iend - 1 && op > 0.0) op = pow(op, 1.0 / cfg.cloud_inhom_decorr_scaling);
-    W(K_OPI, jlev) = op;
-  }
-  RngLane r{rng_state + cloc, (size_t)nloc, 0};
-  rng_init(r, in.iseed[col] + seed_offset);
-  // rand_top(1:ng) is ONE batch request in the reference (radiation_cloud_generator.F90:206), drawn
-  // before any per-g-point draws; park it in the ng tail rows of the work slab.
-  double* odsc = od_scaling + (size_t)ng * nlev * cloc;
-  rng_draw(r, ng, [&](int k, double x) { work[((size_t)K_NUM * nlev + k) * nloc + cloc] = x; });
-  for (int jg = 0; jg < ng; ++jg) {
-    const double trigger = work[((size_t)K_NUM * nlev + jg) * nloc + cloc] * tcc;
-    jlev = ibegin;
-    while (trigger > W(K_CUM, jlev) && jlev < iend) jlev++;
-    const int itrigger = jlev;
-    // generate_column_exp_ran, radiation_cloud_generator.F90:262-390
-    int n_layers_to_scale = 1;
-    int iy = 0;
-    rng_draw(r, iend + 1 - itrigger, [&](int k, double x) { W(K_RC, k + 1) = x; });
-    for (jlev = itrigger + 1; jlev <= iend + 1; ++jlev) {
-      bool do_fill = false;
-      if (jlev <= iend) {
-        iy++;
-        const double f_above = FRAC(jlev - 1);
-        if (n_layers_to_scale > 0) {
-          if (W(K_RC, iy) * f_above < FRAC(jlev) + f_above - W(K_PAIR, jlev - 1)) n_layers_to_scale++;
-          else do_fill = true;
-        } else {
-          const double overhang = W(K_CUM, jlev) - W(K_CUM, jlev - 1);
-          if (W(K_RC, iy) * (W(K_CUM, jlev - 1) - f_above) < W(K_PAIR, jlev - 1) - overhang - f_above)
-            n_layers_to_scale = 1;
+    __syncthreads();
+    // cum_cloud_cover_exp_ran / _max_ran (radiation_cloud_cover.F90:169-330): pair cover is independent
+    // per level, the cumulative product is a serial recurrence (wave-uniform)
+    for (int l = lane; l < nlev - 1; l += 64) {
+      const double f0 = g.frac[l], f1 = g.frac[l + 1];
+      double pair;
+      if (cfg.i_overlap_scheme == ECRAD_OVERLAP_EXP_RAN) {
+        double alpha = g.ovp[l];
+        if (cfg.use_beta_overlap) {   // beta2alpha, radiation_cloud_cover.F90:51-68
+          if (alpha < 1.0) {
+            const double frac_diff = fabs(f0 - f1);
+            alpha = alpha + (1.0 - alpha) * frac_diff / (frac_diff + 1.0 / alpha - 1.0);
+          } else alpha = 1.0;
         }
+        pair = alpha * dmax(f0, f1) + (1.0 - alpha) * (f0 + f1 - f0 * f1);
       } else {
-        do_fill = true;
+        pair = dmax(f0, f1);
       }
-      if (do_fill) {
-        rng_draw(r, n_layers_to_scale, [&](int k, double x) { W(K_RI1, k + 1) = x; });
-        rng_draw(r, n_layers_to_scale, [&](int k, double x) { W(K_RI2, k + 1) = x; });
-        double prev = 0.0;
-        for (int jcloud = 1; jcloud <= n_layers_to_scale; ++jcloud) {
-          double x = W(K_RI1, jcloud);
-          if (jcloud >= 2 && W(K_RI2, jcloud) < W(K_OPI, jlev - n_layers_to_scale + jcloud - 2)) x = prev;
-          prev = x;
-          const int lev1 = jlev - n_layers_to_scale + jcloud - 1;
-          odsc[jg + (size_t)ng * (lev1 - 1)] = pdf_sample(cfg.pdf, FSD(lev1), x);
+      g.pair[l] = pair;
+    }
+    __syncthreads();
+    {
+      double cum_product = 1.0 - g.frac[0];
+      if (lane == 0) g.cum[0] = g.frac[0];
+      for (int l = 0; l < nlev - 1; ++l) {
+        const double f0 = g.frac[l];
+        if (f0 >= MaxCloudFrac) cum_product = 0.0;
+        else cum_product = cum_product * (1.0 - g.pair[l]) / (1.0 - f0);
+        if (lane == 0) g.cum[l + 1] = 1.0 - cum_product;
+      }
+    }
+    __syncthreads();
+    const double tcc = g.cum[nlev - 1];
+    if (tcc < cfg.cloud_fraction_threshold) {
+      if (lane == 0) total_cloud_cover[cloc] = 0.0;
+      continue;
+    }
+    if (lane == 0) total_cloud_cover[cloc] = tcc;
+    // first / last cloudy level (1-based ibegin, iend)
+    int ibegin = 1;
+    while (g.frac[ibegin - 1] <= 0.0) ibegin++;
+    int iend = ibegin;
+    for (int jlev = ibegin + 1; jlev <= nlev; ++jlev) if (g.frac[jlev - 1] > 0.0) iend = jlev;
+    for (int l = lane; l < nlev - 1; l += 64) {
+      const int jlev = l + 1;
+      double op = g.ovp[l];
+      if (jlev >= ibegin && jlev <= iend - 1 && op > 0.0) op = pow(op, 1.0 / cfg.cloud_inhom_decorr_scaling);
+      g.opi[l] = op;
+    }
+    // ---- initialize_random_numbers (radiation_random_numbers_mix.F90:142-231), seeding in parallel ---
+    for (int j = lane; j <= JPQ; j += 64) g.X[j] = 0;
+    __syncthreads();
+    {
+      const int32_t JPMASK = 123459876;
+      int32_t v = (in.iseed[col] + seed_offset) ^ JPMASK;
+      if (v < 0) v = -v;
+      if (v == 0) v = JPMASK;
+      uint32_t idum = (uint32_t)v;
+      for (int jj = 0; jj < 64; ++jj) idum = lfsr_step(idum);
+      if (lane == 0) {
+        g.X[2] = (int32_t)((idum & ((1u << (JPMM - 1)) - 1u)) << 1);
+        g.X[JPQ] = (int32_t)(idum >> (JPMM - 1));
+      }
+      __syncthreads();
+      // this lane's register = M^(lane*274) * idum
+      const uint32_t* __restrict__ rows = cfg.lfsr_jump + 32 * lane;
+      uint32_t s = 0;
+#pragma unroll 8
+      for (int i = 0; i < 32; ++i) s |= (uint32_t)(__popc(rows[i] & idum) & 1) << i;
+      int n = lane * kLfsrPerLane;
+      int jbit = n / (JPQ - 3) + 1, jj = n % (JPQ - 3) + 3;
+      const int nend = (n + kLfsrPerLane < kLfsrSteps) ? n + kLfsrPerLane : kLfsrSteps;
+      for (; n < nend; ++n) {
+        if (s & 0x80000000u) atomicOr(&g.X[jj], (int32_t)(1u << jbit));
+        s = lfsr_step(s);
+        if (++jj > JPQ - 1) { jj = 3; ++jbit; }
+      }
+      __syncthreads();
+      if (lane == 0) g.X[JPQ - JPS] |= 1;
+      __syncthreads();
+    }
+    int iused = JPQ;
+    gen_draw(g, lane, iused, 999, nullptr);     // warm-up
+    // rand_top(1:ng) is ONE batch request in the reference (radiation_cloud_generator.F90:206)
+    gen_draw(g, lane, iused, ng, g.rtop);
+    double* odsc = od_scaling + (size_t)ng * nlev * cloc;
+    for (int jg = 0; jg < ng; ++jg) {
+      const double trigger = g.rtop[jg] * tcc;
+      int jlev = ibegin;
+      while (trigger > g.cum[jlev - 1] && jlev < iend) jlev++;
+      const int itrigger = jlev;
+      // generate_column_exp_ran, radiation_cloud_generator.F90:262-390
+      int n_layers_to_scale = 1;
+      int iy = 0;
+      gen_draw(g, lane, iused, iend + 1 - itrigger, g.rc);
+      for (jlev = itrigger + 1; jlev <= iend + 1; ++jlev) {
+        bool do_fill = false;
+        if (jlev <= iend) {
+          iy++;
+          const double f_above = g.frac[jlev - 2];
+          if (n_layers_to_scale > 0) {
+            if (g.rc[iy - 1] * f_above < g.frac[jlev - 1] + f_above - g.pair[jlev - 2]) n_layers_to_scale++;
+            else do_fill = true;
+          } else {
+            const double overhang = g.cum[jlev - 1] - g.cum[jlev - 2];
+            if (g.rc[iy - 1] * (g.cum[jlev - 2] - f_above) < g.pair[jlev - 2] - overhang - f_above)
+              n_layers_to_scale = 1;
+          }
+        } else {
+          do_fill = true;
         }
-        n_layers_to_scale = 0;
+        if (do_fill) {
+          gen_draw(g, lane, iused, n_layers_to_scale, g.ri1);
+          gen_draw(g, lane, iused, n_layers_to_scale, g.ri2);
+          // decorrelation of the inhomogeneity down the run: serial "keep the previous value" (uniform)
+          if (lane == 0) {
+            double prev = 0.0;
+            for (int jcloud = 1; jcloud <= n_layers_to_scale; ++jcloud) {
+              double x = g.ri1[jcloud - 1];
+              if (jcloud >= 2 && g.ri2[jcloud - 1] < g.opi[jlev - n_layers_to_scale + jcloud - 3]) x = prev;
+              prev = x;
+              g.xs[jcloud - 1] = x;
+            }
+          }
+          __syncthreads();
+          for (int jcloud = 1 + lane; jcloud <= n_layers_to_scale; jcloud += 64) {
+            const int lev1 = jlev - n_layers_to_scale + jcloud - 1;
+            odsc[jg + (size_t)ng * (lev1 - 1)] = pdf_sample(cfg.pdf, g.fsd[lev1 - 1], g.xs[jcloud - 1]);
+          }
+          __syncthreads();
+          n_layers_to_scale = 0;
+        }
       }
     }
   }
 }
 
-size_t mcica_work_doubles(int nlev, int ng, int nloc) { return ((size_t)K_NUM * nlev + ng) * nloc; }
+size_t mcica_work_doubles(int nlev, int ng, int nloc) { return 0; }
 
 hipError_t launch_mcica_generator(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int ng, int seed_offset,
                                   double* od_scaling, double* tcc, int32_t* rng_state, double* work) {
   const int nloc = in.iendcol - in.istartcol + 1;
-  hipLaunchKernelGGL(mcica_generator_kernel, dim3((nloc + 63) / 64), dim3(64), 0, st, cfg, in, ng, seed_offset,
-                     od_scaling, tcc, rng_state, work);
+  const size_t lds = mcica_generator_lds_bytes(in.nlev, ng);
+  const int grid = nloc < 256 * 32 ? nloc : 256 * 32;
+  hipLaunchKernelGGL(mcica_generator_kernel, dim3(grid), dim3(64), lds, st, cfg, in, ng, seed_offset, od_scaling, tcc);
   return hipGetLastError();
 }
 
