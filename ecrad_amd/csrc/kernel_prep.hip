@@ -256,32 +256,78 @@ constexpr int kLfsrPerLane = (kLfsrSteps + 63) / 64;     // 274
 
 ECRAD_DEV uint32_t lfsr_step(uint32_t s) { return (s & 0x80000000u) ? (((s ^ 87u) << 1) | 1u) : (s << 1); }
 
+// Bit per level (up to 192 levels), wave-uniform; built from ballots
+struct LevBits {
+  unsigned long long w[3];
+  ECRAD_DEV void clear() { w[0] = w[1] = w[2] = 0ull; }
+  ECRAD_DEV bool get(int i) const { return ((i < 64 ? w[0] : (i < 128 ? w[1] : w[2])) >> (i & 63)) & 1ull; }
+  ECRAD_DEV void set(int i) {
+    const unsigned long long b = 1ull << (i & 63);
+    if (i < 64) w[0] |= b; else if (i < 128) w[1] |= b; else w[2] |= b;
+  }
+  // number of set bits at positions < i
+  ECRAD_DEV int count_below(int i) const {
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int lo = 64 * k;
+      if (i >= lo + 64) c += __popcll(w[k]);
+      else if (i > lo) c += __popcll(w[k] & ((1ull << (i - lo)) - 1ull));
+    }
+    return c;
+  }
+  // highest position <= i holding a ZERO bit (-1 if none)
+  ECRAD_DEV int highest_zero_le(int i) const {
+#pragma unroll
+    for (int k = 2; k >= 0; --k) {
+      const int lo = 64 * k;
+      if (i < lo) continue;
+      const int top = (i - lo >= 63) ? 63 : i - lo;
+      const unsigned long long z = ~w[k] & (top == 63 ? ~0ull : ((2ull << top) - 1ull));
+      if (z) return lo + 63 - __clzll(z);
+    }
+    return -1;
+  }
+  // lowest position >= i holding a ZERO bit (192 if none)
+  ECRAD_DEV int lowest_zero_ge(int i) const {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int lo = 64 * k;
+      if (i >= lo + 64) continue;
+      const int bot = i > lo ? i - lo : 0;
+      const unsigned long long z = ~w[k] & (~0ull << bot);
+      if (z) return lo + __ffsll((long long)z) - 1;
+    }
+    return 192;
+  }
+};
+
 struct GenLds {
   int32_t* X;        // [608], 1-based like the reference
-  double *frac, *fsd, *ovp, *cum, *pair, *opi, *rc, *ri1, *ri2, *xs, *rtop;
+  double *frac, *fsd, *ovp, *cum, *pair, *opi, *rc, *ri, *rtop;
 };
 
 ECRAD_DEV GenLds gen_lds(unsigned char* smem, int nlev, int ng) {
   GenLds g;
   double* d = reinterpret_cast<double*>(smem);
   g.frac = d; d += nlev; g.fsd = d; d += nlev; g.ovp = d; d += nlev; g.cum = d; d += nlev; g.pair = d; d += nlev;
-  g.opi = d; d += nlev; g.rc = d; d += nlev + 1; g.ri1 = d; d += nlev; g.ri2 = d; d += nlev; g.xs = d; d += nlev;
+  g.opi = d; d += nlev; g.rc = d; d += nlev + 1; g.ri = d; d += 2 * nlev;
   g.rtop = d; d += ng;
   g.X = reinterpret_cast<int32_t*>(d);
   return g;
 }
 
-size_t mcica_generator_lds_bytes(int nlev, int ng) { return (size_t)(10 * nlev + 1 + ng) * 8 + 608 * 4; }
+size_t mcica_generator_lds_bytes(int nlev, int ng) { return (size_t)(9 * nlev + 1 + ng) * 8 + 608 * 4; }
 
 // x(1:607) <- next block of the lagged-Fibonacci sequence (radiation_random_numbers_mix.F90:270-282)
 ECRAD_DEV void gen_next_batch(const GenLds& g, int lane) {
   const int32_t IVAR = 0x3FFFFFFF;
   for (int jj = 1 + lane; jj <= JPP; jj += 64) g.X[jj] = IVAR & (g.X[jj] + g.X[jj - JPP + JPQ]);
-  __syncthreads();
+  wave_sync();
   for (int base = JPP + 1; base <= JPQ; base += 64) {     // in order: element j needs the NEW element j-273
     const int jj = base + lane;
     if (jj <= JPQ) g.X[jj] = IVAR & (g.X[jj] + g.X[jj - JPP]);
-    __syncthreads();
+    wave_sync();
   }
 }
 
@@ -298,7 +344,7 @@ ECRAD_DEV void gen_draw(const GenLds& g, int lane, int& iused, int n, double* ds
     iused += take;
     k += take;
   }
-  __syncthreads();
+  wave_sync();
 }
 
 __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, int ng,
@@ -311,15 +357,24 @@ __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __
   const size_t ncol = in.ncol;
   const GenLds g = gen_lds(smem, nlev, ng);
   const double MaxCloudFrac = 1.0 - 2.220446049250313e-16 * 10.0;
+#ifdef ECRAD_TIMING
+  PhaseTimer tm;
+  tm.reset();
+  int tm_cols = 0;
+#endif
   for (int cloc = blockIdx.x; cloc < nloc; cloc += gridDim.x) {
     const int col = in.istartcol - 1 + cloc;
-    __syncthreads();
+    wave_sync();
+#ifdef ECRAD_TIMING
+    tm.start();
+    tm_cols++;
+#endif
     for (int l = lane; l < nlev; l += 64) {
       g.frac[l] = in.cloud_fraction[col + ncol * l];
       g.fsd[l] = in.cloud_fractional_std[col + ncol * l];
       if (l < nlev - 1) g.ovp[l] = in.cloud_overlap_param[col + ncol * l];
     }
-    __syncthreads();
+    wave_sync();
     // cum_cloud_cover_exp_ran / _max_ran (radiation_cloud_cover.F90:169-330): pair cover is independent
     // per level, the cumulative product is a serial recurrence (wave-uniform)
     for (int l = lane; l < nlev - 1; l += 64) {
@@ -339,38 +394,58 @@ __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __
       }
       g.pair[l] = pair;
     }
-    __syncthreads();
+    wave_sync();
+    // first / last cloudy level (1-based ibegin, iend) from one ballot per 64 levels
+    int ibegin = 0, iend = 0;
     {
-      double cum_product = 1.0 - g.frac[0];
-      if (lane == 0) g.cum[0] = g.frac[0];
-      for (int l = 0; l < nlev - 1; ++l) {
+      LevBits cl;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int i = lane + 64 * k;
+        cl.w[k] = __ballot(i < nlev && g.frac[i] > 0.0);
+      }
+      if ((cl.w[0] | cl.w[1] | cl.w[2]) != 0ull) {
+        ibegin = (cl.w[0] ? __ffsll((long long)cl.w[0]) : (cl.w[1] ? 64 + __ffsll((long long)cl.w[1]) : 128 + __ffsll((long long)cl.w[2])));
+        iend = (cl.w[2] ? 192 - __clzll(cl.w[2]) : (cl.w[1] ? 128 - __clzll(cl.w[1]) : 64 - __clzll(cl.w[0])));
+      }
+    }
+    if (ibegin == 0) {       // no cloud at all: total cloud cover 0
+      if (lane == 0) total_cloud_cover[cloc] = 0.0;
+      continue;
+    }
+    // cumulative cover: serial recurrence; above the first and below the last cloudy level the factor
+    // (1-pair)/(1-frac) is exactly 1, so only the cloudy span is walked
+    double tcc;
+    {
+      double cum_product = 1.0;       // = 1 - frac(1) for a cloud-free top level
+      for (int l = lane; l < ibegin - 1; l += 64) g.cum[l] = 0.0;
+      if (ibegin == 1) { cum_product = 1.0 - g.frac[0]; if (lane == 0) g.cum[0] = g.frac[0]; }
+      const int l0 = ibegin >= 2 ? ibegin - 2 : 0, l1 = iend < nlev ? iend : nlev - 1;
+      for (int l = l0; l < l1; ++l) {
         const double f0 = g.frac[l];
         if (f0 >= MaxCloudFrac) cum_product = 0.0;
         else cum_product = cum_product * (1.0 - g.pair[l]) / (1.0 - f0);
         if (lane == 0) g.cum[l + 1] = 1.0 - cum_product;
       }
+      tcc = 1.0 - cum_product;
+      for (int l = l1 + 1 + lane; l < nlev; l += 64) g.cum[l] = tcc;
     }
-    __syncthreads();
-    const double tcc = g.cum[nlev - 1];
+    wave_sync();
     if (tcc < cfg.cloud_fraction_threshold) {
       if (lane == 0) total_cloud_cover[cloc] = 0.0;
       continue;
     }
     if (lane == 0) total_cloud_cover[cloc] = tcc;
-    // first / last cloudy level (1-based ibegin, iend)
-    int ibegin = 1;
-    while (g.frac[ibegin - 1] <= 0.0) ibegin++;
-    int iend = ibegin;
-    for (int jlev = ibegin + 1; jlev <= nlev; ++jlev) if (g.frac[jlev - 1] > 0.0) iend = jlev;
     for (int l = lane; l < nlev - 1; l += 64) {
       const int jlev = l + 1;
       double op = g.ovp[l];
       if (jlev >= ibegin && jlev <= iend - 1 && op > 0.0) op = pow(op, 1.0 / cfg.cloud_inhom_decorr_scaling);
       g.opi[l] = op;
     }
+    ECRAD_LAP0(tm, 0);      // cloud cover, level set-up
     // ---- initialize_random_numbers (radiation_random_numbers_mix.F90:142-231), seeding in parallel ---
     for (int j = lane; j <= JPQ; j += 64) g.X[j] = 0;
-    __syncthreads();
+    wave_sync();
     {
       const int32_t JPMASK = 123459876;
       int32_t v = (in.iseed[col] + seed_offset) ^ JPMASK;
@@ -382,7 +457,7 @@ __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __
         g.X[2] = (int32_t)((idum & ((1u << (JPMM - 1)) - 1u)) << 1);
         g.X[JPQ] = (int32_t)(idum >> (JPMM - 1));
       }
-      __syncthreads();
+      wave_sync();
       // this lane's register = M^(lane*274) * idum
       const uint32_t* __restrict__ rows = cfg.lfsr_jump + 32 * lane;
       uint32_t s = 0;
@@ -396,64 +471,118 @@ __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __
         s = lfsr_step(s);
         if (++jj > JPQ - 1) { jj = 3; ++jbit; }
       }
-      __syncthreads();
+      wave_sync();
       if (lane == 0) g.X[JPQ - JPS] |= 1;
-      __syncthreads();
+      wave_sync();
     }
+    ECRAD_LAP0(tm, 1);      // seeding
     int iused = JPQ;
     gen_draw(g, lane, iused, 999, nullptr);     // warm-up
+    ECRAD_LAP0(tm, 2);      // warm-up
     // rand_top(1:ng) is ONE batch request in the reference (radiation_cloud_generator.F90:206)
     gen_draw(g, lane, iused, ng, g.rtop);
     double* odsc = od_scaling + (size_t)ng * nlev * cloc;
     for (int jg = 0; jg < ng; ++jg) {
       const double trigger = g.rtop[jg] * tcc;
-      int jlev = ibegin;
-      while (trigger > g.cum[jlev - 1] && jlev < iend) jlev++;
-      const int itrigger = jlev;
-      // generate_column_exp_ran, radiation_cloud_generator.F90:262-390
-      int n_layers_to_scale = 1;
-      int iy = 0;
-      gen_draw(g, lane, iused, iend + 1 - itrigger, g.rc);
-      for (jlev = itrigger + 1; jlev <= iend + 1; ++jlev) {
-        bool do_fill = false;
-        if (jlev <= iend) {
-          iy++;
-          const double f_above = g.frac[jlev - 2];
-          if (n_layers_to_scale > 0) {
-            if (g.rc[iy - 1] * f_above < g.frac[jlev - 1] + f_above - g.pair[jlev - 2]) n_layers_to_scale++;
-            else do_fill = true;
-          } else {
-            const double overhang = g.cum[jlev - 1] - g.cum[jlev - 2];
-            if (g.rc[iy - 1] * (g.cum[jlev - 2] - f_above) < g.pair[jlev - 2] - overhang - f_above)
-              n_layers_to_scale = 1;
-          }
-        } else {
-          do_fill = true;
+      // first level from ibegin whose cumulative cover reaches the trigger (iend at the latest)
+      int ti = iend - 1;
+      {
+        unsigned long long stop[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int i = lane + 64 * k;
+          stop[k] = __ballot(i >= ibegin - 1 && i < iend - 1 && !(trigger > g.cum[i]));
         }
-        if (do_fill) {
-          gen_draw(g, lane, iused, n_layers_to_scale, g.ri1);
-          gen_draw(g, lane, iused, n_layers_to_scale, g.ri2);
-          // decorrelation of the inhomogeneity down the run: serial "keep the previous value" (uniform)
-          if (lane == 0) {
-            double prev = 0.0;
-            for (int jcloud = 1; jcloud <= n_layers_to_scale; ++jcloud) {
-              double x = g.ri1[jcloud - 1];
-              if (jcloud >= 2 && g.ri2[jcloud - 1] < g.opi[jlev - n_layers_to_scale + jcloud - 3]) x = prev;
-              prev = x;
-              g.xs[jcloud - 1] = x;
-            }
+        if (stop[0]) ti = __ffsll((long long)stop[0]) - 1;
+        else if (stop[1]) ti = 64 + __ffsll((long long)stop[1]) - 1;
+        else if (stop[2]) ti = 128 + __ffsll((long long)stop[2]) - 1;
+      }
+      const int ei = iend - 1;          // 0-based first (ti) and last (ei) cloudy level of this sub-column
+      ECRAD_LAP0(tm, 3);    // trigger search
+      // generate_column_exp_ran (radiation_cloud_generator.F90:262-390), level-parallel.
+      // The reference walks down the levels with a run counter: inside a cloudy run the run continues
+      // where test A holds, outside it a new run starts where test B holds.  Both tests only involve
+      // this level's random number and fixed profiles, so all levels evaluate them at once (lane = level)
+      // and the run structure follows from the two bit masks.
+      gen_draw(g, lane, iused, ei + 1 - ti, g.rc);     // rand_cloud(1:iend+1-itrigger)
+      ECRAD_LAP0(tm, 4);    // draw rand_cloud
+      LevBits A, B;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int i = lane + 64 * k;
+        bool a = false, b = false;
+        if (i > ti && i <= ei) {
+          const double rc = g.rc[i - ti - 1], f_above = g.frac[i - 1], pr = g.pair[i - 1];
+          a = rc * f_above < g.frac[i] + f_above - pr;
+          const double overhang = g.cum[i] - g.cum[i - 1];
+          b = rc * (g.cum[i - 1] - f_above) < pr - overhang - f_above;
+        }
+        A.w[k] = __ballot(a);
+        B.w[k] = __ballot(b);
+      }
+      LevBits C;                                        // cloudy levels of this sub-column
+      C.clear();
+      {
+        unsigned in_cloud = 1u;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int lo = 64 * k;
+          if (ei < lo || ti > lo + 63) continue;
+          const int first = ti > lo ? ti - lo : 0, last = ei < lo + 63 ? ei - lo : 63;
+          unsigned long long a = A.w[k] >> first, b = B.w[k] >> first, c = 0ull;
+          for (int bit = first; bit <= last; ++bit) {
+            if (lo + bit > ti) in_cloud = (unsigned)((in_cloud ? a : b) & 1ull);
+            c |= (unsigned long long)in_cloud << bit;
+            a >>= 1; b >>= 1;
           }
-          __syncthreads();
-          for (int jcloud = 1 + lane; jcloud <= n_layers_to_scale; jcloud += 64) {
-            const int lev1 = jlev - n_layers_to_scale + jcloud - 1;
-            odsc[jg + (size_t)ng * (lev1 - 1)] = pdf_sample(cfg.pdf, g.fsd[lev1 - 1], g.xs[jcloud - 1]);
-          }
-          __syncthreads();
-          n_layers_to_scale = 0;
+          C.w[k] = c;
         }
       }
+      // every cloudy run draws rand_inhom1(1:n) then rand_inhom2(1:n) (radiation_cloud_generator.F90:
+      // 343-345), runs in top-down order: 2 x (number of cloudy levels) consecutive numbers in all
+      const int ncloudy = C.count_below(192);
+      ECRAD_LAP0(tm, 5);    // tests + run structure
+      gen_draw(g, lane, iused, 2 * ncloudy, g.ri);
+      ECRAD_LAP0(tm, 6);    // draw rand_inhom
+      // "keep the value of the layer above" flags (:350-357), then each level takes rand_inhom1 of the
+      // nearest level at or above it in its run whose flag is clear
+      LevBits K;
+      int run_start[3], run_base[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int i = lane + 64 * k;
+        bool keep = false;
+        run_start[k] = 0; run_base[k] = 0;
+        if (i >= ti && i <= ei && C.get(i)) {
+          const int s0 = C.highest_zero_le(i) + 1;                  // first level of the run (>= ti since ti-1 is clear)
+          const int s = s0 < ti ? ti : s0;
+          const int e = C.lowest_zero_ge(i) - 1;                    // last level of the run
+          const int n = e - s + 1, jc = i - s;                      // 0-based position in the run
+          const int base = 2 * C.count_below(s);
+          run_start[k] = s; run_base[k] = base;
+          if (jc >= 1) keep = g.ri[base + n + jc] < g.opi[i - 1];
+        }
+        K.w[k] = __ballot(keep);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int i = lane + 64 * k;
+        if (i >= ti && i <= ei && C.get(i)) {
+          const int src = K.highest_zero_le(i);                     // >= run start: its flag is clear
+          const double x = g.ri[run_base[k] + (src - run_start[k])];
+          odsc[jg + (size_t)ng * i] = pdf_sample(cfg.pdf, g.fsd[i], x);
+        }
+      }
+      wave_sync();
+      ECRAD_LAP0(tm, 7);    // flags, sampling, stores
     }
   }
+#ifdef ECRAD_TIMING
+  if (blockIdx.x == 0 && lane == 0 && tm_cols > 0)
+    printf("mcica_generator timing (cycles/column): setup %.0f seeding %.0f warmup %.0f | per column over all g: trigger %.0f draw_rc %.0f tests %.0f draw_ri %.0f sample %.0f  (columns %d)\n",
+           (double)tm.acc[0] / tm_cols, (double)tm.acc[1] / tm_cols, (double)tm.acc[2] / tm_cols, (double)tm.acc[3] / tm_cols,
+           (double)tm.acc[4] / tm_cols, (double)tm.acc[5] / tm_cols, (double)tm.acc[6] / tm_cols, (double)tm.acc[7] / tm_cols, tm_cols);
+#endif
 }
 
 size_t mcica_work_doubles(int nlev, int ng, int nloc) { return 0; }

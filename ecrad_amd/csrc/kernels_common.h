@@ -79,6 +79,11 @@ struct PhaseTimer {
 #define ECRAD_LAP0(timer, k) do { } while (0)
 #endif
 
+// Ordering point for code in which ONE wave owns its LDS data: LDS instructions of a wave execute in
+// program order, so no hardware barrier (and no wait for outstanding global memory operations, which
+// __syncthreads() implies) is needed -- only the compiler must not move LDS accesses across it.
+ECRAD_DEV void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
 ECRAD_DEV double dmax(double a, double b) { return a > b ? a : b; }
 ECRAD_DEV double dmin(double a, double b) { return a < b ? a : b; }
 
