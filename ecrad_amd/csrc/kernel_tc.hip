@@ -10,6 +10,10 @@
 #include "optics_device.h"
 #include "launch.h"
 
+#ifndef ECRAD_TC_MIN_WAVES
+#define ECRAD_TC_MIN_WAVES ECRAD_MIN_WAVES
+#endif
+
 namespace ecrad {
 
 // broadcast readers for the per-(column,level) geometry produced by the prep kernel
@@ -25,17 +29,39 @@ struct TcGeom {
 // ===================================================================================================
 // Shortwave
 // ===================================================================================================
-enum { S_R = 0, S_T = 5, S_RD = 10, S_TDF = 15, S_TDD = 20 };   // unused; kept for documentation
-// array index helpers: coefficient k (0 R,1 T,2 rd,3 tdf,4 tdd) of region r (0 clear,1,2)
-ECRAD_DEV int sw_coef(int k, int r) { return k * 3 + r; }                 // 0..14
-constexpr int SW_TA = 15;      // total_albedo[3]          15,16,17
-constexpr int SW_TAD = 18;     // total_albedo_direct[3]   18,19,20
-constexpr int SW_TAC = 21;     // total_albedo_clear
-constexpr int SW_TACD = 22;    // total_albedo_clear_direct
-constexpr int SW_TC_NUM = 23;
+// Two vertical sweeps, as in kernel_ica_sw.hip.  The reference (radiation_tripleclouds_sw.F90) computes
+// all layer coefficients, then sweeps up for the albedo below every half level (per region, with the
+// overlap matrices), then down for the fluxes.  Here sweep 1 goes UP from the surface doing optics,
+// two-stream coefficients and the albedo recurrences (:346-418) in one go, and stores per layer and
+// region only what the flux sweep (:470-540) needs:
+//     a1 = T/(1 - R A),  b = (t_dd Ad R + t_df)/(1 - R A),  t_dd,  A,  Ad
+// with A, Ad the total diffuse / direct albedo below the layer's lower half level in that region
+// (sets 0-2) and the same for the clear-sky column (set 3).  Clear layers only write sets 0 and 3.
+struct TcSwScratch {
+  double* base;
+  // per block: [level][set 0..3][ (a1,b): 512 doubles, (t_dd, A): 512, Ad: 256 ]
+  ECRAD_DEV StreamRef<double2> pair(int set, int k, int lev, int tid) const {
+    return {reinterpret_cast<double2*>(base + ((size_t)(lev * 4 + set) * 5 + 2 * k) * kBlock) + tid};
+  }
+  ECRAD_DEV StreamRef<double> single(int set, int lev, int tid) const {
+    return {base + ((size_t)(lev * 4 + set) * 5 + 4) * kBlock + tid};
+  }
+};
+
+// one region's step of the upward sweep: store the flux-sweep record, return the albedos just below
+// the half level above the layer (before overlap)
+ECRAD_DEV void tc_sw_up(const TcSwScratch& s, int set, int lev, int tid, const SwCoef& c, double A, double Ad,
+                        double& A_new, double& Ad_new) {
+  const double inv = 1.0 / (1.0 - A * c.ref_diff);
+  s.pair(set, 0, lev, tid) = make_double2(c.trans_diff * inv, (c.trans_dir_dir * Ad * c.ref_diff + c.trans_dir_diff) * inv);
+  s.pair(set, 1, lev, tid) = make_double2(c.trans_dir_dir, A);
+  s.single(set, lev, tid) = Ad;
+  A_new = c.ref_diff + c.trans_diff * c.trans_diff * A * inv;
+  Ad_new = c.ref_dir + (c.trans_dir_dir * Ad + c.trans_dir_diff * A) * c.trans_diff * inv;
+}
 
 template <typename TAB, int NGP>
-__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(SpectralArgs args_in_kernarg) {
+__global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
   constexpr int CPB = kBlock / NGP;
@@ -60,7 +86,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(Spectral
     const int grp = next_group;
     if (grp >= ngroups) break;
     const LdsLayout L = make_lds(smem, m.hot.nquad, cfg.n_cloud_types);
-    const Scratch s{a.scratch + (size_t)blockIdx.x * a.per_block, nlev + 1};
+    const TcSwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block};
     const int g = glane < ng ? glane : ng - 1;
     const int ib = cfg.i_band_from_reordered_g_sw[g] - 1;
     const double ray_g = m.rayleigh_molar_scat[g];
@@ -75,75 +101,9 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(Spectral
     const bool sun_up = !(mu0 < 1.0e-10);
     const DevCloudPrep prep = a.prep;
     const TcGeom geo{prep, ncol_loc, nlev, cloc};
-    double alb_dif = 0.0, alb_dir = 0.0, incoming = 0.0;
-    if (sun_up) {
-      albedo_sw_g(cfg, in, col, g, alb_dif, alb_dir);
-      incoming = incoming_sw_g(m, in, g);
-    }
-    LevMask cloudy;
-    cloudy.clear();
 
-    // ---- pass A ---------------------------------------------------------------------------------------
-    for (int l0 = 0; l0 < nlev; l0 += NGP) {
-      __syncthreads();
-      {
-        const SpectralArgs& b = kernarg_block<SpectralArgs>();
-        const int lev = l0 + glane;
-        if (lev < nlev) level_scalars<true>(b.cfg, b.cfg.gas_sw, b.in, L, tid, col, lev, true);
-      }
-      __syncthreads();
-      const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
-      if (sun_up) {
-        const GasHot gh = kernarg_block<SpectralArgs>().gas;
-        for (int j = 0; j < nl; ++j) {
-          const int lev = l0 + j;
-          const int slot = cib * NGP + j;
-          gas_load<TAB>(gh, launder_uniform(gh.nquad), launder_uniform(gh.nplain), L, slot, g, quads);
-          double od = gas_combine<TAB>(launder_uniform(gh.nquad), L, slot, quads);
-          double ssa = L.D(F_SM, slot) * ray_g;
-          od = od + ssa;
-          ssa = ssa / od;
-          double asym = 0.0;
-          if (use_aerosols) {
-            const SpectralArgs& b = kernarg_block<SpectralArgs>();
-            AerosolLayer al = aerosol_layer<true>(b.cfg, b.in, L, slot, col, lev, ib);
-            if (!delta_gases) delta_eddington_extensive_vec(al);
-            merge_aerosol_sw(b.cfg, al, od, ssa, asym);
-          }
-          {
-            const SwCoef c = ref_trans_sw_fused(mu0, od, ssa, asym);
-            s.at(sw_coef(0, 0), lev, tid) = c.ref_diff;
-            s.at(sw_coef(1, 0), lev, tid) = c.trans_diff;
-            s.at(sw_coef(2, 0), lev, tid) = c.ref_dir;
-            s.at(sw_coef(3, 0), lev, tid) = c.trans_dir_diff;
-            s.at(sw_coef(4, 0), lev, tid) = c.trans_dir_dir;
-          }
-          if (L.D(F_FRAC, slot) > 0.0) {
-            cloudy.set(lev);
-            const CloudLayer cl = cloud_layer<true>(kernarg_block<SpectralArgs>().cfg, L, slot, ib);
-#pragma unroll
-            for (int jreg = 1; jreg < 3; ++jreg) {   // radiation_tripleclouds_sw.F90:278-300
-              const double osc = geo.odsc(jreg, lev);
-              const double scat_od = od * ssa;
-              const double scat_od_cloud = cl.od * cl.ssa * osc;
-              double od_total = od + cl.od * osc;
-              double ssa_total = (scat_od + scat_od_cloud) / od_total;
-              double g_total = (scat_od * asym + scat_od_cloud * cl.g) / (scat_od + scat_od_cloud);
-              if (delta_gases) delta_eddington(od_total, ssa_total, g_total);
-              const SwCoef c = ref_trans_sw_fused(mu0, od_total, ssa_total, g_total);
-              s.at(sw_coef(0, jreg), lev, tid) = c.ref_diff;
-              s.at(sw_coef(1, jreg), lev, tid) = c.trans_diff;
-              s.at(sw_coef(2, jreg), lev, tid) = c.ref_dir;
-              s.at(sw_coef(3, jreg), lev, tid) = c.trans_dir_diff;
-              s.at(sw_coef(4, jreg), lev, tid) = c.trans_dir_dir;
-            }
-          }
-        }
-      }
-    }
-
-    const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
     if (!sun_up) {   // radiation_tripleclouds_sw.F90:212-249
+      const DevFlux& fx = a.fx;
       if (col_ok) {
         for (int l = glane; l <= nlev; l += NGP) {     // the lanes of a column share its half levels
           const size_t o = col + ncol * l;
@@ -164,66 +124,91 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(Spectral
       continue;
     }
 
-    // ---- pass B: upward sweep: albedo of everything below each half level, per region ------------
+    double alb_dif = 0.0, alb_dir = 0.0;
+    albedo_sw_g(cfg, in, col, g, alb_dif, alb_dir);
+    const double incoming = incoming_sw_g(m, in, g);
+    // which layers are cloudy (the upward sweep needs the layer ABOVE before it gets there)
+    const LevMask cloudy = column_level_mask<NGP>(in.cloud_fraction + col, ncol, nlev, tid % 64);
+
+    // ---- sweep 1: surface -> top ---------------------------------------------------------------------
     double ta[3], tad[3];
     ta[0] = alb_dif;
     tad[0] = mu0 * alb_dir;
     if (cloudy.test(nlev - 1)) { ta[1] = ta[2] = ta[0]; tad[1] = tad[2] = tad[0]; }
     else { ta[1] = ta[2] = 0.0; tad[1] = tad[2] = 0.0; }
     double tac = ta[0], tacd = tad[0];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) { s.at(SW_TA + r, nlev, tid) = ta[r]; s.at(SW_TAD + r, nlev, tid) = tad[r]; }
-    if (do_clear) { s.at(SW_TAC, nlev, tid) = tac; s.at(SW_TACD, nlev, tid) = tacd; }
-    for (int l = nlev - 1; l >= 0; --l) {
-      const double Rc = s.at(sw_coef(0, 0), l, tid), Tc = s.at(sw_coef(1, 0), l, tid), rdc = s.at(sw_coef(2, 0), l, tid),
-                   tdfc = s.at(sw_coef(3, 0), l, tid), tddc = s.at(sw_coef(4, 0), l, tid);
-      if (do_clear) {
-        const double inv = 1.0 / (1.0 - tac * Rc);
-        const double tac_new = Rc + Tc * Tc * tac * inv;
-        tacd = rdc + (tddc * tacd + tdfc * tac) * Tc * inv;
-        tac = tac_new;
-        s.at(SW_TAC, l, tid) = tac;
-        s.at(SW_TACD, l, tid) = tacd;
-      }
-      double below[3] = {0.0, 0.0, 0.0}, belowd[3] = {0.0, 0.0, 0.0};
+    const int nchunk = (nlev + NGP - 1) / NGP;
+    for (int ch = nchunk - 1; ch >= 0; --ch) {
+      const int l0 = ch * NGP;
+      if (ch != nchunk - 1) __syncthreads();
       {
-        const double inv = 1.0 / (1.0 - ta[0] * Rc);
-        below[0] = Rc + Tc * Tc * ta[0] * inv;
-        belowd[0] = rdc + (tddc * tad[0] + tdfc * ta[0]) * Tc * inv;
+        const SpectralArgs& b = kernarg_block<SpectralArgs>();
+        const int lev = l0 + glane;
+        if (lev < nlev) level_scalars<true>(b.cfg, b.cfg.gas_sw, b.in, L, tid, col, lev, true);
       }
-      const bool cl_here = cloudy.test(l);
-      if (cl_here) {
-#pragma unroll
-        for (int r = 1; r < 3; ++r) {
-          const double R = s.at(sw_coef(0, r), l, tid), T = s.at(sw_coef(1, r), l, tid), rd = s.at(sw_coef(2, r), l, tid),
-                       tdf = s.at(sw_coef(3, r), l, tid), tdd = s.at(sw_coef(4, r), l, tid);
-          const double inv = 1.0 / (1.0 - ta[r] * R);
-          below[r] = R + T * T * ta[r] * inv;
-          belowd[r] = rd + (tdd * tad[r] + tdf * ta[r]) * T * inv;
+      __syncthreads();
+      const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
+      const GasHot gh = kernarg_block<SpectralArgs>().gas;
+      for (int j = nl - 1; j >= 0; --j) {
+        const int l = l0 + j;
+        const int slot = cib * NGP + j;
+        gas_load<TAB>(gh, launder_uniform(gh.nquad), launder_uniform(gh.nplain), L, slot, g, quads);
+        double od = gas_combine<TAB>(launder_uniform(gh.nquad), L, slot, quads);
+        double ssa = L.D(F_SM, slot) * ray_g;
+        od = od + ssa;
+        ssa = ssa / od;
+        double asym = 0.0;
+        if (use_aerosols) {
+          const SpectralArgs& b = kernarg_block<SpectralArgs>();
+          AerosolLayer al = aerosol_layer<true>(b.cfg, b.in, L, slot, col, l, ib);
+          if (!delta_gases) delta_eddington_extensive_vec(al);
+          merge_aerosol_sw(b.cfg, al, od, ssa, asym);
         }
-      }
-      const bool cl_above = l > 0 && cloudy.test(l - 1);
-      if (!cl_here && !cl_above) {
+        double below[3] = {0.0, 0.0, 0.0}, belowd[3] = {0.0, 0.0, 0.0};
+        {
+          const SwCoef c = ref_trans_sw_fused(mu0, od, ssa, asym);
+          if (do_clear) tc_sw_up(s, 3, l, tid, c, tac, tacd, tac, tacd);
+          tc_sw_up(s, 0, l, tid, c, ta[0], tad[0], below[0], belowd[0]);
+        }
+        const bool cl_here = cloudy.test(l);
+        if (cl_here) {
+          const CloudLayer cl = cloud_layer<true>(kernarg_block<SpectralArgs>().cfg, L, slot, ib);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { ta[r] = below[r]; tad[r] = belowd[r]; }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {   // total_albedo(:,jreg,jlev) = sum_jreg2 below(:,jreg2) * v(jreg2,jreg,jlev)
-          double a = 0.0, b = 0.0;
-#pragma unroll
-          for (int r2 = 0; r2 < 3; ++r2) {
-            const double v = geo.v(r2, r, l);
-            a = a + below[r2] * v;
-            b = b + belowd[r2] * v;
+          for (int jreg = 1; jreg < 3; ++jreg) {   // radiation_tripleclouds_sw.F90:278-300
+            const double osc = geo.odsc(jreg, l);
+            const double scat_od = od * ssa;
+            const double scat_od_cloud = cl.od * cl.ssa * osc;
+            double od_total = od + cl.od * osc;
+            double ssa_total = (scat_od + scat_od_cloud) / od_total;
+            double g_total = (scat_od * asym + scat_od_cloud * cl.g) / (scat_od + scat_od_cloud);
+            if (delta_gases) delta_eddington(od_total, ssa_total, g_total);
+            const SwCoef c = ref_trans_sw_fused(mu0, od_total, ssa_total, g_total);
+            tc_sw_up(s, jreg, l, tid, c, ta[jreg], tad[jreg], below[jreg], belowd[jreg]);
           }
-          ta[r] = a; tad[r] = b;
+        }
+        // albedo just above the layer -> albedo below half level l of each region (:390-418)
+        const bool cl_above = l > 0 && cloudy.test(l - 1);
+        if (!cl_here && !cl_above) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) { ta[r] = below[r]; tad[r] = belowd[r]; }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {   // total_albedo(:,jreg,jlev) = sum_jreg2 below(:,jreg2) * v(jreg2,jreg,jlev)
+            double x = 0.0, y = 0.0;
+#pragma unroll
+            for (int r2 = 0; r2 < 3; ++r2) {
+              const double v = geo.v(r2, r, l);
+              x = x + below[r2] * v;
+              y = y + belowd[r2] * v;
+            }
+            ta[r] = x; tad[r] = y;
+          }
         }
       }
-#pragma unroll
-      for (int r = 0; r < 3; ++r) { s.at(SW_TA + r, l, tid) = ta[r]; s.at(SW_TAD + r, l, tid) = tad[r]; }
     }
 
-    // ---- pass C: downward sweep ------------------------------------------------------------------------
+    // ---- sweep 2: top -> surface ---------------------------------------------------------------------
+    const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
     double fdn[3] = {0.0, 0.0, 0.0}, ddn[3], fup[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) { ddn[r] = incoming * geo.frac(r, 0); fup[r] = ddn[r] * tad[r]; }
@@ -238,19 +223,19 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(Spectral
     for (int hl = 0; hl <= nlev; ++hl) {
       if (hl > 0) {
         const int l = hl - 1;
-        const double Rc = s.at(sw_coef(0, 0), l, tid), Tc = s.at(sw_coef(1, 0), l, tid),
-                     tdfc = s.at(sw_coef(3, 0), l, tid), tddc = s.at(sw_coef(4, 0), l, tid);
         if (do_clear) {
-          const double tacn = s.at(SW_TAC, hl, tid), tacdn = s.at(SW_TACD, hl, tid);
-          fdn_c = (Tc * fdn_c + ddn_c * (tddc * tacdn * Rc + tdfc)) / (1.0 - Rc * tacn);
-          ddn_c = tddc * ddn_c;
-          fup_c = ddn_c * tacdn + fdn_c * tacn;
+          const double2 p0 = s.pair(3, 0, l, tid), p1 = s.pair(3, 1, l, tid);
+          const double ad = s.single(3, l, tid);
+          fdn_c = p0.x * fdn_c + ddn_c * p0.y;
+          ddn_c = p1.x * ddn_c;
+          fup_c = ddn_c * ad + fdn_c * p1.y;
         }
         {
-          const double tan_ = s.at(SW_TA + 0, hl, tid), tadn = s.at(SW_TAD + 0, hl, tid);
-          fdn[0] = (Tc * fdn[0] + ddn[0] * (tddc * tadn * Rc + tdfc)) / (1.0 - Rc * tan_);
-          ddn[0] = tddc * ddn[0];
-          fup[0] = ddn[0] * tadn + fdn[0] * tan_;
+          const double2 p0 = s.pair(0, 0, l, tid), p1 = s.pair(0, 1, l, tid);
+          const double ad = s.single(0, l, tid);
+          fdn[0] = p0.x * fdn[0] + ddn[0] * p0.y;
+          ddn[0] = p1.x * ddn[0];
+          fup[0] = ddn[0] * ad + fdn[0] * p1.y;
         }
         const bool cl_here = cloudy.test(l);
         if (!cl_here) {
@@ -258,12 +243,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(Spectral
         } else {
 #pragma unroll
           for (int r = 1; r < 3; ++r) {
-            const double R = s.at(sw_coef(0, r), l, tid), T = s.at(sw_coef(1, r), l, tid),
-                         tdf = s.at(sw_coef(3, r), l, tid), tdd = s.at(sw_coef(4, r), l, tid);
-            const double tan_ = s.at(SW_TA + r, hl, tid), tadn = s.at(SW_TAD + r, hl, tid);
-            fdn[r] = (T * fdn[r] + ddn[r] * (tdd * tadn * R + tdf)) / (1.0 - R * tan_);
-            ddn[r] = tdd * ddn[r];
-            fup[r] = ddn[r] * tadn + fdn[r] * tan_;
+            const double2 p0 = s.pair(r, 0, l, tid), p1 = s.pair(r, 1, l, tid);
+            const double ad = s.single(r, l, tid);
+            fdn[r] = p0.x * fdn[r] + ddn[r] * p0.y;
+            ddn[r] = p1.x * ddn[r];
+            fup[r] = ddn[r] * ad + fdn[r] * p1.y;
           }
         }
         const bool cl_below = hl < nlev && cloudy.test(hl);
@@ -271,14 +255,14 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(Spectral
           double nf[3], nd[3];
 #pragma unroll
           for (int j1 = 0; j1 < 3; ++j1) {
-            double a = 0.0, b = 0.0;
+            double x = 0.0, y = 0.0;
 #pragma unroll
             for (int j2 = 0; j2 < 3; ++j2) {
               const double v = geo.v(j1, j2, hl);
-              a = a + v * fdn[j2];
-              b = b + v * ddn[j2];
+              x = x + v * fdn[j2];
+              y = y + v * ddn[j2];
             }
-            nf[j1] = a; nd[j1] = b;
+            nf[j1] = x; nd[j1] = y;
           }
 #pragma unroll
           for (int r = 0; r < 3; ++r) { fdn[r] = nf[r]; ddn[r] = nd[r]; }
@@ -321,7 +305,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_tc_kernel(Spectral
   }
 }
 
-size_t sw_tc_scratch_doubles(int nlev) { return (size_t)SW_TC_NUM * (nlev + 1) * kBlock; }
+size_t sw_tc_scratch_doubles(int nlev) { return (size_t)4 * 5 * nlev * kBlock; }
 
 hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block,
@@ -344,7 +328,7 @@ constexpr int LT_TS = 14;     // total_source[3]   14..16
 constexpr int LW_TC_NUM = 17;
 
 template <typename TAB, int NGP>
-__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_tc_kernel(SpectralArgs args_in_kernarg) {
+__global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
   constexpr int CPB = kBlock / NGP;

@@ -384,7 +384,31 @@ struct LevMask {
     return (w >> (l & 63)) & 1ull;
   }
   ECRAD_DEV bool any() const { return (w0 | w1 | w2 | w3) != 0ull; }
+  // or in `nbits` (<= 64) flags for levels l0 .. l0+nbits-1; l0 is a multiple of nbits (a power of two)
+  ECRAD_DEV void or_bits(int l0, unsigned long long bits) {
+    const unsigned long long b = bits << (l0 & 63);
+    const int k = l0 >> 6;
+    w0 |= (k == 0) ? b : 0ull; w1 |= (k == 1) ? b : 0ull; w2 |= (k == 2) ? b : 0ull; w3 |= (k == 3) ? b : 0ull;
+  }
 };
+
+// Cloud mask of a column, built cooperatively by the NGP lanes that share it: lane j tests levels
+// j, j+NGP, ... and each ballot hands every lane the NGP flags of its own column.
+template <int NGP>
+ECRAD_DEV LevMask column_level_mask(const double* __restrict__ frac_col, size_t stride, int nlev, int lane_in_wave) {
+  LevMask m;
+  m.clear();
+  const int glane = lane_in_wave % NGP;
+  const int shift = (lane_in_wave / NGP) * NGP;           // position of this column's lanes in the wave
+  for (int l0 = 0; l0 < nlev; l0 += NGP) {
+    const int l = l0 + glane;
+    const bool c = l < nlev && frac_col[stride * l] > 0.0;
+    const unsigned long long b = __ballot(c);
+    const unsigned long long mine = NGP == 64 ? b : ((b >> shift) & ((1ull << (NGP & 63)) - 1ull));
+    m.or_bits(l0, mine);
+  }
+  return m;
+}
 constexpr int kMaxLev = 256;
 
 }  // namespace ecrad
