@@ -628,9 +628,6 @@ int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int ie
     d.aerosol_mixing_ratio = in->aerosol_mixing_ratio;
     return ECRAD_OK;
   }
-  // radiation_reverse (radiation_interface.F90:310-317, :519-661) is not implemented
-  if (in->pressure_hl[(size_t)(istartcol - 1) + (size_t)ncol] < in->pressure_hl[istartcol - 1])
-    return fail(h, ECRAD_EUNSUPPORTED, "inputs ordered surface-first (radiation_reverse) are not implemented");
   const Range& r = cx.r;
   StagedInputs sz = carve_inputs(nullptr, c, *in, r);
   HIP_TRY(h, h->staging_in.ensure(sz.bytes));
@@ -765,9 +762,11 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
         const int ngmax = c.n_g_sw > c.n_g_lw ? c.n_g_sw : c.n_g_lw;
         mcica_work = cv.take<double>(mcica_work_doubles(nlev, ngmax, r.nloc));
       }
+      if (c.do_clouds) cx.din.cloud_fraction_work = cv.take<double>(L * n);
       if (pass == 0) HIP_TRY(h, h->prep.ensure(cv.off));
     }
   }
+  cx.din.reversed = counters + 32;     // level-order flag, set on the device by order_kernel below
   const DevInputs& din = cx.din;
   double* scratch = reinterpret_cast<double*>(h->scratch.p);
 
@@ -775,6 +774,7 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
   HIP_TRY(h, hipEventRecord(h->ev0, stream));
   HIP_TRY(h, hipEventRecord(h->evs[0], stream));
   HIP_TRY(h, hipMemsetAsync(counters, 0, 256, stream));
+  HIP_TRY(h, launch_order(stream, din, counters + 32));                                 // :310-317
   if (c.do_clouds) HIP_TRY(h, launch_crop(stream, h->dcfg, din));                      // :361
   if (sw_tc || lw_tc)
     HIP_TRY(h, launch_tripleclouds_prep(stream, h->dcfg, din, prep, sw_tc ? dfx.cloud_cover_sw : nullptr,
@@ -868,7 +868,14 @@ int ecrad_hip_optics(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, in
     Carver cv(h->staging_out.p);
     for (const OF& f : fields) if (out->*(f.host)) dop.*(f.dev) = cv.take<double>(f.n);
   }
-  if (c.do_clouds) HIP_TRY(h, launch_crop(stream, h->dcfg, cx.din));
+  HIP_TRY(h, h->counters.ensure(256));
+  cx.din.reversed = reinterpret_cast<int32_t*>(h->counters.p) + 32;
+  HIP_TRY(h, launch_order(stream, cx.din, reinterpret_cast<int32_t*>(h->counters.p) + 32));
+  if (c.do_clouds) {
+    HIP_TRY(h, h->prep.ensure((size_t)nlev * r.nloc * 8));
+    cx.din.cloud_fraction_work = reinterpret_cast<double*>(h->prep.p);
+    HIP_TRY(h, launch_crop(stream, h->dcfg, cx.din));
+  }
   const int nct = c.do_clouds ? c.n_cloud_types : 0;
   if (c.do_sw) HIP_TRY(h, launch_optics_dump(true, h->ngp_sw, h->hcfg.gas_sw.table_f32, grid_for(h, r.nloc, h->ngp_sw),
                                              lds_bytes(h->hcfg.gas_sw.hot.nquad, nct), stream, h->dcfg, cx.din, dop));

@@ -119,6 +119,14 @@ struct DevInputs {
   double* cloud_fraction;
   const double *cloud_mixing_ratio, *cloud_effective_radius, *cloud_fractional_std, *cloud_overlap_param;
   const double* aerosol_mixing_ratio;
+  // Device flag set by order_kernel at the start of every call: non-zero when the caller's arrays run
+  // from the surface upwards (pressure decreasing with the level index).  The kernels always work
+  // top-down; they map level indices when they touch the caller's arrays (radiation_reverse,
+  // radiation_interface.F90:310-317, :519-661, without the copies).
+  const int32_t* reversed;
+  // In that case crop_cloud_fraction writes here ([level][local column], caller's level order) instead
+  // of the caller's array: the reference crops a reversed COPY, so cloud%fraction is left untouched.
+  double* cloud_fraction_work;
 };
 
 // Output arrays on the device (same layouts as ecrad_flux_t); NULL = not wanted

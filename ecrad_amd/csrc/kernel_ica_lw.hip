@@ -98,11 +98,12 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
     int ict = nlev;              // 0-based index of the first cloudy layer (= its top half level)
     double fdn_c = 0.0;          // clear-sky downwelling flux at the current half level
     double fdn_ctop = 0.0;       // ... captured at cloud top
-    double planck_top = planck_at<TAB>(m, a.in.temperature_hl[col], g);   // top-of-atmosphere half level
+    const LevelOrder ord = level_order(a.in);
+    double planck_top = planck_at<TAB>(m, a.in.temperature_hl[col + ncol * ord.half(0)], g);   // top-of-atmosphere half level
 
     // ---- pass A: top -> bottom ---------------------------------------------------------------------
     if (lead) {                  // flux_dn(:,1) = 0
-      const size_t o = col;
+      const size_t o = col + ncol * ord.half(0);
       a.fx.lw_dn[o] = 0.0;
       if (have_clear_out) a.fx.lw_dn_clear[o] = 0.0;
     }
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
         planck_top = planck_bot;
       }
       if (col_ok && glane < nl) {
-        const size_t o = col + ncol * (l0 + glane + 1);
+        const size_t o = col + ncol * ord.half(l0 + glane + 1);
         lw_dn[o] = keep_dn;
         if (lw_dn_clear) lw_dn_clear[o] = keep_dn;
       }
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
     double dsum = group_sum<NGP>(valid ? fup : 0.0);
     double deriv = fup / dsum;
     if (lead) {
-      const size_t o = col + ncol * nlev;
+      const size_t o = col + ncol * ord.half(nlev);
       fx.lw_up[o] = dsum;
       if (have_clear_out) fx.lw_up_clear[o] = dsum;
       if (do_deriv) fx.lw_derivatives[o] = 1.0;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
             if ((l & (NGP - 1)) == 0) {
               const int lv = l + glane;
               if (col_ok && lv < nlev) {
-                const size_t o = col + ncol * lv;
+                const size_t o = col + ncol * ord.half(lv);
                 fx.lw_up[o] = keep_up;
                 if (have_clear_out) fx.lw_up_clear[o] = keep_up;
                 if (do_deriv) fx.lw_derivatives[o] = keep_der;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
         if ((l & (NGP - 1)) == 0) {
           const int lv = l + glane;
           if (col_ok && lv <= ict) {
-            const size_t o = col + ncol * lv;
+            const size_t o = col + ncol * ord.half(lv);
             fx.lw_up[o] = blend ? w * keep_up + (1.0 - w) * fx.lw_up_clear[o] : keep_up;
           }
         }
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
       if ((hl & (NGP - 1)) == NGP - 1 || hl == nlev) {
         const int lv = kept.mine(hl, glane);
         if (col_ok && lv > ict && lv <= hl) {
-          const size_t o = col + ncol * lv;
+          const size_t o = col + ncol * ord.half(lv);
           fx.lw_up[o] = blend ? w * kept.v[0] + (1.0 - w) * fx.lw_up_clear[o] : kept.v[0];
           fx.lw_dn[o] = blend ? w * kept.v[1] + (1.0 - w) * fx.lw_dn_clear[o] : kept.v[1];
         }
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
         if ((l & (NGP - 1)) == 0) {
           const int lv = l + glane;
           if (col_ok && lv < nlev) {
-            const size_t o = col + ncol * lv;
+            const size_t o = col + ncol * ord.half(lv);
             fx.lw_derivatives[o] = modify ? (1.0 - wclr) * keep_der + wclr * fx.lw_derivatives[o] : keep_der;
           }
         }

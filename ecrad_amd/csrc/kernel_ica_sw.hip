@@ -88,7 +88,7 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
                              double sig_top, bool valid, bool col_ok, size_t ncol, int col,
                              double* out_up, double* out_dn, double* out_dir, double weight,
                              const double* clr_up, const double* clr_dn, const double* clr_dir,
-                             double* dup_up, double* dup_dn, double* dup_dir,
+                             double* dup_up, double* dup_dn, double* dup_dir, const LevelOrder& ord,
                              double& fdn_surf, double& fdir_surf, double& fup_toa) {
   double Fd = incoming, fdn = 0.0, fup = incoming * sig_top;
   fup_toa = fup;
@@ -106,7 +106,7 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
     if ((l & (NGP - 1)) == NGP - 1 || l == nlev) {
       const int lv = (l & ~(NGP - 1)) + glane;
       if (col_ok && lv <= l) {
-        const size_t o = col + ncol * lv;
+        const size_t o = col + ncol * ord.half(lv);
         double vu = keep_u, vd = keep_d, vdir = keep_dir;
         if (blend) {
           vu = weight * vu + (1.0 - weight) * clr_up[o];
@@ -304,13 +304,14 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
 
     // ---- sweep 2: top -> surface: fluxes ------------------------------------------------------------
     const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
+    const LevelOrder ord = level_order(kernarg_block<SpectralArgs>().in);
     ECRAD_LAP0(tm, 0);
     if (sun_up && !(ECRAD_ABLATE & 4)) {
       double fdn_s = 0.0, fdir_s = 0.0, fup_t = 0.0;
       if (MODE == 0) {
         sw_flux_sweep<NGP>(s, false, -1, tid, nlev, mu0, incoming, st1.sig, valid, col_ok, ncol, col,
                            fx.sw_up, fx.sw_dn, fx.sw_dn_direct, 1.0, nullptr, nullptr, nullptr,
-                           have_clear_out ? fx.sw_up_clear : nullptr, fx.sw_dn_clear, fx.sw_dn_direct_clear,
+                           have_clear_out ? fx.sw_up_clear : nullptr, fx.sw_dn_clear, fx.sw_dn_direct_clear, ord,
                            fdn_s, fdir_s, fup_t);
         if (valid) {
           const size_t og = g + (size_t)ng * col;
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
           // without a second (cloudy) sweep the total-sky profiles are the clear-sky ones
           sw_flux_sweep<NGP>(s, false, -1, tid, nlev, mu0, incoming, st1.sig, valid, col_ok, ncol, col,
                              fx.sw_up_clear, fx.sw_dn_clear, fx.sw_dn_direct_clear, 1.0, nullptr, nullptr, nullptr,
-                             do_set2 ? nullptr : fx.sw_up, fx.sw_dn, fx.sw_dn_direct,
+                             do_set2 ? nullptr : fx.sw_up, fx.sw_dn, fx.sw_dn_direct, ord,
                              fdn_c, fdir_c, fup_c);
           if (valid) {
             const size_t og = g + (size_t)ng * col;
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
           const double w = (MODE == 2) ? tcc : 1.0;
           sw_flux_sweep<NGP>(s, lcb >= 0, lcb, tid, nlev, mu0, incoming, lcb >= 0 ? st2.sig : st1.sig, valid, col_ok, ncol, col,
                              fx.sw_up, fx.sw_dn, fx.sw_dn_direct, w, fx.sw_up_clear, fx.sw_dn_clear,
-                             fx.sw_dn_direct_clear, nullptr, nullptr, nullptr, fdn_s, fdir_s, fup_t);
+                             fx.sw_dn_direct_clear, nullptr, nullptr, nullptr, ord, fdn_s, fdir_s, fup_t);
           if (valid) {
             const size_t og = g + (size_t)ng * col;
             if (MODE == 2) {

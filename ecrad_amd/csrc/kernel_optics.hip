@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
         if (out.lw_emission) out.lw_emission[og] = planck_at<TAB>(m, in.skin_temperature[col], g) * (1.0 - lw_albedo);
       }
     }
-    double planck_top = IS_SW ? 0.0 : planck_at<TAB>(m, in.temperature_hl[col], g);   // top-of-atmosphere half level
+    double planck_top = IS_SW ? 0.0 : planck_at<TAB>(m, in.temperature_hl[col + (size_t)in.ncol * level_order(in).half(0)], g);   // top-of-atmosphere half level
     for (int l0 = 0; l0 < nlev; l0 += NGP) {
       __syncthreads();
       {

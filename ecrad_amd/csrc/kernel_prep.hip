@@ -22,9 +22,21 @@ __global__ void crop_cloud_fraction_kernel(const DevConfig* __restrict__ cfgp, D
     const size_t o = (in.istartcol - 1 + cloc) + ncol * lev;
     double sum_mixing_ratio = 0.0;
     for (int t = 0; t < in.n_cloud_types; ++t) sum_mixing_ratio += in.cloud_mixing_ratio[o + ncol * in.nlev * t];
-    if (in.cloud_fraction[o] < cfg.cloud_fraction_threshold || sum_mixing_ratio < cfg.cloud_mixing_ratio_threshold)
-      in.cloud_fraction[o] = 0.0;
+    const bool crop = in.cloud_fraction[o] < cfg.cloud_fraction_threshold || sum_mixing_ratio < cfg.cloud_mixing_ratio_threshold;
+    if (*in.reversed != 0) in.cloud_fraction_work[(size_t)lev * nloc + cloc] = crop ? 0.0 : in.cloud_fraction[o];
+    else if (crop) in.cloud_fraction[o] = 0.0;
   }
+}
+
+// Level order of the caller's arrays: the test of radiation_interface.F90:310-311 on the first column
+__global__ void order_kernel(DevInputs in, int32_t* flag) {
+  const size_t c0 = in.istartcol - 1;
+  *flag = in.pressure_hl[c0 + in.ncol] < in.pressure_hl[c0] ? 1 : 0;
+}
+
+hipError_t launch_order(hipStream_t st, const DevInputs& in, int32_t* flag) {
+  hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1), 0, st, in, flag);
+  return hipGetLastError();
 }
 
 hipError_t launch_crop(hipStream_t st, const DevConfig* cfg, const DevInputs& in) {
@@ -91,11 +103,13 @@ __global__ void tripleclouds_prep_kernel(const DevConfig* __restrict__ cfgp, Dev
   const double LowerFracFSDIntercept = MinLowerFrac - FSDAtMinLowerFrac * LowerFracFSDGradient;
   double fu[3] = {1.0, 0.0, 0.0}, fl[3], op[3] = {1.0, 1.0, 1.0}, M[9];
   double prod = 1.0;
+  const LevelOrder ord = level_order(in);
+  const FracView fracv = cloud_fraction_view(in, col);
   for (int jlev = 1; jlev <= nlev + 1; ++jlev) {
     if (jlev > nlev) { fl[0] = 1.0; fl[1] = 0.0; fl[2] = 0.0; }
     else {
-      const size_t o = col + ncol * (jlev - 1);
-      const double cf = in.cloud_fraction[o], fsd = in.cloud_fractional_std[o];
+      const size_t o = col + ncol * ord.full(jlev - 1);
+      const double cf = fracv.p[fracv.stride * ord.full(jlev - 1)], fsd = in.cloud_fractional_std[o];
       double os2, os3;
       if (cf < thr) { fl[0] = 1.0; fl[1] = 0.0; fl[2] = 0.0; os2 = 1.0; os3 = 1.0; }
       else if (!do_gamma) {
@@ -116,7 +130,7 @@ __global__ void tripleclouds_prep_kernel(const DevConfig* __restrict__ cfgp, Dev
     }
     if (jlev == 1 || jlev > nlev) { op[0] = op[1] = op[2] = 1.0; }
     else {
-      op[0] = in.cloud_overlap_param[col + ncol * (jlev - 2)];
+      op[0] = in.cloud_overlap_param[col + ncol * ord.iface(jlev - 2)];
       if (op[0] >= 0.0) op[1] = op[2] = pow(op[0], 1.0 / cfg.cloud_inhom_decorr_scaling);
       else op[1] = op[2] = op[0];
     }
@@ -369,10 +383,12 @@ __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __
     tm.start();
     tm_cols++;
 #endif
+    const LevelOrder ord = level_order(in);
+    const FracView fracv = cloud_fraction_view(in, col);
     for (int l = lane; l < nlev; l += 64) {
-      g.frac[l] = in.cloud_fraction[col + ncol * l];
-      g.fsd[l] = in.cloud_fractional_std[col + ncol * l];
-      if (l < nlev - 1) g.ovp[l] = in.cloud_overlap_param[col + ncol * l];
+      g.frac[l] = fracv.p[fracv.stride * ord.full(l)];
+      g.fsd[l] = in.cloud_fractional_std[col + ncol * ord.full(l)];
+      if (l < nlev - 1) g.ovp[l] = in.cloud_overlap_param[col + ncol * ord.iface(l)];
     }
     wave_sync();
     // cum_cloud_cover_exp_ran / _max_ran (radiation_cloud_cover.F90:169-330): pair cover is independent

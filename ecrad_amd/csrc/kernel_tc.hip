@@ -101,12 +101,13 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
     const bool sun_up = !(mu0 < 1.0e-10);
     const DevCloudPrep prep = a.prep;
     const TcGeom geo{prep, ncol_loc, nlev, cloc};
+    const LevelOrder ord = level_order(in);
 
     if (!sun_up) {   // radiation_tripleclouds_sw.F90:212-249
       const DevFlux& fx = a.fx;
       if (col_ok) {
         for (int l = glane; l <= nlev; l += NGP) {     // the lanes of a column share its half levels
-          const size_t o = col + ncol * l;
+          const size_t o = col + ncol * l;      // every half level is zeroed: order irrelevant
           fx.sw_up[o] = 0.0; fx.sw_dn[o] = 0.0;
           if (fx.sw_dn_direct) fx.sw_dn_direct[o] = 0.0;
           if (do_clear) {
@@ -128,7 +129,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
     albedo_sw_g(cfg, in, col, g, alb_dif, alb_dir);
     const double incoming = incoming_sw_g(m, in, g);
     // which layers are cloudy (the upward sweep needs the layer ABOVE before it gets there)
-    const LevMask cloudy = column_level_mask<NGP>(in.cloud_fraction + col, ncol, nlev, tid % 64);
+    const FracView fracv = cloud_fraction_view(in, col);
+    const LevMask cloudy = column_level_mask<NGP>(fracv.p, fracv.stride, nlev, tid % 64, ord);
 
     // ---- sweep 1: surface -> top ---------------------------------------------------------------------
     double ta[3], tad[3];
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
       if ((hl & (NGP - 1)) == NGP - 1 || hl == nlev) {      // write NGP half levels at a time
         const int lv = kept.mine(hl, glane);
         if (col_ok && lv <= hl) {
-          const size_t o = col + ncol * lv;
+          const size_t o = col + ncol * ord.half(lv);
           fx.sw_up[o] = kept.v[0];
           fx.sw_dn[o] = mu0 * kept.v[2] + kept.v[1];
           if (fx.sw_dn_direct) fx.sw_dn_direct[o] = mu0 * kept.v[2];
@@ -373,12 +375,13 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
     cloudy.clear();
     int ict = nlev;             // 0-based layer index of cloud top (= i_cloud_top-1); nlev if none
     double fdn_c = 0.0, fdn_ctop = 0.0;
-    double planck_top = planck_at<TAB>(m, in.temperature_hl[col], g);   // top-of-atmosphere half level
+    const LevelOrder ord = level_order(in);
+    double planck_top = planck_at<TAB>(m, in.temperature_hl[col + ncol * ord.half(0)], g);   // top-of-atmosphere half level
 
     // ---- pass A ---------------------------------------------------------------------------------------
     if (lead) {
-      if (do_clear) a.fx.lw_dn_clear[col] = 0.0;
-      a.fx.lw_dn[col] = 0.0;
+      if (do_clear) a.fx.lw_dn_clear[col + ncol * ord.half(0)] = 0.0;
+      a.fx.lw_dn[col + ncol * ord.half(0)] = 0.0;
     }
     for (int l0 = 0; l0 < nlev; l0 += NGP) {
       __syncthreads();
@@ -438,7 +441,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
         planck_top = planck_bot;
       }
       if (col_ok && glane < nl) {
-        const size_t o = col + ncol * (l0 + glane + 1);
+        const size_t o = col + ncol * ord.half(l0 + glane + 1);
         lw_dn[o] = keep_dn;      // provisional: replaced below cloud top by the all-sky value
         if (lw_dn_clear) lw_dn_clear[o] = keep_dn;
       }
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
     {
       double fup = emission + albedo * fdn_c;
       double su = group_sum<NGP>(valid ? fup : 0.0);
-      if (lead && do_clear) fx.lw_up_clear[col + ncol * nlev] = su;
+      if (lead && do_clear) fx.lw_up_clear[col + ncol * ord.half(nlev)] = su;
       double keep_up = 0.0;
       for (int l = nlev - 1; l >= 0; --l) {
         fup = s.at(LT_T1, l, tid) * fup + s.at(LT_SU1, l, tid);
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
           if ((l & (NGP - 1)) == glane) keep_up = su;
           if ((l & (NGP - 1)) == 0) {
             const int lv = l + glane;
-            if (col_ok && lv < nlev) fx.lw_up_clear[col + ncol * lv] = keep_up;
+            if (col_ok && lv < nlev) fx.lw_up_clear[col + ncol * ord.half(lv)] = keep_up;
           }
         }
       }
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
     double fup[3] = {ts[0] + ta[0] * fdn_ctop, 0.0, 0.0};
     {
       double su = group_sum<NGP>(valid ? fup[0] : 0.0);
-      if (lead) fx.lw_up[col + ncol * ict] = su;
+      if (lead) fx.lw_up[col + ncol * ord.half(ict)] = su;
       double keep_up = 0.0;
       for (int l = ict - 1; l >= 0; --l) {
         fup[0] = s.at(LT_T1, l, tid) * fup[0] + s.at(LT_SU1, l, tid);
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
         if ((l & (NGP - 1)) == glane) keep_up = su;
         if ((l & (NGP - 1)) == 0) {
           const int lv = l + glane;
-          if (col_ok && lv < ict) fx.lw_up[col + ncol * lv] = keep_up;
+          if (col_ok && lv < ict) fx.lw_up[col + ncol * ord.half(lv)] = keep_up;
         }
       }
       if (valid) fx.lw_up_toa_g[g + (size_t)ng * col] = fup[0];
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
       if ((hl & (NGP - 1)) == NGP - 1 || hl == nlev) {
         const int lv = kept.mine(hl, glane);
         if (col_ok && lv > ict && lv <= hl) {
-          const size_t o = col + ncol * lv;
+          const size_t o = col + ncol * ord.half(lv);
           fx.lw_up[o] = kept.v[0];
           fx.lw_dn[o] = kept.v[1];
         }
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
       const double fs = fup[0] + fup[1] + fup[2];
       const double tot = group_sum<NGP>(valid ? fs : 0.0);
       double d[3] = {fs / tot, 0.0, 0.0};
-      if (lead) fx.lw_derivatives[col + ncol * nlev] = 1.0;
+      if (lead) fx.lw_derivatives[col + ncol * ord.half(nlev)] = 1.0;
       double keep_der = 0.0;
       for (int l = nlev - 1; l >= 0; --l) {
         double n[3];
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
         if ((l & (NGP - 1)) == glane) keep_der = sder;
         if ((l & (NGP - 1)) == 0) {
           const int lv = l + glane;
-          if (col_ok && lv < nlev) fx.lw_derivatives[col + ncol * lv] = keep_der;
+          if (col_ok && lv < nlev) fx.lw_derivatives[col + ncol * ord.half(lv)] = keep_der;
         }
       }
     }

@@ -293,6 +293,26 @@ ECRAD_DEV void delta_eddington_extensive(double& od, double& scat_od, double& sc
   scat_od_g = scat_od * g / (1.0 + g);
 }
 
+// ---- level order of the caller's arrays ----------------------------------------------------------------
+struct LevelOrder {
+  int nlev;
+  bool rev;
+  ECRAD_DEV int full(int l) const { return rev ? nlev - 1 - l : l; }          // layer index (0-based)
+  ECRAD_DEV int half(int hl) const { return rev ? nlev - hl : hl; }            // half-level index (0-based)
+  ECRAD_DEV int iface(int k) const { return rev ? nlev - 2 - k : k; }          // interface between layers k, k+1
+};
+ECRAD_DEV LevelOrder level_order(const DevInputs& in) { return {in.nlev, *in.reversed != 0}; }
+
+// Cropped cloud fraction of one column: p[stride*k] is level k in the caller's order (see DevInputs)
+struct FracView {
+  const double* p;
+  size_t stride;
+};
+ECRAD_DEV FracView cloud_fraction_view(const DevInputs& in, int col) {
+  if (*in.reversed != 0) return {in.cloud_fraction_work + (col - (in.istartcol - 1)), (size_t)(in.iendcol - in.istartcol + 1)};
+  return {in.cloud_fraction + col, (size_t)in.ncol};
+}
+
 // ---- streaming accesses -----------------------------------------------------------------------------
 // The sweep scratch is written once and read once per column group and is far larger than the caches;
 // marking its accesses non-temporal keeps it from evicting the gas tables (re-read by every layer of
@@ -395,14 +415,15 @@ struct LevMask {
 // Cloud mask of a column, built cooperatively by the NGP lanes that share it: lane j tests levels
 // j, j+NGP, ... and each ballot hands every lane the NGP flags of its own column.
 template <int NGP>
-ECRAD_DEV LevMask column_level_mask(const double* __restrict__ frac_col, size_t stride, int nlev, int lane_in_wave) {
+ECRAD_DEV LevMask column_level_mask(const double* __restrict__ frac_col, size_t stride, int nlev, int lane_in_wave,
+                                    const LevelOrder& ord) {
   LevMask m;
   m.clear();
   const int glane = lane_in_wave % NGP;
   const int shift = (lane_in_wave / NGP) * NGP;           // position of this column's lanes in the wave
   for (int l0 = 0; l0 < nlev; l0 += NGP) {
     const int l = l0 + glane;
-    const bool c = l < nlev && frac_col[stride * l] > 0.0;
+    const bool c = l < nlev && frac_col[stride * ord.full(l)] > 0.0;
     const unsigned long long b = __ballot(c);
     const unsigned long long mine = NGP == 64 ? b : ((b >> shift) & ((1ull << (NGP & 63)) - 1ull));
     m.or_bits(l0, mine);

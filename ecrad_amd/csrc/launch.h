@@ -34,6 +34,7 @@ hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream
 hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block, int* counter,
                         const DevCkdModel& m);
+hipError_t launch_order(hipStream_t st, const DevInputs& in, int32_t* flag);
 hipError_t launch_crop(hipStream_t st, const DevConfig* cfg, const DevInputs& in);
 hipError_t launch_tripleclouds_prep(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevCloudPrep& prep,
                                     double* cc_sw, double* cc_lw);

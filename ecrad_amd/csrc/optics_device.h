@@ -68,9 +68,12 @@ template <bool IS_SW>
 ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const DevInputs& in,
                              const LdsLayout& L, int slot, int col, int lev, bool want_clouds) {
   const size_t ncol = in.ncol;
-  const size_t i0 = col + ncol * lev, i1 = col + ncol * (lev + 1);
-  const double p0 = in.pressure_hl[i0], p1 = in.pressure_hl[i1];
-  const double t0 = in.temperature_hl[i0], t1 = in.temperature_hl[i1];
+  const LevelOrder ord = level_order(in);
+  const int clev = ord.full(lev);                       // this layer in the caller's arrays
+  const size_t i0 = col + ncol * clev;
+  const size_t ih0 = col + ncol * ord.half(lev), ih1 = col + ncol * ord.half(lev + 1);
+  const double p0 = in.pressure_hl[ih0], p1 = in.pressure_hl[ih1];
+  const double t0 = in.temperature_hl[ih0], t1 = in.temperature_hl[ih1];
   const double temperature_fl = (t0 * p0 + t1 * p1) / (p0 + p1);
   const double log_pressure_fl = log(0.5 * (p0 + p1));
   double pindex1 = (log_pressure_fl - m.log_pressure1) / m.d_log_pressure;
@@ -90,7 +93,7 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
     double mult = simple_multiplier;
     int k = sg.qpos;
     if (sg.i_conc_dependence != ECRAD_CONC_NONE) {
-      const double vmr = in.gas_mixing_ratio[col + ncol * (lev + (size_t)in.nlev * (sg.i_gas_code - 1))];
+      const double vmr = in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (sg.i_gas_code - 1))];
       if (sg.i_conc_dependence == ECRAD_CONC_LINEAR) mult = simple_multiplier * vmr;
       else if (sg.i_conc_dependence == ECRAD_CONC_RELATIVE_LINEAR) mult = simple_multiplier * (vmr - sg.reference_mole_frac);
       else {  // LUT: two quads, weighted (1-cw2, cw2)
@@ -147,7 +150,7 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
   int irh = 0;
   if (cfg.use_aerosols) {
     // rh = h2o_mmr / h2o_sat_liq with h2o_mmr from gas%get(IH2O, IMassMixingRatio) (radiation_gas.F90:605-612)
-    const double h2o_mmr = in.gas_mixing_ratio[col + ncol * (lev + (size_t)in.nlev * (ECRAD_IH2O - 1))]
+    const double h2o_mmr = in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (ECRAD_IH2O - 1))]
                            * (kH2OMolarMass / kAirMolarMass);
     const double rh = h2o_mmr / in.h2o_sat_liq[i0];
     const DevAerosolOptics& ao = cfg.aerosol;
@@ -159,7 +162,7 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
   L.I(I_RH, slot) = irh;
   double frac = 0.0;
   if (want_clouds) {
-    frac = in.cloud_fraction[i0];
+    { const FracView fv = cloud_fraction_view(in, col); frac = fv.p[fv.stride * clev]; }
     for (int t = 0; t < L.nct; ++t) {
       const DevCloudOptics& co = IS_SW ? cfg.cloud_sw[t] : cfg.cloud_lw[t];
       const size_t i3 = i0 + ncol * in.nlev * t;
@@ -372,7 +375,7 @@ template <bool IS_SW>
 ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, const LdsLayout& L, int slot,
                                      int col, int lev, int ib) {
   AerosolLayer a = {0.0, 0.0, 0.0};
-  const int jlev = lev + 1;   // 1-based
+  const int jlev = level_order(in).full(lev) + 1;   // 1-based, in the caller's level order
   if (jlev < in.aerosol_istartlev || jlev > in.aerosol_iendlev) return a;
   const DevAerosolOptics& ao = cfg.aerosol;
   const int nb = IS_SW ? ao.n_bands_sw : ao.n_bands_lw;
