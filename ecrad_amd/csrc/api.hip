@@ -305,7 +305,6 @@ int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
   const bool mcica = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_MCICA) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_MCICA);
   if (mcica) {
     if (!c.do_clear) return fail(h, ECRAD_EINVAL, "McICA requires clear-sky calculation to be performed");  // radiation_mcica_sw.F90:141
-    if (c.i_overlap_scheme == ECRAD_OVERLAP_EXP_EXP) return fail(h, ECRAD_EUNSUPPORTED, "Exp-Exp overlap is not implemented");
     if (c.use_vectorizable_generator) return fail(h, ECRAD_EUNSUPPORTED, "use_vectorizable_generator is not implemented");
     if (!c.pdf_sampler.val) return fail(h, ECRAD_EINVAL, "McICA needs the PDF sampler table");
   }

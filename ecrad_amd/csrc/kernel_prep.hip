@@ -333,6 +333,77 @@ ECRAD_DEV GenLds gen_lds(unsigned char* smem, int nlev, int ng) {
 
 size_t mcica_generator_lds_bytes(int nlev, int ng) { return (size_t)(9 * nlev + 1 + ng) * 8 + 608 * 4; }
 
+// cum_cloud_cover_exp_exp on the LDS arrays of one column (called by one lane).  In: frac, pair (the
+// layer-pair cover from alpha), rc = alpha per interface.  Out: cum, pair (made consistent with the
+// overhang).  Work: cc_obj/alpha_obj in g.ri, i_top/i_max in g.opi, i_base/i_next in g.X.
+ECRAD_DEV void cum_cloud_cover_exp_exp_lds(const GenLds& g, int nlev, double MaxCloudFrac) {
+  const double min_frac = 1.0e-6;
+  double* cc_obj = g.ri;
+  double* alpha_obj = g.ri + nlev;
+  int* i_top = reinterpret_cast<int*>(g.opi);
+  int* i_max = i_top + nlev;
+  int* i_base = g.X;
+  int* i_next = g.X + nlev;
+  int jlev = 0, nobj = 0;                 // 0-based levels and objects
+  while (jlev < nlev) {
+    if (g.frac[jlev] > min_frac) {
+      i_top[nobj] = jlev;
+      jlev++;
+      while (jlev < nlev) { if (g.frac[jlev] < g.frac[jlev - 1]) break; jlev++; }
+      i_max[nobj] = jlev - 1;
+      while (jlev < nlev) { if (g.frac[jlev] > g.frac[jlev - 1] || g.frac[jlev] <= min_frac) break; jlev++; }
+      i_base[nobj] = jlev - 1;
+      i_next[nobj] = nobj + 1;
+      nobj++;
+    } else {
+      jlev++;
+    }
+  }
+  for (int l = 0; l < nlev; ++l) g.cum[l] = 0.0;
+  if (nobj == 0) { for (int l = 0; l < nlev - 1; ++l) g.pair[l] = 0.0; return; }
+  for (int j = 0; j < nobj - 1; ++j) {
+    double prod = 1.0;
+    for (int l = i_max[j]; l <= i_max[j + 1] - 1; ++l) prod = prod * g.rc[l];
+    alpha_obj[j] = prod;
+  }
+  for (int j = 0; j < nobj; ++j) {
+    g.cum[i_top[j]] = g.frac[i_top[j]];
+    for (int l = i_top[j]; l <= i_base[j] - 1; ++l) {
+      if (g.frac[l] >= MaxCloudFrac) g.cum[l + 1] = 1.0;
+      else g.cum[l + 1] = 1.0 - (1.0 - g.cum[l]) * (1.0 - g.pair[l]) / (1.0 - g.frac[l]);
+    }
+    cc_obj[j] = g.cum[i_base[j]];
+  }
+  int iobj1 = 0;
+  int nleft = nobj;
+  while (nleft > 1) {
+    double alpha_max = 0.0;
+    iobj1 = 0;
+    // the reference walks "jobj < nobj" with nobj the number of objects LEFT and jobj following the
+    // linked list from the first object
+    int jobj = 0;
+    while (jobj + 1 < nleft) {
+      if (alpha_obj[jobj] > alpha_max) { alpha_max = alpha_obj[jobj]; iobj1 = jobj; }
+      jobj = i_next[jobj];
+    }
+    const int iobj2 = i_next[iobj1];
+    for (int l = i_base[iobj1] + 1; l <= i_top[iobj2] - 1; ++l) g.cum[l] = g.cum[i_base[iobj1]];
+    const double c1 = cc_obj[iobj1], c2 = cc_obj[iobj2];
+    const double cc_pair = alpha_obj[iobj1] * dmax(c1, c2) + (1.0 - alpha_obj[iobj1]) * (c1 + c2 - c1 * c2);
+    const double scaling = dmin(dmax((cc_pair - c1) / dmax(min_frac, c2), 0.0), 1.0);
+    const double cbase = g.cum[i_base[iobj1]];
+    for (int l = i_top[iobj2]; l <= i_base[iobj2]; ++l) g.cum[l] = cbase + g.cum[l] * scaling;
+    cc_obj[iobj1] = cc_pair;
+    i_base[iobj1] = i_base[iobj2];
+    i_next[iobj1] = i_next[iobj2];
+    alpha_obj[iobj1] = alpha_obj[iobj2];
+    nleft--;
+  }
+  for (int l = i_base[iobj1] + 1; l < nlev; ++l) g.cum[l] = g.cum[i_base[iobj1]];
+  for (int l = 0; l < nlev - 1; ++l) g.pair[l] = dmax(g.pair[l], g.frac[l] + g.cum[l + 1] - g.cum[l]);
+  for (int l = 0; l < nlev; ++l) g.cum[l] = dmin(g.cum[l], 1.0);
+}
+
 // x(1:607) <- next block of the lagged-Fibonacci sequence (radiation_random_numbers_mix.F90:270-282)
 ECRAD_DEV void gen_next_batch(const GenLds& g, int lane) {
   const int32_t IVAR = 0x3FFFFFFF;
@@ -371,6 +442,7 @@ __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __
   const size_t ncol = in.ncol;
   const GenLds g = gen_lds(smem, nlev, ng);
   const double MaxCloudFrac = 1.0 - 2.220446049250313e-16 * 10.0;
+  const bool exp_exp = cfg.i_overlap_scheme == ECRAD_OVERLAP_EXP_EXP;
 #ifdef ECRAD_TIMING
   PhaseTimer tm;
   tm.reset();
@@ -396,7 +468,7 @@ __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __
     for (int l = lane; l < nlev - 1; l += 64) {
       const double f0 = g.frac[l], f1 = g.frac[l + 1];
       double pair;
-      if (cfg.i_overlap_scheme == ECRAD_OVERLAP_EXP_RAN) {
+      if (cfg.i_overlap_scheme != ECRAD_OVERLAP_MAX_RAN) {
         double alpha = g.ovp[l];
         if (cfg.use_beta_overlap) {   // beta2alpha, radiation_cloud_cover.F90:51-68
           if (alpha < 1.0) {
@@ -405,6 +477,7 @@ __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __
           } else alpha = 1.0;
         }
         pair = alpha * dmax(f0, f1) + (1.0 - alpha) * (f0 + f1 - f0 * f1);
+        if (exp_exp) g.rc[l] = alpha;       // kept for the object correlations below
       } else {
         pair = dmax(f0, f1);
       }
@@ -432,7 +505,13 @@ __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __
     // cumulative cover: serial recurrence; above the first and below the last cloudy level the factor
     // (1-pair)/(1-frac) is exactly 1, so only the cloudy span is walked
     double tcc;
-    {
+    if (exp_exp) {
+      // cum_cloud_cover_exp_exp (radiation_cloud_cover.F90:339-623): serial object merging, one lane;
+      // work arrays borrow LDS that is not in use yet (object indices 0-based)
+      if (lane == 0) cum_cloud_cover_exp_exp_lds(g, nlev, MaxCloudFrac);
+      wave_sync();
+      tcc = g.cum[nlev - 1];
+    } else {
       double cum_product = 1.0;       // = 1 - frac(1) for a cloud-free top level
       for (int l = lane; l < ibegin - 1; l += 64) g.cum[l] = 0.0;
       if (ibegin == 1) { cum_product = 1.0 - g.frac[0]; if (lane == 0) g.cum[0] = g.frac[0]; }
@@ -556,7 +635,8 @@ __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __
       }
       // every cloudy run draws rand_inhom1(1:n) then rand_inhom2(1:n) (radiation_cloud_generator.F90:
       // 343-345), runs in top-down order: 2 x (number of cloudy levels) consecutive numbers in all
-      const int ncloudy = C.count_below(192);
+      // Exp-Exp (generate_column_exp_exp, :396-508) draws for ALL layers itrigger..iend as one run
+      const int ncloudy = exp_exp ? ei + 1 - ti : C.count_below(192);
       ECRAD_LAP0(tm, 5);    // tests + run structure
       gen_draw(g, lane, iused, 2 * ncloudy, g.ri);
       ECRAD_LAP0(tm, 6);    // draw rand_inhom
@@ -569,7 +649,12 @@ __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __
         const int i = lane + 64 * k;
         bool keep = false;
         run_start[k] = 0; run_base[k] = 0;
-        if (i >= ti && i <= ei && C.get(i)) {
+        if (exp_exp) {
+          if (i >= ti && i <= ei) {
+            run_start[k] = ti; run_base[k] = 0;
+            if (i > ti) keep = g.ri[ncloudy + (i - ti)] < g.opi[i - 1];
+          }
+        } else if (i >= ti && i <= ei && C.get(i)) {
           const int s0 = C.highest_zero_le(i) + 1;                  // first level of the run (>= ti since ti-1 is clear)
           const int s = s0 < ti ? ti : s0;
           const int e = C.lowest_zero_ge(i) - 1;                    // last level of the run

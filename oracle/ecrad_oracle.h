@@ -67,6 +67,8 @@ void oracle_calc_fluxes_no_scattering_lw(int ncol, int nlev, const double* trans
 /* single-column forms: frac(nlev), overlap_param(nlev-1) */
 void oracle_cum_cloud_cover_exp_ran(int nlev, const double* frac, const double* overlap_param,
      double* cum_cloud_cover, double* pair_cloud_cover, int is_beta_overlap);         /* :231 */
+void oracle_cum_cloud_cover_exp_exp(int nlev, const double* frac, const double* overlap_param,
+     double* cum_cloud_cover, double* pair_cloud_cover, int is_beta_overlap);         /* :339 */
 void oracle_cum_cloud_cover_max_ran(int nlev, const double* frac,
      double* cum_cloud_cover, double* pair_cloud_cover);                              /* :169 */
 void oracle_calc_region_properties(int nlev, int do_gamma, const double* cloud_fraction,

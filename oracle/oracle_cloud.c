@@ -167,6 +167,96 @@ void oracle_calc_overlap_matrices(int nlev, const double* region_fracs, const do
   }
 }
 
+/* radiation_cloud_cover.F90:339-623: Exp-Exp overlap with "concave cloud objects" merged in order of
+   decreasing correlation.  1-based object / level indices as in the reference. */
+void oracle_cum_cloud_cover_exp_exp(int nlev, const double* frac, const double* overlap_param,
+     double* cum_cloud_cover, double* pair_cloud_cover, int is_beta_overlap)
+{
+  const double min_frac = 1.0e-6;
+  int* i_top_obj = (int*)malloc(sizeof(int) * (size_t)(nlev + 2) * 4);
+  int* i_max_obj = i_top_obj + nlev + 2;
+  int* i_base_obj = i_max_obj + nlev + 2;
+  int* i_next_obj = i_base_obj + nlev + 2;
+  double* cc_obj = (double*)malloc(sizeof(double) * (size_t)(nlev + 2) * 3);
+  double* alpha_obj = cc_obj + nlev + 2;
+  double* overlap_alpha = alpha_obj + nlev + 2;
+#define FRAC(j) frac[(j) - 1]
+#define CUM(j) cum_cloud_cover[(j) - 1]
+#define PAIR(j) pair_cloud_cover[(j) - 1]
+  int jlev = 1, nobj = 0;
+  while (jlev <= nlev) {
+    if (FRAC(jlev) > min_frac) {
+      nobj++;
+      i_top_obj[nobj] = jlev;
+      jlev++;
+      while (jlev <= nlev) {
+        if (FRAC(jlev) < FRAC(jlev - 1)) break;
+        jlev++;
+      }
+      i_max_obj[nobj] = jlev - 1;
+      while (jlev <= nlev) {
+        if (FRAC(jlev) > FRAC(jlev - 1) || FRAC(jlev) <= min_frac) break;
+        jlev++;
+      }
+      i_base_obj[nobj] = jlev - 1;
+      i_next_obj[nobj] = nobj + 1;
+    } else {
+      jlev++;
+    }
+  }
+  for (int l = 0; l < nlev; ++l) cum_cloud_cover[l] = 0.0;
+  for (int l = 0; l < nlev - 1; ++l) pair_cloud_cover[l] = 0.0;
+  if (nobj > 0) {
+    for (int l = 1; l <= nlev - 1; ++l)
+      overlap_alpha[l] = is_beta_overlap ? beta2alpha(overlap_param[l - 1], FRAC(l), FRAC(l + 1)) : overlap_param[l - 1];
+    for (int l = 1; l <= nlev - 1; ++l)
+      PAIR(l) = overlap_alpha[l] * dmax(FRAC(l), FRAC(l + 1))
+              + (1.0 - overlap_alpha[l]) * (FRAC(l) + FRAC(l + 1) - FRAC(l) * FRAC(l + 1));
+    for (int jobj = 1; jobj <= nobj - 1; ++jobj) {
+      double prod = 1.0;      /* product(overlap(i_max_obj(jobj):i_max_obj(jobj+1)-1)) */
+      for (int l = i_max_obj[jobj]; l <= i_max_obj[jobj + 1] - 1; ++l) prod = prod * overlap_alpha[l];
+      alpha_obj[jobj] = prod;
+    }
+    for (int jobj = 1; jobj <= nobj; ++jobj) {
+      CUM(i_top_obj[jobj]) = FRAC(i_top_obj[jobj]);
+      for (int l = i_top_obj[jobj]; l <= i_base_obj[jobj] - 1; ++l) {
+        if (FRAC(l) >= MAX_CLOUD_FRAC) CUM(l + 1) = 1.0;
+        else CUM(l + 1) = 1.0 - (1.0 - CUM(l)) * (1.0 - PAIR(l)) / (1.0 - FRAC(l));
+      }
+      cc_obj[jobj] = CUM(i_base_obj[jobj]);
+    }
+    int iobj1 = 1;
+    while (nobj > 1) {
+      double alpha_max = 0.0;
+      iobj1 = 1;
+      int jobj = 1;
+      while (jobj < nobj) {
+        if (alpha_obj[jobj] > alpha_max) { alpha_max = alpha_obj[jobj]; iobj1 = jobj; }
+        jobj = i_next_obj[jobj];
+      }
+      const int iobj2 = i_next_obj[iobj1];
+      for (int l = i_base_obj[iobj1] + 1; l <= i_top_obj[iobj2] - 1; ++l) CUM(l) = CUM(i_base_obj[iobj1]);
+      const double cc_pair = alpha_obj[iobj1] * dmax(cc_obj[iobj1], cc_obj[iobj2])
+                           + (1.0 - alpha_obj[iobj1]) * (cc_obj[iobj1] + cc_obj[iobj2] - cc_obj[iobj1] * cc_obj[iobj2]);
+      const double scaling = dmin(dmax((cc_pair - cc_obj[iobj1]) / dmax(min_frac, cc_obj[iobj2]), 0.0), 1.0);
+      for (int l = i_top_obj[iobj2]; l <= i_base_obj[iobj2]; ++l) CUM(l) = CUM(i_base_obj[iobj1]) + CUM(l) * scaling;
+      cc_obj[iobj1] = cc_pair;
+      i_base_obj[iobj1] = i_base_obj[iobj2];
+      i_next_obj[iobj1] = i_next_obj[iobj2];
+      alpha_obj[iobj1] = alpha_obj[iobj2];
+      nobj--;
+    }
+    for (int l = i_base_obj[iobj1] + 1; l <= nlev; ++l) CUM(l) = CUM(i_base_obj[iobj1]);
+    for (int l = 1; l <= nlev - 1; ++l) PAIR(l) = dmax(PAIR(l), FRAC(l) + CUM(l + 1) - CUM(l));
+    for (int l = 1; l <= nlev; ++l) CUM(l) = dmin(CUM(l), 1.0);
+  }
+#undef FRAC
+#undef CUM
+#undef PAIR
+  free(i_top_obj);
+  free(cc_obj);
+}
+
 /* ---- utilities/radiation_random_numbers_mix.F90 -------------------------------------------- */
 #define JPP 273
 #define JPQ 607
@@ -298,7 +388,45 @@ static void generate_column_exp_ran(int ng, int nlev, int ig, oracle_rng_t* rs,
   }
 }
 
-/* radiation_cloud_generator.F90:37-255 (use_vectorizable_generator = false; Exp-Exp not restated) */
+/* radiation_cloud_generator.F90:396-508 */
+static void generate_column_exp_exp(int ng, int nlev, int ig, oracle_rng_t* rs,
+     const ecrad_pdf_sampler_t* pdf, const double* frac, const double* pair_cloud_cover,
+     const double* cum_cloud_cover, const double* overhang, const double* fractional_std,
+     const double* overlap_param_inhom, int itrigger, int iend, double* od_scaling,
+     double* rand_cloud, double* rand_inhom1, double* rand_inhom2)
+{
+  int* is_cloudy = (int*)calloc((size_t)nlev + 1, sizeof(int));
+  int iy = 0;
+  is_cloudy[itrigger] = 1;
+  oracle_uniform_distribution(rand_cloud, iend + 1 - itrigger, rs);
+  for (int jlev = itrigger + 1; jlev <= iend; ++jlev) {
+    iy++;
+    if (is_cloudy[jlev - 1]) {
+      if (rand_cloud[iy - 1] * frac[jlev - 2] < frac[jlev - 1] + frac[jlev - 2] - pair_cloud_cover[jlev - 2])
+        is_cloudy[jlev] = 1;
+    } else {
+      if (rand_cloud[iy - 1] * (cum_cloud_cover[jlev - 2] - frac[jlev - 2])
+          < pair_cloud_cover[jlev - 2] - overhang[jlev - 2] - frac[jlev - 2])
+        is_cloudy[jlev] = 1;
+    }
+  }
+  const int n_layers_to_scale = iend + 1 - itrigger;
+  oracle_uniform_distribution(rand_inhom1, n_layers_to_scale, rs);
+  oracle_uniform_distribution(rand_inhom2, n_layers_to_scale, rs);
+  for (int jcloud = 2; jcloud <= n_layers_to_scale; ++jcloud)
+    if (rand_inhom2[jcloud - 1] < overlap_param_inhom[iend - n_layers_to_scale + jcloud - 1 - 1])
+      rand_inhom1[jcloud - 1] = rand_inhom1[jcloud - 2];
+  /* pdf_sampler%masked_sample (radiation_pdf_sampler.F90:165-211): same interpolation as sample for the
+     masked elements, the others are left alone (zero) */
+  for (int k = 0; k < n_layers_to_scale; ++k) {
+    const int lev = itrigger + k;
+    if (is_cloudy[lev])
+      od_scaling[ig + (size_t)ng * (lev - 1)] = oracle_pdf_sample(pdf, fractional_std[lev - 1], rand_inhom1[k]);
+  }
+  free(is_cloudy);
+}
+
+/* radiation_cloud_generator.F90:37-255 (use_vectorizable_generator = false) */
 void oracle_cloud_generator(int ng, int nlev, int i_overlap_scheme, int32_t iseed,
      double frac_threshold, const double* frac, const double* overlap_param,
      double decorrelation_scaling, const double* fractional_std,
@@ -315,6 +443,8 @@ void oracle_cloud_generator(int ng, int nlev, int i_overlap_scheme, int32_t isee
   double* rand_top = (double*)malloc(sizeof(double) * ng);
   if (i_overlap_scheme == ECRAD_OVERLAP_EXP_RAN)
     oracle_cum_cloud_cover_exp_ran(nlev, frac, overlap_param, cum_cloud_cover, pair_cloud_cover, use_beta_overlap);
+  else if (i_overlap_scheme == ECRAD_OVERLAP_EXP_EXP)
+    oracle_cum_cloud_cover_exp_exp(nlev, frac, overlap_param, cum_cloud_cover, pair_cloud_cover, use_beta_overlap);
   else
     oracle_cum_cloud_cover_max_ran(nlev, frac, cum_cloud_cover, pair_cloud_cover);
   *total_cloud_cover = cum_cloud_cover[nlev - 1];
@@ -340,9 +470,14 @@ void oracle_cloud_generator(int ng, int nlev, int i_overlap_scheme, int32_t isee
       jlev = ibegin;
       while (trigger > cum_cloud_cover[jlev - 1] && jlev < iend) jlev++;
       int itrigger = jlev;
-      generate_column_exp_ran(ng, nlev, jg, &rs, pdf_sampler, frac, pair_cloud_cover,
-                              cum_cloud_cover, overhang, fractional_std, overlap_param_inhom,
-                              itrigger, iend, od_scaling, rand_cloud, rand_inhom1, rand_inhom2);
+      if (i_overlap_scheme != ECRAD_OVERLAP_EXP_EXP)
+        generate_column_exp_ran(ng, nlev, jg, &rs, pdf_sampler, frac, pair_cloud_cover,
+                                cum_cloud_cover, overhang, fractional_std, overlap_param_inhom,
+                                itrigger, iend, od_scaling, rand_cloud, rand_inhom1, rand_inhom2);
+      else
+        generate_column_exp_exp(ng, nlev, jg, &rs, pdf_sampler, frac, pair_cloud_cover,
+                                cum_cloud_cover, overhang, fractional_std, overlap_param_inhom,
+                                itrigger, iend, od_scaling, rand_cloud, rand_inhom1, rand_inhom2);
     }
   }
   free(cum_cloud_cover);

@@ -136,6 +136,15 @@ contains
     call cum_cloud_cover_exp_ran(1, 1, 1, nlev, frac, overlap_param, cum_cloud_cover, pair_cloud_cover, is_beta /= 0)
   end subroutine
 
+  subroutine ref_cum_cloud_cover_exp_exp(nlev, frac, overlap_param, cum_cloud_cover, pair_cloud_cover, is_beta) &
+       &  bind(C, name='ref_cum_cloud_cover_exp_exp')
+    use radiation_cloud_cover, only : cum_cloud_cover_exp_exp
+    integer(c_int), value :: nlev, is_beta
+    real(c_double), intent(in)  :: frac(1,nlev), overlap_param(1,nlev-1)
+    real(c_double), intent(out) :: cum_cloud_cover(1,nlev), pair_cloud_cover(1,nlev-1)
+    call cum_cloud_cover_exp_exp(1, 1, 1, nlev, frac, overlap_param, cum_cloud_cover, pair_cloud_cover, is_beta /= 0)
+  end subroutine
+
   subroutine ref_cum_cloud_cover_max_ran(nlev, frac, cum_cloud_cover, pair_cloud_cover) &
        &  bind(C, name='ref_cum_cloud_cover_max_ran')
     use radiation_cloud_cover, only : cum_cloud_cover_max_ran

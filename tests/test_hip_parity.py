@@ -25,6 +25,8 @@ CASES = {
     "mcica_aer": dict(sw_solver="McICA"),
     "mcica_noaer": dict(sw_solver="McICA", use_aerosols=False),
     "mcica_maxran": dict(sw_solver="McICA", i_overlap_scheme=0),
+    "mcica_expexp": dict(sw_solver="McICA", i_overlap_scheme=2),
+    "mcica_expexp_beta": dict(sw_solver="McICA", i_overlap_scheme=2, use_beta_overlap=True),
     "tripleclouds_aer": dict(sw_solver="Tripleclouds"),
     "tripleclouds_noaer": dict(sw_solver="Tripleclouds", use_aerosols=False),
     "tripleclouds_lognormal": dict(sw_solver="Tripleclouds", i_cloud_pdf_shape=0),

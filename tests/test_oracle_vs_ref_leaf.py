@@ -204,6 +204,14 @@ def test_cloud_cover(libs, beta):
     ora.oracle_cum_cloud_cover_exp_ran(C.c_int(nlev), p(frac), p(ovp), p(co), p(po), C.c_int(beta))
     close(co, cr)
     close(po, pr)
+    # Exp-Exp: object merging (several cloud profiles, incl. multi-object ones)
+    for seed in range(5):
+        f2, o2, _ = cloud_profile(np.random.default_rng(100 + seed), nlev)
+        o2 = np.abs(o2)
+        ref.ref_cum_cloud_cover_exp_exp(C.c_int(nlev), p(f2), p(o2), p(cr), p(pr), C.c_int(beta))
+        ora.oracle_cum_cloud_cover_exp_exp(C.c_int(nlev), p(f2), p(o2), p(co), p(po), C.c_int(beta))
+        close(co, cr)
+        close(po, pr)
     if not beta:
         ref.ref_cum_cloud_cover_max_ran(C.c_int(nlev), p(frac), p(cr), p(pr))
         ora.oracle_cum_cloud_cover_max_ran(C.c_int(nlev), p(frac), p(co), p(po))
