@@ -103,31 +103,13 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
     const TcGeom geo{prep, ncol_loc, nlev, cloc};
     const LevelOrder ord = level_order(in);
 
-    if (!sun_up) {   // radiation_tripleclouds_sw.F90:212-249
-      const DevFlux& fx = a.fx;
-      if (col_ok) {
-        for (int l = glane; l <= nlev; l += NGP) {     // the lanes of a column share its half levels
-          const size_t o = col + ncol * l;      // every half level is zeroed: order irrelevant
-          fx.sw_up[o] = 0.0; fx.sw_dn[o] = 0.0;
-          if (fx.sw_dn_direct) fx.sw_dn_direct[o] = 0.0;
-          if (do_clear) {
-            fx.sw_up_clear[o] = 0.0; fx.sw_dn_clear[o] = 0.0;
-            if (fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[o] = 0.0;
-          }
-        }
-      }
-      if (valid) {
-        const size_t og = g + (size_t)ng * col;
-        fx.sw_dn_diffuse_surf_g[og] = 0.0;
-        fx.sw_dn_direct_surf_g[og] = 0.0;
-        if (do_clear) { fx.sw_dn_diffuse_surf_clear_g[og] = 0.0; fx.sw_dn_direct_surf_clear_g[og] = 0.0; }
-      }
-      continue;
+    // NB sun_up differs between the columns of a block: every lane must still take part in the
+    // barriers of the chunk loop, so night-time columns only skip the per-layer work
+    double alb_dif = 0.0, alb_dir = 0.0, incoming = 0.0;
+    if (sun_up) {
+      albedo_sw_g(cfg, in, col, g, alb_dif, alb_dir);
+      incoming = incoming_sw_g(m, in, g);
     }
-
-    double alb_dif = 0.0, alb_dir = 0.0;
-    albedo_sw_g(cfg, in, col, g, alb_dif, alb_dir);
-    const double incoming = incoming_sw_g(m, in, g);
     // which layers are cloudy (the upward sweep needs the layer ABOVE before it gets there)
     const FracView fracv = cloud_fraction_view(in, col);
     const LevMask cloudy = column_level_mask<NGP>(fracv.p, fracv.stride, nlev, tid % 64, ord);
@@ -151,6 +133,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
       const GasHot gh = kernarg_block<SpectralArgs>().gas;
+      if (sun_up)
       for (int j = nl - 1; j >= 0; --j) {
         const int l = l0 + j;
         const int slot = cib * NGP + j;
@@ -211,6 +194,27 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
 
     // ---- sweep 2: top -> surface ---------------------------------------------------------------------
     const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
+    if (!sun_up) {   // radiation_tripleclouds_sw.F90:212-249
+      if (col_ok) {
+        for (int l = glane; l <= nlev; l += NGP) {     // the lanes of a column share its half levels
+          const size_t o = col + ncol * l;      // every half level is zeroed: order irrelevant
+          fx.sw_up[o] = 0.0; fx.sw_dn[o] = 0.0;
+          if (fx.sw_dn_direct) fx.sw_dn_direct[o] = 0.0;
+          if (do_clear) {
+            fx.sw_up_clear[o] = 0.0; fx.sw_dn_clear[o] = 0.0;
+            if (fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[o] = 0.0;
+          }
+        }
+      }
+      if (valid) {
+        const size_t og = g + (size_t)ng * col;
+        fx.sw_dn_diffuse_surf_g[og] = 0.0;
+        fx.sw_dn_direct_surf_g[og] = 0.0;
+        if (do_clear) { fx.sw_dn_diffuse_surf_clear_g[og] = 0.0; fx.sw_dn_direct_surf_clear_g[og] = 0.0; }
+      }
+      continue;
+    }
+
     double fdn[3] = {0.0, 0.0, 0.0}, ddn[3], fup[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) { ddn[r] = incoming * geo.frac(r, 0); fup[r] = ddn[r] * tad[r]; }

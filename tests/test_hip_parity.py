@@ -88,6 +88,45 @@ def test_column_subrange_does_not_touch_other_columns(oracle_lib):
     rad.close()
 
 
+def _replicate(inputs, times):
+    """The same columns `times` times over (column axis is the last one)."""
+    ncol, nlev, sl, th, gas, cloud, aer = inputs
+    rep = lambda a: None if a is None else np.ascontiguousarray(np.concatenate([a] * times, axis=-1))
+    for obj, names in ((sl, ("cos_sza", "skin_temperature", "sw_albedo", "lw_emissivity", "sw_albedo_direct", "iseed")),
+                       (th, ("pressure_hl", "temperature_hl", "h2o_sat_liq")), (gas, ("mixing_ratio",)),
+                       (cloud, ("fraction", "mixing_ratio", "effective_radius", "fractional_std", "overlap_param")),
+                       (aer, ("mixing_ratio",))):
+        if obj is None:
+            continue
+        for n in names:
+            if getattr(obj, n, None) is not None:
+                setattr(obj, n, rep(getattr(obj, n)))
+    return ncol * times, nlev, sl, th, gas, cloud, aer
+
+
+@pytest.mark.parametrize("solver", ["Homogeneous", "Tripleclouds", "McICA"])
+def test_many_column_groups_per_block_bitwise(solver):
+    """Size-independent property at a size the persistent blocks see several column groups each
+    (work queue, table quads kept in registers across columns, scratch reuse): 700 copies of the 32
+    meridian columns must give 700 bit-identical copies of the 32-column result."""
+    config = make_config(solver)
+    f32, _, rad = run_case(config, "hip")
+    rad.close()
+    times = 700
+    config2 = make_config(solver)
+    f_big, _, rad2 = run_case(config2, "hip", inputs=_replicate(load_meridian(config2), times))
+    rad2.close()
+    for name, a in f_big.arrays.items():
+        b = f32.arrays[name]
+        if a.ndim == 1:
+            want = np.concatenate([b] * times)
+        elif a.shape[-1] == 32 * times:
+            want = np.concatenate([b] * times, axis=-1)
+        else:
+            want = np.concatenate([b] * times, axis=0)
+        assert np.array_equal(a, want), name
+
+
 def _reverse_levels(inputs):
     """The same columns ordered from the surface upwards (what radiation_reverse undoes)."""
     ncol, nlev, sl, th, gas, cloud, aer = inputs
