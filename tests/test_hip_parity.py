@@ -127,6 +127,32 @@ def test_many_column_groups_per_block_bitwise(solver):
         assert np.array_equal(a, want), name
 
 
+@pytest.mark.parametrize("solver", ["Tripleclouds", "McICA"])
+def test_device_memory_mode_matches_host_memory_mode(solver):
+    """ECRAD_MEM_DEVICE (what bench.py times: caller-owned HBM arrays, kernels only enqueued) gives the
+    same bits as ECRAD_MEM_HOST (staged copies), incl. a column sub-range and the cloud-fraction crop."""
+    import ctypes as C
+    import torch
+    from ecrad_amd.device import DeviceCase
+    from ecrad_amd.interface import Radiation
+    from ecrad_amd.types import Flux
+    config = make_config(solver)
+    f_host, _, rad = run_case(config, "hip", columns=(3, 30))
+    ncol, nlev, sl, th, gas, cloud, aer = load_meridian(config)
+    rad.set_gas_units(gas)
+    th.calc_saturation_wrt_liquid()
+    flux = Flux.allocate(config, ncol, nlev)
+    case = DeviceCase(config, ncol, nlev, sl, th, gas, cloud, aer, flux)
+    st = rad.lib.ecrad_hip_radiation(rad.handle, ncol, nlev, 3, 30, C.byref(case.inputs), C.byref(case.flux))
+    assert st == 0, rad.lib.ecrad_hip_last_error(rad.handle).decode()
+    rad.lib.ecrad_hip_synchronize(rad.handle)
+    torch.cuda.synchronize()
+    case.flux_to_host(flux)
+    for name, a in flux.arrays.items():
+        assert np.array_equal(a, f_host.arrays[name]), name
+    rad.close()
+
+
 def _reverse_levels(inputs):
     """The same columns ordered from the surface upwards (what radiation_reverse undoes)."""
     ncol, nlev, sl, th, gas, cloud, aer = inputs
