@@ -58,18 +58,32 @@ def algorithmic_bytes_per_column(config, nlev, which, clear_sky):
     return stage + W * (inputs + outputs)
 
 
-def cpu_baseline(config, workload, nlev_expected, seconds_target=12.0):
-    """Time the oracle on a bounded sample (2048 columns, repeated) of the same workload."""
+def first_columns(inputs, n):
+    """The first n columns of a make_columns() result (column axis is the last one)."""
+    import copy
+    ncol, nlev, sl, th, gas, cloud, aer = inputs
+    n = min(n, ncol)
+    out = [copy.copy(o) for o in (sl, th, gas, cloud, aer)]
+    for obj in out:
+        if obj is None:
+            continue
+        for k, v in list(vars(obj).items()):
+            if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == ncol:
+                setattr(obj, k, np.ascontiguousarray(v[..., :n]))
+    return (n, nlev, *out)
+
+
+def cpu_baseline(config, workload, sample, seconds_target=12.0):
+    """Time the oracle on a bounded sample (the first 2048 columns of the timed batch, repeated)."""
     from ecrad_amd.interface import Radiation
     from ecrad_amd.synthetic import BENCH_CONFIGS, make_columns
     from ecrad_amd.types import Flux
     from oracle import pyoracle
     pyoracle.build()
     nthreads = pyoracle.lib().ecrad_oracle_max_threads()
-    nsample = 2048
-    spec = BENCH_CONFIGS[workload]
     rad = Radiation(config, backend=pyoracle.make_blocked_backend(nblocksize=32, nthreads=nthreads))
-    ncol, nlev, sl, th, gas, cloud, aer = make_columns(config, nsample, spec["clear_sky"])
+    ncol, nlev, sl, th, gas, cloud, aer = sample
+    nsample = ncol
     flux = Flux.allocate(config, ncol, nlev)
     rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)       # warm-up
     t0 = time.perf_counter()
@@ -80,9 +94,10 @@ def cpu_baseline(config, workload, nlev_expected, seconds_target=12.0):
         dt = time.perf_counter() - t0
         if dt >= seconds_target or reps >= 200:
             break
-    return {"value": nsample * reps / dt, "unit": "columns/s", "cores": int(nthreads), "kind": "port",
-            "sample": f"{nsample} columns x {reps} repeats of the same synthetic workload, oracle/ (plain C, "
-                      f"OpenMP over blocks of 32 columns as in driver/ecrad_driver.F90:348), {dt:.1f} s"}
+    out = {"value": nsample * reps / dt, "unit": "columns/s", "cores": int(nthreads), "kind": "port",
+           "sample": f"{nsample} columns x {reps} repeats of the same synthetic workload, oracle/ (plain C, "
+                     f"OpenMP over blocks of 32 columns as in driver/ecrad_driver.F90:348), {dt:.1f} s"}
+    return out, flux
 
 
 def main():
@@ -134,6 +149,7 @@ def main():
 
     # weak scaling: every rank owns args.ncol columns of the global batch world*args.ncol
     ncol, nlev, sl, th, gas, cloud, aer = make_columns(config, args.ncol, clear_sky, first_column=rank * args.ncol)
+    cpu_sample = first_columns((ncol, nlev, sl, th, gas, cloud, aer), 2048) if world == 1 and not args.no_cpu_baseline else None
     flux = Flux.allocate(config, ncol, nlev)
     case = DeviceCase(config, ncol, nlev, sl, th, gas, cloud, aer, flux, device=f"cuda:{local_rank}")
     profile_names = [n for n in ("lw_up", "lw_dn", "sw_up", "sw_dn", "sw_dn_direct", "lw_up_clear", "lw_dn_clear",
@@ -230,7 +246,19 @@ def main():
                          "stage_ms": {k: float(np.mean(v)) for k, v in stage_ms.items() if v}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(config, args.workload, nlev)
+            out["cpu_baseline"], oracle_flux = cpu_baseline(config, args.workload, cpu_sample)
+            # the oracle's sample is the first columns of this rank's batch: check the timed configuration
+            # against it (outside the timed region; the oracle is the checker, never the thing measured)
+            worst, nchk = 0.0, oracle_flux.ncol
+            for name, t in case.flux_tensors.items():
+                ref = oracle_flux.arrays.get(name)
+                if ref is None:
+                    continue
+                got = t.cpu().numpy()
+                got = got[..., :nchk] if got.shape[-1] == ncol else got[:nchk]
+                scale = np.maximum(np.abs(ref), 1e-3 * np.abs(ref).max() + 1e-300)
+                worst = max(worst, float(np.max(np.abs(got - ref) / scale)))
+            out["parity"] = {"max_rel_diff_vs_oracle": worst, "columns_checked": int(nchk), "tolerance": 1e-6}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
