@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 NMAXGASES = 12
 NMAXCLOUDTYPES = 12
 
@@ -89,7 +89,7 @@ _CONFIG_INTS = [
     "n_g_lw_if_scattering", "n_bands_lw_if_scattering",
     "n_canopy_bands_sw", "n_canopy_bands_lw",
     "n_albedo_intervals_sw", "n_emiss_intervals_lw",
-    "n_cloud_types", "reserved_",
+    "n_cloud_types", "reserved_", "n_spec_sw", "n_spec_lw",
 ]
 
 
@@ -101,6 +101,7 @@ class Config(C.Structure):
            ("i_band_from_reordered_g_sw", c_int32_p), ("i_band_from_reordered_g_lw", c_int32_p),
            ("sw_albedo_weights", c_double_p), ("lw_emiss_weights", c_double_p),
            ("i_albedo_from_band_sw", c_int32_p), ("i_emiss_from_band_lw", c_int32_p),
+           ("i_spec_from_reordered_g_sw", c_int32_p), ("i_spec_from_reordered_g_lw", c_int32_p),
            ("gas_optics_sw", CkdModel), ("gas_optics_lw", CkdModel),
            ("cloud_optics_sw", CloudOptics * NMAXCLOUDTYPES),
            ("cloud_optics_lw", CloudOptics * NMAXCLOUDTYPES),
@@ -138,7 +139,13 @@ FLUX_BAND_FIELDS = ["sw_dn_surf_band", "sw_dn_direct_surf_band", "sw_dn_surf_cle
                     "sw_dn_toa_band", "sw_up_toa_band", "sw_up_toa_clear_band"]
 FLUX_CANOPY_FIELDS = ["lw_dn_surf_canopy", "sw_dn_diffuse_surf_canopy", "sw_dn_direct_surf_canopy"]
 FLUX_COL_FIELDS = ["cloud_cover_lw", "cloud_cover_sw"]
-FLUX_FIELDS = FLUX_PROFILE_FIELDS + FLUX_G_FIELDS + FLUX_BAND_FIELDS + FLUX_CANOPY_FIELDS + FLUX_COL_FIELDS
+# (nspec, ncol, nlev+1) spectral flux profiles (do_save_spectral_flux)
+FLUX_SPEC_LW_FIELDS = ["lw_up_band", "lw_dn_band", "lw_up_clear_band", "lw_dn_clear_band"]
+FLUX_SPEC_SW_FIELDS = ["sw_up_band", "sw_dn_band", "sw_dn_direct_band",
+                       "sw_up_clear_band", "sw_dn_clear_band", "sw_dn_direct_clear_band"]
+FLUX_SPEC_FIELDS = FLUX_SPEC_LW_FIELDS + FLUX_SPEC_SW_FIELDS
+FLUX_FIELDS = (FLUX_PROFILE_FIELDS + FLUX_G_FIELDS + FLUX_BAND_FIELDS + FLUX_CANOPY_FIELDS + FLUX_COL_FIELDS
+               + FLUX_SPEC_FIELDS)
 
 
 class Flux(C.Structure):

@@ -80,6 +80,10 @@ class Config:
     i_aerosol_type_map: List[int] = field(default_factory=list)
     do_save_spectral_flux: bool = False
     do_save_gpoint_flux: bool = False
+    n_spec_sw: int = 0
+    n_spec_lw: int = 0
+    i_spec_from_reordered_g_sw: object = None
+    i_spec_from_reordered_g_lw: object = None
     do_surface_sw_spectral_flux: bool = True
     do_toa_spectral_flux: bool = False
     do_lw_derivatives: bool = False

@@ -264,7 +264,7 @@ StagedInputs carve_inputs(void* base, const ecrad_config_t& c, const ecrad_input
   return s;
 }
 
-struct FluxField { double* ecrad_flux_t::*host; double* DevFlux::*dev; int kind; };   // kind 0 profile,1 g_lw,2 g_sw,3 band_lw,4 band_sw,5 canopy_lw,6 canopy_sw,7 column
+struct FluxField { double* ecrad_flux_t::*host; double* DevFlux::*dev; int kind; };   // kind 0 profile,1 g_lw,2 g_sw,3 band_lw,4 band_sw,5 canopy_lw,6 canopy_sw,7 column,8 spectral profile lw,9 sw
 #define FF(n, k) { &ecrad_flux_t::n, &DevFlux::n, k }
 const FluxField kFluxFields[] = {
   FF(lw_up, 0), FF(lw_dn, 0), FF(sw_up, 0), FF(sw_dn, 0), FF(sw_dn_direct, 0), FF(lw_up_clear, 0), FF(lw_dn_clear, 0),
@@ -276,6 +276,9 @@ const FluxField kFluxFields[] = {
   FF(lw_up_toa_band, 3), FF(lw_up_toa_clear_band, 3), FF(sw_dn_toa_band, 4), FF(sw_up_toa_band, 4), FF(sw_up_toa_clear_band, 4),
   FF(lw_dn_surf_canopy, 5), FF(sw_dn_diffuse_surf_canopy, 6), FF(sw_dn_direct_surf_canopy, 6),
   FF(cloud_cover_lw, 7), FF(cloud_cover_sw, 7),
+  FF(lw_up_band, 8), FF(lw_dn_band, 8), FF(lw_up_clear_band, 8), FF(lw_dn_clear_band, 8),
+  FF(sw_up_band, 9), FF(sw_dn_band, 9), FF(sw_dn_direct_band, 9), FF(sw_up_clear_band, 9), FF(sw_dn_clear_band, 9),
+  FF(sw_dn_direct_clear_band, 9),
 };
 #undef FF
 
@@ -288,6 +291,8 @@ size_t flux_rows(const ecrad_config_t& c, int kind, int nlev) {
     case 4: return c.n_bands_sw;
     case 5: return c.n_canopy_bands_lw;
     case 6: return c.n_canopy_bands_sw;
+    case 8: return ((size_t)nlev + 1) * c.n_spec_lw;
+    case 9: return ((size_t)nlev + 1) * c.n_spec_sw;
     default: return 1;
   }
 }
@@ -300,7 +305,18 @@ int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
     if (s == ECRAD_SOLVER_SPARTACUS) return fail(h, ECRAD_EUNSUPPORTED, "the SPARTACUS solver is not implemented");
     if (s > ECRAD_SOLVER_TRIPLECLOUDS) return fail(h, ECRAD_EINVAL, "unknown solver");
   }
-  if (c.do_save_spectral_flux) return fail(h, ECRAD_EUNSUPPORTED, "do_save_spectral_flux is not implemented");
+  if (c.do_save_spectral_flux) {
+    // spectral flux profiles: only one interval per g-point (bands == g-points, the ecCKD default, or
+    // do_save_gpoint_flux); summing g-points into wider bands per level is not built
+    auto identity = [](const int32_t* m, int n, int nspec) {
+      if (!m || nspec != n) return false;
+      for (int i = 0; i < n; ++i) if (m[i] != i + 1) return false;
+      return true;
+    };
+    if ((c.do_sw && !identity(c.i_spec_from_reordered_g_sw, c.n_g_sw, c.n_spec_sw)) ||
+        (c.do_lw && !identity(c.i_spec_from_reordered_g_lw, c.n_g_lw, c.n_spec_lw)))
+      return fail(h, ECRAD_EUNSUPPORTED, "do_save_spectral_flux is implemented for one spectral interval per g-point only");
+  }
   if (c.do_lw && c.do_lw_aerosol_scattering) return fail(h, ECRAD_EUNSUPPORTED, "do_lw_aerosol_scattering is not implemented");
   const bool mcica = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_MCICA) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_MCICA);
   if (mcica) {
@@ -720,6 +736,19 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
       if (sp.first->kind == 7)
         HIP_TRY(h, hipMemcpyAsync(sp.second, flux->*(sp.first->host) + (r.i0 - 1), r.nloc * 8, hipMemcpyHostToDevice, stream));
   }
+  // The McICA solvers never store spectral flux profiles (radiation_config.F90:1331-1334); without
+  // do_save_spectral_flux nobody does
+  {
+    const bool lw_spec = c.do_save_spectral_flux && c.do_lw && c.i_solver_lw != ECRAD_SOLVER_MCICA;
+    const bool sw_spec = c.do_save_spectral_flux && c.do_sw && c.i_solver_sw != ECRAD_SOLVER_MCICA;
+    if (!lw_spec) dfx.lw_up_band = dfx.lw_dn_band = dfx.lw_up_clear_band = dfx.lw_dn_clear_band = nullptr;
+    if (!sw_spec) dfx.sw_up_band = dfx.sw_dn_band = dfx.sw_dn_direct_band = dfx.sw_up_clear_band = dfx.sw_dn_clear_band =
+                  dfx.sw_dn_direct_clear_band = nullptr;
+    if (lw_spec && (!dfx.lw_up_band || !dfx.lw_dn_band || (c.do_clear && (!dfx.lw_up_clear_band || !dfx.lw_dn_clear_band))))
+      return fail(h, ECRAD_EINVAL, "flux%lw_*_band must be allocated with do_save_spectral_flux");
+    if (sw_spec && (!dfx.sw_up_band || !dfx.sw_dn_band || (c.do_clear && (!dfx.sw_up_clear_band || !dfx.sw_dn_clear_band))))
+      return fail(h, ECRAD_EINVAL, "flux%sw_*_band must be allocated with do_save_spectral_flux");
+  }
   // the solvers write these unconditionally
   if (c.do_lw && (!dfx.lw_up || !dfx.lw_dn || !dfx.lw_dn_surf_g || !dfx.lw_up_toa_g)) return fail(h, ECRAD_EINVAL, "flux%lw_up/lw_dn/lw_dn_surf_g/lw_up_toa_g must be allocated");
   if (c.do_sw && (!dfx.sw_up || !dfx.sw_dn || !dfx.sw_dn_diffuse_surf_g || !dfx.sw_dn_direct_surf_g || !dfx.sw_up_toa_g))
@@ -820,6 +849,11 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
       if (f.kind == 0) {
         HIP_TRY(h, hipMemcpy2DAsync(hostp + (r.i0 - 1), (size_t)r.ncol * 8, sp.second, (size_t)r.nloc * 8,
                                     (size_t)r.nloc * 8, rows, hipMemcpyDeviceToHost, stream));
+      } else if (f.kind >= 8) {     // (nspec, ncol, nlev+1)
+        const size_t nspec = f.kind == 8 ? c.n_spec_lw : c.n_spec_sw;
+        if ((dfx.*(f.dev)) == nullptr) continue;    // not written by this solver: leave the caller's array alone
+        HIP_TRY(h, hipMemcpy2DAsync(hostp + nspec * (r.i0 - 1), (size_t)r.ncol * nspec * 8, sp.second, (size_t)r.nloc * nspec * 8,
+                                    (size_t)r.nloc * nspec * 8, (size_t)nlev + 1, hipMemcpyDeviceToHost, stream));
       } else {
         HIP_TRY(h, hipMemcpyAsync(hostp + rows * (r.i0 - 1), sp.second, rows * r.nloc * 8, hipMemcpyDeviceToHost, stream));
       }

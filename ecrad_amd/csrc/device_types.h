@@ -141,6 +141,10 @@ struct DevFlux {
   double *lw_up_toa_band, *lw_up_toa_clear_band, *sw_dn_toa_band, *sw_up_toa_band, *sw_up_toa_clear_band;
   double *lw_dn_surf_canopy, *sw_dn_diffuse_surf_canopy, *sw_dn_direct_surf_canopy;
   double *cloud_cover_lw, *cloud_cover_sw;
+  // (nspec, ncol, nlev+1) spectral flux profiles (do_save_spectral_flux); only the one-interval-per-
+  // g-point form is built (nspec == ng), so lane g owns interval g
+  double *lw_up_band, *lw_dn_band, *lw_up_clear_band, *lw_dn_clear_band;
+  double *sw_up_band, *sw_dn_band, *sw_dn_direct_band, *sw_up_clear_band, *sw_dn_clear_band, *sw_dn_direct_clear_band;
 };
 
 // Optional stage-interface dump (ecrad_hip_optics); layouts (ng, nlev[+1], ncol_local)

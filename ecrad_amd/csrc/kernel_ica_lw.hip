@@ -107,6 +107,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
       a.fx.lw_dn[o] = 0.0;
       if (have_clear_out) a.fx.lw_dn_clear[o] = 0.0;
     }
+    if (valid && a.fx.lw_dn_band) {     // spectral flux profiles (do_save_spectral_flux), lane g owns interval g
+      const size_t o = col + ncol * ord.half(0);
+      spec_put(a.fx.lw_dn_band, ng, g, o, 0.0);
+      if (have_clear_out) spec_put(a.fx.lw_dn_clear_band, ng, g, o, 0.0);
+    }
     for (int l0 = 0; l0 < nlev; l0 += NGP) {
       __syncthreads();
       {
@@ -122,6 +127,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
       double keep_dn = 0.0;
       double* const lw_dn = c0.fx.lw_dn;
       double* const lw_dn_clear = have_clear_out ? c0.fx.lw_dn_clear : nullptr;
+      double* const lw_dn_band = c0.fx.lw_dn_band;
+      double* const lw_dn_clear_band = have_clear_out ? c0.fx.lw_dn_clear_band : nullptr;
       ECRAD_LAP0(tm, 7);     // level scalars + group set-up (timing build: booked with the up-sweep)
 #if ECRAD_PIPELINE_LOADS
       gas_load<TAB>(gh, nquad, nplain, L, cib * NGP, g, quads);     // see kernel_ica_sw.hip
@@ -190,6 +197,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
         }
         // clear-sky downward recurrence (radiation_adding_ica_lw.F90:305-311) + sum over g
         fdn_c = c.transmittance * fdn_c + c.source_dn;
+        if (lw_dn_band && valid) {     // provisional below cloud top, like lw_dn
+          const size_t o = col + ncol * ord.half(lev + 1);
+          spec_put(lw_dn_band, ng, g, o, fdn_c);
+          spec_put(lw_dn_clear_band, ng, g, o, fdn_c);
+        }
         const double sd = group_sum<NGP>(valid ? fdn_c : 0.0);
         ECRAD_LAP(tm, 5, sd);           // cross-lane sum
         // lane j of the column group keeps the sum of the chunk's layer j; one store per chunk
@@ -219,6 +231,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
       if (have_clear_out) fx.lw_up_clear[o] = dsum;
       if (do_deriv) fx.lw_derivatives[o] = 1.0;
     }
+    if (valid && fx.lw_up_band) {
+      const size_t o = col + ncol * ord.half(nlev);
+      spec_put(fx.lw_up_band, ng, g, o, fup);
+      if (have_clear_out) spec_put(fx.lw_up_clear_band, ng, g, o, fup);
+    }
 #if !(ECRAD_ABLATE & 4)
     {
       // records of the next kLwBatch layers are requested before the current batch is consumed
@@ -237,6 +254,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
           if (l >= 0) {
             const double T = cur[k].x;
             fup = T * fup + cur[k].y;
+            if (fx.lw_up_band && valid) {
+              const size_t o = col + ncol * ord.half(l);
+              spec_put(fx.lw_up_band, ng, g, o, fup);
+              if (have_clear_out) spec_put(fx.lw_up_clear_band, ng, g, o, fup);
+            }
             const double su = group_sum<NGP>(valid ? fup : 0.0);
             double sder = 0.0;
             if (do_deriv) { deriv = deriv * T; sder = group_sum<NGP>(valid ? deriv : 0.0); }
@@ -300,6 +322,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
       double keep_up = 0.0;      // lane (l mod NGP) keeps half level l; written NGP half levels at a time
       for (int l = ict; l >= 0; --l) {
         if (l < ict) { const double2 ts = s.pair(P_CLR, l, tid); fup = ts.x * fup + ts.y; }
+        if (fx.lw_up_band && valid) spec_put(fx.lw_up_band, ng, g, col + ncol * ord.half(l), fup);
         const double su = group_sum<NGP>(valid ? fup : 0.0);
         if ((l & (NGP - 1)) == glane) keep_up = su;
         if ((l & (NGP - 1)) == 0) {
@@ -331,6 +354,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
       fup = albn * fdn + srcn;
       const double sums[2] = {group_sum<NGP>(valid ? fup : 0.0), group_sum<NGP>(valid ? fdn : 0.0)};
       const int hl = l + 1;
+      if (fx.lw_up_band && valid) {
+        const size_t o = col + ncol * ord.half(hl);
+        spec_put(fx.lw_up_band, ng, g, o, fup);
+        spec_put(fx.lw_dn_band, ng, g, o, fdn);
+      }
       kept.keep(hl, glane, sums);
       if ((hl & (NGP - 1)) == NGP - 1 || hl == nlev) {
         const int lv = kept.mine(hl, glane);

@@ -79,6 +79,13 @@ ECRAD_DEV void sw_load_batch(const SwScratch& s, bool set2, int lcb, int tid, in
   }
 }
 
+// Destinations of the per-g-point flux profiles of one sweep (all may be null); a second set receives
+// the same values when two outputs coincide (total sky = clear sky)
+struct SwSpec {
+  double *up, *dn, *dir, *up2, *dn2, *dir2;
+  int ng, g;
+};
+
 // Flux sweep (top -> bottom) for one coefficient set; for SET2 layers below the lowest cloudy layer
 // `lcb` reuse set 1's records (identical there).  Sums over g are written by the group leader.
 // The records of the next kSwBatch layers are requested before the current batch is consumed, so that
@@ -88,7 +95,7 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
                              double sig_top, bool valid, bool col_ok, size_t ncol, int col,
                              double* out_up, double* out_dn, double* out_dir, double weight,
                              const double* clr_up, const double* clr_dn, const double* clr_dir,
-                             double* dup_up, double* dup_dn, double* dup_dir, const LevelOrder& ord,
+                             double* dup_up, double* dup_dn, double* dup_dir, const LevelOrder& ord, const SwSpec& sp,
                              double& fdn_surf, double& fdir_surf, double& fup_toa) {
   double Fd = incoming, fdn = 0.0, fup = incoming * sig_top;
   fup_toa = fup;
@@ -99,6 +106,16 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
   // between the scratch reads of consecutive layers.
   double keep_u = 0.0, keep_d = 0.0, keep_dir = 0.0;
   auto emit = [&](int l) {
+    if (sp.up && valid) {        // spectral flux profiles (radiation_homogeneous_sw.F90:299-311)
+      const size_t o = col + ncol * ord.half(l);
+      const double dir = mu0 * Fd;
+      spec_put(sp.up, sp.ng, sp.g, o, fup);
+      spec_put(sp.dn, sp.ng, sp.g, o, dir + fdn);
+      spec_put(sp.dir, sp.ng, sp.g, o, dir);
+      spec_put(sp.up2, sp.ng, sp.g, o, fup);
+      spec_put(sp.dn2, sp.ng, sp.g, o, dir + fdn);
+      spec_put(sp.dir2, sp.ng, sp.g, o, dir);
+    }
     const double su = group_sum<NGP>(valid ? fup : 0.0);
     const double sd = group_sum<NGP>(valid ? fdn : 0.0);
     const double sdir = group_sum<NGP>(valid ? Fd : 0.0) * mu0;
@@ -312,6 +329,9 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
         sw_flux_sweep<NGP>(s, false, -1, tid, nlev, mu0, incoming, st1.sig, valid, col_ok, ncol, col,
                            fx.sw_up, fx.sw_dn, fx.sw_dn_direct, 1.0, nullptr, nullptr, nullptr,
                            have_clear_out ? fx.sw_up_clear : nullptr, fx.sw_dn_clear, fx.sw_dn_direct_clear, ord,
+                           SwSpec{fx.sw_up_band, fx.sw_dn_band, fx.sw_dn_direct_band,
+                                  have_clear_out ? fx.sw_up_clear_band : nullptr, have_clear_out ? fx.sw_dn_clear_band : nullptr,
+                                  have_clear_out ? fx.sw_dn_direct_clear_band : nullptr, ng, g},
                            fdn_s, fdir_s, fup_t);
         if (valid) {
           const size_t og = g + (size_t)ng * col;
@@ -332,6 +352,9 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
           sw_flux_sweep<NGP>(s, false, -1, tid, nlev, mu0, incoming, st1.sig, valid, col_ok, ncol, col,
                              fx.sw_up_clear, fx.sw_dn_clear, fx.sw_dn_direct_clear, 1.0, nullptr, nullptr, nullptr,
                              do_set2 ? nullptr : fx.sw_up, fx.sw_dn, fx.sw_dn_direct, ord,
+                             SwSpec{fx.sw_up_clear_band, fx.sw_dn_clear_band, fx.sw_dn_direct_clear_band,
+                                    do_set2 ? nullptr : fx.sw_up_band, do_set2 ? nullptr : fx.sw_dn_band,
+                                    do_set2 ? nullptr : fx.sw_dn_direct_band, ng, g},
                              fdn_c, fdir_c, fup_c);
           if (valid) {
             const size_t og = g + (size_t)ng * col;
@@ -344,7 +367,9 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
           const double w = (MODE == 2) ? tcc : 1.0;
           sw_flux_sweep<NGP>(s, lcb >= 0, lcb, tid, nlev, mu0, incoming, lcb >= 0 ? st2.sig : st1.sig, valid, col_ok, ncol, col,
                              fx.sw_up, fx.sw_dn, fx.sw_dn_direct, w, fx.sw_up_clear, fx.sw_dn_clear,
-                             fx.sw_dn_direct_clear, nullptr, nullptr, nullptr, ord, fdn_s, fdir_s, fup_t);
+                             fx.sw_dn_direct_clear, nullptr, nullptr, nullptr, ord,
+                             SwSpec{fx.sw_up_band, fx.sw_dn_band, fx.sw_dn_direct_band, nullptr, nullptr, nullptr, ng, g},
+                             fdn_s, fdir_s, fup_t);
           if (valid) {
             const size_t og = g + (size_t)ng * col;
             if (MODE == 2) {
@@ -380,6 +405,16 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
             fx.sw_up_clear[o] = 0.0;
             fx.sw_dn_clear[o] = 0.0;
             if (fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[o] = 0.0;
+          }
+        }
+      }
+      if (valid && fx.sw_up_band) {      // radiation_homogeneous_sw.F90:355-368
+        for (int l = 0; l <= nlev; ++l) {
+          const size_t o = col + ncol * l;
+          spec_put(fx.sw_up_band, ng, g, o, 0.0); spec_put(fx.sw_dn_band, ng, g, o, 0.0); spec_put(fx.sw_dn_direct_band, ng, g, o, 0.0);
+          if (have_clear_out) {
+            spec_put(fx.sw_up_clear_band, ng, g, o, 0.0); spec_put(fx.sw_dn_clear_band, ng, g, o, 0.0);
+            spec_put(fx.sw_dn_direct_clear_band, ng, g, o, 0.0);
           }
         }
       }

@@ -206,6 +206,16 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
           }
         }
       }
+      if (valid && fx.sw_up_band) {     // radiation_tripleclouds_sw.F90:226-238
+        for (int l = 0; l <= nlev; ++l) {
+          const size_t o = col + ncol * l;
+          spec_put(fx.sw_up_band, ng, g, o, 0.0); spec_put(fx.sw_dn_band, ng, g, o, 0.0); spec_put(fx.sw_dn_direct_band, ng, g, o, 0.0);
+          if (do_clear) {
+            spec_put(fx.sw_up_clear_band, ng, g, o, 0.0); spec_put(fx.sw_dn_clear_band, ng, g, o, 0.0);
+            spec_put(fx.sw_dn_direct_clear_band, ng, g, o, 0.0);
+          }
+        }
+      }
       if (valid) {
         const size_t og = g + (size_t)ng * col;
         fx.sw_dn_diffuse_surf_g[og] = 0.0;
@@ -272,6 +282,18 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
           }
 #pragma unroll
           for (int r = 0; r < 3; ++r) { fdn[r] = nf[r]; ddn[r] = nd[r]; }
+        }
+      }
+      if (fx.sw_up_band && valid) {     // spectral flux profiles: sums over the regions per g-point (:485-498, :611-625)
+        const size_t o = col + ncol * ord.half(hl);
+        const double dir = mu0 * (ddn[0] + ddn[1] + ddn[2]);
+        spec_put(fx.sw_up_band, ng, g, o, fup[0] + fup[1] + fup[2]);
+        spec_put(fx.sw_dn_band, ng, g, o, dir + (fdn[0] + fdn[1] + fdn[2]));
+        spec_put(fx.sw_dn_direct_band, ng, g, o, dir);
+        if (do_clear) {
+          spec_put(fx.sw_up_clear_band, ng, g, o, fup_c);
+          spec_put(fx.sw_dn_clear_band, ng, g, o, mu0 * ddn_c + fdn_c);
+          spec_put(fx.sw_dn_direct_clear_band, ng, g, o, mu0 * ddn_c);
         }
       }
       double sums[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -387,6 +409,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
       if (do_clear) a.fx.lw_dn_clear[col + ncol * ord.half(0)] = 0.0;
       a.fx.lw_dn[col + ncol * ord.half(0)] = 0.0;
     }
+    if (valid && a.fx.lw_dn_band) {     // spectral flux profiles (do_save_spectral_flux), lane g owns interval g
+      const size_t o = col + ncol * ord.half(0);
+      spec_put(a.fx.lw_dn_band, ng, g, o, 0.0);
+      if (do_clear) spec_put(a.fx.lw_dn_clear_band, ng, g, o, 0.0);
+    }
     for (int l0 = 0; l0 < nlev; l0 += NGP) {
       __syncthreads();
       {
@@ -401,6 +428,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
       const PlanckTab<TAB> pt{c0.cfg.gas_lw.planck_function, ng};
       double* const lw_dn = c0.fx.lw_dn;
       double* const lw_dn_clear = do_clear ? c0.fx.lw_dn_clear : nullptr;
+      double* const lw_dn_band = c0.fx.lw_dn_band;
+      double* const lw_dn_clear_band = do_clear ? c0.fx.lw_dn_clear_band : nullptr;
       double keep_dn = 0.0;
       for (int j = 0; j < nl; ++j) {
         const int lev = l0 + j;
@@ -440,6 +469,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
           }
         }
         fdn_c = c.transmittance * fdn_c + c.source_dn;
+        if (lw_dn_band && valid) {        // provisional below cloud top, like lw_dn
+          const size_t o = col + ncol * ord.half(lev + 1);
+          spec_put(lw_dn_band, ng, g, o, fdn_c);
+          spec_put(lw_dn_clear_band, ng, g, o, fdn_c);
+        }
         const double sd = group_sum<NGP>(valid ? fdn_c : 0.0);
         if (glane == j) keep_dn = sd;     // lane j keeps the chunk's layer j; one store per chunk
         planck_top = planck_bot;
@@ -458,9 +492,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
       double fup = emission + albedo * fdn_c;
       double su = group_sum<NGP>(valid ? fup : 0.0);
       if (lead && do_clear) fx.lw_up_clear[col + ncol * ord.half(nlev)] = su;
+      if (valid && do_clear) spec_put(fx.lw_up_clear_band, ng, g, col + ncol * ord.half(nlev), fup);
       double keep_up = 0.0;
       for (int l = nlev - 1; l >= 0; --l) {
         fup = s.at(LT_T1, l, tid) * fup + s.at(LT_SU1, l, tid);
+        if (valid && do_clear) spec_put(fx.lw_up_clear_band, ng, g, col + ncol * ord.half(l), fup);
         if (do_clear) {
           su = group_sum<NGP>(valid ? fup : 0.0);
           if ((l & (NGP - 1)) == glane) keep_up = su;
@@ -532,9 +568,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
     {
       double su = group_sum<NGP>(valid ? fup[0] : 0.0);
       if (lead) fx.lw_up[col + ncol * ord.half(ict)] = su;
+      if (valid) spec_put(fx.lw_up_band, ng, g, col + ncol * ord.half(ict), fup[0]);
       double keep_up = 0.0;
       for (int l = ict - 1; l >= 0; --l) {
         fup[0] = s.at(LT_T1, l, tid) * fup[0] + s.at(LT_SU1, l, tid);
+        if (valid) spec_put(fx.lw_up_band, ng, g, col + ncol * ord.half(l), fup[0]);
         su = group_sum<NGP>(valid ? fup[0] : 0.0);
         if ((l & (NGP - 1)) == glane) keep_up = su;
         if ((l & (NGP - 1)) == 0) {
@@ -581,6 +619,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
       const double sums[2] = {group_sum<NGP>(valid ? fup[0] + fup[1] + fup[2] : 0.0),
                               group_sum<NGP>(valid ? fdn[0] + fdn[1] + fdn[2] : 0.0)};
       const int hl = l + 1;
+      if (fx.lw_up_band && valid) {      // sums over the regions per g-point
+        const size_t o = col + ncol * ord.half(hl);
+        spec_put(fx.lw_up_band, ng, g, o, fup[0] + fup[1] + fup[2]);
+        spec_put(fx.lw_dn_band, ng, g, o, fdn[0] + fdn[1] + fdn[2]);
+      }
       kept.keep(hl, glane, sums);
       if ((hl & (NGP - 1)) == NGP - 1 || hl == nlev) {
         const int lv = kept.mine(hl, glane);

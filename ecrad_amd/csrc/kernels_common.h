@@ -313,6 +313,13 @@ ECRAD_DEV FracView cloud_fraction_view(const DevInputs& in, int col) {
   return {in.cloud_fraction + col, (size_t)in.ncol};
 }
 
+// ---- spectral flux profiles (do_save_spectral_flux) -----------------------------------------------
+// arr is (nspec = ng, ncol, nlev+1) with one interval per g-point, so lane g owns interval g and a
+// column group writes 8*ng contiguous bytes; `o` = column + ncol * (half level in the caller's order)
+ECRAD_DEV void spec_put(double* arr, int ng, int g, size_t o, double v) {
+  if (arr) arr[g + (size_t)ng * o] = v;
+}
+
 // ---- streaming accesses -----------------------------------------------------------------------------
 // The sweep scratch is written once and read once per column group and is far larger than the caches;
 // marking its accesses non-temporal keeps it from evicting the gas tables (re-read by every layer of

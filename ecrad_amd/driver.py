@@ -213,6 +213,18 @@ _SAVE_SPEC = [
 ]
 
 
+# spectral flux profiles (do_save_spectral_flux): dims (column, half_level, band), radiation_save.F90:185-203,
+# :257-286, :359-366, :405-420
+_SAVE_SPECTRAL = [
+    ("spectral_flux_up_lw", "lw_up_band", "band_lw"), ("spectral_flux_dn_lw", "lw_dn_band", "band_lw"),
+    ("spectral_flux_up_lw_clear", "lw_up_clear_band", "band_lw"), ("spectral_flux_dn_lw_clear", "lw_dn_clear_band", "band_lw"),
+    ("spectral_flux_up_sw", "sw_up_band", "band_sw"), ("spectral_flux_dn_sw", "sw_dn_band", "band_sw"),
+    ("spectral_flux_dn_direct_sw", "sw_dn_direct_band", "band_sw"),
+    ("spectral_flux_up_sw_clear", "sw_up_clear_band", "band_sw"), ("spectral_flux_dn_sw_clear", "sw_dn_clear_band", "band_sw"),
+    ("spectral_flux_dn_direct_sw_clear", "sw_dn_direct_clear_band", "band_sw"),
+]
+
+
 def flux_to_output_dict(config: Config, thermodynamics: Thermodynamics, flux: Flux) -> dict:
     """Arrays keyed by the reference's output variable names, each in netCDF order
     (column first), as save_fluxes writes them (radiation_save.F90:153-460)."""
@@ -225,6 +237,11 @@ def flux_to_output_dict(config: Config, thermodynamics: Thermodynamics, flux: Fl
             out[ncname] = arr.T.copy()          # numpy (nlev+1, ncol) -> (column, half_level)
         else:
             out[ncname] = arr.copy()            # numpy (ncol, nband) already (column, band)
+    if config.do_save_spectral_flux:
+        for ncname, member, _ in _SAVE_SPECTRAL:
+            arr = getattr(flux, member)
+            if arr is not None:
+                out[ncname] = np.ascontiguousarray(arr.transpose(1, 0, 2))    # (nlev+1, ncol, nspec) -> (column, half_level, band)
     for n in ("cloud_cover_lw", "cloud_cover_sw"):
         if getattr(flux, n) is not None and ((n.endswith("lw") and config.do_lw) or
                                              (n.endswith("sw") and config.do_sw)):
@@ -240,9 +257,13 @@ def save_fluxes(path: str, config: Config, thermodynamics: Thermodynamics, flux:
     dims = {"column": ncol, "half_level": thermodynamics.pressure_hl.shape[0]}
     variables = {}
     dim2 = {n: d for n, _, d in _SAVE_SPEC}
+    dim3 = {n: d for n, _, d in _SAVE_SPECTRAL}
     for name, arr in out.items():
         if arr.ndim == 1:
             variables[name] = (("column",), arr)
+        elif arr.ndim == 3:
+            dims.setdefault(dim3[name], arr.shape[2])
+            variables[name] = (("column", "half_level", dim3[name]), arr)
         else:
             d = "half_level" if name == "pressure_hl" else dim2[name]
             dims.setdefault(d, arr.shape[1])

@@ -8,7 +8,7 @@ module ecrad_hip_binding
   implicit none
   public
 
-  integer(c_int), parameter :: ECRAD_ABI_VERSION = 1
+  integer(c_int), parameter :: ECRAD_ABI_VERSION = 2
   integer(c_int), parameter :: ECRAD_OK = 0
   integer(c_int), parameter :: ECRAD_NMAXGASES = 12, ECRAD_NMAXCLOUDTYPES = 12
   integer(c_int), parameter :: ECRAD_MEM_HOST = 0, ECRAD_MEM_DEVICE = 1
@@ -71,11 +71,13 @@ module ecrad_hip_binding
     integer(c_int32_t) :: n_canopy_bands_sw, n_canopy_bands_lw
     integer(c_int32_t) :: n_albedo_intervals_sw, n_emiss_intervals_lw
     integer(c_int32_t) :: n_cloud_types, reserved_
+    integer(c_int32_t) :: n_spec_sw, n_spec_lw
     real(c_double) :: cloud_fraction_threshold, cloud_mixing_ratio_threshold
     real(c_double) :: cloud_inhom_decorr_scaling, max_cloud_od
     type(c_ptr) :: i_band_from_reordered_g_sw = c_null_ptr, i_band_from_reordered_g_lw = c_null_ptr
     type(c_ptr) :: sw_albedo_weights = c_null_ptr, lw_emiss_weights = c_null_ptr
     type(c_ptr) :: i_albedo_from_band_sw = c_null_ptr, i_emiss_from_band_lw = c_null_ptr
+    type(c_ptr) :: i_spec_from_reordered_g_sw = c_null_ptr, i_spec_from_reordered_g_lw = c_null_ptr
     type(ecrad_ckd_model_t) :: gas_optics_sw, gas_optics_lw
     type(ecrad_cloud_optics_t) :: cloud_optics_sw(ECRAD_NMAXCLOUDTYPES), cloud_optics_lw(ECRAD_NMAXCLOUDTYPES)
     type(ecrad_aerosol_optics_t) :: aerosol_optics
@@ -115,6 +117,10 @@ module ecrad_hip_binding
     type(c_ptr) :: lw_dn_surf_canopy = c_null_ptr, sw_dn_diffuse_surf_canopy = c_null_ptr
     type(c_ptr) :: sw_dn_direct_surf_canopy = c_null_ptr
     type(c_ptr) :: cloud_cover_lw = c_null_ptr, cloud_cover_sw = c_null_ptr
+    ! (nspec,ncol,nlev+1) spectral flux profiles, config%do_save_spectral_flux
+    type(c_ptr) :: lw_up_band = c_null_ptr, lw_dn_band = c_null_ptr, lw_up_clear_band = c_null_ptr, lw_dn_clear_band = c_null_ptr
+    type(c_ptr) :: sw_up_band = c_null_ptr, sw_dn_band = c_null_ptr, sw_dn_direct_band = c_null_ptr
+    type(c_ptr) :: sw_up_clear_band = c_null_ptr, sw_dn_clear_band = c_null_ptr, sw_dn_direct_clear_band = c_null_ptr
   end type
 
   interface

@@ -63,6 +63,9 @@ module radiation_hip_types
     logical :: do_canopy_fluxes_sw = .false., do_canopy_fluxes_lw = .false.
     logical :: use_canopy_full_spectrum_sw = .false., use_canopy_full_spectrum_lw = .false.
     logical :: do_nearest_spectral_sw_albedo = .false., do_nearest_spectral_lw_emiss = .false.
+    logical :: do_save_spectral_flux = .false.
+    integer :: n_spec_sw = 0, n_spec_lw = 0
+    integer(c_int32_t), allocatable :: i_spec_from_reordered_g_sw(:), i_spec_from_reordered_g_lw(:)
     integer :: n_g_sw = 0, n_g_lw = 0, n_bands_sw = 0, n_bands_lw = 0
     integer :: n_canopy_bands_sw = 1, n_canopy_bands_lw = 1, n_cloud_types = 0
     real(jprb) :: cloud_fraction_threshold = 1.0e-6_jprb, cloud_mixing_ratio_threshold = 1.0e-9_jprb
@@ -107,6 +110,9 @@ module radiation_hip_types
          &  sw_dn_surf_clear_band, sw_dn_direct_surf_clear_band
     real(jprb), allocatable, dimension(:,:) :: lw_dn_surf_canopy, sw_dn_diffuse_surf_canopy, sw_dn_direct_surf_canopy
     real(jprb), allocatable, dimension(:)   :: cloud_cover_lw, cloud_cover_sw
+    ! (nspec,ncol,nlev+1), config%do_save_spectral_flux (radiation_flux.F90:52-59)
+    real(jprb), allocatable, dimension(:,:,:) :: lw_up_band, lw_dn_band, lw_up_clear_band, lw_dn_clear_band, &
+         &  sw_up_band, sw_dn_band, sw_dn_direct_band, sw_up_clear_band, sw_dn_clear_band, sw_dn_direct_clear_band
   contains
     procedure :: allocate => allocate_flux_type
   end type
@@ -146,6 +152,22 @@ contains
            &  this%sw_dn_direct_surf_clear_g(config%n_g_sw,istartcol:iendcol), this%sw_up_toa_clear_g(config%n_g_sw,istartcol:iendcol))
       if (config%do_canopy_fluxes_sw) allocate(this%sw_dn_diffuse_surf_canopy(config%n_canopy_bands_sw,istartcol:iendcol), &
            &                                   this%sw_dn_direct_surf_canopy(config%n_canopy_bands_sw,istartcol:iendcol))
+    end if
+    if (config%do_save_spectral_flux) then
+      if (config%do_lw) then
+        allocate(this%lw_up_band(config%n_spec_lw,istartcol:iendcol,nlev+1), this%lw_dn_band(config%n_spec_lw,istartcol:iendcol,nlev+1))
+        if (config%do_clear) allocate(this%lw_up_clear_band(config%n_spec_lw,istartcol:iendcol,nlev+1), &
+             &                         this%lw_dn_clear_band(config%n_spec_lw,istartcol:iendcol,nlev+1))
+      end if
+      if (config%do_sw) then
+        allocate(this%sw_up_band(config%n_spec_sw,istartcol:iendcol,nlev+1), this%sw_dn_band(config%n_spec_sw,istartcol:iendcol,nlev+1))
+        if (config%do_sw_direct) allocate(this%sw_dn_direct_band(config%n_spec_sw,istartcol:iendcol,nlev+1))
+        if (config%do_clear) then
+          allocate(this%sw_up_clear_band(config%n_spec_sw,istartcol:iendcol,nlev+1), &
+               &   this%sw_dn_clear_band(config%n_spec_sw,istartcol:iendcol,nlev+1))
+          if (config%do_sw_direct) allocate(this%sw_dn_direct_clear_band(config%n_spec_sw,istartcol:iendcol,nlev+1))
+        end if
+      end if
     end if
     allocate(this%cloud_cover_lw(istartcol:iendcol), this%cloud_cover_sw(istartcol:iendcol))
     this%cloud_cover_lw = -1.0_jprb
@@ -249,7 +271,10 @@ contains
     c%use_canopy_full_spectrum_lw = l2i(config%use_canopy_full_spectrum_lw)
     c%do_nearest_spectral_sw_albedo = l2i(config%do_nearest_spectral_sw_albedo)
     c%do_nearest_spectral_lw_emiss = l2i(config%do_nearest_spectral_lw_emiss)
-    c%do_save_spectral_flux = 0
+    c%do_save_spectral_flux = l2i(config%do_save_spectral_flux)
+    c%n_spec_sw = config%n_spec_sw; c%n_spec_lw = config%n_spec_lw
+    if (allocated(config%i_spec_from_reordered_g_sw)) c%i_spec_from_reordered_g_sw = c_loc(config%i_spec_from_reordered_g_sw)
+    if (allocated(config%i_spec_from_reordered_g_lw)) c%i_spec_from_reordered_g_lw = c_loc(config%i_spec_from_reordered_g_lw)
     c%n_g_sw = config%n_g_sw; c%n_g_lw = config%n_g_lw; c%n_bands_sw = config%n_bands_sw; c%n_bands_lw = config%n_bands_lw
     c%n_g_lw_if_scattering = 0; c%n_bands_lw_if_scattering = merge(config%n_bands_lw, 0, config%do_lw_cloud_scattering)
     c%n_canopy_bands_sw = config%n_canopy_bands_sw; c%n_canopy_bands_lw = config%n_canopy_bands_lw
@@ -369,6 +394,16 @@ contains
     cfl%sw_dn_direct_surf_canopy = loc2(flux%sw_dn_direct_surf_canopy)
     if (allocated(flux%cloud_cover_lw)) cfl%cloud_cover_lw = c_loc(flux%cloud_cover_lw)
     if (allocated(flux%cloud_cover_sw)) cfl%cloud_cover_sw = c_loc(flux%cloud_cover_sw)
+    if (allocated(flux%lw_up_band)) cfl%lw_up_band = c_loc(flux%lw_up_band)
+    if (allocated(flux%lw_dn_band)) cfl%lw_dn_band = c_loc(flux%lw_dn_band)
+    if (allocated(flux%lw_up_clear_band)) cfl%lw_up_clear_band = c_loc(flux%lw_up_clear_band)
+    if (allocated(flux%lw_dn_clear_band)) cfl%lw_dn_clear_band = c_loc(flux%lw_dn_clear_band)
+    if (allocated(flux%sw_up_band)) cfl%sw_up_band = c_loc(flux%sw_up_band)
+    if (allocated(flux%sw_dn_band)) cfl%sw_dn_band = c_loc(flux%sw_dn_band)
+    if (allocated(flux%sw_dn_direct_band)) cfl%sw_dn_direct_band = c_loc(flux%sw_dn_direct_band)
+    if (allocated(flux%sw_up_clear_band)) cfl%sw_up_clear_band = c_loc(flux%sw_up_clear_band)
+    if (allocated(flux%sw_dn_clear_band)) cfl%sw_dn_clear_band = c_loc(flux%sw_dn_clear_band)
+    if (allocated(flux%sw_dn_direct_clear_band)) cfl%sw_dn_direct_clear_band = c_loc(flux%sw_dn_direct_clear_band)
     if (ecrad_hip_radiation(hip_handle, int(ncol,c_int), int(nlev,c_int), int(istartcol,c_int), int(iendcol,c_int), &
          &  cin, cfl) /= ECRAD_OK) call radiation_hip_abort('*** Error in ecrad_hip_radiation')
   end subroutine radiation_hip

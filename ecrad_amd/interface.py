@@ -73,8 +73,22 @@ def setup_radiation(config: Config) -> None:
         else:
             config.n_bands_lw = config.gas_optics_lw.spectral_def.nband
             config.i_band_from_reordered_g_lw = config.gas_optics_lw.spectral_def.i_band_number.astype(np.int32)
-    if config.do_save_spectral_flux:
-        raise ConfigError("do_save_spectral_flux (spectral flux profiles) is not implemented in this build")
+    # Spectral intervals of the flux profiles saved with do_save_spectral_flux: g-points or bands
+    # (radiation_config.F90:1568-1590)
+    # (radiation_ecckd_interface.F90:124-143)
+    for sfx in ("sw", "lw"):
+        if not getattr(config, "do_" + sfx) or not config.do_save_spectral_flux:
+            setattr(config, "n_spec_" + sfx, 0)
+            setattr(config, "i_spec_from_reordered_g_" + sfx, None)
+            continue
+        ng = getattr(config, "n_g_" + sfx)
+        if config.do_save_gpoint_flux:
+            setattr(config, "n_spec_" + sfx, ng)
+            setattr(config, "i_spec_from_reordered_g_" + sfx, np.arange(1, ng + 1, dtype=np.int32))
+        else:
+            setattr(config, "n_spec_" + sfx, getattr(config, "n_bands_" + sfx))
+            setattr(config, "i_spec_from_reordered_g_" + sfx,
+                    np.asarray(getattr(config, "i_band_from_reordered_g_" + sfx), dtype=np.int32))
 
     if config.do_lw_aerosol_scattering and not config.do_lw_cloud_scattering:
         raise ConfigError("longwave aerosol scattering requires longwave cloud scattering")
@@ -192,7 +206,7 @@ def build_config_struct(config: Config):
                  "use_canopy_full_spectrum_lw", "do_nearest_spectral_sw_albedo",
                  "do_nearest_spectral_lw_emiss", "do_save_spectral_flux", "n_g_sw", "n_g_lw", "n_bands_sw",
                  "n_bands_lw", "n_g_lw_if_scattering", "n_bands_lw_if_scattering", "n_canopy_bands_sw",
-                 "n_canopy_bands_lw", "n_cloud_types"):
+                 "n_canopy_bands_lw", "n_cloud_types", "n_spec_sw", "n_spec_lw"):
         setattr(c, name, int(getattr(config, name)))
     c.cloud_fraction_threshold = config.cloud_fraction_threshold
     c.cloud_mixing_ratio_threshold = config.cloud_mixing_ratio_threshold
@@ -208,6 +222,8 @@ def build_config_struct(config: Config):
         c.lw_emiss_weights = d(config.lw_emiss_weights)
     c.i_albedo_from_band_sw = i(config.i_albedo_from_band_sw)
     c.i_emiss_from_band_lw = i(config.i_emiss_from_band_lw)
+    c.i_spec_from_reordered_g_sw = i(config.i_spec_from_reordered_g_sw)
+    c.i_spec_from_reordered_g_lw = i(config.i_spec_from_reordered_g_lw)
 
     def fill_ckd(dst, m):
         if m is None:

@@ -162,6 +162,11 @@ class Flux:
                 a["lw_up_toa_clear_g"] = np.zeros((ncol, config.n_g_lw))
             if config.do_canopy_fluxes_lw:
                 a["lw_dn_surf_canopy"] = np.zeros((ncol, config.n_canopy_bands_lw))
+            if config.do_save_spectral_flux:        # (nspec, ncol, nlev+1), radiation_flux.F90:156-170
+                spec = lambda: np.zeros((nlev + 1, ncol, config.n_spec_lw))
+                a["lw_up_band"], a["lw_dn_band"] = spec(), spec()
+                if config.do_clear:
+                    a["lw_up_clear_band"], a["lw_dn_clear_band"] = spec(), spec()
         if config.do_sw:
             a["sw_up"], a["sw_dn"] = prof(), prof()
             if config.do_sw_direct:
@@ -189,6 +194,15 @@ class Flux:
             if config.do_canopy_fluxes_sw:
                 a["sw_dn_diffuse_surf_canopy"] = np.zeros((ncol, config.n_canopy_bands_sw))
                 a["sw_dn_direct_surf_canopy"] = np.zeros((ncol, config.n_canopy_bands_sw))
+            if config.do_save_spectral_flux:        # radiation_flux.F90:219-242
+                spec = lambda: np.zeros((nlev + 1, ncol, config.n_spec_sw))
+                a["sw_up_band"], a["sw_dn_band"] = spec(), spec()
+                if config.do_sw_direct:
+                    a["sw_dn_direct_band"] = spec()
+                if config.do_clear:
+                    a["sw_up_clear_band"], a["sw_dn_clear_band"] = spec(), spec()
+                    if config.do_sw_direct:
+                        a["sw_dn_direct_clear_band"] = spec()
         a["cloud_cover_lw"] = np.full(ncol, -1.0)
         a["cloud_cover_sw"] = np.full(ncol, -1.0)
         return f

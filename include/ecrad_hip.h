@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ECRAD_ABI_VERSION 1
+#define ECRAD_ABI_VERSION 2
 
 /* Status codes */
 #define ECRAD_OK            0
@@ -162,6 +162,8 @@ typedef struct ecrad_config {
   int32_t n_emiss_intervals_lw;    /* = size(lw_emiss_weights,1)  */
   int32_t n_cloud_types;
   int32_t reserved_;
+  int32_t n_spec_sw, n_spec_lw;    /* spectral intervals of the flux profiles saved with do_save_spectral_flux:
+                                      bands, or g-points with do_save_gpoint_flux (radiation_config.F90:1568-1590) */
   /* thresholds */
   double cloud_fraction_threshold, cloud_mixing_ratio_threshold;
   double cloud_inhom_decorr_scaling;
@@ -173,6 +175,8 @@ typedef struct ecrad_config {
   const double*  lw_emiss_weights;            /* (n_emiss_intervals_lw,  n_bands_lw) */
   const int32_t* i_albedo_from_band_sw;       /* (n_bands_sw) 1-based, nearest-albedo mode only */
   const int32_t* i_emiss_from_band_lw;        /* (n_bands_lw) 1-based, nearest-emissivity mode only */
+  const int32_t* i_spec_from_reordered_g_sw;  /* (n_g_sw) 1-based, do_save_spectral_flux only */
+  const int32_t* i_spec_from_reordered_g_lw;  /* (n_g_lw) 1-based, do_save_spectral_flux only */
   /* look-up tables owned by config after setup_radiation */
   ecrad_ckd_model_t      gas_optics_sw, gas_optics_lw;
   ecrad_cloud_optics_t   cloud_optics_sw[ECRAD_NMAXCLOUDTYPES];
@@ -239,6 +243,12 @@ typedef struct ecrad_flux {
   double *lw_dn_surf_canopy, *sw_dn_diffuse_surf_canopy, *sw_dn_direct_surf_canopy;
   /* (ncol) */
   double *cloud_cover_lw, *cloud_cover_sw;
+  /* (nspec,ncol,nlev+1): spectral flux profiles, config%do_save_spectral_flux (radiation_flux.F90:52-59,
+     :156-170, :219-242); written by the cloudless, homogeneous and Tripleclouds solvers -- the reference's
+     McICA solver cannot store them (radiation_config.F90:1331-1334) */
+  double *lw_up_band, *lw_dn_band, *lw_up_clear_band, *lw_dn_clear_band;
+  double *sw_up_band, *sw_dn_band, *sw_dn_direct_band;
+  double *sw_up_clear_band, *sw_dn_clear_band, *sw_dn_direct_clear_band;
 } ecrad_flux_t;
 
 /* ---- stage-interface arrays of radiation(), radiation_interface.F90:260-301 ------------------ */

@@ -3,7 +3,8 @@
  * Restates radiation() (radiation_interface.F90:200-510: stage sequencing) and
  * flux%calc_surface_spectral / calc_toa_spectral (radiation_flux.F90:397-660, non-DWD paths).
  * radiation_reverse (:519-661, inputs ordered surface-first) is not restated: the oracle returns
- * ECRAD_EUNSUPPORTED for such inputs.
+ * ECRAD_EUNSUPPORTED for such inputs.  Spectral flux profiles (do_save_spectral_flux) are restated in
+ * the cloudless, homogeneous and Tripleclouds solvers; the McICA solvers do not store them.
  */
 #include <stdlib.h>
 #include <string.h>
@@ -131,7 +132,6 @@ int ecrad_oracle_radiation(const ecrad_config_t* c, int ncol, int nlev, int ista
   if ((c->do_sw && c->i_gas_model_sw != ECRAD_GAS_ECCKD) || (c->do_lw && c->i_gas_model_lw != ECRAD_GAS_ECCKD))
     return ECRAD_EUNSUPPORTED;
   if (c->i_solver_sw == ECRAD_SOLVER_SPARTACUS || c->i_solver_lw == ECRAD_SOLVER_SPARTACUS) return ECRAD_EUNSUPPORTED;
-  if (c->do_save_spectral_flux) return ECRAD_EUNSUPPORTED;
   if (in->pressure_hl[(size_t)(istartcol - 1) + (size_t)ncol] < in->pressure_hl[istartcol - 1]) return ECRAD_EUNSUPPORTED;
   const int nloc = iendcol - istartcol + 1;
   oracle_optics_buf_t* b = oracle_optics_buf_alloc(c, nlev, nloc);

@@ -89,6 +89,44 @@ static void zero_g(double* a, int ng, int jcol)
   for (int g = 0; g < ng; ++g) GC(a, g, jcol) = 0.0;
 }
 
+/* Spectral flux profiles, config%do_save_spectral_flux: indexed_sum_profile / add_indexed_sum_profile
+   (radiation_flux.F90:777-855) into arrays (nspec, ncol, nlev+1) */
+#define SP(a, nspec, is, jcol, l) (a)[(size_t)(is) + (size_t)(nspec) * ((size_t)(jcol) + (size_t)ncol * (l))]
+static void spec_profile(int add, int ng, int nlev, int ncol, int jcol, const double* src_g, const int32_t* ispec,
+                         int nspec, double* dest)
+{
+  if (!dest) return;
+  for (int l = 0; l <= nlev; ++l) {
+    if (!add) for (int is = 0; is < nspec; ++is) SP(dest, nspec, is, jcol, l) = 0.0;
+    for (int g = 0; g < ng; ++g) SP(dest, nspec, ispec[g] - 1, jcol, l) += src_g[g + (size_t)ng * l];
+  }
+}
+static void spec_copy(int nspec, int nlev, int ncol, int jcol, const double* src, double* dest)
+{
+  if (!dest) return;
+  for (int l = 0; l <= nlev; ++l)
+    for (int is = 0; is < nspec; ++is) SP(dest, nspec, is, jcol, l) = src ? SP(src, nspec, is, jcol, l) : 0.0;
+}
+/* the shortwave trio: up; dn = direct then + diffuse; direct copy of the first stage */
+static void spec_sw(const ecrad_config_t* c, int ng, int nlev, int ncol, int jcol, const double* flux_up,
+                    const double* flux_dn_diffuse, const double* flux_dn_direct, double* up, double* dn, double* dir)
+{
+  if (!c->do_save_spectral_flux || !up) return;
+  const int32_t* is = c->i_spec_from_reordered_g_sw;
+  const int ns = c->n_spec_sw;
+  spec_profile(0, ng, nlev, ncol, jcol, flux_up, is, ns, up);
+  spec_profile(0, ng, nlev, ncol, jcol, flux_dn_direct, is, ns, dn);
+  if (dir) spec_copy(ns, nlev, ncol, jcol, dn, dir);
+  spec_profile(1, ng, nlev, ncol, jcol, flux_dn_diffuse, is, ns, dn);
+}
+static void spec_lw(const ecrad_config_t* c, int ng, int nlev, int ncol, int jcol, const double* flux_up,
+                    const double* flux_dn, double* up, double* dn)
+{
+  if (!c->do_save_spectral_flux || !up) return;
+  spec_profile(0, ng, nlev, ncol, jcol, flux_up, c->i_spec_from_reordered_g_lw, c->n_spec_lw, up);
+  spec_profile(0, ng, nlev, ncol, jcol, flux_dn, c->i_spec_from_reordered_g_lw, c->n_spec_lw, dn);
+}
+
 /* store SW per-g fluxes into broadband profiles: flux%sw_up(jcol,:) = sum(flux_up,1) etc. */
 static void store_sw(int ng, int nlev, int ncol, int jcol, const double* flux_up, const double* flux_dn_diffuse,
                      const double* flux_dn_direct, double* sw_up, double* sw_dn, double* sw_dn_direct)
@@ -146,12 +184,19 @@ void oracle_solver_cloudless_sw(const ecrad_config_t* c, int ncol, int nlev, int
           b->sw_albedo_direct + (size_t)ng * jc, cos_sza_v, reflectance, transmittance, ref_dir,
           trans_dir_diff, trans_dir_dir, flux_up, flux_dn_diffuse, flux_dn_direct);
       store_sw(ng, nlev, ncol, jcol, flux_up, flux_dn_diffuse, flux_dn_direct, flux->sw_up, flux->sw_dn, flux->sw_dn_direct);
+      spec_sw(c, ng, nlev, ncol, jcol, flux_up, flux_dn_diffuse, flux_dn_direct, flux->sw_up_band, flux->sw_dn_band,
+              flux->sw_dn_direct_band);                                   /* radiation_cloudless_sw.F90:169-183 */
       for (int gg = 0; gg < ng; ++gg) {
         GC(flux->sw_dn_diffuse_surf_g, gg, jcol) = flux_dn_diffuse[gg + (size_t)ng * nlev];
         GC(flux->sw_dn_direct_surf_g, gg, jcol) = flux_dn_direct[gg + (size_t)ng * nlev];
         GC(flux->sw_up_toa_g, gg, jcol) = flux_up[gg];
       }
       if (c->do_clear) {
+        if (c->do_save_spectral_flux && flux->sw_up_band) {              /* :195-202 */
+          spec_copy(c->n_spec_sw, nlev, ncol, jcol, flux->sw_up_band, flux->sw_up_clear_band);
+          spec_copy(c->n_spec_sw, nlev, ncol, jcol, flux->sw_dn_band, flux->sw_dn_clear_band);
+          spec_copy(c->n_spec_sw, nlev, ncol, jcol, flux->sw_dn_direct_band, flux->sw_dn_direct_clear_band);
+        }
         for (int l = 0; l <= nlev; ++l) {
           FL(flux->sw_up_clear, jcol, l) = FL(flux->sw_up, jcol, l);
           FL(flux->sw_dn_clear, jcol, l) = FL(flux->sw_dn, jcol, l);
@@ -166,6 +211,14 @@ void oracle_solver_cloudless_sw(const ecrad_config_t* c, int ncol, int nlev, int
     } else {
       zero_profile(flux->sw_up, ncol, nlev, jcol); zero_profile(flux->sw_dn, ncol, nlev, jcol);
       zero_profile(flux->sw_dn_direct, ncol, nlev, jcol);
+      if (c->do_save_spectral_flux && flux->sw_up_band) {
+        spec_copy(c->n_spec_sw, nlev, ncol, jcol, NULL, flux->sw_up_band); spec_copy(c->n_spec_sw, nlev, ncol, jcol, NULL, flux->sw_dn_band);
+        spec_copy(c->n_spec_sw, nlev, ncol, jcol, NULL, flux->sw_dn_direct_band);
+        if (c->do_clear) {
+          spec_copy(c->n_spec_sw, nlev, ncol, jcol, NULL, flux->sw_up_clear_band); spec_copy(c->n_spec_sw, nlev, ncol, jcol, NULL, flux->sw_dn_clear_band);
+          spec_copy(c->n_spec_sw, nlev, ncol, jcol, NULL, flux->sw_dn_direct_clear_band);
+        }
+      }
       zero_g(flux->sw_dn_diffuse_surf_g, ng, jcol); zero_g(flux->sw_dn_direct_surf_g, ng, jcol);
       if (c->do_clear) {
         zero_profile(flux->sw_up_clear, ncol, nlev, jcol); zero_profile(flux->sw_dn_clear, ncol, nlev, jcol);
@@ -223,6 +276,11 @@ void oracle_solver_cloudless_lw(const ecrad_config_t* c, int ncol, int nlev, int
                            b->lw_emission + (size_t)ng * jc, b->lw_albedo + (size_t)ng * jc, flux_up, flux_dn);
     sum_g(ng, nlev + 1, flux_up, tmp); for (int l = 0; l <= nlev; ++l) FL(flux->lw_up, jcol, l) = tmp[l];
     sum_g(ng, nlev + 1, flux_dn, tmp); for (int l = 0; l <= nlev; ++l) FL(flux->lw_dn, jcol, l) = tmp[l];
+    spec_lw(c, ng, nlev, ncol, jcol, flux_up, flux_dn, flux->lw_up_band, flux->lw_dn_band);     /* radiation_cloudless_lw.F90:148-154 */
+    if (c->do_clear && c->do_save_spectral_flux && flux->lw_up_band) {                            /* :162-165 */
+      spec_copy(c->n_spec_lw, nlev, ncol, jcol, flux->lw_up_band, flux->lw_up_clear_band);
+      spec_copy(c->n_spec_lw, nlev, ncol, jcol, flux->lw_dn_band, flux->lw_dn_clear_band);
+    }
     for (int gg = 0; gg < ng; ++gg) {
       GC(flux->lw_dn_surf_g, gg, jcol) = flux_dn[gg + (size_t)ng * nlev];
       GC(flux->lw_up_toa_g, gg, jcol) = flux_up[gg];
@@ -309,6 +367,8 @@ void oracle_solver_homogeneous_sw(const ecrad_config_t* c, int ncol, int nlev, i
             trans_dir_diff, trans_dir_dir, flux_up, flux_dn_diffuse, flux_dn_direct);
         store_sw(ng, nlev, ncol, jcol, flux_up, flux_dn_diffuse, flux_dn_direct,
                  flux->sw_up_clear, flux->sw_dn_clear, flux->sw_dn_direct_clear);
+        spec_sw(c, ng, nlev, ncol, jcol, flux_up, flux_dn_diffuse, flux_dn_direct, flux->sw_up_clear_band,
+                flux->sw_dn_clear_band, flux->sw_dn_direct_clear_band);   /* radiation_homogeneous_sw.F90:211-222 */
         for (int gg = 0; gg < ng; ++gg) {
           GC(flux->sw_dn_diffuse_surf_clear_g, gg, jcol) = flux_dn_diffuse[gg + (size_t)ng * nlev];
           GC(flux->sw_dn_direct_surf_clear_g, gg, jcol) = flux_dn_direct[gg + (size_t)ng * nlev];
@@ -331,12 +391,19 @@ void oracle_solver_homogeneous_sw(const ecrad_config_t* c, int ncol, int nlev, i
             b->sw_albedo_direct + (size_t)ng * jc, cos_sza_v, reflectance, transmittance, ref_dir,
             trans_dir_diff, trans_dir_dir, flux_up, flux_dn_diffuse, flux_dn_direct);
         store_sw(ng, nlev, ncol, jcol, flux_up, flux_dn_diffuse, flux_dn_direct, flux->sw_up, flux->sw_dn, flux->sw_dn_direct);
+        spec_sw(c, ng, nlev, ncol, jcol, flux_up, flux_dn_diffuse, flux_dn_direct, flux->sw_up_band, flux->sw_dn_band,
+                flux->sw_dn_direct_band);                                 /* :299-311 */
         for (int gg = 0; gg < ng; ++gg) {
           GC(flux->sw_dn_diffuse_surf_g, gg, jcol) = flux_dn_diffuse[gg + (size_t)ng * nlev];
           GC(flux->sw_dn_direct_surf_g, gg, jcol) = flux_dn_direct[gg + (size_t)ng * nlev];
           GC(flux->sw_up_toa_g, gg, jcol) = flux_up[gg];
         }
       } else {
+        if (c->do_save_spectral_flux && flux->sw_up_band) {              /* :325-331 */
+          spec_copy(c->n_spec_sw, nlev, ncol, jcol, flux->sw_up_clear_band, flux->sw_up_band);
+          spec_copy(c->n_spec_sw, nlev, ncol, jcol, flux->sw_dn_clear_band, flux->sw_dn_band);
+          spec_copy(c->n_spec_sw, nlev, ncol, jcol, flux->sw_dn_direct_clear_band, flux->sw_dn_direct_band);
+        }
         for (int l = 0; l <= nlev; ++l) {
           FL(flux->sw_up, jcol, l) = FL(flux->sw_up_clear, jcol, l);
           FL(flux->sw_dn, jcol, l) = FL(flux->sw_dn_clear, jcol, l);
@@ -351,6 +418,14 @@ void oracle_solver_homogeneous_sw(const ecrad_config_t* c, int ncol, int nlev, i
     } else {
       zero_profile(flux->sw_up, ncol, nlev, jcol); zero_profile(flux->sw_dn, ncol, nlev, jcol);
       zero_profile(flux->sw_dn_direct, ncol, nlev, jcol);
+      if (c->do_save_spectral_flux && flux->sw_up_band) {
+        spec_copy(c->n_spec_sw, nlev, ncol, jcol, NULL, flux->sw_up_band); spec_copy(c->n_spec_sw, nlev, ncol, jcol, NULL, flux->sw_dn_band);
+        spec_copy(c->n_spec_sw, nlev, ncol, jcol, NULL, flux->sw_dn_direct_band);
+        if (c->do_clear) {
+          spec_copy(c->n_spec_sw, nlev, ncol, jcol, NULL, flux->sw_up_clear_band); spec_copy(c->n_spec_sw, nlev, ncol, jcol, NULL, flux->sw_dn_clear_band);
+          spec_copy(c->n_spec_sw, nlev, ncol, jcol, NULL, flux->sw_dn_direct_clear_band);
+        }
+      }
       zero_g(flux->sw_dn_diffuse_surf_g, ng, jcol); zero_g(flux->sw_dn_direct_surf_g, ng, jcol);
       zero_g(flux->sw_up_toa_g, ng, jcol);
       if (c->do_clear) {
@@ -400,6 +475,7 @@ void oracle_solver_homogeneous_lw(const ecrad_config_t* c, int ncol, int nlev, i
         oracle_calc_fluxes_no_scattering_lw(ng, nlev, transmittance, source_up, source_dn, emission, albedo, flux_up, flux_dn);
       sum_g(ng, nlev + 1, flux_up, tmp); for (int l = 0; l <= nlev; ++l) FL(flux->lw_up_clear, jcol, l) = tmp[l];
       sum_g(ng, nlev + 1, flux_dn, tmp); for (int l = 0; l <= nlev; ++l) FL(flux->lw_dn_clear, jcol, l) = tmp[l];
+      spec_lw(c, ng, nlev, ncol, jcol, flux_up, flux_dn, flux->lw_up_clear_band, flux->lw_dn_clear_band);   /* radiation_homogeneous_lw.F90:190-195 */
       for (int gg = 0; gg < ng; ++gg) {
         GC(flux->lw_dn_surf_clear_g, gg, jcol) = flux_dn[gg + (size_t)ng * nlev];
         GC(flux->lw_up_toa_clear_g, gg, jcol) = flux_up[gg];
@@ -429,11 +505,16 @@ void oracle_solver_homogeneous_lw(const ecrad_config_t* c, int ncol, int nlev, i
         oracle_calc_fluxes_no_scattering_lw(ng, nlev, transmittance, source_up, source_dn, emission, albedo, flux_up, flux_dn);
       sum_g(ng, nlev + 1, flux_up, tmp); for (int l = 0; l <= nlev; ++l) FL(flux->lw_up, jcol, l) = tmp[l];
       sum_g(ng, nlev + 1, flux_dn, tmp); for (int l = 0; l <= nlev; ++l) FL(flux->lw_dn, jcol, l) = tmp[l];
+      spec_lw(c, ng, nlev, ncol, jcol, flux_up, flux_dn, flux->lw_up_band, flux->lw_dn_band);               /* :282-287 */
       for (int gg = 0; gg < ng; ++gg) {
         GC(flux->lw_dn_surf_g, gg, jcol) = flux_dn[gg + (size_t)ng * nlev];
         GC(flux->lw_up_toa_g, gg, jcol) = flux_up[gg];
       }
     } else {
+      if (c->do_save_spectral_flux && flux->lw_up_band) {                /* radiation_homogeneous_lw.F90:297-300 */
+        spec_copy(c->n_spec_lw, nlev, ncol, jcol, flux->lw_up_clear_band, flux->lw_up_band);
+        spec_copy(c->n_spec_lw, nlev, ncol, jcol, flux->lw_dn_clear_band, flux->lw_dn_band);
+      }
       for (int l = 0; l <= nlev; ++l) {
         FL(flux->lw_up, jcol, l) = FL(flux->lw_up_clear, jcol, l);
         FL(flux->lw_dn, jcol, l) = FL(flux->lw_dn_clear, jcol, l);

@@ -55,6 +55,48 @@ static void column_cloud_geometry(const ecrad_config_t* c, int ncol, int nlev, i
 /* =============================================================================================
  * radiation_tripleclouds_sw.F90:42-661
  * ========================================================================================== */
+/* Spectral flux profiles (do_save_spectral_flux): indexed_sum of the region sums at one half level into
+   (nspec, ncol, nlev+1) arrays; nreg = 3 (all-sky) or 1 (clear-sky) */
+#define SPX(a, nspec, is, jcol, l) (a)[(size_t)(is) + (size_t)(nspec) * ((size_t)(jcol) + (size_t)ncol * (l))]
+static void spec_level(int add, double scale, int ng, int nreg, int ncol, int jcol, int l, const double* x /* (ng,nreg) */,
+                       const int32_t* ispec, int nspec, double* dest)
+{
+  if (!dest) return;
+  if (!add) for (int is = 0; is < nspec; ++is) SPX(dest, nspec, is, jcol, l) = 0.0;
+  for (int g = 0; g < ng; ++g) {
+    double v = x[g];
+    for (int r = 1; r < nreg; ++r) v += x[g + (size_t)ng * r];
+    SPX(dest, nspec, ispec[g] - 1, jcol, l) += v;
+  }
+  if (scale != 1.0) for (int is = 0; is < nspec; ++is) SPX(dest, nspec, is, jcol, l) *= scale;
+}
+/* :485-510, :611-640: up; dn = mu0 * direct, copied to the direct array, then + diffuse */
+static void spec_sw_level(const ecrad_config_t* c, ecrad_flux_t* flux, int ng, int ncol, int jcol, int l, double mu0,
+                          const double* flux_up, const double* direct_dn, const double* flux_dn,
+                          const double* flux_up_clear, const double* direct_dn_clear, const double* flux_dn_clear)
+{
+  if (!c->do_save_spectral_flux || !flux->sw_up_band) return;
+  const int32_t* is = c->i_spec_from_reordered_g_sw;
+  const int ns = c->n_spec_sw;
+  spec_level(0, 1.0, ng, 3, ncol, jcol, l, flux_up, is, ns, flux->sw_up_band);
+  spec_level(0, mu0, ng, 3, ncol, jcol, l, direct_dn, is, ns, flux->sw_dn_band);
+  if (flux->sw_dn_direct_band)
+    for (int k = 0; k < ns; ++k) SPX(flux->sw_dn_direct_band, ns, k, jcol, l) = SPX(flux->sw_dn_band, ns, k, jcol, l);
+  spec_level(1, 1.0, ng, 3, ncol, jcol, l, flux_dn, is, ns, flux->sw_dn_band);
+  if (c->do_clear) {
+    spec_level(0, 1.0, ng, 1, ncol, jcol, l, flux_up_clear, is, ns, flux->sw_up_clear_band);
+    spec_level(0, mu0, ng, 1, ncol, jcol, l, direct_dn_clear, is, ns, flux->sw_dn_clear_band);
+    if (flux->sw_dn_direct_clear_band)
+      for (int k = 0; k < ns; ++k) SPX(flux->sw_dn_direct_clear_band, ns, k, jcol, l) = SPX(flux->sw_dn_clear_band, ns, k, jcol, l);
+    spec_level(1, 1.0, ng, 1, ncol, jcol, l, flux_dn_clear, is, ns, flux->sw_dn_clear_band);
+  }
+}
+static void spec_zero(int nspec, int nlev, int ncol, int jcol, double* dest)
+{
+  if (!dest) return;
+  for (int l = 0; l <= nlev; ++l) for (int is = 0; is < nspec; ++is) SPX(dest, nspec, is, jcol, l) = 0.0;
+}
+
 void oracle_solver_tripleclouds_sw(const ecrad_config_t* c, int ncol, int nlev, int istartcol, int iendcol,
      const ecrad_inputs_t* in, const oracle_optics_buf_t* b, ecrad_flux_t* flux)
 {
@@ -91,6 +133,14 @@ void oracle_solver_tripleclouds_sw(const ecrad_config_t* c, int ncol, int nlev, 
     if (mu0 < 1.0e-10) {
       zero_profile(flux->sw_dn, ncol, nlev, jcol); zero_profile(flux->sw_up, ncol, nlev, jcol);
       zero_profile(flux->sw_dn_direct, ncol, nlev, jcol);
+      if (c->do_save_spectral_flux && flux->sw_up_band) {      /* :226-238 */
+        spec_zero(c->n_spec_sw, nlev, ncol, jcol, flux->sw_up_band); spec_zero(c->n_spec_sw, nlev, ncol, jcol, flux->sw_dn_band);
+        spec_zero(c->n_spec_sw, nlev, ncol, jcol, flux->sw_dn_direct_band);
+        if (c->do_clear) {
+          spec_zero(c->n_spec_sw, nlev, ncol, jcol, flux->sw_up_clear_band); spec_zero(c->n_spec_sw, nlev, ncol, jcol, flux->sw_dn_clear_band);
+          spec_zero(c->n_spec_sw, nlev, ncol, jcol, flux->sw_dn_direct_clear_band);
+        }
+      }
       if (c->do_clear) {
         zero_profile(flux->sw_dn_clear, ncol, nlev, jcol); zero_profile(flux->sw_up_clear, ncol, nlev, jcol);
         zero_profile(flux->sw_dn_direct_clear, ncol, nlev, jcol);
@@ -245,6 +295,7 @@ void oracle_solver_tripleclouds_sw(const ecrad_config_t* c, int ncol, int nlev, 
         if (flux->sw_dn_direct_clear) FL(flux->sw_dn_direct_clear, jcol, 0) = FL(flux->sw_dn_clear, jcol, 0);
       }
     }
+    spec_sw_level(c, flux, ng, ncol, jcol, 0, mu0, flux_up, direct_dn, flux_dn, flux_up_clear, direct_dn_clear, flux_dn_clear);
     /* downward sweep */
     for (int jlev = 1; jlev <= nlev; ++jlev) {
       const int l = jlev - 1;
@@ -301,6 +352,7 @@ void oracle_solver_tripleclouds_sw(const ecrad_config_t* c, int ncol, int nlev, 
         FL(flux->sw_dn_clear, jcol, jlev) = mu0 * sum_dn_dir + sum_dn_diff;
         if (flux->sw_dn_direct_clear) FL(flux->sw_dn_direct_clear, jcol, jlev) = mu0 * sum_dn_dir;
       }
+      spec_sw_level(c, flux, ng, ncol, jcol, jlev, mu0, flux_up, direct_dn, flux_dn, flux_up_clear, direct_dn_clear, flux_dn_clear);
     }
     for (int jg = 0; jg < ng; ++jg) {
       GC(flux->sw_dn_diffuse_surf_g, jg, jcol) = flux_dn[jg] + flux_dn[jg + ng] + flux_dn[jg + 2 * (size_t)ng];
@@ -403,6 +455,10 @@ void oracle_solver_tripleclouds_lw(const ecrad_config_t* c, int ncol, int nlev, 
         for (int jg = 0; jg < ng; ++jg) { su += G2(flux_up_clear, jg, l); sd += G2(flux_dn_clear, jg, l); }
         FL(flux->lw_up_clear, jcol, l) = su;
         FL(flux->lw_dn_clear, jcol, l) = sd;
+        if (c->do_save_spectral_flux && flux->lw_up_clear_band) {       /* radiation_tripleclouds_lw.F90:284-289 */
+          spec_level(0, 1.0, ng, 1, ncol, jcol, l, flux_up_clear + (size_t)ng * l, c->i_spec_from_reordered_g_lw, c->n_spec_lw, flux->lw_up_clear_band);
+          spec_level(0, 1.0, ng, 1, ncol, jcol, l, flux_dn_clear + (size_t)ng * l, c->i_spec_from_reordered_g_lw, c->n_spec_lw, flux->lw_dn_clear_band);
+        }
       }
       for (int jg = 0; jg < ng; ++jg) {
         GC(flux->lw_dn_surf_clear_g, jg, jcol) = G2(flux_dn_clear, jg, nlev);
@@ -522,6 +578,9 @@ void oracle_solver_tripleclouds_lw(const ecrad_config_t* c, int ncol, int nlev, 
         for (int jg = 0; jg < ng; ++jg) sd += G2(flux_dn_clear, jg, jlev - 1);
         FL(flux->lw_dn, jcol, jlev - 1) = sd;
       }
+      if (c->do_save_spectral_flux && flux->lw_up_band)                                                            /* :465-481 */
+        spec_level(0, 1.0, ng, 1, ncol, jcol, jlev - 1, flux_dn_clear + (size_t)ng * (jlev - 1), c->i_spec_from_reordered_g_lw,
+                   c->n_spec_lw, flux->lw_dn_band);
     }
     const int ict = i_cloud_top - 1;   /* 0-based half level */
     memset(flux_up, 0, sizeof(double) * 3 * ng);
@@ -532,6 +591,8 @@ void oracle_solver_tripleclouds_lw(const ecrad_config_t* c, int ncol, int nlev, 
         su += flux_up[jg];
       }
       FL(flux->lw_up, jcol, ict) = su;
+      if (c->do_save_spectral_flux && flux->lw_up_band)                                                            /* :500-504 */
+        spec_level(0, 1.0, ng, 1, ncol, jcol, ict, flux_up, c->i_spec_from_reordered_g_lw, c->n_spec_lw, flux->lw_up_band);
     }
     for (int jlev = i_cloud_top - 1; jlev >= 1; --jlev) {
       const int l = jlev - 1;
@@ -541,6 +602,8 @@ void oracle_solver_tripleclouds_lw(const ecrad_config_t* c, int ncol, int nlev, 
         su += flux_up[jg];
       }
       FL(flux->lw_up, jcol, l) = su;
+      if (c->do_save_spectral_flux && flux->lw_up_band)                                                            /* :513-517 */
+        spec_level(0, 1.0, ng, 1, ncol, jcol, l, flux_up, c->i_spec_from_reordered_g_lw, c->n_spec_lw, flux->lw_up_band);
     }
     for (int jg = 0; jg < ng; ++jg)
       GC(flux->lw_up_toa_g, jg, jcol) = flux_up[jg] + flux_up[jg + ng] + flux_up[jg + 2 * (size_t)ng];
@@ -570,6 +633,10 @@ void oracle_solver_tripleclouds_lw(const ecrad_config_t* c, int ncol, int nlev, 
       for (int i = 0; i < 3 * ng; ++i) { su += flux_up[i]; sd += flux_dn[i]; }
       FL(flux->lw_up, jcol, jlev) = su;
       FL(flux->lw_dn, jcol, jlev) = sd;
+      if (c->do_save_spectral_flux && flux->lw_up_band) {                                                          /* :575-582 */
+        spec_level(0, 1.0, ng, 3, ncol, jcol, jlev, flux_up, c->i_spec_from_reordered_g_lw, c->n_spec_lw, flux->lw_up_band);
+        spec_level(0, 1.0, ng, 3, ncol, jcol, jlev, flux_dn, c->i_spec_from_reordered_g_lw, c->n_spec_lw, flux->lw_dn_band);
+      }
     }
     for (int jg = 0; jg < ng; ++jg)
       GC(flux->lw_dn_surf_g, jg, jcol) = flux_dn[jg] + flux_dn[jg + ng] + flux_dn[jg + 2 * (size_t)ng];

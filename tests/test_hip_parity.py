@@ -26,6 +26,11 @@ CASES = {
     "mcica_noaer": dict(sw_solver="McICA", use_aerosols=False),
     "mcica_maxran": dict(sw_solver="McICA", i_overlap_scheme=0),
     "mcica_expexp": dict(sw_solver="McICA", i_overlap_scheme=2),
+    # spectral flux profiles (the reference's ecCKD namelist has do_save_spectral_flux = true)
+    "tripleclouds_spectral": dict(sw_solver="Tripleclouds", do_save_spectral_flux=True),
+    "homogeneous_spectral": dict(sw_solver="Homogeneous", do_save_spectral_flux=True),
+    "cloudless_spectral_gpoint": dict(sw_solver="Cloudless", do_save_spectral_flux=True, do_save_gpoint_flux=True),
+    "tripleclouds_spectral_noclear": dict(sw_solver="Tripleclouds", do_save_spectral_flux=True, do_clear=False),
     "mcica_expexp_beta": dict(sw_solver="McICA", i_overlap_scheme=2, use_beta_overlap=True),
     "tripleclouds_aer": dict(sw_solver="Tripleclouds"),
     "tripleclouds_noaer": dict(sw_solver="Tripleclouds", use_aerosols=False),

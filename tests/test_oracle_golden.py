@@ -60,3 +60,24 @@ def test_night_columns_have_zero_sw_and_cloud_cover_minus_one(oracle_mcica):
     assert night.any()
     assert np.all(out["cloud_cover_sw"][night] == -1.0)
     assert np.all(out["flux_dn_sw"][night] == 0.0)
+
+
+@pytest.mark.parametrize("solver", ["Tripleclouds", "Homogeneous", "Cloudless"])
+def test_oracle_spectral_flux_profiles_sum_to_broadband(solver, oracle_lib):
+    """do_save_spectral_flux (radiation_flux.F90:52-59): the spectral profiles are partitions of the
+    broadband ones -- summing over the spectral intervals must give the broadband profile (property
+    check of the restated indexed_sum_profile calls; parity with the HIP path is in test_hip_parity)."""
+    config = make_config(solver, do_save_spectral_flux=True)
+    f, _, _ = run_case(config, oracle_lib.backend)
+    pairs = [("lw_up_band", "lw_up"), ("lw_dn_band", "lw_dn"), ("sw_up_band", "sw_up"), ("sw_dn_band", "sw_dn"),
+             ("sw_dn_direct_band", "sw_dn_direct"), ("lw_up_clear_band", "lw_up_clear"),
+             ("lw_dn_clear_band", "lw_dn_clear"), ("sw_up_clear_band", "sw_up_clear"),
+             ("sw_dn_clear_band", "sw_dn_clear"), ("sw_dn_direct_clear_band", "sw_dn_direct_clear")]
+    checked = 0
+    for spec, broad in pairs:
+        if spec in f.arrays:
+            assert f.arrays[spec].shape[-1] == (config.n_spec_lw if spec.startswith("lw") else config.n_spec_sw)
+            assert rel_err(f.arrays[spec].sum(axis=-1), f.arrays[broad]) < 1e-13, spec
+            assert np.abs(f.arrays[spec]).max() > 0.0, spec
+            checked += 1
+    assert checked == 10
