@@ -25,8 +25,9 @@ def make_config(sw_solver="Tripleclouds", lw_solver=None, **overrides) -> Config
     c.directory_name = DATA_DIR
     c.i_solver_sw = SOLVER_NAMES.index(sw_solver)
     c.i_solver_lw = SOLVER_NAMES.index(lw_solver or sw_solver)
-    # Spectral flux *profiles* (nspec x ncol x nlev+1 outputs) are outside the implemented scope; the
-    # reference's McICA configuration forces this off too (radiation_config.F90:1331-1334).
+    # Spectral flux *profiles* (nspec x ncol x nlev+1 outputs) are switched off unless a case asks for
+    # them (the *_spectral cases of test_hip_parity.py): they are built for one interval per g-point
+    # only, and the reference's McICA configuration forces them off too (radiation_config.F90:1331-1334).
     c.do_save_spectral_flux = False
     for k, v in overrides.items():
         assert hasattr(c, k), k
