@@ -321,7 +321,8 @@ int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
   const bool mcica = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_MCICA) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_MCICA);
   if (mcica) {
     if (!c.do_clear) return fail(h, ECRAD_EINVAL, "McICA requires clear-sky calculation to be performed");  // radiation_mcica_sw.F90:141
-    if (c.use_vectorizable_generator) return fail(h, ECRAD_EUNSUPPORTED, "use_vectorizable_generator is not implemented");
+    if (c.use_vectorizable_generator && c.i_overlap_scheme == ECRAD_OVERLAP_EXP_EXP)
+      return fail(h, ECRAD_EINVAL, "vectorizable cloud generator is not available with Exp-Exp overlap");   // radiation_cloud_generator.F90:229-232
     if (!c.pdf_sampler.val) return fail(h, ECRAD_EINVAL, "McICA needs the PDF sampler table");
   }
   const bool tc = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_TRIPLECLOUDS) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_TRIPLECLOUDS);
@@ -815,8 +816,11 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
     const size_t lds = lds_bytes(m.hot.nquad, nct);
     if (lw_mcica) {
       HIP_TRY(h, hipMemsetAsync(prep.od_scaling_lw, 0, (size_t)c.n_g_lw * nlev * r.nloc * 8, stream));
-      HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_lw, 997, prep.od_scaling_lw,
-                                        prep.total_cloud_cover_lw, prep.rng_state, mcica_work));
+      if (c.use_vectorizable_generator)
+        HIP_TRY(h, launch_mcica_generator_vec(stream, h->dcfg, din, c.n_g_lw, 997, prep.od_scaling_lw, prep.total_cloud_cover_lw));
+      else
+        HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_lw, 997, prep.od_scaling_lw,
+                                          prep.total_cloud_cover_lw, prep.rng_state, mcica_work));
     }
     if (lw_tc) HIP_TRY(h, launch_lw_tc(h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_lw, counters, m));
     else HIP_TRY(h, launch_lw_ica(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_lw, counters, m));
@@ -828,8 +832,11 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
     const size_t lds = lds_bytes(m.hot.nquad, nct);
     if (sw_mcica) {
       HIP_TRY(h, hipMemsetAsync(prep.od_scaling_sw, 0, (size_t)c.n_g_sw * nlev * r.nloc * 8, stream));
-      HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_sw, 0, prep.od_scaling_sw,
-                                        prep.total_cloud_cover_sw, prep.rng_state, mcica_work));
+      if (c.use_vectorizable_generator)
+        HIP_TRY(h, launch_mcica_generator_vec(stream, h->dcfg, din, c.n_g_sw, 0, prep.od_scaling_sw, prep.total_cloud_cover_sw));
+      else
+        HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_sw, 0, prep.od_scaling_sw,
+                                          prep.total_cloud_cover_sw, prep.rng_state, mcica_work));
     }
     if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m));
     else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m));

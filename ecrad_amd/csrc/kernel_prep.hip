@@ -686,6 +686,178 @@ __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The reference's "vectorizable" generator (use_vectorizable_generator; generate_columns_exp_ran,
+// radiation_cloud_generator.F90:587-734) with its own random-number generator (rng_type /
+// IRngMinstdVector, radiation_random_numbers.F90:126-300): one MINSTD stream per g-point, advanced in
+// lockstep, all operations element-wise over g -- lane = g maps onto it directly.  The reference draws
+// four arrays one after the other from each stream (trigger; rand_cloud for the levels with cloud;
+// rand_inhom for all levels ibegin-1..iend; rand_inhom2 for the levels with cloud); here the level
+// loop consumes the three level-indexed ones together, each from its own copy of the stream advanced
+// to where that array starts (x -> A^k x mod M is itself a MINSTD step with multiplier A^k mod M).
+ECRAD_DEV unsigned long long minstd_step(unsigned long long s, unsigned long long a) { return (a * s) % 2147483647ull; }
+ECRAD_DEV unsigned long long minstd_power(unsigned k) {      // 48271^k mod (2^31-1)
+  unsigned long long r = 1ull, b = 48271ull;
+  while (k) { if (k & 1u) r = (r * b) % 2147483647ull; b = (b * b) % 2147483647ull; k >>= 1; }
+  return r;
+}
+
+// rng%initialize for stream jstr (radiation_random_numbers.F90:168-173):
+//   nint(mod(rseed*jstr*(1 - 0.05*jstr + 0.005*jstr**2)*16807, 2147483647))
+// Every product and sum is rounded on its own (no fused multiply-add): some seeds put the argument of
+// nint exactly half-way between two integers, and a fused operation lands on the other side.
+ECRAD_DEV unsigned long long minstd_seed(int iseed, int jstr) {
+#pragma clang fp contract(off)
+  const double rseed = fabs((double)iseed), dj = (double)jstr;
+  const double t1 = rseed * dj;
+  const double t2 = 0.05 * dj;
+  const double t3 = 0.005 * (double)(jstr * jstr);
+  const double t4 = 1.0 - t2;
+  const double t5 = t4 + t3;
+  const double t6 = t1 * t5;
+  const double x = t6 * 16807.0;
+  return (unsigned long long)llround(fmod(x, 2147483647.0));
+}
+
+template <int NGP>
+__global__ __launch_bounds__(kBlock) void mcica_generator_vec_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, int ng,
+                                                                     int seed_offset, double* od_scaling, double* total_cloud_cover) {
+  const DevConfig& cfg = *cfgp;
+  constexpr int CPB = kBlock / NGP;
+  const int tid = threadIdx.x, glane = tid % NGP, cib = tid / NGP;
+  const int nloc = in.iendcol - in.istartcol + 1;
+  const int nlev = in.nlev;
+  const size_t ncol = in.ncol;
+  const double thr = cfg.cloud_fraction_threshold;
+  const double MaxCloudFrac = 1.0 - 2.220446049250313e-16 * 10.0;
+  const double scale = 1.0 / 2147483647.0;      // IMinstdScale
+  const LevelOrder ord = level_order(in);
+  for (int grp = blockIdx.x; grp * CPB < nloc; grp += gridDim.x) {
+    const int cloc = grp * CPB + cib;
+    if (cloc >= nloc) continue;
+    const int col = in.istartcol - 1 + cloc;
+    const FracView fracv = cloud_fraction_view(in, col);
+    auto FRAC = [&](int lev1) { return fracv.p[fracv.stride * ord.full(lev1 - 1)]; };
+    auto PAIR = [&](int jlev, double f0, double f1) {     // pair_cloud_cover(jlev): layers jlev, jlev+1 (1-based)
+      if (cfg.i_overlap_scheme != ECRAD_OVERLAP_EXP_RAN) return dmax(f0, f1);
+      double alpha = in.cloud_overlap_param[col + ncol * ord.iface(jlev - 1)];
+      if (cfg.use_beta_overlap) {   // beta2alpha, radiation_cloud_cover.F90:51-68
+        if (alpha < 1.0) {
+          const double frac_diff = fabs(f0 - f1);
+          alpha = alpha + (1.0 - alpha) * frac_diff / (frac_diff + 1.0 / alpha - 1.0);
+        } else alpha = 1.0;
+      }
+      return alpha * dmax(f0, f1) + (1.0 - alpha) * (f0 + f1 - f0 * f1);
+    };
+    // pass 1: total cloud cover, first/last cloudy level, number of levels the masked draws cover
+    int ibegin = 0, iend = 0;
+    double tcc;
+    {
+      double f0 = FRAC(1), cum_product = 1.0 - f0;
+      if (f0 > 0.0) { ibegin = 1; iend = 1; }
+      for (int jlev = 1; jlev <= nlev - 1; ++jlev) {
+        const double f1 = FRAC(jlev + 1);
+        if (f1 > 0.0) { if (!ibegin) ibegin = jlev + 1; iend = jlev + 1; }
+        if (f0 >= MaxCloudFrac) cum_product = 0.0;
+        else cum_product = cum_product * (1.0 - PAIR(jlev, f0, f1)) / (1.0 - f0);
+        f0 = f1;
+      }
+      tcc = 1.0 - cum_product;
+    }
+    if (tcc < thr || ibegin == 0) {
+      if (glane == 0) total_cloud_cover[cloc] = 0.0;
+      continue;
+    }
+    if (glane == 0) total_cloud_cover[cloc] = tcc;
+    if (glane >= ng) continue;
+    int nmasked = 0;
+    for (int jlev = ibegin; jlev <= iend; ++jlev) nmasked += FRAC(jlev) >= thr;
+    // rng%initialize(IRngMinstdVector, iseed, nmaxstreams=ng) for stream jstr = g+1; the products are
+    // rounded one by one as in the oracle (no fused multiply-add)
+    unsigned long long s0 = minstd_seed(in.iseed[col] + seed_offset, glane + 1);
+    s0 = minstd_step(s0, 48271ull);                         // one warm-up
+    unsigned long long s_rc = minstd_step(s0, 48271ull);    // the state that produced `trigger`
+    const double trigger = (scale * (double)s_rc) * tcc;
+    unsigned long long s_ri = minstd_step(s_rc, minstd_power((unsigned)nmasked));
+    unsigned long long s_ri2 = minstd_step(s_ri, minstd_power((unsigned)(iend - ibegin + 2)));
+    // pass 2: walk down the cloudy span; cumulative cover is recomputed with the same arithmetic
+    double cum_prev = 0.0, cum_here, f_prev = 0.0, pair_prev = 0.0;
+    {
+      // cumulative cover at level ibegin-1 (0 above the first cloud)
+      double f0 = FRAC(1), cum_product = 1.0 - f0;
+      double cum = f0;
+      for (int jlev = 1; jlev <= ibegin - 1; ++jlev) {
+        const double f1 = FRAC(jlev + 1);
+        const double pr = PAIR(jlev, f0, f1);
+        if (f0 >= MaxCloudFrac) cum_product = 0.0;
+        else cum_product = cum_product * (1.0 - pr) / (1.0 - f0);
+        cum_prev = cum; f_prev = f0; pair_prev = pr;
+        cum = 1.0 - cum_product;
+        f0 = f1;
+      }
+      cum_here = cum;
+      // state for continuing the recurrence inside the loop
+      s_ri = minstd_step(s_ri, 48271ull);
+      double ri_above = scale * (double)s_ri;                // rand_inhom(g, ibegin-1)
+      bool is_cloud = false, found_cloud = false;
+      double fh = f0;                                         // frac(jlev)
+      double* odsc = od_scaling + (size_t)ng * nlev * cloc;
+      for (int jlev = ibegin; jlev <= iend; ++jlev) {
+        s_ri = minstd_step(s_ri, 48271ull);
+        double ri_here = scale * (double)s_ri;                // rand_inhom(g, jlev) as drawn
+        const bool any_cloud = fh >= thr;
+        if (any_cloud) {
+          s_rc = minstd_step(s_rc, 48271ull);
+          s_ri2 = minstd_step(s_ri2, 48271ull);
+          const double rc = scale * (double)s_rc, ri2 = scale * (double)s_ri2;
+          const bool prev_cloud = is_cloud;
+          const bool first_cloud = (trigger <= cum_here) && !found_cloud;
+          found_cloud = found_cloud || first_cloud;
+          const double overhang = cum_here - cum_prev;
+          const bool test = prev_cloud ? (rc * f_prev < fh + f_prev - pair_prev)
+                                       : (rc * (cum_prev - f_prev) < pair_prev - overhang - f_prev);
+          is_cloud = first_cloud || (found_cloud && test);
+          double opi = 0.0;
+          if (jlev >= 2) {
+            opi = in.cloud_overlap_param[col + ncol * ord.iface(jlev - 2)];
+            if (jlev - 1 >= ibegin && jlev - 1 <= iend - 1 && opi > 0.0) opi = pow(opi, 1.0 / cfg.cloud_inhom_decorr_scaling);
+          }
+          const bool keep = (ri2 < opi) && prev_cloud;
+          ri_here = is_cloud ? (keep ? ri_above : ri_here) : 0.0;
+          // masked_block_sample, radiation_pdf_sampler.F90:266-321
+          const double fsd = in.cloud_fractional_std[col + ncol * ord.full(jlev - 1)];
+          odsc[glane + (size_t)ng * (jlev - 1)] = ri_here > 0.0 ? pdf_sample(cfg.pdf, fsd, ri_here) : 0.0;
+        } else {
+          is_cloud = false;
+        }
+        ri_above = ri_here;
+        // advance the cumulative cover to level jlev+1
+        if (jlev < nlev) {
+          const double f1 = FRAC(jlev + 1);
+          const double pr = PAIR(jlev, fh, f1);
+          if (fh >= MaxCloudFrac) cum_product = 0.0;
+          else cum_product = cum_product * (1.0 - pr) / (1.0 - fh);
+          cum_prev = cum_here; f_prev = fh; pair_prev = pr;
+          cum_here = 1.0 - cum_product;
+          fh = f1;
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_mcica_generator_vec(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int ng, int seed_offset,
+                                      double* od_scaling, double* tcc) {
+  const int nloc = in.iendcol - in.istartcol + 1;
+  const int ngp = ng <= 16 ? 16 : (ng <= 32 ? 32 : 64);
+  const int cpb = kBlock / ngp;
+  const int grid = (nloc + cpb - 1) / cpb;
+  if (ngp == 16) hipLaunchKernelGGL((mcica_generator_vec_kernel<16>), dim3(grid), dim3(kBlock), 0, st, cfg, in, ng, seed_offset, od_scaling, tcc);
+  else if (ngp == 32) hipLaunchKernelGGL((mcica_generator_vec_kernel<32>), dim3(grid), dim3(kBlock), 0, st, cfg, in, ng, seed_offset, od_scaling, tcc);
+  else hipLaunchKernelGGL((mcica_generator_vec_kernel<64>), dim3(grid), dim3(kBlock), 0, st, cfg, in, ng, seed_offset, od_scaling, tcc);
+  return hipGetLastError();
+}
+
 size_t mcica_work_doubles(int nlev, int ng, int nloc) { return 0; }
 
 hipError_t launch_mcica_generator(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int ng, int seed_offset,

@@ -40,6 +40,8 @@ hipError_t launch_tripleclouds_prep(hipStream_t st, const DevConfig* cfg, const 
                                     double* cc_sw, double* cc_lw);
 hipError_t launch_mcica_generator(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int ng, int seed_offset,
                                   double* od_scaling, double* tcc, int32_t* rng_state, double* work);
+hipError_t launch_mcica_generator_vec(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int ng, int seed_offset,
+                                      double* od_scaling, double* tcc);
 hipError_t launch_spectral_post(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevFlux& fx);
 hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                               const DevConfig* cfg, const DevInputs& in, const DevOptics& out);

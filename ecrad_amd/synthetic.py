@@ -87,5 +87,6 @@ BENCH_CONFIGS = {
     "tripleclouds_noaer": dict(sw_solver="Tripleclouds", use_aerosols=False, clear_sky=False),
     "tripleclouds_clear_aer": dict(sw_solver="Tripleclouds", use_aerosols=True, clear_sky=True),
     "mcica_noaer": dict(sw_solver="McICA", use_aerosols=False, clear_sky=False),
+    "mcica_vectorizable": dict(sw_solver="McICA", use_aerosols=True, clear_sky=False, use_vectorizable_generator=True),
     "homogeneous_clear_aer": dict(sw_solver="Homogeneous", use_aerosols=True, clear_sky=True),
 }

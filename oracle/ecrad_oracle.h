@@ -85,11 +85,13 @@ typedef struct oracle_rng { int32_t iused; int32_t ix[607]; double zrm; } oracle
 void oracle_initialize_random_numbers(int32_t kseed, oracle_rng_t* s);                /* mix:142 */
 void oracle_uniform_distribution(double* px, int n, oracle_rng_t* s);                 /* mix:237 */
 double oracle_pdf_sample(const ecrad_pdf_sampler_t* p, double fsd, double cdf);       /* pdf:126 */
+void oracle_minstd_initialize(int32_t iseed, int nmaxstreams, uint64_t* istate);   /* radiation_random_numbers.F90:126 */
+void oracle_minstd_uniform(int n, uint64_t* istate, double* randnum);              /* :198 */
 void oracle_cloud_generator(int ng, int nlev, int i_overlap_scheme, int32_t iseed,
      double frac_threshold, const double* frac, const double* overlap_param,
      double decorrelation_scaling, const double* fractional_std,
      const ecrad_pdf_sampler_t* pdf_sampler, double* od_scaling /* (ng,nlev) */,
-     double* total_cloud_cover, int use_beta_overlap);                                /* gen:37 */
+     double* total_cloud_cover, int use_beta_overlap, int use_vectorizable_generator);                                /* gen:37 */
 
 /* ---- stage level --------------------------------------------------------------------------- */
 /* Everything radiation() does before the solvers (radiation_interface.F90:323-401); arrays of

@@ -426,12 +426,105 @@ static void generate_column_exp_exp(int ng, int nlev, int ig, oracle_rng_t* rs,
   free(is_cloudy);
 }
 
-/* radiation_cloud_generator.F90:37-255 (use_vectorizable_generator = false) */
+/* ---- radiation/radiation_random_numbers.F90: rng_type with IRngMinstdVector ------------------- */
+/* :126-191.  The state is held in double precision in the reference (USE_REAL_RNG_STATE) but every
+   value is an exact integer below 2^47, so 64-bit integers give the same sequence. */
+void oracle_minstd_initialize(int32_t iseed, int nmaxstreams, uint64_t* istate)
+{
+  const double rseed = fabs((double)iseed);
+  for (int jstr = 1; jstr <= nmaxstreams; ++jstr) {
+    const double dj = (double)jstr;
+    /* rseed*jstr*(1.0_jprd-0.05_jprd*jstr+0.005_jprd*jstr**2)*IMinstdA0, left to right */
+    volatile double t1 = rseed * dj;
+    volatile double t2 = 0.05 * dj;
+    volatile double t3 = 0.005 * (double)(jstr * jstr);
+    volatile double t4 = 1.0 - t2;
+    volatile double t5 = t4 + t3;
+    volatile double t6 = t1 * t5;
+    volatile double x = t6 * 16807.0;
+    istate[jstr - 1] = (uint64_t)llround(fmod(x, 2147483647.0));
+  }
+  for (int j = 0; j < nmaxstreams; ++j) istate[j] = (48271ull * istate[j]) % 2147483647ull;   /* one warm-up */
+}
+
+/* :198-225: one deviate per stream */
+void oracle_minstd_uniform(int n, uint64_t* istate, double* randnum)
+{
+  const double scale = 1.0 / 2147483647.0;      /* IMinstdScale */
+  for (int i = 0; i < n; ++i) {
+    istate[i] = (48271ull * istate[i]) % 2147483647ull;
+    randnum[i] = scale * (double)istate[i];
+  }
+}
+
+/* radiation_cloud_generator.F90:587-734: the "vectorizable" generator (one MINSTD stream per g-point) */
+static void generate_columns_exp_ran(int ng, int nlev, int32_t iseed, const ecrad_pdf_sampler_t* pdf,
+     double total_cloud_cover, double frac_threshold, const double* frac, const double* pair_cloud_cover,
+     const double* cum_cloud_cover, const double* overhang, const double* fractional_std,
+     const double* overlap_param_inhom, int ibegin, int iend, double* od_scaling)
+{
+  const int nl = iend - ibegin + 1;
+  uint64_t* st = (uint64_t*)malloc(sizeof(uint64_t) * ng);
+  double* trigger = (double*)malloc(sizeof(double) * (size_t)ng * (3 * (nl + 1) + 1));
+  double* rand_cloud = trigger + ng;                       /* (ng, ibegin:iend) */
+  double* rand_inhom = rand_cloud + (size_t)ng * nl;       /* (ng, ibegin-1:iend) */
+  double* rand_inhom2 = rand_inhom + (size_t)ng * (nl + 1);/* (ng, ibegin:iend) */
+  int* flags = (int*)calloc((size_t)ng * 4 + nl, sizeof(int));
+  int *is_cloud = flags, *prev_cloud = flags + ng, *first_cloud = flags + 2 * ng, *found_cloud = flags + 3 * ng;
+  int* is_any_cloud = flags + 4 * ng;
+  for (int k = 0; k < nl; ++k) is_any_cloud[k] = frac[ibegin - 1 + k] >= frac_threshold;
+  oracle_minstd_initialize(iseed, ng, st);
+  oracle_minstd_uniform(ng, st, trigger);
+  for (int k = 0; k < nl; ++k) if (is_any_cloud[k]) oracle_minstd_uniform(ng, st, rand_cloud + (size_t)ng * k);
+  for (int k = 0; k < nl + 1; ++k) oracle_minstd_uniform(ng, st, rand_inhom + (size_t)ng * k);
+  for (int k = 0; k < nl; ++k) if (is_any_cloud[k]) oracle_minstd_uniform(ng, st, rand_inhom2 + (size_t)ng * k);
+  for (int jg = 0; jg < ng; ++jg) trigger[jg] = trigger[jg] * total_cloud_cover;
+  for (int jlev = ibegin; jlev <= iend; ++jlev) {
+    const int k = jlev - ibegin;
+    if (is_any_cloud[k]) {
+      for (int jg = 0; jg < ng; ++jg) {
+        prev_cloud[jg] = is_cloud[jg];
+        first_cloud[jg] = (trigger[jg] <= cum_cloud_cover[jlev - 1]) && !found_cloud[jg];
+        found_cloud[jg] = found_cloud[jg] || first_cloud[jg];
+        const double rc = rand_cloud[jg + (size_t)ng * k];
+        /* frac(jlev-1) etc. are only evaluated by the reference's merge() when jlev-1 >= 1; ibegin == 1
+           makes the reference read frac(0) (out of bounds) with found_cloud possibly true only through
+           first_cloud, so the value cannot matter there */
+        const double f_above = jlev >= 2 ? frac[jlev - 2] : 0.0;
+        const double pair = jlev >= 2 ? pair_cloud_cover[jlev - 2] : 0.0;
+        const double cum_above = jlev >= 2 ? cum_cloud_cover[jlev - 2] : 0.0;
+        const double oh = jlev >= 2 ? overhang[jlev - 2] : 0.0;
+        const int test = prev_cloud[jg] ? (rc * f_above < frac[jlev - 1] + f_above - pair)
+                                        : (rc * (cum_above - f_above) < pair - oh - f_above);
+        is_cloud[jg] = first_cloud[jg] || (found_cloud[jg] && test);
+        const double above = rand_inhom[jg + (size_t)ng * k];           /* rand_inhom(jg,jlev-1) */
+        double* here = &rand_inhom[jg + (size_t)ng * (k + 1)];          /* rand_inhom(jg,jlev) */
+        const double opi = jlev >= 2 ? overlap_param_inhom[jlev - 2] : 0.0;
+        const int keep = (rand_inhom2[jg + (size_t)ng * k] < opi) && prev_cloud[jg];
+        *here = is_cloud[jg] ? (keep ? above : *here) : 0.0;
+      }
+    } else {
+      for (int jg = 0; jg < ng; ++jg) is_cloud[jg] = 0;
+    }
+  }
+  /* pdf_sampler%masked_block_sample (radiation_pdf_sampler.F90:266-321) */
+  for (int k = 0; k < nl; ++k) {
+    if (!is_any_cloud[k]) continue;
+    const int lev = ibegin + k;
+    for (int jg = 0; jg < ng; ++jg) {
+      const double cdf = rand_inhom[jg + (size_t)ng * (k + 1)];
+      od_scaling[jg + (size_t)ng * (lev - 1)] = cdf > 0.0 ? oracle_pdf_sample(pdf, fractional_std[lev - 1], cdf) : 0.0;
+    }
+  }
+  free(st); free(trigger); free(flags);
+}
+
+/* radiation_cloud_generator.F90:37-255 */
 void oracle_cloud_generator(int ng, int nlev, int i_overlap_scheme, int32_t iseed,
      double frac_threshold, const double* frac, const double* overlap_param,
      double decorrelation_scaling, const double* fractional_std,
      const ecrad_pdf_sampler_t* pdf_sampler, double* od_scaling, double* total_cloud_cover,
-     int use_beta_overlap)
+     int use_beta_overlap, int use_vectorizable_generator)
 {
   double* cum_cloud_cover = (double*)malloc(sizeof(double) * nlev * 8);
   double* pair_cloud_cover = cum_cloud_cover + nlev;
@@ -462,6 +555,13 @@ void oracle_cloud_generator(int ng, int nlev, int i_overlap_scheme, int32_t isee
       if (overlap_param[jlev - 1] > 0.0)
         overlap_param_inhom[jlev - 1] = pow(overlap_param[jlev - 1], 1.0 / decorrelation_scaling);
     memset(od_scaling, 0, sizeof(double) * (size_t)ng * nlev);
+    if (use_vectorizable_generator) {      /* :222-240 (not available with Exp-Exp: the caller rejects it) */
+      generate_columns_exp_ran(ng, nlev, iseed, pdf_sampler, *total_cloud_cover, frac_threshold, frac, pair_cloud_cover,
+                               cum_cloud_cover, overhang, fractional_std, overlap_param_inhom, ibegin, iend, od_scaling);
+      free(cum_cloud_cover);
+      free(rand_top);
+      return;
+    }
     oracle_rng_t rs;
     oracle_initialize_random_numbers(iseed, &rs);
     oracle_uniform_distribution(rand_top, ng, &rs);

@@ -585,7 +585,7 @@ void oracle_solver_mcica_sw(const ecrad_config_t* c, int ncol, int nlev, int ist
       double total_cloud_cover;
       oracle_cloud_generator(ng, nlev, c->i_overlap_scheme, in->iseed[jcol], c->cloud_fraction_threshold,
                              frac, ovp, c->cloud_inhom_decorr_scaling, fsd, &c->pdf_sampler, od_scaling,
-                             &total_cloud_cover, c->use_beta_overlap);
+                             &total_cloud_cover, c->use_beta_overlap, c->use_vectorizable_generator);
       flux->cloud_cover_sw[jcol] = total_cloud_cover;
       if (total_cloud_cover >= c->cloud_fraction_threshold) {
         for (int l = 0; l < nlev; ++l) {
@@ -709,7 +709,7 @@ void oracle_solver_mcica_lw(const ecrad_config_t* c, int ncol, int nlev, int ist
     double total_cloud_cover;
     oracle_cloud_generator(ng, nlev, c->i_overlap_scheme, in->iseed[jcol] + 997, c->cloud_fraction_threshold,
                            frac, ovp, c->cloud_inhom_decorr_scaling, fsd, &c->pdf_sampler, od_scaling,
-                           &total_cloud_cover, c->use_beta_overlap);
+                           &total_cloud_cover, c->use_beta_overlap, c->use_vectorizable_generator);
     flux->cloud_cover_lw[jcol] = total_cloud_cover;
     if (total_cloud_cover >= c->cloud_fraction_threshold) {
       int i_cloud_top = nlev + 1;

@@ -180,6 +180,16 @@ contains
 
   ! First n uniform deviates after initialize_random_numbers(iseed) followed by a second request of
   ! m more (exercises the buffering across calls)
+  ! rng_type with IRngMinstdVector (radiation_random_numbers.F90): nblock blocks of nstream deviates
+  subroutine ref_minstd(iseed, nstream, nblock, x) bind(C, name='ref_minstd')
+    use radiation_random_numbers, only : rng_type, IRngMinstdVector
+    integer(c_int), value :: iseed, nstream, nblock
+    real(c_double), intent(out) :: x(nstream, nblock)
+    type(rng_type) :: rng
+    call rng%initialize(IRngMinstdVector, iseed=iseed, nmaxstreams=nstream)
+    call rng%uniform_distribution(x)
+  end subroutine
+
   subroutine ref_random_numbers(iseed, n, x, m, y) bind(C, name='ref_random_numbers')
     use radiation_random_numbers_mix, only : randomnumberstream, initialize_random_numbers, uniform_distribution
     integer(c_int), value :: iseed, n, m

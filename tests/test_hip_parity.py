@@ -26,6 +26,8 @@ CASES = {
     "mcica_noaer": dict(sw_solver="McICA", use_aerosols=False),
     "mcica_maxran": dict(sw_solver="McICA", i_overlap_scheme=0),
     "mcica_expexp": dict(sw_solver="McICA", i_overlap_scheme=2),
+    "mcica_vectorizable": dict(sw_solver="McICA", use_vectorizable_generator=True),
+    "mcica_vectorizable_maxran_beta": dict(sw_solver="McICA", use_vectorizable_generator=True, i_overlap_scheme=0),
     # spectral flux profiles (the reference's ecCKD namelist has do_save_spectral_flux = true)
     "tripleclouds_spectral": dict(sw_solver="Tripleclouds", do_save_spectral_flux=True),
     "homogeneous_spectral": dict(sw_solver="Homogeneous", do_save_spectral_flux=True),

@@ -265,3 +265,21 @@ def test_lagged_fibonacci_rng_is_integer_exact(libs, seed):
     assert np.array_equal(xo, xr)
     assert np.array_equal(yo, yr)
     assert xo.min() >= 0.0 and xo.max() < 1.0
+
+
+@pytest.mark.parametrize("seed", [1, 7, 12345, 2000000000])
+def test_minstd_vector_rng_is_exact(libs, seed):
+    """rng_type with IRngMinstdVector (radiation_random_numbers.F90:126-259), used by the vectorizable
+    cloud generator: every stream's first 50 deviates equal the reference's bit for bit."""
+    ref, ora = libs
+    nstream, nblock = 64, 50
+    xr = np.zeros((nblock, nstream))
+    ref.ref_minstd(C.c_int(seed), C.c_int(nstream), C.c_int(nblock), p(xr))
+    st = np.zeros(nstream, dtype=np.uint64)
+    ora.oracle_minstd_initialize(C.c_int32(seed), C.c_int(nstream), st.ctypes.data_as(C.c_void_p))
+    xo = np.zeros((nblock, nstream))
+    row = np.zeros(nstream)
+    for b in range(nblock):
+        ora.oracle_minstd_uniform(C.c_int(nstream), st.ctypes.data_as(C.c_void_p), p(row))
+        xo[b] = row
+    assert np.array_equal(xo, xr)
