@@ -773,7 +773,6 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
   HIP_TRY(h, h->counters.ensure(256));
   int* counters = reinterpret_cast<int*>(h->counters.p);   // [0] LW kernel, [16] SW kernel work queues
   DevCloudPrep prep{};
-  double* mcica_work = nullptr;
   {
     const size_t n = r.nloc, L = nlev;
     for (int pass = 0; pass < 2; ++pass) {
@@ -786,11 +785,6 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
       }
       if (sw_mcica) { prep.od_scaling_sw = cv.take<double>((size_t)c.n_g_sw * L * n); prep.total_cloud_cover_sw = cv.take<double>(n); }
       if (lw_mcica) { prep.od_scaling_lw = cv.take<double>((size_t)c.n_g_lw * L * n); prep.total_cloud_cover_lw = cv.take<double>(n); }
-      if (sw_mcica || lw_mcica) {
-        prep.rng_state = cv.take<int32_t>(607 * n);
-        const int ngmax = c.n_g_sw > c.n_g_lw ? c.n_g_sw : c.n_g_lw;
-        mcica_work = cv.take<double>(mcica_work_doubles(nlev, ngmax, r.nloc));
-      }
       if (c.do_clouds) cx.din.cloud_fraction_work = cv.take<double>(L * n);
       if (pass == 0) HIP_TRY(h, h->prep.ensure(cv.off));
     }
@@ -820,7 +814,7 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
         HIP_TRY(h, launch_mcica_generator_vec(stream, h->dcfg, din, c.n_g_lw, 997, prep.od_scaling_lw, prep.total_cloud_cover_lw));
       else
         HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_lw, 997, prep.od_scaling_lw,
-                                          prep.total_cloud_cover_lw, prep.rng_state, mcica_work));
+                                          prep.total_cloud_cover_lw));
     }
     if (lw_tc) HIP_TRY(h, launch_lw_tc(h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_lw, counters, m));
     else HIP_TRY(h, launch_lw_ica(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_lw, counters, m));
@@ -836,7 +830,7 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
         HIP_TRY(h, launch_mcica_generator_vec(stream, h->dcfg, din, c.n_g_sw, 0, prep.od_scaling_sw, prep.total_cloud_cover_sw));
       else
         HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_sw, 0, prep.od_scaling_sw,
-                                          prep.total_cloud_cover_sw, prep.rng_state, mcica_work));
+                                          prep.total_cloud_cover_sw));
     }
     if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m));
     else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m));

@@ -168,7 +168,6 @@ struct DevCloudPrep {
   double* od_scaling_lw;
   double* total_cloud_cover_sw;   // [nloc]
   double* total_cloud_cover_lw;   // [nloc]
-  int32_t* rng_state;             // [607][nloc] lagged-Fibonacci state, column fastest
 };
 
 // Argument block of the spectral (lane = g) kernels; see kernarg_block() in kernels_common.h

@@ -160,70 +160,9 @@ hipError_t launch_tripleclouds_prep(hipStream_t st, const DevConfig* cfg, const 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// McICA generator.  One thread per column; all per-column work arrays live in a global slab laid out
-// [k][nloc] so that consecutive lanes touch consecutive addresses.
+// Lagged-Fibonacci generator of utilities/radiation_random_numbers_mix.F90 (p = 273, q = 607, 30-bit
+// words); see the generator kernel below.
 constexpr int JPP = 273, JPQ = 607, JPS = 105, JPMM = 30;
-
-struct RngLane {
-  int32_t* ix;      // points at element 0 for this lane; stride nloc
-  size_t stride;
-  int iused;
-  ECRAD_DEV int32_t& X(int j) const { return ix[(size_t)(j - 1) * stride]; }   // 1-based like the reference
-};
-
-// initialize_random_numbers, radiation_random_numbers_mix.F90:142-231 (integer-exact)
-ECRAD_DEV void rng_next_batch(RngLane& r) {
-  const int32_t IVAR = 0x3FFFFFFF;
-  for (int jj = 1; jj <= JPP; ++jj) r.X(jj) = IVAR & (r.X(jj) + r.X(jj - JPP + JPQ));
-  for (int jj = JPP + 1; jj <= JPQ; ++jj) r.X(jj) = IVAR & (r.X(jj) + r.X(jj - JPP));
-}
-
-// uniform_distribution for ONE deviate at a time is NOT equivalent to the reference when a request
-// straddles a refill (the reference restarts at element 1 of the new batch and discards nothing), so
-// we mirror its batch semantics exactly: rng_draw(n) == CALL UNIFORM_DISTRIBUTION(PX(1:n)).
-template <typename F>
-ECRAD_DEV void rng_draw(RngLane& r, int n, F&& sink) {
-  const double zrm = 1.0 / (double)(1 << JPMM);
-  int ifilled = 0;
-  const int last = (r.iused + n < JPQ) ? r.iused + n : JPQ;
-  for (int jj = r.iused + 1; jj <= last; ++jj) { sink(jj - r.iused - 1, r.X(jj) * zrm); ifilled++; }
-  r.iused += ifilled;
-  while (ifilled < n) {
-    rng_next_batch(r);
-    const int take = (n - ifilled < JPQ) ? n - ifilled : JPQ;
-    r.iused = take;
-    for (int k = 0; k < take; ++k) sink(ifilled + k, r.X(k + 1) * zrm);
-    ifilled += take;
-  }
-}
-
-ECRAD_DEV void rng_init(RngLane& r, int32_t kseed) {
-  const int32_t JPMASK = 123459876;
-  int32_t v = kseed ^ JPMASK;
-  if (v < 0) v = -v;
-  if (v == 0) v = JPMASK;
-  uint32_t idum = (uint32_t)v;
-  for (int jj = 0; jj < 64; ++jj) {
-    if (idum & 0x80000000u) idum = ((idum ^ 87u) << 1) | 1u;
-    else idum = (idum << 1);
-  }
-  for (int j = 1; j <= JPQ - 1; ++j) r.X(j) = 0;
-  r.X(2) = (int32_t)((idum & ((1u << (JPMM - 1)) - 1u)) << 1);
-  r.X(JPQ) = (int32_t)(idum >> (JPMM - 1));
-  for (int jbit = 1; jbit <= JPMM - 1; ++jbit) {
-    for (int jj = 3; jj <= JPQ - 1; ++jj) {
-      if (idum & 0x80000000u) {
-        idum = ((idum ^ 87u) << 1) | 1u;
-        r.X(jj) |= (int32_t)(1u << jbit);
-      } else {
-        idum = (idum << 1);
-      }
-    }
-  }
-  r.X(JPQ - JPS) |= 1;
-  r.iused = JPQ;
-  rng_draw(r, 999, [](int, double) {});   // warm-up
-}
 
 // sample_from_pdf, radiation_pdf_sampler.F90:126-156
 ECRAD_DEV double pdf_sample(const DevPdfSampler& p, double fsd, double cdf) {
@@ -416,7 +355,8 @@ ECRAD_DEV void gen_next_batch(const GenLds& g, int lane) {
   }
 }
 
-// CALL UNIFORM_DISTRIBUTION(dst(1:n)) with the reference's batch semantics (see rng_draw above);
+// CALL UNIFORM_DISTRIBUTION(dst(1:n)) (radiation_random_numbers_mix.F90:237-312): the next n numbers of
+// the stream, refilling the state block when it runs out (nothing is discarded at a refill);
 // dst may be null (warm-up).  iused is wave-uniform.
 ECRAD_DEV void gen_draw(const GenLds& g, int lane, int& iused, int n, double* dst) {
   const double zrm = 1.0 / (double)(1 << JPMM);
@@ -858,10 +798,9 @@ hipError_t launch_mcica_generator_vec(hipStream_t st, const DevConfig* cfg, cons
   return hipGetLastError();
 }
 
-size_t mcica_work_doubles(int nlev, int ng, int nloc) { return 0; }
 
 hipError_t launch_mcica_generator(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int ng, int seed_offset,
-                                  double* od_scaling, double* tcc, int32_t* rng_state, double* work) {
+                                  double* od_scaling, double* tcc) {
   const int nloc = in.iendcol - in.istartcol + 1;
   const size_t lds = mcica_generator_lds_bytes(in.nlev, ng);
   const int grid = nloc < 256 * 32 ? nloc : 256 * 32;

@@ -369,9 +369,11 @@ template <> struct StreamRef<double2> {
 
 // ---- per-block scratch in HBM ----------------------------------------------------------------------
 // Each block owns a private slab reused for every column group it processes (persistent blocks), so
-// the working set stays bounded (and largely L2/Infinity-Cache resident) however many columns a
-// call has.  Array `a`, half-level `lev`: element for thread `tid` at ((a*(nlev+1)+lev)*256 + tid),
-// i.e. every wave reads/writes 512 contiguous bytes.
+// the working set is bounded by the grid, not by the number of columns of a call (it is still ~1 GB
+// for a full grid, i.e. it streams through HBM).  Array `a`, half-level `lev`: element for thread
+// `tid` at ((a*(nlev+1)+lev)*256 + tid), i.e. every wave reads/writes 512 contiguous bytes.
+// (Layout of the Tripleclouds longwave kernel; the other kernels use level-major records of 16-byte
+// pairs, see SwScratch / LwScratch / TcSwScratch.)
 struct Scratch {
   double* base;
   int nlevp1;

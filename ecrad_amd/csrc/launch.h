@@ -20,7 +20,6 @@ size_t sw_ica_scratch_doubles(int mode, int nlev);
 size_t lw_ica_scratch_doubles(int mode, int nlev);
 size_t sw_tc_scratch_doubles(int nlev);
 size_t lw_tc_scratch_doubles(int nlev);
-size_t mcica_work_doubles(int nlev, int ng, int nloc);
 
 hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
@@ -39,7 +38,7 @@ hipError_t launch_crop(hipStream_t st, const DevConfig* cfg, const DevInputs& in
 hipError_t launch_tripleclouds_prep(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevCloudPrep& prep,
                                     double* cc_sw, double* cc_lw);
 hipError_t launch_mcica_generator(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int ng, int seed_offset,
-                                  double* od_scaling, double* tcc, int32_t* rng_state, double* work);
+                                  double* od_scaling, double* tcc);
 hipError_t launch_mcica_generator_vec(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int ng, int seed_offset,
                                       double* od_scaling, double* tcc);
 hipError_t launch_spectral_post(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevFlux& fx);
