@@ -90,7 +90,7 @@ struct SwSpec {
 // `lcb` reuse set 1's records (identical there).  Sums over g are written by the group leader.
 // The records of the next kSwBatch layers are requested before the current batch is consumed, so that
 // each wave keeps 2*kSwBatch layers of scratch reads in flight (the sweep has almost no arithmetic).
-template <int NGP>
+template <int NGP, bool SPEC>
 ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, int nlev, double mu0, double incoming,
                              double sig_top, bool valid, bool col_ok, size_t ncol, int col,
                              double* out_up, double* out_dn, double* out_dir, double weight,
@@ -106,7 +106,7 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
   // between the scratch reads of consecutive layers.
   double keep_u = 0.0, keep_d = 0.0, keep_dir = 0.0;
   auto emit = [&](int l) {
-    if (sp.up && valid) {        // spectral flux profiles (radiation_homogeneous_sw.F90:299-311)
+    if (SPEC && sp.up && valid) {        // spectral flux profiles (radiation_homogeneous_sw.F90:299-311)
       const size_t o = col + ncol * ord.half(l);
       const double dir = mu0 * Fd;
       spec_put(sp.up, sp.ng, sp.g, o, fup);
@@ -165,7 +165,9 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
 // uniform switches of the level loop, gathered once per column group
 enum { SWF_AEROSOLS = 1, SWF_DELTA_GASES = 2 };
 
-template <typename TAB, int NGP, int MODE>
+// SPEC: per-g-point flux profiles wanted (do_save_spectral_flux); a separate instantiation keeps the six
+// extra destinations out of the registers of the common case
+template <typename TAB, int NGP, int MODE, bool SPEC>
 __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
     if (sun_up && !(ECRAD_ABLATE & 4)) {
       double fdn_s = 0.0, fdir_s = 0.0, fup_t = 0.0;
       if (MODE == 0) {
-        sw_flux_sweep<NGP>(s, false, -1, tid, nlev, mu0, incoming, st1.sig, valid, col_ok, ncol, col,
+        sw_flux_sweep<NGP, SPEC>(s, false, -1, tid, nlev, mu0, incoming, st1.sig, valid, col_ok, ncol, col,
                            fx.sw_up, fx.sw_dn, fx.sw_dn_direct, 1.0, nullptr, nullptr, nullptr,
                            have_clear_out ? fx.sw_up_clear : nullptr, fx.sw_dn_clear, fx.sw_dn_direct_clear, ord,
                            SwSpec{fx.sw_up_band, fx.sw_dn_band, fx.sw_dn_direct_band,
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
         const bool do_set2 = (MODE == 1) ? (lcb >= 0 || !have_clear_out) : (tcc >= cloud_fraction_threshold);
         if (have_clear_out) {
           // without a second (cloudy) sweep the total-sky profiles are the clear-sky ones
-          sw_flux_sweep<NGP>(s, false, -1, tid, nlev, mu0, incoming, st1.sig, valid, col_ok, ncol, col,
+          sw_flux_sweep<NGP, SPEC>(s, false, -1, tid, nlev, mu0, incoming, st1.sig, valid, col_ok, ncol, col,
                              fx.sw_up_clear, fx.sw_dn_clear, fx.sw_dn_direct_clear, 1.0, nullptr, nullptr, nullptr,
                              do_set2 ? nullptr : fx.sw_up, fx.sw_dn, fx.sw_dn_direct, ord,
                              SwSpec{fx.sw_up_clear_band, fx.sw_dn_clear_band, fx.sw_dn_direct_clear_band,
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
         }
         if (do_set2) {
           const double w = (MODE == 2) ? tcc : 1.0;
-          sw_flux_sweep<NGP>(s, lcb >= 0, lcb, tid, nlev, mu0, incoming, lcb >= 0 ? st2.sig : st1.sig, valid, col_ok, ncol, col,
+          sw_flux_sweep<NGP, SPEC>(s, lcb >= 0, lcb, tid, nlev, mu0, incoming, lcb >= 0 ? st2.sig : st1.sig, valid, col_ok, ncol, col,
                              fx.sw_up, fx.sw_dn, fx.sw_dn_direct, w, fx.sw_up_clear, fx.sw_dn_clear,
                              fx.sw_dn_direct_clear, nullptr, nullptr, nullptr, ord,
                              SwSpec{fx.sw_up_band, fx.sw_dn_band, fx.sw_dn_direct_band, nullptr, nullptr, nullptr, ng, g},
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
           }
         }
       }
-      if (valid && fx.sw_up_band) {      // radiation_homogeneous_sw.F90:355-368
+      if (SPEC && valid && fx.sw_up_band) {      // radiation_homogeneous_sw.F90:355-368
         for (int l = 0; l <= nlev; ++l) {
           const size_t o = col + ncol * l;
           spec_put(fx.sw_up_band, ng, g, o, 0.0); spec_put(fx.sw_dn_band, ng, g, o, 0.0); spec_put(fx.sw_dn_direct_band, ng, g, o, 0.0);
@@ -442,20 +444,20 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
 #endif
 }
 
-template <typename TAB, int NGP>
+template <typename TAB, int NGP, bool SPEC>
 static hipError_t launch_sw_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const SpectralArgs& args) {
   switch (mode) {
     case ECRAD_SOLVER_CLOUDLESS:
-      ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 0>), lds);
-      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 0>), grid, dim3(kBlock), lds, st, args);
+      ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 0, SPEC>), lds);
+      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 0, SPEC>), grid, dim3(kBlock), lds, st, args);
       break;
     case ECRAD_SOLVER_HOMOGENEOUS:
-      ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 1>), lds);
-      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 1>), grid, dim3(kBlock), lds, st, args);
+      ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 1, SPEC>), lds);
+      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 1, SPEC>), grid, dim3(kBlock), lds, st, args);
       break;
-    default:
-      ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 2>), lds);
-      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 2>), grid, dim3(kBlock), lds, st, args);
+    default:      // McICA never writes spectral profiles (api.hip nulls the destinations)
+      ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 2, false>), lds);
+      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 2, false>), grid, dim3(kBlock), lds, st, args);
       break;
   }
   return hipGetLastError();
@@ -471,7 +473,8 @@ hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds
                          double* scratch, size_t per_block, int* counter, const DevCkdModel& m) {
   dim3 g(grid);
   const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot};
-#define ECRAD_DISPATCH(T, N) return launch_sw_mode<T, N>(mode, g, lds, st, args)
+  const bool spec = fx.sw_up_band != nullptr;
+#define ECRAD_DISPATCH(T, N) return spec ? launch_sw_mode<T, N, true>(mode, g, lds, st, args) : launch_sw_mode<T, N, false>(mode, g, lds, st, args)
   if (table_f32) {
     if (ngp == 16) ECRAD_DISPATCH(float, 16);
     if (ngp == 32) ECRAD_DISPATCH(float, 32);

@@ -809,98 +809,150 @@ hipError_t launch_mcica_generator(hipStream_t st, const DevConfig* cfg, const De
 }
 
 // ---------------------------------------------------------------------------------------------------
-// flux%calc_surface_spectral / calc_toa_spectral (radiation_flux.F90:397-660): one thread per column.
-ECRAD_DEV void indexed_sum(int n, const double* src, const int32_t* ind, int nbin, double* dest) {
-  for (int i = 0; i < nbin; ++i) dest[i] = 0.0;
-  for (int j = 0; j < n; ++j) dest[ind[j] - 1] += src[j];
+// flux%calc_surface_spectral / calc_toa_spectral (radiation_flux.F90:397-660).  One wave per column,
+// lane = g-point / band / albedo interval (all <= 64): the per-g arrays are (ng, ncol), so a column is
+// one contiguous segment and every access is coalesced (a lane-per-column version moved 13x the bytes).
+// Sums keep the reference's order: a band lane adds its g-points in increasing g (indexed_sum, :744-770).
+// No LDS: values are broadcast with v_readlane, and all per-g loads of a column are issued up front.
+constexpr int kPostWaves = 4;
+
+ECRAD_DEV double lane_value(double v, int j) {      // v of lane j (j wave-uniform)
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, j);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), j);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
-__global__ void spectral_post_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevFlux f) {
+// per-lane: sum over j < n (increasing j) of v_j where bin_j == lane; v and bin are held by lane j
+ECRAD_DEV double band_sum(double v, int bin, int n, int lane) {
+  double acc = 0.0;
+  for (int j = 0; j < n; ++j) {
+    const double vj = lane_value(v, j);
+    if (__builtin_amdgcn_readlane(bin, j) == lane) acc += vj;
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(64 * kPostWaves) void spectral_post_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevFlux f) {
   const DevConfig& c = *cfgp;
+  const int lane = threadIdx.x % 64, wave = threadIdx.x / 64;
   const int nloc = in.iendcol - in.istartcol + 1;
-  const int cloc = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cloc >= nloc) return;
-  const size_t jcol = in.istartcol - 1 + cloc;
-  if (c.do_sw && c.do_surface_sw_spectral_flux && f.sw_dn_surf_band) {
-    const int ng = c.n_g_sw, nb = c.n_bands_sw;
-    indexed_sum(ng, f.sw_dn_direct_surf_g + ng * jcol, c.i_band_from_reordered_g_sw, nb, f.sw_dn_direct_surf_band + nb * jcol);
-    indexed_sum(ng, f.sw_dn_diffuse_surf_g + ng * jcol, c.i_band_from_reordered_g_sw, nb, f.sw_dn_surf_band + nb * jcol);
-    for (int jb = 0; jb < nb; ++jb) f.sw_dn_surf_band[jb + nb * jcol] += f.sw_dn_direct_surf_band[jb + nb * jcol];
-    if (c.do_clear && f.sw_dn_surf_clear_band) {
-      indexed_sum(ng, f.sw_dn_direct_surf_clear_g + ng * jcol, c.i_band_from_reordered_g_sw, nb, f.sw_dn_direct_surf_clear_band + nb * jcol);
-      indexed_sum(ng, f.sw_dn_diffuse_surf_clear_g + ng * jcol, c.i_band_from_reordered_g_sw, nb, f.sw_dn_surf_clear_band + nb * jcol);
-      for (int jb = 0; jb < nb; ++jb) f.sw_dn_surf_clear_band[jb + nb * jcol] += f.sw_dn_direct_surf_clear_band[jb + nb * jcol];
-    }
-  }
-  if (c.do_sw && c.do_canopy_fluxes_sw && f.sw_dn_diffuse_surf_canopy) {
-    const int ng = c.n_g_sw, nb = c.n_bands_sw, nc = c.n_canopy_bands_sw;
-    double* dif = f.sw_dn_diffuse_surf_canopy + nc * jcol;
-    double* dir = f.sw_dn_direct_surf_canopy + nc * jcol;
-    if (c.use_canopy_full_spectrum_sw) {
-      for (int i = 0; i < ng; ++i) { dif[i] = f.sw_dn_diffuse_surf_g[i + ng * jcol]; dir[i] = f.sw_dn_direct_surf_g[i + ng * jcol]; }
-    } else if (c.do_nearest_spectral_sw_albedo) {
-      for (int i = 0; i < nc; ++i) { dif[i] = 0.0; dir[i] = 0.0; }
-      for (int jg = 0; jg < ng; ++jg) {
-        const int ia = c.i_albedo_from_band_sw[c.i_band_from_reordered_g_sw[jg] - 1] - 1;
-        dir[ia] += f.sw_dn_direct_surf_g[jg + ng * jcol];
-        dif[ia] += f.sw_dn_diffuse_surf_g[jg + ng * jcol];
+  const int ngs = c.do_sw ? c.n_g_sw : 0, ngl = c.do_lw ? c.n_g_lw : 0;
+  const int nbs = c.n_bands_sw, nbl = c.n_bands_lw;
+  // 0-based band (and albedo / emissivity interval) of this lane's g-point; -1 beyond the spectrum
+  const int ib_sw = lane < ngs ? c.i_band_from_reordered_g_sw[lane] - 1 : -1;
+  const int ib_lw = lane < ngl ? c.i_band_from_reordered_g_lw[lane] - 1 : -1;
+  const bool sw_bands = c.do_sw && c.do_surface_sw_spectral_flux && f.sw_dn_surf_band;
+  const bool sw_bands_clear = sw_bands && c.do_clear && f.sw_dn_surf_clear_band;
+  const bool sw_canopy = c.do_sw && c.do_canopy_fluxes_sw && f.sw_dn_diffuse_surf_canopy;
+  const bool lw_canopy = c.do_lw && c.do_canopy_fluxes_lw && f.lw_dn_surf_canopy;
+  const bool sw_toa = c.do_toa_spectral_flux && c.do_sw && f.sw_up_toa_band;
+  const bool lw_toa = c.do_toa_spectral_flux && c.do_lw && f.lw_up_toa_band;
+  const int ia_sw = (sw_canopy && c.do_nearest_spectral_sw_albedo && ib_sw >= 0) ? c.i_albedo_from_band_sw[ib_sw] - 1 : -1;
+  const int ia_lw = (lw_canopy && c.do_nearest_spectral_lw_emiss && ib_lw >= 0) ? c.i_emiss_from_band_lw[ib_lw] - 1 : -1;
+  for (int cloc = blockIdx.x * kPostWaves + wave; cloc < nloc; cloc += gridDim.x * kPostWaves) {
+    const size_t jcol = in.istartcol - 1 + cloc;
+    const size_t os = lane + (size_t)ngs * jcol, ol = lane + (size_t)ngl * jcol;
+    const bool ls = lane < ngs, ll = lane < ngl;
+    auto get = [](bool on, const double* p, size_t o) { return (on && p) ? p[o] : 0.0; };
+    const double g_dir = get(ls && (sw_bands || sw_canopy), f.sw_dn_direct_surf_g, os);
+    const double g_dif = get(ls && (sw_bands || sw_canopy), f.sw_dn_diffuse_surf_g, os);
+    const double g_dirc = get(ls && sw_bands_clear, f.sw_dn_direct_surf_clear_g, os);
+    const double g_difc = get(ls && sw_bands_clear, f.sw_dn_diffuse_surf_clear_g, os);
+    const double g_lwdn = get(ll && lw_canopy, f.lw_dn_surf_g, ol);
+    const double t_sdn = get(ls && sw_toa && f.sw_dn_toa_band, f.sw_dn_toa_g, os);
+    const double t_sup = get(ls && sw_toa, f.sw_up_toa_g, os);
+    const double t_supc = get(ls && sw_toa && c.do_clear && f.sw_up_toa_clear_band, f.sw_up_toa_clear_g, os);
+    const double t_lup = get(ll && lw_toa, f.lw_up_toa_g, ol);
+    const double t_lupc = get(ll && lw_toa && c.do_clear && f.lw_up_toa_clear_band, f.lw_up_toa_clear_g, ol);
+    // ---- shortwave surface (:397-480) ----------------------------------------------------------------
+    double b_dir = 0.0, b_tot = 0.0;
+    if (sw_bands) {
+      b_dir = band_sum(g_dir, ib_sw, ngs, lane);
+      b_tot = band_sum(g_dif, ib_sw, ngs, lane) + b_dir;       // :424-428
+      if (lane < nbs) {
+        f.sw_dn_direct_surf_band[lane + nbs * jcol] = b_dir;
+        f.sw_dn_surf_band[lane + nbs * jcol] = b_tot;
       }
-    } else {
-      const int nalb = c.n_albedo_intervals_sw;
-      for (int i = 0; i < nc; ++i) { dif[i] = 0.0; dir[i] = 0.0; }
-      for (int jb = 0; jb < nb; ++jb)
-        for (int ja = 0; ja < nalb; ++ja) {
-          const double w = c.sw_albedo_weights[ja + nalb * jb];
-          if (w != 0.0) {
-            dif[ja] = dif[ja] + w * f.sw_dn_surf_band[jb + nb * jcol];
-            dir[ja] = dir[ja] + w * f.sw_dn_direct_surf_band[jb + nb * jcol];
-          }
-        }
-      for (int i = 0; i < nc; ++i) dif[i] = dif[i] - dir[i];
-    }
-  }
-  if (c.do_lw && c.do_canopy_fluxes_lw && f.lw_dn_surf_canopy) {
-    const int ng = c.n_g_lw, nb = c.n_bands_lw, nc = c.n_canopy_bands_lw;
-    double* can = f.lw_dn_surf_canopy + nc * jcol;
-    if (c.use_canopy_full_spectrum_lw) {
-      for (int i = 0; i < ng; ++i) can[i] = f.lw_dn_surf_g[i + ng * jcol];
-    } else if (c.do_nearest_spectral_lw_emiss) {
-      for (int i = 0; i < nc; ++i) can[i] = 0.0;
-      for (int jg = 0; jg < ng; ++jg)
-        can[c.i_emiss_from_band_lw[c.i_band_from_reordered_g_lw[jg] - 1] - 1] += f.lw_dn_surf_g[jg + ng * jcol];
-    } else {
-      const int nalb = c.n_emiss_intervals_lw;
-      for (int i = 0; i < nc; ++i) can[i] = 0.0;
-      for (int jg = 0; jg < ng; ++jg) {   // == indexed_sum to bands then weights (radiation_flux.F90:540-566)
-        const int jb = c.i_band_from_reordered_g_lw[jg] - 1;
-        for (int ja = 0; ja < nalb; ++ja) {
-          const double w = c.lw_emiss_weights[ja + nalb * jb];
-          if (w != 0.0) can[ja] = can[ja] + w * f.lw_dn_surf_g[jg + ng * jcol];
+      if (sw_bands_clear) {
+        const double cd = band_sum(g_dirc, ib_sw, ngs, lane);
+        const double ct = band_sum(g_difc, ib_sw, ngs, lane) + cd;
+        if (lane < nbs) {
+          f.sw_dn_direct_surf_clear_band[lane + nbs * jcol] = cd;
+          f.sw_dn_surf_clear_band[lane + nbs * jcol] = ct;
         }
       }
     }
-  }
-  if (c.do_toa_spectral_flux) {
-    if (c.do_sw && f.sw_up_toa_band) {
-      const int ng = c.n_g_sw, nb = c.n_bands_sw;
-      if (f.sw_dn_toa_band && f.sw_dn_toa_g)
-        indexed_sum(ng, f.sw_dn_toa_g + ng * jcol, c.i_band_from_reordered_g_sw, nb, f.sw_dn_toa_band + nb * jcol);
-      indexed_sum(ng, f.sw_up_toa_g + ng * jcol, c.i_band_from_reordered_g_sw, nb, f.sw_up_toa_band + nb * jcol);
-      if (c.do_clear && f.sw_up_toa_clear_band)
-        indexed_sum(ng, f.sw_up_toa_clear_g + ng * jcol, c.i_band_from_reordered_g_sw, nb, f.sw_up_toa_clear_band + nb * jcol);
+    if (sw_canopy) {
+      const int nc = c.n_canopy_bands_sw;
+      double* dif = f.sw_dn_diffuse_surf_canopy + nc * jcol;
+      double* dir = f.sw_dn_direct_surf_canopy + nc * jcol;
+      if (c.use_canopy_full_spectrum_sw) {
+        if (ls) { dif[lane] = g_dif; dir[lane] = g_dir; }
+      } else if (c.do_nearest_spectral_sw_albedo) {
+        const double sd = band_sum(g_dir, ia_sw, ngs, lane);
+        const double sf = band_sum(g_dif, ia_sw, ngs, lane);
+        if (lane < nc) { dir[lane] = sd; dif[lane] = sf; }
+      } else {                               // :466-480 (uses the band sums above, as the reference does)
+        const int nalb = c.n_albedo_intervals_sw;
+        double sd = 0.0, sf = 0.0;
+        for (int jb = 0; jb < nbs; ++jb) {
+          const double w = lane < nc ? c.sw_albedo_weights[lane + nalb * jb] : 0.0;
+          const double bt = lane_value(b_tot, jb), bd = lane_value(b_dir, jb);
+          if (w != 0.0) { sf = sf + w * bt; sd = sd + w * bd; }
+        }
+        if (lane < nc) { dif[lane] = sf - sd; dir[lane] = sd; }
+      }
     }
-    if (c.do_lw && f.lw_up_toa_band) {
-      const int ng = c.n_g_lw, nb = c.n_bands_lw;
-      indexed_sum(ng, f.lw_up_toa_g + ng * jcol, c.i_band_from_reordered_g_lw, nb, f.lw_up_toa_band + nb * jcol);
-      if (c.do_clear && f.lw_up_toa_clear_band)
-        indexed_sum(ng, f.lw_up_toa_clear_g + ng * jcol, c.i_band_from_reordered_g_lw, nb, f.lw_up_toa_clear_band + nb * jcol);
+    // ---- longwave canopy (:500-566) ---------------------------------------------------------------------
+    if (lw_canopy) {
+      const int nc = c.n_canopy_bands_lw;
+      double* can = f.lw_dn_surf_canopy + nc * jcol;
+      if (c.use_canopy_full_spectrum_lw) {
+        if (ll) can[lane] = g_lwdn;
+      } else if (c.do_nearest_spectral_lw_emiss) {
+        const double sv = band_sum(g_lwdn, ia_lw, ngl, lane);
+        if (lane < nc) can[lane] = sv;
+      } else {                               // == indexed_sum to bands then weights (:540-566)
+        const int nalb = c.n_emiss_intervals_lw;
+        double sv = 0.0;
+        for (int jg = 0; jg < ngl; ++jg) {
+          const int jb = __builtin_amdgcn_readlane(ib_lw, jg);
+          const double w = lane < nc ? c.lw_emiss_weights[lane + nalb * jb] : 0.0;
+          const double v = lane_value(g_lwdn, jg);
+          if (w != 0.0) sv = sv + w * v;
+        }
+        if (lane < nc) can[lane] = sv;
+      }
+    }
+    // ---- top-of-atmosphere spectral fluxes (:579-660) ------------------------------------------------
+    if (sw_toa) {
+      if (f.sw_dn_toa_band && f.sw_dn_toa_g) {
+        const double v = band_sum(t_sdn, ib_sw, ngs, lane);
+        if (lane < nbs) f.sw_dn_toa_band[lane + nbs * jcol] = v;
+      }
+      const double v = band_sum(t_sup, ib_sw, ngs, lane);
+      if (lane < nbs) f.sw_up_toa_band[lane + nbs * jcol] = v;
+      if (c.do_clear && f.sw_up_toa_clear_band) {
+        const double vc = band_sum(t_supc, ib_sw, ngs, lane);
+        if (lane < nbs) f.sw_up_toa_clear_band[lane + nbs * jcol] = vc;
+      }
+    }
+    if (lw_toa) {
+      const double v = band_sum(t_lup, ib_lw, ngl, lane);
+      if (lane < nbl) f.lw_up_toa_band[lane + nbl * jcol] = v;
+      if (c.do_clear && f.lw_up_toa_clear_band) {
+        const double vc = band_sum(t_lupc, ib_lw, ngl, lane);
+        if (lane < nbl) f.lw_up_toa_clear_band[lane + nbl * jcol] = vc;
+      }
     }
   }
 }
 
 hipError_t launch_spectral_post(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevFlux& fx) {
   const int nloc = in.iendcol - in.istartcol + 1;
-  hipLaunchKernelGGL(spectral_post_kernel, dim3((nloc + 127) / 128), dim3(128), 0, st, cfg, in, fx);
+  const int blocks = (nloc + kPostWaves - 1) / kPostWaves;
+  hipLaunchKernelGGL(spectral_post_kernel, dim3(blocks < 256 * 16 ? blocks : 256 * 16), dim3(64 * kPostWaves), 0, st, cfg, in, fx);
   return hipGetLastError();
 }
 
