@@ -824,7 +824,9 @@ ECRAD_DEV double lane_value(double v, int j) {      // v of lane j (j wave-unifo
 }
 
 // per-lane: sum over j < n (increasing j) of v_j where bin_j == lane; v and bin are held by lane j
-ECRAD_DEV double band_sum(double v, int bin, int n, int lane) {
+// (`one_to_one`: bin_j == j for all j, e.g. ecCKD with cloud/aerosol optics per g-point -- the sum is v itself)
+ECRAD_DEV double band_sum(double v, int bin, int n, int lane, bool one_to_one) {
+  if (one_to_one) return 0.0 + v;
   double acc = 0.0;
   for (int j = 0; j < n; ++j) {
     const double vj = lane_value(v, j);
@@ -848,6 +850,20 @@ __global__ __launch_bounds__(64 * kPostWaves) void spectral_post_kernel(const De
   const bool lw_canopy = c.do_lw && c.do_canopy_fluxes_lw && f.lw_dn_surf_canopy;
   const bool sw_toa = c.do_toa_spectral_flux && c.do_sw && f.sw_up_toa_band;
   const bool lw_toa = c.do_toa_spectral_flux && c.do_lw && f.lw_up_toa_band;
+  // canopy weight matrices (config constants, a few KB) staged in LDS: the weighted sums below read one
+  // weight per band and lane, and from global memory that latency is what the kernel would wait on
+  constexpr int kWeightCap = 2048;
+  __shared__ double wl[kWeightCap];
+  const int nw_sw = (sw_canopy && !c.use_canopy_full_spectrum_sw && !c.do_nearest_spectral_sw_albedo) ? c.n_albedo_intervals_sw * nbs : 0;
+  const int nw_lw = (lw_canopy && !c.use_canopy_full_spectrum_lw && !c.do_nearest_spectral_lw_emiss) ? c.n_emiss_intervals_lw * nbl : 0;
+  const bool w_lds = nw_sw + nw_lw <= kWeightCap;
+  if (w_lds) {
+    for (int i = threadIdx.x; i < nw_sw; i += blockDim.x) wl[i] = c.sw_albedo_weights[i];
+    for (int i = threadIdx.x; i < nw_lw; i += blockDim.x) wl[nw_sw + i] = c.lw_emiss_weights[i];
+    __syncthreads();
+  }
+  const bool id_sw = nbs == ngs && __ballot(lane < ngs && ib_sw != lane) == 0;     // wave-uniform
+  const bool id_lw = nbl == ngl && __ballot(lane < ngl && ib_lw != lane) == 0;
   const int ia_sw = (sw_canopy && c.do_nearest_spectral_sw_albedo && ib_sw >= 0) ? c.i_albedo_from_band_sw[ib_sw] - 1 : -1;
   const int ia_lw = (lw_canopy && c.do_nearest_spectral_lw_emiss && ib_lw >= 0) ? c.i_emiss_from_band_lw[ib_lw] - 1 : -1;
   for (int cloc = blockIdx.x * kPostWaves + wave; cloc < nloc; cloc += gridDim.x * kPostWaves) {
@@ -868,15 +884,15 @@ __global__ __launch_bounds__(64 * kPostWaves) void spectral_post_kernel(const De
     // ---- shortwave surface (:397-480) ----------------------------------------------------------------
     double b_dir = 0.0, b_tot = 0.0;
     if (sw_bands) {
-      b_dir = band_sum(g_dir, ib_sw, ngs, lane);
-      b_tot = band_sum(g_dif, ib_sw, ngs, lane) + b_dir;       // :424-428
+      b_dir = band_sum(g_dir, ib_sw, ngs, lane, id_sw);
+      b_tot = band_sum(g_dif, ib_sw, ngs, lane, id_sw) + b_dir;       // :424-428
       if (lane < nbs) {
         f.sw_dn_direct_surf_band[lane + nbs * jcol] = b_dir;
         f.sw_dn_surf_band[lane + nbs * jcol] = b_tot;
       }
       if (sw_bands_clear) {
-        const double cd = band_sum(g_dirc, ib_sw, ngs, lane);
-        const double ct = band_sum(g_difc, ib_sw, ngs, lane) + cd;
+        const double cd = band_sum(g_dirc, ib_sw, ngs, lane, id_sw);
+        const double ct = band_sum(g_difc, ib_sw, ngs, lane, id_sw) + cd;
         if (lane < nbs) {
           f.sw_dn_direct_surf_clear_band[lane + nbs * jcol] = cd;
           f.sw_dn_surf_clear_band[lane + nbs * jcol] = ct;
@@ -890,14 +906,14 @@ __global__ __launch_bounds__(64 * kPostWaves) void spectral_post_kernel(const De
       if (c.use_canopy_full_spectrum_sw) {
         if (ls) { dif[lane] = g_dif; dir[lane] = g_dir; }
       } else if (c.do_nearest_spectral_sw_albedo) {
-        const double sd = band_sum(g_dir, ia_sw, ngs, lane);
-        const double sf = band_sum(g_dif, ia_sw, ngs, lane);
+        const double sd = band_sum(g_dir, ia_sw, ngs, lane, false);
+        const double sf = band_sum(g_dif, ia_sw, ngs, lane, false);
         if (lane < nc) { dir[lane] = sd; dif[lane] = sf; }
       } else {                               // :466-480 (uses the band sums above, as the reference does)
         const int nalb = c.n_albedo_intervals_sw;
         double sd = 0.0, sf = 0.0;
         for (int jb = 0; jb < nbs; ++jb) {
-          const double w = lane < nc ? c.sw_albedo_weights[lane + nalb * jb] : 0.0;
+          const double w = lane < nc ? (w_lds ? wl[lane + nalb * jb] : c.sw_albedo_weights[lane + nalb * jb]) : 0.0;
           const double bt = lane_value(b_tot, jb), bd = lane_value(b_dir, jb);
           if (w != 0.0) { sf = sf + w * bt; sd = sd + w * bd; }
         }
@@ -911,14 +927,14 @@ __global__ __launch_bounds__(64 * kPostWaves) void spectral_post_kernel(const De
       if (c.use_canopy_full_spectrum_lw) {
         if (ll) can[lane] = g_lwdn;
       } else if (c.do_nearest_spectral_lw_emiss) {
-        const double sv = band_sum(g_lwdn, ia_lw, ngl, lane);
+        const double sv = band_sum(g_lwdn, ia_lw, ngl, lane, false);
         if (lane < nc) can[lane] = sv;
       } else {                               // == indexed_sum to bands then weights (:540-566)
         const int nalb = c.n_emiss_intervals_lw;
         double sv = 0.0;
         for (int jg = 0; jg < ngl; ++jg) {
           const int jb = __builtin_amdgcn_readlane(ib_lw, jg);
-          const double w = lane < nc ? c.lw_emiss_weights[lane + nalb * jb] : 0.0;
+          const double w = lane < nc ? (w_lds ? wl[nw_sw + lane + nalb * jb] : c.lw_emiss_weights[lane + nalb * jb]) : 0.0;
           const double v = lane_value(g_lwdn, jg);
           if (w != 0.0) sv = sv + w * v;
         }
@@ -928,21 +944,21 @@ __global__ __launch_bounds__(64 * kPostWaves) void spectral_post_kernel(const De
     // ---- top-of-atmosphere spectral fluxes (:579-660) ------------------------------------------------
     if (sw_toa) {
       if (f.sw_dn_toa_band && f.sw_dn_toa_g) {
-        const double v = band_sum(t_sdn, ib_sw, ngs, lane);
+        const double v = band_sum(t_sdn, ib_sw, ngs, lane, id_sw);
         if (lane < nbs) f.sw_dn_toa_band[lane + nbs * jcol] = v;
       }
-      const double v = band_sum(t_sup, ib_sw, ngs, lane);
+      const double v = band_sum(t_sup, ib_sw, ngs, lane, id_sw);
       if (lane < nbs) f.sw_up_toa_band[lane + nbs * jcol] = v;
       if (c.do_clear && f.sw_up_toa_clear_band) {
-        const double vc = band_sum(t_supc, ib_sw, ngs, lane);
+        const double vc = band_sum(t_supc, ib_sw, ngs, lane, id_sw);
         if (lane < nbs) f.sw_up_toa_clear_band[lane + nbs * jcol] = vc;
       }
     }
     if (lw_toa) {
-      const double v = band_sum(t_lup, ib_lw, ngl, lane);
+      const double v = band_sum(t_lup, ib_lw, ngl, lane, id_lw);
       if (lane < nbl) f.lw_up_toa_band[lane + nbl * jcol] = v;
       if (c.do_clear && f.lw_up_toa_clear_band) {
-        const double vc = band_sum(t_lupc, ib_lw, ngl, lane);
+        const double vc = band_sum(t_lupc, ib_lw, ngl, lane, id_lw);
         if (lane < nbl) f.lw_up_toa_clear_band[lane + nbl * jcol] = vc;
       }
     }
