@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
       if (do_clear) fx.sw_up_toa_clear_g[og] = fup_c;
     }
     LevelSums<NGP, 6> kept;
-    for (int hl = 0; hl <= nlev; ++hl) {
+    for (int hl = 0; hl <= ((ECRAD_ABLATE & 4) ? 0 : nlev); ++hl) {
       if (hl > 0) {
         const int l = hl - 1;
         if (do_clear) {
@@ -349,11 +349,81 @@ hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream
 // ===================================================================================================
 // Longwave
 // ===================================================================================================
-constexpr int LT_T1 = 0, LT_SU1 = 1, LT_SD1 = 2;          // clear-sky layer coefficients (region 1)
-ECRAD_DEV int lw_coef(int k, int r /*1,2*/) { return 3 + k * 2 + (r - 1); }   // k: 0 R,1 T,2 su,3 sd -> 3..10
-constexpr int LT_TA = 11;     // total_albedo[3]   11..13
-constexpr int LT_TS = 14;     // total_source[3]   14..16
-constexpr int LW_TC_NUM = 17;
+// Four vertical sweeps with level-major records of 16-byte pairs in the block's scratch slab, every
+// sweep requesting the records of the next layer before it works on the current one:
+//   A  top -> surface   optics, layer coefficients, clear-sky downward flux (as in the ICA kernel)
+//   B  surface -> top   clear-sky upward flux; below cloud top the total albedo / source recurrences
+//                       (radiation_tripleclouds_lw.F90:392-445) and, per region, the record of sweep C;
+//                       above cloud top the all-sky upward flux (:447-470)
+//   C  cloud top -> surface  fluxes in the three regions (:472-540)
+//   D  surface -> top   lw_derivatives (calc_lw_derivatives_region)
+// Per layer, 24 planes of 256 doubles:
+//   sweep A writes   pair (T1, SU1), single SD1, regions 2-3: pair (R, T), pair (SU, SD)
+//   sweep B writes   per region: pair (a1, c), pair (ts, ta) so that sweep C is
+//                    fdn <- a1 fdn + c,  fup = ts + ta fdn   (ts, ta: total source / albedo just below)
+struct TcLwScratch {
+  double* base;
+  ECRAD_DEV StreamRef<double2> pair(int plane, int lev, int tid) const {
+    return {reinterpret_cast<double2*>(base + ((size_t)lev * 24 + plane) * kBlock) + tid};
+  }
+  ECRAD_DEV StreamRef<double> single(int plane, int lev, int tid) const {
+    return {base + ((size_t)lev * 24 + plane) * kBlock + tid};
+  }
+};
+constexpr int TL_A0 = 0, TL_SD1 = 2;
+ECRAD_DEV constexpr int TL_RT(int r /*1,2*/) { return 4 + 4 * (r - 1); }     // (R, T)
+ECRAD_DEV constexpr int TL_SS(int r /*1,2*/) { return 6 + 4 * (r - 1); }     // (SU, SD)
+ECRAD_DEV constexpr int TL_D(int r /*0..2*/) { return 12 + 4 * r; }          // (a1, c)
+ECRAD_DEV constexpr int TL_DT(int r /*0..2*/) { return 14 + 4 * r; }         // (ts, ta)
+constexpr int LW_TC_PLANES = 24;
+
+// Per-column geometry of one level for the sweeps (3 region fractions, v_matrix, u_matrix: 21 values
+// that all lanes of a column need).  Lane q of the column group loads item q of the NEXT level while
+// the current one is processed -- one load instruction per level instead of 21, off the critical
+// path -- and the items reach the other lanes through the group's level-record area in LDS, which is
+// idle during the sweeps and private to the wave.
+template <int NGP>
+struct GeoFeed {
+  static constexpr int NI = 21, PER = (NI + NGP - 1) / NGP;
+  const double* src[PER];
+  int maxlev[PER];
+  double held[PER];
+  size_t stride;
+  double* stage;
+  int glane;
+  ECRAD_DEV void init(const DevCloudPrep& p, int nloc, int nlev, int cloc, double* lds_stage, int lane_in_group) {
+    stride = nloc; stage = lds_stage; glane = lane_in_group;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int q = glane + u * NGP;
+      held[u] = 0.0;
+      if (q < 3) { src[u] = p.region_fracs + (size_t)q * nlev * nloc + cloc; maxlev[u] = nlev - 1; }
+      else if (q < 12) { src[u] = p.v_matrix + (size_t)(q - 3) * (nlev + 1) * nloc + cloc; maxlev[u] = nlev; }
+      else if (q < NI) { src[u] = p.u_matrix + (size_t)(q - 12) * (nlev + 1) * nloc + cloc; maxlev[u] = nlev; }
+      else { src[u] = p.region_fracs + cloc; maxlev[u] = 0; }
+    }
+  }
+  // fractions of layer `lev`, matrices of half level `lev`
+  ECRAD_DEV void request(int lev) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int l = lev < 0 ? 0 : (lev > maxlev[u] ? maxlev[u] : lev);
+      held[u] = src[u][stride * l];
+    }
+  }
+  ECRAD_DEV void publish() {
+    wave_sync();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int q = glane + u * NGP;
+      if (q < NI) stage[q] = held[u];
+    }
+    wave_sync();
+  }
+  ECRAD_DEV double frac(int r) const { return stage[r]; }
+  ECRAD_DEV double v(int i, int j) const { return stage[3 + i + 3 * j]; }
+  ECRAD_DEV double u(int i, int j) const { return stage[12 + i + 3 * j]; }
+};
 
 template <typename TAB, int NGP>
 __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(SpectralArgs args_in_kernarg) {
@@ -381,7 +451,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
     const int grp = next_group;
     if (grp >= ngroups) break;
     const LdsLayout L = make_lds(smem, m.hot.nquad, cfg.n_cloud_types);
-    const Scratch s{a.scratch + (size_t)blockIdx.x * a.per_block, nlev + 1};
+    const TcLwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block};
     const int g = glane < ng ? glane : ng - 1;
     const int ib = cfg.i_band_from_reordered_g_lw[g] - 1;
     const bool do_clear = cfg.do_clear != 0;
@@ -442,9 +512,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
           od = od + aerosol_layer<false>(b.cfg, b.in, L, slot, col, lev, ib).od;
         }
         const LwCoef c = no_scattering_lw(od, planck_top, planck_bot);
-        s.at(LT_T1, lev, tid) = c.transmittance;
-        s.at(LT_SU1, lev, tid) = c.source_up;
-        s.at(LT_SD1, lev, tid) = c.source_dn;
+        s.pair(TL_A0, lev, tid) = make_double2(c.transmittance, c.source_up);
+        s.single(TL_SD1, lev, tid) = c.source_dn;
         if (L.D(F_FRAC, slot) > 0.0) {
           if (!cloudy.any()) { ict = lev; fdn_ctop = fdn_c; }
           cloudy.set(lev);
@@ -462,10 +531,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
             } else {
               c2 = no_scattering_lw(od_total, planck_top, planck_bot);
             }
-            s.at(lw_coef(0, jreg), lev, tid) = c2.reflectance;
-            s.at(lw_coef(1, jreg), lev, tid) = c2.transmittance;
-            s.at(lw_coef(2, jreg), lev, tid) = c2.source_up;
-            s.at(lw_coef(3, jreg), lev, tid) = c2.source_dn;
+            s.pair(TL_RT(jreg), lev, tid) = make_double2(c2.reflectance, c2.transmittance);
+            s.pair(TL_SS(jreg), lev, tid) = make_double2(c2.source_up, c2.source_dn);
           }
         }
         fdn_c = c.transmittance * fdn_c + c.source_dn;
@@ -486,181 +553,258 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
     }
     if (!cloudy.any()) { ict = nlev; fdn_ctop = fdn_c; }
     const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
+    if (ECRAD_ABLATE & 4) continue;
 
-    // ---- clear-sky upward sweep (calc_fluxes_no_scattering_lw) ---------------------------------------
-    {
-      double fup = emission + albedo * fdn_c;
-      double su = group_sum<NGP>(valid ? fup : 0.0);
-      if (lead && do_clear) fx.lw_up_clear[col + ncol * ord.half(nlev)] = su;
-      if (valid && do_clear) spec_put(fx.lw_up_clear_band, ng, g, col + ncol * ord.half(nlev), fup);
-      double keep_up = 0.0;
-      for (int l = nlev - 1; l >= 0; --l) {
-        fup = s.at(LT_T1, l, tid) * fup + s.at(LT_SU1, l, tid);
-        if (valid && do_clear) spec_put(fx.lw_up_clear_band, ng, g, col + ncol * ord.half(l), fup);
-        if (do_clear) {
-          su = group_sum<NGP>(valid ? fup : 0.0);
-          if ((l & (NGP - 1)) == glane) keep_up = su;
-          if ((l & (NGP - 1)) == 0) {
-            const int lv = l + glane;
-            if (col_ok && lv < nlev) fx.lw_up_clear[col + ncol * ord.half(lv)] = keep_up;
-          }
-        }
-      }
-      if (valid && do_clear) {
-        const size_t og = g + (size_t)ng * col;
-        fx.lw_dn_surf_clear_g[og] = fdn_c;
-        fx.lw_up_toa_clear_g[og] = fup;
-      }
-    }
-
-    // ---- upward sweep from the surface to cloud top (radiation_tripleclouds_lw.F90:392-445) -------
-    double ta[3], ts[3];
+    // wave-uniform first layer at or below a cloud top among the wave's columns
+    int ict_min = nlev;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      ts[r] = geo.frac(r, nlev - 1) * emission;
-      ta[r] = albedo;
-      s.at(LT_TA + r, nlev, tid) = ta[r];
-      s.at(LT_TS + r, nlev, tid) = ts[r];
+    for (int i = 0; i < 64 / NGP; ++i) {
+      const int v = __builtin_amdgcn_readlane(ict, i * NGP);
+      ict_min = v < ict_min ? v : ict_min;
     }
-    for (int l = nlev - 1; l >= ict; --l) {
-      double below[3] = {0.0, 0.0, 0.0}, sbelow[3] = {0.0, 0.0, 0.0};
-      const bool cl_here = cloudy.test(l);
-      const double T1 = s.at(LT_T1, l, tid);
+    GeoFeed<NGP> feed;
+    feed.init(prep, ncol_loc, nlev, cloc, L.d + (size_t)(cib * NGP) * (L.rec2 * 2), glane);
+
+    // ---- sweep B: surface -> top ---------------------------------------------------------------------
+    double fup0 = 0.0;          // all-sky upward flux at and above cloud top
+    {
+      feed.request(nlev - 1);
+      feed.publish();
+      double ta[3], ts[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { ts[r] = feed.frac(r) * emission; ta[r] = albedo; }
+      double fup_c = emission + albedo * fdn_c;
       {
-        const double f = cl_here ? geo.frac(0, l) : 1.0;
-        const double su1 = f * s.at(LT_SU1, l, tid), sd1 = f * s.at(LT_SD1, l, tid);
-        // region 1 has zero reflectance (no longwave aerosol scattering): inv_denom = 1
-        below[0] = T1 * T1 * ta[0];
-        sbelow[0] = su1 + T1 * (ts[0] + ta[0] * sd1);
-      }
-      if (cl_here) {
-#pragma unroll
-        for (int r = 1; r < 3; ++r) {
-          const double f = geo.frac(r, l);
-          const double R = s.at(lw_coef(0, r), l, tid), T = s.at(lw_coef(1, r), l, tid);
-          const double su = f * s.at(lw_coef(2, r), l, tid), sd = f * s.at(lw_coef(3, r), l, tid);
-          const double inv = 1.0 / (1.0 - ta[r] * R);
-          below[r] = R + T * T * ta[r] * inv;
-          sbelow[r] = su + T * (ts[r] + ta[r] * sd) * inv;
+        const double su = group_sum<NGP>(valid ? fup_c : 0.0);
+        if (lead && do_clear) fx.lw_up_clear[col + ncol * ord.half(nlev)] = su;
+        if (valid && do_clear) spec_put(fx.lw_up_clear_band, ng, g, col + ncol * ord.half(nlev), fup_c);
+        if (ict == nlev) {      // no cloud in this column: the surface is the "cloud top"
+          fup0 = ts[0] + ta[0] * fdn_ctop;
+          const double st = group_sum<NGP>(valid ? fup0 : 0.0);
+          if (lead) fx.lw_up[col + ncol * ord.half(nlev)] = st;
+          if (valid) spec_put(fx.lw_up_band, ng, g, col + ncol * ord.half(nlev), fup0);
         }
       }
-      const bool cl_above = l > 0 && cloudy.test(l - 1);
-      if (!cl_here && !cl_above) {
+      double2 a0 = s.pair(TL_A0, nlev - 1, tid);
+      double sd1 = s.single(TL_SD1, nlev - 1, tid);
+      double2 rt[2], ss[2];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { ta[r] = below[r]; ts[r] = sbelow[r]; }
-      } else {
+      for (int r = 0; r < 2; ++r) { rt[r] = make_double2(0.0, 0.0); ss[r] = make_double2(0.0, 0.0); }
+      if (cloudy.test(nlev - 1)) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          double a = 0.0, b = 0.0;
+        for (int r = 0; r < 2; ++r) { rt[r] = s.pair(TL_RT(r + 1), nlev - 1, tid); ss[r] = s.pair(TL_SS(r + 1), nlev - 1, tid); }
+      }
+      double keep_c = 0.0, keep_t = 0.0;
+      for (int l = nlev - 1; l >= 0; --l) {
+        // records and geometry of the layer above, requested before this layer is worked on
+        double2 a0n = a0, rtn[2] = {rt[0], rt[1]}, ssn[2] = {ss[0], ss[1]};
+        double sd1n = sd1;
+        if (l > 0) {
+          a0n = s.pair(TL_A0, l - 1, tid);
+          sd1n = s.single(TL_SD1, l - 1, tid);
+          if (cloudy.test(l - 1)) {
 #pragma unroll
-          for (int r2 = 0; r2 < 3; ++r2) {
-            a = a + below[r2] * geo.v(r2, r, l);       // total_albedo: v_matrix(jreg2,jreg,jlev)
-            b = b + geo.u(r, r2, l) * sbelow[r2];      // total_source: singlemat_x_vec(u_matrix(:,:,jlev), .)
+            for (int r = 0; r < 2; ++r) { rtn[r] = s.pair(TL_RT(r + 1), l - 1, tid); ssn[r] = s.pair(TL_SS(r + 1), l - 1, tid); }
           }
-          ta[r] = a; ts[r] = b;
+          feed.request(l - 1);
         }
-      }
+        const double T1 = a0.x, SU1 = a0.y;
+        fup_c = T1 * fup_c + SU1;
+        if (l >= ict) {
+          double below[3] = {0.0, 0.0, 0.0}, sbelow[3] = {0.0, 0.0, 0.0};
+          const bool cl_here = cloudy.test(l);
+          {
+            const double f = cl_here ? feed.frac(0) : 1.0;
+            const double su1 = f * SU1, sdf = f * sd1;
+            // region 1 has zero reflectance (no longwave aerosol scattering): inv_denom = 1
+            s.pair(TL_D(0), l, tid) = make_double2(T1, sdf);
+            s.pair(TL_DT(0), l, tid) = make_double2(ts[0], ta[0]);
+            below[0] = T1 * T1 * ta[0];
+            sbelow[0] = su1 + T1 * (ts[0] + ta[0] * sdf);
+          }
+          if (cl_here) {
 #pragma unroll
-      for (int r = 0; r < 3; ++r) { s.at(LT_TA + r, l, tid) = ta[r]; s.at(LT_TS + r, l, tid) = ts[r]; }
-    }
-    // ---- flux at cloud top and upward through the clear layers above --------------------------------
-    double fup[3] = {ts[0] + ta[0] * fdn_ctop, 0.0, 0.0};
-    {
-      double su = group_sum<NGP>(valid ? fup[0] : 0.0);
-      if (lead) fx.lw_up[col + ncol * ord.half(ict)] = su;
-      if (valid) spec_put(fx.lw_up_band, ng, g, col + ncol * ord.half(ict), fup[0]);
-      double keep_up = 0.0;
-      for (int l = ict - 1; l >= 0; --l) {
-        fup[0] = s.at(LT_T1, l, tid) * fup[0] + s.at(LT_SU1, l, tid);
-        if (valid) spec_put(fx.lw_up_band, ng, g, col + ncol * ord.half(l), fup[0]);
-        su = group_sum<NGP>(valid ? fup[0] : 0.0);
-        if ((l & (NGP - 1)) == glane) keep_up = su;
+            for (int r = 1; r < 3; ++r) {
+              const double f = feed.frac(r);
+              const double R = rt[r - 1].x, T = rt[r - 1].y;
+              const double su = f * ss[r - 1].x, sd = f * ss[r - 1].y;
+              const double inv = 1.0 / (1.0 - ta[r] * R);
+              s.pair(TL_D(r), l, tid) = make_double2(T * inv, (R * ts[r] + sd) * inv);
+              s.pair(TL_DT(r), l, tid) = make_double2(ts[r], ta[r]);
+              below[r] = R + T * T * ta[r] * inv;
+              sbelow[r] = su + T * (ts[r] + ta[r] * sd) * inv;
+            }
+          }
+          const bool cl_above = l > 0 && cloudy.test(l - 1);
+          if (!cl_here && !cl_above) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { ta[r] = below[r]; ts[r] = sbelow[r]; }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+              double x = 0.0, y = 0.0;
+#pragma unroll
+              for (int r2 = 0; r2 < 3; ++r2) {
+                x = x + below[r2] * feed.v(r2, r);       // total_albedo: v_matrix(jreg2,jreg,jlev)
+                y = y + feed.u(r, r2) * sbelow[r2];      // total_source: singlemat_x_vec(u_matrix(:,:,jlev), .)
+              }
+              ta[r] = x; ts[r] = y;
+            }
+          }
+          if (l == ict) fup0 = ts[0] + ta[0] * fdn_ctop;      // flux at cloud top (:447-455)
+        } else {
+          fup0 = T1 * fup0 + SU1;
+        }
+        if (valid) {
+          if (do_clear) spec_put(fx.lw_up_clear_band, ng, g, col + ncol * ord.half(l), fup_c);
+          if (l <= ict) spec_put(fx.lw_up_band, ng, g, col + ncol * ord.half(l), fup0);
+        }
+        const double sc = do_clear ? group_sum<NGP>(valid ? fup_c : 0.0) : 0.0;
+        const double st = group_sum<NGP>(valid && l <= ict ? fup0 : 0.0);
+        if ((l & (NGP - 1)) == glane) { keep_c = sc; keep_t = st; }
         if ((l & (NGP - 1)) == 0) {
           const int lv = l + glane;
-          if (col_ok && lv < ict) fx.lw_up[col + ncol * ord.half(lv)] = keep_up;
+          if (col_ok && lv < nlev) {
+            const size_t o = col + ncol * ord.half(lv);
+            if (do_clear) fx.lw_up_clear[o] = keep_c;
+            if (lv <= ict) fx.lw_up[o] = keep_t;
+          }
         }
-      }
-      if (valid) fx.lw_up_toa_g[g + (size_t)ng * col] = fup[0];
-    }
-    // ---- downward sweep below cloud top --------------------------------------------------------------
-    double fdn[3];
+        a0 = a0n; sd1 = sd1n;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) fdn[r] = geo.v(r, 0, ict) * fdn_ctop;
-    LevelSums<NGP, 2> kept;
-    for (int l = ict; l < nlev; ++l) {
-      const bool cl_here = cloudy.test(l);
-      {
-        const double f = cl_here ? geo.frac(0, l) : 1.0;
-        const double tsn = s.at(LT_TS + 0, l + 1, tid), tan_ = s.at(LT_TA + 0, l + 1, tid);
-        fdn[0] = s.at(LT_T1, l, tid) * fdn[0] + f * s.at(LT_SD1, l, tid);
-        fup[0] = tsn + fdn[0] * tan_;
+        for (int r = 0; r < 2; ++r) { rt[r] = rtn[r]; ss[r] = ssn[r]; }
+        if (l > 0) feed.publish();
       }
-      if (!cl_here) {
-        fdn[1] = fdn[2] = 0.0; fup[1] = fup[2] = 0.0;
-      } else {
-#pragma unroll
-        for (int r = 1; r < 3; ++r) {
-          const double R = s.at(lw_coef(0, r), l, tid);
-          const double tsn = s.at(LT_TS + r, l + 1, tid), tan_ = s.at(LT_TA + r, l + 1, tid);
-          fdn[r] = (s.at(lw_coef(1, r), l, tid) * fdn[r] + R * tsn + geo.frac(r, l) * s.at(lw_coef(3, r), l, tid))
-                   / (1.0 - R * tan_);
-          fup[r] = tsn + fdn[r] * tan_;
-        }
-      }
-      const bool cl_below = (l + 1) < nlev && cloudy.test(l + 1);
-      if (cl_here || cl_below) {
-        double nf[3];
-#pragma unroll
-        for (int j1 = 0; j1 < 3; ++j1)
-          nf[j1] = geo.v(j1, 0, l + 1) * fdn[0] + geo.v(j1, 1, l + 1) * fdn[1] + geo.v(j1, 2, l + 1) * fdn[2];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) fdn[r] = nf[r];
-      }
-      const double sums[2] = {group_sum<NGP>(valid ? fup[0] + fup[1] + fup[2] : 0.0),
-                              group_sum<NGP>(valid ? fdn[0] + fdn[1] + fdn[2] : 0.0)};
-      const int hl = l + 1;
-      if (fx.lw_up_band && valid) {      // sums over the regions per g-point
-        const size_t o = col + ncol * ord.half(hl);
-        spec_put(fx.lw_up_band, ng, g, o, fup[0] + fup[1] + fup[2]);
-        spec_put(fx.lw_dn_band, ng, g, o, fdn[0] + fdn[1] + fdn[2]);
-      }
-      kept.keep(hl, glane, sums);
-      if ((hl & (NGP - 1)) == NGP - 1 || hl == nlev) {
-        const int lv = kept.mine(hl, glane);
-        if (col_ok && lv > ict && lv <= hl) {
-          const size_t o = col + ncol * ord.half(lv);
-          fx.lw_up[o] = kept.v[0];
-          fx.lw_dn[o] = kept.v[1];
-        }
+      if (valid) {
+        const size_t og = g + (size_t)ng * col;
+        if (do_clear) { fx.lw_dn_surf_clear_g[og] = fdn_c; fx.lw_up_toa_clear_g[og] = fup_c; }
+        fx.lw_up_toa_g[og] = fup0;
       }
     }
-    if (valid) fx.lw_dn_surf_g[g + (size_t)ng * col] = fdn[0] + fdn[1] + fdn[2];
-    if (do_deriv) {   // calc_lw_derivatives_region, radiation_lw_derivatives.F90:200-255
+
+    // ---- sweep C: cloud top -> surface ---------------------------------------------------------------
+    double fup[3] = {0.0, 0.0, 0.0}, fdn[3] = {0.0, 0.0, 0.0};
+    if (ict < nlev) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) fdn[r] = geo.v(r, 0, ict) * fdn_ctop;
+    }
+    if (ict_min < nlev) {
+      feed.request(ict_min + 1);
+      feed.publish();
+      double2 d[3], dt[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { d[r] = make_double2(0.0, 0.0); dt[r] = make_double2(0.0, 0.0); }
+      d[0] = s.pair(TL_D(0), ict_min, tid); dt[0] = s.pair(TL_DT(0), ict_min, tid);
+      if (cloudy.test(ict_min)) {
+#pragma unroll
+        for (int r = 1; r < 3; ++r) { d[r] = s.pair(TL_D(r), ict_min, tid); dt[r] = s.pair(TL_DT(r), ict_min, tid); }
+      }
+      LevelSums<NGP, 2> kept;
+      for (int l = ict_min; l < nlev; ++l) {
+        double2 dn[3] = {d[0], d[1], d[2]}, dtn[3] = {dt[0], dt[1], dt[2]};
+        if (l + 1 < nlev) {
+          dn[0] = s.pair(TL_D(0), l + 1, tid); dtn[0] = s.pair(TL_DT(0), l + 1, tid);
+          if (cloudy.test(l + 1)) {
+#pragma unroll
+            for (int r = 1; r < 3; ++r) { dn[r] = s.pair(TL_D(r), l + 1, tid); dtn[r] = s.pair(TL_DT(r), l + 1, tid); }
+          }
+          feed.request(l + 2);
+        }
+        const bool act = l >= ict;
+        if (act) {
+          const bool cl_here = cloudy.test(l);
+          fdn[0] = d[0].x * fdn[0] + d[0].y;
+          fup[0] = dt[0].x + fdn[0] * dt[0].y;
+          if (!cl_here) {
+            fdn[1] = fdn[2] = 0.0; fup[1] = fup[2] = 0.0;
+          } else {
+#pragma unroll
+            for (int r = 1; r < 3; ++r) {
+              fdn[r] = d[r].x * fdn[r] + d[r].y;
+              fup[r] = dt[r].x + fdn[r] * dt[r].y;
+            }
+          }
+          const bool cl_below = (l + 1) < nlev && cloudy.test(l + 1);
+          if (cl_here || cl_below) {     // singlemat_x_vec(v_matrix(:,:,jlev+1), .)
+            double nf[3];
+#pragma unroll
+            for (int j1 = 0; j1 < 3; ++j1) nf[j1] = feed.v(j1, 0) * fdn[0] + feed.v(j1, 1) * fdn[1] + feed.v(j1, 2) * fdn[2];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) fdn[r] = nf[r];
+          }
+        }
+        const double sums[2] = {group_sum<NGP>(valid && act ? fup[0] + fup[1] + fup[2] : 0.0),
+                                group_sum<NGP>(valid && act ? fdn[0] + fdn[1] + fdn[2] : 0.0)};
+        const int hl = l + 1;
+        if (fx.lw_up_band && valid && act) {      // sums over the regions per g-point
+          const size_t o = col + ncol * ord.half(hl);
+          spec_put(fx.lw_up_band, ng, g, o, fup[0] + fup[1] + fup[2]);
+          spec_put(fx.lw_dn_band, ng, g, o, fdn[0] + fdn[1] + fdn[2]);
+        }
+        kept.keep(hl, glane, sums);
+        if ((hl & (NGP - 1)) == NGP - 1 || hl == nlev) {
+          const int lv = kept.mine(hl, glane);
+          if (col_ok && lv > ict && lv <= hl) {
+            const size_t o = col + ncol * ord.half(lv);
+            fx.lw_up[o] = kept.v[0];
+            fx.lw_dn[o] = kept.v[1];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { d[r] = dn[r]; dt[r] = dtn[r]; }
+        if (l + 1 < nlev) feed.publish();
+      }
+    }
+    // Cloud-free column: the reference's flux_up still holds the top-of-atmosphere spectrum when it
+    // reaches calc_lw_derivatives_region (its loop :533 does not run), and so does this
+    if (ict == nlev) fup[0] = fup0;
+    if (valid) fx.lw_dn_surf_g[g + (size_t)ng * col] = ict < nlev ? fdn[0] + fdn[1] + fdn[2] : fdn_c;
+
+    // ---- sweep D: derivatives (calc_lw_derivatives_region, radiation_lw_derivatives.F90:200-255) --
+    if (do_deriv) {
       const double fs = fup[0] + fup[1] + fup[2];
       const double tot = group_sum<NGP>(valid ? fs : 0.0);
-      double d[3] = {fs / tot, 0.0, 0.0};
+      double dv[3] = {fs / tot, 0.0, 0.0};
       if (lead) fx.lw_derivatives[col + ncol * ord.half(nlev)] = 1.0;
+      feed.request(nlev);
+      feed.publish();
+      double t1 = s.pair(TL_A0, nlev - 1, tid).operator double2().x;
+      double t2 = 1.0, t3 = 1.0;
+      if (cloudy.test(nlev - 1)) {
+        t2 = s.pair(TL_RT(1), nlev - 1, tid).operator double2().y;
+        t3 = s.pair(TL_RT(2), nlev - 1, tid).operator double2().y;
+      }
       double keep_der = 0.0;
       for (int l = nlev - 1; l >= 0; --l) {
+        double t1n = t1, t2n = 1.0, t3n = 1.0;
+        if (l > 0) {
+          t1n = s.pair(TL_A0, l - 1, tid).operator double2().x;
+          if (cloudy.test(l - 1)) {
+            t2n = s.pair(TL_RT(1), l - 1, tid).operator double2().y;
+            t3n = s.pair(TL_RT(2), l - 1, tid).operator double2().y;
+          }
+          feed.request(l);
+        }
         double n[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) n[r] = geo.u(r, 0, l + 1) * d[0] + geo.u(r, 1, l + 1) * d[1] + geo.u(r, 2, l + 1) * d[2];
-        const bool cl_here = l >= ict && cloudy.test(l);
-        d[0] = n[0] * s.at(LT_T1, l, tid);
-        d[1] = n[1] * (cl_here ? s.at(lw_coef(1, 1), l, tid) : 1.0);
-        d[2] = n[2] * (cl_here ? s.at(lw_coef(1, 2), l, tid) : 1.0);
-        const double sder = group_sum<NGP>(valid ? d[0] + d[1] + d[2] : 0.0);
+        for (int r = 0; r < 3; ++r) n[r] = feed.u(r, 0) * dv[0] + feed.u(r, 1) * dv[1] + feed.u(r, 2) * dv[2];
+        dv[0] = n[0] * t1;
+        dv[1] = n[1] * t2;
+        dv[2] = n[2] * t3;
+        const double sder = group_sum<NGP>(valid ? dv[0] + dv[1] + dv[2] : 0.0);
         if ((l & (NGP - 1)) == glane) keep_der = sder;
         if ((l & (NGP - 1)) == 0) {
           const int lv = l + glane;
           if (col_ok && lv < nlev) fx.lw_derivatives[col + ncol * ord.half(lv)] = keep_der;
         }
+        t1 = t1n; t2 = t2n; t3 = t3n;
+        if (l > 0) feed.publish();
       }
     }
   }
 }
 
-size_t lw_tc_scratch_doubles(int nlev) { return (size_t)LW_TC_NUM * (nlev + 1) * kBlock; }
+size_t lw_tc_scratch_doubles(int nlev) { return (size_t)LW_TC_PLANES * nlev * kBlock; }
 
 hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block,

@@ -86,6 +86,7 @@ BENCH_CONFIGS = {
     # attribution variants (not bench lines): the same without aerosols / without clouds
     "tripleclouds_noaer": dict(sw_solver="Tripleclouds", use_aerosols=False, clear_sky=False),
     "tripleclouds_clear_aer": dict(sw_solver="Tripleclouds", use_aerosols=True, clear_sky=True),
+    "tripleclouds_clear_noaer": dict(sw_solver="Tripleclouds", use_aerosols=False, clear_sky=True),
     "mcica_noaer": dict(sw_solver="McICA", use_aerosols=False, clear_sky=False),
     "mcica_vectorizable": dict(sw_solver="McICA", use_aerosols=True, clear_sky=False, use_vectorizable_generator=True),
     "homogeneous_clear_aer": dict(sw_solver="Homogeneous", use_aerosols=True, clear_sky=True),
