@@ -10,6 +10,16 @@
 #include "optics_device.h"
 #include "launch.h"
 
+// layers per batch of record loads in the longwave sweeps B, C, D
+#ifndef ECRAD_TC_BATCH_B
+#define ECRAD_TC_BATCH_B 1
+#endif
+#ifndef ECRAD_TC_BATCH_C
+#define ECRAD_TC_BATCH_C 2
+#endif
+#ifndef ECRAD_TC_BATCH_D
+#define ECRAD_TC_BATCH_D 4
+#endif
 #ifndef ECRAD_TC_MIN_WAVES
 #define ECRAD_TC_MIN_WAVES ECRAD_MIN_WAVES
 #endif
@@ -387,7 +397,6 @@ struct GeoFeed {
   static constexpr int NI = 21, PER = (NI + NGP - 1) / NGP;
   const double* src[PER];
   int maxlev[PER];
-  double held[PER];
   size_t stride;
   double* stage;
   int glane;
@@ -396,33 +405,40 @@ struct GeoFeed {
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int q = glane + u * NGP;
-      held[u] = 0.0;
       if (q < 3) { src[u] = p.region_fracs + (size_t)q * nlev * nloc + cloc; maxlev[u] = nlev - 1; }
       else if (q < 12) { src[u] = p.v_matrix + (size_t)(q - 3) * (nlev + 1) * nloc + cloc; maxlev[u] = nlev; }
       else if (q < NI) { src[u] = p.u_matrix + (size_t)(q - 12) * (nlev + 1) * nloc + cloc; maxlev[u] = nlev; }
       else { src[u] = p.region_fracs + cloc; maxlev[u] = 0; }
     }
   }
-  // fractions of layer `lev`, matrices of half level `lev`
-  ECRAD_DEV void request(int lev) {
+  // Make the items of levels lev0, lev0+step, ..., lev0+(K-1)*step available as batch entries 0..K-1
+  // (fractions of layer `lev`, matrices of half level `lev`; out-of-range levels are clamped)
+  template <int K>
+  ECRAD_DEV void fetch(int lev0, int step) {
+    double held[K][PER];
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int l = lev < 0 ? 0 : (lev > maxlev[u] ? maxlev[u] : lev);
-      held[u] = src[u][stride * l];
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int lev = lev0 + k * step;
+        const int l = lev < 0 ? 0 : (lev > maxlev[u] ? maxlev[u] : lev);
+        held[k][u] = src[u][stride * l];
+      }
     }
-  }
-  ECRAD_DEV void publish() {
     wave_sync();
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int q = glane + u * NGP;
-      if (q < NI) stage[q] = held[u];
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int q = glane + u * NGP;
+        if (q < NI) stage[k * NI + q] = held[k][u];
+      }
     }
     wave_sync();
   }
-  ECRAD_DEV double frac(int r) const { return stage[r]; }
-  ECRAD_DEV double v(int i, int j) const { return stage[3 + i + 3 * j]; }
-  ECRAD_DEV double u(int i, int j) const { return stage[12 + i + 3 * j]; }
+  ECRAD_DEV double frac(int k, int r) const { return stage[k * NI + r]; }
+  ECRAD_DEV double v(int k, int i, int j) const { return stage[k * NI + 3 + i + 3 * j]; }
+  ECRAD_DEV double u(int k, int i, int j) const { return stage[k * NI + 12 + i + 3 * j]; }
 };
 
 template <typename TAB, int NGP>
@@ -452,6 +468,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
     if (grp >= ngroups) break;
     const LdsLayout L = make_lds(smem, m.hot.nquad, cfg.n_cloud_types);
     const TcLwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block};
+    quads.reset();
     const int g = glane < ng ? glane : ng - 1;
     const int ib = cfg.i_band_from_reordered_g_lw[g] - 1;
     const bool do_clear = cfg.do_clear != 0;
@@ -566,13 +583,15 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
     feed.init(prep, ncol_loc, nlev, cloc, L.d + (size_t)(cib * NGP) * (L.rec2 * 2), glane);
 
     // ---- sweep B: surface -> top ---------------------------------------------------------------------
+    // (all sweeps: the records and geometry of K consecutive layers are requested together, so that
+    // one memory round trip is paid per K layers of the recurrence instead of per layer)
     double fup0 = 0.0;          // all-sky upward flux at and above cloud top
     {
-      feed.request(nlev - 1);
-      feed.publish();
+      constexpr int K = ECRAD_TC_BATCH_B;
+      feed.template fetch<1>(nlev - 1, -1);
       double ta[3], ts[3];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) { ts[r] = feed.frac(r) * emission; ta[r] = albedo; }
+      for (int r = 0; r < 3; ++r) { ts[r] = feed.frac(0, r) * emission; ta[r] = albedo; }
       double fup_c = emission + albedo * fdn_c;
       {
         const double su = group_sum<NGP>(valid ? fup_c : 0.0);
@@ -585,95 +604,94 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
           if (valid) spec_put(fx.lw_up_band, ng, g, col + ncol * ord.half(nlev), fup0);
         }
       }
-      double2 a0 = s.pair(TL_A0, nlev - 1, tid);
-      double sd1 = s.single(TL_SD1, nlev - 1, tid);
-      double2 rt[2], ss[2];
-#pragma unroll
-      for (int r = 0; r < 2; ++r) { rt[r] = make_double2(0.0, 0.0); ss[r] = make_double2(0.0, 0.0); }
-      if (cloudy.test(nlev - 1)) {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) { rt[r] = s.pair(TL_RT(r + 1), nlev - 1, tid); ss[r] = s.pair(TL_SS(r + 1), nlev - 1, tid); }
-      }
       double keep_c = 0.0, keep_t = 0.0;
-      for (int l = nlev - 1; l >= 0; --l) {
-        // records and geometry of the layer above, requested before this layer is worked on
-        double2 a0n = a0, rtn[2] = {rt[0], rt[1]}, ssn[2] = {ss[0], ss[1]};
-        double sd1n = sd1;
-        if (l > 0) {
-          a0n = s.pair(TL_A0, l - 1, tid);
-          sd1n = s.single(TL_SD1, l - 1, tid);
-          if (cloudy.test(l - 1)) {
+      for (int l0 = nlev - 1; l0 >= 0; l0 -= K) {
+        double2 a0[K], rt[K][2], ss[K][2];
+        double sd1[K];
 #pragma unroll
-            for (int r = 0; r < 2; ++r) { rtn[r] = s.pair(TL_RT(r + 1), l - 1, tid); ssn[r] = s.pair(TL_SS(r + 1), l - 1, tid); }
-          }
-          feed.request(l - 1);
-        }
-        const double T1 = a0.x, SU1 = a0.y;
-        fup_c = T1 * fup_c + SU1;
-        if (l >= ict) {
-          double below[3] = {0.0, 0.0, 0.0}, sbelow[3] = {0.0, 0.0, 0.0};
-          const bool cl_here = cloudy.test(l);
-          {
-            const double f = cl_here ? feed.frac(0) : 1.0;
-            const double su1 = f * SU1, sdf = f * sd1;
-            // region 1 has zero reflectance (no longwave aerosol scattering): inv_denom = 1
-            s.pair(TL_D(0), l, tid) = make_double2(T1, sdf);
-            s.pair(TL_DT(0), l, tid) = make_double2(ts[0], ta[0]);
-            below[0] = T1 * T1 * ta[0];
-            sbelow[0] = su1 + T1 * (ts[0] + ta[0] * sdf);
-          }
-          if (cl_here) {
+        for (int k = 0; k < K; ++k) {
+          const int l = l0 - k;
+          a0[k] = make_double2(0.0, 0.0); sd1[k] = 0.0;
 #pragma unroll
-            for (int r = 1; r < 3; ++r) {
-              const double f = feed.frac(r);
-              const double R = rt[r - 1].x, T = rt[r - 1].y;
-              const double su = f * ss[r - 1].x, sd = f * ss[r - 1].y;
-              const double inv = 1.0 / (1.0 - ta[r] * R);
-              s.pair(TL_D(r), l, tid) = make_double2(T * inv, (R * ts[r] + sd) * inv);
-              s.pair(TL_DT(r), l, tid) = make_double2(ts[r], ta[r]);
-              below[r] = R + T * T * ta[r] * inv;
-              sbelow[r] = su + T * (ts[r] + ta[r] * sd) * inv;
+          for (int r = 0; r < 2; ++r) { rt[k][r] = make_double2(0.0, 0.0); ss[k][r] = make_double2(0.0, 0.0); }
+          if (l >= 0) {
+            a0[k] = s.pair(TL_A0, l, tid);
+            sd1[k] = s.single(TL_SD1, l, tid);
+            if (cloudy.test(l)) {
+#pragma unroll
+              for (int r = 0; r < 2; ++r) { rt[k][r] = s.pair(TL_RT(r + 1), l, tid); ss[k][r] = s.pair(TL_SS(r + 1), l, tid); }
             }
           }
-          const bool cl_above = l > 0 && cloudy.test(l - 1);
-          if (!cl_here && !cl_above) {
+        }
+        if (l0 >= ict_min) feed.template fetch<K>(l0, -1);     // geometry is only used at and below cloud top
 #pragma unroll
-            for (int r = 0; r < 3; ++r) { ta[r] = below[r]; ts[r] = sbelow[r]; }
-          } else {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-              double x = 0.0, y = 0.0;
-#pragma unroll
-              for (int r2 = 0; r2 < 3; ++r2) {
-                x = x + below[r2] * feed.v(r2, r);       // total_albedo: v_matrix(jreg2,jreg,jlev)
-                y = y + feed.u(r, r2) * sbelow[r2];      // total_source: singlemat_x_vec(u_matrix(:,:,jlev), .)
+        for (int k = 0; k < K; ++k) {
+          const int l = l0 - k;
+          if (l >= 0) {
+            const double T1 = a0[k].x, SU1 = a0[k].y;
+            fup_c = T1 * fup_c + SU1;
+            if (l >= ict) {
+              double below[3] = {0.0, 0.0, 0.0}, sbelow[3] = {0.0, 0.0, 0.0};
+              const bool cl_here = cloudy.test(l);
+              {
+                const double f = cl_here ? feed.frac(k, 0) : 1.0;
+                const double su1 = f * SU1, sdf = f * sd1[k];
+                // region 1 has zero reflectance (no longwave aerosol scattering): inv_denom = 1
+                s.pair(TL_D(0), l, tid) = make_double2(T1, sdf);
+                s.pair(TL_DT(0), l, tid) = make_double2(ts[0], ta[0]);
+                below[0] = T1 * T1 * ta[0];
+                sbelow[0] = su1 + T1 * (ts[0] + ta[0] * sdf);
               }
-              ta[r] = x; ts[r] = y;
+              if (cl_here) {
+#pragma unroll
+                for (int r = 1; r < 3; ++r) {
+                  const double f = feed.frac(k, r);
+                  const double R = rt[k][r - 1].x, T = rt[k][r - 1].y;
+                  const double su = f * ss[k][r - 1].x, sd = f * ss[k][r - 1].y;
+                  const double inv = 1.0 / (1.0 - ta[r] * R);
+                  s.pair(TL_D(r), l, tid) = make_double2(T * inv, (R * ts[r] + sd) * inv);
+                  s.pair(TL_DT(r), l, tid) = make_double2(ts[r], ta[r]);
+                  below[r] = R + T * T * ta[r] * inv;
+                  sbelow[r] = su + T * (ts[r] + ta[r] * sd) * inv;
+                }
+              }
+              const bool cl_above = l > 0 && cloudy.test(l - 1);
+              if (!cl_here && !cl_above) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) { ta[r] = below[r]; ts[r] = sbelow[r]; }
+              } else {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                  double x = 0.0, y = 0.0;
+#pragma unroll
+                  for (int r2 = 0; r2 < 3; ++r2) {
+                    x = x + below[r2] * feed.v(k, r2, r);       // total_albedo: v_matrix(jreg2,jreg,jlev)
+                    y = y + feed.u(k, r, r2) * sbelow[r2];      // total_source: singlemat_x_vec(u_matrix(:,:,jlev), .)
+                  }
+                  ta[r] = x; ts[r] = y;
+                }
+              }
+              if (l == ict) fup0 = ts[0] + ta[0] * fdn_ctop;      // flux at cloud top (:447-455)
+            } else {
+              fup0 = T1 * fup0 + SU1;
+            }
+            if (valid) {
+              if (do_clear) spec_put(fx.lw_up_clear_band, ng, g, col + ncol * ord.half(l), fup_c);
+              if (l <= ict) spec_put(fx.lw_up_band, ng, g, col + ncol * ord.half(l), fup0);
+            }
+            const double sc = do_clear ? group_sum<NGP>(valid ? fup_c : 0.0) : 0.0;
+            const double st = group_sum<NGP>(valid && l <= ict ? fup0 : 0.0);
+            if ((l & (NGP - 1)) == glane) { keep_c = sc; keep_t = st; }
+            if ((l & (NGP - 1)) == 0) {
+              const int lv = l + glane;
+              if (col_ok && lv < nlev) {
+                const size_t o = col + ncol * ord.half(lv);
+                if (do_clear) fx.lw_up_clear[o] = keep_c;
+                if (lv <= ict) fx.lw_up[o] = keep_t;
+              }
             }
           }
-          if (l == ict) fup0 = ts[0] + ta[0] * fdn_ctop;      // flux at cloud top (:447-455)
-        } else {
-          fup0 = T1 * fup0 + SU1;
         }
-        if (valid) {
-          if (do_clear) spec_put(fx.lw_up_clear_band, ng, g, col + ncol * ord.half(l), fup_c);
-          if (l <= ict) spec_put(fx.lw_up_band, ng, g, col + ncol * ord.half(l), fup0);
-        }
-        const double sc = do_clear ? group_sum<NGP>(valid ? fup_c : 0.0) : 0.0;
-        const double st = group_sum<NGP>(valid && l <= ict ? fup0 : 0.0);
-        if ((l & (NGP - 1)) == glane) { keep_c = sc; keep_t = st; }
-        if ((l & (NGP - 1)) == 0) {
-          const int lv = l + glane;
-          if (col_ok && lv < nlev) {
-            const size_t o = col + ncol * ord.half(lv);
-            if (do_clear) fx.lw_up_clear[o] = keep_c;
-            if (lv <= ict) fx.lw_up[o] = keep_t;
-          }
-        }
-        a0 = a0n; sd1 = sd1n;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) { rt[r] = rtn[r]; ss[r] = ssn[r]; }
-        if (l > 0) feed.publish();
       }
       if (valid) {
         const size_t og = g + (size_t)ng * col;
@@ -689,70 +707,71 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
       for (int r = 0; r < 3; ++r) fdn[r] = geo.v(r, 0, ict) * fdn_ctop;
     }
     if (ict_min < nlev) {
-      feed.request(ict_min + 1);
-      feed.publish();
-      double2 d[3], dt[3];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) { d[r] = make_double2(0.0, 0.0); dt[r] = make_double2(0.0, 0.0); }
-      d[0] = s.pair(TL_D(0), ict_min, tid); dt[0] = s.pair(TL_DT(0), ict_min, tid);
-      if (cloudy.test(ict_min)) {
-#pragma unroll
-        for (int r = 1; r < 3; ++r) { d[r] = s.pair(TL_D(r), ict_min, tid); dt[r] = s.pair(TL_DT(r), ict_min, tid); }
-      }
+      constexpr int K = ECRAD_TC_BATCH_C;
       LevelSums<NGP, 2> kept;
-      for (int l = ict_min; l < nlev; ++l) {
-        double2 dn[3] = {d[0], d[1], d[2]}, dtn[3] = {dt[0], dt[1], dt[2]};
-        if (l + 1 < nlev) {
-          dn[0] = s.pair(TL_D(0), l + 1, tid); dtn[0] = s.pair(TL_DT(0), l + 1, tid);
-          if (cloudy.test(l + 1)) {
+      for (int l0 = ict_min; l0 < nlev; l0 += K) {
+        double2 d[K][3], dt[K][3];
 #pragma unroll
-            for (int r = 1; r < 3; ++r) { dn[r] = s.pair(TL_D(r), l + 1, tid); dtn[r] = s.pair(TL_DT(r), l + 1, tid); }
-          }
-          feed.request(l + 2);
-        }
-        const bool act = l >= ict;
-        if (act) {
-          const bool cl_here = cloudy.test(l);
-          fdn[0] = d[0].x * fdn[0] + d[0].y;
-          fup[0] = dt[0].x + fdn[0] * dt[0].y;
-          if (!cl_here) {
-            fdn[1] = fdn[2] = 0.0; fup[1] = fup[2] = 0.0;
-          } else {
+        for (int k = 0; k < K; ++k) {
+          const int l = l0 + k;
 #pragma unroll
-            for (int r = 1; r < 3; ++r) {
-              fdn[r] = d[r].x * fdn[r] + d[r].y;
-              fup[r] = dt[r].x + fdn[r] * dt[r].y;
+          for (int r = 0; r < 3; ++r) { d[k][r] = make_double2(0.0, 0.0); dt[k][r] = make_double2(0.0, 0.0); }
+          if (l < nlev) {
+            d[k][0] = s.pair(TL_D(0), l, tid); dt[k][0] = s.pair(TL_DT(0), l, tid);
+            if (cloudy.test(l)) {
+#pragma unroll
+              for (int r = 1; r < 3; ++r) { d[k][r] = s.pair(TL_D(r), l, tid); dt[k][r] = s.pair(TL_DT(r), l, tid); }
             }
           }
-          const bool cl_below = (l + 1) < nlev && cloudy.test(l + 1);
-          if (cl_here || cl_below) {     // singlemat_x_vec(v_matrix(:,:,jlev+1), .)
-            double nf[3];
+        }
+        feed.template fetch<K>(l0 + 1, 1);      // v_matrix of the half level below each layer
 #pragma unroll
-            for (int j1 = 0; j1 < 3; ++j1) nf[j1] = feed.v(j1, 0) * fdn[0] + feed.v(j1, 1) * fdn[1] + feed.v(j1, 2) * fdn[2];
+        for (int k = 0; k < K; ++k) {
+          const int l = l0 + k;
+          if (l < nlev) {
+            const bool act = l >= ict;
+            if (act) {
+              const bool cl_here = cloudy.test(l);
+              fdn[0] = d[k][0].x * fdn[0] + d[k][0].y;
+              fup[0] = dt[k][0].x + fdn[0] * dt[k][0].y;
+              if (!cl_here) {
+                fdn[1] = fdn[2] = 0.0; fup[1] = fup[2] = 0.0;
+              } else {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) fdn[r] = nf[r];
+                for (int r = 1; r < 3; ++r) {
+                  fdn[r] = d[k][r].x * fdn[r] + d[k][r].y;
+                  fup[r] = dt[k][r].x + fdn[r] * dt[k][r].y;
+                }
+              }
+              const bool cl_below = (l + 1) < nlev && cloudy.test(l + 1);
+              if (cl_here || cl_below) {     // singlemat_x_vec(v_matrix(:,:,jlev+1), .)
+                double nf[3];
+#pragma unroll
+                for (int j1 = 0; j1 < 3; ++j1)
+                  nf[j1] = feed.v(k, j1, 0) * fdn[0] + feed.v(k, j1, 1) * fdn[1] + feed.v(k, j1, 2) * fdn[2];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) fdn[r] = nf[r];
+              }
+            }
+            const double sums[2] = {group_sum<NGP>(valid && act ? fup[0] + fup[1] + fup[2] : 0.0),
+                                    group_sum<NGP>(valid && act ? fdn[0] + fdn[1] + fdn[2] : 0.0)};
+            const int hl = l + 1;
+            if (fx.lw_up_band && valid && act) {      // sums over the regions per g-point
+              const size_t o = col + ncol * ord.half(hl);
+              spec_put(fx.lw_up_band, ng, g, o, fup[0] + fup[1] + fup[2]);
+              spec_put(fx.lw_dn_band, ng, g, o, fdn[0] + fdn[1] + fdn[2]);
+            }
+            kept.keep(hl, glane, sums);
+            if ((hl & (NGP - 1)) == NGP - 1 || hl == nlev) {
+              const int lv = kept.mine(hl, glane);
+              if (col_ok && lv > ict && lv <= hl) {
+                const size_t o = col + ncol * ord.half(lv);
+                fx.lw_up[o] = kept.v[0];
+                fx.lw_dn[o] = kept.v[1];
+              }
+            }
           }
         }
-        const double sums[2] = {group_sum<NGP>(valid && act ? fup[0] + fup[1] + fup[2] : 0.0),
-                                group_sum<NGP>(valid && act ? fdn[0] + fdn[1] + fdn[2] : 0.0)};
-        const int hl = l + 1;
-        if (fx.lw_up_band && valid && act) {      // sums over the regions per g-point
-          const size_t o = col + ncol * ord.half(hl);
-          spec_put(fx.lw_up_band, ng, g, o, fup[0] + fup[1] + fup[2]);
-          spec_put(fx.lw_dn_band, ng, g, o, fdn[0] + fdn[1] + fdn[2]);
-        }
-        kept.keep(hl, glane, sums);
-        if ((hl & (NGP - 1)) == NGP - 1 || hl == nlev) {
-          const int lv = kept.mine(hl, glane);
-          if (col_ok && lv > ict && lv <= hl) {
-            const size_t o = col + ncol * ord.half(lv);
-            fx.lw_up[o] = kept.v[0];
-            fx.lw_dn[o] = kept.v[1];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) { d[r] = dn[r]; dt[r] = dtn[r]; }
-        if (l + 1 < nlev) feed.publish();
       }
     }
     // Cloud-free column: the reference's flux_up still holds the top-of-atmosphere spectrum when it
@@ -762,43 +781,45 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
 
     // ---- sweep D: derivatives (calc_lw_derivatives_region, radiation_lw_derivatives.F90:200-255) --
     if (do_deriv) {
+      constexpr int K = ECRAD_TC_BATCH_D;
       const double fs = fup[0] + fup[1] + fup[2];
       const double tot = group_sum<NGP>(valid ? fs : 0.0);
       double dv[3] = {fs / tot, 0.0, 0.0};
       if (lead) fx.lw_derivatives[col + ncol * ord.half(nlev)] = 1.0;
-      feed.request(nlev);
-      feed.publish();
-      double t1 = s.pair(TL_A0, nlev - 1, tid).operator double2().x;
-      double t2 = 1.0, t3 = 1.0;
-      if (cloudy.test(nlev - 1)) {
-        t2 = s.pair(TL_RT(1), nlev - 1, tid).operator double2().y;
-        t3 = s.pair(TL_RT(2), nlev - 1, tid).operator double2().y;
-      }
       double keep_der = 0.0;
-      for (int l = nlev - 1; l >= 0; --l) {
-        double t1n = t1, t2n = 1.0, t3n = 1.0;
-        if (l > 0) {
-          t1n = s.pair(TL_A0, l - 1, tid).operator double2().x;
-          if (cloudy.test(l - 1)) {
-            t2n = s.pair(TL_RT(1), l - 1, tid).operator double2().y;
-            t3n = s.pair(TL_RT(2), l - 1, tid).operator double2().y;
-          }
-          feed.request(l);
-        }
-        double n[3];
+      for (int l0 = nlev - 1; l0 >= 0; l0 -= K) {
+        double t1[K], t2[K], t3[K];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) n[r] = feed.u(r, 0) * dv[0] + feed.u(r, 1) * dv[1] + feed.u(r, 2) * dv[2];
-        dv[0] = n[0] * t1;
-        dv[1] = n[1] * t2;
-        dv[2] = n[2] * t3;
-        const double sder = group_sum<NGP>(valid ? dv[0] + dv[1] + dv[2] : 0.0);
-        if ((l & (NGP - 1)) == glane) keep_der = sder;
-        if ((l & (NGP - 1)) == 0) {
-          const int lv = l + glane;
-          if (col_ok && lv < nlev) fx.lw_derivatives[col + ncol * ord.half(lv)] = keep_der;
+        for (int k = 0; k < K; ++k) {
+          const int l = l0 - k;
+          t1[k] = t2[k] = t3[k] = 1.0;
+          if (l >= 0) {
+            t1[k] = s.pair(TL_A0, l, tid).operator double2().x;
+            if (cloudy.test(l)) {
+              t2[k] = s.pair(TL_RT(1), l, tid).operator double2().y;
+              t3[k] = s.pair(TL_RT(2), l, tid).operator double2().y;
+            }
+          }
         }
-        t1 = t1n; t2 = t2n; t3 = t3n;
-        if (l > 0) feed.publish();
+        feed.template fetch<K>(l0 + 1, -1);     // u_matrix of the half level below each layer
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const int l = l0 - k;
+          if (l >= 0) {
+            double n[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) n[r] = feed.u(k, r, 0) * dv[0] + feed.u(k, r, 1) * dv[1] + feed.u(k, r, 2) * dv[2];
+            dv[0] = n[0] * t1[k];
+            dv[1] = n[1] * t2[k];
+            dv[2] = n[2] * t3[k];
+            const double sder = group_sum<NGP>(valid ? dv[0] + dv[1] + dv[2] : 0.0);
+            if ((l & (NGP - 1)) == glane) keep_der = sder;
+            if ((l & (NGP - 1)) == 0) {
+              const int lv = l + glane;
+              if (col_ok && lv < nlev) fx.lw_derivatives[col + ncol * ord.half(lv)] = keep_der;
+            }
+          }
+        }
       }
     }
   }

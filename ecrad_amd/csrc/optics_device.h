@@ -203,6 +203,13 @@ struct GasRegs {
   typename QuadOf<TAB>::type q[kMaxQuads];
   int cell, lut;
   ECRAD_DEV void invalidate() { cell = -1; lut = -1; }
+  // invalidate and overwrite: ends the live range of the table values, so that they do not occupy
+  // registers through code that never looks at them (the vertical sweeps after the optics pass)
+  ECRAD_DEV void reset() {
+    invalidate();
+#pragma unroll
+    for (int i = 0; i < kMaxQuads; ++i) q[i] = typename QuadOf<TAB>::type{};
+  }
 };
 
 // Lane = g.  Bring the table quads of one layer into `r` (radiation_ecckd.F90:549-640), re-loading
