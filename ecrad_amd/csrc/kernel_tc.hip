@@ -20,6 +20,9 @@
 #ifndef ECRAD_TC_BATCH_D
 #define ECRAD_TC_BATCH_D 4
 #endif
+#ifndef ECRAD_TC_BATCH_S
+#define ECRAD_TC_BATCH_S 2      // shortwave flux sweep
+#endif
 #ifndef ECRAD_TC_MIN_WAVES
 #define ECRAD_TC_MIN_WAVES ECRAD_MIN_WAVES
 #endif
@@ -34,6 +37,60 @@ struct TcGeom {
   ECRAD_DEV double odsc(int r /*1,2*/, int lev) const { return p.od_scaling_reg[((size_t)(r - 1) * nlev + lev) * nloc + cloc]; }
   ECRAD_DEV double v(int i, int j, int hl) const { return p.v_matrix[((size_t)(i + 3 * j) * (nlev + 1) + hl) * nloc + cloc]; }
   ECRAD_DEV double u(int i, int j, int hl) const { return p.u_matrix[((size_t)(i + 3 * j) * (nlev + 1) + hl) * nloc + cloc]; }
+};
+
+// Per-column geometry of one level for the sweeps (3 region fractions, v_matrix, u_matrix: 21 values
+// that all lanes of a column need).  Lane q of the column group loads item q of the NEXT level while
+// the current one is processed -- one load instruction per level instead of 21, off the critical
+// path -- and the items reach the other lanes through the group's level-record area in LDS, which is
+// idle during the sweeps and private to the wave.
+template <int NGP>
+struct GeoFeed {
+  static constexpr int NI = 21, PER = (NI + NGP - 1) / NGP;
+  const double* src[PER];
+  int maxlev[PER];
+  size_t stride;
+  double* stage;
+  int glane;
+  ECRAD_DEV void init(const DevCloudPrep& p, int nloc, int nlev, int cloc, double* lds_stage, int lane_in_group) {
+    stride = nloc; stage = lds_stage; glane = lane_in_group;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int q = glane + u * NGP;
+      if (q < 3) { src[u] = p.region_fracs + (size_t)q * nlev * nloc + cloc; maxlev[u] = nlev - 1; }
+      else if (q < 12) { src[u] = p.v_matrix + (size_t)(q - 3) * (nlev + 1) * nloc + cloc; maxlev[u] = nlev; }
+      else if (q < NI) { src[u] = p.u_matrix + (size_t)(q - 12) * (nlev + 1) * nloc + cloc; maxlev[u] = nlev; }
+      else { src[u] = p.region_fracs + cloc; maxlev[u] = 0; }
+    }
+  }
+  // Make the items of levels lev0, lev0+step, ..., lev0+(K-1)*step available as batch entries 0..K-1
+  // (fractions of layer `lev`, matrices of half level `lev`; out-of-range levels are clamped)
+  template <int K>
+  ECRAD_DEV void fetch(int lev0, int step) {
+    double held[K][PER];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int lev = lev0 + k * step;
+        const int l = lev < 0 ? 0 : (lev > maxlev[u] ? maxlev[u] : lev);
+        held[k][u] = src[u][stride * l];
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int q = glane + u * NGP;
+        if (q < NI) stage[k * NI + q] = held[k][u];
+      }
+    }
+    wave_sync();
+  }
+  ECRAD_DEV double frac(int k, int r) const { return stage[k * NI + r]; }
+  ECRAD_DEV double v(int k, int i, int j) const { return stage[k * NI + 3 + i + 3 * j]; }
+  ECRAD_DEV double u(int k, int i, int j) const { return stage[k * NI + 12 + i + 3 * j]; }
 };
 
 // ===================================================================================================
@@ -97,6 +154,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
     if (grp >= ngroups) break;
     const LdsLayout L = make_lds(smem, m.hot.nquad, cfg.n_cloud_types);
     const TcSwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block};
+    quads.reset();
     const int g = glane < ng ? glane : ng - 1;
     const int ib = cfg.i_band_from_reordered_g_sw[g] - 1;
     const double ray_g = m.rayleigh_molar_scat[g];
@@ -123,6 +181,18 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
     // which layers are cloudy (the upward sweep needs the layer ABOVE before it gets there)
     const FracView fracv = cloud_fraction_view(in, col);
     const LevMask cloudy = column_level_mask<NGP>(fracv.p, fracv.stride, nlev, tid % 64, ord);
+    // Below the lowest cloudy layer `lcb` region 1 has the clear-sky column's records (same layer, same
+    // albedo below): they are stored once, as set 3, when clear-sky fluxes are wanted
+    const int lcb = cloudy.highest();
+    int cloudy_first = nlev;      // wave-uniform: highest cloud top among the wave's columns
+    {
+      const int mine = cloudy.lowest(nlev);
+#pragma unroll
+      for (int i = 0; i < 64 / NGP; ++i) {
+        const int v = __builtin_amdgcn_readlane(mine, i * NGP);
+        cloudy_first = v < cloudy_first ? v : cloudy_first;
+      }
+    }
 
     // ---- sweep 1: surface -> top ---------------------------------------------------------------------
     double ta[3], tad[3];
@@ -163,7 +233,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
         {
           const SwCoef c = ref_trans_sw_fused(mu0, od, ssa, asym);
           if (do_clear) tc_sw_up(s, 3, l, tid, c, tac, tacd, tac, tacd);
-          tc_sw_up(s, 0, l, tid, c, ta[0], tad[0], below[0], belowd[0]);
+          if (do_clear && l > lcb) { below[0] = tac; belowd[0] = tacd; }
+          else tc_sw_up(s, 0, l, tid, c, ta[0], tad[0], below[0], belowd[0]);
         }
         const bool cl_here = cloudy.test(l);
         if (cl_here) {
@@ -246,54 +317,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
       if (do_clear) fx.sw_up_toa_clear_g[og] = fup_c;
     }
     LevelSums<NGP, 6> kept;
-    for (int hl = 0; hl <= ((ECRAD_ABLATE & 4) ? 0 : nlev); ++hl) {
-      if (hl > 0) {
-        const int l = hl - 1;
-        if (do_clear) {
-          const double2 p0 = s.pair(3, 0, l, tid), p1 = s.pair(3, 1, l, tid);
-          const double ad = s.single(3, l, tid);
-          fdn_c = p0.x * fdn_c + ddn_c * p0.y;
-          ddn_c = p1.x * ddn_c;
-          fup_c = ddn_c * ad + fdn_c * p1.y;
-        }
-        {
-          const double2 p0 = s.pair(0, 0, l, tid), p1 = s.pair(0, 1, l, tid);
-          const double ad = s.single(0, l, tid);
-          fdn[0] = p0.x * fdn[0] + ddn[0] * p0.y;
-          ddn[0] = p1.x * ddn[0];
-          fup[0] = ddn[0] * ad + fdn[0] * p1.y;
-        }
-        const bool cl_here = cloudy.test(l);
-        if (!cl_here) {
-          fdn[1] = fdn[2] = 0.0; fup[1] = fup[2] = 0.0; ddn[1] = ddn[2] = 0.0;
-        } else {
-#pragma unroll
-          for (int r = 1; r < 3; ++r) {
-            const double2 p0 = s.pair(r, 0, l, tid), p1 = s.pair(r, 1, l, tid);
-            const double ad = s.single(r, l, tid);
-            fdn[r] = p0.x * fdn[r] + ddn[r] * p0.y;
-            ddn[r] = p1.x * ddn[r];
-            fup[r] = ddn[r] * ad + fdn[r] * p1.y;
-          }
-        }
-        const bool cl_below = hl < nlev && cloudy.test(hl);
-        if (cl_here || cl_below) {   // singlemat_x_vec(v_matrix(:,:,jlev+1), .)
-          double nf[3], nd[3];
-#pragma unroll
-          for (int j1 = 0; j1 < 3; ++j1) {
-            double x = 0.0, y = 0.0;
-#pragma unroll
-            for (int j2 = 0; j2 < 3; ++j2) {
-              const double v = geo.v(j1, j2, hl);
-              x = x + v * fdn[j2];
-              y = y + v * ddn[j2];
-            }
-            nf[j1] = x; nd[j1] = y;
-          }
-#pragma unroll
-          for (int r = 0; r < 3; ++r) { fdn[r] = nf[r]; ddn[r] = nd[r]; }
-        }
-      }
+    // sums over g of the fluxes at half level hl, kept by lane (hl mod NGP) and written NGP levels at a time
+    auto emit = [&](int hl) {
       if (fx.sw_up_band && valid) {     // spectral flux profiles: sums over the regions per g-point (:485-498, :611-625)
         const size_t o = col + ncol * ord.half(hl);
         const double dir = mu0 * (ddn[0] + ddn[1] + ddn[2]);
@@ -328,6 +353,79 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
             fx.sw_dn_clear[o] = mu0 * kept.v[5] + kept.v[4];
             if (fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[o] = mu0 * kept.v[5];
           }
+        }
+      }
+    };
+    emit(0);
+    GeoFeed<NGP> feed;
+    feed.init(prep, ncol_loc, nlev, cloc, L.d + (size_t)(cib * NGP) * (L.rec2 * 2), glane);
+    constexpr int K = ECRAD_TC_BATCH_S;
+    for (int l0 = 0; l0 < ((ECRAD_ABLATE & 4) ? 0 : nlev); l0 += K) {
+      // records of K layers requested together
+      double2 p0[K][4], p1[K][4];
+      double pad[K][4];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int l = l0 + k;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { p0[k][q] = make_double2(0.0, 0.0); p1[k][q] = make_double2(0.0, 0.0); pad[k][q] = 0.0; }
+        if (l < nlev) {
+          if (do_clear) { p0[k][3] = s.pair(3, 0, l, tid); p1[k][3] = s.pair(3, 1, l, tid); pad[k][3] = s.single(3, l, tid); }
+          if (!do_clear || l <= lcb) { p0[k][0] = s.pair(0, 0, l, tid); p1[k][0] = s.pair(0, 1, l, tid); pad[k][0] = s.single(0, l, tid); }
+          if (cloudy.test(l)) {
+#pragma unroll
+            for (int r = 1; r < 3; ++r) { p0[k][r] = s.pair(r, 0, l, tid); p1[k][r] = s.pair(r, 1, l, tid); pad[k][r] = s.single(r, l, tid); }
+          }
+        }
+      }
+      if (l0 + K - 1 >= cloudy_first - 1) feed.template fetch<K>(l0 + 1, 1);     // v_matrix of the half level below each layer
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int l = l0 + k;
+        if (l < nlev) {
+          if (do_clear) {
+            fdn_c = p0[k][3].x * fdn_c + ddn_c * p0[k][3].y;
+            ddn_c = p1[k][3].x * ddn_c;
+            fup_c = ddn_c * pad[k][3] + fdn_c * p1[k][3].y;
+          }
+          {
+            const bool shared = do_clear && l > lcb;      // region 1 record == clear-sky record
+            const double2 q0 = shared ? p0[k][3] : p0[k][0], q1 = shared ? p1[k][3] : p1[k][0];
+            const double ad = shared ? pad[k][3] : pad[k][0];
+            fdn[0] = q0.x * fdn[0] + ddn[0] * q0.y;
+            ddn[0] = q1.x * ddn[0];
+            fup[0] = ddn[0] * ad + fdn[0] * q1.y;
+          }
+          const bool cl_here = cloudy.test(l);
+          if (!cl_here) {
+            fdn[1] = fdn[2] = 0.0; fup[1] = fup[2] = 0.0; ddn[1] = ddn[2] = 0.0;
+          } else {
+#pragma unroll
+            for (int r = 1; r < 3; ++r) {
+              fdn[r] = p0[k][r].x * fdn[r] + ddn[r] * p0[k][r].y;
+              ddn[r] = p1[k][r].x * ddn[r];
+              fup[r] = ddn[r] * pad[k][r] + fdn[r] * p1[k][r].y;
+            }
+          }
+          const int hl = l + 1;
+          const bool cl_below = hl < nlev && cloudy.test(hl);
+          if (cl_here || cl_below) {   // singlemat_x_vec(v_matrix(:,:,jlev+1), .)
+            double nf[3], nd[3];
+#pragma unroll
+            for (int j1 = 0; j1 < 3; ++j1) {
+              double x = 0.0, y = 0.0;
+#pragma unroll
+              for (int j2 = 0; j2 < 3; ++j2) {
+                const double v = feed.v(k, j1, j2);
+                x = x + v * fdn[j2];
+                y = y + v * ddn[j2];
+              }
+              nf[j1] = x; nd[j1] = y;
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { fdn[r] = nf[r]; ddn[r] = nd[r]; }
+          }
+          emit(hl);
         }
       }
     }
@@ -386,60 +484,6 @@ ECRAD_DEV constexpr int TL_SS(int r /*1,2*/) { return 6 + 4 * (r - 1); }     // 
 ECRAD_DEV constexpr int TL_D(int r /*0..2*/) { return 12 + 4 * r; }          // (a1, c)
 ECRAD_DEV constexpr int TL_DT(int r /*0..2*/) { return 14 + 4 * r; }         // (ts, ta)
 constexpr int LW_TC_PLANES = 24;
-
-// Per-column geometry of one level for the sweeps (3 region fractions, v_matrix, u_matrix: 21 values
-// that all lanes of a column need).  Lane q of the column group loads item q of the NEXT level while
-// the current one is processed -- one load instruction per level instead of 21, off the critical
-// path -- and the items reach the other lanes through the group's level-record area in LDS, which is
-// idle during the sweeps and private to the wave.
-template <int NGP>
-struct GeoFeed {
-  static constexpr int NI = 21, PER = (NI + NGP - 1) / NGP;
-  const double* src[PER];
-  int maxlev[PER];
-  size_t stride;
-  double* stage;
-  int glane;
-  ECRAD_DEV void init(const DevCloudPrep& p, int nloc, int nlev, int cloc, double* lds_stage, int lane_in_group) {
-    stride = nloc; stage = lds_stage; glane = lane_in_group;
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int q = glane + u * NGP;
-      if (q < 3) { src[u] = p.region_fracs + (size_t)q * nlev * nloc + cloc; maxlev[u] = nlev - 1; }
-      else if (q < 12) { src[u] = p.v_matrix + (size_t)(q - 3) * (nlev + 1) * nloc + cloc; maxlev[u] = nlev; }
-      else if (q < NI) { src[u] = p.u_matrix + (size_t)(q - 12) * (nlev + 1) * nloc + cloc; maxlev[u] = nlev; }
-      else { src[u] = p.region_fracs + cloc; maxlev[u] = 0; }
-    }
-  }
-  // Make the items of levels lev0, lev0+step, ..., lev0+(K-1)*step available as batch entries 0..K-1
-  // (fractions of layer `lev`, matrices of half level `lev`; out-of-range levels are clamped)
-  template <int K>
-  ECRAD_DEV void fetch(int lev0, int step) {
-    double held[K][PER];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-#pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const int lev = lev0 + k * step;
-        const int l = lev < 0 ? 0 : (lev > maxlev[u] ? maxlev[u] : lev);
-        held[k][u] = src[u][stride * l];
-      }
-    }
-    wave_sync();
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-#pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const int q = glane + u * NGP;
-        if (q < NI) stage[k * NI + q] = held[k][u];
-      }
-    }
-    wave_sync();
-  }
-  ECRAD_DEV double frac(int k, int r) const { return stage[k * NI + r]; }
-  ECRAD_DEV double v(int k, int i, int j) const { return stage[k * NI + 3 + i + 3 * j]; }
-  ECRAD_DEV double u(int k, int i, int j) const { return stage[k * NI + 12 + i + 3 * j]; }
-};
 
 template <typename TAB, int NGP>
 __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(SpectralArgs args_in_kernarg) {

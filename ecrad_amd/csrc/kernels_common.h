@@ -413,6 +413,22 @@ struct LevMask {
     return (w >> (l & 63)) & 1ull;
   }
   ECRAD_DEV bool any() const { return (w0 | w1 | w2 | w3) != 0ull; }
+  // smallest level whose flag is set; `none` if none
+  ECRAD_DEV int lowest(int none) const {
+    if (w0) return __ffsll((long long)w0) - 1;
+    if (w1) return 63 + __ffsll((long long)w1);
+    if (w2) return 127 + __ffsll((long long)w2);
+    if (w3) return 191 + __ffsll((long long)w3);
+    return none;
+  }
+  // largest level whose flag is set; -1 if none
+  ECRAD_DEV int highest() const {
+    if (w3) return 255 - __clzll((long long)w3);
+    if (w2) return 191 - __clzll((long long)w2);
+    if (w1) return 127 - __clzll((long long)w1);
+    if (w0) return 63 - __clzll((long long)w0);
+    return -1;
+  }
   // or in `nbits` (<= 64) flags for levels l0 .. l0+nbits-1; l0 is a multiple of nbits (a power of two)
   ECRAD_DEV void or_bits(int l0, unsigned long long bits) {
     const unsigned long long b = bits << (l0 & 63);
