@@ -547,6 +547,9 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
       build(a.n_bands_lw, src_lw_pho, src_lw_phi, t01, t2);
       if ((st = upload<double>(h, t01.data(), t01.size(), &o.lw_tab01))) return st;
       if ((st = upload<double>(h, t2.data(), t2.size(), &o.lw_tab2))) return st;
+      std::vector<double> ab(t2.size());
+      for (size_t i = 0; i < ab.size(); ++i) ab[i] = t01[2 * i] * (1.0 - t01[2 * i + 1]);
+      if ((st = upload<double>(h, ab.data(), ab.size(), &o.lw_abs))) return st;
     }
   }
   if (c.pdf_sampler.val) {

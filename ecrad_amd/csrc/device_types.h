@@ -69,6 +69,7 @@ struct DevAerosolOptics {
   // the asymmetry factor; rows [0, n_type_phobic) are the hydrophobic types, then (nrh x n_type_philic)
   // hydrophilic rows.  A column group reads 512 + 256 contiguous bytes per type.
   const double *sw_tab01, *sw_tab2, *lw_tab01, *lw_tab2;
+  const double* lw_abs;        // mass_ext * (1 - ssa), same rows: all the longwave needs without aerosol scattering
   // per ACTIVE type, in the order of the caller's type list, packed as
   //   bits 0-7 index into aerosol%mixing_ratio | bit 8 hydrophilic (add the humidity bin to the row) |
   //   bits 9-31 first row in the tables

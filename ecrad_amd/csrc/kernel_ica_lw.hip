@@ -77,6 +77,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
     const LwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block, MODE == 0 ? L_WIDTH_CLEAR : L_WIDTH_FULL};
     const int g = glane < ng ? glane : ng - 1;
     const int ib = cfg.i_band_from_reordered_g_lw[g] - 1;
+    const int aer_type = aerosol_lane_type(cfg, glane);
     const bool have_clear_out = cfg.do_clear != 0;
     const bool do_deriv = cfg.do_lw_derivatives != 0 && a.fx.lw_derivatives != nullptr;
     const bool use_aerosols = cfg.use_aerosols != 0;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
         ECRAD_LAP(tm, 2, od);           // combine
         if (use_aerosols) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
-          const AerosolLayer al = aerosol_layer<false>(b.cfg, b.in, L, slot, col, lev, ib);
+          const AerosolLayer al = aerosol_layer<false, NGP>(b.cfg, b.in, L, slot, col, lev, ib, aer_type);
           od = od + al.od;   // radiation_aerosol_optics.F90:805-818 (no longwave aerosol scattering)
         }
         const LwCoef c = no_scattering_lw(od, planck_top, planck_bot);

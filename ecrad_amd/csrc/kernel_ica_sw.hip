@@ -209,6 +209,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
     const SwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block, nlev};
     const int g = glane < ng ? glane : ng - 1;
     const int ib = cfg.i_band_from_reordered_g_sw[g] - 1;
+    const int aer_type = aerosol_lane_type(cfg, glane);
     const double ray_g = m.rayleigh_molar_scat[g];
     const bool have_clear_out = cfg.do_clear != 0;
     const unsigned flags = (cfg.use_aerosols ? SWF_AEROSOLS : 0) | (cfg.do_sw_delta_scaling_with_gases ? SWF_DELTA_GASES : 0);
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
           double asym = 0.0;
           if (flags & SWF_AEROSOLS) {
             const SpectralArgs& b = kernarg_block<SpectralArgs>();
-            AerosolLayer al = aerosol_layer<true>(b.cfg, b.in, L, slot, col, lev, ib);
+            AerosolLayer al = aerosol_layer<true, NGP>(b.cfg, b.in, L, slot, col, lev, ib, aer_type);
             if (!(flags & SWF_DELTA_GASES)) delta_eddington_extensive_vec(al);
             merge_aerosol_sw(b.cfg, al, od, ssa, asym);
           }

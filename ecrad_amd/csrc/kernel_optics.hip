@@ -23,6 +23,7 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
   const LdsLayout L = make_lds(smem, m.hot.nquad, nct);
   const int g = glane < ng ? glane : ng - 1;
   const int ib = (IS_SW ? cfg.i_band_from_reordered_g_sw[g] : cfg.i_band_from_reordered_g_lw[g]) - 1;
+  const int aer_type = aerosol_lane_type(cfg, glane);
   const int nb = IS_SW ? cfg.n_bands_sw : cfg.n_bands_lw;
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int cloc_raw = grp * CPB + cib;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
           ssa = ssa / od;
           double asym = 0.0;
           if (cfg.use_aerosols) {
-            AerosolLayer a = aerosol_layer<true>(cfg, in, L, slot, col, lev, ib);
+            AerosolLayer a = aerosol_layer<true, NGP>(cfg, in, L, slot, col, lev, ib, aer_type);
             if (!cfg.do_sw_delta_scaling_with_gases) delta_eddington_extensive_vec(a);
             merge_aerosol_sw(cfg, a, od, ssa, asym);
           }
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
           }
         } else {
             const double planck_bot = planck_lookup<TAB>(m, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
-          if (cfg.use_aerosols) od = od + aerosol_layer<false>(cfg, in, L, slot, col, lev, ib).od;
+          if (cfg.use_aerosols) od = od + aerosol_layer<false, NGP>(cfg, in, L, slot, col, lev, ib, aer_type).od;
           if (valid) {
             if (out.od_lw) out.od_lw[o] = od;
             if (out.planck_hl) {

@@ -157,6 +157,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
     quads.reset();
     const int g = glane < ng ? glane : ng - 1;
     const int ib = cfg.i_band_from_reordered_g_sw[g] - 1;
+    const int aer_type = aerosol_lane_type(cfg, glane);
     const double ray_g = m.rayleigh_molar_scat[g];
     const bool do_clear = cfg.do_clear != 0;
     const bool use_aerosols = cfg.use_aerosols != 0, delta_gases = cfg.do_sw_delta_scaling_with_gases != 0;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
         double asym = 0.0;
         if (use_aerosols) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
-          AerosolLayer al = aerosol_layer<true>(b.cfg, b.in, L, slot, col, l, ib);
+          AerosolLayer al = aerosol_layer<true, NGP>(b.cfg, b.in, L, slot, col, l, ib, aer_type);
           if (!delta_gases) delta_eddington_extensive_vec(al);
           merge_aerosol_sw(b.cfg, al, od, ssa, asym);
         }
@@ -515,6 +516,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
     quads.reset();
     const int g = glane < ng ? glane : ng - 1;
     const int ib = cfg.i_band_from_reordered_g_lw[g] - 1;
+    const int aer_type = aerosol_lane_type(cfg, glane);
     const bool do_clear = cfg.do_clear != 0;
     const bool do_deriv = cfg.do_lw_derivatives != 0 && a.fx.lw_derivatives != nullptr;
     const bool use_aerosols = cfg.use_aerosols != 0, cloud_scattering = cfg.do_lw_cloud_scattering != 0;
@@ -570,7 +572,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
         double od = gas_combine<TAB>(launder_uniform(gh.nquad), L, slot, quads);
         if (use_aerosols) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
-          od = od + aerosol_layer<false>(b.cfg, b.in, L, slot, col, lev, ib).od;
+          od = od + aerosol_layer<false, NGP, 12>(b.cfg, b.in, L, slot, col, lev, ib, aer_type).od;
         }
         const LwCoef c = no_scattering_lw(od, planck_top, planck_bot);
         s.pair(TL_A0, lev, tid) = make_double2(c.transmittance, c.source_up);

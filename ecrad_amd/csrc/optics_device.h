@@ -378,9 +378,21 @@ ECRAD_DEV double incoming_sw_g(const DevCkdModel& m, const DevInputs& in, int g)
 // !lw_scattering, the absorption optical depth only (LW, :655-662).
 struct AerosolLayer { double od, scat, scat_g; };
 
-template <bool IS_SW>
+// Index into aerosol%mixing_ratio of the active type this lane fetches for its column group (lane k of
+// the group fetches active type k, see aerosol_layer); -1 for the other lanes.  Once per column group.
+ECRAD_DEV int aerosol_lane_type(const DevConfig& cfg, int glane) {
+  int t = -1;
+#pragma unroll
+  for (int k = 0; k < kMaxActiveAerosols; ++k)
+    if (k < cfg.aerosol.nactive && k == glane) t = (int)(cfg.aerosol.active[k] & 0xffu);
+  return t;
+}
+
+// KB_LW: types per batch of table loads on the absorption-only longwave path (what is best depends on
+// the register pressure of the calling kernel)
+template <bool IS_SW, int NGP, int KB_LW = 4>
 ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, const LdsLayout& L, int slot,
-                                     int col, int lev, int ib) {
+                                     int col, int lev, int ib, int lane_type) {
   AerosolLayer a = {0.0, 0.0, 0.0};
   const int jlev = level_order(in).full(lev) + 1;   // 1-based, in the caller's level order
   if (jlev < in.aerosol_istartlev || jlev > in.aerosol_iendlev) return a;
@@ -393,45 +405,63 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, 
   const int nlev_aer = in.aerosol_iendlev - in.aerosol_istartlev + 1;
   const size_t type_stride = ncol * (size_t)nlev_aer;
   const double* __restrict__ mr0 = in.aerosol_mixing_ratio + col + ncol * (size_t)(jlev - in.aerosol_istartlev);
-  const double2* __restrict__ tab01 = reinterpret_cast<const double2*>(IS_SW ? ao.sw_tab01 : ao.lw_tab01);
-  const double* __restrict__ tab2 = IS_SW ? ao.sw_tab2 : ao.lw_tab2;
   const int n = ao.nactive;
   const bool scattering = IS_SW || cfg.do_lw_aerosol_scattering;
-  // The loads of kBatch types are requested together (each is a full L2 round trip: the mixing ratio
-  // is one broadcast line per column, the table row 16 + 8 B per lane); the sums keep the reference's
-  // order over types.
+  // The mixing ratios are per column: lane k of the column group fetches type k (ONE load instruction
+  // for all types) and the type loop broadcasts them over the group through the LDS crossbar.
+  const double mr_mine = lane_type >= 0 ? mr0[type_stride * (size_t)lane_type] : 0.0;
+  if (!scattering) {
+    // longwave absorption only (:655-662): one table value per type
+    const double* __restrict__ tab = ao.lw_abs;
+    constexpr int kBatch = KB_LW;
+    for (int k0 = 0; k0 < n; k0 += kBatch) {
+      double t[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        t[u] = 0.0;
+        const int k = k0 + u;
+        if (k < n) {
+          const uint32_t desc = ao.active[k];
+          const int row = (int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0);
+          t[u] = tab[ib + (size_t)nb * row];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u)
+        if (k0 + u < n) a.od = a.od + factor * __shfl(mr_mine, k0 + u, NGP) * t[u];
+    }
+    return a;
+  }
+  const double2* __restrict__ tab01 = reinterpret_cast<const double2*>(IS_SW ? ao.sw_tab01 : ao.lw_tab01);
+  const double* __restrict__ tab2 = IS_SW ? ao.sw_tab2 : ao.lw_tab2;
+  // The table rows of kBatch types are requested together (each a full L2 round trip: 16 + 8 B per
+  // lane); the sums keep the reference's order over types.
 #ifndef ECRAD_AEROSOL_BATCH
 #define ECRAD_AEROSOL_BATCH 4
 #endif
   constexpr int kBatch = ECRAD_AEROSOL_BATCH;
   for (int k0 = 0; k0 < n; k0 += kBatch) {
-    double mr[kBatch];
     double2 t01[kBatch];
     double t2[kBatch];
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
-      mr[u] = 0.0; t01[u] = make_double2(0.0, 0.0); t2[u] = 0.0;
+      t01[u] = make_double2(0.0, 0.0); t2[u] = 0.0;
       const int k = k0 + u;
       if (k < n) {
         const uint32_t desc = ao.active[k];
         const int row = (int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0);
-        mr[u] = mr0[type_stride * (desc & 0xffu)];
         const size_t o = ib + (size_t)nb * row;
         t01[u] = tab01[o];                       // mass_ext, ssa
-        if (scattering) t2[u] = tab2[o];         // asymmetry
+        t2[u] = tab2[o];                         // asymmetry
       }
     }
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
       if (k0 + u < n) {
-        if (scattering) {
-          const double local_od = factor * mr[u] * t01[u].x;
-          a.od = a.od + local_od;
-          a.scat = a.scat + local_od * t01[u].y;
-          a.scat_g = a.scat_g + local_od * t01[u].y * t2[u];
-        } else {
-          a.od = a.od + factor * mr[u] * t01[u].x * (1.0 - t01[u].y);
-        }
+        const double local_od = factor * __shfl(mr_mine, k0 + u, NGP) * t01[u].x;
+        a.od = a.od + local_od;
+        a.scat = a.scat + local_od * t01[u].y;
+        a.scat_g = a.scat_g + local_od * t01[u].y * t2[u];
       }
     }
   }
