@@ -317,7 +317,8 @@ int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
         (c.do_lw && !identity(c.i_spec_from_reordered_g_lw, c.n_g_lw, c.n_spec_lw)))
       return fail(h, ECRAD_EUNSUPPORTED, "do_save_spectral_flux is implemented for one spectral interval per g-point only");
   }
-  if (c.do_lw && c.do_lw_aerosol_scattering) return fail(h, ECRAD_EUNSUPPORTED, "do_lw_aerosol_scattering is not implemented");
+  if (c.do_lw && c.do_lw_aerosol_scattering && !c.do_lw_cloud_scattering)
+    return fail(h, ECRAD_EINVAL, "longwave aerosol scattering requires longwave cloud scattering");   // radiation_interface.F90:84-93
   const bool mcica = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_MCICA) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_MCICA);
   if (mcica) {
     if (!c.do_clear) return fail(h, ECRAD_EINVAL, "McICA requires clear-sky calculation to be performed");  // radiation_mcica_sw.F90:141
@@ -770,7 +771,8 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
   const int grid_sw = c.do_sw ? grid_for(h, r.nloc, h->ngp_sw) : 0;
   const int grid_lw = c.do_lw ? grid_for(h, r.nloc, h->ngp_lw) : 0;
   const size_t per_block_sw = !c.do_sw ? 0 : (sw_tc ? sw_tc_scratch_doubles(nlev) : sw_ica_scratch_doubles(c.i_solver_sw, nlev));
-  const size_t per_block_lw = !c.do_lw ? 0 : (lw_tc ? lw_tc_scratch_doubles(nlev) : lw_ica_scratch_doubles(c.i_solver_lw, nlev));
+  const bool lw_scat = c.do_lw && c.do_lw_aerosol_scattering != 0;
+  const size_t per_block_lw = !c.do_lw ? 0 : (lw_tc ? lw_tc_scratch_doubles(nlev, lw_scat) : lw_scat ? lw_scat_scratch_doubles(nlev) : lw_ica_scratch_doubles(c.i_solver_lw, nlev));
   const size_t need_sw = per_block_sw * grid_sw * 8, need_lw = per_block_lw * grid_lw * 8;
   HIP_TRY(h, h->scratch.ensure(need_sw > need_lw ? need_sw : need_lw));
   HIP_TRY(h, h->counters.ensure(256));
@@ -820,6 +822,7 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
                                           prep.total_cloud_cover_lw));
     }
     if (lw_tc) HIP_TRY(h, launch_lw_tc(h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_lw, counters, m));
+    else if (lw_scat) HIP_TRY(h, launch_lw_scat(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_lw, counters, m));
     else HIP_TRY(h, launch_lw_ica(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_lw, counters, m));
   }
   HIP_TRY(h, hipEventRecord(h->evs[2], stream));

@@ -7,7 +7,8 @@
 // clear-sky down-then-up sweep (radiation_adding_ica_lw.F90:272), the cloudy-sky adding method in its
 // "fast" form (radiation_adding_ica_lw.F90:137; identical numbers to :32 because clear layers have
 // zero reflectance) and the Hogan & Bozzo derivatives (radiation_lw_derivatives.F90:43,88).
-// Longwave aerosol scattering (do_lw_aerosol_scattering) is not implemented: the host rejects it.
+// With longwave aerosol scattering (do_lw_aerosol_scattering) every layer reflects and these shortcuts
+// do not hold: that configuration runs kernel_lw_scat.hip instead.
 #include "kernels_common.h"
 #include "optics_device.h"
 #include "launch.h"

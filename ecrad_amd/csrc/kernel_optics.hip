@@ -79,8 +79,26 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
           }
         } else {
             const double planck_bot = planck_lookup<TAB>(m, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
-          if (cfg.use_aerosols) od = od + aerosol_layer<false, NGP>(cfg, in, L, slot, col, lev, ib, aer_type).od;
+          double ssa = 0.0, asym = 0.0;
+          if (cfg.use_aerosols) {
+            AerosolLayer a = aerosol_layer<false, NGP>(cfg, in, L, slot, col, lev, ib, aer_type);
+            if (cfg.do_lw_aerosol_scattering) {     // radiation_aerosol_optics.F90:778-797
+              delta_eddington_extensive_vec(a);
+              const double local_od = od + a.od;
+              if (local_od > 0.0 && a.od > 0.0) {
+                if (a.scat > 0.0) asym = a.scat_g / a.scat;
+                ssa = a.scat / local_od;
+                od = local_od;
+              }
+            } else {
+              od = od + a.od;
+            }
+          }
           if (valid) {
+            if (cfg.do_lw_aerosol_scattering) {
+              if (out.ssa_lw) out.ssa_lw[o] = ssa;
+              if (out.g_lw) out.g_lw[o] = asym;
+            }
             if (out.od_lw) out.od_lw[o] = od;
             if (out.planck_hl) {
               const size_t op = g + (size_t)ng * (lev + (size_t)(nlev + 1) * cloc);

@@ -472,11 +472,12 @@ hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream
 //                    fdn <- a1 fdn + c,  fup = ts + ta fdn   (ts, ta: total source / albedo just below)
 struct TcLwScratch {
   double* base;
+  int np;       // planes per layer
   ECRAD_DEV StreamRef<double2> pair(int plane, int lev, int tid) const {
-    return {reinterpret_cast<double2*>(base + ((size_t)lev * 24 + plane) * kBlock) + tid};
+    return {reinterpret_cast<double2*>(base + ((size_t)lev * np + plane) * kBlock) + tid};
   }
   ECRAD_DEV StreamRef<double> single(int plane, int lev, int tid) const {
-    return {base + ((size_t)lev * 24 + plane) * kBlock + tid};
+    return {base + ((size_t)lev * np + plane) * kBlock + tid};
   }
 };
 constexpr int TL_A0 = 0, TL_SD1 = 2;
@@ -485,8 +486,14 @@ ECRAD_DEV constexpr int TL_SS(int r /*1,2*/) { return 6 + 4 * (r - 1); }     // 
 ECRAD_DEV constexpr int TL_D(int r /*0..2*/) { return 12 + 4 * r; }          // (a1, c)
 ECRAD_DEV constexpr int TL_DT(int r /*0..2*/) { return 14 + 4 * r; }         // (ts, ta)
 constexpr int LW_TC_PLANES = 24;
+// With longwave aerosol scattering (ASCAT) the clear region reflects too: plane 3 holds its reflectance
+// (pair (SD1, R1) in planes 2-3), cloud top is the top of the atmosphere (radiation_tripleclouds_lw.F90:
+// 225-229) and the clear-sky fluxes need the adding method, i.e. their own downward sweep with records
+// pair (a1, c), pair (albedo, source) in planes 24-27
+constexpr int TL_DC = 24, TL_DCT = 26;
+constexpr int LW_TC_PLANES_ASCAT = 28;
 
-template <typename TAB, int NGP>
+template <typename TAB, int NGP, bool ASCAT>
 __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
     const int grp = next_group;
     if (grp >= ngroups) break;
     const LdsLayout L = make_lds(smem, m.hot.nquad, cfg.n_cloud_types);
-    const TcLwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block};
+    const TcLwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block, ASCAT ? LW_TC_PLANES_ASCAT : LW_TC_PLANES};
     quads.reset();
     const int g = glane < ng ? glane : ng - 1;
     const int ib = cfg.i_band_from_reordered_g_lw[g] - 1;
@@ -570,13 +577,26 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
         gas_load<TAB>(gh, launder_uniform(gh.nquad), launder_uniform(gh.nplain), L, slot, g, quads);
         const double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
         double od = gas_combine<TAB>(launder_uniform(gh.nquad), L, slot, quads);
+        double ssa = 0.0, asym = 0.0;        // clear-region scattering properties (ASCAT only)
         if (use_aerosols) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
-          od = od + aerosol_layer<false, NGP, 12>(b.cfg, b.in, L, slot, col, lev, ib, aer_type).od;
+          if (ASCAT) {                       // radiation_aerosol_optics.F90:778-797
+            AerosolLayer al = aerosol_layer<false, NGP>(b.cfg, b.in, L, slot, col, lev, ib, aer_type);
+            delta_eddington_extensive_vec(al);
+            const double local_od = od + al.od;
+            if (local_od > 0.0 && al.od > 0.0) {
+              if (al.scat > 0.0) asym = al.scat_g / al.scat;
+              ssa = al.scat / local_od;
+              od = local_od;
+            }
+          } else {
+            od = od + aerosol_layer<false, NGP, 12>(b.cfg, b.in, L, slot, col, lev, ib, aer_type).od;
+          }
         }
-        const LwCoef c = no_scattering_lw(od, planck_top, planck_bot);
+        const LwCoef c = ASCAT ? ref_trans_lw(od, ssa, asym, planck_top, planck_bot) : no_scattering_lw(od, planck_top, planck_bot);
         s.pair(TL_A0, lev, tid) = make_double2(c.transmittance, c.source_up);
-        s.single(TL_SD1, lev, tid) = c.source_dn;
+        if (ASCAT) s.pair(TL_SD1, lev, tid) = make_double2(c.source_dn, c.reflectance);
+        else s.single(TL_SD1, lev, tid) = c.source_dn;
         if (L.D(F_FRAC, slot) > 0.0) {
           if (!cloudy.any()) { ict = lev; fdn_ctop = fdn_c; }
           cloudy.set(lev);
@@ -588,8 +608,14 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
             LwCoef c2;
             if (cloud_scattering) {
               double ssa_total = 0.0, g_total = 0.0;
-              if (od_total > 0.0) ssa_total = cl.ssa * od_cloud_new / od_total;
-              if (ssa_total > 0.0 && od_total > 0.0) g_total = cl.g * cl.ssa * od_cloud_new / (ssa_total * od_total);
+              if (ASCAT) {     // :335-343
+                if (od_total > 0.0) ssa_total = (ssa * od + cl.ssa * od_cloud_new) / od_total;
+                if (ssa_total > 0.0 && od_total > 0.0)
+                  g_total = (asym * ssa * od + cl.g * cl.ssa * od_cloud_new) / (ssa_total * od_total);
+              } else {
+                if (od_total > 0.0) ssa_total = cl.ssa * od_cloud_new / od_total;
+                if (ssa_total > 0.0 && od_total > 0.0) g_total = cl.g * cl.ssa * od_cloud_new / (ssa_total * od_total);
+              }
               c2 = ref_trans_lw(od_total, ssa_total, g_total, planck_top, planck_bot);
             } else {
               c2 = no_scattering_lw(od_total, planck_top, planck_bot);
@@ -598,23 +624,26 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
             s.pair(TL_SS(jreg), lev, tid) = make_double2(c2.source_up, c2.source_dn);
           }
         }
-        fdn_c = c.transmittance * fdn_c + c.source_dn;
-        if (lw_dn_band && valid) {        // provisional below cloud top, like lw_dn
-          const size_t o = col + ncol * ord.half(lev + 1);
-          spec_put(lw_dn_band, ng, g, o, fdn_c);
-          spec_put(lw_dn_clear_band, ng, g, o, fdn_c);
+        if (!ASCAT) {     // clear-sky downward flux of calc_fluxes_no_scattering_lw
+          fdn_c = c.transmittance * fdn_c + c.source_dn;
+          if (lw_dn_band && valid) {        // provisional below cloud top, like lw_dn
+            const size_t o = col + ncol * ord.half(lev + 1);
+            spec_put(lw_dn_band, ng, g, o, fdn_c);
+            spec_put(lw_dn_clear_band, ng, g, o, fdn_c);
+          }
+          const double sd = group_sum<NGP>(valid ? fdn_c : 0.0);
+          if (glane == j) keep_dn = sd;     // lane j keeps the chunk's layer j; one store per chunk
         }
-        const double sd = group_sum<NGP>(valid ? fdn_c : 0.0);
-        if (glane == j) keep_dn = sd;     // lane j keeps the chunk's layer j; one store per chunk
         planck_top = planck_bot;
       }
-      if (col_ok && glane < nl) {
+      if (!ASCAT && col_ok && glane < nl) {
         const size_t o = col + ncol * ord.half(l0 + glane + 1);
         lw_dn[o] = keep_dn;      // provisional: replaced below cloud top by the all-sky value
         if (lw_dn_clear) lw_dn_clear[o] = keep_dn;
       }
     }
     if (!cloudy.any()) { ict = nlev; fdn_ctop = fdn_c; }
+    if (ASCAT) { ict = 0; fdn_ctop = 0.0; }       // i_cloud_top = 1: every layer goes through the region sweeps
     const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
     if (ECRAD_ABLATE & 4) continue;
 
@@ -639,10 +668,13 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
 #pragma unroll
       for (int r = 0; r < 3; ++r) { ts[r] = feed.frac(0, r) * emission; ta[r] = albedo; }
       double fup_c = emission + albedo * fdn_c;
+      double alb_c = albedo, src_c = emission;      // ASCAT: clear-sky adding method (adding_ica_lw)
       {
-        const double su = group_sum<NGP>(valid ? fup_c : 0.0);
-        if (lead && do_clear) fx.lw_up_clear[col + ncol * ord.half(nlev)] = su;
-        if (valid && do_clear) spec_put(fx.lw_up_clear_band, ng, g, col + ncol * ord.half(nlev), fup_c);
+        if (!ASCAT) {
+          const double su = group_sum<NGP>(valid ? fup_c : 0.0);
+          if (lead && do_clear) fx.lw_up_clear[col + ncol * ord.half(nlev)] = su;
+          if (valid && do_clear) spec_put(fx.lw_up_clear_band, ng, g, col + ncol * ord.half(nlev), fup_c);
+        }
         if (ict == nlev) {      // no cloud in this column: the surface is the "cloud top"
           fup0 = ts[0] + ta[0] * fdn_ctop;
           const double st = group_sum<NGP>(valid ? fup0 : 0.0);
@@ -653,16 +685,17 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
       double keep_c = 0.0, keep_t = 0.0;
       for (int l0 = nlev - 1; l0 >= 0; l0 -= K) {
         double2 a0[K], rt[K][2], ss[K][2];
-        double sd1[K];
+        double sd1[K], r1[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           const int l = l0 - k;
-          a0[k] = make_double2(0.0, 0.0); sd1[k] = 0.0;
+          a0[k] = make_double2(0.0, 0.0); sd1[k] = 0.0; r1[k] = 0.0;
 #pragma unroll
           for (int r = 0; r < 2; ++r) { rt[k][r] = make_double2(0.0, 0.0); ss[k][r] = make_double2(0.0, 0.0); }
           if (l >= 0) {
             a0[k] = s.pair(TL_A0, l, tid);
-            sd1[k] = s.single(TL_SD1, l, tid);
+            if (ASCAT) { const double2 t = s.pair(TL_SD1, l, tid); sd1[k] = t.x; r1[k] = t.y; }
+            else sd1[k] = s.single(TL_SD1, l, tid);
             if (cloudy.test(l)) {
 #pragma unroll
               for (int r = 0; r < 2; ++r) { rt[k][r] = s.pair(TL_RT(r + 1), l, tid); ss[k][r] = s.pair(TL_SS(r + 1), l, tid); }
@@ -675,18 +708,36 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
           const int l = l0 - k;
           if (l >= 0) {
             const double T1 = a0[k].x, SU1 = a0[k].y;
-            fup_c = T1 * fup_c + SU1;
+            if (!ASCAT) fup_c = T1 * fup_c + SU1;
+            if (ASCAT && do_clear) {      // clear-sky albedo / source recurrences + records of sweep C'
+              const double R1 = r1[k];
+              const double inv = 1.0 / (1.0 - alb_c * R1);
+              s.pair(TL_DC, l, tid) = make_double2(T1 * inv, (R1 * src_c + sd1[k]) * inv);
+              s.pair(TL_DCT, l, tid) = make_double2(alb_c, src_c);
+              const double src_new = SU1 + T1 * (src_c + alb_c * sd1[k]) * inv;
+              alb_c = R1 + T1 * T1 * alb_c * inv;
+              src_c = src_new;
+            }
             if (l >= ict) {
               double below[3] = {0.0, 0.0, 0.0}, sbelow[3] = {0.0, 0.0, 0.0};
               const bool cl_here = cloudy.test(l);
               {
                 const double f = cl_here ? feed.frac(k, 0) : 1.0;
                 const double su1 = f * SU1, sdf = f * sd1[k];
-                // region 1 has zero reflectance (no longwave aerosol scattering): inv_denom = 1
-                s.pair(TL_D(0), l, tid) = make_double2(T1, sdf);
-                s.pair(TL_DT(0), l, tid) = make_double2(ts[0], ta[0]);
-                below[0] = T1 * T1 * ta[0];
-                sbelow[0] = su1 + T1 * (ts[0] + ta[0] * sdf);
+                if (ASCAT) {
+                  const double R1 = r1[k];
+                  const double inv = 1.0 / (1.0 - ta[0] * R1);
+                  s.pair(TL_D(0), l, tid) = make_double2(T1 * inv, (R1 * ts[0] + sdf) * inv);
+                  s.pair(TL_DT(0), l, tid) = make_double2(ts[0], ta[0]);
+                  below[0] = R1 + T1 * T1 * ta[0] * inv;
+                  sbelow[0] = su1 + T1 * (ts[0] + ta[0] * sdf) * inv;
+                } else {
+                  // region 1 has zero reflectance (no longwave aerosol scattering): inv_denom = 1
+                  s.pair(TL_D(0), l, tid) = make_double2(T1, sdf);
+                  s.pair(TL_DT(0), l, tid) = make_double2(ts[0], ta[0]);
+                  below[0] = T1 * T1 * ta[0];
+                  sbelow[0] = su1 + T1 * (ts[0] + ta[0] * sdf);
+                }
               }
               if (cl_here) {
 #pragma unroll
@@ -722,17 +773,17 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
               fup0 = T1 * fup0 + SU1;
             }
             if (valid) {
-              if (do_clear) spec_put(fx.lw_up_clear_band, ng, g, col + ncol * ord.half(l), fup_c);
+              if (do_clear && !ASCAT) spec_put(fx.lw_up_clear_band, ng, g, col + ncol * ord.half(l), fup_c);
               if (l <= ict) spec_put(fx.lw_up_band, ng, g, col + ncol * ord.half(l), fup0);
             }
-            const double sc = do_clear ? group_sum<NGP>(valid ? fup_c : 0.0) : 0.0;
+            const double sc = (do_clear && !ASCAT) ? group_sum<NGP>(valid ? fup_c : 0.0) : 0.0;
             const double st = group_sum<NGP>(valid && l <= ict ? fup0 : 0.0);
             if ((l & (NGP - 1)) == glane) { keep_c = sc; keep_t = st; }
             if ((l & (NGP - 1)) == 0) {
               const int lv = l + glane;
               if (col_ok && lv < nlev) {
                 const size_t o = col + ncol * ord.half(lv);
-                if (do_clear) fx.lw_up_clear[o] = keep_c;
+                if (do_clear && !ASCAT) fx.lw_up_clear[o] = keep_c;
                 if (lv <= ict) fx.lw_up[o] = keep_t;
               }
             }
@@ -741,8 +792,37 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
       }
       if (valid) {
         const size_t og = g + (size_t)ng * col;
-        if (do_clear) { fx.lw_dn_surf_clear_g[og] = fdn_c; fx.lw_up_toa_clear_g[og] = fup_c; }
+        if (do_clear && !ASCAT) { fx.lw_dn_surf_clear_g[og] = fdn_c; fx.lw_up_toa_clear_g[og] = fup_c; }
         fx.lw_up_toa_g[og] = fup0;
+      }
+      if (ASCAT && do_clear) {
+        // ---- sweep C': clear-sky fluxes by the adding method, top -> surface (adding_ica_lw :99-124) --
+        double fdn = 0.0, fup = src_c;
+        if (valid) fx.lw_up_toa_clear_g[g + (size_t)ng * col] = fup;
+        LevelSums<NGP, 2> kc;
+        for (int hl = 0; hl <= nlev; ++hl) {
+          if (hl > 0) {
+            const double2 d = s.pair(TL_DC, hl - 1, tid), as = s.pair(TL_DCT, hl - 1, tid);
+            fdn = d.x * fdn + d.y;
+            fup = as.x * fdn + as.y;
+          }
+          if (valid) {
+            const size_t o = col + ncol * ord.half(hl);
+            spec_put(fx.lw_up_clear_band, ng, g, o, fup);
+            spec_put(fx.lw_dn_clear_band, ng, g, o, fdn);
+          }
+          const double sums[2] = {group_sum<NGP>(valid ? fup : 0.0), group_sum<NGP>(valid ? fdn : 0.0)};
+          kc.keep(hl, glane, sums);
+          if ((hl & (NGP - 1)) == NGP - 1 || hl == nlev) {
+            const int lv = kc.mine(hl, glane);
+            if (col_ok && lv <= hl) {
+              const size_t o = col + ncol * ord.half(lv);
+              fx.lw_up_clear[o] = kc.v[0];
+              fx.lw_dn_clear[o] = kc.v[1];
+            }
+          }
+        }
+        if (valid) fx.lw_dn_surf_clear_g[g + (size_t)ng * col] = fdn;
       }
     }
 
@@ -871,16 +951,20 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
   }
 }
 
-size_t lw_tc_scratch_doubles(int nlev) { return (size_t)LW_TC_PLANES * nlev * kBlock; }
+size_t lw_tc_scratch_doubles(int nlev, bool aerosol_scattering) {
+  return (size_t)(aerosol_scattering ? LW_TC_PLANES_ASCAT : LW_TC_PLANES) * nlev * kBlock;
+}
 
 hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block,
                         int* counter, const DevCkdModel& m) {
   const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot};
-#define ECRAD_L(T, N) do { ECRAD_ALLOW_LDS((lw_tc_kernel<T, N>), lds); hipLaunchKernelGGL((lw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
+#define ECRAD_L2(T, N, A) do { ECRAD_ALLOW_LDS((lw_tc_kernel<T, N, A>), lds); hipLaunchKernelGGL((lw_tc_kernel<T, N, A>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
+#define ECRAD_L(T, N) do { if (cfg.do_lw_aerosol_scattering) ECRAD_L2(T, N, true); else ECRAD_L2(T, N, false); } while (0)
   if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
   else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }
 #undef ECRAD_L
+#undef ECRAD_L2
   return hipGetLastError();
 }
 

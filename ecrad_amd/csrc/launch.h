@@ -18,13 +18,18 @@ namespace ecrad {
 // doubles of block-private sweep scratch each kernel needs per block
 size_t sw_ica_scratch_doubles(int mode, int nlev);
 size_t lw_ica_scratch_doubles(int mode, int nlev);
+size_t lw_scat_scratch_doubles(int nlev);
 size_t sw_tc_scratch_doubles(int nlev);
-size_t lw_tc_scratch_doubles(int nlev);
+size_t lw_tc_scratch_doubles(int nlev, bool aerosol_scattering);
 
 hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
                          double* scratch, size_t per_block, int* counter, const DevCkdModel& m);
 hipError_t launch_lw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
+                         const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
+                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m);
+// the same solvers with longwave aerosol scattering (kernel_lw_scat.hip)
+hipError_t launch_lw_scat(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
                          double* scratch, size_t per_block, int* counter, const DevCkdModel& m);
 hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,

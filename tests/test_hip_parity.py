@@ -44,6 +44,18 @@ CASES = {
     "homogeneous_noclear": dict(sw_solver="Homogeneous", do_clear=False),
     "tripleclouds_noclear": dict(sw_solver="Tripleclouds", do_clear=False, do_sw_direct=False),
     "sw64": dict(sw_solver="Tripleclouds", gas_optics_sw_override_file_name="ecckd-1.2_sw_climate_window-64b_ckd-definition.nc"),
+    # longwave aerosol scattering (the reference's default when the namelist is silent): full adding method
+    "cloudless_lw_aerosol_scat": dict(sw_solver="Cloudless", do_lw_aerosol_scattering=True),
+    "homogeneous_lw_aerosol_scat": dict(sw_solver="Homogeneous", do_lw_aerosol_scattering=True),
+    "homogeneous_lw_aerosol_scat_noclear": dict(sw_solver="Homogeneous", do_lw_aerosol_scattering=True, do_clear=False),
+    "homogeneous_lw_aerosol_scat_spectral": dict(sw_solver="Homogeneous", do_lw_aerosol_scattering=True,
+                                                 do_save_spectral_flux=True),
+    "tripleclouds_lw_aerosol_scat": dict(sw_solver="Tripleclouds", do_lw_aerosol_scattering=True),
+    "tripleclouds_lw_aerosol_scat_noclear": dict(sw_solver="Tripleclouds", do_lw_aerosol_scattering=True, do_clear=False),
+    "tripleclouds_lw_aerosol_scat_spectral": dict(sw_solver="Tripleclouds", do_lw_aerosol_scattering=True,
+                                                  do_save_spectral_flux=True),
+    "mcica_lw_aerosol_scat": dict(sw_solver="McICA", do_lw_aerosol_scattering=True),
+    "mcica_lw_aerosol_scat_noaer": dict(sw_solver="McICA", do_lw_aerosol_scattering=True, use_aerosols=False),
     "mixed_solvers": dict(sw_solver="Tripleclouds", lw_solver="McICA"),
     "per_band_cloud_aerosol": dict(sw_solver="Tripleclouds", do_cloud_aerosol_per_sw_g_point=False,
                                    do_cloud_aerosol_per_lw_g_point=False),
