@@ -39,16 +39,18 @@ struct TcGeom {
   ECRAD_DEV double u(int i, int j, int hl) const { return p.u_matrix[((size_t)(i + 3 * j) * (nlev + 1) + hl) * nloc + cloc]; }
 };
 
-// Per-column geometry of one level for the sweeps (3 region fractions, v_matrix, u_matrix: 21 values
+// Per-column geometry of one level for the sweeps (3 region fractions, v_matrix, u_matrix, 2 optical-depth
+// scalings: 23 values
 // that all lanes of a column need).  Lane q of the column group loads item q of the NEXT level while
 // the current one is processed -- one load instruction per level instead of 21, off the critical
 // path -- and the items reach the other lanes through the group's level-record area in LDS, which is
 // idle during the sweeps and private to the wave.
 template <int NGP>
 struct GeoFeed {
-  static constexpr int NI = 21, PER = (NI + NGP - 1) / NGP;
+  static constexpr int NI = 23, PER = (NI + NGP - 1) / NGP;
   const double* src[PER];
   int maxlev[PER];
+  double held1[PER];      // issue()/commit(): one level in flight
   size_t stride;
   double* stage;
   int glane;
@@ -59,7 +61,8 @@ struct GeoFeed {
       const int q = glane + u * NGP;
       if (q < 3) { src[u] = p.region_fracs + (size_t)q * nlev * nloc + cloc; maxlev[u] = nlev - 1; }
       else if (q < 12) { src[u] = p.v_matrix + (size_t)(q - 3) * (nlev + 1) * nloc + cloc; maxlev[u] = nlev; }
-      else if (q < NI) { src[u] = p.u_matrix + (size_t)(q - 12) * (nlev + 1) * nloc + cloc; maxlev[u] = nlev; }
+      else if (q < 21) { src[u] = p.u_matrix + (size_t)(q - 12) * (nlev + 1) * nloc + cloc; maxlev[u] = nlev; }
+      else if (q < NI) { src[u] = p.od_scaling_reg + (size_t)(q - 21) * nlev * nloc + cloc; maxlev[u] = nlev - 1; }
       else { src[u] = p.region_fracs + cloc; maxlev[u] = 0; }
     }
   }
@@ -88,6 +91,25 @@ struct GeoFeed {
     }
     wave_sync();
   }
+  // The same for one level, in two steps: issue() early in a layer's work, commit() right before the
+  // values are needed (the optics passes, where a layer's own work hides the latency)
+  ECRAD_DEV void issue(int lev) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int l = lev < 0 ? 0 : (lev > maxlev[u] ? maxlev[u] : lev);
+      held1[u] = src[u][stride * l];
+    }
+  }
+  ECRAD_DEV void commit() {
+    wave_sync();
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int q = glane + u * NGP;
+      if (q < NI) stage[q] = held1[u];
+    }
+    wave_sync();
+  }
+  ECRAD_DEV double odsc(int k, int r /*1,2*/) const { return stage[k * NI + 20 + r]; }
   ECRAD_DEV double frac(int k, int r) const { return stage[k * NI + r]; }
   ECRAD_DEV double v(int k, int i, int j) const { return stage[k * NI + 3 + i + 3 * j]; }
   ECRAD_DEV double u(int k, int i, int j) const { return stage[k * NI + 12 + i + 3 * j]; }
@@ -132,6 +154,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
   constexpr int CPB = kBlock / NGP;
+  __shared__ double geo_stage[CPB][24];      // GeoFeed staging of the optics pass (the level records are in use there)
   const int tid = threadIdx.x;
   const int glane = tid % NGP, cib = tid / NGP;
   GasRegs<TAB> quads;
@@ -195,6 +218,9 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
       }
     }
 
+    GeoFeed<NGP> feed1;
+    feed1.init(prep, ncol_loc, nlev, cloc, geo_stage[cib], glane);
+
     // ---- sweep 1: surface -> top ---------------------------------------------------------------------
     double ta[3], tad[3];
     ta[0] = alb_dif;
@@ -218,6 +244,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
       for (int j = nl - 1; j >= 0; --j) {
         const int l = l0 + j;
         const int slot = cib * NGP + j;
+        const bool need_geo = cloudy.test(l) || (l > 0 && cloudy.test(l - 1));
+        if (need_geo) feed1.issue(l);      // consumed after the gas and aerosol optics of this layer
         gas_load<TAB>(gh, launder_uniform(gh.nquad), launder_uniform(gh.nplain), L, slot, g, quads);
         double od = gas_combine<TAB>(launder_uniform(gh.nquad), L, slot, quads);
         double ssa = L.D(F_SM, slot) * ray_g;
@@ -238,11 +266,12 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
           else tc_sw_up(s, 0, l, tid, c, ta[0], tad[0], below[0], belowd[0]);
         }
         const bool cl_here = cloudy.test(l);
+        if (need_geo) feed1.commit();
         if (cl_here) {
           const CloudLayer cl = cloud_layer<true>(kernarg_block<SpectralArgs>().cfg, L, slot, ib);
 #pragma unroll
           for (int jreg = 1; jreg < 3; ++jreg) {   // radiation_tripleclouds_sw.F90:278-300
-            const double osc = geo.odsc(jreg, l);
+            const double osc = feed1.odsc(0, jreg);
             const double scat_od = od * ssa;
             const double scat_od_cloud = cl.od * cl.ssa * osc;
             double od_total = od + cl.od * osc;
@@ -264,7 +293,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
             double x = 0.0, y = 0.0;
 #pragma unroll
             for (int r2 = 0; r2 < 3; ++r2) {
-              const double v = geo.v(r2, r, l);
+              const double v = feed1.v(0, r2, r);
               x = x + below[r2] * v;
               y = y + belowd[r2] * v;
             }
