@@ -508,22 +508,44 @@ ECRAD_DEV CloudLayer cloud_layer(const DevConfig& cfg, const LdsLayout& L, int s
   const double frac = L.D(F_FRAC, slot);
   const bool scat = IS_SW || cfg.do_lw_cloud_scattering;
   double od = 0.0, scat_od = 0.0, scat_g = 0.0;
-  for (int t = 0; t < L.nct; ++t) {
-    const DevCloudOptics& co = IS_SW ? cfg.cloud_sw[t] : cfg.cloud_lw[t];
-    const double wp = L.D(L.f_wp(t), slot);
-    if (scat ? !(frac > 0.0) : !(wp > 0.0)) continue;
-    const double w2 = L.D(L.f_rew(t), slot), w1 = 1.0 - w2;
-    const int o = ib + co.n_bands * L.I(L.i_re(t), slot);
-    const double me = w1 * co.mass_ext[o] + w2 * co.mass_ext[o + co.n_bands];
-    const double ss = w1 * co.ssa[o] + w2 * co.ssa[o + co.n_bands];
-    if (scat) {
-      double od_local = wp * me;
-      od = od + od_local;
-      od_local = od_local * ss;
-      scat_od = scat_od + od_local;
-      scat_g = scat_g + od_local * (w1 * co.asymmetry[o] + w2 * co.asymmetry[o + co.n_bands]);
-    } else {
-      od = od + wp * me * (1.0 - ss);
+  // two cloud types at a time: the table values of both are requested before either is used
+  for (int t0 = 0; t0 < L.nct; t0 += 2) {
+    double wp[2], w2[2], me[2][2], ss[2][2], as[2][2];
+    bool on[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = t0 + u;
+      on[u] = false;
+      wp[u] = 0.0; w2[u] = 0.0;
+      me[u][0] = me[u][1] = ss[u][0] = ss[u][1] = as[u][0] = as[u][1] = 0.0;
+      if (t < L.nct) {
+        const DevCloudOptics& co = IS_SW ? cfg.cloud_sw[t] : cfg.cloud_lw[t];
+        wp[u] = L.D(L.f_wp(t), slot);
+        on[u] = scat ? (frac > 0.0) : (wp[u] > 0.0);
+        if (on[u]) {
+          w2[u] = L.D(L.f_rew(t), slot);
+          const int o = ib + co.n_bands * L.I(L.i_re(t), slot);
+          me[u][0] = co.mass_ext[o]; me[u][1] = co.mass_ext[o + co.n_bands];
+          ss[u][0] = co.ssa[o]; ss[u][1] = co.ssa[o + co.n_bands];
+          if (scat) { as[u][0] = co.asymmetry[o]; as[u][1] = co.asymmetry[o + co.n_bands]; }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!on[u]) continue;
+      const double w1 = 1.0 - w2[u];
+      const double mext = w1 * me[u][0] + w2[u] * me[u][1];
+      const double ssa = w1 * ss[u][0] + w2[u] * ss[u][1];
+      if (scat) {
+        double od_local = wp[u] * mext;
+        od = od + od_local;
+        od_local = od_local * ssa;
+        scat_od = scat_od + od_local;
+        scat_g = scat_g + od_local * (w1 * as[u][0] + w2[u] * as[u][1]);
+      } else {
+        od = od + wp[u] * mext * (1.0 - ssa);
+      }
     }
   }
   if (scat && frac > 0.0) {
