@@ -162,6 +162,9 @@ hipError_t launch_tripleclouds_prep(hipStream_t st, const DevConfig* cfg, const 
 // ---------------------------------------------------------------------------------------------------
 // Lagged-Fibonacci generator of utilities/radiation_random_numbers_mix.F90 (p = 273, q = 607, 30-bit
 // words); see the generator kernel below.
+#ifndef ECRAD_GEN_WAVES
+#define ECRAD_GEN_WAVES 3
+#endif
 constexpr int JPP = 273, JPQ = 607, JPS = 105, JPMM = 30;
 
 // sample_from_pdf, radiation_pdf_sampler.F90:126-156
@@ -181,6 +184,32 @@ ECRAD_DEV double pdf_sample(const DevPdfSampler& p, double fsd, double cdf) {
   if (p.val) { v00 = p.val[o]; v10 = p.val[o + 1]; v01 = p.val[o + p.ncdf]; v11 = p.val[o + p.ncdf + 1]; }
   else { v00 = p.val64[o]; v10 = p.val64[o + 1]; v01 = p.val64[o + p.ncdf]; v11 = p.val64[o + p.ncdf + 1]; }
   return (1.0 - wcdf) * (1.0 - wfsd) * v00 + (1.0 - wcdf) * wfsd * v01 + wcdf * (1.0 - wfsd) * v10 + wcdf * wfsd * v11;
+}
+
+// The same in two steps, so that the four table loads (an L2 round trip) overlap other work
+struct PdfPending {
+  float v00, v10, v01, v11;
+  double wcdf, wfsd;
+};
+ECRAD_DEV PdfPending pdf_issue(const DevPdfSampler& p, double fsd, double cdf) {
+  PdfPending r;
+  double wcdf = cdf * (p.ncdf - 1) + 1.0;
+  int icdf = (int)wcdf;
+  icdf = icdf > p.ncdf - 1 ? p.ncdf - 1 : icdf;
+  icdf = icdf < 1 ? 1 : icdf;
+  r.wcdf = dmax(0.0, dmin(wcdf - icdf, 1.0));
+  double wfsd = (fsd - p.fsd1) * p.inv_fsd_interval + 1.0;
+  int ifsd = (int)wfsd;
+  ifsd = ifsd > p.nfsd - 1 ? p.nfsd - 1 : ifsd;
+  ifsd = ifsd < 1 ? 1 : ifsd;
+  r.wfsd = dmax(0.0, dmin(wfsd - ifsd, 1.0));
+  const size_t o = (size_t)(icdf - 1) + (size_t)p.ncdf * (ifsd - 1);
+  r.v00 = p.val[o]; r.v10 = p.val[o + 1]; r.v01 = p.val[o + p.ncdf]; r.v11 = p.val[o + p.ncdf + 1];
+  return r;
+}
+ECRAD_DEV double pdf_finish(const PdfPending& r) {
+  return (1.0 - r.wcdf) * (1.0 - r.wfsd) * (double)r.v00 + (1.0 - r.wcdf) * r.wfsd * (double)r.v01
+       + r.wcdf * (1.0 - r.wfsd) * (double)r.v10 + r.wcdf * r.wfsd * (double)r.v11;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -372,7 +401,7 @@ ECRAD_DEV void gen_draw(const GenLds& g, int lane, int& iused, int n, double* ds
   wave_sync();
 }
 
-__global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, int ng,
+__global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, int ng,
                                                              int seed_offset, double* od_scaling, double* total_cloud_cover) {
   extern __shared__ __align__(16) unsigned char smem[];
   const DevConfig& cfg = *cfgp;
@@ -517,6 +546,9 @@ __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __
     // rand_top(1:ng) is ONE batch request in the reference (radiation_cloud_generator.F90:206)
     gen_draw(g, lane, iused, ng, g.rtop);
     double* odsc = od_scaling + (size_t)ng * nlev * cloc;
+    PdfPending pend[3];
+    double* pend_dst[3] = {nullptr, nullptr, nullptr};
+    bool pend_on[3] = {false, false, false};
     for (int jg = 0; jg < ng; ++jg) {
       const double trigger = g.rtop[jg] * tcc;
       // first level from ibegin whose cumulative cover reaches the trigger (iend at the latest)
@@ -555,22 +587,35 @@ __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __
         A.w[k] = __ballot(a);
         B.w[k] = __ballot(b);
       }
-      LevBits C;                                        // cloudy levels of this sub-column
+      // Cloudy levels of this sub-column: state_i = state_(i-1) ? A_i : B_i below the trigger level
+      // (which is cloudy).  Where A_i == B_i the state is set outright; elsewhere it is kept (A=1,B=0)
+      // or flipped (A=0,B=1).  So state_i = value at the last "set" level XOR the parity of the flips
+      // since: a prefix XOR and a fill-forward on 64-bit words instead of a loop over levels.
+      LevBits C;
       C.clear();
       {
-        unsigned in_cloud = 1u;
+        unsigned long long carry = ~0ull;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const int lo = 64 * k;
           if (ei < lo || ti > lo + 63) continue;
           const int first = ti > lo ? ti - lo : 0, last = ei < lo + 63 ? ei - lo : 63;
-          unsigned long long a = A.w[k] >> first, b = B.w[k] >> first, c = 0ull;
-          for (int bit = first; bit <= last; ++bit) {
-            if (lo + bit > ti) in_cloud = (unsigned)((in_cloud ? a : b) & 1ull);
-            c |= (unsigned long long)in_cloud << bit;
-            a >>= 1; b >>= 1;
-          }
-          C.w[k] = c;
+          const unsigned long long R = (last == 63 ? ~0ull : ((1ull << (last + 1)) - 1ull)) & ~((1ull << first) - 1ull);
+          unsigned long long a = A.w[k], b = B.w[k];
+          if (ti >= lo) { a |= 1ull << first; b |= 1ull << first; }      // the trigger level itself
+          const unsigned long long S = ~(a ^ b) & R, N = (~a & b) & R;
+          unsigned long long P = N;
+          P ^= P << 1; P ^= P << 2; P ^= P << 4; P ^= P << 8; P ^= P << 16; P ^= P << 32;
+          unsigned long long v = (a ^ P) & S, m = S;
+          v |= (v << 1) & ~m;  m |= m << 1;
+          v |= (v << 2) & ~m;  m |= m << 2;
+          v |= (v << 4) & ~m;  m |= m << 4;
+          v |= (v << 8) & ~m;  m |= m << 8;
+          v |= (v << 16) & ~m; m |= m << 16;
+          v |= (v << 32) & ~m; m |= m << 32;
+          const unsigned long long state = ((v ^ P) & m) | ((carry ^ P) & ~m);
+          C.w[k] = state & R;
+          carry = (state >> 63) ? ~0ull : 0ull;
         }
       }
       // every cloudy run draws rand_inhom1(1:n) then rand_inhom2(1:n) (radiation_cloud_generator.F90:
@@ -605,18 +650,27 @@ __global__ __launch_bounds__(64) void mcica_generator_kernel(const DevConfig* __
         }
         K.w[k] = __ballot(keep);
       }
+      // The table look-ups of this g-point are requested here and finished (interpolated and stored)
+      // while the next g-point's random numbers are being drawn
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int i = lane + 64 * k;
+        if (pend_on[k]) pend_dst[k][0] = pdf_finish(pend[k]);
+        pend_on[k] = false;
         if (i >= ti && i <= ei && C.get(i)) {
           const int src = K.highest_zero_le(i);                     // >= run start: its flag is clear
           const double x = g.ri[run_base[k] + (src - run_start[k])];
-          odsc[jg + (size_t)ng * i] = pdf_sample(cfg.pdf, g.fsd[i], x);
+          double* dst = odsc + jg + (size_t)ng * i;
+          if (cfg.pdf.val) { pend[k] = pdf_issue(cfg.pdf, g.fsd[i], x); pend_dst[k] = dst; pend_on[k] = true; }
+          else *dst = pdf_sample(cfg.pdf, g.fsd[i], x);
         }
       }
       wave_sync();
       ECRAD_LAP0(tm, 7);    // flags, sampling, stores
     }
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (pend_on[k]) pend_dst[k][0] = pdf_finish(pend[k]);
   }
 #ifdef ECRAD_TIMING
   if (blockIdx.x == 0 && lane == 0 && tm_cols > 0)
