@@ -14,6 +14,6 @@ rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python bench.py $ARGS > $OU
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- python bench.py $ARGS > $OUT/bench_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/cal_fetch -o cal -- tools/hbm_calibrate > $OUT/cal_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/cal_write -o cal -- tools/hbm_calibrate > $OUT/cal_write.log 2>&1
-python bench.py --steps 10 --warmup 2 > $OUT/bench.json 2> $OUT/bench.err
+python bench.py --steps 10 --warmup 2 "$@" > $OUT/bench.json 2> $OUT/bench.err
 find $OUT -name "*.csv" | head -50
 tail -2 $OUT/bench.json
