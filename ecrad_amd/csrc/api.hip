@@ -46,6 +46,8 @@ struct ecrad_hip_handle_s {
   DevConfig* dcfg = nullptr;
   std::vector<void*> tables;
   int ngp_sw = 0, ngp_lw = 0;
+  int nchunk_sw = 1;               // launches per shortwave spectrum (> 1 beyond 64 g-points)
+  Buf partial;                     // per-chunk partial broadband profiles
   Buf scratch, prep, staging_in, staging_out, counters;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t evs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries
@@ -120,6 +122,20 @@ std::vector<double> build_pairs(const double* a, int ng, int n) {
 }
 
 int padded_ng(int ng) { return ng <= 16 ? 16 : (ng <= 32 ? 32 : (ng <= 64 ? 64 : 0)); }
+
+// Lanes per column group and number of launches for a spectrum of ng g-points.  Up to 64 g-points one
+// launch covers the spectrum; wider spectra (ecCKD 96-term, RRTMG-size) run in chunks of the lane
+// count that wastes the fewest lanes (ties: fewer, wider chunks).
+int chunk_lanes(int ng, int* nchunk) {
+  if (ng <= 64) { *nchunk = 1; return padded_ng(ng); }
+  int best = 64, best_pad = ((ng + 63) / 64) * 64;
+  for (int n : {32, 16}) {
+    const int pad = ((ng + n - 1) / n) * n;
+    if (pad < best_pad) { best = n; best_pad = pad; }
+  }
+  *nchunk = best_pad / best;
+  return best;
+}
 
 int setup_ckd(ecrad_hip_handle_t h, const ecrad_ckd_model_t& m, DevCkdModel& d) {
   std::memset(&d, 0, sizeof(d));
@@ -328,7 +344,9 @@ int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
   }
   const bool tc = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_TRIPLECLOUDS) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_TRIPLECLOUDS);
   if (tc && c.i_overlap_scheme != ECRAD_OVERLAP_EXP_RAN) return fail(h, ECRAD_EINVAL, "Tripleclouds can only do Exp-Ran overlap");
-  if (c.do_sw && padded_ng(c.n_g_sw) == 0) return fail(h, ECRAD_EUNSUPPORTED, "more than 64 shortwave g-points");
+  { int nch = 1; if (c.do_sw && (c.n_g_sw < 1 || (chunk_lanes(c.n_g_sw, &nch), nch > 15))) return fail(h, ECRAD_EUNSUPPORTED, "shortwave spectrum too wide"); }
+  if (c.do_sw && c.n_g_sw > 64 && c.i_solver_sw == ECRAD_SOLVER_MCICA && c.use_vectorizable_generator == 0 && c.n_g_sw > 512)
+    return fail(h, ECRAD_EUNSUPPORTED, "shortwave spectrum too wide for the cloud generator");
   if (c.do_lw && padded_ng(c.n_g_lw) == 0) return fail(h, ECRAD_EUNSUPPORTED, "more than 64 longwave g-points");
   if (c.do_clouds && (c.n_cloud_types < 1 || c.n_cloud_types > ECRAD_NMAXCLOUDTYPES)) return fail(h, ECRAD_EINVAL, "n_cloud_types out of range");
   return ECRAD_OK;
@@ -387,7 +405,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
   if (!h) return ECRAD_EINVAL;
   (void)hipSetDevice(h->device);
   free_tables(h);
-  h->counters.release(); h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
+  h->counters.release(); h->partial.release(); h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (auto& e : h->evs) if (e) (void)hipEventDestroy(e);
@@ -465,7 +483,7 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
     if (!d.i_band_from_reordered_g_sw) return fail(h, ECRAD_EINVAL, "i_band_from_reordered_g_sw missing");
     if (!c.use_canopy_full_spectrum_sw && !c.do_nearest_spectral_sw_albedo && !d.sw_albedo_weights)
       return fail(h, ECRAD_EINVAL, "sw_albedo_weights missing");
-    h->ngp_sw = padded_ng(c.n_g_sw);
+    h->ngp_sw = chunk_lanes(c.n_g_sw, &h->nchunk_sw);
   }
   if (c.do_lw) {
     if ((st = upload<int32_t>(h, c.i_band_from_reordered_g_lw, c.n_g_lw, &d.i_band_from_reordered_g_lw))) return st;
@@ -838,11 +856,35 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
         HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_sw, 0, prep.od_scaling_sw,
                                           prep.total_cloud_cover_sw));
     }
-    if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m));
-    else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m));
+    if (h->nchunk_sw == 1) {
+      if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m, 0));
+      else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m, 0));
+    } else {
+      // More than 64 g-points: one launch per chunk of `ngp_sw` g-points.  The sums over g of a launch
+      // are partial, so its broadband profiles go to per-chunk buffers (same indexing as the real
+      // arrays) that are added up in chunk order afterwards; per-g outputs are indexed by the true g.
+      // The McICA clear/cloudy blend is linear, so blending partial sums is the blend of the sums.
+      double* DevFlux::* const prof[6] = {&DevFlux::sw_up, &DevFlux::sw_dn, &DevFlux::sw_dn_direct,
+                                          &DevFlux::sw_up_clear, &DevFlux::sw_dn_clear, &DevFlux::sw_dn_direct_clear};
+      const size_t plane = (size_t)din.ncol * (nlev + 1);
+      const int nch = h->nchunk_sw;
+      HIP_TRY(h, h->partial.ensure(plane * nch * 6 * sizeof(double)));
+      double* pbase = reinterpret_cast<double*>(h->partial.p);
+      for (int p = 0; p < nch; ++p) {
+        DevFlux dpart = dfx;
+        for (int k = 0; k < 6; ++k)
+          if (dfx.*(prof[k])) dpart.*(prof[k]) = pbase + plane * ((size_t)k * nch + p);
+        if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, p * h->ngp_sw));
+        else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, p * h->ngp_sw));
+      }
+      for (int k = 0; k < 6; ++k)
+        if (dfx.*(prof[k])) HIP_TRY(h, launch_combine_partials(stream, din, dfx.*(prof[k]), pbase + plane * (size_t)k * nch, plane, nch));
+    }
   }
   HIP_TRY(h, hipEventRecord(h->evs[3], stream));
-  HIP_TRY(h, launch_spectral_post(stream, h->dcfg, din, dfx));                          // :503-504
+  const bool wide = c.n_g_sw > 64 || c.n_g_lw > 64 || c.n_bands_sw > 64 || c.n_bands_lw > 64 ||
+                    c.n_canopy_bands_sw > 64 || c.n_canopy_bands_lw > 64;
+  HIP_TRY(h, launch_spectral_post(stream, h->dcfg, din, dfx, wide));                          // :503-504
   HIP_TRY(h, hipEventRecord(h->evs[4], stream));
   HIP_TRY(h, hipEventRecord(h->ev1, stream));
   h->timing_pending = true;
@@ -917,10 +959,12 @@ int ecrad_hip_optics(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, in
     HIP_TRY(h, launch_crop(stream, h->dcfg, cx.din));
   }
   const int nct = c.do_clouds ? c.n_cloud_types : 0;
-  if (c.do_sw) HIP_TRY(h, launch_optics_dump(true, h->ngp_sw, h->hcfg.gas_sw.table_f32, grid_for(h, r.nloc, h->ngp_sw),
-                                             lds_bytes(h->hcfg.gas_sw.hot.nquad, nct), stream, h->dcfg, cx.din, dop));
+  if (c.do_sw)
+    for (int p = 0; p < h->nchunk_sw; ++p)
+      HIP_TRY(h, launch_optics_dump(true, h->ngp_sw, h->hcfg.gas_sw.table_f32, grid_for(h, r.nloc, h->ngp_sw),
+                                    lds_bytes(h->hcfg.gas_sw.hot.nquad, nct), stream, h->dcfg, cx.din, dop, p * h->ngp_sw));
   if (c.do_lw) HIP_TRY(h, launch_optics_dump(false, h->ngp_lw, h->hcfg.gas_lw.table_f32, grid_for(h, r.nloc, h->ngp_lw),
-                                             lds_bytes(h->hcfg.gas_lw.hot.nquad, nct), stream, h->dcfg, cx.din, dop));
+                                             lds_bytes(h->hcfg.gas_lw.hot.nquad, nct), stream, h->dcfg, cx.din, dop, 0));
   if (host_mem) {
     for (const OF& f : fields)
       if (out->*(f.host)) HIP_TRY(h, hipMemcpyAsync(out->*(f.host), dop.*(f.dev), f.n * 8, hipMemcpyDeviceToHost, stream));

@@ -185,6 +185,8 @@ struct SpectralArgs {
   size_t per_block;
   int* counter;                // dynamic work queue (next column group)
   GasHot gas;
+  int32_t g0;                  // first g-point of this launch (spectra wider than 64 g-points run in chunks)
+  int32_t pad_;
 };
 
 }  // namespace ecrad

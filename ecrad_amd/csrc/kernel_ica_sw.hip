@@ -207,7 +207,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
 
     const LdsLayout L = make_lds(smem, nquad, nct);
     const SwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block, nlev};
-    const int g = glane < ng ? glane : ng - 1;
+    const int gi = a.g0 + glane;       // g-point of this lane
+    const int g = gi < ng ? gi : ng - 1;
     const int ib = cfg.i_band_from_reordered_g_sw[g] - 1;
     const int aer_type = aerosol_lane_type(cfg, glane);
     const double ray_g = m.rayleigh_molar_scat[g];
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
     const int col = a.in.istartcol - 1 + cloc;
-    const bool valid = col_ok && glane < ng;
+    const bool valid = col_ok && gi < ng;
     const bool lead = leader && col_ok;
     const double mu0 = a.in.cos_sza[col];
     const bool sun_up = mu0 > 0.0;
@@ -471,9 +472,9 @@ size_t sw_ica_scratch_doubles(int mode, int nlev) {
 
 hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m) {
+                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0) {
   dim3 g(grid);
-  const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot};
+  const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot, g0, 0};
   const bool spec = fx.sw_up_band != nullptr;
 #define ECRAD_DISPATCH(T, N) return spec ? launch_sw_mode<T, N, true>(mode, g, lds, st, args) : launch_sw_mode<T, N, false>(mode, g, lds, st, args)
   if (table_f32) {

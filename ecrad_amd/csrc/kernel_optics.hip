@@ -8,7 +8,7 @@
 namespace ecrad {
 
 template <typename TAB, int NGP, bool IS_SW>
-__global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevOptics out) {
+__global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevOptics out, int g0) {
   extern __shared__ __align__(16) unsigned char smem[];
   const DevConfig& cfg = *cfgp;
   const DevCkdModel& m = IS_SW ? cfg.gas_sw : cfg.gas_lw;
@@ -21,7 +21,8 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
   const bool want_clouds = cfg.do_clouds != 0;
   const int nct = want_clouds ? cfg.n_cloud_types : 0;
   const LdsLayout L = make_lds(smem, m.hot.nquad, nct);
-  const int g = glane < ng ? glane : ng - 1;
+  const int gi = g0 + glane;
+  const int g = gi < ng ? gi : ng - 1;
   const int ib = (IS_SW ? cfg.i_band_from_reordered_g_sw[g] : cfg.i_band_from_reordered_g_lw[g]) - 1;
   const int aer_type = aerosol_lane_type(cfg, glane);
   const int nb = IS_SW ? cfg.n_bands_sw : cfg.n_bands_lw;
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
     const int col = in.istartcol - 1 + cloc;
-    const bool valid = col_ok && glane < ng;
+    const bool valid = col_ok && gi < ng;
     const size_t og = g + (size_t)ng * cloc;
     double lw_albedo = 0.0;
     if (IS_SW) {
@@ -108,10 +109,10 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
           }
           planck_top = planck_bot;
         }
-        if (want_clouds && glane < nb && col_ok) {
+        if (want_clouds && gi < nb && col_ok) {
           // cloud tables are per band: lane b < n_bands writes band b
-          const CloudLayer cl = cloud_layer<IS_SW>(cfg, L, slot, glane);
-          const size_t oc = glane + (size_t)nb * (lev + (size_t)nlev * cloc);
+          const CloudLayer cl = cloud_layer<IS_SW>(cfg, L, slot, gi);
+          const size_t oc = gi + (size_t)nb * (lev + (size_t)nlev * cloc);
           double* pod = IS_SW ? out.od_sw_cloud : out.od_lw_cloud;
           double* pss = IS_SW ? out.ssa_sw_cloud : out.ssa_lw_cloud;
           double* pg = IS_SW ? out.g_sw_cloud : out.g_lw_cloud;
@@ -125,8 +126,8 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
 }
 
 hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
-                              const DevConfig* cfg, const DevInputs& in, const DevOptics& out) {
-#define ECRAD_L(T, N, S) do { ECRAD_ALLOW_LDS((optics_dump_kernel<T, N, S>), lds); hipLaunchKernelGGL((optics_dump_kernel<T, N, S>), dim3(grid), dim3(kBlock), lds, st, cfg, in, out); } while (0)
+                              const DevConfig* cfg, const DevInputs& in, const DevOptics& out, int g0) {
+#define ECRAD_L(T, N, S) do { ECRAD_ALLOW_LDS((optics_dump_kernel<T, N, S>), lds); hipLaunchKernelGGL((optics_dump_kernel<T, N, S>), dim3(grid), dim3(kBlock), lds, st, cfg, in, out, g0); } while (0)
 #define ECRAD_N(T, S) do { if (ngp == 16) ECRAD_L(T, 16, S); else if (ngp == 32) ECRAD_L(T, 32, S); else ECRAD_L(T, 64, S); } while (0)
   if (is_sw) { if (table_f32) ECRAD_N(float, true); else ECRAD_N(double, true); }
   else { if (table_f32) ECRAD_N(float, false); else ECRAD_N(double, false); }

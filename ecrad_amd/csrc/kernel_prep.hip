@@ -714,7 +714,7 @@ ECRAD_DEV unsigned long long minstd_seed(int iseed, int jstr) {
 }
 
 template <int NGP>
-__global__ __launch_bounds__(kBlock) void mcica_generator_vec_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, int ng,
+__global__ __launch_bounds__(kBlock) void mcica_generator_vec_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, int ng, int g0,
                                                                      int seed_offset, double* od_scaling, double* total_cloud_cover) {
   const DevConfig& cfg = *cfgp;
   constexpr int CPB = kBlock / NGP;
@@ -763,12 +763,13 @@ __global__ __launch_bounds__(kBlock) void mcica_generator_vec_kernel(const DevCo
       continue;
     }
     if (glane == 0) total_cloud_cover[cloc] = tcc;
-    if (glane >= ng) continue;
+    const int gi = g0 + glane;      // this lane's g-point
+    if (gi >= ng) continue;
     int nmasked = 0;
     for (int jlev = ibegin; jlev <= iend; ++jlev) nmasked += FRAC(jlev) >= thr;
     // rng%initialize(IRngMinstdVector, iseed, nmaxstreams=ng) for stream jstr = g+1; the products are
     // rounded one by one as in the oracle (no fused multiply-add)
-    unsigned long long s0 = minstd_seed(in.iseed[col] + seed_offset, glane + 1);
+    unsigned long long s0 = minstd_seed(in.iseed[col] + seed_offset, gi + 1);
     s0 = minstd_step(s0, 48271ull);                         // one warm-up
     unsigned long long s_rc = minstd_step(s0, 48271ull);    // the state that produced `trigger`
     const double trigger = (scale * (double)s_rc) * tcc;
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(kBlock) void mcica_generator_vec_kernel(const DevCo
           ri_here = is_cloud ? (keep ? ri_above : ri_here) : 0.0;
           // masked_block_sample, radiation_pdf_sampler.F90:266-321
           const double fsd = in.cloud_fractional_std[col + ncol * ord.full(jlev - 1)];
-          odsc[glane + (size_t)ng * (jlev - 1)] = ri_here > 0.0 ? pdf_sample(cfg.pdf, fsd, ri_here) : 0.0;
+          odsc[gi + (size_t)ng * (jlev - 1)] = ri_here > 0.0 ? pdf_sample(cfg.pdf, fsd, ri_here) : 0.0;
         } else {
           is_cloud = false;
         }
@@ -846,9 +847,12 @@ hipError_t launch_mcica_generator_vec(hipStream_t st, const DevConfig* cfg, cons
   const int ngp = ng <= 16 ? 16 : (ng <= 32 ? 32 : 64);
   const int cpb = kBlock / ngp;
   const int grid = (nloc + cpb - 1) / cpb;
-  if (ngp == 16) hipLaunchKernelGGL((mcica_generator_vec_kernel<16>), dim3(grid), dim3(kBlock), 0, st, cfg, in, ng, seed_offset, od_scaling, tcc);
-  else if (ngp == 32) hipLaunchKernelGGL((mcica_generator_vec_kernel<32>), dim3(grid), dim3(kBlock), 0, st, cfg, in, ng, seed_offset, od_scaling, tcc);
-  else hipLaunchKernelGGL((mcica_generator_vec_kernel<64>), dim3(grid), dim3(kBlock), 0, st, cfg, in, ng, seed_offset, od_scaling, tcc);
+  // every g-point has its own stream, so spectra wider than 64 g-points simply take several launches
+  for (int g0 = 0; g0 < ng; g0 += ngp) {
+    if (ngp == 16) hipLaunchKernelGGL((mcica_generator_vec_kernel<16>), dim3(grid), dim3(kBlock), 0, st, cfg, in, ng, g0, seed_offset, od_scaling, tcc);
+    else if (ngp == 32) hipLaunchKernelGGL((mcica_generator_vec_kernel<32>), dim3(grid), dim3(kBlock), 0, st, cfg, in, ng, g0, seed_offset, od_scaling, tcc);
+    else hipLaunchKernelGGL((mcica_generator_vec_kernel<64>), dim3(grid), dim3(kBlock), 0, st, cfg, in, ng, g0, seed_offset, od_scaling, tcc);
+  }
   return hipGetLastError();
 }
 
@@ -1019,8 +1023,120 @@ __global__ __launch_bounds__(64 * kPostWaves) void spectral_post_kernel(const De
   }
 }
 
-hipError_t launch_spectral_post(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevFlux& fx) {
+ECRAD_DEV void indexed_sum(int n, const double* src, const int32_t* ind, int nbin, double* dest) {
+  for (int i = 0; i < nbin; ++i) dest[i] = 0.0;
+  for (int j = 0; j < n; ++j) dest[ind[j] - 1] += src[j];
+}
+
+// The same with one thread per column: any number of g-points / bands (spectra wider than a wave)
+__global__ void spectral_post_wide_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevFlux f) {
+  const DevConfig& c = *cfgp;
   const int nloc = in.iendcol - in.istartcol + 1;
+  const int cloc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cloc >= nloc) return;
+  const size_t jcol = in.istartcol - 1 + cloc;
+  if (c.do_sw && c.do_surface_sw_spectral_flux && f.sw_dn_surf_band) {
+    const int ng = c.n_g_sw, nb = c.n_bands_sw;
+    indexed_sum(ng, f.sw_dn_direct_surf_g + ng * jcol, c.i_band_from_reordered_g_sw, nb, f.sw_dn_direct_surf_band + nb * jcol);
+    indexed_sum(ng, f.sw_dn_diffuse_surf_g + ng * jcol, c.i_band_from_reordered_g_sw, nb, f.sw_dn_surf_band + nb * jcol);
+    for (int jb = 0; jb < nb; ++jb) f.sw_dn_surf_band[jb + nb * jcol] += f.sw_dn_direct_surf_band[jb + nb * jcol];
+    if (c.do_clear && f.sw_dn_surf_clear_band) {
+      indexed_sum(ng, f.sw_dn_direct_surf_clear_g + ng * jcol, c.i_band_from_reordered_g_sw, nb, f.sw_dn_direct_surf_clear_band + nb * jcol);
+      indexed_sum(ng, f.sw_dn_diffuse_surf_clear_g + ng * jcol, c.i_band_from_reordered_g_sw, nb, f.sw_dn_surf_clear_band + nb * jcol);
+      for (int jb = 0; jb < nb; ++jb) f.sw_dn_surf_clear_band[jb + nb * jcol] += f.sw_dn_direct_surf_clear_band[jb + nb * jcol];
+    }
+  }
+  if (c.do_sw && c.do_canopy_fluxes_sw && f.sw_dn_diffuse_surf_canopy) {
+    const int ng = c.n_g_sw, nb = c.n_bands_sw, nc = c.n_canopy_bands_sw;
+    double* dif = f.sw_dn_diffuse_surf_canopy + nc * jcol;
+    double* dir = f.sw_dn_direct_surf_canopy + nc * jcol;
+    if (c.use_canopy_full_spectrum_sw) {
+      for (int i = 0; i < ng; ++i) { dif[i] = f.sw_dn_diffuse_surf_g[i + ng * jcol]; dir[i] = f.sw_dn_direct_surf_g[i + ng * jcol]; }
+    } else if (c.do_nearest_spectral_sw_albedo) {
+      for (int i = 0; i < nc; ++i) { dif[i] = 0.0; dir[i] = 0.0; }
+      for (int jg = 0; jg < ng; ++jg) {
+        const int ia = c.i_albedo_from_band_sw[c.i_band_from_reordered_g_sw[jg] - 1] - 1;
+        dir[ia] += f.sw_dn_direct_surf_g[jg + ng * jcol];
+        dif[ia] += f.sw_dn_diffuse_surf_g[jg + ng * jcol];
+      }
+    } else {
+      const int nalb = c.n_albedo_intervals_sw;
+      for (int i = 0; i < nc; ++i) { dif[i] = 0.0; dir[i] = 0.0; }
+      for (int jb = 0; jb < nb; ++jb)
+        for (int ja = 0; ja < nalb; ++ja) {
+          const double w = c.sw_albedo_weights[ja + nalb * jb];
+          if (w != 0.0) {
+            dif[ja] = dif[ja] + w * f.sw_dn_surf_band[jb + nb * jcol];
+            dir[ja] = dir[ja] + w * f.sw_dn_direct_surf_band[jb + nb * jcol];
+          }
+        }
+      for (int i = 0; i < nc; ++i) dif[i] = dif[i] - dir[i];
+    }
+  }
+  if (c.do_lw && c.do_canopy_fluxes_lw && f.lw_dn_surf_canopy) {
+    const int ng = c.n_g_lw, nb = c.n_bands_lw, nc = c.n_canopy_bands_lw;
+    double* can = f.lw_dn_surf_canopy + nc * jcol;
+    if (c.use_canopy_full_spectrum_lw) {
+      for (int i = 0; i < ng; ++i) can[i] = f.lw_dn_surf_g[i + ng * jcol];
+    } else if (c.do_nearest_spectral_lw_emiss) {
+      for (int i = 0; i < nc; ++i) can[i] = 0.0;
+      for (int jg = 0; jg < ng; ++jg)
+        can[c.i_emiss_from_band_lw[c.i_band_from_reordered_g_lw[jg] - 1] - 1] += f.lw_dn_surf_g[jg + ng * jcol];
+    } else {
+      const int nalb = c.n_emiss_intervals_lw;
+      for (int i = 0; i < nc; ++i) can[i] = 0.0;
+      for (int jg = 0; jg < ng; ++jg) {   // == indexed_sum to bands then weights (radiation_flux.F90:540-566)
+        const int jb = c.i_band_from_reordered_g_lw[jg] - 1;
+        for (int ja = 0; ja < nalb; ++ja) {
+          const double w = c.lw_emiss_weights[ja + nalb * jb];
+          if (w != 0.0) can[ja] = can[ja] + w * f.lw_dn_surf_g[jg + ng * jcol];
+        }
+      }
+    }
+  }
+  if (c.do_toa_spectral_flux) {
+    if (c.do_sw && f.sw_up_toa_band) {
+      const int ng = c.n_g_sw, nb = c.n_bands_sw;
+      if (f.sw_dn_toa_band && f.sw_dn_toa_g)
+        indexed_sum(ng, f.sw_dn_toa_g + ng * jcol, c.i_band_from_reordered_g_sw, nb, f.sw_dn_toa_band + nb * jcol);
+      indexed_sum(ng, f.sw_up_toa_g + ng * jcol, c.i_band_from_reordered_g_sw, nb, f.sw_up_toa_band + nb * jcol);
+      if (c.do_clear && f.sw_up_toa_clear_band)
+        indexed_sum(ng, f.sw_up_toa_clear_g + ng * jcol, c.i_band_from_reordered_g_sw, nb, f.sw_up_toa_clear_band + nb * jcol);
+    }
+    if (c.do_lw && f.lw_up_toa_band) {
+      const int ng = c.n_g_lw, nb = c.n_bands_lw;
+      indexed_sum(ng, f.lw_up_toa_g + ng * jcol, c.i_band_from_reordered_g_lw, nb, f.lw_up_toa_band + nb * jcol);
+      if (c.do_clear && f.lw_up_toa_clear_band)
+        indexed_sum(ng, f.lw_up_toa_clear_g + ng * jcol, c.i_band_from_reordered_g_lw, nb, f.lw_up_toa_clear_band + nb * jcol);
+    }
+  }
+}
+
+// Sum of the per-chunk partial profiles of a spectrum wider than 64 g-points, in chunk order
+__global__ void combine_partials_kernel(DevInputs in, double* dst, const double* partial, size_t chunk_stride, int nchunk) {
+  const int nloc = in.iendcol - in.istartcol + 1;
+  const size_t total = (size_t)nloc * (in.nlev + 1);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t o = (in.istartcol - 1 + i % nloc) + (size_t)in.ncol * (i / nloc);
+    double v = partial[o];
+    for (int p = 1; p < nchunk; ++p) v += partial[o + chunk_stride * p];
+    dst[o] = v;
+  }
+}
+
+hipError_t launch_combine_partials(hipStream_t st, const DevInputs& in, double* dst, const double* partial, size_t chunk_stride, int nchunk) {
+  const size_t total = (size_t)(in.iendcol - in.istartcol + 1) * (in.nlev + 1);
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(combine_partials_kernel, dim3(grid), dim3(256), 0, st, in, dst, partial, chunk_stride, nchunk);
+  return hipGetLastError();
+}
+
+hipError_t launch_spectral_post(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevFlux& fx, bool wide) {
+  const int nloc = in.iendcol - in.istartcol + 1;
+  if (wide) {
+    hipLaunchKernelGGL(spectral_post_wide_kernel, dim3((nloc + 127) / 128), dim3(128), 0, st, cfg, in, fx);
+    return hipGetLastError();
+  }
   const int blocks = (nloc + kPostWaves - 1) / kPostWaves;
   hipLaunchKernelGGL(spectral_post_kernel, dim3(blocks < 256 * 16 ? blocks : 256 * 16), dim3(64 * kPostWaves), 0, st, cfg, in, fx);
   return hipGetLastError();

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
     const LdsLayout L = make_lds(smem, m.hot.nquad, cfg.n_cloud_types);
     const TcSwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block};
     quads.reset();
-    const int g = glane < ng ? glane : ng - 1;
+    const int gi = a.g0 + glane;       // g-point of this lane
+    const int g = gi < ng ? gi : ng - 1;
     const int ib = cfg.i_band_from_reordered_g_sw[g] - 1;
     const int aer_type = aerosol_lane_type(cfg, glane);
     const double ray_g = m.rayleigh_molar_scat[g];
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
     const int col = in.istartcol - 1 + cloc;
-    const bool valid = col_ok && glane < ng;
+    const bool valid = col_ok && gi < ng;
     const double mu0 = in.cos_sza[col];
     const bool sun_up = !(mu0 < 1.0e-10);
     const DevCloudPrep prep = a.prep;
@@ -475,8 +476,8 @@ size_t sw_tc_scratch_doubles(int nlev) { return (size_t)4 * 5 * nlev * kBlock; }
 
 hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block,
-                        int* counter, const DevCkdModel& m) {
-  const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot};
+                        int* counter, const DevCkdModel& m, int g0) {
+  const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot, g0, 0};
 #define ECRAD_L(T, N) do { ECRAD_ALLOW_LDS((sw_tc_kernel<T, N>), lds); hipLaunchKernelGGL((sw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
   if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
   else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }

@@ -22,9 +22,10 @@ size_t lw_scat_scratch_doubles(int nlev);
 size_t sw_tc_scratch_doubles(int nlev);
 size_t lw_tc_scratch_doubles(int nlev, bool aerosol_scattering);
 
+// g0: first g-point of the launch (spectra wider than 64 g-points run in chunks of `ngp`)
 hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m);
+                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0);
 hipError_t launch_lw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
                          double* scratch, size_t per_block, int* counter, const DevCkdModel& m);
@@ -34,7 +35,9 @@ hipError_t launch_lw_scat(int mode, int ngp, bool table_f32, int grid, size_t ld
                          double* scratch, size_t per_block, int* counter, const DevCkdModel& m);
 hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block, int* counter,
-                        const DevCkdModel& m);
+                        const DevCkdModel& m, int g0);
+// dst(col, l) = sum over chunks of partial profiles (chunk order), columns istartcol..iendcol
+hipError_t launch_combine_partials(hipStream_t st, const DevInputs& in, double* dst, const double* partial, size_t chunk_stride, int nchunk);
 hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block, int* counter,
                         const DevCkdModel& m);
@@ -46,8 +49,8 @@ hipError_t launch_mcica_generator(hipStream_t st, const DevConfig* cfg, const De
                                   double* od_scaling, double* tcc);
 hipError_t launch_mcica_generator_vec(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int ng, int seed_offset,
                                       double* od_scaling, double* tcc);
-hipError_t launch_spectral_post(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevFlux& fx);
+hipError_t launch_spectral_post(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevFlux& fx, bool wide);
 hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
-                              const DevConfig* cfg, const DevInputs& in, const DevOptics& out);
+                              const DevConfig* cfg, const DevInputs& in, const DevOptics& out, int g0);
 
 }  // namespace ecrad

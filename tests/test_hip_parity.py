@@ -56,6 +56,15 @@ CASES = {
                                                   do_save_spectral_flux=True),
     "mcica_lw_aerosol_scat": dict(sw_solver="McICA", do_lw_aerosol_scattering=True),
     "mcica_lw_aerosol_scat_noaer": dict(sw_solver="McICA", do_lw_aerosol_scattering=True, use_aerosols=False),
+    # 96 shortwave g-points: three launches of 32 lanes with per-chunk partial sums
+    "sw96_tripleclouds": dict(sw_solver="Tripleclouds", gas_optics_sw_override_file_name="ecckd-1.4_sw_climate_vfine-96b_ckd-definition.nc"),
+    "sw96_mcica": dict(sw_solver="McICA", gas_optics_sw_override_file_name="ecckd-1.4_sw_climate_vfine-96b_ckd-definition.nc"),
+    "sw96_mcica_vectorizable": dict(sw_solver="McICA", use_vectorizable_generator=True,
+                                    gas_optics_sw_override_file_name="ecckd-1.4_sw_climate_vfine-96b_ckd-definition.nc"),
+    "sw96_homogeneous_spectral": dict(sw_solver="Homogeneous", do_save_spectral_flux=True,
+                                      gas_optics_sw_override_file_name="ecckd-1.4_sw_climate_vfine-96b_ckd-definition.nc"),
+    "sw96_cloudless_per_band": dict(sw_solver="Cloudless", do_cloud_aerosol_per_sw_g_point=False,
+                                    gas_optics_sw_override_file_name="ecckd-1.4_sw_climate_vfine-96b_ckd-definition.nc"),
     "mixed_solvers": dict(sw_solver="Tripleclouds", lw_solver="McICA"),
     "per_band_cloud_aerosol": dict(sw_solver="Tripleclouds", do_cloud_aerosol_per_sw_g_point=False,
                                    do_cloud_aerosol_per_lw_g_point=False),
