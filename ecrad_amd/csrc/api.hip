@@ -858,7 +858,7 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
     }
     if (h->nchunk_sw == 1) {
       if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m, 0));
-      else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m, 0));
+      else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m, 0, false));
     } else {
       // More than 64 g-points: one launch per chunk of `ngp_sw` g-points.  The sums over g of a launch
       // are partial, so its broadband profiles go to per-chunk buffers (same indexing as the real
@@ -875,7 +875,7 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
         for (int k = 0; k < 6; ++k)
           if (dfx.*(prof[k])) dpart.*(prof[k]) = pbase + plane * ((size_t)k * nch + p);
         if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, p * h->ngp_sw));
-        else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, p * h->ngp_sw));
+        else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, p * h->ngp_sw, true));
       }
       for (int k = 0; k < 6; ++k)
         if (dfx.*(prof[k])) HIP_TRY(h, launch_combine_partials(stream, din, dfx.*(prof[k]), pbase + plane * (size_t)k * nch, plane, nch));

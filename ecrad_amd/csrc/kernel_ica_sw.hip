@@ -167,7 +167,9 @@ enum { SWF_AEROSOLS = 1, SWF_DELTA_GASES = 2 };
 
 // SPEC: per-g-point flux profiles wanted (do_save_spectral_flux); a separate instantiation keeps the six
 // extra destinations out of the registers of the common case
-template <typename TAB, int NGP, int MODE, bool SPEC>
+// WIDE: the launch covers g-points g0 .. g0+NGP-1 of a spectrum wider than 64 (its own instantiation:
+// the common case has no register to spare)
+template <typename TAB, int NGP, int MODE, bool SPEC, bool WIDE>
 __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
 
     const LdsLayout L = make_lds(smem, nquad, nct);
     const SwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block, nlev};
-    const int gi = a.g0 + glane;       // g-point of this lane
+    const int gi = (WIDE ? a.g0 : 0) + glane;       // g-point of this lane
     const int g = gi < ng ? gi : ng - 1;
     const int ib = cfg.i_band_from_reordered_g_sw[g] - 1;
     const int aer_type = aerosol_lane_type(cfg, glane);
@@ -446,20 +448,20 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
 #endif
 }
 
-template <typename TAB, int NGP, bool SPEC>
+template <typename TAB, int NGP, bool SPEC, bool WIDE>
 static hipError_t launch_sw_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const SpectralArgs& args) {
   switch (mode) {
     case ECRAD_SOLVER_CLOUDLESS:
-      ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 0, SPEC>), lds);
-      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 0, SPEC>), grid, dim3(kBlock), lds, st, args);
+      ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 0, SPEC, WIDE>), lds);
+      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 0, SPEC, WIDE>), grid, dim3(kBlock), lds, st, args);
       break;
     case ECRAD_SOLVER_HOMOGENEOUS:
-      ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 1, SPEC>), lds);
-      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 1, SPEC>), grid, dim3(kBlock), lds, st, args);
+      ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 1, SPEC, WIDE>), lds);
+      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 1, SPEC, WIDE>), grid, dim3(kBlock), lds, st, args);
       break;
     default:      // McICA never writes spectral profiles (api.hip nulls the destinations)
-      ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 2, false>), lds);
-      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 2, false>), grid, dim3(kBlock), lds, st, args);
+      ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 2, false, WIDE>), lds);
+      hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 2, false, WIDE>), grid, dim3(kBlock), lds, st, args);
       break;
   }
   return hipGetLastError();
@@ -472,11 +474,12 @@ size_t sw_ica_scratch_doubles(int mode, int nlev) {
 
 hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0) {
+                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0, bool wide) {
   dim3 g(grid);
   const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot, g0, 0};
   const bool spec = fx.sw_up_band != nullptr;
-#define ECRAD_DISPATCH(T, N) return spec ? launch_sw_mode<T, N, true>(mode, g, lds, st, args) : launch_sw_mode<T, N, false>(mode, g, lds, st, args)
+#define ECRAD_DISPATCH(T, N) return wide ? (spec ? launch_sw_mode<T, N, true, true>(mode, g, lds, st, args) : launch_sw_mode<T, N, false, true>(mode, g, lds, st, args)) \
+                                         : (spec ? launch_sw_mode<T, N, true, false>(mode, g, lds, st, args) : launch_sw_mode<T, N, false, false>(mode, g, lds, st, args))
   if (table_f32) {
     if (ngp == 16) ECRAD_DISPATCH(float, 16);
     if (ngp == 32) ECRAD_DISPATCH(float, 32);

@@ -25,7 +25,7 @@ size_t lw_tc_scratch_doubles(int nlev, bool aerosol_scattering);
 // g0: first g-point of the launch (spectra wider than 64 g-points run in chunks of `ngp`)
 hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0);
+                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0, bool wide);
 hipError_t launch_lw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
                          double* scratch, size_t per_block, int* counter, const DevCkdModel& m);
