@@ -219,6 +219,36 @@ def test_surface_first_level_order(solver, oracle_lib):
         assert rel_err(a, b) <= TOL, name
 
 
+def _bottom_levels(inputs, nkeep):
+    """The lowest `nkeep` model levels of the same columns (a shallower, physically odd but valid atmosphere)."""
+    ncol, nlev, sl, th, gas, cloud, aer = inputs
+    k = nlev - nkeep
+    cut = lambda a: np.ascontiguousarray(a[..., k:, :])
+    th.pressure_hl, th.temperature_hl = cut(th.pressure_hl), cut(th.temperature_hl)
+    th.h2o_sat_liq = None
+    gas.mixing_ratio = cut(gas.mixing_ratio)
+    cloud.fraction, cloud.mixing_ratio = cut(cloud.fraction), cut(cloud.mixing_ratio)
+    cloud.effective_radius, cloud.fractional_std = cut(cloud.effective_radius), cut(cloud.fractional_std)
+    cloud.overlap_param = cut(cloud.overlap_param)
+    if aer is not None and aer.mixing_ratio is not None and aer.mixing_ratio.size:
+        aer.mixing_ratio = cut(aer.mixing_ratio)
+        aer.istartlev, aer.iendlev = 1, nkeep
+    return ncol, nkeep, sl, th, gas, cloud, aer
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nkeep", [100, 61, 33, 7])
+@pytest.mark.parametrize("solver", ["Tripleclouds", "McICA", "Homogeneous"])
+def test_other_level_counts(solver, nkeep, oracle_lib):
+    """Level counts that are not 137: not a multiple of the 32-level LDS chunks, fewer levels than
+    lanes per column, a single chunk."""
+    f_hip, _, rad = run_case(make_config(solver), "hip", inputs=_bottom_levels(load_meridian(make_config(solver)), nkeep))
+    rad.close()
+    f_ora, _, _ = run_case(make_config(solver), oracle_lib.backend,
+                           inputs=_bottom_levels(load_meridian(make_config(solver)), nkeep))
+    compare_flux(f_hip, f_ora, TOL)
+
+
 def test_crop_cloud_fraction_side_effect_matches(oracle_lib):
     c1, c2 = make_config("Tripleclouds"), make_config("Tripleclouds")
     in1, in2 = load_meridian(c1), load_meridian(c2)
