@@ -46,7 +46,7 @@ struct ecrad_hip_handle_s {
   DevConfig* dcfg = nullptr;
   std::vector<void*> tables;
   int ngp_sw = 0, ngp_lw = 0;
-  int nchunk_sw = 1;               // launches per shortwave spectrum (> 1 beyond 64 g-points)
+  int nchunk_sw = 1, nchunk_lw = 1;   // launches per spectrum (> 1 beyond 64 g-points)
   Buf partial;                     // per-chunk partial broadband profiles
   Buf scratch, prep, staging_in, staging_out, counters;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -347,7 +347,7 @@ int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
   { int nch = 1; if (c.do_sw && (c.n_g_sw < 1 || (chunk_lanes(c.n_g_sw, &nch), nch > 15))) return fail(h, ECRAD_EUNSUPPORTED, "shortwave spectrum too wide"); }
   if (c.do_sw && c.n_g_sw > 64 && c.i_solver_sw == ECRAD_SOLVER_MCICA && c.use_vectorizable_generator == 0 && c.n_g_sw > 512)
     return fail(h, ECRAD_EUNSUPPORTED, "shortwave spectrum too wide for the cloud generator");
-  if (c.do_lw && padded_ng(c.n_g_lw) == 0) return fail(h, ECRAD_EUNSUPPORTED, "more than 64 longwave g-points");
+  { int nch = 1; if (c.do_lw && (c.n_g_lw < 1 || (chunk_lanes(c.n_g_lw, &nch), nch > 15))) return fail(h, ECRAD_EUNSUPPORTED, "longwave spectrum too wide"); }
   if (c.do_clouds && (c.n_cloud_types < 1 || c.n_cloud_types > ECRAD_NMAXCLOUDTYPES)) return fail(h, ECRAD_EINVAL, "n_cloud_types out of range");
   return ECRAD_OK;
 }
@@ -492,7 +492,7 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
     if ((st = setup_ckd(h, c.gas_optics_lw, d.gas_lw))) return st;
     if (d.gas_lw.ng != c.n_g_lw) return fail(h, ECRAD_EINVAL, "n_g_lw does not match the longwave gas model");
     if (!d.i_band_from_reordered_g_lw) return fail(h, ECRAD_EINVAL, "i_band_from_reordered_g_lw missing");
-    h->ngp_lw = padded_ng(c.n_g_lw);
+    h->ngp_lw = chunk_lanes(c.n_g_lw, &h->nchunk_lw);
   }
   if (c.do_clouds) {
     for (int t = 0; t < c.n_cloud_types; ++t) {
@@ -794,6 +794,10 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
   const size_t need_sw = per_block_sw * grid_sw * 8, need_lw = per_block_lw * grid_lw * 8;
   HIP_TRY(h, h->scratch.ensure(need_sw > need_lw ? need_sw : need_lw));
   HIP_TRY(h, h->counters.ensure(256));
+  {   // per-chunk partial profiles of spectra wider than 64 g-points (6 profiles x chunks, reused by LW then SW)
+    const int nch = std::max(c.do_lw ? h->nchunk_lw : 1, c.do_sw ? h->nchunk_sw : 1);
+    if (nch > 1) HIP_TRY(h, h->partial.ensure((size_t)cx.din.ncol * (nlev + 1) * nch * 6 * sizeof(double)));
+  }
   int* counters = reinterpret_cast<int*>(h->counters.p);   // [0] LW kernel, [16] SW kernel work queues
   DevCloudPrep prep{};
   {
@@ -839,9 +843,36 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
         HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_lw, 997, prep.od_scaling_lw,
                                           prep.total_cloud_cover_lw));
     }
-    if (lw_tc) HIP_TRY(h, launch_lw_tc(h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_lw, counters, m));
-    else if (lw_scat) HIP_TRY(h, launch_lw_scat(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_lw, counters, m));
-    else HIP_TRY(h, launch_lw_ica(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_lw, counters, m));
+    auto launch_lw = [&](const DevFlux& f, int* counter, int g0, bool wide) -> hipError_t {
+      if (lw_tc) return launch_lw_tc(h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
+      if (lw_scat) return launch_lw_scat(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
+      return launch_lw_ica(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
+    };
+    if (h->nchunk_lw == 1) {
+      HIP_TRY(h, launch_lw(dfx, counters, 0, false));
+    } else {
+      // More than 64 g-points: as for the shortwave below, plus the derivatives.  The reference
+      // normalises them by the surface upward flux summed over the WHOLE spectrum, so the chunks
+      // return un-normalised sums (whose surface value is their share of that flux) and
+      // combine_derivatives adds them up, normalises, and does the McICA clear/all-sky blend.
+      double* DevFlux::* const prof[6] = {&DevFlux::lw_up, &DevFlux::lw_dn, &DevFlux::lw_up_clear, &DevFlux::lw_dn_clear,
+                                          &DevFlux::lw_derivatives, &DevFlux::lw_derivatives_aux};
+      const size_t plane = (size_t)din.ncol * (nlev + 1);
+      const int nch = h->nchunk_lw;
+      double* pbase = reinterpret_cast<double*>(h->partial.p);
+      const bool deriv = dfx.lw_derivatives != nullptr && c.do_lw_derivatives;
+      for (int p = 0; p < nch; ++p) {
+        DevFlux dpart = dfx;
+        for (int k = 0; k < 6; ++k)
+          if (dfx.*(prof[k]) || (k == 5 && deriv)) dpart.*(prof[k]) = pbase + plane * ((size_t)k * nch + p);
+        HIP_TRY(h, launch_lw(dpart, counters + p, p * h->ngp_lw, true));
+      }
+      for (int k = 0; k < 4; ++k)
+        if (dfx.*(prof[k])) HIP_TRY(h, launch_combine_partials(stream, din, dfx.*(prof[k]), pbase + plane * (size_t)k * nch, plane, nch));
+      if (deriv)
+        HIP_TRY(h, launch_combine_derivatives(stream, din, dfx.lw_derivatives, pbase + plane * (size_t)4 * nch, pbase + plane * (size_t)5 * nch,
+                                              plane, nch, lw_mcica ? dfx.cloud_cover_lw : nullptr, c.cloud_fraction_threshold));
+    }
   }
   HIP_TRY(h, hipEventRecord(h->evs[2], stream));
   if (c.do_sw) {                                                                        // :459-499
@@ -868,7 +899,6 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
                                           &DevFlux::sw_up_clear, &DevFlux::sw_dn_clear, &DevFlux::sw_dn_direct_clear};
       const size_t plane = (size_t)din.ncol * (nlev + 1);
       const int nch = h->nchunk_sw;
-      HIP_TRY(h, h->partial.ensure(plane * nch * 6 * sizeof(double)));
       double* pbase = reinterpret_cast<double*>(h->partial.p);
       for (int p = 0; p < nch; ++p) {
         DevFlux dpart = dfx;
@@ -963,8 +993,10 @@ int ecrad_hip_optics(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, in
     for (int p = 0; p < h->nchunk_sw; ++p)
       HIP_TRY(h, launch_optics_dump(true, h->ngp_sw, h->hcfg.gas_sw.table_f32, grid_for(h, r.nloc, h->ngp_sw),
                                     lds_bytes(h->hcfg.gas_sw.hot.nquad, nct), stream, h->dcfg, cx.din, dop, p * h->ngp_sw));
-  if (c.do_lw) HIP_TRY(h, launch_optics_dump(false, h->ngp_lw, h->hcfg.gas_lw.table_f32, grid_for(h, r.nloc, h->ngp_lw),
-                                             lds_bytes(h->hcfg.gas_lw.hot.nquad, nct), stream, h->dcfg, cx.din, dop, 0));
+  if (c.do_lw)
+    for (int p = 0; p < h->nchunk_lw; ++p)
+      HIP_TRY(h, launch_optics_dump(false, h->ngp_lw, h->hcfg.gas_lw.table_f32, grid_for(h, r.nloc, h->ngp_lw),
+                                             lds_bytes(h->hcfg.gas_lw.hot.nquad, nct), stream, h->dcfg, cx.din, dop, p * h->ngp_lw));
   if (host_mem) {
     for (const OF& f : fields)
       if (out->*(f.host)) HIP_TRY(h, hipMemcpyAsync(out->*(f.host), dop.*(f.dev), f.n * 8, hipMemcpyDeviceToHost, stream));

@@ -135,6 +135,7 @@ struct DevFlux {
   double *lw_up, *lw_dn, *sw_up, *sw_dn, *sw_dn_direct;
   double *lw_up_clear, *lw_dn_clear, *sw_up_clear, *sw_dn_clear, *sw_dn_direct_clear;
   double *lw_derivatives;
+  double *lw_derivatives_aux;   // internal (chunked longwave spectra): un-normalised all-sky derivative sums, see api.hip
   double *lw_dn_surf_g, *lw_dn_surf_clear_g;
   double *sw_dn_diffuse_surf_g, *sw_dn_direct_surf_g, *sw_dn_diffuse_surf_clear_g, *sw_dn_direct_surf_clear_g;
   double *lw_up_toa_g, *lw_up_toa_clear_g, *sw_dn_toa_g, *sw_up_toa_g, *sw_up_toa_clear_g;

@@ -38,7 +38,10 @@ struct LwScratch {
 #endif
 constexpr int kLwBatch = ECRAD_LW_BATCH;    // (T, S) pairs are 16 B per layer, so the longwave sweep can look further ahead
 
-template <typename TAB, int NGP, int MODE>
+// WIDE: the launch covers g-points g0 .. g0+NGP-1 of a spectrum wider than 64.  Its sums over g are
+// partial; the derivatives, which the reference normalises by the surface flux summed over the whole
+// spectrum, are then left un-normalised (their surface value IS that partial sum) for the host to finish.
+template <typename TAB, int NGP, int MODE, bool WIDE>
 __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
@@ -76,7 +79,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
 
     const LdsLayout L = make_lds(smem, nquad, nct);
     const LwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block, MODE == 0 ? L_WIDTH_CLEAR : L_WIDTH_FULL};
-    const int g = glane < ng ? glane : ng - 1;
+    const int gi = (WIDE ? a.g0 : 0) + glane;       // g-point of this lane
+    const int g = gi < ng ? gi : ng - 1;
     const int ib = cfg.i_band_from_reordered_g_lw[g] - 1;
     const int aer_type = aerosol_lane_type(cfg, glane);
     const bool have_clear_out = cfg.do_clear != 0;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
     const int col = a.in.istartcol - 1 + cloc;
-    const bool valid = col_ok && glane < ng;
+    const bool valid = col_ok && gi < ng;
     const bool lead = glane == 0 && col_ok;
     const double albedo = albedo_lw_g(cfg, a.in, col, g);
     const double emission = planck_at<TAB>(m, a.in.skin_temperature[col], g) * (1.0 - albedo);
@@ -226,12 +230,12 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
     double fup = emission + albedo * fdn_c;
     const double fup_surf_clear = fup;
     double dsum = group_sum<NGP>(valid ? fup : 0.0);
-    double deriv = fup / dsum;
+    double deriv = WIDE ? fup : fup / dsum;
     if (lead) {
       const size_t o = col + ncol * ord.half(nlev);
       fx.lw_up[o] = dsum;
       if (have_clear_out) fx.lw_up_clear[o] = dsum;
-      if (do_deriv) fx.lw_derivatives[o] = 1.0;
+      if (do_deriv) fx.lw_derivatives[o] = WIDE ? dsum : 1.0;
     }
     if (valid && fx.lw_up_band) {
       const size_t o = col + ncol * ord.half(nlev);
@@ -385,8 +389,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
       // calc_lw_derivatives_ica with the all-sky transmittances, then (McICA only)
       // modify_lw_derivatives_ica with weight 1-tcc towards the clear-sky profile already stored
       const double ssurf = group_sum<NGP>(valid ? fup : 0.0);
-      double d = fup / ssurf;
+      double d = WIDE ? fup : fup / ssurf;
       const bool modify = MODE == 2 && tcc < 1.0 - cloud_fraction_threshold;
+      // WIDE: the all-sky sums replace the clear-sky ones, or go next to them when the two are blended
+      double* const wide_dst = (WIDE && modify) ? fx.lw_derivatives_aux : fx.lw_derivatives;
+      if (WIDE && lead) wide_dst[col + ncol * ord.half(nlev)] = ssurf;
       const double wclr = 1.0 - tcc;
       double keep_der = 0.0;
       for (int l = nlev - 1; l >= 0; --l) {
@@ -400,7 +407,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
           const int lv = l + glane;
           if (col_ok && lv < nlev) {
             const size_t o = col + ncol * ord.half(lv);
-            fx.lw_derivatives[o] = modify ? (1.0 - wclr) * keep_der + wclr * fx.lw_derivatives[o] : keep_der;
+            if (WIDE) wide_dst[o] = keep_der;
+            else fx.lw_derivatives[o] = modify ? (1.0 - wclr) * keep_der + wclr * fx.lw_derivatives[o] : keep_der;
           }
         }
       }
@@ -415,20 +423,20 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
 #endif
 }
 
-template <typename TAB, int NGP>
+template <typename TAB, int NGP, bool WIDE>
 static hipError_t launch_lw_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const SpectralArgs& args) {
   switch (mode) {
     case ECRAD_SOLVER_CLOUDLESS:
-      ECRAD_ALLOW_LDS((lw_ica_kernel<TAB, NGP, 0>), lds);
-      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 0>), grid, dim3(kBlock), lds, st, args);
+      ECRAD_ALLOW_LDS((lw_ica_kernel<TAB, NGP, 0, WIDE>), lds);
+      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 0, WIDE>), grid, dim3(kBlock), lds, st, args);
       break;
     case ECRAD_SOLVER_HOMOGENEOUS:
-      ECRAD_ALLOW_LDS((lw_ica_kernel<TAB, NGP, 1>), lds);
-      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 1>), grid, dim3(kBlock), lds, st, args);
+      ECRAD_ALLOW_LDS((lw_ica_kernel<TAB, NGP, 1, WIDE>), lds);
+      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 1, WIDE>), grid, dim3(kBlock), lds, st, args);
       break;
     default:
-      ECRAD_ALLOW_LDS((lw_ica_kernel<TAB, NGP, 2>), lds);
-      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 2>), grid, dim3(kBlock), lds, st, args);
+      ECRAD_ALLOW_LDS((lw_ica_kernel<TAB, NGP, 2, WIDE>), lds);
+      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 2, WIDE>), grid, dim3(kBlock), lds, st, args);
       break;
   }
   return hipGetLastError();
@@ -440,10 +448,10 @@ size_t lw_ica_scratch_doubles(int mode, int nlev) {
 
 hipError_t launch_lw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m) {
+                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0, bool wide) {
   dim3 g(grid);
-  const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot};
-#define ECRAD_DISPATCH(T, N) return launch_lw_mode<T, N>(mode, g, lds, st, args)
+  const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot, g0, 0};
+#define ECRAD_DISPATCH(T, N) return wide ? launch_lw_mode<T, N, true>(mode, g, lds, st, args) : launch_lw_mode<T, N, false>(mode, g, lds, st, args)
   if (table_f32) {
     if (ngp == 16) ECRAD_DISPATCH(float, 16);
     if (ngp == 32) ECRAD_DISPATCH(float, 32);

@@ -29,7 +29,8 @@ struct LwScatScratch {
 };
 enum { LS_RT = 0, LS_SS = 2, LS_RT2 = 4, LS_SS2 = 6, LS_DN = 8, LS_AS = 10 };
 
-template <typename TAB, int NGP, int MODE>
+// WIDE: see kernel_ica_lw.hip
+template <typename TAB, int NGP, int MODE, bool WIDE>
 __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(Spectr
     const LdsLayout L = make_lds(smem, nquad, nct);
     const LwScatScratch s{a.scratch + (size_t)blockIdx.x * a.per_block};
     quads.reset();
-    const int g = glane < ng ? glane : ng - 1;
+    const int gi = (WIDE ? a.g0 : 0) + glane;
+    const int g = gi < ng ? gi : ng - 1;
     const int ib = cfg.i_band_from_reordered_g_lw[g] - 1;
     const int aer_type = aerosol_lane_type(cfg, glane);
     const bool have_clear_out = cfg.do_clear != 0;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(Spectr
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
     const int col = a.in.istartcol - 1 + cloc;
-    const bool valid = col_ok && glane < ng;
+    const bool valid = col_ok && gi < ng;
     const bool lead = glane == 0 && col_ok;
     const double albedo = albedo_lw_g(cfg, a.in, col, g);
     const double emission = planck_at<TAB>(m, a.in.skin_temperature[col], g) * (1.0 - albedo);
@@ -194,10 +196,12 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(Spectr
     };
     // calc_lw_derivatives_ica (radiation_lw_derivatives.F90:43-82); weight < 1: modify_lw_derivatives_ica
     // towards the profile already stored (:88-130)
-    auto derivatives = [&](bool cloudy_sky, double fup_surf, double weight, bool modify) {
+    auto derivatives = [&](bool cloudy_sky, double fup_surf, double weight, bool modify, double* wide_dst) {
       const double ssurf = group_sum<NGP>(valid ? fup_surf : 0.0);
-      double d = fup_surf / ssurf;
-      if (lead) fx.lw_derivatives[col + ncol * ord.half(nlev)] = 1.0;
+      double d = WIDE ? fup_surf : fup_surf / ssurf;
+      // WIDE: un-normalised sums into `wide_dst`; the host normalises and blends (api.hip)
+      double* const dst = WIDE ? wide_dst : fx.lw_derivatives;
+      if (lead) dst[col + ncol * ord.half(nlev)] = WIDE ? ssurf : 1.0;
       double keep_der = 0.0;
       for (int l = nlev - 1; l >= 0; --l) {
         const bool cl = cloudy_sky && cloudy.test(l);
@@ -209,7 +213,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(Spectr
           const int lv = l + glane;
           if (col_ok && lv < nlev) {
             const size_t o = col + ncol * ord.half(lv);
-            fx.lw_derivatives[o] = modify ? (1.0 - weight) * fx.lw_derivatives[o] + weight * keep_der : keep_der;
+            if (WIDE) dst[o] = keep_der;
+            else dst[o] = modify ? (1.0 - weight) * dst[o] + weight * keep_der : keep_der;
           }
         }
       }
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(Spectr
         fx.lw_dn_surf_g[og] = fdn_s; fx.lw_up_toa_g[og] = fup_t;
         if (have_clear_out) { fx.lw_dn_surf_clear_g[og] = fdn_s; fx.lw_up_toa_clear_g[og] = fup_t; }
       }
-      if (do_deriv) derivatives(false, fup_s, 1.0, false);
+      if (do_deriv) derivatives(false, fup_s, 1.0, false, fx.lw_derivatives);
       continue;
     }
     if (MODE == 1) {
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(Spectr
                fdn_s, fup_s, fup_t);
         if (valid) { fx.lw_dn_surf_g[og] = fdn_s; fx.lw_up_toa_g[og] = fup_t; }
       }
-      if (do_deriv) derivatives(do_total, fup_s, 1.0, false);
+      if (do_deriv) derivatives(do_total, fup_s, 1.0, false, fx.lw_derivatives);
       continue;
     }
     // MODE 2: McICA (do_clear is required by the reference, radiation_mcica_lw.F90:141-144)
@@ -263,32 +268,33 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(Spectr
         fx.lw_up_toa_g[og] = tcc * fup_t + (1.0 - tcc) * fup_tc;
       }
       if (do_deriv) {
-        derivatives(true, fup_s, 1.0, false);
-        if (tcc < 1.0 - cloud_fraction_threshold) derivatives(false, fup_sc, 1.0 - tcc, true);
+        const bool modify = tcc < 1.0 - cloud_fraction_threshold;
+        derivatives(true, fup_s, 1.0, false, modify ? fx.lw_derivatives_aux : fx.lw_derivatives);
+        if (modify) derivatives(false, fup_sc, 1.0 - tcc, true, fx.lw_derivatives);
       }
     } else {
       if (valid) { fx.lw_dn_surf_g[og] = fdn_sc; fx.lw_up_toa_g[og] = fup_tc; }
-      if (do_deriv) derivatives(false, fup_sc, 1.0, false);
+      if (do_deriv) derivatives(false, fup_sc, 1.0, false, fx.lw_derivatives);
     }
   }
 }
 
 size_t lw_scat_scratch_doubles(int nlev) { return (size_t)12 * nlev * kBlock; }
 
-template <typename TAB, int NGP>
+template <typename TAB, int NGP, bool WIDE>
 static hipError_t launch_lw_scat_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const SpectralArgs& args) {
   switch (mode) {
     case ECRAD_SOLVER_CLOUDLESS:
-      ECRAD_ALLOW_LDS((lw_scat_kernel<TAB, NGP, 0>), lds);
-      hipLaunchKernelGGL((lw_scat_kernel<TAB, NGP, 0>), grid, dim3(kBlock), lds, st, args);
+      ECRAD_ALLOW_LDS((lw_scat_kernel<TAB, NGP, 0, WIDE>), lds);
+      hipLaunchKernelGGL((lw_scat_kernel<TAB, NGP, 0, WIDE>), grid, dim3(kBlock), lds, st, args);
       break;
     case ECRAD_SOLVER_HOMOGENEOUS:
-      ECRAD_ALLOW_LDS((lw_scat_kernel<TAB, NGP, 1>), lds);
-      hipLaunchKernelGGL((lw_scat_kernel<TAB, NGP, 1>), grid, dim3(kBlock), lds, st, args);
+      ECRAD_ALLOW_LDS((lw_scat_kernel<TAB, NGP, 1, WIDE>), lds);
+      hipLaunchKernelGGL((lw_scat_kernel<TAB, NGP, 1, WIDE>), grid, dim3(kBlock), lds, st, args);
       break;
     default:
-      ECRAD_ALLOW_LDS((lw_scat_kernel<TAB, NGP, 2>), lds);
-      hipLaunchKernelGGL((lw_scat_kernel<TAB, NGP, 2>), grid, dim3(kBlock), lds, st, args);
+      ECRAD_ALLOW_LDS((lw_scat_kernel<TAB, NGP, 2, WIDE>), lds);
+      hipLaunchKernelGGL((lw_scat_kernel<TAB, NGP, 2, WIDE>), grid, dim3(kBlock), lds, st, args);
       break;
   }
   return hipGetLastError();
@@ -296,10 +302,10 @@ static hipError_t launch_lw_scat_mode(int mode, dim3 grid, size_t lds, hipStream
 
 hipError_t launch_lw_scat(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                           const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                          double* scratch, size_t per_block, int* counter, const DevCkdModel& m) {
+                          double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0, bool wide) {
   dim3 g(grid);
-  const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot};
-#define ECRAD_DISPATCH(T, N) return launch_lw_scat_mode<T, N>(mode, g, lds, st, args)
+  const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot, g0, 0};
+#define ECRAD_DISPATCH(T, N) return wide ? launch_lw_scat_mode<T, N, true>(mode, g, lds, st, args) : launch_lw_scat_mode<T, N, false>(mode, g, lds, st, args)
   if (table_f32) {
     if (ngp == 16) ECRAD_DISPATCH(float, 16);
     if (ngp == 32) ECRAD_DISPATCH(float, 32);

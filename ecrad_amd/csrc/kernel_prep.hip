@@ -1124,6 +1124,41 @@ __global__ void combine_partials_kernel(DevInputs in, double* dst, const double*
   }
 }
 
+// lw_derivatives of a chunked longwave spectrum: `a` holds per chunk the un-normalised clear-sky (or only)
+// sums over g of flux_up_surf * prod(transmittance), `b` the all-sky ones where McICA blends the two
+// (radiation_lw_derivatives.F90:43-130); the value at the surface half level is the chunk's surface flux.
+__global__ void combine_derivatives_kernel(DevInputs in, double* dst, const double* a, const double* b, size_t chunk_stride,
+                                           int nchunk, const double* cloud_cover, double threshold) {
+  const int nloc = in.iendcol - in.istartcol + 1;
+  const int nlev = in.nlev;
+  const size_t total = (size_t)nloc * (nlev + 1);
+  const LevelOrder ord = level_order(in);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t col = in.istartcol - 1 + i % nloc;
+    const size_t o = col + (size_t)in.ncol * (i / nloc), os = col + (size_t)in.ncol * ord.half(nlev);
+    double sa = 0.0, sa0 = 0.0;
+    for (int p = 0; p < nchunk; ++p) { sa += a[o + chunk_stride * p]; sa0 += a[os + chunk_stride * p]; }
+    double d = sa / sa0;
+    if (cloud_cover) {
+      const double tcc = cloud_cover[col];
+      if (tcc >= threshold && tcc < 1.0 - threshold) {      // modify_lw_derivatives_ica with weight 1 - tcc
+        double sb = 0.0, sb0 = 0.0;
+        for (int p = 0; p < nchunk; ++p) { sb += b[o + chunk_stride * p]; sb0 += b[os + chunk_stride * p]; }
+        d = tcc * (sb / sb0) + (1.0 - tcc) * d;
+      }
+    }
+    dst[o] = d;
+  }
+}
+
+hipError_t launch_combine_derivatives(hipStream_t st, const DevInputs& in, double* dst, const double* a, const double* b,
+                                      size_t chunk_stride, int nchunk, const double* cloud_cover, double threshold) {
+  const size_t total = (size_t)(in.iendcol - in.istartcol + 1) * (in.nlev + 1);
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(combine_derivatives_kernel, dim3(grid), dim3(256), 0, st, in, dst, a, b, chunk_stride, nchunk, cloud_cover, threshold);
+  return hipGetLastError();
+}
+
 hipError_t launch_combine_partials(hipStream_t st, const DevInputs& in, double* dst, const double* partial, size_t chunk_stride, int nchunk) {
   const size_t total = (size_t)(in.iendcol - in.istartcol + 1) * (in.nlev + 1);
   const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);

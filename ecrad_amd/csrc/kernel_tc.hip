@@ -523,7 +523,8 @@ constexpr int LW_TC_PLANES = 24;
 constexpr int TL_DC = 24, TL_DCT = 26;
 constexpr int LW_TC_PLANES_ASCAT = 28;
 
-template <typename TAB, int NGP, bool ASCAT>
+// WIDE: see kernel_ica_lw.hip
+template <typename TAB, int NGP, bool ASCAT, bool WIDE>
 __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
@@ -551,7 +552,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
     const LdsLayout L = make_lds(smem, m.hot.nquad, cfg.n_cloud_types);
     const TcLwScratch s{a.scratch + (size_t)blockIdx.x * a.per_block, ASCAT ? LW_TC_PLANES_ASCAT : LW_TC_PLANES};
     quads.reset();
-    const int g = glane < ng ? glane : ng - 1;
+    const int gi = (WIDE ? a.g0 : 0) + glane;
+    const int g = gi < ng ? gi : ng - 1;
     const int ib = cfg.i_band_from_reordered_g_lw[g] - 1;
     const int aer_type = aerosol_lane_type(cfg, glane);
     const bool do_clear = cfg.do_clear != 0;
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
     const int col = in.istartcol - 1 + cloc;
-    const bool valid = col_ok && glane < ng;
+    const bool valid = col_ok && gi < ng;
     const bool lead = glane == 0 && col_ok;
     const DevCloudPrep prep = a.prep;
     const TcGeom geo{prep, ncol_loc, nlev, cloc};
@@ -940,8 +942,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
       constexpr int K = ECRAD_TC_BATCH_D;
       const double fs = fup[0] + fup[1] + fup[2];
       const double tot = group_sum<NGP>(valid ? fs : 0.0);
-      double dv[3] = {fs / tot, 0.0, 0.0};
-      if (lead) fx.lw_derivatives[col + ncol * ord.half(nlev)] = 1.0;
+      double dv[3] = {WIDE ? fs : fs / tot, 0.0, 0.0};
+      if (lead) fx.lw_derivatives[col + ncol * ord.half(nlev)] = WIDE ? tot : 1.0;
       double keep_der = 0.0;
       for (int l0 = nlev - 1; l0 >= 0; l0 -= K) {
         double t1[K], t2[K], t3[K];
@@ -987,10 +989,11 @@ size_t lw_tc_scratch_doubles(int nlev, bool aerosol_scattering) {
 
 hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block,
-                        int* counter, const DevCkdModel& m) {
-  const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot};
-#define ECRAD_L2(T, N, A) do { ECRAD_ALLOW_LDS((lw_tc_kernel<T, N, A>), lds); hipLaunchKernelGGL((lw_tc_kernel<T, N, A>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
-#define ECRAD_L(T, N) do { if (cfg.do_lw_aerosol_scattering) ECRAD_L2(T, N, true); else ECRAD_L2(T, N, false); } while (0)
+                        int* counter, const DevCkdModel& m, int g0, bool wide) {
+  const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot, g0, 0};
+#define ECRAD_L2(T, N, A, W) do { ECRAD_ALLOW_LDS((lw_tc_kernel<T, N, A, W>), lds); hipLaunchKernelGGL((lw_tc_kernel<T, N, A, W>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
+#define ECRAD_L(T, N) do { if (cfg.do_lw_aerosol_scattering) { if (wide) ECRAD_L2(T, N, true, true); else ECRAD_L2(T, N, true, false); } \
+                           else { if (wide) ECRAD_L2(T, N, false, true); else ECRAD_L2(T, N, false, false); } } while (0)
   if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
   else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }
 #undef ECRAD_L

@@ -28,19 +28,21 @@ hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds
                          double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0, bool wide);
 hipError_t launch_lw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m);
+                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0, bool wide);
 // the same solvers with longwave aerosol scattering (kernel_lw_scat.hip)
 hipError_t launch_lw_scat(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
-                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m);
+                         double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0, bool wide);
 hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block, int* counter,
                         const DevCkdModel& m, int g0);
 // dst(col, l) = sum over chunks of partial profiles (chunk order), columns istartcol..iendcol
+hipError_t launch_combine_derivatives(hipStream_t st, const DevInputs& in, double* dst, const double* a, const double* b,
+                                      size_t chunk_stride, int nchunk, const double* cloud_cover, double threshold);
 hipError_t launch_combine_partials(hipStream_t st, const DevInputs& in, double* dst, const double* partial, size_t chunk_stride, int nchunk);
 hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block, int* counter,
-                        const DevCkdModel& m);
+                        const DevCkdModel& m, int g0, bool wide);
 hipError_t launch_order(hipStream_t st, const DevInputs& in, int32_t* flag);
 hipError_t launch_crop(hipStream_t st, const DevConfig* cfg, const DevInputs& in);
 hipError_t launch_tripleclouds_prep(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevCloudPrep& prep,

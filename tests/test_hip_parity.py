@@ -12,7 +12,7 @@ import pytest
 
 from ecrad_amd.driver import flux_to_output_dict
 from ecrad_amd.ncfile import NcFile
-from helpers import GOLDEN_DIR, compare_flux, load_meridian, make_config, rel_err, run_case
+from helpers import DATA_DIR, GOLDEN_DIR, compare_flux, load_meridian, make_config, rel_err, run_case
 
 pytestmark = pytest.mark.gpu
 TOL = 1.0e-8
@@ -247,6 +247,57 @@ def test_other_level_counts(solver, nkeep, oracle_lib):
     f_ora, _, _ = run_case(make_config(solver), oracle_lib.backend,
                            inputs=_bottom_levels(load_meridian(make_config(solver)), nkeep))
     compare_flux(f_hip, f_ora, TOL)
+
+
+def _replicated_lw_model(tmp_path, times=3):
+    """A longwave ecCKD model with every g-point of the shipped 32-term model repeated `times` times and
+    1/times of its Planck function and spectral weight: the same physics, `32*times` g-points (there is no
+    longwave model wider than a wave among the reference's data files)."""
+    from scipy.io import netcdf_file
+    src = netcdf_file(os.path.join(DATA_DIR, "ecckd-1.0_lw_climate_fsck-32b_ckd-definition.nc"), "r", mmap=False)
+    path = str(tmp_path / f"ecckd_lw_{32 * times}_replicated.nc")
+    dst = netcdf_file(path, "w", version=1)
+    for k in src._attributes:
+        setattr(dst, k, getattr(src, k))
+    for d, n in src.dimensions.items():
+        dst.createDimension(d, n * times if d == "g_point" else n)
+    for name, v in src.variables.items():
+        a = np.array(v.data)
+        if "g_point" in v.dimensions:
+            ax = v.dimensions.index("g_point")
+            a = np.repeat(a, times, axis=ax)
+            if name in ("planck_function", "gpoint_fraction"):
+                a = (a / times).astype(a.dtype)
+        w = dst.createVariable(name, a.dtype.newbyteorder("="), v.dimensions)
+        for k in v._attributes:
+            setattr(w, k, getattr(v, k))
+        if a.ndim == 0:
+            w.data[...] = a
+        else:
+            w[:] = a
+    dst.close()
+    src.close()
+    return path
+
+
+@pytest.mark.parametrize("case", ["Tripleclouds", "McICA", "Homogeneous", "Cloudless", "McICA_scat", "Tripleclouds_scat"])
+def test_wide_longwave_spectrum(case, tmp_path, oracle_lib):
+    """96 longwave g-points: three launches of 32 lanes; broadband profiles from per-chunk partial sums,
+    derivatives from un-normalised per-chunk sums normalised (and, for McICA, blended) afterwards."""
+    path = _replicated_lw_model(tmp_path)
+    kw = dict(gas_optics_lw_override_file_name=path)
+    if case.endswith("_scat"):
+        kw["do_lw_aerosol_scattering"] = True
+    solver = case.split("_")[0]
+    f_hip, _, rad = run_case(make_config(solver, **kw), "hip")
+    rad.close()
+    f_ora, _, _ = run_case(make_config(solver, **kw), oracle_lib.backend)
+    compare_flux(f_hip, f_ora, TOL)
+    # and the same broadband fluxes as the 32-term model it was built from (float32 Planck/3 rounding)
+    f_32, _, _ = run_case(make_config(solver, **{k: v for k, v in kw.items() if k != "gas_optics_lw_override_file_name"}),
+                          oracle_lib.backend)
+    for name in ("lw_up", "lw_dn"):
+        assert rel_err(f_ora.arrays[name], f_32.arrays[name]) < 1e-5 or solver == "McICA", name
 
 
 def test_crop_cloud_fraction_side_effect_matches(oracle_lib):
