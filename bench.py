@@ -207,8 +207,8 @@ def main():
         workload and column count."""
         import glob
         best = None
-        for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json")),
-                        key=os.path.getmtime):
+        # (sorted by name: the tags are r<round>_<letter>, and file times do not survive a checkout)
+        for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json"))):
             try:
                 d = json.load(open(f))
             except Exception:
