@@ -36,6 +36,9 @@ struct LwScratch {
 #ifndef ECRAD_LW_BATCH
 #define ECRAD_LW_BATCH ECRAD_SWEEP_BATCH
 #endif
+#ifndef ECRAD_LW_AER_BATCH
+#define ECRAD_LW_AER_BATCH(mode) ((mode) == 2 ? 12 : 4)      // aerosol types per batch of table loads, per solver mode (measured)
+#endif
 constexpr int kLwBatch = ECRAD_LW_BATCH;    // (T, S) pairs are 16 B per layer, so the longwave sweep can look further ahead
 
 // WIDE: the launch covers g-points g0 .. g0+NGP-1 of a spectrum wider than 64.  Its sums over g are
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
         ECRAD_LAP(tm, 2, od);           // combine
         if (use_aerosols) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
-          const AerosolLayer al = aerosol_layer<false, NGP>(b.cfg, b.in, L, slot, col, lev, ib, aer_type);
+          const AerosolLayer al = aerosol_layer<false, NGP, ECRAD_LW_AER_BATCH(MODE)>(b.cfg, b.in, L, slot, col, lev, ib, aer_type);
           od = od + al.od;   // radiation_aerosol_optics.F90:805-818 (no longwave aerosol scattering)
         }
         const LwCoef c = no_scattering_lw(od, planck_top, planck_bot);
