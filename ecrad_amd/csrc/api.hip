@@ -47,6 +47,9 @@ struct ecrad_hip_handle_s {
   std::vector<void*> tables;
   int ngp_sw = 0, ngp_lw = 0;
   int nchunk_sw = 1, nchunk_lw = 1;   // launches per spectrum (> 1 beyond 64 g-points)
+  bool spec_sum_sw = false, spec_sum_lw = false;   // spectral flux profiles need summing over g-points
+  const int32_t *d_ispec_sw = nullptr, *d_ispec_lw = nullptr;
+  Buf spec_tmp;                    // per-g spectral flux profiles before that sum
   Buf partial;                     // per-chunk partial broadband profiles
   Buf scratch, prep, staging_in, staging_out, counters;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -322,16 +325,15 @@ int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
     if (s > ECRAD_SOLVER_TRIPLECLOUDS) return fail(h, ECRAD_EINVAL, "unknown solver");
   }
   if (c.do_save_spectral_flux) {
-    // spectral flux profiles: only one interval per g-point (bands == g-points, the ecCKD default, or
-    // do_save_gpoint_flux); summing g-points into wider bands per level is not built
-    auto identity = [](const int32_t* m, int n, int nspec) {
-      if (!m || nspec != n) return false;
-      for (int i = 0; i < n; ++i) if (m[i] != i + 1) return false;
-      return true;
-    };
-    if ((c.do_sw && !identity(c.i_spec_from_reordered_g_sw, c.n_g_sw, c.n_spec_sw)) ||
-        (c.do_lw && !identity(c.i_spec_from_reordered_g_lw, c.n_g_lw, c.n_spec_lw)))
-      return fail(h, ECRAD_EUNSUPPORTED, "do_save_spectral_flux is implemented for one spectral interval per g-point only");
+    // spectral flux profiles: the kernels write one interval per g-point; any other mapping of g-points
+    // to intervals (bands) is summed afterwards from per-g temporaries (spectral_profile_sum_kernel)
+    for (int s = 0; s < 2; ++s) {
+      if (!(s ? c.do_lw : c.do_sw)) continue;
+      const int32_t* m = s ? c.i_spec_from_reordered_g_lw : c.i_spec_from_reordered_g_sw;
+      const int n = s ? c.n_g_lw : c.n_g_sw, nspec = s ? c.n_spec_lw : c.n_spec_sw;
+      if (!m || nspec < 1 || nspec > n) return fail(h, ECRAD_EINVAL, "i_spec_from_reordered_g / n_spec missing or out of range");
+      for (int i = 0; i < n; ++i) if (m[i] < 1 || m[i] > nspec) return fail(h, ECRAD_EINVAL, "i_spec_from_reordered_g out of range");
+    }
   }
   if (c.do_lw && c.do_lw_aerosol_scattering && !c.do_lw_cloud_scattering)
     return fail(h, ECRAD_EINVAL, "longwave aerosol scattering requires longwave cloud scattering");   // radiation_interface.F90:84-93
@@ -405,7 +407,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
   if (!h) return ECRAD_EINVAL;
   (void)hipSetDevice(h->device);
   free_tables(h);
-  h->counters.release(); h->partial.release(); h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
+  h->counters.release(); h->partial.release(); h->spec_tmp.release(); h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (auto& e : h->evs) if (e) (void)hipEventDestroy(e);
@@ -484,6 +486,13 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
     if (!c.use_canopy_full_spectrum_sw && !c.do_nearest_spectral_sw_albedo && !d.sw_albedo_weights)
       return fail(h, ECRAD_EINVAL, "sw_albedo_weights missing");
     h->ngp_sw = chunk_lanes(c.n_g_sw, &h->nchunk_sw);
+    h->spec_sum_sw = false; h->d_ispec_sw = nullptr;
+    if (c.do_save_spectral_flux) {
+      bool ident = c.n_spec_sw == c.n_g_sw;
+      for (int i = 0; ident && i < c.n_g_sw; ++i) ident = c.i_spec_from_reordered_g_sw[i] == i + 1;
+      h->spec_sum_sw = !ident;
+      if (!ident && (st = upload<int32_t>(h, c.i_spec_from_reordered_g_sw, c.n_g_sw, &h->d_ispec_sw))) return st;
+    }
   }
   if (c.do_lw) {
     if ((st = upload<int32_t>(h, c.i_band_from_reordered_g_lw, c.n_g_lw, &d.i_band_from_reordered_g_lw))) return st;
@@ -493,6 +502,13 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
     if (d.gas_lw.ng != c.n_g_lw) return fail(h, ECRAD_EINVAL, "n_g_lw does not match the longwave gas model");
     if (!d.i_band_from_reordered_g_lw) return fail(h, ECRAD_EINVAL, "i_band_from_reordered_g_lw missing");
     h->ngp_lw = chunk_lanes(c.n_g_lw, &h->nchunk_lw);
+    h->spec_sum_lw = false; h->d_ispec_lw = nullptr;
+    if (c.do_save_spectral_flux) {
+      bool ident = c.n_spec_lw == c.n_g_lw;
+      for (int i = 0; ident && i < c.n_g_lw; ++i) ident = c.i_spec_from_reordered_g_lw[i] == i + 1;
+      h->spec_sum_lw = !ident;
+      if (!ident && (st = upload<int32_t>(h, c.i_spec_from_reordered_g_lw, c.n_g_lw, &h->d_ispec_lw))) return st;
+    }
   }
   if (c.do_clouds) {
     for (int t = 0; t < c.n_cloud_types; ++t) {
@@ -772,6 +788,32 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
     if (sw_spec && (!dfx.sw_up_band || !dfx.sw_dn_band || (c.do_clear && (!dfx.sw_up_clear_band || !dfx.sw_dn_clear_band))))
       return fail(h, ECRAD_EINVAL, "flux%sw_*_band must be allocated with do_save_spectral_flux");
   }
+  // Spectral flux profiles in intervals other than one per g-point: the kernels write per-g temporaries
+  // (leading dimension ng) and spectral_profile_sum_kernel adds the g-points of every interval afterwards
+  double* DevFlux::* const spec_arr[10] = {&DevFlux::lw_up_band, &DevFlux::lw_dn_band, &DevFlux::lw_up_clear_band, &DevFlux::lw_dn_clear_band,
+                                           &DevFlux::sw_up_band, &DevFlux::sw_dn_band, &DevFlux::sw_dn_direct_band,
+                                           &DevFlux::sw_up_clear_band, &DevFlux::sw_dn_clear_band, &DevFlux::sw_dn_direct_clear_band};
+  double* spec_real[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  {
+    const size_t plane = (size_t)cx.din.ncol * (nlev + 1);
+    size_t need = 0;
+    for (int k = 0; k < 10; ++k) {
+      const bool lw = k < 4;
+      if ((lw ? h->spec_sum_lw : h->spec_sum_sw) && dfx.*(spec_arr[k])) need += plane * (lw ? c.n_g_lw : c.n_g_sw) * sizeof(double);
+    }
+    if (need) {
+      HIP_TRY(h, h->spec_tmp.ensure(need));
+      double* ptmp = reinterpret_cast<double*>(h->spec_tmp.p);
+      for (int k = 0; k < 10; ++k) {
+        const bool lw = k < 4;
+        if ((lw ? h->spec_sum_lw : h->spec_sum_sw) && dfx.*(spec_arr[k])) {
+          spec_real[k] = dfx.*(spec_arr[k]);
+          dfx.*(spec_arr[k]) = ptmp;
+          ptmp += plane * (lw ? c.n_g_lw : c.n_g_sw);
+        }
+      }
+    }
+  }
   // the solvers write these unconditionally
   if (c.do_lw && (!dfx.lw_up || !dfx.lw_dn || !dfx.lw_dn_surf_g || !dfx.lw_up_toa_g)) return fail(h, ECRAD_EINVAL, "flux%lw_up/lw_dn/lw_dn_surf_g/lw_up_toa_g must be allocated");
   if (c.do_sw && (!dfx.sw_up || !dfx.sw_dn || !dfx.sw_dn_diffuse_surf_g || !dfx.sw_dn_direct_surf_g || !dfx.sw_up_toa_g))
@@ -912,6 +954,13 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
     }
   }
   HIP_TRY(h, hipEventRecord(h->evs[3], stream));
+  for (int k = 0; k < 10; ++k)
+    if (spec_real[k]) {
+      const bool lw = k < 4;
+      HIP_TRY(h, launch_spectral_profile_sum(stream, din, dfx.*(spec_arr[k]), spec_real[k], lw ? c.n_g_lw : c.n_g_sw,
+                                             lw ? c.n_spec_lw : c.n_spec_sw, lw ? h->d_ispec_lw : h->d_ispec_sw));
+      dfx.*(spec_arr[k]) = spec_real[k];      // (the staged copy-back below uses the real arrays)
+    }
   const bool wide = c.n_g_sw > 64 || c.n_g_lw > 64 || c.n_bands_sw > 64 || c.n_bands_lw > 64 ||
                     c.n_canopy_bands_sw > 64 || c.n_canopy_bands_lw > 64;
   HIP_TRY(h, launch_spectral_post(stream, h->dcfg, din, dfx, wide));                          // :503-504

@@ -1124,6 +1124,29 @@ __global__ void combine_partials_kernel(DevInputs in, double* dst, const double*
   }
 }
 
+// indexed_sum_profile (radiation_flux.F90:800-855): spectral flux profiles in nspec intervals from the
+// per-g profiles the solver kernels write, g-points added in increasing g; one thread per (column, half level)
+__global__ void spectral_profile_sum_kernel(DevInputs in, const double* per_g, double* dst, int ng, int nspec,
+                                            const int32_t* __restrict__ ispec) {
+  const int nloc = in.iendcol - in.istartcol + 1;
+  const size_t total = (size_t)nloc * (in.nlev + 1);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t o = (in.istartcol - 1 + i % nloc) + (size_t)in.ncol * (i / nloc);
+    double* out = dst + (size_t)nspec * o;
+    const double* src = per_g + (size_t)ng * o;
+    for (int b = 0; b < nspec; ++b) out[b] = 0.0;
+    for (int g = 0; g < ng; ++g) out[ispec[g] - 1] += src[g];
+  }
+}
+
+hipError_t launch_spectral_profile_sum(hipStream_t st, const DevInputs& in, const double* per_g, double* dst, int ng, int nspec,
+                                       const int32_t* ispec) {
+  const size_t total = (size_t)(in.iendcol - in.istartcol + 1) * (in.nlev + 1);
+  const int grid = (int)((total + 127) / 128 < 8192 ? (total + 127) / 128 : 8192);
+  hipLaunchKernelGGL(spectral_profile_sum_kernel, dim3(grid), dim3(128), 0, st, in, per_g, dst, ng, nspec, ispec);
+  return hipGetLastError();
+}
+
 // lw_derivatives of a chunked longwave spectrum: `a` holds per chunk the un-normalised clear-sky (or only)
 // sums over g of flux_up_surf * prod(transmittance), `b` the all-sky ones where McICA blends the two
 // (radiation_lw_derivatives.F90:43-130); the value at the surface half level is the chunk's surface flux.

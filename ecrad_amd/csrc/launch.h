@@ -37,6 +37,8 @@ hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block, int* counter,
                         const DevCkdModel& m, int g0);
 // dst(col, l) = sum over chunks of partial profiles (chunk order), columns istartcol..iendcol
+hipError_t launch_spectral_profile_sum(hipStream_t st, const DevInputs& in, const double* per_g, double* dst, int ng, int nspec,
+                                       const int32_t* ispec);
 hipError_t launch_combine_derivatives(hipStream_t st, const DevInputs& in, double* dst, const double* a, const double* b,
                                       size_t chunk_stride, int nchunk, const double* cloud_cover, double threshold);
 hipError_t launch_combine_partials(hipStream_t st, const DevInputs& in, double* dst, const double* partial, size_t chunk_stride, int nchunk);

@@ -65,6 +65,13 @@ CASES = {
                                       gas_optics_sw_override_file_name="ecckd-1.4_sw_climate_vfine-96b_ckd-definition.nc"),
     "sw96_cloudless_per_band": dict(sw_solver="Cloudless", do_cloud_aerosol_per_sw_g_point=False,
                                     gas_optics_sw_override_file_name="ecckd-1.4_sw_climate_vfine-96b_ckd-definition.nc"),
+    # spectral flux profiles per band (several g-points per interval): summed from per-g temporaries
+    "tripleclouds_spectral_bands": dict(sw_solver="Tripleclouds", do_save_spectral_flux=True,
+                                        do_cloud_aerosol_per_sw_g_point=False, do_cloud_aerosol_per_lw_g_point=False),
+    "homogeneous_spectral_bands_lw_scat": dict(sw_solver="Homogeneous", do_save_spectral_flux=True, do_lw_aerosol_scattering=True,
+                                               do_cloud_aerosol_per_sw_g_point=False, do_cloud_aerosol_per_lw_g_point=False),
+    "cloudless_spectral_bands_sw96": dict(sw_solver="Cloudless", do_save_spectral_flux=True, do_cloud_aerosol_per_sw_g_point=False,
+                                          gas_optics_sw_override_file_name="ecckd-1.4_sw_climate_vfine-96b_ckd-definition.nc"),
     "mixed_solvers": dict(sw_solver="Tripleclouds", lw_solver="McICA"),
     "per_band_cloud_aerosol": dict(sw_solver="Tripleclouds", do_cloud_aerosol_per_sw_g_point=False,
                                    do_cloud_aerosol_per_lw_g_point=False),
