@@ -417,7 +417,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
 
 int ecrad_hip_scratch_bytes(ecrad_hip_handle_t h, size_t* bytes) {
   if (!h || !bytes) return ECRAD_EINVAL;
-  *bytes = h->scratch.cap + h->prep.cap + h->staging_in.cap + h->staging_out.cap;
+  *bytes = h->scratch.cap + h->prep.cap + h->staging_in.cap + h->staging_out.cap + h->partial.cap + h->spec_tmp.cap;
   return ECRAD_OK;
 }
 
