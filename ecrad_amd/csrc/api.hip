@@ -662,7 +662,7 @@ int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int ie
   }
   const bool mcica = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_MCICA) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_MCICA);
   if (mcica && !in->iseed) return fail(h, ECRAD_EINVAL, "McICA needs single_level%iseed");
-  if (mcica && nlev > 191) return fail(h, ECRAD_EUNSUPPORTED, "McICA cloud generator supports at most 191 levels");
+  if (mcica && nlev > 255) return fail(h, ECRAD_EUNSUPPORTED, "McICA cloud generator supports at most 255 levels");
   cx.host_mem = in->memory == ECRAD_MEM_HOST;
   cx.r = {ncol, nlev, istartcol, iendcol, iendcol - istartcol + 1};
   DevInputs& d = cx.din;

@@ -238,20 +238,48 @@ constexpr int kLfsrPerLane = (kLfsrSteps + 63) / 64;     // 274
 
 ECRAD_DEV uint32_t lfsr_step(uint32_t s) { return (s & 0x80000000u) ? (((s ^ 87u) << 1) | 1u) : (s << 1); }
 
-// Bit per level (up to 192 levels), wave-uniform; built from ballots
-struct LevBits {
-  unsigned long long w[3];
-  ECRAD_DEV void clear() { w[0] = w[1] = w[2] = 0ull; }
-  ECRAD_DEV bool get(int i) const { return ((i < 64 ? w[0] : (i < 128 ? w[1] : w[2])) >> (i & 63)) & 1ull; }
-  ECRAD_DEV void set(int i) {
-    const unsigned long long b = 1ull << (i & 63);
-    if (i < 64) w[0] |= b; else if (i < 128) w[1] |= b; else w[2] |= b;
+// Bit per level (NW words of 64 levels), wave-uniform; built from ballots
+template <int NW>
+struct LevBitsT {
+  unsigned long long w[NW];
+  ECRAD_DEV void clear() {
+#pragma unroll
+    for (int k = 0; k < NW; ++k) w[k] = 0ull;
+  }
+  ECRAD_DEV unsigned long long word(int k) const {
+    unsigned long long v = w[0];
+#pragma unroll
+    for (int j = 1; j < NW; ++j) v = (k == j) ? w[j] : v;
+    return v;
+  }
+  ECRAD_DEV bool get(int i) const {
+    if constexpr (NW == 3) return ((i < 64 ? w[0] : (i < 128 ? w[1] : w[2])) >> (i & 63)) & 1ull;
+    else return (word(i >> 6) >> (i & 63)) & 1ull;
+  }
+  ECRAD_DEV bool any() const {
+    unsigned long long v = 0ull;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) v |= w[k];
+    return v != 0ull;
+  }
+  // lowest / highest set position (call only if any())
+  ECRAD_DEV int first() const {
+    if constexpr (NW == 3) return w[0] ? __ffsll((long long)w[0]) - 1 : (w[1] ? 63 + __ffsll((long long)w[1]) : 127 + __ffsll((long long)w[2]));
+#pragma unroll
+    for (int k = 0; k < NW; ++k) if (w[k]) return 64 * k + __ffsll((long long)w[k]) - 1;
+    return -1;
+  }
+  ECRAD_DEV int last() const {
+    if constexpr (NW == 3) return w[2] ? 191 - __clzll(w[2]) : (w[1] ? 127 - __clzll(w[1]) : 63 - __clzll(w[0]));
+#pragma unroll
+    for (int k = NW - 1; k >= 0; --k) if (w[k]) return 64 * k + 63 - __clzll(w[k]);
+    return -1;
   }
   // number of set bits at positions < i
   ECRAD_DEV int count_below(int i) const {
     int c = 0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < NW; ++k) {
       const int lo = 64 * k;
       if (i >= lo + 64) c += __popcll(w[k]);
       else if (i > lo) c += __popcll(w[k] & ((1ull << (i - lo)) - 1ull));
@@ -261,7 +289,7 @@ struct LevBits {
   // highest position <= i holding a ZERO bit (-1 if none)
   ECRAD_DEV int highest_zero_le(int i) const {
 #pragma unroll
-    for (int k = 2; k >= 0; --k) {
+    for (int k = NW - 1; k >= 0; --k) {
       const int lo = 64 * k;
       if (i < lo) continue;
       const int top = (i - lo >= 63) ? 63 : i - lo;
@@ -270,17 +298,17 @@ struct LevBits {
     }
     return -1;
   }
-  // lowest position >= i holding a ZERO bit (192 if none)
+  // lowest position >= i holding a ZERO bit (64*NW if none)
   ECRAD_DEV int lowest_zero_ge(int i) const {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < NW; ++k) {
       const int lo = 64 * k;
       if (i >= lo + 64) continue;
       const int bot = i > lo ? i - lo : 0;
       const unsigned long long z = ~w[k] & (~0ull << bot);
       if (z) return lo + __ffsll((long long)z) - 1;
     }
-    return 192;
+    return 64 * NW;
   }
 };
 
@@ -401,6 +429,8 @@ ECRAD_DEV void gen_draw(const GenLds& g, int lane, int& iused, int n, double* ds
   wave_sync();
 }
 
+// NW: 64-level words in the level masks (3 up to 191 levels, 4 up to 255)
+template <int NW>
 __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, int ng,
                                                              int seed_offset, double* od_scaling, double* total_cloud_cover) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -409,6 +439,7 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
   const int nloc = in.iendcol - in.istartcol + 1;
   const int nlev = in.nlev;
   const size_t ncol = in.ncol;
+  using LevBits = LevBitsT<NW>;
   const GenLds g = gen_lds(smem, nlev, ng);
   const double MaxCloudFrac = 1.0 - 2.220446049250313e-16 * 10.0;
   const bool exp_exp = cfg.i_overlap_scheme == ECRAD_OVERLAP_EXP_EXP;
@@ -458,14 +489,11 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
     {
       LevBits cl;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 0; k < NW; ++k) {
         const int i = lane + 64 * k;
         cl.w[k] = __ballot(i < nlev && g.frac[i] > 0.0);
       }
-      if ((cl.w[0] | cl.w[1] | cl.w[2]) != 0ull) {
-        ibegin = (cl.w[0] ? __ffsll((long long)cl.w[0]) : (cl.w[1] ? 64 + __ffsll((long long)cl.w[1]) : 128 + __ffsll((long long)cl.w[2])));
-        iend = (cl.w[2] ? 192 - __clzll(cl.w[2]) : (cl.w[1] ? 128 - __clzll(cl.w[1]) : 64 - __clzll(cl.w[0])));
-      }
+      if (cl.any()) { ibegin = cl.first() + 1; iend = cl.last() + 1; }
     }
     if (ibegin == 0) {       // no cloud at all: total cloud cover 0
       if (lane == 0) total_cloud_cover[cloc] = 0.0;
@@ -546,23 +574,23 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
     // rand_top(1:ng) is ONE batch request in the reference (radiation_cloud_generator.F90:206)
     gen_draw(g, lane, iused, ng, g.rtop);
     double* odsc = od_scaling + (size_t)ng * nlev * cloc;
-    PdfPending pend[3];
-    double* pend_dst[3] = {nullptr, nullptr, nullptr};
-    bool pend_on[3] = {false, false, false};
+    PdfPending pend[NW];
+    double* pend_dst[NW];
+    bool pend_on[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { pend_dst[k] = nullptr; pend_on[k] = false; }
     for (int jg = 0; jg < ng; ++jg) {
       const double trigger = g.rtop[jg] * tcc;
       // first level from ibegin whose cumulative cover reaches the trigger (iend at the latest)
       int ti = iend - 1;
       {
-        unsigned long long stop[3];
+        LevBits stop;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < NW; ++k) {
           const int i = lane + 64 * k;
-          stop[k] = __ballot(i >= ibegin - 1 && i < iend - 1 && !(trigger > g.cum[i]));
+          stop.w[k] = __ballot(i >= ibegin - 1 && i < iend - 1 && !(trigger > g.cum[i]));
         }
-        if (stop[0]) ti = __ffsll((long long)stop[0]) - 1;
-        else if (stop[1]) ti = 64 + __ffsll((long long)stop[1]) - 1;
-        else if (stop[2]) ti = 128 + __ffsll((long long)stop[2]) - 1;
+        if (stop.any()) ti = stop.first();
       }
       const int ei = iend - 1;          // 0-based first (ti) and last (ei) cloudy level of this sub-column
       ECRAD_LAP0(tm, 3);    // trigger search
@@ -575,7 +603,7 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
       ECRAD_LAP0(tm, 4);    // draw rand_cloud
       LevBits A, B;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 0; k < NW; ++k) {
         const int i = lane + 64 * k;
         bool a = false, b = false;
         if (i > ti && i <= ei) {
@@ -596,7 +624,7 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
       {
         unsigned long long carry = ~0ull;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < NW; ++k) {
           const int lo = 64 * k;
           if (ei < lo || ti > lo + 63) continue;
           const int first = ti > lo ? ti - lo : 0, last = ei < lo + 63 ? ei - lo : 63;
@@ -621,16 +649,16 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
       // every cloudy run draws rand_inhom1(1:n) then rand_inhom2(1:n) (radiation_cloud_generator.F90:
       // 343-345), runs in top-down order: 2 x (number of cloudy levels) consecutive numbers in all
       // Exp-Exp (generate_column_exp_exp, :396-508) draws for ALL layers itrigger..iend as one run
-      const int ncloudy = exp_exp ? ei + 1 - ti : C.count_below(192);
+      const int ncloudy = exp_exp ? ei + 1 - ti : C.count_below(64 * NW);
       ECRAD_LAP0(tm, 5);    // tests + run structure
       gen_draw(g, lane, iused, 2 * ncloudy, g.ri);
       ECRAD_LAP0(tm, 6);    // draw rand_inhom
       // "keep the value of the layer above" flags (:350-357), then each level takes rand_inhom1 of the
       // nearest level at or above it in its run whose flag is clear
       LevBits K;
-      int run_start[3], run_base[3];
+      int run_start[NW], run_base[NW];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 0; k < NW; ++k) {
         const int i = lane + 64 * k;
         bool keep = false;
         run_start[k] = 0; run_base[k] = 0;
@@ -653,7 +681,7 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
       // The table look-ups of this g-point are requested here and finished (interpolated and stored)
       // while the next g-point's random numbers are being drawn
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 0; k < NW; ++k) {
         const int i = lane + 64 * k;
         if (pend_on[k]) pend_dst[k][0] = pdf_finish(pend[k]);
         pend_on[k] = false;
@@ -669,7 +697,7 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
       ECRAD_LAP0(tm, 7);    // flags, sampling, stores
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < NW; ++k)
       if (pend_on[k]) pend_dst[k][0] = pdf_finish(pend[k]);
   }
 #ifdef ECRAD_TIMING
@@ -862,7 +890,8 @@ hipError_t launch_mcica_generator(hipStream_t st, const DevConfig* cfg, const De
   const int nloc = in.iendcol - in.istartcol + 1;
   const size_t lds = mcica_generator_lds_bytes(in.nlev, ng);
   const int grid = nloc < 256 * 32 ? nloc : 256 * 32;
-  hipLaunchKernelGGL(mcica_generator_kernel, dim3(grid), dim3(64), lds, st, cfg, in, ng, seed_offset, od_scaling, tcc);
+  if (in.nlev <= 191) hipLaunchKernelGGL(mcica_generator_kernel<3>, dim3(grid), dim3(64), lds, st, cfg, in, ng, seed_offset, od_scaling, tcc);
+  else hipLaunchKernelGGL(mcica_generator_kernel<4>, dim3(grid), dim3(64), lds, st, cfg, in, ng, seed_offset, od_scaling, tcc);
   return hipGetLastError();
 }
 

@@ -83,6 +83,12 @@ BENCH_CONFIGS = {
     # north-star target configuration: ecCKD-32 Tripleclouds with clouds and aerosols
     "tripleclouds_ecckd32": dict(sw_solver="Tripleclouds", use_aerosols=True, clear_sky=False),
     "mcica_ecckd32": dict(sw_solver="McICA", use_aerosols=True, clear_sky=False),
+    # BASELINE configs[3] shape on one GPU: Tripleclouds with the 64-term SW model (LW-64 is a missing blob upstream)
+    "tripleclouds_ecckd64": dict(sw_solver="Tripleclouds", use_aerosols=True, clear_sky=False,
+                                 gas_optics_sw_override_file_name="ecckd-1.2_sw_climate_window-64b_ckd-definition.nc"),
+    # the 96-term SW model: three launches of 32 g-points
+    "tripleclouds_ecckd96": dict(sw_solver="Tripleclouds", use_aerosols=True, clear_sky=False,
+                                 gas_optics_sw_override_file_name="ecckd-1.4_sw_climate_vfine-96b_ckd-definition.nc"),
     # attribution variants (not bench lines): the same without aerosols / without clouds
     "tripleclouds_noaer": dict(sw_solver="Tripleclouds", use_aerosols=False, clear_sky=False),
     "tripleclouds_clear_aer": dict(sw_solver="Tripleclouds", use_aerosols=True, clear_sky=True),

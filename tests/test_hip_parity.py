@@ -307,6 +307,49 @@ def test_wide_longwave_spectrum(case, tmp_path, oracle_lib):
         assert rel_err(f_ora.arrays[name], f_32.arrays[name]) < 1e-5 or solver == "McICA", name
 
 
+def _split_lowest_layers(inputs, nsplit):
+    """The same columns with each of the lowest `nsplit` layers split into two equal-mass halves (same
+    composition, maximum overlap across the new interface): more levels than the reference's test case has."""
+    ncol, nlev, sl, th, gas, cloud, aer = inputs
+    k0 = nlev - nsplit
+    rep = np.concatenate([np.arange(k0), np.repeat(np.arange(k0, nlev), 2)])        # layer index of every new layer
+    def half(a):        # half-level array (nlev+1, ncol) -> with mid-points inserted below k0
+        out = [a[i] for i in range(k0 + 1)]
+        for i in range(k0, nlev):
+            out.append(0.5 * (a[i] + a[i + 1]))
+            out.append(a[i + 1])
+        return np.ascontiguousarray(np.stack(out))
+    th.pressure_hl, th.temperature_hl = half(th.pressure_hl), half(th.temperature_hl)
+    th.h2o_sat_liq = None
+    lay = lambda a: np.ascontiguousarray(a[..., rep, :])
+    gas.mixing_ratio = lay(gas.mixing_ratio)
+    cloud.fraction, cloud.mixing_ratio = lay(cloud.fraction), lay(cloud.mixing_ratio)
+    cloud.effective_radius, cloud.fractional_std = lay(cloud.effective_radius), lay(cloud.fractional_std)
+    ov = [cloud.overlap_param[i] for i in range(k0)]          # interfaces above layer k0 unchanged
+    for i in range(k0, nlev):
+        ov.append(np.ones_like(cloud.overlap_param[0]))       # inside the split layer
+        if i < nlev - 1:
+            ov.append(cloud.overlap_param[i])                 # the original interface below it
+    cloud.overlap_param = np.ascontiguousarray(np.stack(ov))
+    n2 = nlev + nsplit
+    if aer is not None and aer.mixing_ratio is not None and aer.mixing_ratio.size:
+        aer.mixing_ratio = lay(aer.mixing_ratio)
+        aer.istartlev, aer.iendlev = 1, n2
+    return ncol, n2, sl, th, gas, cloud, aer
+
+
+@pytest.mark.parametrize("solver", ["McICA", "Tripleclouds"])
+def test_more_than_191_levels(solver, oracle_lib):
+    """217 levels: the McICA generator's level masks take four 64-bit words, the other kernels' per-lane
+    level masks 256 bits."""
+    mk = lambda: _split_lowest_layers(load_meridian(make_config(solver)), 80)
+    assert mk()[1] == 217 and mk()[5].overlap_param.shape[0] == 216
+    f_hip, _, rad = run_case(make_config(solver), "hip", inputs=mk())
+    rad.close()
+    f_ora, _, _ = run_case(make_config(solver), oracle_lib.backend, inputs=mk())
+    compare_flux(f_hip, f_ora, TOL)
+
+
 def test_crop_cloud_fraction_side_effect_matches(oracle_lib):
     c1, c2 = make_config("Tripleclouds"), make_config("Tripleclouds")
     in1, in2 = load_meridian(c1), load_meridian(c2)
