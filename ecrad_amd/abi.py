@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 NMAXGASES = 12
 NMAXCLOUDTYPES = 12
 
@@ -69,6 +69,25 @@ class PdfSampler(C.Structure):
     ]
 
 
+class RrtmgBand(C.Structure):
+    _fields_ = [
+        ("ng", C.c_int32), ("ld", C.c_int32), ("nspa", C.c_int32), ("nspb", C.c_int32),
+        ("layreffr", C.c_int32), ("n_forref", C.c_int32),
+        ("strrat", C.c_double), ("rayl", C.c_double), ("factor", C.c_double),
+        ("absa", c_double_p), ("absb", c_double_p), ("selfref", c_double_p), ("forref", c_double_p),
+        ("fracrefa", c_double_p), ("fracrefb", c_double_p),
+        ("minor", c_double_p * 6), ("xsec", c_double_p * 2), ("rayl_g", c_double_p * 2),
+    ]
+
+
+class Rrtmg(C.Structure):
+    _fields_ = [
+        ("chi_mls", c_double_p), ("preflog_lw", c_double_p), ("tref_lw", c_double_p),
+        ("preflog_sw", c_double_p), ("tref_sw", c_double_p), ("totplnk", c_double_p), ("delwave", c_double_p),
+        ("lw", RrtmgBand * 16), ("sw", RrtmgBand * 14),
+    ]
+
+
 _CONFIG_INTS = [
     "abi_version",
     "do_sw", "do_lw", "do_clear", "do_sw_direct", "do_lw_derivatives",
@@ -106,7 +125,8 @@ class Config(C.Structure):
            ("cloud_optics_sw", CloudOptics * NMAXCLOUDTYPES),
            ("cloud_optics_lw", CloudOptics * NMAXCLOUDTYPES),
            ("aerosol_optics", AerosolOptics),
-           ("pdf_sampler", PdfSampler)]
+           ("pdf_sampler", PdfSampler),
+           ("rrtmg", C.POINTER(Rrtmg)), ("min_gas_od_lw", C.c_double), ("min_gas_od_sw", C.c_double)]
     )
 
 
@@ -161,7 +181,8 @@ class Optics(C.Structure):
     _fields_ = [("memory", C.c_int32), ("reserved_", C.c_int32)] + [(n, c_double_p) for n in OPTICS_FIELDS]
 
 
-STRUCT_BY_INDEX = [Config, Inputs, Flux, Optics, CkdModel, CkdGas, CloudOptics, AerosolOptics, PdfSampler]
+STRUCT_BY_INDEX = [Config, Inputs, Flux, Optics, CkdModel, CkdGas, CloudOptics, AerosolOptics, PdfSampler,
+                   Rrtmg, RrtmgBand]
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -107,6 +107,21 @@ struct DevConfig {
   const uint32_t* lfsr_jump;   // 64 x 32 rows: the seeding shift register advanced by k*274 steps (kernel_prep.hip)
 };
 
+// Stage-interface arrays produced by a separate gas-optics pass (RRTMG, kernel_rrtmg.hip) and read by the
+// solver kernels instead of computing ecCKD gas optics in line; all NULL with ecCKD.
+// (ng, nlev[+1], ncol_local) / (ng, ncol_local), g fastest; lw_emission is the surface Planck term BEFORE the
+// (1 - albedo) factor; levels top-down.
+struct DevGasStage {
+  double *od_lw, *planck_hl, *lw_emission, *od_sw, *ssa_sw, *incoming_sw;
+};
+
+// Work arrays of the RRTMG pass: per-(column, level) interpolation records, [field][level][local column]
+struct RrtmgWork {
+  double *lw_d, *sw_d;
+  int *lw_i, *sw_i;
+  int* isol;      // [shortwave band][local column]: layer of the solar source term, -1 if none
+};
+
 // Input arrays on the device (same layouts as ecrad_inputs_t)
 struct DevInputs {
   int32_t ncol, nlev, istartcol, iendcol;      // 1-based inclusive range as in the reference
@@ -128,6 +143,7 @@ struct DevInputs {
   // In that case crop_cloud_fraction writes here ([level][local column], caller's level order) instead
   // of the caller's array: the reference crops a reversed COPY, so cloud%fraction is left untouched.
   double* cloud_fraction_work;
+  DevGasStage gs;
 };
 
 // Output arrays on the device (same layouts as ecrad_flux_t); NULL = not wanted

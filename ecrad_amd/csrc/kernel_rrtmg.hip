@@ -1,0 +1,207 @@
+// kernel_rrtmg.hip -- RRTMG gas optics on the device:
+//   gas_optics            radiation/radiation_ifs_rrtm.F90:216-613
+//   planck_function_*     radiation/radiation_ifs_rrtm.F90:618-852
+//   RRTM_PREPARE_GASES, RRTM_SETCOEF_140GP, SRTM_SETCOEF, RRTM_TAUMOL1-16, SRTM_TAUMOL16-29 (ifsrrtm/)
+// The physics lives in rrtmg_device.h (descriptor-driven, one evaluator per spectrum); this file maps it to
+// the GPU in three kernels:
+//   rrtmg_setcoef_kernel   lane = column (the caller's arrays are column-fastest: coalesced), levels in
+//                          sequence from the surface: per-layer interpolation records, the tropopause
+//                          counts and, per shortwave band, the level of the solar source term;
+//   rrtmg_taumol_kernel    block = (one level, 64 columns); the 30 bands in turn, lanes = (g-point of the
+//                          band, column) so that a wave always runs ONE descriptor (no divergence); writes
+//                          the stage-interface arrays od_lw, planck_hl, lw_emission, od_sw, ssa_sw and the
+//                          un-normalised incoming_sw, g fastest, for the solver kernels to read;
+//   rrtmg_incoming_kernel  normalises incoming_sw to the solar irradiance (radiation_ifs_rrtm.F90:552-560).
+// Levels are handled top-down (layer 0 = top) whatever the caller's order (LevelOrder); the reference's
+// routines count from the surface, k = nlev - layer.
+#include "kernels_common.h"
+#include "rrtmg_device.h"
+#include "launch.h"
+
+namespace ecrad {
+
+using namespace rrtmg;
+
+struct RecView {
+  const double* d_;
+  const int* i_;
+  size_t stride, off;
+  ECRAD_DEV double d(int f) const { return d_[(size_t)f * stride + off]; }
+  ECRAD_DEV int i(int f) const { return i_[(size_t)f * stride + off]; }
+};
+
+__global__ __launch_bounds__(kBlock) void rrtmg_setcoef_kernel(const DevRrtmg* __restrict__ Tp, DevInputs in, RrtmgWork w, int do_lw, int do_sw) {
+  const DevRrtmg& T = *Tp;
+  const int nloc = in.iendcol - in.istartcol + 1, nlev = in.nlev;
+  const int cloc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cloc >= nloc) return;
+  const int col = in.istartcol - 1 + cloc;
+  const size_t ncol = in.ncol;
+  const LevelOrder ord = level_order(in);
+  const size_t stride = (size_t)nlev * nloc;
+  const bool sunlit = do_sw && in.cos_sza[col] > 0.0;
+  int laytrop_lw = 0, laytrop_sw = 0;
+  auto gasmr = [&](int code, int clev) { return in.gas_mixing_ratio[col + ncol * (clev + (size_t)nlev * (code - 1))]; };
+  for (int k = 1; k <= nlev; ++k) {
+    const int lev = nlev - k;
+    const int clev = ord.full(lev);
+    LayerIn li;
+    li.p_top = in.pressure_hl[col + ncol * ord.half(lev)];
+    li.p_bot = in.pressure_hl[col + ncol * ord.half(lev + 1)];
+    li.t_top = in.temperature_hl[col + ncol * ord.half(lev)];
+    li.t_bot = in.temperature_hl[col + ncol * ord.half(lev + 1)];
+    li.q = gasmr(ECRAD_IH2O, clev); li.co2 = gasmr(ECRAD_ICO2, clev); li.o3 = gasmr(ECRAD_IO3, clev);
+    li.n2o = gasmr(ECRAD_IN2O, clev); li.ch4 = gasmr(ECRAD_ICH4, clev);
+    li.cfc11 = gasmr(ECRAD_ICFC11, clev); li.cfc12 = gasmr(ECRAD_ICFC12, clev);
+    li.hcfc22 = gasmr(ECRAD_IHCFC22, clev); li.ccl4 = gasmr(ECRAD_ICCL4, clev);
+    const Prepared p = prepare_layer(li);
+    const size_t off = (size_t)lev * nloc + cloc;
+    if (do_lw) {
+      const bool lower = log(p.pavel) > 4.56;
+      if (lower) laytrop_lw++;
+      LwLevel r;
+      setcoef_lw(T, p, lower, r);
+      for (int f = 0; f < LD_N; ++f) w.lw_d[(size_t)f * stride + off] = r.d[f];
+      for (int f = 0; f < LI_N; ++f) w.lw_i[(size_t)f * stride + off] = r.i[f];
+    }
+    if (sunlit) {
+      SwLevel r;
+      setcoef_sw(T, p, r);
+      if (r.i[SI_LOWER]) laytrop_sw++;
+      for (int f = 0; f < SD_N; ++f) w.sw_d[(size_t)f * stride + off] = r.d[f];
+      for (int f = 0; f < SI_N; ++f) w.sw_i[(size_t)f * stride + off] = r.i[f];
+    }
+  }
+  // "lower atmosphere" as the band routines decide it: the first laytrop layers from the surface
+  for (int k = 1; k <= nlev; ++k) {
+    const size_t off = (size_t)(nlev - k) * nloc + cloc;
+    if (do_lw) w.lw_i[(size_t)LI_LOWER * stride + off] = k <= laytrop_lw ? 1 : 0;
+    if (sunlit) w.sw_i[(size_t)SI_LOWER * stride + off] = k <= laytrop_sw ? 1 : 0;
+  }
+  if (do_sw) {
+    const int* jpa = w.sw_i + (size_t)SI_JP * stride + cloc;
+    auto jp = [&](int k) { return jpa[(size_t)(nlev - k) * nloc]; };
+    for (int ib = 0; ib < kNBandSw; ++ib) {
+      int lev = -1;
+      if (sunlit) {
+        const int k = solar_source_level(T.sw[ib], nlev, laytrop_sw, jp);
+        if (k > 0) lev = nlev - k;
+      }
+      w.isol[(size_t)ib * nloc + cloc] = lev;
+    }
+  }
+}
+
+constexpr int kTileCols = 64;
+
+__global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __restrict__ Tp, DevInputs in, RrtmgWork w, DevGasStage out,
+                                                              int do_lw, int do_sw) {
+  const DevRrtmg& T = *Tp;
+  const int nloc = in.iendcol - in.istartcol + 1, nlev = in.nlev;
+  const int lev = blockIdx.y;
+  const int c0 = blockIdx.x * kTileCols;
+  const size_t ncol = in.ncol;
+  const size_t stride = (size_t)nlev * nloc;
+  const LevelOrder ord = level_order(in);
+  const int tid = threadIdx.x;
+  if (do_lw) {
+    for (int ib = 0; ib < kNBandLw; ++ib) {
+      const LwBand& B = T.lw[ib];
+      const int ng = B.ng;
+      const int nbp = ng <= 2 ? 2 : (ng <= 4 ? 4 : (ng <= 8 ? 8 : 16));
+      const int items = nbp * kTileCols;
+      for (int i = tid; i < items; i += kBlock) {
+        const int ig = i & (nbp - 1), cloc = c0 + i / nbp;
+        if (ig >= ng || cloc >= nloc) continue;
+        const int col = in.istartcol - 1 + cloc;
+        const RecView r{w.lw_d, w.lw_i, stride, (size_t)lev * nloc + cloc};
+        double tau, pfrac;
+        lw_gpoint(T, B, r, ig, tau, pfrac);
+        const int g = B.g0 + ig;
+        out.od_lw[g + (size_t)kNgLw * (lev + (size_t)nlev * cloc)] = dmax(T.min_gas_od_lw, tau);
+        // planck_hl(g, half level) = band Planck function at the half level x fraction of the layer ABOVE it
+        // (of the top layer for the top half level): radiation_ifs_rrtm.F90:715-724
+        const size_t op = g + (size_t)kNgLw * (lev + (size_t)(nlev + 1) * cloc);
+        out.planck_hl[op + kNgLw] = planck_band(T, in.temperature_hl[col + ncol * ord.half(lev + 1)], ib) * pfrac;
+        if (lev == 0) out.planck_hl[op] = planck_band(T, in.temperature_hl[col + ncol * ord.half(0)], ib) * pfrac;
+        // surface emission before the (1 - albedo) factor: planck_function_surf with the lowest layer's fractions
+        if (lev == nlev - 1) out.lw_emission[g + (size_t)kNgLw * cloc] = planck_band(T, in.skin_temperature[col], ib) * pfrac;
+      }
+    }
+  }
+  if (do_sw) {
+    for (int ib = 0; ib < kNBandSw; ++ib) {
+      const SwBand& B = T.sw[ib];
+      const int ng = B.ng;
+      const int nbp = ng <= 2 ? 2 : (ng <= 4 ? 4 : (ng <= 8 ? 8 : 16));
+      const int items = nbp * kTileCols;
+      for (int i = tid; i < items; i += kBlock) {
+        const int ig = i & (nbp - 1), cloc = c0 + i / nbp;
+        if (ig >= ng || cloc >= nloc) continue;
+        const int col = in.istartcol - 1 + cloc;
+        const int g = B.g0 + ig;
+        const size_t o = g + (size_t)kNgSw * (lev + (size_t)nlev * cloc);
+        if (in.cos_sza[col] > 0.0) {
+          const RecView r{w.sw_d, w.sw_i, stride, (size_t)lev * nloc + cloc};
+          const bool want = w.isol[(size_t)ib * nloc + cloc] == lev;
+          double taug, taur, sflux = 0.0;
+          sw_gpoint(T, B, r, ig, want, taug, taur, sflux);
+          const double od = taur + taug;
+          out.od_sw[o] = dmax(T.min_gas_od_sw, od);
+          out.ssa_sw[o] = taur / od;
+          if (want) out.incoming_sw[g + (size_t)kNgSw * cloc] = sflux;
+        } else {
+          out.od_sw[o] = dmax(T.min_gas_od_sw, 0.0);
+          out.ssa_sw[o] = 0.0;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void rrtmg_incoming_kernel(DevInputs in, DevGasStage out) {
+  const int nloc = in.iendcol - in.istartcol + 1;
+  const int cloc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cloc >= nloc) return;
+  const int col = in.istartcol - 1 + cloc;
+  double* inc = out.incoming_sw + (size_t)kNgSw * cloc;
+  if (in.cos_sza[col] > 0.0) {
+    double sum = 0.0;
+    for (int g = 0; g < kNgSw; ++g) sum = sum + inc[g];
+    const double scale = in.solar_irradiance / sum;
+    for (int g = 0; g < kNgSw; ++g) inc[g] = scale * inc[g];
+  }
+}
+
+size_t rrtmg_work_bytes(int nlev, int nloc) {
+  const size_t n = (size_t)nlev * nloc;
+  return n * (LD_N + SD_N) * 8 + n * (LI_N + SI_N) * 4 + (size_t)kNBandSw * nloc * 4 + 1024;
+}
+
+RrtmgWork rrtmg_carve_work(void* base, int nlev, int nloc) {
+  const size_t n = (size_t)nlev * nloc;
+  RrtmgWork w;
+  char* p = reinterpret_cast<char*>(base);
+  w.lw_d = reinterpret_cast<double*>(p); p += n * LD_N * 8;
+  w.sw_d = reinterpret_cast<double*>(p); p += n * SD_N * 8;
+  w.lw_i = reinterpret_cast<int*>(p); p += n * LI_N * 4;
+  w.sw_i = reinterpret_cast<int*>(p); p += n * SI_N * 4;
+  w.isol = reinterpret_cast<int*>(p);
+  return w;
+}
+
+hipError_t launch_rrtmg_gas_optics(hipStream_t st, const DevRrtmg* tables, const DevInputs& in, const RrtmgWork& w, const DevGasStage& out,
+                                   bool do_lw, bool do_sw) {
+  const int nloc = in.iendcol - in.istartcol + 1, nlev = in.nlev;
+  if (do_sw) {
+    hipError_t e = hipMemsetAsync(out.incoming_sw, 0, (size_t)kNgSw * nloc * sizeof(double), st);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(rrtmg_setcoef_kernel, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, st, tables, in, w, do_lw ? 1 : 0, do_sw ? 1 : 0);
+  hipLaunchKernelGGL(rrtmg_taumol_kernel, dim3((nloc + kTileCols - 1) / kTileCols, nlev), dim3(kBlock), 0, st, tables, in, w, out,
+                     do_lw ? 1 : 0, do_sw ? 1 : 0);
+  if (do_sw) hipLaunchKernelGGL(rrtmg_incoming_kernel, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, st, in, out);
+  return hipGetLastError();
+}
+
+}  // namespace ecrad

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ECRAD_ABI_VERSION 2
+#define ECRAD_ABI_VERSION 3
 
 /* Status codes */
 #define ECRAD_OK            0
@@ -102,6 +102,44 @@ typedef struct ecrad_ckd_model {
   const double* rayleigh_molar_scat;             /* (ng)  SW */
   ecrad_ckd_gas_t single_gas[ECRAD_NMAXGASES];
 } ecrad_ckd_model_t;
+
+/* ---- RRTMG gas optics: the tables of ifsrrtm/yoerrta1-16.F90 and yoesrta16-29.F90 after RRTM_INIT_140GP /
+   SRTM_INIT (radiation_ifs_rrtm.F90:89-99), one struct per band.  A Fortran host passes c_loc() of the
+   module arrays; they are copied to the device by ecrad_hip_setup.  Arrays are in the modules' own
+   layout.  `ld` is the extent of their g-point dimension (= ng in yoerrta*, 16 in yoesrta*).
+   Band-specific arrays (NULL where a band has none):
+     longwave  minor[0..2] lower atmosphere, minor[3..5] upper atmosphere:
+       1: KA_MN2 | KB_MN2      3: KA_MN2O | KB_MN2O     5: KA_MO3            6: KA_MCO2
+       7: KA_MCO2 | KB_MCO2    8: KA_MCO2, KA_MO3, KA_MN2O | KB_MCO2, KB_MN2O
+       9: KA_MN2O | KB_MN2O   11: KA_MO2 | KB_MO2      13: KA_MCO2 | KB_MO3  15: KA_MN2
+     longwave  xsec:  5: CCL4      6: CFC11ADJ, CFC12      8: CFC12, CFC22ADJ
+     shortwave fracrefa = SFLUXREFC;  xsec: 20: ABSCH4C   24, 25: ABSO3AC, ABSO3BC   29: ABSH2OC, ABSCO2C
+     shortwave rayl_g:  23, 25, 26, 27: RAYLC     24: RAYLAC, RAYLBC
+     shortwave scalars: strrat = STRRAT (STRRAT1 in band 16), rayl = RAYL, factor = GIVFAC (23) / SCALEKUR (27) */
+typedef struct ecrad_rrtmg_band {
+  int32_t ng;                 /* g-points of the band: NGn (yoerrta*), NGC (yoesrtwn) */
+  int32_t ld;
+  int32_t nspa, nspb;         /* yoerrtwn / yoesrtwn NSPA, NSPB */
+  int32_t layreffr;           /* shortwave */
+  int32_t n_forref;           /* rows of FORREF / FORREFC: 4 longwave, 3 or 4 shortwave */
+  double  strrat, rayl, factor;
+  const double *absa, *absb;            /* (65*nspa, ld), (235*nspb, ld) */
+  const double *selfref, *forref;       /* (10, ld), (n_forref, ld) */
+  const double *fracrefa, *fracrefb;    /* longwave (ng[,9]), (ng[,5]); shortwave SFLUXREFC (ld[,9|5]) in fracrefa */
+  const double *minor[6];
+  const double *xsec[2];
+  const double *rayl_g[2];
+} ecrad_rrtmg_band_t;
+
+typedef struct ecrad_rrtmg {
+  const double* chi_mls;                /* yoerrtrf CHI_MLS(7,59) */
+  const double *preflog_lw, *tref_lw;   /* yoerrtrf PREFLOG, TREF (59) */
+  const double *preflog_sw, *tref_sw;   /* yoesrtwn PREFLOG, TREF (59) */
+  const double* totplnk;                /* yoerrtwn TOTPLNK(181,16) */
+  const double* delwave;                /* yoerrtwn DELWAVE(16) */
+  ecrad_rrtmg_band_t lw[16];
+  ecrad_rrtmg_band_t sw[14];            /* bands 16-29 */
+} ecrad_rrtmg_t;
 
 /* ---- general_cloud_optics_type, radiation_general_cloud_optics_data.F90:31-62 --------------- */
 typedef struct ecrad_cloud_optics {
@@ -183,6 +221,10 @@ typedef struct ecrad_config {
   ecrad_cloud_optics_t   cloud_optics_lw[ECRAD_NMAXCLOUDTYPES];
   ecrad_aerosol_optics_t aerosol_optics;
   ecrad_pdf_sampler_t    pdf_sampler;
+  /* RRTMG (i_gas_model_* == ECRAD_GAS_IFSRRTMG): gas%mixing_ratio is then MASS mixing ratio
+     (radiation_ifs_rrtm.F90:208) and gas_optics_sw/lw are not read */
+  const ecrad_rrtmg_t*   rrtmg;
+  double min_gas_od_lw, min_gas_od_sw;   /* radiation_config.F90:244-245 */
 } ecrad_config_t;
 
 /* ---- single_level_type + thermodynamics_type + gas_type + cloud_type + aerosol_type --------- */
@@ -211,7 +253,7 @@ typedef struct ecrad_inputs {
   const double* lw_emissivity;    /* (ncol,n_lw_emissivity) */
   const int32_t* iseed;           /* (ncol) McICA only */
   /* gas: mixing_ratio(ncol,nlev,ECRAD_NMAXGASES) already in the units the gas model wants
-     (set_gas_units has been called: volume mixing ratio, scale 1, for ecCKD) */
+     (set_gas_units has been called: volume mixing ratio, scale 1, for ecCKD; mass mixing ratio for RRTMG) */
   const double* gas_mixing_ratio;
   /* cloud */
   double*       cloud_fraction;   /* (ncol,nlev) INOUT: crop_cloud_fraction side effect (radiation_cloud.F90:700) */
@@ -314,7 +356,8 @@ const char* ecrad_hip_last_error(ecrad_hip_handle_t handle);
 int ecrad_hip_destroy(ecrad_hip_handle_t handle);
 
 /* ABI self-description used by the loaders: sizeof the struct `which` (0 config, 1 inputs,
-   2 flux, 3 optics, 4 ckd_model, 5 ckd_gas, 6 cloud_optics, 7 aerosol_optics, 8 pdf_sampler). */
+   2 flux, 3 optics, 4 ckd_model, 5 ckd_gas, 6 cloud_optics, 7 aerosol_optics, 8 pdf_sampler,
+   9 rrtmg, 10 rrtmg_band). */
 size_t ecrad_hip_abi_sizeof(int which);
 int    ecrad_hip_abi_version(void);
 
