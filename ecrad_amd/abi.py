@@ -126,7 +126,9 @@ class Config(C.Structure):
            ("cloud_optics_lw", CloudOptics * NMAXCLOUDTYPES),
            ("aerosol_optics", AerosolOptics),
            ("pdf_sampler", PdfSampler),
-           ("rrtmg", C.POINTER(Rrtmg)), ("min_gas_od_lw", C.c_double), ("min_gas_od_sw", C.c_double)]
+           ("rrtmg", C.POINTER(Rrtmg)), ("min_gas_od_lw", C.c_double), ("min_gas_od_sw", C.c_double),
+           ("i_liq_model", C.c_int32), ("i_ice_model", C.c_int32),
+           ("do_fu_lw_ice_optics_bug", C.c_int32), ("reserved2_", C.c_int32)]
     )
 
 

@@ -21,6 +21,10 @@ GAS_MODEL_NAMES = ["Monochromatic", "RRTMG-IFS", "ECCKD"]
 IGasModelMonochromatic, IGasModelIFSRRTMG, IGasModelECCKD = range(3)
 OVERLAP_NAMES = ["Max-Ran", "Exp-Ran", "Exp-Exp"]
 IOverlapMaximumRandom, IOverlapExponentialRandom, IOverlapExponential = range(3)
+LIQUID_MODEL_NAMES = ["Monochromatic", "SOCRATES", "Slingo", "Jahangir", "Nielsen"]     # radiation_config.F90:109-116
+ILiquidModelMonochromatic, ILiquidModelSOCRATES, ILiquidModelSlingo = range(3)
+ICE_MODEL_NAMES = ["Monochromatic", "Fu-IFS", "Baran-EXPERIMENTAL", "Baran2016", "Baran2017", "Yi"]   # :124-133
+IIceModelMonochromatic, IIceModelFu, IIceModelBaran = range(3)
 PDF_SHAPE_NAMES = ["Lognormal", "Gamma"]
 IPdfShapeLognormal, IPdfShapeGamma = range(2)
 
@@ -63,6 +67,16 @@ class Config:
     do_sw_delta_scaling_with_gases: bool = False
     i_gas_model_sw: int = IGasModelIFSRRTMG
     i_gas_model_lw: int = IGasModelIFSRRTMG
+    i_liq_model: int = ILiquidModelSOCRATES            # radiation_config.F90:307
+    i_ice_model: int = IIceModelBaran                  # :308
+    do_fu_lw_ice_optics_bug: bool = False
+    min_gas_od_lw: float = 1.0e-15                     # :244-245
+    min_gas_od_sw: float = 0.0
+    liq_optics_override_file_name: str = ""
+    ice_optics_override_file_name: str = ""
+    liq_optics_file_name: str = ""
+    ice_optics_file_name: str = ""
+    rrtmg: object = None                               # RrtmgTables (ecrad_amd/rrtmg.py)
     do_nearest_spectral_sw_albedo: bool = False
     do_nearest_spectral_lw_emiss: bool = False
     sw_albedo_wavelength_bound: List[float] = field(default_factory=list)
@@ -152,7 +166,8 @@ class Config:
             "max_cloud_od", "cloud_mixing_ratio_threshold", "n_aerosol_types", "use_aerosols",
             "do_nearest_spectral_sw_albedo", "do_nearest_spectral_lw_emiss",
             "do_cloud_aerosol_per_lw_g_point", "do_cloud_aerosol_per_sw_g_point",
-            "do_weighted_surface_mapping", "use_spectral_solar_cycle",
+            "do_weighted_surface_mapping", "use_spectral_solar_cycle", "do_fu_lw_ice_optics_bug",
+            "min_gas_od_lw", "min_gas_od_sw", "liq_optics_override_file_name", "ice_optics_override_file_name",
         ]
         for k in simple:
             if k in nml and nml[k] is not None:
@@ -187,6 +202,10 @@ class Config:
         if nml.get("gas_model_name"):
             g = _enum(nml["gas_model_name"], GAS_MODEL_NAMES, "gas_model_name")
             c.i_gas_model_sw = c.i_gas_model_lw = g
+        if nml.get("liquid_model_name"):
+            c.i_liq_model = _enum(nml["liquid_model_name"], LIQUID_MODEL_NAMES, "liquid_model_name")
+        if nml.get("ice_model_name"):
+            c.i_ice_model = _enum(nml["ice_model_name"], ICE_MODEL_NAMES, "ice_model_name")
         if nml.get("sw_gas_model_name"):
             c.i_gas_model_sw = _enum(nml["sw_gas_model_name"], GAS_MODEL_NAMES, "sw_gas_model_name")
         if nml.get("lw_gas_model_name"):
@@ -225,6 +244,12 @@ class Config:
         if self.i_gas_model_lw == IGasModelECCKD:
             self.gas_optics_lw_file_name = self._data_path(
                 self.gas_optics_lw_override_file_name, "ecckd-1.0_lw_climate_fsck-32b_ckd-definition.nc")
+        # radiation_config.F90:1243-1290: optics files of the band-fit cloud schemes
+        if not self.use_general_cloud_optics:
+            if self.i_liq_model != ILiquidModelSOCRATES or self.i_ice_model != IIceModelFu:
+                raise ConfigError("band cloud optics: only liquid_model_name='SOCRATES' with ice_model_name='Fu-IFS' is implemented")
+            self.liq_optics_file_name = self._data_path(self.liq_optics_override_file_name, "socrates_droplet_scattering_rrtm.nc")
+            self.ice_optics_file_name = self._data_path(self.ice_optics_override_file_name, "fu_ice_scattering_rrtm.nc")
         if self.use_spectral_solar_cycle:
             raise ConfigError("use_spectral_solar_cycle is not supported by this build")
         self.aerosol_optics_file_name = self._data_path(

@@ -11,6 +11,7 @@
 
 #include "device_types.h"
 #include "launch.h"
+#include "rrtmg_device.h"
 #include "optics_device.h"
 
 using namespace ecrad;
@@ -52,6 +53,9 @@ struct ecrad_hip_handle_s {
   Buf spec_tmp;                    // per-g spectral flux profiles before that sum
   Buf partial;                     // per-chunk partial broadband profiles
   Buf scratch, prep, staging_in, staging_out, counters;
+  const ecrad::rrtmg::DevRrtmg* d_rrtmg = nullptr;   // RRTMG tables (device), see rrtmg_device.h
+  bool rrtmg_sw = false, rrtmg_lw = false;
+  Buf gas_stage, gas_work;         // stage-interface arrays and work records of the RRTMG gas-optics pass
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipEvent_t evs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries
   double stage_ms[4] = {0, 0, 0, 0};
@@ -226,7 +230,48 @@ int setup_ckd(ecrad_hip_handle_t h, const ecrad_ckd_model_t& m, DevCkdModel& d) 
   return ECRAD_OK;
 }
 
+// With RRTMG the solver kernels read gas optics from the stage arrays (DevGasStage); their in-line ecCKD
+// code then runs on an EMPTY model -- no gases, two-point grids -- whose results are overwritten.
+int setup_stage_model(ecrad_hip_handle_t h, bool is_sw, int ng, DevCkdModel& d) {
+  std::memset(&d, 0, sizeof(d));
+  d.is_sw = is_sw; d.ng = ng; d.npress = 2; d.ntemp = 2; d.ngas = 0; d.nplanck = 2;
+  d.log_pressure1 = 0.0; d.d_log_pressure = 1.0; d.d_temperature = 1.0;
+  d.temperature1_planck = 0.0; d.d_temperature_planck = 1.0;
+  d.table_f32 = 0;
+  const std::vector<double> zeros((size_t)ng * 4, 0.0);
+  int st;
+  if ((st = upload<double>(h, zeros.data(), 2, &d.temperature1))) return st;
+  if (is_sw) {
+    if ((st = upload<double>(h, zeros.data(), ng, &d.norm_solar_irradiance))) return st;
+    if ((st = upload<double>(h, zeros.data(), ng, &d.rayleigh_molar_scat))) return st;
+  } else {
+    const double* p;
+    if ((st = upload<double>(h, zeros.data(), (size_t)ng * 2, &p))) return st;
+    d.planck_function = p;
+  }
+  const double* q;
+  if ((st = upload<double>(h, zeros.data(), (size_t)ng * 4, &q))) return st;
+  d.hot.tab = q;
+  d.hot.nquad = 0; d.hot.nplain = 0; d.hot.pad_pos = -1;
+  return ECRAD_OK;
+}
+
+int setup_rrtmg(ecrad_hip_handle_t h, const ecrad_config_t& c) {
+  using namespace ecrad::rrtmg;
+  std::vector<char> host(sizeof(DevRrtmg));
+  DevRrtmg& d = *reinterpret_cast<DevRrtmg*>(host.data());
+  Packer pk;
+  if (const char* e = build_tables(*c.rrtmg, c.min_gas_od_lw, c.min_gas_od_sw, d, pk)) return fail(h, ECRAD_EINVAL, e);
+  int st;
+  if ((st = upload<double>(h, pk.tab.data(), pk.tab.size(), &d.tab))) return st;
+  const char* dev;
+  if ((st = upload<char>(h, host.data(), host.size(), &dev))) return st;
+  h->d_rrtmg = reinterpret_cast<const DevRrtmg*>(dev);
+  return ECRAD_OK;
+}
+
 void free_tables(ecrad_hip_handle_t h) {
+  h->d_rrtmg = nullptr;
   for (void* p : h->tables) (void)hipFree(p);
   h->tables.clear();
   if (h->dcfg) { (void)hipFree(h->dcfg); h->dcfg = nullptr; }
@@ -318,8 +363,17 @@ size_t flux_rows(const ecrad_config_t& c, int kind, int nlev) {
 
 int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
   if (c.abi_version != ECRAD_ABI_VERSION) return fail(h, ECRAD_EINVAL, "ABI version mismatch");
-  if (c.do_sw && c.i_gas_model_sw != ECRAD_GAS_ECCKD) return fail(h, ECRAD_EUNSUPPORTED, "only the ECCKD shortwave gas model is implemented");
-  if (c.do_lw && c.i_gas_model_lw != ECRAD_GAS_ECCKD) return fail(h, ECRAD_EUNSUPPORTED, "only the ECCKD longwave gas model is implemented");
+  for (int s = 0; s < 2; ++s) {
+    if (!(s ? c.do_lw : c.do_sw)) continue;
+    const int model = s ? c.i_gas_model_lw : c.i_gas_model_sw;
+    if (model == ECRAD_GAS_IFSRRTMG) {
+      if (!c.rrtmg) return fail(h, ECRAD_EINVAL, "RRTMG gas optics needs config%rrtmg (the tables of ifsrrtm after RRTM_INIT_140GP/SRTM_INIT)");
+      if ((s ? c.n_g_lw : c.n_g_sw) != (s ? ecrad::rrtmg::kNgLw : ecrad::rrtmg::kNgSw) || (s ? c.n_bands_lw : c.n_bands_sw) != (s ? 16 : 14))
+        return fail(h, ECRAD_EINVAL, "RRTMG has 140/112 g-points in 16/14 bands");
+      if (s ? c.do_cloud_aerosol_per_lw_g_point : c.do_cloud_aerosol_per_sw_g_point)
+        return fail(h, ECRAD_EINVAL, "RRTMG: cloud and aerosol optics are per band (radiation_ifs_rrtm.F90:107,150)");
+    } else if (model != ECRAD_GAS_ECCKD) return fail(h, ECRAD_EUNSUPPORTED, "the monochromatic gas model is not implemented");
+  }
   for (int s : {c.do_sw ? c.i_solver_sw : -1, c.do_lw ? c.i_solver_lw : -1}) {
     if (s == ECRAD_SOLVER_SPARTACUS) return fail(h, ECRAD_EUNSUPPORTED, "the SPARTACUS solver is not implemented");
     if (s > ECRAD_SOLVER_TRIPLECLOUDS) return fail(h, ECRAD_EINVAL, "unknown solver");
@@ -351,6 +405,18 @@ int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
     return fail(h, ECRAD_EUNSUPPORTED, "shortwave spectrum too wide for the cloud generator");
   { int nch = 1; if (c.do_lw && (c.n_g_lw < 1 || (chunk_lanes(c.n_g_lw, &nch), nch > 15))) return fail(h, ECRAD_EUNSUPPORTED, "longwave spectrum too wide"); }
   if (c.do_clouds && (c.n_cloud_types < 1 || c.n_cloud_types > ECRAD_NMAXCLOUDTYPES)) return fail(h, ECRAD_EINVAL, "n_cloud_types out of range");
+  if (c.do_clouds && !c.use_general_cloud_optics) {
+    if (c.i_liq_model != ECRAD_LIQUID_SOCRATES || c.i_ice_model != ECRAD_ICE_FU) return fail(h, ECRAD_EUNSUPPORTED, "band cloud optics: only the SOCRATES liquid and Fu ice models are implemented");
+    if (c.n_cloud_types != 2) return fail(h, ECRAD_EINVAL, "band cloud optics need exactly two cloud types (liquid, ice)");
+    for (int s = 0; s < 2; ++s) {
+      if (!(s ? c.do_lw : c.do_sw)) continue;
+      const ecrad_cloud_optics_t* co = s ? c.cloud_optics_lw : c.cloud_optics_sw;
+      if (co[0].n_effective_radius != 16 || co[1].n_effective_radius != (s ? 11 : 10))
+        return fail(h, ECRAD_EINVAL, "band cloud optics: wrong number of coefficients (SOCRATES 16, Fu 10 shortwave / 11 longwave)");
+    }
+    if ((c.do_sw && c.i_gas_model_sw == ECRAD_GAS_ECCKD) || (c.do_lw && c.i_gas_model_lw == ECRAD_GAS_ECCKD))
+      return fail(h, ECRAD_EINVAL, "ecCKD gas optics requires use_general_cloud_optics");   // radiation_config.F90
+  }
   return ECRAD_OK;
 }
 
@@ -372,6 +438,8 @@ size_t ecrad_hip_abi_sizeof(int which) {
     case 6: return sizeof(ecrad_cloud_optics_t);
     case 7: return sizeof(ecrad_aerosol_optics_t);
     case 8: return sizeof(ecrad_pdf_sampler_t);
+    case 9: return sizeof(ecrad_rrtmg_t);
+    case 10: return sizeof(ecrad_rrtmg_band_t);
     default: return 0;
   }
 }
@@ -407,7 +475,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
   if (!h) return ECRAD_EINVAL;
   (void)hipSetDevice(h->device);
   free_tables(h);
-  h->counters.release(); h->partial.release(); h->spec_tmp.release(); h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
+  h->gas_stage.release(); h->gas_work.release(); h->counters.release(); h->partial.release(); h->spec_tmp.release(); h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (auto& e : h->evs) if (e) (void)hipEventDestroy(e);
@@ -417,7 +485,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
 
 int ecrad_hip_scratch_bytes(ecrad_hip_handle_t h, size_t* bytes) {
   if (!h || !bytes) return ECRAD_EINVAL;
-  *bytes = h->scratch.cap + h->prep.cap + h->staging_in.cap + h->staging_out.cap + h->partial.cap + h->spec_tmp.cap;
+  *bytes = h->scratch.cap + h->prep.cap + h->staging_in.cap + h->staging_out.cap + h->partial.cap + h->spec_tmp.cap + h->gas_stage.cap + h->gas_work.cap;
   return ECRAD_OK;
 }
 
@@ -480,7 +548,8 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
     if ((st = upload<int32_t>(h, c.i_band_from_reordered_g_sw, c.n_g_sw, &d.i_band_from_reordered_g_sw))) return st;
     if ((st = upload<double>(h, c.sw_albedo_weights, (size_t)c.n_albedo_intervals_sw * c.n_bands_sw, &d.sw_albedo_weights))) return st;
     if ((st = upload<int32_t>(h, c.i_albedo_from_band_sw, c.n_bands_sw, &d.i_albedo_from_band_sw))) return st;
-    if ((st = setup_ckd(h, c.gas_optics_sw, d.gas_sw))) return st;
+    h->rrtmg_sw = c.i_gas_model_sw == ECRAD_GAS_IFSRRTMG;
+    if ((st = h->rrtmg_sw ? setup_stage_model(h, true, c.n_g_sw, d.gas_sw) : setup_ckd(h, c.gas_optics_sw, d.gas_sw))) return st;
     if (d.gas_sw.ng != c.n_g_sw) return fail(h, ECRAD_EINVAL, "n_g_sw does not match the shortwave gas model");
     if (!d.i_band_from_reordered_g_sw) return fail(h, ECRAD_EINVAL, "i_band_from_reordered_g_sw missing");
     if (!c.use_canopy_full_spectrum_sw && !c.do_nearest_spectral_sw_albedo && !d.sw_albedo_weights)
@@ -498,7 +567,8 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
     if ((st = upload<int32_t>(h, c.i_band_from_reordered_g_lw, c.n_g_lw, &d.i_band_from_reordered_g_lw))) return st;
     if ((st = upload<double>(h, c.lw_emiss_weights, (size_t)c.n_emiss_intervals_lw * c.n_bands_lw, &d.lw_emiss_weights))) return st;
     if ((st = upload<int32_t>(h, c.i_emiss_from_band_lw, c.n_bands_lw, &d.i_emiss_from_band_lw))) return st;
-    if ((st = setup_ckd(h, c.gas_optics_lw, d.gas_lw))) return st;
+    h->rrtmg_lw = c.i_gas_model_lw == ECRAD_GAS_IFSRRTMG;
+    if ((st = h->rrtmg_lw ? setup_stage_model(h, false, c.n_g_lw, d.gas_lw) : setup_ckd(h, c.gas_optics_lw, d.gas_lw))) return st;
     if (d.gas_lw.ng != c.n_g_lw) return fail(h, ECRAD_EINVAL, "n_g_lw does not match the longwave gas model");
     if (!d.i_band_from_reordered_g_lw) return fail(h, ECRAD_EINVAL, "i_band_from_reordered_g_lw missing");
     h->ngp_lw = chunk_lanes(c.n_g_lw, &h->nchunk_lw);
@@ -510,6 +580,14 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
       if (!ident && (st = upload<int32_t>(h, c.i_spec_from_reordered_g_lw, c.n_g_lw, &h->d_ispec_lw))) return st;
     }
   }
+  if (!c.do_sw) h->rrtmg_sw = false;
+  if (!c.do_lw) h->rrtmg_lw = false;
+  if (c.do_sw && c.do_lw && h->rrtmg_sw != h->rrtmg_lw)
+    return fail(h, ECRAD_EUNSUPPORTED, "RRTMG in one spectrum and ecCKD in the other: gas%mixing_ratio cannot be in both models' units");
+  d.gas_mmr = (h->rrtmg_sw || h->rrtmg_lw) ? 1 : 0;
+  d.cloud_fit = (c.do_clouds && !c.use_general_cloud_optics) ? 1 : 0;
+  d.fu_lw_bug = c.do_fu_lw_ice_optics_bug;
+  if ((h->rrtmg_sw || h->rrtmg_lw) && (st = setup_rrtmg(h, c))) return st;
   if (c.do_clouds) {
     for (int t = 0; t < c.n_cloud_types; ++t) {
       for (int pass = 0; pass < 2; ++pass) {
@@ -522,8 +600,10 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
         o.effective_radius_0 = s.effective_radius_0; o.d_effective_radius = s.d_effective_radius;
         const size_t n = (size_t)s.n_bands * s.n_effective_radius;
         if ((st = upload<double>(h, s.mass_ext, n, &o.mass_ext))) return st;
-        if ((st = upload<double>(h, s.ssa, n, &o.ssa))) return st;
-        if ((st = upload<double>(h, s.asymmetry, n, &o.asymmetry))) return st;
+        if (c.use_general_cloud_optics) {
+          if ((st = upload<double>(h, s.ssa, n, &o.ssa))) return st;
+          if ((st = upload<double>(h, s.asymmetry, n, &o.asymmetry))) return st;
+        }
       }
     }
   }
@@ -725,6 +805,33 @@ int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int ie
   return ECRAD_OK;
 }
 
+// RRTMG: the separate gas-optics pass that fills the stage arrays the solver kernels read (din.gs)
+int run_rrtmg(ecrad_hip_handle_t h, CallCtx& cx) {
+  if (!h->rrtmg_sw && !h->rrtmg_lw) return ECRAD_OK;
+  using namespace ecrad::rrtmg;
+  const size_t n = cx.r.nloc, L = cx.r.nlev;
+  DevGasStage gs{};
+  for (int pass = 0; pass < 2; ++pass) {
+    Carver cv(pass == 0 ? nullptr : h->gas_stage.p);
+    if (h->rrtmg_lw) {
+      gs.od_lw = cv.take<double>(kNgLw * L * n);
+      gs.planck_hl = cv.take<double>(kNgLw * (L + 1) * n);
+      gs.lw_emission = cv.take<double>(kNgLw * n);
+    }
+    if (h->rrtmg_sw) {
+      gs.od_sw = cv.take<double>(kNgSw * L * n);
+      gs.ssa_sw = cv.take<double>(kNgSw * L * n);
+      gs.incoming_sw = cv.take<double>(kNgSw * n);
+    }
+    if (pass == 0) HIP_TRY(h, h->gas_stage.ensure(cv.off));
+  }
+  HIP_TRY(h, h->gas_work.ensure(rrtmg_work_bytes((int)L, (int)n)));
+  const RrtmgWork w = rrtmg_carve_work(h->gas_work.p, (int)L, (int)n);
+  HIP_TRY(h, launch_rrtmg_gas_optics(h->stream, h->d_rrtmg, cx.din, w, gs, h->rrtmg_lw, h->rrtmg_sw));
+  cx.din.gs = gs;
+  return ECRAD_OK;
+}
+
 int grid_for(ecrad_hip_handle_t h, int nloc, int ngp) {
   const int cpb = kBlock / ngp;
   const int groups = (nloc + cpb - 1) / cpb;
@@ -867,6 +974,7 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
   HIP_TRY(h, hipEventRecord(h->evs[0], stream));
   HIP_TRY(h, hipMemsetAsync(counters, 0, 256, stream));
   HIP_TRY(h, launch_order(stream, din, counters + 32));                                 // :310-317
+  if ((st = run_rrtmg(h, cx))) return st;                                               // RRTMG gas optics, :341-357 (accounted to the PREP stage)
   if (c.do_clouds) HIP_TRY(h, launch_crop(stream, h->dcfg, din));                      // :361
   if (sw_tc || lw_tc)
     HIP_TRY(h, launch_tripleclouds_prep(stream, h->dcfg, din, prep, sw_tc ? dfx.cloud_cover_sw : nullptr,
@@ -1032,6 +1140,7 @@ int ecrad_hip_optics(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, in
   HIP_TRY(h, h->counters.ensure(256));
   cx.din.reversed = reinterpret_cast<int32_t*>(h->counters.p) + 32;
   HIP_TRY(h, launch_order(stream, cx.din, reinterpret_cast<int32_t*>(h->counters.p) + 32));
+  if ((st = run_rrtmg(h, cx))) return st;
   if (c.do_clouds) {
     HIP_TRY(h, h->prep.ensure((size_t)nlev * r.nloc * 8));
     cx.din.cloud_fraction_work = reinterpret_cast<double*>(h->prep.p);

@@ -95,7 +95,12 @@ struct DevConfig {
   int32_t use_canopy_full_spectrum_sw, use_canopy_full_spectrum_lw;
   int32_t do_nearest_spectral_sw_albedo, do_nearest_spectral_lw_emiss;
   int32_t n_g_sw, n_g_lw, n_bands_sw, n_bands_lw, n_canopy_bands_sw, n_canopy_bands_lw;
-  int32_t n_albedo_intervals_sw, n_emiss_intervals_lw, n_cloud_types, pad_;
+  int32_t n_albedo_intervals_sw, n_emiss_intervals_lw, n_cloud_types;
+  int32_t gas_mmr;
+  // cloud optics from per-band fits in effective radius (SOCRATES liquid, Fu ice: radiation_cloud_optics.F90) instead
+  // of the general look-up tables; cloud_sw/lw[0] = liquid, [1] = ice, their mass_ext = coefficients (n_bands, ncoeff)
+  int32_t cloud_fit, fu_lw_bug;
+  int32_t pad2_;             // gas%mixing_ratio holds MASS mixing ratios (RRTMG) instead of volume mixing ratios (ecCKD)
   double cloud_fraction_threshold, cloud_mixing_ratio_threshold, cloud_inhom_decorr_scaling;
   const int32_t *i_band_from_reordered_g_sw, *i_band_from_reordered_g_lw;
   const double *sw_albedo_weights, *lw_emiss_weights;

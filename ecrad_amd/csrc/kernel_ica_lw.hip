@@ -99,7 +99,12 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
     const bool valid = col_ok && gi < ng;
     const bool lead = glane == 0 && col_ok;
     const double albedo = albedo_lw_g(cfg, a.in, col, g);
-    const double emission = planck_at<TAB>(m, a.in.skin_temperature[col], g) * (1.0 - albedo);
+    double emission_src = planck_at<TAB>(m, a.in.skin_temperature[col], g);
+    if constexpr (sizeof(TAB) == 8) {      // gas optics from the RRTMG pass (stage arrays; double-table instantiations only)
+      const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+      if (gs.lw_emission) emission_src = gs.lw_emission[g + (size_t)ng * cloc];
+    }
+    const double emission = emission_src * (1.0 - albedo);
     double tcc = 0.0;
     if (MODE == 2) tcc = a.prep.total_cloud_cover_lw[cloc];
     LevMask cloudy;
@@ -109,6 +114,10 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
     double fdn_ctop = 0.0;       // ... captured at cloud top
     const LevelOrder ord = level_order(a.in);
     double planck_top = planck_at<TAB>(m, a.in.temperature_hl[col + ncol * ord.half(0)], g);   // top-of-atmosphere half level
+    if constexpr (sizeof(TAB) == 8) {
+      const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+      if (gs.planck_hl) planck_top = gs.planck_hl[g + (size_t)ng * ((size_t)(nlev + 1) * cloc)];
+    }
 
     // ---- pass A: top -> bottom ---------------------------------------------------------------------
     if (lead) {                  // flux_dn(:,1) = 0
@@ -152,9 +161,16 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
 #ifdef ECRAD_TIMING
         ECRAD_LAP(tm, 0, quads.q[0].x);   // (timing build: table loads alone, booked under "scalars")
 #endif
-        const double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
+        double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
         ECRAD_LAP(tm, 1, planck_bot);   // table + Planck loads returned
         double od = gas_combine<TAB>(nq, L, slot, quads);
+        if constexpr (sizeof(TAB) == 8) {
+          const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+          if (gs.od_lw) {
+            od = gs.od_lw[g + (size_t)ng * (lev + (size_t)nlev * cloc)];
+            planck_bot = gs.planck_hl[g + (size_t)ng * (lev + 1 + (size_t)(nlev + 1) * cloc)];
+          }
+        }
 #if ECRAD_PIPELINE_LOADS
         if (j + 1 < nl) gas_load<TAB>(gh, nq, launder_uniform(nplain), L, slot + 1, g, quads);
 #endif
@@ -176,7 +192,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
             if (!cloudy.any()) { ict = lev; fdn_ctop = fdn_c; }
             cloudy.set(lev);
             const SpectralArgs& b = kernarg_block<SpectralArgs>();
-            const CloudLayer cl = cloud_layer<false>(b.cfg, L, slot, ib);
+            const CloudLayer cl = cloud_layer<false, sizeof(TAB) == 8>(b.cfg, L, slot, ib);
             double od_cloud_new = cl.od;
             if (MODE == 2) od_cloud_new = b.prep.od_scaling_lw[g + (size_t)ng * (lev + (size_t)nlev * cloc)] * cl.od;
             const double od_total = od + od_cloud_new;

@@ -230,6 +230,10 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
     if (sun_up) {
       albedo_sw_g(cfg, a.in, col, g, alb_dif, alb_dir);
       incoming = incoming_sw_g(m, a.in, g);
+      if constexpr (sizeof(TAB) == 8) {      // gas optics from the RRTMG pass (stage arrays; double-table instantiations only)
+        const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+        if (gs.incoming_sw) incoming = gs.incoming_sw[g + (size_t)ng * cloc];
+      }
     }
     double tcc = 0.0;
     if (MODE == 2) tcc = a.prep.total_cloud_cover_sw[cloc];
@@ -276,6 +280,14 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
           double ssa = L.D(F_SM, slot) * ray_g;       // Rayleigh optical depth
           od = od + ssa;
           ssa = ssa / od;
+          if constexpr (sizeof(TAB) == 8) {
+            const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+            if (gs.od_sw) {
+              const size_t o = g + (size_t)ng * (lev + (size_t)nlev * cloc);
+              od = gs.od_sw[o];
+              ssa = gs.ssa_sw[o];
+            }
+          }
           double asym = 0.0;
           if (flags & SWF_AEROSOLS) {
             const SpectralArgs& b = kernarg_block<SpectralArgs>();
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
             if (layer_cloudy) {
               if (lcb < 0) { lcb = lev; st2 = st1; }     // below the lowest cloud both sets coincide
               const SpectralArgs& b = kernarg_block<SpectralArgs>();
-              const CloudLayer cl = cloud_layer<true>(b.cfg, L, slot, ib);
+              const CloudLayer cl = cloud_layer<true, sizeof(TAB) == 8>(b.cfg, L, slot, ib);
               double od_total, ssa_total = 0.0, g_total = 0.0;
               if (MODE == 1) {   // radiation_homogeneous_sw.F90:236-253
                 od_total = od + cl.od;

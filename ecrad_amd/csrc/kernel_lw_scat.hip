@@ -74,13 +74,22 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(Spectr
     const bool valid = col_ok && gi < ng;
     const bool lead = glane == 0 && col_ok;
     const double albedo = albedo_lw_g(cfg, a.in, col, g);
-    const double emission = planck_at<TAB>(m, a.in.skin_temperature[col], g) * (1.0 - albedo);
+    double emission_src = planck_at<TAB>(m, a.in.skin_temperature[col], g);
+    if constexpr (sizeof(TAB) == 8) {      // gas optics from the RRTMG pass (stage arrays; double-table instantiations only)
+      const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+      if (gs.lw_emission) emission_src = gs.lw_emission[g + (size_t)ng * cloc];
+    }
+    const double emission = emission_src * (1.0 - albedo);
     double tcc = 0.0;
     if (MODE == 2) tcc = a.prep.total_cloud_cover_lw[cloc];
     LevMask cloudy;
     cloudy.clear();
     const LevelOrder ord = level_order(a.in);
     double planck_top = planck_at<TAB>(m, a.in.temperature_hl[col + ncol * ord.half(0)], g);
+    if constexpr (sizeof(TAB) == 8) {
+      const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+      if (gs.planck_hl) planck_top = gs.planck_hl[g + (size_t)ng * ((size_t)(nlev + 1) * cloc)];
+    }
 
     // ---- pass A: optics and layer coefficients, top -> bottom ---------------------------------------
     for (int l0 = 0; l0 < nlev; l0 += NGP) {
@@ -100,8 +109,15 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(Spectr
         const int slot = cib * NGP + j;
         const int nq = launder_uniform(nquad);
         gas_load<TAB>(gh, nq, launder_uniform(nplain), L, slot, g, quads);
-        const double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
+        double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
         double od = gas_combine<TAB>(nq, L, slot, quads);
+        if constexpr (sizeof(TAB) == 8) {
+          const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+          if (gs.od_lw) {
+            od = gs.od_lw[g + (size_t)ng * (lev + (size_t)nlev * cloc)];
+            planck_bot = gs.planck_hl[g + (size_t)ng * (lev + 1 + (size_t)(nlev + 1) * cloc)];
+          }
+        }
         double ssa = 0.0, asym = 0.0;        // radiation_interface.F90:397-400: gases do not scatter
         if (use_aerosols) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(Spectr
         if (MODE != 0 && L.D(F_FRAC, slot) >= cloud_fraction_threshold) {
           cloudy.set(lev);
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
-          const CloudLayer cl = cloud_layer<false>(b.cfg, L, slot, ib);
+          const CloudLayer cl = cloud_layer<false, sizeof(TAB) == 8>(b.cfg, L, slot, ib);
           double od_cloud_new = cl.od;
           if (MODE == 2) od_cloud_new = b.prep.od_scaling_lw[g + (size_t)ng * (lev + (size_t)nlev * cloc)] * cl.od;
           const double od_total = od + od_cloud_new;

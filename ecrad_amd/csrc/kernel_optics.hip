@@ -40,16 +40,17 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
       if (valid) {
         if (out.sw_albedo_diffuse) out.sw_albedo_diffuse[og] = ad;
         if (out.sw_albedo_direct) out.sw_albedo_direct[og] = adir;
-        if (out.incoming_sw) out.incoming_sw[og] = incoming_sw_g(m, in, g);
+        if (out.incoming_sw) out.incoming_sw[og] = in.gs.incoming_sw ? in.gs.incoming_sw[og] : incoming_sw_g(m, in, g);
       }
     } else {
       lw_albedo = albedo_lw_g(cfg, in, col, g);
       if (valid) {
         if (out.lw_albedo) out.lw_albedo[og] = lw_albedo;
-        if (out.lw_emission) out.lw_emission[og] = planck_at<TAB>(m, in.skin_temperature[col], g) * (1.0 - lw_albedo);
+        if (out.lw_emission) out.lw_emission[og] = (in.gs.lw_emission ? in.gs.lw_emission[og] : planck_at<TAB>(m, in.skin_temperature[col], g)) * (1.0 - lw_albedo);
       }
     }
     double planck_top = IS_SW ? 0.0 : planck_at<TAB>(m, in.temperature_hl[col + (size_t)in.ncol * level_order(in).half(0)], g);   // top-of-atmosphere half level
+    if (!IS_SW && in.gs.planck_hl) planck_top = in.gs.planck_hl[g + (size_t)ng * ((size_t)(nlev + 1) * cloc)];
     for (int l0 = 0; l0 < nlev; l0 += NGP) {
       __syncthreads();
       {
@@ -67,6 +68,7 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
           double ssa = L.D(F_SM, slot) * m.rayleigh_molar_scat[g];
           od = od + ssa;
           ssa = ssa / od;
+          if (in.gs.od_sw) { od = in.gs.od_sw[o]; ssa = in.gs.ssa_sw[o]; }     // gas optics from the RRTMG pass
           double asym = 0.0;
           if (cfg.use_aerosols) {
             AerosolLayer a = aerosol_layer<true, NGP>(cfg, in, L, slot, col, lev, ib, aer_type);
@@ -79,7 +81,11 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
             if (out.g_sw) out.g_sw[o] = asym;
           }
         } else {
-            const double planck_bot = planck_lookup<TAB>(m, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
+          double planck_bot = planck_lookup<TAB>(m, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
+          if (in.gs.od_lw) {
+            od = in.gs.od_lw[o];
+            planck_bot = in.gs.planck_hl[g + (size_t)ng * (lev + 1 + (size_t)(nlev + 1) * cloc)];
+          }
           double ssa = 0.0, asym = 0.0;
           if (cfg.use_aerosols) {
             AerosolLayer a = aerosol_layer<false, NGP>(cfg, in, L, slot, col, lev, ib, aer_type);
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
         }
         if (want_clouds && gi < nb && col_ok) {
           // cloud tables are per band: lane b < n_bands writes band b
-          const CloudLayer cl = cloud_layer<IS_SW>(cfg, L, slot, gi);
+          const CloudLayer cl = cloud_layer<IS_SW, sizeof(TAB) == 8>(cfg, L, slot, gi);
           const size_t oc = gi + (size_t)nb * (lev + (size_t)nlev * cloc);
           double* pod = IS_SW ? out.od_sw_cloud : out.od_lw_cloud;
           double* pss = IS_SW ? out.ssa_sw_cloud : out.ssa_lw_cloud;

@@ -202,6 +202,10 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
     if (sun_up) {
       albedo_sw_g(cfg, in, col, g, alb_dif, alb_dir);
       incoming = incoming_sw_g(m, in, g);
+      if constexpr (sizeof(TAB) == 8) {      // gas optics from the RRTMG pass (stage arrays; double-table instantiations only)
+        const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+        if (gs.incoming_sw) incoming = gs.incoming_sw[g + (size_t)ng * cloc];
+      }
     }
     // which layers are cloudy (the upward sweep needs the layer ABOVE before it gets there)
     const FracView fracv = cloud_fraction_view(in, col);
@@ -252,6 +256,14 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
         double ssa = L.D(F_SM, slot) * ray_g;
         od = od + ssa;
         ssa = ssa / od;
+        if constexpr (sizeof(TAB) == 8) {
+          const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+          if (gs.od_sw) {
+            const size_t o = g + (size_t)ng * (l + (size_t)nlev * cloc);
+            od = gs.od_sw[o];
+            ssa = gs.ssa_sw[o];
+          }
+        }
         double asym = 0.0;
         if (use_aerosols) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
         const bool cl_here = cloudy.test(l);
         if (need_geo) feed1.commit();
         if (cl_here) {
-          const CloudLayer cl = cloud_layer<true>(kernarg_block<SpectralArgs>().cfg, L, slot, ib);
+          const CloudLayer cl = cloud_layer<true, sizeof(TAB) == 8>(kernarg_block<SpectralArgs>().cfg, L, slot, ib);
 #pragma unroll
           for (int jreg = 1; jreg < 3; ++jreg) {   // radiation_tripleclouds_sw.F90:278-300
             const double osc = feed1.odsc(0, jreg);
@@ -568,13 +580,22 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
     const DevCloudPrep prep = a.prep;
     const TcGeom geo{prep, ncol_loc, nlev, cloc};
     const double albedo = albedo_lw_g(cfg, in, col, g);
-    const double emission = planck_at<TAB>(m, in.skin_temperature[col], g) * (1.0 - albedo);
+    double emission_src = planck_at<TAB>(m, in.skin_temperature[col], g);
+    if constexpr (sizeof(TAB) == 8) {      // gas optics from the RRTMG pass (stage arrays; double-table instantiations only)
+      const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+      if (gs.lw_emission) emission_src = gs.lw_emission[g + (size_t)ng * cloc];
+    }
+    const double emission = emission_src * (1.0 - albedo);
     LevMask cloudy;
     cloudy.clear();
     int ict = nlev;             // 0-based layer index of cloud top (= i_cloud_top-1); nlev if none
     double fdn_c = 0.0, fdn_ctop = 0.0;
     const LevelOrder ord = level_order(in);
     double planck_top = planck_at<TAB>(m, in.temperature_hl[col + ncol * ord.half(0)], g);   // top-of-atmosphere half level
+    if constexpr (sizeof(TAB) == 8) {
+      const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+      if (gs.planck_hl) planck_top = gs.planck_hl[g + (size_t)ng * ((size_t)(nlev + 1) * cloc)];
+    }
 
     // ---- pass A ---------------------------------------------------------------------------------------
     if (lead) {
@@ -607,8 +628,15 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
         gas_load<TAB>(gh, launder_uniform(gh.nquad), launder_uniform(gh.nplain), L, slot, g, quads);
-        const double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
+        double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
         double od = gas_combine<TAB>(launder_uniform(gh.nquad), L, slot, quads);
+        if constexpr (sizeof(TAB) == 8) {
+          const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+          if (gs.od_lw) {
+            od = gs.od_lw[g + (size_t)ng * (lev + (size_t)nlev * cloc)];
+            planck_bot = gs.planck_hl[g + (size_t)ng * (lev + 1 + (size_t)(nlev + 1) * cloc)];
+          }
+        }
         double ssa = 0.0, asym = 0.0;        // clear-region scattering properties (ASCAT only)
         if (use_aerosols) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
@@ -632,7 +660,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
         if (L.D(F_FRAC, slot) > 0.0) {
           if (!cloudy.any()) { ict = lev; fdn_ctop = fdn_c; }
           cloudy.set(lev);
-          const CloudLayer cl = cloud_layer<false>(kernarg_block<SpectralArgs>().cfg, L, slot, ib);
+          const CloudLayer cl = cloud_layer<false, sizeof(TAB) == 8>(kernarg_block<SpectralArgs>().cfg, L, slot, ib);
 #pragma unroll
           for (int jreg = 1; jreg < 3; ++jreg) {    // radiation_tripleclouds_lw.F90:318-372
             const double od_cloud_new = cl.od * geo.odsc(jreg, lev);

@@ -150,8 +150,8 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
   int irh = 0;
   if (cfg.use_aerosols) {
     // rh = h2o_mmr / h2o_sat_liq with h2o_mmr from gas%get(IH2O, IMassMixingRatio) (radiation_gas.F90:605-612)
-    const double h2o_mmr = in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (ECRAD_IH2O - 1))]
-                           * (kH2OMolarMass / kAirMolarMass);
+    const double h2o_in = in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (ECRAD_IH2O - 1))];
+    const double h2o_mmr = cfg.gas_mmr ? h2o_in : h2o_in * (kH2OMolarMass / kAirMolarMass);
     const double rh = h2o_mmr / in.h2o_sat_liq[i0];
     const DevAerosolOptics& ao = cfg.aerosol;
     if (ao.use_hydrophilic) {      // calc_rh_index, radiation_aerosol_optics_data.F90:640-664
@@ -175,7 +175,7 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
                                        co.n_effective_radius - 0.0001));
       int ire = (int)re_index;
       L.D(L.f_wp(t), slot) = water_path;
-      L.D(L.f_rew(t), slot) = re_index - ire;
+      L.D(L.f_rew(t), slot) = cfg.cloud_fit ? re : re_index - ire;      // the band fits take the radius itself
       L.I(L.i_re(t), slot) = ire - 1;
     }
   }
@@ -502,8 +502,64 @@ ECRAD_DEV void merge_aerosol_sw(const DevConfig& cfg, const AerosolLayer& a, dou
 // ssa, g as stored in od_*_cloud/ssa_*_cloud/g_*_cloud (after delta-Eddington and normalisation).
 struct CloudLayer { double od, ssa, g; };
 
+// cloud_optics (radiation_cloud_optics.F90:218-523) for one layer and band with the SOCRATES liquid fit
+// (calc_liq_optics_socrates, radiation_liquid_optics_socrates.F90:40-80) and the Fu ice fits
+// (calc_ice_optics_fu_sw/_lw, radiation_ice_optics_fu.F90:42-137); coefficient tables (n_bands, ncoeff)
 template <bool IS_SW>
+ECRAD_DEV CloudLayer cloud_layer_fit(const DevConfig& cfg, const LdsLayout& L, int slot, int ib) {
+  CloudLayer c = {0.0, 0.0, 0.0};
+  if (!(L.D(F_FRAC, slot) > 0.0)) return c;
+  const DevCloudOptics& liq = IS_SW ? cfg.cloud_sw[0] : cfg.cloud_lw[0];
+  const DevCloudOptics& ice = IS_SW ? cfg.cloud_sw[1] : cfg.cloud_lw[1];
+  const int nb = liq.n_bands;
+  const double lwp = L.D(L.f_wp(0), slot), iwp = L.D(L.f_wp(1), slot);
+  double od_l = 0.0, sc_l = 0.0, g_l = 0.0, od_i = 0.0, sc_i = 0.0, g_i = 0.0;
+  if (lwp > 0.0) {
+    const double* __restrict__ k = liq.mass_ext + ib;
+#define KL(j) k[(size_t)nb * ((j) - 1)]
+    // MinEffectiveRadius / MaxEffectiveRadius are default-real literals in the reference
+    const double re = dmax((double)1.2e-6f, dmin(L.D(L.f_rew(0), slot), (double)50.0e-6f));
+    od_l = lwp * (KL(1) + re * (KL(2) + re * KL(3))) / (1.0 + re * (KL(4) + re * (KL(5) + re * KL(6))));
+    sc_l = od_l * (1.0 - (KL(7) + re * (KL(8) + re * KL(9))) / (1.0 + re * (KL(10) + re * KL(11))));
+    g_l = (KL(12) + re * (KL(13) + re * KL(14))) / (1.0 + re * (KL(15) + re * KL(16)));
+#undef KL
+    if (IS_SW && !cfg.do_sw_delta_scaling_with_gases) { const double f = g_l * g_l; od_l = od_l - sc_l * f; sc_l = sc_l * (1.0 - f); g_l = g_l / (1.0 + g_l); }
+  }
+  if (iwp > 0.0) {
+    const double* __restrict__ k = ice.mass_ext + ib;
+#define KI(j) k[(size_t)nb * ((j) - 1)]
+    const double max_g = 1.0 - 10.0 * 2.220446049250313e-16;
+    const double de_um = dmin(L.D(L.f_rew(1), slot), 100.0e-6) * (1.0e6 / 0.64952);
+    const double inv_de_um = 1.0 / de_um;
+    const double iwp_gm_2 = iwp * 1000.0;
+    if (IS_SW) {
+      od_i = iwp_gm_2 * (KI(1) + KI(2) * inv_de_um);
+      sc_i = od_i * (1.0 - (KI(3) + de_um * (KI(4) + de_um * (KI(5) + de_um * KI(6)))));
+      g_i = dmin(KI(7) + de_um * (KI(8) + de_um * (KI(9) + de_um * KI(10))), max_g);
+    } else {
+      od_i = iwp_gm_2 * (KI(1) + inv_de_um * (KI(2) + inv_de_um * KI(3)));
+      sc_i = od_i - iwp_gm_2 * inv_de_um * (KI(4) + de_um * (KI(5) + de_um * (KI(6) + de_um * KI(7))));
+      g_i = dmin(KI(8) + de_um * (KI(9) + de_um * (KI(10) + de_um * KI(11))), max_g);
+      if (cfg.fu_lw_bug) sc_i = od_i - sc_i;
+    }
+#undef KI
+    if (!IS_SW || !cfg.do_sw_delta_scaling_with_gases) { const double f = g_i * g_i; od_i = od_i - sc_i * f; sc_i = sc_i * (1.0 - f); g_i = g_i / (1.0 + g_i); }
+  }
+  if (IS_SW || cfg.do_lw_cloud_scattering) {
+    c.od = od_l + od_i;
+    if (IS_SW || sc_l + sc_i > 0.0) c.g = (g_l * sc_l + g_i * sc_i) / (sc_l + sc_i);
+    c.ssa = (sc_l + sc_i) / (od_l + od_i);
+  } else {
+    c.od = od_l - sc_l + od_i - sc_i;
+  }
+  return c;
+}
+
+// FIT: the instantiation may be asked for the band fits (only the double-table instantiations are: the
+// reference allows them with RRTMG only)
+template <bool IS_SW, bool FIT = false>
 ECRAD_DEV CloudLayer cloud_layer(const DevConfig& cfg, const LdsLayout& L, int slot, int ib) {
+  if constexpr (FIT) { if (cfg.cloud_fit) return cloud_layer_fit<IS_SW>(cfg, L, slot, ib); }
   CloudLayer c = {0.0, 0.0, 0.0};
   const double frac = L.D(F_FRAC, slot);
   const bool scat = IS_SW || cfg.do_lw_cloud_scattering;

@@ -521,7 +521,7 @@ ECRAD_HD double planck_band(const DevRrtmg& T, double temperature, int iband) {
 // =====================================================================================================
 // Host side: descriptors of the 16 + 14 bands and packing of the caller's tables (ecrad_rrtmg_t)
 // =====================================================================================================
-#ifndef __HIP_DEVICE_COMPILE__
+#if 1
 struct Packer {
   std::vector<double> tab;
   // (rows, ld) Fortran array with the g-point LAST -> [row][ig < ng]
@@ -815,7 +815,7 @@ inline const char* build_tables(const ecrad_rrtmg_t& t, double min_gas_od_lw, do
   if (g0 != kNgSw) return "rrtmg: shortwave band sizes do not add up to 112";
   return nullptr;
 }
-#endif  // !__HIP_DEVICE_COMPILE__
+#endif
 
 }  // namespace rrtmg
 }  // namespace ecrad

@@ -11,11 +11,14 @@ program abi_check
   type(ecrad_cloud_optics_t) :: co
   type(ecrad_aerosol_optics_t) :: ao
   type(ecrad_pdf_sampler_t) :: p
+  type(ecrad_rrtmg_t) :: rr
+  type(ecrad_rrtmg_band_t) :: rb
   logical :: ok
   ok = .true.
   call chk('config', 0, c_sizeof(c)); call chk('inputs', 1, c_sizeof(i)); call chk('flux', 2, c_sizeof(f))
   call chk('ckd_model', 4, c_sizeof(m)); call chk('ckd_gas', 5, c_sizeof(g)); call chk('cloud_optics', 6, c_sizeof(co))
   call chk('aerosol_optics', 7, c_sizeof(ao)); call chk('pdf_sampler', 8, c_sizeof(p))
+  call chk('rrtmg', 9, c_sizeof(rr)); call chk('rrtmg_band', 10, c_sizeof(rb))
   if (ecrad_hip_abi_version() /= ECRAD_ABI_VERSION) ok = .false.
   if (.not. ok) error stop 1
   write(*,'(a)') 'ABI OK'

@@ -8,7 +8,7 @@ module ecrad_hip_binding
   implicit none
   public
 
-  integer(c_int), parameter :: ECRAD_ABI_VERSION = 2
+  integer(c_int), parameter :: ECRAD_ABI_VERSION = 3
   integer(c_int), parameter :: ECRAD_OK = 0
   integer(c_int), parameter :: ECRAD_NMAXGASES = 12, ECRAD_NMAXCLOUDTYPES = 12
   integer(c_int), parameter :: ECRAD_MEM_HOST = 0, ECRAD_MEM_DEVICE = 1
@@ -42,6 +42,18 @@ module ecrad_hip_binding
     type(c_ptr) :: mass_ext_lw_phobic = c_null_ptr, ssa_lw_phobic = c_null_ptr, g_lw_phobic = c_null_ptr
     type(c_ptr) :: mass_ext_sw_philic = c_null_ptr, ssa_sw_philic = c_null_ptr, g_sw_philic = c_null_ptr
     type(c_ptr) :: mass_ext_lw_philic = c_null_ptr, ssa_lw_philic = c_null_ptr, g_lw_philic = c_null_ptr
+  end type
+
+  ! RRTMG tables: c_loc() of the arrays of ifsrrtm/yoerrta*, yoesrta* after RRTM_INIT_140GP / SRTM_INIT
+  type, bind(C) :: ecrad_rrtmg_band_t
+    integer(c_int32_t) :: ng, ld, nspa, nspb, layreffr, n_forref
+    real(c_double) :: strrat, rayl, factor
+    type(c_ptr) :: absa, absb, selfref, forref, fracrefa, fracrefb
+    type(c_ptr) :: minor(6), xsec(2), rayl_g(2)
+  end type
+  type, bind(C) :: ecrad_rrtmg_t
+    type(c_ptr) :: chi_mls, preflog_lw, tref_lw, preflog_sw, tref_sw, totplnk, delwave
+    type(ecrad_rrtmg_band_t) :: lw(16), sw(14)
   end type
 
   type, bind(C) :: ecrad_pdf_sampler_t
@@ -82,6 +94,9 @@ module ecrad_hip_binding
     type(ecrad_cloud_optics_t) :: cloud_optics_sw(ECRAD_NMAXCLOUDTYPES), cloud_optics_lw(ECRAD_NMAXCLOUDTYPES)
     type(ecrad_aerosol_optics_t) :: aerosol_optics
     type(ecrad_pdf_sampler_t) :: pdf_sampler
+    type(c_ptr) :: rrtmg                      ! -> ecrad_rrtmg_t, or c_null_ptr (ecCKD)
+    real(c_double) :: min_gas_od_lw, min_gas_od_sw
+    integer(c_int32_t) :: i_liq_model, i_ice_model, do_fu_lw_ice_optics_bug, reserved2_
   end type
 
   type, bind(C) :: ecrad_inputs_t

@@ -251,6 +251,11 @@ contains
            &  call radiation_hip_abort('*** Error: no usable MI355X device (ecrad_hip_create)')
     end if
     c%abi_version = ECRAD_ABI_VERSION
+    ! this mirror carries ecCKD configurations only; with RRTMG a host passes c_loc() of an ecrad_rrtmg_t filled
+    ! from the ifsrrtm modules (INTEGRATION.md)
+    c%rrtmg = c_null_ptr
+    c%min_gas_od_lw = 1.0e-15_c_double; c%min_gas_od_sw = 0.0_c_double
+    c%i_liq_model = 0; c%i_ice_model = 0; c%do_fu_lw_ice_optics_bug = 0; c%reserved2_ = 0
     c%do_sw = l2i(config%do_sw); c%do_lw = l2i(config%do_lw); c%do_clear = l2i(config%do_clear)
     c%do_sw_direct = l2i(config%do_sw_direct); c%do_lw_derivatives = l2i(config%do_lw_derivatives)
     c%do_clouds = l2i(config%do_clouds); c%use_aerosols = l2i(config%use_aerosols)

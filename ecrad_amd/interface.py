@@ -49,9 +49,12 @@ def setup_radiation(config: Config) -> None:
     """setup_radiation (radiation_interface.F90:37-158): read and map every look-up table."""
     config.consolidate()
     for m in (config.i_gas_model_sw, config.i_gas_model_lw):
-        if m != IGasModelECCKD:
-            raise ConfigError("only the ECCKD gas model is implemented in this build "
-                              "(RRTMG-IFS is a later scope row)")
+        if m == IGasModelMonochromatic:
+            raise ConfigError("the monochromatic gas model is not implemented in this build")
+    if config.do_sw and config.do_lw and config.i_gas_model_sw != config.i_gas_model_lw:
+        raise ConfigError("shortwave and longwave gas models must be the same in this build")
+    if (config.i_gas_model_sw if config.do_sw else config.i_gas_model_lw) == IGasModelIFSRRTMG:
+        return _setup_radiation_rrtmg(config)
     if ISolverSpartacus in (config.i_solver_sw, config.i_solver_lw):
         raise ConfigError("the SPARTACUS solver is not implemented in this build")
     # setup_gas_optics (radiation_ecckd_interface.F90:27-150)
@@ -175,6 +178,114 @@ def setup_radiation(config: Config) -> None:
         config.pdf_sampler = PdfSampler(config.cloud_pdf_file_name)
 
 
+class _BandsOnlyGasOptics:
+    """What setup_radiation needs from a gas-optics model when it is RRTMG: the spectral definition of its bands
+    (radiation_ifs_rrtm.F90:111-121, :155-164)."""
+
+    def __init__(self, spectral_def):
+        self.spectral_def = spectral_def
+
+
+def _setup_radiation_rrtmg(config: Config) -> None:
+    """setup_radiation with gas_model_name = "RRTMG-IFS": setup_gas_optics of radiation_ifs_rrtm.F90:58-213, then the
+    same surface-interval, cloud, aerosol and McICA set-up as above with bands instead of g-points."""
+    from .rrtmg import (LW_WAVENUMBER1, LW_WAVENUMBER2, SW_WAVENUMBER1, SW_WAVENUMBER2, RrtmgTables)
+    from .spectral import SpectralDefinition
+    from .tables import BandFitCloudOptics
+    if ISolverSpartacus in (config.i_solver_sw, config.i_solver_lw):
+        raise ConfigError("the SPARTACUS solver is not implemented in this build")
+    config.rrtmg = RrtmgTables()
+    config.do_cloud_aerosol_per_sw_g_point = False
+    config.do_cloud_aerosol_per_lw_g_point = False
+    sd_sw = SpectralDefinition.bands_only(SOLAR_REFERENCE_TEMPERATURE, SW_WAVENUMBER1, SW_WAVENUMBER2)
+    sd_lw = SpectralDefinition.bands_only(TERRESTRIAL_REFERENCE_TEMPERATURE, LW_WAVENUMBER1, LW_WAVENUMBER2)
+    if config.do_sw:
+        config.n_g_sw, config.n_bands_sw = 112, 14
+        config.i_band_from_reordered_g_sw = config.rrtmg.i_band_from_g_sw.copy()
+        config.gas_optics_sw = _BandsOnlyGasOptics(sd_sw)
+    if config.do_lw:
+        config.n_g_lw, config.n_bands_lw = 140, 16
+        config.i_band_from_reordered_g_lw = config.rrtmg.i_band_from_g_lw.copy()
+        config.gas_optics_lw = _BandsOnlyGasOptics(sd_lw)
+    for sfx in ("sw", "lw"):
+        if not getattr(config, "do_" + sfx) or not (config.do_save_spectral_flux or config.do_toa_spectral_flux):
+            setattr(config, "n_spec_" + sfx, 0)
+            setattr(config, "i_spec_from_reordered_g_" + sfx, None)
+        elif config.do_save_gpoint_flux:
+            ng = getattr(config, "n_g_" + sfx)
+            setattr(config, "n_spec_" + sfx, ng)
+            setattr(config, "i_spec_from_reordered_g_" + sfx, np.arange(1, ng + 1, dtype=np.int32))
+        else:
+            setattr(config, "n_spec_" + sfx, getattr(config, "n_bands_" + sfx))
+            setattr(config, "i_spec_from_reordered_g_" + sfx,
+                    np.asarray(getattr(config, "i_band_from_reordered_g_" + sfx), dtype=np.int32))
+    if config.do_lw_aerosol_scattering and not config.do_lw_cloud_scattering:
+        raise ConfigError("longwave aerosol scattering requires longwave cloud scattering")
+    config.n_g_lw_if_scattering = config.n_g_lw if config.do_lw_aerosol_scattering else 0
+    config.n_bands_lw_if_scattering = config.n_bands_lw if config.do_lw_cloud_scattering else 0
+    if config.do_lw_cloud_scattering and config.i_solver_lw == ISolverMcICA:
+        config.n_g_lw_if_scattering = config.n_g_lw
+
+    def intervals(index, bound, full_spectrum, ng):       # radiation_config.F90:1947-2100, as in setup_radiation
+        ninterval = 0
+        for j, v in enumerate(index[:NMaxAlbedoIntervals]):
+            if v > 0:
+                ninterval = j + 1
+            else:
+                break
+        if ninterval < 1:
+            return [1], [], (ng if full_spectrum else 1)
+        idx = list(index[:ninterval])
+        return idx, list(bound[:ninterval - 1]), (ng if full_spectrum else max(idx))
+
+    if config.do_sw:
+        idx, bnd, config.n_canopy_bands_sw = intervals(config.i_sw_albedo_index, config.sw_albedo_wavelength_bound,
+                                                       config.use_canopy_full_spectrum_sw, config.n_g_sw)
+        config.sw_albedo_weights = np.ascontiguousarray(sd_sw.calc_mapping_from_bands(bnd, idx, use_bands=True))
+        if config.do_nearest_spectral_sw_albedo:
+            config.i_albedo_from_band_sw = (np.argmax(config.sw_albedo_weights, axis=1) + 1).astype(np.int32)
+    if config.do_lw:
+        idx, bnd, config.n_canopy_bands_lw = intervals(config.i_lw_emiss_index, config.lw_emiss_wavelength_bound,
+                                                       config.use_canopy_full_spectrum_lw, config.n_g_lw)
+        config.lw_emiss_weights = np.ascontiguousarray(sd_lw.calc_mapping_from_bands(bnd, idx, use_bands=True))
+        if config.do_nearest_spectral_lw_emiss:
+            config.i_emiss_from_band_lw = (np.argmax(config.lw_emiss_weights, axis=1) + 1).astype(np.int32)
+
+    if config.do_clouds:
+        config.cloud_optics_sw, config.cloud_optics_lw = [], []
+        if config.use_general_cloud_optics:
+            names = [n for n in config.cloud_type_name if n] or ["mie_droplet", "baum-general-habit-mixture_ice"]
+            config.n_cloud_types = len(names)
+            for j, name in enumerate(names):
+                fn = name if name.startswith("/") else os.path.join(
+                    config.directory_name, name if name.endswith(".nc") else name + "_scattering.nc")
+                thick = config.use_thick_cloud_spectral_averaging[j]
+                if config.do_sw:
+                    config.cloud_optics_sw.append(GeneralCloudOptics(fn, sd_sw, True, thick, SOLAR_REFERENCE_TEMPERATURE, name))
+                if config.do_lw:
+                    config.cloud_optics_lw.append(GeneralCloudOptics(fn, sd_lw, True, thick, TERRESTRIAL_REFERENCE_TEMPERATURE, name))
+        else:
+            # setup_cloud_optics (radiation_cloud_optics.F90:38-213): liquid then ice
+            config.n_cloud_types = 2
+            if config.do_sw:
+                config.cloud_optics_sw = [BandFitCloudOptics(config.liq_optics_file_name, "coeff_sw", 14),
+                                          BandFitCloudOptics(config.ice_optics_file_name, "coeff_sw", 14)]
+            if config.do_lw:
+                config.cloud_optics_lw = [BandFitCloudOptics(config.liq_optics_file_name, "coeff_lw", 16),
+                                          BandFitCloudOptics(config.ice_optics_file_name, "coeff_lw", 16)]
+    if config.use_aerosols:
+        if config.n_aerosol_types > 0:
+            if not config.use_general_aerosol_optics:
+                raise ConfigError("only use_general_aerosol_optics=true is implemented")
+            config.aerosol_optics = AerosolOptics(config.aerosol_optics_file_name, sd_sw if config.do_sw else None,
+                                                  sd_lw if config.do_lw else None, False, False, config.do_sw, config.do_lw)
+            config.aerosol_optics.set_types(config.i_aerosol_type_map[:config.n_aerosol_types])
+        else:
+            config.use_aerosols = False
+    if ISolverMcICA in (config.i_solver_sw, config.i_solver_lw):
+        config.pdf_sampler = PdfSampler(config.cloud_pdf_file_name)
+
+
 # ----------------------------------------------------------------------------------------------------
 def build_config_struct(config: Config):
     """Flatten ``config`` into an ecrad_config_t.  Returns (struct, keepalive list)."""
@@ -244,8 +355,15 @@ def build_config_struct(config: Config):
                 g.reference_mole_frac, g.log_mole_frac1, g.d_log_mole_frac
             sg.molar_abs = d(g.molar_abs)
 
-    fill_ckd(c.gas_optics_sw, config.gas_optics_sw)
-    fill_ckd(c.gas_optics_lw, config.gas_optics_lw)
+    if config.rrtmg is not None:
+        keep.append(config.rrtmg)
+        c.rrtmg = C.pointer(config.rrtmg.struct)
+    else:
+        fill_ckd(c.gas_optics_sw, config.gas_optics_sw)
+        fill_ckd(c.gas_optics_lw, config.gas_optics_lw)
+    c.min_gas_od_lw, c.min_gas_od_sw = config.min_gas_od_lw, config.min_gas_od_sw
+    c.i_liq_model, c.i_ice_model = config.i_liq_model, config.i_ice_model
+    c.do_fu_lw_ice_optics_bug = int(config.do_fu_lw_ice_optics_bug)
     for arr, src in ((c.cloud_optics_sw, config.cloud_optics_sw), (c.cloud_optics_lw, config.cloud_optics_lw)):
         for j, co in enumerate(src or []):
             arr[j].n_bands, arr[j].n_effective_radius = co.n_bands, co.n_effective_radius
@@ -362,7 +480,11 @@ class Radiation:
 
     def set_gas_units(self, gas) -> None:
         """set_gas_units (radiation_interface.F90:164-190 -> radiation_ecckd_interface.F90:153-171)."""
-        gas.set_units(IVolumeMixingRatio)
+        if self.config.rrtmg is not None:      # radiation_ifs_rrtm.F90:203-213
+            from .types import IMassMixingRatio
+            gas.set_units(IMassMixingRatio)
+        else:
+            gas.set_units(IVolumeMixingRatio)
 
     def radiation(self, ncol, nlev, istartcol, iendcol, single_level, thermodynamics, gas,
                   cloud, aerosol, flux) -> None:

@@ -72,6 +72,18 @@ class SpectralDefinition:
         s.nband = s.wavenumber1_band.size
         return s
 
+    @classmethod
+    def bands_only(cls, reference_temperature, wavenumber1, wavenumber2) -> "SpectralDefinition":
+        """allocate_bands_only (radiation_spectral_definition.F90:140-165): a definition that knows its bands
+        but not how g-points map to wavenumber (RRTMG)."""
+        s = cls()
+        s.wavenumber1_band = np.asarray(wavenumber1, dtype=np.float64)
+        s.wavenumber2_band = np.asarray(wavenumber2, dtype=np.float64)
+        s.nband = s.wavenumber1_band.size
+        s.reference_temperature = float(reference_temperature)
+        s.ng = 0
+        return s
+
     # -- find_wavenumber (:170-186): 1-based index, 0 if outside ---------------------------------
     def find(self, wavenumber: float) -> int:
         if wavenumber < self.wavenumber1[0] or wavenumber > self.wavenumber2[self.nwav - 1]:

@@ -143,6 +143,27 @@ class GeneralCloudOptics:
 IAerosolClassUndefined, IAerosolClassIgnored, IAerosolClassHydrophobic, IAerosolClassHydrophilic = range(4)
 
 
+class BandFitCloudOptics:
+    """One hydrometeor's coefficients of the band-fit cloud optics (config%cloud_optics%liq_coeff_* / ice_coeff_*,
+    radiation_cloud_optics_data.F90:63-111): ``coeff`` is numpy (ncoeff, n_bands) == Fortran (n_bands, ncoeff) after
+    the reference's transpose_matrices.  Handed to the library in the slots of a general_cloud_optics_type
+    (mass_ext = coefficients, n_effective_radius = ncoeff), see include/ecrad_hip.h."""
+
+    def __init__(self, file_name: str, var: str, n_bands_expected: int):
+        with NcFile(file_name) as nc:
+            a = np.asarray(nc.get(var), dtype=np.float64)
+        if a.shape[0] != n_bands_expected and a.shape[1] == n_bands_expected:
+            a = a.T
+        if a.shape[0] != n_bands_expected:
+            raise ValueError(f"{file_name}:{var}: number of bands does not match the gas optics ({a.shape})")
+        self.n_bands = int(a.shape[0])
+        self.n_effective_radius = int(a.shape[1])        # number of coefficients
+        self.effective_radius_0, self.d_effective_radius = 0.0, 1.0
+        self.mass_ext = np.ascontiguousarray(a.T)        # (ncoeff, n_bands): band fastest
+        self.ssa = None
+        self.asymmetry = None
+
+
 class AerosolOptics:
     """aerosol_optics_type filled by setup_general_aerosol_optics
     (radiation_aerosol_optics.F90:96-338) + initialize_types/set_types

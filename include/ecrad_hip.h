@@ -62,6 +62,9 @@ enum { ECRAD_GAS_MONOCHROMATIC = 0, ECRAD_GAS_IFSRRTMG = 1, ECRAD_GAS_ECCKD = 2 
 enum { ECRAD_OVERLAP_MAX_RAN = 0, ECRAD_OVERLAP_EXP_RAN = 1, ECRAD_OVERLAP_EXP_EXP = 2 };
 /* radiation_config.F90:124-126 */
 enum { ECRAD_PDF_LOGNORMAL = 0, ECRAD_PDF_GAMMA = 1 };
+/* radiation_config.F90:109-126 */
+enum { ECRAD_LIQUID_MONOCHROMATIC = 0, ECRAD_LIQUID_SOCRATES = 1, ECRAD_LIQUID_SLINGO = 2 };
+enum { ECRAD_ICE_MONOCHROMATIC = 0, ECRAD_ICE_FU = 1, ECRAD_ICE_BARAN = 2 };
 /* radiation_aerosol_optics_data.F90 IAerosolClass* */
 enum { ECRAD_AEROSOL_UNDEFINED = 0, ECRAD_AEROSOL_IGNORED = 1, ECRAD_AEROSOL_HYDROPHOBIC = 2,
        ECRAD_AEROSOL_HYDROPHILIC = 3 };
@@ -225,6 +228,11 @@ typedef struct ecrad_config {
      (radiation_ifs_rrtm.F90:208) and gas_optics_sw/lw are not read */
   const ecrad_rrtmg_t*   rrtmg;
   double min_gas_od_lw, min_gas_od_sw;   /* radiation_config.F90:244-245 */
+  /* use_general_cloud_optics == 0: the per-band fits of radiation_cloud_optics.F90.  cloud_optics_sw/lw[0] is liquid,
+     [1] ice; their mass_ext points to the coefficients (n_bands, ncoeff) = config%cloud_optics%liq_coeff_* /
+     ice_coeff_*, n_effective_radius holds ncoeff; ssa/asymmetry are not read.  Implemented: SOCRATES + Fu. */
+  int32_t i_liq_model, i_ice_model;      /* radiation_config.F90:109-126 (ILiquidModel*, IIceModel*) */
+  int32_t do_fu_lw_ice_optics_bug, reserved2_;
 } ecrad_config_t;
 
 /* ---- single_level_type + thermodynamics_type + gas_type + cloud_type + aerosol_type --------- */

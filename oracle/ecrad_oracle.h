@@ -109,6 +109,8 @@ int ecrad_oracle_radiation_blocked(const ecrad_config_t* config, int ncol, int n
                                    int iendcol, int nblocksize, int nthreads,
                                    const ecrad_inputs_t* in, ecrad_flux_t* flux);
 int ecrad_oracle_max_threads(void);
+/* RRTMG: gas-optics stage arrays for all columns, computed by the reference's own routines (see oracle_rrtmg.c) */
+void ecrad_oracle_set_gas_stage(const ecrad_optics_t* stage);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,12 @@ void oracle_gas_optics_ecckd(const ecrad_config_t* c, int ncol, int nlev, int is
      double* planck_hl, double* lw_emission, double* incoming_sw);
 void oracle_calc_planck_function(const ecrad_ckd_model_t* m, int nt, const double* temperature, int tstride,
                                  double* planck);
+int oracle_gas_optics_rrtmg(const ecrad_config_t* c, int ncol, int nlev, int istartcol, int iendcol,
+     const ecrad_inputs_t* in, const double* lw_albedo, double* od_lw, double* od_sw, double* ssa_sw,
+     double* planck_hl, double* lw_emission, double* incoming_sw);
+void oracle_cloud_optics_fit(const ecrad_config_t* c, int ncol, int nlev, int istartcol, int iendcol,
+     const ecrad_inputs_t* in, double* od_lw_cloud, double* ssa_lw_cloud, double* g_lw_cloud,
+     double* od_sw_cloud, double* ssa_sw_cloud, double* g_sw_cloud);
 void oracle_crop_cloud_fraction(const ecrad_config_t* c, int ncol, int nlev, int istartcol, int iendcol,
                                 const ecrad_inputs_t* in);
 void oracle_general_cloud_optics(const ecrad_config_t* c, int ncol, int nlev, int istartcol, int iendcol,

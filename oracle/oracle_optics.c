@@ -404,7 +404,9 @@ void oracle_add_aerosol_optics(const ecrad_config_t* c, int ncol, int nlev, int 
   const double OneOverAccelDueToGravity = 1.0 / 9.80665;
   /* 1.0e-24 in radiation_delta_eddington.h:80 is a default-real (single precision) literal */
   const double tiny_single = (double)1.0e-24f;
-  const double h2o_vmr_to_mmr = 18.0152833 / 28.970;   /* gas%get(IH2O, IMassMixingRatio,...) radiation_gas.F90:605-612 */
+  /* with RRTMG the caller's mixing ratios are already mass mixing ratios (radiation_ifs_rrtm.F90:208) */
+  const int gas_is_mmr = (c->do_sw && c->i_gas_model_sw == ECRAD_GAS_IFSRRTMG) || (c->do_lw && c->i_gas_model_lw == ECRAD_GAS_IFSRRTMG);
+  const double h2o_vmr_to_mmr = gas_is_mmr ? 1.0 : 18.0152833 / 28.970;   /* gas%get(IH2O, IMassMixingRatio,...) radiation_gas.F90:605-612 */
   double* od_sw_aerosol = (double*)calloc((size_t)nbsw * nlev * 3, sizeof(double));
   double* scat_sw_aerosol = od_sw_aerosol + (size_t)nbsw * nlev;
   double* scat_g_sw_aerosol = scat_sw_aerosol + (size_t)nbsw * nlev;
@@ -553,9 +555,17 @@ void oracle_run_optics(const ecrad_config_t* c, int ncol, int nlev, int istartco
                        const ecrad_inputs_t* in, oracle_optics_buf_t* b)
 {
   oracle_get_albedos(c, ncol, istartcol, iendcol, in, b->sw_albedo_direct, b->sw_albedo_diffuse, b->lw_albedo);
+  if ((c->do_sw && c->i_gas_model_sw == ECRAD_GAS_IFSRRTMG) || (c->do_lw && c->i_gas_model_lw == ECRAD_GAS_IFSRRTMG))
+    oracle_gas_optics_rrtmg(c, ncol, nlev, istartcol, iendcol, in, b->lw_albedo, b->od_lw, b->od_sw, b->ssa_sw,
+                            b->planck_hl, b->lw_emission, b->incoming_sw);
+  else
   oracle_gas_optics_ecckd(c, ncol, nlev, istartcol, iendcol, in, b->lw_albedo, b->od_lw, b->od_sw, b->ssa_sw,
                           b->planck_hl, b->lw_emission, b->incoming_sw);
-  if (c->do_clouds) {
+  if (c->do_clouds && !c->use_general_cloud_optics) {
+    oracle_crop_cloud_fraction(c, ncol, nlev, istartcol, iendcol, in);
+    oracle_cloud_optics_fit(c, ncol, nlev, istartcol, iendcol, in, b->od_lw_cloud, b->ssa_lw_cloud,
+                            b->g_lw_cloud, b->od_sw_cloud, b->ssa_sw_cloud, b->g_sw_cloud);
+  } else if (c->do_clouds) {
     oracle_crop_cloud_fraction(c, ncol, nlev, istartcol, iendcol, in);
     oracle_general_cloud_optics(c, ncol, nlev, istartcol, iendcol, in, b->od_lw_cloud, b->ssa_lw_cloud,
                                 b->g_lw_cloud, b->od_sw_cloud, b->ssa_sw_cloud, b->g_sw_cloud);

@@ -77,3 +77,16 @@ def compare_flux(f1: Flux, f2: Flux, tol: float, cols=None):
     bad = {k: v for k, v in worst.items() if not v <= tol}
     assert not bad, f"fields beyond tolerance {tol}: {bad}"
     return worst
+
+
+def make_config_rrtmg(sw_solver="McICA", lw_solver=None, **overrides) -> Config:
+    """The reference's RRTMG test configuration test/ifs/configCY49R1.nam, expressed as its differences from
+    configCY49R1_ecckd.nam: gas_model_name "RRTMG-IFS", SOCRATES/Fu-IFS band cloud optics, cloud and aerosol
+    optics per band, nearest-interval longwave emissivity, spectral surface fluxes."""
+    from ecrad_amd.config import (IGasModelIFSRRTMG, IIceModelFu, ILiquidModelSOCRATES)
+    kw = dict(i_gas_model_sw=IGasModelIFSRRTMG, i_gas_model_lw=IGasModelIFSRRTMG, use_general_cloud_optics=False,
+              i_liq_model=ILiquidModelSOCRATES, i_ice_model=IIceModelFu, do_cloud_aerosol_per_sw_g_point=False,
+              do_cloud_aerosol_per_lw_g_point=False, do_nearest_spectral_lw_emiss=True, do_surface_sw_spectral_flux=True,
+              do_weighted_surface_mapping=False)
+    kw.update(overrides)
+    return make_config(sw_solver, lw_solver, **kw)
