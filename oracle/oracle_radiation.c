@@ -129,7 +129,7 @@ int ecrad_oracle_radiation(const ecrad_config_t* c, int ncol, int nlev, int ista
 {
   if (c->abi_version != ECRAD_ABI_VERSION) return ECRAD_EINVAL;
   if (istartcol < 1 || iendcol > ncol || iendcol < istartcol) return ECRAD_EINVAL;
-  if ((c->do_sw && c->i_gas_model_sw != ECRAD_GAS_ECCKD) || (c->do_lw && c->i_gas_model_lw != ECRAD_GAS_ECCKD))
+  if ((c->do_sw && c->i_gas_model_sw == ECRAD_GAS_MONOCHROMATIC) || (c->do_lw && c->i_gas_model_lw == ECRAD_GAS_MONOCHROMATIC))
     return ECRAD_EUNSUPPORTED;
   if (c->i_solver_sw == ECRAD_SOLVER_SPARTACUS || c->i_solver_lw == ECRAD_SOLVER_SPARTACUS) return ECRAD_EUNSUPPORTED;
   if (in->pressure_hl[(size_t)(istartcol - 1) + (size_t)ncol] < in->pressure_hl[istartcol - 1]) return ECRAD_EUNSUPPORTED;

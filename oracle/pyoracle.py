@@ -87,3 +87,106 @@ def optics_shapes(config, nlev, nloc) -> dict:
         "g_lw_cloud": (nloc, nlev, config.n_bands_lw), "od_sw_cloud": (nloc, nlev, config.n_bands_sw),
         "ssa_sw_cloud": (nloc, nlev, config.n_bands_sw), "g_sw_cloud": (nloc, nlev, config.n_bands_sw),
     }
+
+
+# ---------------------------------------------------------------------------------------------------
+# RRTMG: the oracle's gas optics for this model are the reference's OWN ifsrrtm routines
+# (oracle/_ref/libecrad_refrrtm.so, built by oracle/build_ref_rrtm.sh from /root/reference, unmodified; the
+# library travels to the GPU box with the repo).  What radiation_ifs_rrtm.F90 does around them is restated here.
+REF_RRTM_PATH = os.path.join(_HERE, "_ref", "libecrad_refrrtm.so")
+_DATA = os.path.join(_HERE, "..", "data")
+_ref_rrtm = None
+_NG_LW = [10, 12, 16, 14, 16, 8, 12, 8, 12, 6, 8, 8, 4, 2, 2, 2]
+
+
+def have_ref_rrtm() -> bool:
+    return os.path.exists(REF_RRTM_PATH) and os.path.exists(os.path.join(_DATA, "RADRRTM"))
+
+
+def ref_rrtm():
+    global _ref_rrtm
+    if _ref_rrtm is None:
+        L = C.CDLL(REF_RRTM_PATH)
+        d = os.path.abspath(_DATA).encode()          # RADRRTM / RADSRTM (data files of the reference)
+        L.ref_rrtm_setup(d, C.c_int(len(d)))
+        _ref_rrtm = L
+    return _ref_rrtm
+
+
+def _np_from(ptr, shape, dtype=np.float64):
+    n = int(np.prod(shape))
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double if dtype == np.float64 else C.c_int32)), shape=(n,)).reshape(shape)
+
+
+def rrtmg_gas_stage(config, ncol, nlev, cin):
+    """gas_optics + planck_function_atmos/_surf of radiation/radiation_ifs_rrtm.F90:216-852 for all ncol columns:
+    RRTM_PREPARE_GASES ... SRTM_GAS_OPTICAL_DEPTH by the reference library, then (numpy) the reversal of the level
+    order (:509, :593), max(min_gas_od, .) (:506-512, :590-594), the Planck function from TOTPLNK/DELWAVE (:618-852)
+    and the normalisation of the incoming solar flux (:552-560).  Returns dict of (ncol, nlev[+1], ng) arrays;
+    lw_emission is the surface Planck term before the (1 - albedo) factor."""
+    L = ref_rrtm()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    phl = np.ascontiguousarray(_np_from(cin.pressure_hl, (nlev + 1, ncol)))
+    thl = np.ascontiguousarray(_np_from(cin.temperature_hl, (nlev + 1, ncol)))
+    if not np.all(phl[1] > phl[0]):
+        raise NotImplementedError("the RRTMG oracle glue expects levels ordered from the top")
+    gas = _np_from(cin.gas_mixing_ratio, (12, nlev, ncol))
+    mu0 = np.ascontiguousarray(_np_from(cin.cos_sza, (ncol,))) if cin.cos_sza else np.zeros(ncol)
+    order = [1, 2, 6, 4, 12, 8, 9, 10, 11, 3]      # q co2 ch4 n2o no2 cfc11 cfc12 hcfc22 ccl4 o3 (gas codes)
+    gl = [np.ascontiguousarray(gas[k - 1]) for k in order]
+    od_lw = np.zeros((140, nlev, ncol), order="F"); pfrac = np.zeros((ncol, 140, nlev), order="F")
+    od_sw = np.zeros((ncol, nlev, 112), order="F"); ssa_sw = np.zeros((ncol, nlev, 112), order="F")
+    incsol = np.zeros((ncol, 112), order="F")
+    # a few columns at a time: the reference routines keep (ncol, 140, nlev) automatic arrays on the stack
+    for c0 in range(0, ncol, 4):
+        c1 = min(ncol, c0 + 4)
+        n = c1 - c0
+        cut = lambda a: np.ascontiguousarray(a[..., c0:c1])
+        o_lw = np.zeros((140, nlev, n), order="F"); o_pf = np.zeros((n, 140, nlev), order="F")
+        o_sw = np.zeros((n, nlev, 112), order="F"); o_ssa = np.zeros((n, nlev, 112), order="F"); o_inc = np.zeros((n, 112), order="F")
+        args = [cut(phl), cut(thl)] + [cut(a) for a in gl] + [cut(mu0)]
+        L.ref_rrtm_gas_optics(C.c_int(n), C.c_int(nlev), *[p(a) for a in args], p(o_lw), p(o_pf), p(o_sw), p(o_ssa), p(o_inc))
+        od_lw[:, :, c0:c1] = o_lw; pfrac[c0:c1] = o_pf; od_sw[c0:c1] = o_sw; ssa_sw[c0:c1] = o_ssa; incsol[c0:c1] = o_inc
+    out = {}
+    out["od_lw"] = np.ascontiguousarray(np.maximum(np.transpose(od_lw, (2, 1, 0))[:, ::-1, :], config.min_gas_od_lw))
+    pf = np.transpose(pfrac, (0, 2, 1))[:, ::-1, :]                               # (ncol, layer from top, 140)
+    t = np.load(os.path.join(_DATA, "rrtmg_tables.npz"))
+    totplnk, delwave = t["yoerrtwn.totplnk"], t["yoerrtwn.delwave"]
+    band = np.repeat(np.arange(16), _NG_LW)
+
+    def planck(T):
+        T = np.asarray(T)
+        ind = np.where(T >= 339.0, 180, np.where(T >= 160.0, (T - 159.0).astype(int), 1))
+        frac = np.where(T >= 339.0, T - 339.0, np.where(T >= 160.0, T - np.trunc(T), 0.0))
+        fac = 2.0 * np.arcsin(1.0) * 1.0e4 * delwave[band]
+        lo = totplnk[ind[..., None] - 1, band]
+        return fac * (lo + frac[..., None] * (totplnk[ind[..., None], band] - lo))
+
+    out["planck_hl"] = np.ascontiguousarray(planck(thl.T) * np.concatenate([pf[:, :1, :], pf], axis=1))
+    skin = _np_from(cin.skin_temperature, (ncol,)) if cin.skin_temperature else thl[-1]
+    out["lw_emission"] = np.ascontiguousarray(planck(skin) * pf[:, -1, :])
+    out["od_sw"] = np.ascontiguousarray(np.maximum(od_sw[:, ::-1, :], config.min_gas_od_sw))
+    out["ssa_sw"] = np.ascontiguousarray(ssa_sw[:, ::-1, :])
+    tot = incsol.sum(axis=1)
+    scale = np.where(mu0 > 0.0, cin.solar_irradiance / np.where(tot > 0, tot, 1.0), 1.0)
+    out["incoming_sw"] = np.ascontiguousarray(incsol * scale[:, None])
+    return out
+
+
+def make_rrtmg_backend(config, inner=None):
+    """``backend=`` callable for configurations with gas_model_name = "RRTMG-IFS": computes the gas-optics stage with
+    the reference's routines, hands it to the C oracle, then runs ``inner`` (default: the plain oracle backend)."""
+    from ecrad_amd import abi
+    inner = inner or backend
+
+    def _b(cconfig, ncol, nlev, istartcol, iendcol, cin, cflux) -> int:
+        stage = rrtmg_gas_stage(config, ncol, nlev, cin)
+        st = abi.Optics()
+        for k, a in stage.items():
+            setattr(st, k, abi.dptr(a))
+        lib().ecrad_oracle_set_gas_stage(C.byref(st))
+        try:
+            return inner(cconfig, ncol, nlev, istartcol, iendcol, cin, cflux)
+        finally:
+            lib().ecrad_oracle_set_gas_stage(None)
+    return _b
