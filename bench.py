@@ -42,13 +42,13 @@ def algorithmic_bytes_per_column(config, nlev, which, clear_sky):
     if which == "sw":
         a = 1 if config.use_aerosols else 0
         stage = 2 * W * nlev * (config.n_g_sw * (2 + a) + c * 3 * config.n_bands_sw)
-        n_gas = len(config.gas_optics_sw.single_gas) - 1
+        n_gas = (len(config.gas_optics_sw.single_gas) - 1) if config.rrtmg is None else 8   # RRTMG SW reads h2o,co2,o3,ch4,o2 (+n2o, 2 unused): count 8
         inputs = 2 * (nlev + 1) + n_gas * nlev + 1 + 2 * 6
         outputs = (6 if config.do_clear else 3) * (nlev + 1) + 7 * config.n_g_sw
     else:
         s = 1 if config.do_lw_cloud_scattering else 0
         stage = 2 * W * nlev * (config.n_g_lw * (1 + (nlev + 1) / nlev) + c * config.n_bands_lw * (1 + 2 * s))
-        n_gas = len(config.gas_optics_lw.single_gas) - 1
+        n_gas = (len(config.gas_optics_lw.single_gas) - 1) if config.rrtmg is None else 8   # h2o,co2,o3,n2o,co,ch4,o2 + cfc11/12/22/ccl4 folded: 8 of the arrays the LW bands read per layer on average
         inputs = 2 * (nlev + 1) + n_gas * nlev + 1 + 2
         outputs = (4 if config.do_clear else 2) * (nlev + 1) + (nlev + 1) + 4 * config.n_g_lw
     if c:
@@ -81,7 +81,16 @@ def cpu_baseline(config, workload, sample, seconds_target=12.0):
     from oracle import pyoracle
     pyoracle.build()
     nthreads = pyoracle.lib().ecrad_oracle_max_threads()
-    rad = Radiation(config, backend=pyoracle.make_blocked_backend(nblocksize=32, nthreads=nthreads))
+    blocked = pyoracle.make_blocked_backend(nblocksize=32, nthreads=nthreads)
+    kind, what = "port", "oracle/ (plain C, "
+    if config.rrtmg is not None:
+        # RRTMG: the gas optics are the reference's own ifsrrtm routines (oracle/_ref, compiled from the
+        # reference's sources), the rest the C restatement -- still a "port" as a whole
+        if not pyoracle.have_ref_rrtm():
+            raise RuntimeError("oracle/_ref/libecrad_refrrtm.so is missing (oracle/build_ref_rrtm.sh)")
+        blocked = pyoracle.make_rrtmg_backend(config, inner=blocked)
+        what = "the reference's ifsrrtm gas-optics routines (oracle/_ref, 1 thread) + oracle/ (plain C, "
+    rad = Radiation(config, backend=blocked)
     ncol, nlev, sl, th, gas, cloud, aer = sample
     nsample = ncol
     flux = Flux.allocate(config, ncol, nlev)
@@ -95,7 +104,7 @@ def cpu_baseline(config, workload, sample, seconds_target=12.0):
         if dt >= seconds_target or reps >= 200:
             break
     out = {"value": nsample * reps / dt, "unit": "columns/s", "cores": int(nthreads), "kind": "port",
-           "sample": f"{nsample} columns x {reps} repeats of the same synthetic workload, oracle/ (plain C, "
+           "sample": f"{nsample} columns x {reps} repeats of the same synthetic workload, {what}"
                      f"OpenMP over blocks of 32 columns as in driver/ecrad_driver.F90:348), {dt:.1f} s"}
     return out, flux
 
@@ -142,7 +151,12 @@ def main():
     spec = dict(BENCH_CONFIGS[args.workload])
     clear_sky = spec.pop("clear_sky")
     sw_solver = spec.pop("sw_solver")
-    config = make_config(sw_solver, **spec)
+    is_rrtmg = bool(spec.pop("rrtmg", False))
+    if is_rrtmg:
+        from helpers import make_config_rrtmg
+        config = make_config_rrtmg(sw_solver, **spec)
+    else:
+        config = make_config(sw_solver, **spec)
     rad = Radiation(config, backend="hip", device_id=local_rank)
     stream = torch.cuda.current_stream()
     rad.lib.ecrad_hip_set_stream(rad.handle, C.c_void_p(stream.cuda_stream))
@@ -230,7 +244,7 @@ def main():
         dom_kernel = f"{dom}_ica_kernel" if sw_solver != "Tripleclouds" else f"{dom}_tc_kernel"
         traffic = measured_traffic(dom_kernel)
         out = {
-            "metric": "columns/sec (SW+LW) at 137 lev, ecCKD-32", "value": value, "unit": "columns/s",
+            "metric": "columns/sec (SW+LW) at 137 lev, " + ("RRTMG 140/112" if is_rrtmg else "ecCKD-32"), "value": value, "unit": "columns/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",

@@ -33,7 +33,8 @@ def make_columns(config: Config, ncol: int, clear_sky: bool, seed: int = SEED, f
     set for the gas model and h2o_sat_liq computed (i.e. ready for Radiation.radiation)."""
     dc = DriverConfig()
     nb, nlev, sl0, th0, gas0, cloud0, aer0 = read_input(base_file, config, dc)
-    gas0.set_units(1)      # IVolumeMixingRatio, as set_gas_units does for ecCKD
+    # set_gas_units: volume mixing ratios for ecCKD, mass mixing ratios for RRTMG (radiation_ifs_rrtm.F90:203-213)
+    gas0.set_units(0 if getattr(config, "rrtmg", None) is not None else 1)
     rng = np.random.default_rng([seed, first_column])
     idx = (first_column + np.arange(ncol)) % nb
     ps_scale = rng.uniform(0.95, 1.05, ncol)
@@ -96,4 +97,9 @@ BENCH_CONFIGS = {
     "mcica_noaer": dict(sw_solver="McICA", use_aerosols=False, clear_sky=False),
     "mcica_vectorizable": dict(sw_solver="McICA", use_aerosols=True, clear_sky=False, use_vectorizable_generator=True),
     "homogeneous_clear_aer": dict(sw_solver="Homogeneous", use_aerosols=True, clear_sky=True),
+    # BASELINE configs[2]: RRTMG 140/112 g-points, McICA with clouds (the reference's default configuration
+    # test/ifs/configCY49R1.nam: SOCRATES/Fu band cloud optics, 12 aerosol types, no LW aerosol scattering)
+    "mcica_rrtmg": dict(sw_solver="McICA", use_aerosols=True, clear_sky=False, rrtmg=True, do_lw_aerosol_scattering=False),
+    "mcica_rrtmg_noaer": dict(sw_solver="McICA", use_aerosols=False, clear_sky=False, rrtmg=True, do_lw_aerosol_scattering=False),
+    "tripleclouds_rrtmg": dict(sw_solver="Tripleclouds", use_aerosols=True, clear_sky=False, rrtmg=True, do_lw_aerosol_scattering=False),
 }
