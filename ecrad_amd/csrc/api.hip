@@ -135,6 +135,10 @@ int padded_ng(int ng) { return ng <= 16 ? 16 : (ng <= 32 ? 32 : (ng <= 64 ? 64 :
 // count that wastes the fewest lanes (ties: fewer, wider chunks).
 int chunk_lanes(int ng, int* nchunk) {
   if (ng <= 64) { *nchunk = 1; return padded_ng(ng); }
+  if (const char* e = getenv("ECRAD_CHUNK_LANES")) {      // tuning knob (tools/): force the chunk width
+    const int n = atoi(e);
+    if (n == 16 || n == 32 || n == 64) { *nchunk = (ng + n - 1) / n; return n; }
+  }
   int best = 64, best_pad = ((ng + 63) / 64) * 64;
   for (int n : {32, 16}) {
     const int pad = ((ng + n - 1) / n) * n;

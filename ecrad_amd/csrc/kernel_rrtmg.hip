@@ -7,8 +7,9 @@
 //   rrtmg_setcoef_kernel   lane = column (the caller's arrays are column-fastest: coalesced), levels in
 //                          sequence from the surface: per-layer interpolation records, the tropopause
 //                          counts and, per shortwave band, the level of the solar source term;
-//   rrtmg_taumol_kernel    block = (one level, 64 columns); the 30 bands in turn, lanes = (g-point of the
-//                          band, column) so that a wave always runs ONE descriptor (no divergence); writes
+//   rrtmg_taumol_kernel    block = (one level, 64 columns), whose setcoef records are staged in LDS once; the 30
+//                          bands in turn, lanes = (g-point of the band, column), the lower/upper-atmosphere
+//                          regimes one after the other so that a wave always runs ONE descriptor; writes
 //                          the stage-interface arrays od_lw, planck_hl, lw_emission, od_sw, ssa_sw and the
 //                          un-normalised incoming_sw, g fastest, for the solver kernels to read;
 //   rrtmg_incoming_kernel  normalises incoming_sw to the solar irradiance (radiation_ifs_rrtm.F90:552-560).
@@ -93,6 +94,17 @@ __global__ __launch_bounds__(kBlock) void rrtmg_setcoef_kernel(const DevRrtmg* _
 }
 
 constexpr int kTileCols = 64;
+constexpr int kRecD = LD_N > SD_N ? LD_N : SD_N, kRecI = LI_N > SI_N ? LI_N : SI_N;
+
+// The setcoef records of the block's 64 columns, staged in LDS: field-major, column fastest (as in the work
+// arrays, so the staging loads are fully coalesced); all g-point lanes of a column read the same word (broadcast)
+struct LdsRec {
+  const double* d_;
+  const int* i_;
+  int c;
+  ECRAD_DEV double d(int f) const { return d_[f * kTileCols + c]; }
+  ECRAD_DEV int i(int f) const { return i_[f * kTileCols + c]; }
+};
 
 __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __restrict__ Tp, DevInputs in, RrtmgWork w, DevGasStage out,
                                                               int do_lw, int do_sw) {
@@ -104,48 +116,87 @@ __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __
   const size_t stride = (size_t)nlev * nloc;
   const LevelOrder ord = level_order(in);
   const int tid = threadIdx.x;
+  __shared__ double s_d[kRecD * kTileCols];
+  __shared__ int s_i[kRecI * kTileCols];
+  __shared__ double s_t[3 * kTileCols];      // temperature at the half levels above / below the layer, skin temperature
+  __shared__ int s_sun[kTileCols];
+  const size_t rec0 = (size_t)lev * nloc + c0;
+  for (int i = tid; i < kTileCols; i += kBlock) {
+    const int cloc = c0 + i;
+    if (cloc < nloc) {
+      const int col = in.istartcol - 1 + cloc;
+      s_t[i] = in.temperature_hl[col + ncol * ord.half(lev)];
+      s_t[kTileCols + i] = in.temperature_hl[col + ncol * ord.half(lev + 1)];
+      s_t[2 * kTileCols + i] = in.skin_temperature[col];
+      s_sun[i] = (do_sw && in.cos_sza[col] > 0.0) ? 1 : 0;
+    }
+  }
+  __syncthreads();
   if (do_lw) {
+    for (int i = tid; i < LD_N * kTileCols; i += kBlock) {
+      const int f = i / kTileCols, c = i % kTileCols;
+      if (c0 + c < nloc) s_d[i] = w.lw_d[(size_t)f * stride + rec0 + c];
+    }
+    for (int i = tid; i < LI_N * kTileCols; i += kBlock) {
+      const int f = i / kTileCols, c = i % kTileCols;
+      if (c0 + c < nloc) s_i[i] = w.lw_i[(size_t)f * stride + rec0 + c];
+    }
+    __syncthreads();
     for (int ib = 0; ib < kNBandLw; ++ib) {
       const LwBand& B = T.lw[ib];
       const int ng = B.ng;
       const int nbp = ng <= 2 ? 2 : (ng <= 4 ? 4 : (ng <= 8 ? 8 : 16));
       const int items = nbp * kTileCols;
       for (int i = tid; i < items; i += kBlock) {
-        const int ig = i & (nbp - 1), cloc = c0 + i / nbp;
-        if (ig >= ng || cloc >= nloc) continue;
-        const int col = in.istartcol - 1 + cloc;
-        const RecView r{w.lw_d, w.lw_i, stride, (size_t)lev * nloc + cloc};
-        double tau, pfrac;
-        lw_gpoint(T, B, r, ig, tau, pfrac);
+        const int ig = i & (nbp - 1), c = i / nbp, cloc = c0 + c;
+        const bool active = ig < ng && cloc < nloc;
+        const LdsRec r{s_d, s_i, c};
+        const bool lower = active && r.i(LI_LOWER) != 0;
+        double tau = 0.0, pfrac = 0.0;
+        // the two regimes in turn, each with a wave-uniform descriptor (most waves have lanes in one of them only)
+        for (int rg = 0; rg < 2; ++rg)
+          if (active && lower == (rg == 0)) lw_gpoint_regime(T, B, B.reg[rg], rg == 0, r, ig, tau, pfrac);
+        if (!active) continue;
         const int g = B.g0 + ig;
         out.od_lw[g + (size_t)kNgLw * (lev + (size_t)nlev * cloc)] = dmax(T.min_gas_od_lw, tau);
         // planck_hl(g, half level) = band Planck function at the half level x fraction of the layer ABOVE it
         // (of the top layer for the top half level): radiation_ifs_rrtm.F90:715-724
         const size_t op = g + (size_t)kNgLw * (lev + (size_t)(nlev + 1) * cloc);
-        out.planck_hl[op + kNgLw] = planck_band(T, in.temperature_hl[col + ncol * ord.half(lev + 1)], ib) * pfrac;
-        if (lev == 0) out.planck_hl[op] = planck_band(T, in.temperature_hl[col + ncol * ord.half(0)], ib) * pfrac;
+        out.planck_hl[op + kNgLw] = planck_band(T, s_t[kTileCols + c], ib) * pfrac;
+        if (lev == 0) out.planck_hl[op] = planck_band(T, s_t[c], ib) * pfrac;
         // surface emission before the (1 - albedo) factor: planck_function_surf with the lowest layer's fractions
-        if (lev == nlev - 1) out.lw_emission[g + (size_t)kNgLw * cloc] = planck_band(T, in.skin_temperature[col], ib) * pfrac;
+        if (lev == nlev - 1) out.lw_emission[g + (size_t)kNgLw * cloc] = planck_band(T, s_t[2 * kTileCols + c], ib) * pfrac;
       }
     }
+    __syncthreads();
   }
   if (do_sw) {
+    for (int i = tid; i < SD_N * kTileCols; i += kBlock) {
+      const int f = i / kTileCols, c = i % kTileCols;
+      if (c0 + c < nloc && s_sun[c]) s_d[i] = w.sw_d[(size_t)f * stride + rec0 + c];
+    }
+    for (int i = tid; i < SI_N * kTileCols; i += kBlock) {
+      const int f = i / kTileCols, c = i % kTileCols;
+      if (c0 + c < nloc && s_sun[c]) s_i[i] = w.sw_i[(size_t)f * stride + rec0 + c];
+    }
+    __syncthreads();
     for (int ib = 0; ib < kNBandSw; ++ib) {
       const SwBand& B = T.sw[ib];
       const int ng = B.ng;
       const int nbp = ng <= 2 ? 2 : (ng <= 4 ? 4 : (ng <= 8 ? 8 : 16));
       const int items = nbp * kTileCols;
       for (int i = tid; i < items; i += kBlock) {
-        const int ig = i & (nbp - 1), cloc = c0 + i / nbp;
+        const int ig = i & (nbp - 1), c = i / nbp, cloc = c0 + c;
         if (ig >= ng || cloc >= nloc) continue;
-        const int col = in.istartcol - 1 + cloc;
         const int g = B.g0 + ig;
         const size_t o = g + (size_t)kNgSw * (lev + (size_t)nlev * cloc);
-        if (in.cos_sza[col] > 0.0) {
-          const RecView r{w.sw_d, w.sw_i, stride, (size_t)lev * nloc + cloc};
+        if (s_sun[c]) {
+          const LdsRec r{s_d, s_i, c};
+          const bool lower = r.i(SI_LOWER) != 0;
           const bool want = w.isol[(size_t)ib * nloc + cloc] == lev;
-          double taug, taur, sflux = 0.0;
-          sw_gpoint(T, B, r, ig, want, taug, taur, sflux);
+          double taug = 0.0, taur = 0.0, sflux = 0.0;
+          for (int rg = 0; rg < 2; ++rg)
+            if (lower == (rg == 0)) sw_gpoint_regime(T, B, B.reg[rg], rg == 0, r, ig, want, taug, taur, sflux);
           const double od = taur + taug;
           out.od_sw[o] = dmax(T.min_gas_od_sw, od);
           out.ssa_sw[o] = taur / od;

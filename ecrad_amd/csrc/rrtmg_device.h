@@ -318,10 +318,11 @@ ECRAD_HD double lw_binary_half(const double* A, int ng, int ind, int nsp, const 
 }
 
 // Longwave optical depth and Planck fraction of g-point `ig` (0-based within the band) of one layer
+// (`q` = b.reg[lower ? 0 : 1] is passed in so that a caller whose lanes all share the regime can keep the
+// descriptor tests wave-uniform)
 template <class R>
-ECRAD_HD void lw_gpoint(const DevRrtmg& T, const LwBand& b, const R& r, int ig, double& tau_out, double& pfrac_out) {
-  const bool lower = r.i(LI_LOWER) != 0;
-  const LwRegime& q = b.reg[lower ? 0 : 1];
+ECRAD_HD void lw_gpoint_regime(const DevRrtmg& T, const LwBand& b, const LwRegime& q, bool lower, const R& r, int ig,
+                               double& tau_out, double& pfrac_out) {
   const int ng = b.ng;
   const double* tab = T.tab;
   const int jp = r.i(LI_JP), jt = r.i(LI_JT), jt1 = r.i(LI_JT1);
@@ -417,12 +418,16 @@ ECRAD_HD void lw_gpoint(const DevRrtmg& T, const LwBand& b, const R& r, int ig, 
   pfrac_out = pfrac;
 }
 
+template <class R>
+ECRAD_HD void lw_gpoint(const DevRrtmg& T, const LwBand& b, const R& r, int ig, double& tau_out, double& pfrac_out) {
+  const bool lower = r.i(LI_LOWER) != 0;
+  lw_gpoint_regime(T, b, b.reg[lower ? 0 : 1], lower, r, ig, tau_out, pfrac_out);
+}
+
 // Shortwave gas optical depth, Rayleigh optical depth and (when `want_sflux`) the solar source term
 template <class R>
-ECRAD_HD void sw_gpoint(const DevRrtmg& T, const SwBand& b, const R& r, int ig, bool want_sflux, double& taug_out, double& taur_out,
-                        double& sflux_out) {
-  const bool lower = r.i(SI_LOWER) != 0;
-  const SwRegime& q = b.reg[lower ? 0 : 1];
+ECRAD_HD void sw_gpoint_regime(const DevRrtmg& T, const SwBand& b, const SwRegime& q, bool lower, const R& r, int ig, bool want_sflux,
+                               double& taug_out, double& taur_out, double& sflux_out) {
   const int ng = b.ng;
   const double* tab = T.tab;
   const int jp = r.i(SI_JP), jt = r.i(SI_JT), jt1 = r.i(SI_JT1);
@@ -480,6 +485,13 @@ ECRAD_HD void sw_gpoint(const DevRrtmg& T, const SwBand& b, const R& r, int ig, 
       sflux_out = s0 + m.f * (s1 - s0);
     }
   }
+}
+
+template <class R>
+ECRAD_HD void sw_gpoint(const DevRrtmg& T, const SwBand& b, const R& r, int ig, bool want_sflux, double& taug_out, double& taur_out,
+                        double& sflux_out) {
+  const bool lower = r.i(SI_LOWER) != 0;
+  sw_gpoint_regime(T, b, b.reg[lower ? 0 : 1], lower, r, ig, want_sflux, taug_out, taur_out, sflux_out);
 }
 
 // The level at which a band's solar source term is taken: a replay of the sequential logic of
