@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# PyTorch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so.7).  Whichever copy a process loads first is
+# the one everything else binds to, and torch cannot find the GPU if libecrad_hip.so has already brought in
+# /opt/rocm's: import torch before the library is loaded (bench.py does the same).
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

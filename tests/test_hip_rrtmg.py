@@ -143,3 +143,117 @@ def test_band_cloud_optics_and_aerosols_match_oracle(ref):
         a, b = (got[k][day], want[k][day]) if k in ("od_sw", "ssa_sw", "g_sw", "incoming_sw") else (got[k], want[k])
         assert rel_err(a, b, floor_frac=1e-9) < 1e-9, k
     rad.close()
+
+
+# ---- the edge cases of test_hip_parity.py, with the RRTMG gas optics in front of the solvers ---------------------
+def test_rrtmg_column_subrange(ref):
+    """istartcol..iendcol inside the arrays: columns outside keep their values (the gas-optics pass, its work arrays
+    and the stage arrays are indexed by the local column)."""
+    from test_hip_parity import TOL as TOL_E  # noqa: F401  (same tolerance)
+    c1, c2 = make_config_rrtmg("McICA", do_lw_aerosol_scattering=False), make_config_rrtmg("McICA", do_lw_aerosol_scattering=False)
+    f_hip, _, rad = run_case(c1, "hip", columns=(6, 21))
+    for name, a in f_hip.arrays.items():
+        if name.startswith("cloud_cover"):
+            assert np.all(a[:5] == -1.0) and np.all(a[21:] == -1.0)
+        elif name in abi.FLUX_PROFILE_FIELDS:
+            assert np.all(a[:, :5] == 0.0) and np.all(a[:, 21:] == 0.0), name
+        else:
+            assert np.all(a[:5] == 0.0) and np.all(a[21:] == 0.0), name
+    f_ora, _, _ = run_case(c2, ref.make_rrtmg_backend(c2), columns=(6, 21))
+    worst = compare_flux(f_hip, f_ora, 1.0, cols=(6, 21))
+    bad = {k: v for k, v in worst.items() if v > (TOL_SPECTRAL if k.endswith(("_g", "_band", "_canopy")) else TOL)}
+    assert not bad, bad
+    rad.close()
+
+
+@pytest.mark.parametrize("solver", ["McICA", "Tripleclouds"])
+def test_rrtmg_surface_first_level_order(solver, ref):
+    """radiation_reverse with RRTMG: the setcoef pass walks the levels from the surface whatever the caller's order."""
+    from test_hip_parity import _reverse_levels
+    c1, c2 = make_config_rrtmg(solver, do_lw_aerosol_scattering=False), make_config_rrtmg(solver, do_lw_aerosol_scattering=False)
+    f_rev, _, rad = run_case(c1, "hip", inputs=_reverse_levels(load_meridian(c1)))
+    rad.close()
+    f_ora, _, _ = run_case(c2, ref.make_rrtmg_backend(c2))
+    for name, a in f_rev.arrays.items():
+        b = f_ora.arrays[name]
+        if name in abi.FLUX_PROFILE_FIELDS:
+            a = a[::-1, :]
+        assert rel_err(a, b) <= (TOL_SPECTRAL if name.endswith(("_g", "_band", "_canopy")) else TOL), name
+
+
+@pytest.mark.parametrize("solver", ["McICA", "Tripleclouds"])
+def test_rrtmg_many_columns_bitwise(solver):
+    """Size-independent property: 300 copies of the 32 meridian columns (9 600 columns: 150 column tiles per level in
+    the gas-optics pass, several column groups per persistent solver block, 9/7 chunk launches) give 300
+    bit-identical copies of the 32-column result."""
+    from test_hip_parity import _replicate
+    config = make_config_rrtmg(solver, do_lw_aerosol_scattering=False)
+    f32, _, rad = run_case(config, "hip")
+    rad.close()
+    times = 300
+    config2 = make_config_rrtmg(solver, do_lw_aerosol_scattering=False)
+    f_big, _, rad2 = run_case(config2, "hip", inputs=_replicate(load_meridian(config2), times))
+    rad2.close()
+    for name, a in f_big.arrays.items():
+        b = f32.arrays[name]
+        if a.ndim == 1:
+            want = np.concatenate([b] * times)
+        elif a.shape[-1] == 32 * times:
+            want = np.concatenate([b] * times, axis=-1)
+        else:
+            want = np.concatenate([b] * times, axis=0)
+        assert np.array_equal(a, want), name
+
+
+def test_rrtmg_device_memory_mode_matches_host_memory_mode():
+    """ECRAD_MEM_DEVICE (what bench.py times) gives the same bits as ECRAD_MEM_HOST, incl. a column sub-range."""
+    import torch
+    from ecrad_amd.device import DeviceCase
+    from ecrad_amd.types import Flux
+    config = make_config_rrtmg("McICA", do_lw_aerosol_scattering=False)
+    f_host, _, rad = run_case(config, "hip", columns=(3, 30))
+    ncol, nlev, sl, th, gas, cloud, aer = load_meridian(config)
+    rad.set_gas_units(gas)
+    th.calc_saturation_wrt_liquid()
+    flux = Flux.allocate(config, ncol, nlev)
+    case = DeviceCase(config, ncol, nlev, sl, th, gas, cloud, aer, flux)
+    st = rad.lib.ecrad_hip_radiation(rad.handle, ncol, nlev, 3, 30, C.byref(case.inputs), C.byref(case.flux))
+    assert st == 0, rad.lib.ecrad_hip_last_error(rad.handle).decode()
+    rad.lib.ecrad_hip_synchronize(rad.handle)
+    torch.cuda.synchronize()
+    case.flux_to_host(flux)
+    for name, a in flux.arrays.items():
+        assert np.array_equal(a, f_host.arrays[name]), name
+    rad.close()
+
+
+@pytest.mark.parametrize("nkeep", [120, 100, 90])
+def test_rrtmg_other_level_counts(nkeep, ref):
+    """Level counts other than 137 (the lowest nkeep levels).  The top must stay above 95.6 hPa: in a column that lies
+    wholly in RRTMG's "lower atmosphere" the reference never assigns the solar source term of the bands that look
+    for it in the upper atmosphere (srtm_taumol16.F90 etc.; ZSFLXZEN of srtm_gas_optical_depth.F90:109 is an
+    uninitialised local), so there is nothing defined to compare with; the HIP path returns zero there
+    (test_rrtmg_column_below_the_tropopause_is_defined)."""
+    from test_hip_parity import _bottom_levels
+    c1, c2 = make_config_rrtmg("McICA", do_lw_aerosol_scattering=False), make_config_rrtmg("McICA", do_lw_aerosol_scattering=False)
+    f_hip, _, rad = run_case(c1, "hip", inputs=_bottom_levels(load_meridian(c1), nkeep))
+    rad.close()
+    f_ora, _, _ = run_case(c2, ref.make_rrtmg_backend(c2), inputs=_bottom_levels(load_meridian(c2), nkeep))
+    worst = compare_flux(f_hip, f_ora, 1.0)
+    bad = {k: v for k, v in worst.items() if v > (TOL_SPECTRAL if k.endswith(("_g", "_band", "_canopy")) else TOL)}
+    assert not bad, bad
+
+
+def test_rrtmg_column_below_the_tropopause_is_defined():
+    """33 lowest levels only: every layer is "lower atmosphere".  The reference's result is undefined there (see
+    above); the HIP path gives finite fluxes, with no incoming flux in the bands whose source term is never assigned."""
+    from test_hip_parity import _bottom_levels
+    c1 = make_config_rrtmg("McICA", do_lw_aerosol_scattering=False)
+    f_hip, _, rad = run_case(c1, "hip", inputs=_bottom_levels(load_meridian(c1), 33))
+    rad.close()
+    for name, a in f_hip.arrays.items():
+        assert np.all(np.isfinite(a)), name
+    day = f_hip.arrays["sw_dn"][0] > 0
+    assert day.any()
+    band = f_hip.arrays["sw_dn_surf_band"][day]
+    assert np.all(band[:, [0, 1, 11, 12, 13]] == 0.0) and np.all(band[:, 2:11] > 0.0)
