@@ -48,6 +48,9 @@ template <typename TAB, int NGP, int MODE, bool WIDE>
 __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
+  // Stage mode (gas optics from the RRTMG pass): the stage values of kStageBatch layers are requested together and
+  // parked in LDS (each lane its own words), so that a layer does not wait for HBM on its own
+  __shared__ double stage_ring[sizeof(TAB) == 8 ? kStageBatch * 3 * kBlock : 1];
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
   const int glane = tid % NGP, cib = tid / NGP;
@@ -164,11 +167,31 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
         double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
         ECRAD_LAP(tm, 1, planck_bot);   // table + Planck loads returned
         double od = gas_combine<TAB>(nq, L, slot, quads);
+        double od_scaling_staged = 0.0;
+        bool staged = false;
         if constexpr (sizeof(TAB) == 8) {
-          const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+          const SpectralArgs& b = kernarg_block<SpectralArgs>();
+          const DevGasStage& gs = b.in.gs;
           if (gs.od_lw) {
-            od = gs.od_lw[g + (size_t)ng * (lev + (size_t)nlev * cloc)];
-            planck_bot = gs.planck_hl[g + (size_t)ng * (lev + 1 + (size_t)(nlev + 1) * cloc)];
+            staged = true;
+            if (j % kStageBatch == 0) {
+              double v[kStageBatch][3];
+#pragma unroll
+              for (int k = 0; k < kStageBatch; ++k) {
+                const int lv = lev + k < nlev ? lev + k : nlev - 1;
+                v[k][0] = gs.od_lw[g + (size_t)ng * (lv + (size_t)nlev * cloc)];
+                v[k][1] = gs.planck_hl[g + (size_t)ng * (lv + 1 + (size_t)(nlev + 1) * cloc)];
+                v[k][2] = MODE == 2 ? b.prep.od_scaling_lw[g + (size_t)ng * (lv + (size_t)nlev * cloc)] : 0.0;
+              }
+#pragma unroll
+              for (int k = 0; k < kStageBatch; ++k)
+#pragma unroll
+                for (int f = 0; f < 3; ++f) stage_ring[(k * 3 + f) * kBlock + tid] = v[k][f];
+            }
+            const int k = j % kStageBatch;
+            od = stage_ring[(k * 3 + 0) * kBlock + tid];
+            planck_bot = stage_ring[(k * 3 + 1) * kBlock + tid];
+            od_scaling_staged = stage_ring[(k * 3 + 2) * kBlock + tid];
           }
         }
 #if ECRAD_PIPELINE_LOADS
@@ -194,7 +217,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
             const SpectralArgs& b = kernarg_block<SpectralArgs>();
             const CloudLayer cl = cloud_layer<false, sizeof(TAB) == 8>(b.cfg, L, slot, ib);
             double od_cloud_new = cl.od;
-            if (MODE == 2) od_cloud_new = b.prep.od_scaling_lw[g + (size_t)ng * (lev + (size_t)nlev * cloc)] * cl.od;
+            if (MODE == 2) od_cloud_new = (staged ? od_scaling_staged : b.prep.od_scaling_lw[g + (size_t)ng * (lev + (size_t)nlev * cloc)]) * cl.od;
             const double od_total = od + od_cloud_new;
             LwCoef c2;
             if (cloud_scattering) {

@@ -173,6 +173,8 @@ template <typename TAB, int NGP, int MODE, bool SPEC, bool WIDE>
 __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
+  // Stage mode (gas optics from the RRTMG pass): see kernel_ica_lw.hip
+  __shared__ double stage_ring[sizeof(TAB) == 8 ? kStageBatch * 3 * kBlock : 1];
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
   const int glane = tid % NGP, cib = tid / NGP;
@@ -280,12 +282,32 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
           double ssa = L.D(F_SM, slot) * ray_g;       // Rayleigh optical depth
           od = od + ssa;
           ssa = ssa / od;
+          double od_scaling_staged = 0.0;
+          bool staged = false;
           if constexpr (sizeof(TAB) == 8) {
-            const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+            const SpectralArgs& b = kernarg_block<SpectralArgs>();
+            const DevGasStage& gs = b.in.gs;
             if (gs.od_sw) {
-              const size_t o = g + (size_t)ng * (lev + (size_t)nlev * cloc);
-              od = gs.od_sw[o];
-              ssa = gs.ssa_sw[o];
+              staged = true;
+              const int k = (nl - 1 - j) % kStageBatch;
+              if (k == 0) {       // this layer and the kStageBatch-1 above it
+                double v[kStageBatch][3];
+#pragma unroll
+                for (int kk = 0; kk < kStageBatch; ++kk) {
+                  const int lv = lev - kk >= 0 ? lev - kk : 0;
+                  const size_t o = g + (size_t)ng * (lv + (size_t)nlev * cloc);
+                  v[kk][0] = gs.od_sw[o];
+                  v[kk][1] = gs.ssa_sw[o];
+                  v[kk][2] = MODE == 2 ? b.prep.od_scaling_sw[o] : 0.0;
+                }
+#pragma unroll
+                for (int kk = 0; kk < kStageBatch; ++kk)
+#pragma unroll
+                  for (int f = 0; f < 3; ++f) stage_ring[(kk * 3 + f) * kBlock + tid] = v[kk][f];
+              }
+              od = stage_ring[(k * 3 + 0) * kBlock + tid];
+              ssa = stage_ring[(k * 3 + 1) * kBlock + tid];
+              od_scaling_staged = stage_ring[(k * 3 + 2) * kBlock + tid];
             }
           }
           double asym = 0.0;
@@ -312,7 +334,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
                 if (ssa_total > 0.0 && od_total > 0.0)
                   g_total = (asym * ssa * od + cl.g * cl.ssa * cl.od) / (ssa_total * od_total);
               } else {           // radiation_mcica_sw.F90:250-268
-                const double od_cloud_new = b.prep.od_scaling_sw[g + (size_t)ng * (lev + (size_t)nlev * cloc)] * cl.od;
+                const double od_cloud_new = (staged ? od_scaling_staged : b.prep.od_scaling_sw[g + (size_t)ng * (lev + (size_t)nlev * cloc)]) * cl.od;
                 od_total = od + od_cloud_new;
                 if (od_total > 0.0) {
                   const double scat_od = ssa * od + cl.ssa * od_cloud_new;

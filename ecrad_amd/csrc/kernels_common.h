@@ -11,6 +11,10 @@
 namespace ecrad {
 
 constexpr int kBlock = 256;
+#ifndef ECRAD_STAGE_BATCH
+#define ECRAD_STAGE_BATCH 4     // layers of RRTMG stage values (od, Planck / ssa, od_scaling) requested together by the ICA kernels
+#endif
+constexpr int kStageBatch = ECRAD_STAGE_BATCH;
 // minimum waves per SIMD the register allocator must leave room for (2nd __launch_bounds__ argument)
 #ifndef ECRAD_MIN_WAVES
 #define ECRAD_MIN_WAVES 3
