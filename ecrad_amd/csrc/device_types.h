@@ -118,6 +118,11 @@ struct DevConfig {
 // (1 - albedo) factor; levels top-down.
 struct DevGasStage {
   double *od_lw, *planck_hl, *lw_emission, *od_sw, *ssa_sw, *incoming_sw;
+  // Aerosols folded into the stage arrays by the gas-optics pass (optics per band, ICA-type solvers): od_lw then
+  // includes the aerosol absorption, (od_sw, ssa_sw, g_sw) are the merged gas + aerosol properties
+  // (radiation_aerosol_optics.F90:739-818), and the solver kernels skip their own aerosol optics.
+  double* g_sw;
+  int aer_folded_lw, pad_;
 };
 
 // Work arrays of the RRTMG pass: per-(column, level) interpolation records, [field][level][local column]

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
     const int aer_type = aerosol_lane_type(cfg, glane);
     const bool have_clear_out = cfg.do_clear != 0;
     const bool do_deriv = cfg.do_lw_derivatives != 0 && a.fx.lw_derivatives != nullptr;
-    const bool use_aerosols = cfg.use_aerosols != 0;
+    const bool use_aerosols = cfg.use_aerosols != 0 && !a.in.gs.aer_folded_lw;   // (folded: od_lw of the RRTMG pass includes them)
     const bool cloud_scattering = cfg.do_lw_cloud_scattering != 0;
     const double cloud_fraction_threshold = cfg.cloud_fraction_threshold;
 

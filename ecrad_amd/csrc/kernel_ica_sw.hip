@@ -217,7 +217,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
     const int aer_type = aerosol_lane_type(cfg, glane);
     const double ray_g = m.rayleigh_molar_scat[g];
     const bool have_clear_out = cfg.do_clear != 0;
-    const unsigned flags = (cfg.use_aerosols ? SWF_AEROSOLS : 0) | (cfg.do_sw_delta_scaling_with_gases ? SWF_DELTA_GASES : 0);
+    // (aerosols folded into the stage arrays by the RRTMG pass: od/ssa/g arrive merged)
+    const unsigned flags = ((cfg.use_aerosols && !a.in.gs.g_sw) ? SWF_AEROSOLS : 0) | (cfg.do_sw_delta_scaling_with_gases ? SWF_DELTA_GASES : 0);
     const double cloud_fraction_threshold = cfg.cloud_fraction_threshold;
 
     const int cloc_raw = grp * CPB + cib;
@@ -282,35 +283,38 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
           double ssa = L.D(F_SM, slot) * ray_g;       // Rayleigh optical depth
           od = od + ssa;
           ssa = ssa / od;
-          double od_scaling_staged = 0.0;
+          double od_scaling_staged = 0.0, asym_staged = 0.0;
           bool staged = false;
           if constexpr (sizeof(TAB) == 8) {
             const SpectralArgs& b = kernarg_block<SpectralArgs>();
             const DevGasStage& gs = b.in.gs;
             if (gs.od_sw) {
               staged = true;
-              const int k = (nl - 1 - j) % kStageBatch;
-              if (k == 0) {       // this layer and the kStageBatch-1 above it
-                double v[kStageBatch][3];
+              constexpr int NV = 4, NB = kStageBatch * 3 / NV;     // od, ssa, od_scaling, g of NB layers
+              const int k = (nl - 1 - j) % NB;
+              if (k == 0) {       // this layer and the NB-1 above it
+                double v[NB][NV];
 #pragma unroll
-                for (int kk = 0; kk < kStageBatch; ++kk) {
+                for (int kk = 0; kk < NB; ++kk) {
                   const int lv = lev - kk >= 0 ? lev - kk : 0;
                   const size_t o = g + (size_t)ng * (lv + (size_t)nlev * cloc);
                   v[kk][0] = gs.od_sw[o];
                   v[kk][1] = gs.ssa_sw[o];
                   v[kk][2] = MODE == 2 ? b.prep.od_scaling_sw[o] : 0.0;
+                  v[kk][3] = gs.g_sw ? gs.g_sw[o] : 0.0;
                 }
 #pragma unroll
-                for (int kk = 0; kk < kStageBatch; ++kk)
+                for (int kk = 0; kk < NB; ++kk)
 #pragma unroll
-                  for (int f = 0; f < 3; ++f) stage_ring[(kk * 3 + f) * kBlock + tid] = v[kk][f];
+                  for (int f = 0; f < NV; ++f) stage_ring[(kk * NV + f) * kBlock + tid] = v[kk][f];
               }
-              od = stage_ring[(k * 3 + 0) * kBlock + tid];
-              ssa = stage_ring[(k * 3 + 1) * kBlock + tid];
-              od_scaling_staged = stage_ring[(k * 3 + 2) * kBlock + tid];
+              od = stage_ring[(k * NV + 0) * kBlock + tid];
+              ssa = stage_ring[(k * NV + 1) * kBlock + tid];
+              od_scaling_staged = stage_ring[(k * NV + 2) * kBlock + tid];
+              asym_staged = stage_ring[(k * NV + 3) * kBlock + tid];
             }
           }
-          double asym = 0.0;
+          double asym = asym_staged;
           if (flags & SWF_AEROSOLS) {
             const SpectralArgs& b = kernarg_block<SpectralArgs>();
             AerosolLayer al = aerosol_layer<true, NGP>(b.cfg, b.in, L, slot, col, lev, ib, aer_type);

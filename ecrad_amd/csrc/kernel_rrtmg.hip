@@ -16,6 +16,7 @@
 // Levels are handled top-down (layer 0 = top) whatever the caller's order (LevelOrder); the reference's
 // routines count from the surface, k = nlev - layer.
 #include "kernels_common.h"
+#include "optics_device.h"
 #include "rrtmg_device.h"
 #include "launch.h"
 
@@ -106,9 +107,108 @@ struct LdsRec {
   ECRAD_DEV int i(int f) const { return i_[f * kTileCols + c]; }
 };
 
-__global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __restrict__ Tp, DevInputs in, RrtmgWork w, DevGasStage out,
-                                                              int do_lw, int do_sw) {
+// Aerosol optics of the tile per band (radiation_aerosol_optics.F90:614-700), for folding into the stage arrays.
+// aerosol_tile_inputs: layer mass factor x mixing ratio of every active type and the humidity bin of the tile's 64
+// columns, fetched coalesced and all at once (s_mr[k * 64 + c], s_rh[c]).
+ECRAD_DEV void aerosol_tile_inputs(const DevConfig& cfg, const DevInputs& in, int lev, int c0, int nloc, double* s_mr, int* s_rh) {
+  const DevAerosolOptics& ao = cfg.aerosol;
+  const LevelOrder ord = level_order(in);
+  const size_t ncol = in.ncol;
+  const int clev = ord.full(lev);
+  const int jlev = clev + 1;
+  const bool in_range = jlev >= in.aerosol_istartlev && jlev <= in.aerosol_iendlev;
+  const int nlev_aer = in.aerosol_iendlev - in.aerosol_istartlev + 1;
+  const size_t type_stride = ncol * (size_t)nlev_aer;
+  const int n = ao.nactive;
+  for (int i = threadIdx.x; i < (n + 1) * kTileCols; i += kBlock) {
+    const int k = i / kTileCols, c = i % kTileCols, cloc = c0 + c;
+    if (cloc >= nloc) continue;
+    const int col = in.istartcol - 1 + cloc;
+    if (k < n) {
+      double v = 0.0;
+      if (in_range) {
+        const double p0 = in.pressure_hl[col + ncol * ord.half(lev)], p1 = in.pressure_hl[col + ncol * ord.half(lev + 1)];
+        const double factor = (p1 - p0) * (1.0 / kAccelDueToGravity);
+        v = factor * in.aerosol_mixing_ratio[col + ncol * (size_t)(jlev - in.aerosol_istartlev) + type_stride * (size_t)(ao.active[k] & 0xffu)];
+      }
+      s_mr[k * kTileCols + c] = v;
+    } else {
+      int irh = 0;
+      if (ao.use_hydrophilic) {      // calc_rh_index, radiation_aerosol_optics_data.F90:640-664
+        const double h2o_in = in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (ECRAD_IH2O - 1))];
+        const double h2o_mmr = cfg.gas_mmr ? h2o_in : h2o_in * (kH2OMolarMass / kAirMolarMass);
+        const double rh = h2o_mmr / in.h2o_sat_liq[col + ncol * clev];
+        if (rh > ao.rh_lower[ao.nrh - 1]) irh = ao.nrh;
+        else { irh = 1; while (rh > ao.rh_lower[irh]) irh++; }
+      }
+      s_rh[c] = irh > 0 ? irh - 1 : 0;
+    }
+  }
+}
+
+// items = (band, column of the tile), bands fastest so that the table rows are read coalesced; the sums over the
+// types keep the reference's order.  LW (absorption only): dst[b * 64 + c]; SW: dst[(3 * b + f) * 64 + c] with
+// f = od, scattering od, scattering od x g, delta-Eddington scaled unless the gases are scaled as well (:739-741).
+// The shortwave is done in two halves of kSwAerHalf bands (b0 = 0, kSwAerHalf) to keep the block's LDS below 40 KB
+// (4 blocks per CU); dst is indexed by the band within the half.
+constexpr int kSwAerHalf = 7;
+template <bool IS_SW>
+ECRAD_DEV void aerosol_bands_of_tile(const DevConfig& cfg, int c0, int nloc, const double* s_mr, const int* s_rh, double* dst, int b0) {
+  const DevAerosolOptics& ao = cfg.aerosol;
+  const int nb = IS_SW ? ao.n_bands_sw : ao.n_bands_lw;
+  const int n = ao.nactive;
+  constexpr int KB = 4;        // table rows of KB types requested together
+  constexpr int W = IS_SW ? 8 : 16, NBL = IS_SW ? kSwAerHalf : 16;
+  for (int i = threadIdx.x; i < W * kTileCols; i += kBlock) {
+    const int bl = i % W, c = i / W, b = b0 + bl;
+    if (bl >= NBL || b >= nb || c0 + c >= nloc) continue;
+    AerosolLayer a = {0.0, 0.0, 0.0};
+    const int rh_row = s_rh[c];
+    for (int k0 = 0; k0 < n; k0 += KB) {
+      double2 t01[KB];
+      double t2[KB];
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        t01[u] = make_double2(0.0, 0.0); t2[u] = 0.0;
+        if (k0 + u < n) {
+          const uint32_t desc = ao.active[k0 + u];
+          const size_t o = b + (size_t)nb * ((int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0));
+          if (IS_SW) { t01[u] = reinterpret_cast<const double2*>(ao.sw_tab01)[o]; t2[u] = ao.sw_tab2[o]; }
+          else t01[u].x = ao.lw_abs[o];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < KB; ++u) {
+        if (k0 + u < n) {
+          const double local_od = s_mr[(k0 + u) * kTileCols + c] * t01[u].x;      // (factor * mixing ratio) * mass_ext
+          a.od = a.od + local_od;
+          if (IS_SW) {
+            a.scat = a.scat + local_od * t01[u].y;
+            a.scat_g = a.scat_g + local_od * t01[u].y * t2[u];
+          }
+        }
+      }
+    }
+    if (IS_SW) {
+      if (!cfg.do_sw_delta_scaling_with_gases) delta_eddington_extensive_vec(a);
+      dst[(3 * bl + 0) * kTileCols + c] = a.od;
+      dst[(3 * bl + 1) * kTileCols + c] = a.scat;
+      dst[(3 * bl + 2) * kTileCols + c] = a.scat_g;
+    } else {
+      dst[bl * kTileCols + c] = a.od;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __restrict__ Tp, const DevConfig* __restrict__ cfgp, DevInputs in,
+                                                              RrtmgWork w, DevGasStage out, int do_lw, int do_sw) {
   const DevRrtmg& T = *Tp;
+  const DevConfig& cfg = *cfgp;
+  const bool fold_lw = out.aer_folded_lw != 0, fold_sw = out.g_sw != nullptr;
+  __shared__ double s_aer[3 * kSwAerHalf * kTileCols];     // 16 x 64 (LW) / 3 x 7 x 64 (SW, half the bands) aerosol properties of the tile
+  static_assert(3 * kSwAerHalf >= 16 && 2 * kSwAerHalf >= kNBandSw, "s_aer too small");
+  __shared__ double s_mr[kMaxActiveAerosols * kTileCols];
+  __shared__ int s_rh[kTileCols];
   const int nloc = in.iendcol - in.istartcol + 1, nlev = in.nlev;
   const int lev = blockIdx.y;
   const int c0 = blockIdx.x * kTileCols;
@@ -131,6 +231,7 @@ __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __
       s_sun[i] = (do_sw && in.cos_sza[col] > 0.0) ? 1 : 0;
     }
   }
+  if (fold_lw || fold_sw) aerosol_tile_inputs(cfg, in, lev, c0, nloc, s_mr, s_rh);
   __syncthreads();
   if (do_lw) {
     for (int i = tid; i < LD_N * kTileCols; i += kBlock) {
@@ -141,6 +242,7 @@ __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __
       const int f = i / kTileCols, c = i % kTileCols;
       if (c0 + c < nloc) s_i[i] = w.lw_i[(size_t)f * stride + rec0 + c];
     }
+    if (fold_lw) aerosol_bands_of_tile<false>(cfg, c0, nloc, s_mr, s_rh, s_aer, 0);
     __syncthreads();
     for (int ib = 0; ib < kNBandLw; ++ib) {
       const LwBand& B = T.lw[ib];
@@ -158,7 +260,9 @@ __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __
           if (active && lower == (rg == 0)) lw_gpoint_regime(T, B, B.reg[rg], rg == 0, r, ig, tau, pfrac);
         if (!active) continue;
         const int g = B.g0 + ig;
-        out.od_lw[g + (size_t)kNgLw * (lev + (size_t)nlev * cloc)] = dmax(T.min_gas_od_lw, tau);
+        double od = dmax(T.min_gas_od_lw, tau);
+        if (fold_lw) od = od + s_aer[ib * kTileCols + c];      // radiation_aerosol_optics.F90:805-818
+        out.od_lw[g + (size_t)kNgLw * (lev + (size_t)nlev * cloc)] = od;
         // planck_hl(g, half level) = band Planck function at the half level x fraction of the layer ABOVE it
         // (of the top layer for the top half level): radiation_ifs_rrtm.F90:715-724
         const size_t op = g + (size_t)kNgLw * (lev + (size_t)(nlev + 1) * cloc);
@@ -179,8 +283,15 @@ __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __
       const int f = i / kTileCols, c = i % kTileCols;
       if (c0 + c < nloc && s_sun[c]) s_i[i] = w.sw_i[(size_t)f * stride + rec0 + c];
     }
+    if (fold_sw) aerosol_bands_of_tile<true>(cfg, c0, nloc, s_mr, s_rh, s_aer, 0);
     __syncthreads();
     for (int ib = 0; ib < kNBandSw; ++ib) {
+      if (fold_sw && ib == kSwAerHalf) {       // second half of the bands' aerosol properties
+        __syncthreads();
+        aerosol_bands_of_tile<true>(cfg, c0, nloc, s_mr, s_rh, s_aer, kSwAerHalf);
+        __syncthreads();
+      }
+      const int iba = ib < kSwAerHalf ? ib : ib - kSwAerHalf;
       const SwBand& B = T.sw[ib];
       const int ng = B.ng;
       const int nbp = ng <= 2 ? 2 : (ng <= 4 ? 4 : (ng <= 8 ? 8 : 16));
@@ -197,13 +308,20 @@ __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __
           double taug = 0.0, taur = 0.0, sflux = 0.0;
           for (int rg = 0; rg < 2; ++rg)
             if (lower == (rg == 0)) sw_gpoint_regime(T, B, B.reg[rg], rg == 0, r, ig, want, taug, taur, sflux);
-          const double od = taur + taug;
-          out.od_sw[o] = dmax(T.min_gas_od_sw, od);
-          out.ssa_sw[o] = taur / od;
+          const double od_gas = taur + taug;
+          double od = dmax(T.min_gas_od_sw, od_gas), ssa = taur / od_gas, asym = 0.0;
+          if (fold_sw) {
+            const AerosolLayer al = {s_aer[(3 * iba + 0) * kTileCols + c], s_aer[(3 * iba + 1) * kTileCols + c], s_aer[(3 * iba + 2) * kTileCols + c]};
+            merge_aerosol_sw(cfg, al, od, ssa, asym);
+            out.g_sw[o] = asym;
+          }
+          out.od_sw[o] = od;
+          out.ssa_sw[o] = ssa;
           if (want) out.incoming_sw[g + (size_t)kNgSw * cloc] = sflux;
         } else {
           out.od_sw[o] = dmax(T.min_gas_od_sw, 0.0);
           out.ssa_sw[o] = 0.0;
+          if (fold_sw) out.g_sw[o] = 0.0;
         }
       }
     }
@@ -241,15 +359,15 @@ RrtmgWork rrtmg_carve_work(void* base, int nlev, int nloc) {
   return w;
 }
 
-hipError_t launch_rrtmg_gas_optics(hipStream_t st, const DevRrtmg* tables, const DevInputs& in, const RrtmgWork& w, const DevGasStage& out,
-                                   bool do_lw, bool do_sw) {
+hipError_t launch_rrtmg_gas_optics(hipStream_t st, const DevRrtmg* tables, const DevConfig* cfg, const DevInputs& in, const RrtmgWork& w,
+                                   const DevGasStage& out, bool do_lw, bool do_sw) {
   const int nloc = in.iendcol - in.istartcol + 1, nlev = in.nlev;
   if (do_sw) {
     hipError_t e = hipMemsetAsync(out.incoming_sw, 0, (size_t)kNgSw * nloc * sizeof(double), st);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(rrtmg_setcoef_kernel, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, st, tables, in, w, do_lw ? 1 : 0, do_sw ? 1 : 0);
-  hipLaunchKernelGGL(rrtmg_taumol_kernel, dim3((nloc + kTileCols - 1) / kTileCols, nlev), dim3(kBlock), 0, st, tables, in, w, out,
+  hipLaunchKernelGGL(rrtmg_taumol_kernel, dim3((nloc + kTileCols - 1) / kTileCols, nlev), dim3(kBlock), 0, st, tables, cfg, in, w, out,
                      do_lw ? 1 : 0, do_sw ? 1 : 0);
   if (do_sw) hipLaunchKernelGGL(rrtmg_incoming_kernel, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, st, in, out);
   return hipGetLastError();

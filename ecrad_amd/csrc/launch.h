@@ -61,7 +61,7 @@ hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, siz
 namespace rrtmg { struct DevRrtmg; }
 size_t rrtmg_work_bytes(int nlev, int nloc);
 RrtmgWork rrtmg_carve_work(void* base, int nlev, int nloc);
-hipError_t launch_rrtmg_gas_optics(hipStream_t st, const rrtmg::DevRrtmg* tables, const DevInputs& in, const RrtmgWork& w,
-                                   const DevGasStage& out, bool do_lw, bool do_sw);
+hipError_t launch_rrtmg_gas_optics(hipStream_t st, const rrtmg::DevRrtmg* tables, const DevConfig* cfg, const DevInputs& in,
+                                   const RrtmgWork& w, const DevGasStage& out, bool do_lw, bool do_sw);
 
 }  // namespace ecrad

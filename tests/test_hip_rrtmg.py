@@ -36,6 +36,8 @@ CASES = {
     "cloudless_lw_aerosol_scat": dict(sw_solver="Cloudless"),
     "no_lw_cloud_scattering": dict(sw_solver="McICA", do_lw_cloud_scattering=False, do_lw_aerosol_scattering=False),
     "delta_scaling_with_gases": dict(sw_solver="Tripleclouds", do_sw_delta_scaling_with_gases=True, do_lw_aerosol_scattering=False),
+    "mcica_delta_scaling_with_gases": dict(sw_solver="McICA", do_sw_delta_scaling_with_gases=True, do_lw_aerosol_scattering=False),
+    "homogeneous_lw_aerosol_scat": dict(sw_solver="Homogeneous"),
 }
 
 
