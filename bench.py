@@ -110,6 +110,7 @@ def cpu_baseline(config, workload, sample, seconds_target=12.0):
 
 
 def main():
+    os.environ.setdefault("GFORTRAN_UNBUFFERED_ALL", "1")      # (see the cpu_baseline leg below)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -270,7 +271,15 @@ def main():
                          "stage_ms": {k: float(np.mean(v)) for k, v in stage_ms.items() if v}},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], oracle_flux = cpu_baseline(config, args.workload, cpu_sample)
+            # (the reference's RRTMG set-up routines print to Fortran unit 6: keep stdout for the JSON line)
+            sys.stdout.flush()
+            saved_fd = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                out["cpu_baseline"], oracle_flux = cpu_baseline(config, args.workload, cpu_sample)
+            finally:
+                os.dup2(saved_fd, 1)
+                os.close(saved_fd)
             # the oracle's sample is the first columns of this rank's batch: check the timed configuration
             # against it (outside the timed region; the oracle is the checker, never the thing measured)
             worst, nchk = 0.0, oracle_flux.ncol

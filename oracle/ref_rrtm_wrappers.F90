@@ -39,6 +39,7 @@ contains
     call SURRTRF
     call RRTM_INIT_140GP(trim(dir))
     call SRTM_INIT(trim(dir))
+    flush(6)     ! the set-up routines print to unit 6: emit it now, not when the process exits
   end subroutine
 
   subroutine ref_rrtm_sizes(ng_lw, ng_sw) bind(C, name='ref_rrtm_sizes')
