@@ -817,16 +817,15 @@ int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int ie
 }
 
 // RRTMG: the separate gas-optics pass that fills the stage arrays the solver kernels read (din.gs)
-// `fold_aerosols`: the caller's solver kernels take the aerosols from the stage arrays (ICA-type solvers, optics per band)
+// `fold_aerosols`: the caller's solver kernels take the aerosols from the stage arrays (optics per band, no LW aerosol scattering)
 int run_rrtmg(ecrad_hip_handle_t h, CallCtx& cx, bool fold_aerosols) {
   if (!h->rrtmg_sw && !h->rrtmg_lw) return ECRAD_OK;
   using namespace ecrad::rrtmg;
   const size_t n = cx.r.nloc, L = cx.r.nlev;
   const ecrad_config_t& c = h->cfg;
   const bool aer = fold_aerosols && c.use_aerosols && cx.din.aerosol_mixing_ratio != nullptr && !getenv("ECRAD_NO_AEROSOL_FOLD");
-  const bool fold_lw = aer && h->rrtmg_lw && !c.do_lw_aerosol_scattering && !c.do_cloud_aerosol_per_lw_g_point &&
-                       c.i_solver_lw != ECRAD_SOLVER_TRIPLECLOUDS;
-  const bool fold_sw = aer && h->rrtmg_sw && !c.do_cloud_aerosol_per_sw_g_point && c.i_solver_sw != ECRAD_SOLVER_TRIPLECLOUDS;
+  const bool fold_lw = aer && h->rrtmg_lw && !c.do_lw_aerosol_scattering && !c.do_cloud_aerosol_per_lw_g_point;
+  const bool fold_sw = aer && h->rrtmg_sw && !c.do_cloud_aerosol_per_sw_g_point;
   DevGasStage gs{};
   gs.aer_folded_lw = fold_lw ? 1 : 0;
   for (int pass = 0; pass < 2; ++pass) {

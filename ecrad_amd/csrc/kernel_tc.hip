@@ -256,16 +256,18 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
         double ssa = L.D(F_SM, slot) * ray_g;
         od = od + ssa;
         ssa = ssa / od;
+        double asym = 0.0;
+        bool folded = false;
         if constexpr (sizeof(TAB) == 8) {
           const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
           if (gs.od_sw) {
             const size_t o = g + (size_t)ng * (l + (size_t)nlev * cloc);
             od = gs.od_sw[o];
             ssa = gs.ssa_sw[o];
+            if (gs.g_sw) { asym = gs.g_sw[o]; folded = true; }     // aerosols already merged by the RRTMG pass
           }
         }
-        double asym = 0.0;
-        if (use_aerosols) {
+        if (use_aerosols && !folded) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
           AerosolLayer al = aerosol_layer<true, NGP>(b.cfg, b.in, L, slot, col, l, ib, aer_type);
           if (!delta_gases) delta_eddington_extensive_vec(al);
@@ -638,7 +640,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
           }
         }
         double ssa = 0.0, asym = 0.0;        // clear-region scattering properties (ASCAT only)
-        if (use_aerosols) {
+        if (use_aerosols && !kernarg_block<SpectralArgs>().in.gs.aer_folded_lw) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
           if (ASCAT) {                       // radiation_aerosol_optics.F90:778-797
             AerosolLayer al = aerosol_layer<false, NGP>(b.cfg, b.in, L, slot, col, lev, ib, aer_type);
