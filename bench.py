@@ -88,8 +88,8 @@ def cpu_baseline(config, workload, sample, seconds_target=12.0):
         # reference's sources), the rest the C restatement -- still a "port" as a whole
         if not pyoracle.have_ref_rrtm():
             raise RuntimeError("oracle/_ref/libecrad_refrrtm.so is missing (oracle/build_ref_rrtm.sh)")
-        blocked = pyoracle.make_rrtmg_backend(config, inner=blocked)
-        what = "the reference's ifsrrtm gas-optics routines (oracle/_ref, 1 thread) + oracle/ (plain C, "
+        blocked = pyoracle.make_rrtmg_backend(config, inner=blocked, nthreads=int(nthreads))
+        what = "the reference's ifsrrtm gas-optics routines (oracle/_ref, blocks of 4 columns on a thread pool) + oracle/ (plain C, "
     rad = Radiation(config, backend=blocked)
     ncol, nlev, sl, th, gas, cloud, aer = sample
     nsample = ncol

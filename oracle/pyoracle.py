@@ -118,7 +118,7 @@ def _np_from(ptr, shape, dtype=np.float64):
     return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double if dtype == np.float64 else C.c_int32)), shape=(n,)).reshape(shape)
 
 
-def rrtmg_gas_stage(config, ncol, nlev, cin):
+def rrtmg_gas_stage(config, ncol, nlev, cin, nthreads=1):
     """gas_optics + planck_function_atmos/_surf of radiation/radiation_ifs_rrtm.F90:216-852 for all ncol columns:
     RRTM_PREPARE_GASES ... SRTM_GAS_OPTICAL_DEPTH by the reference library, then (numpy) the reversal of the level
     order (:509, :593), max(min_gas_od, .) (:506-512, :590-594), the Planck function from TOTPLNK/DELWAVE (:618-852)
@@ -137,8 +137,10 @@ def rrtmg_gas_stage(config, ncol, nlev, cin):
     od_lw = np.zeros((140, nlev, ncol), order="F"); pfrac = np.zeros((ncol, 140, nlev), order="F")
     od_sw = np.zeros((ncol, nlev, 112), order="F"); ssa_sw = np.zeros((ncol, nlev, 112), order="F")
     incsol = np.zeros((ncol, 112), order="F")
-    # a few columns at a time: the reference routines keep (ncol, 140, nlev) automatic arrays on the stack
-    for c0 in range(0, ncol, 4):
+    # a few columns at a time: the reference routines keep (ncol, 140, nlev) automatic arrays on the stack.
+    # nthreads > 1: blocks of columns on a thread pool, like the OpenMP loop over blocks of the reference's driver
+    # (driver/ecrad_driver.F90:348); the routines only read their module tables, and ctypes releases the GIL.
+    def block(c0):
         c1 = min(ncol, c0 + 4)
         n = c1 - c0
         cut = lambda a: np.ascontiguousarray(a[..., c0:c1])
@@ -147,6 +149,19 @@ def rrtmg_gas_stage(config, ncol, nlev, cin):
         args = [cut(phl), cut(thl)] + [cut(a) for a in gl] + [cut(mu0)]
         L.ref_rrtm_gas_optics(C.c_int(n), C.c_int(nlev), *[p(a) for a in args], p(o_lw), p(o_pf), p(o_sw), p(o_ssa), p(o_inc))
         od_lw[:, :, c0:c1] = o_lw; pfrac[c0:c1] = o_pf; od_sw[c0:c1] = o_sw; ssa_sw[c0:c1] = o_ssa; incsol[c0:c1] = o_inc
+
+    if nthreads > 1 and ncol > 4:
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        old_size = threading.stack_size(256 * 1024 * 1024)
+        try:
+            with ThreadPoolExecutor(max_workers=nthreads) as ex:
+                list(ex.map(block, range(0, ncol, 4)))
+        finally:
+            threading.stack_size(old_size)
+    else:
+        for c0 in range(0, ncol, 4):
+            block(c0)
     out = {}
     out["od_lw"] = np.ascontiguousarray(np.maximum(np.transpose(od_lw, (2, 1, 0))[:, ::-1, :], config.min_gas_od_lw))
     pf = np.transpose(pfrac, (0, 2, 1))[:, ::-1, :]                               # (ncol, layer from top, 140)
@@ -173,14 +188,14 @@ def rrtmg_gas_stage(config, ncol, nlev, cin):
     return out
 
 
-def make_rrtmg_backend(config, inner=None):
+def make_rrtmg_backend(config, inner=None, nthreads=1):
     """``backend=`` callable for configurations with gas_model_name = "RRTMG-IFS": computes the gas-optics stage with
     the reference's routines, hands it to the C oracle, then runs ``inner`` (default: the plain oracle backend)."""
     from ecrad_amd import abi
     inner = inner or backend
 
     def _b(cconfig, ncol, nlev, istartcol, iendcol, cin, cflux) -> int:
-        stage = rrtmg_gas_stage(config, ncol, nlev, cin)
+        stage = rrtmg_gas_stage(config, ncol, nlev, cin, nthreads=nthreads)
         st = abi.Optics()
         for k, a in stage.items():
             setattr(st, k, abi.dptr(a))
