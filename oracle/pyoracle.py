@@ -134,57 +134,57 @@ def rrtmg_gas_stage(config, ncol, nlev, cin, nthreads=1):
     mu0 = np.ascontiguousarray(_np_from(cin.cos_sza, (ncol,))) if cin.cos_sza else np.zeros(ncol)
     order = [1, 2, 6, 4, 12, 8, 9, 10, 11, 3]      # q co2 ch4 n2o no2 cfc11 cfc12 hcfc22 ccl4 o3 (gas codes)
     gl = [np.ascontiguousarray(gas[k - 1]) for k in order]
-    od_lw = np.zeros((140, nlev, ncol), order="F"); pfrac = np.zeros((ncol, 140, nlev), order="F")
-    od_sw = np.zeros((ncol, nlev, 112), order="F"); ssa_sw = np.zeros((ncol, nlev, 112), order="F")
-    incsol = np.zeros((ncol, 112), order="F")
-    # a few columns at a time: the reference routines keep (ncol, 140, nlev) automatic arrays on the stack.
+    t = np.load(os.path.join(_DATA, "rrtmg_tables.npz"))
+    totplnk, delwave = t["yoerrtwn.totplnk"], t["yoerrtwn.delwave"]
+    band = np.repeat(np.arange(16), _NG_LW)
+    fac = 2.0 * np.arcsin(1.0) * 1.0e4 * delwave[band]
+
+    def planck(T):
+        T = np.asarray(T)
+        ind = np.where(T >= 339.0, 180, np.where(T >= 160.0, (T - 159.0).astype(int), 1))
+        frac = np.where(T >= 339.0, T - 339.0, np.where(T >= 160.0, T - np.trunc(T), 0.0))
+        lo = totplnk[ind[..., None] - 1, band]
+        return fac * (lo + frac[..., None] * (totplnk[ind[..., None], band] - lo))
+
+    skin = _np_from(cin.skin_temperature, (ncol,)) if cin.skin_temperature else thl[-1]
+    out = {"od_lw": np.empty((ncol, nlev, 140)), "planck_hl": np.empty((ncol, nlev + 1, 140)), "lw_emission": np.empty((ncol, 140)),
+           "od_sw": np.empty((ncol, nlev, 112)), "ssa_sw": np.empty((ncol, nlev, 112)), "incoming_sw": np.empty((ncol, 112))}
+    # A few columns at a time: the reference routines keep (ncol, 140, nlev) automatic arrays on the stack.
     # nthreads > 1: blocks of columns on a thread pool, like the OpenMP loop over blocks of the reference's driver
-    # (driver/ecrad_driver.F90:348); the routines only read their module tables, and ctypes releases the GIL.
+    # (driver/ecrad_driver.F90:348); the routines only read their module tables, ctypes and numpy release the GIL.
+    nblock = 4 if nthreads <= 1 else 8
+
     def block(c0):
-        c1 = min(ncol, c0 + 4)
+        c1 = min(ncol, c0 + nblock)
         n = c1 - c0
         cut = lambda a: np.ascontiguousarray(a[..., c0:c1])
         o_lw = np.zeros((140, nlev, n), order="F"); o_pf = np.zeros((n, 140, nlev), order="F")
         o_sw = np.zeros((n, nlev, 112), order="F"); o_ssa = np.zeros((n, nlev, 112), order="F"); o_inc = np.zeros((n, 112), order="F")
         args = [cut(phl), cut(thl)] + [cut(a) for a in gl] + [cut(mu0)]
         L.ref_rrtm_gas_optics(C.c_int(n), C.c_int(nlev), *[p(a) for a in args], p(o_lw), p(o_pf), p(o_sw), p(o_ssa), p(o_inc))
-        od_lw[:, :, c0:c1] = o_lw; pfrac[c0:c1] = o_pf; od_sw[c0:c1] = o_sw; ssa_sw[c0:c1] = o_ssa; incsol[c0:c1] = o_inc
+        # what radiation_ifs_rrtm.F90 does around the routines, on the block
+        out["od_lw"][c0:c1] = np.maximum(np.transpose(o_lw, (2, 1, 0))[:, ::-1, :], config.min_gas_od_lw)
+        pf = np.transpose(o_pf, (0, 2, 1))[:, ::-1, :]                               # (n, layer from top, 140)
+        out["planck_hl"][c0:c1] = planck(thl[:, c0:c1].T) * np.concatenate([pf[:, :1, :], pf], axis=1)
+        out["lw_emission"][c0:c1] = planck(skin[c0:c1]) * pf[:, -1, :]
+        out["od_sw"][c0:c1] = np.maximum(o_sw[:, ::-1, :], config.min_gas_od_sw)
+        out["ssa_sw"][c0:c1] = o_ssa[:, ::-1, :]
+        tot = o_inc.sum(axis=1)
+        scale = np.where(mu0[c0:c1] > 0.0, cin.solar_irradiance / np.where(tot > 0, tot, 1.0), 1.0)
+        out["incoming_sw"][c0:c1] = o_inc * scale[:, None]
 
-    if nthreads > 1 and ncol > 4:
+    if nthreads > 1 and ncol > nblock:
         import threading
         from concurrent.futures import ThreadPoolExecutor
         old_size = threading.stack_size(256 * 1024 * 1024)
         try:
             with ThreadPoolExecutor(max_workers=nthreads) as ex:
-                list(ex.map(block, range(0, ncol, 4)))
+                list(ex.map(block, range(0, ncol, nblock)))
         finally:
             threading.stack_size(old_size)
     else:
-        for c0 in range(0, ncol, 4):
+        for c0 in range(0, ncol, nblock):
             block(c0)
-    out = {}
-    out["od_lw"] = np.ascontiguousarray(np.maximum(np.transpose(od_lw, (2, 1, 0))[:, ::-1, :], config.min_gas_od_lw))
-    pf = np.transpose(pfrac, (0, 2, 1))[:, ::-1, :]                               # (ncol, layer from top, 140)
-    t = np.load(os.path.join(_DATA, "rrtmg_tables.npz"))
-    totplnk, delwave = t["yoerrtwn.totplnk"], t["yoerrtwn.delwave"]
-    band = np.repeat(np.arange(16), _NG_LW)
-
-    def planck(T):
-        T = np.asarray(T)
-        ind = np.where(T >= 339.0, 180, np.where(T >= 160.0, (T - 159.0).astype(int), 1))
-        frac = np.where(T >= 339.0, T - 339.0, np.where(T >= 160.0, T - np.trunc(T), 0.0))
-        fac = 2.0 * np.arcsin(1.0) * 1.0e4 * delwave[band]
-        lo = totplnk[ind[..., None] - 1, band]
-        return fac * (lo + frac[..., None] * (totplnk[ind[..., None], band] - lo))
-
-    out["planck_hl"] = np.ascontiguousarray(planck(thl.T) * np.concatenate([pf[:, :1, :], pf], axis=1))
-    skin = _np_from(cin.skin_temperature, (ncol,)) if cin.skin_temperature else thl[-1]
-    out["lw_emission"] = np.ascontiguousarray(planck(skin) * pf[:, -1, :])
-    out["od_sw"] = np.ascontiguousarray(np.maximum(od_sw[:, ::-1, :], config.min_gas_od_sw))
-    out["ssa_sw"] = np.ascontiguousarray(ssa_sw[:, ::-1, :])
-    tot = incsol.sum(axis=1)
-    scale = np.where(mu0 > 0.0, cin.solar_irradiance / np.where(tot > 0, tot, 1.0), 1.0)
-    out["incoming_sw"] = np.ascontiguousarray(incsol * scale[:, None])
     return out
 
 
