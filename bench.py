@@ -250,7 +250,8 @@ def main():
         launches = 1
         if ng_dom > 64:
             pads = {n: -(-ng_dom // n) * n for n in (64, 32, 16)}
-            best = min((64, 32, 16), key=lambda n: (pads[n], -n))
+            ok = [n for n in (64, 32, 16) if (pads[n] - ng_dom) * 100 <= 15 * ng_dom]
+            best = ok[0] if ok else min((64, 32, 16), key=lambda n: (pads[n], -n))
             launches = pads[best] // best
         if traffic:
             traffic["bytes_per_launch"] *= launches

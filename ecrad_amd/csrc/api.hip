@@ -131,18 +131,21 @@ std::vector<double> build_pairs(const double* a, int ng, int n) {
 int padded_ng(int ng) { return ng <= 16 ? 16 : (ng <= 32 ? 32 : (ng <= 64 ? 64 : 0)); }
 
 // Lanes per column group and number of launches for a spectrum of ng g-points.  Up to 64 g-points one
-// launch covers the spectrum; wider spectra (ecCKD 96-term, RRTMG-size) run in chunks of the lane
-// count that wastes the fewest lanes (ties: fewer, wider chunks).
+// launch covers the spectrum; wider spectra (ecCKD 96-term, RRTMG's 140/112) run in chunks: the widest
+// chunk whose padding stays within 15 % of the spectrum (fewer launches, less per-column work repeated:
+// 140 -> 5 x 32, 112 -> 2 x 64, 96 -> 3 x 32; measured with tools/chunk_sweep.sh), else the width that
+// wastes the fewest lanes.
 int chunk_lanes(int ng, int* nchunk) {
   if (ng <= 64) { *nchunk = 1; return padded_ng(ng); }
   if (const char* e = getenv("ECRAD_CHUNK_LANES")) {      // tuning knob (tools/): force the chunk width
     const int n = atoi(e);
     if (n == 16 || n == 32 || n == 64) { *nchunk = (ng + n - 1) / n; return n; }
   }
-  int best = 64, best_pad = ((ng + 63) / 64) * 64;
-  for (int n : {32, 16}) {
+  int best = 0, best_pad = 0;
+  for (int n : {64, 32, 16}) {
     const int pad = ((ng + n - 1) / n) * n;
-    if (pad < best_pad) { best = n; best_pad = pad; }
+    if ((pad - ng) * 100 <= 15 * ng) { *nchunk = pad / n; return n; }
+    if (!best || pad < best_pad) { best = n; best_pad = pad; }
   }
   *nchunk = best_pad / best;
   return best;
@@ -559,13 +562,6 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
     if (!c.use_canopy_full_spectrum_sw && !c.do_nearest_spectral_sw_albedo && !d.sw_albedo_weights)
       return fail(h, ECRAD_EINVAL, "sw_albedo_weights missing");
     h->ngp_sw = chunk_lanes(c.n_g_sw, &h->nchunk_sw);
-    // The Tripleclouds SW kernel is the exception to "fewest wasted lanes": with full waves per column it is 25 %
-    // faster on the 112-point RRTMG spectrum (2 x 64 lanes against 7 x 16; tools/chunk_sweep.sh), as long as the
-    // padding stays below 15 %
-    if (c.i_solver_sw == ECRAD_SOLVER_TRIPLECLOUDS && c.n_g_sw > 64 && h->ngp_sw != 64 && !getenv("ECRAD_CHUNK_LANES")) {
-      const int pad64 = ((c.n_g_sw + 63) / 64) * 64;
-      if ((pad64 - c.n_g_sw) * 100 <= 15 * c.n_g_sw) { h->ngp_sw = 64; h->nchunk_sw = pad64 / 64; }
-    }
     h->spec_sum_sw = false; h->d_ispec_sw = nullptr;
     if (c.do_save_spectral_flux) {
       bool ident = c.n_spec_sw == c.n_g_sw;
