@@ -26,7 +26,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np  # noqa: E402
 
@@ -142,7 +141,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    from helpers import make_config
+    from ecrad_amd.cases import make_config
     from ecrad_amd.device import DeviceCase
     from ecrad_amd.interface import Radiation
     from ecrad_amd.parallel import gather_profiles, pack_profiles
@@ -154,7 +153,7 @@ def main():
     sw_solver = spec.pop("sw_solver")
     is_rrtmg = bool(spec.pop("rrtmg", False))
     if is_rrtmg:
-        from helpers import make_config_rrtmg
+        from ecrad_amd.cases import make_config_rrtmg
         config = make_config_rrtmg(sw_solver, **spec)
     else:
         config = make_config(sw_solver, **spec)

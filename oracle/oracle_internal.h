@@ -15,7 +15,7 @@ typedef struct oracle_optics_buf {
 
 oracle_optics_buf_t* oracle_optics_buf_alloc(const ecrad_config_t* c, int nlev, int nloc);
 void oracle_optics_buf_free(oracle_optics_buf_t* b);
-void oracle_run_optics(const ecrad_config_t* c, int ncol, int nlev, int istartcol, int iendcol,
+int oracle_run_optics(const ecrad_config_t* c, int ncol, int nlev, int istartcol, int iendcol,
                        const ecrad_inputs_t* in, oracle_optics_buf_t* b);
 
 void oracle_get_albedos(const ecrad_config_t* c, int ncol, int istartcol, int iendcol,

@@ -551,13 +551,16 @@ void oracle_add_aerosol_optics(const ecrad_config_t* c, int ncol, int nlev, int 
 }
 
 /* Stage driver == radiation_interface.F90:323-401.  Allocates what the caller did not supply. */
-void oracle_run_optics(const ecrad_config_t* c, int ncol, int nlev, int istartcol, int iendcol,
-                       const ecrad_inputs_t* in, oracle_optics_buf_t* b)
+int oracle_run_optics(const ecrad_config_t* c, int ncol, int nlev, int istartcol, int iendcol,
+                      const ecrad_inputs_t* in, oracle_optics_buf_t* b)
 {
   oracle_get_albedos(c, ncol, istartcol, iendcol, in, b->sw_albedo_direct, b->sw_albedo_diffuse, b->lw_albedo);
   if ((c->do_sw && c->i_gas_model_sw == ECRAD_GAS_IFSRRTMG) || (c->do_lw && c->i_gas_model_lw == ECRAD_GAS_IFSRRTMG))
-    oracle_gas_optics_rrtmg(c, ncol, nlev, istartcol, iendcol, in, b->lw_albedo, b->od_lw, b->od_sw, b->ssa_sw,
-                            b->planck_hl, b->lw_emission, b->incoming_sw);
+  {
+    /* (fails when pyoracle has not handed over the stage arrays of the reference's ifsrrtm routines) */
+    if (oracle_gas_optics_rrtmg(c, ncol, nlev, istartcol, iendcol, in, b->lw_albedo, b->od_lw, b->od_sw, b->ssa_sw,
+                                b->planck_hl, b->lw_emission, b->incoming_sw) != 0) return -1;
+  }
   else
   oracle_gas_optics_ecckd(c, ncol, nlev, istartcol, iendcol, in, b->lw_albedo, b->od_lw, b->od_sw, b->ssa_sw,
                           b->planck_hl, b->lw_emission, b->incoming_sw);
@@ -581,6 +584,7 @@ void oracle_run_optics(const ecrad_config_t* c, int ncol, int nlev, int istartco
       memset(b->g_lw, 0, sizeof(double) * (size_t)c->n_g_lw * nlev * nloc);
     }
   }
+  return 0;
 }
 
 oracle_optics_buf_t* oracle_optics_buf_alloc(const ecrad_config_t* c, int nlev, int nloc)
@@ -613,7 +617,7 @@ int ecrad_oracle_optics(const ecrad_config_t* c, int ncol, int nlev, int istartc
 {
   const int nloc = iendcol - istartcol + 1;
   oracle_optics_buf_t* b = oracle_optics_buf_alloc(c, nlev, nloc);
-  oracle_run_optics(c, ncol, nlev, istartcol, iendcol, in, b);
+  if (oracle_run_optics(c, ncol, nlev, istartcol, iendcol, in, b) != 0) { oracle_optics_buf_free(b); return -1; }
   size_t nlw = (size_t)c->n_g_lw, nsw = (size_t)c->n_g_sw, nblw = (size_t)c->n_bands_lw, nbsw = (size_t)c->n_bands_sw;
 #define CP(f, n) if (out->f) memcpy(out->f, b->f, sizeof(double) * (n))
   CP(od_lw, nlw * nlev * nloc); CP(ssa_lw, nlw * nlev * nloc); CP(g_lw, nlw * nlev * nloc);

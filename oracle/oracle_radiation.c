@@ -135,7 +135,7 @@ int ecrad_oracle_radiation(const ecrad_config_t* c, int ncol, int nlev, int ista
   if (in->pressure_hl[(size_t)(istartcol - 1) + (size_t)ncol] < in->pressure_hl[istartcol - 1]) return ECRAD_EUNSUPPORTED;
   const int nloc = iendcol - istartcol + 1;
   oracle_optics_buf_t* b = oracle_optics_buf_alloc(c, nlev, nloc);
-  oracle_run_optics(c, ncol, nlev, istartcol, iendcol, in, b);
+  if (oracle_run_optics(c, ncol, nlev, istartcol, iendcol, in, b) != 0) { oracle_optics_buf_free(b); return ECRAD_EINVAL; }
   if (c->do_lw) {
     switch (c->i_solver_lw) {
     case ECRAD_SOLVER_MCICA:        oracle_solver_mcica_lw(c, ncol, nlev, istartcol, iendcol, in, b, flux); break;

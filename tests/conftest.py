@@ -14,7 +14,6 @@ if ROOT not in sys.path:
 
 DATA_DIR = os.path.join(ROOT, "data")
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
-CONFIG_DIR = os.path.join(ROOT, "tests", "configs")
 
 
 def pytest_configure(config):

@@ -90,17 +90,6 @@ def test_hip_matches_oracle_on_meridian(case, oracle_lib):
     print(case, "max rel diff", max(worst.values()))
 
 
-def test_hip_matches_reference_golden():
-    """HIP path vs the reference's own output file (float32): same bar as the oracle pin."""
-    config = make_config("McICA")
-    flux, th, rad = run_case(config, "hip")
-    out = flux_to_output_dict(config, th, flux)
-    with NcFile(os.path.join(GOLDEN_DIR, "ecrad_meridian_ecckd_mcica_out_REFERENCE.nc")) as g:
-        for name in g._f.variables:
-            assert rel_err(out[name], g.get(name)) < 2.0e-7, name
-    rad.close()
-
-
 def test_column_subrange_does_not_touch_other_columns(oracle_lib):
     """radiation(ncol,nlev,istartcol,iendcol,...): columns outside the range keep their values, and the
     crop_cloud_fraction side effect is confined to the range (radiation_interface.F90:200-251)."""

@@ -3,7 +3,7 @@ through the C-ABI against
   * the reference's OWN RRTMG routines (oracle/_ref/libecrad_refrrtm.so, compiled from /root/reference unmodified)
     for the gas-optics stage arrays, and the committed golden vectors made with them;
   * the oracle (those routines + the C restatement of everything downstream) for the fluxes of every solver;
-  * the reference's golden output file of its default RRTMG configuration (test/ifs: `make test_default`).
+  * (the reference's golden output files of its RRTMG configurations: tests/test_reference_goldens.py).
 Tolerance as in test_hip_parity.py: 1e-8 relative on fluxes (bar: 1e-6)."""
 import ctypes as C
 import os
@@ -64,21 +64,6 @@ def test_hip_matches_oracle_with_rrtmg(case, ref):
            if v > (TOL_SPECTRAL if k.endswith(("_g", "_band", "_canopy")) else TOL)}
     assert not bad, bad
     print(case, "max rel diff", max(worst.values()))
-
-
-def test_hip_matches_reference_golden_default_configuration():
-    """The reference's own output for its default (RRTMG, McICA, SOCRATES/Fu, 12 aerosol types) configuration."""
-    config = make_config_rrtmg("McICA", do_lw_aerosol_scattering=False)
-    flux, th, rad = run_case(config, "hip")
-    out = flux_to_output_dict(config, th, flux)
-    checked = 0
-    with NcFile(os.path.join(GOLDEN_DIR, "ecrad_meridian_default_out_REFERENCE.nc")) as g:
-        for name in g._f.variables:
-            if name in out and np.asarray(out[name]).shape == g.get(name).shape:
-                assert rel_err(out[name], g.get(name)) < 2.0e-7, name
-                checked += 1
-    assert checked >= 10
-    rad.close()
 
 
 def _hip_optics(config):
