@@ -3,22 +3,31 @@
 
 Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched by the driver through
 ``python -m torch.distributed.run``).  One "step" = one pass of radiation() over one batch of
-synthetic IFS-shaped columns that is already resident in HBM.  At N=1 the workload is BASELINE.json
-configs[1]: 100 000 clear-sky columns, 137 levels, ecCKD-32 SW+LW, homogeneous solver, double
-precision.  Columns shard across ranks with NO data-path collective: the path has no exchange step and
-every rank keeps the fluxes of the columns it owns, as the ranks of a host model do (weak scaling:
-the per-GPU batch is fixed).  ``--gather`` additionally gathers the flux profiles on rank 0 every step
-(RCCL), which is what an offline driver writing one output file would need.
+synthetic IFS-shaped columns that is already resident in HBM.  The headline workload (``value``) is
+BASELINE.json configs[1]: 100 000 clear-sky columns per GPU, 137 levels, ecCKD-32 SW+LW, homogeneous
+solver, double precision.  Columns shard across ranks with NO data-path collective: the path has no
+exchange step and every rank keeps the fluxes of the columns it owns, as the ranks of a host model do
+(weak scaling: the per-GPU batch is fixed).  At N>1 the run ALSO times the same steps followed by the
+one collective an offline driver writing a single file needs -- the RCCL gather of the flux profiles
+on rank 0 -- and reports it as ``value_with_gather``.
 
 Prints ONE JSON line on rank 0 with the contract's keys plus:
-  "roofline":     dominant kernel's algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak
+  "roofline":     dominant stage's algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak
   "cpu_baseline": the oracle (plain-C restatement, OpenMP over column blocks like the reference's
                   driver) timed on this box's host cores on a bounded sample of the same workload
+  "parity":       the timed configuration checked against the oracle on that sample (a failure nulls
+                  ``value`` and makes the exit status non-zero)
+  "end_to_end_host": the same call through ECRAD_MEM_HOST pointers (H2D + kernels + D2H, PCIe-inclusive)
+  "workloads":    (N=1, default run) the other BASELINE configurations on this GPU, each with its own
+                  value / ms_per_step / roofline / cpu_baseline / parity:
+                  tripleclouds_ecckd32 (north-star shape), mcica_rrtmg (configs[2]) and
+                  tripleclouds_ecckd64 at 1 250 000 columns (the per-GPU shard of configs[3])
 """
 from __future__ import annotations
 
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -30,10 +39,14 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_TRIAD_GBS = 6300.0     # what tools/hbm_ceiling sustains on this box type when reading
+PARITY_TOLERANCE = 1.0e-6  # BASELINE.json north_star: fluxes within 1e-6 relative of the CPU reference
+EXTRA_WORKLOADS = (("tripleclouds_ecckd32", 100000), ("mcica_rrtmg", 100000), ("tripleclouds_ecckd64", 1250000))
+CHUNK_COLUMNS = 125000     # synthetic columns are generated and uploaded this many at a time (bounds host memory)
 
 
 def algorithmic_bytes_per_column(config, nlev, which, clear_sky):
-    """SURVEY.md section 8(d) figure "A", split per fused kernel: stage-interface arrays (each written
+    """SURVEY.md section 8(d) figure "A", split per fused stage: stage-interface arrays (each written
     once by its producer stage and read once by its consumer) + the compulsory inputs/outputs of the
     columns.  `which` is 'sw' or 'lw'.  W = 8 bytes."""
     W = 8
@@ -57,6 +70,18 @@ def algorithmic_bytes_per_column(config, nlev, which, clear_sky):
     return stage + W * (inputs + outputs)
 
 
+def build_config(workload):
+    """(config, clear_sky, description dict) of a named workload of ecrad_amd/synthetic.py: BENCH_CONFIGS."""
+    from ecrad_amd.cases import make_config, make_config_rrtmg
+    from ecrad_amd.synthetic import BENCH_CONFIGS
+    spec = dict(BENCH_CONFIGS[workload])
+    clear_sky = spec.pop("clear_sky")
+    sw_solver = spec.pop("sw_solver")
+    is_rrtmg = bool(spec.pop("rrtmg", False))
+    config = make_config_rrtmg(sw_solver, **spec) if is_rrtmg else make_config(sw_solver, **spec)
+    return config, clear_sky, {"sw_solver": sw_solver, "rrtmg": is_rrtmg}
+
+
 def first_columns(inputs, n):
     """The first n columns of a make_columns() result (column axis is the last one)."""
     import copy
@@ -72,26 +97,31 @@ def first_columns(inputs, n):
     return (n, nlev, *out)
 
 
-def cpu_baseline(config, workload, sample, seconds_target=12.0):
-    """Time the oracle on a bounded sample (the first 2048 columns of the timed batch, repeated)."""
-    from ecrad_amd.interface import Radiation
-    from ecrad_amd.synthetic import BENCH_CONFIGS, make_columns
-    from ecrad_amd.types import Flux
+def oracle_backend(config, nthreads=None):
+    """The checker / CPU baseline: oracle/ with OpenMP over blocks of 32 columns (driver/ecrad_driver.F90:348); for
+    RRTMG its gas optics are the reference's own ifsrrtm routines (oracle/_ref).  Returns (backend, description, threads)."""
     from oracle import pyoracle
     pyoracle.build()
-    nthreads = pyoracle.lib().ecrad_oracle_max_threads()
-    blocked = pyoracle.make_blocked_backend(nblocksize=32, nthreads=nthreads)
-    kind, what = "port", "oracle/ (plain C, "
-    if config.rrtmg is not None:
-        # RRTMG: the gas optics are the reference's own ifsrrtm routines (oracle/_ref, compiled from the
-        # reference's sources), the rest the C restatement -- still a "port" as a whole
+    nthreads = int(nthreads or pyoracle.lib().ecrad_oracle_max_threads())
+    backend = pyoracle.make_blocked_backend(nblocksize=32, nthreads=nthreads)
+    what = "oracle/ (plain C, -O3, "
+    from ecrad_amd.config import IGasModelIFSRRTMG
+    if IGasModelIFSRRTMG in (config.i_gas_model_sw, config.i_gas_model_lw):
         if not pyoracle.have_ref_rrtm():
             raise RuntimeError("oracle/_ref/libecrad_refrrtm.so is missing (oracle/build_ref_rrtm.sh)")
-        blocked = pyoracle.make_rrtmg_backend(config, inner=blocked, nthreads=int(nthreads))
-        what = "the reference's ifsrrtm gas-optics routines (oracle/_ref, blocks of 4 columns on a thread pool) + oracle/ (plain C, "
-    rad = Radiation(config, backend=blocked)
+        backend = pyoracle.make_rrtmg_backend(config, inner=backend, nthreads=nthreads)
+        what = ("gas optics: the reference's ifsrrtm routines (oracle/_ref, \"reference\"; blocks of 8 columns on a thread pool) + "
+                "everything else: oracle/ (plain C, -O3, ")
+    return backend, what, nthreads
+
+
+def cpu_baseline(config, sample, seconds_target=10.0):
+    """Time the oracle on a bounded sample (the first columns of the timed batch, repeated for ~10 s)."""
+    from ecrad_amd.interface import Radiation
+    from ecrad_amd.types import Flux
+    backend, what, nthreads = oracle_backend(config)
+    rad = Radiation(config, backend=backend)
     ncol, nlev, sl, th, gas, cloud, aer = sample
-    nsample = ncol
     flux = Flux.allocate(config, ncol, nlev)
     rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)       # warm-up
     t0 = time.perf_counter()
@@ -102,35 +132,246 @@ def cpu_baseline(config, workload, sample, seconds_target=12.0):
         dt = time.perf_counter() - t0
         if dt >= seconds_target or reps >= 200:
             break
-    out = {"value": nsample * reps / dt, "unit": "columns/s", "cores": int(nthreads), "kind": "port",
-           "sample": f"{nsample} columns x {reps} repeats of the same synthetic workload, {what}"
-                     f"OpenMP over blocks of 32 columns as in driver/ecrad_driver.F90:348), {dt:.1f} s"}
+    out = {"value": ncol * reps / dt, "unit": "columns/s", "cores": nthreads, "kind": "port",
+           "sample": f"{ncol} columns ({ncol // 32} blocks of 32 for {nthreads} threads) x {reps} repeats of the same synthetic "
+                     f"workload, {what}OpenMP over blocks of 32 columns as in driver/ecrad_driver.F90:348), {dt:.1f} s"}
     return out, flux
 
 
+def measured_traffic(workload, ncol, kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/*_traffic.json,
+    written by tools/profile.sh + tools/summarize_prof.py from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    same command), or None if none matches this workload and column count."""
+    best = None
+    # (sorted by name: the tags are r<round>_<letter>, and file times do not survive a checkout)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("columns") != ncol or d.get("workload") != workload:
+            continue
+        for k, v in d.get("traffic_bytes_per_launch", {}).items():
+            if k.startswith(kernel_prefix):
+                best = {"bytes_per_launch": v, "source": "profiles/" + os.path.basename(f)}
+    return best
+
+
+class Workload:
+    """One named workload resident in HBM on this rank: configuration, library handle, device arrays."""
+
+    def __init__(self, name, ncol, rank, local_rank, want_sample):
+        import torch
+        from ecrad_amd.device import DeviceCase
+        from ecrad_amd.interface import Radiation
+        from ecrad_amd.synthetic import make_columns
+        from ecrad_amd.types import Flux
+        self.name, self.ncol = name, ncol
+        self.config, self.clear_sky, self.desc = build_config(name)
+        self.rad = Radiation(self.config, backend="hip", device_id=local_rank)
+        self.rad.lib.ecrad_hip_set_stream(self.rad.handle, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        device = f"cuda:{local_rank}"
+        # weak scaling: every rank owns `ncol` columns of the global batch; generated and uploaded in chunks
+        self.sample, self.host_inputs = None, None
+        cases = []
+        for c0 in range(0, ncol, CHUNK_COLUMNS):
+            n = min(CHUNK_COLUMNS, ncol - c0)
+            inputs = make_columns(self.config, n, self.clear_sky, first_column=rank * ncol + c0)
+            self.nlev = inputs[1]
+            if c0 == 0:
+                if want_sample:
+                    self.sample = first_columns(inputs, want_sample)
+                if ncol <= CHUNK_COLUMNS:
+                    self.host_inputs = inputs
+            cases.append(DeviceCase(self.config, n, self.nlev, *inputs[2:], Flux.allocate(self.config, n, self.nlev), device=device))
+        if len(cases) == 1:
+            self.case = cases[0]
+        else:
+            self.case = DeviceCase.concatenate(self.config, cases)
+            del cases
+            torch.cuda.empty_cache()
+        self.fraction0 = self.case.tensors["cloud_fraction"].clone() if "cloud_fraction" in self.case.tensors else None
+        self.profile_names = [n for n in ("lw_up", "lw_dn", "sw_up", "sw_dn", "sw_dn_direct", "lw_up_clear", "lw_dn_clear",
+                                          "sw_up_clear", "sw_dn_clear", "sw_dn_direct_clear", "lw_derivatives")
+                              if n in self.case.flux_tensors]
+
+    def step(self, gather_world=0):
+        from ecrad_amd.parallel import gather_profiles, pack_profiles
+        rad, case = self.rad, self.case
+        if self.fraction0 is not None:      # radiation() crops cloud%fraction in place: restore the input
+            case.tensors["cloud_fraction"].copy_(self.fraction0)
+        st = rad.lib.ecrad_hip_radiation(rad.handle, self.ncol, self.nlev, 1, self.ncol, C.byref(case.inputs), C.byref(case.flux))
+        if st != 0:
+            raise RuntimeError(rad.lib.ecrad_hip_last_error(rad.handle).decode())
+        if gather_world:
+            packed = pack_profiles(case.flux_tensors, self.profile_names)
+            gather_profiles(packed, [self.ncol] * gather_world, dst=0)
+
+    def stage_ms(self):
+        ms, out = C.c_double(), {}
+        for k, name in ((0, "prep"), (1, "lw"), (2, "sw"), (3, "post")):
+            self.rad.lib.ecrad_hip_last_stage_ms(self.rad.handle, k, C.byref(ms))
+            out[name] = ms.value
+        return out
+
+    def call_info(self):
+        from ecrad_amd import abi
+        info = abi.CallInfo()
+        self.rad.lib.ecrad_hip_last_call_info(self.rad.handle, C.byref(info))
+        return info
+
+    def close(self):
+        import torch
+        self.rad.close()
+        self.case = None
+        self.fraction0 = None
+        torch.cuda.empty_cache()
+
+
+def timed_steps(w, steps, warmup, barrier, gather_world=0):
+    for _ in range(warmup):
+        w.step(gather_world)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        w.step(gather_world)
+    barrier()
+    return time.perf_counter() - t0
+
+
+def roofline_of(w, stage_ms, elapsed_per_step_s):
+    """HIP events on the launch stream bracket the LW and SW stages of a call (ecrad_hip_last_stage_ms); the dominant
+    one is priced against SURVEY 8(d)'s algorithmic bytes of that stage."""
+    config, nlev, ncol = w.config, w.nlev, w.ncol
+    dom = "sw" if stage_ms["sw"] >= stage_ms["lw"] else "lw"
+    dom_ms = stage_ms[dom]
+    a_dom = algorithmic_bytes_per_column(config, nlev, dom, w.clear_sky)
+    a_all = sum(algorithmic_bytes_per_column(config, nlev, k, w.clear_sky) for k in ("sw", "lw"))
+    achieved = a_dom * ncol / (dom_ms * 1e-3) / 1e9
+    info = w.call_info()
+    launches = info.launches_sw if dom == "sw" else info.launches_lw
+    kernel = f"{dom}_tc_kernel" if w.desc["sw_solver"] == "Tripleclouds" else f"{dom}_ica_kernel"
+    traffic = measured_traffic(w.name, ncol, kernel)
+    whole = a_all * ncol / elapsed_per_step_s / 1e9
+    return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_triad": achieved / HBM_TRIAD_GBS,
+            # spectra wider than 64 g-points run as several launches of the kernel; the stage time and the algorithmic
+            # bytes cover all of them (and, for McICA, the cloud generator that feeds them), the PMC figure is per launch
+            "traffic": traffic["bytes_per_launch"] * launches * info.n_tiles if traffic else None,
+            "traffic_source": traffic["source"] if traffic else None,
+            "launches_per_step": launches * info.n_tiles, "column_tiles": info.n_tiles,
+            "algorithmic_bytes": a_dom * ncol, "algorithmic_bytes_per_column": a_dom, "kernel_ms": dom_ms,
+            "whole_step": {"algorithmic_bytes_per_column": a_all, "achieved": whole, "frac": whole / HBM_PEAK_GBS},
+            "stage_ms": stage_ms, "work_bytes": int(info.work_bytes)}
+
+
+def check_parity(w, oracle_flux):
+    """The timed configuration against the oracle on the sample (outside the timed region; the oracle is the checker,
+    never the thing measured).  Names the field, column and level of the largest difference."""
+    worst = {"max_rel_diff_vs_oracle": 0.0, "field": None}
+    nchk = oracle_flux.ncol
+    for name, t in w.case.flux_tensors.items():
+        ref = oracle_flux.arrays.get(name)
+        if ref is None:
+            continue
+        got = (t[..., :nchk] if t.shape[-1] == w.ncol else t[:nchk]).cpu().numpy()
+        scale = np.maximum(np.abs(ref), 1e-3 * np.abs(ref).max() + 1e-300)
+        err = np.abs(got - ref) / scale
+        if not np.all(np.isfinite(got)):
+            return {"max_rel_diff_vs_oracle": float("nan"), "field": name, "columns_checked": int(nchk), "tolerance": PARITY_TOLERANCE, "ok": False}
+        idx = np.unravel_index(int(np.argmax(err)), err.shape)
+        if err[idx] > worst["max_rel_diff_vs_oracle"]:
+            worst = {"max_rel_diff_vs_oracle": float(err[idx]), "field": name, "index": [int(i) for i in idx]}
+    worst.update({"columns_checked": int(nchk), "tolerance": PARITY_TOLERANCE,
+                  "ok": bool(worst["max_rel_diff_vs_oracle"] <= PARITY_TOLERANCE)})
+    return worst
+
+
+def with_stdout_on_stderr(fn, *a, **kw):
+    """(the reference's RRTMG set-up routines print to Fortran unit 6: keep stdout for the JSON line)"""
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return fn(*a, **kw)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+
+
+def end_to_end_host(w, repeats=3):
+    """The same call through ECRAD_MEM_HOST pointers: pageable host arrays, H2D + kernels + D2H inside the call."""
+    from ecrad_amd.types import Flux
+    ncol, nlev, sl, th, gas, cloud, aer = w.host_inputs
+    if cloud is not None:
+        frac0 = cloud.fraction.copy()
+    flux = Flux.allocate(w.config, ncol, nlev)
+    w.rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)
+    t = 0.0
+    for _ in range(repeats):
+        if cloud is not None:
+            cloud.fraction[...] = frac0
+        t0 = time.perf_counter()
+        w.rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)
+        t += time.perf_counter() - t0
+    return {"value": ncol * repeats / t, "unit": "columns/s", "ms_per_call": 1e3 * t / repeats,
+            "note": "ECRAD_MEM_HOST: pageable host arrays, the call stages H2D, runs the kernels and copies back (PCIe-inclusive); never `value`"}
+
+
+def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allreduce_max, do_cpu, do_host_mode):
+    sample_cols = 16384 if do_cpu else 0
+    w = Workload(name, ncol, rank, local_rank, sample_cols)
+    elapsed = allreduce_max(timed_steps(w, steps, warmup, barrier))
+    stage = w.stage_ms()
+    # a few extra untimed steps to average the per-stage duration
+    import torch
+    acc = [stage]
+    for _ in range(2):
+        w.step()
+        torch.cuda.synchronize()
+        acc.append(w.stage_ms())
+    stage = {k: float(np.mean([a[k] for a in acc])) for k in stage}
+    res = {"value": world * ncol * steps / elapsed, "unit": "columns/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": 1e3 * elapsed / steps,
+           "config": {"workload": name, "columns_per_gpu_per_step": ncol, "nlev": w.nlev, "n_g_sw": w.config.n_g_sw,
+                      "n_g_lw": w.config.n_g_lw, "sw_solver": w.desc["sw_solver"], "gas_model": "RRTMG-IFS" if w.desc["rrtmg"] else "ecCKD",
+                      "aerosols": bool(w.config.use_aerosols), "clouds": not w.clear_sky},
+           "roofline": roofline_of(w, stage, elapsed / steps)}
+    if world > 1:
+        e2 = allreduce_max(timed_steps(w, steps, 1, barrier, gather_world=world))
+        res["value_with_gather"] = world * ncol * steps / e2
+        res["ms_per_step_with_gather"] = 1e3 * e2 / steps
+    if do_cpu and rank == 0:
+        w.step()
+        torch.cuda.synchronize()
+        res["cpu_baseline"], oracle_flux = with_stdout_on_stderr(cpu_baseline, w.config, w.sample)
+        res["parity"] = check_parity(w, oracle_flux)
+    if do_host_mode and rank == 0 and w.host_inputs is not None:
+        res["end_to_end_host"] = end_to_end_host(w)
+    w.close()
+    return res
+
+
 def main():
-    os.environ.setdefault("GFORTRAN_UNBUFFERED_ALL", "1")      # (see the cpu_baseline leg below)
+    os.environ.setdefault("GFORTRAN_UNBUFFERED_ALL", "1")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--ncol", type=int, default=100000, help="columns per GPU per step")
-    ap.add_argument("--workload", default="clear_homogeneous_ecckd32")
+    ap.add_argument("--ncol", type=int, default=100000, help="columns per GPU per step of the headline workload")
+    ap.add_argument("--workload", default="clear_homogeneous_ecckd32", help="headline workload (ecrad_amd/synthetic.py: BENCH_CONFIGS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather", action="store_true",
-                    help="at N>1 also gather the flux profiles on rank 0 every step (what an offline driver writing "
-                         "one output file would do); off by default: the path has no exchange step, every rank "
-                         "keeps the columns it owns")
+    ap.add_argument("--headline-only", action="store_true", help="skip the other BASELINE configurations (\"workloads\")")
     args = ap.parse_args()
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes", file=sys.stderr)
-            sys.exit(2)
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes", file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
@@ -141,161 +382,54 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    from ecrad_amd.cases import make_config
-    from ecrad_amd.device import DeviceCase
-    from ecrad_amd.interface import Radiation
-    from ecrad_amd.parallel import gather_profiles, pack_profiles
-    from ecrad_amd.synthetic import BENCH_CONFIGS, make_columns
-    from ecrad_amd.types import Flux
-
-    spec = dict(BENCH_CONFIGS[args.workload])
-    clear_sky = spec.pop("clear_sky")
-    sw_solver = spec.pop("sw_solver")
-    is_rrtmg = bool(spec.pop("rrtmg", False))
-    if is_rrtmg:
-        from ecrad_amd.cases import make_config_rrtmg
-        config = make_config_rrtmg(sw_solver, **spec)
-    else:
-        config = make_config(sw_solver, **spec)
-    rad = Radiation(config, backend="hip", device_id=local_rank)
-    stream = torch.cuda.current_stream()
-    rad.lib.ecrad_hip_set_stream(rad.handle, C.c_void_p(stream.cuda_stream))
-
-    # weak scaling: every rank owns args.ncol columns of the global batch world*args.ncol
-    ncol, nlev, sl, th, gas, cloud, aer = make_columns(config, args.ncol, clear_sky, first_column=rank * args.ncol)
-    cpu_sample = first_columns((ncol, nlev, sl, th, gas, cloud, aer), 2048) if world == 1 and not args.no_cpu_baseline else None
-    flux = Flux.allocate(config, ncol, nlev)
-    case = DeviceCase(config, ncol, nlev, sl, th, gas, cloud, aer, flux, device=f"cuda:{local_rank}")
-    profile_names = [n for n in ("lw_up", "lw_dn", "sw_up", "sw_dn", "sw_dn_direct", "lw_up_clear", "lw_dn_clear",
-                                 "sw_up_clear", "sw_dn_clear", "sw_dn_direct_clear", "lw_derivatives")
-                     if n in case.flux_tensors]
-    do_gather = world > 1 and args.gather
-    fraction0 = case.tensors["cloud_fraction"].clone() if "cloud_fraction" in case.tensors else None
-
-    def step():
-        if fraction0 is not None:      # radiation() crops cloud%fraction in place: restore the input
-            case.tensors["cloud_fraction"].copy_(fraction0)
-        st = rad.lib.ecrad_hip_radiation(rad.handle, ncol, nlev, 1, ncol, C.byref(case.inputs), C.byref(case.flux))
-        if st != 0:
-            raise RuntimeError(rad.lib.ecrad_hip_last_error(rad.handle).decode())
-        if do_gather:
-            packed = pack_profiles(case.flux_tensors, profile_names)
-            gather_profiles(packed, [ncol] * world, dst=0)
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    stage_ms = {"lw": [], "sw": [], "prep": [], "post": []}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        # per-stage HIP-event durations are read after the loop for the LAST step only (reading them
-        # earlier would synchronise the stream inside the timed region)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ms = C.c_double()
-    for k, name in ((0, "prep"), (1, "lw"), (2, "sw"), (3, "post")):
-        rad.lib.ecrad_hip_last_stage_ms(rad.handle, k, C.byref(ms))
-        stage_ms[name].append(ms.value)
-    # a few extra untimed steps to average the per-kernel duration
-    for _ in range(3):
-        step()
-        torch.cuda.synchronize()
-        for k, name in ((1, "lw"), (2, "sw")):
-            rad.lib.ecrad_hip_last_stage_ms(rad.handle, k, C.byref(ms))
-            stage_ms[name].append(ms.value)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+    def allreduce_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
 
-    def measured_traffic(kernel_prefix):
-        """HBM bytes per launch of the dominant kernel from the newest committed PMC summary
-        (profiles/*_traffic.json, written by tools/profile.sh + tools/summarize_prof.py from separate
-        --pmc FETCH_SIZE / WRITE_SIZE passes of this same command), or None if none matches this
-        workload and column count."""
-        import glob
-        best = None
-        # (sorted by name: the tags are r<round>_<letter>, and file times do not survive a checkout)
-        for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_traffic.json"))):
+    do_cpu = world == 1 and not args.no_cpu_baseline
+    head = measure(args.workload, args.ncol, args.steps, args.warmup, rank, local_rank, world, barrier, allreduce_max,
+                   do_cpu, do_host_mode=(world == 1))
+    cfg = head["config"]
+    out = {
+        "metric": "columns/sec (SW+LW) at 137 lev, " + ("RRTMG 140/112" if cfg["gas_model"] != "ecCKD" else f"ecCKD-{cfg['n_g_sw']}"),
+        "value": head["value"], "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": dict(cfg, parallelism=f"columns sharded over {world} GPU(s), no data-path collective"),
+        "roofline": head["roofline"],
+    }
+    for k in ("value_with_gather", "ms_per_step_with_gather", "cpu_baseline", "parity", "end_to_end_host"):
+        if k in head:
+            out[k] = head[k]
+    failed = "parity" in head and not head["parity"]["ok"]
+    if world == 1 and not args.headline_only and args.workload == "clear_homogeneous_ecckd32":
+        out["workloads"] = {}
+        for name, ncol in EXTRA_WORKLOADS:
+            steps = max(2, min(args.steps, 5 if ncol <= 100000 else 3))
             try:
-                d = json.load(open(f))
-            except Exception:
-                continue
-            if d.get("columns") != ncol or d.get("workload") != args.workload:
-                continue
-            for k, v in d.get("traffic_bytes_per_launch", {}).items():
-                if k.startswith(kernel_prefix):
-                    best = {"bytes_per_launch": v, "source": "profiles/" + os.path.basename(f)}
-        return best
-
+                r = measure(name, ncol, steps, 1, rank, local_rank, world, barrier, allreduce_max, do_cpu, do_host_mode=False)
+            except Exception as e:      # an extra workload must not take the headline line down with it
+                r = {"error": f"{type(e).__name__}: {e}"}
+            if "parity" in r and not r["parity"]["ok"]:
+                r["value"] = None
+                failed = True
+            out["workloads"][name] = r
     if rank == 0:
-        total_cols = world * ncol * args.steps
-        value = total_cols / elapsed
-        dom = "sw" if np.mean(stage_ms["sw"]) >= np.mean(stage_ms["lw"]) else "lw"
-        dom_ms = float(np.mean(stage_ms[dom]))
-        a_bytes = algorithmic_bytes_per_column(config, nlev, dom, clear_sky)
-        achieved = a_bytes * ncol / (dom_ms * 1e-3) / 1e9
-        dom_kernel = f"{dom}_ica_kernel" if sw_solver != "Tripleclouds" else f"{dom}_tc_kernel"
-        traffic = measured_traffic(dom_kernel)
-        # spectra wider than 64 g-points run as several launches of the kernel (api.hip: chunk_lanes); the stage time
-        # and the algorithmic bytes cover all of them, so the per-launch PMC figure is scaled by the launch count
-        ng_dom = config.n_g_sw if dom == "sw" else config.n_g_lw
-        launches = 1
-        if ng_dom > 64:
-            pads = {n: -(-ng_dom // n) * n for n in (64, 32, 16)}
-            ok = [n for n in (64, 32, 16) if (pads[n] - ng_dom) * 100 <= 15 * ng_dom]
-            best = ok[0] if ok else min((64, 32, 16), key=lambda n: (pads[n], -n))
-            launches = pads[best] // best
-        if traffic:
-            traffic["bytes_per_launch"] *= launches
-        out = {
-            "metric": "columns/sec (SW+LW) at 137 lev, " + ("RRTMG 140/112" if is_rrtmg else "ecCKD-32"), "value": value, "unit": "columns/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": args.workload, "columns_per_gpu_per_step": ncol, "nlev": nlev,
-                       "n_g_sw": config.n_g_sw, "n_g_lw": config.n_g_lw, "sw_solver": sw_solver,
-                       "aerosols": bool(config.use_aerosols), "clouds": not clear_sky,
-                       "parallelism": f"columns sharded over {world} GPU(s)" + (", flux profiles gathered on rank 0" if do_gather else "")},
-            "roofline": {"bound": "hbm", "kernel": dom_kernel,
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic["bytes_per_launch"] if traffic else None,
-                         "traffic_source": traffic["source"] if traffic else None,
-                         "launches_per_step": launches, "algorithmic_bytes": a_bytes * ncol, "algorithmic_bytes_per_column": a_bytes, "kernel_ms": dom_ms,
-                         "stage_ms": {k: float(np.mean(v)) for k, v in stage_ms.items() if v}},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            # (the reference's RRTMG set-up routines print to Fortran unit 6: keep stdout for the JSON line)
-            sys.stdout.flush()
-            saved_fd = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                out["cpu_baseline"], oracle_flux = cpu_baseline(config, args.workload, cpu_sample)
-            finally:
-                os.dup2(saved_fd, 1)
-                os.close(saved_fd)
-            # the oracle's sample is the first columns of this rank's batch: check the timed configuration
-            # against it (outside the timed region; the oracle is the checker, never the thing measured)
-            worst, nchk = 0.0, oracle_flux.ncol
-            for name, t in case.flux_tensors.items():
-                ref = oracle_flux.arrays.get(name)
-                if ref is None:
-                    continue
-                got = t.cpu().numpy()
-                got = got[..., :nchk] if got.shape[-1] == ncol else got[:nchk]
-                scale = np.maximum(np.abs(ref), 1e-3 * np.abs(ref).max() + 1e-300)
-                worst = max(worst, float(np.max(np.abs(got - ref) / scale)))
-            out["parity"] = {"max_rel_diff_vs_oracle": worst, "columns_checked": int(nchk), "tolerance": 1e-6}
+        if failed and "parity" in head and not head["parity"]["ok"]:
+            out["value"] = None
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(1 if failed else 0)
 
 
 if __name__ == "__main__":

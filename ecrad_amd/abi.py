@@ -183,6 +183,13 @@ class Optics(C.Structure):
     _fields_ = [("memory", C.c_int32), ("reserved_", C.c_int32)] + [(n, c_double_p) for n in OPTICS_FIELDS]
 
 
+class CallInfo(C.Structure):
+    """ecrad_call_info_t"""
+    _fields_ = [("n_tiles", C.c_int32), ("tile_columns", C.c_int32), ("launches_lw", C.c_int32),
+                ("launches_sw", C.c_int32), ("lanes_lw", C.c_int32), ("lanes_sw", C.c_int32),
+                ("work_bytes", C.c_size_t)]
+
+
 STRUCT_BY_INDEX = [Config, Inputs, Flux, Optics, CkdModel, CkdGas, CloudOptics, AerosolOptics, PdfSampler,
                    Rrtmg, RrtmgBand]
 
@@ -245,11 +252,15 @@ def declare_prototypes(lib) -> None:
     lib.ecrad_hip_abi_sizeof.restype = C.c_size_t
     lib.ecrad_hip_abi_version.argtypes = []
     lib.ecrad_hip_abi_version.restype = C.c_int
+    lib.ecrad_hip_set_work_bytes.argtypes = [H, C.c_size_t]
+    lib.ecrad_hip_set_work_bytes.restype = C.c_int
+    lib.ecrad_hip_last_call_info.argtypes = [H, C.POINTER(CallInfo)]
+    lib.ecrad_hip_last_call_info.restype = C.c_int
 
 
 EXPORTED_SYMBOLS = [
     "ecrad_hip_create", "ecrad_hip_setup", "ecrad_hip_set_stream", "ecrad_hip_radiation",
     "ecrad_hip_optics", "ecrad_hip_synchronize", "ecrad_hip_last_kernel_ms", "ecrad_hip_last_stage_ms",
     "ecrad_hip_scratch_bytes", "ecrad_hip_last_error", "ecrad_hip_destroy",
-    "ecrad_hip_abi_sizeof", "ecrad_hip_abi_version",
+    "ecrad_hip_abi_sizeof", "ecrad_hip_abi_version", "ecrad_hip_set_work_bytes", "ecrad_hip_last_call_info",
 ]

@@ -56,8 +56,13 @@ struct ecrad_hip_handle_s {
   const ecrad::rrtmg::DevRrtmg* d_rrtmg = nullptr;   // RRTMG tables (device), see rrtmg_device.h
   bool rrtmg_sw = false, rrtmg_lw = false;
   Buf gas_stage, gas_work;         // stage-interface arrays and work records of the RRTMG gas-optics pass
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  hipEvent_t evs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // stage boundaries
+  // One set of stage-boundary events per column tile of the most recent call (a call whose work arrays
+  // would exceed `work_budget` runs as several tiles of columns, see ecrad_hip_radiation)
+  struct TileEvents { hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; };
+  std::vector<TileEvents> tile_events;
+  int tiles_last_call = 0;
+  int tile_columns_last_call = 0;
+  size_t work_budget = (size_t)64 << 30;      // bytes of per-call work arrays before a call is tiled
   double stage_ms[4] = {0, 0, 0, 0};
   bool timing_pending = false;
   double last_ms = 0.0;
@@ -412,6 +417,44 @@ int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
     return fail(h, ECRAD_EUNSUPPORTED, "shortwave spectrum too wide for the cloud generator");
   { int nch = 1; if (c.do_lw && (c.n_g_lw < 1 || (chunk_lanes(c.n_g_lw, &nch), nch > 15))) return fail(h, ECRAD_EUNSUPPORTED, "longwave spectrum too wide"); }
   if (c.do_clouds && (c.n_cloud_types < 1 || c.n_cloud_types > ECRAD_NMAXCLOUDTYPES)) return fail(h, ECRAD_EINVAL, "n_cloud_types out of range");
+  // Tables the selected options dereference on the device: a NULL here would fault the GPU, not return a status
+  if (c.do_sw) {
+    if (!c.i_band_from_reordered_g_sw) return fail(h, ECRAD_EINVAL, "i_band_from_reordered_g_sw missing");
+    if (c.do_nearest_spectral_sw_albedo && !c.i_albedo_from_band_sw) return fail(h, ECRAD_EINVAL, "do_nearest_spectral_sw_albedo needs i_albedo_from_band_sw");
+    if (!c.do_nearest_spectral_sw_albedo && !c.use_canopy_full_spectrum_sw && !c.sw_albedo_weights) return fail(h, ECRAD_EINVAL, "sw_albedo_weights missing");
+    if (c.i_gas_model_sw == ECRAD_GAS_ECCKD) {
+      const ecrad_ckd_model_t& m = c.gas_optics_sw;
+      if (!m.norm_solar_irradiance || !m.rayleigh_molar_scat) return fail(h, ECRAD_EINVAL, "shortwave ecCKD model needs norm_solar_irradiance and rayleigh_molar_scat");
+      if (!m.temperature1) return fail(h, ECRAD_EINVAL, "shortwave ecCKD model: temperature1 missing");
+      for (int j = 0; j < m.ngas && j < ECRAD_NMAXGASES; ++j) if (!m.single_gas[j].molar_abs) return fail(h, ECRAD_EINVAL, "shortwave ecCKD model: molar_abs missing");
+    }
+  }
+  if (c.do_lw) {
+    if (!c.i_band_from_reordered_g_lw) return fail(h, ECRAD_EINVAL, "i_band_from_reordered_g_lw missing");
+    if (c.do_nearest_spectral_lw_emiss && !c.i_emiss_from_band_lw) return fail(h, ECRAD_EINVAL, "do_nearest_spectral_lw_emiss needs i_emiss_from_band_lw");
+    if (!c.do_nearest_spectral_lw_emiss && !c.use_canopy_full_spectrum_lw && !c.lw_emiss_weights) return fail(h, ECRAD_EINVAL, "lw_emiss_weights missing");
+    if (c.i_gas_model_lw == ECRAD_GAS_ECCKD) {
+      const ecrad_ckd_model_t& m = c.gas_optics_lw;
+      if (!m.planck_function || !m.temperature1) return fail(h, ECRAD_EINVAL, "longwave ecCKD model needs planck_function and temperature1");
+      for (int j = 0; j < m.ngas && j < ECRAD_NMAXGASES; ++j) if (!m.single_gas[j].molar_abs) return fail(h, ECRAD_EINVAL, "longwave ecCKD model: molar_abs missing");
+    }
+  }
+  if (c.do_clouds && c.use_general_cloud_optics)
+    for (int t = 0; t < c.n_cloud_types; ++t) {
+      if (c.do_sw && (!c.cloud_optics_sw[t].mass_ext || !c.cloud_optics_sw[t].ssa || !c.cloud_optics_sw[t].asymmetry))
+        return fail(h, ECRAD_EINVAL, "general cloud optics: mass_ext, ssa and asymmetry are needed for every shortwave cloud type");
+      if (c.do_lw && (!c.cloud_optics_lw[t].mass_ext || (c.do_lw_cloud_scattering && (!c.cloud_optics_lw[t].ssa || !c.cloud_optics_lw[t].asymmetry))))
+        return fail(h, ECRAD_EINVAL, "general cloud optics: mass_ext (and ssa, asymmetry with longwave scattering) are needed for every longwave cloud type");
+    }
+  if (c.use_aerosols) {
+    const ecrad_aerosol_optics_t& a = c.aerosol_optics;
+    if (a.ntype < 1 || !a.iclass || !a.itype) return fail(h, ECRAD_EINVAL, "aerosol optics: iclass/itype missing");
+    if (a.use_hydrophilic && (a.nrh < 1 || !a.rh_lower)) return fail(h, ECRAD_EINVAL, "aerosol optics: rh_lower missing");
+    if (c.do_sw && a.n_type_phobic > 0 && (!a.mass_ext_sw_phobic || !a.ssa_sw_phobic || !a.g_sw_phobic)) return fail(h, ECRAD_EINVAL, "aerosol optics: shortwave hydrophobic tables missing");
+    if (c.do_lw && a.n_type_phobic > 0 && (!a.mass_ext_lw_phobic || !a.ssa_lw_phobic || !a.g_lw_phobic)) return fail(h, ECRAD_EINVAL, "aerosol optics: longwave hydrophobic tables missing");
+    if (a.use_hydrophilic && c.do_sw && a.n_type_philic > 0 && (!a.mass_ext_sw_philic || !a.ssa_sw_philic || !a.g_sw_philic)) return fail(h, ECRAD_EINVAL, "aerosol optics: shortwave hydrophilic tables missing");
+    if (a.use_hydrophilic && c.do_lw && a.n_type_philic > 0 && (!a.mass_ext_lw_philic || !a.ssa_lw_philic || !a.g_lw_philic)) return fail(h, ECRAD_EINVAL, "aerosol optics: longwave hydrophilic tables missing");
+  }
   if (c.do_clouds && !c.use_general_cloud_optics) {
     if (c.i_liq_model != ECRAD_LIQUID_SOCRATES || c.i_ice_model != ECRAD_ICE_FU) return fail(h, ECRAD_EUNSUPPORTED, "band cloud optics: only the SOCRATES liquid and Fu ice models are implemented");
     if (c.n_cloud_types != 2) return fail(h, ECRAD_EINVAL, "band cloud optics need exactly two cloud types (liquid, ice)");
@@ -464,8 +507,7 @@ int ecrad_hip_create(ecrad_hip_handle_t* handle, int device_id) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) h->num_cu = prop.multiProcessorCount;
   if (const char* e = std::getenv("ECRAD_HIP_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= 8) h->blocks_per_cu = v; }
-  if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) { delete h; return ECRAD_EHIP; }
-  for (auto& e : h->evs) if (hipEventCreate(&e) != hipSuccess) { delete h; return ECRAD_EHIP; }
+  if (const char* e = std::getenv("ECRAD_HIP_WORK_GIB")) { const double v = std::atof(e); if (v > 0.0) h->work_budget = (size_t)(v * 1073741824.0); }
   *handle = h;
   return ECRAD_OK;
 }
@@ -483,9 +525,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
   (void)hipSetDevice(h->device);
   free_tables(h);
   h->gas_stage.release(); h->gas_work.release(); h->counters.release(); h->partial.release(); h->spec_tmp.release(); h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
-  if (h->ev0) (void)hipEventDestroy(h->ev0);
-  if (h->ev1) (void)hipEventDestroy(h->ev1);
-  for (auto& e : h->evs) if (e) (void)hipEventDestroy(e);
+  for (auto& t : h->tile_events) for (auto& e : t.e) if (e) (void)hipEventDestroy(e);
   delete h;
   return ECRAD_OK;
 }
@@ -506,13 +546,17 @@ int ecrad_hip_synchronize(ecrad_hip_handle_t h) {
 int ecrad_hip_last_kernel_ms(ecrad_hip_handle_t h, double* ms) {
   if (!h || !ms) return ECRAD_EINVAL;
   if (h->timing_pending) {
-    HIP_TRY(h, hipEventSynchronize(h->ev1));
-    float f = 0.f;
-    HIP_TRY(h, hipEventElapsedTime(&f, h->ev0, h->ev1));
-    h->last_ms = f;
-    for (int k = 0; k < 4; ++k) {
-      HIP_TRY(h, hipEventElapsedTime(&f, h->evs[k], h->evs[k + 1]));
-      h->stage_ms[k] = f;
+    for (int k = 0; k < 4; ++k) h->stage_ms[k] = 0.0;
+    h->last_ms = 0.0;
+    for (int t = 0; t < h->tiles_last_call; ++t) {
+      const auto& ev = h->tile_events[t].e;
+      HIP_TRY(h, hipEventSynchronize(ev[4]));
+      float f = 0.f;
+      for (int k = 0; k < 4; ++k) {
+        HIP_TRY(h, hipEventElapsedTime(&f, ev[k], ev[k + 1]));
+        h->stage_ms[k] += f;
+        h->last_ms += f;
+      }
     }
     h->timing_pending = false;
   }
@@ -747,6 +791,8 @@ int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int ie
     if (in->n_aerosol_types != c.aerosol_optics.ntype) return fail(h, ECRAD_EINVAL, "aerosol%mixing_ratio has the wrong number of types");  // radiation_aerosol_optics.F90:573
     if (in->aerosol_istartlev < 1 || in->aerosol_iendlev > nlev) return fail(h, ECRAD_EINVAL, "aerosol level range");
   }
+  if (c.do_sw && in->spectral_solar_cycle_multiplier != 0.0 && c.i_gas_model_sw == ECRAD_GAS_ECCKD && !c.gas_optics_sw.norm_amplitude_solar_irradiance)
+    return fail(h, ECRAD_EINVAL, "spectral_solar_cycle_multiplier is non-zero but the gas-optics file has no information on the solar cycle");   // radiation_ecckd.F90:955-961
   const bool mcica = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_MCICA) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_MCICA);
   if (mcica && !in->iseed) return fail(h, ECRAD_EINVAL, "McICA needs single_level%iseed");
   if (mcica && nlev > 255) return fail(h, ECRAD_EUNSUPPORTED, "McICA cloud generator supports at most 255 levels");
@@ -853,17 +899,45 @@ int grid_for(ecrad_hip_handle_t h, int nloc, int ngp) {
   return groups < maxgrid ? groups : maxgrid;
 }
 
-}  // namespace
-
-extern "C" {
-
-int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
-                        const ecrad_inputs_t* in, ecrad_flux_t* flux) {
-  if (!h || !in || !flux) return ECRAD_EINVAL;
-  if (!h->is_setup) return fail(h, ECRAD_ENOTSETUP, "ecrad_hip_setup has not been called");
-  HIP_TRY(h, hipSetDevice(h->device));
-  if (in->memory != flux->memory) return fail(h, ECRAD_EINVAL, "inputs and fluxes must live in the same memory space");
+// Bytes of per-call work arrays one column costs (the arrays below that are sized by the number of columns of a
+// call: RRTMG stage arrays and work records, cloud geometry / McICA optical-depth scalings, per-chunk partial
+// profiles, per-g spectral temporaries and, in host-memory mode, the staged inputs and outputs).
+size_t work_bytes_per_column(ecrad_hip_handle_t h, int nlev, const ecrad_inputs_t* in, const ecrad_flux_t* flux) {
   const ecrad_config_t& c = h->cfg;
+  const size_t L = nlev;
+  size_t b = 0;
+  if (h->rrtmg_lw) b += 8 * (size_t)ecrad::rrtmg::kNgLw * (2 * L + 2);
+  if (h->rrtmg_sw) b += 8 * (size_t)ecrad::rrtmg::kNgSw * (3 * L + 1);
+  if (h->rrtmg_lw || h->rrtmg_sw) b += rrtmg_work_bytes(nlev, 4096) / 4096;
+  const bool sw_mcica = c.do_sw && c.i_solver_sw == ECRAD_SOLVER_MCICA, lw_mcica = c.do_lw && c.i_solver_lw == ECRAD_SOLVER_MCICA;
+  const bool tc = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_TRIPLECLOUDS) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_TRIPLECLOUDS);
+  if (tc) b += 8 * (5 * L + 18 * (L + 1));
+  if (sw_mcica) b += 8 * ((size_t)c.n_g_sw * L + 1);
+  if (lw_mcica) b += 8 * ((size_t)c.n_g_lw * L + 1);
+  if (c.do_clouds) b += 8 * L;
+  const int nch = std::max(c.do_lw ? h->nchunk_lw : 1, c.do_sw ? h->nchunk_sw : 1);
+  if (nch > 1) b += 8 * (L + 1) * nch * 6;
+  if (c.do_save_spectral_flux) {
+    if (h->spec_sum_lw) b += 8 * (L + 1) * (size_t)c.n_g_lw * 4;
+    if (h->spec_sum_sw) b += 8 * (L + 1) * (size_t)c.n_g_sw * 6;
+  }
+  if (in->memory == ECRAD_MEM_HOST) {
+    const Range one{1, nlev, 1, 1, 1};
+    b += carve_inputs(nullptr, c, *in, one).bytes;
+    for (const FluxField& f : kFluxFields)
+      if (flux->*(f.host)) b += flux_rows(c, f.kind, nlev) * 8;
+  }
+  return b;
+}
+
+// One tile of columns istartcol..iendcol of a call: everything radiation() does (radiation_interface.F90:200-510)
+int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
+                   const ecrad_inputs_t* in, ecrad_flux_t* flux, int tile) {
+  const ecrad_config_t& c = h->cfg;
+  if ((int)h->tile_events.size() <= tile) h->tile_events.resize(tile + 1);
+  for (auto& e : h->tile_events[tile].e)
+    if (!e) HIP_TRY(h, hipEventCreate(&e));
+  hipEvent_t* const evs = h->tile_events[tile].e;
   CallCtx cx;
   int st = stage_inputs(h, ncol, nlev, istartcol, iendcol, in, cx);
   if (st) return st;
@@ -984,8 +1058,7 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
   double* scratch = reinterpret_cast<double*>(h->scratch.p);
 
   // ---- kernels (radiation_interface.F90:323-504) ------------------------------------------------------
-  HIP_TRY(h, hipEventRecord(h->ev0, stream));
-  HIP_TRY(h, hipEventRecord(h->evs[0], stream));
+  HIP_TRY(h, hipEventRecord(evs[0], stream));
   HIP_TRY(h, hipMemsetAsync(counters, 0, 256, stream));
   HIP_TRY(h, launch_order(stream, din, counters + 32));                                 // :310-317
   if ((st = run_rrtmg(h, cx, true))) return st;                                         // RRTMG gas optics, :341-357 (accounted to the PREP stage)
@@ -994,7 +1067,7 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
     HIP_TRY(h, launch_tripleclouds_prep(stream, h->dcfg, din, prep, sw_tc ? dfx.cloud_cover_sw : nullptr,
                                         lw_tc ? dfx.cloud_cover_lw : nullptr));
   // (the McICA generators are accounted to the LW/SW stage they feed)
-  HIP_TRY(h, hipEventRecord(h->evs[1], stream));
+  HIP_TRY(h, hipEventRecord(evs[1], stream));
   if (c.do_lw) {                                                                        // :422-457
     const DevCkdModel& m = h->hcfg.gas_lw;
     const int nct = (c.i_solver_lw != ECRAD_SOLVER_CLOUDLESS) ? c.n_cloud_types : 0;
@@ -1038,7 +1111,7 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
                                               plane, nch, lw_mcica ? dfx.cloud_cover_lw : nullptr, c.cloud_fraction_threshold));
     }
   }
-  HIP_TRY(h, hipEventRecord(h->evs[2], stream));
+  HIP_TRY(h, hipEventRecord(evs[2], stream));
   if (c.do_sw) {                                                                        // :459-499
     const DevCkdModel& m = h->hcfg.gas_sw;
     const int nct = (c.i_solver_sw != ECRAD_SOLVER_CLOUDLESS) ? c.n_cloud_types : 0;
@@ -1075,7 +1148,7 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
         if (dfx.*(prof[k])) HIP_TRY(h, launch_combine_partials(stream, din, dfx.*(prof[k]), pbase + plane * (size_t)k * nch, plane, nch));
     }
   }
-  HIP_TRY(h, hipEventRecord(h->evs[3], stream));
+  HIP_TRY(h, hipEventRecord(evs[3], stream));
   for (int k = 0; k < 10; ++k)
     if (spec_real[k]) {
       const bool lw = k < 4;
@@ -1086,9 +1159,7 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
   const bool wide = c.n_g_sw > 64 || c.n_g_lw > 64 || c.n_bands_sw > 64 || c.n_bands_lw > 64 ||
                     c.n_canopy_bands_sw > 64 || c.n_canopy_bands_lw > 64;
   HIP_TRY(h, launch_spectral_post(stream, h->dcfg, din, dfx, wide));                          // :503-504
-  HIP_TRY(h, hipEventRecord(h->evs[4], stream));
-  HIP_TRY(h, hipEventRecord(h->ev1, stream));
-  h->timing_pending = true;
+  HIP_TRY(h, hipEventRecord(evs[4], stream));
 
   if (cx.host_mem) {
     // D2H of the processed column range only: columns outside istartcol..iendcol are not touched
@@ -1113,6 +1184,61 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
                                   (size_t)r.nloc * 8, (size_t)r.nloc * 8, nlev, hipMemcpyDeviceToHost, stream));
     HIP_TRY(h, hipStreamSynchronize(stream));
   }
+  return ECRAD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
+                        const ecrad_inputs_t* in, ecrad_flux_t* flux) {
+  if (!h || !in || !flux) return ECRAD_EINVAL;
+  if (!h->is_setup) return fail(h, ECRAD_ENOTSETUP, "ecrad_hip_setup has not been called");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (in->memory != flux->memory) return fail(h, ECRAD_EINVAL, "inputs and fluxes must live in the same memory space");
+  if (ncol < 1 || nlev < 2 || istartcol < 1 || iendcol > ncol || iendcol < istartcol) return fail(h, ECRAD_EINVAL, "bad column/level range");
+  // Column tiling: every work array is sized by the columns of a tile, not of the call, so the device memory a
+  // call needs is bounded by `work_budget` (64 GiB unless ecrad_hip_set_work_bytes / ECRAD_HIP_WORK_GIB say
+  // otherwise) whatever istartcol..iendcol is.  Tiles are whole multiples of 256 columns (every kernel's column
+  // groups divide 256), at least 4096, so a tiled call launches the same column groups as an untiled one.
+  const int nloc = iendcol - istartcol + 1;
+  const size_t per_col = work_bytes_per_column(h, nlev, in, flux);
+  long long tile_cols = per_col ? (long long)(h->work_budget / per_col) : (long long)nloc;
+  tile_cols = std::max(4096ll, tile_cols / 256 * 256);
+  if (tile_cols > nloc) tile_cols = nloc;
+  const int ntile = (int)((nloc + tile_cols - 1) / tile_cols);
+  h->tiles_last_call = 0;
+  h->timing_pending = false;
+  for (int t = 0; t < ntile; ++t) {
+    const int i0 = istartcol + (int)(t * tile_cols);
+    const int i1 = std::min<long long>(iendcol, i0 + tile_cols - 1);
+    const int st = radiation_tile(h, ncol, nlev, i0, i1, in, flux, t);
+    if (st) return st;
+    h->tiles_last_call = t + 1;
+  }
+  h->tile_columns_last_call = (int)tile_cols;
+  h->timing_pending = true;
+  return ECRAD_OK;
+}
+
+int ecrad_hip_set_work_bytes(ecrad_hip_handle_t h, size_t bytes) {
+  if (!h || bytes == 0) return ECRAD_EINVAL;
+  h->work_budget = bytes;
+  return ECRAD_OK;
+}
+
+int ecrad_hip_last_call_info(ecrad_hip_handle_t h, ecrad_call_info_t* info) {
+  if (!h || !info) return ECRAD_EINVAL;
+  info->n_tiles = h->tiles_last_call;
+  info->tile_columns = h->tile_columns_last_call;
+  info->launches_lw = h->cfg.do_lw ? h->nchunk_lw : 0;
+  info->launches_sw = h->cfg.do_sw ? h->nchunk_sw : 0;
+  info->lanes_lw = h->cfg.do_lw ? h->ngp_lw : 0;
+  info->lanes_sw = h->cfg.do_sw ? h->ngp_sw : 0;
+  size_t b = 0;
+  (void)ecrad_hip_scratch_bytes(h, &b);
+  info->work_bytes = b;
   return ECRAD_OK;
 }
 

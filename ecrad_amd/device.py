@@ -78,3 +78,40 @@ class DeviceCase:
 
     def output_bytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.flux_tensors.values())
+
+    @classmethod
+    def concatenate(cls, config, cases):
+        """One DeviceCase over the columns of several (same configuration, same level count), in order.  Used to
+        build batches larger than what is comfortable to generate on the host in one piece."""
+        import torch
+        first = cases[0]
+        self = cls.__new__(cls)
+        self.torch, self.device, self.nlev = torch, first.device, first.nlev
+        self.ncol = sum(c.ncol for c in cases)
+
+        def col_axis(t, n):
+            if t.ndim == 1 or t.shape[-1] == n:
+                return t.ndim - 1
+            return 0 if t.shape[0] == n else 1
+
+        def cat(name, group):
+            parts = [getattr(c, group)[name] for c in cases]
+            out = torch.cat(parts, dim=col_axis(parts[0], first.ncol)).contiguous()
+            for c in cases:
+                del getattr(c, group)[name]
+            return out
+
+        self.tensors = {n: cat(n, "tensors") for n in list(first.tensors)}
+        self.flux_tensors = {n: cat(n, "flux_tensors") for n in list(first.flux_tensors)}
+        s = abi.Inputs()
+        for fname, _ in abi.Inputs._fields_:
+            setattr(s, fname, getattr(first.inputs, fname))
+        for n, t in self.tensors.items():
+            setattr(s, n, abi.raw_iptr(t.data_ptr()) if n == "iseed" else abi.raw_dptr(t.data_ptr()))
+        self.inputs = s
+        f = abi.Flux()
+        f.memory = abi.MEM_DEVICE
+        for n, t in self.flux_tensors.items():
+            setattr(f, n, abi.raw_dptr(t.data_ptr()))
+        self.flux = f
+        return self

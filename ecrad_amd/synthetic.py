@@ -36,7 +36,15 @@ def make_columns(config: Config, ncol: int, clear_sky: bool, seed: int = SEED, f
     # set_gas_units: volume mixing ratios for ecCKD, mass mixing ratios for RRTMG (radiation_ifs_rrtm.F90:203-213)
     gas0.set_units(0 if getattr(config, "rrtmg", None) is not None else 1)
     rng = np.random.default_rng([seed, first_column])
-    idx = (first_column + np.arange(ncol)) % nb
+    # column i takes base profile (first_column + i) mod nb: the base arrays rolled to the first profile and tiled
+    # (a fancy-index gather along the fastest axis is ~10x slower for the 100 000-column batches)
+    reps = -(-ncol // nb)
+
+    def take(a):
+        r = np.roll(a, -(first_column % nb), axis=-1)
+        out = np.empty(a.shape[:-1] + (reps, nb), dtype=a.dtype)
+        out[...] = r[..., None, :]
+        return out.reshape(a.shape[:-1] + (reps * nb,))[..., :ncol]
     ps_scale = rng.uniform(0.95, 1.05, ncol)
     dT = rng.normal(0.0, 2.0, ncol)
     qfac = np.exp(rng.normal(0.0, 0.2, ncol))
@@ -44,34 +52,34 @@ def make_columns(config: Config, ncol: int, clear_sky: bool, seed: int = SEED, f
     dTskin = rng.normal(0.0, 1.0, ncol)
     cf_fac = rng.uniform(0.5, 1.5, ncol)
 
-    pressure_hl = np.ascontiguousarray(th0.pressure_hl[:, idx] * ps_scale[None, :])
-    temperature_hl = np.ascontiguousarray(th0.temperature_hl[:, idx] + dT[None, :])
+    pressure_hl = np.ascontiguousarray(take(th0.pressure_hl) * ps_scale[None, :])
+    temperature_hl = np.ascontiguousarray(take(th0.temperature_hl) + dT[None, :])
     th = Thermodynamics(pressure_hl, temperature_hl)
     th.calc_saturation_wrt_liquid()
     sl = SingleLevel(
         cos_sza=np.ascontiguousarray(cos_sza),
         skin_temperature=np.ascontiguousarray(temperature_hl[nlev] + dTskin),
-        sw_albedo=np.ascontiguousarray(sl0.sw_albedo[:, idx]),
-        lw_emissivity=np.ascontiguousarray(sl0.lw_emissivity[:, idx]),
-        sw_albedo_direct=None if sl0.sw_albedo_direct is None else np.ascontiguousarray(sl0.sw_albedo_direct[:, idx]),
+        sw_albedo=np.ascontiguousarray(take(sl0.sw_albedo)),
+        lw_emissivity=np.ascontiguousarray(take(sl0.lw_emissivity)),
+        sw_albedo_direct=None if sl0.sw_albedo_direct is None else np.ascontiguousarray(take(sl0.sw_albedo_direct)),
         solar_irradiance=sl0.solar_irradiance,
         iseed=(first_column + 1 + np.arange(ncol)).astype(np.int32))
-    gas = Gas(mixing_ratio=np.ascontiguousarray(gas0.mixing_ratio[:, :, idx]))
+    gas = Gas(mixing_ratio=np.ascontiguousarray(take(gas0.mixing_ratio)))
     gas.iunits = list(gas0.iunits)
     gas.scale_factor = list(gas0.scale_factor)
     gas.is_present = list(gas0.is_present)
     gas.mixing_ratio[0] *= qfac[None, :]          # H2O
     cloud = None
     if config.do_clouds:
-        frac = np.zeros((nlev, ncol)) if clear_sky else np.clip(cloud0.fraction[:, idx] * cf_fac[None, :], 0.0, 1.0)
+        frac = np.zeros((nlev, ncol)) if clear_sky else np.clip(take(cloud0.fraction) * cf_fac[None, :], 0.0, 1.0)
         cloud = Cloud(fraction=np.ascontiguousarray(frac),
-                      mixing_ratio=np.ascontiguousarray(cloud0.mixing_ratio[:, :, idx]),
-                      effective_radius=np.ascontiguousarray(cloud0.effective_radius[:, :, idx]),
-                      fractional_std=np.ascontiguousarray(cloud0.fractional_std[:, idx]),
-                      overlap_param=np.ascontiguousarray(cloud0.overlap_param[:, idx]))
+                      mixing_ratio=np.ascontiguousarray(take(cloud0.mixing_ratio)),
+                      effective_radius=np.ascontiguousarray(take(cloud0.effective_radius)),
+                      fractional_std=np.ascontiguousarray(take(cloud0.fractional_std)),
+                      overlap_param=np.ascontiguousarray(take(cloud0.overlap_param)))
     aerosol = None
     if config.use_aerosols and aer0 is not None:
-        aerosol = Aerosol(mixing_ratio=np.ascontiguousarray(aer0.mixing_ratio[:, :, idx]),
+        aerosol = Aerosol(mixing_ratio=np.ascontiguousarray(take(aer0.mixing_ratio)),
                           istartlev=aer0.istartlev, iendlev=aer0.iendlev)
     return ncol, nlev, sl, th, gas, cloud, aerosol
 

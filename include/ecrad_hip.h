@@ -359,6 +359,26 @@ int ecrad_hip_last_stage_ms(ecrad_hip_handle_t handle, int which, double* ms);
 /* Bytes of device scratch currently held by the handle. */
 int ecrad_hip_scratch_bytes(ecrad_hip_handle_t handle, size_t* bytes);
 
+/* Device memory of a call.  Besides the caller's arrays a call needs work arrays that scale with the
+   number of columns processed at once: per column and 137 levels about 25 KB (ecCKD Tripleclouds: region
+   fractions, overlap matrices), 70 KB (ecCKD-32 McICA: optical-depth scalings) and 1.0 MB (RRTMG McICA:
+   stage arrays of the gas-optics pass + scalings + per-chunk partial profiles); in host-memory mode add
+   the staged inputs and outputs (~50 KB).  ecrad_hip_radiation therefore processes istartcol..iendcol in
+   TILES of columns (multiples of 256, at least 4096) such that these arrays stay within a budget --
+   64 GiB by default (environment ECRAD_HIP_WORK_GIB), changed per handle with this call.  Results do not
+   depend on the tiling. */
+int ecrad_hip_set_work_bytes(ecrad_hip_handle_t handle, size_t bytes);
+
+/* How the most recent ecrad_hip_radiation call ran: column tiles, kernel launches per spectrum (a
+   spectrum wider than 64 g-points runs as several launches of `lanes` g-points) and work bytes held. */
+typedef struct ecrad_call_info {
+  int32_t n_tiles, tile_columns;
+  int32_t launches_lw, launches_sw;   /* solver-kernel launches per tile and spectrum */
+  int32_t lanes_lw, lanes_sw;         /* g-point lanes per column group (16, 32 or 64) */
+  size_t  work_bytes;
+} ecrad_call_info_t;
+int ecrad_hip_last_call_info(ecrad_hip_handle_t handle, ecrad_call_info_t* info);
+
 const char* ecrad_hip_last_error(ecrad_hip_handle_t handle);
 
 int ecrad_hip_destroy(ecrad_hip_handle_t handle);
