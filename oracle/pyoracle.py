@@ -53,6 +53,29 @@ def backend(cconfig, ncol, nlev, istartcol, iendcol, cin, cflux) -> int:
                                         C.byref(cin), C.byref(cflux))
 
 
+_lib_fma = None
+
+
+def make_fma_variant_backend(nblocksize: int = 32, nthreads: int = 0):
+    """The oracle compiled with floating-point contraction (oracle/Makefile: fma): NOT the parity reference --
+    the difference to the plain build measures the sensitivity of the formulas to last-bit differences."""
+    global _lib_fma
+    if _lib_fma is None:
+        subprocess.run(["make", "-C", _HERE, "fma"], check=True, capture_output=True)
+        from ecrad_amd import abi
+        L = C.CDLL(os.path.join(_HERE, "libecrad_oracle_fma.so"))
+        L.ecrad_oracle_radiation_blocked.argtypes = [C.POINTER(abi.Config), C.c_int, C.c_int, C.c_int, C.c_int,
+                                                     C.c_int, C.c_int, C.POINTER(abi.Inputs), C.POINTER(abi.Flux)]
+        L.ecrad_oracle_radiation_blocked.restype = C.c_int
+        _lib_fma = L
+
+    def _b(cconfig, ncol, nlev, istartcol, iendcol, cin, cflux) -> int:
+        return _lib_fma.ecrad_oracle_radiation_blocked(C.byref(cconfig), ncol, nlev, istartcol, iendcol,
+                                                       nblocksize, nthreads, C.byref(cin), C.byref(cflux))
+    _b.lib = _lib_fma        # (the library whose RRTMG stage hand-over make_rrtmg_backend must use)
+    return _b
+
+
 def make_blocked_backend(nblocksize: int, nthreads: int = 0):
     def _b(cconfig, ncol, nlev, istartcol, iendcol, cin, cflux) -> int:
         return lib().ecrad_oracle_radiation_blocked(C.byref(cconfig), ncol, nlev, istartcol, iendcol,
@@ -199,9 +222,10 @@ def make_rrtmg_backend(config, inner=None, nthreads=1):
         st = abi.Optics()
         for k, a in stage.items():
             setattr(st, k, abi.dptr(a))
-        lib().ecrad_oracle_set_gas_stage(C.byref(st))
+        L = getattr(inner, "lib", None) or lib()
+        L.ecrad_oracle_set_gas_stage(C.byref(st))
         try:
             return inner(cconfig, ncol, nlev, istartcol, iendcol, cin, cflux)
         finally:
-            lib().ecrad_oracle_set_gas_stage(None)
+            L.ecrad_oracle_set_gas_stage(None)
     return _b
