@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NMAXGASES = 12
 NMAXCLOUDTYPES = 12
 
@@ -128,7 +128,13 @@ class Config(C.Structure):
            ("pdf_sampler", PdfSampler),
            ("rrtmg", C.POINTER(Rrtmg)), ("min_gas_od_lw", C.c_double), ("min_gas_od_sw", C.c_double),
            ("i_liq_model", C.c_int32), ("i_ice_model", C.c_int32),
-           ("do_fu_lw_ice_optics_bug", C.c_int32), ("reserved2_", C.c_int32)]
+           ("do_fu_lw_ice_optics_bug", C.c_int32), ("reserved2_", C.c_int32),
+           ("nregions", C.c_int32), ("i_3d_sw_entrapment", C.c_int32), ("do_3d_effects", C.c_int32),
+           ("do_3d_lw_multilayer_effects", C.c_int32), ("do_lw_side_emissivity", C.c_int32),
+           ("use_expm_everywhere", C.c_int32), ("i_precision", C.c_int32), ("reserved3_", C.c_int32),
+           ("max_3d_transfer_rate", C.c_double), ("max_gas_od_3d", C.c_double),
+           ("min_cloud_effective_size", C.c_double), ("overhang_factor", C.c_double),
+           ("clear_to_thick_fraction", C.c_double), ("overhead_sun_factor", C.c_double)]
     )
 
 
@@ -147,6 +153,7 @@ class Inputs(C.Structure):
         ("cloud_effective_radius", c_double_p), ("cloud_fractional_std", c_double_p),
         ("cloud_overlap_param", c_double_p),
         ("aerosol_mixing_ratio", c_double_p),
+        ("cloud_inv_cloud_effective_size", c_double_p), ("cloud_inv_inhom_effective_size", c_double_p),
     ]
 
 

@@ -25,6 +25,11 @@ LIQUID_MODEL_NAMES = ["Monochromatic", "SOCRATES", "Slingo", "Jahangir", "Nielse
 ILiquidModelMonochromatic, ILiquidModelSOCRATES, ILiquidModelSlingo = range(3)
 ICE_MODEL_NAMES = ["Monochromatic", "Fu-IFS", "Baran-EXPERIMENTAL", "Baran2016", "Baran2017", "Yi"]   # :124-133
 IIceModelMonochromatic, IIceModelFu, IIceModelBaran = range(3)
+ENTRAPMENT_NAMES = ["Zero", "Edge-only", "Explicit", "Non-fractal", "Maximum"]        # :72-86
+ENCROACHMENT_NAMES = ["Zero", "Minimum", "Fractal", "Computed", "Maximum"]             # :90-94 (deprecated spelling)
+(IEntrapmentZero, IEntrapmentEdgeOnly, IEntrapmentExplicit, IEntrapmentExplicitNonFractal,
+ IEntrapmentMaximum) = range(5)
+IPrecisionDouble, IPrecisionSingle = range(2)
 PDF_SHAPE_NAMES = ["Lognormal", "Gamma"]
 IPdfShapeLognormal, IPdfShapeGamma = range(2)
 
@@ -60,6 +65,22 @@ class Config:
     i_cloud_pdf_shape: int = IPdfShapeGamma
     cloud_inhom_decorr_scaling: float = 0.5
     max_cloud_od: float = 16.0
+    # SPARTACUS (radiation_config.F90:226-260, 268, 341-411)
+    nregions: int = 3
+    do_3d_effects: bool = True
+    i_3d_sw_entrapment: int = IEntrapmentExplicit
+    do_3d_lw_multilayer_effects: bool = False
+    do_lw_side_emissivity: bool = True
+    max_3d_transfer_rate: float = 10.0
+    max_gas_od_3d: float = 8.0
+    min_cloud_effective_size: float = 100.0
+    overhang_factor: float = 0.0
+    clear_to_thick_fraction: float = 0.0
+    overhead_sun_factor: float = 0.0
+    use_expm_everywhere: bool = False
+    # Working precision of the SPARTACUS solver kernels (not a namelist entry of the reference, where it is the
+    # compile-time choice PARKIND1_SINGLE): IPrecisionDouble or IPrecisionSingle
+    i_precision: int = IPrecisionDouble
     do_lw_cloud_scattering: bool = True
     do_lw_aerosol_scattering: bool = True
     i_solver_sw: int = ISolverMcICA
@@ -168,6 +189,9 @@ class Config:
             "do_cloud_aerosol_per_lw_g_point", "do_cloud_aerosol_per_sw_g_point",
             "do_weighted_surface_mapping", "use_spectral_solar_cycle", "do_fu_lw_ice_optics_bug",
             "min_gas_od_lw", "min_gas_od_sw", "liq_optics_override_file_name", "ice_optics_override_file_name",
+            "do_3d_effects", "do_3d_lw_multilayer_effects", "do_lw_side_emissivity", "max_3d_transfer_rate",
+            "max_gas_od_3d", "min_cloud_effective_size", "overhang_factor", "clear_to_thick_fraction",
+            "overhead_sun_factor", "use_expm_everywhere",
         ]
         for k in simple:
             if k in nml and nml[k] is not None:
@@ -212,6 +236,16 @@ class Config:
             c.i_gas_model_lw = _enum(nml["lw_gas_model_name"], GAS_MODEL_NAMES, "lw_gas_model_name")
         if nml.get("overlap_scheme_name"):
             c.i_overlap_scheme = _enum(nml["overlap_scheme_name"], OVERLAP_NAMES, "overlap_scheme_name")
+        if nml.get("n_regions") is not None:
+            c.nregions = int(nml["n_regions"])
+        # radiation_config.F90:1046-1054 (sw_encroachment_name is the deprecated spelling; encroachment_scaling of overhang_factor)
+        if nml.get("sw_encroachment_name"):
+            c.i_3d_sw_entrapment = _enum(nml["sw_encroachment_name"], ENCROACHMENT_NAMES, "sw_encroachment_name")
+        elif nml.get("sw_entrapment_name"):
+            c.i_3d_sw_entrapment = _enum(nml["sw_entrapment_name"], ENTRAPMENT_NAMES, "sw_entrapment_name")
+        if nml.get("encroachment_scaling") is not None and float(nml["encroachment_scaling"]) >= 0.0:
+            c.overhang_factor = float(nml["encroachment_scaling"])
+        c.min_cloud_effective_size = max(1.0e-6, c.min_cloud_effective_size)          # :970
         if nml.get("cloud_pdf_shape_name"):
             c.i_cloud_pdf_shape = _enum(nml["cloud_pdf_shape_name"], PDF_SHAPE_NAMES, "cloud_pdf_shape_name")
         if c.do_save_gpoint_flux:
@@ -261,6 +295,11 @@ class Config:
             "mcica_lognormal.nc" if self.i_cloud_pdf_shape == IPdfShapeLognormal else "mcica_gamma.nc")
         if self.n_aerosol_types < 0 or self.n_aerosol_types > NMaxAerosolTypes:
             raise ConfigError("number of aerosol types out of range")
+        spartacus = ((self.do_sw and self.i_solver_sw == ISolverSpartacus) or (self.do_lw and self.i_solver_lw == ISolverSpartacus))
+        if spartacus and self.nregions != 3:
+            raise ConfigError("SPARTACUS: only n_regions = 3 is implemented in this build")
+        if self.do_sw and self.i_solver_sw == ISolverSpartacus and self.do_sw_delta_scaling_with_gases:
+            raise ConfigError("SW delta-Eddington scaling with gases not possible with SPARTACUS solver")     # :1336-1340
         if self.i_solver_sw == ISolverMcICA:
             self.do_save_spectral_flux = False
         if self.do_lw and self.do_sw and ((self.i_solver_sw == ISolverHomogeneous)

@@ -42,6 +42,13 @@ class DriverConfig:
     skin_temperature_override: float = -1.0
     solar_irradiance_override: float = -1.0
     cos_sza_override: float = -1.0
+    low_inv_effective_size_override: float = -1.0
+    cloud_separation_scale_surface: float = -1.0
+    cloud_separation_scale_toa: float = -1.0
+    cloud_separation_scale_power: float = 1.0
+    cloud_inhom_separation_factor: float = 1.0
+    effective_size_scaling: float = -1.0
+    do_ignore_inhom_effective_size: bool = False
     vmr_suffix_str: str = "_vmr"
     gas_scaling: dict = None
 
@@ -128,6 +135,38 @@ def read_input(path: str, config: Config, driver_config: DriverConfig):
                 fractional_std = np.zeros((nlev, ncol))
             cloud = Cloud(fraction, np.ascontiguousarray(mixing_ratio),
                           np.ascontiguousarray(effective_radius), fractional_std, overlap_param)
+            from .config import ISolverSpartacus
+            if ISolverSpartacus in (config.i_solver_sw, config.i_solver_lw):
+                # driver/ecrad_driver_read_input.F90:290-470: of the four ways to specify the cloud scale, the one the
+                # reference's own test inputs use -- inv_cloud_effective_size [and inv_inhom_effective_size] in the file
+                scalable = False
+                if dc.low_inv_effective_size_override >= 0.0:
+                    raise NotImplementedError("[low|middle|high]_inv_effective_size_override of the offline driver")
+                if dc.cloud_separation_scale_surface > 0.0 and dc.cloud_separation_scale_toa > 0.0:
+                    # (2) cloud%param_cloud_effective_separation_eta (radiation_cloud.F90:602-690): what the IFS test
+                    # namelists use (cloud_separation_scale_*)
+                    coeff_e = 1.0 - np.exp(-1.0)
+                    coeff_b = (dc.cloud_separation_scale_toa - dc.cloud_separation_scale_surface) / coeff_e
+                    coeff_a = dc.cloud_separation_scale_toa - coeff_b
+                    isurf = 0 if pressure_hl[0, 0] > pressure_hl[1, 0] else nlev
+                    eta = (pressure_hl[:-1] + pressure_hl[1:]) * (0.5 / pressure_hl[isurf][None, :])
+                    eff_separation = coeff_a + coeff_b * np.exp(-eta ** dc.cloud_separation_scale_power)
+                    cloud.inv_cloud_effective_size = np.ascontiguousarray(
+                        1.0 / (eff_separation * np.sqrt(np.maximum(1.0e-5, fraction * (1.0 - fraction)))))
+                    cloud.inv_inhom_effective_size = np.ascontiguousarray(
+                        1.0 / (eff_separation * dc.cloud_inhom_separation_factor
+                               * np.sqrt(np.maximum(1.0e-5, 0.5 * fraction * (1.0 - 0.5 * fraction)))))
+                elif f.exists("inv_cloud_effective_size"):      # (3)
+                    scalable = True
+                    cloud.inv_cloud_effective_size = _colfast(f.get("inv_cloud_effective_size"))
+                    if f.exists("inv_inhom_effective_size") and not dc.do_ignore_inhom_effective_size:
+                        cloud.inv_inhom_effective_size = _colfast(f.get("inv_inhom_effective_size"))
+                else:
+                    raise RuntimeError("SPARTACUS solver specified but cloud size not, either in namelist or input file")
+                if scalable and dc.effective_size_scaling > 0.0:           # :443-461
+                    cloud.inv_cloud_effective_size /= dc.effective_size_scaling
+                    if cloud.inv_inhom_effective_size is not None:
+                        cloud.inv_inhom_effective_size /= dc.effective_size_scaling
 
         if f.exists("skin_temperature"):
             skin_temperature = np.ascontiguousarray(f.get("skin_temperature"), dtype=np.float64)

@@ -55,8 +55,6 @@ def setup_radiation(config: Config) -> None:
         raise ConfigError("shortwave and longwave gas models must be the same in this build")
     if (config.i_gas_model_sw if config.do_sw else config.i_gas_model_lw) == IGasModelIFSRRTMG:
         return _setup_radiation_rrtmg(config)
-    if ISolverSpartacus in (config.i_solver_sw, config.i_solver_lw):
-        raise ConfigError("the SPARTACUS solver is not implemented in this build")
     # setup_gas_optics (radiation_ecckd_interface.F90:27-150)
     if config.do_sw:
         config.gas_optics_sw = CkdModel(config.gas_optics_sw_file_name)
@@ -192,8 +190,6 @@ def _setup_radiation_rrtmg(config: Config) -> None:
     from .rrtmg import (LW_WAVENUMBER1, LW_WAVENUMBER2, SW_WAVENUMBER1, SW_WAVENUMBER2, RrtmgTables)
     from .spectral import SpectralDefinition
     from .tables import BandFitCloudOptics
-    if ISolverSpartacus in (config.i_solver_sw, config.i_solver_lw):
-        raise ConfigError("the SPARTACUS solver is not implemented in this build")
     config.rrtmg = RrtmgTables()
     config.do_cloud_aerosol_per_sw_g_point = False
     config.do_cloud_aerosol_per_lw_g_point = False
@@ -323,6 +319,19 @@ def build_config_struct(config: Config):
     c.cloud_mixing_ratio_threshold = config.cloud_mixing_ratio_threshold
     c.cloud_inhom_decorr_scaling = config.cloud_inhom_decorr_scaling
     c.max_cloud_od = config.max_cloud_od
+    c.nregions = config.nregions
+    c.i_3d_sw_entrapment = config.i_3d_sw_entrapment
+    c.do_3d_effects = int(config.do_3d_effects)
+    c.do_3d_lw_multilayer_effects = int(config.do_3d_lw_multilayer_effects)
+    c.do_lw_side_emissivity = int(config.do_lw_side_emissivity)
+    c.use_expm_everywhere = int(config.use_expm_everywhere)
+    c.i_precision = int(config.i_precision)
+    c.max_3d_transfer_rate = config.max_3d_transfer_rate
+    c.max_gas_od_3d = config.max_gas_od_3d
+    c.min_cloud_effective_size = config.min_cloud_effective_size
+    c.overhang_factor = config.overhang_factor
+    c.clear_to_thick_fraction = config.clear_to_thick_fraction
+    c.overhead_sun_factor = config.overhead_sun_factor
     c.i_band_from_reordered_g_sw = i(config.i_band_from_reordered_g_sw)
     c.i_band_from_reordered_g_lw = i(config.i_band_from_reordered_g_lw)
     if config.sw_albedo_weights is not None:
@@ -432,6 +441,10 @@ def build_inputs_struct(config: Config, ncol, nlev, single_level, thermodynamics
         s.cloud_effective_radius = d(cloud.effective_radius, (cloud.ntype, nlev, ncol))
         s.cloud_fractional_std = d(cloud.fractional_std, (nlev, ncol))
         s.cloud_overlap_param = d(cloud.overlap_param, (nlev - 1, ncol))
+        if cloud.inv_cloud_effective_size is not None:
+            s.cloud_inv_cloud_effective_size = d(cloud.inv_cloud_effective_size, (nlev, ncol))
+        if cloud.inv_inhom_effective_size is not None:
+            s.cloud_inv_inhom_effective_size = d(cloud.inv_inhom_effective_size, (nlev, ncol))
     if aerosol is not None and config.use_aerosols:
         s.n_aerosol_types = aerosol.mixing_ratio.shape[0]
         s.aerosol_istartlev, s.aerosol_iendlev = aerosol.istartlev, aerosol.iendlev

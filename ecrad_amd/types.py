@@ -110,6 +110,8 @@ class Cloud:
     effective_radius: np.ndarray       # (ntype, nlev, ncol)
     fractional_std: np.ndarray         # (nlev, ncol)
     overlap_param: np.ndarray          # (nlev-1, ncol)
+    inv_cloud_effective_size: Optional[np.ndarray] = None    # (nlev, ncol) m-1: SPARTACUS 3-D effects (radiation_cloud.F90:75-87)
+    inv_inhom_effective_size: Optional[np.ndarray] = None    # (nlev, ncol) m-1
 
     @property
     def ntype(self) -> int:

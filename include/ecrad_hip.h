@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ECRAD_ABI_VERSION 3
+#define ECRAD_ABI_VERSION 4
 
 /* Status codes */
 #define ECRAD_OK            0
@@ -208,7 +208,7 @@ typedef struct ecrad_config {
   /* thresholds */
   double cloud_fraction_threshold, cloud_mixing_ratio_threshold;
   double cloud_inhom_decorr_scaling;
-  double max_cloud_od;             /* reserved for SPARTACUS */
+  double max_cloud_od;             /* SPARTACUS: cap of the in-region optical depth (radiation_config.F90:256) */
   /* index / weight tables */
   const int32_t* i_band_from_reordered_g_sw;  /* (n_g_sw), 1-based */
   const int32_t* i_band_from_reordered_g_lw;  /* (n_g_lw), 1-based */
@@ -233,7 +233,27 @@ typedef struct ecrad_config {
      ice_coeff_*, n_effective_radius holds ncoeff; ssa/asymmetry are not read.  Implemented: SOCRATES + Fu. */
   int32_t i_liq_model, i_ice_model;      /* radiation_config.F90:109-126 (ILiquidModel*, IIceModel*) */
   int32_t do_fu_lw_ice_optics_bug, reserved2_;
+  /* SPARTACUS (i_solver_* == ECRAD_SOLVER_SPARTACUS), radiation_config.F90:226-260,268,341-411 */
+  int32_t nregions;                    /* 3 (2 is not implemented) */
+  int32_t i_3d_sw_entrapment;          /* ECRAD_ENTRAPMENT_* */
+  int32_t do_3d_effects, do_3d_lw_multilayer_effects, do_lw_side_emissivity, use_expm_everywhere;
+  int32_t i_precision;                 /* ECRAD_PRECISION_*: arithmetic of the SPARTACUS solver kernels */
+  int32_t reserved3_;
+  double max_3d_transfer_rate, max_gas_od_3d, min_cloud_effective_size;
+  double overhang_factor, clear_to_thick_fraction, overhead_sun_factor;
 } ecrad_config_t;
+
+/* radiation_config.F90:72-77 */
+#define ECRAD_ENTRAPMENT_ZERO 0
+#define ECRAD_ENTRAPMENT_EDGE_ONLY 1
+#define ECRAD_ENTRAPMENT_EXPLICIT 2
+#define ECRAD_ENTRAPMENT_EXPLICIT_NON_FRACTAL 3
+#define ECRAD_ENTRAPMENT_MAXIMUM 4
+/* Working precision of the SPARTACUS solver kernels: double (jprb = jprd), or single with the reference's
+   PARKIND1_SINGLE semantics (jprb = float; the Meador-Weaver two-stream internals stay double,
+   radiation_two_stream.F90:455-461).  Everything upstream of the solvers, and every array at this boundary, is double. */
+#define ECRAD_PRECISION_DOUBLE 0
+#define ECRAD_PRECISION_SINGLE 1
 
 /* ---- single_level_type + thermodynamics_type + gas_type + cloud_type + aerosol_type --------- */
 /* All arrays use the reference's layout: (ncol, nlev[+1][, ntype]) with the column index     */
@@ -271,6 +291,9 @@ typedef struct ecrad_inputs {
   const double* cloud_overlap_param;    /* (ncol,nlev-1) */
   /* aerosol */
   const double* aerosol_mixing_ratio;   /* (ncol, istartlev:iendlev, n_aerosol_types) */
+  /* cloud geometry for the 3-D effects of SPARTACUS (radiation_cloud.F90:75-87); NULL = not allocated */
+  const double* cloud_inv_cloud_effective_size;  /* (ncol,nlev) m-1 */
+  const double* cloud_inv_inhom_effective_size;  /* (ncol,nlev) m-1 or NULL (= use inv_cloud_effective_size) */
 } ecrad_inputs_t;
 
 /* ---- flux_type, radiation_flux.F90:38-118; any pointer may be NULL (= not allocated) -------- */

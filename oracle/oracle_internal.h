@@ -58,6 +58,15 @@ void oracle_solver_tripleclouds_sw(const ecrad_config_t* c, int ncol, int nlev, 
      const ecrad_inputs_t* in, const oracle_optics_buf_t* b, ecrad_flux_t* flux);
 void oracle_solver_tripleclouds_lw(const ecrad_config_t* c, int ncol, int nlev, int istartcol, int iendcol,
      const ecrad_inputs_t* in, const oracle_optics_buf_t* b, ecrad_flux_t* flux);
+/* oracle_spartacus.c (nregions = 3; no spectral flux profiles) */
+void oracle_solver_spartacus_sw(const ecrad_config_t* c, int ncol, int nlev, int istartcol, int iendcol,
+     const ecrad_inputs_t* in, const oracle_optics_buf_t* b, ecrad_flux_t* flux);
+void oracle_solver_spartacus_lw(const ecrad_config_t* c, int ncol, int nlev, int istartcol, int iendcol,
+     const ecrad_inputs_t* in, const oracle_optics_buf_t* b, ecrad_flux_t* flux);
+/* regions + overlap matrices + cloud cover of one column (oracle_tripleclouds.c); colbuf holds 3*nlev doubles */
+void oracle_column_cloud_geometry(const ecrad_config_t* c, int ncol, int nlev, int jcol, const ecrad_inputs_t* in,
+                                  double* region_fracs, double* od_scaling, double* u_matrix, double* v_matrix,
+                                  double* cloud_cover, double* colbuf);
 void oracle_calc_surface_spectral(const ecrad_config_t* c, int ncol, int istartcol, int iendcol, ecrad_flux_t* flux);
 void oracle_calc_toa_spectral(const ecrad_config_t* c, int ncol, int istartcol, int iendcol, ecrad_flux_t* flux);
 #endif

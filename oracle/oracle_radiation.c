@@ -131,7 +131,10 @@ int ecrad_oracle_radiation(const ecrad_config_t* c, int ncol, int nlev, int ista
   if (istartcol < 1 || iendcol > ncol || iendcol < istartcol) return ECRAD_EINVAL;
   if ((c->do_sw && c->i_gas_model_sw == ECRAD_GAS_MONOCHROMATIC) || (c->do_lw && c->i_gas_model_lw == ECRAD_GAS_MONOCHROMATIC))
     return ECRAD_EUNSUPPORTED;
-  if (c->i_solver_sw == ECRAD_SOLVER_SPARTACUS || c->i_solver_lw == ECRAD_SOLVER_SPARTACUS) return ECRAD_EUNSUPPORTED;
+  if ((c->do_sw && c->i_solver_sw == ECRAD_SOLVER_SPARTACUS) || (c->do_lw && c->i_solver_lw == ECRAD_SOLVER_SPARTACUS)) {
+    if (c->nregions != 3 || c->do_save_spectral_flux) return ECRAD_EUNSUPPORTED;
+    if (c->do_sw && c->i_solver_sw == ECRAD_SOLVER_SPARTACUS && c->do_sw_delta_scaling_with_gases) return ECRAD_EINVAL;
+  }
   if (in->pressure_hl[(size_t)(istartcol - 1) + (size_t)ncol] < in->pressure_hl[istartcol - 1]) return ECRAD_EUNSUPPORTED;
   const int nloc = iendcol - istartcol + 1;
   oracle_optics_buf_t* b = oracle_optics_buf_alloc(c, nlev, nloc);
@@ -140,6 +143,7 @@ int ecrad_oracle_radiation(const ecrad_config_t* c, int ncol, int nlev, int ista
     switch (c->i_solver_lw) {
     case ECRAD_SOLVER_MCICA:        oracle_solver_mcica_lw(c, ncol, nlev, istartcol, iendcol, in, b, flux); break;
     case ECRAD_SOLVER_TRIPLECLOUDS: oracle_solver_tripleclouds_lw(c, ncol, nlev, istartcol, iendcol, in, b, flux); break;
+    case ECRAD_SOLVER_SPARTACUS:    oracle_solver_spartacus_lw(c, ncol, nlev, istartcol, iendcol, in, b, flux); break;
     case ECRAD_SOLVER_HOMOGENEOUS:  oracle_solver_homogeneous_lw(c, ncol, nlev, istartcol, iendcol, in, b, flux); break;
     default:                        oracle_solver_cloudless_lw(c, ncol, nlev, istartcol, iendcol, in, b, flux); break;
     }
@@ -148,6 +152,7 @@ int ecrad_oracle_radiation(const ecrad_config_t* c, int ncol, int nlev, int ista
     switch (c->i_solver_sw) {
     case ECRAD_SOLVER_MCICA:        oracle_solver_mcica_sw(c, ncol, nlev, istartcol, iendcol, in, b, flux); break;
     case ECRAD_SOLVER_TRIPLECLOUDS: oracle_solver_tripleclouds_sw(c, ncol, nlev, istartcol, iendcol, in, b, flux); break;
+    case ECRAD_SOLVER_SPARTACUS:    oracle_solver_spartacus_sw(c, ncol, nlev, istartcol, iendcol, in, b, flux); break;
     case ECRAD_SOLVER_HOMOGENEOUS:  oracle_solver_homogeneous_sw(c, ncol, nlev, istartcol, iendcol, in, b, flux); break;
     default:                        oracle_solver_cloudless_sw(c, ncol, nlev, istartcol, iendcol, in, b, flux); break;
     }

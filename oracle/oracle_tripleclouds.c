@@ -39,7 +39,7 @@ static void zero_profile(double* a, int ncol, int nlev, int jcol)
   for (int l = 0; l <= nlev; ++l) FL(a, jcol, l) = 0.0;
 }
 
-static void column_cloud_geometry(const ecrad_config_t* c, int ncol, int nlev, int jcol, const ecrad_inputs_t* in,
+void oracle_column_cloud_geometry(const ecrad_config_t* c, int ncol, int nlev, int jcol, const ecrad_inputs_t* in,
                                   double* region_fracs, double* od_scaling, double* u_matrix, double* v_matrix,
                                   double* cloud_cover, double* colbuf)
 {
@@ -127,7 +127,7 @@ void oracle_solver_tripleclouds_sw(const ecrad_config_t* c, int ncol, int nlev, 
     const double* ssa = b->ssa_sw + (size_t)ng * nlev * jc;
     const double* g = b->g_sw + (size_t)ng * nlev * jc;
     const double* incoming_sw = b->incoming_sw + (size_t)ng * jc;
-    column_cloud_geometry(c, ncol, nlev, jcol, in, region_fracs, od_scaling, u_matrix, v_matrix,
+    oracle_column_cloud_geometry(c, ncol, nlev, jcol, in, region_fracs, od_scaling, u_matrix, v_matrix,
                           &flux->cloud_cover_sw[jcol], colbuf);
     const double mu0 = in->cos_sza[jcol];
     if (mu0 < 1.0e-10) {
@@ -427,7 +427,7 @@ void oracle_solver_tripleclouds_lw(const ecrad_config_t* c, int ncol, int nlev, 
     const double* planck_hl = b->planck_hl + (size_t)ng * (nlev + 1) * jc;
     const double* emission = b->lw_emission + (size_t)ng * jc;
     const double* albedo = b->lw_albedo + (size_t)ng * jc;
-    column_cloud_geometry(c, ncol, nlev, jcol, in, region_fracs, od_scaling, u_matrix, v_matrix,
+    oracle_column_cloud_geometry(c, ncol, nlev, jcol, in, region_fracs, od_scaling, u_matrix, v_matrix,
                           &flux->cloud_cover_lw[jcol], colbuf);
     for (int l = 0; l <= nlev + 1; ++l) is_clear_sky_layer[l] = 1;
     int i_cloud_top = nlev + 1;

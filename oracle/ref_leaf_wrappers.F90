@@ -200,4 +200,102 @@ contains
     call uniform_distribution(y, stream)
   end subroutine
 
+  ! ---- radiation_matrix.F90 (the batched small-matrix algebra of the SPARTACUS solvers) ----------------------
+  subroutine ref_expm(n, iend, m, A, i_matrix_pattern) bind(C, name='ref_expm')
+    use radiation_matrix, only : expm
+    integer(c_int), value :: n, iend, m, i_matrix_pattern
+    real(c_double), intent(inout) :: A(n,m,m)
+    call expm(n, iend, m, A, i_matrix_pattern)
+  end subroutine
+
+  subroutine ref_mat_x_mat(n, iend, m, A, B, i_matrix_pattern, C) bind(C, name='ref_mat_x_mat')
+    use radiation_matrix, only : mat_x_mat
+    integer(c_int), value :: n, iend, m, i_matrix_pattern
+    real(c_double), intent(in)  :: A(n,m,m), B(n,m,m)
+    real(c_double), intent(out) :: C(n,m,m)
+    C = 0.0_jprb
+    C(1:iend,:,:) = mat_x_mat(n, iend, m, A, B, i_matrix_pattern)
+  end subroutine
+
+  subroutine ref_identity_minus_mat_x_mat(n, iend, m, A, B, C) bind(C, name='ref_identity_minus_mat_x_mat')
+    use radiation_matrix, only : identity_minus_mat_x_mat
+    integer(c_int), value :: n, iend, m
+    real(c_double), intent(in)  :: A(n,m,m), B(n,m,m)
+    real(c_double), intent(out) :: C(n,m,m)
+    C = 0.0_jprb
+    C(1:iend,:,:) = identity_minus_mat_x_mat(n, iend, m, A, B)
+  end subroutine
+
+  subroutine ref_mat_x_vec(n, iend, m, A, b, do_top_left_only, c) bind(C, name='ref_mat_x_vec')
+    use radiation_matrix, only : mat_x_vec
+    integer(c_int), value :: n, iend, m, do_top_left_only
+    real(c_double), intent(in)  :: A(n,m,m), b(n,m)
+    real(c_double), intent(out) :: c(n,m)
+    c = 0.0_jprb
+    c(1:iend,:) = mat_x_vec(n, iend, m, A, b, do_top_left_only /= 0)
+  end subroutine
+
+  subroutine ref_singlemat_x_vec(n, iend, m, A, b, c) bind(C, name='ref_singlemat_x_vec')
+    use radiation_matrix, only : singlemat_x_vec
+    integer(c_int), value :: n, iend, m
+    real(c_double), intent(in)  :: A(m,m), b(n,m)
+    real(c_double), intent(out) :: c(n,m)
+    c = 0.0_jprb
+    c(1:iend,:) = singlemat_x_vec(n, iend, m, A, b)
+  end subroutine
+
+  subroutine ref_singlemat_x_mat(n, iend, m, A, B, C) bind(C, name='ref_singlemat_x_mat')
+    use radiation_matrix, only : singlemat_x_mat
+    integer(c_int), value :: n, iend, m
+    real(c_double), intent(in)  :: A(m,m), B(n,m,m)
+    real(c_double), intent(out) :: C(n,m,m)
+    C = 0.0_jprb
+    C(1:iend,:,:) = singlemat_x_mat(n, iend, m, A, B)
+  end subroutine
+
+  subroutine ref_mat_x_singlemat(n, iend, m, A, B, C) bind(C, name='ref_mat_x_singlemat')
+    use radiation_matrix, only : mat_x_singlemat
+    integer(c_int), value :: n, iend, m
+    real(c_double), intent(in)  :: A(n,m,m), B(m,m)
+    real(c_double), intent(out) :: C(n,m,m)
+    C = 0.0_jprb
+    C(1:iend,:,:) = mat_x_singlemat(n, iend, m, A, B)
+  end subroutine
+
+  subroutine ref_solve_vec(n, iend, m, A, b, x) bind(C, name='ref_solve_vec')
+    use radiation_matrix, only : solve_vec
+    integer(c_int), value :: n, iend, m
+    real(c_double), intent(in)  :: A(n,m,m), b(n,m)
+    real(c_double), intent(out) :: x(n,m)
+    x = 0.0_jprb
+    x(1:iend,:) = solve_vec(n, iend, m, A, b)
+  end subroutine
+
+  subroutine ref_solve_mat(n, iend, m, A, B, X) bind(C, name='ref_solve_mat')
+    use radiation_matrix, only : solve_mat
+    integer(c_int), value :: n, iend, m
+    real(c_double), intent(in)  :: A(n,m,m), B(n,m,m)
+    real(c_double), intent(out) :: X(n,m,m)
+    X = 0.0_jprb
+    X(1:iend,:,:) = solve_mat(n, iend, m, A, B)
+  end subroutine
+
+  subroutine ref_fast_expm_exchange_2(n, iend, a, b, R) bind(C, name='ref_fast_expm_exchange_2')
+    use radiation_matrix, only : fast_expm_exchange_2
+    integer(c_int), value :: n, iend
+    real(c_double), intent(in)  :: a(n), b(n)
+    real(c_double), intent(out) :: R(n,2,2)
+    R = 0.0_jprb
+    call fast_expm_exchange_2(n, iend, a, b, R)
+  end subroutine
+
+  subroutine ref_fast_expm_exchange_3(n, iend, a, b, c, d, R) bind(C, name='ref_fast_expm_exchange_3')
+    use radiation_matrix, only : fast_expm_exchange_3
+    integer(c_int), value :: n, iend
+    real(c_double), intent(in)  :: a(n), b(n), c(n), d(n)
+    real(c_double), intent(out) :: R(n,3,3)
+    R = 0.0_jprb
+    call fast_expm_exchange_3(n, iend, a, b, c, d, R)
+  end subroutine
+
 end module ref_leaf_wrappers
