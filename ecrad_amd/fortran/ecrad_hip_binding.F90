@@ -8,7 +8,7 @@ module ecrad_hip_binding
   implicit none
   public
 
-  integer(c_int), parameter :: ECRAD_ABI_VERSION = 3
+  integer(c_int), parameter :: ECRAD_ABI_VERSION = 4
   integer(c_int), parameter :: ECRAD_OK = 0
   integer(c_int), parameter :: ECRAD_NMAXGASES = 12, ECRAD_NMAXCLOUDTYPES = 12
   integer(c_int), parameter :: ECRAD_MEM_HOST = 0, ECRAD_MEM_DEVICE = 1
@@ -97,6 +97,12 @@ module ecrad_hip_binding
     type(c_ptr) :: rrtmg                      ! -> ecrad_rrtmg_t, or c_null_ptr (ecCKD)
     real(c_double) :: min_gas_od_lw, min_gas_od_sw
     integer(c_int32_t) :: i_liq_model, i_ice_model, do_fu_lw_ice_optics_bug, reserved2_
+    ! SPARTACUS (radiation_config.F90:226-260,268,341-411)
+    integer(c_int32_t) :: nregions = 3, i_3d_sw_entrapment = 2
+    integer(c_int32_t) :: do_3d_effects = 1, do_3d_lw_multilayer_effects = 0, do_lw_side_emissivity = 1, use_expm_everywhere = 0
+    integer(c_int32_t) :: i_precision = 0, reserved3_ = 0
+    real(c_double) :: max_3d_transfer_rate = 10.0_c_double, max_gas_od_3d = 8.0_c_double, min_cloud_effective_size = 100.0_c_double
+    real(c_double) :: overhang_factor = 0.0_c_double, clear_to_thick_fraction = 0.0_c_double, overhead_sun_factor = 0.0_c_double
   end type
 
   type, bind(C) :: ecrad_inputs_t
@@ -112,6 +118,7 @@ module ecrad_hip_binding
     type(c_ptr) :: cloud_effective_radius = c_null_ptr, cloud_fractional_std = c_null_ptr
     type(c_ptr) :: cloud_overlap_param = c_null_ptr
     type(c_ptr) :: aerosol_mixing_ratio = c_null_ptr
+    type(c_ptr) :: cloud_inv_cloud_effective_size = c_null_ptr, cloud_inv_inhom_effective_size = c_null_ptr
   end type
 
   type, bind(C) :: ecrad_flux_t
