@@ -56,6 +56,7 @@ struct ecrad_hip_handle_s {
   const ecrad::rrtmg::DevRrtmg* d_rrtmg = nullptr;   // RRTMG tables (device), see rrtmg_device.h
   bool rrtmg_sw = false, rrtmg_lw = false;
   Buf gas_stage, gas_work;         // stage-interface arrays and work records of the RRTMG gas-optics pass
+  Buf sp_stage;                    // stage-interface arrays read by the SPARTACUS solver kernels
   // One set of stage-boundary events per column tile of the most recent call (a call whose work arrays
   // would exceed `work_budget` runs as several tiles of columns, see ecrad_hip_radiation)
   struct TileEvents { hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; };
@@ -308,7 +309,8 @@ struct Range { int ncol, nlev, i0, i1, nloc; };
 struct StagedInputs {
   double *pressure_hl, *temperature_hl, *h2o_sat_liq, *cos_sza, *skin_temperature, *sw_albedo, *sw_albedo_direct,
          *lw_emissivity, *gas_mixing_ratio, *cloud_fraction, *cloud_mixing_ratio, *cloud_effective_radius,
-         *cloud_fractional_std, *cloud_overlap_param, *aerosol_mixing_ratio;
+         *cloud_fractional_std, *cloud_overlap_param, *aerosol_mixing_ratio, *cloud_inv_cloud_effective_size,
+         *cloud_inv_inhom_effective_size;
   int32_t* iseed;
   size_t bytes;
 };
@@ -333,6 +335,8 @@ StagedInputs carve_inputs(void* base, const ecrad_config_t& c, const ecrad_input
     s.cloud_effective_radius = cv.take<double>(n * L * in.n_cloud_types);
     s.cloud_fractional_std = cv.take<double>(n * L);
     s.cloud_overlap_param = cv.take<double>(n * (L - 1));
+    if (in.cloud_inv_cloud_effective_size) s.cloud_inv_cloud_effective_size = cv.take<double>(n * L);
+    if (in.cloud_inv_inhom_effective_size) s.cloud_inv_inhom_effective_size = cv.take<double>(n * L);
   }
   if (c.use_aerosols)
     s.aerosol_mixing_ratio = cv.take<double>(n * (in.aerosol_iendlev - in.aerosol_istartlev + 1) * in.n_aerosol_types);
@@ -387,8 +391,22 @@ int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
     } else if (model != ECRAD_GAS_ECCKD) return fail(h, ECRAD_EUNSUPPORTED, "the monochromatic gas model is not implemented");
   }
   for (int s : {c.do_sw ? c.i_solver_sw : -1, c.do_lw ? c.i_solver_lw : -1}) {
-    if (s == ECRAD_SOLVER_SPARTACUS) return fail(h, ECRAD_EUNSUPPORTED, "the SPARTACUS solver is not implemented");
     if (s > ECRAD_SOLVER_TRIPLECLOUDS) return fail(h, ECRAD_EINVAL, "unknown solver");
+  }
+  const bool spartacus = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_SPARTACUS) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_SPARTACUS);
+  if (spartacus) {
+    if (c.nregions != 3) return fail(h, ECRAD_EUNSUPPORTED, "SPARTACUS: only nregions = 3 is implemented");
+    if (c.i_3d_sw_entrapment < ECRAD_ENTRAPMENT_ZERO || c.i_3d_sw_entrapment > ECRAD_ENTRAPMENT_MAXIMUM) return fail(h, ECRAD_EINVAL, "SPARTACUS: unknown entrapment option");
+    if (c.i_precision != ECRAD_PRECISION_DOUBLE && c.i_precision != ECRAD_PRECISION_SINGLE) return fail(h, ECRAD_EINVAL, "unknown i_precision");
+    if (c.do_save_spectral_flux) return fail(h, ECRAD_EUNSUPPORTED, "SPARTACUS: spectral flux profiles are not implemented");
+    if (!c.do_clouds) return fail(h, ECRAD_EINVAL, "SPARTACUS needs do_clouds");
+    if (c.i_overlap_scheme != ECRAD_OVERLAP_EXP_RAN) return fail(h, ECRAD_EINVAL, "SPARTACUS can only do Exp-Ran overlap");    // radiation_config.F90:1259-1266
+    if ((c.do_sw && c.i_solver_sw == ECRAD_SOLVER_SPARTACUS && (c.n_g_sw > 64 || c.n_bands_sw > 64)) ||
+        (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_SPARTACUS && (c.n_g_lw > 64 || c.n_bands_lw > 64)))
+      return fail(h, ECRAD_EUNSUPPORTED, "SPARTACUS: spectra of more than 64 g-points are not implemented");
+    if (!(c.max_cloud_od > 0.0) || !(c.min_cloud_effective_size > 0.0)) return fail(h, ECRAD_EINVAL, "SPARTACUS: max_cloud_od and min_cloud_effective_size must be positive");
+  } else if (c.i_precision != ECRAD_PRECISION_DOUBLE) {
+    return fail(h, ECRAD_EUNSUPPORTED, "single precision is implemented for the SPARTACUS solver only");
   }
   if (c.do_save_spectral_flux) {
     // spectral flux profiles: the kernels write one interval per g-point; any other mapping of g-points
@@ -524,7 +542,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
   if (!h) return ECRAD_EINVAL;
   (void)hipSetDevice(h->device);
   free_tables(h);
-  h->gas_stage.release(); h->gas_work.release(); h->counters.release(); h->partial.release(); h->spec_tmp.release(); h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
+  h->gas_stage.release(); h->gas_work.release(); h->sp_stage.release(); h->counters.release(); h->partial.release(); h->spec_tmp.release(); h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
   for (auto& t : h->tile_events) for (auto& e : t.e) if (e) (void)hipEventDestroy(e);
   delete h;
   return ECRAD_OK;
@@ -532,7 +550,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
 
 int ecrad_hip_scratch_bytes(ecrad_hip_handle_t h, size_t* bytes) {
   if (!h || !bytes) return ECRAD_EINVAL;
-  *bytes = h->scratch.cap + h->prep.cap + h->staging_in.cap + h->staging_out.cap + h->partial.cap + h->spec_tmp.cap + h->gas_stage.cap + h->gas_work.cap;
+  *bytes = h->scratch.cap + h->prep.cap + h->staging_in.cap + h->staging_out.cap + h->partial.cap + h->spec_tmp.cap + h->gas_stage.cap + h->gas_work.cap + h->sp_stage.cap;
   return ECRAD_OK;
 }
 
@@ -813,6 +831,8 @@ int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int ie
     d.cloud_mixing_ratio = in->cloud_mixing_ratio; d.cloud_effective_radius = in->cloud_effective_radius;
     d.cloud_fractional_std = in->cloud_fractional_std; d.cloud_overlap_param = in->cloud_overlap_param;
     d.aerosol_mixing_ratio = in->aerosol_mixing_ratio;
+    d.cloud_inv_cloud_effective_size = c.do_clouds ? in->cloud_inv_cloud_effective_size : nullptr;
+    d.cloud_inv_inhom_effective_size = c.do_clouds ? in->cloud_inv_inhom_effective_size : nullptr;
     return ECRAD_OK;
   }
   const Range& r = cx.r;
@@ -843,6 +863,8 @@ int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int ie
     HIP_TRY(h, copy2d(s.cloud_effective_radius, in->cloud_effective_radius, L * in->n_cloud_types, 8));
     HIP_TRY(h, copy2d(s.cloud_fractional_std, in->cloud_fractional_std, L, 8));
     HIP_TRY(h, copy2d(s.cloud_overlap_param, in->cloud_overlap_param, L - 1, 8));
+    HIP_TRY(h, copy2d(s.cloud_inv_cloud_effective_size, in->cloud_inv_cloud_effective_size, L, 8));
+    HIP_TRY(h, copy2d(s.cloud_inv_inhom_effective_size, in->cloud_inv_inhom_effective_size, L, 8));
   }
   if (c.use_aerosols)
     HIP_TRY(h, copy2d(s.aerosol_mixing_ratio, in->aerosol_mixing_ratio,
@@ -855,6 +877,8 @@ int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int ie
   d.cloud_mixing_ratio = s.cloud_mixing_ratio; d.cloud_effective_radius = s.cloud_effective_radius;
   d.cloud_fractional_std = s.cloud_fractional_std; d.cloud_overlap_param = s.cloud_overlap_param;
   d.aerosol_mixing_ratio = s.aerosol_mixing_ratio;
+  d.cloud_inv_cloud_effective_size = s.cloud_inv_cloud_effective_size;
+  d.cloud_inv_inhom_effective_size = s.cloud_inv_inhom_effective_size;
   return ECRAD_OK;
 }
 
@@ -911,7 +935,13 @@ size_t work_bytes_per_column(ecrad_hip_handle_t h, int nlev, const ecrad_inputs_
   if (h->rrtmg_lw || h->rrtmg_sw) b += rrtmg_work_bytes(nlev, 4096) / 4096;
   const bool sw_mcica = c.do_sw && c.i_solver_sw == ECRAD_SOLVER_MCICA, lw_mcica = c.do_lw && c.i_solver_lw == ECRAD_SOLVER_MCICA;
   const bool tc = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_TRIPLECLOUDS) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_TRIPLECLOUDS);
-  if (tc) b += 8 * (5 * L + 18 * (L + 1));
+  const bool sw_sp = c.do_sw && c.i_solver_sw == ECRAD_SOLVER_SPARTACUS, lw_sp = c.do_lw && c.i_solver_lw == ECRAD_SOLVER_SPARTACUS;
+  if (tc || sw_sp || lw_sp) b += 8 * (5 * L + 18 * (L + 1));
+  {   // stage arrays of the SPARTACUS solvers (one buffer, reused by the two spectra)
+    const size_t bsw = sw_sp ? 8 * ((size_t)c.n_g_sw * (3 * L + 3) + (size_t)c.n_bands_sw * 3 * L) : 0;
+    const size_t blw = lw_sp ? 8 * ((size_t)c.n_g_lw * (4 * L + 3) + (size_t)c.n_bands_lw * 3 * L) : 0;
+    b += std::max(bsw, blw);
+  }
   if (sw_mcica) b += 8 * ((size_t)c.n_g_sw * L + 1);
   if (lw_mcica) b += 8 * ((size_t)c.n_g_lw * L + 1);
   if (c.do_clouds) b += 8 * L;
@@ -1023,11 +1053,17 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
   // ---- scratch & prep buffers ------------------------------------------------------------------------
   const bool sw_mcica = c.do_sw && c.i_solver_sw == ECRAD_SOLVER_MCICA, lw_mcica = c.do_lw && c.i_solver_lw == ECRAD_SOLVER_MCICA;
   const bool sw_tc = c.do_sw && c.i_solver_sw == ECRAD_SOLVER_TRIPLECLOUDS, lw_tc = c.do_lw && c.i_solver_lw == ECRAD_SOLVER_TRIPLECLOUDS;
-  const int grid_sw = c.do_sw ? grid_for(h, r.nloc, h->ngp_sw) : 0;
-  const int grid_lw = c.do_lw ? grid_for(h, r.nloc, h->ngp_lw) : 0;
-  const size_t per_block_sw = !c.do_sw ? 0 : (sw_tc ? sw_tc_scratch_doubles(nlev) : sw_ica_scratch_doubles(c.i_solver_sw, nlev));
+  const bool sw_sp = c.do_sw && c.i_solver_sw == ECRAD_SOLVER_SPARTACUS, lw_sp = c.do_lw && c.i_solver_lw == ECRAD_SOLVER_SPARTACUS;
+  const bool sp_single = c.i_precision == ECRAD_PRECISION_SINGLE;
+  // (the SPARTACUS kernels run one block per CU: one wave per SIMD with the whole register file)
+  auto grid_sp = [&](int ngp) { const int groups = (r.nloc + kBlock / ngp - 1) / (kBlock / ngp); return groups < h->num_cu ? groups : h->num_cu; };
+  const int grid_sw = !c.do_sw ? 0 : sw_sp ? grid_sp(h->ngp_sw) : grid_for(h, r.nloc, h->ngp_sw);
+  const int grid_lw = !c.do_lw ? 0 : lw_sp ? grid_sp(h->ngp_lw) : grid_for(h, r.nloc, h->ngp_lw);
+  const size_t sp_word = sp_single ? 4 : 8;
+  const size_t per_block_sw = !c.do_sw ? 0 : sw_sp ? (spartacus_scratch_words(true, nlev) * sp_word + 7) / 8
+                                           : (sw_tc ? sw_tc_scratch_doubles(nlev) : sw_ica_scratch_doubles(c.i_solver_sw, nlev));
   const bool lw_scat = c.do_lw && c.do_lw_aerosol_scattering != 0;
-  const size_t per_block_lw = !c.do_lw ? 0 : (lw_tc ? lw_tc_scratch_doubles(nlev, lw_scat) : lw_scat ? lw_scat_scratch_doubles(nlev) : lw_ica_scratch_doubles(c.i_solver_lw, nlev));
+  const size_t per_block_lw = !c.do_lw ? 0 : lw_sp ? (spartacus_scratch_words(false, nlev) * sp_word + 7) / 8 : (lw_tc ? lw_tc_scratch_doubles(nlev, lw_scat) : lw_scat ? lw_scat_scratch_doubles(nlev) : lw_ica_scratch_doubles(c.i_solver_lw, nlev));
   const size_t need_sw = per_block_sw * grid_sw * 8, need_lw = per_block_lw * grid_lw * 8;
   HIP_TRY(h, h->scratch.ensure(need_sw > need_lw ? need_sw : need_lw));
   HIP_TRY(h, h->counters.ensure(256));
@@ -1041,7 +1077,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     const size_t n = r.nloc, L = nlev;
     for (int pass = 0; pass < 2; ++pass) {
       Carver cv(pass == 0 ? nullptr : h->prep.p);
-      if (sw_tc || lw_tc) {
+      if (sw_tc || lw_tc || sw_sp || lw_sp) {
         prep.region_fracs = cv.take<double>(3 * L * n);
         prep.od_scaling_reg = cv.take<double>(2 * L * n);
         prep.v_matrix = cv.take<double>(9 * (L + 1) * n);
@@ -1063,9 +1099,40 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
   HIP_TRY(h, launch_order(stream, din, counters + 32));                                 // :310-317
   if ((st = run_rrtmg(h, cx, true))) return st;                                         // RRTMG gas optics, :341-357 (accounted to the PREP stage)
   if (c.do_clouds) HIP_TRY(h, launch_crop(stream, h->dcfg, din));                      // :361
-  if (sw_tc || lw_tc)
-    HIP_TRY(h, launch_tripleclouds_prep(stream, h->dcfg, din, prep, sw_tc ? dfx.cloud_cover_sw : nullptr,
-                                        lw_tc ? dfx.cloud_cover_lw : nullptr));
+  if (sw_tc || lw_tc || sw_sp || lw_sp)
+    HIP_TRY(h, launch_tripleclouds_prep(stream, h->dcfg, din, prep, (sw_tc || sw_sp) ? dfx.cloud_cover_sw : nullptr,
+                                        (lw_tc || lw_sp) ? dfx.cloud_cover_lw : nullptr));
+  // SPARTACUS: the optics of a spectrum go through the stage arrays (radiation_interface.F90:260-301) that
+  // optics_dump_kernel writes; the solver kernels read them (kernel_spartacus.hip)
+  auto run_spartacus = [&](bool is_sw) -> int {
+    const size_t n = r.nloc, L = nlev, ngs = is_sw ? c.n_g_sw : c.n_g_lw, nbs = is_sw ? c.n_bands_sw : c.n_bands_lw;
+    DevOptics dop{};
+    for (int pass = 0; pass < 2; ++pass) {
+      Carver cv(pass == 0 ? nullptr : h->sp_stage.p);
+      if (is_sw) {
+        dop.od_sw = cv.take<double>(ngs * L * n); dop.ssa_sw = cv.take<double>(ngs * L * n); dop.g_sw = cv.take<double>(ngs * L * n);
+        dop.sw_albedo_direct = cv.take<double>(ngs * n); dop.sw_albedo_diffuse = cv.take<double>(ngs * n); dop.incoming_sw = cv.take<double>(ngs * n);
+        dop.od_sw_cloud = cv.take<double>(nbs * L * n); dop.ssa_sw_cloud = cv.take<double>(nbs * L * n); dop.g_sw_cloud = cv.take<double>(nbs * L * n);
+      } else {
+        dop.od_lw = cv.take<double>(ngs * L * n);
+        if (c.do_lw_aerosol_scattering) { dop.ssa_lw = cv.take<double>(ngs * L * n); dop.g_lw = cv.take<double>(ngs * L * n); }
+        dop.planck_hl = cv.take<double>(ngs * (L + 1) * n); dop.lw_emission = cv.take<double>(ngs * n); dop.lw_albedo = cv.take<double>(ngs * n);
+        dop.od_lw_cloud = cv.take<double>(nbs * L * n); dop.ssa_lw_cloud = cv.take<double>(nbs * L * n); dop.g_lw_cloud = cv.take<double>(nbs * L * n);
+      }
+      if (pass == 0) HIP_TRY(h, h->sp_stage.ensure(cv.off));
+    }
+    const DevCkdModel& m = is_sw ? h->hcfg.gas_sw : h->hcfg.gas_lw;
+    const int ngp = is_sw ? h->ngp_sw : h->ngp_lw;
+    if (!is_sw && c.do_lw_aerosol_scattering) {   // layers without aerosol keep ssa = g = 0
+      HIP_TRY(h, hipMemsetAsync(dop.ssa_lw, 0, ngs * L * n * 8, stream));
+      HIP_TRY(h, hipMemsetAsync(dop.g_lw, 0, ngs * L * n * 8, stream));
+    }
+    HIP_TRY(h, launch_optics_dump(is_sw, ngp, m.table_f32, grid_for(h, r.nloc, ngp), lds_bytes(m.hot.nquad, c.n_cloud_types), stream, h->dcfg, din, dop, 0));
+    HIP_TRY(h, launch_spartacus(is_sw, sp_single, ngp, is_sw ? grid_sw : grid_lw, stream, c, din, dop, prep, dfx, scratch,
+                                (is_sw ? per_block_sw : per_block_lw) * 8 / sp_word, counters + (is_sw ? 16 : 0),
+                                is_sw ? h->hcfg.i_band_from_reordered_g_sw : h->hcfg.i_band_from_reordered_g_lw));
+    return ECRAD_OK;
+  };
   // (the McICA generators are accounted to the LW/SW stage they feed)
   HIP_TRY(h, hipEventRecord(evs[1], stream));
   if (c.do_lw) {                                                                        // :422-457
@@ -1080,12 +1147,14 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
         HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_lw, 997, prep.od_scaling_lw,
                                           prep.total_cloud_cover_lw));
     }
+    if (lw_sp) { if ((st = run_spartacus(false))) return st; }
     auto launch_lw = [&](const DevFlux& f, int* counter, int g0, bool wide) -> hipError_t {
       if (lw_tc) return launch_lw_tc(h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
       if (lw_scat) return launch_lw_scat(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
       return launch_lw_ica(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
     };
-    if (h->nchunk_lw == 1) {
+    if (lw_sp) {
+    } else if (h->nchunk_lw == 1) {
       HIP_TRY(h, launch_lw(dfx, counters, 0, false));
     } else {
       // More than 64 g-points: as for the shortwave below, plus the derivatives.  The reference
@@ -1124,7 +1193,9 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
         HIP_TRY(h, launch_mcica_generator(stream, h->dcfg, din, c.n_g_sw, 0, prep.od_scaling_sw,
                                           prep.total_cloud_cover_sw));
     }
-    if (h->nchunk_sw == 1) {
+    if (sw_sp) {
+      if ((st = run_spartacus(true))) return st;
+    } else if (h->nchunk_sw == 1) {
       if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m, 0));
       else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m, 0, false));
     } else {

@@ -145,6 +145,7 @@ struct DevInputs {
   double* cloud_fraction;
   const double *cloud_mixing_ratio, *cloud_effective_radius, *cloud_fractional_std, *cloud_overlap_param;
   const double* aerosol_mixing_ratio;
+  const double *cloud_inv_cloud_effective_size, *cloud_inv_inhom_effective_size;   // SPARTACUS 3-D effects; may be NULL
   // Device flag set by order_kernel at the start of every call: non-zero when the caller's arrays run
   // from the surface upwards (pressure decreasing with the level index).  The kernels always work
   // top-down; they map level indices when they touch the caller's arrays (radiation_reverse,

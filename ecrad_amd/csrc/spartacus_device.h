@@ -105,6 +105,17 @@ template <typename R> SP_DEV void lu3_solve(const Lu3<R>& f, R b1, R b2, R b3, R
   x2 = (y2 - f.U23 * x3) / f.U22;
   x1 = (b1 - f.A12 * x2 - f.A13 * x3) / f.A11;
 }
+template <typename R> SP_DEV V3<R> solve(const Lu3<R>& f, const V3<R>& b) {
+  V3<R> x;
+  lu3_solve(f, b.a[0], b.a[1], b.a[2], x.a[0], x.a[1], x.a[2]);
+  return x;
+}
+template <typename R> SP_DEV M3<R> solve(const Lu3<R>& f, const M3<R>& B) {
+  M3<R> X;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) lu3_solve(f, B(0, j), B(1, j), B(2, j), X(0, j), X(1, j), X(2, j));
+  return X;
+}
 template <typename R> SP_DEV V3<R> solve(const M3<R>& A, const V3<R>& b) {
   const Lu3<R> f = lu3(A);
   V3<R> x;
@@ -153,102 +164,133 @@ template <typename R> SP_DEV M3<R> u_x_m_x_v(const R* U, const M3<R>& A, const R
   return O;
 }
 
-// ---- M x M (M = 6, 9): element (r, c) at a[r + M c]; these arrays live in the lane's private scratch ----------
-// mat_x_mat with the reference's two sparsity patterns (:145-216); SW: the bottom-left (M/3 x 2M/3) block is zero
+// ---- M x M (M = 6 longwave, 9 shortwave): element (r, c) at a[r + M c] ----------------------------------------
+// Every loop below has compile-time bounds and is fully unrolled, so the arrays are plain registers (AGPRs take the
+// overflow at one wave per SIMD) and the zero block of the shortwave pattern costs nothing: in the reference's
+// IMatrixPatternShortwave (radiation_matrix.F90:40, :176-204) rows >= 2M/3 of columns < 2M/3 are identically zero --
+// Gamma = (G1 -G2 -G3; G2 -G1 G4; 0 0 G0) -- and stay zero through products, the LU factors and the solve (a zero
+// minus products with zeros), so skipping them is exact, not an approximation.
+template <int M, bool SW> struct Pat {
+  static constexpr int M2 = SW ? 2 * (M / 3) : M;
+  static constexpr bool nz(int r, int c) { return !(SW && r >= M2 && c < M2); }
+};
+// mat_x_mat (:145-216): the inner index runs in increasing order over the range the pattern allows
 template <typename R, int M, bool SW>
-SP_DEV void mmul(const R* __restrict__ A, const R* __restrict__ B, R* __restrict__ C) {
-  constexpr int M2 = SW ? 2 * (M / 3) : M;
+SP_DEV void mmul(const R (&A)[M * M], const R (&B)[M * M], R (&C)[M * M]) {
+  constexpr int M2 = Pat<M, SW>::M2;
+#pragma unroll
   for (int c = 0; c < M; ++c)
+#pragma unroll
     for (int r = 0; r < M; ++r) {
       R s = R(0);
-      if (SW && r >= M2) {
-        if (c >= M2) for (int k = M2; k < M; ++k) s = s + A[r + M * k] * B[k + M * c];
-      } else if (SW && c < M2) {
-        for (int k = 0; k < M2; ++k) s = s + A[r + M * k] * B[k + M * c];
-      } else {
-        for (int k = 0; k < M; ++k) s = s + A[r + M * k] * B[k + M * c];
-      }
+      if (!Pat<M, SW>::nz(r, c)) { C[r + M * c] = s; continue; }
+      const int k0 = (SW && r >= M2) ? M2 : 0;
+      const int k1 = (SW && c < M2) ? M2 : M;
+#pragma unroll
+      for (int k = 0; k < M; ++k)
+        if (k >= k0 && k < k1) s = s + A[r + M * k] * B[k + M * c];
       C[r + M * c] = s;
     }
 }
-// lu_factorization + lu_substitution (:639-706), in place: A becomes LU, then X = A^-1 B column by column
-template <typename R, int M>
-SP_DEV void lu_factor(R* __restrict__ LU) {
+// lu_factorization (:639-674), in place, no pivoting
+template <typename R, int M, bool SW>
+SP_DEV void lu_factor(R (&LU)[M * M]) {
+#pragma unroll
   for (int j2 = 0; j2 < M; ++j2) {
-    for (int j1 = 0; j1 < j2; ++j1) {
+#pragma unroll
+    for (int j1 = 0; j1 < M; ++j1) {
+      if (!Pat<M, SW>::nz(j1, j2)) continue;
       R s = LU[j1 + M * j2];
-      for (int j3 = 0; j3 < j1; ++j3) s = s - LU[j1 + M * j3] * LU[j3 + M * j2];
-      LU[j1 + M * j2] = s;
-    }
-    for (int j1 = j2; j1 < M; ++j1) {
-      R s = LU[j1 + M * j2];
-      for (int j3 = 0; j3 < j2; ++j3) s = s - LU[j1 + M * j3] * LU[j3 + M * j2];
+      const int kend = j1 < j2 ? j1 : j2;
+#pragma unroll
+      for (int j3 = 0; j3 < M; ++j3)
+        if (j3 < kend && Pat<M, SW>::nz(j1, j3) && Pat<M, SW>::nz(j3, j2)) s = s - LU[j1 + M * j3] * LU[j3 + M * j2];
       LU[j1 + M * j2] = s;
     }
     if (j2 != M - 1) {
       const R s = R(1) / LU[j2 + M * j2];
-      for (int j1 = j2 + 1; j1 < M; ++j1) LU[j1 + M * j2] = LU[j1 + M * j2] * s;
+#pragma unroll
+      for (int j1 = 0; j1 < M; ++j1)
+        if (j1 > j2 && Pat<M, SW>::nz(j1, j2)) LU[j1 + M * j2] = LU[j1 + M * j2] * s;
     }
   }
 }
-template <typename R, int M>
-SP_DEV void lu_subst(const R* __restrict__ LU, R* __restrict__ x /* in: b, out: x */) {
-  for (int j2 = 1; j2 < M; ++j2)
-    for (int j1 = 0; j1 < j2; ++j1) x[j2] = x[j2] - x[j1] * LU[j2 + M * j1];
-  for (int j2 = M - 1; j2 >= 0; --j2) {
-    for (int j1 = j2 + 1; j1 < M; ++j1) x[j2] = x[j2] - x[j1] * LU[j2 + M * j1];
+// lu_substitution (:681-706) on one right-hand side held in x.  ZR: rows >= M2 of the right-hand side are zero (a
+// column < M2 of a pattern matrix); they stay zero and are skipped
+template <typename R, int M, bool SW, bool ZR = false>
+SP_DEV void lu_subst(const R (&LU)[M * M], R (&x)[M]) {
+  constexpr int ME = ZR ? Pat<M, SW>::M2 : M;
+#pragma unroll
+  for (int j2 = 1; j2 < ME; ++j2)
+#pragma unroll
+    for (int j1 = 0; j1 < ME; ++j1)
+      if (j1 < j2 && Pat<M, SW>::nz(j2, j1)) x[j2] = x[j2] - x[j1] * LU[j2 + M * j1];
+#pragma unroll
+  for (int j2 = ME - 1; j2 >= 0; --j2) {
+#pragma unroll
+    for (int j1 = 0; j1 < ME; ++j1)
+      if (j1 > j2) x[j2] = x[j2] - x[j1] * LU[j2 + M * j1];
     x[j2] = x[j2] / LU[j2 + M * j2];
   }
 }
 
-// expm (:805-903): A <- exp(A).  W is work space for 4 M x M matrices.
+// expm (:805-903): Higham's scaling and squaring with the order-7 Pade approximant; A <- exp(A)
 template <typename R, int M, bool SW>
-SP_DEV void expm(R* __restrict__ A, R* __restrict__ W) {
+SP_DEV void expm(R (&A)[M * M]) {
   const R theta3 = R(3.925724783138660e+00);
   const R c0 = R(17297280.0), c1 = R(8648640.0), c2 = R(1995840.0), c3 = R(277200.0), c4 = R(25200.0), c5 = R(1512.0), c6 = R(56.0), c7 = R(1.0);
-  R* A2 = W; R* A4 = W + M * M; R* A6 = W + 2 * M * M; R* U = W + 3 * M * M;
   R normA = R(0);
+#pragma unroll
   for (int c = 0; c < M; ++c) {
     R s = R(0);
-    for (int r = 0; r < M; ++r) s = s + sp_abs(A[r + M * c]);
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+      if (Pat<M, SW>::nz(r, c)) s = s + sp_abs(A[r + M * c]);
     if (s > normA) normA = s;
   }
-  // frac = fraction(normA/theta3), expo = exponent(normA/theta3): x = frac 2^expo, 0.5 <= frac < 1
+  // fraction()/exponent(): normA/theta3 = frac 2^expo with 0.5 <= frac < 1
   int expo = 0;
   const R frac = sp_frexp(normA / theta3, &expo);
   if (frac == R(0.5)) expo = expo - 1;
   if (expo < 0) expo = 0;
   const R scaling = sp_ldexp(R(1), -expo);
+#pragma unroll
   for (int k = 0; k < M * M; ++k) A[k] = A[k] * scaling;
+  R A2[M * M], A4[M * M], A6[M * M], V[M * M], U[M * M];
   mmul<R, M, SW>(A, A, A2);
   mmul<R, M, SW>(A2, A2, A4);
   mmul<R, M, SW>(A2, A4, A6);
-  // V = c7 A6 + c5 A4 + c3 A2 + c1 I (held in A6's place is not possible: A6 is needed twice) -> build V in U's
-  // neighbour: U = A V needs V separate, so V goes to A2's successor slot order: use a 5th area = reuse after use.
-  // Order of use: V1 -> U = A V1 ; V2 (needs A2, A4, A6) ; so V1 must not overwrite A2/A4/A6: it takes U's space
-  // and the product goes to a temporary that then replaces it.
-  R* V = U;                                   // V1
+#pragma unroll
   for (int k = 0; k < M * M; ++k) V[k] = c7 * A6[k] + c5 * A4[k] + c3 * A2[k];
+#pragma unroll
   for (int j = 0; j < M; ++j) V[j + M * j] = V[j + M * j] + c1;
-  // U = A * V1 -> written into A's own space is impossible (A is an operand); A6 is still needed.  So: compute V2
-  // first into A6 (elementwise, allowed in place), keep A2 as the temporary for the product.
-  for (int k = 0; k < M * M; ++k) A6[k] = c6 * A6[k] + c4 * A4[k] + c2 * A2[k];     // V2 (without the identity term yet)
-  for (int j = 0; j < M; ++j) A6[j + M * j] = A6[j + M * j] + c0;
-  mmul<R, M, SW>(A, V, A2);                                                          // U = A V1
-  for (int k = 0; k < M * M; ++k) { A6[k] = A6[k] - A2[k]; A2[k] = R(2) * A2[k]; }   // V = V2 - U ; U = 2 U
-  // A = V^-1 U  (solve_mat: general LU for M > 3)
-  lu_factor<R, M>(A6);
+  mmul<R, M, SW>(A, V, U);
+#pragma unroll
+  for (int k = 0; k < M * M; ++k) V[k] = c6 * A6[k] + c4 * A4[k] + c2 * A2[k];
+#pragma unroll
+  for (int j = 0; j < M; ++j) V[j + M * j] = V[j + M * j] + c0;
+#pragma unroll
+  for (int k = 0; k < M * M; ++k) { V[k] = V[k] - U[k]; U[k] = R(2) * U[k]; }
+  // A = V^-1 U (solve_mat, general LU for M > 3), then + identity
+  lu_factor<R, M, SW>(V);
+#pragma unroll
   for (int c = 0; c < M; ++c) {
     R x[M];
-    for (int r = 0; r < M; ++r) x[r] = A2[r + M * c];
-    lu_subst<R, M>(A6, x);
-    for (int r = 0; r < M; ++r) A[r + M * c] = x[r];
+#pragma unroll
+    for (int r = 0; r < M; ++r) x[r] = U[r + M * c];
+    if (SW && c < Pat<M, SW>::M2) lu_subst<R, M, SW, true>(V, x);
+    else lu_subst<R, M, SW, false>(V, x);
+#pragma unroll
+    for (int r = 0; r < M; ++r) A[r + M * c] = Pat<M, SW>::nz(r, c) ? x[r] : R(0);
   }
+#pragma unroll
   for (int j = 0; j < M; ++j) A[j + M * j] = A[j + M * j] + R(1);
-  // repeated_square (:355-427)
-  for (int j4 = 0; j4 < expo; ++j4) {
+  // repeated_square (:355-427): lanes differ in the number of squarings
+  for (int j4 = 0; __any(j4 < expo); ++j4) {
     mmul<R, M, SW>(A, A, A2);
-    for (int k = 0; k < M * M; ++k) A[k] = A2[k];
+    const bool mine = j4 < expo;
+#pragma unroll
+    for (int k = 0; k < M * M; ++k) A[k] = mine ? A2[k] : A[k];
   }
 }
 

@@ -76,6 +76,30 @@ def make_fma_variant_backend(nblocksize: int = 32, nthreads: int = 0):
     return _b
 
 
+_lib_variants = {}
+
+
+def make_variant_backend(target: str, nblocksize: int = 32, nthreads: int = 0):
+    """Another build of the same restatement (oracle/Makefile targets): "sp" = the SPARTACUS solvers and their matrix
+    algebra in single precision (the reference's PARKIND1_SINGLE build); "sp_fma" = that with floating-point contraction
+    allowed, the measure of how sensitive the single-precision formulas are to the last bit."""
+    if target not in _lib_variants:
+        subprocess.run(["make", "-C", _HERE, target], check=True, capture_output=True)
+        from ecrad_amd import abi
+        L = C.CDLL(os.path.join(_HERE, f"libecrad_oracle_{target}.so"))
+        L.ecrad_oracle_radiation_blocked.argtypes = [C.POINTER(abi.Config), C.c_int, C.c_int, C.c_int, C.c_int,
+                                                     C.c_int, C.c_int, C.POINTER(abi.Inputs), C.POINTER(abi.Flux)]
+        L.ecrad_oracle_radiation_blocked.restype = C.c_int
+        _lib_variants[target] = L
+    L = _lib_variants[target]
+
+    def _b(cconfig, ncol, nlev, istartcol, iendcol, cin, cflux) -> int:
+        return L.ecrad_oracle_radiation_blocked(C.byref(cconfig), ncol, nlev, istartcol, iendcol,
+                                                nblocksize, nthreads, C.byref(cin), C.byref(cflux))
+    _b.lib = L
+    return _b
+
+
 def make_blocked_backend(nblocksize: int, nthreads: int = 0):
     def _b(cconfig, ncol, nlev, istartcol, iendcol, cin, cflux) -> int:
         return lib().ecrad_oracle_radiation_blocked(C.byref(cconfig), ncol, nlev, istartcol, iendcol,
