@@ -53,6 +53,10 @@ class DeviceCase:
             s.cloud_effective_radius = abi.raw_dptr(up("cloud_effective_radius", cloud.effective_radius))
             s.cloud_fractional_std = abi.raw_dptr(up("cloud_fractional_std", cloud.fractional_std))
             s.cloud_overlap_param = abi.raw_dptr(up("cloud_overlap_param", cloud.overlap_param))
+            if cloud.inv_cloud_effective_size is not None:
+                s.cloud_inv_cloud_effective_size = abi.raw_dptr(up("cloud_inv_cloud_effective_size", cloud.inv_cloud_effective_size))
+            if cloud.inv_inhom_effective_size is not None:
+                s.cloud_inv_inhom_effective_size = abi.raw_dptr(up("cloud_inv_inhom_effective_size", cloud.inv_inhom_effective_size))
         if aerosol is not None and config.use_aerosols:
             s.n_aerosol_types = aerosol.mixing_ratio.shape[0]
             s.aerosol_istartlev, s.aerosol_iendlev = aerosol.istartlev, aerosol.iendlev

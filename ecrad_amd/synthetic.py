@@ -24,6 +24,7 @@ from .types import Aerosol, Cloud, Gas, SingleLevel, Thermodynamics
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MERIDIAN = os.path.join(ROOT, "tests", "golden", "ecrad_meridian.nc")
+NAMELIST = os.path.join(ROOT, "ecrad_amd", "configs", "configCY49R1_ecckd.nam")
 SEED = 20260929
 
 
@@ -31,7 +32,10 @@ def make_columns(config: Config, ncol: int, clear_sky: bool, seed: int = SEED, f
                  base_file: str = MERIDIAN):
     """Return (ncol, nlev, single_level, thermodynamics, gas, cloud, aerosol) with gas units already
     set for the gas model and h2o_sat_liq computed (i.e. ready for Radiation.radiation)."""
-    dc = DriverConfig()
+    from .config import ISolverSpartacus
+    spartacus = ISolverSpartacus in (config.i_solver_sw, config.i_solver_lw)
+    # (SPARTACUS: the cloud sizes come from the test namelist's cloud_separation_scale_* as in test/ifs)
+    dc = DriverConfig.read(NAMELIST) if spartacus else DriverConfig()
     nb, nlev, sl0, th0, gas0, cloud0, aer0 = read_input(base_file, config, dc)
     # set_gas_units: volume mixing ratios for ecCKD, mass mixing ratios for RRTMG (radiation_ifs_rrtm.F90:203-213)
     gas0.set_units(0 if getattr(config, "rrtmg", None) is not None else 1)
@@ -77,6 +81,10 @@ def make_columns(config: Config, ncol: int, clear_sky: bool, seed: int = SEED, f
                       effective_radius=np.ascontiguousarray(take(cloud0.effective_radius)),
                       fractional_std=np.ascontiguousarray(take(cloud0.fractional_std)),
                       overlap_param=np.ascontiguousarray(take(cloud0.overlap_param)))
+        if spartacus:       # the cloud scales of the base profile (radiation_cloud.F90:602-690)
+            cloud.inv_cloud_effective_size = np.ascontiguousarray(take(cloud0.inv_cloud_effective_size))
+            if cloud0.inv_inhom_effective_size is not None:
+                cloud.inv_inhom_effective_size = np.ascontiguousarray(take(cloud0.inv_inhom_effective_size))
     aerosol = None
     if config.use_aerosols and aer0 is not None:
         aerosol = Aerosol(mixing_ratio=np.ascontiguousarray(take(aer0.mixing_ratio)),
@@ -109,5 +117,8 @@ BENCH_CONFIGS = {
     # test/ifs/configCY49R1.nam: SOCRATES/Fu band cloud optics, 12 aerosol types, no LW aerosol scattering)
     "mcica_rrtmg": dict(sw_solver="McICA", use_aerosols=True, clear_sky=False, rrtmg=True, do_lw_aerosol_scattering=False),
     "mcica_rrtmg_noaer": dict(sw_solver="McICA", use_aerosols=False, clear_sky=False, rrtmg=True, do_lw_aerosol_scattering=False),
+    # BASELINE configs[4]: ecCKD-32, SPARTACUS (3 regions, 3-D effects, explicit entrapment), single precision
+    "spartacus_ecckd32_sp": dict(sw_solver="SPARTACUS", use_aerosols=True, clear_sky=False, i_precision=1),
+    "spartacus_ecckd32_dp": dict(sw_solver="SPARTACUS", use_aerosols=True, clear_sky=False),
     "tripleclouds_rrtmg": dict(sw_solver="Tripleclouds", use_aerosols=True, clear_sky=False, rrtmg=True, do_lw_aerosol_scattering=False),
 }
