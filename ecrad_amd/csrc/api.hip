@@ -938,9 +938,10 @@ size_t work_bytes_per_column(ecrad_hip_handle_t h, int nlev, const ecrad_inputs_
   const bool sw_sp = c.do_sw && c.i_solver_sw == ECRAD_SOLVER_SPARTACUS, lw_sp = c.do_lw && c.i_solver_lw == ECRAD_SOLVER_SPARTACUS;
   if (tc || sw_sp || lw_sp) b += 8 * (5 * L + 18 * (L + 1));
   {   // stage arrays of the SPARTACUS solvers (one buffer, reused by the two spectra)
-    const size_t bsw = sw_sp ? 8 * ((size_t)c.n_g_sw * (3 * L + 3) + (size_t)c.n_bands_sw * 3 * L) : 0;
-    const size_t blw = lw_sp ? 8 * ((size_t)c.n_g_lw * (4 * L + 3) + (size_t)c.n_bands_lw * 3 * L) : 0;
-    b += std::max(bsw, blw);
+    const size_t w = c.i_precision == ECRAD_PRECISION_SINGLE ? 4 : 8;
+    const size_t bsw = sw_sp ? 8 * ((size_t)c.n_g_sw * (3 * L + 3) + (size_t)c.n_bands_sw * 3 * L) + w * L * spartacus_layer_words(true, c.n_g_sw) : 0;
+    const size_t blw = lw_sp ? 8 * ((size_t)c.n_g_lw * (4 * L + 3) + (size_t)c.n_bands_lw * 3 * L) + w * L * spartacus_layer_words(false, c.n_g_lw) : 0;
+    b += std::max(bsw, blw) + 4 * L;
   }
   if (sw_mcica) b += 8 * ((size_t)c.n_g_sw * L + 1);
   if (lw_mcica) b += 8 * ((size_t)c.n_g_lw * L + 1);
@@ -1056,7 +1057,8 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
   const bool sw_sp = c.do_sw && c.i_solver_sw == ECRAD_SOLVER_SPARTACUS, lw_sp = c.do_lw && c.i_solver_lw == ECRAD_SOLVER_SPARTACUS;
   const bool sp_single = c.i_precision == ECRAD_PRECISION_SINGLE;
   // (the SPARTACUS kernels run one block per CU: one wave per SIMD with the whole register file)
-  auto grid_sp = [&](int ngp) { const int groups = (r.nloc + kBlock / ngp - 1) / (kBlock / ngp); return groups < h->num_cu ? groups : h->num_cu; };
+  // (the SPARTACUS sweeps run two blocks per CU in single precision, one in double; the list walk one block per CU)
+  auto grid_sp = [&](int ngp) { const int groups = (r.nloc + kBlock / ngp - 1) / (kBlock / ngp); const int m = h->num_cu * (sp_single ? 2 : 1); return groups < m ? groups : m; };
   const int grid_sw = !c.do_sw ? 0 : sw_sp ? grid_sp(h->ngp_sw) : grid_for(h, r.nloc, h->ngp_sw);
   const int grid_lw = !c.do_lw ? 0 : lw_sp ? grid_sp(h->ngp_lw) : grid_for(h, r.nloc, h->ngp_lw);
   const size_t sp_word = sp_single ? 4 : 8;
@@ -1107,8 +1109,14 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
   auto run_spartacus = [&](bool is_sw) -> int {
     const size_t n = r.nloc, L = nlev, ngs = is_sw ? c.n_g_sw : c.n_g_lw, nbs = is_sw ? c.n_bands_sw : c.n_bands_lw;
     DevOptics dop{};
+    void* lay = nullptr;
+    uint32_t* list = nullptr;
+    int* n_items = nullptr;
     for (int pass = 0; pass < 2; ++pass) {
       Carver cv(pass == 0 ? nullptr : h->sp_stage.p);
+      lay = cv.take<char>(sp_word * L * n * spartacus_layer_words(is_sw, (int)ngs));
+      list = cv.take<uint32_t>(L * n);
+      n_items = cv.take<int>(64);
       if (is_sw) {
         dop.od_sw = cv.take<double>(ngs * L * n); dop.ssa_sw = cv.take<double>(ngs * L * n); dop.g_sw = cv.take<double>(ngs * L * n);
         dop.sw_albedo_direct = cv.take<double>(ngs * n); dop.sw_albedo_diffuse = cv.take<double>(ngs * n); dop.incoming_sw = cv.take<double>(ngs * n);
@@ -1128,9 +1136,9 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
       HIP_TRY(h, hipMemsetAsync(dop.g_lw, 0, ngs * L * n * 8, stream));
     }
     HIP_TRY(h, launch_optics_dump(is_sw, ngp, m.table_f32, grid_for(h, r.nloc, ngp), lds_bytes(m.hot.nquad, c.n_cloud_types), stream, h->dcfg, din, dop, 0));
-    HIP_TRY(h, launch_spartacus(is_sw, sp_single, ngp, is_sw ? grid_sw : grid_lw, stream, c, din, dop, prep, dfx, scratch,
+    HIP_TRY(h, launch_spartacus(is_sw, sp_single, ngp, is_sw ? grid_sw : grid_lw, h->num_cu, stream, c, din, dop, prep, dfx, scratch,
                                 (is_sw ? per_block_sw : per_block_lw) * 8 / sp_word, counters + (is_sw ? 16 : 0),
-                                is_sw ? h->hcfg.i_band_from_reordered_g_sw : h->hcfg.i_band_from_reordered_g_lw));
+                                is_sw ? h->hcfg.i_band_from_reordered_g_sw : h->hcfg.i_band_from_reordered_g_lw, lay, list, n_items));
     return ECRAD_OK;
   };
   // (the McICA generators are accounted to the LW/SW stage they feed)

@@ -13,9 +13,17 @@
 // from the stage arrays that the optics pass (kernel_optics.hip) writes -- 0.8 MB per column once, which at HBM speed
 // is a small fraction of the time the exponentials take.
 //
-// Two vertical sweeps per spectrum instead of the reference's three loops: the layer matrices (section 3) are
-// computed inside the upward albedo/source sweep (section 4) and only what the flux sweep (section 5) needs is
-// parked in a block-private slab of HBM -- per (g, cloudy layer) 60 (SW) / 38 (LW) words, per clear layer 12 / 10.
+// Three kernels per spectrum.  The reference's first loop over layers (section 3) has no vertical dependence, and its
+// cost sits in the cloudy layers only, so:
+//   spartacus_list_kernel    compacts the (column, cloudy layer) pairs of the batch into a work list (lane = column);
+//   spartacus_layers_kernel  walks that list, lane = g-point, 256/NGP items per block: every lane of every wave does
+//                            the same matrix exponential -- no wave pays for the cloudy layers of a neighbour column,
+//                            no clear layer waits at one wave per SIMD -- and writes the layer's reflectance /
+//                            transmittance / source matrices (45 SW, 24 LW words per g-point) to HBM;
+//   spartacus_{sw,lw}_kernel the two vertical sweeps (sections 4 and 5: adding method with overlap and entrapment
+//                            going up, fluxes going down), lane = (column, g-point), two-stream for the clear layers
+//                            in line, the matrices of the cloudy ones read back; what the flux sweep needs of the
+//                            upward sweep is parked in a block-private slab.
 //
 // R is the working precision: double, or float for config%i_precision = single (PARKIND1_SINGLE semantics: jprb =
 // float in the solver, the Meador-Weaver two-stream routines keep double internals, radiation_two_stream.F90:455-461,
@@ -167,6 +175,9 @@ struct SpArgs {
   void* scratch;
   size_t per_block;      // words of R per block
   int* counter;
+  void* lay;             // layer matrices of the listed layers: [(local column * nlev + layer) * NV + k][g], words of R
+  const uint32_t* list;  // work list of spartacus_layers_kernel: (local column << 8) | layer
+  const int* n_items;
 };
 
 // hydrostatic equation and ideal gas law: dz = dp R T / (p g), radiation_spartacus_sw.F90:436-442
@@ -332,16 +343,143 @@ template <int NGP> ECRAD_DEV void put_sum(double* arr, size_t o, double v, bool 
 
 // slots of the shortwave slab
 enum { SW_REFC = 0, SW_TRAC, SW_TDDC, SW_TDIRC, SW_TAC, SW_TADC,     // clear-sky scalars: layer coefficients, albedos below
-       SW_REFL = 6, SW_TRAN = 15, SW_TDD = 24, SW_TDIR = 33, SW_TA = 42, SW_TAD = 51, SW_NSLOT = 60 };
-// (a clear layer stores only the (0,0) elements, in slots SW_REFL .. SW_REFL+5)
+       SW_REFL = 6, SW_TA = 6, SW_TAD = 15, SW_NSLOT = 24 };
+// (a clear layer stores (0,0) elements only: refl, tran, tdd, tdir, ta, tad in slots SW_REFL .. SW_REFL+5; a listed one
+//  the two albedo matrices, its own matrices being in the layer store)
 
 }  // namespace
+
+// ---- section 3 of one listed layer and one g-point: radiation_spartacus_sw.F90:409-785 --------------------------
+template <typename R> struct SwMats { M3<R> refl, tran, rdir, tdd, tdir; };
+
+template <typename R, int NGP>
+ECRAD_DEV SwMats<R> sw_layer(const SpArgs& a, const Geo& gm, const LevelOrder& ord, int col, int cloc, int jl, int g, int ib, int glane,
+                             int tid, bool valid, bool clr, R mu0, R tan_sza) {
+  const SpConfig& c = a.c;
+  const DevInputs& in = a.in;
+  const int ng = c.ng, nb = c.nb, nlev = in.nlev;
+  const R tan_diffuse_angle_3d = R(kPi * 0.5);
+  const R one_over_mu0 = R(1) / mu0;
+  const size_t o = g + (size_t)ng * (jl + (size_t)nlev * cloc);
+  const R odl = R(a.op.od_sw[o]), ssal = R(a.op.ssa_sw[o]), gl = R(a.op.g_sw ? a.op.g_sw[o] : 0.0);
+  const int first = first_exceeding<NGP>(valid && odl > R(c.max_gas_od_3d), tid);
+    // -- section 3: layer matrices --
+    R od_region[3] = {odl, R(0), R(0)}, ssa_region[3] = {ssal, R(0), R(0)};
+    R gamma1[3] = {R(0), R(0), R(0)}, gamma2[3] = {R(0), R(0), R(0)}, gamma3[3] = {R(0), R(0), R(0)};
+    R rate_diffuse[9], rate_direct[9], el[3] = {R(0), R(0), R(0)};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { rate_diffuse[k] = R(0); rate_direct[k] = R(0); }
+    R layer_depth = R(0);
+    int nregactive = 1;
+    bool all3d = c.use_expm_everywhere != 0;
+    if (clr) {
+      gammas_sw(mu0, ssal, gl, gamma1[0], gamma2[0], gamma3[0]);
+    } else {
+      layer_depth = layer_depth_of<R>(in, ord, col, jl);
+      if (edge_lengths<R>(c, in, ord, gm, col, jl, el)) {
+        transfer_rates<R>(c, gm, jl, layer_depth, tan_diffuse_angle_3d, el, rate_diffuse);
+        transfer_rates<R>(c, gm, jl, layer_depth, tan_sza, el, rate_direct);
+        all3d = true;
+      }
+      nregactive = 3;
+      const size_t oc = ib + (size_t)nb * (jl + (size_t)nlev * cloc);
+      const R odc = R(a.op.od_sw_cloud[oc]), ssac = R(a.op.ssa_sw_cloud[oc]), gc = R(a.op.g_sw_cloud[oc]);
+      const R scat_od = odl * ssal;
+      R g_region[3] = {gl, R(0), R(0)};
+#pragma unroll
+      for (int jreg = 1; jreg < 3; ++jreg) {
+        const R ods = R(gm.ods(jreg, jl));
+        const R scat_od_cloud = odc * ssac * ods;
+        od_region[jreg] = odl + odc * ods;
+        ssa_region[jreg] = (scat_od + scat_od_cloud) / od_region[jreg];
+        g_region[jreg] = (scat_od * gl + scat_od_cloud * gc) / (scat_od + scat_od_cloud);
+        if (od_region[jreg] > R(c.max_cloud_od)) od_region[jreg] = R(c.max_cloud_od);
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) gammas_sw(mu0, ssa_region[r], g_region[r], gamma1[r], gamma2[r], gamma3[r]);
+    }
+    const bool is3d = all3d && glane < first;
+
+    M3<R> refl, tran, rdir, tdd, tdir;
+    refl.zero(); tran.zero(); rdir.zero(); tdd.zero(); tdir.zero();
+    if (is3d) {               // 3.3a
+      R G[81];
+#pragma unroll
+      for (int k = 0; k < 81; ++k) G[k] = R(0);
+#define GZ(r, cc) G[(r) + 9 * (cc)]
+#pragma unroll
+      for (int jreg = 0; jreg < 3; ++jreg) {
+        if (jreg >= nregactive) continue;
+        GZ(jreg, jreg) = od_region[jreg] * gamma1[jreg];
+        GZ(jreg + 3, jreg) = od_region[jreg] * gamma2[jreg];
+        GZ(jreg, jreg + 6) = -od_region[jreg] * ssa_region[jreg] * gamma3[jreg];
+        GZ(jreg + 3, jreg + 6) = od_region[jreg] * ssa_region[jreg] * (R(1) - gamma3[jreg]);
+        GZ(jreg + 6, jreg + 6) = -od_region[jreg] * one_over_mu0;
+      }
+      if (nregactive == 3) {
+#pragma unroll
+        for (int jreg = 0; jreg < 2; ++jreg) {
+          GZ(jreg, jreg) = GZ(jreg, jreg) + rate_diffuse[jreg + 3 * (jreg + 1)];
+          GZ(jreg + 1, jreg + 1) = GZ(jreg + 1, jreg + 1) + rate_diffuse[(jreg + 1) + 3 * jreg];
+          GZ(jreg + 1, jreg) = -rate_diffuse[jreg + 3 * (jreg + 1)];
+          GZ(jreg, jreg + 1) = -rate_diffuse[(jreg + 1) + 3 * jreg];
+          GZ(jreg + 6, jreg + 6) = GZ(jreg + 6, jreg + 6) - rate_direct[jreg + 3 * (jreg + 1)];
+          GZ(jreg + 7, jreg + 7) = GZ(jreg + 7, jreg + 7) - rate_direct[(jreg + 1) + 3 * jreg];
+          GZ(jreg + 7, jreg + 6) = rate_direct[jreg + 3 * (jreg + 1)];
+          GZ(jreg + 6, jreg + 7) = rate_direct[(jreg + 1) + 3 * jreg];
+        }
+      }
+      if (el[2] > R(0)) {
+        GZ(0, 0) = GZ(0, 0) + rate_diffuse[0 + 3 * 2];
+        GZ(2, 2) = GZ(2, 2) + rate_diffuse[2 + 3 * 0];
+        GZ(2, 0) = -rate_diffuse[0 + 3 * 2];
+        GZ(0, 2) = -rate_diffuse[2 + 3 * 0];
+        GZ(6, 6) = GZ(6, 6) - rate_direct[0 + 3 * 2];
+        GZ(8, 8) = GZ(8, 8) - rate_direct[2 + 3 * 0];
+        GZ(8, 6) = rate_direct[0 + 3 * 2];
+        GZ(6, 8) = rate_direct[2 + 3 * 0];
+      }
+      // (the reference copies the top-left block over nregactive rows and columns only; the rest is zero anyway)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) GZ(3 + r, 3 + cc) = -GZ(r, cc);
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) GZ(r, 3 + cc) = -GZ(3 + r, cc);
+#undef GZ
+      sp::expm<R, 9, true>(G);
+      tdir = clamp(block<R, 9>(G, 6, 6), R(0), R(1), R(1));
+      const sp::Lu3<R> f1 = sp::lu3(block<R, 9>(G, 0, 0));
+      refl = clamp(sp::solve(f1, block<R, 9>(G, 0, 3)), R(0), R(1), R(-1));
+      const M3<R> sub3 = block<R, 9>(G, 3, 0);
+      tran = clamp(add(sp::mul(sub3, refl), block<R, 9>(G, 3, 3)), R(0), R(1), R(1));
+      rdir = clamp(sp::solve(f1, block<R, 9>(G, 0, 6)), R(0), mu0, R(-1));
+      tdd = clamp(add(sp::mul(sub3, rdir), block<R, 9>(G, 3, 6)), R(0), mu0, R(1));
+    }
+    // 3.3b: clear-sky coefficients (always), and the diagonal of the regions for g-points without 3-D effects
+    const SwLayer<R> cl = ref_trans_sw<R>(mu0, od_region[0], ssa_region[0], gamma1[0], gamma2[0], gamma3[0]);
+    if (!is3d) {
+      refl(0, 0) = cl.ref_diff; tran(0, 0) = cl.trans_diff; rdir(0, 0) = cl.ref_dir; tdd(0, 0) = cl.trans_dir_diff; tdir(0, 0) = cl.trans_dir_dir;
+      if (nregactive == 3) {
+#pragma unroll
+        for (int jreg = 1; jreg < 3; ++jreg) {
+          const SwLayer<R> r = ref_trans_sw<R>(mu0, od_region[jreg], ssa_region[jreg], gamma1[jreg], gamma2[jreg], gamma3[jreg]);
+          refl(jreg, jreg) = r.ref_diff; tran(jreg, jreg) = r.trans_diff; rdir(jreg, jreg) = r.ref_dir;
+          tdd(jreg, jreg) = r.trans_dir_diff; tdir(jreg, jreg) = r.trans_dir_dir;
+        }
+      }
+    }
+
+  return {refl, tran, rdir, tdd, tdir};
+}
 
 // =====================================================================================================================
 //  solver_spartacus_sw
 // =====================================================================================================================
 template <typename R, int NGP>
-__global__ __launch_bounds__(kBlock, 1) void spartacus_sw_kernel(SpArgs args_in_kernarg) {
+__global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? 2 : 1) void spartacus_sw_kernel(SpArgs args_in_kernarg) {
   __shared__ int next_group;
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
@@ -403,120 +541,31 @@ __global__ __launch_bounds__(kBlock, 1) void spartacus_sw_kernel(SpArgs args_in_
       const int jl = jlev - 1;
       const bool clr = !cm.test(jl);
       const bool clr_above = jl == 0 || !cm.test(jl - 1);
-      const size_t o = g + (size_t)ng * (jl + (size_t)nlev * cloc);
-      const R odl = R(a.op.od_sw[o]), ssal = R(a.op.ssa_sw[o]), gl = R(a.op.g_sw ? a.op.g_sw[o] : 0.0);
-      const int first = first_exceeding<NGP>(valid && odl > R(c.max_gas_od_3d), tid);
+      const bool listed = !clr || c.use_expm_everywhere != 0;      // its matrices come from spartacus_layers_kernel
       if (!sun_up) continue;
-
-      // -- section 3: layer matrices --
-      R od_region[3] = {odl, R(0), R(0)}, ssa_region[3] = {ssal, R(0), R(0)};
-      R gamma1[3] = {R(0), R(0), R(0)}, gamma2[3] = {R(0), R(0), R(0)}, gamma3[3] = {R(0), R(0), R(0)};
-      R rate_diffuse[9], rate_direct[9], el[3] = {R(0), R(0), R(0)};
-#pragma unroll
-      for (int k = 0; k < 9; ++k) { rate_diffuse[k] = R(0); rate_direct[k] = R(0); }
-      R layer_depth = R(0);
-      int nregactive = 1;
-      bool all3d = c.use_expm_everywhere != 0;
-      if (clr) {
-        gammas_sw(mu0, ssal, gl, gamma1[0], gamma2[0], gamma3[0]);
-      } else {
-        layer_depth = layer_depth_of<R>(a.in, ord, col, jl);
-        if (edge_lengths<R>(c, a.in, ord, gm, col, jl, el)) {
-          transfer_rates<R>(c, gm, jl, layer_depth, tan_diffuse_angle_3d, el, rate_diffuse);
-          transfer_rates<R>(c, gm, jl, layer_depth, tan_sza, el, rate_direct);
-          all3d = true;
-        }
-        nregactive = 3;
-        const size_t oc = ib + (size_t)nb * (jl + (size_t)nlev * cloc);
-        const R odc = R(a.op.od_sw_cloud[oc]), ssac = R(a.op.ssa_sw_cloud[oc]), gc = R(a.op.g_sw_cloud[oc]);
-        const R scat_od = odl * ssal;
-        R g_region[3] = {gl, R(0), R(0)};
-#pragma unroll
-        for (int jreg = 1; jreg < 3; ++jreg) {
-          const R ods = R(gm.ods(jreg, jl));
-          const R scat_od_cloud = odc * ssac * ods;
-          od_region[jreg] = odl + odc * ods;
-          ssa_region[jreg] = (scat_od + scat_od_cloud) / od_region[jreg];
-          g_region[jreg] = (scat_od * gl + scat_od_cloud * gc) / (scat_od + scat_od_cloud);
-          if (od_region[jreg] > R(c.max_cloud_od)) od_region[jreg] = R(c.max_cloud_od);
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) gammas_sw(mu0, ssa_region[r], g_region[r], gamma1[r], gamma2[r], gamma3[r]);
+      // -- section 3: clear-sky (region 1) two-stream coefficients in line; matrices of the listed layers from HBM --
+      SwLayer<R> cl{R(0), R(0), R(0), R(0), R(0)};
+      if (do_clear || !listed) {
+        const size_t o = g + (size_t)ng * (jl + (size_t)nlev * cloc);
+        const R odl = R(a.op.od_sw[o]), ssal = R(a.op.ssa_sw[o]), gl = R(a.op.g_sw ? a.op.g_sw[o] : 0.0);
+        R g1, g2, g3;
+        gammas_sw(mu0, ssal, gl, g1, g2, g3);
+        cl = ref_trans_sw<R>(mu0, odl, ssal, g1, g2, g3);
       }
-      if (clr && explicit_entr) layer_depth = layer_depth_of<R>(a.in, ord, col, jl);   // (step_migrations below the cloud top)
-      const bool is3d = all3d && glane < first;
-
       M3<R> refl, tran, rdir, tdd, tdir;
-      refl.zero(); tran.zero(); rdir.zero(); tdd.zero(); tdir.zero();
-      if (is3d) {               // 3.3a
-        R G[81];
+      if (listed) {
+        const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 45 * ng + g;
 #pragma unroll
-        for (int k = 0; k < 81; ++k) G[k] = R(0);
-#define GZ(r, cc) G[(r) + 9 * (cc)]
-#pragma unroll
-        for (int jreg = 0; jreg < 3; ++jreg) {
-          if (jreg >= nregactive) continue;
-          GZ(jreg, jreg) = od_region[jreg] * gamma1[jreg];
-          GZ(jreg + 3, jreg) = od_region[jreg] * gamma2[jreg];
-          GZ(jreg, jreg + 6) = -od_region[jreg] * ssa_region[jreg] * gamma3[jreg];
-          GZ(jreg + 3, jreg + 6) = od_region[jreg] * ssa_region[jreg] * (R(1) - gamma3[jreg]);
-          GZ(jreg + 6, jreg + 6) = -od_region[jreg] * one_over_mu0;
+        for (int k = 0; k < 9; ++k) {
+          refl.a[k] = lp[(size_t)k * ng]; tran.a[k] = lp[(size_t)(9 + k) * ng]; rdir.a[k] = lp[(size_t)(18 + k) * ng];
+          tdd.a[k] = lp[(size_t)(27 + k) * ng]; tdir.a[k] = lp[(size_t)(36 + k) * ng];
         }
-        if (nregactive == 3) {
-#pragma unroll
-          for (int jreg = 0; jreg < 2; ++jreg) {
-            GZ(jreg, jreg) = GZ(jreg, jreg) + rate_diffuse[jreg + 3 * (jreg + 1)];
-            GZ(jreg + 1, jreg + 1) = GZ(jreg + 1, jreg + 1) + rate_diffuse[(jreg + 1) + 3 * jreg];
-            GZ(jreg + 1, jreg) = -rate_diffuse[jreg + 3 * (jreg + 1)];
-            GZ(jreg, jreg + 1) = -rate_diffuse[(jreg + 1) + 3 * jreg];
-            GZ(jreg + 6, jreg + 6) = GZ(jreg + 6, jreg + 6) - rate_direct[jreg + 3 * (jreg + 1)];
-            GZ(jreg + 7, jreg + 7) = GZ(jreg + 7, jreg + 7) - rate_direct[(jreg + 1) + 3 * jreg];
-            GZ(jreg + 7, jreg + 6) = rate_direct[jreg + 3 * (jreg + 1)];
-            GZ(jreg + 6, jreg + 7) = rate_direct[(jreg + 1) + 3 * jreg];
-          }
-        }
-        if (el[2] > R(0)) {
-          GZ(0, 0) = GZ(0, 0) + rate_diffuse[0 + 3 * 2];
-          GZ(2, 2) = GZ(2, 2) + rate_diffuse[2 + 3 * 0];
-          GZ(2, 0) = -rate_diffuse[0 + 3 * 2];
-          GZ(0, 2) = -rate_diffuse[2 + 3 * 0];
-          GZ(6, 6) = GZ(6, 6) - rate_direct[0 + 3 * 2];
-          GZ(8, 8) = GZ(8, 8) - rate_direct[2 + 3 * 0];
-          GZ(8, 6) = rate_direct[0 + 3 * 2];
-          GZ(6, 8) = rate_direct[2 + 3 * 0];
-        }
-        // (the reference copies the top-left block over nregactive rows and columns only; the rest is zero anyway)
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-          for (int r = 0; r < 3; ++r) GZ(3 + r, 3 + cc) = -GZ(r, cc);
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-          for (int r = 0; r < 3; ++r) GZ(r, 3 + cc) = -GZ(3 + r, cc);
-#undef GZ
-        sp::expm<R, 9, true>(G);
-        tdir = clamp(block<R, 9>(G, 6, 6), R(0), R(1), R(1));
-        const sp::Lu3<R> f1 = sp::lu3(block<R, 9>(G, 0, 0));
-        refl = clamp(sp::solve(f1, block<R, 9>(G, 0, 3)), R(0), R(1), R(-1));
-        const M3<R> sub3 = block<R, 9>(G, 3, 0);
-        tran = clamp(add(sp::mul(sub3, refl), block<R, 9>(G, 3, 3)), R(0), R(1), R(1));
-        rdir = clamp(sp::solve(f1, block<R, 9>(G, 0, 6)), R(0), mu0, R(-1));
-        tdd = clamp(add(sp::mul(sub3, rdir), block<R, 9>(G, 3, 6)), R(0), mu0, R(1));
+      } else {
+        refl = diag_only(cl.ref_diff); tran = diag_only(cl.trans_diff); rdir = diag_only(cl.ref_dir);
+        tdd = diag_only(cl.trans_dir_diff); tdir = diag_only(cl.trans_dir_dir);
       }
-      // 3.3b: clear-sky coefficients (always), and the diagonal of the regions for g-points without 3-D effects
-      const SwLayer<R> cl = ref_trans_sw<R>(mu0, od_region[0], ssa_region[0], gamma1[0], gamma2[0], gamma3[0]);
-      if (!is3d) {
-        refl(0, 0) = cl.ref_diff; tran(0, 0) = cl.trans_diff; rdir(0, 0) = cl.ref_dir; tdd(0, 0) = cl.trans_dir_diff; tdir(0, 0) = cl.trans_dir_dir;
-        if (nregactive == 3) {
-#pragma unroll
-          for (int jreg = 1; jreg < 3; ++jreg) {
-            const SwLayer<R> r = ref_trans_sw<R>(mu0, od_region[jreg], ssa_region[jreg], gamma1[jreg], gamma2[jreg], gamma3[jreg]);
-            refl(jreg, jreg) = r.ref_diff; tran(jreg, jreg) = r.trans_diff; rdir(jreg, jreg) = r.ref_dir;
-            tdd(jreg, jreg) = r.trans_dir_diff; tdir(jreg, jreg) = r.trans_dir_dir;
-          }
-        }
-      }
+      R layer_depth = R(0);
+      if (explicit_entr && jlev >= i_cloud_top) layer_depth = layer_depth_of<R>(a.in, ord, col, jl);
 
       // -- what the flux sweep needs of this layer and of the half level below it --
       if (do_clear) {
@@ -527,8 +576,7 @@ __global__ __launch_bounds__(kBlock, 1) void spartacus_sw_kernel(SpArgs args_in_
         slab.put(jl, SW_REFL + 0, tid, refl(0, 0)); slab.put(jl, SW_REFL + 1, tid, tran(0, 0)); slab.put(jl, SW_REFL + 2, tid, tdd(0, 0));
         slab.put(jl, SW_REFL + 3, tid, tdir(0, 0)); slab.put(jl, SW_REFL + 4, tid, ta(0, 0)); slab.put(jl, SW_REFL + 5, tid, tad(0, 0));
       } else {
-        slab.put(jl, SW_REFL, tid, refl); slab.put(jl, SW_TRAN, tid, tran); slab.put(jl, SW_TDD, tid, tdd); slab.put(jl, SW_TDIR, tid, tdir);
-        slab.put(jl, SW_TA, tid, ta); slab.put(jl, SW_TAD, tid, tad);
+        slab.put(jl, SW_TA, tid, ta); slab.put(jl, SW_TAD, tid, tad);     // (the layer's own matrices stay in the layer store)
       }
 
       // -- section 4.1: adding method --
@@ -694,7 +742,11 @@ __global__ __launch_bounds__(kBlock, 1) void spartacus_sw_kernel(SpArgs args_in_
           flux_up_above.a[0] = tad1 * direct_dn_above.a[0] + ta1 * flux_dn_above.a[0];
         } else {
           M3<R> refl, tran, tdd, tdir, ta1, tad1;
-          slab.get(jl, SW_REFL, tid, refl); slab.get(jl, SW_TRAN, tid, tran); slab.get(jl, SW_TDD, tid, tdd); slab.get(jl, SW_TDIR, tid, tdir);
+          const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 45 * ng + g;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            refl.a[k] = lp[(size_t)k * ng]; tran.a[k] = lp[(size_t)(9 + k) * ng]; tdd.a[k] = lp[(size_t)(27 + k) * ng]; tdir.a[k] = lp[(size_t)(36 + k) * ng];
+          }
           slab.get(jl, SW_TA, tid, ta1); slab.get(jl, SW_TAD, tid, tad1);
           const V3<R> source_dn = sp::mul(tdd, direct_dn_below);
           direct_dn_above = sp::mul(tdir, direct_dn_below);
@@ -753,17 +805,191 @@ __global__ __launch_bounds__(kBlock, 1) void spartacus_sw_kernel(SpArgs args_in_
   }
 }
 
+// ---- section 3 of one listed layer and one g-point: radiation_spartacus_lw.F90:339-760 --------------------------
+template <typename R> struct LwMats { M3<R> refl, tran; V3<R> source_up, source_dn; };
+
+template <typename R, int NGP>
+ECRAD_DEV LwMats<R> lw_layer(const SpArgs& a, const Geo& gm, const LevelOrder& ord, int col, int cloc, int jl, int g, int ib, int glane,
+                             int tid, bool valid, bool clr) {
+  const SpConfig& c = a.c;
+  const DevInputs& in = a.in;
+  const int ng = c.ng, nb = c.nb, nlev = in.nlev;
+  const size_t ncol = in.ncol;
+  const R side_emiss_thin = R(1.4107), LwDiff = R(kLwDiffusivity);
+  R dz = R(1);
+    const size_t o = g + (size_t)ng * (jl + (size_t)nlev * cloc);
+    const size_t op = g + (size_t)ng * (jl + (size_t)(nlev + 1) * cloc);
+    R od_region[3] = {R(a.op.od_lw[o]), R(0), R(0)}, ssa_region[3] = {R(0), R(0), R(0)}, g_region[3] = {R(0), R(0), R(0)};
+    if (c.do_lw_aerosol_scattering) { ssa_region[0] = R(a.op.ssa_lw[o]); g_region[0] = R(a.op.g_lw[o]); }
+    const R pt = R(a.op.planck_hl[op]), pb = R(a.op.planck_hl[op + ng]);
+    const int first = first_exceeding<NGP>(valid && od_region[0] > R(c.max_gas_od_3d), tid);
+    R gamma1[3] = {R(0), R(0), R(0)}, gamma2[3] = {R(0), R(0), R(0)};
+    R rate[9], el[3] = {R(0), R(0), R(0)};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rate[k] = R(0);
+    R rf[3] = {R(gm.rf(0, jl)), R(0), R(0)};
+    int nregactive = 1;
+    bool all3d = c.use_expm_everywhere != 0;
+    bool side_ok = false;
+    R ics_here = R(0);
+    if (clr) {
+      gammas_lw(ssa_region[0], g_region[0], gamma1[0], gamma2[0]);
+    } else {
+      rf[1] = R(gm.rf(1, jl)); rf[2] = R(gm.rf(2, jl));
+      if (edge_lengths<R>(c, in, ord, gm, col, jl, el)) {
+        dz = layer_depth_of<R>(in, ord, col, jl);
+        transfer_rates<R>(c, gm, jl, dz, R(kPi * 0.5), el, rate);
+        all3d = true;
+        ics_here = R(in.cloud_inv_cloud_effective_size[col + ncol * ord.full(jl)]);
+        side_ok = c.do_lw_side_emissivity && rf[0] > R(0) && rf[1] > R(0);
+      }
+      nregactive = 3;
+      const size_t oc = ib + (size_t)nb * (jl + (size_t)nlev * cloc);
+      const R odc = R(a.op.od_lw_cloud[oc]);
+      const R scat_od = od_region[0] * ssa_region[0];
+#pragma unroll
+      for (int jreg = 1; jreg < 3; ++jreg) {
+        const R ods = R(gm.ods(jreg, jl));
+        od_region[jreg] = od_region[0] + odc * ods;
+        if (c.do_lw_cloud_scattering) {
+          const R scat_od_cloud = odc * R(a.op.ssa_lw_cloud[oc]) * ods;
+          ssa_region[jreg] = (scat_od + scat_od_cloud) / od_region[jreg];
+          if (scat_od + scat_od_cloud > R(0)) g_region[jreg] = (scat_od * g_region[0] + scat_od_cloud * R(a.op.g_lw_cloud[oc])) / (scat_od + scat_od_cloud);
+        }
+        if (od_region[jreg] > R(c.max_cloud_od)) od_region[jreg] = R(c.max_cloud_od);
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) gammas_lw(ssa_region[r], g_region[r], gamma1[r], gamma2[r]);
+    }
+    const bool is3d = all3d && glane < first;
+
+    M3<R> refl, tran;
+    V3<R> source_up, source_dn;
+    refl.zero(); tran.zero(); source_up.zero(); source_dn.zero();
+    if (is3d) {               // 3.3a
+      R G[36], planck_top[6], planck_diff[6];
+#pragma unroll
+      for (int k = 0; k < 36; ++k) G[k] = R(0);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { planck_top[k] = R(0); planck_diff[k] = R(0); }
+#define GZ(r, cc) G[(r) + 6 * (cc)]
+#pragma unroll
+      for (int jreg = 0; jreg < 3; ++jreg) {
+        if (jreg >= nregactive) continue;
+        GZ(jreg, jreg) = od_region[jreg] * gamma1[jreg];
+        GZ(jreg + 3, jreg) = od_region[jreg] * gamma2[jreg];
+        planck_top[3 + jreg] = od_region[jreg] * (R(1) - ssa_region[jreg]) * rf[jreg] * pt * LwDiff;
+        planck_top[jreg] = -planck_top[3 + jreg];
+        planck_diff[3 + jreg] = od_region[jreg] * (R(1) - ssa_region[jreg]) * rf[jreg] * (pb - pt) * LwDiff;
+        planck_diff[jreg] = -planck_diff[3 + jreg];
+      }
+      if (nregactive < 3) {
+#pragma unroll
+        for (int jreg = 1; jreg < 3; ++jreg) { GZ(jreg, jreg) = GZ(0, 0); GZ(3 + jreg, jreg) = GZ(3, 0); }
+      }
+      R side_emiss = R(1);
+      if (side_ok) {        // :558-586
+        const R aspect_ratio = R(1) / (rmin(ics_here, R(1) / R(c.min_cloud_effective_size)) * rf[0] * dz);
+        const R s = od_region[1] * (R(1) - ssa_region[1]) + od_region[2] * (R(1) - ssa_region[2]);
+        const R lateral_od = (aspect_ratio / (R(3) - R(1))) * s;
+        const R sqrt_1_minus_ssa = sp::sp_sqrt(R(1) - ssa_region[1]);
+        const R side_emiss_thick = R(2) * sqrt_1_minus_ssa / (sqrt_1_minus_ssa + sp::sp_sqrt(R(1) - ssa_region[1] * g_region[1]));
+        side_emiss = (side_emiss_thin - side_emiss_thick) / (lateral_od + R(1)) + side_emiss_thick;
+      }
+      if (nregactive == 3) {
+#pragma unroll
+        for (int jreg = 0; jreg < 2; ++jreg) {
+          GZ(jreg, jreg) = GZ(jreg, jreg) + rate[jreg + 3 * (jreg + 1)];
+          GZ(jreg + 1, jreg) = -rate[jreg + 3 * (jreg + 1)];
+          const R se = jreg > 0 ? R(1) : side_emiss;
+          if (jreg > 0) {
+            GZ(jreg + 1, jreg + 1) = GZ(jreg + 1, jreg + 1) + rate[(jreg + 1) + 3 * jreg];
+            GZ(jreg, jreg + 1) = -rate[(jreg + 1) + 3 * jreg];
+          } else {
+            GZ(jreg + 1, jreg + 1) = GZ(jreg + 1, jreg + 1) + se * rate[(jreg + 1) + 3 * jreg];
+            GZ(jreg, jreg + 1) = -se * rate[(jreg + 1) + 3 * jreg];
+          }
+        }
+      }
+      if (el[2] > R(0)) {
+        GZ(0, 0) = GZ(0, 0) + rate[0 + 3 * 2];
+        GZ(2, 0) = -rate[0 + 3 * 2];
+        GZ(2, 2) = GZ(2, 2) + side_emiss * rate[2 + 3 * 0];
+        GZ(0, 2) = -side_emiss * rate[2 + 3 * 0];
+      }
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) GZ(3 + r, 3 + cc) = -GZ(r, cc);
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) GZ(r, 3 + cc) = -GZ(3 + r, cc);
+#undef GZ
+      // particular solution: two solves with the same matrix, so one LU factorisation
+      R solution_diff[6], solution0[6];
+      {
+        R LU[36];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) LU[k] = G[k];
+        sp::lu_factor<R, 6, false>(LU);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) solution_diff[k] = planck_diff[k];
+        sp::lu_subst<R, 6, false>(LU, solution_diff);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) solution_diff[k] = -solution_diff[k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) solution0[k] = solution_diff[k] - planck_top[k];
+        sp::lu_subst<R, 6, false>(LU, solution0);
+      }
+      sp::expm<R, 6, false>(G);
+      const M3<R> sub1 = block<R, 6>(G, 0, 0), sub2 = block<R, 6>(G, 0, 3), sub3 = block<R, 6>(G, 3, 0), sub4 = block<R, 6>(G, 3, 3);
+      const sp::Lu3<R> f1 = sp::lu3(sub1);
+      refl = neg(sp::solve(f1, sub2));
+      tran = add(sp::mul(sub3, refl), sub4);
+      const V3<R> s0_lo{{solution0[0], solution0[1], solution0[2]}}, s0_hi{{solution0[3], solution0[4], solution0[5]}};
+      V3<R> v1 = sp::mul(sub2, s0_hi), tmp;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) tmp.a[r] = s0_lo.a[r] + solution_diff[r] - v1.a[r];
+      v1 = sp::solve(f1, tmp);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) source_up.a[r] = s0_lo.a[r] - v1.a[r];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) tmp.a[r] = source_up.a[r] - s0_lo.a[r];
+      v1 = sp::mul(sub3, tmp);
+      const V3<R> v2 = sp::mul(sub4, s0_hi);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) source_dn.a[r] = v1.a[r] + s0_hi.a[r] - v2.a[r] + solution_diff[3 + r];
+    }
+    // 3.3b
+    const LwLayer<R> cl = ref_trans_lw<R>(od_region[0], gamma1[0], gamma2[0], pt, pb);
+    if (!is3d) {
+      refl(0, 0) = cl.reflectance; tran(0, 0) = cl.transmittance;
+      source_up.a[0] = rf[0] * cl.source_up; source_dn.a[0] = rf[0] * cl.source_dn;
+      if (nregactive == 3) {
+#pragma unroll
+        for (int jreg = 1; jreg < 3; ++jreg) {
+          const LwLayer<R> r = ref_trans_lw<R>(od_region[jreg], gamma1[jreg], gamma2[jreg], rf[jreg] * pt, rf[jreg] * pb);
+          refl(jreg, jreg) = r.reflectance; tran(jreg, jreg) = r.transmittance; source_up.a[jreg] = r.source_up; source_dn.a[jreg] = r.source_dn;
+        }
+      }
+    }
+
+  return {refl, tran, source_up, source_dn};
+}
+
 // =====================================================================================================================
 //  solver_spartacus_lw
 // =====================================================================================================================
 namespace {
 enum { LW_REFC = 0, LW_TRAC, LW_SDNC, LW_TAC, LW_TSC,                 // clear-sky scalars
-       LW_REFL = 5, LW_TRAN = 14, LW_SDN = 23, LW_TA = 26, LW_TS = 35, LW_NSLOT = 38 };
-// (a clear layer stores (0,0) elements only: refl, tran, source_dn, ta, ts in slots LW_REFL .. LW_REFL+4)
+       LW_REFL = 5, LW_TA = 5, LW_TS = 14, LW_NSLOT = 17 };
+// (a clear layer stores (0,0) elements only: refl, tran, source_dn, ta, ts in slots LW_REFL .. LW_REFL+4; a listed one the
+//  albedo matrix and the source vector, its own matrices being in the layer store)
 }
 
 template <typename R, int NGP>
-__global__ __launch_bounds__(kBlock, 1) void spartacus_lw_kernel(SpArgs args_in_kernarg) {
+__global__ __launch_bounds__(kBlock, 2) void spartacus_lw_kernel(SpArgs args_in_kernarg) {
   __shared__ int next_group;
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
@@ -810,168 +1036,34 @@ __global__ __launch_bounds__(kBlock, 1) void spartacus_lw_kernel(SpArgs args_in_
 #pragma unroll
     for (int r = 0; r < 3; ++r) { ta(r, r) = alb; ts.a[r] = R(gm.rf(r, nlev - 1)) * emis; }
     R ta_clear = alb, ts_clear = emis;
-    R dz = R(1);
-
     for (int jlev = nlev; jlev >= 1; --jlev) {
       const int jl = jlev - 1;
       const bool clr = !cm.test(jl);
       const bool clr_above = jl == 0 || !cm.test(jl - 1);
-      const size_t o = g + (size_t)ng * (jl + (size_t)nlev * cloc);
-      const size_t op = g + (size_t)ng * (jl + (size_t)(nlev + 1) * cloc);
-      R od_region[3] = {R(a.op.od_lw[o]), R(0), R(0)}, ssa_region[3] = {R(0), R(0), R(0)}, g_region[3] = {R(0), R(0), R(0)};
-      if (c.do_lw_aerosol_scattering) { ssa_region[0] = R(a.op.ssa_lw[o]); g_region[0] = R(a.op.g_lw[o]); }
-      const R pt = R(a.op.planck_hl[op]), pb = R(a.op.planck_hl[op + ng]);
-      const int first = first_exceeding<NGP>(valid && od_region[0] > R(c.max_gas_od_3d), tid);
-      R gamma1[3] = {R(0), R(0), R(0)}, gamma2[3] = {R(0), R(0), R(0)};
-      R rate[9], el[3] = {R(0), R(0), R(0)};
-#pragma unroll
-      for (int k = 0; k < 9; ++k) rate[k] = R(0);
-      R rf[3] = {R(gm.rf(0, jl)), R(0), R(0)};
-      int nregactive = 1;
-      bool all3d = c.use_expm_everywhere != 0;
-      bool side_ok = false;
-      R ics_here = R(0);
-      if (clr) {
-        gammas_lw(ssa_region[0], g_region[0], gamma1[0], gamma2[0]);
-      } else {
-        rf[1] = R(gm.rf(1, jl)); rf[2] = R(gm.rf(2, jl));
-        if (edge_lengths<R>(c, a.in, ord, gm, col, jl, el)) {
-          dz = layer_depth_of<R>(a.in, ord, col, jl);
-          transfer_rates<R>(c, gm, jl, dz, R(kPi * 0.5), el, rate);
-          all3d = true;
-          ics_here = R(a.in.cloud_inv_cloud_effective_size[col + ncol * ord.full(jl)]);
-          side_ok = c.do_lw_side_emissivity && rf[0] > R(0) && rf[1] > R(0);
-        }
-        nregactive = 3;
-        const size_t oc = ib + (size_t)nb * (jl + (size_t)nlev * cloc);
-        const R odc = R(a.op.od_lw_cloud[oc]);
-        const R scat_od = od_region[0] * ssa_region[0];
-#pragma unroll
-        for (int jreg = 1; jreg < 3; ++jreg) {
-          const R ods = R(gm.ods(jreg, jl));
-          od_region[jreg] = od_region[0] + odc * ods;
-          if (c.do_lw_cloud_scattering) {
-            const R scat_od_cloud = odc * R(a.op.ssa_lw_cloud[oc]) * ods;
-            ssa_region[jreg] = (scat_od + scat_od_cloud) / od_region[jreg];
-            if (scat_od + scat_od_cloud > R(0)) g_region[jreg] = (scat_od * g_region[0] + scat_od_cloud * R(a.op.g_lw_cloud[oc])) / (scat_od + scat_od_cloud);
-          }
-          if (od_region[jreg] > R(c.max_cloud_od)) od_region[jreg] = R(c.max_cloud_od);
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) gammas_lw(ssa_region[r], g_region[r], gamma1[r], gamma2[r]);
+      const bool listed = !clr || c.use_expm_everywhere != 0;      // its matrices come from spartacus_layers_kernel
+      // -- section 3: clear-sky (region 1) two-stream coefficients in line; matrices of the listed layers from HBM --
+      LwLayer<R> cl{R(0), R(0), R(0), R(0)};
+      if (do_clear || !listed) {
+        const size_t o = g + (size_t)ng * (jl + (size_t)nlev * cloc);
+        const size_t op = g + (size_t)ng * (jl + (size_t)(nlev + 1) * cloc);
+        R ssa0 = R(0), g0 = R(0), g1, g2;
+        if (c.do_lw_aerosol_scattering) { ssa0 = R(a.op.ssa_lw[o]); g0 = R(a.op.g_lw[o]); }
+        gammas_lw(ssa0, g0, g1, g2);
+        cl = ref_trans_lw<R>(R(a.op.od_lw[o]), g1, g2, R(a.op.planck_hl[op]), R(a.op.planck_hl[op + ng]));
       }
-      const bool is3d = all3d && glane < first;
-
       M3<R> refl, tran;
       V3<R> source_up, source_dn;
-      refl.zero(); tran.zero(); source_up.zero(); source_dn.zero();
-      if (is3d) {               // 3.3a
-        R G[36], planck_top[6], planck_diff[6];
+      if (listed) {
+        const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ng + g;
 #pragma unroll
-        for (int k = 0; k < 36; ++k) G[k] = R(0);
+        for (int k = 0; k < 9; ++k) { refl.a[k] = lp[(size_t)k * ng]; tran.a[k] = lp[(size_t)(9 + k) * ng]; }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { planck_top[k] = R(0); planck_diff[k] = R(0); }
-#define GZ(r, cc) G[(r) + 6 * (cc)]
-#pragma unroll
-        for (int jreg = 0; jreg < 3; ++jreg) {
-          if (jreg >= nregactive) continue;
-          GZ(jreg, jreg) = od_region[jreg] * gamma1[jreg];
-          GZ(jreg + 3, jreg) = od_region[jreg] * gamma2[jreg];
-          planck_top[3 + jreg] = od_region[jreg] * (R(1) - ssa_region[jreg]) * rf[jreg] * pt * LwDiff;
-          planck_top[jreg] = -planck_top[3 + jreg];
-          planck_diff[3 + jreg] = od_region[jreg] * (R(1) - ssa_region[jreg]) * rf[jreg] * (pb - pt) * LwDiff;
-          planck_diff[jreg] = -planck_diff[3 + jreg];
-        }
-        if (nregactive < 3) {
-#pragma unroll
-          for (int jreg = 1; jreg < 3; ++jreg) { GZ(jreg, jreg) = GZ(0, 0); GZ(3 + jreg, jreg) = GZ(3, 0); }
-        }
-        R side_emiss = R(1);
-        if (side_ok) {        // :558-586
-          const R aspect_ratio = R(1) / (rmin(ics_here, R(1) / R(c.min_cloud_effective_size)) * rf[0] * dz);
-          const R s = od_region[1] * (R(1) - ssa_region[1]) + od_region[2] * (R(1) - ssa_region[2]);
-          const R lateral_od = (aspect_ratio / (R(3) - R(1))) * s;
-          const R sqrt_1_minus_ssa = sp::sp_sqrt(R(1) - ssa_region[1]);
-          const R side_emiss_thick = R(2) * sqrt_1_minus_ssa / (sqrt_1_minus_ssa + sp::sp_sqrt(R(1) - ssa_region[1] * g_region[1]));
-          side_emiss = (side_emiss_thin - side_emiss_thick) / (lateral_od + R(1)) + side_emiss_thick;
-        }
-        if (nregactive == 3) {
-#pragma unroll
-          for (int jreg = 0; jreg < 2; ++jreg) {
-            GZ(jreg, jreg) = GZ(jreg, jreg) + rate[jreg + 3 * (jreg + 1)];
-            GZ(jreg + 1, jreg) = -rate[jreg + 3 * (jreg + 1)];
-            const R se = jreg > 0 ? R(1) : side_emiss;
-            if (jreg > 0) {
-              GZ(jreg + 1, jreg + 1) = GZ(jreg + 1, jreg + 1) + rate[(jreg + 1) + 3 * jreg];
-              GZ(jreg, jreg + 1) = -rate[(jreg + 1) + 3 * jreg];
-            } else {
-              GZ(jreg + 1, jreg + 1) = GZ(jreg + 1, jreg + 1) + se * rate[(jreg + 1) + 3 * jreg];
-              GZ(jreg, jreg + 1) = -se * rate[(jreg + 1) + 3 * jreg];
-            }
-          }
-        }
-        if (el[2] > R(0)) {
-          GZ(0, 0) = GZ(0, 0) + rate[0 + 3 * 2];
-          GZ(2, 0) = -rate[0 + 3 * 2];
-          GZ(2, 2) = GZ(2, 2) + side_emiss * rate[2 + 3 * 0];
-          GZ(0, 2) = -side_emiss * rate[2 + 3 * 0];
-        }
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-          for (int r = 0; r < 3; ++r) GZ(3 + r, 3 + cc) = -GZ(r, cc);
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-          for (int r = 0; r < 3; ++r) GZ(r, 3 + cc) = -GZ(3 + r, cc);
-#undef GZ
-        // particular solution: two solves with the same matrix, so one LU factorisation
-        R solution_diff[6], solution0[6];
-        {
-          R LU[36];
-#pragma unroll
-          for (int k = 0; k < 36; ++k) LU[k] = G[k];
-          sp::lu_factor<R, 6, false>(LU);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) solution_diff[k] = planck_diff[k];
-          sp::lu_subst<R, 6, false>(LU, solution_diff);
-#pragma unroll
-          for (int k = 0; k < 6; ++k) solution_diff[k] = -solution_diff[k];
-#pragma unroll
-          for (int k = 0; k < 6; ++k) solution0[k] = solution_diff[k] - planck_top[k];
-          sp::lu_subst<R, 6, false>(LU, solution0);
-        }
-        sp::expm<R, 6, false>(G);
-        const M3<R> sub1 = block<R, 6>(G, 0, 0), sub2 = block<R, 6>(G, 0, 3), sub3 = block<R, 6>(G, 3, 0), sub4 = block<R, 6>(G, 3, 3);
-        const sp::Lu3<R> f1 = sp::lu3(sub1);
-        refl = neg(sp::solve(f1, sub2));
-        tran = add(sp::mul(sub3, refl), sub4);
-        const V3<R> s0_lo{{solution0[0], solution0[1], solution0[2]}}, s0_hi{{solution0[3], solution0[4], solution0[5]}};
-        V3<R> v1 = sp::mul(sub2, s0_hi), tmp;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) tmp.a[r] = s0_lo.a[r] + solution_diff[r] - v1.a[r];
-        v1 = sp::solve(f1, tmp);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) source_up.a[r] = s0_lo.a[r] - v1.a[r];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) tmp.a[r] = source_up.a[r] - s0_lo.a[r];
-        v1 = sp::mul(sub3, tmp);
-        const V3<R> v2 = sp::mul(sub4, s0_hi);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) source_dn.a[r] = v1.a[r] + s0_hi.a[r] - v2.a[r] + solution_diff[3 + r];
-      }
-      // 3.3b
-      const LwLayer<R> cl = ref_trans_lw<R>(od_region[0], gamma1[0], gamma2[0], pt, pb);
-      if (!is3d) {
-        refl(0, 0) = cl.reflectance; tran(0, 0) = cl.transmittance;
-        source_up.a[0] = rf[0] * cl.source_up; source_dn.a[0] = rf[0] * cl.source_dn;
-        if (nregactive == 3) {
-#pragma unroll
-          for (int jreg = 1; jreg < 3; ++jreg) {
-            const LwLayer<R> r = ref_trans_lw<R>(od_region[jreg], gamma1[jreg], gamma2[jreg], rf[jreg] * pt, rf[jreg] * pb);
-            refl(jreg, jreg) = r.reflectance; tran(jreg, jreg) = r.transmittance; source_up.a[jreg] = r.source_up; source_dn.a[jreg] = r.source_dn;
-          }
-        }
+        for (int k = 0; k < 3; ++k) { source_up.a[k] = lp[(size_t)(18 + k) * ng]; source_dn.a[k] = lp[(size_t)(21 + k) * ng]; }
+      } else {
+        const R rf0 = R(gm.rf(0, jl));
+        refl = diag_only(cl.reflectance); tran = diag_only(cl.transmittance);
+        source_up.zero(); source_dn.zero();
+        source_up.a[0] = rf0 * cl.source_up; source_dn.a[0] = rf0 * cl.source_dn;
       }
 
       // -- what the flux sweep (and the derivatives) need --
@@ -983,8 +1075,7 @@ __global__ __launch_bounds__(kBlock, 1) void spartacus_lw_kernel(SpArgs args_in_
         slab.put(jl, LW_REFL + 0, tid, refl(0, 0)); slab.put(jl, LW_REFL + 1, tid, tran(0, 0)); slab.put(jl, LW_REFL + 2, tid, source_dn.a[0]);
         slab.put(jl, LW_REFL + 3, tid, ta(0, 0)); slab.put(jl, LW_REFL + 4, tid, ts.a[0]);
       } else {
-        slab.put(jl, LW_REFL, tid, refl); slab.put(jl, LW_TRAN, tid, tran); slab.put(jl, LW_SDN, tid, source_dn);
-        slab.put(jl, LW_TA, tid, ta); slab.put(jl, LW_TS, tid, ts);
+        slab.put(jl, LW_TA, tid, ta); slab.put(jl, LW_TS, tid, ts);       // (the layer's own matrices stay in the layer store)
       }
 
       // -- section 4 --
@@ -1067,7 +1158,11 @@ __global__ __launch_bounds__(kBlock, 1) void spartacus_lw_kernel(SpArgs args_in_
       } else {
         M3<R> refl, tran, ta1;
         V3<R> sdn, ts1;
-        slab.get(jl, LW_REFL, tid, refl); slab.get(jl, LW_TRAN, tid, tran); slab.get(jl, LW_SDN, tid, sdn);
+        const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ng + g;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { refl.a[k] = lp[(size_t)k * ng]; tran.a[k] = lp[(size_t)(9 + k) * ng]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sdn.a[k] = lp[(size_t)(21 + k) * ng];
         slab.get(jl, LW_TA, tid, ta1); slab.get(jl, LW_TS, tid, ts1);
         if (matrix_adding) {
           const V3<R> rhs = add(add(sp::mul(tran, flux_dn_below), sp::mul(refl, ts1)), sdn);
@@ -1112,14 +1207,16 @@ __global__ __launch_bounds__(kBlock, 1) void spartacus_lw_kernel(SpArgs args_in_
         R um[9];
         gm.u(jlev, um);
         const V3<R> v1 = sp::smul(um, lwd);
-        if (!cm.test(jl)) {
+        if (cm.test(jl) == false && !c.use_expm_everywhere) {
           // (a clear layer stores its (0,0) transmittance only: the other elements are zero)
           const R t00 = slab.get(jl, LW_REFL + 1, tid);
           lwd.zero();
           lwd.a[0] = t00 * v1.a[0];
         } else {
           M3<R> tran;
-          slab.get(jl, LW_TRAN, tid, tran);
+          const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ng + g;
+#pragma unroll
+          for (int k = 0; k < 9; ++k) tran.a[k] = lp[(size_t)(9 + k) * ng];
           lwd = sp::mul(tran, v1);
         }
         put_sum<NGP>(fx.lw_derivatives, col + ncol * ord.half(jlev - 1), (double)lwd.sum(), valid, lead);
@@ -1128,12 +1225,107 @@ __global__ __launch_bounds__(kBlock, 1) void spartacus_lw_kernel(SpArgs args_in_
   }
 }
 
+
+// =====================================================================================================================
+//  work list and layer matrices
+// =====================================================================================================================
+// One lane per column: the column's listed layers (cloudy ones; all with use_expm_everywhere) are appended to the work
+// list, the space for a wave's columns being reserved by ONE atomic (prefix sum over the wave).
+__global__ void spartacus_list_kernel(DevInputs in, int list_all, uint32_t* __restrict__ list, int* __restrict__ n_items) {
+  const int nloc = in.iendcol - in.istartcol + 1;
+  const int cloc_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool ok = cloc_raw < nloc;
+  const int cloc = ok ? cloc_raw : nloc - 1;
+  const int col = in.istartcol - 1 + cloc;
+  const int nlev = in.nlev;
+  const LevelOrder ord = level_order(in);
+  const FracView fracv = cloud_fraction_view(in, col);
+  int n = 0;
+  if (ok)
+    for (int jl = 0; jl < nlev; ++jl) n += (list_all || fracv.p[fracv.stride * ord.full(jl)] > 0.0) ? 1 : 0;
+  // exclusive prefix over the wave
+  int incl = n;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(incl, d);
+    if ((int)(threadIdx.x & 63) >= d) incl += v;
+  }
+  const int total = __shfl(incl, 63);
+  int base = 0;
+  if ((threadIdx.x & 63) == 63) base = atomicAdd(n_items, total);
+  base = __shfl(base, 63);
+  int pos = base + incl - n;
+  if (ok)
+    for (int jl = 0; jl < nlev; ++jl)
+      if (list_all || fracv.p[fracv.stride * ord.full(jl)] > 0.0) list[pos++] = ((uint32_t)cloc << 8) | (uint32_t)jl;
+}
+
+// lane = g-point, 256/NGP listed layers per block; one wave per SIMD (the 9x9 exponential wants the whole register file)
+template <typename R, int NGP, bool IS_SW>
+__global__ __launch_bounds__(kBlock, 1) void spartacus_layers_kernel(SpArgs args_in_kernarg) {
+  constexpr int CPB = kBlock / NGP;
+  const int tid = threadIdx.x;
+  const int glane = tid % NGP, cib = tid / NGP;
+  const SpArgs& a = kernarg_block<SpArgs>();
+  const SpConfig& c = a.c;
+  const int ng = c.ng, nlev = a.in.nlev;
+  const int nloc = a.in.iendcol - a.in.istartcol + 1;
+  const int n = *a.n_items;
+  const int g = glane < ng ? glane : ng - 1;
+  const bool gvalid = glane < ng;
+  const int ib = c.i_band_from_reordered_g[g] - 1;
+  const LevelOrder ord = level_order(a.in);
+  const R min_mu0_3d = R(0.004625);
+  for (int it0 = blockIdx.x * CPB; it0 < n; it0 += gridDim.x * CPB) {
+    const int it = it0 + cib;
+    const bool ok = it < n;
+    const uint32_t e = a.list[ok ? it : n - 1];
+    const int cloc = (int)(e >> 8), jl = (int)(e & 255u);
+    const int col = a.in.istartcol - 1 + cloc;
+    const Geo gm{&kernarg_block<SpArgs>().prep, nlev, nloc, cloc};
+    const bool clr = !(gm.rf(0, jl) < 1.0);       // (a clear layer is listed only with use_expm_everywhere)
+    const bool valid = ok && gvalid;
+    if (IS_SW) {
+      const R mu0 = R(a.in.cos_sza[col]);
+      const bool sun_up = !(mu0 < R(1.0e-10));
+      const R mu0s = sun_up ? mu0 : R(1);          // (night-time columns are not stored)
+      const R one_over_mu0 = R(1) / mu0s;
+      R tan_sza;                                    // radiation_spartacus_sw.F90:395-405
+      if (mu0s < min_mu0_3d) tan_sza = sp::sp_sqrt(R(1) / (min_mu0_3d * min_mu0_3d) - R(1));
+      else if (one_over_mu0 > R(1)) tan_sza = sp::sp_sqrt(one_over_mu0 * one_over_mu0 - R(1) + R(c.overhead_sun_factor));
+      else tan_sza = sp::sp_sqrt(R(c.overhead_sun_factor));
+      const SwMats<R> m = sw_layer<R, NGP>(a, gm, ord, col, cloc, jl, g, ib, glane, tid, valid, clr, mu0s, tan_sza);
+      if (valid && sun_up) {
+        R* lp = reinterpret_cast<R*>(a.lay) + ((size_t)cloc * nlev + jl) * 45 * ng + g;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          lp[(size_t)k * ng] = m.refl.a[k]; lp[(size_t)(9 + k) * ng] = m.tran.a[k]; lp[(size_t)(18 + k) * ng] = m.rdir.a[k];
+          lp[(size_t)(27 + k) * ng] = m.tdd.a[k]; lp[(size_t)(36 + k) * ng] = m.tdir.a[k];
+        }
+      }
+    } else {
+      const LwMats<R> m = lw_layer<R, NGP>(a, gm, ord, col, cloc, jl, g, ib, glane, tid, valid, clr);
+      if (valid) {
+        R* lp = reinterpret_cast<R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ng + g;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { lp[(size_t)k * ng] = m.refl.a[k]; lp[(size_t)(9 + k) * ng] = m.tran.a[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { lp[(size_t)(18 + k) * ng] = m.source_up.a[k]; lp[(size_t)(21 + k) * ng] = m.source_dn.a[k]; }
+      }
+    }
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------
 size_t spartacus_scratch_words(bool is_sw, int nlev) { return (size_t)nlev * (is_sw ? SW_NSLOT : LW_NSLOT) * kBlock; }
+size_t spartacus_layer_words(bool is_sw, int ng) { return (size_t)(is_sw ? 45 : 24) * ng; }    // per (column, layer)
 
-hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, hipStream_t st, const ecrad_config_t& c, const DevInputs& in,
-                            const DevOptics& op, const DevCloudPrep& prep, const DevFlux& fx, void* scratch, size_t per_block_words,
-                            int* counter, const int32_t* d_i_band_from_reordered_g) {
+// `grid_layers` blocks for the list walk (one block per CU), `grid` for the sweeps; `lay`: spartacus_layer_words x nlev x
+// columns words of R; `list`: nlev x columns entries; `n_items`: one int, zeroed here
+hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, int grid_layers, hipStream_t st, const ecrad_config_t& c,
+                            const DevInputs& in, const DevOptics& op, const DevCloudPrep& prep, const DevFlux& fx, void* scratch,
+                            size_t per_block_words, int* counter, const int32_t* d_i_band_from_reordered_g, void* lay, uint32_t* list,
+                            int* n_items) {
   SpArgs a{};
   SpConfig& s = a.c;
   s.ng = is_sw ? c.n_g_sw : c.n_g_lw;
@@ -1148,9 +1340,16 @@ hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, hipStrea
   s.cloud_fraction_threshold = c.cloud_fraction_threshold;
   s.i_band_from_reordered_g = d_i_band_from_reordered_g;
   a.in = in; a.op = op; a.prep = prep; a.fx = fx; a.scratch = scratch; a.per_block = per_block_words; a.counter = counter;
-  const dim3 g(grid), b(kBlock);
-#define ECRAD_SP(R, N) do { if (is_sw) hipLaunchKernelGGL((spartacus_sw_kernel<R, N>), g, b, 0, st, a); \
-                            else hipLaunchKernelGGL((spartacus_lw_kernel<R, N>), g, b, 0, st, a); } while (0)
+  a.lay = lay; a.list = list; a.n_items = n_items;
+  hipError_t e = hipMemsetAsync(n_items, 0, sizeof(int), st);
+  if (e != hipSuccess) return e;
+  const int nloc = in.iendcol - in.istartcol + 1;
+  hipLaunchKernelGGL(spartacus_list_kernel, dim3((nloc + 255) / 256), dim3(256), 0, st, in, c.use_expm_everywhere, list, n_items);
+  const dim3 g(grid), gl(grid_layers), b(kBlock);
+#define ECRAD_SP(R, N) do { if (is_sw) { hipLaunchKernelGGL((spartacus_layers_kernel<R, N, true>), gl, b, 0, st, a);      \
+                                         hipLaunchKernelGGL((spartacus_sw_kernel<R, N>), g, b, 0, st, a); }                  \
+                            else { hipLaunchKernelGGL((spartacus_layers_kernel<R, N, false>), gl, b, 0, st, a);             \
+                                   hipLaunchKernelGGL((spartacus_lw_kernel<R, N>), g, b, 0, st, a); } } while (0)
   if (single) { if (ngp == 16) ECRAD_SP(float, 16); else if (ngp == 32) ECRAD_SP(float, 32); else ECRAD_SP(float, 64); }
   else { if (ngp == 16) ECRAD_SP(double, 16); else if (ngp == 32) ECRAD_SP(double, 32); else ECRAD_SP(double, 64); }
 #undef ECRAD_SP

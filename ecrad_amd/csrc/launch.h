@@ -57,11 +57,14 @@ hipError_t launch_spectral_post(hipStream_t st, const DevConfig* cfg, const DevI
 hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                               const DevConfig* cfg, const DevInputs& in, const DevOptics& out, int g0);
 
-// SPARTACUS solvers (kernel_spartacus.hip): words of working precision of block-private slab per block, and the launch
+// SPARTACUS solvers (kernel_spartacus.hip): words of working precision of block-private slab per block and of layer
+// matrices per (column, layer); the launch of one spectrum (work list, layer matrices, the two sweeps)
 size_t spartacus_scratch_words(bool is_sw, int nlev);
-hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, hipStream_t st, const ecrad_config_t& c, const DevInputs& in,
-                            const DevOptics& op, const DevCloudPrep& prep, const DevFlux& fx, void* scratch, size_t per_block_words,
-                            int* counter, const int32_t* d_i_band_from_reordered_g);
+size_t spartacus_layer_words(bool is_sw, int ng);
+hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, int grid_layers, hipStream_t st, const ecrad_config_t& c,
+                            const DevInputs& in, const DevOptics& op, const DevCloudPrep& prep, const DevFlux& fx, void* scratch,
+                            size_t per_block_words, int* counter, const int32_t* d_i_band_from_reordered_g, void* lay, uint32_t* list,
+                            int* n_items);
 
 // RRTMG gas optics (kernel_rrtmg.hip)
 namespace rrtmg { struct DevRrtmg; }
