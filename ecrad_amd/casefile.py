@@ -21,8 +21,13 @@ CONFIG_INT_FIELDS = [
     "do_canopy_fluxes_sw", "do_canopy_fluxes_lw", "use_canopy_full_spectrum_sw", "use_canopy_full_spectrum_lw",
     "do_nearest_spectral_sw_albedo", "do_nearest_spectral_lw_emiss", "n_g_sw", "n_g_lw", "n_bands_sw",
     "n_bands_lw", "n_canopy_bands_sw", "n_canopy_bands_lw", "n_cloud_types",
+    "use_general_cloud_optics", "i_liq_model", "i_ice_model", "do_fu_lw_ice_optics_bug", "n_g_lw_if_scattering",
+    "n_bands_lw_if_scattering", "nregions", "i_3d_sw_entrapment", "do_3d_effects", "do_3d_lw_multilayer_effects",
+    "do_lw_side_emissivity", "use_expm_everywhere",
 ]
-CONFIG_REAL_FIELDS = ["cloud_fraction_threshold", "cloud_mixing_ratio_threshold", "cloud_inhom_decorr_scaling"]
+CONFIG_REAL_FIELDS = ["cloud_fraction_threshold", "cloud_mixing_ratio_threshold", "cloud_inhom_decorr_scaling", "max_cloud_od",
+                      "min_gas_od_lw", "min_gas_od_sw", "max_3d_transfer_rate", "max_gas_od_3d", "min_cloud_effective_size",
+                      "overhang_factor", "clear_to_thick_fraction", "overhead_sun_factor"]
 
 
 def _rec(f, name, arr):
@@ -45,16 +50,22 @@ def _rec(f, name, arr):
 def write_case(path, config, ncol, nlev, single_level, thermodynamics, gas, cloud, aerosol, istartcol=1, iendcol=None):
     iendcol = iendcol or ncol
     with open(path, "wb") as f:
-        _rec(f, "config.ints", [int(getattr(config, k)) for k in CONFIG_INT_FIELDS])
-        _rec(f, "config.reals", [float(getattr(config, k)) for k in CONFIG_REAL_FIELDS])
+        _rec(f, "config.ints", [int(getattr(config, k, 0) or 0) for k in CONFIG_INT_FIELDS])
+        _rec(f, "config.reals", [float(getattr(config, k, 0.0) or 0.0) for k in CONFIG_REAL_FIELDS])
         if config.do_sw:
             _rec(f, "config.i_band_from_reordered_g_sw", config.i_band_from_reordered_g_sw)
-            _rec(f, "config.sw_albedo_weights", config.sw_albedo_weights)
+            if getattr(config, "sw_albedo_weights", None) is not None:
+                _rec(f, "config.sw_albedo_weights", config.sw_albedo_weights)
+            if getattr(config, "i_albedo_from_band_sw", None) is not None:
+                _rec(f, "config.i_albedo_from_band_sw", config.i_albedo_from_band_sw)
         if config.do_lw:
             _rec(f, "config.i_band_from_reordered_g_lw", config.i_band_from_reordered_g_lw)
-            _rec(f, "config.lw_emiss_weights", config.lw_emiss_weights)
+            if getattr(config, "lw_emiss_weights", None) is not None:
+                _rec(f, "config.lw_emiss_weights", config.lw_emiss_weights)
+            if getattr(config, "i_emiss_from_band_lw", None) is not None:
+                _rec(f, "config.i_emiss_from_band_lw", config.i_emiss_from_band_lw)
         for tag, m in (("gas_sw", config.gas_optics_sw), ("gas_lw", config.gas_optics_lw)):
-            if m is None:
+            if m is None or getattr(config, "rrtmg", None) is not None:
                 continue
             _rec(f, f"{tag}.ints", [int(m.is_sw), m.ng, m.npress, m.ntemp, m.ngas, m.nplanck])
             _rec(f, f"{tag}.reals", [m.log_pressure1, m.d_log_pressure, m.d_temperature,
@@ -63,19 +74,24 @@ def write_case(path, config, ncol, nlev, single_level, thermodynamics, gas, clou
             if m.is_sw:
                 _rec(f, f"{tag}.norm_solar_irradiance", m.norm_solar_irradiance)
                 _rec(f, f"{tag}.rayleigh_molar_scat", m.rayleigh_molar_scat)
+                if getattr(m, "norm_amplitude_solar_irradiance", None) is not None:
+                    _rec(f, f"{tag}.norm_amplitude_solar_irradiance", m.norm_amplitude_solar_irradiance)
             else:
                 _rec(f, f"{tag}.planck_function", m.planck_function)
             for j, g in enumerate(m.single_gas, start=1):
                 _rec(f, f"{tag}.gas{j:02d}.ints", [g.i_gas_code, g.i_conc_dependence, g.n_mole_frac])
                 _rec(f, f"{tag}.gas{j:02d}.reals", [g.reference_mole_frac, g.log_mole_frac1, g.d_log_mole_frac])
-                _rec(f, f"{tag}.gas{j:02d}.molar_abs", g.molar_abs)
+                # radiation_ecckd_gas.F90:54,59: molar_abs(ng,np,nt), or molar_abs_conc(ng,np,nt,nconc) for a look-up table
+                _rec(f, f"{tag}.gas{j:02d}." + ("molar_abs_conc" if np.ndim(g.molar_abs) == 4 else "molar_abs"), g.molar_abs)
         for tag, lst in (("cloud_sw", config.cloud_optics_sw), ("cloud_lw", config.cloud_optics_lw)):
             for j, co in enumerate(lst or [], start=1):
                 _rec(f, f"{tag}.{j:02d}.ints", [co.n_bands, co.n_effective_radius])
                 _rec(f, f"{tag}.{j:02d}.reals", [co.effective_radius_0, co.d_effective_radius])
                 _rec(f, f"{tag}.{j:02d}.mass_ext", co.mass_ext)
-                _rec(f, f"{tag}.{j:02d}.ssa", co.ssa)
-                _rec(f, f"{tag}.{j:02d}.asymmetry", co.asymmetry)
+                if co.ssa is not None:
+                    _rec(f, f"{tag}.{j:02d}.ssa", co.ssa)
+                if co.asymmetry is not None:
+                    _rec(f, f"{tag}.{j:02d}.asymmetry", co.asymmetry)
         ao = config.aerosol_optics
         if config.use_aerosols and ao is not None:
             _rec(f, "aerosol.ints", [ao.n_bands_sw, ao.n_bands_lw, ao.n_type_phobic, ao.n_type_philic, ao.nrh,
@@ -119,6 +135,10 @@ def write_case(path, config, ncol, nlev, single_level, thermodynamics, gas, clou
             _rec(f, "inputs.cloud_effective_radius", cloud.effective_radius)
             _rec(f, "inputs.cloud_fractional_std", cloud.fractional_std)
             _rec(f, "inputs.cloud_overlap_param", cloud.overlap_param)
+            if getattr(cloud, "inv_cloud_effective_size", None) is not None:
+                _rec(f, "inputs.cloud_inv_cloud_effective_size", cloud.inv_cloud_effective_size)
+            if getattr(cloud, "inv_inhom_effective_size", None) is not None:
+                _rec(f, "inputs.cloud_inv_inhom_effective_size", cloud.inv_inhom_effective_size)
         if aerosol is not None:
             _rec(f, "inputs.aerosol_mixing_ratio", aerosol.mixing_ratio)
         _rec(f, "end", [0])

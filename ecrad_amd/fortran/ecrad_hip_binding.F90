@@ -12,6 +12,7 @@ module ecrad_hip_binding
   integer(c_int), parameter :: ECRAD_OK = 0
   integer(c_int), parameter :: ECRAD_NMAXGASES = 12, ECRAD_NMAXCLOUDTYPES = 12
   integer(c_int), parameter :: ECRAD_MEM_HOST = 0, ECRAD_MEM_DEVICE = 1
+  integer(c_int), parameter :: ECRAD_PRECISION_DOUBLE = 0, ECRAD_PRECISION_SINGLE = 1
 
   type, bind(C) :: ecrad_ckd_gas_t
     integer(c_int32_t) :: i_gas_code, i_conc_dependence, n_mole_frac, reserved_
@@ -48,11 +49,13 @@ module ecrad_hip_binding
   type, bind(C) :: ecrad_rrtmg_band_t
     integer(c_int32_t) :: ng, ld, nspa, nspb, layreffr, n_forref
     real(c_double) :: strrat, rayl, factor
-    type(c_ptr) :: absa, absb, selfref, forref, fracrefa, fracrefb
-    type(c_ptr) :: minor(6), xsec(2), rayl_g(2)
+    type(c_ptr) :: absa = c_null_ptr, absb = c_null_ptr, selfref = c_null_ptr, forref = c_null_ptr
+    type(c_ptr) :: fracrefa = c_null_ptr, fracrefb = c_null_ptr
+    type(c_ptr) :: minor(6) = c_null_ptr, xsec(2) = c_null_ptr, rayl_g(2) = c_null_ptr
   end type
   type, bind(C) :: ecrad_rrtmg_t
-    type(c_ptr) :: chi_mls, preflog_lw, tref_lw, preflog_sw, tref_sw, totplnk, delwave
+    type(c_ptr) :: chi_mls = c_null_ptr, preflog_lw = c_null_ptr, tref_lw = c_null_ptr, preflog_sw = c_null_ptr
+    type(c_ptr) :: tref_sw = c_null_ptr, totplnk = c_null_ptr, delwave = c_null_ptr
     type(ecrad_rrtmg_band_t) :: lw(16), sw(14)
   end type
 

@@ -1,191 +1,46 @@
 ! radiation_hip_interface.F90 -- Fortran host side of the drop-in boundary.
 !
-! Mirrors the operator interface of radiation/radiation_interface.F90 (setup_radiation :37,
-! radiation :200) over *minimal mirror types* that carry the same component names as the reference's
-! derived types (radiation_config.F90:163-649, radiation_single_level.F90:29-102,
-! radiation_thermodynamics.F90:29-49, radiation_gas.F90:36-80, radiation_cloud.F90:33-96,
-! radiation_aerosol.F90:28-57, radiation_flux.F90:38-118, radiation_ecckd.F90:34-119,
-! radiation_ecckd_gas.F90:39-77, radiation_general_cloud_optics_data.F90:31-62,
-! radiation_aerosol_optics_data.F90:50-148, radiation_pdf_sampler.F90:28-50).  Inside the reference,
-! the body of radiation_hip() below is what replaces the CPU stages of radiation(): it only takes
-! c_loc() of the caller's arrays -- no copies, no layout change -- and calls the C-ABI.
-module radiation_hip_types
-  use, intrinsic :: iso_c_binding, only : c_double, c_int32_t
-  implicit none
-  public
-  integer, parameter :: jprb = c_double
-  integer, parameter :: NMaxGases = 12, NMaxCloudTypes = 12
-
-  type ckd_gas_type
-    integer :: i_gas_code = -1, i_conc_dependence = 0, n_mole_frac = 0
-    real(jprb) :: reference_mole_frac = 0.0_jprb, log_mole_frac1 = 0.0_jprb, d_log_mole_frac = 1.0_jprb
-    real(jprb), allocatable :: molar_abs(:)        ! (ng,npress,ntemp[,nconc]) stored flat
-  end type
-  type ckd_model_type
-    integer :: ngas = 0, npress = 0, ntemp = 0, nplanck = 0, ng = 0
-    logical :: is_sw = .false.
-    real(jprb) :: log_pressure1, d_log_pressure, d_temperature
-    real(jprb) :: temperature1_planck = 0.0_jprb, d_temperature_planck = 1.0_jprb
-    real(jprb), allocatable :: temperature1(:), planck_function(:), norm_solar_irradiance(:), rayleigh_molar_scat(:)
-    type(ckd_gas_type) :: single_gas(NMaxGases)
-  end type
-  type general_cloud_optics_type
-    integer :: n_bands = 0, n_effective_radius = 0
-    real(jprb) :: effective_radius_0, d_effective_radius
-    real(jprb), allocatable :: mass_ext(:), ssa(:), asymmetry(:)
-  end type
-  type aerosol_optics_type
-    integer :: n_bands_sw = 0, n_bands_lw = 0, n_type_phobic = 0, n_type_philic = 0, nrh = 0, ntype = 0
-    logical :: use_hydrophilic = .false.
-    integer(c_int32_t), allocatable :: iclass(:), itype(:)
-    real(jprb), allocatable :: rh_lower(:)
-    real(jprb), allocatable :: mass_ext_sw_phobic(:), ssa_sw_phobic(:), g_sw_phobic(:)
-    real(jprb), allocatable :: mass_ext_lw_phobic(:), ssa_lw_phobic(:), g_lw_phobic(:)
-    real(jprb), allocatable :: mass_ext_sw_philic(:), ssa_sw_philic(:), g_sw_philic(:)
-    real(jprb), allocatable :: mass_ext_lw_philic(:), ssa_lw_philic(:), g_lw_philic(:)
-  end type
-  type pdf_sampler_type
-    integer :: ncdf = 0, nfsd = 0
-    real(jprb) :: fsd1, inv_fsd_interval
-    real(jprb), allocatable :: val(:)
-  end type
-
-  type config_type
-    logical :: do_sw = .true., do_lw = .true., do_clear = .true., do_sw_direct = .true.
-    logical :: do_lw_derivatives = .false., do_clouds = .true., use_aerosols = .false.
-    integer :: i_solver_sw = 2, i_solver_lw = 2, i_gas_model_sw = 2, i_gas_model_lw = 2
-    logical :: do_lw_cloud_scattering = .true., do_lw_aerosol_scattering = .false.
-    logical :: do_sw_delta_scaling_with_gases = .false., is_homogeneous = .false.
-    integer :: i_overlap_scheme = 1, i_cloud_pdf_shape = 1
-    logical :: use_beta_overlap = .false., use_vectorizable_generator = .false.
-    logical :: do_cloud_aerosol_per_sw_g_point = .true., do_cloud_aerosol_per_lw_g_point = .true.
-    logical :: do_surface_sw_spectral_flux = .true., do_toa_spectral_flux = .false.
-    logical :: do_canopy_fluxes_sw = .false., do_canopy_fluxes_lw = .false.
-    logical :: use_canopy_full_spectrum_sw = .false., use_canopy_full_spectrum_lw = .false.
-    logical :: do_nearest_spectral_sw_albedo = .false., do_nearest_spectral_lw_emiss = .false.
-    logical :: do_save_spectral_flux = .false.
-    integer :: n_spec_sw = 0, n_spec_lw = 0
-    integer(c_int32_t), allocatable :: i_spec_from_reordered_g_sw(:), i_spec_from_reordered_g_lw(:)
-    integer :: n_g_sw = 0, n_g_lw = 0, n_bands_sw = 0, n_bands_lw = 0
-    integer :: n_canopy_bands_sw = 1, n_canopy_bands_lw = 1, n_cloud_types = 0
-    real(jprb) :: cloud_fraction_threshold = 1.0e-6_jprb, cloud_mixing_ratio_threshold = 1.0e-9_jprb
-    real(jprb) :: cloud_inhom_decorr_scaling = 0.5_jprb
-    integer(c_int32_t), allocatable :: i_band_from_reordered_g_sw(:), i_band_from_reordered_g_lw(:)
-    integer :: n_albedo_intervals_sw = 0, n_emiss_intervals_lw = 0
-    real(jprb), allocatable :: sw_albedo_weights(:), lw_emiss_weights(:)   ! (nalb,nband) flat
-    type(ckd_model_type) :: gas_optics_sw, gas_optics_lw
-    type(general_cloud_optics_type) :: cloud_optics_sw(NMaxCloudTypes), cloud_optics_lw(NMaxCloudTypes)
-    type(aerosol_optics_type) :: aerosol_optics
-    type(pdf_sampler_type) :: pdf_sampler
-  end type
-
-  type single_level_type
-    real(jprb), allocatable :: cos_sza(:), skin_temperature(:)
-    real(jprb), allocatable :: sw_albedo(:,:), sw_albedo_direct(:,:), lw_emissivity(:,:)   ! (ncol,nband)
-    real(jprb) :: solar_irradiance = 1366.0_jprb, spectral_solar_cycle_multiplier = 0.0_jprb
-    integer(c_int32_t), allocatable :: iseed(:)
-  end type
-  type thermodynamics_type
-    real(jprb), allocatable :: pressure_hl(:,:), temperature_hl(:,:), h2o_sat_liq(:,:)     ! (ncol,nlev[+1])
-  end type
-  type gas_type
-    real(jprb), allocatable :: mixing_ratio(:,:,:)                                          ! (ncol,nlev,NMaxGases)
-  end type
-  type cloud_type
-    integer :: ntype = 0
-    real(jprb), allocatable :: mixing_ratio(:,:,:), effective_radius(:,:,:)                 ! (ncol,nlev,ntype)
-    real(jprb), allocatable :: fraction(:,:), fractional_std(:,:), overlap_param(:,:)
-  end type
-  type aerosol_type
-    real(jprb), allocatable :: mixing_ratio(:,:,:)                                          ! (ncol,lev,ntype)
-    integer :: istartlev = 1, iendlev = 0
-  end type
-  type flux_type
-    real(jprb), allocatable, dimension(:,:) :: lw_up, lw_dn, sw_up, sw_dn, sw_dn_direct, &
-         &  lw_up_clear, lw_dn_clear, sw_up_clear, sw_dn_clear, sw_dn_direct_clear, lw_derivatives
-    real(jprb), allocatable, dimension(:,:) :: lw_dn_surf_g, lw_dn_surf_clear_g, sw_dn_diffuse_surf_g, &
-         &  sw_dn_direct_surf_g, sw_dn_diffuse_surf_clear_g, sw_dn_direct_surf_clear_g, &
-         &  lw_up_toa_g, lw_up_toa_clear_g, sw_dn_toa_g, sw_up_toa_g, sw_up_toa_clear_g
-    real(jprb), allocatable, dimension(:,:) :: sw_dn_surf_band, sw_dn_direct_surf_band, &
-         &  sw_dn_surf_clear_band, sw_dn_direct_surf_clear_band
-    real(jprb), allocatable, dimension(:,:) :: lw_dn_surf_canopy, sw_dn_diffuse_surf_canopy, sw_dn_direct_surf_canopy
-    real(jprb), allocatable, dimension(:)   :: cloud_cover_lw, cloud_cover_sw
-    ! (nspec,ncol,nlev+1), config%do_save_spectral_flux (radiation_flux.F90:52-59)
-    real(jprb), allocatable, dimension(:,:,:) :: lw_up_band, lw_dn_band, lw_up_clear_band, lw_dn_clear_band, &
-         &  sw_up_band, sw_dn_band, sw_dn_direct_band, sw_up_clear_band, sw_dn_clear_band, sw_dn_direct_clear_band
-  contains
-    procedure :: allocate => allocate_flux_type
-  end type
-
-contains
-
-  ! flux%allocate (radiation_flux.F90:133-326)
-  subroutine allocate_flux_type(this, config, istartcol, iendcol, nlev)
-    class(flux_type), intent(inout) :: this
-    type(config_type), intent(in)   :: config
-    integer, intent(in) :: istartcol, iendcol, nlev
-    if (config%do_lw) then
-      allocate(this%lw_up(istartcol:iendcol,nlev+1), this%lw_dn(istartcol:iendcol,nlev+1))
-      if (config%do_clear) allocate(this%lw_up_clear(istartcol:iendcol,nlev+1), this%lw_dn_clear(istartcol:iendcol,nlev+1))
-      if (config%do_lw_derivatives) allocate(this%lw_derivatives(istartcol:iendcol,nlev+1))
-      allocate(this%lw_dn_surf_g(config%n_g_lw,istartcol:iendcol), this%lw_up_toa_g(config%n_g_lw,istartcol:iendcol))
-      if (config%do_clear) allocate(this%lw_dn_surf_clear_g(config%n_g_lw,istartcol:iendcol), &
-           &                         this%lw_up_toa_clear_g(config%n_g_lw,istartcol:iendcol))
-      if (config%do_canopy_fluxes_lw) allocate(this%lw_dn_surf_canopy(config%n_canopy_bands_lw,istartcol:iendcol))
-    end if
-    if (config%do_sw) then
-      allocate(this%sw_up(istartcol:iendcol,nlev+1), this%sw_dn(istartcol:iendcol,nlev+1))
-      if (config%do_sw_direct) allocate(this%sw_dn_direct(istartcol:iendcol,nlev+1))
-      if (config%do_clear) then
-        allocate(this%sw_up_clear(istartcol:iendcol,nlev+1), this%sw_dn_clear(istartcol:iendcol,nlev+1))
-        if (config%do_sw_direct) allocate(this%sw_dn_direct_clear(istartcol:iendcol,nlev+1))
-      end if
-      if (config%do_surface_sw_spectral_flux) then
-        allocate(this%sw_dn_surf_band(config%n_bands_sw,istartcol:iendcol), &
-             &   this%sw_dn_direct_surf_band(config%n_bands_sw,istartcol:iendcol))
-        if (config%do_clear) allocate(this%sw_dn_surf_clear_band(config%n_bands_sw,istartcol:iendcol), &
-             &                         this%sw_dn_direct_surf_clear_band(config%n_bands_sw,istartcol:iendcol))
-      end if
-      allocate(this%sw_dn_diffuse_surf_g(config%n_g_sw,istartcol:iendcol), this%sw_dn_direct_surf_g(config%n_g_sw,istartcol:iendcol), &
-           &   this%sw_dn_toa_g(config%n_g_sw,istartcol:iendcol), this%sw_up_toa_g(config%n_g_sw,istartcol:iendcol))
-      if (config%do_clear) allocate(this%sw_dn_diffuse_surf_clear_g(config%n_g_sw,istartcol:iendcol), &
-           &  this%sw_dn_direct_surf_clear_g(config%n_g_sw,istartcol:iendcol), this%sw_up_toa_clear_g(config%n_g_sw,istartcol:iendcol))
-      if (config%do_canopy_fluxes_sw) allocate(this%sw_dn_diffuse_surf_canopy(config%n_canopy_bands_sw,istartcol:iendcol), &
-           &                                   this%sw_dn_direct_surf_canopy(config%n_canopy_bands_sw,istartcol:iendcol))
-    end if
-    if (config%do_save_spectral_flux) then
-      if (config%do_lw) then
-        allocate(this%lw_up_band(config%n_spec_lw,istartcol:iendcol,nlev+1), this%lw_dn_band(config%n_spec_lw,istartcol:iendcol,nlev+1))
-        if (config%do_clear) allocate(this%lw_up_clear_band(config%n_spec_lw,istartcol:iendcol,nlev+1), &
-             &                         this%lw_dn_clear_band(config%n_spec_lw,istartcol:iendcol,nlev+1))
-      end if
-      if (config%do_sw) then
-        allocate(this%sw_up_band(config%n_spec_sw,istartcol:iendcol,nlev+1), this%sw_dn_band(config%n_spec_sw,istartcol:iendcol,nlev+1))
-        if (config%do_sw_direct) allocate(this%sw_dn_direct_band(config%n_spec_sw,istartcol:iendcol,nlev+1))
-        if (config%do_clear) then
-          allocate(this%sw_up_clear_band(config%n_spec_sw,istartcol:iendcol,nlev+1), &
-               &   this%sw_dn_clear_band(config%n_spec_sw,istartcol:iendcol,nlev+1))
-          if (config%do_sw_direct) allocate(this%sw_dn_direct_clear_band(config%n_spec_sw,istartcol:iendcol,nlev+1))
-        end if
-      end if
-    end if
-    allocate(this%cloud_cover_lw(istartcol:iendcol), this%cloud_cover_sw(istartcol:iendcol))
-    this%cloud_cover_lw = -1.0_jprb
-    this%cloud_cover_sw = -1.0_jprb
-  end subroutine allocate_flux_type
-
-end module radiation_hip_types
-
-
+! The operator interface of radiation/radiation_interface.F90 (setup_radiation :37, radiation :200) over the MI355X
+! library: setup_radiation_hip(config) hands the look-up tables that the host's own setup_radiation has read and
+! mapped to the GPU once; radiation_hip(ncol, nlev, istartcol, iendcol, config, single_level, thermodynamics, gas,
+! cloud, aerosol, flux) has the reference's argument list and intents and is what replaces the CPU stages of
+! radiation() (:323-504).  It takes c_loc() of the caller's arrays -- no copies, no layout change -- and calls the
+! C-ABI of include/ecrad_hip.h.
+!
+! Built with -DECRAD_HIP_REFERENCE_TYPES this module uses the reference's OWN derived types (its modules must be on
+! the include path): that is the build a maintainer adds to the reference, and the one tests/test_fortran_conformance.py
+! type-checks against /root/reference.  Without the macro it uses radiation_hip_types, a stand-in with the same
+! component names, ranks and kinds, for the repo's own driver where the reference's sources are absent.
 module radiation_hip_interface
   use, intrinsic :: iso_c_binding
   use ecrad_hip_binding
+#ifdef ECRAD_HIP_REFERENCE_TYPES
+  use parkind1,                 only : jprb
+  use radiation_config,         only : config_type, IGasModelIFSRRTMG
+  use radiation_single_level,   only : single_level_type
+  use radiation_thermodynamics, only : thermodynamics_type
+  use radiation_gas,            only : gas_type
+  use radiation_cloud,          only : cloud_type
+  use radiation_aerosol,        only : aerosol_type
+  use radiation_flux,           only : flux_type
+  use radiation_ecckd,          only : ckd_model_type
+  use radiation_ecckd_gas,      only : IConcDependenceLUT
+  use radiation_general_cloud_optics_data, only : general_cloud_optics_type
+#else
   use radiation_hip_types
+#endif
   implicit none
   private
   public :: setup_radiation_hip, radiation_hip, finalize_radiation_hip, radiation_hip_abort
 
   type(c_ptr), save :: hip_handle = c_null_ptr     ! one handle per process (= per GPU)
+  ! RRTMG: the tables live in the host's ifsrrtm modules; radiation_hip_rrtmg::fill_rrtmg_hip points this at them
+  type(ecrad_rrtmg_t), save, target :: rrtmg_tables
+
+  ! c_loc of an allocatable array of any rank used at the boundary (c_null_ptr when not allocated)
+  interface locd
+    module procedure locd1, locd2, locd3, locd4
+  end interface
 
 contains
 
@@ -201,7 +56,7 @@ contains
     l2i = merge(1_c_int32_t, 0_c_int32_t, l)
   end function
 
-  function loc_d(a) result(p)
+  function locd1(a) result(p)
     real(jprb), allocatable, target, intent(in) :: a(:)
     type(c_ptr) :: p
     p = c_null_ptr
@@ -209,23 +64,69 @@ contains
       if (size(a) > 0) p = c_loc(a)
     end if
   end function
+  function locd2(a) result(p)
+    real(jprb), allocatable, target, intent(in) :: a(:,:)
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (allocated(a)) then
+      if (size(a) > 0) p = c_loc(a)
+    end if
+  end function
+  function locd3(a) result(p)
+    real(jprb), allocatable, target, intent(in) :: a(:,:,:)
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (allocated(a)) then
+      if (size(a) > 0) p = c_loc(a)
+    end if
+  end function
+  function locd4(a) result(p)
+    real(jprb), allocatable, target, intent(in) :: a(:,:,:,:)
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (allocated(a)) then
+      if (size(a) > 0) p = c_loc(a)
+    end if
+  end function
+  function loci(a) result(p)        ! default integers are 32-bit (c_int32_t) in every build of the reference
+    integer, allocatable, target, intent(in) :: a(:)
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (allocated(a)) then
+      if (size(a) > 0) p = c_loc(a)
+    end if
+  end function
+  function locip(a) result(p)
+    integer, pointer, intent(in) :: a(:)
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (associated(a)) then
+      if (size(a) > 0) p = c_loc(a)
+    end if
+  end function
 
+  ! ckd_model_type -> ecrad_ckd_model_t (radiation_ecckd.F90:34-119, radiation_ecckd_gas.F90:39-77)
   subroutine fill_ckd(m, c)
     type(ckd_model_type), intent(in), target :: m
     type(ecrad_ckd_model_t), intent(out) :: c
     integer :: j
     c%is_sw = l2i(m%is_sw); c%ng = m%ng; c%npress = m%npress; c%ntemp = m%ntemp; c%ngas = m%ngas; c%nplanck = m%nplanck
     c%log_pressure1 = m%log_pressure1; c%d_log_pressure = m%d_log_pressure; c%d_temperature = m%d_temperature
-    c%temperature1_planck = m%temperature1_planck; c%d_temperature_planck = m%d_temperature_planck
-    c%temperature1 = loc_d(m%temperature1); c%planck_function = loc_d(m%planck_function)
-    c%norm_solar_irradiance = loc_d(m%norm_solar_irradiance); c%norm_amplitude_solar_irradiance = c_null_ptr
-    c%rayleigh_molar_scat = loc_d(m%rayleigh_molar_scat)
-    do j = 1, NMaxGases
+    c%temperature1_planck = 0.0_c_double; c%d_temperature_planck = 1.0_c_double
+    if (.not. m%is_sw) then
+      c%temperature1_planck = m%temperature1_planck; c%d_temperature_planck = m%d_temperature_planck
+    end if
+    c%temperature1 = locd(m%temperature1); c%planck_function = locd(m%planck_function)
+    c%norm_solar_irradiance = locd(m%norm_solar_irradiance)
+    c%norm_amplitude_solar_irradiance = locd(m%norm_amplitude_solar_irradiance)
+    c%rayleigh_molar_scat = locd(m%rayleigh_molar_scat)
+    do j = 1, ECRAD_NMAXGASES
       c%single_gas(j)%i_gas_code = 0; c%single_gas(j)%i_conc_dependence = 0; c%single_gas(j)%n_mole_frac = 0
       c%single_gas(j)%reserved_ = 0
       c%single_gas(j)%reference_mole_frac = 0; c%single_gas(j)%log_mole_frac1 = 0; c%single_gas(j)%d_log_mole_frac = 1
       c%single_gas(j)%molar_abs = c_null_ptr
     end do
+    if (m%ngas > ECRAD_NMAXGASES) call radiation_hip_abort('*** Error: gas-optics model has more gases than the C-ABI carries')
     do j = 1, m%ngas
       c%single_gas(j)%i_gas_code = m%single_gas(j)%i_gas_code
       c%single_gas(j)%i_conc_dependence = m%single_gas(j)%i_conc_dependence
@@ -233,17 +134,46 @@ contains
       c%single_gas(j)%reference_mole_frac = m%single_gas(j)%reference_mole_frac
       c%single_gas(j)%log_mole_frac1 = m%single_gas(j)%log_mole_frac1
       c%single_gas(j)%d_log_mole_frac = m%single_gas(j)%d_log_mole_frac
-      c%single_gas(j)%molar_abs = loc_d(m%single_gas(j)%molar_abs)
+      ! the C-ABI has one table pointer per gas: molar_abs(ng,np,nt), or molar_abs_conc(ng,np,nt,nconc) for a look-up table
+      if (m%single_gas(j)%i_conc_dependence == IConcDependenceLUT) then
+        c%single_gas(j)%molar_abs = locd(m%single_gas(j)%molar_abs_conc)
+      else
+        c%single_gas(j)%molar_abs = locd(m%single_gas(j)%molar_abs)
+      end if
     end do
   end subroutine
 
+  subroutine fill_cloud(g, c)          ! general_cloud_optics_type, radiation_general_cloud_optics_data.F90:31-62
+    type(general_cloud_optics_type), intent(in), target :: g
+    type(ecrad_cloud_optics_t), intent(out) :: c
+    c%n_bands = 0
+    if (allocated(g%mass_ext)) c%n_bands = size(g%mass_ext, 1)
+    c%n_effective_radius = g%n_effective_radius
+    c%effective_radius_0 = g%effective_radius_0; c%d_effective_radius = g%d_effective_radius
+    c%mass_ext = locd(g%mass_ext); c%ssa = locd(g%ssa); c%asymmetry = locd(g%asymmetry)
+  end subroutine
+  subroutine fill_cloud_fit(coeff, c)  ! cloud_optics_type: per-band fits (radiation_cloud_optics_data.F90:28-40)
+    real(jprb), allocatable, target, intent(in) :: coeff(:,:)      ! (nband, ncoeff)
+    type(ecrad_cloud_optics_t), intent(out) :: c
+    c%n_bands = 0; c%n_effective_radius = 0
+    if (allocated(coeff)) then
+      c%n_bands = size(coeff, 1); c%n_effective_radius = size(coeff, 2)
+    end if
+    c%effective_radius_0 = 0.0_c_double; c%d_effective_radius = 1.0_c_double
+    c%mass_ext = locd(coeff); c%ssa = c_null_ptr; c%asymmetry = c_null_ptr
+  end subroutine
+
   ! setup_radiation (radiation_interface.F90:37): the Fortran host has already read and mapped every
-  ! look-up table into config; hand them to the GPU once.
-  subroutine setup_radiation_hip(config, device_id)
+  ! look-up table into config; hand them to the GPU once.  With RRTMG the host has also run RRTM_INIT_140GP /
+  ! SRTM_INIT (radiation_ifs_rrtm.F90:89-99) and passes the ecrad_rrtmg_t that radiation_hip_rrtmg::fill_rrtmg_hip
+  ! pointed at the ifsrrtm modules.
+  subroutine setup_radiation_hip(config, device_id, rrtmg)
     type(config_type), intent(in), target :: config
     integer, intent(in), optional :: device_id
+    type(ecrad_rrtmg_t), intent(in), optional :: rrtmg
     type(ecrad_config_t) :: c
     integer :: jt, idev
+    if (kind(1.0_jprb) /= c_double) call radiation_hip_abort('*** Error: the MI355X library takes double-precision arrays (jprb = jprd)')
     idev = -1
     if (present(device_id)) idev = device_id
     if (.not. c_associated(hip_handle)) then
@@ -251,11 +181,15 @@ contains
            &  call radiation_hip_abort('*** Error: no usable MI355X device (ecrad_hip_create)')
     end if
     c%abi_version = ECRAD_ABI_VERSION
-    ! this mirror carries ecCKD configurations only; with RRTMG a host passes c_loc() of an ecrad_rrtmg_t filled
-    ! from the ifsrrtm modules (INTEGRATION.md)
     c%rrtmg = c_null_ptr
-    c%min_gas_od_lw = 1.0e-15_c_double; c%min_gas_od_sw = 0.0_c_double
-    c%i_liq_model = 0; c%i_ice_model = 0; c%do_fu_lw_ice_optics_bug = 0; c%reserved2_ = 0
+    if (config%i_gas_model_sw == IGasModelIFSRRTMG .or. config%i_gas_model_lw == IGasModelIFSRRTMG) then
+      if (.not. present(rrtmg)) call radiation_hip_abort('*** Error: RRTMG gas optics needs the ifsrrtm tables (fill_rrtmg_hip)')
+      rrtmg_tables = rrtmg
+      c%rrtmg = c_loc(rrtmg_tables)
+    end if
+    c%min_gas_od_lw = config%min_gas_od_lw; c%min_gas_od_sw = config%min_gas_od_sw
+    c%i_liq_model = config%i_liq_model; c%i_ice_model = config%i_ice_model
+    c%do_fu_lw_ice_optics_bug = l2i(config%do_fu_lw_ice_optics_bug); c%reserved2_ = 0
     c%do_sw = l2i(config%do_sw); c%do_lw = l2i(config%do_lw); c%do_clear = l2i(config%do_clear)
     c%do_sw_direct = l2i(config%do_sw_direct); c%do_lw_derivatives = l2i(config%do_lw_derivatives)
     c%do_clouds = l2i(config%do_clouds); c%use_aerosols = l2i(config%use_aerosols)
@@ -264,7 +198,7 @@ contains
     c%do_lw_cloud_scattering = l2i(config%do_lw_cloud_scattering)
     c%do_lw_aerosol_scattering = l2i(config%do_lw_aerosol_scattering)
     c%do_sw_delta_scaling_with_gases = l2i(config%do_sw_delta_scaling_with_gases)
-    c%use_general_cloud_optics = 1; c%is_homogeneous = l2i(config%is_homogeneous)
+    c%use_general_cloud_optics = l2i(config%use_general_cloud_optics); c%is_homogeneous = l2i(config%is_homogeneous)
     c%i_overlap_scheme = config%i_overlap_scheme; c%use_beta_overlap = l2i(config%use_beta_overlap)
     c%use_vectorizable_generator = l2i(config%use_vectorizable_generator); c%i_cloud_pdf_shape = config%i_cloud_pdf_shape
     c%do_cloud_aerosol_per_sw_g_point = l2i(config%do_cloud_aerosol_per_sw_g_point)
@@ -278,67 +212,60 @@ contains
     c%do_nearest_spectral_lw_emiss = l2i(config%do_nearest_spectral_lw_emiss)
     c%do_save_spectral_flux = l2i(config%do_save_spectral_flux)
     c%n_spec_sw = config%n_spec_sw; c%n_spec_lw = config%n_spec_lw
-    if (allocated(config%i_spec_from_reordered_g_sw)) c%i_spec_from_reordered_g_sw = c_loc(config%i_spec_from_reordered_g_sw)
-    if (allocated(config%i_spec_from_reordered_g_lw)) c%i_spec_from_reordered_g_lw = c_loc(config%i_spec_from_reordered_g_lw)
+    c%i_spec_from_reordered_g_sw = locip(config%i_spec_from_reordered_g_sw)
+    c%i_spec_from_reordered_g_lw = locip(config%i_spec_from_reordered_g_lw)
     c%n_g_sw = config%n_g_sw; c%n_g_lw = config%n_g_lw; c%n_bands_sw = config%n_bands_sw; c%n_bands_lw = config%n_bands_lw
-    c%n_g_lw_if_scattering = 0; c%n_bands_lw_if_scattering = merge(config%n_bands_lw, 0, config%do_lw_cloud_scattering)
+    c%n_g_lw_if_scattering = config%n_g_lw_if_scattering; c%n_bands_lw_if_scattering = config%n_bands_lw_if_scattering
     c%n_canopy_bands_sw = config%n_canopy_bands_sw; c%n_canopy_bands_lw = config%n_canopy_bands_lw
-    c%n_albedo_intervals_sw = config%n_albedo_intervals_sw; c%n_emiss_intervals_lw = config%n_emiss_intervals_lw
+    c%n_albedo_intervals_sw = 0; c%n_emiss_intervals_lw = 0
+    if (allocated(config%sw_albedo_weights)) c%n_albedo_intervals_sw = size(config%sw_albedo_weights, 1)
+    if (allocated(config%lw_emiss_weights))  c%n_emiss_intervals_lw  = size(config%lw_emiss_weights, 1)
     c%n_cloud_types = config%n_cloud_types; c%reserved_ = 0
     c%cloud_fraction_threshold = config%cloud_fraction_threshold
     c%cloud_mixing_ratio_threshold = config%cloud_mixing_ratio_threshold
-    c%cloud_inhom_decorr_scaling = config%cloud_inhom_decorr_scaling; c%max_cloud_od = 16.0_c_double
-    if (allocated(config%i_band_from_reordered_g_sw)) c%i_band_from_reordered_g_sw = c_loc(config%i_band_from_reordered_g_sw)
-    if (allocated(config%i_band_from_reordered_g_lw)) c%i_band_from_reordered_g_lw = c_loc(config%i_band_from_reordered_g_lw)
-    c%sw_albedo_weights = loc_d(config%sw_albedo_weights); c%lw_emiss_weights = loc_d(config%lw_emiss_weights)
-    call fill_ckd(config%gas_optics_sw, c%gas_optics_sw)
-    call fill_ckd(config%gas_optics_lw, c%gas_optics_lw)
-    do jt = 1, NMaxCloudTypes
-      c%cloud_optics_sw(jt)%n_bands = config%cloud_optics_sw(jt)%n_bands
-      c%cloud_optics_sw(jt)%n_effective_radius = config%cloud_optics_sw(jt)%n_effective_radius
-      c%cloud_optics_sw(jt)%effective_radius_0 = config%cloud_optics_sw(jt)%effective_radius_0
-      c%cloud_optics_sw(jt)%d_effective_radius = config%cloud_optics_sw(jt)%d_effective_radius
-      c%cloud_optics_sw(jt)%mass_ext = loc_d(config%cloud_optics_sw(jt)%mass_ext)
-      c%cloud_optics_sw(jt)%ssa = loc_d(config%cloud_optics_sw(jt)%ssa)
-      c%cloud_optics_sw(jt)%asymmetry = loc_d(config%cloud_optics_sw(jt)%asymmetry)
-      c%cloud_optics_lw(jt)%n_bands = config%cloud_optics_lw(jt)%n_bands
-      c%cloud_optics_lw(jt)%n_effective_radius = config%cloud_optics_lw(jt)%n_effective_radius
-      c%cloud_optics_lw(jt)%effective_radius_0 = config%cloud_optics_lw(jt)%effective_radius_0
-      c%cloud_optics_lw(jt)%d_effective_radius = config%cloud_optics_lw(jt)%d_effective_radius
-      c%cloud_optics_lw(jt)%mass_ext = loc_d(config%cloud_optics_lw(jt)%mass_ext)
-      c%cloud_optics_lw(jt)%ssa = loc_d(config%cloud_optics_lw(jt)%ssa)
-      c%cloud_optics_lw(jt)%asymmetry = loc_d(config%cloud_optics_lw(jt)%asymmetry)
-    end do
+    c%cloud_inhom_decorr_scaling = config%cloud_inhom_decorr_scaling; c%max_cloud_od = config%max_cloud_od
+    c%i_band_from_reordered_g_sw = loci(config%i_band_from_reordered_g_sw)
+    c%i_band_from_reordered_g_lw = loci(config%i_band_from_reordered_g_lw)
+    c%sw_albedo_weights = locd(config%sw_albedo_weights); c%lw_emiss_weights = locd(config%lw_emiss_weights)
+    c%i_albedo_from_band_sw = loci(config%i_albedo_from_band_sw); c%i_emiss_from_band_lw = loci(config%i_emiss_from_band_lw)
+    ! SPARTACUS (radiation_config.F90:226-260, :268, :341-411)
+    c%nregions = config%nregions; c%i_3d_sw_entrapment = config%i_3d_sw_entrapment
+    c%do_3d_effects = l2i(config%do_3d_effects); c%do_3d_lw_multilayer_effects = l2i(config%do_3d_lw_multilayer_effects)
+    c%do_lw_side_emissivity = l2i(config%do_lw_side_emissivity); c%use_expm_everywhere = l2i(config%use_expm_everywhere)
+    c%i_precision = ECRAD_PRECISION_DOUBLE; c%reserved3_ = 0
+    c%max_3d_transfer_rate = config%max_3d_transfer_rate; c%max_gas_od_3d = config%max_gas_od_3d
+    c%min_cloud_effective_size = config%min_cloud_effective_size; c%overhang_factor = config%overhang_factor
+    c%clear_to_thick_fraction = config%clear_to_thick_fraction; c%overhead_sun_factor = config%overhead_sun_factor
+    if (config%i_gas_model_sw /= IGasModelIFSRRTMG .and. config%do_sw) call fill_ckd(config%gas_optics_sw, c%gas_optics_sw)
+    if (config%i_gas_model_lw /= IGasModelIFSRRTMG .and. config%do_lw) call fill_ckd(config%gas_optics_lw, c%gas_optics_lw)
+    if (config%use_general_cloud_optics) then
+      if (config%n_cloud_types > ECRAD_NMAXCLOUDTYPES) call radiation_hip_abort('*** Error: too many cloud types for the C-ABI')
+      do jt = 1, config%n_cloud_types
+        if (allocated(config%cloud_optics_sw)) call fill_cloud(config%cloud_optics_sw(jt), c%cloud_optics_sw(jt))
+        if (allocated(config%cloud_optics_lw)) call fill_cloud(config%cloud_optics_lw(jt), c%cloud_optics_lw(jt))
+      end do
+    else        ! SOCRATES liquid + Fu ice fits: type 1 = liquid, type 2 = ice (include/ecrad_hip.h)
+      call fill_cloud_fit(config%cloud_optics%liq_coeff_sw, c%cloud_optics_sw(1))
+      call fill_cloud_fit(config%cloud_optics%ice_coeff_sw, c%cloud_optics_sw(2))
+      call fill_cloud_fit(config%cloud_optics%liq_coeff_lw, c%cloud_optics_lw(1))
+      call fill_cloud_fit(config%cloud_optics%ice_coeff_lw, c%cloud_optics_lw(2))
+    end if
     associate (ao => config%aerosol_optics, a => c%aerosol_optics)
       a%n_bands_sw = ao%n_bands_sw; a%n_bands_lw = ao%n_bands_lw; a%n_type_phobic = ao%n_type_phobic
       a%n_type_philic = ao%n_type_philic; a%nrh = ao%nrh; a%use_hydrophilic = l2i(ao%use_hydrophilic)
       a%ntype = ao%ntype; a%reserved_ = 0
-      if (allocated(ao%iclass)) a%iclass = c_loc(ao%iclass)
-      if (allocated(ao%itype))  a%itype  = c_loc(ao%itype)
-      a%rh_lower = loc_d(ao%rh_lower)
-      a%mass_ext_sw_phobic = loc_d(ao%mass_ext_sw_phobic); a%ssa_sw_phobic = loc_d(ao%ssa_sw_phobic); a%g_sw_phobic = loc_d(ao%g_sw_phobic)
-      a%mass_ext_lw_phobic = loc_d(ao%mass_ext_lw_phobic); a%ssa_lw_phobic = loc_d(ao%ssa_lw_phobic); a%g_lw_phobic = loc_d(ao%g_lw_phobic)
-      a%mass_ext_sw_philic = loc_d(ao%mass_ext_sw_philic); a%ssa_sw_philic = loc_d(ao%ssa_sw_philic); a%g_sw_philic = loc_d(ao%g_sw_philic)
-      a%mass_ext_lw_philic = loc_d(ao%mass_ext_lw_philic); a%ssa_lw_philic = loc_d(ao%ssa_lw_philic); a%g_lw_philic = loc_d(ao%g_lw_philic)
+      a%iclass = loci(ao%iclass); a%itype = loci(ao%itype)
+      a%rh_lower = locd(ao%rh_lower)
+      a%mass_ext_sw_phobic = locd(ao%mass_ext_sw_phobic); a%ssa_sw_phobic = locd(ao%ssa_sw_phobic); a%g_sw_phobic = locd(ao%g_sw_phobic)
+      a%mass_ext_lw_phobic = locd(ao%mass_ext_lw_phobic); a%ssa_lw_phobic = locd(ao%ssa_lw_phobic); a%g_lw_phobic = locd(ao%g_lw_phobic)
+      a%mass_ext_sw_philic = locd(ao%mass_ext_sw_philic); a%ssa_sw_philic = locd(ao%ssa_sw_philic); a%g_sw_philic = locd(ao%g_sw_philic)
+      a%mass_ext_lw_philic = locd(ao%mass_ext_lw_philic); a%ssa_lw_philic = locd(ao%ssa_lw_philic); a%g_lw_philic = locd(ao%g_lw_philic)
     end associate
     c%pdf_sampler%ncdf = config%pdf_sampler%ncdf; c%pdf_sampler%nfsd = config%pdf_sampler%nfsd
     c%pdf_sampler%fsd1 = config%pdf_sampler%fsd1; c%pdf_sampler%inv_fsd_interval = config%pdf_sampler%inv_fsd_interval
-    c%pdf_sampler%val = loc_d(config%pdf_sampler%val)
+    c%pdf_sampler%val = locd(config%pdf_sampler%val)
     if (ecrad_hip_setup(hip_handle, c) /= ECRAD_OK) call radiation_hip_abort('*** Error in ecrad_hip_setup')
   end subroutine setup_radiation_hip
-
-  function loc2(a) result(p)
-    real(jprb), allocatable, target, intent(in) :: a(:,:)
-    type(c_ptr) :: p
-    p = c_null_ptr
-    if (allocated(a)) p = c_loc(a)
-  end function
-  function loc3(a) result(p)
-    real(jprb), allocatable, target, intent(in) :: a(:,:,:)
-    type(c_ptr) :: p
-    p = c_null_ptr
-    if (allocated(a)) p = c_loc(a)
-  end function
 
   ! radiation (radiation_interface.F90:200): same argument list and intents as the reference.
   subroutine radiation_hip(ncol, nlev, istartcol, iendcol, config, &
@@ -357,58 +284,57 @@ contains
     cin%memory = ECRAD_MEM_HOST
     cin%solar_irradiance = single_level%solar_irradiance
     cin%spectral_solar_cycle_multiplier = single_level%spectral_solar_cycle_multiplier
-    cin%pressure_hl = loc2(thermodynamics%pressure_hl); cin%temperature_hl = loc2(thermodynamics%temperature_hl)
-    cin%h2o_sat_liq = loc2(thermodynamics%h2o_sat_liq)
-    cin%cos_sza = loc_d(single_level%cos_sza); cin%skin_temperature = loc_d(single_level%skin_temperature)
+    cin%pressure_hl = locd(thermodynamics%pressure_hl); cin%temperature_hl = locd(thermodynamics%temperature_hl)
+    cin%h2o_sat_liq = locd(thermodynamics%h2o_sat_liq)
+    cin%cos_sza = locd(single_level%cos_sza); cin%skin_temperature = locd(single_level%skin_temperature)
     cin%n_sw_albedo = 0; cin%n_lw_emissivity = 0
     if (allocated(single_level%sw_albedo)) cin%n_sw_albedo = size(single_level%sw_albedo, 2)
     if (allocated(single_level%lw_emissivity)) cin%n_lw_emissivity = size(single_level%lw_emissivity, 2)
-    cin%sw_albedo = loc2(single_level%sw_albedo); cin%sw_albedo_direct = loc2(single_level%sw_albedo_direct)
-    cin%lw_emissivity = loc2(single_level%lw_emissivity)
-    if (allocated(single_level%iseed)) cin%iseed = c_loc(single_level%iseed)
-    cin%gas_mixing_ratio = loc3(gas%mixing_ratio)
+    cin%sw_albedo = locd(single_level%sw_albedo); cin%sw_albedo_direct = locd(single_level%sw_albedo_direct)
+    cin%lw_emissivity = locd(single_level%lw_emissivity)
+    cin%iseed = loci(single_level%iseed)
+    cin%gas_mixing_ratio = locd(gas%mixing_ratio)
     cin%n_cloud_types = 0; cin%n_aerosol_types = 0; cin%aerosol_istartlev = 1; cin%aerosol_iendlev = 0; cin%reserved_ = 0
     if (config%do_clouds) then
       cin%n_cloud_types = cloud%ntype
-      cin%cloud_fraction = loc2(cloud%fraction); cin%cloud_mixing_ratio = loc3(cloud%mixing_ratio)
-      cin%cloud_effective_radius = loc3(cloud%effective_radius)
-      cin%cloud_fractional_std = loc2(cloud%fractional_std); cin%cloud_overlap_param = loc2(cloud%overlap_param)
+      cin%cloud_fraction = locd(cloud%fraction); cin%cloud_mixing_ratio = locd(cloud%mixing_ratio)
+      cin%cloud_effective_radius = locd(cloud%effective_radius)
+      cin%cloud_fractional_std = locd(cloud%fractional_std); cin%cloud_overlap_param = locd(cloud%overlap_param)
+      cin%cloud_inv_cloud_effective_size = locd(cloud%inv_cloud_effective_size)
+      cin%cloud_inv_inhom_effective_size = locd(cloud%inv_inhom_effective_size)
     end if
     if (config%use_aerosols) then
       cin%n_aerosol_types = size(aerosol%mixing_ratio, 3)
       cin%aerosol_istartlev = aerosol%istartlev; cin%aerosol_iendlev = aerosol%iendlev
-      cin%aerosol_mixing_ratio = loc3(aerosol%mixing_ratio)
+      cin%aerosol_mixing_ratio = locd(aerosol%mixing_ratio)
     end if
     cfl%memory = ECRAD_MEM_HOST; cfl%reserved_ = 0
-    cfl%lw_up = loc2(flux%lw_up); cfl%lw_dn = loc2(flux%lw_dn); cfl%sw_up = loc2(flux%sw_up); cfl%sw_dn = loc2(flux%sw_dn)
-    cfl%sw_dn_direct = loc2(flux%sw_dn_direct); cfl%lw_up_clear = loc2(flux%lw_up_clear); cfl%lw_dn_clear = loc2(flux%lw_dn_clear)
-    cfl%sw_up_clear = loc2(flux%sw_up_clear); cfl%sw_dn_clear = loc2(flux%sw_dn_clear)
-    cfl%sw_dn_direct_clear = loc2(flux%sw_dn_direct_clear); cfl%lw_derivatives = loc2(flux%lw_derivatives)
-    cfl%lw_dn_surf_g = loc2(flux%lw_dn_surf_g); cfl%lw_dn_surf_clear_g = loc2(flux%lw_dn_surf_clear_g)
-    cfl%sw_dn_diffuse_surf_g = loc2(flux%sw_dn_diffuse_surf_g); cfl%sw_dn_direct_surf_g = loc2(flux%sw_dn_direct_surf_g)
-    cfl%sw_dn_diffuse_surf_clear_g = loc2(flux%sw_dn_diffuse_surf_clear_g)
-    cfl%sw_dn_direct_surf_clear_g = loc2(flux%sw_dn_direct_surf_clear_g)
-    cfl%lw_up_toa_g = loc2(flux%lw_up_toa_g); cfl%lw_up_toa_clear_g = loc2(flux%lw_up_toa_clear_g)
-    cfl%sw_dn_toa_g = loc2(flux%sw_dn_toa_g); cfl%sw_up_toa_g = loc2(flux%sw_up_toa_g)
-    cfl%sw_up_toa_clear_g = loc2(flux%sw_up_toa_clear_g)
-    cfl%sw_dn_surf_band = loc2(flux%sw_dn_surf_band); cfl%sw_dn_direct_surf_band = loc2(flux%sw_dn_direct_surf_band)
-    cfl%sw_dn_surf_clear_band = loc2(flux%sw_dn_surf_clear_band)
-    cfl%sw_dn_direct_surf_clear_band = loc2(flux%sw_dn_direct_surf_clear_band)
-    cfl%lw_dn_surf_canopy = loc2(flux%lw_dn_surf_canopy)
-    cfl%sw_dn_diffuse_surf_canopy = loc2(flux%sw_dn_diffuse_surf_canopy)
-    cfl%sw_dn_direct_surf_canopy = loc2(flux%sw_dn_direct_surf_canopy)
-    if (allocated(flux%cloud_cover_lw)) cfl%cloud_cover_lw = c_loc(flux%cloud_cover_lw)
-    if (allocated(flux%cloud_cover_sw)) cfl%cloud_cover_sw = c_loc(flux%cloud_cover_sw)
-    if (allocated(flux%lw_up_band)) cfl%lw_up_band = c_loc(flux%lw_up_band)
-    if (allocated(flux%lw_dn_band)) cfl%lw_dn_band = c_loc(flux%lw_dn_band)
-    if (allocated(flux%lw_up_clear_band)) cfl%lw_up_clear_band = c_loc(flux%lw_up_clear_band)
-    if (allocated(flux%lw_dn_clear_band)) cfl%lw_dn_clear_band = c_loc(flux%lw_dn_clear_band)
-    if (allocated(flux%sw_up_band)) cfl%sw_up_band = c_loc(flux%sw_up_band)
-    if (allocated(flux%sw_dn_band)) cfl%sw_dn_band = c_loc(flux%sw_dn_band)
-    if (allocated(flux%sw_dn_direct_band)) cfl%sw_dn_direct_band = c_loc(flux%sw_dn_direct_band)
-    if (allocated(flux%sw_up_clear_band)) cfl%sw_up_clear_band = c_loc(flux%sw_up_clear_band)
-    if (allocated(flux%sw_dn_clear_band)) cfl%sw_dn_clear_band = c_loc(flux%sw_dn_clear_band)
-    if (allocated(flux%sw_dn_direct_clear_band)) cfl%sw_dn_direct_clear_band = c_loc(flux%sw_dn_direct_clear_band)
+    cfl%lw_up = locd(flux%lw_up); cfl%lw_dn = locd(flux%lw_dn); cfl%sw_up = locd(flux%sw_up); cfl%sw_dn = locd(flux%sw_dn)
+    cfl%sw_dn_direct = locd(flux%sw_dn_direct); cfl%lw_up_clear = locd(flux%lw_up_clear); cfl%lw_dn_clear = locd(flux%lw_dn_clear)
+    cfl%sw_up_clear = locd(flux%sw_up_clear); cfl%sw_dn_clear = locd(flux%sw_dn_clear)
+    cfl%sw_dn_direct_clear = locd(flux%sw_dn_direct_clear); cfl%lw_derivatives = locd(flux%lw_derivatives)
+    cfl%lw_dn_surf_g = locd(flux%lw_dn_surf_g); cfl%lw_dn_surf_clear_g = locd(flux%lw_dn_surf_clear_g)
+    cfl%sw_dn_diffuse_surf_g = locd(flux%sw_dn_diffuse_surf_g); cfl%sw_dn_direct_surf_g = locd(flux%sw_dn_direct_surf_g)
+    cfl%sw_dn_diffuse_surf_clear_g = locd(flux%sw_dn_diffuse_surf_clear_g)
+    cfl%sw_dn_direct_surf_clear_g = locd(flux%sw_dn_direct_surf_clear_g)
+    cfl%lw_up_toa_g = locd(flux%lw_up_toa_g); cfl%lw_up_toa_clear_g = locd(flux%lw_up_toa_clear_g)
+    cfl%sw_dn_toa_g = locd(flux%sw_dn_toa_g); cfl%sw_up_toa_g = locd(flux%sw_up_toa_g)
+    cfl%sw_up_toa_clear_g = locd(flux%sw_up_toa_clear_g)
+    cfl%sw_dn_surf_band = locd(flux%sw_dn_surf_band); cfl%sw_dn_direct_surf_band = locd(flux%sw_dn_direct_surf_band)
+    cfl%sw_dn_surf_clear_band = locd(flux%sw_dn_surf_clear_band)
+    cfl%sw_dn_direct_surf_clear_band = locd(flux%sw_dn_direct_surf_clear_band)
+    cfl%lw_up_toa_band = locd(flux%lw_up_toa_band); cfl%lw_up_toa_clear_band = locd(flux%lw_up_toa_clear_band)
+    cfl%sw_dn_toa_band = locd(flux%sw_dn_toa_band); cfl%sw_up_toa_band = locd(flux%sw_up_toa_band)
+    cfl%sw_up_toa_clear_band = locd(flux%sw_up_toa_clear_band)
+    cfl%lw_dn_surf_canopy = locd(flux%lw_dn_surf_canopy)
+    cfl%sw_dn_diffuse_surf_canopy = locd(flux%sw_dn_diffuse_surf_canopy)
+    cfl%sw_dn_direct_surf_canopy = locd(flux%sw_dn_direct_surf_canopy)
+    cfl%cloud_cover_lw = locd(flux%cloud_cover_lw); cfl%cloud_cover_sw = locd(flux%cloud_cover_sw)
+    cfl%lw_up_band = locd(flux%lw_up_band); cfl%lw_dn_band = locd(flux%lw_dn_band)
+    cfl%lw_up_clear_band = locd(flux%lw_up_clear_band); cfl%lw_dn_clear_band = locd(flux%lw_dn_clear_band)
+    cfl%sw_up_band = locd(flux%sw_up_band); cfl%sw_dn_band = locd(flux%sw_dn_band)
+    cfl%sw_dn_direct_band = locd(flux%sw_dn_direct_band); cfl%sw_up_clear_band = locd(flux%sw_up_clear_band)
+    cfl%sw_dn_clear_band = locd(flux%sw_dn_clear_band); cfl%sw_dn_direct_clear_band = locd(flux%sw_dn_direct_clear_band)
     if (ecrad_hip_radiation(hip_handle, int(ncol,c_int), int(nlev,c_int), int(istartcol,c_int), int(iendcol,c_int), &
          &  cin, cfl) /= ECRAD_OK) call radiation_hip_abort('*** Error in ecrad_hip_radiation')
   end subroutine radiation_hip
