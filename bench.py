@@ -141,7 +141,56 @@ def cpu_baseline(config, sample, seconds_target=10.0):
     out = {"value": ncol * reps / dt, "unit": "columns/s", "cores": nthreads, "kind": "port",
            "sample": f"{ncol} columns ({ncol // 32} blocks of 32 for {nthreads} threads) x {reps} repeats of the same synthetic "
                      f"workload, {what}OpenMP over blocks of 32 columns as in driver/ecrad_driver.F90:348), {dt:.1f} s"}
+    try:
+        comp = reference_leaf_component(config, rad, sample, nthreads)
+        if comp:
+            out["components"] = comp
+    except Exception as e:       # the reference-code component is additional information: never take the line down
+        out["components"] = {"error": f"{type(e).__name__}: {e}"}
     return out, flux
+
+
+def reference_leaf_component(config, rad, sample, nthreads, seconds_target=4.0):
+    """The part of the CPU baseline that can run as the REFERENCE's own Fortran on this box: the solver stage of the
+    clear-sky homogeneous workload (two-stream coefficients + adding method, SW and LW) by the reference's leaf routines,
+    compiled unmodified into oracle/_ref/libecrad_refleaf.so, in the reference's calling order with OpenMP over blocks of
+    32 columns (oracle/ref_leaf_wrappers.F90: ref_clear_sky_solvers; pinned by tests/test_oracle_vs_ref_leaf.py).  The
+    stage arrays it works on come from the oracle's optics stage.  Only that workload has a solver stage made of leaf
+    routines alone; the gas-optics stage of ecCKD needs the reference's netCDF-dependent modules and stays "port"."""
+    from oracle import pyoracle
+    from ecrad_amd.config import ISolverHomogeneous
+    if not pyoracle.have_ref_leaf() or config.use_aerosols or config.i_solver_sw != ISolverHomogeneous or config.rrtmg is not None:
+        return None
+    from ecrad_amd.interface import build_inputs_struct
+    ncol, nlev, sl, th, gas, cloud, aer = sample
+    if cloud is not None and float(np.max(cloud.fraction)) > 0.0:
+        return None
+    n0 = min(ncol, 1024)                               # the oracle's optics stage is serial: a small sample, then tiled
+    sub = first_columns(sample, n0)
+    cin, keep = build_inputs_struct(config, *sub)
+    stage = pyoracle.optics(config, rad.cconfig, n0, nlev, 1, n0, cin)
+    reps_t = max(1, 16384 // n0)
+    stage = {k: np.ascontiguousarray(np.concatenate([v] * reps_t, axis=0)) for k, v in stage.items()
+             if k in ("od_sw", "ssa_sw", "g_sw", "incoming_sw", "sw_albedo_diffuse", "sw_albedo_direct", "od_lw", "planck_hl", "lw_emission", "lw_albedo")}
+    mu0 = np.concatenate([sub[2].cos_sza] * reps_t)
+    n = n0 * reps_t
+    os.environ.setdefault("OMP_NUM_THREADS", str(nthreads))
+    pyoracle.ref_clear_sky_solvers(stage, mu0, 32)      # warm-up
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        pyoracle.ref_clear_sky_solvers(stage, mu0, 32)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds_target or reps >= 100:
+            break
+    return {"solver_stage": {"value": n * reps / dt, "unit": "columns/s", "cores": nthreads, "kind": "reference",
+                             "what": "two-stream coefficients + adding method, SW and LW, of the clear-sky homogeneous solvers: the reference's own "
+                                     "calc_two_stream_gammas_sw, calc_reflectance_transmittance_sw, adding_ica_sw, calc_no_scattering_transmittance_lw, "
+                                     "calc_fluxes_no_scattering_lw (amdflang -O3 -fopenmp, oracle/_ref), OpenMP over blocks of 32 columns",
+                             "sample": f"{n} columns ({n0} distinct) x {reps} repeats, {dt:.1f} s"},
+            "everything_else": {"kind": "port", "what": "gas optics, Planck function, albedo mapping, flux post-processing: oracle/ (the reference's "
+                                                         "modules for these need netCDF and cannot be built here)"}}
 
 
 def measured_traffic(workload, ncol, kernel_prefix):

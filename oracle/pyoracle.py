@@ -137,6 +137,34 @@ def optics_shapes(config, nlev, nloc) -> dict:
 
 
 # ---------------------------------------------------------------------------------------------------
+# CPU baseline in the reference's own code: the clear-sky solver stage (two-stream + adding, SW + LW) by the reference's
+# leaf routines in the reference's calling order, OpenMP over column blocks (oracle/ref_leaf_wrappers.F90:
+# ref_clear_sky_solvers, compiled with the reference's modules into oracle/_ref/libecrad_refleaf.so).
+_ref_leaf = None
+
+
+def have_ref_leaf() -> bool:
+    return os.path.exists(REF_LEAF_PATH)
+
+
+def ref_clear_sky_solvers(stage: dict, cos_sza, nblocksize: int = 32):
+    """stage: the arrays of optics() for a clear-sky, aerosol-free configuration.  Returns dict of (nlev+1, ncol) fluxes."""
+    global _ref_leaf
+    if _ref_leaf is None:
+        _ref_leaf = C.CDLL(REF_LEAF_PATH)
+    ncol, nlev, ng_sw = stage["od_sw"].shape
+    ng_lw = stage["od_lw"].shape[2]
+    out = {k: np.zeros((nlev + 1, ncol)) for k in ("sw_up", "sw_dn", "sw_dn_direct", "lw_up", "lw_dn")}
+    p = lambda a: np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))
+    keep = [np.ascontiguousarray(stage[k], dtype=np.float64) for k in
+            ("od_sw", "ssa_sw", "g_sw", "incoming_sw", "sw_albedo_diffuse", "sw_albedo_direct", "od_lw", "planck_hl", "lw_emission", "lw_albedo")]
+    mu0 = np.ascontiguousarray(cos_sza, dtype=np.float64)
+    _ref_leaf.ref_clear_sky_solvers(C.c_int(ncol), C.c_int(nlev), C.c_int(ng_sw), C.c_int(ng_lw), C.c_int(nblocksize), p(mu0),
+                                    *[p(a) for a in keep], *[p(out[k]) for k in ("sw_up", "sw_dn", "sw_dn_direct", "lw_up", "lw_dn")])
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
 # RRTMG (SURVEY.md section 8 row a6): the oracle's gas optics for this model are the reference's OWN ifsrrtm routines
 # (oracle/_ref/libecrad_refrrtm.so, built by oracle/build_ref_rrtm.sh from /root/reference, unmodified; the
 # library travels to the GPU box with the repo).  What radiation_ifs_rrtm.F90 does around them is restated here.

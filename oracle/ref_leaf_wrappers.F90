@@ -298,4 +298,75 @@ contains
     call fast_expm_exchange_3(n, iend, a, b, c, d, R)
   end subroutine
 
+
+  ! ---- CPU baseline in the reference's own code -------------------------------------------------------------------
+  ! The clear-sky solver stage of the headline workload (solver_homogeneous_sw + solver_homogeneous_lw without clouds and
+  ! without aerosols: radiation_homogeneous_sw.F90:160-215,270-330, radiation_homogeneous_lw.F90:150-200,260-300), i.e. the
+  ! reference's leaf routines calc_two_stream_gammas_sw, calc_reflectance_transmittance_sw, adding_ica_sw,
+  ! calc_no_scattering_transmittance_lw and calc_fluxes_no_scattering_lw called in the reference's order, for ncol
+  ! columns with OpenMP over blocks of columns like the driver's loop (driver/ecrad_driver.F90:348).  Stage arrays as
+  ! radiation() passes them: (ng, nlev[+1], ncol).  Nothing of the solvers is restated here: only the calling sequence.
+  subroutine ref_clear_sky_solvers(ncol, nlev, ng_sw, ng_lw, nblocksize, cos_sza, od_sw, ssa_sw, g_sw, incoming_sw, &
+       &  albedo_diffuse, albedo_direct, od_lw, planck_hl, lw_emission, lw_albedo, &
+       &  sw_up, sw_dn, sw_dn_direct, lw_up, lw_dn) bind(C, name='ref_clear_sky_solvers')
+    use radiation_two_stream, only : calc_two_stream_gammas_sw, calc_reflectance_transmittance_sw, &
+         &                           calc_no_scattering_transmittance_lw
+    use radiation_adding_ica_sw, only : adding_ica_sw
+    use radiation_adding_ica_lw, only : calc_fluxes_no_scattering_lw
+    integer(c_int), value :: ncol, nlev, ng_sw, ng_lw, nblocksize
+    real(c_double), intent(in) :: cos_sza(ncol)
+    real(c_double), intent(in), dimension(ng_sw,nlev,ncol) :: od_sw, ssa_sw, g_sw
+    real(c_double), intent(in), dimension(ng_sw,ncol) :: incoming_sw, albedo_diffuse, albedo_direct
+    real(c_double), intent(in) :: od_lw(ng_lw,nlev,ncol), planck_hl(ng_lw,nlev+1,ncol)
+    real(c_double), intent(in), dimension(ng_lw,ncol) :: lw_emission, lw_albedo
+    real(c_double), intent(out), dimension(ncol,nlev+1) :: sw_up, sw_dn, sw_dn_direct, lw_up, lw_dn
+    integer :: jblock, nblock, jcol, jlev, i1, i2
+    real(jprb), dimension(ng_sw) :: gamma1, gamma2, gamma3, mu0v
+    real(jprb), dimension(ng_sw,nlev) :: reflectance, transmittance, ref_dir, trans_dir_diff, trans_dir_dir
+    real(jprb), dimension(ng_sw,nlev+1) :: flux_up, flux_dn_diffuse, flux_dn_direct
+    real(jprb), dimension(ng_lw,nlev) :: trans_lw, source_up, source_dn
+    real(jprb), dimension(ng_lw,nlev+1) :: flux_up_lw, flux_dn_lw
+    nblock = (ncol + nblocksize - 1) / nblocksize
+    !$OMP PARALLEL DO PRIVATE(jblock, jcol, jlev, i1, i2, gamma1, gamma2, gamma3, mu0v, reflectance, transmittance, ref_dir, &
+    !$OMP&   trans_dir_diff, trans_dir_dir, flux_up, flux_dn_diffuse, flux_dn_direct, trans_lw, source_up, source_dn, &
+    !$OMP&   flux_up_lw, flux_dn_lw) SCHEDULE(DYNAMIC)
+    do jblock = 1, nblock
+      i1 = (jblock - 1) * nblocksize + 1
+      i2 = min(i1 + nblocksize - 1, ncol)
+      do jcol = i1, i2
+        ! longwave
+        do jlev = 1, nlev
+          call calc_no_scattering_transmittance_lw(ng_lw, od_lw(:,jlev,jcol), planck_hl(:,jlev,jcol), planck_hl(:,jlev+1,jcol), &
+               &  trans_lw(:,jlev), source_up(:,jlev), source_dn(:,jlev))
+        end do
+        call calc_fluxes_no_scattering_lw(ng_lw, nlev, trans_lw, source_up, source_dn, lw_emission(:,jcol), lw_albedo(:,jcol), &
+             &  flux_up_lw, flux_dn_lw)
+        do jlev = 1, nlev + 1
+          lw_up(jcol,jlev) = sum(flux_up_lw(:,jlev))
+          lw_dn(jcol,jlev) = sum(flux_dn_lw(:,jlev))
+        end do
+        ! shortwave
+        if (cos_sza(jcol) > 0.0_jprb) then
+          mu0v = cos_sza(jcol)
+          do jlev = 1, nlev
+            call calc_two_stream_gammas_sw(ng_sw, cos_sza(jcol), ssa_sw(:,jlev,jcol), g_sw(:,jlev,jcol), gamma1, gamma2, gamma3)
+            call calc_reflectance_transmittance_sw(ng_sw, cos_sza(jcol), od_sw(:,jlev,jcol), ssa_sw(:,jlev,jcol), &
+                 &  gamma1, gamma2, gamma3, reflectance(:,jlev), transmittance(:,jlev), ref_dir(:,jlev), &
+                 &  trans_dir_diff(:,jlev), trans_dir_dir(:,jlev))
+          end do
+          call adding_ica_sw(ng_sw, nlev, incoming_sw(:,jcol), albedo_diffuse(:,jcol), albedo_direct(:,jcol), mu0v, &
+               &  reflectance, transmittance, ref_dir, trans_dir_diff, trans_dir_dir, flux_up, flux_dn_diffuse, flux_dn_direct)
+          do jlev = 1, nlev + 1
+            sw_up(jcol,jlev) = sum(flux_up(:,jlev))
+            sw_dn_direct(jcol,jlev) = sum(flux_dn_direct(:,jlev))
+            sw_dn(jcol,jlev) = sum(flux_dn_diffuse(:,jlev)) + sw_dn_direct(jcol,jlev)
+          end do
+        else
+          sw_up(jcol,:) = 0.0_jprb; sw_dn(jcol,:) = 0.0_jprb; sw_dn_direct(jcol,:) = 0.0_jprb
+        end if
+      end do
+    end do
+    !$OMP END PARALLEL DO
+  end subroutine ref_clear_sky_solvers
+
 end module ref_leaf_wrappers

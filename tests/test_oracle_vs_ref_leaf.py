@@ -283,3 +283,24 @@ def test_minstd_vector_rng_is_exact(libs, seed):
         ora.oracle_minstd_uniform(C.c_int(nstream), st.ctypes.data_as(C.c_void_p), p(row))
         xo[b] = row
     assert np.array_equal(xo, xr)
+
+
+def test_reference_leaf_clear_sky_solver_stage_reproduces_the_oracle(oracle_lib):
+    """bench.py times the reference's own leaf routines as the solver part of the CPU baseline (oracle/ref_leaf_wrappers.F90:
+    ref_clear_sky_solvers: calc_reflectance_transmittance_sw + adding_ica_sw, calc_no_scattering_transmittance_lw +
+    calc_fluxes_no_scattering_lw, in the order of radiation_homogeneous_{sw,lw}.F90).  Driven with the oracle's stage arrays
+    they must give the oracle's clear-sky homogeneous fluxes: that pins the calling sequence that is being timed."""
+    import ctypes as C
+    from ecrad_amd.interface import build_inputs_struct
+    from helpers import load_meridian, make_config, rel_err, run_case
+    if not oracle_lib.have_ref_leaf():
+        pytest.skip("oracle/_ref/libecrad_refleaf.so not built")
+    config = make_config("Homogeneous", use_aerosols=False)
+    f, th, rad = run_case(config, oracle_lib.backend)
+    inp = load_meridian(config)
+    rad.set_gas_units(inp[4]); inp[3].calc_saturation_wrt_liquid()
+    cin, keep = build_inputs_struct(config, *inp)
+    stage = oracle_lib.optics(config, rad.cconfig, 32, 137, 1, 32, cin)
+    got = oracle_lib.ref_clear_sky_solvers(stage, inp[2].cos_sza, nblocksize=8)
+    for name in ("sw_up", "sw_dn", "sw_dn_direct", "lw_up", "lw_dn"):
+        assert rel_err(got[name], f.arrays[name + "_clear"]) < 1.0e-12, name
