@@ -31,6 +31,11 @@ class DriverConfig:
     iverbose: int = 2
     do_write_double_precision: bool = False
     do_save_net_fluxes: bool = False
+    # shortwave diagnostics in user-specified wavelength intervals (m), written to a second file
+    # (driver/ecrad_driver_config.F90:72-82: the first negative bound ends the list)
+    sw_diag_wavelength_bound: list = None
+    sw_diag_file_name: str = "sw_diagnostics.nc"
+    experiment_name: str = ""
     fractional_std_override: float = -1.0
     overlap_decorr_length_override: float = -1.0
     overlap_decorr_length_scaling: float = -1.0
@@ -313,6 +318,89 @@ def save_fluxes(path: str, config: Config, thermodynamics: Thermodynamics, flux:
              double=is_double_precision)
 
 
+def save_net_fluxes(path: str, config: Config, thermodynamics: Thermodynamics, flux: Flux,
+                    is_double_precision: bool = False, experiment_name: str = "") -> None:
+    """save_net_fluxes (radiation_save.F90:464-715): net (down minus up) flux profiles and the surface / TOA downwelling
+    fluxes instead of the separate up and down profiles; same variable names and dimensions as the reference."""
+    ncol = thermodynamics.pressure_hl.shape[1]
+    nhl = thermodynamics.pressure_hl.shape[0]
+    dims = {"column": ncol, "half_level": nhl}
+    v = {"pressure_hl": (("column", "half_level"), thermodynamics.pressure_hl.T.copy())}
+    prof = lambda a: (("column", "half_level"), np.ascontiguousarray(a.T))
+    col = lambda a: (("column",), np.ascontiguousarray(a))
+    if config.do_lw:
+        v["flux_net_lw"] = prof(flux.lw_dn - flux.lw_up)
+        v["flux_dn_lw_surf"] = col(flux.lw_dn[nhl - 1])
+        if config.do_clear:
+            v["flux_net_lw_clear"] = prof(flux.lw_dn_clear - flux.lw_up_clear)
+            v["flux_dn_lw_clear_surf"] = col(flux.lw_dn_clear[nhl - 1])
+        if config.do_lw_derivatives:
+            v["lw_derivative"] = prof(flux.lw_derivatives)
+        if config.do_canopy_fluxes_lw:
+            dims["canopy_band_lw"] = flux.lw_dn_surf_canopy.shape[1]
+            v["canopy_flux_dn_lw_surf"] = (("column", "canopy_band_lw"), flux.lw_dn_surf_canopy.copy())
+    if config.do_sw:
+        v["flux_net_sw"] = prof(flux.sw_dn - flux.sw_up)
+        v["flux_dn_sw_surf"] = col(flux.sw_dn[nhl - 1])
+        v["flux_dn_sw_toa"] = col(flux.sw_dn[0])
+        if config.do_sw_direct:
+            v["flux_dn_direct_sw_surf"] = col(flux.sw_dn_direct[nhl - 1])
+        if config.do_clear:
+            v["flux_net_sw_clear"] = prof(flux.sw_dn_clear - flux.sw_up_clear)
+            v["flux_dn_sw_clear_surf"] = col(flux.sw_dn_clear[nhl - 1])
+            if config.do_sw_direct:
+                v["flux_dn_direct_sw_clear_surf"] = col(flux.sw_dn_direct_clear[nhl - 1])
+        if config.do_canopy_fluxes_sw:
+            dims["canopy_band_sw"] = flux.sw_dn_diffuse_surf_canopy.shape[1]
+            v["canopy_flux_dn_diffuse_sw_surf"] = (("column", "canopy_band_sw"), flux.sw_dn_diffuse_surf_canopy.copy())
+            v["canopy_flux_dn_direct_sw_surf"] = (("column", "canopy_band_sw"), flux.sw_dn_direct_surf_canopy.copy())
+    attrs = {"title": "Radiative flux profiles from the ecrad_amd MI355X radiation path", "source": "ecrad_amd"}
+    if experiment_name.strip():
+        attrs["experiment"] = experiment_name
+    write_nc(path, dims, v, attrs=attrs, double=is_double_precision)
+
+
+def get_sw_mapping(config: Config, wavelength_bound) -> np.ndarray:
+    """config%get_sw_mapping (radiation_config.F90:1766-1815): matrix (ninterval, nband) that turns the shortwave
+    fluxes of the bands (or g-points) into fluxes of user-specified wavelength intervals; the two extra rows of
+    calc_mapping_from_bands for wavelengths below the first and above the last bound are dropped."""
+    if config.n_bands_sw <= 0:
+        raise RuntimeError("get_sw_mapping called before number of shortwave bands set")
+    wb = np.asarray(wavelength_bound, dtype=np.float64)
+    ninterval = wb.size - 1
+    m = config.gas_optics_sw.spectral_def.calc_mapping_from_bands(
+        wb, np.arange(1, ninterval + 3), use_bands=not config.do_cloud_aerosol_per_sw_g_point)    # (nband, ninterval+2)
+    return np.ascontiguousarray(m[:, 1:ninterval + 1].T)
+
+
+def save_sw_diagnostics(path: str, config: Config, wavelength_bound, mapping: np.ndarray, flux: Flux,
+                        is_double_precision: bool = False, experiment_name: str = "") -> None:
+    """save_sw_diagnostics (radiation_save.F90:1314-1470): surface (and, with do_save_spectral_flux, TOA) shortwave
+    fluxes in user-specified wavelength intervals."""
+    wb = np.asarray(wavelength_bound, dtype=np.float64)
+    nwav = wb.size - 1
+    ncol = flux.sw_dn_surf_band.shape[0]
+    dims = {"column": ncol, "wavelength": nwav}
+    m = np.asarray(mapping)                                    # (nwav, nband)
+    to_wav = lambda band_flux: (("column", "wavelength"), np.ascontiguousarray(band_flux @ m.T))
+    v = {"wavelength1": (("wavelength",), wb[:nwav].copy()), "wavelength2": (("wavelength",), wb[1:nwav + 1].copy()),
+         "flux_dn_sw_surf": to_wav(flux.sw_dn_surf_band), "flux_dn_direct_sw_surf": to_wav(flux.sw_dn_direct_surf_band)}
+    if config.do_clear:
+        v["flux_dn_sw_surf_clear"] = to_wav(flux.sw_dn_surf_clear_band)
+        v["flux_dn_direct_sw_surf_clear"] = to_wav(flux.sw_dn_direct_surf_clear_band)
+    if flux.sw_up_band is not None:                            # numpy (nlev+1, ncol, nspec)
+        v["flux_up_sw_surf"] = to_wav(flux.sw_up_band[-1])
+        v["flux_up_sw_toa"] = to_wav(flux.sw_up_band[0])
+        v["flux_dn_sw_toa"] = to_wav(flux.sw_dn_band[0])
+        if flux.sw_up_clear_band is not None:
+            v["flux_up_sw_toa_clear"] = to_wav(flux.sw_up_clear_band[0])
+            v["flux_up_sw_surf_clear"] = to_wav(flux.sw_up_clear_band[-1])
+    attrs = {"title": "Shortwave spectral diagnostics from the ecrad_amd MI355X radiation path", "source": "ecrad_amd"}
+    if experiment_name.strip():
+        attrs["experiment"] = experiment_name
+    write_nc(path, dims, v, attrs=attrs, double=is_double_precision)
+
+
 def main(argv=None) -> int:
     from .interface import Radiation
     argv = sys.argv[1:] if argv is None else argv
@@ -322,6 +410,18 @@ def main(argv=None) -> int:
     config = Config.read(argv[0])
     dc = DriverConfig.read(argv[0])
     rad = Radiation(config)                      # setup_radiation
+    # shortwave diagnostics in user-specified intervals (driver/ecrad_driver.F90:211-222)
+    bounds = [float(b) for b in (dc.sw_diag_wavelength_bound or [])]
+    n_sw_diag = 0
+    for j, b in enumerate(bounds + [-1.0]):
+        if b < 0.0:
+            n_sw_diag = max(0, j - 1)
+            break
+    sw_diag_mapping = None
+    if n_sw_diag > 0:
+        if not config.do_surface_sw_spectral_flux:
+            raise SystemExit("Error: shortwave spectral diagnostics require do_surface_sw_spectral_flux=true")
+        sw_diag_mapping = get_sw_mapping(config, bounds[:n_sw_diag + 1])
     ncol, nlev, single_level, thermodynamics, gas, cloud, aerosol = read_input(argv[1], config, dc)
     iend = dc.iendcol if 1 <= dc.iendcol <= ncol else ncol
     istart = max(dc.istartcol, 1)
@@ -332,7 +432,14 @@ def main(argv=None) -> int:
     for _ in range(max(dc.nrepeat, 1)):
         rad.radiation(ncol, nlev, istart, iend, single_level, thermodynamics, gas, cloud, aerosol, flux)
     print(f"Time elapsed in radiative transfer: {time.perf_counter() - t0:12.5g} seconds")
-    save_fluxes(argv[2], config, thermodynamics, flux, is_double_precision=dc.do_write_double_precision)
+    if not dc.do_save_net_fluxes:                # driver/ecrad_driver.F90:398-417
+        save_fluxes(argv[2], config, thermodynamics, flux, is_double_precision=dc.do_write_double_precision)
+    else:
+        save_net_fluxes(argv[2], config, thermodynamics, flux, is_double_precision=dc.do_write_double_precision,
+                        experiment_name=dc.experiment_name)
+    if n_sw_diag > 0:
+        save_sw_diagnostics(dc.sw_diag_file_name, config, bounds[:n_sw_diag + 1], sw_diag_mapping, flux,
+                            is_double_precision=dc.do_write_double_precision, experiment_name=dc.experiment_name)
     return 0
 
 

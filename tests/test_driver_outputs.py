@@ -1,0 +1,86 @@
+"""The offline driver's other output files: save_net_fluxes (radiation_save.F90:464) and
+save_sw_diagnostics (:1314) with config%get_sw_mapping (radiation_config.F90:1766), through `python -m ecrad_amd.driver`
+pieces on the CPU with the oracle as the backend (the driver logic is host code; the GPU path has its own tests)."""
+import os
+
+import numpy as np
+
+from ecrad_amd.driver import get_sw_mapping, save_fluxes, save_net_fluxes, save_sw_diagnostics
+from ecrad_amd.ncfile import NcFile
+from helpers import make_config, rel_err, run_case
+
+
+def test_net_flux_file_has_the_references_variables(tmp_path, oracle_lib):
+    config = make_config("Tripleclouds", do_lw_derivatives=True, do_canopy_fluxes_sw=True, do_canopy_fluxes_lw=True)
+    flux, th, _ = run_case(config, oracle_lib.backend)
+    p = str(tmp_path / "net.nc")
+    save_net_fluxes(p, config, th, flux, is_double_precision=True, experiment_name="unit test")
+    with NcFile(p) as f:
+        names = set(f._f.variables)
+        want = {"pressure_hl", "flux_net_lw", "flux_dn_lw_surf", "flux_net_lw_clear", "flux_dn_lw_clear_surf", "lw_derivative",
+                "canopy_flux_dn_lw_surf", "flux_net_sw", "flux_dn_sw_surf", "flux_dn_sw_toa", "flux_dn_direct_sw_surf",
+                "flux_net_sw_clear", "flux_dn_sw_clear_surf", "flux_dn_direct_sw_clear_surf",
+                "canopy_flux_dn_diffuse_sw_surf", "canopy_flux_dn_direct_sw_surf"}
+        assert names == want
+        assert np.array_equal(f.get("flux_net_sw"), (flux.sw_dn - flux.sw_up).T)
+        assert np.array_equal(f.get("flux_net_lw_clear"), (flux.lw_dn_clear - flux.lw_up_clear).T)
+        assert np.array_equal(f.get("flux_dn_sw_toa"), flux.sw_dn[0])
+        assert np.array_equal(f.get("flux_dn_lw_surf"), flux.lw_dn[-1])
+        assert f.global_attr("experiment") == "unit test"
+    # and it carries the same information as the full file
+    p2 = str(tmp_path / "full.nc")
+    save_fluxes(p2, config, th, flux, is_double_precision=True)
+    with NcFile(p) as a, NcFile(p2) as b:
+        assert np.array_equal(a.get("flux_net_lw"), b.get("flux_dn_lw") - b.get("flux_up_lw"))
+
+
+def test_sw_diagnostics_partition_the_surface_flux(tmp_path, oracle_lib):
+    """Intervals that cover the whole shortwave spectrum must add up to the broadband surface fluxes; UV / visible / near
+    infrared bounds as in the reference's documentation of sw_diag_wavelength_bound."""
+    config = make_config("Tripleclouds", do_save_spectral_flux=True)
+    flux, th, _ = run_case(config, oracle_lib.backend)
+    bounds = [1.0e-7, 4.0e-7, 7.0e-7, 4.0e-6, 1.0e-3]
+    mapping = get_sw_mapping(config, bounds)
+    assert mapping.shape == (4, config.n_bands_sw)
+    assert np.all(mapping >= 0.0)
+    # every band's flux is shared out between the intervals (and the two discarded end intervals get next to nothing)
+    assert np.abs(mapping.sum(axis=0) - 1.0).max() < 1.0e-3
+    p = str(tmp_path / "sw_diag.nc")
+    save_sw_diagnostics(p, config, bounds, mapping, flux, is_double_precision=True)
+    with NcFile(p) as f:
+        assert np.array_equal(f.get("wavelength1"), np.array(bounds[:4]))
+        assert np.array_equal(f.get("wavelength2"), np.array(bounds[1:]))
+        day = flux.sw_dn[0] > 0
+        assert rel_err(f.get("flux_dn_sw_surf").sum(axis=1)[day], flux.sw_dn[-1][day]) < 2.0e-3
+        assert rel_err(f.get("flux_dn_direct_sw_surf").sum(axis=1)[day], flux.sw_dn_direct[-1][day]) < 2.0e-3
+        assert rel_err(f.get("flux_up_sw_toa").sum(axis=1)[day], flux.sw_up[0][day]) < 2.0e-3
+        assert rel_err(f.get("flux_dn_sw_surf_clear").sum(axis=1)[day], flux.sw_dn_clear[-1][day]) < 2.0e-3
+        for name in ("flux_up_sw_surf", "flux_dn_sw_toa", "flux_up_sw_toa_clear", "flux_up_sw_surf_clear", "flux_dn_direct_sw_surf_clear"):
+            assert f.exists(name), name
+        # the visible interval carries a large part of the surface flux under a high sun, the UV one little
+        vis = f.get("flux_dn_sw_surf")[:, 1]
+        uv = f.get("flux_dn_sw_surf")[:, 0]
+        assert np.all(uv[day] < vis[day])
+
+
+def test_driver_main_writes_net_fluxes_and_diagnostics(tmp_path, oracle_lib, monkeypatch):
+    """The namelist route: do_save_net_fluxes and sw_diag_wavelength_bound in &radiation_driver."""
+    from ecrad_amd import driver, interface
+    from helpers import MERIDIAN, NAMELIST
+    import re
+    nam = open(NAMELIST).read()
+    nam = re.sub(r"(?m)^\s*do_save_net_fluxes\s*=.*$", "", nam)        # (the test namelist sets it to false)
+    nam = nam.replace("&radiation_driver", "&radiation_driver\n do_save_net_fluxes = .true.,\n sw_diag_wavelength_bound = 2.0e-7, 7.0e-7, 5.0e-6,\n"
+                      f" sw_diag_file_name = \"{tmp_path}/diag.nc\",", 1)
+    from helpers import DATA_DIR
+    nam = re.sub(r'directory_name\s*=\s*"[^"]*"', f'directory_name = "{DATA_DIR}"', nam)
+    cfg = tmp_path / "config.nam"
+    cfg.write_text(nam)
+    real = interface.Radiation
+    monkeypatch.setattr(interface, "Radiation", lambda config, **kw: real(config, backend=oracle_lib.backend))
+    out = str(tmp_path / "out.nc")
+    assert driver.main([str(cfg), MERIDIAN, out]) == 0
+    with NcFile(out) as f:
+        assert f.exists("flux_net_sw") and not f.exists("flux_up_sw")
+    with NcFile(str(tmp_path / "diag.nc")) as f:
+        assert f.get("flux_dn_sw_surf").shape == (32, 2)
