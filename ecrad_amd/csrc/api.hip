@@ -1058,9 +1058,9 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
   const bool sp_single = c.i_precision == ECRAD_PRECISION_SINGLE;
   // (the SPARTACUS kernels run one block per CU: one wave per SIMD with the whole register file)
   // (the SPARTACUS sweeps run two blocks per CU in single precision, one in double; the list walk one block per CU)
-  auto grid_sp = [&](int ngp) { const int groups = (r.nloc + kBlock / ngp - 1) / (kBlock / ngp); const int m = h->num_cu * (sp_single ? 2 : 1); return groups < m ? groups : m; };
-  const int grid_sw = !c.do_sw ? 0 : sw_sp ? grid_sp(h->ngp_sw) : grid_for(h, r.nloc, h->ngp_sw);
-  const int grid_lw = !c.do_lw ? 0 : lw_sp ? grid_sp(h->ngp_lw) : grid_for(h, r.nloc, h->ngp_lw);
+  auto grid_sp = [&](int ngp, bool is_sw) { const int groups = (r.nloc + kBlock / ngp - 1) / (kBlock / ngp); const int m = h->num_cu * spartacus_sweep_blocks_per_cu(sp_single, is_sw); return groups < m ? groups : m; };
+  const int grid_sw = !c.do_sw ? 0 : sw_sp ? grid_sp(h->ngp_sw, true) : grid_for(h, r.nloc, h->ngp_sw);
+  const int grid_lw = !c.do_lw ? 0 : lw_sp ? grid_sp(h->ngp_lw, false) : grid_for(h, r.nloc, h->ngp_lw);
   const size_t sp_word = sp_single ? 4 : 8;
   const size_t per_block_sw = !c.do_sw ? 0 : sw_sp ? (spartacus_scratch_words(true, nlev) * sp_word + 7) / 8
                                            : (sw_tc ? sw_tc_scratch_doubles(nlev) : sw_ica_scratch_doubles(c.i_solver_sw, nlev));

@@ -32,6 +32,15 @@
 #include "launch.h"
 #include "spartacus_device.h"
 
+// waves per SIMD of the single-precision sweep kernels (measured on 100 000 columns: SW 2 -> 59 ms, 3 -> 81 ms with
+// 416 B of spills per lane; LW 2 -> 51 ms, 3 -> 45 ms, 4 -> 53 ms)
+#ifndef ECRAD_SP_SWEEP_WAVES_SW
+#define ECRAD_SP_SWEEP_WAVES_SW 2
+#endif
+#ifndef ECRAD_SP_SWEEP_WAVES_LW
+#define ECRAD_SP_SWEEP_WAVES_LW 3
+#endif
+
 namespace ecrad {
 
 using sp::M3;
@@ -479,7 +488,7 @@ ECRAD_DEV SwMats<R> sw_layer(const SpArgs& a, const Geo& gm, const LevelOrder& o
 //  solver_spartacus_sw
 // =====================================================================================================================
 template <typename R, int NGP>
-__global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? 2 : 1) void spartacus_sw_kernel(SpArgs args_in_kernarg) {
+__global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 1) void spartacus_sw_kernel(SpArgs args_in_kernarg) {
   __shared__ int next_group;
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
@@ -537,6 +546,11 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? 2 : 1) void spartacus_sw_k
     V3<R> x_diffuse, x_direct;
     x_diffuse.zero(); x_direct.zero();
 
+    double pf_od, pf_ssa, pf_g;
+    {
+      const size_t o = g + (size_t)ng * (nlev - 1 + (size_t)nlev * cloc);
+      pf_od = a.op.od_sw[o]; pf_ssa = a.op.ssa_sw[o]; pf_g = a.op.g_sw ? a.op.g_sw[o] : 0.0;
+    }
     for (int jlev = nlev; jlev >= 1; --jlev) {
       const int jl = jlev - 1;
       const bool clr = !cm.test(jl);
@@ -545,9 +559,13 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? 2 : 1) void spartacus_sw_k
       if (!sun_up) continue;
       // -- section 3: clear-sky (region 1) two-stream coefficients in line; matrices of the listed layers from HBM --
       SwLayer<R> cl{R(0), R(0), R(0), R(0), R(0)};
+      // (the stage values of the layer above are requested one iteration ahead: the loop is a chain of dependent latencies)
+      const R odl = R(pf_od), ssal = R(pf_ssa), gl = R(pf_g);
+      if (jl > 0) {
+        const size_t o = g + (size_t)ng * (jl - 1 + (size_t)nlev * cloc);
+        pf_od = a.op.od_sw[o]; pf_ssa = a.op.ssa_sw[o]; pf_g = a.op.g_sw ? a.op.g_sw[o] : 0.0;
+      }
       if (do_clear || !listed) {
-        const size_t o = g + (size_t)ng * (jl + (size_t)nlev * cloc);
-        const R odl = R(a.op.od_sw[o]), ssal = R(a.op.ssa_sw[o]), gl = R(a.op.g_sw ? a.op.g_sw[o] : 0.0);
         R g1, g2, g3;
         gammas_sw(mu0, ssal, gl, g1, g2, g3);
         cl = ref_trans_sw<R>(mu0, odl, ssal, g1, g2, g3);
@@ -989,7 +1007,7 @@ enum { LW_REFC = 0, LW_TRAC, LW_SDNC, LW_TAC, LW_TSC,                 // clear-s
 }
 
 template <typename R, int NGP>
-__global__ __launch_bounds__(kBlock, 2) void spartacus_lw_kernel(SpArgs args_in_kernarg) {
+__global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 2) void spartacus_lw_kernel(SpArgs args_in_kernarg) {
   __shared__ int next_group;
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
@@ -1036,6 +1054,13 @@ __global__ __launch_bounds__(kBlock, 2) void spartacus_lw_kernel(SpArgs args_in_
 #pragma unroll
     for (int r = 0; r < 3; ++r) { ta(r, r) = alb; ts.a[r] = R(gm.rf(r, nlev - 1)) * emis; }
     R ta_clear = alb, ts_clear = emis;
+    double pf_od, pf_pt, pf_pb, pf_ssa = 0.0, pf_g = 0.0;
+    {
+      const size_t o = g + (size_t)ng * (nlev - 1 + (size_t)nlev * cloc);
+      const size_t op = g + (size_t)ng * (nlev - 1 + (size_t)(nlev + 1) * cloc);
+      pf_od = a.op.od_lw[o]; pf_pt = a.op.planck_hl[op]; pf_pb = a.op.planck_hl[op + ng];
+      if (c.do_lw_aerosol_scattering) { pf_ssa = a.op.ssa_lw[o]; pf_g = a.op.g_lw[o]; }
+    }
     for (int jlev = nlev; jlev >= 1; --jlev) {
       const int jl = jlev - 1;
       const bool clr = !cm.test(jl);
@@ -1043,13 +1068,19 @@ __global__ __launch_bounds__(kBlock, 2) void spartacus_lw_kernel(SpArgs args_in_
       const bool listed = !clr || c.use_expm_everywhere != 0;      // its matrices come from spartacus_layers_kernel
       // -- section 3: clear-sky (region 1) two-stream coefficients in line; matrices of the listed layers from HBM --
       LwLayer<R> cl{R(0), R(0), R(0), R(0)};
+      // (stage values of the layer above requested one iteration ahead; its lower Planck value is this layer's upper one)
+      const R od0 = R(pf_od), pt0 = R(pf_pt), pb0 = R(pf_pb), ssa0 = R(pf_ssa), g0 = R(pf_g);
+      if (jl > 0) {
+        const size_t o = g + (size_t)ng * (jl - 1 + (size_t)nlev * cloc);
+        pf_od = a.op.od_lw[o];
+        pf_pb = pf_pt;
+        pf_pt = a.op.planck_hl[g + (size_t)ng * (jl - 1 + (size_t)(nlev + 1) * cloc)];
+        if (c.do_lw_aerosol_scattering) { pf_ssa = a.op.ssa_lw[o]; pf_g = a.op.g_lw[o]; }
+      }
       if (do_clear || !listed) {
-        const size_t o = g + (size_t)ng * (jl + (size_t)nlev * cloc);
-        const size_t op = g + (size_t)ng * (jl + (size_t)(nlev + 1) * cloc);
-        R ssa0 = R(0), g0 = R(0), g1, g2;
-        if (c.do_lw_aerosol_scattering) { ssa0 = R(a.op.ssa_lw[o]); g0 = R(a.op.g_lw[o]); }
+        R g1, g2;
         gammas_lw(ssa0, g0, g1, g2);
-        cl = ref_trans_lw<R>(R(a.op.od_lw[o]), g1, g2, R(a.op.planck_hl[op]), R(a.op.planck_hl[op + ng]));
+        cl = ref_trans_lw<R>(od0, g1, g2, pt0, pb0);
       }
       M3<R> refl, tran;
       V3<R> source_up, source_dn;
@@ -1318,6 +1349,7 @@ __global__ __launch_bounds__(kBlock, 1) void spartacus_layers_kernel(SpArgs args
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 size_t spartacus_scratch_words(bool is_sw, int nlev) { return (size_t)nlev * (is_sw ? SW_NSLOT : LW_NSLOT) * kBlock; }
+int spartacus_sweep_blocks_per_cu(bool single, bool is_sw) { return single ? (is_sw ? ECRAD_SP_SWEEP_WAVES_SW : ECRAD_SP_SWEEP_WAVES_LW) : (is_sw ? 1 : 2); }
 size_t spartacus_layer_words(bool is_sw, int ng) { return (size_t)(is_sw ? 45 : 24) * ng; }    // per (column, layer)
 
 // `grid_layers` blocks for the list walk (one block per CU), `grid` for the sweeps; `lay`: spartacus_layer_words x nlev x

@@ -61,6 +61,7 @@ hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, siz
 // matrices per (column, layer); the launch of one spectrum (work list, layer matrices, the two sweeps)
 size_t spartacus_scratch_words(bool is_sw, int nlev);
 size_t spartacus_layer_words(bool is_sw, int ng);
+int spartacus_sweep_blocks_per_cu(bool single, bool is_sw);
 hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, int grid_layers, hipStream_t st, const ecrad_config_t& c,
                             const DevInputs& in, const DevOptics& op, const DevCloudPrep& prep, const DevFlux& fx, void* scratch,
                             size_t per_block_words, int* counter, const int32_t* d_i_band_from_reordered_g, void* lay, uint32_t* list,

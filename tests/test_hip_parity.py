@@ -25,6 +25,7 @@ CASES = {
     "mcica_aer": dict(sw_solver="McICA"),
     "mcica_noaer": dict(sw_solver="McICA", use_aerosols=False),
     "mcica_maxran": dict(sw_solver="McICA", i_overlap_scheme=0),
+    "mcica_lognormal": dict(sw_solver="McICA", i_cloud_pdf_shape=0),          # data/mcica_lognormal.nc
     "mcica_expexp": dict(sw_solver="McICA", i_overlap_scheme=2),
     "mcica_vectorizable": dict(sw_solver="McICA", use_vectorizable_generator=True),
     "mcica_vectorizable_maxran_beta": dict(sw_solver="McICA", use_vectorizable_generator=True, i_overlap_scheme=0),
@@ -348,12 +349,14 @@ def test_crop_cloud_fraction_side_effect_matches(oracle_lib):
     rad.close()
 
 
-def test_stage_intermediates_match_oracle(oracle_lib):
-    """od/ssa/g, Planck, albedos, cloud optics: the arrays radiation() passes between stages."""
+@pytest.mark.parametrize("lw_aerosol_scattering", [False, True])
+def test_stage_intermediates_match_oracle(oracle_lib, lw_aerosol_scattering):
+    """od/ssa/g, Planck, albedos, cloud optics: the arrays radiation() passes between stages.  ssa_lw and g_lw exist only
+    with longwave aerosol scattering (radiation_interface.F90:268-275)."""
     import ctypes as C
     from ecrad_amd import abi
     from ecrad_amd.interface import Radiation, build_inputs_struct
-    config = make_config("Tripleclouds")
+    config = make_config("Tripleclouds", do_lw_aerosol_scattering=lw_aerosol_scattering)
     rad = Radiation(config, backend="hip")
     ncol, nlev, sl, th, gas, cloud, aer = load_meridian(config)
     rad.set_gas_units(gas)
@@ -368,7 +371,9 @@ def test_stage_intermediates_match_oracle(oracle_lib):
     st = rad.lib.ecrad_hip_optics(rad.handle, ncol, nlev, 1, ncol, C.byref(cin), C.byref(out))
     assert st == 0, rad.lib.ecrad_hip_last_error(rad.handle)
     for k in got:
-        if k in ("ssa_lw", "g_lw"):
+        if k in ("ssa_lw", "g_lw") and not lw_aerosol_scattering:
             continue
+        if k in ("ssa_lw", "g_lw"):
+            assert np.abs(want[k]).max() > 0.0
         assert rel_err(got[k], want[k], floor_frac=1e-9) < 1e-10, k
     rad.close()

@@ -8,7 +8,7 @@ extra="$*"
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=$root/build_variants/$name
 mkdir -p $out
-src="api kernel_ica_sw kernel_ica_lw kernel_lw_scat kernel_tc kernel_prep kernel_optics"
+src="api kernel_ica_sw kernel_ica_lw kernel_lw_scat kernel_tc kernel_prep kernel_optics kernel_rrtmg kernel_spartacus"
 for f in $src; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $extra -c $root/ecrad_amd/csrc/$f.hip -o $out/$f.o &
 done
