@@ -118,7 +118,8 @@ BENCH_CONFIGS = {
     "mcica_rrtmg": dict(sw_solver="McICA", use_aerosols=True, clear_sky=False, rrtmg=True, do_lw_aerosol_scattering=False),
     "mcica_rrtmg_noaer": dict(sw_solver="McICA", use_aerosols=False, clear_sky=False, rrtmg=True, do_lw_aerosol_scattering=False),
     # BASELINE configs[4]: ecCKD-32, SPARTACUS (3 regions, 3-D effects, explicit entrapment), single precision
-    "spartacus_ecckd32_sp": dict(sw_solver="SPARTACUS", use_aerosols=True, clear_sky=False, i_precision=1),
-    "spartacus_ecckd32_dp": dict(sw_solver="SPARTACUS", use_aerosols=True, clear_sky=False),
+    # (do_3d_effects is spelt out: the test namelist the configurations start from switches it off)
+    "spartacus_ecckd32_sp": dict(sw_solver="SPARTACUS", use_aerosols=True, clear_sky=False, i_precision=1, do_3d_effects=True),
+    "spartacus_ecckd32_dp": dict(sw_solver="SPARTACUS", use_aerosols=True, clear_sky=False, do_3d_effects=True),
     "tripleclouds_rrtmg": dict(sw_solver="Tripleclouds", use_aerosols=True, clear_sky=False, rrtmg=True, do_lw_aerosol_scattering=False),
 }

@@ -10,6 +10,7 @@
  * libecrad_oracle_sp.so, BASELINE configs[4]: PARKIND1_SINGLE semantics, jprb = float).
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "oracle_matrix.h"

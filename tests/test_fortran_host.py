@@ -69,7 +69,7 @@ def test_fortran_driver_matches_oracle(tmp_path, oracle_lib, solver, nblocksize)
 @pytest.mark.gpu
 @pytest.mark.parametrize("kw", [
     dict(sw_solver="Tripleclouds", do_toa_spectral_flux=True, do_nearest_spectral_sw_albedo=True, do_nearest_spectral_lw_emiss=True),
-    dict(sw_solver="SPARTACUS", max_cloud_od=12.0, do_lw_derivatives=True),
+    dict(sw_solver="SPARTACUS", max_cloud_od=12.0, do_lw_derivatives=True, do_3d_effects=True),
     dict(sw_solver="McICA", do_lw_aerosol_scattering=True, use_beta_overlap=True),
 ], ids=["toa_spectral_nearest", "spartacus_max_cloud_od", "mcica_lw_aerosol_scattering"])
 def test_fortran_driver_forwards_the_whole_configuration(tmp_path, oracle_lib, kw):

@@ -47,7 +47,8 @@ CASES = {
 
 
 def _config(**kw):
-    return make_config("SPARTACUS", do_lw_derivatives=True, **kw)
+    # (the reference's test namelist switches the 3-D effects off: every case here asks for them unless it says otherwise)
+    return make_config("SPARTACUS", **{**dict(do_lw_derivatives=True, do_3d_effects=True), **kw})
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -59,11 +60,21 @@ def test_spartacus_matches_oracle(name, oracle_lib):
     compare_flux(f_hip, f_ora, TOL)
 
 
+def test_the_3d_effects_are_on_in_these_cases(oracle_lib):
+    """Guard: the cases must exercise the matrix exponentials (a configuration read from the test namelist has them off)."""
+    assert _config().do_3d_effects and not _config(do_3d_effects=False).do_3d_effects
+    a, _, _ = run_case(_config(), oracle_lib.backend)
+    b, _, _ = run_case(_config(do_3d_effects=False), oracle_lib.backend)
+    day = a.arrays["sw_dn"][0] > 0
+    assert np.abs(a.arrays["sw_up"][0][day] - b.arrays["sw_up"][0][day]).max() > 0.5       # W m-2
+    assert np.abs(a.arrays["lw_up"][0] - b.arrays["lw_up"][0]).max() > 0.05
+
+
 def test_spartacus_shortwave_with_another_longwave_solver(oracle_lib):
     """The two spectra choose their solvers independently (radiation_interface.F90:422-499)."""
     for sw, lw in (("SPARTACUS", "Tripleclouds"), ("Tripleclouds", "SPARTACUS"), ("SPARTACUS", "McICA")):
-        f_ora, _, _ = run_case(make_config(sw, lw), oracle_lib.backend)
-        f_hip, _, _ = run_case(make_config(sw, lw), "hip")
+        f_ora, _, _ = run_case(make_config(sw, lw, do_3d_effects=True), oracle_lib.backend)
+        f_hip, _, _ = run_case(make_config(sw, lw, do_3d_effects=True), "hip")
         compare_flux(f_hip, f_ora, TOL)
 
 
@@ -90,20 +101,43 @@ def test_spartacus_column_subrange_and_surface_first_levels(oracle_lib):
         assert rel_err(f_rev.arrays[name], f_all.arrays[name]) < TOL, name
 
 
+STABLE_IN_SINGLE = ("sw_", "lw_up_clear", "lw_dn_clear", "lw_dn_surf_clear_g", "lw_up_toa_clear_g", "cloud_cover")
+
+
 @pytest.mark.parametrize("name", ["explicit", "maximum", "no_3d", "lw_multilayer"])
 def test_spartacus_single_precision(name, oracle_lib):
+    """i_precision = single is the reference's PARKIND1_SINGLE build of the solver, instabilities included: with 3-D effects
+    the LONGWAVE solver solves 6x6 systems with the (nearly singular, for optically thin g-points) exponent matrix by
+    unpivoted LU and subtracts the huge particular solutions again (radiation_spartacus_lw.F90:700-740); in float that
+    is chaotic -- the reference only warns (radiation_config.F90:1144).  The oracle's single-precision build shows it: a few
+    per cent of the all-sky longwave values are off by more than 1e-3 and change completely when only floating-point
+    contraction changes.  So: everything is checked against the single-precision oracle within that oracle's own
+    last-bit sensitivity, element by element; the shortwave and the clear-sky longwave (stable) must also be as close to
+    the double-precision answer (2e-3: float rounding through the 9x9 exponential and the unpivoted solves); and where the 3-D effects are off, so
+    must the all-sky longwave."""
     kw = dict(CASES[name], i_precision=IPrecisionSingle)
     f_dp, _, _ = run_case(_config(**CASES[name]), oracle_lib.backend)
     f_sp, _, _ = run_case(_config(**kw), oracle_lib.make_variant_backend("sp"))
     f_sp_fma, _, _ = run_case(_config(**kw), oracle_lib.make_variant_backend("sp_fma"))
     f_hip, _, _ = run_case(_config(**kw), "hip")
-    report = {}
+    chaotic = _config(**kw).do_3d_effects
     for k, a in f_hip.arrays.items():
-        assert np.all(np.isfinite(a)), k
-        sens = rel_err(f_sp_fma.arrays[k], f_sp.arrays[k])
-        got = rel_err(a, f_sp.arrays[k])
-        report[k] = (got, sens)
-        assert got <= max(4.0 * sens, 2.0e-6), (k, got, sens)
-        assert rel_err(a, f_dp.arrays[k]) < (2.0e-3 if k != "lw_derivatives" else 2.0e-2), k
-    worst = max(report, key=lambda k: report[k][0])
-    print(f"{name}: worst {worst} HIP-vs-oracle(sp) {report[worst][0]:.2e}, oracle(sp) fma-vs-plain {report[worst][1]:.2e}")
+        ref, alt, dp = f_sp.arrays[k], f_sp_fma.arrays[k], f_dp.arrays[k]
+        scale = np.maximum(np.abs(dp), 1.0e-3 * np.abs(dp).max() + 1.0e-300)
+        sens = np.abs(alt - ref) / scale                      # what the oracle itself does when its last bits change
+        got = np.abs(a - ref) / scale
+        stable = k.startswith(STABLE_IN_SINGLE) or not chaotic
+        if stable:
+            assert np.all(np.isfinite(a)), k
+            assert got.max() <= max(4.0 * sens.max(), 5.0e-6), (k, got.max(), sens.max())
+            assert (np.abs(a - dp) / scale).max() < 2.0e-3, k      # float rounding through the 9x9 exponential and the unpivoted solves
+        else:
+            # element by element: within the oracle's own sensitivity there, and tight wherever the oracle is stable
+            calm = sens < 1.0e-5
+            assert calm.mean() > 0.8, (k, calm.mean())
+            ok = np.isfinite(a[calm])
+            assert ok.all(), k
+            assert np.median(got[calm]) < 2.0e-6, (k, np.median(got[calm]))
+            assert (got[calm] <= 1.0e-3).mean() > 0.999, (k, (got[calm] > 1.0e-3).mean())
+    off = np.abs(f_sp.arrays["lw_up"] - f_dp.arrays["lw_up"]) / f_dp.arrays["lw_up"] > 1.0e-3
+    print(f"{name}: single-precision ORACLE, all-sky lw_up off by more than 1e-3 from double in {100.0 * off.mean():.2f} % of the values")
