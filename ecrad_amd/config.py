@@ -22,9 +22,9 @@ IGasModelMonochromatic, IGasModelIFSRRTMG, IGasModelECCKD = range(3)
 OVERLAP_NAMES = ["Max-Ran", "Exp-Ran", "Exp-Exp"]
 IOverlapMaximumRandom, IOverlapExponentialRandom, IOverlapExponential = range(3)
 LIQUID_MODEL_NAMES = ["Monochromatic", "SOCRATES", "Slingo", "Jahangir", "Nielsen"]     # radiation_config.F90:109-116
-ILiquidModelMonochromatic, ILiquidModelSOCRATES, ILiquidModelSlingo = range(3)
+ILiquidModelMonochromatic, ILiquidModelSOCRATES, ILiquidModelSlingo, ILiquidModelJahangir, ILiquidModelNielsen = range(5)
 ICE_MODEL_NAMES = ["Monochromatic", "Fu-IFS", "Baran-EXPERIMENTAL", "Baran2016", "Baran2017", "Yi"]   # :124-133
-IIceModelMonochromatic, IIceModelFu, IIceModelBaran = range(3)
+IIceModelMonochromatic, IIceModelFu, IIceModelBaran, IIceModelBaran2016, IIceModelBaran2017, IIceModelYi = range(6)
 ENTRAPMENT_NAMES = ["Zero", "Edge-only", "Explicit", "Non-fractal", "Maximum"]        # :72-86
 ENCROACHMENT_NAMES = ["Zero", "Minimum", "Fractal", "Computed", "Maximum"]             # :90-94 (deprecated spelling)
 (IEntrapmentZero, IEntrapmentEdgeOnly, IEntrapmentExplicit, IEntrapmentExplicitNonFractal,
@@ -280,10 +280,18 @@ class Config:
                 self.gas_optics_lw_override_file_name, "ecckd-1.0_lw_climate_fsck-32b_ckd-definition.nc")
         # radiation_config.F90:1243-1290: optics files of the band-fit cloud schemes
         if not self.use_general_cloud_optics:
-            if self.i_liq_model != ILiquidModelSOCRATES or self.i_ice_model != IIceModelFu:
-                raise ConfigError("band cloud optics: only liquid_model_name='SOCRATES' with ice_model_name='Fu-IFS' is implemented")
-            self.liq_optics_file_name = self._data_path(self.liq_optics_override_file_name, "socrates_droplet_scattering_rrtm.nc")
-            self.ice_optics_file_name = self._data_path(self.ice_optics_override_file_name, "fu_ice_scattering_rrtm.nc")
+            # (the reference's cloud_optics has no branch for the Jahangir and Nielsen liquid models either,
+            #  radiation_cloud_optics.F90:325-347, and ships no coefficient files for them)
+            liq = {ILiquidModelSOCRATES: "socrates_droplet_scattering_rrtm.nc", ILiquidModelSlingo: "slingo_droplet_scattering_rrtm.nc"}
+            ice = {IIceModelFu: "fu_ice_scattering_rrtm.nc", IIceModelBaran: "baran_ice_scattering_rrtm.nc",
+                   IIceModelBaran2016: "baran2016_ice_scattering_rrtm.nc", IIceModelBaran2017: "baran2017_ice_scattering_rrtm.nc",
+                   IIceModelYi: "yi_ice_scattering_rrtm.nc"}
+            if self.i_liq_model not in liq:
+                raise ConfigError(f"band cloud optics: liquid_model_name='{LIQUID_MODEL_NAMES[self.i_liq_model]}' is not implemented")
+            if self.i_ice_model not in ice:
+                raise ConfigError(f"band cloud optics: ice_model_name='{ICE_MODEL_NAMES[self.i_ice_model]}' is not implemented")
+            self.liq_optics_file_name = self._data_path(self.liq_optics_override_file_name, liq[self.i_liq_model])
+            self.ice_optics_file_name = self._data_path(self.ice_optics_override_file_name, ice[self.i_ice_model])
         if self.use_spectral_solar_cycle:
             raise ConfigError("use_spectral_solar_cycle is not supported by this build")
         self.aerosol_optics_file_name = self._data_path(

@@ -474,13 +474,28 @@ int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
     if (a.use_hydrophilic && c.do_lw && a.n_type_philic > 0 && (!a.mass_ext_lw_philic || !a.ssa_lw_philic || !a.g_lw_philic)) return fail(h, ECRAD_EINVAL, "aerosol optics: longwave hydrophilic tables missing");
   }
   if (c.do_clouds && !c.use_general_cloud_optics) {
-    if (c.i_liq_model != ECRAD_LIQUID_SOCRATES || c.i_ice_model != ECRAD_ICE_FU) return fail(h, ECRAD_EUNSUPPORTED, "band cloud optics: only the SOCRATES liquid and Fu ice models are implemented");
+    // the schemes radiation_cloud_optics.F90:325-470 has a branch for
+    if (c.i_liq_model != ECRAD_LIQUID_SOCRATES && c.i_liq_model != ECRAD_LIQUID_SLINGO)
+      return fail(h, ECRAD_EUNSUPPORTED, "band cloud optics: unknown liquid model (implemented: SOCRATES, Slingo)");
+    if (c.i_ice_model < ECRAD_ICE_FU || c.i_ice_model > ECRAD_ICE_YI)
+      return fail(h, ECRAD_EUNSUPPORTED, "band cloud optics: unknown ice model (implemented: Fu-IFS, Baran, Baran2016, Baran2017, Yi)");
     if (c.n_cloud_types != 2) return fail(h, ECRAD_EINVAL, "band cloud optics need exactly two cloud types (liquid, ice)");
     for (int s = 0; s < 2; ++s) {
       if (!(s ? c.do_lw : c.do_sw)) continue;
       const ecrad_cloud_optics_t* co = s ? c.cloud_optics_lw : c.cloud_optics_sw;
-      if (co[0].n_effective_radius != 16 || co[1].n_effective_radius != (s ? 11 : 10))
-        return fail(h, ECRAD_EINVAL, "band cloud optics: wrong number of coefficients (SOCRATES 16, Fu 10 shortwave / 11 longwave)");
+      // numbers of coefficients: radiation_cloud_optics.F90:84-213
+      const int want_liq = c.i_liq_model == ECRAD_LIQUID_SOCRATES ? 16 : (s ? 13 : 6);
+      int want_ice = 0;
+      switch (c.i_ice_model) {
+        case ECRAD_ICE_FU: want_ice = s ? 11 : 10; break;
+        case ECRAD_ICE_BARAN: case ECRAD_ICE_BARAN2017: want_ice = 9; break;
+        case ECRAD_ICE_BARAN2016: want_ice = 5; break;
+        default: want_ice = 69; break;
+      }
+      if (co[0].n_effective_radius != want_liq || co[1].n_effective_radius != want_ice)
+        return fail(h, ECRAD_EINVAL, "band cloud optics: number of optical coefficients does not match number expected");
+      if (c.i_ice_model == ECRAD_ICE_BARAN2017 && (!co[2].mass_ext || co[2].n_effective_radius != 5 || co[2].n_bands != 1))
+        return fail(h, ECRAD_EINVAL, "coeff_gen needed for Baran-2017 ice optics parameterization");   // radiation_cloud_optics.F90:192
     }
     if ((c.do_sw && c.i_gas_model_sw == ECRAD_GAS_ECCKD) || (c.do_lw && c.i_gas_model_lw == ECRAD_GAS_ECCKD))
       return fail(h, ECRAD_EINVAL, "ecCKD gas optics requires use_general_cloud_optics");   // radiation_config.F90
@@ -656,6 +671,15 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
   d.gas_mmr = (h->rrtmg_sw || h->rrtmg_lw) ? 1 : 0;
   d.cloud_fit = (c.do_clouds && !c.use_general_cloud_optics) ? 1 : 0;
   d.fu_lw_bug = c.do_fu_lw_ice_optics_bug;
+  d.i_liq_model = c.i_liq_model; d.i_ice_model = c.i_ice_model;
+  if (d.cloud_fit && c.i_ice_model == ECRAD_ICE_BARAN2017)      // slot [2]: the five band-independent coefficients
+    for (int pass = 0; pass < 2; ++pass) {
+      if ((pass == 0 && !c.do_sw) || (pass == 1 && !c.do_lw)) continue;
+      const ecrad_cloud_optics_t& s = pass == 0 ? c.cloud_optics_sw[2] : c.cloud_optics_lw[2];
+      DevCloudOptics& o = pass == 0 ? d.cloud_sw[2] : d.cloud_lw[2];
+      o.n_bands = 1; o.n_effective_radius = 5;
+      if ((st = upload<double>(h, s.mass_ext, 5, &o.mass_ext))) return st;
+    }
   if ((h->rrtmg_sw || h->rrtmg_lw) && (st = setup_rrtmg(h, c))) return st;
   if (c.do_clouds) {
     for (int t = 0; t < c.n_cloud_types; ++t) {

@@ -100,6 +100,7 @@ struct DevConfig {
   // cloud optics from per-band fits in effective radius (SOCRATES liquid, Fu ice: radiation_cloud_optics.F90) instead
   // of the general look-up tables; cloud_sw/lw[0] = liquid, [1] = ice, their mass_ext = coefficients (n_bands, ncoeff)
   int32_t cloud_fit, fu_lw_bug;
+  int32_t i_liq_model, i_ice_model;   // ECRAD_LIQUID_*, ECRAD_ICE_* (band fits only)
   int32_t pad2_;             // gas%mixing_ratio holds MASS mixing ratios (RRTMG) instead of volume mixing ratios (ecCKD)
   double cloud_fraction_threshold, cloud_mixing_ratio_threshold, cloud_inhom_decorr_scaling;
   const int32_t *i_band_from_reordered_g_sw, *i_band_from_reordered_g_lw;

@@ -37,6 +37,7 @@ struct LdsLayout {
   ECRAD_DEV int f_wp(int t) const { return F_QMULT + nquad + 3 * t; }
   ECRAD_DEV int f_rew(int t) const { return F_QMULT + nquad + 3 * t + 1; }
   ECRAD_DEV int i_re(int t) const { return 2 * (F_QMULT + nquad + 3 * t + 2); }
+  ECRAD_DEV int f_aux(int t) const { return F_QMULT + nquad + 3 * t + 2; }     // the same slot as a double (band fits: free)
   // (nquad here is the model's count rounded up to even)
 };
 
@@ -177,6 +178,12 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
       L.D(L.f_wp(t), slot) = water_path;
       L.D(L.f_rew(t), slot) = cfg.cloud_fit ? re : re_index - ire;      // the band fits take the radius itself
       L.I(L.i_re(t), slot) = ire - 1;
+      if (cfg.cloud_fit && t == 1 && cfg.i_ice_model >= ECRAD_ICE_BARAN && cfg.i_ice_model <= ECRAD_ICE_BARAN2017) {
+        // the Baran schemes are functions of the grid-mean ice mixing ratio and the layer temperature, not of a radius
+        // (radiation_cloud_optics.F90:366-405)
+        L.D(L.f_rew(t), slot) = mr;
+        L.D(L.f_aux(t), slot) = 0.5 * (in.temperature_hl[col + ncol * ord.half(lev)] + in.temperature_hl[col + ncol * ord.half(lev + 1)]);
+      }
     }
   }
   L.D(F_FRAC, slot) = frac;
@@ -517,11 +524,28 @@ ECRAD_DEV CloudLayer cloud_layer_fit(const DevConfig& cfg, const LdsLayout& L, i
   if (lwp > 0.0) {
     const double* __restrict__ k = liq.mass_ext + ib;
 #define KL(j) k[(size_t)nb * ((j) - 1)]
-    // MinEffectiveRadius / MaxEffectiveRadius are default-real literals in the reference
-    const double re = dmax((double)1.2e-6f, dmin(L.D(L.f_rew(0), slot), (double)50.0e-6f));
-    od_l = lwp * (KL(1) + re * (KL(2) + re * KL(3))) / (1.0 + re * (KL(4) + re * (KL(5) + re * KL(6))));
-    sc_l = od_l * (1.0 - (KL(7) + re * (KL(8) + re * KL(9))) / (1.0 + re * (KL(10) + re * KL(11))));
-    g_l = (KL(12) + re * (KL(13) + re * KL(14))) / (1.0 + re * (KL(15) + re * KL(16)));
+    if (cfg.i_liq_model == ECRAD_LIQUID_SLINGO) {
+      const double lwp_gm_2 = lwp * 1000.0;
+      if (IS_SW) {      // calc_liq_optics_slingo, radiation_liquid_optics_slingo.F90:36-60
+        const double re_um = dmin(dmax(4.2, L.D(L.f_rew(0), slot) * 1.0e6), 16.6);
+        const double inv_re_um = 1.0 / re_um;
+        od_l = lwp_gm_2 * (KL(1) + inv_re_um * KL(2));
+        sc_l = od_l * (1.0 - KL(3) - re_um * KL(4));
+        g_l = KL(5) + re_um * KL(6);
+      } else {          // calc_liq_optics_lindner_li, :68-104
+        const double re_um = dmin(dmax(2.0, L.D(L.f_rew(0), slot) * 1.0e6), 40.0);
+        const double inv_re_um = 1.0 / re_um;
+        od_l = lwp_gm_2 * (KL(1) + re_um * KL(2) + inv_re_um * (KL(3) + inv_re_um * (KL(4) + inv_re_um * KL(5))));
+        sc_l = od_l * (1.0 - (KL(6) + inv_re_um * KL(7) + re_um * (KL(8) + re_um * KL(9))));
+        g_l = KL(10) + inv_re_um * KL(11) + re_um * (KL(12) + re_um * KL(13));
+      }
+    } else {
+      // MinEffectiveRadius / MaxEffectiveRadius are default-real literals in the reference
+      const double re = dmax((double)1.2e-6f, dmin(L.D(L.f_rew(0), slot), (double)50.0e-6f));
+      od_l = lwp * (KL(1) + re * (KL(2) + re * KL(3))) / (1.0 + re * (KL(4) + re * (KL(5) + re * KL(6))));
+      sc_l = od_l * (1.0 - (KL(7) + re * (KL(8) + re * KL(9))) / (1.0 + re * (KL(10) + re * KL(11))));
+      g_l = (KL(12) + re * (KL(13) + re * KL(14))) / (1.0 + re * (KL(15) + re * KL(16)));
+    }
 #undef KL
     if (IS_SW && !cfg.do_sw_delta_scaling_with_gases) { const double f = g_l * g_l; od_l = od_l - sc_l * f; sc_l = sc_l * (1.0 - f); g_l = g_l / (1.0 + g_l); }
   }
@@ -529,18 +553,53 @@ ECRAD_DEV CloudLayer cloud_layer_fit(const DevConfig& cfg, const LdsLayout& L, i
     const double* __restrict__ k = ice.mass_ext + ib;
 #define KI(j) k[(size_t)nb * ((j) - 1)]
     const double max_g = 1.0 - 10.0 * 2.220446049250313e-16;
-    const double de_um = dmin(L.D(L.f_rew(1), slot), 100.0e-6) * (1.0e6 / 0.64952);
-    const double inv_de_um = 1.0 / de_um;
-    const double iwp_gm_2 = iwp * 1000.0;
-    if (IS_SW) {
-      od_i = iwp_gm_2 * (KI(1) + KI(2) * inv_de_um);
-      sc_i = od_i * (1.0 - (KI(3) + de_um * (KI(4) + de_um * (KI(5) + de_um * KI(6)))));
-      g_i = dmin(KI(7) + de_um * (KI(8) + de_um * (KI(9) + de_um * KI(10))), max_g);
+    if (cfg.i_ice_model == ECRAD_ICE_FU) {
+      const double de_um = dmin(L.D(L.f_rew(1), slot), 100.0e-6) * (1.0e6 / 0.64952);
+      const double inv_de_um = 1.0 / de_um;
+      const double iwp_gm_2 = iwp * 1000.0;
+      if (IS_SW) {
+        od_i = iwp_gm_2 * (KI(1) + KI(2) * inv_de_um);
+        sc_i = od_i * (1.0 - (KI(3) + de_um * (KI(4) + de_um * (KI(5) + de_um * KI(6)))));
+        g_i = dmin(KI(7) + de_um * (KI(8) + de_um * (KI(9) + de_um * KI(10))), max_g);
+      } else {
+        od_i = iwp_gm_2 * (KI(1) + inv_de_um * (KI(2) + inv_de_um * KI(3)));
+        sc_i = od_i - iwp_gm_2 * inv_de_um * (KI(4) + de_um * (KI(5) + de_um * (KI(6) + de_um * KI(7))));
+        g_i = dmin(KI(8) + de_um * (KI(9) + de_um * (KI(10) + de_um * KI(11))), max_g);
+        if (cfg.fu_lw_bug) sc_i = od_i - sc_i;
+      }
+    } else if (cfg.i_ice_model == ECRAD_ICE_YI) {       // calc_ice_optics_yi_sw/_lw, radiation_ice_optics_yi.F90:42-142: a look-up table in D_e
+      const int NSingleCoeffs = 23;
+      double de_um = L.D(L.f_rew(1), slot) * 2.0e6;
+      de_um = dmin(dmax(de_um, 10.0), 119.99);
+      const double iwp_gm_2 = iwp * 1000.0;
+      const double pos = de_um * 0.2 - 1.0;
+      const int lu = (int)floor(pos);
+      const double w2 = pos - lu, w1 = 1.0 - w2;
+      od_i = 0.001 * iwp_gm_2 * (w1 * KI(lu) + w2 * KI(lu + 1));
+      sc_i = od_i * (w1 * KI(lu + NSingleCoeffs) + w2 * KI(lu + NSingleCoeffs + 1));
+      g_i = w1 * KI(lu + 2 * NSingleCoeffs) + w2 * KI(lu + 2 * NSingleCoeffs + 1);
     } else {
-      od_i = iwp_gm_2 * (KI(1) + inv_de_um * (KI(2) + inv_de_um * KI(3)));
-      sc_i = od_i - iwp_gm_2 * inv_de_um * (KI(4) + de_um * (KI(5) + de_um * (KI(6) + de_um * KI(7))));
-      g_i = dmin(KI(8) + de_um * (KI(9) + de_um * (KI(10) + de_um * KI(11))), max_g);
-      if (cfg.fu_lw_bug) sc_i = od_i - sc_i;
+      const double qi = L.D(L.f_rew(1), slot), temperature = L.D(L.f_aux(1), slot);
+      if (cfg.i_ice_model == ECRAD_ICE_BARAN) {          // calc_ice_optics_baran, radiation_ice_optics_baran.F90:40-60
+        od_i = iwp * (KI(1) + KI(2) / (1.0 + qi * KI(3)));
+        sc_i = od_i * (KI(4) + KI(5) / (1.0 + qi * KI(6)));
+        g_i = KI(7) + KI(8) / (1.0 + qi * KI(9));
+      } else if (cfg.i_ice_model == ECRAD_ICE_BARAN2016) {   // calc_ice_optics_baran2016, radiation_ice_optics_baran2016.F90:37-68
+        const double T2 = temperature * temperature;
+        const double qi_T = (qi < 1.0e-3 ? qi : 1.0e-3) * temperature;
+        const double qi_over_T4 = 1.0 / (T2 * T2);
+        od_i = iwp * KI(1) * qi_over_T4;
+        sc_i = od_i * (KI(2) + KI(3) * qi_T);
+        g_i = KI(4) + KI(5) * qi_T;
+      } else {                                           // calc_ice_optics_baran2017, radiation_ice_optics_baran2017.F90:40-68
+        const DevCloudOptics& gen = IS_SW ? cfg.cloud_sw[2] : cfg.cloud_lw[2];
+        const double* __restrict__ cg = gen.mass_ext;
+        const double qi_mod = qi * exp(cg[0] * (temperature - cg[1]));
+        const double qi_mod_od = pow(qi_mod, cg[2]), qi_mod_ssa = pow(qi_mod, cg[3]), qi_mod_g = pow(qi_mod, cg[4]);
+        od_i = iwp * (KI(1) + KI(2) / (1.0 + qi_mod_od * KI(3)));
+        sc_i = od_i * (KI(4) + KI(5) / (1.0 + qi_mod_ssa * KI(6)));
+        g_i = KI(7) + KI(8) / (1.0 + qi_mod_g * KI(9));
+      }
     }
 #undef KI
     if (!IS_SW || !cfg.do_sw_delta_scaling_with_gases) { const double f = g_i * g_i; od_i = od_i - sc_i * f; sc_i = sc_i * (1.0 - f); g_i = g_i / (1.0 + g_i); }

@@ -249,6 +249,12 @@ contains
       call fill_cloud_fit(config%cloud_optics%ice_coeff_sw, c%cloud_optics_sw(2))
       call fill_cloud_fit(config%cloud_optics%liq_coeff_lw, c%cloud_optics_lw(1))
       call fill_cloud_fit(config%cloud_optics%ice_coeff_lw, c%cloud_optics_lw(2))
+      if (allocated(config%cloud_optics%ice_coeff_gen)) then      ! Baran-2017: band-independent coefficients in slot 3
+        c%cloud_optics_sw(3)%n_bands = 1; c%cloud_optics_sw(3)%n_effective_radius = size(config%cloud_optics%ice_coeff_gen)
+        c%cloud_optics_sw(3)%effective_radius_0 = 0.0_c_double; c%cloud_optics_sw(3)%d_effective_radius = 1.0_c_double
+        c%cloud_optics_sw(3)%mass_ext = locd(config%cloud_optics%ice_coeff_gen)
+        c%cloud_optics_lw(3) = c%cloud_optics_sw(3)
+      end if
     end if
     associate (ao => config%aerosol_optics, a => c%aerosol_optics)
       a%n_bands_sw = ao%n_bands_sw; a%n_bands_lw = ao%n_bands_lw; a%n_type_phobic = ao%n_type_phobic

@@ -52,6 +52,7 @@ module radiation_hip_types
   end type
   type cloud_optics_type
     real(jprb), allocatable, dimension(:,:) :: liq_coeff_lw, liq_coeff_sw, ice_coeff_lw, ice_coeff_sw   ! (nband, ncoeff)
+    real(jprb), allocatable, dimension(:) :: liq_coeff_gen, ice_coeff_gen
   end type
   type aerosol_optics_type
     integer, allocatable, dimension(:) :: iclass, itype

@@ -269,6 +269,23 @@ def _setup_radiation_rrtmg(config: Config) -> None:
             if config.do_lw:
                 config.cloud_optics_lw = [BandFitCloudOptics(config.liq_optics_file_name, "coeff_lw", 16),
                                           BandFitCloudOptics(config.ice_optics_file_name, "coeff_lw", 16)]
+            # number of coefficients each scheme expects (radiation_cloud_optics.F90:84-213)
+            from .config import (IIceModelBaran, IIceModelBaran2016, IIceModelBaran2017, IIceModelFu, IIceModelYi,
+                                 ILiquidModelSlingo, ILiquidModelSOCRATES)
+            want_liq = {ILiquidModelSOCRATES: (16, 16), ILiquidModelSlingo: (6, 13)}[config.i_liq_model]
+            want_ice = {IIceModelFu: (10, 11), IIceModelBaran: (9, 9), IIceModelBaran2016: (5, 5), IIceModelBaran2017: (9, 9),
+                        IIceModelYi: (69, 69)}[config.i_ice_model]
+            for lst, k in ((config.cloud_optics_sw, 0), (config.cloud_optics_lw, 1)):
+                if lst and (lst[0].n_effective_radius != want_liq[k] or lst[1].n_effective_radius != want_ice[k]):
+                    raise ConfigError("number of cloud optical coefficients does not match number expected")
+            if config.i_ice_model == IIceModelBaran2017:
+                from .tables import GeneralCoefficients
+                gen = GeneralCoefficients(config.ice_optics_file_name)
+                if gen.n_effective_radius != 5:
+                    raise ConfigError("number of general ice-particle optical coefficients does not match number expected (5)")
+                for lst in (config.cloud_optics_sw, config.cloud_optics_lw):
+                    if lst:
+                        lst.append(gen)
     if config.use_aerosols:
         if config.n_aerosol_types > 0:
             if not config.use_general_aerosol_optics:

@@ -164,6 +164,23 @@ class BandFitCloudOptics:
         self.asymmetry = None
 
 
+class GeneralCoefficients:
+    """config%cloud_optics%ice_coeff_gen (radiation_cloud_optics_data.F90:36, the five band-independent coefficients of
+    the Baran-2017 ice scheme), handed to the library in the third cloud-optics slot: n_bands = 1, mass_ext = coeff_gen."""
+
+    def __init__(self, file_name: str):
+        with NcFile(file_name) as nc:
+            if not nc.exists("coeff_gen"):
+                raise ValueError("coeff_gen needed for Baran-2017 ice optics parameterization")      # radiation_cloud_optics.F90:192
+            a = np.asarray(nc.get("coeff_gen"), dtype=np.float64).ravel()
+        self.n_bands = 1
+        self.n_effective_radius = int(a.size)
+        self.effective_radius_0, self.d_effective_radius = 0.0, 1.0
+        self.mass_ext = np.ascontiguousarray(a)
+        self.ssa = None
+        self.asymmetry = None
+
+
 class AerosolOptics:
     """aerosol_optics_type filled by setup_general_aerosol_optics
     (radiation_aerosol_optics.F90:96-338) + initialize_types/set_types

@@ -63,8 +63,8 @@ enum { ECRAD_OVERLAP_MAX_RAN = 0, ECRAD_OVERLAP_EXP_RAN = 1, ECRAD_OVERLAP_EXP_E
 /* radiation_config.F90:124-126 */
 enum { ECRAD_PDF_LOGNORMAL = 0, ECRAD_PDF_GAMMA = 1 };
 /* radiation_config.F90:109-126 */
-enum { ECRAD_LIQUID_MONOCHROMATIC = 0, ECRAD_LIQUID_SOCRATES = 1, ECRAD_LIQUID_SLINGO = 2 };
-enum { ECRAD_ICE_MONOCHROMATIC = 0, ECRAD_ICE_FU = 1, ECRAD_ICE_BARAN = 2 };
+enum { ECRAD_LIQUID_MONOCHROMATIC = 0, ECRAD_LIQUID_SOCRATES = 1, ECRAD_LIQUID_SLINGO = 2, ECRAD_LIQUID_JAHANGIR = 3, ECRAD_LIQUID_NIELSEN = 4 };
+enum { ECRAD_ICE_MONOCHROMATIC = 0, ECRAD_ICE_FU = 1, ECRAD_ICE_BARAN = 2, ECRAD_ICE_BARAN2016 = 3, ECRAD_ICE_BARAN2017 = 4, ECRAD_ICE_YI = 5 };
 /* radiation_aerosol_optics_data.F90 IAerosolClass* */
 enum { ECRAD_AEROSOL_UNDEFINED = 0, ECRAD_AEROSOL_IGNORED = 1, ECRAD_AEROSOL_HYDROPHOBIC = 2,
        ECRAD_AEROSOL_HYDROPHILIC = 3 };
@@ -230,7 +230,10 @@ typedef struct ecrad_config {
   double min_gas_od_lw, min_gas_od_sw;   /* radiation_config.F90:244-245 */
   /* use_general_cloud_optics == 0: the per-band fits of radiation_cloud_optics.F90.  cloud_optics_sw/lw[0] is liquid,
      [1] ice; their mass_ext points to the coefficients (n_bands, ncoeff) = config%cloud_optics%liq_coeff_* /
-     ice_coeff_*, n_effective_radius holds ncoeff; ssa/asymmetry are not read.  Implemented: SOCRATES + Fu. */
+     ice_coeff_*, n_effective_radius holds ncoeff; ssa/asymmetry are not read.  With the Baran-2017 ice scheme slot [2] holds
+     config%cloud_optics%ice_coeff_gen: n_bands = 1, n_effective_radius = 5, mass_ext = the five general coefficients.
+     Implemented: liquid SOCRATES, Slingo (SW) / Lindner-Li (LW); ice Fu, Baran, Baran2016, Baran2017, Yi -- the schemes
+     radiation_cloud_optics.F90:325-470 has a branch for. */
   int32_t i_liq_model, i_ice_model;      /* radiation_config.F90:109-126 (ILiquidModel*, IIceModel*) */
   int32_t do_fu_lw_ice_optics_bug, reserved2_;
   /* SPARTACUS (i_solver_* == ECRAD_SOLVER_SPARTACUS), radiation_config.F90:226-260,268,341-411 */

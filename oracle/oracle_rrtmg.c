@@ -2,9 +2,12 @@
  *
  * Rows a6 and a9 of SURVEY.md section 8 on the oracle side.
  *
- * a9  cloud_optics with the SOCRATES liquid and Fu ice fits: a plain-C restatement of
+ * a9  cloud_optics with the per-band fits: a plain-C restatement of
  *     radiation/radiation_cloud_optics.F90:218-523, radiation_liquid_optics_socrates.F90:40-80,
- *     radiation_ice_optics_fu.F90:42-137 and delta_eddington_scat_od (radiation_delta_eddington.h:103-117).
+ *     radiation_liquid_optics_slingo.F90:36-104 (Slingo shortwave, Lindner-Li longwave), radiation_ice_optics_fu.F90:42-137,
+ *     radiation_ice_optics_baran.F90:40-60, _baran2016.F90:37-68, _baran2017.F90:40-68, radiation_ice_optics_yi.F90:42-142
+ *     and delta_eddington_scat_od (radiation_delta_eddington.h:103-117).  The single-layer routines below are pinned
+ *     against the reference's own modules compiled into oracle/_ref (tests/test_oracle_vs_ref_leaf.py).
  *
  * a6  RRTMG gas optics: the oracle does NOT restate the 30 band routines.  Its gas optics for this model are
  *     the reference's OWN ifsrrtm routines, compiled unmodified into oracle/_ref/libecrad_refrrtm.so
@@ -64,6 +67,94 @@ static inline void delta_eddington_scat_od(double* od, double* scat_od, double* 
   *g = *g / (1.0 + *g);
 }
 
+/* One band of one liquid scheme; k(band, j) = coefficient j (1-based) of the band, stored band-fastest (nb, ncoeff).
+   i_liq_model: ECRAD_LIQUID_SOCRATES (radiation_liquid_optics_socrates.F90:40-80) or ECRAD_LIQUID_SLINGO
+   (radiation_liquid_optics_slingo.F90: Slingo 1989 in the shortwave :36-60, Lindner and Li 2000 in the longwave :68-104). */
+void oracle_liq_optics_band(int i_liq_model, int is_lw, int nb, const double* k, int jb, double lwp, double re_in,
+                            double* od, double* scat_od, double* g)
+{
+#define KL(j) k[jb + (size_t)nb * ((j) - 1)]
+  if (i_liq_model == ECRAD_LIQUID_SLINGO) {
+    const double lwp_gm_2 = lwp * 1000.0;
+    if (!is_lw) {
+      const double re_um = dmin(dmax(4.2, re_in * 1.0e6), 16.6);
+      const double inv_re_um = 1.0 / re_um;
+      *od = lwp_gm_2 * (KL(1) + inv_re_um * KL(2));
+      *scat_od = *od * (1.0 - KL(3) - re_um * KL(4));
+      *g = KL(5) + re_um * KL(6);
+    } else {
+      const double re_um = dmin(dmax(2.0, re_in * 1.0e6), 40.0);
+      const double inv_re_um = 1.0 / re_um;
+      *od = lwp_gm_2 * (KL(1) + re_um * KL(2) + inv_re_um * (KL(3) + inv_re_um * (KL(4) + inv_re_um * KL(5))));
+      *scat_od = *od * (1.0 - (KL(6) + inv_re_um * KL(7) + re_um * (KL(8) + re_um * KL(9))));
+      *g = KL(10) + inv_re_um * KL(11) + re_um * (KL(12) + re_um * KL(13));
+    }
+  } else {
+    const double min_re_liq = (double)1.2e-6f, max_re_liq = (double)50.0e-6f;   /* default-real literals, socrates:31-32 */
+    const double re = dmax(min_re_liq, dmin(re_in, max_re_liq));
+    *od = lwp * (KL(1) + re * (KL(2) + re * KL(3))) / (1.0 + re * (KL(4) + re * (KL(5) + re * KL(6))));
+    *scat_od = *od * (1.0 - (KL(7) + re * (KL(8) + re * KL(9))) / (1.0 + re * (KL(10) + re * KL(11))));
+    *g = (KL(12) + re * (KL(13) + re * KL(14))) / (1.0 + re * (KL(15) + re * KL(16)));
+  }
+#undef KL
+}
+
+/* One band of one ice scheme: Fu (radiation_ice_optics_fu.F90:42-137, without the optional scat_od "bug" swap), Baran
+   (radiation_ice_optics_baran.F90:40-60), Baran2016 (radiation_ice_optics_baran2016.F90:37-68), Baran2017
+   (radiation_ice_optics_baran2017.F90:40-68, gen = its five band-independent coefficients), Yi
+   (radiation_ice_optics_yi.F90:42-142: a table in the effective diameter, 23 entries per quantity). */
+void oracle_ice_optics_band(int i_ice_model, int is_lw, int nb, const double* k, const double* gen, int jb, double iwp,
+                            double re_ice, double qi, double temperature, double* od, double* scat_od, double* g)
+{
+#define KI(j) k[jb + (size_t)nb * ((j) - 1)]
+  const double max_re_ice = 100.0e-6, max_g = 1.0 - 10.0 * 2.220446049250313e-16;
+  if (i_ice_model == ECRAD_ICE_FU) {
+    const double de_um = dmin(re_ice, max_re_ice) * (1.0e6 / 0.64952);
+    const double inv_de_um = 1.0 / de_um;
+    const double iwp_gm_2 = iwp * 1000.0;
+    if (!is_lw) {
+      *od = iwp_gm_2 * (KI(1) + KI(2) * inv_de_um);
+      *scat_od = *od * (1.0 - (KI(3) + de_um * (KI(4) + de_um * (KI(5) + de_um * KI(6)))));
+      *g = dmin(KI(7) + de_um * (KI(8) + de_um * (KI(9) + de_um * KI(10))), max_g);
+    } else {
+      *od = iwp_gm_2 * (KI(1) + inv_de_um * (KI(2) + inv_de_um * KI(3)));
+      *scat_od = *od - iwp_gm_2 * inv_de_um * (KI(4) + de_um * (KI(5) + de_um * (KI(6) + de_um * KI(7))));
+      *g = dmin(KI(8) + de_um * (KI(9) + de_um * (KI(10) + de_um * KI(11))), max_g);
+    }
+  } else if (i_ice_model == ECRAD_ICE_YI) {
+    const int NSingleCoeffs = 23;
+    double de_um = re_ice * 2.0e6;
+    de_um = dmax(de_um, 10.0);
+    de_um = dmin(de_um, 119.99);
+    const double iwp_gm_2 = iwp * 1000.0;
+    const double pos = de_um * 0.2 - 1.0;
+    const int lu = (int)floor(pos);
+    const double wts_2 = pos - lu, wts_1 = 1.0 - wts_2;
+    *od = 0.001 * iwp_gm_2 * (wts_1 * KI(lu) + wts_2 * KI(lu + 1));
+    *scat_od = *od * (wts_1 * KI(lu + NSingleCoeffs) + wts_2 * KI(lu + NSingleCoeffs + 1));
+    *g = wts_1 * KI(lu + 2 * NSingleCoeffs) + wts_2 * KI(lu + 2 * NSingleCoeffs + 1);
+  } else if (i_ice_model == ECRAD_ICE_BARAN) {
+    *od = iwp * (KI(1) + KI(2) / (1.0 + qi * KI(3)));
+    *scat_od = *od * (KI(4) + KI(5) / (1.0 + qi * KI(6)));
+    *g = KI(7) + KI(8) / (1.0 + qi * KI(9));
+  } else if (i_ice_model == ECRAD_ICE_BARAN2016) {
+    const double T2 = temperature * temperature;
+    double qi_T, qi_over_T4;
+    if (qi < 1.0e-3) { qi_T = qi * temperature; qi_over_T4 = 1.0 / (T2 * T2); }
+    else { qi_T = 1.0e-3 * temperature; qi_over_T4 = 1.0 / (T2 * T2); }
+    *od = iwp * KI(1) * qi_over_T4;
+    *scat_od = *od * (KI(2) + KI(3) * qi_T);
+    *g = KI(4) + KI(5) * qi_T;
+  } else {   /* Baran2017 */
+    const double qi_mod = qi * exp(gen[0] * (temperature - gen[1]));
+    const double qi_mod_od = pow(qi_mod, gen[2]), qi_mod_ssa = pow(qi_mod, gen[3]), qi_mod_g = pow(qi_mod, gen[4]);
+    *od = iwp * (KI(1) + KI(2) / (1.0 + qi_mod_od * KI(3)));
+    *scat_od = *od * (KI(4) + KI(5) / (1.0 + qi_mod_ssa * KI(6)));
+    *g = KI(7) + KI(8) / (1.0 + qi_mod_g * KI(9));
+  }
+#undef KI
+}
+
 /* radiation_cloud_optics.F90:218-523.  Coefficients: cloud_optics_*[0].mass_ext = liquid (nb,16), [1].mass_ext = ice. */
 void oracle_cloud_optics_fit(const ecrad_config_t* c, int ncol, int nlev, int istartcol, int iendcol,
      const ecrad_inputs_t* in, double* od_lw_cloud, double* ssa_lw_cloud, double* g_lw_cloud,
@@ -81,8 +172,6 @@ void oracle_cloud_optics_fit(const ecrad_config_t* c, int ncol, int nlev, int is
     memset(ssa_lw_cloud, 0, sizeof(double) * (size_t)nblw * nlev * nloc);
     memset(g_lw_cloud, 0, sizeof(double) * (size_t)nblw * nlev * nloc);
   }
-  const double min_re_liq = (double)1.2e-6f, max_re_liq = (double)50.0e-6f;   /* default-real literals, socrates:31-32 */
-  const double max_re_ice = 100.0e-6, max_g = 1.0 - 10.0 * 2.220446049250313e-16;
   for (int jc = 0; jc < nloc; ++jc) {
     const int jcol = istartcol - 1 + jc;
     for (int l = 0; l < nlev; ++l) {
@@ -102,35 +191,19 @@ void oracle_cloud_optics_fit(const ecrad_config_t* c, int ncol, int nlev, int is
         const double* ki = (is_lw ? c->cloud_optics_lw : c->cloud_optics_sw)[1].mass_ext;
         const size_t o = (size_t)nb * (l + (size_t)nlev * jc);
         for (int jb = 0; jb < nb; ++jb) {
-#define KL(j) kl[jb + (size_t)nb * ((j) - 1)]
-#define KI(j) ki[jb + (size_t)nb * ((j) - 1)]
           double od_l = 0, sc_l = 0, g_l = 0, od_i = 0, sc_i = 0, g_i = 0;
           if (lwp > 0.0) {
-            const double re = dmax(min_re_liq, dmin(re_liq, max_re_liq));
-            od_l = lwp * (KL(1) + re * (KL(2) + re * KL(3))) / (1.0 + re * (KL(4) + re * (KL(5) + re * KL(6))));
-            sc_l = od_l * (1.0 - (KL(7) + re * (KL(8) + re * KL(9))) / (1.0 + re * (KL(10) + re * KL(11))));
-            g_l = (KL(12) + re * (KL(13) + re * KL(14))) / (1.0 + re * (KL(15) + re * KL(16)));
+            oracle_liq_optics_band(c->i_liq_model, is_lw, nb, kl, jb, lwp, re_liq, &od_l, &sc_l, &g_l);
             if (!is_lw && !c->do_sw_delta_scaling_with_gases) delta_eddington_scat_od(&od_l, &sc_l, &g_l);
           }
           if (iwp > 0.0) {
-            const double de_um = dmin(re_ice, max_re_ice) * (1.0e6 / 0.64952);
-            const double inv_de_um = 1.0 / de_um;
-            const double iwp_gm_2 = iwp * 1000.0;
-            if (!is_lw) {
-              od_i = iwp_gm_2 * (KI(1) + KI(2) * inv_de_um);
-              sc_i = od_i * (1.0 - (KI(3) + de_um * (KI(4) + de_um * (KI(5) + de_um * KI(6)))));
-              g_i = dmin(KI(7) + de_um * (KI(8) + de_um * (KI(9) + de_um * KI(10))), max_g);
-              if (!c->do_sw_delta_scaling_with_gases) delta_eddington_scat_od(&od_i, &sc_i, &g_i);
-            } else {
-              od_i = iwp_gm_2 * (KI(1) + inv_de_um * (KI(2) + inv_de_um * KI(3)));
-              sc_i = od_i - iwp_gm_2 * inv_de_um * (KI(4) + de_um * (KI(5) + de_um * (KI(6) + de_um * KI(7))));
-              g_i = dmin(KI(8) + de_um * (KI(9) + de_um * (KI(10) + de_um * KI(11))), max_g);
-              if (c->do_fu_lw_ice_optics_bug) sc_i = od_i - sc_i;
-              delta_eddington_scat_od(&od_i, &sc_i, &g_i);
-            }
+            const double qi = in->cloud_mixing_ratio[i2 + (size_t)ncol * nlev];
+            const double temperature = 0.5 * (in->temperature_hl[i2] + in->temperature_hl[(size_t)jcol + (size_t)ncol * (l + 1)]);
+            const double* gen = (is_lw ? c->cloud_optics_lw : c->cloud_optics_sw)[2].mass_ext;
+            oracle_ice_optics_band(c->i_ice_model, is_lw, nb, ki, gen, jb, iwp, re_ice, qi, temperature, &od_i, &sc_i, &g_i);
+            if (is_lw && c->i_ice_model == ECRAD_ICE_FU && c->do_fu_lw_ice_optics_bug) sc_i = od_i - sc_i;
+            if (is_lw || !c->do_sw_delta_scaling_with_gases) delta_eddington_scat_od(&od_i, &sc_i, &g_i);
           }
-#undef KL
-#undef KI
           if (is_lw) {
             if (c->do_lw_cloud_scattering) {
               od_lw_cloud[o + jb] = od_l + od_i;

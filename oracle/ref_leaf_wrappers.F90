@@ -299,6 +299,57 @@ contains
   end subroutine
 
 
+  ! ---- band cloud optics: the reference's own single-layer routines (radiation_liquid_optics_*.F90, radiation_ice_optics_*.F90) ----
+  ! which: 1 SOCRATES, 2 Slingo (SW) / Lindner-Li (LW); coeff is (nb, ncoeff)
+  subroutine ref_liq_optics(which, is_lw, nb, ncoeff, coeff, lwp, re, od, scat_od, g) bind(C, name='ref_liq_optics')
+    use radiation_liquid_optics_socrates, only : calc_liq_optics_socrates
+    use radiation_liquid_optics_slingo,   only : calc_liq_optics_slingo, calc_liq_optics_lindner_li
+    integer(c_int), value :: which, is_lw, nb, ncoeff
+    real(c_double), intent(in) :: coeff(nb, ncoeff)
+    real(c_double), value :: lwp, re
+    real(c_double), intent(out) :: od(nb), scat_od(nb), g(nb)
+    if (which == 1) then
+      call calc_liq_optics_socrates(nb, coeff, lwp, re, od, scat_od, g)
+    else if (is_lw /= 0) then
+      call calc_liq_optics_lindner_li(nb, coeff, lwp, re, od, scat_od, g)
+    else
+      call calc_liq_optics_slingo(nb, coeff, lwp, re, od, scat_od, g)
+    end if
+  end subroutine
+  ! which: 1 Fu, 2 Baran, 3 Baran2016, 4 Baran2017, 5 Yi
+  subroutine ref_ice_optics(which, is_lw, nb, ncoeff, coeff, coeff_gen, iwp, re, qi, temperature, od, scat_od, g) &
+       &  bind(C, name='ref_ice_optics')
+    use radiation_ice_optics_fu,        only : calc_ice_optics_fu_sw, calc_ice_optics_fu_lw
+    use radiation_ice_optics_baran,     only : calc_ice_optics_baran
+    use radiation_ice_optics_baran2016, only : calc_ice_optics_baran2016
+    use radiation_ice_optics_baran2017, only : calc_ice_optics_baran2017
+    use radiation_ice_optics_yi,        only : calc_ice_optics_yi_sw, calc_ice_optics_yi_lw
+    integer(c_int), value :: which, is_lw, nb, ncoeff
+    real(c_double), intent(in) :: coeff(nb, ncoeff), coeff_gen(5)
+    real(c_double), value :: iwp, re, qi, temperature
+    real(c_double), intent(out) :: od(nb), scat_od(nb), g(nb)
+    select case (which)
+    case (1)
+      if (is_lw /= 0) then
+        call calc_ice_optics_fu_lw(nb, coeff, iwp, re, od, scat_od, g)
+      else
+        call calc_ice_optics_fu_sw(nb, coeff, iwp, re, od, scat_od, g)
+      end if
+    case (2)
+      call calc_ice_optics_baran(nb, coeff, iwp, qi, od, scat_od, g)
+    case (3)
+      call calc_ice_optics_baran2016(nb, coeff, iwp, qi, temperature, od, scat_od, g)
+    case (4)
+      call calc_ice_optics_baran2017(nb, coeff_gen, coeff, iwp, qi, temperature, od, scat_od, g)
+    case default
+      if (is_lw /= 0) then
+        call calc_ice_optics_yi_lw(nb, coeff, iwp, re, od, scat_od, g)
+      else
+        call calc_ice_optics_yi_sw(nb, coeff, iwp, re, od, scat_od, g)
+      end if
+    end select
+  end subroutine
+
   ! ---- CPU baseline in the reference's own code -------------------------------------------------------------------
   ! The clear-sky solver stage of the headline workload (solver_homogeneous_sw + solver_homogeneous_lw without clouds and
   ! without aerosols: radiation_homogeneous_sw.F90:160-215,270-330, radiation_homogeneous_lw.F90:150-200,260-300), i.e. the

@@ -38,6 +38,13 @@ CASES = {
     "delta_scaling_with_gases": dict(sw_solver="Tripleclouds", do_sw_delta_scaling_with_gases=True, do_lw_aerosol_scattering=False),
     "mcica_delta_scaling_with_gases": dict(sw_solver="McICA", do_sw_delta_scaling_with_gases=True, do_lw_aerosol_scattering=False),
     "homogeneous_lw_aerosol_scat": dict(sw_solver="Homogeneous"),
+    # the other band cloud-optics schemes of radiation_cloud_optics.F90; model codes of radiation_config.F90:109-133
+    "slingo_liquid": dict(sw_solver="McICA", i_liq_model=2, do_lw_aerosol_scattering=False),
+    "baran_ice": dict(sw_solver="McICA", i_ice_model=2, do_lw_aerosol_scattering=False),
+    "baran2016_ice": dict(sw_solver="Tripleclouds", i_ice_model=3, do_lw_aerosol_scattering=False),
+    "baran2017_ice": dict(sw_solver="McICA", i_ice_model=4, do_lw_aerosol_scattering=False),
+    "yi_ice": dict(sw_solver="Tripleclouds", i_ice_model=5, do_lw_aerosol_scattering=False),
+    "slingo_yi_no_lw_scattering": dict(sw_solver="McICA", i_liq_model=2, i_ice_model=5, do_lw_cloud_scattering=False, do_lw_aerosol_scattering=False),
 }
 
 

@@ -304,3 +304,54 @@ def test_reference_leaf_clear_sky_solver_stage_reproduces_the_oracle(oracle_lib)
     got = oracle_lib.ref_clear_sky_solvers(stage, inp[2].cos_sza, nblocksize=8)
     for name in ("sw_up", "sw_dn", "sw_dn_direct", "lw_up", "lw_dn"):
         assert rel_err(got[name], f.arrays[name + "_clear"]) < 1.0e-12, name
+
+
+@pytest.mark.parametrize("scheme", ["socrates", "slingo", "fu", "baran", "baran2016", "baran2017", "yi"])
+def test_band_cloud_optics_schemes_match_the_reference_routines(oracle_lib, scheme):
+    """The per-band cloud-optics fits of the oracle (oracle/oracle_rrtmg.c: oracle_liq_optics_band / oracle_ice_optics_band)
+    against the reference's own radiation_liquid_optics_{socrates,slingo}.F90 and radiation_ice_optics_{fu,baran,baran2016,
+    baran2017,yi}.F90, compiled unmodified into oracle/_ref, with the reference's coefficient files."""
+    from ecrad_amd.ncfile import NcFile
+    from helpers import DATA_DIR
+    if not oracle_lib.have_ref_leaf():
+        pytest.skip("oracle/_ref/libecrad_refleaf.so not built")
+    ref = C.CDLL(oracle_lib.REF_LEAF_PATH)
+    if not hasattr(ref, "ref_liq_optics"):
+        pytest.skip("oracle/_ref/libecrad_refleaf.so predates the cloud-optics wrappers")
+    ora = oracle_lib.lib()
+    dp = C.POINTER(C.c_double)
+    files = {"socrates": "socrates_droplet_scattering_rrtm.nc", "slingo": "slingo_droplet_scattering_rrtm.nc",
+             "fu": "fu_ice_scattering_rrtm.nc", "baran": "baran_ice_scattering_rrtm.nc", "baran2016": "baran2016_ice_scattering_rrtm.nc",
+             "baran2017": "baran2017_ice_scattering_rrtm.nc", "yi": "yi_ice_scattering_rrtm.nc"}
+    liquid = scheme in ("socrates", "slingo")
+    code = {"socrates": 1, "slingo": 2, "fu": 1, "baran": 2, "baran2016": 3, "baran2017": 4, "yi": 5}[scheme]
+    rng = np.random.default_rng(7)
+    with NcFile(os.path.join(DATA_DIR, files[scheme])) as nc:
+        coeffs = {"sw": np.asarray(nc.get("coeff_sw"), dtype=np.float64), "lw": np.asarray(nc.get("coeff_lw"), dtype=np.float64)}
+        gen = np.asarray(nc.get("coeff_gen"), dtype=np.float64).ravel() if nc.exists("coeff_gen") else np.zeros(5)
+    for is_lw, key in ((0, "sw"), (1, "lw")):
+        a = coeffs[key]                                    # netCDF (band, coeff)
+        nb, ncoeff = a.shape
+        k = np.ascontiguousarray(a.T)                      # band fastest = Fortran (nb, ncoeff)
+        for _ in range(40):
+            wp = float(rng.uniform(1e-4, 0.3))
+            re = float(rng.uniform(1.0e-6, 80.0e-6))
+            qi = float(10.0 ** rng.uniform(-7, -2.5))
+            T = float(rng.uniform(190.0, 272.0))
+            want = [np.zeros(nb) for _ in range(3)]
+            if liquid:
+                ref.ref_liq_optics(C.c_int(code), C.c_int(is_lw), C.c_int(nb), C.c_int(ncoeff), k.ctypes.data_as(dp), C.c_double(wp),
+                                   C.c_double(re), *[w.ctypes.data_as(dp) for w in want])
+            else:
+                ref.ref_ice_optics(C.c_int(code), C.c_int(is_lw), C.c_int(nb), C.c_int(ncoeff), k.ctypes.data_as(dp), gen.ctypes.data_as(dp),
+                                   C.c_double(wp), C.c_double(re), C.c_double(qi), C.c_double(T), *[w.ctypes.data_as(dp) for w in want])
+            for jb in range(nb):
+                o, s, g = C.c_double(), C.c_double(), C.c_double()
+                if liquid:
+                    ora.oracle_liq_optics_band(C.c_int(code), C.c_int(is_lw), C.c_int(nb), k.ctypes.data_as(dp), C.c_int(jb), C.c_double(wp),
+                                               C.c_double(re), C.byref(o), C.byref(s), C.byref(g))
+                else:
+                    ora.oracle_ice_optics_band(C.c_int(code), C.c_int(is_lw), C.c_int(nb), k.ctypes.data_as(dp), gen.ctypes.data_as(dp), C.c_int(jb),
+                                               C.c_double(wp), C.c_double(re), C.c_double(qi), C.c_double(T), C.byref(o), C.byref(s), C.byref(g))
+                for got, w in ((o.value, want[0][jb]), (s.value, want[1][jb]), (g.value, want[2][jb])):
+                    assert abs(got - w) <= 1.0e-12 * max(abs(w), 1.0e-30) + 1.0e-300, (scheme, key, jb, got, w)
