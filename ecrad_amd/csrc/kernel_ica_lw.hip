@@ -18,9 +18,10 @@ namespace ecrad {
 // Block-private scratch, level-major: per level and lane
 //   P_CLR  pair (transmittance, source_up) of the clear-sky layer        S_SD1  its source_dn
 //   P_RT2  pair (reflectance, transmittance) of a cloudy layer           P_S2   pair (source_up, source_dn)
-//   P_AS   pair (albedo, source) below the half level (cloudy-sky sweep)
+//   P_AS   pair (albedo, source) below the layer (cloudy-sky sweeps)
+//   P_DN   pair (a1, c) of the cloudy-sky downward sweep; takes the place of P_S2 once the upward sweep has used it
 // The cloudless solver only needs P_CLR.
-enum { P_CLR = 0, S_SD1 = 2, P_RT2 = 3, P_S2 = 5, P_AS = 7, L_WIDTH_FULL = 9, L_WIDTH_CLEAR = 2 };
+enum { P_CLR = 0, S_SD1 = 2, P_RT2 = 3, P_S2 = 5, P_DN = 5, P_AS = 7, L_WIDTH_FULL = 9, L_WIDTH_CLEAR = 2 };
 
 struct LwScratch {
   double* base;
@@ -39,7 +40,38 @@ struct LwScratch {
 #ifndef ECRAD_LW_AER_BATCH
 #define ECRAD_LW_AER_BATCH(mode) ((mode) == 2 ? 12 : 4)      // aerosol types per batch of table loads, per solver mode (measured)
 #endif
-constexpr int kLwBatch = ECRAD_LW_BATCH;    // (T, S) pairs are 16 B per layer, so the longwave sweep can look further ahead
+constexpr int kLwBatch = ECRAD_LW_BATCH;
+// layers of records requested together by the cloudy-sky sweeps: upward (4 doubles per layer), downward (4), and the
+// one-pair sweeps (clear layers above cloud top, derivatives)
+#ifndef ECRAD_LW_CLD_U
+#define ECRAD_LW_CLD_U 2
+#endif
+#ifndef ECRAD_LW_CLD_D
+#define ECRAD_LW_CLD_D 2
+#endif
+#ifndef ECRAD_LW_CLD_V
+#define ECRAD_LW_CLD_V 2
+#endif
+constexpr int kCldU = ECRAD_LW_CLD_U, kCldD = ECRAD_LW_CLD_D, kCldV = ECRAD_LW_CLD_V;    // (T, S) pairs are 16 B per layer, so the longwave sweep can look further ahead
+
+// Records of one layer for the cloudy-sky sweeps (free functions, not lambdas: the batch arrays must stay in registers)
+ECRAD_DEV int imax(int a, int b) { return a > b ? a : b; }
+ECRAD_DEV int imin(int a, int b) { return a < b ? a : b; }
+struct LwUpRec { double2 a, b; };      // cloudy: a = (R, T), b = (SU, SD);  clear: a = (T, SU), b.y = SD
+ECRAD_DEV void lw_up_load(const LwScratch& s, bool cloudy, int l, int tid, LwUpRec& r) {
+  if (cloudy) { r.a = s.pair(P_RT2, l, tid); r.b = s.pair(P_S2, l, tid); }
+  else { r.a = s.pair(P_CLR, l, tid); r.b = make_double2(0.0, s.single(S_SD1, l, tid)); }
+}
+struct LwDnRec { double2 d, as; };     // (a1, c), (albedo, source) below the layer
+ECRAD_DEV void lw_dn_load(const LwScratch& s, int l, int tid, LwDnRec& r) {
+  r.d = s.pair(P_DN, l, tid);
+  r.as = s.pair(P_AS, l, tid);
+}
+// the layer's transmittance: second of (R, T) if cloudy, first of (T, S) if clear
+ECRAD_DEV double2 lw_trans_load(const LwScratch& s, bool cloudy, int l, int tid) {
+  const double2 v = s.pair(cloudy ? P_RT2 : P_CLR, l, tid);
+  return v;
+}
 
 // WIDE: the launch covers g-points g0 .. g0+NGP-1 of a spectrum wider than 64.  Its sums over g are
 // partial; the derivatives, which the reference normalises by the surface flux summed over the whole
@@ -344,83 +376,130 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
     if (!cloudy.any()) { ict = nlev; fdn_ctop = fdn_c; }
     const double w = (MODE == 2) ? tcc : 1.0;
     const bool blend = w < 1.0;
-    // upward sweep from the surface to cloud top: albedo & source below each half level
+    // The three sweeps below have almost no arithmetic per layer; they would pay one HBM round trip per layer if
+    // each step waited for its own records, so every sweep requests the records of the next kCld* layers before
+    // it works on the current ones (the addresses do not depend on the recurrences).
+    // upward sweep from the surface to cloud top: albedo & source below each half level; it leaves, per layer, the
+    // record of the downward sweep: pair (a1, c) in P_DN (the layer's P_S2 slot, consumed by then) and pair
+    // (albedo, source) below the layer in P_AS, so that   fdn <- a1 fdn + c,   fup = albedo fdn + source
+    // (radiation_adding_ica_lw.F90:192-216 with 1/(1 - albedo R) folded into a1 and c)
     double alb = albedo, src = emission;
-    s.pair(P_AS, nlev, tid) = make_double2(alb, src);
-    for (int l = nlev - 1; l >= ict; --l) {
-      if (cloudy.test(l)) {
-        const double2 rt = s.pair(P_RT2, l, tid), sud = s.pair(P_S2, l, tid);
-        const double R = rt.x, T = rt.y;
-        const double inv = 1.0 / (1.0 - alb * R);
-        const double src_new = sud.x + T * (src + alb * sud.y) * inv;
-        alb = R + T * T * alb * inv;
-        src = src_new;
-      } else {
-        const double2 ts = s.pair(P_CLR, l, tid);
-        const double T = ts.x;
-        const double src_new = ts.y + T * (src + alb * s.single(S_SD1, l, tid));
-        alb = T * T * alb;
-        src = src_new;
+    {
+      // (out-of-range entries of a batch load a clamped layer instead of nothing: every entry is always defined, and
+      // no value has to be carried around the column-group loop)
+      const int ict_c = ict < nlev ? ict : nlev - 1;
+      LwUpRec cur[kCldU], nxt[kCldU];
+#pragma unroll
+      for (int k = 0; k < kCldU; ++k)
+        { const int l = imax(nlev - 1 - k, ict_c); lw_up_load(s, cloudy.test(l), l, tid, cur[k]); }
+      for (int l0 = nlev - 1; l0 >= ict; l0 -= kCldU) {
+#pragma unroll
+        for (int k = 0; k < kCldU; ++k)
+          { const int l = imax(l0 - kCldU - k, ict_c); lw_up_load(s, cloudy.test(l), l, tid, nxt[k]); }
+#pragma unroll
+        for (int k = 0; k < kCldU; ++k) {
+          const int l = l0 - k;
+          if (l >= ict) {
+            s.pair(P_AS, l, tid) = make_double2(alb, src);       // below layer l
+            if (cloudy.test(l)) {
+              const double R = cur[k].a.x, T = cur[k].a.y;
+              const double inv = 1.0 / (1.0 - alb * R);
+              s.pair(P_DN, l, tid) = make_double2(T * inv, (R * src + cur[k].b.y) * inv);
+              const double src_new = cur[k].b.x + T * (src + alb * cur[k].b.y) * inv;
+              alb = R + T * T * alb * inv;
+              src = src_new;
+            } else {
+              const double T = cur[k].a.x;
+              s.pair(P_DN, l, tid) = make_double2(T, cur[k].b.y);
+              const double src_new = cur[k].a.y + T * (src + alb * cur[k].b.y);
+              alb = T * T * alb;
+              src = src_new;
+            }
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < kCldU; ++k) cur[k] = nxt[k];
       }
-      s.pair(P_AS, l, tid) = make_double2(alb, src);
     }
     // flux at cloud top and upward through the clear layers above it
     fup = src + alb * fdn_ctop;
     {
       double keep_up = 0.0;      // lane (l mod NGP) keeps half level l; written NGP half levels at a time
-      for (int l = ict; l >= 0; --l) {
-        if (l < ict) { const double2 ts = s.pair(P_CLR, l, tid); fup = ts.x * fup + ts.y; }
-        if (fx.lw_up_band && valid) spec_put(fx.lw_up_band, ng, g, col + ncol * ord.half(l), fup);
-        const double su = group_sum<NGP>(valid ? fup : 0.0);
-        if ((l & (NGP - 1)) == glane) keep_up = su;
-        if ((l & (NGP - 1)) == 0) {
-          const int lv = l + glane;
-          if (col_ok && lv <= ict) {
-            const size_t o = col + ncol * ord.half(lv);
-            fx.lw_up[o] = blend ? w * keep_up + (1.0 - w) * fx.lw_up_clear[o] : keep_up;
+      // entry k of a batch is half level l0 - k; half level ict itself needs no record
+      double2 cur[kCldV], nxt[kCldV];
+      cur[0] = make_double2(0.0, 0.0);
+#pragma unroll
+      for (int k = 1; k < kCldV; ++k)
+        cur[k] = s.pair(P_CLR, imax(ict - k, 0), tid);
+      for (int l0 = ict; l0 >= 0; l0 -= kCldV) {
+#pragma unroll
+        for (int k = 0; k < kCldV; ++k)
+          nxt[k] = s.pair(P_CLR, imax(l0 - kCldV - k, 0), tid);
+#pragma unroll
+        for (int k = 0; k < kCldV; ++k) {
+          const int l = l0 - k;
+          if (l >= 0) {
+            if (l < ict) fup = cur[k].x * fup + cur[k].y;
+            if (fx.lw_up_band && valid) spec_put(fx.lw_up_band, ng, g, col + ncol * ord.half(l), fup);
+            const double su = group_sum<NGP>(valid ? fup : 0.0);
+            if ((l & (NGP - 1)) == glane) keep_up = su;
+            if ((l & (NGP - 1)) == 0) {
+              const int lv = l + glane;
+              if (col_ok && lv <= ict) {
+                const size_t o = col + ncol * ord.half(lv);
+                fx.lw_up[o] = blend ? w * keep_up + (1.0 - w) * fx.lw_up_clear[o] : keep_up;
+              }
+            }
           }
         }
+#pragma unroll
+        for (int k = 0; k < kCldV; ++k) cur[k] = nxt[k];
       }
     }
     const double fup_toa = fup;
     // downward sweep below cloud top
     double fdn = fdn_ctop;
-    LevelSums<NGP, 2> kept;
-    for (int l = ict; l < nlev; ++l) {
-      const double2 as = s.pair(P_AS, l + 1, tid);
-      const double albn = as.x, srcn = as.y;
-      if (cloudy.test(l)) {
-        const double2 rt = s.pair(P_RT2, l, tid);
-        const double R = rt.x;
-        const double inv = 1.0 / (1.0 - albn * R);
-        const double2 s2 = s.pair(P_S2, l, tid);
-        fdn = (rt.y * fdn + R * srcn + s2.y) * inv;
-      } else {
-        const double2 ts = s.pair(P_CLR, l, tid);
-        fdn = ts.x * fdn + s.single(S_SD1, l, tid);
-      }
-      fup = albn * fdn + srcn;
-      const double sums[2] = {group_sum<NGP>(valid ? fup : 0.0), group_sum<NGP>(valid ? fdn : 0.0)};
-      const int hl = l + 1;
-      if (fx.lw_up_band && valid) {
-        const size_t o = col + ncol * ord.half(hl);
-        spec_put(fx.lw_up_band, ng, g, o, fup);
-        spec_put(fx.lw_dn_band, ng, g, o, fdn);
-      }
-      kept.keep(hl, glane, sums);
-      if ((hl & (NGP - 1)) == NGP - 1 || hl == nlev) {
-        const int lv = kept.mine(hl, glane);
-        if (col_ok && lv > ict && lv <= hl) {
-          const size_t o = col + ncol * ord.half(lv);
-          fx.lw_up[o] = blend ? w * kept.v[0] + (1.0 - w) * fx.lw_up_clear[o] : kept.v[0];
-          fx.lw_dn[o] = blend ? w * kept.v[1] + (1.0 - w) * fx.lw_dn_clear[o] : kept.v[1];
+    {
+      LevelSums<NGP, 2> kept;
+      LwDnRec cur[kCldD], nxt[kCldD];
+#pragma unroll
+      for (int k = 0; k < kCldD; ++k)
+        lw_dn_load(s, imin(ict + k, nlev - 1), tid, cur[k]);
+      for (int l0 = ict; l0 < nlev; l0 += kCldD) {
+#pragma unroll
+        for (int k = 0; k < kCldD; ++k)
+          lw_dn_load(s, imin(l0 + kCldD + k, nlev - 1), tid, nxt[k]);
+#pragma unroll
+        for (int k = 0; k < kCldD; ++k) {
+          const int l = l0 + k;
+          if (l < nlev) {
+            fdn = cur[k].d.x * fdn + cur[k].d.y;
+            fup = cur[k].as.x * fdn + cur[k].as.y;
+            const double sums[2] = {group_sum<NGP>(valid ? fup : 0.0), group_sum<NGP>(valid ? fdn : 0.0)};
+            const int hl = l + 1;
+            if (fx.lw_up_band && valid) {
+              const size_t o = col + ncol * ord.half(hl);
+              spec_put(fx.lw_up_band, ng, g, o, fup);
+              spec_put(fx.lw_dn_band, ng, g, o, fdn);
+            }
+            kept.keep(hl, glane, sums);
+            if ((hl & (NGP - 1)) == NGP - 1 || hl == nlev) {
+              const int lv = kept.mine(hl, glane);
+              if (col_ok && lv > ict && lv <= hl) {
+                const size_t o = col + ncol * ord.half(lv);
+                fx.lw_up[o] = blend ? w * kept.v[0] + (1.0 - w) * fx.lw_up_clear[o] : kept.v[0];
+                fx.lw_dn[o] = blend ? w * kept.v[1] + (1.0 - w) * fx.lw_dn_clear[o] : kept.v[1];
+              }
+            }
+          }
         }
+#pragma unroll
+        for (int k = 0; k < kCldD; ++k) cur[k] = nxt[k];
       }
     }
     if (ict == nlev) {   // no cloudy layer at all: surface values come from the clear-sky sweep
       fdn = fdn_c;
-      const double2 as = s.pair(P_AS, nlev, tid);
-      fup = as.x * fdn + as.y;
+      fup = albedo * fdn + emission;
     }
     if (valid) {
       const size_t og = g + (size_t)ng * col;
@@ -438,21 +517,33 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
       if (WIDE && lead) wide_dst[col + ncol * ord.half(nlev)] = ssurf;
       const double wclr = 1.0 - tcc;
       double keep_der = 0.0;
-      for (int l = nlev - 1; l >= 0; --l) {
-        double tl;
-        if (cloudy.test(l)) { const double2 rt = s.pair(P_RT2, l, tid); tl = rt.y; }
-        else { const double2 ts = s.pair(P_CLR, l, tid); tl = ts.x; }
-        d = d * tl;
-        const double sder = group_sum<NGP>(valid ? d : 0.0);
-        if ((l & (NGP - 1)) == glane) keep_der = sder;
-        if ((l & (NGP - 1)) == 0) {
-          const int lv = l + glane;
-          if (col_ok && lv < nlev) {
-            const size_t o = col + ncol * ord.half(lv);
-            if (WIDE) wide_dst[o] = keep_der;
-            else fx.lw_derivatives[o] = modify ? (1.0 - wclr) * keep_der + wclr * fx.lw_derivatives[o] : keep_der;
+      double2 cur[kCldV], nxt[kCldV];
+#pragma unroll
+      for (int k = 0; k < kCldV; ++k)
+        { const int l = imax(nlev - 1 - k, 0); cur[k] = lw_trans_load(s, cloudy.test(l), l, tid); }
+      for (int l0 = nlev - 1; l0 >= 0; l0 -= kCldV) {
+#pragma unroll
+        for (int k = 0; k < kCldV; ++k)
+          { const int l = imax(l0 - kCldV - k, 0); nxt[k] = lw_trans_load(s, cloudy.test(l), l, tid); }
+#pragma unroll
+        for (int k = 0; k < kCldV; ++k) {
+          const int l = l0 - k;
+          if (l >= 0) {
+            d = d * (cloudy.test(l) ? cur[k].y : cur[k].x);
+            const double sder = group_sum<NGP>(valid ? d : 0.0);
+            if ((l & (NGP - 1)) == glane) keep_der = sder;
+            if ((l & (NGP - 1)) == 0) {
+              const int lv = l + glane;
+              if (col_ok && lv < nlev) {
+                const size_t o = col + ncol * ord.half(lv);
+                if (WIDE) wide_dst[o] = keep_der;
+                else fx.lw_derivatives[o] = modify ? (1.0 - wclr) * keep_der + wclr * fx.lw_derivatives[o] : keep_der;
+              }
+            }
           }
         }
+#pragma unroll
+        for (int k = 0; k < kCldV; ++k) cur[k] = nxt[k];
       }
     }
     (void)fup_surf_clear;

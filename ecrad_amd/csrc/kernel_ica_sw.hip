@@ -15,7 +15,7 @@
 //     a1 = T/(1-A R),  b = (R sigma t_dd + t_df)/(1-A R),  t_dd,  A(l+1),  sigma(l+1)
 // and sweep 2 goes DOWN:  F' = F t_dd;  Fdn' = a1 Fdn + F b;  Fup' = A Fdn' + sigma F'.
 // Same arithmetic as radiation_adding_ica_sw.F90:85-147 up to re-association (parity tests: 1e-8).
-// HBM traffic per (g, layer): 5 doubles written + 5 read (was 7 + 13 with three sweeps).
+// HBM traffic per (g, layer): 5 doubles written + 5 read (was 7 + 13 with three sweeps), packed into 32 bytes each way.
 #include "kernels_common.h"
 #include "optics_device.h"
 #include "launch.h"
@@ -35,6 +35,8 @@ struct SwScratch {
   ECRAD_DEV StreamRef<double> single(int set, int lev, int tid) const {
     return {base + ((size_t)(set * nlev + lev) * 5 + 4) * kBlock + tid};
   }
+  // packed form (ECRAD_PACK_SW): the five values of a record in 32 bytes, see pack5 in kernels_common.h
+  ECRAD_DEV size_t rec(int set, int lev) const { return (size_t)(set * nlev + lev); }
 };
 
 struct SwSweepState {   // albedo / normalised source below the current half level
@@ -49,9 +51,13 @@ ECRAD_DEV void sw_up_step(const SwScratch& s, int set, int lev, int tid, const S
   p1.x = c.trans_dir_dir;
   p1.y = st.alb;
 #if !(ECRAD_ABLATE & 8)
+#if ECRAD_PACK_SW
+  packed5_store(s.base, s.rec(set, lev), tid, pack5(p0.x, p0.y, p1.x, p1.y, st.sig));
+#else
   s.pair(set, 0, lev, tid) = p0;
   s.pair(set, 1, lev, tid) = p1;
   s.single(set, lev, tid) = st.sig;
+#endif
 #endif
   const double sig_new = c.ref_dir + c.trans_diff * (st.sig * c.trans_dir_dir + st.alb * c.trans_dir_diff) * inv;
   st.alb = c.ref_diff + c.trans_diff * c.trans_diff * st.alb * inv;
@@ -59,22 +65,32 @@ ECRAD_DEV void sw_up_step(const SwScratch& s, int set, int lev, int tid, const S
 }
 
 // One layer's record for the flux sweep.
+#if ECRAD_PACK_SW
+typedef Packed5 SwRec;
+#else
 struct SwRec {
   double2 p0, p1;
   double sig;
 };
+#endif
 
 constexpr int kSwBatch = ECRAD_SWEEP_BATCH;     // layers fetched per batch in the flux sweep (software pipelining depth)
 
 ECRAD_DEV void sw_load_batch(const SwScratch& s, bool set2, int lcb, int tid, int nlev, int lay0, SwRec (&r)[kSwBatch]) {
 #pragma unroll
   for (int k = 0; k < kSwBatch; ++k) {
-    const int lay = lay0 + k;
-    if (lay < nlev) {
+    // (past the last layer a batch entry re-reads it: every entry is always defined and nothing is carried around
+    // the column-group loop, which would cost registers in the optics sweep)
+    const int lay = lay0 + k < nlev ? lay0 + k : nlev - 1;
+    {
       const int set = (set2 && lay <= lcb) ? 1 : 0;
+#if ECRAD_PACK_SW
+      r[k] = packed5_load(s.base, s.rec(set, lay), tid);
+#else
       r[k].p0 = s.pair(set, 0, lay, tid);
       r[k].p1 = s.pair(set, 1, lay, tid);
       r[k].sig = s.single(set, lay, tid);
+#endif
     }
   }
 }
@@ -145,13 +161,19 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
   sw_load_batch(s, set2, lcb, tid, nlev, 0, cur);
   emit(0);
   for (int lay0 = 0; lay0 < nlev; lay0 += kSwBatch) {
-    if (lay0 + kSwBatch < nlev) sw_load_batch(s, set2, lcb, tid, nlev, lay0 + kSwBatch, nxt);
+    sw_load_batch(s, set2, lcb, tid, nlev, lay0 + kSwBatch, nxt);
 #pragma unroll
     for (int k = 0; k < kSwBatch; ++k) {
       if (lay0 + k < nlev) {
-        fdn = cur[k].p0.x * fdn + Fd * cur[k].p0.y;
-        Fd = Fd * cur[k].p1.x;
-        fup = cur[k].p1.y * fdn + cur[k].sig * Fd;
+#if ECRAD_PACK_SW
+        double r_a1, r_b, r_tdd, r_alb, r_sig;
+        unpack5(cur[k], r_a1, r_b, r_tdd, r_alb, r_sig);
+#else
+        const double r_a1 = cur[k].p0.x, r_b = cur[k].p0.y, r_tdd = cur[k].p1.x, r_alb = cur[k].p1.y, r_sig = cur[k].sig;
+#endif
+        fdn = r_a1 * fdn + Fd * r_b;
+        Fd = Fd * r_tdd;
+        fup = r_alb * fdn + r_sig * Fd;
         emit(lay0 + k + 1);
       }
     }
@@ -505,9 +527,9 @@ static hipError_t launch_sw_mode(int mode, dim3 grid, size_t lds, hipStream_t st
   return hipGetLastError();
 }
 
-// doubles of scratch per block: [set][level][5 * 256]
+// doubles of scratch per block: [set][level][5 * 256] (packed records use 4 of the 5)
 size_t sw_ica_scratch_doubles(int mode, int nlev) {
-  return (size_t)(mode == ECRAD_SOLVER_CLOUDLESS ? 1 : 2) * nlev * 5 * kBlock;
+  return (size_t)(mode == ECRAD_SOLVER_CLOUDLESS ? 1 : 2) * nlev * (ECRAD_PACK_SW ? 4 : 5) * kBlock;
 }
 
 hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,

@@ -256,12 +256,20 @@ __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __
         const bool lower = active && r.i(LI_LOWER) != 0;
         double tau = 0.0, pfrac = 0.0;
         // the two regimes in turn, each with a wave-uniform descriptor (most waves have lanes in one of them only)
+#if ECRAD_ABLATE & 32      // (tuning only) no evaluation: what the stores alone cost
+        tau = r.d(LD_FAC00); pfrac = r.d(LD_FAC01);
+#else
         for (int rg = 0; rg < 2; ++rg)
           if (active && lower == (rg == 0)) lw_gpoint_regime(T, B, B.reg[rg], rg == 0, r, ig, tau, pfrac);
+#endif
         if (!active) continue;
         const int g = B.g0 + ig;
         double od = dmax(T.min_gas_od_lw, tau);
         if (fold_lw) od = od + s_aer[ib * kTileCols + c];      // radiation_aerosol_optics.F90:805-818
+#if ECRAD_ABLATE & 16      // (tuning only) no stage stores: what the evaluation alone costs
+        if (od + pfrac == -1.2345) out.od_lw[0] = od;
+        continue;
+#endif
         out.od_lw[g + (size_t)kNgLw * (lev + (size_t)nlev * cloc)] = od;
         // planck_hl(g, half level) = band Planck function at the half level x fraction of the layer ABOVE it
         // (of the top layer for the top half level): radiation_ifs_rrtm.F90:715-724
@@ -306,8 +314,12 @@ __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __
           const bool lower = r.i(SI_LOWER) != 0;
           const bool want = w.isol[(size_t)ib * nloc + cloc] == lev;
           double taug = 0.0, taur = 0.0, sflux = 0.0;
+#if ECRAD_ABLATE & 32
+          taug = r.d(SD_FAC00); taur = r.d(SD_FAC01);
+#else
           for (int rg = 0; rg < 2; ++rg)
             if (lower == (rg == 0)) sw_gpoint_regime(T, B, B.reg[rg], rg == 0, r, ig, want, taug, taur, sflux);
+#endif
           const double od_gas = taur + taug;
           double od = dmax(T.min_gas_od_sw, od_gas), ssa = taur / od_gas, asym = 0.0;
           if (fold_sw) {
@@ -315,6 +327,10 @@ __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __
             merge_aerosol_sw(cfg, al, od, ssa, asym);
             out.g_sw[o] = asym;
           }
+#if ECRAD_ABLATE & 16
+          if (od + ssa == -1.2345) out.od_sw[0] = od;
+          continue;
+#endif
           out.od_sw[o] = od;
           out.ssa_sw[o] = ssa;
           if (want) out.incoming_sw[g + (size_t)kNgSw * cloc] = sflux;

@@ -135,6 +135,8 @@ struct TcSwScratch {
   ECRAD_DEV StreamRef<double> single(int set, int lev, int tid) const {
     return {base + ((size_t)(lev * 4 + set) * 5 + 4) * kBlock + tid};
   }
+  // packed form (ECRAD_PACK_SW): the five values of a record in 32 bytes, see pack5 in kernels_common.h
+  ECRAD_DEV size_t rec(int set, int lev) const { return (size_t)(lev * 4 + set); }
 };
 
 // one region's step of the upward sweep: store the flux-sweep record, return the albedos just below
@@ -142,9 +144,14 @@ struct TcSwScratch {
 ECRAD_DEV void tc_sw_up(const TcSwScratch& s, int set, int lev, int tid, const SwCoef& c, double A, double Ad,
                         double& A_new, double& Ad_new) {
   const double inv = 1.0 / (1.0 - A * c.ref_diff);
+#if ECRAD_PACK_SW
+  packed5_store(s.base, s.rec(set, lev), tid,
+                pack5(c.trans_diff * inv, (c.trans_dir_dir * Ad * c.ref_diff + c.trans_dir_diff) * inv, c.trans_dir_dir, A, Ad));
+#else
   s.pair(set, 0, lev, tid) = make_double2(c.trans_diff * inv, (c.trans_dir_dir * Ad * c.ref_diff + c.trans_dir_diff) * inv);
   s.pair(set, 1, lev, tid) = make_double2(c.trans_dir_dir, A);
   s.single(set, lev, tid) = Ad;
+#endif
   A_new = c.ref_diff + c.trans_diff * c.trans_diff * A * inv;
   Ad_new = c.ref_dir + (c.trans_dir_dir * Ad + c.trans_dir_diff * A) * c.trans_diff * inv;
 }
@@ -407,6 +414,21 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
     constexpr int K = ECRAD_TC_BATCH_S;
     for (int l0 = 0; l0 < ((ECRAD_ABLATE & 4) ? 0 : nlev); l0 += K) {
       // records of K layers requested together
+#if ECRAD_PACK_SW
+      Packed5 pk[K][4];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int l = l0 + k < nlev ? l0 + k : nlev - 1;      // (past the last layer: re-read it, unused)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { pk[k][q].w0 = ecrad_v4u{0u, 0u, 0u, 0u}; pk[k][q].w1 = ecrad_v4u{0u, 0u, 0u, 0u}; }
+        if (do_clear) pk[k][3] = packed5_load(s.base, s.rec(3, l), tid);
+        if (!do_clear || l <= lcb) pk[k][0] = packed5_load(s.base, s.rec(0, l), tid);
+        if (cloudy.test(l)) {
+#pragma unroll
+          for (int r = 1; r < 3; ++r) pk[k][r] = packed5_load(s.base, s.rec(r, l), tid);
+        }
+      }
+#else
       double2 p0[K][4], p1[K][4];
       double pad[K][4];
 #pragma unroll
@@ -423,33 +445,47 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
           }
         }
       }
+#endif
       if (l0 + K - 1 >= cloudy_first - 1) feed.template fetch<K>(l0 + 1, 1);     // v_matrix of the half level below each layer
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const int l = l0 + k;
         if (l < nlev) {
+          // one record: fdn <- a1 fdn + b ddn;  ddn <- t_dd ddn;  fup = Ad ddn + A fdn
+          struct R5 { double a1, b, tdd, A, Ad; };
+          auto rec = [&](int q) {
+            R5 r;
+#if ECRAD_PACK_SW
+            unpack5(pk[k][q], r.a1, r.b, r.tdd, r.A, r.Ad);
+#else
+            r.a1 = p0[k][q].x; r.b = p0[k][q].y; r.tdd = p1[k][q].x; r.A = p1[k][q].y; r.Ad = pad[k][q];
+#endif
+            return r;
+          };
+          const R5 rc = rec(3);
           if (do_clear) {
-            fdn_c = p0[k][3].x * fdn_c + ddn_c * p0[k][3].y;
-            ddn_c = p1[k][3].x * ddn_c;
-            fup_c = ddn_c * pad[k][3] + fdn_c * p1[k][3].y;
+            fdn_c = rc.a1 * fdn_c + ddn_c * rc.b;
+            ddn_c = rc.tdd * ddn_c;
+            fup_c = ddn_c * rc.Ad + fdn_c * rc.A;
           }
           {
             const bool shared = do_clear && l > lcb;      // region 1 record == clear-sky record
-            const double2 q0 = shared ? p0[k][3] : p0[k][0], q1 = shared ? p1[k][3] : p1[k][0];
-            const double ad = shared ? pad[k][3] : pad[k][0];
-            fdn[0] = q0.x * fdn[0] + ddn[0] * q0.y;
-            ddn[0] = q1.x * ddn[0];
-            fup[0] = ddn[0] * ad + fdn[0] * q1.y;
+            const R5 r0 = rec(0);
+            const R5 r = shared ? rc : r0;
+            fdn[0] = r.a1 * fdn[0] + ddn[0] * r.b;
+            ddn[0] = r.tdd * ddn[0];
+            fup[0] = ddn[0] * r.Ad + fdn[0] * r.A;
           }
           const bool cl_here = cloudy.test(l);
           if (!cl_here) {
             fdn[1] = fdn[2] = 0.0; fup[1] = fup[2] = 0.0; ddn[1] = ddn[2] = 0.0;
           } else {
 #pragma unroll
-            for (int r = 1; r < 3; ++r) {
-              fdn[r] = p0[k][r].x * fdn[r] + ddn[r] * p0[k][r].y;
-              ddn[r] = p1[k][r].x * ddn[r];
-              fup[r] = ddn[r] * pad[k][r] + fdn[r] * p1[k][r].y;
+            for (int q = 1; q < 3; ++q) {
+              const R5 r = rec(q);
+              fdn[q] = r.a1 * fdn[q] + ddn[q] * r.b;
+              ddn[q] = r.tdd * ddn[q];
+              fup[q] = ddn[q] * r.Ad + fdn[q] * r.A;
             }
           }
           const int hl = l + 1;
@@ -486,7 +522,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
   }
 }
 
-size_t sw_tc_scratch_doubles(int nlev) { return (size_t)4 * 5 * nlev * kBlock; }
+size_t sw_tc_scratch_doubles(int nlev) { return (size_t)4 * (ECRAD_PACK_SW ? 4 : 5) * nlev * kBlock; }
 
 hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block,

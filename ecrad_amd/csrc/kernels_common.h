@@ -371,6 +371,66 @@ template <> struct StreamRef<double2> {
   }
 };
 
+// ---- five doubles in 32 bytes ---------------------------------------------------------------------------
+// The shortwave flux-sweep record of one (g-point, layer) is five doubles (kernel_ica_sw.hip, kernel_tc.hip).  Their
+// high words travel whole (sign, exponent, 20 mantissa bits); of each low word the upper 19 bits are kept: 39
+// mantissa bits, a relative truncation of at most 1.8e-12 per value (the parity tests demand 1e-8 on the fluxes
+// after 137 layers).  8 words instead of 10 per record: the sweep scratch is the dominant HBM traffic of these
+// kernels, and the (un)packing costs 27 integer instructions per layer against ~450 for the layer's optics.
+#ifndef ECRAD_PACK_SW
+#define ECRAD_PACK_SW 1
+#endif
+typedef unsigned ecrad_v4u __attribute__((ext_vector_type(4)));
+struct Packed5 {
+  ecrad_v4u w0, w1;
+};
+ECRAD_DEV Packed5 pack5(double v0, double v1, double v2, double v3, double v4) {
+  const unsigned long long u0 = (unsigned long long)__double_as_longlong(v0), u1 = (unsigned long long)__double_as_longlong(v1),
+                           u2 = (unsigned long long)__double_as_longlong(v2), u3 = (unsigned long long)__double_as_longlong(v3),
+                           u4 = (unsigned long long)__double_as_longlong(v4);
+  const unsigned l0 = (unsigned)u0 >> 13, l1 = (unsigned)u1 >> 13, l2 = (unsigned)u2 >> 13, l3 = (unsigned)u3 >> 13, l4 = (unsigned)u4 >> 13;
+  Packed5 p;
+  p.w0.x = (unsigned)(u0 >> 32); p.w0.y = (unsigned)(u1 >> 32); p.w0.z = (unsigned)(u2 >> 32); p.w0.w = (unsigned)(u3 >> 32);
+  p.w1.x = (unsigned)(u4 >> 32);
+  p.w1.y = l0 | ((l1 & 0x1FFFu) << 19);
+  p.w1.z = (l1 >> 13) | (l2 << 6) | ((l3 & 0x7Fu) << 25);
+  p.w1.w = (l3 >> 7) | (l4 << 12);
+  return p;
+}
+ECRAD_DEV void unpack5(const Packed5& p, double& v0, double& v1, double& v2, double& v3, double& v4) {
+  const unsigned l0 = p.w1.y & 0x7FFFFu;
+  const unsigned l1 = (p.w1.y >> 19) | ((p.w1.z & 0x3Fu) << 13);
+  const unsigned l2 = (p.w1.z >> 6) & 0x7FFFFu;
+  const unsigned l3 = (p.w1.z >> 25) | ((p.w1.w & 0xFFFu) << 7);
+  const unsigned l4 = (p.w1.w >> 12) & 0x7FFFFu;
+  v0 = __longlong_as_double((long long)(((unsigned long long)p.w0.x << 32) | (l0 << 13)));
+  v1 = __longlong_as_double((long long)(((unsigned long long)p.w0.y << 32) | (l1 << 13)));
+  v2 = __longlong_as_double((long long)(((unsigned long long)p.w0.z << 32) | (l2 << 13)));
+  v3 = __longlong_as_double((long long)(((unsigned long long)p.w0.w << 32) | (l3 << 13)));
+  v4 = __longlong_as_double((long long)(((unsigned long long)p.w1.x << 32) | (l4 << 13)));
+}
+// slab of packed records: record r of thread tid at base + (r * 2 * 256 + tid) 16-byte words (+256 for the second word)
+ECRAD_DEV void packed5_store(double* base, size_t rec, int tid, const Packed5& p) {
+  ecrad_v4u* q = reinterpret_cast<ecrad_v4u*>(base) + rec * (2 * kBlock) + tid;
+#if ECRAD_NT_SCRATCH
+  __builtin_nontemporal_store(p.w0, q);
+  __builtin_nontemporal_store(p.w1, q + kBlock);
+#else
+  q[0] = p.w0; q[kBlock] = p.w1;
+#endif
+}
+ECRAD_DEV Packed5 packed5_load(const double* base, size_t rec, int tid) {
+  const ecrad_v4u* q = reinterpret_cast<const ecrad_v4u*>(base) + rec * (2 * kBlock) + tid;
+  Packed5 p;
+#if ECRAD_NT_SCRATCH
+  p.w0 = __builtin_nontemporal_load(q);
+  p.w1 = __builtin_nontemporal_load(q + kBlock);
+#else
+  p.w0 = q[0]; p.w1 = q[kBlock];
+#endif
+  return p;
+}
+
 // ---- per-block scratch in HBM ----------------------------------------------------------------------
 // Each block owns a private slab reused for every column group it processes (persistent blocks), so
 // the working set is bounded by the grid, not by the number of columns of a call (it is still ~1 GB
