@@ -1,8 +1,9 @@
 #!/bin/bash
-# one GPU call: parity tests, then the tuning variants side by side
+# one GPU call: taumol ablations (kernel stats per variant), then the profile of the headline workload
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/r02_e_tests.log 2>&1; echo "pytest exit $?" >> gpurun_out/r02_e_tests.log
-tail -5 gpurun_out/r02_e_tests.log
-for w in clear_homogeneous_ecckd32 tripleclouds_ecckd32 mcica_ecckd32 mcica_rrtmg; do
-  echo "== $w"; bash tools/run_variants.sh --headline-only --workload $w
-done 2>&1 | tee gpurun_out/r02_e_variants.log
+for v in cur abl16 abl32; do
+  echo "== $v"
+  ECRAD_HIP_LIB=$PWD/build_variants/$v/libecrad_hip.so bash tools/kstats.sh mcica_rrtmg 2>&1 | head -8
+done 2>&1 | tee gpurun_out/r02_f_taumol_ablation.log
+bash tools/profile.sh r02_f > gpurun_out/r02_f_profile.log 2>&1
+tail -3 gpurun_out/r02_f_profile.log
