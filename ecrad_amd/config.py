@@ -172,8 +172,14 @@ class Config:
     @classmethod
     def read(cls, file_name: str) -> "Config":
         """config%read (radiation_config.F90:664-1104): the ``&radiation`` group."""
+        return cls().read_into(file_name)
+
+    def read_into(self, file_name: str) -> "Config":
+        """config%read on an object that already holds settings (the reference's read starts from the current
+        values, radiation_config.F90:787-880: ifs/radiation_setup.F90:504-506 relies on that to let a namelist
+        override what the host model chose); entries absent from the namelist keep their values."""
         nml = read_namelist(file_name).get("radiation", {})
-        c = cls()
+        c = self
         simple = [
             "do_sw", "do_lw", "do_sw_direct", "do_clear", "do_save_spectral_flux", "do_save_gpoint_flux",
             "do_surface_sw_spectral_flux", "do_lw_derivatives", "do_toa_spectral_flux",

@@ -198,10 +198,13 @@ class SpectralDefinition:
         return mapping
 
     # -- calc_mapping_from_bands (:515-760), without use_fluxes --------------------------------------
-    def calc_mapping_from_bands(self, wavelength_bound, i_intervals, use_bands=False):
-        """Return mapping as numpy (nout, ninput) == Fortran mapping(ninput, nout).
+    def calc_mapping_from_bands(self, wavelength_bound, i_intervals, use_bands=False, use_fluxes=False):
+        """Return mapping as numpy (nout, ninput) == Fortran mapping(ninput, nout)
+        (radiation_spectral_definition.F90:515-811).
 
-        ``i_intervals`` is 1-based as in the namelist (i_sw_albedo_index / i_lw_emiss_index).
+        ``i_intervals`` is 1-based as in the namelist (i_sw_albedo_index / i_lw_emiss_index).  With ``use_fluxes`` the
+        matrix works the other way round (:504-507): applied to fluxes per band or g-point it returns the fluxes in
+        the user's intervals, each entry being the fraction of the band (g-point) that lies in the interval.
         """
         wavelength_bound = np.asarray(wavelength_bound, dtype=np.float64)
         i_intervals = np.asarray(i_intervals, dtype=np.int64)
@@ -212,6 +215,7 @@ class SpectralDefinition:
                 raise ValueError("wavelength bounds must be monotonically increasing")
         if use_bands:
             mapping = np.zeros((self.nband, ninput))
+            denom = np.zeros((self.nband, ninput))
             weight_sample = np.array([0.5, 1.0, 1.0, 1.0, 0.5])
             for jband in range(self.nband):
                 for jint in range(ninterval):
@@ -224,6 +228,13 @@ class SpectralDefinition:
                         planck_sample = planck_function_wavenumber(sample, self.reference_temperature)
                         mapping[jband, i_intervals[jint] - 1] += \
                             np.sum(planck_sample * weight_sample) * (wn2b - wn1b)
+                        if use_fluxes:      # the same integral over the whole band (:655-664)
+                            w1, w2 = self.wavenumber1_band[jband], self.wavenumber2_band[jband]
+                            sample = w1 + np.arange(5) * (w2 - w1) / 4.0
+                            planck_sample = planck_function_wavenumber(sample, self.reference_temperature)
+                            denom[jband, i_intervals[jint] - 1] += np.sum(planck_sample * weight_sample) * (w2 - w1)
+            if use_fluxes:
+                return mapping / np.maximum(1.0e-12, denom)
         else:
             if self.ng == 0:
                 raise ValueError("requested surface mapping per g-point but only available per band")
@@ -238,5 +249,7 @@ class SpectralDefinition:
                     if wn2b > wn1b:
                         mapping[:, i_intervals[jint] - 1] += self.gpoint_fraction[:, jwav] * (
                             planck[jwav] * (wn2b - wn1b) / (self.wavenumber2[jwav] - self.wavenumber1[jwav]))
+            if use_fluxes:          # :784-788
+                return mapping / (self.gpoint_fraction @ planck)[:, None]
         mapping *= (1.0 / mapping.sum(axis=1))[:, None]
         return mapping

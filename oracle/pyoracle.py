@@ -21,6 +21,7 @@ def build(ref: bool = False) -> None:
     subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
     if ref and os.path.isdir("/root/reference"):
         subprocess.run(["make", "-C", _HERE, "ref"], check=True, capture_output=True)
+        subprocess.run(["make", "-C", _HERE, "refifs"], check=True, capture_output=True)
 
 
 _lib = None
@@ -162,6 +163,60 @@ def ref_clear_sky_solvers(stage: dict, cos_sza, nblocksize: int = 32):
     _ref_leaf.ref_clear_sky_solvers(C.c_int(ncol), C.c_int(nlev), C.c_int(ng_sw), C.c_int(ng_lw), C.c_int(nblocksize), p(mu0),
                                     *[p(a) for a in keep], *[p(out[k]) for k in ("sw_up", "sw_dn", "sw_dn_direct", "lw_up", "lw_dn")])
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# The reference's IFS-side parametrisations (ifs/liquid_effective_radius.F90, ifs/ice_effective_radius.F90,
+# ifs/cloud_overlap_decorr_len.F90) compiled into oracle/_ref/libecrad_refifs.so (oracle/Makefile: refifs) with the
+# bind(C) shims of oracle/ref_ifs_wrappers.F90.  Arrays are numpy (klev, klon) == Fortran (KLON, KLEV).
+REF_IFS_PATH = os.path.join(_HERE, "_ref", "libecrad_refifs.so")
+_ref_ifs = None
+
+
+def have_ref_ifs() -> bool:
+    return os.path.exists(REF_IFS_PATH)
+
+
+def _ref_ifs_lib():
+    global _ref_ifs
+    if _ref_ifs is None:
+        _ref_ifs = C.CDLL(REF_IFS_PATH)
+    return _ref_ifs
+
+
+def _dp(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ref_liquid_effective_radius(y, ppressure, ptemperature, pcloud_frac, pq_liq, pq_rain, pland_frac, pccn_land, pccn_sea):
+    klev, klon = ppressure.shape
+    out = np.zeros((klev, klon))
+    a = [_dp(x) for x in (ppressure, ptemperature, pcloud_frac, pq_liq, pq_rain, pland_frac, pccn_land, pccn_sea)]
+    P = C.POINTER(C.c_double)
+    _ref_ifs_lib().ref_liquid_effective_radius(C.c_int(y.NRADLP), C.c_int(int(y.LCCNL)), C.c_int(int(y.LCCNO)),
+                                               C.c_double(y.RCCNLND), C.c_double(y.RCCNSEA), C.c_int(klon), C.c_int(klev),
+                                               *[x.ctypes.data_as(P) for x in a], out.ctypes.data_as(P))
+    return out
+
+
+def ref_ice_effective_radius(y, ppressure, ptemperature, pcloud_frac, pq_ice, pq_snow, pgemu):
+    klev, klon = ppressure.shape
+    out = np.zeros((klev, klon))
+    a = [_dp(x) for x in (ppressure, ptemperature, pcloud_frac, pq_ice, pq_snow, pgemu)]
+    P = C.POINTER(C.c_double)
+    _ref_ifs_lib().ref_ice_effective_radius(C.c_int(y.NRADIP), C.c_int(y.NMINICE), C.c_double(y.RRE2DE), C.c_double(y.RMINICE),
+                                            C.c_int(klon), C.c_int(klev), *[x.ctypes.data_as(P) for x in a], out.ctypes.data_as(P))
+    return out
+
+
+def ref_cloud_overlap_decorr_len(pgemu, kdecolat):
+    g = _dp(pgemu)
+    out = np.zeros(g.size)
+    ratio = C.c_double(0.0)
+    P = C.POINTER(C.c_double)
+    _ref_ifs_lib().ref_cloud_overlap_decorr_len(C.c_int(g.size), g.ctypes.data_as(P), C.c_int(kdecolat), out.ctypes.data_as(P),
+                                                C.byref(ratio))
+    return out, ratio.value
 
 
 # ---------------------------------------------------------------------------------------------------

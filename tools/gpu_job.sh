@@ -1,9 +1,18 @@
 #!/bin/bash
-# one GPU call: taumol ablations (kernel stats per variant), then the profile of the headline workload
+# one GPU call: tuning variants of the level-record phase on three workloads
 mkdir -p gpurun_out
-for v in cur abl16 abl32; do
-  echo "== $v"
-  ECRAD_HIP_LIB=$PWD/build_variants/$v/libecrad_hip.so bash tools/kstats.sh mcica_rrtmg 2>&1 | head -8
-done 2>&1 | tee gpurun_out/r02_f_taumol_ablation.log
-bash tools/profile.sh r02_f > gpurun_out/r02_f_profile.log 2>&1
-tail -3 gpurun_out/r02_f_profile.log
+run() { python bench.py --steps 8 --warmup 2 --no-cpu-baseline --headline-only --workload $1 2>/dev/null | python -c "
+import sys, json
+for line in sys.stdin:
+    if line.startswith('{'):
+        d = json.loads(line); st = d['roofline']['stage_ms']
+        print('%-14s %-26s %10.0f col/s  lw %7.3f  sw %7.3f' % ('$2', '$1', d['value'], st['lw'], st['sw']))
+"; }
+for rep in 1 2; do
+for w in clear_homogeneous_ecckd32 tripleclouds_ecckd32 mcica_ecckd32; do
+  run $w current
+  for lib in build_variants/*/libecrad_hip.so; do
+    ECRAD_HIP_LIB=$PWD/$lib run $w $(basename $(dirname $lib))
+  done
+done
+done 2>&1 | tee gpurun_out/r02_i_variants.log

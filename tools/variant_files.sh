@@ -1,0 +1,20 @@
+#!/bin/bash
+# tools/variant_files.sh NAME "FLAGS" file1 [file2 ...]: a tuning variant in which only the named kernel files are rebuilt
+# with FLAGS; every other object comes from the current build in ecrad_amd/csrc (run make there first).
+set -e
+name=$1; flags=$2; shift 2
+root=$(cd "$(dirname "$0")/.." && pwd)
+out=$root/build_variants/$name; mkdir -p $out
+objs=""
+for o in api kernel_ica_sw kernel_ica_lw kernel_lw_scat kernel_tc kernel_prep kernel_optics kernel_rrtmg kernel_spartacus; do
+  if [[ " $* " == *" $o "* ]]; then
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $flags -c $root/ecrad_amd/csrc/$o.hip -o $out/$o.o &
+    objs="$objs $out/$o.o"
+  else
+    objs="$objs $root/ecrad_amd/csrc/$o.o"
+  fi
+done
+wait
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out/libecrad_hip.so $objs
+rm -f $out/*.o
+echo "built $out/libecrad_hip.so"
