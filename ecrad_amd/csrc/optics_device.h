@@ -26,6 +26,12 @@ enum { I_PL_BOT = 2 * F_INT1, I_RH = 2 * F_INT1 + 1, I_CELL = 2 * F_INT3, I_LUT 
 
 // cloud types whose inputs level_scalars requests together with everything else (more types: loaded one by one)
 constexpr int kLevelCloudTypes = 2;
+#ifndef ECRAD_LS_BATCH
+#define ECRAD_LS_BATCH 1
+#endif
+#ifndef ECRAD_LS_RH_LDS
+#define ECRAD_LS_RH_LDS 1
+#endif
 #ifndef ECRAD_LS_TRANSPOSE
 #define ECRAD_LS_TRANSPOSE 1
 #endif
@@ -78,7 +84,7 @@ ECRAD_DEV void lds_stage_rh(void* smem, const DevConfig& cfg, int tid) {
 }
 ECRAD_DEV int rh_index(const DevAerosolOptics& ao, const double* rh_lds, double rh) {
   int irh = 1;
-  if (ao.nrh <= kRhInline) {
+  if (ECRAD_LS_RH_LDS && ao.nrh <= kRhInline) {
     if (rh > rh_lds[ao.nrh - 1]) return ao.nrh;
     while (rh > rh_lds[irh]) irh++;
   } else {
@@ -110,11 +116,12 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
   const double p0 = in.pressure_hl[ih0], p1 = in.pressure_hl[ih1];
   const double t0 = in.temperature_hl[ih0], t1 = in.temperature_hl[ih1];
   double h2o_in = 0.0, h2o_sat = 1.0;
+  double frac = 0.0, cl_mr[kLevelCloudTypes], cl_re[kLevelCloudTypes];
+#if ECRAD_LS_BATCH
   if (cfg.use_aerosols) {
     h2o_in = in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (ECRAD_IH2O - 1))];
     h2o_sat = in.h2o_sat_liq[i0];
   }
-  double frac = 0.0, cl_mr[kLevelCloudTypes], cl_re[kLevelCloudTypes];
   if (want_clouds) {
     { const FracView fv = cloud_fraction_view(in, col, ord); frac = fv.p[fv.stride * clev]; }
 #pragma unroll
@@ -127,6 +134,7 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
       }
     }
   }
+#endif
   // ---- arithmetic
   const double temperature_fl = (t0 * p0 + t1 * p1) / (p0 + p1);
   const double log_pressure_fl = log(0.5 * (p0 + p1));
@@ -204,6 +212,10 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
   int irh = 0;
   if (cfg.use_aerosols) {
     // rh = h2o_mmr / h2o_sat_liq with h2o_mmr from gas%get(IH2O, IMassMixingRatio) (radiation_gas.F90:605-612)
+#if !ECRAD_LS_BATCH
+    h2o_in = in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (ECRAD_IH2O - 1))];
+    h2o_sat = in.h2o_sat_liq[i0];
+#endif
     const double h2o_mmr = cfg.gas_mmr ? h2o_in : h2o_in * (kH2OMolarMass / kAirMolarMass);
     const double rh = h2o_mmr / h2o_sat;
     const DevAerosolOptics& ao = cfg.aerosol;
@@ -211,10 +223,13 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
   }
   L.I(I_RH, slot) = irh;
   if (want_clouds) {
+#if !ECRAD_LS_BATCH
+    { const FracView fv = cloud_fraction_view(in, col, ord); frac = fv.p[fv.stride * clev]; }
+#endif
     for (int t = 0; t < L.nct; ++t) {
       const DevCloudOptics& co = IS_SW ? cfg.cloud_sw[t] : cfg.cloud_lw[t];
       double mr, re;
-      if (t < kLevelCloudTypes) { mr = pick(cl_mr, t); re = pick(cl_re, t); }
+      if (ECRAD_LS_BATCH && t < kLevelCloudTypes) { mr = pick(cl_mr, t); re = pick(cl_re, t); }
       else {
         const size_t i3 = i0 + ncol * in.nlev * t;
         mr = in.cloud_mixing_ratio[i3];

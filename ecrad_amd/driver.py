@@ -15,6 +15,7 @@ import numpy as np
 from .config import Config
 from .namelist import read_namelist
 from .ncfile import NcFile, write_nc
+from .hdf5file import write_nc4
 from .tables import GAS_LOWER_CASE_NAMES, NMaxGases, IH2O, IO3
 from .types import (Aerosol, Cloud, Flux, Gas, SingleLevel, Thermodynamics,
                     IMassMixingRatio, IVolumeMixingRatio)
@@ -31,6 +32,7 @@ class DriverConfig:
     iverbose: int = 2
     do_write_double_precision: bool = False
     do_save_net_fluxes: bool = False
+    do_write_hdf5: bool = False              # netCDF-4/HDF5 output instead of classic netCDF (ecrad_driver_config.F90:119)
     # shortwave diagnostics in user-specified wavelength intervals (m), written to a second file
     # (driver/ecrad_driver_config.F90:72-82: the first negative bound ends the list)
     sw_diag_wavelength_bound: list = None
@@ -294,8 +296,19 @@ def flux_to_output_dict(config: Config, thermodynamics: Thermodynamics, flux: Fl
     return out
 
 
+def _units(name: str) -> dict:
+    """units attribute as radiation_save.F90:153-337 gives it"""
+    if name == "pressure_hl":
+        return {"units": "Pa"}
+    if name.startswith("cloud_cover") or name == "lw_derivative":
+        return {"units": "1"}
+    return {"units": "W m-2"}
+
+
 def save_fluxes(path: str, config: Config, thermodynamics: Thermodynamics, flux: Flux,
-                is_double_precision: bool = False) -> None:
+                is_double_precision: bool = False, is_hdf5_file: bool = False, experiment_name: str = "") -> None:
+    """save_fluxes (radiation_save.F90:35-460); ``is_hdf5_file`` selects netCDF-4/HDF5 (ecrad_amd/hdf5file.py) instead
+    of classic netCDF, as easy_netcdf's create(..., is_hdf5_file) does (utilities/easy_netcdf.F90:212-245)."""
     out = flux_to_output_dict(config, thermodynamics, flux)
     ncol = thermodynamics.pressure_hl.shape[1]
     dims = {"column": ncol, "half_level": thermodynamics.pressure_hl.shape[0]}
@@ -304,22 +317,22 @@ def save_fluxes(path: str, config: Config, thermodynamics: Thermodynamics, flux:
     dim3 = {n: d for n, _, d in _SAVE_SPECTRAL}
     for name, arr in out.items():
         if arr.ndim == 1:
-            variables[name] = (("column",), arr)
+            variables[name] = (("column",), arr, _units(name))
         elif arr.ndim == 3:
             dims.setdefault(dim3[name], arr.shape[2])
-            variables[name] = (("column", "half_level", dim3[name]), arr)
+            variables[name] = (("column", "half_level", dim3[name]), arr, _units(name))
         else:
             d = "half_level" if name == "pressure_hl" else dim2[name]
             dims.setdefault(d, arr.shape[1])
-            variables[name] = (("column", d), arr)
-    write_nc(path, dims, variables,
-             attrs={"title": "Radiative flux profiles from the ecrad_amd MI355X radiation path",
-                    "source": "ecrad_amd"},
-             double=is_double_precision)
+            variables[name] = (("column", d), arr, _units(name))
+    attrs = {"title": "Radiative flux profiles from the ecrad_amd MI355X radiation path", "source": "ecrad_amd"}
+    if experiment_name.strip():
+        attrs["experiment"] = experiment_name
+    (write_nc4 if is_hdf5_file else write_nc)(path, dims, variables, attrs=attrs, double=is_double_precision)
 
 
 def save_net_fluxes(path: str, config: Config, thermodynamics: Thermodynamics, flux: Flux,
-                    is_double_precision: bool = False, experiment_name: str = "") -> None:
+                    is_double_precision: bool = False, experiment_name: str = "", is_hdf5_file: bool = False) -> None:
     """save_net_fluxes (radiation_save.F90:464-715): net (down minus up) flux profiles and the surface / TOA downwelling
     fluxes instead of the separate up and down profiles; same variable names and dimensions as the reference."""
     ncol = thermodynamics.pressure_hl.shape[1]
@@ -357,7 +370,7 @@ def save_net_fluxes(path: str, config: Config, thermodynamics: Thermodynamics, f
     attrs = {"title": "Radiative flux profiles from the ecrad_amd MI355X radiation path", "source": "ecrad_amd"}
     if experiment_name.strip():
         attrs["experiment"] = experiment_name
-    write_nc(path, dims, v, attrs=attrs, double=is_double_precision)
+    (write_nc4 if is_hdf5_file else write_nc)(path, dims, v, attrs=attrs, double=is_double_precision)
 
 
 def get_sw_mapping(config: Config, wavelength_bound) -> np.ndarray:
@@ -374,7 +387,7 @@ def get_sw_mapping(config: Config, wavelength_bound) -> np.ndarray:
 
 
 def save_sw_diagnostics(path: str, config: Config, wavelength_bound, mapping: np.ndarray, flux: Flux,
-                        is_double_precision: bool = False, experiment_name: str = "") -> None:
+                        is_double_precision: bool = False, experiment_name: str = "", is_hdf5_file: bool = False) -> None:
     """save_sw_diagnostics (radiation_save.F90:1314-1470): surface (and, with do_save_spectral_flux, TOA) shortwave
     fluxes in user-specified wavelength intervals."""
     wb = np.asarray(wavelength_bound, dtype=np.float64)
@@ -398,7 +411,7 @@ def save_sw_diagnostics(path: str, config: Config, wavelength_bound, mapping: np
     attrs = {"title": "Shortwave spectral diagnostics from the ecrad_amd MI355X radiation path", "source": "ecrad_amd"}
     if experiment_name.strip():
         attrs["experiment"] = experiment_name
-    write_nc(path, dims, v, attrs=attrs, double=is_double_precision)
+    (write_nc4 if is_hdf5_file else write_nc)(path, dims, v, attrs=attrs, double=is_double_precision)
 
 
 def main(argv=None) -> int:
@@ -433,13 +446,15 @@ def main(argv=None) -> int:
         rad.radiation(ncol, nlev, istart, iend, single_level, thermodynamics, gas, cloud, aerosol, flux)
     print(f"Time elapsed in radiative transfer: {time.perf_counter() - t0:12.5g} seconds")
     if not dc.do_save_net_fluxes:                # driver/ecrad_driver.F90:398-417
-        save_fluxes(argv[2], config, thermodynamics, flux, is_double_precision=dc.do_write_double_precision)
+        save_fluxes(argv[2], config, thermodynamics, flux, is_double_precision=dc.do_write_double_precision,
+                    is_hdf5_file=dc.do_write_hdf5, experiment_name=dc.experiment_name)
     else:
         save_net_fluxes(argv[2], config, thermodynamics, flux, is_double_precision=dc.do_write_double_precision,
-                        experiment_name=dc.experiment_name)
+                        experiment_name=dc.experiment_name, is_hdf5_file=dc.do_write_hdf5)
     if n_sw_diag > 0:
         save_sw_diagnostics(dc.sw_diag_file_name, config, bounds[:n_sw_diag + 1], sw_diag_mapping, flux,
-                            is_double_precision=dc.do_write_double_precision, experiment_name=dc.experiment_name)
+                            is_double_precision=dc.do_write_double_precision, experiment_name=dc.experiment_name,
+                            is_hdf5_file=dc.do_write_hdf5)
     return 0
 
 

@@ -795,7 +795,7 @@ def run_ifs_driver(namelist: str, input_file: str, output_file: Optional[str] = 
         cs.do_canopy_fluxes_sw = False
         cs.do_canopy_fluxes_lw = False
         save_net_fluxes(output_file, cs, thermodynamics, flux, is_double_precision=dc.do_write_double_precision,
-                        experiment_name=dc.experiment_name)
+                        experiment_name=dc.experiment_name, is_hdf5_file=dc.do_write_hdf5)
     return c, thermodynamics, flux, diag
 
 
