@@ -95,8 +95,6 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
   int tm_levels = 0;
 #endif
 
-  const LevelOrder ord_u = level_order_uniform(kernarg_block<SpectralArgs>().in);   // once per launch: a scalar
-  lds_stage_rh(smem, kernarg_block<SpectralArgs>().cfg, threadIdx.x);      // (the group loop starts with a barrier)
   for (;;) {
     // ---- per column group (see kernarg_block() for why the arguments are re-read per phase) --------
     const SpectralArgs& a = kernarg_block<SpectralArgs>();
@@ -149,7 +147,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
     int ict = nlev;              // 0-based index of the first cloudy layer (= its top half level)
     double fdn_c = 0.0;          // clear-sky downwelling flux at the current half level
     double fdn_ctop = 0.0;       // ... captured at cloud top
-    const LevelOrder& ord = ord_u;
+    const LevelOrder ord = level_order(a.in);
     double planck_top = planck_at<TAB>(m, a.in.temperature_hl[col + ncol * ord.half(0)], g);   // top-of-atmosphere half level
     if constexpr (sizeof(TAB) == 8) {
       const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
@@ -171,7 +169,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(Spectra
       __syncthreads();
       {
         const SpectralArgs& b = kernarg_block<SpectralArgs>();
-        level_scalars_chunk<false, NGP>(b.cfg, b.cfg.gas_lw, b.in, ord_u, L, tid, grp, l0, nlev, want_clouds);
+        const int lev = l0 + glane;
+        if (lev < nlev) level_scalars<false>(b.cfg, b.cfg.gas_lw, b.in, L, tid, col, lev, want_clouds);
       }
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;

@@ -210,8 +210,6 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
   int tm_levels = 0;
 #endif
 
-  const LevelOrder ord_u = level_order_uniform(kernarg_block<SpectralArgs>().in);   // once per launch: a scalar
-  lds_stage_rh(smem, kernarg_block<SpectralArgs>().cfg, threadIdx.x);      // (the group loop starts with a barrier)
   for (;;) {
     // ---- per column group ---------------------------------------------------------------------------
     const SpectralArgs& a = kernarg_block<SpectralArgs>();
@@ -275,7 +273,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
       ECRAD_LAP0(tm, 5);              // (timing build) wait at the first barrier + group set-up
       {
         const SpectralArgs& b = kernarg_block<SpectralArgs>();
-        level_scalars_chunk<true, NGP>(b.cfg, b.cfg.gas_sw, b.in, ord_u, L, tid, grp, l0, nlev, want_clouds);
+        const int lev = l0 + glane;
+        if (lev < nlev) level_scalars<true>(b.cfg, b.cfg.gas_sw, b.in, L, tid, col, lev, want_clouds);
       }
       ECRAD_LAP0(tm, 7);              // (timing build) level records computed
       __syncthreads();
@@ -388,7 +387,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(Spectra
 
     // ---- sweep 2: top -> surface: fluxes ------------------------------------------------------------
     const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
-    const LevelOrder& ord = ord_u;
+    const LevelOrder ord = level_order(kernarg_block<SpectralArgs>().in);
     ECRAD_LAP0(tm, 0);
     if (sun_up && !(ECRAD_ABLATE & 4)) {
       double fdn_s = 0.0, fdir_s = 0.0, fup_t = 0.0;

@@ -40,8 +40,6 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(Spectr
   const bool want_clouds = MODE != 0;
   GasRegs<TAB> quads;
 
-  const LevelOrder ord_u = level_order_uniform(kernarg_block<SpectralArgs>().in);   // once per launch: a scalar
-  lds_stage_rh(smem, kernarg_block<SpectralArgs>().cfg, threadIdx.x);      // (the group loop starts with a barrier)
   for (;;) {
     const SpectralArgs& a = kernarg_block<SpectralArgs>();
     const DevConfig& cfg = a.cfg;
@@ -86,7 +84,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(Spectr
     if (MODE == 2) tcc = a.prep.total_cloud_cover_lw[cloc];
     LevMask cloudy;
     cloudy.clear();
-    const LevelOrder& ord = ord_u;
+    const LevelOrder ord = level_order(a.in);
     double planck_top = planck_at<TAB>(m, a.in.temperature_hl[col + ncol * ord.half(0)], g);
     if constexpr (sizeof(TAB) == 8) {
       const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
@@ -98,7 +96,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(Spectr
       __syncthreads();
       {
         const SpectralArgs& b = kernarg_block<SpectralArgs>();
-        level_scalars_chunk<false, NGP>(b.cfg, b.cfg.gas_lw, b.in, ord_u, L, tid, grp, l0, nlev, want_clouds);
+        const int lev = l0 + glane;
+        if (lev < nlev) level_scalars<false>(b.cfg, b.cfg.gas_lw, b.in, L, tid, col, lev, want_clouds);
       }
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;

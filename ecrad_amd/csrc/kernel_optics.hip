@@ -26,8 +26,6 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
   const int ib = (IS_SW ? cfg.i_band_from_reordered_g_sw[g] : cfg.i_band_from_reordered_g_lw[g]) - 1;
   const int aer_type = aerosol_lane_type(cfg, glane);
   const int nb = IS_SW ? cfg.n_bands_sw : cfg.n_bands_lw;
-  const LevelOrder ord_u = level_order_uniform(in);
-  lds_stage_rh(smem, cfg, threadIdx.x);      // (a barrier precedes every level_scalars_chunk)
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
@@ -51,12 +49,13 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
         if (out.lw_emission) out.lw_emission[og] = (in.gs.lw_emission ? in.gs.lw_emission[og] : planck_at<TAB>(m, in.skin_temperature[col], g)) * (1.0 - lw_albedo);
       }
     }
-    double planck_top = IS_SW ? 0.0 : planck_at<TAB>(m, in.temperature_hl[col + (size_t)in.ncol * ord_u.half(0)], g);   // top-of-atmosphere half level
+    double planck_top = IS_SW ? 0.0 : planck_at<TAB>(m, in.temperature_hl[col + (size_t)in.ncol * level_order(in).half(0)], g);   // top-of-atmosphere half level
     if (!IS_SW && in.gs.planck_hl) planck_top = in.gs.planck_hl[g + (size_t)ng * ((size_t)(nlev + 1) * cloc)];
     for (int l0 = 0; l0 < nlev; l0 += NGP) {
       __syncthreads();
       {
-        level_scalars_chunk<IS_SW, NGP>(cfg, m, in, ord_u, L, tid, grp, l0, nlev, want_clouds);
+        const int lev = l0 + glane;
+        if (lev < nlev) level_scalars<IS_SW>(cfg, m, in, L, tid, col, lev, want_clouds);
       }
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;

@@ -167,7 +167,6 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
   GasRegs<TAB> quads;
   quads.invalidate();
 
-  lds_stage_rh(smem, kernarg_block<SpectralArgs>().cfg, threadIdx.x);      // (the group loop starts with a barrier)
   for (;;) {
     // per column group; the argument block is re-read per phase (see kernarg_block)
     const SpectralArgs& a = kernarg_block<SpectralArgs>();
@@ -247,7 +246,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
       if (ch != nchunk - 1) __syncthreads();
       {
         const SpectralArgs& b = kernarg_block<SpectralArgs>();
-        level_scalars_chunk<true, NGP>(b.cfg, b.cfg.gas_sw, b.in, ord, L, tid, grp, l0, nlev, true);
+        const int lev = l0 + glane;
+        if (lev < nlev) level_scalars<true>(b.cfg, b.cfg.gas_sw, b.in, L, tid, col, lev, true);
       }
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
@@ -584,7 +584,6 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
   GasRegs<TAB> quads;
   quads.invalidate();
 
-  lds_stage_rh(smem, kernarg_block<SpectralArgs>().cfg, threadIdx.x);      // (the group loop starts with a barrier)
   for (;;) {
     // per column group; the argument block is re-read per phase (see kernarg_block)
     const SpectralArgs& a = kernarg_block<SpectralArgs>();
@@ -650,7 +649,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
       __syncthreads();
       {
         const SpectralArgs& b = kernarg_block<SpectralArgs>();
-        level_scalars_chunk<false, NGP>(b.cfg, b.cfg.gas_lw, b.in, ord, L, tid, grp, l0, nlev, true);
+        const int lev = l0 + glane;
+        if (lev < nlev) level_scalars<false>(b.cfg, b.cfg.gas_lw, b.in, L, tid, col, lev, true);
       }
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;

@@ -306,21 +306,12 @@ struct LevelOrder {
   ECRAD_DEV int iface(int k) const { return rev ? nlev - 2 - k : k; }          // interface between layers k, k+1
 };
 ECRAD_DEV LevelOrder level_order(const DevInputs& in) { return {in.nlev, *in.reversed != 0}; }
-// the same, as a wave-uniform value (one scalar register): the flag is the same for every lane of a launch, and a
-// kernel that reads it once does not pay a memory round trip for it wherever the level order matters
-ECRAD_DEV LevelOrder level_order_uniform(const DevInputs& in) {
-  return {in.nlev, __builtin_amdgcn_readfirstlane(*in.reversed) != 0};
-}
 
 // Cropped cloud fraction of one column: p[stride*k] is level k in the caller's order (see DevInputs)
 struct FracView {
   const double* p;
   size_t stride;
 };
-ECRAD_DEV FracView cloud_fraction_view(const DevInputs& in, int col, const LevelOrder& ord) {
-  if (ord.rev) return {in.cloud_fraction_work + (col - (in.istartcol - 1)), (size_t)(in.iendcol - in.istartcol + 1)};
-  return {in.cloud_fraction + col, (size_t)in.ncol};
-}
 ECRAD_DEV FracView cloud_fraction_view(const DevInputs& in, int col) {
   if (*in.reversed != 0) return {in.cloud_fraction_work + (col - (in.istartcol - 1)), (size_t)(in.iendcol - in.istartcol + 1)};
   return {in.cloud_fraction + col, (size_t)in.ncol};

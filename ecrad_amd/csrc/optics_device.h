@@ -24,23 +24,7 @@ enum { I_PL_BOT = 2 * F_INT1, I_RH = 2 * F_INT1 + 1, I_CELL = 2 * F_INT3, I_LUT 
 // of radiation_ecckd.F90:558-600 times the concentration weight of a look-up-table gas), then per cloud
 // type (water_path, effective-radius weight2, {effective-radius index, pad}).
 
-// cloud types whose inputs level_scalars requests together with everything else (more types: loaded one by one)
-constexpr int kLevelCloudTypes = 2;
-#ifndef ECRAD_LS_BATCH
-#define ECRAD_LS_BATCH 1
-#endif
-#ifndef ECRAD_LS_RH_LDS
-#define ECRAD_LS_RH_LDS 1
-#endif
-#ifndef ECRAD_LS_TRANSPOSE
-#define ECRAD_LS_TRANSPOSE 1
-#endif
-ECRAD_DEV double pick(const double (&a)[kLevelCloudTypes], int t) { return t == 0 ? a[0] : a[1]; }
-
-constexpr int kRhInline = 16;       // humidity-bin bounds staged in LDS (more bins: read from global memory)
-
 struct LdsLayout {
-  double* rh;       // lower bounds of the aerosol humidity bins (lds_stage_rh)
   double* d;
   int rec2;         // 16-byte units per record
   int nquad, nct;
@@ -61,37 +45,16 @@ __host__ __device__ inline int lds_padded_quads(int nquad) { return ECRAD_FIXED_
 __host__ __device__ inline int lds_record_doubles(int nquad, int nct) { return (F_QMULT + lds_padded_quads(nquad) + 3 * nct + 1) & ~1; }
 
 __host__ __device__ inline size_t lds_bytes(int nquad, int nct) {
-  return ((size_t)kBlock * lds_record_doubles(nquad, nct) + kRhInline) * sizeof(double);
+  return (size_t)kBlock * lds_record_doubles(nquad, nct) * sizeof(double);
 }
 
 ECRAD_DEV LdsLayout make_lds(void* smem, int nquad, int nct) {
   LdsLayout L;
-  L.rh = reinterpret_cast<double*>(smem);
-  L.d = L.rh + kRhInline;
+  L.d = reinterpret_cast<double*>(smem);
   L.rec2 = lds_record_doubles(nquad, nct) / 2;
   L.nquad = lds_padded_quads(nquad);
   L.nct = nct;
   return L;
-}
-
-// calc_rh_index (radiation_aerosol_optics_data.F90:640-664).  The walk up the bin bounds is a chain of dependent
-// loads; from global memory that was up to eleven memory round trips per record, so the kernels park the bounds in
-// LDS once per launch (lds_stage_rh, called before the first barrier of the column-group loop).
-ECRAD_DEV void lds_stage_rh(void* smem, const DevConfig& cfg, int tid) {
-  const DevAerosolOptics& ao = cfg.aerosol;
-  if (cfg.use_aerosols && ao.use_hydrophilic && ao.nrh <= kRhInline && tid < ao.nrh)
-    reinterpret_cast<double*>(smem)[tid] = ao.rh_lower[tid];
-}
-ECRAD_DEV int rh_index(const DevAerosolOptics& ao, const double* rh_lds, double rh) {
-  int irh = 1;
-  if (ECRAD_LS_RH_LDS && ao.nrh <= kRhInline) {
-    if (rh > rh_lds[ao.nrh - 1]) return ao.nrh;
-    while (rh > rh_lds[irh]) irh++;
-  } else {
-    if (rh > ao.rh_lower[ao.nrh - 1]) return ao.nrh;
-    while (rh > ao.rh_lower[irh]) irh++;
-  }
-  return irh;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -103,39 +66,15 @@ ECRAD_DEV int rh_index(const DevAerosolOptics& ao, const double* rh_lds, double 
 // position of radiation_general_cloud_optics.F90:196-207 + _data.F90:284-288.
 // col is the 0-based GLOBAL column, lev the 0-based level.
 template <bool IS_SW>
-ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const DevInputs& in, const LevelOrder& ord,
+ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const DevInputs& in,
                              const LdsLayout& L, int slot, int col, int lev, bool want_clouds) {
   const size_t ncol = in.ncol;
+  const LevelOrder ord = level_order(in);
   const int clev = ord.full(lev);                       // this layer in the caller's arrays
   const size_t i0 = col + ncol * clev;
   const size_t ih0 = col + ncol * ord.half(lev), ih1 = col + ncol * ord.half(lev + 1);
-  // ---- the loads that do not depend on the gas model are requested together, before anything is computed.  (Doing
-  // the same for the mixing ratios of the gases -- registers, or the record's own slots as a parking place -- bought
-  // nothing on the GPU: other waves fill those gaps; what did pay was the coalesced mapping of level_scalars_chunk
-  // and keeping the humidity-bin walk and the level-order flag out of global memory: gpurun_out/r02_i_variants.log.)
   const double p0 = in.pressure_hl[ih0], p1 = in.pressure_hl[ih1];
   const double t0 = in.temperature_hl[ih0], t1 = in.temperature_hl[ih1];
-  double h2o_in = 0.0, h2o_sat = 1.0;
-  double frac = 0.0, cl_mr[kLevelCloudTypes], cl_re[kLevelCloudTypes];
-#if ECRAD_LS_BATCH
-  if (cfg.use_aerosols) {
-    h2o_in = in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (ECRAD_IH2O - 1))];
-    h2o_sat = in.h2o_sat_liq[i0];
-  }
-  if (want_clouds) {
-    { const FracView fv = cloud_fraction_view(in, col, ord); frac = fv.p[fv.stride * clev]; }
-#pragma unroll
-    for (int t = 0; t < kLevelCloudTypes; ++t) {
-      cl_mr[t] = 0.0; cl_re[t] = 0.0;
-      if (t < L.nct) {
-        const size_t i3 = i0 + ncol * in.nlev * t;
-        cl_mr[t] = in.cloud_mixing_ratio[i3];
-        cl_re[t] = in.cloud_effective_radius[i3];
-      }
-    }
-  }
-#endif
-  // ---- arithmetic
   const double temperature_fl = (t0 * p0 + t1 * p1) / (p0 + p1);
   const double log_pressure_fl = log(0.5 * (p0 + p1));
   double pindex1 = (log_pressure_fl - m.log_pressure1) / m.d_log_pressure;
@@ -212,29 +151,24 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
   int irh = 0;
   if (cfg.use_aerosols) {
     // rh = h2o_mmr / h2o_sat_liq with h2o_mmr from gas%get(IH2O, IMassMixingRatio) (radiation_gas.F90:605-612)
-#if !ECRAD_LS_BATCH
-    h2o_in = in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (ECRAD_IH2O - 1))];
-    h2o_sat = in.h2o_sat_liq[i0];
-#endif
+    const double h2o_in = in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (ECRAD_IH2O - 1))];
     const double h2o_mmr = cfg.gas_mmr ? h2o_in : h2o_in * (kH2OMolarMass / kAirMolarMass);
-    const double rh = h2o_mmr / h2o_sat;
+    const double rh = h2o_mmr / in.h2o_sat_liq[i0];
     const DevAerosolOptics& ao = cfg.aerosol;
-    if (ao.use_hydrophilic) irh = rh_index(ao, L.rh, rh);
+    if (ao.use_hydrophilic) {      // calc_rh_index, radiation_aerosol_optics_data.F90:640-664
+      if (rh > ao.rh_lower[ao.nrh - 1]) irh = ao.nrh;
+      else { irh = 1; while (rh > ao.rh_lower[irh]) irh++; }
+    }
   }
   L.I(I_RH, slot) = irh;
+  double frac = 0.0;
   if (want_clouds) {
-#if !ECRAD_LS_BATCH
-    { const FracView fv = cloud_fraction_view(in, col, ord); frac = fv.p[fv.stride * clev]; }
-#endif
+    { const FracView fv = cloud_fraction_view(in, col); frac = fv.p[fv.stride * clev]; }
     for (int t = 0; t < L.nct; ++t) {
       const DevCloudOptics& co = IS_SW ? cfg.cloud_sw[t] : cfg.cloud_lw[t];
-      double mr, re;
-      if (ECRAD_LS_BATCH && t < kLevelCloudTypes) { mr = pick(cl_mr, t); re = pick(cl_re, t); }
-      else {
-        const size_t i3 = i0 + ncol * in.nlev * t;
-        mr = in.cloud_mixing_ratio[i3];
-        re = in.cloud_effective_radius[i3];
-      }
+      const size_t i3 = i0 + ncol * in.nlev * t;
+      const double mr = in.cloud_mixing_ratio[i3];
+      const double re = in.cloud_effective_radius[i3];
       double water_path;
       if (cfg.is_homogeneous) water_path = mr * (p1 - p0) * (1.0 / kAccelDueToGravity);
       else water_path = mr * (p1 - p0) * (1.0 / (kAccelDueToGravity * dmax(cfg.cloud_fraction_threshold, frac)));
@@ -248,31 +182,11 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
         // the Baran schemes are functions of the grid-mean ice mixing ratio and the layer temperature, not of a radius
         // (radiation_cloud_optics.F90:366-405)
         L.D(L.f_rew(t), slot) = mr;
-        L.D(L.f_aux(t), slot) = 0.5 * (t0 + t1);
+        L.D(L.f_aux(t), slot) = 0.5 * (in.temperature_hl[col + ncol * ord.half(lev)] + in.temperature_hl[col + ncol * ord.half(lev + 1)]);
       }
     }
   }
   L.D(F_FRAC, slot) = frac;
-}
-
-// The level records of one chunk of NGP levels for the kBlock/NGP columns of a block.  Thread t prepares column
-// (t % CPB), level l0 + t / CPB -- NOT the (column = t / NGP, level = t % NGP) of the lane = g phases: the caller's
-// arrays have the column fastest, so the 64 lanes of a wave touch 64/CPB cache lines per array and use all of each,
-// instead of 32 lines of which they use a quarter.
-template <bool IS_SW, int NGP>
-ECRAD_DEV void level_scalars_chunk(const DevConfig& cfg, const DevCkdModel& m, const DevInputs& in, const LevelOrder& ord,
-                                   const LdsLayout& L, int tid, int grp, int l0, int nlev, bool want_clouds) {
-  constexpr int CPB = kBlock / NGP;
-#if ECRAD_LS_TRANSPOSE
-  const int sc = tid % CPB, sj = tid / CPB;
-#else
-  const int sc = tid / NGP, sj = tid % NGP;      // (tuning only) the mapping of the lane = g phases
-#endif
-  const int ncol_loc = in.iendcol - in.istartcol + 1;
-  const int cl = grp * CPB + sc;
-  const int col = in.istartcol - 1 + (cl < ncol_loc ? cl : ncol_loc - 1);
-  const int lev = l0 + sj;
-  if (lev < nlev) level_scalars<IS_SW>(cfg, m, in, ord, L, sc * NGP + sj, col, lev, want_clouds);
 }
 
 // ---------------------------------------------------------------------------------------------------
