@@ -401,9 +401,6 @@ int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
     if (c.do_save_spectral_flux) return fail(h, ECRAD_EUNSUPPORTED, "SPARTACUS: spectral flux profiles are not implemented");
     if (!c.do_clouds) return fail(h, ECRAD_EINVAL, "SPARTACUS needs do_clouds");
     if (c.i_overlap_scheme != ECRAD_OVERLAP_EXP_RAN) return fail(h, ECRAD_EINVAL, "SPARTACUS can only do Exp-Ran overlap");    // radiation_config.F90:1259-1266
-    if ((c.do_sw && c.i_solver_sw == ECRAD_SOLVER_SPARTACUS && (c.n_g_sw > 64 || c.n_bands_sw > 64)) ||
-        (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_SPARTACUS && (c.n_g_lw > 64 || c.n_bands_lw > 64)))
-      return fail(h, ECRAD_EUNSUPPORTED, "SPARTACUS: spectra of more than 64 g-points are not implemented");
     if (!(c.max_cloud_od > 0.0) || !(c.min_cloud_effective_size > 0.0)) return fail(h, ECRAD_EINVAL, "SPARTACUS: max_cloud_od and min_cloud_effective_size must be positive");
   } else if (c.i_precision != ECRAD_PRECISION_DOUBLE) {
     return fail(h, ECRAD_EUNSUPPORTED, "single precision is implemented for the SPARTACUS solver only");
@@ -963,8 +960,8 @@ size_t work_bytes_per_column(ecrad_hip_handle_t h, int nlev, const ecrad_inputs_
   if (tc || sw_sp || lw_sp) b += 8 * (5 * L + 18 * (L + 1));
   {   // stage arrays of the SPARTACUS solvers (one buffer, reused by the two spectra)
     const size_t w = c.i_precision == ECRAD_PRECISION_SINGLE ? 4 : 8;
-    const size_t bsw = sw_sp ? 8 * ((size_t)c.n_g_sw * (3 * L + 3) + (size_t)c.n_bands_sw * 3 * L) + w * L * spartacus_layer_words(true, c.n_g_sw) : 0;
-    const size_t blw = lw_sp ? 8 * ((size_t)c.n_g_lw * (4 * L + 3) + (size_t)c.n_bands_lw * 3 * L) + w * L * spartacus_layer_words(false, c.n_g_lw) : 0;
+    const size_t bsw = sw_sp ? 8 * ((size_t)c.n_g_sw * (3 * L + 3) + (size_t)c.n_bands_sw * 3 * L) + w * L * spartacus_layer_words(true, std::min(c.n_g_sw, h->ngp_sw)) : 0;
+    const size_t blw = lw_sp ? 8 * ((size_t)c.n_g_lw * (4 * L + 3) + (size_t)c.n_bands_lw * 3 * L) + w * L * spartacus_layer_words(false, std::min(c.n_g_lw, h->ngp_lw)) : 0;
     b += std::max(bsw, blw) + 4 * L;
   }
   if (sw_mcica) b += 8 * ((size_t)c.n_g_sw * L + 1);
@@ -1138,7 +1135,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     int* n_items = nullptr;
     for (int pass = 0; pass < 2; ++pass) {
       Carver cv(pass == 0 ? nullptr : h->sp_stage.p);
-      lay = cv.take<char>(sp_word * L * n * spartacus_layer_words(is_sw, (int)ngs));
+      lay = cv.take<char>(sp_word * L * n * spartacus_layer_words(is_sw, std::min((int)ngs, is_sw ? h->ngp_sw : h->ngp_lw)));
       list = cv.take<uint32_t>(L * n);
       n_items = cv.take<int>(64);
       if (is_sw) {
@@ -1159,10 +1156,44 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
       HIP_TRY(h, hipMemsetAsync(dop.ssa_lw, 0, ngs * L * n * 8, stream));
       HIP_TRY(h, hipMemsetAsync(dop.g_lw, 0, ngs * L * n * 8, stream));
     }
-    HIP_TRY(h, launch_optics_dump(is_sw, ngp, m.table_f32, grid_for(h, r.nloc, ngp), lds_bytes(m.hot.nquad, c.n_cloud_types), stream, h->dcfg, din, dop, 0));
-    HIP_TRY(h, launch_spartacus(is_sw, sp_single, ngp, is_sw ? grid_sw : grid_lw, h->num_cu, stream, c, din, dop, prep, dfx, scratch,
-                                (is_sw ? per_block_sw : per_block_lw) * 8 / sp_word, counters + (is_sw ? 16 : 0),
-                                is_sw ? h->hcfg.i_band_from_reordered_g_sw : h->hcfg.i_band_from_reordered_g_lw, lay, list, n_items));
+    const int nch = is_sw ? h->nchunk_sw : h->nchunk_lw;
+    for (int p = 0; p < nch; ++p)
+      HIP_TRY(h, launch_optics_dump(is_sw, ngp, m.table_f32, grid_for(h, r.nloc, ngp), lds_bytes(m.hot.nquad, c.n_cloud_types), stream, h->dcfg, din, dop, p * ngp));
+    auto launch_sp = [&](const DevFlux& f, int* counter, int g0, bool wide) -> hipError_t {
+      return launch_spartacus(is_sw, sp_single, ngp, is_sw ? grid_sw : grid_lw, h->num_cu, stream, c, din, dop, prep, f, scratch,
+                              (is_sw ? per_block_sw : per_block_lw) * 8 / sp_word, counter,
+                              is_sw ? h->hcfg.i_band_from_reordered_g_sw : h->hcfg.i_band_from_reordered_g_lw, lay, list, n_items, g0, wide);
+    };
+    int* const counter0 = counters + (is_sw ? 16 : 0);
+    if (nch == 1) {
+      HIP_TRY(h, launch_sp(dfx, counter0, 0, false));
+      return ECRAD_OK;
+    }
+    // More than 64 g-points (RRTMG: the reference's own test_spartacus configuration): one launch of the layer and
+    // sweep kernels per chunk of ngp g-points, as for the other solvers below -- broadband profiles are partial sums
+    // that go to per-chunk buffers and are added up in chunk order, the longwave derivatives stay un-normalised
+    // until combine_derivatives has the surface flux of the whole spectrum.
+    double* DevFlux::* const prof_sw[6] = {&DevFlux::sw_up, &DevFlux::sw_dn, &DevFlux::sw_dn_direct,
+                                           &DevFlux::sw_up_clear, &DevFlux::sw_dn_clear, &DevFlux::sw_dn_direct_clear};
+    double* DevFlux::* const prof_lw[6] = {&DevFlux::lw_up, &DevFlux::lw_dn, &DevFlux::lw_up_clear, &DevFlux::lw_dn_clear,
+                                           &DevFlux::lw_derivatives, &DevFlux::lw_derivatives_aux};
+    double* DevFlux::* const* prof = is_sw ? prof_sw : prof_lw;
+    const size_t plane = (size_t)din.ncol * (nlev + 1);
+    double* pbase = reinterpret_cast<double*>(h->partial.p);
+    const bool deriv = !is_sw && dfx.lw_derivatives != nullptr && c.do_lw_derivatives;
+    const int nsum = is_sw ? 6 : 4;
+    for (int p = 0; p < nch; ++p) {
+      DevFlux dpart = dfx;
+      for (int k = 0; k < nsum; ++k)
+        if (dfx.*(prof[k])) dpart.*(prof[k]) = pbase + plane * ((size_t)k * nch + p);
+      if (deriv) dpart.lw_derivatives = pbase + plane * ((size_t)4 * nch + p);
+      HIP_TRY(h, launch_sp(dpart, counter0 + p, p * ngp, true));
+    }
+    for (int k = 0; k < nsum; ++k)
+      if (dfx.*(prof[k])) HIP_TRY(h, launch_combine_partials(stream, din, dfx.*(prof[k]), pbase + plane * (size_t)k * nch, plane, nch));
+    if (deriv)
+      HIP_TRY(h, launch_combine_derivatives(stream, din, dfx.lw_derivatives, pbase + plane * (size_t)4 * nch, pbase + plane * (size_t)5 * nch,
+                                            plane, nch, nullptr, c.cloud_fraction_threshold));
     return ECRAD_OK;
   };
   // (the McICA generators are accounted to the LW/SW stage they feed)

@@ -70,7 +70,9 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
           ssa = ssa / od;
           if (in.gs.od_sw) { od = in.gs.od_sw[o]; ssa = in.gs.ssa_sw[o]; }     // gas optics from the RRTMG pass
           double asym = 0.0;
-          if (cfg.use_aerosols) {
+          if (in.gs.g_sw) {                 // aerosols already folded into the stage arrays by the RRTMG pass
+            asym = in.gs.g_sw[o];
+          } else if (cfg.use_aerosols) {
             AerosolLayer a = aerosol_layer<true, NGP>(cfg, in, L, slot, col, lev, ib, aer_type);
             if (!cfg.do_sw_delta_scaling_with_gases) delta_eddington_extensive_vec(a);
             merge_aerosol_sw(cfg, a, od, ssa, asym);
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
             planck_bot = in.gs.planck_hl[g + (size_t)ng * (lev + 1 + (size_t)(nlev + 1) * cloc)];
           }
           double ssa = 0.0, asym = 0.0;
-          if (cfg.use_aerosols) {
+          if (cfg.use_aerosols && !in.gs.aer_folded_lw) {       // (folded: od_lw of the RRTMG pass includes them)
             AerosolLayer a = aerosol_layer<false, NGP>(cfg, in, L, slot, col, lev, ib, aer_type);
             if (cfg.do_lw_aerosol_scattering) {     // radiation_aerosol_optics.F90:778-797
               delta_eddington_extensive_vec(a);

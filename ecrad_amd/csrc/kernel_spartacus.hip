@@ -170,7 +170,12 @@ struct Geo {
 // What the solvers read of the configuration (by value in the kernel-argument segment)
 struct SpConfig {
   int32_t ng, nb, do_clear, do_3d_effects, i_3d_sw_entrapment, do_3d_lw_multilayer_effects, do_lw_side_emissivity, use_expm_everywhere;
-  int32_t do_lw_aerosol_scattering, do_lw_cloud_scattering, do_lw_derivatives, pad_;
+  int32_t do_lw_aerosol_scattering, do_lw_cloud_scattering, do_lw_derivatives, wide;
+  // Spectra wider than 64 g-points run as several launches ("chunks", as in the other solvers): this launch covers
+  // g-points g0 .. g0+ngl-1, lane = g0 + its index in the column group.  The stage arrays and per-g outputs are indexed
+  // by the true g-point, the layer store by the index within the chunk (stride ngl); the sums over g are partial and go
+  // to per-chunk buffers (api.hip); `wide` leaves the longwave derivatives un-normalised, see spartacus_lw_kernel.
+  int32_t g0, ngl;
   double max_cloud_od, max_3d_transfer_rate, max_gas_od_3d, min_cloud_effective_size, overhang_factor, clear_to_thick_fraction,
          overhead_sun_factor, cloud_fraction_threshold;
   const int32_t* i_band_from_reordered_g;
@@ -247,6 +252,17 @@ template <int NGP> ECRAD_DEV int first_exceeding(bool exceeds, int tid) {
   const int shift = ((tid & 63) / NGP) * NGP;
   const unsigned long long seg = NGP == 64 ? b : ((b >> shift) & ((1ull << (NGP & 63)) - 1ull));
   return seg ? __ffsll((long long)seg) - 1 : NGP;
+}
+// The same for a launch that starts at g-point g0 > 0 of the spectrum: the search of the reference runs over the whole
+// spectrum, so a g-point of an earlier chunk that exceeds the threshold switches the 3-D treatment off for all of this
+// one (first = 0).  `od` is the stage array of the gas optical depth, `o0` the offset of g-point 0 of this (layer, column);
+// lane k of the column group looks at g-points k, k + NGP, ... below g0.
+template <int NGP, typename R> ECRAD_DEV int first_exceeding_chunk(bool exceeds, int tid, const double* od, size_t o0, int g0, int glane, R max_od) {
+  bool before = false;
+  for (int gp = glane; gp < g0; gp += NGP) before = before || R(od[o0 + gp]) > max_od;
+  const int first_before = first_exceeding<NGP>(before, tid);
+  const int first_here = first_exceeding<NGP>(exceeds, tid);
+  return first_before < NGP ? 0 : first_here;
 }
 
 // radiation_spartacus_sw.F90:1606-1721, one g-point
@@ -371,7 +387,7 @@ ECRAD_DEV SwMats<R> sw_layer(const SpArgs& a, const Geo& gm, const LevelOrder& o
   const R one_over_mu0 = R(1) / mu0;
   const size_t o = g + (size_t)ng * (jl + (size_t)nlev * cloc);
   const R odl = R(a.op.od_sw[o]), ssal = R(a.op.ssa_sw[o]), gl = R(a.op.g_sw ? a.op.g_sw[o] : 0.0);
-  const int first = first_exceeding<NGP>(valid && odl > R(c.max_gas_od_3d), tid);
+  const int first = first_exceeding_chunk<NGP, R>(valid && odl > R(c.max_gas_od_3d), tid, a.op.od_sw, o - g, c.g0, glane, R(c.max_gas_od_3d));
     // -- section 3: layer matrices --
     R od_region[3] = {odl, R(0), R(0)}, ssa_region[3] = {ssal, R(0), R(0)};
     R gamma1[3] = {R(0), R(0), R(0)}, gamma2[3] = {R(0), R(0), R(0)}, gamma3[3] = {R(0), R(0), R(0)};
@@ -512,8 +528,10 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
     const bool col_ok = cloc_raw < nloc;
     const int cloc = col_ok ? cloc_raw : nloc - 1;
     const int col = a.in.istartcol - 1 + cloc;
-    const int g = glane < ng ? glane : ng - 1;
-    const bool valid = col_ok && glane < ng;
+    const int gi = c.g0 + glane, ngl = c.ngl;      // g-point of this lane; g-points of this launch
+    const int g = gi < ng ? gi : ng - 1;
+    const int gs = glane < ngl ? glane : ngl - 1;  // its place in the layer store
+    const bool valid = col_ok && gi < ng;
     const bool lead = col_ok && glane == 0;
     const int ib = c.i_band_from_reordered_g[g] - 1;
     const LevelOrder ord = level_order(a.in);
@@ -572,11 +590,11 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
       }
       M3<R> refl, tran, rdir, tdd, tdir;
       if (listed) {
-        const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 45 * ng + g;
+        const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 45 * ngl + gs;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-          refl.a[k] = lp[(size_t)k * ng]; tran.a[k] = lp[(size_t)(9 + k) * ng]; rdir.a[k] = lp[(size_t)(18 + k) * ng];
-          tdd.a[k] = lp[(size_t)(27 + k) * ng]; tdir.a[k] = lp[(size_t)(36 + k) * ng];
+          refl.a[k] = lp[(size_t)k * ngl]; tran.a[k] = lp[(size_t)(9 + k) * ngl]; rdir.a[k] = lp[(size_t)(18 + k) * ngl];
+          tdd.a[k] = lp[(size_t)(27 + k) * ngl]; tdir.a[k] = lp[(size_t)(36 + k) * ngl];
         }
       } else {
         refl = diag_only(cl.ref_diff); tran = diag_only(cl.trans_diff); rdir = diag_only(cl.ref_dir);
@@ -760,10 +778,10 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
           flux_up_above.a[0] = tad1 * direct_dn_above.a[0] + ta1 * flux_dn_above.a[0];
         } else {
           M3<R> refl, tran, tdd, tdir, ta1, tad1;
-          const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 45 * ng + g;
+          const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 45 * ngl + gs;
 #pragma unroll
           for (int k = 0; k < 9; ++k) {
-            refl.a[k] = lp[(size_t)k * ng]; tran.a[k] = lp[(size_t)(9 + k) * ng]; tdd.a[k] = lp[(size_t)(27 + k) * ng]; tdir.a[k] = lp[(size_t)(36 + k) * ng];
+            refl.a[k] = lp[(size_t)k * ngl]; tran.a[k] = lp[(size_t)(9 + k) * ngl]; tdd.a[k] = lp[(size_t)(27 + k) * ngl]; tdir.a[k] = lp[(size_t)(36 + k) * ngl];
           }
           slab.get(jl, SW_TA, tid, ta1); slab.get(jl, SW_TAD, tid, tad1);
           const V3<R> source_dn = sp::mul(tdd, direct_dn_below);
@@ -840,7 +858,7 @@ ECRAD_DEV LwMats<R> lw_layer(const SpArgs& a, const Geo& gm, const LevelOrder& o
     R od_region[3] = {R(a.op.od_lw[o]), R(0), R(0)}, ssa_region[3] = {R(0), R(0), R(0)}, g_region[3] = {R(0), R(0), R(0)};
     if (c.do_lw_aerosol_scattering) { ssa_region[0] = R(a.op.ssa_lw[o]); g_region[0] = R(a.op.g_lw[o]); }
     const R pt = R(a.op.planck_hl[op]), pb = R(a.op.planck_hl[op + ng]);
-    const int first = first_exceeding<NGP>(valid && od_region[0] > R(c.max_gas_od_3d), tid);
+    const int first = first_exceeding_chunk<NGP, R>(valid && od_region[0] > R(c.max_gas_od_3d), tid, a.op.od_lw, o - g, c.g0, glane, R(c.max_gas_od_3d));
     R gamma1[3] = {R(0), R(0), R(0)}, gamma2[3] = {R(0), R(0), R(0)};
     R rate[9], el[3] = {R(0), R(0), R(0)};
 #pragma unroll
@@ -1031,8 +1049,10 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
     const bool col_ok = cloc_raw < nloc;
     const int cloc = col_ok ? cloc_raw : nloc - 1;
     const int col = a.in.istartcol - 1 + cloc;
-    const int g = glane < ng ? glane : ng - 1;
-    const bool valid = col_ok && glane < ng;
+    const int gi = c.g0 + glane, ngl = c.ngl;      // g-point of this lane; g-points of this launch
+    const int g = gi < ng ? gi : ng - 1;
+    const int gs = glane < ngl ? glane : ngl - 1;  // its place in the layer store
+    const bool valid = col_ok && gi < ng;
     const bool lead = col_ok && glane == 0;
     const int ib = c.i_band_from_reordered_g[g] - 1;
     const LevelOrder ord = level_order(a.in);
@@ -1085,11 +1105,11 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
       M3<R> refl, tran;
       V3<R> source_up, source_dn;
       if (listed) {
-        const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ng + g;
+        const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ngl + gs;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { refl.a[k] = lp[(size_t)k * ng]; tran.a[k] = lp[(size_t)(9 + k) * ng]; }
+        for (int k = 0; k < 9; ++k) { refl.a[k] = lp[(size_t)k * ngl]; tran.a[k] = lp[(size_t)(9 + k) * ngl]; }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { source_up.a[k] = lp[(size_t)(18 + k) * ng]; source_dn.a[k] = lp[(size_t)(21 + k) * ng]; }
+        for (int k = 0; k < 3; ++k) { source_up.a[k] = lp[(size_t)(18 + k) * ngl]; source_dn.a[k] = lp[(size_t)(21 + k) * ngl]; }
       } else {
         const R rf0 = R(gm.rf(0, jl));
         refl = diag_only(cl.reflectance); tran = diag_only(cl.transmittance);
@@ -1189,11 +1209,11 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
       } else {
         M3<R> refl, tran, ta1;
         V3<R> sdn, ts1;
-        const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ng + g;
+        const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ngl + gs;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { refl.a[k] = lp[(size_t)k * ng]; tran.a[k] = lp[(size_t)(9 + k) * ng]; }
+        for (int k = 0; k < 9; ++k) { refl.a[k] = lp[(size_t)k * ngl]; tran.a[k] = lp[(size_t)(9 + k) * ngl]; }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) sdn.a[k] = lp[(size_t)(21 + k) * ng];
+        for (int k = 0; k < 3; ++k) sdn.a[k] = lp[(size_t)(21 + k) * ngl];
         slab.get(jl, LW_TA, tid, ta1); slab.get(jl, LW_TS, tid, ts1);
         if (matrix_adding) {
           const V3<R> rhs = add(add(sp::mul(tran, flux_dn_below), sp::mul(refl, ts1)), sdn);
@@ -1231,8 +1251,10 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
       const double tot = group_sum<NGP>(valid ? fus : 0.0);
       V3<R> lwd;
       lwd.zero();
-      lwd.a[0] = R(fus) / R(tot);
-      if (lead) fx.lw_derivatives[col + ncol * ord.half(nlev)] = 1.0;
+      // (a chunk of a wider spectrum leaves its sums un-normalised -- their surface value is the chunk's share of the
+      //  surface flux -- and combine_derivatives_kernel adds the chunks and normalises, as for the other solvers)
+      lwd.a[0] = c.wide ? R(fus) : R(fus) / R(tot);
+      if (lead) fx.lw_derivatives[col + ncol * ord.half(nlev)] = c.wide ? tot : 1.0;
       for (int jlev = nlev; jlev >= 1; --jlev) {
         const int jl = jlev - 1;
         R um[9];
@@ -1245,9 +1267,9 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
           lwd.a[0] = t00 * v1.a[0];
         } else {
           M3<R> tran;
-          const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ng + g;
+          const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ngl + gs;
 #pragma unroll
-          for (int k = 0; k < 9; ++k) tran.a[k] = lp[(size_t)(9 + k) * ng];
+          for (int k = 0; k < 9; ++k) tran.a[k] = lp[(size_t)(9 + k) * ngl];
           lwd = sp::mul(tran, v1);
         }
         put_sum<NGP>(fx.lw_derivatives, col + ncol * ord.half(jlev - 1), (double)lwd.sum(), valid, lead);
@@ -1302,8 +1324,10 @@ __global__ __launch_bounds__(kBlock, 1) void spartacus_layers_kernel(SpArgs args
   const int ng = c.ng, nlev = a.in.nlev;
   const int nloc = a.in.iendcol - a.in.istartcol + 1;
   const int n = *a.n_items;
-  const int g = glane < ng ? glane : ng - 1;
-  const bool gvalid = glane < ng;
+  const int gi = c.g0 + glane, ngl = c.ngl;
+  const int g = gi < ng ? gi : ng - 1;
+  const int gs = glane < ngl ? glane : ngl - 1;
+  const bool gvalid = gi < ng;
   const int ib = c.i_band_from_reordered_g[g] - 1;
   const LevelOrder ord = level_order(a.in);
   const R min_mu0_3d = R(0.004625);
@@ -1327,21 +1351,21 @@ __global__ __launch_bounds__(kBlock, 1) void spartacus_layers_kernel(SpArgs args
       else tan_sza = sp::sp_sqrt(R(c.overhead_sun_factor));
       const SwMats<R> m = sw_layer<R, NGP>(a, gm, ord, col, cloc, jl, g, ib, glane, tid, valid, clr, mu0s, tan_sza);
       if (valid && sun_up) {
-        R* lp = reinterpret_cast<R*>(a.lay) + ((size_t)cloc * nlev + jl) * 45 * ng + g;
+        R* lp = reinterpret_cast<R*>(a.lay) + ((size_t)cloc * nlev + jl) * 45 * ngl + gs;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-          lp[(size_t)k * ng] = m.refl.a[k]; lp[(size_t)(9 + k) * ng] = m.tran.a[k]; lp[(size_t)(18 + k) * ng] = m.rdir.a[k];
-          lp[(size_t)(27 + k) * ng] = m.tdd.a[k]; lp[(size_t)(36 + k) * ng] = m.tdir.a[k];
+          lp[(size_t)k * ngl] = m.refl.a[k]; lp[(size_t)(9 + k) * ngl] = m.tran.a[k]; lp[(size_t)(18 + k) * ngl] = m.rdir.a[k];
+          lp[(size_t)(27 + k) * ngl] = m.tdd.a[k]; lp[(size_t)(36 + k) * ngl] = m.tdir.a[k];
         }
       }
     } else {
       const LwMats<R> m = lw_layer<R, NGP>(a, gm, ord, col, cloc, jl, g, ib, glane, tid, valid, clr);
       if (valid) {
-        R* lp = reinterpret_cast<R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ng + g;
+        R* lp = reinterpret_cast<R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ngl + gs;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { lp[(size_t)k * ng] = m.refl.a[k]; lp[(size_t)(9 + k) * ng] = m.tran.a[k]; }
+        for (int k = 0; k < 9; ++k) { lp[(size_t)k * ngl] = m.refl.a[k]; lp[(size_t)(9 + k) * ngl] = m.tran.a[k]; }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { lp[(size_t)(18 + k) * ng] = m.source_up.a[k]; lp[(size_t)(21 + k) * ng] = m.source_dn.a[k]; }
+        for (int k = 0; k < 3; ++k) { lp[(size_t)(18 + k) * ngl] = m.source_up.a[k]; lp[(size_t)(21 + k) * ngl] = m.source_dn.a[k]; }
       }
     }
   }
@@ -1350,14 +1374,14 @@ __global__ __launch_bounds__(kBlock, 1) void spartacus_layers_kernel(SpArgs args
 // ---- host side -------------------------------------------------------------------------------------------------------
 size_t spartacus_scratch_words(bool is_sw, int nlev) { return (size_t)nlev * (is_sw ? SW_NSLOT : LW_NSLOT) * kBlock; }
 int spartacus_sweep_blocks_per_cu(bool single, bool is_sw) { return single ? (is_sw ? ECRAD_SP_SWEEP_WAVES_SW : ECRAD_SP_SWEEP_WAVES_LW) : (is_sw ? 1 : 2); }
-size_t spartacus_layer_words(bool is_sw, int ng) { return (size_t)(is_sw ? 45 : 24) * ng; }    // per (column, layer)
+size_t spartacus_layer_words(bool is_sw, int ng) { return (size_t)(is_sw ? 45 : 24) * ng; }    // per (column, layer); ng = g-points of one launch
 
 // `grid_layers` blocks for the list walk (one block per CU), `grid` for the sweeps; `lay`: spartacus_layer_words x nlev x
 // columns words of R; `list`: nlev x columns entries; `n_items`: one int, zeroed here
 hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, int grid_layers, hipStream_t st, const ecrad_config_t& c,
                             const DevInputs& in, const DevOptics& op, const DevCloudPrep& prep, const DevFlux& fx, void* scratch,
                             size_t per_block_words, int* counter, const int32_t* d_i_band_from_reordered_g, void* lay, uint32_t* list,
-                            int* n_items) {
+                            int* n_items, int g0, bool wide) {
   SpArgs a{};
   SpConfig& s = a.c;
   s.ng = is_sw ? c.n_g_sw : c.n_g_lw;
@@ -1371,12 +1395,15 @@ hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, int grid
   s.clear_to_thick_fraction = c.clear_to_thick_fraction; s.overhead_sun_factor = c.overhead_sun_factor;
   s.cloud_fraction_threshold = c.cloud_fraction_threshold;
   s.i_band_from_reordered_g = d_i_band_from_reordered_g;
+  s.g0 = g0; s.ngl = std::min(ngp, s.ng - g0); s.wide = wide ? 1 : 0;
   a.in = in; a.op = op; a.prep = prep; a.fx = fx; a.scratch = scratch; a.per_block = per_block_words; a.counter = counter;
   a.lay = lay; a.list = list; a.n_items = n_items;
-  hipError_t e = hipMemsetAsync(n_items, 0, sizeof(int), st);
-  if (e != hipSuccess) return e;
-  const int nloc = in.iendcol - in.istartcol + 1;
-  hipLaunchKernelGGL(spartacus_list_kernel, dim3((nloc + 255) / 256), dim3(256), 0, st, in, c.use_expm_everywhere, list, n_items);
+  if (g0 == 0) {       // the work list is the same for every chunk of the spectrum
+    hipError_t e = hipMemsetAsync(n_items, 0, sizeof(int), st);
+    if (e != hipSuccess) return e;
+    const int nloc = in.iendcol - in.istartcol + 1;
+    hipLaunchKernelGGL(spartacus_list_kernel, dim3((nloc + 255) / 256), dim3(256), 0, st, in, c.use_expm_everywhere, list, n_items);
+  }
   const dim3 g(grid), gl(grid_layers), b(kBlock);
 #define ECRAD_SP(R, N) do { if (is_sw) { hipLaunchKernelGGL((spartacus_layers_kernel<R, N, true>), gl, b, 0, st, a);      \
                                          hipLaunchKernelGGL((spartacus_sw_kernel<R, N>), g, b, 0, st, a); }                  \

@@ -65,7 +65,7 @@ int spartacus_sweep_blocks_per_cu(bool single, bool is_sw);
 hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, int grid_layers, hipStream_t st, const ecrad_config_t& c,
                             const DevInputs& in, const DevOptics& op, const DevCloudPrep& prep, const DevFlux& fx, void* scratch,
                             size_t per_block_words, int* counter, const int32_t* d_i_band_from_reordered_g, void* lay, uint32_t* list,
-                            int* n_items);
+                            int* n_items, int g0, bool wide);
 
 // RRTMG gas optics (kernel_rrtmg.hip)
 namespace rrtmg { struct DevRrtmg; }

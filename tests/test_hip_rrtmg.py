@@ -45,6 +45,16 @@ CASES = {
     "baran2017_ice": dict(sw_solver="McICA", i_ice_model=4, do_lw_aerosol_scattering=False),
     "yi_ice": dict(sw_solver="Tripleclouds", i_ice_model=5, do_lw_aerosol_scattering=False),
     "slingo_yi_no_lw_scattering": dict(sw_solver="McICA", i_liq_model=2, i_ice_model=5, do_lw_cloud_scattering=False, do_lw_aerosol_scattering=False),
+    # SPARTACUS on the 140/112-point spectra (five / two launches of the layer and sweep kernels per spectrum): the
+    # reference's own test_spartacus and test_spartacus_maxentr targets (test/ifs/Makefile:76-90) -- the 3-D effects on,
+    # do_sw_delta_scaling_with_gases off as in configCY49R1.nam -- and variants.  entrapment codes: radiation_config.F90:98-104
+    "spartacus": dict(sw_solver="SPARTACUS", do_3d_effects=True, do_lw_derivatives=True, do_lw_aerosol_scattering=False),
+    "spartacus_maxentr": dict(sw_solver="SPARTACUS", do_3d_effects=True, i_3d_sw_entrapment=4, do_lw_derivatives=True, do_lw_aerosol_scattering=False),
+    "spartacus_lw_aerosol_scat": dict(sw_solver="SPARTACUS", do_3d_effects=True, do_lw_derivatives=True),
+    # (a low threshold: the g-point from which the 3-D treatment is switched off lies in an EARLIER launch for most chunks)
+    "spartacus_tight_caps": dict(sw_solver="SPARTACUS", do_3d_effects=True, max_gas_od_3d=0.05, max_3d_transfer_rate=1.0, do_lw_aerosol_scattering=False),
+    "spartacus_expm_everywhere_noaer": dict(sw_solver="SPARTACUS", do_3d_effects=True, use_expm_everywhere=True, use_aerosols=False, do_lw_aerosol_scattering=False),
+    "spartacus_no_3d": dict(sw_solver="SPARTACUS", do_3d_effects=False, do_lw_aerosol_scattering=False),
 }
 
 

@@ -43,6 +43,9 @@ CASES = {
     "noclear": dict(do_clear=False, do_sw_direct=False),
     "lognormal_beta": dict(i_cloud_pdf_shape=0, use_beta_overlap=True),
     "sw64": dict(gas_optics_sw_override_file_name="ecckd-1.2_sw_climate_window-64b_ckd-definition.nc"),
+    # 96 shortwave g-points: three launches of 32 lanes per column (see also the RRTMG cases of test_hip_rrtmg.py)
+    "sw96": dict(gas_optics_sw_override_file_name="ecckd-1.4_sw_climate_vfine-96b_ckd-definition.nc"),
+    "sw96_tight_caps": dict(gas_optics_sw_override_file_name="ecckd-1.4_sw_climate_vfine-96b_ckd-definition.nc", max_gas_od_3d=0.5),
 }
 
 
@@ -141,3 +144,17 @@ def test_spartacus_single_precision(name, oracle_lib):
             assert (got[calm] <= 1.0e-3).mean() > 0.999, (k, (got[calm] > 1.0e-3).mean())
     off = np.abs(f_sp.arrays["lw_up"] - f_dp.arrays["lw_up"]) / f_dp.arrays["lw_up"] > 1.0e-3
     print(f"{name}: single-precision ORACLE, all-sky lw_up off by more than 1e-3 from double in {100.0 * off.mean():.2f} % of the values")
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(max_gas_od_3d=0.5), dict(do_lw_aerosol_scattering=True)], ids=["default", "tight_caps", "aerosol_scat"])
+def test_spartacus_wide_longwave_spectrum(kw, tmp_path, oracle_lib):
+    """96 longwave g-points (the 32-term model with every g-point three times: the reference ships no wider ecCKD
+    longwave model): three launches per kernel, broadband profiles from per-chunk partial sums, derivatives normalised
+    by the surface flux of the whole spectrum afterwards, and the g-point that switches the 3-D treatment off searched
+    over the whole spectrum (radiation_spartacus_lw.F90, section 3.2)."""
+    from test_hip_parity import _replicated_lw_model
+    kw = dict(kw, gas_optics_lw_override_file_name=_replicated_lw_model(tmp_path))
+    f_ora, _, _ = run_case(_config(**kw), oracle_lib.backend)
+    f_hip, _, rad = run_case(_config(**kw), "hip")
+    rad.close()
+    compare_flux(f_hip, f_ora, TOL)
