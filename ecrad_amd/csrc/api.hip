@@ -202,6 +202,7 @@ int setup_ckd(ecrad_hip_handle_t h, const ecrad_ckd_model_t& m, DevCkdModel& d) 
     dg.i_gas_code = g.i_gas_code; dg.i_conc_dependence = g.i_conc_dependence; dg.n_mole_frac = g.n_mole_frac;
     dg.reference_mole_frac = g.reference_mole_frac; dg.log_mole_frac1 = g.log_mole_frac1;
     dg.d_log_mole_frac = g.d_log_mole_frac; dg.mole_frac1 = std::exp(g.log_mole_frac1);
+    dg.conc_scaling = 1.0;       // (ecrad_hip_setup sets it once it knows the units of gas%mixing_ratio)
     if (g.i_conc_dependence != ECRAD_CONC_NONE && (g.i_gas_code < 1 || g.i_gas_code > ECRAD_NMAXGASES))
       return fail(h, ECRAD_EINVAL, "ckd model: gas code out of range");
     const bool lut = g.i_conc_dependence == ECRAD_CONC_LUT;
@@ -663,9 +664,20 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
   }
   if (!c.do_sw) h->rrtmg_sw = false;
   if (!c.do_lw) h->rrtmg_lw = false;
-  if (c.do_sw && c.do_lw && h->rrtmg_sw != h->rrtmg_lw)
-    return fail(h, ECRAD_EUNSUPPORTED, "RRTMG in one spectrum and ecCKD in the other: gas%mixing_ratio cannot be in both models' units");
   d.gas_mmr = (h->rrtmg_sw || h->rrtmg_lw) ? 1 : 0;
+  if (d.gas_mmr) {
+    // RRTMG in one spectrum and ecCKD in the other (the reference's test_mixed_gas configurations): set_gas_units has
+    // made gas%mixing_ratio mass mixing ratio for both (radiation_interface.F90:177-181); the ecCKD model converts
+    // with the scaling gas%get_scaling returns (radiation_ecckd_interface.F90:249-255, radiation_gas.F90:471-486)
+    static const double gas_molar_mass[ECRAD_NMAXGASES] = {18.0152833, 44.011, 47.9982, 44.013, 28.0101, 16.043, 31.9988,
+                                                           137.3686, 120.914, 86.469, 153.823, 46.0055};      // radiation_gas_constants.F90:43-56
+    for (DevCkdModel* m : {&d.gas_sw, &d.gas_lw}) {
+      const bool ckd = m == &d.gas_sw ? (c.do_sw && !h->rrtmg_sw) : (c.do_lw && !h->rrtmg_lw);
+      if (!ckd) continue;
+      for (int j = 0; j < m->ngas; ++j)
+        if (m->gas[j].i_gas_code >= 1) m->gas[j].conc_scaling = 1.0 * kAirMolarMass / gas_molar_mass[m->gas[j].i_gas_code - 1];
+    }
+  }
   d.cloud_fit = (c.do_clouds && !c.use_general_cloud_optics) ? 1 : 0;
   d.fu_lw_bug = c.do_fu_lw_ice_optics_bug;
   d.i_liq_model = c.i_liq_model; d.i_ice_model = c.i_ice_model;

@@ -23,6 +23,9 @@ struct DevCkdGas {
   double reference_mole_frac, log_mole_frac1, d_log_mole_frac, mole_frac1;
   int32_t qpos;               // position of this gas's (first) quad in the model's quad order
   int32_t pad2_;
+  // concentration_scaling of calc_optical_depth (radiation_ecckd.F90:518-519): 1 when gas%mixing_ratio is volume mixing
+  // ratio; AirMolarMass / GasMolarMass when RRTMG in the other spectrum has made it mass mixing ratio (radiation_gas.F90:471-486)
+  double conc_scaling;
 };
 
 // What the lane=g loops need from a gas-optics model, small enough to live in scalar registers:

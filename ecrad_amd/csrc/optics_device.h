@@ -95,15 +95,16 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
     int k = sg.qpos;
     if (sg.i_conc_dependence != ECRAD_CONC_NONE) {
       const double vmr = in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (sg.i_gas_code - 1))];
-      if (sg.i_conc_dependence == ECRAD_CONC_LINEAR) mult = simple_multiplier * vmr;
-      else if (sg.i_conc_dependence == ECRAD_CONC_RELATIVE_LINEAR) mult = simple_multiplier * (vmr - sg.reference_mole_frac);
+      const double scaling = sg.conc_scaling;      // (the products below in the reference's order, :559-562, :574-576, :607, :625)
+      if (sg.i_conc_dependence == ECRAD_CONC_LINEAR) mult = simple_multiplier * vmr * scaling;
+      else if (sg.i_conc_dependence == ECRAD_CONC_RELATIVE_LINEAR) mult = simple_multiplier * (vmr * scaling - sg.reference_mole_frac);
       else {  // LUT: two quads, weighted (1-cw2, cw2)
-        double log_conc = log(dmax(vmr, sg.mole_frac1));
+        double log_conc = log(dmax(vmr * scaling, sg.mole_frac1));
         double cindex1 = (log_conc - sg.log_mole_frac1) / sg.d_log_mole_frac;
         cindex1 = 1.0 + dmax(0.0, dmin(cindex1, sg.n_mole_frac - 1.0001));
         ic1 = (int)cindex1;
         const double cw2 = cindex1 - ic1;
-        mult = simple_multiplier * vmr;
+        mult = simple_multiplier * vmr * scaling;
         L.D(F_QMULT + k, slot) = mult * (1.0 - cw2);
         k++;
         mult = mult * cw2;

@@ -51,10 +51,8 @@ def setup_radiation(config: Config) -> None:
     for m in (config.i_gas_model_sw, config.i_gas_model_lw):
         if m == IGasModelMonochromatic:
             raise ConfigError("the monochromatic gas model is not implemented in this build")
-    if config.do_sw and config.do_lw and config.i_gas_model_sw != config.i_gas_model_lw:
-        raise ConfigError("shortwave and longwave gas models must be the same in this build")
-    if (config.i_gas_model_sw if config.do_sw else config.i_gas_model_lw) == IGasModelIFSRRTMG:
-        return _setup_radiation_rrtmg(config)
+    if (config.do_sw and config.i_gas_model_sw == IGasModelIFSRRTMG) or (config.do_lw and config.i_gas_model_lw == IGasModelIFSRRTMG):
+        return _setup_radiation_rrtmg(config)     # (RRTMG in at least one spectrum; the other may be ecCKD)
     # setup_gas_optics (radiation_ecckd_interface.F90:27-150)
     if config.do_sw:
         config.gas_optics_sw = CkdModel(config.gas_optics_sw_file_name)
@@ -185,26 +183,57 @@ class _BandsOnlyGasOptics:
 
 
 def _setup_radiation_rrtmg(config: Config) -> None:
-    """setup_radiation with gas_model_name = "RRTMG-IFS": setup_gas_optics of radiation_ifs_rrtm.F90:58-213, then the
-    same surface-interval, cloud, aerosol and McICA set-up as above with bands instead of g-points."""
+    """setup_radiation with "RRTMG-IFS" as the gas model of at least one spectrum: setup_gas_optics of
+    radiation_ifs_rrtm.F90:58-213 for the spectra that use it (and of radiation_ecckd_interface.F90:27-150 for one that
+    uses ecCKD: sw_gas_model_name / lw_gas_model_name may differ, the reference's test_mixed_gas configurations), then
+    the same surface-interval, cloud, aerosol and McICA set-up as above, with bands instead of g-points where RRTMG is."""
     from .rrtmg import (LW_WAVENUMBER1, LW_WAVENUMBER2, SW_WAVENUMBER1, SW_WAVENUMBER2, RrtmgTables)
     from .spectral import SpectralDefinition
     from .tables import BandFitCloudOptics
     config.rrtmg = RrtmgTables()
-    config.do_cloud_aerosol_per_sw_g_point = False
-    config.do_cloud_aerosol_per_lw_g_point = False
-    sd_sw = SpectralDefinition.bands_only(SOLAR_REFERENCE_TEMPERATURE, SW_WAVENUMBER1, SW_WAVENUMBER2)
-    sd_lw = SpectralDefinition.bands_only(TERRESTRIAL_REFERENCE_TEMPERATURE, LW_WAVENUMBER1, LW_WAVENUMBER2)
-    if config.do_sw:
+    rrtmg_sw = config.do_sw and config.i_gas_model_sw == IGasModelIFSRRTMG
+    rrtmg_lw = config.do_lw and config.i_gas_model_lw == IGasModelIFSRRTMG
+    sd_sw = sd_lw = None
+    if config.do_sw and rrtmg_sw:
+        config.do_cloud_aerosol_per_sw_g_point = False
+        sd_sw = SpectralDefinition.bands_only(SOLAR_REFERENCE_TEMPERATURE, SW_WAVENUMBER1, SW_WAVENUMBER2)
         config.n_g_sw, config.n_bands_sw = 112, 14
         config.i_band_from_reordered_g_sw = config.rrtmg.i_band_from_g_sw.copy()
         config.gas_optics_sw = _BandsOnlyGasOptics(sd_sw)
-    if config.do_lw:
+    elif config.do_sw:
+        config.gas_optics_sw = CkdModel(config.gas_optics_sw_file_name)
+        sd_sw = config.gas_optics_sw.spectral_def
+        config.n_g_sw = config.gas_optics_sw.ng
+        if config.do_cloud_aerosol_per_sw_g_point:
+            config.n_bands_sw = config.n_g_sw
+            config.i_band_from_reordered_g_sw = np.arange(1, config.n_g_sw + 1, dtype=np.int32)
+        else:
+            config.n_bands_sw = sd_sw.nband
+            config.i_band_from_reordered_g_sw = sd_sw.i_band_number.astype(np.int32)
+    if config.do_lw and rrtmg_lw:
+        config.do_cloud_aerosol_per_lw_g_point = False
+        sd_lw = SpectralDefinition.bands_only(TERRESTRIAL_REFERENCE_TEMPERATURE, LW_WAVENUMBER1, LW_WAVENUMBER2)
         config.n_g_lw, config.n_bands_lw = 140, 16
         config.i_band_from_reordered_g_lw = config.rrtmg.i_band_from_g_lw.copy()
         config.gas_optics_lw = _BandsOnlyGasOptics(sd_lw)
+    elif config.do_lw:
+        config.gas_optics_lw = CkdModel(config.gas_optics_lw_file_name)
+        sd_lw = config.gas_optics_lw.spectral_def
+        config.n_g_lw = config.gas_optics_lw.ng
+        if config.do_cloud_aerosol_per_lw_g_point:
+            config.n_bands_lw = config.n_g_lw
+            config.i_band_from_reordered_g_lw = np.arange(1, config.n_g_lw + 1, dtype=np.int32)
+        else:
+            config.n_bands_lw = sd_lw.nband
+            config.i_band_from_reordered_g_lw = sd_lw.i_band_number.astype(np.int32)
+    mixed = (config.do_sw and not rrtmg_sw) or (config.do_lw and not rrtmg_lw)
+    use_bands_sw, use_bands_lw = not config.do_cloud_aerosol_per_sw_g_point, not config.do_cloud_aerosol_per_lw_g_point
+    if mixed and config.do_clouds and not config.use_general_cloud_optics:
+        raise ConfigError("the per-band cloud-optics fits exist for the RRTMG bands only: an ecCKD spectrum needs use_general_cloud_optics=true")
     for sfx in ("sw", "lw"):
-        if not getattr(config, "do_" + sfx) or not (config.do_save_spectral_flux or config.do_toa_spectral_flux):
+        is_rrtmg = rrtmg_sw if sfx == "sw" else rrtmg_lw
+        want = (config.do_save_spectral_flux or config.do_toa_spectral_flux) if is_rrtmg else config.do_save_spectral_flux
+        if not getattr(config, "do_" + sfx) or not want:
             setattr(config, "n_spec_" + sfx, 0)
             setattr(config, "i_spec_from_reordered_g_" + sfx, None)
         elif config.do_save_gpoint_flux:
@@ -237,13 +266,13 @@ def _setup_radiation_rrtmg(config: Config) -> None:
     if config.do_sw:
         idx, bnd, config.n_canopy_bands_sw = intervals(config.i_sw_albedo_index, config.sw_albedo_wavelength_bound,
                                                        config.use_canopy_full_spectrum_sw, config.n_g_sw)
-        config.sw_albedo_weights = np.ascontiguousarray(sd_sw.calc_mapping_from_bands(bnd, idx, use_bands=True))
+        config.sw_albedo_weights = np.ascontiguousarray(sd_sw.calc_mapping_from_bands(bnd, idx, use_bands=use_bands_sw))
         if config.do_nearest_spectral_sw_albedo:
             config.i_albedo_from_band_sw = (np.argmax(config.sw_albedo_weights, axis=1) + 1).astype(np.int32)
     if config.do_lw:
         idx, bnd, config.n_canopy_bands_lw = intervals(config.i_lw_emiss_index, config.lw_emiss_wavelength_bound,
                                                        config.use_canopy_full_spectrum_lw, config.n_g_lw)
-        config.lw_emiss_weights = np.ascontiguousarray(sd_lw.calc_mapping_from_bands(bnd, idx, use_bands=True))
+        config.lw_emiss_weights = np.ascontiguousarray(sd_lw.calc_mapping_from_bands(bnd, idx, use_bands=use_bands_lw))
         if config.do_nearest_spectral_lw_emiss:
             config.i_emiss_from_band_lw = (np.argmax(config.lw_emiss_weights, axis=1) + 1).astype(np.int32)
 
@@ -257,9 +286,9 @@ def _setup_radiation_rrtmg(config: Config) -> None:
                     config.directory_name, name if name.endswith(".nc") else name + "_scattering.nc")
                 thick = config.use_thick_cloud_spectral_averaging[j]
                 if config.do_sw:
-                    config.cloud_optics_sw.append(GeneralCloudOptics(fn, sd_sw, True, thick, SOLAR_REFERENCE_TEMPERATURE, name))
+                    config.cloud_optics_sw.append(GeneralCloudOptics(fn, sd_sw, use_bands_sw, thick, SOLAR_REFERENCE_TEMPERATURE, name))
                 if config.do_lw:
-                    config.cloud_optics_lw.append(GeneralCloudOptics(fn, sd_lw, True, thick, TERRESTRIAL_REFERENCE_TEMPERATURE, name))
+                    config.cloud_optics_lw.append(GeneralCloudOptics(fn, sd_lw, use_bands_lw, thick, TERRESTRIAL_REFERENCE_TEMPERATURE, name))
         else:
             # setup_cloud_optics (radiation_cloud_optics.F90:38-213): liquid then ice
             config.n_cloud_types = 2
@@ -291,7 +320,8 @@ def _setup_radiation_rrtmg(config: Config) -> None:
             if not config.use_general_aerosol_optics:
                 raise ConfigError("only use_general_aerosol_optics=true is implemented")
             config.aerosol_optics = AerosolOptics(config.aerosol_optics_file_name, sd_sw if config.do_sw else None,
-                                                  sd_lw if config.do_lw else None, False, False, config.do_sw, config.do_lw)
+                                                  sd_lw if config.do_lw else None, config.do_cloud_aerosol_per_sw_g_point,
+                                                  config.do_cloud_aerosol_per_lw_g_point, config.do_sw, config.do_lw)
             config.aerosol_optics.set_types(config.i_aerosol_type_map[:config.n_aerosol_types])
         else:
             config.use_aerosols = False
@@ -384,8 +414,9 @@ def build_config_struct(config: Config):
     if config.rrtmg is not None:
         keep.append(config.rrtmg)
         c.rrtmg = C.pointer(config.rrtmg.struct)
-    else:
+    if isinstance(config.gas_optics_sw, CkdModel):
         fill_ckd(c.gas_optics_sw, config.gas_optics_sw)
+    if isinstance(config.gas_optics_lw, CkdModel):
         fill_ckd(c.gas_optics_lw, config.gas_optics_lw)
     c.min_gas_od_lw, c.min_gas_od_sw = config.min_gas_od_lw, config.min_gas_od_sw
     c.i_liq_model, c.i_ice_model = config.i_liq_model, config.i_ice_model

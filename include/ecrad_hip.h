@@ -224,8 +224,9 @@ typedef struct ecrad_config {
   ecrad_cloud_optics_t   cloud_optics_lw[ECRAD_NMAXCLOUDTYPES];
   ecrad_aerosol_optics_t aerosol_optics;
   ecrad_pdf_sampler_t    pdf_sampler;
-  /* RRTMG (i_gas_model_* == ECRAD_GAS_IFSRRTMG): gas%mixing_ratio is then MASS mixing ratio
-     (radiation_ifs_rrtm.F90:208) and gas_optics_sw/lw are not read */
+  /* RRTMG (i_gas_model_sw and/or i_gas_model_lw == ECRAD_GAS_IFSRRTMG; the two spectra choose independently):
+     gas%mixing_ratio is then MASS mixing ratio (radiation_ifs_rrtm.F90:208) and gas_optics_sw/lw of a spectrum that
+     uses RRTMG is not read */
   const ecrad_rrtmg_t*   rrtmg;
   double min_gas_od_lw, min_gas_od_sw;   /* radiation_config.F90:244-245 */
   /* use_general_cloud_optics == 0: the per-band fits of radiation_cloud_optics.F90.  cloud_optics_sw/lw[0] is liquid,
@@ -283,8 +284,10 @@ typedef struct ecrad_inputs {
   const double* sw_albedo_direct; /* (ncol,n_sw_albedo) or NULL (= use sw_albedo) */
   const double* lw_emissivity;    /* (ncol,n_lw_emissivity) */
   const int32_t* iseed;           /* (ncol) McICA only */
-  /* gas: mixing_ratio(ncol,nlev,ECRAD_NMAXGASES) already in the units the gas model wants
-     (set_gas_units has been called: volume mixing ratio, scale 1, for ecCKD; mass mixing ratio for RRTMG) */
+  /* gas: mixing_ratio(ncol,nlev,ECRAD_NMAXGASES) in the units set_gas_units gives them (radiation_interface.F90:164-187):
+     volume mixing ratio, scale 1, when both spectra use ecCKD; mass mixing ratio, scale 1, when either uses RRTMG --
+     an ecCKD model in the other spectrum then applies the concentration scaling of gas%get_scaling itself
+     (radiation_ecckd_interface.F90:249-255, radiation_gas.F90:471-486) */
   const double* gas_mixing_ratio;
   /* cloud */
   double*       cloud_fraction;   /* (ncol,nlev) INOUT: crop_cloud_fraction side effect (radiation_cloud.F90:700) */

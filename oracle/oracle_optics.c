@@ -103,7 +103,8 @@ void oracle_get_albedos(const ecrad_config_t* c, int ncol, int istartcol, int ie
 static void calc_optical_depth_ckd_model(const ecrad_ckd_model_t* m, int ncol, int nlev, int jcol,
      const double* pressure_hl, const double* temperature_fl /* (nlev) this column */,
      const double* mole_fraction_fl /* (ncol,nlev,NMAXGASES) */,
-     double* optical_depth_fl, double* rayleigh_od_fl)
+     double* optical_depth_fl, double* rayleigh_od_fl,
+     const double* concentration_scaling /* (NMAXGASES) by gas code, or NULL = 1 (radiation_ecckd.F90:518-519) */)
 {
   const int ng = m->ng;
   const double global_multiplier = 1.0 / (9.80665 * 0.001 * 28.970);
@@ -134,6 +135,7 @@ static void calc_optical_depth_ckd_model(const ecrad_ckd_model_t* m, int ncol, i
   for (int jgas = 0; jgas < m->ngas; ++jgas) {
     const ecrad_ckd_gas_t* sg = &m->single_gas[jgas];
     const int igascode = sg->i_gas_code;
+    const double scaling = (concentration_scaling && igascode >= 1) ? concentration_scaling[igascode - 1] : 1.0;
     const double* ma = sg->molar_abs;
 #define MA(g, ip, it) ma[(g) + (size_t)ng * (((ip) - 1) + np * ((it) - 1))]
 #define MAC(g, ip, it, ic) ma[(g) + (size_t)ng * (((ip) - 1) + np * (((it) - 1) + nt * ((ic) - 1)))]
@@ -142,10 +144,12 @@ static void calc_optical_depth_ckd_model(const ecrad_ckd_model_t* m, int ncol, i
     case ECRAD_CONC_RELATIVE_LINEAR:
     case ECRAD_CONC_NONE:
       for (int l = 0; l < nlev; ++l) {
-        if (sg->i_conc_dependence == ECRAD_CONC_LINEAR)
+        if (sg->i_conc_dependence == ECRAD_CONC_LINEAR) {           /* :559-562 */
           multiplier[l] = simple_multiplier[l] * MF(l, igascode);
-        else if (sg->i_conc_dependence == ECRAD_CONC_RELATIVE_LINEAR)
-          multiplier[l] = simple_multiplier[l] * (MF(l, igascode) - sg->reference_mole_frac);
+          multiplier[l] = multiplier[l] * scaling;
+        }
+        else if (sg->i_conc_dependence == ECRAD_CONC_RELATIVE_LINEAR)   /* :574-576 */
+          multiplier[l] = simple_multiplier[l] * (MF(l, igascode) * scaling - sg->reference_mole_frac);
         else
           multiplier[l] = simple_multiplier[l];
       }
@@ -158,7 +162,7 @@ static void calc_optical_depth_ckd_model(const ecrad_ckd_model_t* m, int ncol, i
     case ECRAD_CONC_LUT: {
       double mole_frac1 = exp(sg->log_mole_frac1);
       for (int l = 0; l < nlev; ++l) {
-        double log_conc = log(dmax(MF(l, igascode), mole_frac1));
+        double log_conc = log(dmax(MF(l, igascode) * scaling, mole_frac1));   /* :607 */
         double cindex1 = (log_conc - sg->log_mole_frac1) / sg->d_log_mole_frac;
         cindex1 = 1.0 + dmax(0.0, dmin(cindex1, sg->n_mole_frac - 1.0001));
         ic1[l] = (int)cindex1;
@@ -166,7 +170,7 @@ static void calc_optical_depth_ckd_model(const ecrad_ckd_model_t* m, int ncol, i
         cw1[l] = 1.0 - cw2[l];
       }
       for (int l = 0; l < nlev; ++l) {
-        double mult = simple_multiplier[l] * MF(l, igascode);
+        double mult = simple_multiplier[l] * MF(l, igascode) * scaling;   /* :625 */
         for (int g = 0; g < ng; ++g)
           optical_depth_fl[g + (size_t)ng * l] += mult * (
               (cw1[l] * tw1[l] * pw1[l]) * MAC(g, ip1[l], it1[l], ic1[l])
@@ -225,6 +229,17 @@ void oracle_gas_optics_ecckd(const ecrad_config_t* c, int ncol, int nlev, int is
 {
   const int nloc = iendcol - istartcol + 1;
   double* temperature_fl = (double*)malloc(sizeof(double) * nlev);
+  /* gas%assert_units / get_scaling (:249-255; radiation_gas.F90:471-486): with RRTMG in the other spectrum set_gas_units
+     (radiation_interface.F90:177-181) has put the mixing ratios in mass-mixing-ratio units, and ecCKD scales them to
+     volume mixing ratio by AirMolarMass / GasMolarMass (radiation_gas_constants.F90:42-56) */
+  static const double gas_molar_mass[ECRAD_NMAXGASES] = {18.0152833, 44.011, 47.9982, 44.013, 28.0101, 16.043, 31.9988,
+                                                         137.3686, 120.914, 86.469, 153.823, 46.0055};
+  double scaling_buf[ECRAD_NMAXGASES];
+  const double* scaling = NULL;
+  if ((c->do_sw && c->i_gas_model_sw == ECRAD_GAS_IFSRRTMG) || (c->do_lw && c->i_gas_model_lw == ECRAD_GAS_IFSRRTMG)) {
+    for (int k = 0; k < ECRAD_NMAXGASES; ++k) scaling_buf[k] = 1.0 * 28.970 / gas_molar_mass[k];
+    scaling = scaling_buf;
+  }
   for (int jc = 0; jc < nloc; ++jc) {
     const int jcol = istartcol - 1 + jc;
 #define PHL(l) in->pressure_hl[(size_t)jcol + (size_t)ncol * (l)]
@@ -236,7 +251,7 @@ void oracle_gas_optics_ecckd(const ecrad_config_t* c, int ncol, int nlev, int is
       double* od = od_sw + (size_t)ng * nlev * jc;
       double* ssa = ssa_sw + (size_t)ng * nlev * jc;
       calc_optical_depth_ckd_model(&c->gas_optics_sw, ncol, nlev, jcol, in->pressure_hl, temperature_fl,
-                                   in->gas_mixing_ratio, od, ssa);
+                                   in->gas_mixing_ratio, od, ssa, scaling);
       for (size_t i = 0; i < (size_t)ng * nlev; ++i) {
         od[i] = od[i] + ssa[i];
         ssa[i] = ssa[i] / od[i];
@@ -255,7 +270,7 @@ void oracle_gas_optics_ecckd(const ecrad_config_t* c, int ncol, int nlev, int is
     if (c->do_lw && c->i_gas_model_lw == ECRAD_GAS_ECCKD) {
       const int ng = c->n_g_lw;
       calc_optical_depth_ckd_model(&c->gas_optics_lw, ncol, nlev, jcol, in->pressure_hl, temperature_fl,
-                                   in->gas_mixing_ratio, od_lw + (size_t)ng * nlev * jc, NULL);
+                                   in->gas_mixing_ratio, od_lw + (size_t)ng * nlev * jc, NULL, scaling);
       oracle_calc_planck_function(&c->gas_optics_lw, nlev + 1, &THL(0), ncol,
                                   planck_hl + (size_t)ng * (nlev + 1) * jc);
       oracle_calc_planck_function(&c->gas_optics_lw, 1, &in->skin_temperature[jcol], 1,
@@ -561,7 +576,8 @@ int oracle_run_optics(const ecrad_config_t* c, int ncol, int nlev, int istartcol
     if (oracle_gas_optics_rrtmg(c, ncol, nlev, istartcol, iendcol, in, b->lw_albedo, b->od_lw, b->od_sw, b->ssa_sw,
                                 b->planck_hl, b->lw_emission, b->incoming_sw) != 0) return -1;
   }
-  else
+  /* (each routine does the spectra that use its model: radiation_interface.F90:341-357) */
+  if ((c->do_sw && c->i_gas_model_sw == ECRAD_GAS_ECCKD) || (c->do_lw && c->i_gas_model_lw == ECRAD_GAS_ECCKD))
   oracle_gas_optics_ecckd(c, ncol, nlev, istartcol, iendcol, in, b->lw_albedo, b->od_lw, b->od_sw, b->ssa_sw,
                           b->planck_hl, b->lw_emission, b->incoming_sw);
   if (c->do_clouds && !c->use_general_cloud_optics) {

@@ -44,13 +44,13 @@ int oracle_gas_optics_rrtmg(const ecrad_config_t* c, int ncol, int nlev, int ist
   const int nloc = iendcol - istartcol + 1;
   const size_t c0 = (size_t)(istartcol - 1);
   (void)ncol; (void)in;
-  if (c->do_lw) {
+  if (c->do_lw && c->i_gas_model_lw == ECRAD_GAS_IFSRRTMG) {
     const size_t ng = (size_t)c->n_g_lw;
     memcpy(od_lw, g_stage.od_lw + ng * nlev * c0, sizeof(double) * ng * nlev * nloc);
     memcpy(planck_hl, g_stage.planck_hl + ng * (nlev + 1) * c0, sizeof(double) * ng * (nlev + 1) * nloc);
     for (size_t i = 0; i < ng * nloc; ++i) lw_emission[i] = g_stage.lw_emission[ng * c0 + i] * (1.0 - lw_albedo[i]);
   }
-  if (c->do_sw) {
+  if (c->do_sw && c->i_gas_model_sw == ECRAD_GAS_IFSRRTMG) {
     const size_t ng = (size_t)c->n_g_sw;
     memcpy(od_sw, g_stage.od_sw + ng * nlev * c0, sizeof(double) * ng * nlev * nloc);
     memcpy(ssa_sw, g_stage.ssa_sw + ng * nlev * c0, sizeof(double) * ng * nlev * nloc);
