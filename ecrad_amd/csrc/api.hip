@@ -35,6 +35,12 @@ struct Buf {
 
 }  // namespace
 
+struct ChunkPlan {
+  static constexpr int kMax = 15;
+  int n = 1, max_ngp = 0;
+  int g0[kMax] = {0}, ngp[kMax] = {0};
+};
+
 struct ecrad_hip_handle_s {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -46,8 +52,9 @@ struct ecrad_hip_handle_s {
   DevConfig hcfg{};                // host copy of the device config (device pointers inside)
   DevConfig* dcfg = nullptr;
   std::vector<void*> tables;
-  int ngp_sw = 0, ngp_lw = 0;
+  int ngp_sw = 0, ngp_lw = 0;         // lanes per column group (the widest launch of the spectrum)
   int nchunk_sw = 1, nchunk_lw = 1;   // launches per spectrum (> 1 beyond 64 g-points)
+  ChunkPlan plan_sw, plan_lw;         // which g-points each launch covers, see chunk_plan()
   bool spec_sum_sw = false, spec_sum_lw = false;   // spectral flux profiles need summing over g-points
   const int32_t *d_ispec_sw = nullptr, *d_ispec_lw = nullptr;
   Buf spec_tmp;                    // per-g spectral flux profiles before that sum
@@ -155,6 +162,42 @@ int chunk_lanes(int ng, int* nchunk) {
   }
   *nchunk = best_pad / best;
   return best;
+}
+
+// The launches of one spectrum: launch p covers g-points g0[p] .. g0[p]+ngp[p]-1 (the last one may be padded).
+// Default for spectra wider than 64 g-points: chunks of DIFFERENT widths, as wide as possible and with as little
+// padding as possible -- 140 -> 64 + 64 + 16 (144 lanes instead of 5 x 32 = 160), 112 -> 64 + 32 + 16 (no padding
+// instead of 2 x 64 = 128), 96 -> 64 + 32; the cost of the solver kernels is per (lane, level, column).
+// Measured on 100 000 columns of the RRTMG workloads (profiles/r02_o_chunkplan.log): McICA LW 123 -> 105 ms, SW 90 -> 86 ms;
+// Tripleclouds LW 180 -> 144 ms -- but Tripleclouds SW 82 -> 88 ms (its 16- and 32-lane instantiations are the slow
+// ones), so that kernel keeps chunks of one width (`prefer_uniform`), chosen by chunk_lanes.
+// ECRAD_CHUNK_PLAN=uniform|mixed forces one or the other everywhere, ECRAD_CHUNK_LANES=n one width.
+ChunkPlan chunk_plan(int ng, bool prefer_uniform) {
+  ChunkPlan pl;
+  const char* mode = getenv("ECRAD_CHUNK_PLAN");
+  if (mode && std::strcmp(mode, "uniform") == 0) prefer_uniform = true;
+  if (mode && std::strcmp(mode, "mixed") == 0) prefer_uniform = false;
+  const bool uniform = ng <= 64 || getenv("ECRAD_CHUNK_LANES") || prefer_uniform;
+  if (uniform) {
+    int nch = 1;
+    const int n = chunk_lanes(ng, &nch);
+    pl.n = nch; pl.max_ngp = n;
+    for (int p = 0; p < nch && p < ChunkPlan::kMax; ++p) { pl.g0[p] = p * n; pl.ngp[p] = n; }
+    return pl;
+  }
+  int rem = ng, g0 = 0;
+  pl.n = 0; pl.max_ngp = 0;
+  while (rem > 0) {
+    int n = 0;
+    for (int w : {16, 32, 64})        // the narrowest width that takes all the rest, if its padding is small
+      if (!n && w >= rem && ((w - rem) * 100 <= 15 * w || w == 16)) n = w;
+    if (!n) for (int w : {64, 32, 16}) if (!n && w <= rem) n = w;      // else the widest that fits
+    if (pl.n < ChunkPlan::kMax) { pl.g0[pl.n] = g0; pl.ngp[pl.n] = n; }
+    pl.n++;
+    pl.max_ngp = std::max(pl.max_ngp, n);
+    g0 += n; rem -= n;
+  }
+  return pl;
 }
 
 int setup_ckd(ecrad_hip_handle_t h, const ecrad_ckd_model_t& m, DevCkdModel& d) {
@@ -428,10 +471,10 @@ int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
   }
   const bool tc = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_TRIPLECLOUDS) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_TRIPLECLOUDS);
   if (tc && c.i_overlap_scheme != ECRAD_OVERLAP_EXP_RAN) return fail(h, ECRAD_EINVAL, "Tripleclouds can only do Exp-Ran overlap");
-  { int nch = 1; if (c.do_sw && (c.n_g_sw < 1 || (chunk_lanes(c.n_g_sw, &nch), nch > 15))) return fail(h, ECRAD_EUNSUPPORTED, "shortwave spectrum too wide"); }
+  if (c.do_sw && (c.n_g_sw < 1 || chunk_plan(c.n_g_sw, c.i_solver_sw == ECRAD_SOLVER_TRIPLECLOUDS).n > ChunkPlan::kMax)) return fail(h, ECRAD_EUNSUPPORTED, "shortwave spectrum too wide");
   if (c.do_sw && c.n_g_sw > 64 && c.i_solver_sw == ECRAD_SOLVER_MCICA && c.use_vectorizable_generator == 0 && c.n_g_sw > 512)
     return fail(h, ECRAD_EUNSUPPORTED, "shortwave spectrum too wide for the cloud generator");
-  { int nch = 1; if (c.do_lw && (c.n_g_lw < 1 || (chunk_lanes(c.n_g_lw, &nch), nch > 15))) return fail(h, ECRAD_EUNSUPPORTED, "longwave spectrum too wide"); }
+  if (c.do_lw && (c.n_g_lw < 1 || chunk_plan(c.n_g_lw, false).n > ChunkPlan::kMax)) return fail(h, ECRAD_EUNSUPPORTED, "longwave spectrum too wide");
   if (c.do_clouds && (c.n_cloud_types < 1 || c.n_cloud_types > ECRAD_NMAXCLOUDTYPES)) return fail(h, ECRAD_EINVAL, "n_cloud_types out of range");
   // Tables the selected options dereference on the device: a NULL here would fault the GPU, not return a status
   if (c.do_sw) {
@@ -636,7 +679,7 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
     if (!d.i_band_from_reordered_g_sw) return fail(h, ECRAD_EINVAL, "i_band_from_reordered_g_sw missing");
     if (!c.use_canopy_full_spectrum_sw && !c.do_nearest_spectral_sw_albedo && !d.sw_albedo_weights)
       return fail(h, ECRAD_EINVAL, "sw_albedo_weights missing");
-    h->ngp_sw = chunk_lanes(c.n_g_sw, &h->nchunk_sw);
+    h->plan_sw = chunk_plan(c.n_g_sw, c.i_solver_sw == ECRAD_SOLVER_TRIPLECLOUDS); h->ngp_sw = h->plan_sw.max_ngp; h->nchunk_sw = h->plan_sw.n;
     h->spec_sum_sw = false; h->d_ispec_sw = nullptr;
     if (c.do_save_spectral_flux) {
       bool ident = c.n_spec_sw == c.n_g_sw;
@@ -653,7 +696,7 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
     if ((st = h->rrtmg_lw ? setup_stage_model(h, false, c.n_g_lw, d.gas_lw) : setup_ckd(h, c.gas_optics_lw, d.gas_lw))) return st;
     if (d.gas_lw.ng != c.n_g_lw) return fail(h, ECRAD_EINVAL, "n_g_lw does not match the longwave gas model");
     if (!d.i_band_from_reordered_g_lw) return fail(h, ECRAD_EINVAL, "i_band_from_reordered_g_lw missing");
-    h->ngp_lw = chunk_lanes(c.n_g_lw, &h->nchunk_lw);
+    h->plan_lw = chunk_plan(c.n_g_lw, false); h->ngp_lw = h->plan_lw.max_ngp; h->nchunk_lw = h->plan_lw.n;
     h->spec_sum_lw = false; h->d_ispec_lw = nullptr;
     if (c.do_save_spectral_flux) {
       bool ident = c.n_spec_lw == c.n_g_lw;
@@ -1163,16 +1206,17 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
       if (pass == 0) HIP_TRY(h, h->sp_stage.ensure(cv.off));
     }
     const DevCkdModel& m = is_sw ? h->hcfg.gas_sw : h->hcfg.gas_lw;
-    const int ngp = is_sw ? h->ngp_sw : h->ngp_lw;
+    const ChunkPlan& plan = is_sw ? h->plan_sw : h->plan_lw;
     if (!is_sw && c.do_lw_aerosol_scattering) {   // layers without aerosol keep ssa = g = 0
       HIP_TRY(h, hipMemsetAsync(dop.ssa_lw, 0, ngs * L * n * 8, stream));
       HIP_TRY(h, hipMemsetAsync(dop.g_lw, 0, ngs * L * n * 8, stream));
     }
-    const int nch = is_sw ? h->nchunk_sw : h->nchunk_lw;
+    const int nch = plan.n;
     for (int p = 0; p < nch; ++p)
-      HIP_TRY(h, launch_optics_dump(is_sw, ngp, m.table_f32, grid_for(h, r.nloc, ngp), lds_bytes(m.hot.nquad, c.n_cloud_types), stream, h->dcfg, din, dop, p * ngp));
-    auto launch_sp = [&](const DevFlux& f, int* counter, int g0, bool wide) -> hipError_t {
-      return launch_spartacus(is_sw, sp_single, ngp, is_sw ? grid_sw : grid_lw, h->num_cu, stream, c, din, dop, prep, f, scratch,
+      HIP_TRY(h, launch_optics_dump(is_sw, plan.ngp[p], m.table_f32, grid_for(h, r.nloc, plan.ngp[p]), lds_bytes(m.hot.nquad, c.n_cloud_types), stream, h->dcfg, din, dop, plan.g0[p]));
+    auto launch_sp = [&](const DevFlux& f, int* counter, int p, bool wide) -> hipError_t {
+      const int ngp = plan.ngp[p], g0 = plan.g0[p];
+      return launch_spartacus(is_sw, sp_single, ngp, grid_sp(ngp, is_sw), h->num_cu, stream, c, din, dop, prep, f, scratch,
                               (is_sw ? per_block_sw : per_block_lw) * 8 / sp_word, counter,
                               is_sw ? h->hcfg.i_band_from_reordered_g_sw : h->hcfg.i_band_from_reordered_g_lw, lay, list, n_items, g0, wide);
     };
@@ -1199,7 +1243,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
       for (int k = 0; k < nsum; ++k)
         if (dfx.*(prof[k])) dpart.*(prof[k]) = pbase + plane * ((size_t)k * nch + p);
       if (deriv) dpart.lw_derivatives = pbase + plane * ((size_t)4 * nch + p);
-      HIP_TRY(h, launch_sp(dpart, counter0 + p, p * ngp, true));
+      HIP_TRY(h, launch_sp(dpart, counter0 + p, p, true));
     }
     for (int k = 0; k < nsum; ++k)
       if (dfx.*(prof[k])) HIP_TRY(h, launch_combine_partials(stream, din, dfx.*(prof[k]), pbase + plane * (size_t)k * nch, plane, nch));
@@ -1223,10 +1267,11 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
                                           prep.total_cloud_cover_lw));
     }
     if (lw_sp) { if ((st = run_spartacus(false))) return st; }
-    auto launch_lw = [&](const DevFlux& f, int* counter, int g0, bool wide) -> hipError_t {
-      if (lw_tc) return launch_lw_tc(h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
-      if (lw_scat) return launch_lw_scat(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
-      return launch_lw_ica(c.i_solver_lw, h->ngp_lw, m.table_f32, grid_lw, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
+    auto launch_lw = [&](const DevFlux& f, int* counter, int p, bool wide) -> hipError_t {
+      const int ngp = h->plan_lw.ngp[p], g0 = h->plan_lw.g0[p], grid = grid_for(h, r.nloc, ngp);
+      if (lw_tc) return launch_lw_tc(ngp, m.table_f32, grid, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
+      if (lw_scat) return launch_lw_scat(c.i_solver_lw, ngp, m.table_f32, grid, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
+      return launch_lw_ica(c.i_solver_lw, ngp, m.table_f32, grid, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
     };
     if (lw_sp) {
     } else if (h->nchunk_lw == 1) {
@@ -1246,7 +1291,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
         DevFlux dpart = dfx;
         for (int k = 0; k < 6; ++k)
           if (dfx.*(prof[k]) || (k == 5 && deriv)) dpart.*(prof[k]) = pbase + plane * ((size_t)k * nch + p);
-        HIP_TRY(h, launch_lw(dpart, counters + p, p * h->ngp_lw, true));
+        HIP_TRY(h, launch_lw(dpart, counters + p, p, true));
       }
       for (int k = 0; k < 4; ++k)
         if (dfx.*(prof[k])) HIP_TRY(h, launch_combine_partials(stream, din, dfx.*(prof[k]), pbase + plane * (size_t)k * nch, plane, nch));
@@ -1287,8 +1332,9 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
         DevFlux dpart = dfx;
         for (int k = 0; k < 6; ++k)
           if (dfx.*(prof[k])) dpart.*(prof[k]) = pbase + plane * ((size_t)k * nch + p);
-        if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, p * h->ngp_sw));
-        else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, p * h->ngp_sw, true));
+        const int ngp = h->plan_sw.ngp[p], g0 = h->plan_sw.g0[p], grid = grid_for(h, r.nloc, ngp);
+        if (sw_tc) HIP_TRY(h, launch_sw_tc(ngp, m.table_f32, grid, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, g0));
+        else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, ngp, m.table_f32, grid, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, g0, true));
       }
       for (int k = 0; k < 6; ++k)
         if (dfx.*(prof[k])) HIP_TRY(h, launch_combine_partials(stream, din, dfx.*(prof[k]), pbase + plane * (size_t)k * nch, plane, nch));
@@ -1434,13 +1480,13 @@ int ecrad_hip_optics(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, in
   }
   const int nct = c.do_clouds ? c.n_cloud_types : 0;
   if (c.do_sw)
-    for (int p = 0; p < h->nchunk_sw; ++p)
-      HIP_TRY(h, launch_optics_dump(true, h->ngp_sw, h->hcfg.gas_sw.table_f32, grid_for(h, r.nloc, h->ngp_sw),
-                                    lds_bytes(h->hcfg.gas_sw.hot.nquad, nct), stream, h->dcfg, cx.din, dop, p * h->ngp_sw));
+    for (int p = 0; p < h->plan_sw.n; ++p)
+      HIP_TRY(h, launch_optics_dump(true, h->plan_sw.ngp[p], h->hcfg.gas_sw.table_f32, grid_for(h, r.nloc, h->plan_sw.ngp[p]),
+                                    lds_bytes(h->hcfg.gas_sw.hot.nquad, nct), stream, h->dcfg, cx.din, dop, h->plan_sw.g0[p]));
   if (c.do_lw)
-    for (int p = 0; p < h->nchunk_lw; ++p)
-      HIP_TRY(h, launch_optics_dump(false, h->ngp_lw, h->hcfg.gas_lw.table_f32, grid_for(h, r.nloc, h->ngp_lw),
-                                             lds_bytes(h->hcfg.gas_lw.hot.nquad, nct), stream, h->dcfg, cx.din, dop, p * h->ngp_lw));
+    for (int p = 0; p < h->plan_lw.n; ++p)
+      HIP_TRY(h, launch_optics_dump(false, h->plan_lw.ngp[p], h->hcfg.gas_lw.table_f32, grid_for(h, r.nloc, h->plan_lw.ngp[p]),
+                                    lds_bytes(h->hcfg.gas_lw.hot.nquad, nct), stream, h->dcfg, cx.din, dop, h->plan_lw.g0[p]));
   if (host_mem) {
     for (const OF& f : fields)
       if (out->*(f.host)) HIP_TRY(h, hipMemcpyAsync(out->*(f.host), dop.*(f.dev), f.n * 8, hipMemcpyDeviceToHost, stream));

@@ -1,18 +1,17 @@
 #!/bin/bash
-# one GPU call: ingredient variants of the level-record phase on the cloudy workloads
+# one GPU call: chunk plan A/B (chunks of different widths vs one width) on the wide-spectrum workloads, after the tests that cover it
 mkdir -p gpurun_out
-run() { python bench.py --steps 8 --warmup 2 --no-cpu-baseline --headline-only --workload $1 2>/dev/null | python -c "
+true
+run() { python bench.py --steps 5 --warmup 1 --no-cpu-baseline --headline-only --workload $1 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
         d = json.loads(line); st = d['roofline']['stage_ms']
-        print('%-14s %-26s %10.0f col/s  lw %7.3f  sw %7.3f' % ('$2', '$1', d['value'], st['lw'], st['sw']))
+        print('%-10s %-22s %10.0f col/s  prep %7.2f lw %7.2f  sw %7.2f  parity %.2e' % ('$2', '$1', d['value'], st['prep'], st['lw'], st['sw'], (d.get('parity') or {}).get('max_rel_diff_vs_oracle', float('nan'))))
 "; }
 for rep in 1 2; do
-for w in tripleclouds_ecckd32 mcica_ecckd32; do
-  run $w current
-  for lib in build_variants/*/libecrad_hip.so; do
-    ECRAD_HIP_LIB=$PWD/$lib run $w $(basename $(dirname $lib))
-  done
+for w in mcica_rrtmg tripleclouds_rrtmg; do
+  run $w mixed
+  ECRAD_CHUNK_PLAN=uniform run $w uniform
 done
-done 2>&1 | tee gpurun_out/r02_k_variants.log
+done
