@@ -95,6 +95,18 @@ __global__ __launch_bounds__(kBlock) void rrtmg_setcoef_kernel(const DevRrtmg* _
 }
 
 constexpr int kTileCols = 64;
+// g-points per lane of rrtmg_taumol_kernel (see Vec<G> in rrtmg_device.h)
+#ifndef ECRAD_TAUMOL_G
+#define ECRAD_TAUMOL_G 2
+#endif
+constexpr int kTauG = ECRAD_TAUMOL_G;
+static_assert(kTauG == 1 || kTauG == 2, "every RRTMG band has an even number of g-points; wider vectors would read past the table rows");
+// nk (<= G) consecutive values; the 16-byte form when the destination allows it (stage arrays: even offsets)
+template <int G> ECRAD_DEV void vstore(double* p, const Vec<G>& v, int nk) {
+  if (G == 2 && nk == 2 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) { *reinterpret_cast<double2*>(p) = make_double2(v.v[0], v.v[G - 1]); return; }
+#pragma unroll
+  for (int k = 0; k < G; ++k) if (k < nk) p[k] = v.v[k];
+}
 constexpr int kRecD = LD_N > SD_N ? LD_N : SD_N, kRecI = LI_N > SI_N ? LI_N : SI_N;
 
 // The setcoef records of the block's 64 columns, staged in LDS: field-major, column fastest (as in the work
@@ -247,37 +259,53 @@ __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __
     for (int ib = 0; ib < kNBandLw; ++ib) {
       const LwBand& B = T.lw[ib];
       const int ng = B.ng;
-      const int nbp = ng <= 2 ? 2 : (ng <= 4 ? 4 : (ng <= 8 ? 8 : 16));
+      // lanes = (kTauG consecutive g-points of the band, column): every band has an even number of g-points
+      constexpr int G = kTauG;
+      const int nv = (ng + G - 1) / G;
+      const int nbp = nv <= 1 ? 1 : (nv <= 2 ? 2 : (nv <= 4 ? 4 : (nv <= 8 ? 8 : 16)));
       const int items = nbp * kTileCols;
       for (int i = tid; i < items; i += kBlock) {
-        const int ig = i & (nbp - 1), c = i / nbp, cloc = c0 + c;
-        const bool active = ig < ng && cloc < nloc;
+        const int iv = i & (nbp - 1), c = i / nbp, cloc = c0 + c;
+        const int ig = iv * G;
+        const bool active = iv < nv && cloc < nloc;
         const LdsRec r{s_d, s_i, c};
         const bool lower = active && r.i(LI_LOWER) != 0;
-        double tau = 0.0, pfrac = 0.0;
+        Vec<G> tau = vsplat<G>(0.0), pfrac = vsplat<G>(0.0);
         // the two regimes in turn, each with a wave-uniform descriptor (most waves have lanes in one of them only)
 #if ECRAD_ABLATE & 32      // (tuning only) no evaluation: what the stores alone cost
-        tau = r.d(LD_FAC00); pfrac = r.d(LD_FAC01);
+        tau = vsplat<G>(r.d(LD_FAC00)); pfrac = vsplat<G>(r.d(LD_FAC01));
 #else
         for (int rg = 0; rg < 2; ++rg)
-          if (active && lower == (rg == 0)) lw_gpoint_regime(T, B, B.reg[rg], rg == 0, r, ig, tau, pfrac);
+          if (active && lower == (rg == 0)) lw_gpoints_regime<G>(T, B, B.reg[rg], rg == 0, r, ig, tau, pfrac);
 #endif
         if (!active) continue;
         const int g = B.g0 + ig;
-        double od = dmax(T.min_gas_od_lw, tau);
-        if (fold_lw) od = od + s_aer[ib * kTileCols + c];      // radiation_aerosol_optics.F90:805-818
+        Vec<G> od;
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+          od.v[k] = dmax(T.min_gas_od_lw, tau.v[k]);
+          if (fold_lw) od.v[k] = od.v[k] + s_aer[ib * kTileCols + c];      // radiation_aerosol_optics.F90:805-818
+        }
 #if ECRAD_ABLATE & 16      // (tuning only) no stage stores: what the evaluation alone costs
-        if (od + pfrac == -1.2345) out.od_lw[0] = od;
+        if (od.v[0] + pfrac.v[G - 1] == -1.2345) out.od_lw[0] = od.v[0];
         continue;
 #endif
-        out.od_lw[g + (size_t)kNgLw * (lev + (size_t)nlev * cloc)] = od;
         // planck_hl(g, half level) = band Planck function at the half level x fraction of the layer ABOVE it
         // (of the top layer for the top half level): radiation_ifs_rrtm.F90:715-724
-        const size_t op = g + (size_t)kNgLw * (lev + (size_t)(nlev + 1) * cloc);
-        out.planck_hl[op + kNgLw] = planck_band(T, s_t[kTileCols + c], ib) * pfrac;
-        if (lev == 0) out.planck_hl[op] = planck_band(T, s_t[c], ib) * pfrac;
         // surface emission before the (1 - albedo) factor: planck_function_surf with the lowest layer's fractions
-        if (lev == nlev - 1) out.lw_emission[g + (size_t)kNgLw * cloc] = planck_band(T, s_t[2 * kTileCols + c], ib) * pfrac;
+        const double pl_bot = planck_band(T, s_t[kTileCols + c], ib);
+        const double pl_top = lev == 0 ? planck_band(T, s_t[c], ib) : 0.0;
+        const double pl_surf = lev == nlev - 1 ? planck_band(T, s_t[2 * kTileCols + c], ib) : 0.0;
+        const size_t oo = g + (size_t)kNgLw * (lev + (size_t)nlev * cloc);
+        const size_t op = g + (size_t)kNgLw * (lev + (size_t)(nlev + 1) * cloc);
+        Vec<G> pb, ptop, ps;
+#pragma unroll
+        for (int k = 0; k < G; ++k) { pb.v[k] = pl_bot * pfrac.v[k]; ptop.v[k] = pl_top * pfrac.v[k]; ps.v[k] = pl_surf * pfrac.v[k]; }
+        const int nk = ng - ig < G ? ng - ig : G;
+        vstore<G>(out.od_lw + oo, od, nk);
+        vstore<G>(out.planck_hl + op + kNgLw, pb, nk);
+        if (lev == 0) vstore<G>(out.planck_hl + op, ptop, nk);
+        if (lev == nlev - 1) vstore<G>(out.lw_emission + g + (size_t)kNgLw * cloc, ps, nk);
       }
     }
     __syncthreads();
@@ -302,43 +330,51 @@ __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __
       const int iba = ib < kSwAerHalf ? ib : ib - kSwAerHalf;
       const SwBand& B = T.sw[ib];
       const int ng = B.ng;
-      const int nbp = ng <= 2 ? 2 : (ng <= 4 ? 4 : (ng <= 8 ? 8 : 16));
+      constexpr int G = kTauG;
+      const int nv = (ng + G - 1) / G;
+      const int nbp = nv <= 1 ? 1 : (nv <= 2 ? 2 : (nv <= 4 ? 4 : (nv <= 8 ? 8 : 16)));
       const int items = nbp * kTileCols;
       for (int i = tid; i < items; i += kBlock) {
-        const int ig = i & (nbp - 1), c = i / nbp, cloc = c0 + c;
-        if (ig >= ng || cloc >= nloc) continue;
+        const int iv = i & (nbp - 1), c = i / nbp, cloc = c0 + c;
+        const int ig = iv * G;
+        if (iv >= nv || cloc >= nloc) continue;
         const int g = B.g0 + ig;
+        const int nk = ng - ig < G ? ng - ig : G;
         const size_t o = g + (size_t)kNgSw * (lev + (size_t)nlev * cloc);
+        Vec<G> vod, vssa, vg = vsplat<G>(0.0);
         if (s_sun[c]) {
           const LdsRec r{s_d, s_i, c};
           const bool lower = r.i(SI_LOWER) != 0;
           const bool want = w.isol[(size_t)ib * nloc + cloc] == lev;
-          double taug = 0.0, taur = 0.0, sflux = 0.0;
+          Vec<G> taug = vsplat<G>(0.0), taur = vsplat<G>(0.0), sflux = vsplat<G>(0.0);
 #if ECRAD_ABLATE & 32
-          taug = r.d(SD_FAC00); taur = r.d(SD_FAC01);
+          taug = vsplat<G>(r.d(SD_FAC00)); taur = vsplat<G>(r.d(SD_FAC01));
 #else
           for (int rg = 0; rg < 2; ++rg)
-            if (lower == (rg == 0)) sw_gpoint_regime(T, B, B.reg[rg], rg == 0, r, ig, want, taug, taur, sflux);
+            if (lower == (rg == 0)) sw_gpoints_regime<G>(T, B, B.reg[rg], rg == 0, r, ig, want, taug, taur, sflux);
 #endif
-          const double od_gas = taur + taug;
-          double od = dmax(T.min_gas_od_sw, od_gas), ssa = taur / od_gas, asym = 0.0;
-          if (fold_sw) {
-            const AerosolLayer al = {s_aer[(3 * iba + 0) * kTileCols + c], s_aer[(3 * iba + 1) * kTileCols + c], s_aer[(3 * iba + 2) * kTileCols + c]};
-            merge_aerosol_sw(cfg, al, od, ssa, asym);
-            out.g_sw[o] = asym;
+#pragma unroll
+          for (int k = 0; k < G; ++k) {
+            const double od_gas = taur.v[k] + taug.v[k];
+            double od = dmax(T.min_gas_od_sw, od_gas), ssa = taur.v[k] / od_gas, asym = 0.0;
+            if (fold_sw) {
+              const AerosolLayer al = {s_aer[(3 * iba + 0) * kTileCols + c], s_aer[(3 * iba + 1) * kTileCols + c], s_aer[(3 * iba + 2) * kTileCols + c]};
+              merge_aerosol_sw(cfg, al, od, ssa, asym);
+            }
+            vod.v[k] = od; vssa.v[k] = ssa; vg.v[k] = asym;
           }
 #if ECRAD_ABLATE & 16
-          if (od + ssa == -1.2345) out.od_sw[0] = od;
+          if (vod.v[0] + vssa.v[G - 1] == -1.2345) out.od_sw[0] = vod.v[0];
           continue;
 #endif
-          out.od_sw[o] = od;
-          out.ssa_sw[o] = ssa;
-          if (want) out.incoming_sw[g + (size_t)kNgSw * cloc] = sflux;
+          if (want) vstore<G>(out.incoming_sw + g + (size_t)kNgSw * cloc, sflux, nk);
         } else {
-          out.od_sw[o] = dmax(T.min_gas_od_sw, 0.0);
-          out.ssa_sw[o] = 0.0;
-          if (fold_sw) out.g_sw[o] = 0.0;
+          vod = vsplat<G>(dmax(T.min_gas_od_sw, 0.0));
+          vssa = vsplat<G>(0.0);
         }
+        vstore<G>(out.od_sw + o, vod, nk);
+        vstore<G>(out.ssa_sw + o, vssa, nk);
+        if (fold_sw) vstore<G>(out.g_sw + o, vg, nk);
       }
     }
   }

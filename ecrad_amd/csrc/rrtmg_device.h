@@ -297,10 +297,29 @@ ECRAD_HD Mix mixing(double colA, double colB, double ratio, double mult) {
   return m;
 }
 
+// ---- G consecutive g-points of one band at a time ------------------------------------------------------
+// Everything in a band routine except the table values themselves -- mixing parameters, interpolation weights,
+// minor-gas amounts (a pow() each), table rows -- is the same for all g-points of a (band, layer, column).  The
+// evaluators below therefore work on G consecutive g-points per call (Vec<G>: element-wise arithmetic, each
+// element rounded exactly as a scalar evaluation would be), so that a GPU lane pays for that common part once per
+// G g-points and has G independent table loads in flight per look-up.  G = 1 is the scalar form the host check uses.
+template <int G> struct Vec {
+  double v[G];
+};
+template <int G> ECRAD_HD Vec<G> vload(const double* p) { Vec<G> r; for (int k = 0; k < G; ++k) r.v[k] = p[k]; return r; }
+template <int G> ECRAD_HD Vec<G> vsplat(double a) { Vec<G> r; for (int k = 0; k < G; ++k) r.v[k] = a; return r; }
+template <int G> ECRAD_HD Vec<G> operator+(const Vec<G>& a, const Vec<G>& b) { Vec<G> r; for (int k = 0; k < G; ++k) r.v[k] = a.v[k] + b.v[k]; return r; }
+template <int G> ECRAD_HD Vec<G> operator-(const Vec<G>& a, const Vec<G>& b) { Vec<G> r; for (int k = 0; k < G; ++k) r.v[k] = a.v[k] - b.v[k]; return r; }
+template <int G> ECRAD_HD Vec<G> operator*(double a, const Vec<G>& b) { Vec<G> r; for (int k = 0; k < G; ++k) r.v[k] = a * b.v[k]; return r; }
+template <int G> ECRAD_HD Vec<G> operator*(const Vec<G>& a, double b) { Vec<G> r; for (int k = 0; k < G; ++k) r.v[k] = a.v[k] * b; return r; }
+template <int G> ECRAD_HD Vec<G> operator*(const Vec<G>& a, const Vec<G>& b) { Vec<G> r; for (int k = 0; k < G; ++k) r.v[k] = a.v[k] * b.v[k]; return r; }
+template <int G> ECRAD_HD Vec<G> operator+(const Vec<G>& a, double b) { Vec<G> r; for (int k = 0; k < G; ++k) r.v[k] = a.v[k] + b; return r; }
+
 // One (p,T) half of a binary major term of the longwave (rrtm_taumol3.F90:158-285): linear in the mixing
 // parameter, cubic-like near its ends (lower atmosphere only, 9 nodes)
-ECRAD_HD double lw_binary_half(const double* A, int ng, int ind, int nsp, const Mix& m, double facA, double facB, bool ends) {
-#define AT(row) A[(size_t)((row) - 1) * ng]
+template <int G>
+ECRAD_HD Vec<G> lw_binary_half(const double* A, int ng, int ind, int nsp, const Mix& m, double facA, double facB, bool ends) {
+#define AT(row) vload<G>(A + (size_t)((row) - 1) * ng)
   if (ends && m.parm < 0.125) {
     const double p = m.f - 1.0, p2 = p * p, p4 = p2 * p2;
     const double fk0 = p4, fk1 = 1.0 - p - 2.0 * p4, fk2 = p + p4;
@@ -317,12 +336,12 @@ ECRAD_HD double lw_binary_half(const double* A, int ng, int ind, int nsp, const 
 #undef AT
 }
 
-// Longwave optical depth and Planck fraction of g-point `ig` (0-based within the band) of one layer
+// Longwave optical depth and Planck fraction of g-points `ig` .. `ig`+G-1 (0-based within the band) of one layer
 // (`q` = b.reg[lower ? 0 : 1] is passed in so that a caller whose lanes all share the regime can keep the
 // descriptor tests wave-uniform)
-template <class R>
-ECRAD_HD void lw_gpoint_regime(const DevRrtmg& T, const LwBand& b, const LwRegime& q, bool lower, const R& r, int ig,
-                               double& tau_out, double& pfrac_out) {
+template <int G, class R>
+ECRAD_HD void lw_gpoints_regime(const DevRrtmg& T, const LwBand& b, const LwRegime& q, bool lower, const R& r, int ig,
+                                Vec<G>& tau_out, Vec<G>& pfrac_out) {
   const int ng = b.ng;
   const double* tab = T.tab;
   const int jp = r.i(LI_JP), jt = r.i(LI_JT), jt1 = r.i(LI_JT1);
@@ -332,30 +351,30 @@ ECRAD_HD void lw_gpoint_regime(const DevRrtmg& T, const LwBand& b, const LwRegim
   const double mult = lower ? 8.0 : 4.0;
   double colA = 0.0, colB = 0.0;
   if (q.major) colA = r.d(LD_COL0 + q.gasA);
-  double tau = 0.0;
+  Vec<G> tau = vsplat<G>(0.0);
   if (q.major == 1) {
     const double* A = tab + q.t_abs + ig;
     const int ind0 = base0 * nsp + 1, ind1 = base1 * nsp + 1;
-    tau = colA * (r.d(LD_FAC00) * A[(size_t)(ind0 - 1) * ng] + r.d(LD_FAC10) * A[(size_t)ind0 * ng] +
-                  r.d(LD_FAC01) * A[(size_t)(ind1 - 1) * ng] + r.d(LD_FAC11) * A[(size_t)ind1 * ng]);
+    tau = colA * (r.d(LD_FAC00) * vload<G>(A + (size_t)(ind0 - 1) * ng) + r.d(LD_FAC10) * vload<G>(A + (size_t)ind0 * ng) +
+                  r.d(LD_FAC01) * vload<G>(A + (size_t)(ind1 - 1) * ng) + r.d(LD_FAC11) * vload<G>(A + (size_t)ind1 * ng));
   } else if (q.major == 2) {
     colB = r.d(LD_COL0 + q.gasB);
     const Mix m0 = mixing(colA, colB, T.rat[q.pair][jp - 1], mult);
     const Mix m1 = mixing(colA, colB, T.rat[q.pair][jp], mult);
     const double* A = tab + q.t_abs + ig;
-    tau = lw_binary_half(A, ng, base0 * nsp + m0.j, nsp, m0, r.d(LD_FAC00), r.d(LD_FAC10), lower) +
-          lw_binary_half(A, ng, base1 * nsp + m1.j, nsp, m1, r.d(LD_FAC01), r.d(LD_FAC11), lower);
+    tau = lw_binary_half<G>(A, ng, base0 * nsp + m0.j, nsp, m0, r.d(LD_FAC00), r.d(LD_FAC10), lower) +
+          lw_binary_half<G>(A, ng, base1 * nsp + m1.j, nsp, m1, r.d(LD_FAC01), r.d(LD_FAC11), lower);
   }
   if (q.self) {
     const double* S = tab + q.t_self + ig;
     const int inds = r.i(LI_INDSELF);
-    const double s0 = S[(size_t)(inds - 1) * ng], s1 = S[(size_t)inds * ng];
+    const Vec<G> s0 = vload<G>(S + (size_t)(inds - 1) * ng), s1 = vload<G>(S + (size_t)inds * ng);
     tau = tau + r.d(LD_SELFFAC) * (s0 + r.d(LD_SELFFRAC) * (s1 - s0));
   }
   if (q.forc) {
     const double* Fo = tab + q.t_for + ig;
     const int indf = r.i(LI_INDFOR);
-    const double f0 = Fo[(size_t)(indf - 1) * ng], f1 = Fo[(size_t)indf * ng];
+    const Vec<G> f0 = vload<G>(Fo + (size_t)(indf - 1) * ng), f1 = vload<G>(Fo + (size_t)indf * ng);
     tau = tau + r.d(LD_FORFAC) * (f0 + r.d(LD_FORFRAC) * (f1 - f0));
   }
   const int indm = r.i(LI_INDMINOR);
@@ -363,15 +382,16 @@ ECRAD_HD void lw_gpoint_regime(const DevRrtmg& T, const LwBand& b, const LwRegim
   for (int k = 0; k < q.nminor; ++k) {
     const Minor& mn = q.minor[k];
     const double* K = tab + mn.tab + ig;
-    double absm;
+    Vec<G> absm;
     if (mn.binary) {
       const Mix mm = mixing(colA, colB, mn.refrat, mult);
       const size_t r1 = (size_t)((mm.j - 1) + nsp * (indm - 1)) * ng, r2 = r1 + (size_t)nsp * ng;
-      const double a1 = K[r1] + mm.f * (K[r1 + ng] - K[r1]);
-      const double a2 = K[r2] + mm.f * (K[r2 + ng] - K[r2]);
+      const Vec<G> k1 = vload<G>(K + r1), k2 = vload<G>(K + r2);
+      const Vec<G> a1 = k1 + mm.f * (vload<G>(K + r1 + ng) - k1);
+      const Vec<G> a2 = k2 + mm.f * (vload<G>(K + r2 + ng) - k2);
       absm = a1 + minorfrac * (a2 - a1);
     } else {
-      const double k0 = K[(size_t)(indm - 1) * ng], k1 = K[(size_t)indm * ng];
+      const Vec<G> k0 = vload<G>(K + (size_t)(indm - 1) * ng), k1 = vload<G>(K + (size_t)indm * ng);
       absm = k0 + minorfrac * (k1 - k0);
     }
     double amount;
@@ -404,18 +424,27 @@ ECRAD_HD void lw_gpoint_regime(const DevRrtmg& T, const LwBand& b, const LwRegim
     else corr = 1.0 - .05 * (pp - 100.0) / 900.0;
     tau = corr * tau;
   }
-  for (int k = 0; k < q.nxsec; ++k) tau = tau + r.d(LD_WX0 + q.xsec_wx[k]) * tab[q.t_xsec[k] + ig];
-  if (q.t_scale >= 0) tau = tau * tab[q.t_scale + ig];
-  double pfrac = 0.0;
-  if (q.planck == 1) pfrac = tab[q.t_frac + ig];
+  for (int k = 0; k < q.nxsec; ++k) tau = tau + r.d(LD_WX0 + q.xsec_wx[k]) * vload<G>(tab + q.t_xsec[k] + ig);
+  if (q.t_scale >= 0) tau = tau * vload<G>(tab + q.t_scale + ig);
+  Vec<G> pfrac = vsplat<G>(0.0);
+  if (q.planck == 1) pfrac = vload<G>(tab + q.t_frac + ig);
   else if (q.planck == 2) {
     const Mix mp = mixing(colA, colB, q.refrat_planck, mult);
     const double* Fr = tab + q.t_frac + ig;
-    const double f0 = Fr[(size_t)(mp.j - 1) * ng], f1 = Fr[(size_t)mp.j * ng];
+    const Vec<G> f0 = vload<G>(Fr + (size_t)(mp.j - 1) * ng), f1 = vload<G>(Fr + (size_t)mp.j * ng);
     pfrac = f0 + mp.f * (f1 - f0);
   }
   tau_out = tau;
   pfrac_out = pfrac;
+}
+
+template <class R>
+ECRAD_HD void lw_gpoint_regime(const DevRrtmg& T, const LwBand& b, const LwRegime& q, bool lower, const R& r, int ig,
+                               double& tau_out, double& pfrac_out) {
+  Vec<1> tau, pfrac;
+  lw_gpoints_regime<1>(T, b, q, lower, r, ig, tau, pfrac);
+  tau_out = tau.v[0];
+  pfrac_out = pfrac.v[0];
 }
 
 template <class R>
@@ -424,10 +453,11 @@ ECRAD_HD void lw_gpoint(const DevRrtmg& T, const LwBand& b, const R& r, int ig, 
   lw_gpoint_regime(T, b, b.reg[lower ? 0 : 1], lower, r, ig, tau_out, pfrac_out);
 }
 
-// Shortwave gas optical depth, Rayleigh optical depth and (when `want_sflux`) the solar source term
-template <class R>
-ECRAD_HD void sw_gpoint_regime(const DevRrtmg& T, const SwBand& b, const SwRegime& q, bool lower, const R& r, int ig, bool want_sflux,
-                               double& taug_out, double& taur_out, double& sflux_out) {
+// Shortwave gas optical depth, Rayleigh optical depth and (when `want_sflux`) the solar source term of g-points
+// `ig` .. `ig`+G-1 of the band
+template <int G, class R>
+ECRAD_HD void sw_gpoints_regime(const DevRrtmg& T, const SwBand& b, const SwRegime& q, bool lower, const R& r, int ig, bool want_sflux,
+                                Vec<G>& taug_out, Vec<G>& taur_out, Vec<G>& sflux_out) {
   const int ng = b.ng;
   const double* tab = T.tab;
   const int jp = r.i(SI_JP), jt = r.i(SI_JT), jt1 = r.i(SI_JT1);
@@ -436,55 +466,66 @@ ECRAD_HD void sw_gpoint_regime(const DevRrtmg& T, const SwBand& b, const SwRegim
   const int base1 = lower ? (jp * 5 + (jt1 - 1)) : ((jp - 12) * 5 + (jt1 - 1));
   const double fac00 = r.d(SD_FAC00), fac01 = r.d(SD_FAC01), fac10 = r.d(SD_FAC10), fac11 = r.d(SD_FAC11);
   const double colh2o = r.d(SD_COL0 + G_H2O);
-  double cont = 0.0;          // self + foreign continuum per unit water vapour
+  Vec<G> cont = vsplat<G>(0.0);          // self + foreign continuum per unit water vapour
   if (q.self) {
     const double* S = tab + q.t_self + ig;
     const int inds = r.i(SI_INDSELF);
-    const double s0 = S[(size_t)(inds - 1) * ng], s1 = S[(size_t)inds * ng];
+    const Vec<G> s0 = vload<G>(S + (size_t)(inds - 1) * ng), s1 = vload<G>(S + (size_t)inds * ng);
     cont = r.d(SD_SELFFAC) * (s0 + r.d(SD_SELFFRAC) * (s1 - s0));
   }
   if (q.forc) {
     const double* Fo = tab + q.t_for + ig;
     const int indf = r.i(SI_INDFOR);
-    const double f0 = Fo[(size_t)(indf - 1) * ng], f1 = Fo[(size_t)indf * ng];
+    const Vec<G> f0 = vload<G>(Fo + (size_t)(indf - 1) * ng), f1 = vload<G>(Fo + (size_t)indf * ng);
     cont = cont + r.d(SD_FORFAC) * (f0 + r.d(SD_FORFRAC) * (f1 - f0));
   }
   Mix m{0.0, 0.0, 0.0, 1};
-  double taug = 0.0;
+  Vec<G> taug = vsplat<G>(0.0);
   if (q.major == 2) {
     m = mixing(r.d(SD_COL0 + q.gasA), r.d(SD_COL0 + q.gasB), q.strrat, lower ? 8.0 : 4.0);
     const double* A = tab + q.t_abs + ig;
     const size_t i0 = (size_t)(base0 * nsp + m.j - 1) * ng, i1 = (size_t)(base1 * nsp + m.j - 1) * ng, dT = (size_t)nsp * ng;
-    taug = m.comb * ((1.0 - m.f) * (A[i0] * fac00 + A[i0 + dT] * fac10 + A[i1] * fac01 + A[i1 + dT] * fac11) +
-                     m.f * (A[i0 + ng] * fac00 + A[i0 + dT + ng] * fac10 + A[i1 + ng] * fac01 + A[i1 + dT + ng] * fac11));
+    taug = m.comb * ((1.0 - m.f) * (vload<G>(A + i0) * fac00 + vload<G>(A + i0 + dT) * fac10 + vload<G>(A + i1) * fac01 + vload<G>(A + i1 + dT) * fac11) +
+                     m.f * (vload<G>(A + i0 + ng) * fac00 + vload<G>(A + i0 + dT + ng) * fac10 + vload<G>(A + i1 + ng) * fac01 + vload<G>(A + i1 + dT + ng) * fac11));
     if (q.self || q.forc) taug = taug + colh2o * cont;
   } else if (q.major == 1) {
     const double* A = tab + q.t_abs + ig;
     const size_t i0 = (size_t)(base0 * nsp) * ng, i1 = (size_t)(base1 * nsp) * ng;
-    const double major = fac00 * A[i0] + fac10 * A[i0 + ng] + fac01 * A[i1] + fac11 * A[i1 + ng];
+    const Vec<G> major = fac00 * vload<G>(A + i0) + fac10 * vload<G>(A + i0 + ng) + fac01 * vload<G>(A + i1) + fac11 * vload<G>(A + i1 + ng);
     if (q.self || q.forc) taug = r.d(SD_COL0 + q.gasA) * (q.mult * major + cont);
     else taug = r.d(SD_COL0 + q.gasA) * q.mult * major;
   }
-  for (int k = 0; k < q.nextra; ++k) taug = taug + r.d(SD_COL0 + q.extra_gas[k]) * tab[q.t_extra[k] + ig];
+  for (int k = 0; k < q.nextra; ++k) taug = taug + r.d(SD_COL0 + q.extra_gas[k]) * vload<G>(tab + q.t_extra[k] + ig);
   if (q.o2cont) taug = taug + F32(4.35e-4) * r.d(SD_COL0 + G_O2) / (350.0 * 2.0);
-  double ray;
-  if (q.rayl_kind == 0) ray = b.rayl;
-  else if (q.rayl_kind == 1) ray = tab[q.t_rayl + ig];
+  Vec<G> ray;
+  if (q.rayl_kind == 0) ray = vsplat<G>(b.rayl);
+  else if (q.rayl_kind == 1) ray = vload<G>(tab + q.t_rayl + ig);
   else {
     const double* Ry = tab + q.t_rayl + ig;
-    const double r0 = Ry[(size_t)(m.j - 1) * ng], r1 = Ry[(size_t)m.j * ng];
+    const Vec<G> r0 = vload<G>(Ry + (size_t)(m.j - 1) * ng), r1 = vload<G>(Ry + (size_t)m.j * ng);
     ray = r0 + m.f * (r1 - r0);
   }
   taug_out = taug;
   taur_out = r.d(SD_COLMOL) * ray;
   if (want_sflux) {
-    if (b.sflux_kind == 0) sflux_out = b.sflux_scale * tab[b.t_sflux + ig];
+    if (b.sflux_kind == 0) sflux_out = b.sflux_scale * vload<G>(tab + b.t_sflux + ig);
     else {
       const double* S = tab + b.t_sflux + ig;
-      const double s0 = S[(size_t)(m.j - 1) * ng], s1 = S[(size_t)m.j * ng];
+      const Vec<G> s0 = vload<G>(S + (size_t)(m.j - 1) * ng), s1 = vload<G>(S + (size_t)m.j * ng);
       sflux_out = s0 + m.f * (s1 - s0);
     }
   }
+}
+
+template <class R>
+ECRAD_HD void sw_gpoint_regime(const DevRrtmg& T, const SwBand& b, const SwRegime& q, bool lower, const R& r, int ig, bool want_sflux,
+                               double& taug_out, double& taur_out, double& sflux_out) {
+  Vec<1> taug, taur, sflux;
+  sflux.v[0] = sflux_out;
+  sw_gpoints_regime<1>(T, b, q, lower, r, ig, want_sflux, taug, taur, sflux);
+  taug_out = taug.v[0];
+  taur_out = taur.v[0];
+  sflux_out = sflux.v[0];
 }
 
 template <class R>
