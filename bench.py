@@ -206,9 +206,13 @@ def measured_traffic(workload, ncol, kernel_prefix):
             continue
         if d.get("columns") != ncol or d.get("workload") != workload:
             continue
-        for k, v in d.get("traffic_bytes_per_launch", {}).items():
-            if k.startswith(kernel_prefix):
-                best = {"bytes_per_launch": v, "source": "profiles/" + os.path.basename(f)}
+        # A spectrum wider than 64 g-points runs as launches of DIFFERENT instantiations of the kernel (chunks of 64, 32
+        # and 16 lanes): the per-launch figure is the average over the launches the profile saw, weighted by their counts
+        tb, nl = d.get("traffic_bytes_per_launch", {}), d.get("launches_profiled", {})
+        names = [k for k in tb if k.startswith(kernel_prefix)]
+        if names:
+            wsum = sum(nl.get(k, 1) for k in names)
+            best = {"bytes_per_launch": sum(tb[k] * nl.get(k, 1) for k in names) / wsum, "source": "profiles/" + os.path.basename(f)}
     return best
 
 
@@ -306,7 +310,10 @@ def roofline_of(w, stage_ms, elapsed_per_step_s):
     info = w.call_info()
     launches = info.launches_sw if dom == "sw" else info.launches_lw
     kernel = {"Tripleclouds": f"{dom}_tc_kernel", "SPARTACUS": f"spartacus_{dom}_kernel"}.get(w.desc["sw_solver"], f"{dom}_ica_kernel")
-    traffic = measured_traffic(w.name, ncol, kernel)
+    # (instantiations over float tables serve the ecCKD models, over double the RRTMG stage arrays: a profile of the
+    #  default run holds both, e.g. sw_ica_kernel<float, 32, 1, ...> and sw_ica_kernel<double, 64, 2, ...>)
+    is_rrtmg = bool(w.desc.get("rrtmg"))
+    traffic = measured_traffic(w.name, ncol, kernel + ("<double," if is_rrtmg else "<float,"))
     whole = a_all * ncol / elapsed_per_step_s / 1e9
     extra = {}
     if w.desc["sw_solver"] == "SPARTACUS":

@@ -403,7 +403,7 @@ int ecrad_hip_set_work_bytes(ecrad_hip_handle_t handle, size_t bytes);
 typedef struct ecrad_call_info {
   int32_t n_tiles, tile_columns;
   int32_t launches_lw, launches_sw;   /* solver-kernel launches per tile and spectrum */
-  int32_t lanes_lw, lanes_sw;         /* g-point lanes per column group (16, 32 or 64) */
+  int32_t lanes_lw, lanes_sw;         /* g-point lanes per column group (16, 32 or 64) of the widest launch */
   size_t  work_bytes;
 } ecrad_call_info_t;
 int ecrad_hip_last_call_info(ecrad_hip_handle_t handle, ecrad_call_info_t* info);

@@ -1,7 +1,7 @@
 #!/bin/bash
-# one GPU call: taumol with 2 g-points per lane vs 1 (build_variants/g1), after the RRTMG tests
+# one GPU call: McICA tests, then the McICA workloads (generator: level words outside the cloudy span skipped)
 mkdir -p gpurun_out
-python -m pytest tests/test_hip_rrtmg.py tests/test_mixed_gas.py -m gpu -x -q 2>&1 | tail -4
+python -m pytest tests -m gpu -x -q -k "mcica or McICA or golden or synthetic" 2>&1 | tail -4
 run() { python bench.py --steps 5 --warmup 1 --no-cpu-baseline --headline-only --workload $1 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
@@ -10,8 +10,8 @@ for line in sys.stdin:
         print('%-10s %-22s %10.0f col/s  prep %7.2f lw %7.2f  sw %7.2f' % ('$2', '$1', d['value'], st['prep'], st['lw'], st['sw']))
 "; }
 for rep in 1 2; do
-for w in mcica_rrtmg; do
-  run $w g2
-  ECRAD_HIP_LIB=$PWD/build_variants/g1/libecrad_hip.so run $w g1
+for w in mcica_rrtmg mcica_ecckd32; do
+  run $w new
 done
 done
+tools/kstats.sh mcica_rrtmg --headline-only 2>&1 | grep generator

@@ -62,7 +62,7 @@ def main(tag):
     out += ["## HBM traffic per launch (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, corrected)", "",
             f"| kernel | read GB | written GB | total GB | KB/column ({ncol} columns) | avg duration (ms) | HBM GB/s |",
             "|---|---|---|---|---|---|---|"]
-    traffic = {}
+    traffic, calls = {}, {}
     for k in fetch:
         if k not in write or "ecrad" not in k:
             continue
@@ -70,12 +70,13 @@ def main(tag):
         w = write[k][0] / write[k][1] * w_corr * 1024 / 1e9
         ms = avg.get(k, 0) / 1e3      # top_kernels durations are in microseconds
         traffic[short(k)] = (r + w) * 1e9
+        calls[short(k)] = fetch[k][1]
         out.append(f"| `{short(k)}` | {r:.2f} | {w:.2f} | {r+w:.2f} | {(r+w)*1e6/ncol:.1f} | {ms:.3f} | {((r+w)/(ms*1e-3)) if ms else 0:.0f} |")
     out.append("")
     os.makedirs("profiles", exist_ok=True)
     path = os.path.join("profiles", f"{tag}.md")
     open(path, "w").write("\n".join(out) + "\n")
-    json.dump({"traffic_bytes_per_launch": traffic, "fetch_correction": f_corr, "write_correction": w_corr,
+    json.dump({"traffic_bytes_per_launch": traffic, "launches_profiled": calls, "fetch_correction": f_corr, "write_correction": w_corr,
                "columns": ncol, "workload": bench["config"]["workload"] if bench else None},
               open(os.path.join("profiles", f"{tag}_traffic.json"), "w"), indent=1)
     print("\n".join(out))
