@@ -212,7 +212,8 @@ def measured_traffic(workload, ncol, kernel_prefix):
         names = [k for k in tb if k.startswith(kernel_prefix)]
         if names:
             wsum = sum(nl.get(k, 1) for k in names)
-            best = {"bytes_per_launch": sum(tb[k] * nl.get(k, 1) for k in names) / wsum, "source": "profiles/" + os.path.basename(f)}
+            best = {"bytes_per_launch": sum(tb[k] * nl.get(k, 1) for k in names) / wsum, "source": "profiles/" + os.path.basename(f),
+                    "columns_per_launch": d.get("columns_per_launch", ncol)}
     return best
 
 
@@ -333,7 +334,8 @@ def roofline_of(w, stage_ms, elapsed_per_step_s):
             "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_triad": achieved / HBM_TRIAD_GBS,
             # spectra wider than 64 g-points run as several launches of the kernel; the stage time and the algorithmic
             # bytes cover all of them (and, for McICA, the cloud generator that feeds them), the PMC figure is per launch
-            "traffic": traffic["bytes_per_launch"] * launches * info.n_tiles if traffic else None,
+            # (scaled by columns per launch: the profile may have run the call as a different number of column tiles)
+            "traffic": traffic["bytes_per_launch"] / traffic["columns_per_launch"] * ncol * launches if traffic else None,
             "traffic_source": traffic["source"] if traffic else None,
             "launches_per_step": launches * info.n_tiles, "column_tiles": info.n_tiles,
             "algorithmic_bytes": a_dom * ncol, "algorithmic_bytes_per_column": a_dom, "kernel_ms": dom_ms,

@@ -70,7 +70,7 @@ struct ecrad_hip_handle_s {
   std::vector<TileEvents> tile_events;
   int tiles_last_call = 0;
   int tile_columns_last_call = 0;
-  size_t work_budget = (size_t)64 << 30;      // bytes of per-call work arrays before a call is tiled
+  size_t work_budget = 0;                     // bytes of per-call work arrays before a call is tiled; 0 = half of the device's memory
   double stage_ms[4] = {0, 0, 0, 0};
   bool timing_pending = false;
   double last_ms = 0.0;
@@ -1391,12 +1391,26 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
   if (in->memory != flux->memory) return fail(h, ECRAD_EINVAL, "inputs and fluxes must live in the same memory space");
   if (ncol < 1 || nlev < 2 || istartcol < 1 || iendcol > ncol || iendcol < istartcol) return fail(h, ECRAD_EINVAL, "bad column/level range");
   // Column tiling: every work array is sized by the columns of a tile, not of the call, so the device memory a
-  // call needs is bounded by `work_budget` (64 GiB unless ecrad_hip_set_work_bytes / ECRAD_HIP_WORK_GIB say
-  // otherwise) whatever istartcol..iendcol is.  Tiles are whole multiples of 256 columns (every kernel's column
+  // call needs is bounded by `work_budget` (half of the device's memory unless ecrad_hip_set_work_bytes /
+  // ECRAD_HIP_WORK_GIB say otherwise) whatever istartcol..iendcol is.  Tiles are whole multiples of 256 columns (every kernel's column
   // groups divide 256), at least 4096, so a tiled call launches the same column groups as an untiled one.
   const int nloc = iendcol - istartcol + 1;
   const size_t per_col = work_bytes_per_column(h, nlev, in, flux);
-  long long tile_cols = per_col ? (long long)(h->work_budget / per_col) : (long long)nloc;
+  size_t budget = h->work_budget;
+  {
+    // Default: half of the device's memory (144 GB of the MI355X's 288 GB: 100 000 RRTMG columns, 72 GB of work arrays,
+    // then run as one tile instead of two, +2 %), and never more than 90 % of what is free now plus what this handle
+    // already holds (another process, or the caller's own arrays, may have taken the rest)
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
+    if (!budget) budget = total_b / 2;
+    size_t held = 0;
+    for (const Buf* b : {&h->spec_tmp, &h->partial, &h->scratch, &h->prep, &h->staging_in, &h->staging_out, &h->gas_stage, &h->gas_work, &h->sp_stage})
+      held += b->cap;
+    const size_t avail = (size_t)(0.9 * (double)(free_b + held));
+    if (budget > avail) budget = avail;
+  }
+  long long tile_cols = per_col ? (long long)(budget / per_col) : (long long)nloc;
   tile_cols = std::max(4096ll, tile_cols / 256 * 256);
   if (tile_cols > nloc) tile_cols = nloc;
   const int ntile = (int)((nloc + tile_cols - 1) / tile_cols);

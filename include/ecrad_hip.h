@@ -394,7 +394,7 @@ int ecrad_hip_scratch_bytes(ecrad_hip_handle_t handle, size_t* bytes);
    stage arrays of the gas-optics pass + scalings + per-chunk partial profiles); in host-memory mode add
    the staged inputs and outputs (~50 KB).  ecrad_hip_radiation therefore processes istartcol..iendcol in
    TILES of columns (multiples of 256, at least 4096) such that these arrays stay within a budget --
-   64 GiB by default (environment ECRAD_HIP_WORK_GIB), changed per handle with this call.  Results do not
+   half of the device memory by default, and never more than what is free (environment ECRAD_HIP_WORK_GIB), changed per handle with this call.  Results do not
    depend on the tiling. */
 int ecrad_hip_set_work_bytes(ecrad_hip_handle_t handle, size_t bytes);
 

@@ -77,7 +77,9 @@ def main(tag):
     path = os.path.join("profiles", f"{tag}.md")
     open(path, "w").write("\n".join(out) + "\n")
     json.dump({"traffic_bytes_per_launch": traffic, "launches_profiled": calls, "fetch_correction": f_corr, "write_correction": w_corr,
-               "columns": ncol, "workload": bench["config"]["workload"] if bench else None},
+               "columns": ncol, "workload": bench["config"]["workload"] if bench else None,
+               # columns one launch of the solver kernels covers (a call may run as several column tiles)
+               "columns_per_launch": ncol // max(1, bench["roofline"].get("column_tiles", 1)) if bench else ncol},
               open(os.path.join("profiles", f"{tag}_traffic.json"), "w"), indent=1)
     print("\n".join(out))
 
