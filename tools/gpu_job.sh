@@ -1,15 +1,18 @@
 #!/bin/bash
-# one GPU call: work-budget experiment (one tile instead of two), then the profiles of every workload of the default run
+# one GPU call: cacheable scratch records for the top K levels of the shortwave ICA kernel (written last, read first)
 mkdir -p gpurun_out
-run() { python bench.py --steps 5 --warmup 1 --no-cpu-baseline --headline-only --workload $1 2>/dev/null | python -c "
+run() { python bench.py --steps 10 --warmup 2 --no-cpu-baseline --headline-only --workload $1 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
         d = json.loads(line); st = d['roofline']['stage_ms']
-        print('%-10s %-22s %10.0f col/s  prep %7.2f lw %7.2f  sw %7.2f tiles %d' % ('$2', '$1', d['value'], st['prep'], st['lw'], st['sw'], d['roofline']['column_tiles']))
+        print('%-10s %-26s %10.0f col/s  lw %7.3f  sw %7.3f' % ('$2', '$1', d['value'], st['lw'], st['sw']))
 "; }
-for w in mcica_rrtmg spartacus_ecckd32_sp; do
-  run $w 64GiB
-  ECRAD_HIP_WORK_GIB=200 run $w 200GiB
-done 2>&1 | tee gpurun_out/r02_t_workgib.log
-tools/profile_all.sh r02_t
+for rep in 1 2; do
+for w in clear_homogeneous_ecckd32 mcica_ecckd32; do
+  run $w current
+  for lib in build_variants/*/libecrad_hip.so; do
+    ECRAD_HIP_LIB=$PWD/$lib run $w $(basename $(dirname $lib))
+  done
+done
+done
