@@ -155,6 +155,9 @@ struct DevInputs {
   // top-down; they map level indices when they touch the caller's arrays (radiation_reverse,
   // radiation_interface.F90:310-317, :519-661, without the copies).
   const int32_t* reversed;
+  // Order in which the solver kernels take the local columns (null: as they come): within every window of 64 columns
+  // the columns with similar cloud structure are neighbours, see column_order_kernel
+  const int32_t* col_order;
   // In that case crop_cloud_fraction writes here ([level][local column], caller's level order) instead
   // of the caller's array: the reference crops a reversed COPY, so cloud%fraction is left untouched.
   double* cloud_fraction_work;

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(Spectr
     const double cloud_fraction_threshold = cfg.cloud_fraction_threshold;
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
-    const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
+    const int cloc = ordered_column(kernarg_block<SpectralArgs>().in, col_ok ? cloc_raw : ncol_loc - 1);
     const int col = a.in.istartcol - 1 + cloc;
     const bool valid = col_ok && gi < ng;
     const bool lead = glane == 0 && col_ok;

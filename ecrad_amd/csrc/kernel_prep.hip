@@ -39,6 +39,52 @@ hipError_t launch_order(hipStream_t st, const DevInputs& in, int32_t* flag) {
   return hipGetLastError();
 }
 
+// ---- order of the columns within windows of 16 ... 256 ----------------------------------------------------------------
+// The solver kernels put 256/NGP columns in a block (two in a wave at 32 lanes per column); a block is done when its
+// slowest column is, and the two columns of a wave run through each other's cloudy layers.  What a column costs
+// follows from where its clouds are -- the sweeps below cloud top, the extra regions / sub-columns of the cloudy
+// layers -- so within every window of 64 consecutive columns (one wave of this kernel, lane = column: coalesced reads of
+// the cropped cloud fraction) the columns are ranked by (cloud top, number of cloudy layers) and the solver kernels take
+// them in that order: neighbours in the order have similar work.  Windows keep the inputs of a block within a few
+// cache lines per level.  The results do not depend on the order (no sum runs over columns).
+// Measured (profiles/r02_v_divergence.log: columns with identical cloud structure side by side): up to +11 % Tripleclouds,
+// +15 % McICA.
+__global__ __launch_bounds__(256) void column_order_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, int32_t* __restrict__ order, int W) {
+  __shared__ int skey[256];
+  const int tid = threadIdx.x;
+  const int nloc = in.iendcol - in.istartcol + 1, nlev = in.nlev;
+  const int cloc = blockIdx.x * blockDim.x + tid;       // thread = column (coalesced reads), windows of W consecutive threads
+  const bool ok = cloc < nloc;
+  int key = 0x7fffffff;                                  // (columns beyond the range go last)
+  if (ok) {
+    const LevelOrder ord = level_order(in);
+    const FracView fracv = cloud_fraction_view(in, in.istartcol - 1 + cloc);
+    const double thr = cfgp->cloud_fraction_threshold;
+    int first = nlev, count = 0;
+    for (int l = 0; l < nlev; ++l)
+      if (fracv.p[fracv.stride * ord.full(l)] >= thr) { if (first == nlev) first = l; ++count; }
+    key = ((nlev - first) << 10) | count;       // cloud-free columns first, then from the lowest cloud top up
+  }
+  skey[tid] = key;
+  __syncthreads();
+  const int w0 = tid & ~(W - 1);
+  int rank = 0;
+  for (int j = 0; j < W; ++j) {
+    const int kj = skey[w0 + j];
+    rank += (kj < key || (kj == key && w0 + j < tid)) ? 1 : 0;
+  }
+  if (ok) order[cloc - (tid - w0) + rank] = cloc;
+}
+
+// `window`: 16, 32, 64, 128 or 256 columns
+hipError_t launch_column_order(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int32_t* order, int window) {
+  const int nloc = in.iendcol - in.istartcol + 1;
+  if (const char* e = getenv("ECRAD_ORDER_WINDOW")) window = atoi(e);
+  if (window != 16 && window != 32 && window != 64 && window != 128 && window != 256) window = 64;
+  hipLaunchKernelGGL(column_order_kernel, dim3((nloc + 255) / 256), dim3(256), 0, st, cfg, in, order, window);
+  return hipGetLastError();
+}
+
 hipError_t launch_crop(hipStream_t st, const DevConfig* cfg, const DevInputs& in) {
   const size_t total = (size_t)(in.iendcol - in.istartcol + 1) * in.nlev;
   int grid = (int)((total + 255) / 256);

@@ -526,7 +526,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
 
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < nloc;
-    const int cloc = col_ok ? cloc_raw : nloc - 1;
+    const int cloc = ordered_column(kernarg_block<SpArgs>().in, col_ok ? cloc_raw : nloc - 1);
     const int col = a.in.istartcol - 1 + cloc;
     const int gi = c.g0 + glane, ngl = c.ngl;      // g-point of this lane; g-points of this launch
     const int g = gi < ng ? gi : ng - 1;
@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
 
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < nloc;
-    const int cloc = col_ok ? cloc_raw : nloc - 1;
+    const int cloc = ordered_column(kernarg_block<SpArgs>().in, col_ok ? cloc_raw : nloc - 1);
     const int col = a.in.istartcol - 1 + cloc;
     const int gi = c.g0 + glane, ngl = c.ngl;      // g-point of this lane; g-points of this launch
     const int g = gi < ng ? gi : ng - 1;

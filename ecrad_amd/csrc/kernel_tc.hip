@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void sw_tc_kernel(Spect
     const bool use_aerosols = cfg.use_aerosols != 0, delta_gases = cfg.do_sw_delta_scaling_with_gases != 0;
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
-    const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
+    const int cloc = ordered_column(kernarg_block<SpectralArgs>().in, col_ok ? cloc_raw : ncol_loc - 1);
     const int col = in.istartcol - 1 + cloc;
     const bool valid = col_ok && gi < ng;
     const double mu0 = in.cos_sza[col];
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
     const bool use_aerosols = cfg.use_aerosols != 0, cloud_scattering = cfg.do_lw_cloud_scattering != 0;
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
-    const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
+    const int cloc = ordered_column(kernarg_block<SpectralArgs>().in, col_ok ? cloc_raw : ncol_loc - 1);
     const int col = in.istartcol - 1 + cloc;
     const bool valid = col_ok && gi < ng;
     const bool lead = glane == 0 && col_ok;

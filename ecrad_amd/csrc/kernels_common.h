@@ -10,7 +10,10 @@
 
 namespace ecrad {
 
-constexpr int kBlock = 256;
+#ifndef ECRAD_BLOCK
+#define ECRAD_BLOCK 256     // threads per block of the spectral kernels (a multiple of 64; tuning knob)
+#endif
+constexpr int kBlock = ECRAD_BLOCK;
 #ifndef ECRAD_STAGE_BATCH
 #define ECRAD_STAGE_BATCH 4     // layers of RRTMG stage values (od, Planck / ssa, od_scaling) requested together by the ICA kernels
 #endif
@@ -306,6 +309,8 @@ struct LevelOrder {
   ECRAD_DEV int iface(int k) const { return rev ? nlev - 2 - k : k; }          // interface between layers k, k+1
 };
 ECRAD_DEV LevelOrder level_order(const DevInputs& in) { return {in.nlev, *in.reversed != 0}; }
+// the local column that slot `i` of the launch's column groups works on
+ECRAD_DEV int ordered_column(const DevInputs& in, int i) { return in.col_order ? in.col_order[i] : i; }
 
 // Cropped cloud fraction of one column: p[stride*k] is level k in the caller's order (see DevInputs)
 struct FracView {

@@ -44,8 +44,15 @@ def make_columns(config: Config, ncol: int, clear_sky: bool, seed: int = SEED, f
     # (a fancy-index gather along the fastest axis is ~10x slower for the 100 000-column batches)
     reps = -(-ncol // nb)
 
+    group = int(os.environ.get("ECRAD_SYNTH_SAME_PROFILE", "1"))     # (diagnostic) runs of this many columns share a base profile
+
     def take(a):
         r = np.roll(a, -(first_column % nb), axis=-1)
+        if group > 1:
+            r = np.repeat(r, group, axis=-1)
+            out = np.empty(a.shape[:-1] + (-(-ncol // (nb * group)), nb * group), dtype=a.dtype)
+            out[...] = r[..., None, :]
+            return out.reshape(a.shape[:-1] + (-1,))[..., :ncol]
         out = np.empty(a.shape[:-1] + (reps, nb), dtype=a.dtype)
         out[...] = r[..., None, :]
         return out.reshape(a.shape[:-1] + (reps * nb,))[..., :ncol]

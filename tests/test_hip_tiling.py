@@ -124,3 +124,21 @@ def test_solar_cycle_without_amplitude_table_is_an_error():
     with pytest.raises(EcradHipError, match="solar cycle"):
         rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)
     rad.close()
+
+
+@pytest.mark.parametrize("case", ["tripleclouds_ecckd", "mcica_rrtmg", "spartacus_ecckd", "homogeneous_ecckd"])
+def test_column_order_does_not_change_the_results(case, monkeypatch):
+    """The cloudy solvers take the columns of every window of 16 / 256 in the order of their cloud structure
+    (column_order_kernel, kernel_prep.hip) so that the columns sharing a wave or a block have similar work; no sum runs
+    over columns, so every output must have the same bits as with the columns taken as they come."""
+    mk = {"tripleclouds_ecckd": lambda: make_config("Tripleclouds"),
+          "mcica_rrtmg": lambda: make_config_rrtmg("McICA", do_lw_aerosol_scattering=False),
+          "spartacus_ecckd": lambda: make_config("SPARTACUS", do_3d_effects=True, do_lw_derivatives=True),
+          "homogeneous_ecckd": lambda: make_config("Homogeneous")}[case]
+    c1, c2 = mk(), mk()
+    f1, frac1, _ = _run(c1, _replicate(load_meridian(c1), 40))
+    monkeypatch.setenv("ECRAD_NO_COLUMN_ORDER", "1")
+    f2, frac2, _ = _run(c2, _replicate(load_meridian(c2), 40))
+    for name, a in f1.arrays.items():
+        assert np.array_equal(a, f2.arrays[name]), name
+    assert np.array_equal(frac1, frac2)

@@ -1,18 +1,17 @@
 #!/bin/bash
-# one GPU call: cacheable scratch records for the top K levels of the shortwave ICA kernel (written last, read first)
+# one GPU call: per-spectrum ordering windows -- full test suite, then every cloudy workload against ECRAD_NO_COLUMN_ORDER
 mkdir -p gpurun_out
-run() { python bench.py --steps 10 --warmup 2 --no-cpu-baseline --headline-only --workload $1 2>/dev/null | python -c "
+python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+run() { python bench.py --steps 8 --warmup 2 --no-cpu-baseline --headline-only --workload $1 $3 2>/dev/null | python -c "
 import sys, json
 for line in sys.stdin:
     if line.startswith('{'):
         d = json.loads(line); st = d['roofline']['stage_ms']
-        print('%-10s %-26s %10.0f col/s  lw %7.3f  sw %7.3f' % ('$2', '$1', d['value'], st['lw'], st['sw']))
+        print('%-10s %-26s %10.0f col/s  prep %6.2f lw %7.3f  sw %7.3f' % ('$2', '$1', d['value'], st['prep'], st['lw'], st['sw']))
 "; }
-for rep in 1 2; do
-for w in clear_homogeneous_ecckd32 mcica_ecckd32; do
-  run $w current
-  for lib in build_variants/*/libecrad_hip.so; do
-    ECRAD_HIP_LIB=$PWD/$lib run $w $(basename $(dirname $lib))
-  done
+for w in tripleclouds_ecckd32 mcica_ecckd32 mcica_rrtmg tripleclouds_rrtmg spartacus_ecckd32_sp; do
+  ECRAD_NO_COLUMN_ORDER=1 run $w asis
+  run $w ordered
 done
-done
+ECRAD_NO_COLUMN_ORDER=1 run tripleclouds_ecckd64 asis "--ncol 1250000"
+run tripleclouds_ecckd64 ordered "--ncol 1250000"
