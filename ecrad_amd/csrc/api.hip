@@ -1229,7 +1229,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     }
     const int nch = plan.n;
     for (int p = 0; p < nch; ++p)
-      HIP_TRY(h, launch_optics_dump(is_sw, plan.ngp[p], m.table_f32, grid_for(h, r.nloc, plan.ngp[p]), lds_bytes(m.hot.nquad, c.n_cloud_types), stream, h->dcfg, din, dop, plan.g0[p]));
+      HIP_TRY(h, launch_optics_dump(is_sw, plan.ngp[p], m.table_f32, grid_for(h, r.nloc, plan.ngp[p]), lds_bytes(m.hot.nquad, c.n_cloud_types), stream, h->hcfg, din, dop, plan.g0[p]));
     auto launch_sp = [&](const DevFlux& f, int* counter, int p, bool wide) -> hipError_t {
       const int ngp = plan.ngp[p], g0 = plan.g0[p];
       return launch_spartacus(is_sw, sp_single, ngp, grid_sp(ngp, is_sw), h->num_cu, stream, c, din, dop, prep, f, scratch,
@@ -1515,11 +1515,11 @@ int ecrad_hip_optics(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, in
   if (c.do_sw)
     for (int p = 0; p < h->plan_sw.n; ++p)
       HIP_TRY(h, launch_optics_dump(true, h->plan_sw.ngp[p], h->hcfg.gas_sw.table_f32, grid_for(h, r.nloc, h->plan_sw.ngp[p]),
-                                    lds_bytes(h->hcfg.gas_sw.hot.nquad, nct), stream, h->dcfg, cx.din, dop, h->plan_sw.g0[p]));
+                                    lds_bytes(h->hcfg.gas_sw.hot.nquad, nct), stream, h->hcfg, cx.din, dop, h->plan_sw.g0[p]));
   if (c.do_lw)
     for (int p = 0; p < h->plan_lw.n; ++p)
       HIP_TRY(h, launch_optics_dump(false, h->plan_lw.ngp[p], h->hcfg.gas_lw.table_f32, grid_for(h, r.nloc, h->plan_lw.ngp[p]),
-                                    lds_bytes(h->hcfg.gas_lw.hot.nquad, nct), stream, h->dcfg, cx.din, dop, h->plan_lw.g0[p]));
+                                    lds_bytes(h->hcfg.gas_lw.hot.nquad, nct), stream, h->hcfg, cx.din, dop, h->plan_lw.g0[p]));
   if (host_mem) {
     for (const OF& f : fields)
       if (out->*(f.host)) HIP_TRY(h, hipMemcpyAsync(out->*(f.host), dop.*(f.dev), f.n * 8, hipMemcpyDeviceToHost, stream));

@@ -7,10 +7,26 @@
 
 namespace ecrad {
 
+// The configuration travels BY VALUE in the kernel-argument segment, as in the solver kernels (kernarg_block, DESIGN.md
+// section 4), and the kernel is held to three waves per SIMD (the longwave instantiation used 170 registers, two waves).
+// The SPARTACUS solvers run this kernel for every call (40 of their 119 ms per 100 000 columns): that is the cost of the
+// optics themselves -- gas look-ups, 12 aerosol types, cloud optics: what the optics pass of the Tripleclouds kernels
+// costs as well -- and did not change with either measure (profiles/r02_ze_dump_byvalue.log).
+struct DumpArgs {
+  DevConfig cfg;
+  DevInputs in;
+  DevOptics out;
+  int32_t g0, pad_;
+};
+
 template <typename TAB, int NGP, bool IS_SW>
-__global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevOptics out, int g0) {
+__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void optics_dump_kernel(DumpArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
-  const DevConfig& cfg = *cfgp;
+  const DumpArgs& a0 = kernarg_block<DumpArgs>();
+  const DevConfig& cfg = a0.cfg;
+  const DevInputs& in = a0.in;
+  const DevOptics& out = a0.out;
+  const int g0 = a0.g0;
   const DevCkdModel& m = IS_SW ? cfg.gas_sw : cfg.gas_lw;
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
@@ -55,13 +71,19 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
       __syncthreads();
       {
         const int lev = l0 + glane;
-        if (lev < nlev) level_scalars<IS_SW>(cfg, m, in, L, tid, col, lev, want_clouds);
+        const DumpArgs& b = kernarg_block<DumpArgs>();
+        if (lev < nlev) level_scalars<IS_SW>(b.cfg, IS_SW ? b.cfg.gas_sw : b.cfg.gas_lw, b.in, L, tid, col, lev, want_clouds);
       }
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
       for (int j = 0; j < nl; ++j) {
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
+        const DumpArgs& b = kernarg_block<DumpArgs>();
+        const DevConfig& cfg = b.cfg;
+        const DevInputs& in = b.in;
+        const DevOptics& out = b.out;
+        const DevCkdModel& m = IS_SW ? cfg.gas_sw : cfg.gas_lw;
         const size_t o = g + (size_t)ng * (lev + (size_t)nlev * cloc);
         double od = gas_absorption_od<TAB>(m.hot, L, slot, g);
         if (IS_SW) {
@@ -134,8 +156,9 @@ __global__ __launch_bounds__(kBlock) void optics_dump_kernel(const DevConfig* __
 }
 
 hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
-                              const DevConfig* cfg, const DevInputs& in, const DevOptics& out, int g0) {
-#define ECRAD_L(T, N, S) do { ECRAD_ALLOW_LDS((optics_dump_kernel<T, N, S>), lds); hipLaunchKernelGGL((optics_dump_kernel<T, N, S>), dim3(grid), dim3(kBlock), lds, st, cfg, in, out, g0); } while (0)
+                              const DevConfig& cfg, const DevInputs& in, const DevOptics& out, int g0) {
+  const DumpArgs args{cfg, in, out, g0, 0};
+#define ECRAD_L(T, N, S) do { ECRAD_ALLOW_LDS((optics_dump_kernel<T, N, S>), lds); hipLaunchKernelGGL((optics_dump_kernel<T, N, S>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
 #define ECRAD_N(T, S) do { if (ngp == 16) ECRAD_L(T, 16, S); else if (ngp == 32) ECRAD_L(T, 32, S); else ECRAD_L(T, 64, S); } while (0)
   if (is_sw) { if (table_f32) ECRAD_N(float, true); else ECRAD_N(double, true); }
   else { if (table_f32) ECRAD_N(float, false); else ECRAD_N(double, false); }

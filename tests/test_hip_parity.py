@@ -119,7 +119,8 @@ def _replicate(inputs, times):
     rep = lambda a: None if a is None else np.ascontiguousarray(np.concatenate([a] * times, axis=-1))
     for obj, names in ((sl, ("cos_sza", "skin_temperature", "sw_albedo", "lw_emissivity", "sw_albedo_direct", "iseed")),
                        (th, ("pressure_hl", "temperature_hl", "h2o_sat_liq")), (gas, ("mixing_ratio",)),
-                       (cloud, ("fraction", "mixing_ratio", "effective_radius", "fractional_std", "overlap_param")),
+                       (cloud, ("fraction", "mixing_ratio", "effective_radius", "fractional_std", "overlap_param",
+                                "inv_cloud_effective_size", "inv_inhom_effective_size")),
                        (aer, ("mixing_ratio",))):
         if obj is None:
             continue
