@@ -475,38 +475,49 @@ ECRAD_DEV void gen_draw(const GenLds& g, int lane, int& iused, int n, double* ds
   wave_sync();
 }
 
-// NW: 64-level words in the level masks (3 up to 191 levels, 4 up to 255)
+#define GEN_LAP(tm, k) tm.lap(k)
+// (timing build only) cycles per phase of the generator
+struct GenTimer {
+#ifdef ECRAD_TIMING
+  PhaseTimer t;
+  int cols;
+  ECRAD_DEV void reset() { t.reset(); cols = 0; }
+  ECRAD_DEV void start_column() { t.start(); cols++; }
+  ECRAD_DEV void lap(int k) { t.lap(k); }
+  ECRAD_DEV void report(bool who) {
+    if (who && cols > 0)
+      printf("mcica_generator timing (cycles/column): setup %.0f seeding %.0f warmup %.0f | per column over all g: trigger %.0f draw_rc %.0f tests %.0f draw_ri %.0f sample %.0f  (columns %d)\n",
+             (double)t.acc[0] / cols, (double)t.acc[1] / cols, (double)t.acc[2] / cols, (double)t.acc[3] / cols,
+             (double)t.acc[4] / cols, (double)t.acc[5] / cols, (double)t.acc[6] / cols, (double)t.acc[7] / cols, cols);
+  }
+#else
+  ECRAD_DEV void reset() {}
+  ECRAD_DEV void start_column() {}
+  ECRAD_DEV void lap(int) {}
+  ECRAD_DEV void report(bool) {}
+#endif
+};
+
+// One column (radiation_cloud_generator.F90:36-255).  NW: 64-level words in the level masks.  The column is handed over
+// as levels L0 .. L0+nlev-1 of the caller's: the generator does not care about cloud-free levels above the highest cloud
+// (no random number is drawn for them, the cumulative cover is zero there), so a 137-level column whose top 9 levels are
+// cloud-free -- every column in practice -- runs as 128 levels in TWO words instead of three: the per-level work of the
+// g-point loop (ballots, the bit manipulation of the run structure, the PDF look-ups) is per word.
 template <int NW>
-__global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, int ng,
-                                                             int seed_offset, double* od_scaling, double* total_cloud_cover) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const DevConfig& cfg = *cfgp;
-  const int lane = threadIdx.x;
-  const int nloc = in.iendcol - in.istartcol + 1;
-  const int nlev = in.nlev;
+ECRAD_DEV void mcica_generator_column(const DevConfig& cfg, const DevInputs& in, const GenLds& g, int ng, int seed_offset, double* od_scaling,
+                                      double* total_cloud_cover, int cloc, int lane, int nlev, int L0, GenTimer& tm) {
   const size_t ncol = in.ncol;
   using LevBits = LevBitsT<NW>;
-  const GenLds g = gen_lds(smem, nlev, ng);
   const double MaxCloudFrac = 1.0 - 2.220446049250313e-16 * 10.0;
   const bool exp_exp = cfg.i_overlap_scheme == ECRAD_OVERLAP_EXP_EXP;
-#ifdef ECRAD_TIMING
-  PhaseTimer tm;
-  tm.reset();
-  int tm_cols = 0;
-#endif
-  for (int cloc = blockIdx.x; cloc < nloc; cloc += gridDim.x) {
     const int col = in.istartcol - 1 + cloc;
     wave_sync();
-#ifdef ECRAD_TIMING
-    tm.start();
-    tm_cols++;
-#endif
     const LevelOrder ord = level_order(in);
     const FracView fracv = cloud_fraction_view(in, col);
     for (int l = lane; l < nlev; l += 64) {
-      g.frac[l] = fracv.p[fracv.stride * ord.full(l)];
-      g.fsd[l] = in.cloud_fractional_std[col + ncol * ord.full(l)];
-      if (l < nlev - 1) g.ovp[l] = in.cloud_overlap_param[col + ncol * ord.iface(l)];
+      g.frac[l] = fracv.p[fracv.stride * ord.full(l + L0)];
+      g.fsd[l] = in.cloud_fractional_std[col + ncol * ord.full(l + L0)];
+      if (l < nlev - 1) g.ovp[l] = in.cloud_overlap_param[col + ncol * ord.iface(l + L0)];
     }
     wave_sync();
     // cum_cloud_cover_exp_ran / _max_ran (radiation_cloud_cover.F90:169-330): pair cover is independent
@@ -543,7 +554,7 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
     }
     if (ibegin == 0) {       // no cloud at all: total cloud cover 0
       if (lane == 0) total_cloud_cover[cloc] = 0.0;
-      continue;
+      return;
     }
     // cumulative cover: serial recurrence; above the first and below the last cloudy level the factor
     // (1-pair)/(1-frac) is exactly 1, so only the cloudy span is walked
@@ -571,7 +582,7 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
     wave_sync();
     if (tcc < cfg.cloud_fraction_threshold) {
       if (lane == 0) total_cloud_cover[cloc] = 0.0;
-      continue;
+      return;
     }
     if (lane == 0) total_cloud_cover[cloc] = tcc;
     for (int l = lane; l < nlev - 1; l += 64) {
@@ -580,7 +591,7 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
       if (jlev >= ibegin && jlev <= iend - 1 && op > 0.0) op = pow(op, 1.0 / cfg.cloud_inhom_decorr_scaling);
       g.opi[l] = op;
     }
-    ECRAD_LAP0(tm, 0);      // cloud cover, level set-up
+    GEN_LAP(tm, 0);      // cloud cover, level set-up
     // ---- initialize_random_numbers (radiation_random_numbers_mix.F90:142-231), seeding in parallel ---
     for (int j = lane; j <= JPQ; j += 64) g.X[j] = 0;
     wave_sync();
@@ -613,13 +624,13 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
       if (lane == 0) g.X[JPQ - JPS] |= 1;
       wave_sync();
     }
-    ECRAD_LAP0(tm, 1);      // seeding
+    GEN_LAP(tm, 1);      // seeding
     int iused = JPQ;
     gen_draw(g, lane, iused, 999, nullptr);     // warm-up
-    ECRAD_LAP0(tm, 2);      // warm-up
+    GEN_LAP(tm, 2);      // warm-up
     // rand_top(1:ng) is ONE batch request in the reference (radiation_cloud_generator.F90:206)
     gen_draw(g, lane, iused, ng, g.rtop);
-    double* odsc = od_scaling + (size_t)ng * nlev * cloc;
+    double* odsc = od_scaling + (size_t)ng * ((size_t)in.nlev * cloc + L0);     // (row of the first level kept)
     PdfPending pend[NW];
     double* pend_dst[NW];
     bool pend_on[NW];
@@ -639,14 +650,14 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
         if (stop.any()) ti = stop.first();
       }
       const int ei = iend - 1;          // 0-based first (ti) and last (ei) cloudy level of this sub-column
-      ECRAD_LAP0(tm, 3);    // trigger search
+      GEN_LAP(tm, 3);    // trigger search
       // generate_column_exp_ran (radiation_cloud_generator.F90:262-390), level-parallel.
       // The reference walks down the levels with a run counter: inside a cloudy run the run continues
       // where test A holds, outside it a new run starts where test B holds.  Both tests only involve
       // this level's random number and fixed profiles, so all levels evaluate them at once (lane = level)
       // and the run structure follows from the two bit masks.
       gen_draw(g, lane, iused, ei + 1 - ti, g.rc);     // rand_cloud(1:iend+1-itrigger)
-      ECRAD_LAP0(tm, 4);    // draw rand_cloud
+      GEN_LAP(tm, 4);    // draw rand_cloud
       LevBits A, B;
 #pragma unroll
       for (int k = 0; k < NW; ++k) {
@@ -696,9 +707,9 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
       // 343-345), runs in top-down order: 2 x (number of cloudy levels) consecutive numbers in all
       // Exp-Exp (generate_column_exp_exp, :396-508) draws for ALL layers itrigger..iend as one run
       const int ncloudy = exp_exp ? ei + 1 - ti : C.count_below(64 * NW);
-      ECRAD_LAP0(tm, 5);    // tests + run structure
+      GEN_LAP(tm, 5);    // tests + run structure
       gen_draw(g, lane, iused, 2 * ncloudy, g.ri);
-      ECRAD_LAP0(tm, 6);    // draw rand_inhom
+      GEN_LAP(tm, 6);    // draw rand_inhom
       // "keep the value of the layer above" flags (:350-357), then each level takes rand_inhom1 of the
       // nearest level at or above it in its run whose flag is clear
       LevBits K;
@@ -740,18 +751,45 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
         }
       }
       wave_sync();
-      ECRAD_LAP0(tm, 7);    // flags, sampling, stores
+      GEN_LAP(tm, 7);    // flags, sampling, stores
     }
 #pragma unroll
     for (int k = 0; k < NW; ++k)
       if (pend_on[k]) pend_dst[k][0] = pdf_finish(pend[k]);
+}
+
+// NWMAX: words for the whole column (3 up to 191 levels, 4 up to 255), used only when a column has cloud in the levels
+// that two words cannot hold
+template <int NWMAX>
+__global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, int ng,
+                                                             int seed_offset, double* od_scaling, double* total_cloud_cover) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const DevConfig& cfg = *cfgp;
+  const int lane = threadIdx.x;
+  const int nloc = in.iendcol - in.istartcol + 1;
+  const int nlev = in.nlev;
+  const GenLds g = gen_lds(smem, nlev, ng);
+  GenTimer tm;
+  tm.reset();
+  for (int cloc = blockIdx.x; cloc < nloc; cloc += gridDim.x) {
+    const int col = in.istartcol - 1 + cloc;
+    tm.start_column();
+    // the highest cloudy level of the column (0-based; nlev if none)
+    int ib = nlev;
+    {
+      const LevelOrder ord = level_order(in);
+      const FracView fracv = cloud_fraction_view(in, col);
+      for (int l0 = 0; l0 < nlev && ib == nlev; l0 += 64) {
+        const int l = l0 + lane;
+        const unsigned long long b = __ballot(l < nlev && fracv.p[fracv.stride * ord.full(l)] > 0.0);
+        if (b) ib = l0 + __ffsll((long long)b) - 1;
+      }
+    }
+    const int L0 = nlev > 128 ? nlev - 128 : 0;       // (the column's lowest 128 levels)
+    if (nlev <= 128 || ib > L0) mcica_generator_column<2>(cfg, in, g, ng, seed_offset, od_scaling, total_cloud_cover, cloc, lane, nlev - L0, L0, tm);
+    else mcica_generator_column<NWMAX>(cfg, in, g, ng, seed_offset, od_scaling, total_cloud_cover, cloc, lane, nlev, 0, tm);
   }
-#ifdef ECRAD_TIMING
-  if (blockIdx.x == 0 && lane == 0 && tm_cols > 0)
-    printf("mcica_generator timing (cycles/column): setup %.0f seeding %.0f warmup %.0f | per column over all g: trigger %.0f draw_rc %.0f tests %.0f draw_ri %.0f sample %.0f  (columns %d)\n",
-           (double)tm.acc[0] / tm_cols, (double)tm.acc[1] / tm_cols, (double)tm.acc[2] / tm_cols, (double)tm.acc[3] / tm_cols,
-           (double)tm.acc[4] / tm_cols, (double)tm.acc[5] / tm_cols, (double)tm.acc[6] / tm_cols, (double)tm.acc[7] / tm_cols, tm_cols);
-#endif
+  tm.report(blockIdx.x == 0 && lane == 0);
 }
 
 // ---------------------------------------------------------------------------------------------------
