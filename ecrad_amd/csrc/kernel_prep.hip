@@ -499,10 +499,10 @@ struct GenTimer {
 };
 
 // One column (radiation_cloud_generator.F90:36-255).  NW: 64-level words in the level masks.  The column is handed over
-// as levels L0 .. L0+nlev-1 of the caller's: the generator does not care about cloud-free levels above the highest cloud
-// (no random number is drawn for them, the cumulative cover is zero there), so a 137-level column whose top 9 levels are
-// cloud-free -- every column in practice -- runs as 128 levels in TWO words instead of three: the per-level work of the
-// g-point loop (ballots, the bit manipulation of the run structure, the PDF look-ups) is per word.
+// as levels L0 .. L0+nlev-1 of the caller's: the generator does not see the cloud-free levels above the highest cloud or
+// below the lowest one (no random number is drawn for them; the cumulative cover is zero above and the total cover
+// below), so the caller trims them and picks the word count the cloudy span needs: the per-level work of the g-point
+// loop (ballots, the bit manipulation of the run structure, the PDF look-ups) is per word.
 template <int NW>
 ECRAD_DEV void mcica_generator_column(const DevConfig& cfg, const DevInputs& in, const GenLds& g, int ng, int seed_offset, double* od_scaling,
                                       double* total_cloud_cover, int cloc, int lane, int nlev, int L0, GenTimer& tm) {
@@ -758,8 +758,8 @@ ECRAD_DEV void mcica_generator_column(const DevConfig& cfg, const DevInputs& in,
       if (pend_on[k]) pend_dst[k][0] = pdf_finish(pend[k]);
 }
 
-// NWMAX: words for the whole column (3 up to 191 levels, 4 up to 255), used only when a column has cloud in the levels
-// that two words cannot hold
+// NWMAX: words for the whole column (3 up to 191 levels, 4 up to 255), used only when a column's clouds span more than
+// 128 levels
 template <int NWMAX>
 __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, int ng,
                                                              int seed_offset, double* od_scaling, double* total_cloud_cover) {
@@ -774,19 +774,27 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
   for (int cloc = blockIdx.x; cloc < nloc; cloc += gridDim.x) {
     const int col = in.istartcol - 1 + cloc;
     tm.start_column();
-    // the highest cloudy level of the column (0-based; nlev if none)
-    int ib = nlev;
+    // the highest and the lowest cloudy level of the column (0-based; none: ib = nlev)
+    int ib = nlev, il = -1;
     {
       const LevelOrder ord = level_order(in);
       const FracView fracv = cloud_fraction_view(in, col);
-      for (int l0 = 0; l0 < nlev && ib == nlev; l0 += 64) {
+      for (int l0 = 0; l0 < nlev; l0 += 64) {
         const int l = l0 + lane;
         const unsigned long long b = __ballot(l < nlev && fracv.p[fracv.stride * ord.full(l)] > 0.0);
-        if (b) ib = l0 + __ffsll((long long)b) - 1;
+        if (b) {
+          if (ib == nlev) ib = l0 + __ffsll((long long)b) - 1;
+          il = l0 + 63 - __clzll(b);
+        }
       }
     }
-    const int L0 = nlev > 128 ? nlev - 128 : 0;       // (the column's lowest 128 levels)
-    if (nlev <= 128 || ib > L0) mcica_generator_column<2>(cfg, in, g, ng, seed_offset, od_scaling, total_cloud_cover, cloc, lane, nlev - L0, L0, tm);
+    // The column is handed over as the levels from the one above its highest cloud down to its lowest cloud: 64-level
+    // words cost per-level work in every g-point, and a cloudy span of at most 64 levels (most columns) needs ONE.
+    // (A cloud in the very top level keeps the top level: the generator treats that case separately.)
+    const int L0 = ib > 0 && ib < nlev ? ib - 1 : 0;
+    const int span = il >= 0 ? il + 1 - L0 : (nlev < 64 ? nlev : 64);      // (cloud-free: any valid count; the column returns at once)
+    if (span <= 64) mcica_generator_column<1>(cfg, in, g, ng, seed_offset, od_scaling, total_cloud_cover, cloc, lane, span, L0, tm);
+    else if (span <= 128) mcica_generator_column<2>(cfg, in, g, ng, seed_offset, od_scaling, total_cloud_cover, cloc, lane, span, L0, tm);
     else mcica_generator_column<NWMAX>(cfg, in, g, ng, seed_offset, od_scaling, total_cloud_cover, cloc, lane, nlev, 0, tm);
   }
   tm.report(blockIdx.x == 0 && lane == 0);

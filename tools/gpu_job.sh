@@ -9,5 +9,5 @@ for line in sys.stdin:
         d = json.loads(line); st = d['roofline']['stage_ms']
         print('%-10s %-26s %10.0f col/s  prep %6.2f lw %7.3f  sw %7.3f' % ('$2', '$1', d['value'], st['prep'], st['lw'], st['sw']))
 "; }
-for w in mcica_ecckd32 mcica_rrtmg; do run $w gen2w; done
+for w in mcica_ecckd32 mcica_rrtmg; do run $w gen1w; done
 tools/kstats.sh mcica_rrtmg --headline-only 2>&1 | grep generator
