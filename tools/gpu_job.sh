@@ -1,15 +1,16 @@
 #!/bin/bash
-# one GPU call: full GPU suite, the driver's bench command, and the profile of the RRTMG McICA workload on this build
+# one GPU call (diagnostic): what taking columns out of their memory order costs the 32-lane kernels
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee gpurun_out/r02_zi_tests.log
-python bench.py --steps 20 --warmup 5 > gpurun_out/r02_zi_bench.json 2> gpurun_out/r02_zi_bench.err
-w=mcica_rrtmg; OUT=$PWD/gpurun_out/r02_zi_$w; mkdir -p $OUT
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --headline-only --workload $w --ncol 100000"
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python bench.py $ARGS > $OUT/bench_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python bench.py $ARGS > $OUT/bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- python bench.py $ARGS > $OUT/bench_write.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $OUT/cal_fetch -o cal -- tools/hbm_calibrate > $OUT/cal_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/cal_write -o cal -- tools/hbm_calibrate > $OUT/cal_write.log 2>&1
-python bench.py --steps 5 --warmup 1 --no-cpu-baseline --headline-only --workload $w > $OUT/bench.json 2> $OUT/bench.err
-head -c 300 gpurun_out/r02_zi_bench.json
+run() { python bench.py --steps 8 --warmup 2 --no-cpu-baseline --headline-only --workload $1 2>/dev/null | python -c "
+import sys, json
+for line in sys.stdin:
+    if line.startswith('{'):
+        d = json.loads(line); st = d['roofline']['stage_ms']
+        print('%-16s %-26s %10.0f col/s  lw %7.3f  sw %7.3f' % ('$2', '$1', d['value'], st['lw'], st['sw']))
+"; }
+for w in tripleclouds_ecckd32 mcica_ecckd32; do
+ECRAD_SYNTH_SAME_PROFILE=2 ECRAD_NO_COLUMN_ORDER=1 run $w same2_asis
+ECRAD_SYNTH_SAME_PROFILE=2 ECRAD_ORDER_WINDOW=16 run $w same2_win16
+ECRAD_SYNTH_SAME_PROFILE=2 ECRAD_ORDER_WINDOW=64 run $w same2_win64
+ECRAD_SYNTH_SAME_PROFILE=2 ECRAD_ORDER_WINDOW=256 run $w same2_win256
+done
