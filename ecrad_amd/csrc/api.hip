@@ -49,6 +49,10 @@ struct ecrad_hip_handle_s {
   // join the main stream before the solver that reads their optical-depth scalings (fork after crop, join by events)
   hipStream_t aux_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_gen_lw = nullptr, ev_gen_sw = nullptr;
+  // Small batches (an NPROMA block of a host model): one column group takes ~1 ms per spectrum whatever the batch is --
+  // 137 levels of dependent latencies -- and the GPU is mostly empty, so the shortwave stage runs on the second stream
+  // next to the longwave one (fork after the preparation kernels, join before the post-processing)
+  hipEvent_t ev_fork_sw = nullptr, ev_sw_done = nullptr;
   int num_cu = 256;
   int blocks_per_cu = 4;
   std::string err;
@@ -605,7 +609,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
   free_tables(h);
   h->gas_stage.release(); h->gas_work.release(); h->sp_stage.release(); h->counters.release(); h->partial.release(); h->spec_tmp.release(); h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
   for (auto& t : h->tile_events) for (auto& e : t.e) if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : {h->ev_fork, h->ev_gen_lw, h->ev_gen_sw}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {h->ev_fork, h->ev_gen_lw, h->ev_gen_sw, h->ev_fork_sw, h->ev_sw_done}) if (e) (void)hipEventDestroy(e);
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   delete h;
   return ECRAD_OK;
@@ -1044,6 +1048,13 @@ size_t work_bytes_per_column(ecrad_hip_handle_t h, int nlev, const ecrad_inputs_
   return b;
 }
 
+int ensure_aux_stream(ecrad_hip_handle_t h) {
+  if (h->aux_stream) return ECRAD_OK;
+  HIP_TRY(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
+  for (hipEvent_t* e : {&h->ev_fork, &h->ev_gen_lw, &h->ev_gen_sw, &h->ev_fork_sw, &h->ev_sw_done}) HIP_TRY(h, hipEventCreateWithFlags(e, hipEventDisableTiming));
+  return ECRAD_OK;
+}
+
 // One tile of columns istartcol..iendcol of a call: everything radiation() does (radiation_interface.F90:200-510)
 int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
                    const ecrad_inputs_t* in, ecrad_flux_t* flux, int tile) {
@@ -1149,8 +1160,11 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
                                            : (sw_tc ? sw_tc_scratch_doubles(nlev) : sw_ica_scratch_doubles(c.i_solver_sw, nlev));
   const bool lw_scat = c.do_lw && c.do_lw_aerosol_scattering != 0;
   const size_t per_block_lw = !c.do_lw ? 0 : lw_sp ? (spartacus_scratch_words(false, nlev) * sp_word + 7) / 8 : (lw_tc ? lw_tc_scratch_doubles(nlev, lw_scat) : lw_scat ? lw_scat_scratch_doubles(nlev) : lw_ica_scratch_doubles(c.i_solver_lw, nlev));
-  const size_t need_sw = per_block_sw * grid_sw * 8, need_lw = per_block_lw * grid_lw * 8;
-  HIP_TRY(h, h->scratch.ensure(need_sw > need_lw ? need_sw : need_lw));
+  const size_t need_sw = per_block_sw * grid_sw * 8, need_lw = (per_block_lw * grid_lw * 8 + 255) / 256 * 256;
+  // both spectra at once when together they do not fill the GPU (each with its own sweep scratch then)
+  const bool spectra_overlap = c.do_sw && c.do_lw && !sw_sp && !lw_sp && h->nchunk_sw == 1 && h->nchunk_lw == 1 &&
+                               grid_sw + grid_lw <= 2 * h->num_cu && !getenv("ECRAD_NO_SPECTRA_OVERLAP");      // (<= 2048 columns at 32 lanes: beyond, 4096 columns were 6 % slower side by side, profiles/r02_zo_spectra_overlap.log)
+  HIP_TRY(h, h->scratch.ensure(spectra_overlap ? need_sw + need_lw : (need_sw > need_lw ? need_sw : need_lw)));
   HIP_TRY(h, h->counters.ensure(256));
   {   // per-chunk partial profiles of spectra wider than 64 g-points (6 profiles x chunks, reused by LW then SW)
     const int nch = std::max(c.do_lw ? h->nchunk_lw : 1, c.do_sw ? h->nchunk_sw : 1);
@@ -1210,10 +1224,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     return ECRAD_OK;
   };
   if (gen_overlap) {
-    if (!h->aux_stream) {
-      HIP_TRY(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-      for (hipEvent_t* e : {&h->ev_fork, &h->ev_gen_lw, &h->ev_gen_sw}) HIP_TRY(h, hipEventCreateWithFlags(e, hipEventDisableTiming));
-    }
+    if ((st = ensure_aux_stream(h))) return st;
     // (the main stream is serial: everything of the previous tile or call that read the scalings is behind ev_fork)
     HIP_TRY(h, hipEventRecord(h->ev_fork, stream));
     HIP_TRY(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
@@ -1300,6 +1311,15 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
   };
   // (the McICA generators are accounted to the LW/SW stage they feed)
   HIP_TRY(h, hipEventRecord(evs[1], stream));
+  hipStream_t sw_stream = stream;
+  double* scratch_sw = scratch;
+  if (spectra_overlap) {
+    if ((st = ensure_aux_stream(h))) return st;
+    HIP_TRY(h, hipEventRecord(h->ev_fork_sw, stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork_sw, 0));
+    sw_stream = h->aux_stream;
+    scratch_sw = scratch + need_lw / 8;
+  }
   cx.din.col_order = col_order_lw;     // (din refers to cx.din: the launches below see it)
   if (c.do_lw) {                                                                        // :422-457
     const DevCkdModel& m = h->hcfg.gas_lw;
@@ -1351,13 +1371,13 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     const size_t lds = lds_bytes(m.hot.nquad, nct);
     if (sw_mcica) {
       if (gen_overlap) HIP_TRY(h, hipStreamWaitEvent(stream, h->ev_gen_sw, 0));
-      else if ((st = run_generator(true, stream))) return st;
+      else if ((st = run_generator(true, sw_stream))) return st;
     }
     if (sw_sp) {
       if ((st = run_spartacus(true))) return st;
     } else if (h->nchunk_sw == 1) {
-      if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m, 0));
-      else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, stream, h->hcfg, din, dfx, prep, scratch, per_block_sw, counters + 16, m, 0, false));
+      if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, sw_stream, h->hcfg, din, dfx, prep, scratch_sw, per_block_sw, counters + 16, m, 0));
+      else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, sw_stream, h->hcfg, din, dfx, prep, scratch_sw, per_block_sw, counters + 16, m, 0, false));
     } else {
       // More than 64 g-points: one launch per chunk of `ngp_sw` g-points.  The sums over g of a launch
       // are partial, so its broadband profiles go to per-chunk buffers (same indexing as the real
@@ -1381,6 +1401,10 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     }
   }
   cx.din.col_order = nullptr;
+  if (spectra_overlap) {
+    HIP_TRY(h, hipEventRecord(h->ev_sw_done, h->aux_stream));
+    HIP_TRY(h, hipStreamWaitEvent(stream, h->ev_sw_done, 0));
+  }
   HIP_TRY(h, hipEventRecord(evs[3], stream));
   for (int k = 0; k < 10; ++k)
     if (spec_real[k]) {
