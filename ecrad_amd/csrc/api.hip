@@ -451,7 +451,6 @@ int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
     if (c.nregions != 3) return fail(h, ECRAD_EUNSUPPORTED, "SPARTACUS: only nregions = 3 is implemented");
     if (c.i_3d_sw_entrapment < ECRAD_ENTRAPMENT_ZERO || c.i_3d_sw_entrapment > ECRAD_ENTRAPMENT_MAXIMUM) return fail(h, ECRAD_EINVAL, "SPARTACUS: unknown entrapment option");
     if (c.i_precision != ECRAD_PRECISION_DOUBLE && c.i_precision != ECRAD_PRECISION_SINGLE) return fail(h, ECRAD_EINVAL, "unknown i_precision");
-    if (c.do_save_spectral_flux) return fail(h, ECRAD_EUNSUPPORTED, "SPARTACUS: spectral flux profiles are not implemented");
     if (!c.do_clouds) return fail(h, ECRAD_EINVAL, "SPARTACUS needs do_clouds");
     if (c.i_overlap_scheme != ECRAD_OVERLAP_EXP_RAN) return fail(h, ECRAD_EINVAL, "SPARTACUS can only do Exp-Ran overlap");    // radiation_config.F90:1259-1266
     if (!(c.max_cloud_od > 0.0) || !(c.min_cloud_effective_size > 0.0)) return fail(h, ECRAD_EINVAL, "SPARTACUS: max_cloud_od and min_cloud_effective_size must be positive");

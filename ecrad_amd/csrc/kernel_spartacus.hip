@@ -750,6 +750,17 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
           if (lead) { fx.sw_dn_clear[o0] = dn0; if (fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[o0] = dn0; }
           if (valid) fx.sw_up_toa_clear_g[og] = (double)flux_up_clear;
         }
+        if (valid && fx.sw_up_band) {      // spectral flux profiles, :1403-1424 (lane g owns interval g, see spec_put)
+          const double dir0 = (double)(mu0 * direct_dn_below.sum());
+          spec_put(fx.sw_up_band, ng, g, o0, (double)flux_up_above.sum());
+          spec_put(fx.sw_dn_band, ng, g, o0, dir0);
+          spec_put(fx.sw_dn_direct_band, ng, g, o0, dir0);
+          if (do_clear) {
+            spec_put(fx.sw_up_clear_band, ng, g, o0, (double)flux_up_clear);
+            spec_put(fx.sw_dn_clear_band, ng, g, o0, dir0);
+            spec_put(fx.sw_dn_direct_clear_band, ng, g, o0, dir0);
+          }
+        }
       }
       for (int jlev = 1; jlev <= nlev; ++jlev) {
         const int jl = jlev - 1;
@@ -812,6 +823,18 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
           const double s = sw_dn_clear_direct + group_sum<NGP>(valid ? (double)flux_dn_clear : 0.0);
           if (lead) fx.sw_dn_clear[oh] = s;
         }
+        if (valid && fx.sw_up_band) {      // :1472-1493, :1557-1572
+          const R dirv = mu0 * direct_dn_above.sum();
+          spec_put(fx.sw_up_band, ng, g, oh, (double)flux_up_above.sum());
+          spec_put(fx.sw_dn_band, ng, g, oh, (double)(dirv + flux_dn_above.sum()));
+          spec_put(fx.sw_dn_direct_band, ng, g, oh, (double)dirv);
+          if (do_clear) {
+            const R dirc = mu0 * direct_dn_clear;
+            spec_put(fx.sw_up_clear_band, ng, g, oh, (double)flux_up_clear);
+            spec_put(fx.sw_dn_clear_band, ng, g, oh, (double)(dirc + flux_dn_clear));
+            spec_put(fx.sw_dn_direct_clear_band, ng, g, oh, (double)dirc);
+          }
+        }
       }
       if (valid) {
         fx.sw_dn_diffuse_surf_g[og] = (double)flux_dn_above.sum();
@@ -836,6 +859,12 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
       if (valid) {
         fx.sw_dn_diffuse_surf_g[og] = 0.0; fx.sw_dn_direct_surf_g[og] = 0.0; fx.sw_up_toa_g[og] = 0.0;
         if (do_clear) { fx.sw_dn_diffuse_surf_clear_g[og] = 0.0; fx.sw_dn_direct_surf_clear_g[og] = 0.0; fx.sw_up_toa_clear_g[og] = 0.0; }
+        if (fx.sw_up_band)               // :357-370
+          for (int l = 0; l <= nlev; ++l) {
+            const size_t o = col + ncol * l;
+            spec_put(fx.sw_up_band, ng, g, o, 0.0); spec_put(fx.sw_dn_band, ng, g, o, 0.0); spec_put(fx.sw_dn_direct_band, ng, g, o, 0.0);
+            if (do_clear) { spec_put(fx.sw_up_clear_band, ng, g, o, 0.0); spec_put(fx.sw_dn_clear_band, ng, g, o, 0.0); spec_put(fx.sw_dn_direct_clear_band, ng, g, o, 0.0); }
+          }
       }
     }
   }
@@ -1188,6 +1217,11 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
         put_sum<NGP>(fx.lw_up_clear, o0, (double)ts_clear, valid, lead);
         if (valid) fx.lw_up_toa_clear_g[og] = (double)ts_clear;
       }
+      if (valid && fx.lw_up_band) {      // :956-967
+        spec_put(fx.lw_up_band, ng, g, o0, (double)ts.sum());
+        spec_put(fx.lw_dn_band, ng, g, o0, 0.0);
+        if (do_clear) { spec_put(fx.lw_up_clear_band, ng, g, o0, (double)ts_clear); spec_put(fx.lw_dn_clear_band, ng, g, o0, 0.0); }
+      }
     }
     for (int jlev = 1; jlev <= nlev; ++jlev) {
       const int jl = jlev - 1;
@@ -1239,6 +1273,14 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
       if (do_clear) {
         put_sum<NGP>(fx.lw_up_clear, oh, (double)flux_up_clear, valid, lead);
         put_sum<NGP>(fx.lw_dn_clear, oh, (double)flux_dn_clear, valid, lead);
+      }
+      if (valid && fx.lw_up_band) {      // spectral flux profiles, radiation_spartacus_lw.F90:1033-1048
+        spec_put(fx.lw_up_band, ng, g, oh, (double)flux_up_above.sum());
+        spec_put(fx.lw_dn_band, ng, g, oh, (double)flux_dn_above.sum());
+        if (do_clear) {
+          spec_put(fx.lw_up_clear_band, ng, g, oh, (double)flux_up_clear);
+          spec_put(fx.lw_dn_clear_band, ng, g, oh, (double)flux_dn_clear);
+        }
       }
     }
     if (valid) {

@@ -4,8 +4,8 @@
  *   solver_spartacus_sw  radiation/radiation_spartacus_sw.F90:64-1600  + step_migrations :1606-1721
  *   solver_spartacus_lw  radiation/radiation_spartacus_lw.F90:49-1085
  *   calc_lw_derivatives_matrix  radiation/radiation_lw_derivatives.F90:138-193
- * for nregions = 3, every shortwave entrapment option, with and without 3-D effects, without
- * do_save_spectral_flux.  It keeps the reference's structure: per column, arrays (ng, nreg, nreg, nlev) with the
+ * for nregions = 3, every shortwave entrapment option, with and without 3-D effects, with the spectral flux
+ * profiles of do_save_spectral_flux.  It keeps the reference's structure: per column, arrays (ng, nreg, nreg, nlev) with the
  * g-point index fastest, the loops over g inside every operation, and the matrix algebra of oracle_matrix.c
  * (itself pinned to the reference's radiation_matrix.F90 at 1e-12, tests/test_oracle_matrix.py).
  *
@@ -44,6 +44,32 @@ static const double kLwDiffusivity = 1.66;
 
 static real_t rmin(real_t a, real_t b) { return a < b ? a : b; }
 static real_t rmax(real_t a, real_t b) { return a > b ? a : b; }
+/* ---- spectral flux profiles (do_save_spectral_flux): indexed_sum / add_indexed_sum of radiation_flux.F90 in working
+ *      precision into the (nspec, ncol, nlev+1) arrays; x is (ng, nreg), summed over its regions first --------------- */
+#define SPX(a, nspec, is, jcol, l) (a)[(size_t)(is) + (size_t)(nspec) * ((size_t)(jcol) + (size_t)ncol * (l))]
+static void sp_spec(int add, real_t scale, int ng, int nreg, int ncol, int jcol, int l, const real_t* x, const int32_t* ispec, int nspec,
+                    double* dest)
+{
+  if (!dest) return;
+  if (!add) for (int is = 0; is < nspec; ++is) SPX(dest, nspec, is, jcol, l) = 0.0;
+  for (int g = 0; g < ng; ++g) {
+    real_t v = x[g];
+    for (int r = 1; r < nreg; ++r) v += x[g + (size_t)ng * r];
+    SPX(dest, nspec, ispec[g] - 1, jcol, l) = (double)((real_t)SPX(dest, nspec, ispec[g] - 1, jcol, l) + v);
+  }
+  if (scale != (real_t)1) for (int is = 0; is < nspec; ++is) SPX(dest, nspec, is, jcol, l) = (double)(scale * (real_t)SPX(dest, nspec, is, jcol, l));
+}
+static void sp_spec_copy(int ncol, int jcol, int l, int nspec, const double* src, double* dest)
+{
+  if (!dest || !src) return;
+  for (int is = 0; is < nspec; ++is) SPX(dest, nspec, is, jcol, l) = SPX(src, nspec, is, jcol, l);
+}
+static void sp_spec_zero(int ncol, int jcol, int nlev, int nspec, double* dest)
+{
+  if (!dest) return;
+  for (int l = 0; l <= nlev; ++l) for (int is = 0; is < nspec; ++is) SPX(dest, nspec, is, jcol, l) = 0.0;
+}
+
 #ifdef ORACLE_SINGLE
 #define R_EPS 1.1920929e-07f
 #else
@@ -320,6 +346,14 @@ void oracle_solver_spartacus_sw(const ecrad_config_t* c, int ncol, int nlev, int
       if (c->do_clear) {
         zero_profile(flux->sw_dn_clear, ncol, nlev, jcol); zero_profile(flux->sw_up_clear, ncol, nlev, jcol);
         zero_profile(flux->sw_dn_direct_clear, ncol, nlev, jcol);
+      }
+      if (c->do_save_spectral_flux) {       /* :357-370 */
+        sp_spec_zero(ncol, jcol, nlev, c->n_spec_sw, flux->sw_dn_band); sp_spec_zero(ncol, jcol, nlev, c->n_spec_sw, flux->sw_up_band);
+        sp_spec_zero(ncol, jcol, nlev, c->n_spec_sw, flux->sw_dn_direct_band);
+        if (c->do_clear) {
+          sp_spec_zero(ncol, jcol, nlev, c->n_spec_sw, flux->sw_dn_clear_band); sp_spec_zero(ncol, jcol, nlev, c->n_spec_sw, flux->sw_up_clear_band);
+          sp_spec_zero(ncol, jcol, nlev, c->n_spec_sw, flux->sw_dn_direct_clear_band);
+        }
       }
       for (int g = 0; g < ng; ++g) {
         flux->sw_dn_diffuse_surf_g[g + (size_t)ng * jcol] = 0.0; flux->sw_dn_direct_surf_g[g + (size_t)ng * jcol] = 0.0;
@@ -627,6 +661,19 @@ void oracle_solver_spartacus_sw(const ecrad_config_t* c, int ncol, int nlev, int
       for (int g = 0; g < ng; ++g) flux->sw_up_toa_clear_g[g + (size_t)ng * jcol] = (double)flux_up_clear[g];
       if (flux->sw_dn_direct_clear) FL(flux->sw_dn_direct_clear, jcol, 0) = FL(flux->sw_dn_clear, jcol, 0);
     }
+    const int32_t* isp = c->i_spec_from_reordered_g_sw;
+    const int nsp = c->n_spec_sw;
+    const int do_spec = c->do_save_spectral_flux && flux->sw_up_band;
+    if (do_spec) {        /* :1403-1424 */
+      sp_spec(0, 1, ng, NREG, ncol, jcol, 0, flux_up_above, isp, nsp, flux->sw_up_band);
+      sp_spec(0, mu0, ng, NREG, ncol, jcol, 0, direct_dn_below, isp, nsp, flux->sw_dn_band);
+      sp_spec_copy(ncol, jcol, 0, nsp, flux->sw_dn_band, flux->sw_dn_direct_band);
+      if (c->do_clear) {
+        sp_spec_copy(ncol, jcol, 0, nsp, flux->sw_dn_band, flux->sw_dn_clear_band);
+        sp_spec(0, 1, ng, 1, ncol, jcol, 0, flux_up_clear, isp, nsp, flux->sw_up_clear_band);
+        sp_spec_copy(ncol, jcol, 0, nsp, flux->sw_dn_clear_band, flux->sw_dn_direct_clear_band);
+      }
+    }
     for (int jlev = 1; jlev <= nlev; ++jlev) {
       const int jl = jlev - 1;
       const real_t *refl = &M4(reflectance, 0, 0, 0, jl), *tran = &M4(transmittance, 0, 0, 0, jl),
@@ -678,6 +725,18 @@ void oracle_solver_spartacus_sw(const ecrad_config_t* c, int ncol, int nlev, int
       if (c->do_clear) {
         FL(flux->sw_up_clear, jcol, jlev) = sum_all(flux_up_clear, ng);
         FL(flux->sw_dn_clear, jcol, jlev) = (double)(sw_dn_clear + (real_t)sum_all(flux_dn_clear, ng));
+      }
+      if (do_spec) {      /* :1472-1493 (direct part), :1557-1572 */
+        sp_spec(0, mu0, ng, NREG, ncol, jcol, jlev, direct_dn_above, isp, nsp, flux->sw_dn_band);
+        sp_spec_copy(ncol, jcol, jlev, nsp, flux->sw_dn_band, flux->sw_dn_direct_band);
+        sp_spec(0, 1, ng, NREG, ncol, jcol, jlev, flux_up_above, isp, nsp, flux->sw_up_band);
+        sp_spec(1, 1, ng, NREG, ncol, jcol, jlev, flux_dn_above, isp, nsp, flux->sw_dn_band);
+        if (c->do_clear) {
+          sp_spec(0, mu0, ng, 1, ncol, jcol, jlev, direct_dn_clear, isp, nsp, flux->sw_dn_clear_band);
+          sp_spec_copy(ncol, jcol, jlev, nsp, flux->sw_dn_clear_band, flux->sw_dn_direct_clear_band);
+          sp_spec(0, 1, ng, 1, ncol, jcol, jlev, flux_up_clear, isp, nsp, flux->sw_up_clear_band);
+          sp_spec(1, 1, ng, 1, ncol, jcol, jlev, flux_dn_clear, isp, nsp, flux->sw_dn_clear_band);
+        }
       }
     }
     for (int g = 0; g < ng; ++g) {
@@ -972,6 +1031,17 @@ void oracle_solver_spartacus_lw(const ecrad_config_t* c, int ncol, int nlev, int
       FL(flux->lw_up_clear, jcol, 0) = sum_all(&G2(total_source_clear, 0, 0), ng);
       for (int g = 0; g < ng; ++g) flux->lw_up_toa_clear_g[g + (size_t)ng * jcol] = (double)G2(total_source_clear, g, 0);
     }
+    const int32_t* isp = c->i_spec_from_reordered_g_lw;
+    const int nsp = c->n_spec_lw;
+    const int do_spec = c->do_save_spectral_flux && flux->lw_up_band;
+    if (do_spec) {        /* radiation_spartacus_lw.F90:956-967 */
+      sp_spec(0, 1, ng, nreg, ncol, jcol, 0, &V3(total_source, 0, 0, 0), isp, nsp, flux->lw_up_band);
+      for (int is = 0; is < nsp; ++is) SPX(flux->lw_dn_band, nsp, is, jcol, 0) = 0.0;
+      if (c->do_clear) {
+        sp_spec(0, 1, ng, 1, ncol, jcol, 0, &G2(total_source_clear, 0, 0), isp, nsp, flux->lw_up_clear_band);
+        for (int is = 0; is < nsp; ++is) SPX(flux->lw_dn_clear_band, nsp, is, jcol, 0) = 0.0;
+      }
+    }
     for (int jlev = 1; jlev <= nlev; ++jlev) {
       const int jl = jlev - 1;
       const real_t *refl = &M4(reflectance, 0, 0, 0, jl), *tran = &M4(transmittance, 0, 0, 0, jl);
@@ -1010,6 +1080,14 @@ void oracle_solver_spartacus_lw(const ecrad_config_t* c, int ncol, int nlev, int
       FL(flux->lw_up, jcol, jlev) = sum_g_then_reg(ng, flux_up_above);
       FL(flux->lw_dn, jcol, jlev) = sum_g_then_reg(ng, flux_dn_above);
       if (c->do_clear) { FL(flux->lw_up_clear, jcol, jlev) = sum_all(flux_up_clear, ng); FL(flux->lw_dn_clear, jcol, jlev) = sum_all(flux_dn_clear, ng); }
+      if (do_spec) {      /* :1033-1048 */
+        sp_spec(0, 1, ng, nreg, ncol, jcol, jlev, flux_up_above, isp, nsp, flux->lw_up_band);
+        sp_spec(0, 1, ng, nreg, ncol, jcol, jlev, flux_dn_above, isp, nsp, flux->lw_dn_band);
+        if (c->do_clear) {
+          sp_spec(0, 1, ng, 1, ncol, jcol, jlev, flux_up_clear, isp, nsp, flux->lw_up_clear_band);
+          sp_spec(0, 1, ng, 1, ncol, jcol, jlev, flux_dn_clear, isp, nsp, flux->lw_dn_clear_band);
+        }
+      }
     }
     for (int g = 0; g < ng; ++g) {
       flux->lw_dn_surf_g[g + (size_t)ng * jcol] = (double)sum_reg(ng, flux_dn_above, g);

@@ -54,6 +54,7 @@ CASES = {
     # (a low threshold: the g-point from which the 3-D treatment is switched off lies in an EARLIER launch for most chunks)
     "spartacus_tight_caps": dict(sw_solver="SPARTACUS", do_3d_effects=True, max_gas_od_3d=0.05, max_3d_transfer_rate=1.0, do_lw_aerosol_scattering=False),
     "spartacus_expm_everywhere_noaer": dict(sw_solver="SPARTACUS", do_3d_effects=True, use_expm_everywhere=True, use_aerosols=False, do_lw_aerosol_scattering=False),
+    "spartacus_spectral": dict(sw_solver="SPARTACUS", do_3d_effects=True, do_save_spectral_flux=True, do_lw_aerosol_scattering=False),   # test_spartacus as its namelist has it
     "spartacus_no_3d": dict(sw_solver="SPARTACUS", do_3d_effects=False, do_lw_aerosol_scattering=False),
 }
 

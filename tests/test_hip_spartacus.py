@@ -45,6 +45,11 @@ CASES = {
     "sw64": dict(gas_optics_sw_override_file_name="ecckd-1.2_sw_climate_window-64b_ckd-definition.nc"),
     # 96 shortwave g-points: three launches of 32 lanes per column (see also the RRTMG cases of test_hip_rrtmg.py)
     "sw96": dict(gas_optics_sw_override_file_name="ecckd-1.4_sw_climate_vfine-96b_ckd-definition.nc"),
+    # spectral flux profiles (do_save_spectral_flux is on in both of the reference's test namelists, hence in its
+    # test_spartacus / test_ecckd_spartacus runs): one interval per g-point, and per band (per-g temporaries summed afterwards)
+    "spectral": dict(do_save_spectral_flux=True),
+    "spectral_bands": dict(do_save_spectral_flux=True, do_cloud_aerosol_per_sw_g_point=False, do_cloud_aerosol_per_lw_g_point=False),
+    "spectral_noclear_no3d": dict(do_save_spectral_flux=True, do_clear=False, do_3d_effects=False),
     "sw96_tight_caps": dict(gas_optics_sw_override_file_name="ecckd-1.4_sw_climate_vfine-96b_ckd-definition.nc", max_gas_od_3d=0.5),
 }
 

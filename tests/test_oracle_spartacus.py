@@ -129,3 +129,26 @@ def test_expm_everywhere_agrees_with_meador_weaver_in_clear_layers(oracle_lib):
     b = spartacus(oracle_lib, do_3d_effects=True, use_expm_everywhere=True).arrays
     for name in ("sw_up", "sw_dn", "lw_up", "lw_dn"):
         assert rel_err(b[name], a[name]) < 5.0e-5, name
+
+
+@pytest.mark.parametrize("per_band", [False, True], ids=["gpoints", "bands"])
+def test_spectral_flux_profiles(oracle_lib, per_band):
+    """do_save_spectral_flux (radiation_spartacus_sw.F90:1403-1424, :1472-1493, :1557-1572; _lw.F90:956-967, :1033-1048; on in
+    both of the reference's test namelists, hence in its test_spartacus / test_ecckd_spartacus runs): the shortwave profiles
+    of the 1-D limit are those of the (golden-pinned) Tripleclouds restatement, and the intervals of every profile add up to
+    the broadband one."""
+    kw = dict(do_save_spectral_flux=True)
+    if per_band:
+        kw.update(do_cloud_aerosol_per_sw_g_point=False, do_cloud_aerosol_per_lw_g_point=False)
+    tc, _, _ = run_case(make_config("Tripleclouds", **kw), oracle_lib.backend)
+    sp1d, _, _ = run_case(make_config("SPARTACUS", do_3d_effects=False, i_3d_sw_entrapment=IEntrapmentZero, max_cloud_od=1.0e30, **kw),
+                          oracle_lib.backend)
+    for name in ("sw_up_band", "sw_dn_band", "sw_dn_direct_band", "sw_up_clear_band", "sw_dn_clear_band", "sw_dn_direct_clear_band"):
+        assert sp1d.arrays[name].shape == tc.arrays[name].shape
+        assert rel_err(sp1d.arrays[name], tc.arrays[name]) < 1.0e-12, name
+    sp3d, _, _ = run_case(make_config("SPARTACUS", do_3d_effects=True, **kw), oracle_lib.backend)
+    a = sp3d.arrays
+    for spec, broad in (("sw_up_band", "sw_up"), ("sw_dn_band", "sw_dn"), ("sw_dn_direct_band", "sw_dn_direct"),
+                        ("sw_up_clear_band", "sw_up_clear"), ("sw_dn_clear_band", "sw_dn_clear"), ("sw_dn_direct_clear_band", "sw_dn_direct_clear"),
+                        ("lw_up_band", "lw_up"), ("lw_dn_band", "lw_dn"), ("lw_up_clear_band", "lw_up_clear"), ("lw_dn_clear_band", "lw_dn_clear")):
+        assert rel_err(a[spec].sum(axis=-1), a[broad]) < 1.0e-12, spec      # numpy (half_level, column, interval)
