@@ -694,8 +694,10 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
         const LwCoef c = ASCAT ? ref_trans_lw(od, ssa, asym, planck_top, planck_bot) : no_scattering_lw(od, planck_top, planck_bot);
         s.pair(TL_A0, lev, tid) = make_double2(c.transmittance, c.source_up);
         if (ASCAT) s.pair(TL_SD1, lev, tid) = make_double2(c.source_dn, c.reflectance);
-        else s.single(TL_SD1, lev, tid) = c.source_dn;
-        if (L.D(F_FRAC, slot) > 0.0) {
+        const bool layer_cloudy = L.D(F_FRAC, slot) > 0.0;
+        // (without aerosol scattering the downward source of a clear layer is only needed from cloud top down)
+        if (!ASCAT && (layer_cloudy || cloudy.any())) s.single(TL_SD1, lev, tid) = c.source_dn;
+        if (layer_cloudy) {
           if (!cloudy.any()) { ict = lev; fdn_ctop = fdn_c; }
           cloudy.set(lev);
           const CloudLayer cl = cloud_layer<false, sizeof(TAB) == 8>(kernarg_block<SpectralArgs>().cfg, L, slot, ib);
@@ -793,7 +795,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TC_MIN_WAVES) void lw_tc_kernel(Spect
           if (l >= 0) {
             a0[k] = s.pair(TL_A0, l, tid);
             if (ASCAT) { const double2 t = s.pair(TL_SD1, l, tid); sd1[k] = t.x; r1[k] = t.y; }
-            else sd1[k] = s.single(TL_SD1, l, tid);
+            else if (l >= ict_min) sd1[k] = s.single(TL_SD1, l, tid);      // (written from this column's cloud top down, used from there)
             if (cloudy.test(l)) {
 #pragma unroll
               for (int r = 0; r < 2; ++r) { rt[k][r] = s.pair(TL_RT(r + 1), l, tid); ss[k][r] = s.pair(TL_SS(r + 1), l, tid); }
