@@ -1,11 +1,7 @@
 #!/bin/bash
+# one GPU call: the final build -- full GPU suite, smoke, default-run profile (tools/profile.sh: rocprofv3 stats + PMC passes + the bench line)
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q -k "tripleclouds or Tripleclouds or tc or golden or targets" 2>&1 | tail -4
-run() { python bench.py --steps 8 --warmup 2 --no-cpu-baseline --headline-only --workload $1 2>/dev/null | python -c "
-import sys, json
-for line in sys.stdin:
-    if line.startswith('{'):
-        d = json.loads(line); st = d['roofline']['stage_ms']
-        print('%-10s %-26s %10.0f col/s  lw %7.3f  sw %7.3f' % ('$2', '$1', d['value'], st['lw'], st['sw']))
-"; }
-for rep in 1 2; do run tripleclouds_ecckd32 new; run tripleclouds_rrtmg new; done
+python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee gpurun_out/r02_zs_tests.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee -a gpurun_out/r02_zs_tests.log
+tools/profile.sh r02_zs --steps 20 --warmup 5 > gpurun_out/r02_zs_profile.log 2>&1
+tail -c 400 gpurun_out/r02_zs/bench.json
