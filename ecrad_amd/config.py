@@ -115,6 +115,7 @@ class Config:
     i_aerosol_type_map: List[int] = field(default_factory=list)
     do_save_spectral_flux: bool = False
     do_save_gpoint_flux: bool = False
+    do_save_radiative_properties: bool = False      # radiation() dumps the stage-interface arrays (radiation_interface.F90:403-419)
     n_spec_sw: int = 0
     n_spec_lw: int = 0
     i_spec_from_reordered_g_sw: object = None
@@ -181,7 +182,7 @@ class Config:
         nml = read_namelist(file_name).get("radiation", {})
         c = self
         simple = [
-            "do_sw", "do_lw", "do_sw_direct", "do_clear", "do_save_spectral_flux", "do_save_gpoint_flux",
+            "do_sw", "do_lw", "do_sw_direct", "do_clear", "do_save_spectral_flux", "do_save_gpoint_flux", "do_save_radiative_properties",
             "do_surface_sw_spectral_flux", "do_lw_derivatives", "do_toa_spectral_flux",
             "do_lw_aerosol_scattering", "do_lw_cloud_scattering", "directory_name",
             "aerosol_optics_override_file_name", "cloud_pdf_override_file_name",

@@ -331,6 +331,61 @@ def save_fluxes(path: str, config: Config, thermodynamics: Thermodynamics, flux:
     (write_nc4 if is_hdf5_file else write_nc)(path, dims, variables, attrs=attrs, double=is_double_precision)
 
 
+def save_radiative_properties(path: str, config: Config, nlev: int, istartcol: int, iendcol: int, single_level, thermodynamics,
+                              cloud, props: dict) -> None:
+    """save_radiative_properties (radiation_save.F90:716-1021): the intermediate arrays of radiation() for columns
+    istartcol..iendcol -- variable and dimension names, the conditions on each variable and lw_emissivity = 1 - lw_albedo
+    as in the reference.  ``props``: Radiation.optics(), arrays (column, level[+1], g-point or band)."""
+    c0, c1 = istartcol - 1, iendcol
+    cols = lambda a: np.ascontiguousarray(np.asarray(a)[..., c0:c1].T)        # (nlev, ncol) -> (column, level)
+    dims = {"column": c1 - c0, "level": nlev, "half_level": nlev + 1}
+    v = {}
+    v["pressure_hl"] = (("column", "half_level"), cols(thermodynamics.pressure_hl), {"units": "Pa"})
+    if thermodynamics.h2o_sat_liq is not None and config.use_aerosols:
+        v["q_sat_liquid"] = (("column", "level"), cols(thermodynamics.h2o_sat_liq), {"units": "kg kg-1"})
+    if config.do_sw:
+        v["cos_solar_zenith_angle"] = (("column",), np.asarray(single_level.cos_sza)[c0:c1], {"units": "1"})
+    if config.do_clouds:
+        dims["level_interface"] = nlev - 1
+        v["cloud_fraction"] = (("column", "level"), cols(cloud.fraction), {"units": "1"})
+        v["overlap_param"] = (("column", "level_interface"), cols(cloud.overlap_param), {"units": "1"})
+    if config.do_lw:
+        dims["gpoint_lw"] = config.n_g_lw
+        v["planck_hl"] = (("column", "half_level", "gpoint_lw"), props["planck_hl"], {"units": "W m-2"})
+        v["lw_emission"] = (("column", "gpoint_lw"), props["lw_emission"], {"units": "W m-2"})
+        v["lw_emissivity"] = (("column", "gpoint_lw"), 1.0 - props["lw_albedo"], {"units": "1"})
+        v["od_lw"] = (("column", "level", "gpoint_lw"), props["od_lw"], {"units": "1"})
+        if config.do_lw_aerosol_scattering:
+            v["ssa_lw"] = (("column", "level", "gpoint_lw"), props["ssa_lw"], {"units": "1"})
+            v["asymmetry_lw"] = (("column", "level", "gpoint_lw"), props["g_lw"], {"units": "1"})
+        if config.do_clouds:
+            dims["band_lw"] = config.n_bands_lw
+            v["od_lw_cloud"] = (("column", "level", "band_lw"), props["od_lw_cloud"], {"units": "1"})
+            if config.do_lw_cloud_scattering:
+                v["ssa_lw_cloud"] = (("column", "level", "band_lw"), props["ssa_lw_cloud"], {"units": "1"})
+                v["asymmetry_lw_cloud"] = (("column", "level", "band_lw"), props["g_lw_cloud"], {"units": "1"})
+    if config.do_sw:
+        dims["gpoint_sw"] = config.n_g_sw
+        v["incoming_sw"] = (("column", "gpoint_sw"), props["incoming_sw"], {"units": "W m-2"})
+        v["sw_albedo"] = (("column", "gpoint_sw"), props["sw_albedo_diffuse"], {"units": "1"})
+        v["sw_albedo_direct"] = (("column", "gpoint_sw"), props["sw_albedo_direct"], {"units": "1"})
+        for name, key in (("od_sw", "od_sw"), ("ssa_sw", "ssa_sw"), ("asymmetry_sw", "g_sw")):
+            v[name] = (("column", "level", "gpoint_sw"), props[key], {"units": "1"})
+        if config.do_clouds:
+            dims["band_sw"] = config.n_bands_sw
+            for name, key in (("od_sw_cloud", "od_sw_cloud"), ("ssa_sw_cloud", "ssa_sw_cloud"), ("asymmetry_sw_cloud", "g_sw_cloud")):
+                v[name] = (("column", "level", "band_sw"), props[key], {"units": "1"})
+    if config.do_clouds:
+        if cloud.fractional_std is not None:
+            v["fractional_std"] = (("column", "level"), cols(cloud.fractional_std), {"units": "1"})
+        if getattr(cloud, "inv_cloud_effective_size", None) is not None:
+            v["inv_cloud_effective_size"] = (("column", "level"), cols(cloud.inv_cloud_effective_size), {"units": "m-1"})
+        if getattr(cloud, "inv_inhom_effective_size", None) is not None:
+            v["inv_inhom_effective_size"] = (("column", "level"), cols(cloud.inv_inhom_effective_size), {"units": "m-1"})
+    write_nc(path, dims, v, attrs={"title": "Radiative property profiles from the ecrad_amd MI355X radiation path", "source": "ecrad_amd"},
+             double=True)
+
+
 def save_net_fluxes(path: str, config: Config, thermodynamics: Thermodynamics, flux: Flux,
                     is_double_precision: bool = False, experiment_name: str = "", is_hdf5_file: bool = False) -> None:
     """save_net_fluxes (radiation_save.F90:464-715): net (down minus up) flux profiles and the surface / TOA downwelling

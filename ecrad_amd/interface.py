@@ -547,8 +547,43 @@ class Radiation:
         else:
             gas.set_units(IVolumeMixingRatio)
 
+    def optics(self, ncol, nlev, istartcol, iendcol, single_level, thermodynamics, gas, cloud, aerosol) -> dict:
+        """The arrays radiation() passes between its stages (radiation_interface.F90:260-301) for columns
+        istartcol..iendcol, as numpy arrays (ncol_local, nlev[+1], ng): ecrad_hip_optics."""
+        cin, keep = build_inputs_struct(self.config, ncol, nlev, single_level, thermodynamics, gas, cloud, aerosol)
+        c, nloc = self.config, iendcol - istartcol + 1
+        shapes = {"od_lw": (nloc, nlev, c.n_g_lw), "ssa_lw": (nloc, nlev, c.n_g_lw), "g_lw": (nloc, nlev, c.n_g_lw),
+                  "od_sw": (nloc, nlev, c.n_g_sw), "ssa_sw": (nloc, nlev, c.n_g_sw), "g_sw": (nloc, nlev, c.n_g_sw),
+                  "planck_hl": (nloc, nlev + 1, c.n_g_lw), "lw_emission": (nloc, c.n_g_lw), "lw_albedo": (nloc, c.n_g_lw),
+                  "sw_albedo_direct": (nloc, c.n_g_sw), "sw_albedo_diffuse": (nloc, c.n_g_sw), "incoming_sw": (nloc, c.n_g_sw),
+                  "od_lw_cloud": (nloc, nlev, c.n_bands_lw), "ssa_lw_cloud": (nloc, nlev, c.n_bands_lw),
+                  "g_lw_cloud": (nloc, nlev, c.n_bands_lw), "od_sw_cloud": (nloc, nlev, c.n_bands_sw),
+                  "ssa_sw_cloud": (nloc, nlev, c.n_bands_sw), "g_sw_cloud": (nloc, nlev, c.n_bands_sw)}
+        want = {k: v for k, v in shapes.items()
+                if (c.do_lw if "lw" in k or k == "planck_hl" else c.do_sw) and (c.do_clouds or not k.endswith("_cloud"))}
+        if self.backend == "hip":
+            out = abi.Optics()
+            arrs = {k: np.zeros(v) for k, v in want.items()}
+            for k, a in arrs.items():
+                setattr(out, k, abi.dptr(a))
+            self._check(self.lib.ecrad_hip_optics(self.handle, ncol, nlev, istartcol, iendcol, C.byref(cin), C.byref(out)),
+                        "ecrad_hip_optics")
+        else:
+            fn = getattr(self.backend, "optics", None)
+            if fn is None:
+                raise RuntimeError("this backend has no optics()")
+            arrs = {k: a for k, a in fn(self.config, self.cconfig, ncol, nlev, istartcol, iendcol, cin).items() if k in want}
+        del keep
+        return arrs
+
     def radiation(self, ncol, nlev, istartcol, iendcol, single_level, thermodynamics, gas,
                   cloud, aerosol, flux) -> None:
+        if self.config.do_save_radiative_properties:       # radiation_interface.F90:403-419
+            from .driver import save_radiative_properties
+            name = "radiative_properties.nc" if (istartcol == 1 and iendcol == ncol) else \
+                f"radiative_properties_{istartcol:04d}-{iendcol:04d}.nc"
+            props = self.optics(ncol, nlev, istartcol, iendcol, single_level, thermodynamics, gas, cloud, aerosol)
+            save_radiative_properties(name, self.config, nlev, istartcol, iendcol, single_level, thermodynamics, cloud, props)
         cin, keep = build_inputs_struct(self.config, ncol, nlev, single_level, thermodynamics, gas, cloud, aerosol)
         cflux = build_flux_struct(flux)
         if self.backend == "hip":

@@ -124,6 +124,9 @@ def optics(config, cconfig, ncol, nlev, istartcol, iendcol, cin) -> dict:
     return arrs
 
 
+backend.optics = optics        # (Radiation.optics with the oracle as the backend: tests of save_radiative_properties)
+
+
 def optics_shapes(config, nlev, nloc) -> dict:
     return {
         "od_lw": (nloc, nlev, config.n_g_lw), "ssa_lw": (nloc, nlev, config.n_g_lw), "g_lw": (nloc, nlev, config.n_g_lw),

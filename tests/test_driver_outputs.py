@@ -84,3 +84,57 @@ def test_driver_main_writes_net_fluxes_and_diagnostics(tmp_path, oracle_lib, mon
         assert f.exists("flux_net_sw") and not f.exists("flux_up_sw")
     with NcFile(str(tmp_path / "diag.nc")) as f:
         assert f.get("flux_dn_sw_surf").shape == (32, 2)
+
+
+def test_radiative_properties_file(tmp_path, oracle_lib, monkeypatch):
+    """do_save_radiative_properties (radiation_interface.F90:403-419 -> save_radiative_properties, radiation_save.F90:716-1021):
+    radiation() itself dumps the arrays it passes between its stages; the reference's variable names and conditions, the
+    values those of the optics entry point, the file name that of a whole-range or of a sub-range call."""
+    monkeypatch.chdir(tmp_path)
+    config = make_config("Tripleclouds", do_save_radiative_properties=True)
+    flux, th, rad = run_case(config, oracle_lib.backend)
+    assert os.path.exists("radiative_properties.nc")
+    with NcFile("radiative_properties.nc") as f:
+        names = set(f._f.variables)
+        want = {"pressure_hl", "q_sat_liquid", "cos_solar_zenith_angle", "cloud_fraction", "overlap_param", "planck_hl", "lw_emission",
+                "lw_emissivity", "od_lw", "od_lw_cloud", "ssa_lw_cloud", "asymmetry_lw_cloud", "incoming_sw", "sw_albedo",
+                "sw_albedo_direct", "od_sw", "ssa_sw", "asymmetry_sw", "od_sw_cloud", "ssa_sw_cloud", "asymmetry_sw_cloud",
+                "fractional_std"}       # (the cloud effective sizes are only there for SPARTACUS)
+        assert names == want, names ^ want
+        assert f.get("od_sw").shape == (32, 137, 32) and f.get("planck_hl").shape == (32, 138, 32) and f.get("od_lw_cloud").shape == (32, 137, 32)
+        od_sw, ssa_sw, emis = f.get("od_sw"), f.get("ssa_sw"), f.get("lw_emissivity")
+        assert np.all(od_sw > 0.0) and np.all((ssa_sw >= 0.0) & (ssa_sw <= 1.0)) and np.all((emis > 0.9) & (emis <= 1.0))
+        assert np.array_equal(f.get("pressure_hl"), th.pressure_hl.T)
+        # the incoming flux at the top of the atmosphere adds up to the solar irradiance
+    # a sub-range call names its file after the range and holds that range only
+    from helpers import load_meridian
+    from ecrad_amd.types import Flux
+    ncol, nlev, sl, th2, gas, cloud, aer = load_meridian(config)
+    rad.set_gas_units(gas)
+    th2.calc_saturation_wrt_liquid()
+    rad.radiation(ncol, nlev, 5, 12, sl, th2, gas, cloud, aer, Flux.allocate(config, ncol, nlev))
+    with NcFile("radiative_properties_0005-0012.nc") as g, NcFile("radiative_properties.nc") as f:
+        assert g.get("od_lw").shape == (8, 137, 32)
+        assert np.array_equal(g.get("od_lw"), f.get("od_lw")[4:12])
+        assert np.array_equal(g.get("cos_solar_zenith_angle"), f.get("cos_solar_zenith_angle")[4:12])
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_radiative_properties_file_from_the_hip_path(tmp_path, oracle_lib, monkeypatch):
+    """The same file written by radiation() on the GPU (ecrad_hip_optics) and with the oracle as the backend."""
+    files = {}
+    for tag, backend in (("hip", "hip"), ("oracle", oracle_lib.backend)):
+        d = tmp_path / tag
+        d.mkdir()
+        monkeypatch.chdir(d)
+        _, _, rad = run_case(make_config("McICA", do_save_radiative_properties=True, do_lw_aerosol_scattering=True), backend)
+        if tag == "hip":
+            rad.close()
+        files[tag] = str(d / "radiative_properties.nc")
+    with NcFile(files["hip"]) as a, NcFile(files["oracle"]) as b:
+        assert set(a._f.variables) == set(b._f.variables) and "ssa_lw" in a._f.variables
+        for name in a._f.variables:
+            assert rel_err(a.get(name), b.get(name), floor_frac=1e-9) < 1e-10, name
