@@ -32,6 +32,8 @@ class DriverConfig:
     iverbose: int = 2
     do_write_double_precision: bool = False
     do_save_net_fluxes: bool = False
+    do_save_inputs: bool = False             # the inputs as radiation() gets them, to "inputs.nc" (ecrad_driver.F90:283-289)
+    do_save_aerosol_optics: bool = False     # the mapped aerosol tables, to "aerosol_optics.nc" (ecrad_driver.F90:224-226)
     do_write_hdf5: bool = False              # netCDF-4/HDF5 output instead of classic netCDF (ecrad_driver_config.F90:119)
     # shortwave diagnostics in user-specified wavelength intervals (m), written to a second file
     # (driver/ecrad_driver_config.F90:72-82: the first negative bound ends the list)
@@ -331,6 +333,63 @@ def save_fluxes(path: str, config: Config, thermodynamics: Thermodynamics, flux:
     (write_nc4 if is_hdf5_file else write_nc)(path, dims, variables, attrs=attrs, double=is_double_precision)
 
 
+def save_inputs(path: str, config: Config, single_level, thermodynamics, gas, cloud, aerosol, lat=None, lon=None) -> None:
+    """save_inputs (radiation_save.F90:1026-1320): the input variables of radiation() in a file the offline driver can read
+    back -- water vapour and ozone as mass mixing ratios ("q", "o3_mmr"), the other gases present as volume mixing ratios."""
+    from .tables import GAS_LOWER_CASE_NAMES
+    from .types import IMassMixingRatio, IVolumeMixingRatio
+    T = lambda a: np.ascontiguousarray(np.asarray(a).T)            # numpy (x, column) -> netCDF (column, x)
+    nhl, ncol = thermodynamics.pressure_hl.shape
+    nlev = nhl - 1
+    dims = {"column": ncol, "level": nlev, "half_level": nlev + 1}
+    v = {}
+    do_aerosol = config.use_aerosols and aerosol is not None
+    dims["sw_albedo_band"] = single_level.sw_albedo.shape[0]
+    dims["lw_emissivity_band"] = single_level.lw_emissivity.shape[0]
+    v["solar_irradiance"] = ((), np.float64(single_level.solar_irradiance), {"units": "W m-2"})
+    if lat is not None:
+        v["lat"] = (("column",), np.asarray(lat, dtype=np.float64), {"units": "degrees_north"})
+    if lon is not None:
+        v["lon"] = (("column",), np.asarray(lon, dtype=np.float64), {"units": "degrees_east"})
+    v["skin_temperature"] = (("column",), single_level.skin_temperature, {"units": "K"})
+    if config.do_sw:
+        v["cos_solar_zenith_angle"] = (("column",), single_level.cos_sza, {"units": "1"})
+    v["sw_albedo"] = (("column", "sw_albedo_band"), T(single_level.sw_albedo), {"units": "1"})
+    if single_level.sw_albedo_direct is not None:
+        v["sw_albedo_direct"] = (("column", "sw_albedo_band"), T(single_level.sw_albedo_direct), {"units": "1"})
+    v["lw_emissivity"] = (("column", "lw_emissivity_band"), T(single_level.lw_emissivity), {"units": "1"})
+    if config.do_clouds and single_level.iseed is not None:
+        v["iseed"] = (("column",), np.asarray(single_level.iseed, dtype=np.float64), {"units": "1"})      # (is_double in the reference)
+    v["pressure_hl"] = (("column", "half_level"), T(thermodynamics.pressure_hl), {"units": "Pa"})
+    v["temperature_hl"] = (("column", "half_level"), T(thermodynamics.temperature_hl), {"units": "K"})
+    v["q"] = (("column", "level"), T(gas.get(IH2O, IMassMixingRatio)), {"units": "1"})
+    v["o3_mmr"] = (("column", "level"), T(gas.get(IO3, IMassMixingRatio)), {"units": "1"})
+    for jgas in range(1, NMaxGases + 1):
+        if gas.is_present[jgas] and jgas not in (IH2O, IO3):
+            v[GAS_LOWER_CASE_NAMES[jgas - 1] + "_vmr"] = (("column", "level"), T(gas.get(jgas, IVolumeMixingRatio)), {"units": "1"})
+    if config.do_clouds and cloud is not None:
+        v["cloud_fraction"] = (("column", "level"), T(cloud.fraction), {"units": "1"})
+        v["q_liquid"] = (("column", "level"), T(cloud.mixing_ratio[0]), {"units": "1"})
+        v["q_ice"] = (("column", "level"), T(cloud.mixing_ratio[1]), {"units": "1"})
+        v["re_liquid"] = (("column", "level"), T(cloud.effective_radius[0]), {"units": "m"})
+        v["re_ice"] = (("column", "level"), T(cloud.effective_radius[1]), {"units": "m"})
+        if cloud.overlap_param is not None:
+            dims["level_interface"] = nlev - 1
+            v["overlap_param"] = (("column", "level_interface"), T(cloud.overlap_param), {"units": "1"})
+        if cloud.fractional_std is not None:
+            v["fractional_std"] = (("column", "level"), T(cloud.fractional_std), {"units": "1"})
+        if getattr(cloud, "inv_cloud_effective_size", None) is not None:
+            v["inv_cloud_effective_size"] = (("column", "level"), T(cloud.inv_cloud_effective_size), {"units": "m-1"})
+        if getattr(cloud, "inv_inhom_effective_size", None) is not None:
+            v["inv_inhom_effective_size"] = (("column", "level"), T(cloud.inv_inhom_effective_size), {"units": "m-1"})
+    if do_aerosol:
+        dims["aerosol_type"] = aerosol.mixing_ratio.shape[0]
+        # numpy (type, level, column) -> netCDF (column, aerosol_type, level)
+        v["aerosol_mmr"] = (("column", "aerosol_type", "level"), np.ascontiguousarray(np.transpose(aerosol.mixing_ratio, (2, 0, 1))),
+                            {"units": "kg kg-1"})
+    write_nc(path, dims, v, attrs={"title": "Input profiles to the ecrad_amd MI355X radiation path", "source": "ecrad_amd"}, double=True)
+
+
 def save_radiative_properties(path: str, config: Config, nlev: int, istartcol: int, iendcol: int, single_level, thermodynamics,
                               cloud, props: dict) -> None:
     """save_radiative_properties (radiation_save.F90:716-1021): the intermediate arrays of radiation() for columns
@@ -493,6 +552,10 @@ def main(argv=None) -> int:
     ncol, nlev, single_level, thermodynamics, gas, cloud, aerosol = read_input(argv[1], config, dc)
     iend = dc.iendcol if 1 <= dc.iendcol <= ncol else ncol
     istart = max(dc.istartcol, 1)
+    if dc.do_save_aerosol_optics and config.use_aerosols and config.aerosol_optics is not None:      # driver/ecrad_driver.F90:224-226
+        config.aerosol_optics.save("aerosol_optics.nc")
+    if dc.do_save_inputs:                        # driver/ecrad_driver.F90:283-289 (before set_gas_units, lat = lon = 0)
+        save_inputs("inputs.nc", config, single_level, thermodynamics, gas, cloud, aerosol, lat=np.zeros(ncol), lon=np.zeros(ncol))
     rad.set_gas_units(gas)
     thermodynamics.calc_saturation_wrt_liquid()
     flux = Flux.allocate(config, ncol, nlev)

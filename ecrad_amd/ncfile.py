@@ -80,7 +80,7 @@ def write_nc(path: str, dims: dict, variables: dict, attrs: dict | None = None,
         for ak, av in vattrs.items():
             setattr(v, ak, av)
         if arr.ndim == 0:
-            v.assignValue(arr.astype(v.data.dtype if hasattr(v.data, "dtype") else arr.dtype))
+            v.data[...] = arr
         else:
             v[:] = arr
     f.close()

@@ -230,6 +230,24 @@ class AerosolOptics:
         self.iclass = np.zeros(0, dtype=np.int32)
         self.itype = np.zeros(0, dtype=np.int32)
 
+    def save(self, file_name: str) -> None:
+        """aerosol_optics_type%save (radiation_aerosol_optics_data.F90:405-503; the driver's do_save_aerosol_optics and the
+        reference's test_aerosol_averaging target): the optical properties in the spectral intervals of the radiation
+        scheme -- variable and dimension names as in the reference, arrays (type[, relative humidity], band)."""
+        from .ncfile import write_nc
+        dims = {"band_lw": self.n_bands_lw, "band_sw": self.n_bands_sw, "hydrophilic": self.n_type_philic,
+                "hydrophobic": self.n_type_phobic, "relative_humidity": self.nrh}
+        v = {}
+        units = {"mass_ext": "m2 kg-1", "ssa": "1", "asymmetry": "1"}
+        for kind, long_kind, dnames in (("phobic", "hydrophobic", ("hydrophobic",)), ("philic", "hydrophilic", ("hydrophilic", "relative_humidity"))):
+            for tag in ("sw", "lw"):
+                for out, attr in (("mass_ext", "mass_ext"), ("ssa", "ssa"), ("asymmetry", "g")):
+                    a = getattr(self, f"{attr}_{tag}_{kind}", None)
+                    if a is not None and getattr(self, "n_bands_" + tag) > 0:
+                        v[f"{out}_{tag}_{long_kind}"] = (dnames + ("band_" + tag,), a, {"units": units[out]})
+        write_nc(file_name, {k: n for k, n in dims.items() if n > 0}, v,
+                 attrs={"title": "Aerosol optical properties in the spectral intervals of the radiation scheme", "source": "ecrad_amd"}, double=True)
+
     def set_types(self, itypes) -> None:
         self.ntype = len(itypes)
         self.iclass = np.full(self.ntype, IAerosolClassUndefined, dtype=np.int32)

@@ -138,3 +138,59 @@ def test_radiative_properties_file_from_the_hip_path(tmp_path, oracle_lib, monke
         assert set(a._f.variables) == set(b._f.variables) and "ssa_lw" in a._f.variables
         for name in a._f.variables:
             assert rel_err(a.get(name), b.get(name), floor_frac=1e-9) < 1e-10, name
+
+
+def test_saved_inputs_read_back_as_the_inputs(tmp_path):
+    """save_inputs (radiation_save.F90:1026-1320; the driver's do_save_inputs): the file must be an input file of the driver
+    again -- what it reads from it is what was saved (the gases through their unit conversions: last bits)."""
+    from ecrad_amd.driver import DriverConfig, read_input, save_inputs
+    from helpers import MERIDIAN, NAMELIST
+    config = make_config("SPARTACUS")
+    dc = DriverConfig.read(NAMELIST)
+    a = read_input(MERIDIAN, config, dc)
+    p = str(tmp_path / "inputs.nc")
+    save_inputs(p, config, a[2], a[3], a[4], a[5], a[6], lat=np.zeros(a[0]), lon=np.zeros(a[0]))
+    # (the effective cloud sizes now come from the file, not from the namelist's parametrisation)
+    dc2 = DriverConfig.read(NAMELIST)
+    dc2.cloud_separation_scale_surface = dc2.cloud_separation_scale_toa = -1.0
+    b = read_input(p, config, dc2)
+    assert a[:2] == b[:2]
+    for obj_a, obj_b, names in ((a[2], b[2], ("cos_sza", "skin_temperature", "sw_albedo", "lw_emissivity", "sw_albedo_direct", "iseed")),
+                                (a[3], b[3], ("pressure_hl", "temperature_hl")),
+                                (a[5], b[5], ("fraction", "mixing_ratio", "effective_radius", "fractional_std", "overlap_param",
+                                              "inv_cloud_effective_size", "inv_inhom_effective_size")),
+                                (a[6], b[6], ("mixing_ratio",))):
+        for n in names:
+            x, y = getattr(obj_a, n), getattr(obj_b, n)
+            assert (x is None) == (y is None), n
+            if x is not None:
+                assert np.array_equal(np.asarray(x), np.asarray(y)), n
+    assert a[2].solar_irradiance == b[2].solar_irradiance
+    ga, gb = a[4], b[4]
+    assert ga.is_present == gb.is_present
+    from ecrad_amd.types import IVolumeMixingRatio
+    for jgas in range(1, 13):
+        if ga.is_present[jgas]:
+            assert rel_err(gb.get(jgas, IVolumeMixingRatio), ga.get(jgas, IVolumeMixingRatio), floor_frac=1e-30) < 1e-14, jgas
+    with NcFile(p) as f:
+        assert {"q", "o3_mmr", "co2_vmr", "lat", "lon", "aerosol_mmr", "re_ice", "iseed"} <= set(f._f.variables)
+
+
+def test_aerosol_optics_file(tmp_path):
+    """aerosol_optics_type%save (the driver's do_save_aerosol_optics; the reference's test_aerosol_averaging target): the
+    mapped tables under the reference's names, per g-point (ecCKD) and per band (RRTMG)."""
+    from ecrad_amd.interface import setup_radiation
+    from helpers import make_config_rrtmg
+    for config, nsw, nlw in ((make_config("Tripleclouds"), 32, 32), (make_config_rrtmg("McICA"), 14, 16)):
+        setup_radiation(config)
+        p = str(tmp_path / f"aerosol_optics_{nsw}.nc")
+        config.aerosol_optics.save(p)
+        ao = config.aerosol_optics
+        with NcFile(p) as f:
+            assert {"mass_ext_sw_hydrophobic", "ssa_sw_hydrophobic", "asymmetry_sw_hydrophobic", "mass_ext_lw_hydrophobic", "ssa_lw_hydrophobic",
+                    "asymmetry_lw_hydrophobic", "mass_ext_sw_hydrophilic", "ssa_sw_hydrophilic", "asymmetry_sw_hydrophilic",
+                    "mass_ext_lw_hydrophilic", "ssa_lw_hydrophilic", "asymmetry_lw_hydrophilic"} == set(f._f.variables)
+            assert f.get("mass_ext_sw_hydrophobic").shape == (ao.n_type_phobic, nsw)
+            assert f.get("asymmetry_lw_hydrophilic").shape == (ao.n_type_philic, ao.nrh, nlw)
+            assert np.array_equal(f.get("ssa_sw_hydrophilic"), ao.ssa_sw_philic)
+            assert np.all((f.get("ssa_lw_hydrophobic") >= 0.0) & (f.get("ssa_lw_hydrophobic") <= 1.0))
