@@ -34,6 +34,7 @@ class DriverConfig:
     do_save_net_fluxes: bool = False
     do_save_inputs: bool = False             # the inputs as radiation() gets them, to "inputs.nc" (ecrad_driver.F90:283-289)
     do_save_aerosol_optics: bool = False     # the mapped aerosol tables, to "aerosol_optics.nc" (ecrad_driver.F90:224-226)
+    do_save_cloud_optics: bool = False       # the mapped general cloud-optics tables, "hydrometeor_optics_{sw,lw}_<type>.nc" (:228-230)
     do_write_hdf5: bool = False              # netCDF-4/HDF5 output instead of classic netCDF (ecrad_driver_config.F90:119)
     # shortwave diagnostics in user-specified wavelength intervals (m), written to a second file
     # (driver/ecrad_driver_config.F90:72-82: the first negative bound ends the list)
@@ -554,6 +555,10 @@ def main(argv=None) -> int:
     istart = max(dc.istartcol, 1)
     if dc.do_save_aerosol_optics and config.use_aerosols and config.aerosol_optics is not None:      # driver/ecrad_driver.F90:224-226
         config.aerosol_optics.save("aerosol_optics.nc")
+    if dc.do_save_cloud_optics and config.do_clouds and config.use_general_cloud_optics:          # driver/ecrad_driver.F90:228-230
+        for tag, tables in (("sw", config.cloud_optics_sw if config.do_sw else []), ("lw", config.cloud_optics_lw if config.do_lw else [])):
+            for co in tables or []:
+                co.save(f"hydrometeor_optics_{tag}_{co.type_name}.nc")
     if dc.do_save_inputs:                        # driver/ecrad_driver.F90:283-289 (before set_gas_units, lat = lon = 0)
         save_inputs("inputs.nc", config, single_level, thermodynamics, gas, cloud, aerosol, lat=np.zeros(ncol), lon=np.zeros(ncol))
     rad.set_gas_units(gas)

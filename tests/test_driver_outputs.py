@@ -194,3 +194,19 @@ def test_aerosol_optics_file(tmp_path):
             assert f.get("asymmetry_lw_hydrophilic").shape == (ao.n_type_philic, ao.nrh, nlw)
             assert np.array_equal(f.get("ssa_sw_hydrophilic"), ao.ssa_sw_philic)
             assert np.all((f.get("ssa_lw_hydrophobic") >= 0.0) & (f.get("ssa_lw_hydrophobic") <= 1.0))
+
+
+def test_cloud_optics_files(tmp_path):
+    """general_cloud_optics_type%save (the driver's do_save_cloud_optics): one file per hydrometeor type and spectrum."""
+    from ecrad_amd.interface import setup_radiation
+    config = make_config("Tripleclouds")
+    setup_radiation(config)
+    for tag, tables in (("sw", config.cloud_optics_sw), ("lw", config.cloud_optics_lw)):
+        for co in tables:
+            p = str(tmp_path / f"hydrometeor_optics_{tag}_{co.type_name}.nc")
+            co.save(p)
+            with NcFile(p) as f:
+                assert f.get("mass_extinction_coefficient").shape == (co.n_effective_radius, co.n_bands)
+                assert np.array_equal(f.get("single_scattering_albedo"), co.ssa)
+                re = f.get("effective_radius")
+                assert re[0] == co.effective_radius_0 and abs((re[1] - re[0]) / co.d_effective_radius - 1.0) < 1e-12
