@@ -132,9 +132,12 @@ def read_input(path: str, config: Config, driver_config: DriverConfig):
             if dc.cloud_fraction_scaling >= 0.0 and dc.cloud_fraction_scaling != 1.0:
                 fraction *= dc.cloud_fraction_scaling
             if dc.overlap_decorr_length_override > 0.0 or overlap_param is None:
-                raise NotImplementedError("overlap_param must be present in the input file "
-                                          "(cloud%set_overlap_param is not implemented)")
-            if dc.overlap_decorr_length_scaling > 0.0:
+                # cloud%set_overlap_param with the namelist's decorrelation length, or the driver's default of 2 km when the
+                # file has no overlap parameter (ecrad_driver_read_input.F90:68, :233-246)
+                from .ifs import set_overlap_param
+                overlap_param = np.ascontiguousarray(set_overlap_param(
+                    thermodynamics, dc.overlap_decorr_length_override if dc.overlap_decorr_length_override > 0.0 else 2000.0))
+            elif dc.overlap_decorr_length_scaling > 0.0:
                 pos = overlap_param > 0.0
                 overlap_param[pos] = overlap_param[pos] ** (1.0 / dc.overlap_decorr_length_scaling)
             elif dc.overlap_decorr_length_scaling == 0.0:

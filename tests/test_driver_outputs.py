@@ -210,3 +210,17 @@ def test_cloud_optics_files(tmp_path):
                 assert np.array_equal(f.get("single_scattering_albedo"), co.ssa)
                 re = f.get("effective_radius")
                 assert re[0] == co.effective_radius_0 and abs((re[1] - re[0]) / co.d_effective_radius - 1.0) < 1e-12
+
+
+def test_overlap_decorrelation_length_override():
+    """overlap_decorr_length_override of the driver namelist (ecrad_driver_read_input.F90:233-246): cloud%set_overlap_param
+    (pinned to the reference's routine in tests/test_ifs_scheme.py) replaces the file's overlap parameter."""
+    from ecrad_amd.driver import DriverConfig, read_input
+    from ecrad_amd.ifs import set_overlap_param
+    from helpers import MERIDIAN, NAMELIST
+    config = make_config("Tripleclouds")
+    dc = DriverConfig.read(NAMELIST)
+    dc.overlap_decorr_length_override = 1500.0
+    inp = read_input(MERIDIAN, config, dc)
+    assert np.array_equal(inp[5].overlap_param, set_overlap_param(inp[3], 1500.0))
+    assert np.all((inp[5].overlap_param > 0.0) & (inp[5].overlap_param < 1.0))
