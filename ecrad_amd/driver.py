@@ -53,6 +53,8 @@ class DriverConfig:
     solar_irradiance_override: float = -1.0
     cos_sza_override: float = -1.0
     low_inv_effective_size_override: float = -1.0
+    middle_inv_effective_size_override: float = -1.0
+    high_inv_effective_size_override: float = -1.0
     cloud_separation_scale_surface: float = -1.0
     cloud_separation_scale_toa: float = -1.0
     cloud_separation_scale_power: float = 1.0
@@ -153,9 +155,17 @@ def read_input(path: str, config: Config, driver_config: DriverConfig):
                 # driver/ecrad_driver_read_input.F90:290-470: of the four ways to specify the cloud scale, the one the
                 # reference's own test inputs use -- inv_cloud_effective_size [and inv_inhom_effective_size] in the file
                 scalable = False
-                if dc.low_inv_effective_size_override >= 0.0:
-                    raise NotImplementedError("[low|middle|high]_inv_effective_size_override of the offline driver")
-                if dc.cloud_separation_scale_surface > 0.0 and dc.cloud_separation_scale_toa > 0.0:
+                sizes = (dc.low_inv_effective_size_override, dc.middle_inv_effective_size_override, dc.high_inv_effective_size_override)
+                if max(sizes) >= 0.0:
+                    # (1) cloud%create_inv_cloud_effective_size_eta (radiation_cloud.F90:524-594) with the driver's bounds
+                    # eta = 0.8 and 0.45 between low / mid-level / high clouds (ecrad_driver_read_input.F90:305-331)
+                    if min(sizes) < 0.0:
+                        raise RuntimeError("if one of [low|middle|high]_inv_effective_size_override is provided then all must be")
+                    isurf = 0 if pressure_hl[0, 0] > pressure_hl[1, 0] else nlev
+                    eta = (pressure_hl[:-1] + pressure_hl[1:]) * (0.5 / pressure_hl[isurf][None, :])
+                    cloud.inv_cloud_effective_size = np.ascontiguousarray(
+                        np.where(eta > 0.8, sizes[0], np.where(eta > 0.45, sizes[1], sizes[2])))
+                elif dc.cloud_separation_scale_surface > 0.0 and dc.cloud_separation_scale_toa > 0.0:
                     # (2) cloud%param_cloud_effective_separation_eta (radiation_cloud.F90:602-690): what the IFS test
                     # namelists use (cloud_separation_scale_*)
                     coeff_e = 1.0 - np.exp(-1.0)

@@ -224,3 +224,19 @@ def test_overlap_decorrelation_length_override():
     inp = read_input(MERIDIAN, config, dc)
     assert np.array_equal(inp[5].overlap_param, set_overlap_param(inp[3], 1500.0))
     assert np.all((inp[5].overlap_param > 0.0) & (inp[5].overlap_param < 1.0))
+
+
+def test_effective_size_overrides_by_height():
+    """[low|middle|high]_inv_effective_size_override (ecrad_driver_read_input.F90:305-331 -> create_inv_cloud_effective_size_eta,
+    radiation_cloud.F90:524-594): one inverse cloud size per height range, split at eta = p/p_surface = 0.8 and 0.45."""
+    from ecrad_amd.driver import DriverConfig, read_input
+    from helpers import MERIDIAN, NAMELIST
+    config = make_config("SPARTACUS")
+    dc = DriverConfig.read(NAMELIST)
+    dc.low_inv_effective_size_override, dc.middle_inv_effective_size_override, dc.high_inv_effective_size_override = 1.0e-3, 5.0e-4, 1.0e-4
+    inp = read_input(MERIDIAN, config, dc)
+    ics, p = inp[5].inv_cloud_effective_size, inp[3].pressure_hl
+    assert inp[5].inv_inhom_effective_size is None and ics.shape == (137, 32)
+    eta = 0.5 * (p[:-1] + p[1:]) / p[-1]
+    assert np.array_equal(ics == 1.0e-3, eta > 0.8) and np.array_equal(ics == 1.0e-4, eta <= 0.45)
+    assert set(np.unique(ics)) == {1.0e-3, 5.0e-4, 1.0e-4}
