@@ -135,6 +135,9 @@ class Config:
     do_cloud_aerosol_per_lw_g_point: bool = True
     do_weighted_surface_mapping: bool = True
     use_spectral_solar_cycle: bool = False
+    use_updated_solar_spectrum: bool = False
+    ssi_override_file_name: str = ""
+    ssi_file_name: str = ""
     iverbose: int = 1
     iverbosesetup: int = 2
 
@@ -194,7 +197,7 @@ class Config:
             "max_cloud_od", "cloud_mixing_ratio_threshold", "n_aerosol_types", "use_aerosols",
             "do_nearest_spectral_sw_albedo", "do_nearest_spectral_lw_emiss",
             "do_cloud_aerosol_per_lw_g_point", "do_cloud_aerosol_per_sw_g_point",
-            "do_weighted_surface_mapping", "use_spectral_solar_cycle", "do_fu_lw_ice_optics_bug",
+            "do_weighted_surface_mapping", "use_spectral_solar_cycle", "use_updated_solar_spectrum", "ssi_override_file_name", "do_fu_lw_ice_optics_bug",
             "min_gas_od_lw", "min_gas_od_sw", "liq_optics_override_file_name", "ice_optics_override_file_name",
             "do_3d_effects", "do_3d_lw_multilayer_effects", "do_lw_side_emissivity", "max_3d_transfer_rate",
             "max_gas_od_3d", "min_cloud_effective_size", "overhang_factor", "clear_to_thick_fraction",
@@ -299,8 +302,10 @@ class Config:
                 raise ConfigError(f"band cloud optics: ice_model_name='{ICE_MODEL_NAMES[self.i_ice_model]}' is not implemented")
             self.liq_optics_file_name = self._data_path(self.liq_optics_override_file_name, liq[self.i_liq_model])
             self.ice_optics_file_name = self._data_path(self.ice_optics_override_file_name, ice[self.i_ice_model])
-        if self.use_spectral_solar_cycle:
-            raise ConfigError("use_spectral_solar_cycle is not supported by this build")
+        if self.use_spectral_solar_cycle:                 # radiation_config.F90:1200-1218
+            if IGasModelECCKD != self.i_gas_model_sw:
+                raise ConfigError("solar cycle only available with ecCKD gas optics model")
+            self.ssi_file_name = self._data_path(self.ssi_override_file_name, "ssi_nrl2.nc")
         self.aerosol_optics_file_name = self._data_path(
             self.aerosol_optics_override_file_name,
             "aerosol_ifs_49R1_20230119.nc" if self.use_general_aerosol_optics

@@ -52,6 +52,7 @@ class DriverConfig:
     skin_temperature_override: float = -1.0
     solar_irradiance_override: float = -1.0
     cos_sza_override: float = -1.0
+    solar_cycle_multiplier_override: float = -2.0e6      # ecrad_driver_config.F90:262
     low_inv_effective_size_override: float = -1.0
     middle_inv_effective_size_override: float = -1.0
     high_inv_effective_size_override: float = -1.0
@@ -216,6 +217,11 @@ def read_input(path: str, config: Config, driver_config: DriverConfig):
                                    sw_albedo=sw_albedo, lw_emissivity=lw_emissivity,
                                    sw_albedo_direct=sw_albedo_direct,
                                    solar_irradiance=solar_irradiance, iseed=iseed)
+        # position in the solar cycle, +1 = maximum, -1 = minimum (ecrad_driver_read_input.F90:115-127)
+        if dc.solar_cycle_multiplier_override > -1.0e6:
+            single_level.spectral_solar_cycle_multiplier = float(dc.solar_cycle_multiplier_override)
+        elif f.exists("spectral_solar_cycle_multiplier"):
+            single_level.spectral_solar_cycle_multiplier = float(f.get_scalar("spectral_solar_cycle_multiplier"))
 
         aerosol = None
         if config.use_aerosols:

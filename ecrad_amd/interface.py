@@ -56,6 +56,8 @@ def setup_radiation(config: Config) -> None:
     # setup_gas_optics (radiation_ecckd_interface.F90:27-150)
     if config.do_sw:
         config.gas_optics_sw = CkdModel(config.gas_optics_sw_file_name)
+        if config.use_spectral_solar_cycle:       # radiation_ecckd_interface.F90:78-82
+            config.gas_optics_sw.read_spectral_solar_cycle(config.ssi_file_name, config.use_updated_solar_spectrum)
         config.n_g_sw = config.gas_optics_sw.ng
         if config.do_cloud_aerosol_per_sw_g_point:
             config.n_bands_sw = config.n_g_sw

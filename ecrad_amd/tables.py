@@ -94,6 +94,38 @@ class CkdModel:
                 self.single_gas.append(CkdGas(nc, name, code))
 
 
+    def read_spectral_solar_cycle(self, file_name: str, use_updated_solar_spectrum: bool = False) -> None:
+        """ckd_model_type%read_spectral_solar_cycle (radiation_ecckd.F90:295-451): the mean solar spectral irradiance and the
+        amplitude of its solar cycle (W m-2 cm), interpolated to the model's wavenumber grid and projected on its g-points,
+        with the mean removed -- the host scales with the total solar irradiance and
+        single_level%spectral_solar_cycle_multiplier (+1 at solar maximum, -1 at minimum)."""
+        sd = self.spectral_def
+        with NcFile(file_name) as nc:
+            wavenumber = np.asarray(nc.get("wavenumber"), dtype=np.float64)
+            ssi = np.asarray(nc.get("mean_solar_spectral_irradiance"), dtype=np.float64)
+            amp = np.asarray(nc.get("ssi_solar_cycle_amplitude"), dtype=np.float64)
+        grid = 0.5 * (np.asarray(sd.wavenumber1, dtype=np.float64) + np.asarray(sd.wavenumber2, dtype=np.float64))
+        dwav = float(sd.wavenumber2[0] - sd.wavenumber1[0])
+        ssi_grid, amp_grid = np.zeros(grid.size), np.zeros(grid.size)
+        # the interval with wavenumber(j) < grid <= wavenumber(j+1); grid points outside the file's range keep zero
+        j = np.searchsorted(wavenumber, grid, side="left") - 1
+        ok = (j >= 0) & (j < wavenumber.size - 1)
+        j0 = j[ok]
+        w0, w1 = wavenumber[j0], wavenumber[j0 + 1]
+        ssi_grid[ok] = (ssi[j0] * (w1 - grid[ok]) + ssi[j0 + 1] * (grid[ok] - w0)) * dwav / (w1 - w0)
+        amp_grid[ok] = (amp[j0] * (w1 - grid[ok]) + amp[j0 + 1] * (grid[ok] - w0)) * dwav / (w1 - w0)
+        gf = np.asarray(sd.gpoint_fraction, dtype=np.float64)          # numpy (ng, nwav)
+        norm = np.asarray(self.norm_solar_irradiance, dtype=np.float64)
+        if use_updated_solar_spectrum:
+            if sd.solar_spectral_irradiance is None:
+                raise ValueError("Cannot use_updated_solar_spectrum unless gas optics model is from ecCKD >= 1.4")
+            norm = norm * (gf @ ssi_grid) / (gf @ np.asarray(sd.solar_spectral_irradiance, dtype=np.float64))
+            norm = norm / norm.sum()
+            sd.solar_spectral_irradiance = ssi_grid
+            self.norm_solar_irradiance = norm
+        a = norm * (gf @ amp_grid) / (gf @ ssi_grid)
+        self.norm_amplitude_solar_irradiance = (norm + a) / np.sum(norm + a) - norm
+
 class GeneralCloudOptics:
     """general_cloud_optics_type%setup (radiation_general_cloud_optics_data.F90:71-243)."""
 
