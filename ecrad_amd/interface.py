@@ -161,7 +161,7 @@ def setup_radiation(config: Config) -> None:
     if config.use_aerosols:
         if config.n_aerosol_types > 0:
             if not config.use_general_aerosol_optics:
-                raise ConfigError("only use_general_aerosol_optics=true is implemented")
+                raise ConfigError("band-wise aerosol files (use_general_aerosol_optics=false) hold the RRTMG bands: not for ecCKD")
             config.aerosol_optics = AerosolOptics(
                 config.aerosol_optics_file_name,
                 config.gas_optics_sw.spectral_def if config.do_sw else None,
@@ -319,11 +319,15 @@ def _setup_radiation_rrtmg(config: Config) -> None:
                         lst.append(gen)
     if config.use_aerosols:
         if config.n_aerosol_types > 0:
-            if not config.use_general_aerosol_optics:
-                raise ConfigError("only use_general_aerosol_optics=true is implemented")
+            if not config.use_general_aerosol_optics and mixed:
+                raise ConfigError("band-wise aerosol files (use_general_aerosol_optics=false) hold the RRTMG bands: not for an ecCKD spectrum")
             config.aerosol_optics = AerosolOptics(config.aerosol_optics_file_name, sd_sw if config.do_sw else None,
                                                   sd_lw if config.do_lw else None, config.do_cloud_aerosol_per_sw_g_point,
                                                   config.do_cloud_aerosol_per_lw_g_point, config.do_sw, config.do_lw)
+            # radiation_aerosol_optics.F90:67-77
+            if (config.do_lw and config.n_bands_lw != config.aerosol_optics.n_bands_lw) or \
+               (config.do_sw and config.n_bands_sw != config.aerosol_optics.n_bands_sw):
+                raise ConfigError("number of bands does not match aerosol optics look-up table")
             config.aerosol_optics.set_types(config.i_aerosol_type_map[:config.n_aerosol_types])
         else:
             config.use_aerosols = False

@@ -236,7 +236,10 @@ class AerosolOptics:
                  do_sw: bool = True, do_lw: bool = True):
         with NcFile(file_name) as nc:
             if not nc.exists("wavenumber"):
-                raise ValueError("legacy band-wise aerosol files are not supported: " + file_name)
+                # aerosol_optics_type%setup (radiation_aerosol_optics_data.F90:157-315, use_general_aerosol_optics = false:
+                # the namelists of the IFS cycles before 48R1): properties already in the bands of the gas-optics scheme
+                self._read_band_file(nc, do_sw, do_lw)
+                return
             self.use_hydrophilic = nc.exists("mass_ext_hydrophilic")
             wavenumber = nc.get("wavenumber")
             me_pho = nc.get("mass_ext_hydrophobic")     # (ntype, nwav)
@@ -272,6 +275,27 @@ class AerosolOptics:
                 setattr(self, f"mass_ext_{tag}_philic", m)
                 setattr(self, f"ssa_{tag}_philic", s)
                 setattr(self, f"g_{tag}_philic", a)
+        self.ntype = 0
+        self.iclass = np.zeros(0, dtype=np.int32)
+        self.itype = np.zeros(0, dtype=np.int32)
+
+    def _read_band_file(self, nc, do_sw: bool, do_lw: bool) -> None:
+        self.use_hydrophilic = nc.exists("mass_ext_sw_hydrophilic")
+        get = lambda name: np.ascontiguousarray(np.asarray(nc.get(name), dtype=np.float64))
+        self.n_bands_sw = self.n_bands_lw = 0
+        for tag, do in (("sw", do_sw), ("lw", do_lw)):
+            if not do:
+                continue
+            for out, var in (("mass_ext", "mass_ext"), ("ssa", "ssa"), ("g", "asymmetry")):
+                setattr(self, f"{out}_{tag}_phobic", get(f"{var}_{tag}_hydrophobic"))          # (type, band)
+                if self.use_hydrophilic:
+                    setattr(self, f"{out}_{tag}_philic", get(f"{var}_{tag}_hydrophilic"))      # (type, relative humidity, band)
+            setattr(self, "n_bands_" + tag, int(getattr(self, f"mass_ext_{tag}_phobic").shape[-1]))
+        self.n_type_phobic = int(nc.get("mass_ext_sw_hydrophobic").shape[0])
+        self.n_type_philic = int(nc.get("mass_ext_sw_hydrophilic").shape[0]) if self.use_hydrophilic else 0
+        if self.use_hydrophilic:
+            self.rh_lower = get("relative_humidity1")
+        self.nrh = int(self.rh_lower.size) if self.use_hydrophilic else 0
         self.ntype = 0
         self.iclass = np.zeros(0, dtype=np.int32)
         self.itype = np.zeros(0, dtype=np.int32)

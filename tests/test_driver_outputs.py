@@ -240,3 +240,23 @@ def test_effective_size_overrides_by_height():
     eta = 0.5 * (p[:-1] + p[1:]) / p[-1]
     assert np.array_equal(ics == 1.0e-3, eta > 0.8) and np.array_equal(ics == 1.0e-4, eta <= 0.45)
     assert set(np.unique(ics)) == {1.0e-3, 5.0e-4, 1.0e-4}
+
+
+def test_band_wise_aerosol_file_is_read_as_it_is():
+    """use_general_aerosol_optics = false (aerosol_optics_type%setup, radiation_aerosol_optics_data.F90:157-315): the
+    properties are already in the RRTMG bands -- no averaging, the arrays of the file."""
+    from ecrad_amd.interface import setup_radiation
+    from helpers import DATA_DIR, make_config_rrtmg
+    config = make_config_rrtmg("McICA", use_general_aerosol_optics=False)
+    setup_radiation(config)
+    ao = config.aerosol_optics
+    assert (ao.n_bands_sw, ao.n_bands_lw, ao.n_type_phobic, ao.n_type_philic, ao.nrh) == (14, 16, 14, 10, 12)
+    with NcFile(os.path.join(DATA_DIR, "aerosol_ifs_rrtm_46R1_with_NI_AM.nc")) as f:
+        assert np.array_equal(ao.mass_ext_sw_phobic, f.get("mass_ext_sw_hydrophobic"))
+        assert np.array_equal(ao.g_lw_philic, f.get("asymmetry_lw_hydrophilic"))
+        assert np.array_equal(ao.rh_lower, f.get("relative_humidity1"))
+    # and the ecCKD models cannot use it
+    import pytest
+    from ecrad_amd.config import ConfigError
+    with pytest.raises(ConfigError):
+        setup_radiation(make_config("Tripleclouds", use_general_aerosol_optics=False))

@@ -29,6 +29,12 @@ TARGETS = {
     "test_ecckd_tc": ("ecckd", "Tripleclouds", {}),                                                   # :111
     "test_ecckd_noaer": ("ecckd", "Tripleclouds", dict(use_aerosols=False)),                          # :124, :165
     "test_ecckd_spartacus": ("ecckd", "SPARTACUS", dict(do_3d_effects=True)),                         # :158
+    # the namelists of earlier IFS cycles that test/ifs holds next to CY49R1 (Makefile:10-14): aerosol optics from the
+    # band-wise file (use_general_aerosol_optics = false), no spectral surface fluxes; CY47R1 also Exp-Exp overlap and
+    # another aerosol type map
+    "configCY47R3": ("rrtmg", "McICA", dict(use_general_aerosol_optics=False, do_surface_sw_spectral_flux=False)),
+    "configCY47R1": ("rrtmg", "McICA", dict(use_general_aerosol_optics=False, do_surface_sw_spectral_flux=False, i_overlap_scheme=2,
+                                            i_aerosol_type_map=[-1, -2, -3, 1, 2, 3, -4, 10, 11, 11, -5, 14])),
     # test_mixed_gas (:114-122): configCY49R1_mixed.nam and its three edits
     "test_mixed_gas_ecckd_ecckd": ("ecckd", "Tripleclouds", dict(do_save_spectral_flux=False)),
     "test_mixed_gas_sw_ecckd_lw_rrtmg": ("rrtmg", "Tripleclouds", dict(MIXED, i_gas_model_sw=IGasModelECCKD, do_cloud_aerosol_per_sw_g_point=True)),
