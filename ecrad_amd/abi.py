@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NMAXGASES = 12
 NMAXCLOUDTYPES = 12
 
@@ -154,6 +154,7 @@ class Inputs(C.Structure):
         ("cloud_overlap_param", c_double_p),
         ("aerosol_mixing_ratio", c_double_p),
         ("cloud_inv_cloud_effective_size", c_double_p), ("cloud_inv_inhom_effective_size", c_double_p),
+        ("spectral_solar_scaling", c_double_p),      # host memory always
     ]
 
 

@@ -135,6 +135,7 @@ class Config:
     do_cloud_aerosol_per_lw_g_point: bool = True
     do_weighted_surface_mapping: bool = True
     use_spectral_solar_cycle: bool = False
+    use_spectral_solar_scaling: bool = False     # single_level%spectral_solar_scaling scales the RRTMG shortwave bands (radiation_config.F90:169)
     use_updated_solar_spectrum: bool = False
     ssi_override_file_name: str = ""
     ssi_file_name: str = ""
@@ -197,7 +198,7 @@ class Config:
             "max_cloud_od", "cloud_mixing_ratio_threshold", "n_aerosol_types", "use_aerosols",
             "do_nearest_spectral_sw_albedo", "do_nearest_spectral_lw_emiss",
             "do_cloud_aerosol_per_lw_g_point", "do_cloud_aerosol_per_sw_g_point",
-            "do_weighted_surface_mapping", "use_spectral_solar_cycle", "use_updated_solar_spectrum", "ssi_override_file_name", "do_fu_lw_ice_optics_bug",
+            "do_weighted_surface_mapping", "use_spectral_solar_cycle", "use_spectral_solar_scaling", "use_updated_solar_spectrum", "ssi_override_file_name", "do_fu_lw_ice_optics_bug",
             "min_gas_od_lw", "min_gas_od_sw", "liq_optics_override_file_name", "ice_optics_override_file_name",
             "do_3d_effects", "do_3d_lw_multilayer_effects", "do_lw_side_emissivity", "max_3d_transfer_rate",
             "max_gas_od_3d", "min_cloud_effective_size", "overhang_factor", "clear_to_thick_fraction",

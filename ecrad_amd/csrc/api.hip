@@ -872,6 +872,7 @@ struct CallCtx {
   Range r{};
   StagedInputs si{};
   bool host_mem = false;
+  const double* solar_scaling = nullptr;      // single_level%spectral_solar_scaling (host memory), RRTMG shortwave only
 };
 
 int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol, const ecrad_inputs_t* in, CallCtx& cx) {
@@ -879,6 +880,7 @@ int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int ie
   if (ncol < 1 || nlev < 2 || istartcol < 1 || iendcol > ncol || iendcol < istartcol) return fail(h, ECRAD_EINVAL, "bad column/level range");
   if (nlev > 256) return fail(h, ECRAD_EUNSUPPORTED, "more than 256 levels");
   if (!in->pressure_hl || !in->temperature_hl || !in->gas_mixing_ratio) return fail(h, ECRAD_EINVAL, "thermodynamics/gas arrays missing");
+  cx.solar_scaling = (c.do_sw && h->rrtmg_sw) ? in->spectral_solar_scaling : nullptr;
   if (c.do_sw && (!in->cos_sza || !in->sw_albedo)) return fail(h, ECRAD_EINVAL, "cos_sza/sw_albedo missing");
   if (c.do_lw && (!in->skin_temperature || !in->lw_emissivity)) return fail(h, ECRAD_EINVAL, "skin_temperature/lw_emissivity missing");
   if (c.do_sw && !c.use_canopy_full_spectrum_sw && !c.do_nearest_spectral_sw_albedo && in->n_sw_albedo != c.n_albedo_intervals_sw)
@@ -997,7 +999,7 @@ int run_rrtmg(ecrad_hip_handle_t h, CallCtx& cx, bool fold_aerosols) {
   }
   HIP_TRY(h, h->gas_work.ensure(rrtmg_work_bytes((int)L, (int)n)));
   const RrtmgWork w = rrtmg_carve_work(h->gas_work.p, (int)L, (int)n);
-  HIP_TRY(h, launch_rrtmg_gas_optics(h->stream, h->d_rrtmg, h->dcfg, cx.din, w, gs, h->rrtmg_lw, h->rrtmg_sw));
+  HIP_TRY(h, launch_rrtmg_gas_optics(h->stream, h->d_rrtmg, h->dcfg, cx.din, w, gs, h->rrtmg_lw, h->rrtmg_sw, cx.solar_scaling));
   cx.din.gs = gs;
   return ECRAD_OK;
 }

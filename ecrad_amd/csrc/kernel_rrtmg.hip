@@ -380,13 +380,24 @@ __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __
   }
 }
 
-__global__ __launch_bounds__(kBlock) void rrtmg_incoming_kernel(DevInputs in, DevGasStage out) {
+// single_level%spectral_solar_scaling, by value (14 factors; `on` = 0: none)
+struct SolarScaling {
+  double v[kNBandSw];
+  int on;
+};
+
+__global__ __launch_bounds__(kBlock) void rrtmg_incoming_kernel(const DevRrtmg* __restrict__ Tp, DevInputs in, DevGasStage out, SolarScaling sc) {
   const int nloc = in.iendcol - in.istartcol + 1;
   const int cloc = blockIdx.x * blockDim.x + threadIdx.x;
   if (cloc >= nloc) return;
   const int col = in.istartcol - 1 + cloc;
   double* inc = out.incoming_sw + (size_t)kNgSw * cloc;
   if (in.cos_sza[col] > 0.0) {
+    if (sc.on)          // radiation_ifs_rrtm.F90:545-551: per band, before the normalisation
+      for (int ib = 0; ib < kNBandSw; ++ib) {
+        const SwBand& B = Tp->sw[ib];
+        for (int ig = 0; ig < B.ng; ++ig) inc[B.g0 + ig] = inc[B.g0 + ig] * sc.v[ib];
+      }
     double sum = 0.0;
     for (int g = 0; g < kNgSw; ++g) sum = sum + inc[g];
     const double scale = in.solar_irradiance / sum;
@@ -412,7 +423,7 @@ RrtmgWork rrtmg_carve_work(void* base, int nlev, int nloc) {
 }
 
 hipError_t launch_rrtmg_gas_optics(hipStream_t st, const DevRrtmg* tables, const DevConfig* cfg, const DevInputs& in, const RrtmgWork& w,
-                                   const DevGasStage& out, bool do_lw, bool do_sw) {
+                                   const DevGasStage& out, bool do_lw, bool do_sw, const double* solar_scaling_host) {
   const int nloc = in.iendcol - in.istartcol + 1, nlev = in.nlev;
   if (do_sw) {
     hipError_t e = hipMemsetAsync(out.incoming_sw, 0, (size_t)kNgSw * nloc * sizeof(double), st);
@@ -421,7 +432,11 @@ hipError_t launch_rrtmg_gas_optics(hipStream_t st, const DevRrtmg* tables, const
   hipLaunchKernelGGL(rrtmg_setcoef_kernel, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, st, tables, in, w, do_lw ? 1 : 0, do_sw ? 1 : 0);
   hipLaunchKernelGGL(rrtmg_taumol_kernel, dim3((nloc + kTileCols - 1) / kTileCols, nlev), dim3(kBlock), 0, st, tables, cfg, in, w, out,
                      do_lw ? 1 : 0, do_sw ? 1 : 0);
-  if (do_sw) hipLaunchKernelGGL(rrtmg_incoming_kernel, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, st, in, out);
+  if (do_sw) {
+    SolarScaling sc{};
+    if (solar_scaling_host) { sc.on = 1; for (int ib = 0; ib < kNBandSw; ++ib) sc.v[ib] = solar_scaling_host[ib]; }
+    hipLaunchKernelGGL(rrtmg_incoming_kernel, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, st, tables, in, out, sc);
+  }
   return hipGetLastError();
 }
 

@@ -73,6 +73,6 @@ namespace rrtmg { struct DevRrtmg; }
 size_t rrtmg_work_bytes(int nlev, int nloc);
 RrtmgWork rrtmg_carve_work(void* base, int nlev, int nloc);
 hipError_t launch_rrtmg_gas_optics(hipStream_t st, const rrtmg::DevRrtmg* tables, const DevConfig* cfg, const DevInputs& in,
-                                   const RrtmgWork& w, const DevGasStage& out, bool do_lw, bool do_sw);
+                                   const RrtmgWork& w, const DevGasStage& out, bool do_lw, bool do_sw, const double* solar_scaling_host);
 
 }  // namespace ecrad

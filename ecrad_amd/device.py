@@ -45,6 +45,9 @@ class DeviceCase:
         s.lw_emissivity = abi.raw_dptr(up("lw_emissivity", single_level.lw_emissivity))
         if single_level.iseed is not None:
             s.iseed = abi.raw_iptr(up("iseed", np.ascontiguousarray(single_level.iseed, dtype=np.int32)))
+        if config.use_spectral_solar_scaling and config.do_sw and single_level.spectral_solar_scaling is not None:
+            self._solar_scaling = np.ascontiguousarray(single_level.spectral_solar_scaling, dtype=np.float64)      # host memory (include/ecrad_hip.h)
+            s.spectral_solar_scaling = abi.dptr(self._solar_scaling)
         s.gas_mixing_ratio = abi.raw_dptr(up("gas_mixing_ratio", gas.mixing_ratio))
         if cloud is not None and config.do_clouds:
             s.n_cloud_types = cloud.ntype

@@ -8,7 +8,7 @@ module ecrad_hip_binding
   implicit none
   public
 
-  integer(c_int), parameter :: ECRAD_ABI_VERSION = 4
+  integer(c_int), parameter :: ECRAD_ABI_VERSION = 5
   integer(c_int), parameter :: ECRAD_OK = 0
   integer(c_int), parameter :: ECRAD_NMAXGASES = 12, ECRAD_NMAXCLOUDTYPES = 12
   integer(c_int), parameter :: ECRAD_MEM_HOST = 0, ECRAD_MEM_DEVICE = 1
@@ -122,6 +122,7 @@ module ecrad_hip_binding
     type(c_ptr) :: cloud_overlap_param = c_null_ptr
     type(c_ptr) :: aerosol_mixing_ratio = c_null_ptr
     type(c_ptr) :: cloud_inv_cloud_effective_size = c_null_ptr, cloud_inv_inhom_effective_size = c_null_ptr
+    type(c_ptr) :: spectral_solar_scaling = c_null_ptr      ! (n_bands_sw), host memory always
   end type
 
   type, bind(C) :: ecrad_flux_t

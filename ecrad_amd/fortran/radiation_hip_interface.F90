@@ -299,6 +299,10 @@ contains
     cin%sw_albedo = locd(single_level%sw_albedo); cin%sw_albedo_direct = locd(single_level%sw_albedo_direct)
     cin%lw_emissivity = locd(single_level%lw_emissivity)
     cin%iseed = loci(single_level%iseed)
+    ! radiation_ifs_rrtm.F90:545-551: the per-band scaling of the RRTMG solar spectrum (the IFS's NSOLARSPECTRUM)
+    cin%spectral_solar_scaling = c_null_ptr
+    if (config%use_spectral_solar_scaling .and. allocated(single_level%spectral_solar_scaling)) &
+         &  cin%spectral_solar_scaling = locd(single_level%spectral_solar_scaling)
     cin%gas_mixing_ratio = locd(gas%mixing_ratio)
     cin%n_cloud_types = 0; cin%n_aerosol_types = 0; cin%aerosol_istartlev = 1; cin%aerosol_iendlev = 0; cin%reserved_ = 0
     if (config%do_clouds) then

@@ -100,6 +100,7 @@ module radiation_hip_types
     logical :: do_save_spectral_flux = .false., do_surface_sw_spectral_flux = .true., do_toa_spectral_flux = .false.
     logical :: do_lw_derivatives = .false.
     logical :: do_fu_lw_ice_optics_bug = .false.
+    logical :: use_spectral_solar_scaling = .false.
     logical :: do_canopy_fluxes_sw = .false., do_canopy_fluxes_lw = .false.
     logical :: use_canopy_full_spectrum_sw = .false., use_canopy_full_spectrum_lw = .false.
     logical :: do_cloud_aerosol_per_sw_g_point = .true., do_cloud_aerosol_per_lw_g_point = .true.
@@ -125,6 +126,7 @@ module radiation_hip_types
     real(jprb), allocatable, dimension(:) :: cos_sza, skin_temperature
     real(jprb), allocatable, dimension(:,:) :: sw_albedo, sw_albedo_direct, lw_emissivity   ! (ncol,nband)
     real(jprb) :: solar_irradiance = 1366.0_jprb, spectral_solar_cycle_multiplier = 0.0_jprb
+    real(jprb), allocatable, dimension(:) :: spectral_solar_scaling                          ! (n_bands_sw)
     integer, allocatable, dimension(:) :: iseed
   end type
   type thermodynamics_type

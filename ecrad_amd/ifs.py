@@ -214,9 +214,9 @@ def setup_radiation_scheme(yradiation: TRADIATION, file_name: Optional[str] = No
         c.read_into(file_name)
         if directory_name is not None:
             c.directory_name = directory_name
+    if y.NSOLARSPECTRUM > 0 and c.i_gas_model_sw == IGasModelIFSRRTMG:             # :523-533 (decided before the handle is configured)
+        c.use_spectral_solar_scaling = True      # (RRTMG always has the 14 bands the scaling needs)
     yradiation.radiation = Radiation(c, backend=backend, device_id=device_id)      # SETUP_RADIATION (:514)
-    if y.NSOLARSPECTRUM > 0 and c.i_gas_model_sw == IGasModelIFSRRTMG:             # :523-533
-        raise ConfigError("NSOLARSPECTRUM > 0 (single_level%spectral_solar_scaling) is not supported by this build")
     if c.do_sw:
         yradiation.iband_uv, yradiation.weight_uv = get_sw_weights(c, 0.2e-6, 0.4415e-6)     # :538-545
         yradiation.iband_par, yradiation.weight_par = get_sw_weights(c, 0.4e-6, 0.7e-6)
@@ -387,6 +387,13 @@ def radiation_scheme(yradiation: TRADIATION, kidia: int, kfdia: int, klon: int, 
                                lw_emissivity=np.ascontiguousarray(f64(PSPECTRALEMISS)),
                                sw_albedo_direct=np.ascontiguousarray(f64(PALBEDO_DIR)),
                                solar_irradiance=float(PSOLAR_IRRADIANCE), iseed=iseed)
+    if config.use_spectral_solar_scaling:
+        # ifs/radiation_scheme.F90:369-397: RRTMG uses the old Kurucz solar spectrum; per-band factors towards the Whole
+        # Heliosphere Interval 2008 reference spectrum (NSOLARSPECTRUM = 1) or the Coddington et al. (2016) climate data record
+        single_level.spectral_solar_scaling = np.array(
+            [1.0000, 1.0000, 1.0000, 1.0478, 1.0404, 1.0317, 1.0231, 1.0054, 0.98413, 0.99863, 0.99907, 0.90589, 0.92213, 1.0000]
+            if yradiation.yrerad.NSOLARSPECTRUM == 1 else
+            [0.99892, 0.99625, 1.00822, 1.01587, 1.01898, 1.01044, 1.08441, 0.99398, 1.00553, 0.99533, 1.01509, 0.92331, 0.92681, 0.99749])
 
     # clouds (:389-455)
     cloud = None
@@ -726,13 +733,14 @@ def net_to_up(config: Config, flux: Flux, nlev: int) -> None:
 
 
 def run_ifs_driver(namelist: str, input_file: str, output_file: Optional[str] = None, blocked: bool = False,
-                   bitidentity: bool = False, per_block: bool = False, backend="hip", directory_name: Optional[str] = None):
+                   bitidentity: bool = False, per_block: bool = False, backend="hip", directory_name: Optional[str] = None,
+                   yrerad: Optional[TERAD] = None):
     """The offline IFS-style drivers (driver/ecrad_ifs_driver.F90, driver/ecrad_ifs_driver_blocked.F90): read the
     input file as the ordinary driver does, hand the fields to ``radiation_scheme`` as IFS arrays (optionally through
     the NPROMA-blocked array), and write the net fluxes.  Returns (config, thermodynamics, flux, diagnostics)."""
     from .driver import DriverConfig, read_input, save_net_fluxes
     dc = DriverConfig.read(namelist)
-    yr = TRADIATION()
+    yr = TRADIATION() if yrerad is None else TRADIATION(yrerad=yrerad)          # (host switches the namelist does not hold)
     yr.rad_config.read_into(namelist)
     yr.yrerad.NAERMACC = 1 if yr.rad_config.use_aerosols else 0            # ecrad_ifs_driver.F90:153-157
     setup_radiation_scheme(yr, file_name=namelist, directory_name=directory_name, backend=backend)

@@ -484,6 +484,10 @@ def build_inputs_struct(config: Config, ncol, nlev, single_level, thermodynamics
         iseed = np.ascontiguousarray(single_level.iseed, dtype=np.int32)
         keep.append(iseed)
         s.iseed = abi.iptr(iseed)
+    if config.use_spectral_solar_scaling and config.do_sw:       # radiation_ifs_rrtm.F90:545-551
+        if single_level.spectral_solar_scaling is None:
+            raise ValueError("use_spectral_solar_scaling needs single_level%spectral_solar_scaling")
+        s.spectral_solar_scaling = d(single_level.spectral_solar_scaling, (config.n_bands_sw,))
     s.gas_mixing_ratio = d(gas.mixing_ratio, (12, nlev, ncol))
     if cloud is not None and config.do_clouds:
         s.n_cloud_types = cloud.ntype

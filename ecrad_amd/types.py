@@ -43,6 +43,7 @@ class SingleLevel:
     sw_albedo_direct: Optional[np.ndarray] = None
     solar_irradiance: float = 1366.0
     spectral_solar_cycle_multiplier: float = 0.0
+    spectral_solar_scaling: object = None      # (n_bands_sw) with config%use_spectral_solar_scaling (radiation_single_level.F90:76)
     iseed: Optional[np.ndarray] = None  # (ncol) int32
 
     def init_seed_simple(self, ncol: int) -> None:

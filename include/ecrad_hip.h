@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ECRAD_ABI_VERSION 4
+#define ECRAD_ABI_VERSION 5
 
 /* Status codes */
 #define ECRAD_OK            0
@@ -300,6 +300,11 @@ typedef struct ecrad_inputs {
   /* cloud geometry for the 3-D effects of SPARTACUS (radiation_cloud.F90:75-87); NULL = not allocated */
   const double* cloud_inv_cloud_effective_size;  /* (ncol,nlev) m-1 */
   const double* cloud_inv_inhom_effective_size;  /* (ncol,nlev) m-1 or NULL (= use inv_cloud_effective_size) */
+  /* single_level%spectral_solar_scaling (n_bands_sw), or NULL: factors applied to the incoming solar flux of the RRTMG
+     shortwave bands before it is normalised to solar_irradiance (config%use_spectral_solar_scaling,
+     radiation_ifs_rrtm.F90:545-551; the IFS's NSOLARSPECTRUM).  HOST memory in both memory modes, like the scalars above;
+     pass it only when config%use_spectral_solar_scaling is set.  Ignored by an ecCKD shortwave model, as in the reference. */
+  const double* spectral_solar_scaling;
 } ecrad_inputs_t;
 
 /* ---- flux_type, radiation_flux.F90:38-118; any pointer may be NULL (= not allocated) -------- */

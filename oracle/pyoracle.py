@@ -230,6 +230,7 @@ REF_RRTM_PATH = os.path.join(_HERE, "_ref", "libecrad_refrrtm.so")
 _DATA = os.path.join(_HERE, "..", "data")
 _ref_rrtm = None
 _NG_LW = [10, 12, 16, 14, 16, 8, 12, 8, 12, 6, 8, 8, 4, 2, 2, 2]
+_NG_SW = [6, 12, 8, 8, 10, 10, 2, 10, 8, 6, 6, 8, 6, 12]
 
 
 def have_ref_rrtm() -> bool:
@@ -302,6 +303,8 @@ def rrtmg_gas_stage(config, ncol, nlev, cin, nthreads=1):
         out["lw_emission"][c0:c1] = planck(skin[c0:c1]) * pf[:, -1, :]
         out["od_sw"][c0:c1] = np.maximum(o_sw[:, ::-1, :], config.min_gas_od_sw)
         out["ssa_sw"][c0:c1] = o_ssa[:, ::-1, :]
+        if cin.spectral_solar_scaling:        # radiation_ifs_rrtm.F90:545-551: per band, before the normalisation
+            o_inc = o_inc * _np_from(cin.spectral_solar_scaling, (14,))[np.repeat(np.arange(14), _NG_SW)][None, :]
         tot = o_inc.sum(axis=1)
         scale = np.where(mu0[c0:c1] > 0.0, cin.solar_irradiance / np.where(tot > 0, tot, 1.0), 1.0)
         out["incoming_sw"][c0:c1] = o_inc * scale[:, None]

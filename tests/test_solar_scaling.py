@@ -1,0 +1,97 @@
+"""use_spectral_solar_scaling / single_level%spectral_solar_scaling (radiation_config.F90 use_spectral_solar_scaling;
+radiation_ifs_rrtm.F90:545-551): per-band factors on RRTMG's (Kurucz) incoming solar spectrum, applied before the
+g-point irradiances are normalised to the host's total solar irradiance; the IFS sets them from NSOLARSPECTRUM
+(ifs/radiation_setup.F90:523-533, ifs/radiation_scheme.F90:369-397).  The factors are a host array of the C-ABI
+(include/ecrad_hip.h, ABI version 5)."""
+import numpy as np
+import pytest
+
+from ecrad_amd import ifs
+from ecrad_amd.cases import DATA_DIR, MERIDIAN, NAMELIST
+from helpers import compare_flux, load_meridian, make_config_rrtmg, rel_err, run_case
+
+WHI = np.array([1.0, 1.0, 1.0, 1.0478, 1.0404, 1.0317, 1.0231, 1.0054, 0.98413, 0.99863, 0.99907, 0.90589, 0.92213, 1.0])
+
+
+def _rrtmg_namelist(tmp_path):
+    """test/ifs/configCY49R1.nam as its differences from the ecCKD namelist this repo holds (cf. make_config_rrtmg)."""
+    text = open(NAMELIST).read()
+    for old, new in (('"ECCKD"', '"RRTMG-IFS"'), ("use_general_cloud_optics = true", "use_general_cloud_optics = false"),
+                     ("do_cloud_aerosol_per_sw_g_point=true", "do_cloud_aerosol_per_sw_g_point=false"),
+                     ("do_cloud_aerosol_per_lw_g_point=true", "do_cloud_aerosol_per_lw_g_point=false")):
+        assert text.count(old) == 1, old
+        text = text.replace(old, new)
+    path = tmp_path / "configCY49R1.nam"
+    path.write_text(text)
+    return str(path)
+
+
+def _run(backend_of, scaling, solver="Tripleclouds", **kw):
+    config = make_config_rrtmg(solver, use_spectral_solar_scaling=scaling is not None, do_save_spectral_flux=True, **kw)
+    inputs = load_meridian(config)
+    inputs[2].spectral_solar_scaling = scaling
+    f, _, rad = run_case(config, backend_of(config), inputs=inputs)
+    if hasattr(rad, "close"):
+        rad.close()
+    return f
+
+
+def _need_ref(oracle_lib):
+    if not oracle_lib.have_ref_rrtm():
+        pytest.skip("oracle/_ref/libecrad_refrrtm.so (the reference's RRTMG routines) has not been built")
+
+
+def test_oracle_scaling_redistributes_the_incoming_spectrum(oracle_lib):
+    _need_ref(oracle_lib)
+    f0 = _run(oracle_lib.make_rrtmg_backend, None)
+    f1 = _run(oracle_lib.make_rrtmg_backend, np.ones(14))
+    fw = _run(oracle_lib.make_rrtmg_backend, WHI)
+    f2 = _run(oracle_lib.make_rrtmg_backend, 2.0 * WHI)
+    for n in ("sw_dn", "sw_up", "sw_dn_band"):
+        assert np.array_equal(f0.arrays[n], f1.arrays[n]), n             # all ones = the switch off
+        assert rel_err(f2.arrays[n], fw.arrays[n]) < 1e-13, n            # a common factor drops out in the normalisation
+    day = f0.sw_dn[0] > 0
+    assert rel_err(fw.sw_dn[0], f0.sw_dn[0]) < 1e-13                     # the total at the top is the host's ...
+    toa0, toaw = f0.arrays["sw_dn_band"][0][day], fw.arrays["sw_dn_band"][0][day]      # (column, band)
+    ratio = toaw / toa0
+    expect = WHI[None, :] * (toa0.sum(axis=1) / (WHI[None, :] * toa0).sum(axis=1))[:, None]
+    assert np.abs(ratio / expect - 1.0).max() < 1e-12                    # ... split between the bands by the factors
+    assert 1e-4 < rel_err(fw.sw_dn[-1], f0.sw_dn[-1]) < 2e-2             # and the surface flux feels it
+
+
+def test_missing_scaling_array_is_an_error(oracle_lib):
+    _need_ref(oracle_lib)
+    config = make_config_rrtmg("Tripleclouds", use_spectral_solar_scaling=True)
+    inputs = load_meridian(config)
+    with pytest.raises(ValueError):
+        run_case(config, oracle_lib.make_rrtmg_backend(config), inputs=inputs)
+
+
+def test_ifs_nsolarspectrum_sets_the_factors(oracle_lib, tmp_path):
+    _need_ref(oracle_lib)
+    nam = _rrtmg_namelist(tmp_path)
+    res = {}
+    backend = oracle_lib.make_rrtmg_backend(make_config_rrtmg("Tripleclouds"))      # (the stage only reads the gas optical depth floors)
+    for ns in (0, 1, 2):
+        c, th, flux, diag = ifs.run_ifs_driver(nam, MERIDIAN, None, bitidentity=True, directory_name=DATA_DIR,
+                                               backend=backend, yrerad=ifs.TERAD(NSOLARSPECTRUM=ns))
+        assert c.use_spectral_solar_scaling == (ns > 0)
+        res[ns] = flux
+    net = lambda f: f.sw_dn - f.sw_up
+    assert rel_err(net(res[1])[0] + res[1].sw_up[0], net(res[0])[0] + res[0].sw_up[0]) < 1e-13        # same incoming
+    assert 1e-4 < rel_err(net(res[1])[-1], net(res[0])[-1]) < 2e-2
+    assert 1e-4 < rel_err(net(res[2])[-1], net(res[1])[-1]) < 2e-2                                    # the two spectra differ
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["McICA", "Tripleclouds", "SPARTACUS"])
+def test_hip_matches_oracle_with_solar_scaling(solver, oracle_lib):
+    _need_ref(oracle_lib)
+    kw = dict(do_3d_effects=True, do_sw_delta_scaling_with_gases=False) if solver == "SPARTACUS" else {}
+    f_hip = _run(lambda c: "hip", WHI, solver, **kw)
+    f_ora = _run(oracle_lib.make_rrtmg_backend, WHI, solver, **kw)
+    worst = compare_flux(f_hip, f_ora, 1.0)
+    bad = {k: v for k, v in worst.items() if v > (1.0e-6 if k.endswith(("_g", "_band", "_canopy")) else 1.0e-8)}
+    assert not bad, bad
+    f_0 = _run(oracle_lib.make_rrtmg_backend, None, solver, **kw)
+    assert rel_err(f_hip.sw_dn[-1], f_0.sw_dn[-1]) > 1e-4               # (the factors reached the device)
