@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 NMAXGASES = 12
 NMAXCLOUDTYPES = 12
 
@@ -85,6 +85,7 @@ class Rrtmg(C.Structure):
         ("chi_mls", c_double_p), ("preflog_lw", c_double_p), ("tref_lw", c_double_p),
         ("preflog_sw", c_double_p), ("tref_sw", c_double_p), ("totplnk", c_double_p), ("delwave", c_double_p),
         ("lw", RrtmgBand * 16), ("sw", RrtmgBand * 14),
+        ("i_g_from_reordered_g_lw", c_int32_p), ("i_g_from_reordered_g_sw", c_int32_p),
     ]
 
 

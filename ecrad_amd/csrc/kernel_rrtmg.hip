@@ -107,6 +107,12 @@ template <int G> ECRAD_DEV void vstore(double* p, const Vec<G>& v, int nk) {
 #pragma unroll
   for (int k = 0; k < G; ++k) if (k < nk) p[k] = v.v[k];
 }
+// the same at offset `g` of a row of the stage arrays, or -- with the reference's g-point reordering -- each value at its own position
+template <int G> ECRAD_DEV void pstore(double* row, int g, const short* pos, const Vec<G>& v, int nk) {
+  if (!pos) { vstore<G>(row + g, v, nk); return; }
+#pragma unroll
+  for (int k = 0; k < G; ++k) if (k < nk) row[pos[g + k]] = v.v[k];
+}
 constexpr int kRecD = LD_N > SD_N ? LD_N : SD_N, kRecI = LI_N > SI_N ? LI_N : SI_N;
 
 // The setcoef records of the block's 64 columns, staged in LDS: field-major, column fastest (as in the work
@@ -296,16 +302,17 @@ __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __
         const double pl_bot = planck_band(T, s_t[kTileCols + c], ib);
         const double pl_top = lev == 0 ? planck_band(T, s_t[c], ib) : 0.0;
         const double pl_surf = lev == nlev - 1 ? planck_band(T, s_t[2 * kTileCols + c], ib) : 0.0;
-        const size_t oo = g + (size_t)kNgLw * (lev + (size_t)nlev * cloc);
-        const size_t op = g + (size_t)kNgLw * (lev + (size_t)(nlev + 1) * cloc);
+        const size_t oo = (size_t)kNgLw * (lev + (size_t)nlev * cloc);
+        const size_t op = (size_t)kNgLw * (lev + (size_t)(nlev + 1) * cloc);
+        const short* pos = T.permute_lw ? T.pos_lw : nullptr;
         Vec<G> pb, ptop, ps;
 #pragma unroll
         for (int k = 0; k < G; ++k) { pb.v[k] = pl_bot * pfrac.v[k]; ptop.v[k] = pl_top * pfrac.v[k]; ps.v[k] = pl_surf * pfrac.v[k]; }
         const int nk = ng - ig < G ? ng - ig : G;
-        vstore<G>(out.od_lw + oo, od, nk);
-        vstore<G>(out.planck_hl + op + kNgLw, pb, nk);
-        if (lev == 0) vstore<G>(out.planck_hl + op, ptop, nk);
-        if (lev == nlev - 1) vstore<G>(out.lw_emission + g + (size_t)kNgLw * cloc, ps, nk);
+        pstore<G>(out.od_lw + oo, g, pos, od, nk);
+        pstore<G>(out.planck_hl + op + kNgLw, g, pos, pb, nk);
+        if (lev == 0) pstore<G>(out.planck_hl + op, g, pos, ptop, nk);
+        if (lev == nlev - 1) pstore<G>(out.lw_emission + (size_t)kNgLw * cloc, g, pos, ps, nk);
       }
     }
     __syncthreads();
@@ -340,7 +347,8 @@ __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __
         if (iv >= nv || cloc >= nloc) continue;
         const int g = B.g0 + ig;
         const int nk = ng - ig < G ? ng - ig : G;
-        const size_t o = g + (size_t)kNgSw * (lev + (size_t)nlev * cloc);
+        const size_t o = (size_t)kNgSw * (lev + (size_t)nlev * cloc);
+        const short* pos = T.permute_sw ? T.pos_sw : nullptr;
         Vec<G> vod, vssa, vg = vsplat<G>(0.0);
         if (s_sun[c]) {
           const LdsRec r{s_d, s_i, c};
@@ -367,14 +375,14 @@ __global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __
           if (vod.v[0] + vssa.v[G - 1] == -1.2345) out.od_sw[0] = vod.v[0];
           continue;
 #endif
-          if (want) vstore<G>(out.incoming_sw + g + (size_t)kNgSw * cloc, sflux, nk);
+          if (want) pstore<G>(out.incoming_sw + (size_t)kNgSw * cloc, g, pos, sflux, nk);
         } else {
           vod = vsplat<G>(dmax(T.min_gas_od_sw, 0.0));
           vssa = vsplat<G>(0.0);
         }
-        vstore<G>(out.od_sw + o, vod, nk);
-        vstore<G>(out.ssa_sw + o, vssa, nk);
-        if (fold_sw) vstore<G>(out.g_sw + o, vg, nk);
+        pstore<G>(out.od_sw + o, g, pos, vod, nk);
+        pstore<G>(out.ssa_sw + o, g, pos, vssa, nk);
+        if (fold_sw) pstore<G>(out.g_sw + o, g, pos, vg, nk);
       }
     }
   }
@@ -396,7 +404,10 @@ __global__ __launch_bounds__(kBlock) void rrtmg_incoming_kernel(const DevRrtmg* 
     if (sc.on)          // radiation_ifs_rrtm.F90:545-551: per band, before the normalisation
       for (int ib = 0; ib < kNBandSw; ++ib) {
         const SwBand& B = Tp->sw[ib];
-        for (int ig = 0; ig < B.ng; ++ig) inc[B.g0 + ig] = inc[B.g0 + ig] * sc.v[ib];
+        for (int ig = 0; ig < B.ng; ++ig) {
+          const int j = Tp->permute_sw ? Tp->pos_sw[B.g0 + ig] : B.g0 + ig;
+          inc[j] = inc[j] * sc.v[ib];
+        }
       }
     double sum = 0.0;
     for (int g = 0; g < kNgSw; ++g) sum = sum + inc[g];

@@ -114,6 +114,10 @@ struct DevRrtmg {
   double min_gas_od_lw, min_gas_od_sw;
   LwBand lw[kNBandLw];
   SwBand sw[kNBandSw];
+  // position of RRTMG's g-point g in the stage arrays (identity unless the host asks for the reference's reordering for SPARTACUS,
+  // ecrad_rrtmg_t::i_g_from_reordered_g_*)
+  short pos_lw[140], pos_sw[112];
+  int permute_lw, permute_sw;
 };
 
 // ---- per-(column, level) records ("setcoef" results) -------------------------------------------------
@@ -625,6 +629,21 @@ inline const char* build_tables(const ecrad_rrtmg_t& t, double min_gas_od_lw, do
   for (int b = 0; b < 16; ++b) {
     d.delwave[b] = t.delwave[b];
     for (int k = 0; k < 181; ++k) d.totplnk[b][k] = t.totplnk[k + 181 * b];
+  }
+  // position of every g-point in the stage arrays: the inverse of i_g_from_reordered_g (1-based), which must be a permutation
+  for (int spec = 0; spec < 2; ++spec) {
+    const int n = spec ? 112 : 140;
+    const int32_t* from = spec ? t.i_g_from_reordered_g_sw : t.i_g_from_reordered_g_lw;
+    short* pos = spec ? d.pos_sw : d.pos_lw;
+    for (int g = 0; g < n; ++g) pos[g] = from ? (short)-1 : (short)g;
+    bool moved = false;
+    for (int j = 0; from && j < n; ++j) {
+      const int g = from[j] - 1;
+      if (g < 0 || g >= n || pos[g] >= 0) return "rrtmg: i_g_from_reordered_g is not a permutation of the g-points";
+      pos[g] = (short)j;
+      moved = moved || g != j;
+    }
+    (spec ? d.permute_sw : d.permute_lw) = moved ? 1 : 0;
   }
 
   // ---- longwave -------------------------------------------------------------------------------------

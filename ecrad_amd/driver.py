@@ -62,6 +62,7 @@ class DriverConfig:
     cloud_inhom_separation_factor: float = 1.0
     effective_size_scaling: float = -1.0
     do_ignore_inhom_effective_size: bool = False
+    do_correct_unphysical_inputs: bool = False           # clip inputs outside their physical range (ecrad_driver.F90:313-323)
     vmr_suffix_str: str = "_vmr"
     gas_scaling: dict = None
 
@@ -70,13 +71,78 @@ class DriverConfig:
         nml = read_namelist(file_name).get("radiation_driver", {})
         d = cls()
         d.gas_scaling = {}
+        # the namelist names of the overrides differ from the names of the members they set (ecrad_driver_config.F90:216-234,
+        # :328-383); the member names are accepted as well
         for k, v in nml.items():
+            k = NAMELIST_TO_MEMBER.get(k, k)
             if k.endswith("_scaling") and k[:-8] in GAS_LOWER_CASE_NAMES:
                 d.gas_scaling[k[:-8]] = float(v)
+            elif k == "inv_effective_size":
+                pass
             elif hasattr(d, k) and k != "gas_scaling" and v is not None:
                 cur = getattr(d, k)
                 setattr(d, k, float(v) if isinstance(cur, float) else v)
+        # one inverse effective size for all heights, which the three height ranges override (:337-363)
+        ies = nml.get("inv_effective_size")
+        ranges = ("high_inv_effective_size_override", "middle_inv_effective_size_override", "low_inv_effective_size_override")
+        some = any(getattr(d, r) >= 0.0 for r in ranges)
+        if ies is not None and float(ies) >= 0.0:
+            for r, given in zip(ranges, ("high_inv_effective_size", "middle_inv_effective_size", "low_inv_effective_size")):
+                if not (given in nml or r in nml) or getattr(d, r) < 0.0:
+                    setattr(d, r, float(ies))
+        if some and any(getattr(d, r) < 0.0 for r in ranges):
+            raise ValueError("Driver configuration error: inverse effective cloud size not specified for high, middle and low clouds")
         return d
+
+
+NAMELIST_TO_MEMBER = {
+    "fractional_std": "fractional_std_override", "overlap_decorr_length": "overlap_decorr_length_override",
+    "sw_albedo": "sw_albedo_override", "lw_emissivity": "lw_emissivity_override", "q_liquid_scaling": "q_liq_scaling",
+    "skin_temperature": "skin_temperature_override", "cos_solar_zenith_angle": "cos_sza_override",
+    "high_inv_effective_size": "high_inv_effective_size_override", "middle_inv_effective_size": "middle_inv_effective_size_override",
+    "low_inv_effective_size": "low_inv_effective_size_override",
+}
+
+
+def out_of_physical_bounds(istartcol: int, iendcol: int, do_fix: bool, single_level, thermodynamics, gas, cloud, aerosol,
+                           out=print) -> bool:
+    """The driver's check of its inputs (ecrad_driver.F90:313-323): every array of the input types against the physical
+    range the reference gives it (the `out_of_physical_bounds` of radiation_gas.F90:679, radiation_single_level.F90:401-410,
+    radiation_thermodynamics.F90:319-324, radiation_cloud.F90:768-781, radiation_aerosol.F90:179-192; messages of
+    radiation_check.F90:124-134), columns istartcol..iendcol; with ``do_fix`` the values are clipped in place.  Pressure is
+    never clipped (a layer could end up with no pressure difference)."""
+    c = slice(istartcol - 1, iendcol)
+    checks = [(gas, "mixing_ratio", "gas%mixing_ratio", 0.0, 1.0, do_fix),
+              (single_level, "cos_sza", "cos_sza", -1.0, 1.0, do_fix),
+              (single_level, "skin_temperature", "skin_temperature", 173.0, 373.0, do_fix),
+              (single_level, "sw_albedo", "sw_albedo", 0.0, 1.0, do_fix),
+              (single_level, "sw_albedo_direct", "sw_albedo", 0.0, 1.0, do_fix),
+              (single_level, "lw_emissivity", "lw_emissivity", 0.0, 1.0, do_fix),
+              (thermodynamics, "pressure_hl", "pressure_hl", 0.0, 110000.0, False),
+              (thermodynamics, "temperature_hl", "temperature_hl", 100.0, 400.0, do_fix),
+              (thermodynamics, "h2o_sat_liq", "h2o_sat_liq", 0.0, 1.0, do_fix),
+              (cloud, "mixing_ratio", "cloud%mixing_ratio", 0.0, 1.0, do_fix),
+              (cloud, "effective_radius", "cloud%effective_radius", 0.0, 0.1, do_fix),
+              (cloud, "fraction", "cloud%fraction", 0.0, 1.0, do_fix),
+              (cloud, "fractional_std", "fractional_std", 0.0, 10.0, do_fix),
+              (cloud, "inv_cloud_effective_size", "inv_cloud_effective_size", 0.0, 1.0, do_fix),
+              (cloud, "inv_inhom_effective_size", "inv_inhom_effective_size", 0.0, 1.0, do_fix),
+              (cloud, "overlap_param", "overlap_param", -0.5, 1.0, do_fix),
+              (aerosol, "mixing_ratio", "aerosol%mixing_ratio", 0.0, 1.0, do_fix)]
+    is_bad = False
+    for obj, member, name, lo, hi, fix in checks:
+        var = getattr(obj, member, None) if obj is not None else None
+        if var is None or not isinstance(var, np.ndarray) or var.size == 0:
+            continue
+        part = var[..., c]                      # (the column is the fastest index of every input array)
+        vmin, vmax = float(part.min()), float(part.max())
+        if vmin < lo or vmax > hi:
+            is_bad = True
+            out(f"*** Warning: {name} range{vmin:12.4g} to{vmax:12.4g} is out of physical range{lo:12.4g}to{hi:12.4g}"
+                + (": corrected" if fix else ""))
+            if fix:
+                np.clip(part, lo, hi, out=part)
+    return is_bad
 
 
 def _colfast(a: np.ndarray) -> np.ndarray:
@@ -582,6 +648,7 @@ def main(argv=None) -> int:
         save_inputs("inputs.nc", config, single_level, thermodynamics, gas, cloud, aerosol, lat=np.zeros(ncol), lon=np.zeros(ncol))
     rad.set_gas_units(gas)
     thermodynamics.calc_saturation_wrt_liquid()
+    out_of_physical_bounds(istart, iend, dc.do_correct_unphysical_inputs, single_level, thermodynamics, gas, cloud, aerosol)
     flux = Flux.allocate(config, ncol, nlev)
     t0 = time.perf_counter()
     for _ in range(max(dc.nrepeat, 1)):

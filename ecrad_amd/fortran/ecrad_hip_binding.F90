@@ -8,7 +8,7 @@ module ecrad_hip_binding
   implicit none
   public
 
-  integer(c_int), parameter :: ECRAD_ABI_VERSION = 5
+  integer(c_int), parameter :: ECRAD_ABI_VERSION = 6
   integer(c_int), parameter :: ECRAD_OK = 0
   integer(c_int), parameter :: ECRAD_NMAXGASES = 12, ECRAD_NMAXCLOUDTYPES = 12
   integer(c_int), parameter :: ECRAD_MEM_HOST = 0, ECRAD_MEM_DEVICE = 1
@@ -57,6 +57,8 @@ module ecrad_hip_binding
     type(c_ptr) :: chi_mls = c_null_ptr, preflog_lw = c_null_ptr, tref_lw = c_null_ptr, preflog_sw = c_null_ptr
     type(c_ptr) :: tref_sw = c_null_ptr, totplnk = c_null_ptr, delwave = c_null_ptr
     type(ecrad_rrtmg_band_t) :: lw(16), sw(14)
+    ! config%i_g_from_reordered_g_lw / _sw (SPARTACUS: radiation_ifs_rrtm.F90:122-130, :167-174), or c_null_ptr
+    type(c_ptr) :: i_g_from_reordered_g_lw = c_null_ptr, i_g_from_reordered_g_sw = c_null_ptr
   end type
 
   type, bind(C) :: ecrad_pdf_sampler_t

@@ -185,6 +185,10 @@ contains
     if (config%i_gas_model_sw == IGasModelIFSRRTMG .or. config%i_gas_model_lw == IGasModelIFSRRTMG) then
       if (.not. present(rrtmg)) call radiation_hip_abort('*** Error: RRTMG gas optics needs the ifsrrtm tables (fill_rrtmg_hip)')
       rrtmg_tables = rrtmg
+      ! the order in which the configuration holds the g-points (reordered for SPARTACUS by setup_gas_optics,
+      ! radiation_ifs_rrtm.F90:122-130, :167-174); i_band_from_reordered_g_* below is in that order already
+      if (allocated(config%i_g_from_reordered_g_lw)) rrtmg_tables%i_g_from_reordered_g_lw = loci(config%i_g_from_reordered_g_lw)
+      if (allocated(config%i_g_from_reordered_g_sw)) rrtmg_tables%i_g_from_reordered_g_sw = loci(config%i_g_from_reordered_g_sw)
       c%rrtmg = c_loc(rrtmg_tables)
     end if
     c%min_gas_od_lw = config%min_gas_od_lw; c%min_gas_od_sw = config%min_gas_od_sw

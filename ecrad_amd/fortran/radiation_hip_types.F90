@@ -107,6 +107,7 @@ module radiation_hip_types
     integer, allocatable, dimension(:) :: i_albedo_from_band_sw, i_emiss_from_band_lw
     real(jprb), allocatable, dimension(:,:) :: sw_albedo_weights, lw_emiss_weights       ! (ninterval, nband)
     integer, allocatable, dimension(:) :: i_band_from_reordered_g_lw, i_band_from_reordered_g_sw
+    integer, allocatable, dimension(:) :: i_g_from_reordered_g_lw, i_g_from_reordered_g_sw
     integer, pointer, dimension(:) :: i_spec_from_reordered_g_lw => null(), i_spec_from_reordered_g_sw => null()
     integer :: n_canopy_bands_sw = 1, n_canopy_bands_lw = 1
     type(ckd_model_type) :: gas_optics_sw, gas_optics_lw

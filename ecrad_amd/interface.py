@@ -196,11 +196,16 @@ def _setup_radiation_rrtmg(config: Config) -> None:
     rrtmg_sw = config.do_sw and config.i_gas_model_sw == IGasModelIFSRRTMG
     rrtmg_lw = config.do_lw and config.i_gas_model_lw == IGasModelIFSRRTMG
     sd_sw = sd_lw = None
+    # SPARTACUS gets RRTMG's g-points in approximately increasing order of optical depth (radiation_ifs_rrtm.F90:122-130, :167-174)
+    reorder_sw, reorder_lw = rrtmg_sw and config.i_solver_sw == ISolverSpartacus, rrtmg_lw and config.i_solver_lw == ISolverSpartacus
+    config.rrtmg.set_reordering(reorder_lw, reorder_sw)
     if config.do_sw and rrtmg_sw:
         config.do_cloud_aerosol_per_sw_g_point = False
         sd_sw = SpectralDefinition.bands_only(SOLAR_REFERENCE_TEMPERATURE, SW_WAVENUMBER1, SW_WAVENUMBER2)
         config.n_g_sw, config.n_bands_sw = 112, 14
         config.i_band_from_reordered_g_sw = config.rrtmg.i_band_from_g_sw.copy()
+        if reorder_sw:
+            config.i_band_from_reordered_g_sw = config.rrtmg.i_band_from_g_sw[config.rrtmg.i_g_from_reordered_g_sw - 1].copy()
         config.gas_optics_sw = _BandsOnlyGasOptics(sd_sw)
     elif config.do_sw:
         config.gas_optics_sw = CkdModel(config.gas_optics_sw_file_name)
@@ -217,6 +222,8 @@ def _setup_radiation_rrtmg(config: Config) -> None:
         sd_lw = SpectralDefinition.bands_only(TERRESTRIAL_REFERENCE_TEMPERATURE, LW_WAVENUMBER1, LW_WAVENUMBER2)
         config.n_g_lw, config.n_bands_lw = 140, 16
         config.i_band_from_reordered_g_lw = config.rrtmg.i_band_from_g_lw.copy()
+        if reorder_lw:
+            config.i_band_from_reordered_g_lw = config.rrtmg.i_band_from_g_lw[config.rrtmg.i_g_from_reordered_g_lw - 1].copy()
         config.gas_optics_lw = _BandsOnlyGasOptics(sd_lw)
     elif config.do_lw:
         config.gas_optics_lw = CkdModel(config.gas_optics_lw_file_name)

@@ -28,6 +28,27 @@ LW_WAVENUMBER1 = [10.0, 350.0, 500.0, 630.0, 700.0, 820.0, 980.0, 1080.0, 1180.0
 LW_WAVENUMBER2 = [350.0, 500.0, 630.0, 700.0, 820.0, 980.0, 1080.0, 1180.0, 1390.0, 1480.0, 1800.0, 2080.0, 2250.0, 2380.0, 2600.0, 3250.0]
 
 
+# RRTM_GPOINT_REORDERING_LW / _SW (radiation_ifs_rrtm.F90:51-72; data): RRTMG's g-points in approximately increasing order of gas
+# optical depth, the order in which the reference hands them to SPARTACUS (config%i_g_from_reordered_g_*, 1-based)
+GPOINT_REORDERING_LW = np.array([
+    89, 90, 139, 77, 137, 69, 131, 97, 91, 70, 78, 71, 53, 72, 123, 54, 79, 98, 92, 55,
+    80, 132, 124, 81, 73, 56, 99, 82, 57, 23, 125, 100, 24, 74, 93, 58, 25, 83, 126, 75,
+    26, 11, 101, 133, 59, 27, 76, 140, 12, 84, 102, 94, 28, 127, 85, 13, 39, 60, 86, 103,
+    87, 109, 14, 29, 115, 40, 95, 15, 61, 88, 41, 110, 104, 1, 116, 42, 30, 134, 128, 138,
+    96, 62, 16, 43, 117, 63, 111, 44, 2, 64, 31, 65, 105, 17, 45, 66, 118, 32, 3, 33,
+    67, 18, 129, 135, 46, 112, 34, 106, 68, 35, 4, 119, 36, 47, 107, 19, 37, 38, 113, 48,
+    130, 5, 120, 49, 108, 20, 50, 51, 114, 21, 121, 52, 136, 122, 6, 22, 7, 8, 9, 10,
+], dtype=np.int32)
+GPOINT_REORDERING_SW = np.array([
+    35, 45, 19, 27, 36, 57, 20, 46, 58, 21, 28, 67, 55, 68, 37, 1, 69, 22, 29, 59,
+    78, 101, 79, 77, 70, 76, 47, 75, 30, 81, 60, 102, 80, 82, 23, 2, 83, 84, 85, 86,
+    103, 61, 31, 87, 56, 38, 71, 48, 88, 3, 62, 89, 24, 7, 49, 32, 104, 72, 90, 63,
+    39, 4, 8, 50, 91, 64, 40, 33, 25, 51, 95, 96, 73, 65, 9, 41, 97, 92, 105, 52,
+    5, 98, 10, 42, 99, 100, 66, 11, 74, 34, 53, 26, 6, 106, 12, 43, 13, 54, 93, 44,
+    107, 94, 14, 108, 15, 16, 109, 17, 18, 110, 111, 112,
+], dtype=np.int32)
+
+
 class RrtmgTables:
     """Holds the arrays (Fortran order, float64) and the ctypes struct that points into them."""
 
@@ -53,6 +74,14 @@ class RrtmgTables:
         # g-point -> band (1-based), radiation_ifs_rrtm.F90:128, :171
         self.i_band_from_g_lw = np.repeat(np.arange(1, 17), self.ng_lw).astype(np.int32)
         self.i_band_from_g_sw = np.repeat(np.arange(1, 15), self.ng_sw).astype(np.int32)
+        self.i_g_from_reordered_g_lw = self.i_g_from_reordered_g_sw = None
+
+    def set_reordering(self, lw: bool, sw: bool) -> None:
+        """radiation_ifs_rrtm.F90:122-130, :167-174: the spectrum a SPARTACUS solver works on has its g-points reordered."""
+        self.i_g_from_reordered_g_lw = GPOINT_REORDERING_LW.copy() if lw else None
+        self.i_g_from_reordered_g_sw = GPOINT_REORDERING_SW.copy() if sw else None
+        self.struct.i_g_from_reordered_g_lw = abi.iptr(self.i_g_from_reordered_g_lw) if lw else None
+        self.struct.i_g_from_reordered_g_sw = abi.iptr(self.i_g_from_reordered_g_sw) if sw else None
 
     def _p(self, name, optional=False):
         if name is None or name not in self.t:

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define ECRAD_ABI_VERSION 5
+#define ECRAD_ABI_VERSION 6
 
 /* Status codes */
 #define ECRAD_OK            0
@@ -142,6 +142,15 @@ typedef struct ecrad_rrtmg {
   const double* delwave;                /* yoerrtwn DELWAVE(16) */
   ecrad_rrtmg_band_t lw[16];
   ecrad_rrtmg_band_t sw[14];            /* bands 16-29 */
+  /* config%i_g_from_reordered_g_lw (140) / _sw (112), 1-based as in Fortran, or NULL for the natural order: the reference
+     hands SPARTACUS the g-points in approximately increasing order of gas optical depth (radiation_ifs_rrtm.F90:51-72,
+     :122-130, :167-174; the solver treats the g-points up to the first one whose clear-sky optical depth exceeds
+     max_gas_od_3d with the matrix-exponential method, radiation_spartacus_sw.F90:472-478).  With a table, position j of
+     every per-g-point array of the spectrum -- the gas-optics stage and ALL per-g-point inputs and outputs of the call --
+     holds RRTMG's g-point table[j], and i_band_from_g_* / the other g-indexed tables of ecrad_config_t must be given in
+     that order as well (config%i_band_from_reordered_g_*). */
+  const int32_t* i_g_from_reordered_g_lw;
+  const int32_t* i_g_from_reordered_g_sw;
 } ecrad_rrtmg_t;
 
 /* ---- general_cloud_optics_type, radiation_general_cloud_optics_data.F90:31-62 --------------- */

@@ -321,6 +321,13 @@ def rrtmg_gas_stage(config, ncol, nlev, cin, nthreads=1):
     else:
         for c0 in range(0, ncol, nblock):
             block(c0)
+    # the g-points of a spectrum SPARTACUS works on, in the reference's order (radiation_ifs_rrtm.F90:480-503, :571-586)
+    r = getattr(config, "rrtmg", None)
+    for names, perm in ((("od_lw", "planck_hl", "lw_emission"), getattr(r, "i_g_from_reordered_g_lw", None)),
+                        (("od_sw", "ssa_sw", "incoming_sw"), getattr(r, "i_g_from_reordered_g_sw", None))):
+        if perm is not None:
+            for n in names:
+                out[n] = np.ascontiguousarray(out[n][..., np.asarray(perm) - 1])
     return out
 
 
