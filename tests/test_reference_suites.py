@@ -132,7 +132,10 @@ def test_ckdmip_hip_against_line_by_line_and_oracle(gas_model, oracle_lib):
     else:
         _check_against_line_by_line(flux, MU0, **ECCKD_VS_LBL)
     both = _ckdmip_run(lambda c: "hip", model, 0.3)                       # both spectra in one call, against the oracle
-    compare_flux(both, _ckdmip_run(ora, model, 0.3), 1.0e-8)
+    worst = compare_flux(both, _ckdmip_run(ora, model, 0.3), 1.0)
+    # (1e-8 on the broadband profiles, the bar itself on the per-g-point values: see tests/test_reference_targets.py)
+    bad = {k: v for k, v in worst.items() if v > (1.0e-6 if k.endswith(("_g", "_band", "_canopy")) else 1.0e-8)}
+    assert not bad, bad
 
 
 # ---- I3RC ---------------------------------------------------------------------------------------------------------------
