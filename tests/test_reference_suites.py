@@ -250,3 +250,23 @@ def test_out_of_physical_bounds_reports_and_corrects(oracle_lib):
     assert out_of_physical_bounds(1, ncol, True, sl, th, gas, cloud, aer, out=msgs.append)
     assert cloud.fraction[5, 3] == 1.0 and th.temperature_hl[7, 2] == 100.0 and sl.cos_sza[9] == 1.0
     assert th.pressure_hl[-1, 4] == 120000.0                   # pressure is reported, never clipped
+
+
+def test_rrtmg_gpoint_reordering_tables_and_where_they_apply():
+    """radiation_ifs_rrtm.F90:51-72, :122-130, :167-174: permutations of the g-points, used for a spectrum that SPARTACUS solves and
+    for nothing else; the band table the rest of the path works with is the band of the REORDERED g-point."""
+    from ecrad_amd.interface import setup_radiation
+    from ecrad_amd.rrtmg import GPOINT_REORDERING_LW, GPOINT_REORDERING_SW
+    from helpers import make_config_rrtmg
+    assert sorted(GPOINT_REORDERING_LW) == list(range(1, 141)) and sorted(GPOINT_REORDERING_SW) == list(range(1, 113))
+    c = make_config_rrtmg("SPARTACUS")
+    setup_radiation(c)
+    r = c.rrtmg
+    assert np.array_equal(r.i_g_from_reordered_g_sw, GPOINT_REORDERING_SW) and np.array_equal(r.i_g_from_reordered_g_lw, GPOINT_REORDERING_LW)
+    assert np.array_equal(c.i_band_from_reordered_g_sw, r.i_band_from_g_sw[GPOINT_REORDERING_SW - 1])
+    assert np.array_equal(c.i_band_from_reordered_g_lw, r.i_band_from_g_lw[GPOINT_REORDERING_LW - 1])
+    assert len(set(c.i_band_from_reordered_g_sw[:14])) > 5          # the first positions: the most transparent g-point of many bands
+    c2 = make_config_rrtmg("Tripleclouds", "SPARTACUS")              # per spectrum
+    setup_radiation(c2)
+    assert c2.rrtmg.i_g_from_reordered_g_sw is None and c2.rrtmg.i_g_from_reordered_g_lw is not None
+    assert np.array_equal(c2.i_band_from_reordered_g_sw, c2.rrtmg.i_band_from_g_sw)
