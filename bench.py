@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- columns/sec (SW+LW) of the radiation() hot path on MI355X.
 
-Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 is launched by the driver through
-``python -m torch.distributed.run``).  One "step" = one pass of radiation() over one batch of
+Contract: ``python bench.py --gpus N --steps K --warmup W``.  For N>1 it runs one process per GPU: either the driver
+launches it through ``python -m torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or, started
+plainly, it starts its own N ranks (ecrad_amd/parallel.py: launch_ranks) and exits with their status.  One "step" = one pass of radiation() over one batch of
 synthetic IFS-shaped columns that is already resident in HBM.  The headline workload (``value``) is
 BASELINE.json configs[1]: 100 000 clear-sky columns per GPU, 137 levels, ecCKD-32 SW+LW, homogeneous
 solver, double precision.  Columns shard across ranks with NO data-path collective: the path has no
@@ -265,7 +266,9 @@ class Workload:
             raise RuntimeError(rad.lib.ecrad_hip_last_error(rad.handle).decode())
         if gather_world:
             packed = pack_profiles(case.flux_tensors, self.profile_names)
-            gather_profiles(packed, [self.ncol] * gather_world, dst=0)
+            if os.environ.get("ECRAD_BENCH_TEST_SHARED_GPU") == "1":
+                packed = packed.cpu()       # (gloo has no device gather)
+            self.gathered, _ = gather_profiles(packed, [self.ncol] * gather_world, dst=0)
 
     def stage_ms(self):
         ms, out = C.c_double(), {}
@@ -424,7 +427,9 @@ def end_to_end_host(w, repeats=3):
 def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allreduce_max, do_cpu, do_host_mode):
     sample_cols = 16384 if do_cpu else 0
     w = Workload(name, ncol, rank, local_rank, sample_cols)
-    elapsed = allreduce_max(timed_steps(w, steps, warmup, barrier))
+    elapsed_rank = timed_steps(w, steps, warmup, barrier)
+    elapsed = allreduce_max(elapsed_rank)
+    elapsed_min = -allreduce_max(-elapsed_rank)
     stage = w.stage_ms()
     # a few extra untimed steps to average the per-stage duration
     import torch
@@ -441,9 +446,14 @@ def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allredu
                       "aerosols": bool(w.config.use_aerosols), "clouds": not w.clear_sky},
            "roofline": roofline_of(w, stage, elapsed / steps)}
     if world > 1:
+        # every rank times the same K steps between the same two barriers: the slowest rank is `ms_per_step`
+        res["ms_per_step_ranks"] = {"min": 1e3 * elapsed_min / steps, "max": 1e3 * elapsed / steps}
         e2 = allreduce_max(timed_steps(w, steps, 1, barrier, gather_world=world))
         res["value_with_gather"] = world * ncol * steps / e2
         res["ms_per_step_with_gather"] = 1e3 * e2 / steps
+        if rank == 0:      # rank 0 holds every rank's profiles: (ranks, fields, half levels, columns per rank)
+            res["gathered"] = {"ranks": len(w.gathered), "shape_per_rank": list(w.gathered[0].shape), "fields": w.profile_names,
+                               "bytes_received": int(sum(b.numel() * b.element_size() for b in w.gathered[1:]))}
     if do_cpu and rank == 0:
         w.step()
         torch.cuda.synchronize()
@@ -471,18 +481,39 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes", file=sys.stderr)
-        sys.exit(2)
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    # TEST MODE (tests/test_bench_launcher.py on a 1-GPU box): the N ranks share the visible GPU(s), rendezvous over gloo
+    # and stage the gather through the host -- it exercises the N>1 code of this file, its numbers mean nothing.
+    shared = os.environ.get("ECRAD_BENCH_TEST_SHARED_GPU") == "1"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under torch.distributed.run: start the N ranks ourselves (one process per GPU, same argv) and wait for them
+        have = torch.cuda.device_count()
+        if have < args.gpus and not shared:
+            print(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible on this node", file=sys.stderr)
+            sys.exit(2)
+        from ecrad_amd.parallel import launch_ranks
+        sys.exit(launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if shared:
+        local_rank = local_rank % torch.cuda.device_count()
+    if local_rank >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} has no GPU (LOCAL_RANK={local_rank}, {torch.cuda.device_count()} visible)", file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dist = None
+    rccl_ranks = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("gloo" if shared else "nccl", rank=rank, world_size=world)
+        one = torch.ones(1, dtype=torch.float64, device="cpu" if shared else f"cuda:{local_rank}")
+        dist.all_reduce(one)                      # an actual RCCL collective over all ranks: its sum IS the rank count
+        rccl_ranks = int(round(float(one.item())))
 
     def barrier():
         if dist is not None:
@@ -492,7 +523,7 @@ def main():
     def allreduce_max(x):
         if dist is None:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if shared else f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -502,13 +533,15 @@ def main():
     cfg = head["config"]
     out = {
         "metric": "columns/sec (SW+LW) at 137 lev, " + ("RRTMG 140/112" if cfg["gas_model"] != "ecCKD" else f"ecCKD-{cfg['n_g_sw']}"),
-        "value": head["value"], "unit": "columns/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": head["value"], "unit": "columns/s", "n_gpus": world, "rccl_ranks": rccl_ranks, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": head.get("dtype", "f64"), "data": "synthetic",
         "config": dict(cfg, parallelism=f"columns sharded over {world} GPU(s), no data-path collective"),
         "roofline": head["roofline"],
     }
-    for k in ("value_with_gather", "ms_per_step_with_gather", "cpu_baseline", "parity", "end_to_end_host"):
+    if shared:
+        out["test_shared_gpu"] = "ranks share the visible GPU(s) over gloo: exercises the N>1 code only, not a measurement"
+    for k in ("ms_per_step_ranks", "value_with_gather", "ms_per_step_with_gather", "gathered", "cpu_baseline", "parity", "end_to_end_host"):
         if k in head:
             out[k] = head[k]
     failed = "parity" in head and not head["parity"]["ok"]

@@ -54,3 +54,45 @@ def assemble(bufs, counts: List[int]):
     """Concatenate the gathered buffers along the column axis, dropping the padding."""
     import torch
     return torch.cat([b[..., :n] for b, n in zip(bufs, counts)], dim=-1)
+
+
+def launch_ranks(argv: List[str], nproc: int, env: Optional[dict] = None, timeout: Optional[float] = None) -> int:
+    """One process per GPU of this node: run `argv` `nproc` times with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set (what `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` would set), stdout/stderr
+    inherited.  Rank r owns GPU r and -- with `shard_range` -- the r-th contiguous column range, the reference driver's
+    partitioning of its blocks (driver/ecrad_driver.F90:348-354).  Returns the largest exit status; when one rank fails or
+    the timeout expires the others are terminated (exactly the PIDs started here), so a missing GPU is an error, not a hang."""
+    import os
+    import socket
+    import subprocess
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ if env is None else env)
+    base.update({"WORLD_SIZE": str(nproc), "LOCAL_WORLD_SIZE": str(nproc), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(nproc):
+        procs.append(subprocess.Popen(argv, env=dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")))
+    t0, rc = time.monotonic(), 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                rc = max(rc, abs(code))
+        failed = rc != 0 or (timeout is not None and time.monotonic() - t0 > timeout)
+        if failed and live:
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            return rc or 124
+        time.sleep(0.05)
+    return rc
