@@ -16,8 +16,8 @@ Prints ONE JSON line on rank 0 with the contract's keys plus:
   "roofline":     dominant stage's algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak
   "cpu_baseline": the oracle (plain-C restatement, OpenMP over column blocks like the reference's
                   driver) timed on this box's host cores on a bounded sample of the same workload
-  "parity":       the timed configuration checked against the oracle on that sample (a failure nulls
-                  ``value`` and makes the exit status non-zero)
+  "parity":       the timed configuration checked against the oracle on EVERY timed column (batches of up to 125 000
+                  columns; the first 16 384 of larger ones); a failure nulls ``value`` and makes the exit status non-zero
   "end_to_end_host": the same call through ECRAD_MEM_HOST pointers (H2D + kernels + D2H, PCIe-inclusive)
   "workloads":    (N=1, default run) the other BASELINE configurations on this GPU, each with its own
                   value / ms_per_step / roofline / cpu_baseline / parity:
@@ -40,7 +40,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-HBM_TRIAD_GBS = 6300.0     # what tools/hbm_ceiling sustains on this box type when reading
+HBM_TRIAD_GBS = None       # measured on THIS box when the first workload is set up (ecrad_hip_hbm_triad: a = b + s c, 3 x 1 GiB)
+FP64_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (MI355X_MICROARCH.md quotes the FP32 vector peak, 157.3 = 2 x this)
 PARITY_TOLERANCE = 1.0e-6  # BASELINE.json north_star: fluxes within 1e-6 relative of the CPU reference
 EXTRA_WORKLOADS = (("tripleclouds_ecckd32", 100000), ("mcica_rrtmg", 100000), ("tripleclouds_ecckd64", 1250000),
                    ("spartacus_ecckd32_sp", 100000))
@@ -74,6 +75,18 @@ def algorithmic_bytes_per_column(config, nlev, which, clear_sky):
     return stage + W * (inputs + outputs)
 
 
+def algorithmic_flops_per_column(config, nlev, clear_sky):
+    """SURVEY.md section 8(d), "ALGORITHMIC flops per column (estimate, count exp ~ 40, sqrt/div ~ 15 flop-equivalents)":
+    gas optics ~ 80 per (g, level) and spectrum, shortwave two-stream + adding ~ 250, longwave no-scatter ~ 100
+    => 2.2 MFLOP for the clear-sky ecCKD-32 column; Tripleclouds ~ 3x that, McICA ~ 2x (+ the serial generator).
+    An estimate by the survey's own count, used for `roofline.fp64_fraction` only."""
+    from ecrad_amd.config import ISolverMcICA, ISolverTripleclouds, ISolverSpartacus
+    base = nlev * (config.n_g_sw * (80 + 250) + config.n_g_lw * (80 + 100))
+    if clear_sky or not config.do_clouds:
+        return float(base)
+    return float(base * {ISolverTripleclouds: 3.0, ISolverSpartacus: 3.0, ISolverMcICA: 2.0}.get(config.i_solver_sw, 1.0))
+
+
 def build_config(workload):
     """(config, clear_sky, description dict) of a named workload of ecrad_amd/synthetic.py: BENCH_CONFIGS."""
     from ecrad_amd.cases import make_config, make_config_rrtmg
@@ -101,17 +114,23 @@ def first_columns(inputs, n):
     return (n, nlev, *out)
 
 
-def oracle_backend(config, nthreads=None):
+def oracle_backend(config, nthreads=None, fma=False):
     """The checker / CPU baseline: oracle/ with OpenMP over blocks of 32 columns (driver/ecrad_driver.F90:348); for
-    RRTMG its gas optics are the reference's own ifsrrtm routines (oracle/_ref).  Returns (backend, description, threads)."""
+    RRTMG its gas optics are the reference's own ifsrrtm routines (oracle/_ref).  Returns (backend, description, threads).
+    fma: the same restatement compiled with floating-point contraction -- never the parity reference, only the measure of
+    how far the reference's own formulas move when nothing but the rounding of a*b+c changes."""
     from oracle import pyoracle
     pyoracle.build()
     nthreads = int(nthreads or pyoracle.lib().ecrad_oracle_max_threads())
-    backend = pyoracle.make_blocked_backend(nblocksize=32, nthreads=nthreads)
-    what = "oracle/ (plain C, -O3, "
-    if getattr(config, "i_precision", 0) == 1:      # the single-precision build of the SPARTACUS restatement (PARKIND1_SINGLE)
+    single = getattr(config, "i_precision", 0) == 1     # the single-precision build of the SPARTACUS restatement (PARKIND1_SINGLE)
+    if fma:
+        backend = (pyoracle.make_variant_backend("sp_fma", nblocksize=32, nthreads=nthreads) if single
+                   else pyoracle.make_fma_variant_backend(nblocksize=32, nthreads=nthreads))
+    elif single:
         backend = pyoracle.make_variant_backend("sp", nblocksize=32, nthreads=nthreads)
-        what = "oracle/ (plain C, -O3, SPARTACUS solvers in single precision, "
+    else:
+        backend = pyoracle.make_blocked_backend(nblocksize=32, nthreads=nthreads)
+    what = "oracle/ (plain C, -O3, " + ("SPARTACUS solvers in single precision, " if single else "")
     from ecrad_amd.config import IGasModelIFSRRTMG
     if IGasModelIFSRRTMG in (config.i_gas_model_sw, config.i_gas_model_lw):
         if not pyoracle.have_ref_rrtm():
@@ -120,6 +139,33 @@ def oracle_backend(config, nthreads=None):
         what = ("gas optics: the reference's ifsrrtm routines (oracle/_ref, \"reference\"; blocks of 8 columns on a thread pool) + "
                 "everything else: oracle/ (plain C, -O3, ")
     return backend, what, nthreads
+
+
+def oracle_flux_of(config, inputs, fma=False):
+    """Fluxes of the oracle for make_columns()-style inputs (all their columns)."""
+    from ecrad_amd.interface import Radiation
+    from ecrad_amd.types import Flux
+    backend, _, _ = oracle_backend(config, fma=fma)
+    rad = Radiation(config, backend=backend)
+    ncol, nlev, sl, th, gas, cloud, aer = inputs
+    flux = Flux.allocate(config, ncol, nlev)
+    rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)
+    return flux
+
+
+def columns_of(inputs, c0, n):
+    """Columns c0 .. c0+n-1 of a make_columns() result (column axis is the last one)."""
+    import copy
+    ncol, nlev, sl, th, gas, cloud, aer = inputs
+    n = min(n, ncol - c0)
+    out = [copy.copy(o) for o in (sl, th, gas, cloud, aer)]
+    for obj in out:
+        if obj is None:
+            continue
+        for k, v in list(vars(obj).items()):
+            if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == ncol:
+                setattr(obj, k, np.ascontiguousarray(v[..., c0:c0 + n]))
+    return (n, nlev, *out)
 
 
 def cpu_baseline(config, sample, seconds_target=10.0):
@@ -231,6 +277,12 @@ class Workload:
         self.config, self.clear_sky, self.desc = build_config(name)
         self.rad = Radiation(self.config, backend="hip", device_id=local_rank)
         self.rad.lib.ecrad_hip_set_stream(self.rad.handle, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        global HBM_TRIAD_GBS
+        if HBM_TRIAD_GBS is None:       # once per process, before the batch occupies the memory
+            gbs = C.c_double()
+            if self.rad.lib.ecrad_hip_hbm_triad(self.rad.handle, C.c_size_t(1 << 30), 5, C.byref(gbs)) != 0:
+                raise RuntimeError(self.rad.lib.ecrad_hip_last_error(self.rad.handle).decode())
+            HBM_TRIAD_GBS = gbs.value
         device = f"cuda:{local_rank}"
         # weak scaling: every rank owns `ncol` columns of the global batch; generated and uploaded in chunks
         self.sample, self.host_inputs = None, None
@@ -333,8 +385,18 @@ def roofline_of(w, stage_ms, elapsed_per_step_s):
         extra["compute"] = {"bound": "valu_fp32" if single else "valu_fp64", "estimated_flops": flops, "cloudy_layers_per_column": cloudy / ncol,
                             "achieved": flops / (dom_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                             "frac": flops / (dom_ms * 1e-3) / 1e12 / peak}
+    single = getattr(config, "i_precision", 0) == 1
+    flops = algorithmic_flops_per_column(config, nlev, w.clear_sky)
+    vpeak = 2 * FP64_PEAK_TFLOPS if single else FP64_PEAK_TFLOPS
+    packed = w.desc["sw_solver"] in ("Cloudless", "Homogeneous", "McICA", "Tripleclouds")
     return {**extra, "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "frac_of_measured_triad": achieved / HBM_TRIAD_GBS,
+            "frac": achieved / HBM_PEAK_GBS, "measured_triad": HBM_TRIAD_GBS, "frac_of_measured_triad": achieved / HBM_TRIAD_GBS,
+            # SURVEY 8(d)'s third number: columns/s x estimated flops per column / the vector peak of the working precision
+            "fp64_fraction": ncol / elapsed_per_step_s * flops / 1e12 / vpeak,
+            "flops_per_column_estimate": flops, "vector_peak_tflops": vpeak,
+            # the shortwave sweep records of these solvers travel as five doubles in 32 bytes: 39 mantissa bits, rounded to
+            # nearest (kernels_common.h: pack5); everything else, and all arithmetic, is binary64
+            "scratch_mantissa_bits": 39 if packed else (24 if single else 53),
             # spectra wider than 64 g-points run as several launches of the kernel; the stage time and the algorithmic
             # bytes cover all of them (and, for McICA, the cloud generator that feeds them), the PMC figure is per launch
             # (scaled by columns per launch: the profile may have run the call as a different number of column tiles)
@@ -358,18 +420,23 @@ def parity_tolerance(config):
     return 2.0e-3 if getattr(config, "i_precision", 0) == 1 else PARITY_TOLERANCE
 
 
-def check_parity(w, oracle_flux):
-    """The timed configuration against the oracle on the sample (outside the timed region; the oracle is the checker,
-    never the thing measured).  Names the field, column and level of the largest difference."""
+def check_parity(w, oracle_flux, inputs=None):
+    """The timed configuration against the oracle on EVERY column the oracle was run on (outside the timed region; the
+    oracle is the checker, never the thing measured).  Names the field, column and level of the largest difference and,
+    when that difference exceeds 1e-8, how far the oracle ITSELF moves at that very element when it is compiled with
+    floating-point contraction (`oracle_fma_vs_plain_there`): a difference of the size of the formulas' own last-bit
+    sensitivity is conditioning (the Meador-Weaver direct-beam bracket divided by 1 - (k mu0)^2), not a defect."""
     worst = {"max_rel_diff_vs_oracle": 0.0, "field": None}
     nchk = oracle_flux.ncol
     single = getattr(w.config, "i_precision", 0) == 1
     unstable = {}
+    worst_col = None
     for name, t in w.case.flux_tensors.items():
         ref = oracle_flux.arrays.get(name)
         if ref is None:
             continue
-        got = (t[..., :nchk] if t.shape[-1] == w.ncol else t[:nchk]).cpu().numpy()
+        col_last = t.shape[-1] == w.ncol
+        got = (t[..., :nchk] if col_last else t[:nchk]).cpu().numpy()
         scale = np.maximum(np.abs(ref), 1e-3 * np.abs(ref).max() + 1e-300)
         err = np.abs(got - ref) / scale
         if single and not name.startswith(STABLE_IN_SINGLE):
@@ -382,8 +449,20 @@ def check_parity(w, oracle_flux):
         idx = np.unravel_index(int(np.argmax(err)), err.shape)
         if err[idx] > worst["max_rel_diff_vs_oracle"]:
             worst = {"max_rel_diff_vs_oracle": float(err[idx]), "field": name, "index": [int(i) for i in idx]}
-    worst.update({"columns_checked": int(nchk), "tolerance": parity_tolerance(w.config),
+            worst_col = int(idx[-1] if col_last else idx[0])
+            worst_local = (name, idx, col_last, float(scale[idx]))
+    worst.update({"columns_checked": int(nchk), "columns_timed": int(w.ncol), "tolerance": parity_tolerance(w.config),
                   "ok": bool(worst["max_rel_diff_vs_oracle"] <= parity_tolerance(w.config))})
+    if inputs is not None and worst_col is not None and worst["max_rel_diff_vs_oracle"] > 1.0e-8 and not single:
+        # the block of 32 columns (the oracle's own blocking) that holds the worst element, plain and contracted
+        name, idx, col_last, scale_at = worst_local
+        c0 = (worst_col // 32) * 32
+        blk = columns_of(inputs, c0, 32)
+        a = oracle_flux_of(w.config, blk).arrays[name]
+        b = oracle_flux_of(w.config, blk, fma=True).arrays[name]
+        j = list(idx)
+        j[-1 if col_last else 0] = worst_col - c0
+        worst["oracle_fma_vs_plain_there"] = float(abs(a[tuple(j)] - b[tuple(j)]) / scale_at)
     if unstable:
         worst["all_sky_longwave_single_precision"] = {
             "note": "chaotic in single precision in the reference's own formulation; statistics against the single-precision oracle, not part of `ok`",
@@ -458,7 +537,12 @@ def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allredu
         w.step()
         torch.cuda.synchronize()
         res["cpu_baseline"], oracle_flux = with_stdout_on_stderr(cpu_baseline, w.config, w.sample)
-        res["parity"] = check_parity(w, oracle_flux)
+        inputs_all = w.sample
+        if w.host_inputs is not None and w.host_inputs[0] > w.sample[0]:
+            # every timed column (batches of up to CHUNK_COLUMNS columns are still on the host), not only the timing sample
+            inputs_all = w.host_inputs
+            oracle_flux = with_stdout_on_stderr(oracle_flux_of, w.config, inputs_all)
+        res["parity"] = with_stdout_on_stderr(check_parity, w, oracle_flux, inputs_all)
     if do_host_mode and rank == 0 and w.host_inputs is not None:
         res["end_to_end_host"] = end_to_end_host(w)
     w.close()

@@ -251,6 +251,8 @@ def declare_prototypes(lib) -> None:
     lib.ecrad_hip_last_kernel_ms.restype = C.c_int
     lib.ecrad_hip_last_stage_ms.argtypes = [H, C.c_int, C.POINTER(C.c_double)]
     lib.ecrad_hip_last_stage_ms.restype = C.c_int
+    lib.ecrad_hip_hbm_triad.argtypes = [H, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+    lib.ecrad_hip_hbm_triad.restype = C.c_int
     lib.ecrad_hip_scratch_bytes.argtypes = [H, C.POINTER(C.c_size_t)]
     lib.ecrad_hip_scratch_bytes.restype = C.c_int
     lib.ecrad_hip_last_error.argtypes = [H]
@@ -272,4 +274,5 @@ EXPORTED_SYMBOLS = [
     "ecrad_hip_optics", "ecrad_hip_synchronize", "ecrad_hip_last_kernel_ms", "ecrad_hip_last_stage_ms",
     "ecrad_hip_scratch_bytes", "ecrad_hip_last_error", "ecrad_hip_destroy",
     "ecrad_hip_abi_sizeof", "ecrad_hip_abi_version", "ecrad_hip_set_work_bytes", "ecrad_hip_last_call_info",
+    "ecrad_hip_hbm_triad",
 ]

@@ -1,6 +1,6 @@
 """Named configurations of the path: the reference's two test namelists and namelist-style edits to them.
 
-`make_config` starts from ecrad_amd/configs/configCY49R1_ecckd.nam (byte-identical to the reference's
+`make_config` starts from tests/golden/configCY49R1_ecckd.nam (byte-identical to the reference's
 test/ifs/configCY49R1_ecckd.nam: a configuration fixture, data); `make_config_rrtmg` expresses
 test/ifs/configCY49R1.nam as its differences from that file (the `diff` of the two namelists).  Tests, bench.py
 and smoke() all build their configurations here, the way test/common/change_namelist.sh does for the
@@ -17,7 +17,7 @@ from .types import Flux
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DATA_DIR = os.path.join(ROOT, "data")
-NAMELIST = os.path.join(ROOT, "ecrad_amd", "configs", "configCY49R1_ecckd.nam")
+NAMELIST = os.path.join(ROOT, "tests", "golden", "configCY49R1_ecckd.nam")
 MERIDIAN = os.path.join(ROOT, "tests", "golden", "ecrad_meridian.nc")
 
 

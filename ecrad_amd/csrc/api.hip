@@ -620,6 +620,47 @@ int ecrad_hip_scratch_bytes(ecrad_hip_handle_t h, size_t* bytes) {
   return ECRAD_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void hbm_triad_kernel(double2* __restrict__ a, const double2* __restrict__ b,
+                                                        const double2* __restrict__ c, double s, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double2 x = b[i], y = c[i];
+    a[i] = make_double2(x.x + s * y.x, x.y + s * y.y);
+  }
+}
+}  // namespace
+
+int ecrad_hip_hbm_triad(ecrad_hip_handle_t h, size_t nbytes, int repeats, double* gbs) {
+  if (!h || !gbs || nbytes < 4096 || repeats < 1) return ECRAD_EINVAL;
+  HIP_TRY(h, hipSetDevice(h->device));
+  double2 *a = nullptr, *b = nullptr, *c = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int st = ECRAD_OK;
+  float best = 1e30f;
+  const size_t n = nbytes / sizeof(double2);
+  if (hipMalloc(&a, nbytes) != hipSuccess || hipMalloc(&b, nbytes) != hipSuccess || hipMalloc(&c, nbytes) != hipSuccess) {
+    st = fail(h, ECRAD_ENOMEM, "ecrad_hip_hbm_triad: cannot allocate the three arrays");
+  } else if (hipMemsetAsync(b, 0, nbytes, h->stream) != hipSuccess || hipMemsetAsync(c, 0, nbytes, h->stream) != hipSuccess ||
+             hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    st = fail(h, ECRAD_EHIP, "ecrad_hip_hbm_triad: set-up failed");
+  } else {
+    for (int rep = 0; rep <= repeats && st == ECRAD_OK; ++rep) {       // (the first launch is a warm-up)
+      (void)hipEventRecord(e0, h->stream);
+      hipLaunchKernelGGL(hbm_triad_kernel, dim3(256 * 16), dim3(256), 0, h->stream, a, b, c, 3.0, n);
+      (void)hipEventRecord(e1, h->stream);
+      float ms = 0.f;
+      if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) st = fail(h, ECRAD_EHIP, "ecrad_hip_hbm_triad: launch failed");
+      else if (rep > 0 && ms < best) best = ms;
+    }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(a); (void)hipFree(b); (void)hipFree(c);
+  if (st == ECRAD_OK) *gbs = 3.0 * (double)nbytes / ((double)best * 1.0e6);
+  return st;
+}
+
 int ecrad_hip_synchronize(ecrad_hip_handle_t h) {
   if (!h) return ECRAD_EINVAL;
   HIP_TRY(h, hipSetDevice(h->device));

@@ -193,7 +193,18 @@ ECRAD_DEV SwCoef ref_trans_sw_fused(double mu0, double od, double ssa, double as
 
 // calc_two_stream_gammas_sw + calc_reflectance_transmittance_sw
 // (radiation_two_stream.F90:96-140, :421-550): cloudless/homogeneous solvers
+// The direct-beam terms divide a bracket that cancels to O(od) by 1 - (k mu0)^2, which passes through zero inside a
+// column (the reference only steps aside within 1000 eps of it): roundings are amplified by 1 / |1 - (k mu0)^2|.
+// Evaluated WITHOUT floating-point contraction, i.e. every product and sum rounded as the reference's source spells
+// them (gfortran -O2 without -ffast-math on x86-64-v1 does the same), so that what is left between this routine
+// and the CPU restatement is the last bit of exp() only.
+#ifndef ECRAD_CLASSIC_CONTRACT
+#define ECRAD_CLASSIC_CONTRACT 0
+#endif
 ECRAD_DEV SwCoef ref_trans_sw_classic(double mu0, double od, double ssa, double g) {
+#if !ECRAD_CLASSIC_CONTRACT
+#pragma clang fp contract(off)
+#endif
   SwCoef c;
   double factor = 0.75 * g;
   double gamma1 = 2.0 - ssa * (1.25 + factor);
@@ -379,9 +390,13 @@ template <> struct StreamRef<double2> {
 // ---- five doubles in 32 bytes ---------------------------------------------------------------------------
 // The shortwave flux-sweep record of one (g-point, layer) is five doubles (kernel_ica_sw.hip, kernel_tc.hip).  Their
 // high words travel whole (sign, exponent, 20 mantissa bits); of each low word the upper 19 bits are kept: 39
-// mantissa bits, a relative truncation of at most 1.8e-12 per value (the parity tests demand 1e-8 on the fluxes
-// after 137 layers).  8 words instead of 10 per record: the sweep scratch is the dominant HBM traffic of these
-// kernels, and the (un)packing costs 27 integer instructions per layer against ~450 for the layer's optics.
+// mantissa bits, ROUNDED to nearest (half away from zero: add half a unit of the last kept place to the 64-bit
+// pattern, the carry runs into the exponent as it should), a relative error of at most 9.1e-13 per value and
+// unbiased -- truncation would push every record the same way through a 137-step recurrence.  The parity tests
+// demand 1e-8 on the fluxes; tests/test_hip_parity.py compares a build without packing (ECRAD_PACK_SW=0) and
+// finds < 1e-10.  8 words instead of 10 per record: the sweep scratch is the dominant HBM traffic of these
+// kernels, and the (un)packing costs ~37 integer instructions per layer against ~450 for the layer's optics.
+// bench.py reports it as roofline.scratch_mantissa_bits = 39.
 #ifndef ECRAD_PACK_SW
 #define ECRAD_PACK_SW 1
 #endif
@@ -390,9 +405,10 @@ struct Packed5 {
   ecrad_v4u w0, w1;
 };
 ECRAD_DEV Packed5 pack5(double v0, double v1, double v2, double v3, double v4) {
-  const unsigned long long u0 = (unsigned long long)__double_as_longlong(v0), u1 = (unsigned long long)__double_as_longlong(v1),
-                           u2 = (unsigned long long)__double_as_longlong(v2), u3 = (unsigned long long)__double_as_longlong(v3),
-                           u4 = (unsigned long long)__double_as_longlong(v4);
+  constexpr unsigned long long half = 1ull << 12;      // half a unit of the last kept mantissa bit
+  const unsigned long long u0 = (unsigned long long)__double_as_longlong(v0) + half, u1 = (unsigned long long)__double_as_longlong(v1) + half,
+                           u2 = (unsigned long long)__double_as_longlong(v2) + half, u3 = (unsigned long long)__double_as_longlong(v3) + half,
+                           u4 = (unsigned long long)__double_as_longlong(v4) + half;
   const unsigned l0 = (unsigned)u0 >> 13, l1 = (unsigned)u1 >> 13, l2 = (unsigned)u2 >> 13, l3 = (unsigned)u3 >> 13, l4 = (unsigned)u4 >> 13;
   Packed5 p;
   p.w0.x = (unsigned)(u0 >> 32); p.w0.y = (unsigned)(u1 >> 32); p.w0.z = (unsigned)(u2 >> 32); p.w0.w = (unsigned)(u3 >> 32);

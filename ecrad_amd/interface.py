@@ -9,6 +9,7 @@ construction of :class:`Radiation` with ``backend="hip"`` raises.  (tests/ and b
 from __future__ import annotations
 
 import ctypes as C
+from typing import Optional
 import os
 
 import numpy as np
@@ -532,7 +533,7 @@ class Radiation:
     """Owns a configured handle: ``Radiation(config)`` == ``call setup_radiation(config)``;
     ``.radiation(...)`` == ``call radiation(ncol,nlev,istartcol,iendcol,config,...)``."""
 
-    def __init__(self, config: Config, backend="hip", device_id: int = -1):
+    def __init__(self, config: Config, backend="hip", device_id: int = -1, lib_path: Optional[str] = None):
         if not config.is_consolidated or config.gas_optics_lw is None and config.gas_optics_sw is None:
             setup_radiation(config)
         self.config = config
@@ -541,7 +542,7 @@ class Radiation:
         self.lib = None
         self.handle = None
         if backend == "hip":
-            self.lib = load_library()
+            self.lib = load_library(lib_path or LIB_PATH)      # (lib_path: a tuning / test variant of the library)
             h = C.c_void_p()
             st = self.lib.ecrad_hip_create(C.byref(h), device_id)
             if st != 0:

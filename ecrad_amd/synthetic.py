@@ -24,7 +24,7 @@ from .types import Aerosol, Cloud, Gas, SingleLevel, Thermodynamics
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MERIDIAN = os.path.join(ROOT, "tests", "golden", "ecrad_meridian.nc")
-NAMELIST = os.path.join(ROOT, "ecrad_amd", "configs", "configCY49R1_ecckd.nam")
+NAMELIST = os.path.join(ROOT, "tests", "golden", "configCY49R1_ecckd.nam")
 SEED = 20260929
 
 

@@ -399,6 +399,12 @@ int ecrad_hip_last_kernel_ms(ecrad_hip_handle_t handle, double* ms);
 #define ECRAD_STAGE_POST 3   /* surface/TOA spectral sums */
 int ecrad_hip_last_stage_ms(ecrad_hip_handle_t handle, int which, double* ms);
 
+/* What this device's HBM sustains ("use the measured triad bandwidth as the practical 100 %"):
+   a[i] = b[i] + s * c[i] over three arrays of nbytes_per_array bytes each (16 bytes per lane, grid-stride), best of
+   `repeats` launches timed with HIP events on the handle's stream; *gbs = 3 * nbytes_per_array / time.  The arrays are
+   allocated and freed inside the call.  Measurement aid of bench.py; touches nothing else of the handle. */
+int ecrad_hip_hbm_triad(ecrad_hip_handle_t handle, size_t nbytes_per_array, int repeats, double* gbs);
+
 /* Bytes of device scratch currently held by the handle. */
 int ecrad_hip_scratch_bytes(ecrad_hip_handle_t handle, size_t* bytes);
 

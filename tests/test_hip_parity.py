@@ -378,3 +378,31 @@ def test_stage_intermediates_match_oracle(oracle_lib, lw_aerosol_scattering):
             assert np.abs(want[k]).max() > 0.0
         assert rel_err(got[k], want[k], floor_frac=1e-9) < 1e-10, k
     rad.close()
+
+
+def test_packed_sweep_records_change_nothing_that_matters():
+    """The shortwave sweep records travel as five doubles in 32 bytes (39 mantissa bits, rounded to nearest:
+    kernels_common.h pack5).  The same sources built with -DECRAD_PACK_SW=0 (tests/_build/variants/nopack, made by
+    __graft_entry__.build()) keep all 53 bits; the two builds must agree to 1e-10 on every flux -- two orders below the
+    1e-8 the parity tests demand -- for the homogeneous / McICA kernel and the Tripleclouds kernel."""
+    import os
+    from ecrad_amd.interface import Radiation
+    from ecrad_amd.types import Flux
+    nopack = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "_build", "variants", "nopack", "libecrad_hip.so")
+    assert os.path.exists(nopack), "tests/_build/variants/nopack/libecrad_hip.so is missing: run __graft_entry__.build()"
+    for solver in ("Homogeneous", "Tripleclouds", "McICA"):
+        out = []
+        for path in (None, nopack):
+            config = make_config(solver)
+            rad = Radiation(config, backend="hip", lib_path=path)
+            ncol, nlev, sl, th, gas, cloud, aer = load_meridian(config)
+            rad.set_gas_units(gas)
+            th.calc_saturation_wrt_liquid()
+            flux = Flux.allocate(config, ncol, nlev)
+            rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)
+            rad.close()
+            out.append(flux)
+        worst = compare_flux(out[0], out[1], 1e-10)
+        changed = max(float(np.max(np.abs(out[0].arrays[n] - out[1].arrays[n]))) for n in ("sw_up", "sw_dn"))
+        assert changed > 0.0, "the two builds are identical: the variant is not a build without packing"
+        print(solver, "packed vs unpacked records:", max(worst.values()))

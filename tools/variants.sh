@@ -1,12 +1,12 @@
 #!/bin/bash
 # tools/variants.sh NAME "EXTRA_HIPCC_FLAGS"
 # Build a tuning/ablation variant of libecrad_hip.so into build_variants/NAME/ (git-ignored, but it
-# travels to the GPU box).  Time it with:  ECRAD_HIP_LIB=build_variants/NAME/libecrad_hip.so python bench.py ...
+# travels to the GPU box; ECRAD_VARIANT_DIR puts it elsewhere, e.g. tests/_build/variants for the variants the tests load).  Time it with:  ECRAD_HIP_LIB=build_variants/NAME/libecrad_hip.so python bench.py ...
 set -e
 name=$1; shift
 extra="$*"
 root=$(cd "$(dirname "$0")/.." && pwd)
-out=$root/build_variants/$name
+out=${ECRAD_VARIANT_DIR:-$root/build_variants}/$name
 mkdir -p $out
 src="api kernel_ica_sw kernel_ica_lw kernel_lw_scat kernel_tc kernel_prep kernel_optics kernel_rrtmg kernel_spartacus"
 for f in $src; do
