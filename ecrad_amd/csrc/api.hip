@@ -1055,6 +1055,23 @@ int grid_for(ecrad_hip_handle_t h, int nloc, int ngp) {
 // Bytes of per-call work arrays one column costs (the arrays below that are sized by the number of columns of a
 // call: RRTMG stage arrays and work records, cloud geometry / McICA optical-depth scalings, per-chunk partial
 // profiles, per-g spectral temporaries and, in host-memory mode, the staged inputs and outputs).
+// Work arrays laid out like the flux profiles, (columns of the flux arrays) x (nlev+1) planes: the per-chunk partial
+// broadband profiles of spectra wider than 64 g-points and the per-g temporaries of spectral flux profiles.  Bytes per
+// column OF THE FLUX ARRAYS: the tile's columns in host-memory mode, the caller's whole ncol in device-memory mode
+// (where they do not shrink with the tile and come off the budget before the tile size is chosen).
+size_t plane_bytes_per_column(ecrad_hip_handle_t h, int nlev) {
+  const ecrad_config_t& c = h->cfg;
+  const size_t L = nlev;
+  size_t b = 0;
+  const int nch = std::max(c.do_lw ? h->nchunk_lw : 1, c.do_sw ? h->nchunk_sw : 1);
+  if (nch > 1) b += 8 * (L + 1) * nch * 6;
+  if (c.do_save_spectral_flux) {
+    if (h->spec_sum_lw) b += 8 * (L + 1) * (size_t)c.n_g_lw * 4;
+    if (h->spec_sum_sw) b += 8 * (L + 1) * (size_t)c.n_g_sw * 6;
+  }
+  return b;
+}
+
 size_t work_bytes_per_column(ecrad_hip_handle_t h, int nlev, const ecrad_inputs_t* in, const ecrad_flux_t* flux) {
   const ecrad_config_t& c = h->cfg;
   const size_t L = nlev;
@@ -1075,12 +1092,9 @@ size_t work_bytes_per_column(ecrad_hip_handle_t h, int nlev, const ecrad_inputs_
   if (sw_mcica) b += 8 * ((size_t)c.n_g_sw * L + 1);
   if (lw_mcica) b += 8 * ((size_t)c.n_g_lw * L + 1);
   if (c.do_clouds) b += 8 * L;
-  const int nch = std::max(c.do_lw ? h->nchunk_lw : 1, c.do_sw ? h->nchunk_sw : 1);
-  if (nch > 1) b += 8 * (L + 1) * nch * 6;
-  if (c.do_save_spectral_flux) {
-    if (h->spec_sum_lw) b += 8 * (L + 1) * (size_t)c.n_g_lw * 4;
-    if (h->spec_sum_sw) b += 8 * (L + 1) * (size_t)c.n_g_sw * 6;
-  }
+  // (per-chunk partial profiles and per-g spectral temporaries are indexed like the caller's flux arrays: in host-memory
+  //  mode those are the staged arrays of the tile, in device-memory mode the caller's own ncol -- see plane_bytes_per_column)
+  if (in->memory == ECRAD_MEM_HOST) b += plane_bytes_per_column(h, nlev);
   if (in->memory == ECRAD_MEM_HOST) {
     const Range one{1, nlev, 1, 1, 1};
     b += carve_inputs(nullptr, c, *in, one).bytes;
@@ -1516,6 +1530,11 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
       held += b->cap;
     const size_t avail = (size_t)(0.9 * (double)(free_b + held));
     if (budget > avail) budget = avail;
+    if (in->memory != ECRAD_MEM_HOST) {      // the ncol-sized planes do not shrink with the tile: they come off the top
+      const size_t planes = plane_bytes_per_column(h, nlev) * (size_t)ncol;
+      if (planes >= budget) return fail(h, ECRAD_ENOMEM, "work budget too small for the per-chunk / per-g-point profile planes of this call (ecrad_hip_set_work_bytes)");
+      budget -= planes;
+    }
   }
   long long tile_cols = per_col ? (long long)(budget / per_col) : (long long)nloc;
   tile_cols = std::max(4096ll, tile_cols / 256 * 256);

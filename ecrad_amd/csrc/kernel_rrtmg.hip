@@ -405,7 +405,13 @@ __global__ __launch_bounds__(kBlock) void rrtmg_incoming_kernel(const DevRrtmg* 
       for (int ib = 0; ib < kNBandSw; ++ib) {
         const SwBand& B = Tp->sw[ib];
         for (int ig = 0; ig < B.ng; ++ig) {
-          const int j = Tp->permute_sw ? Tp->pos_sw[B.g0 + ig] : B.g0 + ig;
+          // The reference scales ZINCSOL(:,jg), jg in RRTMG's NATIVE order, by the factor of band
+          // i_band_from_reordered_g_sw(jg) -- the band of the g-point that sits at position jg of the REORDERED spectrum.
+          // Without SPARTACUS's reordering that is jg's own band.  With it, it is the band of another g-point; kept as the
+          // reference has it (identical results on identical inputs): g-point n = pos[g'] is the one whose position-n
+          // occupant g' belongs to band ib, and it sits at pos[n] of the stage arrays.
+          const int g = B.g0 + ig;
+          const int j = Tp->permute_sw ? Tp->pos_sw[Tp->pos_sw[g]] : g;
           inc[j] = inc[j] * sc.v[ib];
         }
       }

@@ -249,7 +249,11 @@ def _setup_radiation_rrtmg(config: Config) -> None:
         elif config.do_save_gpoint_flux:
             ng = getattr(config, "n_g_" + sfx)
             setattr(config, "n_spec_" + sfx, ng)
-            setattr(config, "i_spec_from_reordered_g_" + sfx, np.arange(1, ng + 1, dtype=np.int32))
+            # radiation_ifs_rrtm.F90:139-141: i_spec_from_reordered_g => i_g_from_reordered_g -- with SPARTACUS's
+            # reordering the per-g-point flux profiles are stored by the NATIVE RRTMG g-point index
+            perm = getattr(config.rrtmg, "i_g_from_reordered_g_" + sfx, None) if is_rrtmg else None
+            setattr(config, "i_spec_from_reordered_g_" + sfx,
+                    np.arange(1, ng + 1, dtype=np.int32) if perm is None else np.asarray(perm, dtype=np.int32).copy())
         else:
             setattr(config, "n_spec_" + sfx, getattr(config, "n_bands_" + sfx))
             setattr(config, "i_spec_from_reordered_g_" + sfx,

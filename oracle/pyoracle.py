@@ -304,7 +304,11 @@ def rrtmg_gas_stage(config, ncol, nlev, cin, nthreads=1):
         out["od_sw"][c0:c1] = np.maximum(o_sw[:, ::-1, :], config.min_gas_od_sw)
         out["ssa_sw"][c0:c1] = o_ssa[:, ::-1, :]
         if cin.spectral_solar_scaling:        # radiation_ifs_rrtm.F90:545-551: per band, before the normalisation
-            o_inc = o_inc * _np_from(cin.spectral_solar_scaling, (14,))[np.repeat(np.arange(14), _NG_SW)][None, :]
+            # (native g-point jg takes the factor of band i_band_from_reordered_g_sw(jg): with SPARTACUS's reordering that
+            #  is the band of the g-point AT POSITION jg of the reordered spectrum, as the reference has it)
+            ib = getattr(config, "i_band_from_reordered_g_sw", None)
+            ib = np.repeat(np.arange(14), _NG_SW) if ib is None or len(ib) != 112 else np.asarray(ib) - 1
+            o_inc = o_inc * _np_from(cin.spectral_solar_scaling, (14,))[ib][None, :]
         tot = o_inc.sum(axis=1)
         scale = np.where(mu0[c0:c1] > 0.0, cin.solar_irradiance / np.where(tot > 0, tot, 1.0), 1.0)
         out["incoming_sw"][c0:c1] = o_inc * scale[:, None]

@@ -270,3 +270,47 @@ def test_rrtmg_gpoint_reordering_tables_and_where_they_apply():
     setup_radiation(c2)
     assert c2.rrtmg.i_g_from_reordered_g_sw is None and c2.rrtmg.i_g_from_reordered_g_lw is not None
     assert np.array_equal(c2.i_band_from_reordered_g_sw, c2.rrtmg.i_band_from_g_sw)
+
+
+def _gpoint_profiles_case(solver, make_backend):
+    from helpers import make_config_rrtmg, run_case
+    cfg = make_config_rrtmg(solver, do_save_spectral_flux=True, do_save_gpoint_flux=True, do_3d_effects=False,
+                            i_3d_sw_entrapment=0, max_cloud_od=1.0e30)
+    flux, _, rad = run_case(cfg, make_backend(cfg))
+    if hasattr(rad, "close"):
+        rad.close()
+    return cfg, flux
+
+
+def _check_gpoint_profiles_native_order(make_backend):
+    """SPARTACUS on RRTMG takes the g-points reordered, but stores per-g-point spectral flux PROFILES by the native RRTMG
+    g-point (radiation_ifs_rrtm.F90:139-141: i_spec_from_reordered_g => i_g_from_reordered_g).  Without 3-D effects the
+    shortwave solver is Tripleclouds (tests/test_oracle_spartacus.py), which runs un-reordered: profile g of the one must be
+    profile g of the other -- a permuted store would be off by whole g-points."""
+    from helpers import rel_err
+    csp, sp = _gpoint_profiles_case("SPARTACUS", make_backend)
+    ctc, tc = _gpoint_profiles_case("Tripleclouds", make_backend)
+    assert not np.array_equal(csp.i_spec_from_reordered_g_sw, np.arange(1, 113)) and sorted(csp.i_spec_from_reordered_g_sw) == list(range(1, 113))
+    assert np.array_equal(csp.i_spec_from_reordered_g_sw, csp.rrtmg.i_g_from_reordered_g_sw)
+    assert np.array_equal(csp.i_spec_from_reordered_g_lw, csp.rrtmg.i_g_from_reordered_g_lw)
+    assert np.array_equal(ctc.i_spec_from_reordered_g_sw, np.arange(1, 113))
+    perm = csp.rrtmg.i_g_from_reordered_g_sw - 1
+    for name in ("sw_up_band", "sw_dn_band", "sw_dn_direct_band", "sw_up_clear_band", "sw_dn_clear_band"):
+        a, b = sp.arrays[name], tc.arrays[name]
+        assert a.shape == b.shape and a.shape[-1] == 112       # numpy order of (nspec, ncol, nlev+1)
+        assert rel_err(a, b) < 1.0e-10, name
+        assert rel_err(a[..., perm], b) > 1.0e-2, name      # ... and it IS a test of the order: permuted, the same data are far off
+    # longwave: the clear-sky profiles of the two solvers agree closely (different clear-layer routines), a permutation would not
+    for name in ("lw_up_clear_band", "lw_dn_clear_band"):
+        assert rel_err(sp.arrays[name], tc.arrays[name]) < 1.0e-3, name
+
+
+def test_gpoint_flux_profiles_of_reordered_spartacus_are_in_native_order(oracle_lib):
+    if not oracle_lib.have_ref_rrtm():
+        pytest.skip("oracle/_ref/libecrad_refrrtm.so (the reference's RRTMG routines) has not been built")
+    _check_gpoint_profiles_native_order(lambda cfg: oracle_lib.make_rrtmg_backend(cfg))
+
+
+@pytest.mark.gpu
+def test_gpoint_flux_profiles_of_reordered_spartacus_are_in_native_order_hip():
+    _check_gpoint_profiles_native_order(lambda cfg: "hip")

@@ -95,3 +95,33 @@ def test_hip_matches_oracle_with_solar_scaling(solver, oracle_lib):
     assert not bad, bad
     f_0 = _run(oracle_lib.make_rrtmg_backend, None, solver, **kw)
     assert rel_err(f_hip.sw_dn[-1], f_0.sw_dn[-1]) > 1e-4               # (the factors reached the device)
+
+
+def test_scaling_under_the_spartacus_reordering_follows_the_reference(oracle_lib):
+    """radiation_ifs_rrtm.F90:545-551 indexes the factors with i_band_from_reordered_g_sw(jg) while jg runs over RRTMG's NATIVE
+    g-points: with SPARTACUS's reordering g-point jg gets the factor of the band of the g-point at POSITION jg of the reordered
+    spectrum.  The restatement keeps that (identical results on identical inputs); this pins what it means: the per-g-point
+    incoming flux at the top of the atmosphere, un-reordered, is the unscaled one times WHI[band at position g], renormalised."""
+    _need_ref(oracle_lib)
+    kw = dict(do_3d_effects=False, do_save_gpoint_flux=True)
+    f0 = _run(oracle_lib.make_rrtmg_backend, None, solver="SPARTACUS", **kw)
+    fw = _run(oracle_lib.make_rrtmg_backend, WHI, solver="SPARTACUS", **kw)
+    cfg = make_config_rrtmg("SPARTACUS", **kw)
+    from ecrad_amd.interface import setup_radiation
+    setup_radiation(cfg)
+    band_at_position = np.asarray(cfg.i_band_from_reordered_g_sw) - 1
+    assert not np.array_equal(band_at_position, np.asarray(cfg.rrtmg.i_band_from_g_sw) - 1)
+    day = f0.sw_dn[0] > 0
+    toa0, toaw = f0.arrays["sw_dn_band"][0][day], fw.arrays["sw_dn_band"][0][day]        # (column, native g-point)
+    expect = toa0 * WHI[band_at_position][None, :]
+    expect = expect * (toa0.sum(axis=1) / expect.sum(axis=1))[:, None]
+    assert np.abs(toaw / expect - 1.0).max() < 1e-12
+
+
+@pytest.mark.gpu
+def test_hip_scaling_under_the_spartacus_reordering(oracle_lib):
+    _need_ref(oracle_lib)
+    kw = dict(do_3d_effects=True, do_save_gpoint_flux=True)
+    f_ora = _run(oracle_lib.make_rrtmg_backend, WHI, solver="SPARTACUS", **kw)
+    f_hip = _run(lambda c: "hip", WHI, solver="SPARTACUS", **kw)
+    compare_flux(f_hip, f_ora, 1e-8)
