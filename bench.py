@@ -21,8 +21,9 @@ Prints ONE JSON line on rank 0 with the contract's keys plus:
   "end_to_end_host": the same call through ECRAD_MEM_HOST pointers (H2D + kernels + D2H, PCIe-inclusive)
   "workloads":    (N=1, default run) the other BASELINE configurations on this GPU, each with its own
                   value / ms_per_step / roofline / cpu_baseline / parity:
-                  tripleclouds_ecckd32 (north-star shape), mcica_rrtmg (configs[2]) and
-                  tripleclouds_ecckd64 at 1 250 000 columns (the per-GPU shard of configs[3])
+                  tripleclouds_ecckd32 (north-star shape), mcica_rrtmg (configs[2]), tripleclouds_ecckd64 at
+                  1 250 000 columns (the per-GPU shard of configs[3]), spartacus_ecckd32_sp at 100 000 and at 1 250 000
+                  columns (the per-GPU shard of configs[4])
 """
 from __future__ import annotations
 
@@ -44,7 +45,7 @@ HBM_TRIAD_GBS = None       # measured on THIS box when the first workload is set
 FP64_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (MI355X_MICROARCH.md quotes the FP32 vector peak, 157.3 = 2 x this)
 PARITY_TOLERANCE = 1.0e-6  # BASELINE.json north_star: fluxes within 1e-6 relative of the CPU reference
 EXTRA_WORKLOADS = (("tripleclouds_ecckd32", 100000), ("mcica_rrtmg", 100000), ("tripleclouds_ecckd64", 1250000),
-                   ("spartacus_ecckd32_sp", 100000))
+                   ("spartacus_ecckd32_sp", 100000), ("spartacus_ecckd32_sp", 1250000))
 CHUNK_COLUMNS = 125000     # synthetic columns are generated and uploaded this many at a time (bounds host memory)
 
 
@@ -640,7 +641,7 @@ def main():
             if "parity" in r and not r["parity"]["ok"]:
                 r["value"] = None
                 failed = True
-            out["workloads"][name] = r
+            out["workloads"][name if name not in out["workloads"] else f"{name}_{ncol}"] = r
     if rank == 0:
         if failed and "parity" in head and not head["parity"]["ok"]:
             out["value"] = None

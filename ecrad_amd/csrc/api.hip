@@ -72,7 +72,8 @@ struct ecrad_hip_handle_s {
   const ecrad::rrtmg::DevRrtmg* d_rrtmg = nullptr;   // RRTMG tables (device), see rrtmg_device.h
   bool rrtmg_sw = false, rrtmg_lw = false;
   Buf gas_stage, gas_work;         // stage-interface arrays and work records of the RRTMG gas-optics pass
-  Buf sp_stage;                    // stage-interface arrays read by the SPARTACUS solver kernels
+  Buf sp_stage;                    // stage-interface arrays read by the SPARTACUS solver kernels + the layer store of the listed layers
+  Buf sp_list;                     // SPARTACUS work list: (column, cloudy layer) items, their index per (column, layer), the count
   // One set of stage-boundary events per column tile of the most recent call (a call whose work arrays
   // would exceed `work_budget` runs as several tiles of columns, see ecrad_hip_radiation)
   struct TileEvents { hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; };
@@ -606,7 +607,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
   if (!h) return ECRAD_EINVAL;
   (void)hipSetDevice(h->device);
   free_tables(h);
-  h->gas_stage.release(); h->gas_work.release(); h->sp_stage.release(); h->counters.release(); h->partial.release(); h->spec_tmp.release(); h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
+  h->gas_stage.release(); h->gas_work.release(); h->sp_stage.release(); h->sp_list.release(); h->counters.release(); h->partial.release(); h->spec_tmp.release(); h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
   for (auto& t : h->tile_events) for (auto& e : t.e) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : {h->ev_fork, h->ev_gen_lw, h->ev_gen_sw, h->ev_fork_sw, h->ev_sw_done}) if (e) (void)hipEventDestroy(e);
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
@@ -616,7 +617,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
 
 int ecrad_hip_scratch_bytes(ecrad_hip_handle_t h, size_t* bytes) {
   if (!h || !bytes) return ECRAD_EINVAL;
-  *bytes = h->scratch.cap + h->prep.cap + h->staging_in.cap + h->staging_out.cap + h->partial.cap + h->spec_tmp.cap + h->gas_stage.cap + h->gas_work.cap + h->sp_stage.cap;
+  *bytes = h->scratch.cap + h->prep.cap + h->staging_in.cap + h->staging_out.cap + h->partial.cap + h->spec_tmp.cap + h->gas_stage.cap + h->gas_work.cap + h->sp_stage.cap + h->sp_list.cap;
   return ECRAD_OK;
 }
 
@@ -1085,9 +1086,9 @@ size_t work_bytes_per_column(ecrad_hip_handle_t h, int nlev, const ecrad_inputs_
   if (tc || sw_sp || lw_sp) b += 8 * (5 * L + 18 * (L + 1));
   {   // stage arrays of the SPARTACUS solvers (one buffer, reused by the two spectra)
     const size_t w = c.i_precision == ECRAD_PRECISION_SINGLE ? 4 : 8;
-    const size_t bsw = sw_sp ? 8 * ((size_t)c.n_g_sw * (3 * L + 3) + (size_t)c.n_bands_sw * 3 * L) + w * L * spartacus_layer_words(true, std::min(c.n_g_sw, h->ngp_sw)) : 0;
-    const size_t blw = lw_sp ? 8 * ((size_t)c.n_g_lw * (4 * L + 3) + (size_t)c.n_bands_lw * 3 * L) + w * L * spartacus_layer_words(false, std::min(c.n_g_lw, h->ngp_lw)) : 0;
-    b += std::max(bsw, blw) + 4 * L;
+    const size_t bsw = sw_sp ? w * ((size_t)c.n_g_sw * (3 * L + 3) + (size_t)c.n_bands_sw * 3 * L) + w * L * spartacus_layer_words(true, std::min(c.n_g_sw, h->ngp_sw)) : 0;
+    const size_t blw = lw_sp ? w * ((size_t)c.n_g_lw * (4 * L + 3) + (size_t)c.n_bands_lw * 3 * L) + w * L * spartacus_layer_words(false, std::min(c.n_g_lw, h->ngp_lw)) : 0;
+    b += std::max(bsw, blw) + ((sw_sp || lw_sp) ? 8 * L : 0);      // (+ work list and item index; the layer store counted for the worst case: every layer listed)
   }
   if (sw_mcica) b += 8 * ((size_t)c.n_g_sw * L + 1);
   if (lw_mcica) b += 8 * ((size_t)c.n_g_lw * L + 1);
@@ -1267,6 +1268,24 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
   HIP_TRY(h, hipMemsetAsync(counters, 0, 256, stream));
   HIP_TRY(h, launch_order(stream, din, counters + 32));                                 // :310-317
   if (c.do_clouds) HIP_TRY(h, launch_crop(stream, h->dcfg, din));                      // :361 (before the gas optics, which do not read the clouds: the generators below only wait for this)
+  // SPARTACUS: the work list of the tile's (column, cloudy layer) pairs, the same for both spectra.  Its length sizes the
+  // layer store, so it is read back here: the one point at which a call waits for the device (a few microseconds into
+  // the tile; the list kernel only needs the cropped cloud fraction).
+  uint32_t* sp_items = nullptr;
+  int *sp_item_of = nullptr, *sp_n_items = nullptr;
+  int sp_n = 0;
+  if (sw_sp || lw_sp) {
+    for (int pass = 0; pass < 2; ++pass) {
+      Carver cv(pass == 0 ? nullptr : h->sp_list.p);
+      sp_items = cv.take<uint32_t>((size_t)nlev * r.nloc);
+      sp_item_of = cv.take<int>((size_t)nlev * r.nloc);
+      sp_n_items = cv.take<int>(64);
+      if (pass == 0) HIP_TRY(h, h->sp_list.ensure(cv.off));
+    }
+    HIP_TRY(h, launch_spartacus_list(stream, c, din, sp_items, sp_item_of, sp_n_items));
+    HIP_TRY(h, hipMemcpyAsync(&sp_n, sp_n_items, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(h, hipStreamSynchronize(stream));
+  }
   // (only next to the RRTMG gas-optics pass: 212.8 -> 208.6 ms per 100 000 columns, profiles/r02_zk_gen_overlap.log; next to
   //  the other spectrum's solver kernel of an ecCKD run it gains nothing -- both are bound by instruction issue)
   const bool gen_overlap = (sw_mcica || lw_mcica) && (h->rrtmg_sw || h->rrtmg_lw) && !getenv("ECRAD_NO_GEN_OVERLAP");
@@ -1299,39 +1318,39 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     const size_t n = r.nloc, L = nlev, ngs = is_sw ? c.n_g_sw : c.n_g_lw, nbs = is_sw ? c.n_bands_sw : c.n_bands_lw;
     DevOptics dop{};
     void* lay = nullptr;
-    uint32_t* list = nullptr;
-    int* n_items = nullptr;
     for (int pass = 0; pass < 2; ++pass) {
       Carver cv(pass == 0 ? nullptr : h->sp_stage.p);
-      lay = cv.take<char>(sp_word * L * n * spartacus_layer_words(is_sw, std::min((int)ngs, is_sw ? h->ngp_sw : h->ngp_lw)));
-      list = cv.take<uint32_t>(L * n);
-      n_items = cv.take<int>(64);
+      // the layer store holds the listed layers only (45 SW / 24 LW words per g-point of a launch each)
+      lay = cv.take<char>(sp_word * (size_t)std::max(sp_n, 1) * spartacus_layer_words(is_sw, std::min((int)ngs, is_sw ? h->ngp_sw : h->ngp_lw)));
+      // stage arrays in the solver's working precision (optics_dump_kernel<..., OUT>): float in single precision
+      auto stage = [&](size_t count) { return reinterpret_cast<double*>(cv.take<char>(count * sp_word)); };
       if (is_sw) {
-        dop.od_sw = cv.take<double>(ngs * L * n); dop.ssa_sw = cv.take<double>(ngs * L * n); dop.g_sw = cv.take<double>(ngs * L * n);
-        dop.sw_albedo_direct = cv.take<double>(ngs * n); dop.sw_albedo_diffuse = cv.take<double>(ngs * n); dop.incoming_sw = cv.take<double>(ngs * n);
-        dop.od_sw_cloud = cv.take<double>(nbs * L * n); dop.ssa_sw_cloud = cv.take<double>(nbs * L * n); dop.g_sw_cloud = cv.take<double>(nbs * L * n);
+        dop.od_sw = stage(ngs * L * n); dop.ssa_sw = stage(ngs * L * n); dop.g_sw = stage(ngs * L * n);
+        dop.sw_albedo_direct = stage(ngs * n); dop.sw_albedo_diffuse = stage(ngs * n); dop.incoming_sw = stage(ngs * n);
+        dop.od_sw_cloud = stage(nbs * L * n); dop.ssa_sw_cloud = stage(nbs * L * n); dop.g_sw_cloud = stage(nbs * L * n);
       } else {
-        dop.od_lw = cv.take<double>(ngs * L * n);
-        if (c.do_lw_aerosol_scattering) { dop.ssa_lw = cv.take<double>(ngs * L * n); dop.g_lw = cv.take<double>(ngs * L * n); }
-        dop.planck_hl = cv.take<double>(ngs * (L + 1) * n); dop.lw_emission = cv.take<double>(ngs * n); dop.lw_albedo = cv.take<double>(ngs * n);
-        dop.od_lw_cloud = cv.take<double>(nbs * L * n); dop.ssa_lw_cloud = cv.take<double>(nbs * L * n); dop.g_lw_cloud = cv.take<double>(nbs * L * n);
+        dop.od_lw = stage(ngs * L * n);
+        if (c.do_lw_aerosol_scattering) { dop.ssa_lw = stage(ngs * L * n); dop.g_lw = stage(ngs * L * n); }
+        dop.planck_hl = stage(ngs * (L + 1) * n); dop.lw_emission = stage(ngs * n); dop.lw_albedo = stage(ngs * n);
+        dop.od_lw_cloud = stage(nbs * L * n); dop.ssa_lw_cloud = stage(nbs * L * n); dop.g_lw_cloud = stage(nbs * L * n);
       }
       if (pass == 0) HIP_TRY(h, h->sp_stage.ensure(cv.off));
     }
     const DevCkdModel& m = is_sw ? h->hcfg.gas_sw : h->hcfg.gas_lw;
     const ChunkPlan& plan = is_sw ? h->plan_sw : h->plan_lw;
     if (!is_sw && c.do_lw_aerosol_scattering) {   // layers without aerosol keep ssa = g = 0
-      HIP_TRY(h, hipMemsetAsync(dop.ssa_lw, 0, ngs * L * n * 8, stream));
-      HIP_TRY(h, hipMemsetAsync(dop.g_lw, 0, ngs * L * n * 8, stream));
+      HIP_TRY(h, hipMemsetAsync(dop.ssa_lw, 0, ngs * L * n * sp_word, stream));
+      HIP_TRY(h, hipMemsetAsync(dop.g_lw, 0, ngs * L * n * sp_word, stream));
     }
     const int nch = plan.n;
     for (int p = 0; p < nch; ++p)
-      HIP_TRY(h, launch_optics_dump(is_sw, plan.ngp[p], m.table_f32, grid_for(h, r.nloc, plan.ngp[p]), lds_bytes(m.hot.nquad, c.n_cloud_types), stream, h->hcfg, din, dop, plan.g0[p]));
+      HIP_TRY(h, launch_optics_dump(is_sw, plan.ngp[p], m.table_f32, grid_for(h, r.nloc, plan.ngp[p]), lds_bytes(m.hot.nquad, c.n_cloud_types), stream, h->hcfg, din, dop, plan.g0[p],
+                                    sp_single, /*cloudy_only=*/true));
     auto launch_sp = [&](const DevFlux& f, int* counter, int p, bool wide) -> hipError_t {
       const int ngp = plan.ngp[p], g0 = plan.g0[p];
       return launch_spartacus(is_sw, sp_single, ngp, grid_sp(ngp, is_sw), h->num_cu, stream, c, din, dop, prep, f, scratch,
                               (is_sw ? per_block_sw : per_block_lw) * 8 / sp_word, counter,
-                              is_sw ? h->hcfg.i_band_from_reordered_g_sw : h->hcfg.i_band_from_reordered_g_lw, lay, list, n_items, g0, wide);
+                              is_sw ? h->hcfg.i_band_from_reordered_g_sw : h->hcfg.i_band_from_reordered_g_lw, lay, sp_items, sp_item_of, sp_n_items, g0, wide);
     };
     int* const counter0 = counters + (is_sw ? 16 : 0);
     if (nch == 1) {
@@ -1526,7 +1545,7 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
     HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
     if (!budget) budget = total_b / 2;
     size_t held = 0;
-    for (const Buf* b : {&h->spec_tmp, &h->partial, &h->scratch, &h->prep, &h->staging_in, &h->staging_out, &h->gas_stage, &h->gas_work, &h->sp_stage})
+    for (const Buf* b : {&h->spec_tmp, &h->partial, &h->scratch, &h->prep, &h->staging_in, &h->staging_out, &h->gas_stage, &h->gas_work, &h->sp_stage, &h->sp_list})
       held += b->cap;
     const size_t avail = (size_t)(0.9 * (double)(free_b + held));
     if (budget > avail) budget = avail;

@@ -16,10 +16,16 @@ struct DumpArgs {
   DevConfig cfg;
   DevInputs in;
   DevOptics out;
-  int32_t g0, pad_;
+  int32_t g0;
+  int32_t cloudy_only;      // write the cloud arrays of cloudy layers only (the SPARTACUS solvers read no others)
 };
 
-template <typename TAB, int NGP, bool IS_SW>
+// OUT: element type of the arrays written.  double for ecrad_hip_optics; float when the arrays feed the SPARTACUS solvers in
+// single precision, which round every stage value to float at their door (PARKIND1_SINGLE: jprb = float in the solver) --
+// rounding at the store instead is the same number and half the bytes both ways.
+template <typename OUT> ECRAD_DEV void put_stage(double* arr, size_t o, double v) { reinterpret_cast<OUT*>(arr)[o] = (OUT)v; }
+
+template <typename TAB, int NGP, bool IS_SW, typename OUT>
 __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void optics_dump_kernel(DumpArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   const DumpArgs& a0 = kernarg_block<DumpArgs>();
@@ -54,15 +60,15 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void optics_dump_kernel(Du
       double ad, adir;
       albedo_sw_g(cfg, in, col, g, ad, adir);
       if (valid) {
-        if (out.sw_albedo_diffuse) out.sw_albedo_diffuse[og] = ad;
-        if (out.sw_albedo_direct) out.sw_albedo_direct[og] = adir;
-        if (out.incoming_sw) out.incoming_sw[og] = in.gs.incoming_sw ? in.gs.incoming_sw[og] : incoming_sw_g(m, in, g);
+        if (out.sw_albedo_diffuse) put_stage<OUT>(out.sw_albedo_diffuse, og, ad);
+        if (out.sw_albedo_direct) put_stage<OUT>(out.sw_albedo_direct, og, adir);
+        if (out.incoming_sw) put_stage<OUT>(out.incoming_sw, og, in.gs.incoming_sw ? in.gs.incoming_sw[og] : incoming_sw_g(m, in, g));
       }
     } else {
       lw_albedo = albedo_lw_g(cfg, in, col, g);
       if (valid) {
-        if (out.lw_albedo) out.lw_albedo[og] = lw_albedo;
-        if (out.lw_emission) out.lw_emission[og] = (in.gs.lw_emission ? in.gs.lw_emission[og] : planck_at<TAB>(m, in.skin_temperature[col], g)) * (1.0 - lw_albedo);
+        if (out.lw_albedo) put_stage<OUT>(out.lw_albedo, og, lw_albedo);
+        if (out.lw_emission) put_stage<OUT>(out.lw_emission, og, (in.gs.lw_emission ? in.gs.lw_emission[og] : planck_at<TAB>(m, in.skin_temperature[col], g)) * (1.0 - lw_albedo));
       }
     }
     double planck_top = IS_SW ? 0.0 : planck_at<TAB>(m, in.temperature_hl[col + (size_t)in.ncol * level_order(in).half(0)], g);   // top-of-atmosphere half level
@@ -100,9 +106,9 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void optics_dump_kernel(Du
             merge_aerosol_sw(cfg, a, od, ssa, asym);
           }
           if (valid) {
-            if (out.od_sw) out.od_sw[o] = od;
-            if (out.ssa_sw) out.ssa_sw[o] = ssa;
-            if (out.g_sw) out.g_sw[o] = asym;
+            if (out.od_sw) put_stage<OUT>(out.od_sw, o, od);
+            if (out.ssa_sw) put_stage<OUT>(out.ssa_sw, o, ssa);
+            if (out.g_sw) put_stage<OUT>(out.g_sw, o, asym);
           }
         } else {
           double planck_bot = planck_lookup<TAB>(m, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
@@ -127,28 +133,28 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void optics_dump_kernel(Du
           }
           if (valid) {
             if (cfg.do_lw_aerosol_scattering) {
-              if (out.ssa_lw) out.ssa_lw[o] = ssa;
-              if (out.g_lw) out.g_lw[o] = asym;
+              if (out.ssa_lw) put_stage<OUT>(out.ssa_lw, o, ssa);
+              if (out.g_lw) put_stage<OUT>(out.g_lw, o, asym);
             }
-            if (out.od_lw) out.od_lw[o] = od;
+            if (out.od_lw) put_stage<OUT>(out.od_lw, o, od);
             if (out.planck_hl) {
               const size_t op = g + (size_t)ng * (lev + (size_t)(nlev + 1) * cloc);
-              if (lev == 0) out.planck_hl[op] = planck_top;
-              out.planck_hl[op + ng] = planck_bot;
+              if (lev == 0) put_stage<OUT>(out.planck_hl, op, planck_top);
+              put_stage<OUT>(out.planck_hl, op + ng, planck_bot);
             }
           }
           planck_top = planck_bot;
         }
-        if (want_clouds && gi < nb && col_ok) {
+        if (want_clouds && gi < nb && col_ok && !(kernarg_block<DumpArgs>().cloudy_only && !(L.D(F_FRAC, slot) > 0.0))) {
           // cloud tables are per band: lane b < n_bands writes band b
           const CloudLayer cl = cloud_layer<IS_SW, sizeof(TAB) == 8>(cfg, L, slot, gi);
           const size_t oc = gi + (size_t)nb * (lev + (size_t)nlev * cloc);
           double* pod = IS_SW ? out.od_sw_cloud : out.od_lw_cloud;
           double* pss = IS_SW ? out.ssa_sw_cloud : out.ssa_lw_cloud;
           double* pg = IS_SW ? out.g_sw_cloud : out.g_lw_cloud;
-          if (pod) pod[oc] = cl.od;
-          if (pss) pss[oc] = cl.ssa;
-          if (pg) pg[oc] = cl.g;
+          if (pod) put_stage<OUT>(pod, oc, cl.od);
+          if (pss) put_stage<OUT>(pss, oc, cl.ssa);
+          if (pg) put_stage<OUT>(pg, oc, cl.g);
         }
       }
     }
@@ -156,12 +162,14 @@ __global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void optics_dump_kernel(Du
 }
 
 hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
-                              const DevConfig& cfg, const DevInputs& in, const DevOptics& out, int g0) {
-  const DumpArgs args{cfg, in, out, g0, 0};
-#define ECRAD_L(T, N, S) do { ECRAD_ALLOW_LDS((optics_dump_kernel<T, N, S>), lds); hipLaunchKernelGGL((optics_dump_kernel<T, N, S>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
-#define ECRAD_N(T, S) do { if (ngp == 16) ECRAD_L(T, 16, S); else if (ngp == 32) ECRAD_L(T, 32, S); else ECRAD_L(T, 64, S); } while (0)
-  if (is_sw) { if (table_f32) ECRAD_N(float, true); else ECRAD_N(double, true); }
-  else { if (table_f32) ECRAD_N(float, false); else ECRAD_N(double, false); }
+                              const DevConfig& cfg, const DevInputs& in, const DevOptics& out, int g0, bool out_f32, bool cloudy_only) {
+  const DumpArgs args{cfg, in, out, g0, cloudy_only ? 1 : 0};
+#define ECRAD_L(T, N, S, O) do { ECRAD_ALLOW_LDS((optics_dump_kernel<T, N, S, O>), lds); hipLaunchKernelGGL((optics_dump_kernel<T, N, S, O>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
+#define ECRAD_N(T, S, O) do { if (ngp == 16) ECRAD_L(T, 16, S, O); else if (ngp == 32) ECRAD_L(T, 32, S, O); else ECRAD_L(T, 64, S, O); } while (0)
+#define ECRAD_O(T, S) do { if (out_f32) ECRAD_N(T, S, float); else ECRAD_N(T, S, double); } while (0)
+  if (is_sw) { if (table_f32) ECRAD_O(float, true); else ECRAD_O(double, true); }
+  else { if (table_f32) ECRAD_O(float, false); else ECRAD_O(double, false); }
+#undef ECRAD_O
 #undef ECRAD_N
 #undef ECRAD_L
   return hipGetLastError();

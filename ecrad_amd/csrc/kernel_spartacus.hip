@@ -189,8 +189,9 @@ struct SpArgs {
   void* scratch;
   size_t per_block;      // words of R per block
   int* counter;
-  void* lay;             // layer matrices of the listed layers: [(local column * nlev + layer) * NV + k][g], words of R
+  void* lay;             // layer matrices of the listed layers: [(item of the work list) * NV + k][g], words of R
   const uint32_t* list;  // work list of spartacus_layers_kernel: (local column << 8) | layer
+  const int* item_of;    // [local column * nlev + layer]: the layer's item in the work list (listed layers only)
   const int* n_items;
 };
 
@@ -247,6 +248,9 @@ ECRAD_DEV void transfer_rates(const SpConfig& c, const Geo& gm, int jl, R dz, R 
 
 // first g-point of the column whose gas optical depth exceeds max_gas_od_3d (NGP if none): the reference switches the
 // 3-D treatment off from that g-point on (radiation_spartacus_sw.F90:466-471, :661-668); every lane of the wave calls
+// Stage arrays (DevOptics) hold elements of the working precision R: written by optics_dump_kernel<..., OUT = R>
+template <typename R> ECRAD_DEV R stg(const double* arr, size_t o) { return reinterpret_cast<const R*>(arr)[o]; }
+
 template <int NGP> ECRAD_DEV int first_exceeding(bool exceeds, int tid) {
   const unsigned long long b = __ballot(exceeds);
   const int shift = ((tid & 63) / NGP) * NGP;
@@ -259,7 +263,7 @@ template <int NGP> ECRAD_DEV int first_exceeding(bool exceeds, int tid) {
 // lane k of the column group looks at g-points k, k + NGP, ... below g0.
 template <int NGP, typename R> ECRAD_DEV int first_exceeding_chunk(bool exceeds, int tid, const double* od, size_t o0, int g0, int glane, R max_od) {
   bool before = false;
-  for (int gp = glane; gp < g0; gp += NGP) before = before || R(od[o0 + gp]) > max_od;
+  for (int gp = glane; gp < g0; gp += NGP) before = before || stg<R>(od, o0 + gp) > max_od;
   const int first_before = first_exceeding<NGP>(before, tid);
   const int first_here = first_exceeding<NGP>(exceeds, tid);
   return first_before < NGP ? 0 : first_here;
@@ -386,7 +390,7 @@ ECRAD_DEV SwMats<R> sw_layer(const SpArgs& a, const Geo& gm, const LevelOrder& o
   const R tan_diffuse_angle_3d = R(kPi * 0.5);
   const R one_over_mu0 = R(1) / mu0;
   const size_t o = g + (size_t)ng * (jl + (size_t)nlev * cloc);
-  const R odl = R(a.op.od_sw[o]), ssal = R(a.op.ssa_sw[o]), gl = R(a.op.g_sw ? a.op.g_sw[o] : 0.0);
+  const R odl = R(stg<R>(a.op.od_sw, o)), ssal = R(stg<R>(a.op.ssa_sw, o)), gl = R(a.op.g_sw ? stg<R>(a.op.g_sw, o) : 0.0);
   const int first = first_exceeding_chunk<NGP, R>(valid && odl > R(c.max_gas_od_3d), tid, a.op.od_sw, o - g, c.g0, glane, R(c.max_gas_od_3d));
     // -- section 3: layer matrices --
     R od_region[3] = {odl, R(0), R(0)}, ssa_region[3] = {ssal, R(0), R(0)};
@@ -408,7 +412,7 @@ ECRAD_DEV SwMats<R> sw_layer(const SpArgs& a, const Geo& gm, const LevelOrder& o
       }
       nregactive = 3;
       const size_t oc = ib + (size_t)nb * (jl + (size_t)nlev * cloc);
-      const R odc = R(a.op.od_sw_cloud[oc]), ssac = R(a.op.ssa_sw_cloud[oc]), gc = R(a.op.g_sw_cloud[oc]);
+      const R odc = R(stg<R>(a.op.od_sw_cloud, oc)), ssac = R(stg<R>(a.op.ssa_sw_cloud, oc)), gc = R(stg<R>(a.op.g_sw_cloud, oc));
       const R scat_od = odl * ssal;
       R g_region[3] = {gl, R(0), R(0)};
 #pragma unroll
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
 
     const R mu0 = R(a.in.cos_sza[col]);
     const bool sun_up = !(mu0 < R(1.0e-10));      // :343
-    const R inc = R(a.op.incoming_sw[sg]), albdif = R(a.op.sw_albedo_diffuse[sg]), albdir = R(a.op.sw_albedo_direct[sg]);
+    const R inc = R(stg<R>(a.op.incoming_sw, sg)), albdif = R(stg<R>(a.op.sw_albedo_diffuse, sg)), albdir = R(stg<R>(a.op.sw_albedo_direct, sg));
     const R one_over_mu0 = R(1) / rmax(mu0, R(1.0e-30));
     R tan_sza;                                    // :395-405
     if (mu0 < min_mu0_3d) tan_sza = sp::sp_sqrt(R(1) / (min_mu0_3d * min_mu0_3d) - R(1));
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
     double pf_od, pf_ssa, pf_g;
     {
       const size_t o = g + (size_t)ng * (nlev - 1 + (size_t)nlev * cloc);
-      pf_od = a.op.od_sw[o]; pf_ssa = a.op.ssa_sw[o]; pf_g = a.op.g_sw ? a.op.g_sw[o] : 0.0;
+      pf_od = stg<R>(a.op.od_sw, o); pf_ssa = stg<R>(a.op.ssa_sw, o); pf_g = a.op.g_sw ? stg<R>(a.op.g_sw, o) : 0.0;
     }
     for (int jlev = nlev; jlev >= 1; --jlev) {
       const int jl = jlev - 1;
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
       const R odl = R(pf_od), ssal = R(pf_ssa), gl = R(pf_g);
       if (jl > 0) {
         const size_t o = g + (size_t)ng * (jl - 1 + (size_t)nlev * cloc);
-        pf_od = a.op.od_sw[o]; pf_ssa = a.op.ssa_sw[o]; pf_g = a.op.g_sw ? a.op.g_sw[o] : 0.0;
+        pf_od = stg<R>(a.op.od_sw, o); pf_ssa = stg<R>(a.op.ssa_sw, o); pf_g = a.op.g_sw ? stg<R>(a.op.g_sw, o) : 0.0;
       }
       if (do_clear || !listed) {
         R g1, g2, g3;
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
       }
       M3<R> refl, tran, rdir, tdd, tdir;
       if (listed) {
-        const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 45 * ngl + gs;
+        const R* lp = reinterpret_cast<const R*>(a.lay) + (size_t)a.item_of[(size_t)cloc * nlev + jl] * 45 * ngl + gs;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
           refl.a[k] = lp[(size_t)k * ngl]; tran.a[k] = lp[(size_t)(9 + k) * ngl]; rdir.a[k] = lp[(size_t)(18 + k) * ngl];
@@ -789,7 +793,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
           flux_up_above.a[0] = tad1 * direct_dn_above.a[0] + ta1 * flux_dn_above.a[0];
         } else {
           M3<R> refl, tran, tdd, tdir, ta1, tad1;
-          const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 45 * ngl + gs;
+          const R* lp = reinterpret_cast<const R*>(a.lay) + (size_t)a.item_of[(size_t)cloc * nlev + jl] * 45 * ngl + gs;
 #pragma unroll
           for (int k = 0; k < 9; ++k) {
             refl.a[k] = lp[(size_t)k * ngl]; tran.a[k] = lp[(size_t)(9 + k) * ngl]; tdd.a[k] = lp[(size_t)(27 + k) * ngl]; tdir.a[k] = lp[(size_t)(36 + k) * ngl];
@@ -884,9 +888,9 @@ ECRAD_DEV LwMats<R> lw_layer(const SpArgs& a, const Geo& gm, const LevelOrder& o
   R dz = R(1);
     const size_t o = g + (size_t)ng * (jl + (size_t)nlev * cloc);
     const size_t op = g + (size_t)ng * (jl + (size_t)(nlev + 1) * cloc);
-    R od_region[3] = {R(a.op.od_lw[o]), R(0), R(0)}, ssa_region[3] = {R(0), R(0), R(0)}, g_region[3] = {R(0), R(0), R(0)};
-    if (c.do_lw_aerosol_scattering) { ssa_region[0] = R(a.op.ssa_lw[o]); g_region[0] = R(a.op.g_lw[o]); }
-    const R pt = R(a.op.planck_hl[op]), pb = R(a.op.planck_hl[op + ng]);
+    R od_region[3] = {R(stg<R>(a.op.od_lw, o)), R(0), R(0)}, ssa_region[3] = {R(0), R(0), R(0)}, g_region[3] = {R(0), R(0), R(0)};
+    if (c.do_lw_aerosol_scattering) { ssa_region[0] = R(stg<R>(a.op.ssa_lw, o)); g_region[0] = R(stg<R>(a.op.g_lw, o)); }
+    const R pt = R(stg<R>(a.op.planck_hl, op)), pb = R(stg<R>(a.op.planck_hl, op + ng));
     const int first = first_exceeding_chunk<NGP, R>(valid && od_region[0] > R(c.max_gas_od_3d), tid, a.op.od_lw, o - g, c.g0, glane, R(c.max_gas_od_3d));
     R gamma1[3] = {R(0), R(0), R(0)}, gamma2[3] = {R(0), R(0), R(0)};
     R rate[9], el[3] = {R(0), R(0), R(0)};
@@ -910,16 +914,16 @@ ECRAD_DEV LwMats<R> lw_layer(const SpArgs& a, const Geo& gm, const LevelOrder& o
       }
       nregactive = 3;
       const size_t oc = ib + (size_t)nb * (jl + (size_t)nlev * cloc);
-      const R odc = R(a.op.od_lw_cloud[oc]);
+      const R odc = R(stg<R>(a.op.od_lw_cloud, oc));
       const R scat_od = od_region[0] * ssa_region[0];
 #pragma unroll
       for (int jreg = 1; jreg < 3; ++jreg) {
         const R ods = R(gm.ods(jreg, jl));
         od_region[jreg] = od_region[0] + odc * ods;
         if (c.do_lw_cloud_scattering) {
-          const R scat_od_cloud = odc * R(a.op.ssa_lw_cloud[oc]) * ods;
+          const R scat_od_cloud = odc * R(stg<R>(a.op.ssa_lw_cloud, oc)) * ods;
           ssa_region[jreg] = (scat_od + scat_od_cloud) / od_region[jreg];
-          if (scat_od + scat_od_cloud > R(0)) g_region[jreg] = (scat_od * g_region[0] + scat_od_cloud * R(a.op.g_lw_cloud[oc])) / (scat_od + scat_od_cloud);
+          if (scat_od + scat_od_cloud > R(0)) g_region[jreg] = (scat_od * g_region[0] + scat_od_cloud * R(stg<R>(a.op.g_lw_cloud, oc))) / (scat_od + scat_od_cloud);
         }
         if (od_region[jreg] > R(c.max_cloud_od)) od_region[jreg] = R(c.max_cloud_od);
       }
@@ -1093,7 +1097,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
     const bool do_clear = c.do_clear != 0;
     const size_t og = g + (size_t)ng * col;
     const size_t sg = g + (size_t)ng * cloc;
-    const R emis = R(a.op.lw_emission[sg]), alb = R(a.op.lw_albedo[sg]);
+    const R emis = R(stg<R>(a.op.lw_emission, sg)), alb = R(stg<R>(a.op.lw_albedo, sg));
     const bool matrix_adding = c.do_3d_effects || c.do_3d_lw_multilayer_effects;
 
     // ---- sections 3 + 4: surface -> top ------------------------------------------------------------------------
@@ -1107,8 +1111,8 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
     {
       const size_t o = g + (size_t)ng * (nlev - 1 + (size_t)nlev * cloc);
       const size_t op = g + (size_t)ng * (nlev - 1 + (size_t)(nlev + 1) * cloc);
-      pf_od = a.op.od_lw[o]; pf_pt = a.op.planck_hl[op]; pf_pb = a.op.planck_hl[op + ng];
-      if (c.do_lw_aerosol_scattering) { pf_ssa = a.op.ssa_lw[o]; pf_g = a.op.g_lw[o]; }
+      pf_od = stg<R>(a.op.od_lw, o); pf_pt = stg<R>(a.op.planck_hl, op); pf_pb = stg<R>(a.op.planck_hl, op + ng);
+      if (c.do_lw_aerosol_scattering) { pf_ssa = stg<R>(a.op.ssa_lw, o); pf_g = stg<R>(a.op.g_lw, o); }
     }
     for (int jlev = nlev; jlev >= 1; --jlev) {
       const int jl = jlev - 1;
@@ -1121,10 +1125,10 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
       const R od0 = R(pf_od), pt0 = R(pf_pt), pb0 = R(pf_pb), ssa0 = R(pf_ssa), g0 = R(pf_g);
       if (jl > 0) {
         const size_t o = g + (size_t)ng * (jl - 1 + (size_t)nlev * cloc);
-        pf_od = a.op.od_lw[o];
+        pf_od = stg<R>(a.op.od_lw, o);
         pf_pb = pf_pt;
-        pf_pt = a.op.planck_hl[g + (size_t)ng * (jl - 1 + (size_t)(nlev + 1) * cloc)];
-        if (c.do_lw_aerosol_scattering) { pf_ssa = a.op.ssa_lw[o]; pf_g = a.op.g_lw[o]; }
+        pf_pt = stg<R>(a.op.planck_hl, g + (size_t)ng * (jl - 1 + (size_t)(nlev + 1) * cloc));
+        if (c.do_lw_aerosol_scattering) { pf_ssa = stg<R>(a.op.ssa_lw, o); pf_g = stg<R>(a.op.g_lw, o); }
       }
       if (do_clear || !listed) {
         R g1, g2;
@@ -1134,7 +1138,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
       M3<R> refl, tran;
       V3<R> source_up, source_dn;
       if (listed) {
-        const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ngl + gs;
+        const R* lp = reinterpret_cast<const R*>(a.lay) + (size_t)a.item_of[(size_t)cloc * nlev + jl] * 24 * ngl + gs;
 #pragma unroll
         for (int k = 0; k < 9; ++k) { refl.a[k] = lp[(size_t)k * ngl]; tran.a[k] = lp[(size_t)(9 + k) * ngl]; }
 #pragma unroll
@@ -1243,7 +1247,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
       } else {
         M3<R> refl, tran, ta1;
         V3<R> sdn, ts1;
-        const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ngl + gs;
+        const R* lp = reinterpret_cast<const R*>(a.lay) + (size_t)a.item_of[(size_t)cloc * nlev + jl] * 24 * ngl + gs;
 #pragma unroll
         for (int k = 0; k < 9; ++k) { refl.a[k] = lp[(size_t)k * ngl]; tran.a[k] = lp[(size_t)(9 + k) * ngl]; }
 #pragma unroll
@@ -1309,7 +1313,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
           lwd.a[0] = t00 * v1.a[0];
         } else {
           M3<R> tran;
-          const R* lp = reinterpret_cast<const R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ngl + gs;
+          const R* lp = reinterpret_cast<const R*>(a.lay) + (size_t)a.item_of[(size_t)cloc * nlev + jl] * 24 * ngl + gs;
 #pragma unroll
           for (int k = 0; k < 9; ++k) tran.a[k] = lp[(size_t)(9 + k) * ngl];
           lwd = sp::mul(tran, v1);
@@ -1326,7 +1330,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
 // =====================================================================================================================
 // One lane per column: the column's listed layers (cloudy ones; all with use_expm_everywhere) are appended to the work
 // list, the space for a wave's columns being reserved by ONE atomic (prefix sum over the wave).
-__global__ void spartacus_list_kernel(DevInputs in, int list_all, uint32_t* __restrict__ list, int* __restrict__ n_items) {
+__global__ void spartacus_list_kernel(DevInputs in, int list_all, uint32_t* __restrict__ list, int* __restrict__ item_of, int* __restrict__ n_items) {
   const int nloc = in.iendcol - in.istartcol + 1;
   const int cloc_raw = blockIdx.x * blockDim.x + threadIdx.x;
   const bool ok = cloc_raw < nloc;
@@ -1352,7 +1356,10 @@ __global__ void spartacus_list_kernel(DevInputs in, int list_all, uint32_t* __re
   int pos = base + incl - n;
   if (ok)
     for (int jl = 0; jl < nlev; ++jl)
-      if (list_all || fracv.p[fracv.stride * ord.full(jl)] > 0.0) list[pos++] = ((uint32_t)cloc << 8) | (uint32_t)jl;
+      if (list_all || fracv.p[fracv.stride * ord.full(jl)] > 0.0) {
+        item_of[(size_t)cloc * nlev + jl] = pos;
+        list[pos++] = ((uint32_t)cloc << 8) | (uint32_t)jl;
+      }
 }
 
 // lane = g-point, 256/NGP listed layers per block; one wave per SIMD (the 9x9 exponential wants the whole register file)
@@ -1393,7 +1400,7 @@ __global__ __launch_bounds__(kBlock, 1) void spartacus_layers_kernel(SpArgs args
       else tan_sza = sp::sp_sqrt(R(c.overhead_sun_factor));
       const SwMats<R> m = sw_layer<R, NGP>(a, gm, ord, col, cloc, jl, g, ib, glane, tid, valid, clr, mu0s, tan_sza);
       if (valid && sun_up) {
-        R* lp = reinterpret_cast<R*>(a.lay) + ((size_t)cloc * nlev + jl) * 45 * ngl + gs;
+        R* lp = reinterpret_cast<R*>(a.lay) + (size_t)it * 45 * ngl + gs;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
           lp[(size_t)k * ngl] = m.refl.a[k]; lp[(size_t)(9 + k) * ngl] = m.tran.a[k]; lp[(size_t)(18 + k) * ngl] = m.rdir.a[k];
@@ -1403,7 +1410,7 @@ __global__ __launch_bounds__(kBlock, 1) void spartacus_layers_kernel(SpArgs args
     } else {
       const LwMats<R> m = lw_layer<R, NGP>(a, gm, ord, col, cloc, jl, g, ib, glane, tid, valid, clr);
       if (valid) {
-        R* lp = reinterpret_cast<R*>(a.lay) + ((size_t)cloc * nlev + jl) * 24 * ngl + gs;
+        R* lp = reinterpret_cast<R*>(a.lay) + (size_t)it * 24 * ngl + gs;
 #pragma unroll
         for (int k = 0; k < 9; ++k) { lp[(size_t)k * ngl] = m.refl.a[k]; lp[(size_t)(9 + k) * ngl] = m.tran.a[k]; }
 #pragma unroll
@@ -1418,12 +1425,22 @@ size_t spartacus_scratch_words(bool is_sw, int nlev) { return (size_t)nlev * (is
 int spartacus_sweep_blocks_per_cu(bool single, bool is_sw) { return single ? (is_sw ? ECRAD_SP_SWEEP_WAVES_SW : ECRAD_SP_SWEEP_WAVES_LW) : (is_sw ? 1 : 2); }
 size_t spartacus_layer_words(bool is_sw, int ng) { return (size_t)(is_sw ? 45 : 24) * ng; }    // per (column, layer); ng = g-points of one launch
 
-// `grid_layers` blocks for the list walk (one block per CU), `grid` for the sweeps; `lay`: spartacus_layer_words x nlev x
-// columns words of R; `list`: nlev x columns entries; `n_items`: one int, zeroed here
+// The work list of a batch of columns (the same for the two spectra and for every chunk of a spectrum): `list` and
+// `item_of` hold nlev x columns entries each, `n_items` one int (zeroed here).  The caller reads n_items back to size the
+// layer store: spartacus_layer_words x n_items words of R.
+hipError_t launch_spartacus_list(hipStream_t st, const ecrad_config_t& c, const DevInputs& in, uint32_t* list, int* item_of, int* n_items) {
+  hipError_t e = hipMemsetAsync(n_items, 0, sizeof(int), st);
+  if (e != hipSuccess) return e;
+  const int nloc = in.iendcol - in.istartcol + 1;
+  hipLaunchKernelGGL(spartacus_list_kernel, dim3((nloc + 255) / 256), dim3(256), 0, st, in, c.use_expm_everywhere, list, item_of, n_items);
+  return hipGetLastError();
+}
+
+// `grid_layers` blocks for the list walk (one block per CU), `grid` for the sweeps; `lay`: the layer store (see above)
 hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, int grid_layers, hipStream_t st, const ecrad_config_t& c,
                             const DevInputs& in, const DevOptics& op, const DevCloudPrep& prep, const DevFlux& fx, void* scratch,
-                            size_t per_block_words, int* counter, const int32_t* d_i_band_from_reordered_g, void* lay, uint32_t* list,
-                            int* n_items, int g0, bool wide) {
+                            size_t per_block_words, int* counter, const int32_t* d_i_band_from_reordered_g, void* lay, const uint32_t* list,
+                            const int* item_of, const int* n_items, int g0, bool wide) {
   SpArgs a{};
   SpConfig& s = a.c;
   s.ng = is_sw ? c.n_g_sw : c.n_g_lw;
@@ -1439,13 +1456,7 @@ hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, int grid
   s.i_band_from_reordered_g = d_i_band_from_reordered_g;
   s.g0 = g0; s.ngl = std::min(ngp, s.ng - g0); s.wide = wide ? 1 : 0;
   a.in = in; a.op = op; a.prep = prep; a.fx = fx; a.scratch = scratch; a.per_block = per_block_words; a.counter = counter;
-  a.lay = lay; a.list = list; a.n_items = n_items;
-  if (g0 == 0) {       // the work list is the same for every chunk of the spectrum
-    hipError_t e = hipMemsetAsync(n_items, 0, sizeof(int), st);
-    if (e != hipSuccess) return e;
-    const int nloc = in.iendcol - in.istartcol + 1;
-    hipLaunchKernelGGL(spartacus_list_kernel, dim3((nloc + 255) / 256), dim3(256), 0, st, in, c.use_expm_everywhere, list, n_items);
-  }
+  a.lay = lay; a.list = list; a.item_of = item_of; a.n_items = n_items;
   const dim3 g(grid), gl(grid_layers), b(kBlock);
 #define ECRAD_SP(R, N) do { if (is_sw) { hipLaunchKernelGGL((spartacus_layers_kernel<R, N, true>), gl, b, 0, st, a);      \
                                          hipLaunchKernelGGL((spartacus_sw_kernel<R, N>), g, b, 0, st, a); }                  \

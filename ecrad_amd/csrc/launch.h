@@ -56,7 +56,8 @@ hipError_t launch_mcica_generator_vec(hipStream_t st, const DevConfig* cfg, cons
                                       double* od_scaling, double* tcc);
 hipError_t launch_spectral_post(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevFlux& fx, bool wide);
 hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
-                              const DevConfig& cfg, const DevInputs& in, const DevOptics& out, int g0);
+                              const DevConfig& cfg, const DevInputs& in, const DevOptics& out, int g0, bool out_f32 = false,
+                              bool cloudy_only = false);
 
 // SPARTACUS solvers (kernel_spartacus.hip): words of working precision of block-private slab per block and of layer
 // matrices per (column, layer); the launch of one spectrum (work list, layer matrices, the two sweeps)
@@ -65,8 +66,9 @@ size_t spartacus_layer_words(bool is_sw, int ng);
 int spartacus_sweep_blocks_per_cu(bool single, bool is_sw);
 hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, int grid_layers, hipStream_t st, const ecrad_config_t& c,
                             const DevInputs& in, const DevOptics& op, const DevCloudPrep& prep, const DevFlux& fx, void* scratch,
-                            size_t per_block_words, int* counter, const int32_t* d_i_band_from_reordered_g, void* lay, uint32_t* list,
-                            int* n_items, int g0, bool wide);
+                            size_t per_block_words, int* counter, const int32_t* d_i_band_from_reordered_g, void* lay, const uint32_t* list,
+                            const int* item_of, const int* n_items, int g0, bool wide);
+hipError_t launch_spartacus_list(hipStream_t st, const ecrad_config_t& c, const DevInputs& in, uint32_t* list, int* item_of, int* n_items);
 
 // RRTMG gas optics (kernel_rrtmg.hip)
 namespace rrtmg { struct DevRrtmg; }
