@@ -53,6 +53,7 @@ struct ecrad_hip_handle_s {
   // 137 levels of dependent latencies -- and the GPU is mostly empty, so the shortwave stage runs on the second stream
   // next to the longwave one (fork after the preparation kernels, join before the post-processing)
   hipEvent_t ev_fork_sw = nullptr, ev_sw_done = nullptr;
+  hipEvent_t ev_rrtmg_rec = nullptr, ev_rrtmg_sw = nullptr;    // RRTMG: shortwave bands evaluated on aux_stream next to the longwave solver
   int num_cu = 256;
   int blocks_per_cu = 4;
   std::string err;
@@ -609,7 +610,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
   free_tables(h);
   h->gas_stage.release(); h->gas_work.release(); h->sp_stage.release(); h->sp_list.release(); h->counters.release(); h->partial.release(); h->spec_tmp.release(); h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
   for (auto& t : h->tile_events) for (auto& e : t.e) if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : {h->ev_fork, h->ev_gen_lw, h->ev_gen_sw, h->ev_fork_sw, h->ev_sw_done}) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : {h->ev_fork, h->ev_gen_lw, h->ev_gen_sw, h->ev_fork_sw, h->ev_sw_done, h->ev_rrtmg_rec, h->ev_rrtmg_sw}) if (e) (void)hipEventDestroy(e);
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
   delete h;
   return ECRAD_OK;
@@ -1014,7 +1015,11 @@ int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int ie
 
 // RRTMG: the separate gas-optics pass that fills the stage arrays the solver kernels read (din.gs)
 // `fold_aerosols`: the caller's solver kernels take the aerosols from the stage arrays (optics per band, no LW aerosol scattering)
-int run_rrtmg(ecrad_hip_handle_t h, CallCtx& cx, bool fold_aerosols) {
+int ensure_aux_stream(ecrad_hip_handle_t h);
+
+// split_sw: evaluate the shortwave bands on the handle's second stream, so that the longwave solver can start as soon as
+// the longwave bands are done; *sw_pending then tells the caller to make its shortwave stage wait for h->ev_rrtmg_sw
+int run_rrtmg(ecrad_hip_handle_t h, CallCtx& cx, bool fold_aerosols, bool split_sw = false, bool* sw_pending = nullptr) {
   if (!h->rrtmg_sw && !h->rrtmg_lw) return ECRAD_OK;
   using namespace ecrad::rrtmg;
   const size_t n = cx.r.nloc, L = cx.r.nlev;
@@ -1041,7 +1046,14 @@ int run_rrtmg(ecrad_hip_handle_t h, CallCtx& cx, bool fold_aerosols) {
   }
   HIP_TRY(h, h->gas_work.ensure(rrtmg_work_bytes((int)L, (int)n)));
   const RrtmgWork w = rrtmg_carve_work(h->gas_work.p, (int)L, (int)n);
-  HIP_TRY(h, launch_rrtmg_gas_optics(h->stream, h->d_rrtmg, h->dcfg, cx.din, w, gs, h->rrtmg_lw, h->rrtmg_sw, cx.solar_scaling));
+  // (measured, profiles/r03_rrtmg_split.log: the gas-optics stage drops from 83 to 61 ms per 100 000 columns, but the longwave
+  //  solver kernels, which are bound by HBM bandwidth, slow down from 70 to 98 ms next to the shortwave band evaluation:
+  //  222 against 209 ms per step.  Off unless ECRAD_RRTMG_SPLIT is set.)
+  const bool split = split_sw && h->rrtmg_lw && h->rrtmg_sw && getenv("ECRAD_RRTMG_SPLIT");
+  if (split) { const int st = ensure_aux_stream(h); if (st) return st; }
+  HIP_TRY(h, launch_rrtmg_gas_optics(h->stream, h->d_rrtmg, h->dcfg, cx.din, w, gs, h->rrtmg_lw, h->rrtmg_sw, cx.solar_scaling,
+                                     split ? h->aux_stream : h->stream, h->ev_rrtmg_rec, h->ev_rrtmg_sw));
+  if (sw_pending) *sw_pending = split;
   cx.din.gs = gs;
   return ECRAD_OK;
 }
@@ -1108,7 +1120,7 @@ size_t work_bytes_per_column(ecrad_hip_handle_t h, int nlev, const ecrad_inputs_
 int ensure_aux_stream(ecrad_hip_handle_t h) {
   if (h->aux_stream) return ECRAD_OK;
   HIP_TRY(h, hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking));
-  for (hipEvent_t* e : {&h->ev_fork, &h->ev_gen_lw, &h->ev_gen_sw, &h->ev_fork_sw, &h->ev_sw_done}) HIP_TRY(h, hipEventCreateWithFlags(e, hipEventDisableTiming));
+  for (hipEvent_t* e : {&h->ev_fork, &h->ev_gen_lw, &h->ev_gen_sw, &h->ev_fork_sw, &h->ev_sw_done, &h->ev_rrtmg_rec, &h->ev_rrtmg_sw}) HIP_TRY(h, hipEventCreateWithFlags(e, hipEventDisableTiming));
   return ECRAD_OK;
 }
 
@@ -1306,7 +1318,8 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     if (lw_mcica) { if ((st = run_generator(false, h->aux_stream))) return st; HIP_TRY(h, hipEventRecord(h->ev_gen_lw, h->aux_stream)); }
     if (sw_mcica) { if ((st = run_generator(true, h->aux_stream))) return st; HIP_TRY(h, hipEventRecord(h->ev_gen_sw, h->aux_stream)); }
   }
-  if ((st = run_rrtmg(h, cx, true))) return st;                                         // RRTMG gas optics, :341-357 (accounted to the PREP stage)
+  bool rrtmg_sw_pending = false;
+  if ((st = run_rrtmg(h, cx, true, /*split_sw=*/true, &rrtmg_sw_pending))) return st;  // RRTMG gas optics, :341-357 (accounted to the PREP stage)
   if (col_order_lw) HIP_TRY(h, launch_column_order(stream, h->dcfg, din, col_order_lw, win_lw));
   if (col_order_sw && col_order_sw != col_order_lw) HIP_TRY(h, launch_column_order(stream, h->dcfg, din, col_order_sw, win_sw));
   if (sw_tc || lw_tc || sw_sp || lw_sp)
@@ -1440,6 +1453,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
   }
   HIP_TRY(h, hipEventRecord(evs[2], stream));
   cx.din.col_order = col_order_sw;
+  if (rrtmg_sw_pending) HIP_TRY(h, hipStreamWaitEvent(stream, h->ev_rrtmg_sw, 0));      // the shortwave stage arrays of the RRTMG pass
   if (c.do_sw) {                                                                        // :459-499
     const DevCkdModel& m = h->hcfg.gas_sw;
     const int nct = (c.i_solver_sw != ECRAD_SOLVER_CLOUDLESS) ? c.n_cloud_types : 0;
@@ -1550,9 +1564,9 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
     const size_t avail = (size_t)(0.9 * (double)(free_b + held));
     if (budget > avail) budget = avail;
     if (in->memory != ECRAD_MEM_HOST) {      // the ncol-sized planes do not shrink with the tile: they come off the top
+      // (a budget smaller than the planes cannot be honoured: the call then runs in the smallest tiles, 4096 columns)
       const size_t planes = plane_bytes_per_column(h, nlev) * (size_t)ncol;
-      if (planes >= budget) return fail(h, ECRAD_ENOMEM, "work budget too small for the per-chunk / per-g-point profile planes of this call (ecrad_hip_set_work_bytes)");
-      budget -= planes;
+      budget = planes < budget ? budget - planes : 0;
     }
   }
   long long tile_cols = per_col ? (long long)(budget / per_col) : (long long)nloc;

@@ -439,20 +439,40 @@ RrtmgWork rrtmg_carve_work(void* base, int nlev, int nloc) {
   return w;
 }
 
+// st_sw: the stream of the shortwave half (band evaluation + incoming solar).  When it differs from `st` the interpolation
+// records are announced by `ev_records` (recorded on st, awaited by st_sw) and the shortwave stage arrays by `ev_sw_done`
+// (recorded on st_sw; the caller makes its shortwave solver wait for it): the longwave solver then starts as soon as the
+// longwave bands are done and the shortwave bands are evaluated next to it.
 hipError_t launch_rrtmg_gas_optics(hipStream_t st, const DevRrtmg* tables, const DevConfig* cfg, const DevInputs& in, const RrtmgWork& w,
-                                   const DevGasStage& out, bool do_lw, bool do_sw, const double* solar_scaling_host) {
+                                   const DevGasStage& out, bool do_lw, bool do_sw, const double* solar_scaling_host,
+                                   hipStream_t st_sw, hipEvent_t ev_records, hipEvent_t ev_sw_done) {
   const int nloc = in.iendcol - in.istartcol + 1, nlev = in.nlev;
+  const bool split = do_sw && do_lw && st_sw != st;
   if (do_sw) {
     hipError_t e = hipMemsetAsync(out.incoming_sw, 0, (size_t)kNgSw * nloc * sizeof(double), st);
     if (e != hipSuccess) return e;
   }
+  const dim3 tiles((nloc + kTileCols - 1) / kTileCols, nlev);
   hipLaunchKernelGGL(rrtmg_setcoef_kernel, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, st, tables, in, w, do_lw ? 1 : 0, do_sw ? 1 : 0);
-  hipLaunchKernelGGL(rrtmg_taumol_kernel, dim3((nloc + kTileCols - 1) / kTileCols, nlev), dim3(kBlock), 0, st, tables, cfg, in, w, out,
-                     do_lw ? 1 : 0, do_sw ? 1 : 0);
+  hipStream_t ssw = st;
+  if (split) {
+    hipError_t e = hipEventRecord(ev_records, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(st_sw, ev_records, 0);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rrtmg_taumol_kernel, tiles, dim3(kBlock), 0, st, tables, cfg, in, w, out, 1, 0);
+    hipLaunchKernelGGL(rrtmg_taumol_kernel, tiles, dim3(kBlock), 0, st_sw, tables, cfg, in, w, out, 0, 1);
+    ssw = st_sw;
+  } else {
+    hipLaunchKernelGGL(rrtmg_taumol_kernel, tiles, dim3(kBlock), 0, st, tables, cfg, in, w, out, do_lw ? 1 : 0, do_sw ? 1 : 0);
+  }
   if (do_sw) {
     SolarScaling sc{};
     if (solar_scaling_host) { sc.on = 1; for (int ib = 0; ib < kNBandSw; ++ib) sc.v[ib] = solar_scaling_host[ib]; }
-    hipLaunchKernelGGL(rrtmg_incoming_kernel, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, st, tables, in, out, sc);
+    hipLaunchKernelGGL(rrtmg_incoming_kernel, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, ssw, tables, in, out, sc);
+  }
+  if (split) {
+    hipError_t e = hipEventRecord(ev_sw_done, st_sw);
+    if (e != hipSuccess) return e;
   }
   return hipGetLastError();
 }

@@ -153,9 +153,17 @@ ECRAD_DEV double group_sum(double v) {
 constexpr double kLwDiffusivity = 1.66;   // radiation_two_stream.F90:38-39
 
 struct SwCoef { double ref_diff, trans_diff, ref_dir, trans_dir_diff, trans_dir_dir; };
+#ifndef ECRAD_CLASSIC_CONTRACT
+#define ECRAD_CLASSIC_CONTRACT 0     // 1: let the compiler contract a*b+c in the shortwave two-stream routines (tuning / diagnosis only)
+#endif
 
 // calc_ref_trans_sw (radiation_two_stream.F90:563-771, double precision, non-DWD): McICA/Tripleclouds
+// (the same conditioning as ref_trans_sw_classic below -- the direct-beam bracket over 1 - (k mu0)^2 -- and the same
+//  remedy: no floating-point contraction, every operation rounded as the reference's source spells it)
 ECRAD_DEV SwCoef ref_trans_sw_fused(double mu0, double od, double ssa, double asymmetry) {
+#if !ECRAD_CLASSIC_CONTRACT
+#pragma clang fp contract(off)
+#endif
   SwCoef c;
   double t = dmax(-dmax(od * (1.0 / mu0), 0.0), -1000.0);
   c.trans_dir_dir = exp(t);
@@ -198,9 +206,6 @@ ECRAD_DEV SwCoef ref_trans_sw_fused(double mu0, double od, double ssa, double as
 // Evaluated WITHOUT floating-point contraction, i.e. every product and sum rounded as the reference's source spells
 // them (gfortran -O2 without -ffast-math on x86-64-v1 does the same), so that what is left between this routine
 // and the CPU restatement is the last bit of exp() only.
-#ifndef ECRAD_CLASSIC_CONTRACT
-#define ECRAD_CLASSIC_CONTRACT 0
-#endif
 ECRAD_DEV SwCoef ref_trans_sw_classic(double mu0, double od, double ssa, double g) {
 #if !ECRAD_CLASSIC_CONTRACT
 #pragma clang fp contract(off)

@@ -75,6 +75,7 @@ namespace rrtmg { struct DevRrtmg; }
 size_t rrtmg_work_bytes(int nlev, int nloc);
 RrtmgWork rrtmg_carve_work(void* base, int nlev, int nloc);
 hipError_t launch_rrtmg_gas_optics(hipStream_t st, const rrtmg::DevRrtmg* tables, const DevConfig* cfg, const DevInputs& in,
-                                   const RrtmgWork& w, const DevGasStage& out, bool do_lw, bool do_sw, const double* solar_scaling_host);
+                                   const RrtmgWork& w, const DevGasStage& out, bool do_lw, bool do_sw, const double* solar_scaling_host,
+                                   hipStream_t st_sw, hipEvent_t ev_records, hipEvent_t ev_sw_done);
 
 }  // namespace ecrad

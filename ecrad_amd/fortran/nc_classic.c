@@ -1,0 +1,602 @@
+/* nc_classic.c -- netCDF "classic" files (CDF-1, and CDF-2 = 64-bit offsets) read and written from scratch.
+ *
+ * The Fortran host of the radiation() drop-in (SURVEY.md 8(b) last row: "netCDF reader/writer ... re-written in the repo")
+ * does its file I/O through the `netcdf` module of netcdf.F90, which is a thin generic-interface layer over this file.
+ * Every input, look-up-table and golden file of the reference is classic format (magic "CDF\001"), and the reference's
+ * own wrapper utilities/easy_netcdf.F90 uses 25 entry points of the nf90 API; those are what exists here.
+ *
+ * File format (NetCDF Users Guide, "File Format Specification", classic):
+ *   header   = magic numrecs dim_list gatt_list var_list        all integers big-endian
+ *   x_list   = ABSENT(0,0) | tag nelems [x ...]                 tags: dimension 0x0A, variable 0x0B, attribute 0x0C
+ *   dim      = name length                                      length 0 = the record dimension
+ *   attr     = name nc_type nelems [values, padded to 4 bytes]
+ *   var      = name rank [dimid ...] vatt_list nc_type vsize begin   (begin: 4 bytes in CDF-1, 8 in CDF-2)
+ *   data     = fixed-size variables in order, then the records: each record holds one slab of every record variable
+ * Numeric values are converted between the file's type and the caller's memory type (as nc_get_vara_double etc. do).
+ *
+ * Scope: everything is synchronous stdio; define mode -> nc_enddef -> data mode, no re-entering define mode; files being
+ * written have fixed dimensions only (the reference never defines NF90_UNLIMITED); record variables are READ (the
+ * reference's test inputs have "column" as record dimension).  Not thread-safe per file; the table of open files is
+ * guarded by the caller (Fortran I/O in the reference's driver is serial).
+ */
+#define _FILE_OFFSET_BITS 64
+#define _POSIX_C_SOURCE 200809L
+#include <errno.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ECNC_MAX_FILES 64
+#define ECNC_MAX_DIMS 8
+#define ECNC_MAX_NAME 256
+
+enum { T_BYTE = 1, T_CHAR = 2, T_SHORT = 3, T_INT = 4, T_FLOAT = 5, T_DOUBLE = 6 };
+enum { E_BADID = -33, E_NFILE = -34, E_INVAL = -36, E_PERM = -37, E_NOTINDEFINE = -38, E_INDEFINE = -39, E_INVALCOORDS = -40,
+       E_MAXDIMS = -41, E_NAMEINUSE = -42, E_NOTATT = -43, E_BADTYPE = -45, E_BADDIM = -46, E_NOTVAR = -49, E_NOTNC = -51,
+       E_MAXNAME = -53, E_UNLIMIT = -54, E_CHAR = -56, E_EDGE = -57, E_RANGE = -60, E_NOMEM = -61 };
+
+typedef struct { char name[ECNC_MAX_NAME]; uint64_t len; } Dim;
+typedef struct { char name[ECNC_MAX_NAME]; int type; uint64_t n; void* v; /* n values of the file type, host byte order */ } Att;
+typedef struct {
+  char name[ECNC_MAX_NAME];
+  int rank, dimid[ECNC_MAX_DIMS], type, natt, is_rec;
+  Att* att;
+  uint64_t vsize, begin;
+} Var;
+typedef struct {
+  FILE* fp;
+  int used, writable, define_mode, version;
+  uint64_t numrecs, recsize;
+  int ndim, nvar, ngatt, recdim;
+  Dim* dim;
+  Var* var;
+  Att* gatt;
+} File;
+
+static File g_files[ECNC_MAX_FILES];
+
+static size_t tsize(int t) { return t == T_BYTE || t == T_CHAR ? 1 : t == T_SHORT ? 2 : t == T_INT || t == T_FLOAT ? 4 : t == T_DOUBLE ? 8 : 0; }
+static uint64_t pad4(uint64_t n) { return (n + 3) & ~(uint64_t)3; }
+static File* file_of(int ncid) {
+  const int i = ncid - 1000;
+  return (i >= 0 && i < ECNC_MAX_FILES && g_files[i].used) ? &g_files[i] : NULL;
+}
+
+/* ---- big-endian primitives ------------------------------------------------------------------------ */
+static int rd_u32(FILE* fp, uint32_t* v) { unsigned char b[4]; if (fread(b, 1, 4, fp) != 4) return E_NOTNC; *v = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3]; return 0; }
+static int rd_u64(FILE* fp, uint64_t* v) { uint32_t a, b; if (rd_u32(fp, &a) || rd_u32(fp, &b)) return E_NOTNC; *v = ((uint64_t)a << 32) | b; return 0; }
+static void wr_u32(FILE* fp, uint32_t v) { unsigned char b[4] = {(unsigned char)(v >> 24), (unsigned char)(v >> 16), (unsigned char)(v >> 8), (unsigned char)v}; fwrite(b, 1, 4, fp); }
+static void wr_u64(FILE* fp, uint64_t v) { wr_u32(fp, (uint32_t)(v >> 32)); wr_u32(fp, (uint32_t)v); }
+static void swap_in_place(void* p, size_t ts, uint64_t n) {
+  unsigned char* b = (unsigned char*)p;
+  if (ts == 1) return;
+  for (uint64_t i = 0; i < n; ++i, b += ts)
+    for (size_t k = 0; k < ts / 2; ++k) { unsigned char t = b[k]; b[k] = b[ts - 1 - k]; b[ts - 1 - k] = t; }
+}
+
+static int rd_name(FILE* fp, char* name) {
+  uint32_t n;
+  if (rd_u32(fp, &n)) return E_NOTNC;
+  if (n >= ECNC_MAX_NAME) return E_MAXNAME;
+  char buf[ECNC_MAX_NAME + 4];
+  if (fread(buf, 1, pad4(n), fp) != pad4(n)) return E_NOTNC;
+  memcpy(name, buf, n);
+  name[n] = 0;
+  return 0;
+}
+static void wr_name(FILE* fp, const char* name) {
+  const uint32_t n = (uint32_t)strlen(name);
+  const char zero[4] = {0, 0, 0, 0};
+  wr_u32(fp, n);
+  fwrite(name, 1, n, fp);
+  fwrite(zero, 1, pad4(n) - n, fp);
+}
+static uint64_t name_bytes(const char* name) { return 4 + pad4(strlen(name)); }
+
+static int rd_atts(FILE* fp, int* natt, Att** att) {
+  uint32_t tag, n;
+  if (rd_u32(fp, &tag) || rd_u32(fp, &n)) return E_NOTNC;
+  *natt = 0; *att = NULL;
+  if (tag == 0 && n == 0) return 0;
+  if (tag != 0x0C) return E_NOTNC;
+  *att = (Att*)calloc(n ? n : 1, sizeof(Att));
+  if (!*att) return E_NOMEM;
+  *natt = (int)n;
+  for (uint32_t i = 0; i < n; ++i) {
+    Att* a = &(*att)[i];
+    uint32_t t, ne;
+    int st = rd_name(fp, a->name);
+    if (st) return st;
+    if (rd_u32(fp, &t) || rd_u32(fp, &ne)) return E_NOTNC;
+    if (!tsize((int)t)) return E_BADTYPE;
+    a->type = (int)t; a->n = ne;
+    const uint64_t nb = (uint64_t)ne * tsize(a->type);
+    a->v = malloc(pad4(nb) + 8);
+    if (!a->v) return E_NOMEM;
+    if (fread(a->v, 1, pad4(nb), fp) != pad4(nb)) return E_NOTNC;
+    swap_in_place(a->v, tsize(a->type), ne);
+  }
+  return 0;
+}
+static uint64_t atts_bytes(int natt, const Att* att) {
+  uint64_t b = 8;
+  for (int i = 0; i < natt; ++i) b += name_bytes(att[i].name) + 8 + pad4(att[i].n * tsize(att[i].type));
+  return b;
+}
+static void wr_atts(FILE* fp, int natt, const Att* att) {
+  if (natt == 0) { wr_u32(fp, 0); wr_u32(fp, 0); return; }
+  wr_u32(fp, 0x0C); wr_u32(fp, (uint32_t)natt);
+  for (int i = 0; i < natt; ++i) {
+    const Att* a = &att[i];
+    const size_t ts = tsize(a->type);
+    const uint64_t nb = a->n * ts;
+    wr_name(fp, a->name);
+    wr_u32(fp, (uint32_t)a->type); wr_u32(fp, (uint32_t)a->n);
+    unsigned char* tmp = (unsigned char*)calloc(1, pad4(nb) + 8);
+    memcpy(tmp, a->v, nb);
+    swap_in_place(tmp, ts, a->n);
+    fwrite(tmp, 1, pad4(nb), fp);
+    free(tmp);
+  }
+}
+
+static void free_file(File* f) {
+  for (int i = 0; i < f->ngatt; ++i) free(f->gatt[i].v);
+  for (int v = 0; v < f->nvar; ++v) {
+    for (int i = 0; i < f->var[v].natt; ++i) free(f->var[v].att[i].v);
+    free(f->var[v].att);
+  }
+  free(f->gatt); free(f->var); free(f->dim);
+  if (f->fp) fclose(f->fp);
+  memset(f, 0, sizeof(*f));
+}
+
+static int new_slot(File** out, int* ncid) {
+  for (int i = 0; i < ECNC_MAX_FILES; ++i)
+    if (!g_files[i].used) {
+      memset(&g_files[i], 0, sizeof(File));
+      g_files[i].used = 1; g_files[i].recdim = -1;
+      *out = &g_files[i]; *ncid = 1000 + i;
+      return 0;
+    }
+  return E_NFILE;
+}
+
+/* elements of one slab of a variable (the record dimension counts as 1) */
+static uint64_t var_slab_elems(const File* f, const Var* v) {
+  uint64_t n = 1;
+  for (int k = 0; k < v->rank; ++k) if (!(k == 0 && v->is_rec)) n *= f->dim[v->dimid[k]].len;
+  return n;
+}
+
+/* ---- open ------------------------------------------------------------------------------------------ */
+int ecnc_open(const char* path, int* ncid) {
+  File* f;
+  int st = new_slot(&f, ncid);
+  if (st) return st;
+  f->fp = fopen(path, "rb");
+  if (!f->fp) { st = errno ? errno : 2; f->used = 0; return st; }
+  unsigned char magic[4];
+  uint32_t tag, n, u;
+  if (fread(magic, 1, 4, f->fp) != 4 || magic[0] != 'C' || magic[1] != 'D' || magic[2] != 'F' || (magic[3] != 1 && magic[3] != 2)) { free_file(f); return E_NOTNC; }
+  f->version = magic[3];
+  if (rd_u32(f->fp, &u)) { free_file(f); return E_NOTNC; }
+  f->numrecs = u;
+  if (rd_u32(f->fp, &tag) || rd_u32(f->fp, &n)) { free_file(f); return E_NOTNC; }
+  if (!(tag == 0 && n == 0) && tag != 0x0A) { free_file(f); return E_NOTNC; }
+  f->ndim = (int)n;
+  f->dim = (Dim*)calloc(n ? n : 1, sizeof(Dim));
+  for (uint32_t i = 0; i < n; ++i) {
+    if ((st = rd_name(f->fp, f->dim[i].name)) || rd_u32(f->fp, &u)) { free_file(f); return st ? st : E_NOTNC; }
+    f->dim[i].len = u;
+    if (u == 0) f->recdim = (int)i;
+  }
+  if ((st = rd_atts(f->fp, &f->ngatt, &f->gatt))) { free_file(f); return st; }
+  if (rd_u32(f->fp, &tag) || rd_u32(f->fp, &n)) { free_file(f); return E_NOTNC; }
+  if (!(tag == 0 && n == 0) && tag != 0x0B) { free_file(f); return E_NOTNC; }
+  f->nvar = (int)n;
+  f->var = (Var*)calloc(n ? n : 1, sizeof(Var));
+  int nrec = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    Var* v = &f->var[i];
+    if ((st = rd_name(f->fp, v->name)) || rd_u32(f->fp, &u)) { free_file(f); return st ? st : E_NOTNC; }
+    if (u > ECNC_MAX_DIMS) { free_file(f); return E_MAXDIMS; }
+    v->rank = (int)u;
+    for (int k = 0; k < v->rank; ++k) {
+      if (rd_u32(f->fp, &u) || (int)u >= f->ndim) { free_file(f); return E_NOTNC; }
+      v->dimid[k] = (int)u;
+    }
+    v->is_rec = v->rank > 0 && v->dimid[0] == f->recdim;
+    if ((st = rd_atts(f->fp, &v->natt, &v->att))) { free_file(f); return st; }
+    if (rd_u32(f->fp, &u) || !tsize((int)u)) { free_file(f); return E_BADTYPE; }
+    v->type = (int)u;
+    if (rd_u32(f->fp, &u)) { free_file(f); return E_NOTNC; }
+    v->vsize = u;
+    if (f->version == 1) { if (rd_u32(f->fp, &u)) { free_file(f); return E_NOTNC; } v->begin = u; }
+    else if (rd_u64(f->fp, &v->begin)) { free_file(f); return E_NOTNC; }
+    /* (vsize is recomputed: the stored field saturates at 2^32-4 for large variables) */
+    v->vsize = pad4(var_slab_elems(f, v) * tsize(v->type));
+    if (v->is_rec) { f->recsize += v->vsize; ++nrec; }
+  }
+  if (nrec == 1)   /* a lone record variable is not padded */
+    for (int i = 0; i < f->nvar; ++i)
+      if (f->var[i].is_rec) f->recsize = var_slab_elems(f, &f->var[i]) * tsize(f->var[i].type);
+  if (f->recdim >= 0) f->dim[f->recdim].len = f->numrecs;     /* report the current length */
+  return 0;
+}
+
+/* ---- create / define ------------------------------------------------------------------------------- */
+int ecnc_create(const char* path, int use_64bit_offset, int* ncid) {
+  File* f;
+  int st = new_slot(&f, ncid);
+  if (st) return st;
+  f->fp = fopen(path, "wb+");
+  if (!f->fp) { st = errno ? errno : 13; f->used = 0; return st; }
+  f->writable = 1; f->define_mode = 1; f->version = use_64bit_offset ? 2 : 1;
+  return 0;
+}
+
+int ecnc_def_dim(int ncid, const char* name, long long len, int* dimid) {
+  File* f = file_of(ncid);
+  if (!f) return E_BADID;
+  if (!f->define_mode) return E_NOTINDEFINE;
+  if (len <= 0) return E_UNLIMIT;      /* record dimensions are not written by this library */
+  if (strlen(name) >= ECNC_MAX_NAME) return E_MAXNAME;
+  for (int i = 0; i < f->ndim; ++i) if (!strcmp(f->dim[i].name, name)) return E_NAMEINUSE;
+  f->dim = (Dim*)realloc(f->dim, (size_t)(f->ndim + 1) * sizeof(Dim));
+  memset(&f->dim[f->ndim], 0, sizeof(Dim));
+  strcpy(f->dim[f->ndim].name, name);
+  f->dim[f->ndim].len = (uint64_t)len;
+  *dimid = f->ndim++;
+  return 0;
+}
+
+int ecnc_def_var(int ncid, const char* name, int xtype, int rank, const int* dimids, int* varid) {
+  File* f = file_of(ncid);
+  if (!f) return E_BADID;
+  if (!f->define_mode) return E_NOTINDEFINE;
+  if (!tsize(xtype)) return E_BADTYPE;
+  if (rank < 0 || rank > ECNC_MAX_DIMS) return E_MAXDIMS;
+  if (strlen(name) >= ECNC_MAX_NAME) return E_MAXNAME;
+  for (int i = 0; i < f->nvar; ++i) if (!strcmp(f->var[i].name, name)) return E_NAMEINUSE;
+  for (int k = 0; k < rank; ++k) if (dimids[k] < 0 || dimids[k] >= f->ndim) return E_BADDIM;
+  f->var = (Var*)realloc(f->var, (size_t)(f->nvar + 1) * sizeof(Var));
+  Var* v = &f->var[f->nvar];
+  memset(v, 0, sizeof(Var));
+  strcpy(v->name, name);
+  v->rank = rank; v->type = xtype;
+  for (int k = 0; k < rank; ++k) v->dimid[k] = dimids[k];
+  *varid = f->nvar++;
+  return 0;
+}
+
+static int att_slot(File* f, int varid, int** natt, Att*** att) {
+  static Att* dummy;
+  (void)dummy;
+  if (varid == -1) { *natt = &f->ngatt; *att = &f->gatt; return 0; }
+  if (varid < 0 || varid >= f->nvar) return E_NOTVAR;
+  *natt = &f->var[varid].natt; *att = &f->var[varid].att;
+  return 0;
+}
+
+/* mem -> file-type conversion of n values; memtype and xtype are T_* codes */
+static int convert(const void* src, int stype, void* dst, int dtype, uint64_t n) {
+  if ((stype == T_CHAR) != (dtype == T_CHAR)) return E_CHAR;
+  if (stype == dtype) { memcpy(dst, src, n * tsize(stype)); return 0; }
+  int range = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    double x;
+    switch (stype) {
+      case T_BYTE: x = ((const signed char*)src)[i]; break;
+      case T_SHORT: x = ((const int16_t*)src)[i]; break;
+      case T_INT: x = ((const int32_t*)src)[i]; break;
+      case T_FLOAT: x = ((const float*)src)[i]; break;
+      default: x = ((const double*)src)[i]; break;
+    }
+    switch (dtype) {
+      case T_BYTE: if (x < -128 || x > 127) range = 1; ((signed char*)dst)[i] = (signed char)x; break;
+      case T_SHORT: if (x < -32768 || x > 32767) range = 1; ((int16_t*)dst)[i] = (int16_t)x; break;
+      case T_INT: if (x < -2147483648.0 || x > 2147483647.0) range = 1; ((int32_t*)dst)[i] = (int32_t)x; break;
+      case T_FLOAT: ((float*)dst)[i] = (float)x; break;
+      default: ((double*)dst)[i] = x; break;
+    }
+  }
+  return range ? E_RANGE : 0;
+}
+
+int ecnc_put_att(int ncid, int varid, const char* name, int xtype, long long n, int memtype, const void* values) {
+  File* f = file_of(ncid);
+  if (!f) return E_BADID;
+  if (!f->define_mode) return E_NOTINDEFINE;
+  if (!tsize(xtype) || !tsize(memtype) || n < 0) return E_BADTYPE;
+  if (strlen(name) >= ECNC_MAX_NAME) return E_MAXNAME;
+  int* natt; Att** att;
+  int st = att_slot(f, varid, &natt, &att);
+  if (st) return st;
+  Att* a = NULL;
+  for (int i = 0; i < *natt; ++i) if (!strcmp((*att)[i].name, name)) a = &(*att)[i];
+  if (!a) {
+    *att = (Att*)realloc(*att, (size_t)(*natt + 1) * sizeof(Att));
+    a = &(*att)[(*natt)++];
+    memset(a, 0, sizeof(Att));
+    strcpy(a->name, name);
+  }
+  free(a->v);
+  a->type = xtype; a->n = (uint64_t)n;
+  a->v = calloc(1, (size_t)n * tsize(xtype) + 8);
+  if (!a->v) return E_NOMEM;
+  st = convert(values, memtype, a->v, xtype, (uint64_t)n);
+  return st == E_RANGE ? 0 : st;
+}
+
+static const Att* find_att(File* f, int varid, const char* name, int* st) {
+  int* natt; Att** att;
+  *st = att_slot(f, varid, &natt, &att);
+  if (*st) return NULL;
+  for (int i = 0; i < *natt; ++i) if (!strcmp((*att)[i].name, name)) return &(*att)[i];
+  *st = E_NOTATT;
+  return NULL;
+}
+
+int ecnc_inq_att(int ncid, int varid, const char* name, int* xtype, long long* len) {
+  File* f = file_of(ncid);
+  if (!f) return E_BADID;
+  int st;
+  const Att* a = find_att(f, varid, name, &st);
+  if (!a) return st;
+  if (xtype) *xtype = a->type;
+  if (len) *len = (long long)a->n;
+  return 0;
+}
+
+int ecnc_inq_attname(int ncid, int varid, int attnum, char* name, int name_cap) {
+  File* f = file_of(ncid);
+  if (!f) return E_BADID;
+  int* natt; Att** att;
+  int st = att_slot(f, varid, &natt, &att);
+  if (st) return st;
+  if (attnum < 0 || attnum >= *natt) return E_NOTATT;
+  snprintf(name, (size_t)name_cap, "%s", (*att)[attnum].name);
+  return 0;
+}
+
+/* up to `cap` values, converted to memtype; *n = number of values of the attribute */
+int ecnc_get_att(int ncid, int varid, const char* name, int memtype, void* out, long long cap, long long* n) {
+  File* f = file_of(ncid);
+  if (!f) return E_BADID;
+  int st;
+  const Att* a = find_att(f, varid, name, &st);
+  if (!a) return st;
+  if (n) *n = (long long)a->n;
+  const uint64_t m = a->n < (uint64_t)cap ? a->n : (uint64_t)cap;
+  st = convert(a->v, a->type, out, memtype, m);
+  return st;
+}
+
+int ecnc_copy_att(int ncid_in, int varid_in, const char* name, int ncid_out, int varid_out) {
+  File* f = file_of(ncid_in);
+  if (!f) return E_BADID;
+  int st;
+  const Att* a = find_att(f, varid_in, name, &st);
+  if (!a) return st;
+  return ecnc_put_att(ncid_out, varid_out, name, a->type, (long long)a->n, a->type, a->v);
+}
+
+int ecnc_enddef(int ncid) {
+  File* f = file_of(ncid);
+  if (!f) return E_BADID;
+  if (!f->define_mode) return E_NOTINDEFINE;
+  /* header size, then the variables one after the other */
+  const uint64_t beg_bytes = f->version == 2 ? 8 : 4;
+  uint64_t h = 8 + 8;
+  for (int i = 0; i < f->ndim; ++i) h += name_bytes(f->dim[i].name) + 4;
+  h += atts_bytes(f->ngatt, f->gatt) + 8;
+  for (int v = 0; v < f->nvar; ++v) h += name_bytes(f->var[v].name) + 4 + 4 * (uint64_t)f->var[v].rank + atts_bytes(f->var[v].natt, f->var[v].att) + 8 + beg_bytes;
+  uint64_t pos = pad4(h);
+  for (int v = 0; v < f->nvar; ++v) {
+    Var* x = &f->var[v];
+    x->vsize = pad4(var_slab_elems(f, x) * tsize(x->type));
+    x->begin = pos;
+    pos += x->vsize;
+  }
+  if (f->version == 1 && pos > 0x7FFFFFFFull) {      /* does not fit 32-bit offsets: switch to CDF-2 and lay out again */
+    f->version = 2;
+    return ecnc_enddef(ncid);
+  }
+  rewind(f->fp);
+  const unsigned char magic[4] = {'C', 'D', 'F', (unsigned char)f->version};
+  fwrite(magic, 1, 4, f->fp);
+  wr_u32(f->fp, 0);
+  if (f->ndim) { wr_u32(f->fp, 0x0A); wr_u32(f->fp, (uint32_t)f->ndim); } else { wr_u32(f->fp, 0); wr_u32(f->fp, 0); }
+  for (int i = 0; i < f->ndim; ++i) { wr_name(f->fp, f->dim[i].name); wr_u32(f->fp, (uint32_t)f->dim[i].len); }
+  wr_atts(f->fp, f->ngatt, f->gatt);
+  if (f->nvar) { wr_u32(f->fp, 0x0B); wr_u32(f->fp, (uint32_t)f->nvar); } else { wr_u32(f->fp, 0); wr_u32(f->fp, 0); }
+  for (int v = 0; v < f->nvar; ++v) {
+    const Var* x = &f->var[v];
+    wr_name(f->fp, x->name);
+    wr_u32(f->fp, (uint32_t)x->rank);
+    for (int k = 0; k < x->rank; ++k) wr_u32(f->fp, (uint32_t)x->dimid[k]);
+    wr_atts(f->fp, x->natt, x->att);
+    wr_u32(f->fp, (uint32_t)x->type);
+    wr_u32(f->fp, x->vsize > 0xFFFFFFFCull ? 0xFFFFFFFFu : (uint32_t)x->vsize);
+    if (f->version == 2) wr_u64(f->fp, x->begin); else wr_u32(f->fp, (uint32_t)x->begin);
+  }
+  /* the data section exists from the start (zeros until written) */
+  if (pos > 0) {
+    if (fseeko(f->fp, (off_t)(pos - 1), SEEK_SET)) return errno;
+    fputc(0, f->fp);
+  }
+  fflush(f->fp);
+  f->define_mode = 0;
+  return ferror(f->fp) ? 5 : 0;
+}
+
+int ecnc_close(int ncid) {
+  File* f = file_of(ncid);
+  if (!f) return E_BADID;
+  int st = 0;
+  if (f->writable && f->define_mode) st = ecnc_enddef(ncid);
+  if (f->writable && fflush(f->fp)) st = errno;
+  free_file(f);
+  return st;
+}
+
+/* ---- inquiries ------------------------------------------------------------------------------------- */
+int ecnc_inq(int ncid, int* ndims, int* nvars, int* ngatts, int* unlimdimid) {
+  File* f = file_of(ncid);
+  if (!f) return E_BADID;
+  if (ndims) *ndims = f->ndim;
+  if (nvars) *nvars = f->nvar;
+  if (ngatts) *ngatts = f->ngatt;
+  if (unlimdimid) *unlimdimid = f->recdim;
+  return 0;
+}
+int ecnc_inq_dimid(int ncid, const char* name, int* dimid) {
+  File* f = file_of(ncid);
+  if (!f) return E_BADID;
+  for (int i = 0; i < f->ndim; ++i) if (!strcmp(f->dim[i].name, name)) { *dimid = i; return 0; }
+  return E_BADDIM;
+}
+int ecnc_inq_dim(int ncid, int dimid, char* name, int name_cap, long long* len) {
+  File* f = file_of(ncid);
+  if (!f) return E_BADID;
+  if (dimid < 0 || dimid >= f->ndim) return E_BADDIM;
+  if (name) snprintf(name, (size_t)name_cap, "%s", f->dim[dimid].name);
+  if (len) *len = (long long)f->dim[dimid].len;
+  return 0;
+}
+int ecnc_inq_varid(int ncid, const char* name, int* varid) {
+  File* f = file_of(ncid);
+  if (!f) return E_BADID;
+  for (int i = 0; i < f->nvar; ++i) if (!strcmp(f->var[i].name, name)) { *varid = i; return 0; }
+  return E_NOTVAR;
+}
+int ecnc_inq_var(int ncid, int varid, char* name, int name_cap, int* xtype, int* rank, int* dimids, int* natts) {
+  File* f = file_of(ncid);
+  if (!f) return E_BADID;
+  if (varid < 0 || varid >= f->nvar) return E_NOTVAR;
+  const Var* v = &f->var[varid];
+  if (name) snprintf(name, (size_t)name_cap, "%s", v->name);
+  if (xtype) *xtype = v->type;
+  if (rank) *rank = v->rank;
+  if (dimids) for (int k = 0; k < v->rank; ++k) dimids[k] = v->dimid[k];
+  if (natts) *natts = v->natt;
+  return 0;
+}
+
+/* ---- data ------------------------------------------------------------------------------------------ */
+/* hyperslab access: start/count in the file's (C, slowest first) dimension order; the memory buffer is contiguous in the
+   same order.  nstart = 0 means the whole variable. */
+static int vara(int ncid, int varid, int memtype, void* buf, int nidx, const long long* start, const long long* count, int writing) {
+  File* f = file_of(ncid);
+  if (!f) return E_BADID;
+  if (f->define_mode) return E_INDEFINE;
+  if (writing && !f->writable) return E_PERM;
+  if (varid < 0 || varid >= f->nvar) return E_NOTVAR;
+  const Var* v = &f->var[varid];
+  if ((memtype == T_CHAR) != (v->type == T_CHAR)) return E_CHAR;
+  long long s[ECNC_MAX_DIMS + 1], c[ECNC_MAX_DIMS + 1], len[ECNC_MAX_DIMS + 1];
+  const int r = v->rank;
+  for (int k = 0; k < r; ++k) {
+    len[k] = (long long)f->dim[v->dimid[k]].len;
+    s[k] = nidx ? start[k] : 0;
+    c[k] = nidx ? count[k] : len[k];
+    if (s[k] < 0 || (c[k] > 0 && s[k] >= len[k] && len[k] > 0)) return E_INVALCOORDS;
+    if (c[k] < 0 || s[k] + c[k] > len[k]) return E_EDGE;
+  }
+  if (nidx && nidx != r) return E_INVALCOORDS;
+  const size_t ts = tsize(v->type), ms = tsize(memtype);
+  /* contiguous run: the last dimension (a scalar is one element) -- unless that is the record dimension itself (a
+     one-dimensional record variable: one element per record) */
+  const int nouter = (r == 1 && v->is_rec) ? 1 : (r ? r - 1 : 0);      /* dimensions iterated over */
+  const long long run = (r && nouter == r - 1) ? c[r - 1] : 1;
+  uint64_t nruns = 1;
+  for (int k = 0; k < nouter; ++k) nruns *= (uint64_t)c[k];
+  if (run == 0 || nruns == 0) return 0;
+  /* element strides within one slab (the record dimension is handled through recsize) */
+  uint64_t stride[ECNC_MAX_DIMS + 1];
+  uint64_t acc = 1;
+  for (int k = r - 1; k >= 0; --k) { stride[k] = acc; if (!(k == 0 && v->is_rec)) acc *= (uint64_t)len[k]; }
+  unsigned char* tmp = (unsigned char*)malloc((size_t)run * ts + 8);
+  if (!tmp) return E_NOMEM;
+  long long idx[ECNC_MAX_DIMS + 1];
+  for (int k = 0; k < r; ++k) idx[k] = 0;
+  int st = 0, range = 0;
+  unsigned char* mem = (unsigned char*)buf;
+  for (uint64_t it = 0; it < nruns && !st; ++it) {
+    uint64_t off = v->begin;
+    for (int k = 0; k < r; ++k) {
+      const uint64_t i = (uint64_t)(s[k] + (k >= nouter ? 0 : idx[k]));
+      if (k == 0 && v->is_rec) off += i * f->recsize; else off += i * stride[k] * ts;
+    }
+    if (fseeko(f->fp, (off_t)off, SEEK_SET)) { st = errno; break; }
+    if (writing) {
+      int cs = convert(mem, memtype, tmp, v->type, (uint64_t)run);
+      if (cs == E_RANGE) range = 1; else if (cs) { st = cs; break; }
+      swap_in_place(tmp, ts, (uint64_t)run);
+      if (fwrite(tmp, ts, (size_t)run, f->fp) != (size_t)run) { st = errno ? errno : 5; break; }
+    } else {
+      if (fread(tmp, ts, (size_t)run, f->fp) != (size_t)run) { st = E_EDGE; break; }
+      swap_in_place(tmp, ts, (uint64_t)run);
+      int cs = convert(tmp, v->type, mem, memtype, (uint64_t)run);
+      if (cs == E_RANGE) range = 1; else if (cs) { st = cs; break; }
+    }
+    mem += (size_t)run * ms;
+    for (int k = nouter - 1; k >= 0; --k) { if (++idx[k] < c[k]) break; idx[k] = 0; }
+  }
+  free(tmp);
+  return st ? st : (range ? E_RANGE : 0);
+}
+
+int ecnc_get_vara(int ncid, int varid, int memtype, void* buf, int nidx, const long long* start, const long long* count) {
+  return vara(ncid, varid, memtype, buf, nidx, start, count, 0);
+}
+int ecnc_put_vara(int ncid, int varid, int memtype, const void* buf, int nidx, const long long* start, const long long* count) {
+  return vara(ncid, varid, memtype, (void*)buf, nidx, start, count, 1);
+}
+
+/* number of elements of a whole variable (records included) */
+int ecnc_var_elems(int ncid, int varid, long long* n) {
+  File* f = file_of(ncid);
+  if (!f) return E_BADID;
+  if (varid < 0 || varid >= f->nvar) return E_NOTVAR;
+  uint64_t m = 1;
+  for (int k = 0; k < f->var[varid].rank; ++k) m *= f->dim[f->var[varid].dimid[k]].len;
+  *n = (long long)m;
+  return 0;
+}
+
+const char* ecnc_strerror(int st) {
+  switch (st) {
+    case 0: return "No error";
+    case E_BADID: return "NetCDF: Not a valid ID";
+    case E_NFILE: return "NetCDF: Too many files open";
+    case E_INVAL: return "NetCDF: Invalid argument";
+    case E_PERM: return "NetCDF: Write to read only";
+    case E_NOTINDEFINE: return "NetCDF: Operation not allowed in data mode";
+    case E_INDEFINE: return "NetCDF: Operation not allowed in define mode";
+    case E_INVALCOORDS: return "NetCDF: Index exceeds dimension bound";
+    case E_MAXDIMS: return "NetCDF: NC_MAX_DIMS exceeded";
+    case E_NAMEINUSE: return "NetCDF: String match to name in use";
+    case E_NOTATT: return "NetCDF: Attribute not found";
+    case E_BADTYPE: return "NetCDF: Not a valid data type or _FillValue type mismatch";
+    case E_BADDIM: return "NetCDF: Invalid dimension ID or name";
+    case E_NOTVAR: return "NetCDF: Variable not found";
+    case E_NOTNC: return "NetCDF: Unknown file format (this library reads classic CDF-1 / CDF-2 files)";
+    case E_MAXNAME: return "NetCDF: NC_MAX_NAME exceeded";
+    case E_UNLIMIT: return "NetCDF: NC_UNLIMITED size already in use (this library writes fixed dimensions only)";
+    case E_CHAR: return "NetCDF: Attempt to convert between text & numbers";
+    case E_EDGE: return "NetCDF: Start+count exceeds dimension bound";
+    case E_RANGE: return "NetCDF: Numeric conversion not representable";
+    case E_NOMEM: return "NetCDF: Memory allocation (malloc) failure";
+    default: return st > 0 ? strerror(st) : "NetCDF: Unknown error";
+  }
+}
+
+/* ---- the four Fortran-77 entry points utilities/easy_netcdf.F90:3262-3324 calls as externals ----------- */
+/* (gfortran / flang name mangling: lower case + underscore; arguments by reference; varid is 1-based) */
+int nf_get_var_double_(const int* ncid, const int* varid, double* vals) { return vara(*ncid, *varid - 1, T_DOUBLE, vals, 0, NULL, NULL, 0); }
+int nf_put_var_double_(const int* ncid, const int* varid, const double* vals) { return vara(*ncid, *varid - 1, T_DOUBLE, (void*)vals, 0, NULL, NULL, 1); }
+int nf_get_var_int_(const int* ncid, const int* varid, int* vals) { return vara(*ncid, *varid - 1, T_INT, vals, 0, NULL, NULL, 0); }
+int nf_put_var_int_(const int* ncid, const int* varid, const int* vals) { return vara(*ncid, *varid - 1, T_INT, (void*)vals, 0, NULL, NULL, 1); }

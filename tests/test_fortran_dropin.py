@@ -1,0 +1,133 @@
+"""The drop-in executed inside its host (BOUNDARY PROOF, not an oracle pin).
+
+tests/_build/dropin/ecrad_hip (tools/build_dropin.py, built where /root/reference exists; the binary travels) is the
+reference's OWN offline driver -- driver/ecrad_driver.F90 with its namelist reader, input reader, setup_radiation table
+preparation, save_fluxes, every radiation/ module -- compiled unmodified from where it lies, EXCEPT that the module
+radiation_interface is ecrad_amd/fortran/radiation_interface.F90 (radiation() -> radiation_hip() over the reference's
+real derived types, -DECRAD_HIP_REFERENCE_TYPES) and the netCDF library is ecrad_amd/fortran/netcdf.F90 + nc_classic.c.
+Here it runs the reference's test/ifs configurations (test/ifs/Makefile targets, namelists made from
+configCY49R1_ecckd.nam by change_namelist-style edits) on test/ifs/ecrad_meridian.nc and the output FILE must equal the
+reference's golden output file of that target, variable by variable, to float32 rounding."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from ecrad_amd.ncfile import NcFile
+from helpers import GOLDEN_DIR, rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "_build", "dropin", "ecrad_hip")
+NAMELIST = os.path.join(GOLDEN_DIR, "configCY49R1_ecckd.nam")
+MERIDIAN = os.path.join(GOLDEN_DIR, "ecrad_meridian.nc")
+DATA_DIR = os.path.join(ROOT, "data")
+FLOAT32_TOL = 2.0e-7
+
+# test/ifs/configCY49R1.nam as its differences from configCY49R1_ecckd.nam (diff of the two files)
+RRTMG = {"use_general_cloud_optics": "false", "liquid_model_name": '"SOCRATES"', "ice_model_name": '"Fu-IFS"',
+         "sw_solver_name": '"McICA"', "lw_solver_name": '"McICA"', "gas_model_name": '"RRTMG-IFS"',
+         "do_surface_sw_spectral_flux": "true", "do_cloud_aerosol_per_sw_g_point": "false",
+         "do_cloud_aerosol_per_lw_g_point": "false", "do_nearest_spectral_lw_emiss": "true", "do_weighted_surface_mapping": "false"}
+# the targets of test/ifs/Makefile that have a golden file (:34-118): namelist family + change_namelist.sh arguments
+TARGETS = {
+    "ecckd_mcica": ({}, {"sw_solver_name": '"McICA"', "lw_solver_name": '"McICA"'}),
+    "default": (RRTMG, {}),
+    "noaer": (RRTMG, {"use_aerosols": "false"}),
+    "expexp": (RRTMG, {"overlap_scheme_name": '"Exp-Exp"'}),
+    "tripleclouds": (RRTMG, {"sw_solver_name": '"Tripleclouds"', "lw_solver_name": '"Tripleclouds"'}),
+    "cloudless": (RRTMG, {"use_aerosols": "false", "sw_solver_name": '"Cloudless"', "lw_solver_name": '"Cloudless"'}),
+}
+
+
+def write_namelist(path, *edits):
+    """change_namelist.sh: set key = value in the &radiation group (replace the assignment, or add it)."""
+    text = open(NAMELIST).read()
+    changes = {"directory_name": f'"{DATA_DIR}"'}
+    for e in edits:
+        changes.update(e)
+    head, rad = text.split("&radiation\n", 1)
+    for k, v in changes.items():
+        pat = re.compile(r"^(\s*)" + re.escape(k) + r"\s*=[^,\n]*,?", re.M)
+        if pat.search(rad):
+            rad = pat.sub(lambda m: f"{m.group(1)}{k} = {v},", rad, count=1)
+        else:
+            rad = f"{k} = {v},\n" + rad
+    with open(path, "w") as f:
+        f.write(head + "&radiation\n" + rad)
+
+
+def run_driver(tmp_path, name, *edits):
+    nam, out = str(tmp_path / f"config_{name}.nam"), str(tmp_path / f"ecrad_meridian_{name}_out.nc")
+    write_namelist(nam, *edits)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    p = subprocess.run([EXE, nam, MERIDIAN, out], capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=900)
+    return p, out
+
+
+needs_exe = pytest.mark.skipif(not os.path.exists(EXE), reason="tests/_build/dropin/ecrad_hip has not been built (tools/build_dropin.py)")
+
+
+@needs_exe
+@pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="a GPU is visible")
+def test_without_a_device_the_host_prepares_its_tables_and_the_dropin_fails_loudly(tmp_path):
+    """On a box without a GPU: the namelist is read, the reference's setup routines read and map every look-up table
+    through the repo's netCDF module, and the first thing the drop-in does -- create its handle -- aborts the run through
+    radiation_abort; there is no CPU path behind radiation()."""
+    p, out = run_driver(tmp_path, "ecckd_tc")
+    text = p.stdout + p.stderr
+    assert p.returncode != 0 and not os.path.exists(out)
+    assert "OFFLINE ECRAD RADIATION SCHEME" in text
+    assert "Reading NetCDF file" in text and "ecckd-1.0_lw_climate_fsck-32b_ckd-definition.nc" in text
+    assert "Aerosol mapping:" in text and "Sea salt, bin 1" in text          # (string attributes of the aerosol file)
+    assert "no usable MI355X device" in text
+
+
+@needs_exe
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(TARGETS))
+def test_reference_driver_with_the_dropin_reproduces_the_golden_file(tmp_path, name):
+    family, edits = TARGETS[name]
+    p, out = run_driver(tmp_path, name, family, edits)
+    assert p.returncode == 0 and os.path.exists(out), (p.stdout + p.stderr)[-3000:]
+    worst = {}
+    with NcFile(os.path.join(GOLDEN_DIR, f"ecrad_meridian_{name}_out_REFERENCE.nc")) as g, NcFile(out) as o:
+        names = list(g._f.variables)
+        assert sorted(names) == sorted(o._f.variables), (sorted(names), sorted(o._f.variables))
+        for v in names:
+            ref, got = g.get(v), o.get(v)
+            assert got.shape == ref.shape, (v, got.shape, ref.shape)
+            assert g._f.variables[v].dimensions == o._f.variables[v].dimensions, v
+            worst[v] = rel_err(got, ref)
+    bad = {k: e for k, e in worst.items() if not e < FLOAT32_TOL}
+    assert not bad, f"{name}: beyond float32 rounding: {bad}"
+    print(name, "drop-in driver vs golden file: max", max(worst.values()))
+
+
+@needs_exe
+@pytest.mark.gpu
+def test_reference_driver_spartacus_target_matches_the_python_host(tmp_path, oracle_lib):
+    """test_spartacus of test/ifs/Makefile (no golden file exists): the reference's driver + drop-in against the oracle run
+    through the Python host on the same namelist -- two independent hosts (Fortran table preparation by the reference's
+    own routines, Python restatement of it), one device library."""
+    if not oracle_lib.have_ref_rrtm():
+        pytest.skip("oracle/_ref/libecrad_refrrtm.so (the reference's RRTMG routines) has not been built")
+    from ecrad_amd.driver import flux_to_output_dict
+    from helpers import make_config_rrtmg, run_case
+    edits = {"sw_solver_name": '"SPARTACUS"', "lw_solver_name": '"SPARTACUS"', "do_3d_effects": "true",
+             "do_sw_delta_scaling_with_gases": "false", "do_write_double_precision": "true"}
+    nam, out = str(tmp_path / "config_spartacus.nam"), str(tmp_path / "out.nc")
+    write_namelist(nam, RRTMG, edits)
+    # (do_write_double_precision belongs to the driver group)
+    text = open(nam).read().replace("do_write_double_precision = false", "do_write_double_precision = true")
+    open(nam, "w").write(text)
+    p = subprocess.run([EXE, nam, MERIDIAN, out], capture_output=True, text=True, cwd=str(tmp_path), env=dict(os.environ, OMP_NUM_THREADS="1"), timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    cfg = make_config_rrtmg("SPARTACUS", do_3d_effects=True, do_sw_delta_scaling_with_gases=False, do_save_spectral_flux=True)
+    flux, th, _ = run_case(cfg, oracle_lib.make_rrtmg_backend(cfg))
+    want = flux_to_output_dict(cfg, th, flux)
+    with NcFile(out) as o:
+        for v in ("flux_up_lw", "flux_dn_lw", "flux_up_sw", "flux_dn_sw", "flux_dn_direct_sw", "flux_up_lw_clear", "flux_up_sw_clear",
+                  "cloud_cover_sw", "cloud_cover_lw", "lw_derivative"):
+            assert rel_err(o.get(v), np.asarray(want[v])) < 1.0e-6, v

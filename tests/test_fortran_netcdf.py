@@ -1,0 +1,86 @@
+"""The Fortran host's netCDF layer (ecrad_amd/fortran/netcdf.F90 + nc_classic.c: the `netcdf` module the reference's
+utilities/easy_netcdf.F90 is written against, over classic-format files) on the CPU:
+  * a Fortran program writes a file through the nf90 API (whole arrays, slabs, scalars, attributes of every type easy_netcdf
+    uses) and reads it back; scipy's independent reader of the same format must see the same file;
+  * record variables of the reference's own input file (test/ifs/ecrad_meridian.nc has `column` as record dimension) read
+    through the module equal what scipy reads."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+from scipy.io import netcdf_file
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FDIR = os.path.join(ROOT, "ecrad_amd", "fortran")
+BUILD = os.path.join(ROOT, "tests", "_build", "nctest")
+FC, CC = "/opt/rocm/bin/amdflang", "/opt/rocm/lib/llvm/bin/clang"
+MERIDIAN = os.path.join(ROOT, "tests", "golden", "ecrad_meridian.nc")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    path = os.path.join(BUILD, "nc_roundtrip")
+    srcs = [os.path.join(FDIR, "netcdf.F90"), os.path.join(FDIR, "nc_classic.c"), os.path.join(ROOT, "tests", "_src", "nc_roundtrip.F90")]
+    if os.path.exists(path) and os.path.getmtime(path) >= max(os.path.getmtime(s) for s in srcs):
+        return path
+    if not (os.path.exists(FC) and os.path.exists(CC)):
+        if os.path.exists(path):
+            return path
+        pytest.skip("amdflang / clang not available and tests/_build/nctest/nc_roundtrip has not been built")
+    os.makedirs(BUILD, exist_ok=True)
+    subprocess.run([CC, "-O2", "-fPIC", "-c", srcs[1], "-o", os.path.join(BUILD, "nc_classic.o")], check=True)
+    subprocess.run([FC, "-O1", "-cpp", "-module-dir", BUILD, "-c", srcs[0], "-o", os.path.join(BUILD, "netcdf.o")], check=True)
+    subprocess.run([FC, "-O1", "-cpp", f"-I{BUILD}", "-module-dir", BUILD, srcs[2], os.path.join(BUILD, "netcdf.o"),
+                    os.path.join(BUILD, "nc_classic.o"), "-o", path], check=True)
+    return path
+
+
+def test_write_then_read_through_the_module_and_through_scipy(exe, tmp_path):
+    f = str(tmp_path / "t.nc")
+    p = subprocess.run([exe, "write", f], capture_output=True, text=True)
+    assert p.returncode == 0 and "WRITE OK" in p.stdout, p.stdout + p.stderr
+    p = subprocess.run([exe, "read", f], capture_output=True, text=True)
+    assert p.returncode == 0 and "READ OK" in p.stdout, p.stdout + p.stderr
+    assert open(f, "rb").read(4) == b"CDF\x01"
+    with netcdf_file(f, "r", mmap=False) as nc:
+        a = nc.variables["a"]
+        assert a.dimensions == ("level", "column") and a.typecode() == "d"          # Fortran (column, level) = C (level, column)
+        want = 10.0 * np.arange(1, 4)[:, None] + np.arange(1, 5)[None, :] + 0.125
+        assert np.array_equal(a[:], want)
+        assert a.units == b"W m-2" and a.long_name == b"A matrix" and a._FillValue == -999.0
+        assert nc.title == b"round trip"
+        b = nc.variables["b"]
+        assert b.typecode() == "f" and np.array_equal(b[:], np.array([1.5, -2.25, 3.0, 1.0e10, 0.1], dtype=np.float32))
+        assert b._FillValue == np.float32(-1.0)
+        i = nc.variables["i"]
+        assert i.typecode() == "i" and list(i[:]) == [7, -8, 9, 2147483647, 77] and i.answer == 42
+        assert nc.variables["s"].shape == () and float(nc.variables["s"].getValue()) == 3.141592653589793
+        assert nc.variables["f"].typecode() == "h" and list(nc.variables["f"][:]) == [1, 2, 3, -4, 5]
+
+
+@pytest.mark.parametrize("var", ["pressure_hl", "temperature_hl", "q", "cloud_fraction", "cos_solar_zenith_angle", "skin_temperature"])
+def test_record_variables_of_the_reference_input_file(exe, var):
+    p = subprocess.run([exe, "dump", MERIDIAN, var], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.startswith("DUMP"), p.stdout + p.stderr
+    t = p.stdout.split()
+    rank, n1, n2 = int(t[1]), int(t[2]), int(t[3])
+    total, first, last = float(t[4]), float(t[5]), float(t[6])
+    with netcdf_file(MERIDIAN, "r", mmap=False) as nc:
+        v = nc.variables[var][:].astype(np.float64)
+    assert v.ndim == rank and v.shape[::-1] == ((n1, n2) if rank == 2 else (n1,))
+    flat = v.reshape(-1)
+    assert first == flat[0] and last == flat[-1]
+    assert abs(total - flat.sum()) <= 1e-12 * np.abs(flat).sum()
+
+
+def test_errors_are_netcdf_status_codes(exe, tmp_path):
+    p = subprocess.run([exe, "dump", str(tmp_path / "absent.nc"), "x"], capture_output=True, text=True)
+    assert p.returncode != 0 and "FAILED open" in p.stdout and "No such file" in p.stdout
+    junk = tmp_path / "junk.nc"
+    junk.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    p = subprocess.run([exe, "dump", str(junk), "x"], capture_output=True, text=True)
+    assert p.returncode != 0 and "Unknown file format" in p.stdout
+    p = subprocess.run([exe, "dump", MERIDIAN, "no_such_variable"], capture_output=True, text=True)
+    assert p.returncode != 0 and "Variable not found" in p.stdout

@@ -1,0 +1,115 @@
+#!/usr/bin/env python
+"""Build the reference's OWN offline driver with the GPU drop-in in place of its radiation_interface module.
+
+    python tools/build_dropin.py [--ref /root/reference] [--out tests/_build/dropin] [-j 8]
+
+What is compiled, all with amdflang, objects and .mod files only under --out (git-ignored; the binary travels to the GPU box):
+  * from where they lie under --ref, unmodified: ifsaux/, drhook/yomhook_dummy.F90, utilities/, ifsrrtm/, radiation/ EXCEPT
+    radiation_interface.F90, and of driver/ the program ecrad_driver.F90 with ecrad_driver_config / _read_input /
+    print_matrix_mod -- the host side the north star wants kept: namelist, config_type, table preparation, netCDF I/O;
+  * from this repo: ecrad_amd/fortran/netcdf.F90 + nc_classic.c (the `netcdf` module the reference's easy_netcdf.F90 is
+    written against, over classic-format files: this image has no libnetcdff), ecrad_hip_binding.F90,
+    radiation_hip_interface.F90 and radiation_hip_rrtmg.F90 with -DECRAD_HIP_REFERENCE_TYPES, and
+    ecrad_amd/fortran/radiation_interface.F90 -- the drop-in module of the reference's name;
+  * linked against ecrad_amd/csrc/libecrad_hip.so (rpath relative to the binary) -> <out>/ecrad_hip.
+No OpenMP: one handle per process, the driver's loop over blocks runs serially.
+
+This is BOUNDARY PROOF (the drop-in executed inside its host), not an oracle pin: the reference's Fortran here only prepares
+tables and moves files; every flux comes from the HIP library.  Nothing of the reference is copied into the repo."""
+import argparse
+import os
+import re
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FC = "/opt/rocm/bin/amdflang"
+CC = "/opt/rocm/lib/llvm/bin/clang"
+
+
+def sources(ref):
+    src = []
+    for d in ("ifsaux", "utilities", "ifsrrtm", "radiation"):
+        for f in sorted(os.listdir(os.path.join(ref, d))):
+            # (easy_netcdf_read_mpi.F90 belongs to builds with the IFS's FIAT library only: utilities/CMakeLists.txt:17)
+            if f.endswith(".F90") and not (d == "radiation" and f == "radiation_interface.F90") and f != "easy_netcdf_read_mpi.F90":
+                src.append(os.path.join(ref, d, f))
+    src.append(os.path.join(ref, "drhook", "yomhook_dummy.F90"))
+    for f in ("ecrad_driver_config.F90", "ecrad_driver_read_input.F90", "print_matrix_mod.F90", "ecrad_driver.F90"):
+        src.append(os.path.join(ref, "driver", f))
+    ours = os.path.join(ROOT, "ecrad_amd", "fortran")
+    for f in ("netcdf.F90", "ecrad_hip_binding.F90", "radiation_hip_interface.F90", "radiation_hip_rrtmg.F90", "radiation_interface.F90"):
+        src.append(os.path.join(ours, f))
+    return src
+
+
+def scan(path):
+    """(modules defined, modules used) by a source file."""
+    defines, uses = set(), set()
+    for line in open(path, errors="replace"):
+        s = line.split("!")[0].strip().lower()
+        m = re.match(r"module\s+(\w+)\s*$", s)
+        if m and m.group(1) != "procedure":
+            defines.add(m.group(1))
+        m = re.match(r"use\s*(?:,\s*(?:non_)?intrinsic\s*)?(?:::)?\s*(\w+)", s)
+        if m:
+            uses.add(m.group(1))
+    return defines, uses
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "_build", "dropin"))
+    ap.add_argument("-j", type=int, default=8)
+    args = ap.parse_args()
+    out, obj = os.path.abspath(args.out), os.path.join(os.path.abspath(args.out), "obj")
+    os.makedirs(obj, exist_ok=True)
+    src = sources(args.ref)
+    info = {f: scan(f) for f in src}
+    owner = {}
+    for f, (d, _) in info.items():
+        for m in d:
+            owner[m] = f
+    deps = {f: {owner[m] for m in u if m in owner and owner[m] != f} for f, (_, u) in info.items()}
+    flags = ["-O1", "-fPIC", "-cpp", "-DECRAD_HIP_REFERENCE_TYPES", f"-I{args.ref}/include", f"-I{args.ref}/radiation",
+             f"-I{args.ref}/ifsaux", f"-I{args.ref}/ifsrrtm", f"-I{obj}", "-module-dir", obj]
+
+    def obj_of(f):
+        return os.path.join(obj, os.path.basename(f)[:-4] + ".o")
+
+    def compile_one(f):
+        o = obj_of(f)
+        if os.path.exists(o) and os.path.getmtime(o) >= max([os.path.getmtime(f)] + [os.path.getmtime(obj_of(d)) for d in deps[f] if os.path.exists(obj_of(d))]):
+            return f, 0, ""
+        p = subprocess.run([FC, *flags, "-c", f, "-o", o], capture_output=True, text=True)
+        return f, p.returncode, p.stderr[-3000:]
+
+    done, todo = set(), set(src)
+    with ThreadPoolExecutor(max_workers=args.j) as ex:
+        while todo:
+            ready = [f for f in todo if deps[f] <= done]
+            if not ready:
+                sys.exit("dependency cycle among: " + ", ".join(sorted(os.path.basename(f) for f in todo)))
+            for f, rc, err in ex.map(compile_one, ready):
+                if rc != 0:
+                    sys.exit(f"{f} failed:\n{err}")
+                done.add(f)
+                todo.discard(f)
+    nc_o = os.path.join(obj, "nc_classic.o")
+    subprocess.run([CC, "-O2", "-fPIC", "-c", os.path.join(ROOT, "ecrad_amd", "fortran", "nc_classic.c"), "-o", nc_o], check=True)
+    exe = os.path.join(out, "ecrad_hip")
+    csrc = os.path.join(ROOT, "ecrad_amd", "csrc")
+    rel = os.path.relpath(csrc, out)
+    # (-fopenmp at the link only: the driver calls omp_get_wtime / omp_get_thread_num unconditionally; the sources are
+    #  compiled without it, so its loop over blocks is serial)
+    p = subprocess.run([FC, "-fopenmp", "-o", exe, *[obj_of(f) for f in src], nc_o, f"-L{csrc}", "-lecrad_hip", f"-Wl,-rpath,$ORIGIN/{rel}"],
+                       capture_output=True, text=True)
+    if p.returncode != 0:
+        sys.exit("link failed:\n" + p.stderr[-4000:])
+    print("built", exe)
+
+
+if __name__ == "__main__":
+    main()
