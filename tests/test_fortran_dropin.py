@@ -116,12 +116,13 @@ def test_reference_driver_spartacus_target_matches_the_python_host(tmp_path, ora
     from ecrad_amd.driver import flux_to_output_dict
     from helpers import make_config_rrtmg, run_case
     edits = {"sw_solver_name": '"SPARTACUS"', "lw_solver_name": '"SPARTACUS"', "do_3d_effects": "true",
-             "do_sw_delta_scaling_with_gases": "false", "do_write_double_precision": "true"}
+             "do_sw_delta_scaling_with_gases": "false"}
     nam, out = str(tmp_path / "config_spartacus.nam"), str(tmp_path / "out.nc")
     write_namelist(nam, RRTMG, edits)
     # (do_write_double_precision belongs to the driver group)
-    text = open(nam).read().replace("do_write_double_precision = false", "do_write_double_precision = true")
-    open(nam, "w").write(text)
+    text = open(nam).read()
+    assert text.count("do_write_double_precision = false") == 1
+    open(nam, "w").write(text.replace("do_write_double_precision = false", "do_write_double_precision = true"))
     p = subprocess.run([EXE, nam, MERIDIAN, out], capture_output=True, text=True, cwd=str(tmp_path), env=dict(os.environ, OMP_NUM_THREADS="1"), timeout=900)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     cfg = make_config_rrtmg("SPARTACUS", do_3d_effects=True, do_sw_delta_scaling_with_gases=False, do_save_spectral_flux=True)
