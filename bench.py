@@ -169,7 +169,7 @@ def columns_of(inputs, c0, n):
     return (n, nlev, *out)
 
 
-def cpu_baseline(config, sample, seconds_target=10.0):
+def cpu_baseline(config, sample, seconds_target=10.0, workload_name=None):
     """Time the oracle on a bounded sample (the first columns of the timed batch, repeated for ~10 s)."""
     from ecrad_amd.interface import Radiation
     from ecrad_amd.types import Flux
@@ -195,6 +195,12 @@ def cpu_baseline(config, sample, seconds_target=10.0):
             out["components"] = comp
     except Exception as e:       # the reference-code component is additional information: never take the line down
         out["components"] = {"error": f"{type(e).__name__}: {e}"}
+    try:
+        ref = reference_executable_component(workload_name, config, sample, nthreads) if workload_name else None
+        if ref:
+            out.setdefault("components", {})["reference_executable"] = ref
+    except Exception as e:
+        out.setdefault("components", {})["reference_executable"] = {"error": f"{type(e).__name__}: {e}"}
     return out, flux
 
 
@@ -239,6 +245,66 @@ def reference_leaf_component(config, rad, sample, nthreads, seconds_target=4.0):
                              "sample": f"{n} columns ({n0} distinct) x {reps} repeats, {dt:.1f} s"},
             "everything_else": {"kind": "port", "what": "gas optics, Planck function, albedo mapping, flux post-processing: oracle/ (the reference's "
                                                          "modules for these need netCDF and cannot be built here)"}}
+
+
+REFERENCE_EXE = os.path.join(ROOT, "tests", "_build", "reference", "ecrad_ref")
+
+# bench workload -> change_namelist.sh-style edits of tests/golden/configCY49R1_ecckd.nam (= test/ifs/configCY49R1_ecckd.nam)
+REFERENCE_NAMELIST_EDITS = {
+    "clear_homogeneous_ecckd32": {"sw_solver_name": '"Homogeneous"', "lw_solver_name": '"Homogeneous"', "use_aerosols": "false",
+                                  "do_save_spectral_flux": "false"},
+    "tripleclouds_ecckd32": {"do_save_spectral_flux": "false"},
+}
+
+
+def reference_executable_component(name, config, sample, nthreads, seconds_target=8.0):
+    """The reference's OWN offline executable timed on this box's host cores (north_star: "next to the reference Fortran /
+    OpenMP path timed on the same box's host cores"): tests/_build/reference/ecrad_ref is ecmwf-ifs/ecrad 1.7.1 compiled
+    unmodified by tools/build_dropin.py --reference (amdflang -O3 -fopenmp) -- every line of radiation() is the reference's --
+    on top of this repo's netCDF library (the image has no libnetcdff), which only serves the file reads before and the write
+    after the timed loop.  Because of that library it is reported as a component next to the "port" figure, not as
+    oracle/_ref.  The sample's columns are written to a netCDF file (ecrad_amd.driver.save_inputs), the driver runs them in
+    blocks of 32 columns over all host threads (its own !$OMP PARALLEL DO, driver/ecrad_driver.F90:348) `nrepeat` times and
+    prints its own timer (:387)."""
+    import re
+    import subprocess
+    import tempfile
+    if not os.path.exists(REFERENCE_EXE) or name not in REFERENCE_NAMELIST_EDITS:
+        return None
+    from ecrad_amd.driver import save_inputs
+    ncol, nlev, sl, th, gas, cloud, aer = sample
+    ncol_ref = min(ncol, 8192)
+    sub = first_columns(sample, ncol_ref)
+    with tempfile.TemporaryDirectory() as tmp:
+        inp = os.path.join(tmp, "inputs.nc")
+        save_inputs(inp, config, *sub[2:])
+        text = open(os.path.join(ROOT, "tests", "golden", "configCY49R1_ecckd.nam")).read()
+        head, rad = text.split("&radiation\n", 1)
+        edits = dict(REFERENCE_NAMELIST_EDITS[name], directory_name=f'"{os.path.join(ROOT, "data")}"', iverbosesetup="0", iverbose="0")
+        for k, v in edits.items():
+            pat = re.compile(r"^(\s*)" + re.escape(k) + r"\s*=[^,\n]*,?", re.M)
+            rad = pat.sub(lambda m: f"{m.group(1)}{k} = {v},", rad, count=1) if pat.search(rad) else f"{k} = {v},\n" + rad
+
+        def run(nrepeat):
+            h = re.sub(r"nrepeat\s*=\s*\d+", f"nrepeat = {nrepeat}", head)
+            h = re.sub(r"nblocksize\s*=\s*\d+", "nblocksize = 32", h)
+            nam = os.path.join(tmp, "config.nam")
+            open(nam, "w").write(h + "&radiation\n" + rad)
+            env = dict(os.environ, OMP_NUM_THREADS=str(nthreads), OMP_STACKSIZE="1G")
+            p = subprocess.run(f"ulimit -s unlimited; exec {REFERENCE_EXE} {nam} {inp} {os.path.join(tmp, 'out.nc')}", shell=True,
+                               capture_output=True, text=True, env=env, cwd=tmp, timeout=600)
+            m = re.search(r"Time elapsed in radiative transfer:\s*([0-9.Ee+-]+)\s*seconds", p.stdout + p.stderr)
+            if p.returncode != 0 or not m:
+                raise RuntimeError((p.stdout + p.stderr)[-500:])
+            return float(m.group(1))
+        t1 = run(1)
+        nrepeat = int(max(1, min(200, seconds_target / max(t1, 1e-3))))
+        t = run(nrepeat)
+    return {"value": ncol_ref * nrepeat / t, "unit": "columns/s", "cores": nthreads, "kind": "reference",
+            "what": "the reference's own offline executable (ecmwf-ifs/ecrad 1.7.1 compiled unmodified, amdflang -O3 -fopenmp; its netCDF "
+                    "reads and writes, outside the timed loop, served by this repo's netcdf module), OpenMP over blocks of 32 columns, "
+                    "the driver's own timer",
+            "sample": f"{ncol_ref} columns x nrepeat = {nrepeat}, {t:.1f} s"}
 
 
 def measured_traffic(workload, ncol, kernel_prefix):
@@ -625,7 +691,7 @@ def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allredu
     if do_cpu and rank == 0:
         w.step()
         torch.cuda.synchronize()
-        res["cpu_baseline"], oracle_flux = with_stdout_on_stderr(cpu_baseline, w.config, w.sample)
+        res["cpu_baseline"], oracle_flux = with_stdout_on_stderr(cpu_baseline, w.config, w.sample, workload_name=name)
         inputs_all = w.sample
         if w.host_inputs is not None and w.host_inputs[0] > w.sample[0]:
             # every timed column (batches of up to CHUNK_COLUMNS columns are still on the host), not only the timing sample

@@ -105,6 +105,64 @@ def test_reference_driver_with_the_dropin_reproduces_the_golden_file(tmp_path, n
     print(name, "drop-in driver vs golden file: max", max(worst.values()))
 
 
+# Targets of test/ifs/Makefile WITHOUT a golden file: (namelist family, change_namelist.sh arguments, the same as a Python-host config)
+OTHER_TARGETS = {
+    "test_lwscat": (RRTMG, {"do_lw_cloud_scattering": "true"}, ("rrtmg", "McICA", dict(do_lw_cloud_scattering=True))),
+    "test_vec": (RRTMG, {"use_vectorizable_generator": "true"}, ("rrtmg", "McICA", dict(use_vectorizable_generator=True))),
+    "test_spartacus": (RRTMG, {"sw_solver_name": '"SPARTACUS"', "lw_solver_name": '"SPARTACUS"', "do_3d_effects": "true",
+                               "do_sw_delta_scaling_with_gases": "false"},
+                       ("rrtmg", "SPARTACUS", dict(do_3d_effects=True, do_sw_delta_scaling_with_gases=False))),
+    "test_spartacus_maxentr": (RRTMG, {"sw_solver_name": '"SPARTACUS"', "lw_solver_name": '"SPARTACUS"', "do_3d_effects": "true",
+                                       "sw_entrapment_name": '"Maximum"', "do_sw_delta_scaling_with_gases": "false"},
+                               ("rrtmg", "SPARTACUS", dict(do_3d_effects=True, i_3d_sw_entrapment=4, do_sw_delta_scaling_with_gases=False))),
+    "test_ecckd_tc": ({}, {}, ("ecckd", "Tripleclouds", {})),
+    "test_ecckd_noaer": ({}, {"use_aerosols": "false"}, ("ecckd", "Tripleclouds", dict(use_aerosols=False))),
+    "test_ecckd_spartacus": ({}, {"sw_solver_name": '"SPARTACUS"', "lw_solver_name": '"SPARTACUS"', "do_3d_effects": "true"},
+                             ("ecckd", "SPARTACUS", dict(do_3d_effects=True))),
+}
+
+
+@needs_exe
+@pytest.mark.gpu
+@pytest.mark.parametrize("target", sorted(OTHER_TARGETS))
+def test_reference_driver_targets_without_golden_match_the_python_host(tmp_path, target):
+    """The other targets of the reference's test suite: the reference's driver + drop-in (Fortran table preparation by the
+    reference's own set-up routines, file I/O through the repo's netCDF module) against the Python host
+    (ecrad_amd/spectral.py, tables.py: a restatement of that table preparation) -- two independent hosts, ONE device library,
+    the same namelist.  Every variable of the output file, double precision, 1e-9: what differs between the two is only what
+    the hosts hand to ecrad_hip_setup."""
+    from ecrad_amd.driver import flux_to_output_dict
+    from helpers import make_config, make_config_rrtmg, run_case
+    family, edits, (fam, solver, kw) = OTHER_TARGETS[target]
+    nam, out = str(tmp_path / f"config_{target}.nam"), str(tmp_path / "out.nc")
+    write_namelist(nam, family, edits)
+    text = open(nam).read()
+    assert text.count("do_write_double_precision = false") == 1
+    open(nam, "w").write(text.replace("do_write_double_precision = false", "do_write_double_precision = true"))
+    p = subprocess.run([EXE, nam, MERIDIAN, out], capture_output=True, text=True, cwd=str(tmp_path), env=dict(os.environ, OMP_NUM_THREADS="1"), timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    kw = dict(do_save_spectral_flux=True, do_lw_aerosol_scattering=False, **kw)
+    cfg = make_config_rrtmg(solver, **kw) if fam == "rrtmg" else make_config(solver, **kw)
+    flux, th, rad = run_case(cfg, "hip")
+    rad.close()
+    want = flux_to_output_dict(cfg, th, flux)
+    worst = {}
+    with NcFile(out) as o:
+        names = list(o._f.variables)
+        assert len(names) >= 20
+        for v in names:
+            assert v in want, f"{target}: the Python host does not produce {v}"
+            got, ref = o.get(v), np.asarray(want[v])
+            assert got.shape == ref.shape, (v, got.shape, ref.shape)
+            worst[v] = rel_err(got, ref)
+    # (the longwave 3-D terms of SPARTACUS -- unpivoted 6x6 solves with a nearly singular matrix, radiation_spartacus_lw.F90:700-740 --
+    #  amplify the last bits by which the two hosts' tables differ)
+    tol = 1.0e-7 if solver == "SPARTACUS" else 1.0e-9
+    bad = {k: e for k, e in worst.items() if not e < tol}
+    assert not bad, f"{target}: Fortran host vs Python host: {bad}"
+    print(target, "reference driver + drop-in vs Python host: max", max(worst.values()))
+
+
 @needs_exe
 @pytest.mark.gpu
 def test_reference_driver_spartacus_target_matches_the_python_host(tmp_path, oracle_lib):

@@ -1,0 +1,82 @@
+"""Cross-check of the oracle against the reference's OWN code, end to end, for the configurations that have no golden file --
+above all the SPARTACUS solvers, whose restatement (oracle/oracle_spartacus.c) is otherwise pinned only
+piecewise.
+
+tests/_build/reference/ecrad_ref (tools/build_dropin.py --reference, built where /root/reference exists) is ecmwf-ifs/ecrad
+1.7.1 compiled UNMODIFIED with amdflang: driver, namelist reader, setup_radiation, every solver.  The one thing under it that
+is not the reference's is the netCDF library: this image has no libnetcdff, and utilities/easy_netcdf.F90 is linked against this
+repo's netcdf module (ecrad_amd/fortran/netcdf.F90 + nc_classic.c, tests/test_fortran_netcdf.py), which only moves files.
+By the letter of the task that makes this a CROSS-CHECK, NOT A PIN (the reference build rests on a library of the repo's);
+it is recorded as what it is: every variable of the reference's double-precision output file of each target of
+test/ifs/Makefile against the oracle through the Python host."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ecrad_amd.driver import flux_to_output_dict
+from ecrad_amd.ncfile import NcFile
+from helpers import make_config, make_config_rrtmg, rel_err, run_case
+from test_fortran_dropin import MERIDIAN, OTHER_TARGETS, RRTMG, TARGETS, write_namelist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "tests", "_build", "reference", "ecrad_ref")
+pytestmark = pytest.mark.skipif(not os.path.exists(REF), reason="tests/_build/reference/ecrad_ref has not been built (tools/build_dropin.py --reference)")
+
+# what the two may differ by: rounding (flang -O3 vs gcc, contraction) amplified by the solver's own conditioning -- the
+# 9x9 / 6x6 matrix exponentials and unpivoted solves of SPARTACUS (the longwave 3-D terms most: radiation_spartacus_lw.F90:700-740)
+TOL = {"test_spartacus": 1.0e-8, "test_spartacus_maxentr": 1.0e-8, "test_ecckd_spartacus": 1.0e-7}
+
+
+def run_reference(tmp_path, name, family, edits):
+    nam, out = str(tmp_path / f"{name}.nam"), str(tmp_path / f"{name}_ref.nc")
+    write_namelist(nam, family, edits)
+    text = open(nam).read()
+    assert text.count("do_write_double_precision = false") == 1
+    open(nam, "w").write(text.replace("do_write_double_precision = false", "do_write_double_precision = true"))
+    env = dict(os.environ, OMP_NUM_THREADS="4", OMP_STACKSIZE="1G")
+    p = subprocess.run(f"ulimit -s unlimited; exec {REF} {nam} {MERIDIAN} {out}", shell=True, capture_output=True, text=True,
+                       cwd=str(tmp_path), env=env, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    return out
+
+
+@pytest.mark.parametrize("target", sorted(OTHER_TARGETS))
+def test_oracle_against_the_unmodified_reference_executable(tmp_path, target, oracle_lib):
+    family, edits, (fam, solver, kw) = OTHER_TARGETS[target]
+    if fam == "rrtmg" and not oracle_lib.have_ref_rrtm():
+        pytest.skip("oracle/_ref/libecrad_refrrtm.so (the reference's RRTMG routines) has not been built")
+    out = run_reference(tmp_path, target, family, edits)
+    kw = dict(do_save_spectral_flux=True, do_lw_aerosol_scattering=False, **kw)
+    cfg = make_config_rrtmg(solver, **kw) if fam == "rrtmg" else make_config(solver, **kw)
+    flux, th, _ = run_case(cfg, oracle_lib.make_rrtmg_backend(cfg) if fam == "rrtmg" else oracle_lib.backend)
+    want = flux_to_output_dict(cfg, th, flux)
+    worst = {}
+    with NcFile(out) as o:
+        names = list(o._f.variables)
+        assert len(names) >= 20
+        for v in names:
+            assert v in want, f"{target}: the oracle's host does not produce {v}"
+            got, ref = o.get(v), np.asarray(want[v])
+            assert got.shape == ref.shape, (v, got.shape, ref.shape)
+            worst[v] = rel_err(ref, got)
+    tol = TOL.get(target, 1.0e-10)
+    bad = {k: e for k, e in worst.items() if not e < tol}
+    assert not bad, f"{target}: oracle vs the reference executable: {bad}"
+    print(target, "oracle vs reference executable: max", max(worst.values()))
+
+
+def test_the_reference_executable_reproduces_its_own_golden_file(tmp_path):
+    """(that the build is the reference: test_tripleclouds through it equals test/ifs/ecrad_meridian_tripleclouds_out_REFERENCE.nc)"""
+    family, edits = TARGETS["tripleclouds"]
+    nam, out = str(tmp_path / "tc.nam"), str(tmp_path / "tc_out.nc")
+    write_namelist(nam, family, edits)
+    env = dict(os.environ, OMP_NUM_THREADS="4", OMP_STACKSIZE="1G")
+    p = subprocess.run(f"ulimit -s unlimited; exec {REF} {nam} {MERIDIAN} {out}", shell=True, capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    golden = os.path.join(ROOT, "tests", "golden", "ecrad_meridian_tripleclouds_out_REFERENCE.nc")
+    with NcFile(golden) as g, NcFile(out) as o:
+        assert sorted(g._f.variables) == sorted(o._f.variables)
+        for v in g._f.variables:
+            assert rel_err(o.get(v), g.get(v)) < 2.0e-7, v

@@ -28,18 +28,19 @@ FC = "/opt/rocm/bin/amdflang"
 CC = "/opt/rocm/lib/llvm/bin/clang"
 
 
-def sources(ref):
+def sources(ref, reference_build=False):
     src = []
     for d in ("ifsaux", "utilities", "ifsrrtm", "radiation"):
         for f in sorted(os.listdir(os.path.join(ref, d))):
             # (easy_netcdf_read_mpi.F90 belongs to builds with the IFS's FIAT library only: utilities/CMakeLists.txt:17)
-            if f.endswith(".F90") and not (d == "radiation" and f == "radiation_interface.F90") and f != "easy_netcdf_read_mpi.F90":
+            if f.endswith(".F90") and not (d == "radiation" and f == "radiation_interface.F90" and not reference_build) and f != "easy_netcdf_read_mpi.F90":
                 src.append(os.path.join(ref, d, f))
     src.append(os.path.join(ref, "drhook", "yomhook_dummy.F90"))
     for f in ("ecrad_driver_config.F90", "ecrad_driver_read_input.F90", "print_matrix_mod.F90", "ecrad_driver.F90"):
         src.append(os.path.join(ref, "driver", f))
     ours = os.path.join(ROOT, "ecrad_amd", "fortran")
-    for f in ("netcdf.F90", "ecrad_hip_binding.F90", "radiation_hip_interface.F90", "radiation_hip_rrtmg.F90", "radiation_interface.F90"):
+    mine = ("netcdf.F90",) if reference_build else ("netcdf.F90", "ecrad_hip_binding.F90", "radiation_hip_interface.F90", "radiation_hip_rrtmg.F90", "radiation_interface.F90")
+    for f in mine:
         src.append(os.path.join(ours, f))
     return src
 
@@ -63,17 +64,22 @@ def main():
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "_build", "dropin"))
     ap.add_argument("-j", type=int, default=8)
+    ap.add_argument("--reference", action="store_true",
+                    help="the UNMODIFIED reference instead (its own radiation_interface.F90, OpenMP on, no GPU library): the CPU "
+                         "executable `ecrad_ref`, whose only non-reference part is the netCDF library underneath easy_netcdf.F90")
     args = ap.parse_args()
+    if args.reference and args.out.endswith("dropin"):
+        args.out = os.path.join(ROOT, "tests", "_build", "reference")
     out, obj = os.path.abspath(args.out), os.path.join(os.path.abspath(args.out), "obj")
     os.makedirs(obj, exist_ok=True)
-    src = sources(args.ref)
+    src = sources(args.ref, args.reference)
     info = {f: scan(f) for f in src}
     owner = {}
     for f, (d, _) in info.items():
         for m in d:
             owner[m] = f
     deps = {f: {owner[m] for m in u if m in owner and owner[m] != f} for f, (_, u) in info.items()}
-    flags = ["-O1", "-fPIC", "-cpp", "-DECRAD_HIP_REFERENCE_TYPES", f"-I{args.ref}/include", f"-I{args.ref}/radiation",
+    flags = (["-O3", "-fopenmp", "-fPIC", "-cpp"] if args.reference else ["-O1", "-fPIC", "-cpp", "-DECRAD_HIP_REFERENCE_TYPES"]) + [ f"-I{args.ref}/include", f"-I{args.ref}/radiation",
              f"-I{args.ref}/ifsaux", f"-I{args.ref}/ifsrrtm", f"-I{obj}", "-module-dir", obj]
 
     def obj_of(f):
@@ -99,13 +105,17 @@ def main():
                 todo.discard(f)
     nc_o = os.path.join(obj, "nc_classic.o")
     subprocess.run([CC, "-O2", "-fPIC", "-c", os.path.join(ROOT, "ecrad_amd", "fortran", "nc_classic.c"), "-o", nc_o], check=True)
-    exe = os.path.join(out, "ecrad_hip")
-    csrc = os.path.join(ROOT, "ecrad_amd", "csrc")
-    rel = os.path.relpath(csrc, out)
-    # (-fopenmp at the link only: the driver calls omp_get_wtime / omp_get_thread_num unconditionally; the sources are
-    #  compiled without it, so its loop over blocks is serial)
-    p = subprocess.run([FC, "-fopenmp", "-o", exe, *[obj_of(f) for f in src], nc_o, f"-L{csrc}", "-lecrad_hip", f"-Wl,-rpath,$ORIGIN/{rel}"],
-                       capture_output=True, text=True)
+    if args.reference:
+        exe = os.path.join(out, "ecrad_ref")
+        p = subprocess.run([FC, "-fopenmp", "-o", exe, *[obj_of(f) for f in src], nc_o], capture_output=True, text=True)
+    else:
+        exe = os.path.join(out, "ecrad_hip")
+        csrc = os.path.join(ROOT, "ecrad_amd", "csrc")
+        rel = os.path.relpath(csrc, out)
+        # (-fopenmp at the link only: the driver calls omp_get_wtime / omp_get_thread_num unconditionally; the sources are
+        #  compiled without it, so its loop over blocks is serial)
+        p = subprocess.run([FC, "-fopenmp", "-o", exe, *[obj_of(f) for f in src], nc_o, f"-L{csrc}", "-lecrad_hip", f"-Wl,-rpath,$ORIGIN/{rel}"],
+                           capture_output=True, text=True)
     if p.returncode != 0:
         sys.exit("link failed:\n" + p.stderr[-4000:])
     print("built", exe)
