@@ -44,13 +44,13 @@ constexpr int kLwBatch = ECRAD_LW_BATCH;
 // layers of records requested together by the cloudy-sky sweeps: upward (4 doubles per layer), downward (4), and the
 // one-pair sweeps (clear layers above cloud top, derivatives)
 #ifndef ECRAD_LW_CLD_U
-#define ECRAD_LW_CLD_U 2
+#define ECRAD_LW_CLD_U 3      // (2 -> 3: McICA longwave stage 25.2 -> 24.6 ms ecCKD-32, 60.8 -> 58.2 ms RRTMG per 100 000 columns, profiles/r03_variants.log)
 #endif
 #ifndef ECRAD_LW_CLD_D
-#define ECRAD_LW_CLD_D 2
+#define ECRAD_LW_CLD_D 3      // (2 -> 3: McICA longwave stage 25.2 -> 24.6 ms ecCKD-32, 60.8 -> 58.2 ms RRTMG per 100 000 columns, profiles/r03_variants.log)
 #endif
 #ifndef ECRAD_LW_CLD_V
-#define ECRAD_LW_CLD_V 2
+#define ECRAD_LW_CLD_V 4      // (2 -> 4: McICA longwave stage 25.2 -> 24.6 ms ecCKD-32, 60.8 -> 58.2 ms RRTMG per 100 000 columns, profiles/r03_variants.log)
 #endif
 constexpr int kCldU = ECRAD_LW_CLD_U, kCldD = ECRAD_LW_CLD_D, kCldV = ECRAD_LW_CLD_V;    // (T, S) pairs are 16 B per layer, so the longwave sweep can look further ahead
 
@@ -77,7 +77,7 @@ ECRAD_DEV double2 lw_trans_load(const LwScratch& s, bool cloudy, int l, int tid)
 // partial; the derivatives, which the reference normalises by the surface flux summed over the whole
 // spectrum, are then left un-normalised (their surface value IS that partial sum) for the host to finish.
 template <typename TAB, int NGP, int MODE, bool WIDE>
-__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_ica_kernel(SpectralArgs args_in_kernarg) {
+__global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void lw_ica_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
   // Stage mode (gas optics from the RRTMG pass): the stage values of kStageBatch layers are requested together and

@@ -192,7 +192,7 @@ enum { SWF_AEROSOLS = 1, SWF_DELTA_GASES = 2 };
 // WIDE: the launch covers g-points g0 .. g0+NGP-1 of a spectrum wider than 64 (its own instantiation:
 // the common case has no register to spare)
 template <typename TAB, int NGP, int MODE, bool SPEC, bool WIDE>
-__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void sw_ica_kernel(SpectralArgs args_in_kernarg) {
+__global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void sw_ica_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
   // Stage mode (gas optics from the RRTMG pass): see kernel_ica_lw.hip

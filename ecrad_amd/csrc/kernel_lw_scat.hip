@@ -31,7 +31,7 @@ enum { LS_RT = 0, LS_SS = 2, LS_RT2 = 4, LS_SS2 = 6, LS_DN = 8, LS_AS = 10 };
 
 // WIDE: see kernel_ica_lw.hip
 template <typename TAB, int NGP, int MODE, bool WIDE>
-__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void lw_scat_kernel(SpectralArgs args_in_kernarg) {
+__global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void lw_scat_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
   constexpr int CPB = kBlock / NGP;

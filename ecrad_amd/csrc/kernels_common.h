@@ -22,6 +22,15 @@ constexpr int kStageBatch = ECRAD_STAGE_BATCH;
 #ifndef ECRAD_MIN_WAVES
 #define ECRAD_MIN_WAVES 3
 #endif
+// ... of the instantiations over double tables, i.e. the stage mode of the RRTMG spectra (gas optics from the stage arrays of
+// the gas-optics pass, up to 64 lanes per column): those kernels are bound by HBM bandwidth, and at 168 registers they spilled
+// 90-150 of them (400 B per lane); at two waves per SIMD they keep everything in registers.  Measured per 100 000 columns
+// (profiles/r03_variants.log): RRTMG McICA 208.5 -> 196.9 ms per step with every kernel at 2, while the ecCKD kernels lose
+// (Tripleclouds 49.6 -> 56.8 ms), hence per table type.
+#ifndef ECRAD_MIN_WAVES_STAGE
+#define ECRAD_MIN_WAVES_STAGE 2
+#endif
+template <typename TAB> constexpr int min_waves_for(int ecckd) { return sizeof(TAB) == 8 ? ECRAD_MIN_WAVES_STAGE : ecckd; }
 // Tuning / ablation knobs (tools/variants.sh builds and times alternatives; the shipped library uses
 // the defaults).  ECRAD_ABLATE bits give WRONG results and exist only to attribute time:
 //   1 no table loads, 2 no cross-lane sums, 4 no flux sweep, 8 no scratch stores in the optics sweep

@@ -190,3 +190,138 @@ def test_reference_driver_spartacus_target_matches_the_python_host(tmp_path, ora
         for v in ("flux_up_lw", "flux_dn_lw", "flux_up_sw", "flux_dn_sw", "flux_dn_direct_sw", "flux_up_lw_clear", "flux_up_sw_clear",
                   "cloud_cover_sw", "cloud_cover_lw", "lw_derivative"):
             assert rel_err(o.get(v), np.asarray(want[v])) < 1.0e-6, v
+
+
+IFS_EXE = os.path.join(ROOT, "tests", "_build", "dropin", "ecrad_ifs_hip")
+IFS_BLOCKED_EXE = os.path.join(ROOT, "tests", "_build", "dropin", "ecrad_ifs_blocked_hip")
+IFS_REF = os.path.join(ROOT, "tests", "_build", "reference", "ecrad_ifs_ref")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(IFS_EXE) and os.path.exists(IFS_REF)), reason="the IFS-driver builds of tools/build_dropin.py are missing")
+@pytest.mark.parametrize("solver", ["Tripleclouds", "McICA"])
+def test_the_second_caller_ifs_radiation_scheme_through_the_dropin(tmp_path, solver):
+    """radiation() has a second call site, ifs/radiation_scheme.F90:540: the reference's IFS-style driver
+    (driver/ecrad_ifs_driver.F90 and its NPROMA-blocked twin: radiation_setup, effective radii and overlap decorrelation
+    length from the IFS parametrisations, radiation_scheme) built with the drop-in module runs on the GPU and is compared with
+    the same program built from the UNMODIFIED reference and run on the CPU of this box (the target `test_ifsdriver` of
+    test/ifs/Makefile: net fluxes, double precision).  A cross-check in the sense of tests/test_oracle_vs_reference_build.py."""
+    nam = str(tmp_path / "config_net.nam")
+    write_namelist(nam, RRTMG, {"sw_solver_name": f'"{solver}"', "lw_solver_name": f'"{solver}"'})
+    text = open(nam).read()
+    assert text.count("do_write_double_precision = false") == 1 and text.count("do_save_net_fluxes = false") == 1
+    open(nam, "w").write(text.replace("do_write_double_precision = false", "do_write_double_precision = true")
+                             .replace("do_save_net_fluxes = false", "do_save_net_fluxes = true"))
+    # The reference's IFS drivers allocate `land_frac` and never assign it (driver/ecrad_ifs_driver.F90:345,434;
+    # ecrad_ifs_driver_blocked.F90:346,369): the land-sea mask that picks the droplet number concentration of the liquid
+    # effective radius (ifs/liquid_effective_radius.F90:124) is whatever the heap holds.  A fresh CPU process gets zero pages
+    # (sea everywhere); a process that has loaded the HIP runtime does not always, and then the ALL-SKY fluxes of a column or
+    # two change by a few per cent -- in the unmodified reference too (it changes its own output under MALLOC_PERTURB_=165).
+    # So: clear-sky variables must agree on every attempt; the all-sky ones on one of up to six attempts.
+    def attempt(k):
+        outs = {}
+        for label, exe in (("hip", IFS_EXE), ("hip_blocked", IFS_BLOCKED_EXE), ("ref", IFS_REF)):
+            out = str(tmp_path / f"{label}_{k}.nc")
+            env = dict(os.environ, OMP_NUM_THREADS="1" if label != "ref" else "8", OMP_STACKSIZE="1G", MALLOC_PERTURB_="85")
+            p = subprocess.run(f"ulimit -s unlimited; exec {exe} {nam} {MERIDIAN} {out}", shell=True, capture_output=True, text=True,
+                               cwd=str(tmp_path), env=env, timeout=900)
+            assert p.returncode == 0, label + ": " + (p.stdout + p.stderr)[-3000:]
+            outs[label] = out
+        bad = {}
+        with NcFile(outs["hip"]) as h, NcFile(outs["hip_blocked"]) as hb, NcFile(outs["ref"]) as r:
+            names = list(r._f.variables)
+            assert len(names) >= 12 and sorted(names) == sorted(h._f.variables)
+            for v in names:
+                e1, e2 = rel_err(h.get(v), r.get(v)), rel_err(hb.get(v), h.get(v))       # GPU vs CPU reference; NPROMA blocking changes nothing
+                if "clear" in v or v in ("pressure_hl", "flux_dn_sw_toa"):
+                    assert e1 < 1.0e-6 and e2 < 1.0e-12, (v, e1, e2)
+                elif not (e1 < 1.0e-6 and e2 < 1.0e-12):
+                    bad[v] = (e1, e2)
+        return bad
+    for k in range(6):
+        bad = attempt(k)
+        if not bad:
+            break
+    assert not bad, bad
+
+
+REF_EXE = os.path.join(ROOT, "tests", "_build", "reference", "ecrad_ref")
+ALL_TARGETS = {**{k: (fam, ed) for k, (fam, ed) in TARGETS.items()}, **{k: (fam, ed) for k, (fam, ed, _) in OTHER_TARGETS.items()}}
+
+
+def _run_both(tmp_path, nam, inp):
+    outs = {}
+    for label, exe, threads in (("hip", EXE, "1"), ("ref", REF_EXE, "8")):
+        out = str(tmp_path / f"{label}_out.nc")
+        env = dict(os.environ, OMP_NUM_THREADS=threads, OMP_STACKSIZE="1G")
+        p = subprocess.run(f"ulimit -s unlimited; exec {exe} {nam} {inp} {out}", shell=True, capture_output=True, text=True,
+                           cwd=str(tmp_path), env=env, timeout=1800)
+        assert p.returncode == 0, label + ": " + (p.stdout + p.stderr)[-3000:]
+        outs[label] = out
+    return outs
+
+
+def _double_precision_output(nam):
+    text = open(nam).read()
+    assert text.count("do_write_double_precision = false") == 1
+    open(nam, "w").write(text.replace("do_write_double_precision = false", "do_write_double_precision = true"))
+
+
+def _compare_files(outs, tol):
+    worst = {}
+    with NcFile(outs["hip"]) as h, NcFile(outs["ref"]) as r:
+        names = list(r._f.variables)
+        assert len(names) >= 20 and sorted(names) == sorted(h._f.variables)
+        for v in names:
+            a, b = h.get(v), r.get(v)
+            assert a.shape == b.shape, v
+            worst[v] = rel_err(a, b)
+    bad = {k: e for k, e in worst.items() if not e < tol}
+    assert not bad, bad
+    return max(worst.values())
+
+
+both_exes = pytest.mark.skipif(not (os.path.exists(EXE) and os.path.exists(REF_EXE)), reason="tools/build_dropin.py [--reference] builds are missing")
+
+
+@both_exes
+@pytest.mark.gpu
+@pytest.mark.parametrize("target", sorted(ALL_TARGETS))
+def test_gpu_dropin_against_the_reference_executable_on_identical_netcdf_inputs(tmp_path, target):
+    """north_star: "fluxes must match the reference CPU OpenMP path on identical netCDF inputs to <= 1e-6 relative (double
+    precision)".  Literally that: the same namelist and the same input file through the reference's offline executable on this
+    box's CPU (tests/_build/reference/ecrad_ref: ecRad 1.7.1 compiled unmodified, OpenMP) and through the same executable with the
+    drop-in module (tests/_build/dropin/ecrad_hip, the MI355X), every variable of the two double-precision output files, for
+    every target of test/ifs/Makefile.  (Both rest on the repo's netCDF library for file I/O: a cross-check by the task's rules,
+    cf. tests/test_oracle_vs_reference_build.py.)"""
+    family, edits = ALL_TARGETS[target]
+    nam = str(tmp_path / f"config_{target}.nam")
+    write_namelist(nam, family, edits)
+    _double_precision_output(nam)
+    worst = _compare_files(_run_both(tmp_path, nam, MERIDIAN), 1.0e-6)
+    print(target, "GPU drop-in vs reference executable: max", worst)
+
+
+@both_exes
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["clear_homogeneous_ecckd32", "tripleclouds_ecckd32", "mcica_ecckd32", "mcica_rrtmg"])
+def test_gpu_dropin_against_the_reference_executable_on_synthetic_ifs_shaped_columns(tmp_path, workload):
+    """The same on 4 096 of the synthetic IFS-shaped columns bench.py times (ecrad_amd/synthetic.py), written to a
+    netCDF file the way the reference's own save_inputs would (ecrad_amd.driver.save_inputs): identical file, two executables."""
+    from bench import build_config
+    from ecrad_amd.driver import save_inputs
+    from ecrad_amd.interface import setup_radiation
+    from ecrad_amd.synthetic import make_columns
+    config, clear_sky, desc = build_config(workload)
+    setup_radiation(config)
+    inputs = make_columns(config, 4096, clear_sky)
+    inp = str(tmp_path / "synthetic.nc")
+    save_inputs(inp, config, *inputs[2:])
+    solver = f'"{desc["sw_solver"]}"'
+    edits = {"sw_solver_name": solver, "lw_solver_name": solver, "do_save_spectral_flux": "false",
+             "use_aerosols": "true" if config.use_aerosols else "false"}
+    nam = str(tmp_path / "config.nam")
+    write_namelist(nam, RRTMG if desc["rrtmg"] else {}, edits)
+    _double_precision_output(nam)
+    worst = _compare_files(_run_both(tmp_path, nam, inp), 1.0e-6)
+    print(workload, "4096 synthetic columns, GPU drop-in vs reference executable: max", worst)

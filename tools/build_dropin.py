@@ -36,13 +36,22 @@ def sources(ref, reference_build=False):
             if f.endswith(".F90") and not (d == "radiation" and f == "radiation_interface.F90" and not reference_build) and f != "easy_netcdf_read_mpi.F90":
                 src.append(os.path.join(ref, d, f))
     src.append(os.path.join(ref, "drhook", "yomhook_dummy.F90"))
-    for f in ("ecrad_driver_config.F90", "ecrad_driver_read_input.F90", "print_matrix_mod.F90", "ecrad_driver.F90"):
+    for f in ("ecrad_driver_config.F90", "ecrad_driver_read_input.F90", "print_matrix_mod.F90"):
         src.append(os.path.join(ref, "driver", f))
+    # the IFS-side caller (ifs/radiation_scheme.F90:540 is the second call site of radiation()) and its blocking
+    for f in sorted(os.listdir(os.path.join(ref, "ifs"))):
+        if f.endswith(".F90") and f != "cos_sza.F90":       # (not among the SOURCES of ifs/Makefile)
+            src.append(os.path.join(ref, "ifs", f))
+    src.append(os.path.join(ref, "driver", "ifs_blocking.F90"))
     ours = os.path.join(ROOT, "ecrad_amd", "fortran")
     mine = ("netcdf.F90",) if reference_build else ("netcdf.F90", "ecrad_hip_binding.F90", "radiation_hip_interface.F90", "radiation_hip_rrtmg.F90", "radiation_interface.F90")
     for f in mine:
         src.append(os.path.join(ours, f))
     return src
+
+
+# executable -> the file of driver/ that holds its main program
+PROGRAMS = {"ecrad": "ecrad_driver.F90", "ecrad_ifs": "ecrad_ifs_driver.F90", "ecrad_ifs_blocked": "ecrad_ifs_driver_blocked.F90"}
 
 
 def scan(path):
@@ -72,7 +81,9 @@ def main():
         args.out = os.path.join(ROOT, "tests", "_build", "reference")
     out, obj = os.path.abspath(args.out), os.path.join(os.path.abspath(args.out), "obj")
     os.makedirs(obj, exist_ok=True)
-    src = sources(args.ref, args.reference)
+    lib = sources(args.ref, args.reference)
+    mains = {exe: os.path.join(args.ref, "driver", f) for exe, f in PROGRAMS.items()}
+    src = lib + list(mains.values())
     info = {f: scan(f) for f in src}
     owner = {}
     for f, (d, _) in info.items():
@@ -80,7 +91,7 @@ def main():
             owner[m] = f
     deps = {f: {owner[m] for m in u if m in owner and owner[m] != f} for f, (_, u) in info.items()}
     flags = (["-O3", "-fopenmp", "-fPIC", "-cpp"] if args.reference else ["-O1", "-fPIC", "-cpp", "-DECRAD_HIP_REFERENCE_TYPES"]) + [ f"-I{args.ref}/include", f"-I{args.ref}/radiation",
-             f"-I{args.ref}/ifsaux", f"-I{args.ref}/ifsrrtm", f"-I{obj}", "-module-dir", obj]
+             f"-I{args.ref}/ifsaux", f"-I{args.ref}/ifsrrtm", f"-I{args.ref}/ifs", f"-I{obj}", "-module-dir", obj]
 
     def obj_of(f):
         return os.path.join(obj, os.path.basename(f)[:-4] + ".o")
@@ -105,20 +116,21 @@ def main():
                 todo.discard(f)
     nc_o = os.path.join(obj, "nc_classic.o")
     subprocess.run([CC, "-O2", "-fPIC", "-c", os.path.join(ROOT, "ecrad_amd", "fortran", "nc_classic.c"), "-o", nc_o], check=True)
-    if args.reference:
-        exe = os.path.join(out, "ecrad_ref")
-        p = subprocess.run([FC, "-fopenmp", "-o", exe, *[obj_of(f) for f in src], nc_o], capture_output=True, text=True)
-    else:
-        exe = os.path.join(out, "ecrad_hip")
-        csrc = os.path.join(ROOT, "ecrad_amd", "csrc")
-        rel = os.path.relpath(csrc, out)
-        # (-fopenmp at the link only: the driver calls omp_get_wtime / omp_get_thread_num unconditionally; the sources are
-        #  compiled without it, so its loop over blocks is serial)
-        p = subprocess.run([FC, "-fopenmp", "-o", exe, *[obj_of(f) for f in src], nc_o, f"-L{csrc}", "-lecrad_hip", f"-Wl,-rpath,$ORIGIN/{rel}"],
-                           capture_output=True, text=True)
-    if p.returncode != 0:
-        sys.exit("link failed:\n" + p.stderr[-4000:])
-    print("built", exe)
+    csrc = os.path.join(ROOT, "ecrad_amd", "csrc")
+    rel = os.path.relpath(csrc, out)
+    for name, main_src in mains.items():
+        exe = os.path.join(out, (name + "_ref") if args.reference else (name + "_hip"))
+        objs = [obj_of(f) for f in lib] + [obj_of(main_src), nc_o]
+        if args.reference:
+            cmd = [FC, "-fopenmp", "-o", exe, *objs]
+        else:
+            # (-fopenmp at the link only: the drivers call omp_get_wtime / omp_get_thread_num unconditionally; the sources are
+            #  compiled without it, so their loops over blocks are serial)
+            cmd = [FC, "-fopenmp", "-o", exe, *objs, f"-L{csrc}", "-lecrad_hip", f"-Wl,-rpath,$ORIGIN/{rel}"]
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        if p.returncode != 0:
+            sys.exit(f"link of {exe} failed:\n" + p.stderr[-4000:])
+        print("built", exe)
 
 
 if __name__ == "__main__":
