@@ -42,6 +42,23 @@ module radiation_hip_interface
     module procedure locd1, locd2, locd3, locd4
   end interface
 
+  ! Single-precision hosts (the reference built with -DPARKIND1_SINGLE: jprb = real32, as the IFS runs operationally).  The
+  ! library's arrays are binary64, so in such a build every real array that crosses the boundary does so as a double copy:
+  ! tables once at set-up, the inputs of a call on the way in, the fluxes (and the cropped cloud fraction) on the way out.
+  ! The two-stream / adding arithmetic on the device stays double -- more accurate than the host's own single-precision
+  ! path, not less -- and the SPARTACUS solvers run in float as the reference's single-precision build does
+  ! (ecrad_config_t::i_precision).  In a double-precision build dloc() is c_loc(): nothing is copied.
+  type dcopy
+    real(c_double), allocatable :: d(:)
+    type(c_ptr) :: src = c_null_ptr       ! the host's own array
+    integer(c_size_t) :: n = 0
+    logical :: write_back = .false.
+  end type
+  integer, parameter :: max_copies = 256
+  type(dcopy), save, target :: pool(max_copies)
+  integer, save :: npool = 0
+  logical, save :: outputs_from_here = .false.
+
 contains
 
   subroutine radiation_hip_abort(text)     ! radiation_abort, utilities/radiation_io.F90:44-67
@@ -56,12 +73,49 @@ contains
     l2i = merge(1_c_int32_t, 0_c_int32_t, l)
   end function
 
+  ! the address the library gets for `n` reals at `src`
+  function dloc(src, n) result(p)
+    type(c_ptr), intent(in) :: src
+    integer(c_size_t), intent(in) :: n
+    type(c_ptr) :: p
+#ifdef PARKIND1_SINGLE
+    real(jprb), pointer :: f(:)
+    if (npool >= max_copies) call radiation_hip_abort('*** Error: too many arrays at the boundary (max_copies)')
+    npool = npool + 1
+    call c_f_pointer(src, f, [n])
+    if (allocated(pool(npool)%d)) deallocate(pool(npool)%d)
+    allocate(pool(npool)%d(n))
+    pool(npool)%d = real(f, c_double)
+    pool(npool)%src = src; pool(npool)%n = n; pool(npool)%write_back = outputs_from_here
+    p = c_loc(pool(npool)%d)
+#else
+    p = src
+#endif
+  end function dloc
+
+  ! after a call: what the library wrote goes back to the host's arrays; then the copies are dropped
+  subroutine finish_copies()
+#ifdef PARKIND1_SINGLE
+    real(jprb), pointer :: f(:)
+    integer :: k
+    do k = 1, npool
+      if (pool(k)%write_back) then
+        call c_f_pointer(pool(k)%src, f, [pool(k)%n])
+        f = real(pool(k)%d, jprb)
+      end if
+      deallocate(pool(k)%d)
+    end do
+#endif
+    npool = 0
+    outputs_from_here = .false.
+  end subroutine finish_copies
+
   function locd1(a) result(p)
     real(jprb), allocatable, target, intent(in) :: a(:)
     type(c_ptr) :: p
     p = c_null_ptr
     if (allocated(a)) then
-      if (size(a) > 0) p = c_loc(a)
+      if (size(a) > 0) p = dloc(c_loc(a), size(a, kind=c_size_t))
     end if
   end function
   function locd2(a) result(p)
@@ -69,7 +123,7 @@ contains
     type(c_ptr) :: p
     p = c_null_ptr
     if (allocated(a)) then
-      if (size(a) > 0) p = c_loc(a)
+      if (size(a) > 0) p = dloc(c_loc(a), size(a, kind=c_size_t))
     end if
   end function
   function locd3(a) result(p)
@@ -77,7 +131,7 @@ contains
     type(c_ptr) :: p
     p = c_null_ptr
     if (allocated(a)) then
-      if (size(a) > 0) p = c_loc(a)
+      if (size(a) > 0) p = dloc(c_loc(a), size(a, kind=c_size_t))
     end if
   end function
   function locd4(a) result(p)
@@ -85,7 +139,7 @@ contains
     type(c_ptr) :: p
     p = c_null_ptr
     if (allocated(a)) then
-      if (size(a) > 0) p = c_loc(a)
+      if (size(a) > 0) p = dloc(c_loc(a), size(a, kind=c_size_t))
     end if
   end function
   function loci(a) result(p)        ! default integers are 32-bit (c_int32_t) in every build of the reference
@@ -173,7 +227,6 @@ contains
     type(ecrad_rrtmg_t), intent(in), optional :: rrtmg
     type(ecrad_config_t) :: c
     integer :: jt, idev
-    if (kind(1.0_jprb) /= c_double) call radiation_hip_abort('*** Error: the MI355X library takes double-precision arrays (jprb = jprd)')
     idev = -1
     if (present(device_id)) idev = device_id
     if (.not. c_associated(hip_handle)) then
@@ -237,6 +290,9 @@ contains
     c%do_3d_effects = l2i(config%do_3d_effects); c%do_3d_lw_multilayer_effects = l2i(config%do_3d_lw_multilayer_effects)
     c%do_lw_side_emissivity = l2i(config%do_lw_side_emissivity); c%use_expm_everywhere = l2i(config%use_expm_everywhere)
     c%i_precision = ECRAD_PRECISION_DOUBLE; c%reserved3_ = 0
+#ifdef PARKIND1_SINGLE
+    c%i_precision = ECRAD_PRECISION_SINGLE       ! the SPARTACUS solvers in float, as in the host's own build
+#endif
     c%max_3d_transfer_rate = config%max_3d_transfer_rate; c%max_gas_od_3d = config%max_gas_od_3d
     c%min_cloud_effective_size = config%min_cloud_effective_size; c%overhang_factor = config%overhang_factor
     c%clear_to_thick_fraction = config%clear_to_thick_fraction; c%overhead_sun_factor = config%overhead_sun_factor
@@ -275,6 +331,7 @@ contains
     c%pdf_sampler%fsd1 = config%pdf_sampler%fsd1; c%pdf_sampler%inv_fsd_interval = config%pdf_sampler%inv_fsd_interval
     c%pdf_sampler%val = locd(config%pdf_sampler%val)
     if (ecrad_hip_setup(hip_handle, c) /= ECRAD_OK) call radiation_hip_abort('*** Error in ecrad_hip_setup')
+    call finish_copies()       ! (the library holds its own copies of every table now)
   end subroutine setup_radiation_hip
 
   ! radiation (radiation_interface.F90:200): same argument list and intents as the reference.
@@ -311,7 +368,10 @@ contains
     cin%n_cloud_types = 0; cin%n_aerosol_types = 0; cin%aerosol_istartlev = 1; cin%aerosol_iendlev = 0; cin%reserved_ = 0
     if (config%do_clouds) then
       cin%n_cloud_types = cloud%ntype
-      cin%cloud_fraction = locd(cloud%fraction); cin%cloud_mixing_ratio = locd(cloud%mixing_ratio)
+      outputs_from_here = .true.      ! (intent(inout): the crop_cloud_fraction side effect)
+      cin%cloud_fraction = locd(cloud%fraction)
+      outputs_from_here = .false.
+      cin%cloud_mixing_ratio = locd(cloud%mixing_ratio)
       cin%cloud_effective_radius = locd(cloud%effective_radius)
       cin%cloud_fractional_std = locd(cloud%fractional_std); cin%cloud_overlap_param = locd(cloud%overlap_param)
       cin%cloud_inv_cloud_effective_size = locd(cloud%inv_cloud_effective_size)
@@ -323,6 +383,7 @@ contains
       cin%aerosol_mixing_ratio = locd(aerosol%mixing_ratio)
     end if
     cfl%memory = ECRAD_MEM_HOST; cfl%reserved_ = 0
+    outputs_from_here = .true.
     cfl%lw_up = locd(flux%lw_up); cfl%lw_dn = locd(flux%lw_dn); cfl%sw_up = locd(flux%sw_up); cfl%sw_dn = locd(flux%sw_dn)
     cfl%sw_dn_direct = locd(flux%sw_dn_direct); cfl%lw_up_clear = locd(flux%lw_up_clear); cfl%lw_dn_clear = locd(flux%lw_dn_clear)
     cfl%sw_up_clear = locd(flux%sw_up_clear); cfl%sw_dn_clear = locd(flux%sw_dn_clear)
@@ -351,6 +412,7 @@ contains
     cfl%sw_dn_clear_band = locd(flux%sw_dn_clear_band); cfl%sw_dn_direct_clear_band = locd(flux%sw_dn_direct_clear_band)
     if (ecrad_hip_radiation(hip_handle, int(ncol,c_int), int(nlev,c_int), int(istartcol,c_int), int(iendcol,c_int), &
          &  cin, cfl) /= ECRAD_OK) call radiation_hip_abort('*** Error in ecrad_hip_radiation')
+    call finish_copies()
   end subroutine radiation_hip
 
   subroutine finalize_radiation_hip()

@@ -325,3 +325,96 @@ def test_gpu_dropin_against_the_reference_executable_on_synthetic_ifs_shaped_col
     _double_precision_output(nam)
     worst = _compare_files(_run_both(tmp_path, nam, inp), 1.0e-6)
     print(workload, "4096 synthetic columns, GPU drop-in vs reference executable: max", worst)
+
+
+# ---- the reference's two other test directories through the two executables ---------------------------------------------
+def _suite_namelist(src, dst, radiation_edits=None, driver_edits=None):
+    text = open(src).read()
+    drv, rad = text.split("&radiation\n", 1)
+    def apply(block, edits):
+        for k, v in (edits or {}).items():
+            pat = re.compile(r"^(\s*)" + re.escape(k) + r"\s*=[^,\n]*,?", re.M)
+            block = pat.sub(lambda m: f"{m.group(1)}{k} = {v},", block, count=1) if pat.search(block) else f"{k} = {v},\n" + block
+        return block
+    rad = apply(rad, dict(radiation_edits or {}, directory_name=f'"{DATA_DIR}"'))
+    head, body = drv.split("&radiation_driver\n", 1)
+    body = apply(body, dict(driver_edits or {}, do_write_double_precision="true"))
+    open(dst, "w").write(head + "&radiation_driver\n" + body + "&radiation\n" + rad)
+
+
+SUITES = {
+    # test/ckdmip: 50 clear-sky CKDMIP profiles (54 levels, gases as "<gas>_mole_fraction_fl"), ecCKD and RRTMG
+    "ckdmip_ecckd": ("ckdmip/ckdmip.nam", "ckdmip/ckdmip_evaluation1_concentrations_present_reduced.nc", {}, {}),
+    "ckdmip_rrtmg": ("ckdmip/ckdmip.nam", "ckdmip/ckdmip_evaluation1_concentrations_present_reduced.nc", {"gas_model_name": '"RRTMG-IFS"'},
+                     {"cos_solar_zenith_angle": "0.1"}),
+    # test/i3rc: the I3RC cumulus profile (164 levels) over 46 solar zenith angles, SPARTACUS with 3-D effects on RRTMG's spectra
+    "i3rc_maximum": ("i3rc/i3rc.nam", "i3rc/i3rc_mls_cumulus.nc", {}, {}),
+    "i3rc_explicit": ("i3rc/i3rc.nam", "i3rc/i3rc_mls_cumulus.nc", {"sw_entrapment_name": '"Explicit"'}, {}),
+    "i3rc_1d": ("i3rc/i3rc.nam", "i3rc/i3rc_mls_cumulus.nc", {"do_3d_effects": "false"}, {}),
+    "i3rc_tripleclouds": ("i3rc/i3rc.nam", "i3rc/i3rc_mls_cumulus.nc", {"sw_solver_name": '"Tripleclouds"', "lw_solver_name": '"Tripleclouds"'}, {}),
+    "i3rc_mcica": ("i3rc/i3rc.nam", "i3rc/i3rc_mls_cumulus.nc", {"sw_solver_name": '"McICA"', "lw_solver_name": '"McICA"'}, {}),
+}
+
+
+@both_exes
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(SUITES))
+def test_gpu_dropin_against_the_reference_executable_on_the_other_reference_suites(tmp_path, case):
+    """test/ckdmip and test/i3rc of the reference (input files byte-identical under tests/golden/; the namelists are the ones
+    tests/test_reference_suites.py uses): other level counts (54, 164), gases as scalars / under other variable names, black
+    surface and solar zenith angle from the driver namelist, cloud effective sizes from the file -- read by the reference's own
+    input reader in both programs."""
+    nam_src, inp, rad_edits, drv_edits = SUITES[case]
+    nam = str(tmp_path / "config.nam")
+    _suite_namelist(os.path.join(GOLDEN_DIR, nam_src), nam, rad_edits, drv_edits)
+    outs = _run_both(tmp_path, nam, os.path.join(GOLDEN_DIR, inp))
+    worst = {}
+    with NcFile(outs["hip"]) as h, NcFile(outs["ref"]) as r:
+        names = list(r._f.variables)
+        assert len(names) >= 8 and sorted(names) == sorted(h._f.variables)
+        for v in names:
+            worst[v] = rel_err(h.get(v), r.get(v))
+    bad = {k: e for k, e in worst.items() if not e < 1.0e-6}
+    assert not bad, bad
+    print(case, "GPU drop-in vs reference executable: max", max(worst.values()))
+
+
+# ---- a single-precision host (the reference built with -DPARKIND1_SINGLE, jprb = real32: how the IFS runs operationally) ---
+SP_EXE = os.path.join(ROOT, "tests", "_build", "dropin_sp", "ecrad_hip")
+SP_REF = os.path.join(ROOT, "tests", "_build", "reference_sp", "ecrad_ref")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(SP_EXE) and os.path.exists(SP_REF) and os.path.exists(EXE)),
+                    reason="tools/build_dropin.py --single [--reference] builds are missing")
+@pytest.mark.parametrize("target", ["ecckd_mcica", "test_ecckd_tc", "default", "tripleclouds", "test_spartacus"])
+def test_single_precision_host_through_the_dropin(tmp_path, target):
+    """In a single-precision build of the host every real array crosses the boundary as a double copy made by the wrapper
+    (radiation_hip_interface.F90: dloc / finish_copies; the RRTMG module tables likewise) and the device arithmetic stays
+    double.  So the single-precision host + GPU must equal the DOUBLE-precision host + GPU up to the rounding of its inputs and
+    outputs to float (1e-5 here; SPARTACUS, whose solver then runs in float as the reference's own single-precision build
+    does, 2e-3), and must be at least as close to the double-precision result as the reference's own single-precision CPU
+    executable is."""
+    family, edits = ALL_TARGETS[target]
+    nam = str(tmp_path / "config.nam")
+    write_namelist(nam, family, edits)
+    _double_precision_output(nam)
+    outs = {}
+    for label, exe, threads in (("sp_hip", SP_EXE, "1"), ("dp_hip", EXE, "1"), ("sp_ref", SP_REF, "8")):
+        out = str(tmp_path / f"{label}.nc")
+        p = subprocess.run(f"ulimit -s unlimited; exec {exe} {nam} {MERIDIAN} {out}", shell=True, capture_output=True, text=True,
+                           cwd=str(tmp_path), env=dict(os.environ, OMP_NUM_THREADS=threads, OMP_STACKSIZE="1G"), timeout=900)
+        assert p.returncode == 0, label + ": " + (p.stdout + p.stderr)[-3000:]
+        outs[label] = out
+    spartacus = "spartacus" in target
+    broadband = ("flux_up_lw", "flux_dn_lw", "flux_up_sw", "flux_dn_sw", "flux_dn_direct_sw", "flux_up_lw_clear", "flux_up_sw_clear")
+    with NcFile(outs["sp_hip"]) as a, NcFile(outs["dp_hip"]) as b, NcFile(outs["sp_ref"]) as c:
+        assert sorted(a._f.variables) == sorted(b._f.variables)
+        e_hip = {v: rel_err(a.get(v), b.get(v)) for v in broadband}
+        e_ref = {v: rel_err(c.get(v), b.get(v)) for v in broadband}
+    print(target, "single-precision host + GPU vs double:", max(e_hip.values()), "; the reference's single-precision CPU run vs double:", max(e_ref.values()))
+    for v in broadband:
+        if spartacus and v in ("flux_up_lw", "flux_dn_lw"):
+            continue        # (all-sky longwave with 3-D effects: chaotic in single precision in the reference's own formulation)
+        assert e_hip[v] < (2.0e-3 if spartacus else 1.0e-5), (v, e_hip[v])
+        assert e_hip[v] <= max(2.0 * e_ref[v], 1.0e-6), (v, e_hip[v], e_ref[v])

@@ -76,9 +76,12 @@ def main():
     ap.add_argument("--reference", action="store_true",
                     help="the UNMODIFIED reference instead (its own radiation_interface.F90, OpenMP on, no GPU library): the CPU "
                          "executable `ecrad_ref`, whose only non-reference part is the netCDF library underneath easy_netcdf.F90")
+    ap.add_argument("--single", action="store_true", help="the host in single precision (-DPARKIND1_SINGLE: jprb = real32, as the IFS runs)")
     args = ap.parse_args()
     if args.reference and args.out.endswith("dropin"):
         args.out = os.path.join(ROOT, "tests", "_build", "reference")
+    if args.single:
+        args.out += "_sp"
     out, obj = os.path.abspath(args.out), os.path.join(os.path.abspath(args.out), "obj")
     os.makedirs(obj, exist_ok=True)
     lib = sources(args.ref, args.reference)
@@ -92,6 +95,8 @@ def main():
     deps = {f: {owner[m] for m in u if m in owner and owner[m] != f} for f, (_, u) in info.items()}
     flags = (["-O3", "-fopenmp", "-fPIC", "-cpp"] if args.reference else ["-O1", "-fPIC", "-cpp", "-DECRAD_HIP_REFERENCE_TYPES"]) + [ f"-I{args.ref}/include", f"-I{args.ref}/radiation",
              f"-I{args.ref}/ifsaux", f"-I{args.ref}/ifsrrtm", f"-I{args.ref}/ifs", f"-I{obj}", "-module-dir", obj]
+    if args.single:
+        flags.append("-DPARKIND1_SINGLE")
 
     def obj_of(f):
         return os.path.join(obj, os.path.basename(f)[:-4] + ".o")
