@@ -16,7 +16,7 @@ module radiation_hip_interface
   use ecrad_hip_binding
 #ifdef ECRAD_HIP_REFERENCE_TYPES
   use parkind1,                 only : jprb
-  use radiation_config,         only : config_type, IGasModelIFSRRTMG
+  use radiation_config,         only : config_type, IGasModelIFSRRTMG, ISolverSpartacus
   use radiation_single_level,   only : single_level_type
   use radiation_thermodynamics, only : thermodynamics_type
   use radiation_gas,            only : gas_type
@@ -291,7 +291,8 @@ contains
     c%do_lw_side_emissivity = l2i(config%do_lw_side_emissivity); c%use_expm_everywhere = l2i(config%use_expm_everywhere)
     c%i_precision = ECRAD_PRECISION_DOUBLE; c%reserved3_ = 0
 #ifdef PARKIND1_SINGLE
-    c%i_precision = ECRAD_PRECISION_SINGLE       ! the SPARTACUS solvers in float, as in the host's own build
+    ! the SPARTACUS solvers in float, as in the host's own build (the other solvers compute in double whatever the host is)
+    if (config%i_solver_sw == ISolverSpartacus .or. config%i_solver_lw == ISolverSpartacus) c%i_precision = ECRAD_PRECISION_SINGLE
 #endif
     c%max_3d_transfer_rate = config%max_3d_transfer_rate; c%max_gas_od_3d = config%max_gas_od_3d
     c%min_cloud_effective_size = config%min_cloud_effective_size; c%overhang_factor = config%overhang_factor
