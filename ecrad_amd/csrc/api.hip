@@ -1301,6 +1301,9 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
   // (only next to the RRTMG gas-optics pass: 212.8 -> 208.6 ms per 100 000 columns, profiles/r02_zk_gen_overlap.log; next to
   //  the other spectrum's solver kernel of an ecCKD run it gains nothing -- both are bound by instruction issue)
   const bool gen_overlap = (sw_mcica || lw_mcica) && (h->rrtmg_sw || h->rrtmg_lw) && !getenv("ECRAD_NO_GEN_OVERLAP");
+  // (the SHORTWAVE generator of a run with both spectra on McICA goes next to the longwave solver kernels instead: 192.6 -> 190.4 ms,
+  //  profiles/r03_variants.log; ECRAD_GEN_SW_EARLY puts it back next to the gas optics)
+  const bool gen_sw_late = gen_overlap && sw_mcica && lw_mcica && !getenv("ECRAD_GEN_SW_EARLY");
   auto run_generator = [&](bool is_sw, hipStream_t gs) -> int {
     double* ods = is_sw ? prep.od_scaling_sw : prep.od_scaling_lw;
     double* tcc = is_sw ? prep.total_cloud_cover_sw : prep.total_cloud_cover_lw;
@@ -1316,7 +1319,8 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     HIP_TRY(h, hipEventRecord(h->ev_fork, stream));
     HIP_TRY(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
     if (lw_mcica) { if ((st = run_generator(false, h->aux_stream))) return st; HIP_TRY(h, hipEventRecord(h->ev_gen_lw, h->aux_stream)); }
-    if (sw_mcica) { if ((st = run_generator(true, h->aux_stream))) return st; HIP_TRY(h, hipEventRecord(h->ev_gen_sw, h->aux_stream)); }
+    // (ECRAD_GEN_SW_LATE: the shortwave generator next to the longwave SOLVER -- HBM-bound -- instead of next to the gas optics)
+    if (sw_mcica && !(lw_mcica && gen_sw_late)) { if ((st = run_generator(true, h->aux_stream))) return st; HIP_TRY(h, hipEventRecord(h->ev_gen_sw, h->aux_stream)); }
   }
   bool rrtmg_sw_pending = false;
   if ((st = run_rrtmg(h, cx, true, /*split_sw=*/true, &rrtmg_sw_pending))) return st;  // RRTMG gas optics, :341-357 (accounted to the PREP stage)
@@ -1416,6 +1420,12 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     if (lw_mcica) {
       if (gen_overlap) HIP_TRY(h, hipStreamWaitEvent(stream, h->ev_gen_lw, 0));
       else if ((st = run_generator(false, stream))) return st;
+      if (gen_sw_late && sw_mcica) {      // fork here: the shortwave generator runs on the second stream while the longwave solver kernels do
+        HIP_TRY(h, hipEventRecord(h->ev_fork_sw, stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork_sw, 0));
+        if ((st = run_generator(true, h->aux_stream))) return st;
+        HIP_TRY(h, hipEventRecord(h->ev_gen_sw, h->aux_stream));
+      }
     }
     if (lw_sp) { if ((st = run_spartacus(false))) return st; }
     auto launch_lw = [&](const DevFlux& f, int* counter, int p, bool wide) -> hipError_t {

@@ -255,13 +255,13 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
             if (cloud_scattering) {
               double ssa_total = 0.0, g_total = 0.0;
               if (MODE == 1) {    // radiation_homogeneous_lw.F90:218-228
-                if (od_total > 0.0) ssa_total = cl.ssa * od_cloud_new / od_total;
-                if (ssa_total > 0.0 && od_total > 0.0) g_total = cl.g * cl.ssa * od_cloud_new / (ssa_total * od_total);
+                if (od_total > 0.0) ssa_total = fdiv(cl.ssa * od_cloud_new, od_total);
+                if (ssa_total > 0.0 && od_total > 0.0) g_total = fdiv(cl.g * cl.ssa * od_cloud_new, ssa_total * od_total);
               } else {            // radiation_mcica_lw.F90:280-293
                 if (od_total > 0.0) {
                   const double scat_od = cl.ssa * od_cloud_new;
-                  ssa_total = scat_od / od_total;
-                  if (scat_od > 0.0) g_total = cl.g * cl.ssa * od_cloud_new / scat_od;
+                  ssa_total = fdiv(scat_od, od_total);
+                  if (scat_od > 0.0) g_total = fdiv(cl.g * cl.ssa * od_cloud_new, scat_od);
                 }
               }
               c2 = ref_trans_lw(od_total, ssa_total, g_total, planck_top, planck_bot);
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
             s.pair(P_AS, l, tid) = make_double2(alb, src);       // below layer l
             if (cloudy.test(l)) {
               const double R = cur[k].a.x, T = cur[k].a.y;
-              const double inv = 1.0 / (1.0 - alb * R);
+              const double inv = frcp(1.0 - alb * R);
               s.pair(P_DN, l, tid) = make_double2(T * inv, (R * src + cur[k].b.y) * inv);
               const double src_new = cur[k].b.x + T * (src + alb * cur[k].b.y) * inv;
               alb = R + T * T * alb * inv;

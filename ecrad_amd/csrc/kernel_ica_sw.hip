@@ -44,7 +44,7 @@ struct SwSweepState {   // albedo / normalised source below the current half lev
 };
 
 ECRAD_DEV void sw_up_step(const SwScratch& s, int set, int lev, int tid, const SwCoef& c, SwSweepState& st) {
-  const double inv = 1.0 / (1.0 - st.alb * c.ref_diff);
+  const double inv = frcp(1.0 - st.alb * c.ref_diff);
   double2 p0, p1;
   p0.x = c.trans_diff * inv;                                                       // a1
   p0.y = (c.ref_diff * st.sig * c.trans_dir_dir + c.trans_dir_diff) * inv;         // b
@@ -112,15 +112,16 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
                              double* out_up, double* out_dn, double* out_dir, double weight,
                              const double* clr_up, const double* clr_dn, const double* clr_dir,
                              double* dup_up, double* dup_dn, double* dup_dir, const LevelOrder& ord, const SwSpec& sp,
-                             double& fdn_surf, double& fdir_surf, double& fup_toa) {
-  double Fd = incoming, fdn = 0.0, fup = incoming * sig_top;
+                             lds_double* red, double& fdn_surf, double& fdir_surf, double& fup_toa) {
+  // (lanes without a g-point or column start from a zero beam: every flux of theirs is zero, the sums need no mask)
+  double Fd = valid ? incoming : 0.0, fdn = 0.0, fup = Fd * sig_top;
   fup_toa = fup;
   const bool blend = weight < 1.0;
   const int glane = tid % NGP;
-  // The sums over g of half level l are kept by lane (l mod NGP) of the column group and written NGP
-  // half levels at a time: 3 store instructions per NGP levels instead of 3 per level, and no stores
-  // between the scratch reads of consecutive layers.
-  double keep_u = 0.0, keep_d = 0.0, keep_dir = 0.0;
+  // The sums over g of four half levels at a time go through LDS (LevelReduce, kernels_common.h): rows (up, l mod 4),
+  // (diffuse down, l mod 4), (direct beam, l mod 4); the lane that ends up with a row's sum blends and stores it.
+  static_assert(kSwBatch == 2 || kSwBatch == 4, "a group of four half levels ends with a batch of layers");
+  const LevelReduce<NGP, 3, 3 - (kSwBatch & 3)> rd{red, tid & 63, glane};
   auto emit = [&](int l) {
     if (SPEC && sp.up && valid) {        // spectral flux profiles (radiation_homogeneous_sw.F90:299-311)
       const size_t o = col + ncol * ord.half(l);
@@ -132,29 +133,26 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
       spec_put(sp.dn2, sp.ng, sp.g, o, dir + fdn);
       spec_put(sp.dir2, sp.ng, sp.g, o, dir);
     }
-    const double su = group_sum<NGP>(valid ? fup : 0.0);
-    const double sd = group_sum<NGP>(valid ? fdn : 0.0);
-    const double sdir = group_sum<NGP>(valid ? Fd : 0.0) * mu0;
-    if ((l & (NGP - 1)) == glane) { keep_u = su; keep_d = sd + sdir; keep_dir = sdir; }
-    if ((l & (NGP - 1)) == NGP - 1 || l == nlev) {
-      const int lv = (l & ~(NGP - 1)) + glane;
-      if (col_ok && lv <= l) {
-        const size_t o = col + ncol * ord.half(lv);
-        double vu = keep_u, vd = keep_d, vdir = keep_dir;
-        if (blend) {
-          vu = weight * vu + (1.0 - weight) * clr_up[o];
-          vd = weight * vd + (1.0 - weight) * clr_dn[o];
-          if (out_dir) vdir = weight * vdir + (1.0 - weight) * clr_dir[o];
-        }
-        out_up[o] = vu;
-        out_dn[o] = vd;
-        if (out_dir) out_dir[o] = vdir;
-        if (dup_up) {              // the same profile is also another output (e.g. total sky = clear sky)
-          dup_up[o] = vu;
-          dup_dn[o] = vd;
-          if (dup_dir) dup_dir[o] = vdir;
-        }
-      }
+    rd.put(0, l, fup);
+    rd.put(1, l, fdn);
+    rd.put(2, l, Fd);
+  };
+  // sums of the group of half levels that ends with l: blend with the clear-sky profile, store
+  // (one predicated block per destination array: a pointer selected per lane becomes a table in private memory)
+  auto flush = [&](int l) {
+    const double acc = rd.sum();
+    const double below = dpp_move<0x104>(acc);       // row_shl:4 -- the direct-beam sum, seen from the diffuse row's lanes
+    const int q = rd.q_of();
+    if (col_ok && rd.owner(l)) {
+      const size_t o = col + ncol * ord.half(rd.level_of(l));
+      auto put = [&](double v, double* out, const double* clr, double* dup) {
+        if (blend) v = weight * v + (1.0 - weight) * clr[o];
+        out[o] = v;
+        if (dup_up && dup) dup[o] = v;       // the same profile is also another output (e.g. total sky = clear sky)
+      };
+      if (q == 0) put(acc, out_up, clr_up, dup_up);
+      if (q == 1) put(acc + below * mu0, out_dn, clr_dn, dup_dn);
+      if (q == 2 && out_dir) put(acc * mu0, out_dir, clr_dir, dup_dir);
     }
   };
   SwRec cur[kSwBatch], nxt[kSwBatch];
@@ -176,6 +174,10 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
         fup = r_alb * fdn + r_sig * Fd;
         emit(lay0 + k + 1);
       }
+    }
+    {
+      const int l_end = lay0 + kSwBatch < nlev ? lay0 + kSwBatch : nlev;
+      if (rd.complete(l_end) || l_end == nlev) flush(l_end);
     }
 #pragma unroll
     for (int k = 0; k < kSwBatch; ++k) cur[k] = nxt[k];
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void s
           ECRAD_LAP(tm, 2, od);             // combine
           double ssa = L.D(F_SM, slot) * ray_g;       // Rayleigh optical depth
           od = od + ssa;
-          ssa = ssa / od;
+          ssa = fdiv(ssa, od);
           double od_scaling_staged = 0.0, asym_staged = 0.0;
           bool staged = false;
           if constexpr (sizeof(TAB) == 8) {
@@ -356,16 +358,16 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void s
               double od_total, ssa_total = 0.0, g_total = 0.0;
               if (MODE == 1) {   // radiation_homogeneous_sw.F90:236-253
                 od_total = od + cl.od;
-                if (od_total > 0.0) ssa_total = (ssa * od + cl.ssa * cl.od) / od_total;
+                if (od_total > 0.0) ssa_total = fdiv(ssa * od + cl.ssa * cl.od, od_total);
                 if (ssa_total > 0.0 && od_total > 0.0)
-                  g_total = (asym * ssa * od + cl.g * cl.ssa * cl.od) / (ssa_total * od_total);
+                  g_total = fdiv(asym * ssa * od + cl.g * cl.ssa * cl.od, ssa_total * od_total);
               } else {           // radiation_mcica_sw.F90:250-268
                 const double od_cloud_new = (staged ? od_scaling_staged : b.prep.od_scaling_sw[g + (size_t)ng * (lev + (size_t)nlev * cloc)]) * cl.od;
                 od_total = od + od_cloud_new;
                 if (od_total > 0.0) {
                   const double scat_od = ssa * od + cl.ssa * od_cloud_new;
-                  ssa_total = scat_od / od_total;
-                  if (scat_od > 0.0) g_total = (asym * ssa * od + cl.g * cl.ssa * od_cloud_new) / scat_od;
+                  ssa_total = fdiv(scat_od, od_total);
+                  if (scat_od > 0.0) g_total = fdiv(asym * ssa * od + cl.g * cl.ssa * od_cloud_new, scat_od);
                 }
               }
               if (flags & SWF_DELTA_GASES) delta_eddington(od_total, ssa_total, g_total);
@@ -386,6 +388,8 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void s
     }
 
     // ---- sweep 2: top -> surface: fluxes ------------------------------------------------------------
+    // (the table values die here: the flux sweep has the registers for its batches of records and of LDS reads)
+    quads.reset();
     const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
     const LevelOrder ord = level_order(kernarg_block<SpectralArgs>().in);
     ECRAD_LAP0(tm, 0);
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void s
                            SwSpec{fx.sw_up_band, fx.sw_dn_band, fx.sw_dn_direct_band,
                                   have_clear_out ? fx.sw_up_clear_band : nullptr, have_clear_out ? fx.sw_dn_clear_band : nullptr,
                                   have_clear_out ? fx.sw_dn_direct_clear_band : nullptr, ng, g},
-                           fdn_s, fdir_s, fup_t);
+                           lds_wave_area(smem, L.rec2 * 2, tid), fdn_s, fdir_s, fup_t);
         if (valid) {
           const size_t og = g + (size_t)ng * col;
           fx.sw_dn_diffuse_surf_g[og] = fdn_s;
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void s
                              SwSpec{fx.sw_up_clear_band, fx.sw_dn_clear_band, fx.sw_dn_direct_clear_band,
                                     do_set2 ? nullptr : fx.sw_up_band, do_set2 ? nullptr : fx.sw_dn_band,
                                     do_set2 ? nullptr : fx.sw_dn_direct_band, ng, g},
-                             fdn_c, fdir_c, fup_c);
+                             lds_wave_area(smem, L.rec2 * 2, tid), fdn_c, fdir_c, fup_c);
           if (valid) {
             const size_t og = g + (size_t)ng * col;
             fx.sw_dn_diffuse_surf_clear_g[og] = fdn_c;
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void s
                              fx.sw_up, fx.sw_dn, fx.sw_dn_direct, w, fx.sw_up_clear, fx.sw_dn_clear,
                              fx.sw_dn_direct_clear, nullptr, nullptr, nullptr, ord,
                              SwSpec{fx.sw_up_band, fx.sw_dn_band, fx.sw_dn_direct_band, nullptr, nullptr, nullptr, ng, g},
-                             fdn_s, fdir_s, fup_t);
+                             lds_wave_area(smem, L.rec2 * 2, tid), fdn_s, fdir_s, fup_t);
           if (valid) {
             const size_t og = g + (size_t)ng * col;
             if (MODE == 2) {

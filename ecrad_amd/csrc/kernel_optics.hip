@@ -26,7 +26,10 @@ struct DumpArgs {
 template <typename OUT> ECRAD_DEV void put_stage(double* arr, size_t o, double v) { reinterpret_cast<OUT*>(arr)[o] = (OUT)v; }
 
 template <typename TAB, int NGP, bool IS_SW, typename OUT>
-__global__ __launch_bounds__(kBlock, ECRAD_MIN_WAVES) void optics_dump_kernel(DumpArgs args_in_kernarg) {
+#ifndef ECRAD_DUMP_MIN_WAVES
+#define ECRAD_DUMP_MIN_WAVES ECRAD_MIN_WAVES
+#endif
+__global__ __launch_bounds__(kBlock, ECRAD_DUMP_MIN_WAVES) void optics_dump_kernel(DumpArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   const DumpArgs& a0 = kernarg_block<DumpArgs>();
   const DevConfig& cfg = a0.cfg;

@@ -143,7 +143,7 @@ struct TcSwScratch {
 // the half level above the layer (before overlap)
 ECRAD_DEV void tc_sw_up(const TcSwScratch& s, int set, int lev, int tid, const SwCoef& c, double A, double Ad,
                         double& A_new, double& Ad_new) {
-  const double inv = 1.0 / (1.0 - A * c.ref_diff);
+  const double inv = frcp(1.0 - A * c.ref_diff);
 #if ECRAD_PACK_SW
   packed5_store(s.base, s.rec(set, lev), tid,
                 pack5(c.trans_diff * inv, (c.trans_dir_dir * Ad * c.ref_diff + c.trans_dir_diff) * inv, c.trans_dir_dir, A, Ad));
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
         double od = gas_combine<TAB>(launder_uniform(gh.nquad), L, slot, quads);
         double ssa = L.D(F_SM, slot) * ray_g;
         od = od + ssa;
-        ssa = ssa / od;
+        ssa = fdiv(ssa, od);
         double asym = 0.0;
         bool folded = false;
         if constexpr (sizeof(TAB) == 8) {
@@ -297,8 +297,8 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
             const double scat_od = od * ssa;
             const double scat_od_cloud = cl.od * cl.ssa * osc;
             double od_total = od + cl.od * osc;
-            double ssa_total = (scat_od + scat_od_cloud) / od_total;
-            double g_total = (scat_od * asym + scat_od_cloud * cl.g) / (scat_od + scat_od_cloud);
+            double ssa_total = fdiv(scat_od + scat_od_cloud, od_total);
+            double g_total = fdiv(scat_od * asym + scat_od_cloud * cl.g, scat_od + scat_od_cloud);
             if (delta_gases) delta_eddington(od_total, ssa_total, g_total);
             const SwCoef c = ref_trans_sw_fused(mu0, od_total, ssa_total, g_total);
             tc_sw_up(s, jreg, l, tid, c, ta[jreg], tad[jreg], below[jreg], belowd[jreg]);
@@ -709,12 +709,12 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
             if (cloud_scattering) {
               double ssa_total = 0.0, g_total = 0.0;
               if (ASCAT) {     // :335-343
-                if (od_total > 0.0) ssa_total = (ssa * od + cl.ssa * od_cloud_new) / od_total;
+                if (od_total > 0.0) ssa_total = fdiv(ssa * od + cl.ssa * od_cloud_new, od_total);
                 if (ssa_total > 0.0 && od_total > 0.0)
-                  g_total = (asym * ssa * od + cl.g * cl.ssa * od_cloud_new) / (ssa_total * od_total);
+                  g_total = fdiv(asym * ssa * od + cl.g * cl.ssa * od_cloud_new, ssa_total * od_total);
               } else {
-                if (od_total > 0.0) ssa_total = cl.ssa * od_cloud_new / od_total;
-                if (ssa_total > 0.0 && od_total > 0.0) g_total = cl.g * cl.ssa * od_cloud_new / (ssa_total * od_total);
+                if (od_total > 0.0) ssa_total = fdiv(cl.ssa * od_cloud_new, od_total);
+                if (ssa_total > 0.0 && od_total > 0.0) g_total = fdiv(cl.g * cl.ssa * od_cloud_new, ssa_total * od_total);
               }
               c2 = ref_trans_lw(od_total, ssa_total, g_total, planck_top, planck_bot);
             } else {
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
             if (!ASCAT) fup_c = T1 * fup_c + SU1;
             if (ASCAT && do_clear) {      // clear-sky albedo / source recurrences + records of sweep C'
               const double R1 = r1[k];
-              const double inv = 1.0 / (1.0 - alb_c * R1);
+              const double inv = frcp(1.0 - alb_c * R1);
               s.pair(TL_DC, l, tid) = make_double2(T1 * inv, (R1 * src_c + sd1[k]) * inv);
               s.pair(TL_DCT, l, tid) = make_double2(alb_c, src_c);
               const double src_new = SU1 + T1 * (src_c + alb_c * sd1[k]) * inv;
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
                 const double su1 = f * SU1, sdf = f * sd1[k];
                 if (ASCAT) {
                   const double R1 = r1[k];
-                  const double inv = 1.0 / (1.0 - ta[0] * R1);
+                  const double inv = frcp(1.0 - ta[0] * R1);
                   s.pair(TL_D(0), l, tid) = make_double2(T1 * inv, (R1 * ts[0] + sdf) * inv);
                   s.pair(TL_DT(0), l, tid) = make_double2(ts[0], ta[0]);
                   below[0] = R1 + T1 * T1 * ta[0] * inv;
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
                   const double f = feed.frac(k, r);
                   const double R = rt[k][r - 1].x, T = rt[k][r - 1].y;
                   const double su = f * ss[k][r - 1].x, sd = f * ss[k][r - 1].y;
-                  const double inv = 1.0 / (1.0 - ta[r] * R);
+                  const double inv = frcp(1.0 - ta[r] * R);
                   s.pair(TL_D(r), l, tid) = make_double2(T * inv, (R * ts[r] + sd) * inv);
                   s.pair(TL_DT(r), l, tid) = make_double2(ts[r], ta[r]);
                   below[r] = R + T * T * ta[r] * inv;

@@ -100,8 +100,47 @@ struct PhaseTimer {
 // __syncthreads() implies) is needed -- only the compiler must not move LDS accesses across it.
 ECRAD_DEV void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
-ECRAD_DEV double dmax(double a, double b) { return a > b ? a : b; }
-ECRAD_DEV double dmin(double a, double b) { return a < b ? a : b; }
+// (v_max_f64 / v_min_f64: one instruction instead of a compare and two selects; the same value for every pair of numbers)
+ECRAD_DEV double dmax(double a, double b) { return __builtin_fmax(a, b); }
+ECRAD_DEV double dmin(double a, double b) { return __builtin_fmin(a, b); }
+
+// a / b and 1 / b in the hot loops: the instruction sequence the compiler emits for `/` (v_rcp_f64, two Newton steps, the
+// quotient and one correction step -- correctly rounded) WITHOUT its two v_div_scale_f64 and the v_div_fixup_f64 (8 / 7
+// instructions instead of 11).  Those three only act when an operand or the quotient is within a few hundred binades of the
+// ends of the exponent range, and give inf for a zero denominator where this gives NaN: the sites that use fdiv / frcp
+// divide by optical depths, 1 - albedo x reflectance and the like.  Same bits otherwise (tests/test_hip_parity.py:
+// ECRAD_FAST_DIV=0 variant).  Every VALU instruction of these kernels costs the same four cycles per wave, FP64 or not, and
+// the shortwave kernels run at ~80 % VALU utilisation (profiles/r03_p_sq.md): instructions are what there is to save.
+#ifndef ECRAD_FAST_DIV
+#define ECRAD_FAST_DIV 1
+#endif
+ECRAD_DEV double frcp(double b) {
+#if ECRAD_FAST_DIV
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  return __builtin_fma(e, r, r);
+#else
+  return 1.0 / b;
+#endif
+}
+ECRAD_DEV double fdiv(double a, double b) {
+#if ECRAD_FAST_DIV
+  double r = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-b, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  const double q = a * r;
+  e = __builtin_fma(-b, q, a);
+  return __builtin_fma(e, r, q);
+#else
+  return a / b;
+#endif
+}
 
 // Sum over the NGP lanes of a column group (NGP = 16, 32 or 64 consecutive lanes).  All lanes get the
 // result.  Butterfly on the VALU's data-parallel primitives -- quad_perm / row mirrors within a row
@@ -112,8 +151,15 @@ template <int CTRL>
 ECRAD_DEV double dpp_move(double v) {
   const unsigned long long u = (unsigned long long)__double_as_longlong(v);
   unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+  // (mov_dpp, not update_dpp(old = src): every lane of these patterns has a source lane, and a tied `old` operand costs a
+  //  register copy per half -- 5 instructions per butterfly step instead of 3)
+#if ECRAD_DPP_TIED      // (the round-1/2 form, kept for A/B timing)
   lo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
   hi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+#else
+  lo = (unsigned)__builtin_amdgcn_mov_dpp((int)lo, CTRL, 0xf, 0xf, true);
+  hi = (unsigned)__builtin_amdgcn_mov_dpp((int)hi, CTRL, 0xf, 0xf, true);
+#endif
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
@@ -158,6 +204,62 @@ ECRAD_DEV double group_sum(double v) {
 #endif
 }
 
+// Sums over the lanes of a column group for FOUR consecutive half levels at a time, through LDS.  The butterfly above costs
+// 17 VALU instructions per sum (two 32-bit moves per step: DPP does not move 64-bit values) and hands the result to every
+// lane, although one lane keeps it; the vertical sweeps have 2-3 such sums per half level next to a handful of FMAs, and
+// every VALU instruction costs the same four cycles.  Here each lane parks its term of quantity q at half level l in
+// row (q, l mod 4) of an LDS array (one ds_write_b64, LDS pipe); after four half levels lane r < 4 NQ of each 16-lane part
+// of the group adds up the 16 terms of row r that its part wrote (8 ds_read_b128 + 16 adds, for FOUR half levels of NQ
+// quantities at once), and the parts are combined across rows of 16 lanes with the swap instructions: ~10 VALU instructions
+// per half level instead of 17 NQ.  The order of the additions differs from the butterfly's (last-bit differences).
+// The LDS is the level-record area of the WAVE's own 64 slots (slot = lane of the block in both phases of the optics pass, so
+// a wave only ever reads records that its own lanes wrote): idle during the sweeps, and no other wave looks at it, so no
+// block barrier is needed although the waves of a block leave the optics pass at different times.  lds_record_doubles()
+// makes the records large enough for 16 rows; rows are padded by 16 bytes so that the 16 rows read together fall in
+// different banks.
+constexpr int kRedStride = 64 + 2;                      // doubles per row (one wave)
+constexpr int kRedRecordDoubles = (16 * kRedStride + 63) / 64;      // per slot, so that 64 slots hold 16 rows
+typedef __attribute__((address_space(3))) double lds_double;
+typedef double dvec2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) dvec2 lds_double2;
+// the calling wave's part of the level-record area (records of `rec_doubles` doubles, slot = lane of the block)
+ECRAD_DEV lds_double* lds_wave_area(void* records, int rec_doubles, int tid) { return (lds_double*)records + (tid >> 6) * 64 * rec_doubles; }
+// (a pointer chosen per lane among kernel arguments loses its address space: say that it is global memory)
+typedef __attribute__((address_space(1))) double gl_double;
+ECRAD_DEV gl_double* to_global(double* p) { return (gl_double*)p; }
+ECRAD_DEV const gl_double* to_global(const double* p) { return (const gl_double*)p; }
+template <int NGP, int NQ, int OFF = 0>
+struct LevelReduce {
+  static_assert(NQ >= 1 && NQ <= 4, "at most 16 rows");
+  lds_double* red;        // lds_wave_area() (address space spelled out: through a generic pointer these would be flat_load / flat_store)
+  int lane, glane;        // lane of the wave, lane of the column group
+  // groups of four: half levels l with the same (l + OFF) >> 2 (OFF lets a sweep that takes its layers in batches finish a
+  // group at the end of a batch)
+  ECRAD_DEV void put(int q, int l, double v) const { red[(q * 4 + ((l + OFF) & 3)) * kRedStride + lane] = v; }
+  ECRAD_DEV bool complete(int l) const { return ((l + OFF) & 3) == 3; }
+  // which (quantity, half level) this lane's sum belongs to, after the values of the group that half level l is in are there
+  ECRAD_DEV int q_of() const { return (glane & 15) >> 2; }
+  ECRAD_DEV int level_of(int l) const { return ((l + OFF) & ~3) - OFF + (glane & 3); }
+  ECRAD_DEV bool owner(int l) const { return glane < 16 && q_of() < NQ && level_of(l) >= 0 && level_of(l) <= l; }
+  ECRAD_DEV double sum() const {
+    wave_sync();
+    const int row = (glane & 15) < 4 * NQ ? (glane & 15) : 0;
+    const lds_double2* src = reinterpret_cast<const lds_double2*>(red + row * kRedStride + (lane - glane) + (glane & ~15));
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      const dvec2 u = src[i], v = src[i + 1];
+      a0 = a0 + u.x; a0 = a0 + u.y;
+      a1 = a1 + v.x; a1 = a1 + v.y;
+    }
+    double acc = a0 + a1;
+    if (NGP >= 32) acc = row_pair_sum(acc);
+    if (NGP >= 64) acc = half_pair_sum(acc);
+    wave_sync();
+    return acc;
+  }
+};
+
 // ---- two-stream layer coefficients ---------------------------------------------------------------
 constexpr double kLwDiffusivity = 1.66;   // radiation_two_stream.F90:38-39
 
@@ -191,11 +293,11 @@ ECRAD_DEV SwCoef ref_trans_sw_fused(double mu0, double od, double ssa, double as
   double k_gamma4 = k_exponent * gamma4;
   double exponential2 = exponential * exponential;
   double k_2_exponential = 2.0 * k_exponent * exponential;
-  double reftrans_factor = 1.0 / (k_exponent + gamma1 + (k_exponent - gamma1) * exponential2);
+  double reftrans_factor = frcp(k_exponent + gamma1 + (k_exponent - gamma1) * exponential2);
   c.ref_diff = gamma2 * (1.0 - exponential2) * reftrans_factor;
   c.trans_diff = dmax(0.0, dmin(k_2_exponential * reftrans_factor, 1.0 - c.ref_diff));
   const double eps = 2.220446049250313e-16;
-  reftrans_factor = mu0 * ssa * reftrans_factor / (fabs(one_minus_kmu0_sqr) > eps ? one_minus_kmu0_sqr : eps);
+  reftrans_factor = fdiv(mu0 * ssa * reftrans_factor, fabs(one_minus_kmu0_sqr) > eps ? one_minus_kmu0_sqr : eps);
   double rd = reftrans_factor * ((1.0 - k_mu0) * (alpha2 + k_gamma3)
                                  - (1.0 + k_mu0) * (alpha2 - k_gamma3) * exponential2
                                  - k_2_exponential * (gamma3 - alpha2 * mu0) * c.trans_dir_dir);
@@ -231,7 +333,7 @@ ECRAD_DEV SwCoef ref_trans_sw_classic(double mu0, double od, double ssa, double 
   const double eps = 2.220446049250313e-16;
   double mu0_local = mu0;
   if (fabs(1.0 - k_exponent * mu0) < 1000.0 * eps) mu0_local = mu0 * (1.0 - 10.0 * eps);
-  double od_over_mu0 = dmax(od / mu0_local, 0.0);
+  double od_over_mu0 = dmax(fdiv(od, mu0_local), 0.0);
   double k_mu0 = k_exponent * mu0_local;
   double k_gamma3 = k_exponent * gamma3;
   double k_gamma4 = k_exponent * gamma4;
@@ -240,10 +342,10 @@ ECRAD_DEV SwCoef ref_trans_sw_classic(double mu0, double od, double ssa, double 
   double exponential = exp(-k_exponent * od);
   double exponential2 = exponential * exponential;
   double k_2_exponential = 2.0 * k_exponent * exponential;
-  double reftrans_factor = 1.0 / (k_exponent + gamma1 + (k_exponent - gamma1) * exponential2);
+  double reftrans_factor = frcp(k_exponent + gamma1 + (k_exponent - gamma1) * exponential2);
   c.ref_diff = gamma2 * (1.0 - exponential2) * reftrans_factor;
   c.trans_diff = k_2_exponential * reftrans_factor;
-  reftrans_factor = mu0_local * ssa * reftrans_factor / (1.0 - k_mu0 * k_mu0);
+  reftrans_factor = fdiv(mu0_local * ssa * reftrans_factor, 1.0 - k_mu0 * k_mu0);
   double rd = reftrans_factor * ((1.0 - k_mu0) * (alpha2 + k_gamma3)
                                  - (1.0 + k_mu0) * (alpha2 - k_gamma3) * exponential2
                                  - k_2_exponential * (gamma3 - alpha2 * mu0_local) * exponential0);
@@ -268,10 +370,10 @@ ECRAD_DEV LwCoef ref_trans_lw(double od, double ssa, double asymmetry, double pl
   if (od > 1.0e-3) {
     double exponential = exp(-k_exponent * od);
     double exponential2 = exponential * exponential;
-    double reftrans_factor = 1.0 / (k_exponent + gamma1 + (k_exponent - gamma1) * exponential2);
+    double reftrans_factor = frcp(k_exponent + gamma1 + (k_exponent - gamma1) * exponential2);
     c.reflectance = gamma2 * (1.0 - exponential2) * reftrans_factor;
     c.transmittance = 2.0 * k_exponent * exponential * reftrans_factor;
-    double coeff = (planck_bot - planck_top) / (od * (gamma1 + gamma2));
+    double coeff = fdiv(planck_bot - planck_top, od * (gamma1 + gamma2));
     double coeff_up_top = coeff + planck_top;
     double coeff_up_bot = coeff + planck_bot;
     double coeff_dn_top = -coeff + planck_top;
@@ -280,7 +382,7 @@ ECRAD_DEV LwCoef ref_trans_lw(double od, double ssa, double asymmetry, double pl
     c.source_dn = coeff_dn_bot - c.reflectance * coeff_up_bot - c.transmittance * coeff_dn_top;
   } else {
     c.reflectance = gamma2 * od;
-    c.transmittance = (1.0 - k_exponent * od) / (1.0 + od * (gamma1 - k_exponent));
+    c.transmittance = fdiv(1.0 - k_exponent * od, 1.0 + od * (gamma1 - k_exponent));
     c.source_up = (1.0 - c.reflectance - c.transmittance) * 0.5 * (planck_top + planck_bot);
     c.source_dn = c.source_up;
   }
@@ -294,7 +396,7 @@ ECRAD_DEV LwCoef no_scattering_lw(double od, double planck_top, double planck_bo
   c.transmittance = exp(-kLwDiffusivity * od);
   double coeff = kLwDiffusivity * od;
   if (od > 1.0e-3) {
-    coeff = (planck_bot - planck_top) / coeff;
+    coeff = fdiv(planck_bot - planck_top, coeff);
     double coeff_up_top = coeff + planck_top;
     double coeff_up_bot = coeff + planck_bot;
     double coeff_dn_top = -coeff + planck_top;
@@ -312,17 +414,17 @@ ECRAD_DEV LwCoef no_scattering_lw(double od, double planck_top, double planck_bo
 ECRAD_DEV void delta_eddington(double& od, double& ssa, double& g) {
   double f = g * g;
   od = od * (1.0 - ssa * f);
-  ssa = ssa * (1.0 - f) / (1.0 - ssa * f);
-  g = g / (1.0 + g);
+  ssa = fdiv(ssa * (1.0 - f), 1.0 - ssa * f);
+  g = fdiv(g, 1.0 + g);
 }
 
 // delta_eddington_extensive (radiation_delta_eddington.h:44-58)
 ECRAD_DEV void delta_eddington_extensive(double& od, double& scat_od, double& scat_od_g) {
-  double g = scat_od > 0.0 ? scat_od_g / scat_od : 0.0;
+  double g = scat_od > 0.0 ? fdiv(scat_od_g, scat_od) : 0.0;
   double f = g * g;
   od = od - scat_od * f;
   scat_od = scat_od * (1.0 - f);
-  scat_od_g = scat_od * g / (1.0 + g);
+  scat_od_g = fdiv(scat_od * g, 1.0 + g);
 }
 
 // ---- level order of the caller's arrays ----------------------------------------------------------------

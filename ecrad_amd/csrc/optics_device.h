@@ -42,7 +42,11 @@ struct LdsLayout {
 };
 
 __host__ __device__ inline int lds_padded_quads(int nquad) { return ECRAD_FIXED_QUADS ? kMaxQuads : ((nquad + 1) & ~1); }
-__host__ __device__ inline int lds_record_doubles(int nquad, int nct) { return (F_QMULT + lds_padded_quads(nquad) + 3 * nct + 1) & ~1; }
+// (at least what LevelReduce -- kernels_common.h -- lays over a wave's 64 records during the vertical sweeps)
+__host__ __device__ inline int lds_record_doubles(int nquad, int nct) {
+  const int rec = (F_QMULT + lds_padded_quads(nquad) + 3 * nct + 1) & ~1;
+  return rec > ((kRedRecordDoubles + 1) & ~1) ? rec : ((kRedRecordDoubles + 1) & ~1);
+}
 
 __host__ __device__ inline size_t lds_bytes(int nquad, int nct) {
   return (size_t)kBlock * lds_record_doubles(nquad, nct) * sizeof(double);
@@ -479,11 +483,11 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, 
 // delta_eddington_extensive_vec (radiation_delta_eddington.h:69-95); 1.0e-24 there is a
 // default-real (single-precision) literal, hence the float constant
 ECRAD_DEV void delta_eddington_extensive_vec(AerosolLayer& a) {
-  const double g = a.scat_g / dmax(a.scat, (double)1.0e-24f);
+  const double g = fdiv(a.scat_g, dmax(a.scat, (double)1.0e-24f));
   const double f = g * g;
   a.od = a.od - a.scat * f;
   a.scat = a.scat * (1.0 - f);
-  a.scat_g = a.scat * g / (1.0 + g);
+  a.scat_g = fdiv(a.scat * g, 1.0 + g);
 }
 
 // Merge aerosol into the gas SW properties: radiation_aerosol_optics.F90:739-770
@@ -491,14 +495,14 @@ ECRAD_DEV void merge_aerosol_sw(const DevConfig& cfg, const AerosolLayer& a, dou
   if (cfg.do_cloud_aerosol_per_sw_g_point) {
     const double local_scat = ssa * od + a.scat;
     od = od + a.od;
-    g = a.scat_g / dmax(local_scat, 1.0e-24);
-    ssa = dmin(local_scat / dmax(od, 1.0e-24), 1.0);
+    g = fdiv(a.scat_g, dmax(local_scat, 1.0e-24));
+    ssa = dmin(fdiv(local_scat, dmax(od, 1.0e-24)), 1.0);
   } else {
     const double local_od = od + a.od;
     if (local_od > 0.0 && a.od > 0.0) {
       const double local_scat = ssa * od + a.scat;
-      if (local_scat > 0.0) g = a.scat_g / local_scat;
-      ssa = local_scat / local_od;
+      if (local_scat > 0.0) g = fdiv(a.scat_g, local_scat);
+      ssa = fdiv(local_scat, local_od);
       od = local_od;
     }
   }
@@ -543,12 +547,12 @@ ECRAD_DEV CloudLayer cloud_layer_fit(const DevConfig& cfg, const LdsLayout& L, i
     } else {
       // MinEffectiveRadius / MaxEffectiveRadius are default-real literals in the reference
       const double re = dmax((double)1.2e-6f, dmin(L.D(L.f_rew(0), slot), (double)50.0e-6f));
-      od_l = lwp * (KL(1) + re * (KL(2) + re * KL(3))) / (1.0 + re * (KL(4) + re * (KL(5) + re * KL(6))));
-      sc_l = od_l * (1.0 - (KL(7) + re * (KL(8) + re * KL(9))) / (1.0 + re * (KL(10) + re * KL(11))));
-      g_l = (KL(12) + re * (KL(13) + re * KL(14))) / (1.0 + re * (KL(15) + re * KL(16)));
+      od_l = fdiv(lwp * (KL(1) + re * (KL(2) + re * KL(3))), 1.0 + re * (KL(4) + re * (KL(5) + re * KL(6))));
+      sc_l = od_l * (1.0 - fdiv(KL(7) + re * (KL(8) + re * KL(9)), 1.0 + re * (KL(10) + re * KL(11))));
+      g_l = fdiv(KL(12) + re * (KL(13) + re * KL(14)), 1.0 + re * (KL(15) + re * KL(16)));
     }
 #undef KL
-    if (IS_SW && !cfg.do_sw_delta_scaling_with_gases) { const double f = g_l * g_l; od_l = od_l - sc_l * f; sc_l = sc_l * (1.0 - f); g_l = g_l / (1.0 + g_l); }
+    if (IS_SW && !cfg.do_sw_delta_scaling_with_gases) { const double f = g_l * g_l; od_l = od_l - sc_l * f; sc_l = sc_l * (1.0 - f); g_l = fdiv(g_l, 1.0 + g_l); }
   }
   if (iwp > 0.0) {
     const double* __restrict__ k = ice.mass_ext + ib;
@@ -603,12 +607,12 @@ ECRAD_DEV CloudLayer cloud_layer_fit(const DevConfig& cfg, const LdsLayout& L, i
       }
     }
 #undef KI
-    if (!IS_SW || !cfg.do_sw_delta_scaling_with_gases) { const double f = g_i * g_i; od_i = od_i - sc_i * f; sc_i = sc_i * (1.0 - f); g_i = g_i / (1.0 + g_i); }
+    if (!IS_SW || !cfg.do_sw_delta_scaling_with_gases) { const double f = g_i * g_i; od_i = od_i - sc_i * f; sc_i = sc_i * (1.0 - f); g_i = fdiv(g_i, 1.0 + g_i); }
   }
   if (IS_SW || cfg.do_lw_cloud_scattering) {
     c.od = od_l + od_i;
-    if (IS_SW || sc_l + sc_i > 0.0) c.g = (g_l * sc_l + g_i * sc_i) / (sc_l + sc_i);
-    c.ssa = (sc_l + sc_i) / (od_l + od_i);
+    if (IS_SW || sc_l + sc_i > 0.0) c.g = fdiv(g_l * sc_l + g_i * sc_i, sc_l + sc_i);
+    c.ssa = fdiv(sc_l + sc_i, od_l + od_i);
   } else {
     c.od = od_l - sc_l + od_i - sc_i;
   }
