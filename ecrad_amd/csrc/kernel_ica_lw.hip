@@ -300,6 +300,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
     }
 
     // ---- pass B1: clear-sky upward sweep (+ clear-sky derivatives) --------------------------------
+    quads.reset();      // (the table values die here: the sweeps have the registers for their batches of records)
     const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
     double fup = emission + albedo * fdn_c;
     const double fup_surf_clear = fup;

@@ -23,6 +23,9 @@
 #ifndef ECRAD_TC_BATCH_S
 #define ECRAD_TC_BATCH_S 2      // shortwave flux sweep
 #endif
+#ifndef ECRAD_TC_LW_AER_BATCH
+#define ECRAD_TC_LW_AER_BATCH 12      // aerosol types per batch of table loads in the longwave optics pass
+#endif
 #ifndef ECRAD_TC_MIN_WAVES
 #define ECRAD_TC_MIN_WAVES ECRAD_MIN_WAVES
 #endif
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
               od = local_od;
             }
           } else {
-            od = od + aerosol_layer<false, NGP, 12>(b.cfg, b.in, L, slot, col, lev, ib, aer_type).od;
+            od = od + aerosol_layer<false, NGP, ECRAD_TC_LW_AER_BATCH>(b.cfg, b.in, L, slot, col, lev, ib, aer_type).od;
           }
         }
         const LwCoef c = ASCAT ? ref_trans_lw(od, ssa, asym, planck_top, planck_bot) : no_scattering_lw(od, planck_top, planck_bot);

@@ -391,13 +391,28 @@ ECRAD_DEV double incoming_sw_g(const DevCkdModel& m, const DevInputs& in, int g)
 struct AerosolLayer { double od, scat, scat_g; };
 
 // Index into aerosol%mixing_ratio of the active type this lane fetches for its column group (lane k of
-// the group fetches active type k, see aerosol_layer); -1 for the other lanes.  Once per column group.
+// every 16-lane row of the group fetches active type k, see aerosol_layer); -1 for the other lanes.  Once per column group.
 ECRAD_DEV int aerosol_lane_type(const DevConfig& cfg, int glane) {
   int t = -1;
 #pragma unroll
   for (int k = 0; k < kMaxActiveAerosols; ++k)
-    if (k < cfg.aerosol.nactive && k == glane) t = (int)(cfg.aerosol.active[k] & 0xffu);
+    if (k < cfg.aerosol.nactive && k == (glane & 15)) t = (int)(cfg.aerosol.active[k] & 0xffu);
   return t;
+}
+
+// lane K of the caller's row of 16 lanes: ONE VALU instruction for a 64-bit value (v_mov_b64_dpp row_newbcast)
+template <int K>
+ECRAD_DEV double row_bcast(double v) {
+  return __longlong_as_double(__builtin_amdgcn_mov_dpp(__double_as_longlong(v), 0x150 + K, 0xf, 0xf, true));
+}
+// (k is a constant once the caller's loop is unrolled: the switch folds to one instruction)
+ECRAD_DEV double row_bcast_k(double v, int k) {
+  switch (k & 15) {
+    case 0: return row_bcast<0>(v);   case 1: return row_bcast<1>(v);   case 2: return row_bcast<2>(v);   case 3: return row_bcast<3>(v);
+    case 4: return row_bcast<4>(v);   case 5: return row_bcast<5>(v);   case 6: return row_bcast<6>(v);   case 7: return row_bcast<7>(v);
+    case 8: return row_bcast<8>(v);   case 9: return row_bcast<9>(v);   case 10: return row_bcast<10>(v); case 11: return row_bcast<11>(v);
+    case 12: return row_bcast<12>(v); case 13: return row_bcast<13>(v); case 14: return row_bcast<14>(v); default: return row_bcast<15>(v);
+  }
 }
 
 // KB_LW: types per batch of table loads on the absorption-only longwave path (what is best depends on
@@ -419,28 +434,36 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, 
   const double* __restrict__ mr0 = in.aerosol_mixing_ratio + col + ncol * (size_t)(jlev - in.aerosol_istartlev);
   const int n = ao.nactive;
   const bool scattering = IS_SW || cfg.do_lw_aerosol_scattering;
-  // The mixing ratios are per column: lane k of the column group fetches type k (ONE load instruction
-  // for all types) and the type loop broadcasts them over the group through the LDS crossbar.
-  const double mr_mine = lane_type >= 0 ? mr0[type_stride * (size_t)lane_type] : 0.0;
+  // The mixing ratios are per column: lane k of every 16-lane row of the column group fetches type k (ONE load
+  // instruction for all types), multiplies it by the layer mass, and the unrolled type loop broadcasts the product over
+  // the row with one DPP move per type (row_newbcast: the only DPP pattern that moves 64 bits at a time).
+  const double w_mine = factor * (lane_type >= 0 ? mr0[type_stride * (size_t)lane_type] : 0.0);
   if (!scattering) {
     // longwave absorption only (:655-662): one table value per type
     const double* __restrict__ tab = ao.lw_abs;
     constexpr int kBatch = KB_LW;
-    for (int k0 = 0; k0 < n; k0 += kBatch) {
-      double t[kBatch];
 #pragma unroll
-      for (int u = 0; u < kBatch; ++u) {
-        t[u] = 0.0;
-        const int k = k0 + u;
-        if (k < n) {
-          const uint32_t desc = ao.active[k];
-          const int row = (int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0);
-          t[u] = tab[ib + (size_t)nb * row];
+    for (int k0 = 0; k0 < kMaxActiveAerosols; k0 += kBatch) {
+      if (k0 < n) {
+        double t[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          t[u] = 0.0;
+          const int k = k0 + u;
+          if (k < kMaxActiveAerosols && k < n) {
+            const uint32_t desc = ao.active[k];
+            const int row = (int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0);
+#if ECRAD_ABLATE & 16
+            t[u] = 1e-3 * (row & 7);
+#else
+            t[u] = tab[ib + (size_t)nb * row];
+#endif
+          }
         }
-      }
 #pragma unroll
-      for (int u = 0; u < kBatch; ++u)
-        if (k0 + u < n) a.od = a.od + factor * __shfl(mr_mine, k0 + u, NGP) * t[u];
+        for (int u = 0; u < kBatch; ++u)
+          if (k0 + u < kMaxActiveAerosols && k0 + u < n) a.od = a.od + row_bcast_k(w_mine, k0 + u) * t[u];
+      }
     }
     return a;
   }
@@ -452,28 +475,35 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, 
 #define ECRAD_AEROSOL_BATCH 4
 #endif
   constexpr int kBatch = ECRAD_AEROSOL_BATCH;
-  for (int k0 = 0; k0 < n; k0 += kBatch) {
-    double2 t01[kBatch];
-    double t2[kBatch];
 #pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-      t01[u] = make_double2(0.0, 0.0); t2[u] = 0.0;
-      const int k = k0 + u;
-      if (k < n) {
-        const uint32_t desc = ao.active[k];
-        const int row = (int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0);
-        const size_t o = ib + (size_t)nb * row;
-        t01[u] = tab01[o];                       // mass_ext, ssa
-        t2[u] = tab2[o];                         // asymmetry
+  for (int k0 = 0; k0 < kMaxActiveAerosols; k0 += kBatch) {
+    if (k0 < n) {
+      double2 t01[kBatch];
+      double t2[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) {
+        t01[u] = make_double2(0.0, 0.0); t2[u] = 0.0;
+        const int k = k0 + u;
+        if (k < kMaxActiveAerosols && k < n) {
+          const uint32_t desc = ao.active[k];
+          const int row = (int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0);
+          const size_t o = ib + (size_t)nb * row;
+#if ECRAD_ABLATE & 16
+          t01[u] = make_double2(1e-3 * (row & 7), 0.5); t2[u] = 0.5;
+#else
+          t01[u] = tab01[o];                       // mass_ext, ssa
+          t2[u] = tab2[o];                         // asymmetry
+#endif
+        }
       }
-    }
 #pragma unroll
-    for (int u = 0; u < kBatch; ++u) {
-      if (k0 + u < n) {
-        const double local_od = factor * __shfl(mr_mine, k0 + u, NGP) * t01[u].x;
-        a.od = a.od + local_od;
-        a.scat = a.scat + local_od * t01[u].y;
-        a.scat_g = a.scat_g + local_od * t01[u].y * t2[u];
+      for (int u = 0; u < kBatch; ++u) {
+        if (k0 + u < kMaxActiveAerosols && k0 + u < n) {
+          const double local_od = row_bcast_k(w_mine, k0 + u) * t01[u].x;
+          a.od = a.od + local_od;
+          a.scat = a.scat + local_od * t01[u].y;
+          a.scat_g = a.scat_g + local_od * t01[u].y * t2[u];
+        }
       }
     }
   }

@@ -1,11 +1,21 @@
 #!/bin/bash
-mkdir -p gpurun_out/r03_u
-O=gpurun_out/r03_u
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 > $O/gpu_tests.txt; cat $O/gpu_tests.txt
-python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.err
-python - <<'PY'
-import json
-d=json.loads([l for l in open('gpurun_out/r03_u/bench.json') if l.startswith('{')][0])
-print('headline', d['value'], d['ms_per_step'], d.get('parity',{}).get('max_rel_diff_vs_oracle'), d['roofline']['frac'])
-for k,v in d.get('workloads',{}).items(): print(k, v.get('value'), v.get('ms_per_step'), v.get('parity',{}).get('max_rel_diff_vs_oracle'), v.get('parity',{}).get('ok'))
+mkdir -p gpurun_out/r03_za
+O=gpurun_out/r03_za
+run() {
+  local out=$O/$1_$3.json
+  ECRAD_HIP_LIB=$2 python bench.py --steps 5 --warmup 2 --workload $3 --headline-only --no-cpu-baseline $4 > $out 2> $O/$1_$3.err
+  python - "$out" "$1" "$3" <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][0])
+    st = d["roofline"]["stage_ms"]
+    print("%-10s %-28s %10.0f col/s  %8.2f ms  lw %7.2f sw %7.2f prep %6.2f" % (sys.argv[2], sys.argv[3], d["value"] or 0, d["ms_per_step"], st["lw"], st["sw"], st["prep"]))
+except Exception as e:
+    print(sys.argv[2], sys.argv[3], "failed", e)
 PY
+}
+BASE=$PWD/ecrad_amd/csrc/libecrad_hip.so
+for v in shipped qc0 shipped; do
+  L=$PWD/build_variants/$v/libecrad_hip.so; [ $v = shipped ] && L=$BASE
+  for w in clear_homogeneous_ecckd32 mcica_ecckd32 tripleclouds_ecckd32; do run $v $L $w; done
+done
