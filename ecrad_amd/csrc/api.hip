@@ -1095,7 +1095,8 @@ size_t work_bytes_per_column(ecrad_hip_handle_t h, int nlev, const ecrad_inputs_
   const bool sw_mcica = c.do_sw && c.i_solver_sw == ECRAD_SOLVER_MCICA, lw_mcica = c.do_lw && c.i_solver_lw == ECRAD_SOLVER_MCICA;
   const bool tc = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_TRIPLECLOUDS) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_TRIPLECLOUDS);
   const bool sw_sp = c.do_sw && c.i_solver_sw == ECRAD_SOLVER_SPARTACUS, lw_sp = c.do_lw && c.i_solver_lw == ECRAD_SOLVER_SPARTACUS;
-  if (tc || sw_sp || lw_sp) b += 8 * (5 * L + 18 * (L + 1));
+  if (sw_sp || lw_sp) b += 8 * (5 * L + 18 * (L + 1));
+  if (tc) b += 8 * (size_t)kGeomItems * (L + 1);
   {   // stage arrays of the SPARTACUS solvers (one buffer, reused by the two spectra)
     const size_t w = c.i_precision == ECRAD_PRECISION_SINGLE ? 4 : 8;
     const size_t bsw = sw_sp ? w * ((size_t)c.n_g_sw * (3 * L + 3) + (size_t)c.n_bands_sw * 3 * L) + w * L * spartacus_layer_words(true, std::min(c.n_g_sw, h->ngp_sw)) : 0;
@@ -1257,12 +1258,13 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     const size_t n = r.nloc, L = nlev;
     for (int pass = 0; pass < 2; ++pass) {
       Carver cv(pass == 0 ? nullptr : h->prep.p);
-      if (sw_tc || lw_tc || sw_sp || lw_sp) {
+      if (sw_sp || lw_sp) {
         prep.region_fracs = cv.take<double>(3 * L * n);
         prep.od_scaling_reg = cv.take<double>(2 * L * n);
         prep.v_matrix = cv.take<double>(9 * (L + 1) * n);
         prep.u_matrix = cv.take<double>(9 * (L + 1) * n);
       }
+      if (sw_tc || lw_tc) prep.geom = cv.take<double>((size_t)kGeomItems * (L + 1) * n);      // (the Tripleclouds kernels' form)
       if (sw_mcica) { prep.od_scaling_sw = cv.take<double>((size_t)c.n_g_sw * L * n); prep.total_cloud_cover_sw = cv.take<double>(n); }
       if (lw_mcica) { prep.od_scaling_lw = cv.take<double>((size_t)c.n_g_lw * L * n); prep.total_cloud_cover_lw = cv.take<double>(n); }
       if (c.do_clouds) cx.din.cloud_fraction_work = cv.take<double>(L * n);
@@ -1589,7 +1591,10 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
     const int i0 = istartcol + (int)(t * tile_cols);
     const int i1 = std::min<long long>(iendcol, i0 + tile_cols - 1);
     const int st = radiation_tile(h, ncol, nlev, i0, i1, in, flux, t);
-    if (st) return st;
+    if (st) {      // an error between a fork and its join leaves work on the second stream: wait for it before the caller sees the error
+      if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
+      return st;
+    }
     h->tiles_last_call = t + 1;
   }
   h->tile_columns_last_call = (int)tile_cols;

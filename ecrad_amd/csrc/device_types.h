@@ -192,12 +192,18 @@ struct DevOptics {
 
 // Per-call cloud geometry produced by the "prep" kernels (lane = column) and consumed by the
 // spectral kernels (lane = g-point).
+constexpr int kGeomItems = 24;
 struct DevCloudPrep {
   // Tripleclouds: (ncol_local, nlev[+1], k) with the LOCAL column fastest
   double* region_fracs;    // [3][nlev][nloc]
   double* od_scaling_reg;  // [2][nlev][nloc]      regions 2,3
   double* v_matrix;        // [9][nlev+1][nloc]    element (i + 3*j)
   double* u_matrix;        // [9][nlev+1][nloc]
+  // The same for the Tripleclouds kernels, one record of kGeomItems doubles per (level, local column): [nlev+1][nloc][24] --
+  // items 0-2 region fractions of layer l, 3-11 v_matrix and 12-20 u_matrix of half level l (element i + 3 j), 21-22
+  // od_scaling of regions 2, 3 of layer l, 23 unused.  What a column group needs for one level is 192 contiguous bytes
+  // instead of 23 doubles in 23 cache lines (the prep kernel writes whichever of the two forms has its pointers set).
+  double* geom;
   // McICA: per-g optical-depth scalings, (ng, nlev, nloc) with g fastest; float is NOT used: the
   // values feed 1e-6-level parity
   double* od_scaling_sw;

@@ -135,13 +135,20 @@ __global__ void tripleclouds_prep_kernel(const DevConfig* __restrict__ cfgp, Dev
                                         double* cloud_cover_sw, double* cloud_cover_lw) {
   const DevConfig& cfg = *cfgp;
   const int nloc = in.iendcol - in.istartcol + 1;
-  const int cloc = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cloc >= nloc) return;
+  // (one wave per block; a lane past the last column works on the last column and stores nothing of its own: the records of
+  //  the Tripleclouds kernels leave through LDS, all lanes of the wave together)
+  const int cloc_raw = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = cloc_raw < nloc;
+  const int cloc = active ? cloc_raw : nloc - 1;
   const int col = in.istartcol - 1 + cloc;
   const size_t ncol = in.ncol;
   const int nlev = in.nlev;
   const double thr = cfg.cloud_fraction_threshold;
   const bool do_gamma = cfg.i_cloud_pdf_shape == ECRAD_PDF_GAMMA;
+  constexpr int kTileStride = kGeomItems + 1;      // (odd number of doubles per lane: two lanes per LDS bank at most)
+  __shared__ double tile[64 * kTileStride];
+  double* const mine = tile + threadIdx.x * kTileStride;
+  mine[kGeomItems - 1] = 0.0;      // (item 23 is unused)
   // calc_region_properties constants, radiation_regions.F90:43-61
   const double MinGammaODScaling = 0.025, MinLowerFrac = 0.5, MaxLowerFrac = 0.9;
   const double FSDAtMinLowerFrac = 1.5, FSDAtMaxLowerFrac = 3.725;
@@ -170,9 +177,15 @@ __global__ void tripleclouds_prep_kernel(const DevConfig* __restrict__ cfgp, Dev
         os3 = (cf - fl[1] * os2) / fl[2];
       }
       const size_t ol = (size_t)(jlev - 1) * nloc + cloc;
-      for (int r = 0; r < 3; ++r) prep.region_fracs[(size_t)r * nlev * nloc + ol] = fl[r];
-      prep.od_scaling_reg[ol] = os2;
-      prep.od_scaling_reg[(size_t)nlev * nloc + ol] = os3;
+      if (prep.region_fracs && active) {
+        for (int r = 0; r < 3; ++r) prep.region_fracs[(size_t)r * nlev * nloc + ol] = fl[r];
+        prep.od_scaling_reg[ol] = os2;
+        prep.od_scaling_reg[(size_t)nlev * nloc + ol] = os3;
+      }
+      if (prep.geom) {
+        for (int r = 0; r < 3; ++r) mine[r] = fl[r];
+        mine[21] = os2; mine[22] = os3;
+      }
     }
     if (jlev == 1 || jlev > nlev) { op[0] = op[1] = op[2] = 1.0; }
     else {
@@ -188,14 +201,33 @@ __global__ void tripleclouds_prep_kernel(const DevConfig* __restrict__ cfgp, Dev
       for (int jl = 0; jl < 3; ++jl) {
         const double u = (fl[jl] >= thr) ? M[ju + 3 * jl] / fl[jl] : 0.0;
         const double v = (fu[ju] >= thr) ? M[ju + 3 * jl] / fu[ju] : 0.0;
-        prep.u_matrix[(size_t)(ju + 3 * jl) * stride + oh] = u;
-        prep.v_matrix[(size_t)(jl + 3 * ju) * stride + oh] = v;
+        if (prep.u_matrix && active) {
+          prep.u_matrix[(size_t)(ju + 3 * jl) * stride + oh] = u;
+          prep.v_matrix[(size_t)(jl + 3 * ju) * stride + oh] = v;
+        }
+        if (prep.geom) {
+          mine[12 + (ju + 3 * jl)] = u;
+          mine[3 + (jl + 3 * ju)] = v;
+        }
         if (ju == 0 && jl == 0) prod *= v;
       }
     fu[0] = fl[0]; fu[1] = fl[1]; fu[2] = fl[2];
+    if (prep.geom) {
+      // the 64 records of this level are contiguous in prep.geom: written 64 doubles per instruction
+      wave_sync();
+      const int c0 = blockIdx.x * blockDim.x;
+      const int nrec = (nloc - c0) < 64 ? (nloc - c0) : 64;
+      double* const dst = prep.geom + ((size_t)(jlev - 1) * nloc + c0) * kGeomItems;
+#pragma unroll 4
+      for (int t = 0; t < kGeomItems; ++t) {
+        const int idx = t * 64 + (int)threadIdx.x, c = idx / kGeomItems, i = idx - c * kGeomItems;
+        if (c < nrec) dst[idx] = tile[c * kTileStride + i];
+      }
+      wave_sync();
+    }
   }
-  if (cloud_cover_sw) cloud_cover_sw[col] = 1.0 - prod;
-  if (cloud_cover_lw) cloud_cover_lw[col] = 1.0 - prod;
+  if (cloud_cover_sw && active) cloud_cover_sw[col] = 1.0 - prod;
+  if (cloud_cover_lw && active) cloud_cover_lw[col] = 1.0 - prod;
 }
 
 hipError_t launch_tripleclouds_prep(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevCloudPrep& prep,

@@ -36,10 +36,11 @@ namespace ecrad {
 struct TcGeom {
   const DevCloudPrep& p;
   int nloc, nlev, cloc;
-  ECRAD_DEV double frac(int r, int lev) const { return p.region_fracs[((size_t)r * nlev + lev) * nloc + cloc]; }
-  ECRAD_DEV double odsc(int r /*1,2*/, int lev) const { return p.od_scaling_reg[((size_t)(r - 1) * nlev + lev) * nloc + cloc]; }
-  ECRAD_DEV double v(int i, int j, int hl) const { return p.v_matrix[((size_t)(i + 3 * j) * (nlev + 1) + hl) * nloc + cloc]; }
-  ECRAD_DEV double u(int i, int j, int hl) const { return p.u_matrix[((size_t)(i + 3 * j) * (nlev + 1) + hl) * nloc + cloc]; }
+  ECRAD_DEV const double* rec(int lev) const { return p.geom + ((size_t)lev * nloc + cloc) * kGeomItems; }
+  ECRAD_DEV double frac(int r, int lev) const { return rec(lev)[r]; }
+  ECRAD_DEV double odsc(int r /*1,2*/, int lev) const { return rec(lev)[20 + r]; }
+  ECRAD_DEV double v(int i, int j, int hl) const { return rec(hl)[3 + i + 3 * j]; }
+  ECRAD_DEV double u(int i, int j, int hl) const { return rec(hl)[12 + i + 3 * j]; }
 };
 
 // Per-column geometry of one level for the sweeps (3 region fractions, v_matrix, u_matrix, 2 optical-depth
@@ -58,15 +59,14 @@ struct GeoFeed {
   double* stage;
   int glane;
   ECRAD_DEV void init(const DevCloudPrep& p, int nloc, int nlev, int cloc, double* lds_stage, int lane_in_group) {
-    stride = nloc; stage = lds_stage; glane = lane_in_group;
+    stride = (size_t)nloc * kGeomItems; stage = lds_stage; glane = lane_in_group;
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int q = glane + u * NGP;
-      if (q < 3) { src[u] = p.region_fracs + (size_t)q * nlev * nloc + cloc; maxlev[u] = nlev - 1; }
-      else if (q < 12) { src[u] = p.v_matrix + (size_t)(q - 3) * (nlev + 1) * nloc + cloc; maxlev[u] = nlev; }
-      else if (q < 21) { src[u] = p.u_matrix + (size_t)(q - 12) * (nlev + 1) * nloc + cloc; maxlev[u] = nlev; }
-      else if (q < NI) { src[u] = p.od_scaling_reg + (size_t)(q - 21) * nlev * nloc + cloc; maxlev[u] = nlev - 1; }
-      else { src[u] = p.region_fracs + cloc; maxlev[u] = 0; }
+      // (items of a layer -- fractions, scalings -- exist for levels 0 .. nlev-1, the matrices for half levels 0 .. nlev)
+      src[u] = p.geom + (size_t)cloc * kGeomItems + (q < NI ? q : 0);
+      maxlev[u] = (q >= 3 && q < 21) ? nlev : nlev - 1;
+      if (q >= NI) maxlev[u] = 0;
     }
   }
   // Make the items of levels lev0, lev0+step, ..., lev0+(K-1)*step available as batch entries 0..K-1
