@@ -18,7 +18,7 @@
 #define ECRAD_TC_BATCH_C 2
 #endif
 #ifndef ECRAD_TC_BATCH_D
-#define ECRAD_TC_BATCH_D 4
+#define ECRAD_TC_BATCH_D 8      // (the derivative pass has no recurrence: 4 -> 8 layers per batch, Tripleclouds on RRTMG longwave 75.1 -> 73.7 ms)
 #endif
 #ifndef ECRAD_TC_BATCH_S
 #define ECRAD_TC_BATCH_S 2      // shortwave flux sweep
@@ -548,7 +548,12 @@ hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream
 //                       (radiation_tripleclouds_lw.F90:392-445) and, per region, the record of sweep C;
 //                       above cloud top the all-sky upward flux (:447-470)
 //   C  cloud top -> surface  fluxes in the three regions (:472-540)
-//   D  surface -> top   lw_derivatives (calc_lw_derivatives_region)
+//   D  any order        lw_derivatives (calc_lw_derivatives_region): the reference's upward recurrence
+//                       dv <- T o (U dv) starts from (flux_up_surf / sum, 0, 0), i.e. it is a per-g-point SCALAR
+//                       (known after sweep C) times a vector recurrence that only needs transmittances and overlap
+//                       matrices.  Sweep B -- upward as well, with both in hand -- runs that recurrence from (1, 0, 0)
+//                       and leaves W = the sum over the regions per layer (8 bytes); D multiplies by the scalar and
+//                       sums over g: no recurrence, no matrices, a third of the bytes
 // Per layer, 24 planes of 256 doubles:
 //   sweep A writes   pair (T1, SU1), single SD1, regions 2-3: pair (R, T), pair (SU, SD)
 //   sweep B writes   per region: pair (a1, c), pair (ts, ta) so that sweep C is
@@ -568,13 +573,15 @@ ECRAD_DEV constexpr int TL_RT(int r /*1,2*/) { return 4 + 4 * (r - 1); }     // 
 ECRAD_DEV constexpr int TL_SS(int r /*1,2*/) { return 6 + 4 * (r - 1); }     // (SU, SD)
 ECRAD_DEV constexpr int TL_D(int r /*0..2*/) { return 12 + 4 * r; }          // (a1, c)
 ECRAD_DEV constexpr int TL_DT(int r /*0..2*/) { return 14 + 4 * r; }         // (ts, ta)
-constexpr int LW_TC_PLANES = 24;
+// plane 24 (28 with aerosol scattering): W, the sum over the regions of the derivative weights of sweep B (below)
+constexpr int LW_TC_PLANES = 25;
 // With longwave aerosol scattering (ASCAT) the clear region reflects too: plane 3 holds its reflectance
 // (pair (SD1, R1) in planes 2-3), cloud top is the top of the atmosphere (radiation_tripleclouds_lw.F90:
 // 225-229) and the clear-sky fluxes need the adding method, i.e. their own downward sweep with records
 // pair (a1, c), pair (albedo, source) in planes 24-27
 constexpr int TL_DC = 24, TL_DCT = 26;
-constexpr int LW_TC_PLANES_ASCAT = 28;
+constexpr int LW_TC_PLANES_ASCAT = 29;
+ECRAD_DEV constexpr int TL_W(bool ascat) { return ascat ? 28 : 24; }
 
 // WIDE: see kernel_ica_lw.hip
 template <typename TAB, int NGP, bool ASCAT, bool WIDE>
@@ -772,6 +779,12 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
       for (int r = 0; r < 3; ++r) { ts[r] = feed.frac(0, r) * emission; ta[r] = albedo; }
       double fup_c = emission + albedo * fdn_c;
       double alb_c = albedo, src_c = emission;      // ASCAT: clear-sky adding method (adding_ica_lw)
+      // derivative weights (radiation_lw_derivatives.F90:200-255 from (1, 0, 0)): yv = u_matrix x weights at the half level below
+      double yv[3] = {0.0, 0.0, 0.0};
+      if (do_deriv) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) yv[r] = geo.u(r, 0, nlev);
+      }
       {
         if (!ASCAT) {
           const double su = group_sum<NGP>(valid ? fup_c : 0.0);
@@ -856,6 +869,18 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
                 }
               }
               const bool cl_above = l > 0 && cloudy.test(l - 1);
+              if (do_deriv) {
+                const double w0 = yv[0] * T1;
+                const double w1 = cl_here ? yv[1] * rt[k][0].y : yv[1];
+                const double w2 = cl_here ? yv[2] * rt[k][1].y : yv[2];
+                s.single(TL_W(ASCAT), l, tid) = w0 + w1 + w2;
+                if (!cl_here && !cl_above) {      // one region on both sides of the half level: the matrix is the identity there
+                  yv[0] = w0; yv[1] = 0.0; yv[2] = 0.0;
+                } else {
+#pragma unroll
+                  for (int r = 0; r < 3; ++r) yv[r] = feed.u(k, r, 0) * w0 + feed.u(k, r, 1) * w1 + feed.u(k, r, 2) * w2;
+                }
+              }
               if (!cl_here && !cl_above) {
 #pragma unroll
                 for (int r = 0; r < 3; ++r) { ta[r] = below[r]; ts[r] = sbelow[r]; }
@@ -874,6 +899,10 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
               if (l == ict) fup0 = ts[0] + ta[0] * fdn_ctop;      // flux at cloud top (:447-455)
             } else {
               fup0 = T1 * fup0 + SU1;
+              if (do_deriv) {      // above cloud top: the clear region alone
+                yv[0] = yv[0] * T1;
+                s.single(TL_W(ASCAT), l, tid) = yv[0];
+              }
             }
             if (valid) {
               if (do_clear && !ASCAT) spec_put(fx.lw_up_clear_band, ng, g, col + ncol * ord.half(l), fup_c);
@@ -1008,40 +1037,27 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
     if (ict == nlev) fup[0] = fup0;
     if (valid) fx.lw_dn_surf_g[g + (size_t)ng * col] = ict < nlev ? fdn[0] + fdn[1] + fdn[2] : fdn_c;
 
-    // ---- sweep D: derivatives (calc_lw_derivatives_region, radiation_lw_derivatives.F90:200-255) --
+    // ---- D: derivatives = W of sweep B x the surface upward flux of this g-point, normalised ------------------------
     if (do_deriv) {
       constexpr int K = ECRAD_TC_BATCH_D;
       const double fs = fup[0] + fup[1] + fup[2];
       const double tot = group_sum<NGP>(valid ? fs : 0.0);
-      double dv[3] = {WIDE ? fs : fs / tot, 0.0, 0.0};
+      const double scale = valid ? (WIDE ? fs : fs / tot) : 0.0;
       if (lead) fx.lw_derivatives[col + ncol * ord.half(nlev)] = WIDE ? tot : 1.0;
       double keep_der = 0.0;
       for (int l0 = nlev - 1; l0 >= 0; l0 -= K) {
-        double t1[K], t2[K], t3[K];
+        double w[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           const int l = l0 - k;
-          t1[k] = t2[k] = t3[k] = 1.0;
-          if (l >= 0) {
-            t1[k] = s.pair(TL_A0, l, tid).operator double2().x;
-            if (cloudy.test(l)) {
-              t2[k] = s.pair(TL_RT(1), l, tid).operator double2().y;
-              t3[k] = s.pair(TL_RT(2), l, tid).operator double2().y;
-            }
-          }
+          w[k] = 0.0;
+          if (l >= 0) w[k] = s.single(TL_W(ASCAT), l, tid);
         }
-        feed.template fetch<K>(l0 + 1, -1);     // u_matrix of the half level below each layer
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           const int l = l0 - k;
           if (l >= 0) {
-            double n[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) n[r] = feed.u(k, r, 0) * dv[0] + feed.u(k, r, 1) * dv[1] + feed.u(k, r, 2) * dv[2];
-            dv[0] = n[0] * t1[k];
-            dv[1] = n[1] * t2[k];
-            dv[2] = n[2] * t3[k];
-            const double sder = group_sum<NGP>(valid ? dv[0] + dv[1] + dv[2] : 0.0);
+            const double sder = group_sum<NGP>(w[k] * scale);
             if ((l & (NGP - 1)) == glane) keep_der = sder;
             if ((l & (NGP - 1)) == 0) {
               const int lv = l + glane;

@@ -1,6 +1,6 @@
 #!/bin/bash
-mkdir -p gpurun_out/r03_zc
-O=gpurun_out/r03_zc
+mkdir -p gpurun_out/r03_zd
+O=gpurun_out/r03_zd
 run() {
   local out=$O/$1_$3.json
   ECRAD_HIP_LIB=$2 python bench.py --steps 5 --warmup 2 --workload $3 --headline-only --no-cpu-baseline $4 > $out 2> $O/$1_$3.err
@@ -15,5 +15,8 @@ except Exception as e:
 PY
 }
 BASE=$PWD/ecrad_amd/csrc/libecrad_hip.so
-timeout 900 python -m pytest tests/test_hip_parity.py tests/test_synthetic_workload.py tests/test_hip_tiling.py -x -q -m gpu 2>&1 | tail -3
-for w in tripleclouds_ecckd32 tripleclouds_rrtmg tripleclouds_ecckd32; do run shipped $BASE $w; done
+timeout 900 python -m pytest tests/test_hip_parity.py tests/test_synthetic_workload.py tests/test_hip_tiling.py tests/test_reference_suites.py -x -q -m gpu 2>&1 | tail -3
+for v in shipped tcd8 shipped; do
+  L=$PWD/build_variants/$v/libecrad_hip.so; [ $v = shipped ] && L=$BASE
+  for w in tripleclouds_ecckd32 tripleclouds_rrtmg; do run $v $L $w; done
+done
