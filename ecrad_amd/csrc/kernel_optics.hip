@@ -51,6 +51,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_DUMP_MIN_WAVES) void optics_dump_kern
   const int ib = (IS_SW ? cfg.i_band_from_reordered_g_sw[g] : cfg.i_band_from_reordered_g_lw[g]) - 1;
   const int aer_type = aerosol_lane_type(cfg, glane);
   const int nb = IS_SW ? cfg.n_bands_sw : cfg.n_bands_lw;
+  GasRegs<TAB> quads;        // table values of the cell this lane last looked up (re-loaded when a layer leaves the cell, as in the solver kernels)
+  quads.invalidate();
   for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
@@ -94,7 +96,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_DUMP_MIN_WAVES) void optics_dump_kern
         const DevOptics& out = b.out;
         const DevCkdModel& m = IS_SW ? cfg.gas_sw : cfg.gas_lw;
         const size_t o = g + (size_t)ng * (lev + (size_t)nlev * cloc);
-        double od = gas_absorption_od<TAB>(m.hot, L, slot, g);
+        gas_load<TAB>(m.hot, launder_uniform(m.hot.nquad), launder_uniform(m.hot.nplain), L, slot, g, quads);
+        double od = gas_combine<TAB>(launder_uniform(m.hot.nquad), L, slot, quads);
         if (IS_SW) {
           double ssa = L.D(F_SM, slot) * m.rayleigh_molar_scat[g];
           od = od + ssa;
