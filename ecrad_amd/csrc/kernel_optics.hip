@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_DUMP_MIN_WAVES) void optics_dump_kern
       {
         const int lev = l0 + glane;
         const DumpArgs& b = kernarg_block<DumpArgs>();
-        if (lev < nlev) level_scalars<IS_SW>(b.cfg, IS_SW ? b.cfg.gas_sw : b.cfg.gas_lw, b.in, L, tid, col, lev, want_clouds);
+        if (lev < nlev) level_scalars<IS_SW>(b.cfg, IS_SW ? b.cfg.gas_sw : b.cfg.gas_lw, b.in, L, tid, col, lev, want_clouds, !b.cloudy_only);
       }
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;

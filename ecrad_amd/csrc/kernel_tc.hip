@@ -250,7 +250,9 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
       {
         const SpectralArgs& b = kernarg_block<SpectralArgs>();
         const int lev = l0 + glane;
-        if (lev < nlev) level_scalars<true>(b.cfg, b.cfg.gas_sw, b.in, L, tid, col, lev, true);
+        // (cloud fields of every layer: skipping them for cloud-free layers, as the other kernels do, makes THIS kernel 8 %
+        //  slower -- 22.2 -> 24.0 ms per 100 000 columns -- through nothing but a different register allocation)
+        if (lev < nlev) level_scalars<true>(b.cfg, b.cfg.gas_sw, b.in, L, tid, col, lev, true, true);
       }
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;

@@ -71,7 +71,7 @@ ECRAD_DEV LdsLayout make_lds(void* smem, int nquad, int nct) {
 // col is the 0-based GLOBAL column, lev the 0-based level.
 template <bool IS_SW>
 ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const DevInputs& in,
-                             const LdsLayout& L, int slot, int col, int lev, bool want_clouds) {
+                             const LdsLayout& L, int slot, int col, int lev, bool want_clouds, bool cloud_fields_everywhere = false) {
   const size_t ncol = in.ncol;
   const LevelOrder ord = level_order(in);
   const int clev = ord.full(lev);                       // this layer in the caller's arrays
@@ -169,6 +169,9 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
   double frac = 0.0;
   if (want_clouds) {
     { const FracView fv = cloud_fraction_view(in, col); frac = fv.p[fv.stride * clev]; }
+    // (a cloud-free layer -- most layers -- needs none of the water contents and radii: the solver kernels read the cloud
+    //  fields of cloudy layers only; the stage dump of ecrad_hip_optics wants them everywhere)
+    if (frac > 0.0 || cloud_fields_everywhere || cfg.cloud_fraction_threshold <= 0.0)
     for (int t = 0; t < L.nct; ++t) {
       const DevCloudOptics& co = IS_SW ? cfg.cloud_sw[t] : cfg.cloud_lw[t];
       const size_t i3 = i0 + ncol * in.nlev * t;

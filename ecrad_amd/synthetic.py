@@ -120,6 +120,7 @@ BENCH_CONFIGS = {
     "mcica_noaer": dict(sw_solver="McICA", use_aerosols=False, clear_sky=False),
     "mcica_vectorizable": dict(sw_solver="McICA", use_aerosols=True, clear_sky=False, use_vectorizable_generator=True),
     "homogeneous_clear_aer": dict(sw_solver="Homogeneous", use_aerosols=True, clear_sky=True),
+    "cloudless_clear_noaer": dict(sw_solver="Cloudless", use_aerosols=False, clear_sky=True),
     # BASELINE configs[2]: RRTMG 140/112 g-points, McICA with clouds (the reference's default configuration
     # test/ifs/configCY49R1.nam: SOCRATES/Fu band cloud optics, 12 aerosol types, no LW aerosol scattering)
     "mcica_rrtmg": dict(sw_solver="McICA", use_aerosols=True, clear_sky=False, rrtmg=True, do_lw_aerosol_scattering=False),
