@@ -15,7 +15,7 @@
 
 namespace ecrad {
 
-// Block-private scratch, level-major: per level and lane
+// Block-private scratch: per level and lane
 //   P_CLR  pair (transmittance, source_up) of the clear-sky layer        S_SD1  its source_dn
 //   P_RT2  pair (reflectance, transmittance) of a cloudy layer           P_S2   pair (source_up, source_dn)
 //   P_AS   pair (albedo, source) below the layer (cloudy-sky sweeps)
@@ -23,6 +23,9 @@ namespace ecrad {
 // The cloudless solver only needs P_CLR.
 enum { P_CLR = 0, S_SD1 = 2, P_RT2 = 3, P_S2 = 5, P_DN = 5, P_AS = 7, L_WIDTH_FULL = 9, L_WIDTH_CLEAR = 2 };
 
+// Level-major: the planes of a layer are adjacent.  (Plane-major -- all levels of a plane contiguous, so that a cloud-free
+// column's records are one dense piece -- was measured and is no better for the cloud-free headline and 15 % worse for the
+// cloudy Tripleclouds kernels, whose layers then scatter over 25 regions: profiles/r03_variants.log.)
 struct LwScratch {
   double* base;
   int width;
@@ -557,32 +560,55 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
 #endif
 }
 
+// Two translation units from this one source (kernel_ica_lw_clear.hip includes it with ECRAD_LW_TU_CLEAR): the cloudless and
+// homogeneous instantiations are compiled with LLVM's "max-memory-clause" scheduling strategy, which suits their level loop --
+// table and Planck loads grouped ahead of the arithmetic: lw_ica_kernel<float,32,1> 7.2 -> 6.5 ms per 100 000 clear-sky columns --
+// and costs every other kernel of the library 5-15 % (profiles/r03_variants.log), so it cannot be a flag of the whole build.
+#ifdef ECRAD_LW_TU_CLEAR
 template <typename TAB, int NGP, bool WIDE>
 static hipError_t launch_lw_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const SpectralArgs& args) {
-  switch (mode) {
-    case ECRAD_SOLVER_CLOUDLESS:
-      ECRAD_ALLOW_LDS((lw_ica_kernel<TAB, NGP, 0, WIDE>), lds);
-      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 0, WIDE>), grid, dim3(kBlock), lds, st, args);
-      break;
-    case ECRAD_SOLVER_HOMOGENEOUS:
-      ECRAD_ALLOW_LDS((lw_ica_kernel<TAB, NGP, 1, WIDE>), lds);
-      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 1, WIDE>), grid, dim3(kBlock), lds, st, args);
-      break;
-    default:
-      ECRAD_ALLOW_LDS((lw_ica_kernel<TAB, NGP, 2, WIDE>), lds);
-      hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 2, WIDE>), grid, dim3(kBlock), lds, st, args);
-      break;
+  if (mode == ECRAD_SOLVER_CLOUDLESS) {
+    ECRAD_ALLOW_LDS((lw_ica_kernel<TAB, NGP, 0, WIDE>), lds);
+    hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 0, WIDE>), grid, dim3(kBlock), lds, st, args);
+  } else {
+    ECRAD_ALLOW_LDS((lw_ica_kernel<TAB, NGP, 1, WIDE>), lds);
+    hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 1, WIDE>), grid, dim3(kBlock), lds, st, args);
   }
   return hipGetLastError();
 }
+#define ECRAD_LW_LAUNCHER launch_lw_ica_clear
+#else
+template <typename TAB, int NGP, bool WIDE>
+static hipError_t launch_lw_mode(int mode, dim3 grid, size_t lds, hipStream_t st, const SpectralArgs& args) {
+  ECRAD_ALLOW_LDS((lw_ica_kernel<TAB, NGP, 2, WIDE>), lds);
+  hipLaunchKernelGGL((lw_ica_kernel<TAB, NGP, 2, WIDE>), grid, dim3(kBlock), lds, st, args);
+  return hipGetLastError();
+}
+#define ECRAD_LW_LAUNCHER launch_lw_ica_mcica
 
 size_t lw_ica_scratch_doubles(int mode, int nlev) {
   return (size_t)(mode == ECRAD_SOLVER_CLOUDLESS ? L_WIDTH_CLEAR : L_WIDTH_FULL) * (nlev + 1) * kBlock;
 }
 
+hipError_t launch_lw_ica_clear(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
+                               const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
+                               double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0, bool wide);
+hipError_t launch_lw_ica_mcica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
+                               const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
+                               double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0, bool wide);
+
 hipError_t launch_lw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                          const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
                          double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0, bool wide) {
+  if (mode == ECRAD_SOLVER_CLOUDLESS || mode == ECRAD_SOLVER_HOMOGENEOUS)
+    return launch_lw_ica_clear(mode, ngp, table_f32, grid, lds, st, cfg, in, fx, prep, scratch, per_block, counter, m, g0, wide);
+  return launch_lw_ica_mcica(mode, ngp, table_f32, grid, lds, st, cfg, in, fx, prep, scratch, per_block, counter, m, g0, wide);
+}
+#endif
+
+hipError_t ECRAD_LW_LAUNCHER(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
+                             const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
+                             double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0, bool wide) {
   dim3 g(grid);
   const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot, g0, 0};
 #define ECRAD_DISPATCH(T, N) return wide ? launch_lw_mode<T, N, true>(mode, g, lds, st, args) : launch_lw_mode<T, N, false>(mode, g, lds, st, args)

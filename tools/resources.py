@@ -9,16 +9,18 @@ reports it; dynamic LDS (the level records) is set at launch and is not in the s
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ecrad_amd", "csrc")
-flags = None
+flags, extra = None, {}
 for line in open(os.path.join(CSRC, "Makefile")):
     if line.startswith("CXXFLAGS"):
         flags = line.split("=", 1)[1].strip().replace("$(ARCH)", "gfx950").split()
+    if line.startswith("EXTRA_"):       # per-file flags
+        extra[line.split("=", 1)[0].strip()[len("EXTRA_"):] + ".hip"] = line.split("=", 1)[1].strip().split()
 srcs = sorted(f for f in os.listdir(CSRC) if f.startswith("kernel_") and f.endswith(".hip"))
 print("# Kernel resource usage (hipcc -Rpass-analysis=kernel-resource-usage, gfx950)\n")
 print("Flags: `" + " ".join(flags) + "`.  One row per kernel instantiation; `occ` = waves per SIMD the register budget admits,")
 print("`scratch` = bytes of private (spill) memory per lane, `LDS` = static bytes per block (the level records are dynamic LDS on top).\n")
 for src in srcs:
-    p = subprocess.run(["/opt/rocm/bin/hipcc", *flags, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"],
+    p = subprocess.run(["/opt/rocm/bin/hipcc", *flags, *extra.get(src, []), "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/dev/null"],
                        cwd=CSRC, capture_output=True, text=True)
     rows, cur = [], None
     for ln in p.stderr.splitlines():
@@ -31,7 +33,7 @@ for src in srcs:
             rows.append(cur)
         elif cur is not None:
             cur[k.replace(" ", "").split("[")[0]] = v
-    print(f"## {src}\n\n| kernel | VGPRs | AGPRs | SGPRs | SGPR spills | VGPR spills | scratch | occ | LDS |\n|---|---|---|---|---|---|---|---|---|")
+    print(f"## {src}" + (f" (+ `{' '.join(extra[src])}`)" if src in extra else "") + "\n\n| kernel | VGPRs | AGPRs | SGPRs | SGPR spills | VGPR spills | scratch | occ | LDS |\n|---|---|---|---|---|---|---|---|---|")
     for r in rows:
         name = subprocess.run(["c++filt", r["name"]], capture_output=True, text=True).stdout.strip()
         name = re.sub(r"\(ecrad::.*\)$", "", name).replace("void ecrad::", "").replace("ecrad::", "")
