@@ -1310,7 +1310,8 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     double* ods = is_sw ? prep.od_scaling_sw : prep.od_scaling_lw;
     double* tcc = is_sw ? prep.total_cloud_cover_sw : prep.total_cloud_cover_lw;
     const int ngs = is_sw ? c.n_g_sw : c.n_g_lw, seed_offset = is_sw ? 0 : 997;
-    HIP_TRY(h, hipMemsetAsync(ods, 0, (size_t)ngs * nlev * r.nloc * 8, gs));
+    // (the wave-per-column generator defines every entry the solver kernels read -- the layers of a column's cloudy span -- itself)
+    if (c.use_vectorizable_generator) HIP_TRY(h, hipMemsetAsync(ods, 0, (size_t)ngs * nlev * r.nloc * 8, gs));
     if (c.use_vectorizable_generator) HIP_TRY(h, launch_mcica_generator_vec(gs, h->dcfg, din, ngs, seed_offset, ods, tcc));
     else HIP_TRY(h, launch_mcica_generator(gs, h->dcfg, din, ngs, seed_offset, ods, tcc));
     return ECRAD_OK;

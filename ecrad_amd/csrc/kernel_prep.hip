@@ -259,8 +259,9 @@ ECRAD_DEV double pdf_sample(const DevPdfSampler& p, double fsd, double cdf) {
   wfsd = dmax(0.0, dmin(wfsd - ifsd, 1.0));
   const size_t o = (size_t)(icdf - 1) + (size_t)p.ncdf * (ifsd - 1);
   double v00, v10, v01, v11;
-  if (p.val) { v00 = p.val[o]; v10 = p.val[o + 1]; v01 = p.val[o + p.ncdf]; v11 = p.val[o + p.ncdf + 1]; }
-  else { v00 = p.val64[o]; v10 = p.val64[o + 1]; v01 = p.val64[o + p.ncdf]; v11 = p.val64[o + p.ncdf + 1]; }
+  // (as_global: a pointer read out of the configuration has no address space, its loads would be flat_load)
+  if (p.val) { const auto* t = as_global(p.val); v00 = t[o]; v10 = t[o + 1]; v01 = t[o + p.ncdf]; v11 = t[o + p.ncdf + 1]; }
+  else { const auto* t = as_global(p.val64); v00 = t[o]; v10 = t[o + 1]; v01 = t[o + p.ncdf]; v11 = t[o + p.ncdf + 1]; }
   return (1.0 - wcdf) * (1.0 - wfsd) * v00 + (1.0 - wcdf) * wfsd * v01 + wcdf * (1.0 - wfsd) * v10 + wcdf * wfsd * v11;
 }
 
@@ -282,7 +283,8 @@ ECRAD_DEV PdfPending pdf_issue(const DevPdfSampler& p, double fsd, double cdf) {
   ifsd = ifsd < 1 ? 1 : ifsd;
   r.wfsd = dmax(0.0, dmin(wfsd - ifsd, 1.0));
   const size_t o = (size_t)(icdf - 1) + (size_t)p.ncdf * (ifsd - 1);
-  r.v00 = p.val[o]; r.v10 = p.val[o + 1]; r.v01 = p.val[o + p.ncdf]; r.v11 = p.val[o + p.ncdf + 1];
+  const auto* t = as_global(p.val);
+  r.v00 = t[o]; r.v10 = t[o + 1]; r.v01 = t[o + p.ncdf]; r.v11 = t[o + p.ncdf + 1];
   return r;
 }
 ECRAD_DEV double pdf_finish(const PdfPending& r) {
@@ -640,7 +642,7 @@ ECRAD_DEV void mcica_generator_column(const DevConfig& cfg, const DevInputs& in,
       }
       wave_sync();
       // this lane's register = M^(lane*274) * idum
-      const uint32_t* __restrict__ rows = cfg.lfsr_jump + 32 * lane;
+      const auto* rows = as_global(cfg.lfsr_jump + 32 * lane);
       uint32_t s = 0;
 #pragma unroll 8
       for (int i = 0; i < 32; ++i) s |= (uint32_t)(__popc(rows[i] & idum) & 1) << i;
@@ -772,7 +774,7 @@ ECRAD_DEV void mcica_generator_column(const DevConfig& cfg, const DevInputs& in,
 #pragma unroll
       for (int k = 0; k < NW; ++k) {
         const int i = lane + 64 * k;
-        if (pend_on[k]) pend_dst[k][0] = pdf_finish(pend[k]);
+        if (pend_on[k]) *as_global(pend_dst[k]) = pdf_finish(pend[k]);
         pend_on[k] = false;
         if (i >= ti && i <= ei && C.get(i)) {
           const int src = K.highest_zero_le(i);                     // >= run start: its flag is clear
@@ -780,6 +782,10 @@ ECRAD_DEV void mcica_generator_column(const DevConfig& cfg, const DevInputs& in,
           double* dst = odsc + jg + (size_t)ng * i;
           if (cfg.pdf.val) { pend[k] = pdf_issue(cfg.pdf, g.fsd[i], x); pend_dst[k] = dst; pend_on[k] = true; }
           else *dst = pdf_sample(cfg.pdf, g.fsd[i], x);
+        } else if (i >= ibegin - 1 && i <= ei) {
+          // a level of the column's cloudy span that is clear in this sub-column: the zero is written here, the array is
+          // not cleared beforehand (15 GB per 100 000 columns and 140 g-points); outside the span nothing reads it
+          *as_global(odsc + jg + (size_t)ng * i) = 0.0;
         }
       }
       wave_sync();
@@ -787,7 +793,7 @@ ECRAD_DEV void mcica_generator_column(const DevConfig& cfg, const DevInputs& in,
     }
 #pragma unroll
     for (int k = 0; k < NW; ++k)
-      if (pend_on[k]) pend_dst[k][0] = pdf_finish(pend[k]);
+      if (pend_on[k]) *as_global(pend_dst[k]) = pdf_finish(pend[k]);
 }
 
 // NWMAX: words for the whole column (3 up to 191 levels, 4 up to 255), used only when a column's clouds span more than

@@ -226,6 +226,8 @@ typedef __attribute__((address_space(3))) dvec2 lds_double2;
 ECRAD_DEV lds_double* lds_wave_area(void* records, int rec_doubles, int tid) { return (lds_double*)records + (tid >> 6) * 64 * rec_doubles; }
 // (a pointer chosen per lane among kernel arguments loses its address space: say that it is global memory)
 typedef __attribute__((address_space(1))) double gl_double;
+template <typename T> ECRAD_DEV const __attribute__((address_space(1))) T* as_global(const T* p) { return (const __attribute__((address_space(1))) T*)p; }
+template <typename T> ECRAD_DEV __attribute__((address_space(1))) T* as_global(T* p) { return (__attribute__((address_space(1))) T*)p; }
 ECRAD_DEV gl_double* to_global(double* p) { return (gl_double*)p; }
 ECRAD_DEV const gl_double* to_global(const double* p) { return (const gl_double*)p; }
 template <int NGP, int NQ, int OFF = 0>

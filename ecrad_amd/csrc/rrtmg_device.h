@@ -307,10 +307,20 @@ ECRAD_HD Mix mixing(double colA, double colB, double ratio, double mult) {
 // evaluators below therefore work on G consecutive g-points per call (Vec<G>: element-wise arithmetic, each
 // element rounded exactly as a scalar evaluation would be), so that a GPU lane pays for that common part once per
 // G g-points and has G independent table loads in flight per look-up.  G = 1 is the scalar form the host check uses.
+typedef unsigned ridx;       // index into the packed tables (a few hundred thousand doubles): 32-bit arithmetic per look-up
 template <int G> struct Vec {
   double v[G];
 };
+// (device pass: the tables are global memory -- said explicitly, because a pointer that comes out of a structure in memory has
+//  no address space and its loads would be flat_load, which waits on both memory counters)
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int G> ECRAD_HD Vec<G> vload(const double* p) {
+  const __attribute__((address_space(1))) double* gp = (const __attribute__((address_space(1))) double*)p;
+  Vec<G> r; for (int k = 0; k < G; ++k) r.v[k] = gp[k]; return r;
+}
+#else
 template <int G> ECRAD_HD Vec<G> vload(const double* p) { Vec<G> r; for (int k = 0; k < G; ++k) r.v[k] = p[k]; return r; }
+#endif
 template <int G> ECRAD_HD Vec<G> vsplat(double a) { Vec<G> r; for (int k = 0; k < G; ++k) r.v[k] = a; return r; }
 template <int G> ECRAD_HD Vec<G> operator+(const Vec<G>& a, const Vec<G>& b) { Vec<G> r; for (int k = 0; k < G; ++k) r.v[k] = a.v[k] + b.v[k]; return r; }
 template <int G> ECRAD_HD Vec<G> operator-(const Vec<G>& a, const Vec<G>& b) { Vec<G> r; for (int k = 0; k < G; ++k) r.v[k] = a.v[k] - b.v[k]; return r; }
@@ -323,7 +333,7 @@ template <int G> ECRAD_HD Vec<G> operator+(const Vec<G>& a, double b) { Vec<G> r
 // parameter, cubic-like near its ends (lower atmosphere only, 9 nodes)
 template <int G>
 ECRAD_HD Vec<G> lw_binary_half(const double* A, int ng, int ind, int nsp, const Mix& m, double facA, double facB, bool ends) {
-#define AT(row) vload<G>(A + (size_t)((row) - 1) * ng)
+#define AT(row) vload<G>(A + (ridx)((row) - 1) * ng)
   if (ends && m.parm < 0.125) {
     const double p = m.f - 1.0, p2 = p * p, p4 = p2 * p2;
     const double fk0 = p4, fk1 = 1.0 - p - 2.0 * p4, fk2 = p + p4;
@@ -359,8 +369,8 @@ ECRAD_HD void lw_gpoints_regime(const DevRrtmg& T, const LwBand& b, const LwRegi
   if (q.major == 1) {
     const double* A = tab + q.t_abs + ig;
     const int ind0 = base0 * nsp + 1, ind1 = base1 * nsp + 1;
-    tau = colA * (r.d(LD_FAC00) * vload<G>(A + (size_t)(ind0 - 1) * ng) + r.d(LD_FAC10) * vload<G>(A + (size_t)ind0 * ng) +
-                  r.d(LD_FAC01) * vload<G>(A + (size_t)(ind1 - 1) * ng) + r.d(LD_FAC11) * vload<G>(A + (size_t)ind1 * ng));
+    tau = colA * (r.d(LD_FAC00) * vload<G>(A + (ridx)(ind0 - 1) * ng) + r.d(LD_FAC10) * vload<G>(A + (ridx)ind0 * ng) +
+                  r.d(LD_FAC01) * vload<G>(A + (ridx)(ind1 - 1) * ng) + r.d(LD_FAC11) * vload<G>(A + (ridx)ind1 * ng));
   } else if (q.major == 2) {
     colB = r.d(LD_COL0 + q.gasB);
     const Mix m0 = mixing(colA, colB, T.rat[q.pair][jp - 1], mult);
@@ -372,13 +382,13 @@ ECRAD_HD void lw_gpoints_regime(const DevRrtmg& T, const LwBand& b, const LwRegi
   if (q.self) {
     const double* S = tab + q.t_self + ig;
     const int inds = r.i(LI_INDSELF);
-    const Vec<G> s0 = vload<G>(S + (size_t)(inds - 1) * ng), s1 = vload<G>(S + (size_t)inds * ng);
+    const Vec<G> s0 = vload<G>(S + (ridx)(inds - 1) * ng), s1 = vload<G>(S + (ridx)inds * ng);
     tau = tau + r.d(LD_SELFFAC) * (s0 + r.d(LD_SELFFRAC) * (s1 - s0));
   }
   if (q.forc) {
     const double* Fo = tab + q.t_for + ig;
     const int indf = r.i(LI_INDFOR);
-    const Vec<G> f0 = vload<G>(Fo + (size_t)(indf - 1) * ng), f1 = vload<G>(Fo + (size_t)indf * ng);
+    const Vec<G> f0 = vload<G>(Fo + (ridx)(indf - 1) * ng), f1 = vload<G>(Fo + (ridx)indf * ng);
     tau = tau + r.d(LD_FORFAC) * (f0 + r.d(LD_FORFRAC) * (f1 - f0));
   }
   const int indm = r.i(LI_INDMINOR);
@@ -389,13 +399,13 @@ ECRAD_HD void lw_gpoints_regime(const DevRrtmg& T, const LwBand& b, const LwRegi
     Vec<G> absm;
     if (mn.binary) {
       const Mix mm = mixing(colA, colB, mn.refrat, mult);
-      const size_t r1 = (size_t)((mm.j - 1) + nsp * (indm - 1)) * ng, r2 = r1 + (size_t)nsp * ng;
+      const ridx r1 = (ridx)((mm.j - 1) + nsp * (indm - 1)) * ng, r2 = r1 + (ridx)nsp * ng;
       const Vec<G> k1 = vload<G>(K + r1), k2 = vload<G>(K + r2);
       const Vec<G> a1 = k1 + mm.f * (vload<G>(K + r1 + ng) - k1);
       const Vec<G> a2 = k2 + mm.f * (vload<G>(K + r2 + ng) - k2);
       absm = a1 + minorfrac * (a2 - a1);
     } else {
-      const Vec<G> k0 = vload<G>(K + (size_t)(indm - 1) * ng), k1 = vload<G>(K + (size_t)indm * ng);
+      const Vec<G> k0 = vload<G>(K + (ridx)(indm - 1) * ng), k1 = vload<G>(K + (ridx)indm * ng);
       absm = k0 + minorfrac * (k1 - k0);
     }
     double amount;
@@ -435,7 +445,7 @@ ECRAD_HD void lw_gpoints_regime(const DevRrtmg& T, const LwBand& b, const LwRegi
   else if (q.planck == 2) {
     const Mix mp = mixing(colA, colB, q.refrat_planck, mult);
     const double* Fr = tab + q.t_frac + ig;
-    const Vec<G> f0 = vload<G>(Fr + (size_t)(mp.j - 1) * ng), f1 = vload<G>(Fr + (size_t)mp.j * ng);
+    const Vec<G> f0 = vload<G>(Fr + (ridx)(mp.j - 1) * ng), f1 = vload<G>(Fr + (ridx)mp.j * ng);
     pfrac = f0 + mp.f * (f1 - f0);
   }
   tau_out = tau;
@@ -474,13 +484,13 @@ ECRAD_HD void sw_gpoints_regime(const DevRrtmg& T, const SwBand& b, const SwRegi
   if (q.self) {
     const double* S = tab + q.t_self + ig;
     const int inds = r.i(SI_INDSELF);
-    const Vec<G> s0 = vload<G>(S + (size_t)(inds - 1) * ng), s1 = vload<G>(S + (size_t)inds * ng);
+    const Vec<G> s0 = vload<G>(S + (ridx)(inds - 1) * ng), s1 = vload<G>(S + (ridx)inds * ng);
     cont = r.d(SD_SELFFAC) * (s0 + r.d(SD_SELFFRAC) * (s1 - s0));
   }
   if (q.forc) {
     const double* Fo = tab + q.t_for + ig;
     const int indf = r.i(SI_INDFOR);
-    const Vec<G> f0 = vload<G>(Fo + (size_t)(indf - 1) * ng), f1 = vload<G>(Fo + (size_t)indf * ng);
+    const Vec<G> f0 = vload<G>(Fo + (ridx)(indf - 1) * ng), f1 = vload<G>(Fo + (ridx)indf * ng);
     cont = cont + r.d(SD_FORFAC) * (f0 + r.d(SD_FORFRAC) * (f1 - f0));
   }
   Mix m{0.0, 0.0, 0.0, 1};
@@ -488,13 +498,13 @@ ECRAD_HD void sw_gpoints_regime(const DevRrtmg& T, const SwBand& b, const SwRegi
   if (q.major == 2) {
     m = mixing(r.d(SD_COL0 + q.gasA), r.d(SD_COL0 + q.gasB), q.strrat, lower ? 8.0 : 4.0);
     const double* A = tab + q.t_abs + ig;
-    const size_t i0 = (size_t)(base0 * nsp + m.j - 1) * ng, i1 = (size_t)(base1 * nsp + m.j - 1) * ng, dT = (size_t)nsp * ng;
+    const ridx i0 = (ridx)(base0 * nsp + m.j - 1) * ng, i1 = (ridx)(base1 * nsp + m.j - 1) * ng, dT = (ridx)nsp * ng;
     taug = m.comb * ((1.0 - m.f) * (vload<G>(A + i0) * fac00 + vload<G>(A + i0 + dT) * fac10 + vload<G>(A + i1) * fac01 + vload<G>(A + i1 + dT) * fac11) +
                      m.f * (vload<G>(A + i0 + ng) * fac00 + vload<G>(A + i0 + dT + ng) * fac10 + vload<G>(A + i1 + ng) * fac01 + vload<G>(A + i1 + dT + ng) * fac11));
     if (q.self || q.forc) taug = taug + colh2o * cont;
   } else if (q.major == 1) {
     const double* A = tab + q.t_abs + ig;
-    const size_t i0 = (size_t)(base0 * nsp) * ng, i1 = (size_t)(base1 * nsp) * ng;
+    const ridx i0 = (ridx)(base0 * nsp) * ng, i1 = (ridx)(base1 * nsp) * ng;
     const Vec<G> major = fac00 * vload<G>(A + i0) + fac10 * vload<G>(A + i0 + ng) + fac01 * vload<G>(A + i1) + fac11 * vload<G>(A + i1 + ng);
     if (q.self || q.forc) taug = r.d(SD_COL0 + q.gasA) * (q.mult * major + cont);
     else taug = r.d(SD_COL0 + q.gasA) * q.mult * major;
@@ -506,7 +516,7 @@ ECRAD_HD void sw_gpoints_regime(const DevRrtmg& T, const SwBand& b, const SwRegi
   else if (q.rayl_kind == 1) ray = vload<G>(tab + q.t_rayl + ig);
   else {
     const double* Ry = tab + q.t_rayl + ig;
-    const Vec<G> r0 = vload<G>(Ry + (size_t)(m.j - 1) * ng), r1 = vload<G>(Ry + (size_t)m.j * ng);
+    const Vec<G> r0 = vload<G>(Ry + (ridx)(m.j - 1) * ng), r1 = vload<G>(Ry + (ridx)m.j * ng);
     ray = r0 + m.f * (r1 - r0);
   }
   taug_out = taug;
@@ -515,7 +525,7 @@ ECRAD_HD void sw_gpoints_regime(const DevRrtmg& T, const SwBand& b, const SwRegi
     if (b.sflux_kind == 0) sflux_out = b.sflux_scale * vload<G>(tab + b.t_sflux + ig);
     else {
       const double* S = tab + b.t_sflux + ig;
-      const Vec<G> s0 = vload<G>(S + (size_t)(m.j - 1) * ng), s1 = vload<G>(S + (size_t)m.j * ng);
+      const Vec<G> s0 = vload<G>(S + (ridx)(m.j - 1) * ng), s1 = vload<G>(S + (ridx)m.j * ng);
       sflux_out = s0 + m.f * (s1 - s0);
     }
   }

@@ -1,6 +1,6 @@
 #!/bin/bash
-mkdir -p gpurun_out/r03_zm
-O=gpurun_out/r03_zm
+mkdir -p gpurun_out/r03_zq
+O=gpurun_out/r03_zq
 run() {
   local out=$O/$1_$3.json
   ECRAD_HIP_LIB=$2 timeout 300 python bench.py --steps 5 --warmup 2 --workload $3 --headline-only --no-cpu-baseline $4 > $out 2> $O/$1_$3.err
@@ -15,4 +15,7 @@ except Exception as e:
 PY
 }
 BASE=$PWD/ecrad_amd/csrc/libecrad_hip.so
-for w in clear_homogeneous_ecckd32 cloudless_clear_noaer mcica_ecckd32 tripleclouds_ecckd32 clear_homogeneous_ecckd32; do run shipped $BASE $w; done
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+for w in mcica_rrtmg mcica_ecckd32 tripleclouds_rrtmg mcica_rrtmg; do run shipped $BASE $w; done
+ECRAD_NO_GEN_OVERLAP=1 run nooverlap $BASE mcica_rrtmg
+bash tools/kstats.sh mcica_rrtmg 2>&1 | head -8
