@@ -216,7 +216,11 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
                 const int lv = lev + k < nlev ? lev + k : nlev - 1;
                 v[k][0] = gs.od_lw[g + (size_t)ng * (lv + (size_t)nlev * cloc)];
                 v[k][1] = gs.planck_hl[g + (size_t)ng * (lv + 1 + (size_t)(nlev + 1) * cloc)];
-                v[k][2] = MODE == 2 ? b.prep.od_scaling_lw[g + (size_t)ng * (lv + (size_t)nlev * cloc)] : 0.0;
+                // (the cloud scaling of a layer is read where the column has cloud in that layer: 8 of the ~130 bytes a lane
+                //  moves per layer, in kernels that run at 4-6 TB/s)
+                v[k][2] = 0.0;
+                if (MODE == 2 && L.D(F_FRAC, j + k < nl ? slot + k : slot) >= cloud_fraction_threshold)
+                  v[k][2] = b.prep.od_scaling_lw[g + (size_t)ng * (lv + (size_t)nlev * cloc)];
               }
 #pragma unroll
               for (int k = 0; k < kStageBatch; ++k)

@@ -324,7 +324,8 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void s
                   const size_t o = g + (size_t)ng * (lv + (size_t)nlev * cloc);
                   v[kk][0] = gs.od_sw[o];
                   v[kk][1] = gs.ssa_sw[o];
-                  v[kk][2] = MODE == 2 ? b.prep.od_scaling_sw[o] : 0.0;
+                  v[kk][2] = 0.0;       // (read where the column has cloud in that layer, see kernel_ica_lw.hip)
+                  if (MODE == 2 && L.D(F_FRAC, kk <= j ? slot - kk : slot) >= cloud_fraction_threshold) v[kk][2] = b.prep.od_scaling_sw[o];
                   v[kk][3] = gs.g_sw ? gs.g_sw[o] : 0.0;
                 }
 #pragma unroll
