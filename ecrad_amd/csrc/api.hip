@@ -1235,7 +1235,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
   const bool spectra_overlap = c.do_sw && c.do_lw && !sw_sp && !lw_sp && h->nchunk_sw == 1 && h->nchunk_lw == 1 &&
                                grid_sw + grid_lw <= 2 * h->num_cu && !getenv("ECRAD_NO_SPECTRA_OVERLAP");      // (<= 2048 columns at 32 lanes: beyond, 4096 columns were 6 % slower side by side, profiles/r02_zo_spectra_overlap.log)
   HIP_TRY(h, h->scratch.ensure(spectra_overlap ? need_sw + need_lw : (need_sw > need_lw ? need_sw : need_lw)));
-  HIP_TRY(h, h->counters.ensure(256));
+  HIP_TRY(h, h->counters.ensure(512));
   {   // per-chunk partial profiles of spectra wider than 64 g-points (6 profiles x chunks, reused by LW then SW)
     const int nch = std::max(c.do_lw ? h->nchunk_lw : 1, c.do_sw ? h->nchunk_sw : 1);
     if (nch > 1) HIP_TRY(h, h->partial.ensure((size_t)cx.din.ncol * (nlev + 1) * nch * 6 * sizeof(double)));
@@ -1279,7 +1279,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
 
   // ---- kernels (radiation_interface.F90:323-504) ------------------------------------------------------
   HIP_TRY(h, hipEventRecord(evs[0], stream));
-  HIP_TRY(h, hipMemsetAsync(counters, 0, 256, stream));
+  HIP_TRY(h, hipMemsetAsync(counters, 0, 512, stream));
   HIP_TRY(h, launch_order(stream, din, counters + 32));                                 // :310-317
   if (c.do_clouds) HIP_TRY(h, launch_crop(stream, h->dcfg, din));                      // :361 (before the gas optics, which do not read the clouds: the generators below only wait for this)
   // SPARTACUS: the work list of the tile's (column, cloudy layer) pairs, the same for both spectra.  Its length sizes the
@@ -1365,7 +1365,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     const int nch = plan.n;
     for (int p = 0; p < nch; ++p)
       HIP_TRY(h, launch_optics_dump(is_sw, plan.ngp[p], m.table_f32, grid_for(h, r.nloc, plan.ngp[p]), lds_bytes(m.hot.nquad, c.n_cloud_types), stream, h->hcfg, din, dop, plan.g0[p],
-                                    sp_single, /*cloudy_only=*/true));
+                                    counters + (is_sw ? 80 : 64) + p, sp_single, /*cloudy_only=*/true));      // (counters 64.. / 80..: work queues of this pass)
     auto launch_sp = [&](const DevFlux& f, int* counter, int p, bool wide) -> hipError_t {
       const int ngp = plan.ngp[p], g0 = plan.g0[p];
       return launch_spartacus(is_sw, sp_single, ngp, grid_sp(ngp, is_sw), h->num_cu, stream, c, din, dop, prep, f, scratch,
@@ -1658,7 +1658,9 @@ int ecrad_hip_optics(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, in
     Carver cv(h->staging_out.p);
     for (const OF& f : fields) if (out->*(f.host)) dop.*(f.dev) = cv.take<double>(f.n);
   }
-  HIP_TRY(h, h->counters.ensure(256));
+  HIP_TRY(h, h->counters.ensure(512));
+  HIP_TRY(h, hipMemsetAsync(h->counters.p, 0, 512, stream));      // (the dump launches below take their column groups from queues 64.. / 80..)
+  int* const counters = reinterpret_cast<int*>(h->counters.p);
   cx.din.reversed = reinterpret_cast<int32_t*>(h->counters.p) + 32;
   HIP_TRY(h, launch_order(stream, cx.din, reinterpret_cast<int32_t*>(h->counters.p) + 32));
   if ((st = run_rrtmg(h, cx, false))) return st;
@@ -1671,11 +1673,11 @@ int ecrad_hip_optics(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, in
   if (c.do_sw)
     for (int p = 0; p < h->plan_sw.n; ++p)
       HIP_TRY(h, launch_optics_dump(true, h->plan_sw.ngp[p], h->hcfg.gas_sw.table_f32, grid_for(h, r.nloc, h->plan_sw.ngp[p]),
-                                    lds_bytes(h->hcfg.gas_sw.hot.nquad, nct), stream, h->hcfg, cx.din, dop, h->plan_sw.g0[p]));
+                                    lds_bytes(h->hcfg.gas_sw.hot.nquad, nct), stream, h->hcfg, cx.din, dop, h->plan_sw.g0[p], counters + 80 + p));
   if (c.do_lw)
     for (int p = 0; p < h->plan_lw.n; ++p)
       HIP_TRY(h, launch_optics_dump(false, h->plan_lw.ngp[p], h->hcfg.gas_lw.table_f32, grid_for(h, r.nloc, h->plan_lw.ngp[p]),
-                                    lds_bytes(h->hcfg.gas_lw.hot.nquad, nct), stream, h->hcfg, cx.din, dop, h->plan_lw.g0[p]));
+                                    lds_bytes(h->hcfg.gas_lw.hot.nquad, nct), stream, h->hcfg, cx.din, dop, h->plan_lw.g0[p], counters + 64 + p));
   if (host_mem) {
     for (const OF& f : fields)
       if (out->*(f.host)) HIP_TRY(h, hipMemcpyAsync(out->*(f.host), dop.*(f.dev), f.n * 8, hipMemcpyDeviceToHost, stream));

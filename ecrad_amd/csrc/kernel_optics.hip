@@ -18,6 +18,7 @@ struct DumpArgs {
   DevOptics out;
   int32_t g0;
   int32_t cloudy_only;      // write the cloud arrays of cloudy layers only (the SPARTACUS solvers read no others)
+  int* counter;             // work queue of column groups (zero at launch), as in the solver kernels
 };
 
 // OUT: element type of the arrays written.  double for ecrad_hip_optics; float when the arrays feed the SPARTACUS solvers in
@@ -53,7 +54,16 @@ __global__ __launch_bounds__(kBlock, ECRAD_DUMP_MIN_WAVES) void optics_dump_kern
   const int nb = IS_SW ? cfg.n_bands_sw : cfg.n_bands_lw;
   GasRegs<TAB> quads;        // table values of the cell this lane last looked up (re-loaded when a layer leaves the cell, as in the solver kernels)
   quads.invalidate();
-  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  // Column groups from a queue, not a static stride: the launch has more blocks than fit on the GPU at once (the solver
+  // kernels' grid), and with a stride the blocks of the second round would run at a third of the occupancy -- the pass
+  // averaged two waves per SIMD instead of three (profiles/r03_sq.md).
+  __shared__ int next_group;
+  for (;;) {
+    __syncthreads();
+    if (tid == 0) next_group = atomicAdd(kernarg_block<DumpArgs>().counter, 1);
+    __syncthreads();
+    const int grp = next_group;
+    if (grp >= ngroups) break;
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = col_ok ? cloc_raw : ncol_loc - 1;
@@ -168,8 +178,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_DUMP_MIN_WAVES) void optics_dump_kern
 }
 
 hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
-                              const DevConfig& cfg, const DevInputs& in, const DevOptics& out, int g0, bool out_f32, bool cloudy_only) {
-  const DumpArgs args{cfg, in, out, g0, cloudy_only ? 1 : 0};
+                              const DevConfig& cfg, const DevInputs& in, const DevOptics& out, int g0, int* counter, bool out_f32, bool cloudy_only) {
+  const DumpArgs args{cfg, in, out, g0, cloudy_only ? 1 : 0, counter};
 #define ECRAD_L(T, N, S, O) do { ECRAD_ALLOW_LDS((optics_dump_kernel<T, N, S, O>), lds); hipLaunchKernelGGL((optics_dump_kernel<T, N, S, O>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
 #define ECRAD_N(T, S, O) do { if (ngp == 16) ECRAD_L(T, 16, S, O); else if (ngp == 32) ECRAD_L(T, 32, S, O); else ECRAD_L(T, 64, S, O); } while (0)
 #define ECRAD_O(T, S) do { if (out_f32) ECRAD_N(T, S, float); else ECRAD_N(T, S, double); } while (0)

@@ -56,8 +56,8 @@ hipError_t launch_mcica_generator_vec(hipStream_t st, const DevConfig* cfg, cons
                                       double* od_scaling, double* tcc);
 hipError_t launch_spectral_post(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevFlux& fx, bool wide);
 hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
-                              const DevConfig& cfg, const DevInputs& in, const DevOptics& out, int g0, bool out_f32 = false,
-                              bool cloudy_only = false);
+                              const DevConfig& cfg, const DevInputs& in, const DevOptics& out, int g0, int* counter,
+                              bool out_f32 = false, bool cloudy_only = false);
 
 // SPARTACUS solvers (kernel_spartacus.hip): words of working precision of block-private slab per block and of layer
 // matrices per (column, layer); the launch of one spectrum (work list, layer matrices, the two sweeps)

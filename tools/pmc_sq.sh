@@ -10,6 +10,6 @@ for db in glob.glob("$OUT/sq*/*.db"):
     con=sqlite3.connect(db)
     rows=con.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name").fetchall()
     for k,c,v,n in rows:
-        if 'ica_kernel' in k or 'tc_kernel' in k:
+        if any(t in k for t in ('ica_kernel','tc_kernel','spartacus','taumol','generator','optics_dump')):
             print(k.split('(')[0].replace('void ecrad::',''), c, v/n)
 PY
