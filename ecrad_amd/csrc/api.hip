@@ -1300,12 +1300,13 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     HIP_TRY(h, hipMemcpyAsync(&sp_n, sp_n_items, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_TRY(h, hipStreamSynchronize(stream));
   }
-  // (only next to the RRTMG gas-optics pass: 212.8 -> 208.6 ms per 100 000 columns, profiles/r02_zk_gen_overlap.log; next to
-  //  the other spectrum's solver kernel of an ecCKD run it gains nothing -- both are bound by instruction issue)
-  const bool gen_overlap = (sw_mcica || lw_mcica) && (h->rrtmg_sw || h->rrtmg_lw) && !getenv("ECRAD_NO_GEN_OVERLAP");
-  // (the SHORTWAVE generator of a run with both spectra on McICA goes next to the longwave solver kernels instead: 192.6 -> 190.4 ms,
-  //  profiles/r03_variants.log; ECRAD_GEN_SW_EARLY puts it back next to the gas optics)
-  const bool gen_sw_late = gen_overlap && sw_mcica && lw_mcica && !getenv("ECRAD_GEN_SW_EARLY");
+  // Where the generators run (RRTMG runs, whose gas-optics pass and solver kernels leave room next to them; next to the solver
+  // kernel of an ecCKD run a generator gains nothing -- both are bound by instruction issue).  Since the generator takes its
+  // columns from a queue it is short enough that running it next to the gas-optics pass costs more than it saves
+  // (100 000 columns, profiles/r03_variants.log r03_zx: 176.2 ms next to the gas optics, 169.8 ms in line); ECRAD_GEN_OVERLAP
+  // puts the generators back there.  ECRAD_GEN_SW_LATE: the shortwave generator next to the longwave solver kernels.
+  const bool gen_overlap = (sw_mcica || lw_mcica) && (h->rrtmg_sw || h->rrtmg_lw) && getenv("ECRAD_GEN_OVERLAP");
+  const bool gen_sw_late = sw_mcica && lw_mcica && (h->rrtmg_sw || h->rrtmg_lw) && getenv("ECRAD_GEN_SW_LATE") && !getenv("ECRAD_GEN_SW_EARLY");
   auto run_generator = [&](bool is_sw, hipStream_t gs) -> int {
     double* ods = is_sw ? prep.od_scaling_sw : prep.od_scaling_lw;
     double* tcc = is_sw ? prep.total_cloud_cover_sw : prep.total_cloud_cover_lw;
@@ -1313,7 +1314,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     // (the wave-per-column generator defines every entry the solver kernels read -- the layers of a column's cloudy span -- itself)
     if (c.use_vectorizable_generator) HIP_TRY(h, hipMemsetAsync(ods, 0, (size_t)ngs * nlev * r.nloc * 8, gs));
     if (c.use_vectorizable_generator) HIP_TRY(h, launch_mcica_generator_vec(gs, h->dcfg, din, ngs, seed_offset, ods, tcc));
-    else HIP_TRY(h, launch_mcica_generator(gs, h->dcfg, din, ngs, seed_offset, ods, tcc));
+    else HIP_TRY(h, launch_mcica_generator(gs, h->dcfg, din, ngs, seed_offset, ods, tcc, counters + (is_sw ? 97 : 96)));      // (counters 96, 97: the generators' column queues)
     return ECRAD_OK;
   };
   if (gen_overlap) {
@@ -1323,7 +1324,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     HIP_TRY(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
     if (lw_mcica) { if ((st = run_generator(false, h->aux_stream))) return st; HIP_TRY(h, hipEventRecord(h->ev_gen_lw, h->aux_stream)); }
     // (ECRAD_GEN_SW_LATE: the shortwave generator next to the longwave SOLVER -- HBM-bound -- instead of next to the gas optics)
-    if (sw_mcica && !(lw_mcica && gen_sw_late)) { if ((st = run_generator(true, h->aux_stream))) return st; HIP_TRY(h, hipEventRecord(h->ev_gen_sw, h->aux_stream)); }
+    if (sw_mcica && !gen_sw_late) { if ((st = run_generator(true, h->aux_stream))) return st; HIP_TRY(h, hipEventRecord(h->ev_gen_sw, h->aux_stream)); }
   }
   bool rrtmg_sw_pending = false;
   if ((st = run_rrtmg(h, cx, true, /*split_sw=*/true, &rrtmg_sw_pending))) return st;  // RRTMG gas optics, :341-357 (accounted to the PREP stage)
@@ -1423,7 +1424,8 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     if (lw_mcica) {
       if (gen_overlap) HIP_TRY(h, hipStreamWaitEvent(stream, h->ev_gen_lw, 0));
       else if ((st = run_generator(false, stream))) return st;
-      if (gen_sw_late && sw_mcica) {      // fork here: the shortwave generator runs on the second stream while the longwave solver kernels do
+      if (gen_sw_late) {      // fork here: the shortwave generator runs on the second stream while the longwave solver kernels do
+        if ((st = ensure_aux_stream(h))) return st;
         HIP_TRY(h, hipEventRecord(h->ev_fork_sw, stream));
         HIP_TRY(h, hipStreamWaitEvent(h->aux_stream, h->ev_fork_sw, 0));
         if ((st = run_generator(true, h->aux_stream))) return st;
@@ -1472,7 +1474,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     const int nct = (c.i_solver_sw != ECRAD_SOLVER_CLOUDLESS) ? c.n_cloud_types : 0;
     const size_t lds = lds_bytes(m.hot.nquad, nct);
     if (sw_mcica) {
-      if (gen_overlap) HIP_TRY(h, hipStreamWaitEvent(stream, h->ev_gen_sw, 0));
+      if (gen_overlap || gen_sw_late) HIP_TRY(h, hipStreamWaitEvent(stream, h->ev_gen_sw, 0));
       else if ((st = run_generator(true, sw_stream))) return st;
     }
     if (sw_sp) {

@@ -6,6 +6,7 @@
 //                                  utilities/radiation_random_numbers_mix.F90:142-312,
 //                                  radiation_pdf_sampler.F90:126-156
 //   surface/TOA spectral sums      radiation_flux.F90:397-660
+#include <cstdlib>
 #include "kernels_common.h"
 #include "launch.h"
 
@@ -800,7 +801,7 @@ ECRAD_DEV void mcica_generator_column(const DevConfig& cfg, const DevInputs& in,
 // 128 levels
 template <int NWMAX>
 __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, int ng,
-                                                             int seed_offset, double* od_scaling, double* total_cloud_cover) {
+                                                             int seed_offset, double* od_scaling, double* total_cloud_cover, int* counter) {
   extern __shared__ __align__(16) unsigned char smem[];
   const DevConfig& cfg = *cfgp;
   const int lane = threadIdx.x;
@@ -809,7 +810,15 @@ __global__ __launch_bounds__(64, ECRAD_GEN_WAVES) void mcica_generator_kernel(co
   const GenLds g = gen_lds(smem, nlev, ng);
   GenTimer tm;
   tm.reset();
-  for (int cloc = blockIdx.x; cloc < nloc; cloc += gridDim.x) {
+  // columns from a queue (a cloud-free column costs a fraction of a cloudy one: with a static stride some waves have far more to do)
+  // Every lane takes part in the atomic (lane 0 adds 1, the others 0) and the wave reads lane 0's result.  NOT `if (lane == 0)
+  // ticket = atomicAdd(...)` followed by readfirstlane(ticket): hipcc 7.2 drops that readfirstlane (it takes the merged value
+  // for uniform), the lanes then disagree about the column and the loop exit becomes divergent -- wrong results and a hang
+  // (profiles/r03_variants.log, r03_zw).
+  for (int static_next = blockIdx.x;; static_next += gridDim.x) {
+    int cloc = static_next;
+    if (counter) cloc = __builtin_amdgcn_readfirstlane(atomicAdd(counter, lane == 0 ? 1 : 0));
+    if (cloc >= nloc) break;
     const int col = in.istartcol - 1 + cloc;
     tm.start_column();
     // the highest and the lowest cloudy level of the column (0-based; none: ib = nlev)
@@ -1016,12 +1025,15 @@ hipError_t launch_mcica_generator_vec(hipStream_t st, const DevConfig* cfg, cons
 
 
 hipError_t launch_mcica_generator(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int ng, int seed_offset,
-                                  double* od_scaling, double* tcc) {
+                                  double* od_scaling, double* tcc, int* counter) {
   const int nloc = in.iendcol - in.istartcol + 1;
   const size_t lds = mcica_generator_lds_bytes(in.nlev, ng);
-  const int grid = nloc < 256 * 32 ? nloc : 256 * 32;
-  if (in.nlev <= 191) hipLaunchKernelGGL(mcica_generator_kernel<3>, dim3(grid), dim3(64), lds, st, cfg, in, ng, seed_offset, od_scaling, tcc);
-  else hipLaunchKernelGGL(mcica_generator_kernel<4>, dim3(grid), dim3(64), lds, st, cfg, in, ng, seed_offset, od_scaling, tcc);
+  int grid = nloc < 256 * 32 ? nloc : 256 * 32;
+  // (test hook: fewer blocks than columns at small column counts, so that a wave takes several columns one after the other)
+  if (const char* e = getenv("ECRAD_GEN_GRID")) { const int v = atoi(e); if (v >= 1 && v < grid) grid = v; }
+  if (getenv("ECRAD_GEN_STATIC")) counter = nullptr;      // (static stride over the columns instead of the queue)
+  if (in.nlev <= 191) hipLaunchKernelGGL(mcica_generator_kernel<3>, dim3(grid), dim3(64), lds, st, cfg, in, ng, seed_offset, od_scaling, tcc, counter);
+  else hipLaunchKernelGGL(mcica_generator_kernel<4>, dim3(grid), dim3(64), lds, st, cfg, in, ng, seed_offset, od_scaling, tcc, counter);
   return hipGetLastError();
 }
 

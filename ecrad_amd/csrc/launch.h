@@ -51,7 +51,7 @@ hipError_t launch_column_order(hipStream_t st, const DevConfig* cfg, const DevIn
 hipError_t launch_tripleclouds_prep(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevCloudPrep& prep,
                                     double* cc_sw, double* cc_lw);
 hipError_t launch_mcica_generator(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int ng, int seed_offset,
-                                  double* od_scaling, double* tcc);
+                                  double* od_scaling, double* tcc, int* counter);
 hipError_t launch_mcica_generator_vec(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int ng, int seed_offset,
                                       double* od_scaling, double* tcc);
 hipError_t launch_spectral_post(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevFlux& fx, bool wide);

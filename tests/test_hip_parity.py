@@ -130,6 +130,23 @@ def _replicate(inputs, times):
     return ncol * times, nlev, sl, th, gas, cloud, aer
 
 
+@pytest.mark.parametrize("grid", ["1", "3", "static"])
+def test_mcica_generator_column_queue(grid, oracle_lib, monkeypatch):
+    """The wave-per-column cloud generator takes its columns from a queue (kernel_prep.hip, mcica_generator_kernel).  With
+    fewer waves than columns a wave takes several columns in turn: 1 wave, 3 waves, and the static stride (ECRAD_GEN_STATIC)
+    the queue replaced all give the oracle's sub-columns.  (A first form of the queue was miscompiled -- the wave's lanes
+    disagreed about the column -- and only the column with ticket 0 showed it: every column is compared here.)"""
+    if grid == "static":
+        monkeypatch.setenv("ECRAD_GEN_STATIC", "1")
+        monkeypatch.setenv("ECRAD_GEN_GRID", "3")
+    else:
+        monkeypatch.setenv("ECRAD_GEN_GRID", grid)
+    f_hip, _, rad = run_case(make_config("McICA"), "hip")
+    f_ora, _, _ = run_case(make_config("McICA"), oracle_lib.backend)
+    compare_flux(f_hip, f_ora, TOL)
+    rad.close()
+
+
 @pytest.mark.parametrize("solver", ["Homogeneous", "Tripleclouds", "McICA"])
 def test_many_column_groups_per_block_bitwise(solver):
     """Size-independent property at a size the persistent blocks see several column groups each
