@@ -317,8 +317,8 @@ class Config:
         if self.n_aerosol_types < 0 or self.n_aerosol_types > NMaxAerosolTypes:
             raise ConfigError("number of aerosol types out of range")
         spartacus = ((self.do_sw and self.i_solver_sw == ISolverSpartacus) or (self.do_lw and self.i_solver_lw == ISolverSpartacus))
-        if spartacus and self.nregions != 3:
-            raise ConfigError("SPARTACUS: only n_regions = 3 is implemented in this build")
+        if spartacus and self.nregions not in (2, 3):
+            raise ConfigError("SPARTACUS: n_regions must be 2 or 3")      # radiation_config.F90:268
         if self.do_sw and self.i_solver_sw == ISolverSpartacus and self.do_sw_delta_scaling_with_gases:
             raise ConfigError("SW delta-Eddington scaling with gases not possible with SPARTACUS solver")     # :1336-1340
         if self.i_solver_sw == ISolverMcICA:

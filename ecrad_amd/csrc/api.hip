@@ -450,7 +450,10 @@ int validate_config(ecrad_hip_handle_t h, const ecrad_config_t& c) {
   }
   const bool spartacus = (c.do_sw && c.i_solver_sw == ECRAD_SOLVER_SPARTACUS) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_SPARTACUS);
   if (spartacus) {
-    if (c.nregions != 3) return fail(h, ECRAD_EUNSUPPORTED, "SPARTACUS: only nregions = 3 is implemented");
+    if (c.nregions != 3 && c.nregions != 2) return fail(h, ECRAD_EINVAL, "SPARTACUS: nregions must be 2 or 3");
+    // (two regions run through the three-region arrays with an empty third region, kernel_prep.hip; Tripleclouds always has three)
+    if (c.nregions == 2 && ((c.do_sw && c.i_solver_sw == ECRAD_SOLVER_TRIPLECLOUDS) || (c.do_lw && c.i_solver_lw == ECRAD_SOLVER_TRIPLECLOUDS)))
+      return fail(h, ECRAD_EUNSUPPORTED, "SPARTACUS with nregions = 2 in one spectrum and Tripleclouds in the other is not implemented");
     if (c.i_3d_sw_entrapment < ECRAD_ENTRAPMENT_ZERO || c.i_3d_sw_entrapment > ECRAD_ENTRAPMENT_MAXIMUM) return fail(h, ECRAD_EINVAL, "SPARTACUS: unknown entrapment option");
     if (c.i_precision != ECRAD_PRECISION_DOUBLE && c.i_precision != ECRAD_PRECISION_SINGLE) return fail(h, ECRAD_EINVAL, "unknown i_precision");
     if (!c.do_clouds) return fail(h, ECRAD_EINVAL, "SPARTACUS needs do_clouds");
@@ -1332,7 +1335,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
   if (col_order_sw && col_order_sw != col_order_lw) HIP_TRY(h, launch_column_order(stream, h->dcfg, din, col_order_sw, win_sw));
   if (sw_tc || lw_tc || sw_sp || lw_sp)
     HIP_TRY(h, launch_tripleclouds_prep(stream, h->dcfg, din, prep, (sw_tc || sw_sp) ? dfx.cloud_cover_sw : nullptr,
-                                        (lw_tc || lw_sp) ? dfx.cloud_cover_lw : nullptr));
+                                        (lw_tc || lw_sp) ? dfx.cloud_cover_lw : nullptr, (sw_sp || lw_sp) && c.nregions == 2));
   // SPARTACUS: the optics of a spectrum go through the stage arrays (radiation_interface.F90:260-301) that
   // optics_dump_kernel writes; the solver kernels read them (kernel_spartacus.hip)
   auto run_spartacus = [&](bool is_sw) -> int {

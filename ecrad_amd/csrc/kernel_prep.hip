@@ -132,8 +132,12 @@ ECRAD_DEV void beta_overlap_matrix(const double* op, const double* fu, const dou
   for (int r = 0; r < 3; ++r) M[r + 3 * r] += oxf[r];
 }
 
+// two_regions (SPARTACUS with config%nregions = 2, radiation_regions.F90:105-110, radiation_overlap.F90:169-175): one
+// homogeneous cloudy region.  It runs through the three-region arrays with an empty third region: its fraction is
+// exactly zero, so every overlap-matrix entry, lateral transfer rate and Planck term that involves it is exactly zero and
+// the sums over regions of the solver kernels pick up zeros -- the arithmetic of the two real regions is the reference's.
 __global__ void tripleclouds_prep_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevCloudPrep prep,
-                                        double* cloud_cover_sw, double* cloud_cover_lw) {
+                                        double* cloud_cover_sw, double* cloud_cover_lw, int two_regions) {
   const DevConfig& cfg = *cfgp;
   const int nloc = in.iendcol - in.istartcol + 1;
   // (one wave per block; a lane past the last column works on the last column and stores nothing of its own: the records of
@@ -166,6 +170,7 @@ __global__ void tripleclouds_prep_kernel(const DevConfig* __restrict__ cfgp, Dev
       const double cf = fracv.p[fracv.stride * ord.full(jlev - 1)], fsd = in.cloud_fractional_std[o];
       double os2, os3;
       if (cf < thr) { fl[0] = 1.0; fl[1] = 0.0; fl[2] = 0.0; os2 = 1.0; os3 = 1.0; }
+      else if (two_regions) { fl[0] = 1.0 - cf; fl[1] = cf; fl[2] = 0.0; os2 = 1.0; os3 = 1.0; }
       else if (!do_gamma) {
         fl[0] = 1.0 - cf; fl[1] = cf * 0.5; fl[2] = cf * 0.5;
         os2 = exp(-sqrt(log(fsd * fsd + 1.0))) / sqrt(fsd * fsd + 1.0);
@@ -194,7 +199,16 @@ __global__ void tripleclouds_prep_kernel(const DevConfig* __restrict__ cfgp, Dev
       if (op[0] >= 0.0) op[1] = op[2] = pow(op[0], 1.0 / cfg.cloud_inhom_decorr_scaling);
       else op[1] = op[2] = op[0];
     }
-    if (cfg.use_beta_overlap) beta_overlap_matrix(op, fu, fl, thr, M);
+    if (cfg.use_beta_overlap) beta_overlap_matrix(op, fu, fl, thr, M);      // (generic in the regions: an empty one contributes zeros)
+    else if (two_regions) {
+      const double cf_upper = fu[1], cf_lower = fl[1];
+      const double pair_cloud_cover = op[0] * dmax(cf_upper, cf_lower) + (1.0 - op[0]) * (cf_upper + cf_lower - cf_upper * cf_lower);
+      for (int i = 0; i < 9; ++i) M[i] = 0.0;
+      M[0] = 1.0 - pair_cloud_cover;
+      M[0 + 3 * 1] = pair_cloud_cover - cf_upper;
+      M[1 + 3 * 0] = pair_cloud_cover - cf_lower;
+      M[1 + 3 * 1] = cf_upper + cf_lower - pair_cloud_cover;
+    }
     else alpha_overlap_matrix(op[0], op[1], fu, fl, M);
     const size_t oh = (size_t)(jlev - 1) * nloc + cloc;
     const size_t stride = (size_t)(nlev + 1) * nloc;
@@ -232,9 +246,9 @@ __global__ void tripleclouds_prep_kernel(const DevConfig* __restrict__ cfgp, Dev
 }
 
 hipError_t launch_tripleclouds_prep(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevCloudPrep& prep,
-                                    double* cc_sw, double* cc_lw) {
+                                    double* cc_sw, double* cc_lw, bool two_regions) {
   const int nloc = in.iendcol - in.istartcol + 1;
-  hipLaunchKernelGGL(tripleclouds_prep_kernel, dim3((nloc + 63) / 64), dim3(64), 0, st, cfg, in, prep, cc_sw, cc_lw);
+  hipLaunchKernelGGL(tripleclouds_prep_kernel, dim3((nloc + 63) / 64), dim3(64), 0, st, cfg, in, prep, cc_sw, cc_lw, two_regions ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -171,6 +171,7 @@ struct Geo {
 struct SpConfig {
   int32_t ng, nb, do_clear, do_3d_effects, i_3d_sw_entrapment, do_3d_lw_multilayer_effects, do_lw_side_emissivity, use_expm_everywhere;
   int32_t do_lw_aerosol_scattering, do_lw_cloud_scattering, do_lw_derivatives, wide;
+  int32_t nregions;      // 3, or 2: the third region is empty then (tripleclouds_prep_kernel)
   // Spectra wider than 64 g-points run as several launches ("chunks", as in the other solvers): this launch covers
   // g-points g0 .. g0+ngl-1, lane = g0 + its index in the column group.  The stage arrays and per-g outputs are indexed
   // by the true g-point, the layer store by the index within the chunk (stride ngl); the sums over g are partial and go
@@ -212,6 +213,8 @@ ECRAD_DEV bool edge_lengths(const SpConfig& c, const DevInputs& in, const LevelO
   const size_t o = col + (size_t)in.ncol * ord.full(jl);
   const R ics = R(in.cloud_inv_cloud_effective_size[o]);
   if (!(ics > R(0))) return false;
+  // (two regions: no 3-D effects in an overcast layer, radiation_spartacus_sw.F90:499-500; region 2 holds the cloud fraction then)
+  if (c.nregions == 2 && gm.rf(1, jl) > 1.0 - c.cloud_fraction_threshold) return false;
   const R four_over_pi = R(4.0 / kPi);
   const R inv_min = R(1) / R(c.min_cloud_effective_size);
   const R rf0 = R(gm.rf(0, jl)), rf2 = R(gm.rf(2, jl));
@@ -326,6 +329,7 @@ ECRAD_DEV M3<R> entrapment_exchange(const SpConfig& c, const R (&rate)[9], R xx,
 #pragma unroll
     for (int k = 0; k < 9; ++k) e.a[k] = e.a[k] * s;
   }
+  if (c.nregions == 2) return sp::fast_expm_exchange_2<R>(e(1, 0), e(0, 1));      // radiation_spartacus_sw.F90:1184-1186
   return sp::fast_expm_exchange_3<R>(e(1, 0), e(0, 1), e(2, 1), e(1, 2));
 }
 
@@ -1452,7 +1456,7 @@ hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, int grid
   s.max_cloud_od = c.max_cloud_od; s.max_3d_transfer_rate = c.max_3d_transfer_rate; s.max_gas_od_3d = c.max_gas_od_3d;
   s.min_cloud_effective_size = c.min_cloud_effective_size; s.overhang_factor = c.overhang_factor;
   s.clear_to_thick_fraction = c.clear_to_thick_fraction; s.overhead_sun_factor = c.overhead_sun_factor;
-  s.cloud_fraction_threshold = c.cloud_fraction_threshold;
+  s.cloud_fraction_threshold = c.cloud_fraction_threshold; s.nregions = c.nregions;
   s.i_band_from_reordered_g = d_i_band_from_reordered_g;
   s.g0 = g0; s.ngl = std::min(ngp, s.ng - g0); s.wide = wide ? 1 : 0;
   a.in = in; a.op = op; a.prep = prep; a.fx = fx; a.scratch = scratch; a.per_block = per_block_words; a.counter = counter;

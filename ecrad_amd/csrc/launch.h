@@ -49,7 +49,7 @@ hipError_t launch_order(hipStream_t st, const DevInputs& in, int32_t* flag);
 hipError_t launch_crop(hipStream_t st, const DevConfig* cfg, const DevInputs& in);
 hipError_t launch_column_order(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int32_t* order, int window);
 hipError_t launch_tripleclouds_prep(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevCloudPrep& prep,
-                                    double* cc_sw, double* cc_lw);
+                                    double* cc_sw, double* cc_lw, bool two_regions);
 hipError_t launch_mcica_generator(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int ng, int seed_offset,
                                   double* od_scaling, double* tcc, int* counter);
 hipError_t launch_mcica_generator_vec(hipStream_t st, const DevConfig* cfg, const DevInputs& in, int ng, int seed_offset,

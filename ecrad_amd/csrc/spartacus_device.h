@@ -294,6 +294,21 @@ SP_DEV void expm(R (&A)[M * M]) {
   }
 }
 
+// fast_expm_exchange_2 (:913-936): exp of (-a b; a -b) by Putzer's algorithm, as the top-left block of a 3 x 3 matrix whose
+// third region does not take part
+template <typename R>
+SP_DEV M3<R> fast_expm_exchange_2(R a, R b) {
+  const R factor = (R(1) - sp_exp(-(a + b))) / rmax(R(1.0e-12), a + b);
+  M3<R> Rm;
+  Rm.zero();
+  Rm(0, 0) = R(1) - factor * a;
+  Rm(1, 0) = factor * a;
+  Rm(0, 1) = factor * b;
+  Rm(1, 1) = R(1) - factor * b;
+  Rm(2, 2) = R(1);
+  return Rm;
+}
+
 // fast_expm_exchange_3 (:952-1028): exp of (-a b 0; a -b-c d; 0 c -d), with diag_mat_right_divide_3 (:570-631)
 template <typename R> SP_DEV R sign_of(R a, R b) { return b >= R(0) ? sp_abs(a) : -sp_abs(a); }
 template <typename R>

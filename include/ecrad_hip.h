@@ -247,7 +247,7 @@ typedef struct ecrad_config {
   int32_t i_liq_model, i_ice_model;      /* radiation_config.F90:109-126 (ILiquidModel*, IIceModel*) */
   int32_t do_fu_lw_ice_optics_bug, reserved2_;
   /* SPARTACUS (i_solver_* == ECRAD_SOLVER_SPARTACUS), radiation_config.F90:226-260,268,341-411 */
-  int32_t nregions;                    /* 3 (2 is not implemented) */
+  int32_t nregions;                    /* SPARTACUS: 3 or 2 (radiation_config.F90:268); Tripleclouds always has 3 */
   int32_t i_3d_sw_entrapment;          /* ECRAD_ENTRAPMENT_* */
   int32_t do_3d_effects, do_3d_lw_multilayer_effects, do_lw_side_emissivity, use_expm_everywhere;
   int32_t i_precision;                 /* ECRAD_PRECISION_*: arithmetic of the SPARTACUS solver kernels */

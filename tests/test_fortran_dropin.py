@@ -327,6 +327,55 @@ def test_gpu_dropin_against_the_reference_executable_on_synthetic_ifs_shaped_col
     print(workload, "4096 synthetic columns, GPU drop-in vs reference executable: max", worst)
 
 
+# ---- SPARTACUS with two regions (config%nregions = 2, radiation_config.F90:268) ---------------------------------------------------
+_SP2 = {"sw_solver_name": '"SPARTACUS"', "lw_solver_name": '"SPARTACUS"', "n_regions": "2"}
+TWO_REGION_CASES = {
+    # name: (namelist family, edits, spectra compared)
+    "ecckd_1d": ({}, dict(_SP2, do_3d_effects="false"), ("sw", "lw")),
+    "rrtmg_1d": (RRTMG, dict(_SP2, do_3d_effects="false", do_sw_delta_scaling_with_gases="false"), ("sw", "lw")),
+    "ecckd_1d_beta_overlap": ({}, dict(_SP2, do_3d_effects="false", use_beta_overlap="true"), ("sw", "lw")),
+    "ecckd_3d_explicit_entrapment": ({}, dict(_SP2, do_3d_effects="true"), ("sw",)),
+    "rrtmg_3d_maximum_entrapment": (RRTMG, dict(_SP2, do_3d_effects="true", sw_entrapment_name='"Maximum"',
+                                                do_sw_delta_scaling_with_gases="false"), ("sw",)),
+    "ecckd_3d_zero_entrapment": ({}, dict(_SP2, do_3d_effects="true", sw_entrapment_name='"Zero"'), ("sw",)),
+}
+
+
+@both_exes
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(TWO_REGION_CASES))
+def test_gpu_dropin_against_the_reference_executable_with_two_spartacus_regions(tmp_path, case):
+    """config%nregions = 2 (one homogeneous cloudy region: radiation_regions.F90:105-110, radiation_overlap.F90:169-175,
+    radiation_spartacus_sw.F90:499, :1184): the reference's offline executable on this box's CPU against the same executable
+    with the drop-in, every variable of the two double-precision output files.  The HIP kernels run two regions through their
+    three-region arrays with an empty third region (kernel_prep.hip: tripleclouds_prep_kernel).
+
+    With 3-D effects the LONGWAVE of the reference itself is not usable at nregions = 2: radiation_spartacus_lw.F90:509-520 tests
+    edge_length(3,jlev), which only the nregions > 2 branch (:457) assigns, and then stores into transfer_rate(1,3) / (3,1) of
+    a 2 x 2 array -- the unmodified reference returns longwave fluxes of 1e27 W m-2 on the test/ifs profiles.  Those cases
+    compare the shortwave variables (the same statements exist at radiation_spartacus_sw.F90:583-597; there the reference's
+    output is finite and is reproduced) and check that the drop-in's longwave fluxes are physical."""
+    family, edits, spectra = TWO_REGION_CASES[case]
+    nam = str(tmp_path / f"config_{case}.nam")
+    write_namelist(nam, family, edits)
+    _double_precision_output(nam)
+    outs = _run_both(tmp_path, nam, MERIDIAN)
+    worst = {}
+    with NcFile(outs["hip"]) as h, NcFile(outs["ref"]) as r:
+        names = list(r._f.variables)
+        assert len(names) >= 20 and sorted(names) == sorted(h._f.variables)
+        for v in names:
+            a, b = h.get(v), r.get(v)
+            assert a.shape == b.shape, v
+            if "lw" in v and "lw" not in spectra:
+                assert np.all(np.isfinite(a)) and (v == "lw_derivatives" or (a.min() >= 0.0 and a.max() < 1000.0)), v
+                continue
+            worst[v] = rel_err(a, b)
+    bad = {k: e for k, e in worst.items() if not e < 1.0e-6}
+    assert not bad, bad
+    print(case, "two regions, GPU drop-in vs reference executable: max", max(worst.values()))
+
+
 # ---- the reference's two other test directories through the two executables ---------------------------------------------
 def _suite_namelist(src, dst, radiation_edits=None, driver_edits=None):
     text = open(src).read()
