@@ -4,9 +4,9 @@
 //   RRTM_PREPARE_GASES, RRTM_SETCOEF_140GP, SRTM_SETCOEF, RRTM_TAUMOL1-16, SRTM_TAUMOL16-29 (ifsrrtm/)
 // The physics lives in rrtmg_device.h (descriptor-driven, one evaluator per spectrum); this file maps it to
 // the GPU in three kernels:
-//   rrtmg_setcoef_kernel   lane = column (the caller's arrays are column-fastest: coalesced), levels in
-//                          sequence from the surface: per-layer interpolation records, the tropopause
-//                          counts and, per shortwave band, the level of the solar source term;
+//   rrtmg_setcoef_kernel   thread = (column, layer), columns across the lanes (the caller's arrays are column-fastest:
+//                          coalesced): per-layer interpolation records;
+//   rrtmg_laytrop_kernel   lane = column: the tropopause counts and, per shortwave band, the level of the solar source term;
 //   rrtmg_taumol_kernel    block = (one level, 64 columns), whose setcoef records are staged in LDS once; the 30
 //                          bands in turn, lanes = (g-point of the band, column), the lower/upper-atmosphere
 //                          regimes one after the other so that a wave always runs ONE descriptor; writes
@@ -32,49 +32,65 @@ struct RecView {
   ECRAD_DEV int i(int f) const { return i_[(size_t)f * stride + off]; }
 };
 
+// block = 64 columns x kSetcoefLevels levels, thread = one (column, layer): the records of a layer only need that layer
+// (a lane per column walking its 137 levels left the GPU at 1.5 waves per SIMD: 16 ms per 100 000 columns, profiles/r03_n_mcica_rrtmg.md)
+constexpr int kSetcoefLevels = kBlock / 64;
 __global__ __launch_bounds__(kBlock) void rrtmg_setcoef_kernel(const DevRrtmg* __restrict__ Tp, DevInputs in, RrtmgWork w, int do_lw, int do_sw) {
   const DevRrtmg& T = *Tp;
   const int nloc = in.iendcol - in.istartcol + 1, nlev = in.nlev;
-  const int cloc = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cloc >= nloc) return;
+  const int cloc = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int lev = blockIdx.y * kSetcoefLevels + (threadIdx.x >> 6);
+  if (cloc >= nloc || lev >= nlev) return;
   const int col = in.istartcol - 1 + cloc;
   const size_t ncol = in.ncol;
   const LevelOrder ord = level_order(in);
   const size_t stride = (size_t)nlev * nloc;
   const bool sunlit = do_sw && in.cos_sza[col] > 0.0;
-  int laytrop_lw = 0, laytrop_sw = 0;
   auto gasmr = [&](int code, int clev) { return in.gas_mixing_ratio[col + ncol * (clev + (size_t)nlev * (code - 1))]; };
-  for (int k = 1; k <= nlev; ++k) {
-    const int lev = nlev - k;
-    const int clev = ord.full(lev);
-    LayerIn li;
-    li.p_top = in.pressure_hl[col + ncol * ord.half(lev)];
-    li.p_bot = in.pressure_hl[col + ncol * ord.half(lev + 1)];
-    li.t_top = in.temperature_hl[col + ncol * ord.half(lev)];
-    li.t_bot = in.temperature_hl[col + ncol * ord.half(lev + 1)];
-    li.q = gasmr(ECRAD_IH2O, clev); li.co2 = gasmr(ECRAD_ICO2, clev); li.o3 = gasmr(ECRAD_IO3, clev);
-    li.n2o = gasmr(ECRAD_IN2O, clev); li.ch4 = gasmr(ECRAD_ICH4, clev);
-    li.cfc11 = gasmr(ECRAD_ICFC11, clev); li.cfc12 = gasmr(ECRAD_ICFC12, clev);
-    li.hcfc22 = gasmr(ECRAD_IHCFC22, clev); li.ccl4 = gasmr(ECRAD_ICCL4, clev);
-    const Prepared p = prepare_layer(li);
-    const size_t off = (size_t)lev * nloc + cloc;
-    if (do_lw) {
-      const bool lower = log(p.pavel) > 4.56;
-      if (lower) laytrop_lw++;
-      LwLevel r;
-      setcoef_lw(T, p, lower, r);
-      for (int f = 0; f < LD_N; ++f) w.lw_d[(size_t)f * stride + off] = r.d[f];
-      for (int f = 0; f < LI_N; ++f) w.lw_i[(size_t)f * stride + off] = r.i[f];
-    }
-    if (sunlit) {
-      SwLevel r;
-      setcoef_sw(T, p, r);
-      if (r.i[SI_LOWER]) laytrop_sw++;
-      for (int f = 0; f < SD_N; ++f) w.sw_d[(size_t)f * stride + off] = r.d[f];
-      for (int f = 0; f < SI_N; ++f) w.sw_i[(size_t)f * stride + off] = r.i[f];
-    }
+  const int clev = ord.full(lev);
+  LayerIn li;
+  li.p_top = in.pressure_hl[col + ncol * ord.half(lev)];
+  li.p_bot = in.pressure_hl[col + ncol * ord.half(lev + 1)];
+  li.t_top = in.temperature_hl[col + ncol * ord.half(lev)];
+  li.t_bot = in.temperature_hl[col + ncol * ord.half(lev + 1)];
+  li.q = gasmr(ECRAD_IH2O, clev); li.co2 = gasmr(ECRAD_ICO2, clev); li.o3 = gasmr(ECRAD_IO3, clev);
+  li.n2o = gasmr(ECRAD_IN2O, clev); li.ch4 = gasmr(ECRAD_ICH4, clev);
+  li.cfc11 = gasmr(ECRAD_ICFC11, clev); li.cfc12 = gasmr(ECRAD_ICFC12, clev);
+  li.hcfc22 = gasmr(ECRAD_IHCFC22, clev); li.ccl4 = gasmr(ECRAD_ICCL4, clev);
+  const Prepared p = prepare_layer(li);
+  const size_t off = (size_t)lev * nloc + cloc;
+  // (the LOWER items hold this layer's own test here; rrtmg_laytrop_kernel turns them into the band routines' flag)
+  if (do_lw) {
+    const bool lower = log(p.pavel) > 4.56;
+    LwLevel r;
+    setcoef_lw(T, p, lower, r);
+    for (int f = 0; f < LD_N; ++f) w.lw_d[(size_t)f * stride + off] = r.d[f];
+    for (int f = 0; f < LI_N; ++f) w.lw_i[(size_t)f * stride + off] = r.i[f];
   }
-  // "lower atmosphere" as the band routines decide it: the first laytrop layers from the surface
+  if (sunlit) {
+    SwLevel r;
+    setcoef_sw(T, p, r);
+    for (int f = 0; f < SD_N; ++f) w.sw_d[(size_t)f * stride + off] = r.d[f];
+    for (int f = 0; f < SI_N; ++f) w.sw_i[(size_t)f * stride + off] = r.i[f];
+  }
+}
+
+// lane = column: the tropopause counts (laytrop = number of layers that pass the test), "lower atmosphere" as the band
+// routines decide it -- the first laytrop layers from the surface -- and, per shortwave band, the level of the solar source term
+__global__ __launch_bounds__(kBlock) void rrtmg_laytrop_kernel(const DevRrtmg* __restrict__ Tp, DevInputs in, RrtmgWork w, int do_lw, int do_sw) {
+  const DevRrtmg& T = *Tp;
+  const int nloc = in.iendcol - in.istartcol + 1, nlev = in.nlev;
+  const int cloc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cloc >= nloc) return;
+  const int col = in.istartcol - 1 + cloc;
+  const size_t stride = (size_t)nlev * nloc;
+  const bool sunlit = do_sw && in.cos_sza[col] > 0.0;
+  int laytrop_lw = 0, laytrop_sw = 0;
+  for (int lev = 0; lev < nlev; ++lev) {
+    const size_t off = (size_t)lev * nloc + cloc;
+    if (do_lw) laytrop_lw += w.lw_i[(size_t)LI_LOWER * stride + off];
+    if (sunlit) laytrop_sw += w.sw_i[(size_t)SI_LOWER * stride + off];
+  }
   for (int k = 1; k <= nlev; ++k) {
     const size_t off = (size_t)(nlev - k) * nloc + cloc;
     if (do_lw) w.lw_i[(size_t)LI_LOWER * stride + off] = k <= laytrop_lw ? 1 : 0;
@@ -453,7 +469,8 @@ hipError_t launch_rrtmg_gas_optics(hipStream_t st, const DevRrtmg* tables, const
     if (e != hipSuccess) return e;
   }
   const dim3 tiles((nloc + kTileCols - 1) / kTileCols, nlev);
-  hipLaunchKernelGGL(rrtmg_setcoef_kernel, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, st, tables, in, w, do_lw ? 1 : 0, do_sw ? 1 : 0);
+  hipLaunchKernelGGL(rrtmg_setcoef_kernel, dim3((nloc + 63) / 64, (nlev + kSetcoefLevels - 1) / kSetcoefLevels), dim3(kBlock), 0, st, tables, in, w, do_lw ? 1 : 0, do_sw ? 1 : 0);
+  hipLaunchKernelGGL(rrtmg_laytrop_kernel, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, st, tables, in, w, do_lw ? 1 : 0, do_sw ? 1 : 0);
   hipStream_t ssw = st;
   if (split) {
     hipError_t e = hipEventRecord(ev_records, st);
