@@ -44,7 +44,7 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 T
 HBM_TRIAD_GBS = None       # measured on THIS box when the first workload is set up (ecrad_hip_hbm_triad: a = b + s c, 3 x 1 GiB)
 FP64_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (MI355X_MICROARCH.md quotes the FP32 vector peak, 157.3 = 2 x this)
 PARITY_TOLERANCE = 1.0e-6  # BASELINE.json north_star: fluxes within 1e-6 relative of the CPU reference
-EXTRA_WORKLOADS = (("tripleclouds_ecckd32", 100000), ("mcica_rrtmg", 100000), ("tripleclouds_ecckd64", 1250000),
+EXTRA_WORKLOADS = (("tripleclouds_ecckd32", 100000), ("mcica_ecckd32", 100000), ("mcica_rrtmg", 100000), ("tripleclouds_ecckd64", 1250000),
                    ("spartacus_ecckd32_sp", 100000), ("spartacus_ecckd32_sp", 1250000))
 CHUNK_COLUMNS = 125000     # synthetic columns are generated and uploaded this many at a time (bounds host memory)
 
