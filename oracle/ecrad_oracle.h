@@ -74,6 +74,10 @@ void oracle_cum_cloud_cover_max_ran(int nlev, const double* frac,
 void oracle_calc_region_properties(int nlev, int do_gamma, const double* cloud_fraction,
      const double* frac_std, double frac_threshold, double* reg_fracs /* (3,nlev) */,
      double* od_scaling /* (2,nlev): regions 2..3 */);                                /* regions:35 */
+void oracle_calc_region_properties_2(int nlev, const double* cloud_fraction, double frac_threshold, double* reg_fracs, double* od_scaling);
+void oracle_calc_overlap_matrices_n(int nreg, int nlev, const double* region_fracs, const double* overlap_param,
+     double decorrelation_scaling, double frac_threshold, int use_beta_overlap,
+     double* u_matrix, double* v_matrix, double* cloud_cover);
 void oracle_calc_overlap_matrices(int nlev, const double* region_fracs /* (3,nlev) */,
      const double* overlap_param /* (nlev-1) */, double decorrelation_scaling,
      double frac_threshold, int use_beta_overlap,

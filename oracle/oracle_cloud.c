@@ -57,6 +57,23 @@ void oracle_cum_cloud_cover_exp_ran(int nlev, const double* frac, const double* 
   }
 }
 
+/* Two regions (config%nregions = 2, SPARTACUS only): the arrays keep their three-region shape and the third region is
+ * EMPTY -- fraction exactly zero, so its rows and columns of the overlap matrices, its edge lengths, transfer rates and
+ * Planck terms are exactly zero and the sums over regions pick up zeros; the two real regions get the reference's
+ * nreg == 2 statements (radiation_regions.F90:105-110, radiation_overlap.F90:169-175).  The restatement is pinned against
+ * the reference's own executable run with n_regions = 2 (tests/test_oracle_two_regions.py). */
+void oracle_calc_region_properties_2(int nlev, const double* cloud_fraction, double frac_threshold, double* reg_fracs, double* od_scaling)
+{
+  for (int l = 0; l < nlev; ++l) {
+    double* rf = reg_fracs + 3 * l;
+    double* os = od_scaling + 2 * l;
+    const double cf = cloud_fraction[l];
+    if (cf < frac_threshold) { rf[0] = 1.0; rf[1] = 0.0; rf[2] = 0.0; }
+    else { rf[0] = 1.0 - cf; rf[1] = cf; rf[2] = 0.0; }
+    os[0] = 1.0; os[1] = 1.0;
+  }
+}
+
 /* radiation_regions.F90:35-199, nreg == 3.  reg_fracs(3,nlev), od_scaling(2,nlev) [regions 2,3] */
 void oracle_calc_region_properties(int nlev, int do_gamma, const double* cloud_fraction,
      const double* frac_std, double frac_threshold, double* reg_fracs, double* od_scaling)
@@ -134,8 +151,22 @@ static void calc_alpha_overlap_matrix(double op, double op_inhom, const double* 
 #undef OM
 }
 
-/* radiation_overlap.F90:280-457, single column.  u/v_matrix(3,3,nlev+1), first index fastest. */
-void oracle_calc_overlap_matrices(int nlev, const double* region_fracs, const double* overlap_param,
+/* radiation_overlap.F90:130-175, nreg == 2, in the top-left block of a zero 3 x 3 matrix */
+static void calc_alpha_overlap_matrix_2(double op, const double* frac_upper, const double* frac_lower, double* M)
+{
+  const double cf_upper = frac_upper[1], cf_lower = frac_lower[1];
+  const double pair_cloud_cover = op * dmax(cf_upper, cf_lower)
+      + (1.0 - op) * (cf_upper + cf_lower - cf_upper * cf_lower);
+  for (int i = 0; i < 9; ++i) M[i] = 0.0;
+  M[0 + 3 * 0] = 1.0 - pair_cloud_cover;
+  M[0 + 3 * 1] = pair_cloud_cover - cf_upper;
+  M[1 + 3 * 0] = pair_cloud_cover - cf_lower;
+  M[1 + 3 * 1] = cf_upper + cf_lower - pair_cloud_cover;
+}
+
+/* radiation_overlap.F90:280-457, single column.  u/v_matrix(3,3,nlev+1), first index fastest.  nreg = 3, or 2 with the third
+ * region empty (see oracle_calc_region_properties_2) */
+void oracle_calc_overlap_matrices_n(int nreg, int nlev, const double* region_fracs, const double* overlap_param,
      double decorrelation_scaling, double frac_threshold, int use_beta_overlap,
      double* u_matrix, double* v_matrix, double* cloud_cover)
 {
@@ -150,6 +181,7 @@ void oracle_calc_overlap_matrices(int nlev, const double* region_fracs, const do
       else op[1] = op[2] = op[0];
     }
     if (use_beta_overlap) calc_beta_overlap_matrix(op, frac_upper, frac_lower, frac_threshold, M);
+    else if (nreg == 2) calc_alpha_overlap_matrix_2(op[0], frac_upper, frac_lower, M);
     else calc_alpha_overlap_matrix(op[0], op[1], frac_upper, frac_lower, M);
     double* U = u_matrix + 9 * (jlev - 1);
     double* V = v_matrix + 9 * (jlev - 1);
@@ -165,6 +197,14 @@ void oracle_calc_overlap_matrices(int nlev, const double* region_fracs, const do
     for (int jlev = 0; jlev <= nlev; ++jlev) prod *= v_matrix[9 * jlev];
     *cloud_cover = 1.0 - prod;
   }
+}
+
+void oracle_calc_overlap_matrices(int nlev, const double* region_fracs, const double* overlap_param,
+     double decorrelation_scaling, double frac_threshold, int use_beta_overlap,
+     double* u_matrix, double* v_matrix, double* cloud_cover)
+{
+  oracle_calc_overlap_matrices_n(3, nlev, region_fracs, overlap_param, decorrelation_scaling, frac_threshold, use_beta_overlap,
+                                 u_matrix, v_matrix, cloud_cover);
 }
 
 /* radiation_cloud_cover.F90:339-623: Exp-Exp overlap with "concave cloud objects" merged in order of

@@ -132,7 +132,10 @@ int ecrad_oracle_radiation(const ecrad_config_t* c, int ncol, int nlev, int ista
   if ((c->do_sw && c->i_gas_model_sw == ECRAD_GAS_MONOCHROMATIC) || (c->do_lw && c->i_gas_model_lw == ECRAD_GAS_MONOCHROMATIC))
     return ECRAD_EUNSUPPORTED;
   if ((c->do_sw && c->i_solver_sw == ECRAD_SOLVER_SPARTACUS) || (c->do_lw && c->i_solver_lw == ECRAD_SOLVER_SPARTACUS)) {
-    if (c->nregions != 3) return ECRAD_EUNSUPPORTED;
+    if (c->nregions != 3 && c->nregions != 2) return ECRAD_EINVAL;
+    /* (two regions = an empty third region, oracle_cloud.c; Tripleclouds always has three: the geometry is per column, not per spectrum) */
+    if (c->nregions == 2 && ((c->do_sw && c->i_solver_sw == ECRAD_SOLVER_TRIPLECLOUDS) || (c->do_lw && c->i_solver_lw == ECRAD_SOLVER_TRIPLECLOUDS)))
+      return ECRAD_EUNSUPPORTED;
     if (c->do_sw && c->i_solver_sw == ECRAD_SOLVER_SPARTACUS && c->do_sw_delta_scaling_with_gases) return ECRAD_EINVAL;
   }
   if (in->pressure_hl[(size_t)(istartcol - 1) + (size_t)ncol] < in->pressure_hl[istartcol - 1]) return ECRAD_EUNSUPPORTED;

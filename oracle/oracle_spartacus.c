@@ -157,6 +157,8 @@ static int layer_transfer_rates(const ecrad_config_t* c, int ncol, int nlev, int
   if (!(c->do_3d_effects && in->cloud_inv_cloud_effective_size)) return 0;
   const real_t ics = (real_t)FL(in->cloud_inv_cloud_effective_size, jcol, jlev);
   if (!(ics > 0)) return 0;
+  /* two regions: no 3-D effects in an overcast layer (radiation_spartacus_sw.F90:499-500; region 2 holds the cloud fraction) */
+  if (c->nregions == 2 && RF(1, jlev) > 1.0 - c->cloud_fraction_threshold) return 0;
   const real_t inv_min = (real_t)1 / (real_t)c->min_cloud_effective_size;
   edge_length[0] = four_over_pi * RF(0, jlev) * ((real_t)1 - RF(0, jlev)) * rmin(ics, inv_min);
   const real_t iis = in->cloud_inv_inhom_effective_size ? (real_t)FL(in->cloud_inv_inhom_effective_size, jcol, jlev) : ics;
@@ -281,6 +283,19 @@ static void entrapment_exchange(const ecrad_config_t* c, int ng, const real_t* r
   }
   real_t *a = w4, *b = w4 + ng, *cc = w4 + 2 * ng, *d = w4 + 3 * ng;
   for (int g = 0; g < ng; ++g) { a[g] = M3(entrapment, g, 1, 0); b[g] = M3(entrapment, g, 0, 1); cc[g] = M3(entrapment, g, 2, 1); d[g] = M3(entrapment, g, 1, 2); }
+  if (c->nregions == 2) {      /* radiation_spartacus_sw.F90:1184-1186: the 2 x 2 exchange in the top-left block, the empty region left alone */
+    real_t* r2 = entrapment;      /* (ng,2,2), element (g,r,c) at g + ng (r + 2 c); a and b have been taken out of `entrapment` */
+    om_fast_expm_exchange_2(ng, ng, a, b, r2);
+    for (size_t k = 0; k < (size_t)ng * 9; ++k) albedo_part[k] = 0;
+    for (int g = 0; g < ng; ++g) {
+      M3(albedo_part, g, 0, 0) = r2[g + (size_t)ng * (0 + 2 * 0)];
+      M3(albedo_part, g, 1, 0) = r2[g + (size_t)ng * (1 + 2 * 0)];
+      M3(albedo_part, g, 0, 1) = r2[g + (size_t)ng * (0 + 2 * 1)];
+      M3(albedo_part, g, 1, 1) = r2[g + (size_t)ng * (1 + 2 * 1)];
+      M3(albedo_part, g, 2, 2) = 1;
+    }
+    return;
+  }
   om_fast_expm_exchange_3(ng, ng, a, b, cc, d, albedo_part);
 }
 

@@ -46,10 +46,14 @@ void oracle_column_cloud_geometry(const ecrad_config_t* c, int ncol, int nlev, i
   double *frac = colbuf, *fsd = colbuf + nlev, *ovp = colbuf + 2 * nlev;
   for (int l = 0; l < nlev; ++l) { frac[l] = FL(in->cloud_fraction, jcol, l); fsd[l] = FL(in->cloud_fractional_std, jcol, l); }
   for (int l = 0; l < nlev - 1; ++l) ovp[l] = FL(in->cloud_overlap_param, jcol, l);
-  oracle_calc_region_properties(nlev, c->i_cloud_pdf_shape == ECRAD_PDF_GAMMA, frac, fsd,
-                                c->cloud_fraction_threshold, region_fracs, od_scaling);
-  oracle_calc_overlap_matrices(nlev, region_fracs, ovp, c->cloud_inhom_decorr_scaling,
-                               c->cloud_fraction_threshold, c->use_beta_overlap, u_matrix, v_matrix, cloud_cover);
+  /* (config%nregions only applies to SPARTACUS: radiation_tripleclouds_sw.F90:65 has nregions = 3 as a parameter) */
+  const int spartacus = (c->do_sw && c->i_solver_sw == ECRAD_SOLVER_SPARTACUS) || (c->do_lw && c->i_solver_lw == ECRAD_SOLVER_SPARTACUS);
+  const int nreg = (spartacus && c->nregions == 2) ? 2 : 3;
+  if (nreg == 2) oracle_calc_region_properties_2(nlev, frac, c->cloud_fraction_threshold, region_fracs, od_scaling);
+  else oracle_calc_region_properties(nlev, c->i_cloud_pdf_shape == ECRAD_PDF_GAMMA, frac, fsd,
+                                     c->cloud_fraction_threshold, region_fracs, od_scaling);
+  oracle_calc_overlap_matrices_n(nreg, nlev, region_fracs, ovp, c->cloud_inhom_decorr_scaling,
+                                 c->cloud_fraction_threshold, c->use_beta_overlap, u_matrix, v_matrix, cloud_cover);
 }
 
 /* =============================================================================================

@@ -51,6 +51,16 @@ CASES = {
     "spectral_bands": dict(do_save_spectral_flux=True, do_cloud_aerosol_per_sw_g_point=False, do_cloud_aerosol_per_lw_g_point=False),
     "spectral_noclear_no3d": dict(do_save_spectral_flux=True, do_clear=False, do_3d_effects=False),
     "sw96_tight_caps": dict(gas_optics_sw_override_file_name="ecckd-1.4_sw_climate_vfine-96b_ckd-definition.nc", max_gas_od_3d=0.5),
+    # config%nregions = 2 (one homogeneous cloudy region; the third region of the kernels' arrays stays empty).  The oracle's
+    # two-region path is checked against the reference's own executable in tests/test_oracle_vs_reference_build.py, the HIP path
+    # against that executable in tests/test_fortran_dropin.py; here the longwave with 3-D effects is covered as well (the
+    # reference's own is unusable at two regions)
+    "two_regions": dict(nregions=2),
+    "two_regions_no_3d": dict(nregions=2, do_3d_effects=False),
+    "two_regions_maximum": dict(nregions=2, i_3d_sw_entrapment=IEntrapmentMaximum),
+    "two_regions_explicit_non_fractal_clear_to_thick": dict(nregions=2, i_3d_sw_entrapment=IEntrapmentExplicitNonFractal, clear_to_thick_fraction=0.3),
+    "two_regions_lw_multilayer_beta": dict(nregions=2, do_3d_lw_multilayer_effects=True, use_beta_overlap=True),
+    "two_regions_spectral": dict(nregions=2, do_save_spectral_flux=True),
 }
 
 

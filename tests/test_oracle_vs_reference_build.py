@@ -80,3 +80,50 @@ def test_the_reference_executable_reproduces_its_own_golden_file(tmp_path):
         assert sorted(g._f.variables) == sorted(o._f.variables)
         for v in g._f.variables:
             assert rel_err(o.get(v), g.get(v)) < 2.0e-7, v
+
+
+# ---- SPARTACUS with two regions (config%nregions = 2) -------------------------------------------------------------------------
+_SP2 = {"sw_solver_name": '"SPARTACUS"', "lw_solver_name": '"SPARTACUS"', "n_regions": "2"}
+TWO_REGION_CASES = {
+    # name: (family, namelist edits, Python-host keywords, spectra compared, tolerance)
+    "ecckd_1d": ({}, dict(_SP2, do_3d_effects="false"), ("ecckd", dict(do_3d_effects=False)), ("sw", "lw"), 1.0e-9),
+    "ecckd_1d_beta_overlap": ({}, dict(_SP2, do_3d_effects="false", use_beta_overlap="true"),
+                              ("ecckd", dict(do_3d_effects=False, use_beta_overlap=True)), ("sw", "lw"), 1.0e-9),
+    "rrtmg_1d": (RRTMG, dict(_SP2, do_3d_effects="false", do_sw_delta_scaling_with_gases="false"),
+                 ("rrtmg", dict(do_3d_effects=False, do_sw_delta_scaling_with_gases=False)), ("sw", "lw"), 1.0e-9),
+    "ecckd_3d_explicit_entrapment": ({}, dict(_SP2, do_3d_effects="true"), ("ecckd", dict(do_3d_effects=True)), ("sw",), 1.0e-7),
+    "rrtmg_3d_maximum_entrapment": (RRTMG, dict(_SP2, do_3d_effects="true", sw_entrapment_name='"Maximum"', do_sw_delta_scaling_with_gases="false"),
+                                    ("rrtmg", dict(do_3d_effects=True, i_3d_sw_entrapment=4, do_sw_delta_scaling_with_gases=False)), ("sw",), 1.0e-8),
+}
+
+
+@pytest.mark.parametrize("case", sorted(TWO_REGION_CASES))
+def test_oracle_with_two_spartacus_regions_against_the_unmodified_reference_executable(tmp_path, case, oracle_lib):
+    """The oracle runs config%nregions = 2 as three regions of which the third is EMPTY (oracle/oracle_cloud.c:
+    oracle_calc_region_properties_2) -- the construction the HIP kernels use.  That it is the reference's two-region scheme is
+    checked here against the reference's own code run with n_regions = 2: every variable of its double-precision output file.
+    With 3-D effects only the shortwave: the reference's longwave is unusable at two regions (radiation_spartacus_lw.F90:509-519
+    reads the unassigned edge_length(3,jlev) and stores into transfer_rate(1,3) of a 2 x 2 array; it returns 1e27 W m-2 here)."""
+    family, edits, (fam, kw), spectra, tol = TWO_REGION_CASES[case]
+    if fam == "rrtmg" and not oracle_lib.have_ref_rrtm():
+        pytest.skip("oracle/_ref/libecrad_refrrtm.so (the reference's RRTMG routines) has not been built")
+    out = run_reference(tmp_path, case, family, edits)
+    kw = dict(do_save_spectral_flux=True, do_lw_aerosol_scattering=False, nregions=2, **kw)
+    cfg = make_config_rrtmg("SPARTACUS", **kw) if fam == "rrtmg" else make_config("SPARTACUS", **kw)
+    assert cfg.nregions == 2
+    flux, th, _ = run_case(cfg, oracle_lib.make_rrtmg_backend(cfg) if fam == "rrtmg" else oracle_lib.backend)
+    want = flux_to_output_dict(cfg, th, flux)
+    worst = {}
+    with NcFile(out) as o:
+        names = list(o._f.variables)
+        assert len(names) >= 20
+        for v in names:
+            if "lw" in v and "lw" not in spectra:
+                continue
+            assert v in want, f"{case}: the oracle's host does not produce {v}"
+            got, ref = o.get(v), np.asarray(want[v])
+            assert got.shape == ref.shape, (v, got.shape, ref.shape)
+            worst[v] = rel_err(ref, got)
+    bad = {k: e for k, e in worst.items() if not e < tol}
+    assert not bad, f"{case}: oracle vs the reference executable: {bad}"
+    print(case, "two regions, oracle vs reference executable: max", max(worst.values()))
