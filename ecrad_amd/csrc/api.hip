@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -42,6 +43,10 @@ struct ChunkPlan {
 };
 
 struct ecrad_hip_handle_s {
+  // The reference's radiation() is re-entrant and its driver calls it from an OpenMP PARALLEL DO over blocks of columns
+  // (driver/ecrad_driver.F90:348).  A handle owns one stream and one set of work arrays, so calls on a handle run one after
+  // the other: host threads may call concurrently, the calls queue here.
+  std::mutex call_mutex;
   int device = 0;
   hipStream_t stream = nullptr;
   // The McICA cloud generators need the cropped cloud fraction and nothing else, and are bound by integer instruction
@@ -706,6 +711,7 @@ int ecrad_hip_last_stage_ms(ecrad_hip_handle_t h, int which, double* ms) {
 // ----------------------------------------------------------------------------------------------------
 int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
   if (!h || !cp) return ECRAD_EINVAL;
+  const std::lock_guard<std::mutex> one_call_at_a_time(h->call_mutex);
   HIP_TRY(h, hipSetDevice(h->device));
   const ecrad_config_t& c = *cp;
   int st = validate_config(h, c);
@@ -1558,6 +1564,7 @@ extern "C" {
 int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
                         const ecrad_inputs_t* in, ecrad_flux_t* flux) {
   if (!h || !in || !flux) return ECRAD_EINVAL;
+  const std::lock_guard<std::mutex> one_call_at_a_time(h->call_mutex);
   if (!h->is_setup) return fail(h, ECRAD_ENOTSETUP, "ecrad_hip_setup has not been called");
   HIP_TRY(h, hipSetDevice(h->device));
   if (in->memory != flux->memory) return fail(h, ECRAD_EINVAL, "inputs and fluxes must live in the same memory space");
@@ -1631,6 +1638,7 @@ int ecrad_hip_last_call_info(ecrad_hip_handle_t h, ecrad_call_info_t* info) {
 int ecrad_hip_optics(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
                      const ecrad_inputs_t* in, ecrad_optics_t* out) {
   if (!h || !in || !out) return ECRAD_EINVAL;
+  const std::lock_guard<std::mutex> one_call_at_a_time(h->call_mutex);
   if (!h->is_setup) return fail(h, ECRAD_ENOTSETUP, "ecrad_hip_setup has not been called");
   HIP_TRY(h, hipSetDevice(h->device));
   const ecrad_config_t& c = h->cfg;

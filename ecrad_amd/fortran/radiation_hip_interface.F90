@@ -349,6 +349,10 @@ contains
     type(ecrad_inputs_t) :: cin
     type(ecrad_flux_t)   :: cfl
     if (.not. c_associated(hip_handle)) call radiation_hip_abort('*** Error: setup_radiation_hip not called')
+    ! radiation() is called from an OpenMP PARALLEL DO over blocks of columns in the reference's driver
+    ! (driver/ecrad_driver.F90:348) and from the IFS's threads: one call at a time per handle (the library queues them too;
+    ! this section also covers the copy pool of a single-precision host below)
+    !$omp critical (ecrad_hip_radiation_call)
     cin%memory = ECRAD_MEM_HOST
     cin%solar_irradiance = single_level%solar_irradiance
     cin%spectral_solar_cycle_multiplier = single_level%spectral_solar_cycle_multiplier
@@ -414,6 +418,7 @@ contains
     if (ecrad_hip_radiation(hip_handle, int(ncol,c_int), int(nlev,c_int), int(istartcol,c_int), int(iendcol,c_int), &
          &  cin, cfl) /= ECRAD_OK) call radiation_hip_abort('*** Error in ecrad_hip_radiation')
     call finish_copies()
+    !$omp end critical (ecrad_hip_radiation_call)
   end subroutine radiation_hip
 
   subroutine finalize_radiation_hip()

@@ -105,6 +105,39 @@ def test_reference_driver_with_the_dropin_reproduces_the_golden_file(tmp_path, n
     print(name, "drop-in driver vs golden file: max", max(worst.values()))
 
 
+OMP_EXE = os.path.join(ROOT, "tests", "_build", "dropin_omp", "ecrad_hip")
+
+
+@pytest.mark.skipif(not os.path.exists(OMP_EXE), reason="tests/_build/dropin_omp/ecrad_hip has not been built (tools/build_dropin.py --openmp)")
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["default", "tripleclouds", "ecckd_mcica"])
+def test_openmp_driver_threads_call_the_dropin_concurrently(tmp_path, name):
+    """The reference's radiation() is re-entrant and its driver calls it from `!$OMP PARALLEL DO` over blocks of columns
+    (driver/ecrad_driver.F90:348; SURVEY.md 8(b) "Threading").  Here that driver is compiled WITH OpenMP around the drop-in
+    (tools/build_dropin.py --openmp) and run on 4 threads with blocks of 3 columns: 11 calls of radiation(), up to 4 at once, on
+    the one handle -- they queue in the wrapper's critical section / the library's per-handle mutex -- and the output file
+    still equals the reference's golden file to float32 rounding."""
+    family, edits = TARGETS[name]
+    nam, out = str(tmp_path / f"config_{name}.nam"), str(tmp_path / f"ecrad_meridian_{name}_out.nc")
+    write_namelist(nam, family, edits)
+    text = open(nam).read()
+    assert len(re.findall(r"nblocksize\s*=\s*\d+", text)) == 1
+    open(nam, "w").write(re.sub(r"nblocksize\s*=\s*\d+", "nblocksize = 3", text))
+    env = dict(os.environ, OMP_NUM_THREADS="4", OMP_STACKSIZE="1G")
+    p = subprocess.run(f"ulimit -s unlimited; exec {OMP_EXE} {nam} {MERIDIAN} {out}", shell=True, capture_output=True, text=True,
+                       cwd=str(tmp_path), env=env, timeout=900)
+    assert p.returncode == 0 and os.path.exists(out), (p.stdout + p.stderr)[-3000:]
+    worst = {}
+    with NcFile(os.path.join(GOLDEN_DIR, f"ecrad_meridian_{name}_out_REFERENCE.nc")) as g, NcFile(out) as o:
+        for v in g._f.variables:
+            ref, got = g.get(v), o.get(v)
+            assert got.shape == ref.shape, (v, got.shape, ref.shape)
+            worst[v] = rel_err(got, ref)
+    bad = {k: e for k, e in worst.items() if not e < FLOAT32_TOL}
+    assert not bad, f"{name}: beyond float32 rounding: {bad}"
+    print(name, "OpenMP driver (4 threads, blocks of 3 columns) + drop-in vs golden file: max", max(worst.values()))
+
+
 # Targets of test/ifs/Makefile WITHOUT a golden file: (namelist family, change_namelist.sh arguments, the same as a Python-host config)
 OTHER_TARGETS = {
     "test_lwscat": (RRTMG, {"do_lw_cloud_scattering": "true"}, ("rrtmg", "McICA", dict(do_lw_cloud_scattering=True))),

@@ -12,7 +12,9 @@ What is compiled, all with amdflang, objects and .mod files only under --out (gi
     radiation_hip_interface.F90 and radiation_hip_rrtmg.F90 with -DECRAD_HIP_REFERENCE_TYPES, and
     ecrad_amd/fortran/radiation_interface.F90 -- the drop-in module of the reference's name;
   * linked against ecrad_amd/csrc/libecrad_hip.so (rpath relative to the binary) -> <out>/ecrad_hip.
-No OpenMP: one handle per process, the driver's loop over blocks runs serially.
+Without --openmp the driver's loop over blocks runs serially (what a GPU host wants: one handle per process, large blocks,
+INTEGRATION.md 1.3); with --openmp the PARALLEL DO of driver/ecrad_driver.F90:348 is live and the threads' calls of radiation() queue
+in the drop-in (-> <out>_omp, the re-entrancy test).
 
 This is BOUNDARY PROOF (the drop-in executed inside its host), not an oracle pin: the reference's Fortran here only prepares
 tables and moves files; every flux comes from the HIP library.  Nothing of the reference is copied into the repo."""
@@ -77,11 +79,16 @@ def main():
                     help="the UNMODIFIED reference instead (its own radiation_interface.F90, OpenMP on, no GPU library): the CPU "
                          "executable `ecrad_ref`, whose only non-reference part is the netCDF library underneath easy_netcdf.F90")
     ap.add_argument("--single", action="store_true", help="the host in single precision (-DPARKIND1_SINGLE: jprb = real32, as the IFS runs)")
+    ap.add_argument("--openmp", action="store_true",
+                    help="the drop-in compiled with OpenMP: the driver's PARALLEL DO over blocks (driver/ecrad_driver.F90:348) is live and "
+                         "several host threads call radiation() at once (-> <out>_omp)")
     args = ap.parse_args()
     if args.reference and args.out.endswith("dropin"):
         args.out = os.path.join(ROOT, "tests", "_build", "reference")
     if args.single:
         args.out += "_sp"
+    if args.openmp:
+        args.out += "_omp"
     out, obj = os.path.abspath(args.out), os.path.join(os.path.abspath(args.out), "obj")
     os.makedirs(obj, exist_ok=True)
     lib = sources(args.ref, args.reference)
@@ -97,6 +104,8 @@ def main():
              f"-I{args.ref}/ifsaux", f"-I{args.ref}/ifsrrtm", f"-I{args.ref}/ifs", f"-I{obj}", "-module-dir", obj]
     if args.single:
         flags.append("-DPARKIND1_SINGLE")
+    if args.openmp and not args.reference:
+        flags.append("-fopenmp")
 
     def obj_of(f):
         return os.path.join(obj, os.path.basename(f)[:-4] + ".o")
