@@ -130,6 +130,44 @@ def _replicate(inputs, times):
     return ncol * times, nlev, sl, th, gas, cloud, aer
 
 
+def test_concurrent_calls_on_one_handle_queue(oracle_lib):
+    """radiation() is re-entrant in the reference (driver/ecrad_driver.F90:348 calls it from an OpenMP PARALLEL DO; SURVEY.md
+    8(b) "Threading"): four host threads call ecrad_hip_radiation on ONE handle at once, each with its own block of columns of
+    the shared flux arrays (ctypes releases the interpreter lock for the duration of a call).  The calls queue on the handle's
+    mutex; the result is that of one call over all columns."""
+    import threading
+    from ecrad_amd.interface import Radiation
+    from ecrad_amd.types import Flux
+    config = make_config("McICA")
+    ncol, nlev, sl, th, gas, cloud, aer = load_meridian(config)
+    rad = Radiation(config, backend="hip")
+    rad.set_gas_units(gas)
+    th.calc_saturation_wrt_liquid()
+    whole = Flux.allocate(config, ncol, nlev)
+    frac0 = cloud.fraction.copy()
+    rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, whole)
+    cloud.fraction[...] = frac0
+    flux = Flux.allocate(config, ncol, nlev)
+    errors = []
+
+    def work(i1, i2):
+        try:
+            for _ in range(3):
+                rad.radiation(ncol, nlev, i1, i2, sl, th, gas, cloud, aer, flux)
+        except Exception as e:      # pragma: no cover
+            errors.append(e)
+    blocks = [(1, 5), (6, 13), (14, 14), (15, 32)]
+    threads = [threading.Thread(target=work, args=b) for b in blocks]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for name, a in flux.arrays.items():
+        assert np.array_equal(a, whole.arrays[name]), name
+    rad.close()
+
+
 @pytest.mark.parametrize("grid", ["1", "3", "static"])
 def test_mcica_generator_column_queue(grid, oracle_lib, monkeypatch):
     """The wave-per-column cloud generator takes its columns from a queue (kernel_prep.hip, mcica_generator_kernel).  With
