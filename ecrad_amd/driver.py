@@ -219,8 +219,7 @@ def read_input(path: str, config: Config, driver_config: DriverConfig):
                           np.ascontiguousarray(effective_radius), fractional_std, overlap_param)
             from .config import ISolverSpartacus
             if ISolverSpartacus in (config.i_solver_sw, config.i_solver_lw):
-                # driver/ecrad_driver_read_input.F90:290-470: of the four ways to specify the cloud scale, the one the
-                # reference's own test inputs use -- inv_cloud_effective_size [and inv_inhom_effective_size] in the file
+                # driver/ecrad_driver_read_input.F90:290-470: the four ways to specify the cloud scale
                 scalable = False
                 sizes = (dc.low_inv_effective_size_override, dc.middle_inv_effective_size_override, dc.high_inv_effective_size_override)
                 if max(sizes) >= 0.0:
@@ -251,6 +250,20 @@ def read_input(path: str, config: Config, driver_config: DriverConfig):
                     cloud.inv_cloud_effective_size = _colfast(f.get("inv_cloud_effective_size"))
                     if f.exists("inv_inhom_effective_size") and not dc.do_ignore_inhom_effective_size:
                         cloud.inv_inhom_effective_size = _colfast(f.get("inv_inhom_effective_size"))
+                elif f.exists("inv_cloud_effective_separation"):      # (4) :379-434
+                    scalable = True
+                    thr = config.cloud_fraction_threshold
+                    sep = _colfast(f.get("inv_cloud_effective_separation"))
+                    partly = (fraction > thr) & (fraction < 1.0 - thr)
+                    cloud.inv_cloud_effective_size = np.ascontiguousarray(
+                        np.where(partly, sep / np.sqrt(np.where(partly, fraction * (1.0 - fraction), 1.0)), 0.0))
+                    if f.exists("inv_inhom_effective_separation"):
+                        isep = _colfast(f.get("inv_inhom_effective_separation"))
+                    else:      # the separation of the clouds, divided by the user's factor (inverse sizes)
+                        isep = (1.0 / dc.cloud_inhom_separation_factor) * sep
+                    cloudy = fraction > thr
+                    cloud.inv_inhom_effective_size = np.ascontiguousarray(
+                        np.where(cloudy, isep / np.sqrt(np.where(cloudy, 0.5 * fraction * (1.0 - 0.5 * fraction), 1.0)), 0.0))
                 else:
                     raise RuntimeError("SPARTACUS solver specified but cloud size not, either in namelist or input file")
                 if scalable and dc.effective_size_scaling > 0.0:           # :443-461

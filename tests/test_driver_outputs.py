@@ -260,3 +260,66 @@ def test_band_wise_aerosol_file_is_read_as_it_is():
     from ecrad_amd.config import ConfigError
     with pytest.raises(ConfigError):
         setup_radiation(make_config("Tripleclouds", use_general_aerosol_optics=False))
+
+
+@pytest.mark.parametrize("with_inhom", [False, True])
+def test_cloud_size_from_effective_separation_in_the_input_file(tmp_path, with_inhom):
+    """Case (4) of driver/ecrad_driver_read_input.F90:290-470: the input file holds inv_cloud_effective_separation [and
+    inv_inhom_effective_separation] instead of the effective sizes.  The reference's own executable reads such a file and
+    dumps what it hands to radiation() (do_save_inputs -> inputs.nc); the Python driver derives the same
+    inv_cloud_effective_size / inv_inhom_effective_size from it, including effective_size_scaling."""
+    import re
+    import subprocess
+    from scipy.io import netcdf_file
+    from ecrad_amd.driver import DriverConfig, read_input
+    from helpers import MERIDIAN, NAMELIST
+    from test_fortran_dropin import write_namelist
+    ref = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "_build", "reference", "ecrad_ref")
+    if not os.path.exists(ref):
+        pytest.skip("tests/_build/reference/ecrad_ref has not been built (tools/build_dropin.py --reference)")
+    # the meridian file with the separations in place of the sizes
+    src = netcdf_file(MERIDIAN, "r", mmap=False)
+    inp = str(tmp_path / "separation.nc")
+    dst = netcdf_file(inp, "w", version=1)
+    for d, n in src.dimensions.items():
+        dst.createDimension(d, n)
+    rng = np.random.default_rng(5)
+    shape = None
+    for name, v in src.variables.items():
+        if name in ("inv_cloud_effective_size", "inv_inhom_effective_size"):
+            shape = (v.dimensions, v.shape)
+            continue
+        o = dst.createVariable(name, v.data.dtype.char if v.data.dtype.kind != "f" else v.data.dtype.char, v.dimensions)
+        if v.shape == ():
+            o.data[...] = v.data
+        else:
+            o[:] = v[:]
+    assert shape is not None
+    for name in ["inv_cloud_effective_separation"] + (["inv_inhom_effective_separation"] if with_inhom else []):
+        o = dst.createVariable(name, "d", shape[0])
+        o[:] = 1.0 / rng.uniform(500.0, 20000.0, size=shape[1])
+    dst.close()
+    src.close()
+    nam = str(tmp_path / "config.nam")
+    write_namelist(nam, {"sw_solver_name": '"SPARTACUS"', "lw_solver_name": '"SPARTACUS"', "do_3d_effects": "true"})
+    text = open(nam).read()
+    text = re.sub(r"do_save_inputs\s*=\s*false", "do_save_inputs = true", text)
+    text = re.sub(r"cloud_separation_scale_toa\s*=\s*[0-9.]+", "cloud_separation_scale_toa = -1.0", text)
+    text = re.sub(r"cloud_separation_scale_surface\s*=\s*[0-9.]+", "cloud_separation_scale_surface = -1.0", text)
+    text = text.replace("&radiation_driver\n", "&radiation_driver\neffective_size_scaling = 1.7,\n", 1)
+    open(nam, "w").write(text)
+    p = subprocess.run(f"ulimit -s unlimited; exec {ref} {nam} {inp} {tmp_path / 'out.nc'}", shell=True, capture_output=True, text=True,
+                       cwd=str(tmp_path), env=dict(os.environ, OMP_NUM_THREADS="2", OMP_STACKSIZE="1G"), timeout=900)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    assert "inv_cloud_effective_separation" in p.stdout + p.stderr
+    config = make_config("SPARTACUS", do_3d_effects=True)
+    dc = DriverConfig.read(nam)
+    assert dc.effective_size_scaling == 1.7 and dc.cloud_separation_scale_toa < 0.0
+    cloud = read_input(inp, config, dc)[5]
+    with NcFile(str(tmp_path / "inputs.nc")) as f:
+        for name in ("inv_cloud_effective_size", "inv_inhom_effective_size"):
+            want = f.get(name)                                  # (column, level) as the file has it
+            got = np.asarray(getattr(cloud, name)).T            # the host's arrays are (level, column)
+            assert want.shape == got.shape, name
+            assert want.max() > 0.0
+            assert rel_err(got, want, floor_frac=1e-30) < 1e-6, name      # (inputs.nc is written in single precision)
