@@ -887,7 +887,8 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
   {
     // Jump-ahead matrices of the 32-bit Galois shift register that seeds the McICA random-number
     // generator (utilities/radiation_random_numbers_mix.F90:165-200): row i of block k has bit j set iff
-    // bit j of the register influences bit i after k*274 steps (the step is linear over GF(2)).
+    // bit j of the register influences bit i after k * kLfsrPerLane steps (the step is linear over GF(2)).  Stored row-major over
+    // the lanes ([row][lane]) so that the 64 lanes of a wave read a row in one coalesced load.
     auto step = [](uint32_t s) { return (s & 0x80000000u) ? (((s ^ 87u) << 1) | 1u) : (s << 1); };
     auto mul = [](const uint32_t* A, const uint32_t* B, uint32_t* C) {   // C = A * B (row form)
       for (int i = 0; i < 32; ++i) {
@@ -902,11 +903,13 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
       for (int i = 0; i < 32; ++i) if ((col >> i) & 1u) M[i] |= 1u << j;
     }
     for (int i = 0; i < 32; ++i) P[i] = 1u << i;                    // identity
-    for (int k = 0; k < 274; ++k) { mul(M, P, T); std::memcpy(P, T, sizeof P); }   // P = M^274
+    for (int k = 0; k < kLfsrPerLane; ++k) { mul(M, P, T); std::memcpy(P, T, sizeof P); }   // P = M^kLfsrPerLane
     std::vector<uint32_t> jump(64 * 32);
     for (int i = 0; i < 32; ++i) jump[i] = 1u << i;
     for (int k = 1; k < 64; ++k) mul(P, &jump[32 * (k - 1)], &jump[32 * k]);
-    if ((st = upload<uint32_t>(h, jump.data(), jump.size(), &d.lfsr_jump))) return st;
+    std::vector<uint32_t> jump_t(64 * 32);
+    for (int k = 0; k < 64; ++k) for (int i = 0; i < 32; ++i) jump_t[i * 64 + k] = jump[32 * k + i];
+    if ((st = upload<uint32_t>(h, jump_t.data(), jump_t.size(), &d.lfsr_jump))) return st;
   }
   HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->dcfg), sizeof(DevConfig)));
   HIP_TRY(h, hipMemcpy(h->dcfg, &d, sizeof(DevConfig), hipMemcpyHostToDevice));

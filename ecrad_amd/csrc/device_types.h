@@ -9,6 +9,9 @@ namespace ecrad {
 constexpr int kMaxGas = ECRAD_NMAXGASES;
 constexpr int kMaxCloudTypes = ECRAD_NMAXCLOUDTYPES;
 constexpr int kNReg = 3;
+// output bits of the seeding shift register of the McICA generator that one lane produces (kernel_prep.hip; the jump-ahead
+// matrices of api.hip): 64 x 275 >= 17 516, and an odd stride spreads the lanes' LDS words over all 32 banks
+constexpr int kLfsrPerLane = 275;
 constexpr int kMaxActiveAerosols = 16;   // hydrophobic + hydrophilic types in one call (IFS: 12)
 constexpr int kMaxQuads = 10;   // quad loads per layer: ngas + (number of LUT gases); 9 for ecCKD LW-32
 constexpr double kAccelDueToGravity = 9.80665;          // radiation_constants.F90:26
@@ -113,7 +116,7 @@ struct DevConfig {
   DevCloudOptics cloud_sw[kMaxCloudTypes], cloud_lw[kMaxCloudTypes];
   DevAerosolOptics aerosol;
   DevPdfSampler pdf;
-  const uint32_t* lfsr_jump;   // 64 x 32 rows: the seeding shift register advanced by k*274 steps (kernel_prep.hip)
+  const uint32_t* lfsr_jump;   // [32 rows][64 lanes]: the seeding shift register advanced by lane * kLfsrPerLane steps (kernel_prep.hip)
 };
 
 // Stage-interface arrays produced by a separate gas-optics pass (RRTMG, kernel_rrtmg.hip) and read by the

@@ -329,7 +329,9 @@ ECRAD_DEV double pdf_finish(const PdfPending& r) {
 // Same integer stream and same floating-point expressions as before (integer-exact RNG; the oracle
 // and the reference's golden file pin it).
 constexpr int kLfsrSteps = (JPMM - 1) * (JPQ - 3);      // 17 516 output bits of the seeding register
-constexpr int kLfsrPerLane = (kLfsrSteps + 63) / 64;     // 274
+static_assert(64 * kLfsrPerLane >= kLfsrSteps && 63 * kLfsrPerLane < kLfsrSteps && 62 * kLfsrPerLane + kLfsrPerLane <= kLfsrSteps,
+              "64 lanes must cover the seeding bits, and only the last one may run past them");
+constexpr int kLfsrZ = (JPQ - 3) + kLfsrPerLane - 1;      // words of the linear work array of the seeding (see mcica_generator_column)
 
 ECRAD_DEV uint32_t lfsr_step(uint32_t s) { return (s & 0x80000000u) ? (((s ^ 87u) << 1) | 1u) : (s << 1); }
 
@@ -409,8 +411,13 @@ struct LevBitsT {
 
 struct GenLds {
   int32_t* X;        // [608], 1-based like the reference
+  int32_t* Z;        // [kLfsrZ] work array of the seeding: the space of rc, ri, rtop (+ padding where those are too small)
   double *frac, *fsd, *ovp, *cum, *pair, *opi, *rc, *ri, *rtop;
 };
+__host__ __device__ inline int gen_lds_pad_doubles(int nlev, int ng) {      // so that rc .. rtop hold kLfsrZ 32-bit words
+  const int have = 2 * (3 * nlev + 1 + ng);
+  return have >= kLfsrZ ? 0 : (kLfsrZ - have + 1) / 2;
+}
 
 ECRAD_DEV GenLds gen_lds(unsigned char* smem, int nlev, int ng) {
   GenLds g;
@@ -418,11 +425,13 @@ ECRAD_DEV GenLds gen_lds(unsigned char* smem, int nlev, int ng) {
   g.frac = d; d += nlev; g.fsd = d; d += nlev; g.ovp = d; d += nlev; g.cum = d; d += nlev; g.pair = d; d += nlev;
   g.opi = d; d += nlev; g.rc = d; d += nlev + 1; g.ri = d; d += 2 * nlev;
   g.rtop = d; d += ng;
+  g.Z = reinterpret_cast<int32_t*>(g.rc);
+  d += gen_lds_pad_doubles(nlev, ng);
   g.X = reinterpret_cast<int32_t*>(d);
   return g;
 }
 
-size_t mcica_generator_lds_bytes(int nlev, int ng) { return (size_t)(9 * nlev + 1 + ng) * 8 + 608 * 4; }
+size_t mcica_generator_lds_bytes(int nlev, int ng) { return (size_t)(9 * nlev + 1 + ng + gen_lds_pad_doubles(nlev, ng)) * 8 + 608 * 4; }
 
 // cum_cloud_cover_exp_exp on the LDS arrays of one column (called by one lane).  In: frac, pair (the
 // layer-pair cover from alpha), rc = alpha per interface.  Out: cum, pair (made consistent with the
@@ -642,8 +651,6 @@ ECRAD_DEV void mcica_generator_column(const DevConfig& cfg, const DevInputs& in,
     }
     GEN_LAP(tm, 0);      // cloud cover, level set-up
     // ---- initialize_random_numbers (radiation_random_numbers_mix.F90:142-231), seeding in parallel ---
-    for (int j = lane; j <= JPQ; j += 64) g.X[j] = 0;
-    wave_sync();
     {
       const int32_t JPMASK = 123459876;
       int32_t v = (in.iseed[col] + seed_offset) ^ JPMASK;
@@ -651,26 +658,51 @@ ECRAD_DEV void mcica_generator_column(const DevConfig& cfg, const DevInputs& in,
       if (v == 0) v = JPMASK;
       uint32_t idum = (uint32_t)v;
       for (int jj = 0; jj < 64; ++jj) idum = lfsr_step(idum);
+      // The register's 17 516 output bits fill bit planes 1..29 of X(3:606), word by word.  Lane k produces bits
+      // k*275 .. k*275+274: its register is M^(k*275) * idum (jump-ahead rows built at set-up).  A lane's bits go to consecutive
+      // words of ONE plane, or run over the end of a plane into the start of the next.  To keep the loop free of that test they
+      // are ORed into a linear work array Z (the space of rc / ri / rtop, unused until the first draw) at Z[word-3 + k] with the
+      // bit of the plane the lane started in; Z[604 ..] then holds the overflow, which belongs one plane up (<< 1).
+      int32_t* const Z = g.Z;
+      for (int j = lane; j < kLfsrZ; j += 64) Z[j] = 0;
+      uint32_t s = 0;
+      {
+        const auto* rows = as_global(cfg.lfsr_jump + lane);
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) s |= (uint32_t)(__popc(rows[64 * i] & idum) & 1) << i;
+      }
+      wave_sync();
+      {
+        // (the last lane runs 84 steps past the 17 516th bit: they land in the overflow part with the bit of plane 29, which no
+        //  valid step puts there, and the fold below drops bit 30)
+        const int n0 = lane * kLfsrPerLane;
+        const int32_t bit = (int32_t)(1u << (n0 / (JPQ - 3) + 1));
+        int32_t* z = Z + n0 % (JPQ - 3);
+        static_assert(kLfsrPerLane % 5 == 0, "the loop below is unrolled by 5");
+        for (int k = 0; k < kLfsrPerLane; k += 5) {
+#pragma unroll
+          for (int u = 0; u < 5; ++u) {
+            const int32_t msb = (int32_t)s >> 31;                      // all ones if the output bit is set
+            atomicOr(z + k + u, msb & bit);
+            s = (s << 1) ^ ((uint32_t)msb & 0xAFu);                    // = lfsr_step(s)
+          }
+        }
+      }
+      wave_sync();
+      for (int m = lane; m <= JPQ; m += 64) {
+        int32_t x = 0;
+        if (m >= 3 && m <= JPQ - 1) {
+          x = Z[m - 3];
+          if (m - 3 < kLfsrPerLane - 1) x |= (Z[(JPQ - 3) + (m - 3)] << 1) & (int32_t)((1u << JPMM) - 1u);
+        }
+        g.X[m] = x;
+      }
+      wave_sync();
       if (lane == 0) {
         g.X[2] = (int32_t)((idum & ((1u << (JPMM - 1)) - 1u)) << 1);
         g.X[JPQ] = (int32_t)(idum >> (JPMM - 1));
+        g.X[JPQ - JPS] |= 1;
       }
-      wave_sync();
-      // this lane's register = M^(lane*274) * idum
-      const auto* rows = as_global(cfg.lfsr_jump + 32 * lane);
-      uint32_t s = 0;
-#pragma unroll 8
-      for (int i = 0; i < 32; ++i) s |= (uint32_t)(__popc(rows[i] & idum) & 1) << i;
-      int n = lane * kLfsrPerLane;
-      int jbit = n / (JPQ - 3) + 1, jj = n % (JPQ - 3) + 3;
-      const int nend = (n + kLfsrPerLane < kLfsrSteps) ? n + kLfsrPerLane : kLfsrSteps;
-      for (; n < nend; ++n) {
-        if (s & 0x80000000u) atomicOr(&g.X[jj], (int32_t)(1u << jbit));
-        s = lfsr_step(s);
-        if (++jj > JPQ - 1) { jj = 3; ++jbit; }
-      }
-      wave_sync();
-      if (lane == 0) g.X[JPQ - JPS] |= 1;
       wave_sync();
     }
     GEN_LAP(tm, 1);      // seeding
