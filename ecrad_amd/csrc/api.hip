@@ -1277,6 +1277,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
         prep.u_matrix = cv.take<double>(9 * (L + 1) * n);
       }
       if (sw_tc || lw_tc) prep.geom = cv.take<double>((size_t)kGeomItems * (L + 1) * n);      // (the Tripleclouds kernels' form)
+      if (sw_tc || lw_tc || sw_sp || lw_sp) prep.cc_partial = cv.take<double>((size_t)kPrepChunks * n);
       if (sw_mcica) { prep.od_scaling_sw = cv.take<double>((size_t)c.n_g_sw * L * n); prep.total_cloud_cover_sw = cv.take<double>(n); }
       if (lw_mcica) { prep.od_scaling_lw = cv.take<double>((size_t)c.n_g_lw * L * n); prep.total_cloud_cover_lw = cv.take<double>(n); }
       if (c.do_clouds) cx.din.cloud_fraction_work = cv.take<double>(L * n);

@@ -9,6 +9,7 @@ namespace ecrad {
 constexpr int kMaxGas = ECRAD_NMAXGASES;
 constexpr int kMaxCloudTypes = ECRAD_NMAXCLOUDTYPES;
 constexpr int kNReg = 3;
+constexpr int kPrepChunks = 6;      // level chunks of tripleclouds_prep_kernel (kernel_prep.hip)
 // output bits of the seeding shift register of the McICA generator that one lane produces (kernel_prep.hip; the jump-ahead
 // matrices of api.hip): 64 x 275 >= 17 516, and an odd stride spreads the lanes' LDS words over all 32 banks
 constexpr int kLfsrPerLane = 275;
@@ -207,6 +208,7 @@ struct DevCloudPrep {
   // od_scaling of regions 2, 3 of layer l, 23 unused.  What a column group needs for one level is 192 contiguous bytes
   // instead of 23 doubles in 23 cache lines (the prep kernel writes whichever of the two forms has its pointers set).
   double* geom;
+  double* cc_partial;      // [kPrepChunks][nloc]: the cloud-cover products of the level chunks of tripleclouds_prep_kernel
   // McICA: per-g optical-depth scalings, (ng, nlev, nloc) with g fastest; float is NOT used: the
   // values feed 1e-6-level parity
   double* od_scaling_sw;

@@ -136,6 +136,9 @@ ECRAD_DEV void beta_overlap_matrix(const double* op, const double* fu, const dou
 // homogeneous cloudy region.  It runs through the three-region arrays with an empty third region: its fraction is
 // exactly zero, so every overlap-matrix entry, lateral transfer rate and Planck term that involves it is exactly zero and
 // the sums over regions of the solver kernels pick up zeros -- the arithmetic of the two real regions is the reference's.
+// The levels are split into gridDim.y chunks (a lane per column walking all 138 half levels left the GPU at 1.5 waves per SIMD,
+// each waiting for its loads level by level): a chunk first works out the regions of the layer above its first half level -- all
+// the walk carries down -- and leaves its share of the cloud-cover product in prep.cc_partial for cloud_cover_combine_kernel.
 __global__ void tripleclouds_prep_kernel(const DevConfig* __restrict__ cfgp, DevInputs in, DevCloudPrep prep,
                                         double* cloud_cover_sw, double* cloud_cover_lw, int two_regions) {
   const DevConfig& cfg = *cfgp;
@@ -163,7 +166,10 @@ __global__ void tripleclouds_prep_kernel(const DevConfig* __restrict__ cfgp, Dev
   double prod = 1.0;
   const LevelOrder ord = level_order(in);
   const FracView fracv = cloud_fraction_view(in, col);
-  for (int jlev = 1; jlev <= nlev + 1; ++jlev) {
+  const int per_chunk = (nlev + 1 + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int jfirst = 1 + (int)blockIdx.y * per_chunk, jlast = jfirst + per_chunk - 1 < nlev + 1 ? jfirst + per_chunk - 1 : nlev + 1;
+  for (int jlev = jfirst > 1 ? jfirst - 1 : 1; jlev <= jlast; ++jlev) {
+    const bool warm = jlev < jfirst;      // the layer above the chunk: its regions only
     if (jlev > nlev) { fl[0] = 1.0; fl[1] = 0.0; fl[2] = 0.0; }
     else {
       const size_t o = col + ncol * ord.full(jlev - 1);
@@ -183,7 +189,7 @@ __global__ void tripleclouds_prep_kernel(const DevConfig* __restrict__ cfgp, Dev
         os3 = (cf - fl[1] * os2) / fl[2];
       }
       const size_t ol = (size_t)(jlev - 1) * nloc + cloc;
-      if (prep.region_fracs && active) {
+      if (prep.region_fracs && active && !warm) {
         for (int r = 0; r < 3; ++r) prep.region_fracs[(size_t)r * nlev * nloc + ol] = fl[r];
         prep.od_scaling_reg[ol] = os2;
         prep.od_scaling_reg[(size_t)nlev * nloc + ol] = os3;
@@ -193,6 +199,7 @@ __global__ void tripleclouds_prep_kernel(const DevConfig* __restrict__ cfgp, Dev
         mine[21] = os2; mine[22] = os3;
       }
     }
+    if (warm) { fu[0] = fl[0]; fu[1] = fl[1]; fu[2] = fl[2]; continue; }
     if (jlev == 1 || jlev > nlev) { op[0] = op[1] = op[2] = 1.0; }
     else {
       op[0] = in.cloud_overlap_param[col + ncol * ord.iface(jlev - 2)];
@@ -241,14 +248,33 @@ __global__ void tripleclouds_prep_kernel(const DevConfig* __restrict__ cfgp, Dev
       wave_sync();
     }
   }
-  if (cloud_cover_sw && active) cloud_cover_sw[col] = 1.0 - prod;
-  if (cloud_cover_lw && active) cloud_cover_lw[col] = 1.0 - prod;
+  if (gridDim.y > 1) {
+    if (active) prep.cc_partial[(size_t)blockIdx.y * nloc + cloc] = prod;
+  } else {
+    if (cloud_cover_sw && active) cloud_cover_sw[col] = 1.0 - prod;
+    if (cloud_cover_lw && active) cloud_cover_lw[col] = 1.0 - prod;
+  }
+}
+
+// total cloud cover = 1 - product over the half levels of v_matrix(1,1) (radiation_overlap.F90:446-452): the chunks' products in order
+__global__ void cloud_cover_combine_kernel(DevInputs in, const double* __restrict__ cc_partial, int nchunks, double* cloud_cover_sw, double* cloud_cover_lw) {
+  const int nloc = in.iendcol - in.istartcol + 1;
+  const int cloc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cloc >= nloc) return;
+  double prod = 1.0;
+  for (int c = 0; c < nchunks; ++c) prod *= cc_partial[(size_t)c * nloc + cloc];
+  const int col = in.istartcol - 1 + cloc;
+  if (cloud_cover_sw) cloud_cover_sw[col] = 1.0 - prod;
+  if (cloud_cover_lw) cloud_cover_lw[col] = 1.0 - prod;
 }
 
 hipError_t launch_tripleclouds_prep(hipStream_t st, const DevConfig* cfg, const DevInputs& in, const DevCloudPrep& prep,
                                     double* cc_sw, double* cc_lw, bool two_regions) {
   const int nloc = in.iendcol - in.istartcol + 1;
-  hipLaunchKernelGGL(tripleclouds_prep_kernel, dim3((nloc + 63) / 64), dim3(64), 0, st, cfg, in, prep, cc_sw, cc_lw, two_regions ? 1 : 0);
+  // (a fixed number of chunks whatever the batch: the results do not depend on how many columns a call has)
+  const int nchunks = (prep.cc_partial && in.nlev + 1 >= 2 * kPrepChunks) ? kPrepChunks : 1;
+  hipLaunchKernelGGL(tripleclouds_prep_kernel, dim3((nloc + 63) / 64, nchunks), dim3(64), 0, st, cfg, in, prep, cc_sw, cc_lw, two_regions ? 1 : 0);
+  if (nchunks > 1) hipLaunchKernelGGL(cloud_cover_combine_kernel, dim3((nloc + 255) / 256), dim3(256), 0, st, in, prep.cc_partial, nchunks, cc_sw, cc_lw);
   return hipGetLastError();
 }
 

@@ -5,7 +5,7 @@
 TAG=${1:-prof}
 export TMPDIR=/tmp
 tools/profile.sh $TAG > gpurun_out/${TAG}_profile.log 2>&1
-for w in tripleclouds_ecckd32 mcica_rrtmg tripleclouds_ecckd64 spartacus_ecckd32_sp; do
+for w in tripleclouds_ecckd32 mcica_ecckd32 mcica_rrtmg tripleclouds_ecckd64 spartacus_ecckd32_sp; do
   OUT=$PWD/gpurun_out/${TAG}_$w
   mkdir -p $OUT
   NCOL=100000; [ $w = tripleclouds_ecckd64 ] && NCOL=1250000      # the column counts of the default run (bench.py: EXTRA_WORKLOADS)
