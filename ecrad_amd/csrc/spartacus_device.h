@@ -175,8 +175,51 @@ template <int M, bool SW> struct Pat {
   static constexpr bool nz(int r, int c) { return !(SW && r >= M2 && c < M2); }
 };
 // mat_x_mat (:145-216): the inner index runs in increasing order over the range the pattern allows
+// Single precision: two ROWS of a column at a time as one packed operation (v_pk_fma_f32: both halves of a 64-bit register
+// pair, the element of B broadcast from either half), always the same pairs (rows 2p, 2p+1), so that an element keeps its
+// place in its pair through every product of the exponential.  Each element's sum still runs over k in increasing order
+// with one fused multiply-add per term: the same numbers as the scalar form.
+#ifndef ECRAD_SP_NO_PACKED
+template <int M, bool SW>
+SP_DEV void mmul_packed(const float (&A)[M * M], const float (&B)[M * M], float (&C)[M * M]) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  constexpr int M2 = Pat<M, SW>::M2;
+  static_assert(M2 % 2 == 0, "row pairs must not straddle the pattern's zero block");
+#pragma unroll
+  for (int c = 0; c < M; ++c) {
+#pragma unroll
+    for (int r = 0; r < M; r += 2) {
+      const bool pair = r + 1 < M;
+      if (!Pat<M, SW>::nz(r, c)) { C[r + M * c] = 0.0f; if (pair) C[r + 1 + M * c] = 0.0f; continue; }
+      const int k0 = (SW && r >= M2) ? M2 : 0;
+      const int k1 = (SW && c < M2) ? M2 : M;
+      if (pair) {
+        v2f acc = {0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < M; ++k)
+          if (k >= k0 && k < k1) {
+            const v2f a = {A[r + M * k], A[r + 1 + M * k]};
+            const v2f bb = {B[k + M * c], B[k + M * c]};
+            acc = __builtin_elementwise_fma(a, bb, acc);
+          }
+        C[r + M * c] = acc.x; C[r + 1 + M * c] = acc.y;
+      } else {
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < M; ++k)
+          if (k >= k0 && k < k1) s = __builtin_fmaf(A[r + M * k], B[k + M * c], s);
+        C[r + M * c] = s;
+      }
+    }
+  }
+}
+#endif
+
 template <typename R, int M, bool SW>
 SP_DEV void mmul(const R (&A)[M * M], const R (&B)[M * M], R (&C)[M * M]) {
+#ifndef ECRAD_SP_NO_PACKED
+  if constexpr (sizeof(R) == 4) { mmul_packed<M, SW>(A, B, C); return; }
+#endif
   constexpr int M2 = Pat<M, SW>::M2;
 #pragma unroll
   for (int c = 0; c < M; ++c)
