@@ -411,14 +411,24 @@ class Workload:
 
 
 def timed_steps(w, steps, warmup, barrier, gather_world=0):
+    import gc
     for _ in range(warmup):
         w.step(gather_world)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        w.step(gather_world)
-    barrier()
-    return time.perf_counter() - t0
+    # (the host side of a step is a few dozen microseconds of ctypes; a collection of the interpreter's garbage -- the default run
+    #  has built and dropped several workloads by the time the later ones are timed -- is tens of milliseconds: not inside the region)
+    gc.collect()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            w.step(gather_world)
+        barrier()
+        return time.perf_counter() - t0
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def roofline_of(w, stage_ms, elapsed_per_step_s):
