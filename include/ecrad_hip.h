@@ -8,7 +8,7 @@
  * exactly the reference's Fortran layouts (first index fastest), so the Fortran side passes
  * c_loc(array) with no copies.
  *
- *   ecrad_hip_create      <-> (new) one handle per host thread / GPU
+ *   ecrad_hip_create      <-> (new) one handle per GPU (host threads may share it: calls on a handle queue)
  *   ecrad_hip_setup       <-> setup_radiation(config)          radiation_interface.F90:37
  *                             (called AFTER the Fortran setup has filled config's look-up tables)
  *   ecrad_hip_radiation   <-> radiation(ncol,nlev,istartcol,iendcol,config,single_level,
@@ -376,7 +376,10 @@ int ecrad_hip_set_stream(ecrad_hip_handle_t handle, void* hip_stream);
 /* The operator.  Columns outside istartcol..iendcol (1-based, inclusive) are not touched.
    With ECRAD_MEM_HOST pointers the call stages the needed column range through device buffers
    (H2D, kernels, D2H) and is synchronous; with ECRAD_MEM_DEVICE pointers it only enqueues
-   kernels on the handle's stream (call ecrad_hip_synchronize before reading results). */
+   kernels on the handle's stream (call ecrad_hip_synchronize before reading results).
+   Re-entrant like the reference's radiation() (driver/ecrad_driver.F90:348 calls it from an OpenMP PARALLEL DO over
+   blocks of columns): several host threads may call it on one handle at once, each with its own column range of shared
+   arrays; the calls run one after the other (a per-handle mutex). */
 int ecrad_hip_radiation(ecrad_hip_handle_t handle, int ncol, int nlev, int istartcol, int iendcol,
                         const ecrad_inputs_t* in, ecrad_flux_t* flux);
 
