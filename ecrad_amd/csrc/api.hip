@@ -60,7 +60,7 @@ struct ecrad_hip_handle_s {
   hipEvent_t ev_fork_sw = nullptr, ev_sw_done = nullptr;
   hipEvent_t ev_rrtmg_rec = nullptr, ev_rrtmg_sw = nullptr;    // RRTMG: shortwave bands evaluated on aux_stream next to the longwave solver
   int num_cu = 256;
-  int blocks_per_cu = 4;
+  int blocks_per_cu = 0;      // 0: as many as the kernel keeps resident (grid_for); ECRAD_HIP_BLOCKS_PER_CU overrides
   std::string err;
   bool is_setup = false;
   ecrad_config_t cfg{};            // scalar members only are meaningful (pointers are the caller's)
@@ -1070,10 +1070,15 @@ int run_rrtmg(ecrad_hip_handle_t h, CallCtx& cx, bool fold_aerosols, bool split_
   return ECRAD_OK;
 }
 
-int grid_for(ecrad_hip_handle_t h, int nloc, int ngp) {
+// Persistent blocks that take their column groups from a queue: as many as stay RESIDENT -- a block is four waves, one per SIMD, and
+// the kernels over float tables (ecCKD) are built for three waves per SIMD, those over double tables (the stage mode of the RRTMG
+// spectra) for two (kernels_common.h).  A block more per CU than fits starts when another one ends and takes column groups from the
+// tail of the queue on its own: 100 000 columns, 4 -> 3 blocks per CU: headline 15.05 -> 14.85 ms, ecCKD-32 McICA 40.2 -> 39.5 ms; 4 -> 2
+// for the stage mode: RRTMG Tripleclouds 193.5 -> 189.9 ms (profiles/r03_variants.log, r03_zzg).
+int grid_for(ecrad_hip_handle_t h, int nloc, int ngp, bool table_f32) {
   const int cpb = kBlock / ngp;
   const int groups = (nloc + cpb - 1) / cpb;
-  const int maxgrid = h->num_cu * h->blocks_per_cu;
+  const int maxgrid = h->num_cu * (h->blocks_per_cu > 0 ? h->blocks_per_cu : (table_f32 ? ECRAD_MIN_WAVES : ECRAD_MIN_WAVES_STAGE));
   return groups < maxgrid ? groups : maxgrid;
 }
 
@@ -1235,8 +1240,8 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
   // (the SPARTACUS kernels run one block per CU: one wave per SIMD with the whole register file)
   // (the SPARTACUS sweeps run two blocks per CU in single precision, one in double; the list walk one block per CU)
   auto grid_sp = [&](int ngp, bool is_sw) { const int groups = (r.nloc + kBlock / ngp - 1) / (kBlock / ngp); const int m = h->num_cu * spartacus_sweep_blocks_per_cu(sp_single, is_sw); return groups < m ? groups : m; };
-  const int grid_sw = !c.do_sw ? 0 : sw_sp ? grid_sp(h->ngp_sw, true) : grid_for(h, r.nloc, h->ngp_sw);
-  const int grid_lw = !c.do_lw ? 0 : lw_sp ? grid_sp(h->ngp_lw, false) : grid_for(h, r.nloc, h->ngp_lw);
+  const int grid_sw = !c.do_sw ? 0 : sw_sp ? grid_sp(h->ngp_sw, true) : grid_for(h, r.nloc, h->ngp_sw, h->hcfg.gas_sw.table_f32);
+  const int grid_lw = !c.do_lw ? 0 : lw_sp ? grid_sp(h->ngp_lw, false) : grid_for(h, r.nloc, h->ngp_lw, h->hcfg.gas_lw.table_f32);
   const size_t sp_word = sp_single ? 4 : 8;
   const size_t per_block_sw = !c.do_sw ? 0 : sw_sp ? (spartacus_scratch_words(true, nlev) * sp_word + 7) / 8
                                            : (sw_tc ? sw_tc_scratch_doubles(nlev) : sw_ica_scratch_doubles(c.i_solver_sw, nlev));
@@ -1378,7 +1383,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     }
     const int nch = plan.n;
     for (int p = 0; p < nch; ++p)
-      HIP_TRY(h, launch_optics_dump(is_sw, plan.ngp[p], m.table_f32, grid_for(h, r.nloc, plan.ngp[p]), lds_bytes(m.hot.nquad, c.n_cloud_types), stream, h->hcfg, din, dop, plan.g0[p],
+      HIP_TRY(h, launch_optics_dump(is_sw, plan.ngp[p], m.table_f32, grid_for(h, r.nloc, plan.ngp[p], m.table_f32), lds_bytes(m.hot.nquad, c.n_cloud_types), stream, h->hcfg, din, dop, plan.g0[p],
                                     counters + (is_sw ? 80 : 64) + p, sp_single, /*cloudy_only=*/true));      // (counters 64.. / 80..: work queues of this pass)
     auto launch_sp = [&](const DevFlux& f, int* counter, int p, bool wide) -> hipError_t {
       const int ngp = plan.ngp[p], g0 = plan.g0[p];
@@ -1447,7 +1452,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
     }
     if (lw_sp) { if ((st = run_spartacus(false))) return st; }
     auto launch_lw = [&](const DevFlux& f, int* counter, int p, bool wide) -> hipError_t {
-      const int ngp = h->plan_lw.ngp[p], g0 = h->plan_lw.g0[p], grid = grid_for(h, r.nloc, ngp);
+      const int ngp = h->plan_lw.ngp[p], g0 = h->plan_lw.g0[p], grid = grid_for(h, r.nloc, ngp, m.table_f32);
       if (lw_tc) return launch_lw_tc(ngp, m.table_f32, grid, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
       if (lw_scat) return launch_lw_scat(c.i_solver_lw, ngp, m.table_f32, grid, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
       return launch_lw_ica(c.i_solver_lw, ngp, m.table_f32, grid, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
@@ -1509,7 +1514,7 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
         DevFlux dpart = dfx;
         for (int k = 0; k < 6; ++k)
           if (dfx.*(prof[k])) dpart.*(prof[k]) = pbase + plane * ((size_t)k * nch + p);
-        const int ngp = h->plan_sw.ngp[p], g0 = h->plan_sw.g0[p], grid = grid_for(h, r.nloc, ngp);
+        const int ngp = h->plan_sw.ngp[p], g0 = h->plan_sw.g0[p], grid = grid_for(h, r.nloc, ngp, m.table_f32);
         if (sw_tc) HIP_TRY(h, launch_sw_tc(ngp, m.table_f32, grid, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, g0));
         else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, ngp, m.table_f32, grid, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, g0, true));
       }
@@ -1689,11 +1694,11 @@ int ecrad_hip_optics(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, in
   const int nct = c.do_clouds ? c.n_cloud_types : 0;
   if (c.do_sw)
     for (int p = 0; p < h->plan_sw.n; ++p)
-      HIP_TRY(h, launch_optics_dump(true, h->plan_sw.ngp[p], h->hcfg.gas_sw.table_f32, grid_for(h, r.nloc, h->plan_sw.ngp[p]),
+      HIP_TRY(h, launch_optics_dump(true, h->plan_sw.ngp[p], h->hcfg.gas_sw.table_f32, grid_for(h, r.nloc, h->plan_sw.ngp[p], h->hcfg.gas_sw.table_f32),
                                     lds_bytes(h->hcfg.gas_sw.hot.nquad, nct), stream, h->hcfg, cx.din, dop, h->plan_sw.g0[p], counters + 80 + p));
   if (c.do_lw)
     for (int p = 0; p < h->plan_lw.n; ++p)
-      HIP_TRY(h, launch_optics_dump(false, h->plan_lw.ngp[p], h->hcfg.gas_lw.table_f32, grid_for(h, r.nloc, h->plan_lw.ngp[p]),
+      HIP_TRY(h, launch_optics_dump(false, h->plan_lw.ngp[p], h->hcfg.gas_lw.table_f32, grid_for(h, r.nloc, h->plan_lw.ngp[p], h->hcfg.gas_lw.table_f32),
                                     lds_bytes(h->hcfg.gas_lw.hot.nquad, nct), stream, h->hcfg, cx.din, dop, h->plan_lw.g0[p], counters + 64 + p));
   if (host_mem) {
     for (const OF& f : fields)
