@@ -198,7 +198,11 @@ def cpu_baseline(config, sample, seconds_target=10.0, workload_name=None):
     try:
         ref = reference_executable_component(workload_name, config, sample, nthreads) if workload_name else None
         if ref:
-            out.setdefault("components", {})["reference_executable"] = ref
+            # north_star: "next to the reference Fortran/OpenMP path timed on the same box's host cores".  Where the reference's
+            # own executable exists it IS the baseline (`kind: "reference"`); the oracle's figure stays beside it as a component.
+            port = {k: out[k] for k in ("value", "unit", "cores", "kind", "sample")}
+            comp = out.get("components", {})
+            out = dict(ref, components=dict(comp, port=port))
     except Exception as e:
         out.setdefault("components", {})["reference_executable"] = {"error": f"{type(e).__name__}: {e}"}
     return out, flux
@@ -485,9 +489,6 @@ def roofline_of(w, stage_ms, elapsed_per_step_s):
             "stage_ms": stage_ms, "work_bytes": int(info.work_bytes)}
 
 
-STABLE_IN_SINGLE = ("sw_", "lw_up_clear", "lw_dn_clear", "lw_dn_surf_clear_g", "lw_up_toa_clear_g", "cloud_cover")
-
-
 def parity_tolerance(config):
     """1e-6 (north_star, double precision).  The single-precision SPARTACUS workload is checked against the oracle's
     single-precision build (the reference's PARKIND1_SINGLE semantics): float rounding through 9x9 matrix exponentials and
@@ -498,68 +499,39 @@ def parity_tolerance(config):
 
 
 def check_parity(w, oracle_flux, inputs=None):
-    """The timed configuration against the oracle on EVERY column the oracle was run on (outside the timed region; the
-    oracle is the checker, never the thing measured).  Names the field, column and level of the largest difference and,
-    when that difference exceeds 1e-8, how far the oracle ITSELF moves at that very element when it is compiled with
-    floating-point contraction (`oracle_fma_vs_plain_there`): a difference of the size of the formulas' own last-bit
-    sensitivity is conditioning (the Meador-Weaver direct-beam bracket divided by 1 - (k mu0)^2), not a defect."""
+    """The timed configuration (double precision) against the oracle on EVERY column the oracle was run on (outside the timed
+    region; the oracle is the checker, never the thing measured).  No column is ever set aside: a non-finite value anywhere
+    fails the check.  Names the field, column and level of the largest difference and, when that difference exceeds 1e-8,
+    how far the oracle ITSELF moves at that very element when it is compiled with floating-point contraction
+    (`oracle_fma_vs_plain_there`): a difference of the size of the formulas' own last-bit sensitivity is conditioning (the
+    Meador-Weaver direct-beam bracket divided by 1 - (k mu0)^2), not a defect -- it is NAMED, the gate stays the tolerance."""
     worst = {"max_rel_diff_vs_oracle": 0.0, "field": None}
     worst_broadband = 0.0
     nchk = oracle_flux.ncol
-    single = getattr(w.config, "i_precision", 0) == 1
-    unstable = {}
     worst_col = None
-    # Single precision (PARKIND1_SINGLE semantics): the reference's own formulation overflows / cancels to NaN in a few
-    # columns per 100 000 (deep, optically thick cloud; which ones depends on the last bit, the oracle's single-precision
-    # build has them too).  Columns with a non-finite value on either side are counted and set aside, not compared.
-    skip = np.zeros(nchk, dtype=bool)
-    nonfinite = None
-    if single:
-        bad_hip, bad_ora = np.zeros(nchk, dtype=bool), np.zeros(nchk, dtype=bool)
-        for name, t in w.case.flux_tensors.items():
-            ref = oracle_flux.arrays.get(name)
-            if ref is None:
-                continue
-            col_last = t.shape[-1] == w.ncol
-            got = (t[..., :nchk] if col_last else t[:nchk]).cpu().numpy()
-            ax = tuple(range(got.ndim - 1)) if col_last else tuple(range(1, got.ndim))
-            bad_hip |= ~np.isfinite(got).all(axis=ax) if got.ndim > 1 else ~np.isfinite(got)
-            bad_ora |= ~np.isfinite(ref).all(axis=ax) if ref.ndim > 1 else ~np.isfinite(ref)
-        skip = bad_hip | bad_ora
-        nonfinite = {"columns_hip": int(bad_hip.sum()), "columns_oracle": int(bad_ora.sum()), "columns_both": int((bad_hip & bad_ora).sum()),
-                     "ok": bool(bad_hip.sum() <= max(3 * int(bad_ora.sum()), int(1.0e-4 * nchk) + 1))}
-    keep = ~skip
+    tol = parity_tolerance(w.config)
     for name, t in w.case.flux_tensors.items():
         ref = oracle_flux.arrays.get(name)
         if ref is None:
             continue
         col_last = t.shape[-1] == w.ncol
         got = (t[..., :nchk] if col_last else t[:nchk]).cpu().numpy()
-        if skip.any():
-            got = got[..., keep] if col_last else got[keep]
-            ref = ref[..., keep] if col_last else ref[keep]
+        if not np.all(np.isfinite(got)):
+            return {"max_rel_diff_vs_oracle": float("nan"), "field": name, "columns_checked": int(nchk), "tolerance": tol, "ok": False}
         scale = np.maximum(np.abs(ref), 1e-3 * np.abs(ref).max() + 1e-300)
         err = np.abs(got - ref) / scale
-        if single and not name.startswith(STABLE_IN_SINGLE):
-            fin = np.isfinite(err)
-            unstable[name] = {"median": float(np.median(err[fin])), "fraction_within_1e-3": float((err[fin] <= 1e-3).mean()),
-                              "fraction_finite": float(fin.mean())}
-            continue
-        if not np.all(np.isfinite(got)):
-            return {"max_rel_diff_vs_oracle": float("nan"), "field": name, "columns_checked": int(nchk), "tolerance": parity_tolerance(w.config), "ok": False}
         idx = np.unravel_index(int(np.argmax(err)), err.shape)
         if err[idx] > worst["max_rel_diff_vs_oracle"]:
             worst = {"max_rel_diff_vs_oracle": float(err[idx]), "field": name, "index": [int(i) for i in idx]}
-            worst_col = int(np.nonzero(keep)[0][idx[-1] if col_last else idx[0]])
+            worst_col = int(idx[-1] if col_last else idx[0])
             worst_local = (name, idx, col_last, float(scale[idx]))
         if not name.endswith(("_g", "_band", "_canopy")):
             worst_broadband = max(worst_broadband, float(err[idx]))
-    tol = parity_tolerance(w.config)
     # `max_rel_diff_broadband`: the flux profiles, derivatives and cloud cover (north_star: "fluxes within 1e-6 relative");
     # `max_rel_diff_vs_oracle`: those and every per-g-point / per-band / canopy diagnostic
     worst.update({"max_rel_diff_broadband": worst_broadband, "columns_checked": int(nchk), "columns_timed": int(w.ncol), "tolerance": tol,
                   "ok": bool(worst["max_rel_diff_vs_oracle"] <= tol)})
-    if inputs is not None and worst_col is not None and worst["max_rel_diff_vs_oracle"] > 1.0e-8 and not single:
+    if inputs is not None and worst_col is not None and worst["max_rel_diff_vs_oracle"] > 1.0e-8:
         # the block of 32 columns (the oracle's own blocking) that holds the worst element, plain and contracted
         name, idx, col_last, scale_at = worst_local
         c0 = (worst_col // 32) * 32
@@ -572,22 +544,12 @@ def check_parity(w, oracle_flux, inputs=None):
         worst["oracle_fma_vs_plain_there"] = sens
         # A per-g-point diagnostic at which the reference's OWN formula moves by more than the tolerance when only the
         # rounding of a*b+c changes (the Meador-Weaver direct-beam bracket divided by 1 - (k mu0)^2, a handful of elements
-        # in 10^9) cannot be held to the tolerance by anybody: accepted if the broadband fluxes hold it, the element is
-        # within 10x the tolerance and within 3x that sensitivity -- and said so.
+        # in 10^9) cannot be held to the tolerance by anybody: named as such (`explained_by_conditioning`) if the broadband
+        # fluxes hold the tolerance and the element is within 10x the tolerance and within 3x that sensitivity.  `ok` stays false.
         if (not worst["ok"] and worst_broadband <= tol and worst["field"].endswith(("_g", "_band", "_canopy"))
                 and worst["max_rel_diff_vs_oracle"] <= 10.0 * tol and worst["max_rel_diff_vs_oracle"] <= 3.0 * sens):
-            worst["ok"] = True
-            worst["conditioning_exception"] = ("worst element is a per-g-point diagnostic within 3x the oracle's own fma-vs-plain "
-                                               "movement there; broadband fluxes within tolerance")
-    if nonfinite is not None:
-        worst["single_precision_nonfinite"] = dict(nonfinite, note="columns with a NaN / Inf on either side, set aside: the reference's "
-                                                   "single-precision formulation itself produces them (radiation_config.F90:1144 warns)")
-        worst["ok"] = bool(worst["ok"] and nonfinite["ok"])
-    if unstable:
-        worst["all_sky_longwave_single_precision"] = {
-            "note": "chaotic in single precision in the reference's own formulation; statistics against the single-precision oracle, not part of `ok`",
-            "fields": unstable}
-        worst["ok"] = bool(worst["ok"] and all(v["median"] < 1e-5 and v["fraction_within_1e-3"] > 0.9 for v in unstable.values()))
+            worst["explained_by_conditioning"] = ("worst element is a per-g-point diagnostic within 3x the oracle's own fma-vs-plain "
+                                                  "movement there; broadband fluxes within tolerance")
     return worst
 
 
@@ -624,15 +586,20 @@ def check_parity_single(w, inputs):
         rec = {"columns_off_hip": int((eh > tol).sum()), "columns_off_oracle_float": int((eo > tol).sum()),
                "median_hip": float(np.median(eh)), "median_oracle_float": float(np.median(eo)),
                "nonfinite_columns_hip": int(np.isinf(eh).sum()), "nonfinite_columns_oracle_float": int(np.isinf(eo).sum())}
+        # (a NaN / Inf column counts as "off" on either side; on top of that the GPU may not produce more of them than the
+        #  oracle's float build does -- which columns they are depends on the last bit, how many does not)
         rec["ok"] = bool(rec["columns_off_hip"] <= 1.5 * rec["columns_off_oracle_float"] + 1.0e-4 * nchk + 1
-                         and rec["median_hip"] <= 2.0 * rec["median_oracle_float"] + 1.0e-7)
+                         and rec["median_hip"] <= 2.0 * rec["median_oracle_float"] + 1.0e-7
+                         and rec["nonfinite_columns_hip"] <= 1.5 * rec["nonfinite_columns_oracle_float"] + 2)
         ok = ok and rec["ok"]
         fields[name] = rec
     worst = max(fields, key=lambda k: fields[k]["columns_off_hip"])
+    nonfinite = {"columns_hip": max(v["nonfinite_columns_hip"] for v in fields.values()),
+                 "columns_oracle_float": max(v["nonfinite_columns_oracle_float"] for v in fields.values())}
     summary = {k: fields[k] for k in ("sw_up", "sw_dn", "lw_up_clear", "lw_up", "lw_dn", "sw_dn_diffuse_surf_g") if k in fields}
     return {"reference": "oracle in double precision; yardstick: the oracle's own single-precision build (PARKIND1_SINGLE semantics)",
             "tolerance": tol, "columns_checked": int(nchk), "columns_timed": int(w.ncol), "ok": bool(ok),
-            "fields_checked": len(fields), "fields_failed": [k for k, v in fields.items() if not v["ok"]],
+            "fields_checked": len(fields), "fields_failed": [k for k, v in fields.items() if not v["ok"]], "nonfinite": nonfinite,
             "most_columns_off": {"field": worst, **fields[worst]}, "fields": summary}
 
 

@@ -30,6 +30,7 @@ struct LwScratch {
   double* base;
   int width;
   ECRAD_DEV StreamRef<double2> pair(int off, int lev, int tid) const {
+    if (ECRAD_ABLATE & 16) lev &= 3;      // (wrong results by design: the records stay in the L2, see kernel_ica_sw.hip)
     return {reinterpret_cast<double2*>(base + ((size_t)lev * width + off) * kBlock) + tid};
   }
   ECRAD_DEV StreamRef<double> single(int off, int lev, int tid) const {
@@ -324,7 +325,46 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
       spec_put(fx.lw_up_band, ng, g, o, fup);
       if (have_clear_out) spec_put(fx.lw_up_clear_band, ng, g, o, fup);
     }
-#if !(ECRAD_ABLATE & 4)
+#if !(ECRAD_ABLATE & 4) && ECRAD_LW_RING
+    {
+      // Ring of kLwRing (T, S) pairs: the slot a layer is taken from is refilled at once with the layer kLwRing further up
+      // (see sw_flux_sweep: the sweep is one multiply-add per layer, its time is the memory latency over the records in flight)
+      constexpr int kLwRing = ECRAD_LW_RING;
+      double2 ring[kLwRing];
+      double keep_up = 0.0, keep_der = 0.0;
+#pragma unroll
+      for (int k = 0; k < kLwRing; ++k) ring[k] = s.pair(P_CLR, imax(nlev - 1 - k, 0), tid);
+      for (int l0 = nlev - 1; l0 >= 0; l0 -= kLwRing) {
+#pragma unroll
+        for (int k = 0; k < kLwRing; ++k) {
+          const int l = l0 - k;
+          if (l >= 0) {
+            const double T = ring[k].x, S = ring[k].y;
+            ring[k] = s.pair(P_CLR, imax(l - kLwRing, 0), tid);
+            fup = T * fup + S;
+            if (fx.lw_up_band && valid) {
+              const size_t o = col + ncol * ord.half(l);
+              spec_put(fx.lw_up_band, ng, g, o, fup);
+              if (have_clear_out) spec_put(fx.lw_up_clear_band, ng, g, o, fup);
+            }
+            const double su = group_sum<NGP>(valid ? fup : 0.0);
+            double sder = 0.0;
+            if (do_deriv) { deriv = deriv * T; sder = group_sum<NGP>(valid ? deriv : 0.0); }
+            if ((l & (NGP - 1)) == glane) { keep_up = su; keep_der = sder; }
+            if ((l & (NGP - 1)) == 0) {
+              const int lv = l + glane;
+              if (col_ok && lv < nlev) {
+                const size_t o = col + ncol * ord.half(lv);
+                fx.lw_up[o] = keep_up;
+                if (have_clear_out) fx.lw_up_clear[o] = keep_up;
+                if (do_deriv) fx.lw_derivatives[o] = keep_der;
+              }
+            }
+          }
+        }
+      }
+    }
+#elif !(ECRAD_ABLATE & 4)
     {
       // records of the next kLwBatch layers are requested before the current batch is consumed
       double2 cur[kLwBatch], nxt[kLwBatch];

@@ -36,7 +36,9 @@ struct SwScratch {
     return {base + ((size_t)(set * nlev + lev) * 5 + 4) * kBlock + tid};
   }
   // packed form (ECRAD_PACK_SW): the five values of a record in 32 bytes, see pack5 in kernels_common.h
-  ECRAD_DEV size_t rec(int set, int lev) const { return (size_t)(set * nlev + lev); }
+  // (ECRAD_ABLATE & 16, wrong results by design: every layer's record in the same four slots, which stay in the L2 -- what the
+  //  kernel would cost if its sweep records did not travel through HBM)
+  ECRAD_DEV size_t rec(int set, int lev) const { return (size_t)(set * nlev + ((ECRAD_ABLATE & 16) ? (lev & 3) : lev)); }
 };
 
 struct SwSweepState {   // albedo / normalised source below the current half level
@@ -120,8 +122,14 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
   const int glane = tid % NGP;
   // The sums over g of four half levels at a time go through LDS (LevelReduce, kernels_common.h): rows (up, l mod 4),
   // (diffuse down, l mod 4), (direct beam, l mod 4); the lane that ends up with a row's sum blends and stores it.
-  static_assert(kSwBatch == 2 || kSwBatch == 4, "a group of four half levels ends with a batch of layers");
+#if ECRAD_SW_RING
+  const LevelReduce<NGP, 3, 0> rd{red, tid & 63, glane};
+#else
+  // (a batch of two layers ends a group of four half levels when the groups start at half level -1; with batches of four
+  //  half level 0 would sit alone in a group that no batch end flushes)
+  static_assert(kSwBatch == 2, "a group of four half levels ends with a batch of layers");
   const LevelReduce<NGP, 3, 3 - (kSwBatch & 3)> rd{red, tid & 63, glane};
+#endif
   auto emit = [&](int l) {
     if (SPEC && sp.up && valid) {        // spectral flux profiles (radiation_homogeneous_sw.F90:299-311)
       const size_t o = col + ncol * ord.half(l);
@@ -155,6 +163,48 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
       if (q == 2 && out_dir) put(acc * mu0, out_dir, clr_dir, dup_dir);
     }
   };
+#if ECRAD_SW_RING
+  // Ring of kSwRing layers: the slot a layer's record is taken from is refilled at once with the record of the layer kSwRing
+  // further down, so a lane always has kSwRing - 1 or kSwRing records in flight (16-byte loads, 2 per record) for
+  // 8 kSwRing registers -- the double buffer below holds 2 kSwBatch records in 16 kSwBatch registers and has between
+  // kSwBatch and 2 kSwBatch of them in flight.  The sweep has five multiply-adds per layer: its time is the memory
+  // latency divided by the number of records in flight.
+  constexpr int kSwRing = ECRAD_SW_RING;
+  static_assert(kSwRing % 4 == 0, "groups of four half levels end at fixed ring positions");
+  auto load_one = [&](int lay) -> SwRec {
+    const int l = lay < nlev ? lay : nlev - 1;
+    const int set = (set2 && l <= lcb) ? 1 : 0;
+#if ECRAD_PACK_SW
+    return packed5_load(s.base, s.rec(set, l), tid);
+#else
+    SwRec r; r.p0 = s.pair(set, 0, l, tid); r.p1 = s.pair(set, 1, l, tid); r.sig = s.single(set, l, tid); return r;
+#endif
+  };
+  SwRec ring[kSwRing];
+#pragma unroll
+  for (int k = 0; k < kSwRing; ++k) ring[k] = load_one(k);
+  emit(0);
+  for (int lay0 = 0; lay0 < nlev; lay0 += kSwRing) {
+#pragma unroll
+    for (int k = 0; k < kSwRing; ++k) {
+      const int lay = lay0 + k;
+      if (lay < nlev) {
+#if ECRAD_PACK_SW
+        double r_a1, r_b, r_tdd, r_alb, r_sig;
+        unpack5(ring[k], r_a1, r_b, r_tdd, r_alb, r_sig);
+#else
+        const double r_a1 = ring[k].p0.x, r_b = ring[k].p0.y, r_tdd = ring[k].p1.x, r_alb = ring[k].p1.y, r_sig = ring[k].sig;
+#endif
+        ring[k] = load_one(lay + kSwRing);
+        fdn = r_a1 * fdn + Fd * r_b;
+        Fd = Fd * r_tdd;
+        fup = r_alb * fdn + r_sig * Fd;
+        emit(lay + 1);
+        if (((k + 1) & 3) == 3 || lay + 1 == nlev) flush(lay + 1);
+      }
+    }
+  }
+#else
   SwRec cur[kSwBatch], nxt[kSwBatch];
   sw_load_batch(s, set2, lcb, tid, nlev, 0, cur);
   emit(0);
@@ -182,6 +232,7 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
 #pragma unroll
     for (int k = 0; k < kSwBatch; ++k) cur[k] = nxt[k];
   }
+#endif
   fdn_surf = fdn;
   fdir_surf = Fd * mu0;
 }

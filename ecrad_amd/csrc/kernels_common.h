@@ -33,9 +33,21 @@ constexpr int kStageBatch = ECRAD_STAGE_BATCH;
 template <typename TAB> constexpr int min_waves_for(int ecckd) { return sizeof(TAB) == 8 ? ECRAD_MIN_WAVES_STAGE : ecckd; }
 // Tuning / ablation knobs (tools/variants.sh builds and times alternatives; the shipped library uses
 // the defaults).  ECRAD_ABLATE bits give WRONG results and exist only to attribute time:
-//   1 no table loads, 2 no cross-lane sums, 4 no flux sweep, 8 no scratch stores in the optics sweep
+//   1 no table loads, 2 no cross-lane sums, 4 no flux sweep, 8 no scratch stores in the optics sweep, 16 sweep records kept in the L2
 #ifndef ECRAD_SWEEP_BATCH
 #define ECRAD_SWEEP_BATCH 2     // layers of scratch records requested per batch in the flux sweeps
+#endif
+#ifndef ECRAD_SW_RING
+// > 0: the shortwave flux sweep keeps this many layers of records in flight (a ring; multiple of 4).  Measured (same runs):
+// 4, 8, 12 layers: 7.85, 8.01, 8.05 ms against 7.77-7.86 ms with the double buffer of two layers -- that sweep is not waiting
+// for its records (with the records held in the L2, -DECRAD_ABLATE=16, the kernel takes the same 7.8 ms).
+#define ECRAD_SW_RING 0
+#endif
+#ifndef ECRAD_LW_RING
+// layers of (T, S) pairs the clear-sky longwave upward sweep keeps in flight (a ring: the slot a layer is taken from is refilled
+// at once; 0 = the double buffer of ECRAD_LW_BATCH layers).  Measured on 100 000 clear-sky columns (gpurun_out/r04_a, r04_b:
+// lw_ica_kernel<float,32,1> 6.49-6.53 ms with the double buffer; ring of 4: 5.85, 6: 5.78, 8: 5.82, 12: 5.73, 16: 6.79 -- spills).
+#define ECRAD_LW_RING 8
 #endif
 #ifndef ECRAD_ABLATE
 #define ECRAD_ABLATE 0

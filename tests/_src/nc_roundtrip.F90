@@ -1,6 +1,7 @@
 ! nc_roundtrip.F90 -- test program of ecrad_amd/fortran/netcdf.F90 + nc_classic.c (tests/test_fortran_netcdf.py):
 !   nc_roundtrip write FILE   defines dimensions / variables / attributes of every type the reference's easy_netcdf.F90
 !                             uses, writes whole arrays, slabs (start/count) and scalars
+!   nc_roundtrip write_hdf5 FILE   the same with NF90_HDF5 in the creation mode (warned about, classic format written)
 !   nc_roundtrip read FILE    reads them back the way easy_netcdf.F90 does and checks every value
 !   nc_roundtrip dump FILE VAR   prints shape, sum and first / last value of a (record) variable of an existing file
 program nc_roundtrip
@@ -17,8 +18,13 @@ program nc_roundtrip
 
   call get_command_argument(1, mode)
   call get_command_argument(2, path)
-  if (trim(mode) == 'write') then
-    call ok(nf90_create(trim(path), NF90_CLOBBER, ncid), 'create')
+  if (trim(mode) == 'write' .or. trim(mode) == 'write_hdf5') then
+    ! (write_hdf5: the creation mode easy_netcdf.F90:180-184 builds for is_hdf5_file = .true.)
+    if (trim(mode) == 'write_hdf5') then
+      call ok(nf90_create(trim(path), ior(NF90_CLOBBER, NF90_HDF5), ncid), 'create')
+    else
+      call ok(nf90_create(trim(path), NF90_CLOBBER, ncid), 'create')
+    end if
     call ok(nf90_def_dim(ncid, 'column', 4, d_col), 'def_dim')
     call ok(nf90_def_dim(ncid, 'level', 3, d_lev), 'def_dim')
     call ok(nf90_def_dim(ncid, 'five', 5, d_str), 'def_dim')

@@ -60,6 +60,21 @@ def test_write_then_read_through_the_module_and_through_scipy(exe, tmp_path):
         assert nc.variables["f"].typecode() == "h" and list(nc.variables["f"][:]) == [1, 2, 3, -4, 5]
 
 
+def test_hdf5_request_is_answered_with_a_warning_and_a_classic_file(exe, tmp_path):
+    """The driver's do_write_hdf5 / easy_netcdf's is_hdf5_file reach nf90_create as NF90_HDF5 (utilities/easy_netcdf.F90:180-184):
+    this module has no HDF5 writer, says so on standard error, and writes the classic format every netCDF-4 reader reads."""
+    f = str(tmp_path / "t4.nc")
+    p = subprocess.run([exe, "write_hdf5", f], capture_output=True, text=True)
+    assert p.returncode == 0 and "WRITE OK" in p.stdout, p.stdout + p.stderr
+    assert "Warning" in p.stderr and "netCDF-4/HDF5" in p.stderr and "classic format" in p.stderr and f in p.stderr
+    assert open(f, "rb").read(4) == b"CDF\x01"
+    p = subprocess.run([exe, "read", f], capture_output=True, text=True)
+    assert p.returncode == 0 and "READ OK" in p.stdout, p.stdout + p.stderr
+    # and a plain creation says nothing
+    p = subprocess.run([exe, "write", str(tmp_path / "t3.nc")], capture_output=True, text=True)
+    assert p.returncode == 0 and "Warning" not in p.stderr
+
+
 @pytest.mark.parametrize("var", ["pressure_hl", "temperature_hl", "q", "cloud_fraction", "cos_solar_zenith_angle", "skin_temperature"])
 def test_record_variables_of_the_reference_input_file(exe, var):
     p = subprocess.run([exe, "dump", MERIDIAN, var], capture_output=True, text=True)
