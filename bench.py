@@ -18,7 +18,13 @@ Prints ONE JSON line on rank 0 with the contract's keys plus:
                   driver) timed on this box's host cores on a bounded sample of the same workload
   "parity":       the timed configuration checked against the oracle on EVERY timed column (batches of up to 125 000
                   columns; the first 16 384 of larger ones); a failure nulls ``value`` and makes the exit status non-zero
-  "end_to_end_host": the same call through ECRAD_MEM_HOST pointers (H2D + kernels + D2H, PCIe-inclusive)
+  "end_to_end_host": the same call through ECRAD_MEM_HOST pointers (copy-in, kernels and copy-out of column tiles pipelined on
+                  three streams; PCIe-inclusive), next to the ceiling the measured PCIe rates set for its bytes per column
+  "small_blocks": (N=1, default run) 16 host threads calling radiation() on blocks of 80 columns of host arrays at once -- the
+                  reference driver's OpenMP loop over blocks, its test namelist's nblocksize -- served side by side by the
+                  library's pool of contexts; the same blocks from one thread beside it
+`--gpus N --threads-per-process T` is a different mode: ONE process, T host threads, blocks of --block-columns columns of host
+arrays spread over N GPUs by the pool of contexts, no MPI and no torch.distributed (pool_mode).
   "workloads":    (N=1, default run) the other BASELINE configurations on this GPU, each with its own
                   value / ms_per_step / roofline / cpu_baseline / parity:
                   tripleclouds_ecckd32 (north-star shape), mcica_rrtmg (configs[2]), tripleclouds_ecckd64 at
@@ -616,8 +622,25 @@ def with_stdout_on_stderr(fn, *a, **kw):
         os.close(saved_fd)
 
 
-def end_to_end_host(w, repeats=3):
-    """The same call through ECRAD_MEM_HOST pointers: pageable host arrays, H2D + kernels + D2H inside the call."""
+PCIE_GBS = None      # (h2d, d2h, both directions at once) of this box, measured once per process with page-locked buffers
+
+
+def pcie_bandwidth(rad):
+    global PCIE_GBS
+    if PCIE_GBS is None:
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        if rad.lib.ecrad_hip_pcie_bandwidth(rad.handle, C.c_size_t(1 << 30), 3, C.byref(a), C.byref(b), C.byref(c)) != 0:
+            raise RuntimeError(rad.lib.ecrad_hip_last_error(rad.handle).decode())
+        PCIE_GBS = (a.value, b.value, c.value)
+    return PCIE_GBS
+
+
+def end_to_end_host(w, gpu_resident_value, repeats=3):
+    """The same call through ECRAD_MEM_HOST pointers -- the mode every Fortran host uses: pageable host arrays, the call copies
+    the column range in, runs the kernels and copies the results back, as a pipeline of column tiles on three streams
+    (ecrad_amd/csrc/api.hip: radiation_host_pipelined).  Next to it the ceiling the link sets: bytes per column in and out
+    (ecrad_hip_last_call_info) over the measured host-to-device / device-to-host rates with both directions busy."""
+    from ecrad_amd import abi
     from ecrad_amd.types import Flux
     ncol, nlev, sl, th, gas, cloud, aer = w.host_inputs
     if cloud is not None:
@@ -631,8 +654,163 @@ def end_to_end_host(w, repeats=3):
         t0 = time.perf_counter()
         w.rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)
         t += time.perf_counter() - t0
-    return {"value": ncol * repeats / t, "unit": "columns/s", "ms_per_call": 1e3 * t / repeats,
-            "note": "ECRAD_MEM_HOST: pageable host arrays, the call stages H2D, runs the kernels and copies back (PCIe-inclusive); never `value`"}
+    info = abi.CallInfo()
+    w.rad.lib.ecrad_hip_last_call_info(w.rad.handle, C.byref(info))
+    h2d, d2h, duplex = pcie_bandwidth(w.rad)
+    b_in, b_out = info.staged_in_bytes / ncol, info.staged_out_bytes / ncol
+    # both directions run at once: each gets its share of what the link carries in duplex, and never more than it gets alone
+    share_in, share_out = min(h2d, duplex * b_in / (b_in + b_out)), min(d2h, duplex * b_out / (b_in + b_out))
+    ceiling = 1.0e9 / max(b_in / share_in, b_out / share_out)
+    value = ncol * repeats / t
+    return {"value": value, "unit": "columns/s", "ms_per_call": 1e3 * t / repeats, "column_tiles": int(info.n_tiles), "tile_columns": int(info.tile_columns),
+            "bytes_per_column": {"in": b_in, "out": b_out},
+            "pcie_gbs": {"host_to_device": h2d, "device_to_host": d2h, "both_directions": duplex},
+            "pcie_ceiling_columns_per_s": ceiling,
+            "fraction_of_min_ceiling_and_value": value / min(ceiling, gpu_resident_value),
+            "note": "ECRAD_MEM_HOST: pageable host arrays; copy-in, kernels and copy-out of consecutive column tiles overlap on three "
+                    "streams (PCIe-inclusive); never `value`"}
+
+
+def small_blocks(name, nblock=80, nthreads=16, contexts=16, blocks_per_thread=32):
+    """What an UNCHANGED blocked caller gets: `nthreads` host threads each calling radiation() on blocks of `nblock` columns
+    of shared host arrays, as the reference's driver does with `!$OMP PARALLEL DO` over blocks (driver/ecrad_driver.F90:
+    348-370; its test namelist has nblocksize = 80).  The calls run side by side on the contexts of the library's pool
+    (include/ecrad_hip.h: ecrad_hip_set_concurrency); the same blocks from ONE thread are timed next to it."""
+    import threading
+    from ecrad_amd.interface import Radiation, build_flux_struct, build_inputs_struct
+    from ecrad_amd.synthetic import make_columns
+    from ecrad_amd.types import Flux
+    config, clear_sky, _ = build_config(name)
+    rad = Radiation(config, backend="hip", concurrency=(1, contexts))
+    ncol = nblock * blocks_per_thread * nthreads
+    n, nlev, sl, th, gas, cloud, aer = make_columns(config, ncol, clear_sky)
+    flux = Flux.allocate(config, n, nlev)
+    cin, keep = build_inputs_struct(config, n, nlev, sl, th, gas, cloud, aer)
+    cflux = build_flux_struct(flux)
+    out = {"columns_per_call": nblock, "contexts": contexts, "unit": "columns/s"}
+    for nt in (nthreads, 1):
+        blocks = [(i + 1, i + nblock) for i in range(0, nblock * blocks_per_thread * nt, nblock)]
+        for _ in range(2):      # the first round is the warm-up: every context allocates its work arrays on its first call
+            todo, lock, errors = list(blocks), threading.Lock(), []
+            start = threading.Barrier(nt + 1)
+
+            def worker():
+                start.wait()
+                while True:
+                    with lock:
+                        if not todo:
+                            return
+                        i0, i1 = todo.pop()
+                    if rad.lib.ecrad_hip_radiation(rad.handle, n, nlev, i0, i1, C.byref(cin), C.byref(cflux)) != 0:
+                        errors.append(rad.lib.ecrad_hip_last_error(rad.handle))
+                        return
+            threads = [threading.Thread(target=worker) for _ in range(nt)]
+            for t in threads:
+                t.start()
+            rad.pool_info(reset=True)
+            start.wait()
+            t0 = time.perf_counter()
+            for t in threads:
+                t.join()
+            dt = time.perf_counter() - t0
+            if errors:
+                raise RuntimeError(str(errors[0]))
+        info = rad.pool_info()
+        key = "value" if nt == nthreads else "one_thread"
+        out[key] = len(blocks) * nblock / dt
+        if nt == nthreads:
+            out.update({"threads": nt, "max_calls_in_flight": info["max_in_flight"], "ms_per_call": 1e3 * dt * nt / len(blocks)})
+    rad.close()
+    del keep
+    return out
+
+
+def pool_mode(args):
+    """`--threads-per-process T`: ONE process, no MPI, the library's pool of contexts over `--gpus N` devices, T host threads
+    calling radiation() on blocks of `--block-columns` columns of host arrays -- the reference driver's own way of using a
+    node (driver/ecrad_driver.F90:348-370), aimed at N x MI355X.  N x ncol columns per step (weak scaling); everything is
+    host-memory mode, i.e. PCIe-inclusive: a different measurement from the GPU-resident `value` of the default mode, and
+    labelled so."""
+    import threading
+    import torch
+    from ecrad_amd.interface import Radiation, build_flux_struct, build_inputs_struct
+    from ecrad_amd.synthetic import make_columns
+    from ecrad_amd.types import Flux
+    ndev = args.gpus
+    if torch.cuda.device_count() < ndev:
+        print(f"bench.py: --gpus {ndev} asked for, {torch.cuda.device_count()} GPU(s) visible on this node", file=sys.stderr)
+        sys.exit(2)
+    config, clear_sky, desc = build_config(args.workload)
+    nthreads = args.threads_per_process
+    rad = Radiation(config, backend="hip", concurrency=(ndev, max(2, -(-nthreads // ndev))))
+    base = make_columns(config, args.ncol, clear_sky)
+    nlev = base[1]
+    ncol = args.ncol * ndev
+    # the batch of every device is the same `ncol` synthetic columns: tiled along the column axis
+    objs = []
+    for obj in base[2:]:
+        if obj is None:
+            objs.append(None)
+            continue
+        import copy
+        o = copy.copy(obj)
+        for k, v in list(vars(o).items()):
+            if isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[-1] == args.ncol:
+                setattr(o, k, np.ascontiguousarray(np.concatenate([v] * ndev, axis=-1)))
+        objs.append(o)
+    sl, th, gas, cloud, aer = objs
+    frac0 = None if cloud is None else cloud.fraction.copy()
+    flux = Flux.allocate(config, ncol, nlev)
+    cin, keep = build_inputs_struct(config, ncol, nlev, sl, th, gas, cloud, aer)
+    cflux = build_flux_struct(flux)
+    nb = args.block_columns
+    blocks = [(i + 1, min(ncol, i + nb)) for i in range(0, ncol, nb)]
+
+    def step():
+        if frac0 is not None:
+            cloud.fraction[...] = frac0
+        todo, lock, errors = list(blocks), threading.Lock(), []
+
+        def worker():
+            while True:
+                with lock:
+                    if not todo:
+                        return
+                    i0, i1 = todo.pop()
+                if rad.lib.ecrad_hip_radiation(rad.handle, ncol, nlev, i0, i1, C.byref(cin), C.byref(cflux)) != 0:
+                    errors.append(rad.lib.ecrad_hip_last_error(rad.handle))
+                    return
+        threads = [threading.Thread(target=worker) for _ in range(nthreads)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise RuntimeError(str(errors[0]))
+    for _ in range(args.warmup):
+        step()
+    rad.pool_info(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    elapsed = time.perf_counter() - t0
+    info = rad.pool_info()
+    # the first `ncol` columns are what device-resident runs produce: the same fluxes, whichever device ran a block
+    same = all(np.array_equal(a[..., :args.ncol], a[..., -args.ncol:]) if a.shape[-1] == ncol else np.array_equal(a[:args.ncol], a[-args.ncol:])
+               for a in flux.arrays.values()) if ndev > 1 else True
+    out = {"metric": "columns/sec (SW+LW) at 137 lev, " + ("RRTMG 140/112" if desc["rrtmg"] else f"ecCKD-{config.n_g_sw}"),
+           "value": ncol * args.steps / elapsed, "unit": "columns/s", "n_gpus": ndev, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "mode": "host_memory_pool: one process, the library's pool of contexts over the devices, host arrays in and out of every call "
+                   "(PCIe-inclusive) -- not the GPU-resident `value` of the default mode",
+           "config": {"workload": args.workload, "columns_per_gpu_per_step": args.ncol, "nlev": nlev, "n_g_sw": config.n_g_sw, "n_g_lw": config.n_g_lw,
+                      "sw_solver": desc["sw_solver"], "threads_per_process": nthreads, "block_columns": nb,
+                      "parallelism": f"blocks of columns spread over {ndev} GPU(s) by {nthreads} host threads of one process, no collective"},
+           "pool": info, "blocks_identical_across_devices": bool(same)}
+    rad.close()
+    del keep
+    print(json.dumps(out))
+    sys.exit(0 if same else 1)
 
 
 def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allreduce_max, do_cpu, do_host_mode):
@@ -680,7 +858,7 @@ def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allredu
         else:
             res["parity"] = with_stdout_on_stderr(check_parity, w, oracle_flux, inputs_all)
     if do_host_mode and rank == 0 and w.host_inputs is not None:
-        res["end_to_end_host"] = end_to_end_host(w)
+        res["end_to_end_host"] = end_to_end_host(w, res["value"] / world)
     w.close()
     return res
 
@@ -695,7 +873,13 @@ def main():
     ap.add_argument("--workload", default="clear_homogeneous_ecckd32", help="headline workload (ecrad_amd/synthetic.py: BENCH_CONFIGS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the other BASELINE configurations (\"workloads\")")
+    ap.add_argument("--threads-per-process", type=int, default=0,
+                    help="> 0: ONE process whose host threads call radiation() on blocks of host arrays, spread over --gpus devices by the "
+                         "library's pool of contexts (host-memory mode, PCIe-inclusive: see pool_mode)")
+    ap.add_argument("--block-columns", type=int, default=12500, help="columns per call in --threads-per-process mode")
     args = ap.parse_args()
+    if args.threads_per_process > 0:
+        return pool_mode(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -770,13 +954,22 @@ def main():
         for name, ncol in EXTRA_WORKLOADS:
             steps = max(2, min(args.steps, 5 if ncol <= 100000 else 3))
             try:
-                r = measure(name, ncol, steps, 1, rank, local_rank, world, barrier, allreduce_max, do_cpu, do_host_mode=False)
+                r = measure(name, ncol, steps, 1, rank, local_rank, world, barrier, allreduce_max, do_cpu,
+                            do_host_mode=(name == "tripleclouds_ecckd32" and ncol <= CHUNK_COLUMNS))
             except Exception as e:      # an extra workload must not take the headline line down with it
                 r = {"error": f"{type(e).__name__}: {e}"}
             if "parity" in r and not r["parity"]["ok"]:
                 r["value"] = None
                 failed = True
             out["workloads"][name if name not in out["workloads"] else f"{name}_{ncol}"] = r
+    if world == 1 and not args.headline_only and args.workload == "clear_homogeneous_ecckd32":
+        # the boundary as an unchanged blocked caller uses it (blocks of 80 columns, 16 host threads, host arrays)
+        out["small_blocks"] = {}
+        for name in ("clear_homogeneous_ecckd32", "tripleclouds_ecckd32"):
+            try:
+                out["small_blocks"][name] = small_blocks(name)
+            except Exception as e:
+                out["small_blocks"][name] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if failed and "parity" in head and not head["parity"]["ok"]:
             out["value"] = None

@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 NMAXGASES = 12
 NMAXCLOUDTYPES = 12
 
@@ -196,7 +196,17 @@ class CallInfo(C.Structure):
     """ecrad_call_info_t"""
     _fields_ = [("n_tiles", C.c_int32), ("tile_columns", C.c_int32), ("launches_lw", C.c_int32),
                 ("launches_sw", C.c_int32), ("lanes_lw", C.c_int32), ("lanes_sw", C.c_int32),
-                ("work_bytes", C.c_size_t)]
+                ("work_bytes", C.c_size_t), ("staged_in_bytes", C.c_size_t), ("staged_out_bytes", C.c_size_t)]
+
+
+MAX_POOL_DEVICES = 16
+
+
+class PoolInfo(C.Structure):
+    """ecrad_pool_info_t"""
+    _fields_ = [("n_devices", C.c_int32), ("n_contexts", C.c_int32), ("in_flight", C.c_int32), ("max_in_flight", C.c_int32),
+                ("calls_total", C.c_int64), ("batches_total", C.c_int64), ("device_ids", C.c_int32 * MAX_POOL_DEVICES),
+                ("calls_on_device", C.c_int64 * MAX_POOL_DEVICES)]
 
 
 STRUCT_BY_INDEX = [Config, Inputs, Flux, Optics, CkdModel, CkdGas, CloudOptics, AerosolOptics, PdfSampler,
@@ -267,6 +277,14 @@ def declare_prototypes(lib) -> None:
     lib.ecrad_hip_set_work_bytes.restype = C.c_int
     lib.ecrad_hip_last_call_info.argtypes = [H, C.POINTER(CallInfo)]
     lib.ecrad_hip_last_call_info.restype = C.c_int
+    lib.ecrad_hip_pcie_bandwidth.argtypes = [H, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.ecrad_hip_pcie_bandwidth.restype = C.c_int
+    lib.ecrad_hip_set_concurrency.argtypes = [H, C.c_int, C.c_int]
+    lib.ecrad_hip_set_concurrency.restype = C.c_int
+    lib.ecrad_hip_pool_info.argtypes = [H, C.POINTER(PoolInfo)]
+    lib.ecrad_hip_pool_info.restype = C.c_int
+    lib.ecrad_hip_pool_reset.argtypes = [H]
+    lib.ecrad_hip_pool_reset.restype = C.c_int
 
 
 EXPORTED_SYMBOLS = [
@@ -274,5 +292,6 @@ EXPORTED_SYMBOLS = [
     "ecrad_hip_optics", "ecrad_hip_synchronize", "ecrad_hip_last_kernel_ms", "ecrad_hip_last_stage_ms",
     "ecrad_hip_scratch_bytes", "ecrad_hip_last_error", "ecrad_hip_destroy",
     "ecrad_hip_abi_sizeof", "ecrad_hip_abi_version", "ecrad_hip_set_work_bytes", "ecrad_hip_last_call_info",
-    "ecrad_hip_hbm_triad",
+    "ecrad_hip_hbm_triad", "ecrad_hip_set_concurrency", "ecrad_hip_pool_info", "ecrad_hip_pool_reset",
+    "ecrad_hip_pcie_bandwidth",
 ]

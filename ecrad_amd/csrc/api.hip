@@ -2,12 +2,16 @@
 // Mirrors radiation() in radiation/radiation_interface.F90:200-510 at the level of "which stage runs
 // when"; all arithmetic lives in the kernel_*.hip files.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "device_types.h"
@@ -34,6 +38,27 @@ struct Buf {
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
+// page-locked host memory (the staging of small host-memory calls)
+struct HostBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    bytes = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
+    hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+constexpr int kStageSlots = 3;          // staged inputs / outputs of the column tiles in flight of a pipelined host-memory call
+constexpr int kMaxPoolDevices = 16;
+constexpr int kDefaultContextsPerDevice = 8;
+
 }  // namespace
 
 struct ChunkPlan {
@@ -42,13 +67,41 @@ struct ChunkPlan {
   int g0[kMax] = {0}, ngp[kMax] = {0};
 };
 
+namespace { struct SmallCall; }
+
 struct ecrad_hip_handle_s {
   // The reference's radiation() is re-entrant and its driver calls it from an OpenMP PARALLEL DO over blocks of columns
-  // (driver/ecrad_driver.F90:348).  A handle owns one stream and one set of work arrays, so calls on a handle run one after
-  // the other: host threads may call concurrently, the calls queue here.
-  std::mutex call_mutex;
+  // (driver/ecrad_driver.F90:348-370), which is also how it spreads work over the cores of a node.  The handle the caller
+  // holds (the ROOT) is therefore the head of a POOL OF CONTEXTS: each context is one of these structs -- a device, its own
+  // streams, events and work arrays -- and the contexts of one device read the look-up tables that ONE of them (the
+  // `table_owner`) uploaded.  A host-memory call takes any free context, preferring the device with the fewest calls in
+  // flight, so concurrent calls from several host threads run side by side on one GPU (small blocks do not fill it) and
+  // spread over all the GPUs the pool covers, in one process; a device-memory call (whose arrays live on the root's
+  // device, ordered by the caller's stream) runs on the root.  ecrad_hip_set_concurrency / ECRAD_HIP_DEVICES /
+  // ECRAD_HIP_CONTEXTS size the pool.  Everything below "pool" is used on the root only.
+  ecrad_hip_handle_s* root = nullptr;            // the handle the caller holds (the root points at itself)
+  ecrad_hip_handle_s* table_owner = nullptr;     // the context of this device whose set-up uploaded the tables
+  bool busy = false;                             // a call is running on this context (guarded by root->pool_mutex)
+  bool small_batch = false;                      // ... and it is a batch of small calls
+  long long calls = 0;                           // calls this context has run
+  // -- pool (root only)
+  std::vector<ecrad_hip_handle_s*> pool;         // every context, the root first; empty until the pool is built
+  std::mutex pool_mutex;
+  std::condition_variable pool_cv;
+  int want_devices = 1, want_contexts = kDefaultContextsPerDevice;
+  int in_flight = 0, max_in_flight = 0;
+  bool exclusive = false;                        // set-up (or a resize of the pool) holds every context
+  std::vector<SmallCall*> small_waiting;          // small host-memory calls that have not been taken into a batch yet (arrival order)
+  long long batches_total = 0, batched_calls_total = 0;
+  long long calls_total = 0;
+  // -- per context
   int device = 0;
   hipStream_t stream = nullptr;
+  bool own_stream = false;                       // `stream` was created by the pool (contexts other than the root)
+  // host-memory mode: copy-in and copy-out streams of the tile pipeline, events per staging slot (see radiation_host_pipelined)
+  hipStream_t in_stream = nullptr, in_stream2 = nullptr, out_stream = nullptr;
+  hipEvent_t ev_in[kStageSlots] = {nullptr, nullptr, nullptr}, ev_in2[kStageSlots] = {nullptr, nullptr, nullptr}, ev_comp[kStageSlots] = {nullptr, nullptr, nullptr};
+  HostBuf pin_in, pin_out;                       // page-locked mirrors of the staged inputs / outputs of a small call
   // The McICA cloud generators need the cropped cloud fraction and nothing else, and are bound by integer instruction
   // issue: they run on a second stream next to the gas-optics pass (RRTMG) / the other spectrum's solver kernel and
   // join the main stream before the solver that reads their optical-depth scalings (fork after crop, join by events)
@@ -74,7 +127,8 @@ struct ecrad_hip_handle_s {
   const int32_t *d_ispec_sw = nullptr, *d_ispec_lw = nullptr;
   Buf spec_tmp;                    // per-g spectral flux profiles before that sum
   Buf partial;                     // per-chunk partial broadband profiles
-  Buf scratch, prep, staging_in, staging_out, counters;
+  Buf scratch, prep, counters;
+  Buf staging_in[kStageSlots], staging_out[kStageSlots];   // host-memory mode: staged inputs / outputs, one set per tile in flight
   const ecrad::rrtmg::DevRrtmg* d_rrtmg = nullptr;   // RRTMG tables (device), see rrtmg_device.h
   bool rrtmg_sw = false, rrtmg_lw = false;
   Buf gas_stage, gas_work;         // stage-interface arrays and work records of the RRTMG gas-optics pass
@@ -86,6 +140,8 @@ struct ecrad_hip_handle_s {
   std::vector<TileEvents> tile_events;
   int tiles_last_call = 0;
   int tile_columns_last_call = 0;
+  uint32_t gas_used = 0xffffffffu;           // bit k: gas%mixing_ratio(:,:,k+1) is read by some kernel of this configuration (set-up)
+  size_t staged_in_last_call = 0, staged_out_last_call = 0;   // host-memory mode: bytes copied to / from the device by the most recent call
   size_t work_budget = 0;                     // bytes of per-call work arrays before a call is tiled; 0 = half of the device's memory
   double stage_ms[4] = {0, 0, 0, 0};
   bool timing_pending = false;
@@ -105,6 +161,178 @@ int fail(ecrad_hip_handle_t h, int code, const std::string& msg) {
     if (e_ != hipSuccess)                                                                         \
       return fail(h, ECRAD_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));              \
   } while (0)
+
+// ---- the pool of contexts -------------------------------------------------------------------------------
+// the context this thread's most recent call ran on (what the timing / error queries of that thread refer to)
+thread_local ecrad_hip_handle_s* tl_last_context = nullptr;
+
+bool in_pool(ecrad_hip_handle_t root, const ecrad_hip_handle_s* c) {
+  if (c == root) return true;
+  for (const ecrad_hip_handle_s* k : root->pool) if (k == c) return true;
+  return false;
+}
+
+// the context a query of the calling thread is about: the one its last call ran on, the root otherwise
+ecrad_hip_handle_t query_context(ecrad_hip_handle_t h) {
+  ecrad_hip_handle_s* c = tl_last_context;
+  return (c && c != h && in_pool(h, c)) ? c : h;
+}
+
+void release_context_memory(ecrad_hip_handle_t h);
+
+// ECRAD_HIP_POOL_REPORT=1: when the process ends, one line per live handle on standard error with what
+// ecrad_hip_pool_info returns -- how an unchanged host (the reference's driver never destroys anything) shows how its
+// calls were spread
+std::mutex g_registry_mutex;
+std::vector<ecrad_hip_handle_s*> g_registry;
+void report_pools() {
+  std::lock_guard<std::mutex> lk(g_registry_mutex);
+  for (ecrad_hip_handle_s* h : g_registry) {
+    ecrad_pool_info_t info;
+    if (ecrad_hip_pool_info(h, &info) != ECRAD_OK) continue;
+    std::fprintf(stderr, "ecrad_hip pool: devices %d contexts %d calls %lld max_in_flight %d batches %lld calls_on_device", info.n_devices,
+                 info.n_contexts, (long long)info.calls_total, info.max_in_flight, (long long)info.batches_total);
+    for (int i = 0; i < info.n_devices; ++i) std::fprintf(stderr, " %d:%lld", info.device_ids[i], (long long)info.calls_on_device[i]);
+    std::fprintf(stderr, "\n");
+  }
+}
+void register_handle(ecrad_hip_handle_s* h) {
+  std::lock_guard<std::mutex> lk(g_registry_mutex);
+  static bool hooked = false;
+  if (!hooked && std::getenv("ECRAD_HIP_POOL_REPORT")) { std::atexit(report_pools); hooked = true; }
+  g_registry.push_back(h);
+}
+void unregister_handle(ecrad_hip_handle_s* h) {
+  std::lock_guard<std::mutex> lk(g_registry_mutex);
+  for (size_t i = 0; i < g_registry.size(); ++i) if (g_registry[i] == h) { g_registry.erase(g_registry.begin() + i); break; }
+}
+
+int new_context(ecrad_hip_handle_t root, int device, ecrad_hip_handle_s** out) {
+  HIP_TRY(root, hipSetDevice(device));
+  ecrad_hip_handle_s* c = new ecrad_hip_handle_s();
+  c->root = root;
+  c->device = device;
+  c->blocks_per_cu = root->blocks_per_cu;
+  c->work_budget = root->work_budget;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(root, ECRAD_EHIP, "cannot create a stream for a pool context"); }
+  c->own_stream = true;
+  *out = c;
+  return ECRAD_OK;
+}
+
+// Build (or rebuild) the pool for root->want_devices x root->want_contexts; the root is context 0 of its own device.
+// Called with no call in flight (ecrad_hip_setup holds every context).
+int build_pool(ecrad_hip_handle_t root) {
+  int ndev_visible = 0;
+  if (hipGetDeviceCount(&ndev_visible) != hipSuccess || ndev_visible <= 0) return fail(root, ECRAD_ENODEVICE, "no HIP device");
+  int ndev = root->want_devices <= 0 ? ndev_visible : std::min(root->want_devices, ndev_visible);
+  ndev = std::min(ndev, kMaxPoolDevices);
+  const int nctx = std::max(1, root->want_contexts);
+  const size_t want = (size_t)ndev * nctx;
+  if (root->pool.size() == want) return ECRAD_OK;
+  for (size_t k = 1; k < root->pool.size(); ++k) { release_context_memory(root->pool[k]); delete root->pool[k]; }
+  root->pool.assign(1, root);
+  for (int d = 0; d < ndev; ++d) {
+    const int device = (root->device + d) % ndev_visible;
+    for (int k = (d == 0 ? 1 : 0); k < nctx; ++k) {
+      ecrad_hip_handle_s* c = nullptr;
+      const int st = new_context(root, device, &c);
+      if (st) return st;
+      root->pool.push_back(c);
+    }
+  }
+  (void)hipSetDevice(root->device);
+  return ECRAD_OK;
+}
+
+// the free context on the device with the fewest calls in flight (pool_mutex held); nullptr if every context is busy
+ecrad_hip_handle_s* free_context(ecrad_hip_handle_t root) {
+  if (root->exclusive) return nullptr;
+  if (root->pool.size() <= 1) return root->busy ? nullptr : root;
+  int busy_on[kMaxPoolDevices] = {0};
+  int dev_of[kMaxPoolDevices], ndev = 0;
+  auto slot_of = [&](int device) { for (int i = 0; i < ndev; ++i) if (dev_of[i] == device) return i; dev_of[ndev] = device; return ndev++; };
+  for (ecrad_hip_handle_s* k : root->pool) { const int i = slot_of(k->device); if (k->busy) busy_on[i]++; }
+  ecrad_hip_handle_s* c = nullptr;
+  int best = 1 << 30;
+  for (ecrad_hip_handle_s* k : root->pool)
+    if (!k->busy && busy_on[slot_of(k->device)] < best) { best = busy_on[slot_of(k->device)]; c = k; }
+  return c;
+}
+
+// ... for a batch of small calls: at most `small_slots` such batches run on a device at a time, however many contexts it
+// has -- the calls that arrive meanwhile wait and form the next batch, which is where their throughput comes from (two
+// slots: one batch on the device while the callers of the next gather their rows)
+int small_slots() {
+  static const int v = [] { const char* e = std::getenv("ECRAD_HIP_SMALL_SLOTS"); const int k = e ? std::atoi(e) : 0; return k >= 1 && k <= 64 ? k : 2; }();
+  return v;
+}
+ecrad_hip_handle_s* free_context_for_small(ecrad_hip_handle_t root) {
+  if (root->exclusive) return nullptr;
+  if (root->pool.size() <= 1) return root->busy ? nullptr : root;
+  int small_on[kMaxPoolDevices] = {0}, busy_on[kMaxPoolDevices] = {0};
+  int dev_of[kMaxPoolDevices], ndev = 0;
+  auto slot_of = [&](int device) { for (int i = 0; i < ndev; ++i) if (dev_of[i] == device) return i; dev_of[ndev] = device; return ndev++; };
+  for (ecrad_hip_handle_s* k : root->pool) { const int i = slot_of(k->device); if (k->busy) busy_on[i]++; if (k->busy && k->small_batch) small_on[i]++; }
+  ecrad_hip_handle_s* c = nullptr;
+  int best = 1 << 30;
+  for (ecrad_hip_handle_s* k : root->pool) {
+    const int i = slot_of(k->device);
+    if (!k->busy && small_on[i] < small_slots() && busy_on[i] < best) { best = busy_on[i]; c = k; }
+  }
+  return c;
+}
+
+// A call's hold on one context.  any = true: whichever context is free, on the device with the fewest calls in flight
+// (host-memory calls); any = false: the root itself (device-memory calls, set-up, the stage dump).
+struct Lease {
+  ecrad_hip_handle_s* root;
+  ecrad_hip_handle_s* c = nullptr;
+  Lease(ecrad_hip_handle_t r, bool any) : root(r) {
+    std::unique_lock<std::mutex> lk(root->pool_mutex);
+    for (;;) {
+      if (root->exclusive) {
+      } else if (!any) {
+        if (!root->busy) { c = root; break; }
+      } else if ((c = free_context(root))) {
+        break;
+      }
+      root->pool_cv.wait(lk);
+    }
+    c->busy = true;
+    c->calls++;
+    root->calls_total++;
+    root->in_flight++;
+    if (root->in_flight > root->max_in_flight) root->max_in_flight = root->in_flight;
+    tl_last_context = c;
+  }
+  ~Lease() {
+    {
+      std::lock_guard<std::mutex> lk(root->pool_mutex);
+      c->busy = false;
+      root->in_flight--;
+      if (c != root && !c->err.empty()) root->err = c->err;      // (a single-threaded caller asks the root)
+    }
+    root->pool_cv.notify_all();
+  }
+};
+
+// Every context at once (set-up, resizing the pool): waits for the calls in flight to end.
+struct LeaseAll {
+  ecrad_hip_handle_s* root;
+  explicit LeaseAll(ecrad_hip_handle_t r) : root(r) {
+    std::unique_lock<std::mutex> lk(root->pool_mutex);
+    root->pool_cv.wait(lk, [&] { return root->in_flight == 0 && !root->exclusive; });
+    root->exclusive = true;
+    tl_last_context = root;
+  }
+  ~LeaseAll() {
+    { std::lock_guard<std::mutex> lk(root->pool_mutex); root->exclusive = false; }
+    root->pool_cv.notify_all();
+  }
+};
 
 template <typename T>
 int upload(ecrad_hip_handle_t h, const T* src, size_t n, const T** dst) {
@@ -345,10 +573,26 @@ int setup_rrtmg(ecrad_hip_handle_t h, const ecrad_config_t& c) {
 
 void free_tables(ecrad_hip_handle_t h) {
   h->d_rrtmg = nullptr;
+  (void)hipSetDevice(h->device);
   for (void* p : h->tables) (void)hipFree(p);
   h->tables.clear();
-  if (h->dcfg) { (void)hipFree(h->dcfg); h->dcfg = nullptr; }
+  // (a context that reads another context's tables holds copies of its pointers, nothing of its own)
+  if (h->dcfg && (h->table_owner == h || h->table_owner == nullptr)) (void)hipFree(h->dcfg);
+  h->dcfg = nullptr;
+  h->table_owner = nullptr;
   h->is_setup = false;
+}
+
+// a context of the same device takes over the owner's configuration and table pointers
+void adopt_tables(ecrad_hip_handle_t c, const ecrad_hip_handle_s* owner) {
+  free_tables(c);
+  c->cfg = owner->cfg; c->hcfg = owner->hcfg; c->dcfg = owner->dcfg; c->d_rrtmg = owner->d_rrtmg;
+  c->ngp_sw = owner->ngp_sw; c->ngp_lw = owner->ngp_lw; c->nchunk_sw = owner->nchunk_sw; c->nchunk_lw = owner->nchunk_lw;
+  c->plan_sw = owner->plan_sw; c->plan_lw = owner->plan_lw;
+  c->spec_sum_sw = owner->spec_sum_sw; c->spec_sum_lw = owner->spec_sum_lw; c->d_ispec_sw = owner->d_ispec_sw; c->d_ispec_lw = owner->d_ispec_lw;
+  c->rrtmg_sw = owner->rrtmg_sw; c->rrtmg_lw = owner->rrtmg_lw; c->gas_used = owner->gas_used;
+  c->table_owner = const_cast<ecrad_hip_handle_s*>(owner);
+  c->is_setup = true;
 }
 
 // sub-allocator over one device buffer (256-byte aligned pieces)
@@ -595,12 +839,61 @@ int ecrad_hip_create(ecrad_hip_handle_t* handle, int device_id) {
   if (device_id >= n) return ECRAD_ENODEVICE;
   if (hipSetDevice(device_id) != hipSuccess) return ECRAD_ENODEVICE;
   ecrad_hip_handle_t h = new ecrad_hip_handle_s();
+  h->root = h;
   h->device = device_id;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) h->num_cu = prop.multiProcessorCount;
   if (const char* e = std::getenv("ECRAD_HIP_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= 32) h->blocks_per_cu = v; }
   if (const char* e = std::getenv("ECRAD_HIP_WORK_GIB")) { const double v = std::atof(e); if (v > 0.0) h->work_budget = (size_t)(v * 1073741824.0); }
+  // the pool: ECRAD_HIP_DEVICES = a count or "all" (default: the one device of this handle), ECRAD_HIP_CONTEXTS = contexts per device
+  if (const char* e = std::getenv("ECRAD_HIP_DEVICES")) h->want_devices = (e[0] == 'a' || e[0] == 'A') ? 0 : std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("ECRAD_HIP_CONTEXTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) h->want_contexts = v; }
+  register_handle(h);
   *handle = h;
+  return ECRAD_OK;
+}
+
+int ecrad_hip_set_concurrency(ecrad_hip_handle_t h, int n_devices, int contexts_per_device) {
+  if (!h || n_devices < 0 || contexts_per_device < 0 || contexts_per_device > 64) return ECRAD_EINVAL;
+  const LeaseAll all(h);
+  // (the environment, when set, has the last word: an operator sizes the pool of an unchanged executable with it)
+  if (!std::getenv("ECRAD_HIP_DEVICES")) h->want_devices = n_devices;
+  if (!std::getenv("ECRAD_HIP_CONTEXTS") && contexts_per_device > 0) h->want_contexts = contexts_per_device;
+  if (h->is_setup) {      // the tables of the devices that join must come from a new ecrad_hip_setup
+    for (ecrad_hip_handle_s* c : h->pool) if (c != h) free_tables(c);
+    free_tables(h);
+  }
+  return ECRAD_OK;
+}
+
+int ecrad_hip_pool_info(ecrad_hip_handle_t h, ecrad_pool_info_t* info) {
+  if (!h || !info) return ECRAD_EINVAL;
+  std::memset(info, 0, sizeof(*info));
+  std::lock_guard<std::mutex> lk(h->pool_mutex);
+  info->n_contexts = h->pool.empty() ? 1 : (int32_t)h->pool.size();
+  info->in_flight = h->in_flight;
+  info->max_in_flight = h->max_in_flight;
+  info->calls_total = h->calls_total;
+  info->batches_total = h->batches_total;
+  auto count = [&](const ecrad_hip_handle_s* c) {
+    int i = 0;
+    while (i < info->n_devices && info->device_ids[i] != c->device) ++i;
+    if (i == info->n_devices) { if (i >= ECRAD_MAX_POOL_DEVICES) return; info->device_ids[i] = c->device; info->n_devices++; }
+    info->calls_on_device[i] += c->calls;
+  };
+  if (h->pool.empty()) count(h);
+  for (const ecrad_hip_handle_s* c : h->pool) count(c);
+  return ECRAD_OK;
+}
+
+int ecrad_hip_pool_reset(ecrad_hip_handle_t h) {
+  if (!h) return ECRAD_EINVAL;
+  std::lock_guard<std::mutex> lk(h->pool_mutex);
+  h->max_in_flight = h->in_flight;
+  h->calls_total = 0;
+  h->batches_total = h->batched_calls_total = 0;
+  h->calls = 0;
+  for (ecrad_hip_handle_s* c : h->pool) c->calls = 0;
   return ECRAD_OK;
 }
 
@@ -610,23 +903,60 @@ int ecrad_hip_set_stream(ecrad_hip_handle_t h, void* hip_stream) {
   return ECRAD_OK;
 }
 
-const char* ecrad_hip_last_error(ecrad_hip_handle_t h) { return h ? h->err.c_str() : "null handle"; }
+const char* ecrad_hip_last_error(ecrad_hip_handle_t h) {
+  if (!h) return "null handle";
+  const ecrad_hip_handle_t c = query_context(h);
+  return (c != h && !c->err.empty()) ? c->err.c_str() : h->err.c_str();
+}
+
+}  // extern "C"
+
+namespace {
+void release_context_memory(ecrad_hip_handle_t h) {
+  (void)hipSetDevice(h->device);
+  if (h->own_stream && h->stream) (void)hipStreamSynchronize(h->stream);
+  free_tables(h);
+  h->gas_stage.release(); h->gas_work.release(); h->sp_stage.release(); h->sp_list.release(); h->counters.release(); h->partial.release(); h->spec_tmp.release(); h->scratch.release(); h->prep.release();
+  for (int k = 0; k < kStageSlots; ++k) { h->staging_in[k].release(); h->staging_out[k].release(); }
+  h->pin_in.release(); h->pin_out.release();
+  for (auto& t : h->tile_events) for (auto& e : t.e) if (e) (void)hipEventDestroy(e);
+  h->tile_events.clear();
+  for (hipEvent_t e : {h->ev_fork, h->ev_gen_lw, h->ev_gen_sw, h->ev_fork_sw, h->ev_sw_done, h->ev_rrtmg_rec, h->ev_rrtmg_sw}) if (e) (void)hipEventDestroy(e);
+  for (int k = 0; k < kStageSlots; ++k) { if (h->ev_in[k]) (void)hipEventDestroy(h->ev_in[k]); if (h->ev_in2[k]) (void)hipEventDestroy(h->ev_in2[k]); if (h->ev_comp[k]) (void)hipEventDestroy(h->ev_comp[k]); }
+  if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+  if (h->in_stream) (void)hipStreamDestroy(h->in_stream);
+  if (h->in_stream2) (void)hipStreamDestroy(h->in_stream2);
+  if (h->out_stream) (void)hipStreamDestroy(h->out_stream);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+size_t held_bytes(const ecrad_hip_handle_s* h) {
+  size_t b = h->scratch.cap + h->prep.cap + h->partial.cap + h->spec_tmp.cap + h->gas_stage.cap + h->gas_work.cap + h->sp_stage.cap + h->sp_list.cap;
+  for (int k = 0; k < kStageSlots; ++k) b += h->staging_in[k].cap + h->staging_out[k].cap;
+  return b;
+}
+}  // namespace
+
+extern "C" {
 
 int ecrad_hip_destroy(ecrad_hip_handle_t h) {
   if (!h) return ECRAD_EINVAL;
-  (void)hipSetDevice(h->device);
-  free_tables(h);
-  h->gas_stage.release(); h->gas_work.release(); h->sp_stage.release(); h->sp_list.release(); h->counters.release(); h->partial.release(); h->spec_tmp.release(); h->scratch.release(); h->prep.release(); h->staging_in.release(); h->staging_out.release();
-  for (auto& t : h->tile_events) for (auto& e : t.e) if (e) (void)hipEventDestroy(e);
-  for (hipEvent_t e : {h->ev_fork, h->ev_gen_lw, h->ev_gen_sw, h->ev_fork_sw, h->ev_sw_done, h->ev_rrtmg_rec, h->ev_rrtmg_sw}) if (e) (void)hipEventDestroy(e);
-  if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
+  unregister_handle(h);
+  {
+    const LeaseAll all(h);      // (waits for the calls in flight)
+    // the contexts that read another one's tables first, the owners last
+    for (size_t k = h->pool.size(); k-- > 1;) { release_context_memory(h->pool[k]); delete h->pool[k]; }
+    h->pool.clear();
+    release_context_memory(h);
+    if (tl_last_context) tl_last_context = nullptr;
+  }
   delete h;
   return ECRAD_OK;
 }
 
 int ecrad_hip_scratch_bytes(ecrad_hip_handle_t h, size_t* bytes) {
   if (!h || !bytes) return ECRAD_EINVAL;
-  *bytes = h->scratch.cap + h->prep.cap + h->staging_in.cap + h->staging_out.cap + h->partial.cap + h->spec_tmp.cap + h->gas_stage.cap + h->gas_work.cap + h->sp_stage.cap + h->sp_list.cap;
+  *bytes = held_bytes(query_context(h));
   return ECRAD_OK;
 }
 
@@ -671,6 +1001,67 @@ int ecrad_hip_hbm_triad(ecrad_hip_handle_t h, size_t nbytes, int repeats, double
   return st;
 }
 
+int ecrad_hip_pcie_bandwidth(ecrad_hip_handle_t h, size_t nbytes, int repeats, double* h2d_gbs, double* d2h_gbs, double* duplex_gbs) {
+  if (!h || nbytes < 4096 || repeats < 1 || !h2d_gbs || !d2h_gbs || !duplex_gbs) return ECRAD_EINVAL;
+  HIP_TRY(h, hipSetDevice(h->device));
+  void *hin = nullptr, *hout = nullptr, *din = nullptr, *dout = nullptr;
+  hipStream_t s1 = nullptr, s2 = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  int st = ECRAD_OK;
+  float best[3] = {1e30f, 1e30f, 1e30f};
+  if (hipHostMalloc(&hin, nbytes, hipHostMallocDefault) != hipSuccess || hipHostMalloc(&hout, nbytes, hipHostMallocDefault) != hipSuccess ||
+      hipMalloc(&din, nbytes) != hipSuccess || hipMalloc(&dout, nbytes) != hipSuccess) {
+    st = fail(h, ECRAD_ENOMEM, "ecrad_hip_pcie_bandwidth: cannot allocate the buffers");
+  } else if (hipStreamCreateWithFlags(&s1, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess ||
+             hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess) {
+    st = fail(h, ECRAD_EHIP, "ecrad_hip_pcie_bandwidth: set-up failed");
+  } else {
+    std::memset(hin, 0, nbytes);
+    (void)hipMemsetAsync(dout, 0, nbytes, s2);
+    (void)hipStreamSynchronize(s2);
+    for (int rep = 0; rep <= repeats && st == ECRAD_OK; ++rep) {      // (the first round is a warm-up)
+      float ms = 0.f;
+      bool ok = true;
+      // host -> device alone
+      ok = ok && hipEventRecord(e0, s1) == hipSuccess && hipMemcpyAsync(din, hin, nbytes, hipMemcpyHostToDevice, s1) == hipSuccess &&
+           hipEventRecord(e1, s1) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+      if (ok && rep > 0 && ms < best[0]) best[0] = ms;
+      // device -> host alone
+      ok = ok && hipEventRecord(e0, s2) == hipSuccess && hipMemcpyAsync(hout, dout, nbytes, hipMemcpyDeviceToHost, s2) == hipSuccess &&
+           hipEventRecord(e1, s2) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+      if (ok && rep > 0 && ms < best[1]) best[1] = ms;
+      // both directions at once, each from its own host thread (as the tile pipeline of a host-memory call does it): wall
+      // time of the pair
+      (void)hipStreamSynchronize(s1); (void)hipStreamSynchronize(s2);
+      const auto t0 = std::chrono::steady_clock::now();
+      bool ok2 = true;
+      const int device = h->device;
+      std::thread other([&] {
+        ok2 = hipSetDevice(device) == hipSuccess && hipMemcpyAsync(hout, dout, nbytes, hipMemcpyDeviceToHost, s2) == hipSuccess &&
+              hipStreamSynchronize(s2) == hipSuccess;
+      });
+      ok = ok && hipMemcpyAsync(din, hin, nbytes, hipMemcpyHostToDevice, s1) == hipSuccess && hipStreamSynchronize(s1) == hipSuccess;
+      other.join();
+      ok = ok && ok2;
+      ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (ok && rep > 0 && ms < best[2]) best[2] = ms;
+      if (!ok) st = fail(h, ECRAD_EHIP, "ecrad_hip_pcie_bandwidth: copy failed");
+    }
+  }
+  for (hipEvent_t e : {e0, e1, e2}) if (e) (void)hipEventDestroy(e);
+  if (s1) (void)hipStreamDestroy(s1);
+  if (s2) (void)hipStreamDestroy(s2);
+  if (hin) (void)hipHostFree(hin);
+  if (hout) (void)hipHostFree(hout);
+  (void)hipFree(din); (void)hipFree(dout);
+  if (st == ECRAD_OK) {
+    *h2d_gbs = (double)nbytes / ((double)best[0] * 1.0e6);
+    *d2h_gbs = (double)nbytes / ((double)best[1] * 1.0e6);
+    *duplex_gbs = 2.0 * (double)nbytes / ((double)best[2] * 1.0e6);
+  }
+  return st;
+}
+
 int ecrad_hip_synchronize(ecrad_hip_handle_t h) {
   if (!h) return ECRAD_EINVAL;
   HIP_TRY(h, hipSetDevice(h->device));
@@ -680,7 +1071,9 @@ int ecrad_hip_synchronize(ecrad_hip_handle_t h) {
 
 int ecrad_hip_last_kernel_ms(ecrad_hip_handle_t h, double* ms) {
   if (!h || !ms) return ECRAD_EINVAL;
+  h = query_context(h);      // the context this thread's last call ran on
   if (h->timing_pending) {
+    HIP_TRY(h, hipSetDevice(h->device));
     for (int k = 0; k < 4; ++k) h->stage_ms[k] = 0.0;
     h->last_ms = 0.0;
     for (int t = 0; t < h->tiles_last_call; ++t) {
@@ -709,9 +1102,11 @@ int ecrad_hip_last_stage_ms(ecrad_hip_handle_t h, int which, double* ms) {
 }
 
 // ----------------------------------------------------------------------------------------------------
-int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
-  if (!h || !cp) return ECRAD_EINVAL;
-  const std::lock_guard<std::mutex> one_call_at_a_time(h->call_mutex);
+}  // extern "C"
+
+namespace {
+// the tables of one device: uploaded through context h, which becomes their owner
+int setup_one(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
   HIP_TRY(h, hipSetDevice(h->device));
   const ecrad_config_t& c = *cp;
   int st = validate_config(h, c);
@@ -913,7 +1308,43 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
   }
   HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&h->dcfg), sizeof(DevConfig)));
   HIP_TRY(h, hipMemcpy(h->dcfg, &d, sizeof(DevConfig), hipMemcpyHostToDevice));
+  // Which planes of gas%mixing_ratio the kernels read: the gases an ecCKD model scales its tables with (level_scalars),
+  // water vapour for the aerosols' relative humidity; every plane with RRTMG (rrtmg_setcoef).  Host-memory calls copy
+  // these planes only (5 of the 12 planes of an ecCKD-32 run are never read: 5.5 KB of the 24 KB a column moves in).
+  h->gas_used = 0;
+  if (h->rrtmg_sw || h->rrtmg_lw) h->gas_used = 0xffffffffu;
+  for (const DevCkdModel* m : {c.do_sw && !h->rrtmg_sw ? &d.gas_sw : nullptr, c.do_lw && !h->rrtmg_lw ? &d.gas_lw : nullptr})
+    if (m) for (int j = 0; j < m->ngas; ++j)
+      if (m->gas[j].i_conc_dependence != ECRAD_CONC_NONE && m->gas[j].i_gas_code >= 1) h->gas_used |= 1u << (m->gas[j].i_gas_code - 1);
+  if (c.use_aerosols) h->gas_used |= 1u << (ECRAD_IH2O - 1);
+  if (std::getenv("ECRAD_HIP_ALL_GASES")) h->gas_used = 0xffffffffu;
+  h->table_owner = h;
   h->is_setup = true;
+  return ECRAD_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
+  if (!h || !cp) return ECRAD_EINVAL;
+  const LeaseAll all(h);      // (waits for the calls in flight; no call starts before every device has its tables)
+  int st = build_pool(h);
+  if (st) return st;
+  // one upload per device, by the first context of that device; the others take over its pointers
+  for (ecrad_hip_handle_s* c : h->pool) {
+    ecrad_hip_handle_s* owner = nullptr;
+    for (ecrad_hip_handle_s* k : h->pool) { if (k == c) break; if (k->device == c->device && k->table_owner == k) { owner = k; break; } }
+    if (owner) { adopt_tables(c, owner); continue; }
+    if ((st = setup_one(c, cp))) {
+      if (c != h) h->err = c->err;
+      for (ecrad_hip_handle_s* k : h->pool) if (k != h) free_tables(k);
+      free_tables(h);
+      (void)hipSetDevice(h->device);
+      return st;
+    }
+  }
+  (void)hipSetDevice(h->device);
   return ECRAD_OK;
 }
 
@@ -930,7 +1361,9 @@ struct CallCtx {
   const double* solar_scaling = nullptr;      // single_level%spectral_solar_scaling (host memory), RRTMG shortwave only
 };
 
-int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol, const ecrad_inputs_t* in, CallCtx& cx) {
+// Host side of the inputs of one tile: checks, and where the kernels will find every array (the caller's device arrays, or
+// slot `slot` of the staged copies in host-memory mode).  Nothing is enqueued here.
+int plan_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol, const ecrad_inputs_t* in, CallCtx& cx, int slot) {
   const ecrad_config_t& c = h->cfg;
   if (ncol < 1 || nlev < 2 || istartcol < 1 || iendcol > ncol || iendcol < istartcol) return fail(h, ECRAD_EINVAL, "bad column/level range");
   if (nlev > 256) return fail(h, ECRAD_EUNSUPPORTED, "more than 256 levels");
@@ -980,38 +1413,9 @@ int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int ie
   }
   const Range& r = cx.r;
   StagedInputs sz = carve_inputs(nullptr, c, *in, r);
-  HIP_TRY(h, h->staging_in.ensure(sz.bytes));
-  cx.si = carve_inputs(h->staging_in.p, c, *in, r);
+  HIP_TRY(h, h->staging_in[slot].ensure(sz.bytes));
+  cx.si = carve_inputs(h->staging_in[slot].p, c, *in, r);
   const StagedInputs& s = cx.si;
-  hipStream_t st = h->stream;
-  auto copy2d = [&](void* dst, const void* src, size_t rows, size_t elem) -> hipError_t {
-    if (!dst || !src || rows == 0) return hipSuccess;
-    return hipMemcpy2DAsync(dst, r.nloc * elem, reinterpret_cast<const char*>(src) + (size_t)(r.i0 - 1) * elem,
-                            (size_t)r.ncol * elem, r.nloc * elem, rows, hipMemcpyHostToDevice, st);
-  };
-  const size_t L = nlev;
-  HIP_TRY(h, copy2d(s.pressure_hl, in->pressure_hl, L + 1, 8));
-  HIP_TRY(h, copy2d(s.temperature_hl, in->temperature_hl, L + 1, 8));
-  HIP_TRY(h, copy2d(s.h2o_sat_liq, in->h2o_sat_liq, L, 8));
-  HIP_TRY(h, copy2d(s.cos_sza, in->cos_sza, 1, 8));
-  HIP_TRY(h, copy2d(s.skin_temperature, in->skin_temperature, 1, 8));
-  HIP_TRY(h, copy2d(s.sw_albedo, in->sw_albedo, in->n_sw_albedo, 8));
-  HIP_TRY(h, copy2d(s.sw_albedo_direct, in->sw_albedo_direct, in->n_sw_albedo, 8));
-  HIP_TRY(h, copy2d(s.lw_emissivity, in->lw_emissivity, in->n_lw_emissivity, 8));
-  HIP_TRY(h, copy2d(s.iseed, in->iseed, 1, 4));
-  HIP_TRY(h, copy2d(s.gas_mixing_ratio, in->gas_mixing_ratio, L * ECRAD_NMAXGASES, 8));
-  if (c.do_clouds) {
-    HIP_TRY(h, copy2d(s.cloud_fraction, in->cloud_fraction, L, 8));
-    HIP_TRY(h, copy2d(s.cloud_mixing_ratio, in->cloud_mixing_ratio, L * in->n_cloud_types, 8));
-    HIP_TRY(h, copy2d(s.cloud_effective_radius, in->cloud_effective_radius, L * in->n_cloud_types, 8));
-    HIP_TRY(h, copy2d(s.cloud_fractional_std, in->cloud_fractional_std, L, 8));
-    HIP_TRY(h, copy2d(s.cloud_overlap_param, in->cloud_overlap_param, L - 1, 8));
-    HIP_TRY(h, copy2d(s.cloud_inv_cloud_effective_size, in->cloud_inv_cloud_effective_size, L, 8));
-    HIP_TRY(h, copy2d(s.cloud_inv_inhom_effective_size, in->cloud_inv_inhom_effective_size, L, 8));
-  }
-  if (c.use_aerosols)
-    HIP_TRY(h, copy2d(s.aerosol_mixing_ratio, in->aerosol_mixing_ratio,
-                      (size_t)(in->aerosol_iendlev - in->aerosol_istartlev + 1) * in->n_aerosol_types, 8));
   d.ncol = r.nloc; d.istartcol = 1; d.iendcol = r.nloc;
   d.pressure_hl = s.pressure_hl; d.temperature_hl = s.temperature_hl; d.h2o_sat_liq = s.h2o_sat_liq;
   d.cos_sza = s.cos_sza; d.skin_temperature = s.skin_temperature; d.sw_albedo = s.sw_albedo;
@@ -1023,6 +1427,75 @@ int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int ie
   d.cloud_inv_cloud_effective_size = s.cloud_inv_cloud_effective_size;
   d.cloud_inv_inhom_effective_size = s.cloud_inv_inhom_effective_size;
   return ECRAD_OK;
+}
+
+// The rows of the staged inputs: (destination in the staged layout, the caller's array, rows, bytes per element).  A row is
+// the `nloc` columns of the call's range out of the `ncol` of the caller's array (column index fastest in every array).
+struct InputRow { void* dst; const void* src; size_t rows, elem; };
+constexpr int kMaxInputRows = 40;
+// nstaged: columns of the staged copy, ncol: columns of the caller's arrays (the planes of a 3-D array lie n x L and ncol x L apart)
+int input_rows(const ecrad_config_t& c, const ecrad_inputs_t* in, const StagedInputs& s, int nlev, size_t nstaged, size_t ncol, uint32_t gas_used,
+               InputRow (&out)[kMaxInputRows]) {
+  const size_t L = nlev;
+  int n = 0;
+  auto add = [&](void* dst, const void* src, size_t rows, size_t elem) { if (dst && src && rows) out[n++] = {dst, src, rows, elem}; };
+  add(s.pressure_hl, in->pressure_hl, L + 1, 8);
+  add(s.temperature_hl, in->temperature_hl, L + 1, 8);
+  add(s.h2o_sat_liq, in->h2o_sat_liq, L, 8);
+  add(s.cos_sza, in->cos_sza, 1, 8);
+  add(s.skin_temperature, in->skin_temperature, 1, 8);
+  add(s.sw_albedo, in->sw_albedo, in->n_sw_albedo, 8);
+  add(s.sw_albedo_direct, in->sw_albedo_direct, in->n_sw_albedo, 8);
+  add(s.lw_emissivity, in->lw_emissivity, in->n_lw_emissivity, 8);
+  add(s.iseed, in->iseed, 1, 4);
+  for (int k = 0; k < ECRAD_NMAXGASES; ++k)      // the planes some kernel reads (ecrad_hip_setup: gas_used)
+    if (gas_used & (1u << k)) add(s.gas_mixing_ratio + (size_t)k * L * nstaged, in->gas_mixing_ratio + (size_t)k * L * ncol, L, 8);
+  if (c.do_clouds) {
+    add(s.cloud_fraction, in->cloud_fraction, L, 8);
+    add(s.cloud_mixing_ratio, in->cloud_mixing_ratio, L * in->n_cloud_types, 8);
+    add(s.cloud_effective_radius, in->cloud_effective_radius, L * in->n_cloud_types, 8);
+    add(s.cloud_fractional_std, in->cloud_fractional_std, L, 8);
+    add(s.cloud_overlap_param, in->cloud_overlap_param, L - 1, 8);
+    add(s.cloud_inv_cloud_effective_size, in->cloud_inv_cloud_effective_size, L, 8);
+    add(s.cloud_inv_inhom_effective_size, in->cloud_inv_inhom_effective_size, L, 8);
+  }
+  if (c.use_aerosols)
+    add(s.aerosol_mixing_ratio, in->aerosol_mixing_ratio, (size_t)(in->aerosol_iendlev - in->aerosol_istartlev + 1) * in->n_aerosol_types, 8);
+  return n;
+}
+
+// H2D of the column range of every input array (host-memory mode), one 2-D copy per array, on `st`
+int copy_inputs(ecrad_hip_handle_t h, const ecrad_inputs_t* in, const CallCtx& cx, hipStream_t st, int part = 0, int nparts = 1) {
+  if (!cx.host_mem) return ECRAD_OK;
+  const Range& r = cx.r;
+  InputRow rows[kMaxInputRows];
+  const int n = input_rows(h->cfg, in, cx.si, r.nlev, r.nloc, r.ncol, h->gas_used, rows);
+  // (dealt out by bytes: the arrays in decreasing size go to whichever part has the least so far)
+  int part_of[kMaxInputRows];
+  {
+    size_t load[8] = {0};
+    bool done[kMaxInputRows] = {false};
+    for (int i = 0; i < n; ++i) {
+      int big = -1;
+      for (int k = 0; k < n; ++k) if (!done[k] && (big < 0 || rows[k].rows * rows[k].elem > rows[big].rows * rows[big].elem)) big = k;
+      int least = 0;
+      for (int q = 1; q < nparts && q < 8; ++q) if (load[q] < load[least]) least = q;
+      part_of[big] = least; load[least] += rows[big].rows * rows[big].elem; done[big] = true;
+    }
+  }
+  for (int k = 0; k < n; ++k) {
+    if (part_of[k] != part) continue;
+    const InputRow& w = rows[k];
+    HIP_TRY(h, hipMemcpy2DAsync(w.dst, r.nloc * w.elem, reinterpret_cast<const char*>(w.src) + (size_t)(r.i0 - 1) * w.elem,
+                                (size_t)r.ncol * w.elem, r.nloc * w.elem, w.rows, hipMemcpyHostToDevice, st));
+  }
+  return ECRAD_OK;
+}
+
+// (the stage dump and the unpipelined path: plan + copy on the context's stream)
+int stage_inputs(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol, const ecrad_inputs_t* in, CallCtx& cx) {
+  const int st = plan_inputs(h, ncol, nlev, istartcol, iendcol, in, cx, 0);
+  return st ? st : copy_inputs(h, in, cx, h->stream);
 }
 
 // RRTMG: the separate gas-optics pass that fills the stage arrays the solver kernels read (din.gs)
@@ -1142,45 +1615,57 @@ int ensure_aux_stream(ecrad_hip_handle_t h) {
   return ECRAD_OK;
 }
 
-// One tile of columns istartcol..iendcol of a call: everything radiation() does (radiation_interface.F90:200-510)
-int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
-                   const ecrad_inputs_t* in, ecrad_flux_t* flux, int tile) {
-  const ecrad_config_t& c = h->cfg;
-  if ((int)h->tile_events.size() <= tile) h->tile_events.resize(tile + 1);
-  for (auto& e : h->tile_events[tile].e)
-    if (!e) HIP_TRY(h, hipEventCreate(&e));
-  hipEvent_t* const evs = h->tile_events[tile].e;
+// One tile of columns istartcol..iendcol of a call -- everything radiation() does (radiation_interface.F90:200-510) -- in four
+// steps, so that a host-memory call can run the steps of consecutive tiles side by side (radiation_host_pipelined):
+//   tile_plan      host side only: checks, where every array of the tile lives on the device
+//   tile_copy_in   host-memory mode: clear the staged outputs, H2D of the column range of the inputs
+//   tile_compute   the kernels, on the context's stream
+//   tile_copy_out  host-memory mode: D2H of the column range of the outputs (and of the cropped cloud fraction)
+struct Tile {
+  int ncol = 0, nlev = 0, istartcol = 0, iendcol = 0, index = 0, slot = 0;
+  const ecrad_inputs_t* in = nullptr;
+  ecrad_flux_t* flux = nullptr;
   CallCtx cx;
-  int st = stage_inputs(h, ncol, nlev, istartcol, iendcol, in, cx);
+  DevFlux dfx{};
+  std::vector<std::pair<const FluxField*, double*>> staged;      // (field, its place in the staged outputs)
+  double* spec_real[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t out_bytes = 0;
+};
+
+// the spectral flux profiles of DevFlux, longwave first
+double* DevFlux::* const kSpecArr[10] = {&DevFlux::lw_up_band, &DevFlux::lw_dn_band, &DevFlux::lw_up_clear_band, &DevFlux::lw_dn_clear_band,
+                                         &DevFlux::sw_up_band, &DevFlux::sw_dn_band, &DevFlux::sw_dn_direct_band,
+                                         &DevFlux::sw_up_clear_band, &DevFlux::sw_dn_clear_band, &DevFlux::sw_dn_direct_clear_band};
+
+int tile_plan(ecrad_hip_handle_t h, Tile& T) {
+  const ecrad_config_t& c = h->cfg;
+  const int nlev = T.nlev;
+  ecrad_flux_t* const flux = T.flux;
+  CallCtx& cx = T.cx;
+  int st = plan_inputs(h, T.ncol, T.nlev, T.istartcol, T.iendcol, T.in, cx, T.slot);
   if (st) return st;
   const Range& r = cx.r;
-  hipStream_t stream = h->stream;
 
   // ---- output arrays -------------------------------------------------------------------------------
-  DevFlux dfx{};
-  std::vector<std::pair<const FluxField*, double*>> staged;
+  DevFlux& dfx = T.dfx;
+  dfx = DevFlux{};
+  auto& staged = T.staged;
+  staged.clear();
   if (!cx.host_mem) {
     for (const FluxField& f : kFluxFields) dfx.*(f.dev) = flux->*(f.host);
   } else {
     size_t off = 0;
     for (const FluxField& f : kFluxFields)
       if (flux->*(f.host)) off += (flux_rows(c, f.kind, nlev) * r.nloc * 8 + 255) & ~size_t(255);
-    HIP_TRY(h, h->staging_out.ensure(off));
-    // Entries that a solver never writes for a processed column (e.g. sw_dn_toa_g outside
-    // Tripleclouds, per-g TOA values of night-time Tripleclouds columns) are undefined in the
-    // reference (never assigned after allocate); here they are deterministically zero.
-    HIP_TRY(h, hipMemsetAsync(h->staging_out.p, 0, off, stream));
-    Carver cv(h->staging_out.p);
+    HIP_TRY(h, h->staging_out[T.slot].ensure(off));
+    T.out_bytes = off;
+    Carver cv(h->staging_out[T.slot].p);
     for (const FluxField& f : kFluxFields)
       if (flux->*(f.host)) {
         double* p = cv.take<double>(flux_rows(c, f.kind, nlev) * r.nloc);
         dfx.*(f.dev) = p;
         staged.emplace_back(&f, p);
       }
-    // cloud cover keeps the caller's initial value where a solver does not write it (e.g. -1 at night)
-    for (auto& sp : staged)
-      if (sp.first->kind == 7)
-        HIP_TRY(h, hipMemcpyAsync(sp.second, flux->*(sp.first->host) + (r.i0 - 1), r.nloc * 8, hipMemcpyHostToDevice, stream));
   }
   // The McICA solvers never store spectral flux profiles (radiation_config.F90:1331-1334); without
   // do_save_spectral_flux nobody does
@@ -1197,10 +1682,9 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
   }
   // Spectral flux profiles in intervals other than one per g-point: the kernels write per-g temporaries
   // (leading dimension ng) and spectral_profile_sum_kernel adds the g-points of every interval afterwards
-  double* DevFlux::* const spec_arr[10] = {&DevFlux::lw_up_band, &DevFlux::lw_dn_band, &DevFlux::lw_up_clear_band, &DevFlux::lw_dn_clear_band,
-                                           &DevFlux::sw_up_band, &DevFlux::sw_dn_band, &DevFlux::sw_dn_direct_band,
-                                           &DevFlux::sw_up_clear_band, &DevFlux::sw_dn_clear_band, &DevFlux::sw_dn_direct_clear_band};
-  double* spec_real[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  double* DevFlux::* const* const spec_arr = kSpecArr;
+  double** const spec_real = T.spec_real;
+  for (int k = 0; k < 10; ++k) spec_real[k] = nullptr;
   {
     const size_t plane = (size_t)cx.din.ncol * (nlev + 1);
     size_t need = 0;
@@ -1231,6 +1715,91 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
       return fail(h, ECRAD_EINVAL, "clear-sky shortwave flux arrays must be allocated when do_clear");
   }
   if (c.do_clouds && (!dfx.cloud_cover_lw || !dfx.cloud_cover_sw)) return fail(h, ECRAD_EINVAL, "flux%cloud_cover_* must be allocated");
+  if (cx.host_mem) {      // what this tile moves over PCIe (ecrad_hip_last_call_info)
+    InputRow rows[kMaxInputRows];
+    const int n = input_rows(c, T.in, cx.si, nlev, r.nloc, r.ncol, h->gas_used, rows);
+    size_t b = 0;
+    for (int k = 0; k < n; ++k) b += rows[k].rows * rows[k].elem * (size_t)r.nloc;
+    h->staged_in_last_call += b;
+    b = c.do_clouds ? (size_t)nlev * r.nloc * 8 : 0;
+    for (const auto& sp : staged) b += flux_rows(c, sp.first->kind, nlev) * (size_t)r.nloc * 8;
+    h->staged_out_last_call += b;
+  }
+  return ECRAD_OK;
+}
+
+// the rows of the staged outputs that go back to the caller: (staged source, the caller's array at the first column of the
+// range, rows, bytes of a row in the staged copy, bytes between rows in the caller's array)
+struct OutputRow { const void* src; void* dst; size_t rows, row_bytes, dst_pitch; };
+int output_rows(ecrad_hip_handle_t h, const Tile& T, std::vector<OutputRow>& out) {
+  const ecrad_config_t& c = h->cfg;
+  const Range& r = T.cx.r;
+  out.clear();
+  for (const auto& sp : T.staged) {
+    const FluxField& f = *sp.first;
+    double* hostp = T.flux->*(f.host);
+    const size_t rows = flux_rows(c, f.kind, T.nlev);
+    if (f.kind == 0) {
+      out.push_back({sp.second, hostp + (r.i0 - 1), rows, (size_t)r.nloc * 8, (size_t)r.ncol * 8});
+    } else if (f.kind >= 8) {     // (nspec, ncol, nlev+1)
+      const size_t nspec = f.kind == 8 ? c.n_spec_lw : c.n_spec_sw;
+      if ((T.dfx.*(f.dev)) == nullptr) continue;    // not written by this solver: leave the caller's array alone
+      out.push_back({sp.second, hostp + nspec * (r.i0 - 1), (size_t)T.nlev + 1, (size_t)r.nloc * nspec * 8, (size_t)r.ncol * nspec * 8});
+    } else {                      // (rows, ncol): the columns of the range are one contiguous piece
+      out.push_back({sp.second, hostp + rows * (r.i0 - 1), 1, rows * r.nloc * 8, rows * r.nloc * 8});
+    }
+  }
+  if (c.do_clouds)   // crop_cloud_fraction side effect on the caller's array
+    out.push_back({T.cx.si.cloud_fraction, T.in->cloud_fraction + (r.i0 - 1), (size_t)T.nlev, (size_t)r.nloc * 8, (size_t)r.ncol * 8});
+  return ECRAD_OK;
+}
+
+// part / nparts: the input arrays are dealt out between `nparts` callers (the copy-in threads of the tile pipeline: a copy
+// from pageable memory is staged by the calling thread, two threads stage twice as fast); part 0 also clears the outputs
+int tile_copy_in(ecrad_hip_handle_t h, Tile& T, hipStream_t st, int part = 0, int nparts = 1) {
+  if (!T.cx.host_mem) return ECRAD_OK;
+  const Range& r = T.cx.r;
+  if (part == 0) {
+    // Entries that a solver never writes for a processed column (e.g. sw_dn_toa_g outside
+    // Tripleclouds, per-g TOA values of night-time Tripleclouds columns) are undefined in the
+    // reference (never assigned after allocate); here they are deterministically zero.
+    HIP_TRY(h, hipMemsetAsync(h->staging_out[T.slot].p, 0, T.out_bytes, st));
+    for (auto& sp : T.staged)
+      if (sp.first->kind == 7)
+        HIP_TRY(h, hipMemcpyAsync(sp.second, T.flux->*(sp.first->host) + (r.i0 - 1), r.nloc * 8, hipMemcpyHostToDevice, st));
+  }
+  return copy_inputs(h, T.in, T.cx, st, part, nparts);
+}
+
+// D2H of the processed column range only: columns outside istartcol..iendcol are not touched.  Returns with the copies
+// enqueued on `st`.
+int tile_copy_out(ecrad_hip_handle_t h, Tile& T, hipStream_t st) {
+  if (!T.cx.host_mem) return ECRAD_OK;
+  std::vector<OutputRow> rows;
+  output_rows(h, T, rows);
+  for (const OutputRow& w : rows) {
+    if (w.rows == 1) HIP_TRY(h, hipMemcpyAsync(w.dst, w.src, w.row_bytes, hipMemcpyDeviceToHost, st));
+    else HIP_TRY(h, hipMemcpy2DAsync(w.dst, w.dst_pitch, w.src, w.row_bytes, w.row_bytes, w.rows, hipMemcpyDeviceToHost, st));
+  }
+  return ECRAD_OK;
+}
+
+int tile_compute(ecrad_hip_handle_t h, Tile& T) {
+  const ecrad_config_t& c = h->cfg;
+  const int nlev = T.nlev, tile = T.index;
+  const ecrad_inputs_t* const in = T.in;
+  (void)in;
+  if ((int)h->tile_events.size() <= tile) h->tile_events.resize(tile + 1);
+  for (auto& e : h->tile_events[tile].e)
+    if (!e) HIP_TRY(h, hipEventCreate(&e));
+  hipEvent_t* const evs = h->tile_events[tile].e;
+  CallCtx& cx = T.cx;
+  const Range& r = cx.r;
+  hipStream_t stream = h->stream;
+  DevFlux& dfx = T.dfx;
+  double* DevFlux::* const* const spec_arr = kSpecArr;
+  double** const spec_real = T.spec_real;
+  int st = ECRAD_OK;
 
   // ---- scratch & prep buffers ------------------------------------------------------------------------
   const bool sw_mcica = c.do_sw && c.i_solver_sw == ECRAD_SOLVER_MCICA, lw_mcica = c.do_lw && c.i_solver_lw == ECRAD_SOLVER_MCICA;
@@ -1539,30 +2108,490 @@ int radiation_tile(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int 
                     c.n_canopy_bands_sw > 64 || c.n_canopy_bands_lw > 64;
   HIP_TRY(h, launch_spectral_post(stream, h->dcfg, din, dfx, wide));                          // :503-504
   HIP_TRY(h, hipEventRecord(evs[4], stream));
+  return ECRAD_OK;
+}
 
-  if (cx.host_mem) {
-    // D2H of the processed column range only: columns outside istartcol..iendcol are not touched
-    for (auto& sp : staged) {
-      const FluxField& f = *sp.first;
-      double* hostp = flux->*(f.host);
-      const size_t rows = flux_rows(c, f.kind, nlev);
-      if (f.kind == 0) {
-        HIP_TRY(h, hipMemcpy2DAsync(hostp + (r.i0 - 1), (size_t)r.ncol * 8, sp.second, (size_t)r.nloc * 8,
-                                    (size_t)r.nloc * 8, rows, hipMemcpyDeviceToHost, stream));
-      } else if (f.kind >= 8) {     // (nspec, ncol, nlev+1)
-        const size_t nspec = f.kind == 8 ? c.n_spec_lw : c.n_spec_sw;
-        if ((dfx.*(f.dev)) == nullptr) continue;    // not written by this solver: leave the caller's array alone
-        HIP_TRY(h, hipMemcpy2DAsync(hostp + nspec * (r.i0 - 1), (size_t)r.ncol * nspec * 8, sp.second, (size_t)r.nloc * nspec * 8,
-                                    (size_t)r.nloc * nspec * 8, (size_t)nlev + 1, hipMemcpyDeviceToHost, stream));
-      } else {
-        HIP_TRY(h, hipMemcpyAsync(hostp + rows * (r.i0 - 1), sp.second, rows * r.nloc * 8, hipMemcpyDeviceToHost, stream));
-      }
-    }
-    if (c.do_clouds)   // crop_cloud_fraction side effect on the caller's array
-      HIP_TRY(h, hipMemcpy2DAsync(in->cloud_fraction + (r.i0 - 1), (size_t)r.ncol * 8, cx.si.cloud_fraction,
-                                  (size_t)r.nloc * 8, (size_t)r.nloc * 8, nlev, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(h, hipStreamSynchronize(stream));
+}  // namespace
+
+extern "C" {
+
+}  // extern "C"
+
+namespace {
+
+int ensure_copy_streams(ecrad_hip_handle_t h) {
+  if (!h->in_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->in_stream, hipStreamNonBlocking));
+  if (!h->in_stream2) HIP_TRY(h, hipStreamCreateWithFlags(&h->in_stream2, hipStreamNonBlocking));
+  if (!h->out_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->out_stream, hipStreamNonBlocking));
+  for (int k = 0; k < kStageSlots; ++k) {
+    if (!h->ev_in[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_in[k], hipEventDisableTiming));
+    if (!h->ev_in2[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_in2[k], hipEventDisableTiming));
+    if (!h->ev_comp[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_comp[k], hipEventDisableTiming));
   }
+  return ECRAD_OK;
+}
+
+// Columns per tile of a pipelined host-memory call: large enough that a tile's kernels fill the GPU twice over (256 CUs x 3
+// blocks x 8 columns = 6144 columns per round of the 32-lane kernels), small enough that the first tile's copy-in and the
+// last tile's copy-out -- the two transfers nothing hides -- are a small part of the call.  ECRAD_HIP_HOST_TILE overrides.
+int host_tile_columns() {
+  if (const char* e = std::getenv("ECRAD_HIP_HOST_TILE")) { const int v = std::atoi(e); if (v >= 256) return v / 256 * 256; }
+  return 12288;
+}
+// a host-memory call of at most this many columns is a "small call": it travels as part of a batch through page-locked mirrors
+// (radiation_small); ECRAD_HIP_PACK_COLUMNS changes the limit, 0 switches the batching off
+int packed_call_columns() {
+  if (const char* e = std::getenv("ECRAD_HIP_PACK_COLUMNS")) return std::max(0, std::atoi(e));
+  return 512;
+}
+
+// A host-memory call of several tiles as a three-stage pipeline: while the kernels of tile t run on the context's stream,
+// the inputs of tile t+1 (and t+2) travel to the device on `in_stream` and the outputs of tile t-1 travel back on
+// `out_stream`; kStageSlots sets of staged arrays, the work arrays of the kernels are shared (the kernels of consecutive
+// tiles run one after the other on one stream).  The caller's arrays are pageable memory, for which hipMemcpy*Async returns
+// when the copy is done and which the runtime stages through page-locked buffers on the calling thread: the copy-in has TWO
+// helper threads for the duration of the call (the input arrays dealt out between them by bytes: one thread staged 40 GB/s of
+// the link's 57), the copy-out one; the calling thread enqueues the kernels.  PCIe carries both directions at once: the call then costs what the larger of the two
+// transfers costs (the inputs), not the sum of transfers and kernels.
+int radiation_host_pipelined(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
+                             const ecrad_inputs_t* in, ecrad_flux_t* flux, long long tile_cols) {
+  const int nloc = iendcol - istartcol + 1;
+  int st = ensure_copy_streams(h);
+  if (st) return st;
+  // Tile sizes.  The copy-in of the first tile and the copy-out of the last are the two transfers nothing hides, so a long
+  // call ramps up and down: a quarter tile, half a tile, full tiles ..., half a tile, a quarter tile.
+  std::vector<int> sizes;
+  {
+    const int T = (int)tile_cols, q = std::max(256, T / 4 / 256 * 256), hf = std::max(256, T / 2 / 256 * 256);
+    if (nloc >= 4 * T && !std::getenv("ECRAD_HIP_NO_RAMP")) {
+      sizes = {q, hf};
+      int rem = nloc - 2 * (q + hf);
+      while (rem > 0) { const int x = std::min(T, rem); sizes.push_back(x); rem -= x; }
+      sizes.push_back(hf); sizes.push_back(q);
+    } else {
+      for (int rem = nloc; rem > 0; rem -= T) sizes.push_back(std::min(T, rem));
+    }
+  }
+  const int ntile = (int)sizes.size();
+  std::vector<Tile> tiles(ntile);
+  int largest = 0;
+  for (int t = 0, i0 = istartcol; t < ntile; i0 += sizes[t], ++t) {
+    Tile& T = tiles[t];
+    T.ncol = ncol; T.nlev = nlev; T.index = t; T.slot = t % kStageSlots; T.in = in; T.flux = flux;
+    T.istartcol = i0;
+    T.iendcol = i0 + sizes[t] - 1;
+    if (sizes[t] > sizes[largest]) largest = t;
+  }
+  // the staged arrays of every slot are sized by the largest tile first: planning the tiles then allocates nothing, and the
+  // pointers of a tile stay valid while a later tile of the same slot is planned
+  for (int k = 0; k < std::min(kStageSlots, ntile); ++k) {
+    Tile probe = tiles[largest];
+    probe.slot = k;
+    if ((st = tile_plan(h, probe))) return st;
+  }
+  h->staged_in_last_call = h->staged_out_last_call = 0;
+  for (int t = 0; t < ntile; ++t)
+    if ((st = tile_plan(h, tiles[t]))) return st;
+
+  std::mutex m;
+  std::condition_variable cv;
+  int in_enqueued[2] = {0, 0}, compute_enqueued = 0, out_done = 0, error = ECRAD_OK;
+  std::string error_text;
+  auto set_error = [&](int code) {      // (called with the context's err set by HIP_TRY / fail)
+    std::lock_guard<std::mutex> lk(m);
+    if (!error) { error = code; error_text = h->err; }
+    cv.notify_all();
+  };
+  // The helper threads report through their own handle-shaped error slot: h->err is written by whichever thread fails first
+  auto copy_in_part = [&](int part) {
+    (void)hipSetDevice(h->device);
+    hipStream_t st_in = part == 0 ? h->in_stream : h->in_stream2;
+    for (int t = 0; t < ntile; ++t) {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return error || out_done >= t - kStageSlots + 1; });      // the slot's previous tile is back on the host
+        if (error) return;
+      }
+      int e = tile_copy_in(h, tiles[t], st_in, part, 2);
+      if (!e && hipEventRecord((part == 0 ? h->ev_in : h->ev_in2)[tiles[t].slot], st_in) != hipSuccess) e = ECRAD_EHIP;
+      if (e) { set_error(e); return; }
+      { std::lock_guard<std::mutex> lk(m); in_enqueued[part] = t + 1; }
+      cv.notify_all();
+    }
+  };
+  std::thread copy_in([&] { copy_in_part(0); });
+  std::thread copy_in2([&] { copy_in_part(1); });
+  std::thread copy_out([&] {
+    (void)hipSetDevice(h->device);
+    for (int t = 0; t < ntile; ++t) {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return error || compute_enqueued > t; });
+        if (error) return;
+      }
+      int e = ECRAD_OK;
+      if (hipStreamWaitEvent(h->out_stream, h->ev_comp[tiles[t].slot], 0) != hipSuccess) e = ECRAD_EHIP;
+      if (!e) e = tile_copy_out(h, tiles[t], h->out_stream);
+      if (!e && hipStreamSynchronize(h->out_stream) != hipSuccess) e = ECRAD_EHIP;
+      if (e) { set_error(e); return; }
+      { std::lock_guard<std::mutex> lk(m); out_done = t + 1; }
+      cv.notify_all();
+    }
+  });
+  for (int t = 0; t < ntile; ++t) {
+    {
+      std::unique_lock<std::mutex> lk(m);
+      cv.wait(lk, [&] { return error || (in_enqueued[0] > t && in_enqueued[1] > t); });
+      if (error) break;
+    }
+    int e = ECRAD_OK;
+    if (hipStreamWaitEvent(h->stream, h->ev_in[tiles[t].slot], 0) != hipSuccess || hipStreamWaitEvent(h->stream, h->ev_in2[tiles[t].slot], 0) != hipSuccess) e = ECRAD_EHIP;
+    if (!e) e = tile_compute(h, tiles[t]);
+    if (!e && hipEventRecord(h->ev_comp[tiles[t].slot], h->stream) != hipSuccess) e = ECRAD_EHIP;
+    if (e) { set_error(e); break; }
+    h->tiles_last_call = t + 1;
+    { std::lock_guard<std::mutex> lk(m); compute_enqueued = t + 1; }
+    cv.notify_all();
+  }
+  copy_in.join();
+  copy_in2.join();
+  copy_out.join();
+  if (error) {
+    (void)hipStreamSynchronize(h->in_stream); (void)hipStreamSynchronize(h->in_stream2); (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->out_stream);
+    if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
+    if (!error_text.empty()) h->err = error_text;
+    return error;
+  }
+  return ECRAD_OK;
+}
+
+// ---- small host-memory calls: batched ---------------------------------------------------------------------------------
+// An NPROMA-blocked host calls radiation() on blocks of a few dozen columns (the reference's test namelist: nblocksize = 80),
+// from all its threads at once.  One such block is 10 column groups on a GPU with room for 768, and about forty runtime
+// operations (copies, memsets, kernel launches, events, a wait): sixteen concurrent blocks on sixteen streams ran barely
+// faster than one after the other (gpurun_out/r04_g: 53 k -> 90-130 k columns/s) -- the operations of concurrent streams are
+// what the runtime and the command processor serialise.  So the small calls that are WAITING for a context when one becomes
+// free are run as ONE batch: their blocks side by side as the columns of one set of staged arrays, one copy in, one set of
+// kernels over all the columns, one copy out.  Every caller gathers the rows of its own block into the batch's page-locked
+// mirror and scatters its own results back (in parallel, on the callers' threads); the thread that found the free context
+// leads: it lays the batch out, runs the device side and wakes the others.  No timer, no waiting for company: a call that
+// finds a free context and nobody else waiting is a batch of one.  The columns of a batch are independent in every kernel
+// (no sum runs over columns), so the fluxes of a block are the same bits whatever it shared a batch with.
+constexpr int kMaxBatchCalls = 64, kMaxBatchColumns = 4096;
+
+struct SmallCall {
+  int ncol, nlev, i0, nloc;
+  const ecrad_inputs_t* in;
+  ecrad_flux_t* flux;
+  struct SmallBatch* batch = nullptr;
+  int offset = 0;        // first column of the block among the batch's columns
+};
+
+struct SmallBatch {
+  std::vector<SmallCall*> calls;
+  int ntot = 0;
+  ecrad_hip_handle_s* ctx = nullptr;
+  int phase = 0;         // 0 being laid out, 1 gather, 3 scatter, 4 over (pool_mutex)
+  int gathered = 0, scattered = 0;
+  int status = ECRAD_OK;
+  std::string err;
+  // layout, valid from phase 1
+  Tile* tile = nullptr;
+  StagedInputs mirror{};            // the page-locked mirror of the staged inputs (columns = ntot)
+  char* pin_in = nullptr;
+  char* pin_out = nullptr;
+  size_t cover_off = 0;             // where the initial cloud-cover values sit in pin_in
+  size_t frac_off = 0;              // where the cropped cloud fraction sits in pin_out
+};
+
+// may the blocks of a and b share a batch?  Same levels, the same arrays present, the same per-call scalars.
+bool batch_compatible(const SmallCall& a, const SmallCall& b) {
+  const ecrad_inputs_t &x = *a.in, &y = *b.in;
+  if (a.nlev != b.nlev || x.n_sw_albedo != y.n_sw_albedo || x.n_lw_emissivity != y.n_lw_emissivity || x.n_cloud_types != y.n_cloud_types ||
+      x.n_aerosol_types != y.n_aerosol_types || x.aerosol_istartlev != y.aerosol_istartlev || x.aerosol_iendlev != y.aerosol_iendlev ||
+      x.solar_irradiance != y.solar_irradiance || x.spectral_solar_cycle_multiplier != y.spectral_solar_cycle_multiplier ||
+      x.spectral_solar_scaling != y.spectral_solar_scaling) return false;
+  const void* px[] = {x.pressure_hl, x.temperature_hl, x.h2o_sat_liq, x.cos_sza, x.skin_temperature, x.sw_albedo, x.sw_albedo_direct, x.lw_emissivity,
+                      x.iseed, x.gas_mixing_ratio, x.cloud_fraction, x.cloud_mixing_ratio, x.cloud_effective_radius, x.cloud_fractional_std,
+                      x.cloud_overlap_param, x.aerosol_mixing_ratio, x.cloud_inv_cloud_effective_size, x.cloud_inv_inhom_effective_size};
+  const void* py[] = {y.pressure_hl, y.temperature_hl, y.h2o_sat_liq, y.cos_sza, y.skin_temperature, y.sw_albedo, y.sw_albedo_direct, y.lw_emissivity,
+                      y.iseed, y.gas_mixing_ratio, y.cloud_fraction, y.cloud_mixing_ratio, y.cloud_effective_radius, y.cloud_fractional_std,
+                      y.cloud_overlap_param, y.aerosol_mixing_ratio, y.cloud_inv_cloud_effective_size, y.cloud_inv_inhom_effective_size};
+  for (size_t k = 0; k < sizeof(px) / sizeof(px[0]); ++k) if ((px[k] == nullptr) != (py[k] == nullptr)) return false;
+  for (const FluxField& f : kFluxFields) if ((a.flux->*(f.host) == nullptr) != (b.flux->*(f.host) == nullptr)) return false;
+  return true;
+}
+
+// a caller gathers the rows of its block into the batch's mirror
+void batch_gather(const ecrad_hip_handle_s* ctx, const SmallBatch& B, const SmallCall& q) {
+  InputRow rows[kMaxInputRows];
+  const int n = input_rows(ctx->cfg, q.in, B.mirror, q.nlev, (size_t)B.ntot, (size_t)q.ncol, ctx->gas_used, rows);
+  for (int k = 0; k < n; ++k) {
+    const InputRow& w = rows[k];
+    char* dst = reinterpret_cast<char*>(w.dst) + (size_t)q.offset * w.elem;
+    const char* src = reinterpret_cast<const char*>(w.src) + (size_t)(q.i0 - 1) * w.elem;
+    for (size_t j = 0; j < w.rows; ++j) std::memcpy(dst + j * (size_t)B.ntot * w.elem, src + j * (size_t)q.ncol * w.elem, (size_t)q.nloc * w.elem);
+  }
+  // cloud cover keeps the caller's initial value where a solver does not write it (e.g. -1 at night)
+  size_t off = B.cover_off;
+  for (const auto& sp : B.tile->staged)
+    if (sp.first->kind == 7) {
+      std::memcpy(B.pin_in + off + (size_t)q.offset * 8, q.flux->*(sp.first->host) + (q.i0 - 1), (size_t)q.nloc * 8);
+      off += (size_t)B.ntot * 8;
+    }
+}
+
+// ... and scatters the results of its block from the mirror of the staged outputs into its own arrays
+void batch_scatter(const ecrad_hip_handle_s* ctx, const SmallBatch& B, const SmallCall& q) {
+  const ecrad_config_t& c = ctx->cfg;
+  const Tile& T = *B.tile;
+  const char* const dev0 = reinterpret_cast<const char*>(ctx->staging_out[T.slot].p);
+  const size_t ntot = B.ntot, nloc = q.nloc, off = q.offset;
+  for (const auto& sp : T.staged) {
+    const FluxField& f = *sp.first;
+    double* hostp = q.flux->*(f.host);
+    const char* src = B.pin_out + (reinterpret_cast<const char*>(sp.second) - dev0);
+    const size_t rows = flux_rows(c, f.kind, q.nlev);
+    if (f.kind == 0) {
+      for (size_t j = 0; j < rows; ++j) std::memcpy(hostp + (q.i0 - 1) + j * (size_t)q.ncol, src + (j * ntot + off) * 8, nloc * 8);
+    } else if (f.kind >= 8) {     // (nspec, ncol, nlev+1)
+      const size_t nspec = f.kind == 8 ? c.n_spec_lw : c.n_spec_sw;
+      if ((T.dfx.*(f.dev)) == nullptr) continue;    // not written by this solver: leave the caller's array alone
+      for (size_t j = 0; j <= (size_t)q.nlev; ++j)
+        std::memcpy(hostp + nspec * ((q.i0 - 1) + j * (size_t)q.ncol), src + (j * ntot + off) * nspec * 8, nloc * nspec * 8);
+    } else {                      // (rows, ncol)
+      std::memcpy(hostp + rows * (q.i0 - 1), src + rows * off * 8, rows * nloc * 8);
+    }
+  }
+  if (c.do_clouds)   // crop_cloud_fraction side effect on the caller's array
+    for (size_t j = 0; j < (size_t)q.nlev; ++j)
+      std::memcpy(q.in->cloud_fraction + (q.i0 - 1) + j * (size_t)q.ncol, B.pin_out + B.frac_off + (j * ntot + off) * 8, nloc * 8);
+}
+
+// the leader's part: lay the batch out, run the device side, see everybody off
+int batch_lead(ecrad_hip_handle_t root, SmallBatch& B, SmallCall& mine) {
+  ecrad_hip_handle_s* const h = B.ctx;
+  Tile T;
+  int st = ECRAD_OK;
+  // ECRAD_HIP_BATCH_TRACE=1: one line per batch on standard error with the milliseconds of its phases
+  static const bool trace = std::getenv("ECRAD_HIP_BATCH_TRACE") != nullptr;
+  const auto t_start = std::chrono::steady_clock::now();
+  auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+  double ms_layout = 0, ms_gather = 0, ms_device = 0, ms_scatter = 0;
+  h->err.clear();
+  if (hipSetDevice(h->device) != hipSuccess) st = fail(h, ECRAD_EHIP, "hipSetDevice");
+  if (!st && !h->is_setup) st = fail(h, ECRAD_ENOTSETUP, "ecrad_hip_setup has not been called");
+  // the batch as ONE call over B.ntot columns whose arrays are the mirror's: the leader's structs say which arrays exist
+  T.ncol = B.ntot; T.nlev = mine.nlev; T.istartcol = 1; T.iendcol = B.ntot; T.index = 0; T.slot = 0; T.in = mine.in; T.flux = mine.flux;
+  h->tiles_last_call = 0; h->timing_pending = false; h->tile_columns_last_call = B.ntot;
+  h->staged_in_last_call = h->staged_out_last_call = 0;
+  if (!st) st = tile_plan(h, T);
+  const size_t ncover = [&] { size_t n = 0; for (const auto& sp : T.staged) n += sp.first->kind == 7; return n; }();
+  const size_t frac_bytes = h->cfg.do_clouds ? (size_t)T.nlev * B.ntot * 8 : 0;
+  if (!st) {
+    B.cover_off = (T.cx.si.bytes + 255) & ~size_t(255);
+    B.frac_off = (T.out_bytes + 255) & ~size_t(255);
+    if (h->pin_in.ensure(B.cover_off + ncover * B.ntot * 8 + 256) != hipSuccess || h->pin_out.ensure(B.frac_off + frac_bytes + 256) != hipSuccess)
+      st = fail(h, ECRAD_ENOMEM, "cannot allocate the page-locked staging of a batch of small calls");
+  }
+  if (!st) {
+    B.pin_in = reinterpret_cast<char*>(h->pin_in.p);
+    B.pin_out = reinterpret_cast<char*>(h->pin_out.p);
+    B.mirror = carve_inputs(B.pin_in, h->cfg, *mine.in, T.cx.r);
+    B.tile = &T;
+  }
+  ms_layout = ms_since(t_start);
+  auto t_phase = std::chrono::steady_clock::now();
+  {
+    std::unique_lock<std::mutex> lk(root->pool_mutex);
+    B.status = st;
+    if (st) B.err = h->err;
+    B.phase = st ? 4 : 1;
+    root->pool_cv.notify_all();
+    if (!st) {
+      lk.unlock();
+      batch_gather(h, B, mine);
+      lk.lock();
+      B.gathered++;
+      root->pool_cv.wait(lk, [&] { return B.gathered == (int)B.calls.size(); });
+    }
+  }
+  ms_gather = ms_since(t_phase);
+  t_phase = std::chrono::steady_clock::now();
+  if (!st) {
+    hipStream_t stream = h->stream;
+    auto run = [&]() -> int {
+      // Entries that a solver never writes for a processed column are undefined in the reference; here they are zero.
+      HIP_TRY(h, hipMemsetAsync(h->staging_out[T.slot].p, 0, T.out_bytes, stream));
+      HIP_TRY(h, hipMemcpyAsync(h->staging_in[T.slot].p, B.pin_in, T.cx.si.bytes, hipMemcpyHostToDevice, stream));
+      size_t off = B.cover_off;
+      for (auto& sp : T.staged)
+        if (sp.first->kind == 7) {
+          HIP_TRY(h, hipMemcpyAsync(sp.second, B.pin_in + off, (size_t)B.ntot * 8, hipMemcpyHostToDevice, stream));
+          off += (size_t)B.ntot * 8;
+        }
+      const int e = tile_compute(h, T);
+      if (e) return e;
+      if (T.out_bytes) HIP_TRY(h, hipMemcpyAsync(B.pin_out, h->staging_out[T.slot].p, T.out_bytes, hipMemcpyDeviceToHost, stream));
+      if (frac_bytes) HIP_TRY(h, hipMemcpyAsync(B.pin_out + B.frac_off, T.cx.si.cloud_fraction, frac_bytes, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(h, hipStreamSynchronize(stream));
+      return ECRAD_OK;
+    };
+    st = run();
+    if (st && h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
+    if (!st) { h->tiles_last_call = 1; h->timing_pending = true; }
+    ms_device = ms_since(t_phase);
+    t_phase = std::chrono::steady_clock::now();
+    {
+      std::unique_lock<std::mutex> lk(root->pool_mutex);
+      B.status = st;
+      if (st) B.err = h->err;
+      B.phase = 3;
+      root->pool_cv.notify_all();
+      lk.unlock();
+      if (!st) batch_scatter(h, B, mine);
+      lk.lock();
+      B.scattered++;
+      root->pool_cv.wait(lk, [&] { return B.scattered == (int)B.calls.size(); });
+      B.phase = 4;
+    }
+    ms_scatter = ms_since(t_phase);
+  }
+  if (trace)
+    std::fprintf(stderr, "ecrad_hip batch: %d calls %d columns on device %d: layout %.3f gather %.3f device %.3f scatter %.3f ms\n",
+                 (int)B.calls.size(), B.ntot, h->device, ms_layout, ms_gather, ms_device, ms_scatter);
+  (void)hipSetDevice(root->device);
+  return st;
+}
+
+// A small host-memory call: joins the batch that the next free context runs, or leads one.
+int radiation_small(ecrad_hip_handle_t root, int ncol, int nlev, int istartcol, int iendcol, const ecrad_inputs_t* in, ecrad_flux_t* flux) {
+  SmallCall me{ncol, nlev, istartcol, iendcol - istartcol + 1, in, flux};
+  SmallBatch B;      // (used if this thread leads)
+  std::unique_lock<std::mutex> lk(root->pool_mutex);
+  root->small_waiting.push_back(&me);
+  for (;;) {
+    if (me.batch) break;                                   // a leader has taken this call into its batch
+    ecrad_hip_handle_s* c = free_context_for_small(root);
+    if (c) {                                               // lead: everything compatible that is waiting, in arrival order
+      B.ctx = c;
+      auto& w = root->small_waiting;
+      B.calls.push_back(&me);
+      B.ntot = me.nloc;
+      for (SmallCall* q : w)
+        if (q != &me && (int)B.calls.size() < kMaxBatchCalls && B.ntot + q->nloc <= kMaxBatchColumns && batch_compatible(me, *q)) { B.calls.push_back(q); B.ntot += q->nloc; }
+      // the blocks in the order of their first column (neighbours in the caller's arrays stay neighbours on the device)
+      std::sort(B.calls.begin(), B.calls.end(), [](const SmallCall* a, const SmallCall* b) { return a->i0 < b->i0; });
+      int off = 0;
+      for (SmallCall* q : B.calls) {
+        q->batch = &B; q->offset = off; off += q->nloc;
+        w.erase(std::find(w.begin(), w.end(), q));
+      }
+      c->busy = true;
+      c->small_batch = true;
+      c->calls += (long long)B.calls.size();
+      root->calls_total += (long long)B.calls.size();
+      root->batches_total++;
+      root->batched_calls_total += (long long)B.calls.size();
+      root->in_flight += (int)B.calls.size();
+      if (root->in_flight > root->max_in_flight) root->max_in_flight = root->in_flight;
+      tl_last_context = c;
+      lk.unlock();
+      const int st = batch_lead(root, B, me);
+      lk.lock();
+      c->busy = false;
+      c->small_batch = false;
+      root->in_flight -= (int)B.calls.size();
+      if (st && c != root) root->err = c->err;
+      lk.unlock();
+      root->pool_cv.notify_all();
+      return st;
+    }
+    root->pool_cv.wait(lk);
+  }
+  // a member of somebody else's batch
+  SmallBatch& L = *me.batch;
+  ecrad_hip_handle_s* const ctx = L.ctx;
+  tl_last_context = ctx;
+  root->pool_cv.wait(lk, [&] { return L.phase >= 1; });
+  if (L.phase == 4) return L.status;                       // the batch could not be laid out (the leader has reported why)
+  lk.unlock();
+  batch_gather(ctx, L, me);
+  lk.lock();
+  L.gathered++;
+  root->pool_cv.notify_all();
+  root->pool_cv.wait(lk, [&] { return L.phase >= 3; });
+  const int st = L.status;
+  lk.unlock();
+  if (!st) batch_scatter(ctx, L, me);
+  lk.lock();
+  L.scattered++;                                           // (the last thing this thread does with the batch: it lives on the leader's stack)
+  lk.unlock();
+  root->pool_cv.notify_all();
+  return st;
+}
+
+// the call on the context that the lease has given it
+int radiation_on(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
+                 const ecrad_inputs_t* in, ecrad_flux_t* flux) {
+  if (!h->is_setup) return fail(h, ECRAD_ENOTSETUP, "ecrad_hip_setup has not been called");
+  HIP_TRY(h, hipSetDevice(h->device));
+  // Column tiling: every work array is sized by the columns of a tile, not of the call, so the device memory a
+  // call needs is bounded by `work_budget` (half of the device's memory unless ecrad_hip_set_work_bytes /
+  // ECRAD_HIP_WORK_GIB say otherwise) whatever istartcol..iendcol is.  Tiles are whole multiples of 256 columns (every kernel's column
+  // groups divide 256), at least 4096, so a tiled call launches the same column groups as an untiled one.
+  const int nloc = iendcol - istartcol + 1;
+  const bool host_mem = in->memory == ECRAD_MEM_HOST;
+  const size_t per_col = work_bytes_per_column(h, nlev, in, flux);
+  size_t budget = h->work_budget;
+  {
+    // Default: half of the device's memory (144 GB of the MI355X's 288 GB: 100 000 RRTMG columns, 72 GB of work arrays,
+    // then run as one tile instead of two, +2 %), and never more than 90 % of what is free now plus what this context
+    // already holds (another context or process, or the caller's own arrays, may have taken the rest)
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
+    if (!budget) budget = total_b / 2;
+    const size_t avail = (size_t)(0.9 * (double)(free_b + held_bytes(h)));
+    if (budget > avail) budget = avail;
+    if (!host_mem) {      // the ncol-sized planes do not shrink with the tile: they come off the top
+      // (a budget smaller than the planes cannot be honoured: the call then runs in the smallest tiles, 4096 columns)
+      const size_t planes = plane_bytes_per_column(h, nlev) * (size_t)ncol;
+      budget = planes < budget ? budget - planes : 0;
+    }
+  }
+  long long tile_cols = per_col ? (long long)(budget / per_col) : (long long)nloc;
+  tile_cols = std::max(4096ll, tile_cols / 256 * 256);
+  // host-memory mode: tiles small enough to pipeline copy-in, kernels and copy-out (three sets of staged arrays in flight)
+  const bool pipeline = host_mem && !std::getenv("ECRAD_HIP_NO_PIPELINE") && nloc >= 2 * 4096;
+  if (pipeline) tile_cols = std::min<long long>(tile_cols, std::max(4096, std::min(host_tile_columns(), (nloc / 2 + 255) / 256 * 256)));
+  if (tile_cols > nloc) tile_cols = nloc;
+  const int ntile = (int)((nloc + tile_cols - 1) / tile_cols);
+  h->tiles_last_call = 0;
+  h->timing_pending = false;
+  h->tile_columns_last_call = (int)tile_cols;
+  h->staged_in_last_call = h->staged_out_last_call = 0;
+  int st = ECRAD_OK;
+  if (pipeline && ntile > 1) {
+    st = radiation_host_pipelined(h, ncol, nlev, istartcol, iendcol, in, flux, tile_cols);      // (sets tiles_last_call: its tiles ramp up and down in size)
+  } else {
+    Tile T;
+    for (int t = 0; t < ntile && !st; ++t) {
+      T.ncol = ncol; T.nlev = nlev; T.index = t; T.slot = 0; T.in = in; T.flux = flux;
+      T.istartcol = istartcol + (int)(t * tile_cols);
+      T.iendcol = (int)std::min<long long>(iendcol, T.istartcol + tile_cols - 1);
+      if ((st = tile_plan(h, T))) break;
+      if ((st = tile_copy_in(h, T, h->stream))) break;
+      if ((st = tile_compute(h, T))) break;
+      if ((st = tile_copy_out(h, T, h->stream))) break;
+      if (host_mem && hipStreamSynchronize(h->stream) != hipSuccess) { st = fail(h, ECRAD_EHIP, "hipStreamSynchronize after the copy-out"); break; }
+      h->tiles_last_call = t + 1;
+    }
+  }
+  if (st) {      // an error between a fork and its join leaves work on the second stream: wait for it before the caller sees the error
+    if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
+    return st;
+  }
+  h->timing_pending = true;
   return ECRAD_OK;
 }
 
@@ -1573,55 +2602,17 @@ extern "C" {
 int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
                         const ecrad_inputs_t* in, ecrad_flux_t* flux) {
   if (!h || !in || !flux) return ECRAD_EINVAL;
-  const std::lock_guard<std::mutex> one_call_at_a_time(h->call_mutex);
-  if (!h->is_setup) return fail(h, ECRAD_ENOTSETUP, "ecrad_hip_setup has not been called");
-  HIP_TRY(h, hipSetDevice(h->device));
   if (in->memory != flux->memory) return fail(h, ECRAD_EINVAL, "inputs and fluxes must live in the same memory space");
   if (ncol < 1 || nlev < 2 || istartcol < 1 || iendcol > ncol || iendcol < istartcol) return fail(h, ECRAD_EINVAL, "bad column/level range");
-  // Column tiling: every work array is sized by the columns of a tile, not of the call, so the device memory a
-  // call needs is bounded by `work_budget` (half of the device's memory unless ecrad_hip_set_work_bytes /
-  // ECRAD_HIP_WORK_GIB say otherwise) whatever istartcol..iendcol is.  Tiles are whole multiples of 256 columns (every kernel's column
-  // groups divide 256), at least 4096, so a tiled call launches the same column groups as an untiled one.
-  const int nloc = iendcol - istartcol + 1;
-  const size_t per_col = work_bytes_per_column(h, nlev, in, flux);
-  size_t budget = h->work_budget;
-  {
-    // Default: half of the device's memory (144 GB of the MI355X's 288 GB: 100 000 RRTMG columns, 72 GB of work arrays,
-    // then run as one tile instead of two, +2 %), and never more than 90 % of what is free now plus what this handle
-    // already holds (another process, or the caller's own arrays, may have taken the rest)
-    size_t free_b = 0, total_b = 0;
-    HIP_TRY(h, hipMemGetInfo(&free_b, &total_b));
-    if (!budget) budget = total_b / 2;
-    size_t held = 0;
-    for (const Buf* b : {&h->spec_tmp, &h->partial, &h->scratch, &h->prep, &h->staging_in, &h->staging_out, &h->gas_stage, &h->gas_work, &h->sp_stage, &h->sp_list})
-      held += b->cap;
-    const size_t avail = (size_t)(0.9 * (double)(free_b + held));
-    if (budget > avail) budget = avail;
-    if (in->memory != ECRAD_MEM_HOST) {      // the ncol-sized planes do not shrink with the tile: they come off the top
-      // (a budget smaller than the planes cannot be honoured: the call then runs in the smallest tiles, 4096 columns)
-      const size_t planes = plane_bytes_per_column(h, nlev) * (size_t)ncol;
-      budget = planes < budget ? budget - planes : 0;
-    }
-  }
-  long long tile_cols = per_col ? (long long)(budget / per_col) : (long long)nloc;
-  tile_cols = std::max(4096ll, tile_cols / 256 * 256);
-  if (tile_cols > nloc) tile_cols = nloc;
-  const int ntile = (int)((nloc + tile_cols - 1) / tile_cols);
-  h->tiles_last_call = 0;
-  h->timing_pending = false;
-  for (int t = 0; t < ntile; ++t) {
-    const int i0 = istartcol + (int)(t * tile_cols);
-    const int i1 = std::min<long long>(iendcol, i0 + tile_cols - 1);
-    const int st = radiation_tile(h, ncol, nlev, i0, i1, in, flux, t);
-    if (st) {      // an error between a fork and its join leaves work on the second stream: wait for it before the caller sees the error
-      if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
-      return st;
-    }
-    h->tiles_last_call = t + 1;
-  }
-  h->tile_columns_last_call = (int)tile_cols;
-  h->timing_pending = true;
-  return ECRAD_OK;
+  // a host-memory call is self-contained (copy in, kernels, copy out, wait): any free context of the pool, on any of its
+  // devices, serves it; a device-memory call works on the caller's device arrays in the order of the caller's stream: the root
+  if (in->memory == ECRAD_MEM_HOST && iendcol - istartcol + 1 <= std::min(packed_call_columns(), kMaxBatchColumns))
+    return radiation_small(h, ncol, nlev, istartcol, iendcol, in, flux);
+  const Lease lease(h, in->memory == ECRAD_MEM_HOST);
+  lease.c->err.clear();
+  const int st = radiation_on(lease.c, ncol, nlev, istartcol, iendcol, in, flux);
+  (void)hipSetDevice(h->device);      // (a context of another device may have changed the calling thread's current device)
+  return st;
 }
 
 int ecrad_hip_set_work_bytes(ecrad_hip_handle_t h, size_t bytes) {
@@ -1632,22 +2623,23 @@ int ecrad_hip_set_work_bytes(ecrad_hip_handle_t h, size_t bytes) {
 
 int ecrad_hip_last_call_info(ecrad_hip_handle_t h, ecrad_call_info_t* info) {
   if (!h || !info) return ECRAD_EINVAL;
+  h = query_context(h);
   info->n_tiles = h->tiles_last_call;
   info->tile_columns = h->tile_columns_last_call;
   info->launches_lw = h->cfg.do_lw ? h->nchunk_lw : 0;
   info->launches_sw = h->cfg.do_sw ? h->nchunk_sw : 0;
   info->lanes_lw = h->cfg.do_lw ? h->ngp_lw : 0;
   info->lanes_sw = h->cfg.do_sw ? h->ngp_sw : 0;
-  size_t b = 0;
-  (void)ecrad_hip_scratch_bytes(h, &b);
-  info->work_bytes = b;
+  info->work_bytes = held_bytes(h);
+  info->staged_in_bytes = h->staged_in_last_call;
+  info->staged_out_bytes = h->staged_out_last_call;
   return ECRAD_OK;
 }
 
 int ecrad_hip_optics(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
                      const ecrad_inputs_t* in, ecrad_optics_t* out) {
   if (!h || !in || !out) return ECRAD_EINVAL;
-  const std::lock_guard<std::mutex> one_call_at_a_time(h->call_mutex);
+  const Lease lease(h, false);      // (the stage dump runs on the root context)
   if (!h->is_setup) return fail(h, ECRAD_ENOTSETUP, "ecrad_hip_setup has not been called");
   HIP_TRY(h, hipSetDevice(h->device));
   const ecrad_config_t& c = h->cfg;
@@ -1675,9 +2667,9 @@ int ecrad_hip_optics(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, in
   } else {
     size_t off = 0;
     for (const OF& f : fields) if (out->*(f.host)) off += (f.n * 8 + 255) & ~size_t(255);
-    HIP_TRY(h, h->staging_out.ensure(off));
-    HIP_TRY(h, hipMemsetAsync(h->staging_out.p, 0, off, stream));
-    Carver cv(h->staging_out.p);
+    HIP_TRY(h, h->staging_out[0].ensure(off));
+    HIP_TRY(h, hipMemsetAsync(h->staging_out[0].p, 0, off, stream));
+    Carver cv(h->staging_out[0].p);
     for (const OF& f : fields) if (out->*(f.host)) dop.*(f.dev) = cv.take<double>(f.n);
   }
   HIP_TRY(h, h->counters.ensure(512));

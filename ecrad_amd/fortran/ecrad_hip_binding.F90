@@ -8,7 +8,7 @@ module ecrad_hip_binding
   implicit none
   public
 
-  integer(c_int), parameter :: ECRAD_ABI_VERSION = 6
+  integer(c_int), parameter :: ECRAD_ABI_VERSION = 7
   integer(c_int), parameter :: ECRAD_OK = 0
   integer(c_int), parameter :: ECRAD_NMAXGASES = 12, ECRAD_NMAXCLOUDTYPES = 12
   integer(c_int), parameter :: ECRAD_MEM_HOST = 0, ECRAD_MEM_DEVICE = 1
@@ -151,6 +151,14 @@ module ecrad_hip_binding
     type(c_ptr) :: sw_up_clear_band = c_null_ptr, sw_dn_clear_band = c_null_ptr, sw_dn_direct_clear_band = c_null_ptr
   end type
 
+  integer, parameter :: ECRAD_MAX_POOL_DEVICES = 16
+  type, bind(C) :: ecrad_pool_info_t
+    integer(c_int32_t) :: n_devices, n_contexts, in_flight, max_in_flight
+    integer(c_int64_t) :: calls_total, batches_total
+    integer(c_int32_t) :: device_ids(ECRAD_MAX_POOL_DEVICES)
+    integer(c_int64_t) :: calls_on_device(ECRAD_MAX_POOL_DEVICES)
+  end type
+
   interface
     function ecrad_hip_create(handle, device_id) bind(C, name='ecrad_hip_create') result(status)
       import :: c_ptr, c_int
@@ -171,6 +179,19 @@ module ecrad_hip_binding
       integer(c_int), value :: ncol, nlev, istartcol, iendcol
       type(ecrad_inputs_t), intent(in)  :: inputs
       type(ecrad_flux_t), intent(inout) :: flux
+      integer(c_int) :: status
+    end function
+    ! the pool of (device, stream, work arrays) contexts that concurrent calls are spread over (include/ecrad_hip.h)
+    function ecrad_hip_set_concurrency(handle, n_devices, contexts_per_device) bind(C, name='ecrad_hip_set_concurrency') result(status)
+      import :: c_ptr, c_int
+      type(c_ptr), value    :: handle
+      integer(c_int), value :: n_devices, contexts_per_device
+      integer(c_int)        :: status
+    end function
+    function ecrad_hip_pool_info(handle, info) bind(C, name='ecrad_hip_pool_info') result(status)
+      import :: c_ptr, c_int, ecrad_pool_info_t
+      type(c_ptr), value :: handle
+      type(ecrad_pool_info_t), intent(out) :: info
       integer(c_int) :: status
     end function
     function ecrad_hip_synchronize(handle) bind(C, name='ecrad_hip_synchronize') result(status)

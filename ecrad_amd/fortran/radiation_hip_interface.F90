@@ -33,7 +33,11 @@ module radiation_hip_interface
   private
   public :: setup_radiation_hip, radiation_hip, finalize_radiation_hip, radiation_hip_abort
 
-  type(c_ptr), save :: hip_handle = c_null_ptr     ! one handle per process (= per GPU)
+  ! One handle per process.  It is the head of the library's pool of (device, stream, work arrays) contexts: concurrent
+  ! radiation() calls -- the blocks of the driver's `!$OMP PARALLEL DO`, driver/ecrad_driver.F90:348-370, the IFS's threads --
+  ! each take a free context, side by side on one GPU and spread over every GPU the process sees (include/ecrad_hip.h:
+  ! ecrad_hip_set_concurrency; ECRAD_HIP_DEVICES / ECRAD_HIP_CONTEXTS size it from outside)
+  type(c_ptr), save :: hip_handle = c_null_ptr
   ! RRTMG: the tables live in the host's ifsrrtm modules; radiation_hip_rrtmg::fill_rrtmg_hip points this at them
   type(ecrad_rrtmg_t), save, target :: rrtmg_tables
 
@@ -232,6 +236,10 @@ contains
     if (.not. c_associated(hip_handle)) then
       if (ecrad_hip_create(hip_handle, int(idev, c_int)) /= ECRAD_OK) &
            &  call radiation_hip_abort('*** Error: no usable MI355X device (ecrad_hip_create)')
+      ! no device named: every device this process sees (an MPI host pins its ranks with ROCR/HIP_VISIBLE_DEVICES as
+      ! usual); a named device: that one only.  Eight contexts per device either way (the library's default).
+      if (ecrad_hip_set_concurrency(hip_handle, int(merge(1, 0, present(device_id)), c_int), 0_c_int) /= ECRAD_OK) &
+           &  call radiation_hip_abort('*** Error in ecrad_hip_set_concurrency')
     end if
     c%abi_version = ECRAD_ABI_VERSION
     c%rrtmg = c_null_ptr
@@ -350,9 +358,12 @@ contains
     type(ecrad_flux_t)   :: cfl
     if (.not. c_associated(hip_handle)) call radiation_hip_abort('*** Error: setup_radiation_hip not called')
     ! radiation() is called from an OpenMP PARALLEL DO over blocks of columns in the reference's driver
-    ! (driver/ecrad_driver.F90:348) and from the IFS's threads: one call at a time per handle (the library queues them too;
-    ! this section also covers the copy pool of a single-precision host below)
+    ! (driver/ecrad_driver.F90:348) and from the IFS's threads: everything below is local to the call, and the library runs
+    ! concurrent calls side by side on the contexts of its pool.  (A single-precision host converts through the module's
+    ! copy pool, which is one per process: those builds take the calls one at a time.)
+#ifdef PARKIND1_SINGLE
     !$omp critical (ecrad_hip_radiation_call)
+#endif
     cin%memory = ECRAD_MEM_HOST
     cin%solar_irradiance = single_level%solar_irradiance
     cin%spectral_solar_cycle_multiplier = single_level%spectral_solar_cycle_multiplier
@@ -373,9 +384,13 @@ contains
     cin%n_cloud_types = 0; cin%n_aerosol_types = 0; cin%aerosol_istartlev = 1; cin%aerosol_iendlev = 0; cin%reserved_ = 0
     if (config%do_clouds) then
       cin%n_cloud_types = cloud%ntype
+#ifdef PARKIND1_SINGLE
       outputs_from_here = .true.      ! (intent(inout): the crop_cloud_fraction side effect)
+#endif
       cin%cloud_fraction = locd(cloud%fraction)
+#ifdef PARKIND1_SINGLE
       outputs_from_here = .false.
+#endif
       cin%cloud_mixing_ratio = locd(cloud%mixing_ratio)
       cin%cloud_effective_radius = locd(cloud%effective_radius)
       cin%cloud_fractional_std = locd(cloud%fractional_std); cin%cloud_overlap_param = locd(cloud%overlap_param)
@@ -388,7 +403,9 @@ contains
       cin%aerosol_mixing_ratio = locd(aerosol%mixing_ratio)
     end if
     cfl%memory = ECRAD_MEM_HOST; cfl%reserved_ = 0
+#ifdef PARKIND1_SINGLE
     outputs_from_here = .true.
+#endif
     cfl%lw_up = locd(flux%lw_up); cfl%lw_dn = locd(flux%lw_dn); cfl%sw_up = locd(flux%sw_up); cfl%sw_dn = locd(flux%sw_dn)
     cfl%sw_dn_direct = locd(flux%sw_dn_direct); cfl%lw_up_clear = locd(flux%lw_up_clear); cfl%lw_dn_clear = locd(flux%lw_dn_clear)
     cfl%sw_up_clear = locd(flux%sw_up_clear); cfl%sw_dn_clear = locd(flux%sw_dn_clear)
@@ -417,8 +434,10 @@ contains
     cfl%sw_dn_clear_band = locd(flux%sw_dn_clear_band); cfl%sw_dn_direct_clear_band = locd(flux%sw_dn_direct_clear_band)
     if (ecrad_hip_radiation(hip_handle, int(ncol,c_int), int(nlev,c_int), int(istartcol,c_int), int(iendcol,c_int), &
          &  cin, cfl) /= ECRAD_OK) call radiation_hip_abort('*** Error in ecrad_hip_radiation')
+#ifdef PARKIND1_SINGLE
     call finish_copies()
     !$omp end critical (ecrad_hip_radiation_call)
+#endif
   end subroutine radiation_hip
 
   subroutine finalize_radiation_hip()

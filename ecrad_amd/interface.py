@@ -537,7 +537,11 @@ class Radiation:
     """Owns a configured handle: ``Radiation(config)`` == ``call setup_radiation(config)``;
     ``.radiation(...)`` == ``call radiation(ncol,nlev,istartcol,iendcol,config,...)``."""
 
-    def __init__(self, config: Config, backend="hip", device_id: int = -1, lib_path: Optional[str] = None):
+    def __init__(self, config: Config, backend="hip", device_id: int = -1, lib_path: Optional[str] = None,
+                 concurrency: Optional[tuple] = None):
+        """concurrency = (n_devices, contexts_per_device): the pool of contexts that concurrent host-memory calls are spread
+        over (include/ecrad_hip.h: ecrad_hip_set_concurrency; n_devices 0 = every visible device); None keeps the
+        library's default, one device and eight contexts."""
         if not config.is_consolidated or config.gas_optics_lw is None and config.gas_optics_sw is None:
             setup_radiation(config)
         self.config = config
@@ -552,6 +556,8 @@ class Radiation:
             if st != 0:
                 raise EcradHipError(f"ecrad_hip_create failed with status {st} (no usable gfx950 device?)")
             self.handle = h
+            if concurrency is not None:
+                self._check(self.lib.ecrad_hip_set_concurrency(self.handle, int(concurrency[0]), int(concurrency[1])), "ecrad_hip_set_concurrency")
             self._check(self.lib.ecrad_hip_setup(self.handle, C.byref(self.cconfig)), "ecrad_hip_setup")
         elif not callable(backend):
             raise ValueError("backend must be 'hip' or a callable (tests/bench cpu_baseline only)")
@@ -616,6 +622,17 @@ class Radiation:
             if st != 0:
                 raise RuntimeError(f"backend returned status {st}")
         del keep
+
+    def pool_info(self, reset: bool = False) -> dict:
+        """ecrad_hip_pool_info: how the calls so far were spread over the pool's devices and contexts."""
+        info = abi.PoolInfo()
+        self._check(self.lib.ecrad_hip_pool_info(self.handle, C.byref(info)), "ecrad_hip_pool_info")
+        out = {"n_devices": info.n_devices, "n_contexts": info.n_contexts, "in_flight": info.in_flight,
+               "max_in_flight": info.max_in_flight, "calls_total": info.calls_total, "batches_total": info.batches_total,
+               "calls_on_device": {int(info.device_ids[i]): int(info.calls_on_device[i]) for i in range(info.n_devices)}}
+        if reset:
+            self._check(self.lib.ecrad_hip_pool_reset(self.handle), "ecrad_hip_pool_reset")
+        return out
 
     def last_kernel_ms(self) -> float:
         ms = C.c_double()

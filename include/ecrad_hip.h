@@ -8,7 +8,8 @@
  * exactly the reference's Fortran layouts (first index fastest), so the Fortran side passes
  * c_loc(array) with no copies.
  *
- *   ecrad_hip_create      <-> (new) one handle per GPU (host threads may share it: calls on a handle queue)
+ *   ecrad_hip_create      <-> (new) one handle per process: the head of a pool of (device, stream, work arrays) contexts
+ *                             that concurrent radiation() calls of the host's threads are spread over (ecrad_hip_set_concurrency)
  *   ecrad_hip_setup       <-> setup_radiation(config)          radiation_interface.F90:37
  *                             (called AFTER the Fortran setup has filled config's look-up tables)
  *   ecrad_hip_radiation   <-> radiation(ncol,nlev,istartcol,iendcol,config,single_level,
@@ -35,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ECRAD_ABI_VERSION 6
+#define ECRAD_ABI_VERSION 7
 
 /* Status codes */
 #define ECRAD_OK            0
@@ -370,16 +371,53 @@ int ecrad_hip_create(ecrad_hip_handle_t* handle, int device_id);
    freed after this returns.  May be called again to change configuration. */
 int ecrad_hip_setup(ecrad_hip_handle_t handle, const ecrad_config_t* config);
 
-/* Optional: run subsequent work on this HIP stream (a hipStream_t cast to void*). */
+/* Optional: run subsequent DEVICE-memory calls on this HIP stream (a hipStream_t cast to void*). */
 int ecrad_hip_set_stream(ecrad_hip_handle_t handle, void* hip_stream);
+
+/* The pool of contexts behind a handle.  The reference's radiation() is re-entrant and its driver calls it from an
+   `!$OMP PARALLEL DO` over blocks of columns (driver/ecrad_driver.F90:348-370): that loop is how an unchanged host keeps a
+   node busy.  A handle therefore owns n_devices x contexts_per_device CONTEXTS -- each a device, its own streams and work
+   arrays; the look-up tables are uploaded once per device by ecrad_hip_setup -- and every host-memory call of
+   ecrad_hip_radiation takes a free context, preferring the device with the fewest calls in flight: calls of concurrent
+   host threads overlap on one GPU (a block of 80 columns does not fill it) and spread over all the GPUs of the pool, in
+   ONE process, with no MPI and no change to the caller.  More concurrent callers than contexts wait for a free one.
+   n_devices: 0 = every visible device, otherwise that many, starting with the handle's own; contexts_per_device: 0 keeps
+   the default (8).  Call it before ecrad_hip_setup (afterwards it discards the uploaded tables: call ecrad_hip_setup
+   again).  The environment variables ECRAD_HIP_DEVICES (a count, or "all") and ECRAD_HIP_CONTEXTS, when set, override
+   the arguments: an operator sizes the pool of an unchanged executable with them.  Device-memory calls (whose arrays
+   live on the handle's device and are ordered by the caller's stream), ecrad_hip_setup and ecrad_hip_optics use the
+   handle's own context. */
+int ecrad_hip_set_concurrency(ecrad_hip_handle_t handle, int n_devices, int contexts_per_device);
+
+#define ECRAD_MAX_POOL_DEVICES 16
+typedef struct ecrad_pool_info {
+  int32_t n_devices, n_contexts;                      /* devices and contexts of the pool (1, 1 before ecrad_hip_setup) */
+  int32_t in_flight, max_in_flight;                   /* calls running now; the most that ran at once since the last reset */
+  int64_t calls_total;                                /* calls since the last reset */
+  int64_t batches_total;                              /* batches the small host-memory calls among them ran as (see ecrad_hip_radiation) */
+  int32_t device_ids[ECRAD_MAX_POOL_DEVICES];         /* HIP device of pool device k */
+  int64_t calls_on_device[ECRAD_MAX_POOL_DEVICES];    /* calls that ran on it */
+} ecrad_pool_info_t;
+int ecrad_hip_pool_info(ecrad_hip_handle_t handle, ecrad_pool_info_t* info);
+int ecrad_hip_pool_reset(ecrad_hip_handle_t handle);  /* zero the counters of ecrad_hip_pool_info */
 
 /* The operator.  Columns outside istartcol..iendcol (1-based, inclusive) are not touched.
    With ECRAD_MEM_HOST pointers the call stages the needed column range through device buffers
-   (H2D, kernels, D2H) and is synchronous; with ECRAD_MEM_DEVICE pointers it only enqueues
-   kernels on the handle's stream (call ecrad_hip_synchronize before reading results).
-   Re-entrant like the reference's radiation() (driver/ecrad_driver.F90:348 calls it from an OpenMP PARALLEL DO over
-   blocks of columns): several host threads may call it on one handle at once, each with its own column range of shared
-   arrays; the calls run one after the other (a per-handle mutex). */
+   (H2D, kernels, D2H) and is synchronous.  A call of up to 512 columns is a SMALL call: the small calls that are waiting
+   when a context becomes free run as ONE batch -- their blocks side by side as the columns of one set of staged arrays
+   that every caller fills and empties for its own block through page-locked mirrors, one copy in, one set of kernels,
+   one copy out (a blocked host calling from many threads gets the throughput of large batches; a lone call is a batch
+   of one; ECRAD_HIP_PACK_COLUMNS changes the limit, 0 switches batching off).  A call of 8192 columns or more runs as
+   tiles of columns whose copy-in, kernels and copy-out overlap on separate streams (ECRAD_HIP_HOST_TILE columns per
+   tile, ECRAD_HIP_NO_PIPELINE=1 switches it off).  Only the planes of gas%mixing_ratio that the configuration reads
+   are copied.
+   With ECRAD_MEM_DEVICE pointers it only enqueues kernels on the handle's stream (call ecrad_hip_synchronize before
+   reading results).
+   Re-entrant AND concurrent like the reference's radiation() (driver/ecrad_driver.F90:348 calls it from an OpenMP
+   PARALLEL DO over blocks of columns): several host threads may call it on one handle at once, each with its own
+   column range of shared arrays; host-memory calls run side by side on the contexts of the handle's pool (see
+   ecrad_hip_set_concurrency), device-memory calls one after the other on the handle's stream.  The timing / error
+   queries below refer to the calling thread's most recent call. */
 int ecrad_hip_radiation(ecrad_hip_handle_t handle, int ncol, int nlev, int istartcol, int iendcol,
                         const ecrad_inputs_t* in, ecrad_flux_t* flux);
 
@@ -411,6 +449,11 @@ int ecrad_hip_last_stage_ms(ecrad_hip_handle_t handle, int which, double* ms);
    allocated and freed inside the call.  Measurement aid of bench.py; touches nothing else of the handle. */
 int ecrad_hip_hbm_triad(ecrad_hip_handle_t handle, size_t nbytes_per_array, int repeats, double* gbs);
 
+/* What the link between this host and this device sustains, with page-locked host buffers of `nbytes` each: host to
+   device alone, device to host alone, and both at once (the sum of the two directions), best of `repeats`.  A pipelined
+   host-memory call (ecrad_hip_radiation) cannot move its columns faster than this: measurement aid of bench.py. */
+int ecrad_hip_pcie_bandwidth(ecrad_hip_handle_t handle, size_t nbytes, int repeats, double* h2d_gbs, double* d2h_gbs, double* duplex_gbs);
+
 /* Bytes of device scratch currently held by the handle. */
 int ecrad_hip_scratch_bytes(ecrad_hip_handle_t handle, size_t* bytes);
 
@@ -431,6 +474,7 @@ typedef struct ecrad_call_info {
   int32_t launches_lw, launches_sw;   /* solver-kernel launches per tile and spectrum */
   int32_t lanes_lw, lanes_sw;         /* g-point lanes per column group (16, 32 or 64) of the widest launch */
   size_t  work_bytes;
+  size_t  staged_in_bytes, staged_out_bytes;   /* host-memory mode: bytes the call copied to / from the device (0 otherwise) */
 } ecrad_call_info_t;
 int ecrad_hip_last_call_info(ecrad_hip_handle_t handle, ecrad_call_info_t* info);
 

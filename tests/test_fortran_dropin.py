@@ -59,18 +59,39 @@ def write_namelist(path, *edits):
 
 
 
+# What a GPU process that could not START prints (the HIP runtime found no usable device, or could not initialise): the one
+# kind of failure that is the box's and not the product's.  Round 3 saw one such failure in six full runs of this file and
+# retried on ANY non-zero return code; round 4 ran the 54 GPU cases three times over without any retry (162 processes,
+# gpurun_out/r04_b) and saw none.  The retry is now limited to this signature, before any kernel ran, every retry is
+# written to gpurun_out/dropin_retries.log, and the last test of this file fails if it was needed more than twice.
+STARTUP_SIGNATURES = ("no usable MI355X device", "hipErrorNoDevice", "no ROCm-capable device", "hipErrorInvalidDevice",
+                      "hipErrorNotInitialized", "hipErrorInitializationError", "Unable to open /dev/kfd", "HSA_STATUS_ERROR_OUT_OF_RESOURCES")
+RETRIES = []
+
+
 def _run(*args, **kw):
-    """subprocess.run of one of the executables; a non-zero return code is retried once after a pause.  (A full `-m gpu` run
-    starts some 200 short-lived GPU processes back to back; once in several such runs one of them failed to start on the box --
-    the same command passes on its own every time.  A failure of the code under test fails twice and is reported as before.)"""
+    """subprocess.run of one of the executables.  A process that failed to START on the GPU (STARTUP_SIGNATURES in its
+    output, and nothing of the radiation calculation) is run once more and the retry is recorded; any other failure --
+    wrong results, a crash or a hang of the code under test -- is returned as it is."""
     import sys
     import time
     p = subprocess.run(*args, **kw)
     if p.returncode != 0 and not os.environ.get("ECRAD_TEST_NO_RETRY"):
-        sys.stderr.write("retrying after return code %d:\n%s\n" % (p.returncode, ((p.stdout or "") + (p.stderr or ""))[-1500:]))
-        time.sleep(2.0)
-        p = subprocess.run(*args, **kw)
+        text = (p.stdout or "") + (p.stderr or "")
+        started = "Time elapsed in radiative transfer" in text or "Writing" in text
+        if any(sig in text for sig in STARTUP_SIGNATURES) and not started:
+            RETRIES.append(text[-1500:])
+            sys.stderr.write("GPU process failed to start (return code %d), retrying once:\n%s\n" % (p.returncode, text[-1500:]))
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "dropin_retries.log"), "a") as f:
+                    f.write("==== %s\n%s\n" % (time.strftime("%Y-%m-%d %H:%M:%S"), text[-3000:]))
+            except OSError:
+                pass
+            time.sleep(2.0)
+            p = subprocess.run(*args, **kw)
     return p
+
 
 def run_driver(tmp_path, name, *edits):
     nam, out = str(tmp_path / f"config_{name}.nam"), str(tmp_path / f"ecrad_meridian_{name}_out.nc")
@@ -89,7 +110,9 @@ def test_without_a_device_the_host_prepares_its_tables_and_the_dropin_fails_loud
     """On a box without a GPU: the namelist is read, the reference's setup routines read and map every look-up table
     through the repo's netCDF module, and the first thing the drop-in does -- create its handle -- aborts the run through
     radiation_abort; there is no CPU path behind radiation()."""
-    p, out = run_driver(tmp_path, "ecckd_tc")
+    nam, out = str(tmp_path / "config_ecckd_tc.nam"), str(tmp_path / "ecrad_meridian_ecckd_tc_out.nc")
+    write_namelist(nam)
+    p = subprocess.run([EXE, nam, MERIDIAN, out], capture_output=True, text=True, cwd=str(tmp_path), env=dict(os.environ, OMP_NUM_THREADS="1"), timeout=900)
     text = p.stdout + p.stderr
     assert p.returncode != 0 and not os.path.exists(out)
     assert "OFFLINE ECRAD RADIATION SCHEME" in text
@@ -122,25 +145,36 @@ def test_reference_driver_with_the_dropin_reproduces_the_golden_file(tmp_path, n
 OMP_EXE = os.path.join(ROOT, "tests", "_build", "dropin_omp", "ecrad_hip")
 
 
+def _pool_report(text):
+    """The line ECRAD_HIP_POOL_REPORT=1 makes the library print when the process ends (ecrad_amd/csrc/api.hip: report_pools)."""
+    m = re.search(r"ecrad_hip pool: devices (\d+) contexts (\d+) calls (\d+) max_in_flight (\d+) batches (\d+) calls_on_device(.*)", text)
+    assert m, text[-2000:]
+    return {"devices": int(m.group(1)), "contexts": int(m.group(2)), "calls": int(m.group(3)), "max_in_flight": int(m.group(4)),
+            "batches": int(m.group(5)), "calls_on_device": dict((int(a), int(b)) for a, b in re.findall(r"(\d+):(\d+)", m.group(6)))}
+
+
 @pytest.mark.skipif(not os.path.exists(OMP_EXE), reason="tests/_build/dropin_omp/ecrad_hip has not been built (tools/build_dropin.py --openmp)")
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["default", "tripleclouds", "ecckd_mcica"])
 def test_openmp_driver_threads_call_the_dropin_concurrently(tmp_path, name):
     """The reference's radiation() is re-entrant and its driver calls it from `!$OMP PARALLEL DO` over blocks of columns
     (driver/ecrad_driver.F90:348; SURVEY.md 8(b) "Threading").  Here that driver is compiled WITH OpenMP around the drop-in
-    (tools/build_dropin.py --openmp) and run on 4 threads with blocks of 3 columns: 11 calls of radiation(), up to 4 at once, on
-    the one handle -- they queue in the wrapper's critical section / the library's per-handle mutex -- and the output file
-    still equals the reference's golden file to float32 rounding."""
+    (tools/build_dropin.py --openmp) and run on 16 threads with blocks of 2 columns: 16 calls of radiation() at once on the one
+    handle, which the library runs together: the blocks that wait while a batch is on the device form the next batch (at least
+    8 calls in flight at some point and fewer batches than calls, by the library's own count) -- and the output file still
+    equals the reference's golden file to float32 rounding."""
     family, edits = TARGETS[name]
     nam, out = str(tmp_path / f"config_{name}.nam"), str(tmp_path / f"ecrad_meridian_{name}_out.nc")
     write_namelist(nam, family, edits)
     text = open(nam).read()
     assert len(re.findall(r"nblocksize\s*=\s*\d+", text)) == 1
-    open(nam, "w").write(re.sub(r"nblocksize\s*=\s*\d+", "nblocksize = 3", text))
-    env = dict(os.environ, OMP_NUM_THREADS="4", OMP_STACKSIZE="1G")
+    open(nam, "w").write(re.sub(r"nblocksize\s*=\s*\d+", "nblocksize = 2", text))
+    env = dict(os.environ, OMP_NUM_THREADS="16", OMP_STACKSIZE="1G", ECRAD_HIP_CONTEXTS="16", ECRAD_HIP_DEVICES="1", ECRAD_HIP_POOL_REPORT="1")
     p = _run(f"ulimit -s unlimited; exec {OMP_EXE} {nam} {MERIDIAN} {out}", shell=True, capture_output=True, text=True,
                        cwd=str(tmp_path), env=env, timeout=900)
     assert p.returncode == 0 and os.path.exists(out), (p.stdout + p.stderr)[-3000:]
+    pool = _pool_report(p.stdout + p.stderr)
+    assert pool["contexts"] == 16 and pool["calls"] == 16 and pool["max_in_flight"] >= 8 and pool["batches"] < 16, pool
     worst = {}
     with NcFile(os.path.join(GOLDEN_DIR, f"ecrad_meridian_{name}_out_REFERENCE.nc")) as g, NcFile(out) as o:
         for v in g._f.variables:
@@ -149,7 +183,52 @@ def test_openmp_driver_threads_call_the_dropin_concurrently(tmp_path, name):
             worst[v] = rel_err(got, ref)
     bad = {k: e for k, e in worst.items() if not e < FLOAT32_TOL}
     assert not bad, f"{name}: beyond float32 rounding: {bad}"
-    print(name, "OpenMP driver (4 threads, blocks of 3 columns) + drop-in vs golden file: max", max(worst.values()))
+    print(name, f"OpenMP driver (16 threads, blocks of 2 columns, {pool['max_in_flight']} calls in flight at once) + drop-in vs golden file: max", max(worst.values()))
+
+
+@pytest.mark.skipif(not os.path.exists(OMP_EXE), reason="tests/_build/dropin_omp/ecrad_hip has not been built (tools/build_dropin.py --openmp)")
+@pytest.mark.gpu
+def test_openmp_driver_with_the_reference_block_size_of_80_columns(tmp_path):
+    """The reference's own test namelist sets nblocksize = 80 (test/ifs/configCY49R1_ecckd.nam:12).  5 120 synthetic columns
+    (ecCKD-32 Tripleclouds with clouds and aerosols, written as a driver input file) through the UNCHANGED OpenMP driver +
+    drop-in: 64 blocks of 80 columns on 16 threads against one block of 5 120 columns on one thread -- every variable of
+    the output file identical, at least 8 calls in flight, and the driver's own timer (driver/ecrad_driver.F90:387-388) for both."""
+    from bench import build_config
+    from ecrad_amd.driver import save_inputs
+    from ecrad_amd.synthetic import make_columns
+    config, clear_sky, _ = build_config("tripleclouds_ecckd32")
+    inputs = make_columns(config, 5120, clear_sky)
+    inp = str(tmp_path / "inputs.nc")
+    save_inputs(inp, config, *inputs[2:])
+    write_namelist(str(tmp_path / "base.nam"), {"do_save_spectral_flux": "false", "iverbose": "1", "iverbosesetup": "0"})
+    base = open(str(tmp_path / "base.nam")).read()
+    outs, times = {}, {}
+    for tag, nthreads, nblock in (("blocks", 16, 80), ("whole", 1, 5120)):
+        nam, out = str(tmp_path / f"config_{tag}.nam"), str(tmp_path / f"out_{tag}.nc")
+        # (nrepeat = 20: the driver repeats its block loop inside its timer, driver/ecrad_driver.F90:340-388, so that what each
+        #  context allocates on its first call -- work arrays, page-locked staging -- is a twentieth of what is timed)
+        open(nam, "w").write(re.sub(r"nrepeat\s*=\s*\d+", "nrepeat = 20", re.sub(r"nblocksize\s*=\s*\d+", f"nblocksize = {nblock}", base)))
+        env = dict(os.environ, OMP_NUM_THREADS=str(nthreads), OMP_STACKSIZE="1G", ECRAD_HIP_CONTEXTS="16", ECRAD_HIP_DEVICES="1", ECRAD_HIP_POOL_REPORT="1")
+        p = _run(f"ulimit -s unlimited; exec {OMP_EXE} {nam} {inp} {out}", shell=True, capture_output=True, text=True,
+                 cwd=str(tmp_path), env=env, timeout=900)
+        text = p.stdout + p.stderr
+        assert p.returncode == 0 and os.path.exists(out), text[-3000:]
+        pool = _pool_report(text)
+        m = re.search(r"Time elapsed in radiative transfer:\s*([0-9.Ee+-]+)\s*seconds", text)
+        assert m, text[-2000:]
+        times[tag] = float(m.group(1)) / 20.0
+        outs[tag] = out
+        if tag == "blocks":
+            assert pool["calls"] == 64 * 20 and pool["max_in_flight"] >= 8, pool
+        else:
+            assert pool["calls"] == 20 and pool["max_in_flight"] == 1, pool
+    with NcFile(outs["blocks"]) as a, NcFile(outs["whole"]) as b:      # (the files differ in their time stamp only)
+        names = list(a._f.variables)
+        assert sorted(names) == sorted(b._f.variables) and len(names) >= 10
+        for v in names:
+            assert np.array_equal(a.get(v), b.get(v), equal_nan=True), v
+    print("OpenMP driver + drop-in, 5120 columns, per repeat of 20: 64 blocks of 80 on 16 threads %.4f s (%.0f columns/s); one block on one thread %.4f s (%.0f columns/s)"
+          % (times["blocks"], 5120 / times["blocks"], times["whole"], 5120 / times["whole"]))
 
 
 # Targets of test/ifs/Makefile WITHOUT a golden file: (namelist family, change_namelist.sh arguments, the same as a Python-host config)
@@ -514,3 +593,12 @@ def test_single_precision_host_through_the_dropin(tmp_path, target):
             continue        # (all-sky longwave with 3-D effects: chaotic in single precision in the reference's own formulation)
         assert e_hip[v] < (2.0e-3 if spartacus else 5.0e-5), (v, e_hip[v])
         assert e_hip[v] <= max(2.0 * e_ref[v], 1.0e-6), (v, e_hip[v], e_ref[v])
+
+
+@pytest.mark.gpu
+def test_zz_gpu_processes_started_without_retries():
+    """Last test of the file: how often _run had to start a GPU process twice (see STARTUP_SIGNATURES).  Zero is the rule;
+    one or two are reported (stderr, gpurun_out/dropin_retries.log) as the box's; more than that is a defect."""
+    if RETRIES:
+        print("GPU processes that had to be started twice: %d\n%s" % (len(RETRIES), "\n----\n".join(RETRIES)))
+    assert len(RETRIES) <= 2, RETRIES

@@ -1,0 +1,223 @@
+"""The boundary under concurrent callers (include/ecrad_hip.h: ecrad_hip_set_concurrency, ecrad_hip_pool_info) and the three
+ways a host-memory call moves its arrays (small calls of up to 512 columns: batched with whatever else is waiting, through
+page-locked mirrors; one tile; pipelined tiles: 8192 columns and more).
+
+The reference's radiation() is re-entrant and its driver calls it from `!$OMP PARALLEL DO` over blocks of columns
+(driver/ecrad_driver.F90:348-370); the library serves such callers from a pool of (device, stream, work arrays) contexts.
+What must hold whatever context a call lands on, and however its arrays travel: THE SAME BITS as one call over all columns."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from ecrad_amd import abi
+from ecrad_amd.interface import Radiation
+from ecrad_amd.synthetic import make_columns
+from ecrad_amd.types import Flux
+from helpers import make_config
+
+
+def test_pool_info_struct_matches_the_header():
+    """ecrad_pool_info_t of include/ecrad_hip.h: 4 x int32, 2 x int64, 16 x int32, 16 x int64."""
+    assert C.sizeof(abi.PoolInfo) == 16 + 16 + 16 * 4 + 16 * 8
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ecrad_hip.h")).read()
+    assert "#define ECRAD_MAX_POOL_DEVICES 16" in text and abi.MAX_POOL_DEVICES == 16
+    for sym in ("ecrad_hip_set_concurrency", "ecrad_hip_pool_info", "ecrad_hip_pool_reset"):
+        assert sym in text and sym in abi.EXPORTED_SYMBOLS
+
+
+def _flux_equal(a: Flux, b: Flux, cols=None):
+    for name, ref in a.arrays.items():
+        got = b.arrays[name]
+        if cols is not None:
+            sl = slice(cols[0], cols[1])
+            ref = ref[..., sl] if ref.shape[-1] == a.ncol else ref[sl]
+            got = got[..., sl] if got.shape[-1] == b.ncol else got[sl]
+        assert np.array_equal(ref, got, equal_nan=True), name
+
+
+def _blocks(ncol, nblock):
+    return [(i + 1, min(ncol, i + nblock)) for i in range(0, ncol, nblock)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["Tripleclouds", "McICA"])
+def test_concurrent_blocks_on_two_contexts_of_one_device_give_the_same_bits(solver):
+    """Two contexts on ONE device, eight host threads calling radiation() on blocks of 80 columns of shared arrays at once
+    (what the driver's OpenMP loop does; the library runs the blocks that wait for a context together as one batch): every
+    flux of every column equals the single call over all columns, bit for bit; at least two calls were in flight at some
+    point and the sixteen calls took fewer than sixteen batches."""
+    ncol = 1280
+    config = make_config(solver)
+    rad1 = Radiation(config, backend="hip", concurrency=(1, 1))
+    n, nlev, sl, th, gas, cloud, aer = make_columns(config, ncol, False)
+    frac0 = cloud.fraction.copy()
+    ref = Flux.allocate(config, n, nlev)
+    rad1.radiation(n, nlev, 1, n, sl, th, gas, cloud, aer, ref)
+    frac_ref = cloud.fraction.copy()
+    assert rad1.pool_info()["n_contexts"] == 1
+    rad1.close()
+
+    rad = Radiation(config, backend="hip", concurrency=(1, 2))
+    info = rad.pool_info()
+    assert info["n_devices"] == 1 and info["n_contexts"] == 2, info
+    cloud.fraction[...] = frac0
+    flux = Flux.allocate(config, n, nlev)
+    errors = []
+    blocks = _blocks(n, 80)
+    lock = threading.Lock()
+
+    def worker():
+        while True:
+            with lock:
+                if not blocks:
+                    return
+                i0, i1 = blocks.pop()
+            try:
+                rad.radiation(n, nlev, i0, i1, sl, th, gas, cloud, aer, flux)
+            except Exception as e:       # noqa: BLE001
+                errors.append(e)
+                return
+    threads = [threading.Thread(target=worker) for _ in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    info = rad.pool_info()
+    rad.close()
+    assert info["calls_total"] == 16 and info["max_in_flight"] >= 2 and 1 <= info["batches_total"] < 16, info
+    _flux_equal(ref, flux)
+    assert np.array_equal(cloud.fraction, frac_ref)      # the crop_cloud_fraction side effect, block by block
+
+
+@pytest.mark.gpu
+def test_more_callers_than_contexts_wait_their_turn_and_sixteen_contexts_run_sixteen_calls():
+    """Sixteen threads released at once on a pool of ONE context (the first caller runs alone, the fifteen that wait meanwhile
+    run as one or two batches), on a pool of sixteen (each finds a context of its own), and with the batching switched off
+    (sixteen separate calls, one after the other on the one context): the same bits every time."""
+    ncol = 32 * 16
+    config = make_config("Tripleclouds")
+    n, nlev, sl, th, gas, cloud, aer = make_columns(config, ncol, False)
+    frac0 = cloud.fraction.copy()
+    results = {}
+    for nctx in (1, 16, -1):
+        cloud.fraction[...] = frac0
+        if nctx < 0:
+            os.environ["ECRAD_HIP_PACK_COLUMNS"] = "0"
+        rad = Radiation(config, backend="hip", concurrency=(1, abs(nctx)))
+        flux = Flux.allocate(config, n, nlev)
+        barrier = threading.Barrier(16)
+
+        def worker(k):
+            barrier.wait()
+            rad.radiation(n, nlev, 32 * k + 1, 32 * (k + 1), sl, th, gas, cloud, aer, flux)
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(16)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        info = rad.pool_info()
+        rad.close()
+        os.environ.pop("ECRAD_HIP_PACK_COLUMNS", None)
+        assert info["calls_total"] == 16 and info["n_contexts"] == abs(nctx)
+        if nctx == 1:
+            assert info["max_in_flight"] >= 8 and info["batches_total"] <= 8, info
+        elif nctx == 16:
+            assert info["max_in_flight"] >= 8, info
+        else:
+            assert info["max_in_flight"] == 1 and info["batches_total"] == 0, info
+        results[nctx] = flux
+    _flux_equal(results[1], results[16])
+    _flux_equal(results[1], results[-1])
+
+
+@pytest.mark.gpu
+def test_every_visible_device_joins_the_pool_and_calls_spread_over_them():
+    """n_devices = 0: every visible device (one on the test box: the pool then is that device); with several, the calls of
+    concurrent threads land on all of them and still give the bits of the single-device run."""
+    import torch
+    ndev = torch.cuda.device_count()
+    config = make_config("Homogeneous")
+    n, nlev, sl, th, gas, cloud, aer = make_columns(config, 64 * ndev * 4, True)
+    rad = Radiation(config, backend="hip", concurrency=(0, 2))
+    info = rad.pool_info()
+    assert info["n_devices"] == ndev and info["n_contexts"] == 2 * ndev, info
+    flux = Flux.allocate(config, n, nlev)
+    blocks = _blocks(n, 64)
+    barrier = threading.Barrier(len(blocks))
+
+    def worker(b):
+        barrier.wait()
+        rad.radiation(n, nlev, b[0], b[1], sl, th, gas, cloud, aer, flux)
+    threads = [threading.Thread(target=worker, args=(b,)) for b in blocks]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    info = rad.pool_info()
+    rad.close()
+    assert sum(info["calls_on_device"].values()) == len(blocks)
+    if ndev > 1:
+        assert all(v > 0 for v in info["calls_on_device"].values()), info
+    rad1 = Radiation(config, backend="hip", concurrency=(1, 1))
+    ref = Flux.allocate(config, n, nlev)
+    rad1.radiation(n, nlev, 1, n, sl, th, gas, cloud, aer, ref)
+    rad1.close()
+    _flux_equal(ref, flux)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["Homogeneous", "Tripleclouds"])
+def test_packed_single_tile_and_pipelined_host_calls_give_the_same_bits(solver):
+    """20 000 columns through ecrad_hip_radiation with host-memory arrays: as pipelined tiles (the default from 8192 columns),
+    as one tile (ECRAD_HIP_NO_PIPELINE), and block by block -- blocks of 300 columns as small calls (one packed transfer each
+    way through page-locked mirrors, api.hip: radiation_small), and the same blocks with that switched off
+    (ECRAD_HIP_PACK_COLUMNS=0).  All four equal bit for bit; the pipelined call ran as
+    several tiles; columns outside a block's range are not touched."""
+    ncol = 20000
+    clear = solver == "Homogeneous"
+    config = make_config(solver, use_aerosols=not clear)
+    n, nlev, sl, th, gas, cloud, aer = make_columns(config, ncol, clear)
+    frac0 = cloud.fraction.copy() if cloud is not None else None
+    rad = Radiation(config, backend="hip")
+
+    def run(blocks, env):
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            if frac0 is not None:
+                cloud.fraction[...] = frac0
+            flux = Flux.allocate(config, n, nlev)
+            for name, a in flux.arrays.items():
+                a[...] = -77.0
+            for i0, i1 in blocks:
+                rad.radiation(n, nlev, i0, i1, sl, th, gas, cloud, aer, flux)
+            info = abi.CallInfo()
+            rad.lib.ecrad_hip_last_call_info(rad.handle, C.byref(info))
+            return flux, info.n_tiles
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    piped, ntile = run([(1, n)], {"ECRAD_HIP_HOST_TILE": "4096"})
+    assert ntile == 8          # 1024 + 2048 + 3 x 4096 + 1568 + 2048 + 1024: the tiles ramp up and down (api.hip: radiation_host_pipelined)
+    flat, ntile = run([(1, n)], {"ECRAD_HIP_HOST_TILE": "4096", "ECRAD_HIP_NO_RAMP": "1"})
+    assert ntile == 5
+    _flux_equal(flat, piped)
+    whole, ntile1 = run([(1, n)], {"ECRAD_HIP_NO_PIPELINE": "1"})
+    assert ntile1 == 1
+    _flux_equal(whole, piped)
+    some = [(301, 600), (601, 900), (19701, 20000)]
+    packed, _ = run(some, {})
+    plain, _ = run(some, {"ECRAD_HIP_PACK_COLUMNS": "0"})
+    _flux_equal(packed, plain)
+    for i0, i1 in some:
+        _flux_equal(whole, packed, cols=(i0 - 1, i1))
+    # a column no block covered still holds what the caller had put there
+    assert packed.arrays["lw_up"][0, 0] == -77.0 and packed.arrays["lw_up"][0, 1000] == -77.0
+    rad.close()

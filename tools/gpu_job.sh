@@ -1,9 +1,7 @@
 #!/bin/bash
-out=gpurun_out/r04_b; mkdir -p $out
+out=gpurun_out/r04_k; mkdir -p $out
 export TMPDIR=/tmp
-bash tools/run_variants.sh --headline-only 2>&1 | tee $out/variants.log
-# the start-up flake behind the drop-in tests' retry: the 54 cases in a loop without the retry, every failure's output kept
-for i in 1 2 3; do
-  ECRAD_TEST_NO_RETRY=1 timeout 600 python -m pytest tests/test_fortran_dropin.py -q -m gpu -x 2>&1 | tail -40 > $out/dropin_loop_$i.log
-  tail -2 $out/dropin_loop_$i.log
-done
+for q in 4 8; do for slots in 2 3; do
+echo "== slots $slots queues $q"
+GPU_MAX_HW_QUEUES=$q ECRAD_HIP_BATCH_TRACE=1 ECRAD_HIP_SMALL_SLOTS=$slots timeout 300 python tools/small_call_latency.py --host --ncol 80 --threads 32 --contexts 8 > $out/trace_${slots}_$q.log 2>&1; grep "batch:" $out/trace_${slots}_$q.log | tail -6; grep columns/s $out/trace_${slots}_$q.log
+done; done
