@@ -26,12 +26,17 @@ namespace {
 struct Buf {
   void* p = nullptr;
   size_t cap = 0;
+  // grows by at least half of what it holds: a context whose calls grow little by little (the batches of small calls of a
+  // blocked host, api.hip: radiation_small) is not re-allocated -- a hipFree waits for the device -- on every new maximum
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
+    const size_t want = cap ? std::max(bytes, cap + cap / 2) : bytes;
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
-    hipError_t e = hipMalloc(&p, bytes);
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess && want > bytes) e = hipMalloc(&p, bytes);      // (no room for the headroom)
+    else if (e == hipSuccess) { cap = want; return e; }
     if (e == hipSuccess) cap = bytes;
     return e;
   }
@@ -44,10 +49,10 @@ struct HostBuf {
   size_t cap = 0;
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
+    bytes = (std::max(bytes, cap + cap / 2) + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);      // (page-locking is slow: grow in strides)
     if (p) (void)hipHostFree(p);
     p = nullptr;
     cap = 0;
-    bytes = (bytes + (size_t(1) << 20) - 1) & ~((size_t(1) << 20) - 1);
     hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
     if (e == hipSuccess) cap = bytes;
     return e;
@@ -2293,6 +2298,8 @@ struct SmallBatch {
   ecrad_hip_handle_s* ctx = nullptr;
   int phase = 0;         // 0 being laid out, 1 gather, 3 scatter, 4 over (pool_mutex)
   int gathered = 0, scattered = 0;
+  std::condition_variable cv;       // the members of THIS batch wait here (with the pool's mutex): the pool's own condition
+                                    // variable is for callers that wait for a context, and wakes only those
   int status = ECRAD_OK;
   std::string err;
   // layout, valid from phase 1
@@ -2407,13 +2414,14 @@ int batch_lead(ecrad_hip_handle_t root, SmallBatch& B, SmallCall& mine) {
     B.status = st;
     if (st) B.err = h->err;
     B.phase = st ? 4 : 1;
-    root->pool_cv.notify_all();
+    B.cv.notify_all();
+    if (st) B.cv.wait(lk, [&] { return B.scattered == (int)B.calls.size() - 1; });
     if (!st) {
       lk.unlock();
       batch_gather(h, B, mine);
       lk.lock();
       B.gathered++;
-      root->pool_cv.wait(lk, [&] { return B.gathered == (int)B.calls.size(); });
+      B.cv.wait(lk, [&] { return B.gathered == (int)B.calls.size(); });
     }
   }
   ms_gather = ms_since(t_phase);
@@ -2447,12 +2455,12 @@ int batch_lead(ecrad_hip_handle_t root, SmallBatch& B, SmallCall& mine) {
       B.status = st;
       if (st) B.err = h->err;
       B.phase = 3;
-      root->pool_cv.notify_all();
+      B.cv.notify_all();
       lk.unlock();
       if (!st) batch_scatter(h, B, mine);
       lk.lock();
       B.scattered++;
-      root->pool_cv.wait(lk, [&] { return B.scattered == (int)B.calls.size(); });
+      B.cv.wait(lk, [&] { return B.scattered == (int)B.calls.size(); });
       B.phase = 4;
     }
     ms_scatter = ms_since(t_phase);
@@ -2497,6 +2505,7 @@ int radiation_small(ecrad_hip_handle_t root, int ncol, int nlev, int istartcol, 
       if (root->in_flight > root->max_in_flight) root->max_in_flight = root->in_flight;
       tl_last_context = c;
       lk.unlock();
+      if (B.calls.size() > 1) root->pool_cv.notify_all();      // (the members wait there until they see that they belong to a batch)
       const int st = batch_lead(root, B, me);
       lk.lock();
       c->busy = false;
@@ -2513,21 +2522,24 @@ int radiation_small(ecrad_hip_handle_t root, int ncol, int nlev, int istartcol, 
   SmallBatch& L = *me.batch;
   ecrad_hip_handle_s* const ctx = L.ctx;
   tl_last_context = ctx;
-  root->pool_cv.wait(lk, [&] { return L.phase >= 1; });
-  if (L.phase == 4) return L.status;                       // the batch could not be laid out (the leader has reported why)
+  L.cv.wait(lk, [&] { return L.phase >= 1; });
+  if (L.phase == 4) {                                      // the batch could not be laid out (the leader has reported why)
+    const int st = L.status;
+    if (++L.scattered == (int)L.calls.size() - 1) L.cv.notify_all();      // (the leader waits for its members to have read this)
+    return st;
+  }
   lk.unlock();
   batch_gather(ctx, L, me);
   lk.lock();
-  L.gathered++;
-  root->pool_cv.notify_all();
-  root->pool_cv.wait(lk, [&] { return L.phase >= 3; });
+  if (++L.gathered == (int)L.calls.size()) L.cv.notify_all();
+  L.cv.wait(lk, [&] { return L.phase >= 3; });
   const int st = L.status;
   lk.unlock();
   if (!st) batch_scatter(ctx, L, me);
   lk.lock();
-  L.scattered++;                                           // (the last thing this thread does with the batch: it lives on the leader's stack)
-  lk.unlock();
-  root->pool_cv.notify_all();
+  // (the last thing this thread does with the batch, under the mutex: the batch lives on the leader's stack and the leader
+  //  leaves when the count is full)
+  if (++L.scattered == (int)L.calls.size()) L.cv.notify_all();
   return st;
 }
 
@@ -2561,7 +2573,10 @@ int radiation_on(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int ie
   }
   long long tile_cols = per_col ? (long long)(budget / per_col) : (long long)nloc;
   tile_cols = std::max(4096ll, tile_cols / 256 * 256);
-  // host-memory mode: tiles small enough to pipeline copy-in, kernels and copy-out (three sets of staged arrays in flight)
+  // host-memory mode: tiles small enough to pipeline copy-in, kernels and copy-out (three sets of staged arrays in flight).
+  // From 8192 columns on, tiles of at least 4096: the kernels of a tile take the same 1.5-2.5 ms whether it has 1000 columns or
+  // 6000 (a column group is a chain of 137 levels of latencies; 6144 columns fill the GPU once), so smaller tiles only add
+  // kernel time -- 5120 columns as four tiles of 1280: 7.5 ms against 5.0 ms as one tile (gpurun_out/r04_m)
   const bool pipeline = host_mem && !std::getenv("ECRAD_HIP_NO_PIPELINE") && nloc >= 2 * 4096;
   if (pipeline) tile_cols = std::min<long long>(tile_cols, std::max(4096, std::min(host_tile_columns(), (nloc / 2 + 255) / 256 * 256)));
   if (tile_cols > nloc) tile_cols = nloc;
