@@ -190,6 +190,12 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
 #if ECRAD_PIPELINE_LOADS
       gas_load<TAB>(gh, nquad, nplain, L, cib * NGP, g, quads);     // see kernel_ica_sw.hip
 #endif
+#if ECRAD_LW_PLANCK_AHEAD
+      // The Planck function of a layer's lower half level is one table load per layer whose address comes straight from the
+      // level record: requested a layer ahead, it travels while the previous layer's optics are computed instead of standing
+      // at the head of every layer's chain (gas optics -> transmittance -> sources -> downward flux)
+      typename PlanckTab<TAB>::Pair planck_pair = pt.fetch(L.I(I_PL_BOT, cib * NGP), g);
+#endif
       for (int j = 0; j < nl; ++j) {
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
@@ -200,7 +206,12 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
 #ifdef ECRAD_TIMING
         ECRAD_LAP(tm, 0, quads.q[0].x);   // (timing build: table loads alone, booked under "scalars")
 #endif
+#if ECRAD_LW_PLANCK_AHEAD
+        double planck_bot = PlanckTab<TAB>::value(planck_pair, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot));
+        if (j + 1 < nl) planck_pair = pt.fetch(L.I(I_PL_BOT, slot + 1), g);
+#else
         double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
+#endif
         ECRAD_LAP(tm, 1, planck_bot);   // table + Planck loads returned
         double od = gas_combine<TAB>(nq, L, slot, quads);
         double od_scaling_staged = 0.0;

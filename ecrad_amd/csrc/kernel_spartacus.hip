@@ -40,6 +40,10 @@
 #ifndef ECRAD_SP_SWEEP_WAVES_LW
 #define ECRAD_SP_SWEEP_WAVES_LW 3
 #endif
+// levels of slab scalars the flux sweeps keep in flight (a ring, see section 5 of spartacus_sw_kernel)
+#ifndef ECRAD_SP_RING
+#define ECRAD_SP_RING 4
+#endif
 
 namespace ecrad {
 
@@ -50,6 +54,7 @@ using sp::rmin;
 
 namespace {
 
+constexpr int kSpRing = ECRAD_SP_RING;
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kGasConstantDryAir = 287.058;      // radiation_constants.F90:31
 
@@ -770,15 +775,29 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
           }
         }
       }
-      for (int jlev = 1; jlev <= nlev; ++jlev) {
+      // The scalars of a level -- the clear-sky set and, for a cloud-free layer, region 1's: slots 0-11 of the slab -- come
+      // through a RING of kSpRing levels: the slot a level is taken from is refilled at once with the level kSpRing further
+      // down.  (Until round 4 every level asked for its own twelve values and waited for them: one trip to HBM per level of
+      // a sweep that has a few dozen operations per level.)  The matrices of a cloudy layer are still fetched when it is met.
+      R ring_c[kSpRing][6], ring_r[kSpRing][6];
+      auto fetch_level = [&](int jl_want, R (&c6)[6], R (&r6)[6]) {
+        const int l = jl_want < nlev ? jl_want : nlev - 1;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { c6[k] = do_clear ? slab.get(l, SW_REFC + k, tid) : R(0); }
+        const bool cl = !cm.test(l);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { r6[k] = cl ? slab.get(l, SW_REFL + k, tid) : R(0); }
+      };
+#pragma unroll
+      for (int k = 0; k < kSpRing; ++k) fetch_level(k, ring_c[k], ring_r[k]);
+      auto flux_level = [&](const int jlev, const R (&c6)[6], const R (&r6)[6]) {
         const int jl = jlev - 1;
         const bool clr = !cm.test(jl);
         const bool clr_below = jlev == nlev || !cm.test(jl + 1);
         const size_t oh = col + ncol * ord.half(jlev);
         double sw_dn_clear_direct = 0.0;
         if (do_clear) {
-          const R refc = slab.get(jl, SW_REFC, tid), trac = slab.get(jl, SW_TRAC, tid), tddc = slab.get(jl, SW_TDDC, tid),
-                  tdirc = slab.get(jl, SW_TDIRC, tid), tac = slab.get(jl, SW_TAC, tid), tadc = slab.get(jl, SW_TADC, tid);
+          const R refc = c6[0], trac = c6[1], tddc = c6[2], tdirc = c6[3], tac = c6[4], tadc = c6[5];
           const R source_dn_clear = tddc * direct_dn_clear;
           direct_dn_clear = tdirc * direct_dn_clear;
           flux_dn_clear = (trac * flux_dn_clear + refc * tadc * direct_dn_clear + source_dn_clear) / (R(1) - refc * tac);
@@ -787,8 +806,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
           if (lead && fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[oh] = sw_dn_clear_direct;
         }
         if (clr) {
-          const R refl = slab.get(jl, SW_REFL + 0, tid), tran = slab.get(jl, SW_REFL + 1, tid), tdd = slab.get(jl, SW_REFL + 2, tid),
-                  tdir = slab.get(jl, SW_REFL + 3, tid), ta1 = slab.get(jl, SW_REFL + 4, tid), tad1 = slab.get(jl, SW_REFL + 5, tid);
+          const R refl = r6[0], tran = r6[1], tdd = r6[2], tdir = r6[3], ta1 = r6[4], tad1 = r6[5];
           const R source_dn = tdd * direct_dn_below.a[0];
           direct_dn_above.zero();
           direct_dn_above.a[0] = tdir * direct_dn_below.a[0];
@@ -841,6 +859,19 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
             spec_put(fx.sw_up_clear_band, ng, g, oh, (double)flux_up_clear);
             spec_put(fx.sw_dn_clear_band, ng, g, oh, (double)(dirc + flux_dn_clear));
             spec_put(fx.sw_dn_direct_clear_band, ng, g, oh, (double)dirc);
+          }
+        }
+      };
+      for (int j0 = 1; j0 <= nlev; j0 += kSpRing) {
+#pragma unroll
+        for (int k = 0; k < kSpRing; ++k) {
+          const int jlev = j0 + k;
+          if (jlev <= nlev) {
+            R c6[6], r6[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { c6[q] = ring_c[k][q]; r6[q] = ring_r[k][q]; }
+            fetch_level(jlev - 1 + kSpRing, ring_c[k], ring_r[k]);
+            flux_level(jlev, c6, r6);
           }
         }
       }
@@ -1231,20 +1262,30 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
         if (do_clear) { spec_put(fx.lw_up_clear_band, ng, g, o0, (double)ts_clear); spec_put(fx.lw_dn_clear_band, ng, g, o0, 0.0); }
       }
     }
-    for (int jlev = 1; jlev <= nlev; ++jlev) {
+    // (the scalars of a level -- slots 0-9 of the slab -- through a ring of kSpRing levels, see spartacus_sw_kernel)
+    R ring_c[kSpRing][5], ring_r[kSpRing][5];
+    auto fetch_level = [&](int jl_want, R (&c5)[5], R (&r5)[5]) {
+      const int l = jl_want < nlev ? jl_want : nlev - 1;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) { c5[k] = do_clear ? slab.get(l, LW_REFC + k, tid) : R(0); }
+      const bool cl = !cm.test(l);
+#pragma unroll
+      for (int k = 0; k < 5; ++k) { r5[k] = cl ? slab.get(l, LW_REFL + k, tid) : R(0); }
+    };
+#pragma unroll
+    for (int k = 0; k < kSpRing; ++k) fetch_level(k, ring_c[k], ring_r[k]);
+    auto flux_level = [&](const int jlev, const R (&c5)[5], const R (&r5)[5]) {
       const int jl = jlev - 1;
       const bool clr = !cm.test(jl);
       const bool clr_below = jlev == nlev || !cm.test(jl + 1);
       const size_t oh = col + ncol * ord.half(jlev);
       if (do_clear) {
-        const R refc = slab.get(jl, LW_REFC, tid), trac = slab.get(jl, LW_TRAC, tid), sdnc = slab.get(jl, LW_SDNC, tid),
-                tac = slab.get(jl, LW_TAC, tid), tsc = slab.get(jl, LW_TSC, tid);
+        const R refc = c5[0], trac = c5[1], sdnc = c5[2], tac = c5[3], tsc = c5[4];
         flux_dn_clear = (trac * flux_dn_clear + refc * tsc + sdnc) / (R(1) - refc * tac);
         flux_up_clear = tsc + tac * flux_dn_clear;
       }
       if (clr) {
-        const R refl = slab.get(jl, LW_REFL + 0, tid), tran = slab.get(jl, LW_REFL + 1, tid), sdn = slab.get(jl, LW_REFL + 2, tid),
-                ta1 = slab.get(jl, LW_REFL + 3, tid), ts1 = slab.get(jl, LW_REFL + 4, tid);
+        const R refl = r5[0], tran = r5[1], sdn = r5[2], ta1 = r5[3], ts1 = r5[4];
         flux_dn_above.zero(); flux_up_above.zero();
         flux_dn_above.a[0] = (tran * flux_dn_below.a[0] + refl * ts1 + sdn) / (R(1) - refl * ta1);
         flux_up_above.a[0] = ts1 + ta1 * flux_dn_above.a[0];
@@ -1288,6 +1329,19 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
         if (do_clear) {
           spec_put(fx.lw_up_clear_band, ng, g, oh, (double)flux_up_clear);
           spec_put(fx.lw_dn_clear_band, ng, g, oh, (double)flux_dn_clear);
+        }
+      }
+    };
+    for (int j0 = 1; j0 <= nlev; j0 += kSpRing) {
+#pragma unroll
+      for (int k = 0; k < kSpRing; ++k) {
+        const int jlev = j0 + k;
+        if (jlev <= nlev) {
+          R c5[5], r5[5];
+#pragma unroll
+          for (int q = 0; q < 5; ++q) { c5[q] = ring_c[k][q]; r5[q] = ring_r[k][q]; }
+          fetch_level(jlev - 1 + kSpRing, ring_c[k], ring_r[k]);
+          flux_level(jlev, c5, r5);
         }
       }
     }

@@ -49,6 +49,16 @@ template <typename TAB> constexpr int min_waves_for(int ecckd) { return sizeof(T
 // lw_ica_kernel<float,32,1> 6.49-6.53 ms with the double buffer; ring of 4: 5.85, 6: 5.78, 8: 5.82, 12: 5.73, 16: 6.79 -- spills).
 #define ECRAD_LW_RING 8
 #endif
+#ifndef ECRAD_LW_PLANCK_AHEAD
+// 1: the longwave ICA kernels request a layer's Planck table pair one layer ahead of its use.  On for the cloudless / homogeneous
+// instantiations (kernel_ica_lw_clear.hip: lw_ica_kernel<float,32,1> 5.81 -> 5.69 ms per 100 000 columns), off for McICA, whose
+// kernel it made 1 % slower (gpurun_out/r04_o)
+#ifdef ECRAD_LW_TU_CLEAR
+#define ECRAD_LW_PLANCK_AHEAD 1
+#else
+#define ECRAD_LW_PLANCK_AHEAD 0
+#endif
+#endif
 #ifndef ECRAD_ABLATE
 #define ECRAD_ABLATE 0
 #endif

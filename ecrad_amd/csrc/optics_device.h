@@ -321,6 +321,17 @@ struct PlanckTab {
     }
     return (double)pf[g].x * w2;
   }
+  // the same in two steps, so that the load can be issued a layer ahead of its use: fetch() the (T, T+1) pair of position `it`
+  // (the first pair below the table), value() interpolates -- the same expressions as lookup()
+  typedef typename QuadOf<TAB>::pair Pair;
+  ECRAD_DEV Pair fetch(int it, int g) const {
+    const Pair* __restrict__ pf = reinterpret_cast<const Pair*>(table);
+    return pf[g + ng * (it >= 0 ? it : 0)];
+  }
+  static ECRAD_DEV double value(const Pair& p, int it, double w2) {
+    if (it >= 0) return (1.0 - w2) * p.x + w2 * p.y;
+    return (double)p.x * w2;
+  }
 };
 
 // Planck function for an arbitrary temperature (surface emission)
