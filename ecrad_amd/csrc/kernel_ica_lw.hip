@@ -274,13 +274,13 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
             if (cloud_scattering) {
               double ssa_total = 0.0, g_total = 0.0;
               if (MODE == 1) {    // radiation_homogeneous_lw.F90:218-228
-                if (od_total > 0.0) ssa_total = fdiv(cl.ssa * od_cloud_new, od_total);
-                if (ssa_total > 0.0 && od_total > 0.0) g_total = fdiv(cl.g * cl.ssa * od_cloud_new, ssa_total * od_total);
+                if (od_total > 0.0) ssa_total = gdiv(cl.ssa * od_cloud_new, od_total);
+                if (ssa_total > 0.0 && od_total > 0.0) g_total = gdiv(cl.g * cl.ssa * od_cloud_new, ssa_total * od_total);
               } else {            // radiation_mcica_lw.F90:280-293
                 if (od_total > 0.0) {
                   const double scat_od = cl.ssa * od_cloud_new;
                   ssa_total = fdiv(scat_od, od_total);
-                  if (scat_od > 0.0) g_total = fdiv(cl.g * cl.ssa * od_cloud_new, scat_od);
+                  if (scat_od > 0.0) g_total = gdiv(cl.g * cl.ssa * od_cloud_new, scat_od);
                 }
               }
               c2 = ref_trans_lw(od_total, ssa_total, g_total, planck_top, planck_bot);

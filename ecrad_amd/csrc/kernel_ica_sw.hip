@@ -410,16 +410,16 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void s
               double od_total, ssa_total = 0.0, g_total = 0.0;
               if (MODE == 1) {   // radiation_homogeneous_sw.F90:236-253
                 od_total = od + cl.od;
-                if (od_total > 0.0) ssa_total = fdiv(ssa * od + cl.ssa * cl.od, od_total);
+                if (od_total > 0.0) ssa_total = gdiv(ssa * od + cl.ssa * cl.od, od_total);
                 if (ssa_total > 0.0 && od_total > 0.0)
-                  g_total = fdiv(asym * ssa * od + cl.g * cl.ssa * cl.od, ssa_total * od_total);
+                  g_total = gdiv(asym * ssa * od + cl.g * cl.ssa * cl.od, ssa_total * od_total);
               } else {           // radiation_mcica_sw.F90:250-268
                 const double od_cloud_new = (staged ? od_scaling_staged : b.prep.od_scaling_sw[g + (size_t)ng * (lev + (size_t)nlev * cloc)]) * cl.od;
                 od_total = od + od_cloud_new;
                 if (od_total > 0.0) {
                   const double scat_od = ssa * od + cl.ssa * od_cloud_new;
                   ssa_total = fdiv(scat_od, od_total);
-                  if (scat_od > 0.0) g_total = fdiv(asym * ssa * od + cl.g * cl.ssa * od_cloud_new, scat_od);
+                  if (scat_od > 0.0) g_total = gdiv(asym * ssa * od + cl.g * cl.ssa * od_cloud_new, scat_od);
                 }
               }
               if (flags & SWF_DELTA_GASES) delta_eddington(od_total, ssa_total, g_total);

@@ -142,14 +142,14 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
           const double od_total = od + od_cloud_new;
           double ssa_total = 0.0, g_total = 0.0;
           if (MODE == 1) {    // radiation_homogeneous_lw.F90:215-233 with aerosol scattering
-            if (od_total > 0.0) ssa_total = fdiv(ssa * od + cl.ssa * od_cloud_new, od_total);
+            if (od_total > 0.0) ssa_total = gdiv(ssa * od + cl.ssa * od_cloud_new, od_total);
             if (ssa_total > 0.0 && od_total > 0.0)
-              g_total = fdiv(asym * ssa * od + cl.g * cl.ssa * od_cloud_new, ssa_total * od_total);
+              g_total = gdiv(asym * ssa * od + cl.g * cl.ssa * od_cloud_new, ssa_total * od_total);
           } else {            // radiation_mcica_lw.F90:258-279
             if (od_total > 0.0) {
               const double scat = ssa * od + cl.ssa * od_cloud_new;
               ssa_total = fdiv(scat, od_total);
-              if (scat > 0.0) g_total = fdiv(asym * ssa * od + cl.g * cl.ssa * od_cloud_new, scat);
+              if (scat > 0.0) g_total = gdiv(asym * ssa * od + cl.g * cl.ssa * od_cloud_new, scat);
             }
           }
           const LwCoef c2 = ref_trans_lw(od_total, ssa_total, g_total, planck_top, planck_bot);

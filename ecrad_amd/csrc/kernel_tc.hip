@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
             const double scat_od_cloud = cl.od * cl.ssa * osc;
             double od_total = od + cl.od * osc;
             double ssa_total = fdiv(scat_od + scat_od_cloud, od_total);
-            double g_total = fdiv(scat_od * asym + scat_od_cloud * cl.g, scat_od + scat_od_cloud);
+            double g_total = gdiv(scat_od * asym + scat_od_cloud * cl.g, scat_od + scat_od_cloud);
             if (delta_gases) delta_eddington(od_total, ssa_total, g_total);
             const SwCoef c = ref_trans_sw_fused(mu0, od_total, ssa_total, g_total);
             tc_sw_up(s, jreg, l, tid, c, ta[jreg], tad[jreg], below[jreg], belowd[jreg]);
@@ -721,12 +721,12 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
             if (cloud_scattering) {
               double ssa_total = 0.0, g_total = 0.0;
               if (ASCAT) {     // :335-343
-                if (od_total > 0.0) ssa_total = fdiv(ssa * od + cl.ssa * od_cloud_new, od_total);
+                if (od_total > 0.0) ssa_total = gdiv(ssa * od + cl.ssa * od_cloud_new, od_total);
                 if (ssa_total > 0.0 && od_total > 0.0)
-                  g_total = fdiv(asym * ssa * od + cl.g * cl.ssa * od_cloud_new, ssa_total * od_total);
+                  g_total = gdiv(asym * ssa * od + cl.g * cl.ssa * od_cloud_new, ssa_total * od_total);
               } else {
-                if (od_total > 0.0) ssa_total = fdiv(cl.ssa * od_cloud_new, od_total);
-                if (ssa_total > 0.0 && od_total > 0.0) g_total = fdiv(cl.g * cl.ssa * od_cloud_new, ssa_total * od_total);
+                if (od_total > 0.0) ssa_total = gdiv(cl.ssa * od_cloud_new, od_total);
+                if (ssa_total > 0.0 && od_total > 0.0) g_total = gdiv(cl.g * cl.ssa * od_cloud_new, ssa_total * od_total);
               }
               c2 = ref_trans_lw(od_total, ssa_total, g_total, planck_top, planck_bot);
             } else {

@@ -149,6 +149,9 @@ ECRAD_DEV double frcp(double b) {
   return 1.0 / b;
 #endif
 }
+// a / b where the denominator is only known to be > 0 (a scattering optical depth, a sum of them: possibly subnormal or tiny):
+// the compiler's full division, with its range scaling -- fdiv would give NaN where this gives a finite quotient
+ECRAD_DEV double gdiv(double a, double b) { return a / b; }
 ECRAD_DEV double fdiv(double a, double b) {
 #if ECRAD_FAST_DIV
   double r = __builtin_amdgcn_rcp(b);
@@ -444,7 +447,7 @@ ECRAD_DEV void delta_eddington(double& od, double& ssa, double& g) {
 
 // delta_eddington_extensive (radiation_delta_eddington.h:44-58)
 ECRAD_DEV void delta_eddington_extensive(double& od, double& scat_od, double& scat_od_g) {
-  double g = scat_od > 0.0 ? fdiv(scat_od_g, scat_od) : 0.0;
+  double g = scat_od > 0.0 ? gdiv(scat_od_g, scat_od) : 0.0;
   double f = g * g;
   od = od - scat_od * f;
   scat_od = scat_od * (1.0 - f);

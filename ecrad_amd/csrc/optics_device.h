@@ -545,7 +545,7 @@ ECRAD_DEV void merge_aerosol_sw(const DevConfig& cfg, const AerosolLayer& a, dou
     const double local_od = od + a.od;
     if (local_od > 0.0 && a.od > 0.0) {
       const double local_scat = ssa * od + a.scat;
-      if (local_scat > 0.0) g = fdiv(a.scat_g, local_scat);
+      if (local_scat > 0.0) g = gdiv(a.scat_g, local_scat);
       ssa = fdiv(local_scat, local_od);
       od = local_od;
     }
@@ -655,7 +655,7 @@ ECRAD_DEV CloudLayer cloud_layer_fit(const DevConfig& cfg, const LdsLayout& L, i
   }
   if (IS_SW || cfg.do_lw_cloud_scattering) {
     c.od = od_l + od_i;
-    if (IS_SW || sc_l + sc_i > 0.0) c.g = fdiv(g_l * sc_l + g_i * sc_i, sc_l + sc_i);
+    if (IS_SW || sc_l + sc_i > 0.0) c.g = gdiv(g_l * sc_l + g_i * sc_i, sc_l + sc_i);
     c.ssa = fdiv(sc_l + sc_i, od_l + od_i);
   } else {
     c.od = od_l - sc_l + od_i - sc_i;
