@@ -104,7 +104,7 @@ struct ecrad_hip_handle_s {
   hipStream_t stream = nullptr;
   bool own_stream = false;                       // `stream` was created by the pool (contexts other than the root)
   // host-memory mode: copy-in and copy-out streams of the tile pipeline, events per staging slot (see radiation_host_pipelined)
-  hipStream_t in_stream = nullptr, in_stream2 = nullptr, out_stream = nullptr;
+  hipStream_t in_stream = nullptr, in_stream2 = nullptr, out_stream = nullptr, out_stream2 = nullptr;
   hipEvent_t ev_in[kStageSlots] = {nullptr, nullptr, nullptr}, ev_in2[kStageSlots] = {nullptr, nullptr, nullptr}, ev_comp[kStageSlots] = {nullptr, nullptr, nullptr};
   HostBuf pin_in, pin_out;                       // page-locked mirrors of the staged inputs / outputs of a small call
   // The McICA cloud generators need the cropped cloud fraction and nothing else, and are bound by integer instruction
@@ -533,6 +533,7 @@ int setup_ckd(ecrad_hip_handle_t h, const ecrad_ckd_model_t& m, DevCkdModel& d) 
   if (f32) st = upload_as_float(h, all_quads.data(), all_quads.size(), &hot.tab);
   else { const double* p; st = upload<double>(h, all_quads.data(), all_quads.size(), &p); hot.tab = p; }
   if (st) return st;
+  d.std_quads = (layout_is_std_quads(d) && !std::getenv("ECRAD_HIP_GENERIC_QUADS")) ? 1 : 0;
   return ECRAD_OK;
 }
 
@@ -932,6 +933,7 @@ void release_context_memory(ecrad_hip_handle_t h) {
   if (h->in_stream) (void)hipStreamDestroy(h->in_stream);
   if (h->in_stream2) (void)hipStreamDestroy(h->in_stream2);
   if (h->out_stream) (void)hipStreamDestroy(h->out_stream);
+  if (h->out_stream2) (void)hipStreamDestroy(h->out_stream2);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
 }
 
@@ -1778,11 +1780,29 @@ int tile_copy_in(ecrad_hip_handle_t h, Tile& T, hipStream_t st, int part = 0, in
 
 // D2H of the processed column range only: columns outside istartcol..iendcol are not touched.  Returns with the copies
 // enqueued on `st`.
-int tile_copy_out(ecrad_hip_handle_t h, Tile& T, hipStream_t st) {
+// part / nparts: the output arrays dealt out between the copy-out threads of the tile pipeline, by bytes (see copy_inputs)
+int tile_copy_out(ecrad_hip_handle_t h, Tile& T, hipStream_t st, int part = 0, int nparts = 1) {
   if (!T.cx.host_mem) return ECRAD_OK;
   std::vector<OutputRow> rows;
   output_rows(h, T, rows);
-  for (const OutputRow& w : rows) {
+  std::vector<int> part_of(rows.size(), 0);
+  if (nparts > 1) {
+    std::vector<size_t> order(rows.size());
+    for (size_t k = 0; k < rows.size(); ++k) order[k] = k;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+      const size_t ba = rows[a].rows * rows[a].row_bytes, bb = rows[b].rows * rows[b].row_bytes;
+      return ba != bb ? ba > bb : a < b;
+    });
+    size_t load[8] = {0};
+    for (size_t k : order) {
+      int least = 0;
+      for (int q = 1; q < nparts && q < 8; ++q) if (load[q] < load[least]) least = q;
+      part_of[k] = least; load[least] += rows[k].rows * rows[k].row_bytes;
+    }
+  }
+  for (size_t k = 0; k < rows.size(); ++k) {
+    if (part_of[k] != part) continue;
+    const OutputRow& w = rows[k];
     if (w.rows == 1) HIP_TRY(h, hipMemcpyAsync(w.dst, w.src, w.row_bytes, hipMemcpyDeviceToHost, st));
     else HIP_TRY(h, hipMemcpy2DAsync(w.dst, w.dst_pitch, w.src, w.row_bytes, w.row_bytes, w.rows, hipMemcpyDeviceToHost, st));
   }
@@ -2128,6 +2148,7 @@ int ensure_copy_streams(ecrad_hip_handle_t h) {
   if (!h->in_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->in_stream, hipStreamNonBlocking));
   if (!h->in_stream2) HIP_TRY(h, hipStreamCreateWithFlags(&h->in_stream2, hipStreamNonBlocking));
   if (!h->out_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->out_stream, hipStreamNonBlocking));
+  if (!h->out_stream2) HIP_TRY(h, hipStreamCreateWithFlags(&h->out_stream2, hipStreamNonBlocking));
   for (int k = 0; k < kStageSlots; ++k) {
     if (!h->ev_in[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_in[k], hipEventDisableTiming));
     if (!h->ev_in2[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_in2[k], hipEventDisableTiming));
@@ -2226,8 +2247,13 @@ int radiation_host_pipelined(ecrad_hip_handle_t h, int ncol, int nlev, int istar
   };
   std::thread copy_in([&] { copy_in_part(0); });
   std::thread copy_in2([&] { copy_in_part(1); });
-  std::thread copy_out([&] {
+  // (two copy-out threads as well: the runtime moves a device-to-host copy into pageable memory through its page-locked
+  //  buffers on the calling thread -- one thread brought 27 GB/s of the link's 55 back, and the outputs are as many bytes as
+  //  the inputs; a tile is back on the host when both parts are)
+  int out_part_done[2] = {0, 0};
+  auto copy_out_part = [&](int part) {
     (void)hipSetDevice(h->device);
+    hipStream_t st_out = part == 0 ? h->out_stream : h->out_stream2;
     for (int t = 0; t < ntile; ++t) {
       {
         std::unique_lock<std::mutex> lk(m);
@@ -2235,14 +2261,16 @@ int radiation_host_pipelined(ecrad_hip_handle_t h, int ncol, int nlev, int istar
         if (error) return;
       }
       int e = ECRAD_OK;
-      if (hipStreamWaitEvent(h->out_stream, h->ev_comp[tiles[t].slot], 0) != hipSuccess) e = ECRAD_EHIP;
-      if (!e) e = tile_copy_out(h, tiles[t], h->out_stream);
-      if (!e && hipStreamSynchronize(h->out_stream) != hipSuccess) e = ECRAD_EHIP;
+      if (hipStreamWaitEvent(st_out, h->ev_comp[tiles[t].slot], 0) != hipSuccess) e = ECRAD_EHIP;
+      if (!e) e = tile_copy_out(h, tiles[t], st_out, part, 2);
+      if (!e && hipStreamSynchronize(st_out) != hipSuccess) e = ECRAD_EHIP;
       if (e) { set_error(e); return; }
-      { std::lock_guard<std::mutex> lk(m); out_done = t + 1; }
+      { std::lock_guard<std::mutex> lk(m); out_part_done[part] = t + 1; out_done = std::min(out_part_done[0], out_part_done[1]); }
       cv.notify_all();
     }
-  });
+  };
+  std::thread copy_out([&] { copy_out_part(0); });
+  std::thread copy_out2([&] { copy_out_part(1); });
   for (int t = 0; t < ntile; ++t) {
     {
       std::unique_lock<std::mutex> lk(m);
@@ -2261,8 +2289,9 @@ int radiation_host_pipelined(ecrad_hip_handle_t h, int ncol, int nlev, int istar
   copy_in.join();
   copy_in2.join();
   copy_out.join();
+  copy_out2.join();
   if (error) {
-    (void)hipStreamSynchronize(h->in_stream); (void)hipStreamSynchronize(h->in_stream2); (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->out_stream);
+    (void)hipStreamSynchronize(h->in_stream); (void)hipStreamSynchronize(h->in_stream2); (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->out_stream); (void)hipStreamSynchronize(h->out_stream2);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     if (!error_text.empty()) h->err = error_text;
     return error;

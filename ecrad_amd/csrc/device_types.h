@@ -49,7 +49,7 @@ struct GasHot {
 struct DevCkdModel {
   int32_t is_sw, ng, npress, ntemp, ngas, nplanck;
   int32_t table_f32;          // 1: molar_abs / planck tables stored as float (lossless), 0: double
-  int32_t pad_;
+  int32_t std_quads;          // 1: float tables in the standard gas layout -> the kernels with compile-time quad counts (FixedF, optics_device.h)
   double log_pressure1, d_log_pressure, d_temperature;
   double temperature1_planck, d_temperature_planck;
   const double* temperature1;              // (npress)

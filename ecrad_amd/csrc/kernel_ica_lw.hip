@@ -199,9 +199,10 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
       for (int j = 0; j < nl; ++j) {
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
-        const int nq = launder_uniform(nquad);
+        const int nq = quad_count<TAB, false>(nquad), npl = plain_count<TAB, false>(nplain);      // (constants for TAB = FixedF)
+        constexpr int SKIPQ = SkipQuad<TAB, false>::value;
 #if !ECRAD_PIPELINE_LOADS
-        gas_load<TAB>(gh, nq, launder_uniform(nplain), L, slot, g, quads);
+        gas_load<TAB, SKIPQ>(gh, nq, npl, L, slot, g, quads);
 #endif
 #ifdef ECRAD_TIMING
         ECRAD_LAP(tm, 0, quads.q[0].x);   // (timing build: table loads alone, booked under "scalars")
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
         double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
 #endif
         ECRAD_LAP(tm, 1, planck_bot);   // table + Planck loads returned
-        double od = gas_combine<TAB>(nq, L, slot, quads);
+        double od = gas_combine<TAB, SKIPQ>(nq, L, slot, quads);
         double od_scaling_staged = 0.0;
         bool staged = false;
         if constexpr (sizeof(TAB) == 8) {
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
           }
         }
 #if ECRAD_PIPELINE_LOADS
-        if (j + 1 < nl) gas_load<TAB>(gh, nq, launder_uniform(nplain), L, slot + 1, g, quads);
+        if (j + 1 < nl) gas_load<TAB, SKIPQ>(gh, nq, npl, L, slot + 1, g, quads);
 #endif
         ECRAD_LAP(tm, 2, od);           // combine
         if (use_aerosols) {
@@ -667,7 +668,11 @@ hipError_t ECRAD_LW_LAUNCHER(int mode, int ngp, bool table_f32, int grid, size_t
   dim3 g(grid);
   const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot, g0, 0};
 #define ECRAD_DISPATCH(T, N) return wide ? launch_lw_mode<T, N, true>(mode, g, lds, st, args) : launch_lw_mode<T, N, false>(mode, g, lds, st, args)
-  if (table_f32) {
+  if (model_has_std_quads(m)) {
+    if (ngp == 16) ECRAD_DISPATCH(FixedF, 16);
+    if (ngp == 32) ECRAD_DISPATCH(FixedF, 32);
+    ECRAD_DISPATCH(FixedF, 64);
+  } else if (table_f32) {
     if (ngp == 16) ECRAD_DISPATCH(float, 16);
     if (ngp == 32) ECRAD_DISPATCH(float, 32);
     ECRAD_DISPATCH(float, 64);

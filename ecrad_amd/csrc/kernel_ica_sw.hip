@@ -344,15 +344,16 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void s
         for (int j = nl - 1; j >= 0; --j) {
           const int lev = l0 + j;
           const int slot = cib * NGP + j;
-          const int nq = launder_uniform(nquad);
+          const int nq = quad_count<TAB, true>(nquad), npl = plain_count<TAB, true>(nplain);      // (constants for TAB = FixedF)
+          constexpr int SKIPQ = SkipQuad<TAB, true>::value;
           // gas optics: radiation_ecckd_interface.F90:256-281
 #if !ECRAD_PIPELINE_LOADS
-          gas_load<TAB>(gh, nq, launder_uniform(nplain), L, slot, g, quads);
+          gas_load<TAB, SKIPQ>(gh, nq, npl, L, slot, g, quads);
 #endif
           ECRAD_LAP(tm, 1, quads.q[0].x);   // table loads returned
-          double od = gas_combine<TAB>(nq, L, slot, quads);
+          double od = gas_combine<TAB, SKIPQ>(nq, L, slot, quads);
 #if ECRAD_PIPELINE_LOADS
-          if (j > 0) gas_load<TAB>(gh, nq, launder_uniform(nplain), L, slot - 1, g, quads);
+          if (j > 0) gas_load<TAB, SKIPQ>(gh, nq, npl, L, slot - 1, g, quads);
 #endif
           ECRAD_LAP(tm, 2, od);             // combine
           double ssa = L.D(F_SM, slot) * ray_g;       // Rayleigh optical depth
@@ -596,7 +597,11 @@ hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds
   const bool spec = fx.sw_up_band != nullptr;
 #define ECRAD_DISPATCH(T, N) return wide ? (spec ? launch_sw_mode<T, N, true, true>(mode, g, lds, st, args) : launch_sw_mode<T, N, false, true>(mode, g, lds, st, args)) \
                                          : (spec ? launch_sw_mode<T, N, true, false>(mode, g, lds, st, args) : launch_sw_mode<T, N, false, false>(mode, g, lds, st, args))
-  if (table_f32) {
+  if (model_has_std_quads(m)) {
+    if (ngp == 16) ECRAD_DISPATCH(FixedF, 16);
+    if (ngp == 32) ECRAD_DISPATCH(FixedF, 32);
+    ECRAD_DISPATCH(FixedF, 64);
+  } else if (table_f32) {
     if (ngp == 16) ECRAD_DISPATCH(float, 16);
     if (ngp == 32) ECRAD_DISPATCH(float, 32);
     ECRAD_DISPATCH(float, 64);

@@ -107,10 +107,11 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
       for (int j = 0; j < nl; ++j) {
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
-        const int nq = launder_uniform(nquad);
-        gas_load<TAB>(gh, nq, launder_uniform(nplain), L, slot, g, quads);
+        const int nq = quad_count<TAB, false>(nquad);
+        constexpr int SKIPQ = SkipQuad<TAB, false>::value;
+        gas_load<TAB, SKIPQ>(gh, nq, plain_count<TAB, false>(nplain), L, slot, g, quads);
         double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
-        double od = gas_combine<TAB>(nq, L, slot, quads);
+        double od = gas_combine<TAB, SKIPQ>(nq, L, slot, quads);
         if constexpr (sizeof(TAB) == 8) {
           const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
           if (gs.od_lw) {
@@ -322,7 +323,11 @@ hipError_t launch_lw_scat(int mode, int ngp, bool table_f32, int grid, size_t ld
   dim3 g(grid);
   const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot, g0, 0};
 #define ECRAD_DISPATCH(T, N) return wide ? launch_lw_scat_mode<T, N, true>(mode, g, lds, st, args) : launch_lw_scat_mode<T, N, false>(mode, g, lds, st, args)
-  if (table_f32) {
+  if (model_has_std_quads(m)) {
+    if (ngp == 16) ECRAD_DISPATCH(FixedF, 16);
+    if (ngp == 32) ECRAD_DISPATCH(FixedF, 32);
+    ECRAD_DISPATCH(FixedF, 64);
+  } else if (table_f32) {
     if (ngp == 16) ECRAD_DISPATCH(float, 16);
     if (ngp == 32) ECRAD_DISPATCH(float, 32);
     ECRAD_DISPATCH(float, 64);

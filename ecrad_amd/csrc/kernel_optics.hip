@@ -106,8 +106,9 @@ __global__ __launch_bounds__(kBlock, ECRAD_DUMP_MIN_WAVES) void optics_dump_kern
         const DevOptics& out = b.out;
         const DevCkdModel& m = IS_SW ? cfg.gas_sw : cfg.gas_lw;
         const size_t o = g + (size_t)ng * (lev + (size_t)nlev * cloc);
-        gas_load<TAB>(m.hot, launder_uniform(m.hot.nquad), launder_uniform(m.hot.nplain), L, slot, g, quads);
-        double od = gas_combine<TAB>(launder_uniform(m.hot.nquad), L, slot, quads);
+        constexpr int SKIPQ = SkipQuad<TAB, IS_SW>::value;
+        gas_load<TAB, SKIPQ>(m.hot, quad_count<TAB, IS_SW>(m.hot.nquad), plain_count<TAB, IS_SW>(m.hot.nplain), L, slot, g, quads);
+        double od = gas_combine<TAB, SKIPQ>(quad_count<TAB, IS_SW>(m.hot.nquad), L, slot, quads);
         if (IS_SW) {
           double ssa = L.D(F_SM, slot) * m.rayleigh_molar_scat[g];
           od = od + ssa;
@@ -183,8 +184,9 @@ hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, siz
 #define ECRAD_L(T, N, S, O) do { ECRAD_ALLOW_LDS((optics_dump_kernel<T, N, S, O>), lds); hipLaunchKernelGGL((optics_dump_kernel<T, N, S, O>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
 #define ECRAD_N(T, S, O) do { if (ngp == 16) ECRAD_L(T, 16, S, O); else if (ngp == 32) ECRAD_L(T, 32, S, O); else ECRAD_L(T, 64, S, O); } while (0)
 #define ECRAD_O(T, S) do { if (out_f32) ECRAD_N(T, S, float); else ECRAD_N(T, S, double); } while (0)
-  if (is_sw) { if (table_f32) ECRAD_O(float, true); else ECRAD_O(double, true); }
-  else { if (table_f32) ECRAD_O(float, false); else ECRAD_O(double, false); }
+  const bool fixed = model_has_std_quads(is_sw ? cfg.gas_sw : cfg.gas_lw);
+  if (is_sw) { if (fixed) ECRAD_O(FixedF, true); else if (table_f32) ECRAD_O(float, true); else ECRAD_O(double, true); }
+  else { if (fixed) ECRAD_O(FixedF, false); else if (table_f32) ECRAD_O(float, false); else ECRAD_O(double, false); }
 #undef ECRAD_O
 #undef ECRAD_N
 #undef ECRAD_L

@@ -263,8 +263,9 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
         const int slot = cib * NGP + j;
         const bool need_geo = cloudy.test(l) || (l > 0 && cloudy.test(l - 1));
         if (need_geo) feed1.issue(l);      // consumed after the gas and aerosol optics of this layer
-        gas_load<TAB>(gh, launder_uniform(gh.nquad), launder_uniform(gh.nplain), L, slot, g, quads);
-        double od = gas_combine<TAB>(launder_uniform(gh.nquad), L, slot, quads);
+        constexpr int SKIPQ = SkipQuad<TAB, true>::value;
+        gas_load<TAB, SKIPQ>(gh, quad_count<TAB, true>(gh.nquad), plain_count<TAB, true>(gh.nplain), L, slot, g, quads);
+        double od = gas_combine<TAB, SKIPQ>(quad_count<TAB, true>(gh.nquad), L, slot, quads);
         double ssa = L.D(F_SM, slot) * ray_g;
         od = od + ssa;
         ssa = fdiv(ssa, od);
@@ -534,7 +535,8 @@ hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream
                         int* counter, const DevCkdModel& m, int g0) {
   const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot, g0, 0};
 #define ECRAD_L(T, N) do { ECRAD_ALLOW_LDS((sw_tc_kernel<T, N>), lds); hipLaunchKernelGGL((sw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
-  if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
+  if (model_has_std_quads(m)) { if (ngp == 16) ECRAD_L(FixedF, 16); else if (ngp == 32) ECRAD_L(FixedF, 32); else ECRAD_L(FixedF, 64); }
+  else if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
   else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }
 #undef ECRAD_L
   return hipGetLastError();
@@ -677,9 +679,10 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
       for (int j = 0; j < nl; ++j) {
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
-        gas_load<TAB>(gh, launder_uniform(gh.nquad), launder_uniform(gh.nplain), L, slot, g, quads);
+        constexpr int SKIPQ = SkipQuad<TAB, false>::value;
+        gas_load<TAB, SKIPQ>(gh, quad_count<TAB, false>(gh.nquad), plain_count<TAB, false>(gh.nplain), L, slot, g, quads);
         double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
-        double od = gas_combine<TAB>(launder_uniform(gh.nquad), L, slot, quads);
+        double od = gas_combine<TAB, SKIPQ>(quad_count<TAB, false>(gh.nquad), L, slot, quads);
         if constexpr (sizeof(TAB) == 8) {
           const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
           if (gs.od_lw) {
@@ -1083,7 +1086,8 @@ hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream
 #define ECRAD_L2(T, N, A, W) do { ECRAD_ALLOW_LDS((lw_tc_kernel<T, N, A, W>), lds); hipLaunchKernelGGL((lw_tc_kernel<T, N, A, W>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
 #define ECRAD_L(T, N) do { if (cfg.do_lw_aerosol_scattering) { if (wide) ECRAD_L2(T, N, true, true); else ECRAD_L2(T, N, true, false); } \
                            else { if (wide) ECRAD_L2(T, N, false, true); else ECRAD_L2(T, N, false, false); } } while (0)
-  if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
+  if (model_has_std_quads(m)) { if (ngp == 16) ECRAD_L(FixedF, 16); else if (ngp == 32) ECRAD_L(FixedF, 32); else ECRAD_L(FixedF, 64); }
+  else if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
   else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }
 #undef ECRAD_L
 #undef ECRAD_L2

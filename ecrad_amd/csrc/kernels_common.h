@@ -59,6 +59,9 @@ template <typename TAB> constexpr int min_waves_for(int ecckd) { return sizeof(T
 #define ECRAD_LW_PLANCK_AHEAD 0
 #endif
 #endif
+#ifndef ECRAD_SCALARS_AHEAD
+#define ECRAD_SCALARS_AHEAD 1   // level_scalars issues the mixing-ratio loads of the first eight gases before the loop over the gases (optics_device.h)
+#endif
 #ifndef ECRAD_ABLATE
 #define ECRAD_ABLATE 0
 #endif

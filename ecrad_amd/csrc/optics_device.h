@@ -7,6 +7,7 @@
 // broadcast) at compile-time field offsets, so one address register serves the whole record and
 // neighbouring fields merge into 16-byte reads.
 #pragma once
+#include <cstdlib>
 #include "kernels_common.h"
 
 namespace ecrad {
@@ -77,8 +78,29 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
   const int clev = ord.full(lev);                       // this layer in the caller's arrays
   const size_t i0 = col + ncol * clev;
   const size_t ih0 = col + ncol * ord.half(lev), ih1 = col + ncol * ord.half(lev + 1);
+  // Every global load whose address does not depend on another load is issued before the first value is used: the arrays are
+  // column-major (a lane walks down a column with a stride of ncol values), i.e. every load is its own trip to HBM, and the
+  // loop over the gases below -- a switch per gas around one load each -- used to make those trips one after the other
+  // (seven of them per chunk of levels for the longwave model: ~20 000 cycles during which the block's four waves sat at the
+  // barrier; -DECRAD_TIMING: 700 cycles per layer).  Gases beyond the first kGasAhead of a model load theirs in the loop.
+  constexpr int kGasAhead = 8;
   const double p0 = in.pressure_hl[ih0], p1 = in.pressure_hl[ih1];
   const double t0 = in.temperature_hl[ih0], t1 = in.temperature_hl[ih1];
+#if ECRAD_SCALARS_AHEAD
+  double vmr_ahead[kGasAhead];
+#pragma unroll
+  for (int j = 0; j < kGasAhead; ++j) {
+    vmr_ahead[j] = 0.0;
+    if (j < m.ngas && m.gas[j].i_conc_dependence != ECRAD_CONC_NONE)
+      vmr_ahead[j] = in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (m.gas[j].i_gas_code - 1))];
+  }
+#endif
+  double h2o_ahead = 0.0, sat_ahead = 1.0, frac = 0.0;
+  if (cfg.use_aerosols) {
+    h2o_ahead = in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (ECRAD_IH2O - 1))];
+    sat_ahead = in.h2o_sat_liq[i0];
+  }
+  if (want_clouds) { const FracView fv = cloud_fraction_view(in, col); frac = fv.p[fv.stride * clev]; }
   const double temperature_fl = (t0 * p0 + t1 * p1) / (p0 + p1);
   const double log_pressure_fl = log(0.5 * (p0 + p1));
   double pindex1 = (log_pressure_fl - m.log_pressure1) / m.d_log_pressure;
@@ -93,12 +115,10 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
   const double global_multiplier = 1.0 / (kAccelDueToGravity * 0.001 * kAirMolarMass);
   const double simple_multiplier = global_multiplier * (p1 - p0);
   int ic1 = 1;
-  for (int j = 0; j < m.ngas; ++j) {
-    const DevCkdGas& sg = m.gas[j];
+  auto one_gas = [&](const DevCkdGas& sg, double vmr) {
     double mult = simple_multiplier;
     int k = sg.qpos;
     if (sg.i_conc_dependence != ECRAD_CONC_NONE) {
-      const double vmr = in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (sg.i_gas_code - 1))];
       const double scaling = sg.conc_scaling;      // (the products below in the reference's order, :559-562, :574-576, :607, :625)
       if (sg.i_conc_dependence == ECRAD_CONC_LINEAR) mult = simple_multiplier * vmr * scaling;
       else if (sg.i_conc_dependence == ECRAD_CONC_RELATIVE_LINEAR) mult = simple_multiplier * (vmr * scaling - sg.reference_mole_frac);
@@ -115,6 +135,17 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
       }
     }
     L.D(F_QMULT + k, slot) = mult;
+  };
+#if ECRAD_SCALARS_AHEAD
+#pragma unroll
+  for (int j = 0; j < kGasAhead; ++j)
+    if (j < m.ngas) one_gas(m.gas[j], vmr_ahead[j]);
+  for (int j = kGasAhead; j < m.ngas; ++j) {
+#else
+  for (int j = 0; j < m.ngas; ++j) {
+#endif
+    const DevCkdGas& sg = m.gas[j];
+    one_gas(sg, sg.i_conc_dependence != ECRAD_CONC_NONE ? in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (sg.i_gas_code - 1))] : 0.0);
   }
   if (m.hot.pad_pos >= 0) L.D(F_QMULT + m.hot.pad_pos, slot) = 0.0;
 #if ECRAD_FIXED_QUADS
@@ -156,9 +187,9 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
   int irh = 0;
   if (cfg.use_aerosols) {
     // rh = h2o_mmr / h2o_sat_liq with h2o_mmr from gas%get(IH2O, IMassMixingRatio) (radiation_gas.F90:605-612)
-    const double h2o_in = in.gas_mixing_ratio[col + ncol * (clev + (size_t)in.nlev * (ECRAD_IH2O - 1))];
+    const double h2o_in = h2o_ahead;
     const double h2o_mmr = cfg.gas_mmr ? h2o_in : h2o_in * (kH2OMolarMass / kAirMolarMass);
-    const double rh = h2o_mmr / in.h2o_sat_liq[i0];
+    const double rh = h2o_mmr / sat_ahead;
     const DevAerosolOptics& ao = cfg.aerosol;
     if (ao.use_hydrophilic) {      // calc_rh_index, radiation_aerosol_optics_data.F90:640-664
       if (rh > ao.rh_lower[ao.nrh - 1]) irh = ao.nrh;
@@ -166,9 +197,7 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
     }
   }
   L.I(I_RH, slot) = irh;
-  double frac = 0.0;
   if (want_clouds) {
-    { const FracView fv = cloud_fraction_view(in, col); frac = fv.p[fv.stride * clev]; }
     // (a cloud-free layer -- most layers -- needs none of the water contents and radii: the solver kernels read the cloud
     //  fields of cloudy layers only; the stage dump of ecrad_hip_optics wants them everywhere)
     if (frac > 0.0 || cloud_fields_everywhere || cfg.cloud_fraction_threshold <= 0.0)
@@ -209,6 +238,34 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
 template <typename TAB> struct QuadOf;
 template <> struct QuadOf<float> { using type = float4; using pair = float2; };
 template <> struct QuadOf<double> { using type = double4; using pair = double2; };
+// A third table type: float tables whose gases are laid out as in every ecCKD model shipped with the reference (composite, O3,
+// CO2, CH4, N2O [, CFC11, CFC12] as plain quads -- an odd count, padded to even -- then the two slices of the H2O look-up table).
+// The quad counts are then compile-time constants: the level loops lose their ten scalar tests and branches per layer (each
+// `k < nquad` block was a basic block of its own that the scheduler could not move loads or conversions across), and the padding
+// quad -- a table load and nine instructions for a product with zero -- is skipped.  Measured on 100 000 clear-sky columns
+// (gpurun_out/r04_t): sw_ica_kernel 7.93 -> 7.50 ms, lw_ica_kernel 5.74 -> 5.55 ms, and the shortwave kernel stops spilling.
+// Any other model (ecrad_hip_setup accepts up to ten quads in any split) runs the `float` instantiations with run-time counts;
+// ECRAD_HIP_GENERIC_QUADS=1 at set-up forces them (tests/test_hip_parity.py compares the two).
+struct FixedF { float v; };
+static_assert(sizeof(FixedF) == 4, "sizeof(TAB) tells the table types apart");
+template <> struct QuadOf<FixedF> { using type = float4; using pair = float2; };
+template <bool IS_SW> struct StdQuads {
+  static constexpr int nquad = IS_SW ? 8 : 10, nplain = IS_SW ? 6 : 8, pad = nplain - 1;
+};
+template <typename TAB> struct FixedLayout { static constexpr bool value = false; };
+template <> struct FixedLayout<FixedF> { static constexpr bool value = true; };
+// quad counts of a level loop and the quad to skip (-1: none)
+template <typename TAB, bool IS_SW> ECRAD_DEV int quad_count(int nquad) { return FixedLayout<TAB>::value ? StdQuads<IS_SW>::nquad : launder_uniform(nquad); }
+template <typename TAB, bool IS_SW> ECRAD_DEV int plain_count(int nplain) { return FixedLayout<TAB>::value ? StdQuads<IS_SW>::nplain : launder_uniform(nplain); }
+template <typename TAB, bool IS_SW> struct SkipQuad { static constexpr int value = FixedLayout<TAB>::value ? StdQuads<IS_SW>::pad : -1; };
+// (decided once per model by ecrad_hip_setup -> DevCkdModel::std_quads; ECRAD_HIP_GENERIC_QUADS in the environment of the
+//  setup call keeps a handle on the run-time counts)
+inline bool layout_is_std_quads(const DevCkdModel& m) {
+  if (!m.table_f32) return false;
+  return m.is_sw ? (m.hot.nquad == StdQuads<true>::nquad && m.hot.nplain == StdQuads<true>::nplain && m.hot.pad_pos == StdQuads<true>::pad)
+                 : (m.hot.nquad == StdQuads<false>::nquad && m.hot.nplain == StdQuads<false>::nplain && m.hot.pad_pos == StdQuads<false>::pad);
+}
+inline bool model_has_std_quads(const DevCkdModel& m) { return m.std_quads != 0; }
 
 // Registers holding one layer's table quads for one lane, and which cells they were loaded from.
 // Model layers are finer than the table's (p,T) grid, so consecutive layers of a column mostly fall
@@ -231,7 +288,7 @@ struct GasRegs {
 // only the pairs whose cell differs from what `r` holds.  Quads are handled in pairs.
 // `nquad`/`nplain` should be values the compiler cannot hoist tests of out of the level loop (see
 // launder_uniform): otherwise it materialises one 64-bit lane mask per test and runs out of SGPRs.
-template <typename TAB>
+template <typename TAB, int SKIP = -1>
 ECRAD_DEV void gas_load(const GasHot& gh, int nquad, int nplain, const LdsLayout& L, int slot, int g, GasRegs<TAB>& r) {
   using Quad = typename QuadOf<TAB>::type;
   const Quad* __restrict__ tab = reinterpret_cast<const Quad*>(gh.tab);
@@ -258,7 +315,7 @@ ECRAD_DEV void gas_load(const GasHot& gh, int nquad, int nplain, const LdsLayout
 #else
         const unsigned base = is_plain ? plain_g : lut_g;
         r.q[k] = tab[base + gh.qoff[k]];
-        r.q[k + 1] = tab[base + gh.qoff[k + 1]];
+        if (k + 1 != SKIP) r.q[k + 1] = tab[base + gh.qoff[k + 1]];      // (SKIP: the padding quad of a fixed layout)
 #endif
       }
     }
@@ -268,7 +325,7 @@ ECRAD_DEV void gas_load(const GasHot& gh, int nquad, int nplain, const LdsLayout
 }
 
 // Combine the loaded quads into the layer's absorption optical depth.
-template <typename TAB>
+template <typename TAB, int SKIP = -1>
 ECRAD_DEV double gas_combine(int nquad, const LdsLayout& L, int slot, const GasRegs<TAB>& r) {
   const double* rec = L.R(slot);
   const double2 w = *reinterpret_cast<const double2*>(rec + F_PW2);
@@ -281,7 +338,7 @@ ECRAD_DEV double gas_combine(int nquad, const LdsLayout& L, int slot, const GasR
     if (ECRAD_FIXED_QUADS || k < nquad) {
       const double2 qm = *reinterpret_cast<const double2*>(rec + F_QMULT + k);
       od += qm.x * (w00 * r.q[k].x + w10 * r.q[k].y + w01 * r.q[k].z + w11 * r.q[k].w);
-      od += qm.y * (w00 * r.q[k + 1].x + w10 * r.q[k + 1].y + w01 * r.q[k + 1].z + w11 * r.q[k + 1].w);
+      if (k + 1 != SKIP) od += qm.y * (w00 * r.q[k + 1].x + w10 * r.q[k + 1].y + w01 * r.q[k + 1].z + w11 * r.q[k + 1].w);
     }
   }
   return dmax(0.0, od);

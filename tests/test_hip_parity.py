@@ -435,6 +435,35 @@ def test_stage_intermediates_match_oracle(oracle_lib, lw_aerosol_scattering):
     rad.close()
 
 
+def test_compile_time_quad_counts_change_nothing():
+    """Every ecCKD model shipped with the reference has the same gas layout, and the kernels run it with compile-time quad
+    counts and without the padding quad (optics_device.h: FixedF).  ECRAD_HIP_GENERIC_QUADS in the environment of the set-up
+    keeps a handle on the run-time counts every other model would use: the two must agree to the last bits (a product with a
+    zero multiplier left out) for every solver family that evaluates gas optics in its own kernels."""
+    import os
+    from ecrad_amd.interface import Radiation
+    from ecrad_amd.types import Flux
+    for solver in ("Cloudless", "Homogeneous", "Tripleclouds", "McICA", "SPARTACUS"):
+        out = []
+        for generic in (False, True):
+            if generic:
+                os.environ["ECRAD_HIP_GENERIC_QUADS"] = "1"
+            try:
+                config = make_config(solver)
+                rad = Radiation(config, backend="hip")
+            finally:
+                os.environ.pop("ECRAD_HIP_GENERIC_QUADS", None)
+            ncol, nlev, sl, th, gas, cloud, aer = load_meridian(config)
+            rad.set_gas_units(gas)
+            th.calc_saturation_wrt_liquid()
+            flux = Flux.allocate(config, ncol, nlev)
+            rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)
+            rad.close()
+            out.append(flux)
+        worst = compare_flux(out[0], out[1], 1e-12)
+        print(solver, "compile-time vs run-time quad counts:", max(worst.values()))
+
+
 def test_packed_sweep_records_change_nothing_that_matters():
     """The shortwave sweep records travel as five doubles in 32 bytes (39 mantissa bits, rounded to nearest:
     kernels_common.h pack5).  The same sources built with -DECRAD_PACK_SW=0 (tests/_build/variants/nopack, made by
