@@ -60,6 +60,7 @@ struct HostBuf {
   void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
 
+constexpr int kMaxCopyThreads = 4;      // copy-in / copy-out helper threads (and streams) of a pipelined host-memory call, each way
 constexpr int kStageSlots = 3;          // staged inputs / outputs of the column tiles in flight of a pipelined host-memory call
 constexpr int kMaxPoolDevices = 16;
 constexpr int kDefaultContextsPerDevice = 8;
@@ -104,8 +105,8 @@ struct ecrad_hip_handle_s {
   hipStream_t stream = nullptr;
   bool own_stream = false;                       // `stream` was created by the pool (contexts other than the root)
   // host-memory mode: copy-in and copy-out streams of the tile pipeline, events per staging slot (see radiation_host_pipelined)
-  hipStream_t in_stream = nullptr, in_stream2 = nullptr, out_stream = nullptr, out_stream2 = nullptr;
-  hipEvent_t ev_in[kStageSlots] = {nullptr, nullptr, nullptr}, ev_in2[kStageSlots] = {nullptr, nullptr, nullptr}, ev_comp[kStageSlots] = {nullptr, nullptr, nullptr};
+  hipStream_t in_streams[kMaxCopyThreads] = {}, out_streams[kMaxCopyThreads] = {};
+  hipEvent_t ev_in[kMaxCopyThreads][kStageSlots] = {}, ev_comp[kStageSlots] = {nullptr, nullptr, nullptr};
   HostBuf pin_in, pin_out;                       // page-locked mirrors of the staged inputs / outputs of a small call
   // The McICA cloud generators need the cropped cloud fraction and nothing else, and are bound by integer instruction
   // issue: they run on a second stream next to the gas-optics pass (RRTMG) / the other spectrum's solver kernel and
@@ -928,12 +929,12 @@ void release_context_memory(ecrad_hip_handle_t h) {
   for (auto& t : h->tile_events) for (auto& e : t.e) if (e) (void)hipEventDestroy(e);
   h->tile_events.clear();
   for (hipEvent_t e : {h->ev_fork, h->ev_gen_lw, h->ev_gen_sw, h->ev_fork_sw, h->ev_sw_done, h->ev_rrtmg_rec, h->ev_rrtmg_sw}) if (e) (void)hipEventDestroy(e);
-  for (int k = 0; k < kStageSlots; ++k) { if (h->ev_in[k]) (void)hipEventDestroy(h->ev_in[k]); if (h->ev_in2[k]) (void)hipEventDestroy(h->ev_in2[k]); if (h->ev_comp[k]) (void)hipEventDestroy(h->ev_comp[k]); }
+  for (int k = 0; k < kStageSlots; ++k) { for (int q = 0; q < kMaxCopyThreads; ++q) if (h->ev_in[q][k]) (void)hipEventDestroy(h->ev_in[q][k]); if (h->ev_comp[k]) (void)hipEventDestroy(h->ev_comp[k]); }
   if (h->aux_stream) (void)hipStreamDestroy(h->aux_stream);
-  if (h->in_stream) (void)hipStreamDestroy(h->in_stream);
-  if (h->in_stream2) (void)hipStreamDestroy(h->in_stream2);
-  if (h->out_stream) (void)hipStreamDestroy(h->out_stream);
-  if (h->out_stream2) (void)hipStreamDestroy(h->out_stream2);
+  for (int q = 0; q < kMaxCopyThreads; ++q) {
+    if (h->in_streams[q]) (void)hipStreamDestroy(h->in_streams[q]);
+    if (h->out_streams[q]) (void)hipStreamDestroy(h->out_streams[q]);
+  }
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
 }
 
@@ -2145,13 +2146,13 @@ extern "C" {
 namespace {
 
 int ensure_copy_streams(ecrad_hip_handle_t h) {
-  if (!h->in_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->in_stream, hipStreamNonBlocking));
-  if (!h->in_stream2) HIP_TRY(h, hipStreamCreateWithFlags(&h->in_stream2, hipStreamNonBlocking));
-  if (!h->out_stream) HIP_TRY(h, hipStreamCreateWithFlags(&h->out_stream, hipStreamNonBlocking));
-  if (!h->out_stream2) HIP_TRY(h, hipStreamCreateWithFlags(&h->out_stream2, hipStreamNonBlocking));
+  for (int q = 0; q < kMaxCopyThreads; ++q) {
+    if (!h->in_streams[q]) HIP_TRY(h, hipStreamCreateWithFlags(&h->in_streams[q], hipStreamNonBlocking));
+    if (!h->out_streams[q]) HIP_TRY(h, hipStreamCreateWithFlags(&h->out_streams[q], hipStreamNonBlocking));
+  }
   for (int k = 0; k < kStageSlots; ++k) {
-    if (!h->ev_in[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_in[k], hipEventDisableTiming));
-    if (!h->ev_in2[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_in2[k], hipEventDisableTiming));
+    for (int q = 0; q < kMaxCopyThreads; ++q)
+      if (!h->ev_in[q][k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_in[q][k], hipEventDisableTiming));
     if (!h->ev_comp[k]) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_comp[k], hipEventDisableTiming));
   }
   return ECRAD_OK;
@@ -2221,7 +2222,13 @@ int radiation_host_pipelined(ecrad_hip_handle_t h, int ncol, int nlev, int istar
 
   std::mutex m;
   std::condition_variable cv;
-  int in_enqueued[2] = {0, 0}, compute_enqueued = 0, out_done = 0, error = ECRAD_OK;
+  // helper threads each way (ECRAD_HIP_COPY_THREADS="in,out" overrides; at most kMaxCopyThreads)
+  int n_in = 2, n_out = 2;
+  if (const char* e = std::getenv("ECRAD_HIP_COPY_THREADS")) {
+    int a = 0, b = 0;
+    if (std::sscanf(e, "%d,%d", &a, &b) == 2) { n_in = std::min(std::max(a, 1), kMaxCopyThreads); n_out = std::min(std::max(b, 1), kMaxCopyThreads); }
+  }
+  int in_enqueued[kMaxCopyThreads] = {}, out_part_done[kMaxCopyThreads] = {}, compute_enqueued = 0, out_done = 0, error = ECRAD_OK;
   std::string error_text;
   auto set_error = [&](int code) {      // (called with the context's err set by HIP_TRY / fail)
     std::lock_guard<std::mutex> lk(m);
@@ -2231,29 +2238,26 @@ int radiation_host_pipelined(ecrad_hip_handle_t h, int ncol, int nlev, int istar
   // The helper threads report through their own handle-shaped error slot: h->err is written by whichever thread fails first
   auto copy_in_part = [&](int part) {
     (void)hipSetDevice(h->device);
-    hipStream_t st_in = part == 0 ? h->in_stream : h->in_stream2;
+    hipStream_t st_in = h->in_streams[part];
     for (int t = 0; t < ntile; ++t) {
       {
         std::unique_lock<std::mutex> lk(m);
         cv.wait(lk, [&] { return error || out_done >= t - kStageSlots + 1; });      // the slot's previous tile is back on the host
         if (error) return;
       }
-      int e = tile_copy_in(h, tiles[t], st_in, part, 2);
-      if (!e && hipEventRecord((part == 0 ? h->ev_in : h->ev_in2)[tiles[t].slot], st_in) != hipSuccess) e = ECRAD_EHIP;
+      int e = tile_copy_in(h, tiles[t], st_in, part, n_in);
+      if (!e && hipEventRecord(h->ev_in[part][tiles[t].slot], st_in) != hipSuccess) e = ECRAD_EHIP;
       if (e) { set_error(e); return; }
       { std::lock_guard<std::mutex> lk(m); in_enqueued[part] = t + 1; }
       cv.notify_all();
     }
   };
-  std::thread copy_in([&] { copy_in_part(0); });
-  std::thread copy_in2([&] { copy_in_part(1); });
-  // (two copy-out threads as well: the runtime moves a device-to-host copy into pageable memory through its page-locked
+  // (several copy-out threads as well: the runtime moves a device-to-host copy into pageable memory through its page-locked
   //  buffers on the calling thread -- one thread brought 27 GB/s of the link's 55 back, and the outputs are as many bytes as
-  //  the inputs; a tile is back on the host when both parts are)
-  int out_part_done[2] = {0, 0};
+  //  the inputs; a tile is back on the host when every part is)
   auto copy_out_part = [&](int part) {
     (void)hipSetDevice(h->device);
-    hipStream_t st_out = part == 0 ? h->out_stream : h->out_stream2;
+    hipStream_t st_out = h->out_streams[part];
     for (int t = 0; t < ntile; ++t) {
       {
         std::unique_lock<std::mutex> lk(m);
@@ -2262,23 +2266,31 @@ int radiation_host_pipelined(ecrad_hip_handle_t h, int ncol, int nlev, int istar
       }
       int e = ECRAD_OK;
       if (hipStreamWaitEvent(st_out, h->ev_comp[tiles[t].slot], 0) != hipSuccess) e = ECRAD_EHIP;
-      if (!e) e = tile_copy_out(h, tiles[t], st_out, part, 2);
+      if (!e) e = tile_copy_out(h, tiles[t], st_out, part, n_out);
       if (!e && hipStreamSynchronize(st_out) != hipSuccess) e = ECRAD_EHIP;
       if (e) { set_error(e); return; }
-      { std::lock_guard<std::mutex> lk(m); out_part_done[part] = t + 1; out_done = std::min(out_part_done[0], out_part_done[1]); }
+      {
+        std::lock_guard<std::mutex> lk(m);
+        out_part_done[part] = t + 1;
+        int done = out_part_done[0];
+        for (int q = 1; q < n_out; ++q) done = std::min(done, out_part_done[q]);
+        out_done = done;
+      }
       cv.notify_all();
     }
   };
-  std::thread copy_out([&] { copy_out_part(0); });
-  std::thread copy_out2([&] { copy_out_part(1); });
+  std::vector<std::thread> helpers;
+  for (int q = 0; q < n_in; ++q) helpers.emplace_back([&, q] { copy_in_part(q); });
+  for (int q = 0; q < n_out; ++q) helpers.emplace_back([&, q] { copy_out_part(q); });
   for (int t = 0; t < ntile; ++t) {
     {
       std::unique_lock<std::mutex> lk(m);
-      cv.wait(lk, [&] { return error || (in_enqueued[0] > t && in_enqueued[1] > t); });
+      cv.wait(lk, [&] { if (error) return true; for (int q = 0; q < n_in; ++q) if (in_enqueued[q] <= t) return false; return true; });
       if (error) break;
     }
     int e = ECRAD_OK;
-    if (hipStreamWaitEvent(h->stream, h->ev_in[tiles[t].slot], 0) != hipSuccess || hipStreamWaitEvent(h->stream, h->ev_in2[tiles[t].slot], 0) != hipSuccess) e = ECRAD_EHIP;
+    for (int q = 0; q < n_in && !e; ++q)
+      if (hipStreamWaitEvent(h->stream, h->ev_in[q][tiles[t].slot], 0) != hipSuccess) e = ECRAD_EHIP;
     if (!e) e = tile_compute(h, tiles[t]);
     if (!e && hipEventRecord(h->ev_comp[tiles[t].slot], h->stream) != hipSuccess) e = ECRAD_EHIP;
     if (e) { set_error(e); break; }
@@ -2286,12 +2298,10 @@ int radiation_host_pipelined(ecrad_hip_handle_t h, int ncol, int nlev, int istar
     { std::lock_guard<std::mutex> lk(m); compute_enqueued = t + 1; }
     cv.notify_all();
   }
-  copy_in.join();
-  copy_in2.join();
-  copy_out.join();
-  copy_out2.join();
+  for (auto& th : helpers) th.join();
   if (error) {
-    (void)hipStreamSynchronize(h->in_stream); (void)hipStreamSynchronize(h->in_stream2); (void)hipStreamSynchronize(h->stream); (void)hipStreamSynchronize(h->out_stream); (void)hipStreamSynchronize(h->out_stream2);
+    for (int q = 0; q < kMaxCopyThreads; ++q) { (void)hipStreamSynchronize(h->in_streams[q]); (void)hipStreamSynchronize(h->out_streams[q]); }
+    (void)hipStreamSynchronize(h->stream);
     if (h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     if (!error_text.empty()) h->err = error_text;
     return error;

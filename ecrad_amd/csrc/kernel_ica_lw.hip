@@ -344,6 +344,13 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
       constexpr int kLwRing = ECRAD_LW_RING;
       double2 ring[kLwRing];
       double keep_up = 0.0, keep_der = 0.0;
+#if ECRAD_LW_REDUCE
+      // The sums over g of (upward flux, derivative) of the EIGHT half levels of a turn of the ring go through LDS (LevelReduce,
+      // kernels_common.h: the level-record area of the wave's own slots, idle after pass A) instead of one 17-instruction
+      // butterfly per sum: groups of eight half levels that end where a turn of the ring ends.
+      static_assert(kLwRing == 8, "a turn of the ring is a group of LevelReduce<NGP, 2, 8>");
+      const LevelReduce<NGP, 2, 8> rd{lds_wave_area(smem, L.rec2 * 2, tid), tid & 63, glane, (8 - nlev) & 7};
+#endif
 #pragma unroll
       for (int k = 0; k < kLwRing; ++k) ring[k] = s.pair(P_CLR, imax(nlev - 1 - k, 0), tid);
       for (int l0 = nlev - 1; l0 >= 0; l0 -= kLwRing) {
@@ -359,6 +366,22 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
               spec_put(fx.lw_up_band, ng, g, o, fup);
               if (have_clear_out) spec_put(fx.lw_up_clear_band, ng, g, o, fup);
             }
+#if ECRAD_LW_REDUCE
+            rd.put(0, l, valid ? fup : 0.0);
+            if (do_deriv) { deriv = deriv * T; rd.put(1, l, valid ? deriv : 0.0); }
+            if (k == kLwRing - 1 || l == 0) {
+              const double acc = rd.sum();
+              if (col_ok && rd.owner_in(l, l, l0)) {
+                const size_t o = col + ncol * ord.half(rd.level_of(l));
+                if (rd.q_of() == 0) {
+                  fx.lw_up[o] = acc;
+                  if (have_clear_out) fx.lw_up_clear[o] = acc;
+                } else if (do_deriv) {
+                  fx.lw_derivatives[o] = acc;
+                }
+              }
+            }
+#else
             const double su = group_sum<NGP>(valid ? fup : 0.0);
             double sder = 0.0;
             if (do_deriv) { deriv = deriv * T; sder = group_sum<NGP>(valid ? deriv : 0.0); }
@@ -372,9 +395,11 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
                 if (do_deriv) fx.lw_derivatives[o] = keep_der;
               }
             }
+#endif
           }
         }
       }
+      (void)keep_up; (void)keep_der;
     }
 #elif !(ECRAD_ABLATE & 4)
     {
@@ -433,6 +458,10 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
     const bool do_set2 = (MODE == 1) ? (cloudy.any() || !have_clear_out) : (tcc >= cloud_fraction_threshold);
     if (MODE == 2 && lead) fx.cloud_cover_lw[col] = tcc;
     if (!do_set2) continue;
+#if ECRAD_LW_REDUCE
+    // (the clear-sky profile this column blends with below was stored by other lanes of the wave than those that read it back)
+    __threadfence();
+#endif
     if (!cloudy.any()) { ict = nlev; fdn_ctop = fdn_c; }
     const double w = (MODE == 2) ? tcc : 1.0;
     const bool blend = w < 1.0;

@@ -123,12 +123,12 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
   // The sums over g of four half levels at a time go through LDS (LevelReduce, kernels_common.h): rows (up, l mod 4),
   // (diffuse down, l mod 4), (direct beam, l mod 4); the lane that ends up with a row's sum blends and stores it.
 #if ECRAD_SW_RING
-  const LevelReduce<NGP, 3, 0> rd{red, tid & 63, glane};
+  const LevelReduce<NGP, 3, 4> rd{red, tid & 63, glane, 0};
 #else
   // (a batch of two layers ends a group of four half levels when the groups start at half level -1; with batches of four
   //  half level 0 would sit alone in a group that no batch end flushes)
   static_assert(kSwBatch == 2, "a group of four half levels ends with a batch of layers");
-  const LevelReduce<NGP, 3, 3 - (kSwBatch & 3)> rd{red, tid & 63, glane};
+  const LevelReduce<NGP, 3, 4> rd{red, tid & 63, glane, 3 - (kSwBatch & 3)};
 #endif
   auto emit = [&](int l) {
     if (SPEC && sp.up && valid) {        // spectral flux profiles (radiation_homogeneous_sw.F90:299-311)

@@ -49,6 +49,13 @@ template <typename TAB> constexpr int min_waves_for(int ecckd) { return sizeof(T
 // lw_ica_kernel<float,32,1> 6.49-6.53 ms with the double buffer; ring of 4: 5.85, 6: 5.78, 8: 5.82, 12: 5.73, 16: 6.79 -- spills).
 #define ECRAD_LW_RING 8
 #endif
+#ifndef ECRAD_LW_REDUCE
+// 1: the clear-sky longwave upward sweep sums over g through LDS, eight half levels at a time (LevelReduce); 0: a butterfly per sum.
+// Measured (gpurun_out/r04_w): lw_ica_kernel<FixedF,32,1> 5.11-5.17 -> 5.07-5.10 ms per 100 000 clear-sky columns -- the sweep waits
+// for its records, not for the vector unit -- while the McICA kernel, whose cloudy-sky sweeps read the clear-sky profile back and
+// then need a fence (other lanes wrote it), goes 17.5 -> 19.7 ms: off.
+#define ECRAD_LW_REDUCE 0
+#endif
 #ifndef ECRAD_LW_PLANCK_AHEAD
 // 1: the longwave ICA kernels request a layer's Planck table pair one layer ahead of its use.  On for the cloudless / homogeneous
 // instantiations (kernel_ica_lw_clear.hip: lw_ica_kernel<float,32,1> 5.81 -> 5.69 ms per 100 000 columns), off for McICA, whose
@@ -134,7 +141,7 @@ ECRAD_DEV double dmin(double a, double b) { return __builtin_fmin(a, b); }
 // instructions instead of 11).  Those three only act when an operand or the quotient is within a few hundred binades of the
 // ends of the exponent range, and give inf for a zero denominator where this gives NaN: the sites that use fdiv / frcp
 // divide by optical depths, 1 - albedo x reflectance and the like.  Same bits otherwise (tests/test_hip_parity.py:
-// ECRAD_FAST_DIV=0 variant).  Every VALU instruction of these kernels costs the same four cycles per wave, FP64 or not, and
+// the nopack variant is built with ECRAD_FAST_DIV=0).  Every VALU instruction of these kernels costs the same four cycles per wave, FP64 or not, and
 // the shortwave kernels run at ~80 % VALU utilisation (profiles/r03_p_sq.md): instructions are what there is to save.
 #ifndef ECRAD_FAST_DIV
 #define ECRAD_FAST_DIV 1
@@ -150,6 +157,26 @@ ECRAD_DEV double frcp(double b) {
   return __builtin_fma(e, r, r);
 #else
   return 1.0 / b;
+#endif
+}
+// sqrt(x) for 1e-12 <= x < 1e300 (the k exponent of the two-stream routines: the square root of a clamped product of gammas):
+// the compiler's own sequence -- v_rsq_f64, one coupled Newton step on (g, h) = (sqrt x, 1 / (2 sqrt x)) and two corrections of
+// g: correctly rounded -- WITHOUT the scaling of arguments below 2^-767 and the test for zero / infinity around it (10
+// instructions instead of 18).  Same bits as sqrt() in that range (tests/test_hip_parity.py: the nopack variant is built with ECRAD_FAST_DIV=0).
+ECRAD_DEV double fsqrt(double x) {
+#if ECRAD_FAST_DIV
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  double d = __builtin_fma(-g, g, x);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+#else
+  return sqrt(x);
 #endif
 }
 // a / b where the denominator is only known to be > 0 (a scattering optical depth, a sum of them: possibly subnormal or tiny):
@@ -258,22 +285,27 @@ template <typename T> ECRAD_DEV const __attribute__((address_space(1))) T* as_gl
 template <typename T> ECRAD_DEV __attribute__((address_space(1))) T* as_global(T* p) { return (__attribute__((address_space(1))) T*)p; }
 ECRAD_DEV gl_double* to_global(double* p) { return (gl_double*)p; }
 ECRAD_DEV const gl_double* to_global(const double* p) { return (const gl_double*)p; }
-template <int NGP, int NQ, int OFF = 0>
+// NQ quantities x NL half levels per group (NQ NL <= 16 rows; NL a power of two): a sweep with fewer quantities sums more half
+// levels at a time -- one quantity, sixteen half levels: two instructions per half level.  `off` shifts the groups so that a
+// sweep that takes its layers in batches (or from a ring) finishes a group at a fixed place of the batch.
+template <int NGP, int NQ, int NL = 4>
 struct LevelReduce {
-  static_assert(NQ >= 1 && NQ <= 4, "at most 16 rows");
+  static_assert(NQ >= 1 && NQ * NL <= 16 && (NL & (NL - 1)) == 0, "at most 16 rows");
   lds_double* red;        // lds_wave_area() (address space spelled out: through a generic pointer these would be flat_load / flat_store)
   int lane, glane;        // lane of the wave, lane of the column group
-  // groups of four: half levels l with the same (l + OFF) >> 2 (OFF lets a sweep that takes its layers in batches finish a
-  // group at the end of a batch)
-  ECRAD_DEV void put(int q, int l, double v) const { red[(q * 4 + ((l + OFF) & 3)) * kRedStride + lane] = v; }
-  ECRAD_DEV bool complete(int l) const { return ((l + OFF) & 3) == 3; }
+  int off;                // groups: half levels l with the same (l + off) / NL
+  ECRAD_DEV void put(int q, int l, double v) const { red[(q * NL + ((l + off) & (NL - 1))) * kRedStride + lane] = v; }
+  ECRAD_DEV bool complete(int l) const { return ((l + off) & (NL - 1)) == NL - 1; }      // (a sweep towards larger l)
+  ECRAD_DEV bool complete_down(int l) const { return ((l + off) & (NL - 1)) == 0; }      // (a sweep towards smaller l)
   // which (quantity, half level) this lane's sum belongs to, after the values of the group that half level l is in are there
-  ECRAD_DEV int q_of() const { return (glane & 15) >> 2; }
-  ECRAD_DEV int level_of(int l) const { return ((l + OFF) & ~3) - OFF + (glane & 3); }
+  ECRAD_DEV int q_of() const { return (glane & 15) / NL; }
+  ECRAD_DEV int level_of(int l) const { return ((l + off) & ~(NL - 1)) - off + (glane & (NL - 1)); }
   ECRAD_DEV bool owner(int l) const { return glane < 16 && q_of() < NQ && level_of(l) >= 0 && level_of(l) <= l; }
+  // ... of a group that holds the half levels lo .. hi only (the first or last group of a sweep)
+  ECRAD_DEV bool owner_in(int l, int lo, int hi) const { return glane < 16 && q_of() < NQ && level_of(l) >= lo && level_of(l) <= hi; }
   ECRAD_DEV double sum() const {
     wave_sync();
-    const int row = (glane & 15) < 4 * NQ ? (glane & 15) : 0;
+    const int row = (glane & 15) < NL * NQ ? (glane & 15) : 0;
     const lds_double2* src = reinterpret_cast<const lds_double2*>(red + row * kRedStride + (lane - glane) + (glane & ~15));
     double a0 = 0.0, a1 = 0.0;
 #pragma unroll
@@ -315,7 +347,7 @@ ECRAD_DEV SwCoef ref_trans_sw_fused(double mu0, double od, double ssa, double as
   double gamma4 = 1.0 - gamma3;
   double alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
   double alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
-  double k_exponent = sqrt(dmax((gamma1 - gamma2) * (gamma1 + gamma2), 1.0e-12));
+  double k_exponent = fsqrt(dmax((gamma1 - gamma2) * (gamma1 + gamma2), 1.0e-12));
   double exponential = exp(-k_exponent * od);
   double k_mu0 = k_exponent * mu0;
   double one_minus_kmu0_sqr = 1.0 - k_mu0 * k_mu0;
@@ -359,7 +391,7 @@ ECRAD_DEV SwCoef ref_trans_sw_classic(double mu0, double od, double ssa, double 
   double gamma4 = 1.0 - gamma3;
   double alpha1 = gamma1 * gamma4 + gamma2 * gamma3;
   double alpha2 = gamma1 * gamma3 + gamma2 * gamma4;
-  double k_exponent = sqrt(dmax((gamma1 - gamma2) * (gamma1 + gamma2), 1.0e-12));
+  double k_exponent = fsqrt(dmax((gamma1 - gamma2) * (gamma1 + gamma2), 1.0e-12));
   const double eps = 2.220446049250313e-16;
   double mu0_local = mu0;
   if (fabs(1.0 - k_exponent * mu0) < 1000.0 * eps) mu0_local = mu0 * (1.0 - 10.0 * eps);
@@ -396,7 +428,7 @@ ECRAD_DEV LwCoef ref_trans_lw(double od, double ssa, double asymmetry, double pl
   double factor = (kLwDiffusivity * 0.5) * ssa;
   double gamma1 = kLwDiffusivity - factor * (1.0 + asymmetry);
   double gamma2 = factor * (1.0 - asymmetry);
-  double k_exponent = sqrt(dmax((gamma1 - gamma2) * (gamma1 + gamma2), 1.0e-12));
+  double k_exponent = fsqrt(dmax((gamma1 - gamma2) * (gamma1 + gamma2), 1.0e-12));
   if (od > 1.0e-3) {
     double exponential = exp(-k_exponent * od);
     double exponential2 = exponential * exponential;

@@ -466,8 +466,9 @@ def test_compile_time_quad_counts_change_nothing():
 
 def test_packed_sweep_records_change_nothing_that_matters():
     """The shortwave sweep records travel as five doubles in 32 bytes (39 mantissa bits, rounded to nearest:
-    kernels_common.h pack5).  The same sources built with -DECRAD_PACK_SW=0 (tests/_build/variants/nopack, made by
-    __graft_entry__.build()) keep all 53 bits; the two builds must agree to 1e-10 on every flux -- two orders below the
+    kernels_common.h pack5).  The same sources built with -DECRAD_PACK_SW=0 -DECRAD_FAST_DIV=0 (tests/_build/variants/nopack,
+    made by __graft_entry__.build()) keep all 53 bits and use the compiler's own division and square root in place of
+    fdiv / frcp / fsqrt (the same instruction sequences without the range scaling); the two builds must agree to 1e-10 on every flux -- two orders below the
     1e-8 the parity tests demand -- for the homogeneous / McICA kernel and the Tripleclouds kernel."""
     import os
     from ecrad_amd.interface import Radiation

@@ -1,14 +1,13 @@
 #!/bin/bash
-out=gpurun_out/r04_u; mkdir -p $out
+out=gpurun_out/r04_x; mkdir -p $out
 export TMPDIR=/tmp
-timeout 400 bash tools/run_variants.sh --headline-only < /dev/null 2>&1 | tee $out/variants.log
-for w in tripleclouds_ecckd32 mcica_ecckd32 spartacus_ecckd32_sp; do
-  echo "== $w"; ECRAD_VARIANT_PASSES=1 timeout 400 bash tools/run_variants.sh --headline-only --workload $w < /dev/null 2>&1
-done | tee $out/variants_other.log
-timeout 300 python bench.py --steps 5 --no-cpu-baseline --headline-only < /dev/null 2>/dev/null | python -c "
-import sys, json
-for line in sys.stdin:
-    if line.startswith('{'):
-        d = json.loads(line); print(json.dumps(d.get('end_to_end_host'), indent=1)); print(d['value'], d.get('parity'))
-" | tee $out/host.log
-timeout 600 python -m pytest tests/test_hip_parity.py -q -m gpu -x -k "compile_time or packed or golden or stage" < /dev/null 2>&1 | tail -5 | tee $out/tests.log
+for ct in 1,1 2,2 3,3 4,4 2,4 4,2; do
+  echo "== ECRAD_HIP_COPY_THREADS=$ct"
+  ECRAD_HIP_COPY_THREADS=$ct timeout 200 python tools/host_mode_rate.py clear_homogeneous_ecckd32 100000 < /dev/null 2>&1 | tail -3
+done 2>&1 | tee $out/host_threads.log
+for tile in 6144 8192 16384 24576; do
+  echo "== ECRAD_HIP_HOST_TILE=$tile (threads 3,3)"
+  ECRAD_HIP_COPY_THREADS=3,3 ECRAD_HIP_HOST_TILE=$tile timeout 200 python tools/host_mode_rate.py clear_homogeneous_ecckd32 100000 < /dev/null 2>&1 | tail -2
+done 2>&1 | tee $out/host_tiles.log
+echo "== tripleclouds 3,3"; ECRAD_HIP_COPY_THREADS=3,3 timeout 200 python tools/host_mode_rate.py tripleclouds_ecckd32 100000 < /dev/null 2>&1 | tail -2 | tee $out/host_tc.log
+echo "== tripleclouds 2,2"; ECRAD_HIP_COPY_THREADS=2,2 timeout 200 python tools/host_mode_rate.py tripleclouds_ecckd32 100000 < /dev/null 2>&1 | tail -2 | tee -a $out/host_tc.log
