@@ -333,7 +333,7 @@ def measured_traffic(workload, ncol, kernel_prefix):
         # A spectrum wider than 64 g-points runs as launches of DIFFERENT instantiations of the kernel (chunks of 64, 32
         # and 16 lanes): the per-launch figure is the average over the launches the profile saw, weighted by their counts
         tb, nl = d.get("traffic_bytes_per_launch", {}), d.get("launches_profiled", {})
-        names = [k for k in tb if k.startswith(kernel_prefix)]
+        names = [k for k in tb if k.startswith(tuple(kernel_prefix) if isinstance(kernel_prefix, (tuple, list)) else kernel_prefix)]
         if names:
             wsum = sum(nl.get(k, 1) for k in names)
             best = {"bytes_per_launch": sum(tb[k] * nl.get(k, 1) for k in names) / wsum, "source": "profiles/" + os.path.basename(f),
@@ -456,7 +456,8 @@ def roofline_of(w, stage_ms, elapsed_per_step_s):
     # (instantiations over float tables serve the ecCKD models, over double the RRTMG stage arrays: a profile of the
     #  default run holds both, e.g. sw_ica_kernel<float, 32, 1, ...> and sw_ica_kernel<double, 64, 2, ...>)
     is_rrtmg = bool(w.desc.get("rrtmg"))
-    traffic = measured_traffic(w.name, ncol, kernel + ("<double," if is_rrtmg else "<float,"))
+    # (the ecCKD kernels run as their FixedF instantiations -- compile-time quad counts -- for every model shipped so far)
+    traffic = measured_traffic(w.name, ncol, (kernel + "<double,",) if is_rrtmg else (kernel + "<float,", kernel + "<FixedF,"))
     whole = a_all * ncol / elapsed_per_step_s / 1e9
     extra = {}
     if w.desc["sw_solver"] == "SPARTACUS":

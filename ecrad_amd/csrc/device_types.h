@@ -71,6 +71,7 @@ struct DevCloudOptics {
 struct DevAerosolOptics {
   int32_t n_bands_sw, n_bands_lw, n_type_phobic, n_type_philic, nrh, use_hydrophilic, ntype;
   int32_t nactive;             // types that are hydrophobic or hydrophilic (the others are ignored)
+  int32_t nactive4, pad_;      // ... rounded up to a multiple of four: the padding entries of `active` read table row 0 with weight zero
   const double* rh_lower;
   // Tables per spectrum, row-major [row][band] with the band (= lane) fastest: {mass_ext, ssa} pairs and
   // the asymmetry factor; rows [0, n_type_phobic) are the hydrophobic types, then (nrh x n_type_philic)

@@ -9,6 +9,11 @@
 // zero reflectance) and the Hogan & Bozzo derivatives (radiation_lw_derivatives.F90:43,88).
 // With longwave aerosol scattering (do_lw_aerosol_scattering) every layer reflects and these shortcuts
 // do not hold: that configuration runs kernel_lw_scat.hip instead.
+// (the McICA instantiations do not keep a layer's table quads for the next layer -- see kernel_tc.hip: lw_ica_kernel<FixedF,32,2>
+//  17.7 -> 16.9 ms per 100 000 columns, gpurun_out/r04_ad; the cloudless / homogeneous ones, kernel_ica_lw_clear.hip, do)
+#if !defined(ECRAD_LW_TU_CLEAR) && !defined(ECRAD_QUAD_CACHE)
+#define ECRAD_QUAD_CACHE 0
+#endif
 #include "kernels_common.h"
 #include "optics_device.h"
 #include "launch.h"

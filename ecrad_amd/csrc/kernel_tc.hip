@@ -6,6 +6,14 @@
 // tripleclouds_prep_kernel (kernel_prep.hip).  As in the ICA kernels, gas/aerosol/cloud optics and the
 // two-stream coefficients are computed in the same launch; only what the vertical sweeps need later
 // goes through block-private scratch.
+// The table quads of a layer are NOT kept across layers here (ECRAD_QUAD_CACHE, optics_device.h: gas_load): between the gas
+// optics of one layer and the next lie the aerosol and cloud optics and up to three two-stream evaluations, and 28 registers
+// held across all that are 28 registers spilled -- sw_tc_kernel<FixedF,32> 80 -> 37 spilled registers, 24.7 -> 21.4 ms per
+// 100 000 columns, lw_tc_kernel 19.3 -> 18.8 ms (gpurun_out/r04_ad); the cloud-free kernels keep the quads (2.6 layers per
+// table cell: fewer loads, and they have the registers).
+#ifndef ECRAD_QUAD_CACHE
+#define ECRAD_QUAD_CACHE 0
+#endif
 #include "kernels_common.h"
 #include "optics_device.h"
 #include "launch.h"
@@ -25,6 +33,12 @@
 #endif
 #ifndef ECRAD_TC_LW_AER_BATCH
 #define ECRAD_TC_LW_AER_BATCH 12      // aerosol types per batch of table loads in the longwave optics pass
+#endif
+#ifndef ECRAD_TC_REDUCE
+// 1: the shortwave flux sweep sums over g through LDS (LevelReduce<NGP, 6, 2>) instead of six butterflies per half level: 85 fewer
+// vector instructions per layer and sw_tc_kernel 22.1 -> 25.6 ms per 100 000 columns (gpurun_out/r04_aa; the kernel waits for its
+// records, and the different register allocation spills more): off
+#define ECRAD_TC_REDUCE 0
 #endif
 #ifndef ECRAD_TC_MIN_WAVES
 #define ECRAD_TC_MIN_WAVES ECRAD_MIN_WAVES
@@ -375,6 +389,13 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
       if (do_clear) fx.sw_up_toa_clear_g[og] = fup_c;
     }
     LevelSums<NGP, 6> kept;
+#if ECRAD_TC_REDUCE
+    // The six sums over g of a half level go through LDS two half levels at a time (LevelReduce, kernels_common.h: 12 rows in the
+    // level-record area of the wave's own slots, idle during this sweep) instead of six 17-instruction butterflies per half level
+    constexpr int kRedDoubles = 12 * kRedStride + 8;      // (the GeoFeed staging of the wave's column groups follows the rows)
+    lds_double* const red_area = lds_wave_area(smem, L.rec2 * 2, tid);
+    const LevelReduce<NGP, 6, 2> rd{red_area, tid & 63, glane, 1};      // groups (-1, 0), (1, 2), ...: a batch of two layers ends a group
+#endif
     // sums over g of the fluxes at half level hl, kept by lane (hl mod NGP) and written NGP levels at a time
     auto emit = [&](int hl) {
       if (fx.sw_up_band && valid) {     // spectral flux profiles: sums over the regions per g-point (:485-498, :611-625)
@@ -389,6 +410,33 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
           spec_put(fx.sw_dn_direct_clear_band, ng, g, o, mu0 * ddn_c);
         }
       }
+#if ECRAD_TC_REDUCE
+      rd.put(0, hl, valid ? fup[0] + fup[1] + fup[2] : 0.0);
+      rd.put(1, hl, valid ? fdn[0] + fdn[1] + fdn[2] : 0.0);
+      rd.put(2, hl, valid ? ddn[0] + ddn[1] + ddn[2] : 0.0);
+      if (do_clear) {
+        rd.put(3, hl, valid ? fup_c : 0.0);
+        rd.put(4, hl, valid ? fdn_c : 0.0);
+        rd.put(5, hl, valid ? ddn_c : 0.0);
+      }
+      if (rd.complete(hl) || hl == nlev) {
+        const double acc = rd.sum();
+        const double beam = dpp_move<0x102>(acc);      // row_shl:2 -- the direct-beam sum of the same half level, two rows on
+        const int q = rd.q_of();
+        if (col_ok && rd.owner(hl)) {
+          const size_t o = col + ncol * ord.half(rd.level_of(hl));
+          if (q == 0) fx.sw_up[o] = acc;
+          if (q == 1) fx.sw_dn[o] = mu0 * beam + acc;
+          if (q == 2 && fx.sw_dn_direct) fx.sw_dn_direct[o] = mu0 * acc;
+          if (do_clear) {
+            if (q == 3) fx.sw_up_clear[o] = acc;
+            if (q == 4) fx.sw_dn_clear[o] = mu0 * beam + acc;
+            if (q == 5 && fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[o] = mu0 * acc;
+          }
+        }
+      }
+      return;
+#endif
       double sums[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       sums[0] = group_sum<NGP>(valid ? fup[0] + fup[1] + fup[2] : 0.0);
       sums[1] = group_sum<NGP>(valid ? fdn[0] + fdn[1] + fdn[2] : 0.0);
@@ -416,7 +464,12 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
     };
     emit(0);
     GeoFeed<NGP> feed;
+#if ECRAD_TC_REDUCE
+    static_assert(ECRAD_TC_BATCH_S * 23 <= 48, "GeoFeed staging of a column group behind the rows of LevelReduce");
+    feed.init(prep, ncol_loc, nlev, cloc, (double*)(red_area + kRedDoubles + (cib % (64 / NGP)) * 48), glane);
+#else
     feed.init(prep, ncol_loc, nlev, cloc, L.d + (size_t)(cib * NGP) * (L.rec2 * 2), glane);
+#endif
     constexpr int K = ECRAD_TC_BATCH_S;
     for (int l0 = 0; l0 < ((ECRAD_ABLATE & 4) ? 0 : nlev); l0 += K) {
       // records of K layers requested together

@@ -101,6 +101,20 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
     sat_ahead = in.h2o_sat_liq[i0];
   }
   if (want_clouds) { const FracView fv = cloud_fraction_view(in, col); frac = fv.p[fv.stride * clev]; }
+  // (the cloud fields of the first two types as well when they are wanted whatever the fraction: the Tripleclouds and SPARTACUS
+  //  kernels, whose loop over the cloud types otherwise pays a trip to HBM per type)
+  constexpr int kCloudAhead = 2;
+  double mr_ahead[kCloudAhead] = {0.0, 0.0}, re_ahead[kCloudAhead] = {0.0, 0.0};
+  const bool clouds_ahead = ECRAD_CLOUDS_AHEAD && want_clouds && (cloud_fields_everywhere || cfg.cloud_fraction_threshold <= 0.0);
+  if (clouds_ahead) {
+#pragma unroll
+    for (int t = 0; t < kCloudAhead; ++t)
+      if (t < L.nct) {
+        const size_t i3 = i0 + ncol * in.nlev * t;
+        mr_ahead[t] = in.cloud_mixing_ratio[i3];
+        re_ahead[t] = in.cloud_effective_radius[i3];
+      }
+  }
   const double temperature_fl = (t0 * p0 + t1 * p1) / (p0 + p1);
   const double log_pressure_fl = log(0.5 * (p0 + p1));
   double pindex1 = (log_pressure_fl - m.log_pressure1) / m.d_log_pressure;
@@ -204,8 +218,9 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
     for (int t = 0; t < L.nct; ++t) {
       const DevCloudOptics& co = IS_SW ? cfg.cloud_sw[t] : cfg.cloud_lw[t];
       const size_t i3 = i0 + ncol * in.nlev * t;
-      const double mr = in.cloud_mixing_ratio[i3];
-      const double re = in.cloud_effective_radius[i3];
+      double mr, re;
+      if (clouds_ahead && t < kCloudAhead) { mr = t == 0 ? mr_ahead[0] : mr_ahead[1]; re = t == 0 ? re_ahead[0] : re_ahead[1]; }
+      else { mr = in.cloud_mixing_ratio[i3]; re = in.cloud_effective_radius[i3]; }
       double water_path;
       if (cfg.is_homogeneous) water_path = mr * (p1 - p0) * (1.0 / kAccelDueToGravity);
       else water_path = mr * (p1 - p0) * (1.0 / (kAccelDueToGravity * dmax(cfg.cloud_fraction_threshold, frac)));
@@ -503,7 +518,7 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, 
   const int nlev_aer = in.aerosol_iendlev - in.aerosol_istartlev + 1;
   const size_t type_stride = ncol * (size_t)nlev_aer;
   const double* __restrict__ mr0 = in.aerosol_mixing_ratio + col + ncol * (size_t)(jlev - in.aerosol_istartlev);
-  const int n = ao.nactive;
+  const int n = ao.nactive4;      // (whole groups of four types: the padding has weight zero)
   const bool scattering = IS_SW || cfg.do_lw_aerosol_scattering;
   // The mixing ratios are per column: lane k of every 16-lane row of the column group fetches type k (ONE load
   // instruction for all types), multiplies it by the layer mass, and the unrolled type loop broadcasts the product over
@@ -521,7 +536,7 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, 
         for (int u = 0; u < kBatch; ++u) {
           t[u] = 0.0;
           const int k = k0 + u;
-          if (k < kMaxActiveAerosols && k < n) {
+          if (k < kMaxActiveAerosols && (k & ~3) < n) {
             const uint32_t desc = ao.active[k];
             const int row = (int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0);
 #if ECRAD_ABLATE & 16
@@ -533,7 +548,7 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, 
         }
 #pragma unroll
         for (int u = 0; u < kBatch; ++u)
-          if (k0 + u < kMaxActiveAerosols && k0 + u < n) a.od = a.od + row_bcast_k(w_mine, k0 + u) * t[u];
+          if (k0 + u < kMaxActiveAerosols && ((k0 + u) & ~3) < n) a.od = a.od + row_bcast_k(w_mine, k0 + u) * t[u];
       }
     }
     return a;
@@ -555,7 +570,7 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, 
       for (int u = 0; u < kBatch; ++u) {
         t01[u] = make_double2(0.0, 0.0); t2[u] = 0.0;
         const int k = k0 + u;
-        if (k < kMaxActiveAerosols && k < n) {
+        if (k < kMaxActiveAerosols && (k & ~3) < n) {
           const uint32_t desc = ao.active[k];
           const int row = (int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0);
           const size_t o = ib + (size_t)nb * row;
@@ -569,7 +584,7 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, 
       }
 #pragma unroll
       for (int u = 0; u < kBatch; ++u) {
-        if (k0 + u < kMaxActiveAerosols && k0 + u < n) {
+        if (k0 + u < kMaxActiveAerosols && ((k0 + u) & ~3) < n) {
           const double local_od = row_bcast_k(w_mine, k0 + u) * t01[u].x;
           a.od = a.od + local_od;
           a.scat = a.scat + local_od * t01[u].y;

@@ -64,7 +64,9 @@ def write_nc(path: str, dims: dict, variables: dict, attrs: dict | None = None,
 
     Counterpart of radiation_save.F90's use of easy_netcdf for the offline driver's outputs.
     """
-    f = netcdf_file(path, "w", version=1)
+    # (64-bit offsets -- CDF-2, what the reference's easy_netcdf creates for large files -- when the data do not fit CDF-1's 2 GiB)
+    nbytes = sum(np.asarray(spec[1]).size * (8 if double or np.asarray(spec[1]).dtype.kind != "f" else 4) for spec in variables.values())
+    f = netcdf_file(path, "w", version=2 if nbytes > 2**31 - 2**24 else 1)
     for k, v in (attrs or {}).items():
         setattr(f, k, v)
     for d, n in dims.items():

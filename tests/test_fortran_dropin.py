@@ -453,6 +453,54 @@ def test_gpu_dropin_against_the_reference_executable_on_synthetic_ifs_shaped_col
     print(workload, "4096 synthetic columns, GPU drop-in vs reference executable: max", worst)
 
 
+@needs_exe
+@pytest.mark.gpu
+def test_the_dropins_own_timer_at_100000_columns_in_one_call(tmp_path):
+    """The boundary as the reference's offline driver uses it at the size of BASELINE configs[1]: 100 000 synthetic clear-sky
+    columns in a netCDF file, ONE block (nblocksize = 100 000), i.e. one radiation() call on host arrays per repeat -- the
+    drop-in pipelines it over PCIe as column tiles (api.hip: radiation_host_pipelined) -- timed by the driver's own timer
+    (driver/ecrad_driver.F90:387-388: "Time elapsed in radiative transfer").  Printed; the bound asserted is a loose one
+    (half of what one MI355X box gave: 2.1 M columns/s, bench.py end_to_end_host), the number is for the log."""
+    from bench import build_config
+    from ecrad_amd.driver import save_inputs
+    from ecrad_amd.interface import setup_radiation
+    from ecrad_amd.synthetic import make_columns
+    ncol = 100000
+    config, clear_sky, desc = build_config("clear_homogeneous_ecckd32")
+    setup_radiation(config)
+    inputs = make_columns(config, ncol, clear_sky)
+    inp = str(tmp_path / "synthetic100k.nc")
+    save_inputs(inp, config, *inputs[2:])
+    del inputs
+    nam, out = str(tmp_path / "config.nam"), str(tmp_path / "out.nc")
+    env = dict(os.environ, OMP_NUM_THREADS="1", OMP_STACKSIZE="1G")
+
+    def timed(nrepeat):
+        write_namelist(nam, {"sw_solver_name": '"Homogeneous"', "lw_solver_name": '"Homogeneous"', "use_aerosols": "false",
+                             "do_save_spectral_flux": "false"})
+        text = open(nam).read()
+        text = re.sub(r"nblocksize\s*=\s*\d+", f"nblocksize = {ncol}", text)
+        text = re.sub(r"nrepeat\s*=\s*\d+", f"nrepeat = {nrepeat}", text)
+        assert f"nblocksize = {ncol}" in text and f"nrepeat = {nrepeat}" in text
+        open(nam, "w").write(text)
+        p = _run(f"ulimit -s unlimited; exec {EXE} {nam} {inp} {out}", shell=True, capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=1800)
+        assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+        m = re.search(r"Time elapsed in radiative transfer:\s*([0-9.eE+-]+)", p.stdout + p.stderr)
+        assert m, (p.stdout + p.stderr)[-2000:]
+        return float(m.group(1))
+
+    # (the first call of a process allocates the device arrays and touches the freshly allocated flux arrays of the driver for
+    #  the first time: it is timed on its own, the calls after it by the difference between a run of one and a run of five)
+    first, five = timed(1), timed(5)
+    seconds = (five - first) / 4
+    print(f"reference driver + drop-in, {ncol} clear-sky columns in one call, the driver's own timer: first call {first * 1e3:.1f} ms, "
+          f"then {seconds * 1e3:.1f} ms per call -> {ncol / seconds:.0f} columns/s (host arrays, PCIe-inclusive)")
+    assert ncol / seconds > 1.0e6
+    with NcFile(out) as f:
+        up = f.get("flux_up_lw")
+        assert up.shape[0] == ncol and np.isfinite(up).all() and up.min() > 50.0
+
+
 # ---- SPARTACUS with two regions (config%nregions = 2, radiation_config.F90:268) ---------------------------------------------------
 _SP2 = {"sw_solver_name": '"SPARTACUS"', "lw_solver_name": '"SPARTACUS"', "n_regions": "2"}
 TWO_REGION_CASES = {

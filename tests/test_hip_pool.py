@@ -209,6 +209,17 @@ def test_packed_single_tile_and_pipelined_host_calls_give_the_same_bits(solver):
     flat, ntile = run([(1, n)], {"ECRAD_HIP_HOST_TILE": "4096", "ECRAD_HIP_NO_RAMP": "1"})
     assert ntile == 5
     _flux_equal(flat, piped)
+    # (the default pipeline leaves the staging of the caller's pageable arrays to the runtime, api.hip: radiation_host_pipelined;
+    #  ECRAD_HIP_PIPELINE=mirrored moves the tiles through page-locked mirrors of the staged arrays, radiation_host_mirrored)
+    mirrored, ntile = run([(1, n)], {"ECRAD_HIP_HOST_TILE": "4096", "ECRAD_HIP_PIPELINE": "mirrored"})
+    assert ntile == 8
+    _flux_equal(mirrored, piped)
+    for threads in ("1,3", "3,2"):
+        other, ntile = run([(1, n)], {"ECRAD_HIP_HOST_TILE": "4096", "ECRAD_HIP_COPY_THREADS": threads})
+        assert ntile == 8
+        _flux_equal(other, piped)
+        other, ntile = run([(1, n)], {"ECRAD_HIP_HOST_TILE": "4096", "ECRAD_HIP_PIPELINE": "mirrored", "ECRAD_HIP_COPY_THREADS": threads})
+        _flux_equal(other, piped)
     whole, ntile1 = run([(1, n)], {"ECRAD_HIP_NO_PIPELINE": "1"})
     assert ntile1 == 1
     _flux_equal(whole, piped)
