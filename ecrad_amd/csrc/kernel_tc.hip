@@ -20,7 +20,9 @@
 
 // layers per batch of record loads in the longwave sweeps B, C, D
 #ifndef ECRAD_TC_BATCH_B
-#define ECRAD_TC_BATCH_B 3      // (1 -> 2 -> 3: longwave kernel 24.3 -> 23.2 -> 22.7 ms per 100 000 columns, profiles/r03_variants.log)
+// (round 3: 1 -> 2 -> 3: longwave kernel 24.3 -> 23.2 -> 22.7 ms per 100 000 columns, profiles/r03_variants.log; round 4, with
+//  the table quads no longer held across layers: 3 -> 2: 18.4 -> 17.7 ms, gpurun_out/r04_af -- the third layer's records cost spills)
+#define ECRAD_TC_BATCH_B 2
 #endif
 #ifndef ECRAD_TC_BATCH_C
 #define ECRAD_TC_BATCH_C 2
