@@ -883,6 +883,9 @@ def main():
     ap.add_argument("--workload", default="clear_homogeneous_ecckd32", help="headline workload (ecrad_amd/synthetic.py: BENCH_CONFIGS)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the other BASELINE configurations (\"workloads\")")
+    ap.add_argument("--no-host-mode", action="store_true",
+                    help="skip end_to_end_host / small_blocks (the profiling runs: their column tiles and small batches are launches of the "
+                         "same kernels and would enter the per-kernel averages)")
     ap.add_argument("--threads-per-process", type=int, default=0,
                     help="> 0: ONE process whose host threads call radiation() on blocks of host arrays, spread over --gpus devices by the "
                          "library's pool of contexts (host-memory mode, PCIe-inclusive: see pool_mode)")
@@ -943,7 +946,7 @@ def main():
 
     do_cpu = world == 1 and not args.no_cpu_baseline
     head = measure(args.workload, args.ncol, args.steps, args.warmup, rank, local_rank, world, barrier, allreduce_max,
-                   do_cpu, do_host_mode=(world == 1))
+                   do_cpu, do_host_mode=(world == 1 and not args.no_host_mode))
     cfg = head["config"]
     out = {
         "metric": "columns/sec (SW+LW) at 137 lev, " + ("RRTMG 140/112" if cfg["gas_model"] != "ecCKD" else f"ecCKD-{cfg['n_g_sw']}"),
@@ -965,14 +968,14 @@ def main():
             steps = max(2, min(args.steps, 5 if ncol <= 100000 else 3))
             try:
                 r = measure(name, ncol, steps, 1, rank, local_rank, world, barrier, allreduce_max, do_cpu,
-                            do_host_mode=(name == "tripleclouds_ecckd32" and ncol <= CHUNK_COLUMNS))
+                            do_host_mode=(name == "tripleclouds_ecckd32" and ncol <= CHUNK_COLUMNS and not args.no_host_mode))
             except Exception as e:      # an extra workload must not take the headline line down with it
                 r = {"error": f"{type(e).__name__}: {e}"}
             if "parity" in r and not r["parity"]["ok"]:
                 r["value"] = None
                 failed = True
             out["workloads"][name if name not in out["workloads"] else f"{name}_{ncol}"] = r
-    if world == 1 and not args.headline_only and args.workload == "clear_homogeneous_ecckd32":
+    if world == 1 and not args.headline_only and not args.no_host_mode and args.workload == "clear_homogeneous_ecckd32":
         # the boundary as an unchanged blocked caller uses it (blocks of 80 columns, 16 host threads, host arrays)
         out["small_blocks"] = {}
         for name in ("clear_homogeneous_ecckd32", "tripleclouds_ecckd32"):

@@ -8,7 +8,7 @@ TAG=${1:-prof}; shift
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --headline-only $@"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --headline-only --no-host-mode $@"
 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python bench.py $ARGS > $OUT/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch -- python bench.py $ARGS > $OUT/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- python bench.py $ARGS > $OUT/bench_write.log 2>&1

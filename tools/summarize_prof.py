@@ -37,7 +37,10 @@ def main(tag):
     ncol = bench["config"]["columns_per_gpu_per_step"] if bench else 100000
     stats = q(os.path.join(src, "stats", "stats_results.db"),
               "select name, total_calls, total_duration, average, percentage from top_kernels")
-    out += ["## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline`", "",
+    wl = bench["config"]["workload"] if bench else "clear_homogeneous_ecckd32"
+    extra = "" if wl == "clear_homogeneous_ecckd32" else f" --workload {wl} --ncol {ncol}"
+    out += [f"## `rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --headline-only --no-host-mode{extra}`", "",
+            "(`--no-host-mode`: without the PCIe-inclusive measurements, whose column tiles and small batches are launches of the same kernels)", "",
             "| kernel | calls | total (ms) | average (ms) | % |", "|---|---|---|---|---|"]
     for n, c, t, a, p in stats:
         out.append(f"| `{short(n)}` | {c} | {t/1e3:.2f} | {a/1e3:.3f} | {p:.2f} |")
