@@ -573,6 +573,7 @@ int setup_rrtmg(ecrad_hip_handle_t h, const ecrad_config_t& c) {
   Packer pk;
   if (const char* e = build_tables(*c.rrtmg, c.min_gas_od_lw, c.min_gas_od_sw, d, pk)) return fail(h, ECRAD_EINVAL, e);
   int st;
+  pk.tab.resize(pk.tab.size() + 4, 0.0);      // (the gas-optics pass reads table rows four g-points at a time: kernel_rrtmg.hip, kTauG)
   if ((st = upload<double>(h, pk.tab.data(), pk.tab.size(), &d.tab))) return st;
   const char* dev;
   if ((st = upload<char>(h, host.data(), host.size(), &dev))) return st;
@@ -1842,12 +1843,16 @@ int tile_compute(ecrad_hip_handle_t h, Tile& T) {
   // (the SPARTACUS kernels run one block per CU: one wave per SIMD with the whole register file)
   // (the SPARTACUS sweeps run two blocks per CU in single precision, one in double; the list walk one block per CU)
   auto grid_sp = [&](int ngp, bool is_sw) { const int groups = (r.nloc + kBlock / ngp - 1) / (kBlock / ngp); const int m = h->num_cu * spartacus_sweep_blocks_per_cu(sp_single, is_sw); return groups < m ? groups : m; };
-  const int grid_sw = !c.do_sw ? 0 : sw_sp ? grid_sp(h->ngp_sw, true) : grid_for(h, r.nloc, h->ngp_sw, h->hcfg.gas_sw.table_f32);
-  const int grid_lw = !c.do_lw ? 0 : lw_sp ? grid_sp(h->ngp_lw, false) : grid_for(h, r.nloc, h->ngp_lw, h->hcfg.gas_lw.table_f32);
+  const bool lw_scat = c.do_lw && c.do_lw_aerosol_scattering != 0;
+  // blocks per CU as for the float-table kernels (three): also the ICA kernels in stage mode, which have no tables (StageD);
+  // the Tripleclouds and aerosol-scattering kernels run the RRTMG spectra in their double-table instantiations (two)
+  const bool three_sw = h->hcfg.gas_sw.table_f32 || (h->rrtmg_sw && !sw_tc && !sw_sp);
+  const bool three_lw = h->hcfg.gas_lw.table_f32 || (h->rrtmg_lw && !lw_tc && !lw_sp && !lw_scat);
+  const int grid_sw = !c.do_sw ? 0 : sw_sp ? grid_sp(h->ngp_sw, true) : grid_for(h, r.nloc, h->ngp_sw, three_sw);
+  const int grid_lw = !c.do_lw ? 0 : lw_sp ? grid_sp(h->ngp_lw, false) : grid_for(h, r.nloc, h->ngp_lw, three_lw);
   const size_t sp_word = sp_single ? 4 : 8;
   const size_t per_block_sw = !c.do_sw ? 0 : sw_sp ? (spartacus_scratch_words(true, nlev) * sp_word + 7) / 8
                                            : (sw_tc ? sw_tc_scratch_doubles(nlev) : sw_ica_scratch_doubles(c.i_solver_sw, nlev));
-  const bool lw_scat = c.do_lw && c.do_lw_aerosol_scattering != 0;
   const size_t per_block_lw = !c.do_lw ? 0 : lw_sp ? (spartacus_scratch_words(false, nlev) * sp_word + 7) / 8 : (lw_tc ? lw_tc_scratch_doubles(nlev, lw_scat) : lw_scat ? lw_scat_scratch_doubles(nlev) : lw_ica_scratch_doubles(c.i_solver_lw, nlev));
   const size_t need_sw = per_block_sw * grid_sw * 8, need_lw = (per_block_lw * grid_lw * 8 + 255) / 256 * 256;
   // both spectra at once when together they do not fill the GPU (each with its own sweep scratch then)
@@ -2054,7 +2059,7 @@ int tile_compute(ecrad_hip_handle_t h, Tile& T) {
     }
     if (lw_sp) { if ((st = run_spartacus(false))) return st; }
     auto launch_lw = [&](const DevFlux& f, int* counter, int p, bool wide) -> hipError_t {
-      const int ngp = h->plan_lw.ngp[p], g0 = h->plan_lw.g0[p], grid = grid_for(h, r.nloc, ngp, m.table_f32);
+      const int ngp = h->plan_lw.ngp[p], g0 = h->plan_lw.g0[p], grid = grid_for(h, r.nloc, ngp, three_lw);
       if (lw_tc) return launch_lw_tc(ngp, m.table_f32, grid, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
       if (lw_scat) return launch_lw_scat(c.i_solver_lw, ngp, m.table_f32, grid, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
       return launch_lw_ica(c.i_solver_lw, ngp, m.table_f32, grid, lds, stream, h->hcfg, din, f, prep, scratch, per_block_lw, counter, m, g0, wide);
@@ -2116,7 +2121,7 @@ int tile_compute(ecrad_hip_handle_t h, Tile& T) {
         DevFlux dpart = dfx;
         for (int k = 0; k < 6; ++k)
           if (dfx.*(prof[k])) dpart.*(prof[k]) = pbase + plane * ((size_t)k * nch + p);
-        const int ngp = h->plan_sw.ngp[p], g0 = h->plan_sw.g0[p], grid = grid_for(h, r.nloc, ngp, m.table_f32);
+        const int ngp = h->plan_sw.ngp[p], g0 = h->plan_sw.g0[p], grid = grid_for(h, r.nloc, ngp, three_sw);
         if (sw_tc) HIP_TRY(h, launch_sw_tc(ngp, m.table_f32, grid, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, g0));
         else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, ngp, m.table_f32, grid, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, g0, true));
       }

@@ -61,6 +61,15 @@ constexpr int kLwBatch = ECRAD_LW_BATCH;
 #ifndef ECRAD_LW_CLD_V
 #define ECRAD_LW_CLD_V 4      // (2 -> 4: McICA longwave stage 25.2 -> 24.6 ms ecCKD-32, 60.8 -> 58.2 ms RRTMG per 100 000 columns, profiles/r03_variants.log)
 #endif
+#ifndef ECRAD_LW_MERGED
+// McICA: sweeps U, D, then ONE upward sweep W (see W in lw_ica_kernel) instead of B1, U, V, D and the derivative sweep: a sixth fewer
+// bytes through the scratch and SLOWER -- lw stage 59.9 -> 63.9 ms per 100 000 columns with the RRTMG spectra, 16.7 -> 17.1 ms with
+// ecCKD-32 (gpurun_out/r04_bb, profiles/r04_variants.log): the sweeps are paid per instruction and per dependent step, not per byte
+#define ECRAD_LW_MERGED 0
+#endif
+#ifndef ECRAD_LW_W_RING
+#define ECRAD_LW_W_RING 4     // layers of (T, S) pairs W keeps in flight
+#endif
 constexpr int kCldU = ECRAD_LW_CLD_U, kCldD = ECRAD_LW_CLD_D, kCldV = ECRAD_LW_CLD_V;    // (T, S) pairs are 16 B per layer, so the longwave sweep can look further ahead
 
 // Records of one layer for the cloudy-sky sweeps (free functions, not lambdas: the batch arrays must stay in registers)
@@ -89,9 +98,10 @@ template <typename TAB, int NGP, int MODE, bool WIDE>
 __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void lw_ica_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
-  // Stage mode (gas optics from the RRTMG pass): the stage values of kStageBatch layers are requested together and
+  constexpr int kStB = stage_batch_for<TAB>();      // layers of stage values requested together
+  // Stage mode (gas optics from the RRTMG pass): the stage values of kStB layers are requested together and
   // parked in LDS (each lane its own words), so that a layer does not wait for HBM on its own
-  __shared__ double stage_ring[sizeof(TAB) == 8 ? kStageBatch * 3 * kBlock : 1];
+  __shared__ double stage_ring[sizeof(TAB) == 8 ? kStB * 3 * kBlock : 1];
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
   const int glane = tid % NGP, cib = tid / NGP;
@@ -225,12 +235,12 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
         if constexpr (sizeof(TAB) == 8) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
           const DevGasStage& gs = b.in.gs;
-          if (gs.od_lw) {
+          if (IsStage<TAB>::value || gs.od_lw) {
             staged = true;
-            if (j % kStageBatch == 0) {
-              double v[kStageBatch][3];
+            if (j % kStB == 0) {
+              double v[kStB][3];
 #pragma unroll
-              for (int k = 0; k < kStageBatch; ++k) {
+              for (int k = 0; k < kStB; ++k) {
                 const int lv = lev + k < nlev ? lev + k : nlev - 1;
                 v[k][0] = gs.od_lw[g + (size_t)ng * (lv + (size_t)nlev * cloc)];
                 v[k][1] = gs.planck_hl[g + (size_t)ng * (lv + 1 + (size_t)(nlev + 1) * cloc)];
@@ -241,11 +251,11 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
                   v[k][2] = b.prep.od_scaling_lw[g + (size_t)ng * (lv + (size_t)nlev * cloc)];
               }
 #pragma unroll
-              for (int k = 0; k < kStageBatch; ++k)
+              for (int k = 0; k < kStB; ++k)
 #pragma unroll
                 for (int f = 0; f < 3; ++f) stage_ring[(k * 3 + f) * kBlock + tid] = v[k][f];
             }
-            const int k = j % kStageBatch;
+            const int k = j % kStB;
             od = stage_ring[(k * 3 + 0) * kBlock + tid];
             planck_bot = stage_ring[(k * 3 + 1) * kBlock + tid];
             od_scaling_staged = stage_ring[(k * 3 + 2) * kBlock + tid];
@@ -327,8 +337,12 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
     // ---- pass B1: clear-sky upward sweep (+ clear-sky derivatives) --------------------------------
     quads.reset();      // (the table values die here: the sweeps have the registers for their batches of records)
     const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
+    // MERGED (McICA): the cloudy-sky sweeps U and D come first and ONE upward sweep W then carries everything that climbs
+    // from the surface -- see W below; B1, V and the derivative sweep are the cloudless / homogeneous solvers' only
+    constexpr bool MERGED = (MODE == 2) && (ECRAD_LW_MERGED != 0);
     double fup = emission + albedo * fdn_c;
     const double fup_surf_clear = fup;
+    if constexpr (!MERGED) {
     double dsum = group_sum<NGP>(valid ? fup : 0.0);
     double deriv = WIDE ? fup : fup / dsum;
     if (lead) {
@@ -456,13 +470,14 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
       fx.lw_up_toa_g[og] = fup;
       if (have_clear_out) { fx.lw_dn_surf_clear_g[og] = fdn_c; fx.lw_up_toa_clear_g[og] = fup; }
     }
+    }       // !MERGED
     ECRAD_LAP0(tm, 7);                  // clear-sky upward sweep
     if (MODE == 0) continue;
 
     // ---- cloudy-sky calculation ---------------------------------------------------------------------
     const bool do_set2 = (MODE == 1) ? (cloudy.any() || !have_clear_out) : (tcc >= cloud_fraction_threshold);
     if (MODE == 2 && lead) fx.cloud_cover_lw[col] = tcc;
-    if (!do_set2) continue;
+    if constexpr (!MERGED) { if (!do_set2) continue; }
 #if ECRAD_LW_REDUCE
     // (the clear-sky profile this column blends with below was stored by other lanes of the wave than those that read it back)
     __threadfence();
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
     // (albedo, source) below the layer in P_AS, so that   fdn <- a1 fdn + c,   fup = albedo fdn + source
     // (radiation_adding_ica_lw.F90:192-216 with 1/(1 - albedo R) folded into a1 and c)
     double alb = albedo, src = emission;
-    {
+    if (do_set2) {
       // (out-of-range entries of a batch load a clamped layer instead of nothing: every entry is always defined, and
       // no value has to be carried around the column-group loop)
       const int ict_c = ict < nlev ? ict : nlev - 1;
@@ -517,7 +532,8 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
     }
     // flux at cloud top and upward through the clear layers above it
     fup = src + alb * fdn_ctop;
-    {
+    const double fup_top = fup;  // all-sky upward flux at cloud top
+    if constexpr (!MERGED) {
       double keep_up = 0.0;      // lane (l mod NGP) keeps half level l; written NGP half levels at a time
       // entry k of a batch is half level l0 - k; half level ict itself needs no record
       double2 cur[kCldV], nxt[kCldV];
@@ -553,7 +569,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
     const double fup_toa = fup;
     // downward sweep below cloud top
     double fdn = fdn_ctop;
-    {
+    if (do_set2) {
       LevelSums<NGP, 2> kept;
       LwDnRec cur[kCldD], nxt[kCldD];
 #pragma unroll
@@ -581,7 +597,8 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
               const int lv = kept.mine(hl, glane);
               if (col_ok && lv > ict && lv <= hl) {
                 const size_t o = col + ncol * ord.half(lv);
-                fx.lw_up[o] = blend ? w * kept.v[0] + (1.0 - w) * fx.lw_up_clear[o] : kept.v[0];
+                // (MERGED: the cloudy-sky sum; W, which has the clear-sky one, blends -- same lane, same address)
+                fx.lw_up[o] = (blend && !MERGED) ? w * kept.v[0] + (1.0 - w) * fx.lw_up_clear[o] : kept.v[0];
                 fx.lw_dn[o] = blend ? w * kept.v[1] + (1.0 - w) * fx.lw_dn_clear[o] : kept.v[1];
               }
             }
@@ -594,6 +611,102 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
     if (ict == nlev) {   // no cloudy layer at all: surface values come from the clear-sky sweep
       fdn = fdn_c;
       fup = albedo * fdn + emission;
+    }
+    if constexpr (MERGED) {
+      // ---- W: surface -> top of atmosphere, once over the clear-sky (T, S) pairs ------------------------------------
+      // Four recurrences: clear-sky upward flux and derivative (B1 of the other solvers), all-sky derivative (the product
+      // of the transmittances of what each layer IS, a cloudy layer's coming from its (R, T) pair) and, from cloud top
+      // upwards, the all-sky upward flux (the clear-sky recurrence from another starting value, V).  A cloudy column used
+      // to read its pairs three times for these; the double-table instantiations (the RRTMG spectra) run at the bandwidth
+      // of exactly such records.  Half level nlev (no layer below it) goes through the same sums and stores as the others.
+      const bool set2 = do_set2;
+      const bool modify = set2 && tcc < 1.0 - cloud_fraction_threshold;      // modify_lw_derivatives_ica
+      const double wclr = 1.0 - tcc;
+      double* const wide_aux = (WIDE && modify) ? fx.lw_derivatives_aux : nullptr;
+      const double fdn_all = fdn, fup_all = fup;       // all-sky fluxes at the surface (set2 only)
+      double fup_c = fup_surf_clear;
+      double fup_a = 0.0;
+      double dclr = 0.0, dall = 0.0;
+      {
+        const double dsum_c = group_sum<NGP>(valid ? fup_c : 0.0);
+        dclr = WIDE ? fup_c : fup_c / dsum_c;
+        if (set2 && do_deriv) {
+          const double ssurf = group_sum<NGP>(valid ? fup_all : 0.0);
+          dall = WIDE ? fup_all : fup_all / ssurf;
+        }
+      }
+      constexpr int kW = ECRAD_LW_W_RING;
+      double2 ring_c[kW];
+      double ring_t[kW];
+      auto fetch = [&](int lr, double2& c, double& t) {
+        const int l = imax(lr, 0);
+        c = s.pair(P_CLR, l, tid);
+        t = 0.0;
+        if (set2 && cloudy.test(l)) { const double2 rt = s.pair(P_RT2, l, tid); t = rt.y; }
+      };
+#pragma unroll
+      for (int k = 0; k < kW; ++k) fetch(nlev - 1 - k, ring_c[k], ring_t[k]);
+      double keep_c = 0.0, keep_a = 0.0, keep_dc = 0.0, keep_da = 0.0;
+      // sums over g of half level hl, kept by lane (hl mod NGP); NGP half levels stored at a time
+      auto level = [&](int hl) {
+        if (set2 && hl == ict) fup_a = fup_top;
+        if (fx.lw_up_band && valid) {
+          const size_t o = col + ncol * ord.half(hl);
+          if (have_clear_out) spec_put(fx.lw_up_clear_band, ng, g, o, fup_c);
+          if (!set2) spec_put(fx.lw_up_band, ng, g, o, fup_c);
+          else if (hl <= ict) spec_put(fx.lw_up_band, ng, g, o, fup_a);
+        }
+        const double su_c = group_sum<NGP>(valid ? fup_c : 0.0);
+        double su_a = 0.0, sd_c = 0.0, sd_a = 0.0;
+        if (do_deriv) sd_c = group_sum<NGP>(valid ? dclr : 0.0);
+        if (set2) {
+          if (hl <= ict) su_a = group_sum<NGP>(valid ? fup_a : 0.0);
+          if (do_deriv) sd_a = group_sum<NGP>(valid ? dall : 0.0);
+        }
+        if ((hl & (NGP - 1)) == glane) { keep_c = su_c; keep_a = su_a; keep_dc = sd_c; keep_da = sd_a; }
+        if ((hl & (NGP - 1)) == 0) {
+          const int lv = hl + glane;
+          if (col_ok && lv <= nlev) {
+            const size_t o = col + ncol * ord.half(lv);
+            if (have_clear_out) fx.lw_up_clear[o] = keep_c;
+            if (!set2) fx.lw_up[o] = keep_c;
+            else if (lv <= ict) fx.lw_up[o] = blend ? w * keep_a + (1.0 - w) * keep_c : keep_a;
+            else if (blend) fx.lw_up[o] = w * fx.lw_up[o] + (1.0 - w) * keep_c;      // (D's cloudy-sky sum, stored by this lane)
+            if (do_deriv) {
+              if (WIDE) {
+                fx.lw_derivatives[o] = (set2 && !modify) ? keep_da : keep_dc;
+                if (wide_aux) wide_aux[o] = keep_da;
+              } else {
+                const double v = !set2 ? keep_dc : (modify ? (1.0 - wclr) * keep_da + wclr * keep_dc : keep_da);
+                fx.lw_derivatives[o] = lv == nlev ? 1.0 : v;
+              }
+            }
+          }
+        }
+      };
+      level(nlev);
+      for (int l0 = nlev - 1; l0 >= 0; l0 -= kW) {
+#pragma unroll
+        for (int k = 0; k < kW; ++k) {
+          const int l = l0 - k;
+          if (l >= 0) {
+            const double T = ring_c[k].x, S = ring_c[k].y;
+            const double Tall = (set2 && cloudy.test(l)) ? ring_t[k] : T;
+            fetch(l - kW, ring_c[k], ring_t[k]);
+            fup_c = T * fup_c + S;
+            if (do_deriv) { dclr = dclr * T; dall = dall * Tall; }
+            if (set2 && l < ict) fup_a = T * fup_a + S;
+            level(l);
+          }
+        }
+      }
+      if (valid) {
+        const size_t og = g + (size_t)ng * col;
+        fx.lw_dn_surf_g[og] = set2 ? (blend ? w * fdn_all + (1.0 - w) * fdn_c : fdn_all) : fdn_c;
+        fx.lw_up_toa_g[og] = set2 ? (blend ? w * fup_a + (1.0 - w) * fup_c : fup_a) : fup_c;
+        if (have_clear_out) { fx.lw_dn_surf_clear_g[og] = fdn_c; fx.lw_up_toa_clear_g[og] = fup_c; }
+      }
+      continue;
     }
     if (valid) {
       const size_t og = g + (size_t)ng * col;
@@ -702,7 +815,11 @@ hipError_t ECRAD_LW_LAUNCHER(int mode, int ngp, bool table_f32, int grid, size_t
   dim3 g(grid);
   const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot, g0, 0};
 #define ECRAD_DISPATCH(T, N) return wide ? launch_lw_mode<T, N, true>(mode, g, lds, st, args) : launch_lw_mode<T, N, false>(mode, g, lds, st, args)
-  if (model_has_std_quads(m)) {
+  if (in.gs.od_lw) {      // gas optics from the RRTMG pass: the instantiations without tables (StageD, kernels_common.h)
+    if (ngp == 16) ECRAD_DISPATCH(StageD, 16);
+    if (ngp == 32) ECRAD_DISPATCH(StageD, 32);
+    ECRAD_DISPATCH(StageD, 64);
+  } else if (model_has_std_quads(m)) {
     if (ngp == 16) ECRAD_DISPATCH(FixedF, 16);
     if (ngp == 32) ECRAD_DISPATCH(FixedF, 32);
     ECRAD_DISPATCH(FixedF, 64);

@@ -248,8 +248,9 @@ template <typename TAB, int NGP, int MODE, bool SPEC, bool WIDE>
 __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void sw_ica_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
+  constexpr int kStB = stage_batch_for<TAB>();      // layers of stage values requested together
   // Stage mode (gas optics from the RRTMG pass): see kernel_ica_lw.hip
-  __shared__ double stage_ring[sizeof(TAB) == 8 ? kStageBatch * 3 * kBlock : 1];
+  __shared__ double stage_ring[sizeof(TAB) == 8 ? kStB * 3 * kBlock : 1];
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
   const int glane = tid % NGP, cib = tid / NGP;
@@ -356,17 +357,20 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void s
           if (j > 0) gas_load<TAB, SKIPQ>(gh, nq, npl, L, slot - 1, g, quads);
 #endif
           ECRAD_LAP(tm, 2, od);             // combine
-          double ssa = L.D(F_SM, slot) * ray_g;       // Rayleigh optical depth
-          od = od + ssa;
-          ssa = fdiv(ssa, od);
+          double ssa = 0.0;
+          if constexpr (!IsStage<TAB>::value) {
+            ssa = L.D(F_SM, slot) * ray_g;       // Rayleigh optical depth
+            od = od + ssa;
+            ssa = fdiv(ssa, od);
+          }
           double od_scaling_staged = 0.0, asym_staged = 0.0;
           bool staged = false;
           if constexpr (sizeof(TAB) == 8) {
             const SpectralArgs& b = kernarg_block<SpectralArgs>();
             const DevGasStage& gs = b.in.gs;
-            if (gs.od_sw) {
+            if (IsStage<TAB>::value || gs.od_sw) {
               staged = true;
-              constexpr int NV = 4, NB = kStageBatch * 3 / NV;     // od, ssa, od_scaling, g of NB layers
+              constexpr int NV = 4, NB = kStB * 3 / NV;     // od, ssa, od_scaling, g of NB layers
               const int k = (nl - 1 - j) % NB;
               if (k == 0) {       // this layer and the NB-1 above it
                 double v[NB][NV];
@@ -597,7 +601,11 @@ hipError_t launch_sw_ica(int mode, int ngp, bool table_f32, int grid, size_t lds
   const bool spec = fx.sw_up_band != nullptr;
 #define ECRAD_DISPATCH(T, N) return wide ? (spec ? launch_sw_mode<T, N, true, true>(mode, g, lds, st, args) : launch_sw_mode<T, N, false, true>(mode, g, lds, st, args)) \
                                          : (spec ? launch_sw_mode<T, N, true, false>(mode, g, lds, st, args) : launch_sw_mode<T, N, false, false>(mode, g, lds, st, args))
-  if (model_has_std_quads(m)) {
+  if (in.gs.od_sw) {      // gas optics from the RRTMG pass: the instantiations without tables (StageD, kernels_common.h)
+    if (ngp == 16) ECRAD_DISPATCH(StageD, 16);
+    if (ngp == 32) ECRAD_DISPATCH(StageD, 32);
+    ECRAD_DISPATCH(StageD, 64);
+  } else if (model_has_std_quads(m)) {
     if (ngp == 16) ECRAD_DISPATCH(FixedF, 16);
     if (ngp == 32) ECRAD_DISPATCH(FixedF, 32);
     ECRAD_DISPATCH(FixedF, 64);

@@ -116,10 +116,18 @@ constexpr int kTileCols = 64;
 #define ECRAD_TAUMOL_G 2
 #endif
 constexpr int kTauG = ECRAD_TAUMOL_G;
-static_assert(kTauG == 1 || kTauG == 2, "every RRTMG band has an even number of g-points; wider vectors would read past the table rows");
+#ifndef ECRAD_TAUMOL_MIN_WAVES
+#define ECRAD_TAUMOL_MIN_WAVES 1     // waves per SIMD the register allocation of rrtmg_taumol_kernel is held to
+#endif
+static_assert(kTauG == 1 || kTauG == 2 || kTauG == 4, "every RRTMG band has an even number of g-points; with 4 the last vector of a row of 4k+2 values reads two values of what follows it (the packed tables end with padding, rrtmg_device.h: build_tables), which are never stored");
 // nk (<= G) consecutive values; the 16-byte form when the destination allows it (stage arrays: even offsets)
 template <int G> ECRAD_DEV void vstore(double* p, const Vec<G>& v, int nk) {
   if (G == 2 && nk == 2 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) { *reinterpret_cast<double2*>(p) = make_double2(v.v[0], v.v[G - 1]); return; }
+  if (G == 4 && (nk & 1) == 0 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) {      // (every band has an even number of g-points: nk is 2 or 4)
+    reinterpret_cast<double2*>(p)[0] = make_double2(v.v[0], v.v[G > 1 ? 1 : 0]);
+    if (nk == 4) reinterpret_cast<double2*>(p)[1] = make_double2(v.v[G > 2 ? 2 : 0], v.v[G - 1]);
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < G; ++k) if (k < nk) p[k] = v.v[k];
 }
@@ -234,7 +242,7 @@ ECRAD_DEV void aerosol_bands_of_tile(const DevConfig& cfg, int c0, int nloc, con
   }
 }
 
-__global__ __launch_bounds__(kBlock) void rrtmg_taumol_kernel(const DevRrtmg* __restrict__ Tp, const DevConfig* __restrict__ cfgp, DevInputs in,
+__global__ __launch_bounds__(kBlock, ECRAD_TAUMOL_MIN_WAVES) void rrtmg_taumol_kernel(const DevRrtmg* __restrict__ Tp, const DevConfig* __restrict__ cfgp, DevInputs in,
                                                               RrtmgWork w, DevGasStage out, int do_lw, int do_sw) {
   const DevRrtmg& T = *Tp;
   const DevConfig& cfg = *cfgp;

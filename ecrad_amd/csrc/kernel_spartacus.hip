@@ -622,8 +622,13 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
         slab.put(jl, SW_TDIRC, tid, cl.trans_dir_dir); slab.put(jl, SW_TAC, tid, ta_clear); slab.put(jl, SW_TADC, tid, tad_clear);
       }
       if (clr) {
-        slab.put(jl, SW_REFL + 0, tid, refl(0, 0)); slab.put(jl, SW_REFL + 1, tid, tran(0, 0)); slab.put(jl, SW_REFL + 2, tid, tdd(0, 0));
-        slab.put(jl, SW_REFL + 3, tid, tdir(0, 0)); slab.put(jl, SW_REFL + 4, tid, ta(0, 0)); slab.put(jl, SW_REFL + 5, tid, tad(0, 0));
+        // (region 1 of a cloud-free layer that is not listed IS the clear-sky layer: with the clear-sky set stored, its four
+        //  coefficients are not stored a second time -- a third of what a cloud-free level moves through the slab)
+        if (!(do_clear && !listed)) {
+          slab.put(jl, SW_REFL + 0, tid, refl(0, 0)); slab.put(jl, SW_REFL + 1, tid, tran(0, 0)); slab.put(jl, SW_REFL + 2, tid, tdd(0, 0));
+          slab.put(jl, SW_REFL + 3, tid, tdir(0, 0));
+        }
+        slab.put(jl, SW_REFL + 4, tid, ta(0, 0)); slab.put(jl, SW_REFL + 5, tid, tad(0, 0));
       } else {
         slab.put(jl, SW_TA, tid, ta); slab.put(jl, SW_TAD, tid, tad);     // (the layer's own matrices stay in the layer store)
       }
@@ -785,8 +790,11 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
 #pragma unroll
         for (int k = 0; k < 6; ++k) { c6[k] = do_clear ? slab.get(l, SW_REFC + k, tid) : R(0); }
         const bool cl = !cm.test(l);
+        const bool same = do_clear && !c.use_expm_everywhere;      // (the layer coefficients of region 1 are the clear-sky ones)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { r6[k] = cl ? slab.get(l, SW_REFL + k, tid) : R(0); }
+        for (int k = 0; k < 4; ++k) { r6[k] = cl ? (same ? c6[k] : slab.get(l, SW_REFL + k, tid)) : R(0); }
+#pragma unroll
+        for (int k = 4; k < 6; ++k) { r6[k] = cl ? slab.get(l, SW_REFL + k, tid) : R(0); }
       };
 #pragma unroll
       for (int k = 0; k < kSpRing; ++k) fetch_level(k, ring_c[k], ring_r[k]);
@@ -1191,7 +1199,11 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
         slab.put(jl, LW_TAC, tid, ta_clear); slab.put(jl, LW_TSC, tid, ts_clear);
       }
       if (clr) {
-        slab.put(jl, LW_REFL + 0, tid, refl(0, 0)); slab.put(jl, LW_REFL + 1, tid, tran(0, 0)); slab.put(jl, LW_REFL + 2, tid, source_dn.a[0]);
+        // (as in the shortwave: region 1 of an unlisted cloud-free layer is the clear-sky layer -- its fraction is exactly 1 --
+        //  and its three coefficients are stored once)
+        if (!(do_clear && !listed)) {
+          slab.put(jl, LW_REFL + 0, tid, refl(0, 0)); slab.put(jl, LW_REFL + 1, tid, tran(0, 0)); slab.put(jl, LW_REFL + 2, tid, source_dn.a[0]);
+        }
         slab.put(jl, LW_REFL + 3, tid, ta(0, 0)); slab.put(jl, LW_REFL + 4, tid, ts.a[0]);
       } else {
         slab.put(jl, LW_TA, tid, ta); slab.put(jl, LW_TS, tid, ts);       // (the layer's own matrices stay in the layer store)
@@ -1269,8 +1281,11 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
 #pragma unroll
       for (int k = 0; k < 5; ++k) { c5[k] = do_clear ? slab.get(l, LW_REFC + k, tid) : R(0); }
       const bool cl = !cm.test(l);
+      const bool same = do_clear && !c.use_expm_everywhere;
 #pragma unroll
-      for (int k = 0; k < 5; ++k) { r5[k] = cl ? slab.get(l, LW_REFL + k, tid) : R(0); }
+      for (int k = 0; k < 3; ++k) { r5[k] = cl ? (same ? c5[k] : slab.get(l, LW_REFL + k, tid)) : R(0); }
+#pragma unroll
+      for (int k = 3; k < 5; ++k) { r5[k] = cl ? slab.get(l, LW_REFL + k, tid) : R(0); }
     };
 #pragma unroll
     for (int k = 0; k < kSpRing; ++k) fetch_level(k, ring_c[k], ring_r[k]);
@@ -1366,7 +1381,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
         const V3<R> v1 = sp::smul(um, lwd);
         if (cm.test(jl) == false && !c.use_expm_everywhere) {
           // (a clear layer stores its (0,0) transmittance only: the other elements are zero)
-          const R t00 = slab.get(jl, LW_REFL + 1, tid);
+          const R t00 = slab.get(jl, do_clear ? LW_TRAC : LW_REFL + 1, tid);
           lwd.zero();
           lwd.a[0] = t00 * v1.a[0];
         } else {

@@ -30,7 +30,23 @@ constexpr int kStageBatch = ECRAD_STAGE_BATCH;
 #ifndef ECRAD_MIN_WAVES_STAGE
 #define ECRAD_MIN_WAVES_STAGE 2
 #endif
-template <typename TAB> constexpr int min_waves_for(int ecckd) { return sizeof(TAB) == 8 ? ECRAD_MIN_WAVES_STAGE : ecckd; }
+// Round 4: the stage mode of the ICA kernels is a table type of its own, StageD (sizeof 8 like `double`, so that every
+// `sizeof(TAB) == 8` branch of the stage mode applies to it), with NO tables: what made the `double` instantiations need two waves per
+// SIMD was not the stage mode but the 80 registers of table values (ten double4 quads) that a kernel which may also be asked to
+// interpolate double-precision ecCKD tables has to keep -- dead weight for the RRTMG spectra, whose gas optics arrive in the stage
+// arrays.  Without them the kernels fit the 168 registers of three waves per SIMD like the float-table ones.
+struct StageD { double v; };
+template <typename TAB> struct IsStage { static constexpr bool value = false; };
+template <> struct IsStage<StageD> { static constexpr bool value = true; };
+#ifndef ECRAD_MIN_WAVES_STAGED
+#define ECRAD_MIN_WAVES_STAGED 3
+#endif
+// ... and its ring of stage values is three layers deep instead of four: 18 KB + 29 KB of level records per block, three blocks per CU
+#ifndef ECRAD_STAGE_BATCH_STAGED
+#define ECRAD_STAGE_BATCH_STAGED 3
+#endif
+template <typename TAB> constexpr int stage_batch_for() { return IsStage<TAB>::value ? ECRAD_STAGE_BATCH_STAGED : kStageBatch; }
+template <typename TAB> constexpr int min_waves_for(int ecckd) { return IsStage<TAB>::value ? ECRAD_MIN_WAVES_STAGED : sizeof(TAB) == 8 ? ECRAD_MIN_WAVES_STAGE : ecckd; }
 // Tuning / ablation knobs (tools/variants.sh builds and times alternatives; the shipped library uses
 // the defaults).  ECRAD_ABLATE bits give WRONG results and exist only to attribute time:
 //   1 no table loads, 2 no cross-lane sums, 4 no flux sweep, 8 no scratch stores in the optics sweep, 16 sweep records kept in the L2
@@ -278,7 +294,11 @@ ECRAD_DEV double group_sum(double v) {
 // makes the records large enough for 16 rows; rows are padded by 16 bytes so that the 16 rows read together fall in
 // different banks.
 constexpr int kRedStride = 64 + 2;                      // doubles per row (one wave)
-constexpr int kRedRecordDoubles = (16 * kRedStride + 63) / 64;      // per slot, so that 64 slots hold 16 rows
+// rows the widest LevelReduce of the build lays over a wave's records: 3 quantities x 4 half levels (shortwave flux sweep), 6 x 2
+// (Tripleclouds, a measured switch); 2 x 8 only with ECRAD_LW_REDUCE.  (Round 4: it was 16 throughout, which made the records of the
+// RRTMG spectra -- no table quads -- 18 doubles instead of 14 and kept a third block per CU out of the LDS.)
+constexpr int kRedRows = ECRAD_LW_REDUCE ? 16 : 12;
+constexpr int kRedRecordDoubles = (kRedRows * kRedStride + 63) / 64;      // per slot, so that 64 slots hold kRedRows rows
 typedef __attribute__((address_space(3))) double lds_double;
 typedef double dvec2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) dvec2 lds_double2;
@@ -295,7 +315,7 @@ ECRAD_DEV const gl_double* to_global(const double* p) { return (const gl_double*
 // sweep that takes its layers in batches (or from a ring) finishes a group at a fixed place of the batch.
 template <int NGP, int NQ, int NL = 4>
 struct LevelReduce {
-  static_assert(NQ >= 1 && NQ * NL <= 16 && (NL & (NL - 1)) == 0, "at most 16 rows");
+  static_assert(NQ >= 1 && NQ * NL <= kRedRows && (NL & (NL - 1)) == 0, "at most kRedRows rows: lds_record_doubles() makes room for that many");
   lds_double* red;        // lds_wave_area() (address space spelled out: through a generic pointer these would be flat_load / flat_store)
   int lane, glane;        // lane of the wave, lane of the column group
   int off;                // groups: half levels l with the same (l + off) / NL

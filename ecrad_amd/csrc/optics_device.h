@@ -253,6 +253,7 @@ ECRAD_DEV void level_scalars(const DevConfig& cfg, const DevCkdModel& m, const D
 template <typename TAB> struct QuadOf;
 template <> struct QuadOf<float> { using type = float4; using pair = float2; };
 template <> struct QuadOf<double> { using type = double4; using pair = double2; };
+template <> struct QuadOf<StageD> { using type = double4; using pair = double2; };      // (never loaded: see GasRegs<StageD>)
 // A third table type: float tables whose gases are laid out as in every ecCKD model shipped with the reference (composite, O3,
 // CO2, CH4, N2O [, CFC11, CFC12] as plain quads -- an odd count, padded to even -- then the two slices of the H2O look-up table).
 // The quad counts are then compile-time constants: the level loops lose their ten scalar tests and branches per layer (each
@@ -270,8 +271,8 @@ template <bool IS_SW> struct StdQuads {
 template <typename TAB> struct FixedLayout { static constexpr bool value = false; };
 template <> struct FixedLayout<FixedF> { static constexpr bool value = true; };
 // quad counts of a level loop and the quad to skip (-1: none)
-template <typename TAB, bool IS_SW> ECRAD_DEV int quad_count(int nquad) { return FixedLayout<TAB>::value ? StdQuads<IS_SW>::nquad : launder_uniform(nquad); }
-template <typename TAB, bool IS_SW> ECRAD_DEV int plain_count(int nplain) { return FixedLayout<TAB>::value ? StdQuads<IS_SW>::nplain : launder_uniform(nplain); }
+template <typename TAB, bool IS_SW> ECRAD_DEV int quad_count(int nquad) { return IsStage<TAB>::value ? 0 : FixedLayout<TAB>::value ? StdQuads<IS_SW>::nquad : launder_uniform(nquad); }
+template <typename TAB, bool IS_SW> ECRAD_DEV int plain_count(int nplain) { return IsStage<TAB>::value ? 0 : FixedLayout<TAB>::value ? StdQuads<IS_SW>::nplain : launder_uniform(nplain); }
 template <typename TAB, bool IS_SW> struct SkipQuad { static constexpr int value = FixedLayout<TAB>::value ? StdQuads<IS_SW>::pad : -1; };
 // (decided once per model by ecrad_hip_setup -> DevCkdModel::std_quads; ECRAD_HIP_GENERIC_QUADS in the environment of the
 //  setup call keeps a handle on the run-time counts)
@@ -299,12 +300,21 @@ struct GasRegs {
   }
 };
 
+// stage mode: no tables, no registers for them
+template <>
+struct GasRegs<StageD> {
+  struct { double x; } q[1];
+  ECRAD_DEV void invalidate() {}
+  ECRAD_DEV void reset() {}
+};
+
 // Lane = g.  Bring the table quads of one layer into `r` (radiation_ecckd.F90:549-640), re-loading
 // only the pairs whose cell differs from what `r` holds.  Quads are handled in pairs.
 // `nquad`/`nplain` should be values the compiler cannot hoist tests of out of the level loop (see
 // launder_uniform): otherwise it materialises one 64-bit lane mask per test and runs out of SGPRs.
 template <typename TAB, int SKIP = -1>
 ECRAD_DEV void gas_load(const GasHot& gh, int nquad, int nplain, const LdsLayout& L, int slot, int g, GasRegs<TAB>& r) {
+  if constexpr (IsStage<TAB>::value) return; else {
   using Quad = typename QuadOf<TAB>::type;
   const Quad* __restrict__ tab = reinterpret_cast<const Quad*>(gh.tab);
   const int2 key = *reinterpret_cast<const int2*>(reinterpret_cast<const int*>(L.R(slot)) + I_CELL);   // {cell, lut}
@@ -337,11 +347,13 @@ ECRAD_DEV void gas_load(const GasHot& gh, int nquad, int nplain, const LdsLayout
   }
   r.cell = key.x;
   r.lut = key.y;
+  }
 }
 
 // Combine the loaded quads into the layer's absorption optical depth.
 template <typename TAB, int SKIP = -1>
 ECRAD_DEV double gas_combine(int nquad, const LdsLayout& L, int slot, const GasRegs<TAB>& r) {
+  if constexpr (IsStage<TAB>::value) return 0.0; else {
   const double* rec = L.R(slot);
   const double2 w = *reinterpret_cast<const double2*>(rec + F_PW2);
   const double pw2 = w.x, pw1 = 1.0 - pw2;
@@ -357,6 +369,7 @@ ECRAD_DEV double gas_combine(int nquad, const LdsLayout& L, int slot, const GasR
     }
   }
   return dmax(0.0, od);
+  }
 }
 
 template <typename TAB>
@@ -370,6 +383,7 @@ ECRAD_DEV double gas_absorption_od(const GasHot& gh, const LdsLayout& L, int slo
 // calc_planck_function (radiation_ecckd.F90:900-928) at position (it, w2) prepared by level_scalars
 template <typename TAB>
 ECRAD_DEV double planck_lookup(const DevCkdModel& m, int it, double w2, int g) {
+  if constexpr (IsStage<TAB>::value) return 0.0;      // (the Planck function of the RRTMG spectra comes in the stage arrays)
   using Pair = typename QuadOf<TAB>::pair;
   const Pair* __restrict__ pf = reinterpret_cast<const Pair*>(m.planck_function);
   if (it >= 0) {
@@ -385,6 +399,7 @@ struct PlanckTab {
   const void* table;
   int ng;
   ECRAD_DEV double lookup(int it, double w2, int g) const {
+    if constexpr (IsStage<TAB>::value) return 0.0;
     using Pair = typename QuadOf<TAB>::pair;
     const Pair* __restrict__ pf = reinterpret_cast<const Pair*>(table);
     if (it >= 0) {
@@ -397,10 +412,12 @@ struct PlanckTab {
   // (the first pair below the table), value() interpolates -- the same expressions as lookup()
   typedef typename QuadOf<TAB>::pair Pair;
   ECRAD_DEV Pair fetch(int it, int g) const {
+    if constexpr (IsStage<TAB>::value) return Pair{};
     const Pair* __restrict__ pf = reinterpret_cast<const Pair*>(table);
     return pf[g + ng * (it >= 0 ? it : 0)];
   }
   static ECRAD_DEV double value(const Pair& p, int it, double w2) {
+    if constexpr (IsStage<TAB>::value) return 0.0;
     if (it >= 0) return (1.0 - w2) * p.x + w2 * p.y;
     return (double)p.x * w2;
   }
