@@ -282,14 +282,17 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
         constexpr int SKIPQ = SkipQuad<TAB, true>::value;
         gas_load<TAB, SKIPQ>(gh, quad_count<TAB, true>(gh.nquad), plain_count<TAB, true>(gh.nplain), L, slot, g, quads);
         double od = gas_combine<TAB, SKIPQ>(quad_count<TAB, true>(gh.nquad), L, slot, quads);
-        double ssa = L.D(F_SM, slot) * ray_g;
-        od = od + ssa;
-        ssa = fdiv(ssa, od);
+        double ssa = 0.0;
+        if constexpr (!IsStage<TAB>::value) {
+          ssa = L.D(F_SM, slot) * ray_g;
+          od = od + ssa;
+          ssa = fdiv(ssa, od);
+        }
         double asym = 0.0;
         bool folded = false;
         if constexpr (sizeof(TAB) == 8) {
           const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
-          if (gs.od_sw) {
+          if (IsStage<TAB>::value || gs.od_sw) {
             const size_t o = g + (size_t)ng * (l + (size_t)nlev * cloc);
             od = gs.od_sw[o];
             ssa = gs.ssa_sw[o];
@@ -590,7 +593,8 @@ hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream
                         int* counter, const DevCkdModel& m, int g0) {
   const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot, g0, 0};
 #define ECRAD_L(T, N) do { ECRAD_ALLOW_LDS((sw_tc_kernel<T, N>), lds); hipLaunchKernelGGL((sw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
-  if (model_has_std_quads(m)) { if (ngp == 16) ECRAD_L(FixedF, 16); else if (ngp == 32) ECRAD_L(FixedF, 32); else ECRAD_L(FixedF, 64); }
+  if (in.gs.od_sw) { if (ngp == 16) ECRAD_L(StageD, 16); else if (ngp == 32) ECRAD_L(StageD, 32); else ECRAD_L(StageD, 64); }      // (RRTMG spectra: no tables, kernels_common.h)
+  else if (model_has_std_quads(m)) { if (ngp == 16) ECRAD_L(FixedF, 16); else if (ngp == 32) ECRAD_L(FixedF, 32); else ECRAD_L(FixedF, 64); }
   else if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
   else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }
 #undef ECRAD_L
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
         double od = gas_combine<TAB, SKIPQ>(quad_count<TAB, false>(gh.nquad), L, slot, quads);
         if constexpr (sizeof(TAB) == 8) {
           const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
-          if (gs.od_lw) {
+          if (IsStage<TAB>::value || gs.od_lw) {
             od = gs.od_lw[g + (size_t)ng * (lev + (size_t)nlev * cloc)];
             planck_bot = gs.planck_hl[g + (size_t)ng * (lev + 1 + (size_t)(nlev + 1) * cloc)];
           }
@@ -1141,7 +1145,8 @@ hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream
 #define ECRAD_L2(T, N, A, W) do { ECRAD_ALLOW_LDS((lw_tc_kernel<T, N, A, W>), lds); hipLaunchKernelGGL((lw_tc_kernel<T, N, A, W>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
 #define ECRAD_L(T, N) do { if (cfg.do_lw_aerosol_scattering) { if (wide) ECRAD_L2(T, N, true, true); else ECRAD_L2(T, N, true, false); } \
                            else { if (wide) ECRAD_L2(T, N, false, true); else ECRAD_L2(T, N, false, false); } } while (0)
-  if (model_has_std_quads(m)) { if (ngp == 16) ECRAD_L(FixedF, 16); else if (ngp == 32) ECRAD_L(FixedF, 32); else ECRAD_L(FixedF, 64); }
+  if (in.gs.od_lw) { if (ngp == 16) ECRAD_L(StageD, 16); else if (ngp == 32) ECRAD_L(StageD, 32); else ECRAD_L(StageD, 64); }      // (RRTMG spectra: no tables, kernels_common.h)
+  else if (model_has_std_quads(m)) { if (ngp == 16) ECRAD_L(FixedF, 16); else if (ngp == 32) ECRAD_L(FixedF, 32); else ECRAD_L(FixedF, 64); }
   else if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
   else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }
 #undef ECRAD_L
