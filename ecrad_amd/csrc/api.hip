@@ -1844,10 +1844,9 @@ int tile_compute(ecrad_hip_handle_t h, Tile& T) {
   // (the SPARTACUS sweeps run two blocks per CU in single precision, one in double; the list walk one block per CU)
   auto grid_sp = [&](int ngp, bool is_sw) { const int groups = (r.nloc + kBlock / ngp - 1) / (kBlock / ngp); const int m = h->num_cu * spartacus_sweep_blocks_per_cu(sp_single, is_sw); return groups < m ? groups : m; };
   const bool lw_scat = c.do_lw && c.do_lw_aerosol_scattering != 0;
-  // blocks per CU as for the float-table kernels (three): also the ICA kernels in stage mode, which have no tables (StageD);
-  // the McICA / homogeneous kernels with longwave aerosol scattering (kernel_lw_scat.hip) run the RRTMG spectra in their double-table instantiations (two)
+  // blocks per CU as for the float-table kernels (three): also the kernels in stage mode, which have no tables (StageD)
   const bool three_sw = h->hcfg.gas_sw.table_f32 || (h->rrtmg_sw && !sw_sp);
-  const bool three_lw = h->hcfg.gas_lw.table_f32 || (h->rrtmg_lw && !lw_sp && (lw_tc || !lw_scat));
+  const bool three_lw = h->hcfg.gas_lw.table_f32 || (h->rrtmg_lw && !lw_sp);
   const int grid_sw = !c.do_sw ? 0 : sw_sp ? grid_sp(h->ngp_sw, true) : grid_for(h, r.nloc, h->ngp_sw, three_sw);
   const int grid_lw = !c.do_lw ? 0 : lw_sp ? grid_sp(h->ngp_lw, false) : grid_for(h, r.nloc, h->ngp_lw, three_lw);
   const size_t sp_word = sp_single ? 4 : 8;

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
         double od = gas_combine<TAB, SKIPQ>(nq, L, slot, quads);
         if constexpr (sizeof(TAB) == 8) {
           const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
-          if (gs.od_lw) {
+          if (IsStage<TAB>::value || gs.od_lw) {
             od = gs.od_lw[g + (size_t)ng * (lev + (size_t)nlev * cloc)];
             planck_bot = gs.planck_hl[g + (size_t)ng * (lev + 1 + (size_t)(nlev + 1) * cloc)];
           }
@@ -323,7 +323,11 @@ hipError_t launch_lw_scat(int mode, int ngp, bool table_f32, int grid, size_t ld
   dim3 g(grid);
   const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot, g0, 0};
 #define ECRAD_DISPATCH(T, N) return wide ? launch_lw_scat_mode<T, N, true>(mode, g, lds, st, args) : launch_lw_scat_mode<T, N, false>(mode, g, lds, st, args)
-  if (model_has_std_quads(m)) {
+  if (in.gs.od_lw) {      // RRTMG spectra: the instantiations without tables (StageD, kernels_common.h)
+    if (ngp == 16) ECRAD_DISPATCH(StageD, 16);
+    if (ngp == 32) ECRAD_DISPATCH(StageD, 32);
+    ECRAD_DISPATCH(StageD, 64);
+  } else if (model_has_std_quads(m)) {
     if (ngp == 16) ECRAD_DISPATCH(FixedF, 16);
     if (ngp == 32) ECRAD_DISPATCH(FixedF, 32);
     ECRAD_DISPATCH(FixedF, 64);

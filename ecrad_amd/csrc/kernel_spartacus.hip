@@ -1436,8 +1436,17 @@ __global__ void spartacus_list_kernel(DevInputs in, int list_all, uint32_t* __re
 }
 
 // lane = g-point, 256/NGP listed layers per block; one wave per SIMD (the 9x9 exponential wants the whole register file)
+// (single precision: the longwave's 6x6 exponential needs 276 of the 512 registers of a lane -- ECRAD_SP_LAYERS_WAVES_LW = 2 holds it
+//  to 256 so that two waves share a SIMD; the shortwave's 9x9 needs 326)
+#ifndef ECRAD_SP_LAYERS_WAVES_LW
+#define ECRAD_SP_LAYERS_WAVES_LW 1
+#endif
+#ifndef ECRAD_SP_LAYERS_WAVES_SW
+#define ECRAD_SP_LAYERS_WAVES_SW 1
+#endif
+template <typename R, bool IS_SW> constexpr int sp_layers_waves() { return sizeof(R) == 8 ? 1 : (IS_SW ? ECRAD_SP_LAYERS_WAVES_SW : ECRAD_SP_LAYERS_WAVES_LW); }
 template <typename R, int NGP, bool IS_SW>
-__global__ __launch_bounds__(kBlock, 1) void spartacus_layers_kernel(SpArgs args_in_kernarg) {
+__global__ __launch_bounds__(kBlock, (sp_layers_waves<R, IS_SW>())) void spartacus_layers_kernel(SpArgs args_in_kernarg) {
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
   const int glane = tid % NGP, cib = tid / NGP;
@@ -1530,10 +1539,10 @@ hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, int grid
   s.g0 = g0; s.ngl = std::min(ngp, s.ng - g0); s.wide = wide ? 1 : 0;
   a.in = in; a.op = op; a.prep = prep; a.fx = fx; a.scratch = scratch; a.per_block = per_block_words; a.counter = counter;
   a.lay = lay; a.list = list; a.item_of = item_of; a.n_items = n_items;
-  const dim3 g(grid), gl(grid_layers), b(kBlock);
-#define ECRAD_SP(R, N) do { if (is_sw) { hipLaunchKernelGGL((spartacus_layers_kernel<R, N, true>), gl, b, 0, st, a);      \
+  const dim3 g(grid), b(kBlock);
+#define ECRAD_SP(R, N) do { if (is_sw) { hipLaunchKernelGGL((spartacus_layers_kernel<R, N, true>), dim3(grid_layers * sp_layers_waves<R, true>()), b, 0, st, a);      \
                                          hipLaunchKernelGGL((spartacus_sw_kernel<R, N>), g, b, 0, st, a); }                  \
-                            else { hipLaunchKernelGGL((spartacus_layers_kernel<R, N, false>), gl, b, 0, st, a);             \
+                            else { hipLaunchKernelGGL((spartacus_layers_kernel<R, N, false>), dim3(grid_layers * sp_layers_waves<R, false>()), b, 0, st, a);             \
                                    hipLaunchKernelGGL((spartacus_lw_kernel<R, N>), g, b, 0, st, a); } } while (0)
   if (single) { if (ngp == 16) ECRAD_SP(float, 16); else if (ngp == 32) ECRAD_SP(float, 32); else ECRAD_SP(float, 64); }
   else { if (ngp == 16) ECRAD_SP(double, 16); else if (ngp == 32) ECRAD_SP(double, 32); else ECRAD_SP(double, 64); }
