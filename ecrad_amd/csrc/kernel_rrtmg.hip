@@ -116,6 +116,9 @@ constexpr int kTileCols = 64;
 #define ECRAD_TAUMOL_G 2
 #endif
 constexpr int kTauG = ECRAD_TAUMOL_G;
+#ifndef ECRAD_TAUMOL_LEVFAST
+#define ECRAD_TAUMOL_LEVFAST 0
+#endif
 #ifndef ECRAD_TAUMOL_EXACT
 #define ECRAD_TAUMOL_EXACT 1
 #endif
@@ -124,7 +127,13 @@ constexpr int kTauG = ECRAD_TAUMOL_G;
 #endif
 static_assert(kTauG == 1 || kTauG == 2 || kTauG == 4, "every RRTMG band has an even number of g-points; with 4 the last vector of a row of 4k+2 values reads two values of what follows it (the packed tables end with padding, rrtmg_device.h: build_tables), which are never stored");
 // nk (<= G) consecutive values; the 16-byte form when the destination allows it (stage arrays: even offsets)
+#ifndef ECRAD_TAUMOL_NT
+#define ECRAD_TAUMOL_NT 0      // 1: the stage arrays are written with non-temporal stores (nothing reads them before the pass has ended)
+#endif
 template <int G> ECRAD_DEV void vstore(double* p, const Vec<G>& v, int nk) {
+#if ECRAD_TAUMOL_NT
+  if (G == 2 && nk == 2 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) { ecrad_v2d t; t.x = v.v[0]; t.y = v.v[G - 1]; __builtin_nontemporal_store(t, reinterpret_cast<ecrad_v2d*>(p)); return; }
+#endif
   if (G == 2 && nk == 2 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) { *reinterpret_cast<double2*>(p) = make_double2(v.v[0], v.v[G - 1]); return; }
   if (G == 4 && (nk & 1) == 0 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) {      // (every band has an even number of g-points: nk is 2 or 4)
     reinterpret_cast<double2*>(p)[0] = make_double2(v.v[0], v.v[G > 1 ? 1 : 0]);
@@ -255,8 +264,13 @@ __global__ __launch_bounds__(kBlock, ECRAD_TAUMOL_MIN_WAVES) void rrtmg_taumol_k
   __shared__ double s_mr[kMaxActiveAerosols * kTileCols];
   __shared__ int s_rh[kTileCols];
   const int nloc = in.iendcol - in.istartcol + 1, nlev = in.nlev;
+#if ECRAD_TAUMOL_LEVFAST
+  const int lev = blockIdx.x;        // (the layers of a column tile next to each other in launch order: their rows are neighbours in the stage arrays)
+  const int c0 = blockIdx.y * kTileCols;
+#else
   const int lev = blockIdx.y;
   const int c0 = blockIdx.x * kTileCols;
+#endif
   const size_t ncol = in.ncol;
   const size_t stride = (size_t)nlev * nloc;
   const LevelOrder ord = level_order(in);
@@ -504,7 +518,11 @@ hipError_t launch_rrtmg_gas_optics(hipStream_t st, const DevRrtmg* tables, const
     hipError_t e = hipMemsetAsync(out.incoming_sw, 0, (size_t)kNgSw * nloc * sizeof(double), st);
     if (e != hipSuccess) return e;
   }
+#if ECRAD_TAUMOL_LEVFAST
+  const dim3 tiles(nlev, (nloc + kTileCols - 1) / kTileCols);
+#else
   const dim3 tiles((nloc + kTileCols - 1) / kTileCols, nlev);
+#endif
   hipLaunchKernelGGL(rrtmg_setcoef_kernel, dim3((nloc + 63) / 64, (nlev + kSetcoefLevels - 1) / kSetcoefLevels), dim3(kBlock), 0, st, tables, in, w, do_lw ? 1 : 0, do_sw ? 1 : 0);
   hipLaunchKernelGGL(rrtmg_laytrop_kernel, dim3((nloc + kBlock - 1) / kBlock), dim3(kBlock), 0, st, tables, in, w, do_lw ? 1 : 0, do_sw ? 1 : 0);
   hipStream_t ssw = st;

@@ -1436,10 +1436,11 @@ __global__ void spartacus_list_kernel(DevInputs in, int list_all, uint32_t* __re
 }
 
 // lane = g-point, 256/NGP listed layers per block; one wave per SIMD (the 9x9 exponential wants the whole register file)
-// (single precision: the longwave's 6x6 exponential needs 276 of the 512 registers of a lane -- ECRAD_SP_LAYERS_WAVES_LW = 2 holds it
-//  to 256 so that two waves share a SIMD; the shortwave's 9x9 needs 326)
+// (single precision: the longwave's 6x6 exponential needs 276 of the 512 registers of a lane; held to 256 -- 20 of them spilled --
+//  two waves share a SIMD: longwave stage 37.3 -> 35.0 ms per 100 000 columns.  The shortwave's 9x9 needs 326; at 256 it spills
+//  119 and its stage goes 49.1 -> 54.6 ms: gpurun_out/r04_bh)
 #ifndef ECRAD_SP_LAYERS_WAVES_LW
-#define ECRAD_SP_LAYERS_WAVES_LW 1
+#define ECRAD_SP_LAYERS_WAVES_LW 2
 #endif
 #ifndef ECRAD_SP_LAYERS_WAVES_SW
 #define ECRAD_SP_LAYERS_WAVES_SW 1
