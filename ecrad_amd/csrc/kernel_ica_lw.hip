@@ -372,6 +372,51 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
 #endif
 #pragma unroll
       for (int k = 0; k < kLwRing; ++k) ring[k] = s.pair(P_CLR, imax(nlev - 1 - k, 0), tid);
+#if ECRAD_LW_SUM4 && !ECRAD_LW_REDUCE
+      // Four half levels per butterfly (group_sum4): lane i of the column group receives the sum of the half level whose count from
+      // the bottom, m = nlev - 1 - l, has m & 3 == i & 3; the lane with glane == m mod NGP keeps it, and NGP half levels are stored
+      // at a time as before.  15 instructions per sum became 8 (the upward flux and, with the derivatives, their weight).
+      static_assert(kLwRing % 4 == 0, "a turn of the ring is a whole number of groups of four half levels");
+      for (int l0 = nlev - 1; l0 >= 0; l0 -= kLwRing) {
+#pragma unroll
+        for (int k4 = 0; k4 < kLwRing; k4 += 4) {
+          double vu[4], vd[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int k = k4 + q, l = l0 - k;
+            vu[q] = 0.0; vd[q] = 0.0;
+            if (l >= 0) {
+              const double T = ring[k].x, S = ring[k].y;
+              ring[k] = s.pair(P_CLR, imax(l - kLwRing, 0), tid);
+              fup = T * fup + S;
+              if (fx.lw_up_band && valid) {
+                const size_t o = col + ncol * ord.half(l);
+                spec_put(fx.lw_up_band, ng, g, o, fup);
+                if (have_clear_out) spec_put(fx.lw_up_clear_band, ng, g, o, fup);
+              }
+              vu[q] = valid ? fup : 0.0;
+              if (do_deriv) { deriv = deriv * T; vd[q] = valid ? deriv : 0.0; }
+            }
+          }
+          const int lg = l0 - k4;        // the group's first (lowest) half level
+          if (lg >= 0) {
+            const double ru = group_sum4<NGP>(vu[0], vu[1], vu[2], vu[3], glane);
+            const double rder = do_deriv ? group_sum4<NGP>(vd[0], vd[1], vd[2], vd[3], glane) : 0.0;
+            const int m0 = nlev - 1 - lg, m_end = m0 + 3;
+            if ((glane >> 2) == ((m0 & (NGP - 1)) >> 2)) { keep_up = ru; keep_der = rder; }
+            if ((m_end & (NGP - 1)) == NGP - 1 || lg <= 3) {
+              const int mm = (m0 & ~(NGP - 1)) + glane, lv = nlev - 1 - mm;
+              if (col_ok && lv >= 0 && mm <= m_end) {
+                const size_t o = col + ncol * ord.half(lv);
+                fx.lw_up[o] = keep_up;
+                if (have_clear_out) fx.lw_up_clear[o] = keep_up;
+                if (do_deriv) fx.lw_derivatives[o] = keep_der;
+              }
+            }
+          }
+        }
+      }
+#else
       for (int l0 = nlev - 1; l0 >= 0; l0 -= kLwRing) {
 #pragma unroll
         for (int k = 0; k < kLwRing; ++k) {
@@ -418,6 +463,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
           }
         }
       }
+#endif
       (void)keep_up; (void)keep_der;
     }
 #elif !(ECRAD_ABLATE & 4)

@@ -65,6 +65,12 @@ template <typename TAB> constexpr int min_waves_for(int ecckd) { return IsStage<
 // lw_ica_kernel<float,32,1> 6.49-6.53 ms with the double buffer; ring of 4: 5.85, 6: 5.78, 8: 5.82, 12: 5.73, 16: 6.79 -- spills).
 #define ECRAD_LW_RING 8
 #endif
+// 1: the clear-sky longwave upward sweep sums four half levels per butterfly (group_sum4: 8 instructions per sum instead of 15).
+// Measured (gpurun_out/r04_bk): lw_ica_kernel 5.2 -> 5.8 ms per 100 000 clear-sky columns, McICA 17.0 -> 17.6 ms: the sweep is a chain
+// of dependent steps whose sums fill otherwise idle issue slots; taking four levels at a time only lengthens the chain.  Off.
+#ifndef ECRAD_LW_SUM4
+#define ECRAD_LW_SUM4 0
+#endif
 #ifndef ECRAD_LW_REDUCE
 // 1: the clear-sky longwave upward sweep sums over g through LDS, eight half levels at a time (LevelReduce); 0: a butterfly per sum.
 // Measured (gpurun_out/r04_w): lw_ica_kernel<FixedF,32,1> 5.11-5.17 -> 5.07-5.10 ms per 100 000 clear-sky columns -- the sweep waits
@@ -278,6 +284,29 @@ ECRAD_DEV double group_sum(double v) {
   if (NGP >= 64) v = half_pair_sum(v);
   return v;
 #endif
+}
+
+// FOUR sums over the lanes of a column group in one butterfly: lane i ends up with the sum of quantity (i & 3).  The first two
+// steps halve the number of quantities a lane carries instead of doubling the lanes a sum covers (a lane sends the quantity it gives
+// up and adds what it receives to the one it keeps), the remaining steps add lanes 4, 8, 16, 32 apart, which leaves (i & 3) alone:
+// 31 VALU instructions for four sums (NGP = 32) against 4 x 15.  Every lane with the same (i & 3) holds the same total, so the lane
+// that keeps a half level for the deferred store must be chosen with that in mind (see the longwave upward sweep).  The order of the
+// additions differs from group_sum's (last-bit differences).
+template <int NGP>
+ECRAD_DEV double group_sum4(double q0, double q1, double q2, double q3, int lane) {
+  static_assert(NGP == 16 || NGP == 32 || NGP == 64, "column groups are 16, 32 or 64 lanes");
+#if ECRAD_ABLATE & 2
+  return q0;
+#endif
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+  const double r01 = (b0 ? q1 : q0) + dpp_move<0xB1>(b0 ? q0 : q1);      // quad_perm [1,0,3,2]
+  const double r23 = (b0 ? q3 : q2) + dpp_move<0xB1>(b0 ? q2 : q3);
+  double r = (b1 ? r23 : r01) + dpp_move<0x4E>(b1 ? r01 : r23);           // quad_perm [2,3,0,1]
+  r += dpp_move<0x124>(r);    // row_ror:4
+  r += dpp_move<0x128>(r);    // row_ror:8
+  if (NGP >= 32) r = row_pair_sum(r);
+  if (NGP >= 64) r = half_pair_sum(r);
+  return r;
 }
 
 // Sums over the lanes of a column group for FOUR consecutive half levels at a time, through LDS.  The butterfly above costs
