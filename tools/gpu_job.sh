@@ -1,8 +1,9 @@
 #!/bin/bash
-out=gpurun_out/r04_bk; mkdir -p $out
+out=gpurun_out/r04_bl; mkdir -p $out
 export TMPDIR=/tmp
-( timeout 900 python -m pytest tests/test_hip_parity.py tests/test_synthetic_workload.py -q -m gpu -x < /dev/null ) 2>&1 | tail -4 | tee $out/tests.log
-for w in clear_homogeneous_ecckd32 mcica_ecckd32 mcica_rrtmg; do
+for w in mcica_rrtmg; do
 echo "== $w"
-ECRAD_VARIANT_PASSES=3 bash tools/run_variants.sh --workload $w --steps 10 --headline-only --no-host-mode 2>&1
+ECRAD_VARIANT_PASSES=2 bash tools/run_variants.sh --workload $w --steps 4 --headline-only --no-host-mode 2>&1
+echo "== $w without aerosol folding"
+ECRAD_NO_AEROSOL_FOLD=1 ECRAD_VARIANT_PASSES=1 bash tools/run_variants.sh --workload $w --steps 4 --headline-only --no-host-mode 2>&1
 done | tee $out/variants.log
