@@ -63,8 +63,9 @@ constexpr int kLwBatch = ECRAD_LW_BATCH;
 #endif
 #ifndef ECRAD_LW_MERGED
 // McICA: sweeps U, D, then ONE upward sweep W (see W in lw_ica_kernel) instead of B1, U, V, D and the derivative sweep: a sixth fewer
-// bytes through the scratch and SLOWER -- lw stage 59.9 -> 63.9 ms per 100 000 columns with the RRTMG spectra, 16.7 -> 17.1 ms with
-// ecCKD-32 (gpurun_out/r04_bb, profiles/r04_variants.log): the sweeps are paid per instruction and per dependent step, not per byte
+// bytes through the scratch.  With ecCKD tables SLOWER (16.7 -> 17.1 ms per 100 000 columns, gpurun_out/r04_bb; and 59.9 -> 63.9 ms for
+// the RRTMG spectra while they ran in the double-table instantiations at two waves per SIMD): those sweeps are paid per dependent step,
+// not per byte.  1 forces it for every table type; the StageD instantiations have it regardless (see MERGED in the kernel)
 #define ECRAD_LW_MERGED 0
 #endif
 #ifndef ECRAD_LW_W_RING
@@ -339,7 +340,9 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
     const DevFlux& fx = kernarg_block<SpectralArgs>().fx;
     // MERGED (McICA): the cloudy-sky sweeps U and D come first and ONE upward sweep W then carries everything that climbs
     // from the surface -- see W below; B1, V and the derivative sweep are the cloudless / homogeneous solvers' only
-    constexpr bool MERGED = (MODE == 2) && (ECRAD_LW_MERGED != 0);
+    // (on for the RRTMG spectra, StageD, whose kernels move 6 TB/s at three waves per SIMD: longwave stage 49.4 -> 48.1 ms per
+    //  100 000 columns, gpurun_out/r04_bm; with ecCKD tables -- latency-bound -- it loses: ECRAD_LW_MERGED above)
+    constexpr bool MERGED = (MODE == 2) && (ECRAD_LW_MERGED != 0 || IsStage<TAB>::value);
     double fup = emission + albedo * fdn_c;
     const double fup_surf_clear = fup;
     if constexpr (!MERGED) {

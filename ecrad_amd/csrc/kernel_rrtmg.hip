@@ -110,7 +110,10 @@ __global__ __launch_bounds__(kBlock) void rrtmg_laytrop_kernel(const DevRrtmg* _
   }
 }
 
-constexpr int kTileCols = 64;
+#ifndef ECRAD_TAUMOL_TILE
+#define ECRAD_TAUMOL_TILE 64      // columns of a block of rrtmg_taumol_kernel (its LDS: 0.55 KB per column)
+#endif
+constexpr int kTileCols = ECRAD_TAUMOL_TILE;
 // g-points per lane of rrtmg_taumol_kernel (see Vec<G> in rrtmg_device.h)
 #ifndef ECRAD_TAUMOL_G
 #define ECRAD_TAUMOL_G 2

@@ -464,6 +464,36 @@ def test_compile_time_quad_counts_change_nothing():
         print(solver, "compile-time vs run-time quad counts:", max(worst.values()))
 
 
+def test_switched_off_forms_of_round_4_still_give_the_same_fluxes():
+    """Round 4 built several restructurings that were measured and left OFF (profiles/r04_variants.log): one upward sweep W for the
+    McICA longwave instead of B1 / V / derivative sweeps (ECRAD_LW_MERGED), four sums over g per butterfly in the clear-sky longwave
+    sweep (ECRAD_LW_SUM4), and in the RRTMG gas-optics pass four g-points per lane, level-fast launch order and non-temporal stage
+    stores (ECRAD_TAUMOL_G / _LEVFAST / _NT).  tests/_build/variants/alt (made by __graft_entry__.build(): ALT_FLAGS) is the library
+    with all of them ON; it must agree with the shipped one to 1e-10 on every flux (the sums are taken in another order, the blend of
+    the two skies in two steps), for ecCKD and for the RRTMG spectra."""
+    import os
+    from ecrad_amd.interface import Radiation
+    from ecrad_amd.types import Flux
+    from helpers import make_config_rrtmg
+    alt = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "_build", "variants", "alt", "libecrad_hip.so")
+    assert os.path.exists(alt), "tests/_build/variants/alt/libecrad_hip.so is missing: run __graft_entry__.build()"
+    cases = [("Homogeneous", make_config), ("McICA", make_config), ("McICA", make_config_rrtmg), ("Tripleclouds", make_config_rrtmg)]
+    for solver, mk in cases:
+        out = []
+        for path in (None, alt):
+            config = mk(solver)
+            rad = Radiation(config, backend="hip", lib_path=path)
+            ncol, nlev, sl, th, gas, cloud, aer = load_meridian(config)
+            rad.set_gas_units(gas)
+            th.calc_saturation_wrt_liquid()
+            flux = Flux.allocate(config, ncol, nlev)
+            rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)
+            rad.close()
+            out.append(flux)
+        worst = compare_flux(out[0], out[1], 1e-10)
+        print(solver, mk.__name__, "alternative forms vs shipped:", max(worst.values()))
+
+
 def test_packed_sweep_records_change_nothing_that_matters():
     """The shortwave sweep records travel as five doubles in 32 bytes (39 mantissa bits, rounded to nearest:
     kernels_common.h pack5).  The same sources built with -DECRAD_PACK_SW=0 -DECRAD_FAST_DIV=0 (tests/_build/variants/nopack,

@@ -1,9 +1,8 @@
 #!/bin/bash
-out=gpurun_out/r04_bl; mkdir -p $out
+out=gpurun_out/r04_bn; mkdir -p $out
 export TMPDIR=/tmp
+( ECRAD_HIP_LIB=$PWD/build_variants/t32w6/libecrad_hip.so timeout 600 python -m pytest tests/test_hip_rrtmg.py -q -m gpu -x < /dev/null ) 2>&1 | tail -3 | tee $out/tests.log
 for w in mcica_rrtmg; do
 echo "== $w"
-ECRAD_VARIANT_PASSES=2 bash tools/run_variants.sh --workload $w --steps 4 --headline-only --no-host-mode 2>&1
-echo "== $w without aerosol folding"
-ECRAD_NO_AEROSOL_FOLD=1 ECRAD_VARIANT_PASSES=1 bash tools/run_variants.sh --workload $w --steps 4 --headline-only --no-host-mode 2>&1
+ECRAD_VARIANT_PASSES=3 bash tools/run_variants.sh --workload $w --steps 6 --headline-only --no-host-mode 2>&1
 done | tee $out/variants.log
