@@ -114,6 +114,11 @@ __global__ __launch_bounds__(kBlock) void rrtmg_laytrop_kernel(const DevRrtmg* _
 #define ECRAD_TAUMOL_TILE 64      // columns of a block of rrtmg_taumol_kernel (its LDS: 0.55 KB per column)
 #endif
 constexpr int kTileCols = ECRAD_TAUMOL_TILE;
+#ifndef ECRAD_TAUMOL_BLOCK
+#define ECRAD_TAUMOL_BLOCK ECRAD_BLOCK      // threads of a block of rrtmg_taumol_kernel (a power of two)
+#endif
+constexpr int kTauBlock = ECRAD_TAUMOL_BLOCK;
+static_assert((kTauBlock & (kTauBlock - 1)) == 0 && kTauBlock >= 64, "the bands' items are dealt to the threads modulo the block size");
 // g-points per lane of rrtmg_taumol_kernel (see Vec<G> in rrtmg_device.h)
 #ifndef ECRAD_TAUMOL_G
 #define ECRAD_TAUMOL_G 2
@@ -177,7 +182,7 @@ ECRAD_DEV void aerosol_tile_inputs(const DevConfig& cfg, const DevInputs& in, in
   const int nlev_aer = in.aerosol_iendlev - in.aerosol_istartlev + 1;
   const size_t type_stride = ncol * (size_t)nlev_aer;
   const int n = ao.nactive;
-  for (int i = threadIdx.x; i < (n + 1) * kTileCols; i += kBlock) {
+  for (int i = threadIdx.x; i < (n + 1) * kTileCols; i += kTauBlock) {
     const int k = i / kTileCols, c = i % kTileCols, cloc = c0 + c;
     if (cloc >= nloc) continue;
     const int col = in.istartcol - 1 + cloc;
@@ -216,7 +221,7 @@ ECRAD_DEV void aerosol_bands_of_tile(const DevConfig& cfg, int c0, int nloc, con
   const int n = ao.nactive;
   constexpr int KB = 4;        // table rows of KB types requested together
   constexpr int W = IS_SW ? 8 : 16, NBL = IS_SW ? kSwAerHalf : 16;
-  for (int i = threadIdx.x; i < W * kTileCols; i += kBlock) {
+  for (int i = threadIdx.x; i < W * kTileCols; i += kTauBlock) {
     const int bl = i % W, c = i / W, b = b0 + bl;
     if (bl >= NBL || b >= nb || c0 + c >= nloc) continue;
     AerosolLayer a = {0.0, 0.0, 0.0};
@@ -257,7 +262,7 @@ ECRAD_DEV void aerosol_bands_of_tile(const DevConfig& cfg, int c0, int nloc, con
   }
 }
 
-__global__ __launch_bounds__(kBlock, ECRAD_TAUMOL_MIN_WAVES) void rrtmg_taumol_kernel(const DevRrtmg* __restrict__ Tp, const DevConfig* __restrict__ cfgp, DevInputs in,
+__global__ __launch_bounds__(kTauBlock, ECRAD_TAUMOL_MIN_WAVES) void rrtmg_taumol_kernel(const DevRrtmg* __restrict__ Tp, const DevConfig* __restrict__ cfgp, DevInputs in,
                                                               RrtmgWork w, DevGasStage out, int do_lw, int do_sw) {
   const DevRrtmg& T = *Tp;
   const DevConfig& cfg = *cfgp;
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TAUMOL_MIN_WAVES) void rrtmg_taumol_k
   __shared__ int s_sun[kTileCols];
   const size_t rec0 = (size_t)lev * nloc + c0;
   int rot = 0;      // thread at which the next band's items start (ECRAD_TAUMOL_EXACT)
-  for (int i = tid; i < kTileCols; i += kBlock) {
+  for (int i = tid; i < kTileCols; i += kTauBlock) {
     const int cloc = c0 + i;
     if (cloc < nloc) {
       const int col = in.istartcol - 1 + cloc;
@@ -297,11 +302,11 @@ __global__ __launch_bounds__(kBlock, ECRAD_TAUMOL_MIN_WAVES) void rrtmg_taumol_k
   if (fold_lw || fold_sw) aerosol_tile_inputs(cfg, in, lev, c0, nloc, s_mr, s_rh);
   __syncthreads();
   if (do_lw) {
-    for (int i = tid; i < LD_N * kTileCols; i += kBlock) {
+    for (int i = tid; i < LD_N * kTileCols; i += kTauBlock) {
       const int f = i / kTileCols, c = i % kTileCols;
       if (c0 + c < nloc) s_d[i] = w.lw_d[(size_t)f * stride + rec0 + c];
     }
-    for (int i = tid; i < LI_N * kTileCols; i += kBlock) {
+    for (int i = tid; i < LI_N * kTileCols; i += kTauBlock) {
       const int f = i / kTileCols, c = i % kTileCols;
       if (c0 + c < nloc) s_i[i] = w.lw_i[(size_t)f * stride + rec0 + c];
     }
@@ -320,12 +325,12 @@ __global__ __launch_bounds__(kBlock, ECRAD_TAUMOL_MIN_WAVES) void rrtmg_taumol_k
       // wave 0 taking the head of every band.  c = i / nv by multiplication (i < 1024, nv <= 16).
       const int items = nv * kTileCols;
       const unsigned magic = (65536u + (unsigned)nv - 1u) / (unsigned)nv;
-      for (int i = (tid - rot) & (kBlock - 1); i < items; i += kBlock) {
+      for (int i = (tid - rot) & (kTauBlock - 1); i < items; i += kTauBlock) {
         const int c = (int)(((unsigned)i * magic) >> 16), iv = i - c * nv, cloc = c0 + c;
 #else
       const int nbp = nv <= 1 ? 1 : (nv <= 2 ? 2 : (nv <= 4 ? 4 : (nv <= 8 ? 8 : 16)));
       const int items = nbp * kTileCols;
-      for (int i = tid; i < items; i += kBlock) {
+      for (int i = tid; i < items; i += kTauBlock) {
         const int iv = i & (nbp - 1), c = i / nbp, cloc = c0 + c;
 #endif
         const int ig = iv * G;
@@ -371,17 +376,17 @@ __global__ __launch_bounds__(kBlock, ECRAD_TAUMOL_MIN_WAVES) void rrtmg_taumol_k
         if (lev == nlev - 1) pstore<G>(out.lw_emission + (size_t)kNgLw * cloc, g, pos, ps, nk);
       }
 #if ECRAD_TAUMOL_EXACT
-      rot = (rot + items) & (kBlock - 1);
+      rot = (rot + items) & (kTauBlock - 1);
 #endif
     }
     __syncthreads();
   }
   if (do_sw) {
-    for (int i = tid; i < SD_N * kTileCols; i += kBlock) {
+    for (int i = tid; i < SD_N * kTileCols; i += kTauBlock) {
       const int f = i / kTileCols, c = i % kTileCols;
       if (c0 + c < nloc && s_sun[c]) s_d[i] = w.sw_d[(size_t)f * stride + rec0 + c];
     }
-    for (int i = tid; i < SI_N * kTileCols; i += kBlock) {
+    for (int i = tid; i < SI_N * kTileCols; i += kTauBlock) {
       const int f = i / kTileCols, c = i % kTileCols;
       if (c0 + c < nloc && s_sun[c]) s_i[i] = w.sw_i[(size_t)f * stride + rec0 + c];
     }
@@ -401,12 +406,12 @@ __global__ __launch_bounds__(kBlock, ECRAD_TAUMOL_MIN_WAVES) void rrtmg_taumol_k
 #if ECRAD_TAUMOL_EXACT
       const int items = nv * kTileCols;
       const unsigned magic = (65536u + (unsigned)nv - 1u) / (unsigned)nv;
-      for (int i = (tid - rot) & (kBlock - 1); i < items; i += kBlock) {
+      for (int i = (tid - rot) & (kTauBlock - 1); i < items; i += kTauBlock) {
         const int c = (int)(((unsigned)i * magic) >> 16), iv = i - c * nv, cloc = c0 + c;
 #else
       const int nbp = nv <= 1 ? 1 : (nv <= 2 ? 2 : (nv <= 4 ? 4 : (nv <= 8 ? 8 : 16)));
       const int items = nbp * kTileCols;
-      for (int i = tid; i < items; i += kBlock) {
+      for (int i = tid; i < items; i += kTauBlock) {
         const int iv = i & (nbp - 1), c = i / nbp, cloc = c0 + c;
 #endif
         const int ig = iv * G;
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(kBlock, ECRAD_TAUMOL_MIN_WAVES) void rrtmg_taumol_k
         if (fold_sw) pstore<G>(out.g_sw + o, g, pos, vg, nk);
       }
 #if ECRAD_TAUMOL_EXACT
-      rot = (rot + items) & (kBlock - 1);
+      rot = (rot + items) & (kTauBlock - 1);
 #endif
     }
   }
@@ -533,11 +538,11 @@ hipError_t launch_rrtmg_gas_optics(hipStream_t st, const DevRrtmg* tables, const
     hipError_t e = hipEventRecord(ev_records, st);
     if (e == hipSuccess) e = hipStreamWaitEvent(st_sw, ev_records, 0);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(rrtmg_taumol_kernel, tiles, dim3(kBlock), 0, st, tables, cfg, in, w, out, 1, 0);
-    hipLaunchKernelGGL(rrtmg_taumol_kernel, tiles, dim3(kBlock), 0, st_sw, tables, cfg, in, w, out, 0, 1);
+    hipLaunchKernelGGL(rrtmg_taumol_kernel, tiles, dim3(kTauBlock), 0, st, tables, cfg, in, w, out, 1, 0);
+    hipLaunchKernelGGL(rrtmg_taumol_kernel, tiles, dim3(kTauBlock), 0, st_sw, tables, cfg, in, w, out, 0, 1);
     ssw = st_sw;
   } else {
-    hipLaunchKernelGGL(rrtmg_taumol_kernel, tiles, dim3(kBlock), 0, st, tables, cfg, in, w, out, do_lw ? 1 : 0, do_sw ? 1 : 0);
+    hipLaunchKernelGGL(rrtmg_taumol_kernel, tiles, dim3(kTauBlock), 0, st, tables, cfg, in, w, out, do_lw ? 1 : 0, do_sw ? 1 : 0);
   }
   if (do_sw) {
     SolarScaling sc{};
