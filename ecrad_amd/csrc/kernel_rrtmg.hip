@@ -111,11 +111,15 @@ __global__ __launch_bounds__(kBlock) void rrtmg_laytrop_kernel(const DevRrtmg* _
 }
 
 #ifndef ECRAD_TAUMOL_TILE
-#define ECRAD_TAUMOL_TILE 64      // columns of a block of rrtmg_taumol_kernel (its LDS: 0.55 KB per column)
+// columns and threads of a block of rrtmg_taumol_kernel (its LDS: 0.55 KB per column).  Measured per 100 000 columns (gas-optics stage,
+// gpurun_out/r04_bn ... r04_bp): 256 threads x 64 columns 44.6-45.1 ms, 512 x 128 (two blocks of eight waves per CU: the same four waves
+// per SIMD and columns per wave, half as many blocks to stage records and fold aerosols for) 42.1-43.7, 1024 x 256 46.5-46.9,
+// 256 x 32 55, 128 x 64 (two waves per SIMD) 67
+#define ECRAD_TAUMOL_TILE 128
 #endif
 constexpr int kTileCols = ECRAD_TAUMOL_TILE;
 #ifndef ECRAD_TAUMOL_BLOCK
-#define ECRAD_TAUMOL_BLOCK ECRAD_BLOCK      // threads of a block of rrtmg_taumol_kernel (a power of two)
+#define ECRAD_TAUMOL_BLOCK 512      // threads of a block of rrtmg_taumol_kernel (a power of two)
 #endif
 constexpr int kTauBlock = ECRAD_TAUMOL_BLOCK;
 static_assert((kTauBlock & (kTauBlock - 1)) == 0 && kTauBlock >= 64, "the bands' items are dealt to the threads modulo the block size");
