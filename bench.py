@@ -453,11 +453,12 @@ def roofline_of(w, stage_ms, elapsed_per_step_s):
     info = w.call_info()
     launches = info.launches_sw if dom == "sw" else info.launches_lw
     kernel = {"Tripleclouds": f"{dom}_tc_kernel", "SPARTACUS": f"spartacus_{dom}_kernel"}.get(w.desc["sw_solver"], f"{dom}_ica_kernel")
-    # (instantiations over float tables serve the ecCKD models, over double the RRTMG stage arrays: a profile of the
-    #  default run holds both, e.g. sw_ica_kernel<float, 32, 1, ...> and sw_ica_kernel<double, 64, 2, ...>)
+    # (instantiations over float tables serve the ecCKD models, the table-free StageD ones -- `double` before the second half of
+    #  round 4 -- the RRTMG stage arrays: a profile of the default run holds both, e.g. sw_ica_kernel<FixedF, 32, 1, ...> and
+    #  sw_ica_kernel<StageD, 64, 2, ...>)
     is_rrtmg = bool(w.desc.get("rrtmg"))
     # (the ecCKD kernels run as their FixedF instantiations -- compile-time quad counts -- for every model shipped so far)
-    traffic = measured_traffic(w.name, ncol, (kernel + "<double,",) if is_rrtmg else (kernel + "<float,", kernel + "<FixedF,"))
+    traffic = measured_traffic(w.name, ncol, (kernel + "<StageD,", kernel + "<double,") if is_rrtmg else (kernel + "<float,", kernel + "<FixedF,"))
     whole = a_all * ncol / elapsed_per_step_s / 1e9
     extra = {}
     if w.desc["sw_solver"] == "SPARTACUS":
