@@ -1,11 +1,23 @@
 #!/bin/bash
-out=gpurun_out/r04_bs; mkdir -p $out
+out=gpurun_out/r04_bt; mkdir -p $out
 export TMPDIR=/tmp
-p='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print("%-40s %9d col/s %8.2f ms " % (sys.argv[1], d["value"], d["ms_per_step"]), {k: round(v, 2) for k, v in d["roofline"]["stage_ms"].items()})'
-run() { timeout -s KILL 300 python bench.py --no-cpu-baseline --steps 6 --headline-only --no-host-mode --workload mcica_rrtmg 2>/dev/null | python -c "$p" "$1"; }
-for rep in 1 2 3; do
-run default
-ECRAD_GEN_OVERLAP=1 run gen_overlap
-ECRAD_GEN_SW_LATE=1 run gen_sw_late
-done 2>&1 | tee $out/knobs.log
-timeout 1200 python bench.py < /dev/null > $out/bench.json 2> $out/bench.err; tail -c 300 $out/bench.json
+rocprofv3 --list-avail 2>/dev/null | grep -oE "\b(TCP|TCC|TA|TD|SQ|SQC|GRBM)_[A-Za-z0-9_]+" | sort -u > $out/counters.txt
+wc -l $out/counters.txt
+ARGS="--steps 1 --warmup 1 --no-cpu-baseline --headline-only --no-host-mode --workload mcica_rrtmg --ncol 100000"
+for set in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TA_TA_BUSY_sum" "TCP_TA_TCP_STATE_READ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum" "TCC_EA0_WRREQ_STALL_sum TCC_TAG_STALL_sum TCC_EA0_RDREQ_32B_sum"; do
+  tag=$(echo $set | tr ' ' '_' | cut -c1-40)
+  timeout 300 rocprofv3 --pmc $set -d $out/pmc_$tag -o pmc -- python bench.py $ARGS > $out/log_$tag.txt 2>&1
+  python - <<PY
+import sqlite3,glob
+for db in glob.glob("$out/pmc_$tag/**/*.db", recursive=True):
+    try:
+        con=sqlite3.connect(db)
+        tabs=[r[0] for r in con.execute("select name from sqlite_master where type='view' or type='table'")]
+        t=[x for x in tabs if x.startswith('counters_collection')]
+        rows=con.execute("select kernel_name, counter_name, sum(value), count(*) from %s group by kernel_name, counter_name" % t[0]).fetchall()
+        for k,c,v,n in rows:
+            if 'taumol' in k or 'StageD, 64' in k: print(k[:60], c, v, n)
+    except Exception as e: print('ERR', db, e)
+PY
+done 2>&1 | tee $out/pmc.log
+find gpurun_out -name "*.db" -delete
