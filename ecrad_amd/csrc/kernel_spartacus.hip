@@ -32,10 +32,11 @@
 #include "launch.h"
 #include "spartacus_device.h"
 
-// waves per SIMD of the single-precision sweep kernels (measured on 100 000 columns: SW 2 -> 59 ms, 3 -> 81 ms with
-// 416 B of spills per lane; LW 2 -> 51 ms, 3 -> 45 ms, 4 -> 53 ms)
+// waves per SIMD of the single-precision sweep kernels (measured on 100 000 columns; round 2: SW 2 -> 59 ms, 3 -> 81 ms with
+// 416 B of spills per lane; LW 2 -> 51 ms, 3 -> 45 ms, 4 -> 53 ms.  End of round 4, after the rings and the leaner slab: the shortwave
+// stage 49.0 ms at 2, 45.9 ms at 3 (168 registers, 60 spilled: 140 B per lane); the longwave 34.6 ms at 3, 37.7 at 4: gpurun_out/r04_bu)
 #ifndef ECRAD_SP_SWEEP_WAVES_SW
-#define ECRAD_SP_SWEEP_WAVES_SW 2
+#define ECRAD_SP_SWEEP_WAVES_SW 3
 #endif
 #ifndef ECRAD_SP_SWEEP_WAVES_LW
 #define ECRAD_SP_SWEEP_WAVES_LW 3
