@@ -1,5 +1,7 @@
 #!/bin/bash
-out=gpurun_out/r04_bv; mkdir -p $out
+out=gpurun_out/r04_bw; mkdir -p $out
 export TMPDIR=/tmp
-( timeout 1200 python -m pytest tests/test_hip_spartacus.py tests/test_synthetic_workload.py tests/test_reference_suites.py -q -m gpu -x < /dev/null ) 2>&1 | tail -4 | tee $out/tests.log
-bash tools/workloads.sh spartacus_ecckd32_sp spartacus_ecckd32_dp 2>&1 | tee $out/workloads.log
+for w in spartacus_ecckd32_sp; do
+echo "== $w"
+ECRAD_VARIANT_PASSES=2 bash tools/run_variants.sh --workload $w --steps 6 --headline-only --no-host-mode 2>&1
+done | tee $out/variants.log
