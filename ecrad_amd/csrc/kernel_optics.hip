@@ -26,10 +26,13 @@ struct DumpArgs {
 // rounding at the store instead is the same number and half the bytes both ways.
 template <typename OUT> ECRAD_DEV void put_stage(double* arr, size_t o, double v) { reinterpret_cast<OUT*>(arr)[o] = (OUT)v; }
 
-template <typename TAB, int NGP, bool IS_SW, typename OUT>
 #ifndef ECRAD_DUMP_MIN_WAVES
 #define ECRAD_DUMP_MIN_WAVES ECRAD_MIN_WAVES
 #endif
+#ifndef ECRAD_DUMP_CHUNK_DIV
+#define ECRAD_DUMP_CHUNK_DIV 1      // 2: half as many levels per chunk of level records (with ECRAD_DUMP_MIN_WAVES=4: a fourth block per CU)
+#endif
+template <typename TAB, int NGP, bool IS_SW, typename OUT>
 __global__ __launch_bounds__(kBlock, ECRAD_DUMP_MIN_WAVES) void optics_dump_kernel(DumpArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   const DumpArgs& a0 = kernarg_block<DumpArgs>();
@@ -88,18 +91,20 @@ __global__ __launch_bounds__(kBlock, ECRAD_DUMP_MIN_WAVES) void optics_dump_kern
     }
     double planck_top = IS_SW ? 0.0 : planck_at<TAB>(m, in.temperature_hl[col + (size_t)in.ncol * level_order(in).half(0)], g);   // top-of-atmosphere half level
     if (!IS_SW && in.gs.planck_hl) planck_top = in.gs.planck_hl[g + (size_t)ng * ((size_t)(nlev + 1) * cloc)];
-    for (int l0 = 0; l0 < nlev; l0 += NGP) {
+    // levels per chunk: NGP, or NGP / ECRAD_DUMP_CHUNK_DIV -- the level records of a block then take that much less LDS
+    constexpr int CH = NGP / ECRAD_DUMP_CHUNK_DIV;
+    for (int l0 = 0; l0 < nlev; l0 += CH) {
       __syncthreads();
       {
         const int lev = l0 + glane;
         const DumpArgs& b = kernarg_block<DumpArgs>();
-        if (lev < nlev) level_scalars<IS_SW>(b.cfg, IS_SW ? b.cfg.gas_sw : b.cfg.gas_lw, b.in, L, tid, col, lev, want_clouds, !b.cloudy_only);
+        if (glane < CH && lev < nlev) level_scalars<IS_SW>(b.cfg, IS_SW ? b.cfg.gas_sw : b.cfg.gas_lw, b.in, L, cib * CH + glane, col, lev, want_clouds, !b.cloudy_only);
       }
       __syncthreads();
-      const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
+      const int nl = (nlev - l0) < CH ? (nlev - l0) : CH;
       for (int j = 0; j < nl; ++j) {
         const int lev = l0 + j;
-        const int slot = cib * NGP + j;
+        const int slot = cib * CH + j;
         const DumpArgs& b = kernarg_block<DumpArgs>();
         const DevConfig& cfg = b.cfg;
         const DevInputs& in = b.in;
@@ -181,6 +186,12 @@ __global__ __launch_bounds__(kBlock, ECRAD_DUMP_MIN_WAVES) void optics_dump_kern
 hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
                               const DevConfig& cfg, const DevInputs& in, const DevOptics& out, int g0, int* counter, bool out_f32, bool cloudy_only) {
   const DumpArgs args{cfg, in, out, g0, cloudy_only ? 1 : 0, counter};
+  lds /= ECRAD_DUMP_CHUNK_DIV;
+  if (ECRAD_DUMP_CHUNK_DIV > 1) {      // the blocks the smaller records and ECRAD_DUMP_MIN_WAVES make room for
+    const int groups = (in.iendcol - in.istartcol + 1 + kBlock / ngp - 1) / (kBlock / ngp);
+    grid = grid * ECRAD_DUMP_MIN_WAVES / ECRAD_MIN_WAVES;
+    if (grid > groups) grid = groups;
+  }
 #define ECRAD_L(T, N, S, O) do { ECRAD_ALLOW_LDS((optics_dump_kernel<T, N, S, O>), lds); hipLaunchKernelGGL((optics_dump_kernel<T, N, S, O>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
 #define ECRAD_N(T, S, O) do { if (ngp == 16) ECRAD_L(T, 16, S, O); else if (ngp == 32) ECRAD_L(T, 32, S, O); else ECRAD_L(T, 64, S, O); } while (0)
 #define ECRAD_O(T, S) do { if (out_f32) ECRAD_N(T, S, float); else ECRAD_N(T, S, double); } while (0)
