@@ -104,32 +104,42 @@ def test_more_callers_than_contexts_wait_their_turn_and_sixteen_contexts_run_six
     frac0 = cloud.fraction.copy()
     results = {}
     for nctx in (1, 16, -1):
-        cloud.fraction[...] = frac0
-        if nctx < 0:
-            os.environ["ECRAD_HIP_PACK_COLUMNS"] = "0"
-        rad = Radiation(config, backend="hip", concurrency=(1, abs(nctx)))
-        flux = Flux.allocate(config, n, nlev)
-        barrier = threading.Barrier(16)
+        # How many of the sixteen calls overlap is up to the host's thread scheduler (a call of 32 columns is 2-4 ms, a Python
+        # thread needs the interpreter lock to get into it): the round is repeated, up to three times, until it has shown the
+        # overlap asserted below -- once in five runs of the whole suite a single round had not.  The bits are checked every time.
+        for attempt in range(3):
+            cloud.fraction[...] = frac0
+            if nctx < 0:
+                os.environ["ECRAD_HIP_PACK_COLUMNS"] = "0"
+            rad = Radiation(config, backend="hip", concurrency=(1, abs(nctx)))
+            flux = Flux.allocate(config, n, nlev)
+            barrier = threading.Barrier(16)
 
-        def worker(k):
-            barrier.wait()
-            rad.radiation(n, nlev, 32 * k + 1, 32 * (k + 1), sl, th, gas, cloud, aer, flux)
-        threads = [threading.Thread(target=worker, args=(k,)) for k in range(16)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        info = rad.pool_info()
-        rad.close()
-        os.environ.pop("ECRAD_HIP_PACK_COLUMNS", None)
-        assert info["calls_total"] == 16 and info["n_contexts"] == abs(nctx)
+            def worker(k):
+                barrier.wait()
+                rad.radiation(n, nlev, 32 * k + 1, 32 * (k + 1), sl, th, gas, cloud, aer, flux)
+            threads = [threading.Thread(target=worker, args=(k,)) for k in range(16)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            info = rad.pool_info()
+            rad.close()
+            os.environ.pop("ECRAD_HIP_PACK_COLUMNS", None)
+            assert info["calls_total"] == 16 and info["n_contexts"] == abs(nctx)
+            if nctx in results:
+                _flux_equal(results[nctx], flux)
+            results[nctx] = flux
+            overlapped = (info["max_in_flight"] >= 8 and info["batches_total"] <= 8) if nctx == 1 else info["max_in_flight"] >= 8
+            if nctx < 0 or overlapped:
+                break
+            print(f"pool of {nctx}: round {attempt + 1} showed {info}; repeating")
         if nctx == 1:
             assert info["max_in_flight"] >= 8 and info["batches_total"] <= 8, info
         elif nctx == 16:
             assert info["max_in_flight"] >= 8, info
         else:
             assert info["max_in_flight"] == 1 and info["batches_total"] == 0, info
-        results[nctx] = flux
     _flux_equal(results[1], results[16])
     _flux_equal(results[1], results[-1])
 
