@@ -41,6 +41,14 @@
 #ifndef ECRAD_SP_SWEEP_WAVES_LW
 #define ECRAD_SP_SWEEP_WAVES_LW 3
 #endif
+// ... and of the double-precision ones (end of round 4, gpurun_out/r04_cc: the shortwave stage 85.4 ms at one wave per SIMD, 80.0 at two
+// -- 256 registers, the accumulation registers' share spilled --; the longwave 46.6 ms at two, 57.1 at three)
+#ifndef ECRAD_SP_DP_SWEEP_WAVES_SW
+#define ECRAD_SP_DP_SWEEP_WAVES_SW 2
+#endif
+#ifndef ECRAD_SP_DP_SWEEP_WAVES_LW
+#define ECRAD_SP_DP_SWEEP_WAVES_LW 2
+#endif
 // levels of slab scalars the flux sweeps keep in flight (a ring, see section 5 of spartacus_sw_kernel)
 #ifndef ECRAD_SP_RING
 #define ECRAD_SP_RING 4
@@ -518,7 +526,7 @@ ECRAD_DEV SwMats<R> sw_layer(const SpArgs& a, const Geo& gm, const LevelOrder& o
 //  solver_spartacus_sw
 // =====================================================================================================================
 template <typename R, int NGP>
-__global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 1) void spartacus_sw_kernel(SpArgs args_in_kernarg) {
+__global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : ECRAD_SP_DP_SWEEP_WAVES_SW) void spartacus_sw_kernel(SpArgs args_in_kernarg) {
   __shared__ int next_group;
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
@@ -1102,7 +1110,7 @@ enum { LW_REFC = 0, LW_TRAC, LW_SDNC, LW_TAC, LW_TSC,                 // clear-s
 }
 
 template <typename R, int NGP>
-__global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 2) void spartacus_lw_kernel(SpArgs args_in_kernarg) {
+__global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : ECRAD_SP_DP_SWEEP_WAVES_LW) void spartacus_lw_kernel(SpArgs args_in_kernarg) {
   __shared__ int next_group;
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
@@ -1506,7 +1514,7 @@ __global__ __launch_bounds__(kBlock, (sp_layers_waves<R, IS_SW>())) void spartac
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 size_t spartacus_scratch_words(bool is_sw, int nlev) { return (size_t)nlev * (is_sw ? SW_NSLOT : LW_NSLOT) * kBlock; }
-int spartacus_sweep_blocks_per_cu(bool single, bool is_sw) { return single ? (is_sw ? ECRAD_SP_SWEEP_WAVES_SW : ECRAD_SP_SWEEP_WAVES_LW) : (is_sw ? 1 : 2); }
+int spartacus_sweep_blocks_per_cu(bool single, bool is_sw) { return single ? (is_sw ? ECRAD_SP_SWEEP_WAVES_SW : ECRAD_SP_SWEEP_WAVES_LW) : (is_sw ? ECRAD_SP_DP_SWEEP_WAVES_SW : ECRAD_SP_DP_SWEEP_WAVES_LW); }
 size_t spartacus_layer_words(bool is_sw, int ng) { return (size_t)(is_sw ? 45 : 24) * ng; }    // per (column, layer); ng = g-points of one launch
 
 // The work list of a batch of columns (the same for the two spectra and for every chunk of a spectrum): `list` and

@@ -1,6 +1,5 @@
 #!/bin/bash
-out=gpurun_out/r04_cb; mkdir -p $out
+out=gpurun_out/r04_cd; mkdir -p $out
 export TMPDIR=/tmp
-for i in 1 2; do
-( time timeout 2400 python -m pytest tests -q -m gpu -x < /dev/null ) 2>&1 | tail -60 | tee $out/tests_$i.log | tail -6
-done
+( timeout 1500 python -m pytest tests/test_hip_spartacus.py tests/test_reference_suites.py tests/test_synthetic_workload.py -q -m gpu -x < /dev/null ) 2>&1 | tail -4 | tee $out/tests.log
+bash tools/workloads.sh spartacus_ecckd32_dp 2>&1 | tee $out/workloads.log
