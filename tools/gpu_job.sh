@@ -1,5 +1,6 @@
 #!/bin/bash
-out=gpurun_out/r04_cd; mkdir -p $out
+out=gpurun_out/r04_ce; mkdir -p $out
 export TMPDIR=/tmp
-( timeout 1500 python -m pytest tests/test_hip_spartacus.py tests/test_reference_suites.py tests/test_synthetic_workload.py -q -m gpu -x < /dev/null ) 2>&1 | tail -4 | tee $out/tests.log
-bash tools/workloads.sh spartacus_ecckd32_dp 2>&1 | tee $out/workloads.log
+( time timeout 2400 python -m pytest tests -q -m gpu -x < /dev/null ) 2>&1 | tail -8 | tee $out/tests.log
+timeout 1200 python bench.py < /dev/null > $out/bench.json 2> $out/bench.err; tail -c 300 $out/bench.json
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 | tee $out/smoke.log
