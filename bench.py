@@ -12,7 +12,9 @@ exchange step and every rank keeps the fluxes of the columns it owns, as the ran
 one collective an offline driver writing a single file needs -- the RCCL gather of the flux profiles
 on rank 0 -- and reports it as ``value_with_gather``.
 
-Prints ONE JSON line on rank 0 with the contract's keys plus:
+Prints ONE compact JSON line (< 4 KB, strict JSON: compact_line) LAST on rank 0's standard output -- the contract's keys, `roofline`,
+`cpu_baseline`, a parity summary, one short record per extra workload -- and writes the FULL record, which holds everything listed
+below, to gpurun_out/bench_detail.json (emit).  The full record has the contract's keys plus:
   "roofline":     dominant stage's algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak
   "cpu_baseline": the oracle (plain-C restatement, OpenMP over column blocks like the reference's
                   driver) timed on this box's host cores on a bounded sample of the same workload
@@ -341,6 +343,23 @@ def measured_traffic(workload, ncol, kernel_prefix):
     return best
 
 
+def measured_valu(workload, kernel_prefix):
+    """VALU-issue figures of the dominant kernel from the newest committed SQ-counter summary (profiles/*_sq.json, written by
+    tools/summarize_sq.py from the `rocprofv3 --pmc` passes of tools/pmc_sq.sh over this same command), or None."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq.json"))):
+        try:
+            ks = json.load(open(f))["workloads"].get(workload, {})
+        except Exception:
+            continue
+        names = [k for k in ks if k.startswith(tuple(kernel_prefix)) and ks[k].get("valu_busy") is not None]
+        if names:
+            k = max(names, key=lambda n: ks[n].get("valu_insts") or 0.0)
+            best = {"busy": ks[k]["valu_busy"], "waiting": ks[k]["waiting"], "insts_per_wave_layer": ks[k].get("valu_per_wave_layer"),
+                    "kernel": k, "source": "profiles/" + os.path.basename(f)}
+    return best
+
+
 class Workload:
     """One named workload resident in HBM on this rank: configuration, library handle, device arrays."""
 
@@ -458,7 +477,9 @@ def roofline_of(w, stage_ms, elapsed_per_step_s):
     #  sw_ica_kernel<StageD, 64, 2, ...>)
     is_rrtmg = bool(w.desc.get("rrtmg"))
     # (the ecCKD kernels run as their FixedF instantiations -- compile-time quad counts -- for every model shipped so far)
-    traffic = measured_traffic(w.name, ncol, (kernel + "<StageD,", kernel + "<double,") if is_rrtmg else (kernel + "<float,", kernel + "<FixedF,"))
+    prefixes = (kernel + "<StageD,", kernel + "<double,") if is_rrtmg else (kernel + "<float,", kernel + "<FixedF,")
+    traffic = measured_traffic(w.name, ncol, prefixes)
+    valu = measured_valu(w.name, prefixes)
     whole = a_all * ncol / elapsed_per_step_s / 1e9
     extra = {}
     if w.desc["sw_solver"] == "SPARTACUS":
@@ -485,7 +506,16 @@ def roofline_of(w, stage_ms, elapsed_per_step_s):
         scope = f"stage: mcica_generator_kernel + {launches} launch(es) of {kernel}"
     else:
         scope = f"{launches} launch(es) of {kernel}"
-    return {**extra, "bound": "hbm", "kernel": kernel, "kernel_ms_scope": scope, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # Which roof binds.  `bound`/`achieved`/`peak`/`frac` price the kernel against HBM with SURVEY 8(d)'s ALGORITHMIC bytes (the
+    # contract's definition); next to it the fraction of the HBM peak the kernel's COUNTED traffic makes, and the fraction of
+    # cycles its SIMDs spend issuing vector instructions (SQ counters of a committed profile).  The largest of the three is the
+    # roof the kernel is closest to: `binding_roof`.
+    t_bytes = traffic["bytes_per_launch"] / traffic["columns_per_launch"] * ncol * launches if traffic else None
+    fractions = {"hbm_algorithmic": achieved / HBM_PEAK_GBS,
+                 "hbm_counter": (t_bytes / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_bytes else None,
+                 "valu_issue": valu["busy"] if valu else None}
+    binding = max((k for k in fractions if fractions[k] is not None), key=lambda k: fractions[k])
+    return {**extra, "bound": "hbm", "binding_roof": binding, "fractions": fractions, "valu": valu, "kernel": kernel, "kernel_ms_scope": scope, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "measured_triad": HBM_TRIAD_GBS, "frac_of_measured_triad": achieved / HBM_TRIAD_GBS,
             # SURVEY 8(d)'s third number: columns/s x estimated flops per column / the vector peak of the working precision
             "fp64_fraction": ncol / elapsed_per_step_s * flops / 1e12 / vpeak,
@@ -496,7 +526,7 @@ def roofline_of(w, stage_ms, elapsed_per_step_s):
             # spectra wider than 64 g-points run as several launches of the kernel; the stage time and the algorithmic
             # bytes cover all of them (and, for McICA, the cloud generator that feeds them), the PMC figure is per launch
             # (scaled by columns per launch: the profile may have run the call as a different number of column tiles)
-            "traffic": traffic["bytes_per_launch"] / traffic["columns_per_launch"] * ncol * launches if traffic else None,
+            "traffic": t_bytes,
             "traffic_source": traffic["source"] if traffic else None,
             "launches_per_step": launches * info.n_tiles, "column_tiles": info.n_tiles,
             "algorithmic_bytes": a_dom * ncol, "algorithmic_bytes_per_column": a_dom, "kernel_ms": dom_ms,
@@ -820,7 +850,7 @@ def pool_mode(args):
            "pool": info, "blocks_identical_across_devices": bool(same)}
     rad.close()
     del keep
-    print(json.dumps(out))
+    emit(out)
     sys.exit(0 if same else 1)
 
 
@@ -872,6 +902,130 @@ def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allredu
         res["end_to_end_host"] = end_to_end_host(w, res["value"] / world)
     w.close()
     return res
+
+
+LINE_LIMIT = 4096          # the driver keeps a bounded tail of stdout: the final line has to fit it with room to spare
+
+
+def _finite(x):
+    """JSON has no NaN / Infinity: non-finite floats become null, numpy scalars become Python ones (recursively)."""
+    if isinstance(x, dict):
+        return {str(k): _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    if isinstance(x, (np.floating, np.integer, np.bool_)):
+        x = x.item()
+    if isinstance(x, float) and not np.isfinite(x):
+        return None
+    return x
+
+
+def _sig(x, n=6):
+    """Floats of the compact line carry n significant digits (the detail file keeps every digit)."""
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_sig(v, n) for v in x]
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}")
+    return x
+
+
+def _compact_roofline(r):
+    keep = ("bound", "binding_roof", "fractions", "valu", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+            "kernel_ms", "stage_ms", "algorithmic_bytes_per_column", "launches_per_step", "scratch_mantissa_bits", "measured_triad")
+    out = {k: r[k] for k in keep if k in r}
+    if "whole_step" in r:
+        out["whole_step_frac"] = r["whole_step"]["frac"]
+    if "compute" in r:
+        out["compute"] = {k: r["compute"][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+    return out
+
+
+def _compact_cpu(c):
+    out = {k: c[k] for k in ("value", "unit", "cores", "kind") if k in c}
+    sample = c.get("sample", "")
+    out["sample"] = sample if len(sample) <= 200 else sample[:197] + "..."
+    port = c.get("components", {}).get("port")
+    if port and "value" in port:
+        out["port_value"] = port["value"]       # the oracle's own figure next to the reference executable's
+    return out
+
+
+def _compact_parity(p):
+    keep = ("ok", "max_rel_diff_vs_oracle", "max_rel_diff_broadband", "field", "columns_checked", "tolerance",
+            "oracle_fma_vs_plain_there", "fields_checked", "fields_failed", "nonfinite")
+    return {k: p[k] for k in keep if k in p}
+
+
+def compact_line(out, detail_path=None):
+    """The ONE line the driver parses: the contract's keys + `roofline` + `cpu_baseline` + a parity summary + one short
+    record per extra workload.  Everything else of `out` (per-field single-precision parity, cpu_baseline.components,
+    small_blocks, end_to_end_host, per-stage times) is in the detail file (gpurun_out/bench_detail.json).  Strict JSON: non-finite
+    floats are null (`allow_nan=False`).  Always shorter than LINE_LIMIT (tests/test_bench_line.py)."""
+    out = _finite(out)
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data", "config") if k in out}
+    for k in ("ms_per_step_ranks", "value_with_gather", "ms_per_step_with_gather", "gathered", "mode", "test_shared_gpu",
+              "blocks_identical_across_devices"):
+        if k in out:
+            line[k] = out[k]
+    if "roofline" in out:
+        line["roofline"] = _compact_roofline(out["roofline"])
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = _compact_cpu(out["cpu_baseline"])
+    if "parity" in out:
+        line["parity"] = _compact_parity(out["parity"])
+    if "end_to_end_host" in out:
+        e = out["end_to_end_host"]
+        line["end_to_end_host"] = {k: e[k] for k in ("value", "unit", "pcie_ceiling_columns_per_s") if k in e}
+    if "workloads" in out:
+        wl = {}
+        for name, r in out["workloads"].items():
+            if "error" in r:
+                wl[name] = {"error": str(r["error"])[:120]}
+                continue
+            rec = {"value": r.get("value"), "ms_per_step": r.get("ms_per_step"), "ncol": r.get("config", {}).get("columns_per_gpu_per_step")}
+            if "roofline" in r:
+                rec["frac"] = r["roofline"]["frac"]
+                rec["kernel_ms"] = r["roofline"]["kernel_ms"]
+            if "parity" in r:
+                rec["parity_ok"] = r["parity"]["ok"]
+            if "cpu_baseline" in r:
+                rec["cpu"] = r["cpu_baseline"].get("value")
+            wl[name] = rec
+        line["workloads"] = wl
+    if "small_blocks" in out:
+        line["small_blocks"] = {k: (v.get("value") if "error" not in v else None) for k, v in out["small_blocks"].items()}
+    if detail_path:
+        line["detail"] = detail_path
+    text = json.dumps(_sig(line), allow_nan=False, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:      # (cannot happen with the workloads of this file; a longer list sheds its optional parts)
+        for k in ("small_blocks", "workloads", "end_to_end_host"):
+            line.pop(k, None)
+            text = json.dumps(_sig(line), allow_nan=False, separators=(",", ":"))
+            if len(text) < LINE_LIMIT:
+                break
+    return text
+
+
+def emit(out):
+    """Write the full record to the detail file, print the compact line LAST on standard output."""
+    full = _finite(out)
+    detail_dir = os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else ROOT
+    path = os.path.join(detail_dir, "bench_detail.json")
+    rel = None
+    try:
+        with open(path, "w") as f:
+            json.dump(full, f, allow_nan=False, indent=1)
+        rel = os.path.relpath(path, ROOT)
+    except OSError:
+        pass
+    # (NOT echoed on standard error: the driver's record is a bounded tail of stdout AND stderr together)
+    print(f"bench.py: full record in {rel}" if rel else "bench.py: the detail file could not be written", file=sys.stderr)
+    sys.stderr.flush()
+    sys.stdout.flush()
+    print(compact_line(out, rel), flush=True)
 
 
 def main():
@@ -987,7 +1141,7 @@ def main():
     if rank == 0:
         if failed and "parity" in head and not head["parity"]["ok"]:
             out["value"] = None
-        print(json.dumps(out))
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

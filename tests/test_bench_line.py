@@ -1,0 +1,77 @@
+"""The ONE line bench.py prints for the driver (round 4's was 20.9 KB and the driver's record came back unparsed): built from a
+canned full record -- the round-4 record, tests/golden/bench_record_r04.json -- it has to be short, strict JSON, and carry the
+contract's keys with `roofline` and `cpu_baseline`."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline", "cpu_baseline")
+
+
+def _no_constants(name):
+    raise AssertionError(f"bare {name} in the JSON line")
+
+
+def _canned():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "bench_record_r04.json")))
+
+
+def test_line_is_short_strict_and_complete():
+    rec = _canned()
+    assert len(json.dumps(rec)) > 15000          # the canned record IS the long one
+    line = bench.compact_line(rec, "gpurun_out/bench_detail.json")
+    assert "\n" not in line and len(line) < bench.LINE_LIMIT
+    out = json.loads(line, parse_constant=_no_constants)
+    for k in CONTRACT:
+        assert k in out, k
+    assert out["value"] == float(f"{rec['value']:.6g}") and out["unit"] == "columns/s" and out["n_gpus"] == 1
+    r = out["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    c = out["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("reference", "port") and len(c["sample"]) <= 200
+    assert out["parity"]["ok"] is True
+    assert set(out["workloads"]) == set(rec["workloads"])
+    for name, w in out["workloads"].items():
+        assert w["parity_ok"] is True and w["value"] > 0 and 0 < w["frac"] < 1
+
+
+def test_non_finite_values_become_null():
+    rec = _canned()
+    rec["parity"]["max_rel_diff_vs_oracle"] = float("nan")
+    rec["roofline"]["traffic"] = float("inf")
+    rec["workloads"]["mcica_rrtmg"]["value"] = None
+    line = bench.compact_line(rec)
+    out = json.loads(line, parse_constant=_no_constants)
+    assert out["parity"]["max_rel_diff_vs_oracle"] is None and out["roofline"]["traffic"] is None
+    assert out["workloads"]["mcica_rrtmg"]["value"] is None
+
+
+def test_a_failed_workload_and_a_long_list_still_fit():
+    rec = _canned()
+    rec["workloads"]["broken"] = {"error": "RuntimeError: " + "x" * 5000}
+    for i in range(40):
+        rec["workloads"][f"extra_{i}"] = dict(rec["workloads"]["tripleclouds_ecckd32"])
+    line = bench.compact_line(rec)
+    assert len(line) < bench.LINE_LIMIT
+    out = json.loads(line, parse_constant=_no_constants)
+    assert "roofline" in out and "cpu_baseline" in out
+
+
+def test_multi_rank_keys_survive():
+    rec = _canned()
+    rec.update({"n_gpus": 8, "rccl_ranks": 8, "ms_per_step_ranks": {"min": 12.0, "max": 13.0}, "value_with_gather": 5.0e7,
+                "ms_per_step_with_gather": 16.0})
+    out = json.loads(bench.compact_line(rec))
+    assert out["rccl_ranks"] == 8 and out["ms_per_step_ranks"]["max"] == 13.0 and out["value_with_gather"] == 5.0e7
+
+
+def test_valu_figures_come_from_a_committed_profile():
+    v = bench.measured_valu("clear_homogeneous_ecckd32", ("sw_ica_kernel<float,", "sw_ica_kernel<FixedF,"))
+    assert v is not None and 0.0 < v["busy"] <= 1.0 and v["source"].startswith("profiles/") and os.path.exists(os.path.join(ROOT, v["source"]))

@@ -15,5 +15,6 @@ rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write -- python bench.py $ARGS > $OU
 rocprofv3 --pmc FETCH_SIZE -d $OUT/cal_fetch -o cal -- tools/hbm_calibrate > $OUT/cal_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/cal_write -o cal -- tools/hbm_calibrate > $OUT/cal_write.log 2>&1
 python bench.py --steps 10 --warmup 2 "$@" > $OUT/bench.json 2> $OUT/bench.err
+cp gpurun_out/bench_detail.json $OUT/bench_detail.json 2>/dev/null
 find $OUT -name "*.csv" | head -50
 tail -2 $OUT/bench.json
