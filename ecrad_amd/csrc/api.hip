@@ -95,6 +95,7 @@ struct ecrad_hip_handle_s {
   std::mutex pool_mutex;
   std::condition_variable pool_cv;
   int want_devices = 1, want_contexts = kDefaultContextsPerDevice;
+  int built_devices = 0, built_contexts = 0;     // what the pool was last built for (build_pool)
   int in_flight = 0, max_in_flight = 0;
   bool exclusive = false;                        // set-up (or a resize of the pool) holds every context
   std::vector<SmallCall*> small_waiting;          // small host-memory calls that have not been taken into a batch yet (arrival order)
@@ -151,9 +152,7 @@ struct ecrad_hip_handle_s {
   uint32_t gas_used = 0xffffffffu;           // bit k: gas%mixing_ratio(:,:,k+1) is read by some kernel of this configuration (set-up)
   size_t staged_in_last_call = 0, staged_out_last_call = 0;   // host-memory mode: bytes copied to / from the device by the most recent call
   size_t work_budget = 0;                     // bytes of per-call work arrays before a call is tiled; 0 = half of the device's memory
-  double stage_ms[4] = {0, 0, 0, 0};
-  bool timing_pending = false;
-  double last_ms = 0.0;
+  bool timing_pending = false;                // the stage events of the most recent call have not been read yet (resolve_timing)
 };
 
 namespace {
@@ -171,8 +170,21 @@ int fail(ecrad_hip_handle_t h, int code, const std::string& msg) {
   } while (0)
 
 // ---- the pool of contexts -------------------------------------------------------------------------------
-// the context this thread's most recent call ran on (what the timing / error queries of that thread refer to)
-thread_local ecrad_hip_handle_s* tl_last_context = nullptr;
+// What the timing / size / error queries of a thread answer from: a record of ITS most recent call on a handle, taken at the end
+// of that call while the call still held its context.  (Round 4 answered from the context itself, found through a thread-local
+// pointer: once the call had returned, the next call of another thread could already be rewriting that context's events,
+// error text and work arrays.)  A host-memory call is complete when it returns, so its stage times are resolved into the
+// record; a device-memory call is only enqueued -- its events are resolved at the first query, on the root context, which
+// device-memory calls are serialised on and whose stream order is the caller's.
+struct CallRecord {
+  const ecrad_hip_handle_s* root = nullptr;      // the handle the call was made on
+  ecrad_hip_handle_s* pending = nullptr;         // device-memory call: the context (the root) whose events are still to be read
+  std::string err;
+  int n_tiles = 0, tile_columns = 0;
+  size_t staged_in = 0, staged_out = 0, work_bytes = 0;
+  double stage_ms[4] = {0, 0, 0, 0}, last_ms = 0.0;
+};
+thread_local CallRecord tl_record;
 
 bool in_pool(ecrad_hip_handle_t root, const ecrad_hip_handle_s* c) {
   if (c == root) return true;
@@ -180,10 +192,54 @@ bool in_pool(ecrad_hip_handle_t root, const ecrad_hip_handle_s* c) {
   return false;
 }
 
-// the context a query of the calling thread is about: the one its last call ran on, the root otherwise
-ecrad_hip_handle_t query_context(ecrad_hip_handle_t h) {
-  ecrad_hip_handle_s* c = tl_last_context;
-  return (c && c != h && in_pool(h, c)) ? c : h;
+size_t held_bytes(const ecrad_hip_handle_s* h);
+
+// the stage times of the context's most recent call out of its events (the call's work must have been waited for, or the
+// caller accepts waiting here)
+int resolve_timing(ecrad_hip_handle_s* c, double stage_ms[4], double* total) {
+  for (int k = 0; k < 4; ++k) stage_ms[k] = 0.0;
+  *total = 0.0;
+  if (!c->timing_pending) return ECRAD_OK;
+  if (hipSetDevice(c->device) != hipSuccess) return ECRAD_EHIP;
+  for (int t = 0; t < c->tiles_last_call; ++t) {
+    const auto& ev = c->tile_events[t].e;
+    if (hipEventSynchronize(ev[4]) != hipSuccess) return ECRAD_EHIP;
+    float f = 0.f;
+    for (int k = 0; k < 4; ++k) {
+      if (hipEventElapsedTime(&f, ev[k], ev[k + 1]) != hipSuccess) return ECRAD_EHIP;
+      stage_ms[k] += f;
+      *total += f;
+    }
+  }
+  return ECRAD_OK;
+}
+
+// The record of the call that has just run on context `c` (still held by the caller).  complete: the call's work has been
+// waited for (host-memory mode).
+CallRecord take_record(ecrad_hip_handle_t root, ecrad_hip_handle_s* c, bool complete) {
+  CallRecord r;
+  r.root = root;
+  r.err = c->err;
+  r.n_tiles = c->tiles_last_call;
+  r.tile_columns = c->tile_columns_last_call;
+  r.staged_in = c->staged_in_last_call;
+  r.staged_out = c->staged_out_last_call;
+  r.work_bytes = held_bytes(c);
+  if (complete) {
+    (void)resolve_timing(c, r.stage_ms, &r.last_ms);
+    c->timing_pending = false;
+  } else if (c->timing_pending) {
+    r.pending = c;
+  }
+  return r;
+}
+
+// an error of a call that never got a context (bad arguments): the calling thread's record, not the shared root's text
+int fail_call(ecrad_hip_handle_t h, int code, const std::string& msg) {
+  tl_record = CallRecord{};
+  tl_record.root = h;
+  tl_record.err = msg;
+  return code;
 }
 
 void release_context_memory(ecrad_hip_handle_t h);
@@ -221,7 +277,6 @@ int new_context(ecrad_hip_handle_t root, int device, ecrad_hip_handle_s** out) {
   c->root = root;
   c->device = device;
   c->blocks_per_cu = root->blocks_per_cu;
-  c->work_budget = root->work_budget;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(root, ECRAD_EHIP, "cannot create a stream for a pool context"); }
@@ -238,19 +293,29 @@ int build_pool(ecrad_hip_handle_t root) {
   int ndev = root->want_devices <= 0 ? ndev_visible : std::min(root->want_devices, ndev_visible);
   ndev = std::min(ndev, kMaxPoolDevices);
   const int nctx = std::max(1, root->want_contexts);
-  const size_t want = (size_t)ndev * nctx;
-  if (root->pool.size() == want) return ECRAD_OK;
-  for (size_t k = 1; k < root->pool.size(); ++k) { release_context_memory(root->pool[k]); delete root->pool[k]; }
-  root->pool.assign(1, root);
+  // (the same SPLIT, not only the same product: 2 x 4 and then 1 x 8 is a different spread over the devices)
+  if (!root->pool.empty() && root->built_devices == ndev && root->built_contexts == nctx) return ECRAD_OK;
+  auto drop_contexts = [&] {
+    for (size_t k = 1; k < root->pool.size(); ++k) { release_context_memory(root->pool[k]); delete root->pool[k]; }
+    root->pool.assign(1, root);
+    root->built_devices = root->built_contexts = 0;
+  };
+  drop_contexts();
   for (int d = 0; d < ndev; ++d) {
     const int device = (root->device + d) % ndev_visible;
     for (int k = (d == 0 ? 1 : 0); k < nctx; ++k) {
       ecrad_hip_handle_s* c = nullptr;
       const int st = new_context(root, device, &c);
-      if (st) return st;
+      if (st) {      // no half-built pool: the root alone, on its own device
+        drop_contexts();
+        (void)hipSetDevice(root->device);
+        return st;
+      }
       root->pool.push_back(c);
     }
   }
+  root->built_devices = ndev;
+  root->built_contexts = nctx;
   (void)hipSetDevice(root->device);
   return ECRAD_OK;
 }
@@ -314,14 +379,12 @@ struct Lease {
     root->calls_total++;
     root->in_flight++;
     if (root->in_flight > root->max_in_flight) root->max_in_flight = root->in_flight;
-    tl_last_context = c;
   }
   ~Lease() {
     {
       std::lock_guard<std::mutex> lk(root->pool_mutex);
       c->busy = false;
       root->in_flight--;
-      if (c != root && !c->err.empty()) root->err = c->err;      // (a single-threaded caller asks the root)
     }
     root->pool_cv.notify_all();
   }
@@ -334,7 +397,6 @@ struct LeaseAll {
     std::unique_lock<std::mutex> lk(root->pool_mutex);
     root->pool_cv.wait(lk, [&] { return root->in_flight == 0 && !root->exclusive; });
     root->exclusive = true;
-    tl_last_context = root;
   }
   ~LeaseAll() {
     { std::lock_guard<std::mutex> lk(root->pool_mutex); root->exclusive = false; }
@@ -915,8 +977,15 @@ int ecrad_hip_set_stream(ecrad_hip_handle_t h, void* hip_stream) {
 
 const char* ecrad_hip_last_error(ecrad_hip_handle_t h) {
   if (!h) return "null handle";
-  const ecrad_hip_handle_t c = query_context(h);
-  return (c != h && !c->err.empty()) ? c->err.c_str() : h->err.c_str();
+  // the calling thread's own most recent call first; otherwise the root's text (set-up, the root context's calls) unless
+  // another thread's call is on the root context right now
+  if (tl_record.root == h && !tl_record.err.empty()) return tl_record.err.c_str();
+  thread_local std::string text;
+  {
+    std::lock_guard<std::mutex> lk(h->pool_mutex);
+    text = (h->busy || h->exclusive) ? std::string() : h->err;
+  }
+  return text.c_str();
 }
 
 }  // extern "C"
@@ -960,7 +1029,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
     for (size_t k = h->pool.size(); k-- > 1;) { release_context_memory(h->pool[k]); delete h->pool[k]; }
     h->pool.clear();
     release_context_memory(h);
-    if (tl_last_context) tl_last_context = nullptr;
+    if (tl_record.root == h) tl_record = CallRecord{};
   }
   delete h;
   return ECRAD_OK;
@@ -968,7 +1037,9 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
 
 int ecrad_hip_scratch_bytes(ecrad_hip_handle_t h, size_t* bytes) {
   if (!h || !bytes) return ECRAD_EINVAL;
-  *bytes = held_bytes(query_context(h));
+  if (tl_record.root == h) { *bytes = tl_record.work_bytes; return ECRAD_OK; }      // (of the context this thread's last call ran on)
+  std::lock_guard<std::mutex> lk(h->pool_mutex);
+  *bytes = h->busy ? 0 : held_bytes(h);
   return ECRAD_OK;
 }
 
@@ -1083,24 +1154,16 @@ int ecrad_hip_synchronize(ecrad_hip_handle_t h) {
 
 int ecrad_hip_last_kernel_ms(ecrad_hip_handle_t h, double* ms) {
   if (!h || !ms) return ECRAD_EINVAL;
-  h = query_context(h);      // the context this thread's last call ran on
-  if (h->timing_pending) {
-    HIP_TRY(h, hipSetDevice(h->device));
-    for (int k = 0; k < 4; ++k) h->stage_ms[k] = 0.0;
-    h->last_ms = 0.0;
-    for (int t = 0; t < h->tiles_last_call; ++t) {
-      const auto& ev = h->tile_events[t].e;
-      HIP_TRY(h, hipEventSynchronize(ev[4]));
-      float f = 0.f;
-      for (int k = 0; k < 4; ++k) {
-        HIP_TRY(h, hipEventElapsedTime(&f, ev[k], ev[k + 1]));
-        h->stage_ms[k] += f;
-        h->last_ms += f;
-      }
-    }
-    h->timing_pending = false;
+  CallRecord& r = tl_record;      // this thread's most recent call (see CallRecord)
+  if (r.root != h) { *ms = 0.0; return ECRAD_OK; }
+  if (r.pending) {                // a device-memory call: its events are read now (waits for them)
+    ecrad_hip_handle_s* const c = r.pending;
+    r.pending = nullptr;
+    if (resolve_timing(c, r.stage_ms, &r.last_ms) != ECRAD_OK) return fail_call(h, ECRAD_EHIP, "reading the stage events of the last call");
+    c->timing_pending = false;
+    (void)hipSetDevice(h->device);
   }
-  *ms = h->last_ms;
+  *ms = r.last_ms;
   return ECRAD_OK;
 }
 
@@ -1109,7 +1172,7 @@ int ecrad_hip_last_stage_ms(ecrad_hip_handle_t h, int which, double* ms) {
   double total;
   int st = ecrad_hip_last_kernel_ms(h, &total);
   if (st) return st;
-  *ms = h->stage_ms[which];
+  *ms = tl_record.root == h ? tl_record.stage_ms[which] : 0.0;
   return ECRAD_OK;
 }
 
@@ -2539,6 +2602,7 @@ struct SmallBatch {
                                     // variable is for callers that wait for a context, and wakes only those
   int status = ECRAD_OK;
   std::string err;
+  CallRecord record;                // what the queries of every member's thread answer from (taken by the leader, valid from phase 3 / 4)
   // layout, valid from phase 1
   Tile* tile = nullptr;
   StagedInputs mirror{};            // the page-locked mirror of the staged inputs (columns = ntot)
@@ -2649,7 +2713,7 @@ int batch_lead(ecrad_hip_handle_t root, SmallBatch& B, SmallCall& mine) {
   {
     std::unique_lock<std::mutex> lk(root->pool_mutex);
     B.status = st;
-    if (st) B.err = h->err;
+    if (st) { B.err = h->err; B.record = take_record(root, h, true); }
     B.phase = st ? 4 : 1;
     B.cv.notify_all();
     if (st) B.cv.wait(lk, [&] { return B.scattered == (int)B.calls.size() - 1; });
@@ -2685,6 +2749,7 @@ int batch_lead(ecrad_hip_handle_t root, SmallBatch& B, SmallCall& mine) {
     st = run();
     if (st && h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     if (!st) { h->tiles_last_call = 1; h->timing_pending = true; }
+    B.record = take_record(root, h, true);      // (the stream has been waited for: the stage events are complete)
     ms_device = ms_since(t_phase);
     t_phase = std::chrono::steady_clock::now();
     {
@@ -2740,15 +2805,14 @@ int radiation_small(ecrad_hip_handle_t root, int ncol, int nlev, int istartcol, 
       root->batched_calls_total += (long long)B.calls.size();
       root->in_flight += (int)B.calls.size();
       if (root->in_flight > root->max_in_flight) root->max_in_flight = root->in_flight;
-      tl_last_context = c;
       lk.unlock();
       if (B.calls.size() > 1) root->pool_cv.notify_all();      // (the members wait there until they see that they belong to a batch)
       const int st = batch_lead(root, B, me);
+      tl_record = B.record;      // (taken by batch_lead while it held the context)
       lk.lock();
       c->busy = false;
       c->small_batch = false;
       root->in_flight -= (int)B.calls.size();
-      if (st && c != root) root->err = c->err;
       lk.unlock();
       root->pool_cv.notify_all();
       return st;
@@ -2758,10 +2822,10 @@ int radiation_small(ecrad_hip_handle_t root, int ncol, int nlev, int istartcol, 
   // a member of somebody else's batch
   SmallBatch& L = *me.batch;
   ecrad_hip_handle_s* const ctx = L.ctx;
-  tl_last_context = ctx;
   L.cv.wait(lk, [&] { return L.phase >= 1; });
   if (L.phase == 4) {                                      // the batch could not be laid out (the leader has reported why)
     const int st = L.status;
+    tl_record = L.record;
     if (++L.scattered == (int)L.calls.size() - 1) L.cv.notify_all();      // (the leader waits for its members to have read this)
     return st;
   }
@@ -2774,6 +2838,7 @@ int radiation_small(ecrad_hip_handle_t root, int ncol, int nlev, int istartcol, 
   lk.unlock();
   if (!st) batch_scatter(ctx, L, me);
   lk.lock();
+  tl_record = L.record;      // (the leader took it before phase 3: the batch's times and sizes are every member's)
   // (the last thing this thread does with the batch, under the mutex: the batch lives on the leader's stack and the leader
   //  leaves when the count is full)
   if (++L.scattered == (int)L.calls.size()) L.cv.notify_all();
@@ -2792,7 +2857,8 @@ int radiation_on(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int ie
   const int nloc = iendcol - istartcol + 1;
   const bool host_mem = in->memory == ECRAD_MEM_HOST;
   const size_t per_col = work_bytes_per_column(h, nlev, in, flux);
-  size_t budget = h->work_budget;
+  size_t budget;
+  { std::lock_guard<std::mutex> lk(h->root->pool_mutex); budget = h->root->work_budget; }
   {
     // Default: half of the device's memory (144 GB of the MI355X's 288 GB: 100 000 RRTMG columns, 72 GB of work arrays,
     // then run as one tile instead of two, +2 %), and never more than 90 % of what is free now plus what this context
@@ -2858,8 +2924,8 @@ extern "C" {
 int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
                         const ecrad_inputs_t* in, ecrad_flux_t* flux) {
   if (!h || !in || !flux) return ECRAD_EINVAL;
-  if (in->memory != flux->memory) return fail(h, ECRAD_EINVAL, "inputs and fluxes must live in the same memory space");
-  if (ncol < 1 || nlev < 2 || istartcol < 1 || iendcol > ncol || iendcol < istartcol) return fail(h, ECRAD_EINVAL, "bad column/level range");
+  if (in->memory != flux->memory) return fail_call(h, ECRAD_EINVAL, "inputs and fluxes must live in the same memory space");
+  if (ncol < 1 || nlev < 2 || istartcol < 1 || iendcol > ncol || iendcol < istartcol) return fail_call(h, ECRAD_EINVAL, "bad column/level range");
   // a host-memory call is self-contained (copy in, kernels, copy out, wait): any free context of the pool, on any of its
   // devices, serves it; a device-memory call works on the caller's device arrays in the order of the caller's stream: the root
   if (in->memory == ECRAD_MEM_HOST && iendcol - istartcol + 1 <= std::min(packed_call_columns(), kMaxBatchColumns))
@@ -2867,28 +2933,33 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
   const Lease lease(h, in->memory == ECRAD_MEM_HOST);
   lease.c->err.clear();
   const int st = radiation_on(lease.c, ncol, nlev, istartcol, iendcol, in, flux);
+  tl_record = take_record(h, lease.c, in->memory == ECRAD_MEM_HOST);      // (while the context is still this call's)
   (void)hipSetDevice(h->device);      // (a context of another device may have changed the calling thread's current device)
   return st;
 }
 
 int ecrad_hip_set_work_bytes(ecrad_hip_handle_t h, size_t bytes) {
   if (!h || bytes == 0) return ECRAD_EINVAL;
+  // (the budget of the HANDLE: every context of the pool reads the root's value at the start of a call -- round 4 copied it
+  //  into the contexts when the pool was built, so a budget set after ecrad_hip_setup reached the root context only)
+  std::lock_guard<std::mutex> lk(h->pool_mutex);
   h->work_budget = bytes;
   return ECRAD_OK;
 }
 
 int ecrad_hip_last_call_info(ecrad_hip_handle_t h, ecrad_call_info_t* info) {
   if (!h || !info) return ECRAD_EINVAL;
-  h = query_context(h);
-  info->n_tiles = h->tiles_last_call;
-  info->tile_columns = h->tile_columns_last_call;
+  const CallRecord& r = tl_record;      // this thread's most recent call (zeros if it has made none on this handle)
+  const bool mine = r.root == h;
+  info->n_tiles = mine ? r.n_tiles : 0;
+  info->tile_columns = mine ? r.tile_columns : 0;
   info->launches_lw = h->cfg.do_lw ? h->nchunk_lw : 0;
   info->launches_sw = h->cfg.do_sw ? h->nchunk_sw : 0;
   info->lanes_lw = h->cfg.do_lw ? h->ngp_lw : 0;
   info->lanes_sw = h->cfg.do_sw ? h->ngp_sw : 0;
-  info->work_bytes = held_bytes(h);
-  info->staged_in_bytes = h->staged_in_last_call;
-  info->staged_out_bytes = h->staged_out_last_call;
+  info->work_bytes = mine ? r.work_bytes : 0;
+  info->staged_in_bytes = mine ? r.staged_in : 0;
+  info->staged_out_bytes = mine ? r.staged_out : 0;
   return ECRAD_OK;
 }
 

@@ -217,6 +217,9 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
         const int slot = cib * NGP + j;
         const int nq = quad_count<TAB, false>(nquad), npl = plain_count<TAB, false>(nplain);      // (constants for TAB = FixedF)
         constexpr int SKIPQ = SkipQuad<TAB, false>::value;
+        // (a layer's aerosol mixing ratios are requested with its gas-table loads: optics_device.h, aerosol_weight)
+        AerosolWeight aw = {0.0, false};
+        if (use_aerosols) aw = aerosol_weight(kernarg_block<SpectralArgs>().in, ord, col, lev, aer_type);
 #if !ECRAD_PIPELINE_LOADS
         gas_load<TAB, SKIPQ>(gh, nq, npl, L, slot, g, quads);
 #endif
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
         ECRAD_LAP(tm, 2, od);           // combine
         if (use_aerosols) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
-          const AerosolLayer al = aerosol_layer<false, NGP, ECRAD_LW_AER_BATCH(MODE)>(b.cfg, b.in, L, slot, col, lev, ib, aer_type);
+          const AerosolLayer al = aerosol_layer<false, NGP, ECRAD_LW_AER_BATCH(MODE)>(b.cfg, L, slot, ib, aw);
           od = od + al.od;   // radiation_aerosol_optics.F90:805-818 (no longwave aerosol scattering)
         }
         const LwCoef c = no_scattering_lw(od, planck_top, planck_bot);

@@ -320,6 +320,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void s
     SwSweepState st1{alb_dif, alb_dir * mu0}, st2{alb_dif, alb_dir * mu0};
 
     // ---- sweep 1: surface -> top: optics + two-stream + albedo/source recurrences ---------------
+    const LevelOrder ord_aer = level_order(kernarg_block<SpectralArgs>().in);      // (aerosol_weight: read once per column group)
     const int nchunk = (nlev + NGP - 1) / NGP;
     for (int ch = nchunk - 1; ch >= 0; --ch) {
       const int l0 = ch * NGP;
@@ -347,6 +348,9 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void s
           const int slot = cib * NGP + j;
           const int nq = quad_count<TAB, true>(nquad), npl = plain_count<TAB, true>(nplain);      // (constants for TAB = FixedF)
           constexpr int SKIPQ = SkipQuad<TAB, true>::value;
+          // (a layer's aerosol mixing ratios are requested with its gas-table loads: optics_device.h, aerosol_weight)
+          AerosolWeight aw = {0.0, false};
+          if (flags & SWF_AEROSOLS) aw = aerosol_weight(kernarg_block<SpectralArgs>().in, ord_aer, col, lev, aer_type);
           // gas optics: radiation_ecckd_interface.F90:256-281
 #if !ECRAD_PIPELINE_LOADS
           gas_load<TAB, SKIPQ>(gh, nq, npl, L, slot, g, quads);
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void s
           double asym = asym_staged;
           if (flags & SWF_AEROSOLS) {
             const SpectralArgs& b = kernarg_block<SpectralArgs>();
-            AerosolLayer al = aerosol_layer<true, NGP>(b.cfg, b.in, L, slot, col, lev, ib, aer_type);
+            AerosolLayer al = aerosol_layer<true, NGP>(b.cfg, L, slot, ib, aw);
             if (!(flags & SWF_DELTA_GASES)) delta_eddington_extensive_vec(al);
             merge_aerosol_sw(b.cfg, al, od, ssa, asym);
           }

@@ -109,6 +109,8 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
         const int slot = cib * NGP + j;
         const int nq = quad_count<TAB, false>(nquad);
         constexpr int SKIPQ = SkipQuad<TAB, false>::value;
+        AerosolWeight aw = {0.0, false};      // (requested with the gas-table loads: optics_device.h, aerosol_weight)
+        if (use_aerosols) aw = aerosol_weight(kernarg_block<SpectralArgs>().in, ord, col, lev, aer_type);
         gas_load<TAB, SKIPQ>(gh, nq, plain_count<TAB, false>(nplain), L, slot, g, quads);
         double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
         double od = gas_combine<TAB, SKIPQ>(nq, L, slot, quads);
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
         double ssa = 0.0, asym = 0.0;        // radiation_interface.F90:397-400: gases do not scatter
         if (use_aerosols) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
-          AerosolLayer al = aerosol_layer<false, NGP>(b.cfg, b.in, L, slot, col, lev, ib, aer_type);
+          AerosolLayer al = aerosol_layer<false, NGP>(b.cfg, L, slot, ib, aw);
           delta_eddington_extensive_vec(al);                       // radiation_aerosol_optics.F90:780-781
           const double local_od = od + al.od;                      // :783-797
           if (local_od > 0.0 && al.od > 0.0) {

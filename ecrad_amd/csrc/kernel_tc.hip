@@ -45,6 +45,11 @@
 #ifndef ECRAD_TC_MIN_WAVES
 #define ECRAD_TC_MIN_WAVES ECRAD_MIN_WAVES
 #endif
+#ifndef ECRAD_TC_AER_AHEAD
+// 1: a layer's aerosol mixing ratios are requested at the top of the layer's work, with the gas-table loads, instead of in a round
+// trip of their own after the gas optics (round 5; either way the level order comes from the column group's set-up: aerosol_weight)
+#define ECRAD_TC_AER_AHEAD 1
+#endif
 
 namespace ecrad {
 
@@ -163,7 +168,8 @@ struct TcSwScratch {
 ECRAD_DEV void tc_sw_up(const TcSwScratch& s, int set, int lev, int tid, const SwCoef& c, double A, double Ad,
                         double& A_new, double& Ad_new) {
   const double inv = frcp(1.0 - A * c.ref_diff);
-#if ECRAD_PACK_SW
+#if ECRAD_ABLATE & 8
+#elif ECRAD_PACK_SW
   packed5_store(s.base, s.rec(set, lev), tid,
                 pack5(c.trans_diff * inv, (c.trans_dir_dir * Ad * c.ref_diff + c.trans_dir_diff) * inv, c.trans_dir_dir, A, Ad));
 #else
@@ -280,6 +286,11 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
         const bool need_geo = cloudy.test(l) || (l > 0 && cloudy.test(l - 1));
         if (need_geo) feed1.issue(l);      // consumed after the gas and aerosol optics of this layer
         constexpr int SKIPQ = SkipQuad<TAB, true>::value;
+#if ECRAD_TC_AER_AHEAD
+        AerosolWeight aw = {0.0, false};
+        if (use_aerosols && !(sizeof(TAB) == 8 && kernarg_block<SpectralArgs>().in.gs.g_sw))      // (not when the RRTMG pass has merged them)
+          aw = aerosol_weight(kernarg_block<SpectralArgs>().in, ord, col, l, aer_type);
+#endif
         gas_load<TAB, SKIPQ>(gh, quad_count<TAB, true>(gh.nquad), plain_count<TAB, true>(gh.nplain), L, slot, g, quads);
         double od = gas_combine<TAB, SKIPQ>(quad_count<TAB, true>(gh.nquad), L, slot, quads);
         double ssa = 0.0;
@@ -301,7 +312,10 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
         }
         if (use_aerosols && !folded) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
-          AerosolLayer al = aerosol_layer<true, NGP>(b.cfg, b.in, L, slot, col, l, ib, aer_type);
+#if !ECRAD_TC_AER_AHEAD
+          const AerosolWeight aw = aerosol_weight(b.in, ord, col, l, aer_type);
+#endif
+          AerosolLayer al = aerosol_layer<true, NGP>(b.cfg, L, slot, ib, aw);
           if (!delta_gases) delta_eddington_extensive_vec(al);
           merge_aerosol_sw(b.cfg, al, od, ssa, asym);
         }
@@ -739,6 +753,11 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
         constexpr int SKIPQ = SkipQuad<TAB, false>::value;
+        const bool aer_here = use_aerosols && !kernarg_block<SpectralArgs>().in.gs.aer_folded_lw;
+#if ECRAD_TC_AER_AHEAD
+        AerosolWeight aw = {0.0, false};
+        if (aer_here) aw = aerosol_weight(kernarg_block<SpectralArgs>().in, ord, col, lev, aer_type);
+#endif
         gas_load<TAB, SKIPQ>(gh, quad_count<TAB, false>(gh.nquad), plain_count<TAB, false>(gh.nplain), L, slot, g, quads);
         double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
         double od = gas_combine<TAB, SKIPQ>(quad_count<TAB, false>(gh.nquad), L, slot, quads);
@@ -750,10 +769,13 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
           }
         }
         double ssa = 0.0, asym = 0.0;        // clear-region scattering properties (ASCAT only)
-        if (use_aerosols && !kernarg_block<SpectralArgs>().in.gs.aer_folded_lw) {
+        if (aer_here) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
+#if !ECRAD_TC_AER_AHEAD
+          const AerosolWeight aw = aerosol_weight(b.in, ord, col, lev, aer_type);
+#endif
           if (ASCAT) {                       // radiation_aerosol_optics.F90:778-797
-            AerosolLayer al = aerosol_layer<false, NGP>(b.cfg, b.in, L, slot, col, lev, ib, aer_type);
+            AerosolLayer al = aerosol_layer<false, NGP>(b.cfg, L, slot, ib, aw);
             delta_eddington_extensive_vec(al);
             const double local_od = od + al.od;
             if (local_od > 0.0 && al.od > 0.0) {
@@ -762,7 +784,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
               od = local_od;
             }
           } else {
-            od = od + aerosol_layer<false, NGP, ECRAD_TC_LW_AER_BATCH>(b.cfg, b.in, L, slot, col, lev, ib, aer_type).od;
+            od = od + aerosol_layer<false, NGP, ECRAD_TC_LW_AER_BATCH>(b.cfg, L, slot, ib, aw).od;
           }
         }
         const LwCoef c = ASCAT ? ref_trans_lw(od, ssa, asym, planck_top, planck_bot) : no_scattering_lw(od, planck_top, planck_bot);

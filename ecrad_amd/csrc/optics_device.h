@@ -518,29 +518,40 @@ ECRAD_DEV double row_bcast_k(double v, int k) {
   }
 }
 
+// The mixing ratio of the active aerosol type this lane fetches for its column group (lane k of every 16-lane row
+// fetches type k: ONE load instruction for all types; aerosol_layer broadcasts the products over the row).  Its own function
+// so that a kernel can request it at the TOP of a layer's work, next to the gas-table loads, instead of in a round trip of its
+// own between the gas and the aerosol optics (round 5); `ord` comes from the caller because level_order() reads the order flag
+// from global memory -- a vector load and a full wait per layer once the kernel has stored anything.
+struct AerosolWeight { double w; bool in_range; };
+ECRAD_DEV AerosolWeight aerosol_weight(const DevInputs& in, const LevelOrder& ord, int col, int lev, int lane_type) {
+  const int jlev = ord.full(lev) + 1;   // 1-based, in the caller's level order
+  if (jlev < in.aerosol_istartlev || jlev > in.aerosol_iendlev) return {0.0, false};
+  const size_t ncol = in.ncol;
+  const int nlev_aer = in.aerosol_iendlev - in.aerosol_istartlev + 1;
+  const size_t type_stride = ncol * (size_t)nlev_aer;
+  const double* __restrict__ mr0 = in.aerosol_mixing_ratio + col + ncol * (size_t)(jlev - in.aerosol_istartlev);
+  const double mr = lane_type >= 0 ? mr0[type_stride * (size_t)lane_type] : 0.0;
+  return {mr, true};
+}
+
 // KB_LW: types per batch of table loads on the absorption-only longwave path (what is best depends on
 // the register pressure of the calling kernel)
 template <bool IS_SW, int NGP, int KB_LW = 4>
-ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, const LdsLayout& L, int slot,
-                                     int col, int lev, int ib, int lane_type) {
+ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const LdsLayout& L, int slot, int ib, const AerosolWeight& aw) {
   AerosolLayer a = {0.0, 0.0, 0.0};
-  const int jlev = level_order(in).full(lev) + 1;   // 1-based, in the caller's level order
-  if (jlev < in.aerosol_istartlev || jlev > in.aerosol_iendlev) return a;
+  if (!aw.in_range) return a;
   const DevAerosolOptics& ao = cfg.aerosol;
   const int nb = IS_SW ? ao.n_bands_sw : ao.n_bands_lw;
   const double factor = L.D(F_DPG, slot);
   const int irh = L.I(I_RH, slot);
   const int rh_row = irh > 0 ? irh - 1 : 0;
-  const size_t ncol = in.ncol;
-  const int nlev_aer = in.aerosol_iendlev - in.aerosol_istartlev + 1;
-  const size_t type_stride = ncol * (size_t)nlev_aer;
-  const double* __restrict__ mr0 = in.aerosol_mixing_ratio + col + ncol * (size_t)(jlev - in.aerosol_istartlev);
   const int n = ao.nactive4;      // (whole groups of four types: the padding has weight zero)
   const bool scattering = IS_SW || cfg.do_lw_aerosol_scattering;
-  // The mixing ratios are per column: lane k of every 16-lane row of the column group fetches type k (ONE load
-  // instruction for all types), multiplies it by the layer mass, and the unrolled type loop broadcasts the product over
-  // the row with one DPP move per type (row_newbcast: the only DPP pattern that moves 64 bits at a time).
-  const double w_mine = factor * (lane_type >= 0 ? mr0[type_stride * (size_t)lane_type] : 0.0);
+  // The mixing ratios are per column: lane k of every 16-lane row of the column group has fetched type k, multiplies it by
+  // the layer mass, and the unrolled type loop broadcasts the product over the row with one DPP move per type (row_newbcast:
+  // the only DPP pattern that moves 64 bits at a time).
+  const double w_mine = factor * aw.w;
   if (!scattering) {
     // longwave absorption only (:655-662): one table value per type
     const double* __restrict__ tab = ao.lw_abs;
@@ -611,6 +622,13 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, 
     }
   }
   return a;
+}
+
+// (the layer's weight fetched on the spot: the callers that have nothing to overlap it with)
+template <bool IS_SW, int NGP, int KB_LW = 4>
+ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, const LdsLayout& L, int slot,
+                                     int col, int lev, int ib, int lane_type) {
+  return aerosol_layer<IS_SW, NGP, KB_LW>(cfg, L, slot, ib, aerosol_weight(in, level_order(in), col, lev, lane_type));
 }
 
 // delta_eddington_extensive_vec (radiation_delta_eddington.h:69-95); 1.0e-24 there is a

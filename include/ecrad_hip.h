@@ -428,8 +428,13 @@ int ecrad_hip_optics(ecrad_hip_handle_t handle, int ncol, int nlev, int istartco
 
 int ecrad_hip_synchronize(ecrad_hip_handle_t handle);
 
-/* Timing of the most recent ecrad_hip_radiation call, measured with HIP events on the handle's
-   stream: milliseconds spent in the kernels (excludes H2D/D2H staging). */
+/* Timing of the CALLING THREAD's most recent ecrad_hip_radiation call on this handle, measured with HIP events on the
+   stream of the context the call ran on: milliseconds spent in the kernels (excludes H2D/D2H staging).  This and the
+   other ecrad_hip_last_* queries (and ecrad_hip_scratch_bytes) answer from a record the call leaves with the thread that
+   made it -- taken while the call still held its context of the pool -- so they stay that call's whatever other threads
+   have run on the handle since; a thread that has made no call gets zeros.  A host-memory call is complete when it
+   returns and its times are in the record; a device-memory call is only enqueued and its events are read (and waited
+   for) by the first query -- make that query before the next device-memory call on the handle. */
 int ecrad_hip_last_kernel_ms(ecrad_hip_handle_t handle, double* ms);
 
 /* Same, per stage of the most recent call: which = ECRAD_STAGE_* (HIP events recorded on the
@@ -454,7 +459,7 @@ int ecrad_hip_hbm_triad(ecrad_hip_handle_t handle, size_t nbytes_per_array, int 
    host-memory call (ecrad_hip_radiation) cannot move its columns faster than this: measurement aid of bench.py. */
 int ecrad_hip_pcie_bandwidth(ecrad_hip_handle_t handle, size_t nbytes, int repeats, double* h2d_gbs, double* d2h_gbs, double* duplex_gbs);
 
-/* Bytes of device scratch currently held by the handle. */
+/* Bytes of device work arrays held by the context the calling thread's most recent call ran on (at the end of that call). */
 int ecrad_hip_scratch_bytes(ecrad_hip_handle_t handle, size_t* bytes);
 
 /* Device memory of a call.  Besides the caller's arrays a call needs work arrays that scale with the
@@ -463,7 +468,8 @@ int ecrad_hip_scratch_bytes(ecrad_hip_handle_t handle, size_t* bytes);
    stage arrays of the gas-optics pass + scalings + per-chunk partial profiles); in host-memory mode add
    the staged inputs and outputs (~50 KB).  ecrad_hip_radiation therefore processes istartcol..iendcol in
    TILES of columns (multiples of 256, at least 4096) such that these arrays stay within a budget --
-   half of the device memory by default, and never more than what is free (environment ECRAD_HIP_WORK_GIB), changed per handle with this call.  Results do not
+   half of the device memory by default, and never more than what is free (environment ECRAD_HIP_WORK_GIB), changed per handle with this call
+   -- at any time: every context of the handle's pool reads the handle's budget at the start of a call.  Results do not
    depend on the tiling. */
 int ecrad_hip_set_work_bytes(ecrad_hip_handle_t handle, size_t bytes);
 
@@ -478,6 +484,8 @@ typedef struct ecrad_call_info {
 } ecrad_call_info_t;
 int ecrad_hip_last_call_info(ecrad_hip_handle_t handle, ecrad_call_info_t* info);
 
+/* Text of the calling thread's most recent failed call on this handle; otherwise of the handle's set-up.  Valid until
+   the thread's next call into the library. */
 const char* ecrad_hip_last_error(ecrad_hip_handle_t handle);
 
 int ecrad_hip_destroy(ecrad_hip_handle_t handle);

@@ -242,3 +242,83 @@ def test_packed_single_tile_and_pipelined_host_calls_give_the_same_bits(solver):
     # a column no block covered still holds what the caller had put there
     assert packed.arrays["lw_up"][0, 0] == -77.0 and packed.arrays["lw_up"][0, 1000] == -77.0
     rad.close()
+
+
+@pytest.mark.gpu
+def test_work_budget_set_after_setup_reaches_every_context():
+    """ecrad_hip_set_work_bytes after ecrad_hip_setup (what ecrad_amd/interface.py and tests/test_hip_tiling.py do): a
+    host-memory call that lands on a context OTHER than the root is tiled by the same budget (round 4 copied the budget
+    into the contexts when the pool was built, so only the root saw a later value).  Two threads call at once on a pool of
+    two contexts: one of them necessarily runs on the second context; each asks ecrad_hip_last_call_info for ITS call."""
+    ncol = 9600
+    config = make_config("Tripleclouds")
+    inputs = make_columns(config, ncol, False)
+    n, nlev, sl, th, gas, cloud, aer = inputs
+    rad = Radiation(config, backend="hip", concurrency=(1, 2))
+    ref = Flux.allocate(config, n, nlev)
+    frac0 = cloud.fraction.copy()
+    os.environ["ECRAD_HIP_NO_PIPELINE"] = "1"      # (the pipeline would tile the call on its own)
+    try:
+        rad.radiation(n, nlev, 1, n, sl, th, gas, cloud, aer, ref)
+        info = abi.CallInfo()
+        rad.lib.ecrad_hip_last_call_info(rad.handle, C.byref(info))
+        assert info.n_tiles == 1
+        # a budget that holds 4 096 columns of work arrays and no more: three tiles
+        per_col = info.work_bytes / ncol
+        assert rad.lib.ecrad_hip_set_work_bytes(rad.handle, int(per_col * 4200)) == 0
+        from ecrad_amd.interface import build_flux_struct, build_inputs_struct
+        clouds = [type(cloud).__new__(type(cloud)) for _ in range(2)]
+        fluxes, tiles, errors = [Flux.allocate(config, n, nlev) for _ in range(2)], [None, None], []
+        for c in clouds:
+            c.__dict__.update(cloud.__dict__)
+            c.fraction = frac0.copy()
+        start = threading.Barrier(2)
+
+        def worker(k):
+            cin, keep = build_inputs_struct(config, n, nlev, sl, th, gas, clouds[k], aer)
+            cflux = build_flux_struct(fluxes[k])
+            start.wait()
+            if rad.lib.ecrad_hip_radiation(rad.handle, n, nlev, 1, n, C.byref(cin), C.byref(cflux)) != 0:
+                errors.append(rad.lib.ecrad_hip_last_error(rad.handle))
+                return
+            mine = abi.CallInfo()
+            rad.lib.ecrad_hip_last_call_info(rad.handle, C.byref(mine))
+            ms = C.c_double()
+            rad.lib.ecrad_hip_last_kernel_ms(rad.handle, C.byref(ms))
+            tiles[k] = (mine.n_tiles, mine.tile_columns, ms.value)
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        pool = rad.pool_info()
+        assert pool["max_in_flight"] == 2, pool            # the two calls did overlap: two contexts were in use
+        for k in range(2):
+            assert tiles[k][0] == 3 and tiles[k][1] == 4096 and tiles[k][2] > 0.0, tiles
+            _flux_equal(ref, fluxes[k])
+        # a thread that has made no call on the handle gets zeros, not another thread's record
+        seen = []
+        t = threading.Thread(target=lambda: (lambda i: (rad.lib.ecrad_hip_last_call_info(rad.handle, C.byref(i)), seen.append(i.n_tiles)))(abi.CallInfo()))
+        t.start()
+        t.join()
+        assert seen == [0]
+    finally:
+        os.environ.pop("ECRAD_HIP_NO_PIPELINE", None)
+        rad.close()
+
+
+@pytest.mark.gpu
+def test_pool_is_rebuilt_when_the_split_changes_at_the_same_size():
+    """ecrad_hip_set_concurrency(1, 4) then (1, 2) then back to (1, 4) -- and (2, 2) where there are two devices: the pool is
+    rebuilt for what was asked (round 4 compared the product of devices and contexts only)."""
+    import torch
+    config = make_config("Homogeneous", use_aerosols=False)
+    rad = Radiation(config, backend="hip", concurrency=(1, 4))
+    assert rad.pool_info()["n_contexts"] == 4 and rad.pool_info()["n_devices"] == 1
+    for ndev, nctx in ((1, 2), (1, 4)) + (((2, 2),) if torch.cuda.device_count() >= 2 else ()):
+        assert rad.lib.ecrad_hip_set_concurrency(rad.handle, ndev, nctx) == 0
+        rad._check(rad.lib.ecrad_hip_setup(rad.handle, C.byref(rad.cconfig)), "ecrad_hip_setup")      # (a new pool needs its tables)
+        info = rad.pool_info()
+        assert info["n_devices"] == ndev and info["n_contexts"] == ndev * nctx, info
+    rad.close()
