@@ -778,7 +778,10 @@ def pool_mode(args):
     from ecrad_amd.synthetic import make_columns
     from ecrad_amd.types import Flux
     ndev = args.gpus
-    if torch.cuda.device_count() < ndev:
+    # (ECRAD_HIP_FAKE_DEVICES=N, a TEST switch of the library: N device slots all mapped onto this box's GPU -- the dry run of
+    #  an N-GPU node's pool on a 1-GPU box, tests/test_bench_launcher.py; the line says so and its numbers mean nothing)
+    fake = int(os.environ.get("ECRAD_HIP_FAKE_DEVICES", "0") or 0)
+    if max(torch.cuda.device_count(), fake) < ndev:
         print(f"bench.py: --gpus {ndev} asked for, {torch.cuda.device_count()} GPU(s) visible on this node", file=sys.stderr)
         sys.exit(2)
     config, clear_sky, desc = build_config(args.workload)
@@ -848,6 +851,8 @@ def pool_mode(args):
                       "sw_solver": desc["sw_solver"], "threads_per_process": nthreads, "block_columns": nb,
                       "parallelism": f"blocks of columns spread over {ndev} GPU(s) by {nthreads} host threads of one process, no collective"},
            "pool": info, "blocks_identical_across_devices": bool(same)}
+    if fake:
+        out["test_fake_devices"] = f"{fake} device slots mapped onto one GPU (ECRAD_HIP_FAKE_DEVICES): exercises the pool's code, not a measurement"
     rad.close()
     del keep
     emit(out)
@@ -967,7 +972,7 @@ def compact_line(out, detail_path=None):
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
                                  "scaling", "vs_baseline", "dtype", "data", "config") if k in out}
     for k in ("ms_per_step_ranks", "value_with_gather", "ms_per_step_with_gather", "gathered", "mode", "test_shared_gpu",
-              "blocks_identical_across_devices"):
+              "test_fake_devices", "blocks_identical_across_devices", "pool"):
         if k in out:
             line[k] = out[k]
     if "roofline" in out:

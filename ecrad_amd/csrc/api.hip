@@ -102,7 +102,9 @@ struct ecrad_hip_handle_s {
   long long batches_total = 0, batched_calls_total = 0;
   long long calls_total = 0;
   // -- per context
-  int device = 0;
+  int device = 0;                                // the HIP device the context's streams and arrays live on
+  int slot = 0;                                  // the device SLOT of the pool it belongs to: the same as `device` unless
+                                                 // ECRAD_HIP_FAKE_DEVICES maps several slots onto one device (build_pool)
   hipStream_t stream = nullptr;
   bool own_stream = false;                       // `stream` was created by the pool (contexts other than the root)
   // host-memory mode: copy-in and copy-out streams of the tile pipeline, events per staging slot (see radiation_host_pipelined)
@@ -271,11 +273,12 @@ void unregister_handle(ecrad_hip_handle_s* h) {
   for (size_t i = 0; i < g_registry.size(); ++i) if (g_registry[i] == h) { g_registry.erase(g_registry.begin() + i); break; }
 }
 
-int new_context(ecrad_hip_handle_t root, int device, ecrad_hip_handle_s** out) {
+int new_context(ecrad_hip_handle_t root, int device, int slot, ecrad_hip_handle_s** out) {
   HIP_TRY(root, hipSetDevice(device));
   ecrad_hip_handle_s* c = new ecrad_hip_handle_s();
   c->root = root;
   c->device = device;
+  c->slot = slot;
   c->blocks_per_cu = root->blocks_per_cu;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
@@ -288,8 +291,15 @@ int new_context(ecrad_hip_handle_t root, int device, ecrad_hip_handle_s** out) {
 // Build (or rebuild) the pool for root->want_devices x root->want_contexts; the root is context 0 of its own device.
 // Called with no call in flight (ecrad_hip_setup holds every context).
 int build_pool(ecrad_hip_handle_t root) {
-  int ndev_visible = 0;
-  if (hipGetDeviceCount(&ndev_visible) != hipSuccess || ndev_visible <= 0) return fail(root, ECRAD_ENODEVICE, "no HIP device");
+  int ndev_real = 0;
+  if (hipGetDeviceCount(&ndev_real) != hipSuccess || ndev_real <= 0) return fail(root, ECRAD_ENODEVICE, "no HIP device");
+  // TEST SWITCH, ECRAD_HIP_FAKE_DEVICES=N (tests/test_hip_pool.py): the pool is laid out as on a node with N devices -- N
+  // device slots, each with its own contexts, its own upload of the tables, its own share of the calls -- but every slot is
+  // the root's one physical device.  What an 8-GPU node exercises of this file (per-device table upload, context -> device
+  // mapping, the spread of the calls) then runs on a 1-GPU box; its throughput means nothing.
+  int nfake = 0;
+  if (const char* e = std::getenv("ECRAD_HIP_FAKE_DEVICES")) nfake = std::max(0, std::min(std::atoi(e), kMaxPoolDevices));
+  const int ndev_visible = nfake > 0 ? nfake : ndev_real;
   int ndev = root->want_devices <= 0 ? ndev_visible : std::min(root->want_devices, ndev_visible);
   ndev = std::min(ndev, kMaxPoolDevices);
   const int nctx = std::max(1, root->want_contexts);
@@ -302,10 +312,12 @@ int build_pool(ecrad_hip_handle_t root) {
   };
   drop_contexts();
   for (int d = 0; d < ndev; ++d) {
-    const int device = (root->device + d) % ndev_visible;
+    const int slot = nfake > 0 ? d : (root->device + d) % ndev_visible;
+    const int device = nfake > 0 ? root->device : slot;
+    if (d == 0) root->slot = slot;
     for (int k = (d == 0 ? 1 : 0); k < nctx; ++k) {
       ecrad_hip_handle_s* c = nullptr;
-      const int st = new_context(root, device, &c);
+      const int st = new_context(root, device, slot, &c);
       if (st) {      // no half-built pool: the root alone, on its own device
         drop_contexts();
         (void)hipSetDevice(root->device);
@@ -327,11 +339,11 @@ ecrad_hip_handle_s* free_context(ecrad_hip_handle_t root) {
   int busy_on[kMaxPoolDevices] = {0};
   int dev_of[kMaxPoolDevices], ndev = 0;
   auto slot_of = [&](int device) { for (int i = 0; i < ndev; ++i) if (dev_of[i] == device) return i; dev_of[ndev] = device; return ndev++; };
-  for (ecrad_hip_handle_s* k : root->pool) { const int i = slot_of(k->device); if (k->busy) busy_on[i]++; }
+  for (ecrad_hip_handle_s* k : root->pool) { const int i = slot_of(k->slot); if (k->busy) busy_on[i]++; }
   ecrad_hip_handle_s* c = nullptr;
   int best = 1 << 30;
   for (ecrad_hip_handle_s* k : root->pool)
-    if (!k->busy && busy_on[slot_of(k->device)] < best) { best = busy_on[slot_of(k->device)]; c = k; }
+    if (!k->busy && busy_on[slot_of(k->slot)] < best) { best = busy_on[slot_of(k->slot)]; c = k; }
   return c;
 }
 
@@ -348,11 +360,11 @@ ecrad_hip_handle_s* free_context_for_small(ecrad_hip_handle_t root) {
   int small_on[kMaxPoolDevices] = {0}, busy_on[kMaxPoolDevices] = {0};
   int dev_of[kMaxPoolDevices], ndev = 0;
   auto slot_of = [&](int device) { for (int i = 0; i < ndev; ++i) if (dev_of[i] == device) return i; dev_of[ndev] = device; return ndev++; };
-  for (ecrad_hip_handle_s* k : root->pool) { const int i = slot_of(k->device); if (k->busy) busy_on[i]++; if (k->busy && k->small_batch) small_on[i]++; }
+  for (ecrad_hip_handle_s* k : root->pool) { const int i = slot_of(k->slot); if (k->busy) busy_on[i]++; if (k->busy && k->small_batch) small_on[i]++; }
   ecrad_hip_handle_s* c = nullptr;
   int best = 1 << 30;
   for (ecrad_hip_handle_s* k : root->pool) {
-    const int i = slot_of(k->device);
+    const int i = slot_of(k->slot);
     if (!k->busy && small_on[i] < small_slots() && busy_on[i] < best) { best = busy_on[i]; c = k; }
   }
   return c;
@@ -913,6 +925,7 @@ int ecrad_hip_create(ecrad_hip_handle_t* handle, int device_id) {
   ecrad_hip_handle_t h = new ecrad_hip_handle_s();
   h->root = h;
   h->device = device_id;
+  h->slot = device_id;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) h->num_cu = prop.multiProcessorCount;
   if (const char* e = std::getenv("ECRAD_HIP_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= 32) h->blocks_per_cu = v; }
@@ -949,8 +962,8 @@ int ecrad_hip_pool_info(ecrad_hip_handle_t h, ecrad_pool_info_t* info) {
   info->batches_total = h->batches_total;
   auto count = [&](const ecrad_hip_handle_s* c) {
     int i = 0;
-    while (i < info->n_devices && info->device_ids[i] != c->device) ++i;
-    if (i == info->n_devices) { if (i >= ECRAD_MAX_POOL_DEVICES) return; info->device_ids[i] = c->device; info->n_devices++; }
+    while (i < info->n_devices && info->device_ids[i] != c->slot) ++i;
+    if (i == info->n_devices) { if (i >= ECRAD_MAX_POOL_DEVICES) return; info->device_ids[i] = c->slot; info->n_devices++; }
     info->calls_on_device[i] += c->calls;
   };
   if (h->pool.empty()) count(h);
@@ -1413,7 +1426,7 @@ int ecrad_hip_setup(ecrad_hip_handle_t h, const ecrad_config_t* cp) {
   // one upload per device, by the first context of that device; the others take over its pointers
   for (ecrad_hip_handle_s* c : h->pool) {
     ecrad_hip_handle_s* owner = nullptr;
-    for (ecrad_hip_handle_s* k : h->pool) { if (k == c) break; if (k->device == c->device && k->table_owner == k) { owner = k; break; } }
+    for (ecrad_hip_handle_s* k : h->pool) { if (k == c) break; if (k->slot == c->slot && k->table_owner == k) { owner = k; break; } }
     if (owner) { adopt_tables(c, owner); continue; }
     if ((st = setup_one(c, cp))) {
       if (c != h) h->err = c->err;
@@ -2936,6 +2949,139 @@ int ecrad_hip_radiation(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol,
   tl_record = take_record(h, lease.c, in->memory == ECRAD_MEM_HOST);      // (while the context is still this call's)
   (void)hipSetDevice(h->device);      // (a context of another device may have changed the calling thread's current device)
   return st;
+}
+
+// ---- a single-precision host ------------------------------------------------------------------------------------------
+// The reference built with -DPARKIND1_SINGLE (ifsaux/parkind1.F90: jprb = real32, how the IFS runs) passes real32 arrays to
+// radiation() (radiation_interface.F90:200-251).  ecrad_hip_radiation_f32 takes the SAME structs with every `double*` member
+// pointing at float data.  The calling thread widens columns istartcol..iendcol -- and only those -- of every input into a
+// compact slab of its own (thread-local, reused from call to call), the call proper then runs on that slab as a call over
+// nloc columns (batched with whatever other small calls are waiting, or tiled, like any host-memory call), and the range
+// comes back narrowed into the caller's arrays: the cost per call is proportional to the columns of the call, nothing outside
+// the range is read or written, and concurrent callers share nothing.  (Round 4's Fortran wrapper converted whole ncol-sized
+// arrays through one copy pool per process inside an OpenMP critical section.)
+namespace {
+
+struct ConvJob { double* d; float* f; size_t rows, n, f_pitch; };      // rows of n reals: slab row k at d + k n, caller's row at f + k f_pitch
+
+void run_conv(const std::vector<ConvJob>& jobs, bool widen) {
+  size_t total = 0;
+  for (const ConvJob& j : jobs) total += j.rows * j.n;
+  auto work = [&](int t, int nt) {
+    size_t row_id = 0;
+    for (const ConvJob& j : jobs)
+      for (size_t k = 0; k < j.rows; ++k, ++row_id) {
+        if ((int)(row_id % (size_t)nt) != t) continue;
+        double* const d = j.d + k * j.n;
+        float* const f = j.f + k * j.f_pitch;
+        if (widen) for (size_t i = 0; i < j.n; ++i) d[i] = (double)f[i];
+        else for (size_t i = 0; i < j.n; ++i) f[i] = (float)d[i];
+      }
+  };
+  // (a block of a host model is a few thousand values per array: one thread; a call over 10^5 columns is gigabytes)
+  const int nt = total < (size_t)4 << 20 ? 1 : (int)std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency() / 2));
+  if (nt == 1) { work(0, 1); return; }
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; ++t) th.emplace_back(work, t, nt);
+  work(0, nt);
+  for (auto& x : th) x.join();
+}
+
+}  // namespace
+
+int ecrad_hip_radiation_f32(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
+                            const ecrad_inputs_t* in, ecrad_flux_t* flux) {
+  if (!h || !in || !flux) return ECRAD_EINVAL;
+  if (in->memory != ECRAD_MEM_HOST || flux->memory != ECRAD_MEM_HOST)
+    return fail_call(h, ECRAD_EUNSUPPORTED, "ecrad_hip_radiation_f32 takes host arrays (a single-precision HOST model)");
+  if (ncol < 1 || nlev < 2 || istartcol < 1 || iendcol > ncol || iendcol < istartcol) return fail_call(h, ECRAD_EINVAL, "bad column/level range");
+  if (!h->is_setup) return fail_call(h, ECRAD_ENOTSETUP, "ecrad_hip_setup has not been called");
+  if (!in->pressure_hl || !in->temperature_hl || !in->gas_mixing_ratio) return fail_call(h, ECRAD_EINVAL, "thermodynamics/gas arrays missing");
+  const ecrad_config_t& c = h->cfg;
+  if (c.do_clouds && (!in->cloud_fraction || in->n_cloud_types != c.n_cloud_types)) return fail_call(h, ECRAD_EINVAL, "cloud arrays missing");
+  if (c.use_aerosols && (in->aerosol_istartlev < 1 || in->aerosol_iendlev > nlev || in->aerosol_iendlev < in->aerosol_istartlev))
+    return fail_call(h, ECRAD_EINVAL, "aerosol level range");
+  const size_t n = (size_t)(iendcol - istartcol + 1), N = (size_t)ncol, L = (size_t)nlev, i0 = (size_t)(istartcol - 1);
+  const Range r{(int)n, nlev, 1, (int)n, (int)n};
+  // the slab: the staged-input layout of a call over n columns, then one array per flux field the caller asks for
+  const StagedInputs lay0 = carve_inputs(nullptr, c, *in, r);
+  size_t out_doubles = 0;
+  for (const FluxField& f : kFluxFields)
+    if (flux->*(f.host)) out_doubles += flux_rows(c, f.kind, nlev) * n;
+  thread_local std::vector<double> slab;
+  const size_t in_doubles = (lay0.bytes + 7) / 8;
+  if (slab.size() < in_doubles + out_doubles) slab.resize(in_doubles + out_doubles);
+  const StagedInputs s = carve_inputs(slab.data(), c, *in, r);
+  std::vector<ConvJob> jobs;
+  auto F = [](const double* p) { return reinterpret_cast<float*>(const_cast<double*>(p)); };      // (the members hold float data here)
+  // profiles (ncol, rows): the range is n of every row's ncol values
+  auto prof = [&](double* d, const double* src, size_t rows) { if (d && src && rows) jobs.push_back({d, F(src) + i0, rows, n, N}); };
+  prof(s.pressure_hl, in->pressure_hl, L + 1);
+  prof(s.temperature_hl, in->temperature_hl, L + 1);
+  prof(s.h2o_sat_liq, in->h2o_sat_liq, L);
+  prof(s.cos_sza, in->cos_sza, 1);
+  prof(s.skin_temperature, in->skin_temperature, 1);
+  prof(s.sw_albedo, in->sw_albedo, (size_t)in->n_sw_albedo);
+  prof(s.sw_albedo_direct, in->sw_albedo_direct, (size_t)in->n_sw_albedo);
+  prof(s.lw_emissivity, in->lw_emissivity, (size_t)in->n_lw_emissivity);
+  for (int k = 0; k < ECRAD_NMAXGASES; ++k)      // the planes some kernel reads (ecrad_hip_setup: gas_used)
+    if (h->gas_used & (1u << k)) jobs.push_back({s.gas_mixing_ratio + (size_t)k * L * n, F(in->gas_mixing_ratio) + (size_t)k * L * N + i0, L, n, N});
+  if (c.do_clouds) {
+    prof(s.cloud_fraction, in->cloud_fraction, L);
+    prof(s.cloud_mixing_ratio, in->cloud_mixing_ratio, L * in->n_cloud_types);
+    prof(s.cloud_effective_radius, in->cloud_effective_radius, L * in->n_cloud_types);
+    prof(s.cloud_fractional_std, in->cloud_fractional_std, L);
+    prof(s.cloud_overlap_param, in->cloud_overlap_param, L - 1);
+    prof(s.cloud_inv_cloud_effective_size, in->cloud_inv_cloud_effective_size, L);
+    prof(s.cloud_inv_inhom_effective_size, in->cloud_inv_inhom_effective_size, L);
+  }
+  if (c.use_aerosols)
+    prof(s.aerosol_mixing_ratio, in->aerosol_mixing_ratio, (size_t)(in->aerosol_iendlev - in->aerosol_istartlev + 1) * in->n_aerosol_types);
+  ecrad_inputs_t din = *in;
+  din.pressure_hl = s.pressure_hl; din.temperature_hl = s.temperature_hl; din.h2o_sat_liq = s.h2o_sat_liq;
+  din.cos_sza = in->cos_sza ? s.cos_sza : nullptr; din.skin_temperature = in->skin_temperature ? s.skin_temperature : nullptr;
+  din.sw_albedo = s.sw_albedo; din.sw_albedo_direct = s.sw_albedo_direct; din.lw_emissivity = s.lw_emissivity;
+  din.iseed = in->iseed ? in->iseed + i0 : nullptr;      // (integers: the caller's own, from the first column of the range)
+  din.gas_mixing_ratio = s.gas_mixing_ratio;
+  din.cloud_fraction = s.cloud_fraction; din.cloud_mixing_ratio = s.cloud_mixing_ratio;
+  din.cloud_effective_radius = s.cloud_effective_radius; din.cloud_fractional_std = s.cloud_fractional_std;
+  din.cloud_overlap_param = s.cloud_overlap_param; din.cloud_inv_cloud_effective_size = s.cloud_inv_cloud_effective_size;
+  din.cloud_inv_inhom_effective_size = s.cloud_inv_inhom_effective_size; din.aerosol_mixing_ratio = s.aerosol_mixing_ratio;
+  // RRTMG's per-band scaling of the solar spectrum is a small array without a column dimension: widened whole
+  thread_local std::vector<double> scaling;
+  if (in->spectral_solar_scaling) {
+    scaling.assign((size_t)c.n_bands_sw, 1.0);
+    for (int k = 0; k < c.n_bands_sw; ++k) scaling[k] = (double)F(in->spectral_solar_scaling)[k];
+    din.spectral_solar_scaling = scaling.data();
+  }
+  // the flux arrays of the slab; (rows, ncol) arrays -- per g-point, band, canopy interval -- are contiguous per column
+  ecrad_flux_t dfl = *flux;
+  std::vector<ConvJob> outs, ins_of_outputs;
+  double* cur = slab.data() + in_doubles;
+  for (const FluxField& f : kFluxFields) {
+    const double* const hp = flux->*(f.host);
+    if (!hp) continue;
+    const size_t rows = flux_rows(c, f.kind, nlev);
+    dfl.*(f.host) = cur;
+    ConvJob j;
+    if (f.kind == 0) j = {cur, F(hp) + i0, rows, n, N};
+    else if (f.kind >= 8) {      // (nspec, ncol, nlev+1)
+      const size_t nspec = f.kind == 8 ? (size_t)c.n_spec_lw : (size_t)c.n_spec_sw;
+      j = {cur, F(hp) + nspec * i0, L + 1, nspec * n, nspec * N};
+    } else j = {cur, F(hp) + rows * i0, 1, rows * n, rows * n};
+    outs.push_back(j);
+    // what the call reads of its outputs, or may leave as it finds it: the initial cloud cover (kind 7); spectral flux
+    // profiles, which a solver that does not compute them leaves alone (the reference's McICA never stores them)
+    if (f.kind == 7 || f.kind >= 8) ins_of_outputs.push_back(j);
+    cur += rows * n;
+  }
+  jobs.insert(jobs.end(), ins_of_outputs.begin(), ins_of_outputs.end());
+  run_conv(jobs, true);
+  const int st = ecrad_hip_radiation(h, (int)n, nlev, 1, (int)n, &din, &dfl);
+  if (st) return st;
+  if (c.do_clouds) outs.push_back({s.cloud_fraction, F(in->cloud_fraction) + i0, L, n, N});      // the crop_cloud_fraction side effect
+  run_conv(outs, false);
+  return ECRAD_OK;
 }
 
 int ecrad_hip_set_work_bytes(ecrad_hip_handle_t h, size_t bytes) {

@@ -14,6 +14,7 @@
 #ifndef ECRAD_QUAD_CACHE
 #define ECRAD_QUAD_CACHE 0
 #endif
+#include <cstdlib>
 #include "kernels_common.h"
 #include "optics_device.h"
 #include "launch.h"
@@ -181,7 +182,18 @@ ECRAD_DEV void tc_sw_up(const TcSwScratch& s, int set, int lev, int tid, const S
   Ad_new = c.ref_dir + (c.trans_dir_dir * Ad + c.trans_dir_diff * A) * c.trans_diff * inv;
 }
 
-template <typename TAB, int NGP>
+// FX: the CONFIGURATION at compile time, as FixedF is the table layout at compile time (round 5).  0: every switch read from the
+// configuration at run time.  1: the configuration of the reference's Tripleclouds test namelist (test/ifs/configCY49R1_ecckd.nam
+// with sw_solver_name = "Tripleclouds"; BASELINE's north-star shape and bench.py's tripleclouds_* workloads): clear-sky fluxes
+// wanted, aerosols on with 9-12 active types on every level, cloud and aerosol optics per g-point, no delta scaling with
+// gases, direct fluxes wanted, no spectral flux profiles (sw_tc_fixed_config below decides).  The uniform tests of all that, the
+// scalar registers that hold their operands and the basic-block boundaries they make disappear from the level loops.
+template <int FX> struct TcFixed {
+  static constexpr bool on = FX != 0;
+  static constexpr int nact4 = FX == 1 ? 12 : 0;
+};
+
+template <typename TAB, int NGP, int FX = 0>
 __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) void sw_tc_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
@@ -215,8 +227,8 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
     const int ib = cfg.i_band_from_reordered_g_sw[g] - 1;
     const int aer_type = aerosol_lane_type(cfg, glane);
     const double ray_g = m.rayleigh_molar_scat[g];
-    const bool do_clear = cfg.do_clear != 0;
-    const bool use_aerosols = cfg.use_aerosols != 0, delta_gases = cfg.do_sw_delta_scaling_with_gases != 0;
+    const bool do_clear = FX ? true : cfg.do_clear != 0;
+    const bool use_aerosols = FX ? true : cfg.use_aerosols != 0, delta_gases = FX ? false : cfg.do_sw_delta_scaling_with_gases != 0;
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
     const int cloc = ordered_column(kernarg_block<SpectralArgs>().in, col_ok ? cloc_raw : ncol_loc - 1);
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
 #if ECRAD_TC_AER_AHEAD
         AerosolWeight aw = {0.0, false};
         if (use_aerosols && !(sizeof(TAB) == 8 && kernarg_block<SpectralArgs>().in.gs.g_sw))      // (not when the RRTMG pass has merged them)
-          aw = aerosol_weight(kernarg_block<SpectralArgs>().in, ord, col, l, aer_type);
+          aw = aerosol_weight<FX != 0>(kernarg_block<SpectralArgs>().in, ord, col, l, aer_type);
 #endif
         gas_load<TAB, SKIPQ>(gh, quad_count<TAB, true>(gh.nquad), plain_count<TAB, true>(gh.nplain), L, slot, g, quads);
         double od = gas_combine<TAB, SKIPQ>(quad_count<TAB, true>(gh.nquad), L, slot, quads);
@@ -315,9 +327,9 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
 #if !ECRAD_TC_AER_AHEAD
           const AerosolWeight aw = aerosol_weight(b.in, ord, col, l, aer_type);
 #endif
-          AerosolLayer al = aerosol_layer<true, NGP>(b.cfg, L, slot, ib, aw);
+          AerosolLayer al = aerosol_layer<true, NGP, 4, TcFixed<FX>::nact4>(b.cfg, L, slot, ib, aw);
           if (!delta_gases) delta_eddington_extensive_vec(al);
-          merge_aerosol_sw(b.cfg, al, od, ssa, asym);
+          merge_aerosol_sw<FX ? 1 : -1>(b.cfg, al, od, ssa, asym);
         }
         double below[3] = {0.0, 0.0, 0.0}, belowd[3] = {0.0, 0.0, 0.0};
         {
@@ -417,7 +429,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
 #endif
     // sums over g of the fluxes at half level hl, kept by lane (hl mod NGP) and written NGP levels at a time
     auto emit = [&](int hl) {
-      if (fx.sw_up_band && valid) {     // spectral flux profiles: sums over the regions per g-point (:485-498, :611-625)
+      if (!FX && fx.sw_up_band && valid) {     // spectral flux profiles: sums over the regions per g-point (:485-498, :611-625)
         const size_t o = col + ncol * ord.half(hl);
         const double dir = mu0 * (ddn[0] + ddn[1] + ddn[2]);
         spec_put(fx.sw_up_band, ng, g, o, fup[0] + fup[1] + fup[2]);
@@ -472,11 +484,11 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
           const size_t o = col + ncol * ord.half(lv);
           fx.sw_up[o] = kept.v[0];
           fx.sw_dn[o] = mu0 * kept.v[2] + kept.v[1];
-          if (fx.sw_dn_direct) fx.sw_dn_direct[o] = mu0 * kept.v[2];
+          if (FX || fx.sw_dn_direct) fx.sw_dn_direct[o] = mu0 * kept.v[2];
           if (do_clear) {
             fx.sw_up_clear[o] = kept.v[3];
             fx.sw_dn_clear[o] = mu0 * kept.v[5] + kept.v[4];
-            if (fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[o] = mu0 * kept.v[5];
+            if (FX || fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[o] = mu0 * kept.v[5];
           }
         }
       }
@@ -602,13 +614,30 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
 
 size_t sw_tc_scratch_doubles(int nlev) { return (size_t)4 * (ECRAD_PACK_SW ? 4 : 5) * nlev * kBlock; }
 
+#ifndef ECRAD_TC_FIXED_CONFIG
+#define ECRAD_TC_FIXED_CONFIG 1      // 0: never take the FX = 1 instantiations (A/B switch; tests compare the two)
+#endif
+// does this call have the configuration that sw_tc_kernel<..., 1> is compiled for?
+static bool sw_tc_fixed_config(const DevConfig& cfg, const DevInputs& in, const DevFlux& fx) {
+  if (!ECRAD_TC_FIXED_CONFIG || std::getenv("ECRAD_HIP_NO_FIXED_CONFIG")) return false;
+  return cfg.do_clear && cfg.use_aerosols && !cfg.do_sw_delta_scaling_with_gases && cfg.do_cloud_aerosol_per_sw_g_point &&
+         cfg.aerosol.nactive4 == TcFixed<1>::nact4 && in.aerosol_istartlev == 1 && in.aerosol_iendlev == in.nlev &&
+         fx.sw_dn_direct && fx.sw_dn_direct_clear && !fx.sw_up_band && !in.gs.od_sw;
+}
+
 hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block,
                         int* counter, const DevCkdModel& m, int g0) {
   const SpectralArgs args{cfg, in, fx, prep, scratch, per_block, counter, m.hot, g0, 0};
 #define ECRAD_L(T, N) do { ECRAD_ALLOW_LDS((sw_tc_kernel<T, N>), lds); hipLaunchKernelGGL((sw_tc_kernel<T, N>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
   if (in.gs.od_sw) { if (ngp == 16) ECRAD_L(StageD, 16); else if (ngp == 32) ECRAD_L(StageD, 32); else ECRAD_L(StageD, 64); }      // (RRTMG spectra: no tables, kernels_common.h)
-  else if (model_has_std_quads(m)) { if (ngp == 16) ECRAD_L(FixedF, 16); else if (ngp == 32) ECRAD_L(FixedF, 32); else ECRAD_L(FixedF, 64); }
+  else if (model_has_std_quads(m)) {
+    if (sw_tc_fixed_config(cfg, in, fx)) {
+#define ECRAD_LF(N) do { ECRAD_ALLOW_LDS((sw_tc_kernel<FixedF, N, 1>), lds); hipLaunchKernelGGL((sw_tc_kernel<FixedF, N, 1>), dim3(grid), dim3(kBlock), lds, st, args); } while (0)
+      if (ngp == 16) ECRAD_LF(16); else if (ngp == 32) ECRAD_LF(32); else ECRAD_LF(64);
+#undef ECRAD_LF
+    } else { if (ngp == 16) ECRAD_L(FixedF, 16); else if (ngp == 32) ECRAD_L(FixedF, 32); else ECRAD_L(FixedF, 64); }
+  }
   else if (table_f32) { if (ngp == 16) ECRAD_L(float, 16); else if (ngp == 32) ECRAD_L(float, 32); else ECRAD_L(float, 64); }
   else { if (ngp == 16) ECRAD_L(double, 16); else if (ngp == 32) ECRAD_L(double, 32); else ECRAD_L(double, 64); }
 #undef ECRAD_L

@@ -524,9 +524,10 @@ ECRAD_DEV double row_bcast_k(double v, int k) {
 // own between the gas and the aerosol optics (round 5); `ord` comes from the caller because level_order() reads the order flag
 // from global memory -- a vector load and a full wait per layer once the kernel has stored anything.
 struct AerosolWeight { double w; bool in_range; };
+template <bool ALL_LEVELS = false>      // (true: aerosol%istartlev = 1, iendlev = nlev, known to the caller's instantiation)
 ECRAD_DEV AerosolWeight aerosol_weight(const DevInputs& in, const LevelOrder& ord, int col, int lev, int lane_type) {
   const int jlev = ord.full(lev) + 1;   // 1-based, in the caller's level order
-  if (jlev < in.aerosol_istartlev || jlev > in.aerosol_iendlev) return {0.0, false};
+  if (!ALL_LEVELS && (jlev < in.aerosol_istartlev || jlev > in.aerosol_iendlev)) return {0.0, false};
   const size_t ncol = in.ncol;
   const int nlev_aer = in.aerosol_iendlev - in.aerosol_istartlev + 1;
   const size_t type_stride = ncol * (size_t)nlev_aer;
@@ -537,16 +538,18 @@ ECRAD_DEV AerosolWeight aerosol_weight(const DevInputs& in, const LevelOrder& or
 
 // KB_LW: types per batch of table loads on the absorption-only longwave path (what is best depends on
 // the register pressure of the calling kernel)
-template <bool IS_SW, int NGP, int KB_LW = 4>
+// NACT4 > 0: the number of active types (rounded up to four) is that compile-time constant and every layer has aerosols
+// (a kernel instantiated for one configuration: no test per batch of types, no test of the level range)
+template <bool IS_SW, int NGP, int KB_LW = 4, int NACT4 = 0>
 ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const LdsLayout& L, int slot, int ib, const AerosolWeight& aw) {
   AerosolLayer a = {0.0, 0.0, 0.0};
-  if (!aw.in_range) return a;
+  if (NACT4 == 0 && !aw.in_range) return a;
   const DevAerosolOptics& ao = cfg.aerosol;
   const int nb = IS_SW ? ao.n_bands_sw : ao.n_bands_lw;
   const double factor = L.D(F_DPG, slot);
   const int irh = L.I(I_RH, slot);
   const int rh_row = irh > 0 ? irh - 1 : 0;
-  const int n = ao.nactive4;      // (whole groups of four types: the padding has weight zero)
+  const int n = NACT4 > 0 ? NACT4 : ao.nactive4;      // (whole groups of four types: the padding has weight zero)
   const bool scattering = IS_SW || cfg.do_lw_aerosol_scattering;
   // The mixing ratios are per column: lane k of every 16-lane row of the column group has fetched type k, multiplies it by
   // the layer mass, and the unrolled type loop broadcasts the product over the row with one DPP move per type (row_newbcast:
@@ -588,6 +591,9 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const LdsLayout& L, i
 #ifndef ECRAD_AEROSOL_BATCH
 #define ECRAD_AEROSOL_BATCH 4
 #endif
+#ifndef ECRAD_AER_SCHED_BARRIER
+#define ECRAD_AER_SCHED_BARRIER 1
+#endif
   constexpr int kBatch = ECRAD_AEROSOL_BATCH;
 #pragma unroll
   for (int k0 = 0; k0 < kMaxActiveAerosols; k0 += kBatch) {
@@ -619,6 +625,11 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const LdsLayout& L, i
           a.scat_g = a.scat_g + local_od * t01[u].y * t2[u];
         }
       }
+#if ECRAD_AER_SCHED_BARRIER
+      // (a compile-time number of types leaves no branch between the batches: without a fence the scheduler requests the
+      //  rows of ALL the types at once -- 72 registers -- and spills)
+      if (NACT4 > 0) __builtin_amdgcn_sched_barrier(0);
+#endif
     }
   }
   return a;
@@ -642,8 +653,9 @@ ECRAD_DEV void delta_eddington_extensive_vec(AerosolLayer& a) {
 }
 
 // Merge aerosol into the gas SW properties: radiation_aerosol_optics.F90:739-770
+template <int PER_G = -1>      // (1 / 0: do_cloud_aerosol_per_sw_g_point known at compile time)
 ECRAD_DEV void merge_aerosol_sw(const DevConfig& cfg, const AerosolLayer& a, double& od, double& ssa, double& g) {
-  if (cfg.do_cloud_aerosol_per_sw_g_point) {
+  if (PER_G >= 0 ? PER_G != 0 : cfg.do_cloud_aerosol_per_sw_g_point != 0) {
     const double local_scat = ssa * od + a.scat;
     od = od + a.od;
     g = fdiv(a.scat_g, dmax(local_scat, 1.0e-24));

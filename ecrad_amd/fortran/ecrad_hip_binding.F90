@@ -181,6 +181,16 @@ module ecrad_hip_binding
       type(ecrad_flux_t), intent(inout) :: flux
       integer(c_int) :: status
     end function
+    ! ... for a single-precision host: the same structs whose real arrays are real32 (include/ecrad_hip.h)
+    function ecrad_hip_radiation_f32(handle, ncol, nlev, istartcol, iendcol, inputs, flux) &
+         &  bind(C, name='ecrad_hip_radiation_f32') result(status)
+      import :: c_ptr, c_int, ecrad_inputs_t, ecrad_flux_t
+      type(c_ptr), value    :: handle
+      integer(c_int), value :: ncol, nlev, istartcol, iendcol
+      type(ecrad_inputs_t), intent(in)  :: inputs
+      type(ecrad_flux_t), intent(inout) :: flux
+      integer(c_int) :: status
+    end function
     ! the pool of (device, stream, work arrays) contexts that concurrent calls are spread over (include/ecrad_hip.h)
     function ecrad_hip_set_concurrency(handle, n_devices, contexts_per_device) bind(C, name='ecrad_hip_set_concurrency') result(status)
       import :: c_ptr, c_int

@@ -46,9 +46,16 @@ module radiation_hip_interface
     module procedure locd1, locd2, locd3, locd4
   end interface
 
+  ! c_loc of an allocatable real array of a CALL (c_null_ptr when not allocated): never a copy, whatever jprb is
+  interface locr
+    module procedure locr1, locr2, locr3
+  end interface
+
   ! Single-precision hosts (the reference built with -DPARKIND1_SINGLE: jprb = real32, as the IFS runs operationally).  The
-  ! library's arrays are binary64, so in such a build every real array that crosses the boundary does so as a double copy:
-  ! tables once at set-up, the inputs of a call on the way in, the fluxes (and the cropped cloud fraction) on the way out.
+  ! library's TABLES are binary64, so in such a build every table crosses the boundary as a double copy, once, at set-up
+  ! (dloc / finish_copies below; set-up is not concurrent).  The arrays of a CALL are not copied here at all: radiation_hip
+  ! hands the host's real32 arrays to ecrad_hip_radiation_f32, which widens the columns of the call on the library's side
+  ! (round 4 converted whole ncol-sized arrays here, inside an OpenMP critical section).
   ! The two-stream / adding arithmetic on the device stays double -- more accurate than the host's own single-precision
   ! path, not less -- and the SPARTACUS solvers run in float as the reference's single-precision build does
   ! (ecrad_config_t::i_precision).  In a double-precision build dloc() is c_loc(): nothing is copied.
@@ -56,12 +63,10 @@ module radiation_hip_interface
     real(c_double), allocatable :: d(:)
     type(c_ptr) :: src = c_null_ptr       ! the host's own array
     integer(c_size_t) :: n = 0
-    logical :: write_back = .false.
   end type
   integer, parameter :: max_copies = 256
   type(dcopy), save, target :: pool(max_copies)
   integer, save :: npool = 0
-  logical, save :: outputs_from_here = .false.
 
 contains
 
@@ -90,29 +95,48 @@ contains
     if (allocated(pool(npool)%d)) deallocate(pool(npool)%d)
     allocate(pool(npool)%d(n))
     pool(npool)%d = real(f, c_double)
-    pool(npool)%src = src; pool(npool)%n = n; pool(npool)%write_back = outputs_from_here
+    pool(npool)%src = src; pool(npool)%n = n
     p = c_loc(pool(npool)%d)
 #else
     p = src
 #endif
   end function dloc
 
-  ! after a call: what the library wrote goes back to the host's arrays; then the copies are dropped
+  ! after set-up: the library holds its own copies of every table, the double copies made here are dropped
   subroutine finish_copies()
 #ifdef PARKIND1_SINGLE
-    real(jprb), pointer :: f(:)
     integer :: k
     do k = 1, npool
-      if (pool(k)%write_back) then
-        call c_f_pointer(pool(k)%src, f, [pool(k)%n])
-        f = real(pool(k)%d, jprb)
-      end if
       deallocate(pool(k)%d)
     end do
 #endif
     npool = 0
-    outputs_from_here = .false.
   end subroutine finish_copies
+
+  function locr1(a) result(p)
+    real(jprb), allocatable, target, intent(in) :: a(:)
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (allocated(a)) then
+      if (size(a) > 0) p = c_loc(a)
+    end if
+  end function
+  function locr2(a) result(p)
+    real(jprb), allocatable, target, intent(in) :: a(:,:)
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (allocated(a)) then
+      if (size(a) > 0) p = c_loc(a)
+    end if
+  end function
+  function locr3(a) result(p)
+    real(jprb), allocatable, target, intent(in) :: a(:,:,:)
+    type(c_ptr) :: p
+    p = c_null_ptr
+    if (allocated(a)) then
+      if (size(a) > 0) p = c_loc(a)
+    end if
+  end function
 
   function locd1(a) result(p)
     real(jprb), allocatable, target, intent(in) :: a(:)
@@ -359,84 +383,73 @@ contains
     if (.not. c_associated(hip_handle)) call radiation_hip_abort('*** Error: setup_radiation_hip not called')
     ! radiation() is called from an OpenMP PARALLEL DO over blocks of columns in the reference's driver
     ! (driver/ecrad_driver.F90:348) and from the IFS's threads: everything below is local to the call, and the library runs
-    ! concurrent calls side by side on the contexts of its pool.  (A single-precision host converts through the module's
-    ! copy pool, which is one per process: those builds take the calls one at a time.)
-#ifdef PARKIND1_SINGLE
-    !$omp critical (ecrad_hip_radiation_call)
-#endif
+    ! concurrent calls side by side on the contexts of its pool -- in a single-precision build too: the host's real32 arrays
+    ! go to the library as they are (ecrad_hip_radiation_f32 widens the columns of the call, and only those, on its side).
     cin%memory = ECRAD_MEM_HOST
     cin%solar_irradiance = single_level%solar_irradiance
     cin%spectral_solar_cycle_multiplier = single_level%spectral_solar_cycle_multiplier
-    cin%pressure_hl = locd(thermodynamics%pressure_hl); cin%temperature_hl = locd(thermodynamics%temperature_hl)
-    cin%h2o_sat_liq = locd(thermodynamics%h2o_sat_liq)
-    cin%cos_sza = locd(single_level%cos_sza); cin%skin_temperature = locd(single_level%skin_temperature)
+    cin%pressure_hl = locr(thermodynamics%pressure_hl); cin%temperature_hl = locr(thermodynamics%temperature_hl)
+    cin%h2o_sat_liq = locr(thermodynamics%h2o_sat_liq)
+    cin%cos_sza = locr(single_level%cos_sza); cin%skin_temperature = locr(single_level%skin_temperature)
     cin%n_sw_albedo = 0; cin%n_lw_emissivity = 0
     if (allocated(single_level%sw_albedo)) cin%n_sw_albedo = size(single_level%sw_albedo, 2)
     if (allocated(single_level%lw_emissivity)) cin%n_lw_emissivity = size(single_level%lw_emissivity, 2)
-    cin%sw_albedo = locd(single_level%sw_albedo); cin%sw_albedo_direct = locd(single_level%sw_albedo_direct)
-    cin%lw_emissivity = locd(single_level%lw_emissivity)
+    cin%sw_albedo = locr(single_level%sw_albedo); cin%sw_albedo_direct = locr(single_level%sw_albedo_direct)
+    cin%lw_emissivity = locr(single_level%lw_emissivity)
     cin%iseed = loci(single_level%iseed)
     ! radiation_ifs_rrtm.F90:545-551: the per-band scaling of the RRTMG solar spectrum (the IFS's NSOLARSPECTRUM)
     cin%spectral_solar_scaling = c_null_ptr
     if (config%use_spectral_solar_scaling .and. allocated(single_level%spectral_solar_scaling)) &
-         &  cin%spectral_solar_scaling = locd(single_level%spectral_solar_scaling)
-    cin%gas_mixing_ratio = locd(gas%mixing_ratio)
+         &  cin%spectral_solar_scaling = locr(single_level%spectral_solar_scaling)
+    cin%gas_mixing_ratio = locr(gas%mixing_ratio)
     cin%n_cloud_types = 0; cin%n_aerosol_types = 0; cin%aerosol_istartlev = 1; cin%aerosol_iendlev = 0; cin%reserved_ = 0
     if (config%do_clouds) then
       cin%n_cloud_types = cloud%ntype
-#ifdef PARKIND1_SINGLE
-      outputs_from_here = .true.      ! (intent(inout): the crop_cloud_fraction side effect)
-#endif
-      cin%cloud_fraction = locd(cloud%fraction)
-#ifdef PARKIND1_SINGLE
-      outputs_from_here = .false.
-#endif
-      cin%cloud_mixing_ratio = locd(cloud%mixing_ratio)
-      cin%cloud_effective_radius = locd(cloud%effective_radius)
-      cin%cloud_fractional_std = locd(cloud%fractional_std); cin%cloud_overlap_param = locd(cloud%overlap_param)
-      cin%cloud_inv_cloud_effective_size = locd(cloud%inv_cloud_effective_size)
-      cin%cloud_inv_inhom_effective_size = locd(cloud%inv_inhom_effective_size)
+      cin%cloud_fraction = locr(cloud%fraction)      ! (intent(inout): the crop_cloud_fraction side effect)
+      cin%cloud_mixing_ratio = locr(cloud%mixing_ratio)
+      cin%cloud_effective_radius = locr(cloud%effective_radius)
+      cin%cloud_fractional_std = locr(cloud%fractional_std); cin%cloud_overlap_param = locr(cloud%overlap_param)
+      cin%cloud_inv_cloud_effective_size = locr(cloud%inv_cloud_effective_size)
+      cin%cloud_inv_inhom_effective_size = locr(cloud%inv_inhom_effective_size)
     end if
     if (config%use_aerosols) then
       cin%n_aerosol_types = size(aerosol%mixing_ratio, 3)
       cin%aerosol_istartlev = aerosol%istartlev; cin%aerosol_iendlev = aerosol%iendlev
-      cin%aerosol_mixing_ratio = locd(aerosol%mixing_ratio)
+      cin%aerosol_mixing_ratio = locr(aerosol%mixing_ratio)
     end if
     cfl%memory = ECRAD_MEM_HOST; cfl%reserved_ = 0
+    cfl%lw_up = locr(flux%lw_up); cfl%lw_dn = locr(flux%lw_dn); cfl%sw_up = locr(flux%sw_up); cfl%sw_dn = locr(flux%sw_dn)
+    cfl%sw_dn_direct = locr(flux%sw_dn_direct); cfl%lw_up_clear = locr(flux%lw_up_clear); cfl%lw_dn_clear = locr(flux%lw_dn_clear)
+    cfl%sw_up_clear = locr(flux%sw_up_clear); cfl%sw_dn_clear = locr(flux%sw_dn_clear)
+    cfl%sw_dn_direct_clear = locr(flux%sw_dn_direct_clear); cfl%lw_derivatives = locr(flux%lw_derivatives)
+    cfl%lw_dn_surf_g = locr(flux%lw_dn_surf_g); cfl%lw_dn_surf_clear_g = locr(flux%lw_dn_surf_clear_g)
+    cfl%sw_dn_diffuse_surf_g = locr(flux%sw_dn_diffuse_surf_g); cfl%sw_dn_direct_surf_g = locr(flux%sw_dn_direct_surf_g)
+    cfl%sw_dn_diffuse_surf_clear_g = locr(flux%sw_dn_diffuse_surf_clear_g)
+    cfl%sw_dn_direct_surf_clear_g = locr(flux%sw_dn_direct_surf_clear_g)
+    cfl%lw_up_toa_g = locr(flux%lw_up_toa_g); cfl%lw_up_toa_clear_g = locr(flux%lw_up_toa_clear_g)
+    cfl%sw_dn_toa_g = locr(flux%sw_dn_toa_g); cfl%sw_up_toa_g = locr(flux%sw_up_toa_g)
+    cfl%sw_up_toa_clear_g = locr(flux%sw_up_toa_clear_g)
+    cfl%sw_dn_surf_band = locr(flux%sw_dn_surf_band); cfl%sw_dn_direct_surf_band = locr(flux%sw_dn_direct_surf_band)
+    cfl%sw_dn_surf_clear_band = locr(flux%sw_dn_surf_clear_band)
+    cfl%sw_dn_direct_surf_clear_band = locr(flux%sw_dn_direct_surf_clear_band)
+    cfl%lw_up_toa_band = locr(flux%lw_up_toa_band); cfl%lw_up_toa_clear_band = locr(flux%lw_up_toa_clear_band)
+    cfl%sw_dn_toa_band = locr(flux%sw_dn_toa_band); cfl%sw_up_toa_band = locr(flux%sw_up_toa_band)
+    cfl%sw_up_toa_clear_band = locr(flux%sw_up_toa_clear_band)
+    cfl%lw_dn_surf_canopy = locr(flux%lw_dn_surf_canopy)
+    cfl%sw_dn_diffuse_surf_canopy = locr(flux%sw_dn_diffuse_surf_canopy)
+    cfl%sw_dn_direct_surf_canopy = locr(flux%sw_dn_direct_surf_canopy)
+    cfl%cloud_cover_lw = locr(flux%cloud_cover_lw); cfl%cloud_cover_sw = locr(flux%cloud_cover_sw)
+    cfl%lw_up_band = locr(flux%lw_up_band); cfl%lw_dn_band = locr(flux%lw_dn_band)
+    cfl%lw_up_clear_band = locr(flux%lw_up_clear_band); cfl%lw_dn_clear_band = locr(flux%lw_dn_clear_band)
+    cfl%sw_up_band = locr(flux%sw_up_band); cfl%sw_dn_band = locr(flux%sw_dn_band)
+    cfl%sw_dn_direct_band = locr(flux%sw_dn_direct_band); cfl%sw_up_clear_band = locr(flux%sw_up_clear_band)
+    cfl%sw_dn_clear_band = locr(flux%sw_dn_clear_band); cfl%sw_dn_direct_clear_band = locr(flux%sw_dn_direct_clear_band)
 #ifdef PARKIND1_SINGLE
-    outputs_from_here = .true.
-#endif
-    cfl%lw_up = locd(flux%lw_up); cfl%lw_dn = locd(flux%lw_dn); cfl%sw_up = locd(flux%sw_up); cfl%sw_dn = locd(flux%sw_dn)
-    cfl%sw_dn_direct = locd(flux%sw_dn_direct); cfl%lw_up_clear = locd(flux%lw_up_clear); cfl%lw_dn_clear = locd(flux%lw_dn_clear)
-    cfl%sw_up_clear = locd(flux%sw_up_clear); cfl%sw_dn_clear = locd(flux%sw_dn_clear)
-    cfl%sw_dn_direct_clear = locd(flux%sw_dn_direct_clear); cfl%lw_derivatives = locd(flux%lw_derivatives)
-    cfl%lw_dn_surf_g = locd(flux%lw_dn_surf_g); cfl%lw_dn_surf_clear_g = locd(flux%lw_dn_surf_clear_g)
-    cfl%sw_dn_diffuse_surf_g = locd(flux%sw_dn_diffuse_surf_g); cfl%sw_dn_direct_surf_g = locd(flux%sw_dn_direct_surf_g)
-    cfl%sw_dn_diffuse_surf_clear_g = locd(flux%sw_dn_diffuse_surf_clear_g)
-    cfl%sw_dn_direct_surf_clear_g = locd(flux%sw_dn_direct_surf_clear_g)
-    cfl%lw_up_toa_g = locd(flux%lw_up_toa_g); cfl%lw_up_toa_clear_g = locd(flux%lw_up_toa_clear_g)
-    cfl%sw_dn_toa_g = locd(flux%sw_dn_toa_g); cfl%sw_up_toa_g = locd(flux%sw_up_toa_g)
-    cfl%sw_up_toa_clear_g = locd(flux%sw_up_toa_clear_g)
-    cfl%sw_dn_surf_band = locd(flux%sw_dn_surf_band); cfl%sw_dn_direct_surf_band = locd(flux%sw_dn_direct_surf_band)
-    cfl%sw_dn_surf_clear_band = locd(flux%sw_dn_surf_clear_band)
-    cfl%sw_dn_direct_surf_clear_band = locd(flux%sw_dn_direct_surf_clear_band)
-    cfl%lw_up_toa_band = locd(flux%lw_up_toa_band); cfl%lw_up_toa_clear_band = locd(flux%lw_up_toa_clear_band)
-    cfl%sw_dn_toa_band = locd(flux%sw_dn_toa_band); cfl%sw_up_toa_band = locd(flux%sw_up_toa_band)
-    cfl%sw_up_toa_clear_band = locd(flux%sw_up_toa_clear_band)
-    cfl%lw_dn_surf_canopy = locd(flux%lw_dn_surf_canopy)
-    cfl%sw_dn_diffuse_surf_canopy = locd(flux%sw_dn_diffuse_surf_canopy)
-    cfl%sw_dn_direct_surf_canopy = locd(flux%sw_dn_direct_surf_canopy)
-    cfl%cloud_cover_lw = locd(flux%cloud_cover_lw); cfl%cloud_cover_sw = locd(flux%cloud_cover_sw)
-    cfl%lw_up_band = locd(flux%lw_up_band); cfl%lw_dn_band = locd(flux%lw_dn_band)
-    cfl%lw_up_clear_band = locd(flux%lw_up_clear_band); cfl%lw_dn_clear_band = locd(flux%lw_dn_clear_band)
-    cfl%sw_up_band = locd(flux%sw_up_band); cfl%sw_dn_band = locd(flux%sw_dn_band)
-    cfl%sw_dn_direct_band = locd(flux%sw_dn_direct_band); cfl%sw_up_clear_band = locd(flux%sw_up_clear_band)
-    cfl%sw_dn_clear_band = locd(flux%sw_dn_clear_band); cfl%sw_dn_direct_clear_band = locd(flux%sw_dn_direct_clear_band)
+    if (ecrad_hip_radiation_f32(hip_handle, int(ncol,c_int), int(nlev,c_int), int(istartcol,c_int), int(iendcol,c_int), &
+         &  cin, cfl) /= ECRAD_OK) call radiation_hip_abort('*** Error in ecrad_hip_radiation_f32')
+#else
     if (ecrad_hip_radiation(hip_handle, int(ncol,c_int), int(nlev,c_int), int(istartcol,c_int), int(iendcol,c_int), &
          &  cin, cfl) /= ECRAD_OK) call radiation_hip_abort('*** Error in ecrad_hip_radiation')
-#ifdef PARKIND1_SINGLE
-    call finish_copies()
-    !$omp end critical (ecrad_hip_radiation_call)
 #endif
   end subroutine radiation_hip
 

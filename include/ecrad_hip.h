@@ -421,6 +421,18 @@ int ecrad_hip_pool_reset(ecrad_hip_handle_t handle);  /* zero the counters of ec
 int ecrad_hip_radiation(ecrad_hip_handle_t handle, int ncol, int nlev, int istartcol, int iendcol,
                         const ecrad_inputs_t* in, ecrad_flux_t* flux);
 
+/* The same call for a SINGLE-PRECISION host: the reference built with -DPARKIND1_SINGLE (ifsaux/parkind1.F90: jprb = real32,
+   how the IFS runs) passes real32 arrays to radiation() (radiation/radiation_interface.F90:200-251).  Same structs, same
+   shapes; every `double*` member of `in` and `flux` points at FLOAT data (the int32 members are what they are; the scalar
+   members stay double).  Host memory only.  The calling thread widens columns istartcol..iendcol of the inputs -- those and no
+   others -- into a slab of its own, the call runs on the slab like any host-memory call over iendcol - istartcol + 1 columns
+   (batched with other small calls, or tiled), and the same range of every flux array (and of cloud_fraction: the crop side
+   effect) comes back narrowed to float.  Cost proportional to the columns of the call; nothing outside the range is read or
+   written; concurrent callers share nothing.  The arithmetic on the device is what ecrad_config_t::i_precision says:
+   double, or float inside the SPARTACUS solvers. */
+int ecrad_hip_radiation_f32(ecrad_hip_handle_t handle, int ncol, int nlev, int istartcol, int iendcol,
+                            const ecrad_inputs_t* in_float_arrays, ecrad_flux_t* flux_float_arrays);
+
 /* Stage-level entry: everything radiation() computes before the solvers (albedo mapping, gas
    optics, cloud optics, aerosol optics), written to the arrays of `out` that are non-NULL. */
 int ecrad_hip_optics(ecrad_hip_handle_t handle, int ncol, int nlev, int istartcol, int iendcol,

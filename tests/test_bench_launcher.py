@@ -86,3 +86,19 @@ def test_bench_two_ranks_end_to_end_on_a_shared_gpu():
     assert d["value"] > 0 and d["value_with_gather"] > 0 and d["value_with_gather"] <= d["value"] * 1.05
     assert d["ms_per_step_ranks"]["min"] <= d["ms_per_step_ranks"]["max"] == d["ms_per_step"]
     assert d["gathered"]["ranks"] == 2 and d["gathered"]["shape_per_rank"][-1] == 4096
+
+
+@pytest.mark.gpu
+def test_bench_pool_mode_over_eight_device_slots_on_this_gpu():
+    """`bench.py --gpus 8 --threads-per-process 16` -- ONE process whose 16 host threads spread blocks of host arrays over the
+    pool's eight devices -- run for real with ECRAD_HIP_FAKE_DEVICES=8 (eight device slots on this box's GPU): the compact line
+    parses, says what it is, every slot served blocks and the blocks of the eight shards are identical."""
+    env = dict(os.environ, ECRAD_HIP_FAKE_DEVICES="8")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--threads-per-process", "16", "--steps", "2", "--warmup", "1",
+                        "--ncol", "4096", "--block-columns", "1024", "--workload", "tripleclouds_ecckd32"], capture_output=True, text=True, timeout=1200, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 4096, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and "test_fake_devices" in d and d["blocks_identical_across_devices"] is True and d["value"] > 0
+    assert d["pool"]["n_devices"] == 8 and len(d["pool"]["calls_on_device"]) == 8 and all(v > 0 for v in d["pool"]["calls_on_device"].values()), d["pool"]

@@ -612,9 +612,10 @@ SP_REF = os.path.join(ROOT, "tests", "_build", "reference_sp", "ecrad_ref")
                     reason="tools/build_dropin.py --single [--reference] builds are missing")
 @pytest.mark.parametrize("target", ["ecckd_mcica", "test_ecckd_tc", "default", "tripleclouds", "test_spartacus"])
 def test_single_precision_host_through_the_dropin(tmp_path, target):
-    """In a single-precision build of the host every real array crosses the boundary as a double copy made by the wrapper
-    (radiation_hip_interface.F90: dloc / finish_copies; the RRTMG module tables likewise) and the device arithmetic stays
-    double.  So the single-precision host + GPU must equal the DOUBLE-precision host + GPU up to the rounding of its inputs and
+    """In a single-precision build of the host the tables cross the boundary as double copies made once at set-up
+    (radiation_hip_interface.F90: dloc / finish_copies; the RRTMG module tables likewise), the real32 arrays of a call go to
+    ecrad_hip_radiation_f32 as they are (include/ecrad_hip.h: the library widens the columns of the call), and the device
+    arithmetic stays double.  So the single-precision host + GPU must equal the DOUBLE-precision host + GPU up to the rounding of its inputs and
     outputs to float (5e-5 here: McICA turns a rounded cloud fraction into a different sub-column now and then; SPARTACUS, whose solver then runs in float as the reference's own single-precision build
     does, 2e-3), and must be at least as close to the double-precision result as the reference's own single-precision CPU
     executable is."""
@@ -641,6 +642,51 @@ def test_single_precision_host_through_the_dropin(tmp_path, target):
             continue        # (all-sky longwave with 3-D effects: chaotic in single precision in the reference's own formulation)
         assert e_hip[v] < (2.0e-3 if spartacus else 5.0e-5), (v, e_hip[v])
         assert e_hip[v] <= max(2.0 * e_ref[v], 1.0e-6), (v, e_hip[v], e_ref[v])
+
+
+SP_OMP_EXE = os.path.join(ROOT, "tests", "_build", "dropin_sp_omp", "ecrad_hip")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(SP_OMP_EXE) and os.path.exists(SP_EXE)), reason="tools/build_dropin.py --single [--openmp] builds are missing")
+def test_single_precision_openmp_driver_blocks_of_80_run_concurrently(tmp_path):
+    """The -DPARKIND1_SINGLE drop-in under the driver compiled WITH OpenMP: 5 120 synthetic columns as 64 blocks of 80 (the
+    reference's nblocksize, test/ifs/configCY49R1_ecckd.nam:12) on 16 threads against the serial single-precision drop-in over
+    one block of 5 120 -- every variable identical, and at least 8 calls of ecrad_hip_radiation_f32 in flight at once by the
+    library's own count (round 4's wrapper took the calls of a single-precision host one at a time, inside an OpenMP critical
+    section, converting whole ncol-sized arrays per call)."""
+    from bench import build_config
+    from ecrad_amd.driver import save_inputs
+    from ecrad_amd.synthetic import make_columns
+    config, clear_sky, _ = build_config("tripleclouds_ecckd32")
+    inputs = make_columns(config, 5120, clear_sky)
+    inp = str(tmp_path / "inputs.nc")
+    save_inputs(inp, config, *inputs[2:])
+    write_namelist(str(tmp_path / "base.nam"), {"do_save_spectral_flux": "false", "iverbose": "1", "iverbosesetup": "0"})
+    base = open(str(tmp_path / "base.nam")).read()
+    outs, times = {}, {}
+    for tag, exe, nthreads, nblock in (("blocks", SP_OMP_EXE, 16, 80), ("whole", SP_EXE, 1, 5120)):
+        nam, out = str(tmp_path / f"config_{tag}.nam"), str(tmp_path / f"out_{tag}.nc")
+        open(nam, "w").write(re.sub(r"nrepeat\s*=\s*\d+", "nrepeat = 10", re.sub(r"nblocksize\s*=\s*\d+", f"nblocksize = {nblock}", base)))
+        env = dict(os.environ, OMP_NUM_THREADS=str(nthreads), OMP_STACKSIZE="1G", ECRAD_HIP_CONTEXTS="16", ECRAD_HIP_DEVICES="1", ECRAD_HIP_POOL_REPORT="1")
+        p = _run(f"ulimit -s unlimited; exec {exe} {nam} {inp} {out}", shell=True, capture_output=True, text=True,
+                 cwd=str(tmp_path), env=env, timeout=900)
+        text = p.stdout + p.stderr
+        assert p.returncode == 0 and os.path.exists(out), text[-3000:]
+        pool = _pool_report(text)
+        m = re.search(r"Time elapsed in radiative transfer:\s*([0-9.Ee+-]+)\s*seconds", text)
+        assert m, text[-2000:]
+        times[tag] = float(m.group(1)) / 10.0
+        outs[tag] = out
+        if tag == "blocks":
+            assert pool["calls"] == 64 * 10 and pool["max_in_flight"] >= 8, pool
+    with NcFile(outs["blocks"]) as a, NcFile(outs["whole"]) as b:
+        names = list(a._f.variables)
+        assert sorted(names) == sorted(b._f.variables) and len(names) >= 10
+        for v in names:
+            assert np.array_equal(a.get(v), b.get(v), equal_nan=True), v
+    print("single-precision OpenMP driver + drop-in, 5120 columns, per repeat of 10: 64 blocks of 80 on 16 threads %.4f s (%.0f columns/s); one block %.4f s (%.0f columns/s)"
+          % (times["blocks"], 5120 / times["blocks"], times["whole"], 5120 / times["whole"]))
 
 
 @pytest.mark.gpu

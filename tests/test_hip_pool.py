@@ -263,9 +263,8 @@ def test_work_budget_set_after_setup_reaches_every_context():
         info = abi.CallInfo()
         rad.lib.ecrad_hip_last_call_info(rad.handle, C.byref(info))
         assert info.n_tiles == 1
-        # a budget that holds 4 096 columns of work arrays and no more: three tiles
-        per_col = info.work_bytes / ncol
-        assert rad.lib.ecrad_hip_set_work_bytes(rad.handle, int(per_col * 4200)) == 0
+        # a budget smaller than any tile's work arrays: the call runs in the smallest tiles, 4 096 columns, i.e. three of them
+        assert rad.lib.ecrad_hip_set_work_bytes(rad.handle, 1 << 20) == 0
         from ecrad_amd.interface import build_flux_struct, build_inputs_struct
         clouds = [type(cloud).__new__(type(cloud)) for _ in range(2)]
         fluxes, tiles, errors = [Flux.allocate(config, n, nlev) for _ in range(2)], [None, None], []
@@ -321,4 +320,60 @@ def test_pool_is_rebuilt_when_the_split_changes_at_the_same_size():
         rad._check(rad.lib.ecrad_hip_setup(rad.handle, C.byref(rad.cconfig)), "ecrad_hip_setup")      # (a new pool needs its tables)
         info = rad.pool_info()
         assert info["n_devices"] == ndev and info["n_contexts"] == ndev * nctx, info
+    rad.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["Tripleclouds", "McICA"])
+def test_eight_device_slots_mapped_onto_this_gpu(solver, monkeypatch):
+    """Dry run of an 8-GPU node on a 1-GPU box (ECRAD_HIP_FAKE_DEVICES=8, ecrad_amd/csrc/api.hip: build_pool): the pool is laid
+    out as eight device slots of two contexts each, every slot uploads ITS OWN copy of the tables at ecrad_hip_setup, and the
+    contiguous column shards of ecrad_amd/parallel.py: shard_range(ncol, r, 8) -- what rank r of `bench.py --gpus 8` owns --
+    are called from eight host threads at once, which the pool spreads over the slots (least busy first).  Every flux of every
+    column equals the ONE call over all columns on an ordinary single-device handle, bit for bit, and every slot has served."""
+    from ecrad_amd.parallel import shard_range
+    ncol = 8 * 2048 + 5                      # (uneven shards: 2049 x 5, 2048 x 3)
+    config = make_config(solver)
+    n, nlev, sl, th, gas, cloud, aer = make_columns(config, ncol, False)
+    frac0 = cloud.fraction.copy()
+    one = Radiation(config, backend="hip", concurrency=(1, 1))
+    ref = Flux.allocate(config, n, nlev)
+    one.radiation(n, nlev, 1, n, sl, th, gas, cloud, aer, ref)
+    frac_ref = cloud.fraction.copy()
+    one.close()
+    monkeypatch.setenv("ECRAD_HIP_FAKE_DEVICES", "8")
+    rad = Radiation(config, backend="hip", concurrency=(8, 2))
+    info = rad.pool_info()
+    assert info["n_devices"] == 8 and info["n_contexts"] == 16 and sorted(info["calls_on_device"]) == list(range(8)), info
+    from ecrad_amd.interface import build_flux_struct, build_inputs_struct
+    shards = [shard_range(n, r, 8) for r in range(8)]
+    assert shards[0][0] == 1 and shards[-1][1] == n and all(shards[r][1] + 1 == shards[r + 1][0] for r in range(7))
+    served = {k: 0 for k in range(8)}
+    for _round in range(4):
+        cloud.fraction[...] = frac0
+        flux = Flux.allocate(config, n, nlev)
+        cin, keep = build_inputs_struct(config, n, nlev, sl, th, gas, cloud, aer)
+        cflux = build_flux_struct(flux)
+        start, errors = threading.Barrier(8), []
+
+        def worker(r):
+            i0, i1 = shards[r]
+            start.wait()
+            if rad.lib.ecrad_hip_radiation(rad.handle, n, nlev, i0, i1, C.byref(cin), C.byref(cflux)) != 0:
+                errors.append(rad.lib.ecrad_hip_last_error(rad.handle))
+        threads = [threading.Thread(target=worker, args=(r,)) for r in range(8)]
+        rad.pool_info(reset=True)
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        _flux_equal(ref, flux)
+        assert np.array_equal(cloud.fraction, frac_ref)
+        info = rad.pool_info()
+        assert info["calls_total"] == 8
+        for k, v in info["calls_on_device"].items():
+            served[k] += v
+    assert all(v >= 1 for v in served.values()), served      # the tables of every slot have been read by a call
+    print(solver, "calls per device slot over four rounds of eight concurrent shards:", served)
     rad.close()
