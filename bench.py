@@ -677,7 +677,7 @@ def pcie_bandwidth(rad):
 def end_to_end_host(w, gpu_resident_value, repeats=3):
     """The same call through ECRAD_MEM_HOST pointers -- the mode every Fortran host uses: pageable host arrays, the call copies
     the column range in, runs the kernels and copies the results back, as a pipeline of column tiles on three streams
-    (ecrad_amd/csrc/api.hip: radiation_host_pipelined).  Next to it the ceiling the link sets: bytes per column in and out
+    (ecrad_amd/csrc/pipeline.hip: radiation_host_pipelined).  Next to it the ceiling the link sets: bytes per column in and out
     (ecrad_hip_last_call_info) over the measured host-to-device / device-to-host rates with both directions busy."""
     from ecrad_amd import abi
     from ecrad_amd.types import Flux

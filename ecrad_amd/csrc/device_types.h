@@ -11,7 +11,7 @@ constexpr int kMaxCloudTypes = ECRAD_NMAXCLOUDTYPES;
 constexpr int kNReg = 3;
 constexpr int kPrepChunks = 6;      // level chunks of tripleclouds_prep_kernel (kernel_prep.hip)
 // output bits of the seeding shift register of the McICA generator that one lane produces (kernel_prep.hip; the jump-ahead
-// matrices of api.hip): 64 x 275 >= 17 516, and an odd stride spreads the lanes' LDS words over all 32 banks
+// matrices of setup.hip): 64 x 275 >= 17 516, and an odd stride spreads the lanes' LDS words over all 32 banks
 constexpr int kLfsrPerLane = 275;
 constexpr int kMaxActiveAerosols = 16;   // hydrophobic + hydrophilic types in one call (IFS: 12)
 constexpr int kMaxQuads = 10;   // quad loads per layer: ngas + (number of LUT gases); 9 for ecCKD LW-32
@@ -174,7 +174,7 @@ struct DevFlux {
   double *lw_up, *lw_dn, *sw_up, *sw_dn, *sw_dn_direct;
   double *lw_up_clear, *lw_dn_clear, *sw_up_clear, *sw_dn_clear, *sw_dn_direct_clear;
   double *lw_derivatives;
-  double *lw_derivatives_aux;   // internal (chunked longwave spectra): un-normalised all-sky derivative sums, see api.hip
+  double *lw_derivatives_aux;   // internal (chunked longwave spectra): un-normalised all-sky derivative sums, see pipeline.hip: tile_compute
   double *lw_dn_surf_g, *lw_dn_surf_clear_g;
   double *sw_dn_diffuse_surf_g, *sw_dn_direct_surf_g, *sw_dn_diffuse_surf_clear_g, *sw_dn_direct_surf_clear_g;
   double *lw_up_toa_g, *lw_up_toa_clear_g, *sw_dn_toa_g, *sw_up_toa_g, *sw_up_toa_clear_g;

@@ -584,7 +584,7 @@ static hipError_t launch_sw_mode(int mode, dim3 grid, size_t lds, hipStream_t st
       ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 1, SPEC, WIDE>), lds);
       hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 1, SPEC, WIDE>), grid, dim3(kBlock), lds, st, args);
       break;
-    default:      // McICA never writes spectral profiles (api.hip nulls the destinations)
+    default:      // McICA never writes spectral profiles (pipeline.hip: tile_plan nulls the destinations)
       ECRAD_ALLOW_LDS((sw_ica_kernel<TAB, NGP, 2, false, WIDE>), lds);
       hipLaunchKernelGGL((sw_ica_kernel<TAB, NGP, 2, false, WIDE>), grid, dim3(kBlock), lds, st, args);
       break;

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
     auto derivatives = [&](bool cloudy_sky, double fup_surf, double weight, bool modify, double* wide_dst) {
       const double ssurf = group_sum<NGP>(valid ? fup_surf : 0.0);
       double d = WIDE ? fup_surf : fup_surf / ssurf;
-      // WIDE: un-normalised sums into `wide_dst`; the host normalises and blends (api.hip)
+      // WIDE: un-normalised sums into `wide_dst`; the host normalises and blends (pipeline.hip: tile_compute)
       double* const dst = WIDE ? wide_dst : fx.lw_derivatives;
       if (lead) dst[col + ncol * ord.half(nlev)] = WIDE ? ssurf : 1.0;
       double keep_der = 0.0;

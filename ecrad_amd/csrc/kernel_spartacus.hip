@@ -189,7 +189,7 @@ struct SpConfig {
   // Spectra wider than 64 g-points run as several launches ("chunks", as in the other solvers): this launch covers
   // g-points g0 .. g0+ngl-1, lane = g0 + its index in the column group.  The stage arrays and per-g outputs are indexed
   // by the true g-point, the layer store by the index within the chunk (stride ngl); the sums over g are partial and go
-  // to per-chunk buffers (api.hip); `wide` leaves the longwave derivatives un-normalised, see spartacus_lw_kernel.
+  // to per-chunk buffers (pipeline.hip: tile_compute); `wide` leaves the longwave derivatives un-normalised, see spartacus_lw_kernel.
   int32_t g0, ngl;
   double max_cloud_od, max_3d_transfer_rate, max_gas_od_3d, min_cloud_effective_size, overhang_factor, clear_to_thick_fraction,
          overhead_sun_factor, cloud_fraction_threshold;

@@ -592,7 +592,7 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const LdsLayout& L, i
 #define ECRAD_AEROSOL_BATCH 4
 #endif
 #ifndef ECRAD_AER_SCHED_BARRIER
-#define ECRAD_AER_SCHED_BARRIER 1
+#define ECRAD_AER_SCHED_BARRIER 0
 #endif
   constexpr int kBatch = ECRAD_AEROSOL_BATCH;
 #pragma unroll

@@ -146,7 +146,7 @@ OMP_EXE = os.path.join(ROOT, "tests", "_build", "dropin_omp", "ecrad_hip")
 
 
 def _pool_report(text):
-    """The line ECRAD_HIP_POOL_REPORT=1 makes the library print when the process ends (ecrad_amd/csrc/api.hip: report_pools)."""
+    """The line ECRAD_HIP_POOL_REPORT=1 makes the library print when the process ends (ecrad_amd/csrc/pool.hip: report_pools)."""
     m = re.search(r"ecrad_hip pool: devices (\d+) contexts (\d+) calls (\d+) max_in_flight (\d+) batches (\d+) calls_on_device(.*)", text)
     assert m, text[-2000:]
     return {"devices": int(m.group(1)), "contexts": int(m.group(2)), "calls": int(m.group(3)), "max_in_flight": int(m.group(4)),
@@ -458,7 +458,7 @@ def test_gpu_dropin_against_the_reference_executable_on_synthetic_ifs_shaped_col
 def test_the_dropins_own_timer_at_100000_columns_in_one_call(tmp_path):
     """The boundary as the reference's offline driver uses it at the size of BASELINE configs[1]: 100 000 synthetic clear-sky
     columns in a netCDF file, ONE block (nblocksize = 100 000), i.e. one radiation() call on host arrays per repeat -- the
-    drop-in pipelines it over PCIe as column tiles (api.hip: radiation_host_pipelined) -- timed by the driver's own timer
+    drop-in pipelines it over PCIe as column tiles (pipeline.hip: radiation_host_pipelined) -- timed by the driver's own timer
     (driver/ecrad_driver.F90:387-388: "Time elapsed in radiative transfer").  Printed; the bound asserted is a loose one
     (half of what one MI355X box gave: 2.1 M columns/s, bench.py end_to_end_host), the number is for the log."""
     from bench import build_config

@@ -184,7 +184,7 @@ def test_every_visible_device_joins_the_pool_and_calls_spread_over_them():
 def test_packed_single_tile_and_pipelined_host_calls_give_the_same_bits(solver):
     """20 000 columns through ecrad_hip_radiation with host-memory arrays: as pipelined tiles (the default from 8192 columns),
     as one tile (ECRAD_HIP_NO_PIPELINE), and block by block -- blocks of 300 columns as small calls (one packed transfer each
-    way through page-locked mirrors, api.hip: radiation_small), and the same blocks with that switched off
+    way through page-locked mirrors, pipeline.hip: radiation_small), and the same blocks with that switched off
     (ECRAD_HIP_PACK_COLUMNS=0).  All four equal bit for bit; the pipelined call ran as
     several tiles; columns outside a block's range are not touched."""
     ncol = 20000
@@ -215,11 +215,11 @@ def test_packed_single_tile_and_pipelined_host_calls_give_the_same_bits(solver):
                 else:
                     os.environ[k] = v
     piped, ntile = run([(1, n)], {"ECRAD_HIP_HOST_TILE": "4096"})
-    assert ntile == 8          # 1024 + 2048 + 3 x 4096 + 1568 + 2048 + 1024: the tiles ramp up and down (api.hip: radiation_host_pipelined)
+    assert ntile == 8          # 1024 + 2048 + 3 x 4096 + 1568 + 2048 + 1024: the tiles ramp up and down (pipeline.hip: radiation_host_pipelined)
     flat, ntile = run([(1, n)], {"ECRAD_HIP_HOST_TILE": "4096", "ECRAD_HIP_NO_RAMP": "1"})
     assert ntile == 5
     _flux_equal(flat, piped)
-    # (the default pipeline leaves the staging of the caller's pageable arrays to the runtime, api.hip: radiation_host_pipelined;
+    # (the default pipeline leaves the staging of the caller's pageable arrays to the runtime, pipeline.hip: radiation_host_pipelined;
     #  ECRAD_HIP_PIPELINE=mirrored moves the tiles through page-locked mirrors of the staged arrays, radiation_host_mirrored)
     mirrored, ntile = run([(1, n)], {"ECRAD_HIP_HOST_TILE": "4096", "ECRAD_HIP_PIPELINE": "mirrored"})
     assert ntile == 8
@@ -326,7 +326,7 @@ def test_pool_is_rebuilt_when_the_split_changes_at_the_same_size():
 @pytest.mark.gpu
 @pytest.mark.parametrize("solver", ["Tripleclouds", "McICA"])
 def test_eight_device_slots_mapped_onto_this_gpu(solver, monkeypatch):
-    """Dry run of an 8-GPU node on a 1-GPU box (ECRAD_HIP_FAKE_DEVICES=8, ecrad_amd/csrc/api.hip: build_pool): the pool is laid
+    """Dry run of an 8-GPU node on a 1-GPU box (ECRAD_HIP_FAKE_DEVICES=8, ecrad_amd/csrc/pool.hip: build_pool): the pool is laid
     out as eight device slots of two contexts each, every slot uploads ITS OWN copy of the tables at ecrad_hip_setup, and the
     contiguous column shards of ecrad_amd/parallel.py: shard_range(ncol, r, 8) -- what rank r of `bench.py --gpus 8` owns --
     are called from eight host threads at once, which the pool spreads over the slots (least busy first).  Every flux of every

@@ -73,7 +73,7 @@ def test_tiled_call_is_bitwise_the_untiled_call(case, device):
         assert np.array_equal(a, f2.arrays[name]), name
     assert np.array_equal(frac1, frac2)
     if case == "mcica_rrtmg":
-        # (140 g-points as chunks of 64 + 64 + 16 lanes, 112 as 64 + 32 + 16: chunk_plan in api.hip; lanes = the widest)
+        # (140 g-points as chunks of 64 + 64 + 16 lanes, 112 as 64 + 32 + 16: chunk_plan in setup.hip; lanes = the widest)
         assert (info1.launches_lw, info1.lanes_lw, info1.launches_sw, info1.lanes_sw) == (3, 64, 3, 64)
 
 

@@ -8,7 +8,7 @@ extra="$*"
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=${ECRAD_VARIANT_DIR:-$root/build_variants}/$name
 mkdir -p $out
-src="api kernel_ica_sw kernel_ica_lw kernel_ica_lw_clear kernel_lw_scat kernel_tc kernel_prep kernel_optics kernel_rrtmg kernel_spartacus"
+src="pool setup pipeline abi kernel_ica_sw kernel_ica_lw kernel_ica_lw_clear kernel_lw_scat kernel_tc kernel_prep kernel_optics kernel_rrtmg kernel_spartacus"
 for f in $src; do
   x=""; [ $f = kernel_ica_lw_clear ] && x="-mllvm -amdgpu-sched-strategy=max-memory-clause"      # (as ecrad_amd/csrc/Makefile: EXTRA_kernel_ica_lw_clear)
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $x $extra -c $root/ecrad_amd/csrc/$f.hip -o $out/$f.o &
