@@ -29,6 +29,12 @@ template <typename OUT> ECRAD_DEV void put_stage(double* arr, size_t o, double v
 #ifndef ECRAD_DUMP_MIN_WAVES
 #define ECRAD_DUMP_MIN_WAVES ECRAD_MIN_WAVES
 #endif
+#ifndef ECRAD_DUMP_PIPE
+#define ECRAD_DUMP_PIPE 1      // the level loop with every load of a layer ahead of the previous layer's stores (see there)
+#endif
+#ifndef ECRAD_DUMP_PIPE_SW
+#define ECRAD_DUMP_PIPE_SW 0
+#endif
 #ifndef ECRAD_DUMP_CHUNK_DIV
 #define ECRAD_DUMP_CHUNK_DIV 1      // 2: half as many levels per chunk of level records (with ECRAD_DUMP_MIN_WAVES=4: a fourth block per CU)
 #endif
@@ -102,6 +108,115 @@ __global__ __launch_bounds__(kBlock, ECRAD_DUMP_MIN_WAVES) void optics_dump_kern
       }
       __syncthreads();
       const int nl = (nlev - l0) < CH ? (nlev - l0) : CH;
+#if ECRAD_DUMP_PIPE
+      // The layers of this pass are independent of each other, and a layer's loads queue behind whatever was stored before
+      // them (memory operations complete in issue order): so ALL the table rows of layer j -- gas quads, aerosol mixing ratios,
+      // the rows of every aerosol type -- are requested first, THEN the values of layer j - 1 are stored, then layer j is
+      // computed.  The stores of a layer have a whole layer's arithmetic to complete in before anything waits behind them.
+      // (Stage arrays of the RRTMG pass, and configurations with more than 12 active aerosol types, take the plain loop below.)
+      constexpr int NT = 12;
+      bool pipe_ok;
+      {
+        const DumpArgs& b = kernarg_block<DumpArgs>();
+        // Longwave, absorption-only aerosols (one table value per type: 12 registers in flight): optics pass of the SPARTACUS
+        // longwave 9.2 -> 7.3 ms per 100 000 columns.  NOT the shortwave (ECRAD_DUMP_PIPE_SW): its 24 rows per layer are 72
+        // registers, the kernel then spills 71 and every reload queues behind the prefetch: 10.5 -> 20.8 ms (gpurun_out/r05_i).
+        pipe_ok = b.cfg.aerosol.nactive4 <= NT && !b.in.gs.od_sw && !b.in.gs.od_lw && sizeof(TAB) != 8 &&
+                  (IS_SW ? ECRAD_DUMP_PIPE_SW != 0 : !b.cfg.do_lw_aerosol_scattering);
+      }
+      if (pipe_ok) {
+        const LevelOrder ord = level_order(kernarg_block<DumpArgs>().in);
+        // the values of the previous layer, not stored yet: (od, ssa, g) shortwave; (od, ssa, g, planck at its lower half level) longwave
+        double p_od = 0.0, p_ssa = 0.0, p_g = 0.0, p_pl = 0.0, p_pltop = 0.0;
+        size_t p_o = 0, p_op = 0;
+        bool p_have = false, p_first = false;
+        auto store_pending = [&]() {
+          if (!p_have || !valid) return;
+          const DumpArgs& b = kernarg_block<DumpArgs>();
+          const DevOptics& out = b.out;
+          if (IS_SW) {
+            if (out.od_sw) put_stage<OUT>(out.od_sw, p_o, p_od);
+            if (out.ssa_sw) put_stage<OUT>(out.ssa_sw, p_o, p_ssa);
+            if (out.g_sw) put_stage<OUT>(out.g_sw, p_o, p_g);
+          } else {
+            if (b.cfg.do_lw_aerosol_scattering) {
+              if (out.ssa_lw) put_stage<OUT>(out.ssa_lw, p_o, p_ssa);
+              if (out.g_lw) put_stage<OUT>(out.g_lw, p_o, p_g);
+            }
+            if (out.od_lw) put_stage<OUT>(out.od_lw, p_o, p_od);
+            if (out.planck_hl) {
+              if (p_first) put_stage<OUT>(out.planck_hl, p_op, p_pltop);
+              put_stage<OUT>(out.planck_hl, p_op + ng, p_pl);
+            }
+          }
+        };
+        for (int j = 0; j < nl; ++j) {
+          const int lev = l0 + j;
+          const int slot = cib * CH + j;
+          const DumpArgs& b = kernarg_block<DumpArgs>();
+          const DevConfig& cfg = b.cfg;
+          const DevCkdModel& m = IS_SW ? cfg.gas_sw : cfg.gas_lw;
+          const size_t o = g + (size_t)ng * (lev + (size_t)nlev * cloc);
+          constexpr int SKIPQ = SkipQuad<TAB, IS_SW>::value;
+          const bool aer = cfg.use_aerosols != 0;
+          // ---- every load of layer j
+          AerosolWeight aw = {0.0, false};
+          AerosolRows<IS_SW ? NT : 1> rows;
+          AerosolAbsRows<IS_SW ? 1 : NT> arows;
+          if (aer) aw = aerosol_weight(b.in, ord, col, lev, aer_type);
+          gas_load<TAB, SKIPQ>(m.hot, quad_count<TAB, IS_SW>(m.hot.nquad), plain_count<TAB, IS_SW>(m.hot.nplain), L, slot, g, quads);
+          typename PlanckTab<TAB>::Pair ppair{};
+          const PlanckTab<TAB> pt{m.planck_function, ng};
+          if (!IS_SW) ppair = pt.fetch(L.I(I_PL_BOT, slot), g);
+          if (aer && aw.in_range) {
+            if constexpr (IS_SW) aerosol_rows_issue<true, NT>(cfg, L, slot, ib, rows);
+            else aerosol_abs_rows_issue<NT>(cfg, L, slot, ib, arows);
+          }
+          asm volatile("" ::: "memory");
+          // ---- the stores of layer j - 1
+          store_pending();
+          asm volatile("" ::: "memory");
+          // ---- layer j
+          double od = gas_combine<TAB, SKIPQ>(quad_count<TAB, IS_SW>(m.hot.nquad), L, slot, quads);
+          if (IS_SW) {
+            double ssa = L.D(F_SM, slot) * m.rayleigh_molar_scat[g];
+            od = od + ssa;
+            ssa = ssa / od;
+            double asym = 0.0;
+            if (aer) {
+              AerosolLayer a = {0.0, 0.0, 0.0};
+              if constexpr (IS_SW) { if (aw.in_range) a = aerosol_layer_rows<NT>(L, slot, aw, rows); }
+              if (!cfg.do_sw_delta_scaling_with_gases) delta_eddington_extensive_vec(a);
+              merge_aerosol_sw(cfg, a, od, ssa, asym);
+            }
+            p_od = od; p_ssa = ssa; p_g = asym;
+          } else {
+            const double planck_bot = PlanckTab<TAB>::value(ppair, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot));
+            double ssa = 0.0, asym = 0.0;
+            if constexpr (!IS_SW) { if (aer && aw.in_range) od = od + aerosol_abs_layer_rows<NT>(L, slot, aw, arows); }
+            p_od = od; p_ssa = ssa; p_g = asym; p_pl = planck_bot; p_pltop = planck_top;
+            p_first = lev == 0;
+            p_op = g + (size_t)ng * (lev + (size_t)(nlev + 1) * cloc);
+            planck_top = planck_bot;
+          }
+          p_o = o; p_have = true;
+          if (want_clouds && gi < nb && col_ok && !(b.cloudy_only && !(L.D(F_FRAC, slot) > 0.0))) {
+            // cloud tables are per band: lane b < n_bands writes band b
+            const DevOptics& out = b.out;
+            const CloudLayer cl = cloud_layer<IS_SW, sizeof(TAB) == 8>(cfg, L, slot, gi);
+            const size_t oc = gi + (size_t)nb * (lev + (size_t)nlev * cloc);
+            double* pod = IS_SW ? out.od_sw_cloud : out.od_lw_cloud;
+            double* pss = IS_SW ? out.ssa_sw_cloud : out.ssa_lw_cloud;
+            double* pg = IS_SW ? out.g_sw_cloud : out.g_lw_cloud;
+            if (pod) put_stage<OUT>(pod, oc, cl.od);
+            if (pss) put_stage<OUT>(pss, oc, cl.ssa);
+            if (pg) put_stage<OUT>(pg, oc, cl.g);
+          }
+        }
+        store_pending();
+        continue;
+      }
+#endif
       for (int j = 0; j < nl; ++j) {
         const int lev = l0 + j;
         const int slot = cib * CH + j;

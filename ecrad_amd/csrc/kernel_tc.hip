@@ -46,6 +46,17 @@
 #ifndef ECRAD_TC_MIN_WAVES
 #define ECRAD_TC_MIN_WAVES ECRAD_MIN_WAVES
 #endif
+#ifndef ECRAD_TC_PIPE
+// 1: in the FX = 1 instantiations of the shortwave kernel the table rows of layer l - 1 -- gas quads, aerosol mixing ratios, the
+// {mass_ext, ssa, g} rows of all twelve aerosol types -- are requested as soon as layer l's have been consumed, i.e. BEFORE layer
+// l's two-stream arithmetic and BEFORE its record stores: they travel while that arithmetic runs and -- memory operations
+// complete in the order of their issue -- do not queue behind the stores.  MEASURED AND OFF (round 5, gpurun_out/r05_h): the rows
+// of a layer (102 registers) live across the two-stream arithmetic, and at two waves per SIMD (256 registers) the kernel still
+// spills 216 of them; every spill reload after the prefetch is a memory operation behind it in the same queue, i.e. a full wait
+// for the prefetch -- 45.5 ms per 100 000 columns against 20.6.  The form stays compiled behind this switch; it needs a kernel
+// whose sweep state is smaller (or hand-allocated registers) to pay.
+#define ECRAD_TC_PIPE 0
+#endif
 #ifndef ECRAD_TC_AER_AHEAD
 // 1: a layer's aerosol mixing ratios are requested at the top of the layer's work, with the gas-table loads, instead of in a round
 // trip of their own after the gas optics (round 5; either way the level order comes from the column group's set-up: aerosol_weight)
@@ -193,8 +204,11 @@ template <int FX> struct TcFixed {
   static constexpr int nact4 = FX == 1 ? 12 : 0;
 };
 
+#ifndef ECRAD_TC_PIPE_WAVES
+#define ECRAD_TC_PIPE_WAVES 2      // waves per SIMD of the pipelined instantiations: a layer's rows in flight under the previous layer's arithmetic want 256 registers
+#endif
 template <typename TAB, int NGP, int FX = 0>
-__global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) void sw_tc_kernel(SpectralArgs args_in_kernarg) {
+__global__ __launch_bounds__(kBlock, (FX != 0 && ECRAD_TC_PIPE) ? ECRAD_TC_PIPE_WAVES : min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) void sw_tc_kernel(SpectralArgs args_in_kernarg) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ int next_group;
   constexpr int CPB = kBlock / NGP;
@@ -291,20 +305,46 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
       __syncthreads();
       const int nl = (nlev - l0) < NGP ? (nlev - l0) : NGP;
       const GasHot gh = kernarg_block<SpectralArgs>().gas;
+      constexpr bool PIPE = ECRAD_TC_PIPE && FX != 0;
+      constexpr int SKIPQ = SkipQuad<TAB, true>::value;
+      constexpr int NT = TcFixed<FX>::nact4 > 0 ? TcFixed<FX>::nact4 : 4;
+      AerosolRows<NT> rows;
+      AerosolWeight aw_next = {0.0, false};
+      if (PIPE && sun_up) {      // the rows of the chunk's first layer (its lowest)
+        const SpectralArgs& b = kernarg_block<SpectralArgs>();
+        const int slot = cib * NGP + nl - 1;
+        aw_next = aerosol_weight<true>(b.in, ord, col, l0 + nl - 1, aer_type);
+        gas_load<TAB, SKIPQ>(gh, quad_count<TAB, true>(gh.nquad), plain_count<TAB, true>(gh.nplain), L, slot, g, quads);
+        aerosol_rows_issue<true, NT>(b.cfg, L, slot, ib, rows);
+      }
       if (sun_up)
       for (int j = nl - 1; j >= 0; --j) {
         const int l = l0 + j;
         const int slot = cib * NGP + j;
         const bool need_geo = cloudy.test(l) || (l > 0 && cloudy.test(l - 1));
         if (need_geo) feed1.issue(l);      // consumed after the gas and aerosol optics of this layer
-        constexpr int SKIPQ = SkipQuad<TAB, true>::value;
-#if ECRAD_TC_AER_AHEAD
         AerosolWeight aw = {0.0, false};
-        if (use_aerosols && !(sizeof(TAB) == 8 && kernarg_block<SpectralArgs>().in.gs.g_sw))      // (not when the RRTMG pass has merged them)
+        if (PIPE) aw = aw_next;
+#if ECRAD_TC_AER_AHEAD
+        if (!PIPE && use_aerosols && !(sizeof(TAB) == 8 && kernarg_block<SpectralArgs>().in.gs.g_sw))      // (not when the RRTMG pass has merged them)
           aw = aerosol_weight<FX != 0>(kernarg_block<SpectralArgs>().in, ord, col, l, aer_type);
 #endif
-        gas_load<TAB, SKIPQ>(gh, quad_count<TAB, true>(gh.nquad), plain_count<TAB, true>(gh.nplain), L, slot, g, quads);
+        if (!PIPE) gas_load<TAB, SKIPQ>(gh, quad_count<TAB, true>(gh.nquad), plain_count<TAB, true>(gh.nplain), L, slot, g, quads);
         double od = gas_combine<TAB, SKIPQ>(quad_count<TAB, true>(gh.nquad), L, slot, quads);
+        AerosolLayer al_pipe = {0.0, 0.0, 0.0};
+        if (PIPE) {
+          al_pipe = aerosol_layer_rows<NT>(L, slot, aw, rows);
+          // (the fences keep memory operations on their side: the next layer's loads after this layer's rows have been read
+          //  out of their registers, and ahead of everything this layer stores)
+          asm volatile("" ::: "memory");
+          if (j > 0) {
+            const SpectralArgs& b = kernarg_block<SpectralArgs>();
+            aw_next = aerosol_weight<true>(b.in, ord, col, l - 1, aer_type);
+            gas_load<TAB, SKIPQ>(gh, quad_count<TAB, true>(gh.nquad), plain_count<TAB, true>(gh.nplain), L, slot - 1, g, quads);
+            aerosol_rows_issue<true, NT>(b.cfg, L, slot - 1, ib, rows);
+          }
+          asm volatile("" ::: "memory");
+        }
         double ssa = 0.0;
         if constexpr (!IsStage<TAB>::value) {
           ssa = L.D(F_SM, slot) * ray_g;
@@ -325,9 +365,9 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
         if (use_aerosols && !folded) {
           const SpectralArgs& b = kernarg_block<SpectralArgs>();
 #if !ECRAD_TC_AER_AHEAD
-          const AerosolWeight aw = aerosol_weight(b.in, ord, col, l, aer_type);
+          if (!PIPE) aw = aerosol_weight(b.in, ord, col, l, aer_type);
 #endif
-          AerosolLayer al = aerosol_layer<true, NGP, 4, TcFixed<FX>::nact4>(b.cfg, L, slot, ib, aw);
+          AerosolLayer al = PIPE ? al_pipe : aerosol_layer<true, NGP, 4, TcFixed<FX>::nact4>(b.cfg, L, slot, ib, aw);
           if (!delta_gases) delta_eddington_extensive_vec(al);
           merge_aerosol_sw<FX ? 1 : -1>(b.cfg, al, od, ssa, asym);
         }

@@ -635,6 +635,64 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const LdsLayout& L, i
   return a;
 }
 
+// The same in two steps for a kernel instantiated for NT active types (a multiple of four) whose rows it wants in flight a
+// layer AHEAD of their use (kernel_tc.hip, ECRAD_TC_PIPE): aerosol_rows_issue requests {mass_ext, ssa} and the asymmetry factor of
+// every type for the layer of `slot`, aerosol_layer_rows is the sum over the types -- the expressions of aerosol_layer, in its order.
+template <int NT> struct AerosolRows { double2 t01[NT]; double t2[NT]; };
+template <bool IS_SW, int NT>
+ECRAD_DEV void aerosol_rows_issue(const DevConfig& cfg, const LdsLayout& L, int slot, int ib, AerosolRows<NT>& r) {
+  const DevAerosolOptics& ao = cfg.aerosol;
+  const int nb = IS_SW ? ao.n_bands_sw : ao.n_bands_lw;
+  const int irh = L.I(I_RH, slot);
+  const int rh_row = irh > 0 ? irh - 1 : 0;
+  const double2* __restrict__ tab01 = reinterpret_cast<const double2*>(IS_SW ? ao.sw_tab01 : ao.lw_tab01);
+  const double* __restrict__ tab2 = IS_SW ? ao.sw_tab2 : ao.lw_tab2;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const uint32_t desc = ao.active[k];
+    const size_t o = ib + (size_t)nb * ((int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0));
+    r.t01[k] = tab01[o];
+    r.t2[k] = tab2[o];
+  }
+}
+template <int NT>
+ECRAD_DEV AerosolLayer aerosol_layer_rows(const LdsLayout& L, int slot, const AerosolWeight& aw, const AerosolRows<NT>& r) {
+  AerosolLayer a = {0.0, 0.0, 0.0};
+  const double w_mine = L.D(F_DPG, slot) * aw.w;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const double local_od = row_bcast_k(w_mine, k) * r.t01[k].x;
+    a.od = a.od + local_od;
+    a.scat = a.scat + local_od * r.t01[k].y;
+    a.scat_g = a.scat_g + local_od * r.t01[k].y * r.t2[k];
+  }
+  return a;
+}
+
+// ... and for the absorption-only longwave path: one table value per type
+template <int NT> struct AerosolAbsRows { double t[NT]; };
+template <int NT>
+ECRAD_DEV void aerosol_abs_rows_issue(const DevConfig& cfg, const LdsLayout& L, int slot, int ib, AerosolAbsRows<NT>& r) {
+  const DevAerosolOptics& ao = cfg.aerosol;
+  const int nb = ao.n_bands_lw;
+  const int irh = L.I(I_RH, slot);
+  const int rh_row = irh > 0 ? irh - 1 : 0;
+  const double* __restrict__ tab = ao.lw_abs;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) {
+    const uint32_t desc = ao.active[k];
+    r.t[k] = tab[ib + (size_t)nb * ((int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0))];
+  }
+}
+template <int NT>
+ECRAD_DEV double aerosol_abs_layer_rows(const LdsLayout& L, int slot, const AerosolWeight& aw, const AerosolAbsRows<NT>& r) {
+  double od = 0.0;
+  const double w_mine = L.D(F_DPG, slot) * aw.w;
+#pragma unroll
+  for (int k = 0; k < NT; ++k) od = od + row_bcast_k(w_mine, k) * r.t[k];
+  return od;
+}
+
 // (the layer's weight fetched on the spot: the callers that have nothing to overlap it with)
 template <bool IS_SW, int NGP, int KB_LW = 4>
 ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const DevInputs& in, const LdsLayout& L, int slot,
