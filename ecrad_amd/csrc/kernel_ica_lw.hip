@@ -212,6 +212,19 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
       // at the head of every layer's chain (gas optics -> transmittance -> sources -> downward flux)
       typename PlanckTab<TAB>::Pair planck_pair = pt.fetch(L.I(I_PL_BOT, cib * NGP), g);
 #endif
+      // ECRAD_LW_STORE_LATE: the (T, S) record of a layer is stored AFTER the loads of the layer below it have been requested
+      // (gas quads, Planck pair, aerosol mixing ratios and the one absorption value per aerosol type): memory operations
+      // complete in issue order, so a load requested right after a store waits for that store (kernel_tc.hip: ECRAD_TC_LW_PIPE)
+      constexpr int NTL = 12;
+      const bool store_late = ECRAD_LW_STORE_LATE && sizeof(TAB) != 8 && c0.cfg.aerosol.nactive4 <= NTL;
+      double pend_t = 0.0, pend_su = 0.0;
+      int pend_lev = -1;
+      auto store_pending = [&]() {
+#if !(ECRAD_ABLATE & 8)
+        if (pend_lev >= 0) s.pair(P_CLR, pend_lev, tid) = make_double2(pend_t, pend_su);
+#endif
+        pend_lev = -1;
+      };
       for (int j = 0; j < nl; ++j) {
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
@@ -226,11 +239,28 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
 #ifdef ECRAD_TIMING
         ECRAD_LAP(tm, 0, quads.q[0].x);   // (timing build: table loads alone, booked under "scalars")
 #endif
+        AerosolAbsRows<NTL> arows;
 #if ECRAD_LW_PLANCK_AHEAD
         double planck_bot = PlanckTab<TAB>::value(planck_pair, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot));
         if (j + 1 < nl) planck_pair = pt.fetch(L.I(I_PL_BOT, slot + 1), g);
+        if (store_late) {
+          if (use_aerosols && aw.in_range) aerosol_abs_rows_issue<NTL>(kernarg_block<SpectralArgs>().cfg, L, slot, ib, arows);
+          asm volatile("" ::: "memory");
+          store_pending();
+          asm volatile("" ::: "memory");
+        }
 #else
-        double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
+        double planck_bot;
+        if (store_late) {
+          const typename PlanckTab<TAB>::Pair ppair = pt.fetch(L.I(I_PL_BOT, slot), g);
+          if (use_aerosols && aw.in_range) aerosol_abs_rows_issue<NTL>(kernarg_block<SpectralArgs>().cfg, L, slot, ib, arows);
+          asm volatile("" ::: "memory");
+          store_pending();
+          asm volatile("" ::: "memory");
+          planck_bot = PlanckTab<TAB>::value(ppair, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot));
+        } else {
+          planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
+        }
 #endif
         ECRAD_LAP(tm, 1, planck_bot);   // table + Planck loads returned
         double od = gas_combine<TAB, SKIPQ>(nq, L, slot, quads);
@@ -270,15 +300,23 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
 #endif
         ECRAD_LAP(tm, 2, od);           // combine
         if (use_aerosols) {
-          const SpectralArgs& b = kernarg_block<SpectralArgs>();
-          const AerosolLayer al = aerosol_layer<false, NGP, ECRAD_LW_AER_BATCH(MODE)>(b.cfg, L, slot, ib, aw);
-          od = od + al.od;   // radiation_aerosol_optics.F90:805-818 (no longwave aerosol scattering)
+          if (store_late) {
+            if (aw.in_range) od = od + aerosol_abs_layer_rows<NTL>(L, slot, aw, arows);
+          } else {
+            const SpectralArgs& b = kernarg_block<SpectralArgs>();
+            const AerosolLayer al = aerosol_layer<false, NGP, ECRAD_LW_AER_BATCH(MODE)>(b.cfg, L, slot, ib, aw);
+            od = od + al.od;   // radiation_aerosol_optics.F90:805-818 (no longwave aerosol scattering)
+          }
         }
         const LwCoef c = no_scattering_lw(od, planck_top, planck_bot);
         ECRAD_LAP(tm, 3, c.source_dn);  // layer coefficients
+        if (store_late) {
+          pend_t = c.transmittance; pend_su = c.source_up; pend_lev = lev;
+        } else {
 #if !(ECRAD_ABLATE & 8)
-        s.pair(P_CLR, lev, tid) = make_double2(c.transmittance, c.source_up);
+          s.pair(P_CLR, lev, tid) = make_double2(c.transmittance, c.source_up);
 #endif
+        }
         ECRAD_LAP0(tm, 4);              // scratch store acknowledged
         if (MODE != 0) {
           const bool layer_cloudy = L.D(F_FRAC, slot) >= cloud_fraction_threshold;
@@ -330,6 +368,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
 #endif
         planck_top = planck_bot;
       }
+      store_pending();
       if (col_ok && glane < nl) {
         const size_t o = col + ncol * ord.half(l0 + glane + 1);
         lw_dn[o] = keep_dn;

@@ -239,6 +239,9 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
 
 // uniform switches of the level loop, gathered once per column group
 enum { SWF_AEROSOLS = 1, SWF_DELTA_GASES = 2 };
+#ifndef ECRAD_SW_CLASSIC_G0
+#define ECRAD_SW_CLASSIC_G0 1      // the g = 0 form of the classic two-stream routine where the call has no aerosols (kernels_common.h)
+#endif
 
 // SPEC: per-g-point flux profiles wanted (do_save_spectral_flux); a separate instantiation keeps the six
 // extra destinations out of the registers of the common case
@@ -408,7 +411,14 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void s
           }
           double od1 = od, ssa1 = ssa, g1 = asym;
           if (flags & SWF_DELTA_GASES) delta_eddington(od1, ssa1, g1);
+#if ECRAD_SW_CLASSIC_G0
+          // (no aerosols in this call and no stage arrays: the clear-sky asymmetry factor is zero in every layer, a uniform test)
+          const bool g_zero = !(flags & SWF_AEROSOLS) && !staged;
+          const SwCoef c = (MODE == 2) ? ref_trans_sw_fused(mu0, od1, ssa1, g1)
+                                       : (g_zero ? ref_trans_sw_classic_g0(mu0, od1, ssa1) : ref_trans_sw_classic(mu0, od1, ssa1, g1));
+#else
           const SwCoef c = (MODE == 2) ? ref_trans_sw_fused(mu0, od1, ssa1, g1) : ref_trans_sw_classic(mu0, od1, ssa1, g1);
+#endif
           ECRAD_LAP(tm, 3, c.trans_dir_diff + c.ref_dir);   // Rayleigh, delta-Eddington, two-stream
           if (MODE != 0) {
             const bool layer_cloudy = L.D(F_FRAC, slot) >= cloud_fraction_threshold;

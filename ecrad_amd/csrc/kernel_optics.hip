@@ -33,7 +33,7 @@ template <typename OUT> ECRAD_DEV void put_stage(double* arr, size_t o, double v
 #define ECRAD_DUMP_PIPE 1      // the level loop with every load of a layer ahead of the previous layer's stores (see there)
 #endif
 #ifndef ECRAD_DUMP_PIPE_SW
-#define ECRAD_DUMP_PIPE_SW 0
+#define ECRAD_DUMP_PIPE_SW 1
 #endif
 #ifndef ECRAD_DUMP_CHUNK_DIV
 #define ECRAD_DUMP_CHUNK_DIV 1      // 2: half as many levels per chunk of level records (with ECRAD_DUMP_MIN_WAVES=4: a fourth block per CU)
@@ -161,7 +161,8 @@ __global__ __launch_bounds__(kBlock, ECRAD_DUMP_MIN_WAVES) void optics_dump_kern
           const bool aer = cfg.use_aerosols != 0;
           // ---- every load of layer j
           AerosolWeight aw = {0.0, false};
-          AerosolRows<IS_SW ? NT : 1> rows;
+          constexpr int NH = NT / 2;      // shortwave: the types in two halves (36 registers of rows in flight, not 72)
+          AerosolRows<IS_SW ? NH : 1> rows;
           AerosolAbsRows<IS_SW ? 1 : NT> arows;
           if (aer) aw = aerosol_weight(b.in, ord, col, lev, aer_type);
           gas_load<TAB, SKIPQ>(m.hot, quad_count<TAB, IS_SW>(m.hot.nquad), plain_count<TAB, IS_SW>(m.hot.nplain), L, slot, g, quads);
@@ -169,23 +170,30 @@ __global__ __launch_bounds__(kBlock, ECRAD_DUMP_MIN_WAVES) void optics_dump_kern
           const PlanckTab<TAB> pt{m.planck_function, ng};
           if (!IS_SW) ppair = pt.fetch(L.I(I_PL_BOT, slot), g);
           if (aer && aw.in_range) {
-            if constexpr (IS_SW) aerosol_rows_issue<true, NT>(cfg, L, slot, ib, rows);
+            if constexpr (IS_SW) aerosol_rows_issue<true, NH, 0>(cfg, L, slot, ib, rows);
             else aerosol_abs_rows_issue<NT>(cfg, L, slot, ib, arows);
           }
-          asm volatile("" ::: "memory");
-          // ---- the stores of layer j - 1
-          store_pending();
-          asm volatile("" ::: "memory");
           // ---- layer j
           double od = gas_combine<TAB, SKIPQ>(quad_count<TAB, IS_SW>(m.hot.nquad), L, slot, quads);
+          AerosolLayer a = {0.0, 0.0, 0.0};
+          if constexpr (IS_SW) {
+            if (aer && aw.in_range) {      // first half summed, second half requested: the last loads of the layer
+              aerosol_layer_rows_add<NH, 0>(L, slot, aw, rows, a);
+              asm volatile("" ::: "memory");
+              aerosol_rows_issue<true, NH, NH>(cfg, L, slot, ib, rows);
+            }
+          }
+          asm volatile("" ::: "memory");
+          // ---- the stores of layer j - 1, behind every load of layer j
+          store_pending();
+          asm volatile("" ::: "memory");
           if (IS_SW) {
             double ssa = L.D(F_SM, slot) * m.rayleigh_molar_scat[g];
             od = od + ssa;
             ssa = ssa / od;
             double asym = 0.0;
             if (aer) {
-              AerosolLayer a = {0.0, 0.0, 0.0};
-              if constexpr (IS_SW) { if (aw.in_range) a = aerosol_layer_rows<NT>(L, slot, aw, rows); }
+              if constexpr (IS_SW) { if (aw.in_range) aerosol_layer_rows_add<NH, NH>(L, slot, aw, rows, a); }
               if (!cfg.do_sw_delta_scaling_with_gases) delta_eddington_extensive_vec(a);
               merge_aerosol_sw(cfg, a, od, ssa, asym);
             }

@@ -57,6 +57,15 @@
 // whose sweep state is smaller (or hand-allocated registers) to pay.
 #define ECRAD_TC_PIPE 0
 #endif
+#ifndef ECRAD_TC_LW_PIPE
+// 1: longwave pass A (not with aerosol scattering, not on the RRTMG stage arrays, up to 12 active aerosol types): every load of
+// a layer -- gas quads, the Planck pair, the aerosol mixing ratios and the one absorption value per aerosol type -- is requested
+// first, THEN the clear-region record of the layer above is stored, then the layer is computed: the stores of a layer have a
+// layer's arithmetic to complete in before a load queues behind them (memory operations complete in issue order).  Few
+// registers in flight (14 + the quads), unlike the shortwave form (ECRAD_TC_PIPE).  MEASURED AND OFF (gpurun_out/r05_j): longwave kernel 16.95 -> 17.5 ms per
+// 100 000 columns -- this pass does not wait for its stores (the optics pass of the SPARTACUS solvers, which has no sweep state, does: kernel_optics.hip).
+#define ECRAD_TC_LW_PIPE 0
+#endif
 #ifndef ECRAD_TC_AER_AHEAD
 // 1: a layer's aerosol mixing ratios are requested at the top of the layer's work, with the gas-table loads, instead of in a round
 // trip of their own after the gas optics (round 5; either way the level order comes from the column group's set-up: aerosol_weight)
@@ -818,6 +827,18 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
       double* const lw_dn_band = c0.fx.lw_dn_band;
       double* const lw_dn_clear_band = do_clear ? c0.fx.lw_dn_clear_band : nullptr;
       double keep_dn = 0.0;
+      constexpr int NTL = 12;
+      const bool lw_pipe = ECRAD_TC_LW_PIPE && !ASCAT && sizeof(TAB) != 8 && c0.cfg.aerosol.nactive4 <= NTL;
+      // (lw_pipe) the clear-region record of the previous layer, not stored yet
+      double pend_t = 0.0, pend_su = 0.0, pend_sd = 0.0;
+      int pend_lev = -1;
+      bool pend_want_sd = false;
+      auto store_pending = [&]() {
+        if (pend_lev < 0) return;
+        s.pair(TL_A0, pend_lev, tid) = make_double2(pend_t, pend_su);
+        if (pend_want_sd) s.single(TL_SD1, pend_lev, tid) = pend_sd;
+        pend_lev = -1;
+      };
       for (int j = 0; j < nl; ++j) {
         const int lev = l0 + j;
         const int slot = cib * NGP + j;
@@ -828,7 +849,18 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
         if (aer_here) aw = aerosol_weight(kernarg_block<SpectralArgs>().in, ord, col, lev, aer_type);
 #endif
         gas_load<TAB, SKIPQ>(gh, quad_count<TAB, false>(gh.nquad), plain_count<TAB, false>(gh.nplain), L, slot, g, quads);
-        double planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
+        double planck_bot;
+        AerosolAbsRows<NTL> arows;
+        if (lw_pipe) {
+          const typename PlanckTab<TAB>::Pair ppair = pt.fetch(L.I(I_PL_BOT, slot), g);
+          if (aer_here && aw.in_range) aerosol_abs_rows_issue<NTL>(kernarg_block<SpectralArgs>().cfg, L, slot, ib, arows);
+          asm volatile("" ::: "memory");      // (memory operations stay on their side of the fences)
+          store_pending();
+          asm volatile("" ::: "memory");
+          planck_bot = PlanckTab<TAB>::value(ppair, L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot));
+        } else {
+          planck_bot = pt.lookup(L.I(I_PL_BOT, slot), L.D(F_PLW_BOT, slot), g);
+        }
         double od = gas_combine<TAB, SKIPQ>(quad_count<TAB, false>(gh.nquad), L, slot, quads);
         if constexpr (sizeof(TAB) == 8) {
           const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
@@ -852,16 +884,23 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
               ssa = al.scat / local_od;
               od = local_od;
             }
+          } else if (lw_pipe) {
+            if (aw.in_range) od = od + aerosol_abs_layer_rows<NTL>(L, slot, aw, arows);
           } else {
             od = od + aerosol_layer<false, NGP, ECRAD_TC_LW_AER_BATCH>(b.cfg, L, slot, ib, aw).od;
           }
         }
         const LwCoef c = ASCAT ? ref_trans_lw(od, ssa, asym, planck_top, planck_bot) : no_scattering_lw(od, planck_top, planck_bot);
-        s.pair(TL_A0, lev, tid) = make_double2(c.transmittance, c.source_up);
-        if (ASCAT) s.pair(TL_SD1, lev, tid) = make_double2(c.source_dn, c.reflectance);
         const bool layer_cloudy = L.D(F_FRAC, slot) > 0.0;
-        // (without aerosol scattering the downward source of a clear layer is only needed from cloud top down)
-        if (!ASCAT && (layer_cloudy || cloudy.any())) s.single(TL_SD1, lev, tid) = c.source_dn;
+        if (lw_pipe) {
+          pend_t = c.transmittance; pend_su = c.source_up; pend_sd = c.source_dn; pend_lev = lev;
+          pend_want_sd = layer_cloudy || cloudy.any();
+        } else {
+          s.pair(TL_A0, lev, tid) = make_double2(c.transmittance, c.source_up);
+          if (ASCAT) s.pair(TL_SD1, lev, tid) = make_double2(c.source_dn, c.reflectance);
+          // (without aerosol scattering the downward source of a clear layer is only needed from cloud top down)
+          if (!ASCAT && (layer_cloudy || cloudy.any())) s.single(TL_SD1, lev, tid) = c.source_dn;
+        }
         if (layer_cloudy) {
           if (!cloudy.any()) { ict = lev; fdn_ctop = fdn_c; }
           cloudy.set(lev);
@@ -901,6 +940,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
         }
         planck_top = planck_bot;
       }
+      store_pending();
       if (!ASCAT && col_ok && glane < nl) {
         const size_t o = col + ncol * ord.half(l0 + glane + 1);
         lw_dn[o] = keep_dn;      // provisional: replaced below cloud top by the all-sky value

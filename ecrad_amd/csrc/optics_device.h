@@ -638,8 +638,9 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const LdsLayout& L, i
 // The same in two steps for a kernel instantiated for NT active types (a multiple of four) whose rows it wants in flight a
 // layer AHEAD of their use (kernel_tc.hip, ECRAD_TC_PIPE): aerosol_rows_issue requests {mass_ext, ssa} and the asymmetry factor of
 // every type for the layer of `slot`, aerosol_layer_rows is the sum over the types -- the expressions of aerosol_layer, in its order.
+// (K0: the first of the NT types -- a kernel short of registers takes the types in two halves)
 template <int NT> struct AerosolRows { double2 t01[NT]; double t2[NT]; };
-template <bool IS_SW, int NT>
+template <bool IS_SW, int NT, int K0 = 0>
 ECRAD_DEV void aerosol_rows_issue(const DevConfig& cfg, const LdsLayout& L, int slot, int ib, AerosolRows<NT>& r) {
   const DevAerosolOptics& ao = cfg.aerosol;
   const int nb = IS_SW ? ao.n_bands_sw : ao.n_bands_lw;
@@ -649,23 +650,27 @@ ECRAD_DEV void aerosol_rows_issue(const DevConfig& cfg, const LdsLayout& L, int 
   const double* __restrict__ tab2 = IS_SW ? ao.sw_tab2 : ao.lw_tab2;
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
-    const uint32_t desc = ao.active[k];
+    const uint32_t desc = ao.active[K0 + k];
     const size_t o = ib + (size_t)nb * ((int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0));
     r.t01[k] = tab01[o];
     r.t2[k] = tab2[o];
   }
 }
-template <int NT>
-ECRAD_DEV AerosolLayer aerosol_layer_rows(const LdsLayout& L, int slot, const AerosolWeight& aw, const AerosolRows<NT>& r) {
-  AerosolLayer a = {0.0, 0.0, 0.0};
+template <int NT, int K0 = 0>
+ECRAD_DEV void aerosol_layer_rows_add(const LdsLayout& L, int slot, const AerosolWeight& aw, const AerosolRows<NT>& r, AerosolLayer& a) {
   const double w_mine = L.D(F_DPG, slot) * aw.w;
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
-    const double local_od = row_bcast_k(w_mine, k) * r.t01[k].x;
+    const double local_od = row_bcast_k(w_mine, K0 + k) * r.t01[k].x;
     a.od = a.od + local_od;
     a.scat = a.scat + local_od * r.t01[k].y;
     a.scat_g = a.scat_g + local_od * r.t01[k].y * r.t2[k];
   }
+}
+template <int NT>
+ECRAD_DEV AerosolLayer aerosol_layer_rows(const LdsLayout& L, int slot, const AerosolWeight& aw, const AerosolRows<NT>& r) {
+  AerosolLayer a = {0.0, 0.0, 0.0};
+  aerosol_layer_rows_add<NT, 0>(L, slot, aw, r, a);
   return a;
 }
 
