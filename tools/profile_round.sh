@@ -15,6 +15,9 @@ cp gpurun_out/$TAG/bench.json $out/${TAG}_bench.json 2>/dev/null
 timeout 500 bash tools/pmc_sq.sh ${TAG}_sq --headline-only < /dev/null > $out/sq_headline.log 2>&1
 timeout 500 bash tools/pmc_sq.sh ${TAG}_sq_tc --headline-only --workload tripleclouds_ecckd32 < /dev/null > $out/sq_tripleclouds.log 2>&1
 timeout 500 bash tools/pmc_sq.sh ${TAG}_sq_mc --headline-only --workload mcica_ecckd32 < /dev/null > $out/sq_mcica.log 2>&1
+timeout 600 bash tools/pmc_sq.sh ${TAG}_sq_rr --headline-only --workload mcica_rrtmg < /dev/null > $out/sq_rrtmg.log 2>&1
+timeout 600 bash tools/pmc_sq.sh ${TAG}_sq_sp --headline-only --workload spartacus_ecckd32_sp < /dev/null > $out/sq_spartacus.log 2>&1
+python tools/summarize_sq.py $TAG $out > $out/sq_summary.txt 2>&1; cp profiles/${TAG}_sq.json $out/ 2>/dev/null
 find gpurun_out -name "*.db" -delete
 rm -rf gpurun_out/$TAG/stats gpurun_out/$TAG/fetch gpurun_out/$TAG/write
 du -sh gpurun_out | tail -1
