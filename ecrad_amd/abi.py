@@ -254,6 +254,10 @@ def declare_prototypes(lib) -> None:
     lib.ecrad_hip_radiation.restype = C.c_int
     lib.ecrad_hip_radiation_f32.argtypes = lib.ecrad_hip_radiation.argtypes      # (same structs, float arrays behind the pointers)
     lib.ecrad_hip_radiation_f32.restype = C.c_int
+    lib.ecrad_hip_host_register.argtypes = [H, C.c_void_p, C.c_size_t]
+    lib.ecrad_hip_host_register.restype = C.c_int
+    lib.ecrad_hip_host_unregister.argtypes = [H, C.c_void_p]
+    lib.ecrad_hip_host_unregister.restype = C.c_int
     lib.ecrad_hip_optics.argtypes = [H, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.POINTER(Inputs), C.POINTER(Optics)]
     lib.ecrad_hip_optics.restype = C.c_int
@@ -295,5 +299,5 @@ EXPORTED_SYMBOLS = [
     "ecrad_hip_scratch_bytes", "ecrad_hip_last_error", "ecrad_hip_destroy",
     "ecrad_hip_abi_sizeof", "ecrad_hip_abi_version", "ecrad_hip_set_work_bytes", "ecrad_hip_last_call_info",
     "ecrad_hip_hbm_triad", "ecrad_hip_set_concurrency", "ecrad_hip_pool_info", "ecrad_hip_pool_reset",
-    "ecrad_hip_pcie_bandwidth", "ecrad_hip_radiation_f32",
+    "ecrad_hip_pcie_bandwidth", "ecrad_hip_radiation_f32", "ecrad_hip_host_register", "ecrad_hip_host_unregister",
 ]

@@ -166,6 +166,25 @@ int ecrad_hip_radiation_f32(ecrad_hip_handle_t h, int ncol, int nlev, int istart
 
 extern "C" {
 
+int ecrad_hip_host_register(ecrad_hip_handle_t h, void* p, size_t bytes) {
+  if (!h || !p || bytes == 0) return ECRAD_EINVAL;
+  // (portable: page-locked for every device of the pool, not only the calling thread's current one)
+  if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail_call(h, ECRAD_EHIP, "hipHostRegister refused the range (already registered, or not host memory)");
+  }
+  return ECRAD_OK;
+}
+
+int ecrad_hip_host_unregister(ecrad_hip_handle_t h, void* p) {
+  if (!h || !p) return ECRAD_EINVAL;
+  if (hipHostUnregister(p) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail_call(h, ECRAD_EHIP, "hipHostUnregister: the range is not registered");
+  }
+  return ECRAD_OK;
+}
+
 int ecrad_hip_optics(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int iendcol,
                      const ecrad_inputs_t* in, ecrad_optics_t* out) {
   if (!h || !in || !out) return ECRAD_EINVAL;

@@ -191,6 +191,18 @@ module ecrad_hip_binding
       type(ecrad_flux_t), intent(inout) :: flux
       integer(c_int) :: status
     end function
+    ! page-lock a range of the host's own memory for the copy engines (optional; include/ecrad_hip.h)
+    function ecrad_hip_host_register(handle, p, bytes) bind(C, name='ecrad_hip_host_register') result(status)
+      import :: c_ptr, c_int, c_size_t
+      type(c_ptr), value :: handle, p
+      integer(c_size_t), value :: bytes
+      integer(c_int) :: status
+    end function
+    function ecrad_hip_host_unregister(handle, p) bind(C, name='ecrad_hip_host_unregister') result(status)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: handle, p
+      integer(c_int) :: status
+    end function
     ! the pool of (device, stream, work arrays) contexts that concurrent calls are spread over (include/ecrad_hip.h)
     function ecrad_hip_set_concurrency(handle, n_devices, contexts_per_device) bind(C, name='ecrad_hip_set_concurrency') result(status)
       import :: c_ptr, c_int

@@ -471,6 +471,16 @@ int ecrad_hip_hbm_triad(ecrad_hip_handle_t handle, size_t nbytes_per_array, int 
    host-memory call (ecrad_hip_radiation) cannot move its columns faster than this: measurement aid of bench.py. */
 int ecrad_hip_pcie_bandwidth(ecrad_hip_handle_t handle, size_t nbytes, int repeats, double* h2d_gbs, double* d2h_gbs, double* duplex_gbs);
 
+/* Page-lock (and map for the devices of the pool) a range of the CALLER's host memory, and release it again.  Optional: a
+   host-memory call works on pageable arrays, which the runtime stages through buffers of its own by the calling threads --
+   40 of the link's 57 GB/s at best; arrays registered ONCE (a host model's arrays live as long as the model runs) are read and written by
+   the copy engines directly, and the tiles of a pipelined call (8192 columns or more) then move at the link's rate.  Thin
+   wrappers over hipHostRegister / hipHostUnregister so that a Fortran host need not link the HIP runtime itself; the range
+   must stay allocated until it is unregistered.  ecrad_hip_host_register fails with ECRAD_EHIP (and changes nothing) when
+   the runtime refuses the range, e.g. because part of it is registered already. */
+int ecrad_hip_host_register(ecrad_hip_handle_t handle, void* p, size_t bytes);
+int ecrad_hip_host_unregister(ecrad_hip_handle_t handle, void* p);
+
 /* Bytes of device work arrays held by the context the calling thread's most recent call ran on (at the end of that call). */
 int ecrad_hip_scratch_bytes(ecrad_hip_handle_t handle, size_t* bytes);
 

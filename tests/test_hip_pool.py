@@ -384,6 +384,41 @@ def test_eight_device_slots_mapped_onto_this_gpu(solver, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_registered_host_arrays_give_the_same_bits():
+    """ecrad_hip_host_register (include/ecrad_hip.h): the caller's arrays page-locked once, the pipelined host-memory call then
+    moves its tiles by the copy engines directly.  Same bits as the call on pageable arrays; a range registered twice is refused
+    with a status, not a fault; unregistering gives the memory back."""
+    from ecrad_amd.interface import build_flux_struct, build_inputs_struct
+    ncol = 20000
+    config = make_config("Tripleclouds")
+    n, nlev, sl, th, gas, cloud, aer = make_columns(config, ncol, False)
+    frac0 = cloud.fraction.copy()
+    rad = Radiation(config, backend="hip")
+    ref = Flux.allocate(config, n, nlev)
+    rad.radiation(n, nlev, 1, n, sl, th, gas, cloud, aer, ref)
+    frac_ref = cloud.fraction.copy()
+    cloud.fraction[...] = frac0
+    flux = Flux.allocate(config, n, nlev)
+    cin, keep = build_inputs_struct(config, n, nlev, sl, th, gas, cloud, aer)
+    cflux = build_flux_struct(flux)
+    arrays = [a for a in keep + [cloud.fraction] + list(flux.arrays.values()) if a.nbytes >= (1 << 16)]
+    lib, h = rad.lib, rad.handle
+    pinned = [a for a in arrays if lib.ecrad_hip_host_register(h, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes)) == 0]
+    assert len(pinned) >= len(arrays) - 2, (len(pinned), len(arrays))      # (two small arrays may share a page with a pinned neighbour)
+    assert lib.ecrad_hip_host_register(h, C.c_void_p(pinned[0].ctypes.data), C.c_size_t(pinned[0].nbytes)) != 0
+    assert b"hipHostRegister" in lib.ecrad_hip_last_error(h)
+    try:
+        assert lib.ecrad_hip_radiation(h, n, nlev, 1, n, C.byref(cin), C.byref(cflux)) == 0, lib.ecrad_hip_last_error(h)
+    finally:
+        for a in pinned:
+            assert lib.ecrad_hip_host_unregister(h, C.c_void_p(a.ctypes.data)) == 0
+    assert lib.ecrad_hip_host_unregister(h, C.c_void_p(pinned[0].ctypes.data)) != 0
+    _flux_equal(ref, flux)
+    assert np.array_equal(cloud.fraction, frac_ref)
+    rad.close()
+
+
+@pytest.mark.gpu
 def test_zz_rounds_repeated_to_show_overlap():
     """Last test of the file: how often a 16-thread round of the concurrency test above had to be repeated before it showed the
     overlap it asserts (the bits are compared in every round; what is repeated is only the demonstration that calls were in
