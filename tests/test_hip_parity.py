@@ -464,6 +464,37 @@ def test_compile_time_quad_counts_change_nothing():
         print(solver, "compile-time vs run-time quad counts:", max(worst.values()))
 
 
+def test_compile_time_configuration_changes_nothing(monkeypatch):
+    """The Tripleclouds shortwave kernel runs the reference's test configuration (clear-sky fluxes, aerosols on every level, per-g-point
+    optics, no spectral profiles) as an instantiation with that configuration at compile time (kernel_tc.hip: FX = 1,
+    sw_tc_fixed_config).  ECRAD_HIP_NO_FIXED_CONFIG in the environment of a call keeps it on the run-time switches every other
+    configuration uses: the same bits, on the meridian slice and on 2 048 synthetic columns."""
+    import numpy as np
+    from ecrad_amd.interface import Radiation
+    from ecrad_amd.synthetic import make_columns
+    from ecrad_amd.types import Flux
+    config = make_config("Tripleclouds")
+    rad = Radiation(config, backend="hip")
+    for inputs in (load_meridian(config), make_columns(config, 2048, False)):
+        ncol, nlev, sl, th, gas, cloud, aer = inputs
+        rad.set_gas_units(gas)
+        th.calc_saturation_wrt_liquid()
+        frac0 = cloud.fraction.copy()
+        out = []
+        for generic in (False, True):
+            if generic:
+                monkeypatch.setenv("ECRAD_HIP_NO_FIXED_CONFIG", "1")
+            else:
+                monkeypatch.delenv("ECRAD_HIP_NO_FIXED_CONFIG", raising=False)
+            cloud.fraction[...] = frac0
+            flux = Flux.allocate(config, ncol, nlev)
+            rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)
+            out.append(flux)
+        for name, a in out[0].arrays.items():
+            assert np.array_equal(a, out[1].arrays[name], equal_nan=True), name
+    rad.close()
+
+
 def test_switched_off_forms_of_round_4_still_give_the_same_fluxes():
     """Round 4 built several restructurings that were measured and left OFF (profiles/r04_variants.log): one upward sweep W for the
     McICA longwave instead of B1 / V / derivative sweeps (ECRAD_LW_MERGED), four sums over g per butterfly in the clear-sky longwave
