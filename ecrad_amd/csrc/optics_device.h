@@ -284,6 +284,16 @@ inline bool layout_is_std_quads(const DevCkdModel& m) {
 inline bool model_has_std_quads(const DevCkdModel& m) { return m.std_quads != 0; }
 
 // Registers holding one layer's table quads for one lane, and which cells they were loaded from.
+// A table value at a UNIFORM base plus a 32-bit BYTE offset per lane: the form the hardware takes directly (`global_load ... v_off,
+// s[base:base+1]`): one register and one add per address instead of a 64-bit multiply-add and a register pair (round 5:
+// the aerosol optics spent 8 vector instructions per type on addresses, ECRAD_OFF32).  The tables are a few hundred KB.
+#ifndef ECRAD_OFF32
+#define ECRAD_OFF32 1
+#endif
+template <typename T> ECRAD_DEV T load_off32(const void* base, uint32_t byte_offset) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_offset);
+}
+
 // Model layers are finer than the table's (p,T) grid, so consecutive layers of a column mostly fall
 // in the same cell: the quads are then still valid and only the interpolation weights change.
 template <typename TAB>
@@ -339,8 +349,13 @@ ECRAD_DEV void gas_load(const GasHot& gh, int nquad, int nplain, const LdsLayout
         r.q[k + 1] = r.q[k];
 #else
         const unsigned base = is_plain ? plain_g : lut_g;
+#if ECRAD_OFF32
+        r.q[k] = load_off32<Quad>(tab, (base + (uint32_t)gh.qoff[k]) * (uint32_t)sizeof(Quad));
+        if (k + 1 != SKIP) r.q[k + 1] = load_off32<Quad>(tab, (base + (uint32_t)gh.qoff[k + 1]) * (uint32_t)sizeof(Quad));      // (SKIP: the padding quad of a fixed layout)
+#else
         r.q[k] = tab[base + gh.qoff[k]];
         if (k + 1 != SKIP) r.q[k + 1] = tab[base + gh.qoff[k + 1]];      // (SKIP: the padding quad of a fixed layout)
+#endif
 #endif
       }
     }
@@ -403,7 +418,11 @@ struct PlanckTab {
     using Pair = typename QuadOf<TAB>::pair;
     const Pair* __restrict__ pf = reinterpret_cast<const Pair*>(table);
     if (it >= 0) {
+#if ECRAD_OFF32
+      const Pair p = load_off32<Pair>(pf, (uint32_t)(g + ng * it) * (uint32_t)sizeof(Pair));
+#else
       const Pair p = pf[g + ng * it];
+#endif
       return (1.0 - w2) * p.x + w2 * p.y;
     }
     return (double)pf[g].x * w2;
@@ -414,7 +433,11 @@ struct PlanckTab {
   ECRAD_DEV Pair fetch(int it, int g) const {
     if constexpr (IsStage<TAB>::value) return Pair{};
     const Pair* __restrict__ pf = reinterpret_cast<const Pair*>(table);
+#if ECRAD_OFF32
+    return load_off32<Pair>(pf, (uint32_t)(g + ng * (it >= 0 ? it : 0)) * (uint32_t)sizeof(Pair));
+#else
     return pf[g + ng * (it >= 0 ? it : 0)];
+#endif
   }
   static ECRAD_DEV double value(const Pair& p, int it, double w2) {
     if constexpr (IsStage<TAB>::value) return 0.0;
@@ -555,6 +578,11 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const LdsLayout& L, i
   // the layer mass, and the unrolled type loop broadcasts the product over the row with one DPP move per type (row_newbcast:
   // the only DPP pattern that moves 64 bits at a time).
   const double w_mine = factor * aw.w;
+#if ECRAD_OFF32
+  // byte offsets into a table of doubles of a hydrophobic type's row (no humidity bin) and of a hydrophilic one's, for this lane
+  const uint32_t off_pho = (uint32_t)ib * 8u, off_phi = off_pho + (uint32_t)rh_row * (uint32_t)nb * 8u;
+  const uint32_t row_bytes = (uint32_t)nb * 8u;
+#endif
   if (!scattering) {
     // longwave absorption only (:655-662): one table value per type
     const double* __restrict__ tab = ao.lw_abs;
@@ -572,6 +600,8 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const LdsLayout& L, i
             const int row = (int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0);
 #if ECRAD_ABLATE & 16
             t[u] = 1e-3 * (row & 7);
+#elif ECRAD_OFF32
+            t[u] = load_off32<double>(tab, ((desc & 0x100u) ? off_phi : off_pho) + (desc >> 9) * row_bytes);
 #else
             t[u] = tab[ib + (size_t)nb * row];
 #endif
@@ -610,6 +640,10 @@ ECRAD_DEV AerosolLayer aerosol_layer(const DevConfig& cfg, const LdsLayout& L, i
           const size_t o = ib + (size_t)nb * row;
 #if ECRAD_ABLATE & 16
           t01[u] = make_double2(1e-3 * (row & 7), 0.5); t2[u] = 0.5;
+#elif ECRAD_OFF32
+          const uint32_t o8 = ((desc & 0x100u) ? off_phi : off_pho) + (desc >> 9) * row_bytes;
+          t01[u] = load_off32<double2>(tab01, 2u * o8);      // mass_ext, ssa
+          t2[u] = load_off32<double>(tab2, o8);              // asymmetry
 #else
           t01[u] = tab01[o];                       // mass_ext, ssa
           t2[u] = tab2[o];                         // asymmetry
@@ -648,12 +682,21 @@ ECRAD_DEV void aerosol_rows_issue(const DevConfig& cfg, const LdsLayout& L, int 
   const int rh_row = irh > 0 ? irh - 1 : 0;
   const double2* __restrict__ tab01 = reinterpret_cast<const double2*>(IS_SW ? ao.sw_tab01 : ao.lw_tab01);
   const double* __restrict__ tab2 = IS_SW ? ao.sw_tab2 : ao.lw_tab2;
+#if ECRAD_OFF32
+  const uint32_t off_pho = (uint32_t)ib * 8u, off_phi = off_pho + (uint32_t)rh_row * (uint32_t)nb * 8u, row_bytes = (uint32_t)nb * 8u;
+#endif
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     const uint32_t desc = ao.active[K0 + k];
+#if ECRAD_OFF32
+    const uint32_t o8 = ((desc & 0x100u) ? off_phi : off_pho) + (desc >> 9) * row_bytes;
+    r.t01[k] = load_off32<double2>(tab01, 2u * o8);
+    r.t2[k] = load_off32<double>(tab2, o8);
+#else
     const size_t o = ib + (size_t)nb * ((int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0));
     r.t01[k] = tab01[o];
     r.t2[k] = tab2[o];
+#endif
   }
 }
 template <int NT, int K0 = 0>
@@ -683,10 +726,17 @@ ECRAD_DEV void aerosol_abs_rows_issue(const DevConfig& cfg, const LdsLayout& L, 
   const int irh = L.I(I_RH, slot);
   const int rh_row = irh > 0 ? irh - 1 : 0;
   const double* __restrict__ tab = ao.lw_abs;
+#if ECRAD_OFF32
+  const uint32_t off_pho = (uint32_t)ib * 8u, off_phi = off_pho + (uint32_t)rh_row * (uint32_t)nb * 8u, row_bytes = (uint32_t)nb * 8u;
+#endif
 #pragma unroll
   for (int k = 0; k < NT; ++k) {
     const uint32_t desc = ao.active[k];
+#if ECRAD_OFF32
+    r.t[k] = load_off32<double>(tab, ((desc & 0x100u) ? off_phi : off_pho) + (desc >> 9) * row_bytes);
+#else
     r.t[k] = tab[ib + (size_t)nb * ((int)(desc >> 9) + ((desc & 0x100u) ? rh_row : 0))];
+#endif
   }
 }
 template <int NT>
