@@ -386,8 +386,8 @@ def test_eight_device_slots_mapped_onto_this_gpu(solver, monkeypatch):
 @pytest.mark.gpu
 def test_registered_host_arrays_give_the_same_bits():
     """ecrad_hip_host_register (include/ecrad_hip.h): the caller's arrays page-locked once, the pipelined host-memory call then
-    moves its tiles by the copy engines directly.  Same bits as the call on pageable arrays; a range registered twice is refused
-    with a status, not a fault; unregistering gives the memory back."""
+    moves its tiles by the copy engines directly.  Same bits as the call on pageable arrays; bad arguments are a status, not a
+    fault; unregistering gives the memory back."""
     from ecrad_amd.interface import build_flux_struct, build_inputs_struct
     ncol = 20000
     config = make_config("Tripleclouds")
@@ -405,14 +405,16 @@ def test_registered_host_arrays_give_the_same_bits():
     lib, h = rad.lib, rad.handle
     pinned = [a for a in arrays if lib.ecrad_hip_host_register(h, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes)) == 0]
     assert len(pinned) >= len(arrays) - 2, (len(pinned), len(arrays))      # (two small arrays may share a page with a pinned neighbour)
-    assert lib.ecrad_hip_host_register(h, C.c_void_p(pinned[0].ctypes.data), C.c_size_t(pinned[0].nbytes)) != 0
-    assert b"hipHostRegister" in lib.ecrad_hip_last_error(h)
+    # (a null range is an argument error; whether a range may be registered twice is the runtime's business -- ROCm 7.2 allows it)
+    assert lib.ecrad_hip_host_register(h, None, C.c_size_t(8)) != 0
     try:
         assert lib.ecrad_hip_radiation(h, n, nlev, 1, n, C.byref(cin), C.byref(cflux)) == 0, lib.ecrad_hip_last_error(h)
     finally:
         for a in pinned:
             assert lib.ecrad_hip_host_unregister(h, C.c_void_p(a.ctypes.data)) == 0
-    assert lib.ecrad_hip_host_unregister(h, C.c_void_p(pinned[0].ctypes.data)) != 0
+    unknown = np.zeros(1 << 14)
+    assert lib.ecrad_hip_host_unregister(h, C.c_void_p(unknown.ctypes.data)) != 0      # never registered: a status, not a fault
+    assert b"hipHostUnregister" in lib.ecrad_hip_last_error(h)
     _flux_equal(ref, flux)
     assert np.array_equal(cloud.fraction, frac_ref)
     rad.close()
