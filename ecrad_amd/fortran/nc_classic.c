@@ -55,6 +55,7 @@ typedef struct {
 } File;
 
 static File g_files[ECNC_MAX_FILES];
+static int ecnc_h5_enddef(File* f);
 
 static size_t tsize(int t) { return t == T_BYTE || t == T_CHAR ? 1 : t == T_SHORT ? 2 : t == T_INT || t == T_FLOAT ? 4 : t == T_DOUBLE ? 8 : 0; }
 static uint64_t pad4(uint64_t n) { return (n + 3) & ~(uint64_t)3; }
@@ -233,7 +234,8 @@ int ecnc_create(const char* path, int use_64bit_offset, int* ncid) {
   if (st) return st;
   f->fp = fopen(path, "wb+");
   if (!f->fp) { st = errno ? errno : 13; f->used = 0; return st; }
-  f->writable = 1; f->define_mode = 1; f->version = use_64bit_offset ? 2 : 1;
+  /* (use_64bit_offset: 0 = CDF-1, 1 = CDF-2, 2 = netCDF-4 / HDF5: ecnc_h5_enddef below) */
+  f->writable = 1; f->define_mode = 1; f->version = use_64bit_offset == 2 ? 5 : use_64bit_offset ? 2 : 1;
   return 0;
 }
 
@@ -387,6 +389,7 @@ int ecnc_enddef(int ncid) {
   File* f = file_of(ncid);
   if (!f) return E_BADID;
   if (!f->define_mode) return E_NOTINDEFINE;
+  if (f->version == 5) return ecnc_h5_enddef(f);
   /* header size, then the variables one after the other */
   const uint64_t beg_bytes = f->version == 2 ? 8 : 4;
   uint64_t h = 8 + 8;
@@ -534,11 +537,11 @@ static int vara(int ncid, int varid, int memtype, void* buf, int nidx, const lon
     if (writing) {
       int cs = convert(mem, memtype, tmp, v->type, (uint64_t)run);
       if (cs == E_RANGE) range = 1; else if (cs) { st = cs; break; }
-      swap_in_place(tmp, ts, (uint64_t)run);
+      if (f->version != 5) swap_in_place(tmp, ts, (uint64_t)run);      /* (an HDF5 file of this library holds little-endian values) */
       if (fwrite(tmp, ts, (size_t)run, f->fp) != (size_t)run) { st = errno ? errno : 5; break; }
     } else {
       if (fread(tmp, ts, (size_t)run, f->fp) != (size_t)run) { st = E_EDGE; break; }
-      swap_in_place(tmp, ts, (uint64_t)run);
+      if (f->version != 5) swap_in_place(tmp, ts, (uint64_t)run);
       int cs = convert(tmp, v->type, mem, memtype, (uint64_t)run);
       if (cs == E_RANGE) range = 1; else if (cs) { st = cs; break; }
     }
@@ -592,6 +595,355 @@ const char* ecnc_strerror(int st) {
     case E_NOMEM: return "NetCDF: Memory allocation (malloc) failure";
     default: return st > 0 ? strerror(st) : "NetCDF: Unknown error";
   }
+}
+
+
+/* ==== netCDF-4 / HDF5 output ========================================================================================
+ * nf90_create(..., NF90_HDF5) -- easy_netcdf's is_hdf5_file (utilities/easy_netcdf.F90:212-245), the driver namelist's
+ * do_write_hdf5 -- gives a file in the HDF5 format, written directly (the image has no libnetcdf / libhdf5 for the Fortran
+ * host): the same subset, laid out the same way, as the Python host's writer (ecrad_amd/hdf5file.py: write_nc4, which
+ * tests/test_hdf5_output.py reads back with the HDF5 library's own C API) --
+ *   superblock version 0; the root group in the original symbol-table form (one B-tree node, a local heap, one symbol node);
+ *   version-1 object headers; contiguous little-endian datasets of int32 / float32 / float64; attributes in the object
+ *   headers; one global heap collection for the variable-length DIMENSION_LIST attributes;
+ * plus what makes an HDF5 file a netCDF-4 file (libnetcdf's nc4hdf.c): every dimension a "dimension scale" dataset (CLASS,
+ * NAME, _Netcdf4Dimid, REFERENCE_LIST), every variable with DIMENSION_LIST and _Netcdf4Coordinates, _NCProperties on the root.
+ * Define mode collects dimensions, variables and attributes as for the classic format; ecnc_h5_enddef lays the whole file out
+ * (every size is known then), writes the metadata and reserves the data; ecnc_put_vara then writes into the datasets at
+ * Var.begin exactly as it does for a classic file, minus the byte swap.  Fixed dimensions; numeric variables (byte, short, int,
+ * float, double: radiation_save.F90 writes float / double / int); files written this way are not read back by this library (ecnc_open reads classic).
+ */
+typedef struct { unsigned char* p; size_t n, cap; } HBuf;
+static void hb_need(HBuf* b, size_t more) {
+  if (b->n + more <= b->cap) return;
+  size_t cap = b->cap ? b->cap : 256;
+  while (cap < b->n + more) cap *= 2;
+  b->p = (unsigned char*)realloc(b->p, cap);
+  b->cap = cap;
+}
+static void hb_put(HBuf* b, const void* src, size_t n) { hb_need(b, n); if (n) memcpy(b->p + b->n, src, n); b->n += n; }
+static void hb_zero(HBuf* b, size_t n) { hb_need(b, n); memset(b->p + b->n, 0, n); b->n += n; }
+static void hb_u8(HBuf* b, unsigned v) { unsigned char c = (unsigned char)v; hb_put(b, &c, 1); }
+static void hb_u16(HBuf* b, unsigned v) { unsigned char c[2] = {(unsigned char)v, (unsigned char)(v >> 8)}; hb_put(b, c, 2); }
+static void hb_u32(HBuf* b, uint32_t v) { unsigned char c[4] = {(unsigned char)v, (unsigned char)(v >> 8), (unsigned char)(v >> 16), (unsigned char)(v >> 24)}; hb_put(b, c, 4); }
+static void hb_u64(HBuf* b, uint64_t v) { hb_u32(b, (uint32_t)v); hb_u32(b, (uint32_t)(v >> 32)); }
+static void hb_pad8(HBuf* b, size_t from) { const size_t len = b->n - from; hb_zero(b, (8 - len % 8) % 8); }
+static void hb_free(HBuf* b) { free(b->p); b->p = NULL; b->n = b->cap = 0; }
+#define H5_UNDEF 0xFFFFFFFFFFFFFFFFull
+#define H5_LEAF_K 64
+#define H5_INTERNAL_K 16
+
+/* ---- datatype messages */
+static void h5_dt_float(HBuf* b, int nbytes) {
+  if (nbytes == 8) { hb_u8(b, 0x11); hb_u8(b, 0x20); hb_u8(b, 0x3F); hb_u8(b, 0); hb_u32(b, 8); hb_u16(b, 0); hb_u16(b, 64); hb_u8(b, 52); hb_u8(b, 11); hb_u8(b, 0); hb_u8(b, 52); hb_u32(b, 1023); }
+  else { hb_u8(b, 0x11); hb_u8(b, 0x20); hb_u8(b, 0x1F); hb_u8(b, 0); hb_u32(b, 4); hb_u16(b, 0); hb_u16(b, 32); hb_u8(b, 23); hb_u8(b, 8); hb_u8(b, 0); hb_u8(b, 23); hb_u32(b, 127); }
+}
+static void h5_dt_int(HBuf* b, unsigned nbytes) { hb_u8(b, 0x10); hb_u8(b, 0x08); hb_u8(b, 0); hb_u8(b, 0); hb_u32(b, nbytes); hb_u16(b, 0); hb_u16(b, 8 * nbytes); }      /* signed, little-endian */
+static void h5_dt_int32(HBuf* b) { h5_dt_int(b, 4); }
+static void h5_dt_string(HBuf* b, uint32_t n) { hb_u8(b, 0x13); hb_u8(b, 0); hb_u8(b, 0); hb_u8(b, 0); hb_u32(b, n); }
+static void h5_dt_objref(HBuf* b) { hb_u8(b, 0x17); hb_u8(b, 0); hb_u8(b, 0); hb_u8(b, 0); hb_u32(b, 8); }
+static void h5_dt_vlen_objref(HBuf* b) { hb_u8(b, 0x19); hb_u8(b, 0); hb_u8(b, 0); hb_u8(b, 0); hb_u32(b, 16); h5_dt_objref(b); }
+static void h5_dt_member(HBuf* b, const char* name, uint32_t offset, int is_ref) {
+  const size_t from = b->n;
+  hb_put(b, name, strlen(name) + 1); hb_pad8(b, from);
+  hb_u32(b, offset); hb_u8(b, 0); hb_zero(b, 3); hb_u32(b, 0); hb_u32(b, 0); for (int k = 0; k < 4; ++k) hb_u32(b, 0);
+  if (is_ref) h5_dt_objref(b); else h5_dt_int32(b);
+}
+static void h5_dt_reference_list(HBuf* b) {      /* compound { object reference "dataset" @0; int32 "dimension" @8 }, 16 bytes */
+  hb_u8(b, 0x16); hb_u8(b, 2); hb_u8(b, 0); hb_u8(b, 0); hb_u32(b, 16);
+  h5_dt_member(b, "dataset", 0, 1); h5_dt_member(b, "dimension", 8, 0);
+}
+static void h5_dataspace(HBuf* b, int rank, const uint64_t* shape) {
+  hb_u8(b, 1); hb_u8(b, (unsigned)rank); hb_u8(b, 0); hb_u8(b, 0); hb_u32(b, 0);
+  for (int k = 0; k < rank; ++k) hb_u64(b, shape[k]);
+}
+/* attribute message: name, datatype and dataspace each padded to 8 bytes, then the data */
+static void h5_attribute(HBuf* out, const char* name, const HBuf* dtype, int rank, const uint64_t* shape, const void* data, size_t nbytes) {
+  HBuf ds = {0};
+  h5_dataspace(&ds, rank, shape);
+  const size_t nm = strlen(name) + 1;
+  hb_u8(out, 1); hb_u8(out, 0); hb_u16(out, (unsigned)nm); hb_u16(out, (unsigned)dtype->n); hb_u16(out, (unsigned)ds.n);
+  size_t from = out->n; hb_put(out, name, nm); hb_pad8(out, from);
+  from = out->n; hb_put(out, dtype->p, dtype->n); hb_pad8(out, from);
+  from = out->n; hb_put(out, ds.p, ds.n); hb_pad8(out, from);
+  hb_put(out, data, nbytes);
+  hb_free(&ds);
+}
+static void h5_attr_string(HBuf* out, const char* name, const char* value, size_t len /* without the terminator */) {
+  HBuf dt = {0};
+  char* v = (char*)calloc(1, len + 1);
+  memcpy(v, value, len);
+  h5_dt_string(&dt, (uint32_t)(len + 1));
+  h5_attribute(out, name, &dt, 0, NULL, v, len + 1);
+  free(v);
+  hb_free(&dt);
+}
+/* a numeric attribute as the Python writer stores it: integers (byte, short, int) as int32, float as float32, double as float64 */
+static void h5_attr_numeric(HBuf* out, const Att* a) {
+  HBuf dt = {0}, data = {0};
+  const uint64_t shape[1] = {a->n};
+  if (a->type == T_FLOAT) { h5_dt_float(&dt, 4); hb_put(&data, a->v, (size_t)a->n * 4); }
+  else if (a->type == T_DOUBLE) { h5_dt_float(&dt, 8); hb_put(&data, a->v, (size_t)a->n * 8); }
+  else {
+    h5_dt_int32(&dt);
+    for (uint64_t i = 0; i < a->n; ++i)
+      hb_u32(&data, (uint32_t)(a->type == T_BYTE ? ((const signed char*)a->v)[i] : a->type == T_SHORT ? ((const int16_t*)a->v)[i] : ((const int32_t*)a->v)[i]));
+  }
+  h5_attribute(out, a->name, &dt, 1, shape, data.p, data.n);
+  hb_free(&dt); hb_free(&data);
+}
+static void h5_user_attr(HBuf* out, const Att* a) {
+  if (a->type == T_CHAR) h5_attr_string(out, a->name, (const char*)a->v, (size_t)a->n);
+  else h5_attr_numeric(out, a);
+}
+
+typedef struct {
+  char name[ECNC_MAX_NAME];
+  int varid;            /* the variable this dataset is, or -1: a dimension without a variable of its name */
+  int dimid;            /* the dimension this dataset is the scale of, or -1 */
+  int is_coord;         /* a scale that is also a (coordinate) variable */
+  int rank, type;
+  int dn[ECNC_MAX_DIMS];        /* dimension ids of a variable (none for a pure scale) */
+  int ndn;
+  uint64_t shape[ECNC_MAX_DIMS];
+  uint64_t addr, data_addr, nbytes;
+} H5Obj;
+typedef struct { int obj, k, dim; } H5Ref;      /* (dataset, index of the dimension in it, dimension) */
+
+static int h5_cmp_obj(const void* a, const void* b) { return strcmp(((const H5Obj*)a)->name, ((const H5Obj*)b)->name); }
+
+/* messages of one object header (version 1): type, size of the padded body, flags, 3 reserved bytes, body */
+static void h5_message(HBuf* hdr, unsigned type, const HBuf* body, int* nmsg) {
+  const size_t padded = (body->n + 7) & ~(size_t)7;
+  hb_u16(hdr, type); hb_u16(hdr, (unsigned)padded); hb_u8(hdr, 0); hb_zero(hdr, 3);
+  hb_put(hdr, body->p, body->n); hb_zero(hdr, padded - body->n);
+  ++*nmsg;
+}
+static void h5_object_header(HBuf* out, const HBuf* messages, int nmsg) {
+  hb_u8(out, 1); hb_u8(out, 0); hb_u16(out, (unsigned)nmsg); hb_u32(out, 1); hb_u32(out, (uint32_t)messages->n); hb_zero(out, 4);
+  hb_put(out, messages->p, messages->n);
+}
+
+static int ecnc_h5_enddef(File* f) {
+  for (int d = 0; d < f->ndim; ++d) if (f->dim[d].len == 0) return E_UNLIMIT;
+  for (int v = 0; v < f->nvar; ++v) if (f->var[v].type == T_CHAR) return E_BADTYPE;      /* (no text variables: radiation_save.F90 writes none) */
+  const int nobj_max = f->nvar + f->ndim;
+  if (nobj_max > 2 * H5_LEAF_K) return E_MAXDIMS;      /* (one symbol-table node: up to 128 dimensions + variables) */
+  H5Obj* objs = (H5Obj*)calloc((size_t)nobj_max + 1, sizeof(H5Obj));
+  if (!objs) return E_NOMEM;
+  int nobj = 0;
+  for (int v = 0; v < f->nvar; ++v) {
+    const Var* x = &f->var[v];
+    H5Obj* o = &objs[nobj++];
+    strcpy(o->name, x->name);
+    o->varid = v; o->dimid = -1; o->rank = x->rank; o->type = x->type; o->ndn = x->rank;
+    o->nbytes = tsize(x->type);
+    for (int k = 0; k < x->rank; ++k) { o->dn[k] = x->dimid[k]; o->shape[k] = f->dim[x->dimid[k]].len; o->nbytes *= o->shape[k]; }
+  }
+  /* a dimension without a variable of its name becomes a float32 dataset that is never written (netCDF-4's own habit) */
+  for (int d = 0; d < f->ndim; ++d) {
+    int found = -1;
+    for (int i = 0; i < nobj; ++i) if (objs[i].varid >= 0 && !strcmp(objs[i].name, f->dim[d].name)) found = i;
+    if (found >= 0) {
+      if (!(objs[found].ndn == 1 && objs[found].dn[0] == d)) { free(objs); return E_NAMEINUSE; }      /* named like a dimension, not its coordinate variable */
+      objs[found].dimid = d; objs[found].is_coord = 1;
+    } else {
+      H5Obj* o = &objs[nobj++];
+      strcpy(o->name, f->dim[d].name);
+      o->varid = -1; o->dimid = d; o->rank = 1; o->type = T_FLOAT; o->ndn = 0; o->shape[0] = f->dim[d].len; o->nbytes = 4 * o->shape[0];
+    }
+  }
+  qsort(objs, (size_t)nobj, sizeof(H5Obj), h5_cmp_obj);      /* symbol-table entries are kept in strcmp order */
+  int* scale_of_dim = (int*)calloc((size_t)f->ndim + 1, sizeof(int));
+  for (int i = 0; i < nobj; ++i) if (objs[i].dimid >= 0) scale_of_dim[objs[i].dimid] = i;
+  /* global heap: one object (a sequence of one object reference) per (variable, dimension it is attached to) */
+  H5Ref* gitems = (H5Ref*)calloc((size_t)nobj * ECNC_MAX_DIMS + 1, sizeof(H5Ref));
+  int ngitems = 0;
+  for (int i = 0; i < nobj; ++i)
+    if (objs[i].varid >= 0)
+      for (int k = 0; k < objs[i].ndn; ++k) {
+        if (scale_of_dim[objs[i].dn[k]] == i) continue;      /* a coordinate variable is not attached to itself */
+        gitems[ngitems].obj = i; gitems[ngitems].k = k; gitems[ngitems].dim = objs[i].dn[k]; ++ngitems;
+      }
+  const uint64_t gheap_used = 16 + 24 * (uint64_t)ngitems;
+  uint64_t gheap_size = ((gheap_used + 16 + 4095) / 4096) * 4096;
+  if (gheap_size < 4096) gheap_size = 4096;
+
+  /* local heap of the root group: the names */
+  HBuf heap = {0};
+  hb_zero(&heap, 8);
+  uint64_t* name_off = (uint64_t*)calloc((size_t)nobj + 1, sizeof(uint64_t));
+  for (int i = 0; i < nobj; ++i) { name_off[i] = heap.n; const size_t from = heap.n; hb_put(&heap, objs[i].name, strlen(objs[i].name) + 1); hb_pad8(&heap, from); }
+  const uint64_t heap_free = heap.n;
+  hb_u64(&heap, 1); hb_u64(&heap, 32); hb_zero(&heap, 16);
+  const uint64_t btree_size = 24 + (2 * H5_INTERNAL_K + 1) * 8 + 2 * H5_INTERNAL_K * 8;
+  const uint64_t snod_size = 8 + 2 * H5_LEAF_K * 40;
+
+  uint64_t gheap_addr = 0, btree_addr = 0, heap_addr = 0;
+  HBuf root = {0};
+  HBuf* hdr = (HBuf*)calloc((size_t)nobj + 1, sizeof(HBuf));
+  uint64_t root_addr = 96, heap_data_addr = 0, snod_addr = 0, eof = 0;
+  /* two passes: the sizes of the headers do not depend on the addresses inside them; the second pass has the addresses */
+  for (int pass = 0; pass < 2; ++pass) {
+    /* root group: symbol-table message + _NCProperties + the global attributes */
+    {
+      HBuf msgs = {0}, body = {0};
+      int nmsg = 0;
+      hb_u64(&body, btree_addr); hb_u64(&body, heap_addr);
+      h5_message(&msgs, 0x0011, &body, &nmsg);
+      body.n = 0;
+      h5_attr_string(&body, "_NCProperties", "version=2,ecrad_amd=1", strlen("version=2,ecrad_amd=1"));
+      h5_message(&msgs, 0x000C, &body, &nmsg);
+      for (int a = 0; a < f->ngatt; ++a) { body.n = 0; h5_user_attr(&body, &f->gatt[a]); h5_message(&msgs, 0x000C, &body, &nmsg); }
+      root.n = 0;
+      h5_object_header(&root, &msgs, nmsg);
+      hb_free(&msgs); hb_free(&body);
+    }
+    for (int i = 0; i < nobj; ++i) {
+      const H5Obj* o = &objs[i];
+      HBuf msgs = {0}, body = {0};
+      int nmsg = 0;
+      h5_dataspace(&body, o->rank, o->shape); h5_message(&msgs, 0x0001, &body, &nmsg);
+      body.n = 0;
+      if (o->type == T_FLOAT || o->type == T_DOUBLE) h5_dt_float(&body, o->type == T_DOUBLE ? 8 : 4); else h5_dt_int(&body, (unsigned)tsize(o->type));
+      h5_message(&msgs, 0x0003, &body, &nmsg);
+      body.n = 0; hb_u8(&body, 2); hb_u8(&body, 2); hb_u8(&body, 2); hb_u8(&body, 1); hb_u32(&body, 0); h5_message(&msgs, 0x0005, &body, &nmsg);
+      body.n = 0; hb_u8(&body, 3); hb_u8(&body, 1); hb_u64(&body, o->data_addr); hb_u64(&body, o->nbytes); h5_message(&msgs, 0x0008, &body, &nmsg);
+      if (o->dimid >= 0) {      /* a dimension scale */
+        body.n = 0; h5_attr_string(&body, "CLASS", "DIMENSION_SCALE", 15); h5_message(&msgs, 0x000C, &body, &nmsg);
+        body.n = 0;
+        if (o->is_coord) h5_attr_string(&body, "NAME", o->name, strlen(o->name));
+        else {
+          char nm[128];
+          snprintf(nm, sizeof nm, "This is a netCDF dimension but not a netCDF variable.%10llu", (unsigned long long)o->shape[0]);
+          h5_attr_string(&body, "NAME", nm, strlen(nm));
+        }
+        h5_message(&msgs, 0x000C, &body, &nmsg);
+        {
+          HBuf dt = {0}; h5_dt_int32(&dt);
+          const int32_t id = o->dimid;
+          body.n = 0; h5_attribute(&body, "_Netcdf4Dimid", &dt, 0, NULL, &id, 4); h5_message(&msgs, 0x000C, &body, &nmsg);
+          hb_free(&dt);
+        }
+        /* REFERENCE_LIST: the (dataset, index) pairs that use this dimension, in the order of the datasets */
+        HBuf refs = {0};
+        uint64_t nrefs = 0;
+        for (int v = 0; v < f->nvar; ++v) {      /* (in the order the variables were defined, as the Python writer's `users`) */
+          int u = -1;
+          for (int j = 0; j < nobj; ++j) if (objs[j].varid == v) u = j;
+          if (u == i) continue;
+          for (int k = 0; k < objs[u].ndn; ++k)
+            if (objs[u].dn[k] == o->dimid) { hb_u64(&refs, objs[u].addr); hb_u32(&refs, (uint32_t)k); hb_zero(&refs, 4); ++nrefs; }
+        }
+        if (nrefs) {
+          HBuf dt = {0}; h5_dt_reference_list(&dt);
+          body.n = 0; h5_attribute(&body, "REFERENCE_LIST", &dt, 1, &nrefs, refs.p, refs.n); h5_message(&msgs, 0x000C, &body, &nmsg);
+          hb_free(&dt);
+        }
+        hb_free(&refs);
+      }
+      int attached = 0;
+      for (int k = 0; k < o->ndn; ++k) if (scale_of_dim[o->dn[k]] != i) attached = 1;
+      if (attached) {
+        HBuf dt = {0}, data = {0};
+        h5_dt_vlen_objref(&dt);
+        for (int k = 0; k < o->ndn; ++k) {
+          uint32_t index = 0;
+          for (int q = 0; q < ngitems; ++q) if (gitems[q].obj == i && gitems[q].k == k) index = (uint32_t)q + 1;
+          hb_u32(&data, 1); hb_u64(&data, gheap_addr); hb_u32(&data, index);
+        }
+        const uint64_t n = (uint64_t)o->ndn;
+        body.n = 0; h5_attribute(&body, "DIMENSION_LIST", &dt, 1, &n, data.p, data.n); h5_message(&msgs, 0x000C, &body, &nmsg);
+        hb_free(&dt); hb_free(&data);
+      }
+      if (o->ndn > 0 && !(o->dimid >= 0 && !o->is_coord)) {
+        HBuf dt = {0}, data = {0};
+        h5_dt_int32(&dt);
+        for (int k = 0; k < o->ndn; ++k) hb_u32(&data, (uint32_t)o->dn[k]);
+        const uint64_t n = (uint64_t)o->ndn;
+        body.n = 0; h5_attribute(&body, "_Netcdf4Coordinates", &dt, 1, &n, data.p, data.n); h5_message(&msgs, 0x000C, &body, &nmsg);
+        hb_free(&dt); hb_free(&data);
+      }
+      if (o->varid >= 0)
+        for (int a = 0; a < f->var[o->varid].natt; ++a) { body.n = 0; h5_user_attr(&body, &f->var[o->varid].att[a]); h5_message(&msgs, 0x000C, &body, &nmsg); }
+      hdr[i].n = 0;
+      h5_object_header(&hdr[i], &msgs, nmsg);
+      hb_free(&msgs); hb_free(&body);
+    }
+    if (pass == 0) {      /* the layout */
+      uint64_t pos = root_addr + root.n;
+      btree_addr = pos; pos += btree_size;
+      heap_addr = pos; pos += 32;
+      heap_data_addr = pos; pos += heap.n;
+      snod_addr = pos; pos += snod_size;
+      gheap_addr = pos; pos += gheap_size;
+      for (int i = 0; i < nobj; ++i) { objs[i].addr = pos; pos += hdr[i].n; }
+      for (int i = 0; i < nobj; ++i) {
+        objs[i].data_addr = H5_UNDEF;
+        if (objs[i].varid >= 0 && objs[i].nbytes > 0) { pos += (8 - pos % 8) % 8; objs[i].data_addr = pos; pos += objs[i].nbytes; }
+      }
+      eof = pos;
+    }
+  }
+  /* ---- write */
+  HBuf sb = {0};
+  static const unsigned char sig[8] = {0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n'};
+  hb_put(&sb, sig, 8);
+  hb_u8(&sb, 0); hb_u8(&sb, 0); hb_u8(&sb, 0); hb_u8(&sb, 0); hb_u8(&sb, 0); hb_u8(&sb, 8); hb_u8(&sb, 8); hb_u8(&sb, 0);
+  hb_u16(&sb, H5_LEAF_K); hb_u16(&sb, H5_INTERNAL_K); hb_u32(&sb, 0);
+  hb_u64(&sb, 0); hb_u64(&sb, H5_UNDEF); hb_u64(&sb, eof); hb_u64(&sb, H5_UNDEF);
+  hb_u64(&sb, 0); hb_u64(&sb, root_addr); hb_u32(&sb, 1); hb_u32(&sb, 0); hb_u64(&sb, btree_addr); hb_u64(&sb, heap_addr);
+  int st = 0;
+  FILE* fp = f->fp;
+  rewind(fp);
+  fwrite(sb.p, 1, sb.n, fp);                                  /* 96 bytes */
+  fwrite(root.p, 1, root.n, fp);
+  {
+    HBuf bt = {0};
+    hb_put(&bt, "TREE", 4); hb_u8(&bt, 0); hb_u8(&bt, 0); hb_u16(&bt, 1); hb_u64(&bt, H5_UNDEF); hb_u64(&bt, H5_UNDEF);
+    hb_u64(&bt, 0); hb_u64(&bt, snod_addr); hb_u64(&bt, nobj ? name_off[nobj - 1] : 0);
+    hb_zero(&bt, (size_t)btree_size - bt.n);
+    fwrite(bt.p, 1, bt.n, fp);
+    hb_free(&bt);
+  }
+  {
+    HBuf hh = {0};
+    hb_put(&hh, "HEAP", 4); hb_u8(&hh, 0); hb_zero(&hh, 3); hb_u64(&hh, heap.n); hb_u64(&hh, heap_free); hb_u64(&hh, heap_data_addr);
+    fwrite(hh.p, 1, hh.n, fp);
+    hb_free(&hh);
+  }
+  fwrite(heap.p, 1, heap.n, fp);
+  {
+    HBuf sn = {0};
+    hb_put(&sn, "SNOD", 4); hb_u8(&sn, 1); hb_u8(&sn, 0); hb_u16(&sn, (unsigned)nobj);
+    for (int i = 0; i < nobj; ++i) { hb_u64(&sn, name_off[i]); hb_u64(&sn, objs[i].addr); hb_u32(&sn, 0); hb_u32(&sn, 0); hb_zero(&sn, 16); }
+    hb_zero(&sn, (size_t)snod_size - sn.n);
+    fwrite(sn.p, 1, sn.n, fp);
+    hb_free(&sn);
+  }
+  {
+    HBuf gh = {0};
+    hb_put(&gh, "GCOL", 4); hb_u8(&gh, 1); hb_zero(&gh, 3); hb_u64(&gh, gheap_size);
+    for (int q = 0; q < ngitems; ++q) { hb_u16(&gh, (unsigned)q + 1); hb_u16(&gh, 1); hb_zero(&gh, 4); hb_u64(&gh, 8); hb_u64(&gh, objs[scale_of_dim[gitems[q].dim]].addr); }
+    { const uint64_t left = gheap_size - gh.n; hb_u16(&gh, 0); hb_u16(&gh, 0); hb_zero(&gh, 4); hb_u64(&gh, left); }      /* object 0: the free space (size includes this header) */
+    hb_zero(&gh, (size_t)gheap_size - gh.n);
+    fwrite(gh.p, 1, gh.n, fp);
+    hb_free(&gh);
+  }
+  for (int i = 0; i < nobj; ++i) fwrite(hdr[i].p, 1, hdr[i].n, fp);
+  /* the data section exists from the start (zeros until written) */
+  if (eof > 0) {
+    if (fseeko(fp, (off_t)(eof - 1), SEEK_SET)) st = errno; else fputc(0, fp);
+  }
+  fflush(fp);
+  for (int i = 0; i < nobj; ++i)
+    if (objs[i].varid >= 0) { f->var[objs[i].varid].begin = objs[i].data_addr; f->var[objs[i].varid].vsize = objs[i].nbytes; }
+  f->define_mode = 0;
+  if (ferror(fp) && !st) st = 5;
+  for (int i = 0; i < nobj; ++i) hb_free(&hdr[i]);
+  hb_free(&root); hb_free(&heap); hb_free(&sb);
+  free(hdr); free(objs); free(gitems); free(name_off); free(scale_of_dim);
+  return st;
 }
 
 /* ---- the four Fortran-77 entry points utilities/easy_netcdf.F90:3262-3324 calls as externals ----------- */

@@ -11,9 +11,9 @@
 ! This file is only argument plumbing: index order (Fortran's first-fastest dimensions and 1-based ids against the
 ! file's slowest-first, 0-based ones), optional arguments, and one specific per memory type -- buffers are assumed-rank
 ! dummies of a known type, so one specific serves scalars and arrays of every rank.  The format itself is nc_classic.c.
-! NF90_HDF5 (easy_netcdf's is_hdf5_file, utilities/easy_netcdf.F90:180-184,:226-230; the driver's do_write_hdf5) is accepted by
-! nf90_create, which says on standard error that the file is written in classic format instead (64-bit offsets when
-! needed) -- once per file, never silently: every reader of netCDF-4 files reads classic files too.
+! NF90_HDF5 (easy_netcdf's is_hdf5_file, utilities/easy_netcdf.F90:212-245 when compiled with NC_NETCDF4; the driver's
+! do_write_hdf5) makes nf90_create open a netCDF-4 / HDF5 file, which nc_classic.c writes itself (ecnc_h5_enddef: fixed
+! dimensions, numeric variables, netCDF-4's dimension-scale conventions).  Files are READ in classic format only.
 module netcdf
 
   use, intrinsic :: iso_c_binding
@@ -278,11 +278,9 @@ contains
     integer(c_int) :: big
     big = 0
     if (iand(cmode, NF90_64BIT_OFFSET) /= 0) big = 1
-    if (iand(cmode, NF90_HDF5) /= 0) then
-      ! (unit 0 = radiation_io's nulerr; this module sits below the reference's own modules and uses none of them)
-      write(0,'(a,a,a)') '*** Warning: netCDF-4/HDF5 format requested for ', trim(path), &
-           &  ', but this netCDF module writes the classic format (CDF-1/CDF-2); writing classic format'
-    end if
+    ! NF90_HDF5 / NF90_NETCDF4 (easy_netcdf's is_hdf5_file, the driver's do_write_hdf5): the netCDF-4 / HDF5 format, written by
+    ! nc_classic.c itself (ecnc_h5_enddef) -- fixed dimensions, variables of type int / float / double
+    if (iand(cmode, NF90_HDF5) /= 0) big = 2
     st = ecnc_create(cstr(path), big, ncid)
   end function nf90_create
 

@@ -1,7 +1,7 @@
 ! nc_roundtrip.F90 -- test program of ecrad_amd/fortran/netcdf.F90 + nc_classic.c (tests/test_fortran_netcdf.py):
 !   nc_roundtrip write FILE   defines dimensions / variables / attributes of every type the reference's easy_netcdf.F90
 !                             uses, writes whole arrays, slabs (start/count) and scalars
-!   nc_roundtrip write_hdf5 FILE   the same with NF90_HDF5 in the creation mode (warned about, classic format written)
+!   nc_roundtrip write_hdf5 FILE   the same with NF90_HDF5 in the creation mode: the netCDF-4 / HDF5 format
 !   nc_roundtrip read FILE    reads them back the way easy_netcdf.F90 does and checks every value
 !   nc_roundtrip dump FILE VAR   prints shape, sum and first / last value of a (record) variable of an existing file
 program nc_roundtrip

@@ -644,6 +644,36 @@ def test_single_precision_host_through_the_dropin(tmp_path, target):
         assert e_hip[v] <= max(2.0 * e_ref[v], 1.0e-6), (v, e_hip[v], e_ref[v])
 
 
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(EXE), reason="tests/_build/dropin/ecrad_hip has not been built (tools/build_dropin.py)")
+def test_dropin_driver_writes_netcdf4_when_asked(tmp_path):
+    """`do_write_hdf5 = true` in the driver's namelist (driver/ecrad_driver.F90:400 -> easy_netcdf's is_hdf5_file): the drop-in
+    executable's output is a netCDF-4 / HDF5 file written by the repo's netcdf module (nc_classic.c: ecnc_h5_enddef), which the
+    HDF5 library of the image reads back with the numbers of the classic file of the same run."""
+    from test_hdf5_output import H5
+    h5 = H5()
+    family, edits = TARGETS["tripleclouds"]
+    outs = {}
+    for tag, hdf5 in (("classic", "false"), ("nc4", "true")):
+        nam, out = str(tmp_path / f"{tag}.nam"), str(tmp_path / f"{tag}_out.nc")
+        write_namelist(nam, family, edits)
+        text = open(nam).read()
+        open(nam, "w").write(text.replace("&radiation_driver\n", f"&radiation_driver\ndo_write_hdf5 = {hdf5},\n", 1))
+        p = _run(f"ulimit -s unlimited; exec {EXE} {nam} {MERIDIAN} {out}", shell=True, capture_output=True, text=True,
+                 cwd=str(tmp_path), env=dict(os.environ, OMP_NUM_THREADS="1", OMP_STACKSIZE="1G"), timeout=900)
+        assert p.returncode == 0 and os.path.exists(out), (p.stdout + p.stderr)[-3000:]
+        outs[tag] = out
+    assert open(outs["classic"], "rb").read(3) == b"CDF" and open(outs["nc4"], "rb").read(4) == b"\x89HDF"
+    f = h5.open(outs["nc4"])
+    with NcFile(outs["classic"]) as c:
+        names = set(c._f.variables)
+        assert len(names) >= 20 and names <= set(h5.names(f))
+        for n in names:
+            _, a, _ = h5.read(f, n)
+            assert np.array_equal(a, np.asarray(c.get(n), dtype=np.float64)), n
+    h5.h5.H5Fclose(f)
+
+
 SP_OMP_EXE = os.path.join(ROOT, "tests", "_build", "dropin_sp_omp", "ecrad_hip")
 
 

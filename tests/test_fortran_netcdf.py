@@ -60,19 +60,59 @@ def test_write_then_read_through_the_module_and_through_scipy(exe, tmp_path):
         assert nc.variables["f"].typecode() == "h" and list(nc.variables["f"][:]) == [1, 2, 3, -4, 5]
 
 
-def test_hdf5_request_is_answered_with_a_warning_and_a_classic_file(exe, tmp_path):
+def test_hdf5_request_gives_a_netcdf4_file_the_hdf5_library_reads(exe, tmp_path):
     """The driver's do_write_hdf5 / easy_netcdf's is_hdf5_file reach nf90_create as NF90_HDF5 (utilities/easy_netcdf.F90:180-184):
-    this module has no HDF5 writer, says so on standard error, and writes the classic format every netCDF-4 reader reads."""
+    the module then writes the netCDF-4 / HDF5 format itself (nc_classic.c: ecnc_h5_enddef -- the same layout as the Python
+    host's writer, ecrad_amd/hdf5file.py).  The HDF5 library of this image (through ctypes, as tests/test_hdf5_output.py)
+    reads every variable, slab and attribute the program wrote, and finds every dimension as a netCDF-4 dimension scale
+    attached to the variables that use it."""
+    from test_hdf5_output import H5
     f = str(tmp_path / "t4.nc")
     p = subprocess.run([exe, "write_hdf5", f], capture_output=True, text=True)
     assert p.returncode == 0 and "WRITE OK" in p.stdout, p.stdout + p.stderr
-    assert "Warning" in p.stderr and "netCDF-4/HDF5" in p.stderr and "classic format" in p.stderr and f in p.stderr
-    assert open(f, "rb").read(4) == b"CDF\x01"
-    p = subprocess.run([exe, "read", f], capture_output=True, text=True)
-    assert p.returncode == 0 and "READ OK" in p.stdout, p.stdout + p.stderr
-    # and a plain creation says nothing
+    assert "Warning" not in p.stderr
+    raw = open(f, "rb").read()
+    assert raw[:8] == b"\x89HDF\r\n\x1a\n" and raw[8] == 0
+    import struct
+    assert struct.unpack("<Q", raw[40:48])[0] == len(raw)                       # end-of-file address of the superblock
+    for sig in (b"TREE", b"HEAP", b"SNOD", b"GCOL"):
+        assert raw.count(sig) == 1, sig
+    h5 = H5()
+    fid = h5.open(f)
+    assert sorted(h5.names(fid)) == sorted(["a", "b", "i", "s", "f", "column", "level", "five"])
+    _, a, size = h5.read(fid, "a")
+    want = 10.0 * np.arange(1, 4)[:, None] + np.arange(1, 5)[None, :] + 0.125      # Fortran (column, level) = C (level, column)
+    assert size == 8 and np.array_equal(a, want)                                    # (written as two slabs)
+    _, b, size = h5.read(fid, "b")
+    assert size == 4 and np.array_equal(b, np.array([1.5, -2.25, 3.0, 1.0e10, 0.1], dtype=np.float32).astype(np.float64))
+    _, i, size = h5.read(fid, "i")
+    assert size == 4 and list(i) == [7, -8, 9, 2147483647, 77]                     # (the last element written on its own)
+    _, sc, _ = h5.read(fid, "s")
+    assert sc.shape == () and float(sc) == 3.141592653589793
+    _, sh, size = h5.read(fid, "f")
+    assert size == 2 and list(sh) == [1, 2, 3, -4, 5]
+    assert h5.string_attr(fid, "a", "units") == "W m-2" and h5.string_attr(fid, "a", "long_name") == "A matrix"
+    assert h5.int_attr(fid, "i", "answer") == [42]
+    assert h5.string_attr(fid, "/", "title") == "round trip"
+    assert h5.string_attr(fid, "/", "_NCProperties").startswith("version=2")
+    ids = {}
+    for k, (name, n) in enumerate((("column", 4), ("level", 3), ("five", 5))):
+        d, v, _ = h5.read(fid, name, keep=True)
+        ids[name] = d
+        assert h5.hl.H5DSis_scale(d) > 0 and v.shape == (n,)
+        assert h5.string_attr(fid, name, "CLASS") == "DIMENSION_SCALE" and h5.int_attr(fid, name, "_Netcdf4Dimid") == [k]
+        assert h5.string_attr(fid, name, "NAME") == "This is a netCDF dimension but not a netCDF variable.%10d" % n
+    for name, dn in (("a", ("level", "column")), ("b", ("five",)), ("i", ("five",)), ("f", ("five",))):
+        d, _, _ = h5.read(fid, name, keep=True)
+        for k, dname in enumerate(dn):
+            assert h5.hl.H5DSget_num_scales(d, k) == 1 and h5.hl.H5DSis_attached(d, ids[dname], k) > 0, (name, dname)
+        h5.h5.H5Dclose(d)
+    for d in ids.values():
+        h5.h5.H5Dclose(d)
+    h5.h5.H5Fclose(fid)
+    # a plain creation still gives the classic format
     p = subprocess.run([exe, "write", str(tmp_path / "t3.nc")], capture_output=True, text=True)
-    assert p.returncode == 0 and "Warning" not in p.stderr
+    assert p.returncode == 0 and open(str(tmp_path / "t3.nc"), "rb").read(4) == b"CDF\x01"
 
 
 @pytest.mark.parametrize("var", ["pressure_hl", "temperature_hl", "q", "cloud_fraction", "cos_solar_zenith_angle", "skin_temperature"])

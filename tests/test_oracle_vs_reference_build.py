@@ -82,6 +82,44 @@ def test_the_reference_executable_reproduces_its_own_golden_file(tmp_path):
             assert rel_err(o.get(v), g.get(v)) < 2.0e-7, v
 
 
+def test_the_reference_driver_writes_netcdf4_through_the_repos_netcdf_module(tmp_path):
+    """SURVEY section 8 row f4 in the FORTRAN host: the reference's unmodified driver with `do_write_hdf5 = true` (driver/
+    ecrad_driver.F90:400 -> save_fluxes(..., is_hdf5_file) -> utilities/easy_netcdf.F90:212-245 -> nf90_create(NF90_HDF5)) on top of
+    this repo's netcdf module: the output is a netCDF-4 / HDF5 file (nc_classic.c: ecnc_h5_enddef) that the HDF5 library of this
+    image reads, holding the same variables, dimensions and NUMBERS as the classic file of the same run."""
+    from test_hdf5_output import H5
+    h5 = H5()
+    family, edits = TARGETS["tripleclouds"]
+    outs = {}
+    for tag, hdf5 in (("classic", "false"), ("nc4", "true")):
+        nam, out = str(tmp_path / f"{tag}.nam"), str(tmp_path / f"{tag}_out.nc")
+        write_namelist(nam, family, edits)
+        text = open(nam).read()
+        assert text.count("&radiation_driver\n") == 1
+        open(nam, "w").write(text.replace("&radiation_driver\n", f"&radiation_driver\ndo_write_hdf5 = {hdf5},\n"))
+        env = dict(os.environ, OMP_NUM_THREADS="4", OMP_STACKSIZE="1G")
+        p = subprocess.run(f"ulimit -s unlimited; exec {REF} {nam} {MERIDIAN} {out}", shell=True, capture_output=True, text=True, cwd=str(tmp_path), env=env, timeout=900)
+        assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+        outs[tag] = out
+    assert open(outs["classic"], "rb").read(3) == b"CDF" and open(outs["nc4"], "rb").read(8) == b"\x89HDF\r\n\x1a\n"
+    f = h5.open(outs["nc4"])
+    with NcFile(outs["classic"]) as c:
+        names, dims = set(c._f.variables), dict(c.dims())
+        assert len(names) >= 20 and set(h5.names(f)) == names | set(dims)
+        for n in names:
+            _, a, size = h5.read(f, n)
+            ref = c.get(n)
+            assert size == c._f.variables[n].data.dtype.itemsize and np.array_equal(a, np.asarray(ref, dtype=np.float64)), n
+            for att in ("units", "long_name"):
+                if att in c._f.variables[n]._attributes:
+                    assert h5.string_attr(f, n, att) == c._f.variables[n]._attributes[att].decode(), (n, att)
+        for dn, n in dims.items():
+            d, a, _ = h5.read(f, dn, keep=True)
+            assert a.shape == (n,) and h5.hl.H5DSis_scale(d) > 0, dn
+            h5.h5.H5Dclose(d)
+    h5.h5.H5Fclose(f)
+
+
 # ---- SPARTACUS with two regions (config%nregions = 2) -------------------------------------------------------------------------
 _SP2 = {"sw_solver_name": '"SPARTACUS"', "lw_solver_name": '"SPARTACUS"', "n_regions": "2"}
 TWO_REGION_CASES = {

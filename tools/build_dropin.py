@@ -102,6 +102,9 @@ def main():
     deps = {f: {owner[m] for m in u if m in owner and owner[m] != f} for f, (_, u) in info.items()}
     flags = (["-O3", "-fopenmp", "-fPIC", "-cpp"] if args.reference else ["-O1", "-fPIC", "-cpp", "-DECRAD_HIP_REFERENCE_TYPES"]) + [ f"-I{args.ref}/include", f"-I{args.ref}/radiation",
              f"-I{args.ref}/ifsaux", f"-I{args.ref}/ifsrrtm", f"-I{args.ref}/ifs", f"-I{obj}", "-module-dir", obj]
+    # (utilities/easy_netcdf.F90:232-240: the reference asks for NF90_HDF5 -- is_hdf5_file, the driver's do_write_hdf5 -- only when it is
+    #  compiled with NC_NETCDF4, as its own Makefile does where the netCDF library has netCDF-4; this repo's netcdf module writes that format)
+    flags.append("-DNC_NETCDF4")
     if args.single:
         flags.append("-DPARKIND1_SINGLE")
     if args.openmp and not args.reference:
