@@ -68,11 +68,34 @@ constexpr double kPi = 3.14159265358979323846;
 constexpr double kGasConstantDryAir = 287.058;      // radiation_constants.F90:31
 
 // ---- block-private slab: [level][slot][256 lanes] of R -------------------------------------------------------------
+typedef unsigned ecrad_v2u __attribute__((ext_vector_type(2)));
+// Accessed through the BUFFER instructions: the block's slab is the buffer (its base in a scalar resource descriptor), the lane
+// offset tid * sizeof(R) the vector offset, the (level, slot) part a scalar offset -- no vector instruction per access, where the
+// flat form `global_load v, v[lo:hi]` costs a 64-bit vector add for most of them (round 5: a sixth of the vector instructions of a
+// cloud-free level in the sweep kernels were such adds).  Non-temporal as before (aux = 2: every value is written once and read once).
+#ifndef ECRAD_SP_SLAB_BUFFER
+#define ECRAD_SP_SLAB_BUFFER 1
+#endif
 template <typename R> struct Slab {
   R* base;
   int nslot;
+#if ECRAD_SP_SLAB_BUFFER
+  __amdgpu_buffer_rsrc_t rsrc;
+  ECRAD_DEV Slab(R* b, int ns) : base(b), nslot(ns), rsrc(__builtin_amdgcn_make_buffer_rsrc(b, 0, 0x7fffffff, 0x00020000)) {}
+  ECRAD_DEV int soff(int lev, int slot) const { return (lev * nslot + slot) * (kBlock * (int)sizeof(R)); }
+  ECRAD_DEV void put(int lev, int slot, int tid, R v) const {
+    if constexpr (sizeof(R) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc, tid * 4, soff(lev, slot), 2);
+    else __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ecrad_v2u, v), rsrc, tid * 8, soff(lev, slot), 2);
+  }
+  ECRAD_DEV R get(int lev, int slot, int tid) const {
+    if constexpr (sizeof(R) == 4) return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b32(rsrc, tid * 4, soff(lev, slot), 2));
+    else return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b64(rsrc, tid * 8, soff(lev, slot), 2));
+  }
+#else
+  ECRAD_DEV Slab(R* b, int ns) : base(b), nslot(ns) {}
   ECRAD_DEV void put(int lev, int slot, int tid, R v) const { __builtin_nontemporal_store(v, base + ((size_t)lev * nslot + slot) * kBlock + tid); }
   ECRAD_DEV R get(int lev, int slot, int tid) const { return __builtin_nontemporal_load(base + ((size_t)lev * nslot + slot) * kBlock + tid); }
+#endif
   ECRAD_DEV void put(int lev, int slot0, int tid, const M3<R>& m) const {
 #pragma unroll
     for (int k = 0; k < 9; ++k) put(lev, slot0 + k, tid, m.a[k]);
@@ -188,7 +211,8 @@ struct SpConfig {
   int32_t nregions;      // 3, or 2: the third region is empty then (tripleclouds_prep_kernel)
   // Spectra wider than 64 g-points run as several launches ("chunks", as in the other solvers): this launch covers
   // g-points g0 .. g0+ngl-1, lane = g0 + its index in the column group.  The stage arrays and per-g outputs are indexed
-  // by the true g-point, the layer store by the index within the chunk (stride ngl); the sums over g are partial and go
+  // by the true g-point, the layer store by the index within the chunk (stride NGP, the kernels' lanes per column: a compile-time
+  // stride, so that the 24 / 45 values of a layer are read at constant offsets from one address); the sums over g are partial and go
   // to per-chunk buffers (pipeline.hip: tile_compute); `wide` leaves the longwave derivatives un-normalised, see spartacus_lw_kernel.
   int32_t g0, ngl;
   double max_cloud_od, max_3d_transfer_rate, max_gas_od_3d, min_cloud_effective_size, overhang_factor, clear_to_thick_fraction,
@@ -382,7 +406,9 @@ template <typename R> ECRAD_DEV V3<R> add(const V3<R>& a, const V3<R>& b) {
 }
 template <typename R> ECRAD_DEV M3<R> diag_only(R v) { M3<R> m; m.zero(); m(0, 0) = v; return m; }
 
-// the sums over the g-points of a column are written by its first lane
+// the sums over the g-points of a column are written by its first lane.  (In double also in the single-precision kernels: the
+// working-precision butterfly -- one v_add_f32_dpp per step instead of two moves and an add -- was measured in round 5: 0.3 % of the
+// step, the sums are not what the sweeps wait for, and the float sums of 32 terms cost the parity tests their margin.)
 template <int NGP> ECRAD_DEV void put_sum(double* arr, size_t o, double v, bool valid, bool lead) {
   const double s = group_sum<NGP>(valid ? v : 0.0);
   if (lead && arr) arr[o] = s;
@@ -560,7 +586,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
     const FracView fracv = cloud_fraction_view(a.in, col);
     const LevMask cm = column_level_mask<NGP>(fracv.p, fracv.stride, nlev, tid & 63, ord);
     const Geo gm{&kernarg_block<SpArgs>().prep, nlev, nloc, cloc};
-    const Slab<R> slab{reinterpret_cast<R*>(a.scratch) + (size_t)blockIdx.x * a.per_block, SW_NSLOT};
+    const Slab<R> slab(reinterpret_cast<R*>(a.scratch) + (size_t)blockIdx.x * a.per_block, SW_NSLOT);
     const DevFlux& fx = kernarg_block<SpArgs>().fx;
     const bool do_clear = c.do_clear != 0;
     const size_t og = g + (size_t)ng * col;      // per-g outputs (ng, ncol)
@@ -612,11 +638,11 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
       }
       M3<R> refl, tran, rdir, tdd, tdir;
       if (listed) {
-        const R* lp = reinterpret_cast<const R*>(a.lay) + (size_t)a.item_of[(size_t)cloc * nlev + jl] * 45 * ngl + gs;
+        const R* lp = reinterpret_cast<const R*>(a.lay) + (size_t)a.item_of[(size_t)cloc * nlev + jl] * (45 * NGP) + gs;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-          refl.a[k] = lp[(size_t)k * ngl]; tran.a[k] = lp[(size_t)(9 + k) * ngl]; rdir.a[k] = lp[(size_t)(18 + k) * ngl];
-          tdd.a[k] = lp[(size_t)(27 + k) * ngl]; tdir.a[k] = lp[(size_t)(36 + k) * ngl];
+          refl.a[k] = lp[k * NGP]; tran.a[k] = lp[(9 + k) * NGP]; rdir.a[k] = lp[(18 + k) * NGP];
+          tdd.a[k] = lp[(27 + k) * NGP]; tdir.a[k] = lp[(36 + k) * NGP];
         }
       } else {
         refl = diag_only(cl.ref_diff); tran = diag_only(cl.trans_diff); rdir = diag_only(cl.ref_dir);
@@ -644,7 +670,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
 
       // -- section 4.1: adding method --
       if (do_clear) {
-        const R inv = R(1) / (R(1) - ta_clear * cl.ref_diff);
+        const R inv = sp::prcp(R(1) - ta_clear * cl.ref_diff);
         const R tac_new = cl.ref_diff + cl.trans_diff * cl.trans_diff * ta_clear * inv;
         tad_clear = cl.ref_dir + (cl.trans_dir_dir * tad_clear + cl.trans_dir_diff * ta_clear) * cl.trans_diff * inv;
         ta_clear = tac_new;
@@ -652,7 +678,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
       M3<R> ta_below, tad_below;             // total_albedo_below, total_albedo_below_direct (top of layer, before overlap)
       if (clr) {
         ta_below.zero(); tad_below.zero();
-        const R inv = R(1) / (R(1) - ta(0, 0) * refl(0, 0));
+        const R inv = sp::prcp(R(1) - ta(0, 0) * refl(0, 0));
         ta_below(0, 0) = refl(0, 0) + tran(0, 0) * tran(0, 0) * ta(0, 0) * inv;
         tad_below(0, 0) = rdir(0, 0) + (tdir(0, 0) * tad(0, 0) + tdd(0, 0) * ta(0, 0)) * tran(0, 0) * inv;
       } else {
@@ -817,7 +843,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
           const R refc = c6[0], trac = c6[1], tddc = c6[2], tdirc = c6[3], tac = c6[4], tadc = c6[5];
           const R source_dn_clear = tddc * direct_dn_clear;
           direct_dn_clear = tdirc * direct_dn_clear;
-          flux_dn_clear = (trac * flux_dn_clear + refc * tadc * direct_dn_clear + source_dn_clear) / (R(1) - refc * tac);
+          flux_dn_clear = sp::pdiv(trac * flux_dn_clear + refc * tadc * direct_dn_clear + source_dn_clear, R(1) - refc * tac);
           flux_up_clear = tadc * direct_dn_clear + tac * flux_dn_clear;
           sw_dn_clear_direct = (double)mu0 * group_sum<NGP>(valid ? (double)direct_dn_clear : 0.0);
           if (lead && fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[oh] = sw_dn_clear_direct;
@@ -828,14 +854,14 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
           direct_dn_above.zero();
           direct_dn_above.a[0] = tdir * direct_dn_below.a[0];
           flux_dn_above.zero(); flux_up_above.zero();
-          flux_dn_above.a[0] = (tran * flux_dn_below.a[0] + refl * tad1 * direct_dn_above.a[0] + source_dn) / (R(1) - refl * ta1);
+          flux_dn_above.a[0] = sp::pdiv(tran * flux_dn_below.a[0] + refl * tad1 * direct_dn_above.a[0] + source_dn, R(1) - refl * ta1);
           flux_up_above.a[0] = tad1 * direct_dn_above.a[0] + ta1 * flux_dn_above.a[0];
         } else {
           M3<R> refl, tran, tdd, tdir, ta1, tad1;
-          const R* lp = reinterpret_cast<const R*>(a.lay) + (size_t)a.item_of[(size_t)cloc * nlev + jl] * 45 * ngl + gs;
+          const R* lp = reinterpret_cast<const R*>(a.lay) + (size_t)a.item_of[(size_t)cloc * nlev + jl] * (45 * NGP) + gs;
 #pragma unroll
           for (int k = 0; k < 9; ++k) {
-            refl.a[k] = lp[(size_t)k * ngl]; tran.a[k] = lp[(size_t)(9 + k) * ngl]; tdd.a[k] = lp[(size_t)(27 + k) * ngl]; tdir.a[k] = lp[(size_t)(36 + k) * ngl];
+            refl.a[k] = lp[k * NGP]; tran.a[k] = lp[(9 + k) * NGP]; tdd.a[k] = lp[(27 + k) * NGP]; tdir.a[k] = lp[(36 + k) * NGP];
           }
           slab.get(jl, SW_TA, tid, ta1); slab.get(jl, SW_TAD, tid, tad1);
           const V3<R> source_dn = sp::mul(tdd, direct_dn_below);
@@ -1144,7 +1170,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
     const FracView fracv = cloud_fraction_view(a.in, col);
     const LevMask cm = column_level_mask<NGP>(fracv.p, fracv.stride, nlev, tid & 63, ord);
     const Geo gm{&kernarg_block<SpArgs>().prep, nlev, nloc, cloc};
-    const Slab<R> slab{reinterpret_cast<R*>(a.scratch) + (size_t)blockIdx.x * a.per_block, LW_NSLOT};
+    const Slab<R> slab(reinterpret_cast<R*>(a.scratch) + (size_t)blockIdx.x * a.per_block, LW_NSLOT);
     const DevFlux& fx = kernarg_block<SpArgs>().fx;
     const bool do_clear = c.do_clear != 0;
     const size_t og = g + (size_t)ng * col;
@@ -1190,11 +1216,11 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
       M3<R> refl, tran;
       V3<R> source_up, source_dn;
       if (listed) {
-        const R* lp = reinterpret_cast<const R*>(a.lay) + (size_t)a.item_of[(size_t)cloc * nlev + jl] * 24 * ngl + gs;
+        const R* lp = reinterpret_cast<const R*>(a.lay) + (size_t)a.item_of[(size_t)cloc * nlev + jl] * (24 * NGP) + gs;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { refl.a[k] = lp[(size_t)k * ngl]; tran.a[k] = lp[(size_t)(9 + k) * ngl]; }
+        for (int k = 0; k < 9; ++k) { refl.a[k] = lp[k * NGP]; tran.a[k] = lp[(9 + k) * NGP]; }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { source_up.a[k] = lp[(size_t)(18 + k) * ngl]; source_dn.a[k] = lp[(size_t)(21 + k) * ngl]; }
+        for (int k = 0; k < 3; ++k) { source_up.a[k] = lp[(18 + k) * NGP]; source_dn.a[k] = lp[(21 + k) * NGP]; }
       } else {
         const R rf0 = R(gm.rf(0, jl));
         refl = diag_only(cl.reflectance); tran = diag_only(cl.transmittance);
@@ -1220,7 +1246,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
 
       // -- section 4 --
       if (do_clear) {
-        const R inv = R(1) / (R(1) - ta_clear * cl.reflectance);
+        const R inv = sp::prcp(R(1) - ta_clear * cl.reflectance);
         const R tac_new = cl.reflectance + cl.transmittance * cl.transmittance * ta_clear * inv;
         ts_clear = cl.source_up + cl.transmittance * (ts_clear + ta_clear * cl.source_dn) * inv;
         ta_clear = tac_new;
@@ -1229,7 +1255,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
       V3<R> ts_below;
       ta_below.zero(); ts_below.zero();
       if (clr) {
-        const R inv = R(1) / (R(1) - ta(0, 0) * refl(0, 0));
+        const R inv = sp::prcp(R(1) - ta(0, 0) * refl(0, 0));
         ta_below(0, 0) = refl(0, 0) + tran(0, 0) * tran(0, 0) * ta(0, 0) * inv;
         ts_below.a[0] = source_up.a[0] + tran(0, 0) * (ts.a[0] + ta(0, 0) * source_dn.a[0]) * inv;
       } else if (matrix_adding) {
@@ -1239,7 +1265,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
       } else {
 #pragma unroll
         for (int jreg = 0; jreg < 3; ++jreg) {
-          const R inv = R(1) / (R(1) - ta(jreg, jreg) * refl(jreg, jreg));
+          const R inv = sp::prcp(R(1) - ta(jreg, jreg) * refl(jreg, jreg));
           ta_below(jreg, jreg) = refl(jreg, jreg) + tran(jreg, jreg) * tran(jreg, jreg) * ta(jreg, jreg) * inv;
           ts_below.a[jreg] = source_up.a[jreg] + tran(jreg, jreg) * (ts.a[jreg] + ta(jreg, jreg) * source_dn.a[jreg]) * inv;
         }
@@ -1305,22 +1331,22 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
       const size_t oh = col + ncol * ord.half(jlev);
       if (do_clear) {
         const R refc = c5[0], trac = c5[1], sdnc = c5[2], tac = c5[3], tsc = c5[4];
-        flux_dn_clear = (trac * flux_dn_clear + refc * tsc + sdnc) / (R(1) - refc * tac);
+        flux_dn_clear = sp::pdiv(trac * flux_dn_clear + refc * tsc + sdnc, R(1) - refc * tac);
         flux_up_clear = tsc + tac * flux_dn_clear;
       }
       if (clr) {
         const R refl = r5[0], tran = r5[1], sdn = r5[2], ta1 = r5[3], ts1 = r5[4];
         flux_dn_above.zero(); flux_up_above.zero();
-        flux_dn_above.a[0] = (tran * flux_dn_below.a[0] + refl * ts1 + sdn) / (R(1) - refl * ta1);
+        flux_dn_above.a[0] = sp::pdiv(tran * flux_dn_below.a[0] + refl * ts1 + sdn, R(1) - refl * ta1);
         flux_up_above.a[0] = ts1 + ta1 * flux_dn_above.a[0];
       } else {
         M3<R> refl, tran, ta1;
         V3<R> sdn, ts1;
-        const R* lp = reinterpret_cast<const R*>(a.lay) + (size_t)a.item_of[(size_t)cloc * nlev + jl] * 24 * ngl + gs;
+        const R* lp = reinterpret_cast<const R*>(a.lay) + (size_t)a.item_of[(size_t)cloc * nlev + jl] * (24 * NGP) + gs;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { refl.a[k] = lp[(size_t)k * ngl]; tran.a[k] = lp[(size_t)(9 + k) * ngl]; }
+        for (int k = 0; k < 9; ++k) { refl.a[k] = lp[k * NGP]; tran.a[k] = lp[(9 + k) * NGP]; }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) sdn.a[k] = lp[(size_t)(21 + k) * ngl];
+        for (int k = 0; k < 3; ++k) sdn.a[k] = lp[(21 + k) * NGP];
         slab.get(jl, LW_TA, tid, ta1); slab.get(jl, LW_TS, tid, ts1);
         if (matrix_adding) {
           const V3<R> rhs = add(add(sp::mul(tran, flux_dn_below), sp::mul(refl, ts1)), sdn);
@@ -1329,8 +1355,8 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
         } else {
 #pragma unroll
           for (int jreg = 0; jreg < 3; ++jreg) {
-            flux_dn_above.a[jreg] = (tran(jreg, jreg) * flux_dn_below.a[jreg] + refl(jreg, jreg) * ts1.a[jreg] + sdn.a[jreg])
-                                    / (R(1) - refl(jreg, jreg) * ta1(jreg, jreg));
+            flux_dn_above.a[jreg] = sp::pdiv(tran(jreg, jreg) * flux_dn_below.a[jreg] + refl(jreg, jreg) * ts1.a[jreg] + sdn.a[jreg],
+                                             R(1) - refl(jreg, jreg) * ta1(jreg, jreg));
             flux_up_above.a[jreg] = ts1.a[jreg] + ta1(jreg, jreg) * flux_dn_above.a[jreg];
           }
         }
@@ -1395,9 +1421,9 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
           lwd.a[0] = t00 * v1.a[0];
         } else {
           M3<R> tran;
-          const R* lp = reinterpret_cast<const R*>(a.lay) + (size_t)a.item_of[(size_t)cloc * nlev + jl] * 24 * ngl + gs;
+          const R* lp = reinterpret_cast<const R*>(a.lay) + (size_t)a.item_of[(size_t)cloc * nlev + jl] * (24 * NGP) + gs;
 #pragma unroll
-          for (int k = 0; k < 9; ++k) tran.a[k] = lp[(size_t)(9 + k) * ngl];
+          for (int k = 0; k < 9; ++k) tran.a[k] = lp[(9 + k) * NGP];
           lwd = sp::mul(tran, v1);
         }
         put_sum<NGP>(fx.lw_derivatives, col + ncol * ord.half(jlev - 1), (double)lwd.sum(), valid, lead);
@@ -1492,21 +1518,21 @@ __global__ __launch_bounds__(kBlock, (sp_layers_waves<R, IS_SW>())) void spartac
       else tan_sza = sp::sp_sqrt(R(c.overhead_sun_factor));
       const SwMats<R> m = sw_layer<R, NGP>(a, gm, ord, col, cloc, jl, g, ib, glane, tid, valid, clr, mu0s, tan_sza);
       if (valid && sun_up) {
-        R* lp = reinterpret_cast<R*>(a.lay) + (size_t)it * 45 * ngl + gs;
+        R* lp = reinterpret_cast<R*>(a.lay) + (size_t)it * (45 * NGP) + gs;
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-          lp[(size_t)k * ngl] = m.refl.a[k]; lp[(size_t)(9 + k) * ngl] = m.tran.a[k]; lp[(size_t)(18 + k) * ngl] = m.rdir.a[k];
-          lp[(size_t)(27 + k) * ngl] = m.tdd.a[k]; lp[(size_t)(36 + k) * ngl] = m.tdir.a[k];
+          lp[k * NGP] = m.refl.a[k]; lp[(9 + k) * NGP] = m.tran.a[k]; lp[(18 + k) * NGP] = m.rdir.a[k];
+          lp[(27 + k) * NGP] = m.tdd.a[k]; lp[(36 + k) * NGP] = m.tdir.a[k];
         }
       }
     } else {
       const LwMats<R> m = lw_layer<R, NGP>(a, gm, ord, col, cloc, jl, g, ib, glane, tid, valid, clr);
       if (valid) {
-        R* lp = reinterpret_cast<R*>(a.lay) + (size_t)it * 24 * ngl + gs;
+        R* lp = reinterpret_cast<R*>(a.lay) + (size_t)it * (24 * NGP) + gs;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { lp[(size_t)k * ngl] = m.refl.a[k]; lp[(size_t)(9 + k) * ngl] = m.tran.a[k]; }
+        for (int k = 0; k < 9; ++k) { lp[k * NGP] = m.refl.a[k]; lp[(9 + k) * NGP] = m.tran.a[k]; }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { lp[(size_t)(18 + k) * ngl] = m.source_up.a[k]; lp[(size_t)(21 + k) * ngl] = m.source_dn.a[k]; }
+        for (int k = 0; k < 3; ++k) { lp[(18 + k) * NGP] = m.source_up.a[k]; lp[(21 + k) * NGP] = m.source_dn.a[k]; }
       }
     }
   }
@@ -1515,7 +1541,7 @@ __global__ __launch_bounds__(kBlock, (sp_layers_waves<R, IS_SW>())) void spartac
 // ---- host side -------------------------------------------------------------------------------------------------------
 size_t spartacus_scratch_words(bool is_sw, int nlev) { return (size_t)nlev * (is_sw ? SW_NSLOT : LW_NSLOT) * kBlock; }
 int spartacus_sweep_blocks_per_cu(bool single, bool is_sw) { return single ? (is_sw ? ECRAD_SP_SWEEP_WAVES_SW : ECRAD_SP_SWEEP_WAVES_LW) : (is_sw ? ECRAD_SP_DP_SWEEP_WAVES_SW : ECRAD_SP_DP_SWEEP_WAVES_LW); }
-size_t spartacus_layer_words(bool is_sw, int ng) { return (size_t)(is_sw ? 45 : 24) * ng; }    // per (column, layer); ng = g-points of one launch
+size_t spartacus_layer_words(bool is_sw, int ngp) { return (size_t)(is_sw ? 45 : 24) * ngp; }    // per (column, layer); ngp = lanes per column of the kernels (their NGP)
 
 // The work list of a batch of columns (the same for the two spectra and for every chunk of a spectrum): `list` and
 // `item_of` hold nlev x columns entries each, `n_items` one int (zeroed here).  The caller reads n_items back to size the

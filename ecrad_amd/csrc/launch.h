@@ -62,7 +62,7 @@ hipError_t launch_optics_dump(bool is_sw, int ngp, bool table_f32, int grid, siz
 // SPARTACUS solvers (kernel_spartacus.hip): words of working precision of block-private slab per block and of layer
 // matrices per (column, layer); the launch of one spectrum (work list, layer matrices, the two sweeps)
 size_t spartacus_scratch_words(bool is_sw, int nlev);
-size_t spartacus_layer_words(bool is_sw, int ng);
+size_t spartacus_layer_words(bool is_sw, int ngp);
 int spartacus_sweep_blocks_per_cu(bool single, bool is_sw);
 hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, int grid_layers, hipStream_t st, const ecrad_config_t& c,
                             const DevInputs& in, const DevOptics& op, const DevCloudPrep& prep, const DevFlux& fx, void* scratch,

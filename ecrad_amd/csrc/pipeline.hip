@@ -301,8 +301,8 @@ size_t work_bytes_per_column(ecrad_hip_handle_t h, int nlev, const ecrad_inputs_
   if (tc) b += 8 * (size_t)kGeomItems * (L + 1);
   {   // stage arrays of the SPARTACUS solvers (one buffer, reused by the two spectra)
     const size_t w = c.i_precision == ECRAD_PRECISION_SINGLE ? 4 : 8;
-    const size_t bsw = sw_sp ? w * ((size_t)c.n_g_sw * (3 * L + 3) + (size_t)c.n_bands_sw * 3 * L) + w * L * spartacus_layer_words(true, std::min(c.n_g_sw, h->ngp_sw)) : 0;
-    const size_t blw = lw_sp ? w * ((size_t)c.n_g_lw * (4 * L + 3) + (size_t)c.n_bands_lw * 3 * L) + w * L * spartacus_layer_words(false, std::min(c.n_g_lw, h->ngp_lw)) : 0;
+    const size_t bsw = sw_sp ? w * ((size_t)c.n_g_sw * (3 * L + 3) + (size_t)c.n_bands_sw * 3 * L) + w * L * spartacus_layer_words(true, h->ngp_sw) : 0;
+    const size_t blw = lw_sp ? w * ((size_t)c.n_g_lw * (4 * L + 3) + (size_t)c.n_bands_lw * 3 * L) + w * L * spartacus_layer_words(false, h->ngp_lw) : 0;
     b += std::max(bsw, blw) + ((sw_sp || lw_sp) ? 8 * L : 0);      // (+ work list and item index; the layer store counted for the worst case: every layer listed)
   }
   if (sw_mcica) b += 8 * ((size_t)c.n_g_sw * L + 1);
@@ -643,10 +643,12 @@ int tile_compute(ecrad_hip_handle_t h, Tile& T) {
     const size_t n = r.nloc, L = nlev, ngs = is_sw ? c.n_g_sw : c.n_g_lw, nbs = is_sw ? c.n_bands_sw : c.n_bands_lw;
     DevOptics dop{};
     void* lay = nullptr;
+    int ngp_store = is_sw ? h->ngp_sw : h->ngp_lw;      // stride of the layer store: the widest launch's lanes per column
+    { const ChunkPlan& pl = is_sw ? h->plan_sw : h->plan_lw; for (int p = 0; p < pl.n; ++p) ngp_store = std::max(ngp_store, pl.ngp[p]); }
     for (int pass = 0; pass < 2; ++pass) {
       Carver cv(pass == 0 ? nullptr : h->sp_stage.p);
       // the layer store holds the listed layers only (45 SW / 24 LW words per g-point of a launch each)
-      lay = cv.take<char>(sp_word * (size_t)std::max(sp_n, 1) * spartacus_layer_words(is_sw, std::min((int)ngs, is_sw ? h->ngp_sw : h->ngp_lw)));
+      lay = cv.take<char>(sp_word * (size_t)std::max(sp_n, 1) * spartacus_layer_words(is_sw, ngp_store));
       // stage arrays in the solver's working precision (optics_dump_kernel<..., OUT>): float in single precision
       auto stage = [&](size_t count) { return reinterpret_cast<double*>(cv.take<char>(count * sp_word)); };
       if (is_sw) {

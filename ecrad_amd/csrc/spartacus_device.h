@@ -28,6 +28,23 @@ SP_DEV double sp_ldexp(double x, int e) { return ldexp(x, e); }
 SP_DEV float sp_ldexp(float x, int e) { return ldexpf(x, e); }
 SP_DEV double sp_pow(double x, double y) { return pow(x, y); }
 SP_DEV float sp_pow(float x, float y) { return powf(x, y); }
+// Division.  kernel_spartacus.hip is compiled with -fno-hip-fp32-correctly-rounded-divide-sqrt (ECRAD_SP_FAST_DIV, Makefile):
+// a float quotient a / b is a * rcp(b) with the hardware's reciprocal, within 2.5 units of the last place, in 2-3
+// instructions instead of the ~10 of the correctly rounded sequence (the solver kernels hold 65-210 float divisions each; double
+// precision is not affected).  The flux and albedo RECURRENCES -- one quotient per level, 137 of them chained -- go through
+// pdiv / prcp instead: the reciprocal, one multiplication and one residual correction, within one unit of the last place.
+#ifndef ECRAD_SP_FAST_DIV
+#define ECRAD_SP_FAST_DIV 0
+#endif
+template <typename R> SP_DEV R pdiv(R a, R b) { return a / b; }
+#if ECRAD_SP_FAST_DIV
+template <> SP_DEV float pdiv<float>(float a, float b) {
+  const float r = __builtin_amdgcn_rcpf(b);
+  const float q = a * r;
+  return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
+#endif
+template <typename R> SP_DEV R prcp(R b) { return pdiv<R>(R(1), b); }
 template <typename R> struct Eps;
 template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-07f; };

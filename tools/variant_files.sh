@@ -9,6 +9,7 @@ objs=""
 for o in pool setup pipeline abi kernel_ica_sw kernel_ica_lw kernel_ica_lw_clear kernel_lw_scat kernel_tc kernel_prep kernel_optics kernel_rrtmg kernel_spartacus; do
   if [[ " $* " == *" $o "* ]]; then
     x=""; [ $o = kernel_ica_lw_clear ] && x="-mllvm -amdgpu-sched-strategy=max-memory-clause"
+    [ $o = kernel_spartacus ] && [[ "$flags" != *FAST_DIV=0* ]] && x="-fno-hip-fp32-correctly-rounded-divide-sqrt -DECRAD_SP_FAST_DIV=1"
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $x $flags -c $root/ecrad_amd/csrc/$o.hip -o $out/$o.o &
     objs="$objs $out/$o.o"
   else
