@@ -1436,6 +1436,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
 // =====================================================================================================================
 //  work list and layer matrices
 // =====================================================================================================================
+#ifndef ECRAD_SP_TU_LW_SWEEP
 // One lane per column: the column's listed layers (cloudy ones; all with use_expm_everywhere) are appended to the work
 // list, the space for a wave's columns being reserved by ONE atomic (prefix sum over the wave).
 __global__ void spartacus_list_kernel(DevInputs in, int list_all, uint32_t* __restrict__ list, int* __restrict__ item_of, int* __restrict__ n_items) {
@@ -1469,6 +1470,7 @@ __global__ void spartacus_list_kernel(DevInputs in, int list_all, uint32_t* __re
         list[pos++] = ((uint32_t)cloc << 8) | (uint32_t)jl;
       }
 }
+#endif
 
 // lane = g-point, 256/NGP listed layers per block; one wave per SIMD (the 9x9 exponential wants the whole register file)
 // (single precision: the longwave's 6x6 exponential needs 276 of the 512 registers of a lane; held to 256 -- 20 of them spilled --
@@ -1539,6 +1541,21 @@ __global__ __launch_bounds__(kBlock, (sp_layers_waves<R, IS_SW>())) void spartac
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------
+// Two translation units from this source: kernel_spartacus_lw.hip includes it with ECRAD_SP_TU_LW_SWEEP and holds the
+// instantiations of spartacus_lw_kernel only -- that kernel is faster WITH the compiler's SLP vectoriser (v_pk_* pairs), everything
+// else here without it (Makefile: EXTRA_kernel_spartacus; round 5, profiles/r05_variants.log r05_zc).
+hipError_t launch_spartacus_lw_sweep(const void* sp_args, bool single, int ngp, int grid, hipStream_t st);
+#ifdef ECRAD_SP_TU_LW_SWEEP
+hipError_t launch_spartacus_lw_sweep(const void* sp_args, bool single, int ngp, int grid, hipStream_t st) {
+  const SpArgs& a = *static_cast<const SpArgs*>(sp_args);
+  const dim3 g(grid), b(kBlock);
+#define ECRAD_SP(R, N) hipLaunchKernelGGL((spartacus_lw_kernel<R, N>), g, b, 0, st, a)
+  if (single) { if (ngp == 16) ECRAD_SP(float, 16); else if (ngp == 32) ECRAD_SP(float, 32); else ECRAD_SP(float, 64); }
+  else { if (ngp == 16) ECRAD_SP(double, 16); else if (ngp == 32) ECRAD_SP(double, 32); else ECRAD_SP(double, 64); }
+#undef ECRAD_SP
+  return hipGetLastError();
+}
+#else
 size_t spartacus_scratch_words(bool is_sw, int nlev) { return (size_t)nlev * (is_sw ? SW_NSLOT : LW_NSLOT) * kBlock; }
 int spartacus_sweep_blocks_per_cu(bool single, bool is_sw) { return single ? (is_sw ? ECRAD_SP_SWEEP_WAVES_SW : ECRAD_SP_SWEEP_WAVES_LW) : (is_sw ? ECRAD_SP_DP_SWEEP_WAVES_SW : ECRAD_SP_DP_SWEEP_WAVES_LW); }
 size_t spartacus_layer_words(bool is_sw, int ngp) { return (size_t)(is_sw ? 45 : 24) * ngp; }    // per (column, layer); ngp = lanes per column of the kernels (their NGP)
@@ -1579,11 +1596,12 @@ hipError_t launch_spartacus(bool is_sw, bool single, int ngp, int grid, int grid
 #define ECRAD_SP(R, N) do { if (is_sw) { hipLaunchKernelGGL((spartacus_layers_kernel<R, N, true>), dim3(grid_layers * sp_layers_waves<R, true>()), b, 0, st, a);      \
                                          hipLaunchKernelGGL((spartacus_sw_kernel<R, N>), g, b, 0, st, a); }                  \
                             else { hipLaunchKernelGGL((spartacus_layers_kernel<R, N, false>), dim3(grid_layers * sp_layers_waves<R, false>()), b, 0, st, a);             \
-                                   hipLaunchKernelGGL((spartacus_lw_kernel<R, N>), g, b, 0, st, a); } } while (0)
+                                   const hipError_t e = launch_spartacus_lw_sweep(&a, single, ngp, grid, st); if (e != hipSuccess) return e; } } while (0)
   if (single) { if (ngp == 16) ECRAD_SP(float, 16); else if (ngp == 32) ECRAD_SP(float, 32); else ECRAD_SP(float, 64); }
   else { if (ngp == 16) ECRAD_SP(double, 16); else if (ngp == 32) ECRAD_SP(double, 32); else ECRAD_SP(double, 64); }
 #undef ECRAD_SP
   return hipGetLastError();
 }
+#endif      // ECRAD_SP_TU_LW_SWEEP
 
 }  // namespace ecrad
