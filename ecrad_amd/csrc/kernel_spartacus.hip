@@ -49,9 +49,18 @@
 #ifndef ECRAD_SP_DP_SWEEP_WAVES_LW
 #define ECRAD_SP_DP_SWEEP_WAVES_LW 2
 #endif
-// levels of slab scalars the flux sweeps keep in flight (a ring, see section 5 of spartacus_sw_kernel)
-#ifndef ECRAD_SP_RING
-#define ECRAD_SP_RING 4
+// levels of slab scalars the flux sweeps keep in flight (a ring, see section 5 of spartacus_sw_kernel).  Round 4: 4 for both; re-measured
+// in round 5 after the kernels had lost a sixth of their instructions (gpurun_out/r05_zg, r05_zh; single precision, 100 000 columns):
+// shortwave stage 42.4 ms with 4, 42.0-42.2 with 6, 48 with 8 (spills); longwave stage 29.1-29.2 with 4, 28.3-28.6 with 2, 29.1-29.5 with 6.
+// (double precision, two waves per SIMD and 125 spilled registers as it is: shortwave stage 79.4 ms with 4, 86.5 with 6)
+#ifndef ECRAD_SP_RING_SW
+#define ECRAD_SP_RING_SW 6
+#endif
+#ifndef ECRAD_SP_DP_RING_SW
+#define ECRAD_SP_DP_RING_SW 4
+#endif
+#ifndef ECRAD_SP_RING_LW
+#define ECRAD_SP_RING_LW 2
 #endif
 
 namespace ecrad {
@@ -63,7 +72,8 @@ using sp::rmin;
 
 namespace {
 
-constexpr int kSpRing = ECRAD_SP_RING;
+constexpr int kSpRingLw = ECRAD_SP_RING_LW;
+template <typename R> constexpr int sp_ring_sw() { return sizeof(R) == 4 ? ECRAD_SP_RING_SW : ECRAD_SP_DP_RING_SW; }
 constexpr double kPi = 3.14159265358979323846;
 constexpr double kGasConstantDryAir = 287.058;      // radiation_constants.F90:31
 
@@ -553,6 +563,7 @@ ECRAD_DEV SwMats<R> sw_layer(const SpArgs& a, const Geo& gm, const LevelOrder& o
 // =====================================================================================================================
 template <typename R, int NGP>
 __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : ECRAD_SP_DP_SWEEP_WAVES_SW) void spartacus_sw_kernel(SpArgs args_in_kernarg) {
+  constexpr int kSpRingSw = sp_ring_sw<R>();
   __shared__ int next_group;
   constexpr int CPB = kBlock / NGP;
   const int tid = threadIdx.x;
@@ -816,10 +827,10 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
         }
       }
       // The scalars of a level -- the clear-sky set and, for a cloud-free layer, region 1's: slots 0-11 of the slab -- come
-      // through a RING of kSpRing levels: the slot a level is taken from is refilled at once with the level kSpRing further
+      // through a RING of kSpRingSw levels: the slot a level is taken from is refilled at once with the level kSpRingSw further
       // down.  (Until round 4 every level asked for its own twelve values and waited for them: one trip to HBM per level of
       // a sweep that has a few dozen operations per level.)  The matrices of a cloudy layer are still fetched when it is met.
-      R ring_c[kSpRing][6], ring_r[kSpRing][6];
+      R ring_c[kSpRingSw][6], ring_r[kSpRingSw][6];
       auto fetch_level = [&](int jl_want, R (&c6)[6], R (&r6)[6]) {
         const int l = jl_want < nlev ? jl_want : nlev - 1;
 #pragma unroll
@@ -832,7 +843,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
         for (int k = 4; k < 6; ++k) { r6[k] = cl ? slab.get(l, SW_REFL + k, tid) : R(0); }
       };
 #pragma unroll
-      for (int k = 0; k < kSpRing; ++k) fetch_level(k, ring_c[k], ring_r[k]);
+      for (int k = 0; k < kSpRingSw; ++k) fetch_level(k, ring_c[k], ring_r[k]);
       auto flux_level = [&](const int jlev, const R (&c6)[6], const R (&r6)[6]) {
         const int jl = jlev - 1;
         const bool clr = !cm.test(jl);
@@ -905,15 +916,15 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
           }
         }
       };
-      for (int j0 = 1; j0 <= nlev; j0 += kSpRing) {
+      for (int j0 = 1; j0 <= nlev; j0 += kSpRingSw) {
 #pragma unroll
-        for (int k = 0; k < kSpRing; ++k) {
+        for (int k = 0; k < kSpRingSw; ++k) {
           const int jlev = j0 + k;
           if (jlev <= nlev) {
             R c6[6], r6[6];
 #pragma unroll
             for (int q = 0; q < 6; ++q) { c6[q] = ring_c[k][q]; r6[q] = ring_r[k][q]; }
-            fetch_level(jlev - 1 + kSpRing, ring_c[k], ring_r[k]);
+            fetch_level(jlev - 1 + kSpRingSw, ring_c[k], ring_r[k]);
             flux_level(jlev, c6, r6);
           }
         }
@@ -1309,8 +1320,8 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
         if (do_clear) { spec_put(fx.lw_up_clear_band, ng, g, o0, (double)ts_clear); spec_put(fx.lw_dn_clear_band, ng, g, o0, 0.0); }
       }
     }
-    // (the scalars of a level -- slots 0-9 of the slab -- through a ring of kSpRing levels, see spartacus_sw_kernel)
-    R ring_c[kSpRing][5], ring_r[kSpRing][5];
+    // (the scalars of a level -- slots 0-9 of the slab -- through a ring of kSpRingLw levels, see spartacus_sw_kernel)
+    R ring_c[kSpRingLw][5], ring_r[kSpRingLw][5];
     auto fetch_level = [&](int jl_want, R (&c5)[5], R (&r5)[5]) {
       const int l = jl_want < nlev ? jl_want : nlev - 1;
 #pragma unroll
@@ -1323,7 +1334,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
       for (int k = 3; k < 5; ++k) { r5[k] = cl ? slab.get(l, LW_REFL + k, tid) : R(0); }
     };
 #pragma unroll
-    for (int k = 0; k < kSpRing; ++k) fetch_level(k, ring_c[k], ring_r[k]);
+    for (int k = 0; k < kSpRingLw; ++k) fetch_level(k, ring_c[k], ring_r[k]);
     auto flux_level = [&](const int jlev, const R (&c5)[5], const R (&r5)[5]) {
       const int jl = jlev - 1;
       const bool clr = !cm.test(jl);
@@ -1382,15 +1393,15 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_LW : 
         }
       }
     };
-    for (int j0 = 1; j0 <= nlev; j0 += kSpRing) {
+    for (int j0 = 1; j0 <= nlev; j0 += kSpRingLw) {
 #pragma unroll
-      for (int k = 0; k < kSpRing; ++k) {
+      for (int k = 0; k < kSpRingLw; ++k) {
         const int jlev = j0 + k;
         if (jlev <= nlev) {
           R c5[5], r5[5];
 #pragma unroll
           for (int q = 0; q < 5; ++q) { c5[q] = ring_c[k][q]; r5[q] = ring_r[k][q]; }
-          fetch_level(jlev - 1 + kSpRing, ring_c[k], ring_r[k]);
+          fetch_level(jlev - 1 + kSpRingLw, ring_c[k], ring_r[k]);
           flux_level(jlev, c5, r5);
         }
       }
