@@ -32,7 +32,9 @@
 #define ECRAD_TC_BATCH_D 8      // (the derivative pass has no recurrence: 4 -> 8 layers per batch, Tripleclouds on RRTMG longwave 75.1 -> 73.7 ms)
 #endif
 #ifndef ECRAD_TC_BATCH_S
-#define ECRAD_TC_BATCH_S 2      // shortwave flux sweep
+// shortwave flux sweep.  (2 until round 5; re-measured then, gpurun_out/r05_zk / r05_zl: 3 takes sw_tc_kernel<FixedF,32> 20.28 -> 20.08 ms per 100 000
+// columns and the 64-g-point kernel 39.1 -> 38.7; 4 spills and costs 28 ms.  B, C, D re-measured in the same run: as they are.)
+#define ECRAD_TC_BATCH_S 3
 #endif
 #ifndef ECRAD_TC_LW_AER_BATCH
 #define ECRAD_TC_LW_AER_BATCH 12      // aerosol types per batch of table loads in the longwave optics pass
