@@ -20,6 +20,7 @@ import pytest
 
 from ecrad_amd.config import (IEntrapmentEdgeOnly, IEntrapmentExplicit, IEntrapmentExplicitNonFractal,
                               IEntrapmentMaximum, IEntrapmentZero, IPrecisionSingle)
+from ecrad_amd.types import Flux
 from helpers import compare_flux, make_config, rel_err, run_case
 
 pytestmark = pytest.mark.gpu
@@ -161,6 +162,46 @@ def test_spartacus_single_precision(name, oracle_lib):
             assert (got[calm] <= 1.0e-3).mean() > 0.999, (k, (got[calm] > 1.0e-3).mean())
     off = np.abs(f_sp.arrays["lw_up"] - f_dp.arrays["lw_up"]) / f_dp.arrays["lw_up"] > 1.0e-3
     print(f"{name}: single-precision ORACLE, all-sky lw_up off by more than 1e-3 from double in {100.0 * off.mean():.2f} % of the values")
+
+
+def test_single_precision_division_by_reciprocal_changes_nothing_that_matters(oracle_lib):
+    """The single-precision kernels divide by the hardware reciprocal (2.5 units of the last place) off the albedo / flux recurrences
+    and by reciprocal + one residual correction (one unit) on them (spartacus_device.h: pdiv; Makefile: SP_FAST_DIV).  The variant
+    tests/_build/variants/nopack is built without that flag -- correctly rounded float division everywhere.  On the meridian slice the two
+    builds are compared with the double-precision oracle, field by field for everything that is stable in single precision: the
+    shipped build's largest difference from double within 1.5 x the correctly rounded build's (+ 1e-5; and below the 2e-3 of
+    test_spartacus_single_precision), its median difference within 1.25 x (+ 1e-7), and the two must differ somewhere (the variant
+    IS another build)."""
+    from ecrad_amd.interface import Radiation
+    from helpers import load_meridian
+    nopack = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "_build", "variants", "nopack", "libecrad_hip.so")
+    assert os.path.exists(nopack), "tests/_build/variants/nopack/libecrad_hip.so is missing: run __graft_entry__.build()"
+    kw = dict(CASES["explicit"], i_precision=IPrecisionSingle)
+    f_dp, _, _ = run_case(_config(**CASES["explicit"]), oracle_lib.backend)
+    out = []
+    for path in (None, nopack):
+        config = _config(**kw)
+        rad = Radiation(config, backend="hip", lib_path=path)
+        ncol, nlev, sl, th, gas, cloud, aer = load_meridian(config)
+        rad.set_gas_units(gas)
+        th.calc_saturation_wrt_liquid()
+        flux = Flux.allocate(config, ncol, nlev)
+        rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)
+        rad.close()
+        out.append(flux)
+    differ = 0.0
+    for k, dp in f_dp.arrays.items():
+        if not k.startswith(STABLE_IN_SINGLE):
+            continue
+        scale = np.maximum(np.abs(dp), 1.0e-3 * np.abs(dp).max() + 1.0e-300)
+        d_fast, d_ieee = np.abs(out[0].arrays[k] - dp) / scale, np.abs(out[1].arrays[k] - dp) / scale
+        differ = max(differ, float(np.abs(out[0].arrays[k] - out[1].arrays[k]).max()))
+        print(f"{k}: largest / median difference from double: shipped {d_fast.max():.2e} / {np.median(d_fast):.2e}, "
+              f"correctly rounded division {d_ieee.max():.2e} / {np.median(d_ieee):.2e}")
+        # (the largest element is one number; the median says what the division did to the field)
+        assert d_fast.max() < 2.0e-3 and d_fast.max() <= 1.5 * d_ieee.max() + 1.0e-5, (k, d_fast.max(), d_ieee.max())
+        assert np.median(d_fast) <= 1.25 * np.median(d_ieee) + 1.0e-7, (k, np.median(d_fast), np.median(d_ieee))
+    assert differ > 0.0, "the two builds are identical: the variant is not a build with the compiler's own float division"
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(max_gas_od_3d=0.5), dict(do_lw_aerosol_scattering=True)], ids=["default", "tight_caps", "aerosol_scat"])
