@@ -9,13 +9,25 @@ reports it; dynamic LDS (the level records) is set at launch and is not in the s
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ecrad_amd", "csrc")
-flags, extra = None, {}
+flags, extra, mkvars = None, {}, {"ARCH": "gfx950"}
+
+
+def expand(text):      # $(NAME) of the Makefile's own variables
+    return re.sub(r"\$\((\w+)\)", lambda m: mkvars.get(m.group(1), ""), text)
+
+
 for line in open(os.path.join(CSRC, "Makefile")):
-    if line.startswith("CXXFLAGS"):
-        flags = line.split("=", 1)[1].strip().replace("$(ARCH)", "gfx950").split()
-    if line.startswith("EXTRA_"):       # per-file flags
-        extra[line.split("=", 1)[0].strip()[len("EXTRA_"):] + ".hip"] = line.split("=", 1)[1].strip().split()
-srcs = sorted(f for f in os.listdir(CSRC) if f.startswith("kernel_") and f.endswith(".hip"))
+    m = re.match(r"^(\w+)\s*\??=\s*(.*)$", line)
+    if not m:
+        continue
+    name, value = m.group(1), expand(m.group(2).strip())
+    mkvars.setdefault(name, value) if name == "ARCH" else mkvars.__setitem__(name, value)
+    if name == "CXXFLAGS":
+        flags = value.split()
+    if name.startswith("EXTRA_"):       # per-file flags
+        extra[name[len("EXTRA_"):] + ".hip"] = value.split()
+only = set(sys.argv[1:])      # (optional: restrict to these kernel_*.hip files)
+srcs = sorted(f for f in os.listdir(CSRC) if f.startswith("kernel_") and f.endswith(".hip") and (not only or f in only))
 print("# Kernel resource usage (hipcc -Rpass-analysis=kernel-resource-usage, gfx950)\n")
 print("Flags: `" + " ".join(flags) + "`.  One row per kernel instantiation; `occ` = waves per SIMD the register budget admits,")
 print("`scratch` = bytes of private (spill) memory per lane, `LDS` = static bytes per block (the level records are dynamic LDS on top).\n")
