@@ -34,7 +34,12 @@
 #ifndef ECRAD_TC_BATCH_S
 // shortwave flux sweep.  (2 until round 5; re-measured then, gpurun_out/r05_zk / r05_zl: 3 takes sw_tc_kernel<FixedF,32> 20.28 -> 20.08 ms per 100 000
 // columns and the 64-g-point kernel 39.1 -> 38.7; 4 spills and costs 28 ms.  B, C, D re-measured in the same run: as they are.)
+// Only in the compile-time configuration (FX = 1): the general instantiation (FX = 0: every other namelist) has no registers for a
+// third layer -- 20.2 -> 23.9 ms with 3 -- and keeps ECRAD_TC_BATCH_S_GENERAL.
 #define ECRAD_TC_BATCH_S 3
+#endif
+#ifndef ECRAD_TC_BATCH_S_GENERAL
+#define ECRAD_TC_BATCH_S_GENERAL 2
 #endif
 #ifndef ECRAD_TC_LW_AER_BATCH
 #define ECRAD_TC_LW_AER_BATCH 12      // aerosol types per batch of table loads in the longwave optics pass
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(kBlock, (FX != 0 && ECRAD_TC_PIPE) ? ECRAD_TC_PIPE_
 #else
     feed.init(prep, ncol_loc, nlev, cloc, L.d + (size_t)(cib * NGP) * (L.rec2 * 2), glane);
 #endif
-    constexpr int K = ECRAD_TC_BATCH_S;
+    constexpr int K = FX ? ECRAD_TC_BATCH_S : ECRAD_TC_BATCH_S_GENERAL;
     for (int l0 = 0; l0 < ((ECRAD_ABLATE & 4) ? 0 : nlev); l0 += K) {
       // records of K layers requested together
 #if ECRAD_PACK_SW

@@ -468,7 +468,10 @@ def test_compile_time_configuration_changes_nothing(monkeypatch):
     """The Tripleclouds shortwave kernel runs the reference's test configuration (clear-sky fluxes, aerosols on every level, per-g-point
     optics, no spectral profiles) as an instantiation with that configuration at compile time (kernel_tc.hip: FX = 1,
     sw_tc_fixed_config).  ECRAD_HIP_NO_FIXED_CONFIG in the environment of a call keeps it on the run-time switches every other
-    configuration uses: the same bits, on the meridian slice and on 2 048 synthetic columns."""
+    configuration uses: the same numbers, on the meridian slice and on 2 048 synthetic columns.  (The same BITS while the two
+    instantiations took their flux-sweep records in batches of the same size; since round 5 the fixed one takes three layers per batch, the
+    general one two -- ECRAD_TC_BATCH_S / _GENERAL -- and the compiler contracts a handful of multiply-adds of the cloudy layers differently
+    in the two loop bodies: 3 % of the all-sky shortwave values differ, by at most 3e-15 relative; the clear-sky values are the same bits.)"""
     import numpy as np
     from ecrad_amd.interface import Radiation
     from ecrad_amd.synthetic import make_columns
@@ -491,7 +494,13 @@ def test_compile_time_configuration_changes_nothing(monkeypatch):
             rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)
             out.append(flux)
         for name, a in out[0].arrays.items():
-            assert np.array_equal(a, out[1].arrays[name], equal_nan=True), name
+            b = out[1].arrays[name]
+            if "clear" in name or name.startswith("lw_"):
+                assert np.array_equal(a, b, equal_nan=True), name
+            else:
+                assert np.array_equal(np.isnan(a), np.isnan(b)), name
+                scale = np.maximum(np.abs(a), 1.0e-3 * np.nanmax(np.abs(a)) + 1.0e-300)
+                assert np.nanmax(np.abs(a - b) / scale) < 1.0e-13, name
     rad.close()
 
 
