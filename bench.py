@@ -895,10 +895,17 @@ def pool_mode(args):
     sys.exit(0 if same else 1)
 
 
-def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allreduce_max, do_cpu, do_host_mode):
+def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allreduce_max, do_cpu, do_host_mode, regions=1):
+    """`regions` > 1 (the extra workloads, five steps each): the K-step region is timed that many times and the fastest kept -- one
+    hiccup of the box (35 ms once, seen in round 5) is 7 ms per step of a five-step region.  The headline is timed ONCE, K steps exactly."""
     sample_cols = 16384 if do_cpu else 0
     w = Workload(name, ncol, rank, local_rank, sample_cols)
     elapsed_rank = timed_steps(w, steps, warmup, barrier)
+    region_ms = [1e3 * elapsed_rank / steps]
+    for _ in range(regions - 1):
+        e = timed_steps(w, steps, 0, barrier)
+        region_ms.append(1e3 * e / steps)
+        elapsed_rank = min(elapsed_rank, e)
     elapsed = allreduce_max(elapsed_rank)
     elapsed_min = -allreduce_max(-elapsed_rank)
     stage = w.stage_ms()
@@ -916,6 +923,8 @@ def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allredu
                       "n_g_lw": w.config.n_g_lw, "sw_solver": w.desc["sw_solver"], "gas_model": "RRTMG-IFS" if w.desc["rrtmg"] else "ecCKD",
                       "aerosols": bool(w.config.use_aerosols), "clouds": not w.clear_sky},
            "roofline": roofline_of(w, stage, elapsed / steps)}
+    if regions > 1:
+        res["timed_regions"] = {"count": regions, "ms_per_step_each": region_ms, "kept": "fastest"}
     if world > 1:
         # every rank times the same K steps between the same two barriers: the slowest rank is `ms_per_step`
         res["ms_per_step_ranks"] = {"min": 1e3 * elapsed_min / steps, "max": 1e3 * elapsed / steps}
@@ -1166,7 +1175,7 @@ def main():
             steps = max(2, min(args.steps, 5 if ncol <= 100000 else 3))
             try:
                 r = measure(name, ncol, steps, 1, rank, local_rank, world, barrier, allreduce_max, do_cpu,
-                            do_host_mode=(name == "tripleclouds_ecckd32" and ncol <= CHUNK_COLUMNS and not args.no_host_mode))
+                            do_host_mode=(name == "tripleclouds_ecckd32" and ncol <= CHUNK_COLUMNS and not args.no_host_mode), regions=2)
             except Exception as e:      # an extra workload must not take the headline line down with it
                 r = {"error": f"{type(e).__name__}: {e}"}
             if "parity" in r and not r["parity"]["ok"]:
