@@ -498,7 +498,8 @@ def roofline_of(w, stage_ms, elapsed_per_step_s):
     single = getattr(config, "i_precision", 0) == 1
     flops = algorithmic_flops_per_column(config, nlev, w.clear_sky)
     vpeak = 2 * FP64_PEAK_TFLOPS if single else FP64_PEAK_TFLOPS
-    packed = w.desc["sw_solver"] in ("Cloudless", "Homogeneous", "McICA", "Tripleclouds")
+    # (ECRAD_HIP_EXACT_SCRATCH=1 in the environment: the handle runs the unpacked instantiations, include/ecrad_hip.h)
+    packed = w.desc["sw_solver"] in ("Cloudless", "Homogeneous", "McICA", "Tripleclouds") and os.environ.get("ECRAD_HIP_EXACT_SCRATCH", "")[:1] != "1"
     # what `kernel_ms` (HIP events around the LW / SW stage of a call) covers besides the dominant kernel named in `kernel`
     if w.desc["sw_solver"] == "SPARTACUS":
         scope = f"stage: optics_dump_kernel + spartacus_layers_kernel + spartacus_{dom}_kernel (`traffic` is the sweep kernel's own)"

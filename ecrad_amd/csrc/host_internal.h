@@ -131,6 +131,10 @@ struct ecrad_hip_handle_s {
   hipEvent_t ev_rrtmg_rec = nullptr, ev_rrtmg_sw = nullptr;    // RRTMG: shortwave bands evaluated on aux_stream next to the longwave solver
   int num_cu = 256;
   int blocks_per_cu = 0;      // 0: as many as the kernel keeps resident (grid_for); ECRAD_HIP_BLOCKS_PER_CU overrides
+  // ECRAD_HIP_EXACT_SCRATCH=1 in the environment of ecrad_hip_create: the shortwave sweep records travel as five whole doubles (40 bytes)
+  // instead of the packed 32 (39 mantissa bits, kernels_common.h: pack5): the instantiations of kernel_ica_sw_exact.hip /
+  // kernel_tc_sw_exact.hip -- every value of the path a binary64 from table to flux
+  bool exact_scratch = false;
   std::string err;
   bool is_setup = false;
   ecrad_config_t cfg{};            // scalar members only are meaningful (pointers are the caller's)

@@ -557,7 +557,7 @@ __global__ __launch_bounds__(kBlock, (FX != 0 && ECRAD_TC_PIPE) ? ECRAD_TC_PIPE_
 #else
     feed.init(prep, ncol_loc, nlev, cloc, L.d + (size_t)(cib * NGP) * (L.rec2 * 2), glane);
 #endif
-    constexpr int K = FX ? ECRAD_TC_BATCH_S : ECRAD_TC_BATCH_S_GENERAL;
+    constexpr int K = (FX && ECRAD_PACK_SW) ? ECRAD_TC_BATCH_S : ECRAD_TC_BATCH_S_GENERAL;      // (unpacked records, kernel_tc_sw_exact.hip: two)
     for (int l0 = 0; l0 < ((ECRAD_ABLATE & 4) ? 0 : nlev); l0 += K) {
       // records of K layers requested together
 #if ECRAD_PACK_SW
@@ -1272,6 +1272,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_TC_MIN_WAVES)) voi
   }
 }
 
+#ifndef ECRAD_TC_TU_EXACT      // (kernel_tc_sw_exact.hip holds the shortwave instantiations only)
 size_t lw_tc_scratch_doubles(int nlev, bool aerosol_scattering) {
   return (size_t)(aerosol_scattering ? LW_TC_PLANES_ASCAT : LW_TC_PLANES) * nlev * kBlock;
 }
@@ -1291,5 +1292,7 @@ hipError_t launch_lw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream
 #undef ECRAD_L2
   return hipGetLastError();
 }
+
+#endif      // ECRAD_TC_TU_EXACT
 
 }  // namespace ecrad

@@ -36,6 +36,16 @@ hipError_t launch_lw_scat(int mode, int ngp, bool table_f32, int grid, size_t ld
 hipError_t launch_sw_tc(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
                         const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block, int* counter,
                         const DevCkdModel& m, int g0);
+// the same two shortwave launchers with UNPACKED sweep records (kernel_ica_sw_exact.hip, kernel_tc_sw_exact.hip: ECRAD_PACK_SW = 0),
+// chosen per handle by ECRAD_HIP_EXACT_SCRATCH (host_internal.h: exact_scratch)
+size_t sw_ica_scratch_doubles_exact(int mode, int nlev);
+size_t sw_tc_scratch_doubles_exact(int nlev);
+hipError_t launch_sw_ica_exact(int mode, int ngp, bool table_f32, int grid, size_t lds, hipStream_t st,
+                               const DevConfig& cfg, const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep,
+                               double* scratch, size_t per_block, int* counter, const DevCkdModel& m, int g0, bool wide);
+hipError_t launch_sw_tc_exact(int ngp, bool table_f32, int grid, size_t lds, hipStream_t st, const DevConfig& cfg,
+                              const DevInputs& in, const DevFlux& fx, const DevCloudPrep& prep, double* scratch, size_t per_block, int* counter,
+                              const DevCkdModel& m, int g0);
 // dst(col, l) = sum over chunks of partial profiles (chunk order), columns istartcol..iendcol
 hipError_t launch_spectral_profile_sum(hipStream_t st, const DevInputs& in, const double* per_g, double* dst, int ng, int nspec,
                                        const int32_t* ispec);

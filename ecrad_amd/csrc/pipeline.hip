@@ -531,7 +531,8 @@ int tile_compute(ecrad_hip_handle_t h, Tile& T) {
   const int grid_lw = !c.do_lw ? 0 : lw_sp ? grid_sp(h->ngp_lw, false) : grid_for(h, r.nloc, h->ngp_lw, three_lw);
   const size_t sp_word = sp_single ? 4 : 8;
   const size_t per_block_sw = !c.do_sw ? 0 : sw_sp ? (spartacus_scratch_words(true, nlev) * sp_word + 7) / 8
-                                           : (sw_tc ? sw_tc_scratch_doubles(nlev) : sw_ica_scratch_doubles(c.i_solver_sw, nlev));
+                                           : (sw_tc ? (h->exact_scratch ? sw_tc_scratch_doubles_exact(nlev) : sw_tc_scratch_doubles(nlev))
+                                                    : (h->exact_scratch ? sw_ica_scratch_doubles_exact(c.i_solver_sw, nlev) : sw_ica_scratch_doubles(c.i_solver_sw, nlev)));
   const size_t per_block_lw = !c.do_lw ? 0 : lw_sp ? (spartacus_scratch_words(false, nlev) * sp_word + 7) / 8 : (lw_tc ? lw_tc_scratch_doubles(nlev, lw_scat) : lw_scat ? lw_scat_scratch_doubles(nlev) : lw_ica_scratch_doubles(c.i_solver_lw, nlev));
   const size_t need_sw = per_block_sw * grid_sw * 8, need_lw = (per_block_lw * grid_lw * 8 + 255) / 256 * 256;
   // both spectra at once when together they do not fill the GPU (each with its own sweep scratch then)
@@ -786,8 +787,8 @@ int tile_compute(ecrad_hip_handle_t h, Tile& T) {
     if (sw_sp) {
       if ((st = run_spartacus(true))) return st;
     } else if (h->nchunk_sw == 1) {
-      if (sw_tc) HIP_TRY(h, launch_sw_tc(h->ngp_sw, m.table_f32, grid_sw, lds, sw_stream, h->hcfg, din, dfx, prep, scratch_sw, per_block_sw, counters + 16, m, 0));
-      else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, sw_stream, h->hcfg, din, dfx, prep, scratch_sw, per_block_sw, counters + 16, m, 0, false));
+      if (sw_tc) HIP_TRY(h, (h->exact_scratch ? launch_sw_tc_exact : launch_sw_tc)(h->ngp_sw, m.table_f32, grid_sw, lds, sw_stream, h->hcfg, din, dfx, prep, scratch_sw, per_block_sw, counters + 16, m, 0));
+      else HIP_TRY(h, (h->exact_scratch ? launch_sw_ica_exact : launch_sw_ica)(c.i_solver_sw, h->ngp_sw, m.table_f32, grid_sw, lds, sw_stream, h->hcfg, din, dfx, prep, scratch_sw, per_block_sw, counters + 16, m, 0, false));
     } else {
       // More than 64 g-points: one launch per chunk of `ngp_sw` g-points.  The sums over g of a launch
       // are partial, so its broadband profiles go to per-chunk buffers (same indexing as the real
@@ -803,8 +804,8 @@ int tile_compute(ecrad_hip_handle_t h, Tile& T) {
         for (int k = 0; k < 6; ++k)
           if (dfx.*(prof[k])) dpart.*(prof[k]) = pbase + plane * ((size_t)k * nch + p);
         const int ngp = h->plan_sw.ngp[p], g0 = h->plan_sw.g0[p], grid = grid_for(h, r.nloc, ngp, three_sw);
-        if (sw_tc) HIP_TRY(h, launch_sw_tc(ngp, m.table_f32, grid, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, g0));
-        else HIP_TRY(h, launch_sw_ica(c.i_solver_sw, ngp, m.table_f32, grid, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, g0, true));
+        if (sw_tc) HIP_TRY(h, (h->exact_scratch ? launch_sw_tc_exact : launch_sw_tc)(ngp, m.table_f32, grid, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, g0));
+        else HIP_TRY(h, (h->exact_scratch ? launch_sw_ica_exact : launch_sw_ica)(c.i_solver_sw, ngp, m.table_f32, grid, lds, stream, h->hcfg, din, dpart, prep, scratch, per_block_sw, counters + 16 + p, m, g0, true));
       }
       for (int k = 0; k < 6; ++k)
         if (dfx.*(prof[k])) HIP_TRY(h, launch_combine_partials(stream, din, dfx.*(prof[k]), pbase + plane * (size_t)k * nch, plane, nch));

@@ -107,6 +107,7 @@ int new_context(ecrad_hip_handle_t root, int device, int slot, ecrad_hip_handle_
   c->device = device;
   c->slot = slot;
   c->blocks_per_cu = root->blocks_per_cu;
+  c->exact_scratch = root->exact_scratch;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(root, ECRAD_EHIP, "cannot create a stream for a pool context"); }
@@ -236,6 +237,7 @@ int ecrad_hip_create(ecrad_hip_handle_t* handle, int device_id) {
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) h->num_cu = prop.multiProcessorCount;
   if (const char* e = std::getenv("ECRAD_HIP_BLOCKS_PER_CU")) { int v = std::atoi(e); if (v >= 1 && v <= 32) h->blocks_per_cu = v; }
   if (const char* e = std::getenv("ECRAD_HIP_WORK_GIB")) { const double v = std::atof(e); if (v > 0.0) h->work_budget = (size_t)(v * 1073741824.0); }
+  if (const char* e = std::getenv("ECRAD_HIP_EXACT_SCRATCH")) h->exact_scratch = e[0] == '1';
   // the pool: ECRAD_HIP_DEVICES = a count or "all" (default: the one device of this handle), ECRAD_HIP_CONTEXTS = contexts per device
   if (const char* e = std::getenv("ECRAD_HIP_DEVICES")) h->want_devices = (e[0] == 'a' || e[0] == 'A') ? 0 : std::max(1, std::atoi(e));
   if (const char* e = std::getenv("ECRAD_HIP_CONTEXTS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) h->want_contexts = v; }

@@ -362,7 +362,11 @@ typedef struct ecrad_optics {
 
 typedef struct ecrad_hip_handle_s* ecrad_hip_handle_t;
 
-/* Create a context bound to HIP device `device_id` (-1 = current device). */
+/* Create a context bound to HIP device `device_id` (-1 = current device).
+   Environment read here, per handle: ECRAD_HIP_EXACT_SCRATCH=1 -- the shortwave kernels of the cloudless / homogeneous / McICA /
+   Tripleclouds solvers keep their block-private sweep records as five whole doubles instead of 39-bit mantissas packed into 32 bytes
+   (the one place where the default path rounds an intermediate below binary64; results agree to 1e-10, the exact form moves a quarter
+   more scratch bytes); ECRAD_HIP_WORK_GIB, ECRAD_HIP_DEVICES, ECRAD_HIP_CONTEXTS -- see ecrad_hip_set_work_bytes / _set_concurrency. */
 int ecrad_hip_create(ecrad_hip_handle_t* handle, int device_id);
 
 /* Copy every look-up table reachable from `config` to the device (tables whose values are

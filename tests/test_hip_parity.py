@@ -504,6 +504,41 @@ def test_compile_time_configuration_changes_nothing(monkeypatch):
     rad.close()
 
 
+def test_exact_scratch_option(monkeypatch, oracle_lib):
+    """ECRAD_HIP_EXACT_SCRATCH=1 in the environment of ecrad_hip_create: the handle launches the shortwave instantiations whose sweep
+    records are five whole doubles (kernel_ica_sw_exact.hip, kernel_tc_sw_exact.hip) instead of the packed 32 bytes -- every value
+    of the path a binary64.  Same library, chosen per handle: the two handles agree to 1e-10 (what packing costs, as
+    test_packed_sweep_records_change_nothing_that_matters finds for the build without packing), differ somewhere in the shortwave,
+    are identical in the longwave, and the exact one meets the oracle like the shipped one."""
+    from ecrad_amd.interface import Radiation
+    from ecrad_amd.types import Flux
+    for solver in ("Homogeneous", "Tripleclouds", "McICA"):
+        out = []
+        for exact in (False, True):
+            if exact:
+                monkeypatch.setenv("ECRAD_HIP_EXACT_SCRATCH", "1")
+            else:
+                monkeypatch.delenv("ECRAD_HIP_EXACT_SCRATCH", raising=False)
+            config = make_config(solver)
+            rad = Radiation(config, backend="hip")
+            ncol, nlev, sl, th, gas, cloud, aer = load_meridian(config)
+            rad.set_gas_units(gas)
+            th.calc_saturation_wrt_liquid()
+            flux = Flux.allocate(config, ncol, nlev)
+            rad.radiation(ncol, nlev, 1, ncol, sl, th, gas, cloud, aer, flux)
+            rad.close()
+            out.append(flux)
+        monkeypatch.delenv("ECRAD_HIP_EXACT_SCRATCH", raising=False)
+        worst = compare_flux(out[0], out[1], 1e-10)
+        changed = max(float(np.max(np.abs(out[0].arrays[n] - out[1].arrays[n]))) for n in ("sw_up", "sw_dn"))
+        assert changed > 0.0, "the two handles gave the same bits: ECRAD_HIP_EXACT_SCRATCH did not select the unpacked kernels"
+        for n in ("lw_up", "lw_dn"):
+            assert np.array_equal(out[0].arrays[n], out[1].arrays[n]), n
+        f_ora, _, _ = run_case(make_config(solver), oracle_lib.backend)
+        compare_flux(out[1], f_ora, TOL)
+        print(solver, "exact against packed sweep records:", max(worst.values()))
+
+
 def test_switched_off_forms_of_round_4_still_give_the_same_fluxes():
     """Round 4 built several restructurings that were measured and left OFF (profiles/r04_variants.log): one upward sweep W for the
     McICA longwave instead of B1 / V / derivative sweeps (ECRAD_LW_MERGED), four sums over g per butterfly in the clear-sky longwave
