@@ -1385,8 +1385,9 @@ int batch_lead(ecrad_hip_handle_t root, SmallBatch& B, SmallCall& mine) {
     ms_scatter = ms_since(t_phase);
   }
   if (trace)
-    std::fprintf(stderr, "ecrad_hip batch: %d calls %d columns on device %d: layout %.3f gather %.3f device %.3f scatter %.3f ms\n",
-                 (int)B.calls.size(), B.ntot, h->device, ms_layout, ms_gather, ms_device, ms_scatter);
+    std::fprintf(stderr, "ecrad_hip batch: %d calls %d columns on device %d: layout %.3f gather %.3f device %.3f (kernels: prep %.3f lw %.3f sw %.3f post %.3f; %.1f MB in, %.1f MB out) scatter %.3f ms\n",
+                 (int)B.calls.size(), B.ntot, h->device, ms_layout, ms_gather, ms_device, B.record.stage_ms[0], B.record.stage_ms[1], B.record.stage_ms[2],
+                 B.record.stage_ms[3], T.cx.si.bytes / 1.0e6, (T.out_bytes + frac_bytes) / 1.0e6, ms_scatter);
   (void)hipSetDevice(root->device);
   return st;
 }
