@@ -135,6 +135,10 @@ struct ecrad_hip_handle_s {
   // instead of the packed 32 (39 mantissa bits, kernels_common.h: pack5): the instantiations of kernel_ica_sw_exact.hip /
   // kernel_tc_sw_exact.hip -- every value of the path a binary64 from table to flux
   bool exact_scratch = false;
+  // set while a pipelined host-memory call runs its column tiles (copies and kernels of three tiles in flight on the context's
+  // streams): the tiles' spectra stay one after the other there (pipeline.hip: spectra_overlap -- side by side they cost the
+  // pipeline its overlap: 67 -> 98 ms per 100 000 Tripleclouds columns, gpurun_out/r05_zu)
+  bool tiles_in_flight = false;
   std::string err;
   bool is_setup = false;
   ecrad_config_t cfg{};            // scalar members only are meaningful (pointers are the caller's)

@@ -535,9 +535,20 @@ int tile_compute(ecrad_hip_handle_t h, Tile& T) {
                                                     : (h->exact_scratch ? sw_ica_scratch_doubles_exact(c.i_solver_sw, nlev) : sw_ica_scratch_doubles(c.i_solver_sw, nlev)));
   const size_t per_block_lw = !c.do_lw ? 0 : lw_sp ? (spartacus_scratch_words(false, nlev) * sp_word + 7) / 8 : (lw_tc ? lw_tc_scratch_doubles(nlev, lw_scat) : lw_scat ? lw_scat_scratch_doubles(nlev) : lw_ica_scratch_doubles(c.i_solver_lw, nlev));
   const size_t need_sw = per_block_sw * grid_sw * 8, need_lw = (per_block_lw * grid_lw * 8 + 255) / 256 * 256;
-  // both spectra at once when together they do not fill the GPU (each with its own sweep scratch then)
+  // Both spectra at once, each on its stream with its own sweep scratch: (1) when together they do not fill the GPU (<= 2048 columns at 32
+  // lanes; round 2: at 4096 columns side by side was 6 % slower, profiles/r02_zo_spectra_overlap.log -- still so for the cloudy solvers);
+  // (2) round 5 (gpurun_out/r05_zr..zt, profiles/NOTES_r05.md section 13): the persistent grid of the second kernel moves into the
+  // slots the first one's blocks leave as its column queue runs dry -- the clear-sky solvers gain at every size (5.5 % at 4 096 columns,
+  // 1-4 % from 8 192 to 100 000), Tripleclouds 13 / 5 / 3.5 % at 8 192 / 16 384 / 32 768 columns and nothing at 100 000, McICA 9 / 1.5 /
+  // 0.5 % and LOSES 2 % at 100 000 (its generators share the streams).  ECRAD_NO_SPECTRA_OVERLAP / ECRAD_FORCE_SPECTRA_OVERLAP: A/B switches.
+  // So: calls of 8 192 (clear-sky solvers: 4 096) to 65 536 (McICA: 32 768) columns -- not the column tiles of a pipelined host-memory
+  // call, whose copies and kernels already share the context's streams (host_internal.h: tiles_in_flight).  Above that
+  // the spectra stay one after the other -- also because the events that bracket the stages (ecrad_hip_last_stage_ms, bench.py's
+  // roofline) then time each kernel on its own.
+  const bool clear_solvers = !sw_mcica && !lw_mcica && !sw_tc && !lw_tc;
+  const bool mid_size = !h->tiles_in_flight && r.nloc >= (clear_solvers ? 4096 : 8192) && r.nloc <= ((sw_mcica || lw_mcica) ? 32768 : 65536);
   const bool spectra_overlap = c.do_sw && c.do_lw && !sw_sp && !lw_sp && h->nchunk_sw == 1 && h->nchunk_lw == 1 &&
-                               grid_sw + grid_lw <= 2 * h->num_cu && !getenv("ECRAD_NO_SPECTRA_OVERLAP");      // (<= 2048 columns at 32 lanes: beyond, 4096 columns were 6 % slower side by side, profiles/r02_zo_spectra_overlap.log)
+                               (grid_sw + grid_lw <= 2 * h->num_cu || mid_size || getenv("ECRAD_FORCE_SPECTRA_OVERLAP")) && !getenv("ECRAD_NO_SPECTRA_OVERLAP");
   HIP_TRY(h, h->scratch.ensure(spectra_overlap ? need_sw + need_lw : (need_sw > need_lw ? need_sw : need_lw)));
   HIP_TRY(h, h->counters.ensure(512));
   {   // per-chunk partial profiles of spectra wider than 64 g-points (6 profiles x chunks, reused by LW then SW)
@@ -1511,8 +1522,10 @@ int radiation_on(ecrad_hip_handle_t h, int ncol, int nlev, int istartcol, int ie
     // (both set tiles_last_call: their tiles ramp up and down in size)
     const char* const pe = std::getenv("ECRAD_HIP_PIPELINE");
     const bool mirrored = pe && std::strcmp(pe, "mirrored") == 0;
+    h->tiles_in_flight = true;
     st = mirrored ? radiation_host_mirrored(h, ncol, nlev, istartcol, iendcol, in, flux, tile_cols) : ECRAD_ENOMEM;
     if (st == ECRAD_ENOMEM) st = radiation_host_pipelined(h, ncol, nlev, istartcol, iendcol, in, flux, tile_cols);      // (the default; and when no page-locked memory is to be had)
+    h->tiles_in_flight = false;
   } else {
     Tile T;
     for (int t = 0; t < ntile && !st; ++t) {

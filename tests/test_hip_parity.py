@@ -504,6 +504,49 @@ def test_compile_time_configuration_changes_nothing(monkeypatch):
     rad.close()
 
 
+@pytest.mark.parametrize("solver", ["Homogeneous", "Tripleclouds", "McICA"])
+def test_spectra_side_by_side_change_no_bit(solver, monkeypatch):
+    """Calls of 8 192 (clear-sky solvers: 4 096) to 65 536 columns run the longwave and the shortwave kernels on two streams, the second
+    kernel's blocks moving in as the first one's column queue runs dry (pipeline.hip: spectra_overlap; round 5).  ECRAD_NO_SPECTRA_OVERLAP
+    in the environment of a call keeps them one after the other: the same bits in every output, on 16 384 synthetic columns in
+    device memory and through host arrays (whose pipelined column tiles keep the spectra one after the other either way)."""
+    import ctypes as C
+    import torch
+    from ecrad_amd.device import DeviceCase
+    from ecrad_amd.interface import Radiation
+    from ecrad_amd.synthetic import make_columns
+    from ecrad_amd.types import Flux
+    config = make_config(solver)
+    rad = Radiation(config, backend="hip")
+    inputs = make_columns(config, 16384, solver == "Homogeneous")
+    n, nlev, sl, th, gas, cloud, aer = inputs
+    out = []
+    for serial in (False, True):
+        if serial:
+            monkeypatch.setenv("ECRAD_NO_SPECTRA_OVERLAP", "1")
+        else:
+            monkeypatch.delenv("ECRAD_NO_SPECTRA_OVERLAP", raising=False)
+        flux = Flux.allocate(config, n, nlev)
+        case = DeviceCase(config, n, nlev, sl, th, gas, cloud, aer, flux)
+        assert rad.lib.ecrad_hip_radiation(rad.handle, n, nlev, 1, n, C.byref(case.inputs), C.byref(case.flux)) == 0
+        rad.lib.ecrad_hip_synchronize(rad.handle)
+        torch.cuda.synchronize()
+        dev = {k: t.cpu().numpy().copy() for k, t in case.flux_tensors.items()}
+        if cloud is not None:
+            frac0 = cloud.fraction.copy()
+        host = Flux.allocate(config, n, nlev)
+        rad.radiation(n, nlev, 1, n, sl, th, gas, cloud, aer, host)
+        if cloud is not None:
+            cloud.fraction[...] = frac0
+        out.append((dev, host))
+    for k, a in out[0][0].items():
+        assert np.array_equal(a, out[1][0][k], equal_nan=True), ("device memory", k)
+    for k, a in out[0][1].arrays.items():
+        assert np.array_equal(a, out[1][1].arrays[k], equal_nan=True), ("host memory", k)
+    assert np.isfinite(out[0][1].arrays["lw_up"]).all() and np.isfinite(out[0][1].arrays["sw_up"]).all()
+    rad.close()
+
+
 def test_exact_scratch_option(monkeypatch, oracle_lib):
     """ECRAD_HIP_EXACT_SCRATCH=1 in the environment of ecrad_hip_create: the handle launches the shortwave instantiations whose sweep
     records are five whole doubles (kernel_ica_sw_exact.hip, kernel_tc_sw_exact.hip) instead of the packed 32 bytes -- every value
