@@ -535,8 +535,8 @@ int tile_compute(ecrad_hip_handle_t h, Tile& T) {
                                                     : (h->exact_scratch ? sw_ica_scratch_doubles_exact(c.i_solver_sw, nlev) : sw_ica_scratch_doubles(c.i_solver_sw, nlev)));
   const size_t per_block_lw = !c.do_lw ? 0 : lw_sp ? (spartacus_scratch_words(false, nlev) * sp_word + 7) / 8 : (lw_tc ? lw_tc_scratch_doubles(nlev, lw_scat) : lw_scat ? lw_scat_scratch_doubles(nlev) : lw_ica_scratch_doubles(c.i_solver_lw, nlev));
   const size_t need_sw = per_block_sw * grid_sw * 8, need_lw = (per_block_lw * grid_lw * 8 + 255) / 256 * 256;
-  // Both spectra at once, each on its stream with its own sweep scratch: (1) when together they do not fill the GPU (<= 2048 columns at 32
-  // lanes; round 2: at 4096 columns side by side was 6 % slower, profiles/r02_zo_spectra_overlap.log -- still so for the cloudy solvers);
+  // Both spectra at once, each on its stream with its own sweep scratch: (1) when together they do not fill the GPU (round 2: at 4096
+  // columns side by side was 6 % slower, profiles/r02_zo_spectra_overlap.log -- still so for the cloudy solvers);
   // (2) round 5 (gpurun_out/r05_zr..zt, profiles/NOTES_r05.md section 13): the persistent grid of the second kernel moves into the
   // slots the first one's blocks leave as its column queue runs dry -- the clear-sky solvers gain at every size (5.5 % at 4 096 columns,
   // 1-4 % from 8 192 to 100 000), Tripleclouds 13 / 5 / 3.5 % at 8 192 / 16 384 / 32 768 columns and nothing at 100 000, McICA 9 / 1.5 /
@@ -545,10 +545,14 @@ int tile_compute(ecrad_hip_handle_t h, Tile& T) {
   // call, whose copies and kernels already share the context's streams (host_internal.h: tiles_in_flight).  Above that
   // the spectra stay one after the other -- also because the events that bracket the stages (ecrad_hip_last_stage_ms, bench.py's
   // roofline) then time each kernel on its own.
+  // (1) re-measured in round 5 as well (r05_zv): together within what the GPU keeps RESIDENT (three blocks per CU for the kernels at three
+  // waves per SIMD: 3 072 columns at 32 lanes, until then 2 048) -- Tripleclouds 1.93 -> 1.34 ms at 2 560 columns, 1.96 -> 1.42 at 3 072,
+  // unchanged at 3 584, slower at 4 096; clear-sky 0.63 -> 0.51, 0.65 -> 0.54, 0.68 -> 0.65.  (The batches of small host-memory calls are such calls.)
+  const int resident_blocks = h->num_cu * ((three_sw && three_lw) ? 3 : 2);
   const bool clear_solvers = !sw_mcica && !lw_mcica && !sw_tc && !lw_tc;
   const bool mid_size = !h->tiles_in_flight && r.nloc >= (clear_solvers ? 4096 : 8192) && r.nloc <= ((sw_mcica || lw_mcica) ? 32768 : 65536);
   const bool spectra_overlap = c.do_sw && c.do_lw && !sw_sp && !lw_sp && h->nchunk_sw == 1 && h->nchunk_lw == 1 &&
-                               (grid_sw + grid_lw <= 2 * h->num_cu || mid_size || getenv("ECRAD_FORCE_SPECTRA_OVERLAP")) && !getenv("ECRAD_NO_SPECTRA_OVERLAP");
+                               (grid_sw + grid_lw <= resident_blocks || mid_size || getenv("ECRAD_FORCE_SPECTRA_OVERLAP")) && !getenv("ECRAD_NO_SPECTRA_OVERLAP");
   HIP_TRY(h, h->scratch.ensure(spectra_overlap ? need_sw + need_lw : (need_sw > need_lw ? need_sw : need_lw)));
   HIP_TRY(h, h->counters.ensure(512));
   {   // per-chunk partial profiles of spectra wider than 64 g-points (6 profiles x chunks, reused by LW then SW)
