@@ -1317,7 +1317,7 @@ int batch_lead(ecrad_hip_handle_t root, SmallBatch& B, SmallCall& mine) {
   static const bool trace = std::getenv("ECRAD_HIP_BATCH_TRACE") != nullptr;
   const auto t_start = std::chrono::steady_clock::now();
   auto ms_since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
-  double ms_layout = 0, ms_gather = 0, ms_device = 0, ms_scatter = 0;
+  double ms_layout = 0, ms_gather = 0, ms_device = 0, ms_scatter = 0, ms_enqueue = 0;
   h->err.clear();
   if (hipSetDevice(h->device) != hipSuccess) st = fail(h, ECRAD_EHIP, "hipSetDevice");
   if (!st && !h->is_setup) st = fail(h, ECRAD_ENOTSETUP, "ecrad_hip_setup has not been called");
@@ -1361,8 +1361,11 @@ int batch_lead(ecrad_hip_handle_t root, SmallBatch& B, SmallCall& mine) {
   t_phase = std::chrono::steady_clock::now();
   if (!st) {
     hipStream_t stream = h->stream;
+    hipEvent_t tev[4] = {nullptr, nullptr, nullptr, nullptr};      // (trace only: copy-in / kernels / copy-out of the batch on its stream)
+    if (trace) for (auto& e : tev) (void)hipEventCreate(&e);
     auto run = [&]() -> int {
       // Entries that a solver never writes for a processed column are undefined in the reference; here they are zero.
+      if (trace) (void)hipEventRecord(tev[0], stream);
       HIP_TRY(h, hipMemsetAsync(h->staging_out[T.slot].p, 0, T.out_bytes, stream));
       HIP_TRY(h, hipMemcpyAsync(h->staging_in[T.slot].p, B.pin_in, T.cx.si.bytes, hipMemcpyHostToDevice, stream));
       size_t off = B.cover_off;
@@ -1371,14 +1374,25 @@ int batch_lead(ecrad_hip_handle_t root, SmallBatch& B, SmallCall& mine) {
           HIP_TRY(h, hipMemcpyAsync(sp.second, B.pin_in + off, (size_t)B.ntot * 8, hipMemcpyHostToDevice, stream));
           off += (size_t)B.ntot * 8;
         }
+      if (trace) (void)hipEventRecord(tev[1], stream);
       const int e = tile_compute(h, T);
       if (e) return e;
+      if (trace) (void)hipEventRecord(tev[2], stream);
       if (T.out_bytes) HIP_TRY(h, hipMemcpyAsync(B.pin_out, h->staging_out[T.slot].p, T.out_bytes, hipMemcpyDeviceToHost, stream));
       if (frac_bytes) HIP_TRY(h, hipMemcpyAsync(B.pin_out + B.frac_off, T.cx.si.cloud_fraction, frac_bytes, hipMemcpyDeviceToHost, stream));
+      if (trace) (void)hipEventRecord(tev[3], stream);
+      ms_enqueue = ms_since(t_phase);
       HIP_TRY(h, hipStreamSynchronize(stream));
       return ECRAD_OK;
     };
     st = run();
+    float ms_h2d = 0, ms_kern = 0, ms_d2h = 0;
+    if (trace) {
+      if (!st) { (void)hipEventElapsedTime(&ms_h2d, tev[0], tev[1]); (void)hipEventElapsedTime(&ms_kern, tev[1], tev[2]); (void)hipEventElapsedTime(&ms_d2h, tev[2], tev[3]); }
+      for (auto& e : tev) (void)hipEventDestroy(e);
+      std::fprintf(stderr, "ecrad_hip batch stream: copy-in %.3f kernels %.3f copy-out %.3f ms; host: everything enqueued after %.3f, waited until %.3f ms\n", ms_h2d, ms_kern, ms_d2h,
+                   ms_enqueue, ms_since(t_phase));
+    }
     if (st && h->aux_stream) (void)hipStreamSynchronize(h->aux_stream);
     if (!st) { h->tiles_last_call = 1; h->timing_pending = true; }
     B.record = take_record(root, h, true);      // (the stream has been waited for: the stage events are complete)
