@@ -1382,7 +1382,7 @@ int batch_lead(ecrad_hip_handle_t root, SmallBatch& B, SmallCall& mine) {
       if (frac_bytes) HIP_TRY(h, hipMemcpyAsync(B.pin_out + B.frac_off, T.cx.si.cloud_fraction, frac_bytes, hipMemcpyDeviceToHost, stream));
       if (trace) (void)hipEventRecord(tev[3], stream);
       ms_enqueue = ms_since(t_phase);
-      HIP_TRY(h, hipStreamSynchronize(stream));
+      HIP_TRY(h, hipStreamSynchronize(stream));      // (polling the stream instead of sleeping on it: no faster, gpurun_out/r05_zw)
       return ECRAD_OK;
     };
     st = run();
