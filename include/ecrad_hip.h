@@ -459,7 +459,8 @@ int ecrad_hip_last_kernel_ms(ecrad_hip_handle_t handle, double* ms);
 #define ECRAD_STAGE_LW   1   /* fused longwave kernel  (gas optics ... solver) */
 #define ECRAD_STAGE_SW   2   /* fused shortwave kernel (gas optics ... solver) */
 #define ECRAD_STAGE_POST 3   /* surface/TOA spectral sums */
-/* (Calls of at most 2048 columns run the two spectra side by side on two streams: the events are on the handle's stream,
+/* (Calls of at most 3072 columns, and device-memory calls of 8192 (clear-sky solvers: 4096) to 65536 (McICA: 32768) columns,
+   run the two spectra side by side on two streams: the events are on the handle's stream,
    so ECRAD_STAGE_LW then covers the longwave stage and ECRAD_STAGE_SW only what was left of the shortwave one when the
    longwave one had finished -- read their SUM for such calls.) */
 int ecrad_hip_last_stage_ms(ecrad_hip_handle_t handle, int which, double* ms);
