@@ -374,6 +374,17 @@ __global__ __launch_bounds__(kTauBlock, ECRAD_TAUMOL_MIN_WAVES) void rrtmg_taumo
 #pragma unroll
         for (int k = 0; k < G; ++k) { pb.v[k] = pl_bot * pfrac.v[k]; ptop.v[k] = pl_top * pfrac.v[k]; ps.v[k] = pl_surf * pfrac.v[k]; }
         const int nk = ng - ig < G ? ng - ig : G;
+#if ECRAD_ABLATE & 64      // (tuning only, wrong results) the block's values at consecutive addresses in item order: what the stores cost when every wave writes whole lines
+        {
+          const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+          size_t reg = blk * (size_t)(kNgLw * kTileCols);
+          if (reg + (size_t)kNgLw * kTileCols > (size_t)kNgLw * nlev * nloc) reg = 0;
+          const size_t at = reg + ((size_t)(B.g0 / G) * kTileCols + i) * G;
+          vstore<G>(out.od_lw + at, od, nk);
+          vstore<G>(out.planck_hl + at, pb, nk);
+          continue;
+        }
+#endif
         pstore<G>(out.od_lw + oo, g, pos, od, nk);
         pstore<G>(out.planck_hl + op + kNgLw, g, pos, pb, nk);
         if (lev == 0) pstore<G>(out.planck_hl + op, g, pos, ptop, nk);
@@ -455,6 +466,18 @@ __global__ __launch_bounds__(kTauBlock, ECRAD_TAUMOL_MIN_WAVES) void rrtmg_taumo
           vod = vsplat<G>(dmax(T.min_gas_od_sw, 0.0));
           vssa = vsplat<G>(0.0);
         }
+#if ECRAD_ABLATE & 64
+        {
+          const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+          size_t reg = blk * (size_t)(kNgSw * kTileCols);
+          if (reg + (size_t)kNgSw * kTileCols > (size_t)kNgSw * nlev * nloc) reg = 0;
+          const size_t at = reg + ((size_t)(B.g0 / G) * kTileCols + i) * G;
+          vstore<G>(out.od_sw + at, vod, nk);
+          vstore<G>(out.ssa_sw + at, vssa, nk);
+          if (fold_sw) vstore<G>(out.g_sw + at, vg, nk);
+          continue;
+        }
+#endif
         pstore<G>(out.od_sw + o, g, pos, vod, nk);
         pstore<G>(out.ssa_sw + o, g, pos, vssa, nk);
         if (fold_sw) pstore<G>(out.g_sw + o, g, pos, vg, nk);
