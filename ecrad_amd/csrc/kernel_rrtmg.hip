@@ -376,7 +376,7 @@ __global__ __launch_bounds__(kTauBlock, ECRAD_TAUMOL_MIN_WAVES) void rrtmg_taumo
         const int nk = ng - ig < G ? ng - ig : G;
 #if ECRAD_ABLATE & 64      // (tuning only, wrong results) the block's values at consecutive addresses in item order: what the stores cost when every wave writes whole lines
         {
-          const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+          const size_t blk = (ECRAD_ABLATE & 128) ? (size_t)(blockIdx.x & 7) : (size_t)blockIdx.y * gridDim.x + blockIdx.x;      // (& 128: every block into the same eight regions, which stay in the L2 -- what the stores cost without their HBM traffic)
           size_t reg = blk * (size_t)(kNgLw * kTileCols);
           if (reg + (size_t)kNgLw * kTileCols > (size_t)kNgLw * nlev * nloc) reg = 0;
           const size_t at = reg + ((size_t)(B.g0 / G) * kTileCols + i) * G;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(kTauBlock, ECRAD_TAUMOL_MIN_WAVES) void rrtmg_taumo
         }
 #if ECRAD_ABLATE & 64
         {
-          const size_t blk = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+          const size_t blk = (ECRAD_ABLATE & 128) ? (size_t)(blockIdx.x & 7) : (size_t)blockIdx.y * gridDim.x + blockIdx.x;      // (& 128: every block into the same eight regions, which stay in the L2 -- what the stores cost without their HBM traffic)
           size_t reg = blk * (size_t)(kNgSw * kTileCols);
           if (reg + (size_t)kNgSw * kTileCols > (size_t)kNgSw * nlev * nloc) reg = 0;
           const size_t at = reg + ((size_t)(B.g0 / G) * kTileCols + i) * G;
