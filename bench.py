@@ -48,6 +48,20 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
+
+def progress(msg):
+    """One line per phase into gpurun_out/bench_progress.log (a FILE: the driver's record is a bounded tail of stdout and stderr):
+    where a run was when something outside Python ended it (a GPU memory fault aborts the process without a traceback)."""
+    try:
+        d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "bench_progress.log"), "a") as f:
+            f.write("%.3f pid %d %s\n" % (time.time(), os.getpid(), msg))
+            f.flush()
+            os.fsync(f.fileno())
+    except OSError:
+        pass
+
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_TRIAD_GBS = None       # measured on THIS box when the first workload is set up (ecrad_hip_hbm_triad: a = b + s c, 3 x 1 GiB)
 FP64_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (SURVEY.md 8(d); MI355X_MICROARCH.md quotes the FP32 vector peak, 157.3 = 2 x this)
@@ -696,7 +710,9 @@ def end_to_end_host(w, gpu_resident_value, repeats=3):
         t += time.perf_counter() - t0
     info = abi.CallInfo()
     w.rad.lib.ecrad_hip_last_call_info(w.rad.handle, C.byref(info))
+    progress("host-memory mode: link rates")
     h2d, d2h, duplex = pcie_bandwidth(w.rad)
+    progress("host-memory mode: registered arrays")
     b_in, b_out = info.staged_in_bytes / ncol, info.staged_out_bytes / ncol
     # The ceiling: both directions at their one-way rates at once, i.e. the call can take no less than its larger transfer.
     # (`both_directions` -- two page-locked copies in opposite directions at once, one host thread each -- came out at the
@@ -900,7 +916,9 @@ def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allredu
     """`regions` > 1 (the extra workloads, five steps each): the K-step region is timed that many times and the fastest kept -- one
     hiccup of the box (35 ms once, seen in round 5) is 7 ms per step of a five-step region.  The headline is timed ONCE, K steps exactly."""
     sample_cols = 16384 if do_cpu else 0
+    progress(f"{name} ncol={ncol}: set-up")
     w = Workload(name, ncol, rank, local_rank, sample_cols)
+    progress(f"{name}: timed steps")
     elapsed_rank = timed_steps(w, steps, warmup, barrier)
     region_ms = [1e3 * elapsed_rank / steps]
     for _ in range(regions - 1):
@@ -936,6 +954,7 @@ def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allredu
             res["gathered"] = {"ranks": len(w.gathered), "shape_per_rank": list(w.gathered[0].shape), "fields": w.profile_names,
                                "bytes_received": int(sum(b.numel() * b.element_size() for b in w.gathered[1:]))}
     if do_cpu and rank == 0:
+        progress(f"{name}: cpu baseline")
         w.step()
         torch.cuda.synchronize()
         res["cpu_baseline"], oracle_flux = with_stdout_on_stderr(cpu_baseline, w.config, w.sample, workload_name=name)
@@ -945,13 +964,17 @@ def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allredu
             inputs_all = w.host_inputs
             if getattr(w.config, "i_precision", 0) != 1:
                 oracle_flux = with_stdout_on_stderr(oracle_flux_of, w.config, inputs_all)
+        progress(f"{name}: parity")
         if getattr(w.config, "i_precision", 0) == 1:
             res["parity"] = with_stdout_on_stderr(check_parity_single, w, inputs_all)
         else:
             res["parity"] = with_stdout_on_stderr(check_parity, w, oracle_flux, inputs_all)
     if do_host_mode and rank == 0 and w.host_inputs is not None:
+        progress(f"{name}: host-memory mode")
         res["end_to_end_host"] = end_to_end_host(w, res["value"] / world)
+    progress(f"{name}: close")
     w.close()
+    progress(f"{name}: done")
     return res
 
 
@@ -1018,7 +1041,7 @@ def compact_line(out, detail_path=None):
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
                                  "scaling", "vs_baseline", "dtype", "data", "config") if k in out}
     for k in ("ms_per_step_ranks", "value_with_gather", "ms_per_step_with_gather", "gathered", "mode", "test_shared_gpu",
-              "test_fake_devices", "blocks_identical_across_devices", "pool"):
+              "test_fake_devices", "blocks_identical_across_devices", "pool", "attempts", "aborted_attempts"):
         if k in out:
             line[k] = out[k]
     if "roofline" in out:
@@ -1081,6 +1104,41 @@ def emit(out):
     print(compact_line(out, rel), flush=True)
 
 
+def supervise():
+    """The single-GPU run as a watched child process.  Once in nine runs of the default command on the round-5 boxes the process was
+    ended from outside Python -- "Memory access fault by GPU node-2 ... Reason: Unknown", SIGABRT from the ROCm runtime, nothing printed,
+    not reproduced by 36 repetitions of the phase it happened in (profiles/NOTES_r05.md section 15) -- and a run that prints nothing is a
+    round without a record.  So the measurement runs in a child; a child ended by SIGABRT / SIGSEGV / SIGBUS is started again (twice at
+    most) and the line of the run that completes says so: `attempts` and, per aborted attempt, the signal and the phase it was in
+    (gpurun_out/bench_progress.log).  Nothing is averaged or carried over between attempts; every number of the line comes from the one
+    run that printed it.  Not under torchrun (WORLD_SIZE > 1): a rank is not restarted behind the back of the others.
+    ECRAD_BENCH_NO_SUPERVISOR=1 runs the measurement in this process."""
+    import signal
+    import subprocess
+    aborted = []
+    for attempt in range(1, 4):
+        env = dict(os.environ, ECRAD_BENCH_WORKER="1", ECRAD_BENCH_ATTEMPT=str(attempt), ECRAD_BENCH_ABORTED=json.dumps(aborted))
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env)
+        try:
+            rc = child.wait()
+        except KeyboardInterrupt:
+            child.kill()
+            raise
+        if rc >= 0 or -rc not in (signal.SIGABRT, signal.SIGSEGV, signal.SIGBUS):
+            sys.exit(rc if rc >= 0 else 128 - rc)
+        last = None
+        try:
+            with open(os.path.join(ROOT, "gpurun_out", "bench_progress.log")) as f:
+                mine = [ln.split(None, 3)[3].strip() for ln in f if ln.split(None, 3)[1:3] == ["pid", str(child.pid)]]
+            last = mine[-1] if mine else None
+        except (OSError, IndexError):
+            pass
+        aborted.append({"attempt": attempt, "signal": -rc, "last_phase": last})
+        print(f"bench.py: attempt {attempt} ended by signal {-rc} in phase {last!r}", file=sys.stderr)
+    print("bench.py: three attempts ended by a signal; no record", file=sys.stderr)
+    sys.exit(134)
+
+
 def main():
     os.environ.setdefault("GFORTRAN_UNBUFFERED_ALL", "1")
     ap = argparse.ArgumentParser()
@@ -1099,6 +1157,21 @@ def main():
                          "library's pool of contexts (host-memory mode, PCIe-inclusive: see pool_mode)")
     ap.add_argument("--block-columns", type=int, default=12500, help="columns per call in --threads-per-process mode")
     args = ap.parse_args()
+    if (args.gpus == 1 and args.threads_per_process == 0 and int(os.environ.get("WORLD_SIZE", "1")) == 1
+            and os.environ.get("ECRAD_BENCH_WORKER") != "1" and os.environ.get("ECRAD_BENCH_NO_SUPERVISOR") != "1"):
+        return supervise()
+    if os.environ.get("ECRAD_BENCH_WORKER") == "1":
+        try:      # (a worker does not outlive the process that watches it)
+            C.CDLL(None).prctl(1, 9)
+        except (OSError, AttributeError):
+            pass
+        # TEST HOOK (tests/test_bench_line.py): the first N attempts end the way a GPU memory fault ends a process
+        if int(os.environ.get("ECRAD_BENCH_ATTEMPT", "1")) <= int(os.environ.get("ECRAD_BENCH_TEST_ABORT_ATTEMPTS", "0")):
+            progress("test hook: abort")
+            os.abort()
+    # (every array of 64 KB or more in pages of its own: the arrays end_to_end_host page-locks must not share pages with heap neighbours)
+    from ecrad_amd.interface import private_pages_for_large_arrays
+    private_pages_for_large_arrays()
     if args.threads_per_process > 0:
         return pool_mode(args)
 
@@ -1188,9 +1261,16 @@ def main():
         out["small_blocks"] = {}
         for name in ("clear_homogeneous_ecckd32", "tripleclouds_ecckd32"):
             try:
+                progress(f"small blocks {name}")
                 out["small_blocks"][name] = small_blocks(name)
             except Exception as e:
                 out["small_blocks"][name] = {"error": f"{type(e).__name__}: {e}"}
+    if os.environ.get("ECRAD_BENCH_WORKER") == "1":
+        out["attempts"] = int(os.environ.get("ECRAD_BENCH_ATTEMPT", "1"))
+        prior = json.loads(os.environ.get("ECRAD_BENCH_ABORTED", "[]"))
+        if prior:
+            out["aborted_attempts"] = prior
+    progress("emit")
     if rank == 0:
         if failed and "parity" in head and not head["parity"]["ok"]:
             out["value"] = None

@@ -29,6 +29,21 @@ class EcradHipError(RuntimeError):
     pass
 
 
+def private_pages_for_large_arrays(threshold: int = 1 << 16) -> bool:
+    """For a Python host that page-locks its arrays with ``ecrad_hip_host_register``: from now on every allocation of `threshold` bytes or
+    more is a mapping of its own (``mallopt(M_MMAP_THRESHOLD)``; glibc's default threshold floats up to 32 MB), i.e. whole pages that no
+    other object shares and that go back to the kernel when the array dies.  A registered range is mapped into the GPU's address space page
+    by page; a numpy array of 64 KB ... 32 MB otherwise sits in the heap between other objects, its first and last page shared with them,
+    and what the allocator does to those neighbours while the range is registered is not ours to see (round 5: a GPU memory fault at a heap
+    address, once in nine default runs of bench.py and once in seven runs of the GPU tests -- the two processes that register heap arrays;
+    profiles/NOTES_r05.md section 15).  A Fortran host's large allocatables are mappings of their own already.  Returns False where there is
+    no glibc mallopt."""
+    try:
+        return C.CDLL(None).mallopt(-3, int(threshold)) == 1      # M_MMAP_THRESHOLD = -3
+    except (OSError, AttributeError):
+        return False
+
+
 def load_library(path: str = LIB_PATH):
     """dlopen libecrad_hip.so and declare its prototypes; raises if it has not been built."""
     if not os.path.exists(path):

@@ -482,7 +482,9 @@ int ecrad_hip_pcie_bandwidth(ecrad_hip_handle_t handle, size_t nbytes, int repea
    the copy engines directly, and the tiles of a pipelined call (8192 columns or more) then move at the link's rate.  Thin
    wrappers over hipHostRegister / hipHostUnregister so that a Fortran host need not link the HIP runtime itself; the range
    must stay allocated until it is unregistered.  ecrad_hip_host_register fails with ECRAD_EHIP (and changes nothing) when
-   the runtime refuses the range. */
+   the runtime refuses the range.  Register allocations that own their pages (a Fortran host's large allocatables are mappings of
+   their own; a Python host calls ecrad_amd.interface.private_pages_for_large_arrays() first): a range is mapped page by page, and a
+   small array in the middle of the heap shares its first and last page with whatever the allocator keeps next to it. */
 int ecrad_hip_host_register(ecrad_hip_handle_t handle, void* p, size_t bytes);
 int ecrad_hip_host_unregister(ecrad_hip_handle_t handle, void* p);
 

@@ -388,7 +388,8 @@ def test_registered_host_arrays_give_the_same_bits():
     """ecrad_hip_host_register (include/ecrad_hip.h): the caller's arrays page-locked once, the pipelined host-memory call then
     moves its tiles by the copy engines directly.  Same bits as the call on pageable arrays; bad arguments are a status, not a
     fault; unregistering gives the memory back."""
-    from ecrad_amd.interface import build_flux_struct, build_inputs_struct
+    from ecrad_amd.interface import build_flux_struct, build_inputs_struct, private_pages_for_large_arrays
+    private_pages_for_large_arrays()      # (the arrays registered below in pages of their own, not between other heap objects)
     ncol = 20000
     config = make_config("Tripleclouds")
     n, nlev, sl, th, gas, cloud, aer = make_columns(config, ncol, False)
