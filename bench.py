@@ -724,14 +724,15 @@ def end_to_end_host(w, gpu_resident_value, repeats=3):
     # runs): the copy engines read and write them directly instead of the runtime staging pageable memory through the calling threads.
     registered = None
     try:
-        from ecrad_amd.interface import build_flux_struct, build_inputs_struct
+        from ecrad_amd.interface import build_flux_struct, build_inputs_struct, owns_its_pages
         if cloud is not None:
             cloud.fraction[...] = frac0
         cin, keep = build_inputs_struct(w.config, ncol, nlev, sl, th, gas, cloud, aer)
         cflux = build_flux_struct(flux)
         arrays, seen = [], set()
         for a in keep + ([cloud.fraction] if cloud is not None else []) + list(flux.arrays.values()):
-            if a is not None and a.ctypes.data not in seen and a.nbytes >= (1 << 16):
+            # (only allocations that own their pages: an array in the heap shares its first and last page with its neighbours)
+            if a is not None and a.ctypes.data not in seen and a.nbytes >= (1 << 16) and owns_its_pages(a):
                 seen.add(a.ctypes.data)
                 arrays.append(a)
         pinned = [a for a in arrays if w.rad.lib.ecrad_hip_host_register(w.rad.handle, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes)) == 0]

@@ -37,11 +37,27 @@ def private_pages_for_large_arrays(threshold: int = 1 << 16) -> bool:
     and what the allocator does to those neighbours while the range is registered is not ours to see (round 5: a GPU memory fault at a heap
     address, once in nine default runs of bench.py and once in seven runs of the GPU tests -- the two processes that register heap arrays;
     profiles/NOTES_r05.md section 15).  A Fortran host's large allocatables are mappings of their own already.  Returns False where there is
-    no glibc mallopt."""
+    no glibc mallopt.  Not a promise -- the allocator still serves a request from a free chunk of the heap when it has one --: check the arrays
+    with ``owns_its_pages`` before registering them."""
     try:
         return C.CDLL(None).mallopt(-3, int(threshold)) == 1      # M_MMAP_THRESHOLD = -3
     except (OSError, AttributeError):
         return False
+
+
+def owns_its_pages(a) -> bool:
+    """True when numpy array `a` is an allocation that glibc mapped on its own (the data 16 bytes into a page, above the heap): the only
+    arrays a Python host should hand to ``ecrad_hip_host_register``.  ``private_pages_for_large_arrays`` makes that the rule for new large
+    arrays but cannot promise it -- a request the heap's free chunks or its top can satisfy is still served from there."""
+    try:
+        libc = C.CDLL(None)
+        libc.sbrk.restype = C.c_void_p
+        libc.sbrk.argtypes = [C.c_ssize_t]
+        brk = libc.sbrk(0) or 0
+    except (OSError, AttributeError):
+        return False
+    addr = a.ctypes.data
+    return addr > brk and (addr & 0xfff) == 0x10
 
 
 def load_library(path: str = LIB_PATH):

@@ -55,3 +55,24 @@ def test_create_without_gpu_fails_loudly(lib):
     from helpers import make_config
     with pytest.raises(EcradHipError):
         Radiation(make_config("Cloudless"), backend="hip")
+
+
+def test_large_arrays_in_pages_of_their_own():
+    """ecrad_amd.interface.private_pages_for_large_arrays / owns_its_pages (what a Python host uses before it page-locks arrays with
+    ecrad_hip_host_register): arrays well above the threshold are mappings of their own -- 16 bytes into a page, above the heap --, a small
+    array never is, and an array the allocator served from the heap's top is recognised as such.  Run in a child: the setting stays for
+    the life of a process."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from ecrad_amd.interface import owns_its_pages, private_pages_for_large_arrays\n"
+            "assert private_pages_for_large_arrays(1 << 16)\n"
+            "big = [np.zeros(n) for n in (1 << 16, 1 << 18, 1 << 20) for _ in range(4)]\n"
+            "small = [np.zeros(n) for n in (16, 128, 1024)]\n"
+            "edge = [np.zeros(1 << 13) for _ in range(4)]\n"
+            "ok = all(owns_its_pages(a) for a in big) and not any(owns_its_pages(a) for a in small)\n"
+            "ok = ok and all(owns_its_pages(a) == ((a.ctypes.data & 0xfff) == 0x10 and a.ctypes.data > 0x700000000000) for a in edge)\n"
+            "print(ok)\n") % ROOT
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip() == "True", (p.stdout, p.stderr[-400:])
