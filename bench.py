@@ -63,6 +63,7 @@ def progress(msg):
         pass
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_READ_GBS = HBM_COPY_GBS = None      # ecrad_hip_hbm_rates: pure read / copy, 16 bytes per lane, four requests in flight (2 x 1 GiB)
 HBM_TRIAD_GBS = None       # measured on THIS box when the first workload is set up (ecrad_hip_hbm_triad: a = b + s c, 3 x 1 GiB)
 FP64_PEAK_TFLOPS = 78.6    # MI355X vector FP64 (MI355X_MICROARCH.md quotes the FP32 vector peak, 157.3 = 2 x this)
 PARITY_TOLERANCE = 1.0e-6  # BASELINE.json north_star: fluxes within 1e-6 relative of the CPU reference
@@ -393,6 +394,11 @@ class Workload:
             if self.rad.lib.ecrad_hip_hbm_triad(self.rad.handle, C.c_size_t(1 << 30), 5, C.byref(gbs)) != 0:
                 raise RuntimeError(self.rad.lib.ecrad_hip_last_error(self.rad.handle).decode())
             HBM_TRIAD_GBS = gbs.value
+            global HBM_READ_GBS, HBM_COPY_GBS
+            rd, cp = C.c_double(), C.c_double()
+            if self.rad.lib.ecrad_hip_hbm_rates(self.rad.handle, C.c_size_t(1 << 30), 5, C.byref(rd), C.byref(cp)) != 0:
+                raise RuntimeError(self.rad.lib.ecrad_hip_last_error(self.rad.handle).decode())
+            HBM_READ_GBS, HBM_COPY_GBS = rd.value, cp.value
         device = f"cuda:{local_rank}"
         # weak scaling: every rank owns `ncol` columns of the global batch; generated and uploaded in chunks
         self.sample, self.host_inputs = None, None
@@ -532,6 +538,7 @@ def roofline_of(w, stage_ms, elapsed_per_step_s):
     binding = max((k for k in fractions if fractions[k] is not None), key=lambda k: fractions[k])
     return {**extra, "bound": "hbm", "binding_roof": binding, "fractions": fractions, "valu": valu, "kernel": kernel, "kernel_ms_scope": scope, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "measured_triad": HBM_TRIAD_GBS, "frac_of_measured_triad": achieved / HBM_TRIAD_GBS,
+            "measured_read": HBM_READ_GBS, "measured_copy": HBM_COPY_GBS, "frac_of_measured_copy": achieved / HBM_COPY_GBS if HBM_COPY_GBS else None,
             # SURVEY 8(d)'s third number: columns/s x estimated flops per column / the vector peak of the working precision
             "fp64_fraction": ncol / elapsed_per_step_s * flops / 1e12 / vpeak,
             "flops_per_column_estimate": flops, "vector_peak_tflops": vpeak,
@@ -720,40 +727,41 @@ def end_to_end_host(w, gpu_resident_value, repeats=3):
     #  reported, not used.)
     ceiling = 1.0e9 / max(b_in / h2d, b_out / d2h)
     value = ncol * repeats / t
-    # The same call on arrays the host has page-locked ONCE with ecrad_hip_host_register (a host model's arrays live as long as it
-    # runs): the copy engines read and write them directly instead of the runtime staging pageable memory through the calling threads.
+    # The same call on arrays the host keeps in page-locked memory (ecrad_hip_host_alloc: a host model's arrays live as long as it runs):
+    # the copy engines read and write them directly instead of the runtime staging pageable memory through the calling threads.
     registered = None
     try:
-        from ecrad_amd.interface import build_flux_struct, build_inputs_struct, owns_its_pages
+        from ecrad_amd.interface import HostArrays, build_flux_struct, build_inputs_struct, relocate_call_arrays
         if cloud is not None:
             cloud.fraction[...] = frac0
-        cin, keep = build_inputs_struct(w.config, ncol, nlev, sl, th, gas, cloud, aer)
-        cflux = build_flux_struct(flux)
-        arrays, seen = [], set()
-        for a in keep + ([cloud.fraction] if cloud is not None else []) + list(flux.arrays.values()):
-            # (only allocations that own their pages: an array in the heap shares its first and last page with its neighbours)
-            if a is not None and a.ctypes.data not in seen and a.nbytes >= (1 << 16) and owns_its_pages(a):
-                seen.add(a.ctypes.data)
-                arrays.append(a)
-        pinned = [a for a in arrays if w.rad.lib.ecrad_hip_host_register(w.rad.handle, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes)) == 0]
+        import copy
+        arena = HostArrays(w.rad)
+        # (shallow copies of the workload's objects: the page-locked arrays hang on the copies, the workload keeps its own)
+        sl2, th2, gas2, cloud2, aer2 = (copy.copy(o) if o is not None else None for o in (sl, th, gas, cloud, aer))
+        flux2 = Flux.allocate(w.config, ncol, nlev)
         try:
+            moved = relocate_call_arrays(arena.copy_of, (sl2, th2, gas2, cloud2, aer2), flux2)
+            cin, keep = build_inputs_struct(w.config, ncol, nlev, sl2, th2, gas2, cloud2, aer2)
+            cflux = build_flux_struct(flux2)
+
             def call():
                 if w.rad.lib.ecrad_hip_radiation(w.rad.handle, ncol, nlev, 1, ncol, C.byref(cin), C.byref(cflux)) != 0:
                     raise RuntimeError(w.rad.lib.ecrad_hip_last_error(w.rad.handle).decode())
             call()
             tr = 0.0
             for _ in range(repeats):
-                if cloud is not None:
-                    cloud.fraction[...] = frac0
+                if cloud2 is not None:
+                    cloud2.fraction[...] = frac0
                 t0 = time.perf_counter()
                 call()
                 tr += time.perf_counter() - t0
-            registered = {"value": ncol * repeats / tr, "unit": "columns/s", "ms_per_call": 1e3 * tr / repeats,
-                          "arrays_registered": len(pinned), "arrays": len(arrays), "bytes_registered": int(sum(a.nbytes for a in pinned))}
+            same = all(np.array_equal(v, flux2.arrays[k], equal_nan=True) for k, v in flux.arrays.items())
+            registered = {"value": ncol * repeats / tr, "unit": "columns/s", "ms_per_call": 1e3 * tr / repeats, "same_bits_as_pageable": bool(same),
+                          "arrays_page_locked": len(moved), "bytes_page_locked": int(arena.nbytes), "how": "ecrad_hip_host_alloc"}
         finally:
-            for a in pinned:
-                w.rad.lib.ecrad_hip_host_unregister(w.rad.handle, C.c_void_p(a.ctypes.data))
-        del keep
+            cin = cflux = keep = moved = sl2 = th2 = gas2 = cloud2 = aer2 = None      # (nothing may hold the memory that goes back now)
+            flux2.arrays.clear()
+            arena.close()
     except Exception as e:      # (additional information: never take the line down)
         registered = {"error": f"{type(e).__name__}: {e}"}
     return {"value": value, "unit": "columns/s", "ms_per_call": 1e3 * t / repeats, "registered_host_arrays": registered,
@@ -914,18 +922,21 @@ def pool_mode(args):
 
 
 def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allreduce_max, do_cpu, do_host_mode, regions=1):
-    """`regions` > 1 (the extra workloads, five steps each): the K-step region is timed that many times and the fastest kept -- one
-    hiccup of the box (35 ms once, seen in round 5) is 7 ms per step of a five-step region.  The headline is timed ONCE, K steps exactly."""
+    """`regions` > 1 (the extra workloads, five steps each): the K-step region is timed that many times (three) and the MEDIAN is the
+    workload's figure; every region's ms per step is in the record (`timed_regions`), so that one hiccup of the box (35 ms once, seen in
+    round 5: 7 ms per step of a five-step region) is visible and neither kept nor picked against.  The headline is timed ONCE, K steps exactly."""
     sample_cols = 16384 if do_cpu else 0
     progress(f"{name} ncol={ncol}: set-up")
     w = Workload(name, ncol, rank, local_rank, sample_cols)
     progress(f"{name}: timed steps")
     elapsed_rank = timed_steps(w, steps, warmup, barrier)
     region_ms = [1e3 * elapsed_rank / steps]
+    region_s = [elapsed_rank]
     for _ in range(regions - 1):
         e = timed_steps(w, steps, 0, barrier)
         region_ms.append(1e3 * e / steps)
-        elapsed_rank = min(elapsed_rank, e)
+        region_s.append(e)
+    elapsed_rank = sorted(region_s)[(len(region_s) - 1) // 2]      # the median (of three); the lower middle of an even count
     elapsed = allreduce_max(elapsed_rank)
     elapsed_min = -allreduce_max(-elapsed_rank)
     stage = w.stage_ms()
@@ -944,7 +955,7 @@ def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allredu
                       "aerosols": bool(w.config.use_aerosols), "clouds": not w.clear_sky},
            "roofline": roofline_of(w, stage, elapsed / steps)}
     if regions > 1:
-        res["timed_regions"] = {"count": regions, "ms_per_step_each": region_ms, "kept": "fastest"}
+        res["timed_regions"] = {"count": regions, "ms_per_step_each": region_ms, "kept": "median", "fastest": min(region_ms), "slowest": max(region_ms)}
     if world > 1:
         # every rank times the same K steps between the same two barriers: the slowest rank is `ms_per_step`
         res["ms_per_step_ranks"] = {"min": 1e3 * elapsed_min / steps, "max": 1e3 * elapsed / steps}
@@ -1008,7 +1019,7 @@ def _sig(x, n=6):
 
 def _compact_roofline(r):
     keep = ("bound", "binding_roof", "fractions", "valu", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
-            "kernel_ms", "stage_ms", "algorithmic_bytes_per_column", "launches_per_step", "scratch_mantissa_bits", "measured_triad")
+            "kernel_ms", "stage_ms", "algorithmic_bytes_per_column", "launches_per_step", "scratch_mantissa_bits", "measured_triad", "measured_read", "measured_copy")
     out = {k: r[k] for k in keep if k in r}
     if "whole_step" in r:
         out["whole_step_frac"] = r["whole_step"]["frac"]
@@ -1042,7 +1053,7 @@ def compact_line(out, detail_path=None):
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
                                  "scaling", "vs_baseline", "dtype", "data", "config") if k in out}
     for k in ("ms_per_step_ranks", "value_with_gather", "ms_per_step_with_gather", "gathered", "mode", "test_shared_gpu",
-              "test_fake_devices", "blocks_identical_across_devices", "pool", "attempts", "aborted_attempts"):
+              "test_fake_devices", "blocks_identical_across_devices", "pool", "attempts", "aborted_attempts", "fault"):
         if k in out:
             line[k] = out[k]
     if "roofline" in out:
@@ -1106,18 +1117,18 @@ def emit(out):
 
 
 def supervise():
-    """The single-GPU run as a watched child process.  Once in nine runs of the default command on the round-5 boxes the process was
-    ended from outside Python -- "Memory access fault by GPU node-2 ... Reason: Unknown", SIGABRT from the ROCm runtime, nothing printed,
-    not reproduced by 36 repetitions of the phase it happened in (profiles/NOTES_r05.md section 15) -- and a run that prints nothing is a
-    round without a record.  So the measurement runs in a child; a child ended by SIGABRT / SIGSEGV / SIGBUS is started again (twice at
-    most) and the line of the run that completes says so: `attempts` and, per aborted attempt, the signal and the phase it was in
-    (gpurun_out/bench_progress.log).  Nothing is averaged or carried over between attempts; every number of the line comes from the one
-    run that printed it.  Not under torchrun (WORLD_SIZE > 1): a rank is not restarted behind the back of the others.
+    """The single-GPU run as a watched child process, so that a run the ROCm runtime ends from outside Python (SIGABRT after "Memory access
+    fault by GPU", round 5: profiles/NOTES_r05.md section 15, root cause and fix profiles/NOTES_r06.md section 1) still leaves a record: the
+    parent prints ONE line `{"metric": ..., "value": null, "fault": true, "signal": ..., "last_phase": ...}` and exits with 128 + signal.
+    A run is NOT started again: a crash of the library is a failed bench.  ECRAD_BENCH_RETRY=N (a debugging aid, never set by bench.py
+    itself or by the tests of the default path) allows N further attempts after SIGABRT; the line of an attempt that then completes carries
+    `"fault": true`, `attempts` and the aborted attempts, and the exit status is 70, not 0.  Not under torchrun (WORLD_SIZE > 1).
     ECRAD_BENCH_NO_SUPERVISOR=1 runs the measurement in this process."""
     import signal
     import subprocess
     aborted = []
-    for attempt in range(1, 4):
+    retries = max(0, int(os.environ.get("ECRAD_BENCH_RETRY", "0")))
+    for attempt in range(1, retries + 2):
         env = dict(os.environ, ECRAD_BENCH_WORKER="1", ECRAD_BENCH_ATTEMPT=str(attempt), ECRAD_BENCH_ABORTED=json.dumps(aborted))
         child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env)
         try:
@@ -1125,8 +1136,8 @@ def supervise():
         except KeyboardInterrupt:
             child.kill()
             raise
-        if rc >= 0 or -rc not in (signal.SIGABRT, signal.SIGSEGV, signal.SIGBUS):
-            sys.exit(rc if rc >= 0 else 128 - rc)
+        if rc >= 0:
+            sys.exit(70 if (rc == 0 and aborted) else rc)
         last = None
         try:
             with open(os.path.join(ROOT, "gpurun_out", "bench_progress.log")) as f:
@@ -1136,8 +1147,13 @@ def supervise():
             pass
         aborted.append({"attempt": attempt, "signal": -rc, "last_phase": last})
         print(f"bench.py: attempt {attempt} ended by signal {-rc} in phase {last!r}", file=sys.stderr)
-    print("bench.py: three attempts ended by a signal; no record", file=sys.stderr)
-    sys.exit(134)
+        if -rc != signal.SIGABRT:
+            break
+    sys.stderr.flush()
+    print(json.dumps({"metric": "columns/sec (SW+LW) at 137 lev, ecCKD-32; 1/2/4/8 GPU + %HBM roofline", "value": None, "unit": "columns/s",
+                      "n_gpus": 1, "higher_is_better": True, "fault": True, "signal": aborted[-1]["signal"],
+                      "last_phase": aborted[-1]["last_phase"], "aborted_attempts": aborted}), flush=True)
+    sys.exit(128 + aborted[-1]["signal"])
 
 
 def main():
@@ -1170,9 +1186,6 @@ def main():
         if int(os.environ.get("ECRAD_BENCH_ATTEMPT", "1")) <= int(os.environ.get("ECRAD_BENCH_TEST_ABORT_ATTEMPTS", "0")):
             progress("test hook: abort")
             os.abort()
-    # (every array of 64 KB or more in pages of its own: the arrays end_to_end_host page-locks must not share pages with heap neighbours)
-    from ecrad_amd.interface import private_pages_for_large_arrays
-    private_pages_for_large_arrays()
     if args.threads_per_process > 0:
         return pool_mode(args)
 
@@ -1250,7 +1263,7 @@ def main():
             steps = max(2, min(args.steps, 5 if ncol <= 100000 else 3))
             try:
                 r = measure(name, ncol, steps, 1, rank, local_rank, world, barrier, allreduce_max, do_cpu,
-                            do_host_mode=(name == "tripleclouds_ecckd32" and ncol <= CHUNK_COLUMNS and not args.no_host_mode), regions=2)
+                            do_host_mode=(name == "tripleclouds_ecckd32" and ncol <= CHUNK_COLUMNS and not args.no_host_mode), regions=3)
             except Exception as e:      # an extra workload must not take the headline line down with it
                 r = {"error": f"{type(e).__name__}: {e}"}
             if "parity" in r and not r["parity"]["ok"]:
@@ -1271,6 +1284,7 @@ def main():
         prior = json.loads(os.environ.get("ECRAD_BENCH_ABORTED", "[]"))
         if prior:
             out["aborted_attempts"] = prior
+            out["fault"] = True
     progress("emit")
     if rank == 0:
         if failed and "parity" in head and not head["parity"]["ok"]:

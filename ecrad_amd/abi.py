@@ -7,11 +7,12 @@ import ctypes as C
 
 import numpy as np
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 NMAXGASES = 12
 NMAXCLOUDTYPES = 12
 
 MEM_HOST, MEM_DEVICE = 0, 1
+OK, EINVAL, ENODEVICE, EUNSUPPORTED, EHIP, ENOMEM, ENOTSETUP = 0, -1, -2, -3, -4, -5, -6      # include/ecrad_hip.h:42-48
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -254,6 +255,10 @@ def declare_prototypes(lib) -> None:
     lib.ecrad_hip_radiation.restype = C.c_int
     lib.ecrad_hip_radiation_f32.argtypes = lib.ecrad_hip_radiation.argtypes      # (same structs, float arrays behind the pointers)
     lib.ecrad_hip_radiation_f32.restype = C.c_int
+    lib.ecrad_hip_host_alloc.argtypes = [H, C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.ecrad_hip_host_alloc.restype = C.c_int
+    lib.ecrad_hip_host_free.argtypes = [H, C.c_void_p]
+    lib.ecrad_hip_host_free.restype = C.c_int
     lib.ecrad_hip_host_register.argtypes = [H, C.c_void_p, C.c_size_t]
     lib.ecrad_hip_host_register.restype = C.c_int
     lib.ecrad_hip_host_unregister.argtypes = [H, C.c_void_p]
@@ -269,6 +274,8 @@ def declare_prototypes(lib) -> None:
     lib.ecrad_hip_last_stage_ms.restype = C.c_int
     lib.ecrad_hip_hbm_triad.argtypes = [H, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     lib.ecrad_hip_hbm_triad.restype = C.c_int
+    lib.ecrad_hip_hbm_rates.argtypes = [H, C.c_size_t, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.ecrad_hip_hbm_rates.restype = C.c_int
     lib.ecrad_hip_scratch_bytes.argtypes = [H, C.POINTER(C.c_size_t)]
     lib.ecrad_hip_scratch_bytes.restype = C.c_int
     lib.ecrad_hip_last_error.argtypes = [H]
@@ -298,6 +305,6 @@ EXPORTED_SYMBOLS = [
     "ecrad_hip_optics", "ecrad_hip_synchronize", "ecrad_hip_last_kernel_ms", "ecrad_hip_last_stage_ms",
     "ecrad_hip_scratch_bytes", "ecrad_hip_last_error", "ecrad_hip_destroy",
     "ecrad_hip_abi_sizeof", "ecrad_hip_abi_version", "ecrad_hip_set_work_bytes", "ecrad_hip_last_call_info",
-    "ecrad_hip_hbm_triad", "ecrad_hip_set_concurrency", "ecrad_hip_pool_info", "ecrad_hip_pool_reset",
-    "ecrad_hip_pcie_bandwidth", "ecrad_hip_radiation_f32", "ecrad_hip_host_register", "ecrad_hip_host_unregister",
+    "ecrad_hip_hbm_triad", "ecrad_hip_hbm_rates", "ecrad_hip_set_concurrency", "ecrad_hip_pool_info", "ecrad_hip_pool_reset",
+    "ecrad_hip_pcie_bandwidth", "ecrad_hip_radiation_f32", "ecrad_hip_host_alloc", "ecrad_hip_host_free", "ecrad_hip_host_register", "ecrad_hip_host_unregister",
 ]

@@ -1,6 +1,8 @@
 // abi.hip -- the entry points of a call (include/ecrad_hip.h: ecrad_hip_radiation, ecrad_hip_radiation_f32, ecrad_hip_optics) and
 // the measurement aids of bench.py (ecrad_hip_hbm_triad, ecrad_hip_pcie_bandwidth).  The work is in pipeline.hip / pool.hip.
 #include "host_internal.h"
+#include <map>
+#include <unistd.h>
 
 using namespace ecrad;
 using namespace ecrad_host;
@@ -166,21 +168,85 @@ int ecrad_hip_radiation_f32(ecrad_hip_handle_t h, int ncol, int nlev, int istart
 
 extern "C" {
 
+// ---- the caller's arrays page-locked (include/ecrad_hip.h) ----------------------------------------------------------------------------
+// A page-locked range is mapped into the device's address space PAGE BY PAGE.  The library therefore deals in whole pages only:
+// ecrad_hip_host_alloc hands out page-locked memory of its own (hipHostMalloc), ecrad_hip_host_register takes ranges that begin on a
+// page boundary and span whole pages and refuses everything else -- a range that shares its first or last page with another object of
+// the caller's heap is the one way this boundary could hand the device a page whose life it does not control (round 5's "Memory access
+// fault by GPU" at a heap address; tools/stress/register_fault.hip, profiles/NOTES_r06.md section 1).  Ranges are kept in a table of the
+// process: no page is registered twice, only what was registered here is unregistered, and both release calls wait until no call of the
+// handle is in flight (LeaseAll), so memory is never taken from under the copy engines.
+namespace {
+std::mutex g_host_mutex;
+std::map<uintptr_t, size_t> g_registered, g_allocated;      // base -> bytes
+size_t host_page() { static const size_t p = (size_t)sysconf(_SC_PAGESIZE); return p; }
+bool overlaps(const std::map<uintptr_t, size_t>& m, uintptr_t a, size_t n) {
+  auto it = m.upper_bound(a);
+  if (it != m.end() && it->first < a + n) return true;
+  if (it != m.begin()) { --it; if (it->first + it->second > a) return true; }
+  return false;
+}
+}  // namespace
+
+int ecrad_hip_host_alloc(ecrad_hip_handle_t h, size_t bytes, void** p) {
+  if (!h || !p || bytes == 0) return ECRAD_EINVAL;
+  *p = nullptr;
+  void* q = nullptr;
+  if (hipHostMalloc(&q, bytes, hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail_call(h, ECRAD_ENOMEM, "ecrad_hip_host_alloc: hipHostMalloc failed");
+  }
+  { std::lock_guard<std::mutex> lk(g_host_mutex); g_allocated[reinterpret_cast<uintptr_t>(q)] = bytes; }
+  *p = q;
+  return ECRAD_OK;
+}
+
+int ecrad_hip_host_free(ecrad_hip_handle_t h, void* p) {
+  if (!h || !p) return ECRAD_EINVAL;
+  {
+    std::lock_guard<std::mutex> lk(g_host_mutex);
+    if (!g_allocated.count(reinterpret_cast<uintptr_t>(p))) return fail_call(h, ECRAD_EINVAL, "ecrad_hip_host_free: not a pointer ecrad_hip_host_alloc returned");
+  }
+  const LeaseAll quiet(h);      // (no call of this handle in flight: nothing is copying to or from the memory)
+  {
+    std::lock_guard<std::mutex> lk(g_host_mutex);
+    if (!g_allocated.erase(reinterpret_cast<uintptr_t>(p))) return fail_call(h, ECRAD_EINVAL, "ecrad_hip_host_free: freed by another thread meanwhile");
+  }
+  if (hipHostFree(p) != hipSuccess) { (void)hipGetLastError(); return fail_call(h, ECRAD_EHIP, "hipHostFree failed"); }
+  return ECRAD_OK;
+}
+
 int ecrad_hip_host_register(ecrad_hip_handle_t h, void* p, size_t bytes) {
   if (!h || !p || bytes == 0) return ECRAD_EINVAL;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  if (a % host_page() || bytes % host_page())
+    return fail_call(h, ECRAD_EINVAL, "ecrad_hip_host_register takes whole pages only: a range that begins on a page boundary and is a multiple of the "
+                                      "page size long (allocate with ecrad_hip_host_alloc, or page-aligned: posix_memalign / mmap)");
+  std::lock_guard<std::mutex> lk(g_host_mutex);
+  if (overlaps(g_registered, a, bytes) || overlaps(g_allocated, a, bytes))
+    return fail_call(h, ECRAD_EINVAL, "ecrad_hip_host_register: the range overlaps one that is page-locked already");
   // (portable: page-locked for every device of the pool, not only the calling thread's current one)
   if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) {
     (void)hipGetLastError();
-    return fail_call(h, ECRAD_EHIP, "hipHostRegister refused the range (already registered, or not host memory)");
+    return fail_call(h, ECRAD_EHIP, "hipHostRegister refused the range (not host memory of this process, or locked-memory limit)");
   }
+  g_registered[a] = bytes;
   return ECRAD_OK;
 }
 
 int ecrad_hip_host_unregister(ecrad_hip_handle_t h, void* p) {
   if (!h || !p) return ECRAD_EINVAL;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  {
+    std::lock_guard<std::mutex> lk(g_host_mutex);
+    if (!g_registered.count(a)) return fail_call(h, ECRAD_EINVAL, "ecrad_hip_host_unregister: not the start of a range ecrad_hip_host_register accepted");
+  }
+  const LeaseAll quiet(h);
+  std::lock_guard<std::mutex> lk(g_host_mutex);
+  if (!g_registered.erase(a)) return fail_call(h, ECRAD_EINVAL, "ecrad_hip_host_unregister: unregistered by another thread meanwhile");
   if (hipHostUnregister(p) != hipSuccess) {
     (void)hipGetLastError();
-    return fail_call(h, ECRAD_EHIP, "hipHostUnregister: the range is not registered");
+    return fail_call(h, ECRAD_EHIP, "hipHostUnregister failed");
   }
   return ECRAD_OK;
 }
@@ -296,6 +362,78 @@ int ecrad_hip_hbm_triad(ecrad_hip_handle_t h, size_t nbytes, int repeats, double
   if (e1) (void)hipEventDestroy(e1);
   (void)hipFree(a); (void)hipFree(b); (void)hipFree(c);
   if (st == ECRAD_OK) *gbs = 3.0 * (double)nbytes / ((double)best * 1.0e6);
+  return st;
+}
+
+}  // extern "C"
+
+namespace ecrad_host {
+
+// 16 bytes per lane, four requests of a lane in flight before the first is used (what the guide's 6.3 TB/s "float4 copy" figure is
+// measured with: /opt/skills/guides/MI355X_MICROARCH.md, HBM).  The triad above has one request per array in flight per lane and a
+// read : write mix of 2 : 1; these two say what the box gives a pure read and a 1 : 1 copy.
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void hbm_read_kernel(const v2d* __restrict__ a, size_t n, double* __restrict__ sink) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const v2d v0 = __builtin_nontemporal_load(a + i), v1 = __builtin_nontemporal_load(a + i + stride),
+              v2 = __builtin_nontemporal_load(a + i + 2 * stride), v3 = __builtin_nontemporal_load(a + i + 3 * stride);
+    acc += (v0.x + v1.x) + (v2.x + v3.x) + (v0.y + v1.y) + (v2.y + v3.y);
+  }
+  if (acc == 12345.678) sink[0] = acc;      // (never true for the zero-filled arrays: keeps the loads alive)
+}
+
+__global__ __launch_bounds__(256) void hbm_copy_kernel(v2d* __restrict__ b, const v2d* __restrict__ a, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const v2d v0 = __builtin_nontemporal_load(a + i), v1 = __builtin_nontemporal_load(a + i + stride),
+              v2 = __builtin_nontemporal_load(a + i + 2 * stride), v3 = __builtin_nontemporal_load(a + i + 3 * stride);
+    __builtin_nontemporal_store(v0, b + i); __builtin_nontemporal_store(v1, b + i + stride);
+    __builtin_nontemporal_store(v2, b + i + 2 * stride); __builtin_nontemporal_store(v3, b + i + 3 * stride);
+  }
+}
+
+}  // namespace ecrad_host
+
+extern "C" {
+
+int ecrad_hip_hbm_rates(ecrad_hip_handle_t h, size_t nbytes, int repeats, double* read_gbs, double* copy_gbs) {
+  if (!h || !read_gbs || !copy_gbs || nbytes < (1u << 20) || repeats < 1) return ECRAD_EINVAL;
+  HIP_TRY(h, hipSetDevice(h->device));
+  v2d *a = nullptr, *b = nullptr;
+  double* sink = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int st = ECRAD_OK;
+  float best[2] = {1e30f, 1e30f};
+  const size_t n = nbytes / sizeof(v2d);
+  if (hipMalloc(&a, nbytes) != hipSuccess || hipMalloc(&b, nbytes) != hipSuccess || hipMalloc(&sink, 8) != hipSuccess) {
+    st = fail(h, ECRAD_ENOMEM, "ecrad_hip_hbm_rates: cannot allocate the two arrays");
+  } else if (hipMemsetAsync(a, 0, nbytes, h->stream) != hipSuccess || hipMemsetAsync(b, 0, nbytes, h->stream) != hipSuccess ||
+             hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    st = fail(h, ECRAD_EHIP, "ecrad_hip_hbm_rates: set-up failed");
+  } else {
+    for (int which = 0; which < 2 && st == ECRAD_OK; ++which)
+      for (int rep = 0; rep <= repeats && st == ECRAD_OK; ++rep) {       // (the first launch is a warm-up)
+        (void)hipEventRecord(e0, h->stream);
+        if (which == 0) hipLaunchKernelGGL(hbm_read_kernel, dim3(256 * 32), dim3(256), 0, h->stream, a, n, sink);
+        else hipLaunchKernelGGL(hbm_copy_kernel, dim3(256 * 32), dim3(256), 0, h->stream, b, a, n);
+        (void)hipEventRecord(e1, h->stream);
+        float ms = 0.f;
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) st = fail(h, ECRAD_EHIP, "ecrad_hip_hbm_rates: launch failed");
+        else if (rep > 0 && ms < best[which]) best[which] = ms;
+      }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipFree(a); (void)hipFree(b); (void)hipFree(sink);
+  if (st == ECRAD_OK) {
+    *read_gbs = (double)nbytes / ((double)best[0] * 1.0e6);
+    *copy_gbs = 2.0 * (double)nbytes / ((double)best[1] * 1.0e6);
+  }
   return st;
 }
 

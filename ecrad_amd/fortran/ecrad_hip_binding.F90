@@ -8,7 +8,7 @@ module ecrad_hip_binding
   implicit none
   public
 
-  integer(c_int), parameter :: ECRAD_ABI_VERSION = 7
+  integer(c_int), parameter :: ECRAD_ABI_VERSION = 8
   integer(c_int), parameter :: ECRAD_OK = 0
   integer(c_int), parameter :: ECRAD_NMAXGASES = 12, ECRAD_NMAXCLOUDTYPES = 12
   integer(c_int), parameter :: ECRAD_MEM_HOST = 0, ECRAD_MEM_DEVICE = 1
@@ -191,7 +191,20 @@ module ecrad_hip_binding
       type(ecrad_flux_t), intent(inout) :: flux
       integer(c_int) :: status
     end function
-    ! page-lock a range of the host's own memory for the copy engines (optional; include/ecrad_hip.h)
+    ! page-locked host memory (optional; include/ecrad_hip.h): the library's own -- map it onto an array pointer with
+    ! c_f_pointer(p, array, shape) -- or whole pages of the host's own memory registered
+    function ecrad_hip_host_alloc(handle, bytes, p) bind(C, name='ecrad_hip_host_alloc') result(status)
+      import :: c_ptr, c_int, c_size_t
+      type(c_ptr), value :: handle
+      integer(c_size_t), value :: bytes
+      type(c_ptr), intent(out) :: p
+      integer(c_int) :: status
+    end function
+    function ecrad_hip_host_free(handle, p) bind(C, name='ecrad_hip_host_free') result(status)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: handle, p
+      integer(c_int) :: status
+    end function
     function ecrad_hip_host_register(handle, p, bytes) bind(C, name='ecrad_hip_host_register') result(status)
       import :: c_ptr, c_int, c_size_t
       type(c_ptr), value :: handle, p

@@ -29,35 +29,74 @@ class EcradHipError(RuntimeError):
     pass
 
 
-def private_pages_for_large_arrays(threshold: int = 1 << 16) -> bool:
-    """For a Python host that page-locks its arrays with ``ecrad_hip_host_register``: from now on every allocation of `threshold` bytes or
-    more is a mapping of its own (``mallopt(M_MMAP_THRESHOLD)``; glibc's default threshold floats up to 32 MB), i.e. whole pages that no
-    other object shares and that go back to the kernel when the array dies.  A registered range is mapped into the GPU's address space page
-    by page; a numpy array of 64 KB ... 32 MB otherwise sits in the heap between other objects, its first and last page shared with them,
-    and what the allocator does to those neighbours while the range is registered is not ours to see (round 5: a GPU memory fault at a heap
-    address, once in nine default runs of bench.py and once in seven runs of the GPU tests -- the two processes that register heap arrays;
-    profiles/NOTES_r05.md section 15).  A Fortran host's large allocatables are mappings of their own already.  Returns False where there is
-    no glibc mallopt.  Not a promise -- the allocator still serves a request from a free chunk of the heap when it has one --: check the arrays
-    with ``owns_its_pages`` before registering them."""
-    try:
-        return C.CDLL(None).mallopt(-3, int(threshold)) == 1      # M_MMAP_THRESHOLD = -3
-    except (OSError, AttributeError):
-        return False
+class HostArrays:
+    """Page-locked host memory for a Python host (include/ecrad_hip.h: ecrad_hip_host_alloc / ecrad_hip_host_free): numpy arrays whose
+    storage the library allocated page-locked, so that the tiles of a pipelined host-memory call move by the copy engines directly.
+    ``empty`` / ``copy_of`` hand out arrays; ``close`` gives the memory back (no array handed out may be used after it).  A host model
+    allocates its long-lived arrays here once; nothing is registered or guessed about the allocator (round 5 registered numpy arrays
+    where glibc happened to put them: profiles/NOTES_r06.md section 1)."""
+
+    def __init__(self, rad: "Radiation"):
+        self.lib, self.handle = rad.lib, rad.handle
+        self._blocks = []
+        self.nbytes = 0
+
+    def empty(self, shape, dtype=np.float64):
+        dtype = np.dtype(dtype)
+        count = int(np.prod(shape, dtype=np.int64))
+        nbytes = max(count * dtype.itemsize, 1)
+        p = C.c_void_p()
+        st = self.lib.ecrad_hip_host_alloc(self.handle, C.c_size_t(nbytes), C.byref(p))
+        if st != 0 or not p.value:
+            raise EcradHipError(f"ecrad_hip_host_alloc({nbytes}) failed with status {st}")
+        self._blocks.append(p.value)
+        self.nbytes += nbytes
+        buf = (C.c_char * nbytes).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+
+    def copy_of(self, a):
+        b = self.empty(a.shape, a.dtype)
+        b[...] = a
+        return b
+
+    def close(self):
+        for p in self._blocks:
+            self.lib.ecrad_hip_host_free(self.handle, C.c_void_p(p))
+        self._blocks = []
+        self.nbytes = 0
 
 
-def owns_its_pages(a) -> bool:
-    """True when numpy array `a` is an allocation that glibc mapped on its own (the data 16 bytes into a page, above the heap): the only
-    arrays a Python host should hand to ``ecrad_hip_host_register``.  ``private_pages_for_large_arrays`` makes that the rule for new large
-    arrays but cannot promise it -- a request the heap's free chunks or its top can satisfy is still served from there."""
-    try:
-        libc = C.CDLL(None)
-        libc.sbrk.restype = C.c_void_p
-        libc.sbrk.argtypes = [C.c_ssize_t]
-        brk = libc.sbrk(0) or 0
-    except (OSError, AttributeError):
-        return False
-    addr = a.ctypes.data
-    return addr > brk and (addr & 0xfff) == 0x10
+def page_aligned_empty(shape, dtype=np.float64):
+    """A numpy array that is a private mapping of whole pages (``mmap``), i.e. a range ecrad_hip_host_register accepts: returns
+    (array, address, bytes) with `bytes` the length of the mapping, a multiple of the page size.  The mapping lives as long as the array."""
+    import mmap
+    dtype = np.dtype(dtype)
+    count = int(np.prod(shape, dtype=np.int64))
+    nbytes = -(-max(count * dtype.itemsize, 1) // mmap.PAGESIZE) * mmap.PAGESIZE
+    m = mmap.mmap(-1, nbytes)
+    a = np.frombuffer(m, dtype=dtype, count=count).reshape(shape)
+    return a, a.ctypes.data, nbytes
+
+
+def relocate_call_arrays(copy_of, objects, flux=None, min_bytes=1 << 16):
+    """Move the numpy arrays of a call -- the ndarray members of `objects` (single_level, thermodynamics, gas, cloud, aerosol; None
+    entries skipped) and the arrays of `flux` -- of `min_bytes` or more into memory that `copy_of(array)` provides (HostArrays.copy_of:
+    page-locked; a wrapper of page_aligned_empty: whole pages for ecrad_hip_host_register).  In place: the objects then hold the new
+    arrays.  Returns the list of new arrays."""
+    moved = []
+    for obj in objects:
+        if obj is None:
+            continue
+        for k, v in list(vars(obj).items()):
+            if isinstance(v, np.ndarray) and v.nbytes >= min_bytes:
+                setattr(obj, k, copy_of(np.ascontiguousarray(v)))
+                moved.append(getattr(obj, k))
+    if flux is not None:
+        for k, v in list(flux.arrays.items()):
+            if v.nbytes >= min_bytes:
+                flux.arrays[k] = copy_of(v)
+                moved.append(flux.arrays[k])
+    return moved
 
 
 def load_library(path: str = LIB_PATH):

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define ECRAD_ABI_VERSION 7
+#define ECRAD_ABI_VERSION 8
 
 /* Status codes */
 #define ECRAD_OK            0
@@ -471,20 +471,37 @@ int ecrad_hip_last_stage_ms(ecrad_hip_handle_t handle, int which, double* ms);
    allocated and freed inside the call.  Measurement aid of bench.py; touches nothing else of the handle. */
 int ecrad_hip_hbm_triad(ecrad_hip_handle_t handle, size_t nbytes_per_array, int repeats, double* gbs);
 
+/* The same device's rate for a pure read and for a copy (16 bytes per lane, four requests of a lane in flight, non-temporal): the
+   pattern /opt/skills/guides/MI355X_MICROARCH.md quotes 6.3 TB/s for.  The triad has a 2 : 1 read : write mix and one request per
+   array in flight per lane and comes out lower; bench.py prints all three (roofline.measured_read / _copy / _triad).  Arrays of
+   `nbytes` each (take them larger than the 256 MiB Infinity Cache), allocated and freed inside the call. */
+int ecrad_hip_hbm_rates(ecrad_hip_handle_t handle, size_t nbytes, int repeats, double* read_gbs, double* copy_gbs);
+
 /* What the link between this host and this device sustains, with page-locked host buffers of `nbytes` each: host to
    device alone, device to host alone, and both at once (the sum of the two directions), best of `repeats`.  A pipelined
    host-memory call (ecrad_hip_radiation) cannot move its columns faster than this: measurement aid of bench.py. */
 int ecrad_hip_pcie_bandwidth(ecrad_hip_handle_t handle, size_t nbytes, int repeats, double* h2d_gbs, double* d2h_gbs, double* duplex_gbs);
 
-/* Page-lock (and map for the devices of the pool) a range of the CALLER's host memory, and release it again.  Optional: a
-   host-memory call works on pageable arrays, which the runtime stages through buffers of its own by the calling threads --
-   40 of the link's 57 GB/s at best; arrays registered ONCE (a host model's arrays live as long as the model runs) are read and written by
-   the copy engines directly, and the tiles of a pipelined call (8192 columns or more) then move at the link's rate.  Thin
-   wrappers over hipHostRegister / hipHostUnregister so that a Fortran host need not link the HIP runtime itself; the range
-   must stay allocated until it is unregistered.  ecrad_hip_host_register fails with ECRAD_EHIP (and changes nothing) when
-   the runtime refuses the range.  Register allocations that own their pages (a Fortran host's large allocatables are mappings of
-   their own; a Python host calls ecrad_amd.interface.private_pages_for_large_arrays() first): a range is mapped page by page, and a
-   small array in the middle of the heap shares its first and last page with whatever the allocator keeps next to it. */
+/* Page-locked host memory for the arrays of host-memory calls.  Optional: a host-memory call works on pageable arrays, which the
+   runtime stages through buffers of its own by the calling threads -- 40 of the link's 57 GB/s at best; arrays that are page-locked
+   ONCE (a host model's arrays live as long as the model runs) are read and written by the copy engines directly, and the tiles of a
+   pipelined call (8192 columns or more) then move at the link's rate.  So that a Fortran host need not link the HIP runtime itself:
+
+   ecrad_hip_host_alloc / ecrad_hip_host_free: page-locked memory of the library's own (hipHostMalloc, usable from every device of the
+     pool), page-aligned; a Fortran host maps it onto an array pointer with c_f_pointer (ecrad_hip_binding.F90), a Python host with
+     numpy.frombuffer (ecrad_amd.interface.HostArrays).  THE way for new code.
+   ecrad_hip_host_register / ecrad_hip_host_unregister: page-lock memory the caller allocated.  A page-locked range is mapped for the
+     device PAGE BY PAGE, so the range must consist of whole pages of its own: `p` on a page boundary (sysconf(_SC_PAGESIZE)), `bytes`
+     a multiple of the page size (posix_memalign / aligned_alloc / mmap, with the size rounded up), not overlapping a range that is
+     page-locked already.  Anything else is ECRAD_EINVAL and nothing is changed: an array in the middle of the heap shares its first and
+     last page with whatever the allocator keeps next to it, and the life of those pages is not the array's (round 5: a GPU memory
+     fault at a heap address in processes that registered such arrays; tools/stress/register_fault.hip).  ECRAD_EHIP when the runtime
+     refuses the range.  Only the start of a range registered here can be unregistered (ECRAD_EINVAL otherwise).
+   The memory must stay allocated until it is unregistered.  ecrad_hip_host_unregister and ecrad_hip_host_free wait until no call of
+   the handle is in flight, so they never take memory from under a copy; do not call them from a thread that holds arrays of a call
+   another thread is about to make. */
+int ecrad_hip_host_alloc(ecrad_hip_handle_t handle, size_t bytes, void** p);
+int ecrad_hip_host_free(ecrad_hip_handle_t handle, void* p);
 int ecrad_hip_host_register(ecrad_hip_handle_t handle, void* p, size_t bytes);
 int ecrad_hip_host_unregister(ecrad_hip_handle_t handle, void* p);
 

@@ -57,22 +57,35 @@ def test_create_without_gpu_fails_loudly(lib):
         Radiation(make_config("Cloudless"), backend="hip")
 
 
-def test_large_arrays_in_pages_of_their_own():
-    """ecrad_amd.interface.private_pages_for_large_arrays / owns_its_pages (what a Python host uses before it page-locks arrays with
-    ecrad_hip_host_register): arrays well above the threshold are mappings of their own -- 16 bytes into a page, above the heap --, a small
-    array never is, and an array the allocator served from the heap's top is recognised as such.  Run in a child: the setting stays for
-    the life of a process."""
-    import subprocess
-    import sys
-    code = ("import sys; sys.path.insert(0, %r)\n"
-            "import numpy as np\n"
-            "from ecrad_amd.interface import owns_its_pages, private_pages_for_large_arrays\n"
-            "assert private_pages_for_large_arrays(1 << 16)\n"
-            "big = [np.zeros(n) for n in (1 << 16, 1 << 18, 1 << 20) for _ in range(4)]\n"
-            "small = [np.zeros(n) for n in (16, 128, 1024)]\n"
-            "edge = [np.zeros(1 << 13) for _ in range(4)]\n"
-            "ok = all(owns_its_pages(a) for a in big) and not any(owns_its_pages(a) for a in small)\n"
-            "ok = ok and all(owns_its_pages(a) == ((a.ctypes.data & 0xfff) == 0x10 and a.ctypes.data > 0x700000000000) for a in edge)\n"
-            "print(ok)\n") % ROOT
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
-    assert p.returncode == 0 and p.stdout.strip() == "True", (p.stdout, p.stderr[-400:])
+def test_call_arrays_move_into_whole_pages():
+    """ecrad_amd.interface.page_aligned_empty / relocate_call_arrays (what a Python host uses before it page-locks arrays with
+    ecrad_hip_host_register, which takes whole pages only): every large array of a call becomes a private mapping that begins on a page
+    boundary and spans whole pages, with the same values; small arrays stay where they are."""
+    import mmap
+    import numpy as np
+    from ecrad_amd.interface import page_aligned_empty, relocate_call_arrays
+    from ecrad_amd.synthetic import make_columns
+    from ecrad_amd.types import Flux
+    from helpers import make_config
+    config = make_config("Tripleclouds")
+    config.n_g_lw = config.n_g_sw = 32      # (what Flux.allocate needs of a set-up configuration)
+    config.n_bands_lw = config.n_bands_sw = 13
+    n, nlev, sl, th, gas, cloud, aer = make_columns(config, 200, False)
+    flux = Flux.allocate(config, n, nlev)
+    before = {k: v.copy() for k, v in vars(cloud).items() if isinstance(v, np.ndarray)}
+    ranges = []
+
+    def own_pages(a):
+        b, addr, nbytes = page_aligned_empty(a.shape, a.dtype)
+        b[...] = a
+        ranges.append((addr, nbytes, a.nbytes))
+        return b
+
+    moved = relocate_call_arrays(own_pages, (sl, th, gas, cloud, aer, None), flux, min_bytes=1 << 12)
+    assert len(moved) >= 20
+    for addr, nbytes, used in ranges:
+        assert addr % mmap.PAGESIZE == 0 and nbytes % mmap.PAGESIZE == 0 and used <= nbytes < used + mmap.PAGESIZE
+    for k, v in before.items():
+        assert np.array_equal(getattr(cloud, k), v)
+    assert sl.cos_sza.nbytes < 1 << 12 and sl.cos_sza.ctypes.data not in [r[0] for r in ranges]      # a small array: left alone
+    assert all(a.flags.c_contiguous and a.flags.writeable for a in moved)

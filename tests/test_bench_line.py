@@ -85,25 +85,31 @@ def _run_bench(extra_env):
                           text=True, timeout=300)
 
 
-def test_supervisor_restarts_a_run_ended_by_a_signal_and_says_so():
-    """bench.py runs the single-GPU measurement in a watched child (bench.py: supervise): a child ended by SIGABRT -- how a GPU memory fault
-    ends a process -- is started again, twice at most.  Here (no GPU) the attempt that is not aborted by the test hook ends with the
-    'no GPU visible' exit code 2, which is passed on unchanged; three aborted attempts give 134 and no line."""
+def test_a_run_ended_by_a_signal_is_a_failed_bench_with_a_record():
+    """bench.py runs the single-GPU measurement in a watched child (bench.py: supervise) so that a process the runtime aborts still leaves a
+    record -- and a crash is a FAILED bench: no second attempt, one line with `"fault": true` and `"value": null`, exit status 128 + signal.
+    Only with ECRAD_BENCH_RETRY=N (debugging aid) is the run started again; then (no GPU here) the attempt that survives ends with the
+    'no GPU visible' exit code 2, passed on unchanged."""
     import torch
     if torch.cuda.is_available():
         import pytest
         pytest.skip("the CPU form of the check: the surviving attempt is expected to stop at 'no GPU visible'")
-    p = _run_bench({"ECRAD_BENCH_TEST_ABORT_ATTEMPTS": "2"})
+    p = _run_bench({"ECRAD_BENCH_TEST_ABORT_ATTEMPTS": "1"})
+    assert p.returncode == 134, (p.returncode, p.stderr[-500:])
+    assert "attempt 1 ended by signal 6 in phase 'test hook: abort'" in p.stderr and "attempt 2" not in p.stderr
+    line = json.loads(p.stdout.strip().splitlines()[-1], parse_constant=_no_constants)
+    assert line["fault"] is True and line["value"] is None and line["signal"] == 6 and line["last_phase"] == "test hook: abort"
+    p = _run_bench({"ECRAD_BENCH_TEST_ABORT_ATTEMPTS": "2", "ECRAD_BENCH_RETRY": "2"})
     assert p.returncode == 2, (p.returncode, p.stderr[-500:])
-    assert "attempt 1 ended by signal 6 in phase 'test hook: abort'" in p.stderr and "attempt 2 ended by signal 6" in p.stderr
-    assert "no GPU visible" in p.stderr and p.stdout.strip() == ""
-    p = _run_bench({"ECRAD_BENCH_TEST_ABORT_ATTEMPTS": "3"})
-    assert p.returncode == 134 and "three attempts ended by a signal" in p.stderr and p.stdout.strip() == ""
+    assert "attempt 2 ended by signal 6" in p.stderr and "no GPU visible" in p.stderr and p.stdout.strip() == ""
+    p = _run_bench({"ECRAD_BENCH_TEST_ABORT_ATTEMPTS": "3", "ECRAD_BENCH_RETRY": "2"})
+    assert p.returncode == 134 and json.loads(p.stdout.strip().splitlines()[-1])["aborted_attempts"][2]["attempt"] == 3
 
 
 def test_attempts_travel_in_the_line():
     rec = _canned()
     rec["attempts"] = 2
     rec["aborted_attempts"] = [{"attempt": 1, "signal": 6, "last_phase": "tripleclouds_ecckd32: host-memory mode"}]
+    rec["fault"] = True
     out = json.loads(bench.compact_line(rec, "gpurun_out/bench_detail.json"), parse_constant=_no_constants)
-    assert out["attempts"] == 2 and out["aborted_attempts"][0]["signal"] == 6
+    assert out["attempts"] == 2 and out["aborted_attempts"][0]["signal"] == 6 and out["fault"] is True

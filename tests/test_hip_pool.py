@@ -383,43 +383,147 @@ def test_eight_device_slots_mapped_onto_this_gpu(solver, monkeypatch):
     rad.close()
 
 
-@pytest.mark.gpu
-def test_registered_host_arrays_give_the_same_bits():
-    """ecrad_hip_host_register (include/ecrad_hip.h): the caller's arrays page-locked once, the pipelined host-memory call then
-    moves its tiles by the copy engines directly.  Same bits as the call on pageable arrays; bad arguments are a status, not a
-    fault; unregistering gives the memory back."""
-    from ecrad_amd.interface import build_flux_struct, build_inputs_struct, owns_its_pages, private_pages_for_large_arrays
-    private_pages_for_large_arrays()      # (the arrays registered below in pages of their own, not between other heap objects)
-    ncol = 20000
+def _host_call_setup(ncol):
     config = make_config("Tripleclouds")
     n, nlev, sl, th, gas, cloud, aer = make_columns(config, ncol, False)
     frac0 = cloud.fraction.copy()
     rad = Radiation(config, backend="hip")
     ref = Flux.allocate(config, n, nlev)
-    rad.radiation(n, nlev, 1, n, sl, th, gas, cloud, aer, ref)
+    rad.radiation(n, nlev, 1, n, sl, th, gas, cloud, aer, ref)      # pageable arrays: the reference bits
     frac_ref = cloud.fraction.copy()
+    return config, n, nlev, sl, th, gas, cloud, aer, frac0, frac_ref, rad, ref
+
+
+@pytest.mark.gpu
+def test_page_locked_host_arrays_give_the_same_bits():
+    """ecrad_hip_host_alloc / ecrad_hip_host_free (include/ecrad_hip.h): every array of the call in page-locked memory the LIBRARY
+    allocated (ecrad_amd.interface.HostArrays), the pipelined host-memory call then moves its tiles by the copy engines directly.
+    Same bits as the call on pageable arrays; bad arguments are a status, not a fault; freeing gives the memory back."""
+    from ecrad_amd.interface import HostArrays, build_flux_struct, build_inputs_struct, relocate_call_arrays
+    config, n, nlev, sl, th, gas, cloud, aer, frac0, frac_ref, rad, ref = _host_call_setup(20000)
+    lib, h = rad.lib, rad.handle
     cloud.fraction[...] = frac0
     flux = Flux.allocate(config, n, nlev)
+    arena = HostArrays(rad)
+    moved = relocate_call_arrays(arena.copy_of, (sl, th, gas, cloud, aer), flux)
+    assert len(moved) >= 40 and all(a.ctypes.data % 4096 == 0 for a in moved), len(moved)
     cin, keep = build_inputs_struct(config, n, nlev, sl, th, gas, cloud, aer)
     cflux = build_flux_struct(flux)
-    big = [a for a in keep + [cloud.fraction] + list(flux.arrays.values()) if a.nbytes >= (1 << 16)]
-    arrays = [a for a in big if owns_its_pages(a)]      # (the rest -- served from a free chunk of the heap -- stay pageable)
-    assert len(arrays) >= len(big) - 4 and len(arrays) >= 20, (len(arrays), len(big))
+    assert lib.ecrad_hip_radiation(h, n, nlev, 1, n, C.byref(cin), C.byref(cflux)) == 0, lib.ecrad_hip_last_error(h)
+    _flux_equal(ref, flux)
+    assert np.array_equal(cloud.fraction, frac_ref)
+    # memory of the library's own is page-locked already: registering it again is refused, so is freeing what it did not allocate
+    assert lib.ecrad_hip_host_register(h, C.c_void_p(moved[0].ctypes.data), C.c_size_t(4096)) == abi.EINVAL
+    stranger = np.zeros(1 << 14)
+    assert lib.ecrad_hip_host_free(h, C.c_void_p(stranger.ctypes.data)) == abi.EINVAL
+    p = C.c_void_p()
+    assert lib.ecrad_hip_host_alloc(h, C.c_size_t(0), C.byref(p)) == abi.EINVAL
+    got = {k: v.copy() for k, v in flux.arrays.items()}
+    del cin, cflux, keep, moved
+    flux.arrays.clear()
+    arena.close()
+    assert arena.nbytes == 0
+    for k, v in ref.arrays.items():
+        assert np.array_equal(v, got[k], equal_nan=True)
+    rad.close()
+
+
+@pytest.mark.gpu
+def test_registered_host_arrays_give_the_same_bits():
+    """ecrad_hip_host_register / ecrad_hip_host_unregister (include/ecrad_hip.h): arrays the CALLER allocated as whole pages of their
+    own (private mappings: ecrad_amd.interface.page_aligned_empty) page-locked once, same bits as the call on pageable arrays.  The
+    library takes whole pages only: a range that begins inside a page, or ends inside one, or overlaps a registered range, is
+    ECRAD_EINVAL and nothing changes (a heap array shares its first and last page with its neighbours: round 5's GPU memory fault)."""
+    from ecrad_amd.interface import build_flux_struct, build_inputs_struct, page_aligned_empty, relocate_call_arrays
+    config, n, nlev, sl, th, gas, cloud, aer, frac0, frac_ref, rad, ref = _host_call_setup(20000)
     lib, h = rad.lib, rad.handle
-    pinned = [a for a in arrays if lib.ecrad_hip_host_register(h, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes)) == 0]
-    assert len(pinned) == len(arrays), (len(pinned), len(arrays))
-    # (a null range is an argument error; whether a range may be registered twice is the runtime's business -- ROCm 7.2 allows it)
-    assert lib.ecrad_hip_host_register(h, None, C.c_size_t(8)) != 0
+    cloud.fraction[...] = frac0
+    flux = Flux.allocate(config, n, nlev)
+    ranges = []
+
+    def own_pages(a):
+        b, addr, nbytes = page_aligned_empty(a.shape, a.dtype)
+        b[...] = a
+        ranges.append((addr, nbytes))
+        return b
+
+    moved = relocate_call_arrays(own_pages, (sl, th, gas, cloud, aer), flux)
+    assert len(moved) >= 40
+    cin, keep = build_inputs_struct(config, n, nlev, sl, th, gas, cloud, aer)
+    cflux = build_flux_struct(flux)
+    # what the library refuses, before anything is registered and after
+    addr0, nbytes0 = ranges[0]
+    assert lib.ecrad_hip_host_register(h, None, C.c_size_t(4096)) == abi.EINVAL
+    assert lib.ecrad_hip_host_register(h, C.c_void_p(addr0 + 16), C.c_size_t(nbytes0 - 4096)) == abi.EINVAL      # begins inside a page
+    assert lib.ecrad_hip_host_register(h, C.c_void_p(addr0), C.c_size_t(nbytes0 - 8)) == abi.EINVAL              # ends inside a page
+    assert b"whole pages" in lib.ecrad_hip_last_error(h)
+    heap = np.zeros(100000)      # an array wherever the allocator put it
+    assert lib.ecrad_hip_host_register(h, C.c_void_p(heap.ctypes.data), C.c_size_t(heap.nbytes)) == abi.EINVAL
+    for addr, nbytes in ranges:
+        assert lib.ecrad_hip_host_register(h, C.c_void_p(addr), C.c_size_t(nbytes)) == 0, lib.ecrad_hip_last_error(h)
+    assert lib.ecrad_hip_host_register(h, C.c_void_p(addr0), C.c_size_t(nbytes0)) == abi.EINVAL                 # registered already
+    assert lib.ecrad_hip_host_register(h, C.c_void_p(addr0 + 4096), C.c_size_t(4096)) == abi.EINVAL             # inside a registered range
     try:
         assert lib.ecrad_hip_radiation(h, n, nlev, 1, n, C.byref(cin), C.byref(cflux)) == 0, lib.ecrad_hip_last_error(h)
     finally:
-        for a in pinned:
-            assert lib.ecrad_hip_host_unregister(h, C.c_void_p(a.ctypes.data)) == 0
-    unknown = np.zeros(1 << 14)
-    assert lib.ecrad_hip_host_unregister(h, C.c_void_p(unknown.ctypes.data)) != 0      # never registered: a status, not a fault
-    assert b"hipHostUnregister" in lib.ecrad_hip_last_error(h)
+        assert lib.ecrad_hip_host_unregister(h, C.c_void_p(addr0 + 4096)) == abi.EINVAL      # not the start of a range
+        for addr, nbytes in ranges:
+            assert lib.ecrad_hip_host_unregister(h, C.c_void_p(addr)) == 0
+    assert lib.ecrad_hip_host_unregister(h, C.c_void_p(addr0)) == abi.EINVAL                  # never registered (any more): a status, not a fault
+    assert b"ecrad_hip_host_unregister" in lib.ecrad_hip_last_error(h)
     _flux_equal(ref, flux)
     assert np.array_equal(cloud.fraction, frac_ref)
+    rad.close()
+
+
+@pytest.mark.gpu
+def test_unregister_waits_for_the_calls_in_flight():
+    """One thread makes six calls back to back on registered arrays while another unregisters every range: each release waits until no
+    call of the handle is in flight (include/ecrad_hip.h), the calls that follow find some of their arrays pageable again -- the bits of
+    every call are those of the undisturbed call, nothing faults."""
+    from ecrad_amd.interface import build_flux_struct, build_inputs_struct, page_aligned_empty, relocate_call_arrays
+    config, n, nlev, sl, th, gas, cloud, aer, frac0, frac_ref, rad, ref = _host_call_setup(20000)
+    lib, h = rad.lib, rad.handle
+    cloud.fraction[...] = frac0
+    flux = Flux.allocate(config, n, nlev)
+    ranges = []
+
+    def own_pages(a):
+        b, addr, nbytes = page_aligned_empty(a.shape, a.dtype)
+        b[...] = a
+        ranges.append((addr, nbytes))
+        return b
+
+    relocate_call_arrays(own_pages, (sl, th, gas, cloud, aer), flux)
+    frac_pages = cloud.fraction
+    cin, keep = build_inputs_struct(config, n, nlev, sl, th, gas, cloud, aer)
+    cflux = build_flux_struct(flux)
+    for addr, nbytes in ranges:
+        assert lib.ecrad_hip_host_register(h, C.c_void_p(addr), C.c_size_t(nbytes)) == 0
+    failures = []
+    under_way = threading.Event()
+
+    def caller():
+        for k in range(6):
+            frac_pages[...] = frac0
+            for a in flux.arrays.values():
+                a[...] = -7.0
+            under_way.set()
+            if lib.ecrad_hip_radiation(h, n, nlev, 1, n, C.byref(cin), C.byref(cflux)) != 0:
+                failures.append((k, lib.ecrad_hip_last_error(h)))
+            for name, r in ref.arrays.items():
+                if not np.array_equal(r, flux.arrays[name], equal_nan=True):
+                    failures.append((k, name))
+            if not np.array_equal(frac_pages, frac_ref):
+                failures.append((k, "cloud fraction"))
+
+    t = threading.Thread(target=caller)
+    t.start()
+    under_way.wait()
+    released = [lib.ecrad_hip_host_unregister(h, C.c_void_p(addr)) for addr, _ in ranges]
+    t.join()
+    assert released == [0] * len(ranges)
+    assert not failures, failures
     rad.close()
 
 
