@@ -480,6 +480,70 @@ def timed_steps(w, steps, warmup, barrier, gather_world=0):
             gc.enable()
 
 
+LIBRARY_GATHER_HUNG = False      # set when the library's RCCL gather did not come back: the process then leaves through os._exit after its line
+
+
+def library_gather_leg(w, world, rank, steps, barrier, allreduce_max, timeout=180.0):
+    """The same K steps with the profiles put together on rank 0 by the LIBRARY's own gather (include/ecrad_hip.h: ecrad_hip_comm_init,
+    ecrad_hip_gather_profiles: RCCL directly, what a Fortran host with one rank per GPU calls) instead of torch.distributed.  Rank 0's id
+    travels to the other ranks over the process group that is there anyway (an MPI host would MPI_Bcast it).  The result is compared with
+    what torch's gather delivered.  Runs in a thread with a deadline: multi-rank RCCL cannot be tried on the one-GPU boxes this was built
+    on (RCCL refuses two ranks on one device), so a communicator that never forms must not cost the run its line -- after `timeout`
+    seconds the record says so and the process ends without waiting for the stuck thread."""
+    import threading
+    import torch
+    box = {}
+
+    def body():
+        try:
+            from ecrad_amd.parallel import library_comm_init, library_gather_profiles
+
+            def bcast(b):
+                if world == 1:
+                    return b
+                import torch.distributed as dist
+                obj = [b]
+                dist.broadcast_object_list(obj, src=0)
+                return obj[0]
+            library_comm_init(w.rad, rank, world, bcast)
+            names, nrows = w.profile_names, w.nlev + 1
+            local = [w.case.flux_tensors[n] for n in names]
+            assert all(t.is_contiguous() and tuple(t.shape) == (nrows, w.ncol) for t in local)
+            glob = torch.zeros((len(names), nrows, world * w.ncol), dtype=torch.float64, device=local[0].device) if rank == 0 else None
+            lp = [t.data_ptr() for t in local]
+            gp = [glob[i].data_ptr() for i in range(len(names))] if rank == 0 else None
+
+            def step():
+                w.step(0)
+                library_gather_profiles(w.rad, None, [w.ncol] * world, root=0, rank=rank, device_pointers=(lp, gp, nrows))
+            step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            barrier()
+            e = allreduce_max(time.perf_counter() - t0)
+            rec = {"value": world * w.ncol * steps / e, "ms_per_step": 1e3 * e / steps, "how": "ecrad_hip_gather_profiles (librccl, no torch on the data path)"}
+            if rank == 0:
+                rec["own_share_intact"] = bool(all(torch.equal(glob[i][:, :w.ncol], local[i]) for i in range(len(names))))
+                if getattr(w, "gathered", None) is not None and len(w.gathered) == world:
+                    rec["same_as_torch_gather"] = bool(all(torch.equal(glob[:, :, r * w.ncol:(r + 1) * w.ncol], w.gathered[r][..., :w.ncol].to(glob.device))
+                                                           for r in range(world)))
+            w.rad.lib.ecrad_hip_comm_destroy(w.rad.handle)
+            box["rec"] = rec
+        except Exception as e:
+            box["rec"] = {"error": f"{type(e).__name__}: {e}"}
+
+    t = threading.Thread(target=body, daemon=True)
+    t.start()
+    t.join(timeout)
+    if t.is_alive():
+        global LIBRARY_GATHER_HUNG
+        LIBRARY_GATHER_HUNG = True
+        return {"error": f"no completion within {timeout:.0f} s (rank {rank}); the line above it is unaffected"}
+    return box["rec"]
+
+
 def roofline_of(w, stage_ms, elapsed_per_step_s):
     """HIP events on the launch stream bracket the LW and SW stages of a call (ecrad_hip_last_stage_ms); the dominant
     one is priced against SURVEY 8(d)'s algorithmic bytes of that stage."""
@@ -654,10 +718,11 @@ def check_parity_single(w, inputs):
                "median_hip": float(np.median(eh)), "median_oracle_float": float(np.median(eo)),
                "nonfinite_columns_hip": int(np.isinf(eh).sum()), "nonfinite_columns_oracle_float": int(np.isinf(eo).sum())}
         # (a NaN / Inf column counts as "off" on either side; on top of that the GPU may not produce more of them than the
-        #  oracle's float build does -- which columns they are depends on the last bit, how many does not)
+        #  oracle's float build -- the reference's own arithmetic -- does.  Since round 6 the float instantiation of the HIP shortwave
+        #  solver keeps its albedo matrices within [0, 1] (kernel_spartacus.hip, section 4.1) and produces none on the synthetic workload)
         rec["ok"] = bool(rec["columns_off_hip"] <= 1.5 * rec["columns_off_oracle_float"] + 1.0e-4 * nchk + 1
                          and rec["median_hip"] <= 2.0 * rec["median_oracle_float"] + 1.0e-7
-                         and rec["nonfinite_columns_hip"] <= 1.5 * rec["nonfinite_columns_oracle_float"] + 2)
+                         and rec["nonfinite_columns_hip"] <= rec["nonfinite_columns_oracle_float"])
         ok = ok and rec["ok"]
         fields[name] = rec
     worst = max(fields, key=lambda k: fields[k]["columns_off_hip"])
@@ -772,6 +837,45 @@ def end_to_end_host(w, gpu_resident_value, repeats=3):
             "fraction_of_min_ceiling_and_value": value / min(ceiling, gpu_resident_value),
             "note": "ECRAD_MEM_HOST: pageable host arrays; copy-in, kernels and copy-out of consecutive column tiles overlap on three "
                     "streams (PCIe-inclusive); never `value`"}
+
+
+class HostOnlyWorkload:
+    """What end_to_end_host needs of a Workload, without a device batch and without torch: the configuration, the library, the columns on
+    the host (the same seeded columns as the timed workload: ecrad_amd/synthetic.py)."""
+
+    def __init__(self, name, ncol):
+        from ecrad_amd.interface import Radiation
+        from ecrad_amd.synthetic import make_columns
+        self.name, self.ncol = name, ncol
+        self.config, self.clear_sky, self.desc = build_config(name)
+        self.rad = Radiation(self.config, backend="hip")
+        self.host_inputs = make_columns(self.config, ncol, self.clear_sky)
+
+
+def host_mode_child(name, ncol, gpu_resident_value, timeout=600):
+    """end_to_end_host in a child process that never imports torch (ECRAD_BENCH_HOST_CHILD); returns its record or {"error": ...}."""
+    import subprocess
+    env = dict(os.environ, ECRAD_BENCH_HOST_CHILD=f"{name}:{ncol}:{gpu_resident_value!r}")
+    env.pop("ECRAD_BENCH_WORKER", None)
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=timeout)
+        if p.returncode != 0:
+            return {"error": f"child exit {p.returncode}: {p.stderr[-300:]}"}
+        return json.loads(p.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def host_mode_child_main(spec):
+    name, ncol, value = spec.split(":")
+    assert "torch" not in sys.modules
+    w = HostOnlyWorkload(name, int(ncol))
+    r = end_to_end_host(w, float(value))
+    assert "torch" not in sys.modules, "the host-only child must not load PyTorch's copy of the HIP runtime"
+    r["hip_runtime"] = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln})
+    r["process"] = "host-only child: libecrad_hip.so with /opt/rocm's HIP runtime, no PyTorch in the process (what a Fortran host loads)"
+    w.rad.close()
+    print(json.dumps(_finite(r), allow_nan=False), flush=True)
 
 
 def small_blocks(name, nblock=80, nthreads=16, contexts=16, blocks_per_thread=32):
@@ -965,6 +1069,13 @@ def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allredu
         if rank == 0:      # rank 0 holds every rank's profiles: (ranks, fields, half levels, columns per rank)
             res["gathered"] = {"ranks": len(w.gathered), "shape_per_rank": list(w.gathered[0].shape), "fields": w.profile_names,
                                "bytes_received": int(sum(b.numel() * b.element_size() for b in w.gathered[1:]))}
+        if os.environ.get("ECRAD_BENCH_TEST_SHARED_GPU") != "1" and os.environ.get("ECRAD_BENCH_NO_LIBRARY_GATHER") != "1":
+            progress(f"{name}: library gather")
+            res["library_gather"] = library_gather_leg(w, world, rank, steps, barrier, allreduce_max)
+            if LIBRARY_GATHER_HUNG:
+                return res      # (the stuck thread holds the context: closing the workload would wait for it)
+    if world == 1 and os.environ.get("ECRAD_BENCH_FORCE_LIBRARY_GATHER") == "1":      # (tests: the leg on a one-rank communicator)
+        res["library_gather"] = library_gather_leg(w, 1, 0, steps, barrier, allreduce_max)
     if do_cpu and rank == 0:
         progress(f"{name}: cpu baseline")
         w.step()
@@ -983,7 +1094,20 @@ def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allredu
             res["parity"] = with_stdout_on_stderr(check_parity, w, oracle_flux, inputs_all)
     if do_host_mode and rank == 0 and w.host_inputs is not None:
         progress(f"{name}: host-memory mode")
-        res["end_to_end_host"] = end_to_end_host(w, res["value"] / world)
+        # In THIS process the HIP runtime is the copy PyTorch bundles (it is imported first: tests/conftest.py), under which two page-locked
+        # copies in opposite directions share ONE direction's rate (57 GB/s together on the round-6 boxes) and pageable copies stage slowly.
+        # A Fortran host has /opt/rocm's runtime: both directions at once reach 97 GB/s there (profiles/NOTES_r06.md section 3).  So the
+        # figure of record comes from a child process that never loads torch -- the library as its real callers load it -- and the
+        # in-process figure stays next to it.
+        here = end_to_end_host(w, res["value"] / world)
+        child = host_mode_child(name, w.ncol, res["value"] / world)
+        if child is not None and "value" in child:
+            child["under_pytorch_runtime"] = {k: here.get(k) for k in ("value", "ms_per_call", "pcie_gbs", "pcie_ceiling_columns_per_s")}
+            child["under_pytorch_runtime"]["page_locked_value"] = (here.get("registered_host_arrays") or {}).get("value")
+            res["end_to_end_host"] = child
+        else:
+            here["host_only_child"] = child
+            res["end_to_end_host"] = here
     progress(f"{name}: close")
     w.close()
     progress(f"{name}: done")
@@ -1052,7 +1176,7 @@ def compact_line(out, detail_path=None):
     out = _finite(out)
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
                                  "scaling", "vs_baseline", "dtype", "data", "config") if k in out}
-    for k in ("ms_per_step_ranks", "value_with_gather", "ms_per_step_with_gather", "gathered", "mode", "test_shared_gpu",
+    for k in ("ms_per_step_ranks", "value_with_gather", "ms_per_step_with_gather", "gathered", "library_gather", "mode", "test_shared_gpu",
               "test_fake_devices", "blocks_identical_across_devices", "pool", "attempts", "aborted_attempts", "fault"):
         if k in out:
             line[k] = out[k]
@@ -1065,6 +1189,9 @@ def compact_line(out, detail_path=None):
     if "end_to_end_host" in out:
         e = out["end_to_end_host"]
         line["end_to_end_host"] = {k: e[k] for k in ("value", "unit", "pcie_ceiling_columns_per_s") if k in e}
+        if "under_pytorch_runtime" in e:
+            line["end_to_end_host"]["runtime"] = "/opt/rocm (host-only child)"
+            line["end_to_end_host"]["value_under_pytorch_runtime"] = e["under_pytorch_runtime"].get("value")
         if isinstance(e.get("registered_host_arrays"), dict) and "value" in e["registered_host_arrays"]:
             line["end_to_end_host"]["registered_value"] = e["registered_host_arrays"]["value"]
     if "workloads" in out:
@@ -1079,6 +1206,8 @@ def compact_line(out, detail_path=None):
                 rec["kernel_ms"] = r["roofline"]["kernel_ms"]
             if "parity" in r:
                 rec["parity_ok"] = r["parity"]["ok"]
+                if "nonfinite" in r["parity"]:      # single precision: columns with a non-finite flux, HIP / the oracle's float build
+                    rec["nonfinite_columns"] = {"hip": r["parity"]["nonfinite"]["columns_hip"], "oracle_float": r["parity"]["nonfinite"]["columns_oracle_float"]}
             if "cpu_baseline" in r:
                 rec["cpu"] = r["cpu_baseline"].get("value")
             wl[name] = rec
@@ -1158,6 +1287,8 @@ def supervise():
 
 def main():
     os.environ.setdefault("GFORTRAN_UNBUFFERED_ALL", "1")
+    if os.environ.get("ECRAD_BENCH_HOST_CHILD"):
+        return host_mode_child_main(os.environ["ECRAD_BENCH_HOST_CHILD"])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -1253,7 +1384,7 @@ def main():
     }
     if shared:
         out["test_shared_gpu"] = "ranks share the visible GPU(s) over gloo: exercises the N>1 code only, not a measurement"
-    for k in ("ms_per_step_ranks", "value_with_gather", "ms_per_step_with_gather", "gathered", "cpu_baseline", "parity", "end_to_end_host"):
+    for k in ("ms_per_step_ranks", "value_with_gather", "ms_per_step_with_gather", "gathered", "library_gather", "cpu_baseline", "parity", "end_to_end_host"):
         if k in head:
             out[k] = head[k]
     failed = "parity" in head and not head["parity"]["ok"]
@@ -1290,6 +1421,8 @@ def main():
         if failed and "parity" in head and not head["parity"]["ok"]:
             out["value"] = None
         emit(out)
+    if LIBRARY_GATHER_HUNG:
+        os._exit(1 if failed else 0)      # (a thread is stuck in RCCL: no barrier, no clean-up)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

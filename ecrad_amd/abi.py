@@ -12,6 +12,7 @@ NMAXGASES = 12
 NMAXCLOUDTYPES = 12
 
 MEM_HOST, MEM_DEVICE = 0, 1
+COMM_ID_BYTES = 128
 OK, EINVAL, ENODEVICE, EUNSUPPORTED, EHIP, ENOMEM, ENOTSETUP = 0, -1, -2, -3, -4, -5, -6      # include/ecrad_hip.h:42-48
 
 c_double_p = C.POINTER(C.c_double)
@@ -255,6 +256,14 @@ def declare_prototypes(lib) -> None:
     lib.ecrad_hip_radiation.restype = C.c_int
     lib.ecrad_hip_radiation_f32.argtypes = lib.ecrad_hip_radiation.argtypes      # (same structs, float arrays behind the pointers)
     lib.ecrad_hip_radiation_f32.restype = C.c_int
+    lib.ecrad_hip_comm_id.argtypes = [H, C.c_void_p]
+    lib.ecrad_hip_comm_id.restype = C.c_int
+    lib.ecrad_hip_comm_init.argtypes = [H, C.c_void_p, C.c_int, C.c_int]
+    lib.ecrad_hip_comm_init.restype = C.c_int
+    lib.ecrad_hip_gather_profiles.argtypes = [H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]
+    lib.ecrad_hip_gather_profiles.restype = C.c_int
+    lib.ecrad_hip_comm_destroy.argtypes = [H]
+    lib.ecrad_hip_comm_destroy.restype = C.c_int
     lib.ecrad_hip_host_alloc.argtypes = [H, C.c_size_t, C.POINTER(C.c_void_p)]
     lib.ecrad_hip_host_alloc.restype = C.c_int
     lib.ecrad_hip_host_free.argtypes = [H, C.c_void_p]
@@ -306,5 +315,5 @@ EXPORTED_SYMBOLS = [
     "ecrad_hip_scratch_bytes", "ecrad_hip_last_error", "ecrad_hip_destroy",
     "ecrad_hip_abi_sizeof", "ecrad_hip_abi_version", "ecrad_hip_set_work_bytes", "ecrad_hip_last_call_info",
     "ecrad_hip_hbm_triad", "ecrad_hip_hbm_rates", "ecrad_hip_set_concurrency", "ecrad_hip_pool_info", "ecrad_hip_pool_reset",
-    "ecrad_hip_pcie_bandwidth", "ecrad_hip_radiation_f32", "ecrad_hip_host_alloc", "ecrad_hip_host_free", "ecrad_hip_host_register", "ecrad_hip_host_unregister",
+    "ecrad_hip_pcie_bandwidth", "ecrad_hip_radiation_f32", "ecrad_hip_comm_id", "ecrad_hip_comm_init", "ecrad_hip_gather_profiles", "ecrad_hip_comm_destroy", "ecrad_hip_host_alloc", "ecrad_hip_host_free", "ecrad_hip_host_register", "ecrad_hip_host_unregister",
 ]

@@ -122,10 +122,19 @@ int ecrad_hip_radiation_f32(ecrad_hip_handle_t h, int ncol, int nlev, int istart
   din.sw_albedo = s.sw_albedo; din.sw_albedo_direct = s.sw_albedo_direct; din.lw_emissivity = s.lw_emissivity;
   din.iseed = in->iseed ? in->iseed + i0 : nullptr;      // (integers: the caller's own, from the first column of the range)
   din.gas_mixing_ratio = s.gas_mixing_ratio;
-  din.cloud_fraction = s.cloud_fraction; din.cloud_mixing_ratio = s.cloud_mixing_ratio;
-  din.cloud_effective_radius = s.cloud_effective_radius; din.cloud_fractional_std = s.cloud_fractional_std;
-  din.cloud_overlap_param = s.cloud_overlap_param; din.cloud_inv_cloud_effective_size = s.cloud_inv_cloud_effective_size;
-  din.cloud_inv_inhom_effective_size = s.cloud_inv_inhom_effective_size; din.aerosol_mixing_ratio = s.aerosol_mixing_ratio;
+  // (an array the caller did not pass stays null, so that the call proper reports it -- plan_inputs: ECRAD_EINVAL -- instead of
+  //  reading whatever the slab holds from an earlier call)
+  auto same = [](const double* callers, double* slab_p) -> double* { return callers ? slab_p : nullptr; };
+  din.h2o_sat_liq = same(in->h2o_sat_liq, s.h2o_sat_liq);
+  din.sw_albedo = same(in->sw_albedo, s.sw_albedo); din.sw_albedo_direct = same(in->sw_albedo_direct, s.sw_albedo_direct);
+  din.lw_emissivity = same(in->lw_emissivity, s.lw_emissivity);
+  din.cloud_fraction = same(in->cloud_fraction, s.cloud_fraction); din.cloud_mixing_ratio = same(in->cloud_mixing_ratio, s.cloud_mixing_ratio);
+  din.cloud_effective_radius = same(in->cloud_effective_radius, s.cloud_effective_radius);
+  din.cloud_fractional_std = same(in->cloud_fractional_std, s.cloud_fractional_std);
+  din.cloud_overlap_param = same(in->cloud_overlap_param, s.cloud_overlap_param);
+  din.cloud_inv_cloud_effective_size = same(in->cloud_inv_cloud_effective_size, s.cloud_inv_cloud_effective_size);
+  din.cloud_inv_inhom_effective_size = same(in->cloud_inv_inhom_effective_size, s.cloud_inv_inhom_effective_size);
+  din.aerosol_mixing_ratio = same(in->aerosol_mixing_ratio, s.aerosol_mixing_ratio);
   // RRTMG's per-band scaling of the solar spectrum is a small array without a column dimension: widened whole
   thread_local std::vector<double> scaling;
   if (in->spectral_solar_scaling) {

@@ -94,6 +94,7 @@ struct ecrad_hip_handle_s {
   // device, ordered by the caller's stream) runs on the root.  ecrad_hip_set_concurrency / ECRAD_HIP_DEVICES /
   // ECRAD_HIP_CONTEXTS size the pool.  Everything below "pool" is used on the root only.
   ecrad_hip_handle_s* root = nullptr;            // the handle the caller holds (the root points at itself)
+  uint64_t generation = 0;                       // unique per ecrad_hip_create over the life of the process (see CallRecord::is_of)
   ecrad_hip_handle_s* table_owner = nullptr;     // the context of this device whose set-up uploaded the tables
   bool busy = false;                             // a call is running on this context (guarded by root->pool_mutex)
   bool small_batch = false;                      // ... and it is a batch of small calls
@@ -119,6 +120,9 @@ struct ecrad_hip_handle_s {
   hipStream_t in_streams[kMaxCopyThreads] = {}, out_streams[kMaxCopyThreads] = {};
   hipEvent_t ev_in[kMaxCopyThreads][kStageSlots] = {}, ev_comp[kStageSlots] = {nullptr, nullptr, nullptr};
   HostBuf pin_in, pin_out;                       // page-locked mirrors of the staged inputs / outputs of a small call
+  void* comm = nullptr;                          // RCCL communicator of the multi-GPU gather (comm.hip; root only), ncclComm_t
+  int comm_rank = 0, comm_world = 0;
+  Buf comm_send, comm_recv;                      // device staging of ecrad_hip_gather_profiles
   // The McICA cloud generators need the cropped cloud fraction and nothing else, and are bound by integer instruction
   // issue: they run on a second stream next to the gas-optics pass (RRTMG) / the other spectrum's solver kernel and
   // join the main stream before the solver that reads their optical-depth scalings (fork after crop, join by events)
@@ -194,6 +198,8 @@ int fail(ecrad_hip_handle_t h, int code, const std::string& msg);
 // device-memory calls are serialised on and whose stream order is the caller's.
 struct CallRecord {
   const ecrad_hip_handle_s* root = nullptr;      // the handle the call was made on
+  uint64_t generation = 0;                       // ... and its generation: a later handle allocated at the same address is another handle
+  bool is_of(const ecrad_hip_handle_s* h) const;
   ecrad_hip_handle_s* pending = nullptr;         // device-memory call: the context (the root) whose events are still to be read
   std::string err;
   int n_tiles = 0, tile_columns = 0;
@@ -201,6 +207,7 @@ struct CallRecord {
   double stage_ms[4] = {0, 0, 0, 0}, last_ms = 0.0;
 };
 extern thread_local CallRecord tl_record;
+inline bool CallRecord::is_of(const ecrad_hip_handle_s* h) const { return root == h && generation == h->generation; }
 
 // ---- pool.hip
 bool in_pool(ecrad_hip_handle_t root, const ecrad_hip_handle_s* c);

@@ -697,6 +697,22 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
         ta_below = add(refl, sp::mul(tran, sp::solve(fd, sp::mul(ta, tran))));
         tad_below = add(rdir, sp::mul(tran, sp::solve(fd, add(sp::mul(tad, tdir), sp::mul(ta, tdd)))));
       }
+      // SINGLE PRECISION ONLY: the entries of the two albedo matrices are fractions of the incident flux -- within [0, 1] and [0, mu0] in
+      // exact arithmetic, like the layer's own reflectance / transmittance matrices, which the reference clamps to those ranges
+      // (radiation_spartacus_sw.F90:893-915).  In single precision the matrix adding above leaves the range in strongly absorbing g-points
+      // under tens of partly cloudy layers (the reference warns: radiation_config.F90:1144-1148): an albedo of -0.9 then meets the 1e-8
+      // floor of `top_albedo` in step_migrations, the migration distance grows by 1e8 per layer and the column is NaN from the top of the
+      // atmosphere down four layers later (oracle trace of column 3569 of the synthetic workload, g-point 17: profiles/NOTES_r06.md section 4).
+      // Held to their range here, the matrices stay what they mean; the double-precision instantiation is untouched (bit for bit).
+      if constexpr (sizeof(R) == 4) {
+        if (!clr) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            ta_below.a[k] = rmin(R(1), rmax(R(0), ta_below.a[k]));
+            tad_below.a[k] = rmin(mu0, rmax(R(0), tad_below.a[k]));
+          }
+        }
+      }
       // -- section 4.2: overlap and entrapment --
       if (explicit_entr && jlev >= i_cloud_top)
         step_migrations<R>(R(fracv.p[fracv.stride * ord.full(jl)]), layer_depth, tan_diffuse_angle_3d, tan_sza, refl, tran, rdir, tdir, tdd,

@@ -1,6 +1,7 @@
 // pool.hip -- the handle behind the C-ABI and its pool of contexts (host_internal.h): creation and destruction, the leases of
 // concurrent calls, the per-thread call records and the queries that answer from them.
 #include "host_internal.h"
+#include <atomic>
 
 using namespace ecrad;
 using namespace ecrad_host;
@@ -48,6 +49,7 @@ int resolve_timing(ecrad_hip_handle_s* c, double stage_ms[4], double* total) {
 CallRecord take_record(ecrad_hip_handle_t root, ecrad_hip_handle_s* c, bool complete) {
   CallRecord r;
   r.root = root;
+  r.generation = root->generation;
   r.err = c->err;
   r.n_tiles = c->tiles_last_call;
   r.tile_columns = c->tile_columns_last_call;
@@ -67,6 +69,7 @@ CallRecord take_record(ecrad_hip_handle_t root, ecrad_hip_handle_s* c, bool comp
 int fail_call(ecrad_hip_handle_t h, int code, const std::string& msg) {
   tl_record = CallRecord{};
   tl_record.root = h;
+  tl_record.generation = h->generation;
   tl_record.err = msg;
   return code;
 }
@@ -230,6 +233,8 @@ int ecrad_hip_create(ecrad_hip_handle_t* handle, int device_id) {
   if (device_id >= n) return ECRAD_ENODEVICE;
   if (hipSetDevice(device_id) != hipSuccess) return ECRAD_ENODEVICE;
   ecrad_hip_handle_t h = new ecrad_hip_handle_s();
+  static std::atomic<uint64_t> generations{0};
+  h->generation = ++generations;
   h->root = h;
   h->device = device_id;
   h->slot = device_id;
@@ -300,7 +305,7 @@ const char* ecrad_hip_last_error(ecrad_hip_handle_t h) {
   if (!h) return "null handle";
   // the calling thread's own most recent call first; otherwise the root's text (set-up, the root context's calls) unless
   // another thread's call is on the root context right now
-  if (tl_record.root == h && !tl_record.err.empty()) return tl_record.err.c_str();
+  if (tl_record.is_of(h) && !tl_record.err.empty()) return tl_record.err.c_str();
   thread_local std::string text;
   {
     std::lock_guard<std::mutex> lk(h->pool_mutex);
@@ -345,6 +350,7 @@ extern "C" {
 
 int ecrad_hip_destroy(ecrad_hip_handle_t h) {
   if (!h) return ECRAD_EINVAL;
+  if (h->comm) (void)ecrad_hip_comm_destroy(h);
   unregister_handle(h);
   {
     const LeaseAll all(h);      // (waits for the calls in flight)
@@ -352,7 +358,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
     for (size_t k = h->pool.size(); k-- > 1;) { release_context_memory(h->pool[k]); delete h->pool[k]; }
     h->pool.clear();
     release_context_memory(h);
-    if (tl_record.root == h) tl_record = CallRecord{};
+    if (tl_record.is_of(h)) tl_record = CallRecord{};
   }
   delete h;
   return ECRAD_OK;
@@ -360,7 +366,7 @@ int ecrad_hip_destroy(ecrad_hip_handle_t h) {
 
 int ecrad_hip_scratch_bytes(ecrad_hip_handle_t h, size_t* bytes) {
   if (!h || !bytes) return ECRAD_EINVAL;
-  if (tl_record.root == h) { *bytes = tl_record.work_bytes; return ECRAD_OK; }      // (of the context this thread's last call ran on)
+  if (tl_record.is_of(h)) { *bytes = tl_record.work_bytes; return ECRAD_OK; }      // (of the context this thread's last call ran on)
   std::lock_guard<std::mutex> lk(h->pool_mutex);
   *bytes = h->busy ? 0 : held_bytes(h);
   return ECRAD_OK;
@@ -380,10 +386,20 @@ int ecrad_hip_synchronize(ecrad_hip_handle_t h) {
 int ecrad_hip_last_kernel_ms(ecrad_hip_handle_t h, double* ms) {
   if (!h || !ms) return ECRAD_EINVAL;
   CallRecord& r = tl_record;      // this thread's most recent call (see CallRecord)
-  if (r.root != h) { *ms = 0.0; return ECRAD_OK; }
+  if (!r.is_of(h)) { *ms = 0.0; return ECRAD_OK; }
   if (r.pending) {                // a device-memory call: its events are read now (waits for them)
     ecrad_hip_handle_s* const c = r.pending;
     r.pending = nullptr;
+    // (on the root context, held like a device-memory call holds it: no other thread's call resizes its event table meanwhile)
+    struct RootHold {      // (not a Lease: a query is not a call and does not count as one in ecrad_hip_pool_info)
+      ecrad_hip_handle_s* root;
+      explicit RootHold(ecrad_hip_handle_s* r) : root(r) {
+        std::unique_lock<std::mutex> lk(root->pool_mutex);
+        root->pool_cv.wait(lk, [&] { return !root->busy && !root->exclusive; });
+        root->busy = true;
+      }
+      ~RootHold() { { std::lock_guard<std::mutex> lk(root->pool_mutex); root->busy = false; } root->pool_cv.notify_all(); }
+    } const hold(h);
     if (resolve_timing(c, r.stage_ms, &r.last_ms) != ECRAD_OK) return fail_call(h, ECRAD_EHIP, "reading the stage events of the last call");
     c->timing_pending = false;
     (void)hipSetDevice(h->device);
@@ -397,7 +413,7 @@ int ecrad_hip_last_stage_ms(ecrad_hip_handle_t h, int which, double* ms) {
   double total;
   int st = ecrad_hip_last_kernel_ms(h, &total);
   if (st) return st;
-  *ms = tl_record.root == h ? tl_record.stage_ms[which] : 0.0;
+  *ms = tl_record.is_of(h) ? tl_record.stage_ms[which] : 0.0;
   return ECRAD_OK;
 }
 
@@ -423,7 +439,7 @@ extern "C" {
 int ecrad_hip_last_call_info(ecrad_hip_handle_t h, ecrad_call_info_t* info) {
   if (!h || !info) return ECRAD_EINVAL;
   const CallRecord& r = tl_record;      // this thread's most recent call (zeros if it has made none on this handle)
-  const bool mine = r.root == h;
+  const bool mine = r.is_of(h);
   info->n_tiles = mine ? r.n_tiles : 0;
   info->tile_columns = mine ? r.tile_columns : 0;
   info->launches_lw = h->cfg.do_lw ? h->nchunk_lw : 0;

@@ -191,6 +191,35 @@ module ecrad_hip_binding
       type(ecrad_flux_t), intent(inout) :: flux
       integer(c_int) :: status
     end function
+    ! multi-GPU (one rank per GPU): the gather of flux profiles over RCCL (include/ecrad_hip.h); the host distributes the 128-byte id
+    ! of rank 0 itself (MPI_Bcast)
+    function ecrad_hip_comm_id(handle, id) bind(C, name='ecrad_hip_comm_id') result(status)
+      import :: c_ptr, c_int, c_signed_char
+      type(c_ptr), value :: handle
+      integer(c_signed_char), intent(out) :: id(128)
+      integer(c_int) :: status
+    end function
+    function ecrad_hip_comm_init(handle, id, rank, world) bind(C, name='ecrad_hip_comm_init') result(status)
+      import :: c_ptr, c_int, c_signed_char
+      type(c_ptr), value :: handle
+      integer(c_signed_char), intent(in) :: id(128)
+      integer(c_int), value :: rank, world
+      integer(c_int) :: status
+    end function
+    function ecrad_hip_gather_profiles(handle, n_fields, local, global, n_rows, ncol_local, ncol_of_rank, root, memory) &
+         &  bind(C, name='ecrad_hip_gather_profiles') result(status)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: handle
+      integer(c_int), value :: n_fields, n_rows, ncol_local, root, memory
+      type(c_ptr), intent(in) :: local(*), global(*)      ! c_loc of every field's array
+      integer(c_int), intent(in) :: ncol_of_rank(*)
+      integer(c_int) :: status
+    end function
+    function ecrad_hip_comm_destroy(handle) bind(C, name='ecrad_hip_comm_destroy') result(status)
+      import :: c_ptr, c_int
+      type(c_ptr), value :: handle
+      integer(c_int) :: status
+    end function
     ! page-locked host memory (optional; include/ecrad_hip.h): the library's own -- map it onto an array pointer with
     ! c_f_pointer(p, array, shape) -- or whole pages of the host's own memory registered
     function ecrad_hip_host_alloc(handle, bytes, p) bind(C, name='ecrad_hip_host_alloc') result(status)

@@ -56,6 +56,64 @@ def assemble(bufs, counts: List[int]):
     return torch.cat([b[..., :n] for b, n in zip(bufs, counts)], dim=-1)
 
 
+def gather_offsets(counts: List[int]):
+    """Column offset of every rank's share in the gathered arrays (rank r's columns follow those of ranks 0 .. r-1)."""
+    off, out = 0, []
+    for n in counts:
+        out.append(off)
+        off += int(n)
+    return out, off
+
+
+def library_comm_init(rad, rank: int, world: int, bcast_id):
+    """Join the library's own RCCL communicator (include/ecrad_hip.h: ecrad_hip_comm_id / ecrad_hip_comm_init).  `bcast_id(id_or_None)`
+    is the host's way of handing rank 0's 128-byte id to every rank -- MPI_Bcast in an MPI host, torch.distributed.broadcast_object_list
+    in bench.py, the identity at world size 1: it gets the id (bytes) on rank 0 and None elsewhere and returns the id on every rank."""
+    import ctypes as C
+    from . import abi
+    ident = (C.c_ubyte * abi.COMM_ID_BYTES)()
+    mine = None
+    if rank == 0:
+        if rad.lib.ecrad_hip_comm_id(rad.handle, ident) != 0:
+            raise RuntimeError(rad.lib.ecrad_hip_last_error(rad.handle).decode())
+        mine = bytes(ident)
+    got = bcast_id(mine)
+    ident = (C.c_ubyte * abi.COMM_ID_BYTES).from_buffer_copy(got)
+    if rad.lib.ecrad_hip_comm_init(rad.handle, ident, rank, world) != 0:
+        raise RuntimeError(rad.lib.ecrad_hip_last_error(rad.handle).decode())
+
+
+def library_gather_profiles(rad, fields, counts: List[int], root: int = 0, rank: int = 0, device_pointers=None):
+    """ecrad_hip_gather_profiles on host numpy arrays `fields` (each (n_rows, counts[rank]), C-contiguous float64): returns on `root` the
+    list of (n_rows, sum(counts)) arrays, elsewhere None.  With `device_pointers` = (local pointers, global pointers or None, n_rows) the
+    arrays are device memory and nothing is returned (the root's global arrays are the caller's).  The handle must be in a communicator
+    (library_comm_init)."""
+    import ctypes as C
+    from . import abi
+    lib, h = rad.lib, rad.handle
+    world = len(counts)
+    cnt = (C.c_int * world)(*[int(c) for c in counts])
+    if device_pointers is not None:
+        lp_list, gp_list, n_rows = device_pointers
+        n = len(lp_list)
+        lp = (C.c_void_p * n)(*lp_list)
+        gp = (C.c_void_p * n)(*(gp_list if gp_list is not None else [None] * n))
+        st = lib.ecrad_hip_gather_profiles(h, n, lp, gp, int(n_rows), int(counts[rank]), cnt, root, abi.MEM_DEVICE)
+        if st != 0:
+            raise RuntimeError(lib.ecrad_hip_last_error(h).decode())
+        return None
+    fields = [np.ascontiguousarray(f, dtype=np.float64) for f in fields]
+    n_rows = fields[0].shape[0]
+    _, total = gather_offsets(counts)
+    out = [np.empty((n_rows, total)) for _ in fields] if rank == root else None
+    n = len(fields)
+    lp = (C.c_void_p * n)(*[f.ctypes.data for f in fields])
+    gp = (C.c_void_p * n)(*([o.ctypes.data for o in out] if out is not None else [None] * n))
+    if lib.ecrad_hip_gather_profiles(h, n, lp, gp, n_rows, int(counts[rank]), cnt, root, abi.MEM_HOST) != 0:
+        raise RuntimeError(lib.ecrad_hip_last_error(h).decode())
+    return out
+
+
 def launch_ranks(argv: List[str], nproc: int, env: Optional[dict] = None, timeout: Optional[float] = None) -> int:
     """One process per GPU of this node: run `argv` `nproc` times with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
     MASTER_PORT set (what `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` would set), stdout/stderr

@@ -505,6 +505,28 @@ int ecrad_hip_host_free(ecrad_hip_handle_t handle, void* p);
 int ecrad_hip_host_register(ecrad_hip_handle_t handle, void* p, size_t bytes);
 int ecrad_hip_host_unregister(ecrad_hip_handle_t handle, void* p);
 
+/* Multi-GPU: one process per GPU, the columns sharded in contiguous ranges exactly as the reference's driver deals its blocks out
+   (driver/ecrad_driver.F90:348-354), look-up tables replicated, NO exchange on the data path.  The one collective is the reassembly of
+   the flux profiles on one rank, done here over RCCL directly (xGMI between the GPUs of a node); librccl is loaded at the first of these
+   calls, a single-GPU host never needs it (ECRAD_EUNSUPPORTED when it cannot be loaded).
+     ecrad_hip_comm_id      rank 0 only: the id of a new communicator (ECRAD_COMM_ID_BYTES bytes).  The HOST hands it to the other ranks:
+                            MPI_Bcast of 128 bytes in an MPI host, a file or the environment under a launcher.
+     ecrad_hip_comm_init    every rank, collectively: join as `rank` of `world` on this handle's device.
+     ecrad_hip_gather_profiles   every rank, collectively: `n_fields` arrays of (n_rows, ncol_local) doubles, column index fastest --
+                            flux profiles (n_rows = nlev + 1), (ng, ncol) surface values taken as rows ... -- are put together on `root`
+                            into `n_fields` arrays of (n_rows, sum of ncol_of_rank), rank r's columns after those of ranks 0 .. r-1.
+                            `memory` says where BOTH the local and the global arrays live (ECRAD_MEM_HOST / ECRAD_MEM_DEVICE);
+                            `global` is read on the root only.  Returns when the root's arrays are complete.
+     ecrad_hip_comm_destroy (also done by ecrad_hip_destroy)
+   Replaces: nothing in the reference (its driver is one shared-memory process); it is the north-star's "single RCCL gather over xGMI
+   only to reassemble flux profiles" behind the C-ABI, for hosts that run one rank per GPU. */
+#define ECRAD_COMM_ID_BYTES 128
+int ecrad_hip_comm_id(ecrad_hip_handle_t handle, unsigned char* id);
+int ecrad_hip_comm_init(ecrad_hip_handle_t handle, const unsigned char* id, int rank, int world);
+int ecrad_hip_gather_profiles(ecrad_hip_handle_t handle, int n_fields, const double* const* local, double* const* global, int n_rows,
+                              int ncol_local, const int* ncol_of_rank, int root, int memory);
+int ecrad_hip_comm_destroy(ecrad_hip_handle_t handle);
+
 /* Bytes of device work arrays held by the context the calling thread's most recent call ran on (at the end of that call). */
 int ecrad_hip_scratch_bytes(ecrad_hip_handle_t handle, size_t* bytes);
 

@@ -20,6 +20,7 @@
  * build: jprb = float everywhere in the solver, while the Meador-Weaver routines keep double internals
  * (radiation_two_stream.F90:455-461, :181-185) -- here: float in, the pinned double routine, float out.
  */
+#include <stdio.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -234,7 +235,11 @@ static void step_migrations(int ng, real_t cloud_frac, real_t layer_depth, real_
              + M3(trans_dir_dir, g, jreg, jreg) * Ad * (V2(x_direct, g, jreg) + x_layer_direct))
           * T / top_albedo);
       top_albedo = rmax((real_t)1.0e-8, R + ms_enhancement * T * A);
+      const real_t x_before = V2(x_diffuse, g, jreg);
       V2(x_diffuse, g, jreg) = x_layer_diffuse + x_enhancement * A * (T * T) * (V2(x_diffuse, g, jreg) + x_layer_diffuse) / top_albedo;
+      if (getenv("ECRAD_ORACLE_TRACE_NONFINITE") && (!(V2(x_diffuse, g, jreg) >= 0) || V2(x_diffuse, g, jreg) > (real_t)1e7))
+        fprintf(stderr, "TRACE step_migrations g %d region %d: x_diffuse %.6g -> %.6g; R %.6g T %.6g A %.6g Ad %.6g top_albedo %.6g x_enhancement %.6g\n", g, jreg,
+                (double)x_before, (double)V2(x_diffuse, g, jreg), (double)R, (double)T, (double)A, (double)Ad, (double)top_albedo, (double)x_enhancement);
     }
   if (iendreg < NREG - 1) {
     for (int jreg = iendreg + 1; jreg < NREG; ++jreg) for (int g = 0; g < ng; ++g) { V2(x_diffuse, g, jreg) = 0; V2(x_direct, g, jreg) = 0; }
@@ -475,7 +480,16 @@ void oracle_solver_spartacus_sw(const ecrad_config_t* c, int ncol, int nlev, int
         for (int cc = 0; cc < nregactive; ++cc)
           for (int r = 0; r < nregactive; ++r)
             for (int g = 0; g < ng3D; ++g) GZ(Gamma_z1, g, r, nreg + cc) = -GZ(Gamma_z1, g, nreg + r, cc);
+        const int trace = getenv("ECRAD_ORACLE_TRACE_NONFINITE") != NULL;      /* (diagnostic of tools/sp_nonfinite.py: where a non-finite value first appears) */
+        real_t gz_norm[64];
+        if (trace) for (int g = 0; g < ng3D && g < 64; ++g) { real_t mx = 0; for (int k = 0; k < m * m; ++k) { const real_t v = Gamma_z1[g + (size_t)ng * k]; if (fabs((double)v) > mx) mx = (real_t)fabs((double)v); } gz_norm[g] = mx; }
         om_expm(ng, ng3D, m, Gamma_z1, OM_PATTERN_SHORTWAVE);
+        if (trace) for (int g = 0; g < ng3D && g < 64; ++g) {
+          int bad = 0; real_t mx = 0;
+          for (int k = 0; k < m * m; ++k) { const real_t v = Gamma_z1[g + (size_t)ng * k]; if (!isfinite((double)v)) bad = 1; else if (fabs((double)v) > mx) mx = (real_t)fabs((double)v); }
+          if (bad || mx > 1e30) fprintf(stderr, "TRACE sw col %d layer %d g %d: exp(Gamma) %s (largest finite |entry| %.3g), largest |Gamma| entry %.6g, od_region %.6g %.6g %.6g, frac %.6g\n", jcol, jlev, g,
+                              bad ? "NON-FINITE" : "huge", (double)mx, (double)gz_norm[g], (double)V2(od_region, g, 0), (double)V2(od_region, g, 1), (double)V2(od_region, g, 2), FL(in->cloud_fraction, jcol, jl));
+        }
         /* sub-blocks of exp(Gamma) as (ng,3,3) arrays */
 #define BLOCK(dst, r0, c0) for (int cc = 0; cc < 3; ++cc) for (int r = 0; r < 3; ++r) for (int g = 0; g < ng3D; ++g) M3(dst, g, r, cc) = GZ(Gamma_z1, g, (r0) + r, (c0) + cc)
         real_t *refl = &M4(reflectance, 0, 0, 0, jl), *tran = &M4(transmittance, 0, 0, 0, jl), *rdir = &M4(ref_dir, 0, 0, 0, jl),
@@ -494,6 +508,11 @@ void oracle_solver_spartacus_sw(const ecrad_config_t* c, int ncol, int nlev, int
         BLOCK(t2, nreg, 2 * nreg);
         om_mat_x_mat(ng, ng3D, nreg, sub3, rdir, OM_PATTERN_DENSE, t1);
         for (int k = 0; k < 9; ++k) for (int g = 0; g < ng3D; ++g) tdd[g + (size_t)ng * k] = rmin(mu0, rmax((real_t)0, t1[g + (size_t)ng * k] + t2[g + (size_t)ng * k]));
+        if (trace) for (int g = 0; g < ng3D; ++g) for (int k = 0; k < 9; ++k) {
+          const real_t* arrs5[5] = {refl, tran, rdir, tdd, tdir};
+          const char* nm[5] = {"reflectance", "transmittance", "ref_dir", "trans_dir_diff", "trans_dir_dir"};
+          for (int a = 0; a < 5; ++a) if (!isfinite((double)arrs5[a][g + (size_t)ng * k])) { fprintf(stderr, "TRACE sw col %d layer %d g %d: %s(%d) non-finite\n", jcol, jlev, g, nm[a], k); a = 5; k = 9; }
+        }
 #undef BLOCK
       }
       /* ---- 3.3b: g-points without 3-D effects --------------------------------------------------------------- */
@@ -563,6 +582,20 @@ void oracle_solver_spartacus_sw(const ecrad_config_t* c, int ncol, int nlev, int
         om_solve_mat(ng, ng, NREG, denominator, t1, t2);
         om_mat_x_mat(ng, ng, NREG, tran, t2, OM_PATTERN_DENSE, t1);
         for (size_t k = 0; k < n9; ++k) total_albedo_below_direct[k] = rdir[k] + t1[k];
+      }
+      if (getenv("ECRAD_ORACLE_TRACE_NONFINITE")) {
+        for (int g = 0; g < ng; ++g) {
+          int bad = 0;
+          for (int k = 0; k < 9; ++k) if (!isfinite((double)total_albedo_below[g + (size_t)ng * k]) || !isfinite((double)total_albedo_below_direct[g + (size_t)ng * k])) bad = 1;
+          if (bad) {
+            fprintf(stderr, "TRACE sw col %d layer %d g %d: total_albedo_below non-finite (4.1); frac %.6g; albedo below:", jcol, jlev, g, FL(in->cloud_fraction, jcol, jl));
+            for (int k = 0; k < 9; ++k) fprintf(stderr, " %.6g", (double)ta_below_lev[g + (size_t)ng * k]);
+            fprintf(stderr, "; reflectance:");
+            for (int k = 0; k < 9; ++k) fprintf(stderr, " %.6g", (double)refl[g + (size_t)ng * k]);
+            if (!is_clear_sky_layer[jlev]) { fprintf(stderr, "; denominator:"); for (int k = 0; k < 9; ++k) fprintf(stderr, " %.9g", (double)denominator[g + (size_t)ng * k]); }
+            fprintf(stderr, "\n");
+          }
+        }
       }
       /* 4.2 overlap and entrapment */
       if (explicit_entr && jlev >= i_cloud_top)
@@ -646,6 +679,21 @@ void oracle_solver_spartacus_sw(const ecrad_config_t* c, int ncol, int nlev, int
           }
         }
       }
+      if (getenv("ECRAD_ORACLE_TRACE_G")) {
+        const int g = atoi(getenv("ECRAD_ORACLE_TRACE_G"));
+        fprintf(stderr, "TRACE albedo col %d layer %d g %d frac %.4g: total_albedo (after 4.2):", jcol, jlev, g, FL(in->cloud_fraction, jcol, jl));
+        for (int k = 0; k < 9; ++k) fprintf(stderr, " %.5g", (double)ta[g + (size_t)ng * k]);
+        fprintf(stderr, " | below (4.1):");
+        for (int k = 0; k < 9; ++k) fprintf(stderr, " %.5g", (double)total_albedo_below[g + (size_t)ng * k]);
+        fprintf(stderr, " | x_diffuse %.5g %.5g %.5g\n", (double)V2(x_diffuse, g, 0), (double)V2(x_diffuse, g, 1), (double)V2(x_diffuse, g, 2));
+      }
+      if (getenv("ECRAD_ORACLE_TRACE_NONFINITE"))
+        for (int g = 0; g < ng; ++g) {
+          int bad = 0;
+          for (int k = 0; k < 9; ++k) if (!isfinite((double)ta[g + (size_t)ng * k]) || !isfinite((double)tad[g + (size_t)ng * k])) bad = 1;
+          if (bad) fprintf(stderr, "TRACE sw col %d layer %d g %d: total_albedo non-finite after 4.2 (overlap / entrapment); x_diffuse %.6g %.6g %.6g\n", jcol, jlev, g,
+                           (double)V2(x_diffuse, g, 0), (double)V2(x_diffuse, g, 1), (double)V2(x_diffuse, g, 2));
+        }
       if (explicit_entr && !(is_clear_sky_layer[jlev] && is_clear_sky_layer[jlev - 1])) {      /* :1331-1359 */
         for (size_t k = 0; k < n3; ++k) { x_direct_above[k] = 0; x_diffuse_above[k] = 0; }
         const int nra = is_clear_sky_layer[jlev] ? 1 : NREG;

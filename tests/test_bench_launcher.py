@@ -102,3 +102,16 @@ def test_bench_pool_mode_over_eight_device_slots_on_this_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and "test_fake_devices" in d and d["blocks_identical_across_devices"] is True and d["value"] > 0
     assert d["pool"]["n_devices"] == 8 and len(d["pool"]["calls_on_device"]) == 8 and all(v > 0 for v in d["pool"]["calls_on_device"].values()), d["pool"]
+
+
+@pytest.mark.gpu
+def test_bench_library_gather_leg_on_a_one_rank_communicator():
+    """The leg of bench.py that puts the profiles together with the LIBRARY's own RCCL gather (bench.py: library_gather_leg; what runs at
+    every N > 1), forced at world size 1: the communicator forms, the timed steps run, rank 0's share arrives bit for bit."""
+    env = dict(os.environ, ECRAD_BENCH_FORCE_LIBRARY_GATHER="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--ncol", "4096", "--headline-only",
+                        "--no-cpu-baseline", "--no-host-mode"], capture_output=True, text=True, timeout=1200, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    lg = d["library_gather"]
+    assert "error" not in lg and lg["value"] > 0 and lg["own_share_intact"] is True, lg

@@ -64,6 +64,7 @@ def write_namelist(path, *edits):
 # retried on ANY non-zero return code; round 4 ran the 54 GPU cases three times over without any retry (162 processes,
 # gpurun_out/r04_b) and saw none.  The retry is now limited to this signature, before any kernel ran, every retry is
 # written to gpurun_out/dropin_retries.log, and the last test of this file fails if it was needed more than twice.
+LW_SP_ENVELOPE = 4.0      # all-sky longwave of single-precision SPARTACUS: HIP sp vs dp may be this many times the reference sp vs dp (see the test)
 STARTUP_SIGNATURES = ("no usable MI355X device", "hipErrorNoDevice", "no ROCm-capable device", "hipErrorInvalidDevice",
                       "hipErrorNotInitialized", "hipErrorInitializationError", "Unable to open /dev/kfd", "HSA_STATUS_ERROR_OUT_OF_RESOURCES")
 RETRIES = []
@@ -637,9 +638,16 @@ def test_single_precision_host_through_the_dropin(tmp_path, target):
         e_hip = {v: rel_err(a.get(v), b.get(v)) for v in broadband}
         e_ref = {v: rel_err(c.get(v), b.get(v)) for v in broadband}
     print(target, "single-precision host + GPU vs double:", max(e_hip.values()), "; the reference's single-precision CPU run vs double:", max(e_ref.values()))
+    print(target, "per variable (HIP sp vs dp, reference sp vs dp):", {v: (float(f"{e_hip[v]:.3g}"), float(f"{e_ref[v]:.3g}")) for v in broadband})
     for v in broadband:
         if spartacus and v in ("flux_up_lw", "flux_dn_lw"):
-            continue        # (all-sky longwave with 3-D effects: chaotic in single precision in the reference's own formulation)
+            # All-sky longwave with 3-D effects: in single precision the reference's own formulation amplifies the last bit (its sp run
+            # is itself percents away from its dp run in a few layers), so the HIP path is not held to 2e-3 here but to the reference's
+            # own envelope: finite everywhere and no further from double than a few times what the reference's sp build is.
+            with NcFile(outs["sp_hip"]) as a:
+                assert np.all(np.isfinite(a.get(v))), v
+            assert e_hip[v] <= max(LW_SP_ENVELOPE * e_ref[v], 2.0e-3), (v, e_hip[v], e_ref[v])
+            continue
         assert e_hip[v] < (2.0e-3 if spartacus else 5.0e-5), (v, e_hip[v])
         assert e_hip[v] <= max(2.0 * e_ref[v], 1.0e-6), (v, e_hip[v], e_ref[v])
 

@@ -8,7 +8,7 @@ extra="$*"
 root=$(cd "$(dirname "$0")/.." && pwd)
 out=${ECRAD_VARIANT_DIR:-$root/build_variants}/$name
 mkdir -p $out
-src="pool setup pipeline abi kernel_ica_sw kernel_ica_lw kernel_ica_lw_clear kernel_lw_scat kernel_tc kernel_prep kernel_optics kernel_rrtmg kernel_spartacus kernel_spartacus_lw kernel_ica_sw_exact kernel_tc_sw_exact"
+src="pool setup pipeline abi comm kernel_ica_sw kernel_ica_lw kernel_ica_lw_clear kernel_lw_scat kernel_tc kernel_prep kernel_optics kernel_rrtmg kernel_spartacus kernel_spartacus_lw kernel_ica_sw_exact kernel_tc_sw_exact"
 for f in $src; do
   x=""; [ $f = kernel_ica_lw_clear ] && x="-mllvm -amdgpu-sched-strategy=max-memory-clause"      # (as ecrad_amd/csrc/Makefile: EXTRA_kernel_ica_lw_clear)
   # (EXTRA_kernel_spartacus; a variant asking for ..FAST_DIV=0 -- nopack -- gets the correctly rounded float division as well)
@@ -17,6 +17,6 @@ for f in $src; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $x $extra -c $root/ecrad_amd/csrc/$f.hip -o $out/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out/libecrad_hip.so $out/*.o
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out/libecrad_hip.so $out/*.o -ldl
 rm -f $out/*.o
 echo "built $out/libecrad_hip.so"
