@@ -1174,7 +1174,7 @@ def compact_line(out, detail_path=None):
     small_blocks, end_to_end_host, per-stage times) is in the detail file (gpurun_out/bench_detail.json).  Strict JSON: non-finite
     floats are null (`allow_nan=False`).  Always shorter than LINE_LIMIT (tests/test_bench_line.py)."""
     out = _finite(out)
-    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "higher_is_better",
+    line = {k: out[k] for k in ("metric", "value", "value_exact_scratch", "unit", "n_gpus", "rccl_ranks", "steps", "warmup", "ms_per_step", "ms_per_step_exact_scratch", "higher_is_better",
                                  "scaling", "vs_baseline", "dtype", "data", "config") if k in out}
     for k in ("ms_per_step_ranks", "value_with_gather", "ms_per_step_with_gather", "gathered", "library_gather", "mode", "test_shared_gpu",
               "test_fake_devices", "blocks_identical_across_devices", "pool", "attempts", "aborted_attempts", "fault"):
@@ -1388,6 +1388,23 @@ def main():
         if k in head:
             out[k] = head[k]
     failed = "parity" in head and not head["parity"]["ok"]
+    if world == 1 and head["roofline"].get("scratch_mantissa_bits") == 39 and os.environ.get("ECRAD_HIP_EXACT_SCRATCH") != "1":
+        # the same K steps with whole doubles in the shortwave sweep records (the library's ECRAD_HIP_EXACT_SCRATCH=1: the instantiations of
+        # kernel_ica_sw_exact.hip / kernel_tc_sw_exact.hip, 40 bytes per record instead of 32): what the 39-bit packing buys, next to `value`
+        try:
+            progress("exact-scratch leg")
+            os.environ["ECRAD_HIP_EXACT_SCRATCH"] = "1"
+            try:
+                wx = Workload(args.workload, args.ncol, rank, local_rank, 0)
+            finally:
+                del os.environ["ECRAD_HIP_EXACT_SCRATCH"]
+            ex = timed_steps(wx, args.steps, args.warmup, barrier)
+            out["value_exact_scratch"] = args.ncol * args.steps / ex
+            out["ms_per_step_exact_scratch"] = 1e3 * ex / args.steps
+            wx.close()
+        except Exception as e:
+            out["value_exact_scratch"] = None
+            out["exact_scratch_error"] = f"{type(e).__name__}: {e}"
     if world == 1 and not args.headline_only and args.workload == "clear_homogeneous_ecckd32":
         out["workloads"] = {}
         for name, ncol in EXTRA_WORKLOADS:

@@ -36,10 +36,10 @@ struct LwScratch {
   int width;
   ECRAD_DEV StreamRef<double2> pair(int off, int lev, int tid) const {
     if (ECRAD_ABLATE & 16) lev &= 3;      // (wrong results by design: the records stay in the L2, see kernel_ica_sw.hip)
-    return {reinterpret_cast<double2*>(base + ((size_t)lev * width + off) * kBlock) + tid};
+    return {reinterpret_cast<double2*>(base + ((size_t)lev * width + off) * kBlock) + tid, cached_level(lev)};
   }
   ECRAD_DEV StreamRef<double> single(int off, int lev, int tid) const {
-    return {base + ((size_t)lev * width + off) * kBlock + tid};
+    return {base + ((size_t)lev * width + off) * kBlock + tid, cached_level(lev)};
   }
 };
 

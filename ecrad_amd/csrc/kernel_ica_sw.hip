@@ -54,7 +54,7 @@ ECRAD_DEV void sw_up_step(const SwScratch& s, int set, int lev, int tid, const S
   p1.y = st.alb;
 #if !(ECRAD_ABLATE & 8)
 #if ECRAD_PACK_SW
-  packed5_store(s.base, s.rec(set, lev), tid, pack5(p0.x, p0.y, p1.x, p1.y, st.sig));
+  packed5_store(s.base, s.rec(set, lev), tid, pack5(p0.x, p0.y, p1.x, p1.y, st.sig), cached_level(lev));
 #else
   s.pair(set, 0, lev, tid) = p0;
   s.pair(set, 1, lev, tid) = p1;
@@ -87,7 +87,7 @@ ECRAD_DEV void sw_load_batch(const SwScratch& s, bool set2, int lcb, int tid, in
     {
       const int set = (set2 && lay <= lcb) ? 1 : 0;
 #if ECRAD_PACK_SW
-      r[k] = packed5_load(s.base, s.rec(set, lay), tid);
+      r[k] = packed5_load(s.base, s.rec(set, lay), tid, cached_level(lay));
 #else
       r[k].p0 = s.pair(set, 0, lay, tid);
       r[k].p1 = s.pair(set, 1, lay, tid);
@@ -175,7 +175,7 @@ ECRAD_DEV void sw_flux_sweep(const SwScratch& s, bool set2, int lcb, int tid, in
     const int l = lay < nlev ? lay : nlev - 1;
     const int set = (set2 && l <= lcb) ? 1 : 0;
 #if ECRAD_PACK_SW
-    return packed5_load(s.base, s.rec(set, l), tid);
+    return packed5_load(s.base, s.rec(set, l), tid, cached_level(l));
 #else
     SwRec r; r.p0 = s.pair(set, 0, l, tid); r.p1 = s.pair(set, 1, l, tid); r.sig = s.single(set, l, tid); return r;
 #endif

@@ -334,8 +334,14 @@ ECRAD_DEV void step_migrations(R cloud_frac, R layer_depth, R tan_diffuse_angle_
   for (int jreg = 0; jreg < 3; ++jreg) {
     if (jreg < istartreg || jreg > iendreg) continue;
     const R Rf = reflectance(jreg, jreg), T = transmittance(jreg, jreg), A = total_albedo_diff(jreg, jreg), Ad = total_albedo_dir(jreg, jreg);
-    const R ms_enhancement = T / (R(1) - Rf * A);
-    const R x_enhancement = sp::sp_pow(R(1) - Rf * A, R(-1.5));
+    // (single precision only, see the guard after section 4.1 in spartacus_sw_kernel: with both the layer's reflectance and the albedo below held
+    //  to [0, 1], 1 - R A can be exactly 0 where it is a small positive number in exact arithmetic -- low sun, strong 3-D transport: column
+    //  65 490 of the synthetic workload, layer 111 --; (1 - R A)^-1.5 is then infinite and the column NaN.  The distances are capped at 1e8 m:
+    //  never reached by a column in its right mind, it keeps a geometric growth from overflowing into inf x 0 in entrapment_exchange)
+    R one_minus_ra = R(1) - Rf * A;
+    if constexpr (sizeof(R) == 4) one_minus_ra = rmax(one_minus_ra, R(1.0e-6));
+    const R ms_enhancement = T / one_minus_ra;
+    const R x_enhancement = sp::sp_pow(one_minus_ra, R(-1.5));
     R top_albedo = rmax(R(1.0e-8), ref_dir(jreg, jreg) + ms_enhancement * (trans_dir_diff(jreg, jreg) * A + trans_dir_dir(jreg, jreg) * Ad));
     x_direct.a[jreg] = rmax(R(0), x_layer_direct
         + ((trans_dir_diff(jreg, jreg) * A * x_enhancement + trans_dir_dir(jreg, jreg) * Ad * (x_enhancement - R(1)))
@@ -344,6 +350,7 @@ ECRAD_DEV void step_migrations(R cloud_frac, R layer_depth, R tan_diffuse_angle_
           * T / top_albedo);
     top_albedo = rmax(R(1.0e-8), Rf + ms_enhancement * T * A);
     x_diffuse.a[jreg] = x_layer_diffuse + x_enhancement * A * (T * T) * (x_diffuse.a[jreg] + x_layer_diffuse) / top_albedo;
+    if constexpr (sizeof(R) == 4) { x_direct.a[jreg] = rmin(x_direct.a[jreg], R(1.0e8)); x_diffuse.a[jreg] = rmin(x_diffuse.a[jreg], R(1.0e8)); }
   }
   if (iendreg < 2) {
 #pragma unroll
@@ -378,7 +385,11 @@ ECRAD_DEV M3<R> entrapment_exchange(const SpConfig& c, const R (&rate)[9], R xx,
     for (int k = 0; k < 9; ++k) e.a[k] = e.a[k] * s;
   }
   if (c.nregions == 2) return sp::fast_expm_exchange_2<R>(e(1, 0), e(0, 1));      // radiation_spartacus_sw.F90:1184-1186
-  return sp::fast_expm_exchange_3<R>(e(1, 0), e(0, 1), e(2, 1), e(1, 2));
+  M3<R> x = sp::fast_expm_exchange_3<R>(e(1, 0), e(0, 1), e(2, 1), e(1, 2));
+  if constexpr (sizeof(R) == 4) {      // (single precision only: spartacus_device.h, expm_exchange_3_scaled)
+    if (!sp::is_transition_matrix(x)) x = sp::expm_exchange_3_scaled<R>(e(1, 0), e(0, 1), e(2, 1), e(1, 2));
+  }
+  return x;
 }
 
 // sub-block (r0.., c0..) of an M x M matrix as a 3 x 3 one
@@ -622,6 +633,16 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
     R ta_clear = albdif, tad_clear = mu0 * albdir;
     V3<R> x_diffuse, x_direct;
     x_diffuse.zero(); x_direct.zero();
+#ifdef ECRAD_SP_TRACE
+    // (diagnostic build only, tools/sp_column.py: 1000 * layer + stage of the FIRST quantity of sections 3-4 that is not finite or leaves its
+    //  range, written over sw_up_toa_g.  Stages: 1 layer matrices, 2 adding step, 3 migration distances, 4 overlap / entrapment,
+    //  5 albedo outside [-0.001, 1.001] after the adding step)
+    int trace_code = 0, trace_range = 0;
+    auto trace_m = [&](const M3<R>& m) { bool bad = false; for (int k = 0; k < 9; ++k) bad = bad || !(sp::sp_abs(m.a[k]) < R(3.0e38)); return bad; };
+#define SP_TRACE(stage, cond) do { if (trace_code == 0 && (cond)) trace_code = 1000 * jlev + (stage); } while (0)
+#else
+#define SP_TRACE(stage, cond) do { } while (0)
+#endif
 
     double pf_od, pf_ssa, pf_g;
     {
@@ -697,6 +718,11 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
         ta_below = add(refl, sp::mul(tran, sp::solve(fd, sp::mul(ta, tran))));
         tad_below = add(rdir, sp::mul(tran, sp::solve(fd, add(sp::mul(tad, tdir), sp::mul(ta, tdd)))));
       }
+      SP_TRACE(1, trace_m(refl) || trace_m(tran) || trace_m(rdir) || trace_m(tdd) || trace_m(tdir));
+      SP_TRACE(2, trace_m(ta_below) || trace_m(tad_below));
+#ifdef ECRAD_SP_TRACE
+      { bool out = false; for (int k = 0; k < 9; ++k) out = out || ta_below.a[k] < R(-1.0e-3) || ta_below.a[k] > R(1.001); if (trace_range == 0 && out) trace_range = jlev; }
+#endif
       // SINGLE PRECISION ONLY: the entries of the two albedo matrices are fractions of the incident flux -- within [0, 1] and [0, mu0] in
       // exact arithmetic, like the layer's own reflectance / transmittance matrices, which the reference clamps to those ranges
       // (radiation_spartacus_sw.F90:893-915).  In single precision the matrix adding above leaves the range in strongly absorbing g-points
@@ -717,6 +743,8 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
       if (explicit_entr && jlev >= i_cloud_top)
         step_migrations<R>(R(fracv.p[fracv.stride * ord.full(jl)]), layer_depth, tan_diffuse_angle_3d, tan_sza, refl, tran, rdir, tdir, tdd,
                            ta, tad, x_diffuse, x_direct);
+      SP_TRACE(3, !(sp::sp_abs(x_diffuse.a[0]) < R(3.0e38)) || !(sp::sp_abs(x_diffuse.a[1]) < R(3.0e38)) || !(sp::sp_abs(x_diffuse.a[2]) < R(3.0e38)) ||
+                  !(sp::sp_abs(x_direct.a[0]) < R(3.0e38)) || !(sp::sp_abs(x_direct.a[1]) < R(3.0e38)) || !(sp::sp_abs(x_direct.a[2]) < R(3.0e38)));
       if (clr && clr_above) {
         ta = diag_only(ta_below(0, 0));
         tad = diag_only(tad_below(0, 0));
@@ -809,6 +837,7 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
           x_direct = xda; x_diffuse = xfa;
         }
       }
+      SP_TRACE(4, trace_m(ta) || trace_m(tad));
     }
 
     // ---- section 5: top -> surface ------------------------------------------------------------------------------
@@ -825,6 +854,9 @@ __global__ __launch_bounds__(kBlock, sizeof(R) == 4 ? ECRAD_SP_SWEEP_WAVES_SW : 
         const double dn0 = (double)mu0 * group_sum<NGP>(valid ? (double)inc : 0.0);
         if (lead) { fx.sw_dn[o0] = dn0; if (fx.sw_dn_direct) fx.sw_dn_direct[o0] = dn0; }
         if (valid) fx.sw_up_toa_g[og] = (double)flux_up_above.sum();
+#ifdef ECRAD_SP_TRACE
+        if (valid) fx.sw_up_toa_g[og] = (double)trace_code + 1.0e-4 * trace_range;
+#endif
         if (do_clear) {
           put_sum<NGP>(fx.sw_up_clear, o0, (double)flux_up_clear, valid, lead);
           if (lead) { fx.sw_dn_clear[o0] = dn0; if (fx.sw_dn_direct_clear) fx.sw_dn_direct_clear[o0] = dn0; }

@@ -199,7 +199,7 @@ ECRAD_DEV void tc_sw_up(const TcSwScratch& s, int set, int lev, int tid, const S
 #if ECRAD_ABLATE & 8
 #elif ECRAD_PACK_SW
   packed5_store(s.base, s.rec(set, lev), tid,
-                pack5(c.trans_diff * inv, (c.trans_dir_dir * Ad * c.ref_diff + c.trans_dir_diff) * inv, c.trans_dir_dir, A, Ad));
+                pack5(c.trans_diff * inv, (c.trans_dir_dir * Ad * c.ref_diff + c.trans_dir_diff) * inv, c.trans_dir_dir, A, Ad), cached_level(lev));
 #else
   s.pair(set, 0, lev, tid) = make_double2(c.trans_diff * inv, (c.trans_dir_dir * Ad * c.ref_diff + c.trans_dir_diff) * inv);
   s.pair(set, 1, lev, tid) = make_double2(c.trans_dir_dir, A);
@@ -567,11 +567,11 @@ __global__ __launch_bounds__(kBlock, (FX != 0 && ECRAD_TC_PIPE) ? ECRAD_TC_PIPE_
         const int l = l0 + k < nlev ? l0 + k : nlev - 1;      // (past the last layer: re-read it, unused)
 #pragma unroll
         for (int q = 0; q < 4; ++q) { pk[k][q].w0 = ecrad_v4u{0u, 0u, 0u, 0u}; pk[k][q].w1 = ecrad_v4u{0u, 0u, 0u, 0u}; }
-        if (do_clear) pk[k][3] = packed5_load(s.base, s.rec(3, l), tid);
-        if (!do_clear || l <= lcb) pk[k][0] = packed5_load(s.base, s.rec(0, l), tid);
+        if (do_clear) pk[k][3] = packed5_load(s.base, s.rec(3, l), tid, cached_level(l));
+        if (!do_clear || l <= lcb) pk[k][0] = packed5_load(s.base, s.rec(0, l), tid, cached_level(l));
         if (cloudy.test(l)) {
 #pragma unroll
-          for (int r = 1; r < 3; ++r) pk[k][r] = packed5_load(s.base, s.rec(r, l), tid);
+          for (int r = 1; r < 3; ++r) pk[k][r] = packed5_load(s.base, s.rec(r, l), tid, cached_level(l));
         }
       }
 #else
@@ -724,10 +724,10 @@ struct TcLwScratch {
   double* base;
   int np;       // planes per layer
   ECRAD_DEV StreamRef<double2> pair(int plane, int lev, int tid) const {
-    return {reinterpret_cast<double2*>(base + ((size_t)lev * np + plane) * kBlock) + tid};
+    return {reinterpret_cast<double2*>(base + ((size_t)lev * np + plane) * kBlock) + tid, cached_level(lev)};
   }
   ECRAD_DEV StreamRef<double> single(int plane, int lev, int tid) const {
-    return {base + ((size_t)lev * np + plane) * kBlock + tid};
+    return {base + ((size_t)lev * np + plane) * kBlock + tid, cached_level(lev)};
   }
 };
 constexpr int TL_A0 = 0, TL_SD1 = 2;

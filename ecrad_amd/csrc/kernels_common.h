@@ -622,18 +622,30 @@ ECRAD_DEV void spec_put(double* arr, int ng, int g, size_t o, double v) {
 #endif
 typedef double ecrad_v2d __attribute__((ext_vector_type(2)));
 
+// ECRAD_CACHED_TOP = K > 0 (tuning, round 6; 0 = off, the shipped form): the records of the K levels nearest the top of the atmosphere --
+// written LAST by the upward sweeps and read FIRST by the downward ones -- travel with the default cache policy instead, so that they can
+// be served from the L2 / Infinity Cache (256 MiB against ~840 MB of slabs in flight) when they are read back.  `cached_level(lev)` is
+// wave-uniform.  Measured: profiles/NOTES_r06.md section 5.
+#ifndef ECRAD_CACHED_TOP
+#define ECRAD_CACHED_TOP 0
+#endif
+ECRAD_DEV bool cached_level(int lev) { return ECRAD_CACHED_TOP > 0 && lev < ECRAD_CACHED_TOP; }
+
 template <typename T> struct StreamRef;
 template <> struct StreamRef<double> {
   double* p;
+  bool cached = false;
   ECRAD_DEV void operator=(double v) const {
 #if ECRAD_NT_SCRATCH
-    __builtin_nontemporal_store(v, p);
+    if (ECRAD_CACHED_TOP > 0 && cached) *p = v;
+    else __builtin_nontemporal_store(v, p);
 #else
     *p = v;
 #endif
   }
   ECRAD_DEV operator double() const {
 #if ECRAD_NT_SCRATCH
+    if (ECRAD_CACHED_TOP > 0 && cached) return *p;
     return __builtin_nontemporal_load(p);
 #else
     return *p;
@@ -642,8 +654,10 @@ template <> struct StreamRef<double> {
 };
 template <> struct StreamRef<double2> {
   double2* p;
+  bool cached = false;
   ECRAD_DEV void operator=(const double2& v) const {
 #if ECRAD_NT_SCRATCH
+    if (ECRAD_CACHED_TOP > 0 && cached) { *p = v; return; }
     ecrad_v2d t; t.x = v.x; t.y = v.y;
     __builtin_nontemporal_store(t, reinterpret_cast<ecrad_v2d*>(p));
 #else
@@ -652,6 +666,7 @@ template <> struct StreamRef<double2> {
   }
   ECRAD_DEV operator double2() const {
 #if ECRAD_NT_SCRATCH
+    if (ECRAD_CACHED_TOP > 0 && cached) return *p;
     const ecrad_v2d t = __builtin_nontemporal_load(reinterpret_cast<const ecrad_v2d*>(p));
     return make_double2(t.x, t.y);
 #else
@@ -704,8 +719,9 @@ ECRAD_DEV void unpack5(const Packed5& p, double& v0, double& v1, double& v2, dou
   v4 = __longlong_as_double((long long)(((unsigned long long)p.w1.x << 32) | (l4 << 13)));
 }
 // slab of packed records: record r of thread tid at base + (r * 2 * 256 + tid) 16-byte words (+256 for the second word)
-ECRAD_DEV void packed5_store(double* base, size_t rec, int tid, const Packed5& p) {
+ECRAD_DEV void packed5_store(double* base, size_t rec, int tid, const Packed5& p, bool cached = false) {
   ecrad_v4u* q = reinterpret_cast<ecrad_v4u*>(base) + rec * (2 * kBlock) + tid;
+  if (ECRAD_CACHED_TOP > 0 && cached) { q[0] = p.w0; q[kBlock] = p.w1; return; }
 #if ECRAD_NT_SCRATCH
   __builtin_nontemporal_store(p.w0, q);
   __builtin_nontemporal_store(p.w1, q + kBlock);
@@ -713,9 +729,10 @@ ECRAD_DEV void packed5_store(double* base, size_t rec, int tid, const Packed5& p
   q[0] = p.w0; q[kBlock] = p.w1;
 #endif
 }
-ECRAD_DEV Packed5 packed5_load(const double* base, size_t rec, int tid) {
+ECRAD_DEV Packed5 packed5_load(const double* base, size_t rec, int tid, bool cached = false) {
   const ecrad_v4u* q = reinterpret_cast<const ecrad_v4u*>(base) + rec * (2 * kBlock) + tid;
   Packed5 p;
+  if (ECRAD_CACHED_TOP > 0 && cached) { p.w0 = q[0]; p.w1 = q[kBlock]; return p; }
 #if ECRAD_NT_SCRATCH
   p.w0 = __builtin_nontemporal_load(q);
   p.w1 = __builtin_nontemporal_load(q + kBlock);

@@ -415,5 +415,42 @@ SP_DEV M3<R> fast_expm_exchange_3(R a, R b, R c, R d) {
   return Rm;
 }
 
+// exp of the same exchange matrix by scaling and squaring (Taylor series of order 10 of the matrix scaled below 1/2, squared back): the
+// fall-back of entrapment_exchange in SINGLE precision for the cases in which the closed form above fails -- its eigenvector matrix is
+// factorised without pivoting, and where the two non-zero eigenvalues nearly coincide (tmp2 at its floor eps x tmp1) U22 = 1 - V01 / V00 is
+// zero or a rounding error in float: entries of the result outside [0, 1] or not finite (column 65 490 of the synthetic workload, layer
+// 111, round 6).  The exponential of a matrix with non-negative off-diagonal entries and zero column sums is a transition matrix: every
+// entry in [0, 1], which is what the test for the fall-back checks.
+template <typename R>
+SP_DEV M3<R> expm_exchange_3_scaled(R a, R b, R c, R d) {
+  M3<R> B;
+  B.zero();
+  B(0, 0) = -a; B(1, 0) = a; B(0, 1) = b; B(1, 1) = -b - c; B(2, 1) = c; B(1, 2) = d; B(2, 2) = -d;
+  R nrm = R(2) * rmax(rmax(a, b + c), d);      // (largest column sum of absolute values)
+  int s = 0;
+  R sc = R(1);
+  while (nrm * sc > R(0.5) && s < 60) { sc = sc * R(0.5); ++s; }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) B.a[k] = B.a[k] * sc;
+  M3<R> E;
+  E.zero();
+  E(0, 0) = E(1, 1) = E(2, 2) = R(1);
+  for (int k = 10; k >= 1; --k) {      // Horner: E = I + B / k * E
+    E = mul(B, E);
+    const R inv = R(1) / R(k);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) E.a[j] = E.a[j] * inv;
+    E(0, 0) = E(0, 0) + R(1); E(1, 1) = E(1, 1) + R(1); E(2, 2) = E(2, 2) + R(1);
+  }
+  for (int i = 0; i < s; ++i) E = mul(E, E);
+  return E;
+}
+template <typename R> SP_DEV bool is_transition_matrix(const M3<R>& m) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) ok = ok && m.a[k] >= R(-1.0e-3) && m.a[k] <= R(1.001);      // (false for NaN)
+  return ok;
+}
+
 }  // namespace sp
 }  // namespace ecrad

@@ -64,7 +64,7 @@ def write_namelist(path, *edits):
 # retried on ANY non-zero return code; round 4 ran the 54 GPU cases three times over without any retry (162 processes,
 # gpurun_out/r04_b) and saw none.  The retry is now limited to this signature, before any kernel ran, every retry is
 # written to gpurun_out/dropin_retries.log, and the last test of this file fails if it was needed more than twice.
-LW_SP_ENVELOPE = 4.0      # all-sky longwave of single-precision SPARTACUS: HIP sp vs dp may be this many times the reference sp vs dp (see the test)
+LW_SP_ENVELOPE = 2.0      # all-sky longwave of single-precision SPARTACUS: HIP sp vs dp may be this many times the reference sp vs dp (round 6: 0.0029 / 0.0031 and 0.0355 / 0.0354)
 STARTUP_SIGNATURES = ("no usable MI355X device", "hipErrorNoDevice", "no ROCm-capable device", "hipErrorInvalidDevice",
                       "hipErrorNotInitialized", "hipErrorInitializationError", "Unable to open /dev/kfd", "HSA_STATUS_ERROR_OUT_OF_RESOURCES")
 RETRIES = []
