@@ -791,6 +791,10 @@ def end_to_end_host(w, gpu_resident_value, repeats=3):
     #  one-way rate on the boxes of round 4, less than what the pipelined call itself moves in both directions together:
     #  reported, not used.)
     ceiling = 1.0e9 / max(b_in / h2d, b_out / d2h)
+    # ... and what the link sustains with BOTH directions busy (measured: two page-locked copies at once): the call moves b_in + b_out bytes
+    # per column through it, so it cannot beat duplex / (b_in + b_out) either -- the tighter of the two ceilings whenever the duplex rate is
+    # less than twice the one-way rate (round 6, /opt/rocm's runtime: 97 GB/s against 2 x 57)
+    ceiling_duplex = 1.0e9 * duplex / (b_in + b_out)
     value = ncol * repeats / t
     # The same call on arrays the host keeps in page-locked memory (ecrad_hip_host_alloc: a host model's arrays live as long as it runs):
     # the copy engines read and write them directly instead of the runtime staging pageable memory through the calling threads.
@@ -833,7 +837,8 @@ def end_to_end_host(w, gpu_resident_value, repeats=3):
             "column_tiles": int(info.n_tiles), "tile_columns": int(info.tile_columns),
             "bytes_per_column": {"in": b_in, "out": b_out},
             "pcie_gbs": {"host_to_device": h2d, "device_to_host": d2h, "both_directions": duplex},
-            "pcie_ceiling_columns_per_s": ceiling,
+            "pcie_ceiling_columns_per_s": ceiling, "pcie_duplex_ceiling_columns_per_s": ceiling_duplex,
+            "fraction_of_pcie_ceiling": value / min(ceiling, ceiling_duplex),
             "fraction_of_min_ceiling_and_value": value / min(ceiling, gpu_resident_value),
             "note": "ECRAD_MEM_HOST: pageable host arrays; copy-in, kernels and copy-out of consecutive column tiles overlap on three "
                     "streams (PCIe-inclusive); never `value`"}
@@ -1188,7 +1193,7 @@ def compact_line(out, detail_path=None):
         line["parity"] = _compact_parity(out["parity"])
     if "end_to_end_host" in out:
         e = out["end_to_end_host"]
-        line["end_to_end_host"] = {k: e[k] for k in ("value", "unit", "pcie_ceiling_columns_per_s") if k in e}
+        line["end_to_end_host"] = {k: e[k] for k in ("value", "unit", "pcie_ceiling_columns_per_s", "pcie_duplex_ceiling_columns_per_s") if k in e}
         if "under_pytorch_runtime" in e:
             line["end_to_end_host"]["runtime"] = "/opt/rocm (host-only child)"
             line["end_to_end_host"]["value_under_pytorch_runtime"] = e["under_pytorch_runtime"].get("value")

@@ -170,6 +170,9 @@ int ecrad_hip_radiation_f32(ecrad_hip_handle_t h, int ncol, int nlev, int istart
   if (st) return st;
   if (c.do_clouds) outs.push_back({s.cloud_fraction, F(in->cloud_fraction) + i0, L, n, N});      // the crop_cloud_fraction side effect
   run_conv(outs, false);
+  // (the slab of a call over 10^5 columns is gigabytes: not kept by the thread for the life of the process; the blocks of a host model
+  //  stay far below the limit and keep theirs from call to call)
+  if (slab.capacity() * sizeof(double) > (size_t)256 << 20) std::vector<double>().swap(slab);
   return ECRAD_OK;
 }
 

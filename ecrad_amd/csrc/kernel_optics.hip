@@ -119,8 +119,9 @@ __global__ __launch_bounds__(kBlock, ECRAD_DUMP_MIN_WAVES) void optics_dump_kern
       {
         const DumpArgs& b = kernarg_block<DumpArgs>();
         // Longwave, absorption-only aerosols (one table value per type: 12 registers in flight): optics pass of the SPARTACUS
-        // longwave 9.2 -> 7.3 ms per 100 000 columns.  NOT the shortwave (ECRAD_DUMP_PIPE_SW): its 24 rows per layer are 72
-        // registers, the kernel then spills 71 and every reload queues behind the prefetch: 10.5 -> 20.8 ms (gpurun_out/r05_i).
+        // longwave 9.2 -> 7.3 ms per 100 000 columns.  The shortwave (ECRAD_DUMP_PIPE_SW = 1) takes it with its types in two halves of
+        // six (NH below: 36 registers of rows in flight): with all 24 rows of a layer at once -- 72 registers -- the kernel spilled 71 and
+        // every reload queued behind the prefetch: 10.5 -> 20.8 ms (gpurun_out/r05_i); in halves it is level with the plain loop.
         pipe_ok = b.cfg.aerosol.nactive4 <= NT && !b.in.gs.od_sw && !b.in.gs.od_lw && sizeof(TAB) != 8 &&
                   (IS_SW ? ECRAD_DUMP_PIPE_SW != 0 : !b.cfg.do_lw_aerosol_scattering);
       }

@@ -1218,6 +1218,7 @@ int small_call_limit() { return std::min(packed_call_columns(), kMaxBatchColumns
 
 struct SmallCall {
   int ncol, nlev, i0, nloc;
+  int n_bands_sw = 0;    // (length of in->spectral_solar_scaling)
   const ecrad_inputs_t* in;
   ecrad_flux_t* flux;
   struct SmallBatch* batch = nullptr;
@@ -1250,7 +1251,11 @@ bool batch_compatible(const SmallCall& a, const SmallCall& b) {
   if (a.nlev != b.nlev || x.n_sw_albedo != y.n_sw_albedo || x.n_lw_emissivity != y.n_lw_emissivity || x.n_cloud_types != y.n_cloud_types ||
       x.n_aerosol_types != y.n_aerosol_types || x.aerosol_istartlev != y.aerosol_istartlev || x.aerosol_iendlev != y.aerosol_iendlev ||
       x.solar_irradiance != y.solar_irradiance || x.spectral_solar_cycle_multiplier != y.spectral_solar_cycle_multiplier ||
-      x.spectral_solar_scaling != y.spectral_solar_scaling) return false;
+      (x.spectral_solar_scaling == nullptr) != (y.spectral_solar_scaling == nullptr)) return false;
+  // (RRTMG's per-band scaling of the solar spectrum: the VALUES decide, not the address -- ecrad_hip_radiation_f32 widens it into a
+  //  thread-local copy, so every calling thread of a single-precision host has a pointer of its own)
+  if (x.spectral_solar_scaling && x.spectral_solar_scaling != y.spectral_solar_scaling)
+    for (int k = 0; k < a.n_bands_sw; ++k) if (x.spectral_solar_scaling[k] != y.spectral_solar_scaling[k]) return false;
   const void* px[] = {x.pressure_hl, x.temperature_hl, x.h2o_sat_liq, x.cos_sza, x.skin_temperature, x.sw_albedo, x.sw_albedo_direct, x.lw_emissivity,
                       x.iseed, x.gas_mixing_ratio, x.cloud_fraction, x.cloud_mixing_ratio, x.cloud_effective_radius, x.cloud_fractional_std,
                       x.cloud_overlap_param, x.aerosol_mixing_ratio, x.cloud_inv_cloud_effective_size, x.cloud_inv_inhom_effective_size};
@@ -1423,7 +1428,7 @@ int batch_lead(ecrad_hip_handle_t root, SmallBatch& B, SmallCall& mine) {
 
 // A small host-memory call: joins the batch that the next free context runs, or leads one.
 int radiation_small(ecrad_hip_handle_t root, int ncol, int nlev, int istartcol, int iendcol, const ecrad_inputs_t* in, ecrad_flux_t* flux) {
-  SmallCall me{ncol, nlev, istartcol, iendcol - istartcol + 1, in, flux};
+  SmallCall me{ncol, nlev, istartcol, iendcol - istartcol + 1, root->cfg.n_bands_sw, in, flux};
   SmallBatch B;      // (used if this thread leads)
   std::unique_lock<std::mutex> lk(root->pool_mutex);
   root->small_waiting.push_back(&me);
