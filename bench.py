@@ -505,9 +505,10 @@ def library_gather_leg(w, world, rank, steps, barrier, allreduce_max, timeout=18
                 obj = [b]
                 dist.broadcast_object_list(obj, src=0)
                 return obj[0]
-            library_comm_init(w.rad, rank, world, bcast)
             names, nrows = w.profile_names, w.nlev + 1
             local = [w.case.flux_tensors[n] for n in names]
+            torch.cuda.set_device(local[0].device)      # (a new thread starts on device 0: the barrier's collective must run on this rank's GPU)
+            library_comm_init(w.rad, rank, world, bcast)
             assert all(t.is_contiguous() and tuple(t.shape) == (nrows, w.ncol) for t in local)
             glob = torch.zeros((len(names), nrows, world * w.ncol), dtype=torch.float64, device=local[0].device) if rank == 0 else None
             lp = [t.data_ptr() for t in local]
