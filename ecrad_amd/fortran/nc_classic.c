@@ -34,7 +34,7 @@
 enum { T_BYTE = 1, T_CHAR = 2, T_SHORT = 3, T_INT = 4, T_FLOAT = 5, T_DOUBLE = 6 };
 enum { E_BADID = -33, E_NFILE = -34, E_INVAL = -36, E_PERM = -37, E_NOTINDEFINE = -38, E_INDEFINE = -39, E_INVALCOORDS = -40,
        E_MAXDIMS = -41, E_NAMEINUSE = -42, E_NOTATT = -43, E_BADTYPE = -45, E_BADDIM = -46, E_NOTVAR = -49, E_NOTNC = -51,
-       E_MAXNAME = -53, E_UNLIMIT = -54, E_CHAR = -56, E_EDGE = -57, E_RANGE = -60, E_NOMEM = -61 };
+       E_MAXNAME = -53, E_UNLIMIT = -54, E_CHAR = -56, E_EDGE = -57, E_RANGE = -60, E_NOMEM = -61, E_HDFERR = -101, E_NOHDF5 = -1101 };
 
 typedef struct { char name[ECNC_MAX_NAME]; uint64_t len; } Dim;
 typedef struct { char name[ECNC_MAX_NAME]; int type; uint64_t n; void* v; /* n values of the file type, host byte order */ } Att;
@@ -46,6 +46,7 @@ typedef struct {
 } Var;
 typedef struct {
   FILE* fp;
+  int64_t h5;      /* version 6: the file is netCDF-4 / HDF5 and is READ through the HDF5 library (ecnc_h5_open) */
   int used, writable, define_mode, version;
   uint64_t numrecs, recsize;
   int ndim, nvar, ngatt, recdim;
@@ -56,6 +57,9 @@ typedef struct {
 
 static File g_files[ECNC_MAX_FILES];
 static int ecnc_h5_enddef(File* f);
+static int ecnc_h5_open(File* f, const char* path);
+static int ecnc_h5_read(File* f, const Var* v, int memtype, void* buf, const long long* s, const long long* c);
+static void ecnc_h5_close(File* f);
 
 static size_t tsize(int t) { return t == T_BYTE || t == T_CHAR ? 1 : t == T_SHORT ? 2 : t == T_INT || t == T_FLOAT ? 4 : t == T_DOUBLE ? 8 : 0; }
 static uint64_t pad4(uint64_t n) { return (n + 3) & ~(uint64_t)3; }
@@ -149,6 +153,7 @@ static void free_file(File* f) {
     free(f->var[v].att);
   }
   free(f->gatt); free(f->var); free(f->dim);
+  if (f->version == 6) ecnc_h5_close(f);
   if (f->fp) fclose(f->fp);
   memset(f, 0, sizeof(*f));
 }
@@ -180,7 +185,14 @@ int ecnc_open(const char* path, int* ncid) {
   if (!f->fp) { st = errno ? errno : 2; f->used = 0; return st; }
   unsigned char magic[4];
   uint32_t tag, n, u;
-  if (fread(magic, 1, 4, f->fp) != 4 || magic[0] != 'C' || magic[1] != 'D' || magic[2] != 'F' || (magic[3] != 1 && magic[3] != 2)) { free_file(f); return E_NOTNC; }
+  if (fread(magic, 1, 4, f->fp) != 4) { free_file(f); return E_NOTNC; }
+  if (magic[0] == 0x89 && magic[1] == 'H' && magic[2] == 'D' && magic[3] == 'F') {      /* netCDF-4: an HDF5 file (signature \211HDF\r\n\032\n) */
+    fclose(f->fp); f->fp = NULL;
+    st = ecnc_h5_open(f, path);
+    if (st) free_file(f);
+    return st;
+  }
+  if (magic[0] != 'C' || magic[1] != 'D' || magic[2] != 'F' || (magic[3] != 1 && magic[3] != 2)) { free_file(f); return E_NOTNC; }
   f->version = magic[3];
   if (rd_u32(f->fp, &u)) { free_file(f); return E_NOTNC; }
   f->numrecs = u;
@@ -509,6 +521,11 @@ static int vara(int ncid, int varid, int memtype, void* buf, int nidx, const lon
     if (c[k] < 0 || s[k] + c[k] > len[k]) return E_EDGE;
   }
   if (nidx && nidx != r) return E_INVALCOORDS;
+  if (f->version == 6) {
+    if (writing) return E_PERM;
+    for (int k = 0; k < r; ++k) if (c[k] == 0) return 0;
+    return ecnc_h5_read(f, v, memtype, buf, s, c);
+  }
   const size_t ts = tsize(v->type), ms = tsize(memtype);
   /* contiguous run: the last dimension (a scalar is one element) -- unless that is the record dimension itself (a
      one-dimensional record variable: one element per record) */
@@ -593,6 +610,8 @@ const char* ecnc_strerror(int st) {
     case E_EDGE: return "NetCDF: Start+count exceeds dimension bound";
     case E_RANGE: return "NetCDF: Numeric conversion not representable";
     case E_NOMEM: return "NetCDF: Memory allocation (malloc) failure";
+    case E_NOHDF5: return "NetCDF: the file is netCDF-4 / HDF5 and no HDF5 library could be loaded (libhdf5.so; set ECRAD_HDF5_LIB)";
+    case E_HDFERR: return "NetCDF: HDF error";
     default: return st > 0 ? strerror(st) : "NetCDF: Unknown error";
   }
 }
@@ -952,3 +971,323 @@ int nf_get_var_double_(const int* ncid, const int* varid, double* vals) { return
 int nf_put_var_double_(const int* ncid, const int* varid, const double* vals) { return vara(*ncid, *varid - 1, T_DOUBLE, (void*)vals, 0, NULL, NULL, 1); }
 int nf_get_var_int_(const int* ncid, const int* varid, int* vals) { return vara(*ncid, *varid - 1, T_INT, vals, 0, NULL, NULL, 0); }
 int nf_put_var_int_(const int* ncid, const int* varid, const int* vals) { return vara(*ncid, *varid - 1, T_INT, (void*)vals, 0, NULL, NULL, 1); }
+
+/* ==================================================================================================================
+ * netCDF-4 INPUT: files in HDF5 format are read through the HDF5 library, loaded at run time (dlopen) -- the host needs it only
+ * when it is handed such a file, and says so when it is not there (E_NOHDF5).  What libnetcdf would do on top of libhdf5 for the
+ * subset a radiation driver meets (utilities/easy_netcdf.F90:133-200 opens whatever the library opens):
+ *   dimensions  = datasets of the root group with CLASS = "DIMENSION_SCALE"; their id is `_Netcdf4Dimid` where the file has it,
+ *                 the order of appearance otherwise; a dataset whose NAME begins "This is a netCDF dimension but not a netCDF
+ *                 variable" is a dimension only, every other dataset is a variable (a coordinate variable is both);
+ *   a variable's dimensions = the scales its DIMENSION_LIST attribute refers to (object references, dereferenced and looked up
+ *                 by name); a dataset without the attribute (a plain HDF5 file) gets anonymous dimensions by length;
+ *   types       = 1/2/4-byte integers, 8-byte integers (read as double), float, double, fixed-length strings of one byte (char);
+ *   attributes  = numeric arrays and fixed- or variable-length strings; HDF5's and netCDF-4's own book-keeping attributes are hidden.
+ * Groups, user-defined types and NC_STRING variables are not read (the reference's files have none).  Values are converted by the HDF5
+ * library to the caller's memory type; hyperslabs map one to one.
+ * ================================================================================================================== */
+#include <dlfcn.h>
+typedef int64_t hid_t;
+typedef int herr_t;
+typedef unsigned long long hsize_t;
+typedef struct { size_t len; void* p; } hvl_t;
+typedef herr_t (*H5A_operator2_t)(hid_t loc, const char* name, const void* ainfo, void* op_data);
+static struct {
+  void* lib;
+  int tried;
+  herr_t (*open)(void);
+  hid_t (*Fopen)(const char*, unsigned, hid_t);
+  herr_t (*Fclose)(hid_t);
+  herr_t (*Gget_num_objs)(hid_t, hsize_t*);
+  long (*Gget_objname_by_idx)(hid_t, hsize_t, char*, size_t);
+  int (*Gget_objtype_by_idx)(hid_t, hsize_t);
+  hid_t (*Dopen2)(hid_t, const char*, hid_t);
+  herr_t (*Dclose)(hid_t);
+  hid_t (*Dget_space)(hid_t);
+  hid_t (*Dget_type)(hid_t);
+  herr_t (*Dread)(hid_t, hid_t, hid_t, hid_t, hid_t, void*);
+  herr_t (*Dvlen_reclaim)(hid_t, hid_t, hid_t, void*);
+  int (*Sget_simple_extent_ndims)(hid_t);
+  int (*Sget_simple_extent_dims)(hid_t, hsize_t*, hsize_t*);
+  long long (*Sget_simple_extent_npoints)(hid_t);
+  hid_t (*Screate_simple)(int, const hsize_t*, const hsize_t*);
+  herr_t (*Sselect_hyperslab)(hid_t, int, const hsize_t*, const hsize_t*, const hsize_t*, const hsize_t*);
+  herr_t (*Sclose)(hid_t);
+  int (*Tget_class)(hid_t);
+  size_t (*Tget_size)(hid_t);
+  int (*Tis_variable_str)(hid_t);
+  hid_t (*Tcopy)(hid_t);
+  herr_t (*Tset_size)(hid_t, size_t);
+  herr_t (*Tclose)(hid_t);
+  int (*Aexists)(hid_t, const char*);
+  hid_t (*Aopen)(hid_t, const char*, hid_t);
+  herr_t (*Aclose)(hid_t);
+  hid_t (*Aget_type)(hid_t);
+  hid_t (*Aget_space)(hid_t);
+  herr_t (*Aread)(hid_t, hid_t, void*);
+  herr_t (*Aiterate2)(hid_t, int, int, hsize_t*, H5A_operator2_t, void*);
+  hid_t (*Rdereference2)(hid_t, hid_t, int, const void*);
+  hid_t (*Rdereference1)(hid_t, int, const void*);
+  long (*Iget_name)(hid_t, char*, size_t);
+  herr_t (*Oclose)(hid_t);
+  herr_t (*Eset_auto2)(hid_t, void*, void*);
+  herr_t (*free_memory)(void*);
+  hid_t t_double, t_float, t_int, t_short, t_schar, t_c_s1, t_ref_obj;
+} H5;
+
+static int h5_load(void) {
+  if (H5.tried) return H5.lib ? 0 : E_NOHDF5;
+  H5.tried = 1;
+  const char* names[] = {getenv("ECRAD_HDF5_LIB"), "libhdf5.so", "libhdf5_serial.so", "libhdf5.so.103", "libhdf5.so.200", "libhdf5.so.310",
+                         "/opt/conda/lib/libhdf5.so", "/usr/lib/x86_64-linux-gnu/hdf5/serial/libhdf5.so"};
+  void* lib = NULL;
+  for (size_t i = 0; i < sizeof names / sizeof names[0] && !lib; ++i)
+    if (names[i] && names[i][0]) lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+  if (!lib) return E_NOHDF5;
+  int missing = 0;
+#define H5SYM(field, sym) do { *(void**)&H5.field = dlsym(lib, sym); if (!H5.field) missing = 1; } while (0)
+  H5SYM(open, "H5open"); H5SYM(Fopen, "H5Fopen"); H5SYM(Fclose, "H5Fclose"); H5SYM(Gget_num_objs, "H5Gget_num_objs");
+  H5SYM(Gget_objname_by_idx, "H5Gget_objname_by_idx"); H5SYM(Gget_objtype_by_idx, "H5Gget_objtype_by_idx");
+  H5SYM(Dopen2, "H5Dopen2"); H5SYM(Dclose, "H5Dclose"); H5SYM(Dget_space, "H5Dget_space"); H5SYM(Dget_type, "H5Dget_type"); H5SYM(Dread, "H5Dread");
+  H5SYM(Sget_simple_extent_ndims, "H5Sget_simple_extent_ndims"); H5SYM(Sget_simple_extent_dims, "H5Sget_simple_extent_dims");
+  H5SYM(Sget_simple_extent_npoints, "H5Sget_simple_extent_npoints"); H5SYM(Screate_simple, "H5Screate_simple");
+  H5SYM(Sselect_hyperslab, "H5Sselect_hyperslab"); H5SYM(Sclose, "H5Sclose");
+  H5SYM(Tget_class, "H5Tget_class"); H5SYM(Tget_size, "H5Tget_size"); H5SYM(Tis_variable_str, "H5Tis_variable_str"); H5SYM(Tcopy, "H5Tcopy");
+  H5SYM(Tset_size, "H5Tset_size"); H5SYM(Tclose, "H5Tclose");
+  H5SYM(Aexists, "H5Aexists"); H5SYM(Aopen, "H5Aopen"); H5SYM(Aclose, "H5Aclose"); H5SYM(Aget_type, "H5Aget_type"); H5SYM(Aget_space, "H5Aget_space");
+  H5SYM(Aread, "H5Aread"); H5SYM(Aiterate2, "H5Aiterate2"); H5SYM(Iget_name, "H5Iget_name"); H5SYM(Oclose, "H5Oclose");
+#undef H5SYM
+  *(void**)&H5.Rdereference2 = dlsym(lib, "H5Rdereference2");
+  *(void**)&H5.Rdereference1 = dlsym(lib, "H5Rdereference1");
+  if (!H5.Rdereference2 && !H5.Rdereference1) *(void**)&H5.Rdereference1 = dlsym(lib, "H5Rdereference");      /* (1.8: the three-argument form) */
+  *(void**)&H5.Dvlen_reclaim = dlsym(lib, "H5Dvlen_reclaim");
+  *(void**)&H5.Eset_auto2 = dlsym(lib, "H5Eset_auto2");
+  *(void**)&H5.free_memory = dlsym(lib, "H5free_memory");
+  if (missing || (!H5.Rdereference2 && !H5.Rdereference1) || H5.open() < 0) { dlclose(lib); return E_NOHDF5; }
+  const char* tn[] = {"H5T_NATIVE_DOUBLE_g", "H5T_NATIVE_FLOAT_g", "H5T_NATIVE_INT_g", "H5T_NATIVE_SHORT_g", "H5T_NATIVE_SCHAR_g", "H5T_C_S1_g", "H5T_STD_REF_OBJ_g"};
+  hid_t* tv[] = {&H5.t_double, &H5.t_float, &H5.t_int, &H5.t_short, &H5.t_schar, &H5.t_c_s1, &H5.t_ref_obj};
+  for (int i = 0; i < 7; ++i) { const hid_t* g = (const hid_t*)dlsym(lib, tn[i]); if (!g) { dlclose(lib); return E_NOHDF5; } *tv[i] = *g; }
+  if (H5.Eset_auto2) H5.Eset_auto2(0, NULL, NULL);      /* errors come back as statuses, not as text on standard error */
+  H5.lib = lib;
+  return 0;
+}
+
+static hid_t h5_memtype(int t) { return t == T_DOUBLE ? H5.t_double : t == T_FLOAT ? H5.t_float : t == T_INT ? H5.t_int : t == T_SHORT ? H5.t_short : H5.t_schar; }
+
+static int h5_hidden_att(const char* name) {
+  const char* hide[] = {"DIMENSION_LIST", "REFERENCE_LIST", "CLASS", "NAME", "_Netcdf4Dimid", "_Netcdf4Coordinates", "_nc3_strict", "_NCProperties",
+                        "_NCZARR_ATTR", "_Netcdf4BitGroomingOk"};
+  for (size_t i = 0; i < sizeof hide / sizeof hide[0]; ++i) if (!strcmp(name, hide[i])) return 1;
+  return 0;
+}
+
+/* a string attribute of `obj` (fixed or variable length) into buf; 0 if absent or not a string */
+static int h5_string_att(hid_t obj, const char* name, char* buf, size_t cap) {
+  buf[0] = 0;
+  if (H5.Aexists(obj, name) <= 0) return 0;
+  const hid_t a = H5.Aopen(obj, name, 0);
+  if (a < 0) return 0;
+  const hid_t t = H5.Aget_type(a);
+  int ok = 0;
+  if (H5.Tget_class(t) == 3) {
+    if (H5.Tis_variable_str(t) > 0) {
+      char* p = NULL;
+      if (H5.Aread(a, t, &p) >= 0 && p) { strncpy(buf, p, cap - 1); buf[cap - 1] = 0; ok = 1; if (H5.free_memory) H5.free_memory(p); }
+    } else {
+      const size_t n = H5.Tget_size(t);
+      char* tmp = (char*)calloc(n + 1, 1);
+      if (tmp && H5.Aread(a, t, tmp) >= 0) { strncpy(buf, tmp, cap - 1); buf[cap - 1] = 0; ok = 1; }
+      free(tmp);
+    }
+  }
+  H5.Tclose(t); H5.Aclose(a);
+  return ok;
+}
+
+typedef struct { Att** att; int* natt; int st; hid_t obj; } H5AttWalk;
+static herr_t h5_att_cb(hid_t loc, const char* name, const void* ainfo, void* op) {
+  (void)ainfo;
+  H5AttWalk* w = (H5AttWalk*)op;
+  if (h5_hidden_att(name) || strlen(name) >= ECNC_MAX_NAME) return 0;
+  const hid_t a = H5.Aopen(loc, name, 0);
+  if (a < 0) return 0;
+  const hid_t t = H5.Aget_type(a), sp = H5.Aget_space(a);
+  const int cls = H5.Tget_class(t);
+  const size_t sz = H5.Tget_size(t);
+  const long long np = H5.Sget_simple_extent_npoints(sp);
+  Att x;
+  memset(&x, 0, sizeof x);
+  strcpy(x.name, name);
+  int keep = 0;
+  if (cls == 3) {      /* string: one netCDF text attribute */
+    x.type = T_CHAR;
+    if (H5.Tis_variable_str(t) > 0) {
+      char* p = NULL;
+      if (np == 1 && H5.Aread(a, t, &p) >= 0 && p) { x.n = strlen(p); x.v = malloc(x.n + 1); if (x.v) { memcpy(x.v, p, x.n + 1); keep = 1; } if (H5.free_memory) H5.free_memory(p); }
+    } else if (np >= 1) {
+      x.v = calloc((size_t)np * sz + 1, 1);
+      if (x.v && H5.Aread(a, t, x.v) >= 0) { x.n = strnlen((const char*)x.v, (size_t)np * sz); keep = 1; }
+    }
+  } else if ((cls == 0 || cls == 1) && np >= 1) {
+    x.type = cls == 1 ? (sz == 4 ? T_FLOAT : T_DOUBLE) : (sz == 1 ? T_BYTE : sz == 2 ? T_SHORT : sz == 4 ? T_INT : T_DOUBLE);
+    x.n = (uint64_t)np;
+    x.v = malloc((size_t)np * tsize(x.type));
+    if (x.v && H5.Aread(a, h5_memtype(x.type), x.v) >= 0) keep = 1;
+  }
+  H5.Sclose(sp); H5.Tclose(t); H5.Aclose(a);
+  if (!keep) { free(x.v); return 0; }
+  Att* grown = (Att*)realloc(*w->att, (size_t)(*w->natt + 1) * sizeof(Att));
+  if (!grown) { free(x.v); w->st = E_NOMEM; return -1; }
+  *w->att = grown;
+  grown[(*w->natt)++] = x;
+  return 0;
+}
+static int h5_read_atts(hid_t obj, int* natt, Att** att) {
+  H5AttWalk w = {att, natt, 0, obj};
+  hsize_t idx = 0;
+  *natt = 0; *att = NULL;
+  /* in creation order where the file tracks it (files of libnetcdf do), otherwise in the order the attributes lie in the object header
+     (H5_ITER_NATIVE over the name index): the order in which they were written, which is what nf90_inq_attname numbers */
+  if (H5.Aiterate2(obj, 1 /* H5_INDEX_CRT_ORDER */, 0 /* H5_ITER_INC */, &idx, h5_att_cb, &w) < 0 && !w.st) {
+    for (int i = 0; i < *natt; ++i) free((*att)[i].v);
+    free(*att);
+    *natt = 0; *att = NULL; idx = 0;
+    H5.Aiterate2(obj, 0 /* H5_INDEX_NAME */, 2 /* H5_ITER_NATIVE */, &idx, h5_att_cb, &w);
+  }
+  return w.st;
+}
+
+static int ecnc_h5_open(File* f, const char* path) {
+  int st = h5_load();
+  if (st) return st;
+  const hid_t fid = H5.Fopen(path, 0, 0);
+  if (fid < 0) return E_HDFERR;
+  f->h5 = fid; f->version = 6; f->recdim = -1;
+  hsize_t nobj = 0;
+  if (H5.Gget_num_objs(fid, &nobj) < 0) return E_HDFERR;
+  f->dim = (Dim*)calloc((size_t)nobj * (ECNC_MAX_DIMS + 1) + 1, sizeof(Dim));      /* (room for anonymous dimensions of plain HDF5 files) */
+  f->var = (Var*)calloc((size_t)nobj + 1, sizeof(Var));
+  if (!f->dim || !f->var) return E_NOMEM;
+  /* pass 1: the dimension scales, in the order of their ids where the file carries them */
+  int* dimid_of = (int*)malloc(((size_t)nobj + 1) * sizeof(int));
+  int* pure = (int*)calloc((size_t)nobj + 1, sizeof(int));
+  char (*names)[ECNC_MAX_NAME] = (char (*)[ECNC_MAX_NAME])calloc((size_t)nobj + 1, ECNC_MAX_NAME);
+  if (!dimid_of || !pure || !names) { free(dimid_of); free(pure); free(names); return E_NOMEM; }
+  int nscale = 0, have_ids = 1;
+  for (hsize_t i = 0; i < nobj; ++i) {
+    dimid_of[i] = -1;
+    if (H5.Gget_objtype_by_idx(fid, i) != 1 /* H5G_DATASET */) continue;
+    if (H5.Gget_objname_by_idx(fid, i, names[i], ECNC_MAX_NAME) <= 0) { names[i][0] = 0; continue; }
+    const hid_t d = H5.Dopen2(fid, names[i], 0);
+    if (d < 0) { names[i][0] = 0; continue; }
+    char cls[64], nm[128];
+    if (h5_string_att(d, "CLASS", cls, sizeof cls) && !strcmp(cls, "DIMENSION_SCALE")) {
+      dimid_of[i] = -2 - nscale++;      /* provisional: order of appearance */
+      if (H5.Aexists(d, "_Netcdf4Dimid") > 0) {
+        const hid_t a = H5.Aopen(d, "_Netcdf4Dimid", 0);
+        int id = -1;
+        if (a >= 0 && H5.Aread(a, H5.t_int, &id) >= 0 && id >= 0 && (hsize_t)id < nobj) dimid_of[i] = id; else have_ids = 0;
+        if (a >= 0) H5.Aclose(a);
+      } else have_ids = 0;
+      if (h5_string_att(d, "NAME", nm, sizeof nm) && !strncmp(nm, "This is a netCDF dimension but not a netCDF variable", 52)) pure[i] = 1;
+    }
+    H5.Dclose(d);
+  }
+  for (hsize_t i = 0, k = 0; i < nobj; ++i) {
+    if (dimid_of[i] == -1) continue;
+    const int id = have_ids && dimid_of[i] >= 0 && dimid_of[i] < nscale ? dimid_of[i] : (int)k;
+    if (!have_ids || dimid_of[i] < 0 || dimid_of[i] >= nscale) dimid_of[i] = id;
+    ++k;
+    const hid_t d = H5.Dopen2(fid, names[i], 0), sp = H5.Dget_space(d);
+    hsize_t len[ECNC_MAX_DIMS + 24] = {0}, mx[ECNC_MAX_DIMS + 24] = {0};
+    if (H5.Sget_simple_extent_ndims(sp) >= 1 && H5.Sget_simple_extent_ndims(sp) <= ECNC_MAX_DIMS) H5.Sget_simple_extent_dims(sp, len, mx);
+    strncpy(f->dim[id].name, names[i], ECNC_MAX_NAME - 1);
+    f->dim[id].len = len[0];
+    if (mx[0] == (hsize_t)-1 && f->recdim < 0) f->recdim = id;      /* H5S_UNLIMITED: reported as the record dimension (its current length is its length) */
+    H5.Sclose(sp); H5.Dclose(d);
+  }
+  f->ndim = nscale;
+  /* pass 2: the variables */
+  for (hsize_t i = 0; i < nobj && !st; ++i) {
+    if (!names[i][0] || pure[i]) continue;
+    const hid_t d = H5.Dopen2(fid, names[i], 0);
+    if (d < 0) continue;
+    const hid_t sp = H5.Dget_space(d), t = H5.Dget_type(d);
+    const int rank = H5.Sget_simple_extent_ndims(sp), cls = H5.Tget_class(t);
+    const size_t sz = H5.Tget_size(t);
+    int type = 0;
+    if (cls == 1) type = sz == 4 ? T_FLOAT : sz == 8 ? T_DOUBLE : 0;
+    else if (cls == 0) type = sz == 1 ? T_BYTE : sz == 2 ? T_SHORT : sz == 4 ? T_INT : sz == 8 ? T_DOUBLE : 0;
+    else if (cls == 3 && sz == 1 && H5.Tis_variable_str(t) <= 0) type = T_CHAR;
+    if (type && rank >= 0 && rank <= ECNC_MAX_DIMS) {
+      Var* v = &f->var[f->nvar];
+      strncpy(v->name, names[i], ECNC_MAX_NAME - 1);
+      v->type = type; v->rank = rank;
+      hsize_t len[ECNC_MAX_DIMS + 1] = {0};
+      if (rank) H5.Sget_simple_extent_dims(sp, len, NULL);
+      int resolved = 0;
+      if (dimid_of[i] >= 0 && rank == 1) { v->dimid[0] = dimid_of[i]; resolved = 1; }      /* a coordinate variable */
+      else if (rank && H5.Aexists(d, "DIMENSION_LIST") > 0) {
+        const hid_t a = H5.Aopen(d, "DIMENSION_LIST", 0), at = H5.Aget_type(a), as = H5.Aget_space(a);
+        hvl_t refs[ECNC_MAX_DIMS];
+        memset(refs, 0, sizeof refs);
+        if (H5.Sget_simple_extent_npoints(as) == rank && H5.Aread(a, at, refs) >= 0) {
+          resolved = 1;
+          for (int k = 0; k < rank; ++k) {
+            v->dimid[k] = -1;
+            if (refs[k].len >= 1 && refs[k].p) {
+              const hid_t o = H5.Rdereference2 ? H5.Rdereference2(fid, 0, 0 /* H5R_OBJECT */, refs[k].p) : H5.Rdereference1(fid, 0, refs[k].p);
+              char on[ECNC_MAX_NAME + 2];
+              if (o >= 0 && H5.Iget_name(o, on, sizeof on) > 0)
+                for (int q = 0; q < f->ndim; ++q) if (!strcmp(f->dim[q].name, on[0] == '/' ? on + 1 : on)) v->dimid[k] = q;
+              if (o >= 0) H5.Oclose(o);
+            }
+            if (v->dimid[k] < 0) resolved = 0;
+          }
+          if (H5.Dvlen_reclaim) H5.Dvlen_reclaim(at, as, 0, refs);
+        }
+        H5.Sclose(as); H5.Tclose(at); H5.Aclose(a);
+      }
+      if (rank && !resolved)      /* a plain HDF5 dataset: anonymous dimensions, one per distinct length (as libnetcdf's phony_dim_N) */
+        for (int k = 0; k < rank; ++k) {
+          int q = -1;
+          for (int j = nscale; j < f->ndim; ++j) if (f->dim[j].len == len[k]) q = j;
+          if (q < 0) { q = f->ndim++; snprintf(f->dim[q].name, ECNC_MAX_NAME, "phony_dim_%d", q - nscale); f->dim[q].len = len[k]; }
+          v->dimid[k] = q;
+        }
+      v->is_rec = 0;
+      st = h5_read_atts(d, &v->natt, &v->att);
+      f->nvar++;
+    }
+    H5.Tclose(t); H5.Sclose(sp); H5.Dclose(d);
+  }
+  if (!st) st = h5_read_atts(fid, &f->ngatt, &f->gatt);
+  free(dimid_of); free(pure); free(names);
+  return st;
+}
+
+static int ecnc_h5_read(File* f, const Var* v, int memtype, void* buf, const long long* s, const long long* c) {
+  const hid_t d = H5.Dopen2((hid_t)f->h5, v->name, 0);
+  if (d < 0) return E_HDFERR;
+  int st = 0;
+  hid_t mt = h5_memtype(memtype), own = -1;
+  if (memtype == T_CHAR) { own = H5.Tcopy(H5.t_c_s1); H5.Tset_size(own, 1); mt = own; }
+  if (v->rank == 0) {
+    if (H5.Dread(d, mt, 0, 0, 0, buf) < 0) st = E_HDFERR;
+  } else {
+    hsize_t start[ECNC_MAX_DIMS], count[ECNC_MAX_DIMS];
+    for (int k = 0; k < v->rank; ++k) { start[k] = (hsize_t)s[k]; count[k] = (hsize_t)c[k]; }
+    const hid_t fs = H5.Dget_space(d), ms = H5.Screate_simple(v->rank, count, NULL);
+    if (fs < 0 || ms < 0 || H5.Sselect_hyperslab(fs, 0 /* H5S_SELECT_SET */, start, NULL, count, NULL) < 0 || H5.Dread(d, mt, ms, fs, 0, buf) < 0) st = E_HDFERR;
+    if (ms >= 0) H5.Sclose(ms);
+    if (fs >= 0) H5.Sclose(fs);
+  }
+  if (own >= 0) H5.Tclose(own);
+  H5.Dclose(d);
+  return st;
+}
+
+static void ecnc_h5_close(File* f) {
+  if (H5.lib && f->h5 > 0) H5.Fclose((hid_t)f->h5);
+  f->h5 = 0;
+}

@@ -131,10 +131,11 @@ def write_nc4(path: str, dims: dict, variables: dict, attrs: dict | None = None,
     for name, spec in variables.items():
         dn, arr = tuple(spec[0]), np.asarray(spec[1])
         vattrs = spec[2] if len(spec) > 2 else {}
+        shape0 = arr.shape      # (ascontiguousarray makes a scalar one-dimensional)
         if arr.dtype.kind == "f":
-            arr = np.ascontiguousarray(arr, dtype="<f8" if double else "<f4")
+            arr = np.ascontiguousarray(arr, dtype="<f8" if double else "<f4").reshape(shape0)
         else:
-            arr = np.ascontiguousarray(arr, dtype="<i4")
+            arr = np.ascontiguousarray(arr, dtype="<i4").reshape(shape0)
         if tuple(arr.shape) != tuple(dims[d] for d in dn):
             raise ValueError(f"{name}: shape {arr.shape} does not match dimensions {dn}")
         ds = _Dataset(name, arr.shape, arr.dtype, arr.tobytes())

@@ -682,6 +682,36 @@ def test_dropin_driver_writes_netcdf4_when_asked(tmp_path):
     h5.h5.H5Fclose(f)
 
 
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(EXE), reason="tests/_build/dropin/ecrad_hip has not been built (tools/build_dropin.py)")
+def test_dropin_driver_reads_a_netcdf4_input_file(tmp_path):
+    """The reference's unmodified driver + the drop-in, handed its input as a netCDF-4 / HDF5 file (test/ifs/ecrad_meridian.nc rewritten by
+    ecrad_amd/hdf5file.py; easy_netcdf.F90:133-200 opens whatever the netCDF library opens): the repo's netcdf module reads it through the HDF5
+    library (nc_classic.c: ecnc_h5_open), and every variable of the output equals the run on the classic file."""
+    from scipy.io import netcdf_file
+    from ecrad_amd.hdf5file import write_nc4
+    with netcdf_file(MERIDIAN, "r", mmap=False) as nc:
+        dims = {d: (n if n is not None else nc.variables["pressure_hl"].shape[0]) for d, n in nc.dimensions.items()}
+        variables = {name: (v.dimensions, np.array(v.data).reshape(v.shape)) for name, v in nc.variables.items()}
+    inp4 = str(tmp_path / "meridian4.nc")
+    write_nc4(inp4, dims, variables, double=True)
+    assert open(inp4, "rb").read(4) == b"\x89HDF"
+    family, edits = TARGETS["tripleclouds"]
+    outs = {}
+    for tag, inp in (("classic", MERIDIAN), ("nc4", inp4)):
+        nam, out = str(tmp_path / f"{tag}.nam"), str(tmp_path / f"{tag}_out.nc")
+        write_namelist(nam, family, edits)
+        p = _run(f"ulimit -s unlimited; exec {EXE} {nam} {inp} {out}", shell=True, capture_output=True, text=True,
+                 cwd=str(tmp_path), env=dict(os.environ, OMP_NUM_THREADS="1", OMP_STACKSIZE="1G"), timeout=900)
+        assert p.returncode == 0 and os.path.exists(out), (p.stdout + p.stderr)[-3000:]
+        outs[tag] = out
+    with NcFile(outs["classic"]) as a, NcFile(outs["nc4"]) as b:
+        names = list(a._f.variables)
+        assert len(names) >= 20 and sorted(names) == sorted(b._f.variables)
+        for v in names:
+            assert np.array_equal(a.get(v), b.get(v), equal_nan=True), v
+
+
 SP_OMP_EXE = os.path.join(ROOT, "tests", "_build", "dropin_sp_omp", "ecrad_hip")
 
 

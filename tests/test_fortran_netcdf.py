@@ -134,7 +134,10 @@ def test_errors_are_netcdf_status_codes(exe, tmp_path):
     p = subprocess.run([exe, "dump", str(tmp_path / "absent.nc"), "x"], capture_output=True, text=True)
     assert p.returncode != 0 and "FAILED open" in p.stdout and "No such file" in p.stdout
     junk = tmp_path / "junk.nc"
-    junk.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)
+    junk.write_bytes(b"\x89HDF\r\n\x1a\n" + b"\0" * 64)      # the HDF5 signature and nothing behind it: the HDF5 library (netCDF-4 input, round 6) refuses it
+    p = subprocess.run([exe, "dump", str(junk), "x"], capture_output=True, text=True)
+    assert p.returncode != 0 and ("HDF error" in p.stdout or "no HDF5 library" in p.stdout)
+    junk.write_bytes(b"not a netCDF file at all")
     p = subprocess.run([exe, "dump", str(junk), "x"], capture_output=True, text=True)
     assert p.returncode != 0 and "Unknown file format" in p.stdout
     p = subprocess.run([exe, "dump", MERIDIAN, "no_such_variable"], capture_output=True, text=True)
