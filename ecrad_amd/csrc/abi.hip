@@ -74,9 +74,18 @@ int ecrad_hip_radiation_f32(ecrad_hip_handle_t h, int ncol, int nlev, int istart
   if (in->memory != ECRAD_MEM_HOST || flux->memory != ECRAD_MEM_HOST)
     return fail_call(h, ECRAD_EUNSUPPORTED, "ecrad_hip_radiation_f32 takes host arrays (a single-precision HOST model)");
   if (ncol < 1 || nlev < 2 || istartcol < 1 || iendcol > ncol || iendcol < istartcol) return fail_call(h, ECRAD_EINVAL, "bad column/level range");
-  if (!h->is_setup) return fail_call(h, ECRAD_ENOTSETUP, "ecrad_hip_setup has not been called");
+  // (the configuration as the last completed set-up left it: a set-up or a change of the pool that is under way on another thread holds the
+  //  handle exclusively -- LeaseAll -- and this call waits for it instead of reading a half-written struct)
+  ecrad_config_t c;
+  bool is_setup;
+  uint32_t gas_used;
+  {
+    std::unique_lock<std::mutex> lk(h->pool_mutex);
+    h->pool_cv.wait(lk, [&] { return !h->exclusive; });
+    is_setup = h->is_setup; c = h->cfg; gas_used = h->gas_used;
+  }
+  if (!is_setup) return fail_call(h, ECRAD_ENOTSETUP, "ecrad_hip_setup has not been called");
   if (!in->pressure_hl || !in->temperature_hl || !in->gas_mixing_ratio) return fail_call(h, ECRAD_EINVAL, "thermodynamics/gas arrays missing");
-  const ecrad_config_t& c = h->cfg;
   if (c.do_clouds && (!in->cloud_fraction || in->n_cloud_types != c.n_cloud_types)) return fail_call(h, ECRAD_EINVAL, "cloud arrays missing");
   if (c.use_aerosols && (in->aerosol_istartlev < 1 || in->aerosol_iendlev > nlev || in->aerosol_iendlev < in->aerosol_istartlev))
     return fail_call(h, ECRAD_EINVAL, "aerosol level range");
@@ -104,7 +113,7 @@ int ecrad_hip_radiation_f32(ecrad_hip_handle_t h, int ncol, int nlev, int istart
   prof(s.sw_albedo_direct, in->sw_albedo_direct, (size_t)in->n_sw_albedo);
   prof(s.lw_emissivity, in->lw_emissivity, (size_t)in->n_lw_emissivity);
   for (int k = 0; k < ECRAD_NMAXGASES; ++k)      // the planes some kernel reads (ecrad_hip_setup: gas_used)
-    if (h->gas_used & (1u << k)) jobs.push_back({s.gas_mixing_ratio + (size_t)k * L * n, F(in->gas_mixing_ratio) + (size_t)k * L * N + i0, L, n, N});
+    if (gas_used & (1u << k)) jobs.push_back({s.gas_mixing_ratio + (size_t)k * L * n, F(in->gas_mixing_ratio) + (size_t)k * L * N + i0, L, n, N});
   if (c.do_clouds) {
     prof(s.cloud_fraction, in->cloud_fraction, L);
     prof(s.cloud_mixing_ratio, in->cloud_mixing_ratio, L * in->n_cloud_types);

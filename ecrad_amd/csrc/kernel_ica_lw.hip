@@ -71,6 +71,14 @@ constexpr int kLwBatch = ECRAD_LW_BATCH;
 #ifndef ECRAD_LW_W_RING
 #define ECRAD_LW_W_RING 4     // layers of (T, S) pairs W keeps in flight
 #endif
+#ifndef ECRAD_LW_RECOMPUTE_CLEAR
+// McICA on the RRTMG stage arrays (StageD, MERGED): the clear-sky record of a layer -- (T, SU) and, below cloud top, SD -- is NOT written by
+// pass A and read back by the upward sweeps U and W; they read the layer's (od, Planck) from the stage arrays instead -- the same 16-24
+// bytes -- and evaluate no_scattering_lw again (one exponential).  16-24 of the ~100 bytes a (g-point, layer) moves through HBM in these
+// kernels, which run at the bandwidth of exactly such records.  Only where the stage optical depth is the layer's whole clear-sky optical
+// depth (aerosols folded in by the gas-optics pass, or none).  Same function, same inputs: the same (T, SU, SD).
+#define ECRAD_LW_RECOMPUTE_CLEAR 1
+#endif
 constexpr int kCldU = ECRAD_LW_CLD_U, kCldD = ECRAD_LW_CLD_D, kCldV = ECRAD_LW_CLD_V;    // (T, S) pairs are 16 B per layer, so the longwave sweep can look further ahead
 
 // Records of one layer for the cloudy-sky sweeps (free functions, not lambdas: the batch arrays must stay in registers)
@@ -80,6 +88,12 @@ struct LwUpRec { double2 a, b; };      // cloudy: a = (R, T), b = (SU, SD);  cle
 ECRAD_DEV void lw_up_load(const LwScratch& s, bool cloudy, int l, int tid, LwUpRec& r) {
   if (cloudy) { r.a = s.pair(P_RT2, l, tid); r.b = s.pair(P_S2, l, tid); }
   else { r.a = s.pair(P_CLR, l, tid); r.b = make_double2(0.0, s.single(S_SD1, l, tid)); }
+}
+// ECRAD_LW_RECOMPUTE_CLEAR: a clear layer's entry is (od, Planck at its lower half level), (Planck at its upper half level, -)
+// from the stage arrays (od at `sod`, Planck at `spl`: this lane's g-point of this column, layer stride ng); lw_up_clear turns it into (T, SU), SD
+ECRAD_DEV void lw_up_load_stage(const LwScratch& s, bool cloudy, int l, int tid, const double* sod, const double* spl, size_t ng, LwUpRec& r) {
+  if (cloudy) { r.a = s.pair(P_RT2, l, tid); r.b = s.pair(P_S2, l, tid); }
+  else { r.a = make_double2(sod[ng * (size_t)l], spl[ng * (size_t)(l + 1)]); r.b = make_double2(spl[ng * (size_t)l], 0.0); }
 }
 struct LwDnRec { double2 d, as; };     // (a1, c), (albedo, source) below the layer
 ECRAD_DEV void lw_dn_load(const LwScratch& s, int l, int tid, LwDnRec& r) {
@@ -146,6 +160,8 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
     const bool use_aerosols = cfg.use_aerosols != 0 && !a.in.gs.aer_folded_lw;   // (folded: od_lw of the RRTMG pass includes them)
     const bool cloud_scattering = cfg.do_lw_cloud_scattering != 0;
     const double cloud_fraction_threshold = cfg.cloud_fraction_threshold;
+    constexpr bool kRecompute = ECRAD_LW_RECOMPUTE_CLEAR != 0 && MODE == 2 && IsStage<TAB>::value;      // (see ECRAD_LW_RECOMPUTE_CLEAR)
+    const bool recompute = kRecompute && !use_aerosols;
 
     const int cloc_raw = grp * CPB + cib;
     const bool col_ok = cloc_raw < ncol_loc;
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
           pend_t = c.transmittance; pend_su = c.source_up; pend_lev = lev;
         } else {
 #if !(ECRAD_ABLATE & 8)
-          s.pair(P_CLR, lev, tid) = make_double2(c.transmittance, c.source_up);
+          if (!recompute) s.pair(P_CLR, lev, tid) = make_double2(c.transmittance, c.source_up);
 #endif
         }
         ECRAD_LAP0(tm, 4);              // scratch store acknowledged
@@ -347,7 +363,7 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
             }
             s.pair(P_RT2, lev, tid) = make_double2(c2.reflectance, c2.transmittance);
             s.pair(P_S2, lev, tid) = make_double2(c2.source_up, c2.source_dn);
-          } else if (cloudy.any()) {
+          } else if (cloudy.any() && !recompute) {
             // clear layer below the first cloudy one: the cloudy-sky sweep needs its downward source too
             s.single(S_SD1, lev, tid) = c.source_dn;
           }
@@ -584,6 +600,18 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
     // (albedo, source) below the layer in P_AS, so that   fdn <- a1 fdn + c,   fup = albedo fdn + source
     // (radiation_adding_ica_lw.F90:192-216 with 1/(1 - albedo R) folded into a1 and c)
     double alb = albedo, src = emission;
+    // (ECRAD_LW_RECOMPUTE_CLEAR: this lane's column of the stage arrays, layer / half-level stride ng)
+    const double* sod = nullptr;
+    const double* spl = nullptr;
+    if constexpr (kRecompute) {
+      const DevGasStage& gs = kernarg_block<SpectralArgs>().in.gs;
+      sod = gs.od_lw + (g + (size_t)ng * ((size_t)nlev * cloc));
+      spl = gs.planck_hl + (g + (size_t)ng * ((size_t)(nlev + 1) * cloc));
+    }
+    auto up_load = [&](bool is_cloudy, int l, LwUpRec& r) {
+      if (kRecompute && recompute) lw_up_load_stage(s, is_cloudy, l, tid, sod, spl, (size_t)ng, r);
+      else lw_up_load(s, is_cloudy, l, tid, r);
+    };
     if (do_set2) {
       // (out-of-range entries of a batch load a clamped layer instead of nothing: every entry is always defined, and
       // no value has to be carried around the column-group loop)
@@ -591,11 +619,11 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
       LwUpRec cur[kCldU], nxt[kCldU];
 #pragma unroll
       for (int k = 0; k < kCldU; ++k)
-        { const int l = imax(nlev - 1 - k, ict_c); lw_up_load(s, cloudy.test(l), l, tid, cur[k]); }
+        { const int l = imax(nlev - 1 - k, ict_c); up_load(cloudy.test(l), l, cur[k]); }
       for (int l0 = nlev - 1; l0 >= ict; l0 -= kCldU) {
 #pragma unroll
         for (int k = 0; k < kCldU; ++k)
-          { const int l = imax(l0 - kCldU - k, ict_c); lw_up_load(s, cloudy.test(l), l, tid, nxt[k]); }
+          { const int l = imax(l0 - kCldU - k, ict_c); up_load(cloudy.test(l), l, nxt[k]); }
 #pragma unroll
         for (int k = 0; k < kCldU; ++k) {
           const int l = l0 - k;
@@ -609,9 +637,13 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
               alb = R + T * T * alb * inv;
               src = src_new;
             } else {
-              const double T = cur[k].a.x;
-              s.pair(P_DN, l, tid) = make_double2(T, cur[k].b.y);
-              const double src_new = cur[k].a.y + T * (src + alb * cur[k].b.y);
+              double T = cur[k].a.x, SU = cur[k].a.y, SD = cur[k].b.y;
+              if (kRecompute && recompute) {      // the entry is (od, Planck below), (Planck above, -)
+                const LwCoef cc = no_scattering_lw(cur[k].a.x, cur[k].b.x, cur[k].a.y);
+                T = cc.transmittance; SU = cc.source_up; SD = cc.source_dn;
+              }
+              s.pair(P_DN, l, tid) = make_double2(T, SD);
+              const double src_new = SU + T * (src + alb * SD);
               alb = T * T * alb;
               src = src_new;
             }
@@ -729,9 +761,12 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
       constexpr int kW = ECRAD_LW_W_RING;
       double2 ring_c[kW];
       double ring_t[kW];
+      double pl_below = 0.0;      // (recompute) Planck function at the half level below the layer W is at
+      if (kRecompute && recompute) pl_below = spl[(size_t)ng * (size_t)nlev];
       auto fetch = [&](int lr, double2& c, double& t) {
         const int l = imax(lr, 0);
-        c = s.pair(P_CLR, l, tid);
+        if (kRecompute && recompute) c = make_double2(sod[(size_t)ng * (size_t)l], spl[(size_t)ng * (size_t)l]);      // (od, Planck at the layer's upper half level)
+        else c = s.pair(P_CLR, l, tid);
         t = 0.0;
         if (set2 && cloudy.test(l)) { const double2 rt = s.pair(P_RT2, l, tid); t = rt.y; }
       };
@@ -781,7 +816,12 @@ __global__ __launch_bounds__(kBlock, min_waves_for<TAB>(ECRAD_MIN_WAVES)) void l
         for (int k = 0; k < kW; ++k) {
           const int l = l0 - k;
           if (l >= 0) {
-            const double T = ring_c[k].x, S = ring_c[k].y;
+            double T = ring_c[k].x, S = ring_c[k].y;
+            if (kRecompute && recompute) {
+              const LwCoef cc = no_scattering_lw(ring_c[k].x, ring_c[k].y, pl_below);
+              T = cc.transmittance; S = cc.source_up;
+              pl_below = ring_c[k].y;
+            }
             const double Tall = (set2 && cloudy.test(l)) ? ring_t[k] : T;
             fetch(l - kW, ring_c[k], ring_t[k]);
             fup_c = T * fup_c + S;
