@@ -481,6 +481,7 @@ def timed_steps(w, steps, warmup, barrier, gather_world=0):
 
 
 LIBRARY_GATHER_HUNG = False      # set when the library's RCCL gather did not come back: the process then leaves through os._exit after its line
+LIBRARY_GATHER_FAILED = False    # set when this rank's leg ended with an error while others may be waiting in its collective: the same exit
 
 
 def library_gather_leg(w, world, rank, steps, barrier, allreduce_max, timeout=180.0):
@@ -538,10 +539,12 @@ def library_gather_leg(w, world, rank, steps, barrier, allreduce_max, timeout=18
     t = threading.Thread(target=body, daemon=True)
     t.start()
     t.join(timeout)
+    global LIBRARY_GATHER_HUNG, LIBRARY_GATHER_FAILED
     if t.is_alive():
-        global LIBRARY_GATHER_HUNG
         LIBRARY_GATHER_HUNG = True
         return {"error": f"no completion within {timeout:.0f} s (rank {rank}); the line above it is unaffected"}
+    if "error" in box["rec"] and world > 1:
+        LIBRARY_GATHER_FAILED = True      # (the other ranks are stuck in the collective this rank left: no barrier with them at the end)
     return box["rec"]
 
 
@@ -1445,8 +1448,10 @@ def main():
         if failed and "parity" in head and not head["parity"]["ok"]:
             out["value"] = None
         emit(out)
-    if LIBRARY_GATHER_HUNG:
-        os._exit(1 if failed else 0)      # (a thread is stuck in RCCL: no barrier, no clean-up)
+    if LIBRARY_GATHER_HUNG or LIBRARY_GATHER_FAILED:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1 if failed else 0)      # (a thread of this or another rank is stuck in RCCL: no barrier, no clean-up)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
