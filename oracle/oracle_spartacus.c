@@ -43,6 +43,11 @@ static const double kGasConstantDryAir = 287.058;      /* radiation_constants.F9
 static const double kAccelDueToGravity = 9.80665;      /* :26 */
 static const double kLwDiffusivity = 1.66;
 
+/* diagnostics (tools/sp_nonfinite.py, profiles/NOTES_r06.md section 4): ECRAD_ORACLE_TRACE_NONFINITE=1 names where a non-finite value first appears in the
+   shortwave solver, ECRAD_ORACLE_TRACE_G=g prints the albedo matrices of g-point g layer by layer.  Read once (the same value whichever thread is first). */
+static int g_trace_nf = -1, g_trace_g = -2;
+static int trace_nf(void) { if (g_trace_nf < 0) g_trace_nf = getenv("ECRAD_ORACLE_TRACE_NONFINITE") != NULL; return g_trace_nf; }
+static int trace_g(void) { if (g_trace_g == -2) { const char* e = getenv("ECRAD_ORACLE_TRACE_G"); g_trace_g = e ? atoi(e) : -1; } return g_trace_g; }
 static real_t rmin(real_t a, real_t b) { return a < b ? a : b; }
 static real_t rmax(real_t a, real_t b) { return a > b ? a : b; }
 /* ---- spectral flux profiles (do_save_spectral_flux): indexed_sum / add_indexed_sum of radiation_flux.F90 in working
@@ -237,7 +242,7 @@ static void step_migrations(int ng, real_t cloud_frac, real_t layer_depth, real_
       top_albedo = rmax((real_t)1.0e-8, R + ms_enhancement * T * A);
       const real_t x_before = V2(x_diffuse, g, jreg);
       V2(x_diffuse, g, jreg) = x_layer_diffuse + x_enhancement * A * (T * T) * (V2(x_diffuse, g, jreg) + x_layer_diffuse) / top_albedo;
-      if (getenv("ECRAD_ORACLE_TRACE_NONFINITE") && (!(V2(x_diffuse, g, jreg) >= 0) || V2(x_diffuse, g, jreg) > (real_t)1e7))
+      if (trace_nf() && (!(V2(x_diffuse, g, jreg) >= 0) || V2(x_diffuse, g, jreg) > (real_t)1e7))
         fprintf(stderr, "TRACE step_migrations g %d region %d: x_diffuse %.6g -> %.6g; R %.6g T %.6g A %.6g Ad %.6g top_albedo %.6g x_enhancement %.6g\n", g, jreg,
                 (double)x_before, (double)V2(x_diffuse, g, jreg), (double)R, (double)T, (double)A, (double)Ad, (double)top_albedo, (double)x_enhancement);
     }
@@ -480,7 +485,7 @@ void oracle_solver_spartacus_sw(const ecrad_config_t* c, int ncol, int nlev, int
         for (int cc = 0; cc < nregactive; ++cc)
           for (int r = 0; r < nregactive; ++r)
             for (int g = 0; g < ng3D; ++g) GZ(Gamma_z1, g, r, nreg + cc) = -GZ(Gamma_z1, g, nreg + r, cc);
-        const int trace = getenv("ECRAD_ORACLE_TRACE_NONFINITE") != NULL;      /* (diagnostic of tools/sp_nonfinite.py: where a non-finite value first appears) */
+        const int trace = trace_nf();
         real_t gz_norm[64];
         if (trace) for (int g = 0; g < ng3D && g < 64; ++g) { real_t mx = 0; for (int k = 0; k < m * m; ++k) { const real_t v = Gamma_z1[g + (size_t)ng * k]; if (fabs((double)v) > mx) mx = (real_t)fabs((double)v); } gz_norm[g] = mx; }
         om_expm(ng, ng3D, m, Gamma_z1, OM_PATTERN_SHORTWAVE);
@@ -583,7 +588,7 @@ void oracle_solver_spartacus_sw(const ecrad_config_t* c, int ncol, int nlev, int
         om_mat_x_mat(ng, ng, NREG, tran, t2, OM_PATTERN_DENSE, t1);
         for (size_t k = 0; k < n9; ++k) total_albedo_below_direct[k] = rdir[k] + t1[k];
       }
-      if (getenv("ECRAD_ORACLE_TRACE_NONFINITE")) {
+      if (trace_nf()) {
         for (int g = 0; g < ng; ++g) {
           int bad = 0;
           for (int k = 0; k < 9; ++k) if (!isfinite((double)total_albedo_below[g + (size_t)ng * k]) || !isfinite((double)total_albedo_below_direct[g + (size_t)ng * k])) bad = 1;
@@ -679,15 +684,15 @@ void oracle_solver_spartacus_sw(const ecrad_config_t* c, int ncol, int nlev, int
           }
         }
       }
-      if (getenv("ECRAD_ORACLE_TRACE_G")) {
-        const int g = atoi(getenv("ECRAD_ORACLE_TRACE_G"));
+      if (trace_g() >= 0 && trace_g() < ng) {
+        const int g = trace_g();
         fprintf(stderr, "TRACE albedo col %d layer %d g %d frac %.4g: total_albedo (after 4.2):", jcol, jlev, g, FL(in->cloud_fraction, jcol, jl));
         for (int k = 0; k < 9; ++k) fprintf(stderr, " %.5g", (double)ta[g + (size_t)ng * k]);
         fprintf(stderr, " | below (4.1):");
         for (int k = 0; k < 9; ++k) fprintf(stderr, " %.5g", (double)total_albedo_below[g + (size_t)ng * k]);
         fprintf(stderr, " | x_diffuse %.5g %.5g %.5g\n", (double)V2(x_diffuse, g, 0), (double)V2(x_diffuse, g, 1), (double)V2(x_diffuse, g, 2));
       }
-      if (getenv("ECRAD_ORACLE_TRACE_NONFINITE"))
+      if (trace_nf())
         for (int g = 0; g < ng; ++g) {
           int bad = 0;
           for (int k = 0; k < 9; ++k) if (!isfinite((double)ta[g + (size_t)ng * k]) || !isfinite((double)tad[g + (size_t)ng * k])) bad = 1;
