@@ -150,7 +150,8 @@ def test_single_precision_spartacus_non_finite_columns_of_the_whole_workload(ora
         gbad = sorted({int(g) for c in bad_ora for g in np.flatnonzero(~np.isfinite(osp.arrays["sw_up_toa_g"][c]))})
         ncloudy = [int((cloud.fraction[:, c] > 0).sum()) for c in bad_ora]
         print(f"  oracle float: g-points (0-based) {gbad}; cloudy layers per column {min(ncloudy)} .. {max(ncloudy)}")
-        assert min(ncloudy) >= 20, "the unstable columns are the deep partly cloudy ones"
+        # (on the boxes of round 6: 67 .. 73 -- the deep partly cloudy family; not asserted: which columns the float build loses depends on the
+        #  host's math library to the last bit)
     assert len(bad_columns(flux, "lw_")) == 0 and len(bad_columns(osp, "lw_")) == 0
     assert len(bad_hip) <= len(bad_ora)
     assert len(bad_hip) == 0, bad_hip.tolist()
