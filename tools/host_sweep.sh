@@ -12,6 +12,3 @@ done
 echo "== no ramp" >> $out
 ECRAD_HIP_NO_RAMP=1 python tools/host_link_probe.py notorch $W 100000 2>&1 | grep "arrays" >> $out
 cat $out
-rocprofv3 --kernel-trace --memory-copy-trace -d gpurun_out/host_tl -o tl -- python tools/host_link_probe.py notorch $W 100000 > gpurun_out/host_tl.log 2>&1
-python tools/host_timeline.py gpurun_out/host_tl | tee gpurun_out/host_timeline.log
-find gpurun_out/host_tl -name "*.csv" | head; find gpurun_out/host_tl -name "*.csv" -size +5M -delete
