@@ -1078,7 +1078,10 @@ def measure(name, ncol, steps, warmup, rank, local_rank, world, barrier, allredu
         if rank == 0:      # rank 0 holds every rank's profiles: (ranks, fields, half levels, columns per rank)
             res["gathered"] = {"ranks": len(w.gathered), "shape_per_rank": list(w.gathered[0].shape), "fields": w.profile_names,
                                "bytes_received": int(sum(b.numel() * b.element_size() for b in w.gathered[1:]))}
-        if os.environ.get("ECRAD_BENCH_TEST_SHARED_GPU") != "1" and os.environ.get("ECRAD_BENCH_NO_LIBRARY_GATHER") != "1":
+        # (TEST HOOK: ECRAD_BENCH_TEST_LIBRARY_GATHER_ANYWAY=1 runs the leg although the ranks share a GPU -- RCCL then refuses the communicator,
+        #  which is how tests/test_bench_launcher.py exercises what happens to the line when the leg fails on every rank)
+        if ((os.environ.get("ECRAD_BENCH_TEST_SHARED_GPU") != "1" or os.environ.get("ECRAD_BENCH_TEST_LIBRARY_GATHER_ANYWAY") == "1")
+                and os.environ.get("ECRAD_BENCH_NO_LIBRARY_GATHER") != "1"):
             progress(f"{name}: library gather")
             res["library_gather"] = library_gather_leg(w, world, rank, steps, barrier, allreduce_max)
             if LIBRARY_GATHER_HUNG:

@@ -115,3 +115,20 @@ def test_bench_library_gather_leg_on_a_one_rank_communicator():
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     lg = d["library_gather"]
     assert "error" not in lg and lg["value"] > 0 and lg["own_share_intact"] is True, lg
+
+
+@pytest.mark.gpu
+def test_bench_line_survives_a_library_gather_that_cannot_form():
+    """Two ranks on ONE GPU with the library-gather leg forced on: RCCL refuses a communicator with two ranks on one device, the leg fails on
+    both ranks -- and the run still prints its one line, with the failure in `library_gather`, every other field as usual, exit status 0
+    (bench.py: LIBRARY_GATHER_FAILED -- the ranks leave without the final barrier).  What a communicator that cannot form on a real
+    multi-GPU node would do to the record."""
+    env = dict(os.environ, ECRAD_BENCH_TEST_SHARED_GPU="1", ECRAD_BENCH_TEST_LIBRARY_GATHER_ANYWAY="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--ncol", "4096",
+                        "--headline-only", "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["value_with_gather"] > 0
+    assert "error" in d["library_gather"], d["library_gather"]
