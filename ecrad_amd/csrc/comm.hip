@@ -58,7 +58,7 @@ int rccl_fail(ecrad_hip_handle_t h, const char* what, ncclResult_t e) {
   Rccl& r = rccl();
   return fail_call(h, ECRAD_EHIP, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(e) : "RCCL error"));
 }
-#define RCCL_TRY(h, call) do { const ncclResult_t e_ = (call); if (e_ != ncclSuccess) return rccl_fail(h, #call, e_); } while (0)
+#define RCCL_TRY(h, what, call) do { const ncclResult_t e_ = (call); if (e_ != ncclSuccess) return rccl_fail(h, what, e_); } while (0)
 
 static_assert(ECRAD_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "include/ecrad_hip.h: ECRAD_COMM_ID_BYTES is RCCL's NCCL_UNIQUE_ID_BYTES");
 
@@ -71,7 +71,7 @@ int ecrad_hip_comm_id(ecrad_hip_handle_t h, unsigned char* id) {
   Rccl& r = rccl();
   if (!r.why.empty()) return fail_call(h, ECRAD_EUNSUPPORTED, r.why);
   ncclUniqueId u;
-  RCCL_TRY(h, r.GetUniqueId(&u));
+  RCCL_TRY(h, "ncclGetUniqueId", r.GetUniqueId(&u));
   std::memcpy(id, u.internal, ECRAD_COMM_ID_BYTES);
   return ECRAD_OK;
 }
@@ -86,7 +86,7 @@ int ecrad_hip_comm_init(ecrad_hip_handle_t h, const unsigned char* id, int rank,
   ncclUniqueId u;
   std::memcpy(u.internal, id, ECRAD_COMM_ID_BYTES);
   ncclComm_t comm = nullptr;
-  RCCL_TRY(h, r.CommInitRank(&comm, world, u, rank));
+  RCCL_TRY(h, "ncclCommInitRank (one rank per device: RCCL refuses two ranks on one GPU)", r.CommInitRank(&comm, world, u, rank));
   h->comm = comm; h->comm_rank = rank; h->comm_world = world;
   return ECRAD_OK;
 }
@@ -134,7 +134,7 @@ int ecrad_hip_gather_profiles(ecrad_hip_handle_t h, int n_fields, const double* 
   }
   if (rank == root && total) HIP_TRY(h, h->comm_recv.ensure(total * (size_t)n_rows * n_fields * 8));
   double* const recv0 = static_cast<double*>(h->comm_recv.p);
-  RCCL_TRY(h, R.GroupStart());
+  RCCL_TRY(h, "ncclGroupStart", R.GroupStart());
   ncclResult_t bad = ncclSuccess;
   if (rank == root) {
     size_t off = 0;      // rank r's share: n_fields pieces of n_rows x ncol_of_rank[r], in rank order
