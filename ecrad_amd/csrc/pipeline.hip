@@ -1215,6 +1215,16 @@ int radiation_host_mirrored(ecrad_hip_handle_t h, int ncol, int nlev, int istart
 // (no sum runs over columns), so the fluxes of a block are the same bits whatever it shared a batch with.
 constexpr int kMaxBatchCalls = 64, kMaxBatchColumns = 4096;
 int small_call_limit() { return std::min(packed_call_columns(), kMaxBatchColumns); }
+// Columns a batch takes at most (ECRAD_HIP_BATCH_COLUMNS overrides).  A leader used to take everything that was waiting (up to 4096 columns): with
+// many callers -- 64 OpenMP threads on blocks of 80 -- the first batch then held 51 of them for 6.4 ms (99 MB in, 70 MB out: its copy-in, kernels and
+// copy-out one after the other) while the second slot got the stragglers.  Capped at 1280 columns, with three batches in flight per device
+// (pool.hip: small_slots), the waiting calls spread over batches whose copy-ins and copy-outs overlap: the reference's OpenMP driver on 64 threads
+// 0.56 -> 0.67 M columns/s clear-sky, 0.36 -> 0.51 M Tripleclouds; on 16 threads (at most 1280 columns in flight anyway) unchanged within the noise
+// (tools/batch_sweep.sh, profiles/r06_batch_sweep.log).
+int batch_column_cap() {
+  static const int v = [] { const char* e = std::getenv("ECRAD_HIP_BATCH_COLUMNS"); const int k = e ? std::atoi(e) : 0; return k >= 64 && k <= kMaxBatchColumns ? k : 1280; }();
+  return v;
+}
 
 struct SmallCall {
   int ncol, nlev, i0, nloc;
@@ -1441,7 +1451,7 @@ int radiation_small(ecrad_hip_handle_t root, int ncol, int nlev, int istartcol, 
       B.calls.push_back(&me);
       B.ntot = me.nloc;
       for (SmallCall* q : w)
-        if (q != &me && (int)B.calls.size() < kMaxBatchCalls && B.ntot + q->nloc <= kMaxBatchColumns && batch_compatible(me, *q)) { B.calls.push_back(q); B.ntot += q->nloc; }
+        if (q != &me && (int)B.calls.size() < kMaxBatchCalls && B.ntot + q->nloc <= batch_column_cap() && batch_compatible(me, *q)) { B.calls.push_back(q); B.ntot += q->nloc; }
       // the blocks in the order of their first column (neighbours in the caller's arrays stay neighbours on the device)
       std::sort(B.calls.begin(), B.calls.end(), [](const SmallCall* a, const SmallCall* b) { return a->i0 < b->i0; });
       int off = 0;

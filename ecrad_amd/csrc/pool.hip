@@ -179,10 +179,11 @@ ecrad_hip_handle_s* free_context(ecrad_hip_handle_t root) {
 }
 
 // ... for a batch of small calls: at most `small_slots` such batches run on a device at a time, however many contexts it
-// has -- the calls that arrive meanwhile wait and form the next batch, which is where their throughput comes from (two
-// slots: one batch on the device while the callers of the next gather their rows)
+// has -- the calls that arrive meanwhile wait and form the next batch, which is where their throughput comes from (three
+// slots since round 6, with batches capped at 1280 columns: one batch copying in, one in its kernels or copying out, one gathering;
+// pipeline.hip: batch_column_cap)
 int small_slots() {
-  static const int v = [] { const char* e = std::getenv("ECRAD_HIP_SMALL_SLOTS"); const int k = e ? std::atoi(e) : 0; return k >= 1 && k <= 64 ? k : 2; }();
+  static const int v = [] { const char* e = std::getenv("ECRAD_HIP_SMALL_SLOTS"); const int k = e ? std::atoi(e) : 0; return k >= 1 && k <= 64 ? k : 3; }();
   return v;
 }
 ecrad_hip_handle_s* free_context_for_small(ecrad_hip_handle_t root) {

@@ -21,7 +21,7 @@ for workload, edits in (("clear_homogeneous_ecckd32", {"sw_solver_name": '"Homog
         save_inputs(inp, config, *inputs[2:])
         write_namelist(os.path.join(tmp, "base.nam"), dict({"do_save_spectral_flux": "false", "iverbose": "1", "iverbosesetup": "0"}, **edits))
         base = open(os.path.join(tmp, "base.nam")).read()
-        for nblock, threads in ([(80, 16)] if os.environ.get("ECRAD_HIP_BATCH_TRACE") else [(80, 16), (80, 64), (320, 16), (1280, 16), (5120, 8), (ncol, 1)]):
+        for nblock, threads in ([(80, int(os.environ.get("TRACE_THREADS", "16")))] if (os.environ.get("ECRAD_HIP_BATCH_TRACE") or os.environ.get("TRACE_THREADS")) else [(80, 16), (80, 64), (320, 16), (1280, 16), (5120, 8), (ncol, 1)]):
             nam, out = os.path.join(tmp, "c.nam"), os.path.join(tmp, "out.nc")
             open(nam, "w").write(re.sub(r"nrepeat\s*=\s*\d+", "nrepeat = 20", re.sub(r"nblocksize\s*=\s*\d+", f"nblocksize = {nblock}", base)))
             env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_STACKSIZE="1G", ECRAD_HIP_CONTEXTS="16", ECRAD_HIP_DEVICES="1", ECRAD_HIP_POOL_REPORT="1")
